@@ -1,0 +1,125 @@
+/*
+ * stc_hip.h -- C ABI of libstc_hip.so: the MI355X (gfx950) kernels behind the
+ * STC-GNN multi-graph message-passing path.
+ *
+ * The reference (underdoc-wang/STC-GNN) is pure Python and has no FFI; the
+ * "interface each entry point replaces" is therefore a span of torch ops in
+ * framework/STC_GNN.py, cited per function.  The Python host
+ * (stc-gnn_amd/stc_hip/_lib.py) binds these with ctypes and is the only
+ * caller; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (tensor.data_ptr());
+ *     nothing is allocated, freed or retained; buffers must stay alive until the
+ *     stream has run the launch
+ *   - all tensors are dense, row-major, contiguous fp32 unless stated;
+ *     CSR indices are int32
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream); launches
+ *     are asynchronous; functions are re-entrant and keep no state
+ *   - return 0 on success; STC_EINVAL (-1) bad argument / shape, STC_EALIGN (-2)
+ *     misaligned pointer, STC_ELIMIT (-3) size beyond a kernel limit; > 0 is a
+ *     hipError_t from the launch.  stc_last_error() gives a thread-local text.
+ *   - sizes of zero elements are legal and launch nothing
+ */
+#ifndef STC_HIP_H
+#define STC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STC_ABI_VERSION 1
+#define STC_MAX_K 4          /* highest Chebyshev order (Ks, Kc) the node kernels accept */
+
+#define STC_OK 0
+#define STC_EINVAL (-1)
+#define STC_EALIGN (-2)
+#define STC_ELIMIT (-3)
+
+int stc_version(void);
+const char* stc_last_error(void);
+
+/* ---- spatial aggregation -------------------------------------------------
+ * Y[b,i,:] = alpha * sum_{j in row i} val[j] * X[b, colidx[j], :] + beta * Y0[b,i,:]
+ *
+ * X (batch, n_cols, F), Y0/Y (batch, n_rows, F).  Y0 may be NULL when beta == 0
+ * and may alias Y (in-place epilogue).  With CSR(Gs^T) this is the reference's
+ * 1-mode product torch.einsum('bncl,nm->bmcl', X, Gs) of STC_GNN.py:37 (F = C*L);
+ * with alpha=2, beta=-1, Y0=Z_{k-2} it is one step of the Chebyshev recurrence
+ * of STC_GNN.py:28 applied to the features; with CSR(Gs) it is the backward of both.
+ */
+int stc_csr_spmm_f32(const int32_t* rowptr, const int32_t* colidx, const float* val,
+                     int32_t n_rows, int32_t n_cols,
+                     const float* X, const float* Y0, float* Y,
+                     int32_t batch, int32_t F, float alpha, float beta, void* stream);
+
+/* out[j] (+)= alpha * sum_b < A[b,i,:], Bm[b,colidx[j],:] >   for j in row i
+ * A (batch, n_rows, F), Bm (batch, n_cols, F), out (nnz).  Gradient of the
+ * 1-mode product w.r.t. the graph values on a fixed pattern (autograd of :37);
+ * with the full N x N pattern it yields the dense dGs of the learned graph. */
+int stc_csr_sddmm_f32(const int32_t* rowptr, const int32_t* colidx,
+                      int32_t n_rows, int32_t n_cols,
+                      const float* A, const float* Bm, float* out,
+                      int32_t batch, int32_t F, float alpha, int32_t accumulate, void* stream);
+
+/* ---- category graph ------------------------------------------------------
+ * T (K, n, n): T_0 = I, T_1 = G, T_k = (2G) T_{k-1} - T_{k-2}   (STC_GNN.py:24-29,
+ * matrix side, same order as the reference).  n <= 128. */
+int stc_cheby_dense_fwd_f32(const float* G, int32_t n, int32_t K, float* T, void* stream);
+/* dG from dT (K,n,n); dT is used as scratch and destroyed. */
+int stc_cheby_dense_bwd_f32(const float* G, const float* T, float* dT, int32_t n, int32_t K,
+                            float* dG, void* stream);
+
+/* ---- node kernel: 2-mode product + concat + projection + bias -------------
+ * Y[r,d,:] = bias + sum_{n<Ks} sum_{c<Kc} sum_{c'} Tc[c][c',d] * ( Z_n[r,c',:] . W_{n,c} )
+ * r over `nodes` = batch*N rows; Z_n (nodes, C, L); Tc (Kc, C, C); W (Ks*Kc*L, Ho)
+ * with row blocks n-major, c-minor (STC_GNN.py:35-41); Y (nodes, C, Ho).
+ * Replaces STC_GNN.py:38-45 without materialising the K*K*L concat.
+ * Z is a HOST array of Ks device pointers. */
+int stc_bdg_node_fwd_f32(const float* const* Z, int32_t Ks, const float* Tc, int32_t Kc,
+                         const float* W, const float* bias, float* Y,
+                         int64_t nodes, int32_t C, int32_t L, int32_t Ho, void* stream);
+
+/* Backward of the node kernel.  dZ: HOST array of Ks device pointers (nodes,C,L),
+ * overwritten.  dW (Ks*Kc*L, Ho), db (Ho) or NULL, dTc (Kc,C,C) or NULL: overwritten.
+ * workspace: >= stc_bdg_node_bwd_workspace_bytes(...) bytes, 16-byte aligned. */
+size_t stc_bdg_node_bwd_workspace_bytes(int32_t Ks, int32_t Kc, int32_t C, int32_t L, int32_t Ho,
+                                        int32_t want_dTc);
+int stc_bdg_node_bwd_f32(const float* const* Z, int32_t Ks, const float* Tc, int32_t Kc,
+                         const float* W, const float* dY,
+                         float* const* dZ, float* dW, float* db, float* dTc,
+                         void* workspace, size_t workspace_bytes,
+                         int64_t nodes, int32_t C, int32_t L, int32_t Ho, void* stream);
+
+/* ---- GRU gate math (STC_GNN.py:68-78) --------------------------------------
+ * gates:  U = sigmoid(G[:, :h]); Rg = sigmoid(G[:, h:]); CandIn = [Xt | Rg*H]
+ *         G (rows, 2h), Xt (rows, cin), H/U/Rg (rows, h), CandIn (rows, cin+h) */
+int stc_gru_gates_fwd_f32(const float* G, const float* Xt, const float* H,
+                          float* U, float* Rg, float* CandIn,
+                          int64_t rows, int32_t cin, int32_t h, void* stream);
+int stc_gru_gates_bwd_f32(const float* dCandIn, const float* dU, const float* H,
+                          const float* U, const float* Rg,
+                          float* dG, float* dXt, float* dH,
+                          int64_t rows, int32_t cin, int32_t h, void* stream);
+/* blend:  Cand = tanh(Cpre); Hnew = (1-U)*H + U*Cand      (n = rows*h elements) */
+int stc_gru_blend_fwd_f32(const float* Cpre, const float* U, const float* H,
+                          float* Cand, float* Hnew, int64_t n, void* stream);
+int stc_gru_blend_bwd_f32(const float* dHnew, const float* U, const float* H, const float* Cand,
+                          float* dCpre, float* dU, float* dH, int64_t n, void* stream);
+
+/* ---- small helpers ---------------------------------------------------------
+ * y += a*x over n elements (Chebyshev backward g_{k-2} -= g_k) */
+int stc_axpy_f32(float a, const float* x, float* y, int64_t n, void* stream);
+/* out (rows, a+b) = [A (rows,a) | B (rows,b)]   (torch.cat of STC_GNN.py:68) and its inverse */
+int stc_concat2_f32(const float* A, const float* B, float* out,
+                    int64_t rows, int32_t a, int32_t b, void* stream);
+int stc_split2_f32(const float* src, float* A, float* B,
+                   int64_t rows, int32_t a, int32_t b, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STC_HIP_H */

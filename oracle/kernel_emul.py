@@ -1,0 +1,164 @@
+"""CPU emulation of the C-ABI kernels of ``include/stc_hip.h``.  TEST INFRASTRUCTURE ONLY.
+
+One method per exported kernel, same argument meaning, computing with torch
+CPU ops in float64-free plain fp32 (or whatever dtype the tensors carry, so
+the tests can also run the whole decomposition in fp64).  It serves two ends:
+
+* per-kernel reference for the ``-m gpu`` parity tests (HIP kernel vs this, on
+  the same seeded inputs);
+* a stand-in kernel set that the CPU tests inject into the host orchestration
+  (``stc_hip.ops``) to prove, against the oracle's autograd, that the
+  decomposition the HIP path uses -- feature-side Chebyshev recurrence,
+  project-then-mix node kernel, hand-derived backward -- is the reference's
+  math.  The product never imports this module and has no CPU path of its own.
+
+Reference lines each kernel accounts for are cited per method.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+
+Tensor = torch.Tensor
+
+
+def _expand_rows(rowptr: Tensor) -> Tensor:
+    counts = (rowptr[1:] - rowptr[:-1]).long()
+    return torch.repeat_interleave(torch.arange(counts.numel()), counts)
+
+
+class EmulatedKernels:
+    """Drop-in for ``stc_hip._lib.HipKernels`` on CPU tensors."""
+
+    name = 'emulated-cpu'
+
+    # ---- stc_csr_spmm_f32: 1-mode product + Chebyshev epilogue (STC_GNN.py:28, 37)
+    def csr_spmm(self, rowptr, colidx, val, n_rows, n_cols, X, Y0, Y, alpha, beta):
+        B, nc, F = X.shape
+        assert nc == n_cols and Y.shape == (B, n_rows, F)
+        rows = _expand_rows(rowptr)
+        acc = torch.zeros(B, n_rows, F, dtype=X.dtype)
+        contrib = X[:, colidx.long(), :] * val.to(X.dtype)[None, :, None]
+        acc.index_add_(1, rows, contrib)
+        out = alpha * acc
+        if beta != 0.0:
+            out = out + beta * Y0
+        Y.copy_(out)
+
+    # ---- stc_csr_sddmm_f32: gradient of the 1-mode product w.r.t. the graph values (autograd of :37)
+    def csr_sddmm(self, rowptr, colidx, n_rows, n_cols, A, Bm, out, alpha, accumulate):
+        rows = _expand_rows(rowptr)
+        dots = (A[:, rows, :] * Bm[:, colidx.long(), :]).sum(dim=(0, 2))
+        if accumulate:
+            out.add_(alpha * dots)
+        else:
+            out.copy_(alpha * dots)
+
+    # ---- stc_cheby_dense_fwd/bwd_f32: matrix-side Chebyshev set of the small C x C graph (STC_GNN.py:24-29)
+    def cheby_dense_fwd(self, G, K, T):
+        n = G.shape[0]
+        T[0].copy_(torch.eye(n, dtype=G.dtype))
+        if K > 1:
+            T[1].copy_(G)
+        for k in range(2, K):
+            T[k].copy_(torch.mm(2 * G, T[k - 1]) - T[k - 2])
+
+    def cheby_dense_bwd(self, G, T, dT, dG):
+        """dT (K,n,n) is consumed (used as scratch); dG overwritten."""
+        K = T.shape[0]
+        dG.zero_()
+        for k in range(K - 1, 1, -1):
+            dG.add_(2 * torch.mm(dT[k], T[k - 1].t()))
+            dT[k - 1].add_(2 * torch.mm(G.t(), dT[k]))
+            dT[k - 2].sub_(dT[k])
+        if K > 1:
+            dG.add_(dT[1])
+
+    # ---- stc_bdg_node_fwd_f32: 2-mode product + concat + projection + bias (STC_GNN.py:38-45)
+    def bdg_node_fwd(self, Zs: Sequence[Tensor], Tc: Tensor, W: Tensor, bias: Optional[Tensor], Y: Tensor):
+        """Y[r,d,:] = bias + sum_{n,c} sum_{c'} Tc[c][c',d] * (Z_n[r,c',:] @ W_{n,c}).
+
+        Project-then-mix order: U_c = sum_n Z_n W_{n,c}, then Y = sum_c Tc[c]^T U_c.
+        """
+        Ks, Kc = len(Zs), Tc.shape[0]
+        R, C, L = Zs[0].shape
+        Ho = W.shape[1]
+        Wv = W.view(Ks, Kc, L, Ho)
+        out = torch.zeros(R, C, Ho, dtype=W.dtype)
+        for c in range(Kc):
+            U = torch.zeros(R, C, Ho, dtype=W.dtype)
+            for n in range(Ks):
+                U += Zs[n] @ Wv[n, c]
+            out += torch.einsum('pd,rpo->rdo', Tc[c], U)
+        if bias is not None:
+            out += bias
+        Y.copy_(out)
+
+    # ---- stc_bdg_node_bwd_f32: autograd of the above
+    def bdg_node_bwd(self, Zs, Tc, W, dY, dZs, dW, db, dTc):
+        Ks, Kc = len(Zs), Tc.shape[0]
+        R, C, L = Zs[0].shape
+        Ho = W.shape[1]
+        Wv = W.view(Ks, Kc, L, Ho)
+        dWv = torch.zeros_like(Wv)
+        # Q_c[r,c',:] = sum_d Tc[c][c',d] dY[r,d,:]
+        Q = [torch.einsum('pd,rdo->rpo', Tc[c], dY) for c in range(Kc)]
+        for n in range(Ks):
+            acc = torch.zeros(R, C, L, dtype=W.dtype)
+            for c in range(Kc):
+                acc += Q[c] @ Wv[n, c].t()
+                dWv[n, c] = torch.einsum('rpl,rpo->lo', Zs[n], Q[c])
+            dZs[n].copy_(acc)
+        dW.copy_(dWv.view(Ks * Kc * L, Ho))
+        if db is not None:
+            db.copy_(dY.sum(dim=(0, 1)))
+        if dTc is not None:
+            for c in range(Kc):
+                U = torch.zeros(R, C, Ho, dtype=W.dtype)
+                for n in range(Ks):
+                    U += Zs[n] @ Wv[n, c]
+                dTc[c].copy_(torch.einsum('rpo,rdo->pd', U, dY))
+
+    # ---- stc_gru_gates_fwd/bwd_f32: split + sigmoids + reset*H + second concat (STC_GNN.py:71-75)
+    def gru_gates_fwd(self, G, Xt, H, U, Rg, CandIn):
+        h = H.shape[-1]
+        cin = Xt.shape[-1]
+        U.copy_(torch.sigmoid(G[..., :h]))
+        Rg.copy_(torch.sigmoid(G[..., h:]))
+        CandIn[..., :cin].copy_(Xt)
+        CandIn[..., cin:].copy_(Rg * H)
+
+    def gru_gates_bwd(self, dCandIn, dU, H, U, Rg, dG, dXt, dH):
+        h = H.shape[-1]
+        cin = dXt.shape[-1]
+        dRH = dCandIn[..., cin:]
+        dG[..., :h].copy_(dU * U * (1 - U))
+        dG[..., h:].copy_(dRH * H * Rg * (1 - Rg))
+        dXt.copy_(dCandIn[..., :cin])
+        dH.copy_(dRH * Rg)
+
+    # ---- stc_gru_blend_fwd/bwd_f32: tanh + GRU blend (STC_GNN.py:76-78)
+    def gru_blend_fwd(self, Cpre, U, H, Cand, Hnew):
+        Cand.copy_(torch.tanh(Cpre))
+        Hnew.copy_((1.0 - U) * H + U * Cand)
+
+    def gru_blend_bwd(self, dHnew, U, H, Cand, dCpre, dU, dH):
+        dCpre.copy_(dHnew * U * (1 - Cand * Cand))
+        dU.copy_(dHnew * (Cand - H))
+        dH.copy_(dHnew * (1 - U))
+
+    # ---- stc_axpy_f32: y += a*x (Chebyshev recurrence backward, g_{k-2} -= g_k)
+    def axpy(self, a, x, y):
+        y.add_(x, alpha=a)
+
+    # ---- stc_concat2_f32 / split: cat([A,B],-1) (STC_GNN.py:68) and its backward
+    def concat2(self, A, Bm, out):
+        a = A.shape[-1]
+        out[..., :a].copy_(A)
+        out[..., a:].copy_(Bm)
+
+    def split2(self, src, A, Bm):
+        a = A.shape[-1]
+        A.copy_(src[..., :a])
+        Bm.copy_(src[..., a:])

@@ -1,0 +1,272 @@
+"""Drop-in for the reference's ``framework/STC_GNN.py``, computing on MI355X.
+
+Put this directory on ``sys.path`` ahead of (or instead of) ``framework/`` and
+``from STC_GNN import STCGNN`` (reference ``Model_Trainer.py:5``) resolves
+here.  Class names, constructor arguments, ``forward`` signatures, parameter
+creation order and ``state_dict`` keys are the reference's
+(``STC_GNN.py:5-261``); the arithmetic of the message-passing path -- every
+``BDG_Dif``, the gate math of ``STC_Cell`` -- is a sequence of hand-written
+HIP kernels (``stc_hip.ops``), not torch ops.  Only the small-N graph
+generator ``MGP_Gen`` / ``MixedFusion``, the 16->8->1 output head and the
+``torch.stack`` bookkeeping stay on torch.
+
+Beyond the reference:
+
+* ``Gs`` may be a fixed sparse graph (``stc_hip.CsrGraph`` or a torch sparse
+  tensor) anywhere a dense ``(N, N)`` tensor is accepted; the reference's dense
+  learned ``Gs`` is handled as the full-pattern special case and stays
+  differentiable.
+* ``STCGNN(..., graph_mode='csr-fixed')`` skips ``MGP_Gen`` (whose
+  ``MixedFusion`` holds 2*N^4 parameters and cannot exist beyond N ~ 300) and
+  uses ``As`` / ``Ac`` directly as ``Gs`` / ``Gc``.
+
+Inputs must live on a ROCm device; there is no CPU execution path.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Union
+
+import torch
+from torch import nn
+
+from stc_hip import ops
+from stc_hip.graph import CsrGraph, SpatialOperand, csr_operand, dense_operand
+
+GraphLike = Union[torch.Tensor, CsrGraph, 'GraphPair']
+
+
+class GraphPair:
+    """The two graphs of one forward pass, prepared once for every BDG_Dif in it.
+
+    ``spatial``: CSR operand of ``Gs`` (both orientations); ``Tc``: (Kc, C, C)
+    Chebyshev stack of ``Gc`` (differentiable when ``Gc`` is).
+    """
+
+    def __init__(self, Gs, Gc: torch.Tensor, Ks: int, Kc: int):
+        if isinstance(Gs, CsrGraph):
+            self.spatial: SpatialOperand = csr_operand(Gs, Gc.device)
+        elif isinstance(Gs, torch.Tensor) and Gs.layout != torch.strided:
+            cached = getattr(Gs, '_stc_csr', None)
+            if cached is None:
+                cached = CsrGraph.from_torch_sparse(Gs)
+                try:
+                    Gs._stc_csr = cached
+                except AttributeError:
+                    pass
+            self.spatial = csr_operand(cached, Gc.device)
+        elif isinstance(Gs, torch.Tensor):
+            self.spatial = dense_operand(Gs)
+        else:
+            raise TypeError(f'Gs must be a tensor or a CsrGraph, got {type(Gs).__name__}')
+        self.Ks, self.Kc = Ks, Kc
+        self.Tc = ops.cheby_dense(Gc, Kc)
+
+
+def _graphs(Gs: GraphLike, Gc: Optional[torch.Tensor], Ks: int, Kc: int) -> GraphPair:
+    if isinstance(Gs, GraphPair):
+        if (Gs.Ks, Gs.Kc) != (Ks, Kc):
+            raise ValueError(f'GraphPair prepared for orders {(Gs.Ks, Gs.Kc)}, layer uses {(Ks, Kc)}')
+        return Gs
+    return GraphPair(Gs, Gc, Ks, Kc)
+
+
+class BDG_Dif(nn.Module):
+    """Bi-dimensional graph diffusion convolution (reference ``STC_GNN.py:5-47``)."""
+
+    def __init__(self, Ks: int, Kc: int, input_dim: int, hidden_dim: int, use_bias=True, activation=None):
+        super().__init__()
+        self.Ks, self.Kc = Ks, Kc
+        self.input_dim, self.hidden_dim = input_dim, hidden_dim
+        self.use_bias = use_bias
+        self.activation = None if activation is None else activation()
+        self.W = nn.Parameter(torch.empty(input_dim * Ks * Kc, hidden_dim))
+        nn.init.xavier_normal_(self.W)
+        if use_bias:
+            self.b = nn.Parameter(torch.zeros(hidden_dim))
+
+    def forward(self, X: torch.Tensor, Gs: GraphLike, Gc: Optional[torch.Tensor] = None):
+        pair = _graphs(Gs, Gc, self.Ks, self.Kc)
+        out = ops.bdg_dif(X, pair.spatial, pair.Tc, self.W, self.b if self.use_bias else None, self.Ks)
+        return out if self.activation is None else self.activation(out)
+
+
+class STC_Cell(nn.Module):
+    """GRU-style co-evolution cell (reference ``STC_GNN.py:51-79``)."""
+
+    def __init__(self, num_nodes: int, num_categories: int, Ks: int, Kc: int, input_dim: int, hidden_dim: int,
+                 use_bias=True, activation=None):
+        super().__init__()
+        self.num_nodes, self.num_categories, self.hidden_dim = num_nodes, num_categories, hidden_dim
+        self.gates = BDG_Dif(Ks, Kc, input_dim + hidden_dim, hidden_dim * 2, use_bias, activation)
+        self.candi = BDG_Dif(Ks, Kc, input_dim + hidden_dim, hidden_dim, use_bias, activation)
+
+    def init_hidden(self, batch_size: int):
+        ref = self.gates.W
+        return ref.new_zeros(batch_size, self.num_nodes, self.num_categories, self.hidden_dim)
+
+    def forward(self, Gs: GraphLike, Gc: Optional[torch.Tensor], Xt: torch.Tensor, Ht_1: torch.Tensor):
+        assert Xt.dim() == 4 and Ht_1.dim() == 4, 'STC-cell must take in 4D tensor as input [Xt, Ht-1]'
+        pair = _graphs(Gs, Gc, self.gates.Ks, self.gates.Kc)
+        pre = self.gates(ops.concat2(Xt, Ht_1), pair)                 # (B,N,C,2h) update|reset pre-activations
+        update, cand_in = ops.gru_gates(pre, Xt, Ht_1)                # sigmoid, reset*H and the second concat, fused
+        cand_pre = self.candi(cand_in, pair)
+        return ops.gru_blend(cand_pre, update, Ht_1)                  # (1-u)*H + u*tanh(.)
+
+
+def _per_layer(value, num_layers: int) -> list:
+    return value if isinstance(value, list) else [value] * num_layers
+
+
+class STC_Encoder(nn.Module):
+    """Layer-major stack of cells over the observed sequence (reference ``STC_GNN.py:83-135``)."""
+
+    def __init__(self, num_nodes: int, num_categories: int, Ks: int, Kc: int, input_dim: int, hidden_dim,
+                 num_layers: int, use_bias=True, activation=None, return_all_layers=True):
+        super().__init__()
+        self.hidden_dim = _per_layer(hidden_dim, num_layers)
+        self.num_layers = num_layers
+        self.return_all_layers = return_all_layers
+        assert len(self.hidden_dim) == num_layers, 'Input [hidden, layer] length must be consistent'
+        self.cell_list = nn.ModuleList(
+            STC_Cell(num_nodes, num_categories, Ks, Kc, input_dim if i == 0 else self.hidden_dim[i - 1],
+                     self.hidden_dim[i], use_bias=use_bias, activation=activation)
+            for i in range(num_layers))
+
+    def _init_hidden(self, batch_size: int):
+        return [cell.init_hidden(batch_size) for cell in self.cell_list]
+
+    def forward(self, Gs: GraphLike, Gc: Optional[torch.Tensor], X_seq: torch.Tensor, H0_l=None):
+        assert X_seq.dim() == 5, 'STC-encoder must take in 5D tensor as input X_seq'
+        first = self.cell_list[0].gates
+        pair = _graphs(Gs, Gc, first.Ks, first.Kc)
+        steps = X_seq.shape[1]
+        states = self._init_hidden(X_seq.shape[0]) if H0_l is None else H0_l
+        layer_in = X_seq
+        all_seq, all_last = [], []
+        for cell, h in zip(self.cell_list, states):
+            outs = []
+            for t in range(steps):
+                h = cell(pair, None, layer_in[:, t], h)
+                outs.append(h)
+            layer_in = torch.stack(outs, dim=1)                       # (B, T, N, C, h): next layer's input
+            all_seq.append(layer_in)
+            all_last.append(h)
+        if not self.return_all_layers:
+            return all_seq[-1:], all_last[-1:]
+        return all_seq, all_last
+
+
+class STC_Decoder(nn.Module):
+    """One autoregressive step through the layer stack (reference ``STC_GNN.py:139-172``)."""
+
+    def __init__(self, num_nodes: int, num_categories: int, Ks: int, Kc: int, output_dim: int, hidden_dim,
+                 num_layers: int, out_horizon: int, use_bias=True, activation=None):
+        super().__init__()
+        self.out_horizon = out_horizon
+        self.hidden_dim = _per_layer(hidden_dim, num_layers)
+        self.num_layers = num_layers
+        assert len(self.hidden_dim) == num_layers, 'Input [hidden, layer] length must be consistent'
+        self.cell_list = nn.ModuleList(
+            STC_Cell(num_nodes, num_categories, Ks, Kc, output_dim if i == 0 else self.hidden_dim[i - 1],
+                     self.hidden_dim[i], use_bias=use_bias, activation=activation)
+            for i in range(num_layers))
+
+    def forward(self, Gs: GraphLike, Gc: Optional[torch.Tensor], Xt: torch.Tensor, H0_l: Sequence[torch.Tensor]):
+        assert Xt.dim() == 4, 'STC-decoder must take in 4D tensor as input Xt'
+        first = self.cell_list[0].gates
+        pair = _graphs(Gs, Gc, first.Ks, first.Kc)
+        new_states: List[torch.Tensor] = []
+        x = Xt
+        for cell, h in zip(self.cell_list, H0_l):
+            x = cell(pair, None, x, h)
+            new_states.append(x)
+        return x, new_states
+
+
+class MixedFusion(nn.Module):
+    """Element-wise gated mix of a prior graph A and a learned graph P (reference ``STC_GNN.py:246-261``).
+
+    Two ``Linear(n^2, n^2)`` layers: usable for small n only; stays on torch (rocBLAS GEMV).
+    """
+
+    def __init__(self, in_dim: int):
+        super().__init__()
+        self.in_dim = in_dim
+        self.lin_A = nn.Linear(in_dim ** 2, in_dim ** 2)
+        self.lin_P = nn.Linear(in_dim ** 2, in_dim ** 2)
+
+    def forward(self, A: torch.Tensor, P: torch.Tensor):
+        assert A.dim() == 2 and P.dim() == 2
+        n = self.in_dim
+        gate = torch.sigmoid(self.lin_A(A.reshape(n * n)) + self.lin_P(P.reshape(n * n))).reshape(n, n)
+        return gate * A + (1 - gate) * P
+
+
+class MGP_Gen(nn.Module):
+    """Learned mixed graph pair (Gs, Gc) from the input window (reference ``STC_GNN.py:210-243``)."""
+
+    def __init__(self, num_nodes: int, num_categories: int, hidden_dim: int, alpha: int = 3):
+        super().__init__()
+        self.alpha = alpha
+        self.params_S = self.init_params(num_categories, hidden_dim)
+        self.aggreg_S = MixedFusion(num_nodes)
+        self.params_C = self.init_params(num_nodes, hidden_dim)
+        self.aggreg_C = MixedFusion(num_categories)
+
+    @staticmethod
+    def init_params(in_dim: int, hidden_dim: int):
+        params = nn.ParameterDict()
+        for key in ('Wu', 'Wv'):
+            params[key] = nn.Parameter(torch.randn(in_dim, hidden_dim))
+        for p in params.values():
+            nn.init.xavier_normal_(p)
+        return params
+
+    def _learned(self, X: torch.Tensor, params) -> torch.Tensor:
+        U = torch.tanh(self.alpha * torch.matmul(X, params['Wu']))
+        V = torch.tanh(self.alpha * torch.matmul(X, params['Wv']))
+        flat_u, flat_v = U.flatten(0, 1), V.flatten(0, 1)             # sum over batch and time
+        P = torch.einsum('knh,kmh->nm', flat_u, flat_v)
+        return torch.softmax(torch.relu(P - P.t()), dim=-1)
+
+    def forward(self, X_seq: torch.Tensor, As: torch.Tensor, Ac: torch.Tensor):
+        Gs = self.aggreg_S(As, self._learned(X_seq, self.params_S))
+        Gc = self.aggreg_C(Ac, self._learned(X_seq.transpose(2, 3), self.params_C))
+        return Gs, Gc
+
+
+class STCGNN(nn.Module):
+    """Encoder-decoder STC-GNN (reference ``STC_GNN.py:175-207``); the drop-in boundary."""
+
+    def __init__(self, num_nodes: int, num_categories: int, Ks: int, Kc: int, input_dim: int, hidden_dim: int,
+                 num_layers: int, out_horizon: int, use_bias=True, activation=None,
+                 graph_mode: str = 'dense-learned'):
+        super().__init__()
+        if graph_mode not in ('dense-learned', 'csr-fixed'):
+            raise ValueError("graph_mode must be 'dense-learned' (reference semantics) or 'csr-fixed'")
+        self.graph_mode = graph_mode
+        self.Ks, self.Kc = Ks, Kc
+        if graph_mode == 'dense-learned':
+            self.mix_graph_pair = MGP_Gen(num_nodes, num_categories, hidden_dim)
+        self.encoder = STC_Encoder(num_nodes, num_categories, Ks, Kc, input_dim, hidden_dim, num_layers,
+                                   use_bias, activation, return_all_layers=True)
+        self.decoder = STC_Decoder(num_nodes, num_categories, Ks, Kc, hidden_dim, hidden_dim, num_layers,
+                                   out_horizon, use_bias, activation)
+        self.out_proj = nn.Sequential(nn.Linear(hidden_dim, hidden_dim // 2, bias=use_bias),
+                                      nn.Linear(hidden_dim // 2, input_dim, bias=use_bias))
+
+    def forward(self, X_seq: torch.Tensor, As: GraphLike, Ac: torch.Tensor):
+        assert X_seq.dim() == 4, 'STC-GNN must take in 4D tensor as input X_seq'
+        if self.graph_mode == 'dense-learned':
+            Gs, Gc = self.mix_graph_pair(X_seq, As, Ac)
+        else:
+            Gs, Gc = As, Ac
+        pair = _graphs(Gs, Gc, self.Ks, self.Kc)
+        _, states = self.encoder(pair, None, X_seq.unsqueeze(-1))
+        step_in = states[-1]
+        outs = []
+        for _ in range(self.decoder.out_horizon):
+            step_in, states = self.decoder(pair, None, step_in, states)
+            outs.append(step_in)
+        y = torch.sigmoid(self.out_proj(torch.stack(outs, dim=1)))
+        return y.squeeze(dim=-1)

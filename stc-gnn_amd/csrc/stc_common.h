@@ -1,0 +1,72 @@
+// Shared host-side helpers for libstc_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "stc_hip.h"
+
+namespace stc {
+
+// thread-local text behind stc_last_error()
+char* error_buffer();
+
+inline int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(error_buffer(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+inline int hip_status(hipError_t e, const char* what) {
+    if (e == hipSuccess) return STC_OK;
+    snprintf(error_buffer(), 512, "%s: %s", what, hipGetErrorString(e));
+    return (int)e;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// MI355X: 256 CUs in 8 XCDs; workgroups are dealt round-robin to the XCDs.
+constexpr int kNumXcd = 8;
+constexpr int kNumCu = 256;
+constexpr int kWave = 64;
+constexpr size_t kMaxLdsBytes = 160 * 1024;
+
+// Raise the dynamic-LDS cap of a kernel when it asks for more than the 64 KiB default.
+template <typename K>
+inline hipError_t allow_lds(K kernel, size_t bytes) {
+    if (bytes <= 48 * 1024) return hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+#define STC_REQUIRE(cond, code, ...) \
+    do {                             \
+        if (!(cond)) return ::stc::fail(code, __VA_ARGS__); \
+    } while (0)
+
+#define STC_LAUNCH_CHECK(what) \
+    do {                        \
+        hipError_t e__ = hipGetLastError(); \
+        if (e__ != hipSuccess) return ::stc::hip_status(e__, what); \
+    } while (0)
+
+}  // namespace stc
+
+// ---- device helpers ---------------------------------------------------------
+// Contiguous band of tiles per XCD: blocks b and b+8 share an XCD (and its L2),
+// so give XCD x the tiles [x*per, (x+1)*per).  Returns -1 for the padding blocks.
+__device__ __forceinline__ int stc_xcd_tile(int bid, int n_tiles) {
+    const int per = (n_tiles + stc::kNumXcd - 1) / stc::kNumXcd;
+    const int tile = (bid % stc::kNumXcd) * per + bid / stc::kNumXcd;
+    return tile < n_tiles && (bid / stc::kNumXcd) < per ? tile : -1;
+}
+
+__device__ __forceinline__ float stc_wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}

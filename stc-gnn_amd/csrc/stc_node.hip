@@ -1,0 +1,410 @@
+// Node kernel of the BDG_Dif layer: category (2-mode) product + the K*K*L concat
+// + projection + bias, forward and backward, any (C, L, Ho, Ks, Kc) -- gfx950.
+//
+// Reference span: STC_GNN.py:38-45 (forward) and its autograd.  Per node row r
+// (one (batch, node) pair; C category rows of L features in each of the Ks
+// Chebyshev slabs Z_n):
+//
+//   U[c', (c,o)]  = sum_{n,l} Z_n[r,c',l] * W[(n,c,l), o]            "project"   (rows x KD) . (KD x J)
+//   Y[d, o]       = bias[o] + U[d,(0,o)] + sum_{c>=1} sum_{c'} T_c[c',d] * U[c',(c,o)]   "mix"
+//
+// i.e. project first, mix categories second: the concat of the reference is
+// never formed, T_0 = I costs nothing, and the mix runs on Ho (<= L) columns.
+// KD = Ks*L, J = Kc*Ho.  Backward, with Q[c',(c,o)] = sum_d T_c[c',d] dY[d,o]:
+//
+//   dZ_n[c',l] = sum_{c,o} Q[c',(c,o)] W[(n,c,l),o]       dW[(n,c,l),o] = sum_rows Z_n[c',l] Q[c',(c,o)]
+//   db[o] = sum_rows dY[d,o]                               dT_c[c',d] = sum_{node,o} U[c',(c,o)] dY[d,o]
+//
+// This file is the general fp32 VALU version (LDS-tiled, persistent workgroups);
+// weight-gradient partials are summed in a fixed order by a second kernel, so
+// results are bitwise reproducible.
+#include "stc_common.h"
+
+namespace {
+
+constexpr int NODE_THREADS = 256;
+constexpr int NODE_BWD_MAX_GRID = 512;
+
+struct ZPtrs { const float* p[STC_MAX_K]; };
+struct DZPtrs { float* p[STC_MAX_K]; };
+
+struct NodeDims {
+    int Ks, Kc, C, L, Ho;
+    int KD, J, KDp, Jp;     // contraction widths and their round-ups to 4
+    int TN, rows;           // nodes per tile, category rows per tile (TN*C)
+    int zs, qs, ds, wts;    // LDS row strides (floats): Zt, Ut/Qt, dYt, WsT
+};
+
+inline int up4(int v) { return (v + 3) & ~3; }
+
+NodeDims make_dims(int Ks, int Kc, int C, int L, int Ho) {
+    NodeDims d;
+    d.Ks = Ks; d.Kc = Kc; d.C = C; d.L = L; d.Ho = Ho;
+    d.KD = Ks * L; d.J = Kc * Ho;
+    d.KDp = up4(d.KD); d.Jp = up4(d.J);
+    d.TN = C >= 32 ? 1 : 32 / C;
+    d.rows = d.TN * C;
+    d.zs = d.KDp + 4; d.qs = d.Jp + 4; d.ds = up4(Ho) + 4; d.wts = d.KDp + 4;
+    return d;
+}
+
+// forward LDS carve (floats)
+struct FwdCarve { int Ws, Ts, bias, Zt, Ut, total; };
+FwdCarve fwd_carve(const NodeDims& d) {
+    FwdCarve c; int o = 0;
+    c.Ws = o;   o += d.KD * d.Jp;
+    c.Ts = o;   o += up4((d.Kc > 1 ? d.Kc - 1 : 0) * d.C * d.C);
+    c.bias = o; o += up4(d.Ho);
+    c.Zt = o;   o += d.rows * d.zs;
+    c.Ut = o;   o += d.rows * d.qs;
+    c.total = o;
+    return c;
+}
+
+// backward LDS carve (floats)
+struct BwdCarve { int WsT, Ts, Zt, dYt, Qt, Ut, dWacc, dbacc, dTacc, total; };
+BwdCarve bwd_carve(const NodeDims& d, bool want_dT) {
+    BwdCarve c; int o = 0;
+    const int nT = (d.Kc > 1 ? d.Kc - 1 : 0) * d.C * d.C;
+    c.WsT = o;   o += d.J * d.wts;
+    c.Ts = o;    o += up4(nT);
+    c.Zt = o;    o += d.rows * d.zs;
+    c.dYt = o;   o += d.rows * d.ds;
+    c.Qt = o;    o += d.rows * d.qs;
+    c.Ut = o;    o += want_dT ? d.rows * d.qs : 0;
+    c.dWacc = o; o += d.KDp * d.Jp;
+    c.dbacc = o; o += up4(d.Ho);
+    c.dTacc = o; o += want_dT ? up4(nT) : 0;
+    c.total = o;
+    return c;
+}
+
+__device__ __forceinline__ void fma4(float4& a, float s, const float4& w) {
+    a.x = fmaf(s, w.x, a.x); a.y = fmaf(s, w.y, a.y); a.z = fmaf(s, w.z, a.z); a.w = fmaf(s, w.w, a.w);
+}
+
+// ------------------------------------------------------------------ forward
+__global__ __launch_bounds__(NODE_THREADS) void bdg_node_fwd_kernel(
+    ZPtrs Z, const float* __restrict__ Tc, const float* __restrict__ W, const float* __restrict__ bias,
+    float* __restrict__ Y, long long total_rows, NodeDims d, FwdCarve cv, int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ws = smem + cv.Ws;
+    float* Ts = smem + cv.Ts;
+    float* sb = smem + cv.bias;
+    float* Zt = smem + cv.Zt;
+    float* Ut = smem + cv.Ut;
+    const int tid = threadIdx.x;
+    const int CC = d.C * d.C;
+
+    // stage W as Ws[k=(n,l)][j=(c,o)], T_1.. and the bias once per workgroup
+    for (int idx = tid; idx < d.KD * d.Jp; idx += NODE_THREADS) {
+        const int k = idx / d.Jp, j = idx - k * d.Jp;
+        float v = 0.f;
+        if (j < d.J) {
+            const int n = k / d.L, l = k - n * d.L, c = j / d.Ho, o = j - c * d.Ho;
+            v = W[((size_t)(n * d.Kc + c) * d.L + l) * d.Ho + o];
+        }
+        Ws[idx] = v;
+    }
+    for (int idx = tid; idx < (d.Kc - 1) * CC; idx += NODE_THREADS) Ts[idx] = Tc[CC + idx];
+    for (int idx = tid; idx < d.Ho; idx += NODE_THREADS) sb[idx] = bias ? bias[idx] : 0.f;
+    __syncthreads();
+
+    const int n_cg = d.Jp / 4;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const long long row0 = (long long)tile * d.rows;
+        const int rows_here = (int)min((long long)d.rows, total_rows - row0);
+        for (int n = 0; n < d.Ks; ++n) {
+            const float* src = Z.p[n] + row0 * d.L;
+            for (int idx = tid; idx < d.rows * d.L; idx += NODE_THREADS) {
+                const int r = idx / d.L, l = idx - r * d.L;
+                Zt[r * d.zs + n * d.L + l] = idx < rows_here * d.L ? src[idx] : 0.f;
+            }
+        }
+        __syncthreads();
+        // project: Ut[r][j0..j0+3] = sum_k Zt[r][k] * Ws[k][j0..j0+3]
+        for (int mt = tid; mt < d.rows * n_cg; mt += NODE_THREADS) {
+            const int r = mt / n_cg, j0 = (mt - r * n_cg) * 4;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float* zr = Zt + r * d.zs;
+            for (int k = 0; k < d.KD; ++k) fma4(acc, zr[k], *reinterpret_cast<const float4*>(Ws + k * d.Jp + j0));
+            *reinterpret_cast<float4*>(Ut + r * d.qs + j0) = acc;
+        }
+        __syncthreads();
+        // mix: Y[r=(node,dd)][o] = b[o] + U[r][(0,o)] + sum_{c>=1} sum_{c'} T_c[c'][dd] U[(node,c')][(c,o)]
+        for (int e = tid; e < rows_here * d.Ho; e += NODE_THREADS) {
+            const int r = e / d.Ho, o = e - r * d.Ho;
+            const int node = r / d.C, dd = r - node * d.C;
+            float y = sb[o] + Ut[r * d.qs + o];
+            for (int c = 1; c < d.Kc; ++c) {
+                const float* T = Ts + (c - 1) * CC + dd;
+                const float* Uc = Ut + (node * d.C) * d.qs + c * d.Ho + o;
+                for (int cp = 0; cp < d.C; ++cp) y = fmaf(T[cp * d.C], Uc[cp * d.qs], y);
+            }
+            Y[(row0 + r) * d.Ho + o] = y;
+        }
+        // no barrier needed here: the next tile's load only writes Zt, which the mix does not read,
+        // and its project phase (which rewrites Ut) sits behind the barrier after that load.
+    }
+}
+
+// ------------------------------------------------------------------ backward
+__global__ __launch_bounds__(NODE_THREADS) void bdg_node_bwd_kernel(
+    ZPtrs Z, const float* __restrict__ Tc, const float* __restrict__ W, const float* __restrict__ dY,
+    DZPtrs dZ, float* __restrict__ partial, long long total_rows, NodeDims d, BwdCarve cv,
+    int n_tiles, int want_dT, int want_db) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* WsT = smem + cv.WsT;
+    float* Ts = smem + cv.Ts;
+    float* Zt = smem + cv.Zt;
+    float* dYt = smem + cv.dYt;
+    float* Qt = smem + cv.Qt;
+    float* Ut = smem + cv.Ut;
+    float* dWacc = smem + cv.dWacc;
+    float* dbacc = smem + cv.dbacc;
+    float* dTacc = smem + cv.dTacc;
+    const int tid = threadIdx.x;
+    const int CC = d.C * d.C;
+    const int nT = (d.Kc - 1) * CC;
+
+    // WsT[j=(c,o)][k=(n,l)] (k padded with zeros), T_1.., zeroed accumulators and pad columns
+    for (int idx = tid; idx < d.J * d.wts; idx += NODE_THREADS) {
+        const int j = idx / d.wts, k = idx - j * d.wts;
+        float v = 0.f;
+        if (k < d.KD) {
+            const int n = k / d.L, l = k - n * d.L, c = j / d.Ho, o = j - c * d.Ho;
+            v = W[((size_t)(n * d.Kc + c) * d.L + l) * d.Ho + o];
+        }
+        WsT[idx] = v;
+    }
+    for (int idx = tid; idx < nT; idx += NODE_THREADS) Ts[idx] = Tc[CC + idx];
+    for (int idx = tid; idx < d.KDp * d.Jp; idx += NODE_THREADS) dWacc[idx] = 0.f;
+    for (int idx = tid; idx < d.Ho; idx += NODE_THREADS) dbacc[idx] = 0.f;
+    if (want_dT) for (int idx = tid; idx < nT; idx += NODE_THREADS) dTacc[idx] = 0.f;
+    for (int idx = tid; idx < d.rows * d.zs; idx += NODE_THREADS) Zt[idx] = 0.f;
+    for (int idx = tid; idx < d.rows * d.qs; idx += NODE_THREADS) Qt[idx] = 0.f;
+    __syncthreads();
+
+    const int n_kg = d.KDp / 4, n_jg = d.Jp / 4;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const long long row0 = (long long)tile * d.rows;
+        const int rows_here = (int)min((long long)d.rows, total_rows - row0);
+        for (int n = 0; n < d.Ks; ++n) {
+            const float* src = Z.p[n] + row0 * d.L;
+            for (int idx = tid; idx < d.rows * d.L; idx += NODE_THREADS) {
+                const int r = idx / d.L, l = idx - r * d.L;
+                Zt[r * d.zs + n * d.L + l] = idx < rows_here * d.L ? src[idx] : 0.f;
+            }
+        }
+        {
+            const float* src = dY + row0 * d.Ho;
+            for (int idx = tid; idx < d.rows * d.Ho; idx += NODE_THREADS) {
+                const int r = idx / d.Ho, o = idx - r * d.Ho;
+                dYt[r * d.ds + o] = idx < rows_here * d.Ho ? src[idx] : 0.f;
+            }
+        }
+        __syncthreads();
+        // Q[r=(node,c')][(c,o)] = sum_dd T_c[c'][dd] dY[(node,dd)][o]   (c = 0: Q = dY)
+        for (int e = tid; e < d.rows * d.J; e += NODE_THREADS) {
+            const int r = e / d.J, j = e - r * d.J;
+            const int c = j / d.Ho, o = j - c * d.Ho;
+            float q;
+            if (c == 0) {
+                q = dYt[r * d.ds + o];
+            } else {
+                const int node = r / d.C, cp = r - node * d.C;
+                const float* T = Ts + (c - 1) * CC + cp * d.C;
+                const float* g = dYt + (node * d.C) * d.ds + o;
+                q = 0.f;
+                for (int dd = 0; dd < d.C; ++dd) q = fmaf(T[dd], g[dd * d.ds], q);
+            }
+            Qt[r * d.qs + j] = q;
+        }
+        if (want_dT) {   // U recomputed for dT_c: U[r][j] = sum_k Zt[r][k] * WsT[j][k]
+            for (int e = tid; e < d.rows * d.J; e += NODE_THREADS) {
+                const int r = e / d.J, j = e - r * d.J;
+                const float* zr = Zt + r * d.zs;
+                const float* wr = WsT + j * d.wts;
+                float u = 0.f;
+                for (int k = 0; k < d.KD; ++k) u = fmaf(zr[k], wr[k], u);
+                Ut[r * d.qs + j] = u;
+            }
+        }
+        __syncthreads();
+        // dZ[r][k0..k0+3] = sum_j Q[r][j] * WsT[j][k0..k0+3]
+        for (int mt = tid; mt < rows_here * n_kg; mt += NODE_THREADS) {
+            const int r = mt / n_kg, k0 = (mt - r * n_kg) * 4;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float* qr = Qt + r * d.qs;
+            for (int j = 0; j < d.J; ++j) fma4(acc, qr[j], *reinterpret_cast<const float4*>(WsT + j * d.wts + k0));
+            const float a[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = k0 + q;
+                if (k < d.KD) {
+                    const int n = k / d.L, l = k - n * d.L;
+                    dZ.p[n][(row0 + r) * d.L + l] = a[q];
+                }
+            }
+        }
+        // dW[k0..k0+3][j0..j0+3] += sum_r Zt[r][k] * Q[r][j]     (4x4 block per thread, accumulators in LDS)
+        for (int blk = tid; blk < n_kg * n_jg; blk += NODE_THREADS) {
+            const int k0 = (blk / n_jg) * 4, j0 = (blk - (blk / n_jg) * n_jg) * 4;
+            float4 a0 = *reinterpret_cast<float4*>(dWacc + (k0 + 0) * d.Jp + j0);
+            float4 a1 = *reinterpret_cast<float4*>(dWacc + (k0 + 1) * d.Jp + j0);
+            float4 a2 = *reinterpret_cast<float4*>(dWacc + (k0 + 2) * d.Jp + j0);
+            float4 a3 = *reinterpret_cast<float4*>(dWacc + (k0 + 3) * d.Jp + j0);
+            for (int r = 0; r < d.rows; ++r) {
+                const float4 z = *reinterpret_cast<const float4*>(Zt + r * d.zs + k0);
+                const float4 q = *reinterpret_cast<const float4*>(Qt + r * d.qs + j0);
+                fma4(a0, z.x, q); fma4(a1, z.y, q); fma4(a2, z.z, q); fma4(a3, z.w, q);
+            }
+            *reinterpret_cast<float4*>(dWacc + (k0 + 0) * d.Jp + j0) = a0;
+            *reinterpret_cast<float4*>(dWacc + (k0 + 1) * d.Jp + j0) = a1;
+            *reinterpret_cast<float4*>(dWacc + (k0 + 2) * d.Jp + j0) = a2;
+            *reinterpret_cast<float4*>(dWacc + (k0 + 3) * d.Jp + j0) = a3;
+        }
+        if (want_db) {
+            for (int o = tid; o < d.Ho; o += NODE_THREADS) {
+                float s = dbacc[o];
+                for (int r = 0; r < d.rows; ++r) s += dYt[r * d.ds + o];
+                dbacc[o] = s;
+            }
+        }
+        if (want_dT) {   // dT_c[c'][dd] += sum_{node,o} U[(node,c')][(c,o)] * dY[(node,dd)][o]
+            for (int e = tid; e < nT; e += NODE_THREADS) {
+                const int c1 = e / CC, rem = e - c1 * CC;
+                const int cp = rem / d.C, dd = rem - cp * d.C;
+                float s = dTacc[e];
+                for (int node = 0; node < d.TN; ++node) {
+                    const float* u = Ut + (node * d.C + cp) * d.qs + (c1 + 1) * d.Ho;
+                    const float* g = dYt + (node * d.C + dd) * d.ds;
+                    for (int o = 0; o < d.Ho; ++o) s = fmaf(u[o], g[o], s);
+                }
+                dTacc[e] = s;
+            }
+        }
+        __syncthreads();   // Zt/dYt/Qt/Ut are rewritten by the next tile
+    }
+
+    // this workgroup's partial sums, already in destination layout: [dW (Ks*Kc*L*Ho) | db (Ho) | dT (Kc*C*C)]
+    const int nW = d.Ks * d.Kc * d.L * d.Ho;
+    float* out = partial + (size_t)blockIdx.x * (nW + d.Ho + d.Kc * CC);
+    for (int idx = tid; idx < nW; idx += NODE_THREADS) {
+        const int o = idx % d.Ho;
+        int t = idx / d.Ho;
+        const int l = t % d.L; t /= d.L;
+        const int c = t % d.Kc, n = t / d.Kc;
+        out[idx] = dWacc[(n * d.L + l) * d.Jp + c * d.Ho + o];
+    }
+    for (int idx = tid; idx < d.Ho; idx += NODE_THREADS) out[nW + idx] = dbacc[idx];
+    for (int idx = tid; idx < d.Kc * CC; idx += NODE_THREADS)
+        out[nW + d.Ho + idx] = (want_dT && idx >= CC) ? dTacc[idx - CC] : 0.f;
+}
+
+// Fixed-order sum of the per-workgroup partials into dW | db | dT.
+__global__ __launch_bounds__(NODE_THREADS) void bdg_node_reduce_kernel(
+    const float* __restrict__ partial, int n_parts, int stride, int nW, int Ho, int nT,
+    float* dW, float* db, float* dT) {
+    const int e = blockIdx.x * NODE_THREADS + threadIdx.x;
+    if (e >= stride) return;
+    float s = 0.f;
+    for (int p = 0; p < n_parts; ++p) s += partial[(size_t)p * stride + e];
+    if (e < nW) dW[e] = s;
+    else if (e < nW + Ho) { if (db) db[e - nW] = s; }
+    else if (dT) dT[e - nW - Ho] = s;
+}
+
+int check_dims(const char* who, int Ks, int Kc, int C, int L, int Ho, long long nodes) {
+    STC_REQUIRE(Ks >= 1 && Ks <= STC_MAX_K && Kc >= 1 && Kc <= STC_MAX_K, STC_ELIMIT,
+                "%s: Chebyshev orders Ks=%d Kc=%d outside [1,%d]", who, Ks, Kc, STC_MAX_K);
+    STC_REQUIRE(C >= 1 && L >= 1 && Ho >= 1 && nodes >= 0, STC_EINVAL,
+                "%s: bad sizes C=%d L=%d Ho=%d nodes=%lld", who, C, L, Ho, nodes);
+    STC_REQUIRE(nodes * (long long)C < (1ll << 31), STC_ELIMIT, "%s: nodes*C = %lld exceeds 2^31", who, nodes * (long long)C);
+    return STC_OK;
+}
+
+int bwd_grid(const NodeDims& d, long long nodes) {
+    const long long n_tiles = (nodes + d.TN - 1) / d.TN;
+    return (int)(n_tiles < NODE_BWD_MAX_GRID ? n_tiles : NODE_BWD_MAX_GRID);
+}
+
+}  // namespace
+
+extern "C" int stc_bdg_node_fwd_f32(const float* const* Z, int32_t Ks, const float* Tc, int32_t Kc,
+                                    const float* W, const float* bias, float* Y,
+                                    int64_t nodes, int32_t C, int32_t L, int32_t Ho, void* stream) {
+    if (int rc = check_dims("stc_bdg_node_fwd_f32", Ks, Kc, C, L, Ho, nodes)) return rc;
+    if (nodes == 0) return STC_OK;
+    STC_REQUIRE(Z && W && Y && (Kc == 1 || Tc), STC_EINVAL, "stc_bdg_node_fwd_f32: null Z/W/Y/Tc");
+    ZPtrs zp{};
+    for (int n = 0; n < Ks; ++n) {
+        STC_REQUIRE(Z[n], STC_EINVAL, "stc_bdg_node_fwd_f32: Z[%d] is null", n);
+        zp.p[n] = Z[n];
+    }
+    const NodeDims d = make_dims(Ks, Kc, C, L, Ho);
+    const FwdCarve cv = fwd_carve(d);
+    const size_t lds = (size_t)cv.total * sizeof(float);
+    STC_REQUIRE(lds <= stc::kMaxLdsBytes, STC_ELIMIT,
+                "stc_bdg_node_fwd_f32: needs %zu B of LDS (C=%d L=%d Ho=%d Ks=%d Kc=%d), limit %zu", lds, C, L, Ho, Ks, Kc, stc::kMaxLdsBytes);
+    if (int rc = stc::hip_status(stc::allow_lds(bdg_node_fwd_kernel, lds), "hipFuncSetAttribute(node fwd)")) return rc;
+    const long long n_tiles = (nodes + d.TN - 1) / d.TN;
+    const int grid = (int)(n_tiles < 4 * stc::kNumCu ? n_tiles : 4 * stc::kNumCu);
+    hipLaunchKernelGGL(bdg_node_fwd_kernel, dim3(grid), dim3(NODE_THREADS), lds, static_cast<hipStream_t>(stream),
+                       zp, Tc, W, bias, Y, (long long)nodes * C, d, cv, (int)n_tiles);
+    STC_LAUNCH_CHECK("stc_bdg_node_fwd_f32 launch");
+    return STC_OK;
+}
+
+extern "C" size_t stc_bdg_node_bwd_workspace_bytes(int32_t Ks, int32_t Kc, int32_t C, int32_t L, int32_t Ho,
+                                                   int32_t /*want_dTc*/) {
+    if (Ks < 1 || Kc < 1 || C < 1 || L < 1 || Ho < 1) return 0;
+    const size_t per = (size_t)Ks * Kc * L * Ho + Ho + (size_t)Kc * C * C;
+    return per * sizeof(float) * NODE_BWD_MAX_GRID;
+}
+
+extern "C" int stc_bdg_node_bwd_f32(const float* const* Z, int32_t Ks, const float* Tc, int32_t Kc,
+                                    const float* W, const float* dY,
+                                    float* const* dZ, float* dW, float* db, float* dTc,
+                                    void* workspace, size_t workspace_bytes,
+                                    int64_t nodes, int32_t C, int32_t L, int32_t Ho, void* stream) {
+    if (int rc = check_dims("stc_bdg_node_bwd_f32", Ks, Kc, C, L, Ho, nodes)) return rc;
+    STC_REQUIRE(Z && W && dZ && dW && (Kc == 1 || Tc), STC_EINVAL, "stc_bdg_node_bwd_f32: null Z/W/dZ/dW/Tc");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int nW = Ks * Kc * L * Ho, nT = Kc * C * C;
+    if (nodes == 0) {   // gradients of an empty batch are zero
+        if (int rc = stc::hip_status(hipMemsetAsync(dW, 0, (size_t)nW * sizeof(float), s), "memset dW")) return rc;
+        if (db) if (int rc = stc::hip_status(hipMemsetAsync(db, 0, (size_t)Ho * sizeof(float), s), "memset db")) return rc;
+        if (dTc) if (int rc = stc::hip_status(hipMemsetAsync(dTc, 0, (size_t)nT * sizeof(float), s), "memset dTc")) return rc;
+        return STC_OK;
+    }
+    STC_REQUIRE(dY, STC_EINVAL, "stc_bdg_node_bwd_f32: null dY");
+    ZPtrs zp{};
+    DZPtrs dzp{};
+    for (int n = 0; n < Ks; ++n) {
+        STC_REQUIRE(Z[n] && dZ[n], STC_EINVAL, "stc_bdg_node_bwd_f32: Z[%d]/dZ[%d] is null", n, n);
+        zp.p[n] = Z[n];
+        dzp.p[n] = dZ[n];
+    }
+    STC_REQUIRE(workspace && stc::aligned16(workspace), STC_EALIGN, "stc_bdg_node_bwd_f32: workspace null or not 16-byte aligned");
+    STC_REQUIRE(workspace_bytes >= stc_bdg_node_bwd_workspace_bytes(Ks, Kc, C, L, Ho, dTc != nullptr), STC_EINVAL,
+                "stc_bdg_node_bwd_f32: workspace of %zu B is too small", workspace_bytes);
+    const NodeDims d = make_dims(Ks, Kc, C, L, Ho);
+    const bool want_dT = dTc != nullptr && Kc > 1;
+    const BwdCarve cv = bwd_carve(d, want_dT);
+    const size_t lds = (size_t)cv.total * sizeof(float);
+    STC_REQUIRE(lds <= stc::kMaxLdsBytes, STC_ELIMIT,
+                "stc_bdg_node_bwd_f32: needs %zu B of LDS (C=%d L=%d Ho=%d Ks=%d Kc=%d), limit %zu", lds, C, L, Ho, Ks, Kc, stc::kMaxLdsBytes);
+    if (int rc = stc::hip_status(stc::allow_lds(bdg_node_bwd_kernel, lds), "hipFuncSetAttribute(node bwd)")) return rc;
+    const long long n_tiles = (nodes + d.TN - 1) / d.TN;
+    const int grid = bwd_grid(d, nodes);
+    float* partial = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(bdg_node_bwd_kernel, dim3(grid), dim3(NODE_THREADS), lds, s,
+                       zp, Tc, W, dY, dzp, partial, (long long)nodes * C, d, cv, (int)n_tiles, (int)want_dT, (int)(db != nullptr));
+    STC_LAUNCH_CHECK("stc_bdg_node_bwd_f32 launch");
+    const int stride = nW + Ho + nT;
+    hipLaunchKernelGGL(bdg_node_reduce_kernel, dim3((stride + NODE_THREADS - 1) / NODE_THREADS), dim3(NODE_THREADS), 0, s,
+                       partial, grid, stride, nW, Ho, nT, dW, db, dTc);
+    STC_LAUNCH_CHECK("stc_bdg_node_reduce launch");
+    return STC_OK;
+}

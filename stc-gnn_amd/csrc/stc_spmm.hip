@@ -1,0 +1,246 @@
+// CSR SpMM / SDDMM for the spatial (1-mode) aggregation of STC-GNN on gfx950.
+//
+//   Y[b,i,:] = alpha * sum_j val[j] * X[b, col[j], :] + beta * Y0[b,i,:]
+//
+// Replaces torch.einsum('bncl,nm->bmcl', X, T_n(Gs)) (reference STC_GNN.py:37)
+// and, with (alpha,beta) = (2,-1), one step of the Chebyshev recurrence of
+// STC_GNN.py:28 applied on the feature side.  HBM-bound: a feature row is
+// F = C*L contiguous floats (4 KiB at C=32, L=32) and is streamed with one
+// 16-byte load per lane, 1 KiB per wave instruction.
+//
+// Layout of one launch (vector path):
+//   workgroup  = SPMM_ROWS consecutive output rows of one batch element
+//   CSR stage  = rowptr slice + the (col,val) segment of those rows -> LDS, one coalesced pass
+//   wave       = one output row at a time; (col,val) read from LDS are wave-uniform and
+//                moved to SGPRs (readfirstlane) so the row base address is scalar
+//   lane       = VPT float4 chunks of the row, 4 neighbour rows in flight (16 loads/lane)
+//   blocks     = remapped so each XCD walks a contiguous band of rows: the rows a band
+//                gathers (its own +- the graph bandwidth) stay in that XCD's 4 MiB L2
+#include "stc_common.h"
+
+namespace {
+
+constexpr int SPMM_THREADS = 256;
+constexpr int SPMM_WAVES = SPMM_THREADS / 64;
+constexpr int SPMM_ROWS = 8;         // output rows per workgroup
+constexpr int SPMM_SEG_CAP = 1024;   // CSR entries staged in LDS per workgroup
+
+__device__ __forceinline__ float uniform_f(float v) {
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
+
+__device__ __forceinline__ void fma4(float4& acc, float s, const float4& x) {
+    acc.x = fmaf(s, x.x, acc.x);
+    acc.y = fmaf(s, x.y, acc.y);
+    acc.z = fmaf(s, x.z, acc.z);
+    acc.w = fmaf(s, x.w, acc.w);
+}
+
+template <int VPT>
+__global__ __launch_bounds__(SPMM_THREADS) void spmm_wave_row_kernel(
+    const int* __restrict__ rowptr, const int* __restrict__ colidx, const float* __restrict__ val,
+    int n_rows, int n_cols, const float4* __restrict__ X, const float4* Y0, float4* Y,
+    int F4, float alpha, float beta, int n_tiles) {
+    __shared__ int s_rp[SPMM_ROWS + 1];
+    __shared__ int s_col[SPMM_SEG_CAP];
+    __shared__ float s_val[SPMM_SEG_CAP];
+
+    const int tile = stc_xcd_tile(blockIdx.x, n_tiles);
+    if (tile < 0) return;                       // whole workgroup leaves together
+    const int b = blockIdx.y;
+    const int row0 = tile * SPMM_ROWS;
+    const int nr = min(SPMM_ROWS, n_rows - row0);
+
+    if ((int)threadIdx.x <= nr) s_rp[threadIdx.x] = rowptr[row0 + threadIdx.x];
+    __syncthreads();
+    const int seg0 = s_rp[0];
+    const int seg_n = min(s_rp[nr] - seg0, SPMM_SEG_CAP);
+    for (int t = threadIdx.x; t < seg_n; t += SPMM_THREADS) {
+        s_col[t] = colidx[seg0 + t];
+        s_val[t] = val[seg0 + t];
+    }
+    __syncthreads();
+
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const float4* Xb = X + (size_t)b * n_cols * F4;
+    const size_t out_base = (size_t)b * n_rows * F4;
+
+    for (int r = wave; r < nr; r += SPMM_WAVES) {
+        const int js = s_rp[r] - seg0;
+        const int je = s_rp[r + 1] - seg0;
+        const size_t orow = out_base + (size_t)(row0 + r) * F4;
+        for (int cb = 0; cb < F4; cb += 64 * VPT) {
+            float4 acc[VPT];
+#pragma unroll
+            for (int p = 0; p < VPT; ++p) acc[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+            auto entry = [&](int j, int& c, float& v) {
+                if (j < SPMM_SEG_CAP) {
+                    c = s_col[j];
+                    v = s_val[j];
+                } else {                       // rows longer than the staged segment (dense graphs)
+                    c = colidx[seg0 + j];
+                    v = val[seg0 + j];
+                }
+                c = __builtin_amdgcn_readfirstlane(c);
+                v = uniform_f(v);
+            };
+
+            int j = js;
+            for (; j + 4 <= je; j += 4) {
+                int c[4];
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) entry(j + u, c[u], v[u]);
+                float4 x[4][VPT];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float4* xr = Xb + (size_t)c[u] * F4;
+#pragma unroll
+                    for (int p = 0; p < VPT; ++p) {
+                        const int ch = cb + lane + 64 * p;
+                        x[u][p] = ch < F4 ? xr[ch] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int p = 0; p < VPT; ++p) fma4(acc[p], v[u], x[u][p]);
+            }
+            for (; j < je; ++j) {
+                int c;
+                float v;
+                entry(j, c, v);
+                const float4* xr = Xb + (size_t)c * F4;
+#pragma unroll
+                for (int p = 0; p < VPT; ++p) {
+                    const int ch = cb + lane + 64 * p;
+                    if (ch < F4) fma4(acc[p], v, xr[ch]);
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < VPT; ++p) {
+                const int ch = cb + lane + 64 * p;
+                if (ch < F4) {
+                    float4 o = make_float4(alpha * acc[p].x, alpha * acc[p].y, alpha * acc[p].z, alpha * acc[p].w);
+                    if (beta != 0.f) {
+                        const float4 y0 = Y0[orow + ch];
+                        o.x = fmaf(beta, y0.x, o.x);
+                        o.y = fmaf(beta, y0.y, o.y);
+                        o.z = fmaf(beta, y0.z, o.z);
+                        o.w = fmaf(beta, y0.w, o.w);
+                    }
+                    Y[orow + ch] = o;
+                }
+            }
+        }
+    }
+}
+
+// Any F, any alignment (SF shape: F = C*L = 85): lanes_per_row threads share a row.
+__global__ __launch_bounds__(SPMM_THREADS) void spmm_generic_kernel(
+    const int* __restrict__ rowptr, const int* __restrict__ colidx, const float* __restrict__ val,
+    int n_rows, int n_cols, const float* __restrict__ X, const float* Y0, float* Y,
+    int F, float alpha, float beta, int lanes_per_row) {
+    const int rows_per_block = SPMM_THREADS / lanes_per_row;
+    const int r = threadIdx.x / lanes_per_row;
+    const int lr = threadIdx.x % lanes_per_row;
+    const int i = blockIdx.x * rows_per_block + r;
+    if (i >= n_rows) return;
+    const int b = blockIdx.y;
+    const int js = rowptr[i], je = rowptr[i + 1];
+    const float* Xb = X + (size_t)b * n_cols * F;
+    const size_t orow = ((size_t)b * n_rows + i) * F;
+    for (int f = lr; f < F; f += lanes_per_row) {
+        float acc = 0.f;
+        for (int j = js; j < je; ++j) acc = fmaf(val[j], Xb[(size_t)colidx[j] * F + f], acc);
+        float o = alpha * acc;
+        if (beta != 0.f) o = fmaf(beta, Y0[orow + f], o);
+        Y[orow + f] = o;
+    }
+}
+
+// out[j] (+)= alpha * sum_b <A[b,i,:], Bm[b,col[j],:]> ; one wave per stored entry.
+__global__ __launch_bounds__(SPMM_THREADS) void sddmm_kernel(
+    const int* __restrict__ rowptr, const int* __restrict__ colidx, int n_rows, int n_cols,
+    const float* __restrict__ A, const float* __restrict__ Bm, float* out,
+    int batch, int F, float alpha, int accumulate) {
+    const int i = blockIdx.x;
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int js = rowptr[i], je = rowptr[i + 1];
+    for (int j = js + wave; j < je; j += SPMM_WAVES) {
+        const int c = colidx[j];
+        float s = 0.f;
+        for (int b = 0; b < batch; ++b) {
+            const float* a = A + ((size_t)b * n_rows + i) * F;
+            const float* bm = Bm + ((size_t)b * n_cols + c) * F;
+            for (int f = lane; f < F; f += 64) s = fmaf(a[f], bm[f], s);
+        }
+        s = stc_wave_sum(s);
+        if (lane == 0) out[j] = accumulate ? fmaf(alpha, s, out[j]) : alpha * s;
+    }
+}
+
+int next_pow2(int v) {
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+}  // namespace
+
+extern "C" int stc_csr_spmm_f32(const int32_t* rowptr, const int32_t* colidx, const float* val,
+                                int32_t n_rows, int32_t n_cols,
+                                const float* X, const float* Y0, float* Y,
+                                int32_t batch, int32_t F, float alpha, float beta, void* stream) {
+    STC_REQUIRE(n_rows >= 0 && n_cols >= 0 && batch >= 0 && F >= 0, STC_EINVAL,
+                "stc_csr_spmm_f32: negative size (n_rows=%d n_cols=%d batch=%d F=%d)", n_rows, n_cols, batch, F);
+    if (n_rows == 0 || batch == 0 || F == 0) return STC_OK;
+    STC_REQUIRE(rowptr && Y, STC_EINVAL, "stc_csr_spmm_f32: null rowptr/Y");
+    STC_REQUIRE(n_cols > 0 && X, STC_EINVAL, "stc_csr_spmm_f32: null X or n_cols == 0 with rows to produce");
+    STC_REQUIRE(colidx && val, STC_EINVAL, "stc_csr_spmm_f32: null colidx/val");
+    STC_REQUIRE(beta == 0.f || Y0, STC_EINVAL, "stc_csr_spmm_f32: beta != 0 needs Y0");
+    STC_REQUIRE(batch <= 65535, STC_ELIMIT, "stc_csr_spmm_f32: batch %d > 65535 (grid.y)", batch);
+    STC_REQUIRE(X != Y, STC_EINVAL, "stc_csr_spmm_f32: X must not alias Y");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+
+    const bool vec = (F % 4 == 0) && stc::aligned16(X) && stc::aligned16(Y) && (Y0 == nullptr || stc::aligned16(Y0)) && F >= 64;
+    if (vec) {
+        const int F4 = F / 4;
+        const int n_tiles = (n_rows + SPMM_ROWS - 1) / SPMM_ROWS;
+        const int per = (n_tiles + stc::kNumXcd - 1) / stc::kNumXcd;
+        dim3 grid(per * stc::kNumXcd, batch), block(SPMM_THREADS);
+        const float4* X4 = reinterpret_cast<const float4*>(X);
+        const float4* Y04 = reinterpret_cast<const float4*>(Y0);
+        float4* Y4 = reinterpret_cast<float4*>(Y);
+        if (F4 <= 64)
+            hipLaunchKernelGGL(spmm_wave_row_kernel<1>, grid, block, 0, s, rowptr, colidx, val, n_rows, n_cols, X4, Y04, Y4, F4, alpha, beta, n_tiles);
+        else if (F4 <= 128)
+            hipLaunchKernelGGL(spmm_wave_row_kernel<2>, grid, block, 0, s, rowptr, colidx, val, n_rows, n_cols, X4, Y04, Y4, F4, alpha, beta, n_tiles);
+        else
+            hipLaunchKernelGGL(spmm_wave_row_kernel<4>, grid, block, 0, s, rowptr, colidx, val, n_rows, n_cols, X4, Y04, Y4, F4, alpha, beta, n_tiles);
+    } else {
+        const int lanes = next_pow2(F) < SPMM_THREADS ? next_pow2(F) : SPMM_THREADS;
+        const int rows_per_block = SPMM_THREADS / lanes;
+        dim3 grid((n_rows + rows_per_block - 1) / rows_per_block, batch), block(SPMM_THREADS);
+        hipLaunchKernelGGL(spmm_generic_kernel, grid, block, 0, s, rowptr, colidx, val, n_rows, n_cols, X, Y0, Y, F, alpha, beta, lanes);
+    }
+    STC_LAUNCH_CHECK("stc_csr_spmm_f32 launch");
+    return STC_OK;
+}
+
+extern "C" int stc_csr_sddmm_f32(const int32_t* rowptr, const int32_t* colidx,
+                                 int32_t n_rows, int32_t n_cols,
+                                 const float* A, const float* Bm, float* out,
+                                 int32_t batch, int32_t F, float alpha, int32_t accumulate, void* stream) {
+    STC_REQUIRE(n_rows >= 0 && n_cols >= 0 && batch >= 0 && F >= 0, STC_EINVAL, "stc_csr_sddmm_f32: negative size");
+    if (n_rows == 0) return STC_OK;
+    STC_REQUIRE(rowptr && colidx && out, STC_EINVAL, "stc_csr_sddmm_f32: null rowptr/colidx/out");
+    STC_REQUIRE((batch == 0 || F == 0) || (A && Bm), STC_EINVAL, "stc_csr_sddmm_f32: null A/Bm");
+    hipLaunchKernelGGL(sddmm_kernel, dim3(n_rows), dim3(SPMM_THREADS), 0, static_cast<hipStream_t>(stream),
+                       rowptr, colidx, n_rows, n_cols, A, Bm, out, batch, F, alpha, accumulate);
+    STC_LAUNCH_CHECK("stc_csr_sddmm_f32 launch");
+    return STC_OK;
+}

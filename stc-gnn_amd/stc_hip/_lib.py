@@ -1,0 +1,331 @@
+"""ctypes binding of ``libstc_hip.so`` (C ABI: ``include/stc_hip.h``).
+
+``HipKernels`` exposes one method per exported kernel, taking torch tensors
+that live on the MI355X: it checks device / dtype / contiguity / shapes on
+the host (a wrong shape handed to a hand-written kernel can fault the GPU),
+passes raw device pointers plus the current HIP stream, and turns a non-zero
+return code into ``StcError`` carrying ``stc_last_error()``.
+
+There is no CPU implementation behind this class: if the shared library is
+missing or a tensor is not a ROCm tensor the call fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import torch
+
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG_ROOT, 'libstc_hip.so')
+ABI_VERSION = 1
+MAX_K = 4
+
+#: every symbol ``include/stc_hip.h`` declares (the CPU test-suite checks the .so exports them all)
+EXPORTS = (
+    'stc_version', 'stc_last_error',
+    'stc_csr_spmm_f32', 'stc_csr_sddmm_f32',
+    'stc_cheby_dense_fwd_f32', 'stc_cheby_dense_bwd_f32',
+    'stc_bdg_node_fwd_f32', 'stc_bdg_node_bwd_workspace_bytes', 'stc_bdg_node_bwd_f32',
+    'stc_gru_gates_fwd_f32', 'stc_gru_gates_bwd_f32', 'stc_gru_blend_fwd_f32', 'stc_gru_blend_bwd_f32',
+    'stc_axpy_f32', 'stc_concat2_f32', 'stc_split2_f32',
+)
+
+
+class StcError(RuntimeError):
+    """A C-ABI call returned non-zero, or the HIP extension cannot be used."""
+
+
+_p = C.c_void_p
+_i32 = C.c_int32
+_i64 = C.c_int64
+_f32 = C.c_float
+
+
+def _declare(lib):
+    lib.stc_version.restype = C.c_int
+    lib.stc_version.argtypes = []
+    lib.stc_last_error.restype = C.c_char_p
+    lib.stc_last_error.argtypes = []
+    sig = {
+        'stc_csr_spmm_f32': [_p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _f32, _p],
+        'stc_csr_sddmm_f32': [_p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _i32, _p],
+        'stc_cheby_dense_fwd_f32': [_p, _i32, _i32, _p, _p],
+        'stc_cheby_dense_bwd_f32': [_p, _p, _p, _i32, _i32, _p, _p],
+        'stc_bdg_node_fwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _i64, _i32, _i32, _i32, _p],
+        'stc_bdg_node_bwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, C.POINTER(_p), _p, _p, _p,
+                                 _p, C.c_size_t, _i64, _i32, _i32, _i32, _p],
+        'stc_gru_gates_fwd_f32': [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p],
+        'stc_gru_gates_bwd_f32': [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p],
+        'stc_gru_blend_fwd_f32': [_p, _p, _p, _p, _p, _i64, _p],
+        'stc_gru_blend_bwd_f32': [_p, _p, _p, _p, _p, _p, _p, _i64, _p],
+        'stc_axpy_f32': [_f32, _p, _p, _i64, _p],
+        'stc_concat2_f32': [_p, _p, _p, _i64, _i32, _i32, _p],
+        'stc_split2_f32': [_p, _p, _p, _i64, _i32, _i32, _p],
+    }
+    for name, argtypes in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = C.c_int
+        fn.argtypes = argtypes
+    lib.stc_bdg_node_bwd_workspace_bytes.restype = C.c_size_t
+    lib.stc_bdg_node_bwd_workspace_bytes.argtypes = [_i32, _i32, _i32, _i32, _i32, _i32]
+
+
+_LIB = None
+
+
+def load_library(path: str = LIB_PATH):
+    """dlopen the kernel library (once) and check its ABI version."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(path):
+        raise StcError(
+            f'{path} not found: the HIP kernels are not built. Run '
+            f'`make -C {os.path.join(_PKG_ROOT, "csrc")}` (or `python -c "import __graft_entry__ as g; g.build()"`). '
+            'There is no CPU fallback for the STC-GNN hot path.')
+    lib = C.CDLL(path)
+    _declare(lib)
+    v = lib.stc_version()
+    if v != ABI_VERSION:
+        raise StcError(f'{path}: ABI version {v}, host expects {ABI_VERSION}')
+    _LIB = lib
+    return lib
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+class HipKernels:
+    """Tensor-level front of the C ABI; the one object ``stc_hip.ops`` launches through."""
+
+    name = 'hip-gfx950'
+
+    def __init__(self):
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise StcError('no ROCm device visible: the STC-GNN hot path runs on MI355X only (no CPU fallback)')
+        self._workspace = {}
+
+    # ---- host-side checks -------------------------------------------------------
+    @staticmethod
+    def _f32(name, t, shape=None):
+        if not isinstance(t, torch.Tensor) or not t.is_cuda:
+            raise StcError(f'{name}: expected a ROCm (cuda) tensor, got {type(t).__name__}'
+                           f'{"" if not isinstance(t, torch.Tensor) else " on " + str(t.device)}; no CPU fallback')
+        if t.dtype != torch.float32:
+            raise StcError(f'{name}: expected float32, got {t.dtype} (the reference path is fp32-only)')
+        if not t.is_contiguous():
+            raise StcError(f'{name}: tensor must be contiguous')
+        if shape is not None and tuple(t.shape) != tuple(shape):
+            raise StcError(f'{name}: shape {tuple(t.shape)}, expected {tuple(shape)}')
+        return t
+
+    @staticmethod
+    def _i32(name, t, numel=None):
+        if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.int32 or not t.is_contiguous():
+            raise StcError(f'{name}: expected a contiguous int32 ROCm tensor')
+        if numel is not None and t.numel() != numel:
+            raise StcError(f'{name}: {t.numel()} elements, expected {numel}')
+        return t
+
+    @staticmethod
+    def _stream(t):
+        return torch.cuda.current_stream(t.device).cuda_stream
+
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self.lib.stc_last_error()
+            raise StcError(f'{what} failed with code {rc}: {msg.decode() if msg else "?"}')
+
+    def _same_device(self, *ts):
+        devs = {t.device for t in ts if t is not None}
+        if len(devs) > 1:
+            raise StcError(f'tensors on different devices: {devs}')
+
+    # ---- spatial aggregation ------------------------------------------------------
+    def csr_spmm(self, rowptr, colidx, val, n_rows, n_cols, X, Y0, Y, alpha, beta):
+        B, nc, F = X.shape
+        self._f32('spmm.X', X, (B, n_cols, F))
+        self._f32('spmm.Y', Y, (B, n_rows, F))
+        if Y0 is not None:
+            self._f32('spmm.Y0', Y0, (B, n_rows, F))
+        self._i32('spmm.rowptr', rowptr, n_rows + 1)
+        self._i32('spmm.colidx', colidx)
+        self._f32('spmm.val', val, (colidx.numel(),))
+        self._same_device(rowptr, colidx, val, X, Y0, Y)
+        with torch.cuda.device(X.device):
+            rc = self.lib.stc_csr_spmm_f32(_ptr(rowptr), _ptr(colidx), _ptr(val), n_rows, n_cols,
+                                           _ptr(X), _ptr(Y0), _ptr(Y), B, F, float(alpha), float(beta),
+                                           self._stream(X))
+        self._check(rc, 'stc_csr_spmm_f32')
+
+    def csr_sddmm(self, rowptr, colidx, n_rows, n_cols, A, Bm, out, alpha, accumulate):
+        B, nr, F = A.shape
+        self._f32('sddmm.A', A, (B, n_rows, F))
+        self._f32('sddmm.Bm', Bm, (B, n_cols, F))
+        self._i32('sddmm.rowptr', rowptr, n_rows + 1)
+        self._i32('sddmm.colidx', colidx)
+        self._f32('sddmm.out', out, (colidx.numel(),))
+        self._same_device(rowptr, colidx, A, Bm, out)
+        with torch.cuda.device(A.device):
+            rc = self.lib.stc_csr_sddmm_f32(_ptr(rowptr), _ptr(colidx), n_rows, n_cols, _ptr(A), _ptr(Bm), _ptr(out),
+                                            B, F, float(alpha), int(bool(accumulate)), self._stream(A))
+        self._check(rc, 'stc_csr_sddmm_f32')
+
+    # ---- category graph --------------------------------------------------------------
+    def cheby_dense_fwd(self, G, K, T):
+        n = G.shape[0]
+        self._f32('cheby.G', G, (n, n))
+        self._f32('cheby.T', T, (K, n, n))
+        with torch.cuda.device(G.device):
+            rc = self.lib.stc_cheby_dense_fwd_f32(_ptr(G), n, K, _ptr(T), self._stream(G))
+        self._check(rc, 'stc_cheby_dense_fwd_f32')
+
+    def cheby_dense_bwd(self, G, T, dT, dG):
+        K, n, _ = T.shape
+        self._f32('cheby.G', G, (n, n))
+        self._f32('cheby.T', T, (K, n, n))
+        self._f32('cheby.dT', dT, (K, n, n))
+        self._f32('cheby.dG', dG, (n, n))
+        with torch.cuda.device(G.device):
+            rc = self.lib.stc_cheby_dense_bwd_f32(_ptr(G), _ptr(T), _ptr(dT), n, K, _ptr(dG), self._stream(G))
+        self._check(rc, 'stc_cheby_dense_bwd_f32')
+
+    # ---- node kernel -------------------------------------------------------------------
+    @staticmethod
+    def _ptr_array(tensors):
+        arr = (_p * len(tensors))()
+        for i, t in enumerate(tensors):
+            arr[i] = t.data_ptr()
+        return arr
+
+    def _node_shapes(self, Zs, Tc, W):
+        Ks, Kc = len(Zs), Tc.shape[0]
+        if not (1 <= Ks <= MAX_K and 1 <= Kc <= MAX_K):
+            raise StcError(f'Chebyshev orders Ks={Ks}, Kc={Kc} outside [1,{MAX_K}]')
+        R, Cc, L = Zs[0].shape
+        Ho = W.shape[1]
+        for i, z in enumerate(Zs):
+            self._f32(f'node.Z[{i}]', z, (R, Cc, L))
+        self._f32('node.Tc', Tc, (Kc, Cc, Cc))
+        self._f32('node.W', W, (Ks * Kc * L, Ho))
+        return Ks, Kc, R, Cc, L, Ho
+
+    def bdg_node_fwd(self, Zs: Sequence[torch.Tensor], Tc, W, bias, Y):
+        Ks, Kc, R, Cc, L, Ho = self._node_shapes(Zs, Tc, W)
+        if bias is not None:
+            self._f32('node.bias', bias, (Ho,))
+        self._f32('node.Y', Y, (R, Cc, Ho))
+        self._same_device(*Zs, Tc, W, bias, Y)
+        with torch.cuda.device(Y.device):
+            rc = self.lib.stc_bdg_node_fwd_f32(self._ptr_array(Zs), Ks, _ptr(Tc), Kc, _ptr(W), _ptr(bias), _ptr(Y),
+                                               R, Cc, L, Ho, self._stream(Y))
+        self._check(rc, 'stc_bdg_node_fwd_f32')
+
+    def _get_workspace(self, device, nbytes):
+        ws = self._workspace.get(device)
+        if ws is None or ws.numel() < nbytes:
+            # persistent per-device scratch: survives the trainer's torch.cuda.empty_cache() after every step
+            ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+            self._workspace[device] = ws
+        return ws
+
+    def bdg_node_bwd(self, Zs, Tc, W, dY, dZs, dW, db, dTc):
+        Ks, Kc, R, Cc, L, Ho = self._node_shapes(Zs, Tc, W)
+        self._f32('node.dY', dY, (R, Cc, Ho))
+        if len(dZs) != Ks:
+            raise StcError('node.dZ: need one gradient slab per Chebyshev order')
+        for i, z in enumerate(dZs):
+            self._f32(f'node.dZ[{i}]', z, (R, Cc, L))
+        self._f32('node.dW', dW, (Ks * Kc * L, Ho))
+        if db is not None:
+            self._f32('node.db', db, (Ho,))
+        if dTc is not None:
+            self._f32('node.dTc', dTc, (Kc, Cc, Cc))
+        self._same_device(*Zs, Tc, W, dY, *dZs, dW, db, dTc)
+        nbytes = self.lib.stc_bdg_node_bwd_workspace_bytes(Ks, Kc, Cc, L, Ho, int(dTc is not None))
+        ws = self._get_workspace(dY.device, nbytes)
+        with torch.cuda.device(dY.device):
+            rc = self.lib.stc_bdg_node_bwd_f32(self._ptr_array(Zs), Ks, _ptr(Tc), Kc, _ptr(W), _ptr(dY),
+                                               self._ptr_array(dZs), _ptr(dW), _ptr(db), _ptr(dTc),
+                                               _ptr(ws), ws.numel(), R, Cc, L, Ho, self._stream(dY))
+        self._check(rc, 'stc_bdg_node_bwd_f32')
+
+    # ---- GRU gate math -------------------------------------------------------------------
+    def gru_gates_fwd(self, G, Xt, H, U, Rg, CandIn):
+        rows, h = H.shape[:-1].numel(), H.shape[-1]
+        cin = Xt.shape[-1]
+        for name, t, w in (('G', G, 2 * h), ('Xt', Xt, cin), ('H', H, h), ('U', U, h), ('Rg', Rg, h),
+                           ('CandIn', CandIn, cin + h)):
+            self._f32('gates.' + name, t)
+            if t.shape[-1] != w or t.numel() != rows * w:
+                raise StcError(f'gates.{name}: shape {tuple(t.shape)} does not match rows={rows}, width={w}')
+        with torch.cuda.device(H.device):
+            rc = self.lib.stc_gru_gates_fwd_f32(_ptr(G), _ptr(Xt), _ptr(H), _ptr(U), _ptr(Rg), _ptr(CandIn),
+                                                rows, cin, h, self._stream(H))
+        self._check(rc, 'stc_gru_gates_fwd_f32')
+
+    def gru_gates_bwd(self, dCandIn, dU, H, U, Rg, dG, dXt, dH):
+        rows, h = H.shape[:-1].numel(), H.shape[-1]
+        cin = dXt.shape[-1]
+        for name, t, w in (('dCandIn', dCandIn, cin + h), ('dU', dU, h), ('H', H, h), ('U', U, h), ('Rg', Rg, h),
+                           ('dG', dG, 2 * h), ('dXt', dXt, cin), ('dH', dH, h)):
+            self._f32('gates_bwd.' + name, t)
+            if t.shape[-1] != w or t.numel() != rows * w:
+                raise StcError(f'gates_bwd.{name}: shape {tuple(t.shape)} does not match rows={rows}, width={w}')
+        with torch.cuda.device(H.device):
+            rc = self.lib.stc_gru_gates_bwd_f32(_ptr(dCandIn), _ptr(dU), _ptr(H), _ptr(U), _ptr(Rg),
+                                                _ptr(dG), _ptr(dXt), _ptr(dH), rows, cin, h, self._stream(H))
+        self._check(rc, 'stc_gru_gates_bwd_f32')
+
+    def _same_numel(self, what, *ts):
+        n = ts[0].numel()
+        for i, t in enumerate(ts):
+            self._f32(f'{what}[{i}]', t)
+            if t.numel() != n:
+                raise StcError(f'{what}: operand {i} has {t.numel()} elements, expected {n}')
+        return n
+
+    def gru_blend_fwd(self, Cpre, U, H, Cand, Hnew):
+        n = self._same_numel('blend', Cpre, U, H, Cand, Hnew)
+        with torch.cuda.device(H.device):
+            rc = self.lib.stc_gru_blend_fwd_f32(_ptr(Cpre), _ptr(U), _ptr(H), _ptr(Cand), _ptr(Hnew), n, self._stream(H))
+        self._check(rc, 'stc_gru_blend_fwd_f32')
+
+    def gru_blend_bwd(self, dHnew, U, H, Cand, dCpre, dU, dH):
+        n = self._same_numel('blend_bwd', dHnew, U, H, Cand, dCpre, dU, dH)
+        with torch.cuda.device(H.device):
+            rc = self.lib.stc_gru_blend_bwd_f32(_ptr(dHnew), _ptr(U), _ptr(H), _ptr(Cand), _ptr(dCpre), _ptr(dU), _ptr(dH),
+                                                n, self._stream(H))
+        self._check(rc, 'stc_gru_blend_bwd_f32')
+
+    # ---- helpers --------------------------------------------------------------------------
+    def axpy(self, a, x, y):
+        n = self._same_numel('axpy', x, y)
+        with torch.cuda.device(x.device):
+            rc = self.lib.stc_axpy_f32(float(a), _ptr(x), _ptr(y), n, self._stream(x))
+        self._check(rc, 'stc_axpy_f32')
+
+    def _cat_shapes(self, what, A, Bm, whole):
+        a, b = A.shape[-1], Bm.shape[-1]
+        rows = whole.shape[:-1].numel()
+        for name, t, w in (('A', A, a), ('B', Bm, b), ('whole', whole, a + b)):
+            self._f32(f'{what}.{name}', t)
+            if t.shape[-1] != w or t.numel() != rows * w:
+                raise StcError(f'{what}.{name}: shape {tuple(t.shape)} does not match rows={rows}, width={w}')
+        return rows, a, b
+
+    def concat2(self, A, Bm, out):
+        rows, a, b = self._cat_shapes('concat2', A, Bm, out)
+        with torch.cuda.device(out.device):
+            rc = self.lib.stc_concat2_f32(_ptr(A), _ptr(Bm), _ptr(out), rows, a, b, self._stream(out))
+        self._check(rc, 'stc_concat2_f32')
+
+    def split2(self, src, A, Bm):
+        rows, a, b = self._cat_shapes('split2', A, Bm, src)
+        with torch.cuda.device(src.device):
+            rc = self.lib.stc_split2_f32(_ptr(src), _ptr(A), _ptr(Bm), rows, a, b, self._stream(src))
+        self._check(rc, 'stc_split2_f32')

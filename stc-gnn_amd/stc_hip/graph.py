@@ -1,0 +1,187 @@
+"""Spatial-graph containers for the HIP path.
+
+The reference only ever multiplies by a dense, learned ``Gs`` (STC_GNN.py:37).
+Here the spatial operand is always a CSR pair with int32 indices in HBM:
+
+* ``CsrGraph``        a fixed sparse graph supplied by the caller (``csr-fixed`` mode), holding
+                      CSR(Gs^T) for the forward 1-mode product ``Gs^T . X`` and CSR(Gs) for its
+                      backward (the reference's einsum is the TRANSPOSED aggregation);
+* ``dense_operand``   the learned dense ``Gs`` of the reference viewed as a CSR matrix with the
+                      full N x N pattern (``dense-learned`` mode, small N), values differentiable.
+
+Index arrays are validated on the host when a graph is built: the kernels trust them.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+INT32_MAX = 2 ** 31 - 1
+
+
+def _csr_from_coo(rows: np.ndarray, cols: np.ndarray, vals: np.ndarray, n: int):
+    """Sort COO by (row, col) and build rowptr; returns (rowptr, colidx, vals, order)."""
+    order = np.lexsort((cols, rows))
+    r, c = rows[order], cols[order]
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(rowptr, r + 1, 1)
+    np.cumsum(rowptr, out=rowptr)
+    return rowptr.astype(np.int32), c.astype(np.int32), vals[order].astype(np.float32), order
+
+
+class CsrGraph:
+    """A fixed N x N spatial graph ``Gs`` resident in HBM as CSR(Gs^T) + CSR(Gs).
+
+    ``fwd_*`` describe Gs^T (row m lists the nodes n with Gs[n, m] != 0): the operand of the
+    forward aggregation.  ``bwd_*`` describe Gs itself, used for dX.  ``bwd_perm`` maps the
+    backward value order onto the forward one (``bwd_val = fwd_val[bwd_perm]``).
+    """
+
+    def __init__(self, n: int, rows, cols, vals, device=None):
+        rows = np.asarray(rows, dtype=np.int64).ravel()
+        cols = np.asarray(cols, dtype=np.int64).ravel()
+        vals = np.asarray(vals, dtype=np.float32).ravel()
+        if not (rows.shape == cols.shape == vals.shape):
+            raise ValueError('rows / cols / vals must have the same length')
+        if n < 0 or n > INT32_MAX or rows.size > INT32_MAX:
+            raise ValueError('graph too large for int32 CSR indices')
+        if rows.size and (rows.min() < 0 or rows.max() >= n or cols.min() < 0 or cols.max() >= n):
+            raise ValueError(f'edge index outside [0, {n})')
+        if rows.size:
+            key = rows * n + cols
+            if np.unique(key).size != key.size:
+                raise ValueError('duplicate (row, col) entries: coalesce the graph first')
+        self.n = int(n)
+        self.nnz = int(rows.size)
+        # forward operand Gs^T: entry (n_, m) of Gs is stored in row m, column n_
+        f_rp, f_ci, f_v, f_order = _csr_from_coo(cols, rows, vals, n)
+        b_rp, b_ci, b_v, b_order = _csr_from_coo(rows, cols, vals, n)
+        inv_f = np.empty_like(f_order)
+        inv_f[f_order] = np.arange(f_order.size)
+        perm = inv_f[b_order]                      # position in fwd order of each bwd entry
+        self._host = dict(fwd_rowptr=f_rp, fwd_colidx=f_ci, fwd_val=f_v,
+                          bwd_rowptr=b_rp, bwd_colidx=b_ci, bwd_val=b_v, bwd_perm=perm.astype(np.int64))
+        self._dev: Dict[torch.device, Dict[str, torch.Tensor]] = {}
+        if device is not None:
+            self.on(torch.device(device))
+
+    # -- constructors -------------------------------------------------------------------
+    @classmethod
+    def from_dense(cls, G, device=None) -> 'CsrGraph':
+        G = G.detach().cpu() if isinstance(G, torch.Tensor) else torch.as_tensor(np.asarray(G))
+        if G.dim() != 2 or G.shape[0] != G.shape[1]:
+            raise ValueError('from_dense wants a square matrix')
+        idx = G.nonzero(as_tuple=False)
+        return cls(G.shape[0], idx[:, 0].numpy(), idx[:, 1].numpy(), G[idx[:, 0], idx[:, 1]].numpy(), device)
+
+    @classmethod
+    def from_torch_sparse(cls, S: torch.Tensor, device=None) -> 'CsrGraph':
+        if S.dim() != 2 or S.shape[0] != S.shape[1]:
+            raise ValueError('sparse spatial graph must be square')
+        coo = S.detach().cpu().to_sparse_coo().coalesce()
+        i = coo.indices().numpy()
+        return cls(S.shape[0], i[0], i[1], coo.values().numpy(), device if device is not None else S.device)
+
+    @classmethod
+    def queen_grid(cls, H: int, W: int, normalize: bool = True, permute_seed: Optional[int] = None,
+                   device=None) -> 'CsrGraph':
+        """H x W 8-neighbour grid, node id h*W + w (the SF ``s_adj`` for 10 x 10); optionally
+        row-stochastic (A / rowsum) and under a seeded random node permutation."""
+        hh, ww = np.divmod(np.arange(H * W, dtype=np.int64), W)
+        rows, cols = [], []
+        for dh in (-1, 0, 1):
+            for dw in (-1, 0, 1):
+                if dh == 0 and dw == 0:
+                    continue
+                nh, nw = hh + dh, ww + dw
+                ok = (nh >= 0) & (nh < H) & (nw >= 0) & (nw < W)
+                rows.append((hh * W + ww)[ok])
+                cols.append((nh * W + nw)[ok])
+        r, c = np.concatenate(rows), np.concatenate(cols)
+        v = np.ones(r.size, dtype=np.float32)
+        if normalize:
+            deg = np.bincount(r, minlength=H * W).astype(np.float32)
+            v = v / deg[r]
+        if permute_seed is not None:
+            g = torch.Generator().manual_seed(permute_seed)
+            p = torch.randperm(H * W, generator=g).numpy()      # new matrix A[p][:, p]: new id i is old node p[i]
+            inv = np.empty_like(p)
+            inv[p] = np.arange(p.size)
+            r, c = inv[r], inv[c]
+        return cls(H * W, r, c, v, device)
+
+    # -- device residency -----------------------------------------------------------------
+    def on(self, device: torch.device) -> Dict[str, torch.Tensor]:
+        device = torch.device(device)
+        if device.type == 'cuda' and device.index is None:
+            device = torch.device('cuda', torch.cuda.current_device())
+        d = self._dev.get(device)
+        if d is None:
+            d = {k: torch.from_numpy(v).to(device) for k, v in self._host.items()}
+            self._dev[device] = d
+        return d
+
+    def to_dense(self) -> torch.Tensor:
+        h = self._host
+        G = torch.zeros(self.n, self.n)
+        rows = np.repeat(np.arange(self.n), np.diff(h['bwd_rowptr']))
+        G[torch.from_numpy(rows), torch.from_numpy(h['bwd_colidx'].astype(np.int64))] = torch.from_numpy(h['bwd_val'])
+        return G
+
+    def __repr__(self):
+        return f'CsrGraph(n={self.n}, nnz={self.nnz})'
+
+
+@dataclass
+class SpatialOperand:
+    """What one BDG_Dif call needs of the spatial graph (either mode)."""
+    n: int
+    fwd_rowptr: torch.Tensor
+    fwd_colidx: torch.Tensor
+    fwd_val: torch.Tensor            # may carry autograd history (learned dense graph)
+    bwd_rowptr: torch.Tensor
+    bwd_colidx: torch.Tensor
+    bwd_val: torch.Tensor            # never differentiable
+    nnz: int
+
+
+_PATTERN_CACHE: Dict[Tuple[int, torch.device], Tuple[torch.Tensor, torch.Tensor]] = {}
+
+
+def full_pattern(n: int, device: torch.device):
+    """rowptr / colidx of the dense n x n pattern (cached per size and device)."""
+    device = torch.device(device)
+    key = (n, device)
+    got = _PATTERN_CACHE.get(key)
+    if got is None:
+        if n * n > INT32_MAX:
+            raise ValueError(f'dense spatial graph of {n} nodes does not fit int32 CSR; use a CsrGraph')
+        rowptr = (torch.arange(n + 1, dtype=torch.int64) * n).to(torch.int32).to(device)
+        colidx = torch.arange(n, dtype=torch.int32).repeat(n).to(device)
+        got = (rowptr, colidx)
+        _PATTERN_CACHE[key] = got
+    return got
+
+
+def dense_operand(Gs: torch.Tensor) -> SpatialOperand:
+    """The reference's learned dense ``Gs`` (N,N) as a full-pattern CSR operand.
+
+    The forward values are ``Gs^T`` flattened (differentiable: autograd carries the transpose
+    back to ``Gs``), the backward values ``Gs`` itself.
+    """
+    if Gs.dim() != 2 or Gs.shape[0] != Gs.shape[1]:
+        raise ValueError(f'Gs must be (N, N), got {tuple(Gs.shape)}')
+    n = Gs.shape[0]
+    rowptr, colidx = full_pattern(n, Gs.device)
+    fwd_val = Gs.t().contiguous().reshape(-1)
+    bwd_val = Gs.detach().contiguous().reshape(-1)
+    return SpatialOperand(n, rowptr, colidx, fwd_val, rowptr, colidx, bwd_val, n * n)
+
+
+def csr_operand(graph: CsrGraph, device: torch.device) -> SpatialOperand:
+    d = graph.on(device)
+    return SpatialOperand(graph.n, d['fwd_rowptr'], d['fwd_colidx'], d['fwd_val'],
+                          d['bwd_rowptr'], d['bwd_colidx'], d['bwd_val'], graph.nnz)

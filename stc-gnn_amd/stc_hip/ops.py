@@ -1,0 +1,230 @@
+"""Autograd operators of the STC-GNN hot path, each a thin host sequence of HIP launches.
+
+    bdg_dif      BDG_Dif.forward  (reference STC_GNN.py:31-47)  = SpMM hops + node kernel
+    gru_gates    split / sigmoid / reset*H / second concat (STC_GNN.py:71-75)
+    gru_blend    tanh + GRU blend (STC_GNN.py:76-78)
+    concat2      torch.cat([Xt, Ht_1], -1) (STC_GNN.py:68)
+    cheby_dense  BDG_Dif.cheby_poly on the small category graph (STC_GNN.py:24-29)
+
+Decomposition of one BDG_Dif (K = Ks = Kc in the reference, kept separate here):
+
+    Z_0 = X,  Z_1 = Gs^T X,  Z_k = 2 Gs^T Z_{k-1} - Z_{k-2}         K-1 CSR SpMM launches
+    Y   = node(Z_0..Z_{K-1}; T_c(Gc), W, b)                         one fused node kernel
+
+i.e. the Chebyshev recurrence runs on the FEATURES (never forms Gs^2; equal math because
+polynomials of Gs commute with Gs) and the K*K*L concat is never written.  Backward:
+
+    dZ_k, dW, db, dT_c = node_bwd(dY)
+    for k = K-1 .. 2:   dZ_{k-1} += 2 Gs dZ_k ;  dZ_{k-2} -= dZ_k ;  dGs += 2 <Z_{k-1}, dZ_k>
+    dX = dZ_0 + Gs dZ_1 ;  dGs += <Z_0, dZ_1>
+
+All launches go to ``kernels()`` -- the ctypes front of libstc_hip.so.  There is no other
+implementation in the product: without the built library or without a ROCm device the
+first call raises ``StcError``.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from .graph import SpatialOperand
+
+_kernels = None
+
+
+def kernels():
+    """The kernel set every operator launches through (HIP; created on first use)."""
+    global _kernels
+    if _kernels is None:
+        from ._lib import HipKernels
+        _kernels = HipKernels()
+    return _kernels
+
+
+def _c(t: torch.Tensor) -> torch.Tensor:
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ----------------------------------------------------------------------------- Chebyshev set of Gc
+class _ChebyDense(Function):
+    @staticmethod
+    def forward(ctx, G, K: int):
+        G = _c(G)
+        T = G.new_empty((K,) + tuple(G.shape))
+        kernels().cheby_dense_fwd(G, K, T)
+        ctx.save_for_backward(G, T)
+        return T
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dT):
+        G, T = ctx.saved_tensors
+        dG = torch.empty_like(G)
+        kernels().cheby_dense_bwd(G, T, dT.contiguous().clone(), dG)    # dT is consumed as scratch
+        return dG, None
+
+
+def cheby_dense(G: torch.Tensor, K: int) -> torch.Tensor:
+    """(K, n, n) stack T_0..T_{K-1} of a small dense graph, matrix side as the reference."""
+    if G.dim() != 2 or G.shape[0] != G.shape[1]:
+        raise ValueError(f'category graph must be square, got {tuple(G.shape)}')
+    return _ChebyDense.apply(G, K)
+
+
+# ----------------------------------------------------------------------------- BDG_Dif
+class _BdgDif(Function):
+    @staticmethod
+    def forward(ctx, X, W, b, Tc, fwd_val, op: SpatialOperand, Ks: int):
+        k = kernels()
+        X, W, Tc, fwd_val = _c(X), _c(W), _c(Tc), _c(fwd_val)
+        B, N, C, L = X.shape
+        Ho = W.shape[1]
+        F = C * L
+        Zs = [X]
+        for order in range(1, Ks):
+            Zk = torch.empty_like(X)
+            if order == 1:
+                k.csr_spmm(op.fwd_rowptr, op.fwd_colidx, fwd_val, N, N, X.view(B, N, F), None, Zk.view(B, N, F), 1.0, 0.0)
+            else:
+                k.csr_spmm(op.fwd_rowptr, op.fwd_colidx, fwd_val, N, N, Zs[-1].view(B, N, F),
+                           Zs[-2].view(B, N, F), Zk.view(B, N, F), 2.0, -1.0)
+            Zs.append(Zk)
+        Y = X.new_empty(B, N, C, Ho)
+        k.bdg_node_fwd([z.view(B * N, C, L) for z in Zs], Tc, W, b, Y.view(B * N, C, Ho))
+        ctx.save_for_backward(W, Tc, *Zs)
+        ctx.op = op
+        ctx.has_bias = b is not None
+        ctx.Ks = Ks
+        return Y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dY):
+        k = kernels()
+        W, Tc, *Zs = ctx.saved_tensors
+        op, Ks = ctx.op, ctx.Ks
+        need_X, _, _, need_Tc, need_val = ctx.needs_input_grad[:5]
+        B, N, C, L = Zs[0].shape
+        Ho = W.shape[1]
+        F = C * L
+        dY = _c(dY)
+        dZ = [torch.empty_like(Zs[0]) for _ in range(Ks)]
+        dW = torch.empty_like(W)
+        db = W.new_empty(Ho) if ctx.has_bias else None
+        dTc = torch.empty_like(Tc) if need_Tc else None
+        k.bdg_node_bwd([z.view(B * N, C, L) for z in Zs], Tc, W, dY.view(B * N, C, Ho),
+                       [z.view(B * N, C, L) for z in dZ], dW, db, dTc)
+        dval = torch.zeros_like(op.fwd_val) if need_val else None
+        v3 = lambda t: t.view(B, N, F)
+        for order in range(Ks - 1, 1, -1):
+            k.csr_spmm(op.bwd_rowptr, op.bwd_colidx, op.bwd_val, N, N, v3(dZ[order]), v3(dZ[order - 1]),
+                       v3(dZ[order - 1]), 2.0, 1.0)
+            k.axpy(-1.0, dZ[order], dZ[order - 2])
+            if need_val:
+                k.csr_sddmm(op.fwd_rowptr, op.fwd_colidx, N, N, v3(dZ[order]), v3(Zs[order - 1]), dval, 2.0, True)
+        if Ks > 1:
+            if need_X:
+                k.csr_spmm(op.bwd_rowptr, op.bwd_colidx, op.bwd_val, N, N, v3(dZ[1]), v3(dZ[0]), v3(dZ[0]), 1.0, 1.0)
+            if need_val:
+                k.csr_sddmm(op.fwd_rowptr, op.fwd_colidx, N, N, v3(dZ[1]), v3(Zs[0]), dval, 1.0, True)
+        return (dZ[0] if need_X else None), dW, db, dTc, dval, None, None
+
+
+def bdg_dif(X: torch.Tensor, op: SpatialOperand, Tc: torch.Tensor, W: torch.Tensor,
+            b: Optional[torch.Tensor], Ks: int) -> torch.Tensor:
+    """Y (B,N,C,Ho) of one bi-dimensional graph diffusion; ``Tc`` from ``cheby_dense``."""
+    if X.dim() != 4:
+        raise ValueError(f'BDG_Dif input must be (B,N,C,L), got {tuple(X.shape)}')
+    B, N, C, L = X.shape
+    Kc = Tc.shape[0]
+    if N != op.n:
+        raise ValueError(f'X has {N} nodes, the spatial graph {op.n}')
+    if Tc.shape[1] != C:
+        raise ValueError(f'X has {C} categories, the category graph {Tc.shape[1]}')
+    if W.shape[0] != Ks * Kc * L:
+        raise ValueError(f'W has {W.shape[0]} rows, expected Ks*Kc*L = {Ks * Kc * L}')
+    return _BdgDif.apply(X, W, b, Tc, op.fwd_val, op, Ks)
+
+
+# ----------------------------------------------------------------------------- GRU gate math
+class _GruGates(Function):
+    @staticmethod
+    def forward(ctx, G, Xt, H):
+        G, Xt, H = _c(G), _c(Xt), _c(H)
+        U = torch.empty_like(H)
+        Rg = torch.empty_like(H)
+        CandIn = H.new_empty(H.shape[:-1] + (Xt.shape[-1] + H.shape[-1],))
+        kernels().gru_gates_fwd(G, Xt, H, U, Rg, CandIn)
+        ctx.save_for_backward(H, U, Rg)
+        ctx.cin = Xt.shape[-1]
+        ctx.xshape = Xt.shape
+        return U, CandIn
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dU, dCandIn):
+        H, U, Rg = ctx.saved_tensors
+        dU = torch.zeros_like(U) if dU is None else _c(dU)
+        dCandIn = H.new_zeros(H.shape[:-1] + (ctx.cin + H.shape[-1],)) if dCandIn is None else _c(dCandIn)
+        dG = H.new_empty(H.shape[:-1] + (2 * H.shape[-1],))
+        dXt = H.new_empty(ctx.xshape)
+        dH = torch.empty_like(H)
+        kernels().gru_gates_bwd(dCandIn, dU, H, U, Rg, dG, dXt, dH)
+        return dG, dXt, dH
+
+
+def gru_gates(G, Xt, H):
+    """(update, cat[Xt, reset*H]) from the gate pre-activations G (.., 2h)."""
+    return _GruGates.apply(G, Xt, H)
+
+
+class _GruBlend(Function):
+    @staticmethod
+    def forward(ctx, Cpre, U, H):
+        Cpre, U, H = _c(Cpre), _c(U), _c(H)
+        Cand = torch.empty_like(H)
+        Hnew = torch.empty_like(H)
+        kernels().gru_blend_fwd(Cpre, U, H, Cand, Hnew)
+        ctx.save_for_backward(U, H, Cand)
+        return Hnew
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dHnew):
+        U, H, Cand = ctx.saved_tensors
+        dCpre, dU, dH = torch.empty_like(H), torch.empty_like(H), torch.empty_like(H)
+        kernels().gru_blend_bwd(_c(dHnew), U, H, Cand, dCpre, dU, dH)
+        return dCpre, dU, dH
+
+
+def gru_blend(Cpre, U, H):
+    """(1-U)*H + U*tanh(Cpre)."""
+    return _GruBlend.apply(Cpre, U, H)
+
+
+class _Concat2(Function):
+    @staticmethod
+    def forward(ctx, A, Bm):
+        A, Bm = _c(A), _c(Bm)
+        out = A.new_empty(A.shape[:-1] + (A.shape[-1] + Bm.shape[-1],))
+        kernels().concat2(A, Bm, out)
+        ctx.shapes = (A.shape, Bm.shape)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, d):
+        sa, sb = ctx.shapes
+        dA, dB = d.new_empty(sa), d.new_empty(sb)
+        kernels().split2(_c(d), dA, dB)
+        return dA, dB
+
+
+def concat2(A, Bm):
+    """cat([A, B], dim=-1) for tensors that agree on every leading dimension."""
+    if A.shape[:-1] != Bm.shape[:-1]:
+        raise ValueError(f'concat2: leading shapes differ: {tuple(A.shape)} vs {tuple(Bm.shape)}')
+    return _Concat2.apply(A, Bm)
