@@ -94,6 +94,29 @@ def load_library(path: str = LIB_PATH):
     return lib
 
 
+class KernelTimer:
+    """Per-launch HIP-event timing for ``bench.py``: events are recorded on the stream the kernel is
+    launched on (torch's current stream), immediately around the launch."""
+
+    def __init__(self):
+        self.spans = []          # (name, start_event, end_event, algorithmic_bytes)
+
+    def add(self, name, start, end, nbytes):
+        self.spans.append((name, start, end, nbytes))
+
+    def summary(self):
+        """{name: dict(launches, ms, bytes)} after synchronising; clears the recorded spans."""
+        torch.cuda.synchronize()
+        out = {}
+        for name, s, e, nb in self.spans:
+            d = out.setdefault(name, dict(launches=0, ms=0.0, bytes=0))
+            d['launches'] += 1
+            d['ms'] += s.elapsed_time(e)
+            d['bytes'] += nb
+        self.spans = []
+        return out
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
@@ -108,6 +131,24 @@ class HipKernels:
         if not torch.cuda.is_available():
             raise StcError('no ROCm device visible: the STC-GNN hot path runs on MI355X only (no CPU fallback)')
         self._workspace = {}
+        self.timer: Optional[KernelTimer] = None      # set by bench.py to time every launch with HIP events
+
+    def _launch(self, name, on, *args, nbytes=0):
+        """Call C entry point ``name`` with ``args`` + the current stream of ``on``'s device."""
+        fn = getattr(self.lib, name)
+        with torch.cuda.device(on.device):
+            stream = torch.cuda.current_stream(on.device)
+            if self.timer is None:
+                rc = fn(*args, stream.cuda_stream)
+            else:
+                start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                start.record(stream)
+                rc = fn(*args, stream.cuda_stream)
+                end.record(stream)
+                self.timer.add(name, start, end, nbytes)
+        if rc != 0:
+            msg = self.lib.stc_last_error()
+            raise StcError(f'{name} failed with code {rc}: {msg.decode() if msg else "?"}')
 
     # ---- host-side checks -------------------------------------------------------
     @staticmethod
@@ -156,11 +197,8 @@ class HipKernels:
         self._i32('spmm.colidx', colidx)
         self._f32('spmm.val', val, (colidx.numel(),))
         self._same_device(rowptr, colidx, val, X, Y0, Y)
-        with torch.cuda.device(X.device):
-            rc = self.lib.stc_csr_spmm_f32(_ptr(rowptr), _ptr(colidx), _ptr(val), n_rows, n_cols,
-                                           _ptr(X), _ptr(Y0), _ptr(Y), B, F, float(alpha), float(beta),
-                                           self._stream(X))
-        self._check(rc, 'stc_csr_spmm_f32')
+        self._launch('stc_csr_spmm_f32', X, _ptr(rowptr), _ptr(colidx), _ptr(val), n_rows, n_cols, _ptr(X), _ptr(Y0), _ptr(Y), B, F, float(alpha), float(beta),
+                     nbytes=colidx.numel() * 8 + 4 * (n_rows + 1) + 2 * 4 * B * n_rows * F)
 
     def csr_sddmm(self, rowptr, colidx, n_rows, n_cols, A, Bm, out, alpha, accumulate):
         B, nr, F = A.shape
@@ -170,19 +208,14 @@ class HipKernels:
         self._i32('sddmm.colidx', colidx)
         self._f32('sddmm.out', out, (colidx.numel(),))
         self._same_device(rowptr, colidx, A, Bm, out)
-        with torch.cuda.device(A.device):
-            rc = self.lib.stc_csr_sddmm_f32(_ptr(rowptr), _ptr(colidx), n_rows, n_cols, _ptr(A), _ptr(Bm), _ptr(out),
-                                            B, F, float(alpha), int(bool(accumulate)), self._stream(A))
-        self._check(rc, 'stc_csr_sddmm_f32')
+        self._launch('stc_csr_sddmm_f32', A, _ptr(rowptr), _ptr(colidx), n_rows, n_cols, _ptr(A), _ptr(Bm), _ptr(out), B, F, float(alpha), int(bool(accumulate)))
 
     # ---- category graph --------------------------------------------------------------
     def cheby_dense_fwd(self, G, K, T):
         n = G.shape[0]
         self._f32('cheby.G', G, (n, n))
         self._f32('cheby.T', T, (K, n, n))
-        with torch.cuda.device(G.device):
-            rc = self.lib.stc_cheby_dense_fwd_f32(_ptr(G), n, K, _ptr(T), self._stream(G))
-        self._check(rc, 'stc_cheby_dense_fwd_f32')
+        self._launch('stc_cheby_dense_fwd_f32', G, _ptr(G), n, K, _ptr(T))
 
     def cheby_dense_bwd(self, G, T, dT, dG):
         K, n, _ = T.shape
@@ -190,9 +223,7 @@ class HipKernels:
         self._f32('cheby.T', T, (K, n, n))
         self._f32('cheby.dT', dT, (K, n, n))
         self._f32('cheby.dG', dG, (n, n))
-        with torch.cuda.device(G.device):
-            rc = self.lib.stc_cheby_dense_bwd_f32(_ptr(G), _ptr(T), _ptr(dT), n, K, _ptr(dG), self._stream(G))
-        self._check(rc, 'stc_cheby_dense_bwd_f32')
+        self._launch('stc_cheby_dense_bwd_f32', G, _ptr(G), _ptr(T), _ptr(dT), n, K, _ptr(dG))
 
     # ---- node kernel -------------------------------------------------------------------
     @staticmethod
@@ -220,10 +251,7 @@ class HipKernels:
             self._f32('node.bias', bias, (Ho,))
         self._f32('node.Y', Y, (R, Cc, Ho))
         self._same_device(*Zs, Tc, W, bias, Y)
-        with torch.cuda.device(Y.device):
-            rc = self.lib.stc_bdg_node_fwd_f32(self._ptr_array(Zs), Ks, _ptr(Tc), Kc, _ptr(W), _ptr(bias), _ptr(Y),
-                                               R, Cc, L, Ho, self._stream(Y))
-        self._check(rc, 'stc_bdg_node_fwd_f32')
+        self._launch('stc_bdg_node_fwd_f32', Y, self._ptr_array(Zs), Ks, _ptr(Tc), Kc, _ptr(W), _ptr(bias), _ptr(Y), R, Cc, L, Ho)
 
     def _get_workspace(self, device, nbytes):
         ws = self._workspace.get(device)
@@ -248,11 +276,7 @@ class HipKernels:
         self._same_device(*Zs, Tc, W, dY, *dZs, dW, db, dTc)
         nbytes = self.lib.stc_bdg_node_bwd_workspace_bytes(Ks, Kc, Cc, L, Ho, int(dTc is not None))
         ws = self._get_workspace(dY.device, nbytes)
-        with torch.cuda.device(dY.device):
-            rc = self.lib.stc_bdg_node_bwd_f32(self._ptr_array(Zs), Ks, _ptr(Tc), Kc, _ptr(W), _ptr(dY),
-                                               self._ptr_array(dZs), _ptr(dW), _ptr(db), _ptr(dTc),
-                                               _ptr(ws), ws.numel(), R, Cc, L, Ho, self._stream(dY))
-        self._check(rc, 'stc_bdg_node_bwd_f32')
+        self._launch('stc_bdg_node_bwd_f32', dY, self._ptr_array(Zs), Ks, _ptr(Tc), Kc, _ptr(W), _ptr(dY), self._ptr_array(dZs), _ptr(dW), _ptr(db), _ptr(dTc), _ptr(ws), ws.numel(), R, Cc, L, Ho)
 
     # ---- GRU gate math -------------------------------------------------------------------
     def gru_gates_fwd(self, G, Xt, H, U, Rg, CandIn):
@@ -263,10 +287,7 @@ class HipKernels:
             self._f32('gates.' + name, t)
             if t.shape[-1] != w or t.numel() != rows * w:
                 raise StcError(f'gates.{name}: shape {tuple(t.shape)} does not match rows={rows}, width={w}')
-        with torch.cuda.device(H.device):
-            rc = self.lib.stc_gru_gates_fwd_f32(_ptr(G), _ptr(Xt), _ptr(H), _ptr(U), _ptr(Rg), _ptr(CandIn),
-                                                rows, cin, h, self._stream(H))
-        self._check(rc, 'stc_gru_gates_fwd_f32')
+        self._launch('stc_gru_gates_fwd_f32', H, _ptr(G), _ptr(Xt), _ptr(H), _ptr(U), _ptr(Rg), _ptr(CandIn), rows, cin, h)
 
     def gru_gates_bwd(self, dCandIn, dU, H, U, Rg, dG, dXt, dH):
         rows, h = H.shape[:-1].numel(), H.shape[-1]
@@ -276,10 +297,7 @@ class HipKernels:
             self._f32('gates_bwd.' + name, t)
             if t.shape[-1] != w or t.numel() != rows * w:
                 raise StcError(f'gates_bwd.{name}: shape {tuple(t.shape)} does not match rows={rows}, width={w}')
-        with torch.cuda.device(H.device):
-            rc = self.lib.stc_gru_gates_bwd_f32(_ptr(dCandIn), _ptr(dU), _ptr(H), _ptr(U), _ptr(Rg),
-                                                _ptr(dG), _ptr(dXt), _ptr(dH), rows, cin, h, self._stream(H))
-        self._check(rc, 'stc_gru_gates_bwd_f32')
+        self._launch('stc_gru_gates_bwd_f32', H, _ptr(dCandIn), _ptr(dU), _ptr(H), _ptr(U), _ptr(Rg), _ptr(dG), _ptr(dXt), _ptr(dH), rows, cin, h)
 
     def _same_numel(self, what, *ts):
         n = ts[0].numel()
@@ -291,23 +309,16 @@ class HipKernels:
 
     def gru_blend_fwd(self, Cpre, U, H, Cand, Hnew):
         n = self._same_numel('blend', Cpre, U, H, Cand, Hnew)
-        with torch.cuda.device(H.device):
-            rc = self.lib.stc_gru_blend_fwd_f32(_ptr(Cpre), _ptr(U), _ptr(H), _ptr(Cand), _ptr(Hnew), n, self._stream(H))
-        self._check(rc, 'stc_gru_blend_fwd_f32')
+        self._launch('stc_gru_blend_fwd_f32', H, _ptr(Cpre), _ptr(U), _ptr(H), _ptr(Cand), _ptr(Hnew), n)
 
     def gru_blend_bwd(self, dHnew, U, H, Cand, dCpre, dU, dH):
         n = self._same_numel('blend_bwd', dHnew, U, H, Cand, dCpre, dU, dH)
-        with torch.cuda.device(H.device):
-            rc = self.lib.stc_gru_blend_bwd_f32(_ptr(dHnew), _ptr(U), _ptr(H), _ptr(Cand), _ptr(dCpre), _ptr(dU), _ptr(dH),
-                                                n, self._stream(H))
-        self._check(rc, 'stc_gru_blend_bwd_f32')
+        self._launch('stc_gru_blend_bwd_f32', H, _ptr(dHnew), _ptr(U), _ptr(H), _ptr(Cand), _ptr(dCpre), _ptr(dU), _ptr(dH), n)
 
     # ---- helpers --------------------------------------------------------------------------
     def axpy(self, a, x, y):
         n = self._same_numel('axpy', x, y)
-        with torch.cuda.device(x.device):
-            rc = self.lib.stc_axpy_f32(float(a), _ptr(x), _ptr(y), n, self._stream(x))
-        self._check(rc, 'stc_axpy_f32')
+        self._launch('stc_axpy_f32', x, float(a), _ptr(x), _ptr(y), n)
 
     def _cat_shapes(self, what, A, Bm, whole):
         a, b = A.shape[-1], Bm.shape[-1]
@@ -320,12 +331,8 @@ class HipKernels:
 
     def concat2(self, A, Bm, out):
         rows, a, b = self._cat_shapes('concat2', A, Bm, out)
-        with torch.cuda.device(out.device):
-            rc = self.lib.stc_concat2_f32(_ptr(A), _ptr(Bm), _ptr(out), rows, a, b, self._stream(out))
-        self._check(rc, 'stc_concat2_f32')
+        self._launch('stc_concat2_f32', out, _ptr(A), _ptr(Bm), _ptr(out), rows, a, b)
 
     def split2(self, src, A, Bm):
         rows, a, b = self._cat_shapes('split2', A, Bm, src)
-        with torch.cuda.device(src.device):
-            rc = self.lib.stc_split2_f32(_ptr(src), _ptr(A), _ptr(Bm), rows, a, b, self._stream(src))
-        self._check(rc, 'stc_split2_f32')
+        self._launch('stc_split2_f32', src, _ptr(src), _ptr(A), _ptr(Bm), rows, a, b)

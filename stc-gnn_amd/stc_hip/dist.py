@@ -1,0 +1,97 @@
+"""Batch-sharded training across the GPUs of one node: one process per GPU, RCCL over xGMI.
+
+The reference has no distributed code.  The hot path shards naturally over the
+batch (= sliding-window sample) dimension and only there: every op keeps ``b`` independent,
+time is a true recurrence, the graph is replicated.  So the data path needs no
+collective at all; the single exchange per iteration is the sum of the parameter gradients.
+
+``GradBucket`` keeps every parameter's ``.grad`` as a view into ONE flat fp32 buffer, so the
+exchange is a single in-place ``all_reduce`` (``backend='nccl'`` is RCCL on ROCm) with no
+pack/unpack copies.  In ``csr-fixed`` mode the bucket is 22 033 floats (88 KB) at h=16, K=2,
+2 layers: latency-bound, one call.  With equal shards and the reference's ComboLoss (mean BCE +
+per-sample Dice averaged over the batch, Model_Trainer.py:14-23) the averaged shard gradients
+equal the single-process full-batch gradients exactly (tests/test_dist_gloo.py).
+
+``dense-learned`` mode is NOT shardable as is: MGP_Gen sums over batch and time before its
+softmax (STC_GNN.py:231), so the graphs depend on the whole mini-batch.
+"""
+from __future__ import annotations
+
+from typing import Iterable, List
+
+import torch
+import torch.distributed as dist
+
+
+def shard_batch(t: torch.Tensor, rank: int, world: int) -> torch.Tensor:
+    """Contiguous, equal shard ``rank`` of ``world`` along dim 0 (the sample dimension)."""
+    n = t.shape[0]
+    if n % world:
+        raise ValueError(f'global batch {n} is not divisible by world size {world}: shards must be equal '
+                         'for the averaged gradients to equal the full-batch gradients')
+    per = n // world
+    return t[rank * per:(rank + 1) * per]
+
+
+class GradBucket:
+    """All gradients of ``params`` in one flat buffer; ``allreduce_mean()`` is the only collective."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter]):
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError('no trainable parameters')
+        dev = {p.device for p in self.params}
+        dt = {p.dtype for p in self.params}
+        if len(dev) != 1 or len(dt) != 1:
+            raise ValueError(f'parameters must share one device and dtype, got {dev} / {dt}')
+        total = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(total, dtype=self.params[0].dtype, device=self.params[0].device)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)      # autograd accumulates into the view in place
+            off += n
+
+    @property
+    def nbytes(self) -> int:
+        return self.flat.numel() * self.flat.element_size()
+
+    def zero(self):
+        """Replaces ``optimizer.zero_grad()``: keeps the views, zeroes the storage in one fill."""
+        self.flat.zero_()
+
+    def check_views(self):
+        """True while every ``.grad`` still aliases the bucket (``zero_grad(set_to_none=True)`` breaks it)."""
+        base = self.flat.untyped_storage().data_ptr()
+        return all(p.grad is not None and p.grad.untyped_storage().data_ptr() == base for p in self.params)
+
+    def allreduce_mean(self, group=None, async_op: bool = False):
+        """Sum the bucket over ranks and divide by the world size (gradient of the global-batch mean loss)."""
+        if not (dist.is_available() and dist.is_initialized()):
+            return None
+        world = dist.get_world_size(group)
+        if world == 1:
+            return None
+        if not self.check_views():
+            raise RuntimeError('a parameter .grad no longer aliases the bucket: use bucket.zero(), not '
+                               'optimizer.zero_grad(set_to_none=True)')
+        self.flat.div_(world)                                # pre-scale: the sum then is the mean
+        return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+
+def init_from_env(backend: str = None) -> tuple:
+    """(rank, world, local_rank) from torchrun's environment; initialises the process group when world > 1."""
+    import os
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, local

@@ -1,0 +1,74 @@
+"""CPU: the C-ABI library loads and exports every symbol include/stc_hip.h declares; argument
+validation that happens before any launch works without a GPU; the product fails loudly without one."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from stc_hip import _lib
+from tests.conftest import REPO
+
+
+def _declared_symbols():
+    text = open(os.path.join(REPO, 'include', 'stc_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(stc_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_header_and_python_export_lists_agree():
+    assert _declared_symbols() == sorted(_lib.EXPORTS)
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    assert os.path.exists(_lib.LIB_PATH), 'libstc_hip.so not built: python -c "import __graft_entry__ as g; g.build()"'
+    lib = _lib.load_library()
+    for name in _declared_symbols():
+        assert hasattr(lib, name), f'{name} declared in include/stc_hip.h but not exported'
+    assert lib.stc_version() == _lib.ABI_VERSION
+
+
+def test_argument_validation_needs_no_gpu():
+    lib = _lib.load_library()
+    # negative sizes / null pointers are rejected before any HIP call
+    rc = lib.stc_csr_spmm_f32(None, None, None, -1, 4, None, None, None, 1, 8, 1.0, 0.0, None)
+    assert rc == -1 and b'negative' in lib.stc_last_error()
+    rc = lib.stc_csr_spmm_f32(None, None, None, 4, 4, None, None, None, 1, 8, 1.0, 0.0, None)
+    assert rc == -1 and b'null' in lib.stc_last_error()
+    assert lib.stc_csr_spmm_f32(None, None, None, 0, 4, None, None, None, 1, 8, 1.0, 0.0, None) == 0   # empty: no launch
+    arr = (ctypes.c_void_p * 1)()
+    rc = lib.stc_bdg_node_fwd_f32(arr, 9, None, 2, None, None, None, 10, 3, 5, 4, None)
+    assert rc == -3 and b'Chebyshev' in lib.stc_last_error()          # order above STC_MAX_K
+    assert lib.stc_bdg_node_bwd_workspace_bytes(2, 2, 32, 32, 32, 1) == 512 * 4 * (2 * 2 * 32 * 32 + 32 + 2 * 32 * 32)
+    assert lib.stc_gru_blend_fwd_f32(None, None, None, None, None, 0, None) == 0
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='only meaningful without a GPU')
+def test_product_fails_loudly_without_gpu():
+    """No CPU fallback: the kernel front refuses to come up, and the drop-in module raises on CPU tensors."""
+    import STC_GNN as M
+    from stc_hip import ops
+    assert ops._kernels is None or ops._kernels.name == 'hip-gfx950'
+    with pytest.raises(_lib.StcError):
+        _lib.HipKernels()
+    layer = M.BDG_Dif(2, 2, 5, 4)
+    with pytest.raises(_lib.StcError):
+        layer(torch.randn(2, 12, 3, 5), torch.randn(12, 12), torch.randn(3, 3))
+
+
+def test_missing_library_message(tmp_path, monkeypatch):
+    monkeypatch.setattr(_lib, '_LIB', None)
+    with pytest.raises(_lib.StcError, match='not built'):
+        _lib.load_library(str(tmp_path / 'nope.so'))
+
+
+def test_combo_loss_matches_oracle():
+    from oracle import stc_oracle as O
+    from stc_hip.loss import ComboLoss
+    g = torch.Generator().manual_seed(0)
+    p = torch.rand(3, 2, 12, 3, generator=g).clamp(0.01, 0.99).requires_grad_()
+    y = (torch.rand(3, 2, 12, 3, generator=g) < 0.3).float()
+    a = ComboLoss()(p, y)
+    b = O.combo_loss(p.detach().clone().requires_grad_(), y)
+    assert abs(float(a.detach()) - float(b.detach())) < 1e-7

@@ -1,0 +1,103 @@
+"""world_size-2 (gloo, CPU) check of the batch-sharded path: averaged shard gradients == full-batch gradients.
+
+Compute runs on the emulated kernel set (test infrastructure) because there is no GPU here; what is
+under test is ``stc_hip.dist`` -- the flat gradient bucket, the equal contiguous sharding and the one
+all-reduce -- on the real drop-in modules in ``csr-fixed`` mode with the reference's ComboLoss.
+"""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests.conftest import PKG, REPO
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _build(seed=0):
+    import STC_GNN as M
+    from stc_hip import CsrGraph
+    torch.manual_seed(seed)
+    H, W, C, h, K = 4, 5, 3, 4, 2
+    graph = CsrGraph.queen_grid(H, W, normalize=True)
+    model = M.STCGNN(H * W, C, K, K, 1, h, 2, 2, graph_mode='csr-fixed')
+    Gc = torch.softmax(torch.randn(C, C), -1)
+    X = (torch.rand(4, 3, H * W, C) < 0.3).float()
+    Y = (torch.rand(4, 2, H * W, C) < 0.3).float()
+    return model, graph, Gc, X, Y
+
+
+def _worker(rank, world, port, out_dir):
+    for p in (REPO, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from oracle import stc_oracle as O
+    from oracle.kernel_emul import EmulatedKernels
+    from stc_hip import dist as sdist, ops
+    ops._kernels = EmulatedKernels()
+    r, w, _ = sdist.init_from_env(backend='gloo')
+    assert (r, w) == (rank, world)
+    model, graph, Gc, X, Y = _build()
+    bucket = sdist.GradBucket(model.parameters())
+    bucket.zero()
+    xs, ys = sdist.shard_batch(X, rank, world), sdist.shard_batch(Y, rank, world)
+    loss = O.combo_loss(model(X_seq=xs, As=graph, Ac=Gc), ys)
+    loss.backward()
+    assert bucket.check_views()
+    bucket.allreduce_mean()
+    torch.save({'flat': bucket.flat.clone(), 'loss': loss.detach()}, os.path.join(out_dir, f'rank{rank}.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_gradients_equal_full_batch(tmp_path):
+    world = 2
+    port = _free_port()
+    mp.start_processes(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method='spawn')
+    got = [torch.load(tmp_path / f'rank{r}.pt') for r in range(world)]
+    assert torch.equal(got[0]['flat'], got[1]['flat'])                    # every rank holds the same averaged bucket
+
+    from oracle import stc_oracle as O
+    from oracle.kernel_emul import EmulatedKernels
+    from stc_hip import dist as sdist, ops
+    old = ops._kernels
+    ops._kernels = EmulatedKernels()
+    try:
+        model, graph, Gc, X, Y = _build()
+        bucket = sdist.GradBucket(model.parameters())
+        loss = O.combo_loss(model(X_seq=X, As=graph, Ac=Gc), Y)
+        loss.backward()
+        assert bucket.allreduce_mean() is None                            # no process group: a no-op
+        full = bucket.flat.clone()
+    finally:
+        ops._kernels = old
+    denom = float(full.abs().max())
+    assert float((got[0]['flat'] - full).abs().max()) / denom < 5e-6
+    assert abs(float((got[0]['loss'] + got[1]['loss']) / 2 - loss.detach())) < 1e-6   # equal shards: mean of shard losses
+    assert bucket.nbytes == 4 * sum(p.numel() for p in model.parameters())
+
+
+def test_shard_batch_and_bucket_guards():
+    from stc_hip import dist as sdist
+    with pytest.raises(ValueError):
+        sdist.shard_batch(torch.zeros(5, 2), 0, 2)
+    assert sdist.shard_batch(torch.arange(8).view(8, 1), 1, 4).flatten().tolist() == [2, 3]
+    lin = torch.nn.Linear(3, 2)
+    bucket = sdist.GradBucket(lin.parameters())
+    assert bucket.flat.numel() == 8 and bucket.check_views()
+    lin(torch.ones(1, 3)).sum().backward()
+    assert float(bucket.flat.abs().sum()) > 0
+    bucket.zero()
+    assert float(lin.weight.grad.abs().sum()) == 0.0 and bucket.check_views()
+    torch.optim.SGD(lin.parameters(), lr=0.1).zero_grad(set_to_none=True)
+    assert not bucket.check_views()

@@ -1,0 +1,294 @@
+"""-m gpu: every exported HIP kernel against its CPU twin (oracle/kernel_emul.py), called through
+the C ABI (ctypes front ``stc_hip._lib.HipKernels``) on the same seeded inputs.
+
+Tolerance: 1e-5 relative (max|a-b| / max|b|), the bound BASELINE.json's north_star states for
+fp32; observed differences are summation-order noise around 1e-6.  Index outputs do not exist on
+this path (all results are fp32).  Edge cases: empty rows, rows longer than the LDS-staged
+segment, ragged last tiles, widths that are not multiples of 4 (SF shape F = 85), zero sizes,
+in-place epilogue.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle.kernel_emul import EmulatedKernels
+from stc_hip import CsrGraph
+from tests.conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+EM = EmulatedKernels()
+
+
+@pytest.fixture(scope='module')
+def hip():
+    from stc_hip._lib import HipKernels
+    return HipKernels()
+
+
+def cu(t):
+    return None if t is None else t.cuda()
+
+
+def random_csr(n_rows, n_cols, density, seed, empty_rows=()):
+    g = torch.Generator().manual_seed(seed)
+    mask = torch.rand(n_rows, n_cols, generator=g) < density
+    for r in empty_rows:
+        mask[r] = False
+    vals = torch.randn(n_rows, n_cols, generator=g) * mask
+    idx = mask.nonzero(as_tuple=False)
+    rowptr = torch.zeros(n_rows + 1, dtype=torch.int64)
+    rowptr[1:] = torch.cumsum(mask.sum(1), 0)
+    return rowptr.to(torch.int32), idx[:, 1].to(torch.int32).contiguous(), vals[mask].contiguous(), vals
+
+
+@pytest.mark.parametrize('n_rows,n_cols,F,B,density', [
+    (37, 37, 1024, 2, 0.2),      # vector path VPT=4, ragged last tile
+    (64, 50, 160, 3, 0.3),       # vector path VPT=1 (SF layer>=1: C*L = 5*32)
+    (100, 100, 85, 2, 1.0),      # scalar path, dense rows (SF layer 0: C*L = 5*17)
+    (40, 40, 512, 1, 1.0),       # vector path VPT=2
+    (300, 300, 256, 1, 1.0),     # rows longer than the staged segment (8 rows x 300 > 1024 entries)
+    (9, 9, 2048, 1, 0.5),        # two column blocks per row
+    (5, 7, 3, 1, 0.5),           # tiny scalar
+])
+@pytest.mark.parametrize('alpha,beta', [(1.0, 0.0), (2.0, -1.0)])
+def test_csr_spmm(hip, n_rows, n_cols, F, B, density, alpha, beta):
+    rowptr, colidx, val, dense = random_csr(n_rows, n_cols, density, seed=n_rows * 7 + F, empty_rows=(1, n_rows - 1))
+    g = torch.Generator().manual_seed(F)
+    X = torch.randn(B, n_cols, F, generator=g)
+    Y0 = torch.randn(B, n_rows, F, generator=g) if beta != 0 else None
+    want = torch.empty(B, n_rows, F)
+    EM.csr_spmm(rowptr, colidx, val, n_rows, n_cols, X, Y0, want, alpha, beta)
+    dense_want = alpha * torch.einsum('rc,bcf->brf', dense, X) + (beta * Y0 if Y0 is not None else 0)
+    assert rel_err(want, dense_want) < 1e-5                      # the twin itself vs a dense matmul
+    got = torch.full((B, n_rows, F), float('nan')).cuda()
+    hip.csr_spmm(cu(rowptr), cu(colidx), cu(val), n_rows, n_cols, cu(X), cu(Y0), got, alpha, beta)
+    assert rel_err(got, want) < TOL
+    if Y0 is not None:                                          # in-place epilogue: Y0 aliases Y
+        buf = Y0.clone().cuda()
+        hip.csr_spmm(cu(rowptr), cu(colidx), cu(val), n_rows, n_cols, cu(X), buf, buf, alpha, beta)
+        assert torch.equal(buf, got)
+
+
+def test_csr_spmm_zero_sizes_and_errors(hip):
+    from stc_hip._lib import StcError
+    rowptr = torch.zeros(1, dtype=torch.int32).cuda()
+    empty_i = torch.zeros(0, dtype=torch.int32).cuda()
+    empty_f = torch.zeros(0).cuda()
+    hip.csr_spmm(rowptr, empty_i, empty_f, 0, 4, torch.randn(2, 4, 8).cuda(), None, torch.empty(2, 0, 8).cuda(), 1.0, 0.0)
+    rp = torch.zeros(5, dtype=torch.int32).cuda()               # 4 empty rows -> zeros
+    Y = torch.full((1, 4, 64), 7.0).cuda()
+    hip.csr_spmm(rp, empty_i, empty_f, 4, 4, torch.randn(1, 4, 64).cuda(), None, Y, 1.0, 0.0)
+    assert float(Y.abs().max()) == 0.0
+    with pytest.raises(StcError):                               # CPU tensor: no fallback
+        hip.csr_spmm(rp.cpu(), empty_i, empty_f, 4, 4, torch.randn(1, 4, 64), None, torch.empty(1, 4, 64), 1.0, 0.0)
+    with pytest.raises(StcError):                               # wrong dtype
+        hip.csr_spmm(rp, empty_i, empty_f, 4, 4, torch.randn(1, 4, 64).double().cuda(), None, Y, 1.0, 0.0)
+    with pytest.raises(StcError):                               # shape mismatch caught on the host
+        hip.csr_spmm(rp, empty_i, empty_f, 4, 4, torch.randn(1, 5, 64).cuda(), None, Y, 1.0, 0.0)
+    with pytest.raises(StcError):                               # beta without Y0: rejected by the C side
+        hip.csr_spmm(rp, empty_i, empty_f, 4, 4, torch.randn(1, 4, 64).cuda(), None, Y, 1.0, 1.0)
+
+
+@pytest.mark.parametrize('n,F,B,density', [(33, 85, 2, 1.0), (50, 256, 3, 0.2), (12, 7, 1, 0.6)])
+def test_csr_sddmm(hip, n, F, B, density):
+    rowptr, colidx, val, _ = random_csr(n, n, density, seed=n + F, empty_rows=(0,))
+    g = torch.Generator().manual_seed(n)
+    A, Bm = torch.randn(B, n, F, generator=g), torch.randn(B, n, F, generator=g)
+    base = torch.randn(colidx.numel(), generator=g)
+    for acc in (False, True):
+        want = base.clone()
+        EM.csr_sddmm(rowptr, colidx, n, n, A, Bm, want, 2.0, acc)
+        got = base.clone().cuda()
+        hip.csr_sddmm(cu(rowptr), cu(colidx), n, n, cu(A), cu(Bm), got, 2.0, acc)
+        assert rel_err(got, want) < TOL
+
+
+@pytest.mark.parametrize('n,K', [(3, 1), (5, 2), (8, 3), (32, 4), (64, 3)])
+def test_cheby_dense_fwd_bwd(hip, n, K):
+    g = torch.Generator().manual_seed(n * 10 + K)
+    G = torch.randn(n, n, generator=g) / n ** 0.5
+    T_want = torch.empty(K, n, n)
+    EM.cheby_dense_fwd(G, K, T_want)
+    T = torch.empty(K, n, n).cuda()
+    hip.cheby_dense_fwd(cu(G), K, T)
+    assert rel_err(T, T_want) < TOL
+    dT = torch.randn(K, n, n, generator=g)
+    dG_want = torch.empty(n, n)
+    EM.cheby_dense_bwd(G, T_want, dT.clone(), dG_want)
+    dG = torch.empty(n, n).cuda()
+    hip.cheby_dense_bwd(cu(G), T, cu(dT.clone()), dG)
+    assert rel_err(dG, dG_want) < TOL
+
+
+NODE_SHAPES = [
+    # nodes, C, L, Ho, Ks, Kc
+    (24, 3, 5, 4, 1, 1),
+    (24, 3, 5, 4, 2, 2),
+    (24, 3, 5, 4, 3, 3),
+    (200, 5, 17, 32, 2, 2),      # SF encoder layer 0 gates
+    (200, 5, 32, 16, 2, 2),      # SF candidate
+    (70, 8, 32, 32, 3, 3),       # config 2 width, K=3, ragged tile (TN=4)
+    (33, 32, 32, 32, 2, 2),      # headline width C=32
+    (17, 32, 17, 16, 3, 2),      # Ks != Kc
+    (5, 64, 32, 32, 2, 2),       # config 5 category count
+    (9, 7, 6, 3, 4, 4),          # highest supported order
+]
+
+
+def _node_inputs(nodes, C, L, Ho, Ks, Kc, seed):
+    g = torch.Generator().manual_seed(seed)
+    Zs = [torch.randn(nodes, C, L, generator=g) for _ in range(Ks)]
+    Tc = torch.randn(Kc, C, C, generator=g) / C ** 0.5
+    Tc[0] = torch.eye(C)
+    W = torch.randn(Ks * Kc * L, Ho, generator=g) / (Ks * Kc * L) ** 0.5
+    b = torch.randn(Ho, generator=g)
+    dY = torch.randn(nodes, C, Ho, generator=g)
+    return Zs, Tc, W, b, dY
+
+
+@pytest.mark.parametrize('shape', NODE_SHAPES)
+@pytest.mark.parametrize('bias', [True, False])
+def test_bdg_node_fwd(hip, shape, bias):
+    nodes, C, L, Ho, Ks, Kc = shape
+    Zs, Tc, W, b, _ = _node_inputs(*shape, seed=sum(shape))
+    b = b if bias else None
+    want = torch.empty(nodes, C, Ho)
+    EM.bdg_node_fwd(Zs, Tc, W, b, want)
+    got = torch.full((nodes, C, Ho), float('nan')).cuda()
+    hip.bdg_node_fwd([cu(z) for z in Zs], cu(Tc), cu(W), cu(b), got)
+    assert rel_err(got, want) < TOL
+
+
+@pytest.mark.parametrize('shape', NODE_SHAPES)
+@pytest.mark.parametrize('want_dT', [True, False])
+def test_bdg_node_bwd(hip, shape, want_dT):
+    nodes, C, L, Ho, Ks, Kc = shape
+    Zs, Tc, W, b, dY = _node_inputs(*shape, seed=sum(shape) + 1)
+    dZ_w = [torch.empty(nodes, C, L) for _ in range(Ks)]
+    dW_w, db_w = torch.empty_like(W), torch.empty(Ho)
+    dT_w = torch.empty_like(Tc) if want_dT else None
+    EM.bdg_node_bwd(Zs, Tc, W, dY, dZ_w, dW_w, db_w, dT_w)
+    nan = float('nan')
+    dZ = [torch.full((nodes, C, L), nan).cuda() for _ in range(Ks)]
+    dW, db = torch.full_like(W, nan).cuda(), torch.full((Ho,), nan).cuda()
+    dT = torch.full_like(Tc, nan).cuda() if want_dT else None
+    hip.bdg_node_bwd([cu(z) for z in Zs], cu(Tc), cu(W), cu(dY), dZ, dW, db, dT)
+    for a, w in zip(dZ, dZ_w):
+        assert rel_err(a, w) < TOL
+    assert rel_err(dW, dW_w) < TOL and rel_err(db, db_w) < TOL
+    if want_dT:
+        assert float(dT[0].abs().max()) == 0.0                  # T_0 = I is a constant
+        if Kc > 1:
+            assert rel_err(dT[1:], dT_w[1:]) < TOL
+    # bitwise reproducible: partial sums are combined in a fixed order
+    dW2 = torch.empty_like(dW)
+    hip.bdg_node_bwd([cu(z) for z in Zs], cu(Tc), cu(W), cu(dY), dZ, dW2, db, dT)
+    assert torch.equal(dW, dW2)
+
+
+def test_bdg_node_bwd_many_tiles_exercises_grid_stride(hip):
+    shape = (3000, 8, 9, 5, 2, 2)                               # 750 tiles > 512 workgroups
+    nodes, C, L, Ho, Ks, Kc = shape
+    Zs, Tc, W, b, dY = _node_inputs(*shape, seed=5)
+    dZ_w = [torch.empty(nodes, C, L) for _ in range(Ks)]
+    dW_w, db_w, dT_w = torch.empty_like(W), torch.empty(Ho), torch.empty_like(Tc)
+    EM.bdg_node_bwd(Zs, Tc, W, dY, dZ_w, dW_w, db_w, dT_w)
+    dZ = [torch.empty(nodes, C, L).cuda() for _ in range(Ks)]
+    dW, db, dT = torch.empty_like(W).cuda(), torch.empty(Ho).cuda(), torch.empty_like(Tc).cuda()
+    hip.bdg_node_bwd([cu(z) for z in Zs], cu(Tc), cu(W), cu(dY), dZ, dW, db, dT)
+    assert rel_err(dZ[1], dZ_w[1]) < TOL and rel_err(dW, dW_w) < TOL and rel_err(db, db_w) < TOL
+    assert rel_err(dT[1], dT_w[1]) < TOL
+    Y_w = torch.empty(nodes, C, Ho)
+    EM.bdg_node_fwd(Zs, Tc, W, b, Y_w)
+    Y = torch.empty(nodes, C, Ho).cuda()
+    hip.bdg_node_fwd([cu(z) for z in Zs], cu(Tc), cu(W), cu(b), Y)
+    assert rel_err(Y, Y_w) < TOL
+
+
+@pytest.mark.parametrize('rows_shape,cin,h', [((2, 7, 3), 1, 4), ((3, 50, 5), 16, 16), ((1, 9, 2), 4, 5)])
+def test_gru_gates_and_blend(hip, rows_shape, cin, h):
+    g = torch.Generator().manual_seed(cin * 100 + h)
+    G = torch.randn(*rows_shape, 2 * h, generator=g)
+    Xt = torch.randn(*rows_shape, cin, generator=g)
+    H = torch.randn(*rows_shape, h, generator=g)
+    U_w, R_w, Ci_w = torch.empty_like(H), torch.empty_like(H), torch.empty(*rows_shape, cin + h)
+    EM.gru_gates_fwd(G, Xt, H, U_w, R_w, Ci_w)
+    U, R, Ci = torch.empty_like(H).cuda(), torch.empty_like(H).cuda(), torch.empty(*rows_shape, cin + h).cuda()
+    hip.gru_gates_fwd(cu(G), cu(Xt), cu(H), U, R, Ci)
+    assert rel_err(U, U_w) < TOL and rel_err(R, R_w) < TOL and rel_err(Ci, Ci_w) < TOL
+    dCi, dU = torch.randn(*rows_shape, cin + h, generator=g), torch.randn(*rows_shape, h, generator=g)
+    dG_w, dX_w, dH_w = torch.empty_like(G), torch.empty_like(Xt), torch.empty_like(H)
+    EM.gru_gates_bwd(dCi, dU, H, U_w, R_w, dG_w, dX_w, dH_w)
+    dG, dX, dH = torch.empty_like(G).cuda(), torch.empty_like(Xt).cuda(), torch.empty_like(H).cuda()
+    hip.gru_gates_bwd(cu(dCi), cu(dU), cu(H), cu(U_w), cu(R_w), dG, dX, dH)
+    assert rel_err(dG, dG_w) < TOL and rel_err(dX, dX_w) < TOL and rel_err(dH, dH_w) < TOL
+
+    Cpre = torch.randn(*rows_shape, h, generator=g) * 2
+    Cand_w, Hn_w = torch.empty_like(H), torch.empty_like(H)
+    EM.gru_blend_fwd(Cpre, U_w, H, Cand_w, Hn_w)
+    Cand, Hn = torch.empty_like(H).cuda(), torch.empty_like(H).cuda()
+    hip.gru_blend_fwd(cu(Cpre), cu(U_w), cu(H), Cand, Hn)
+    assert rel_err(Cand, Cand_w) < TOL and rel_err(Hn, Hn_w) < TOL
+    dHn = torch.randn(*rows_shape, h, generator=g)
+    outs_w = [torch.empty_like(H) for _ in range(3)]
+    EM.gru_blend_bwd(dHn, U_w, H, Cand_w, *outs_w)
+    outs = [torch.empty_like(H).cuda() for _ in range(3)]
+    hip.gru_blend_bwd(cu(dHn), cu(U_w), cu(H), cu(Cand_w), *outs)
+    for a, w in zip(outs, outs_w):
+        assert rel_err(a, w) < TOL
+
+
+def test_axpy_concat_split(hip):
+    g = torch.Generator().manual_seed(3)
+    x, y = torch.randn(1000, generator=g), torch.randn(1000, generator=g)
+    yd = y.clone().cuda()
+    hip.axpy(-1.0, cu(x), yd)
+    assert rel_err(yd, y - x) < 1e-7
+    A, Bm = torch.randn(4, 9, 3, 1, generator=g), torch.randn(4, 9, 3, 16, generator=g)
+    out = torch.empty(4, 9, 3, 17).cuda()
+    hip.concat2(cu(A), cu(Bm), out)
+    assert torch.equal(out.cpu(), torch.cat([A, Bm], -1))
+    A2, B2 = torch.empty_like(A).cuda(), torch.empty_like(Bm).cuda()
+    hip.split2(out, A2, B2)
+    assert torch.equal(A2.cpu(), A) and torch.equal(B2.cpu(), Bm)
+
+
+# ------------------------------------------------------------------ full-size properties (N = 50 176)
+def test_full_size_spmm_properties(hip):
+    """BASELINE metric size (224x224 queen grid, C=32, L=32 -> F=1024): properties that need no oracle.
+
+    * CSR(Gs) of the row-stochastic grid maps the all-ones field to itself;
+    * adjoint identity <Gs^T x, y> = <x, Gs y> ties the forward and backward operands together;
+    * linearity in X;
+    * a randomly permuted node order gives the permuted result.
+    """
+    H = W = 224
+    graph = CsrGraph.queen_grid(H, W, normalize=True)
+    d = graph.on(torch.device('cuda'))
+    N, F = H * W, 1024
+    assert graph.nnz == 398724
+    ones = torch.ones(1, N, F, device='cuda')
+    out = torch.empty_like(ones)
+    hip.csr_spmm(d['bwd_rowptr'], d['bwd_colidx'], d['bwd_val'], N, N, ones, None, out, 1.0, 0.0)
+    assert float((out - 1).abs().max()) < 1e-6
+    g = torch.Generator(device='cuda').manual_seed(0)
+    x = torch.randn(1, N, F, device='cuda', generator=g)
+    y = torch.randn(1, N, F, device='cuda', generator=g)
+    STx, Sy = torch.empty_like(x), torch.empty_like(x)
+    hip.csr_spmm(d['fwd_rowptr'], d['fwd_colidx'], d['fwd_val'], N, N, x, None, STx, 1.0, 0.0)
+    hip.csr_spmm(d['bwd_rowptr'], d['bwd_colidx'], d['bwd_val'], N, N, y, None, Sy, 1.0, 0.0)
+    lhs, rhs = (STx.double() * y.double()).sum(), (x.double() * Sy.double()).sum()
+    assert abs(float(lhs - rhs)) < 1e-6 * abs(float(rhs)) + 1e-3
+    both = torch.empty_like(x)
+    hip.csr_spmm(d['fwd_rowptr'], d['fwd_colidx'], d['fwd_val'], N, N, 2 * x + y, None, both, 1.0, 0.0)
+    STy = torch.empty_like(x)
+    hip.csr_spmm(d['fwd_rowptr'], d['fwd_colidx'], d['fwd_val'], N, N, y, None, STy, 1.0, 0.0)
+    assert rel_err(both, 2 * STx + STy) < TOL
+    # permuted node order (seed 1234): P-conjugated graph on P-permuted features = permuted result
+    perm_graph = CsrGraph.queen_grid(H, W, normalize=True, permute_seed=1234)
+    p = torch.randperm(N, generator=torch.Generator().manual_seed(1234)).cuda()
+    dp = perm_graph.on(torch.device('cuda'))
+    out_p = torch.empty_like(x)
+    hip.csr_spmm(dp['fwd_rowptr'], dp['fwd_colidx'], dp['fwd_val'], N, N, x[:, p].contiguous(), None, out_p, 1.0, 0.0)
+    assert rel_err(out_p, STx[:, p]) < TOL
