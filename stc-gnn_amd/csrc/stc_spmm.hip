@@ -200,7 +200,7 @@ extern "C" int stc_csr_spmm_f32(const int32_t* rowptr, const int32_t* colidx, co
     if (n_rows == 0 || batch == 0 || F == 0) return STC_OK;
     STC_REQUIRE(rowptr && Y, STC_EINVAL, "stc_csr_spmm_f32: null rowptr/Y");
     STC_REQUIRE(n_cols > 0 && X, STC_EINVAL, "stc_csr_spmm_f32: null X or n_cols == 0 with rows to produce");
-    STC_REQUIRE(colidx && val, STC_EINVAL, "stc_csr_spmm_f32: null colidx/val");
+    // colidx/val may be null for a graph without edges (rowptr all zero): they are then never read
     STC_REQUIRE(beta == 0.f || Y0, STC_EINVAL, "stc_csr_spmm_f32: beta != 0 needs Y0");
     STC_REQUIRE(batch <= 65535, STC_ELIMIT, "stc_csr_spmm_f32: batch %d > 65535 (grid.y)", batch);
     STC_REQUIRE(X != Y, STC_EINVAL, "stc_csr_spmm_f32: X must not alias Y");
