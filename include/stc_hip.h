@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define STC_ABI_VERSION 1
+#define STC_ABI_VERSION 2
 #define STC_MAX_K 4          /* highest Chebyshev order (Ks, Kc) the node kernels accept */
 
 #define STC_OK 0
@@ -75,16 +75,19 @@ int stc_cheby_dense_bwd_f32(const float* G, const float* T, float* dT, int32_t n
 
 /* ---- node kernel: 2-mode product + concat + projection + bias -------------
  * Y[r,d,:] = bias + sum_{n<Ks} sum_{c<Kc} sum_{c'} Tc[c][c',d] * ( Z_n[r,c',:] . W_{n,c} )
- * r over `nodes` = batch*N rows; Z_n (nodes, C, L); Tc (Kc, C, C); W (Ks*Kc*L, Ho)
+ * r over `nodes` = batch*N rows; Z_n (nodes, C, L); Tc (Kc, C, C); W (Ks*Kc*Lw, Ho)
  * with row blocks n-major, c-minor (STC_GNN.py:35-41); Y (nodes, C, Ho).
  * Replaces STC_GNN.py:38-45 without materialising the K*K*L concat.
- * Z is a HOST array of Ks device pointers. */
+ * Z is a HOST array of Ks device pointers.
+ * Lw <= L: the slabs may carry L - Lw trailing pad columns per row (the host pads L = in + hidden
+ * up to a multiple of 4 so that every row is 16-byte aligned: 17 -> 20); W has Lw rows per block,
+ * pad columns are ignored in the forward and receive zero gradient. */
 int stc_bdg_node_fwd_f32(const float* const* Z, int32_t Ks, const float* Tc, int32_t Kc,
                          const float* W, const float* bias, float* Y,
-                         int64_t nodes, int32_t C, int32_t L, int32_t Ho, void* stream);
+                         int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t Ho, void* stream);
 
 /* Backward of the node kernel.  dZ: HOST array of Ks device pointers (nodes,C,L),
- * overwritten.  dW (Ks*Kc*L, Ho), db (Ho) or NULL, dTc (Kc,C,C) or NULL: overwritten.
+ * overwritten.  dW (Ks*Kc*Lw, Ho), db (Ho) or NULL, dTc (Kc,C,C) or NULL: overwritten.
  * workspace: >= stc_bdg_node_bwd_workspace_bytes(...) bytes, 16-byte aligned. */
 size_t stc_bdg_node_bwd_workspace_bytes(int32_t Ks, int32_t Kc, int32_t C, int32_t L, int32_t Ho,
                                         int32_t want_dTc);
@@ -92,18 +95,18 @@ int stc_bdg_node_bwd_f32(const float* const* Z, int32_t Ks, const float* Tc, int
                          const float* W, const float* dY,
                          float* const* dZ, float* dW, float* db, float* dTc,
                          void* workspace, size_t workspace_bytes,
-                         int64_t nodes, int32_t C, int32_t L, int32_t Ho, void* stream);
+                         int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t Ho, void* stream);
 
 /* ---- GRU gate math (STC_GNN.py:68-78) --------------------------------------
- * gates:  U = sigmoid(G[:, :h]); Rg = sigmoid(G[:, h:]); CandIn = [Xt | Rg*H]
- *         G (rows, 2h), Xt (rows, cin), H/U/Rg (rows, h), CandIn (rows, cin+h) */
+ * gates:  U = sigmoid(G[:, :h]); Rg = sigmoid(G[:, h:]); CandIn = [Xt | Rg*H | 0-pad]
+ *         G (rows, 2h), Xt (rows, cin), H/U/Rg (rows, h), CandIn/dCandIn (rows, cin+h+pad) */
 int stc_gru_gates_fwd_f32(const float* G, const float* Xt, const float* H,
                           float* U, float* Rg, float* CandIn,
-                          int64_t rows, int32_t cin, int32_t h, void* stream);
+                          int64_t rows, int32_t cin, int32_t h, int32_t pad, void* stream);
 int stc_gru_gates_bwd_f32(const float* dCandIn, const float* dU, const float* H,
                           const float* U, const float* Rg,
                           float* dG, float* dXt, float* dH,
-                          int64_t rows, int32_t cin, int32_t h, void* stream);
+                          int64_t rows, int32_t cin, int32_t h, int32_t pad, void* stream);
 /* blend:  Cand = tanh(Cpre); Hnew = (1-U)*H + U*Cand      (n = rows*h elements) */
 int stc_gru_blend_fwd_f32(const float* Cpre, const float* U, const float* H,
                           float* Cand, float* Hnew, int64_t n, void* stream);
@@ -113,11 +116,11 @@ int stc_gru_blend_bwd_f32(const float* dHnew, const float* U, const float* H, co
 /* ---- small helpers ---------------------------------------------------------
  * y += a*x over n elements (Chebyshev backward g_{k-2} -= g_k) */
 int stc_axpy_f32(float a, const float* x, float* y, int64_t n, void* stream);
-/* out (rows, a+b) = [A (rows,a) | B (rows,b)]   (torch.cat of STC_GNN.py:68) and its inverse */
+/* out (rows, a+b+pad) = [A (rows,a) | B (rows,b) | zeros]   (torch.cat of STC_GNN.py:68) and its inverse */
 int stc_concat2_f32(const float* A, const float* B, float* out,
-                    int64_t rows, int32_t a, int32_t b, void* stream);
+                    int64_t rows, int32_t a, int32_t b, int32_t pad, void* stream);
 int stc_split2_f32(const float* src, float* A, float* B,
-                   int64_t rows, int32_t a, int32_t b, void* stream);
+                   int64_t rows, int32_t a, int32_t b, int32_t pad, void* stream);
 
 #ifdef __cplusplus
 }

@@ -84,12 +84,13 @@ class EmulatedKernels:
         Ks, Kc = len(Zs), Tc.shape[0]
         R, C, L = Zs[0].shape
         Ho = W.shape[1]
-        Wv = W.view(Ks, Kc, L, Ho)
+        Lw = W.shape[0] // (Ks * Kc)          # slab columns [Lw, L) are padding: ignored
+        Wv = W.view(Ks, Kc, Lw, Ho)
         out = torch.zeros(R, C, Ho, dtype=W.dtype)
         for c in range(Kc):
             U = torch.zeros(R, C, Ho, dtype=W.dtype)
             for n in range(Ks):
-                U += Zs[n] @ Wv[n, c]
+                U += Zs[n][..., :Lw] @ Wv[n, c]
             out += torch.einsum('pd,rpo->rdo', Tc[c], U)
         if bias is not None:
             out += bias
@@ -100,24 +101,25 @@ class EmulatedKernels:
         Ks, Kc = len(Zs), Tc.shape[0]
         R, C, L = Zs[0].shape
         Ho = W.shape[1]
-        Wv = W.view(Ks, Kc, L, Ho)
+        Lw = W.shape[0] // (Ks * Kc)
+        Wv = W.view(Ks, Kc, Lw, Ho)
         dWv = torch.zeros_like(Wv)
         # Q_c[r,c',:] = sum_d Tc[c][c',d] dY[r,d,:]
         Q = [torch.einsum('pd,rdo->rpo', Tc[c], dY) for c in range(Kc)]
         for n in range(Ks):
-            acc = torch.zeros(R, C, L, dtype=W.dtype)
+            acc = torch.zeros(R, C, L, dtype=W.dtype)            # pad columns get zero gradient
             for c in range(Kc):
-                acc += Q[c] @ Wv[n, c].t()
-                dWv[n, c] = torch.einsum('rpl,rpo->lo', Zs[n], Q[c])
+                acc[..., :Lw] += Q[c] @ Wv[n, c].t()
+                dWv[n, c] = torch.einsum('rpl,rpo->lo', Zs[n][..., :Lw], Q[c])
             dZs[n].copy_(acc)
-        dW.copy_(dWv.view(Ks * Kc * L, Ho))
+        dW.copy_(dWv.view(Ks * Kc * Lw, Ho))
         if db is not None:
             db.copy_(dY.sum(dim=(0, 1)))
         if dTc is not None:
             for c in range(Kc):
                 U = torch.zeros(R, C, Ho, dtype=W.dtype)
                 for n in range(Ks):
-                    U += Zs[n] @ Wv[n, c]
+                    U += Zs[n][..., :Lw] @ Wv[n, c]
                 dTc[c].copy_(torch.einsum('rpo,rdo->pd', U, dY))
 
     # ---- stc_gru_gates_fwd/bwd_f32: split + sigmoids + reset*H + second concat (STC_GNN.py:71-75)
@@ -127,12 +129,13 @@ class EmulatedKernels:
         U.copy_(torch.sigmoid(G[..., :h]))
         Rg.copy_(torch.sigmoid(G[..., h:]))
         CandIn[..., :cin].copy_(Xt)
-        CandIn[..., cin:].copy_(Rg * H)
+        CandIn[..., cin:cin + h].copy_(Rg * H)
+        CandIn[..., cin + h:].zero_()                      # optional zero padding up to the row width
 
     def gru_gates_bwd(self, dCandIn, dU, H, U, Rg, dG, dXt, dH):
         h = H.shape[-1]
         cin = dXt.shape[-1]
-        dRH = dCandIn[..., cin:]
+        dRH = dCandIn[..., cin:cin + h]
         dG[..., :h].copy_(dU * U * (1 - U))
         dG[..., h:].copy_(dRH * H * Rg * (1 - Rg))
         dXt.copy_(dCandIn[..., :cin])
@@ -154,11 +157,12 @@ class EmulatedKernels:
 
     # ---- stc_concat2_f32 / split: cat([A,B],-1) (STC_GNN.py:68) and its backward
     def concat2(self, A, Bm, out):
-        a = A.shape[-1]
+        a, b = A.shape[-1], Bm.shape[-1]
         out[..., :a].copy_(A)
-        out[..., a:].copy_(Bm)
+        out[..., a:a + b].copy_(Bm)
+        out[..., a + b:].zero_()
 
     def split2(self, src, A, Bm):
-        a = A.shape[-1]
+        a, b = A.shape[-1], Bm.shape[-1]
         A.copy_(src[..., :a])
-        Bm.copy_(src[..., a:])
+        Bm.copy_(src[..., a:a + b])

@@ -84,9 +84,9 @@ class BDG_Dif(nn.Module):
         if use_bias:
             self.b = nn.Parameter(torch.zeros(hidden_dim))
 
-    def forward(self, X: torch.Tensor, Gs: GraphLike, Gc: Optional[torch.Tensor] = None):
+    def forward(self, X: torch.Tensor, Gs: GraphLike, Gc: Optional[torch.Tensor] = None, _pad: int = 0):
         pair = _graphs(Gs, Gc, self.Ks, self.Kc)
-        out = ops.bdg_dif(X, pair.spatial, pair.Tc, self.W, self.b if self.use_bias else None, self.Ks)
+        out = ops.bdg_dif(X, pair.spatial, pair.Tc, self.W, self.b if self.use_bias else None, self.Ks, _pad)
         return out if self.activation is None else self.activation(out)
 
 
@@ -107,9 +107,12 @@ class STC_Cell(nn.Module):
     def forward(self, Gs: GraphLike, Gc: Optional[torch.Tensor], Xt: torch.Tensor, Ht_1: torch.Tensor):
         assert Xt.dim() == 4 and Ht_1.dim() == 4, 'STC-cell must take in 4D tensor as input [Xt, Ht-1]'
         pair = _graphs(Gs, Gc, self.gates.Ks, self.gates.Kc)
-        pre = self.gates(ops.concat2(Xt, Ht_1), pair)                 # (B,N,C,2h) update|reset pre-activations
-        update, cand_in = ops.gru_gates(pre, Xt, Ht_1)                # sigmoid, reset*H and the second concat, fused
-        cand_pre = self.candi(cand_in, pair)
+        # feature rows are padded with zeros to a multiple of 4 floats (in + hidden = 17 -> 20) so that every
+        # (node, category) row is 16-byte aligned for the vector / MFMA kernels; W keeps its reference shape
+        pad = -(Xt.shape[-1] + Ht_1.shape[-1]) % 4
+        pre = self.gates(ops.concat2(Xt, Ht_1, pad), pair, None, pad)  # (B,N,C,2h) update|reset pre-activations
+        update, cand_in = ops.gru_gates(pre, Xt, Ht_1, pad)           # sigmoid, reset*H and the second concat, fused
+        cand_pre = self.candi(cand_in, pair, None, pad)
         return ops.gru_blend(cand_pre, update, Ht_1)                  # (1-u)*H + u*tanh(.)
 
 

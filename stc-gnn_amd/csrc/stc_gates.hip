@@ -19,14 +19,16 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-
 __global__ __launch_bounds__(EW_THREADS) void gru_gates_fwd_kernel(
     const float* __restrict__ G, const float* __restrict__ Xt, const float* __restrict__ H,
     float* __restrict__ U, float* __restrict__ Rg, float* __restrict__ CandIn,
-    long long rows, int cin, int h) {
-    const int L = cin + h;
+    long long rows, int cin, int h, int pad) {
+    const int L = cin + h + pad;
     const long long n = rows * L;
     for (long long e = (long long)blockIdx.x * EW_THREADS + threadIdx.x; e < n; e += (long long)gridDim.x * EW_THREADS) {
         const long long r = e / L;
         const int l = (int)(e - r * L);
         if (l < cin) {
             CandIn[e] = Xt[r * cin + l];
+        } else if (l >= cin + h) {
+            CandIn[e] = 0.f;
         } else {
             const int k = l - cin;
             const float u = sigmoidf_(G[r * 2 * h + k]);
@@ -42,15 +44,15 @@ __global__ __launch_bounds__(EW_THREADS) void gru_gates_bwd_kernel(
     const float* __restrict__ dCandIn, const float* __restrict__ dU, const float* __restrict__ H,
     const float* __restrict__ U, const float* __restrict__ Rg,
     float* __restrict__ dG, float* __restrict__ dXt, float* __restrict__ dH,
-    long long rows, int cin, int h) {
-    const int L = cin + h;
+    long long rows, int cin, int h, int pad) {
+    const int L = cin + h + pad;
     const long long n = rows * L;
     for (long long e = (long long)blockIdx.x * EW_THREADS + threadIdx.x; e < n; e += (long long)gridDim.x * EW_THREADS) {
         const long long r = e / L;
         const int l = (int)(e - r * L);
         if (l < cin) {
             dXt[r * cin + l] = dCandIn[e];
-        } else {
+        } else if (l < cin + h) {
             const int k = l - cin;
             const long long i = r * h + k;
             const float u = U[i], g = Rg[i], d = dCandIn[e];
@@ -91,25 +93,25 @@ __global__ __launch_bounds__(EW_THREADS) void axpy_kernel(float a, const float* 
 }
 
 __global__ __launch_bounds__(EW_THREADS) void concat2_kernel(const float* __restrict__ A, const float* __restrict__ B,
-                                                              float* __restrict__ out, long long rows, int a, int b) {
-    const int L = a + b;
+                                                              float* __restrict__ out, long long rows, int a, int b, int pad) {
+    const int L = a + b + pad;
     const long long n = rows * L;
     for (long long e = (long long)blockIdx.x * EW_THREADS + threadIdx.x; e < n; e += (long long)gridDim.x * EW_THREADS) {
         const long long r = e / L;
         const int l = (int)(e - r * L);
-        out[e] = l < a ? A[r * a + l] : B[r * b + (l - a)];
+        out[e] = l < a ? A[r * a + l] : (l < a + b ? B[r * b + (l - a)] : 0.f);
     }
 }
 
 __global__ __launch_bounds__(EW_THREADS) void split2_kernel(const float* __restrict__ src, float* __restrict__ A,
-                                                             float* __restrict__ B, long long rows, int a, int b) {
-    const int L = a + b;
+                                                             float* __restrict__ B, long long rows, int a, int b, int pad) {
+    const int L = a + b + pad;
     const long long n = rows * L;
     for (long long e = (long long)blockIdx.x * EW_THREADS + threadIdx.x; e < n; e += (long long)gridDim.x * EW_THREADS) {
         const long long r = e / L;
         const int l = (int)(e - r * L);
         if (l < a) A[r * a + l] = src[e];
-        else B[r * b + (l - a)] = src[e];
+        else if (l < a + b) B[r * b + (l - a)] = src[e];
     }
 }
 
@@ -165,21 +167,21 @@ __global__ __launch_bounds__(EW_THREADS) void cheby_bwd_final_kernel(const float
     hipStream_t s = static_cast<hipStream_t>(stream)
 
 extern "C" int stc_gru_gates_fwd_f32(const float* G, const float* Xt, const float* H, float* U, float* Rg, float* CandIn,
-                                     int64_t rows, int32_t cin, int32_t h, void* stream) {
-    STC_REQUIRE(cin >= 0 && h >= 1, STC_EINVAL, "stc_gru_gates_fwd_f32: bad widths cin=%d h=%d", cin, h);
+                                     int64_t rows, int32_t cin, int32_t h, int32_t pad, void* stream) {
+    STC_REQUIRE(cin >= 0 && h >= 1 && pad >= 0, STC_EINVAL, "stc_gru_gates_fwd_f32: bad widths cin=%d h=%d pad=%d", cin, h, pad);
     STC_EW_PROLOGUE("stc_gru_gates_fwd_f32", rows, G && H && U && Rg && CandIn && (cin == 0 || Xt));
-    const long long n = (long long)rows * (cin + h);
-    hipLaunchKernelGGL(gru_gates_fwd_kernel, ew_grid(n), dim3(EW_THREADS), 0, s, G, Xt, H, U, Rg, CandIn, (long long)rows, cin, h);
+    const long long n = (long long)rows * (cin + h + pad);
+    hipLaunchKernelGGL(gru_gates_fwd_kernel, ew_grid(n), dim3(EW_THREADS), 0, s, G, Xt, H, U, Rg, CandIn, (long long)rows, cin, h, pad);
     STC_LAUNCH_CHECK("stc_gru_gates_fwd_f32 launch");
     return STC_OK;
 }
 
 extern "C" int stc_gru_gates_bwd_f32(const float* dCandIn, const float* dU, const float* H, const float* U, const float* Rg,
-                                     float* dG, float* dXt, float* dH, int64_t rows, int32_t cin, int32_t h, void* stream) {
-    STC_REQUIRE(cin >= 0 && h >= 1, STC_EINVAL, "stc_gru_gates_bwd_f32: bad widths cin=%d h=%d", cin, h);
+                                     float* dG, float* dXt, float* dH, int64_t rows, int32_t cin, int32_t h, int32_t pad, void* stream) {
+    STC_REQUIRE(cin >= 0 && h >= 1 && pad >= 0, STC_EINVAL, "stc_gru_gates_bwd_f32: bad widths cin=%d h=%d pad=%d", cin, h, pad);
     STC_EW_PROLOGUE("stc_gru_gates_bwd_f32", rows, dCandIn && dU && H && U && Rg && dG && dH && (cin == 0 || dXt));
-    const long long n = (long long)rows * (cin + h);
-    hipLaunchKernelGGL(gru_gates_bwd_kernel, ew_grid(n), dim3(EW_THREADS), 0, s, dCandIn, dU, H, U, Rg, dG, dXt, dH, (long long)rows, cin, h);
+    const long long n = (long long)rows * (cin + h + pad);
+    hipLaunchKernelGGL(gru_gates_bwd_kernel, ew_grid(n), dim3(EW_THREADS), 0, s, dCandIn, dU, H, U, Rg, dG, dXt, dH, (long long)rows, cin, h, pad);
     STC_LAUNCH_CHECK("stc_gru_gates_bwd_f32 launch");
     return STC_OK;
 }
@@ -207,20 +209,20 @@ extern "C" int stc_axpy_f32(float a, const float* x, float* y, int64_t n, void* 
     return STC_OK;
 }
 
-extern "C" int stc_concat2_f32(const float* A, const float* B, float* out, int64_t rows, int32_t a, int32_t b, void* stream) {
-    STC_REQUIRE(a >= 0 && b >= 0, STC_EINVAL, "stc_concat2_f32: negative width");
-    const long long n = (long long)rows * (a + b);
+extern "C" int stc_concat2_f32(const float* A, const float* B, float* out, int64_t rows, int32_t a, int32_t b, int32_t pad, void* stream) {
+    STC_REQUIRE(a >= 0 && b >= 0 && pad >= 0, STC_EINVAL, "stc_concat2_f32: negative width");
+    const long long n = (long long)rows * (a + b + pad);
     STC_EW_PROLOGUE("stc_concat2_f32", n, out && (a == 0 || A) && (b == 0 || B));
-    hipLaunchKernelGGL(concat2_kernel, ew_grid(n), dim3(EW_THREADS), 0, s, A, B, out, (long long)rows, a, b);
+    hipLaunchKernelGGL(concat2_kernel, ew_grid(n), dim3(EW_THREADS), 0, s, A, B, out, (long long)rows, a, b, pad);
     STC_LAUNCH_CHECK("stc_concat2_f32 launch");
     return STC_OK;
 }
 
-extern "C" int stc_split2_f32(const float* src, float* A, float* B, int64_t rows, int32_t a, int32_t b, void* stream) {
-    STC_REQUIRE(a >= 0 && b >= 0, STC_EINVAL, "stc_split2_f32: negative width");
-    const long long n = (long long)rows * (a + b);
+extern "C" int stc_split2_f32(const float* src, float* A, float* B, int64_t rows, int32_t a, int32_t b, int32_t pad, void* stream) {
+    STC_REQUIRE(a >= 0 && b >= 0 && pad >= 0, STC_EINVAL, "stc_split2_f32: negative width");
+    const long long n = (long long)rows * (a + b + pad);
     STC_EW_PROLOGUE("stc_split2_f32", n, src && (a == 0 || A) && (b == 0 || B));
-    hipLaunchKernelGGL(split2_kernel, ew_grid(n), dim3(EW_THREADS), 0, s, src, A, B, (long long)rows, a, b);
+    hipLaunchKernelGGL(split2_kernel, ew_grid(n), dim3(EW_THREADS), 0, s, src, A, B, (long long)rows, a, b, pad);
     STC_LAUNCH_CHECK("stc_split2_f32 launch");
     return STC_OK;
 }

@@ -19,6 +19,9 @@
 // weight-gradient partials are summed in a fixed order by a second kernel, so
 // results are bitwise reproducible.
 #include "stc_common.h"
+#include "stc_node_mfma.h"
+
+#include <cstdlib>
 
 namespace {
 
@@ -29,7 +32,7 @@ struct ZPtrs { const float* p[STC_MAX_K]; };
 struct DZPtrs { float* p[STC_MAX_K]; };
 
 struct NodeDims {
-    int Ks, Kc, C, L, Ho;
+    int Ks, Kc, C, L, Lw, Ho;   // Lw <= L: feature rows of W per block; slab columns [Lw, L) are padding
     int KD, J, KDp, Jp;     // contraction widths and their round-ups to 4
     int TN, rows;           // nodes per tile, category rows per tile (TN*C)
     int zs, qs, ds, wts;    // LDS row strides (floats): Zt, Ut/Qt, dYt, WsT
@@ -37,9 +40,9 @@ struct NodeDims {
 
 inline int up4(int v) { return (v + 3) & ~3; }
 
-NodeDims make_dims(int Ks, int Kc, int C, int L, int Ho) {
+NodeDims make_dims(int Ks, int Kc, int C, int L, int Lw, int Ho) {
     NodeDims d;
-    d.Ks = Ks; d.Kc = Kc; d.C = C; d.L = L; d.Ho = Ho;
+    d.Ks = Ks; d.Kc = Kc; d.C = C; d.L = L; d.Lw = Lw; d.Ho = Ho;
     d.KD = Ks * L; d.J = Kc * Ho;
     d.KDp = up4(d.KD); d.Jp = up4(d.J);
     d.TN = C >= 32 ? 1 : 32 / C;
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(NODE_THREADS) void bdg_node_fwd_kernel(
         float v = 0.f;
         if (j < d.J) {
             const int n = k / d.L, l = k - n * d.L, c = j / d.Ho, o = j - c * d.Ho;
-            v = W[((size_t)(n * d.Kc + c) * d.L + l) * d.Ho + o];
+            if (l < d.Lw) v = W[((size_t)(n * d.Kc + c) * d.Lw + l) * d.Ho + o];
         }
         Ws[idx] = v;
     }
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(NODE_THREADS) void bdg_node_bwd_kernel(
         float v = 0.f;
         if (k < d.KD) {
             const int n = k / d.L, l = k - n * d.L, c = j / d.Ho, o = j - c * d.Ho;
-            v = W[((size_t)(n * d.Kc + c) * d.L + l) * d.Ho + o];
+            if (l < d.Lw) v = W[((size_t)(n * d.Kc + c) * d.Lw + l) * d.Ho + o];
         }
         WsT[idx] = v;
     }
@@ -288,12 +291,12 @@ __global__ __launch_bounds__(NODE_THREADS) void bdg_node_bwd_kernel(
     }
 
     // this workgroup's partial sums, already in destination layout: [dW (Ks*Kc*L*Ho) | db (Ho) | dT (Kc*C*C)]
-    const int nW = d.Ks * d.Kc * d.L * d.Ho;
+    const int nW = d.Ks * d.Kc * d.Lw * d.Ho;
     float* out = partial + (size_t)blockIdx.x * (nW + d.Ho + d.Kc * CC);
     for (int idx = tid; idx < nW; idx += NODE_THREADS) {
         const int o = idx % d.Ho;
         int t = idx / d.Ho;
-        const int l = t % d.L; t /= d.L;
+        const int l = t % d.Lw; t /= d.Lw;
         const int c = t % d.Kc, n = t / d.Kc;
         out[idx] = dWacc[(n * d.L + l) * d.Jp + c * d.Ho + o];
     }
@@ -315,13 +318,20 @@ __global__ __launch_bounds__(NODE_THREADS) void bdg_node_reduce_kernel(
     else if (dT) dT[e - nW - Ho] = s;
 }
 
-int check_dims(const char* who, int Ks, int Kc, int C, int L, int Ho, long long nodes) {
+int check_dims(const char* who, int Ks, int Kc, int C, int L, int Lw, int Ho, long long nodes) {
+    STC_REQUIRE(Lw >= 1 && Lw <= L, STC_EINVAL, "%s: Lw=%d must be in [1, L=%d]", who, Lw, L);
     STC_REQUIRE(Ks >= 1 && Ks <= STC_MAX_K && Kc >= 1 && Kc <= STC_MAX_K, STC_ELIMIT,
                 "%s: Chebyshev orders Ks=%d Kc=%d outside [1,%d]", who, Ks, Kc, STC_MAX_K);
     STC_REQUIRE(C >= 1 && L >= 1 && Ho >= 1 && nodes >= 0, STC_EINVAL,
                 "%s: bad sizes C=%d L=%d Ho=%d nodes=%lld", who, C, L, Ho, nodes);
     STC_REQUIRE(nodes * (long long)C < (1ll << 31), STC_ELIMIT, "%s: nodes*C = %lld exceeds 2^31", who, nodes * (long long)C);
     return STC_OK;
+}
+
+// STC_DISABLE_MFMA=1 forces the generic kernels (A/B runs, tests of both paths)
+bool mfma_enabled() {
+    const char* e = std::getenv("STC_DISABLE_MFMA");
+    return !(e && e[0] == '1');
 }
 
 int bwd_grid(const NodeDims& d, long long nodes) {
@@ -333,8 +343,8 @@ int bwd_grid(const NodeDims& d, long long nodes) {
 
 extern "C" int stc_bdg_node_fwd_f32(const float* const* Z, int32_t Ks, const float* Tc, int32_t Kc,
                                     const float* W, const float* bias, float* Y,
-                                    int64_t nodes, int32_t C, int32_t L, int32_t Ho, void* stream) {
-    if (int rc = check_dims("stc_bdg_node_fwd_f32", Ks, Kc, C, L, Ho, nodes)) return rc;
+                                    int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t Ho, void* stream) {
+    if (int rc = check_dims("stc_bdg_node_fwd_f32", Ks, Kc, C, L, Lw, Ho, nodes)) return rc;
     if (nodes == 0) return STC_OK;
     STC_REQUIRE(Z && W && Y && (Kc == 1 || Tc), STC_EINVAL, "stc_bdg_node_fwd_f32: null Z/W/Y/Tc");
     ZPtrs zp{};
@@ -342,7 +352,11 @@ extern "C" int stc_bdg_node_fwd_f32(const float* const* Z, int32_t Ks, const flo
         STC_REQUIRE(Z[n], STC_EINVAL, "stc_bdg_node_fwd_f32: Z[%d] is null", n);
         zp.p[n] = Z[n];
     }
-    const NodeDims d = make_dims(Ks, Kc, C, L, Ho);
+    if (mfma_enabled()) {
+        const int rc = stc_node_fwd_mfma(Z, Ks, Tc, Kc, W, bias, Y, nodes, C, L, Lw, Ho, static_cast<hipStream_t>(stream));
+        if (rc != STC_NOT_HANDLED) return rc;
+    }
+    const NodeDims d = make_dims(Ks, Kc, C, L, Lw, Ho);
     const FwdCarve cv = fwd_carve(d);
     const size_t lds = (size_t)cv.total * sizeof(float);
     STC_REQUIRE(lds <= stc::kMaxLdsBytes, STC_ELIMIT,
@@ -367,11 +381,11 @@ extern "C" int stc_bdg_node_bwd_f32(const float* const* Z, int32_t Ks, const flo
                                     const float* W, const float* dY,
                                     float* const* dZ, float* dW, float* db, float* dTc,
                                     void* workspace, size_t workspace_bytes,
-                                    int64_t nodes, int32_t C, int32_t L, int32_t Ho, void* stream) {
-    if (int rc = check_dims("stc_bdg_node_bwd_f32", Ks, Kc, C, L, Ho, nodes)) return rc;
+                                    int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t Ho, void* stream) {
+    if (int rc = check_dims("stc_bdg_node_bwd_f32", Ks, Kc, C, L, Lw, Ho, nodes)) return rc;
     STC_REQUIRE(Z && W && dZ && dW && (Kc == 1 || Tc), STC_EINVAL, "stc_bdg_node_bwd_f32: null Z/W/dZ/dW/Tc");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int nW = Ks * Kc * L * Ho, nT = Kc * C * C;
+    const int nW = Ks * Kc * Lw * Ho, nT = Kc * C * C;
     if (nodes == 0) {   // gradients of an empty batch are zero
         if (int rc = stc::hip_status(hipMemsetAsync(dW, 0, (size_t)nW * sizeof(float), s), "memset dW")) return rc;
         if (db) if (int rc = stc::hip_status(hipMemsetAsync(db, 0, (size_t)Ho * sizeof(float), s), "memset db")) return rc;
@@ -389,7 +403,20 @@ extern "C" int stc_bdg_node_bwd_f32(const float* const* Z, int32_t Ks, const flo
     STC_REQUIRE(workspace && stc::aligned16(workspace), STC_EALIGN, "stc_bdg_node_bwd_f32: workspace null or not 16-byte aligned");
     STC_REQUIRE(workspace_bytes >= stc_bdg_node_bwd_workspace_bytes(Ks, Kc, C, L, Ho, dTc != nullptr), STC_EINVAL,
                 "stc_bdg_node_bwd_f32: workspace of %zu B is too small", workspace_bytes);
-    const NodeDims d = make_dims(Ks, Kc, C, L, Ho);
+    if (mfma_enabled() && dTc == nullptr) {
+        int n_parts = 0;
+        float* partial = static_cast<float*>(workspace);
+        const int rc = stc_node_bwd_mfma(Z, Ks, Tc, Kc, W, dY, dZ, partial, &n_parts, db != nullptr, nodes, C, L, Lw, Ho, s);
+        if (rc == STC_OK) {
+            const int stride = nW + Ho;
+            hipLaunchKernelGGL(bdg_node_reduce_kernel, dim3((stride + NODE_THREADS - 1) / NODE_THREADS), dim3(NODE_THREADS), 0, s,
+                               partial, n_parts, stride, nW, Ho, 0, dW, db, static_cast<float*>(nullptr));
+            STC_LAUNCH_CHECK("stc_bdg_node_reduce launch");
+            return STC_OK;
+        }
+        if (rc != STC_NOT_HANDLED) return rc;
+    }
+    const NodeDims d = make_dims(Ks, Kc, C, L, Lw, Ho);
     const bool want_dT = dTc != nullptr && Kc > 1;
     const BwdCarve cv = bwd_carve(d, want_dT);
     const size_t lds = (size_t)cv.total * sizeof(float);

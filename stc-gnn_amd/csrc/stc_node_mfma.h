@@ -1,0 +1,18 @@
+// Internal: MFMA fast path of the node kernels (stc_node_mfma.hip), tried first by the C entry
+// points in stc_node.hip.  Returns STC_OK when it launched, STC_NOT_HANDLED when the shape is
+// outside the fast path (the generic VALU kernels then run), or an error code.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+constexpr int STC_NOT_HANDLED = 1 << 20;
+
+int stc_node_fwd_mfma(const float* const* Z, int Ks, const float* Tc, int Kc, const float* W, const float* bias,
+                      float* Y, long long nodes, int C, int L, int Lw, int Ho, hipStream_t stream);
+
+// partial: workspace of >= stc_node_bwd_mfma_partials() * (Ks*Kc*L*Ho + Ho) floats; on success
+// *n_partials tells the caller how many per-workgroup partial rows to reduce.
+int stc_node_bwd_mfma_max_partials();
+int stc_node_bwd_mfma(const float* const* Z, int Ks, const float* Tc, int Kc, const float* W, const float* dY,
+                      float* const* dZ, float* partial, int* n_partials, int want_db,
+                      long long nodes, int C, int L, int Lw, int Ho, hipStream_t stream);

@@ -1,0 +1,423 @@
+// MFMA fast path of the BDG_Dif node kernel (reference STC_GNN.py:38-45 and its autograd) for
+// gfx950: exact-fp32 matrix cores (v_mfma_f32_16x16x4_f32: bit-for-bit an fmaf chain, 64 FLOP/clk/SIMD).
+//
+// Shapes: C = 16*NRB categories, Ho = 16*HB outputs, L = 4*LQ features per slab, Ks = Kc = K.
+// One WAVE owns one node row (C x L per Chebyshev slab) at a time; waves stream independently
+// through the nodes -- no barrier in the main loop.  Everything that is the same for every node
+// (W, T_c) is laid out once per workgroup in LDS in MFMA *fragment order* (64 consecutive floats per
+// k-step, so each operand fetch is one conflict-free ds_read_b32); everything per-node stays in
+// registers:
+//
+//   forward   U = Z.W      A = Z rows straight from HBM (lane = category row, 16-byte loads),
+//                          B = W fragments (LDS), accumulators = U tiles [NRB][K*HB]
+//             Y = U_0 + sum_c T_c^T U_c     the U_c accumulators ARE the B operand (their register
+//                          index is the contraction index c'), A = T_c fragments (LDS): no LDS trip
+//   backward  Q_c = T_c dY in both orientations (operands swapped), dZ^T = W Q^T, dW += Z^T Q,
+//             with the accumulators of one product again feeding the next as B operands;
+//             dW/db live in registers across all nodes of a wave and are combined per workgroup
+//             in a fixed order (bitwise reproducible), then summed by bdg_node_reduce_kernel.
+//
+// A k-step of the 16x16x4 MFMA takes lane quarter q = lane>>4 as its k index.  Since a sum over k
+// does not care about order, lane (row, q) simply owns columns {16m+4q .. 16m+4q+3} of its row
+// (one float4), used at steps 4m..4m+3: kcol(s,q) below.  Both operands are built with the same map.
+#include "stc_common.h"
+#include "stc_node_mfma.h"
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int MF_THREADS = 256;
+constexpr int MF_WAVES = MF_THREADS / 64;
+constexpr int MF_BWD_MAX_GRID = 512;
+
+struct ZPtrs { const float* p[STC_MAX_K]; };
+struct DZPtrs { float* p[STC_MAX_K]; };
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// slab column that lane quarter q contributes at k-step s (LQ = L/4 steps per slab)
+template <int LQ>
+__host__ __device__ constexpr int kcol(int s, int q) {
+    constexpr int N16 = LQ / 4;
+    return s < 4 * N16 ? 16 * (s / 4) + 4 * q + (s % 4) : 16 * N16 + 4 * (s - 4 * N16) + q;
+}
+
+template <int N>
+struct AtLeast1 { static constexpr int v = N > 0 ? N : 1; };
+
+// --------------------------------------------------------------------------------------- forward
+template <int NRB, int HB, int K, int LQ>
+__global__ __launch_bounds__(MF_THREADS) void node_fwd_mfma_kernel(
+    ZPtrs Z, const float* __restrict__ Tc, const float* __restrict__ W, const float* __restrict__ bias,
+    float* __restrict__ Y, int nodes, int Lw) {
+    constexpr int C = 16 * NRB, Ho = 16 * HB, L = 4 * LQ, NCB = K * HB;
+    constexpr int N16 = LQ / 4, NREM = LQ - 4 * N16;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Wf = smem;                              // [K][LQ][NCB][64]   B fragments of the projection
+    float* Tf = smem + K * LQ * NCB * 64;          // [K-1][NRB rb][NRB kb][4][64]   A fragments of the mix
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, q = lane >> 4;
+
+    for (int idx = tid; idx < K * LQ * NCB * 64; idx += MF_THREADS) {
+        const int ll = idx & 63;
+        int t = idx >> 6;
+        const int cb = t % NCB; t /= NCB;
+        const int s = t % LQ, n = t / LQ;
+        const int kc = kcol<LQ>(s, ll >> 4);
+        const int c = cb / HB, o = (cb % HB) * 16 + (ll & 15);
+        Wf[idx] = kc < Lw ? W[((size_t)(n * K + c) * Lw + kc) * Ho + o] : 0.f;   // pad columns [Lw, L) contribute nothing
+    }
+    for (int idx = tid; idx < (K - 1) * NRB * NRB * 4 * 64; idx += MF_THREADS) {
+        const int ll = idx & 63;
+        int t = idx >> 6;
+        const int st = t & 3; t >>= 2;
+        const int kb = t % NRB; t /= NRB;
+        const int rb = t % NRB, c1 = t / NRB;
+        // A[i = d][k = c'] = T_c[c'][d]  with c' = 16kb + 4q + st, d = 16rb + i
+        Tf[idx] = Tc[(size_t)(c1 + 1) * C * C + (16 * kb + 4 * (ll >> 4) + st) * C + 16 * rb + (ll & 15)];
+    }
+    __syncthreads();
+
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nw = gridDim.x * MF_WAVES;
+    float bv[HB];
+#pragma unroll
+    for (int hb = 0; hb < HB; ++hb) bv[hb] = bias ? bias[16 * hb + j] : 0.f;
+
+    for (int node = blockIdx.x * MF_WAVES + wave; node < nodes; node += nw) {
+        // this lane's row of every slab / row block: columns 16m + 4q .. +3 (and the 4-column remainder)
+        float4 a4[K][NRB][AtLeast1<N16>::v];
+        float ar[K][NRB][AtLeast1<NREM>::v];
+#pragma unroll
+        for (int n = 0; n < K; ++n)
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+                const float* row = Z.p[n] + ((size_t)node * C + 16 * rb + j) * L;
+#pragma unroll
+                for (int m = 0; m < N16; ++m) a4[n][rb][m] = *reinterpret_cast<const float4*>(row + 16 * m + 4 * q);
+#pragma unroll
+                for (int u = 0; u < NREM; ++u) ar[n][rb][u] = row[16 * N16 + 4 * u + q];
+            }
+
+        f32x4 acc[NRB][NCB];
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        // project: U[rb][cb] += A(Z) * B(W)
+#pragma unroll
+        for (int n = 0; n < K; ++n)
+#pragma unroll
+            for (int s = 0; s < LQ; ++s) {
+                float a[NRB];
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) {
+                    if (s < 4 * N16) {
+                        const float4 v = a4[n][rb][s / 4 < N16 ? s / 4 : 0];
+                        a[rb] = (s % 4 == 0) ? v.x : (s % 4 == 1) ? v.y : (s % 4 == 2) ? v.z : v.w;
+                    } else {
+                        a[rb] = ar[n][rb][s - 4 * N16 < NREM ? s - 4 * N16 : 0];
+                    }
+                }
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) {
+                    const float b = Wf[((n * LQ + s) * NCB + cb) * 64 + lane];
+#pragma unroll
+                    for (int rb = 0; rb < NRB; ++rb) acc[rb][cb] = mfma16(a[rb], b, acc[rb][cb]);
+                }
+            }
+
+        // mix: Y[rb][hb] = U_0[rb][hb] + sum_{c>=1} sum_kb T_c^T[rb][kb] U_c[kb][hb]   (U_c read from its accumulators)
+        f32x4 y[NRB][HB];
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb) y[rb][hb] = acc[rb][hb];
+#pragma unroll
+        for (int c1 = 0; c1 < K - 1; ++c1)
+#pragma unroll
+            for (int kb = 0; kb < NRB; ++kb)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int rb = 0; rb < NRB; ++rb) {
+                        const float a = Tf[((((c1 * NRB + rb) * NRB + kb) * 4 + t)) * 64 + lane];
+#pragma unroll
+                        for (int hb = 0; hb < HB; ++hb)
+                            y[rb][hb] = mfma16(a, acc[kb][(c1 + 1) * HB + hb][t], y[rb][hb]);
+                    }
+
+        // accumulator layout: lane (j, q), register r  <->  row 4q + r, column j of the 16 x 16 tile
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    Y[((size_t)node * C + 16 * rb + 4 * q + r) * Ho + 16 * hb + j] = y[rb][hb][r] + bv[hb];
+    }
+}
+
+// --------------------------------------------------------------------------------------- backward
+template <int NRB, int HB, int K, int LQ>
+__global__ __launch_bounds__(MF_THREADS) void node_bwd_mfma_kernel(
+    ZPtrs Z, const float* __restrict__ Tc, const float* __restrict__ W, const float* __restrict__ dY,
+    DZPtrs dZ, float* __restrict__ partial, int nodes, int want_db, int Lw) {
+    constexpr int C = 16 * NRB, Ho = 16 * HB, L = 4 * LQ, LB = (L + 15) / 16;
+    const int nW = K * K * Lw * Ho;
+    constexpr int nTf = (K - 1) * NRB * NRB * 4 * 64;
+    constexpr int nWf = K * LB * K * HB * 4 * 64;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* TfA = smem;                 // [K-1][NRB rb][NRB kb][4][64]      T_c[16rb+i][16kb+4q+t]
+    float* WfD = smem + nTf;           // [K n][LB][K c][HB][4][64]         W[(n,c,16lb+i)][16hb+4q+t]
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, q = lane >> 4;
+
+    for (int idx = tid; idx < nTf; idx += MF_THREADS) {
+        const int ll = idx & 63;
+        int t = idx >> 6;
+        const int st = t & 3; t >>= 2;
+        const int kb = t % NRB; t /= NRB;
+        const int rb = t % NRB, c1 = t / NRB;
+        TfA[idx] = Tc[(size_t)(c1 + 1) * C * C + (16 * rb + (ll & 15)) * C + 16 * kb + 4 * (ll >> 4) + st];
+    }
+    for (int idx = tid; idx < nWf; idx += MF_THREADS) {
+        const int ll = idx & 63;
+        int t = idx >> 6;
+        const int st = t & 3; t >>= 2;
+        const int hb = t % HB; t /= HB;
+        const int c = t % K; t /= K;
+        const int lb = t % LB, n = t / LB;
+        const int l = 16 * lb + (ll & 15);
+        WfD[idx] = l < Lw ? W[((size_t)(n * K + c) * Lw + l) * Ho + 16 * hb + 4 * (ll >> 4) + st] : 0.f;
+    }
+    __syncthreads();
+
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nw = gridDim.x * MF_WAVES;
+
+    f32x4 dWt[K][LB][K][HB];          // dW tiles: rows l = 16lb + 4q + r, columns o = 16hb + j
+    float dbp[HB];
+#pragma unroll
+    for (int n = 0; n < K; ++n)
+#pragma unroll
+        for (int lb = 0; lb < LB; ++lb)
+#pragma unroll
+            for (int c = 0; c < K; ++c)
+#pragma unroll
+                for (int hb = 0; hb < HB; ++hb) dWt[n][lb][c][hb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int hb = 0; hb < HB; ++hb) dbp[hb] = 0.f;
+
+    for (int node = blockIdx.x * MF_WAVES + wave; node < nodes; node += nw) {
+        const size_t r0 = (size_t)node * C;
+        // Qd[c][rb][hb]: Q_c tile rows c' (register), columns o (lane)    -- B operand of dW
+        // Qv[c][rb][hb]: Q_c^T tile rows o (register), columns c' (lane)  -- B operand of dZ
+        f32x4 Qd[K][NRB][HB], Qv[K][NRB][HB];
+#pragma unroll
+        for (int kb = 0; kb < NRB; ++kb)
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) Qd[0][kb][hb][t] = dY[(r0 + 16 * kb + 4 * q + t) * Ho + 16 * hb + j];
+                const float4 v = *reinterpret_cast<const float4*>(dY + (r0 + 16 * kb + j) * Ho + 16 * hb + 4 * q);
+                Qv[0][kb][hb] = f32x4{v.x, v.y, v.z, v.w};
+                dbp[hb] += (Qd[0][kb][hb][0] + Qd[0][kb][hb][1]) + (Qd[0][kb][hb][2] + Qd[0][kb][hb][3]);
+            }
+#pragma unroll
+        for (int c1 = 0; c1 < K - 1; ++c1) {
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                for (int hb = 0; hb < HB; ++hb) {
+                    Qd[c1 + 1][rb][hb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    Qv[c1 + 1][rb][hb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+            for (int kb = 0; kb < NRB; ++kb)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int rb = 0; rb < NRB; ++rb) {
+                        const float tf = TfA[(((c1 * NRB + rb) * NRB + kb) * 4 + t) * 64 + lane];
+#pragma unroll
+                        for (int hb = 0; hb < HB; ++hb) {
+                            const float g = Qd[0][kb][hb][t];
+                            Qd[c1 + 1][rb][hb] = mfma16(tf, g, Qd[c1 + 1][rb][hb]);     // T_c . dY
+                            Qv[c1 + 1][rb][hb] = mfma16(g, tf, Qv[c1 + 1][rb][hb]);     // dY^T . T_c^T
+                        }
+                    }
+        }
+
+        // dZ_n^T tile (rows l, columns c') = sum_{c,o} W[(n,c,l)][o] * Q_c[c'][o]
+#pragma unroll
+        for (int n = 0; n < K; ++n)
+#pragma unroll
+            for (int lb = 0; lb < LB; ++lb) {
+                f32x4 z[NRB];
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) z[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < K; ++c)
+#pragma unroll
+                    for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const float wf = WfD[((((n * LB + lb) * K + c) * HB + hb) * 4 + t) * 64 + lane];
+#pragma unroll
+                            for (int rb = 0; rb < NRB; ++rb) z[rb] = mfma16(wf, Qv[c][rb][hb][t], z[rb]);
+                        }
+                if (16 * lb + 4 * q < L) {
+#pragma unroll
+                    for (int rb = 0; rb < NRB; ++rb)
+                        *reinterpret_cast<float4*>(dZ.p[n] + (r0 + 16 * rb + j) * L + 16 * lb + 4 * q) =
+                            make_float4(z[rb][0], z[rb][1], z[rb][2], z[rb][3]);
+                }
+            }
+
+        // dW_{n,c} tile (rows l, columns o) += sum_{c'} Z_n[c'][l] * Q_c[c'][o]
+#pragma unroll
+        for (int n = 0; n < K; ++n)
+#pragma unroll
+            for (int lb = 0; lb < LB; ++lb) {
+                const bool ok = 16 * lb + j < L;
+                const float* col = Z.p[n] + r0 * L + 16 * lb + (ok ? j : 0);
+#pragma unroll
+                for (int kb = 0; kb < NRB; ++kb)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const float zv = col[(size_t)(16 * kb + 4 * q + t) * L];
+                        const float a = ok ? zv : 0.f;
+#pragma unroll
+                        for (int c = 0; c < K; ++c)
+#pragma unroll
+                            for (int hb = 0; hb < HB; ++hb)
+                                dWt[n][lb][c][hb] = mfma16(a, Qd[c][kb][hb][t], dWt[n][lb][c][hb]);
+                    }
+            }
+    }
+
+    // combine the four waves of the workgroup in a fixed order, then one partial row per workgroup
+    __syncthreads();                                   // every wave is done with the fragment tables
+    float* slab = smem + (size_t)wave * (nW + Ho);     // [dW in W layout | db]
+#pragma unroll
+    for (int n = 0; n < K; ++n)
+#pragma unroll
+        for (int lb = 0; lb < LB; ++lb)
+#pragma unroll
+            for (int c = 0; c < K; ++c)
+#pragma unroll
+                for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int l = 16 * lb + 4 * q + r;
+                        if (l < Lw) slab[((n * K + c) * Lw + l) * Ho + 16 * hb + j] = dWt[n][lb][c][hb][r];
+                    }
+#pragma unroll
+    for (int hb = 0; hb < HB; ++hb) {
+        float v = dbp[hb];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (q == 0) slab[nW + 16 * hb + j] = v;
+    }
+    __syncthreads();
+    float* out = partial + (size_t)blockIdx.x * (nW + Ho);
+    for (int e = tid; e < nW + Ho; e += MF_THREADS) {
+        float s = smem[e];
+#pragma unroll
+        for (int w = 1; w < MF_WAVES; ++w) s += smem[(size_t)w * (nW + Ho) + e];
+        out[e] = (e >= nW && !want_db) ? 0.f : s;
+    }
+}
+
+template <int NRB, int HB, int K, int LQ>
+int launch_fwd(const float* const* Z, const float* Tc, const float* W, const float* bias, float* Y,
+               long long nodes, int Lw, hipStream_t stream) {
+    constexpr int NCB = K * HB;
+    const size_t lds = (size_t)(K * LQ * NCB * 64 + (K - 1) * NRB * NRB * 4 * 64) * sizeof(float);
+    if (lds > stc::kMaxLdsBytes) return STC_NOT_HANDLED;
+    auto kern = node_fwd_mfma_kernel<NRB, HB, K, LQ>;
+    if (int rc = stc::hip_status(stc::allow_lds(kern, lds), "hipFuncSetAttribute(node fwd mfma)")) return rc;
+    ZPtrs zp{};
+    for (int n = 0; n < K; ++n) zp.p[n] = Z[n];
+    const long long want = (nodes + MF_WAVES - 1) / MF_WAVES;
+    const int grid = (int)(want < 4 * stc::kNumCu ? want : 4 * stc::kNumCu);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(MF_THREADS), lds, stream, zp, Tc, W, bias, Y, (int)nodes, Lw);
+    STC_LAUNCH_CHECK("node_fwd_mfma launch");
+    return STC_OK;
+}
+
+template <int NRB, int HB, int K, int LQ>
+int launch_bwd(const float* const* Z, const float* Tc, const float* W, const float* dY, float* const* dZ,
+               float* partial, int* n_partials, int want_db, long long nodes, int Lw, hipStream_t stream) {
+    constexpr int L = 4 * LQ, Ho = 16 * HB, LB = (L + 15) / 16, nW = K * K * L * Ho;
+    const size_t frag = (size_t)((K - 1) * NRB * NRB * 4 * 64 + K * LB * K * HB * 4 * 64);
+    const size_t slabs = (size_t)MF_WAVES * (nW + Ho);
+    const size_t lds = (frag > slabs ? frag : slabs) * sizeof(float);
+    if (lds > stc::kMaxLdsBytes) return STC_NOT_HANDLED;
+    auto kern = node_bwd_mfma_kernel<NRB, HB, K, LQ>;
+    if (int rc = stc::hip_status(stc::allow_lds(kern, lds), "hipFuncSetAttribute(node bwd mfma)")) return rc;
+    ZPtrs zp{};
+    DZPtrs dzp{};
+    for (int n = 0; n < K; ++n) { zp.p[n] = Z[n]; dzp.p[n] = dZ[n]; }
+    const long long want = (nodes + MF_WAVES - 1) / MF_WAVES;
+    const int grid = (int)(want < MF_BWD_MAX_GRID ? want : MF_BWD_MAX_GRID);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(MF_THREADS), lds, stream, zp, Tc, W, dY, dzp, partial, (int)nodes, want_db, Lw);
+    STC_LAUNCH_CHECK("node_bwd_mfma launch");
+    *n_partials = grid;
+    return STC_OK;
+}
+
+bool fast_path_shape(int Ks, int Kc, int C, int L, int Ho, long long nodes) {
+    return Ks == Kc && Ks >= 1 && Ks <= 3 && (C == 16 || C == 32 || C == 64) && (Ho == 16 || Ho == 32) &&
+           (L == 20 || L == 32) && nodes > 0 && nodes < (1ll << 31) / C;
+}
+
+bool all_aligned16(const float* const* p, int n) {
+    for (int i = 0; i < n; ++i)
+        if (!stc::aligned16(p[i])) return false;
+    return true;
+}
+
+}  // namespace
+
+// C in {16,32,64} x Ho in {16,32} x K in {1,2,3} x L in {20,32}
+#define STC_MF_CASE(NRB_, HB_, CALL)                                                                    \
+    if (C == 16 * NRB_ && Ho == 16 * HB_) {                                                             \
+        if (Ks == 1 && L == 20) return CALL(NRB_, HB_, 1, 5);                                           \
+        if (Ks == 1 && L == 32) return CALL(NRB_, HB_, 1, 8);                                           \
+        if (Ks == 2 && L == 20) return CALL(NRB_, HB_, 2, 5);                                           \
+        if (Ks == 2 && L == 32) return CALL(NRB_, HB_, 2, 8);                                           \
+        if (Ks == 3 && L == 20) return CALL(NRB_, HB_, 3, 5);                                           \
+        if (Ks == 3 && L == 32) return CALL(NRB_, HB_, 3, 8);                                           \
+    }
+#define STC_MF_DISPATCH(CALL)                                                                           \
+    STC_MF_CASE(1, 1, CALL) STC_MF_CASE(1, 2, CALL) STC_MF_CASE(2, 1, CALL)                             \
+    STC_MF_CASE(2, 2, CALL) STC_MF_CASE(4, 1, CALL) STC_MF_CASE(4, 2, CALL)
+
+int stc_node_fwd_mfma(const float* const* Z, int Ks, const float* Tc, int Kc, const float* W, const float* bias,
+                      float* Y, long long nodes, int C, int L, int Lw, int Ho, hipStream_t stream) {
+    if (!fast_path_shape(Ks, Kc, C, L, Ho, nodes)) return STC_NOT_HANDLED;
+    if (!all_aligned16(Z, Ks) || !stc::aligned16(Y)) return STC_NOT_HANDLED;
+#define FWD_CALL(a, b, c, d) launch_fwd<a, b, c, d>(Z, Tc, W, bias, Y, nodes, Lw, stream)
+    STC_MF_DISPATCH(FWD_CALL)
+#undef FWD_CALL
+    return STC_NOT_HANDLED;
+}
+
+int stc_node_bwd_mfma_max_partials() { return MF_BWD_MAX_GRID; }
+
+int stc_node_bwd_mfma(const float* const* Z, int Ks, const float* Tc, int Kc, const float* W, const float* dY,
+                      float* const* dZ, float* partial, int* n_partials, int want_db,
+                      long long nodes, int C, int L, int Lw, int Ho, hipStream_t stream) {
+    if (!fast_path_shape(Ks, Kc, C, L, Ho, nodes)) return STC_NOT_HANDLED;
+    if (!all_aligned16(Z, Ks) || !stc::aligned16(dY)) return STC_NOT_HANDLED;
+    for (int n = 0; n < Ks; ++n)
+        if (!stc::aligned16(dZ[n])) return STC_NOT_HANDLED;
+#define BWD_CALL(a, b, c, d) launch_bwd<a, b, c, d>(Z, Tc, W, dY, dZ, partial, n_partials, want_db, nodes, Lw, stream)
+    STC_MF_DISPATCH(BWD_CALL)
+#undef BWD_CALL
+    return STC_NOT_HANDLED;
+}

@@ -19,7 +19,7 @@ import torch
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG_ROOT, 'libstc_hip.so')
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_K = 4
 
 #: every symbol ``include/stc_hip.h`` declares (the CPU test-suite checks the .so exports them all)
@@ -53,16 +53,16 @@ def _declare(lib):
         'stc_csr_sddmm_f32': [_p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _i32, _p],
         'stc_cheby_dense_fwd_f32': [_p, _i32, _i32, _p, _p],
         'stc_cheby_dense_bwd_f32': [_p, _p, _p, _i32, _i32, _p, _p],
-        'stc_bdg_node_fwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _i64, _i32, _i32, _i32, _p],
+        'stc_bdg_node_fwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
         'stc_bdg_node_bwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, C.POINTER(_p), _p, _p, _p,
-                                 _p, C.c_size_t, _i64, _i32, _i32, _i32, _p],
-        'stc_gru_gates_fwd_f32': [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p],
-        'stc_gru_gates_bwd_f32': [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p],
+                                 _p, C.c_size_t, _i64, _i32, _i32, _i32, _i32, _p],
+        'stc_gru_gates_fwd_f32': [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p],
+        'stc_gru_gates_bwd_f32': [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p],
         'stc_gru_blend_fwd_f32': [_p, _p, _p, _p, _p, _i64, _p],
         'stc_gru_blend_bwd_f32': [_p, _p, _p, _p, _p, _p, _p, _i64, _p],
         'stc_axpy_f32': [_f32, _p, _p, _i64, _p],
-        'stc_concat2_f32': [_p, _p, _p, _i64, _i32, _i32, _p],
-        'stc_split2_f32': [_p, _p, _p, _i64, _i32, _i32, _p],
+        'stc_concat2_f32': [_p, _p, _p, _i64, _i32, _i32, _i32, _p],
+        'stc_split2_f32': [_p, _p, _p, _i64, _i32, _i32, _i32, _p],
     }
     for name, argtypes in sig.items():
         fn = getattr(lib, name)
@@ -239,19 +239,22 @@ class HipKernels:
             raise StcError(f'Chebyshev orders Ks={Ks}, Kc={Kc} outside [1,{MAX_K}]')
         R, Cc, L = Zs[0].shape
         Ho = W.shape[1]
+        Lw = W.shape[0] // (Ks * Kc)            # feature rows per W block; slab columns [Lw, L) are zero padding
+        if Lw < 1 or Lw > L:
+            raise StcError(f'node.W: {W.shape[0]} rows give Lw={Lw} per block, slabs are {L} wide')
         for i, z in enumerate(Zs):
             self._f32(f'node.Z[{i}]', z, (R, Cc, L))
         self._f32('node.Tc', Tc, (Kc, Cc, Cc))
-        self._f32('node.W', W, (Ks * Kc * L, Ho))
-        return Ks, Kc, R, Cc, L, Ho
+        self._f32('node.W', W, (Ks * Kc * Lw, Ho))
+        return Ks, Kc, R, Cc, L, Lw, Ho
 
     def bdg_node_fwd(self, Zs: Sequence[torch.Tensor], Tc, W, bias, Y):
-        Ks, Kc, R, Cc, L, Ho = self._node_shapes(Zs, Tc, W)
+        Ks, Kc, R, Cc, L, Lw, Ho = self._node_shapes(Zs, Tc, W)
         if bias is not None:
             self._f32('node.bias', bias, (Ho,))
         self._f32('node.Y', Y, (R, Cc, Ho))
         self._same_device(*Zs, Tc, W, bias, Y)
-        self._launch('stc_bdg_node_fwd_f32', Y, self._ptr_array(Zs), Ks, _ptr(Tc), Kc, _ptr(W), _ptr(bias), _ptr(Y), R, Cc, L, Ho)
+        self._launch('stc_bdg_node_fwd_f32', Y, self._ptr_array(Zs), Ks, _ptr(Tc), Kc, _ptr(W), _ptr(bias), _ptr(Y), R, Cc, L, Lw, Ho)
 
     def _get_workspace(self, device, nbytes):
         ws = self._workspace.get(device)
@@ -262,13 +265,13 @@ class HipKernels:
         return ws
 
     def bdg_node_bwd(self, Zs, Tc, W, dY, dZs, dW, db, dTc):
-        Ks, Kc, R, Cc, L, Ho = self._node_shapes(Zs, Tc, W)
+        Ks, Kc, R, Cc, L, Lw, Ho = self._node_shapes(Zs, Tc, W)
         self._f32('node.dY', dY, (R, Cc, Ho))
         if len(dZs) != Ks:
             raise StcError('node.dZ: need one gradient slab per Chebyshev order')
         for i, z in enumerate(dZs):
             self._f32(f'node.dZ[{i}]', z, (R, Cc, L))
-        self._f32('node.dW', dW, (Ks * Kc * L, Ho))
+        self._f32('node.dW', dW, (Ks * Kc * Lw, Ho))
         if db is not None:
             self._f32('node.db', db, (Ho,))
         if dTc is not None:
@@ -276,28 +279,34 @@ class HipKernels:
         self._same_device(*Zs, Tc, W, dY, *dZs, dW, db, dTc)
         nbytes = self.lib.stc_bdg_node_bwd_workspace_bytes(Ks, Kc, Cc, L, Ho, int(dTc is not None))
         ws = self._get_workspace(dY.device, nbytes)
-        self._launch('stc_bdg_node_bwd_f32', dY, self._ptr_array(Zs), Ks, _ptr(Tc), Kc, _ptr(W), _ptr(dY), self._ptr_array(dZs), _ptr(dW), _ptr(db), _ptr(dTc), _ptr(ws), ws.numel(), R, Cc, L, Ho)
+        self._launch('stc_bdg_node_bwd_f32', dY, self._ptr_array(Zs), Ks, _ptr(Tc), Kc, _ptr(W), _ptr(dY), self._ptr_array(dZs), _ptr(dW), _ptr(db), _ptr(dTc), _ptr(ws), ws.numel(), R, Cc, L, Lw, Ho)
 
     # ---- GRU gate math -------------------------------------------------------------------
     def gru_gates_fwd(self, G, Xt, H, U, Rg, CandIn):
         rows, h = H.shape[:-1].numel(), H.shape[-1]
         cin = Xt.shape[-1]
+        pad = CandIn.shape[-1] - cin - h
+        if pad < 0:
+            raise StcError(f'gates.CandIn: width {CandIn.shape[-1]} < cin + h = {cin + h}')
         for name, t, w in (('G', G, 2 * h), ('Xt', Xt, cin), ('H', H, h), ('U', U, h), ('Rg', Rg, h),
-                           ('CandIn', CandIn, cin + h)):
+                           ('CandIn', CandIn, cin + h + pad)):
             self._f32('gates.' + name, t)
             if t.shape[-1] != w or t.numel() != rows * w:
                 raise StcError(f'gates.{name}: shape {tuple(t.shape)} does not match rows={rows}, width={w}')
-        self._launch('stc_gru_gates_fwd_f32', H, _ptr(G), _ptr(Xt), _ptr(H), _ptr(U), _ptr(Rg), _ptr(CandIn), rows, cin, h)
+        self._launch('stc_gru_gates_fwd_f32', H, _ptr(G), _ptr(Xt), _ptr(H), _ptr(U), _ptr(Rg), _ptr(CandIn), rows, cin, h, pad)
 
     def gru_gates_bwd(self, dCandIn, dU, H, U, Rg, dG, dXt, dH):
         rows, h = H.shape[:-1].numel(), H.shape[-1]
         cin = dXt.shape[-1]
-        for name, t, w in (('dCandIn', dCandIn, cin + h), ('dU', dU, h), ('H', H, h), ('U', U, h), ('Rg', Rg, h),
+        pad = dCandIn.shape[-1] - cin - h
+        if pad < 0:
+            raise StcError(f'gates_bwd.dCandIn: width {dCandIn.shape[-1]} < cin + h = {cin + h}')
+        for name, t, w in (('dCandIn', dCandIn, cin + h + pad), ('dU', dU, h), ('H', H, h), ('U', U, h), ('Rg', Rg, h),
                            ('dG', dG, 2 * h), ('dXt', dXt, cin), ('dH', dH, h)):
             self._f32('gates_bwd.' + name, t)
             if t.shape[-1] != w or t.numel() != rows * w:
                 raise StcError(f'gates_bwd.{name}: shape {tuple(t.shape)} does not match rows={rows}, width={w}')
-        self._launch('stc_gru_gates_bwd_f32', H, _ptr(dCandIn), _ptr(dU), _ptr(H), _ptr(U), _ptr(Rg), _ptr(dG), _ptr(dXt), _ptr(dH), rows, cin, h)
+        self._launch('stc_gru_gates_bwd_f32', H, _ptr(dCandIn), _ptr(dU), _ptr(H), _ptr(U), _ptr(Rg), _ptr(dG), _ptr(dXt), _ptr(dH), rows, cin, h, pad)
 
     def _same_numel(self, what, *ts):
         n = ts[0].numel()
@@ -323,16 +332,19 @@ class HipKernels:
     def _cat_shapes(self, what, A, Bm, whole):
         a, b = A.shape[-1], Bm.shape[-1]
         rows = whole.shape[:-1].numel()
-        for name, t, w in (('A', A, a), ('B', Bm, b), ('whole', whole, a + b)):
+        pad = whole.shape[-1] - a - b
+        if pad < 0:
+            raise StcError(f'{what}: joined width {whole.shape[-1]} < {a} + {b}')
+        for name, t, w in (('A', A, a), ('B', Bm, b), ('whole', whole, a + b + pad)):
             self._f32(f'{what}.{name}', t)
             if t.shape[-1] != w or t.numel() != rows * w:
                 raise StcError(f'{what}.{name}: shape {tuple(t.shape)} does not match rows={rows}, width={w}')
-        return rows, a, b
+        return rows, a, b, pad
 
     def concat2(self, A, Bm, out):
-        rows, a, b = self._cat_shapes('concat2', A, Bm, out)
-        self._launch('stc_concat2_f32', out, _ptr(A), _ptr(Bm), _ptr(out), rows, a, b)
+        rows, a, b, pad = self._cat_shapes('concat2', A, Bm, out)
+        self._launch('stc_concat2_f32', out, _ptr(A), _ptr(Bm), _ptr(out), rows, a, b, pad)
 
     def split2(self, src, A, Bm):
-        rows, a, b = self._cat_shapes('split2', A, Bm, src)
-        self._launch('stc_split2_f32', src, _ptr(src), _ptr(A), _ptr(Bm), rows, a, b)
+        rows, a, b, pad = self._cat_shapes('split2', A, Bm, src)
+        self._launch('stc_split2_f32', src, _ptr(src), _ptr(A), _ptr(Bm), rows, a, b, pad)

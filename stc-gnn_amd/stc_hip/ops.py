@@ -134,8 +134,13 @@ class _BdgDif(Function):
 
 
 def bdg_dif(X: torch.Tensor, op: SpatialOperand, Tc: torch.Tensor, W: torch.Tensor,
-            b: Optional[torch.Tensor], Ks: int) -> torch.Tensor:
-    """Y (B,N,C,Ho) of one bi-dimensional graph diffusion; ``Tc`` from ``cheby_dense``."""
+            b: Optional[torch.Tensor], Ks: int, pad: int = 0) -> torch.Tensor:
+    """Y (B,N,C,Ho) of one bi-dimensional graph diffusion; ``Tc`` from ``cheby_dense``.
+
+    ``pad``: the last ``pad`` columns of X's feature axis are zero padding added by the caller
+    (``concat2(..., pad)`` / ``gru_gates(..., pad)``) to make rows 16-byte aligned; W keeps its
+    reference shape (Ks*Kc*(L-pad), Ho).
+    """
     if X.dim() != 4:
         raise ValueError(f'BDG_Dif input must be (B,N,C,L), got {tuple(X.shape)}')
     B, N, C, L = X.shape
@@ -144,22 +149,23 @@ def bdg_dif(X: torch.Tensor, op: SpatialOperand, Tc: torch.Tensor, W: torch.Tens
         raise ValueError(f'X has {N} nodes, the spatial graph {op.n}')
     if Tc.shape[1] != C:
         raise ValueError(f'X has {C} categories, the category graph {Tc.shape[1]}')
-    if W.shape[0] != Ks * Kc * L:
-        raise ValueError(f'W has {W.shape[0]} rows, expected Ks*Kc*L = {Ks * Kc * L}')
+    if W.shape[0] != Ks * Kc * (L - pad):
+        raise ValueError(f'W has {W.shape[0]} rows, expected Ks*Kc*L = {Ks * Kc * (L - pad)}')
     return _BdgDif.apply(X, W, b, Tc, op.fwd_val, op, Ks)
 
 
 # ----------------------------------------------------------------------------- GRU gate math
 class _GruGates(Function):
     @staticmethod
-    def forward(ctx, G, Xt, H):
+    def forward(ctx, G, Xt, H, pad):
         G, Xt, H = _c(G), _c(Xt), _c(H)
         U = torch.empty_like(H)
         Rg = torch.empty_like(H)
-        CandIn = H.new_empty(H.shape[:-1] + (Xt.shape[-1] + H.shape[-1],))
+        CandIn = H.new_empty(H.shape[:-1] + (Xt.shape[-1] + H.shape[-1] + pad,))
         kernels().gru_gates_fwd(G, Xt, H, U, Rg, CandIn)
         ctx.save_for_backward(H, U, Rg)
         ctx.cin = Xt.shape[-1]
+        ctx.pad = pad
         ctx.xshape = Xt.shape
         return U, CandIn
 
@@ -168,17 +174,17 @@ class _GruGates(Function):
     def backward(ctx, dU, dCandIn):
         H, U, Rg = ctx.saved_tensors
         dU = torch.zeros_like(U) if dU is None else _c(dU)
-        dCandIn = H.new_zeros(H.shape[:-1] + (ctx.cin + H.shape[-1],)) if dCandIn is None else _c(dCandIn)
+        dCandIn = H.new_zeros(H.shape[:-1] + (ctx.cin + H.shape[-1] + ctx.pad,)) if dCandIn is None else _c(dCandIn)
         dG = H.new_empty(H.shape[:-1] + (2 * H.shape[-1],))
         dXt = H.new_empty(ctx.xshape)
         dH = torch.empty_like(H)
         kernels().gru_gates_bwd(dCandIn, dU, H, U, Rg, dG, dXt, dH)
-        return dG, dXt, dH
+        return dG, dXt, dH, None
 
 
-def gru_gates(G, Xt, H):
-    """(update, cat[Xt, reset*H]) from the gate pre-activations G (.., 2h)."""
-    return _GruGates.apply(G, Xt, H)
+def gru_gates(G, Xt, H, pad: int = 0):
+    """(update, cat[Xt, reset*H, zeros(pad)]) from the gate pre-activations G (.., 2h)."""
+    return _GruGates.apply(G, Xt, H, pad)
 
 
 class _GruBlend(Function):
@@ -207,9 +213,9 @@ def gru_blend(Cpre, U, H):
 
 class _Concat2(Function):
     @staticmethod
-    def forward(ctx, A, Bm):
+    def forward(ctx, A, Bm, pad):
         A, Bm = _c(A), _c(Bm)
-        out = A.new_empty(A.shape[:-1] + (A.shape[-1] + Bm.shape[-1],))
+        out = A.new_empty(A.shape[:-1] + (A.shape[-1] + Bm.shape[-1] + pad,))
         kernels().concat2(A, Bm, out)
         ctx.shapes = (A.shape, Bm.shape)
         return out
@@ -220,11 +226,11 @@ class _Concat2(Function):
         sa, sb = ctx.shapes
         dA, dB = d.new_empty(sa), d.new_empty(sb)
         kernels().split2(_c(d), dA, dB)
-        return dA, dB
+        return dA, dB, None
 
 
-def concat2(A, Bm):
-    """cat([A, B], dim=-1) for tensors that agree on every leading dimension."""
+def concat2(A, Bm, pad: int = 0):
+    """cat([A, B, zeros(pad)], dim=-1) for tensors that agree on every leading dimension."""
     if A.shape[:-1] != Bm.shape[:-1]:
         raise ValueError(f'concat2: leading shapes differ: {tuple(A.shape)} vs {tuple(Bm.shape)}')
-    return _Concat2.apply(A, Bm)
+    return _Concat2.apply(A, Bm, pad)

@@ -38,7 +38,7 @@ def test_argument_validation_needs_no_gpu():
     assert rc == -1 and b'null' in lib.stc_last_error()
     assert lib.stc_csr_spmm_f32(None, None, None, 0, 4, None, None, None, 1, 8, 1.0, 0.0, None) == 0   # empty: no launch
     arr = (ctypes.c_void_p * 1)()
-    rc = lib.stc_bdg_node_fwd_f32(arr, 9, None, 2, None, None, None, 10, 3, 5, 4, None)
+    rc = lib.stc_bdg_node_fwd_f32(arr, 9, None, 2, None, None, None, 10, 3, 5, 5, 4, None)
     assert rc == -3 and b'Chebyshev' in lib.stc_last_error()          # order above STC_MAX_K
     assert lib.stc_bdg_node_bwd_workspace_bytes(2, 2, 32, 32, 32, 1) == 512 * 4 * (2 * 2 * 32 * 32 + 32 + 2 * 32 * 32)
     assert lib.stc_gru_blend_fwd_f32(None, None, None, None, None, 0, None) == 0

@@ -133,6 +133,17 @@ NODE_SHAPES = [
     (17, 32, 17, 16, 3, 2),      # Ks != Kc
     (5, 64, 32, 32, 2, 2),       # config 5 category count
     (9, 7, 6, 3, 4, 4),          # highest supported order
+    # MFMA fast path: C in {16,32,64}, Ho in {16,32}, L in {20,32}, Ks = Kc in {1,2,3}
+    (50, 32, 32, 16, 2, 2),      # candidate conv at the headline width
+    (50, 32, 20, 32, 2, 2),      # encoder layer 0 (in=1 padded to L=20), gates
+    (50, 32, 20, 16, 2, 2),      # encoder layer 0, candidate
+    (21, 16, 32, 32, 2, 2),
+    (21, 16, 20, 16, 3, 3),
+    (13, 64, 20, 16, 2, 2),
+    (13, 32, 32, 32, 3, 3),      # config 4 order
+    (13, 32, 32, 16, 1, 1),
+    (4500, 32, 32, 32, 2, 2),    # more nodes than resident waves: grid-stride + cross-workgroup reduction
+    (4500, 32, 20, 16, 2, 2),
 ]
 
 
@@ -147,9 +158,19 @@ def _node_inputs(nodes, C, L, Ho, Ks, Kc, seed):
     return Zs, Tc, W, b, dY
 
 
+@pytest.fixture(params=['mfma-or-generic', 'generic-only'])
+def node_path(request, monkeypatch):
+    """Run every node-kernel case twice: default dispatch (MFMA where the shape allows) and generic VALU only."""
+    if request.param == 'generic-only':
+        monkeypatch.setenv('STC_DISABLE_MFMA', '1')
+    else:
+        monkeypatch.delenv('STC_DISABLE_MFMA', raising=False)
+    return request.param
+
+
 @pytest.mark.parametrize('shape', NODE_SHAPES)
 @pytest.mark.parametrize('bias', [True, False])
-def test_bdg_node_fwd(hip, shape, bias):
+def test_bdg_node_fwd(hip, shape, bias, node_path):
     nodes, C, L, Ho, Ks, Kc = shape
     Zs, Tc, W, b, _ = _node_inputs(*shape, seed=sum(shape))
     b = b if bias else None
@@ -162,7 +183,7 @@ def test_bdg_node_fwd(hip, shape, bias):
 
 @pytest.mark.parametrize('shape', NODE_SHAPES)
 @pytest.mark.parametrize('want_dT', [True, False])
-def test_bdg_node_bwd(hip, shape, want_dT):
+def test_bdg_node_bwd(hip, shape, want_dT, node_path):
     nodes, C, L, Ho, Ks, Kc = shape
     Zs, Tc, W, b, dY = _node_inputs(*shape, seed=sum(shape) + 1)
     dZ_w = [torch.empty(nodes, C, L) for _ in range(Ks)]
@@ -187,6 +208,42 @@ def test_bdg_node_bwd(hip, shape, want_dT):
     assert torch.equal(dW, dW2)
 
 
+@pytest.mark.parametrize('nodes,C,L,Lw,Ho,K', [
+    (50, 32, 20, 17, 32, 2),     # encoder layer 0 at the headline width: in + hidden = 17, rows padded to 20 (MFMA path)
+    (50, 32, 20, 17, 16, 2),
+    (4100, 32, 20, 17, 32, 2),
+    (21, 16, 20, 18, 16, 3),
+    (40, 5, 20, 17, 32, 2),      # SF shape, padded (generic path)
+    (30, 3, 8, 5, 4, 3),
+])
+def test_bdg_node_padded_feature_rows(hip, nodes, C, L, Lw, Ho, K, node_path):
+    """Slabs carry L - Lw zero-pad columns; W has Lw rows per block; pad columns get zero gradient."""
+    g = torch.Generator().manual_seed(nodes + L + Lw)
+    Zs = [torch.randn(nodes, C, L, generator=g) for _ in range(K)]
+    for z in Zs:
+        z[..., Lw:] = 7.0                                         # garbage in the pad columns must not matter
+    Tc = torch.randn(K, C, C, generator=g) / C ** 0.5
+    Tc[0] = torch.eye(C)
+    W = torch.randn(K * K * Lw, Ho, generator=g) / (K * K * Lw) ** 0.5
+    b = torch.randn(Ho, generator=g)
+    dY = torch.randn(nodes, C, Ho, generator=g)
+    Y_w = torch.empty(nodes, C, Ho)
+    EM.bdg_node_fwd(Zs, Tc, W, b, Y_w)
+    Y = torch.empty(nodes, C, Ho).cuda()
+    hip.bdg_node_fwd([cu(z) for z in Zs], cu(Tc), cu(W), cu(b), Y)
+    assert rel_err(Y, Y_w) < TOL
+    dZ_w = [torch.empty(nodes, C, L) for _ in range(K)]
+    dW_w, db_w = torch.empty_like(W), torch.empty(Ho)
+    EM.bdg_node_bwd(Zs, Tc, W, dY, dZ_w, dW_w, db_w, None)
+    dZ = [torch.full((nodes, C, L), float('nan')).cuda() for _ in range(K)]
+    dW, db = torch.empty_like(W).cuda(), torch.empty(Ho).cuda()
+    hip.bdg_node_bwd([cu(z) for z in Zs], cu(Tc), cu(W), cu(dY), dZ, dW, db, None)
+    for a, w in zip(dZ, dZ_w):
+        assert rel_err(a, w) < TOL
+        assert float(a[..., Lw:].abs().max()) == 0.0
+    assert rel_err(dW, dW_w) < TOL and rel_err(db, db_w) < TOL
+
+
 def test_bdg_node_bwd_many_tiles_exercises_grid_stride(hip):
     shape = (3000, 8, 9, 5, 2, 2)                               # 750 tiles > 512 workgroups
     nodes, C, L, Ho, Ks, Kc = shape
@@ -206,18 +263,19 @@ def test_bdg_node_bwd_many_tiles_exercises_grid_stride(hip):
     assert rel_err(Y, Y_w) < TOL
 
 
-@pytest.mark.parametrize('rows_shape,cin,h', [((2, 7, 3), 1, 4), ((3, 50, 5), 16, 16), ((1, 9, 2), 4, 5)])
-def test_gru_gates_and_blend(hip, rows_shape, cin, h):
+@pytest.mark.parametrize('rows_shape,cin,h,pad', [((2, 7, 3), 1, 4, 0), ((3, 50, 5), 16, 16, 0), ((1, 9, 2), 4, 5, 3),
+                                                ((2, 11, 32), 1, 16, 3)])
+def test_gru_gates_and_blend(hip, rows_shape, cin, h, pad):
     g = torch.Generator().manual_seed(cin * 100 + h)
     G = torch.randn(*rows_shape, 2 * h, generator=g)
     Xt = torch.randn(*rows_shape, cin, generator=g)
     H = torch.randn(*rows_shape, h, generator=g)
-    U_w, R_w, Ci_w = torch.empty_like(H), torch.empty_like(H), torch.empty(*rows_shape, cin + h)
+    U_w, R_w, Ci_w = torch.empty_like(H), torch.empty_like(H), torch.full((*rows_shape, cin + h + pad), 3.0)
     EM.gru_gates_fwd(G, Xt, H, U_w, R_w, Ci_w)
-    U, R, Ci = torch.empty_like(H).cuda(), torch.empty_like(H).cuda(), torch.empty(*rows_shape, cin + h).cuda()
+    U, R, Ci = torch.empty_like(H).cuda(), torch.empty_like(H).cuda(), torch.full((*rows_shape, cin + h + pad), 5.0).cuda()
     hip.gru_gates_fwd(cu(G), cu(Xt), cu(H), U, R, Ci)
     assert rel_err(U, U_w) < TOL and rel_err(R, R_w) < TOL and rel_err(Ci, Ci_w) < TOL
-    dCi, dU = torch.randn(*rows_shape, cin + h, generator=g), torch.randn(*rows_shape, h, generator=g)
+    dCi, dU = torch.randn(*rows_shape, cin + h + pad, generator=g), torch.randn(*rows_shape, h, generator=g)
     dG_w, dX_w, dH_w = torch.empty_like(G), torch.empty_like(Xt), torch.empty_like(H)
     EM.gru_gates_bwd(dCi, dU, H, U_w, R_w, dG_w, dX_w, dH_w)
     dG, dX, dH = torch.empty_like(G).cuda(), torch.empty_like(Xt).cuda(), torch.empty_like(H).cuda()
@@ -251,6 +309,11 @@ def test_axpy_concat_split(hip):
     assert torch.equal(out.cpu(), torch.cat([A, Bm], -1))
     A2, B2 = torch.empty_like(A).cuda(), torch.empty_like(Bm).cuda()
     hip.split2(out, A2, B2)
+    assert torch.equal(A2.cpu(), A) and torch.equal(B2.cpu(), Bm)
+    padded = torch.full((4, 9, 3, 20), 9.0).cuda()                # 1 + 16 -> 20: three zero pad columns
+    hip.concat2(cu(A), cu(Bm), padded)
+    assert torch.equal(padded.cpu(), torch.cat([A, Bm, torch.zeros(4, 9, 3, 3)], -1))
+    hip.split2(padded, A2, B2)
     assert torch.equal(A2.cpu(), A) and torch.equal(B2.cpu(), Bm)
 
 

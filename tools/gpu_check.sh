@@ -23,3 +23,7 @@ if [ "${PROFILE:-1}" = "1" ]; then
   # keep only the small summaries (the raw trace can be large)
   find gpurun_out/prof -name "*kernel_trace.csv" -size +20M -delete
 fi
+if [ "${KBENCH:-1}" = "1" ]; then
+  echo "== per-kernel timings"
+  timeout 600 python tools/bench_kernels.py > gpurun_out/kbench.log 2>&1; echo "kbench exit $?"; cat gpurun_out/kbench.log
+fi
