@@ -43,6 +43,21 @@ inline hipError_t allow_lds(K kernel, size_t bytes) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
+// Workgroups of `kernel` that are resident at once on the whole device (occupancy API x CU count).
+// Persistent kernels size their grid with it: a grid above residency runs in sequential rounds.
+template <typename K>
+inline int resident_blocks(K kernel, int threads, size_t lds, int fallback_per_cu = 1) {
+    int per_cu = 0, dev = 0, cus = kNumCu;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds) != hipSuccess || per_cu < 1)
+        per_cu = fallback_per_cu;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    (void)hipGetLastError();
+    return per_cu * cus;
+}
+
 #define STC_REQUIRE(cond, code, ...) \
     do {                             \
         if (!(cond)) return ::stc::fail(code, __VA_ARGS__); \

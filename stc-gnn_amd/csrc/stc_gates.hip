@@ -3,6 +3,8 @@
 // All of these are streaming, HBM-bound kernels: one pass over each operand.
 #include "stc_common.h"
 
+#include <initializer_list>
+
 namespace {
 
 constexpr int EW_THREADS = 256;
@@ -86,6 +88,117 @@ __global__ __launch_bounds__(EW_THREADS) void gru_blend_bwd_kernel(
         dH[e] = g * (1.f - u);
     }
 }
+
+
+// ---- 16-byte versions (every width a multiple of 4 floats, pointers 16-byte aligned): one float4 per thread
+__device__ __forceinline__ float4 sig4(float4 x) { return make_float4(sigmoidf_(x.x), sigmoidf_(x.y), sigmoidf_(x.z), sigmoidf_(x.w)); }
+__device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+
+__global__ __launch_bounds__(EW_THREADS) void gru_gates_fwd_vec_kernel(
+    const float4* __restrict__ G, const float4* __restrict__ Xt, const float4* __restrict__ H,
+    float4* __restrict__ U, float4* __restrict__ Rg, float4* __restrict__ CandIn,
+    long long rows, int cin4, int h4, int pad4) {
+    const int L4 = cin4 + h4 + pad4;
+    const long long n = rows * L4;
+    for (long long e = (long long)blockIdx.x * EW_THREADS + threadIdx.x; e < n; e += (long long)gridDim.x * EW_THREADS) {
+        const long long r = e / L4;
+        const int l = (int)(e - r * L4);
+        if (l < cin4) {
+            CandIn[e] = Xt[r * cin4 + l];
+        } else if (l >= cin4 + h4) {
+            CandIn[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            const int k = l - cin4;
+            const float4 u = sig4(G[r * 2 * h4 + k]);
+            const float4 g = sig4(G[r * 2 * h4 + h4 + k]);
+            U[r * h4 + k] = u;
+            Rg[r * h4 + k] = g;
+            CandIn[e] = mul4(g, H[r * h4 + k]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(EW_THREADS) void gru_gates_bwd_vec_kernel(
+    const float4* __restrict__ dCandIn, const float4* __restrict__ dU, const float4* __restrict__ H,
+    const float4* __restrict__ U, const float4* __restrict__ Rg,
+    float4* __restrict__ dG, float4* __restrict__ dXt, float4* __restrict__ dH,
+    long long rows, int cin4, int h4, int pad4) {
+    const int L4 = cin4 + h4 + pad4;
+    const long long n = rows * L4;
+    for (long long e = (long long)blockIdx.x * EW_THREADS + threadIdx.x; e < n; e += (long long)gridDim.x * EW_THREADS) {
+        const long long r = e / L4;
+        const int l = (int)(e - r * L4);
+        if (l < cin4) {
+            dXt[r * cin4 + l] = dCandIn[e];
+        } else if (l < cin4 + h4) {
+            const int k = l - cin4;
+            const long long i = r * h4 + k;
+            const float4 u = U[i], g = Rg[i], d = dCandIn[e], du = dU[i], hh = H[i];
+            dG[r * 2 * h4 + k] = make_float4(du.x * u.x * (1.f - u.x), du.y * u.y * (1.f - u.y), du.z * u.z * (1.f - u.z), du.w * u.w * (1.f - u.w));
+            dG[r * 2 * h4 + h4 + k] = make_float4(d.x * hh.x * g.x * (1.f - g.x), d.y * hh.y * g.y * (1.f - g.y),
+                                                  d.z * hh.z * g.z * (1.f - g.z), d.w * hh.w * g.w * (1.f - g.w));
+            dH[i] = mul4(d, g);
+        }
+    }
+}
+
+__global__ __launch_bounds__(EW_THREADS) void gru_blend_fwd_vec_kernel(
+    const float4* __restrict__ Cpre, const float4* __restrict__ U, const float4* __restrict__ H,
+    float4* __restrict__ Cand, float4* __restrict__ Hnew, long long n4) {
+    for (long long e = (long long)blockIdx.x * EW_THREADS + threadIdx.x; e < n4; e += (long long)gridDim.x * EW_THREADS) {
+        const float4 p = Cpre[e], u = U[e], hh = H[e];
+        const float4 c = make_float4(tanhf(p.x), tanhf(p.y), tanhf(p.z), tanhf(p.w));
+        Cand[e] = c;
+        Hnew[e] = make_float4((1.f - u.x) * hh.x + u.x * c.x, (1.f - u.y) * hh.y + u.y * c.y,
+                              (1.f - u.z) * hh.z + u.z * c.z, (1.f - u.w) * hh.w + u.w * c.w);
+    }
+}
+
+__global__ __launch_bounds__(EW_THREADS) void gru_blend_bwd_vec_kernel(
+    const float4* __restrict__ dHnew, const float4* __restrict__ U, const float4* __restrict__ H,
+    const float4* __restrict__ Cand, float4* __restrict__ dCpre, float4* __restrict__ dU, float4* __restrict__ dH,
+    long long n4) {
+    for (long long e = (long long)blockIdx.x * EW_THREADS + threadIdx.x; e < n4; e += (long long)gridDim.x * EW_THREADS) {
+        const float4 g = dHnew[e], u = U[e], c = Cand[e], hh = H[e];
+        dCpre[e] = make_float4(g.x * u.x * (1.f - c.x * c.x), g.y * u.y * (1.f - c.y * c.y),
+                               g.z * u.z * (1.f - c.z * c.z), g.w * u.w * (1.f - c.w * c.w));
+        dU[e] = make_float4(g.x * (c.x - hh.x), g.y * (c.y - hh.y), g.z * (c.z - hh.z), g.w * (c.w - hh.w));
+        dH[e] = make_float4(g.x * (1.f - u.x), g.y * (1.f - u.y), g.z * (1.f - u.z), g.w * (1.f - u.w));
+    }
+}
+
+__global__ __launch_bounds__(EW_THREADS) void concat2_vec_kernel(const float4* __restrict__ A, const float4* __restrict__ B,
+                                                                  float4* __restrict__ out, long long rows, int a4, int b4, int pad4) {
+    const int L4 = a4 + b4 + pad4;
+    const long long n = rows * L4;
+    for (long long e = (long long)blockIdx.x * EW_THREADS + threadIdx.x; e < n; e += (long long)gridDim.x * EW_THREADS) {
+        const long long r = e / L4;
+        const int l = (int)(e - r * L4);
+        out[e] = l < a4 ? A[r * a4 + l] : (l < a4 + b4 ? B[r * b4 + (l - a4)] : make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+}
+
+__global__ __launch_bounds__(EW_THREADS) void split2_vec_kernel(const float4* __restrict__ src, float4* __restrict__ A,
+                                                                 float4* __restrict__ B, long long rows, int a4, int b4, int pad4) {
+    const int L4 = a4 + b4 + pad4;
+    const long long n = rows * L4;
+    for (long long e = (long long)blockIdx.x * EW_THREADS + threadIdx.x; e < n; e += (long long)gridDim.x * EW_THREADS) {
+        const long long r = e / L4;
+        const int l = (int)(e - r * L4);
+        if (l < a4) A[r * a4 + l] = src[e];
+        else if (l < a4 + b4) B[r * b4 + (l - a4)] = src[e];
+    }
+}
+
+inline bool vec_ok(std::initializer_list<const void*> ptrs, std::initializer_list<long long> widths) {
+    for (const void* p : ptrs)
+        if (p && !stc::aligned16(p)) return false;
+    for (long long w : widths)
+        if (w % 4) return false;
+    return true;
+}
+#define F4C(p) reinterpret_cast<const float4*>(p)
+#define F4M(p) reinterpret_cast<float4*>(p)
 
 __global__ __launch_bounds__(EW_THREADS) void axpy_kernel(float a, const float* __restrict__ x, float* y, long long n) {
     for (long long e = (long long)blockIdx.x * EW_THREADS + threadIdx.x; e < n; e += (long long)gridDim.x * EW_THREADS)
@@ -171,7 +284,11 @@ extern "C" int stc_gru_gates_fwd_f32(const float* G, const float* Xt, const floa
     STC_REQUIRE(cin >= 0 && h >= 1 && pad >= 0, STC_EINVAL, "stc_gru_gates_fwd_f32: bad widths cin=%d h=%d pad=%d", cin, h, pad);
     STC_EW_PROLOGUE("stc_gru_gates_fwd_f32", rows, G && H && U && Rg && CandIn && (cin == 0 || Xt));
     const long long n = (long long)rows * (cin + h + pad);
-    hipLaunchKernelGGL(gru_gates_fwd_kernel, ew_grid(n), dim3(EW_THREADS), 0, s, G, Xt, H, U, Rg, CandIn, (long long)rows, cin, h, pad);
+    if (vec_ok({G, Xt, H, U, Rg, CandIn}, {cin, h, pad}))
+        hipLaunchKernelGGL(gru_gates_fwd_vec_kernel, ew_grid(n / 4), dim3(EW_THREADS), 0, s, F4C(G), F4C(Xt), F4C(H), F4M(U), F4M(Rg),
+                           F4M(CandIn), (long long)rows, cin / 4, h / 4, pad / 4);
+    else
+        hipLaunchKernelGGL(gru_gates_fwd_kernel, ew_grid(n), dim3(EW_THREADS), 0, s, G, Xt, H, U, Rg, CandIn, (long long)rows, cin, h, pad);
     STC_LAUNCH_CHECK("stc_gru_gates_fwd_f32 launch");
     return STC_OK;
 }
@@ -181,7 +298,11 @@ extern "C" int stc_gru_gates_bwd_f32(const float* dCandIn, const float* dU, cons
     STC_REQUIRE(cin >= 0 && h >= 1 && pad >= 0, STC_EINVAL, "stc_gru_gates_bwd_f32: bad widths cin=%d h=%d pad=%d", cin, h, pad);
     STC_EW_PROLOGUE("stc_gru_gates_bwd_f32", rows, dCandIn && dU && H && U && Rg && dG && dH && (cin == 0 || dXt));
     const long long n = (long long)rows * (cin + h + pad);
-    hipLaunchKernelGGL(gru_gates_bwd_kernel, ew_grid(n), dim3(EW_THREADS), 0, s, dCandIn, dU, H, U, Rg, dG, dXt, dH, (long long)rows, cin, h, pad);
+    if (vec_ok({dCandIn, dU, H, U, Rg, dG, dXt, dH}, {cin, h, pad}))
+        hipLaunchKernelGGL(gru_gates_bwd_vec_kernel, ew_grid(n / 4), dim3(EW_THREADS), 0, s, F4C(dCandIn), F4C(dU), F4C(H), F4C(U), F4C(Rg),
+                           F4M(dG), F4M(dXt), F4M(dH), (long long)rows, cin / 4, h / 4, pad / 4);
+    else
+        hipLaunchKernelGGL(gru_gates_bwd_kernel, ew_grid(n), dim3(EW_THREADS), 0, s, dCandIn, dU, H, U, Rg, dG, dXt, dH, (long long)rows, cin, h, pad);
     STC_LAUNCH_CHECK("stc_gru_gates_bwd_f32 launch");
     return STC_OK;
 }
@@ -189,7 +310,10 @@ extern "C" int stc_gru_gates_bwd_f32(const float* dCandIn, const float* dU, cons
 extern "C" int stc_gru_blend_fwd_f32(const float* Cpre, const float* U, const float* H, float* Cand, float* Hnew,
                                      int64_t n, void* stream) {
     STC_EW_PROLOGUE("stc_gru_blend_fwd_f32", n, Cpre && U && H && Cand && Hnew);
-    hipLaunchKernelGGL(gru_blend_fwd_kernel, ew_grid(n), dim3(EW_THREADS), 0, s, Cpre, U, H, Cand, Hnew, (long long)n);
+    if (vec_ok({Cpre, U, H, Cand, Hnew}, {n}))
+        hipLaunchKernelGGL(gru_blend_fwd_vec_kernel, ew_grid(n / 4), dim3(EW_THREADS), 0, s, F4C(Cpre), F4C(U), F4C(H), F4M(Cand), F4M(Hnew), (long long)n / 4);
+    else
+        hipLaunchKernelGGL(gru_blend_fwd_kernel, ew_grid(n), dim3(EW_THREADS), 0, s, Cpre, U, H, Cand, Hnew, (long long)n);
     STC_LAUNCH_CHECK("stc_gru_blend_fwd_f32 launch");
     return STC_OK;
 }
@@ -197,7 +321,11 @@ extern "C" int stc_gru_blend_fwd_f32(const float* Cpre, const float* U, const fl
 extern "C" int stc_gru_blend_bwd_f32(const float* dHnew, const float* U, const float* H, const float* Cand,
                                      float* dCpre, float* dU, float* dH, int64_t n, void* stream) {
     STC_EW_PROLOGUE("stc_gru_blend_bwd_f32", n, dHnew && U && H && Cand && dCpre && dU && dH);
-    hipLaunchKernelGGL(gru_blend_bwd_kernel, ew_grid(n), dim3(EW_THREADS), 0, s, dHnew, U, H, Cand, dCpre, dU, dH, (long long)n);
+    if (vec_ok({dHnew, U, H, Cand, dCpre, dU, dH}, {n}))
+        hipLaunchKernelGGL(gru_blend_bwd_vec_kernel, ew_grid(n / 4), dim3(EW_THREADS), 0, s, F4C(dHnew), F4C(U), F4C(H), F4C(Cand), F4M(dCpre), F4M(dU),
+                           F4M(dH), (long long)n / 4);
+    else
+        hipLaunchKernelGGL(gru_blend_bwd_kernel, ew_grid(n), dim3(EW_THREADS), 0, s, dHnew, U, H, Cand, dCpre, dU, dH, (long long)n);
     STC_LAUNCH_CHECK("stc_gru_blend_bwd_f32 launch");
     return STC_OK;
 }
@@ -213,7 +341,10 @@ extern "C" int stc_concat2_f32(const float* A, const float* B, float* out, int64
     STC_REQUIRE(a >= 0 && b >= 0 && pad >= 0, STC_EINVAL, "stc_concat2_f32: negative width");
     const long long n = (long long)rows * (a + b + pad);
     STC_EW_PROLOGUE("stc_concat2_f32", n, out && (a == 0 || A) && (b == 0 || B));
-    hipLaunchKernelGGL(concat2_kernel, ew_grid(n), dim3(EW_THREADS), 0, s, A, B, out, (long long)rows, a, b, pad);
+    if (vec_ok({A, B, out}, {a, b, pad}))
+        hipLaunchKernelGGL(concat2_vec_kernel, ew_grid(n / 4), dim3(EW_THREADS), 0, s, F4C(A), F4C(B), F4M(out), (long long)rows, a / 4, b / 4, pad / 4);
+    else
+        hipLaunchKernelGGL(concat2_kernel, ew_grid(n), dim3(EW_THREADS), 0, s, A, B, out, (long long)rows, a, b, pad);
     STC_LAUNCH_CHECK("stc_concat2_f32 launch");
     return STC_OK;
 }
@@ -222,7 +353,10 @@ extern "C" int stc_split2_f32(const float* src, float* A, float* B, int64_t rows
     STC_REQUIRE(a >= 0 && b >= 0 && pad >= 0, STC_EINVAL, "stc_split2_f32: negative width");
     const long long n = (long long)rows * (a + b + pad);
     STC_EW_PROLOGUE("stc_split2_f32", n, src && (a == 0 || A) && (b == 0 || B));
-    hipLaunchKernelGGL(split2_kernel, ew_grid(n), dim3(EW_THREADS), 0, s, src, A, B, (long long)rows, a, b, pad);
+    if (vec_ok({src, A, B}, {a, b, pad}))
+        hipLaunchKernelGGL(split2_vec_kernel, ew_grid(n / 4), dim3(EW_THREADS), 0, s, F4C(src), F4M(A), F4M(B), (long long)rows, a / 4, b / 4, pad / 4);
+    else
+        hipLaunchKernelGGL(split2_kernel, ew_grid(n), dim3(EW_THREADS), 0, s, src, A, B, (long long)rows, a, b, pad);
     STC_LAUNCH_CHECK("stc_split2_f32 launch");
     return STC_OK;
 }

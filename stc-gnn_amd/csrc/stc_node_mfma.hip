@@ -29,7 +29,7 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int MF_THREADS = 256;
 constexpr int MF_WAVES = MF_THREADS / 64;
-constexpr int MF_BWD_MAX_GRID = 512;
+constexpr int MF_BWD_MAX_GRID = 512;     // partial rows the caller's workspace holds
 
 struct ZPtrs { const float* p[STC_MAX_K]; };
 struct DZPtrs { float* p[STC_MAX_K]; };
@@ -48,13 +48,48 @@ __host__ __device__ constexpr int kcol(int s, int q) {
 template <int N>
 struct AtLeast1 { static constexpr int v = N > 0 ? N : 1; };
 
+// A value the optimiser cannot see through: keeps LDS fragment fetches inside the node loop instead of
+// being hoisted into ~80 registers (which costs a wave of occupancy per SIMD).
+__device__ __forceinline__ int opaque(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 // --------------------------------------------------------------------------------------- forward
+template <int NRB, int K, int LQ>
+struct ZFrag {      // one node's A operand: this lane's row of every slab / row block
+    static constexpr int N16 = LQ / 4, NREM = LQ - 4 * (LQ / 4);
+    float4 v4[K][NRB][AtLeast1<N16>::v];
+    float r[K][NRB][AtLeast1<NREM>::v];
+
+    __device__ __forceinline__ void load(const ZPtrs& Z, int node, int j, int q) {
+        constexpr int C = 16 * NRB, L = 4 * LQ;
+#pragma unroll
+        for (int n = 0; n < K; ++n)
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+                const float* row = Z.p[n] + ((size_t)node * C + 16 * rb + j) * L;
+#pragma unroll
+                for (int m = 0; m < N16; ++m) v4[n][rb][m] = *reinterpret_cast<const float4*>(row + 16 * m + 4 * q);
+#pragma unroll
+                for (int u = 0; u < NREM; ++u) r[n][rb][u] = row[16 * N16 + 4 * u + q];
+            }
+    }
+    // value this lane contributes at k-step s of slab n, row block rb (s is a compile-time constant after unrolling)
+    __device__ __forceinline__ float at(int n, int rb, int s) const {
+        if (s < 4 * N16) {
+            const float4 v = v4[n][rb][s / 4 < N16 ? s / 4 : 0];
+            return (s % 4 == 0) ? v.x : (s % 4 == 1) ? v.y : (s % 4 == 2) ? v.z : v.w;
+        }
+        return r[n][rb][s - 4 * N16 < NREM && s >= 4 * N16 ? s - 4 * N16 : 0];
+    }
+};
+
 template <int NRB, int HB, int K, int LQ>
-__global__ __launch_bounds__(MF_THREADS) void node_fwd_mfma_kernel(
+__global__ __launch_bounds__(MF_THREADS, ((NRB * K * LQ <= 32) ? 3 : 2)) void node_fwd_mfma_kernel(
     ZPtrs Z, const float* __restrict__ Tc, const float* __restrict__ W, const float* __restrict__ bias,
     float* __restrict__ Y, int nodes, int Lw) {
     constexpr int C = 16 * NRB, Ho = 16 * HB, L = 4 * LQ, NCB = K * HB;
-    constexpr int N16 = LQ / 4, NREM = LQ - 4 * N16;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Wf = smem;                              // [K][LQ][NCB][64]   B fragments of the projection
     float* Tf = smem + K * LQ * NCB * 64;          // [K-1][NRB rb][NRB kb][4][64]   A fragments of the mix
@@ -86,20 +121,14 @@ __global__ __launch_bounds__(MF_THREADS) void node_fwd_mfma_kernel(
 #pragma unroll
     for (int hb = 0; hb < HB; ++hb) bv[hb] = bias ? bias[16 * hb + j] : 0.f;
 
-    for (int node = blockIdx.x * MF_WAVES + wave; node < nodes; node += nw) {
-        // this lane's row of every slab / row block: columns 16m + 4q .. +3 (and the 4-column remainder)
-        float4 a4[K][NRB][AtLeast1<N16>::v];
-        float ar[K][NRB][AtLeast1<NREM>::v];
-#pragma unroll
-        for (int n = 0; n < K; ++n)
-#pragma unroll
-            for (int rb = 0; rb < NRB; ++rb) {
-                const float* row = Z.p[n] + ((size_t)node * C + 16 * rb + j) * L;
-#pragma unroll
-                for (int m = 0; m < N16; ++m) a4[n][rb][m] = *reinterpret_cast<const float4*>(row + 16 * m + 4 * q);
-#pragma unroll
-                for (int u = 0; u < NREM; ++u) ar[n][rb][u] = row[16 * N16 + 4 * u + q];
-            }
+    int node = blockIdx.x * MF_WAVES + wave;
+    ZFrag<NRB, K, LQ> cur, nxt;
+    if (node < nodes) cur.load(Z, node, j, q);
+    while (node < nodes) {
+        const int next_node = node + nw;
+        if (next_node < nodes) nxt.load(Z, next_node, j, q);     // software prefetch: lands while this node computes
+        __builtin_amdgcn_sched_barrier(0);
+        const int lo = opaque(lane);
 
         f32x4 acc[NRB][NCB];
 #pragma unroll
@@ -112,30 +141,15 @@ __global__ __launch_bounds__(MF_THREADS) void node_fwd_mfma_kernel(
         for (int n = 0; n < K; ++n)
 #pragma unroll
             for (int s = 0; s < LQ; ++s) {
-                float a[NRB];
-#pragma unroll
-                for (int rb = 0; rb < NRB; ++rb) {
-                    if (s < 4 * N16) {
-                        const float4 v = a4[n][rb][s / 4 < N16 ? s / 4 : 0];
-                        a[rb] = (s % 4 == 0) ? v.x : (s % 4 == 1) ? v.y : (s % 4 == 2) ? v.z : v.w;
-                    } else {
-                        a[rb] = ar[n][rb][s - 4 * N16 < NREM ? s - 4 * N16 : 0];
-                    }
-                }
 #pragma unroll
                 for (int cb = 0; cb < NCB; ++cb) {
-                    const float b = Wf[((n * LQ + s) * NCB + cb) * 64 + lane];
+                    const float b = Wf[((n * LQ + s) * NCB + cb) * 64 + lo];
 #pragma unroll
-                    for (int rb = 0; rb < NRB; ++rb) acc[rb][cb] = mfma16(a[rb], b, acc[rb][cb]);
+                    for (int rb = 0; rb < NRB; ++rb) acc[rb][cb] = mfma16(cur.at(n, rb, s), b, acc[rb][cb]);
                 }
             }
 
         // mix: Y[rb][hb] = U_0[rb][hb] + sum_{c>=1} sum_kb T_c^T[rb][kb] U_c[kb][hb]   (U_c read from its accumulators)
-        f32x4 y[NRB][HB];
-#pragma unroll
-        for (int rb = 0; rb < NRB; ++rb)
-#pragma unroll
-            for (int hb = 0; hb < HB; ++hb) y[rb][hb] = acc[rb][hb];
 #pragma unroll
         for (int c1 = 0; c1 < K - 1; ++c1)
 #pragma unroll
@@ -144,10 +158,10 @@ __global__ __launch_bounds__(MF_THREADS) void node_fwd_mfma_kernel(
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
                     for (int rb = 0; rb < NRB; ++rb) {
-                        const float a = Tf[((((c1 * NRB + rb) * NRB + kb) * 4 + t)) * 64 + lane];
+                        const float a = Tf[((((c1 * NRB + rb) * NRB + kb) * 4 + t)) * 64 + lo];
 #pragma unroll
                         for (int hb = 0; hb < HB; ++hb)
-                            y[rb][hb] = mfma16(a, acc[kb][(c1 + 1) * HB + hb][t], y[rb][hb]);
+                            acc[rb][hb] = mfma16(a, acc[kb][(c1 + 1) * HB + hb][t], acc[rb][hb]);
                     }
 
         // accumulator layout: lane (j, q), register r  <->  row 4q + r, column j of the 16 x 16 tile
@@ -157,16 +171,46 @@ __global__ __launch_bounds__(MF_THREADS) void node_fwd_mfma_kernel(
             for (int hb = 0; hb < HB; ++hb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    Y[((size_t)node * C + 16 * rb + 4 * q + r) * Ho + 16 * hb + j] = y[rb][hb][r] + bv[hb];
+                    Y[((size_t)node * C + 16 * rb + 4 * q + r) * Ho + 16 * hb + j] = acc[rb][hb][r] + bv[hb];
+        cur = nxt;
+        node = next_node;
     }
 }
 
 // --------------------------------------------------------------------------------------- backward
+// rough register need of the prefetching schedule; above ~210 the kernel runs one wave per SIMD without prefetch
 template <int NRB, int HB, int K, int LQ>
-__global__ __launch_bounds__(MF_THREADS) void node_bwd_mfma_kernel(
+struct BwdPlan {
+    static constexpr int LB = (4 * LQ + 15) / 16;
+    static constexpr int regs = K * LB * K * HB * 4 + 2 * (2 * NRB * HB * 4) + K * LB * NRB * 4 + 2 * NRB * HB * 4 + 4 * NRB + 24;
+    static constexpr bool prefetch = regs <= 232;
+};
+
+template <int NRB, int HB>
+struct DyFrag {     // one node's dY in both register layouts
+    f32x4 d[NRB][HB];   // component t: dY[16kb + 4q + t][16hb + j]        (tile rows d, columns o; lane = o)
+    f32x4 v[NRB][HB];   // dY[16rb + j][16hb + 4q + 0..3]                   (tile rows o, columns d; lane = d)
+    __device__ __forceinline__ void load(const float* __restrict__ dY, int node, int j, int q) {
+        constexpr int C = 16 * NRB, Ho = 16 * HB;
+        const size_t r0 = (size_t)node * C;
+#pragma unroll
+        for (int kb = 0; kb < NRB; ++kb)
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) d[kb][hb][t] = dY[(r0 + 16 * kb + 4 * q + t) * Ho + 16 * hb + j];
+                const float4 x = *reinterpret_cast<const float4*>(dY + (r0 + 16 * kb + j) * Ho + 16 * hb + 4 * q);
+                v[kb][hb] = f32x4{x.x, x.y, x.z, x.w};
+            }
+    }
+};
+
+template <int NRB, int HB, int K, int LQ>
+__global__ __launch_bounds__(MF_THREADS, (BwdPlan<NRB, HB, K, LQ>::prefetch ? 2 : 1)) void node_bwd_mfma_kernel(
     ZPtrs Z, const float* __restrict__ Tc, const float* __restrict__ W, const float* __restrict__ dY,
     DZPtrs dZ, float* __restrict__ partial, int nodes, int want_db, int Lw) {
     constexpr int C = 16 * NRB, Ho = 16 * HB, L = 4 * LQ, LB = (L + 15) / 16;
+    constexpr bool PF = BwdPlan<NRB, HB, K, LQ>::prefetch;
     const int nW = K * K * Lw * Ho;
     constexpr int nTf = (K - 1) * NRB * NRB * 4 * 64;
     constexpr int nWf = K * LB * K * HB * 4 * 64;
@@ -211,47 +255,60 @@ __global__ __launch_bounds__(MF_THREADS) void node_bwd_mfma_kernel(
 #pragma unroll
     for (int hb = 0; hb < HB; ++hb) dbp[hb] = 0.f;
 
-    for (int node = blockIdx.x * MF_WAVES + wave; node < nodes; node += nw) {
+    int node = blockIdx.x * MF_WAVES + wave;
+    DyFrag<NRB, HB> g, gn;
+    if (PF && node < nodes) g.load(dY, node, j, q);
+    while (node < nodes) {
+        const int next_node = node + nw;
         const size_t r0 = (size_t)node * C;
-        // Qd[c][rb][hb]: Q_c tile rows c' (register), columns o (lane)    -- B operand of dW
-        // Qv[c][rb][hb]: Q_c^T tile rows o (register), columns c' (lane)  -- B operand of dZ
-        f32x4 Qd[K][NRB][HB], Qv[K][NRB][HB];
+        if (!PF) g.load(dY, node, j, q);
+        // this node's Z columns for the dW product (needed last: in flight during the Q and dZ phases)
+        float za[K][LB][NRB][4];
+#pragma unroll
+        for (int n = 0; n < K; ++n)
+#pragma unroll
+            for (int lb = 0; lb < LB; ++lb) {
+                const bool ok = 16 * lb + j < L;
+                const float* col = Z.p[n] + r0 * L + 16 * lb + (ok ? j : 0);
+#pragma unroll
+                for (int kb = 0; kb < NRB; ++kb)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const float zv = col[(size_t)(16 * kb + 4 * q + t) * L];
+                        za[n][lb][kb][t] = ok ? zv : 0.f;
+                    }
+            }
+        if (PF && next_node < nodes) gn.load(dY, next_node, j, q);
+        if (PF) __builtin_amdgcn_sched_barrier(0);
+        const int lo = opaque(lane);
+
 #pragma unroll
         for (int kb = 0; kb < NRB; ++kb)
 #pragma unroll
-            for (int hb = 0; hb < HB; ++hb) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) Qd[0][kb][hb][t] = dY[(r0 + 16 * kb + 4 * q + t) * Ho + 16 * hb + j];
-                const float4 v = *reinterpret_cast<const float4*>(dY + (r0 + 16 * kb + j) * Ho + 16 * hb + 4 * q);
-                Qv[0][kb][hb] = f32x4{v.x, v.y, v.z, v.w};
-                dbp[hb] += (Qd[0][kb][hb][0] + Qd[0][kb][hb][1]) + (Qd[0][kb][hb][2] + Qd[0][kb][hb][3]);
-            }
+            for (int hb = 0; hb < HB; ++hb)
+                dbp[hb] += (g.d[kb][hb][0] + g.d[kb][hb][1]) + (g.d[kb][hb][2] + g.d[kb][hb][3]);
+
+        // ---- Q_c^T tiles (rows o, columns c'): B operands of dZ.   Q_0^T = dY^T is g.v
+        f32x4 Qv[AtLeast1<K - 1>::v][NRB][HB];
 #pragma unroll
         for (int c1 = 0; c1 < K - 1; ++c1) {
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
-                for (int hb = 0; hb < HB; ++hb) {
-                    Qd[c1 + 1][rb][hb] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    Qv[c1 + 1][rb][hb] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
+                for (int hb = 0; hb < HB; ++hb) Qv[c1][rb][hb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kb = 0; kb < NRB; ++kb)
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
                     for (int rb = 0; rb < NRB; ++rb) {
-                        const float tf = TfA[(((c1 * NRB + rb) * NRB + kb) * 4 + t) * 64 + lane];
+                        const float tf = TfA[(((c1 * NRB + rb) * NRB + kb) * 4 + t) * 64 + lo];
 #pragma unroll
-                        for (int hb = 0; hb < HB; ++hb) {
-                            const float g = Qd[0][kb][hb][t];
-                            Qd[c1 + 1][rb][hb] = mfma16(tf, g, Qd[c1 + 1][rb][hb]);     // T_c . dY
-                            Qv[c1 + 1][rb][hb] = mfma16(g, tf, Qv[c1 + 1][rb][hb]);     // dY^T . T_c^T
-                        }
+                        for (int hb = 0; hb < HB; ++hb) Qv[c1][rb][hb] = mfma16(g.d[kb][hb][t], tf, Qv[c1][rb][hb]);   // dY^T . T_c^T
                     }
         }
 
-        // dZ_n^T tile (rows l, columns c') = sum_{c,o} W[(n,c,l)][o] * Q_c[c'][o]
+        // ---- dZ_n^T tile (rows l, columns c') = sum_{c,o} W[(n,c,l)][o] * Q_c[c'][o]
 #pragma unroll
         for (int n = 0; n < K; ++n)
 #pragma unroll
@@ -265,9 +322,12 @@ __global__ __launch_bounds__(MF_THREADS) void node_bwd_mfma_kernel(
                     for (int hb = 0; hb < HB; ++hb)
 #pragma unroll
                         for (int t = 0; t < 4; ++t) {
-                            const float wf = WfD[((((n * LB + lb) * K + c) * HB + hb) * 4 + t) * 64 + lane];
+                            const float wf = WfD[((((n * LB + lb) * K + c) * HB + hb) * 4 + t) * 64 + lo];
 #pragma unroll
-                            for (int rb = 0; rb < NRB; ++rb) z[rb] = mfma16(wf, Qv[c][rb][hb][t], z[rb]);
+                            for (int rb = 0; rb < NRB; ++rb) {
+                                const float qv = c == 0 ? g.v[rb][hb][t] : Qv[c > 0 ? c - 1 : 0][rb][hb][t];
+                                z[rb] = mfma16(wf, qv, z[rb]);
+                            }
                         }
                 if (16 * lb + 4 * q < L) {
 #pragma unroll
@@ -277,26 +337,44 @@ __global__ __launch_bounds__(MF_THREADS) void node_bwd_mfma_kernel(
                 }
             }
 
-        // dW_{n,c} tile (rows l, columns o) += sum_{c'} Z_n[c'][l] * Q_c[c'][o]
+        // ---- Q_c tiles (rows c', columns o): B operands of dW.   Q_0 = dY is g.d
+        f32x4 Qd[AtLeast1<K - 1>::v][NRB][HB];
+#pragma unroll
+        for (int c1 = 0; c1 < K - 1; ++c1) {
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                for (int hb = 0; hb < HB; ++hb) Qd[c1][rb][hb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < NRB; ++kb)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int rb = 0; rb < NRB; ++rb) {
+                        const float tf = TfA[(((c1 * NRB + rb) * NRB + kb) * 4 + t) * 64 + lo];
+#pragma unroll
+                        for (int hb = 0; hb < HB; ++hb) Qd[c1][rb][hb] = mfma16(tf, g.d[kb][hb][t], Qd[c1][rb][hb]);   // T_c . dY
+                    }
+        }
+
+        // ---- dW_{n,c} tile (rows l, columns o) += sum_{c'} Z_n[c'][l] * Q_c[c'][o]
 #pragma unroll
         for (int n = 0; n < K; ++n)
 #pragma unroll
-            for (int lb = 0; lb < LB; ++lb) {
-                const bool ok = 16 * lb + j < L;
-                const float* col = Z.p[n] + r0 * L + 16 * lb + (ok ? j : 0);
+            for (int lb = 0; lb < LB; ++lb)
 #pragma unroll
                 for (int kb = 0; kb < NRB; ++kb)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const float zv = col[(size_t)(16 * kb + 4 * q + t) * L];
-                        const float a = ok ? zv : 0.f;
+                    for (int t = 0; t < 4; ++t)
 #pragma unroll
                         for (int c = 0; c < K; ++c)
 #pragma unroll
-                            for (int hb = 0; hb < HB; ++hb)
-                                dWt[n][lb][c][hb] = mfma16(a, Qd[c][kb][hb][t], dWt[n][lb][c][hb]);
-                    }
-            }
+                            for (int hb = 0; hb < HB; ++hb) {
+                                const float qd = c == 0 ? g.d[kb][hb][t] : Qd[c > 0 ? c - 1 : 0][kb][hb][t];
+                                dWt[n][lb][c][hb] = mfma16(za[n][lb][kb][t], qd, dWt[n][lb][c][hb]);
+                            }
+        if (PF) g = gn;
+        node = next_node;
     }
 
     // combine the four waves of the workgroup in a fixed order, then one partial row per workgroup
@@ -340,10 +418,11 @@ int launch_fwd(const float* const* Z, const float* Tc, const float* W, const flo
     if (lds > stc::kMaxLdsBytes) return STC_NOT_HANDLED;
     auto kern = node_fwd_mfma_kernel<NRB, HB, K, LQ>;
     if (int rc = stc::hip_status(stc::allow_lds(kern, lds), "hipFuncSetAttribute(node fwd mfma)")) return rc;
+    static const int resident = stc::resident_blocks(kern, MF_THREADS, lds, 2);   // persistent grid = what fits at once
     ZPtrs zp{};
     for (int n = 0; n < K; ++n) zp.p[n] = Z[n];
     const long long want = (nodes + MF_WAVES - 1) / MF_WAVES;
-    const int grid = (int)(want < 4 * stc::kNumCu ? want : 4 * stc::kNumCu);
+    const int grid = (int)(want < resident ? want : resident);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(MF_THREADS), lds, stream, zp, Tc, W, bias, Y, (int)nodes, Lw);
     STC_LAUNCH_CHECK("node_fwd_mfma launch");
     return STC_OK;
@@ -359,11 +438,13 @@ int launch_bwd(const float* const* Z, const float* Tc, const float* W, const flo
     if (lds > stc::kMaxLdsBytes) return STC_NOT_HANDLED;
     auto kern = node_bwd_mfma_kernel<NRB, HB, K, LQ>;
     if (int rc = stc::hip_status(stc::allow_lds(kern, lds), "hipFuncSetAttribute(node bwd mfma)")) return rc;
+    static const int resident = stc::resident_blocks(kern, MF_THREADS, lds, 1);
     ZPtrs zp{};
     DZPtrs dzp{};
     for (int n = 0; n < K; ++n) { zp.p[n] = Z[n]; dzp.p[n] = dZ[n]; }
     const long long want = (nodes + MF_WAVES - 1) / MF_WAVES;
-    const int grid = (int)(want < MF_BWD_MAX_GRID ? want : MF_BWD_MAX_GRID);
+    int grid = resident < MF_BWD_MAX_GRID ? resident : MF_BWD_MAX_GRID;
+    if (want < grid) grid = (int)want;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(MF_THREADS), lds, stream, zp, Tc, W, dY, dzp, partial, (int)nodes, want_db, Lw);
     STC_LAUNCH_CHECK("node_bwd_mfma launch");
     *n_partials = grid;

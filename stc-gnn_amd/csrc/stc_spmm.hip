@@ -18,11 +18,16 @@
 //                gathers (its own +- the graph bandwidth) stay in that XCD's 4 MiB L2
 #include "stc_common.h"
 
+#include <cstdlib>
+
+#ifndef STC_SPMM_DEFAULT_VARIANT
+#define STC_SPMM_DEFAULT_VARIANT 0
+#endif
+
 namespace {
 
 constexpr int SPMM_THREADS = 256;
 constexpr int SPMM_WAVES = SPMM_THREADS / 64;
-constexpr int SPMM_ROWS = 8;         // output rows per workgroup
 constexpr int SPMM_SEG_CAP = 1024;   // CSR entries staged in LDS per workgroup
 
 __device__ __forceinline__ float uniform_f(float v) {
@@ -36,11 +41,16 @@ __device__ __forceinline__ void fma4(float4& acc, float s, const float4& x) {
     acc.w = fmaf(s, x.w, acc.w);
 }
 
-template <int VPT>
+// ROWS consecutive output rows per workgroup; NT: non-temporal stores of Y (written once, never re-read by
+// this launch: keeps the output stream from evicting the X rows the neighbours still need from L2).
+// gridDim.z > 1 splits the feature row into column blocks of 64*VPT float4 (one 1 KiB piece per lane-row at
+// VPT = 1): a tile's gather set (~3x its rows for a banded graph) then fits the CU's 32 KiB L1.
+template <int VPT, int ROWS, bool NT>
 __global__ __launch_bounds__(SPMM_THREADS) void spmm_wave_row_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ colidx, const float* __restrict__ val,
     int n_rows, int n_cols, const float4* __restrict__ X, const float4* Y0, float4* Y,
     int F4, float alpha, float beta, int n_tiles) {
+    constexpr int SPMM_ROWS = ROWS;
     __shared__ int s_rp[SPMM_ROWS + 1];
     __shared__ int s_col[SPMM_SEG_CAP];
     __shared__ float s_val[SPMM_SEG_CAP];
@@ -70,7 +80,7 @@ __global__ __launch_bounds__(SPMM_THREADS) void spmm_wave_row_kernel(
         const int js = s_rp[r] - seg0;
         const int je = s_rp[r + 1] - seg0;
         const size_t orow = out_base + (size_t)(row0 + r) * F4;
-        for (int cb = 0; cb < F4; cb += 64 * VPT) {
+        for (int cb = blockIdx.z * 64 * VPT; cb < F4; cb += gridDim.z * 64 * VPT) {
             float4 acc[VPT];
 #pragma unroll
             for (int p = 0; p < VPT; ++p) acc[p] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -131,7 +141,12 @@ __global__ __launch_bounds__(SPMM_THREADS) void spmm_wave_row_kernel(
                         o.z = fmaf(beta, y0.z, o.z);
                         o.w = fmaf(beta, y0.w, o.w);
                     }
-                    Y[orow + ch] = o;
+                    if (NT) {
+                        using v4f = __attribute__((ext_vector_type(4))) float;
+                        __builtin_nontemporal_store(v4f{o.x, o.y, o.z, o.w}, reinterpret_cast<v4f*>(&Y[orow + ch]));
+                    } else {
+                        Y[orow + ch] = o;
+                    }
                 }
             }
         }
@@ -209,18 +224,32 @@ extern "C" int stc_csr_spmm_f32(const int32_t* rowptr, const int32_t* colidx, co
     const bool vec = (F % 4 == 0) && stc::aligned16(X) && stc::aligned16(Y) && (Y0 == nullptr || stc::aligned16(Y0)) && F >= 64;
     if (vec) {
         const int F4 = F / 4;
-        const int n_tiles = (n_rows + SPMM_ROWS - 1) / SPMM_ROWS;
-        const int per = (n_tiles + stc::kNumXcd - 1) / stc::kNumXcd;
-        dim3 grid(per * stc::kNumXcd, batch), block(SPMM_THREADS);
         const float4* X4 = reinterpret_cast<const float4*>(X);
         const float4* Y04 = reinterpret_cast<const float4*>(Y0);
         float4* Y4 = reinterpret_cast<float4*>(Y);
-        if (F4 <= 64)
-            hipLaunchKernelGGL(spmm_wave_row_kernel<1>, grid, block, 0, s, rowptr, colidx, val, n_rows, n_cols, X4, Y04, Y4, F4, alpha, beta, n_tiles);
-        else if (F4 <= 128)
-            hipLaunchKernelGGL(spmm_wave_row_kernel<2>, grid, block, 0, s, rowptr, colidx, val, n_rows, n_cols, X4, Y04, Y4, F4, alpha, beta, n_tiles);
-        else
-            hipLaunchKernelGGL(spmm_wave_row_kernel<4>, grid, block, 0, s, rowptr, colidx, val, n_rows, n_cols, X4, Y04, Y4, F4, alpha, beta, n_tiles);
+        // STC_SPMM_VARIANT (A/B runs): 0 = whole rows, 8 rows per workgroup; 1 = 1 KiB column blocks (grid.z);
+        // 2 = whole rows, 16 rows per workgroup; +10 = non-temporal stores
+        static const int variant = [] { const char* e = std::getenv("STC_SPMM_VARIANT"); return e ? std::atoi(e) : STC_SPMM_DEFAULT_VARIANT; }();
+        const bool nt = variant >= 10;
+        const int shape = variant % 10;
+#define STC_SPMM_LAUNCH(VPT_, ROWS_, NT_, GZ_)                                                                          \
+    do {                                                                                                               \
+        const int n_tiles = (n_rows + ROWS_ - 1) / ROWS_;                                                              \
+        const int per = (n_tiles + stc::kNumXcd - 1) / stc::kNumXcd;                                                   \
+        dim3 grid(per * stc::kNumXcd, batch, GZ_), block(SPMM_THREADS);                                                \
+        hipLaunchKernelGGL((spmm_wave_row_kernel<VPT_, ROWS_, NT_>), grid, block, 0, s, rowptr, colidx, val, n_rows,   \
+                           n_cols, X4, Y04, Y4, F4, alpha, beta, n_tiles);                                             \
+    } while (0)
+#define STC_SPMM_BY_NT(VPT_, ROWS_, GZ_) do { if (nt) STC_SPMM_LAUNCH(VPT_, ROWS_, true, GZ_); else STC_SPMM_LAUNCH(VPT_, ROWS_, false, GZ_); } while (0)
+        if (shape == 1 && F4 > 64) {
+            STC_SPMM_BY_NT(1, 8, (F4 + 63) / 64);
+        } else if (shape == 2) {
+            if (F4 <= 64) STC_SPMM_BY_NT(1, 16, 1); else if (F4 <= 128) STC_SPMM_BY_NT(2, 16, 1); else STC_SPMM_BY_NT(4, 16, 1);
+        } else {
+            if (F4 <= 64) STC_SPMM_BY_NT(1, 8, 1); else if (F4 <= 128) STC_SPMM_BY_NT(2, 8, 1); else STC_SPMM_BY_NT(4, 8, 1);
+        }
+#undef STC_SPMM_BY_NT
+#undef STC_SPMM_LAUNCH
     } else {
         const int lanes = next_pow2(F) < SPMM_THREADS ? next_pow2(F) : SPMM_THREADS;
         const int rows_per_block = SPMM_THREADS / lanes;

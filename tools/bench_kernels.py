@@ -36,13 +36,15 @@ def main():
     ap.add_argument('--B', type=int, default=1)
     ap.add_argument('--iters', type=int, default=30)
     ap.add_argument('--permute', action='store_true')
+    ap.add_argument('--only', default='', help="'spmm' = just the SpMM lines")
     a = ap.parse_args()
     hip = HipKernels()
     dev = torch.device('cuda')
     N, C, h, K, B = a.grid ** 2, a.C, a.h, a.K, a.B
     g = CsrGraph.queen_grid(a.grid, a.grid, permute_seed=1234 if a.permute else None, device=dev).on(dev)
     nnz = g['fwd_colidx'].numel()
-    print(f'# N={N} nnz={nnz} C={C} h={h} K={K} B={B} permute={a.permute} MFMA={"off" if os.environ.get("STC_DISABLE_MFMA") == "1" else "on"}')
+    print(f'# N={N} nnz={nnz} C={C} h={h} K={K} B={B} permute={a.permute} MFMA={"off" if os.environ.get("STC_DISABLE_MFMA") == "1" else "on"} '
+          f'SPMM_VARIANT={os.environ.get("STC_SPMM_VARIANT", "default")}')
 
     def report(name, us, nbytes):
         print(f'{name:34s} {us:9.1f} us   {nbytes/1e6:9.1f} MB   {nbytes/us/1e3:8.1f} GB/s', flush=True)
@@ -55,6 +57,8 @@ def main():
         report(f'spmm fwd F={F}', us, nnz * 8 + 4 * (N + 1) + 2 * B * N * F * 4)
         us = timeit(lambda: hip.csr_spmm(g['bwd_rowptr'], g['bwd_colidx'], g['bwd_val'], N, N, X, Y, Y, 1.0, 1.0), a.iters)
         report(f'spmm bwd F={F} (+=, in place)', us, nnz * 8 + 4 * (N + 1) + 3 * B * N * F * 4)
+        if a.only == 'spmm':
+            continue
         Tc = torch.softmax(torch.randn(K, C, C, device=dev), -1)
         Tc[0] = torch.eye(C, device=dev)
         for Ho in (2 * h, h):
@@ -69,6 +73,8 @@ def main():
             dW, db = torch.empty_like(W), torch.empty_like(b)
             us = timeit(lambda: hip.bdg_node_bwd(Zs, Tc, W, dY, dZs, dW, db, None), a.iters)
             report(f'node bwd L={L} Ho={Ho}', us, (2 * K * L + Ho) * B * N * C * 4)
+    if a.only == 'spmm':
+        return
     rows = (B, N, C)
     G = torch.randn(*rows, 2 * h, device=dev)
     Xt = torch.randn(*rows, h, device=dev)
