@@ -21,7 +21,7 @@
 #include <cstdlib>
 
 #ifndef STC_SPMM_DEFAULT_VARIANT
-#define STC_SPMM_DEFAULT_VARIANT 0
+#define STC_SPMM_DEFAULT_VARIANT 10
 #endif
 
 namespace {
@@ -135,7 +135,14 @@ __global__ __launch_bounds__(SPMM_THREADS) void spmm_wave_row_kernel(
                 if (ch < F4) {
                     float4 o = make_float4(alpha * acc[p].x, alpha * acc[p].y, alpha * acc[p].z, alpha * acc[p].w);
                     if (beta != 0.f) {
-                        const float4 y0 = Y0[orow + ch];
+                        float4 y0;
+                        if (NT) {   // read once (often the very line this thread overwrites): keep it out of the gather's L2
+                            using v4f = __attribute__((ext_vector_type(4))) float;
+                            const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(&Y0[orow + ch]));
+                            y0 = make_float4(t[0], t[1], t[2], t[3]);
+                        } else {
+                            y0 = Y0[orow + ch];
+                        }
                         o.x = fmaf(beta, y0.x, o.x);
                         o.y = fmaf(beta, y0.y, o.y);
                         o.z = fmaf(beta, y0.z, o.z);
