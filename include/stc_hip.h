@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define STC_ABI_VERSION 2
+#define STC_ABI_VERSION 3
 #define STC_MAX_K 4          /* highest Chebyshev order (Ks, Kc) the node kernels accept */
 
 #define STC_OK 0
@@ -103,8 +103,10 @@ int stc_bdg_node_bwd_f32(const float* const* Z, int32_t Ks, const float* Tc, int
 int stc_gru_gates_fwd_f32(const float* G, const float* Xt, const float* H,
                           float* U, float* Rg, float* CandIn,
                           int64_t rows, int32_t cin, int32_t h, int32_t pad, void* stream);
+/* dH_in (rows, h) or NULL: a gradient already owed to H by another consumer (the blend), added into dH
+ * so that autograd does not need a separate accumulation pass; may alias dH. */
 int stc_gru_gates_bwd_f32(const float* dCandIn, const float* dU, const float* H,
-                          const float* U, const float* Rg,
+                          const float* U, const float* Rg, const float* dH_in,
                           float* dG, float* dXt, float* dH,
                           int64_t rows, int32_t cin, int32_t h, int32_t pad, void* stream);
 /* blend:  Cand = tanh(Cpre); Hnew = (1-U)*H + U*Cand      (n = rows*h elements) */
@@ -119,7 +121,8 @@ int stc_axpy_f32(float a, const float* x, float* y, int64_t n, void* stream);
 /* out (rows, a+b+pad) = [A (rows,a) | B (rows,b) | zeros]   (torch.cat of STC_GNN.py:68) and its inverse */
 int stc_concat2_f32(const float* A, const float* B, float* out,
                     int64_t rows, int32_t a, int32_t b, int32_t pad, void* stream);
-int stc_split2_f32(const float* src, float* A, float* B,
+/* split: A = src[:, :a] (+ addA), B = src[:, a:a+b] (+ addB); addA/addB may be NULL and may alias A/B */
+int stc_split2_f32(const float* src, const float* addA, const float* addB, float* A, float* B,
                    int64_t rows, int32_t a, int32_t b, int32_t pad, void* stream);
 
 #ifdef __cplusplus

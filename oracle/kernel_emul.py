@@ -132,14 +132,14 @@ class EmulatedKernels:
         CandIn[..., cin:cin + h].copy_(Rg * H)
         CandIn[..., cin + h:].zero_()                      # optional zero padding up to the row width
 
-    def gru_gates_bwd(self, dCandIn, dU, H, U, Rg, dG, dXt, dH):
+    def gru_gates_bwd(self, dCandIn, dU, H, U, Rg, dG, dXt, dH, dH_in=None):
         h = H.shape[-1]
         cin = dXt.shape[-1]
         dRH = dCandIn[..., cin:cin + h]
         dG[..., :h].copy_(dU * U * (1 - U))
         dG[..., h:].copy_(dRH * H * Rg * (1 - Rg))
         dXt.copy_(dCandIn[..., :cin])
-        dH.copy_(dRH * Rg)
+        dH.copy_(dRH * Rg + (dH_in if dH_in is not None else 0))
 
     # ---- stc_gru_blend_fwd/bwd_f32: tanh + GRU blend (STC_GNN.py:76-78)
     def gru_blend_fwd(self, Cpre, U, H, Cand, Hnew):
@@ -162,7 +162,7 @@ class EmulatedKernels:
         out[..., a:a + b].copy_(Bm)
         out[..., a + b:].zero_()
 
-    def split2(self, src, A, Bm):
+    def split2(self, src, A, Bm, addA=None, addB=None):
         a, b = A.shape[-1], Bm.shape[-1]
-        A.copy_(src[..., :a])
-        Bm.copy_(src[..., a:a + b])
+        A.copy_(src[..., :a] + (addA if addA is not None else 0))
+        Bm.copy_(src[..., a:a + b] + (addB if addB is not None else 0))

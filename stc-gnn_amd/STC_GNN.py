@@ -107,6 +107,11 @@ class STC_Cell(nn.Module):
     def forward(self, Gs: GraphLike, Gc: Optional[torch.Tensor], Xt: torch.Tensor, Ht_1: torch.Tensor):
         assert Xt.dim() == 4 and Ht_1.dim() == 4, 'STC-cell must take in 4D tensor as input [Xt, Ht-1]'
         pair = _graphs(Gs, Gc, self.gates.Ks, self.gates.Kc)
+        if self.gates.activation is None and self.candi.activation is None:       # always, in the reference's use
+            g, c = self.gates, self.candi
+            return ops.stc_cell(Xt, Ht_1, pair.spatial, pair.Tc, g.W, g.b if g.use_bias else None,
+                                c.W, c.b if c.use_bias else None, g.Ks)
+        # a BDG_Dif activation sits between the convolution and the gate math: composed path
         # feature rows are padded with zeros to a multiple of 4 floats (in + hidden = 17 -> 20) so that every
         # (node, category) row is 16-byte aligned for the vector / MFMA kernels; W keeps its reference shape
         pad = -(Xt.shape[-1] + Ht_1.shape[-1]) % 4

@@ -44,8 +44,8 @@ __global__ __launch_bounds__(EW_THREADS) void gru_gates_fwd_kernel(
 
 __global__ __launch_bounds__(EW_THREADS) void gru_gates_bwd_kernel(
     const float* __restrict__ dCandIn, const float* __restrict__ dU, const float* __restrict__ H,
-    const float* __restrict__ U, const float* __restrict__ Rg,
-    float* __restrict__ dG, float* __restrict__ dXt, float* __restrict__ dH,
+    const float* __restrict__ U, const float* __restrict__ Rg, const float* dH_in,
+    float* __restrict__ dG, float* __restrict__ dXt, float* dH,
     long long rows, int cin, int h, int pad) {
     const int L = cin + h + pad;
     const long long n = rows * L;
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(EW_THREADS) void gru_gates_bwd_kernel(
             const float u = U[i], g = Rg[i], d = dCandIn[e];
             dG[r * 2 * h + k] = dU[i] * u * (1.f - u);
             dG[r * 2 * h + h + k] = d * H[i] * g * (1.f - g);
-            dH[i] = d * g;
+            dH[i] = dH_in ? fmaf(d, g, dH_in[i]) : d * g;
         }
     }
 }
@@ -120,8 +120,8 @@ __global__ __launch_bounds__(EW_THREADS) void gru_gates_fwd_vec_kernel(
 
 __global__ __launch_bounds__(EW_THREADS) void gru_gates_bwd_vec_kernel(
     const float4* __restrict__ dCandIn, const float4* __restrict__ dU, const float4* __restrict__ H,
-    const float4* __restrict__ U, const float4* __restrict__ Rg,
-    float4* __restrict__ dG, float4* __restrict__ dXt, float4* __restrict__ dH,
+    const float4* __restrict__ U, const float4* __restrict__ Rg, const float4* dH_in,
+    float4* __restrict__ dG, float4* __restrict__ dXt, float4* dH,
     long long rows, int cin4, int h4, int pad4) {
     const int L4 = cin4 + h4 + pad4;
     const long long n = rows * L4;
@@ -137,7 +137,9 @@ __global__ __launch_bounds__(EW_THREADS) void gru_gates_bwd_vec_kernel(
             dG[r * 2 * h4 + k] = make_float4(du.x * u.x * (1.f - u.x), du.y * u.y * (1.f - u.y), du.z * u.z * (1.f - u.z), du.w * u.w * (1.f - u.w));
             dG[r * 2 * h4 + h4 + k] = make_float4(d.x * hh.x * g.x * (1.f - g.x), d.y * hh.y * g.y * (1.f - g.y),
                                                   d.z * hh.z * g.z * (1.f - g.z), d.w * hh.w * g.w * (1.f - g.w));
-            dH[i] = mul4(d, g);
+            float4 o = mul4(d, g);
+            if (dH_in) { const float4 p = dH_in[i]; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+            dH[i] = o;
         }
     }
 }
@@ -178,15 +180,22 @@ __global__ __launch_bounds__(EW_THREADS) void concat2_vec_kernel(const float4* _
     }
 }
 
-__global__ __launch_bounds__(EW_THREADS) void split2_vec_kernel(const float4* __restrict__ src, float4* __restrict__ A,
-                                                                 float4* __restrict__ B, long long rows, int a4, int b4, int pad4) {
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+__global__ __launch_bounds__(EW_THREADS) void split2_vec_kernel(const float4* __restrict__ src, const float4* addA, const float4* addB,
+                                                                 float4* A, float4* B, long long rows, int a4, int b4, int pad4) {
     const int L4 = a4 + b4 + pad4;
     const long long n = rows * L4;
     for (long long e = (long long)blockIdx.x * EW_THREADS + threadIdx.x; e < n; e += (long long)gridDim.x * EW_THREADS) {
         const long long r = e / L4;
         const int l = (int)(e - r * L4);
-        if (l < a4) A[r * a4 + l] = src[e];
-        else if (l < a4 + b4) B[r * b4 + (l - a4)] = src[e];
+        if (l < a4) {
+            const long long i = r * a4 + l;
+            A[i] = addA ? add4(src[e], addA[i]) : src[e];
+        } else if (l < a4 + b4) {
+            const long long i = r * b4 + (l - a4);
+            B[i] = addB ? add4(src[e], addB[i]) : src[e];
+        }
     }
 }
 
@@ -216,15 +225,20 @@ __global__ __launch_bounds__(EW_THREADS) void concat2_kernel(const float* __rest
     }
 }
 
-__global__ __launch_bounds__(EW_THREADS) void split2_kernel(const float* __restrict__ src, float* __restrict__ A,
-                                                             float* __restrict__ B, long long rows, int a, int b, int pad) {
+__global__ __launch_bounds__(EW_THREADS) void split2_kernel(const float* __restrict__ src, const float* addA, const float* addB,
+                                                             float* A, float* B, long long rows, int a, int b, int pad) {
     const int L = a + b + pad;
     const long long n = rows * L;
     for (long long e = (long long)blockIdx.x * EW_THREADS + threadIdx.x; e < n; e += (long long)gridDim.x * EW_THREADS) {
         const long long r = e / L;
         const int l = (int)(e - r * L);
-        if (l < a) A[r * a + l] = src[e];
-        else if (l < a + b) B[r * b + (l - a)] = src[e];
+        if (l < a) {
+            const long long i = r * a + l;
+            A[i] = addA ? src[e] + addA[i] : src[e];
+        } else if (l < a + b) {
+            const long long i = r * b + (l - a);
+            B[i] = addB ? src[e] + addB[i] : src[e];
+        }
     }
 }
 
@@ -294,15 +308,16 @@ extern "C" int stc_gru_gates_fwd_f32(const float* G, const float* Xt, const floa
 }
 
 extern "C" int stc_gru_gates_bwd_f32(const float* dCandIn, const float* dU, const float* H, const float* U, const float* Rg,
-                                     float* dG, float* dXt, float* dH, int64_t rows, int32_t cin, int32_t h, int32_t pad, void* stream) {
+                                     const float* dH_in, float* dG, float* dXt, float* dH,
+                                     int64_t rows, int32_t cin, int32_t h, int32_t pad, void* stream) {
     STC_REQUIRE(cin >= 0 && h >= 1 && pad >= 0, STC_EINVAL, "stc_gru_gates_bwd_f32: bad widths cin=%d h=%d pad=%d", cin, h, pad);
     STC_EW_PROLOGUE("stc_gru_gates_bwd_f32", rows, dCandIn && dU && H && U && Rg && dG && dH && (cin == 0 || dXt));
     const long long n = (long long)rows * (cin + h + pad);
-    if (vec_ok({dCandIn, dU, H, U, Rg, dG, dXt, dH}, {cin, h, pad}))
+    if (vec_ok({dCandIn, dU, H, U, Rg, dH_in, dG, dXt, dH}, {cin, h, pad}))
         hipLaunchKernelGGL(gru_gates_bwd_vec_kernel, ew_grid(n / 4), dim3(EW_THREADS), 0, s, F4C(dCandIn), F4C(dU), F4C(H), F4C(U), F4C(Rg),
-                           F4M(dG), F4M(dXt), F4M(dH), (long long)rows, cin / 4, h / 4, pad / 4);
+                           F4C(dH_in), F4M(dG), F4M(dXt), F4M(dH), (long long)rows, cin / 4, h / 4, pad / 4);
     else
-        hipLaunchKernelGGL(gru_gates_bwd_kernel, ew_grid(n), dim3(EW_THREADS), 0, s, dCandIn, dU, H, U, Rg, dG, dXt, dH, (long long)rows, cin, h, pad);
+        hipLaunchKernelGGL(gru_gates_bwd_kernel, ew_grid(n), dim3(EW_THREADS), 0, s, dCandIn, dU, H, U, Rg, dH_in, dG, dXt, dH, (long long)rows, cin, h, pad);
     STC_LAUNCH_CHECK("stc_gru_gates_bwd_f32 launch");
     return STC_OK;
 }
@@ -349,14 +364,16 @@ extern "C" int stc_concat2_f32(const float* A, const float* B, float* out, int64
     return STC_OK;
 }
 
-extern "C" int stc_split2_f32(const float* src, float* A, float* B, int64_t rows, int32_t a, int32_t b, int32_t pad, void* stream) {
+extern "C" int stc_split2_f32(const float* src, const float* addA, const float* addB, float* A, float* B,
+                              int64_t rows, int32_t a, int32_t b, int32_t pad, void* stream) {
     STC_REQUIRE(a >= 0 && b >= 0 && pad >= 0, STC_EINVAL, "stc_split2_f32: negative width");
     const long long n = (long long)rows * (a + b + pad);
     STC_EW_PROLOGUE("stc_split2_f32", n, src && (a == 0 || A) && (b == 0 || B));
-    if (vec_ok({src, A, B}, {a, b, pad}))
-        hipLaunchKernelGGL(split2_vec_kernel, ew_grid(n / 4), dim3(EW_THREADS), 0, s, F4C(src), F4M(A), F4M(B), (long long)rows, a / 4, b / 4, pad / 4);
+    if (vec_ok({src, addA, addB, A, B}, {a, b, pad}))
+        hipLaunchKernelGGL(split2_vec_kernel, ew_grid(n / 4), dim3(EW_THREADS), 0, s, F4C(src), F4C(addA), F4C(addB), F4M(A), F4M(B),
+                           (long long)rows, a / 4, b / 4, pad / 4);
     else
-        hipLaunchKernelGGL(split2_kernel, ew_grid(n), dim3(EW_THREADS), 0, s, src, A, B, (long long)rows, a, b, pad);
+        hipLaunchKernelGGL(split2_kernel, ew_grid(n), dim3(EW_THREADS), 0, s, src, addA, addB, A, B, (long long)rows, a, b, pad);
     STC_LAUNCH_CHECK("stc_split2_f32 launch");
     return STC_OK;
 }

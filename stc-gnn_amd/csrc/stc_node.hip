@@ -305,14 +305,23 @@ __global__ __launch_bounds__(NODE_THREADS) void bdg_node_bwd_kernel(
         out[nW + d.Ho + idx] = (want_dT && idx >= CC) ? dTacc[idx - CC] : 0.f;
 }
 
-// Fixed-order sum of the per-workgroup partials into dW | db | dT.
+// Fixed-order sum of the per-workgroup partials into dW | db | dT.  16 output elements per workgroup,
+// 16 thread groups each summing every 16th partial row, then a fixed-order combine through LDS:
+// bitwise reproducible, and wide enough (stride/16 workgroups) to take microseconds, not 100+.
+constexpr int RED_ELEMS = 16, RED_GROUPS = NODE_THREADS / RED_ELEMS;
 __global__ __launch_bounds__(NODE_THREADS) void bdg_node_reduce_kernel(
     const float* __restrict__ partial, int n_parts, int stride, int nW, int Ho, int nT,
     float* dW, float* db, float* dT) {
-    const int e = blockIdx.x * NODE_THREADS + threadIdx.x;
-    if (e >= stride) return;
+    __shared__ float red[RED_GROUPS][RED_ELEMS];
+    const int le = threadIdx.x % RED_ELEMS, g = threadIdx.x / RED_ELEMS;
+    const int e = blockIdx.x * RED_ELEMS + le;
     float s = 0.f;
-    for (int p = 0; p < n_parts; ++p) s += partial[(size_t)p * stride + e];
+    if (e < stride)
+        for (int p = g; p < n_parts; p += RED_GROUPS) s += partial[(size_t)p * stride + e];
+    red[g][le] = s;
+    __syncthreads();
+    if (g != 0 || e >= stride) return;
+    for (int k = 1; k < RED_GROUPS; ++k) s += red[k][le];
     if (e < nW) dW[e] = s;
     else if (e < nW + Ho) { if (db) db[e - nW] = s; }
     else if (dT) dT[e - nW - Ho] = s;
@@ -409,7 +418,7 @@ extern "C" int stc_bdg_node_bwd_f32(const float* const* Z, int32_t Ks, const flo
         const int rc = stc_node_bwd_mfma(Z, Ks, Tc, Kc, W, dY, dZ, partial, &n_parts, db != nullptr, nodes, C, L, Lw, Ho, s);
         if (rc == STC_OK) {
             const int stride = nW + Ho;
-            hipLaunchKernelGGL(bdg_node_reduce_kernel, dim3((stride + NODE_THREADS - 1) / NODE_THREADS), dim3(NODE_THREADS), 0, s,
+            hipLaunchKernelGGL(bdg_node_reduce_kernel, dim3((stride + RED_ELEMS - 1) / RED_ELEMS), dim3(NODE_THREADS), 0, s,
                                partial, n_parts, stride, nW, Ho, 0, dW, db, static_cast<float*>(nullptr));
             STC_LAUNCH_CHECK("stc_bdg_node_reduce launch");
             return STC_OK;
@@ -430,7 +439,7 @@ extern "C" int stc_bdg_node_bwd_f32(const float* const* Z, int32_t Ks, const flo
                        zp, Tc, W, dY, dzp, partial, (long long)nodes * C, d, cv, (int)n_tiles, (int)want_dT, (int)(db != nullptr));
     STC_LAUNCH_CHECK("stc_bdg_node_bwd_f32 launch");
     const int stride = nW + Ho + nT;
-    hipLaunchKernelGGL(bdg_node_reduce_kernel, dim3((stride + NODE_THREADS - 1) / NODE_THREADS), dim3(NODE_THREADS), 0, s,
+    hipLaunchKernelGGL(bdg_node_reduce_kernel, dim3((stride + RED_ELEMS - 1) / RED_ELEMS), dim3(NODE_THREADS), 0, s,
                        partial, grid, stride, nW, Ho, nT, dW, db, dTc);
     STC_LAUNCH_CHECK("stc_bdg_node_reduce launch");
     return STC_OK;

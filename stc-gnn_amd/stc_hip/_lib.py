@@ -19,7 +19,7 @@ import torch
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG_ROOT, 'libstc_hip.so')
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_K = 4
 
 #: every symbol ``include/stc_hip.h`` declares (the CPU test-suite checks the .so exports them all)
@@ -57,12 +57,12 @@ def _declare(lib):
         'stc_bdg_node_bwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, C.POINTER(_p), _p, _p, _p,
                                  _p, C.c_size_t, _i64, _i32, _i32, _i32, _i32, _p],
         'stc_gru_gates_fwd_f32': [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p],
-        'stc_gru_gates_bwd_f32': [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p],
+        'stc_gru_gates_bwd_f32': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p],
         'stc_gru_blend_fwd_f32': [_p, _p, _p, _p, _p, _i64, _p],
         'stc_gru_blend_bwd_f32': [_p, _p, _p, _p, _p, _p, _p, _i64, _p],
         'stc_axpy_f32': [_f32, _p, _p, _i64, _p],
         'stc_concat2_f32': [_p, _p, _p, _i64, _i32, _i32, _i32, _p],
-        'stc_split2_f32': [_p, _p, _p, _i64, _i32, _i32, _i32, _p],
+        'stc_split2_f32': [_p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p],
     }
     for name, argtypes in sig.items():
         fn = getattr(lib, name)
@@ -295,18 +295,18 @@ class HipKernels:
                 raise StcError(f'gates.{name}: shape {tuple(t.shape)} does not match rows={rows}, width={w}')
         self._launch('stc_gru_gates_fwd_f32', H, _ptr(G), _ptr(Xt), _ptr(H), _ptr(U), _ptr(Rg), _ptr(CandIn), rows, cin, h, pad)
 
-    def gru_gates_bwd(self, dCandIn, dU, H, U, Rg, dG, dXt, dH):
+    def gru_gates_bwd(self, dCandIn, dU, H, U, Rg, dG, dXt, dH, dH_in=None):
         rows, h = H.shape[:-1].numel(), H.shape[-1]
         cin = dXt.shape[-1]
         pad = dCandIn.shape[-1] - cin - h
         if pad < 0:
             raise StcError(f'gates_bwd.dCandIn: width {dCandIn.shape[-1]} < cin + h = {cin + h}')
         for name, t, w in (('dCandIn', dCandIn, cin + h + pad), ('dU', dU, h), ('H', H, h), ('U', U, h), ('Rg', Rg, h),
-                           ('dG', dG, 2 * h), ('dXt', dXt, cin), ('dH', dH, h)):
+                           ('dG', dG, 2 * h), ('dXt', dXt, cin), ('dH', dH, h)) + ((('dH_in', dH_in, h),) if dH_in is not None else ()):
             self._f32('gates_bwd.' + name, t)
             if t.shape[-1] != w or t.numel() != rows * w:
                 raise StcError(f'gates_bwd.{name}: shape {tuple(t.shape)} does not match rows={rows}, width={w}')
-        self._launch('stc_gru_gates_bwd_f32', H, _ptr(dCandIn), _ptr(dU), _ptr(H), _ptr(U), _ptr(Rg), _ptr(dG), _ptr(dXt), _ptr(dH), rows, cin, h, pad)
+        self._launch('stc_gru_gates_bwd_f32', H, _ptr(dCandIn), _ptr(dU), _ptr(H), _ptr(U), _ptr(Rg), _ptr(dH_in), _ptr(dG), _ptr(dXt), _ptr(dH), rows, cin, h, pad)
 
     def _same_numel(self, what, *ts):
         n = ts[0].numel()
@@ -345,6 +345,9 @@ class HipKernels:
         rows, a, b, pad = self._cat_shapes('concat2', A, Bm, out)
         self._launch('stc_concat2_f32', out, _ptr(A), _ptr(Bm), _ptr(out), rows, a, b, pad)
 
-    def split2(self, src, A, Bm):
+    def split2(self, src, A, Bm, addA=None, addB=None):
         rows, a, b, pad = self._cat_shapes('split2', A, Bm, src)
-        self._launch('stc_split2_f32', src, _ptr(src), _ptr(A), _ptr(Bm), rows, a, b, pad)
+        for name, t, like in (('addA', addA, A), ('addB', addB, Bm)):
+            if t is not None:
+                self._f32('split2.' + name, t, like.shape)
+        self._launch('stc_split2_f32', src, _ptr(src), _ptr(addA), _ptr(addB), _ptr(A), _ptr(Bm), rows, a, b, pad)

@@ -75,25 +75,60 @@ def cheby_dense(G: torch.Tensor, K: int) -> torch.Tensor:
 
 
 # ----------------------------------------------------------------------------- BDG_Dif
+def _bdg_forward(X, W, b, Tc, fwd_val, op: SpatialOperand, Ks: int):
+    """Launch sequence of one BDG_Dif forward on raw tensors; returns (Y, [Z_0..Z_{Ks-1}])."""
+    k = kernels()
+    B, N, C, L = X.shape
+    Ho = W.shape[1]
+    F = C * L
+    Zs = [X]
+    for order in range(1, Ks):
+        Zk = torch.empty_like(X)
+        if order == 1:
+            k.csr_spmm(op.fwd_rowptr, op.fwd_colidx, fwd_val, N, N, X.view(B, N, F), None, Zk.view(B, N, F), 1.0, 0.0)
+        else:
+            k.csr_spmm(op.fwd_rowptr, op.fwd_colidx, fwd_val, N, N, Zs[-1].view(B, N, F),
+                       Zs[-2].view(B, N, F), Zk.view(B, N, F), 2.0, -1.0)
+        Zs.append(Zk)
+    Y = X.new_empty(B, N, C, Ho)
+    k.bdg_node_fwd([z.view(B * N, C, L) for z in Zs], Tc, W, b, Y.view(B * N, C, Ho))
+    return Y, Zs
+
+
+def _bdg_backward(dY, Zs, W, Tc, op: SpatialOperand, Ks: int, has_bias: bool, need_X: bool, need_Tc: bool, need_val: bool):
+    """Launch sequence of one BDG_Dif backward; returns (dX | None, dW, db | None, dTc | None, dval | None)."""
+    k = kernels()
+    B, N, C, L = Zs[0].shape
+    Ho = W.shape[1]
+    F = C * L
+    dY = _c(dY)
+    dZ = [torch.empty_like(Zs[0]) for _ in range(Ks)]
+    dW = torch.empty_like(W)
+    db = W.new_empty(Ho) if has_bias else None
+    dTc = torch.empty_like(Tc) if need_Tc else None
+    k.bdg_node_bwd([z.view(B * N, C, L) for z in Zs], Tc, W, dY.view(B * N, C, Ho),
+                   [z.view(B * N, C, L) for z in dZ], dW, db, dTc)
+    dval = torch.zeros_like(op.fwd_val) if need_val else None
+    v3 = lambda t: t.view(B, N, F)
+    for order in range(Ks - 1, 1, -1):
+        k.csr_spmm(op.bwd_rowptr, op.bwd_colidx, op.bwd_val, N, N, v3(dZ[order]), v3(dZ[order - 1]),
+                   v3(dZ[order - 1]), 2.0, 1.0)
+        k.axpy(-1.0, dZ[order], dZ[order - 2])
+        if need_val:
+            k.csr_sddmm(op.fwd_rowptr, op.fwd_colidx, N, N, v3(dZ[order]), v3(Zs[order - 1]), dval, 2.0, True)
+    if Ks > 1:
+        if need_X:
+            k.csr_spmm(op.bwd_rowptr, op.bwd_colidx, op.bwd_val, N, N, v3(dZ[1]), v3(dZ[0]), v3(dZ[0]), 1.0, 1.0)
+        if need_val:
+            k.csr_sddmm(op.fwd_rowptr, op.fwd_colidx, N, N, v3(dZ[1]), v3(Zs[0]), dval, 1.0, True)
+    return (dZ[0] if need_X else None), dW, db, dTc, dval
+
+
 class _BdgDif(Function):
     @staticmethod
     def forward(ctx, X, W, b, Tc, fwd_val, op: SpatialOperand, Ks: int):
-        k = kernels()
         X, W, Tc, fwd_val = _c(X), _c(W), _c(Tc), _c(fwd_val)
-        B, N, C, L = X.shape
-        Ho = W.shape[1]
-        F = C * L
-        Zs = [X]
-        for order in range(1, Ks):
-            Zk = torch.empty_like(X)
-            if order == 1:
-                k.csr_spmm(op.fwd_rowptr, op.fwd_colidx, fwd_val, N, N, X.view(B, N, F), None, Zk.view(B, N, F), 1.0, 0.0)
-            else:
-                k.csr_spmm(op.fwd_rowptr, op.fwd_colidx, fwd_val, N, N, Zs[-1].view(B, N, F),
-                           Zs[-2].view(B, N, F), Zk.view(B, N, F), 2.0, -1.0)
-            Zs.append(Zk)
-        Y = X.new_empty(B, N, C, Ho)
-        k.bdg_node_fwd([z.view(B * N, C, L) for z in Zs], Tc, W, b, Y.view(B * N, C, Ho))
+        Y, Zs = _bdg_forward(X, W, b, Tc, fwd_val, op, Ks)
         ctx.save_for_backward(W, Tc, *Zs)
         ctx.op = op
         ctx.has_bias = b is not None
@@ -103,34 +138,10 @@ class _BdgDif(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, dY):
-        k = kernels()
         W, Tc, *Zs = ctx.saved_tensors
-        op, Ks = ctx.op, ctx.Ks
         need_X, _, _, need_Tc, need_val = ctx.needs_input_grad[:5]
-        B, N, C, L = Zs[0].shape
-        Ho = W.shape[1]
-        F = C * L
-        dY = _c(dY)
-        dZ = [torch.empty_like(Zs[0]) for _ in range(Ks)]
-        dW = torch.empty_like(W)
-        db = W.new_empty(Ho) if ctx.has_bias else None
-        dTc = torch.empty_like(Tc) if need_Tc else None
-        k.bdg_node_bwd([z.view(B * N, C, L) for z in Zs], Tc, W, dY.view(B * N, C, Ho),
-                       [z.view(B * N, C, L) for z in dZ], dW, db, dTc)
-        dval = torch.zeros_like(op.fwd_val) if need_val else None
-        v3 = lambda t: t.view(B, N, F)
-        for order in range(Ks - 1, 1, -1):
-            k.csr_spmm(op.bwd_rowptr, op.bwd_colidx, op.bwd_val, N, N, v3(dZ[order]), v3(dZ[order - 1]),
-                       v3(dZ[order - 1]), 2.0, 1.0)
-            k.axpy(-1.0, dZ[order], dZ[order - 2])
-            if need_val:
-                k.csr_sddmm(op.fwd_rowptr, op.fwd_colidx, N, N, v3(dZ[order]), v3(Zs[order - 1]), dval, 2.0, True)
-        if Ks > 1:
-            if need_X:
-                k.csr_spmm(op.bwd_rowptr, op.bwd_colidx, op.bwd_val, N, N, v3(dZ[1]), v3(dZ[0]), v3(dZ[0]), 1.0, 1.0)
-            if need_val:
-                k.csr_sddmm(op.fwd_rowptr, op.fwd_colidx, N, N, v3(dZ[1]), v3(Zs[0]), dval, 1.0, True)
-        return (dZ[0] if need_X else None), dW, db, dTc, dval, None, None
+        dX, dW, db, dTc, dval = _bdg_backward(dY, Zs, W, Tc, ctx.op, ctx.Ks, ctx.has_bias, need_X, need_Tc, need_val)
+        return dX, dW, db, dTc, dval, None, None
 
 
 def bdg_dif(X: torch.Tensor, op: SpatialOperand, Tc: torch.Tensor, W: torch.Tensor,
@@ -234,3 +245,73 @@ def concat2(A, Bm, pad: int = 0):
     if A.shape[:-1] != Bm.shape[:-1]:
         raise ValueError(f'concat2: leading shapes differ: {tuple(A.shape)} vs {tuple(Bm.shape)}')
     return _Concat2.apply(A, Bm, pad)
+
+
+# ----------------------------------------------------------------------------- whole STC_Cell
+class _StcCell(Function):
+    """One STC_Cell step (reference STC_GNN.py:65-79) as a single autograd node.
+
+    Same kernels as the composed path (concat2 -> bdg -> gru_gates -> bdg -> gru_blend); what it adds is
+    the backward bookkeeping: the three gradients owed to H (blend, reset gate, concat) and the two owed
+    to Xt are summed inside the gate / split kernels instead of by separate autograd accumulation passes,
+    and nothing but the slabs the backward really needs is kept (Z of both convolutions, U, R, Cand, H).
+    """
+
+    @staticmethod
+    def forward(ctx, Xt, H, Wg, bg, Wc, bc, Tc, fwd_val, op: SpatialOperand, Ks: int):
+        k = kernels()
+        Xt, H, Wg, Wc, Tc, fwd_val = _c(Xt), _c(H), _c(Wg), _c(Wc), _c(Tc), _c(fwd_val)
+        cin, h = Xt.shape[-1], H.shape[-1]
+        pad = -(cin + h) % 4                      # rows padded to 16 bytes (17 -> 20); W keeps its reference shape
+        lead = H.shape[:-1]
+        XH = H.new_empty(lead + (cin + h + pad,))
+        k.concat2(Xt, H, XH)
+        G, Zg = _bdg_forward(XH, Wg, bg, Tc, fwd_val, op, Ks)
+        U, Rg, CandIn = torch.empty_like(H), torch.empty_like(H), torch.empty_like(XH)
+        k.gru_gates_fwd(G, Xt, H, U, Rg, CandIn)
+        del G
+        Cpre, Zc = _bdg_forward(CandIn, Wc, bc, Tc, fwd_val, op, Ks)
+        Cand, Hnew = torch.empty_like(H), torch.empty_like(H)
+        k.gru_blend_fwd(Cpre, U, H, Cand, Hnew)
+        ctx.save_for_backward(H, U, Rg, Cand, Wg, Wc, Tc, *Zg, *Zc)
+        ctx.op, ctx.Ks, ctx.cin = op, Ks, cin
+        ctx.bias = (bg is not None, bc is not None)
+        return Hnew
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dHnew):
+        k = kernels()
+        H, U, Rg, Cand, Wg, Wc, Tc, *Z = ctx.saved_tensors
+        Ks, op, cin = ctx.Ks, ctx.op, ctx.cin
+        Zg, Zc = Z[:Ks], Z[Ks:]
+        need_Xt, need_H = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        need_Tc, need_val = ctx.needs_input_grad[6], ctx.needs_input_grad[7]
+        dCpre, dU, dH = torch.empty_like(H), torch.empty_like(H), torch.empty_like(H)
+        k.gru_blend_bwd(_c(dHnew), U, H, Cand, dCpre, dU, dH)                     # dH = dHnew * (1 - U)
+        dCandIn, dWc, dbc, dTc, dval = _bdg_backward(dCpre, Zc, Wc, Tc, op, Ks, ctx.bias[1], True, need_Tc, need_val)
+        dG = H.new_empty(H.shape[:-1] + (2 * H.shape[-1],))
+        dXt = H.new_empty(H.shape[:-1] + (cin,))
+        k.gru_gates_bwd(dCandIn, dU, H, U, Rg, dG, dXt, dH, dH_in=dH)             # dH += dCandIn[h part] * R ; dXt = dCandIn[x part]
+        dXH, dWg, dbg, dTc2, dval2 = _bdg_backward(dG, Zg, Wg, Tc, op, Ks, ctx.bias[0], need_Xt or need_H, need_Tc, need_val)
+        if need_Xt or need_H:
+            k.split2(dXH, dXt, dH, addA=dXt, addB=dH)                             # + the concat's share, in place
+        if need_Tc:
+            dTc = dTc + dTc2
+        if need_val:
+            dval = dval + dval2
+        return (dXt if need_Xt else None), (dH if need_H else None), dWg, dbg, dWc, dbc, dTc, dval, None, None
+
+
+def stc_cell(Xt, H, op: SpatialOperand, Tc, Wg, bg, Wc, bc, Ks: int):
+    """Ht of one STC_Cell step; gates / candidate BDG_Dif parameters in the reference's shapes."""
+    if Xt.dim() != 4 or H.dim() != 4 or Xt.shape[:-1] != H.shape[:-1]:
+        raise ValueError(f'stc_cell: Xt {tuple(Xt.shape)} and H {tuple(H.shape)} must be (B,N,C,*) with equal leading shape')
+    B, N, C, h = H.shape
+    L = Xt.shape[-1] + h
+    Kc = Tc.shape[0]
+    if N != op.n or Tc.shape[1] != C:
+        raise ValueError(f'stc_cell: graphs are for N={op.n}, C={Tc.shape[1]}; got N={N}, C={C}')
+    if Wg.shape != (Ks * Kc * L, 2 * h) or Wc.shape != (Ks * Kc * L, h):
+        raise ValueError(f'stc_cell: W shapes {tuple(Wg.shape)}, {tuple(Wc.shape)} do not match Ks*Kc*L={Ks * Kc * L}, h={h}')
+    return _StcCell.apply(Xt, H, Wg, bg, Wc, bc, Tc, op.fwd_val, op, Ks)

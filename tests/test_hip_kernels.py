@@ -281,6 +281,10 @@ def test_gru_gates_and_blend(hip, rows_shape, cin, h, pad):
     dG, dX, dH = torch.empty_like(G).cuda(), torch.empty_like(Xt).cuda(), torch.empty_like(H).cuda()
     hip.gru_gates_bwd(cu(dCi), cu(dU), cu(H), cu(U_w), cu(R_w), dG, dX, dH)
     assert rel_err(dG, dG_w) < TOL and rel_err(dX, dX_w) < TOL and rel_err(dH, dH_w) < TOL
+    owed = torch.randn(*rows_shape, h, generator=g)                 # a gradient already owed to H, accumulated in place
+    dH2 = owed.clone().cuda()
+    hip.gru_gates_bwd(cu(dCi), cu(dU), cu(H), cu(U_w), cu(R_w), dG, dX, dH2, dH_in=dH2)
+    assert rel_err(dH2, dH_w + owed) < TOL
 
     Cpre = torch.randn(*rows_shape, h, generator=g) * 2
     Cand_w, Hn_w = torch.empty_like(H), torch.empty_like(H)
@@ -315,6 +319,14 @@ def test_axpy_concat_split(hip):
     assert torch.equal(padded.cpu(), torch.cat([A, Bm, torch.zeros(4, 9, 3, 3)], -1))
     hip.split2(padded, A2, B2)
     assert torch.equal(A2.cpu(), A) and torch.equal(B2.cpu(), Bm)
+    hip.split2(padded, A2, B2, addA=A2, addB=B2)                  # accumulate into existing gradients, in place
+    assert torch.equal(A2.cpu(), 2 * A) and torch.equal(B2.cpu(), 2 * Bm)
+    A3, B3 = torch.randn(4, 9, 3, 4, generator=g), torch.randn(4, 9, 3, 16, generator=g)   # 16-byte path
+    whole = torch.empty(4, 9, 3, 20).cuda()
+    hip.concat2(cu(A3), cu(B3), whole)
+    oa, ob = torch.ones(4, 9, 3, 4).cuda(), torch.ones(4, 9, 3, 16).cuda()
+    hip.split2(whole, oa, ob, addA=oa, addB=None)
+    assert torch.equal(oa.cpu(), A3 + 1) and torch.equal(ob.cpu(), B3)
 
 
 # ------------------------------------------------------------------ full-size properties (N = 50 176)

@@ -113,6 +113,20 @@ def test_stc_cell_module(cin, K):
         _close(grads[k].grad, v, GRAD, 'd' + k)
 
 
+def test_stc_cell_composed_path_with_activation_module():
+    """A BDG_Dif activation (Identity here) routes the cell through the composed operator sequence."""
+    g = _golden('g2_cell_in4_k3')
+    B, N, C, h = g['Ht'].shape
+    cell = M.STC_Cell(N, C, 3, 3, 4, h, activation=torch.nn.Identity).to(DEV)
+    cell.load_state_dict(sub_dict(g, 'sd/'))
+    Xt, Ht, Gs, Gc = (_leaf(g[k]) for k in ('Xt', 'Ht', 'Gs', 'Gc'))
+    out = cell(Gs=Gs, Gc=Gc, Xt=Xt, Ht_1=Ht)
+    _close(out, g['Hout'], FWD, 'Ht (composed)')
+    (out * g['R']).sum().backward()
+    for name, leaf in (('dXt', Xt), ('dHt', Ht), ('dGs', Gs), ('dGc', Gc)):
+        _close(leaf.grad, g[name], GRAD, name + ' (composed)')
+
+
 def test_encoder_decoder_modules():
     g = _golden('g3_encdec')
     K, h, layers = int(g['K']), int(g['h']), int(g['layers'])
