@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define STC_ABI_VERSION 3
+#define STC_ABI_VERSION 4
 #define STC_MAX_K 4          /* highest Chebyshev order (Ks, Kc) the node kernels accept */
 
 #define STC_OK 0
@@ -114,6 +114,20 @@ int stc_gru_blend_fwd_f32(const float* Cpre, const float* U, const float* H,
                           float* Cand, float* Hnew, int64_t n, void* stream);
 int stc_gru_blend_bwd_f32(const float* dHnew, const float* U, const float* H, const float* Cand,
                           float* dCpre, float* dU, float* dH, int64_t n, void* stream);
+
+/* ---- output head (STC_GNN.py:182-183, 206) -----------------------------------
+ * The reference applies Linear(h, h/2) then Linear(h/2, 1) with NO nonlinearity in between, then a sigmoid:
+ * that is one affine map h -> 1.  The host folds the two layers into w (h) and b (1 element, device) with
+ * two tiny torch matmuls (which also route the gradient back to both layers) and these kernels do the
+ * streaming part:   y[r] = sigmoid( <H[r,:], w> + b[0] )            H (rows, h), y (rows)
+ * backward:         g = dy * y * (1 - y);  dH[r,:] = g[r] * w;  dw = sum_r g[r] H[r,:];  db = sum_r g[r]
+ * dwb (h + 1 floats: dw | db) is overwritten; workspace >= stc_head_bwd_workspace_bytes(h), 16-byte aligned. */
+int stc_head_fwd_f32(const float* H, const float* w, const float* b, float* y,
+                     int64_t rows, int32_t h, void* stream);
+size_t stc_head_bwd_workspace_bytes(int32_t h);
+int stc_head_bwd_f32(const float* H, const float* w, const float* y, const float* dy,
+                     float* dH, float* dwb, void* workspace, size_t workspace_bytes,
+                     int64_t rows, int32_t h, void* stream);
 
 /* ---- small helpers ---------------------------------------------------------
  * y += a*x over n elements (Chebyshev backward g_{k-2} -= g_k) */

@@ -151,6 +151,16 @@ class EmulatedKernels:
         dU.copy_(dHnew * (Cand - H))
         dH.copy_(dHnew * (1 - U))
 
+    # ---- stc_head_fwd/bwd_f32: the two bias-ful Linears of the output head folded into one map + sigmoid (STC_GNN.py:182-183, 206)
+    def head_fwd(self, H, w, b, y):
+        y.copy_(torch.sigmoid(H @ w + b))
+
+    def head_bwd(self, H, w, y, dy, dH, dwb):
+        g = dy * y * (1 - y)
+        dH.copy_(g.unsqueeze(-1) * w)
+        dwb[:-1].copy_((g.unsqueeze(-1) * H).reshape(-1, H.shape[-1]).sum(0))
+        dwb[-1] = g.sum()
+
     # ---- stc_axpy_f32: y += a*x (Chebyshev recurrence backward, g_{k-2} -= g_k)
     def axpy(self, a, x, y):
         y.add_(x, alpha=a)

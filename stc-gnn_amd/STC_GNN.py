@@ -145,23 +145,31 @@ class STC_Encoder(nn.Module):
 
     def forward(self, Gs: GraphLike, Gc: Optional[torch.Tensor], X_seq: torch.Tensor, H0_l=None):
         assert X_seq.dim() == 5, 'STC-encoder must take in 5D tensor as input X_seq'
+        per_layer, last = self._run(Gs, Gc, X_seq, H0_l)
+        seqs = [torch.stack(outs, dim=1) for outs in per_layer]        # (B, T, N, C, h) per layer, as the reference returns
+        if not self.return_all_layers:
+            return seqs[-1:], last[-1:]
+        return seqs, last
+
+    def _run(self, Gs, Gc, X_seq, H0_l=None):
+        """Layer-major, then time.  Layer l reads layer l-1's per-step outputs directly: the reference stacks them
+        and slices the stack again (STC_GNN.py:114-115, 111) -- same values, but every slice of a stacked
+        tensor costs autograd a full-size zero-fill + add in backward."""
         first = self.cell_list[0].gates
         pair = _graphs(Gs, Gc, first.Ks, first.Kc)
         steps = X_seq.shape[1]
         states = self._init_hidden(X_seq.shape[0]) if H0_l is None else H0_l
-        layer_in = X_seq
-        all_seq, all_last = [], []
+        layer_in = [X_seq[:, t] for t in range(steps)]
+        per_layer, last = [], []
         for cell, h in zip(self.cell_list, states):
             outs = []
-            for t in range(steps):
-                h = cell(pair, None, layer_in[:, t], h)
+            for x in layer_in:
+                h = cell(pair, None, x, h)
                 outs.append(h)
-            layer_in = torch.stack(outs, dim=1)                       # (B, T, N, C, h): next layer's input
-            all_seq.append(layer_in)
-            all_last.append(h)
-        if not self.return_all_layers:
-            return all_seq[-1:], all_last[-1:]
-        return all_seq, all_last
+            layer_in = outs
+            per_layer.append(outs)
+            last.append(h)
+        return per_layer, last
 
 
 class STC_Decoder(nn.Module):
@@ -270,11 +278,25 @@ class STCGNN(nn.Module):
         else:
             Gs, Gc = As, Ac
         pair = _graphs(Gs, Gc, self.Ks, self.Kc)
-        _, states = self.encoder(pair, None, X_seq.unsqueeze(-1))
+        _, states = self.encoder._run(pair, None, X_seq.unsqueeze(-1))     # per-layer output stacks are not needed here
         step_in = states[-1]
         outs = []
         for _ in range(self.decoder.out_horizon):
             step_in, states = self.decoder(pair, None, step_in, states)
             outs.append(step_in)
-        y = torch.sigmoid(self.out_proj(torch.stack(outs, dim=1)))
-        return y.squeeze(dim=-1)
+        return self._head(torch.stack(outs, dim=1))                      # (B, horizon, N, C)
+
+    def _head(self, H: torch.Tensor) -> torch.Tensor:
+        """sigmoid(out_proj(H)).squeeze(-1) (reference STC_GNN.py:206-207).  The two Linears have no nonlinearity
+        between them, so they are folded into one h -> 1 map (two tiny matmuls, differentiable) and the
+        streaming part runs in one fused HIP kernel instead of two skinny GEMMs."""
+        lin1, lin2 = self.out_proj[0], self.out_proj[1]
+        h = lin1.in_features
+        if lin2.out_features != 1 or h % 4 or h > 64:
+            return torch.sigmoid(self.out_proj(H)).squeeze(dim=-1)
+        w = (lin2.weight @ lin1.weight).reshape(h)
+        if lin1.bias is not None:
+            b = lin2.weight @ lin1.bias + lin2.bias
+        else:
+            b = w.new_zeros(1)
+        return ops.head(H, w, b)

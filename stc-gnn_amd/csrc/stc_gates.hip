@@ -209,6 +209,91 @@ inline bool vec_ok(std::initializer_list<const void*> ptrs, std::initializer_lis
 #define F4C(p) reinterpret_cast<const float4*>(p)
 #define F4M(p) reinterpret_cast<float4*>(p)
 
+// ---- output head: y = sigmoid(<H[r,:], w> + b)  (the reference's two bias-ful Linears folded into one map)
+constexpr int HEAD_MAX_H = 64;
+constexpr int HEAD_PARTS = 1024;
+
+__global__ __launch_bounds__(EW_THREADS) void head_fwd_kernel(const float* __restrict__ H, const float* __restrict__ w,
+                                                               const float* __restrict__ b, float* __restrict__ y,
+                                                               long long rows, int h) {
+    __shared__ float sw[HEAD_MAX_H + 1];
+    if ((int)threadIdx.x < h) sw[threadIdx.x] = w[threadIdx.x];
+    if (threadIdx.x == 0) sw[HEAD_MAX_H] = b[0];
+    __syncthreads();
+    const int h4 = h / 4;
+    for (long long r = (long long)blockIdx.x * EW_THREADS + threadIdx.x; r < rows; r += (long long)gridDim.x * EW_THREADS) {
+        const float4* row = reinterpret_cast<const float4*>(H + r * h);
+        float s = sw[HEAD_MAX_H];
+        for (int k = 0; k < h4; ++k) {
+            const float4 v = row[k];
+            s = fmaf(v.x, sw[4 * k], fmaf(v.y, sw[4 * k + 1], fmaf(v.z, sw[4 * k + 2], fmaf(v.w, sw[4 * k + 3], s))));
+        }
+        y[r] = sigmoidf_(s);
+    }
+}
+
+// dH = g * w (streamed); per-workgroup partial sums of dw | db in a fixed order -> workspace[block][h+1]
+__global__ __launch_bounds__(EW_THREADS) void head_bwd_kernel(const float* __restrict__ H, const float* __restrict__ w,
+                                                               const float* __restrict__ y, const float* __restrict__ dy,
+                                                               float* __restrict__ dH, float* __restrict__ partial,
+                                                               long long rows, int h) {
+    __shared__ float sw[HEAD_MAX_H];
+    __shared__ float red[EW_THREADS / 64][HEAD_MAX_H + 1];
+    if ((int)threadIdx.x < h) sw[threadIdx.x] = w[threadIdx.x];
+    __syncthreads();
+    const int h4 = h / 4;
+    float acc[HEAD_MAX_H + 1];
+#pragma unroll
+    for (int k = 0; k <= HEAD_MAX_H; ++k) acc[k] = 0.f;
+    for (long long r = (long long)blockIdx.x * EW_THREADS + threadIdx.x; r < rows; r += (long long)gridDim.x * EW_THREADS) {
+        const float yy = y[r];
+        const float g = dy[r] * yy * (1.f - yy);
+        const float4* row = reinterpret_cast<const float4*>(H + r * h);
+        float4* out = reinterpret_cast<float4*>(dH + r * h);
+        acc[HEAD_MAX_H] += g;
+#pragma unroll
+        for (int k = 0; k < HEAD_MAX_H / 4; ++k) {
+            if (k < h4) {
+                const float4 v = row[k];
+                out[k] = make_float4(g * sw[4 * k], g * sw[4 * k + 1], g * sw[4 * k + 2], g * sw[4 * k + 3]);
+                acc[4 * k] = fmaf(g, v.x, acc[4 * k]);
+                acc[4 * k + 1] = fmaf(g, v.y, acc[4 * k + 1]);
+                acc[4 * k + 2] = fmaf(g, v.z, acc[4 * k + 2]);
+                acc[4 * k + 3] = fmaf(g, v.w, acc[4 * k + 3]);
+            }
+        }
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k <= HEAD_MAX_H; ++k) {
+        if (k < h || k == HEAD_MAX_H) {
+            const float v = stc_wave_sum(acc[k]);
+            if (lane == 0) red[wave][k] = v;
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x <= h) {
+        const int k = (int)threadIdx.x < h ? threadIdx.x : HEAD_MAX_H;
+        float v = red[0][k];
+        for (int wv = 1; wv < EW_THREADS / 64; ++wv) v += red[wv][k];
+        partial[(size_t)blockIdx.x * (h + 1) + threadIdx.x] = v;
+    }
+}
+
+__global__ __launch_bounds__(EW_THREADS) void head_reduce_kernel(const float* __restrict__ partial, int n_parts, int stride, float* __restrict__ out) {
+    __shared__ float red[EW_THREADS];
+    const int e = blockIdx.x;                       // one output element per workgroup
+    float s = 0.f;
+    for (int p = threadIdx.x; p < n_parts; p += EW_THREADS) s += partial[(size_t)p * stride + e];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = EW_THREADS / 2; off > 0; off >>= 1) {      // fixed tree: bitwise reproducible
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[e] = red[0];
+}
+
 __global__ __launch_bounds__(EW_THREADS) void axpy_kernel(float a, const float* __restrict__ x, float* y, long long n) {
     for (long long e = (long long)blockIdx.x * EW_THREADS + threadIdx.x; e < n; e += (long long)gridDim.x * EW_THREADS)
         y[e] = fmaf(a, x[e], y[e]);
@@ -342,6 +427,37 @@ extern "C" int stc_gru_blend_bwd_f32(const float* dHnew, const float* U, const f
     else
         hipLaunchKernelGGL(gru_blend_bwd_kernel, ew_grid(n), dim3(EW_THREADS), 0, s, dHnew, U, H, Cand, dCpre, dU, dH, (long long)n);
     STC_LAUNCH_CHECK("stc_gru_blend_bwd_f32 launch");
+    return STC_OK;
+}
+
+
+extern "C" int stc_head_fwd_f32(const float* H, const float* w, const float* b, float* y, int64_t rows, int32_t h, void* stream) {
+    STC_REQUIRE(h >= 4 && h <= HEAD_MAX_H && h % 4 == 0, STC_ELIMIT, "stc_head_fwd_f32: h=%d must be a multiple of 4 in [4,%d]", h, HEAD_MAX_H);
+    STC_EW_PROLOGUE("stc_head_fwd_f32", rows, H && w && b && y);
+    STC_REQUIRE(stc::aligned16(H), STC_EALIGN, "stc_head_fwd_f32: H not 16-byte aligned");
+    hipLaunchKernelGGL(head_fwd_kernel, ew_grid(rows), dim3(EW_THREADS), 0, s, H, w, b, y, (long long)rows, h);
+    STC_LAUNCH_CHECK("stc_head_fwd_f32 launch");
+    return STC_OK;
+}
+
+extern "C" size_t stc_head_bwd_workspace_bytes(int32_t h) { return h < 1 ? 0 : (size_t)HEAD_PARTS * (h + 1) * sizeof(float); }
+
+extern "C" int stc_head_bwd_f32(const float* H, const float* w, const float* y, const float* dy, float* dH, float* dwb,
+                                void* workspace, size_t workspace_bytes, int64_t rows, int32_t h, void* stream) {
+    STC_REQUIRE(h >= 4 && h <= HEAD_MAX_H && h % 4 == 0, STC_ELIMIT, "stc_head_bwd_f32: h=%d must be a multiple of 4 in [4,%d]", h, HEAD_MAX_H);
+    STC_REQUIRE(rows >= 0 && dwb, STC_EINVAL, "stc_head_bwd_f32: negative rows or null dwb");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (rows == 0) return stc::hip_status(hipMemsetAsync(dwb, 0, (size_t)(h + 1) * sizeof(float), s), "memset dwb");
+    STC_REQUIRE(H && w && y && dy && dH, STC_EINVAL, "stc_head_bwd_f32: null pointer");
+    STC_REQUIRE(stc::aligned16(H) && stc::aligned16(dH) && workspace && stc::aligned16(workspace), STC_EALIGN,
+                "stc_head_bwd_f32: H/dH/workspace must be 16-byte aligned");
+    STC_REQUIRE(workspace_bytes >= stc_head_bwd_workspace_bytes(h), STC_EINVAL, "stc_head_bwd_f32: workspace too small");
+    long long blocks = (rows + EW_THREADS - 1) / EW_THREADS;
+    const int grid = (int)(blocks < HEAD_PARTS ? blocks : HEAD_PARTS);
+    float* partial = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(head_bwd_kernel, dim3(grid), dim3(EW_THREADS), 0, s, H, w, y, dy, dH, partial, (long long)rows, h);
+    hipLaunchKernelGGL(head_reduce_kernel, dim3(h + 1), dim3(EW_THREADS), 0, s, partial, grid, h + 1, dwb);
+    STC_LAUNCH_CHECK("stc_head_bwd_f32 launch");
     return STC_OK;
 }
 

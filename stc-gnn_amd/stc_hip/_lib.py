@@ -19,7 +19,7 @@ import torch
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG_ROOT, 'libstc_hip.so')
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_K = 4
 
 #: every symbol ``include/stc_hip.h`` declares (the CPU test-suite checks the .so exports them all)
@@ -29,6 +29,7 @@ EXPORTS = (
     'stc_cheby_dense_fwd_f32', 'stc_cheby_dense_bwd_f32',
     'stc_bdg_node_fwd_f32', 'stc_bdg_node_bwd_workspace_bytes', 'stc_bdg_node_bwd_f32',
     'stc_gru_gates_fwd_f32', 'stc_gru_gates_bwd_f32', 'stc_gru_blend_fwd_f32', 'stc_gru_blend_bwd_f32',
+    'stc_head_fwd_f32', 'stc_head_bwd_workspace_bytes', 'stc_head_bwd_f32',
     'stc_axpy_f32', 'stc_concat2_f32', 'stc_split2_f32',
 )
 
@@ -60,6 +61,8 @@ def _declare(lib):
         'stc_gru_gates_bwd_f32': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p],
         'stc_gru_blend_fwd_f32': [_p, _p, _p, _p, _p, _i64, _p],
         'stc_gru_blend_bwd_f32': [_p, _p, _p, _p, _p, _p, _p, _i64, _p],
+        'stc_head_fwd_f32': [_p, _p, _p, _p, _i64, _i32, _p],
+        'stc_head_bwd_f32': [_p, _p, _p, _p, _p, _p, _p, C.c_size_t, _i64, _i32, _p],
         'stc_axpy_f32': [_f32, _p, _p, _i64, _p],
         'stc_concat2_f32': [_p, _p, _p, _i64, _i32, _i32, _i32, _p],
         'stc_split2_f32': [_p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p],
@@ -68,6 +71,8 @@ def _declare(lib):
         fn = getattr(lib, name)
         fn.restype = C.c_int
         fn.argtypes = argtypes
+    lib.stc_head_bwd_workspace_bytes.restype = C.c_size_t
+    lib.stc_head_bwd_workspace_bytes.argtypes = [_i32]
     lib.stc_bdg_node_bwd_workspace_bytes.restype = C.c_size_t
     lib.stc_bdg_node_bwd_workspace_bytes.argtypes = [_i32, _i32, _i32, _i32, _i32, _i32]
 
@@ -323,6 +328,28 @@ class HipKernels:
     def gru_blend_bwd(self, dHnew, U, H, Cand, dCpre, dU, dH):
         n = self._same_numel('blend_bwd', dHnew, U, H, Cand, dCpre, dU, dH)
         self._launch('stc_gru_blend_bwd_f32', H, _ptr(dHnew), _ptr(U), _ptr(H), _ptr(Cand), _ptr(dCpre), _ptr(dU), _ptr(dH), n)
+
+    # ---- output head -----------------------------------------------------------------------
+    def head_fwd(self, H, w, b, y):
+        h = H.shape[-1]
+        rows = H.shape[:-1].numel()
+        self._f32('head.H', H)
+        self._f32('head.w', w, (h,))
+        self._f32('head.b', b, (1,))
+        self._f32('head.y', y, tuple(H.shape[:-1]))
+        self._launch('stc_head_fwd_f32', H, _ptr(H), _ptr(w), _ptr(b), _ptr(y), rows, h)
+
+    def head_bwd(self, H, w, y, dy, dH, dwb):
+        h = H.shape[-1]
+        rows = H.shape[:-1].numel()
+        self._f32('head.H', H)
+        self._f32('head.w', w, (h,))
+        self._f32('head.y', y, tuple(H.shape[:-1]))
+        self._f32('head.dy', dy, tuple(H.shape[:-1]))
+        self._f32('head.dH', dH, tuple(H.shape))
+        self._f32('head.dwb', dwb, (h + 1,))
+        ws = self._get_workspace(H.device, self.lib.stc_head_bwd_workspace_bytes(h))
+        self._launch('stc_head_bwd_f32', H, _ptr(H), _ptr(w), _ptr(y), _ptr(dy), _ptr(dH), _ptr(dwb), _ptr(ws), ws.numel(), rows, h)
 
     # ---- helpers --------------------------------------------------------------------------
     def axpy(self, a, x, y):

@@ -247,6 +247,34 @@ def concat2(A, Bm, pad: int = 0):
     return _Concat2.apply(A, Bm, pad)
 
 
+# ----------------------------------------------------------------------------- output head
+class _Head(Function):
+    @staticmethod
+    def forward(ctx, H, w, b):
+        H, w, b = _c(H), _c(w), _c(b)
+        y = H.new_empty(H.shape[:-1])
+        kernels().head_fwd(H, w, b, y)
+        ctx.save_for_backward(H, w, y)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        H, w, y = ctx.saved_tensors
+        dH = torch.empty_like(H)
+        dwb = w.new_empty(w.numel() + 1)
+        kernels().head_bwd(H, w, y, _c(dy), dH, dwb)
+        return dH, dwb[:-1], dwb[-1:]
+
+
+def head(H: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """sigmoid(<H[..., :], w> + b): the reference's Linear(h, h/2) -> Linear(h/2, 1) -> sigmoid with the two
+    layers folded by the caller (no nonlinearity between them); returns H's shape without the last axis."""
+    if w.shape != (H.shape[-1],) or b.shape != (1,):
+        raise ValueError(f'head: w {tuple(w.shape)} / b {tuple(b.shape)} do not match feature width {H.shape[-1]}')
+    return _Head.apply(H, w, b)
+
+
 # ----------------------------------------------------------------------------- whole STC_Cell
 class _StcCell(Function):
     """One STC_Cell step (reference STC_GNN.py:65-79) as a single autograd node.

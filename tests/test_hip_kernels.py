@@ -301,6 +301,27 @@ def test_gru_gates_and_blend(hip, rows_shape, cin, h, pad):
         assert rel_err(a, w) < TOL
 
 
+@pytest.mark.parametrize('shape,h', [((2, 3, 50, 5), 16), ((1, 6, 777, 4), 8), ((3, 7), 64), ((1, 300000), 16)])
+def test_output_head(hip, shape, h):
+    g = torch.Generator().manual_seed(h + len(shape))
+    H = torch.randn(*shape, h, generator=g)
+    w, b = torch.randn(h, generator=g) * 0.5, torch.randn(1, generator=g)
+    y_w = torch.empty(*shape)
+    EM.head_fwd(H, w, b, y_w)
+    y = torch.empty(*shape).cuda()
+    hip.head_fwd(cu(H), cu(w), cu(b), y)
+    assert rel_err(y, y_w) < TOL
+    dy = torch.randn(*shape, generator=g)
+    dH_w, dwb_w = torch.empty_like(H), torch.empty(h + 1)
+    EM.head_bwd(H, w, y_w, dy, dH_w, dwb_w)
+    dH, dwb = torch.empty_like(H).cuda(), torch.empty(h + 1).cuda()
+    hip.head_bwd(cu(H), cu(w), cu(y_w), cu(dy), dH, dwb)
+    assert rel_err(dH, dH_w) < TOL and rel_err(dwb, dwb_w) < 2e-5
+    dwb2 = torch.empty(h + 1).cuda()
+    hip.head_bwd(cu(H), cu(w), cu(y_w), cu(dy), dH, dwb2)
+    assert torch.equal(dwb, dwb2)                                  # fixed-order reduction
+
+
 def test_axpy_concat_split(hip):
     g = torch.Generator().manual_seed(3)
     x, y = torch.randn(1000, generator=g), torch.randn(1000, generator=g)

@@ -15,13 +15,15 @@ from stc_hip._lib import HipKernels  # noqa: E402
 
 
 def timeit(fn, iters, warm=3):
-    for _ in range(warm):
-        fn()
+    """fn(i): the caller rotates over several buffer sets by i so that no launch finds its operands in the
+    256 MiB Infinity Cache left there by the previous one (a re-used 205 MB tensor would read far too fast)."""
+    for i in range(warm):
+        fn(i)
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
-    for _ in range(iters):
-        fn()
+    for i in range(iters):
+        fn(i)
     e.record()
     torch.cuda.synchronize()
     return 1e3 * s.elapsed_time(e) / iters
@@ -49,52 +51,63 @@ def main():
     def report(name, us, nbytes):
         print(f'{name:34s} {us:9.1f} us   {nbytes/1e6:9.1f} MB   {nbytes/us/1e3:8.1f} GB/s', flush=True)
 
+    R = 4                                  # buffer sets rotated through (4 x >= 200 MB >> 256 MiB of Infinity Cache)
     for L in (32, 20):
         F = C * L
-        X = torch.randn(B, N, F, device=dev)
-        Y = torch.empty_like(X)
-        us = timeit(lambda: hip.csr_spmm(g['fwd_rowptr'], g['fwd_colidx'], g['fwd_val'], N, N, X, None, Y, 1.0, 0.0), a.iters)
+        Xs = [torch.randn(B, N, F, device=dev) for _ in range(R)]
+        Ys = [torch.empty(B, N, F, device=dev) for _ in range(R)]
+        us = timeit(lambda i: hip.csr_spmm(g['fwd_rowptr'], g['fwd_colidx'], g['fwd_val'], N, N, Xs[i % R], None, Ys[i % R], 1.0, 0.0), a.iters)
         report(f'spmm fwd F={F}', us, nnz * 8 + 4 * (N + 1) + 2 * B * N * F * 4)
-        us = timeit(lambda: hip.csr_spmm(g['bwd_rowptr'], g['bwd_colidx'], g['bwd_val'], N, N, X, Y, Y, 1.0, 1.0), a.iters)
+        us = timeit(lambda i: hip.csr_spmm(g['bwd_rowptr'], g['bwd_colidx'], g['bwd_val'], N, N, Xs[i % R], Ys[i % R], Ys[i % R], 1.0, 1.0), a.iters)
         report(f'spmm bwd F={F} (+=, in place)', us, nnz * 8 + 4 * (N + 1) + 3 * B * N * F * 4)
         if a.only == 'spmm':
             continue
         Tc = torch.softmax(torch.randn(K, C, C, device=dev), -1)
         Tc[0] = torch.eye(C, device=dev)
         for Ho in (2 * h, h):
-            Zs = [torch.randn(B * N, C, L, device=dev) for _ in range(K)]
+            Zs = [[torch.randn(B * N, C, L, device=dev) for _ in range(K)] for _ in range(R)]
             W = torch.randn(K * K * L, Ho, device=dev) * 0.1
             b = torch.randn(Ho, device=dev)
-            Yn = torch.empty(B * N, C, Ho, device=dev)
-            us = timeit(lambda: hip.bdg_node_fwd(Zs, Tc, W, b, Yn), a.iters)
+            Yn = [torch.empty(B * N, C, Ho, device=dev) for _ in range(R)]
+            us = timeit(lambda i: hip.bdg_node_fwd(Zs[i % R], Tc, W, b, Yn[i % R]), a.iters)
             report(f'node fwd L={L} Ho={Ho}', us, (K * L + Ho) * B * N * C * 4)
-            dY = torch.randn_like(Yn)
-            dZs = [torch.empty_like(z) for z in Zs]
+            dY = [torch.randn_like(y) for y in Yn]
+            dZs = [[torch.empty_like(z) for z in zs] for zs in Zs]
             dW, db = torch.empty_like(W), torch.empty_like(b)
-            us = timeit(lambda: hip.bdg_node_bwd(Zs, Tc, W, dY, dZs, dW, db, None), a.iters)
+            us = timeit(lambda i: hip.bdg_node_bwd(Zs[i % R], Tc, W, dY[i % R], dZs[i % R], dW, db, None), a.iters)
             report(f'node bwd L={L} Ho={Ho}', us, (2 * K * L + Ho) * B * N * C * 4)
+        del Xs, Ys, Zs, Yn, dY, dZs
     if a.only == 'spmm':
         return
     rows = (B, N, C)
-    G = torch.randn(*rows, 2 * h, device=dev)
-    Xt = torch.randn(*rows, h, device=dev)
-    H = torch.randn(*rows, h, device=dev)
-    U, R, Ci = torch.empty_like(H), torch.empty_like(H), torch.empty(*rows, 2 * h, device=dev)
+    mk = lambda w: [torch.randn(*rows, w, device=dev) for _ in range(R)]
+    G, Xt, H, U, Rg, Ci = mk(2 * h), mk(h), mk(h), mk(h), mk(h), mk(2 * h)
     n = B * N * C
-    us = timeit(lambda: hip.gru_gates_fwd(G, Xt, H, U, R, Ci), a.iters)
+    us = timeit(lambda i: hip.gru_gates_fwd(G[i % R], Xt[i % R], H[i % R], U[i % R], Rg[i % R], Ci[i % R]), a.iters)
     report('gru_gates_fwd cin=16', us, n * 4 * (2 * h + h + h + h + h + 2 * h))
-    dG, dX, dH = torch.empty_like(G), torch.empty_like(Xt), torch.empty_like(H)
-    us = timeit(lambda: hip.gru_gates_bwd(Ci, U, H, U, R, dG, dX, dH), a.iters)
+    dG, dX, dH = mk(2 * h), mk(h), mk(h)
+    us = timeit(lambda i: hip.gru_gates_bwd(Ci[i % R], U[i % R], H[i % R], U[i % R], Rg[i % R], dG[i % R], dX[i % R], dH[i % R]), a.iters)
     report('gru_gates_bwd cin=16', us, n * 4 * (2 * h + h + h + h + h + 2 * h + h + h))
-    us = timeit(lambda: hip.gru_blend_fwd(H, U, H, R, dH), a.iters)
+    us = timeit(lambda i: hip.gru_blend_fwd(H[i % R], U[i % R], Xt[i % R], Rg[i % R], dH[i % R]), a.iters)
     report('gru_blend_fwd', us, n * 4 * 5 * h)
-    us = timeit(lambda: hip.gru_blend_bwd(H, U, H, R, dH, dX, Xt), a.iters)
+    us = timeit(lambda i: hip.gru_blend_bwd(H[i % R], U[i % R], Xt[i % R], Rg[i % R], dH[i % R], dX[i % R], G[i % R][..., :h].contiguous() if False else dG[i % R][..., :h].reshape(-1)[:n * h].view(*rows, h)), a.iters)
     report('gru_blend_bwd', us, n * 4 * 7 * h)
-    us = timeit(lambda: hip.concat2(Xt, H, Ci), a.iters)
+    us = timeit(lambda i: hip.concat2(Xt[i % R], H[i % R], Ci[i % R]), a.iters)
     report('concat2 16+16', us, n * 4 * 4 * h)
-    Xc = torch.empty_like(X)
-    us = timeit(lambda: Xc.copy_(X), a.iters)
-    report('torch copy (HBM reference)', us, 2 * X.numel() * 4)
+    us = timeit(lambda i: hip.split2(Ci[i % R], dX[i % R], dH[i % R], addA=dX[i % R], addB=dH[i % R]), a.iters)
+    report('split2 16+16 (+=)', us, n * 4 * 6 * h)
+    Hh = [torch.randn(B, 6, N, C, h, device=dev) for _ in range(2)]
+    w, bb = torch.randn(h, device=dev), torch.randn(1, device=dev)
+    yy = torch.empty(B, 6, N, C, device=dev)
+    us = timeit(lambda i: hip.head_fwd(Hh[i % 2], w, bb, yy), a.iters)
+    report('head fwd (6 steps)', us, 6 * n * 4 * (h + 1))
+    dHh, dwb = torch.empty_like(Hh[0]), torch.empty(h + 1, device=dev)
+    us = timeit(lambda i: hip.head_bwd(Hh[i % 2], w, yy, yy, dHh, dwb), a.iters)
+    report('head bwd (6 steps)', us, 6 * n * 4 * (2 * h + 2))
+    Xc = [torch.randn(B, N, C * 32, device=dev) for _ in range(R)]
+    Yc = [torch.empty_like(x) for x in Xc]
+    us = timeit(lambda i: Yc[i % R].copy_(Xc[i % R]), a.iters)
+    report('torch copy (HBM reference)', us, 2 * Xc[0].numel() * 4)
 
 
 if __name__ == '__main__':
