@@ -34,7 +34,7 @@ class EmulatedKernels:
     name = 'emulated-cpu'
 
     # ---- stc_csr_spmm_f32: 1-mode product + Chebyshev epilogue (STC_GNN.py:28, 37)
-    def csr_spmm(self, rowptr, colidx, val, n_rows, n_cols, X, Y0, Y, alpha, beta):
+    def csr_spmm(self, rowptr, colidx, val, n_rows, n_cols, X, Y0, Y, alpha, beta, plan=None):
         B, nc, F = X.shape
         assert nc == n_cols and Y.shape == (B, n_rows, F)
         rows = _expand_rows(rowptr)

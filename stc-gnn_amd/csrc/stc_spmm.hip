@@ -160,6 +160,68 @@ __global__ __launch_bounds__(SPMM_THREADS) void spmm_wave_row_kernel(
     }
 }
 
+
+// ---- LDS-tiled variant: distinct neighbour rows of a tile staged once per 1 KiB column block ----------------
+constexpr int TL_ROWS = STC_SPMM_TILE_ROWS, TL_COLS = STC_SPMM_TILE_MAX_COLS, TL_NNZ = STC_SPMM_TILE_MAX_NNZ;
+
+__global__ __launch_bounds__(SPMM_THREADS) void spmm_tiled_kernel(
+    const int* __restrict__ rowptr, const float* __restrict__ val,
+    const int* __restrict__ tile_ptr, const int* __restrict__ tile_cols, const unsigned short* __restrict__ local,
+    int n_rows, int n_cols, const float4* __restrict__ X, const float4* Y0, float4* Y,
+    int F4, float alpha, float beta, int n_tiles) {
+    __shared__ float4 xs[TL_COLS * 64];           // [distinct column][64 x 16 B]: one 1 KiB piece of each neighbour row
+    __shared__ int s_rp[TL_ROWS + 1];
+    __shared__ int s_cols[TL_COLS];
+    __shared__ unsigned short s_loc[TL_NNZ];
+    __shared__ float s_val[TL_NNZ];
+
+    const int tile = stc_xcd_tile(blockIdx.x, n_tiles);
+    if (tile < 0) return;
+    const int b = blockIdx.y;
+    const int ch0 = blockIdx.z * 64;              // first float4 of this column block
+    const int row0 = tile * TL_ROWS;
+    const int nr = min(TL_ROWS, n_rows - row0);
+    const int tid = threadIdx.x;
+    const int d0 = tile_ptr[tile];
+    const int nd = tile_ptr[tile + 1] - d0;
+    if (tid <= nr) s_rp[tid] = rowptr[row0 + tid];
+    if (tid < nd) s_cols[tid] = tile_cols[d0 + tid];
+    __syncthreads();
+    const int seg0 = s_rp[0];
+    const int seg_n = s_rp[nr] - seg0;            // <= TL_NNZ by construction of the plan
+    for (int t = tid; t < seg_n; t += SPMM_THREADS) {
+        s_loc[t] = local[seg0 + t];
+        s_val[t] = val[seg0 + t];
+    }
+    const float4* Xb = X + (size_t)b * n_cols * F4;
+    const int kk = tid & 63;
+    if (ch0 + kk < F4)
+        for (int d = tid >> 6; d < nd; d += SPMM_THREADS / 64)
+            xs[d * 64 + kk] = Xb[(size_t)s_cols[d] * F4 + ch0 + kk];
+    __syncthreads();
+
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    if (ch0 + lane >= F4) return;                 // ragged last column block (no barrier below)
+    for (int r = wave; r < nr; r += SPMM_WAVES) {
+        const int js = s_rp[r] - seg0, je = s_rp[r + 1] - seg0;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = js; j < je; ++j) {
+            const int li = __builtin_amdgcn_readfirstlane((int)s_loc[j]);
+            fma4(acc, uniform_f(s_val[j]), xs[li * 64 + lane]);
+        }
+        const size_t o = ((size_t)b * n_rows + row0 + r) * F4 + ch0 + lane;
+        float4 out = make_float4(alpha * acc.x, alpha * acc.y, alpha * acc.z, alpha * acc.w);
+        using v4f = __attribute__((ext_vector_type(4))) float;
+        if (beta != 0.f) {
+            const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(&Y0[o]));
+            out.x = fmaf(beta, t[0], out.x); out.y = fmaf(beta, t[1], out.y);
+            out.z = fmaf(beta, t[2], out.z); out.w = fmaf(beta, t[3], out.w);
+        }
+        __builtin_nontemporal_store(v4f{out.x, out.y, out.z, out.w}, reinterpret_cast<v4f*>(&Y[o]));
+    }
+}
+
 // Any F, any alignment (SF shape: F = C*L = 85): lanes_per_row threads share a row.
 __global__ __launch_bounds__(SPMM_THREADS) void spmm_generic_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ colidx, const float* __restrict__ val,
@@ -264,6 +326,33 @@ extern "C" int stc_csr_spmm_f32(const int32_t* rowptr, const int32_t* colidx, co
         hipLaunchKernelGGL(spmm_generic_kernel, grid, block, 0, s, rowptr, colidx, val, n_rows, n_cols, X, Y0, Y, F, alpha, beta, lanes);
     }
     STC_LAUNCH_CHECK("stc_csr_spmm_f32 launch");
+    return STC_OK;
+}
+
+
+extern "C" int stc_csr_spmm_tiled_f32(const int32_t* rowptr, const float* val,
+                                      const int32_t* tile_ptr, const int32_t* tile_cols, const uint16_t* local,
+                                      int32_t n_rows, int32_t n_cols,
+                                      const float* X, const float* Y0, float* Y,
+                                      int32_t batch, int32_t F, float alpha, float beta, void* stream) {
+    STC_REQUIRE(n_rows >= 0 && n_cols >= 0 && batch >= 0 && F >= 0, STC_EINVAL, "stc_csr_spmm_tiled_f32: negative size");
+    if (n_rows == 0 || batch == 0 || F == 0) return STC_OK;
+    STC_REQUIRE(rowptr && val && tile_ptr && tile_cols && local && X && Y, STC_EINVAL, "stc_csr_spmm_tiled_f32: null pointer");
+    STC_REQUIRE(beta == 0.f || Y0, STC_EINVAL, "stc_csr_spmm_tiled_f32: beta != 0 needs Y0");
+    STC_REQUIRE(X != Y, STC_EINVAL, "stc_csr_spmm_tiled_f32: X must not alias Y");
+    STC_REQUIRE(F % 4 == 0, STC_EINVAL, "stc_csr_spmm_tiled_f32: F=%d must be a multiple of 4", F);
+    STC_REQUIRE(stc::aligned16(X) && stc::aligned16(Y) && (!Y0 || stc::aligned16(Y0)), STC_EALIGN,
+                "stc_csr_spmm_tiled_f32: X / Y / Y0 must be 16-byte aligned");
+    const int F4 = F / 4;
+    const int n_chunks = (F4 + 63) / 64;
+    STC_REQUIRE(batch <= 65535 && n_chunks <= 65535, STC_ELIMIT, "stc_csr_spmm_tiled_f32: batch %d / column blocks %d exceed the grid", batch, n_chunks);
+    const int n_tiles = (n_rows + TL_ROWS - 1) / TL_ROWS;
+    const int per = (n_tiles + stc::kNumXcd - 1) / stc::kNumXcd;
+    hipLaunchKernelGGL(spmm_tiled_kernel, dim3(per * stc::kNumXcd, batch, n_chunks), dim3(SPMM_THREADS), 0,
+                       static_cast<hipStream_t>(stream), rowptr, val, tile_ptr, tile_cols, local, n_rows, n_cols,
+                       reinterpret_cast<const float4*>(X), reinterpret_cast<const float4*>(Y0), reinterpret_cast<float4*>(Y),
+                       F4, alpha, beta, n_tiles);
+    STC_LAUNCH_CHECK("stc_csr_spmm_tiled_f32 launch");
     return STC_OK;
 }
 

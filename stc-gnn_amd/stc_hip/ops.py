@@ -85,10 +85,10 @@ def _bdg_forward(X, W, b, Tc, fwd_val, op: SpatialOperand, Ks: int):
     for order in range(1, Ks):
         Zk = torch.empty_like(X)
         if order == 1:
-            k.csr_spmm(op.fwd_rowptr, op.fwd_colidx, fwd_val, N, N, X.view(B, N, F), None, Zk.view(B, N, F), 1.0, 0.0)
+            k.csr_spmm(op.fwd_rowptr, op.fwd_colidx, fwd_val, N, N, X.view(B, N, F), None, Zk.view(B, N, F), 1.0, 0.0, plan=op.fwd_plan)
         else:
             k.csr_spmm(op.fwd_rowptr, op.fwd_colidx, fwd_val, N, N, Zs[-1].view(B, N, F),
-                       Zs[-2].view(B, N, F), Zk.view(B, N, F), 2.0, -1.0)
+                       Zs[-2].view(B, N, F), Zk.view(B, N, F), 2.0, -1.0, plan=op.fwd_plan)
         Zs.append(Zk)
     Y = X.new_empty(B, N, C, Ho)
     k.bdg_node_fwd([z.view(B * N, C, L) for z in Zs], Tc, W, b, Y.view(B * N, C, Ho))
@@ -112,13 +112,13 @@ def _bdg_backward(dY, Zs, W, Tc, op: SpatialOperand, Ks: int, has_bias: bool, ne
     v3 = lambda t: t.view(B, N, F)
     for order in range(Ks - 1, 1, -1):
         k.csr_spmm(op.bwd_rowptr, op.bwd_colidx, op.bwd_val, N, N, v3(dZ[order]), v3(dZ[order - 1]),
-                   v3(dZ[order - 1]), 2.0, 1.0)
+                   v3(dZ[order - 1]), 2.0, 1.0, plan=op.bwd_plan)
         k.axpy(-1.0, dZ[order], dZ[order - 2])
         if need_val:
             k.csr_sddmm(op.fwd_rowptr, op.fwd_colidx, N, N, v3(dZ[order]), v3(Zs[order - 1]), dval, 2.0, True)
     if Ks > 1:
         if need_X:
-            k.csr_spmm(op.bwd_rowptr, op.bwd_colidx, op.bwd_val, N, N, v3(dZ[1]), v3(dZ[0]), v3(dZ[0]), 1.0, 1.0)
+            k.csr_spmm(op.bwd_rowptr, op.bwd_colidx, op.bwd_val, N, N, v3(dZ[1]), v3(dZ[0]), v3(dZ[0]), 1.0, 1.0, plan=op.bwd_plan)
         if need_val:
             k.csr_sddmm(op.fwd_rowptr, op.fwd_colidx, N, N, v3(dZ[1]), v3(Zs[0]), dval, 1.0, True)
     return (dZ[0] if need_X else None), dW, db, dTc, dval

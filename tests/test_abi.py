@@ -72,3 +72,22 @@ def test_combo_loss_matches_oracle():
     a = ComboLoss()(p, y)
     b = O.combo_loss(p.detach().clone().requires_grad_(), y)
     assert abs(float(a.detach()) - float(b.detach())) < 1e-7
+
+
+def test_tile_plan_reconstructs_the_graph():
+    """Host logic of the LDS-tiled SpMM: (tile_cols, local) must address exactly the CSR column of every entry."""
+    import numpy as np
+    from stc_hip import CsrGraph
+    from stc_hip.graph import TILE_MAX_COLS, TILE_ROWS
+    g = CsrGraph.queen_grid(13, 9)
+    assert g.tiled == (True, True)
+    for side in ('fwd', 'bwd'):
+        h = g._host
+        rp, ci = h[f'{side}_rowptr'].astype(np.int64), h[f'{side}_colidx']
+        tp, tc, loc = h[f'{side}_tile_ptr'], h[f'{side}_tile_cols'], h[f'{side}_local']
+        row_of = np.repeat(np.arange(g.n), np.diff(rp))
+        assert np.array_equal(tc[tp[row_of // TILE_ROWS] + loc], ci)
+        assert np.diff(tp).max() <= TILE_MAX_COLS and tp[-1] == tc.size
+        for t in range(len(tp) - 1):                                   # distinct and sorted within a tile
+            assert np.all(np.diff(tc[tp[t]:tp[t + 1]]) > 0)
+    assert CsrGraph.queen_grid(13, 9, permute_seed=3).tiled == (False, False)
