@@ -56,21 +56,18 @@ int stc_csr_spmm_f32(const int32_t* rowptr, const int32_t* colidx, const float* 
                      const float* X, const float* Y0, float* Y,
                      int32_t batch, int32_t F, float alpha, float beta, void* stream);
 
-/* Same product for graphs with locality, LDS-tiled.  The host groups the rows into tiles of
- * STC_SPMM_TILE_ROWS consecutive rows and lists, per tile, the DISTINCT columns its rows touch
- * (tile_ptr (n_tiles+1), tile_cols) and for every stored entry its position in that list (local, uint16).
- * A workgroup stages each distinct neighbour row once in LDS (1 KiB column block at a time) and all rows
- * of the tile read it from there: a banded graph needs ~3.75 instead of ~9 row fetches from L2 per output
- * row.  Preconditions checked by the host that builds the plan: every tile has <= STC_SPMM_TILE_MAX_COLS
- * distinct columns and <= STC_SPMM_TILE_MAX_NNZ entries; F % 4 == 0 and 16-byte aligned operands here. */
-#define STC_SPMM_TILE_ROWS 8
-#define STC_SPMM_TILE_MAX_COLS 40
-#define STC_SPMM_TILE_MAX_NNZ 512
-int stc_csr_spmm_tiled_f32(const int32_t* rowptr, const float* val,
-                           const int32_t* tile_ptr, const int32_t* tile_cols, const uint16_t* local,
-                           int32_t n_rows, int32_t n_cols,
-                           const float* X, const float* Y0, float* Y,
-                           int32_t batch, int32_t F, float alpha, float beta, void* stream);
+/* Same product on the row-blocked form of a FIXED graph (BCSR, STC_SPMM_BLOCK_ROWS x 1 blocks): the host
+ * groups the rows 4 at a time and lists, per block, the distinct columns its rows touch (blk_ptr
+ * (n_blocks+1), blk_cols) with the 4 values of each column, one per row of the block, zero where a row has
+ * no such entry (blk_vals, nnzb x 4).  One wave produces the 4 rows of a block together, so a neighbour
+ * row shared by several of them is fetched once: the 8-neighbour grid needs 18 instead of 36 row fetches
+ * per 4 output rows (the direct kernel is bound by exactly that L2 -> CU gather traffic).  A graph without
+ * locality degenerates to the same number of fetches as CSR.  Y0 / alpha / beta as stc_csr_spmm_f32. */
+#define STC_SPMM_BLOCK_ROWS 4
+int stc_bcsr_spmm_f32(const int32_t* blk_ptr, const int32_t* blk_cols, const float* blk_vals,
+                      int32_t n_rows, int32_t n_cols,
+                      const float* X, const float* Y0, float* Y,
+                      int32_t batch, int32_t F, float alpha, float beta, void* stream);
 
 /* out[j] (+)= alpha * sum_b < A[b,i,:], Bm[b,colidx[j],:] >   for j in row i
  * A (batch, n_rows, F), Bm (batch, n_cols, F), out (nnz).  Gradient of the

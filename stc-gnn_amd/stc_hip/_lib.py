@@ -25,7 +25,7 @@ MAX_K = 4
 #: every symbol ``include/stc_hip.h`` declares (the CPU test-suite checks the .so exports them all)
 EXPORTS = (
     'stc_version', 'stc_last_error',
-    'stc_csr_spmm_f32', 'stc_csr_spmm_tiled_f32', 'stc_csr_sddmm_f32',
+    'stc_csr_spmm_f32', 'stc_bcsr_spmm_f32', 'stc_csr_sddmm_f32',
     'stc_cheby_dense_fwd_f32', 'stc_cheby_dense_bwd_f32',
     'stc_bdg_node_fwd_f32', 'stc_bdg_node_bwd_workspace_bytes', 'stc_bdg_node_bwd_f32',
     'stc_gru_gates_fwd_f32', 'stc_gru_gates_bwd_f32', 'stc_gru_blend_fwd_f32', 'stc_gru_blend_bwd_f32',
@@ -51,7 +51,7 @@ def _declare(lib):
     lib.stc_last_error.argtypes = []
     sig = {
         'stc_csr_spmm_f32': [_p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _f32, _p],
-        'stc_csr_spmm_tiled_f32': [_p, _p, _p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _f32, _p],
+        'stc_bcsr_spmm_f32': [_p, _p, _p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _f32, _p],
         'stc_csr_sddmm_f32': [_p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _i32, _p],
         'stc_cheby_dense_fwd_f32': [_p, _i32, _i32, _p, _p],
         'stc_cheby_dense_bwd_f32': [_p, _p, _p, _i32, _i32, _p, _p],
@@ -194,8 +194,9 @@ class HipKernels:
 
     # ---- spatial aggregation ------------------------------------------------------
     def csr_spmm(self, rowptr, colidx, val, n_rows, n_cols, X, Y0, Y, alpha, beta, plan=None):
-        """``plan`` = (tile_ptr, tile_cols, local) of ``graph._tile_plan``: use the LDS-tiled kernel when the
-        operands allow it (F % 4 == 0, 16-byte aligned); otherwise, or without a plan, the direct kernel."""
+        """``plan`` = (blk_ptr, blk_cols, blk_vals) of ``graph._row_block_plan`` (fixed graphs): use the
+        row-blocked kernel when the operands allow it (F % 4 == 0, 16-byte aligned); otherwise, or without a
+        plan (learned dense graph: values change every step), the CSR kernel."""
         B, nc, F = X.shape
         self._f32('spmm.X', X, (B, n_cols, F))
         self._f32('spmm.Y', Y, (B, n_rows, F))
@@ -205,18 +206,17 @@ class HipKernels:
         self._i32('spmm.colidx', colidx)
         self._f32('spmm.val', val, (colidx.numel(),))
         self._same_device(rowptr, colidx, val, X, Y0, Y)
-        nbytes = colidx.numel() * 8 + 4 * (n_rows + 1) + 2 * 4 * B * n_rows * F
+        nbytes = colidx.numel() * 8 + 4 * (n_rows + 1) + (2 if Y0 is None or beta == 0 else 3) * 4 * B * n_rows * F
         if plan is not None and F % 4 == 0 and F >= 64 and all(t is None or t.data_ptr() % 16 == 0 for t in (X, Y0, Y)):
-            tile_ptr, tile_cols, local = plan
-            self._i32('spmm.tile_ptr', tile_ptr, (n_rows + 7) // 8 + 1)
-            self._i32('spmm.tile_cols', tile_cols)
-            if local.dtype != torch.int16 or not local.is_cuda or local.numel() != colidx.numel():
-                raise StcError('spmm.local: expected one (u)int16 per stored entry on the device')
-            self._launch('stc_csr_spmm_tiled_f32', X, _ptr(rowptr), _ptr(val), _ptr(tile_ptr), _ptr(tile_cols), _ptr(local),
-                         n_rows, n_cols, _ptr(X), _ptr(Y0), _ptr(Y), B, F, float(alpha), float(beta), nbytes=nbytes)
+            blk_ptr, blk_cols, blk_vals = plan
+            self._i32('spmm.blk_ptr', blk_ptr, (n_rows + 3) // 4 + 1)
+            self._i32('spmm.blk_cols', blk_cols)
+            self._f32('spmm.blk_vals', blk_vals, (blk_cols.numel(), 4))
+            self._launch('stc_bcsr_spmm_f32', X, _ptr(blk_ptr), _ptr(blk_cols), _ptr(blk_vals), n_rows, n_cols,
+                         _ptr(X), _ptr(Y0), _ptr(Y), B, F, float(alpha), float(beta), nbytes=nbytes)
             return
         self._launch('stc_csr_spmm_f32', X, _ptr(rowptr), _ptr(colidx), _ptr(val), n_rows, n_cols, _ptr(X), _ptr(Y0), _ptr(Y), B, F, float(alpha), float(beta),
-                     nbytes=colidx.numel() * 8 + 4 * (n_rows + 1) + 2 * 4 * B * n_rows * F)
+                     nbytes=nbytes)
 
     def csr_sddmm(self, rowptr, colidx, n_rows, n_cols, A, Bm, out, alpha, accumulate):
         B, nr, F = A.shape

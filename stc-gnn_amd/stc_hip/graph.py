@@ -32,32 +32,25 @@ def _csr_from_coo(rows: np.ndarray, cols: np.ndarray, vals: np.ndarray, n: int):
     return rowptr.astype(np.int32), c.astype(np.int32), vals[order].astype(np.float32), order
 
 
-TILE_ROWS, TILE_MAX_COLS, TILE_MAX_NNZ = 8, 40, 512      # = STC_SPMM_TILE_* of include/stc_hip.h
+BLOCK_ROWS = 4      # = STC_SPMM_BLOCK_ROWS of include/stc_hip.h
 
 
-def _tile_plan(rowptr: np.ndarray, colidx: np.ndarray, n: int):
-    """Per-tile distinct-column lists for the LDS-tiled SpMM, or None when the graph has no locality to use.
+def _row_block_plan(rowptr: np.ndarray, colidx: np.ndarray, val: np.ndarray, n: int):
+    """Row-blocked (BCSR, BLOCK_ROWS x 1) form of a CSR matrix for ``stc_bcsr_spmm_f32``.
 
-    Rows are grouped TILE_ROWS at a time; a tile qualifies when its rows touch <= TILE_MAX_COLS distinct
-    columns and hold <= TILE_MAX_NNZ entries.  All tiles must qualify (a banded graph such as the queen grid
-    in row-major order has ~30 distinct columns per 8 rows; the same graph under a random node permutation
-    has ~65 and keeps the direct kernel).
+    Per block of BLOCK_ROWS consecutive rows: the sorted distinct columns its rows touch (blk_ptr, blk_cols)
+    and, per column, one value per row of the block (zero where that row has no such entry).  A neighbour
+    row shared by several rows of a block is then fetched once per block instead of once per row.
     """
-    nnz = colidx.size
-    if n == 0 or nnz == 0:
-        return None
-    n_tiles = (n + TILE_ROWS - 1) // TILE_ROWS
+    n_blocks = (n + BLOCK_ROWS - 1) // BLOCK_ROWS
     row_of = np.repeat(np.arange(n, dtype=np.int64), np.diff(rowptr.astype(np.int64)))
-    tile_of = row_of // TILE_ROWS
-    if np.bincount(tile_of, minlength=n_tiles).max() > TILE_MAX_NNZ:
-        return None
-    key = tile_of * n + colidx.astype(np.int64)
-    uniq, inverse = np.unique(key, return_inverse=True)           # sorted by tile, then column
-    tile_ptr = np.searchsorted(uniq // n, np.arange(n_tiles + 1)).astype(np.int64)
-    if np.diff(tile_ptr).max() > TILE_MAX_COLS:
-        return None
-    local = (inverse - tile_ptr[tile_of]).astype(np.uint16)
-    return dict(tile_ptr=tile_ptr.astype(np.int32), tile_cols=(uniq % n).astype(np.int32), local=local)
+    blk_of = row_of // BLOCK_ROWS
+    key = blk_of * max(n, 1) + colidx.astype(np.int64)
+    uniq, inverse = np.unique(key, return_inverse=True)           # sorted by block, then column
+    blk_ptr = np.searchsorted(uniq // max(n, 1), np.arange(n_blocks + 1))
+    vals = np.zeros((uniq.size, BLOCK_ROWS), dtype=np.float32)
+    vals[inverse, row_of % BLOCK_ROWS] = val
+    return dict(blk_ptr=blk_ptr.astype(np.int32), blk_cols=(uniq % max(n, 1)).astype(np.int32), blk_vals=vals)
 
 
 class CsrGraph:
@@ -92,11 +85,10 @@ class CsrGraph:
         perm = inv_f[b_order]                      # position in fwd order of each bwd entry
         self._host = dict(fwd_rowptr=f_rp, fwd_colidx=f_ci, fwd_val=f_v,
                           bwd_rowptr=b_rp, bwd_colidx=b_ci, bwd_val=b_v, bwd_perm=perm.astype(np.int64))
-        for side, (rp, ci) in (('fwd', (f_rp, f_ci)), ('bwd', (b_rp, b_ci))):
-            plan = _tile_plan(rp, ci, n)
-            if plan is not None:
-                self._host.update({f'{side}_{k}': v for k, v in plan.items()})
-        self.tiled = ('fwd_tile_ptr' in self._host, 'bwd_tile_ptr' in self._host)
+        for side, (rp, ci, v) in (('fwd', (f_rp, f_ci, f_v)), ('bwd', (b_rp, b_ci, b_v))):
+            self._host.update({f'{side}_{k}': a for k, a in _row_block_plan(rp, ci, v, n).items()})
+        #: distinct neighbour rows fetched per output row by the row-blocked kernel (CSR: nnz / n)
+        self.fetches_per_row = tuple(self._host[f'{s_}_blk_cols'].size / max(n, 1) for s_ in ('fwd', 'bwd'))
         self._dev: Dict[torch.device, Dict[str, torch.Tensor]] = {}
         if device is not None:
             self.on(torch.device(device))
@@ -153,7 +145,7 @@ class CsrGraph:
             device = torch.device('cuda', torch.cuda.current_device())
         d = self._dev.get(device)
         if d is None:
-            d = {k: torch.from_numpy(v.view(np.int16) if v.dtype == np.uint16 else v).to(device) for k, v in self._host.items()}
+            d = {k: torch.from_numpy(v).to(device) for k, v in self._host.items()}
             self._dev[device] = d
         return d
 
@@ -179,7 +171,7 @@ class SpatialOperand:
     bwd_colidx: torch.Tensor
     bwd_val: torch.Tensor            # never differentiable
     nnz: int
-    fwd_plan: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None   # (tile_ptr, tile_cols, local) or None
+    fwd_plan: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None   # (blk_ptr, blk_cols, blk_vals) of a fixed graph
     bwd_plan: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None
 
 
@@ -218,6 +210,6 @@ def dense_operand(Gs: torch.Tensor) -> SpatialOperand:
 
 def csr_operand(graph: CsrGraph, device: torch.device) -> SpatialOperand:
     d = graph.on(device)
-    plan = lambda side: (d[f'{side}_tile_ptr'], d[f'{side}_tile_cols'], d[f'{side}_local']) if f'{side}_tile_ptr' in d else None
+    plan = lambda side: (d[f'{side}_blk_ptr'], d[f'{side}_blk_cols'], d[f'{side}_blk_vals'])
     return SpatialOperand(graph.n, d['fwd_rowptr'], d['fwd_colidx'], d['fwd_val'],
                           d['bwd_rowptr'], d['bwd_colidx'], d['bwd_val'], graph.nnz, plan('fwd'), plan('bwd'))

@@ -74,20 +74,24 @@ def test_combo_loss_matches_oracle():
     assert abs(float(a.detach()) - float(b.detach())) < 1e-7
 
 
-def test_tile_plan_reconstructs_the_graph():
-    """Host logic of the LDS-tiled SpMM: (tile_cols, local) must address exactly the CSR column of every entry."""
+def test_row_block_plan_reconstructs_the_graph():
+    """Host logic of the row-blocked SpMM: the BCSR arrays must hold exactly the entries of the CSR matrix."""
     import numpy as np
     from stc_hip import CsrGraph
-    from stc_hip.graph import TILE_MAX_COLS, TILE_ROWS
-    g = CsrGraph.queen_grid(13, 9)
-    assert g.tiled == (True, True)
-    for side in ('fwd', 'bwd'):
-        h = g._host
-        rp, ci = h[f'{side}_rowptr'].astype(np.int64), h[f'{side}_colidx']
-        tp, tc, loc = h[f'{side}_tile_ptr'], h[f'{side}_tile_cols'], h[f'{side}_local']
-        row_of = np.repeat(np.arange(g.n), np.diff(rp))
-        assert np.array_equal(tc[tp[row_of // TILE_ROWS] + loc], ci)
-        assert np.diff(tp).max() <= TILE_MAX_COLS and tp[-1] == tc.size
-        for t in range(len(tp) - 1):                                   # distinct and sorted within a tile
-            assert np.all(np.diff(tc[tp[t]:tp[t + 1]]) > 0)
-    assert CsrGraph.queen_grid(13, 9, permute_seed=3).tiled == (False, False)
+    from stc_hip.graph import BLOCK_ROWS
+    for g in (CsrGraph.queen_grid(13, 9), CsrGraph.queen_grid(7, 5, permute_seed=3), CsrGraph.from_dense(torch.zeros(6, 6))):
+        dense = g.to_dense().numpy()
+        for side, want in (('fwd', dense.T), ('bwd', dense)):
+            h = g._host
+            bp, bc, bv = h[f'{side}_blk_ptr'], h[f'{side}_blk_cols'], h[f'{side}_blk_vals']
+            got = np.zeros_like(want)
+            for blk in range(len(bp) - 1):
+                cols = bc[bp[blk]:bp[blk + 1]]
+                assert np.all(np.diff(cols) > 0)                       # distinct and sorted within a block
+                for r in range(BLOCK_ROWS):
+                    if blk * BLOCK_ROWS + r < g.n:
+                        got[blk * BLOCK_ROWS + r, cols] = bv[bp[blk]:bp[blk + 1], r]
+                    else:
+                        assert not bv[bp[blk]:bp[blk + 1], r].any()    # rows past the end carry zeros
+            assert np.array_equal(got, want)
+            assert bp[-1] == bc.size == bv.shape[0] and bv.shape[1] == BLOCK_ROWS

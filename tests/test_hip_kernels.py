@@ -79,34 +79,32 @@ def _banded_graph(n, half_width, seed):
     return CsrGraph.from_dense(V), V
 
 
-@pytest.mark.parametrize('n,F,B,hw', [(203, 1024, 1, 4), (77, 640, 2, 3), (64, 256, 1, 6), (1000, 64, 1, 2)])
-def test_csr_spmm_lds_tiled_equals_direct(hip, n, F, B, hw):
-    """LDS-tiled kernel (per-tile distinct-column plan) vs the direct kernel vs the CPU twin; ragged last tile,
-    ragged last 1 KiB column block (F=640), in-place beta epilogue, both orientations of the graph."""
+@pytest.mark.parametrize('n,F,B,hw', [(203, 1024, 1, 4), (77, 640, 2, 3), (64, 256, 1, 6), (1001, 64, 1, 2), (30, 2048, 1, 40)])
+def test_bcsr_spmm_equals_csr(hip, n, F, B, hw):
+    """Row-blocked kernel (4 output rows per wave, distinct neighbour rows fetched once per block) vs the CSR kernel
+    vs a dense matmul; ragged last block (n % 4 != 0), an empty row, block lists longer than the LDS-staged
+    segment (dense band, hw=40), two column blocks (F=2048), in-place beta epilogue, both graph orientations."""
     graph, V = _banded_graph(n, hw, seed=n + F)
-    assert graph.tiled == (True, True)
     d = graph.on(torch.device('cuda'))
     g = torch.Generator().manual_seed(F)
     X = torch.randn(B, n, F, generator=g)
     Y0 = torch.randn(B, n, F, generator=g)
     for side, dense in (('fwd', V.t()), ('bwd', V)):
         rp, ci, vals = d[f'{side}_rowptr'], d[f'{side}_colidx'], d[f'{side}_val']
-        plan = (d[f'{side}_tile_ptr'], d[f'{side}_tile_cols'], d[f'{side}_local'])
+        plan = (d[f'{side}_blk_ptr'], d[f'{side}_blk_cols'], d[f'{side}_blk_vals'])
         for alpha, beta in ((1.0, 0.0), (2.0, -1.0)):
             want = alpha * torch.einsum('rc,bcf->brf', dense, X) + beta * Y0
-            direct = Y0.clone().cuda()
-            hip.csr_spmm(rp, ci, vals, n, n, cu(X), direct if beta else None, direct, alpha, beta)
-            tiled = Y0.clone().cuda()
-            hip.csr_spmm(rp, ci, vals, n, n, cu(X), tiled if beta else None, tiled, alpha, beta, plan=plan)
-            assert rel_err(direct, want) < TOL and rel_err(tiled, want) < TOL
-            assert rel_err(tiled, direct) < 2e-6
+            csr = Y0.clone().cuda()
+            hip.csr_spmm(rp, ci, vals, n, n, cu(X), csr if beta else None, csr, alpha, beta)
+            blocked = Y0.clone().cuda()
+            hip.csr_spmm(rp, ci, vals, n, n, cu(X), blocked if beta else None, blocked, alpha, beta, plan=plan)
+            assert rel_err(csr, want) < TOL and rel_err(blocked, want) < TOL
+            assert rel_err(blocked, csr) < 2e-6
 
 
-def test_tile_plan_absent_without_locality():
-    assert CsrGraph.queen_grid(40, 40).tiled == (True, True)
-    assert CsrGraph.queen_grid(40, 40, permute_seed=1).tiled == (False, False)     # random node order: direct kernel
-    dense = CsrGraph.from_dense(torch.ones(64, 64))
-    assert dense.tiled == (False, False)
+def test_row_block_plan_fetch_counts():
+    assert CsrGraph.queen_grid(40, 40).fetches_per_row[0] < 5.0                      # 18 fetches per 4 rows in the interior
+    assert CsrGraph.queen_grid(40, 40, permute_seed=1).fetches_per_row[0] > 7.0     # random node order: nothing to share
 
 
 def test_csr_spmm_zero_sizes_and_errors(hip):
@@ -402,9 +400,9 @@ def test_full_size_spmm_properties(hip):
     graph = CsrGraph.queen_grid(H, W, normalize=True)
     d = graph.on(torch.device('cuda'))
     N, F = H * W, 1024
-    assert graph.nnz == 398724 and graph.tiled == (True, True)
-    plan_f = (d['fwd_tile_ptr'], d['fwd_tile_cols'], d['fwd_local'])
-    plan_b = (d['bwd_tile_ptr'], d['bwd_tile_cols'], d['bwd_local'])
+    assert graph.nnz == 398724 and 4.4 < graph.fetches_per_row[0] < 4.6
+    plan_f = (d['fwd_blk_ptr'], d['fwd_blk_cols'], d['fwd_blk_vals'])
+    plan_b = (d['bwd_blk_ptr'], d['bwd_blk_cols'], d['bwd_blk_vals'])
     ones = torch.ones(1, N, F, device='cuda')
     out = torch.empty_like(ones)
     hip.csr_spmm(d['bwd_rowptr'], d['bwd_colidx'], d['bwd_val'], N, N, ones, None, out, 1.0, 0.0, plan=plan_b)
@@ -413,7 +411,7 @@ def test_full_size_spmm_properties(hip):
     x = torch.randn(1, N, F, device='cuda', generator=g)
     y = torch.randn(1, N, F, device='cuda', generator=g)
     STx, Sy = torch.empty_like(x), torch.empty_like(x)
-    hip.csr_spmm(d['fwd_rowptr'], d['fwd_colidx'], d['fwd_val'], N, N, x, None, STx, 1.0, 0.0, plan=plan_f)   # LDS-tiled
+    hip.csr_spmm(d['fwd_rowptr'], d['fwd_colidx'], d['fwd_val'], N, N, x, None, STx, 1.0, 0.0, plan=plan_f)   # row-blocked
     hip.csr_spmm(d['bwd_rowptr'], d['bwd_colidx'], d['bwd_val'], N, N, y, None, Sy, 1.0, 0.0)                # direct
     lhs, rhs = (STx.double() * y.double()).sum(), (x.double() * Sy.double()).sum()
     assert abs(float(lhs - rhs)) < 1e-6 * abs(float(rhs)) + 1e-3

@@ -39,17 +39,17 @@ def main():
     ap.add_argument('--iters', type=int, default=30)
     ap.add_argument('--permute', action='store_true')
     ap.add_argument('--only', default='', help="'spmm' = just the SpMM lines")
-    ap.add_argument('--no-tile', action='store_true', help='direct SpMM kernel even when the graph has a tile plan')
+    ap.add_argument('--no-tile', action='store_true', help='CSR SpMM kernel instead of the row-blocked one')
     a = ap.parse_args()
     hip = HipKernels()
     dev = torch.device('cuda')
     N, C, h, K, B = a.grid ** 2, a.C, a.h, a.K, a.B
     g = CsrGraph.queen_grid(a.grid, a.grid, permute_seed=1234 if a.permute else None, device=dev).on(dev)
     nnz = g['fwd_colidx'].numel()
-    plan_f = (g['fwd_tile_ptr'], g['fwd_tile_cols'], g['fwd_local']) if 'fwd_tile_ptr' in g and not a.no_tile else None
-    plan_b = (g['bwd_tile_ptr'], g['bwd_tile_cols'], g['bwd_local']) if 'bwd_tile_ptr' in g and not a.no_tile else None
+    plan_f = (g['fwd_blk_ptr'], g['fwd_blk_cols'], g['fwd_blk_vals']) if not a.no_tile else None
+    plan_b = (g['bwd_blk_ptr'], g['bwd_blk_cols'], g['bwd_blk_vals']) if not a.no_tile else None
     print(f'# N={N} nnz={nnz} C={C} h={h} K={K} B={B} permute={a.permute} MFMA={"off" if os.environ.get("STC_DISABLE_MFMA") == "1" else "on"} '
-          f'SPMM_VARIANT={os.environ.get("STC_SPMM_VARIANT", "default")} tiled={plan_f is not None}')
+          f'SPMM_VARIANT={os.environ.get("STC_SPMM_VARIANT", "default")} row_blocked={plan_f is not None}')
 
     def report(name, us, nbytes):
         print(f'{name:34s} {us:9.1f} us   {nbytes/1e6:9.1f} MB   {nbytes/us/1e3:8.1f} GB/s', flush=True)

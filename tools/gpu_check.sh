@@ -28,6 +28,7 @@ if [ "${KBENCH:-1}" = "1" ]; then
   timeout 600 python tools/bench_kernels.py > gpurun_out/kbench.log 2>&1; echo "kbench exit $?"; cat gpurun_out/kbench.log
   timeout 300 python tools/bench_kernels.py --only spmm --no-tile 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/kbench.log
   timeout 300 python tools/bench_kernels.py --only spmm --permute 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/kbench.log
+  timeout 300 python tools/bench_kernels.py --only spmm --permute --no-tile 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/kbench.log
   for v in ${SPMM_VARIANTS:-}; do
     STC_SPMM_VARIANT=$v timeout 300 python tools/bench_kernels.py --only spmm 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/kbench_spmm.log
     STC_SPMM_VARIANT=$v timeout 300 python tools/bench_kernels.py --only spmm --permute 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/kbench_spmm.log
