@@ -51,7 +51,7 @@ def _declare(lib):
     lib.stc_last_error.argtypes = []
     sig = {
         'stc_csr_spmm_f32': [_p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _f32, _p],
-        'stc_bcsr_spmm_f32': [_p, _p, _p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _f32, _p],
+        'stc_bcsr_spmm_f32': [_p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _f32, _p],
         'stc_csr_sddmm_f32': [_p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _i32, _p],
         'stc_cheby_dense_fwd_f32': [_p, _i32, _i32, _p, _p],
         'stc_cheby_dense_bwd_f32': [_p, _p, _p, _i32, _i32, _p, _p],

@@ -95,3 +95,32 @@ def test_row_block_plan_reconstructs_the_graph():
                         assert not bv[bp[blk]:bp[blk + 1], r].any()    # rows past the end carry zeros
             assert np.array_equal(got, want)
             assert bp[-1] == bc.size == bv.shape[0] and bv.shape[1] == BLOCK_ROWS
+
+
+def test_ctypes_signatures_match_the_header():
+    """Every prototype in include/stc_hip.h has the same number and kinds of parameters as its ctypes argtypes
+    (a mismatch only shows up as a TypeError at the first launch on the GPU box otherwise)."""
+    import ctypes as C
+    text = open(os.path.join(REPO, 'include', 'stc_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    lib = _lib.load_library()
+    protos = re.findall(r'\b(?:int|size_t|const char\*)\s+(stc_[a-z0-9_]+)\s*\(([^)]*)\)\s*;', text)
+    assert len(protos) == len(_lib.EXPORTS)
+    kind = {C.c_void_p: 'ptr', C.c_int32: 'i32', C.c_int64: 'i64', C.c_float: 'f32', C.c_size_t: 'size', C.POINTER(C.c_void_p): 'ptr'}
+    for name, params in protos:
+        want = []
+        for prm in [q.strip() for q in params.split(',') if q.strip() and q.strip() != 'void']:
+            if '*' in prm:
+                want.append('ptr')
+            elif prm.startswith('int32_t'):
+                want.append('i32')
+            elif prm.startswith('int64_t'):
+                want.append('i64')
+            elif prm.startswith('float'):
+                want.append('f32')
+            elif prm.startswith('size_t'):
+                want.append('size')
+            else:
+                raise AssertionError(f'{name}: unparsed parameter {prm!r}')
+        got = [kind[t] for t in (getattr(lib, name).argtypes or [])]
+        assert got == want, f'{name}: ctypes {got} vs header {want}'
