@@ -12,7 +12,8 @@ the batch x time-window dimension is sharded, the graph replicated, no data-path
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline      the CSR-SpMM aggregation (the kernel the metric names): algorithmic bytes per launch
-                (nnz*(4+4) + 4*(N+1) + 2*B*N*F*4) / mean launch duration, measured with
+                (nnz*(4+4) + 4*(N+1) + 2*B*N*F*4; + B*N*F*4 for the launches whose epilogue
+                also reads Y0, i.e. Y = Y0 + S.X of the backward) / mean launch duration, measured with
                 HIP events on the launching stream around every SpMM launch of the timed steps
   kernels       time share of every C-ABI entry point over the same steps (same events)
   cpu_baseline  the CPU oracle (oracle/stc_oracle.py, sparse feature-side variant because the
@@ -143,7 +144,10 @@ def main():
 
     if rank == 0:
         total_ms = sum(d['ms'] for d in per_kernel.values()) or 1.0
-        spmm = per_kernel.get('stc_csr_spmm_f32', dict(launches=0, ms=0.0, bytes=0))
+        spmm = dict(launches=0, ms=0.0, bytes=0)           # both forms of the aggregation: CSR and row-blocked CSR
+        for name in ('stc_csr_spmm_f32', 'stc_bcsr_spmm_f32'):
+            for key, v in per_kernel.get(name, {}).items():
+                spmm[key] += v
         achieved = (spmm['bytes'] / 1e9) / (spmm['ms'] / 1e3) if spmm['ms'] > 0 else 0.0
         out = {
             'metric': METRIC, 'value': world * B * a.steps / elapsed, 'unit': 'samples/s',
@@ -154,7 +158,7 @@ def main():
                                    f'hidden={a.hidden}, K={a.order}, layers={a.layers}, T={a.obs}+{a.pred}',
                        'global_batch': world * B, 'batch_per_gpu': B, 'parallelism': f'batch-shard x{world}',
                        'grad_bucket_bytes': bucket.nbytes},
-            'roofline': {'bound': 'hbm', 'kernel': 'stc_csr_spmm_f32', 'achieved': achieved, 'peak': HBM_PEAK_GBPS,
+            'roofline': {'bound': 'hbm', 'kernel': 'stc_bcsr_spmm_f32 + stc_csr_spmm_f32 (all launches of the timed steps)', 'achieved': achieved, 'peak': HBM_PEAK_GBPS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,
                          'launches': spmm['launches'],
                          'avg_launch_us': 1e3 * spmm['ms'] / max(1, spmm['launches']),

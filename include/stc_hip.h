@@ -31,13 +31,14 @@
 extern "C" {
 #endif
 
-#define STC_ABI_VERSION 5
+#define STC_ABI_VERSION 6
 #define STC_MAX_K 4          /* highest Chebyshev order (Ks, Kc) the node kernels accept */
 
 #define STC_OK 0
 #define STC_EINVAL (-1)
 #define STC_EALIGN (-2)
 #define STC_ELIMIT (-3)
+#define STC_EUNSUPPORTED (-4) /* shape outside a fused fast path: use the unfused entry points */
 
 int stc_version(void);
 const char* stc_last_error(void);
@@ -127,6 +128,25 @@ int stc_gru_blend_fwd_f32(const float* Cpre, const float* U, const float* H,
                           float* Cand, float* Hnew, int64_t n, void* stream);
 int stc_gru_blend_bwd_f32(const float* dHnew, const float* U, const float* H, const float* Cand,
                           float* dCpre, float* dU, float* dH, int64_t n, void* stream);
+
+/* ---- fused cell convolutions (STC_GNN.py:69-78) ------------------------------------
+ * The two BDG_Dif of an STC_Cell with the gate math folded into the node kernel's epilogue, so the
+ * pre-activations never go to HBM:
+ *   gates: [U | R] = sigmoid(node_fwd(Z; W, bias)),  CandIn = [Xt | R*H | 0-pad]   (Xt = first cin columns of Z[0])
+ *   blend: Cand = tanh(node_fwd(Z; W, bias)),        Hnew = (1-U)*H + U*Cand
+ * Z, Tc, W, bias, L, Lw as stc_bdg_node_fwd_f32 (W (Ks*Kc*Lw, 2h) resp. (Ks*Kc*Lw, h)); H/U/R/Cand/Hnew
+ * (nodes, C, h); CandIn (nodes, C, L).  Only the MFMA shapes are fused: stc_cell_fused_supported() tells
+ * (h = 16, C in {16,32,64}, L in {20,32}, Ks = Kc <= 3); otherwise these return STC_EUNSUPPORTED and the
+ * caller runs stc_bdg_node_fwd_f32 + stc_gru_gates_fwd_f32 / stc_gru_blend_fwd_f32. */
+int stc_cell_fused_supported(int32_t Ks, int32_t Kc, int32_t C, int32_t L, int32_t h);
+int stc_cell_gates_fwd_f32(const float* const* Z, int32_t Ks, const float* Tc, int32_t Kc,
+                           const float* W, const float* bias, const float* H,
+                           float* U, float* Rg, float* CandIn,
+                           int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t h, int32_t cin, void* stream);
+int stc_cell_blend_fwd_f32(const float* const* Z, int32_t Ks, const float* Tc, int32_t Kc,
+                           const float* W, const float* bias, const float* U, const float* H,
+                           float* Cand, float* Hnew,
+                           int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t h, void* stream);
 
 /* ---- output head (STC_GNN.py:182-183, 206) -----------------------------------
  * The reference applies Linear(h, h/2) then Linear(h/2, 1) with NO nonlinearity in between, then a sigmoid:

@@ -122,6 +122,22 @@ class EmulatedKernels:
                     U += Zs[n][..., :Lw] @ Wv[n, c]
                 dTc[c].copy_(torch.einsum('rpo,rdo->pd', U, dY))
 
+    # ---- stc_cell_gates/blend_fwd_f32: node kernel + gate math in its epilogue (STC_GNN.py:69-78)
+    def cell_fused_supported(self, Ks, Kc, Cc, L, h) -> bool:
+        return Ks == Kc                 # the twin composes the unfused kernels, any shape
+
+    def cell_gates_fwd(self, Zs, Tc, W, bias, H, U, Rg, CandIn):
+        h = H.shape[-1]
+        cin = W.shape[0] // (len(Zs) * Tc.shape[0]) - h
+        G = torch.empty(H.shape[:-1] + (2 * h,), dtype=W.dtype)
+        self.bdg_node_fwd(Zs, Tc, W, bias, G)
+        self.gru_gates_fwd(G, Zs[0][..., :cin], H, U, Rg, CandIn)
+
+    def cell_blend_fwd(self, Zs, Tc, W, bias, U, H, Cand, Hnew):
+        Cpre = torch.empty_like(H)
+        self.bdg_node_fwd(Zs, Tc, W, bias, Cpre)
+        self.gru_blend_fwd(Cpre, U, H, Cand, Hnew)
+
     # ---- stc_gru_gates_fwd/bwd_f32: split + sigmoids + reset*H + second concat (STC_GNN.py:71-75)
     def gru_gates_fwd(self, G, Xt, H, U, Rg, CandIn):
         h = H.shape[-1]

@@ -379,6 +379,38 @@ extern "C" int stc_bdg_node_fwd_f32(const float* const* Z, int32_t Ks, const flo
     return STC_OK;
 }
 
+extern "C" int stc_cell_fused_supported(int32_t Ks, int32_t Kc, int32_t C, int32_t L, int32_t h) {
+    return (mfma_enabled() && Ks == Kc && stc_cell_fused_shape_ok(Ks, C, L, h)) ? 1 : 0;
+}
+
+extern "C" int stc_cell_gates_fwd_f32(const float* const* Z, int32_t Ks, const float* Tc, int32_t Kc,
+                                      const float* W, const float* bias, const float* H,
+                                      float* U, float* Rg, float* CandIn,
+                                      int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t h, int32_t cin, void* stream) {
+    if (int rc = check_dims("stc_cell_gates_fwd_f32", Ks, Kc, C, L, Lw, 2 * h, nodes)) return rc;
+    STC_REQUIRE(cin >= 0 && cin + h <= L, STC_EINVAL, "stc_cell_gates_fwd_f32: cin=%d + h=%d exceed the row width L=%d", cin, h, L);
+    if (!stc_cell_fused_supported(Ks, Kc, C, L, h)) return stc::fail(STC_EUNSUPPORTED, "stc_cell_gates_fwd_f32: shape not on the fused path");
+    if (nodes == 0) return STC_OK;
+    STC_REQUIRE(Z && W && H && U && Rg && CandIn && (Kc == 1 || Tc), STC_EINVAL, "stc_cell_gates_fwd_f32: null pointer");
+    for (int n = 0; n < Ks; ++n) STC_REQUIRE(Z[n], STC_EINVAL, "stc_cell_gates_fwd_f32: Z[%d] is null", n);
+    STC_REQUIRE(Z[0] != CandIn, STC_EINVAL, "stc_cell_gates_fwd_f32: CandIn must not alias Z[0]");
+    const int rc = stc_cell_gates_fwd_mfma(Z, Ks, Tc, W, bias, H, U, Rg, CandIn, nodes, C, L, Lw, cin, static_cast<hipStream_t>(stream));
+    return rc == STC_NOT_HANDLED ? stc::fail(STC_EUNSUPPORTED, "stc_cell_gates_fwd_f32: operands not usable by the fused path (alignment)") : rc;
+}
+
+extern "C" int stc_cell_blend_fwd_f32(const float* const* Z, int32_t Ks, const float* Tc, int32_t Kc,
+                                      const float* W, const float* bias, const float* U, const float* H,
+                                      float* Cand, float* Hnew,
+                                      int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t h, void* stream) {
+    if (int rc = check_dims("stc_cell_blend_fwd_f32", Ks, Kc, C, L, Lw, h, nodes)) return rc;
+    if (!stc_cell_fused_supported(Ks, Kc, C, L, h)) return stc::fail(STC_EUNSUPPORTED, "stc_cell_blend_fwd_f32: shape not on the fused path");
+    if (nodes == 0) return STC_OK;
+    STC_REQUIRE(Z && W && U && H && Cand && Hnew && (Kc == 1 || Tc), STC_EINVAL, "stc_cell_blend_fwd_f32: null pointer");
+    for (int n = 0; n < Ks; ++n) STC_REQUIRE(Z[n], STC_EINVAL, "stc_cell_blend_fwd_f32: Z[%d] is null", n);
+    const int rc = stc_cell_blend_fwd_mfma(Z, Ks, Tc, W, bias, U, H, Cand, Hnew, nodes, C, L, Lw, static_cast<hipStream_t>(stream));
+    return rc == STC_NOT_HANDLED ? stc::fail(STC_EUNSUPPORTED, "stc_cell_blend_fwd_f32: operands not usable by the fused path (alignment)") : rc;
+}
+
 extern "C" size_t stc_bdg_node_bwd_workspace_bytes(int32_t Ks, int32_t Kc, int32_t C, int32_t L, int32_t Ho,
                                                    int32_t /*want_dTc*/) {
     if (Ks < 1 || Kc < 1 || C < 1 || L < 1 || Ho < 1) return 0;

@@ -16,3 +16,12 @@ int stc_node_bwd_mfma_max_partials();
 int stc_node_bwd_mfma(const float* const* Z, int Ks, const float* Tc, int Kc, const float* W, const float* dY,
                       float* const* dZ, float* partial, int* n_partials, int want_db,
                       long long nodes, int C, int L, int Lw, int Ho, hipStream_t stream);
+
+// Fused STC_Cell epilogues (hidden width 16 only): STC_NOT_HANDLED outside the MFMA shapes.
+int stc_cell_fused_shape_ok(int K, int C, int L, int h);
+int stc_cell_gates_fwd_mfma(const float* const* Z, int K, const float* Tc, const float* W, const float* bias,
+                            const float* H, float* U, float* R, float* CandIn,
+                            long long nodes, int C, int L, int Lw, int cin, hipStream_t stream);
+int stc_cell_blend_fwd_mfma(const float* const* Z, int K, const float* Tc, const float* W, const float* bias,
+                            const float* U, const float* H, float* Cand, float* Hnew,
+                            long long nodes, int C, int L, int Lw, hipStream_t stream);

@@ -85,11 +85,31 @@ struct ZFrag {      // one node's A operand: this lane's row of every slab / row
     }
 };
 
-template <int NRB, int HB, int K, int LQ>
+// Fused epilogues of the two convolutions of an STC_Cell (reference STC_GNN.py:71-78), hidden width 16:
+//   EPI_GATES (Ho = 32): U = sigmoid(y[:, :16]), R = sigmoid(y[:, 16:]), CandIn = [Xt | R*H | 0-pad]  -- the
+//              gate pre-activations are never written; Xt is copied from this wave's own A fragment of slab 0
+//   EPI_BLEND (Ho = 16): Cand = tanh(y), Hnew = (1-U)*H + U*Cand
+enum { EPI_NONE = 0, EPI_GATES = 1, EPI_BLEND = 2 };
+struct FwdEpi {
+    const float* H;       // (nodes, C, 16) previous state
+    const float* U;       // BLEND in : update gate
+    float* U_out;         // GATES out: update gate
+    float* R_out;         // GATES out: reset gate
+    float* CandIn;        // GATES out: (nodes, C, L) input rows of the candidate convolution
+    float* Cand;          // BLEND out: tanh(candidate)
+    float* Hnew;          // BLEND out: new state
+    int cin;              // GATES: width of Xt inside a row (the H part starts there)
+};
+
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+
+template <int NRB, int HB, int K, int LQ, int EPI>
 __global__ __launch_bounds__(MF_THREADS, ((NRB * K * LQ <= 32) ? 3 : 2)) void node_fwd_mfma_kernel(
     ZPtrs Z, const float* __restrict__ Tc, const float* __restrict__ W, const float* __restrict__ bias,
-    float* __restrict__ Y, int nodes, int Lw) {
+    float* __restrict__ Y, int nodes, int Lw, FwdEpi epi) {
     constexpr int C = 16 * NRB, Ho = 16 * HB, L = 4 * LQ, NCB = K * HB;
+    constexpr int HID = 16;            // hidden width the fused epilogues are built for
+    static_assert(EPI == EPI_NONE || (EPI == EPI_GATES && HB == 2) || (EPI == EPI_BLEND && HB == 1), "epilogue needs hidden = 16");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Wf = smem;                              // [K][LQ][NCB][64]   B fragments of the projection
     float* Tf = smem + K * LQ * NCB * 64;          // [K-1][NRB rb][NRB kb][4][64]   A fragments of the mix
@@ -127,6 +147,18 @@ __global__ __launch_bounds__(MF_THREADS, ((NRB * K * LQ <= 32) ? 3 : 2)) void no
     while (node < nodes) {
         const int next_node = node + nw;
         if (next_node < nodes) nxt.load(Z, next_node, j, q);     // software prefetch: lands while this node computes
+        // epilogue operands in accumulator layout (row 16rb + 4q + r, column j): needed only after the MFMAs
+        float hv[NRB][4], uv[NRB][4];
+        if (EPI != EPI_NONE) {
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const size_t e = ((size_t)node * C + 16 * rb + 4 * q + r) * HID + j;
+                    hv[rb][r] = epi.H[e];
+                    if (EPI == EPI_BLEND) uv[rb][r] = epi.U[e];
+                }
+        }
         __builtin_amdgcn_sched_barrier(0);
         const int lo = opaque(lane);
 
@@ -165,13 +197,49 @@ __global__ __launch_bounds__(MF_THREADS, ((NRB * K * LQ <= 32) ? 3 : 2)) void no
                     }
 
         // accumulator layout: lane (j, q), register r  <->  row 4q + r, column j of the 16 x 16 tile
+        if (EPI == EPI_NONE) {
 #pragma unroll
-        for (int rb = 0; rb < NRB; ++rb)
+            for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
-            for (int hb = 0; hb < HB; ++hb)
+                for (int hb = 0; hb < HB; ++hb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    Y[((size_t)node * C + 16 * rb + 4 * q + r) * Ho + 16 * hb + j] = acc[rb][hb][r] + bv[hb];
+                    for (int r = 0; r < 4; ++r)
+                        Y[((size_t)node * C + 16 * rb + 4 * q + r) * Ho + 16 * hb + j] = acc[rb][hb][r] + bv[hb];
+        } else if (EPI == EPI_GATES) {
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const size_t row = (size_t)node * C + 16 * rb + 4 * q + r;
+                    const float u = sigmoid_f(acc[rb][0][r] + bv[0]);
+                    const float g = sigmoid_f(acc[rb][HB - 1][r] + bv[HB - 1]);
+                    epi.U_out[row * HID + j] = u;
+                    epi.R_out[row * HID + j] = g;
+                    epi.CandIn[row * L + epi.cin + j] = g * hv[rb][r];
+                }
+            // the Xt columns and the zero padding of CandIn come from this lane's own row of slab 0
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+                float* crow = epi.CandIn + ((size_t)node * C + 16 * rb + j) * L;
+#pragma unroll
+                for (int s = 0; s < LQ; ++s) {
+                    const int col = kcol<LQ>(s, q);
+                    if (col < epi.cin) crow[col] = cur.at(0, rb, s);
+                    else if (col >= epi.cin + HID) crow[col] = 0.f;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const size_t e = ((size_t)node * C + 16 * rb + 4 * q + r) * HID + j;
+                    const float c = tanhf(acc[rb][0][r] + bv[0]);
+                    const float u = uv[rb][r];
+                    epi.Cand[e] = c;
+                    epi.Hnew[e] = (1.f - u) * hv[rb][r] + u * c;
+                }
+        }
         cur = nxt;
         node = next_node;
     }
@@ -410,20 +478,20 @@ __global__ __launch_bounds__(MF_THREADS, (BwdPlan<NRB, HB, K, LQ>::prefetch ? 2 
     }
 }
 
-template <int NRB, int HB, int K, int LQ>
+template <int NRB, int HB, int K, int LQ, int EPI = EPI_NONE>
 int launch_fwd(const float* const* Z, const float* Tc, const float* W, const float* bias, float* Y,
-               long long nodes, int Lw, hipStream_t stream) {
+               long long nodes, int Lw, hipStream_t stream, FwdEpi epi = FwdEpi{}) {
     constexpr int NCB = K * HB;
     const size_t lds = (size_t)(K * LQ * NCB * 64 + (K - 1) * NRB * NRB * 4 * 64) * sizeof(float);
     if (lds > stc::kMaxLdsBytes) return STC_NOT_HANDLED;
-    auto kern = node_fwd_mfma_kernel<NRB, HB, K, LQ>;
+    auto kern = node_fwd_mfma_kernel<NRB, HB, K, LQ, EPI>;
     if (int rc = stc::hip_status(stc::allow_lds(kern, lds), "hipFuncSetAttribute(node fwd mfma)")) return rc;
     static const int resident = stc::resident_blocks(kern, MF_THREADS, lds, 2);   // persistent grid = what fits at once
     ZPtrs zp{};
     for (int n = 0; n < K; ++n) zp.p[n] = Z[n];
     const long long want = (nodes + MF_WAVES - 1) / MF_WAVES;
     const int grid = (int)(want < resident ? want : resident);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(MF_THREADS), lds, stream, zp, Tc, W, bias, Y, (int)nodes, Lw);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(MF_THREADS), lds, stream, zp, Tc, W, bias, Y, (int)nodes, Lw, epi);
     STC_LAUNCH_CHECK("node_fwd_mfma launch");
     return STC_OK;
 }
@@ -485,6 +553,45 @@ int stc_node_fwd_mfma(const float* const* Z, int Ks, const float* Tc, int Kc, co
 #define FWD_CALL(a, b, c, d) launch_fwd<a, b, c, d>(Z, Tc, W, bias, Y, nodes, Lw, stream)
     STC_MF_DISPATCH(FWD_CALL)
 #undef FWD_CALL
+    return STC_NOT_HANDLED;
+}
+
+// ---- fused cell epilogues: hidden width 16, C in {16,32,64}, L in {20,32}, K in {1,2,3}
+#define STC_MF_EPI_CASE(NRB_, CALL)                                                                     \
+    if (C == 16 * NRB_) {                                                                               \
+        if (K == 1 && L == 20) return CALL(NRB_, 1, 5);                                                 \
+        if (K == 1 && L == 32) return CALL(NRB_, 1, 8);                                                 \
+        if (K == 2 && L == 20) return CALL(NRB_, 2, 5);                                                 \
+        if (K == 2 && L == 32) return CALL(NRB_, 2, 8);                                                 \
+        if (K == 3 && L == 20) return CALL(NRB_, 3, 5);                                                 \
+        if (K == 3 && L == 32) return CALL(NRB_, 3, 8);                                                 \
+    }
+
+int stc_cell_fused_shape_ok(int K, int C, int L, int h) {
+    return K >= 1 && K <= 3 && (C == 16 || C == 32 || C == 64) && (L == 20 || L == 32) && h == 16;
+}
+
+int stc_cell_gates_fwd_mfma(const float* const* Z, int K, const float* Tc, const float* W, const float* bias,
+                            const float* H, float* U, float* R, float* CandIn,
+                            long long nodes, int C, int L, int Lw, int cin, hipStream_t stream) {
+    if (!stc_cell_fused_shape_ok(K, C, L, 16) || nodes <= 0 || nodes >= (1ll << 31) / C || !all_aligned16(Z, K)) return STC_NOT_HANDLED;
+    FwdEpi epi{};
+    epi.H = H; epi.U_out = U; epi.R_out = R; epi.CandIn = CandIn; epi.cin = cin;
+#define GATES_CALL(a, c, d) launch_fwd<a, 2, c, d, EPI_GATES>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi)
+    STC_MF_EPI_CASE(1, GATES_CALL) STC_MF_EPI_CASE(2, GATES_CALL) STC_MF_EPI_CASE(4, GATES_CALL)
+#undef GATES_CALL
+    return STC_NOT_HANDLED;
+}
+
+int stc_cell_blend_fwd_mfma(const float* const* Z, int K, const float* Tc, const float* W, const float* bias,
+                            const float* U, const float* H, float* Cand, float* Hnew,
+                            long long nodes, int C, int L, int Lw, hipStream_t stream) {
+    if (!stc_cell_fused_shape_ok(K, C, L, 16) || nodes <= 0 || nodes >= (1ll << 31) / C || !all_aligned16(Z, K)) return STC_NOT_HANDLED;
+    FwdEpi epi{};
+    epi.H = H; epi.U = U; epi.Cand = Cand; epi.Hnew = Hnew;
+#define BLEND_CALL(a, c, d) launch_fwd<a, 1, c, d, EPI_BLEND>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi)
+    STC_MF_EPI_CASE(1, BLEND_CALL) STC_MF_EPI_CASE(2, BLEND_CALL) STC_MF_EPI_CASE(4, BLEND_CALL)
+#undef BLEND_CALL
     return STC_NOT_HANDLED;
 }
 

@@ -19,7 +19,7 @@ import torch
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG_ROOT, 'libstc_hip.so')
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_K = 4
 
 #: every symbol ``include/stc_hip.h`` declares (the CPU test-suite checks the .so exports them all)
@@ -28,6 +28,7 @@ EXPORTS = (
     'stc_csr_spmm_f32', 'stc_bcsr_spmm_f32', 'stc_csr_sddmm_f32',
     'stc_cheby_dense_fwd_f32', 'stc_cheby_dense_bwd_f32',
     'stc_bdg_node_fwd_f32', 'stc_bdg_node_bwd_workspace_bytes', 'stc_bdg_node_bwd_f32',
+    'stc_cell_fused_supported', 'stc_cell_gates_fwd_f32', 'stc_cell_blend_fwd_f32',
     'stc_gru_gates_fwd_f32', 'stc_gru_gates_bwd_f32', 'stc_gru_blend_fwd_f32', 'stc_gru_blend_bwd_f32',
     'stc_head_fwd_f32', 'stc_head_bwd_workspace_bytes', 'stc_head_bwd_f32',
     'stc_axpy_f32', 'stc_concat2_f32', 'stc_split2_f32',
@@ -58,6 +59,8 @@ def _declare(lib):
         'stc_bdg_node_fwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
         'stc_bdg_node_bwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, C.POINTER(_p), _p, _p, _p,
                                  _p, C.c_size_t, _i64, _i32, _i32, _i32, _i32, _p],
+        'stc_cell_gates_fwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _i32, _p],
+        'stc_cell_blend_fwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
         'stc_gru_gates_fwd_f32': [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p],
         'stc_gru_gates_bwd_f32': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p],
         'stc_gru_blend_fwd_f32': [_p, _p, _p, _p, _p, _i64, _p],
@@ -72,6 +75,8 @@ def _declare(lib):
         fn = getattr(lib, name)
         fn.restype = C.c_int
         fn.argtypes = argtypes
+    lib.stc_cell_fused_supported.restype = C.c_int
+    lib.stc_cell_fused_supported.argtypes = [_i32, _i32, _i32, _i32, _i32]
     lib.stc_head_bwd_workspace_bytes.restype = C.c_size_t
     lib.stc_head_bwd_workspace_bytes.argtypes = [_i32]
     lib.stc_bdg_node_bwd_workspace_bytes.restype = C.c_size_t
@@ -298,6 +303,38 @@ class HipKernels:
         nbytes = self.lib.stc_bdg_node_bwd_workspace_bytes(Ks, Kc, Cc, L, Ho, int(dTc is not None))
         ws = self._get_workspace(dY.device, nbytes)
         self._launch('stc_bdg_node_bwd_f32', dY, self._ptr_array(Zs), Ks, _ptr(Tc), Kc, _ptr(W), _ptr(dY), self._ptr_array(dZs), _ptr(dW), _ptr(db), _ptr(dTc), _ptr(ws), ws.numel(), R, Cc, L, Lw, Ho)
+
+    # ---- fused cell convolutions ----------------------------------------------------------
+    def cell_fused_supported(self, Ks, Kc, Cc, L, h) -> bool:
+        return bool(self.lib.stc_cell_fused_supported(Ks, Kc, Cc, L, h))
+
+    def cell_gates_fwd(self, Zs, Tc, W, bias, H, U, Rg, CandIn):
+        Ks, Kc, R, Cc, L, Lw, Ho = self._node_shapes(Zs, Tc, W)
+        h = H.shape[-1]
+        cin = Lw - h
+        if Ho != 2 * h or cin < 0:
+            raise StcError(f'cell_gates: W gives Ho={Ho}, Lw={Lw} for hidden {h}')
+        if bias is not None:
+            self._f32('cell.bias', bias, (Ho,))
+        for name, t in (('H', H), ('U', U), ('Rg', Rg)):
+            self._f32('cell.' + name, t, (R, Cc, h))
+        self._f32('cell.CandIn', CandIn, (R, Cc, L))
+        self._same_device(*Zs, Tc, W, bias, H, U, Rg, CandIn)
+        self._launch('stc_cell_gates_fwd_f32', H, self._ptr_array(Zs), Ks, _ptr(Tc), Kc, _ptr(W), _ptr(bias), _ptr(H),
+                     _ptr(U), _ptr(Rg), _ptr(CandIn), R, Cc, L, Lw, h, cin)
+
+    def cell_blend_fwd(self, Zs, Tc, W, bias, U, H, Cand, Hnew):
+        Ks, Kc, R, Cc, L, Lw, Ho = self._node_shapes(Zs, Tc, W)
+        h = H.shape[-1]
+        if Ho != h:
+            raise StcError(f'cell_blend: W gives Ho={Ho} for hidden {h}')
+        if bias is not None:
+            self._f32('cell.bias', bias, (Ho,))
+        for name, t in (('U', U), ('H', H), ('Cand', Cand), ('Hnew', Hnew)):
+            self._f32('cell.' + name, t, (R, Cc, h))
+        self._same_device(*Zs, Tc, W, bias, U, H, Cand, Hnew)
+        self._launch('stc_cell_blend_fwd_f32', H, self._ptr_array(Zs), Ks, _ptr(Tc), Kc, _ptr(W), _ptr(bias), _ptr(U), _ptr(H),
+                     _ptr(Cand), _ptr(Hnew), R, Cc, L, Lw, h)
 
     # ---- GRU gate math -------------------------------------------------------------------
     def gru_gates_fwd(self, G, Xt, H, U, Rg, CandIn):

@@ -75,11 +75,10 @@ def cheby_dense(G: torch.Tensor, K: int) -> torch.Tensor:
 
 
 # ----------------------------------------------------------------------------- BDG_Dif
-def _bdg_forward(X, W, b, Tc, fwd_val, op: SpatialOperand, Ks: int):
-    """Launch sequence of one BDG_Dif forward on raw tensors; returns (Y, [Z_0..Z_{Ks-1}])."""
+def _spatial_slabs(X, fwd_val, op: SpatialOperand, Ks: int):
+    """[Z_0 = X, Z_1 = Gs^T X, Z_k = 2 Gs^T Z_{k-1} - Z_{k-2}]: the Ks-1 SpMM launches of one BDG_Dif."""
     k = kernels()
     B, N, C, L = X.shape
-    Ho = W.shape[1]
     F = C * L
     Zs = [X]
     for order in range(1, Ks):
@@ -90,6 +89,15 @@ def _bdg_forward(X, W, b, Tc, fwd_val, op: SpatialOperand, Ks: int):
             k.csr_spmm(op.fwd_rowptr, op.fwd_colidx, fwd_val, N, N, Zs[-1].view(B, N, F),
                        Zs[-2].view(B, N, F), Zk.view(B, N, F), 2.0, -1.0, plan=op.fwd_plan)
         Zs.append(Zk)
+    return Zs
+
+
+def _bdg_forward(X, W, b, Tc, fwd_val, op: SpatialOperand, Ks: int):
+    """Launch sequence of one BDG_Dif forward on raw tensors; returns (Y, [Z_0..Z_{Ks-1}])."""
+    k = kernels()
+    B, N, C, L = X.shape
+    Ho = W.shape[1]
+    Zs = _spatial_slabs(X, fwd_val, op, Ks)
     Y = X.new_empty(B, N, C, Ho)
     k.bdg_node_fwd([z.view(B * N, C, L) for z in Zs], Tc, W, b, Y.view(B * N, C, Ho))
     return Y, Zs
@@ -294,13 +302,22 @@ class _StcCell(Function):
         lead = H.shape[:-1]
         XH = H.new_empty(lead + (cin + h + pad,))
         k.concat2(Xt, H, XH)
-        G, Zg = _bdg_forward(XH, Wg, bg, Tc, fwd_val, op, Ks)
         U, Rg, CandIn = torch.empty_like(H), torch.empty_like(H), torch.empty_like(XH)
-        k.gru_gates_fwd(G, Xt, H, U, Rg, CandIn)
-        del G
-        Cpre, Zc = _bdg_forward(CandIn, Wc, bc, Tc, fwd_val, op, Ks)
         Cand, Hnew = torch.empty_like(H), torch.empty_like(H)
-        k.gru_blend_fwd(Cpre, U, H, Cand, Hnew)
+        B, N, C, L = XH.shape
+        if k.cell_fused_supported(Ks, Tc.shape[0], C, L, h):
+            # gate math in the node kernels' epilogues: the pre-activations never go to HBM
+            rows = lambda ts: [t.view(B * N, C, t.shape[-1]) for t in ts]
+            Zg = _spatial_slabs(XH, fwd_val, op, Ks)
+            k.cell_gates_fwd(rows(Zg), Tc, Wg, bg, *rows((H, U, Rg, CandIn)))
+            Zc = _spatial_slabs(CandIn, fwd_val, op, Ks)
+            k.cell_blend_fwd(rows(Zc), Tc, Wc, bc, *rows((U, H, Cand, Hnew)))
+        else:
+            G, Zg = _bdg_forward(XH, Wg, bg, Tc, fwd_val, op, Ks)
+            k.gru_gates_fwd(G, Xt, H, U, Rg, CandIn)
+            del G
+            Cpre, Zc = _bdg_forward(CandIn, Wc, bc, Tc, fwd_val, op, Ks)
+            k.gru_blend_fwd(Cpre, U, H, Cand, Hnew)
         ctx.save_for_backward(H, U, Rg, Cand, Wg, Wc, Tc, *Zg, *Zc)
         ctx.op, ctx.Ks, ctx.cin = op, Ks, cin
         ctx.bias = (bg is not None, bc is not None)

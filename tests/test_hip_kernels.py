@@ -281,6 +281,57 @@ def test_bdg_node_padded_feature_rows(hip, nodes, C, L, Lw, Ho, K, node_path):
     assert rel_err(dW, dW_w) < TOL and rel_err(db, db_w) < TOL
 
 
+@pytest.mark.parametrize('nodes,C,cin,K', [(50, 32, 16, 2), (50, 32, 1, 2), (21, 16, 16, 3), (13, 64, 1, 2), (4500, 32, 16, 2),
+                                            (4100, 32, 1, 2), (9, 32, 16, 1)])
+def test_fused_cell_epilogues(hip, nodes, C, cin, K):
+    """Gate math fused into the node kernel's epilogue (hidden 16) vs node kernel + gate kernels of the CPU twin."""
+    h = 16
+    Lw = cin + h
+    L = Lw + (-Lw) % 4
+    assert hip.cell_fused_supported(K, K, C, L, h)
+    g = torch.Generator().manual_seed(nodes + C + cin + K)
+    Zs = [torch.randn(nodes, C, L, generator=g) for _ in range(K)]
+    Zs[0][..., Lw:] = 0.0                                         # pad columns of the concatenated input are zeros
+    Tc = torch.randn(K, C, C, generator=g) / C ** 0.5
+    Tc[0] = torch.eye(C)
+    H = torch.randn(nodes, C, h, generator=g)
+    Wg = torch.randn(K * K * Lw, 2 * h, generator=g) / (K * K * Lw) ** 0.5
+    bg = torch.randn(2 * h, generator=g)
+    U_w, R_w, Ci_w = torch.empty_like(H), torch.empty_like(H), torch.empty(nodes, C, L)
+    EM.cell_gates_fwd(Zs, Tc, Wg, bg, H, U_w, R_w, Ci_w)
+    U, R, Ci = (torch.full(t.shape, float('nan')).cuda() for t in (U_w, R_w, Ci_w))
+    hip.cell_gates_fwd([cu(z) for z in Zs], cu(Tc), cu(Wg), cu(bg), cu(H), U, R, Ci)
+    assert rel_err(U, U_w) < TOL and rel_err(R, R_w) < TOL and rel_err(Ci, Ci_w) < TOL
+    assert float(Ci[..., Lw:].abs().max()) == 0.0 if L > Lw else True
+    assert torch.equal(Ci[..., :cin].cpu(), Zs[0][..., :cin])    # Xt is copied bit for bit
+
+    Wc = torch.randn(K * K * Lw, h, generator=g) / (K * K * Lw) ** 0.5
+    bc = torch.randn(h, generator=g)
+    Cand_w, Hn_w = torch.empty_like(H), torch.empty_like(H)
+    EM.cell_blend_fwd(Zs, Tc, Wc, None, U_w, H, Cand_w, Hn_w)
+    Cand, Hn = torch.full(H.shape, float('nan')).cuda(), torch.full(H.shape, float('nan')).cuda()
+    hip.cell_blend_fwd([cu(z) for z in Zs], cu(Tc), cu(Wc), None, cu(U_w), cu(H), Cand, Hn)
+    assert rel_err(Cand, Cand_w) < TOL and rel_err(Hn, Hn_w) < TOL
+    EM.cell_blend_fwd(Zs, Tc, Wc, bc, U_w, H, Cand_w, Hn_w)
+    hip.cell_blend_fwd([cu(z) for z in Zs], cu(Tc), cu(Wc), cu(bc), cu(U_w), cu(H), Cand, Hn)
+    assert rel_err(Cand, Cand_w) < TOL and rel_err(Hn, Hn_w) < TOL
+
+
+def test_fused_cell_unsupported_shapes_are_refused(hip, monkeypatch):
+    from stc_hip._lib import StcError
+    assert not hip.cell_fused_supported(2, 2, 5, 20, 16)          # SF category count
+    assert not hip.cell_fused_supported(2, 2, 32, 32, 8)          # hidden != 16
+    assert not hip.cell_fused_supported(2, 3, 32, 32, 16)         # Ks != Kc
+    Zs = [torch.randn(6, 5, 20).cuda() for _ in range(2)]
+    Tc = torch.eye(5).repeat(2, 1, 1).cuda()
+    H = torch.randn(6, 5, 16).cuda()
+    with pytest.raises(StcError, match='fused path'):
+        hip.cell_gates_fwd(Zs, Tc, torch.randn(2 * 2 * 17, 32).cuda(), None, H, torch.empty_like(H), torch.empty_like(H),
+                           torch.empty(6, 5, 20).cuda())
+    monkeypatch.setenv('STC_DISABLE_MFMA', '1')
+    assert not hip.cell_fused_supported(2, 2, 32, 32, 16)
+
+
 def test_bdg_node_bwd_many_tiles_exercises_grid_stride(hip):
     shape = (3000, 8, 9, 5, 2, 2)                               # 750 tiles > 512 workgroups
     nodes, C, L, Ho, Ks, Kc = shape
