@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define STC_ABI_VERSION 6
+#define STC_ABI_VERSION 7
 #define STC_MAX_K 4          /* highest Chebyshev order (Ks, Kc) the node kernels accept */
 
 #define STC_OK 0
@@ -69,6 +69,26 @@ int stc_bcsr_spmm_f32(const int32_t* blk_ptr, const int32_t* blk_cols, const flo
                       int32_t n_rows, int32_t n_cols,
                       const float* X, const float* Y0, float* Y,
                       int32_t batch, int32_t F, float alpha, float beta, void* stream);
+
+/* Backward products of an STC_Cell with the element-wise consumer folded into the epilogue (autograd of
+ * STC_GNN.py:68-75).  Rows are node rows of C categories x (cin + h + pad) features (the [Xt | H | 0-pad]
+ * layout of stc_concat2_f32).  The graph comes in either form: BCSR when blk_ptr != NULL, else CSR.
+ *   gates:  d = Y0 + S.X   (= gradient of [Xt | R*H | pad]);   dXt = d[x part];
+ *           dG = [dU*U*(1-U) | d[h part]*H*R*(1-R)];   dH = d[h part]*R + dH_in      (dH_in may be NULL / alias dH)
+ *   split:  d = Y0 + S.X   (= gradient of [Xt | H | pad]);     outA = d[x part] + addA;  outB = d[h part] + addB
+ *           (addA / addB may be NULL and may alias outA / outB)
+ * X, Y0 (batch, n, C*(cin+h+pad)); dU, H, U, Rg, dH_in, dH (batch*n*C, h); dG (.., 2h); dXt / outA (.., cin). */
+int stc_spmm_bwd_gates_f32(const int32_t* rowptr, const int32_t* colidx, const float* val,
+                           const int32_t* blk_ptr, const int32_t* blk_cols, const float* blk_vals,
+                           int32_t n_rows, int32_t n_cols, const float* X, const float* Y0,
+                           const float* dU, const float* H, const float* U, const float* Rg, const float* dH_in,
+                           float* dG, float* dXt, float* dH,
+                           int32_t batch, int32_t C, int32_t cin, int32_t h, int32_t pad, void* stream);
+int stc_spmm_bwd_split_f32(const int32_t* rowptr, const int32_t* colidx, const float* val,
+                           const int32_t* blk_ptr, const int32_t* blk_cols, const float* blk_vals,
+                           int32_t n_rows, int32_t n_cols, const float* X, const float* Y0,
+                           const float* addA, const float* addB, float* outA, float* outB,
+                           int32_t batch, int32_t C, int32_t cin, int32_t h, int32_t pad, void* stream);
 
 /* out[j] (+)= alpha * sum_b < A[b,i,:], Bm[b,colidx[j],:] >   for j in row i
  * A (batch, n_rows, F), Bm (batch, n_cols, F), out (nnz).  Gradient of the

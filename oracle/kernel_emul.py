@@ -46,6 +46,25 @@ class EmulatedKernels:
             out = out + beta * Y0
         Y.copy_(out)
 
+    # ---- stc_spmm_bwd_gates/split_f32: backward products with their element-wise consumer in the epilogue
+    def spmm_bwd_gates(self, rowptr, colidx, val, plan, X, Y0, dU, H, U, Rg, dH_in, dG, dXt, dH):
+        B, n, F = X.shape
+        d = torch.empty_like(Y0)
+        self.csr_spmm(rowptr, colidx, val, n, n, X, Y0, d, 1.0, 1.0)
+        Cc = H.shape[-2]
+        self.gru_gates_bwd(d.view(B * n * Cc, F // Cc), dU.reshape(-1, dU.shape[-1]), H.reshape(-1, H.shape[-1]),
+                           U.reshape(-1, H.shape[-1]), Rg.reshape(-1, H.shape[-1]), dG.view(-1, dG.shape[-1]),
+                           dXt.view(-1, dXt.shape[-1]), dH.view(-1, dH.shape[-1]),
+                           dH_in=None if dH_in is None else dH_in.reshape(-1, H.shape[-1]).clone())
+
+    def spmm_bwd_split(self, rowptr, colidx, val, plan, X, Y0, Cc, outA, outB, addA=None, addB=None):
+        B, n, F = X.shape
+        d = torch.empty_like(Y0)
+        self.csr_spmm(rowptr, colidx, val, n, n, X, Y0, d, 1.0, 1.0)
+        self.split2(d.view(B * n * Cc, F // Cc), outA.view(-1, outA.shape[-1]), outB.view(-1, outB.shape[-1]),
+                    addA=None if addA is None else addA.reshape(-1, outA.shape[-1]).clone(),
+                    addB=None if addB is None else addB.reshape(-1, outB.shape[-1]).clone())
+
     # ---- stc_csr_sddmm_f32: gradient of the 1-mode product w.r.t. the graph values (autograd of :37)
     def csr_sddmm(self, rowptr, colidx, n_rows, n_cols, A, Bm, out, alpha, accumulate):
         rows = _expand_rows(rowptr)

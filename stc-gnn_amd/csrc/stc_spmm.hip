@@ -1,34 +1,37 @@
-// CSR SpMM / SDDMM for the spatial (1-mode) aggregation of STC-GNN on gfx950.
+// CSR / row-blocked CSR SpMM and SDDMM for the spatial (1-mode) aggregation of STC-GNN on gfx950.
 //
 //   Y[b,i,:] = alpha * sum_j val[j] * X[b, col[j], :] + beta * Y0[b,i,:]
 //
-// Replaces torch.einsum('bncl,nm->bmcl', X, T_n(Gs)) (reference STC_GNN.py:37)
-// and, with (alpha,beta) = (2,-1), one step of the Chebyshev recurrence of
-// STC_GNN.py:28 applied on the feature side.  HBM-bound: a feature row is
-// F = C*L contiguous floats (4 KiB at C=32, L=32) and is streamed with one
-// 16-byte load per lane, 1 KiB per wave instruction.
+// Replaces torch.einsum('bncl,nm->bmcl', X, T_n(Gs)) (reference STC_GNN.py:37) and, with (alpha,beta) = (2,-1),
+// one step of the Chebyshev recurrence of STC_GNN.py:28 applied on the feature side.  HBM-bound: a feature row
+// is F = C*L contiguous floats (4 KiB at C=32, L=32), streamed with one 16-byte load per lane, 1 KiB per wave
+// instruction.
 //
-// Layout of one launch (vector path):
-//   workgroup  = SPMM_ROWS consecutive output rows of one batch element
-//   CSR stage  = rowptr slice + the (col,val) segment of those rows -> LDS, one coalesced pass
-//   wave       = one output row at a time; (col,val) read from LDS are wave-uniform and
-//                moved to SGPRs (readfirstlane) so the row base address is scalar
-//   lane       = VPT float4 chunks of the row, 4 neighbour rows in flight (16 loads/lane)
-//   blocks     = remapped so each XCD walks a contiguous band of rows: the rows a band
-//                gathers (its own +- the graph bandwidth) stay in that XCD's 4 MiB L2
+// Layout of one launch (vector path, both kernels):
+//   workgroup  = a run of consecutive output rows of one batch element
+//   CSR stage  = row-pointer slice + the (col,val) segment of those rows -> LDS, one coalesced pass
+//   wave       = one output row (CSR) or one block of 4 rows (BCSR) at a time; (col,val) read from LDS are
+//                wave-uniform and moved to SGPRs (readfirstlane) so the neighbour-row base address is scalar
+//   lane       = VPT float4 pieces of the row, 4 neighbour rows in flight (16 loads per lane)
+//   blocks     = remapped so each XCD walks a contiguous band of rows: the rows a band gathers (its own +-
+//                the graph bandwidth) stay in that XCD's 4 MiB L2
+//   output     = non-temporal stores (written once; keeps the output stream from evicting the X rows the
+//                neighbours still need from L2); Y0 read non-temporally for the same reason
+//
+// Epilogues.  The backward of an STC_Cell consumes the result of two of these products element-wise
+// (reference STC_GNN.py:68-75 through autograd): EP_GATES turns  dCandIn = dZ0 + Gs.dZ1  straight into the
+// gate pre-activation gradients dG, dXt and the running dH;  EP_SPLIT turns  d[Xt|H] = dZ0 + Gs.dZ1  into
+// dXt += ..., dH += ... -- so neither concatenated gradient tensor is ever written to HBM.
 #include "stc_common.h"
-
-#include <cstdlib>
-
-#ifndef STC_SPMM_DEFAULT_VARIANT
-#define STC_SPMM_DEFAULT_VARIANT 10
-#endif
 
 namespace {
 
 constexpr int SPMM_THREADS = 256;
 constexpr int SPMM_WAVES = SPMM_THREADS / 64;
+constexpr int SPMM_ROWS = 8;         // CSR kernel: output rows per workgroup
 constexpr int SPMM_SEG_CAP = 1024;   // CSR entries staged in LDS per workgroup
+
+using v4f = __attribute__((ext_vector_type(4))) float;
 
 __device__ __forceinline__ float uniform_f(float v) {
     return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
@@ -41,16 +44,114 @@ __device__ __forceinline__ void fma4(float4& acc, float s, const float4& x) {
     acc.w = fmaf(s, x.w, acc.w);
 }
 
-// ROWS consecutive output rows per workgroup; NT: non-temporal stores of Y (written once, never re-read by
-// this launch: keeps the output stream from evicting the X rows the neighbours still need from L2).
-// gridDim.z > 1 splits the feature row into column blocks of 64*VPT float4 (one 1 KiB piece per lane-row at
-// VPT = 1): a tile's gather set (~3x its rows for a banded graph) then fits the CU's 32 KiB L1.
-template <int VPT, int ROWS, bool NT>
+__device__ __forceinline__ float4 nt_load4(const float4* p) {
+    const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+    return make_float4(t[0], t[1], t[2], t[3]);
+}
+__device__ __forceinline__ void nt_store4(float4* p, const float4& v) {
+    __builtin_nontemporal_store(v4f{v.x, v.y, v.z, v.w}, reinterpret_cast<v4f*>(p));
+}
+
+enum { EP_PLAIN = 0, EP_SPLIT = 1, EP_GATES = 2 };
+
+struct EpiArgs {
+    const float4* Y0;                       // base term (PLAIN: optional, scaled by beta; SPLIT/GATES: added)
+    float4* Y;                              // PLAIN output
+    float alpha, beta;                      // PLAIN
+    int C, L, cin, h;                       // row geometry of SPLIT/GATES: F = C*L, L = cin + h + pad
+    const float *dU, *H, *U, *R, *dH_in;    // GATES inputs, (rows*C, h)
+    float* dG;                              // GATES output, (rows*C, 2h)
+    const float *addA, *addB;               // SPLIT: gradients already owed to Xt / H (may be null, may alias outA/outB)
+    float *outA, *outB;                     // dXt (rows*C, cin), dH (rows*C, h)
+};
+
+// one element of a [Xt | H | pad] row: l = column, e = (row, category) index, v = its gradient
+template <int MODE>
+__device__ __forceinline__ void route_scalar(const EpiArgs& a, size_t e, int l, float v) {
+    if (l < a.cin) {
+        const size_t i = e * a.cin + l;
+        a.outA[i] = (MODE == EP_SPLIT && a.addA) ? v + a.addA[i] : v;
+    } else if (l < a.cin + a.h) {
+        const int k = l - a.cin;
+        const size_t i = e * a.h + k;
+        if (MODE == EP_SPLIT) {
+            a.outB[i] = a.addB ? v + a.addB[i] : v;
+        } else {
+            const float u = a.U[i], r = a.R[i];
+            a.dG[e * 2 * a.h + k] = a.dU[i] * u * (1.f - u);
+            a.dG[e * 2 * a.h + a.h + k] = v * a.H[i] * r * (1.f - r);
+            a.outB[i] = a.dH_in ? fmaf(v, r, a.dH_in[i]) : v * r;
+        }
+    }
+}
+
+// rowg = b*n_rows + row; ch = float4 index inside the row; acc = sum_j val_j X[col_j] for that piece
+template <int MODE>
+__device__ __forceinline__ void epilogue(const EpiArgs& a, size_t rowg, int F4, int ch, const float4& acc) {
+    const size_t o = rowg * F4 + ch;
+    if (MODE == EP_PLAIN) {
+        float4 r = make_float4(a.alpha * acc.x, a.alpha * acc.y, a.alpha * acc.z, a.alpha * acc.w);
+        if (a.beta != 0.f) {
+            const float4 y0 = nt_load4(a.Y0 + o);
+            r.x = fmaf(a.beta, y0.x, r.x); r.y = fmaf(a.beta, y0.y, r.y);
+            r.z = fmaf(a.beta, y0.z, r.z); r.w = fmaf(a.beta, y0.w, r.w);
+        }
+        nt_store4(a.Y + o, r);
+        return;
+    }
+    const float4 y0 = nt_load4(a.Y0 + o);
+    const float4 v = make_float4(acc.x + y0.x, acc.y + y0.y, acc.z + y0.z, acc.w + y0.w);
+    const int f = ch * 4;
+    const int c = f / a.L, l = f - c * a.L;
+    const size_t e = rowg * a.C + c;
+    if (((a.cin | a.h) & 3) == 0) {          // a 16-byte piece never straddles the Xt | H | pad boundaries
+        if (l < a.cin) {
+            float4* dst = reinterpret_cast<float4*>(a.outA + e * a.cin + l);
+            if (MODE == EP_SPLIT && a.addA) {
+                const float4 p = *reinterpret_cast<const float4*>(a.addA + e * a.cin + l);
+                *dst = make_float4(v.x + p.x, v.y + p.y, v.z + p.z, v.w + p.w);
+            } else {
+                *dst = v;
+            }
+        } else if (l < a.cin + a.h) {
+            const size_t i = e * a.h + (l - a.cin);
+            float4* dst = reinterpret_cast<float4*>(a.outB + i);
+            if (MODE == EP_SPLIT) {
+                if (a.addB) {
+                    const float4 p = *reinterpret_cast<const float4*>(a.addB + i);
+                    *dst = make_float4(v.x + p.x, v.y + p.y, v.z + p.z, v.w + p.w);
+                } else {
+                    *dst = v;
+                }
+            } else {
+                const float4 u = *reinterpret_cast<const float4*>(a.U + i), r = *reinterpret_cast<const float4*>(a.R + i);
+                const float4 du = *reinterpret_cast<const float4*>(a.dU + i), hh = *reinterpret_cast<const float4*>(a.H + i);
+                float* g = a.dG + e * 2 * a.h + (l - a.cin);
+                *reinterpret_cast<float4*>(g) = make_float4(du.x * u.x * (1.f - u.x), du.y * u.y * (1.f - u.y),
+                                                            du.z * u.z * (1.f - u.z), du.w * u.w * (1.f - u.w));
+                *reinterpret_cast<float4*>(g + a.h) = make_float4(v.x * hh.x * r.x * (1.f - r.x), v.y * hh.y * r.y * (1.f - r.y),
+                                                                  v.z * hh.z * r.z * (1.f - r.z), v.w * hh.w * r.w * (1.f - r.w));
+                float4 dh = make_float4(v.x * r.x, v.y * r.y, v.z * r.z, v.w * r.w);
+                if (a.dH_in) {
+                    const float4 p = *reinterpret_cast<const float4*>(a.dH_in + i);
+                    dh.x += p.x; dh.y += p.y; dh.z += p.z; dh.w += p.w;
+                }
+                *dst = dh;
+            }
+        }
+    } else {                                   // in + hidden = 17 padded to 20: route the four elements one by one
+        route_scalar<MODE>(a, e, l, v.x);
+        route_scalar<MODE>(a, e, l + 1, v.y);
+        route_scalar<MODE>(a, e, l + 2, v.z);
+        route_scalar<MODE>(a, e, l + 3, v.w);
+    }
+}
+
+// ---- CSR: one wave per output row ------------------------------------------------------------------------------
+template <int VPT, int MODE>
 __global__ __launch_bounds__(SPMM_THREADS) void spmm_wave_row_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ colidx, const float* __restrict__ val,
-    int n_rows, int n_cols, const float4* __restrict__ X, const float4* Y0, float4* Y,
-    int F4, float alpha, float beta, int n_tiles) {
-    constexpr int SPMM_ROWS = ROWS;
+    int n_rows, int n_cols, const float4* __restrict__ X, int F4, int n_tiles, EpiArgs ep) {
     __shared__ int s_rp[SPMM_ROWS + 1];
     __shared__ int s_col[SPMM_SEG_CAP];
     __shared__ float s_val[SPMM_SEG_CAP];
@@ -74,13 +175,12 @@ __global__ __launch_bounds__(SPMM_THREADS) void spmm_wave_row_kernel(
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const float4* Xb = X + (size_t)b * n_cols * F4;
-    const size_t out_base = (size_t)b * n_rows * F4;
 
     for (int r = wave; r < nr; r += SPMM_WAVES) {
         const int js = s_rp[r] - seg0;
         const int je = s_rp[r + 1] - seg0;
-        const size_t orow = out_base + (size_t)(row0 + r) * F4;
-        for (int cb = blockIdx.z * 64 * VPT; cb < F4; cb += gridDim.z * 64 * VPT) {
+        const size_t rowg = (size_t)b * n_rows + row0 + r;
+        for (int cb = 0; cb < F4; cb += 64 * VPT) {
             float4 acc[VPT];
 #pragma unroll
             for (int p = 0; p < VPT; ++p) acc[p] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -132,54 +232,29 @@ __global__ __launch_bounds__(SPMM_THREADS) void spmm_wave_row_kernel(
 #pragma unroll
             for (int p = 0; p < VPT; ++p) {
                 const int ch = cb + lane + 64 * p;
-                if (ch < F4) {
-                    float4 o = make_float4(alpha * acc[p].x, alpha * acc[p].y, alpha * acc[p].z, alpha * acc[p].w);
-                    if (beta != 0.f) {
-                        float4 y0;
-                        if (NT) {   // read once (often the very line this thread overwrites): keep it out of the gather's L2
-                            using v4f = __attribute__((ext_vector_type(4))) float;
-                            const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(&Y0[orow + ch]));
-                            y0 = make_float4(t[0], t[1], t[2], t[3]);
-                        } else {
-                            y0 = Y0[orow + ch];
-                        }
-                        o.x = fmaf(beta, y0.x, o.x);
-                        o.y = fmaf(beta, y0.y, o.y);
-                        o.z = fmaf(beta, y0.z, o.z);
-                        o.w = fmaf(beta, y0.w, o.w);
-                    }
-                    if (NT) {
-                        using v4f = __attribute__((ext_vector_type(4))) float;
-                        __builtin_nontemporal_store(v4f{o.x, o.y, o.z, o.w}, reinterpret_cast<v4f*>(&Y[orow + ch]));
-                    } else {
-                        Y[orow + ch] = o;
-                    }
-                }
+                if (ch < F4) epilogue<MODE>(ep, rowg, F4, ch, acc[p]);
             }
         }
     }
 }
 
-
-// ---- row-blocked (BCSR 4x1) variant: one wave produces 4 consecutive output rows -----------------------------
-// Same skeleton as spmm_wave_row_kernel (CSR segment staged in LDS, scalar column index, 16-byte streaming of
-// the neighbour row, 4 entries = 16 loads in flight per lane), but every fetched neighbour row is accumulated
-// into the 4 rows of the block with its 4 wave-uniform values.  (An LDS-staged tile variant -- distinct rows
-// of 8 output rows copied to LDS per 1 KiB column block -- was measured at 234 us vs 128 us for the direct
-// kernel: three dependent memory latencies per workgroup and too few bytes in flight; dropped.)
+// ---- row-blocked (BCSR 4x1): one wave produces 4 consecutive output rows -----------------------------------------
+// Same skeleton, but every fetched neighbour row is accumulated into the 4 rows of the block with its 4
+// wave-uniform values: a row shared by several rows of the block is fetched once (18 instead of 36 fetches per 4
+// rows of the 8-neighbour grid; the CSR kernel is bound by exactly that L2 -> CU gather traffic).  (An LDS-staged
+// tile variant -- distinct rows of 8 output rows copied to LDS per 1 KiB column block -- measured 234 us vs 128 us
+// for the CSR kernel: three dependent memory latencies per workgroup, too few bytes in flight; dropped.)
 constexpr int BR = STC_SPMM_BLOCK_ROWS;
 constexpr int BC_BLOCKS = 8;          // row blocks per workgroup (2 per wave)
 constexpr int BC_CAP = 512;           // block entries staged in LDS per workgroup
 
-template <int VPT>
+template <int VPT, int MODE>
 __global__ __launch_bounds__(SPMM_THREADS) void spmm_bcsr_kernel(
     const int* __restrict__ blk_ptr, const int* __restrict__ blk_cols, const float* __restrict__ blk_vals,
-    int n_rows, int n_cols, const float4* __restrict__ X, const float4* Y0, float4* Y,
-    int F4, float alpha, float beta, int n_blocks, int n_tiles) {
+    int n_rows, int n_cols, const float4* __restrict__ X, int F4, int n_blocks, int n_tiles, EpiArgs ep) {
     __shared__ int s_bp[BC_BLOCKS + 1];
     __shared__ int s_col[BC_CAP];
     __shared__ float s_val[BC_CAP * BR];
-    using v4f = __attribute__((ext_vector_type(4))) float;
 
     const int tile = stc_xcd_tile(blockIdx.x, n_tiles);
     if (tile < 0) return;
@@ -265,19 +340,11 @@ __global__ __launch_bounds__(SPMM_THREADS) void spmm_bcsr_kernel(
 #pragma unroll
             for (int r = 0; r < BR; ++r) {
                 if (r < rows_here) {
-                    const size_t orow = ((size_t)b * n_rows + row_base + r) * F4;
+                    const size_t rowg = (size_t)b * n_rows + row_base + r;
 #pragma unroll
                     for (int p = 0; p < VPT; ++p) {
                         const int ch = cb + lane + 64 * p;
-                        if (ch < F4) {
-                            float4 o = make_float4(alpha * acc[r][p].x, alpha * acc[r][p].y, alpha * acc[r][p].z, alpha * acc[r][p].w);
-                            if (beta != 0.f) {
-                                const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(&Y0[orow + ch]));
-                                o.x = fmaf(beta, t[0], o.x); o.y = fmaf(beta, t[1], o.y);
-                                o.z = fmaf(beta, t[2], o.z); o.w = fmaf(beta, t[3], o.w);
-                            }
-                            __builtin_nontemporal_store(v4f{o.x, o.y, o.z, o.w}, reinterpret_cast<v4f*>(&Y[orow + ch]));
-                        }
+                        if (ch < F4) epilogue<MODE>(ep, rowg, F4, ch, acc[r][p]);
                     }
                 }
             }
@@ -336,6 +403,56 @@ int next_pow2(int v) {
     return p;
 }
 
+struct GraphArgs {      // either form of the same matrix; BCSR is used when blk_ptr is given
+    const int32_t *rowptr, *colidx; const float* val;
+    const int32_t *blk_ptr, *blk_cols; const float* blk_vals;
+};
+
+template <int MODE>
+int launch_vector(const char* who, const GraphArgs& g, int n_rows, int n_cols, const float* X, int batch, int F,
+                  const EpiArgs& ep, hipStream_t s) {
+    const int F4 = F / 4;
+    const float4* X4 = reinterpret_cast<const float4*>(X);
+    if (g.blk_ptr) {
+        const int n_blocks = (n_rows + BR - 1) / BR;
+        const int n_tiles = (n_blocks + BC_BLOCKS - 1) / BC_BLOCKS;
+        const int per = (n_tiles + stc::kNumXcd - 1) / stc::kNumXcd;
+        const dim3 grid(per * stc::kNumXcd, batch), block(SPMM_THREADS);
+        if (F4 <= 64)
+            hipLaunchKernelGGL((spmm_bcsr_kernel<1, MODE>), grid, block, 0, s, g.blk_ptr, g.blk_cols, g.blk_vals, n_rows, n_cols, X4, F4, n_blocks, n_tiles, ep);
+        else if (F4 <= 128)
+            hipLaunchKernelGGL((spmm_bcsr_kernel<2, MODE>), grid, block, 0, s, g.blk_ptr, g.blk_cols, g.blk_vals, n_rows, n_cols, X4, F4, n_blocks, n_tiles, ep);
+        else
+            hipLaunchKernelGGL((spmm_bcsr_kernel<4, MODE>), grid, block, 0, s, g.blk_ptr, g.blk_cols, g.blk_vals, n_rows, n_cols, X4, F4, n_blocks, n_tiles, ep);
+    } else {
+        const int n_tiles = (n_rows + SPMM_ROWS - 1) / SPMM_ROWS;
+        const int per = (n_tiles + stc::kNumXcd - 1) / stc::kNumXcd;
+        const dim3 grid(per * stc::kNumXcd, batch), block(SPMM_THREADS);
+        if (F4 <= 64)
+            hipLaunchKernelGGL((spmm_wave_row_kernel<1, MODE>), grid, block, 0, s, g.rowptr, g.colidx, g.val, n_rows, n_cols, X4, F4, n_tiles, ep);
+        else if (F4 <= 128)
+            hipLaunchKernelGGL((spmm_wave_row_kernel<2, MODE>), grid, block, 0, s, g.rowptr, g.colidx, g.val, n_rows, n_cols, X4, F4, n_tiles, ep);
+        else
+            hipLaunchKernelGGL((spmm_wave_row_kernel<4, MODE>), grid, block, 0, s, g.rowptr, g.colidx, g.val, n_rows, n_cols, X4, F4, n_tiles, ep);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return stc::hip_status(e, who);
+    return STC_OK;
+}
+
+int check_fused(const char* who, const GraphArgs& g, int n_rows, int n_cols, const float* X, const float* Y0,
+                int batch, int C, int cin, int h, int pad) {
+    STC_REQUIRE(n_rows >= 0 && n_cols >= 0 && batch >= 0 && C >= 1 && cin >= 0 && h >= 1 && pad >= 0, STC_EINVAL, "%s: bad sizes", who);
+    STC_REQUIRE((cin + h + pad) % 4 == 0, STC_EINVAL, "%s: row width cin+h+pad = %d must be a multiple of 4", who, cin + h + pad);
+    STC_REQUIRE((long long)C * (cin + h + pad) >= 64, STC_ELIMIT, "%s: node row of %d floats is too narrow for the vector kernels", who, C * (cin + h + pad));
+    STC_REQUIRE(batch <= 65535, STC_ELIMIT, "%s: batch %d > 65535 (grid.y)", who, batch);
+    if (n_rows == 0 || batch == 0) return STC_OK;
+    STC_REQUIRE((g.blk_ptr && g.blk_cols && g.blk_vals) || (g.rowptr && g.colidx && g.val), STC_EINVAL, "%s: neither graph form given", who);
+    STC_REQUIRE(X && Y0 && n_cols > 0, STC_EINVAL, "%s: null X / Y0", who);
+    STC_REQUIRE(stc::aligned16(X) && stc::aligned16(Y0), STC_EALIGN, "%s: X / Y0 must be 16-byte aligned", who);
+    return STC_OK;
+}
+
 }  // namespace
 
 extern "C" int stc_csr_spmm_f32(const int32_t* rowptr, const int32_t* colidx, const float* val,
@@ -355,43 +472,21 @@ extern "C" int stc_csr_spmm_f32(const int32_t* rowptr, const int32_t* colidx, co
 
     const bool vec = (F % 4 == 0) && stc::aligned16(X) && stc::aligned16(Y) && (Y0 == nullptr || stc::aligned16(Y0)) && F >= 64;
     if (vec) {
-        const int F4 = F / 4;
-        const float4* X4 = reinterpret_cast<const float4*>(X);
-        const float4* Y04 = reinterpret_cast<const float4*>(Y0);
-        float4* Y4 = reinterpret_cast<float4*>(Y);
-        // STC_SPMM_VARIANT (A/B runs): 0 = whole rows, 8 rows per workgroup; 1 = 1 KiB column blocks (grid.z);
-        // 2 = whole rows, 16 rows per workgroup; +10 = non-temporal stores
-        static const int variant = [] { const char* e = std::getenv("STC_SPMM_VARIANT"); return e ? std::atoi(e) : STC_SPMM_DEFAULT_VARIANT; }();
-        const bool nt = variant >= 10;
-        const int shape = variant % 10;
-#define STC_SPMM_LAUNCH(VPT_, ROWS_, NT_, GZ_)                                                                          \
-    do {                                                                                                               \
-        const int n_tiles = (n_rows + ROWS_ - 1) / ROWS_;                                                              \
-        const int per = (n_tiles + stc::kNumXcd - 1) / stc::kNumXcd;                                                   \
-        dim3 grid(per * stc::kNumXcd, batch, GZ_), block(SPMM_THREADS);                                                \
-        hipLaunchKernelGGL((spmm_wave_row_kernel<VPT_, ROWS_, NT_>), grid, block, 0, s, rowptr, colidx, val, n_rows,   \
-                           n_cols, X4, Y04, Y4, F4, alpha, beta, n_tiles);                                             \
-    } while (0)
-#define STC_SPMM_BY_NT(VPT_, ROWS_, GZ_) do { if (nt) STC_SPMM_LAUNCH(VPT_, ROWS_, true, GZ_); else STC_SPMM_LAUNCH(VPT_, ROWS_, false, GZ_); } while (0)
-        if (shape == 1 && F4 > 64) {
-            STC_SPMM_BY_NT(1, 8, (F4 + 63) / 64);
-        } else if (shape == 2) {
-            if (F4 <= 64) STC_SPMM_BY_NT(1, 16, 1); else if (F4 <= 128) STC_SPMM_BY_NT(2, 16, 1); else STC_SPMM_BY_NT(4, 16, 1);
-        } else {
-            if (F4 <= 64) STC_SPMM_BY_NT(1, 8, 1); else if (F4 <= 128) STC_SPMM_BY_NT(2, 8, 1); else STC_SPMM_BY_NT(4, 8, 1);
-        }
-#undef STC_SPMM_BY_NT
-#undef STC_SPMM_LAUNCH
-    } else {
-        const int lanes = next_pow2(F) < SPMM_THREADS ? next_pow2(F) : SPMM_THREADS;
-        const int rows_per_block = SPMM_THREADS / lanes;
-        dim3 grid((n_rows + rows_per_block - 1) / rows_per_block, batch), block(SPMM_THREADS);
-        hipLaunchKernelGGL(spmm_generic_kernel, grid, block, 0, s, rowptr, colidx, val, n_rows, n_cols, X, Y0, Y, F, alpha, beta, lanes);
+        EpiArgs ep{};
+        ep.Y0 = reinterpret_cast<const float4*>(Y0);
+        ep.Y = reinterpret_cast<float4*>(Y);
+        ep.alpha = alpha;
+        ep.beta = beta;
+        const GraphArgs g{rowptr, colidx, val, nullptr, nullptr, nullptr};
+        return launch_vector<EP_PLAIN>("stc_csr_spmm_f32 launch", g, n_rows, n_cols, X, batch, F, ep, s);
     }
+    const int lanes = next_pow2(F) < SPMM_THREADS ? next_pow2(F) : SPMM_THREADS;
+    const int rows_per_block = SPMM_THREADS / lanes;
+    dim3 grid((n_rows + rows_per_block - 1) / rows_per_block, batch), block(SPMM_THREADS);
+    hipLaunchKernelGGL(spmm_generic_kernel, grid, block, 0, s, rowptr, colidx, val, n_rows, n_cols, X, Y0, Y, F, alpha, beta, lanes);
     STC_LAUNCH_CHECK("stc_csr_spmm_f32 launch");
     return STC_OK;
 }
-
 
 extern "C" int stc_bcsr_spmm_f32(const int32_t* blk_ptr, const int32_t* blk_cols, const float* blk_vals,
                                  int32_t n_rows, int32_t n_cols,
@@ -402,27 +497,59 @@ extern "C" int stc_bcsr_spmm_f32(const int32_t* blk_ptr, const int32_t* blk_cols
     STC_REQUIRE(blk_ptr && X && Y, STC_EINVAL, "stc_bcsr_spmm_f32: null pointer");
     STC_REQUIRE(beta == 0.f || Y0, STC_EINVAL, "stc_bcsr_spmm_f32: beta != 0 needs Y0");
     STC_REQUIRE(X != Y, STC_EINVAL, "stc_bcsr_spmm_f32: X must not alias Y");
-    STC_REQUIRE(F % 4 == 0, STC_EINVAL, "stc_bcsr_spmm_f32: F=%d must be a multiple of 4", F);
+    STC_REQUIRE(F % 4 == 0 && F >= 4, STC_EINVAL, "stc_bcsr_spmm_f32: F=%d must be a positive multiple of 4", F);
     STC_REQUIRE(stc::aligned16(X) && stc::aligned16(Y) && (!Y0 || stc::aligned16(Y0)), STC_EALIGN,
                 "stc_bcsr_spmm_f32: X / Y / Y0 must be 16-byte aligned");
     STC_REQUIRE(batch <= 65535, STC_ELIMIT, "stc_bcsr_spmm_f32: batch %d > 65535 (grid.y)", batch);
-    const int F4 = F / 4;
-    const int n_blocks = (n_rows + BR - 1) / BR;
-    const int n_tiles = (n_blocks + BC_BLOCKS - 1) / BC_BLOCKS;
-    const int per = (n_tiles + stc::kNumXcd - 1) / stc::kNumXcd;
-    const dim3 grid(per * stc::kNumXcd, batch), block(SPMM_THREADS);
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const float4* X4 = reinterpret_cast<const float4*>(X);
-    const float4* Y04 = reinterpret_cast<const float4*>(Y0);
-    float4* Y4 = reinterpret_cast<float4*>(Y);
-    if (F4 <= 64)
-        hipLaunchKernelGGL(spmm_bcsr_kernel<1>, grid, block, 0, s, blk_ptr, blk_cols, blk_vals, n_rows, n_cols, X4, Y04, Y4, F4, alpha, beta, n_blocks, n_tiles);
-    else if (F4 <= 128)
-        hipLaunchKernelGGL(spmm_bcsr_kernel<2>, grid, block, 0, s, blk_ptr, blk_cols, blk_vals, n_rows, n_cols, X4, Y04, Y4, F4, alpha, beta, n_blocks, n_tiles);
-    else
-        hipLaunchKernelGGL(spmm_bcsr_kernel<4>, grid, block, 0, s, blk_ptr, blk_cols, blk_vals, n_rows, n_cols, X4, Y04, Y4, F4, alpha, beta, n_blocks, n_tiles);
-    STC_LAUNCH_CHECK("stc_bcsr_spmm_f32 launch");
-    return STC_OK;
+    EpiArgs ep{};
+    ep.Y0 = reinterpret_cast<const float4*>(Y0);
+    ep.Y = reinterpret_cast<float4*>(Y);
+    ep.alpha = alpha;
+    ep.beta = beta;
+    const GraphArgs g{nullptr, nullptr, nullptr, blk_ptr, blk_cols, blk_vals};
+    return launch_vector<EP_PLAIN>("stc_bcsr_spmm_f32 launch", g, n_rows, n_cols, X, batch, F, ep, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int stc_spmm_bwd_gates_f32(const int32_t* rowptr, const int32_t* colidx, const float* val,
+                                      const int32_t* blk_ptr, const int32_t* blk_cols, const float* blk_vals,
+                                      int32_t n_rows, int32_t n_cols, const float* X, const float* Y0,
+                                      const float* dU, const float* H, const float* U, const float* Rg, const float* dH_in,
+                                      float* dG, float* dXt, float* dH,
+                                      int32_t batch, int32_t C, int32_t cin, int32_t h, int32_t pad, void* stream) {
+    const GraphArgs g{rowptr, colidx, val, blk_ptr, blk_cols, blk_vals};
+    if (int rc = check_fused("stc_spmm_bwd_gates_f32", g, n_rows, n_cols, X, Y0, batch, C, cin, h, pad)) return rc;
+    if (n_rows == 0 || batch == 0) return STC_OK;
+    STC_REQUIRE(dU && H && U && Rg && dG && dH && (cin == 0 || dXt), STC_EINVAL, "stc_spmm_bwd_gates_f32: null pointer");
+    if (((cin | h) & 3) == 0)
+        STC_REQUIRE(stc::aligned16(dU) && stc::aligned16(H) && stc::aligned16(U) && stc::aligned16(Rg) && stc::aligned16(dG) &&
+                        stc::aligned16(dH) && (!dH_in || stc::aligned16(dH_in)) && (!dXt || stc::aligned16(dXt)),
+                    STC_EALIGN, "stc_spmm_bwd_gates_f32: operands must be 16-byte aligned");
+    EpiArgs ep{};
+    ep.Y0 = reinterpret_cast<const float4*>(Y0);
+    ep.C = C; ep.L = cin + h + pad; ep.cin = cin; ep.h = h;
+    ep.dU = dU; ep.H = H; ep.U = U; ep.R = Rg; ep.dH_in = dH_in; ep.dG = dG; ep.outA = dXt; ep.outB = dH;
+    return launch_vector<EP_GATES>("stc_spmm_bwd_gates_f32 launch", g, n_rows, n_cols, X, batch, C * (cin + h + pad), ep,
+                                   static_cast<hipStream_t>(stream));
+}
+
+extern "C" int stc_spmm_bwd_split_f32(const int32_t* rowptr, const int32_t* colidx, const float* val,
+                                      const int32_t* blk_ptr, const int32_t* blk_cols, const float* blk_vals,
+                                      int32_t n_rows, int32_t n_cols, const float* X, const float* Y0,
+                                      const float* addA, const float* addB, float* outA, float* outB,
+                                      int32_t batch, int32_t C, int32_t cin, int32_t h, int32_t pad, void* stream) {
+    const GraphArgs g{rowptr, colidx, val, blk_ptr, blk_cols, blk_vals};
+    if (int rc = check_fused("stc_spmm_bwd_split_f32", g, n_rows, n_cols, X, Y0, batch, C, cin, h, pad)) return rc;
+    if (n_rows == 0 || batch == 0) return STC_OK;
+    STC_REQUIRE(outB && (cin == 0 || outA), STC_EINVAL, "stc_spmm_bwd_split_f32: null output");
+    if (((cin | h) & 3) == 0)
+        STC_REQUIRE(stc::aligned16(outB) && (!outA || stc::aligned16(outA)) && (!addA || stc::aligned16(addA)) && (!addB || stc::aligned16(addB)),
+                    STC_EALIGN, "stc_spmm_bwd_split_f32: operands must be 16-byte aligned");
+    EpiArgs ep{};
+    ep.Y0 = reinterpret_cast<const float4*>(Y0);
+    ep.C = C; ep.L = cin + h + pad; ep.cin = cin; ep.h = h;
+    ep.addA = addA; ep.addB = addB; ep.outA = outA; ep.outB = outB;
+    return launch_vector<EP_SPLIT>("stc_spmm_bwd_split_f32 launch", g, n_rows, n_cols, X, batch, C * (cin + h + pad), ep,
+                                   static_cast<hipStream_t>(stream));
 }
 
 extern "C" int stc_csr_sddmm_f32(const int32_t* rowptr, const int32_t* colidx,

@@ -19,13 +19,13 @@ import torch
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG_ROOT, 'libstc_hip.so')
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_K = 4
 
 #: every symbol ``include/stc_hip.h`` declares (the CPU test-suite checks the .so exports them all)
 EXPORTS = (
     'stc_version', 'stc_last_error',
-    'stc_csr_spmm_f32', 'stc_bcsr_spmm_f32', 'stc_csr_sddmm_f32',
+    'stc_csr_spmm_f32', 'stc_bcsr_spmm_f32', 'stc_spmm_bwd_gates_f32', 'stc_spmm_bwd_split_f32', 'stc_csr_sddmm_f32',
     'stc_cheby_dense_fwd_f32', 'stc_cheby_dense_bwd_f32',
     'stc_bdg_node_fwd_f32', 'stc_bdg_node_bwd_workspace_bytes', 'stc_bdg_node_bwd_f32',
     'stc_cell_fused_supported', 'stc_cell_gates_fwd_f32', 'stc_cell_blend_fwd_f32',
@@ -53,6 +53,8 @@ def _declare(lib):
     sig = {
         'stc_csr_spmm_f32': [_p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _f32, _p],
         'stc_bcsr_spmm_f32': [_p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _f32, _p],
+        'stc_spmm_bwd_gates_f32': [_p] * 6 + [_i32, _i32] + [_p] * 10 + [_i32] * 5 + [_p],
+        'stc_spmm_bwd_split_f32': [_p] * 6 + [_i32, _i32] + [_p] * 6 + [_i32] * 5 + [_p],
         'stc_csr_sddmm_f32': [_p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _i32, _p],
         'stc_cheby_dense_fwd_f32': [_p, _i32, _i32, _p, _p],
         'stc_cheby_dense_bwd_f32': [_p, _p, _p, _i32, _i32, _p, _p],
@@ -222,6 +224,56 @@ class HipKernels:
             return
         self._launch('stc_csr_spmm_f32', X, _ptr(rowptr), _ptr(colidx), _ptr(val), n_rows, n_cols, _ptr(X), _ptr(Y0), _ptr(Y), B, F, float(alpha), float(beta),
                      nbytes=nbytes)
+
+    def _graph_ptrs(self, rowptr, colidx, val, plan, n_rows):
+        self._i32('spmm.rowptr', rowptr, n_rows + 1)
+        self._i32('spmm.colidx', colidx)
+        self._f32('spmm.val', val, (colidx.numel(),))
+        if plan is None:
+            return [_ptr(rowptr), _ptr(colidx), _ptr(val), None, None, None]
+        blk_ptr, blk_cols, blk_vals = plan
+        self._i32('spmm.blk_ptr', blk_ptr, (n_rows + 3) // 4 + 1)
+        self._i32('spmm.blk_cols', blk_cols)
+        self._f32('spmm.blk_vals', blk_vals, (blk_cols.numel(), 4))
+        return [_ptr(rowptr), _ptr(colidx), _ptr(val), _ptr(blk_ptr), _ptr(blk_cols), _ptr(blk_vals)]
+
+    def _cell_rows(self, what, X, Y0, C, cin, h):
+        """Shapes shared by the two fused backward products: X/Y0 (B, n, C*(cin+h+pad)); returns (B, n, pad)."""
+        B, n, F = X.shape
+        self._f32(what + '.X', X)
+        self._f32(what + '.Y0', Y0, (B, n, F))
+        if F % C or F // C < cin + h:
+            raise StcError(f'{what}: row of {F} floats is not C={C} x (cin={cin} + h={h} + pad)')
+        return B, n, F // C - cin - h
+
+    def spmm_bwd_gates(self, rowptr, colidx, val, plan, X, Y0, dU, H, U, Rg, dH_in, dG, dXt, dH):
+        """dCandIn = Y0 + S.X consumed in the epilogue: dG, dXt, dH (+= dH_in).  See stc_spmm_bwd_gates_f32."""
+        Cc, h, cin = H.shape[-2], H.shape[-1], dXt.shape[-1]
+        B, n, pad = self._cell_rows('spmm_bwd_gates', X, Y0, Cc, cin, h)
+        for name, t, w in (('dU', dU, h), ('H', H, h), ('U', U, h), ('Rg', Rg, h), ('dH', dH, h), ('dG', dG, 2 * h), ('dXt', dXt, cin)) \
+                + ((('dH_in', dH_in, h),) if dH_in is not None else ()):
+            self._f32('spmm_bwd_gates.' + name, t)
+            if t.numel() != B * n * Cc * w:
+                raise StcError(f'spmm_bwd_gates.{name}: {t.numel()} elements, expected {B * n * Cc * w}')
+        g = self._graph_ptrs(rowptr, colidx, val, plan, n)
+        self._launch('stc_spmm_bwd_gates_f32', X, *g, n, n, _ptr(X), _ptr(Y0), _ptr(dU), _ptr(H), _ptr(U), _ptr(Rg), _ptr(dH_in),
+                     _ptr(dG), _ptr(dXt), _ptr(dH), B, Cc, cin, h, pad,
+                     nbytes=colidx.numel() * 8 + 4 * (n + 1) + 4 * B * n * Cc * (2 * (cin + h + pad) + 5 * h + 2 * h + cin + h))
+
+    def spmm_bwd_split(self, rowptr, colidx, val, plan, X, Y0, Cc, outA, outB, addA=None, addB=None):
+        """d[Xt|H] = Y0 + S.X consumed in the epilogue: outA = d[x] (+ addA), outB = d[h] (+ addB)."""
+        cin, h = outA.shape[-1], outB.shape[-1]
+        B, n, pad = self._cell_rows('spmm_bwd_split', X, Y0, Cc, cin, h)
+        for name, t, w in (('outA', outA, cin), ('outB', outB, h)) + ((('addA', addA, cin),) if addA is not None else ()) \
+                + ((('addB', addB, h),) if addB is not None else ()):
+            self._f32('spmm_bwd_split.' + name, t)
+            if t.numel() != B * n * Cc * w:
+                raise StcError(f'spmm_bwd_split.{name}: {t.numel()} elements, expected {B * n * Cc * w}')
+        g = self._graph_ptrs(rowptr, colidx, val, plan, n)
+        self._launch('stc_spmm_bwd_split_f32', X, *g, n, n, _ptr(X), _ptr(Y0), _ptr(addA), _ptr(addB), _ptr(outA), _ptr(outB),
+                     B, Cc, cin, h, pad,
+                     nbytes=colidx.numel() * 8 + 4 * (n + 1) + 4 * B * n * Cc * (2 * (cin + h + pad) + (2 if addA is not None else 1) * cin
+                                                                                  + (2 if addB is not None else 1) * h))
 
     def csr_sddmm(self, rowptr, colidx, n_rows, n_cols, A, Bm, out, alpha, accumulate):
         B, nr, F = A.shape

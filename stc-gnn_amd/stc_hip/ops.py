@@ -103,8 +103,13 @@ def _bdg_forward(X, W, b, Tc, fwd_val, op: SpatialOperand, Ks: int):
     return Y, Zs
 
 
-def _bdg_backward(dY, Zs, W, Tc, op: SpatialOperand, Ks: int, has_bias: bool, need_X: bool, need_Tc: bool, need_val: bool):
-    """Launch sequence of one BDG_Dif backward; returns (dX | None, dW, db | None, dTc | None, dval | None)."""
+def _bdg_backward_slabs(dY, Zs, W, Tc, op: SpatialOperand, Ks: int, has_bias: bool, need_Tc: bool, need_val: bool):
+    """Node-kernel backward and every hop of the Chebyshev recurrence but the last.
+
+    Returns (g, dW, db | None, dTc | None, dval | None) with g = [g_0, g_1, ...] such that
+    dX = g_0 + Gs.g_1 (g_1 absent for Ks = 1): the caller performs that last product, plain or with an
+    element-wise consumer fused into its epilogue.
+    """
     k = kernels()
     B, N, C, L = Zs[0].shape
     Ho = W.shape[1]
@@ -124,12 +129,19 @@ def _bdg_backward(dY, Zs, W, Tc, op: SpatialOperand, Ks: int, has_bias: bool, ne
         k.axpy(-1.0, dZ[order], dZ[order - 2])
         if need_val:
             k.csr_sddmm(op.fwd_rowptr, op.fwd_colidx, N, N, v3(dZ[order]), v3(Zs[order - 1]), dval, 2.0, True)
-    if Ks > 1:
-        if need_X:
-            k.csr_spmm(op.bwd_rowptr, op.bwd_colidx, op.bwd_val, N, N, v3(dZ[1]), v3(dZ[0]), v3(dZ[0]), 1.0, 1.0, plan=op.bwd_plan)
-        if need_val:
-            k.csr_sddmm(op.fwd_rowptr, op.fwd_colidx, N, N, v3(dZ[1]), v3(Zs[0]), dval, 1.0, True)
-    return (dZ[0] if need_X else None), dW, db, dTc, dval
+    if Ks > 1 and need_val:
+        k.csr_sddmm(op.fwd_rowptr, op.fwd_colidx, N, N, v3(dZ[1]), v3(Zs[0]), dval, 1.0, True)
+    return dZ[:2], dW, db, dTc, dval
+
+
+def _bdg_backward(dY, Zs, W, Tc, op: SpatialOperand, Ks: int, has_bias: bool, need_X: bool, need_Tc: bool, need_val: bool):
+    """Launch sequence of one BDG_Dif backward; returns (dX | None, dW, db | None, dTc | None, dval | None)."""
+    g, dW, db, dTc, dval = _bdg_backward_slabs(dY, Zs, W, Tc, op, Ks, has_bias, need_Tc, need_val)
+    if Ks > 1 and need_X:
+        B, N, C, L = g[0].shape
+        v3 = lambda t: t.view(B, N, C * L)
+        kernels().csr_spmm(op.bwd_rowptr, op.bwd_colidx, op.bwd_val, N, N, v3(g[1]), v3(g[0]), v3(g[0]), 1.0, 1.0, plan=op.bwd_plan)
+    return (g[0] if need_X else None), dW, db, dTc, dval
 
 
 class _BdgDif(Function):
@@ -334,13 +346,29 @@ class _StcCell(Function):
         need_Tc, need_val = ctx.needs_input_grad[6], ctx.needs_input_grad[7]
         dCpre, dU, dH = torch.empty_like(H), torch.empty_like(H), torch.empty_like(H)
         k.gru_blend_bwd(_c(dHnew), U, H, Cand, dCpre, dU, dH)                     # dH = dHnew * (1 - U)
-        dCandIn, dWc, dbc, dTc, dval = _bdg_backward(dCpre, Zc, Wc, Tc, op, Ks, ctx.bias[1], True, need_Tc, need_val)
         dG = H.new_empty(H.shape[:-1] + (2 * H.shape[-1],))
         dXt = H.new_empty(H.shape[:-1] + (cin,))
-        k.gru_gates_bwd(dCandIn, dU, H, U, Rg, dG, dXt, dH, dH_in=dH)             # dH += dCandIn[h part] * R ; dXt = dCandIn[x part]
-        dXH, dWg, dbg, dTc2, dval2 = _bdg_backward(dG, Zg, Wg, Tc, op, Ks, ctx.bias[0], need_Xt or need_H, need_Tc, need_val)
+        B, N, C, L = Zc[0].shape
+        v3 = lambda t: t.view(B, N, C * L)
+        bwd = (op.bwd_rowptr, op.bwd_colidx, op.bwd_val, op.bwd_plan)
+        fuse = Ks > 1 and C * L >= 64        # the last hop of each backward exists and is wide enough for the vector kernels
+        # candidate convolution: d[Xt | R*H] = g0 + Gs.g1, consumed by the gate backward
+        g, dWc, dbc, dTc, dval = _bdg_backward_slabs(dCpre, Zc, Wc, Tc, op, Ks, ctx.bias[1], need_Tc, need_val)
+        if fuse:
+            k.spmm_bwd_gates(*bwd, v3(g[1]), v3(g[0]), dU, H, U, Rg, dH, dG, dXt, dH)   # dH += d[h part] * R ; dXt = d[x part]
+        else:
+            if Ks > 1:
+                k.csr_spmm(*bwd[:3], N, N, v3(g[1]), v3(g[0]), v3(g[0]), 1.0, 1.0, plan=op.bwd_plan)
+            k.gru_gates_bwd(g[0], dU, H, U, Rg, dG, dXt, dH, dH_in=dH)
+        # gates convolution: d[Xt | H] = g0 + Gs.g1, split and added to what Xt and H are already owed
+        g, dWg, dbg, dTc2, dval2 = _bdg_backward_slabs(dG, Zg, Wg, Tc, op, Ks, ctx.bias[0], need_Tc, need_val)
         if need_Xt or need_H:
-            k.split2(dXH, dXt, dH, addA=dXt, addB=dH)                             # + the concat's share, in place
+            if fuse:
+                k.spmm_bwd_split(*bwd, v3(g[1]), v3(g[0]), C, dXt, dH, addA=dXt, addB=dH)
+            else:
+                if Ks > 1:
+                    k.csr_spmm(*bwd[:3], N, N, v3(g[1]), v3(g[0]), v3(g[0]), 1.0, 1.0, plan=op.bwd_plan)
+                k.split2(g[0], dXt, dH, addA=dXt, addB=dH)                        # + the concat's share, in place
         if need_Tc:
             dTc = dTc + dTc2
         if need_val:

@@ -102,6 +102,40 @@ def test_bcsr_spmm_equals_csr(hip, n, F, B, hw):
             assert rel_err(blocked, csr) < 2e-6
 
 
+@pytest.mark.parametrize('n,C,cin,h,B,form', [(203, 8, 16, 16, 1, 'bcsr'), (203, 8, 16, 16, 2, 'csr'), (90, 5, 1, 16, 2, 'bcsr'),
+                                                (90, 5, 1, 16, 1, 'csr'), (64, 8, 2, 8, 1, 'bcsr'), (37, 32, 16, 16, 1, 'bcsr')])
+def test_spmm_backward_epilogues(hip, n, C, cin, h, B, form):
+    """dZ0 + Gs.dZ1 with the gate backward / the split-and-accumulate folded into the epilogue, vs the CPU twin
+    (SpMM, then the element-wise kernel).  cin = 16: 16-byte routing; cin = 1, 2: padded rows, element routing."""
+    graph, V = _banded_graph(n, 3, seed=n + C + cin)
+    d = graph.on(torch.device('cuda'))
+    L = cin + h + (-(cin + h)) % 4
+    g = torch.Generator().manual_seed(cin * 7 + h)
+    rnd = lambda *s_: torch.randn(*s_, generator=g)
+    X, Y0 = rnd(B, n, C * L), rnd(B, n, C * L)
+    dU, H, U, Rg, owed = rnd(B, n, C, h), rnd(B, n, C, h), torch.rand(B, n, C, h, generator=g), torch.rand(B, n, C, h, generator=g), rnd(B, n, C, h)
+    args_cpu = (graph._host['bwd_rowptr'], graph._host['bwd_colidx'], graph._host['bwd_val'])
+    args_cpu = tuple(torch.from_numpy(a) for a in args_cpu)
+    plan = (d['bwd_blk_ptr'], d['bwd_blk_cols'], d['bwd_blk_vals']) if form == 'bcsr' else None
+    gargs = (d['bwd_rowptr'], d['bwd_colidx'], d['bwd_val'], plan)
+
+    dG_w, dXt_w, dH_w = torch.empty(B, n, C, 2 * h), torch.empty(B, n, C, cin), owed.clone()
+    EM.spmm_bwd_gates(*args_cpu, None, X, Y0, dU, H, U, Rg, dH_w, dG_w, dXt_w, dH_w)
+    dG, dXt, dH = torch.full((B, n, C, 2 * h), float('nan')).cuda(), torch.full((B, n, C, cin), float('nan')).cuda(), owed.clone().cuda()
+    hip.spmm_bwd_gates(*gargs, cu(X), cu(Y0), cu(dU), cu(H), cu(U), cu(Rg), dH, dG, dXt, dH)
+    assert rel_err(dG, dG_w) < TOL and rel_err(dXt, dXt_w) < TOL and rel_err(dH, dH_w) < TOL
+
+    oa_w, ob_w = rnd(B, n, C, cin), rnd(B, n, C, h)
+    oa, ob = oa_w.clone().cuda(), ob_w.clone().cuda()
+    EM.spmm_bwd_split(*args_cpu, None, X, Y0, C, oa_w, ob_w, addA=oa_w, addB=ob_w)
+    hip.spmm_bwd_split(*gargs, cu(X), cu(Y0), C, oa, ob, addA=oa, addB=ob)
+    assert rel_err(oa, oa_w) < TOL and rel_err(ob, ob_w) < TOL
+    oa2, ob2 = torch.full_like(oa, float('nan')), torch.full_like(ob, float('nan'))
+    hip.spmm_bwd_split(*gargs, cu(X), cu(Y0), C, oa2, ob2)               # no accumulation operands
+    ref = (Y0 + torch.einsum('rc,bcf->brf', V, X)).view(B, n, C, L)
+    assert rel_err(oa2, ref[..., :cin]) < TOL and rel_err(ob2, ref[..., cin:cin + h]) < TOL
+
+
 def test_row_block_plan_fetch_counts():
     assert CsrGraph.queen_grid(40, 40).fetches_per_row[0] < 5.0                      # 18 fetches per 4 rows in the interior
     assert CsrGraph.queen_grid(40, 40, permute_seed=1).fetches_per_row[0] > 7.0     # random node order: nothing to share
