@@ -64,7 +64,7 @@ def cpu_baseline(a, graph_dense_sparseT, Gc, sd_cpu):
     and an N^3 cheby_poly), validated against the dense reference at N = 1 024 / 10 000 in tests/.
     """
     from oracle import stc_oracle as O
-    threads = os.cpu_count() or 1
+    threads = min(os.cpu_count() or 1, 32)      # more threads than this only slow the torch CPU ops down on a 2-socket host
     torch.set_num_threads(threads)
     N, C = a.grid * a.grid, a.categories
     g = torch.Generator().manual_seed(0)

@@ -24,6 +24,7 @@ first call raises ``StcError``.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -33,6 +34,7 @@ from torch.autograd.function import once_differentiable
 from .graph import SpatialOperand
 
 _kernels = None
+_FUSE_BWD = os.environ.get('STC_FUSE_BWD') == '1'
 
 
 def kernels():
@@ -351,7 +353,10 @@ class _StcCell(Function):
         B, N, C, L = Zc[0].shape
         v3 = lambda t: t.view(B, N, C * L)
         bwd = (op.bwd_rowptr, op.bwd_colidx, op.bwd_val, op.bwd_plan)
-        fuse = Ks > 1 and C * L >= 64        # the last hop of each backward exists and is wide enough for the vector kernels
+        # Folding the gate backward / the split into the last SpMM's epilogue is available (stc_spmm_bwd_*_f32) but measured
+        # slower in the full step on MI355X (397 us vs ~354 us for SpMM + gate kernel: the epilogue's loads are not
+        # overlapped with the gather, and the intermediate is served from the Infinity Cache anyway): opt-in only.
+        fuse = _FUSE_BWD and Ks > 1 and C * L >= 64
         # candidate convolution: d[Xt | R*H] = g0 + Gs.g1, consumed by the gate backward
         g, dWc, dbc, dTc, dval = _bdg_backward_slabs(dCpre, Zc, Wc, Tc, op, Ks, ctx.bias[1], need_Tc, need_val)
         if fuse:

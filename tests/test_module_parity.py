@@ -263,6 +263,16 @@ def test_large_n10000_against_dense_reference_rows():
     _close(out[:, g['rows']], g['Hout'], FWD, 'Ht rows N=10000')
 
 
+@pytest.mark.parametrize('golden', ['g5_sf_shape', 'g7_csr_n1024'])
+def test_opt_in_fused_backward_epilogues(monkeypatch, golden):
+    """STC_FUSE_BWD=1 routes the cell backward through stc_spmm_bwd_gates/split_f32: same gradients."""
+    monkeypatch.setattr(ops, '_FUSE_BWD', True)
+    if golden == 'g5_sf_shape':
+        test_sf_shape_fixed_graphs_through_modules()
+    else:
+        test_csr_fixed_graph_equals_dense_reference('g7', golden, 'CsrGraph')
+
+
 def test_shape_errors_are_python_exceptions():
     layer = M.BDG_Dif(2, 2, 5, 4).to(DEV)
     t = lambda *s: torch.randn(*s, device=DEV)

@@ -29,7 +29,11 @@ for Ho in (32, 16):
 g = CsrGraph.queen_grid(224, 224, device=dev).on(dev)
 X = Zs[0].view(1, N, C * L)
 Yo = torch.empty_like(X)
-for _ in range(iters):
-    hip.csr_spmm(g['fwd_rowptr'], g['fwd_colidx'], g['fwd_val'], N, N, X, None, Yo, 1.0, 0.0)
+Xs = [torch.randn(1, N, C * L, device=dev) for _ in range(3)]          # rotate: nothing left in the Infinity Cache
+plan = (g['fwd_blk_ptr'], g['fwd_blk_cols'], g['fwd_blk_vals'])
+for i in range(iters):
+    hip.csr_spmm(g['fwd_rowptr'], g['fwd_colidx'], g['fwd_val'], N, N, Xs[i % 3], None, Yo, 1.0, 0.0, plan=plan)
+for i in range(iters):
+    hip.csr_spmm(g['fwd_rowptr'], g['fwd_colidx'], g['fwd_val'], N, N, Xs[i % 3], None, Yo, 1.0, 0.0)
 torch.cuda.synchronize()
 print('done')
