@@ -24,6 +24,12 @@
 // dXt += ..., dH += ... -- so neither concatenated gradient tensor is ever written to HBM.
 #include "stc_common.h"
 
+#include <cstdlib>
+
+#ifndef STC_BCSR_DEFAULT_BLOCKS
+#define STC_BCSR_DEFAULT_BLOCKS 8
+#endif
+
 namespace {
 
 constexpr int SPMM_THREADS = 256;
@@ -244,11 +250,14 @@ __global__ __launch_bounds__(SPMM_THREADS) void spmm_wave_row_kernel(
 // rows of the 8-neighbour grid; the CSR kernel is bound by exactly that L2 -> CU gather traffic).  (An LDS-staged
 // tile variant -- distinct rows of 8 output rows copied to LDS per 1 KiB column block -- measured 234 us vs 128 us
 // for the CSR kernel: three dependent memory latencies per workgroup, too few bytes in flight; dropped.)
+// BLOCKS row blocks per workgroup: 8 (two per wave), 4 (one per wave) or 2 (two waves share a block and split its
+// column blocks).  Fewer rows per workgroup keep the set of rows all resident workgroups of an XCD are gathering
+// (their "window") small enough for that XCD's 4 MiB L2: at 32 rows per workgroup the window is ~12 MB and
+// FETCH_SIZE shows every X row fetched 1.8 times from beyond L2.
 constexpr int BR = STC_SPMM_BLOCK_ROWS;
-constexpr int BC_BLOCKS = 8;          // row blocks per workgroup (2 per wave)
 constexpr int BC_CAP = 512;           // block entries staged in LDS per workgroup
 
-template <int VPT, int MODE>
+template <int VPT, int MODE, int BC_BLOCKS>
 __global__ __launch_bounds__(SPMM_THREADS) void spmm_bcsr_kernel(
     const int* __restrict__ blk_ptr, const int* __restrict__ blk_cols, const float* __restrict__ blk_vals,
     int n_rows, int n_cols, const float4* __restrict__ X, int F4, int n_blocks, int n_tiles, EpiArgs ep) {
@@ -269,15 +278,16 @@ __global__ __launch_bounds__(SPMM_THREADS) void spmm_bcsr_kernel(
     for (int t = threadIdx.x; t < seg_n * BR; t += SPMM_THREADS) s_val[t] = blk_vals[(size_t)seg0 * BR + t];
     __syncthreads();
 
+    constexpr int WPB = BC_BLOCKS >= SPMM_WAVES ? 1 : SPMM_WAVES / BC_BLOCKS;      // waves sharing one row block
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const float4* Xb = X + (size_t)b * n_cols * F4;
 
-    for (int bi = wave; bi < nb; bi += SPMM_WAVES) {
+    for (int bi = wave / WPB; bi < nb; bi += SPMM_WAVES / WPB) {
         const int js = s_bp[bi] - seg0, je = s_bp[bi + 1] - seg0;
         const int row_base = (blk0 + bi) * BR;
         const int rows_here = min(BR, n_rows - row_base);
-        for (int cb = 0; cb < F4; cb += 64 * VPT) {
+        for (int cb = (wave % WPB) * 64 * VPT; cb < F4; cb += WPB * 64 * VPT) {
             float4 acc[BR][VPT];
 #pragma unroll
             for (int r = 0; r < BR; ++r)
@@ -415,15 +425,22 @@ int launch_vector(const char* who, const GraphArgs& g, int n_rows, int n_cols, c
     const float4* X4 = reinterpret_cast<const float4*>(X);
     if (g.blk_ptr) {
         const int n_blocks = (n_rows + BR - 1) / BR;
-        const int n_tiles = (n_blocks + BC_BLOCKS - 1) / BC_BLOCKS;
+        // STC_BCSR_BLOCKS (A/B runs): row blocks per workgroup, 2 / 4 / 8
+        static const int blocks = [] { const char* e = std::getenv("STC_BCSR_BLOCKS"); const int v = e ? std::atoi(e) : STC_BCSR_DEFAULT_BLOCKS;
+                                       return (v == 2 || v == 4 || v == 8) ? v : STC_BCSR_DEFAULT_BLOCKS; }();
+        const int n_tiles = (n_blocks + blocks - 1) / blocks;
         const int per = (n_tiles + stc::kNumXcd - 1) / stc::kNumXcd;
         const dim3 grid(per * stc::kNumXcd, batch), block(SPMM_THREADS);
-        if (F4 <= 64)
-            hipLaunchKernelGGL((spmm_bcsr_kernel<1, MODE>), grid, block, 0, s, g.blk_ptr, g.blk_cols, g.blk_vals, n_rows, n_cols, X4, F4, n_blocks, n_tiles, ep);
-        else if (F4 <= 128)
-            hipLaunchKernelGGL((spmm_bcsr_kernel<2, MODE>), grid, block, 0, s, g.blk_ptr, g.blk_cols, g.blk_vals, n_rows, n_cols, X4, F4, n_blocks, n_tiles, ep);
-        else
-            hipLaunchKernelGGL((spmm_bcsr_kernel<4, MODE>), grid, block, 0, s, g.blk_ptr, g.blk_cols, g.blk_vals, n_rows, n_cols, X4, F4, n_blocks, n_tiles, ep);
+#define STC_BCSR_GO(VPT_, BLK_) hipLaunchKernelGGL((spmm_bcsr_kernel<VPT_, MODE, BLK_>), grid, block, 0, s, g.blk_ptr, g.blk_cols, g.blk_vals, \
+                                                   n_rows, n_cols, X4, F4, n_blocks, n_tiles, ep)
+        if (blocks == 2) {            // two waves per block: each covers every other column block of 64*VPT float4
+            if (F4 <= 128) STC_BCSR_GO(1, 2); else if (F4 <= 256) STC_BCSR_GO(2, 2); else STC_BCSR_GO(4, 2);
+        } else if (blocks == 4) {
+            if (F4 <= 64) STC_BCSR_GO(1, 4); else if (F4 <= 128) STC_BCSR_GO(2, 4); else STC_BCSR_GO(4, 4);
+        } else {
+            if (F4 <= 64) STC_BCSR_GO(1, 8); else if (F4 <= 128) STC_BCSR_GO(2, 8); else STC_BCSR_GO(4, 8);
+        }
+#undef STC_BCSR_GO
     } else {
         const int n_tiles = (n_rows + SPMM_ROWS - 1) / SPMM_ROWS;
         const int per = (n_tiles + stc::kNumXcd - 1) / stc::kNumXcd;
