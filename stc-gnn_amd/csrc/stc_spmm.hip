@@ -27,7 +27,7 @@
 #include <cstdlib>
 
 #ifndef STC_BCSR_DEFAULT_BLOCKS
-#define STC_BCSR_DEFAULT_BLOCKS 8
+#define STC_BCSR_DEFAULT_BLOCKS 2
 #endif
 
 namespace {
