@@ -149,6 +149,18 @@ def main():
             for key, v in per_kernel.get(name, {}).items():
                 spmm[key] += v
         achieved = (spmm['bytes'] / 1e9) / (spmm['ms'] / 1e3) if spmm['ms'] > 0 else 0.0
+        # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 --pmc runs
+        # as MI355X_MICROARCH.md prescribes): valid for the forward F = C*L = 1024 launch of the metric shape only
+        traffic, traffic_note = None, None
+        tpath = os.path.join(REPO, 'profiles', 'r01', 'c_spmm_hbm_traffic.json')
+        if (a.grid, C, a.hidden, B, a.permute) == (224, 32, 16, 1, False) and os.path.exists(tpath):
+            with open(tpath) as fh:
+                doc = json.load(fh)
+            k = next((v for name, v in doc['kernels'].items() if name.startswith('spmm_bcsr_kernel')), None)
+            if k:
+                traffic = k['hbm_bytes_per_launch']
+                traffic_note = ('PMC, forward launch F=1024 only (algorithmic 414 432 292 B): profiles/r01/c_spmm_hbm_traffic.json; '
+                                'roofline.achieved averages all SpMM launches of the step (F=1024 and 640, with and without Y0)')
         out = {
             'metric': METRIC, 'value': world * B * a.steps / elapsed, 'unit': 'samples/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * elapsed / a.steps,
@@ -159,7 +171,7 @@ def main():
                        'global_batch': world * B, 'batch_per_gpu': B, 'parallelism': f'batch-shard x{world}',
                        'grad_bucket_bytes': bucket.nbytes},
             'roofline': {'bound': 'hbm', 'kernel': 'stc_bcsr_spmm_f32 + stc_csr_spmm_f32 (all launches of the timed steps)', 'achieved': achieved, 'peak': HBM_PEAK_GBPS,
-                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,
+                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic, 'traffic_note': traffic_note,
                          'launches': spmm['launches'],
                          'avg_launch_us': 1e3 * spmm['ms'] / max(1, spmm['launches']),
                          'algorithmic_bytes_per_launch': spmm['bytes'] / max(1, spmm['launches'])},
