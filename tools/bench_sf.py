@@ -18,6 +18,7 @@ from stc_hip.loss import ComboLoss
 ap = argparse.ArgumentParser()
 ap.add_argument('--mode', default='csr-fixed')
 ap.add_argument('--steps', type=int, default=10)
+ap.add_argument('--graph', action='store_true', help='capture the whole train step in a HIP graph and replay it')
 a = ap.parse_args()
 dev = torch.device('cuda')
 torch.manual_seed(0)
@@ -31,7 +32,7 @@ else:
     As = CsrGraph.queen_grid(10, 10, normalize=False).to_dense().to(dev)
 Ac = torch.rand(C, C, device=dev)
 crit = ComboLoss()
-opt = torch.optim.Adam(model.parameters(), lr=2e-3, weight_decay=1e-4)
+opt = torch.optim.Adam(model.parameters(), lr=2e-3, weight_decay=1e-4, capturable=a.graph)
 
 
 def step():
@@ -45,10 +46,23 @@ def step():
 for _ in range(3):
     step()
 torch.cuda.synchronize()
+if a.graph:
+    # static inputs X, Y; grads live in the graph's private pool (set_to_none=True recreates them at each replay)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        static_loss = step()
+    eager_step, step = step, (lambda: (graph.replay(), static_loss)[1])
+    torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(a.steps):
     loss = step()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.steps
-print(f'SF shape {a.mode}: {1e3 * dt:.2f} ms/step, {B / dt:.1f} samples/s, loss {float(loss.detach()):.4f}, '
+print(f'SF shape {a.mode}{" hipGraph" if a.graph else ""}: {1e3 * dt:.2f} ms/step, {B / dt:.1f} samples/s, loss {float(loss.detach()):.4f}, '
       f'{sum(p.numel() for p in model.parameters())} parameters', flush=True)

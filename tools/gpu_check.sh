@@ -17,6 +17,7 @@ timeout 900 python bench.py --steps ${BENCH_STEPS:-2} --warmup 1 ${BENCH_ARGS:-}
 echo "== torchrun single-rank launch path + SF shape"
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/bench_torchrun.log 2>&1; echo "torchrun exit $?"; tail -1 gpurun_out/bench_torchrun.log | cut -c1-200
 timeout 300 python tools/bench_sf.py --mode csr-fixed 2>&1 | tail -1 | tee gpurun_out/bench_sf.log
+timeout 300 python tools/bench_sf.py --mode csr-fixed --graph --steps 50 2>&1 | tail -3 | tee -a gpurun_out/bench_sf.log
 timeout 600 python tools/bench_sf.py --mode dense-learned --steps 5 2>&1 | tail -1 | tee -a gpurun_out/bench_sf.log
 if [ "${PROFILE:-1}" = "1" ]; then
   echo "== rocprofv3 kernel trace"
