@@ -1,0 +1,105 @@
+"""Training / evaluation harness counterpart of the reference's ``framework/Model_Trainer.py:26-158``.
+
+Same protocol: ``STCGNN`` built from the same ``params`` keys, ComboLoss, Adam(lr, weight_decay), epoch loop over
+the modes, best-validation checkpoint ``{epoch, train_loss, val_loss, state_dict}`` written to
+``<output_dir>/<model>-<time_slice>.pkl``, early stopping, ``test()`` from that checkpoint.  Deliberate
+differences: the running loss is accumulated as a Python float (the reference adds the loss TENSOR and so keeps
+every step's autograd graph alive: +0.7 GB per step, ``Model_Trainer.py:85``); evaluation runs under
+``no_grad`` (``:136-138`` does not); no ``empty_cache()`` per step.  Checkpoints interchange with the reference.
+"""
+from __future__ import annotations
+
+import os
+import time
+from typing import Dict, Iterable, List, Optional
+
+import numpy as np
+import torch
+from torch import optim
+
+from .loss import ComboLoss
+
+
+class Trainer:
+    def __init__(self, params: dict, data: dict, graph_mode: str = 'dense-learned'):
+        from STC_GNN import STCGNN
+        self.params = params
+        dev = params['device']
+        if not str(dev).startswith('cuda') and not params.get('_allow_cpu_for_tests'):
+            raise ValueError("device must be 'cuda:k': the STC-GNN hot path has no CPU implementation")
+        self.mask = data.get('mask')
+        self.threshold = data.get('HA')
+        self.prior_graph = [torch.from_numpy(np.asarray(data['s_adj'])).float().to(dev),
+                            torch.from_numpy(np.asarray(data['c_cor'])).float().to(dev)]
+        if params.get('model', 'STC-GNN') != 'STC-GNN':
+            raise NotImplementedError('Invalid model name.')
+        self.model = STCGNN(num_nodes=params['H'] * params['W'], num_categories=params['C'],
+                            Ks=params['cheby_order'], Kc=params['cheby_order'], input_dim=1,
+                            hidden_dim=params['hidden_dim'], num_layers=params['nn_layers'],
+                            out_horizon=params['pred_len'], graph_mode=graph_mode).to(dev)
+        self.criterion = ComboLoss()
+        self.optimizer = optim.Adam(self.model.parameters(), lr=params['learn_rate'], weight_decay=params['decay_rate'])
+
+    @property
+    def checkpoint_path(self) -> str:
+        return os.path.join(self.params['output_dir'], f'{self.params.get("model", "STC-GNN")}-{self.params["time_slice"]}.pkl')
+
+    def _forward(self, x_seq):
+        return self.model(X_seq=x_seq, As=self.prior_graph[0], Ac=self.prior_graph[1])
+
+    def train(self, data_loader: Dict[str, Iterable], modes: List[str] = ('train', 'validate'),
+              early_stop_patience: int = 10, verbose: bool = True) -> dict:
+        history = {m: [] for m in modes}
+        run_time = {m: [] for m in modes}
+        best_val, patience = np.inf, early_stop_patience
+        os.makedirs(self.params['output_dir'], exist_ok=True)
+        for epoch in range(1, 1 + self.params['num_epochs']):
+            for mode in modes:
+                self.model.train(mode == 'train')
+                total, seen, t0 = 0.0, 0, time.time()
+                for x_seq, y_true in data_loader[mode]:
+                    with torch.set_grad_enabled(mode == 'train'):
+                        loss = self.criterion(self._forward(x_seq), y_true)
+                        if mode == 'train':
+                            self.optimizer.zero_grad()
+                            loss.backward()
+                            self.optimizer.step()
+                    total += float(loss.detach()) * y_true.shape[0]     # a float: no graph is kept alive
+                    seen += y_true.shape[0]
+                run_time[mode].append(time.time() - t0)
+                history[mode].append(total / max(seen, 1))
+            val = history['validate'][-1] if 'validate' in history else history['train'][-1]
+            if val < best_val:
+                best_val, patience = val, early_stop_patience
+                torch.save({'epoch': epoch, 'train_loss': history['train'][-1], 'val_loss': val,
+                            'state_dict': self.model.state_dict()}, self.checkpoint_path)
+                note = 'checkpoint updated'
+            else:
+                patience -= 1
+                note = f'no improvement ({patience} left)'
+            if verbose:
+                print(f'Epoch {epoch}: train {history["train"][-1]:.4f} ({run_time["train"][-1]:.2f} s), '
+                      f'validate {val:.4f}; {note}')
+            if patience == 0:
+                if verbose:
+                    print(f'Early stopping triggered at epoch {epoch}.')
+                break
+        return dict(loss=history, seconds=run_time, best_val=best_val)
+
+    @torch.no_grad()
+    def test(self, data_loader: Dict[str, Iterable], modes: List[str] = ('test',), checkpoint: Optional[str] = None) -> dict:
+        ckpt = torch.load(checkpoint or self.checkpoint_path, map_location=self.params['device'])
+        self.model.load_state_dict(ckpt['state_dict'])
+        self.model.eval()
+        out = {}
+        for mode in modes:
+            pred, truth = [], []
+            for x_seq, y_true in data_loader[mode]:
+                pred.append(self._forward(x_seq).cpu().numpy())
+                truth.append(y_true.cpu().numpy())
+            pred, truth = np.concatenate(pred, 0), np.concatenate(truth, 0)
+            eps = 1e-7
+            bce = float(-(truth * np.log(np.clip(pred, eps, 1)) + (1 - truth) * np.log(np.clip(1 - pred, eps, 1))).mean())
+            out[mode] = dict(forecast=pred, ground_truth=truth, bce=bce, mae=float(np.abs(pred - truth).mean()),
+                             epoch=ckpt['epoch'])
+        return out

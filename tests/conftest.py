@@ -36,7 +36,7 @@ def load_golden(name):
     with np.load(os.path.join(GOLDEN, name + '.npz')) as z:
         for k in z.files:
             a = z[k]
-            out[k] = torch.from_numpy(a) if a.ndim > 0 else a[()]
+            out[k] = torch.from_numpy(a) if (a.ndim > 0 and a.dtype.kind in 'fiub') else (a if a.ndim > 0 else a[()])
     return out
 
 

@@ -19,6 +19,7 @@ stored, only numbers.  Sets follow SURVEY.md section 8(c4):
   g6_mgp            MGP_Gen / MixedFusion at N=12 and N=100 (closed-form weights)
   g7_csr_n1024      one STC_Cell on a 32x32 row-normalised queen grid (+permuted), dense reference
   g8_large_n10000   one STC_Cell at N=10 000, C=32, h=16 through the dense reference, sampled rows
+  g9_pipeline       Data_Container windows/split/batches and a 2-epoch Model_Trainer run on a synthetic series
 
 Large inputs (g7, g8) are regenerated from seeds by ``synth_inputs`` below,
 which the tests import too; a few checksums are stored to catch RNG drift.
@@ -318,5 +319,78 @@ def main():
           chk_Ht=s['Ht'].double().sum(), chk_W=s['gates_W'].double().sum())
 
 
+def pipeline_inputs():
+    """Synthetic incident series + trainer params shared by make_golden and the tests (g9)."""
+    g = torch.Generator().manual_seed(9)
+    T, H, W, C = 30, 2, 3, 2
+    inc = (torch.rand(T, H, W, C, generator=g) < 0.3).to(torch.int32).numpy()
+    r, c = queen_grid_adjacency(H, W)
+    s_adj = np.zeros((H * W, H * W), dtype=np.float64)
+    s_adj[r.numpy(), c.numpy()] = 1.0
+    c_cor = torch.rand(C, C, generator=g).double().numpy()
+    data = dict(inc=inc, mask=[(0, 0)], HA=inc.reshape(T, -1, C).mean((0, 1)), s_adj=s_adj, c_cor=c_cor)
+    params = dict(device='cpu', H=H, W=W, C=C, batch_size=4, obs_len=3, pred_len=2, split_ratio=[6, 1, 1],
+                  model='STC-GNN', cheby_order=2, hidden_dim=4, nn_layers=1, learn_rate=2e-3, decay_rate=1e-4,
+                  num_epochs=2, time_slice=4, city='SYN')
+    return data, params
+
+
+def pipeline_golden(ref_framework='/root/reference/framework'):
+    import contextlib
+    import io
+    import re
+    import tempfile
+    sys.path.insert(0, ref_framework)
+    import Data_Container as DC
+    import Model_Trainer as MT
+    data, params = pipeline_inputs()
+    gen = DC.DataGenerator(obs_len=params['obs_len'], pred_len=params['pred_len'], data_split_ratio=params['split_ratio'])
+    loaders = gen.get_data_loader(params=params, data=data)
+    out = {}
+    for mode in ('train', 'validate', 'test'):
+        batches = list(loaders[mode])
+        out[f'{mode}_len'] = len(loaders[mode].dataset)
+        out[f'{mode}_batches'] = len(batches)
+        out[f'{mode}_x0'], out[f'{mode}_y0'] = batches[0]
+        out[f'{mode}_xlast'], out[f'{mode}_ylast'] = batches[-1]
+    # the reference's train loop (Model_Trainer.py:61-92) on the reference's classes, exact epoch losses
+    torch.manual_seed(123)
+    with tempfile.TemporaryDirectory() as tmp:
+        params = dict(params, output_dir=tmp)
+        trainer = MT.ModelTrainer(params=params, data=data)
+        sd0 = {k: v.clone() for k, v in trainer.model.state_dict().items()}
+        curves = {'train': [], 'validate': []}
+        for _ in range(params['num_epochs']):
+            for mode in ('train', 'validate'):
+                trainer.model.train(mode == 'train')
+                tot, seen = 0.0, 0
+                for x, y in loaders[mode]:
+                    with torch.set_grad_enabled(mode == 'train'):
+                        loss = trainer.criterion(trainer.model(X_seq=x, As=trainer.prior_graph[0], Ac=trainer.prior_graph[1]), y)
+                        if mode == 'train':
+                            trainer.optimizer.zero_grad(); loss.backward(); trainer.optimizer.step()
+                    tot += float(loss.detach()) * y.shape[0]; seen += y.shape[0]
+                curves[mode].append(tot / seen)
+        # cross-check against the reference's own ModelTrainer.train printout (4 significant digits)
+        torch.manual_seed(123)
+        t2 = MT.ModelTrainer(params=params, data=data)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            t2.train(data_loader=loaders, modes=['train', 'validate'])
+        printed = [float(v) for v in re.findall(r'training loss: ([0-9.]+)', buf.getvalue())]
+        assert len(printed) == params['num_epochs'] and all(abs(a - b) < 2e-3 * b for a, b in zip(printed, curves['train'])), (printed, curves)
+        ck = torch.load(os.path.join(tmp, 'STC-GNN-4.pkl'))
+        out['ckpt_keys'] = np.array(sorted(ck.keys()))
+        out['ckpt_epoch'] = ck['epoch']
+    out['train_curve'] = np.array(curves['train'])
+    out['val_curve'] = np.array(curves['validate'])
+    out.update({'sd0/' + k: v for k, v in sd0.items()})
+    _save('g9_pipeline', **out)
+
+
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'pipeline':
+        pipeline_golden()
+    else:
+        main()
+        pipeline_golden()

@@ -1,0 +1,154 @@
+"""SURVEY 8(f1, f2): data-pipeline and trainer counterparts against the reference's Data_Container / Model_Trainer.
+
+Goldens (tests/golden/g9_pipeline.npz) come from the reference run on a small synthetic incident series; the
+trainer runs here on the emulated kernel set (CPU) -- the GPU run of the same loop is in test_module_parity's
+Adam-trajectory case and tools/train.py.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.kernel_emul import EmulatedKernels
+from stc_hip import data as sdata, ops
+from stc_hip.trainer import Trainer
+from tests.conftest import load_golden, sub_dict
+from tests.golden.make_golden import pipeline_inputs
+
+SF = '/root/reference/data/SF-incidents-4h.npz'
+
+
+def test_windows_split_and_batches_match_the_reference():
+    g = load_golden('g9_pipeline')
+    data, params = pipeline_inputs()
+    loaders = sdata.get_data_loader(params, data, params['obs_len'], params['pred_len'], params['split_ratio'])
+    for mode in sdata.MODES:
+        ld = loaders[mode]
+        assert ld.length == int(g[f'{mode}_len']) and len(ld) == int(g[f'{mode}_batches'])
+        batches = list(ld)
+        assert torch.equal(batches[0][0], g[f'{mode}_x0']) and torch.equal(batches[0][1], g[f'{mode}_y0'])
+        assert torch.equal(batches[-1][0], g[f'{mode}_xlast']) and torch.equal(batches[-1][1], g[f'{mode}_ylast'])
+        assert batches[0][0].dtype == torch.float32 and batches[0][0].is_contiguous()
+
+
+def test_sliding_windows_are_views_and_edge_cases():
+    series = torch.arange(10 * 2 * 1, dtype=torch.float32).view(10, 2, 1)
+    x, y = sdata.sliding_windows(series, 3, 2)
+    assert x.shape == (5, 3, 2, 1) and y.shape == (5, 2, 2, 1)            # T - obs - pred windows
+    assert x.untyped_storage().data_ptr() == series.untyped_storage().data_ptr()   # no copy
+    assert torch.equal(x[0], series[0:3]) and torch.equal(y[0], series[3:5])
+    assert torch.equal(x[4], series[4:7]) and torch.equal(y[4], series[7:9])
+    with pytest.raises(ValueError):
+        sdata.sliding_windows(series, 8, 2)
+    assert sdata.split_lengths(5112, [6, 1, 1]) == {'validate': 639, 'test': 639, 'train': 3834}
+    assert sdata.split_lengths(7, [1, 3, 3]) == {'validate': 3, 'test': 3, 'train': 1}
+
+
+@pytest.mark.skipif(not os.path.exists(SF), reason='SF data file not present')
+def test_sf_file_counts():
+    data = sdata.load_incidents(SF)
+    assert data['inc'].shape == (5124, 10, 10, 5) and data['s_adj'].shape == (100, 100) and data['c_cor'].shape == (5, 5)
+    params = dict(device='cpu', H=10, W=10, C=5, batch_size=32)
+    loaders = sdata.get_data_loader(params, data, 9, 3, [6, 1, 1])
+    assert [loaders[m].length for m in sdata.MODES] == [3834, 639, 639]
+    x0, y0 = next(iter(loaders['train']))
+    inc = torch.from_numpy(data['inc'].reshape(5124, 100, 5)).float()
+    assert torch.equal(x0[0], inc[0:9]) and torch.equal(y0[0], inc[9:12]) and len(loaders['train']) == 120
+
+
+def test_trainer_reproduces_the_reference_epoch_losses(tmp_path, monkeypatch):
+    """Same seed -> same initial parameters (same creation order) -> the reference's 2-epoch loss curves."""
+    monkeypatch.setattr(ops, '_kernels', EmulatedKernels())
+    g = load_golden('g9_pipeline')
+    data, params = pipeline_inputs()
+    params = dict(params, output_dir=str(tmp_path), _allow_cpu_for_tests=True)
+    loaders = sdata.get_data_loader(params, data, params['obs_len'], params['pred_len'], params['split_ratio'])
+    torch.manual_seed(123)
+    trainer = Trainer(params, data)
+    for k, v in sub_dict(g, 'sd0/').items():                         # identical initialisation, key for key
+        assert torch.equal(trainer.model.state_dict()[k], v), k
+    hist = trainer.train(loaders, verbose=False)
+    assert np.allclose(hist['loss']['train'], g['train_curve'].numpy(), rtol=0, atol=2e-5)
+    assert np.allclose(hist['loss']['validate'], g['val_curve'].numpy(), rtol=0, atol=2e-5)
+    ck = torch.load(trainer.checkpoint_path)
+    assert sorted(ck.keys()) == ['epoch', 'state_dict', 'train_loss', 'val_loss'] and ck['epoch'] == int(g['ckpt_epoch'])
+    assert os.path.basename(trainer.checkpoint_path) == 'STC-GNN-4.pkl'
+    res = trainer.test(loaders)
+    assert res['test']['forecast'].shape == (loaders['test'].length, 2, 6, 2) and 0 < res['test']['bce'] < 2
+
+
+def test_trainer_refuses_cpu_device():
+    data, params = pipeline_inputs()
+    with pytest.raises(ValueError, match='no CPU implementation'):
+        Trainer(dict(params, output_dir='/tmp'), data)
+
+
+@pytest.mark.gpu
+def test_trainer_on_the_gpu_reproduces_the_reference_epoch_losses(tmp_path, monkeypatch):
+    """The same 2-epoch run through libstc_hip.so on the MI355X (learned dense graphs, MGP_Gen included)."""
+    monkeypatch.setattr(ops, '_kernels', None)
+    g = load_golden('g9_pipeline')
+    data, params = pipeline_inputs()
+    params = dict(params, device='cuda:0', output_dir=str(tmp_path))
+    loaders = sdata.get_data_loader(params, data, params['obs_len'], params['pred_len'], params['split_ratio'])
+    torch.manual_seed(123)
+    trainer = Trainer(params, data)
+    hist = trainer.train(loaders, verbose=False)
+    assert np.allclose(hist['loss']['train'], g['train_curve'].numpy(), rtol=0, atol=5e-5), hist['loss']
+    assert np.allclose(hist['loss']['validate'], g['val_curve'].numpy(), rtol=0, atol=5e-5), hist['loss']
+    assert trainer.test(loaders)['test']['forecast'].shape[0] == loaders['test'].length
+
+
+@pytest.mark.gpu
+def test_hip_graph_replay_of_a_train_step_equals_eager(monkeypatch):
+    """The whole step (forward, ComboLoss, backward, Adam) captured with torch.cuda.graph: every launch goes to the
+    capturing stream and allocates only through torch, so replay must reproduce the eager parameters bit for bit."""
+    import STC_GNN as M
+    from stc_hip import CsrGraph
+    from stc_hip.loss import ComboLoss
+    monkeypatch.setattr(ops, '_kernels', None)
+    dev = torch.device('cuda')
+
+    def build():
+        torch.manual_seed(5)
+        model = M.STCGNN(64, 5, 2, 2, 1, 16, 2, 2, graph_mode='csr-fixed').to(dev)
+        opt = torch.optim.Adam(model.parameters(), lr=2e-3, weight_decay=1e-4, capturable=True)
+        return model, opt
+
+    graph = CsrGraph.queen_grid(8, 8, device=dev)
+    gen = torch.Generator().manual_seed(1)
+    X = (torch.rand(4, 3, 64, 5, generator=gen) < 0.3).float().to(dev)
+    Y = (torch.rand(4, 2, 64, 5, generator=gen) < 0.3).float().to(dev)
+    Gc = torch.softmax(torch.randn(5, 5, generator=gen), -1).to(dev)
+    crit = ComboLoss()
+
+    def make_step(model, opt):
+        def step():
+            opt.zero_grad(set_to_none=True)
+            loss = crit(model(X_seq=X, As=graph, Ac=Gc), Y)
+            loss.backward()
+            opt.step()
+            return loss
+        return step
+
+    m1, o1 = build()
+    s1 = make_step(m1, o1)
+    for _ in range(5):
+        s1()
+    m2, o2 = build()
+    s2 = make_step(m2, o2)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            s2()                                   # warm-up steps count: 2 eager + 1 capture-less... see below
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        s2()                                       # capture does not execute
+    for _ in range(3):
+        g.replay()                                 # 2 eager + 3 replays = 5 steps
+    torch.cuda.synchronize()
+    for (k, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
