@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define STC_ABI_VERSION 7
+#define STC_ABI_VERSION 8
 #define STC_MAX_K 4          /* highest Chebyshev order (Ks, Kc) the node kernels accept */
 
 #define STC_OK 0
@@ -162,6 +162,16 @@ int stc_cell_fused_supported(int32_t Ks, int32_t Kc, int32_t C, int32_t L, int32
 int stc_cell_gates_fwd_f32(const float* const* Z, int32_t Ks, const float* Tc, int32_t Kc,
                            const float* W, const float* bias, const float* H,
                            float* U, float* Rg, float* CandIn,
+                           int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t h, int32_t cin, void* stream);
+/* Backward of the gates convolution with the gate backward as its prologue (autograd of STC_GNN.py:69-75):
+ *   dG = [dU*U*(1-U) | dCandIn[:, cin:cin+h]*H*Rg*(1-Rg)] is formed per node inside the kernel and never stored;
+ *   outputs dZ / dW / db as stc_bdg_node_bwd_f32 for dY = dG, plus dXt = dCandIn[:, :cin] and
+ *   dH = dCandIn[h part]*Rg + dH_in (dH_in may be NULL and may alias dH).
+ * dCandIn (nodes, C, L); dU/H/U/Rg/dH (nodes, C, h); dXt (nodes, C, cin).  Fused shapes only (else STC_EUNSUPPORTED). */
+int stc_cell_gates_bwd_f32(const float* const* Z, int32_t Ks, const float* Tc, int32_t Kc, const float* W,
+                           const float* dCandIn, const float* dU, const float* H, const float* U, const float* Rg,
+                           const float* dH_in, float* const* dZ, float* dW, float* db, float* dXt, float* dH,
+                           void* workspace, size_t workspace_bytes,
                            int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t h, int32_t cin, void* stream);
 int stc_cell_blend_fwd_f32(const float* const* Z, int32_t Ks, const float* Tc, int32_t Kc,
                            const float* W, const float* bias, const float* U, const float* H,

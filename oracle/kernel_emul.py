@@ -152,6 +152,11 @@ class EmulatedKernels:
         self.bdg_node_fwd(Zs, Tc, W, bias, G)
         self.gru_gates_fwd(G, Zs[0][..., :cin], H, U, Rg, CandIn)
 
+    def cell_gates_bwd(self, Zs, Tc, W, dCandIn, dU, H, U, Rg, dH_in, dZs, dW, db, dXt, dH):
+        dG = torch.empty(H.shape[:-1] + (2 * H.shape[-1],), dtype=W.dtype)
+        self.gru_gates_bwd(dCandIn, dU, H, U, Rg, dG, dXt, dH, dH_in=None if dH_in is None else dH_in.clone())
+        self.bdg_node_bwd(Zs, Tc, W, dG, dZs, dW, db, None)
+
     def cell_blend_fwd(self, Zs, Tc, W, bias, U, H, Cand, Hnew):
         Cpre = torch.empty_like(H)
         self.bdg_node_fwd(Zs, Tc, W, bias, Cpre)

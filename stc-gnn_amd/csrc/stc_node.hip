@@ -398,6 +398,40 @@ extern "C" int stc_cell_gates_fwd_f32(const float* const* Z, int32_t Ks, const f
     return rc == STC_NOT_HANDLED ? stc::fail(STC_EUNSUPPORTED, "stc_cell_gates_fwd_f32: operands not usable by the fused path (alignment)") : rc;
 }
 
+extern "C" int stc_cell_gates_bwd_f32(const float* const* Z, int32_t Ks, const float* Tc, int32_t Kc, const float* W,
+                                      const float* dCandIn, const float* dU, const float* H, const float* U, const float* Rg,
+                                      const float* dH_in, float* const* dZ, float* dW, float* db, float* dXt, float* dH,
+                                      void* workspace, size_t workspace_bytes,
+                                      int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t h, int32_t cin, void* stream) {
+    if (int rc = check_dims("stc_cell_gates_bwd_f32", Ks, Kc, C, L, Lw, 2 * h, nodes)) return rc;
+    STC_REQUIRE(cin >= 0 && cin + h <= L, STC_EINVAL, "stc_cell_gates_bwd_f32: cin=%d + h=%d exceed the row width L=%d", cin, h, L);
+    if (!stc_cell_fused_supported(Ks, Kc, C, L, h)) return stc::fail(STC_EUNSUPPORTED, "stc_cell_gates_bwd_f32: shape not on the fused path");
+    STC_REQUIRE(Z && W && dZ && dW && (Kc == 1 || Tc), STC_EINVAL, "stc_cell_gates_bwd_f32: null Z/W/dZ/dW/Tc");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int nW = Ks * Kc * Lw * 2 * h, Ho = 2 * h;
+    if (nodes == 0) {
+        if (int rc = stc::hip_status(hipMemsetAsync(dW, 0, (size_t)nW * sizeof(float), s), "memset dW")) return rc;
+        if (db) if (int rc = stc::hip_status(hipMemsetAsync(db, 0, (size_t)Ho * sizeof(float), s), "memset db")) return rc;
+        return STC_OK;
+    }
+    STC_REQUIRE(dCandIn && dU && H && U && Rg && dH && (cin == 0 || dXt), STC_EINVAL, "stc_cell_gates_bwd_f32: null pointer");
+    for (int n = 0; n < Ks; ++n) STC_REQUIRE(Z[n] && dZ[n], STC_EINVAL, "stc_cell_gates_bwd_f32: Z[%d]/dZ[%d] is null", n, n);
+    STC_REQUIRE(workspace && stc::aligned16(workspace), STC_EALIGN, "stc_cell_gates_bwd_f32: workspace null or not 16-byte aligned");
+    STC_REQUIRE(workspace_bytes >= stc_bdg_node_bwd_workspace_bytes(Ks, Kc, C, L, Ho, 0), STC_EINVAL,
+                "stc_cell_gates_bwd_f32: workspace of %zu B is too small", workspace_bytes);
+    int n_parts = 0;
+    float* partial = static_cast<float*>(workspace);
+    const int rc = stc_cell_gates_bwd_mfma(Z, Ks, Tc, W, dCandIn, dU, H, U, Rg, dH_in, dZ, dXt, dH, partial, &n_parts, db != nullptr,
+                                           nodes, C, L, Lw, cin, s);
+    if (rc == STC_NOT_HANDLED) return stc::fail(STC_EUNSUPPORTED, "stc_cell_gates_bwd_f32: operands not usable by the fused path (alignment)");
+    if (rc != STC_OK) return rc;
+    const int stride = nW + Ho;
+    hipLaunchKernelGGL(bdg_node_reduce_kernel, dim3((stride + RED_ELEMS - 1) / RED_ELEMS), dim3(NODE_THREADS), 0, s,
+                       partial, n_parts, stride, nW, Ho, 0, dW, db, static_cast<float*>(nullptr));
+    STC_LAUNCH_CHECK("stc_bdg_node_reduce launch");
+    return STC_OK;
+}
+
 extern "C" int stc_cell_blend_fwd_f32(const float* const* Z, int32_t Ks, const float* Tc, int32_t Kc,
                                       const float* W, const float* bias, const float* U, const float* H,
                                       float* Cand, float* Hnew,

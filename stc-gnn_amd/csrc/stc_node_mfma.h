@@ -25,3 +25,7 @@ int stc_cell_gates_fwd_mfma(const float* const* Z, int K, const float* Tc, const
 int stc_cell_blend_fwd_mfma(const float* const* Z, int K, const float* Tc, const float* W, const float* bias,
                             const float* U, const float* H, float* Cand, float* Hnew,
                             long long nodes, int C, int L, int Lw, hipStream_t stream);
+int stc_cell_gates_bwd_mfma(const float* const* Z, int K, const float* Tc, const float* W,
+                            const float* dCandIn, const float* dU, const float* H, const float* U, const float* R, const float* dH_in,
+                            float* const* dZ, float* dXt, float* dH, float* partial, int* n_partials, int want_db,
+                            long long nodes, int C, int L, int Lw, int cin, hipStream_t stream);

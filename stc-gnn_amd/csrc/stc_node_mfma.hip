@@ -273,12 +273,63 @@ struct DyFrag {     // one node's dY in both register layouts
     }
 };
 
-template <int NRB, int HB, int K, int LQ>
+// Prologue of the gates convolution's backward (autograd of reference STC_GNN.py:71-75, hidden 16): instead of
+// reading a precomputed dY, build it per node from the gradient of [Xt | R*H | pad] and the saved gates,
+//   dY[:, :16] = dU * U * (1 - U),   dY[:, 16:] = dCandIn[:, cin:cin+16] * H * R * (1 - R),
+// and emit the two by-products dXt = dCandIn[:, :cin], dH = dCandIn[h part] * R + dH_in on the way.  The kernel is
+// MFMA-bound with ~180 us of memory slack per launch, so these streams ride along for free and the separate
+// gate-backward pass (and the dG round trip through HBM) disappears.
+enum { PRO_NONE = 0, PRO_GATES = 1 };
+struct BwdPro {
+    const float *dCandIn, *dU, *H, *U, *R, *dH_in;   // (nodes,C,L) and (nodes,C,16) operands; dH_in may be null / alias dH
+    float *dXt, *dH;                                  // (nodes,C,cin), (nodes,C,16)
+    int cin;
+};
+
+template <int NRB, int HB, int L>
+__device__ __forceinline__ void load_gates_grad(DyFrag<NRB, HB>& g, const BwdPro& p, int node, int j, int q) {
+    static_assert(HB == 2, "gates prologue needs Ho = 2 * 16");
+    constexpr int C = 16 * NRB, HID = 16;
+    const size_t r0 = (size_t)node * C;
+#pragma unroll
+    for (int kb = 0; kb < NRB; ++kb) {
+        // accumulator-style layout: rows 16kb + 4q + t, column j
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const size_t row = r0 + 16 * kb + 4 * q + t, e = row * HID + j;
+            const float u = p.U[e], r = p.R[e];
+            g.d[kb][0][t] = p.dU[e] * u * (1.f - u);
+            g.d[kb][1][t] = p.dCandIn[row * L + p.cin + j] * p.H[e] * r * (1.f - r);
+        }
+        // row-on-lane layout: row 16kb + j, columns 4q .. 4q+3; this is also where dXt and dH are produced
+        const size_t row = r0 + 16 * kb + j, e = row * HID + 4 * q;
+        const float4 u = *reinterpret_cast<const float4*>(p.U + e), r = *reinterpret_cast<const float4*>(p.R + e);
+        const float4 du = *reinterpret_cast<const float4*>(p.dU + e), hh = *reinterpret_cast<const float4*>(p.H + e);
+        const float* cr = p.dCandIn + row * L;
+        float4 d;
+        if ((p.cin & 3) == 0) d = *reinterpret_cast<const float4*>(cr + p.cin + 4 * q);
+        else d = make_float4(cr[p.cin + 4 * q], cr[p.cin + 4 * q + 1], cr[p.cin + 4 * q + 2], cr[p.cin + 4 * q + 3]);
+        g.v[kb][0] = f32x4{du.x * u.x * (1.f - u.x), du.y * u.y * (1.f - u.y), du.z * u.z * (1.f - u.z), du.w * u.w * (1.f - u.w)};
+        g.v[kb][1] = f32x4{d.x * hh.x * r.x * (1.f - r.x), d.y * hh.y * r.y * (1.f - r.y), d.z * hh.z * r.z * (1.f - r.z), d.w * hh.w * r.w * (1.f - r.w)};
+        float4 dh = make_float4(d.x * r.x, d.y * r.y, d.z * r.z, d.w * r.w);
+        if (p.dH_in) {
+            const float4 o = *reinterpret_cast<const float4*>(p.dH_in + e);
+            dh.x += o.x; dh.y += o.y; dh.z += o.z; dh.w += o.w;
+        }
+        *reinterpret_cast<float4*>(p.dH + e) = dh;
+        for (int c0 = 4 * q; c0 < p.cin; c0 += 16)
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+                if (c0 + x < p.cin) p.dXt[row * p.cin + c0 + x] = cr[c0 + x];
+    }
+}
+
+template <int NRB, int HB, int K, int LQ, int PRO>
 __global__ __launch_bounds__(MF_THREADS, (BwdPlan<NRB, HB, K, LQ>::prefetch ? 2 : 1)) void node_bwd_mfma_kernel(
     ZPtrs Z, const float* __restrict__ Tc, const float* __restrict__ W, const float* __restrict__ dY,
-    DZPtrs dZ, float* __restrict__ partial, int nodes, int want_db, int Lw) {
+    DZPtrs dZ, float* __restrict__ partial, int nodes, int want_db, int Lw, BwdPro pro) {
     constexpr int C = 16 * NRB, Ho = 16 * HB, L = 4 * LQ, LB = (L + 15) / 16;
-    constexpr bool PF = BwdPlan<NRB, HB, K, LQ>::prefetch;
+    constexpr bool PF = BwdPlan<NRB, HB, K, LQ>::prefetch && PRO == PRO_NONE;
     const int nW = K * K * Lw * Ho;
     constexpr int nTf = (K - 1) * NRB * NRB * 4 * 64;
     constexpr int nWf = K * LB * K * HB * 4 * 64;
@@ -329,7 +380,8 @@ __global__ __launch_bounds__(MF_THREADS, (BwdPlan<NRB, HB, K, LQ>::prefetch ? 2 
     while (node < nodes) {
         const int next_node = node + nw;
         const size_t r0 = (size_t)node * C;
-        if (!PF) g.load(dY, node, j, q);
+        if constexpr (PRO == PRO_GATES) load_gates_grad<NRB, HB, L>(g, pro, node, j, q);
+        else if (!PF) g.load(dY, node, j, q);
         // this node's Z columns for the dW product (needed last: in flight during the Q and dZ phases)
         float za[K][LB][NRB][4];
 #pragma unroll
@@ -496,15 +548,15 @@ int launch_fwd(const float* const* Z, const float* Tc, const float* W, const flo
     return STC_OK;
 }
 
-template <int NRB, int HB, int K, int LQ>
+template <int NRB, int HB, int K, int LQ, int PRO = PRO_NONE>
 int launch_bwd(const float* const* Z, const float* Tc, const float* W, const float* dY, float* const* dZ,
-               float* partial, int* n_partials, int want_db, long long nodes, int Lw, hipStream_t stream) {
+               float* partial, int* n_partials, int want_db, long long nodes, int Lw, hipStream_t stream, BwdPro pro = BwdPro{}) {
     constexpr int L = 4 * LQ, Ho = 16 * HB, LB = (L + 15) / 16, nW = K * K * L * Ho;
     const size_t frag = (size_t)((K - 1) * NRB * NRB * 4 * 64 + K * LB * K * HB * 4 * 64);
     const size_t slabs = (size_t)MF_WAVES * (nW + Ho);
     const size_t lds = (frag > slabs ? frag : slabs) * sizeof(float);
     if (lds > stc::kMaxLdsBytes) return STC_NOT_HANDLED;
-    auto kern = node_bwd_mfma_kernel<NRB, HB, K, LQ>;
+    auto kern = node_bwd_mfma_kernel<NRB, HB, K, LQ, PRO>;
     if (int rc = stc::hip_status(stc::allow_lds(kern, lds), "hipFuncSetAttribute(node bwd mfma)")) return rc;
     static const int resident = stc::resident_blocks(kern, MF_THREADS, lds, 1);
     ZPtrs zp{};
@@ -513,7 +565,7 @@ int launch_bwd(const float* const* Z, const float* Tc, const float* W, const flo
     const long long want = (nodes + MF_WAVES - 1) / MF_WAVES;
     int grid = resident < MF_BWD_MAX_GRID ? resident : MF_BWD_MAX_GRID;
     if (want < grid) grid = (int)want;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(MF_THREADS), lds, stream, zp, Tc, W, dY, dzp, partial, (int)nodes, want_db, Lw);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(MF_THREADS), lds, stream, zp, Tc, W, dY, dzp, partial, (int)nodes, want_db, Lw, pro);
     STC_LAUNCH_CHECK("node_bwd_mfma launch");
     *n_partials = grid;
     return STC_OK;
@@ -592,6 +644,24 @@ int stc_cell_blend_fwd_mfma(const float* const* Z, int K, const float* Tc, const
 #define BLEND_CALL(a, c, d) launch_fwd<a, 1, c, d, EPI_BLEND>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi)
     STC_MF_EPI_CASE(1, BLEND_CALL) STC_MF_EPI_CASE(2, BLEND_CALL) STC_MF_EPI_CASE(4, BLEND_CALL)
 #undef BLEND_CALL
+    return STC_NOT_HANDLED;
+}
+
+int stc_cell_gates_bwd_mfma(const float* const* Z, int K, const float* Tc, const float* W,
+                            const float* dCandIn, const float* dU, const float* H, const float* U, const float* R, const float* dH_in,
+                            float* const* dZ, float* dXt, float* dH, float* partial, int* n_partials, int want_db,
+                            long long nodes, int C, int L, int Lw, int cin, hipStream_t stream) {
+    if (!stc_cell_fused_shape_ok(K, C, L, 16) || nodes <= 0 || nodes >= (1ll << 31) / C || !all_aligned16(Z, K)) return STC_NOT_HANDLED;
+    for (int n = 0; n < K; ++n)
+        if (!stc::aligned16(dZ[n])) return STC_NOT_HANDLED;
+    if (!(stc::aligned16(dCandIn) && stc::aligned16(dU) && stc::aligned16(H) && stc::aligned16(U) && stc::aligned16(R) &&
+          stc::aligned16(dH) && (!dH_in || stc::aligned16(dH_in))))
+        return STC_NOT_HANDLED;
+    BwdPro pro{};
+    pro.dCandIn = dCandIn; pro.dU = dU; pro.H = H; pro.U = U; pro.R = R; pro.dH_in = dH_in; pro.dXt = dXt; pro.dH = dH; pro.cin = cin;
+#define GBWD_CALL(a, c, d) launch_bwd<a, 2, c, d, PRO_GATES>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro)
+    STC_MF_EPI_CASE(1, GBWD_CALL) STC_MF_EPI_CASE(2, GBWD_CALL) STC_MF_EPI_CASE(4, GBWD_CALL)
+#undef GBWD_CALL
     return STC_NOT_HANDLED;
 }
 

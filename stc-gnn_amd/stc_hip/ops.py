@@ -105,7 +105,7 @@ def _bdg_forward(X, W, b, Tc, fwd_val, op: SpatialOperand, Ks: int):
     return Y, Zs
 
 
-def _bdg_backward_slabs(dY, Zs, W, Tc, op: SpatialOperand, Ks: int, has_bias: bool, need_Tc: bool, need_val: bool):
+def _bdg_backward_slabs(dY, Zs, W, Tc, op: SpatialOperand, Ks: int, has_bias: bool, need_Tc: bool, need_val: bool, gates=None):
     """Node-kernel backward and every hop of the Chebyshev recurrence but the last.
 
     Returns (g, dW, db | None, dTc | None, dval | None) with g = [g_0, g_1, ...] such that
@@ -116,13 +116,17 @@ def _bdg_backward_slabs(dY, Zs, W, Tc, op: SpatialOperand, Ks: int, has_bias: bo
     B, N, C, L = Zs[0].shape
     Ho = W.shape[1]
     F = C * L
-    dY = _c(dY)
     dZ = [torch.empty_like(Zs[0]) for _ in range(Ks)]
     dW = torch.empty_like(W)
     db = W.new_empty(Ho) if has_bias else None
     dTc = torch.empty_like(Tc) if need_Tc else None
-    k.bdg_node_bwd([z.view(B * N, C, L) for z in Zs], Tc, W, dY.view(B * N, C, Ho),
-                   [z.view(B * N, C, L) for z in dZ], dW, db, dTc)
+    rows = lambda ts: [t.view(B * N, C, t.shape[-1]) for t in ts]
+    if gates is not None:       # dY = gate pre-activation gradient, formed inside the kernel from (dCandIn, dU, H, U, R)
+        dCandIn, dU, H, U, Rg, dXt, dH = gates
+        k.cell_gates_bwd(rows(Zs), Tc, W, *rows((dCandIn, dU, H, U, Rg, dH)), rows(dZ), dW, db, *rows((dXt, dH)))
+    else:
+        dY = _c(dY)
+        k.bdg_node_bwd(rows(Zs), Tc, W, dY.view(B * N, C, Ho), rows(dZ), dW, db, dTc)
     dval = torch.zeros_like(op.fwd_val) if need_val else None
     v3 = lambda t: t.view(B, N, F)
     for order in range(Ks - 1, 1, -1):
@@ -359,14 +363,20 @@ class _StcCell(Function):
         fuse = _FUSE_BWD and Ks > 1 and C * L >= 64
         # candidate convolution: d[Xt | R*H] = g0 + Gs.g1, consumed by the gate backward
         g, dWc, dbc, dTc, dval = _bdg_backward_slabs(dCpre, Zc, Wc, Tc, op, Ks, ctx.bias[1], need_Tc, need_val)
+        gates_pro = None
         if fuse:
             k.spmm_bwd_gates(*bwd, v3(g[1]), v3(g[0]), dU, H, U, Rg, dH, dG, dXt, dH)   # dH += d[h part] * R ; dXt = d[x part]
         else:
             if Ks > 1:
                 k.csr_spmm(*bwd[:3], N, N, v3(g[1]), v3(g[0]), v3(g[0]), 1.0, 1.0, plan=op.bwd_plan)
-            k.gru_gates_bwd(g[0], dU, H, U, Rg, dG, dXt, dH, dH_in=dH)
+            if not (need_Tc or need_val) and k.cell_fused_supported(Ks, Tc.shape[0], C, L, H.shape[-1]):
+                # the gate backward runs as the prologue of the gates convolution's node backward (dG is never stored)
+                gates_pro = (g[0], dU, H, U, Rg, dXt, dH)
+                dG = None
+            else:
+                k.gru_gates_bwd(g[0], dU, H, U, Rg, dG, dXt, dH, dH_in=dH)
         # gates convolution: d[Xt | H] = g0 + Gs.g1, split and added to what Xt and H are already owed
-        g, dWg, dbg, dTc2, dval2 = _bdg_backward_slabs(dG, Zg, Wg, Tc, op, Ks, ctx.bias[0], need_Tc, need_val)
+        g, dWg, dbg, dTc2, dval2 = _bdg_backward_slabs(dG, Zg, Wg, Tc, op, Ks, ctx.bias[0], need_Tc, need_val, gates=gates_pro)
         if need_Xt or need_H:
             if fuse:
                 k.spmm_bwd_split(*bwd, v3(g[1]), v3(g[0]), C, dXt, dH, addA=dXt, addB=dH)

@@ -351,6 +351,37 @@ def test_fused_cell_epilogues(hip, nodes, C, cin, K):
     assert rel_err(Cand, Cand_w) < TOL and rel_err(Hn, Hn_w) < TOL
 
 
+@pytest.mark.parametrize('nodes,C,cin,K', [(50, 32, 16, 2), (50, 32, 1, 2), (21, 16, 16, 3), (13, 64, 1, 2), (4500, 32, 16, 2), (9, 32, 13, 1)])
+def test_fused_gates_backward_prologue(hip, nodes, C, cin, K):
+    """Gate backward as the prologue of the node backward (dG never stored) vs gate kernel + node backward of the twin."""
+    h = 16
+    Lw = cin + h
+    L = Lw + (-Lw) % 4
+    g = torch.Generator().manual_seed(nodes + C + cin + K + 1)
+    rnd = lambda *s_: torch.randn(*s_, generator=g)
+    Zs = [rnd(nodes, C, L) for _ in range(K)]
+    Tc = rnd(K, C, C) / C ** 0.5
+    Tc[0] = torch.eye(C)
+    W = rnd(K * K * Lw, 2 * h) / (K * K * Lw) ** 0.5
+    dCand, dU, H = rnd(nodes, C, L), rnd(nodes, C, h), rnd(nodes, C, h)
+    U, R, owed = torch.rand(nodes, C, h, generator=g), torch.rand(nodes, C, h, generator=g), rnd(nodes, C, h)
+    dZ_w = [torch.empty(nodes, C, L) for _ in range(K)]
+    dW_w, db_w, dXt_w, dH_w = torch.empty_like(W), torch.empty(2 * h), torch.empty(nodes, C, cin), owed.clone()
+    EM.cell_gates_bwd(Zs, Tc, W, dCand, dU, H, U, R, dH_w, dZ_w, dW_w, db_w, dXt_w, dH_w)
+    nan = float('nan')
+    dZ = [torch.full((nodes, C, L), nan).cuda() for _ in range(K)]
+    dW, db = torch.full_like(W, nan).cuda(), torch.full((2 * h,), nan).cuda()
+    dXt, dH = torch.full((nodes, C, cin), nan).cuda(), owed.clone().cuda()
+    hip.cell_gates_bwd([cu(z) for z in Zs], cu(Tc), cu(W), cu(dCand), cu(dU), cu(H), cu(U), cu(R), dH, dZ, dW, db, dXt, dH)
+    for a, w in zip(dZ, dZ_w):
+        assert rel_err(a, w) < TOL
+    assert rel_err(dW, dW_w) < TOL and rel_err(db, db_w) < TOL
+    assert torch.equal(dXt.cpu(), dCand[..., :cin]) and rel_err(dH, dH_w) < TOL
+    dH2 = torch.full((nodes, C, h), nan).cuda()                  # nothing owed yet: dH_in = NULL
+    hip.cell_gates_bwd([cu(z) for z in Zs], cu(Tc), cu(W), cu(dCand), cu(dU), cu(H), cu(U), cu(R), None, dZ, dW, None, dXt, dH2)
+    assert rel_err(dH2, dH_w - owed) < TOL
+
+
 def test_fused_cell_unsupported_shapes_are_refused(hip, monkeypatch):
     from stc_hip._lib import StcError
     assert not hip.cell_fused_supported(2, 2, 5, 20, 16)          # SF category count
