@@ -49,7 +49,7 @@ def parse():
     ap.add_argument('--layers', type=int, default=2)
     ap.add_argument('--obs', type=int, default=18)
     ap.add_argument('--pred', type=int, default=6)
-    ap.add_argument('--batch-per-gpu', type=int, default=1)
+    ap.add_argument('--batch-per-gpu', type=int, default=2, help='samples per GPU (weak scaling); 2 = ~116 GB of saved activations')
     ap.add_argument('--permute', action='store_true', help='random node order (seed 1234) instead of row-major')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     return ap.parse_args()
