@@ -224,6 +224,7 @@ class MGP_Gen(nn.Module):
     def __init__(self, num_nodes: int, num_categories: int, hidden_dim: int, alpha: int = 3):
         super().__init__()
         self.alpha = alpha
+        self.batch_sharded = False      # True: the batch is split over ranks -> all-reduce the batch-summed pre-activation
         self.params_S = self.init_params(num_categories, hidden_dim)
         self.aggreg_S = MixedFusion(num_nodes)
         self.params_C = self.init_params(num_nodes, hidden_dim)
@@ -243,6 +244,9 @@ class MGP_Gen(nn.Module):
         V = torch.tanh(self.alpha * torch.matmul(X, params['Wv']))
         flat_u, flat_v = U.flatten(0, 1), V.flatten(0, 1)             # sum over batch and time
         P = torch.einsum('knh,kmh->nm', flat_u, flat_v)
+        if self.batch_sharded:
+            from stc_hip.dist import allreduce_sum
+            P = allreduce_sum(P)                                      # exact under batch sharding
         return torch.softmax(torch.relu(P - P.t()), dim=-1)
 
     def forward(self, X_seq: torch.Tensor, As: torch.Tensor, Ac: torch.Tensor):
@@ -256,14 +260,16 @@ class STCGNN(nn.Module):
 
     def __init__(self, num_nodes: int, num_categories: int, Ks: int, Kc: int, input_dim: int, hidden_dim: int,
                  num_layers: int, out_horizon: int, use_bias=True, activation=None,
-                 graph_mode: str = 'dense-learned'):
+                 graph_mode: str = 'dense-learned', reorder_nodes: bool = True, batch_sharded: bool = False):
         super().__init__()
         if graph_mode not in ('dense-learned', 'csr-fixed'):
             raise ValueError("graph_mode must be 'dense-learned' (reference semantics) or 'csr-fixed'")
         self.graph_mode = graph_mode
+        self.reorder_nodes = reorder_nodes      # csr-fixed + CsrGraph: renumber nodes internally when that restores locality
         self.Ks, self.Kc = Ks, Kc
         if graph_mode == 'dense-learned':
             self.mix_graph_pair = MGP_Gen(num_nodes, num_categories, hidden_dim)
+            self.mix_graph_pair.batch_sharded = batch_sharded
         self.encoder = STC_Encoder(num_nodes, num_categories, Ks, Kc, input_dim, hidden_dim, num_layers,
                                    use_bias, activation, return_all_layers=True)
         self.decoder = STC_Decoder(num_nodes, num_categories, Ks, Kc, hidden_dim, hidden_dim, num_layers,
@@ -273,10 +279,23 @@ class STCGNN(nn.Module):
 
     def forward(self, X_seq: torch.Tensor, As: GraphLike, Ac: torch.Tensor):
         assert X_seq.dim() == 4, 'STC-GNN must take in 4D tensor as input X_seq'
+        inv = None
         if self.graph_mode == 'dense-learned':
             Gs, Gc = self.mix_graph_pair(X_seq, As, Ac)
         else:
             Gs, Gc = As, Ac
+            if self.reorder_nodes and isinstance(Gs, CsrGraph):
+                # a graph given in a cache-hostile node order is renumbered once (reverse Cuthill-McKee); inputs are
+                # gathered into that order here and the prediction scattered back, so callers never see it
+                Gs, order = Gs.with_locality()
+                if order is not None:
+                    idx = getattr(Gs, '_order_dev', {}).get(X_seq.device)
+                    if idx is None:
+                        o = torch.from_numpy(order).to(X_seq.device)
+                        idx = (o, torch.argsort(o))
+                        Gs._order_dev = {**getattr(Gs, '_order_dev', {}), X_seq.device: idx}
+                    X_seq = X_seq.index_select(2, idx[0])
+                    inv = idx[1]
         pair = _graphs(Gs, Gc, self.Ks, self.Kc)
         _, states = self.encoder._run(pair, None, X_seq.unsqueeze(-1))     # per-layer output stacks are not needed here
         step_in = states[-1]
@@ -284,7 +303,8 @@ class STCGNN(nn.Module):
         for _ in range(self.decoder.out_horizon):
             step_in, states = self.decoder(pair, None, step_in, states)
             outs.append(step_in)
-        return self._head(torch.stack(outs, dim=1))                      # (B, horizon, N, C)
+        y = self._head(torch.stack(outs, dim=1))                         # (B, horizon, N, C)
+        return y if inv is None else y.index_select(2, inv)
 
     def _head(self, H: torch.Tensor) -> torch.Tensor:
         """sigmoid(out_proj(H)).squeeze(-1) (reference STC_GNN.py:206-207).  The two Linears have no nonlinearity

@@ -12,8 +12,10 @@ pack/unpack copies.  In ``csr-fixed`` mode the bucket is 22 033 floats (88 KB) a
 per-sample Dice averaged over the batch, Model_Trainer.py:14-23) the averaged shard gradients
 equal the single-process full-batch gradients exactly (tests/test_dist_gloo.py).
 
-``dense-learned`` mode is NOT shardable as is: MGP_Gen sums over batch and time before its
-softmax (STC_GNN.py:231), so the graphs depend on the whole mini-batch.
+``dense-learned`` mode couples the batch: MGP_Gen sums its pre-activation over batch and time before the
+softmax (STC_GNN.py:231), so the graphs depend on the whole mini-batch.  ``allreduce_sum`` makes that
+exact under sharding: the (N x N and C x C) partial sums are all-reduced in forward and their gradient in
+backward -- ``STCGNN(..., batch_sharded=True)``; two small collectives per step on top of the bucket.
 """
 from __future__ import annotations
 
@@ -77,6 +79,32 @@ class GradBucket:
                                'optimizer.zero_grad(set_to_none=True)')
         self.flat.div_(world)                                # pre-scale: the sum then is the mean
         return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+
+class _AllReduceSum(torch.autograd.Function):
+    """y = sum over ranks of x, differentiable: the gradient of a replicated consumer w.r.t. one rank's summand is
+    the sum of every rank's local gradient (the gradient bucket then averages parameter gradients over ranks, so
+    together they yield d(mean over ranks of the shard losses)/d(theta))."""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        ctx.group = group
+        y = x.contiguous().clone()
+        dist.all_reduce(y, op=dist.ReduceOp.SUM, group=group)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous().clone()
+        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)
+        return g, None
+
+
+def allreduce_sum(x: torch.Tensor, group=None) -> torch.Tensor:
+    """Differentiable cross-rank sum; identity when no process group is initialised or it has one rank."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return x
+    return _AllReduceSum.apply(x, group)
 
 
 def init_from_env(backend: str = None) -> tuple:

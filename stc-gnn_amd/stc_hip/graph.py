@@ -138,6 +138,44 @@ class CsrGraph:
             r, c = inv[r], inv[c]
         return cls(H * W, r, c, v, device)
 
+    # -- locality ------------------------------------------------------------------------------
+    def locality_order(self) -> np.ndarray:
+        """Reverse Cuthill-McKee order of the symmetrised pattern: new node i is old node order[i].
+
+        The SpMM gathers whole feature rows; what it costs is set by how many DISTINCT neighbour rows a block of
+        consecutive output rows touches and whether they are still in the XCD's L2.  A graph handed over in an
+        arbitrary node order (e.g. the queen grid under a random permutation: 7.9 fetches per row, SpMM at 23 % of
+        HBM peak) is brought back to a banded form (4.5 fetches per row, 50 %) by renumbering the nodes once.
+        """
+        import scipy.sparse as sp
+        from scipy.sparse.csgraph import reverse_cuthill_mckee
+        h = self._host
+        A = sp.csr_matrix((np.ones(self.nnz, dtype=np.int8), h['bwd_colidx'], h['bwd_rowptr']), shape=(self.n, self.n))
+        return np.asarray(reverse_cuthill_mckee((A + A.T).tocsr(), symmetric_mode=True), dtype=np.int64)
+
+    def permuted(self, order: np.ndarray) -> 'CsrGraph':
+        """The same graph with nodes renumbered: G'[i, j] = G[order[i], order[j]]."""
+        order = np.asarray(order, dtype=np.int64)
+        inv = np.empty_like(order)
+        inv[order] = np.arange(order.size)
+        h = self._host
+        rows = np.repeat(np.arange(self.n, dtype=np.int64), np.diff(h['bwd_rowptr'].astype(np.int64)))
+        return CsrGraph(self.n, inv[rows], inv[h['bwd_colidx'].astype(np.int64)], h['bwd_val'])
+
+    def with_locality(self, min_gain: float = 1.25):
+        """(graph, order): a renumbered copy when that cuts the row fetches of the row-blocked SpMM by at least
+        ``min_gain``, else (self, None).  Computed once and cached."""
+        cached = getattr(self, '_locality', None)
+        if cached is None:
+            cached = (self, None)
+            if self.n > 64 and self.nnz > 0:
+                order = self.locality_order()
+                cand = self.permuted(order)
+                if self.fetches_per_row[0] >= min_gain * cand.fetches_per_row[0]:
+                    cached = (cand, order)
+            self._locality = cached
+        return cached
+
     # -- device residency -----------------------------------------------------------------
     def on(self, device: torch.device) -> Dict[str, torch.Tensor]:
         device = torch.device(device)

@@ -87,6 +87,64 @@ def test_two_rank_sharded_gradients_equal_full_batch(tmp_path):
     assert bucket.nbytes == 4 * sum(p.numel() for p in model.parameters())
 
 
+def _worker_learned(rank, world, port, out_dir):
+    for p in (REPO, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from oracle import stc_oracle as O
+    from oracle.kernel_emul import EmulatedKernels
+    from stc_hip import dist as sdist, ops
+    ops._kernels = EmulatedKernels()
+    sdist.init_from_env(backend='gloo')
+    model, As, Ac, X, Y = _build_learned(batch_sharded=True)
+    bucket = sdist.GradBucket(model.parameters())
+    xs, ys = sdist.shard_batch(X, rank, world), sdist.shard_batch(Y, rank, world)
+    Gs, _ = model.mix_graph_pair(xs, As, Ac)                          # graphs of the WHOLE batch on every rank
+    bucket.zero()
+    O.combo_loss(model(X_seq=xs, As=As, Ac=Ac), ys).backward()
+    bucket.allreduce_mean()
+    torch.save({'flat': bucket.flat.clone(), 'Gs': Gs.detach()}, os.path.join(out_dir, f'rank{rank}.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _build_learned(batch_sharded):
+    import STC_GNN as M
+    torch.manual_seed(11)
+    N, C = 12, 3
+    model = M.STCGNN(N, C, 2, 2, 1, 4, 1, 2, batch_sharded=batch_sharded)
+    As = (torch.rand(N, N) < 0.3).float()
+    Ac = torch.rand(C, C)
+    X = (torch.rand(4, 3, N, C) < 0.3).float()
+    Y = (torch.rand(4, 2, N, C) < 0.3).float()
+    return model, As, Ac, X, Y
+
+
+def test_two_rank_learned_graphs_are_exact_under_batch_sharding(tmp_path):
+    """dense-learned mode: MGP_Gen's batch-summed pre-activation is all-reduced (forward and backward), so the
+    sharded run reproduces the full-batch graphs and, after the bucket all-reduce, the full-batch gradients."""
+    world = 2
+    mp.start_processes(_worker_learned, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True, start_method='spawn')
+    got = [torch.load(tmp_path / f'rank{r}.pt') for r in range(world)]
+    from oracle import stc_oracle as O
+    from oracle.kernel_emul import EmulatedKernels
+    from stc_hip import dist as sdist, ops
+    old = ops._kernels
+    ops._kernels = EmulatedKernels()
+    try:
+        model, As, Ac, X, Y = _build_learned(batch_sharded=False)
+        bucket = sdist.GradBucket(model.parameters())
+        Gs, _ = model.mix_graph_pair(X, As, Ac)
+        O.combo_loss(model(X_seq=X, As=As, Ac=Ac), Y).backward()
+        full = bucket.flat.clone()
+    finally:
+        ops._kernels = old
+    assert float((got[0]['Gs'] - Gs).abs().max()) < 1e-6 and torch.equal(got[0]['Gs'], got[1]['Gs'])
+    assert float((got[0]['flat'] - full).abs().max()) / float(full.abs().max()) < 1e-5
+
+
 def test_shard_batch_and_bucket_guards():
     from stc_hip import dist as sdist
     with pytest.raises(ValueError):

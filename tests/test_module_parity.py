@@ -273,6 +273,30 @@ def test_opt_in_fused_backward_epilogues(monkeypatch, golden):
         test_csr_fixed_graph_equals_dense_reference('g7', golden, 'CsrGraph')
 
 
+def test_internal_node_reordering_is_invisible():
+    """A graph handed over in a random node order is renumbered internally (reverse Cuthill-McKee); predictions and
+    gradients are those of the un-reordered run (only the summation order inside a row changes)."""
+    graph = CsrGraph.queen_grid(12, 11, permute_seed=4)
+    cand, order = graph.with_locality()
+    assert order is not None and cand.fetches_per_row[0] * 1.25 <= graph.fetches_per_row[0]
+    assert CsrGraph.queen_grid(12, 11).with_locality()[1] is None            # already banded: left alone
+    torch.manual_seed(3)
+    N, C = graph.n, 4
+    kw = dict(num_nodes=N, num_categories=C, Ks=2, Kc=2, input_dim=1, hidden_dim=8, num_layers=2, out_horizon=2, graph_mode='csr-fixed')
+    plain = M.STCGNN(**kw, reorder_nodes=False).to(DEV)
+    smart = M.STCGNN(**kw).to(DEV)
+    smart.load_state_dict(plain.state_dict())
+    X = (torch.rand(2, 3, N, C) < 0.3).float().to(DEV)
+    Gc = torch.softmax(torch.randn(C, C), -1).to(DEV)
+    R = torch.randn(2, 2, N, C).to(DEV)
+    ya, yb = plain(X_seq=X, As=graph, Ac=Gc), smart(X_seq=X, As=graph, Ac=Gc)
+    _close(yb, ya, FWD, 'reordered yhat')
+    (ya * R).sum().backward()
+    (yb * R).sum().backward()
+    for (k, pa), (_, pb) in zip(plain.named_parameters(), smart.named_parameters()):
+        _close(pb.grad, pa.grad, GRAD, 'reordered d' + k)
+
+
 def test_shape_errors_are_python_exceptions():
     layer = M.BDG_Dif(2, 2, 5, 4).to(DEV)
     t = lambda *s: torch.randn(*s, device=DEV)
