@@ -20,6 +20,7 @@ stored, only numbers.  Sets follow SURVEY.md section 8(c4):
   g7_csr_n1024      one STC_Cell on a 32x32 row-normalised queen grid (+permuted), dense reference
   g8_large_n10000   one STC_Cell at N=10 000, C=32, h=16 through the dense reference, sampled rows
   g9_pipeline       Data_Container windows/split/batches and a 2-epoch Model_Trainer run on a synthetic series
+  g10_metrics       Metrics.mask_data and ModelEvaluator.one_step_eval_bi on synthetic predictions
 
 Large inputs (g7, g8) are regenerated from seeds by ``synth_inputs`` below,
 which the tests import too; a few checksums are stored to catch RNG drift.
@@ -388,9 +389,40 @@ def pipeline_golden(ref_framework='/root/reference/framework'):
     _save('g9_pipeline', **out)
 
 
+def metrics_inputs():
+    rng = np.random.default_rng(10)
+    S, hor, H, W, C = 40, 2, 4, 5, 3
+    true = (rng.random((S, hor, H * W, C)) < 0.25).astype(np.float32)
+    prob = np.clip(0.6 * true + 0.5 * rng.random((S, hor, H * W, C)), 0.001, 0.999).astype(np.float32)
+    prob = np.round(prob, 2)                                   # plenty of ties for the AUC code
+    thr = true.reshape(-1, C).mean(0)
+    mask = [(0, 0), (3, 4), (2, 2)]
+    return prob, true, thr, mask, H, W
+
+
+def metrics_golden(ref_framework='/root/reference/framework'):
+    import contextlib
+    import io
+    sys.path.insert(0, ref_framework)
+    import Metrics as RM
+    prob, true, thr, mask, H, W = metrics_inputs()
+    pm, tm = RM.mask_data(prob, H, W, mask), RM.mask_data(true, H, W, mask)
+    ev = RM.ModelEvaluator(dict(C=prob.shape[-1], pred_len=prob.shape[1]))
+    out = dict(prob_masked=pm, true_masked=tm, unmasked=RM.mask_data(prob, H, W, None))
+    with contextlib.redirect_stdout(io.StringIO()):
+        for step in range(prob.shape[1]):
+            m = ev.one_step_eval_bi(pm[:, step], tm[:, step], list(thr))
+            out[f'names{step}'] = np.array(list(m.keys()))
+            out[f'values{step}'] = np.array([float(v) for v in m.values()])
+    _save('g10_metrics', **out)
+
+
 if __name__ == '__main__':
-    if len(sys.argv) > 1 and sys.argv[1] == 'pipeline':
+    if len(sys.argv) > 1 and sys.argv[1] == 'metrics':
+        metrics_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'pipeline':
         pipeline_golden()
     else:
         main()
         pipeline_golden()
+        metrics_golden()

@@ -152,3 +152,20 @@ def test_hip_graph_replay_of_a_train_step_equals_eager(monkeypatch):
     torch.cuda.synchronize()
     for (k, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
         assert torch.equal(a, b), k
+
+
+def test_metrics_match_the_reference():
+    """mask_data and the per-step metric dict equal the reference's (scikit-learn based) values."""
+    from stc_hip import metrics as smetrics
+    from tests.golden.make_golden import metrics_inputs
+    g = load_golden('g10_metrics')
+    prob, true, thr, mask, H, W = metrics_inputs()
+    pm, tm = smetrics.mask_data(prob, H, W, mask), smetrics.mask_data(true, H, W, mask)
+    assert np.array_equal(pm, g['prob_masked'].numpy()) and np.array_equal(tm, g['true_masked'].numpy())
+    assert np.array_equal(smetrics.mask_data(prob, H, W, None), g['unmasked'].numpy())
+    grid = prob.reshape(prob.shape[0], prob.shape[1], H, W, -1).transpose(0, 1, 4, 2, 3)      # (S, hor, C, H, W) layout
+    assert np.array_equal(smetrics.mask_data(grid, H, W, mask), pm)
+    steps = smetrics.evaluate_binary(pm, tm, list(thr))
+    for s, got in enumerate(steps):
+        assert list(got.keys()) == list(g[f'names{s}'])
+        assert np.allclose(list(got.values()), g[f'values{s}'].numpy(), rtol=0, atol=1.01e-4), (got, g[f'values{s}'])
