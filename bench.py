@@ -51,6 +51,7 @@ def parse():
     ap.add_argument('--pred', type=int, default=6)
     ap.add_argument('--batch-per-gpu', type=int, default=2, help='samples per GPU (weak scaling); 2 = ~116 GB of saved activations')
     ap.add_argument('--permute', action='store_true', help='random node order (seed 1234) instead of row-major')
+    ap.add_argument('--no-reorder', action='store_true', help='keep the given node order (skip the internal RCM renumbering)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     return ap.parse_args()
 
@@ -101,7 +102,7 @@ def main():
     graph = CsrGraph.queen_grid(a.grid, a.grid, normalize=True, permute_seed=1234 if a.permute else None, device=dev)
     Gc_cpu = torch.softmax(torch.randn(C, C, generator=torch.Generator().manual_seed(7)), -1)
     torch.manual_seed(42)                                                       # same parameters on every rank
-    model = M.STCGNN(N, C, a.order, a.order, 1, a.hidden, a.layers, a.pred, graph_mode='csr-fixed')
+    model = M.STCGNN(N, C, a.order, a.order, 1, a.hidden, a.layers, a.pred, graph_mode='csr-fixed', reorder_nodes=not a.no_reorder)
     sd_cpu = {k: v.clone() for k, v in model.state_dict().items()}
     model = model.to(dev)
     Gc = Gc_cpu.to(dev)
