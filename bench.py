@@ -150,18 +150,18 @@ def main():
             for key, v in per_kernel.get(name, {}).items():
                 spmm[key] += v
         achieved = (spmm['bytes'] / 1e9) / (spmm['ms'] / 1e3) if spmm['ms'] > 0 else 0.0
-        # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 --pmc runs
-        # as MI355X_MICROARCH.md prescribes): valid for the forward F = C*L = 1024 launch of the metric shape only
+        # HBM bytes per SpMM launch from the committed PMC passes over this same command (FETCH_SIZE x 2 + WRITE_SIZE in
+        # separate rocprofv3 --pmc runs, as MI355X_MICROARCH.md prescribes; tools/gpu_pmc_bench.sh): averaged over all SpMM
+        # launches of a step exactly like roofline.achieved.  Only valid for the configuration it was collected on.
         traffic, traffic_note = None, None
-        tpath = os.path.join(REPO, 'profiles', 'r01', 'c_spmm_hbm_traffic.json')
-        if (a.grid, C, a.hidden, B, a.permute) == (224, 32, 16, 1, False) and os.path.exists(tpath):
+        tpath = os.path.join(REPO, 'profiles', 'r01', 'e_hbm_traffic_bench_b2.json')
+        if (a.grid, C, a.hidden, B, a.order, a.layers, a.obs, a.pred, a.permute) == (224, 32, 16, 2, 2, 2, 18, 6, False) and os.path.exists(tpath):
             with open(tpath) as fh:
                 doc = json.load(fh)
-            k = next((v for name, v in doc['kernels'].items() if name.startswith('spmm_bcsr_kernel')), None)
-            if k:
-                traffic = k['hbm_bytes_per_launch']
-                traffic_note = ('PMC, forward launch F=1024 only (algorithmic 414 432 292 B): profiles/r01/c_spmm_hbm_traffic.json; '
-                                'roofline.achieved averages all SpMM launches of the step (F=1024 and 640, with and without Y0)')
+            ks = [v for name, v in doc['kernels'].items() if name.startswith('spmm_')]
+            if ks:
+                traffic = sum(v['hbm_bytes_per_launch'] * v['launches'] for v in ks) / sum(v['launches'] for v in ks)
+                traffic_note = 'PMC (2 x FETCH_SIZE + WRITE_SIZE), mean over the SpMM launches of one step of this command: profiles/r01/e_hbm_traffic_bench_b2.json'
         out = {
             'metric': METRIC, 'value': world * B * a.steps / elapsed, 'unit': 'samples/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * elapsed / a.steps,
