@@ -343,6 +343,12 @@ bool mfma_enabled() {
     return !(e && e[0] == '1');
 }
 
+// STC_DISABLE_X3=1 keeps the matrix-core kernels on the fp32 MFMA instead of the split-operand bf16 MFMA
+bool x3_enabled() {
+    const char* e = std::getenv("STC_DISABLE_X3");
+    return mfma_enabled() && !(e && e[0] == '1');
+}
+
 int bwd_grid(const NodeDims& d, long long nodes) {
     const long long n_tiles = (nodes + d.TN - 1) / d.TN;
     return (int)(n_tiles < NODE_BWD_MAX_GRID ? n_tiles : NODE_BWD_MAX_GRID);
@@ -360,6 +366,10 @@ extern "C" int stc_bdg_node_fwd_f32(const float* const* Z, int32_t Ks, const flo
     for (int n = 0; n < Ks; ++n) {
         STC_REQUIRE(Z[n], STC_EINVAL, "stc_bdg_node_fwd_f32: Z[%d] is null", n);
         zp.p[n] = Z[n];
+    }
+    if (x3_enabled()) {
+        const int rc = stc_node_fwd_x3(Z, Ks, Tc, Kc, W, bias, Y, nodes, C, L, Lw, Ho, static_cast<hipStream_t>(stream));
+        if (rc != STC_NOT_HANDLED) return rc;
     }
     if (mfma_enabled()) {
         const int rc = stc_node_fwd_mfma(Z, Ks, Tc, Kc, W, bias, Y, nodes, C, L, Lw, Ho, static_cast<hipStream_t>(stream));
@@ -394,7 +404,9 @@ extern "C" int stc_cell_gates_fwd_f32(const float* const* Z, int32_t Ks, const f
     STC_REQUIRE(Z && W && H && U && Rg && CandIn && (Kc == 1 || Tc), STC_EINVAL, "stc_cell_gates_fwd_f32: null pointer");
     for (int n = 0; n < Ks; ++n) STC_REQUIRE(Z[n], STC_EINVAL, "stc_cell_gates_fwd_f32: Z[%d] is null", n);
     STC_REQUIRE(Z[0] != CandIn, STC_EINVAL, "stc_cell_gates_fwd_f32: CandIn must not alias Z[0]");
-    const int rc = stc_cell_gates_fwd_mfma(Z, Ks, Tc, W, bias, H, U, Rg, CandIn, nodes, C, L, Lw, cin, static_cast<hipStream_t>(stream));
+    int rc = STC_NOT_HANDLED;
+    if (x3_enabled()) rc = stc_cell_gates_fwd_x3(Z, Ks, Tc, W, bias, H, U, Rg, CandIn, nodes, C, L, Lw, cin, static_cast<hipStream_t>(stream));
+    if (rc == STC_NOT_HANDLED) rc = stc_cell_gates_fwd_mfma(Z, Ks, Tc, W, bias, H, U, Rg, CandIn, nodes, C, L, Lw, cin, static_cast<hipStream_t>(stream));
     return rc == STC_NOT_HANDLED ? stc::fail(STC_EUNSUPPORTED, "stc_cell_gates_fwd_f32: operands not usable by the fused path (alignment)") : rc;
 }
 
@@ -421,8 +433,11 @@ extern "C" int stc_cell_gates_bwd_f32(const float* const* Z, int32_t Ks, const f
                 "stc_cell_gates_bwd_f32: workspace of %zu B is too small", workspace_bytes);
     int n_parts = 0;
     float* partial = static_cast<float*>(workspace);
-    const int rc = stc_cell_gates_bwd_mfma(Z, Ks, Tc, W, dCandIn, dU, H, U, Rg, dH_in, dZ, dXt, dH, partial, &n_parts, db != nullptr,
-                                           nodes, C, L, Lw, cin, s);
+    int rc = STC_NOT_HANDLED;
+    if (x3_enabled()) rc = stc_cell_gates_bwd_x3(Z, Ks, Tc, W, dCandIn, dU, H, U, Rg, dH_in, dZ, dXt, dH, partial, &n_parts, db != nullptr,
+                                                 nodes, C, L, Lw, cin, s);
+    if (rc == STC_NOT_HANDLED) rc = stc_cell_gates_bwd_mfma(Z, Ks, Tc, W, dCandIn, dU, H, U, Rg, dH_in, dZ, dXt, dH, partial, &n_parts, db != nullptr,
+                                                            nodes, C, L, Lw, cin, s);
     if (rc == STC_NOT_HANDLED) return stc::fail(STC_EUNSUPPORTED, "stc_cell_gates_bwd_f32: operands not usable by the fused path (alignment)");
     if (rc != STC_OK) return rc;
     const int stride = nW + Ho;
@@ -441,7 +456,9 @@ extern "C" int stc_cell_blend_fwd_f32(const float* const* Z, int32_t Ks, const f
     if (nodes == 0) return STC_OK;
     STC_REQUIRE(Z && W && U && H && Cand && Hnew && (Kc == 1 || Tc), STC_EINVAL, "stc_cell_blend_fwd_f32: null pointer");
     for (int n = 0; n < Ks; ++n) STC_REQUIRE(Z[n], STC_EINVAL, "stc_cell_blend_fwd_f32: Z[%d] is null", n);
-    const int rc = stc_cell_blend_fwd_mfma(Z, Ks, Tc, W, bias, U, H, Cand, Hnew, nodes, C, L, Lw, static_cast<hipStream_t>(stream));
+    int rc = STC_NOT_HANDLED;
+    if (x3_enabled()) rc = stc_cell_blend_fwd_x3(Z, Ks, Tc, W, bias, U, H, Cand, Hnew, nodes, C, L, Lw, static_cast<hipStream_t>(stream));
+    if (rc == STC_NOT_HANDLED) rc = stc_cell_blend_fwd_mfma(Z, Ks, Tc, W, bias, U, H, Cand, Hnew, nodes, C, L, Lw, static_cast<hipStream_t>(stream));
     return rc == STC_NOT_HANDLED ? stc::fail(STC_EUNSUPPORTED, "stc_cell_blend_fwd_f32: operands not usable by the fused path (alignment)") : rc;
 }
 
@@ -481,7 +498,9 @@ extern "C" int stc_bdg_node_bwd_f32(const float* const* Z, int32_t Ks, const flo
     if (mfma_enabled() && dTc == nullptr) {
         int n_parts = 0;
         float* partial = static_cast<float*>(workspace);
-        const int rc = stc_node_bwd_mfma(Z, Ks, Tc, Kc, W, dY, dZ, partial, &n_parts, db != nullptr, nodes, C, L, Lw, Ho, s);
+        int rc = STC_NOT_HANDLED;
+        if (x3_enabled()) rc = stc_node_bwd_x3(Z, Ks, Tc, Kc, W, dY, dZ, partial, &n_parts, db != nullptr, nodes, C, L, Lw, Ho, s);
+        if (rc == STC_NOT_HANDLED) rc = stc_node_bwd_mfma(Z, Ks, Tc, Kc, W, dY, dZ, partial, &n_parts, db != nullptr, nodes, C, L, Lw, Ho, s);
         if (rc == STC_OK) {
             const int stride = nW + Ho;
             hipLaunchKernelGGL(bdg_node_reduce_kernel, dim3((stride + RED_ELEMS - 1) / RED_ELEMS), dim3(NODE_THREADS), 0, s,

@@ -29,3 +29,21 @@ int stc_cell_gates_bwd_mfma(const float* const* Z, int K, const float* Tc, const
                             const float* dCandIn, const float* dU, const float* H, const float* U, const float* R, const float* dH_in,
                             float* const* dZ, float* dXt, float* dH, float* partial, int* n_partials, int want_db,
                             long long nodes, int C, int L, int Lw, int cin, hipStream_t stream);
+
+// Split-operand bf16 MFMA versions of the same five launches (stc_node_x3.hip; C in {32, 64}), tried before the fp32
+// MFMA ones.  Same contract and return values.
+int stc_node_fwd_x3(const float* const* Z, int Ks, const float* Tc, int Kc, const float* W, const float* bias,
+                    float* Y, long long nodes, int C, int L, int Lw, int Ho, hipStream_t stream);
+int stc_node_bwd_x3(const float* const* Z, int Ks, const float* Tc, int Kc, const float* W, const float* dY,
+                    float* const* dZ, float* partial, int* n_partials, int want_db,
+                    long long nodes, int C, int L, int Lw, int Ho, hipStream_t stream);
+int stc_cell_gates_fwd_x3(const float* const* Z, int K, const float* Tc, const float* W, const float* bias,
+                          const float* H, float* U, float* R, float* CandIn,
+                          long long nodes, int C, int L, int Lw, int cin, hipStream_t stream);
+int stc_cell_blend_fwd_x3(const float* const* Z, int K, const float* Tc, const float* W, const float* bias,
+                          const float* U, const float* H, float* Cand, float* Hnew,
+                          long long nodes, int C, int L, int Lw, hipStream_t stream);
+int stc_cell_gates_bwd_x3(const float* const* Z, int K, const float* Tc, const float* W,
+                          const float* dCandIn, const float* dU, const float* H, const float* U, const float* R, const float* dH_in,
+                          float* const* dZ, float* dXt, float* dH, float* partial, int* n_partials, int want_db,
+                          long long nodes, int C, int L, int Lw, int cin, hipStream_t stream);

@@ -20,19 +20,9 @@
 // A k-step of the 16x16x4 MFMA takes lane quarter q = lane>>4 as its k index.  Since a sum over k
 // does not care about order, lane (row, q) simply owns columns {16m+4q .. 16m+4q+3} of its row
 // (one float4), used at steps 4m..4m+3: kcol(s,q) below.  Both operands are built with the same map.
-#include "stc_common.h"
-#include "stc_node_mfma.h"
+#include "stc_node_frag.h"
 
 namespace {
-
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-
-constexpr int MF_THREADS = 256;
-constexpr int MF_WAVES = MF_THREADS / 64;
-constexpr int MF_BWD_MAX_GRID = 512;     // partial rows the caller's workspace holds
-
-struct ZPtrs { const float* p[STC_MAX_K]; };
-struct DZPtrs { float* p[STC_MAX_K]; };
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -43,16 +33,6 @@ template <int LQ>
 __host__ __device__ constexpr int kcol(int s, int q) {
     constexpr int N16 = LQ / 4;
     return s < 4 * N16 ? 16 * (s / 4) + 4 * q + (s % 4) : 16 * N16 + 4 * (s - 4 * N16) + q;
-}
-
-template <int N>
-struct AtLeast1 { static constexpr int v = N > 0 ? N : 1; };
-
-// A value the optimiser cannot see through: keeps LDS fragment fetches inside the node loop instead of
-// being hoisted into ~80 registers (which costs a wave of occupancy per SIMD).
-__device__ __forceinline__ int opaque(int v) {
-    asm volatile("" : "+v"(v));
-    return v;
 }
 
 // --------------------------------------------------------------------------------------- forward
@@ -84,24 +64,6 @@ struct ZFrag {      // one node's A operand: this lane's row of every slab / row
         return r[n][rb][s - 4 * N16 < NREM && s >= 4 * N16 ? s - 4 * N16 : 0];
     }
 };
-
-// Fused epilogues of the two convolutions of an STC_Cell (reference STC_GNN.py:71-78), hidden width 16:
-//   EPI_GATES (Ho = 32): U = sigmoid(y[:, :16]), R = sigmoid(y[:, 16:]), CandIn = [Xt | R*H | 0-pad]  -- the
-//              gate pre-activations are never written; Xt is copied from this wave's own A fragment of slab 0
-//   EPI_BLEND (Ho = 16): Cand = tanh(y), Hnew = (1-U)*H + U*Cand
-enum { EPI_NONE = 0, EPI_GATES = 1, EPI_BLEND = 2 };
-struct FwdEpi {
-    const float* H;       // (nodes, C, 16) previous state
-    const float* U;       // BLEND in : update gate
-    float* U_out;         // GATES out: update gate
-    float* R_out;         // GATES out: reset gate
-    float* CandIn;        // GATES out: (nodes, C, L) input rows of the candidate convolution
-    float* Cand;          // BLEND out: tanh(candidate)
-    float* Hnew;          // BLEND out: new state
-    int cin;              // GATES: width of Xt inside a row (the H part starts there)
-};
-
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
 
 template <int NRB, int HB, int K, int LQ, int EPI>
 __global__ __launch_bounds__(MF_THREADS, ((NRB * K * LQ <= 32) ? 3 : 2)) void node_fwd_mfma_kernel(
@@ -254,83 +216,12 @@ struct BwdPlan {
     static constexpr bool prefetch = regs <= 232;
 };
 
-template <int NRB, int HB>
-struct DyFrag {     // one node's dY in both register layouts
-    f32x4 d[NRB][HB];   // component t: dY[16kb + 4q + t][16hb + j]        (tile rows d, columns o; lane = o)
-    f32x4 v[NRB][HB];   // dY[16rb + j][16hb + 4q + 0..3]                   (tile rows o, columns d; lane = d)
-    __device__ __forceinline__ void load(const float* __restrict__ dY, int node, int j, int q) {
-        constexpr int C = 16 * NRB, Ho = 16 * HB;
-        const size_t r0 = (size_t)node * C;
-#pragma unroll
-        for (int kb = 0; kb < NRB; ++kb)
-#pragma unroll
-            for (int hb = 0; hb < HB; ++hb) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) d[kb][hb][t] = dY[(r0 + 16 * kb + 4 * q + t) * Ho + 16 * hb + j];
-                const float4 x = *reinterpret_cast<const float4*>(dY + (r0 + 16 * kb + j) * Ho + 16 * hb + 4 * q);
-                v[kb][hb] = f32x4{x.x, x.y, x.z, x.w};
-            }
-    }
-};
-
-// Prologue of the gates convolution's backward (autograd of reference STC_GNN.py:71-75, hidden 16): instead of
-// reading a precomputed dY, build it per node from the gradient of [Xt | R*H | pad] and the saved gates,
-//   dY[:, :16] = dU * U * (1 - U),   dY[:, 16:] = dCandIn[:, cin:cin+16] * H * R * (1 - R),
-// and emit the two by-products dXt = dCandIn[:, :cin], dH = dCandIn[h part] * R + dH_in on the way.  The kernel is
-// MFMA-bound with ~180 us of memory slack per launch, so these streams ride along for free and the separate
-// gate-backward pass (and the dG round trip through HBM) disappears.
-enum { PRO_NONE = 0, PRO_GATES = 1 };
-struct BwdPro {
-    const float *dCandIn, *dU, *H, *U, *R, *dH_in;   // (nodes,C,L) and (nodes,C,16) operands; dH_in may be null / alias dH
-    float *dXt, *dH;                                  // (nodes,C,cin), (nodes,C,16)
-    int cin;
-};
-
-template <int NRB, int HB, int L>
-__device__ __forceinline__ void load_gates_grad(DyFrag<NRB, HB>& g, const BwdPro& p, int node, int j, int q) {
-    static_assert(HB == 2, "gates prologue needs Ho = 2 * 16");
-    constexpr int C = 16 * NRB, HID = 16;
-    const size_t r0 = (size_t)node * C;
-#pragma unroll
-    for (int kb = 0; kb < NRB; ++kb) {
-        // accumulator-style layout: rows 16kb + 4q + t, column j
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const size_t row = r0 + 16 * kb + 4 * q + t, e = row * HID + j;
-            const float u = p.U[e], r = p.R[e];
-            g.d[kb][0][t] = p.dU[e] * u * (1.f - u);
-            g.d[kb][1][t] = p.dCandIn[row * L + p.cin + j] * p.H[e] * r * (1.f - r);
-        }
-        // row-on-lane layout: row 16kb + j, columns 4q .. 4q+3; this is also where dXt and dH are produced
-        const size_t row = r0 + 16 * kb + j, e = row * HID + 4 * q;
-        const float4 u = *reinterpret_cast<const float4*>(p.U + e), r = *reinterpret_cast<const float4*>(p.R + e);
-        const float4 du = *reinterpret_cast<const float4*>(p.dU + e), hh = *reinterpret_cast<const float4*>(p.H + e);
-        const float* cr = p.dCandIn + row * L;
-        float4 d;
-        if ((p.cin & 3) == 0) d = *reinterpret_cast<const float4*>(cr + p.cin + 4 * q);
-        else d = make_float4(cr[p.cin + 4 * q], cr[p.cin + 4 * q + 1], cr[p.cin + 4 * q + 2], cr[p.cin + 4 * q + 3]);
-        g.v[kb][0] = f32x4{du.x * u.x * (1.f - u.x), du.y * u.y * (1.f - u.y), du.z * u.z * (1.f - u.z), du.w * u.w * (1.f - u.w)};
-        g.v[kb][1] = f32x4{d.x * hh.x * r.x * (1.f - r.x), d.y * hh.y * r.y * (1.f - r.y), d.z * hh.z * r.z * (1.f - r.z), d.w * hh.w * r.w * (1.f - r.w)};
-        float4 dh = make_float4(d.x * r.x, d.y * r.y, d.z * r.z, d.w * r.w);
-        if (p.dH_in) {
-            const float4 o = *reinterpret_cast<const float4*>(p.dH_in + e);
-            dh.x += o.x; dh.y += o.y; dh.z += o.z; dh.w += o.w;
-        }
-        *reinterpret_cast<float4*>(p.dH + e) = dh;
-        for (int c0 = 4 * q; c0 < p.cin; c0 += 16)
-#pragma unroll
-            for (int x = 0; x < 4; ++x)
-                if (c0 + x < p.cin) p.dXt[row * p.cin + c0 + x] = cr[c0 + x];
-    }
-}
-
 template <int NRB, int HB, int K, int LQ, int PRO>
 __global__ __launch_bounds__(MF_THREADS, (BwdPlan<NRB, HB, K, LQ>::prefetch ? 2 : 1)) void node_bwd_mfma_kernel(
     ZPtrs Z, const float* __restrict__ Tc, const float* __restrict__ W, const float* __restrict__ dY,
     DZPtrs dZ, float* __restrict__ partial, int nodes, int want_db, int Lw, BwdPro pro) {
     constexpr int C = 16 * NRB, Ho = 16 * HB, L = 4 * LQ, LB = (L + 15) / 16;
     constexpr bool PF = BwdPlan<NRB, HB, K, LQ>::prefetch && PRO == PRO_NONE;
-    const int nW = K * K * Lw * Ho;
     constexpr int nTf = (K - 1) * NRB * NRB * 4 * 64;
     constexpr int nWf = K * LB * K * HB * 4 * 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -497,37 +388,7 @@ __global__ __launch_bounds__(MF_THREADS, (BwdPlan<NRB, HB, K, LQ>::prefetch ? 2 
         node = next_node;
     }
 
-    // combine the four waves of the workgroup in a fixed order, then one partial row per workgroup
-    __syncthreads();                                   // every wave is done with the fragment tables
-    float* slab = smem + (size_t)wave * (nW + Ho);     // [dW in W layout | db]
-#pragma unroll
-    for (int n = 0; n < K; ++n)
-#pragma unroll
-        for (int lb = 0; lb < LB; ++lb)
-#pragma unroll
-            for (int c = 0; c < K; ++c)
-#pragma unroll
-                for (int hb = 0; hb < HB; ++hb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int l = 16 * lb + 4 * q + r;
-                        if (l < Lw) slab[((n * K + c) * Lw + l) * Ho + 16 * hb + j] = dWt[n][lb][c][hb][r];
-                    }
-#pragma unroll
-    for (int hb = 0; hb < HB; ++hb) {
-        float v = dbp[hb];
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
-        if (q == 0) slab[nW + 16 * hb + j] = v;
-    }
-    __syncthreads();
-    float* out = partial + (size_t)blockIdx.x * (nW + Ho);
-    for (int e = tid; e < nW + Ho; e += MF_THREADS) {
-        float s = smem[e];
-#pragma unroll
-        for (int w = 1; w < MF_WAVES; ++w) s += smem[(size_t)w * (nW + Ho) + e];
-        out[e] = (e >= nW && !want_db) ? 0.f : s;
-    }
+    combine_dw<K, LB, HB>(smem, dWt, dbp, partial, Lw, want_db);
 }
 
 template <int NRB, int HB, int K, int LQ, int EPI = EPI_NONE>
@@ -574,12 +435,6 @@ int launch_bwd(const float* const* Z, const float* Tc, const float* W, const flo
 bool fast_path_shape(int Ks, int Kc, int C, int L, int Ho, long long nodes) {
     return Ks == Kc && Ks >= 1 && Ks <= 3 && (C == 16 || C == 32 || C == 64) && (Ho == 16 || Ho == 32) &&
            (L == 20 || L == 32) && nodes > 0 && nodes < (1ll << 31) / C;
-}
-
-bool all_aligned16(const float* const* p, int n) {
-    for (int i = 0; i < n; ++i)
-        if (!stc::aligned16(p[i])) return false;
-    return true;
 }
 
 }  // namespace

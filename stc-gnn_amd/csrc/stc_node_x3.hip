@@ -1,0 +1,613 @@
+// Split-operand matrix-core path of the BDG_Dif node kernel (reference STC_GNN.py:38-45 and its autograd) for gfx950.
+//
+// The fp32 MFMA (v_mfma_f32_16x16x4_f32) runs at the fp32 vector rate, 1/16 of the bf16 MFMA, and the node kernels
+// built on it (stc_node_mfma.hip) are bound by it, not by HBM.  Here every fp32 operand a is split EXACTLY into three
+// bf16 pieces, a = a_h + a_m + a_l (8 + 8 + 8 significant bits; each remainder is exact in fp32), and a product
+// sum is accumulated in fp32 from the six piece products of weight >= 2^-16,
+//     A.B ~= Al.Bh + Ah.Bl + Am.Bm + Am.Bh + Ah.Bm + Ah.Bh      (dropped: 2^-24 |a||b| and below, the fp32 rounding level)
+// on v_mfma_f32_16x16x32_bf16 (16 cycles for 16x16x32): 6/16 of the matrix time of the fp32 instruction.  bf16 x bf16
+// products are exact in the fp32 accumulator, so the result differs from an fmaf chain only by summation order and
+// the dropped 2^-24 terms (tools/probes/mfma_bf16_layout.hip: 8.5e-8 vs 1.4e-7 for the fmaf chain, against fp64).
+//
+// Register layout of v_mfma_f32_16x16x32_bf16, lane (x = lane & 15, g = lane >> 4):
+//     A operand: A[x][8g + e], e = 0..7      B operand: B[8g + e][x]      D: D[4g + r][x], r = 0..3
+// The contraction slot 8g + e may stand for any contraction index as long as both operands agree.  Two maps are used:
+//     rows of a feature slab:   slot (g, e) = column 8g + e                 (8 contiguous floats of the lane's row)
+//     accumulator fed operands: slot (g, e) = row 16 (e >> 2) + 4g + (e & 3) of a PAIR of 16-row tiles, which is exactly
+//                               what lane (x, g) holds of those two tiles -- accumulators feed the next product from
+//                               registers, no LDS trip (as in the fp32 kernel).
+// Everything that is the same for every node (W, T_c) is split once per workgroup into LDS in fragment order (three
+// 16-byte pieces per lane, conflict-free ds_read_b128).  One wave owns one node at a time; no barrier in the node loop.
+//
+// Shapes: C = 32 * NB2 categories, Ho = 16 * HB outputs, L <= 32 features per slab (one 32-wide step, zero padded),
+// Ks = Kc = K.  Other shapes stay on the fp32 MFMA / VALU kernels.
+#include "stc_node_frag.h"
+
+namespace {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+
+struct X3 { u32x4 h, m, l; };       // 8 fp32 values as three bf16x8 pieces
+
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {     // v_cvt_pk_bf16_f32: a in the low half
+    const bf16x2 v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, v);
+}
+
+__device__ __forceinline__ void split2(float a0, float a1, unsigned& h, unsigned& m, unsigned& l) {
+    h = pk_bf16(a0, a1);
+    const float r0 = a0 - __uint_as_float(h << 16), r1 = a1 - __uint_as_float(h & 0xffff0000u);      // exact
+    m = pk_bf16(r0, r1);
+    const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);      // exact
+    l = pk_bf16(s0, s1);
+}
+
+__device__ __forceinline__ X3 split8(const f32x4 a, const f32x4 b) {     // slots 0..3 from a, 4..7 from b
+    unsigned h[4], m[4], l[4];
+    split2(a[0], a[1], h[0], m[0], l[0]);
+    split2(a[2], a[3], h[1], m[1], l[1]);
+    split2(b[0], b[1], h[2], m[2], l[2]);
+    split2(b[2], b[3], h[3], m[3], l[3]);
+    X3 r;
+    r.h = u32x4{h[0], h[1], h[2], h[3]};
+    r.m = u32x4{m[0], m[1], m[2], m[3]};
+    r.l = u32x4{l[0], l[1], l[2], l[3]};
+    return r;
+}
+
+__device__ __forceinline__ f32x4 mma(const u32x4 a, const u32x4 b, const f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ f32x4 mma6(const X3& A, const X3& B, f32x4 c) {      // smallest terms first
+    c = mma(A.l, B.h, c);
+    c = mma(A.h, B.l, c);
+    c = mma(A.m, B.m, c);
+    c = mma(A.m, B.h, c);
+    c = mma(A.h, B.m, c);
+    c = mma(A.h, B.h, c);
+    return c;
+}
+
+// LDS fragment tables: entry (frag, piece, lane) is one 16-byte vector
+__device__ __forceinline__ void put_frag(u32x4* tab, int frag, int lane, const float (&v)[8]) {
+    const X3 s = split8(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]});
+    tab[(frag * 3 + 0) * 64 + lane] = s.h;
+    tab[(frag * 3 + 1) * 64 + lane] = s.m;
+    tab[(frag * 3 + 2) * 64 + lane] = s.l;
+}
+
+__device__ __forceinline__ X3 get_frag(const u32x4* tab, int frag, int lo) {
+    X3 r;
+    r.h = tab[(frag * 3 + 0) * 64 + lo];
+    r.m = tab[(frag * 3 + 1) * 64 + lo];
+    r.l = tab[(frag * 3 + 2) * 64 + lo];
+    return r;
+}
+
+// row of a pair of 16-row tiles that slot (g, e) of an accumulator-fed operand stands for
+__host__ __device__ constexpr int pair_row(int g, int e) { return 16 * (e >> 2) + 4 * g + (e & 3); }
+
+#define kZero4 (f32x4{0.f, 0.f, 0.f, 0.f})
+
+// columns 8g .. 8g+7 of a feature row of L floats (L a multiple of 4, <= 32); columns >= L read as zero
+template <int L>
+struct Row8 {
+    f32x4 a, b;
+    __device__ __forceinline__ void load(const float* __restrict__ row, int g) {
+        a = kZero4; b = kZero4;
+        if (L == 32 || 8 * g < L) a = *reinterpret_cast<const f32x4*>(row + 8 * g);
+        if (L == 32 || 8 * g + 4 < L) b = *reinterpret_cast<const f32x4*>(row + 8 * g + 4);
+    }
+    __device__ __forceinline__ float at(int e) const { return e < 4 ? a[e & 3] : b[e & 3]; }
+};
+
+// --------------------------------------------------------------------------------------- forward
+template <int NB2, int HB, int K, int L, int EPI>
+__global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_kernel(
+    ZPtrs Z, const float* __restrict__ Tc, const float* __restrict__ W, const float* __restrict__ bias,
+    float* __restrict__ Y, int nodes, int Lw, FwdEpi epi) {
+    constexpr int NRB = 2 * NB2, C = 32 * NB2, Ho = 16 * HB, NCB = K * HB;
+    constexpr int HID = 16;
+    constexpr int nWx = K * NCB, nTx = (K - 1) * NRB * NB2;
+    static_assert(EPI == EPI_NONE || (EPI == EPI_GATES && HB == 2) || (EPI == EPI_BLEND && HB == 1), "epilogue needs hidden = 16");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32x4* Wx = reinterpret_cast<u32x4*>(smem_raw);        // [K n][NCB]          B: W[(n, c, l = slot)][o = 16 hb + x]
+    u32x4* Tx = Wx + nWx * 3 * 64;                          // [K-1][NRB rb][NB2]  A: T_c[c' = 32 p + pair_row][d = 16 rb + x]
+    const int tid = threadIdx.x, lane = tid & 63, x = lane & 15, g = lane >> 4;
+
+    for (int idx = tid; idx < nWx * 64; idx += MF_THREADS) {
+        const int ll = idx & 63, f = idx >> 6, cb = f % NCB, n = f / NCB;
+        const int c = cb / HB, o = (cb % HB) * 16 + (ll & 15), gg = ll >> 4;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int l = 8 * gg + e;
+            v[e] = l < Lw ? W[((size_t)(n * K + c) * Lw + l) * Ho + o] : 0.f;       // pad columns contribute nothing
+        }
+        put_frag(Wx, f, ll, v);
+    }
+    for (int idx = tid; idx < nTx * 64; idx += MF_THREADS) {
+        const int ll = idx & 63, f = idx >> 6, p = f % NB2, rb = (f / NB2) % NRB, c1 = f / (NB2 * NRB), gg = ll >> 4;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            v[e] = Tc[(size_t)(c1 + 1) * C * C + (32 * p + pair_row(gg, e)) * C + 16 * rb + (ll & 15)];
+        put_frag(Tx, f, ll, v);
+    }
+    __syncthreads();
+
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nw = gridDim.x * MF_WAVES;
+    float bv[HB];
+#pragma unroll
+    for (int hb = 0; hb < HB; ++hb) bv[hb] = bias ? bias[16 * hb + x] : 0.f;
+
+    int node = blockIdx.x * MF_WAVES + wave;
+    Row8<L> cur[K][NRB], nxt[K][NRB];
+    auto load_rows = [&](Row8<L> (&z)[K][NRB], int nd) {
+#pragma unroll
+        for (int n = 0; n < K; ++n)
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) z[n][rb].load(Z.p[n] + ((size_t)nd * C + 16 * rb + x) * L, g);
+    };
+    if (node < nodes) load_rows(cur, node);
+    while (node < nodes) {
+        const int next_node = node + nw;
+        if (next_node < nodes) load_rows(nxt, next_node);        // software prefetch: lands while this node computes
+        // epilogue operands in accumulator layout (row 16rb + 4g + r, column x): needed only after the MFMAs
+        float hv[NRB][4], uv[NRB][4];
+        if (EPI != EPI_NONE) {
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const size_t e = ((size_t)node * C + 16 * rb + 4 * g + r) * HID + x;
+                    hv[rb][r] = epi.H[e];
+                    if (EPI == EPI_BLEND) uv[rb][r] = epi.U[e];
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const int lo = opaque(lane);
+
+        f32x4 acc[NRB][NCB];
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = kZero4;
+
+        // project: U[rb][cb] += Z_n rows (A) * W_{n,c} (B)
+#pragma unroll
+        for (int n = 0; n < K; ++n) {
+            X3 za[NRB];
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) za[rb] = split8(cur[n][rb].a, cur[n][rb].b);
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                const X3 w = get_frag(Wx, n * NCB + cb, lo);
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) acc[rb][cb] = mma6(za[rb], w, acc[rb][cb]);
+            }
+        }
+
+        // mix: Y[rb][hb] = U_0[rb][hb] + sum_{c>=1} T_c^T[rb][:] U_c[:][hb]     (U_c straight from its accumulators)
+#pragma unroll
+        for (int c1 = 0; c1 < K - 1; ++c1)
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+                for (int p = 0; p < NB2; ++p) {
+                    const X3 u = split8(acc[2 * p][(c1 + 1) * HB + hb], acc[2 * p + 1][(c1 + 1) * HB + hb]);
+#pragma unroll
+                    for (int rb = 0; rb < NRB; ++rb) {
+                        const X3 t = get_frag(Tx, (c1 * NRB + rb) * NB2 + p, lo);
+                        acc[rb][hb] = mma6(t, u, acc[rb][hb]);
+                    }
+                }
+
+        if (EPI == EPI_NONE) {
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        Y[((size_t)node * C + 16 * rb + 4 * g + r) * Ho + 16 * hb + x] = acc[rb][hb][r] + bv[hb];
+        } else if (EPI == EPI_GATES) {
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const size_t row = (size_t)node * C + 16 * rb + 4 * g + r;
+                    const float u = sigmoid_f(acc[rb][0][r] + bv[0]);
+                    const float gate = sigmoid_f(acc[rb][HB - 1][r] + bv[HB - 1]);
+                    epi.U_out[row * HID + x] = u;
+                    epi.R_out[row * HID + x] = gate;
+                    epi.CandIn[row * L + epi.cin + x] = gate * hv[rb][r];
+                }
+            // the Xt columns and the zero padding of CandIn come from this lane's own row of slab 0
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+                float* crow = epi.CandIn + ((size_t)node * C + 16 * rb + x) * L;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int col = 8 * g + e;
+                    if (col < L) {
+                        if (col < epi.cin) crow[col] = cur[0][rb].at(e);
+                        else if (col >= epi.cin + HID) crow[col] = 0.f;
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const size_t e = ((size_t)node * C + 16 * rb + 4 * g + r) * HID + x;
+                    const float c = tanhf(acc[rb][0][r] + bv[0]);
+                    const float u = uv[rb][r];
+                    epi.Cand[e] = c;
+                    epi.Hnew[e] = (1.f - u) * hv[rb][r] + u * c;
+                }
+        }
+#pragma unroll
+        for (int n = 0; n < K; ++n)
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) cur[n][rb] = nxt[n][rb];
+        node = next_node;
+    }
+}
+
+// --------------------------------------------------------------------------------------- backward
+// Per node, with Q_0 = dY and Q_c = T_c dY (c >= 1), all contractions on the split-operand MFMA:
+//   Qv_c (rows o, cols c')  = dY^T . T_c^T           A = dY in accumulator layout (slots = rows d), B = T_c table
+//   dZ_n^T (rows l, cols c') = sum_{c,o} W . Q_c^T    A = W table (slots = (c, o) blocks of 16), B = dY rows / Qv accumulators
+//   Qd_c (rows c', cols o)  = T_c . dY               A = T_c table (same table), B = dY in accumulator layout
+//   dW_{n,c} (rows l, cols o) += Z_n^T . Q_c         A = Z columns (slots = rows c'), B = dY / Qd accumulators
+// dW / db stay in registers across all nodes of a wave; fixed-order combine at the end (combine_dw).
+template <int NB2, int HB, int K, int L>
+struct NodeIn {      // what one node contributes from HBM: its dY fragments and its Z columns
+    static constexpr int NRB = 2 * NB2, LB = (L + 15) / 16;
+    DyFrag<NRB, HB> g;
+    float za[K][LB][NRB][4];     // Z_n[16kb + 4g + t][16lb + x]
+    __device__ __forceinline__ void load_z(const ZPtrs& Z, int node, int x, int gq) {
+        constexpr int C = 32 * NB2;
+        const size_t r0 = (size_t)node * C;
+#pragma unroll
+        for (int n = 0; n < K; ++n)
+#pragma unroll
+            for (int lb = 0; lb < LB; ++lb) {
+                const bool ok = 16 * lb + x < L;
+                const float* col = Z.p[n] + r0 * L + 16 * lb + (ok ? x : 0);
+#pragma unroll
+                for (int kb = 0; kb < NRB; ++kb)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const float zv = col[(size_t)(16 * kb + 4 * gq + t) * L];
+                        za[n][lb][kb][t] = ok ? zv : 0.f;
+                    }
+            }
+    }
+};
+
+template <int NB2, int HB, int K, int L, int PRO>
+__global__ __launch_bounds__(MF_THREADS, 1) void node_bwd_x3_kernel(
+    ZPtrs Z, const float* __restrict__ Tc, const float* __restrict__ W, const float* __restrict__ dY,
+    DZPtrs dZ, float* __restrict__ partial, int nodes, int want_db, int Lw, BwdPro pro) {
+    constexpr int NRB = 2 * NB2, C = 32 * NB2, Ho = 16 * HB, LB = (L + 15) / 16;
+    constexpr int NBK = K * HB, S = (NBK + 1) / 2;             // (c, o) blocks of 16 and 32-wide steps over them
+    constexpr int nTB = (K - 1) * NRB * NB2, nWA = K * LB * S;
+    constexpr bool PF = PRO == PRO_NONE;                        // prefetch the next node's operands
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32x4* TB = reinterpret_cast<u32x4*>(smem_raw);     // [K-1][NRB rb][NB2 p]   T_c[16rb + x][32p + pair_row]
+    u32x4* WA = TB + nTB * 3 * 64;                       // [K n][LB][S]           W[(n, c, 16lb + x)][16hb + 4g + (e&3)], block 2s + (e>>2)
+    const int tid = threadIdx.x, lane = tid & 63, x = lane & 15, g = lane >> 4;
+
+    for (int idx = tid; idx < nTB * 64; idx += MF_THREADS) {
+        const int ll = idx & 63, f = idx >> 6, p = f % NB2, rb = (f / NB2) % NRB, c1 = f / (NB2 * NRB), gg = ll >> 4;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            v[e] = Tc[(size_t)(c1 + 1) * C * C + (16 * rb + (ll & 15)) * C + 32 * p + pair_row(gg, e)];
+        put_frag(TB, f, ll, v);
+    }
+    for (int idx = tid; idx < nWA * 64; idx += MF_THREADS) {
+        const int ll = idx & 63, f = idx >> 6, s = f % S, lb = (f / S) % LB, n = f / (S * LB), gg = ll >> 4;
+        const int l = 16 * lb + (ll & 15);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int b = 2 * s + (e >> 2), c = b / HB, hb = b % HB;
+            v[e] = (b < NBK && l < Lw) ? W[((size_t)(n * K + c) * Lw + l) * Ho + 16 * hb + 4 * gg + (e & 3)] : 0.f;
+        }
+        put_frag(WA, f, ll, v);
+    }
+    __syncthreads();
+
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nw = gridDim.x * MF_WAVES;
+
+    f32x4 dWt[K][LB][K][HB];          // dW tiles: rows l = 16lb + 4g + r, columns o = 16hb + x
+    float dbp[HB];
+#pragma unroll
+    for (int n = 0; n < K; ++n)
+#pragma unroll
+        for (int lb = 0; lb < LB; ++lb)
+#pragma unroll
+            for (int c = 0; c < K; ++c)
+#pragma unroll
+                for (int hb = 0; hb < HB; ++hb) dWt[n][lb][c][hb] = kZero4;
+#pragma unroll
+    for (int hb = 0; hb < HB; ++hb) dbp[hb] = 0.f;
+
+    int node = blockIdx.x * MF_WAVES + wave;
+    NodeIn<NB2, HB, K, L> in, nx;
+    if (PF && node < nodes) { in.g.load(dY, node, x, g); in.load_z(Z, node, x, g); }
+    while (node < nodes) {
+        const int next_node = node + nw;
+        const size_t r0 = (size_t)node * C;
+        if constexpr (PRO == PRO_GATES) { load_gates_grad<NRB, HB, L>(in.g, pro, node, x, g); in.load_z(Z, node, x, g); }
+        if (PF && next_node < nodes) { nx.g.load(dY, next_node, x, g); nx.load_z(Z, next_node, x, g); }
+        if (PF) __builtin_amdgcn_sched_barrier(0);
+        const int lo = opaque(lane);
+        const DyFrag<NRB, HB>& gr = in.g;
+
+#pragma unroll
+        for (int kb = 0; kb < NRB; ++kb)
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb)
+                dbp[hb] += (gr.d[kb][hb][0] + gr.d[kb][hb][1]) + (gr.d[kb][hb][2] + gr.d[kb][hb][3]);
+
+        // dY in accumulator layout as an operand: slots = rows d of the tile pair p
+        X3 gd[HB][NB2];
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+            for (int p = 0; p < NB2; ++p) gd[hb][p] = split8(gr.d[2 * p][hb], gr.d[2 * p + 1][hb]);
+
+        // ---- Qv_c tiles (rows o, columns c')
+        f32x4 Qv[AtLeast1<K - 1>::v][NRB][HB];
+#pragma unroll
+        for (int c1 = 0; c1 < K - 1; ++c1)
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+#pragma unroll
+                for (int hb = 0; hb < HB; ++hb) Qv[c1][rb][hb] = kZero4;
+#pragma unroll
+                for (int p = 0; p < NB2; ++p) {
+                    const X3 t = get_frag(TB, (c1 * NRB + rb) * NB2 + p, lo);
+#pragma unroll
+                    for (int hb = 0; hb < HB; ++hb) Qv[c1][rb][hb] = mma6(gd[hb][p], t, Qv[c1][rb][hb]);
+                }
+            }
+
+        // ---- B operands of dZ: step s covers the (c, o) blocks 2s, 2s+1; block (c, hb) of Q_c^T for columns c' = 16rb + x
+        X3 qb[S][NRB];
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+                f32x4 blk[2];
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const int b = 2 * s + h2, c = b / HB, hb = b % HB;
+                    blk[h2] = b >= NBK ? kZero4 : (c == 0 ? gr.v[rb][hb] : Qv[c > 0 ? c - 1 : 0][rb][hb]);
+                }
+                qb[s][rb] = split8(blk[0], blk[1]);
+            }
+
+        // ---- dZ_n^T tile (rows l, columns c')
+#pragma unroll
+        for (int n = 0; n < K; ++n)
+#pragma unroll
+            for (int lb = 0; lb < LB; ++lb) {
+                f32x4 z[NRB];
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) z[rb] = kZero4;
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const X3 w = get_frag(WA, (n * LB + lb) * S + s, lo);
+#pragma unroll
+                    for (int rb = 0; rb < NRB; ++rb) z[rb] = mma6(w, qb[s][rb], z[rb]);
+                }
+                if (16 * lb + 4 * g < L) {
+#pragma unroll
+                    for (int rb = 0; rb < NRB; ++rb)
+                        *reinterpret_cast<f32x4*>(dZ.p[n] + (r0 + 16 * rb + x) * L + 16 * lb + 4 * g) = z[rb];
+                }
+            }
+
+        // ---- Qd_c tiles (rows c', columns o), then as operands: slots = rows c' of the tile pair p
+        X3 qd[AtLeast1<K - 1>::v][HB][NB2];
+#pragma unroll
+        for (int c1 = 0; c1 < K - 1; ++c1) {
+            f32x4 Qd[NRB][HB];
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+#pragma unroll
+                for (int hb = 0; hb < HB; ++hb) Qd[rb][hb] = kZero4;
+#pragma unroll
+                for (int p = 0; p < NB2; ++p) {
+                    const X3 t = get_frag(TB, (c1 * NRB + rb) * NB2 + p, lo);
+#pragma unroll
+                    for (int hb = 0; hb < HB; ++hb) Qd[rb][hb] = mma6(t, gd[hb][p], Qd[rb][hb]);
+                }
+            }
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+                for (int p = 0; p < NB2; ++p) qd[c1][hb][p] = split8(Qd[2 * p][hb], Qd[2 * p + 1][hb]);
+        }
+
+        // ---- dW_{n,c} tile (rows l, columns o) += Z_n^T . Q_c
+#pragma unroll
+        for (int n = 0; n < K; ++n)
+#pragma unroll
+            for (int lb = 0; lb < LB; ++lb)
+#pragma unroll
+                for (int p = 0; p < NB2; ++p) {
+                    const float (&zc)[NRB][4] = in.za[n][lb];
+                    const X3 a = split8(f32x4{zc[2 * p][0], zc[2 * p][1], zc[2 * p][2], zc[2 * p][3]},
+                                        f32x4{zc[2 * p + 1][0], zc[2 * p + 1][1], zc[2 * p + 1][2], zc[2 * p + 1][3]});
+#pragma unroll
+                    for (int c = 0; c < K; ++c)
+#pragma unroll
+                        for (int hb = 0; hb < HB; ++hb)
+                            dWt[n][lb][c][hb] = mma6(a, c == 0 ? gd[hb][p] : qd[c > 0 ? c - 1 : 0][hb][p], dWt[n][lb][c][hb]);
+                }
+        if (PF) in = nx;
+        node = next_node;
+    }
+    combine_dw<K, LB, HB>(reinterpret_cast<float*>(smem_raw), dWt, dbp, partial, Lw, want_db);
+}
+
+// --------------------------------------------------------------------------------------- host side
+template <int NB2, int HB, int K, int L, int EPI = EPI_NONE>
+int launch_fwd(const float* const* Z, const float* Tc, const float* W, const float* bias, float* Y,
+               long long nodes, int Lw, hipStream_t stream, FwdEpi epi = FwdEpi{}) {
+    constexpr int NRB = 2 * NB2, NCB = K * HB;
+    const size_t lds = (size_t)(K * NCB + (K - 1) * NRB * NB2) * 3 * 64 * 16;
+    if (lds > stc::kMaxLdsBytes) return STC_NOT_HANDLED;
+    auto kern = node_fwd_x3_kernel<NB2, HB, K, L, EPI>;
+    if (int rc = stc::hip_status(stc::allow_lds(kern, lds), "hipFuncSetAttribute(node fwd x3)")) return rc;
+    static const int resident = stc::resident_blocks(kern, MF_THREADS, lds, 2);   // persistent grid = what fits at once
+    ZPtrs zp{};
+    for (int n = 0; n < K; ++n) zp.p[n] = Z[n];
+    const long long want = (nodes + MF_WAVES - 1) / MF_WAVES;
+    const int grid = (int)(want < resident ? want : resident);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(MF_THREADS), lds, stream, zp, Tc, W, bias, Y, (int)nodes, Lw, epi);
+    STC_LAUNCH_CHECK("node_fwd_x3 launch");
+    return STC_OK;
+}
+
+template <int NB2, int HB, int K, int L, int PRO = PRO_NONE>
+int launch_bwd(const float* const* Z, const float* Tc, const float* W, const float* dY, float* const* dZ,
+               float* partial, int* n_partials, int want_db, long long nodes, int Lw, hipStream_t stream, BwdPro pro = BwdPro{}) {
+    constexpr int NRB = 2 * NB2, Ho = 16 * HB, LB = (L + 15) / 16, NBK = K * HB, S = (NBK + 1) / 2, nW = K * K * L * Ho;
+    const size_t frag = (size_t)((K - 1) * NRB * NB2 + K * LB * S) * 3 * 64 * 16;
+    const size_t slabs = (size_t)MF_WAVES * (nW + Ho) * sizeof(float);
+    const size_t lds = frag > slabs ? frag : slabs;
+    if (lds > stc::kMaxLdsBytes) return STC_NOT_HANDLED;
+    auto kern = node_bwd_x3_kernel<NB2, HB, K, L, PRO>;
+    if (int rc = stc::hip_status(stc::allow_lds(kern, lds), "hipFuncSetAttribute(node bwd x3)")) return rc;
+    static const int resident = stc::resident_blocks(kern, MF_THREADS, lds, 1);
+    ZPtrs zp{};
+    DZPtrs dzp{};
+    for (int n = 0; n < K; ++n) { zp.p[n] = Z[n]; dzp.p[n] = dZ[n]; }
+    const long long want = (nodes + MF_WAVES - 1) / MF_WAVES;
+    int grid = resident < MF_BWD_MAX_GRID ? resident : MF_BWD_MAX_GRID;
+    if (want < grid) grid = (int)want;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(MF_THREADS), lds, stream, zp, Tc, W, dY, dzp, partial, (int)nodes, want_db, Lw, pro);
+    STC_LAUNCH_CHECK("node_bwd_x3 launch");
+    *n_partials = grid;
+    return STC_OK;
+}
+
+bool x3_shape(int Ks, int Kc, int C, int L, int Ho, long long nodes) {
+    return Ks == Kc && Ks >= 1 && Ks <= (C == 64 ? 2 : 3) && (C == 32 || C == 64) && (Ho == 16 || Ho == 32) &&
+           (L == 20 || L == 32) && nodes > 0 && nodes < (1ll << 31) / C;        // C = 64, K = 3 would spill: fp32 MFMA path
+}
+
+}  // namespace
+
+// C = 32: Ho in {16,32} x K in {1,2,3} x L in {20,32};  C = 64: K in {1,2}
+#define STC_X3_CASE12(NB2_, HB_, CALL)                                                                  \
+    if (C == 32 * NB2_ && Ho == 16 * HB_) {                                                             \
+        if (Ks == 1 && L == 20) return CALL(NB2_, HB_, 1, 20);                                          \
+        if (Ks == 1 && L == 32) return CALL(NB2_, HB_, 1, 32);                                          \
+        if (Ks == 2 && L == 20) return CALL(NB2_, HB_, 2, 20);                                          \
+        if (Ks == 2 && L == 32) return CALL(NB2_, HB_, 2, 32);                                          \
+    }
+#define STC_X3_CASE3(NB2_, HB_, CALL)                                                                   \
+    if (C == 32 * NB2_ && Ho == 16 * HB_) {                                                             \
+        if (Ks == 3 && L == 20) return CALL(NB2_, HB_, 3, 20);                                          \
+        if (Ks == 3 && L == 32) return CALL(NB2_, HB_, 3, 32);                                          \
+    }
+#define STC_X3_DISPATCH(CALL)                                                                           \
+    STC_X3_CASE12(1, 1, CALL) STC_X3_CASE12(1, 2, CALL) STC_X3_CASE12(2, 1, CALL) STC_X3_CASE12(2, 2, CALL) \
+    STC_X3_CASE3(1, 1, CALL) STC_X3_CASE3(1, 2, CALL)
+
+int stc_node_fwd_x3(const float* const* Z, int Ks, const float* Tc, int Kc, const float* W, const float* bias,
+                    float* Y, long long nodes, int C, int L, int Lw, int Ho, hipStream_t stream) {
+    if (!x3_shape(Ks, Kc, C, L, Ho, nodes)) return STC_NOT_HANDLED;
+    if (!all_aligned16(Z, Ks) || !stc::aligned16(Y)) return STC_NOT_HANDLED;
+#define FWD_CALL(a, b, c, d) launch_fwd<a, b, c, d>(Z, Tc, W, bias, Y, nodes, Lw, stream)
+    STC_X3_DISPATCH(FWD_CALL)
+#undef FWD_CALL
+    return STC_NOT_HANDLED;
+}
+
+int stc_node_bwd_x3(const float* const* Z, int Ks, const float* Tc, int Kc, const float* W, const float* dY,
+                    float* const* dZ, float* partial, int* n_partials, int want_db,
+                    long long nodes, int C, int L, int Lw, int Ho, hipStream_t stream) {
+    if (!x3_shape(Ks, Kc, C, L, Ho, nodes)) return STC_NOT_HANDLED;
+    if (!all_aligned16(Z, Ks) || !stc::aligned16(dY)) return STC_NOT_HANDLED;
+    for (int n = 0; n < Ks; ++n)
+        if (!stc::aligned16(dZ[n])) return STC_NOT_HANDLED;
+#define BWD_CALL(a, b, c, d) launch_bwd<a, b, c, d>(Z, Tc, W, dY, dZ, partial, n_partials, want_db, nodes, Lw, stream)
+    STC_X3_DISPATCH(BWD_CALL)
+#undef BWD_CALL
+    return STC_NOT_HANDLED;
+}
+
+// ---- fused cell epilogues / prologue: hidden width 16
+#define STC_X3_EPI_CASE(NB2_, CALL)                                                                     \
+    if (C == 32 * NB2_) {                                                                               \
+        if (K == 1 && L == 20) return CALL(NB2_, 1, 20);                                                \
+        if (K == 1 && L == 32) return CALL(NB2_, 1, 32);                                                \
+        if (K == 2 && L == 20) return CALL(NB2_, 2, 20);                                                \
+        if (K == 2 && L == 32) return CALL(NB2_, 2, 32);                                                \
+    }
+#define STC_X3_EPI_CASE3(CALL)                                                                          \
+    if (C == 32) {                                                                                      \
+        if (K == 3 && L == 20) return CALL(1, 3, 20);                                                   \
+        if (K == 3 && L == 32) return CALL(1, 3, 32);                                                   \
+    }
+
+static bool x3_cell_shape(int K, int C, int L, long long nodes) {
+    return K >= 1 && K <= (C == 64 ? 2 : 3) && (C == 32 || C == 64) && (L == 20 || L == 32) && nodes > 0 && nodes < (1ll << 31) / C;
+}
+
+int stc_cell_gates_fwd_x3(const float* const* Z, int K, const float* Tc, const float* W, const float* bias,
+                          const float* H, float* U, float* R, float* CandIn,
+                          long long nodes, int C, int L, int Lw, int cin, hipStream_t stream) {
+    if (!x3_cell_shape(K, C, L, nodes) || !all_aligned16(Z, K)) return STC_NOT_HANDLED;
+    FwdEpi epi{};
+    epi.H = H; epi.U_out = U; epi.R_out = R; epi.CandIn = CandIn; epi.cin = cin;
+#define GATES_CALL(a, c, d) launch_fwd<a, 2, c, d, EPI_GATES>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi)
+    STC_X3_EPI_CASE(1, GATES_CALL) STC_X3_EPI_CASE(2, GATES_CALL) STC_X3_EPI_CASE3(GATES_CALL)
+#undef GATES_CALL
+    return STC_NOT_HANDLED;
+}
+
+int stc_cell_blend_fwd_x3(const float* const* Z, int K, const float* Tc, const float* W, const float* bias,
+                          const float* U, const float* H, float* Cand, float* Hnew,
+                          long long nodes, int C, int L, int Lw, hipStream_t stream) {
+    if (!x3_cell_shape(K, C, L, nodes) || !all_aligned16(Z, K)) return STC_NOT_HANDLED;
+    FwdEpi epi{};
+    epi.H = H; epi.U = U; epi.Cand = Cand; epi.Hnew = Hnew;
+#define BLEND_CALL(a, c, d) launch_fwd<a, 1, c, d, EPI_BLEND>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi)
+    STC_X3_EPI_CASE(1, BLEND_CALL) STC_X3_EPI_CASE(2, BLEND_CALL) STC_X3_EPI_CASE3(BLEND_CALL)
+#undef BLEND_CALL
+    return STC_NOT_HANDLED;
+}
+
+int stc_cell_gates_bwd_x3(const float* const* Z, int K, const float* Tc, const float* W,
+                          const float* dCandIn, const float* dU, const float* H, const float* U, const float* R, const float* dH_in,
+                          float* const* dZ, float* dXt, float* dH, float* partial, int* n_partials, int want_db,
+                          long long nodes, int C, int L, int Lw, int cin, hipStream_t stream) {
+    if (!x3_cell_shape(K, C, L, nodes) || !all_aligned16(Z, K)) return STC_NOT_HANDLED;
+    for (int n = 0; n < K; ++n)
+        if (!stc::aligned16(dZ[n])) return STC_NOT_HANDLED;
+    if (!(stc::aligned16(dCandIn) && stc::aligned16(dU) && stc::aligned16(H) && stc::aligned16(U) && stc::aligned16(R) &&
+          stc::aligned16(dH) && (!dH_in || stc::aligned16(dH_in))))
+        return STC_NOT_HANDLED;
+    BwdPro pro{};
+    pro.dCandIn = dCandIn; pro.dU = dU; pro.H = H; pro.U = U; pro.R = R; pro.dH_in = dH_in; pro.dXt = dXt; pro.dH = dH; pro.cin = cin;
+#define GBWD_CALL(a, c, d) launch_bwd<a, 2, c, d, PRO_GATES>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro)
+    STC_X3_EPI_CASE(1, GBWD_CALL) STC_X3_EPI_CASE(2, GBWD_CALL) STC_X3_EPI_CASE3(GBWD_CALL)
+#undef GBWD_CALL
+    return STC_NOT_HANDLED;
+}

@@ -213,6 +213,10 @@ NODE_SHAPES = [
     (13, 64, 20, 16, 2, 2),
     (13, 32, 32, 32, 3, 3),      # config 4 order
     (13, 32, 32, 16, 1, 1),
+    (13, 32, 20, 32, 1, 1),      # split-operand path corner shapes: one slab, odd (c, o) block counts, C = 64
+    (21, 32, 20, 16, 3, 3),
+    (7, 64, 32, 32, 1, 1),
+    (9, 64, 32, 16, 2, 2),
     (4500, 32, 32, 32, 2, 2),    # more nodes than resident waves: grid-stride + cross-workgroup reduction
     (4500, 32, 20, 16, 2, 2),
 ]
@@ -229,13 +233,26 @@ def _node_inputs(nodes, C, L, Ho, Ks, Kc, seed):
     return Zs, Tc, W, b, dY
 
 
-@pytest.fixture(params=['mfma-or-generic', 'generic-only'])
+@pytest.fixture(params=['default', 'fp32-mfma', 'generic-only'])
 def node_path(request, monkeypatch):
-    """Run every node-kernel case twice: default dispatch (MFMA where the shape allows) and generic VALU only."""
+    """Run every node-kernel case three times: default dispatch (split-operand bf16 MFMA where the shape allows, then
+    fp32 MFMA, then generic), fp32 MFMA or generic only, generic VALU only."""
+    monkeypatch.delenv('STC_DISABLE_MFMA', raising=False)
+    monkeypatch.delenv('STC_DISABLE_X3', raising=False)
     if request.param == 'generic-only':
         monkeypatch.setenv('STC_DISABLE_MFMA', '1')
-    else:
-        monkeypatch.delenv('STC_DISABLE_MFMA', raising=False)
+    elif request.param == 'fp32-mfma':
+        monkeypatch.setenv('STC_DISABLE_X3', '1')
+    return request.param
+
+
+@pytest.fixture(params=['default', 'fp32-mfma'])
+def fused_path(request, monkeypatch):
+    """The fused cell kernels exist in both matrix-core flavours."""
+    monkeypatch.delenv('STC_DISABLE_MFMA', raising=False)
+    monkeypatch.delenv('STC_DISABLE_X3', raising=False)
+    if request.param == 'fp32-mfma':
+        monkeypatch.setenv('STC_DISABLE_X3', '1')
     return request.param
 
 
@@ -317,7 +334,7 @@ def test_bdg_node_padded_feature_rows(hip, nodes, C, L, Lw, Ho, K, node_path):
 
 @pytest.mark.parametrize('nodes,C,cin,K', [(50, 32, 16, 2), (50, 32, 1, 2), (21, 16, 16, 3), (13, 64, 1, 2), (4500, 32, 16, 2),
                                             (4100, 32, 1, 2), (9, 32, 16, 1)])
-def test_fused_cell_epilogues(hip, nodes, C, cin, K):
+def test_fused_cell_epilogues(hip, nodes, C, cin, K, fused_path):
     """Gate math fused into the node kernel's epilogue (hidden 16) vs node kernel + gate kernels of the CPU twin."""
     h = 16
     Lw = cin + h
@@ -352,7 +369,7 @@ def test_fused_cell_epilogues(hip, nodes, C, cin, K):
 
 
 @pytest.mark.parametrize('nodes,C,cin,K', [(50, 32, 16, 2), (50, 32, 1, 2), (21, 16, 16, 3), (13, 64, 1, 2), (4500, 32, 16, 2), (9, 32, 13, 1)])
-def test_fused_gates_backward_prologue(hip, nodes, C, cin, K):
+def test_fused_gates_backward_prologue(hip, nodes, C, cin, K, fused_path):
     """Gate backward as the prologue of the node backward (dG never stored) vs gate kernel + node backward of the twin."""
     h = 16
     Lw = cin + h
