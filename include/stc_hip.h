@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define STC_ABI_VERSION 8
+#define STC_ABI_VERSION 9
 #define STC_MAX_K 4          /* highest Chebyshev order (Ks, Kc) the node kernels accept */
 
 #define STC_OK 0
@@ -177,6 +177,24 @@ int stc_cell_blend_fwd_f32(const float* const* Z, int32_t Ks, const float* Tc, i
                            const float* W, const float* bias, const float* U, const float* H,
                            float* Cand, float* Hnew,
                            int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t h, void* stream);
+
+/* ---- the same two cell convolutions with the graph aggregation fused in (Ks = Kc = 2) ------------------------------
+ * Replaces STC_GNN.py:37 (the 1-mode product Z1 = Gs^T x Z0, one SpMM launch) + :38-45 + :71-78 in ONE launch per
+ * convolution: each wave gathers the neighbour rows of Z0 for its node from the CSR rows of S = Gs^T (rowptr / colidx /
+ * val over the n nodes of one sample; nodes = batch * n, row (b, i) = b*n + i), accumulates them in CSR order exactly
+ * like stc_csr_spmm_f32, WRITES Z1 (nodes, C, L) for the backward and feeds it to the matrix cores from registers.
+ * Saves the SpMM launch and one HBM pass over Z0 and Z1 per convolution.  Intended for sparse fixed graphs (a row of S
+ * costs one gather per entry); stc_cell_gather_supported() tells whether the shape is on this path
+ * (C in {32, 64}, L in {20, 32}, h = 16), else STC_EUNSUPPORTED.  Other arguments as the non-gather entry points. */
+int stc_cell_gather_supported(int32_t Ks, int32_t Kc, int32_t C, int32_t L, int32_t h);
+int stc_cell_gates_fwd_gather_f32(const int32_t* rowptr, const int32_t* colidx, const float* val, int64_t n,
+                                  const float* Z0, float* Z1, const float* Tc, const float* W, const float* bias,
+                                  const float* H, float* U, float* Rg, float* CandIn,
+                                  int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t h, int32_t cin, void* stream);
+int stc_cell_blend_fwd_gather_f32(const int32_t* rowptr, const int32_t* colidx, const float* val, int64_t n,
+                                  const float* Z0, float* Z1, const float* Tc, const float* W, const float* bias,
+                                  const float* U, const float* H, float* Cand, float* Hnew,
+                                  int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t h, void* stream);
 
 /* ---- output head (STC_GNN.py:182-183, 206) -----------------------------------
  * The reference applies Linear(h, h/2) then Linear(h/2, 1) with NO nonlinearity in between, then a sigmoid:

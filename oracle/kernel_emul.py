@@ -162,6 +162,22 @@ class EmulatedKernels:
         self.bdg_node_fwd(Zs, Tc, W, bias, Cpre)
         self.gru_blend_fwd(Cpre, U, H, Cand, Hnew)
 
+    # ---- stc_cell_*_fwd_gather_f32: the same with Z1 = S.Z0 produced inside (include/stc_hip.h)
+    def cell_gather_supported(self, Ks, Kc, Cc, L, h) -> bool:
+        return Ks == 2 and Kc == 2
+
+    def _gather(self, rowptr, colidx, val, n, Z0, Z1):
+        R, Cc, L = Z0.shape
+        self.csr_spmm(rowptr, colidx, val, n, n, Z0.view(R // n, n, Cc * L), None, Z1.view(R // n, n, Cc * L), 1.0, 0.0)
+
+    def cell_gates_fwd_gather(self, rowptr, colidx, val, n, Z0, Z1, Tc, W, bias, H, U, Rg, CandIn):
+        self._gather(rowptr, colidx, val, n, Z0, Z1)
+        self.cell_gates_fwd([Z0, Z1], Tc, W, bias, H, U, Rg, CandIn)
+
+    def cell_blend_fwd_gather(self, rowptr, colidx, val, n, Z0, Z1, Tc, W, bias, U, H, Cand, Hnew):
+        self._gather(rowptr, colidx, val, n, Z0, Z1)
+        self.cell_blend_fwd([Z0, Z1], Tc, W, bias, U, H, Cand, Hnew)
+
     # ---- stc_gru_gates_fwd/bwd_f32: split + sigmoids + reset*H + second concat (STC_GNN.py:71-75)
     def gru_gates_fwd(self, G, Xt, H, U, Rg, CandIn):
         h = H.shape[-1]

@@ -462,6 +462,51 @@ extern "C" int stc_cell_blend_fwd_f32(const float* const* Z, int32_t Ks, const f
     return rc == STC_NOT_HANDLED ? stc::fail(STC_EUNSUPPORTED, "stc_cell_blend_fwd_f32: operands not usable by the fused path (alignment)") : rc;
 }
 
+extern "C" int stc_cell_gather_supported(int32_t Ks, int32_t Kc, int32_t C, int32_t L, int32_t h) {
+    return (x3_enabled() && Ks == Kc && stc_cell_gather_shape_ok(Ks, C, L, h)) ? 1 : 0;
+}
+
+namespace {
+int check_gather(const char* who, const int32_t* rowptr, const int32_t* colidx, const float* val, int64_t n,
+                 const float* Z0, const float* Z1, int64_t nodes) {
+    STC_REQUIRE(n >= 1 && n < (1ll << 31) && nodes % n == 0, STC_EINVAL, "%s: nodes=%lld is not a multiple of the graph size n=%lld", who, (long long)nodes, (long long)n);
+    STC_REQUIRE(rowptr && Z0 && Z1, STC_EINVAL, "%s: null rowptr / Z0 / Z1", who);
+    STC_REQUIRE(Z0 != Z1, STC_EINVAL, "%s: Z1 must not alias Z0", who);
+    (void)colidx; (void)val;      // may be null for a graph without edges (never read then)
+    return STC_OK;
+}
+}  // namespace
+
+extern "C" int stc_cell_gates_fwd_gather_f32(const int32_t* rowptr, const int32_t* colidx, const float* val, int64_t n,
+                                             const float* Z0, float* Z1, const float* Tc, const float* W, const float* bias,
+                                             const float* H, float* U, float* Rg, float* CandIn,
+                                             int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t h, int32_t cin, void* stream) {
+    if (int rc = check_dims("stc_cell_gates_fwd_gather_f32", 2, 2, C, L, Lw, 2 * h, nodes)) return rc;
+    STC_REQUIRE(cin >= 0 && cin + h <= L, STC_EINVAL, "stc_cell_gates_fwd_gather_f32: cin=%d + h=%d exceed the row width L=%d", cin, h, L);
+    if (!stc_cell_gather_supported(2, 2, C, L, h)) return stc::fail(STC_EUNSUPPORTED, "stc_cell_gates_fwd_gather_f32: shape not on the fused-aggregation path");
+    if (nodes == 0) return STC_OK;
+    if (int rc = check_gather("stc_cell_gates_fwd_gather_f32", rowptr, colidx, val, n, Z0, Z1, nodes)) return rc;
+    STC_REQUIRE(Tc && W && H && U && Rg && CandIn, STC_EINVAL, "stc_cell_gates_fwd_gather_f32: null pointer");
+    STC_REQUIRE(Z0 != CandIn && Z1 != CandIn, STC_EINVAL, "stc_cell_gates_fwd_gather_f32: CandIn must not alias Z0 / Z1");
+    const int rc = stc_cell_gates_fwd_gather_x3(rowptr, colidx, val, n, Z0, Z1, Tc, W, bias, H, U, Rg, CandIn, nodes, C, L, Lw, cin,
+                                                static_cast<hipStream_t>(stream));
+    return rc == STC_NOT_HANDLED ? stc::fail(STC_EUNSUPPORTED, "stc_cell_gates_fwd_gather_f32: operands not usable by the fused path (alignment)") : rc;
+}
+
+extern "C" int stc_cell_blend_fwd_gather_f32(const int32_t* rowptr, const int32_t* colidx, const float* val, int64_t n,
+                                             const float* Z0, float* Z1, const float* Tc, const float* W, const float* bias,
+                                             const float* U, const float* H, float* Cand, float* Hnew,
+                                             int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t h, void* stream) {
+    if (int rc = check_dims("stc_cell_blend_fwd_gather_f32", 2, 2, C, L, Lw, h, nodes)) return rc;
+    if (!stc_cell_gather_supported(2, 2, C, L, h)) return stc::fail(STC_EUNSUPPORTED, "stc_cell_blend_fwd_gather_f32: shape not on the fused-aggregation path");
+    if (nodes == 0) return STC_OK;
+    if (int rc = check_gather("stc_cell_blend_fwd_gather_f32", rowptr, colidx, val, n, Z0, Z1, nodes)) return rc;
+    STC_REQUIRE(Tc && W && U && H && Cand && Hnew, STC_EINVAL, "stc_cell_blend_fwd_gather_f32: null pointer");
+    const int rc = stc_cell_blend_fwd_gather_x3(rowptr, colidx, val, n, Z0, Z1, Tc, W, bias, U, H, Cand, Hnew, nodes, C, L, Lw,
+                                                static_cast<hipStream_t>(stream));
+    return rc == STC_NOT_HANDLED ? stc::fail(STC_EUNSUPPORTED, "stc_cell_blend_fwd_gather_f32: operands not usable by the fused path (alignment)") : rc;
+}
+
 extern "C" size_t stc_bdg_node_bwd_workspace_bytes(int32_t Ks, int32_t Kc, int32_t C, int32_t L, int32_t Ho,
                                                    int32_t /*want_dTc*/) {
     if (Ks < 1 || Kc < 1 || C < 1 || L < 1 || Ho < 1) return 0;

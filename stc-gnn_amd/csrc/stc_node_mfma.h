@@ -47,3 +47,15 @@ int stc_cell_gates_bwd_x3(const float* const* Z, int K, const float* Tc, const f
                           const float* dCandIn, const float* dU, const float* H, const float* U, const float* R, const float* dH_in,
                           float* const* dZ, float* dXt, float* dH, float* partial, int* n_partials, int want_db,
                           long long nodes, int C, int L, int Lw, int cin, hipStream_t stream);
+
+// Fused aggregation variants (Ks = Kc = 2): the kernel gathers Z1 = S.Z0 itself from the CSR rows of S (n nodes per
+// sample, nodes = batch * n) and writes it for the backward.
+int stc_cell_gather_shape_ok(int K, int C, int L, int h);
+int stc_cell_gates_fwd_gather_x3(const int* rowptr, const int* colidx, const float* val, long long n,
+                                 const float* Z0, float* Z1, const float* Tc, const float* W, const float* bias,
+                                 const float* H, float* U, float* R, float* CandIn,
+                                 long long nodes, int C, int L, int Lw, int cin, hipStream_t stream);
+int stc_cell_blend_fwd_gather_x3(const int* rowptr, const int* colidx, const float* val, long long n,
+                                 const float* Z0, float* Z1, const float* Tc, const float* W, const float* bias,
+                                 const float* U, const float* H, float* Cand, float* Hnew,
+                                 long long nodes, int C, int L, int Lw, hipStream_t stream);

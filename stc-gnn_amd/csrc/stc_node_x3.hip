@@ -92,6 +92,15 @@ __host__ __device__ constexpr int pair_row(int g, int e) { return 16 * (e >> 2) 
 
 #define kZero4 (f32x4{0.f, 0.f, 0.f, 0.f})
 
+// Gate nonlinearities of the fused epilogues on the hardware exp2 / rcp (1 ulp each): absolute error < 2e-7, against the
+// ~30 VALU instructions each of the IEEE division and libm expf / tanhf -- these kernels are VALU-issue bound.
+__device__ __forceinline__ float fast_sigmoid(float v) {
+    return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
+}
+__device__ __forceinline__ float fast_tanh(float v) {       // 1 - 2 / (e^{2v} + 1); saturates cleanly at +-1
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.8853900817779268f * v));
+}
+
 // columns 8g .. 8g+7 of a feature row of L floats (L a multiple of 4, <= 32); columns >= L read as zero
 template <int L>
 struct Row8 {
@@ -102,13 +111,34 @@ struct Row8 {
         if (L == 32 || 8 * g + 4 < L) b = *reinterpret_cast<const f32x4*>(row + 8 * g + 4);
     }
     __device__ __forceinline__ float at(int e) const { return e < 4 ? a[e & 3] : b[e & 3]; }
+    __device__ __forceinline__ void fma(float v, const Row8& o) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { a[i] = fmaf(v, o.a[i], a[i]); b[i] = fmaf(v, o.b[i], b[i]); }
+    }
+    __device__ __forceinline__ void store(float* __restrict__ row, int g) const {
+        if (L == 32 || 8 * g < L) *reinterpret_cast<f32x4*>(row + 8 * g) = a;
+        if (L == 32 || 8 * g + 4 < L) *reinterpret_cast<f32x4*>(row + 8 * g + 4) = b;
+    }
+};
+
+// Fused aggregation (K = 2 only): instead of reading a precomputed slab Z_1 = S.Z_0 (one SpMM launch and one more pass
+// over Z_0), the wave gathers the node's neighbour rows of Z_0 itself -- CSR row of S, wave-uniform scalar loads of
+// (column, value), row loads that mostly hit L2 because the node's own row and its neighbours' are being read by the
+// resident waves anyway -- accumulates them in the SpMM kernel's order, writes Z_1 for the backward, and feeds it to the
+// MFMAs from registers.
+struct GatherArgs {
+    const int* rowptr; const int* colidx; const float* val;   // S in CSR over the n nodes of one sample
+    int n;                                                    // nodes per sample: row (b, i) of the batch is b*n + i
+    float* Z1;                                                // out: (nodes, C, L)
 };
 
 // --------------------------------------------------------------------------------------- forward
-template <int NB2, int HB, int K, int L, int EPI>
+template <int NB2, int HB, int K, int L, int EPI, int GATHER>
 __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_kernel(
     ZPtrs Z, const float* __restrict__ Tc, const float* __restrict__ W, const float* __restrict__ bias,
-    float* __restrict__ Y, int nodes, int Lw, FwdEpi epi) {
+    float* __restrict__ Y, int nodes, int Lw, FwdEpi epi, GatherArgs ga) {
+    static_assert(!GATHER || K == 2, "the fused aggregation produces the first-order slab only");
+    constexpr int KL = GATHER ? 1 : K;                  // slabs read from HBM
     constexpr int NRB = 2 * NB2, C = 32 * NB2, Ho = 16 * HB, NCB = K * HB;
     constexpr int HID = 16;
     constexpr int nWx = K * NCB, nTx = (K - 1) * NRB * NB2;
@@ -146,10 +176,10 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
     for (int hb = 0; hb < HB; ++hb) bv[hb] = bias ? bias[16 * hb + x] : 0.f;
 
     int node = blockIdx.x * MF_WAVES + wave;
-    Row8<L> cur[K][NRB], nxt[K][NRB];
-    auto load_rows = [&](Row8<L> (&z)[K][NRB], int nd) {
+    Row8<L> cur[KL][NRB], nxt[KL][NRB];
+    auto load_rows = [&](Row8<L> (&z)[KL][NRB], int nd) {
 #pragma unroll
-        for (int n = 0; n < K; ++n)
+        for (int n = 0; n < KL; ++n)
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) z[n][rb].load(Z.p[n] + ((size_t)nd * C + 16 * rb + x) * L, g);
     };
@@ -158,16 +188,56 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
         const int next_node = node + nw;
         if (next_node < nodes) load_rows(nxt, next_node);        // software prefetch: lands while this node computes
         // epilogue operands in accumulator layout (row 16rb + 4g + r, column x): needed only after the MFMAs
-        float hv[NRB][4], uv[NRB][4];
+        float hv[NRB][4], uv[NRB][4], side[NRB][4];
+        // EPI_GATES: lane x < L - 16 also writes one column of CandIn outside the R*H block, in the same row layout:
+        // column x of Xt (re-read from slab 0, an L2 hit) while x < cin, else the zero of pad column x + 16
+        const bool has_side = EPI == EPI_GATES && x < L - HID;
         if (EPI != EPI_NONE) {
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const size_t e = ((size_t)node * C + 16 * rb + 4 * g + r) * HID + x;
+                    const size_t row = (size_t)node * C + 16 * rb + 4 * g + r, e = row * HID + x;
                     hv[rb][r] = epi.H[e];
                     if (EPI == EPI_BLEND) uv[rb][r] = epi.U[e];
+                    if (EPI == EPI_GATES) side[rb][r] = (has_side && x < epi.cin) ? Z.p[0][row * L + x] : 0.f;
                 }
+        }
+        Row8<L> z1[NRB];
+        if (GATHER) {
+            const int b = node / ga.n, i = node - b * ga.n;
+            const float* Zb = Z.p[0] + ((size_t)b * ga.n * C + x) * L;
+            const int e0 = ga.rowptr[i], e1 = ga.rowptr[i + 1];
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) { z1[rb].a = kZero4; z1[rb].b = kZero4; }
+            int e = e0;
+            for (; e + 3 <= e1; e += 3) {                     // three neighbours' rows in flight
+                Row8<L> t[3][NRB];
+                float v[3];
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const int c = ga.colidx[e + u];
+                    v[u] = ga.val[e + u];
+#pragma unroll
+                    for (int rb = 0; rb < NRB; ++rb) t[u][rb].load(Zb + ((size_t)c * C + 16 * rb) * L, g);
+                }
+#pragma unroll
+                for (int u = 0; u < 3; ++u)
+#pragma unroll
+                    for (int rb = 0; rb < NRB; ++rb) z1[rb].fma(v[u], t[u][rb]);
+            }
+            for (; e < e1; ++e) {
+                const int c = ga.colidx[e];
+                const float v = ga.val[e];
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) {
+                    Row8<L> t;
+                    t.load(Zb + ((size_t)c * C + 16 * rb) * L, g);
+                    z1[rb].fma(v, t);
+                }
+            }
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) z1[rb].store(ga.Z1 + ((size_t)node * C + 16 * rb + x) * L, g);
         }
         __builtin_amdgcn_sched_barrier(0);
         const int lo = opaque(lane);
@@ -183,7 +253,10 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
         for (int n = 0; n < K; ++n) {
             X3 za[NRB];
 #pragma unroll
-            for (int rb = 0; rb < NRB; ++rb) za[rb] = split8(cur[n][rb].a, cur[n][rb].b);
+            for (int rb = 0; rb < NRB; ++rb) {
+                const Row8<L>& zr = (GATHER && n == 1) ? z1[rb] : cur[n < KL ? n : 0][rb];
+                za[rb] = split8(zr.a, zr.b);
+            }
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) {
                 const X3 w = get_frag(Wx, n * NCB + cb, lo);
@@ -221,24 +294,19 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const size_t row = (size_t)node * C + 16 * rb + 4 * g + r;
-                    const float u = sigmoid_f(acc[rb][0][r] + bv[0]);
-                    const float gate = sigmoid_f(acc[rb][HB - 1][r] + bv[HB - 1]);
+                    const float u = fast_sigmoid(acc[rb][0][r] + bv[0]);
+                    const float gate = fast_sigmoid(acc[rb][HB - 1][r] + bv[HB - 1]);
                     epi.U_out[row * HID + x] = u;
                     epi.R_out[row * HID + x] = gate;
                     epi.CandIn[row * L + epi.cin + x] = gate * hv[rb][r];
                 }
-            // the Xt columns and the zero padding of CandIn come from this lane's own row of slab 0
+            if (has_side) {
+                const int scol = x < epi.cin ? x : x + HID;
 #pragma unroll
-            for (int rb = 0; rb < NRB; ++rb) {
-                float* crow = epi.CandIn + ((size_t)node * C + 16 * rb + x) * L;
+                for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int col = 8 * g + e;
-                    if (col < L) {
-                        if (col < epi.cin) crow[col] = cur[0][rb].at(e);
-                        else if (col >= epi.cin + HID) crow[col] = 0.f;
-                    }
-                }
+                    for (int r = 0; r < 4; ++r)
+                        epi.CandIn[((size_t)node * C + 16 * rb + 4 * g + r) * L + scol] = side[rb][r];
             }
         } else {
 #pragma unroll
@@ -246,14 +314,14 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const size_t e = ((size_t)node * C + 16 * rb + 4 * g + r) * HID + x;
-                    const float c = tanhf(acc[rb][0][r] + bv[0]);
+                    const float c = fast_tanh(acc[rb][0][r] + bv[0]);
                     const float u = uv[rb][r];
                     epi.Cand[e] = c;
                     epi.Hnew[e] = (1.f - u) * hv[rb][r] + u * c;
                 }
         }
 #pragma unroll
-        for (int n = 0; n < K; ++n)
+        for (int n = 0; n < KL; ++n)
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) cur[n][rb] = nxt[n][rb];
         node = next_node;
@@ -292,14 +360,19 @@ struct NodeIn {      // what one node contributes from HBM: its dY fragments and
     }
 };
 
+// C = 32 with K <= 2 fits two waves per SIMD (<= 256 registers): the partner wave hides load and LDS latency, so no
+// software prefetch; the larger shapes run one wave per SIMD and prefetch the next node's operands instead.
+template <int NB2, int K>
+struct BwdSched { static constexpr int waves = (NB2 == 1 && K <= 2) ? 2 : 1; };
+
 template <int NB2, int HB, int K, int L, int PRO>
-__global__ __launch_bounds__(MF_THREADS, 1) void node_bwd_x3_kernel(
+__global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bwd_x3_kernel(
     ZPtrs Z, const float* __restrict__ Tc, const float* __restrict__ W, const float* __restrict__ dY,
     DZPtrs dZ, float* __restrict__ partial, int nodes, int want_db, int Lw, BwdPro pro) {
     constexpr int NRB = 2 * NB2, C = 32 * NB2, Ho = 16 * HB, LB = (L + 15) / 16;
     constexpr int NBK = K * HB, S = (NBK + 1) / 2;             // (c, o) blocks of 16 and 32-wide steps over them
     constexpr int nTB = (K - 1) * NRB * NB2, nWA = K * LB * S;
-    constexpr bool PF = PRO == PRO_NONE;                        // prefetch the next node's operands
+    constexpr bool PF = PRO == PRO_NONE && BwdSched<NB2, K>::waves == 1;      // prefetch the next node's operands
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32x4* TB = reinterpret_cast<u32x4*>(smem_raw);     // [K-1][NRB rb][NB2 p]   T_c[16rb + x][32p + pair_row]
     u32x4* WA = TB + nTB * 3 * 64;                       // [K n][LB][S]           W[(n, c, 16lb + x)][16hb + 4g + (e&3)], block 2s + (e>>2)
@@ -349,6 +422,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void node_bwd_x3_kernel(
         const int next_node = node + nw;
         const size_t r0 = (size_t)node * C;
         if constexpr (PRO == PRO_GATES) { load_gates_grad<NRB, HB, L>(in.g, pro, node, x, g); in.load_z(Z, node, x, g); }
+        else if (!PF) { in.g.load(dY, node, x, g); in.load_z(Z, node, x, g); }
         if (PF && next_node < nodes) { nx.g.load(dY, next_node, x, g); nx.load_z(Z, next_node, x, g); }
         if (PF) __builtin_amdgcn_sched_barrier(0);
         const int lo = opaque(lane);
@@ -464,20 +538,20 @@ __global__ __launch_bounds__(MF_THREADS, 1) void node_bwd_x3_kernel(
 }
 
 // --------------------------------------------------------------------------------------- host side
-template <int NB2, int HB, int K, int L, int EPI = EPI_NONE>
+template <int NB2, int HB, int K, int L, int EPI = EPI_NONE, int GATHER = 0>
 int launch_fwd(const float* const* Z, const float* Tc, const float* W, const float* bias, float* Y,
-               long long nodes, int Lw, hipStream_t stream, FwdEpi epi = FwdEpi{}) {
+               long long nodes, int Lw, hipStream_t stream, FwdEpi epi = FwdEpi{}, GatherArgs ga = GatherArgs{}) {
     constexpr int NRB = 2 * NB2, NCB = K * HB;
     const size_t lds = (size_t)(K * NCB + (K - 1) * NRB * NB2) * 3 * 64 * 16;
     if (lds > stc::kMaxLdsBytes) return STC_NOT_HANDLED;
-    auto kern = node_fwd_x3_kernel<NB2, HB, K, L, EPI>;
+    auto kern = node_fwd_x3_kernel<NB2, HB, K, L, EPI, GATHER>;
     if (int rc = stc::hip_status(stc::allow_lds(kern, lds), "hipFuncSetAttribute(node fwd x3)")) return rc;
     static const int resident = stc::resident_blocks(kern, MF_THREADS, lds, 2);   // persistent grid = what fits at once
     ZPtrs zp{};
-    for (int n = 0; n < K; ++n) zp.p[n] = Z[n];
+    for (int n = 0; n < (GATHER ? 1 : K); ++n) zp.p[n] = Z[n];
     const long long want = (nodes + MF_WAVES - 1) / MF_WAVES;
     const int grid = (int)(want < resident ? want : resident);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(MF_THREADS), lds, stream, zp, Tc, W, bias, Y, (int)nodes, Lw, epi);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(MF_THREADS), lds, stream, zp, Tc, W, bias, Y, (int)nodes, Lw, epi, ga);
     STC_LAUNCH_CHECK("node_fwd_x3 launch");
     return STC_OK;
 }
@@ -492,7 +566,7 @@ int launch_bwd(const float* const* Z, const float* Tc, const float* W, const flo
     if (lds > stc::kMaxLdsBytes) return STC_NOT_HANDLED;
     auto kern = node_bwd_x3_kernel<NB2, HB, K, L, PRO>;
     if (int rc = stc::hip_status(stc::allow_lds(kern, lds), "hipFuncSetAttribute(node bwd x3)")) return rc;
-    static const int resident = stc::resident_blocks(kern, MF_THREADS, lds, 1);
+    static const int resident = stc::resident_blocks(kern, MF_THREADS, lds, BwdSched<NB2, K>::waves);
     ZPtrs zp{};
     DZPtrs dzp{};
     for (int n = 0; n < K; ++n) { zp.p[n] = Z[n]; dzp.p[n] = dZ[n]; }
@@ -609,5 +683,46 @@ int stc_cell_gates_bwd_x3(const float* const* Z, int K, const float* Tc, const f
 #define GBWD_CALL(a, c, d) launch_bwd<a, 2, c, d, PRO_GATES>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro)
     STC_X3_EPI_CASE(1, GBWD_CALL) STC_X3_EPI_CASE(2, GBWD_CALL) STC_X3_EPI_CASE3(GBWD_CALL)
 #undef GBWD_CALL
+    return STC_NOT_HANDLED;
+}
+
+// ---- fused aggregation + cell convolution (K = 2): Z1 = S.Z0 is produced by the kernel, not read
+#define STC_X3_GATHER_CASE(CALL)                                                                        \
+    if (C == 32 && L == 20) return CALL(1, 20);                                                         \
+    if (C == 32 && L == 32) return CALL(1, 32);                                                         \
+    if (C == 64 && L == 20) return CALL(2, 20);                                                         \
+    if (C == 64 && L == 32) return CALL(2, 32);
+
+int stc_cell_gather_shape_ok(int K, int C, int L, int h) {
+    return K == 2 && (C == 32 || C == 64) && (L == 20 || L == 32) && h == 16;
+}
+
+int stc_cell_gates_fwd_gather_x3(const int* rowptr, const int* colidx, const float* val, long long n,
+                                 const float* Z0, float* Z1, const float* Tc, const float* W, const float* bias,
+                                 const float* H, float* U, float* R, float* CandIn,
+                                 long long nodes, int C, int L, int Lw, int cin, hipStream_t stream) {
+    if (!x3_cell_shape(2, C, L, nodes) || !stc::aligned16(Z0) || !stc::aligned16(Z1)) return STC_NOT_HANDLED;
+    FwdEpi epi{};
+    epi.H = H; epi.U_out = U; epi.R_out = R; epi.CandIn = CandIn; epi.cin = cin;
+    const GatherArgs ga{rowptr, colidx, val, (int)n, Z1};
+    const float* Z[1] = {Z0};
+#define GG_CALL(a, d) launch_fwd<a, 2, 2, d, EPI_GATES, 1>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi, ga)
+    STC_X3_GATHER_CASE(GG_CALL)
+#undef GG_CALL
+    return STC_NOT_HANDLED;
+}
+
+int stc_cell_blend_fwd_gather_x3(const int* rowptr, const int* colidx, const float* val, long long n,
+                                 const float* Z0, float* Z1, const float* Tc, const float* W, const float* bias,
+                                 const float* U, const float* H, float* Cand, float* Hnew,
+                                 long long nodes, int C, int L, int Lw, hipStream_t stream) {
+    if (!x3_cell_shape(2, C, L, nodes) || !stc::aligned16(Z0) || !stc::aligned16(Z1)) return STC_NOT_HANDLED;
+    FwdEpi epi{};
+    epi.H = H; epi.U = U; epi.Cand = Cand; epi.Hnew = Hnew;
+    const GatherArgs ga{rowptr, colidx, val, (int)n, Z1};
+    const float* Z[1] = {Z0};
+#define BG_CALL(a, d) launch_fwd<a, 1, 2, d, EPI_BLEND, 1>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi, ga)
+    STC_X3_GATHER_CASE(BG_CALL)
+#undef BG_CALL
     return STC_NOT_HANDLED;
 }

@@ -19,7 +19,7 @@ import torch
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG_ROOT, 'libstc_hip.so')
-ABI_VERSION = 8
+ABI_VERSION = 9
 MAX_K = 4
 
 #: every symbol ``include/stc_hip.h`` declares (the CPU test-suite checks the .so exports them all)
@@ -29,6 +29,7 @@ EXPORTS = (
     'stc_cheby_dense_fwd_f32', 'stc_cheby_dense_bwd_f32',
     'stc_bdg_node_fwd_f32', 'stc_bdg_node_bwd_workspace_bytes', 'stc_bdg_node_bwd_f32',
     'stc_cell_fused_supported', 'stc_cell_gates_fwd_f32', 'stc_cell_gates_bwd_f32', 'stc_cell_blend_fwd_f32',
+    'stc_cell_gather_supported', 'stc_cell_gates_fwd_gather_f32', 'stc_cell_blend_fwd_gather_f32',
     'stc_gru_gates_fwd_f32', 'stc_gru_gates_bwd_f32', 'stc_gru_blend_fwd_f32', 'stc_gru_blend_bwd_f32',
     'stc_head_fwd_f32', 'stc_head_bwd_workspace_bytes', 'stc_head_bwd_f32',
     'stc_axpy_f32', 'stc_concat2_f32', 'stc_split2_f32',
@@ -65,6 +66,8 @@ def _declare(lib):
         'stc_cell_gates_bwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _p, C.POINTER(_p), _p, _p, _p, _p,
                                    _p, C.c_size_t, _i64, _i32, _i32, _i32, _i32, _i32, _p],
         'stc_cell_blend_fwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
+        'stc_cell_gates_fwd_gather_f32': [_p, _p, _p, _i64] + [_p] * 9 + [_i64, _i32, _i32, _i32, _i32, _i32, _p],
+        'stc_cell_blend_fwd_gather_f32': [_p, _p, _p, _i64] + [_p] * 9 + [_i64, _i32, _i32, _i32, _i32, _p],
         'stc_gru_gates_fwd_f32': [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p],
         'stc_gru_gates_bwd_f32': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p],
         'stc_gru_blend_fwd_f32': [_p, _p, _p, _p, _p, _i64, _p],
@@ -81,6 +84,8 @@ def _declare(lib):
         fn.argtypes = argtypes
     lib.stc_cell_fused_supported.restype = C.c_int
     lib.stc_cell_fused_supported.argtypes = [_i32, _i32, _i32, _i32, _i32]
+    lib.stc_cell_gather_supported.restype = C.c_int
+    lib.stc_cell_gather_supported.argtypes = [_i32, _i32, _i32, _i32, _i32]
     lib.stc_head_bwd_workspace_bytes.restype = C.c_size_t
     lib.stc_head_bwd_workspace_bytes.argtypes = [_i32]
     lib.stc_bdg_node_bwd_workspace_bytes.restype = C.c_size_t
@@ -411,6 +416,52 @@ class HipKernels:
         self._same_device(*Zs, Tc, W, bias, U, H, Cand, Hnew)
         self._launch('stc_cell_blend_fwd_f32', H, self._ptr_array(Zs), Ks, _ptr(Tc), Kc, _ptr(W), _ptr(bias), _ptr(U), _ptr(H),
                      _ptr(Cand), _ptr(Hnew), R, Cc, L, Lw, h)
+
+    # ---- the same with the aggregation Z1 = S.Z0 fused in (Ks = Kc = 2) -------------------------
+    def cell_gather_supported(self, Ks, Kc, Cc, L, h) -> bool:
+        return bool(self.lib.stc_cell_gather_supported(Ks, Kc, Cc, L, h))
+
+    def _gather_args(self, rowptr, colidx, val, n, Z0, Z1, Tc, W):
+        R, Cc, L = Z0.shape
+        self._f32('gather.Z0', Z0, (R, Cc, L))
+        self._f32('gather.Z1', Z1, (R, Cc, L))
+        if n < 1 or R % n:
+            raise StcError(f'gather: {R} node rows are not a multiple of the graph size {n}')
+        self._i32('gather.rowptr', rowptr, n + 1)
+        self._i32('gather.colidx', colidx)
+        self._f32('gather.val', val, (colidx.numel(),))
+        if Tc.dim() != 3 or Tc.shape[0] != 2:
+            raise StcError(f'gather: the fused aggregation needs Ks = Kc = 2, got Tc {tuple(Tc.shape)}')
+        return self._node_shapes([Z0, Z1], Tc, W)
+
+    def cell_gates_fwd_gather(self, rowptr, colidx, val, n, Z0, Z1, Tc, W, bias, H, U, Rg, CandIn):
+        """cell_gates_fwd with Z1 = S.Z0 gathered inside the kernel (and written to ``Z1``)."""
+        Ks, Kc, R, Cc, L, Lw, Ho = self._gather_args(rowptr, colidx, val, n, Z0, Z1, Tc, W)
+        h = H.shape[-1]
+        cin = Lw - h
+        if Ho != 2 * h or cin < 0:
+            raise StcError(f'cell_gates: W gives Ho={Ho}, Lw={Lw} for hidden {h}')
+        if bias is not None:
+            self._f32('cell.bias', bias, (Ho,))
+        for name, t in (('H', H), ('U', U), ('Rg', Rg)):
+            self._f32('cell.' + name, t, (R, Cc, h))
+        self._f32('cell.CandIn', CandIn, (R, Cc, L))
+        self._same_device(rowptr, colidx, val, Z0, Z1, Tc, W, bias, H, U, Rg, CandIn)
+        self._launch('stc_cell_gates_fwd_gather_f32', H, _ptr(rowptr), _ptr(colidx), _ptr(val), n, _ptr(Z0), _ptr(Z1), _ptr(Tc), _ptr(W),
+                     _ptr(bias), _ptr(H), _ptr(U), _ptr(Rg), _ptr(CandIn), R, Cc, L, Lw, h, cin)
+
+    def cell_blend_fwd_gather(self, rowptr, colidx, val, n, Z0, Z1, Tc, W, bias, U, H, Cand, Hnew):
+        Ks, Kc, R, Cc, L, Lw, Ho = self._gather_args(rowptr, colidx, val, n, Z0, Z1, Tc, W)
+        h = H.shape[-1]
+        if Ho != h:
+            raise StcError(f'cell_blend: W gives Ho={Ho} for hidden {h}')
+        if bias is not None:
+            self._f32('cell.bias', bias, (Ho,))
+        for name, t in (('U', U), ('H', H), ('Cand', Cand), ('Hnew', Hnew)):
+            self._f32('cell.' + name, t, (R, Cc, h))
+        self._same_device(rowptr, colidx, val, Z0, Z1, Tc, W, bias, U, H, Cand, Hnew)
+        self._launch('stc_cell_blend_fwd_gather_f32', H, _ptr(rowptr), _ptr(colidx), _ptr(val), n, _ptr(Z0), _ptr(Z1), _ptr(Tc), _ptr(W),
+                     _ptr(bias), _ptr(U), _ptr(H), _ptr(Cand), _ptr(Hnew), R, Cc, L, Lw, h)
 
     # ---- GRU gate math -------------------------------------------------------------------
     def gru_gates_fwd(self, G, Xt, H, U, Rg, CandIn):

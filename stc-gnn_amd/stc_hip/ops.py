@@ -34,6 +34,11 @@ from torch.autograd.function import once_differentiable
 from .graph import SpatialOperand
 
 _kernels = None
+# Fused aggregation in the cell forward (sparse graphs, Ks = 2; stc_cell_*_fwd_gather_f32).  Opt-in: measured SLOWER in the
+# full step on MI355X (gates 622 us vs 358 + 190 us for kernel + SpMM, 2 samples): one node per wave gathers 9 rows per node
+# through L2 where the row-blocked SpMM needs 4.5, and the node kernel becomes L2-bandwidth bound.
+_FUSE_GATHER = os.environ.get('STC_FUSE_GATHER') == '1'
+_GATHER_MAX_DEGREE = 32                                            # mean entries per row above which the SpMM kernel is kept
 _FUSE_BWD = os.environ.get('STC_FUSE_BWD') == '1'
 
 
@@ -323,9 +328,15 @@ class _StcCell(Function):
         U, Rg, CandIn = torch.empty_like(H), torch.empty_like(H), torch.empty_like(XH)
         Cand, Hnew = torch.empty_like(H), torch.empty_like(H)
         B, N, C, L = XH.shape
-        if k.cell_fused_supported(Ks, Tc.shape[0], C, L, h):
+        rows = lambda ts: [t.view(B * N, C, t.shape[-1]) for t in ts]
+        if _FUSE_GATHER and op.nnz <= _GATHER_MAX_DEGREE * N and k.cell_gather_supported(Ks, Tc.shape[0], C, L, h):
+            # sparse graph, Ks = 2: the aggregation Z1 = S.Z0 is gathered inside the two cell kernels too (no SpMM launch)
+            csr = (op.fwd_rowptr, op.fwd_colidx, fwd_val, N)
+            Zg, Zc = [XH, torch.empty_like(XH)], [CandIn, torch.empty_like(XH)]
+            k.cell_gates_fwd_gather(*csr, *rows(Zg), Tc, Wg, bg, *rows((H, U, Rg, CandIn)))
+            k.cell_blend_fwd_gather(*csr, *rows(Zc), Tc, Wc, bc, *rows((U, H, Cand, Hnew)))
+        elif k.cell_fused_supported(Ks, Tc.shape[0], C, L, h):
             # gate math in the node kernels' epilogues: the pre-activations never go to HBM
-            rows = lambda ts: [t.view(B * N, C, t.shape[-1]) for t in ts]
             Zg = _spatial_slabs(XH, fwd_val, op, Ks)
             k.cell_gates_fwd(rows(Zg), Tc, Wg, bg, *rows((H, U, Rg, CandIn)))
             Zc = _spatial_slabs(CandIn, fwd_val, op, Ks)

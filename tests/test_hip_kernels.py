@@ -368,6 +368,67 @@ def test_fused_cell_epilogues(hip, nodes, C, cin, K, fused_path):
     assert rel_err(Cand, Cand_w) < TOL and rel_err(Hn, Hn_w) < TOL
 
 
+@pytest.mark.parametrize('batch,grid,C,cin', [(2, (5, 5), 32, 16), (3, (4, 7), 32, 1), (1, (3, 3), 64, 1), (2, (40, 56), 32, 16), (1, (1, 1), 32, 16)])
+def test_fused_aggregation_cell_kernels(hip, batch, grid, C, cin):
+    """stc_cell_*_fwd_gather_f32: the kernel gathers Z1 = S.Z0 itself (and writes it) -- vs SpMM + fused cell kernel of the twin.
+    Includes a random sparse matrix with an empty row, besides the queen grids."""
+    from stc_hip import CsrGraph
+    h, K = 16, 2
+    Lw = cin + h
+    L = Lw + (-Lw) % 4
+    assert hip.cell_gather_supported(K, K, C, L, h)
+    graph = CsrGraph.queen_grid(*grid, normalize=True)
+    n = graph.n
+    hst = graph._host
+    rowptr, colidx, val = (torch.from_numpy(hst[k]) for k in ('fwd_rowptr', 'fwd_colidx', 'fwd_val'))
+    if n > 4:                                                      # knock a row out: rows without entries must give Z1 = 0
+        keep = torch.ones(colidx.numel(), dtype=torch.bool)
+        keep[rowptr[2]:rowptr[3]] = False
+        counts = torch.diff(rowptr).clone()
+        counts[2] = 0
+        rowptr = torch.cat([torch.zeros(1, dtype=torch.int32), torch.cumsum(counts, 0).to(torch.int32)])
+        colidx, val = colidx[keep].contiguous(), val[keep].contiguous()
+    nodes = batch * n
+    g = torch.Generator().manual_seed(nodes + C + cin)
+    Z0 = torch.randn(nodes, C, L, generator=g)
+    Z0[..., Lw:] = 0.0
+    Tc = torch.randn(K, C, C, generator=g) / C ** 0.5
+    Tc[0] = torch.eye(C)
+    H = torch.randn(nodes, C, h, generator=g)
+    Wg = torch.randn(K * K * Lw, 2 * h, generator=g) / (K * K * Lw) ** 0.5
+    bg = torch.randn(2 * h, generator=g)
+    Z1_w, U_w, R_w, Ci_w = torch.empty_like(Z0), torch.empty_like(H), torch.empty_like(H), torch.empty(nodes, C, L)
+    EM.cell_gates_fwd_gather(rowptr, colidx, val, n, Z0, Z1_w, Tc, Wg, bg, H, U_w, R_w, Ci_w)
+    nan = lambda t: torch.full(t.shape, float('nan')).cuda()
+    Z1, U, R, Ci = nan(Z0), nan(H), nan(H), nan(Ci_w)
+    csr = (cu(rowptr), cu(colidx), cu(val), n)
+    hip.cell_gates_fwd_gather(*csr, cu(Z0), Z1, cu(Tc), cu(Wg), cu(bg), cu(H), U, R, Ci)
+    assert rel_err(Z1, Z1_w) < TOL and rel_err(U, U_w) < TOL and rel_err(R, R_w) < TOL and rel_err(Ci, Ci_w) < TOL
+    if n > 4:
+        assert float(Z1.view(batch, n, C, L)[:, 2].abs().max()) == 0.0
+    assert torch.equal(Ci[..., :cin].cpu(), Z0[..., :cin])
+
+    Wc = torch.randn(K * K * Lw, h, generator=g) / (K * K * Lw) ** 0.5
+    bc = torch.randn(h, generator=g)
+    Cand_w, Hn_w = torch.empty_like(H), torch.empty_like(H)
+    EM.cell_blend_fwd_gather(rowptr, colidx, val, n, Ci_w, Z1_w, Tc, Wc, bc, U_w, H, Cand_w, Hn_w)
+    Z1c, Cand, Hn = nan(Z0), nan(H), nan(H)
+    hip.cell_blend_fwd_gather(*csr, cu(Ci_w), Z1c, cu(Tc), cu(Wc), cu(bc), cu(U_w), cu(H), Cand, Hn)
+    assert rel_err(Z1c, Z1_w) < TOL and rel_err(Cand, Cand_w) < TOL and rel_err(Hn, Hn_w) < TOL
+
+
+def test_fused_aggregation_is_refused_off_its_shapes(hip):
+    from stc_hip import StcError
+    assert not hip.cell_gather_supported(3, 3, 32, 32, 16) and not hip.cell_gather_supported(2, 2, 16, 32, 16)
+    Z0 = torch.zeros(4, 16, 32).cuda()
+    rp = torch.zeros(5, dtype=torch.int32).cuda()
+    ci, va = torch.zeros(0, dtype=torch.int32).cuda(), torch.zeros(0).cuda()
+    H = torch.zeros(4, 16, 16).cuda()
+    with pytest.raises(StcError):
+        hip.cell_gates_fwd_gather(rp, ci, va, 4, Z0, torch.empty_like(Z0), torch.zeros(2, 16, 16).cuda(), torch.zeros(2 * 2 * 32, 32).cuda(), None,
+                                  H, torch.empty_like(H), torch.empty_like(H), torch.empty_like(Z0))
+
+
 @pytest.mark.parametrize('nodes,C,cin,K', [(50, 32, 16, 2), (50, 32, 1, 2), (21, 16, 16, 3), (13, 64, 1, 2), (4500, 32, 16, 2), (9, 32, 13, 1)])
 def test_fused_gates_backward_prologue(hip, nodes, C, cin, K, fused_path):
     """Gate backward as the prologue of the node backward (dG never stored) vs gate kernel + node backward of the twin."""
