@@ -146,6 +146,8 @@ int stc_gru_gates_bwd_f32(const float* dCandIn, const float* dU, const float* H,
 /* blend:  Cand = tanh(Cpre); Hnew = (1-U)*H + U*Cand      (n = rows*h elements) */
 int stc_gru_blend_fwd_f32(const float* Cpre, const float* U, const float* H,
                           float* Cand, float* Hnew, int64_t n, void* stream);
+/* dCpre = dHnew*U*(1-Cand^2), dU = dHnew*(Cand-H), dH = dHnew*(1-U); dH may be NULL when the consumer forms that
+ * product itself (stc_cell_gates_bwd_f32 with dH_in_scaled) */
 int stc_gru_blend_bwd_f32(const float* dHnew, const float* U, const float* H, const float* Cand,
                           float* dCpre, float* dU, float* dH, int64_t n, void* stream);
 
@@ -166,11 +168,13 @@ int stc_cell_gates_fwd_f32(const float* const* Z, int32_t Ks, const float* Tc, i
 /* Backward of the gates convolution with the gate backward as its prologue (autograd of STC_GNN.py:69-75):
  *   dG = [dU*U*(1-U) | dCandIn[:, cin:cin+h]*H*Rg*(1-Rg)] is formed per node inside the kernel and never stored;
  *   outputs dZ / dW / db as stc_bdg_node_bwd_f32 for dY = dG, plus dXt = dCandIn[:, :cin] and
- *   dH = dCandIn[h part]*Rg + dH_in (dH_in may be NULL and may alias dH).
+ *   dH = dCandIn[h part]*Rg + dH_in (dH_in may be NULL and may alias dH; with dH_in_scaled != 0 it enters as
+ *   dH_in*(1-U), i.e. dH_in is the gradient of the new state and the blend backward need not write its (1-U) share).
+ *   dXt may be NULL when the caller reads dCandIn[:, :cin] in place (stc_split2_f32's addA_ld).
  * dCandIn (nodes, C, L); dU/H/U/Rg/dH (nodes, C, h); dXt (nodes, C, cin).  Fused shapes only (else STC_EUNSUPPORTED). */
 int stc_cell_gates_bwd_f32(const float* const* Z, int32_t Ks, const float* Tc, int32_t Kc, const float* W,
                            const float* dCandIn, const float* dU, const float* H, const float* U, const float* Rg,
-                           const float* dH_in, float* const* dZ, float* dW, float* db, float* dXt, float* dH,
+                           const float* dH_in, int32_t dH_in_scaled, float* const* dZ, float* dW, float* db, float* dXt, float* dH,
                            void* workspace, size_t workspace_bytes,
                            int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t h, int32_t cin, void* stream);
 int stc_cell_blend_fwd_f32(const float* const* Z, int32_t Ks, const float* Tc, int32_t Kc,
@@ -216,9 +220,10 @@ int stc_axpy_f32(float a, const float* x, float* y, int64_t n, void* stream);
 /* out (rows, a+b+pad) = [A (rows,a) | B (rows,b) | zeros]   (torch.cat of STC_GNN.py:68) and its inverse */
 int stc_concat2_f32(const float* A, const float* B, float* out,
                     int64_t rows, int32_t a, int32_t b, int32_t pad, void* stream);
-/* split: A = src[:, :a] (+ addA), B = src[:, a:a+b] (+ addB); addA/addB may be NULL and may alias A/B */
+/* split: A = src[:, :a] (+ addA), B = src[:, a:a+b] (+ addB); addA/addB may be NULL and may alias A/B.
+ * addA_ld: row stride of addA in floats (0 = a, i.e. dense): lets addA be the first a columns of a wider buffer. */
 int stc_split2_f32(const float* src, const float* addA, const float* addB, float* A, float* B,
-                   int64_t rows, int32_t a, int32_t b, int32_t pad, void* stream);
+                   int64_t rows, int32_t a, int32_t b, int32_t pad, int32_t addA_ld, void* stream);
 
 #ifdef __cplusplus
 }

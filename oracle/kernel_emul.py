@@ -152,9 +152,13 @@ class EmulatedKernels:
         self.bdg_node_fwd(Zs, Tc, W, bias, G)
         self.gru_gates_fwd(G, Zs[0][..., :cin], H, U, Rg, CandIn)
 
-    def cell_gates_bwd(self, Zs, Tc, W, dCandIn, dU, H, U, Rg, dH_in, dZs, dW, db, dXt, dH):
+    def cell_gates_bwd(self, Zs, Tc, W, dCandIn, dU, H, U, Rg, dH_in, dZs, dW, db, dXt, dH, dH_in_scaled=False):
         dG = torch.empty(H.shape[:-1] + (2 * H.shape[-1],), dtype=W.dtype)
-        self.gru_gates_bwd(dCandIn, dU, H, U, Rg, dG, dXt, dH, dH_in=None if dH_in is None else dH_in.clone())
+        if dXt is None:                                       # not wanted: the caller reads dCandIn[..., :cin] in place
+            cin = W.shape[0] // (len(Zs) * Tc.shape[0]) - H.shape[-1]
+            dXt = torch.empty(H.shape[:-1] + (cin,), dtype=W.dtype)
+        extra = None if dH_in is None else (dH_in * (1 - U) if dH_in_scaled else dH_in.clone())
+        self.gru_gates_bwd(dCandIn, dU, H, U, Rg, dG, dXt, dH, dH_in=extra)
         self.bdg_node_bwd(Zs, Tc, W, dG, dZs, dW, db, None)
 
     def cell_blend_fwd(self, Zs, Tc, W, bias, U, H, Cand, Hnew):
@@ -205,7 +209,8 @@ class EmulatedKernels:
     def gru_blend_bwd(self, dHnew, U, H, Cand, dCpre, dU, dH):
         dCpre.copy_(dHnew * U * (1 - Cand * Cand))
         dU.copy_(dHnew * (Cand - H))
-        dH.copy_(dHnew * (1 - U))
+        if dH is not None:
+            dH.copy_(dHnew * (1 - U))
 
     # ---- stc_head_fwd/bwd_f32: the two bias-ful Linears of the output head folded into one map + sigmoid (STC_GNN.py:182-183, 206)
     def head_fwd(self, H, w, b, y):
@@ -228,7 +233,7 @@ class EmulatedKernels:
         out[..., a:a + b].copy_(Bm)
         out[..., a + b:].zero_()
 
-    def split2(self, src, A, Bm, addA=None, addB=None):
+    def split2(self, src, A, Bm, addA=None, addB=None, addA_ld=0):
         a, b = A.shape[-1], Bm.shape[-1]
-        A.copy_(src[..., :a] + (addA if addA is not None else 0))
+        A.copy_(src[..., :a] + (addA[..., :a] if addA is not None else 0))
         Bm.copy_(src[..., a:a + b] + (addB if addB is not None else 0))

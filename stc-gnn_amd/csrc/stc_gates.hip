@@ -85,7 +85,7 @@ __global__ __launch_bounds__(EW_THREADS) void gru_blend_bwd_kernel(
         const float g = dHnew[e], u = U[e], c = Cand[e];
         dCpre[e] = g * u * (1.f - c * c);
         dU[e] = g * (c - H[e]);
-        dH[e] = g * (1.f - u);
+        if (dH) dH[e] = g * (1.f - u);
     }
 }
 
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(EW_THREADS) void gru_blend_bwd_vec_kernel(
         dCpre[e] = make_float4(g.x * u.x * (1.f - c.x * c.x), g.y * u.y * (1.f - c.y * c.y),
                                g.z * u.z * (1.f - c.z * c.z), g.w * u.w * (1.f - c.w * c.w));
         dU[e] = make_float4(g.x * (c.x - hh.x), g.y * (c.y - hh.y), g.z * (c.z - hh.z), g.w * (c.w - hh.w));
-        dH[e] = make_float4(g.x * (1.f - u.x), g.y * (1.f - u.y), g.z * (1.f - u.z), g.w * (1.f - u.w));
+        if (dH) dH[e] = make_float4(g.x * (1.f - u.x), g.y * (1.f - u.y), g.z * (1.f - u.z), g.w * (1.f - u.w));
     }
 }
 
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(EW_THREADS) void concat2_vec_kernel(const float4* _
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
 __global__ __launch_bounds__(EW_THREADS) void split2_vec_kernel(const float4* __restrict__ src, const float4* addA, const float4* addB,
-                                                                 float4* A, float4* B, long long rows, int a4, int b4, int pad4) {
+                                                                 float4* A, float4* B, long long rows, int a4, int b4, int pad4, int ldA4) {
     const int L4 = a4 + b4 + pad4;
     const long long n = rows * L4;
     for (long long e = (long long)blockIdx.x * EW_THREADS + threadIdx.x; e < n; e += (long long)gridDim.x * EW_THREADS) {
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(EW_THREADS) void split2_vec_kernel(const float4* __
         const int l = (int)(e - r * L4);
         if (l < a4) {
             const long long i = r * a4 + l;
-            A[i] = addA ? add4(src[e], addA[i]) : src[e];
+            A[i] = addA ? add4(src[e], addA[r * ldA4 + l]) : src[e];
         } else if (l < a4 + b4) {
             const long long i = r * b4 + (l - a4);
             B[i] = addB ? add4(src[e], addB[i]) : src[e];
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(EW_THREADS) void concat2_kernel(const float* __rest
 }
 
 __global__ __launch_bounds__(EW_THREADS) void split2_kernel(const float* __restrict__ src, const float* addA, const float* addB,
-                                                             float* A, float* B, long long rows, int a, int b, int pad) {
+                                                             float* A, float* B, long long rows, int a, int b, int pad, int ldA) {
     const int L = a + b + pad;
     const long long n = rows * L;
     for (long long e = (long long)blockIdx.x * EW_THREADS + threadIdx.x; e < n; e += (long long)gridDim.x * EW_THREADS) {
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(EW_THREADS) void split2_kernel(const float* __restr
         const int l = (int)(e - r * L);
         if (l < a) {
             const long long i = r * a + l;
-            A[i] = addA ? src[e] + addA[i] : src[e];
+            A[i] = addA ? src[e] + addA[r * ldA + l] : src[e];
         } else if (l < a + b) {
             const long long i = r * b + (l - a);
             B[i] = addB ? src[e] + addB[i] : src[e];
@@ -420,7 +420,7 @@ extern "C" int stc_gru_blend_fwd_f32(const float* Cpre, const float* U, const fl
 
 extern "C" int stc_gru_blend_bwd_f32(const float* dHnew, const float* U, const float* H, const float* Cand,
                                      float* dCpre, float* dU, float* dH, int64_t n, void* stream) {
-    STC_EW_PROLOGUE("stc_gru_blend_bwd_f32", n, dHnew && U && H && Cand && dCpre && dU && dH);
+    STC_EW_PROLOGUE("stc_gru_blend_bwd_f32", n, dHnew && U && H && Cand && dCpre && dU);      // dH may be null (not wanted)
     if (vec_ok({dHnew, U, H, Cand, dCpre, dU, dH}, {n}))
         hipLaunchKernelGGL(gru_blend_bwd_vec_kernel, ew_grid(n / 4), dim3(EW_THREADS), 0, s, F4C(dHnew), F4C(U), F4C(H), F4C(Cand), F4M(dCpre), F4M(dU),
                            F4M(dH), (long long)n / 4);
@@ -481,15 +481,17 @@ extern "C" int stc_concat2_f32(const float* A, const float* B, float* out, int64
 }
 
 extern "C" int stc_split2_f32(const float* src, const float* addA, const float* addB, float* A, float* B,
-                              int64_t rows, int32_t a, int32_t b, int32_t pad, void* stream) {
+                              int64_t rows, int32_t a, int32_t b, int32_t pad, int32_t addA_ld, void* stream) {
     STC_REQUIRE(a >= 0 && b >= 0 && pad >= 0, STC_EINVAL, "stc_split2_f32: negative width");
+    STC_REQUIRE(addA_ld == 0 || addA_ld >= a, STC_EINVAL, "stc_split2_f32: addA_ld=%d is smaller than the width a=%d", addA_ld, a);
+    const int ldA = addA_ld ? addA_ld : a;
     const long long n = (long long)rows * (a + b + pad);
     STC_EW_PROLOGUE("stc_split2_f32", n, src && (a == 0 || A) && (b == 0 || B));
-    if (vec_ok({src, addA, addB, A, B}, {a, b, pad}))
+    if (vec_ok({src, addA, addB, A, B}, {a, b, pad, ldA}))
         hipLaunchKernelGGL(split2_vec_kernel, ew_grid(n / 4), dim3(EW_THREADS), 0, s, F4C(src), F4C(addA), F4C(addB), F4M(A), F4M(B),
-                           (long long)rows, a / 4, b / 4, pad / 4);
+                           (long long)rows, a / 4, b / 4, pad / 4, ldA / 4);
     else
-        hipLaunchKernelGGL(split2_kernel, ew_grid(n), dim3(EW_THREADS), 0, s, src, addA, addB, A, B, (long long)rows, a, b, pad);
+        hipLaunchKernelGGL(split2_kernel, ew_grid(n), dim3(EW_THREADS), 0, s, src, addA, addB, A, B, (long long)rows, a, b, pad, ldA);
     STC_LAUNCH_CHECK("stc_split2_f32 launch");
     return STC_OK;
 }

@@ -412,7 +412,7 @@ extern "C" int stc_cell_gates_fwd_f32(const float* const* Z, int32_t Ks, const f
 
 extern "C" int stc_cell_gates_bwd_f32(const float* const* Z, int32_t Ks, const float* Tc, int32_t Kc, const float* W,
                                       const float* dCandIn, const float* dU, const float* H, const float* U, const float* Rg,
-                                      const float* dH_in, float* const* dZ, float* dW, float* db, float* dXt, float* dH,
+                                      const float* dH_in, int32_t dH_in_scaled, float* const* dZ, float* dW, float* db, float* dXt, float* dH,
                                       void* workspace, size_t workspace_bytes,
                                       int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t h, int32_t cin, void* stream) {
     if (int rc = check_dims("stc_cell_gates_bwd_f32", Ks, Kc, C, L, Lw, 2 * h, nodes)) return rc;
@@ -426,7 +426,7 @@ extern "C" int stc_cell_gates_bwd_f32(const float* const* Z, int32_t Ks, const f
         if (db) if (int rc = stc::hip_status(hipMemsetAsync(db, 0, (size_t)Ho * sizeof(float), s), "memset db")) return rc;
         return STC_OK;
     }
-    STC_REQUIRE(dCandIn && dU && H && U && Rg && dH && (cin == 0 || dXt), STC_EINVAL, "stc_cell_gates_bwd_f32: null pointer");
+    STC_REQUIRE(dCandIn && dU && H && U && Rg && dH, STC_EINVAL, "stc_cell_gates_bwd_f32: null pointer");      // dXt may be null (not wanted)
     for (int n = 0; n < Ks; ++n) STC_REQUIRE(Z[n] && dZ[n], STC_EINVAL, "stc_cell_gates_bwd_f32: Z[%d]/dZ[%d] is null", n, n);
     STC_REQUIRE(workspace && stc::aligned16(workspace), STC_EALIGN, "stc_cell_gates_bwd_f32: workspace null or not 16-byte aligned");
     STC_REQUIRE(workspace_bytes >= stc_bdg_node_bwd_workspace_bytes(Ks, Kc, C, L, Ho, 0), STC_EINVAL,
@@ -435,9 +435,9 @@ extern "C" int stc_cell_gates_bwd_f32(const float* const* Z, int32_t Ks, const f
     float* partial = static_cast<float*>(workspace);
     int rc = STC_NOT_HANDLED;
     if (x3_enabled()) rc = stc_cell_gates_bwd_x3(Z, Ks, Tc, W, dCandIn, dU, H, U, Rg, dH_in, dZ, dXt, dH, partial, &n_parts, db != nullptr,
-                                                 nodes, C, L, Lw, cin, s);
+                                                 nodes, C, L, Lw, cin, dH_in_scaled != 0, s);
     if (rc == STC_NOT_HANDLED) rc = stc_cell_gates_bwd_mfma(Z, Ks, Tc, W, dCandIn, dU, H, U, Rg, dH_in, dZ, dXt, dH, partial, &n_parts, db != nullptr,
-                                                            nodes, C, L, Lw, cin, s);
+                                                            nodes, C, L, Lw, cin, dH_in_scaled != 0, s);
     if (rc == STC_NOT_HANDLED) return stc::fail(STC_EUNSUPPORTED, "stc_cell_gates_bwd_f32: operands not usable by the fused path (alignment)");
     if (rc != STC_OK) return rc;
     const int stride = nW + Ho;

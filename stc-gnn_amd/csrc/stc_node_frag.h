@@ -67,13 +67,16 @@ struct DyFrag {     // one node's dY in both register layouts
 // Prologue of the gates convolution's backward (autograd of reference STC_GNN.py:71-75, hidden 16): instead of
 // reading a precomputed dY, build it per node from the gradient of [Xt | R*H | pad] and the saved gates,
 //   dY[:, :16] = dU * U * (1 - U),   dY[:, 16:] = dCandIn[:, cin:cin+16] * H * R * (1 - R),
-// and emit the two by-products dXt = dCandIn[:, :cin], dH = dCandIn[h part] * R + dH_in on the way, so the separate
-// gate-backward pass (and the dG round trip through HBM) disappears.
+// and emit the two by-products dXt = dCandIn[:, :cin] (optional: the caller may read those columns in place) and
+// dH = dCandIn[h part] * R + dH_in on the way, so the separate gate-backward pass (and the dG round trip through HBM)
+// disappears.  With dh_scaled, dH_in is the gradient of the new state itself and is taken times (1 - U) -- the state's
+// share of the GRU blend (reference STC_GNN.py:78) -- so the blend backward need not write that product.
 enum { PRO_NONE = 0, PRO_GATES = 1 };
 struct BwdPro {
     const float *dCandIn, *dU, *H, *U, *R, *dH_in;   // (nodes,C,L) and (nodes,C,16) operands; dH_in may be null / alias dH
-    float *dXt, *dH;                                  // (nodes,C,cin), (nodes,C,16)
+    float *dXt, *dH;                                  // (nodes,C,cin) or null, (nodes,C,16)
     int cin;
+    int dh_scaled;                                    // dH_in enters as dH_in * (1 - U)
 };
 
 template <int NRB, int HB, int L>
@@ -104,13 +107,15 @@ __device__ __forceinline__ void load_gates_grad(DyFrag<NRB, HB>& g, const BwdPro
         float4 dh = make_float4(d.x * r.x, d.y * r.y, d.z * r.z, d.w * r.w);
         if (p.dH_in) {
             const float4 o = *reinterpret_cast<const float4*>(p.dH_in + e);
-            dh.x += o.x; dh.y += o.y; dh.z += o.z; dh.w += o.w;
+            if (p.dh_scaled) { dh.x += o.x * (1.f - u.x); dh.y += o.y * (1.f - u.y); dh.z += o.z * (1.f - u.z); dh.w += o.w * (1.f - u.w); }
+            else { dh.x += o.x; dh.y += o.y; dh.z += o.z; dh.w += o.w; }
         }
         *reinterpret_cast<float4*>(p.dH + e) = dh;
-        for (int c0 = 4 * q; c0 < p.cin; c0 += 16)
+        if (p.dXt)
+            for (int c0 = 4 * q; c0 < p.cin; c0 += 16)
 #pragma unroll
-            for (int x = 0; x < 4; ++x)
-                if (c0 + x < p.cin) p.dXt[row * p.cin + c0 + x] = cr[c0 + x];
+                for (int x = 0; x < 4; ++x)
+                    if (c0 + x < p.cin) p.dXt[row * p.cin + c0 + x] = cr[c0 + x];
     }
 }
 

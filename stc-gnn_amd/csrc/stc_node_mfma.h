@@ -28,7 +28,7 @@ int stc_cell_blend_fwd_mfma(const float* const* Z, int K, const float* Tc, const
 int stc_cell_gates_bwd_mfma(const float* const* Z, int K, const float* Tc, const float* W,
                             const float* dCandIn, const float* dU, const float* H, const float* U, const float* R, const float* dH_in,
                             float* const* dZ, float* dXt, float* dH, float* partial, int* n_partials, int want_db,
-                            long long nodes, int C, int L, int Lw, int cin, hipStream_t stream);
+                            long long nodes, int C, int L, int Lw, int cin, int dh_scaled, hipStream_t stream);
 
 // Split-operand bf16 MFMA versions of the same five launches (stc_node_x3.hip; C in {32, 64}), tried before the fp32
 // MFMA ones.  Same contract and return values.
@@ -46,7 +46,7 @@ int stc_cell_blend_fwd_x3(const float* const* Z, int K, const float* Tc, const f
 int stc_cell_gates_bwd_x3(const float* const* Z, int K, const float* Tc, const float* W,
                           const float* dCandIn, const float* dU, const float* H, const float* U, const float* R, const float* dH_in,
                           float* const* dZ, float* dXt, float* dH, float* partial, int* n_partials, int want_db,
-                          long long nodes, int C, int L, int Lw, int cin, hipStream_t stream);
+                          long long nodes, int C, int L, int Lw, int cin, int dh_scaled, hipStream_t stream);
 
 // Fused aggregation variants (Ks = Kc = 2): the kernel gathers Z1 = S.Z0 itself from the CSR rows of S (n nodes per
 // sample, nodes = batch * n) and writes it for the backward.

@@ -671,7 +671,7 @@ int stc_cell_blend_fwd_x3(const float* const* Z, int K, const float* Tc, const f
 int stc_cell_gates_bwd_x3(const float* const* Z, int K, const float* Tc, const float* W,
                           const float* dCandIn, const float* dU, const float* H, const float* U, const float* R, const float* dH_in,
                           float* const* dZ, float* dXt, float* dH, float* partial, int* n_partials, int want_db,
-                          long long nodes, int C, int L, int Lw, int cin, hipStream_t stream) {
+                          long long nodes, int C, int L, int Lw, int cin, int dh_scaled, hipStream_t stream) {
     if (!x3_cell_shape(K, C, L, nodes) || !all_aligned16(Z, K)) return STC_NOT_HANDLED;
     for (int n = 0; n < K; ++n)
         if (!stc::aligned16(dZ[n])) return STC_NOT_HANDLED;
@@ -679,7 +679,7 @@ int stc_cell_gates_bwd_x3(const float* const* Z, int K, const float* Tc, const f
           stc::aligned16(dH) && (!dH_in || stc::aligned16(dH_in))))
         return STC_NOT_HANDLED;
     BwdPro pro{};
-    pro.dCandIn = dCandIn; pro.dU = dU; pro.H = H; pro.U = U; pro.R = R; pro.dH_in = dH_in; pro.dXt = dXt; pro.dH = dH; pro.cin = cin;
+    pro.dCandIn = dCandIn; pro.dU = dU; pro.H = H; pro.U = U; pro.R = R; pro.dH_in = dH_in; pro.dXt = dXt; pro.dH = dH; pro.cin = cin; pro.dh_scaled = dh_scaled;
 #define GBWD_CALL(a, c, d) launch_bwd<a, 2, c, d, PRO_GATES>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro)
     STC_X3_EPI_CASE(1, GBWD_CALL) STC_X3_EPI_CASE(2, GBWD_CALL) STC_X3_EPI_CASE3(GBWD_CALL)
 #undef GBWD_CALL

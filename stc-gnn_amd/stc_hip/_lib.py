@@ -63,7 +63,7 @@ def _declare(lib):
         'stc_bdg_node_bwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, C.POINTER(_p), _p, _p, _p,
                                  _p, C.c_size_t, _i64, _i32, _i32, _i32, _i32, _p],
         'stc_cell_gates_fwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _i32, _p],
-        'stc_cell_gates_bwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _p, C.POINTER(_p), _p, _p, _p, _p,
+        'stc_cell_gates_bwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _i32, C.POINTER(_p), _p, _p, _p, _p,
                                    _p, C.c_size_t, _i64, _i32, _i32, _i32, _i32, _i32, _p],
         'stc_cell_blend_fwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
         'stc_cell_gates_fwd_gather_f32': [_p, _p, _p, _i64] + [_p] * 9 + [_i64, _i32, _i32, _i32, _i32, _i32, _p],
@@ -76,7 +76,7 @@ def _declare(lib):
         'stc_head_bwd_f32': [_p, _p, _p, _p, _p, _p, _p, C.c_size_t, _i64, _i32, _p],
         'stc_axpy_f32': [_f32, _p, _p, _i64, _p],
         'stc_concat2_f32': [_p, _p, _p, _i64, _i32, _i32, _i32, _p],
-        'stc_split2_f32': [_p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p],
+        'stc_split2_f32': [_p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
     }
     for name, argtypes in sig.items():
         fn = getattr(lib, name)
@@ -382,8 +382,9 @@ class HipKernels:
         self._launch('stc_cell_gates_fwd_f32', H, self._ptr_array(Zs), Ks, _ptr(Tc), Kc, _ptr(W), _ptr(bias), _ptr(H),
                      _ptr(U), _ptr(Rg), _ptr(CandIn), R, Cc, L, Lw, h, cin)
 
-    def cell_gates_bwd(self, Zs, Tc, W, dCandIn, dU, H, U, Rg, dH_in, dZs, dW, db, dXt, dH):
-        """Gate backward as the prologue of the gates convolution's node backward (stc_cell_gates_bwd_f32)."""
+    def cell_gates_bwd(self, Zs, Tc, W, dCandIn, dU, H, U, Rg, dH_in, dZs, dW, db, dXt, dH, dH_in_scaled=False):
+        """Gate backward as the prologue of the gates convolution's node backward (stc_cell_gates_bwd_f32).
+        ``dXt`` may be None (not written); ``dH_in_scaled``: dH_in enters times (1 - U)."""
         Ks, Kc, R, Cc, L, Lw, Ho = self._node_shapes(Zs, Tc, W)
         h = H.shape[-1]
         cin = Lw - h
@@ -392,7 +393,8 @@ class HipKernels:
         self._f32('cell.dCandIn', dCandIn, (R, Cc, L))
         for name, t in (('dU', dU), ('H', H), ('U', U), ('Rg', Rg), ('dH', dH)) + ((('dH_in', dH_in),) if dH_in is not None else ()):
             self._f32('cell.' + name, t, (R, Cc, h))
-        self._f32('cell.dXt', dXt, (R, Cc, cin))
+        if dXt is not None:
+            self._f32('cell.dXt', dXt, (R, Cc, cin))
         for i, z in enumerate(dZs):
             self._f32(f'cell.dZ[{i}]', z, (R, Cc, L))
         self._f32('cell.dW', dW, (Ks * Kc * Lw, Ho))
@@ -401,7 +403,7 @@ class HipKernels:
         self._same_device(*Zs, Tc, W, dCandIn, dU, H, U, Rg, dH_in, *dZs, dW, db, dXt, dH)
         ws = self._get_workspace(H.device, self.lib.stc_bdg_node_bwd_workspace_bytes(Ks, Kc, Cc, L, Ho, 0))
         self._launch('stc_cell_gates_bwd_f32', H, self._ptr_array(Zs), Ks, _ptr(Tc), Kc, _ptr(W), _ptr(dCandIn), _ptr(dU), _ptr(H),
-                     _ptr(U), _ptr(Rg), _ptr(dH_in), self._ptr_array(dZs), _ptr(dW), _ptr(db), _ptr(dXt), _ptr(dH),
+                     _ptr(U), _ptr(Rg), _ptr(dH_in), int(bool(dH_in_scaled)), self._ptr_array(dZs), _ptr(dW), _ptr(db), _ptr(dXt), _ptr(dH),
                      _ptr(ws), ws.numel(), R, Cc, L, Lw, h, cin)
 
     def cell_blend_fwd(self, Zs, Tc, W, bias, U, H, Cand, Hnew):
@@ -503,7 +505,8 @@ class HipKernels:
         self._launch('stc_gru_blend_fwd_f32', H, _ptr(Cpre), _ptr(U), _ptr(H), _ptr(Cand), _ptr(Hnew), n)
 
     def gru_blend_bwd(self, dHnew, U, H, Cand, dCpre, dU, dH):
-        n = self._same_numel('blend_bwd', dHnew, U, H, Cand, dCpre, dU, dH)
+        """``dH`` may be None (the (1 - U) share of the state is then formed by the consumer)."""
+        n = self._same_numel('blend_bwd', dHnew, U, H, Cand, dCpre, dU, *(() if dH is None else (dH,)))
         self._launch('stc_gru_blend_bwd_f32', H, _ptr(dHnew), _ptr(U), _ptr(H), _ptr(Cand), _ptr(dCpre), _ptr(dU), _ptr(dH), n)
 
     # ---- output head -----------------------------------------------------------------------
@@ -549,9 +552,13 @@ class HipKernels:
         rows, a, b, pad = self._cat_shapes('concat2', A, Bm, out)
         self._launch('stc_concat2_f32', out, _ptr(A), _ptr(Bm), _ptr(out), rows, a, b, pad)
 
-    def split2(self, src, A, Bm, addA=None, addB=None):
+    def split2(self, src, A, Bm, addA=None, addB=None, addA_ld=0):
+        """``addA_ld`` > 0: ``addA`` is a (rows, addA_ld) buffer whose first ``a`` columns are added (read in place)."""
         rows, a, b, pad = self._cat_shapes('split2', A, Bm, src)
-        for name, t, like in (('addA', addA, A), ('addB', addB, Bm)):
-            if t is not None:
-                self._f32('split2.' + name, t, like.shape)
-        self._launch('stc_split2_f32', src, _ptr(src), _ptr(addA), _ptr(addB), _ptr(A), _ptr(Bm), rows, a, b, pad)
+        if addA is not None:
+            self._f32('split2.addA', addA, A.shape if not addA_ld else A.shape[:-1] + (addA_ld,))
+            if addA_ld and addA_ld < a:
+                raise StcError(f'split2: addA_ld={addA_ld} is smaller than the width {a}')
+        if addB is not None:
+            self._f32('split2.addB', addB, Bm.shape)
+        self._launch('stc_split2_f32', src, _ptr(src), _ptr(addA), _ptr(addB), _ptr(A), _ptr(Bm), rows, a, b, pad, int(addA_ld if addA is not None else 0))

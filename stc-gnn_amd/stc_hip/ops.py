@@ -127,8 +127,8 @@ def _bdg_backward_slabs(dY, Zs, W, Tc, op: SpatialOperand, Ks: int, has_bias: bo
     dTc = torch.empty_like(Tc) if need_Tc else None
     rows = lambda ts: [t.view(B * N, C, t.shape[-1]) for t in ts]
     if gates is not None:       # dY = gate pre-activation gradient, formed inside the kernel from (dCandIn, dU, H, U, R)
-        dCandIn, dU, H, U, Rg, dXt, dH = gates
-        k.cell_gates_bwd(rows(Zs), Tc, W, *rows((dCandIn, dU, H, U, Rg, dH)), rows(dZ), dW, db, *rows((dXt, dH)))
+        dCandIn, dU, H, U, Rg, dHnew, dH = gates     # dH = dCandIn[h part] * R + dHnew * (1 - U); dXt stays inside dCandIn
+        k.cell_gates_bwd(rows(Zs), Tc, W, *rows((dCandIn, dU, H, U, Rg, dHnew)), rows(dZ), dW, db, None, *rows((dH,)), dH_in_scaled=True)
     else:
         dY = _c(dY)
         k.bdg_node_bwd(rows(Zs), Tc, W, dY.view(B * N, C, Ho), rows(dZ), dW, db, dTc)
@@ -361,10 +361,6 @@ class _StcCell(Function):
         Zg, Zc = Z[:Ks], Z[Ks:]
         need_Xt, need_H = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         need_Tc, need_val = ctx.needs_input_grad[6], ctx.needs_input_grad[7]
-        dCpre, dU, dH = torch.empty_like(H), torch.empty_like(H), torch.empty_like(H)
-        k.gru_blend_bwd(_c(dHnew), U, H, Cand, dCpre, dU, dH)                     # dH = dHnew * (1 - U)
-        dG = H.new_empty(H.shape[:-1] + (2 * H.shape[-1],))
-        dXt = H.new_empty(H.shape[:-1] + (cin,))
         B, N, C, L = Zc[0].shape
         v3 = lambda t: t.view(B, N, C * L)
         bwd = (op.bwd_rowptr, op.bwd_colidx, op.bwd_val, op.bwd_plan)
@@ -372,20 +368,27 @@ class _StcCell(Function):
         # slower in the full step on MI355X (397 us vs ~354 us for SpMM + gate kernel: the epilogue's loads are not
         # overlapped with the gather, and the intermediate is served from the Infinity Cache anyway): opt-in only.
         fuse = _FUSE_BWD and Ks > 1 and C * L >= 64
+        # the gate backward can run as the prologue of the gates convolution's node backward (dG is never stored); it then
+        # also takes over two pure data movements: the state's (1 - U) share of the blend (read from dHnew in place) and
+        # dXt = d[x part] (left in place, added by the final split straight from the candidate gradient's rows)
+        pro = not fuse and not (need_Tc or need_val) and k.cell_fused_supported(Ks, Tc.shape[0], C, L, H.shape[-1])
+        dHnew = _c(dHnew)
+        dCpre, dU, dH = torch.empty_like(H), torch.empty_like(H), torch.empty_like(H)
+        k.gru_blend_bwd(dHnew, U, H, Cand, dCpre, dU, None if pro else dH)        # dH = dHnew * (1 - U)
+        dG = None if pro else H.new_empty(H.shape[:-1] + (2 * H.shape[-1],))
+        dXt = H.new_empty(H.shape[:-1] + (cin,))
         # candidate convolution: d[Xt | R*H] = g0 + Gs.g1, consumed by the gate backward
         g, dWc, dbc, dTc, dval = _bdg_backward_slabs(dCpre, Zc, Wc, Tc, op, Ks, ctx.bias[1], need_Tc, need_val)
-        gates_pro = None
+        gates_pro, dci = None, g[0]
         if fuse:
             k.spmm_bwd_gates(*bwd, v3(g[1]), v3(g[0]), dU, H, U, Rg, dH, dG, dXt, dH)   # dH += d[h part] * R ; dXt = d[x part]
         else:
             if Ks > 1:
                 k.csr_spmm(*bwd[:3], N, N, v3(g[1]), v3(g[0]), v3(g[0]), 1.0, 1.0, plan=op.bwd_plan)
-            if not (need_Tc or need_val) and k.cell_fused_supported(Ks, Tc.shape[0], C, L, H.shape[-1]):
-                # the gate backward runs as the prologue of the gates convolution's node backward (dG is never stored)
-                gates_pro = (g[0], dU, H, U, Rg, dXt, dH)
-                dG = None
+            if pro:
+                gates_pro = (dci, dU, H, U, Rg, dHnew, dH)
             else:
-                k.gru_gates_bwd(g[0], dU, H, U, Rg, dG, dXt, dH, dH_in=dH)
+                k.gru_gates_bwd(dci, dU, H, U, Rg, dG, dXt, dH, dH_in=dH)
         # gates convolution: d[Xt | H] = g0 + Gs.g1, split and added to what Xt and H are already owed
         g, dWg, dbg, dTc2, dval2 = _bdg_backward_slabs(dG, Zg, Wg, Tc, op, Ks, ctx.bias[0], need_Tc, need_val, gates=gates_pro)
         if need_Xt or need_H:
@@ -394,7 +397,10 @@ class _StcCell(Function):
             else:
                 if Ks > 1:
                     k.csr_spmm(*bwd[:3], N, N, v3(g[1]), v3(g[0]), v3(g[0]), 1.0, 1.0, plan=op.bwd_plan)
-                k.split2(g[0], dXt, dH, addA=dXt, addB=dH)                        # + the concat's share, in place
+                if pro:
+                    k.split2(g[0], dXt, dH, addA=dci, addB=dH, addA_ld=L)         # + d[x part] of the candidate, read in place
+                else:
+                    k.split2(g[0], dXt, dH, addA=dXt, addB=dH)                    # + the concat's share, in place
         if need_Tc:
             dTc = dTc + dTc2
         if need_val:

@@ -458,6 +458,13 @@ def test_fused_gates_backward_prologue(hip, nodes, C, cin, K, fused_path):
     dH2 = torch.full((nodes, C, h), nan).cuda()                  # nothing owed yet: dH_in = NULL
     hip.cell_gates_bwd([cu(z) for z in Zs], cu(Tc), cu(W), cu(dCand), cu(dU), cu(H), cu(U), cu(R), None, dZ, dW, None, dXt, dH2)
     assert rel_err(dH2, dH_w - owed) < TOL
+    # dXt not wanted (read in place by the caller) and dH_in = gradient of the new state, taken times (1 - U) inside
+    dH3 = torch.full((nodes, C, h), nan).cuda()
+    hip.cell_gates_bwd([cu(z) for z in Zs], cu(Tc), cu(W), cu(dCand), cu(dU), cu(H), cu(U), cu(R), cu(owed), dZ, dW, None, None, dH3,
+                       dH_in_scaled=True)
+    assert rel_err(dH3, dH_w - owed + owed * (1 - U)) < TOL
+    for a, w in zip(dZ, dZ_w):
+        assert rel_err(a, w) < TOL
 
 
 def test_fused_cell_unsupported_shapes_are_refused(hip, monkeypatch):
@@ -530,6 +537,9 @@ def test_gru_gates_and_blend(hip, rows_shape, cin, h, pad):
     hip.gru_blend_bwd(cu(dHn), cu(U_w), cu(H), cu(Cand_w), *outs)
     for a, w in zip(outs, outs_w):
         assert rel_err(a, w) < TOL
+    keep = outs[2].clone()
+    hip.gru_blend_bwd(cu(dHn), cu(U_w), cu(H), cu(Cand_w), outs[0], outs[1], None)    # the state's share not wanted
+    assert torch.equal(outs[2], keep) and rel_err(outs[0], outs_w[0]) < TOL
 
 
 @pytest.mark.parametrize('shape,h', [((2, 3, 50, 5), 16), ((1, 6, 777, 4), 8), ((3, 7), 64), ((1, 300000), 16)])
@@ -579,6 +589,12 @@ def test_axpy_concat_split(hip):
     oa, ob = torch.ones(4, 9, 3, 4).cuda(), torch.ones(4, 9, 3, 16).cuda()
     hip.split2(whole, oa, ob, addA=oa, addB=None)
     assert torch.equal(oa.cpu(), A3 + 1) and torch.equal(ob.cpu(), B3)
+    # addA read in place from the first columns of a wider buffer (row stride addA_ld): 16-byte and scalar paths
+    wide = torch.randn(4, 9, 3, 20, generator=g)
+    hip.split2(whole, oa, ob, addA=cu(wide), addB=None, addA_ld=20)
+    assert torch.equal(oa.cpu(), A3 + wide[..., :4]) and torch.equal(ob.cpu(), B3)
+    hip.split2(padded, A2, B2, addA=cu(wide), addB=B2, addA_ld=20)
+    assert torch.equal(A2.cpu(), A + wide[..., :1])
 
 
 # ------------------------------------------------------------------ full-size properties (N = 50 176)
