@@ -171,12 +171,22 @@ int stc_cell_gates_fwd_f32(const float* const* Z, int32_t Ks, const float* Tc, i
  *   dH = dCandIn[h part]*Rg + dH_in (dH_in may be NULL and may alias dH; with dH_in_scaled != 0 it enters as
  *   dH_in*(1-U), i.e. dH_in is the gradient of the new state and the blend backward need not write its (1-U) share).
  *   dXt may be NULL when the caller reads dCandIn[:, :cin] in place (stc_split2_f32's addA_ld).
+ *   Give EITHER dU or Cand: with Cand (tanh of the candidate, saved by the forward) dH_in is the gradient dHnew of the
+ *   cell's new state and the kernel forms dU = dHnew*(Cand-H) and the state share dHnew*(1-U) itself (STC_GNN.py:78).
  * dCandIn (nodes, C, L); dU/H/U/Rg/dH (nodes, C, h); dXt (nodes, C, cin).  Fused shapes only (else STC_EUNSUPPORTED). */
 int stc_cell_gates_bwd_f32(const float* const* Z, int32_t Ks, const float* Tc, int32_t Kc, const float* W,
                            const float* dCandIn, const float* dU, const float* H, const float* U, const float* Rg,
-                           const float* dH_in, int32_t dH_in_scaled, float* const* dZ, float* dW, float* db, float* dXt, float* dH,
+                           const float* Cand, const float* dH_in, int32_t dH_in_scaled, float* const* dZ, float* dW, float* db, float* dXt, float* dH,
                            void* workspace, size_t workspace_bytes,
                            int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t h, int32_t cin, void* stream);
+/* Backward of the candidate convolution with the blend backward as its prologue (autograd of STC_GNN.py:76-78):
+ *   dY = dHnew*U*(1-Cand^2) is formed per node inside the kernel; outputs dZ / dW / db as stc_bdg_node_bwd_f32.
+ * dHnew/U/Cand (nodes, C, h).  Together with the Cand form of stc_cell_gates_bwd_f32 this replaces stc_gru_blend_bwd_f32. */
+int stc_cell_cand_bwd_f32(const float* const* Z, int32_t Ks, const float* Tc, int32_t Kc, const float* W,
+                          const float* dHnew, const float* U, const float* Cand,
+                          float* const* dZ, float* dW, float* db,
+                          void* workspace, size_t workspace_bytes,
+                          int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t h, void* stream);
 int stc_cell_blend_fwd_f32(const float* const* Z, int32_t Ks, const float* Tc, int32_t Kc,
                            const float* W, const float* bias, const float* U, const float* H,
                            float* Cand, float* Hnew,

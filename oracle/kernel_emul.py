@@ -152,8 +152,13 @@ class EmulatedKernels:
         self.bdg_node_fwd(Zs, Tc, W, bias, G)
         self.gru_gates_fwd(G, Zs[0][..., :cin], H, U, Rg, CandIn)
 
-    def cell_gates_bwd(self, Zs, Tc, W, dCandIn, dU, H, U, Rg, dH_in, dZs, dW, db, dXt, dH, dH_in_scaled=False):
+    def cell_cand_bwd(self, Zs, Tc, W, dHnew, U, Cand, dZs, dW, db):
+        self.bdg_node_bwd(Zs, Tc, W, dHnew * U * (1 - Cand * Cand), dZs, dW, db, None)
+
+    def cell_gates_bwd(self, Zs, Tc, W, dCandIn, dU, H, U, Rg, dH_in, dZs, dW, db, dXt, dH, dH_in_scaled=False, Cand=None):
         dG = torch.empty(H.shape[:-1] + (2 * H.shape[-1],), dtype=W.dtype)
+        if Cand is not None:                                  # dH_in = dHnew: both blend products are formed here
+            dU, dH_in_scaled = dH_in * (Cand - H), True
         if dXt is None:                                       # not wanted: the caller reads dCandIn[..., :cin] in place
             cin = W.shape[0] // (len(Zs) * Tc.shape[0]) - H.shape[-1]
             dXt = torch.empty(H.shape[:-1] + (cin,), dtype=W.dtype)

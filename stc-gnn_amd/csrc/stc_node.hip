@@ -412,7 +412,7 @@ extern "C" int stc_cell_gates_fwd_f32(const float* const* Z, int32_t Ks, const f
 
 extern "C" int stc_cell_gates_bwd_f32(const float* const* Z, int32_t Ks, const float* Tc, int32_t Kc, const float* W,
                                       const float* dCandIn, const float* dU, const float* H, const float* U, const float* Rg,
-                                      const float* dH_in, int32_t dH_in_scaled, float* const* dZ, float* dW, float* db, float* dXt, float* dH,
+                                      const float* Cand, const float* dH_in, int32_t dH_in_scaled, float* const* dZ, float* dW, float* db, float* dXt, float* dH,
                                       void* workspace, size_t workspace_bytes,
                                       int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t h, int32_t cin, void* stream) {
     if (int rc = check_dims("stc_cell_gates_bwd_f32", Ks, Kc, C, L, Lw, 2 * h, nodes)) return rc;
@@ -426,7 +426,9 @@ extern "C" int stc_cell_gates_bwd_f32(const float* const* Z, int32_t Ks, const f
         if (db) if (int rc = stc::hip_status(hipMemsetAsync(db, 0, (size_t)Ho * sizeof(float), s), "memset db")) return rc;
         return STC_OK;
     }
-    STC_REQUIRE(dCandIn && dU && H && U && Rg && dH, STC_EINVAL, "stc_cell_gates_bwd_f32: null pointer");      // dXt may be null (not wanted)
+    STC_REQUIRE(dCandIn && H && U && Rg && dH, STC_EINVAL, "stc_cell_gates_bwd_f32: null pointer");      // dXt may be null (not wanted)
+    STC_REQUIRE((dU != nullptr) != (Cand != nullptr), STC_EINVAL, "stc_cell_gates_bwd_f32: give either dU or Cand (dU is then formed from dH_in = dHnew)");
+    STC_REQUIRE(!Cand || dH_in, STC_EINVAL, "stc_cell_gates_bwd_f32: Cand needs dH_in = gradient of the new state");
     for (int n = 0; n < Ks; ++n) STC_REQUIRE(Z[n] && dZ[n], STC_EINVAL, "stc_cell_gates_bwd_f32: Z[%d]/dZ[%d] is null", n, n);
     STC_REQUIRE(workspace && stc::aligned16(workspace), STC_EALIGN, "stc_cell_gates_bwd_f32: workspace null or not 16-byte aligned");
     STC_REQUIRE(workspace_bytes >= stc_bdg_node_bwd_workspace_bytes(Ks, Kc, C, L, Ho, 0), STC_EINVAL,
@@ -434,11 +436,45 @@ extern "C" int stc_cell_gates_bwd_f32(const float* const* Z, int32_t Ks, const f
     int n_parts = 0;
     float* partial = static_cast<float*>(workspace);
     int rc = STC_NOT_HANDLED;
-    if (x3_enabled()) rc = stc_cell_gates_bwd_x3(Z, Ks, Tc, W, dCandIn, dU, H, U, Rg, dH_in, dZ, dXt, dH, partial, &n_parts, db != nullptr,
+    if (x3_enabled()) rc = stc_cell_gates_bwd_x3(Z, Ks, Tc, W, dCandIn, dU, H, U, Rg, dH_in, Cand, dZ, dXt, dH, partial, &n_parts, db != nullptr,
                                                  nodes, C, L, Lw, cin, dH_in_scaled != 0, s);
-    if (rc == STC_NOT_HANDLED) rc = stc_cell_gates_bwd_mfma(Z, Ks, Tc, W, dCandIn, dU, H, U, Rg, dH_in, dZ, dXt, dH, partial, &n_parts, db != nullptr,
+    if (rc == STC_NOT_HANDLED) rc = stc_cell_gates_bwd_mfma(Z, Ks, Tc, W, dCandIn, dU, H, U, Rg, dH_in, Cand, dZ, dXt, dH, partial, &n_parts, db != nullptr,
                                                             nodes, C, L, Lw, cin, dH_in_scaled != 0, s);
     if (rc == STC_NOT_HANDLED) return stc::fail(STC_EUNSUPPORTED, "stc_cell_gates_bwd_f32: operands not usable by the fused path (alignment)");
+    if (rc != STC_OK) return rc;
+    const int stride = nW + Ho;
+    hipLaunchKernelGGL(bdg_node_reduce_kernel, dim3((stride + RED_ELEMS - 1) / RED_ELEMS), dim3(NODE_THREADS), 0, s,
+                       partial, n_parts, stride, nW, Ho, 0, dW, db, static_cast<float*>(nullptr));
+    STC_LAUNCH_CHECK("stc_bdg_node_reduce launch");
+    return STC_OK;
+}
+
+extern "C" int stc_cell_cand_bwd_f32(const float* const* Z, int32_t Ks, const float* Tc, int32_t Kc, const float* W,
+                                    const float* dHnew, const float* U, const float* Cand,
+                                    float* const* dZ, float* dW, float* db,
+                                    void* workspace, size_t workspace_bytes,
+                                    int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t h, void* stream) {
+    if (int rc = check_dims("stc_cell_cand_bwd_f32", Ks, Kc, C, L, Lw, h, nodes)) return rc;
+    if (!stc_cell_fused_supported(Ks, Kc, C, L, h)) return stc::fail(STC_EUNSUPPORTED, "stc_cell_cand_bwd_f32: shape not on the fused path");
+    STC_REQUIRE(Z && W && dZ && dW && (Kc == 1 || Tc), STC_EINVAL, "stc_cell_cand_bwd_f32: null Z/W/dZ/dW/Tc");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int nW = Ks * Kc * Lw * h, Ho = h;
+    if (nodes == 0) {
+        if (int rc = stc::hip_status(hipMemsetAsync(dW, 0, (size_t)nW * sizeof(float), s), "memset dW")) return rc;
+        if (db) if (int rc = stc::hip_status(hipMemsetAsync(db, 0, (size_t)Ho * sizeof(float), s), "memset db")) return rc;
+        return STC_OK;
+    }
+    STC_REQUIRE(dHnew && U && Cand, STC_EINVAL, "stc_cell_cand_bwd_f32: null pointer");
+    for (int n = 0; n < Ks; ++n) STC_REQUIRE(Z[n] && dZ[n], STC_EINVAL, "stc_cell_cand_bwd_f32: Z[%d]/dZ[%d] is null", n, n);
+    STC_REQUIRE(workspace && stc::aligned16(workspace), STC_EALIGN, "stc_cell_cand_bwd_f32: workspace null or not 16-byte aligned");
+    STC_REQUIRE(workspace_bytes >= stc_bdg_node_bwd_workspace_bytes(Ks, Kc, C, L, Ho, 0), STC_EINVAL,
+                "stc_cell_cand_bwd_f32: workspace of %zu B is too small", workspace_bytes);
+    int n_parts = 0;
+    float* partial = static_cast<float*>(workspace);
+    int rc = STC_NOT_HANDLED;
+    if (x3_enabled()) rc = stc_cell_cand_bwd_x3(Z, Ks, Tc, W, dHnew, U, Cand, dZ, partial, &n_parts, db != nullptr, nodes, C, L, Lw, s);
+    if (rc == STC_NOT_HANDLED) rc = stc_cell_cand_bwd_mfma(Z, Ks, Tc, W, dHnew, U, Cand, dZ, partial, &n_parts, db != nullptr, nodes, C, L, Lw, s);
+    if (rc == STC_NOT_HANDLED) return stc::fail(STC_EUNSUPPORTED, "stc_cell_cand_bwd_f32: operands not usable by the fused path (alignment)");
     if (rc != STC_OK) return rc;
     const int stride = nW + Ho;
     hipLaunchKernelGGL(bdg_node_reduce_kernel, dim3((stride + RED_ELEMS - 1) / RED_ELEMS), dim3(NODE_THREADS), 0, s,

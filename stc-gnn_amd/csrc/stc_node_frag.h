@@ -71,16 +71,22 @@ struct DyFrag {     // one node's dY in both register layouts
 // dH = dCandIn[h part] * R + dH_in on the way, so the separate gate-backward pass (and the dG round trip through HBM)
 // disappears.  With dh_scaled, dH_in is the gradient of the new state itself and is taken times (1 - U) -- the state's
 // share of the GRU blend (reference STC_GNN.py:78) -- so the blend backward need not write that product.
-enum { PRO_NONE = 0, PRO_GATES = 1 };
+//
+// With Cand given (and dU null), dH_in is the gradient dHnew of the cell's new state and the prologue also forms the
+// blend's two other products itself: dU = dHnew * (Cand - H) and the state share dHnew * (1 - U) (dh_scaled implied).
+// PRO_BLEND is the candidate convolution's counterpart (hidden 16, Ho = 16): dY = dHnew * U * (1 - Cand^2) is formed per
+// node, so the blend backward pass (stc_gru_blend_bwd_f32) is not run at all.
+enum { PRO_NONE = 0, PRO_GATES = 1, PRO_BLEND = 2, PRO_GATES_CAND = 3 };     // _CAND: dU formed here from (dHnew, Cand, H)
 struct BwdPro {
     const float *dCandIn, *dU, *H, *U, *R, *dH_in;   // (nodes,C,L) and (nodes,C,16) operands; dH_in may be null / alias dH
+    const float* Cand;                                // tanh(candidate): PRO_BLEND, and PRO_GATES when dU is to be formed here
     float *dXt, *dH;                                  // (nodes,C,cin) or null, (nodes,C,16)
     int cin;
     int dh_scaled;                                    // dH_in enters as dH_in * (1 - U)
 };
 
-template <int NRB, int HB, int L>
-__device__ __forceinline__ void load_gates_grad(DyFrag<NRB, HB>& g, const BwdPro& p, int node, int j, int q) {
+template <int NRB, int HB, int L, bool FROM_CAND>      // FROM_CAND is a compile-time switch: a run-time branch here would
+__device__ __forceinline__ void load_gates_grad(DyFrag<NRB, HB>& g, const BwdPro& p, int node, int j, int q) {      // split the load batches
     static_assert(HB == 2, "gates prologue needs Ho = 2 * 16");
     constexpr int C = 16 * NRB, HID = 16;
     const size_t r0 = (size_t)node * C;
@@ -91,31 +97,58 @@ __device__ __forceinline__ void load_gates_grad(DyFrag<NRB, HB>& g, const BwdPro
         for (int t = 0; t < 4; ++t) {
             const size_t row = r0 + 16 * kb + 4 * q + t, e = row * HID + j;
             const float u = p.U[e], r = p.R[e];
-            g.d[kb][0][t] = p.dU[e] * u * (1.f - u);
+            const float du_ = FROM_CAND ? p.dH_in[e] * (p.Cand[e] - p.H[e]) : p.dU[e];
+            g.d[kb][0][t] = du_ * u * (1.f - u);
             g.d[kb][1][t] = p.dCandIn[row * L + p.cin + j] * p.H[e] * r * (1.f - r);
         }
         // row-on-lane layout: row 16kb + j, columns 4q .. 4q+3; this is also where dXt and dH are produced
         const size_t row = r0 + 16 * kb + j, e = row * HID + 4 * q;
         const float4 u = *reinterpret_cast<const float4*>(p.U + e), r = *reinterpret_cast<const float4*>(p.R + e);
-        const float4 du = *reinterpret_cast<const float4*>(p.dU + e), hh = *reinterpret_cast<const float4*>(p.H + e);
+        const float4 hh = *reinterpret_cast<const float4*>(p.H + e);
+        float4 du, own = make_float4(0.f, 0.f, 0.f, 0.f);        // own: what H is owed besides the reset-gate path
+        if (FROM_CAND) {
+            const float4 gn = *reinterpret_cast<const float4*>(p.dH_in + e), cd = *reinterpret_cast<const float4*>(p.Cand + e);
+            du = make_float4(gn.x * (cd.x - hh.x), gn.y * (cd.y - hh.y), gn.z * (cd.z - hh.z), gn.w * (cd.w - hh.w));
+            own = make_float4(gn.x * (1.f - u.x), gn.y * (1.f - u.y), gn.z * (1.f - u.z), gn.w * (1.f - u.w));
+        } else {
+            du = *reinterpret_cast<const float4*>(p.dU + e);
+            if (p.dH_in) {
+                const float4 o = *reinterpret_cast<const float4*>(p.dH_in + e);
+                own = p.dh_scaled ? make_float4(o.x * (1.f - u.x), o.y * (1.f - u.y), o.z * (1.f - u.z), o.w * (1.f - u.w)) : o;
+            }
+        }
         const float* cr = p.dCandIn + row * L;
         float4 d;
         if ((p.cin & 3) == 0) d = *reinterpret_cast<const float4*>(cr + p.cin + 4 * q);
         else d = make_float4(cr[p.cin + 4 * q], cr[p.cin + 4 * q + 1], cr[p.cin + 4 * q + 2], cr[p.cin + 4 * q + 3]);
         g.v[kb][0] = f32x4{du.x * u.x * (1.f - u.x), du.y * u.y * (1.f - u.y), du.z * u.z * (1.f - u.z), du.w * u.w * (1.f - u.w)};
         g.v[kb][1] = f32x4{d.x * hh.x * r.x * (1.f - r.x), d.y * hh.y * r.y * (1.f - r.y), d.z * hh.z * r.z * (1.f - r.z), d.w * hh.w * r.w * (1.f - r.w)};
-        float4 dh = make_float4(d.x * r.x, d.y * r.y, d.z * r.z, d.w * r.w);
-        if (p.dH_in) {
-            const float4 o = *reinterpret_cast<const float4*>(p.dH_in + e);
-            if (p.dh_scaled) { dh.x += o.x * (1.f - u.x); dh.y += o.y * (1.f - u.y); dh.z += o.z * (1.f - u.z); dh.w += o.w * (1.f - u.w); }
-            else { dh.x += o.x; dh.y += o.y; dh.z += o.z; dh.w += o.w; }
-        }
-        *reinterpret_cast<float4*>(p.dH + e) = dh;
+        *reinterpret_cast<float4*>(p.dH + e) = make_float4(d.x * r.x + own.x, d.y * r.y + own.y, d.z * r.z + own.z, d.w * r.w + own.w);
         if (p.dXt)
             for (int c0 = 4 * q; c0 < p.cin; c0 += 16)
 #pragma unroll
                 for (int x = 0; x < 4; ++x)
                     if (c0 + x < p.cin) p.dXt[row * p.cin + c0 + x] = cr[c0 + x];
+    }
+}
+
+// dY of the candidate convolution from the blend (reference STC_GNN.py:76-78): dHnew * U * (1 - Cand^2), both layouts
+template <int NRB>
+__device__ __forceinline__ void load_blend_grad(DyFrag<NRB, 1>& g, const BwdPro& p, int node, int j, int q) {
+    constexpr int C = 16 * NRB, HID = 16;
+    const size_t r0 = (size_t)node * C;
+#pragma unroll
+    for (int kb = 0; kb < NRB; ++kb) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const size_t e = (r0 + 16 * kb + 4 * q + t) * HID + j;
+            const float c = p.Cand[e];
+            g.d[kb][0][t] = p.dH_in[e] * p.U[e] * (1.f - c * c);
+        }
+        const size_t e = (r0 + 16 * kb + j) * HID + 4 * q;
+        const float4 gn = *reinterpret_cast<const float4*>(p.dH_in + e), u = *reinterpret_cast<const float4*>(p.U + e);
+        const float4 c = *reinterpret_cast<const float4*>(p.Cand + e);
+        g.v[kb][0] = f32x4{gn.x * u.x * (1.f - c.x * c.x), gn.y * u.y * (1.f - c.y * c.y), gn.z * u.z * (1.f - c.z * c.z), gn.w * u.w * (1.f - c.w * c.w)};
     }
 }
 

@@ -26,7 +26,7 @@ int stc_cell_blend_fwd_mfma(const float* const* Z, int K, const float* Tc, const
                             const float* U, const float* H, float* Cand, float* Hnew,
                             long long nodes, int C, int L, int Lw, hipStream_t stream);
 int stc_cell_gates_bwd_mfma(const float* const* Z, int K, const float* Tc, const float* W,
-                            const float* dCandIn, const float* dU, const float* H, const float* U, const float* R, const float* dH_in,
+                            const float* dCandIn, const float* dU, const float* H, const float* U, const float* R, const float* dH_in, const float* Cand,
                             float* const* dZ, float* dXt, float* dH, float* partial, int* n_partials, int want_db,
                             long long nodes, int C, int L, int Lw, int cin, int dh_scaled, hipStream_t stream);
 
@@ -44,7 +44,7 @@ int stc_cell_blend_fwd_x3(const float* const* Z, int K, const float* Tc, const f
                           const float* U, const float* H, float* Cand, float* Hnew,
                           long long nodes, int C, int L, int Lw, hipStream_t stream);
 int stc_cell_gates_bwd_x3(const float* const* Z, int K, const float* Tc, const float* W,
-                          const float* dCandIn, const float* dU, const float* H, const float* U, const float* R, const float* dH_in,
+                          const float* dCandIn, const float* dU, const float* H, const float* U, const float* R, const float* dH_in, const float* Cand,
                           float* const* dZ, float* dXt, float* dH, float* partial, int* n_partials, int want_db,
                           long long nodes, int C, int L, int Lw, int cin, int dh_scaled, hipStream_t stream);
 
@@ -59,3 +59,13 @@ int stc_cell_blend_fwd_gather_x3(const int* rowptr, const int* colidx, const flo
                                  const float* Z0, float* Z1, const float* Tc, const float* W, const float* bias,
                                  const float* U, const float* H, float* Cand, float* Hnew,
                                  long long nodes, int C, int L, int Lw, hipStream_t stream);
+
+// Candidate convolution's backward with the blend backward as its prologue (hidden 16): dY = dHnew * U * (1 - Cand^2).
+int stc_cell_cand_bwd_mfma(const float* const* Z, int K, const float* Tc, const float* W,
+                           const float* dHnew, const float* U, const float* Cand,
+                           float* const* dZ, float* partial, int* n_partials, int want_db,
+                           long long nodes, int C, int L, int Lw, hipStream_t stream);
+int stc_cell_cand_bwd_x3(const float* const* Z, int K, const float* Tc, const float* W,
+                         const float* dHnew, const float* U, const float* Cand,
+                         float* const* dZ, float* partial, int* n_partials, int want_db,
+                         long long nodes, int C, int L, int Lw, hipStream_t stream);

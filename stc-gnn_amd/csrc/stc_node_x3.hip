@@ -421,7 +421,8 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
     while (node < nodes) {
         const int next_node = node + nw;
         const size_t r0 = (size_t)node * C;
-        if constexpr (PRO == PRO_GATES) { load_gates_grad<NRB, HB, L>(in.g, pro, node, x, g); in.load_z(Z, node, x, g); }
+        if constexpr (PRO == PRO_GATES || PRO == PRO_GATES_CAND) { load_gates_grad<NRB, HB, L, PRO == PRO_GATES_CAND>(in.g, pro, node, x, g); in.load_z(Z, node, x, g); }
+        else if constexpr (PRO == PRO_BLEND) { load_blend_grad<NRB>(in.g, pro, node, x, g); in.load_z(Z, node, x, g); }
         else if (!PF) { in.g.load(dY, node, x, g); in.load_z(Z, node, x, g); }
         if (PF && next_node < nodes) { nx.g.load(dY, next_node, x, g); nx.load_z(Z, next_node, x, g); }
         if (PF) __builtin_amdgcn_sched_barrier(0);
@@ -669,20 +670,38 @@ int stc_cell_blend_fwd_x3(const float* const* Z, int K, const float* Tc, const f
 }
 
 int stc_cell_gates_bwd_x3(const float* const* Z, int K, const float* Tc, const float* W,
-                          const float* dCandIn, const float* dU, const float* H, const float* U, const float* R, const float* dH_in,
+                          const float* dCandIn, const float* dU, const float* H, const float* U, const float* R, const float* dH_in, const float* Cand,
                           float* const* dZ, float* dXt, float* dH, float* partial, int* n_partials, int want_db,
                           long long nodes, int C, int L, int Lw, int cin, int dh_scaled, hipStream_t stream) {
     if (!x3_cell_shape(K, C, L, nodes) || !all_aligned16(Z, K)) return STC_NOT_HANDLED;
     for (int n = 0; n < K; ++n)
         if (!stc::aligned16(dZ[n])) return STC_NOT_HANDLED;
-    if (!(stc::aligned16(dCandIn) && stc::aligned16(dU) && stc::aligned16(H) && stc::aligned16(U) && stc::aligned16(R) &&
+    if (!(stc::aligned16(dCandIn) && (!dU || stc::aligned16(dU)) && (!Cand || stc::aligned16(Cand)) && stc::aligned16(H) && stc::aligned16(U) && stc::aligned16(R) &&
           stc::aligned16(dH) && (!dH_in || stc::aligned16(dH_in))))
         return STC_NOT_HANDLED;
     BwdPro pro{};
+    pro.Cand = Cand;
     pro.dCandIn = dCandIn; pro.dU = dU; pro.H = H; pro.U = U; pro.R = R; pro.dH_in = dH_in; pro.dXt = dXt; pro.dH = dH; pro.cin = cin; pro.dh_scaled = dh_scaled;
-#define GBWD_CALL(a, c, d) launch_bwd<a, 2, c, d, PRO_GATES>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro)
+#define GBWD_CALL(a, c, d) (Cand ? launch_bwd<a, 2, c, d, PRO_GATES_CAND>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro) \
+                                 : launch_bwd<a, 2, c, d, PRO_GATES>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro))
     STC_X3_EPI_CASE(1, GBWD_CALL) STC_X3_EPI_CASE(2, GBWD_CALL) STC_X3_EPI_CASE3(GBWD_CALL)
 #undef GBWD_CALL
+    return STC_NOT_HANDLED;
+}
+
+int stc_cell_cand_bwd_x3(const float* const* Z, int K, const float* Tc, const float* W,
+                         const float* dHnew, const float* U, const float* Cand,
+                         float* const* dZ, float* partial, int* n_partials, int want_db,
+                         long long nodes, int C, int L, int Lw, hipStream_t stream) {
+    if (!x3_cell_shape(K, C, L, nodes) || !all_aligned16(Z, K)) return STC_NOT_HANDLED;
+    for (int n = 0; n < K; ++n)
+        if (!stc::aligned16(dZ[n])) return STC_NOT_HANDLED;
+    if (!(stc::aligned16(dHnew) && stc::aligned16(U) && stc::aligned16(Cand))) return STC_NOT_HANDLED;
+    BwdPro pro{};
+    pro.dH_in = dHnew; pro.U = U; pro.Cand = Cand;
+#define CBWD_CALL(a, c, d) launch_bwd<a, 1, c, d, PRO_BLEND>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro)
+    STC_X3_EPI_CASE(1, CBWD_CALL) STC_X3_EPI_CASE(2, CBWD_CALL) STC_X3_EPI_CASE3(CBWD_CALL)
+#undef CBWD_CALL
     return STC_NOT_HANDLED;
 }
 

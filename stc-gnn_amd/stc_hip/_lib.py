@@ -28,7 +28,7 @@ EXPORTS = (
     'stc_csr_spmm_f32', 'stc_bcsr_spmm_f32', 'stc_spmm_bwd_gates_f32', 'stc_spmm_bwd_split_f32', 'stc_csr_sddmm_f32',
     'stc_cheby_dense_fwd_f32', 'stc_cheby_dense_bwd_f32',
     'stc_bdg_node_fwd_f32', 'stc_bdg_node_bwd_workspace_bytes', 'stc_bdg_node_bwd_f32',
-    'stc_cell_fused_supported', 'stc_cell_gates_fwd_f32', 'stc_cell_gates_bwd_f32', 'stc_cell_blend_fwd_f32',
+    'stc_cell_fused_supported', 'stc_cell_gates_fwd_f32', 'stc_cell_gates_bwd_f32', 'stc_cell_cand_bwd_f32', 'stc_cell_blend_fwd_f32',
     'stc_cell_gather_supported', 'stc_cell_gates_fwd_gather_f32', 'stc_cell_blend_fwd_gather_f32',
     'stc_gru_gates_fwd_f32', 'stc_gru_gates_bwd_f32', 'stc_gru_blend_fwd_f32', 'stc_gru_blend_bwd_f32',
     'stc_head_fwd_f32', 'stc_head_bwd_workspace_bytes', 'stc_head_bwd_f32',
@@ -63,7 +63,8 @@ def _declare(lib):
         'stc_bdg_node_bwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, C.POINTER(_p), _p, _p, _p,
                                  _p, C.c_size_t, _i64, _i32, _i32, _i32, _i32, _p],
         'stc_cell_gates_fwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _i32, _p],
-        'stc_cell_gates_bwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _i32, C.POINTER(_p), _p, _p, _p, _p,
+        'stc_cell_cand_bwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _p, C.POINTER(_p), _p, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _i32, _p],
+        'stc_cell_gates_bwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _i32, C.POINTER(_p), _p, _p, _p, _p,
                                    _p, C.c_size_t, _i64, _i32, _i32, _i32, _i32, _i32, _p],
         'stc_cell_blend_fwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
         'stc_cell_gates_fwd_gather_f32': [_p, _p, _p, _i64] + [_p] * 9 + [_i64, _i32, _i32, _i32, _i32, _i32, _p],
@@ -382,17 +383,21 @@ class HipKernels:
         self._launch('stc_cell_gates_fwd_f32', H, self._ptr_array(Zs), Ks, _ptr(Tc), Kc, _ptr(W), _ptr(bias), _ptr(H),
                      _ptr(U), _ptr(Rg), _ptr(CandIn), R, Cc, L, Lw, h, cin)
 
-    def cell_gates_bwd(self, Zs, Tc, W, dCandIn, dU, H, U, Rg, dH_in, dZs, dW, db, dXt, dH, dH_in_scaled=False):
+    def cell_gates_bwd(self, Zs, Tc, W, dCandIn, dU, H, U, Rg, dH_in, dZs, dW, db, dXt, dH, dH_in_scaled=False, Cand=None):
         """Gate backward as the prologue of the gates convolution's node backward (stc_cell_gates_bwd_f32).
-        ``dXt`` may be None (not written); ``dH_in_scaled``: dH_in enters times (1 - U)."""
+        ``dXt`` may be None (not written); ``dH_in_scaled``: dH_in enters times (1 - U); with ``Cand`` (and dU None)
+        dH_in is dHnew and dU = dHnew * (Cand - H) is formed inside."""
+        if (dU is None) == (Cand is None):
+            raise StcError('cell_gates_bwd: give either dU or Cand')
         Ks, Kc, R, Cc, L, Lw, Ho = self._node_shapes(Zs, Tc, W)
         h = H.shape[-1]
         cin = Lw - h
         if Ho != 2 * h or cin < 0 or len(dZs) != Ks:
             raise StcError(f'cell_gates_bwd: W gives Ho={Ho}, Lw={Lw} for hidden {h}; {len(dZs)} gradient slabs')
         self._f32('cell.dCandIn', dCandIn, (R, Cc, L))
-        for name, t in (('dU', dU), ('H', H), ('U', U), ('Rg', Rg), ('dH', dH)) + ((('dH_in', dH_in),) if dH_in is not None else ()):
-            self._f32('cell.' + name, t, (R, Cc, h))
+        for name, t in (('dU', dU), ('Cand', Cand), ('H', H), ('U', U), ('Rg', Rg), ('dH', dH), ('dH_in', dH_in)):
+            if t is not None:
+                self._f32('cell.' + name, t, (R, Cc, h))
         if dXt is not None:
             self._f32('cell.dXt', dXt, (R, Cc, cin))
         for i, z in enumerate(dZs):
@@ -400,11 +405,29 @@ class HipKernels:
         self._f32('cell.dW', dW, (Ks * Kc * Lw, Ho))
         if db is not None:
             self._f32('cell.db', db, (Ho,))
-        self._same_device(*Zs, Tc, W, dCandIn, dU, H, U, Rg, dH_in, *dZs, dW, db, dXt, dH)
+        self._same_device(*Zs, Tc, W, dCandIn, dU, H, U, Rg, dH_in, Cand, *dZs, dW, db, dXt, dH)
         ws = self._get_workspace(H.device, self.lib.stc_bdg_node_bwd_workspace_bytes(Ks, Kc, Cc, L, Ho, 0))
         self._launch('stc_cell_gates_bwd_f32', H, self._ptr_array(Zs), Ks, _ptr(Tc), Kc, _ptr(W), _ptr(dCandIn), _ptr(dU), _ptr(H),
-                     _ptr(U), _ptr(Rg), _ptr(dH_in), int(bool(dH_in_scaled)), self._ptr_array(dZs), _ptr(dW), _ptr(db), _ptr(dXt), _ptr(dH),
+                     _ptr(U), _ptr(Rg), _ptr(Cand), _ptr(dH_in), int(bool(dH_in_scaled)), self._ptr_array(dZs), _ptr(dW), _ptr(db), _ptr(dXt), _ptr(dH),
                      _ptr(ws), ws.numel(), R, Cc, L, Lw, h, cin)
+
+    def cell_cand_bwd(self, Zs, Tc, W, dHnew, U, Cand, dZs, dW, db):
+        """Blend backward as the prologue of the candidate convolution's node backward (stc_cell_cand_bwd_f32)."""
+        Ks, Kc, R, Cc, L, Lw, Ho = self._node_shapes(Zs, Tc, W)
+        h = U.shape[-1]
+        if Ho != h or len(dZs) != Ks:
+            raise StcError(f'cell_cand_bwd: W gives Ho={Ho} for hidden {h}; {len(dZs)} gradient slabs')
+        for name, t in (('dHnew', dHnew), ('U', U), ('Cand', Cand)):
+            self._f32('cell.' + name, t, (R, Cc, h))
+        for i, z in enumerate(dZs):
+            self._f32(f'cell.dZ[{i}]', z, (R, Cc, L))
+        self._f32('cell.dW', dW, (Ks * Kc * Lw, Ho))
+        if db is not None:
+            self._f32('cell.db', db, (Ho,))
+        self._same_device(*Zs, Tc, W, dHnew, U, Cand, *dZs, dW, db)
+        ws = self._get_workspace(U.device, self.lib.stc_bdg_node_bwd_workspace_bytes(Ks, Kc, Cc, L, Ho, 0))
+        self._launch('stc_cell_cand_bwd_f32', U, self._ptr_array(Zs), Ks, _ptr(Tc), Kc, _ptr(W), _ptr(dHnew), _ptr(U), _ptr(Cand),
+                     self._ptr_array(dZs), _ptr(dW), _ptr(db), _ptr(ws), ws.numel(), R, Cc, L, Lw, h)
 
     def cell_blend_fwd(self, Zs, Tc, W, bias, U, H, Cand, Hnew):
         Ks, Kc, R, Cc, L, Lw, Ho = self._node_shapes(Zs, Tc, W)

@@ -110,7 +110,7 @@ def _bdg_forward(X, W, b, Tc, fwd_val, op: SpatialOperand, Ks: int):
     return Y, Zs
 
 
-def _bdg_backward_slabs(dY, Zs, W, Tc, op: SpatialOperand, Ks: int, has_bias: bool, need_Tc: bool, need_val: bool, gates=None):
+def _bdg_backward_slabs(dY, Zs, W, Tc, op: SpatialOperand, Ks: int, has_bias: bool, need_Tc: bool, need_val: bool, gates=None, cand=None):
     """Node-kernel backward and every hop of the Chebyshev recurrence but the last.
 
     Returns (g, dW, db | None, dTc | None, dval | None) with g = [g_0, g_1, ...] such that
@@ -127,8 +127,11 @@ def _bdg_backward_slabs(dY, Zs, W, Tc, op: SpatialOperand, Ks: int, has_bias: bo
     dTc = torch.empty_like(Tc) if need_Tc else None
     rows = lambda ts: [t.view(B * N, C, t.shape[-1]) for t in ts]
     if gates is not None:       # dY = gate pre-activation gradient, formed inside the kernel from (dCandIn, dU, H, U, R)
-        dCandIn, dU, H, U, Rg, dHnew, dH = gates     # dH = dCandIn[h part] * R + dHnew * (1 - U); dXt stays inside dCandIn
-        k.cell_gates_bwd(rows(Zs), Tc, W, *rows((dCandIn, dU, H, U, Rg, dHnew)), rows(dZ), dW, db, None, *rows((dH,)), dH_in_scaled=True)
+        dCandIn, Cand, H, U, Rg, dHnew, dH = gates   # dU = dHnew * (Cand - H); dH = dCandIn[h part] * R + dHnew * (1 - U); dXt stays in dCandIn
+        dCandIn, Cand, H, U, Rg, dHnew, dH = rows((dCandIn, Cand, H, U, Rg, dHnew, dH))
+        k.cell_gates_bwd(rows(Zs), Tc, W, dCandIn, None, H, U, Rg, dHnew, rows(dZ), dW, db, None, dH, dH_in_scaled=True, Cand=Cand)
+    elif cand is not None:      # dY = dHnew * U * (1 - Cand^2), formed inside the kernel
+        k.cell_cand_bwd(rows(Zs), Tc, W, *rows(cand), rows(dZ), dW, db)
     else:
         dY = _c(dY)
         k.bdg_node_bwd(rows(Zs), Tc, W, dY.view(B * N, C, Ho), rows(dZ), dW, db, dTc)
@@ -373,12 +376,17 @@ class _StcCell(Function):
         # dXt = d[x part] (left in place, added by the final split straight from the candidate gradient's rows)
         pro = not fuse and not (need_Tc or need_val) and k.cell_fused_supported(Ks, Tc.shape[0], C, L, H.shape[-1])
         dHnew = _c(dHnew)
-        dCpre, dU, dH = torch.empty_like(H), torch.empty_like(H), torch.empty_like(H)
-        k.gru_blend_bwd(dHnew, U, H, Cand, dCpre, dU, None if pro else dH)        # dH = dHnew * (1 - U)
-        dG = None if pro else H.new_empty(H.shape[:-1] + (2 * H.shape[-1],))
+        dH = torch.empty_like(H)
         dXt = H.new_empty(H.shape[:-1] + (cin,))
-        # candidate convolution: d[Xt | R*H] = g0 + Gs.g1, consumed by the gate backward
-        g, dWc, dbc, dTc, dval = _bdg_backward_slabs(dCpre, Zc, Wc, Tc, op, Ks, ctx.bias[1], need_Tc, need_val)
+        if pro:         # the blend backward (dCpre, dU, the state share) is formed inside the two node backward kernels
+            dCpre = dU = dG = None
+            g, dWc, dbc, dTc, dval = _bdg_backward_slabs(None, Zc, Wc, Tc, op, Ks, ctx.bias[1], False, False, cand=(dHnew, U, Cand))
+        else:
+            dCpre, dU = torch.empty_like(H), torch.empty_like(H)
+            k.gru_blend_bwd(dHnew, U, H, Cand, dCpre, dU, dH)                     # dH = dHnew * (1 - U)
+            dG = H.new_empty(H.shape[:-1] + (2 * H.shape[-1],))
+            # candidate convolution: d[Xt | R*H] = g0 + Gs.g1, consumed by the gate backward
+            g, dWc, dbc, dTc, dval = _bdg_backward_slabs(dCpre, Zc, Wc, Tc, op, Ks, ctx.bias[1], need_Tc, need_val)
         gates_pro, dci = None, g[0]
         if fuse:
             k.spmm_bwd_gates(*bwd, v3(g[1]), v3(g[0]), dU, H, U, Rg, dH, dG, dXt, dH)   # dH += d[h part] * R ; dXt = d[x part]
@@ -386,7 +394,7 @@ class _StcCell(Function):
             if Ks > 1:
                 k.csr_spmm(*bwd[:3], N, N, v3(g[1]), v3(g[0]), v3(g[0]), 1.0, 1.0, plan=op.bwd_plan)
             if pro:
-                gates_pro = (dci, dU, H, U, Rg, dHnew, dH)
+                gates_pro = (dci, Cand, H, U, Rg, dHnew, dH)
             else:
                 k.gru_gates_bwd(dci, dU, H, U, Rg, dG, dXt, dH, dH_in=dH)
         # gates convolution: d[Xt | H] = g0 + Gs.g1, split and added to what Xt and H are already owed

@@ -465,6 +465,43 @@ def test_fused_gates_backward_prologue(hip, nodes, C, cin, K, fused_path):
     assert rel_err(dH3, dH_w - owed + owed * (1 - U)) < TOL
     for a, w in zip(dZ, dZ_w):
         assert rel_err(a, w) < TOL
+    # Cand form: dH_in is dHnew; dU = dHnew * (Cand - H) and the state share are formed inside (no blend backward pass)
+    Cand = torch.tanh(rnd(nodes, C, h))
+    dH_w4 = torch.empty(nodes, C, h)
+    EM.cell_gates_bwd(Zs, Tc, W, dCand, None, H, U, R, owed, dZ_w, dW_w, db_w, None, dH_w4, Cand=Cand)
+    dH4 = torch.full((nodes, C, h), nan).cuda()
+    hip.cell_gates_bwd([cu(z) for z in Zs], cu(Tc), cu(W), cu(dCand), None, cu(H), cu(U), cu(R), cu(owed), dZ, dW, db, None, dH4,
+                       dH_in_scaled=True, Cand=cu(Cand))
+    for a, w in zip(dZ, dZ_w):
+        assert rel_err(a, w) < TOL
+    assert rel_err(dW, dW_w) < TOL and rel_err(db, db_w) < TOL and rel_err(dH4, dH_w4) < TOL
+
+
+@pytest.mark.parametrize('nodes,C,cin,K', [(50, 32, 16, 2), (50, 32, 1, 2), (21, 16, 16, 3), (13, 64, 1, 2), (4500, 32, 16, 2), (9, 32, 13, 1)])
+def test_fused_candidate_backward_prologue(hip, nodes, C, cin, K, fused_path):
+    """Blend backward as the prologue of the candidate convolution's node backward vs blend kernel + node backward of the twin."""
+    h = 16
+    Lw = cin + h
+    L = Lw + (-Lw) % 4
+    g = torch.Generator().manual_seed(nodes + C + cin + K + 2)
+    rnd = lambda *s_: torch.randn(*s_, generator=g)
+    Zs = [rnd(nodes, C, L) for _ in range(K)]
+    Tc = rnd(K, C, C) / C ** 0.5
+    Tc[0] = torch.eye(C)
+    W = rnd(K * K * Lw, h) / (K * K * Lw) ** 0.5
+    dHn, U, Cand = rnd(nodes, C, h), torch.rand(nodes, C, h, generator=g), torch.tanh(rnd(nodes, C, h))
+    dZ_w = [torch.empty(nodes, C, L) for _ in range(K)]
+    dW_w, db_w = torch.empty_like(W), torch.empty(h)
+    EM.cell_cand_bwd(Zs, Tc, W, dHn, U, Cand, dZ_w, dW_w, db_w)
+    nan = float('nan')
+    dZ = [torch.full((nodes, C, L), nan).cuda() for _ in range(K)]
+    dW, db = torch.full_like(W, nan).cuda(), torch.full((h,), nan).cuda()
+    hip.cell_cand_bwd([cu(z) for z in Zs], cu(Tc), cu(W), cu(dHn), cu(U), cu(Cand), dZ, dW, db)
+    for a, w in zip(dZ, dZ_w):
+        assert rel_err(a, w) < TOL
+    assert rel_err(dW, dW_w) < TOL and rel_err(db, db_w) < TOL
+    hip.cell_cand_bwd([cu(z) for z in Zs], cu(Tc), cu(W), cu(dHn), cu(U), cu(Cand), dZ, dW, None)      # convolution without bias
+    assert rel_err(dW, dW_w) < TOL
 
 
 def test_fused_cell_unsupported_shapes_are_refused(hip, monkeypatch):
