@@ -178,7 +178,7 @@ def main():
                          'algorithmic_bytes_per_launch': spmm['bytes'] / max(1, spmm['launches'])},
             'kernels': {k: {'launches': d['launches'], 'ms_per_step': d['ms'] / a.steps,
                             'share': d['ms'] / total_ms} for k, d in sorted(per_kernel.items(), key=lambda kv: -kv[1]['ms'])},
-            'loss': float(loss),
+            'loss': float(loss.detach()),
         }
         if world == 1 and not a.no_cpu_baseline:
             GsT = graph.to_dense().t().contiguous().to_sparse_csr() if N <= 4096 else _sparse_T(graph)

@@ -108,13 +108,19 @@ def allreduce_sum(x: torch.Tensor, group=None) -> torch.Tensor:
 
 
 def init_from_env(backend: str = None) -> tuple:
-    """(rank, world, local_rank) from torchrun's environment; initialises the process group when world > 1."""
+    """(rank, world, local_rank) from torchrun's environment; initialises the process group when world > 1.
+
+    Test hooks (a 1-GPU box cannot run RCCL between two ranks): ``STC_DIST_BACKEND=gloo`` forces the backend and
+    ``STC_DIST_ONE_DEVICE=1`` maps every rank onto device 0, so the N > 1 code path can be exercised on one GPU."""
     import os
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if os.environ.get('STC_DIST_ONE_DEVICE') == '1':
+        local = 0
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        backend = backend or os.environ.get('STC_DIST_BACKEND')
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         if backend == 'nccl':
