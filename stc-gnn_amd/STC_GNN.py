@@ -199,17 +199,48 @@ class STC_Decoder(nn.Module):
         return x, new_states
 
 
+class FactorisedLinear(nn.Module):
+    """y = U (V^T x) + b: a rank-r stand-in for ``Linear(d, d)`` with 2 d r + d parameters instead of d^2 + d.
+
+    Not in the reference: its ``MixedFusion`` gates every entry of an n x n graph with two dense
+    ``Linear(n^2, n^2)`` layers -- 2 n^4 parameters, 2 x 10^8 at n = 100 and out of reach beyond n ~ 300.  With the
+    factors, n = 1000 costs 2 x 32 M parameters at rank 16.  Initialised like ``nn.Linear`` would initialise the product.
+    """
+
+    def __init__(self, dim: int, rank: int):
+        super().__init__()
+        if rank < 1:
+            raise ValueError(f'rank must be positive, got {rank}')
+        self.dim, self.rank = dim, rank
+        bound = (1.0 / dim) ** 0.5
+        self.U = nn.Parameter(torch.empty(dim, rank).uniform_(-1, 1) * (bound / rank) ** 0.5)
+        self.V = nn.Parameter(torch.empty(dim, rank).uniform_(-1, 1) * (bound / rank) ** 0.5)
+        self.bias = nn.Parameter(torch.empty(dim).uniform_(-bound, bound))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return torch.mv(self.U, torch.mv(self.V.t(), x)) + self.bias
+
+    def dense_weight(self) -> torch.Tensor:
+        """The (dim, dim) weight this layer stands for (small dims / tests only)."""
+        return self.U @ self.V.t()
+
+
 class MixedFusion(nn.Module):
     """Element-wise gated mix of a prior graph A and a learned graph P (reference ``STC_GNN.py:246-261``).
 
-    Two ``Linear(n^2, n^2)`` layers: usable for small n only; stays on torch (rocBLAS GEMV).
+    Two ``Linear(n^2, n^2)`` layers: usable for small n only; stays on torch (rocBLAS GEMV).  ``rank`` (not in the
+    reference) replaces them by rank-r factors so that a learned graph is affordable beyond n ~ 300.
     """
 
-    def __init__(self, in_dim: int):
+    def __init__(self, in_dim: int, rank: Optional[int] = None):
         super().__init__()
         self.in_dim = in_dim
-        self.lin_A = nn.Linear(in_dim ** 2, in_dim ** 2)
-        self.lin_P = nn.Linear(in_dim ** 2, in_dim ** 2)
+        if rank is None:
+            self.lin_A = nn.Linear(in_dim ** 2, in_dim ** 2)
+            self.lin_P = nn.Linear(in_dim ** 2, in_dim ** 2)
+        else:
+            self.lin_A = FactorisedLinear(in_dim ** 2, rank)
+            self.lin_P = FactorisedLinear(in_dim ** 2, rank)
 
     def forward(self, A: torch.Tensor, P: torch.Tensor):
         assert A.dim() == 2 and P.dim() == 2
@@ -221,12 +252,12 @@ class MixedFusion(nn.Module):
 class MGP_Gen(nn.Module):
     """Learned mixed graph pair (Gs, Gc) from the input window (reference ``STC_GNN.py:210-243``)."""
 
-    def __init__(self, num_nodes: int, num_categories: int, hidden_dim: int, alpha: int = 3):
+    def __init__(self, num_nodes: int, num_categories: int, hidden_dim: int, alpha: int = 3, fusion_rank: Optional[int] = None):
         super().__init__()
         self.alpha = alpha
         self.batch_sharded = False      # True: the batch is split over ranks -> all-reduce the batch-summed pre-activation
         self.params_S = self.init_params(num_categories, hidden_dim)
-        self.aggreg_S = MixedFusion(num_nodes)
+        self.aggreg_S = MixedFusion(num_nodes, fusion_rank)         # only the N x N fusion is the 2 N^4 problem
         self.params_C = self.init_params(num_nodes, hidden_dim)
         self.aggreg_C = MixedFusion(num_categories)
 
@@ -260,7 +291,8 @@ class STCGNN(nn.Module):
 
     def __init__(self, num_nodes: int, num_categories: int, Ks: int, Kc: int, input_dim: int, hidden_dim: int,
                  num_layers: int, out_horizon: int, use_bias=True, activation=None,
-                 graph_mode: str = 'dense-learned', reorder_nodes: bool = True, batch_sharded: bool = False):
+                 graph_mode: str = 'dense-learned', reorder_nodes: bool = True, batch_sharded: bool = False,
+                 fusion_rank: Optional[int] = None):
         super().__init__()
         if graph_mode not in ('dense-learned', 'csr-fixed'):
             raise ValueError("graph_mode must be 'dense-learned' (reference semantics) or 'csr-fixed'")
@@ -268,7 +300,7 @@ class STCGNN(nn.Module):
         self.reorder_nodes = reorder_nodes      # csr-fixed + CsrGraph: renumber nodes internally when that restores locality
         self.Ks, self.Kc = Ks, Kc
         if graph_mode == 'dense-learned':
-            self.mix_graph_pair = MGP_Gen(num_nodes, num_categories, hidden_dim)
+            self.mix_graph_pair = MGP_Gen(num_nodes, num_categories, hidden_dim, fusion_rank=fusion_rank)   # rank: SURVEY 8(f3)
             self.mix_graph_pair.batch_sharded = batch_sharded
         self.encoder = STC_Encoder(num_nodes, num_categories, Ks, Kc, input_dim, hidden_dim, num_layers,
                                    use_bias, activation, return_all_layers=True)

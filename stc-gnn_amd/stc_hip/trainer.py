@@ -92,14 +92,23 @@ class Trainer:
         self.model.load_state_dict(ckpt['state_dict'])
         self.model.eval()
         out = {}
+        from . import metrics as smetrics
         for mode in modes:
             pred, truth = [], []
-            for x_seq, y_true in data_loader[mode]:
-                pred.append(self._forward(x_seq).cpu().numpy())
-                truth.append(y_true.cpu().numpy())
-            pred, truth = np.concatenate(pred, 0), np.concatenate(truth, 0)
+            with torch.no_grad():
+                for x_seq, y_true in data_loader[mode]:
+                    pred.append(self._forward(x_seq))
+                    truth.append(y_true)
+            pred_d, truth_d = torch.cat(pred, 0), torch.cat(truth, 0)        # stay on the device for the evaluation
+            pred, truth = pred_d.cpu().numpy(), truth_d.cpu().numpy()
             eps = 1e-7
             bce = float(-(truth * np.log(np.clip(pred, eps, 1)) + (1 - truth) * np.log(np.clip(1 - pred, eps, 1))).mean())
             out[mode] = dict(forecast=pred, ground_truth=truth, bce=bce, mae=float(np.abs(pred - truth).mean()),
                              epoch=ckpt['epoch'])
+            if self.threshold is not None:
+                # the reference's evaluation protocol (Model_Trainer.py:148-154): masked cells dropped, per-step metrics
+                H, W = self.params['H'], self.params['W']
+                mask = None if self.mask is None else [tuple(int(v) for v in m) for m in np.asarray(self.mask).reshape(-1, 2)]
+                out[mode]['metrics'] = smetrics.evaluate_binary(smetrics.mask_data(pred_d, H, W, mask),
+                                                                 smetrics.mask_data(truth_d, H, W, mask), list(np.asarray(self.threshold)))
         return out

@@ -313,3 +313,28 @@ def test_shape_errors_are_python_exceptions():
         M.STCGNN(12, 3, 2, 2, 1, 4, 2, 2).to(DEV)(t(2, 4, 12), t(12, 12), t(3, 3))
     with pytest.raises(ValueError):
         M.STCGNN(12, 3, 2, 2, 1, 4, 2, 2, graph_mode='nope')
+
+
+def test_factorised_mixed_fusion_option(dev):
+    """rank-r MixedFusion.  (1) it IS the dense layer with weight U V^T; (2) a learned-graph model with it
+    runs forward/backward through the kernels; (3) n = 1000 is affordable (the dense form: 2 x 10^12 parameters)."""
+    torch.manual_seed(5)
+    n, r = 6, 3
+    fact, dense = M.MixedFusion(n, rank=r), M.MixedFusion(n)
+    with torch.no_grad():
+        for name in ('lin_A', 'lin_P'):
+            getattr(dense, name).weight.copy_(getattr(fact, name).dense_weight())
+            getattr(dense, name).bias.copy_(getattr(fact, name).bias)
+    A, P = torch.rand(n, n), torch.softmax(torch.randn(n, n), -1)
+    assert float((fact(A, P) - dense(A, P)).abs().max()) < 1e-6
+    N, C = 40, 3
+    model = M.STCGNN(N, C, 2, 2, 1, 4, 1, 2, fusion_rank=4).to(DEV)
+    assert not any(p.numel() > 2 * N * N * 4 + N * N for p in model.parameters())           # no N^2 x N^2 weight anywhere
+    X = (torch.rand(2, 3, N, C) < 0.3).float().to(DEV)
+    As, Ac = (torch.rand(N, N) < 0.2).float().to(DEV), torch.rand(C, C).to(DEV)
+    out = model(X_seq=X, As=As, Ac=Ac)
+    out.sum().backward()
+    assert out.shape == (2, 2, N, C) and all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+    if DEV == 'cpu':
+        big = M.MixedFusion(1000, rank=8)
+        assert sum(p.numel() for p in big.parameters()) == 2 * (2 * 10 ** 6 * 8 + 10 ** 6)

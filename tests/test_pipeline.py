@@ -76,6 +76,8 @@ def test_trainer_reproduces_the_reference_epoch_losses(tmp_path, monkeypatch):
     assert os.path.basename(trainer.checkpoint_path) == 'STC-GNN-4.pkl'
     res = trainer.test(loaders)
     assert res['test']['forecast'].shape == (loaders['test'].length, 2, 6, 2) and 0 < res['test']['bce'] < 2
+    if 'metrics' in res['test']:                                # the reference's evaluation protocol, one dict per horizon step
+        assert len(res['test']['metrics']) == 2 and set(res['test']['metrics'][0]) >= {'Macro-F1', 'Micro-F2', 'ROC-AUC', 'PR-AUC', 'BCE', 'MAE'}
 
 
 def test_trainer_refuses_cpu_device():
@@ -154,17 +156,23 @@ def test_hip_graph_replay_of_a_train_step_equals_eager(monkeypatch):
         assert torch.equal(a, b), k
 
 
-def test_metrics_match_the_reference():
-    """mask_data and the per-step metric dict equal the reference's (scikit-learn based) values."""
+@pytest.mark.parametrize('where', ['numpy', 'cpu', pytest.param('cuda', marks=pytest.mark.gpu)])
+def test_metrics_match_the_reference(where):
+    """mask_data and the per-step metric dict equal the reference's (scikit-learn based) values; the work
+    runs on the device the predictions live on."""
     from stc_hip import metrics as smetrics
     from tests.golden.make_golden import metrics_inputs
     g = load_golden('g10_metrics')
     prob, true, thr, mask, H, W = metrics_inputs()
-    pm, tm = smetrics.mask_data(prob, H, W, mask), smetrics.mask_data(true, H, W, mask)
-    assert np.array_equal(pm, g['prob_masked'].numpy()) and np.array_equal(tm, g['true_masked'].numpy())
-    assert np.array_equal(smetrics.mask_data(prob, H, W, None), g['unmasked'].numpy())
+    conv = (lambda a: a) if where == 'numpy' else (lambda a: torch.from_numpy(a).to(where))
+    host = (lambda a: a) if where == 'numpy' else (lambda a: a.cpu().numpy())
+    pm, tm = smetrics.mask_data(conv(prob), H, W, mask), smetrics.mask_data(conv(true), H, W, mask)
+    if where != 'numpy':
+        assert pm.device.type == where
+    assert np.array_equal(host(pm), g['prob_masked'].numpy()) and np.array_equal(host(tm), g['true_masked'].numpy())
+    assert np.array_equal(host(smetrics.mask_data(conv(prob), H, W, None)), g['unmasked'].numpy())
     grid = prob.reshape(prob.shape[0], prob.shape[1], H, W, -1).transpose(0, 1, 4, 2, 3)      # (S, hor, C, H, W) layout
-    assert np.array_equal(smetrics.mask_data(grid, H, W, mask), pm)
+    assert np.array_equal(host(smetrics.mask_data(conv(np.ascontiguousarray(grid)), H, W, mask)), host(pm))
     steps = smetrics.evaluate_binary(pm, tm, list(thr))
     for s, got in enumerate(steps):
         assert list(got.keys()) == list(g[f'names{s}'])
