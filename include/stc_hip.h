@@ -187,9 +187,16 @@ int stc_cell_cand_bwd_f32(const float* const* Z, int32_t Ks, const float* Tc, in
                           float* const* dZ, float* dW, float* db,
                           void* workspace, size_t workspace_bytes,
                           int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t h, void* stream);
+/* Optional state copies (torch.cat of STC_GNN.py:68 done by the producer): besides Hnew, the new state is written into
+ * columns [off, off+h) of rows of ld floats of up to two more buffers -- the [Xt | H | pad] input rows of the cells that
+ * consume it, which then need no stc_concat2_f32 pass.  copy0 may also have its other columns completed: with side_src
+ * (nodes, C, side_cin; side_cin == copy0_off) columns [0, side_cin) are copied from it and the pad columns
+ * [side_cin+h, copy0_ld) zeroed.  Null copy pointers = none. */
 int stc_cell_blend_fwd_f32(const float* const* Z, int32_t Ks, const float* Tc, int32_t Kc,
                            const float* W, const float* bias, const float* U, const float* H,
                            float* Cand, float* Hnew,
+                           float* copy0, int32_t copy0_ld, int32_t copy0_off, const float* side_src, int32_t side_cin,
+                           float* copy1, int32_t copy1_ld, int32_t copy1_off,
                            int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t h, void* stream);
 
 /* ---- the same two cell convolutions with the graph aggregation fused in (Ks = Kc = 2) ------------------------------
@@ -230,10 +237,12 @@ int stc_axpy_f32(float a, const float* x, float* y, int64_t n, void* stream);
 /* out (rows, a+b+pad) = [A (rows,a) | B (rows,b) | zeros]   (torch.cat of STC_GNN.py:68) and its inverse */
 int stc_concat2_f32(const float* A, const float* B, float* out,
                     int64_t rows, int32_t a, int32_t b, int32_t pad, void* stream);
-/* split: A = src[:, :a] (+ addA), B = src[:, a:a+b] (+ addB); addA/addB may be NULL and may alias A/B.
+/* split: A = src[:, :a] (+ addA + addA2), B = src[:, a:a+b] (+ addB + addB2); the addends may be NULL and may alias A/B
+ * (accumulate in place).  A or B may be NULL when that half is not wanted.
  * addA_ld: row stride of addA in floats (0 = a, i.e. dense): lets addA be the first a columns of a wider buffer. */
 int stc_split2_f32(const float* src, const float* addA, const float* addB, float* A, float* B,
-                   int64_t rows, int32_t a, int32_t b, int32_t pad, int32_t addA_ld, void* stream);
+                   int64_t rows, int32_t a, int32_t b, int32_t pad, int32_t addA_ld,
+                   const float* addA2, const float* addB2, void* stream);
 
 #ifdef __cplusplus
 }

@@ -166,10 +166,17 @@ class EmulatedKernels:
         self.gru_gates_bwd(dCandIn, dU, H, U, Rg, dG, dXt, dH, dH_in=extra)
         self.bdg_node_bwd(Zs, Tc, W, dG, dZs, dW, db, None)
 
-    def cell_blend_fwd(self, Zs, Tc, W, bias, U, H, Cand, Hnew):
+    def cell_blend_fwd(self, Zs, Tc, W, bias, U, H, Cand, Hnew, copies=(), side=None):
         Cpre = torch.empty_like(H)
         self.bdg_node_fwd(Zs, Tc, W, bias, Cpre)
         self.gru_blend_fwd(Cpre, U, H, Cand, Hnew)
+        h = H.shape[-1]
+        for buf, off in copies:                                # the new state dropped into its consumers' input rows
+            buf[..., off:off + h].copy_(Hnew)
+        if side is not None:
+            buf, off = copies[0]
+            buf[..., :off].copy_(side)
+            buf[..., off + h:].zero_()
 
     # ---- stc_cell_*_fwd_gather_f32: the same with Z1 = S.Z0 produced inside (include/stc_hip.h)
     def cell_gather_supported(self, Ks, Kc, Cc, L, h) -> bool:
@@ -238,7 +245,7 @@ class EmulatedKernels:
         out[..., a:a + b].copy_(Bm)
         out[..., a + b:].zero_()
 
-    def split2(self, src, A, Bm, addA=None, addB=None, addA_ld=0):
+    def split2(self, src, A, Bm, addA=None, addB=None, addA_ld=0, addA2=None, addB2=None):
         a, b = A.shape[-1], Bm.shape[-1]
-        A.copy_(src[..., :a] + (addA[..., :a] if addA is not None else 0))
-        Bm.copy_(src[..., a:a + b] + (addB if addB is not None else 0))
+        A.copy_(src[..., :a] + (addA[..., :a] if addA is not None else 0) + (addA2 if addA2 is not None else 0))
+        Bm.copy_(src[..., a:a + b] + (addB if addB is not None else 0) + (addB2 if addB2 is not None else 0))

@@ -183,18 +183,27 @@ __global__ __launch_bounds__(EW_THREADS) void concat2_vec_kernel(const float4* _
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
 __global__ __launch_bounds__(EW_THREADS) void split2_vec_kernel(const float4* __restrict__ src, const float4* addA, const float4* addB,
-                                                                 float4* A, float4* B, long long rows, int a4, int b4, int pad4, int ldA4) {
+                                                                 float4* A, float4* B, long long rows, int a4, int b4, int pad4, int ldA4,
+                                                                 const float4* addA2, const float4* addB2) {
     const int L4 = a4 + b4 + pad4;
     const long long n = rows * L4;
     for (long long e = (long long)blockIdx.x * EW_THREADS + threadIdx.x; e < n; e += (long long)gridDim.x * EW_THREADS) {
         const long long r = e / L4;
         const int l = (int)(e - r * L4);
         if (l < a4) {
-            const long long i = r * a4 + l;
-            A[i] = addA ? add4(src[e], addA[r * ldA4 + l]) : src[e];
+            if (A) {
+                const long long i = r * a4 + l;
+                float4 v = addA ? add4(src[e], addA[r * ldA4 + l]) : src[e];
+                if (addA2) v = add4(v, addA2[i]);
+                A[i] = v;
+            }
         } else if (l < a4 + b4) {
-            const long long i = r * b4 + (l - a4);
-            B[i] = addB ? add4(src[e], addB[i]) : src[e];
+            if (B) {
+                const long long i = r * b4 + (l - a4);
+                float4 v = addB ? add4(src[e], addB[i]) : src[e];
+                if (addB2) v = add4(v, addB2[i]);
+                B[i] = v;
+            }
         }
     }
 }
@@ -311,18 +320,27 @@ __global__ __launch_bounds__(EW_THREADS) void concat2_kernel(const float* __rest
 }
 
 __global__ __launch_bounds__(EW_THREADS) void split2_kernel(const float* __restrict__ src, const float* addA, const float* addB,
-                                                             float* A, float* B, long long rows, int a, int b, int pad, int ldA) {
+                                                             float* A, float* B, long long rows, int a, int b, int pad, int ldA,
+                                                             const float* addA2, const float* addB2) {
     const int L = a + b + pad;
     const long long n = rows * L;
     for (long long e = (long long)blockIdx.x * EW_THREADS + threadIdx.x; e < n; e += (long long)gridDim.x * EW_THREADS) {
         const long long r = e / L;
         const int l = (int)(e - r * L);
         if (l < a) {
-            const long long i = r * a + l;
-            A[i] = addA ? src[e] + addA[r * ldA + l] : src[e];
+            if (A) {
+                const long long i = r * a + l;
+                float v = addA ? src[e] + addA[r * ldA + l] : src[e];
+                if (addA2) v += addA2[i];
+                A[i] = v;
+            }
         } else if (l < a + b) {
-            const long long i = r * b + (l - a);
-            B[i] = addB ? src[e] + addB[i] : src[e];
+            if (B) {
+                const long long i = r * b + (l - a);
+                float v = addB ? src[e] + addB[i] : src[e];
+                if (addB2) v += addB2[i];
+                B[i] = v;
+            }
         }
     }
 }
@@ -481,17 +499,18 @@ extern "C" int stc_concat2_f32(const float* A, const float* B, float* out, int64
 }
 
 extern "C" int stc_split2_f32(const float* src, const float* addA, const float* addB, float* A, float* B,
-                              int64_t rows, int32_t a, int32_t b, int32_t pad, int32_t addA_ld, void* stream) {
+                              int64_t rows, int32_t a, int32_t b, int32_t pad, int32_t addA_ld,
+                              const float* addA2, const float* addB2, void* stream) {
     STC_REQUIRE(a >= 0 && b >= 0 && pad >= 0, STC_EINVAL, "stc_split2_f32: negative width");
     STC_REQUIRE(addA_ld == 0 || addA_ld >= a, STC_EINVAL, "stc_split2_f32: addA_ld=%d is smaller than the width a=%d", addA_ld, a);
     const int ldA = addA_ld ? addA_ld : a;
     const long long n = (long long)rows * (a + b + pad);
-    STC_EW_PROLOGUE("stc_split2_f32", n, src && (a == 0 || A) && (b == 0 || B));
-    if (vec_ok({src, addA, addB, A, B}, {a, b, pad, ldA}))
+    STC_EW_PROLOGUE("stc_split2_f32", n, src && (A || B));
+    if (vec_ok({src, addA, addB, A, B, addA2, addB2}, {a, b, pad, ldA}))
         hipLaunchKernelGGL(split2_vec_kernel, ew_grid(n / 4), dim3(EW_THREADS), 0, s, F4C(src), F4C(addA), F4C(addB), F4M(A), F4M(B),
-                           (long long)rows, a / 4, b / 4, pad / 4, ldA / 4);
+                           (long long)rows, a / 4, b / 4, pad / 4, ldA / 4, F4C(addA2), F4C(addB2));
     else
-        hipLaunchKernelGGL(split2_kernel, ew_grid(n), dim3(EW_THREADS), 0, s, src, addA, addB, A, B, (long long)rows, a, b, pad, ldA);
+        hipLaunchKernelGGL(split2_kernel, ew_grid(n), dim3(EW_THREADS), 0, s, src, addA, addB, A, B, (long long)rows, a, b, pad, ldA, addA2, addB2);
     STC_LAUNCH_CHECK("stc_split2_f32 launch");
     return STC_OK;
 }

@@ -486,15 +486,24 @@ extern "C" int stc_cell_cand_bwd_f32(const float* const* Z, int32_t Ks, const fl
 extern "C" int stc_cell_blend_fwd_f32(const float* const* Z, int32_t Ks, const float* Tc, int32_t Kc,
                                       const float* W, const float* bias, const float* U, const float* H,
                                       float* Cand, float* Hnew,
+                                      float* copy0, int32_t copy0_ld, int32_t copy0_off, const float* side_src, int32_t side_cin,
+                                      float* copy1, int32_t copy1_ld, int32_t copy1_off,
                                       int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t h, void* stream) {
     if (int rc = check_dims("stc_cell_blend_fwd_f32", Ks, Kc, C, L, Lw, h, nodes)) return rc;
     if (!stc_cell_fused_supported(Ks, Kc, C, L, h)) return stc::fail(STC_EUNSUPPORTED, "stc_cell_blend_fwd_f32: shape not on the fused path");
     if (nodes == 0) return STC_OK;
     STC_REQUIRE(Z && W && U && H && Cand && Hnew && (Kc == 1 || Tc), STC_EINVAL, "stc_cell_blend_fwd_f32: null pointer");
     for (int n = 0; n < Ks; ++n) STC_REQUIRE(Z[n], STC_EINVAL, "stc_cell_blend_fwd_f32: Z[%d] is null", n);
+    STC_REQUIRE((!copy0 || (copy0_off >= 0 && copy0_off + h <= copy0_ld)) && (!copy1 || (copy1_off >= 0 && copy1_off + h <= copy1_ld)),
+                STC_EINVAL, "stc_cell_blend_fwd_f32: state copy columns [off, off+%d) do not fit the row width", h);
+    STC_REQUIRE(!side_src || (copy0 && side_cin >= 0 && side_cin == copy0_off), STC_EINVAL,
+                "stc_cell_blend_fwd_f32: side_src needs copy0 with copy0_off == side_cin (the state columns follow the input columns)");
+    StcStateCopies cp{};
+    cp.dst[0] = copy0; cp.ld[0] = copy0_ld; cp.off[0] = copy0_off; cp.side_src = side_src; cp.side_cin = side_cin;
+    cp.dst[1] = copy1; cp.ld[1] = copy1_ld; cp.off[1] = copy1_off;
     int rc = STC_NOT_HANDLED;
-    if (x3_enabled()) rc = stc_cell_blend_fwd_x3(Z, Ks, Tc, W, bias, U, H, Cand, Hnew, nodes, C, L, Lw, static_cast<hipStream_t>(stream));
-    if (rc == STC_NOT_HANDLED) rc = stc_cell_blend_fwd_mfma(Z, Ks, Tc, W, bias, U, H, Cand, Hnew, nodes, C, L, Lw, static_cast<hipStream_t>(stream));
+    if (x3_enabled()) rc = stc_cell_blend_fwd_x3(Z, Ks, Tc, W, bias, U, H, Cand, Hnew, &cp, nodes, C, L, Lw, static_cast<hipStream_t>(stream));
+    if (rc == STC_NOT_HANDLED) rc = stc_cell_blend_fwd_mfma(Z, Ks, Tc, W, bias, U, H, Cand, Hnew, &cp, nodes, C, L, Lw, static_cast<hipStream_t>(stream));
     return rc == STC_NOT_HANDLED ? stc::fail(STC_EUNSUPPORTED, "stc_cell_blend_fwd_f32: operands not usable by the fused path (alignment)") : rc;
 }
 

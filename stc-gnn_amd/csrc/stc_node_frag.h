@@ -34,6 +34,9 @@ __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-
 //              gate pre-activations are never written; Xt is copied from this wave's own A fragment of slab 0
 //   EPI_BLEND (Ho = 16): Cand = tanh(y), Hnew = (1-U)*H + U*Cand
 enum { EPI_NONE = 0, EPI_GATES = 1, EPI_BLEND = 2 };
+// BLEND can also drop the new state straight into the [Xt | H | pad] input rows of the cells that consume it (columns
+// [off, off+16) of rows of ld floats), so those cells need no concat pass (reference STC_GNN.py:68 torch.cat).
+struct StateCopy { float* p; int ld, off; };
 struct FwdEpi {
     const float* H;       // (nodes, C, 16) previous state
     const float* U;       // BLEND in : update gate
@@ -43,7 +46,41 @@ struct FwdEpi {
     float* Cand;          // BLEND out: tanh(candidate)
     float* Hnew;          // BLEND out: new state
     int cin;              // GATES: width of Xt inside a row (the H part starts there)
+    StateCopy also[2];    // BLEND out, optional: further destinations of Hnew
+    const float* side_src;   // BLEND, optional, belongs to also[0]: (nodes, C, side_cin) values for its columns [0, side_cin);
+    int side_cin;            //   its pad columns [side_cin + 16, ld) are zeroed -- the consumer's row is then complete
 };
+
+inline void set_state_copies(FwdEpi& epi, const StcStateCopies* c) {
+    if (!c) return;
+    for (int k = 0; k < 2; ++k) epi.also[k] = StateCopy{c->dst[k], c->ld[k], c->off[k]};
+    epi.side_src = c->dst[0] ? c->side_src : nullptr;
+    epi.side_cin = c->side_cin;
+}
+
+// accumulator-layout lanes (row 4g + r, column x of each 16-row block) write the extra copies of the new state
+template <int NRB>
+__device__ __forceinline__ void store_state_copies(const FwdEpi& epi, size_t row0, int x, int g, const float (&hn)[NRB][4]) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+        if (epi.also[k].p) {
+            float* base = epi.also[k].p + epi.also[k].off + x;
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) base[(row0 + 16 * rb + 4 * g + r) * epi.also[k].ld] = hn[rb][r];
+        }
+    if (epi.side_src && x < epi.also[0].ld - 16) {
+        const int col = x < epi.side_cin ? x : x + 16;
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const size_t row = row0 + 16 * rb + 4 * g + r;
+                epi.also[0].p[row * epi.also[0].ld + col] = x < epi.side_cin ? epi.side_src[row * epi.side_cin + x] : 0.f;
+            }
+    }
+}
 
 template <int NRB, int HB>
 struct DyFrag {     // one node's dY in both register layouts

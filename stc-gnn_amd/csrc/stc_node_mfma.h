@@ -7,6 +7,12 @@
 
 constexpr int STC_NOT_HANDLED = 1 << 20;
 
+// optional extra destinations of the new state of stc_cell_blend_fwd_f32 (host view; null pointer = none)
+struct StcStateCopies {
+    float* dst[2]; int ld[2], off[2];
+    const float* side_src; int side_cin;        // belongs to dst[0]
+};
+
 int stc_node_fwd_mfma(const float* const* Z, int Ks, const float* Tc, int Kc, const float* W, const float* bias,
                       float* Y, long long nodes, int C, int L, int Lw, int Ho, hipStream_t stream);
 
@@ -23,7 +29,7 @@ int stc_cell_gates_fwd_mfma(const float* const* Z, int K, const float* Tc, const
                             const float* H, float* U, float* R, float* CandIn,
                             long long nodes, int C, int L, int Lw, int cin, hipStream_t stream);
 int stc_cell_blend_fwd_mfma(const float* const* Z, int K, const float* Tc, const float* W, const float* bias,
-                            const float* U, const float* H, float* Cand, float* Hnew,
+                            const float* U, const float* H, float* Cand, float* Hnew, const StcStateCopies* copies,
                             long long nodes, int C, int L, int Lw, hipStream_t stream);
 int stc_cell_gates_bwd_mfma(const float* const* Z, int K, const float* Tc, const float* W,
                             const float* dCandIn, const float* dU, const float* H, const float* U, const float* R, const float* dH_in, const float* Cand,
@@ -41,7 +47,7 @@ int stc_cell_gates_fwd_x3(const float* const* Z, int K, const float* Tc, const f
                           const float* H, float* U, float* R, float* CandIn,
                           long long nodes, int C, int L, int Lw, int cin, hipStream_t stream);
 int stc_cell_blend_fwd_x3(const float* const* Z, int K, const float* Tc, const float* W, const float* bias,
-                          const float* U, const float* H, float* Cand, float* Hnew,
+                          const float* U, const float* H, float* Cand, float* Hnew, const StcStateCopies* copies,
                           long long nodes, int C, int L, int Lw, hipStream_t stream);
 int stc_cell_gates_bwd_x3(const float* const* Z, int K, const float* Tc, const float* W,
                           const float* dCandIn, const float* dU, const float* H, const float* U, const float* R, const float* dH_in, const float* Cand,

@@ -191,6 +191,7 @@ __global__ __launch_bounds__(MF_THREADS, ((NRB * K * LQ <= 32) ? 3 : 2)) void no
                 }
             }
         } else {
+            float hn[NRB][4];
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
@@ -198,9 +199,11 @@ __global__ __launch_bounds__(MF_THREADS, ((NRB * K * LQ <= 32) ? 3 : 2)) void no
                     const size_t e = ((size_t)node * C + 16 * rb + 4 * q + r) * HID + j;
                     const float c = tanhf(acc[rb][0][r] + bv[0]);
                     const float u = uv[rb][r];
+                    hn[rb][r] = (1.f - u) * hv[rb][r] + u * c;
                     epi.Cand[e] = c;
-                    epi.Hnew[e] = (1.f - u) * hv[rb][r] + u * c;
+                    epi.Hnew[e] = hn[rb][r];
                 }
+            store_state_copies<NRB>(epi, (size_t)node * C, j, q, hn);
         }
         cur = nxt;
         node = next_node;
@@ -492,11 +495,12 @@ int stc_cell_gates_fwd_mfma(const float* const* Z, int K, const float* Tc, const
 }
 
 int stc_cell_blend_fwd_mfma(const float* const* Z, int K, const float* Tc, const float* W, const float* bias,
-                            const float* U, const float* H, float* Cand, float* Hnew,
+                            const float* U, const float* H, float* Cand, float* Hnew, const StcStateCopies* copies,
                             long long nodes, int C, int L, int Lw, hipStream_t stream) {
     if (!stc_cell_fused_shape_ok(K, C, L, 16) || nodes <= 0 || nodes >= (1ll << 31) / C || !all_aligned16(Z, K)) return STC_NOT_HANDLED;
     FwdEpi epi{};
     epi.H = H; epi.U = U; epi.Cand = Cand; epi.Hnew = Hnew;
+    set_state_copies(epi, copies);
 #define BLEND_CALL(a, c, d) launch_fwd<a, 1, c, d, EPI_BLEND>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi)
     STC_MF_EPI_CASE(1, BLEND_CALL) STC_MF_EPI_CASE(2, BLEND_CALL) STC_MF_EPI_CASE(4, BLEND_CALL)
 #undef BLEND_CALL

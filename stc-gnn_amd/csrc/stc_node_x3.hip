@@ -309,6 +309,7 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
                         epi.CandIn[((size_t)node * C + 16 * rb + 4 * g + r) * L + scol] = side[rb][r];
             }
         } else {
+            float hn[NRB][4];
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
@@ -316,9 +317,11 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
                     const size_t e = ((size_t)node * C + 16 * rb + 4 * g + r) * HID + x;
                     const float c = fast_tanh(acc[rb][0][r] + bv[0]);
                     const float u = uv[rb][r];
+                    hn[rb][r] = (1.f - u) * hv[rb][r] + u * c;
                     epi.Cand[e] = c;
-                    epi.Hnew[e] = (1.f - u) * hv[rb][r] + u * c;
+                    epi.Hnew[e] = hn[rb][r];
                 }
+            store_state_copies<NRB>(epi, (size_t)node * C, x, g, hn);
         }
 #pragma unroll
         for (int n = 0; n < KL; ++n)
@@ -658,11 +661,12 @@ int stc_cell_gates_fwd_x3(const float* const* Z, int K, const float* Tc, const f
 }
 
 int stc_cell_blend_fwd_x3(const float* const* Z, int K, const float* Tc, const float* W, const float* bias,
-                          const float* U, const float* H, float* Cand, float* Hnew,
+                          const float* U, const float* H, float* Cand, float* Hnew, const StcStateCopies* copies,
                           long long nodes, int C, int L, int Lw, hipStream_t stream) {
     if (!x3_cell_shape(K, C, L, nodes) || !all_aligned16(Z, K)) return STC_NOT_HANDLED;
     FwdEpi epi{};
     epi.H = H; epi.U = U; epi.Cand = Cand; epi.Hnew = Hnew;
+    set_state_copies(epi, copies);
 #define BLEND_CALL(a, c, d) launch_fwd<a, 1, c, d, EPI_BLEND>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi)
     STC_X3_EPI_CASE(1, BLEND_CALL) STC_X3_EPI_CASE(2, BLEND_CALL) STC_X3_EPI_CASE3(BLEND_CALL)
 #undef BLEND_CALL

@@ -66,7 +66,8 @@ def _declare(lib):
         'stc_cell_cand_bwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _p, C.POINTER(_p), _p, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _i32, _p],
         'stc_cell_gates_bwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _i32, C.POINTER(_p), _p, _p, _p, _p,
                                    _p, C.c_size_t, _i64, _i32, _i32, _i32, _i32, _i32, _p],
-        'stc_cell_blend_fwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
+        'stc_cell_blend_fwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _p, _i32, _p, _i32, _i32,
+                                   _i64, _i32, _i32, _i32, _i32, _p],
         'stc_cell_gates_fwd_gather_f32': [_p, _p, _p, _i64] + [_p] * 9 + [_i64, _i32, _i32, _i32, _i32, _i32, _p],
         'stc_cell_blend_fwd_gather_f32': [_p, _p, _p, _i64] + [_p] * 9 + [_i64, _i32, _i32, _i32, _i32, _p],
         'stc_gru_gates_fwd_f32': [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p],
@@ -77,7 +78,7 @@ def _declare(lib):
         'stc_head_bwd_f32': [_p, _p, _p, _p, _p, _p, _p, C.c_size_t, _i64, _i32, _p],
         'stc_axpy_f32': [_f32, _p, _p, _i64, _p],
         'stc_concat2_f32': [_p, _p, _p, _i64, _i32, _i32, _i32, _p],
-        'stc_split2_f32': [_p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
+        'stc_split2_f32': [_p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p, _p, _p],
     }
     for name, argtypes in sig.items():
         fn = getattr(lib, name)
@@ -429,7 +430,11 @@ class HipKernels:
         self._launch('stc_cell_cand_bwd_f32', U, self._ptr_array(Zs), Ks, _ptr(Tc), Kc, _ptr(W), _ptr(dHnew), _ptr(U), _ptr(Cand),
                      self._ptr_array(dZs), _ptr(dW), _ptr(db), _ptr(ws), ws.numel(), R, Cc, L, Lw, h)
 
-    def cell_blend_fwd(self, Zs, Tc, W, bias, U, H, Cand, Hnew):
+    def cell_blend_fwd(self, Zs, Tc, W, bias, U, H, Cand, Hnew, copies=(), side=None):
+        """``copies``: up to two (buffer, column offset) pairs -- the new state is also written into columns
+        [off, off + h) of those (rows, C, ld) buffers (the input rows of the cells that consume it).  ``side``: a
+        (rows, C, cin) tensor completing the FIRST copy's row: its columns [0, cin) are filled from it (cin == off) and
+        its pad columns zeroed."""
         Ks, Kc, R, Cc, L, Lw, Ho = self._node_shapes(Zs, Tc, W)
         h = H.shape[-1]
         if Ho != h:
@@ -438,9 +443,26 @@ class HipKernels:
             self._f32('cell.bias', bias, (Ho,))
         for name, t in (('U', U), ('H', H), ('Cand', Cand), ('Hnew', Hnew)):
             self._f32('cell.' + name, t, (R, Cc, h))
-        self._same_device(*Zs, Tc, W, bias, U, H, Cand, Hnew)
+        if len(copies) > 2 or (side is not None and not copies):
+            raise StcError('cell_blend: at most two state copies; side needs a first copy')
+        cp = []
+        for i, (buf, off) in enumerate(copies):
+            self._f32(f'cell.copy{i}', buf)
+            if buf.dim() != 3 or buf.shape[:2] != (R, Cc) or off < 0 or off + h > buf.shape[-1]:
+                raise StcError(f'cell_blend: copy{i} of shape {tuple(buf.shape)} cannot take columns [{off}, {off + h}) of {R} x {Cc} rows')
+            cp.append((buf, buf.shape[-1], off))
+        while len(cp) < 2:
+            cp.append((None, 0, 0))
+        side_cin = 0
+        if side is not None:
+            side_cin = side.shape[-1]
+            self._f32('cell.side', side, (R, Cc, side_cin))
+            if side_cin != cp[0][2]:
+                raise StcError(f'cell_blend: side width {side_cin} must equal the first copy\'s column offset {cp[0][2]}')
+        self._same_device(*Zs, Tc, W, bias, U, H, Cand, Hnew, cp[0][0], cp[1][0], side)
         self._launch('stc_cell_blend_fwd_f32', H, self._ptr_array(Zs), Ks, _ptr(Tc), Kc, _ptr(W), _ptr(bias), _ptr(U), _ptr(H),
-                     _ptr(Cand), _ptr(Hnew), R, Cc, L, Lw, h)
+                     _ptr(Cand), _ptr(Hnew), _ptr(cp[0][0]), cp[0][1], cp[0][2], _ptr(side), side_cin, _ptr(cp[1][0]), cp[1][1], cp[1][2],
+                     R, Cc, L, Lw, h)
 
     # ---- the same with the aggregation Z1 = S.Z0 fused in (Ks = Kc = 2) -------------------------
     def cell_gather_supported(self, Ks, Kc, Cc, L, h) -> bool:
@@ -575,13 +597,16 @@ class HipKernels:
         rows, a, b, pad = self._cat_shapes('concat2', A, Bm, out)
         self._launch('stc_concat2_f32', out, _ptr(A), _ptr(Bm), _ptr(out), rows, a, b, pad)
 
-    def split2(self, src, A, Bm, addA=None, addB=None, addA_ld=0):
-        """``addA_ld`` > 0: ``addA`` is a (rows, addA_ld) buffer whose first ``a`` columns are added (read in place)."""
+    def split2(self, src, A, Bm, addA=None, addB=None, addA_ld=0, addA2=None, addB2=None):
+        """``addA_ld`` > 0: ``addA`` is a (rows, addA_ld) buffer whose first ``a`` columns are added (read in place).
+        ``addA2`` / ``addB2``: one more addend each (e.g. what the halves are already owed from another consumer)."""
         rows, a, b, pad = self._cat_shapes('split2', A, Bm, src)
         if addA is not None:
             self._f32('split2.addA', addA, A.shape if not addA_ld else A.shape[:-1] + (addA_ld,))
             if addA_ld and addA_ld < a:
                 raise StcError(f'split2: addA_ld={addA_ld} is smaller than the width {a}')
-        if addB is not None:
-            self._f32('split2.addB', addB, Bm.shape)
-        self._launch('stc_split2_f32', src, _ptr(src), _ptr(addA), _ptr(addB), _ptr(A), _ptr(Bm), rows, a, b, pad, int(addA_ld if addA is not None else 0))
+        for name, t, like in (('addB', addB, Bm), ('addA2', addA2, A), ('addB2', addB2, Bm)):
+            if t is not None:
+                self._f32('split2.' + name, t, like.shape)
+        self._launch('stc_split2_f32', src, _ptr(src), _ptr(addA), _ptr(addB), _ptr(A), _ptr(Bm), rows, a, b, pad,
+                     int(addA_ld if addA is not None else 0), _ptr(addA2), _ptr(addB2))

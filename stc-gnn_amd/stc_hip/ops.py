@@ -428,3 +428,188 @@ def stc_cell(Xt, H, op: SpatialOperand, Tc, Wg, bg, Wc, bc, Ks: int):
     if Wg.shape != (Ks * Kc * L, 2 * h) or Wc.shape != (Ks * Kc * L, h):
         raise ValueError(f'stc_cell: W shapes {tuple(Wg.shape)}, {tuple(Wc.shape)} do not match Ks*Kc*L={Ks * Kc * L}, h={h}')
     return _StcCell.apply(Xt, H, Wg, bg, Wc, bc, Tc, op.fwd_val, op, Ks)
+
+
+# ----------------------------------------------------------------------------- a whole schedule of cells as ONE autograd node
+_CELL_GRAPH = os.environ.get('STC_CELL_GRAPH', '1') != '0'
+
+
+def cell_graph_supported(op: SpatialOperand, Tc, Ks: int, C: int, h: int, x_widths) -> bool:
+    """Whether ``stc_cell_graph`` can run a schedule: matrix-core cell kernels for every row width that occurs, hidden 16,
+    graphs that need no gradient (``csr-fixed`` mode)."""
+    if not _CELL_GRAPH or h != 16 or Tc.requires_grad or op.fwd_val.requires_grad:
+        return False
+    k = kernels()
+    return all(k.cell_fused_supported(Ks, Tc.shape[0], C, w + h + (-(w + h)) % 4, h) for w in set(x_widths))
+
+
+class _StcCellGraph(Function):
+    """Encoder + decoder (any DAG of STC_Cells whose inputs are other cells' states) as one autograd node.
+
+    Per cell the kernels are those of ``_StcCell``'s fused path.  What owning the whole schedule adds:
+      * no concat passes: a cell's new state is written by the blend epilogue straight into the [Xt | H | pad] input rows
+        of the cells that consume it (``stc_cell_blend_fwd_f32`` state copies; reference STC_GNN.py:68 torch.cat);
+      * no autograd accumulation passes: a state consumed by two cells (next step, next layer) gets its two gradient
+        contributions summed inside the consumers' final split (``stc_split2_f32`` addA2 / addB2), in schedule order.
+    schedule[j] = (stack, ('ext', i) | ('cell', k), ('ext', i) | ('cell', k)): parameter set, source of Xt, source of H.
+    """
+
+    @staticmethod
+    def forward(ctx, op: SpatialOperand, Ks: int, schedule, outputs, n_ext: int, Tc, fwd_val, *tensors):
+        k = kernels()
+        ext = [_c(t) for t in tensors[:n_ext]]
+        flat = tensors[n_ext:]
+        stacks = [tuple(None if p is None else _c(p) for p in flat[i:i + 4]) for i in range(0, len(flat), 4)]   # (Wg, bg, Wc, bc)
+        Tc, fwd_val = _c(Tc), _c(fwd_val)
+        h = 16
+        n_cells = len(schedule)
+        width = lambda src: ext[src[1]].shape[-1] if src[0] == 'ext' else h
+        cin = [width(x) for _, x, _ in schedule]
+        consumers = [[] for _ in range(n_cells)]
+        for j, (_, x, hs) in enumerate(schedule):
+            if hs[0] == 'cell':
+                consumers[hs[1]].append((j, 'h'))
+            if x[0] == 'cell':
+                consumers[x[1]].append((j, 'x'))
+        ref = ext[0]
+        B, N, C = ref.shape[:3]
+        rows = lambda ts: [t.view(B * N, C, t.shape[-1]) for t in ts]
+        XH = {}
+
+        def rows_of(j):                                             # the input rows of cell j, allocated at first touch
+            if j not in XH:
+                L = cin[j] + h + (-(cin[j] + h)) % 4
+                XH[j] = ref.new_empty(B, N, C, L)
+            return XH[j]
+
+        state = [None] * n_cells                                    # plain (B,N,C,h) new state of every cell
+        saved = []
+        for j, (s_id, x, hs) in enumerate(schedule):
+            Wg, bg, Wc, bc = stacks[s_id]
+            Xj = rows_of(j)
+            L = Xj.shape[-1]
+            Hprev = ext[hs[1]] if hs[0] == 'ext' else state[hs[1]]
+            if x[0] == 'ext' and hs[0] == 'ext':
+                k.concat2(ext[x[1]], Hprev, Xj)
+            elif x[0] == 'cell' and hs[0] == 'ext':                 # X part came from its producer; complete the row
+                Xj[..., cin[j]:cin[j] + h].copy_(Hprev)
+                if L > cin[j] + h:
+                    Xj[..., cin[j] + h:].zero_()
+            # (H part from a cell: its producer also wrote an external X part and the pad columns, see below)
+            U, Rg, CandIn = torch.empty_like(Hprev), torch.empty_like(Hprev), torch.empty_like(Xj)
+            Cand, Hnew = torch.empty_like(Hprev), torch.empty_like(Hprev)
+            Zg = _spatial_slabs(Xj, fwd_val, op, Ks)
+            k.cell_gates_fwd(rows(Zg), Tc, Wg, bg, *rows((Hprev, U, Rg, CandIn)))
+            Zc = _spatial_slabs(CandIn, fwd_val, op, Ks)
+            # where else the new state goes: straight into the input rows of the cells that consume it
+            copies, side, late_copies, late_rows = [], None, [], []
+            for (d, role) in consumers[j]:
+                Xd = rows_of(d)
+                view = Xd.view(B * N, C, Xd.shape[-1])
+                if role == 'x':
+                    copies.append((view, 0))
+                elif schedule[d][1][0] == 'ext':                    # H part + the consumer's external X part and pad columns
+                    if side is None:
+                        copies.insert(0, (view, cin[d]))
+                        side = ext[schedule[d][1][1]].view(B * N, C, cin[d])
+                    else:
+                        late_rows.append(d)
+                elif Xd.shape[-1] > cin[d] + h:
+                    late_rows.append(d)                             # pad columns to zero: not a case the kernel handles
+                else:
+                    copies.append((view, cin[d]))
+            first = 1 if side is not None else 0
+            while len(copies) > 2:                                  # the kernel takes two destinations; the rest by torch
+                late_copies.append(copies.pop(len(copies) - 1 if len(copies) - 1 >= first else first))
+            k.cell_blend_fwd(rows(Zc), Tc, Wc, bc, *rows((U, Hprev, Cand, Hnew)), copies=copies, side=side)
+            for buf, off in late_copies:
+                buf[..., off:off + h].copy_(Hnew.view(B * N, C, h))
+            for d in late_rows:
+                Xd, xs = rows_of(d), schedule[d][1]
+                if xs[0] == 'ext':
+                    k.concat2(ext[xs[1]], Hnew, Xd)
+                else:
+                    Xd[..., cin[d]:cin[d] + h].copy_(Hnew)
+                    Xd[..., cin[d] + h:].zero_()
+            state[j] = Hnew
+            saved += [Hprev, U, Rg, Cand, *Zg, *Zc]
+        ctx.save_for_backward(Tc, *[p for st in stacks for p in st if p is not None], *saved)
+        ctx.meta = (op, Ks, schedule, tuple(outputs), cin, [tuple(p is not None for p in st) for st in stacks], (B, N, C))
+        return tuple(state[j] for j in outputs)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *grads):
+        k = kernels()
+        op, Ks, schedule, outputs, cin, present, (B, N, C) = ctx.meta
+        sv = list(ctx.saved_tensors)
+        Tc = sv.pop(0)
+        stacks = []
+        for pres in present:
+            st = [sv.pop(0) if p else None for p in pres]
+            stacks.append(st)
+        per = 4 + 2 * Ks
+        cells = [sv[i * per:(i + 1) * per] for i in range(len(schedule))]
+        h = 16
+        rows = lambda ts: [t.view(B * N, C, t.shape[-1]) for t in ts]
+        bwd = (op.bwd_rowptr, op.bwd_colidx, op.bwd_val)
+        G = {}                                                       # cell -> gradient its state is owed so far
+        for j, g in zip(outputs, grads):
+            if g is not None:
+                G[j] = _c(g) if j not in G else G[j] + g
+        acc = [[None] * 4 for _ in stacks]
+
+        def add_to(slot, i, t):
+            if t is not None:
+                slot[i] = t if slot[i] is None else slot[i].add_(t)
+
+        for j in range(len(schedule) - 1, -1, -1):
+            if j not in G:
+                continue                                             # nothing downstream depends on this cell
+            s_id, x, hs = schedule[j]
+            Wg, bg, Wc, bc = stacks[s_id]
+            Hprev, U, Rg, Cand, *Z = cells[j]
+            Zg, Zc = Z[:Ks], Z[Ks:]
+            dHnew = G.pop(j)
+            L = Zc[0].shape[-1]
+            v3 = lambda t: t.view(B, N, C * L)
+            # candidate convolution, blend backward in its prologue
+            g, dWc, dbc, _, _ = _bdg_backward_slabs(None, Zc, Wc, Tc, op, Ks, bc is not None, False, False, cand=(dHnew, U, Cand))
+            if Ks > 1:
+                k.csr_spmm(*bwd, N, N, v3(g[1]), v3(g[0]), v3(g[0]), 1.0, 1.0, plan=op.bwd_plan)
+            dci = g[0]
+            dH = torch.empty_like(Hprev)
+            # gates convolution, gate + blend backward in its prologue
+            g, dWg, dbg, _, _ = _bdg_backward_slabs(None, Zg, Wg, Tc, op, Ks, bg is not None, False, False,
+                                                    gates=(dci, Cand, Hprev, U, Rg, dHnew, dH))
+            need_x, need_h = x[0] == 'cell', hs[0] == 'cell'
+            if need_x or need_h:
+                if Ks > 1:
+                    k.csr_spmm(*bwd, N, N, v3(g[1]), v3(g[0]), v3(g[0]), 1.0, 1.0, plan=op.bwd_plan)
+                dXt = Hprev.new_empty(Hprev.shape[:-1] + (cin[j],))
+                same = need_x and need_h and x[1] == hs[1]
+                owedA = G.get(x[1]) if need_x else None
+                owedB = G.get(hs[1]) if (need_h and not same) else None
+                k.split2(g[0], dXt, dH, addA=dci, addB=dH, addA_ld=L, addA2=owedA, addB2=owedB)
+                if same:
+                    G[x[1]] = dXt.add_(dH)
+                else:
+                    if need_x:
+                        G[x[1]] = dXt
+                    if need_h:
+                        G[hs[1]] = dH
+            for i, t in enumerate((dWg, dbg, dWc, dbc)):
+                add_to(acc[s_id], i, t)
+        flat = []
+        for st, a in zip(stacks, acc):
+            for p, gsum in zip(st, a):
+                flat.append(None if p is None else (gsum if gsum is not None else torch.zeros_like(p)))
+        n_ext = len(ctx.needs_input_grad) - 7 - len(flat)
+        return (None,) * 7 + (None,) * n_ext + tuple(flat)
+
+
+def stc_cell_graph(op: SpatialOperand, Tc, Ks: int, schedule, outputs, ext, stacks):
+    """Run a schedule of STC_Cells (see ``_StcCellGraph``).  ``ext``: external (B,N,C,*) tensors (inputs, initial states;
+    they get no gradient); ``stacks``: [(Wg, bg, Wc, bc)] parameter sets; returns the new states of the ``outputs`` cells."""
+    flat = [p for st in stacks for p in st]
+    return _StcCellGraph.apply(op, Ks, list(schedule), list(outputs), len(ext), Tc, op.fwd_val, *ext, *flat)

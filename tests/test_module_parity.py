@@ -338,3 +338,46 @@ def test_factorised_mixed_fusion_option(dev):
     if DEV == 'cpu':
         big = M.MixedFusion(1000, rank=8)
         assert sum(p.numel() for p in big.parameters()) == 2 * (2 * 10 ** 6 * 8 + 10 ** 6)
+
+
+@pytest.mark.parametrize('layers,T,horizon,cin', [(2, 4, 3, 1), (1, 3, 2, 1), (3, 2, 2, 4)])
+def test_cell_graph_equals_the_per_cell_path(dev, monkeypatch, layers, T, horizon, cin):
+    """Encoder + decoder as one autograd node (no concat / gradient-accumulation passes between the cells) vs one node per
+    cell: same prediction, same parameter gradients.  Hidden 16; 32 categories on the GPU (matrix-core shapes)."""
+    C = 32 if DEV == 'cuda' else 5
+    Hh, Ww, h, K, B = 5, 6, 16, 2, 2
+    torch.manual_seed(layers * 10 + T)
+    graph = CsrGraph.queen_grid(Hh, Ww, normalize=True)
+    model = M.STCGNN(Hh * Ww, C, K, K, cin, h, layers, horizon, graph_mode='csr-fixed').to(DEV)
+    if cin != 1:                                                   # the head maps back to input_dim; keep it scalar for the loss below
+        model._head = lambda Hs: torch.sigmoid(Hs.sum(-1))
+    Gc = torch.softmax(torch.randn(C, C), -1).to(DEV)
+    X = torch.rand(B, T, Hh * Ww, C, cin).to(DEV)
+    Rw = torch.randn(B, horizon, Hh * Ww, C).to(DEV)
+    calls = []
+    real = ops.stc_cell_graph
+    monkeypatch.setattr(ops, 'stc_cell_graph', lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+
+    def run(flag):
+        monkeypatch.setattr(ops, '_CELL_GRAPH', flag)
+        model.zero_grad(set_to_none=True)
+        pair = M._graphs(graph, Gc, K, K)
+        outs = model._run_cell_graph(pair, X) if flag else None
+        if outs is None:
+            assert not flag
+            _, states = model.encoder._run(pair, None, X)
+            step_in, outs = states[-1], []
+            for _ in range(horizon):
+                step_in, states = model.decoder(pair, None, step_in, states)
+                outs.append(step_in)
+        y = model._head(torch.stack(outs, dim=1))
+        (y * Rw).sum().backward()
+        return y.detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    y1, g1 = run(True)
+    assert calls, 'the cell-graph path was not taken'
+    y0, g0 = run(False)
+    _close(y1, y0, 1e-6, 'cell-graph prediction vs per-cell', gpu_tol=2e-6)
+    assert set(g1) == set(g0)
+    for n in g0:
+        _close(g1[n], g0[n], 2e-6, f'cell-graph d{n} vs per-cell', gpu_tol=5e-6)
