@@ -154,14 +154,14 @@ def main():
         # separate rocprofv3 --pmc runs, as MI355X_MICROARCH.md prescribes; tools/gpu_pmc_bench.sh): averaged over all SpMM
         # launches of a step exactly like roofline.achieved.  Only valid for the configuration it was collected on.
         traffic, traffic_note = None, None
-        tpath = os.path.join(REPO, 'profiles', 'r01', 'f_hbm_traffic_bench_b2.json')
+        tpath = os.path.join(REPO, 'profiles', 'r01', 'g_hbm_traffic_bench_b2.json')
         if (a.grid, C, a.hidden, B, a.order, a.layers, a.obs, a.pred, a.permute) == (224, 32, 16, 2, 2, 2, 18, 6, False) and os.path.exists(tpath):
             with open(tpath) as fh:
                 doc = json.load(fh)
             ks = [v for name, v in doc['kernels'].items() if name.startswith('spmm_')]
             if ks:
                 traffic = sum(v['hbm_bytes_per_launch'] * v['launches'] for v in ks) / sum(v['launches'] for v in ks)
-                traffic_note = 'PMC (2 x FETCH_SIZE + WRITE_SIZE), mean over the SpMM launches of one step of this command: profiles/r01/f_hbm_traffic_bench_b2.json'
+                traffic_note = 'PMC (2 x FETCH_SIZE + WRITE_SIZE), mean over the SpMM launches of one step of this command: profiles/r01/g_hbm_traffic_bench_b2.json'
         out = {
             'metric': METRIC, 'value': world * B * a.steps / elapsed, 'unit': 'samples/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * elapsed / a.steps,
