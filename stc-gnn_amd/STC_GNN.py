@@ -329,22 +329,25 @@ class STCGNN(nn.Module):
                     X_seq = X_seq.index_select(2, idx[0])
                     inv = idx[1]
         pair = _graphs(Gs, Gc, self.Ks, self.Kc)
-        outs = self._run_cell_graph(pair, X_seq.unsqueeze(-1))
-        if outs is None:                                                  # general path: one autograd node per cell
+        stacked = self._run_cell_graph(pair, X_seq.unsqueeze(-1))
+        if stacked is not None:
+            y = self._head(stacked).transpose(0, 1)                       # (horizon, B, N, C) -> (B, horizon, N, C), a view
+        else:                                                             # general path: one autograd node per cell
             _, states = self.encoder._run(pair, None, X_seq.unsqueeze(-1))     # per-layer output stacks are not needed here
             step_in = states[-1]
             outs = []
             for _ in range(self.decoder.out_horizon):
                 step_in, states = self.decoder(pair, None, step_in, states)
                 outs.append(step_in)
-        y = self._head(torch.stack(outs, dim=1))                         # (B, horizon, N, C)
+            y = self._head(torch.stack(outs, dim=1))                     # (B, horizon, N, C)
         return y if inv is None else y.index_select(2, inv)
 
     def _run_cell_graph(self, pair: GraphPair, X: torch.Tensor):
         """Encoder and decoder as ONE autograd node (``ops.stc_cell_graph``) when the kernels allow it: fixed graphs,
         hidden 16 on the matrix-core shapes, no BDG_Dif activation.  Same cells, same order, same values as the general
         path; what changes is that no concat pass and no gradient-accumulation pass runs between the cells.
-        Returns the decoder's top-layer states per horizon step, or None when the general path must be used."""
+        Returns the decoder's top-layer states of all horizon steps, (horizon, B, N, C, h), or None when the general path
+        must be used."""
         enc, dec = self.encoder.cell_list, self.decoder.cell_list
         cells = list(enc) + list(dec)
         hidden = {c.hidden_dim for c in cells}
@@ -372,7 +375,7 @@ class STCGNN(nn.Module):
                 schedule.append((n_layers + l, x, hs))
         stacks = [(c.gates.W, c.gates.b if c.gates.use_bias else None, c.candi.W, c.candi.b if c.candi.use_bias else None) for c in cells]
         outputs = [did(n_layers - 1, s_) for s_ in range(horizon)]
-        return list(ops.stc_cell_graph(pair.spatial, pair.Tc, self.Ks, schedule, outputs, ext, stacks))
+        return ops.stc_cell_graph(pair.spatial, pair.Tc, self.Ks, schedule, outputs, ext, stacks)
 
     def _head(self, H: torch.Tensor) -> torch.Tensor:
         """sigmoid(out_proj(H)).squeeze(-1) (reference STC_GNN.py:206-207).  The two Linears have no nonlinearity

@@ -443,6 +443,14 @@ def cell_graph_supported(op: SpatialOperand, Tc, Ks: int, C: int, h: int, x_widt
     return all(k.cell_fused_supported(Ks, Tc.shape[0], C, w + h + (-(w + h)) % 4, h) for w in set(x_widths))
 
 
+def _alias_slice(base: torch.Tensor, i: int) -> torch.Tensor:
+    """base[i] as a tensor of its own that shares the storage WITHOUT being a view of ``base`` in autograd's books: the
+    slice is saved for backward while ``base`` is returned as the Function's output, which view tracking forbids."""
+    t = base.new_empty(0)
+    t.set_(base.untyped_storage(), base.storage_offset() + i * base.stride(0), base.shape[1:], base.stride()[1:])
+    return t
+
+
 class _StcCellGraph(Function):
     """Encoder + decoder (any DAG of STC_Cells whose inputs are other cells' states) as one autograd node.
 
@@ -483,6 +491,10 @@ class _StcCellGraph(Function):
             return XH[j]
 
         state = [None] * n_cells                                    # plain (B,N,C,h) new state of every cell
+        out_stack = ref.new_empty(len(outputs), B, N, C, h)         # the requested states are produced in place, stacked
+        out_slot = {j: i for i, j in enumerate(outputs)}
+        if len(out_slot) != len(outputs):
+            raise ValueError('stc_cell_graph: duplicate output cells')
         saved = []
         for j, (s_id, x, hs) in enumerate(schedule):
             Wg, bg, Wc, bc = stacks[s_id]
@@ -497,7 +509,8 @@ class _StcCellGraph(Function):
                     Xj[..., cin[j] + h:].zero_()
             # (H part from a cell: its producer also wrote an external X part and the pad columns, see below)
             U, Rg, CandIn = torch.empty_like(Hprev), torch.empty_like(Hprev), torch.empty_like(Xj)
-            Cand, Hnew = torch.empty_like(Hprev), torch.empty_like(Hprev)
+            Cand = torch.empty_like(Hprev)
+            Hnew = _alias_slice(out_stack, out_slot[j]) if j in out_slot else torch.empty_like(Hprev)
             Zg = _spatial_slabs(Xj, fwd_val, op, Ks)
             k.cell_gates_fwd(rows(Zg), Tc, Wg, bg, *rows((Hprev, U, Rg, CandIn)))
             Zc = _spatial_slabs(CandIn, fwd_val, op, Ks)
@@ -535,11 +548,11 @@ class _StcCellGraph(Function):
             saved += [Hprev, U, Rg, Cand, *Zg, *Zc]
         ctx.save_for_backward(Tc, *[p for st in stacks for p in st if p is not None], *saved)
         ctx.meta = (op, Ks, schedule, tuple(outputs), cin, [tuple(p is not None for p in st) for st in stacks], (B, N, C))
-        return tuple(state[j] for j in outputs)
+        return out_stack
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, *grads):
+    def backward(ctx, grad_stack):
         k = kernels()
         op, Ks, schedule, outputs, cin, present, (B, N, C) = ctx.meta
         sv = list(ctx.saved_tensors)
@@ -554,9 +567,9 @@ class _StcCellGraph(Function):
         rows = lambda ts: [t.view(B * N, C, t.shape[-1]) for t in ts]
         bwd = (op.bwd_rowptr, op.bwd_colidx, op.bwd_val)
         G = {}                                                       # cell -> gradient its state is owed so far
-        for j, g in zip(outputs, grads):
-            if g is not None:
-                G[j] = _c(g) if j not in G else G[j] + g
+        grad_stack = _c(grad_stack)
+        for i, j in enumerate(outputs):
+            G[j] = grad_stack[i]                                     # read-only here: sums go to fresh buffers
         acc = [[None] * 4 for _ in stacks]
 
         def add_to(slot, i, t):
@@ -610,6 +623,7 @@ class _StcCellGraph(Function):
 
 def stc_cell_graph(op: SpatialOperand, Tc, Ks: int, schedule, outputs, ext, stacks):
     """Run a schedule of STC_Cells (see ``_StcCellGraph``).  ``ext``: external (B,N,C,*) tensors (inputs, initial states;
-    they get no gradient); ``stacks``: [(Wg, bg, Wc, bc)] parameter sets; returns the new states of the ``outputs`` cells."""
+    they get no gradient); ``stacks``: [(Wg, bg, Wc, bc)] parameter sets; returns the new states of the ``outputs`` cells
+    stacked along a new leading axis, (len(outputs), B, N, C, h) -- written in place by the kernels, no stack pass."""
     flat = [p for st in stacks for p in st]
     return _StcCellGraph.apply(op, Ks, list(schedule), list(outputs), len(ext), Tc, op.fwd_val, *ext, *flat)

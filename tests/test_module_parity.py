@@ -362,15 +362,17 @@ def test_cell_graph_equals_the_per_cell_path(dev, monkeypatch, layers, T, horizo
         monkeypatch.setattr(ops, '_CELL_GRAPH', flag)
         model.zero_grad(set_to_none=True)
         pair = M._graphs(graph, Gc, K, K)
-        outs = model._run_cell_graph(pair, X) if flag else None
-        if outs is None:
+        stacked = model._run_cell_graph(pair, X) if flag else None
+        if stacked is None:
             assert not flag
             _, states = model.encoder._run(pair, None, X)
             step_in, outs = states[-1], []
             for _ in range(horizon):
                 step_in, states = model.decoder(pair, None, step_in, states)
                 outs.append(step_in)
-        y = model._head(torch.stack(outs, dim=1))
+            y = model._head(torch.stack(outs, dim=1))
+        else:
+            y = model._head(stacked).transpose(0, 1)
         (y * Rw).sum().backward()
         return y.detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
 
