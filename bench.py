@@ -49,7 +49,7 @@ def parse():
     ap.add_argument('--layers', type=int, default=2)
     ap.add_argument('--obs', type=int, default=18)
     ap.add_argument('--pred', type=int, default=6)
-    ap.add_argument('--batch-per-gpu', type=int, default=2, help='samples per GPU (weak scaling); 2 = ~116 GB of saved activations')
+    ap.add_argument('--batch-per-gpu', type=int, default=3, help='samples per GPU (weak scaling); 58 GB of saved activations per sample: 3 = 174 GB of the 288 GB (4 fits too: 232 GB)')
     ap.add_argument('--permute', action='store_true', help='random node order (seed 1234) instead of row-major')
     ap.add_argument('--no-reorder', action='store_true', help='keep the given node order (skip the internal RCM renumbering)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -154,14 +154,14 @@ def main():
         # separate rocprofv3 --pmc runs, as MI355X_MICROARCH.md prescribes; tools/gpu_pmc_bench.sh): averaged over all SpMM
         # launches of a step exactly like roofline.achieved.  Only valid for the configuration it was collected on.
         traffic, traffic_note = None, None
-        tpath = os.path.join(REPO, 'profiles', 'r01', 'g_hbm_traffic_bench_b2.json')
-        if (a.grid, C, a.hidden, B, a.order, a.layers, a.obs, a.pred, a.permute) == (224, 32, 16, 2, 2, 2, 18, 6, False) and os.path.exists(tpath):
+        tpath = os.path.join(REPO, 'profiles', 'r01', 'h_hbm_traffic_bench_b3.json')
+        if (a.grid, C, a.hidden, B, a.order, a.layers, a.obs, a.pred, a.permute) == (224, 32, 16, 3, 2, 2, 18, 6, False) and os.path.exists(tpath):
             with open(tpath) as fh:
                 doc = json.load(fh)
             ks = [v for name, v in doc['kernels'].items() if name.startswith('spmm_')]
             if ks:
                 traffic = sum(v['hbm_bytes_per_launch'] * v['launches'] for v in ks) / sum(v['launches'] for v in ks)
-                traffic_note = 'PMC (2 x FETCH_SIZE + WRITE_SIZE), mean over the SpMM launches of one step of this command: profiles/r01/g_hbm_traffic_bench_b2.json'
+                traffic_note = 'PMC (2 x FETCH_SIZE + WRITE_SIZE), mean over the SpMM launches of one step of this command: profiles/r01/h_hbm_traffic_bench_b3.json'
         out = {
             'metric': METRIC, 'value': world * B * a.steps / elapsed, 'unit': 'samples/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * elapsed / a.steps,
@@ -179,6 +179,8 @@ def main():
             'kernels': {k: {'launches': d['launches'], 'ms_per_step': d['ms'] / a.steps,
                             'share': d['ms'] / total_ms} for k, d in sorted(per_kernel.items(), key=lambda kv: -kv[1]['ms'])},
             'loss': float(loss.detach()),
+            'hbm_peak_allocated_gb': torch.cuda.max_memory_allocated(dev) / 1e9,
+            'hbm_peak_reserved_gb': torch.cuda.max_memory_reserved(dev) / 1e9,
         }
         if world == 1 and not a.no_cpu_baseline:
             GsT = graph.to_dense().t().contiguous().to_sparse_csr() if N <= 4096 else _sparse_T(graph)
