@@ -146,10 +146,23 @@ int stc_gru_gates_bwd_f32(const float* dCandIn, const float* dU, const float* H,
 /* blend:  Cand = tanh(Cpre); Hnew = (1-U)*H + U*Cand      (n = rows*h elements) */
 int stc_gru_blend_fwd_f32(const float* Cpre, const float* U, const float* H,
                           float* Cand, float* Hnew, int64_t n, void* stream);
-/* dCpre = dHnew*U*(1-Cand^2), dU = dHnew*(Cand-H), dH = dHnew*(1-U); dH may be NULL when the consumer forms that
- * product itself (stc_cell_gates_bwd_f32 with dH_in_scaled) */
+/* dCpre = dHnew*U*(1-Cand^2), dU = dHnew*(Cand-H), dH = dHnew*(1-U); dU and dH may be NULL when the consumer forms those
+ * products itself (stc_cell_gates_bwd_f32, Cand form); H may be NULL when dU is */
 int stc_gru_blend_bwd_f32(const float* dHnew, const float* U, const float* H, const float* Cand,
                           float* dCpre, float* dU, float* dH, int64_t n, void* stream);
+
+/* ---- post-aggregation form of a Ks = Kc = 2 convolution -----------------------------------------------------------
+ * The aggregation acts on the node axis, projection and category mix on the other two, so STC_GNN.py:35-45 reassociates to
+ *     Y = A + Gs^T x Bm,   A = sum_c T_c^T (X W_{0,c}),  Bm = sum_c T_c^T (X W_{1,c}):
+ * the SpMM runs on rows of C*Ho floats instead of C*L (half the bytes when Ho = 16, L = 32) and the slab Gs^T x X is never
+ * formed.  Backward: dA = dY, dBm = Gs x dY (one narrow stc_csr/bcsr_spmm_f32 by the caller), then this kernel turns
+ * (X, dA, dBm) into dX (nodes, C, L), dW (4*Lw, Ho) and db directly -- no second gradient slab, no SpMM after it.
+ * Shapes: C in {32, 64}, L in {20, 32}, Ho = 16 (stc_bdg_node_post_supported), else STC_EUNSUPPORTED.
+ * workspace as stc_bdg_node_bwd_f32 (stc_bdg_node_bwd_workspace_bytes(2, 2, C, L, Ho, 0)). */
+int stc_bdg_node_post_supported(int32_t Ks, int32_t Kc, int32_t C, int32_t L, int32_t Ho);
+int stc_bdg_node_post_bwd_f32(const float* X, const float* Tc, const float* W, const float* dA, const float* dB,
+                              float* dX, float* dW, float* db, void* workspace, size_t workspace_bytes,
+                              int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t Ho, void* stream);
 
 /* ---- fused cell convolutions (STC_GNN.py:69-78) ------------------------------------
  * The two BDG_Dif of an STC_Cell with the gate math folded into the node kernel's epilogue, so the

@@ -141,6 +141,23 @@ class EmulatedKernels:
                     U += Zs[n][..., :Lw] @ Wv[n, c]
                 dTc[c].copy_(torch.einsum('rpo,rdo->pd', U, dY))
 
+    # ---- stc_bdg_node_post_bwd_f32: Y = A + S.Bm (Ks = Kc = 2); backward from (X, dA, dBm)
+    def node_post_supported(self, Ks, Kc, Cc, L, Ho) -> bool:
+        return Ks == 2 and Kc == 2
+
+    def node_post_bwd(self, X, Tc, W, dA, dB, dX, dW, db):
+        Lw = W.shape[0] // 4
+        dW.zero_()
+        dX.zero_()
+        for n, dYn in enumerate((dA, dB)):                     # slab n sees X with the weight blocks (n, c) and gradient dY_n
+            for c in range(2):
+                Q = dYn if c == 0 else torch.einsum('pd,rdo->rpo', Tc[c], dYn)        # Q_c = T_c dY_n
+                Wnc = W[(n * 2 + c) * Lw:(n * 2 + c + 1) * Lw]                         # (Lw, Ho)
+                dX[..., :Lw] += torch.einsum('rpo,lo->rpl', Q, Wnc)
+                dW[(n * 2 + c) * Lw:(n * 2 + c + 1) * Lw] += torch.einsum('rpl,rpo->lo', X[..., :Lw], Q)
+        if db is not None:
+            db.copy_(dA.sum((0, 1)))
+
     # ---- stc_cell_gates/blend_fwd_f32: node kernel + gate math in its epilogue (STC_GNN.py:69-78)
     def cell_fused_supported(self, Ks, Kc, Cc, L, h) -> bool:
         return Ks == Kc                 # the twin composes the unfused kernels, any shape
@@ -220,7 +237,8 @@ class EmulatedKernels:
 
     def gru_blend_bwd(self, dHnew, U, H, Cand, dCpre, dU, dH):
         dCpre.copy_(dHnew * U * (1 - Cand * Cand))
-        dU.copy_(dHnew * (Cand - H))
+        if dU is not None:
+            dU.copy_(dHnew * (Cand - H))
         if dH is not None:
             dH.copy_(dHnew * (1 - U))
 

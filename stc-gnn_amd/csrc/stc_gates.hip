@@ -84,7 +84,7 @@ __global__ __launch_bounds__(EW_THREADS) void gru_blend_bwd_kernel(
     for (long long e = (long long)blockIdx.x * EW_THREADS + threadIdx.x; e < n; e += (long long)gridDim.x * EW_THREADS) {
         const float g = dHnew[e], u = U[e], c = Cand[e];
         dCpre[e] = g * u * (1.f - c * c);
-        dU[e] = g * (c - H[e]);
+        if (dU) dU[e] = g * (c - H[e]);
         if (dH) dH[e] = g * (1.f - u);
     }
 }
@@ -161,10 +161,13 @@ __global__ __launch_bounds__(EW_THREADS) void gru_blend_bwd_vec_kernel(
     const float4* __restrict__ Cand, float4* __restrict__ dCpre, float4* __restrict__ dU, float4* __restrict__ dH,
     long long n4) {
     for (long long e = (long long)blockIdx.x * EW_THREADS + threadIdx.x; e < n4; e += (long long)gridDim.x * EW_THREADS) {
-        const float4 g = dHnew[e], u = U[e], c = Cand[e], hh = H[e];
+        const float4 g = dHnew[e], u = U[e], c = Cand[e];
         dCpre[e] = make_float4(g.x * u.x * (1.f - c.x * c.x), g.y * u.y * (1.f - c.y * c.y),
                                g.z * u.z * (1.f - c.z * c.z), g.w * u.w * (1.f - c.w * c.w));
-        dU[e] = make_float4(g.x * (c.x - hh.x), g.y * (c.y - hh.y), g.z * (c.z - hh.z), g.w * (c.w - hh.w));
+        if (dU) {
+            const float4 hh = H[e];
+            dU[e] = make_float4(g.x * (c.x - hh.x), g.y * (c.y - hh.y), g.z * (c.z - hh.z), g.w * (c.w - hh.w));
+        }
         if (dH) dH[e] = make_float4(g.x * (1.f - u.x), g.y * (1.f - u.y), g.z * (1.f - u.z), g.w * (1.f - u.w));
     }
 }
@@ -438,7 +441,7 @@ extern "C" int stc_gru_blend_fwd_f32(const float* Cpre, const float* U, const fl
 
 extern "C" int stc_gru_blend_bwd_f32(const float* dHnew, const float* U, const float* H, const float* Cand,
                                      float* dCpre, float* dU, float* dH, int64_t n, void* stream) {
-    STC_EW_PROLOGUE("stc_gru_blend_bwd_f32", n, dHnew && U && H && Cand && dCpre && dU);      // dH may be null (not wanted)
+    STC_EW_PROLOGUE("stc_gru_blend_bwd_f32", n, dHnew && U && Cand && dCpre && (H || !dU));      // dU, dH may be null (not wanted)
     if (vec_ok({dHnew, U, H, Cand, dCpre, dU, dH}, {n}))
         hipLaunchKernelGGL(gru_blend_bwd_vec_kernel, ew_grid(n / 4), dim3(EW_THREADS), 0, s, F4C(dHnew), F4C(U), F4C(H), F4C(Cand), F4M(dCpre), F4M(dU),
                            F4M(dH), (long long)n / 4);

@@ -483,6 +483,39 @@ extern "C" int stc_cell_cand_bwd_f32(const float* const* Z, int32_t Ks, const fl
     return STC_OK;
 }
 
+extern "C" int stc_bdg_node_post_supported(int32_t Ks, int32_t Kc, int32_t C, int32_t L, int32_t Ho) {
+    return (x3_enabled() && Ks == Kc && stc_node_post_shape_ok(Ks, C, L, Ho)) ? 1 : 0;
+}
+
+extern "C" int stc_bdg_node_post_bwd_f32(const float* X, const float* Tc, const float* W, const float* dA, const float* dB,
+                                         float* dX, float* dW, float* db, void* workspace, size_t workspace_bytes,
+                                         int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t Ho, void* stream) {
+    if (int rc = check_dims("stc_bdg_node_post_bwd_f32", 2, 2, C, L, Lw, Ho, nodes)) return rc;
+    if (!stc_bdg_node_post_supported(2, 2, C, L, Ho)) return stc::fail(STC_EUNSUPPORTED, "stc_bdg_node_post_bwd_f32: shape not on the post-aggregation path");
+    STC_REQUIRE(W && dW && Tc, STC_EINVAL, "stc_bdg_node_post_bwd_f32: null W/dW/Tc");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int nW = 4 * Lw * Ho;
+    if (nodes == 0) {
+        if (int rc = stc::hip_status(hipMemsetAsync(dW, 0, (size_t)nW * sizeof(float), s), "memset dW")) return rc;
+        if (db) if (int rc = stc::hip_status(hipMemsetAsync(db, 0, (size_t)Ho * sizeof(float), s), "memset db")) return rc;
+        return STC_OK;
+    }
+    STC_REQUIRE(X && dA && dB && dX, STC_EINVAL, "stc_bdg_node_post_bwd_f32: null pointer");
+    STC_REQUIRE(workspace && stc::aligned16(workspace), STC_EALIGN, "stc_bdg_node_post_bwd_f32: workspace null or not 16-byte aligned");
+    STC_REQUIRE(workspace_bytes >= stc_bdg_node_bwd_workspace_bytes(2, 2, C, L, Ho, 0), STC_EINVAL,
+                "stc_bdg_node_post_bwd_f32: workspace of %zu B is too small", workspace_bytes);
+    int n_parts = 0;
+    float* partial = static_cast<float*>(workspace);
+    const int rc = stc_node_post_bwd_x3(X, Tc, W, dA, dB, dX, partial, &n_parts, db != nullptr, nodes, C, L, Lw, Ho, s);
+    if (rc == STC_NOT_HANDLED) return stc::fail(STC_EUNSUPPORTED, "stc_bdg_node_post_bwd_f32: operands not usable (alignment)");
+    if (rc != STC_OK) return rc;
+    const int stride = nW + Ho;
+    hipLaunchKernelGGL(bdg_node_reduce_kernel, dim3((stride + RED_ELEMS - 1) / RED_ELEMS), dim3(NODE_THREADS), 0, s,
+                       partial, n_parts, stride, nW, Ho, 0, dW, db, static_cast<float*>(nullptr));
+    STC_LAUNCH_CHECK("stc_bdg_node_reduce launch");
+    return STC_OK;
+}
+
 extern "C" int stc_cell_blend_fwd_f32(const float* const* Z, int32_t Ks, const float* Tc, int32_t Kc,
                                       const float* W, const float* bias, const float* U, const float* H,
                                       float* Cand, float* Hnew,

@@ -541,6 +541,188 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
     combine_dw<K, LB, HB>(reinterpret_cast<float*>(smem_raw), dWt, dbp, partial, Lw, want_db);
 }
 
+// --------------------------------------------------------------------------------------- post-aggregation form (K = 2)
+// The aggregation acts on the node axis and the projection / category mix on the other two, so they commute:
+//     Y = sum_c T_c^T (X W_{0,c}) + S . sum_c T_c^T (X W_{1,c})  =  A + S.Bm        (reference STC_GNN.py:35-45 reassociated)
+// i.e. the SpMM can run AFTER the node kernel, on rows of C*Ho floats instead of C*L -- half the bytes for the candidate
+// convolution (Ho = 16 against L = 32) -- and the slab Z_1 = S.X is never formed, stored or re-read.  Backward of this
+// form: dA = dY, dBm = S^T dY (one narrow SpMM by the caller), and the kernel below turns (X, dA, dBm) into dX and dW
+// directly; there is no second gradient slab and no SpMM after it.
+//   per slab n (dY_0 = dA, dY_1 = dBm):  Q^n_0 = dY_n, Q^n_1 = T_1 dY_n
+//   dX^T (rows l, cols c') = sum_n sum_{c,o} W[(n,c,l)][o] Q^n_c[c'][o]        dW_{n,c} (rows l, cols o) += X^T Q^n_c
+template <int NB2, int HB, int L>
+__global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_kernel(
+    const float* __restrict__ X, const float* __restrict__ Tc, const float* __restrict__ W,
+    const float* __restrict__ dA, const float* __restrict__ dB, float* __restrict__ dX,
+    float* __restrict__ partial, int nodes, int want_db, int Lw) {
+    constexpr int K = 2, NRB = 2 * NB2, C = 32 * NB2, Ho = 16 * HB, LB = (L + 15) / 16;
+    constexpr int NBK = K * HB, S = (NBK + 1) / 2;
+    constexpr int nTB = NRB * NB2, nWA = K * LB * S;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32x4* TB = reinterpret_cast<u32x4*>(smem_raw);     // [NRB rb][NB2 p]        T_1[16rb + x][32p + pair_row]
+    u32x4* WA = TB + nTB * 3 * 64;                       // [K n][LB][S]           W[(n, c, 16lb + x)][16hb + 4g + (e&3)], block 2s + (e>>2)
+    const int tid = threadIdx.x, lane = tid & 63, x = lane & 15, g = lane >> 4;
+
+    for (int idx = tid; idx < nTB * 64; idx += MF_THREADS) {
+        const int ll = idx & 63, f = idx >> 6, p = f % NB2, rb = f / NB2, gg = ll >> 4;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = Tc[(size_t)C * C + (16 * rb + (ll & 15)) * C + 32 * p + pair_row(gg, e)];
+        put_frag(TB, f, ll, v);
+    }
+    for (int idx = tid; idx < nWA * 64; idx += MF_THREADS) {
+        const int ll = idx & 63, f = idx >> 6, s = f % S, lb = (f / S) % LB, n = f / (S * LB), gg = ll >> 4;
+        const int l = 16 * lb + (ll & 15);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int b = 2 * s + (e >> 2), c = b / HB, hb = b % HB;
+            v[e] = (b < NBK && l < Lw) ? W[((size_t)(n * K + c) * Lw + l) * Ho + 16 * hb + 4 * gg + (e & 3)] : 0.f;
+        }
+        put_frag(WA, f, ll, v);
+    }
+    __syncthreads();
+
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nw = gridDim.x * MF_WAVES;
+    f32x4 dWt[K][LB][K][HB];
+    float dbp[HB];
+#pragma unroll
+    for (int n = 0; n < K; ++n)
+#pragma unroll
+        for (int lb = 0; lb < LB; ++lb)
+#pragma unroll
+            for (int c = 0; c < K; ++c)
+#pragma unroll
+                for (int hb = 0; hb < HB; ++hb) dWt[n][lb][c][hb] = kZero4;
+#pragma unroll
+    for (int hb = 0; hb < HB; ++hb) dbp[hb] = 0.f;
+
+    for (int node = blockIdx.x * MF_WAVES + wave; node < nodes; node += nw) {
+        const size_t r0 = (size_t)node * C;
+        DyFrag<NRB, HB> gr[K];
+        gr[0].load(dA, node, x, g);
+        gr[1].load(dB, node, x, g);
+        float za[LB][NRB][4];                                   // X[16kb + 4g + t][16lb + x]
+#pragma unroll
+        for (int lb = 0; lb < LB; ++lb) {
+            const bool ok = 16 * lb + x < L;
+            const float* col = X + r0 * L + 16 * lb + (ok ? x : 0);
+#pragma unroll
+            for (int kb = 0; kb < NRB; ++kb)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float zv = col[(size_t)(16 * kb + 4 * g + t) * L];
+                    za[lb][kb][t] = ok ? zv : 0.f;
+                }
+        }
+        const int lo = opaque(lane);
+
+#pragma unroll
+        for (int kb = 0; kb < NRB; ++kb)
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb)                       // the bias sits on A only
+                dbp[hb] += (gr[0].d[kb][hb][0] + gr[0].d[kb][hb][1]) + (gr[0].d[kb][hb][2] + gr[0].d[kb][hb][3]);
+
+        X3 gd[K][HB][NB2];
+#pragma unroll
+        for (int n = 0; n < K; ++n)
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+                for (int p = 0; p < NB2; ++p) gd[n][hb][p] = split8(gr[n].d[2 * p][hb], gr[n].d[2 * p + 1][hb]);
+
+        // ---- B operands of dX: per slab n, step s covers the (c, o) blocks 2s, 2s+1 of (Q^n_c)^T
+        X3 qb[K][S][NRB];
+#pragma unroll
+        for (int n = 0; n < K; ++n) {
+            f32x4 Qv[NRB][HB];                                   // (T_1 dY_n)^T tiles (rows o, columns c')
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+#pragma unroll
+                for (int hb = 0; hb < HB; ++hb) Qv[rb][hb] = kZero4;
+#pragma unroll
+                for (int p = 0; p < NB2; ++p) {
+                    const X3 t = get_frag(TB, rb * NB2 + p, lo);
+#pragma unroll
+                    for (int hb = 0; hb < HB; ++hb) Qv[rb][hb] = mma6(gd[n][hb][p], t, Qv[rb][hb]);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) {
+                    f32x4 blk[2];
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        const int b = 2 * s + h2, c = b / HB, hb = b % HB;
+                        blk[h2] = b >= NBK ? kZero4 : (c == 0 ? gr[n].v[rb][hb] : Qv[rb][hb]);
+                    }
+                    qb[n][s][rb] = split8(blk[0], blk[1]);
+                }
+        }
+
+        // ---- dX^T tile (rows l, columns c'): both slabs' weights against both slabs' gradients
+#pragma unroll
+        for (int lb = 0; lb < LB; ++lb) {
+            f32x4 z[NRB];
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) z[rb] = kZero4;
+#pragma unroll
+            for (int n = 0; n < K; ++n)
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const X3 w = get_frag(WA, (n * LB + lb) * S + s, lo);
+#pragma unroll
+                    for (int rb = 0; rb < NRB; ++rb) z[rb] = mma6(w, qb[n][s][rb], z[rb]);
+                }
+            if (16 * lb + 4 * g < L) {
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb)
+                    *reinterpret_cast<f32x4*>(dX + (r0 + 16 * rb + x) * L + 16 * lb + 4 * g) = z[rb];
+            }
+        }
+
+        // ---- Q^n_1 tiles (rows c', columns o) as operands, then dW_{n,c} += X^T Q^n_c (the X columns are split once)
+        X3 qd[K][HB][NB2];
+#pragma unroll
+        for (int n = 0; n < K; ++n) {
+            f32x4 Qd[NRB][HB];
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+#pragma unroll
+                for (int hb = 0; hb < HB; ++hb) Qd[rb][hb] = kZero4;
+#pragma unroll
+                for (int p = 0; p < NB2; ++p) {
+                    const X3 t = get_frag(TB, rb * NB2 + p, lo);
+#pragma unroll
+                    for (int hb = 0; hb < HB; ++hb) Qd[rb][hb] = mma6(t, gd[n][hb][p], Qd[rb][hb]);
+                }
+            }
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+                for (int p = 0; p < NB2; ++p) qd[n][hb][p] = split8(Qd[2 * p][hb], Qd[2 * p + 1][hb]);
+        }
+#pragma unroll
+        for (int lb = 0; lb < LB; ++lb)
+#pragma unroll
+            for (int p = 0; p < NB2; ++p) {
+                const float (&zc)[NRB][4] = za[lb];
+                const X3 a = split8(f32x4{zc[2 * p][0], zc[2 * p][1], zc[2 * p][2], zc[2 * p][3]},
+                                    f32x4{zc[2 * p + 1][0], zc[2 * p + 1][1], zc[2 * p + 1][2], zc[2 * p + 1][3]});
+#pragma unroll
+                for (int n = 0; n < K; ++n)
+#pragma unroll
+                    for (int c = 0; c < K; ++c)
+#pragma unroll
+                        for (int hb = 0; hb < HB; ++hb)
+                            dWt[n][lb][c][hb] = mma6(a, c == 0 ? gd[n][hb][p] : qd[n][hb][p], dWt[n][lb][c][hb]);
+            }
+    }
+    combine_dw<K, LB, HB>(reinterpret_cast<float*>(smem_raw), dWt, dbp, partial, Lw, want_db);
+}
+
 // --------------------------------------------------------------------------------------- host side
 template <int NB2, int HB, int K, int L, int EPI = EPI_NONE, int GATHER = 0>
 int launch_fwd(const float* const* Z, const float* Tc, const float* W, const float* bias, float* Y,
@@ -747,5 +929,43 @@ int stc_cell_blend_fwd_gather_x3(const int* rowptr, const int* colidx, const flo
 #define BG_CALL(a, d) launch_fwd<a, 1, 2, d, EPI_BLEND, 1>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi, ga)
     STC_X3_GATHER_CASE(BG_CALL)
 #undef BG_CALL
+    return STC_NOT_HANDLED;
+}
+
+// ---- post-aggregation backward (K = 2): (X, dA, dBm) -> dX, dW partials
+template <int NB2, int HB, int L>
+static int launch_bwd2(const float* X, const float* Tc, const float* W, const float* dA, const float* dB, float* dX,
+                       float* partial, int* n_partials, int want_db, long long nodes, int Lw, hipStream_t stream) {
+    constexpr int K = 2, NRB = 2 * NB2, Ho = 16 * HB, LB = (L + 15) / 16, NBK = K * HB, S = (NBK + 1) / 2, nW = K * K * L * Ho;
+    const size_t frag = (size_t)(NRB * NB2 + K * LB * S) * 3 * 64 * 16;
+    const size_t slabs = (size_t)MF_WAVES * (nW + Ho) * sizeof(float);
+    const size_t lds = frag > slabs ? frag : slabs;
+    if (lds > stc::kMaxLdsBytes) return STC_NOT_HANDLED;
+    auto kern = node_bwd2_x3_kernel<NB2, HB, L>;
+    if (int rc = stc::hip_status(stc::allow_lds(kern, lds), "hipFuncSetAttribute(node bwd2 x3)")) return rc;
+    static const int resident = stc::resident_blocks(kern, MF_THREADS, lds, NB2 == 1 ? 2 : 1);
+    const long long want = (nodes + MF_WAVES - 1) / MF_WAVES;
+    int grid = resident < MF_BWD_MAX_GRID ? resident : MF_BWD_MAX_GRID;
+    if (want < grid) grid = (int)want;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(MF_THREADS), lds, stream, X, Tc, W, dA, dB, dX, partial, (int)nodes, want_db, Lw);
+    STC_LAUNCH_CHECK("node_bwd2_x3 launch");
+    *n_partials = grid;
+    return STC_OK;
+}
+
+int stc_node_post_shape_ok(int K, int C, int L, int Ho) {
+    return K == 2 && (C == 32 || C == 64) && (L == 20 || L == 32) && Ho == 16;     // Ho < L: where the narrow SpMM pays
+}
+
+int stc_node_post_bwd_x3(const float* X, const float* Tc, const float* W, const float* dA, const float* dB, float* dX,
+                         float* partial, int* n_partials, int want_db, long long nodes, int C, int L, int Lw, int Ho, hipStream_t stream) {
+    if (!stc_node_post_shape_ok(2, C, L, Ho) || nodes <= 0 || nodes >= (1ll << 31) / C) return STC_NOT_HANDLED;
+    if (!(stc::aligned16(X) && stc::aligned16(dA) && stc::aligned16(dB) && stc::aligned16(dX))) return STC_NOT_HANDLED;
+#define B2_CALL(a, b, d) launch_bwd2<a, b, d>(X, Tc, W, dA, dB, dX, partial, n_partials, want_db, nodes, Lw, stream)
+    if (C == 32 && L == 20) return B2_CALL(1, 1, 20);
+    if (C == 32 && L == 32) return B2_CALL(1, 1, 32);
+    if (C == 64 && L == 20) return B2_CALL(2, 1, 20);
+    if (C == 64 && L == 32) return B2_CALL(2, 1, 32);
+#undef B2_CALL
     return STC_NOT_HANDLED;
 }

@@ -28,6 +28,7 @@ EXPORTS = (
     'stc_csr_spmm_f32', 'stc_bcsr_spmm_f32', 'stc_spmm_bwd_gates_f32', 'stc_spmm_bwd_split_f32', 'stc_csr_sddmm_f32',
     'stc_cheby_dense_fwd_f32', 'stc_cheby_dense_bwd_f32',
     'stc_bdg_node_fwd_f32', 'stc_bdg_node_bwd_workspace_bytes', 'stc_bdg_node_bwd_f32',
+    'stc_bdg_node_post_supported', 'stc_bdg_node_post_bwd_f32',
     'stc_cell_fused_supported', 'stc_cell_gates_fwd_f32', 'stc_cell_gates_bwd_f32', 'stc_cell_cand_bwd_f32', 'stc_cell_blend_fwd_f32',
     'stc_cell_gather_supported', 'stc_cell_gates_fwd_gather_f32', 'stc_cell_blend_fwd_gather_f32',
     'stc_gru_gates_fwd_f32', 'stc_gru_gates_bwd_f32', 'stc_gru_blend_fwd_f32', 'stc_gru_blend_bwd_f32',
@@ -62,6 +63,7 @@ def _declare(lib):
         'stc_bdg_node_fwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
         'stc_bdg_node_bwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, C.POINTER(_p), _p, _p, _p,
                                  _p, C.c_size_t, _i64, _i32, _i32, _i32, _i32, _p],
+        'stc_bdg_node_post_bwd_f32': [_p, _p, _p, _p, _p, _p, _p, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _i32, _p],
         'stc_cell_gates_fwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _i32, _p],
         'stc_cell_cand_bwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _p, C.POINTER(_p), _p, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _i32, _p],
         'stc_cell_gates_bwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _i32, C.POINTER(_p), _p, _p, _p, _p,
@@ -86,6 +88,8 @@ def _declare(lib):
         fn.argtypes = argtypes
     lib.stc_cell_fused_supported.restype = C.c_int
     lib.stc_cell_fused_supported.argtypes = [_i32, _i32, _i32, _i32, _i32]
+    lib.stc_bdg_node_post_supported.restype = C.c_int
+    lib.stc_bdg_node_post_supported.argtypes = [_i32, _i32, _i32, _i32, _i32]
     lib.stc_cell_gather_supported.restype = C.c_int
     lib.stc_cell_gather_supported.argtypes = [_i32, _i32, _i32, _i32, _i32]
     lib.stc_head_bwd_workspace_bytes.restype = C.c_size_t
@@ -365,6 +369,24 @@ class HipKernels:
         ws = self._get_workspace(dY.device, nbytes)
         self._launch('stc_bdg_node_bwd_f32', dY, self._ptr_array(Zs), Ks, _ptr(Tc), Kc, _ptr(W), _ptr(dY), self._ptr_array(dZs), _ptr(dW), _ptr(db), _ptr(dTc), _ptr(ws), ws.numel(), R, Cc, L, Lw, Ho)
 
+    # ---- post-aggregation form (Ks = Kc = 2): Y = A + S.Bm --------------------------------------
+    def node_post_supported(self, Ks, Kc, Cc, L, Ho) -> bool:
+        return bool(self.lib.stc_bdg_node_post_supported(Ks, Kc, Cc, L, Ho))
+
+    def node_post_bwd(self, X, Tc, W, dA, dB, dX, dW, db):
+        """(X, dA = dY, dBm = S^T dY) -> dX, dW, db of the convolution in its post-aggregation form."""
+        Ks, Kc, R, Cc, L, Lw, Ho = self._node_shapes([X, X], Tc, W)
+        for name, t in (('dA', dA), ('dB', dB)):
+            self._f32('post.' + name, t, (R, Cc, Ho))
+        self._f32('post.dX', dX, (R, Cc, L))
+        self._f32('post.dW', dW, (Ks * Kc * Lw, Ho))
+        if db is not None:
+            self._f32('post.db', db, (Ho,))
+        self._same_device(X, Tc, W, dA, dB, dX, dW, db)
+        ws = self._get_workspace(X.device, self.lib.stc_bdg_node_bwd_workspace_bytes(Ks, Kc, Cc, L, Ho, 0))
+        self._launch('stc_bdg_node_post_bwd_f32', X, _ptr(X), _ptr(Tc), _ptr(W), _ptr(dA), _ptr(dB), _ptr(dX), _ptr(dW), _ptr(db),
+                     _ptr(ws), ws.numel(), R, Cc, L, Lw, Ho)
+
     # ---- fused cell convolutions ----------------------------------------------------------
     def cell_fused_supported(self, Ks, Kc, Cc, L, h) -> bool:
         return bool(self.lib.stc_cell_fused_supported(Ks, Kc, Cc, L, h))
@@ -550,9 +572,11 @@ class HipKernels:
         self._launch('stc_gru_blend_fwd_f32', H, _ptr(Cpre), _ptr(U), _ptr(H), _ptr(Cand), _ptr(Hnew), n)
 
     def gru_blend_bwd(self, dHnew, U, H, Cand, dCpre, dU, dH):
-        """``dH`` may be None (the (1 - U) share of the state is then formed by the consumer)."""
-        n = self._same_numel('blend_bwd', dHnew, U, H, Cand, dCpre, dU, *(() if dH is None else (dH,)))
-        self._launch('stc_gru_blend_bwd_f32', H, _ptr(dHnew), _ptr(U), _ptr(H), _ptr(Cand), _ptr(dCpre), _ptr(dU), _ptr(dH), n)
+        """``dU`` / ``dH`` may be None (those products are then formed by the consumer); ``H`` may be None when dU is."""
+        n = self._same_numel('blend_bwd', dHnew, U, Cand, dCpre, *(t for t in (H, dU, dH) if t is not None))
+        if dU is not None and H is None:
+            raise StcError('blend_bwd: dU needs H')
+        self._launch('stc_gru_blend_bwd_f32', U, _ptr(dHnew), _ptr(U), _ptr(H), _ptr(Cand), _ptr(dCpre), _ptr(dU), _ptr(dH), n)
 
     # ---- output head -----------------------------------------------------------------------
     def head_fwd(self, H, w, b, y):

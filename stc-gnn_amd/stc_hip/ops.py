@@ -432,6 +432,7 @@ def stc_cell(Xt, H, op: SpatialOperand, Tc, Wg, bg, Wc, bc, Ks: int):
 
 # ----------------------------------------------------------------------------- a whole schedule of cells as ONE autograd node
 _CELL_GRAPH = os.environ.get('STC_CELL_GRAPH', '1') != '0'
+_POST_AGG = os.environ.get('STC_POST_AGG', '1') != '0'          # candidate convolution as Y = A + S.Bm (narrow SpMM after the node kernel)
 
 
 def cell_graph_supported(op: SpatialOperand, Tc, Ks: int, C: int, h: int, x_widths) -> bool:
@@ -586,11 +587,21 @@ class _StcCellGraph(Function):
             dHnew = G.pop(j)
             L = Zc[0].shape[-1]
             v3 = lambda t: t.view(B, N, C * L)
-            # candidate convolution, blend backward in its prologue
-            g, dWc, dbc, _, _ = _bdg_backward_slabs(None, Zc, Wc, Tc, op, Ks, bc is not None, False, False, cand=(dHnew, U, Cand))
-            if Ks > 1:
-                k.csr_spmm(*bwd, N, N, v3(g[1]), v3(g[0]), v3(g[0]), 1.0, 1.0, plan=op.bwd_plan)
-            dci = g[0]
+            if _POST_AGG and k.node_post_supported(Ks, Tc.shape[0], C, L, h):
+                # candidate convolution in its post-aggregation form Y = A + S.Bm: the aggregation's transpose runs on the
+                # narrow gradient (C*h floats per row, not C*L) and the node kernel yields d[Xt | R*H] directly
+                dY, dBm = torch.empty_like(Hprev), torch.empty_like(Hprev)
+                k.gru_blend_bwd(dHnew, U, None, Cand, dY, None, None)                      # dY = dHnew * U * (1 - Cand^2)
+                k.csr_spmm(*bwd, N, N, dY.view(B, N, C * h), None, dBm.view(B, N, C * h), 1.0, 0.0, plan=op.bwd_plan)
+                dci, dWc = torch.empty_like(Zc[0]), torch.empty_like(Wc)
+                dbc = Wc.new_empty(h) if bc is not None else None
+                k.node_post_bwd(*rows((Zc[0],)), Tc, Wc, *rows((dY, dBm, dci)), dWc, dbc)
+            else:
+                # candidate convolution, blend backward in its prologue
+                g, dWc, dbc, _, _ = _bdg_backward_slabs(None, Zc, Wc, Tc, op, Ks, bc is not None, False, False, cand=(dHnew, U, Cand))
+                if Ks > 1:
+                    k.csr_spmm(*bwd, N, N, v3(g[1]), v3(g[0]), v3(g[0]), 1.0, 1.0, plan=op.bwd_plan)
+                dci = g[0]
             dH = torch.empty_like(Hprev)
             # gates convolution, gate + blend backward in its prologue
             g, dWg, dbg, _, _ = _bdg_backward_slabs(None, Zg, Wg, Tc, op, Ks, bg is not None, False, False,

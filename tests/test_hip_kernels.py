@@ -417,6 +417,31 @@ def test_fused_aggregation_cell_kernels(hip, batch, grid, C, cin):
     assert rel_err(Z1c, Z1_w) < TOL and rel_err(Cand, Cand_w) < TOL and rel_err(Hn, Hn_w) < TOL
 
 
+@pytest.mark.parametrize('nodes,C,L,Lw', [(50, 32, 32, 32), (50, 32, 20, 17), (13, 64, 32, 32), (9, 64, 20, 20), (4500, 32, 32, 32)])
+def test_post_aggregation_backward(hip, nodes, C, L, Lw):
+    """stc_bdg_node_post_bwd_f32: backward of Y = A + S.Bm from (X, dA, dBm) vs the CPU twin; bitwise reproducible dW."""
+    Ho, K = 16, 2
+    assert hip.node_post_supported(K, K, C, L, Ho)
+    g = torch.Generator().manual_seed(nodes + C + L)
+    rnd = lambda *s_: torch.randn(*s_, generator=g)
+    X = rnd(nodes, C, L)
+    X[..., Lw:] = 7.0                                               # garbage in the pad columns must not matter
+    Tc = rnd(K, C, C) / C ** 0.5
+    Tc[0] = torch.eye(C)
+    W = rnd(K * K * Lw, Ho) / (K * K * Lw) ** 0.5
+    dA, dB = rnd(nodes, C, Ho), rnd(nodes, C, Ho)
+    dX_w, dW_w, db_w = torch.empty(nodes, C, L), torch.empty_like(W), torch.empty(Ho)
+    EM.node_post_bwd(X, Tc, W, dA, dB, dX_w, dW_w, db_w)
+    nan = float('nan')
+    dX, dW, db = torch.full((nodes, C, L), nan).cuda(), torch.full_like(W, nan).cuda(), torch.full((Ho,), nan).cuda()
+    hip.node_post_bwd(cu(X), cu(Tc), cu(W), cu(dA), cu(dB), dX, dW, db)
+    assert rel_err(dX, dX_w) < TOL and rel_err(dW, dW_w) < TOL and rel_err(db, db_w) < TOL
+    assert float(dX[..., Lw:].abs().max()) == 0.0 if L > Lw else True
+    dW2 = torch.empty_like(dW)
+    hip.node_post_bwd(cu(X), cu(Tc), cu(W), cu(dA), cu(dB), dX, dW2, None)
+    assert torch.equal(dW, dW2)
+
+
 def test_fused_aggregation_is_refused_off_its_shapes(hip):
     from stc_hip import StcError
     assert not hip.cell_gather_supported(3, 3, 32, 32, 16) and not hip.cell_gather_supported(2, 2, 16, 32, 16)
