@@ -160,6 +160,21 @@ int stc_gru_blend_bwd_f32(const float* dHnew, const float* U, const float* H, co
  * Shapes: C in {32, 64}, L in {20, 32}, Ho = 16 (stc_bdg_node_post_supported), else STC_EUNSUPPORTED.
  * workspace as stc_bdg_node_bwd_f32 (stc_bdg_node_bwd_workspace_bytes(2, 2, C, L, Ho, 0)). */
 int stc_bdg_node_post_supported(int32_t Ks, int32_t Kc, int32_t C, int32_t L, int32_t Ho);
+/* forward: X (nodes, C, L) -> A = sum_c T_c^T (X W_{0,c}) + bias and Bm = sum_c T_c^T (X W_{1,c}), (nodes, C, Ho) each;
+ * the caller finishes Y = A + Gs^T x Bm with stc_csr/bcsr_spmm_f32 (Y0 = A) or, for the STC_Cell's candidate
+ * convolution, with stc_spmm_blend_fwd_f32 (the GRU blend of STC_GNN.py:76-78 in the SpMM's epilogue). */
+int stc_bdg_node_post_fwd_f32(const float* X, const float* Tc, const float* W, const float* bias,
+                              float* A, float* Bm,
+                              int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t Ho, void* stream);
+/* Y = A + S x Bm on rows of C*h floats (h = 16) with the blend as epilogue: Cand = tanh(Y), Hnew = (1-U)*H + U*Cand,
+ * plus the optional state copies / side columns of stc_cell_blend_fwd_f32.  Graph as either form (see stc_spmm_bwd_*). */
+int stc_spmm_blend_fwd_f32(const int32_t* rowptr, const int32_t* colidx, const float* val,
+                           const int32_t* blk_ptr, const int32_t* blk_cols, const float* blk_vals,
+                           int32_t n_rows, int32_t n_cols, const float* Bm, const float* A,
+                           const float* U, const float* H, float* Cand, float* Hnew,
+                           float* copy0, int32_t copy0_ld, int32_t copy0_off, const float* side_src, int32_t side_cin,
+                           float* copy1, int32_t copy1_ld, int32_t copy1_off,
+                           int32_t batch, int32_t C, int32_t h, void* stream);
 int stc_bdg_node_post_bwd_f32(const float* X, const float* Tc, const float* W, const float* dA, const float* dB,
                               float* dX, float* dW, float* db, void* workspace, size_t workspace_bytes,
                               int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t Ho, void* stream);

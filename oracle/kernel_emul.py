@@ -145,6 +145,28 @@ class EmulatedKernels:
     def node_post_supported(self, Ks, Kc, Cc, L, Ho) -> bool:
         return Ks == 2 and Kc == 2
 
+    def node_post_fwd(self, X, Tc, W, bias, A, Bm):
+        Lw = W.shape[0] // 4
+        for n, out in enumerate((A, Bm)):
+            acc = torch.zeros_like(out)
+            for c in range(2):
+                P = X[..., :Lw] @ W[(n * 2 + c) * Lw:(n * 2 + c + 1) * Lw]            # (R, C, Ho)
+                acc += P if c == 0 else torch.einsum('pd,rpo->rdo', Tc[c], P)          # T_c^T P
+            out.copy_(acc + (bias if (bias is not None and n == 0) else 0))
+
+    def spmm_blend_fwd(self, rowptr, colidx, val, plan, Bm, A, U, H, Cand, Hnew, copies=(), side=None):
+        B, n, Cc, h = H.shape
+        Y = torch.empty_like(A)
+        self.csr_spmm(rowptr, colidx, val, n, n, Bm.view(B, n, Cc * h), A.view(B, n, Cc * h), Y.view(B, n, Cc * h), 1.0, 1.0)
+        self.gru_blend_fwd(Y, U, H, Cand, Hnew)
+        flat = Hnew.reshape(B * n, Cc, h)
+        for buf, off in copies:
+            buf[..., off:off + h].copy_(flat)
+        if side is not None:
+            buf, off = copies[0]
+            buf[..., :off].copy_(side)
+            buf[..., off + h:].zero_()
+
     def node_post_bwd(self, X, Tc, W, dA, dB, dX, dW, db):
         Lw = W.shape[0] // 4
         dW.zero_()

@@ -487,6 +487,18 @@ extern "C" int stc_bdg_node_post_supported(int32_t Ks, int32_t Kc, int32_t C, in
     return (x3_enabled() && Ks == Kc && stc_node_post_shape_ok(Ks, C, L, Ho)) ? 1 : 0;
 }
 
+extern "C" int stc_bdg_node_post_fwd_f32(const float* X, const float* Tc, const float* W, const float* bias,
+                                         float* A, float* Bm,
+                                         int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t Ho, void* stream) {
+    if (int rc = check_dims("stc_bdg_node_post_fwd_f32", 2, 2, C, L, Lw, Ho, nodes)) return rc;
+    if (!stc_bdg_node_post_supported(2, 2, C, L, Ho)) return stc::fail(STC_EUNSUPPORTED, "stc_bdg_node_post_fwd_f32: shape not on the post-aggregation path");
+    if (nodes == 0) return STC_OK;
+    STC_REQUIRE(X && Tc && W && A && Bm, STC_EINVAL, "stc_bdg_node_post_fwd_f32: null pointer");
+    STC_REQUIRE(A != Bm && X != A && X != Bm, STC_EINVAL, "stc_bdg_node_post_fwd_f32: outputs must not alias");
+    const int rc = stc_node_post_fwd_x3(X, Tc, W, bias, A, Bm, nodes, C, L, Lw, Ho, static_cast<hipStream_t>(stream));
+    return rc == STC_NOT_HANDLED ? stc::fail(STC_EUNSUPPORTED, "stc_bdg_node_post_fwd_f32: operands not usable (alignment)") : rc;
+}
+
 extern "C" int stc_bdg_node_post_bwd_f32(const float* X, const float* Tc, const float* W, const float* dA, const float* dB,
                                          float* dX, float* dW, float* db, void* workspace, size_t workspace_bytes,
                                          int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t Ho, void* stream) {

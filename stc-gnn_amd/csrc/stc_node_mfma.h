@@ -80,3 +80,5 @@ int stc_cell_cand_bwd_x3(const float* const* Z, int K, const float* Tc, const fl
 int stc_node_post_shape_ok(int K, int C, int L, int Ho);
 int stc_node_post_bwd_x3(const float* X, const float* Tc, const float* W, const float* dA, const float* dB, float* dX,
                          float* partial, int* n_partials, int want_db, long long nodes, int C, int L, int Lw, int Ho, hipStream_t stream);
+int stc_node_post_fwd_x3(const float* X, const float* Tc, const float* W, const float* bias, float* A, float* Bm,
+                         long long nodes, int C, int L, int Lw, int Ho, hipStream_t stream);

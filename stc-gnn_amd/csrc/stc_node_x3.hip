@@ -550,6 +550,106 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
 // directly; there is no second gradient slab and no SpMM after it.
 //   per slab n (dY_0 = dA, dY_1 = dBm):  Q^n_0 = dY_n, Q^n_1 = T_1 dY_n
 //   dX^T (rows l, cols c') = sum_n sum_{c,o} W[(n,c,l)][o] Q^n_c[c'][o]        dW_{n,c} (rows l, cols o) += X^T Q^n_c
+// forward of the post-aggregation form: one input slab X, the two weight sets of the Chebyshev orders kept apart
+//     A = sum_c T_c^T (X W_{0,c}) + b      Bm = sum_c T_c^T (X W_{1,c})           (nodes, C, Ho) each
+template <int NB2, int HB, int L>
+__global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd2_x3_kernel(
+    const float* __restrict__ X, const float* __restrict__ Tc, const float* __restrict__ W, const float* __restrict__ bias,
+    float* __restrict__ A, float* __restrict__ Bm, int nodes, int Lw) {
+    constexpr int K = 2, NRB = 2 * NB2, C = 32 * NB2, Ho = 16 * HB, NCB = K * HB;
+    constexpr int nWx = K * NCB, nTx = NRB * NB2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32x4* Wx = reinterpret_cast<u32x4*>(smem_raw);        // [K n][NCB]     B: W[(n, c, l = slot)][o = 16 hb + x]
+    u32x4* Tx = Wx + nWx * 3 * 64;                          // [NRB rb][NB2]  A: T_1[c' = 32 p + pair_row][d = 16 rb + x]
+    const int tid = threadIdx.x, lane = tid & 63, x = lane & 15, g = lane >> 4;
+
+    for (int idx = tid; idx < nWx * 64; idx += MF_THREADS) {
+        const int ll = idx & 63, f = idx >> 6, cb = f % NCB, n = f / NCB;
+        const int c = cb / HB, o = (cb % HB) * 16 + (ll & 15), gg = ll >> 4;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int l = 8 * gg + e;
+            v[e] = l < Lw ? W[((size_t)(n * K + c) * Lw + l) * Ho + o] : 0.f;
+        }
+        put_frag(Wx, f, ll, v);
+    }
+    for (int idx = tid; idx < nTx * 64; idx += MF_THREADS) {
+        const int ll = idx & 63, f = idx >> 6, p = f % NB2, rb = f / NB2, gg = ll >> 4;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = Tc[(size_t)C * C + (32 * p + pair_row(gg, e)) * C + 16 * rb + (ll & 15)];
+        put_frag(Tx, f, ll, v);
+    }
+    __syncthreads();
+
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nw = gridDim.x * MF_WAVES;
+    float bv[HB];
+#pragma unroll
+    for (int hb = 0; hb < HB; ++hb) bv[hb] = bias ? bias[16 * hb + x] : 0.f;
+
+    int node = blockIdx.x * MF_WAVES + wave;
+    Row8<L> cur[NRB], nxt[NRB];
+    auto load_rows = [&](Row8<L> (&z)[NRB], int nd) {
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) z[rb].load(X + ((size_t)nd * C + 16 * rb + x) * L, g);
+    };
+    if (node < nodes) load_rows(cur, node);
+    while (node < nodes) {
+        const int next_node = node + nw;
+        if (next_node < nodes) load_rows(nxt, next_node);
+        __builtin_amdgcn_sched_barrier(0);
+        const int lo = opaque(lane);
+
+        f32x4 acc[K][NRB][NCB];
+#pragma unroll
+        for (int n = 0; n < K; ++n)
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) acc[n][rb][cb] = kZero4;
+        X3 za[NRB];                                              // the rows are split once for both weight sets
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) za[rb] = split8(cur[rb].a, cur[rb].b);
+#pragma unroll
+        for (int n = 0; n < K; ++n)
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                const X3 w = get_frag(Wx, n * NCB + cb, lo);
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) acc[n][rb][cb] = mma6(za[rb], w, acc[n][rb][cb]);
+            }
+        // mix per weight set: [rb][hb] += T_1^T [.][HB + hb]
+#pragma unroll
+        for (int n = 0; n < K; ++n)
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+                for (int p = 0; p < NB2; ++p) {
+                    const X3 u = split8(acc[n][2 * p][HB + hb], acc[n][2 * p + 1][HB + hb]);
+#pragma unroll
+                    for (int rb = 0; rb < NRB; ++rb) {
+                        const X3 t = get_frag(Tx, rb * NB2 + p, lo);
+                        acc[n][rb][hb] = mma6(t, u, acc[n][rb][hb]);
+                    }
+                }
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const size_t o = ((size_t)node * C + 16 * rb + 4 * g + r) * Ho + 16 * hb + x;
+                    A[o] = acc[0][rb][hb][r] + bv[hb];
+                    Bm[o] = acc[1][rb][hb][r];
+                }
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) cur[rb] = nxt[rb];
+        node = next_node;
+    }
+}
+
 template <int NB2, int HB, int L>
 __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_kernel(
     const float* __restrict__ X, const float* __restrict__ Tc, const float* __restrict__ W,
@@ -953,6 +1053,21 @@ static int launch_bwd2(const float* X, const float* Tc, const float* W, const fl
     return STC_OK;
 }
 
+template <int NB2, int HB, int L>
+static int launch_fwd2(const float* X, const float* Tc, const float* W, const float* bias, float* A, float* Bm,
+                       long long nodes, int Lw, hipStream_t stream) {
+    constexpr int K = 2, NRB = 2 * NB2, NCB = K * HB;
+    const size_t lds = (size_t)(K * NCB + NRB * NB2) * 3 * 64 * 16;
+    auto kern = node_fwd2_x3_kernel<NB2, HB, L>;
+    if (int rc = stc::hip_status(stc::allow_lds(kern, lds), "hipFuncSetAttribute(node fwd2 x3)")) return rc;
+    static const int resident = stc::resident_blocks(kern, MF_THREADS, lds, NB2 == 1 ? 2 : 1);
+    const long long want = (nodes + MF_WAVES - 1) / MF_WAVES;
+    const int grid = (int)(want < resident ? want : resident);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(MF_THREADS), lds, stream, X, Tc, W, bias, A, Bm, (int)nodes, Lw);
+    STC_LAUNCH_CHECK("node_fwd2_x3 launch");
+    return STC_OK;
+}
+
 int stc_node_post_shape_ok(int K, int C, int L, int Ho) {
     return K == 2 && (C == 32 || C == 64) && (L == 20 || L == 32) && Ho == 16;     // Ho < L: where the narrow SpMM pays
 }
@@ -967,5 +1082,18 @@ int stc_node_post_bwd_x3(const float* X, const float* Tc, const float* W, const 
     if (C == 64 && L == 20) return B2_CALL(2, 1, 20);
     if (C == 64 && L == 32) return B2_CALL(2, 1, 32);
 #undef B2_CALL
+    return STC_NOT_HANDLED;
+}
+
+int stc_node_post_fwd_x3(const float* X, const float* Tc, const float* W, const float* bias, float* A, float* Bm,
+                         long long nodes, int C, int L, int Lw, int Ho, hipStream_t stream) {
+    if (!stc_node_post_shape_ok(2, C, L, Ho) || nodes <= 0 || nodes >= (1ll << 31) / C) return STC_NOT_HANDLED;
+    if (!(stc::aligned16(X) && stc::aligned16(A) && stc::aligned16(Bm))) return STC_NOT_HANDLED;
+#define F2_CALL(a, d) launch_fwd2<a, 1, d>(X, Tc, W, bias, A, Bm, nodes, Lw, stream)
+    if (C == 32 && L == 20) return F2_CALL(1, 20);
+    if (C == 32 && L == 32) return F2_CALL(1, 32);
+    if (C == 64 && L == 20) return F2_CALL(2, 20);
+    if (C == 64 && L == 32) return F2_CALL(2, 32);
+#undef F2_CALL
     return STC_NOT_HANDLED;
 }

@@ -58,7 +58,7 @@ __device__ __forceinline__ void nt_store4(float4* p, const float4& v) {
     __builtin_nontemporal_store(v4f{v.x, v.y, v.z, v.w}, reinterpret_cast<v4f*>(p));
 }
 
-enum { EP_PLAIN = 0, EP_SPLIT = 1, EP_GATES = 2 };
+enum { EP_PLAIN = 0, EP_SPLIT = 1, EP_GATES = 2, EP_BLEND = 3 };
 
 struct EpiArgs {
     const float4* Y0;                       // base term (PLAIN: optional, scaled by beta; SPLIT/GATES: added)
@@ -69,6 +69,11 @@ struct EpiArgs {
     float* dG;                              // GATES output, (rows*C, 2h)
     const float *addA, *addB;               // SPLIT: gradients already owed to Xt / H (may be null, may alias outA/outB)
     float *outA, *outB;                     // dXt (rows*C, cin), dH (rows*C, h)
+    // BLEND (forward, post-aggregation candidate convolution): Y0 = A (bias included), rows of C*h floats;
+    // Cand = tanh(A + S.Bm), Hnew = (1-U)*H + U*Cand, plus the state copies of stc_cell_blend_fwd_f32
+    float *Cand, *Hnew;                     // (rows*C, h)
+    float* copy[2]; int copy_ld[2], copy_off[2];
+    const float* side_src; int side_cin;    // belongs to copy[0]
 };
 
 // one element of a [Xt | H | pad] row: l = column, e = (row, category) index, v = its gradient
@@ -91,6 +96,37 @@ __device__ __forceinline__ void route_scalar(const EpiArgs& a, size_t e, int l, 
     }
 }
 
+// the GRU blend on one 16-byte piece of a (row, category) state row, plus its copies (EP_BLEND)
+__device__ __forceinline__ float tanh_fast(float v) {          // 1 - 2 / (e^{2v} + 1) on the hardware exp2 / rcp: |err| < 2e-7
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.8853900817779268f * v));
+}
+__device__ __forceinline__ void blend_piece(const EpiArgs& a, size_t rowg, int ch, size_t o, const float4& v, const float4& u, const float4& hh) {
+    const float4 c = make_float4(tanh_fast(v.x), tanh_fast(v.y), tanh_fast(v.z), tanh_fast(v.w));
+    const float4 hn = make_float4((1.f - u.x) * hh.x + u.x * c.x, (1.f - u.y) * hh.y + u.y * c.y,
+                                  (1.f - u.z) * hh.z + u.z * c.z, (1.f - u.w) * hh.w + u.w * c.w);
+    *reinterpret_cast<float4*>(a.Cand + 4 * o) = c;
+    *reinterpret_cast<float4*>(a.Hnew + 4 * o) = hn;
+    const int q4 = ch & 3;
+    const size_t e = rowg * a.C + (ch >> 2);
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+        if (a.copy[k]) {
+            float* dst = a.copy[k] + e * a.copy_ld[k] + a.copy_off[k] + 4 * q4;
+            if (((a.copy_ld[k] | a.copy_off[k]) & 3) == 0) {
+                *reinterpret_cast<float4*>(dst) = hn;
+            } else {
+                dst[0] = hn.x; dst[1] = hn.y; dst[2] = hn.z; dst[3] = hn.w;
+            }
+        }
+    if (a.side_src) {                   // complete the consumer's row: its input columns and its zero padding
+        float* drow = a.copy[0] + e * a.copy_ld[0];
+        if (q4 == 0)
+            for (int col = 0; col < a.side_cin; ++col) drow[col] = a.side_src[e * a.side_cin + col];
+        if (q4 == 3)
+            for (int col = a.side_cin + a.h; col < a.copy_ld[0]; ++col) drow[col] = 0.f;
+    }
+}
+
 // rowg = b*n_rows + row; ch = float4 index inside the row; acc = sum_j val_j X[col_j] for that piece
 template <int MODE>
 __device__ __forceinline__ void epilogue(const EpiArgs& a, size_t rowg, int F4, int ch, const float4& acc) {
@@ -107,6 +143,11 @@ __device__ __forceinline__ void epilogue(const EpiArgs& a, size_t rowg, int F4, 
     }
     const float4 y0 = nt_load4(a.Y0 + o);
     const float4 v = make_float4(acc.x + y0.x, acc.y + y0.y, acc.z + y0.z, acc.w + y0.w);
+    if (MODE == EP_BLEND) {                 // rows are (category, h) with h = 16: piece ch = 4 * category + quarter
+        const float4 u = *reinterpret_cast<const float4*>(a.U + 4 * o), hh = *reinterpret_cast<const float4*>(a.H + 4 * o);
+        blend_piece(a, rowg, ch, o, v, u, hh);
+        return;
+    }
     const int f = ch * 4;
     const int c = f / a.L, l = f - c * a.L;
     const size_t e = rowg * a.C + c;
@@ -293,6 +334,24 @@ __global__ __launch_bounds__(SPMM_THREADS) void spmm_bcsr_kernel(
             for (int r = 0; r < BR; ++r)
 #pragma unroll
                 for (int p = 0; p < VPT; ++p) acc[r][p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            // EP_BLEND: the epilogue's own operands (A, U, H pieces of the block's rows) are requested BEFORE the gather so
+            // that they arrive under it instead of as a second exposed round trip at the end
+            constexpr int PR = MODE == EP_BLEND ? BR : 1;
+            float4 pa[PR][VPT], pu[PR][VPT], ph[PR][VPT];
+            if (MODE == EP_BLEND) {
+#pragma unroll
+                for (int r = 0; r < PR; ++r)
+#pragma unroll
+                    for (int p = 0; p < VPT; ++p) {
+                        const int ch = cb + lane + 64 * p;
+                        if (r < rows_here && ch < F4) {
+                            const size_t o = ((size_t)b * n_rows + row_base + r) * F4 + ch;
+                            pa[r][p] = nt_load4(ep.Y0 + o);
+                            pu[r][p] = *reinterpret_cast<const float4*>(ep.U + 4 * o);
+                            ph[r][p] = *reinterpret_cast<const float4*>(ep.H + 4 * o);
+                        }
+                    }
+            }
 
             auto entry = [&](int j, int& c, float (&v)[BR]) {
                 if (j < BC_CAP) {
@@ -354,7 +413,16 @@ __global__ __launch_bounds__(SPMM_THREADS) void spmm_bcsr_kernel(
 #pragma unroll
                     for (int p = 0; p < VPT; ++p) {
                         const int ch = cb + lane + 64 * p;
-                        if (ch < F4) epilogue<MODE>(ep, rowg, F4, ch, acc[r][p]);
+                        if (ch < F4) {
+                            if (MODE == EP_BLEND) {
+                                const int rp = MODE == EP_BLEND ? r : 0;
+                                const float4 y = make_float4(acc[r][p].x + pa[rp][p].x, acc[r][p].y + pa[rp][p].y,
+                                                             acc[r][p].z + pa[rp][p].z, acc[r][p].w + pa[rp][p].w);
+                                blend_piece(ep, rowg, ch, rowg * F4 + ch, y, pu[rp][p], ph[rp][p]);
+                            } else {
+                                epilogue<MODE>(ep, rowg, F4, ch, acc[r][p]);
+                            }
+                        }
                     }
                 }
             }
@@ -464,7 +532,8 @@ int check_fused(const char* who, const GraphArgs& g, int n_rows, int n_cols, con
     STC_REQUIRE((long long)C * (cin + h + pad) >= 64, STC_ELIMIT, "%s: node row of %d floats is too narrow for the vector kernels", who, C * (cin + h + pad));
     STC_REQUIRE(batch <= 65535, STC_ELIMIT, "%s: batch %d > 65535 (grid.y)", who, batch);
     if (n_rows == 0 || batch == 0) return STC_OK;
-    STC_REQUIRE((g.blk_ptr && g.blk_cols && g.blk_vals) || (g.rowptr && g.colidx && g.val), STC_EINVAL, "%s: neither graph form given", who);
+    // the column / value arrays may be null for a graph without edges (pointer arrays all zero: they are never read)
+    STC_REQUIRE(g.blk_ptr || g.rowptr, STC_EINVAL, "%s: neither graph form given", who);
     STC_REQUIRE(X && Y0 && n_cols > 0, STC_EINVAL, "%s: null X / Y0", who);
     STC_REQUIRE(stc::aligned16(X) && stc::aligned16(Y0), STC_EALIGN, "%s: X / Y0 must be 16-byte aligned", who);
     return STC_OK;
@@ -567,6 +636,39 @@ extern "C" int stc_spmm_bwd_split_f32(const int32_t* rowptr, const int32_t* coli
     ep.addA = addA; ep.addB = addB; ep.outA = outA; ep.outB = outB;
     return launch_vector<EP_SPLIT>("stc_spmm_bwd_split_f32 launch", g, n_rows, n_cols, X, batch, C * (cin + h + pad), ep,
                                    static_cast<hipStream_t>(stream));
+}
+
+extern "C" int stc_spmm_blend_fwd_f32(const int32_t* rowptr, const int32_t* colidx, const float* val,
+                                      const int32_t* blk_ptr, const int32_t* blk_cols, const float* blk_vals,
+                                      int32_t n_rows, int32_t n_cols, const float* Bm, const float* A,
+                                      const float* U, const float* H, float* Cand, float* Hnew,
+                                      float* copy0, int32_t copy0_ld, int32_t copy0_off, const float* side_src, int32_t side_cin,
+                                      float* copy1, int32_t copy1_ld, int32_t copy1_off,
+                                      int32_t batch, int32_t C, int32_t h, void* stream) {
+    const GraphArgs g{rowptr, colidx, val, blk_ptr, blk_cols, blk_vals};
+    STC_REQUIRE(h == 16, STC_EUNSUPPORTED, "stc_spmm_blend_fwd_f32: hidden width %d (the blend epilogue is built for 16)", h);
+    if (int rc = check_fused("stc_spmm_blend_fwd_f32", g, n_rows, n_cols, Bm, A, batch, C, 0, h, 0)) return rc;
+    if (n_rows == 0 || batch == 0) return STC_OK;
+    STC_REQUIRE(U && H && Cand && Hnew, STC_EINVAL, "stc_spmm_blend_fwd_f32: null pointer");
+    STC_REQUIRE(stc::aligned16(U) && stc::aligned16(H) && stc::aligned16(Cand) && stc::aligned16(Hnew), STC_EALIGN,
+                "stc_spmm_blend_fwd_f32: operands must be 16-byte aligned");
+    STC_REQUIRE(Bm != Cand && Bm != Hnew, STC_EINVAL, "stc_spmm_blend_fwd_f32: outputs must not alias Bm (its rows are gathered by other rows)");
+    STC_REQUIRE((!copy0 || (copy0_off >= 0 && copy0_off + h <= copy0_ld)) && (!copy1 || (copy1_off >= 0 && copy1_off + h <= copy1_ld)),
+                STC_EINVAL, "stc_spmm_blend_fwd_f32: state copy columns [off, off+%d) do not fit the row width", h);
+    STC_REQUIRE(!side_src || (copy0 && side_cin >= 0 && side_cin == copy0_off), STC_EINVAL,
+                "stc_spmm_blend_fwd_f32: side_src needs copy0 with copy0_off == side_cin");
+    STC_REQUIRE((!copy0 || (reinterpret_cast<uintptr_t>(copy0) & 3u) == 0) && (!copy1 || (reinterpret_cast<uintptr_t>(copy1) & 3u) == 0),
+                STC_EALIGN, "stc_spmm_blend_fwd_f32: misaligned copy destination");
+    if (copy0 && ((copy0_ld | copy0_off) & 3) == 0) STC_REQUIRE(stc::aligned16(copy0), STC_EALIGN, "stc_spmm_blend_fwd_f32: copy0 not 16-byte aligned");
+    if (copy1 && ((copy1_ld | copy1_off) & 3) == 0) STC_REQUIRE(stc::aligned16(copy1), STC_EALIGN, "stc_spmm_blend_fwd_f32: copy1 not 16-byte aligned");
+    EpiArgs ep{};
+    ep.Y0 = reinterpret_cast<const float4*>(A);
+    ep.C = C; ep.L = h; ep.cin = 0; ep.h = h;
+    ep.U = U; ep.H = H; ep.Cand = Cand; ep.Hnew = Hnew;
+    ep.copy[0] = copy0; ep.copy_ld[0] = copy0_ld; ep.copy_off[0] = copy0_off;
+    ep.copy[1] = copy1; ep.copy_ld[1] = copy1_ld; ep.copy_off[1] = copy1_off;
+    ep.side_src = copy0 ? side_src : nullptr; ep.side_cin = side_cin;
+    return launch_vector<EP_BLEND>("stc_spmm_blend_fwd_f32 launch", g, n_rows, n_cols, Bm, batch, C * h, ep, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int stc_csr_sddmm_f32(const int32_t* rowptr, const int32_t* colidx,

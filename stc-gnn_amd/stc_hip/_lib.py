@@ -28,7 +28,7 @@ EXPORTS = (
     'stc_csr_spmm_f32', 'stc_bcsr_spmm_f32', 'stc_spmm_bwd_gates_f32', 'stc_spmm_bwd_split_f32', 'stc_csr_sddmm_f32',
     'stc_cheby_dense_fwd_f32', 'stc_cheby_dense_bwd_f32',
     'stc_bdg_node_fwd_f32', 'stc_bdg_node_bwd_workspace_bytes', 'stc_bdg_node_bwd_f32',
-    'stc_bdg_node_post_supported', 'stc_bdg_node_post_bwd_f32',
+    'stc_bdg_node_post_supported', 'stc_bdg_node_post_fwd_f32', 'stc_bdg_node_post_bwd_f32', 'stc_spmm_blend_fwd_f32',
     'stc_cell_fused_supported', 'stc_cell_gates_fwd_f32', 'stc_cell_gates_bwd_f32', 'stc_cell_cand_bwd_f32', 'stc_cell_blend_fwd_f32',
     'stc_cell_gather_supported', 'stc_cell_gates_fwd_gather_f32', 'stc_cell_blend_fwd_gather_f32',
     'stc_gru_gates_fwd_f32', 'stc_gru_gates_bwd_f32', 'stc_gru_blend_fwd_f32', 'stc_gru_blend_bwd_f32',
@@ -63,6 +63,8 @@ def _declare(lib):
         'stc_bdg_node_fwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
         'stc_bdg_node_bwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, C.POINTER(_p), _p, _p, _p,
                                  _p, C.c_size_t, _i64, _i32, _i32, _i32, _i32, _p],
+        'stc_bdg_node_post_fwd_f32': [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
+        'stc_spmm_blend_fwd_f32': [_p] * 6 + [_i32, _i32] + [_p] * 6 + [_p, _i32, _i32, _p, _i32, _p, _i32, _i32] + [_i32] * 3 + [_p],
         'stc_bdg_node_post_bwd_f32': [_p, _p, _p, _p, _p, _p, _p, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _i32, _p],
         'stc_cell_gates_fwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _i32, _p],
         'stc_cell_cand_bwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _p, C.POINTER(_p), _p, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _i32, _p],
@@ -372,6 +374,44 @@ class HipKernels:
     # ---- post-aggregation form (Ks = Kc = 2): Y = A + S.Bm --------------------------------------
     def node_post_supported(self, Ks, Kc, Cc, L, Ho) -> bool:
         return bool(self.lib.stc_bdg_node_post_supported(Ks, Kc, Cc, L, Ho))
+
+    def node_post_fwd(self, X, Tc, W, bias, A, Bm):
+        """X -> A = sum_c T_c^T (X W_{0,c}) + bias, Bm = sum_c T_c^T (X W_{1,c}); the caller finishes Y = A + S.Bm."""
+        Ks, Kc, R, Cc, L, Lw, Ho = self._node_shapes([X, X], Tc, W)
+        if bias is not None:
+            self._f32('post.bias', bias, (Ho,))
+        for name, t in (('A', A), ('Bm', Bm)):
+            self._f32('post.' + name, t, (R, Cc, Ho))
+        self._same_device(X, Tc, W, bias, A, Bm)
+        self._launch('stc_bdg_node_post_fwd_f32', X, _ptr(X), _ptr(Tc), _ptr(W), _ptr(bias), _ptr(A), _ptr(Bm), R, Cc, L, Lw, Ho)
+
+    def spmm_blend_fwd(self, rowptr, colidx, val, plan, Bm, A, U, H, Cand, Hnew, copies=(), side=None):
+        """Y = A + S.Bm with the GRU blend in the epilogue (stc_spmm_blend_fwd_f32).  Bm/A/U/H/Cand/Hnew (B, n, C, h);
+        ``copies`` / ``side`` as in ``cell_blend_fwd`` (buffers (B*n, C, ld))."""
+        B, n, Cc, h = H.shape
+        for name, t in (('Bm', Bm), ('A', A), ('U', U), ('H', H), ('Cand', Cand), ('Hnew', Hnew)):
+            self._f32('spmm_blend.' + name, t, (B, n, Cc, h))
+        if len(copies) > 2 or (side is not None and not copies):
+            raise StcError('spmm_blend: at most two state copies; side needs a first copy')
+        cp = []
+        for i, (buf, off) in enumerate(copies):
+            self._f32(f'spmm_blend.copy{i}', buf)
+            if buf.dim() != 3 or buf.shape[:2] != (B * n, Cc) or off < 0 or off + h > buf.shape[-1]:
+                raise StcError(f'spmm_blend: copy{i} of shape {tuple(buf.shape)} cannot take columns [{off}, {off + h})')
+            cp.append((buf, buf.shape[-1], off))
+        while len(cp) < 2:
+            cp.append((None, 0, 0))
+        side_cin = 0
+        if side is not None:
+            side_cin = side.shape[-1]
+            self._f32('spmm_blend.side', side, (B * n, Cc, side_cin))
+            if side_cin != cp[0][2]:
+                raise StcError(f'spmm_blend: side width {side_cin} must equal the first copy\'s column offset {cp[0][2]}')
+        self._same_device(rowptr, colidx, val, Bm, A, U, H, Cand, Hnew, cp[0][0], cp[1][0], side)
+        g = self._graph_ptrs(rowptr, colidx, val, plan, n)
+        self._launch('stc_spmm_blend_fwd_f32', H, *g, n, n, _ptr(Bm), _ptr(A), _ptr(U), _ptr(H), _ptr(Cand), _ptr(Hnew),
+                     _ptr(cp[0][0]), cp[0][1], cp[0][2], _ptr(side), side_cin, _ptr(cp[1][0]), cp[1][1], cp[1][2], B, Cc, h,
+                     nbytes=colidx.numel() * 8 + 4 * (n + 1) + 4 * B * n * Cc * h * (6 + len(copies)))
 
     def node_post_bwd(self, X, Tc, W, dA, dB, dX, dW, db):
         """(X, dA = dY, dBm = S^T dY) -> dX, dW, db of the convolution in its post-aggregation form."""

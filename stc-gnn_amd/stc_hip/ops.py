@@ -491,6 +491,7 @@ class _StcCellGraph(Function):
                 XH[j] = ref.new_empty(B, N, C, L)
             return XH[j]
 
+        n_saved = []
         state = [None] * n_cells                                    # plain (B,N,C,h) new state of every cell
         out_stack = ref.new_empty(len(outputs), B, N, C, h)         # the requested states are produced in place, stacked
         out_slot = {j: i for i, j in enumerate(outputs)}
@@ -514,7 +515,8 @@ class _StcCellGraph(Function):
             Hnew = _alias_slice(out_stack, out_slot[j]) if j in out_slot else torch.empty_like(Hprev)
             Zg = _spatial_slabs(Xj, fwd_val, op, Ks)
             k.cell_gates_fwd(rows(Zg), Tc, Wg, bg, *rows((Hprev, U, Rg, CandIn)))
-            Zc = _spatial_slabs(CandIn, fwd_val, op, Ks)
+            post = _POST_AGG and k.node_post_supported(Ks, Tc.shape[0], C, L, h)
+            Zc = [CandIn] if post else _spatial_slabs(CandIn, fwd_val, op, Ks)
             # where else the new state goes: straight into the input rows of the cells that consume it
             copies, side, late_copies, late_rows = [], None, [], []
             for (d, role) in consumers[j]:
@@ -535,7 +537,14 @@ class _StcCellGraph(Function):
             first = 1 if side is not None else 0
             while len(copies) > 2:                                  # the kernel takes two destinations; the rest by torch
                 late_copies.append(copies.pop(len(copies) - 1 if len(copies) - 1 >= first else first))
-            k.cell_blend_fwd(rows(Zc), Tc, Wc, bc, *rows((U, Hprev, Cand, Hnew)), copies=copies, side=side)
+            if post:
+                # candidate convolution as Y = A + S.Bm: project first, aggregate the C*h-float rows, blend in the SpMM's epilogue
+                A, Bm = torch.empty_like(Hprev), torch.empty_like(Hprev)
+                k.node_post_fwd(*rows((CandIn,)), Tc, Wc, bc, *rows((A, Bm)))
+                k.spmm_blend_fwd(op.fwd_rowptr, op.fwd_colidx, fwd_val, op.fwd_plan, Bm, A, U, Hprev, Cand, Hnew, copies=copies, side=side)
+                del A, Bm
+            else:
+                k.cell_blend_fwd(rows(Zc), Tc, Wc, bc, *rows((U, Hprev, Cand, Hnew)), copies=copies, side=side)
             for buf, off in late_copies:
                 buf[..., off:off + h].copy_(Hnew.view(B * N, C, h))
             for d in late_rows:
@@ -547,23 +556,26 @@ class _StcCellGraph(Function):
                     Xd[..., cin[d] + h:].zero_()
             state[j] = Hnew
             saved += [Hprev, U, Rg, Cand, *Zg, *Zc]
+            n_saved.append(4 + len(Zg) + len(Zc))
         ctx.save_for_backward(Tc, *[p for st in stacks for p in st if p is not None], *saved)
-        ctx.meta = (op, Ks, schedule, tuple(outputs), cin, [tuple(p is not None for p in st) for st in stacks], (B, N, C))
+        ctx.meta = (op, Ks, schedule, tuple(outputs), cin, [tuple(p is not None for p in st) for st in stacks], (B, N, C), n_saved)
         return out_stack
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_stack):
         k = kernels()
-        op, Ks, schedule, outputs, cin, present, (B, N, C) = ctx.meta
+        op, Ks, schedule, outputs, cin, present, (B, N, C), n_saved = ctx.meta
         sv = list(ctx.saved_tensors)
         Tc = sv.pop(0)
         stacks = []
         for pres in present:
             st = [sv.pop(0) if p else None for p in pres]
             stacks.append(st)
-        per = 4 + 2 * Ks
-        cells = [sv[i * per:(i + 1) * per] for i in range(len(schedule))]
+        cells, at = [], 0
+        for cnt in n_saved:
+            cells.append(sv[at:at + cnt])
+            at += cnt
         h = 16
         rows = lambda ts: [t.view(B * N, C, t.shape[-1]) for t in ts]
         bwd = (op.bwd_rowptr, op.bwd_colidx, op.bwd_val)
@@ -587,7 +599,7 @@ class _StcCellGraph(Function):
             dHnew = G.pop(j)
             L = Zc[0].shape[-1]
             v3 = lambda t: t.view(B, N, C * L)
-            if _POST_AGG and k.node_post_supported(Ks, Tc.shape[0], C, L, h):
+            if len(Zc) == 1 and Ks > 1:                             # the forward ran this convolution as Y = A + S.Bm (no Z_1 slab)
                 # candidate convolution in its post-aggregation form Y = A + S.Bm: the aggregation's transpose runs on the
                 # narrow gradient (C*h floats per row, not C*L) and the node kernel yields d[Xt | R*H] directly
                 dY, dBm = torch.empty_like(Hprev), torch.empty_like(Hprev)

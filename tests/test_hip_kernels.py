@@ -442,6 +442,59 @@ def test_post_aggregation_backward(hip, nodes, C, L, Lw):
     assert torch.equal(dW, dW2)
 
 
+@pytest.mark.parametrize('batch,grid,C,L,Lw,copy_case', [(2, (5, 5), 32, 32, 32, 'pair'), (3, (4, 7), 32, 20, 17, 'side'), (1, (3, 3), 64, 32, 32, 'none'),
+                                                        (2, (40, 56), 32, 32, 32, 'pair'), (1, (1, 1), 32, 20, 20, 'none')])
+def test_post_aggregation_forward(hip, batch, grid, C, L, Lw, copy_case):
+    """Candidate convolution as Y = A + S.Bm: stc_bdg_node_post_fwd_f32 then stc_spmm_blend_fwd_f32 (blend + state copies in the
+    SpMM's epilogue) vs the CPU twin, and vs the slab form (SpMM first, fused node kernel) of the same convolution."""
+    h, K = 16, 2
+    graph = CsrGraph.queen_grid(*grid, normalize=True)
+    n = graph.n
+    nodes = batch * n
+    g = torch.Generator().manual_seed(nodes + C + L)
+    rnd = lambda *s_: torch.randn(*s_, generator=g)
+    X = rnd(nodes, C, L)
+    X[..., Lw:] = 0.0
+    Tc = rnd(K, C, C) / C ** 0.5
+    Tc[0] = torch.eye(C)
+    W, b = rnd(K * K * Lw, h) / (K * K * Lw) ** 0.5, rnd(h)
+    U, H = torch.rand(batch, n, C, h, generator=g), rnd(batch, n, C, h)
+    A_w, B_w = torch.empty(nodes, C, h), torch.empty(nodes, C, h)
+    EM.node_post_fwd(X, Tc, W, b, A_w, B_w)
+    A, Bm = torch.full_like(A_w, float('nan')).cuda(), torch.full_like(B_w, float('nan')).cuda()
+    hip.node_post_fwd(cu(X), cu(Tc), cu(W), cu(b), A, Bm)
+    assert rel_err(A, A_w) < TOL and rel_err(Bm, B_w) < TOL
+
+    hst = graph._host
+    csr = tuple(torch.from_numpy(hst[k]) for k in ('fwd_rowptr', 'fwd_colidx', 'fwd_val'))
+    dev = graph.on(torch.device('cuda'))
+    plan = (dev['fwd_blk_ptr'], dev['fwd_blk_cols'], dev['fwd_blk_vals'])
+    def bufs(where):
+        mk = (lambda *s_: torch.full(s_, 9.0)) if where == 'cpu' else (lambda *s_: torch.full(s_, 9.0).cuda())
+        if copy_case == 'pair':
+            return [(mk(nodes, C, 32), 16), (mk(nodes, C, 32), 0)], None
+        if copy_case == 'side':
+            side = rnd(nodes, C, 1) if where == 'cpu' else None
+            return [(mk(nodes, C, 20), 1)], side
+        return [], None
+    cp_w, side_w = bufs('cpu')
+    Cand_w, Hn_w = torch.empty_like(H), torch.empty_like(H)
+    EM.spmm_blend_fwd(*csr, None, B_w.view(batch, n, C, h), A_w.view(batch, n, C, h), U, H, Cand_w, Hn_w, copies=cp_w, side=side_w)
+    cp, _ = bufs('cuda')
+    Cand, Hn = torch.full_like(H, float('nan')).cuda(), torch.full_like(H, float('nan')).cuda()
+    hip.spmm_blend_fwd(*(cu(t) for t in csr), plan, cu(B_w).view(batch, n, C, h), cu(A_w).view(batch, n, C, h), cu(U), cu(H), Cand, Hn,
+                       copies=cp, side=None if side_w is None else cu(side_w))
+    assert rel_err(Cand, Cand_w) < TOL and rel_err(Hn, Hn_w) < TOL
+    for (got, _), (want, _) in zip(cp, cp_w):
+        assert torch.equal(got.cpu() == 9.0, want == 9.0) and rel_err(got, want) < TOL      # untouched columns stay untouched
+    # the same convolution in its slab form
+    Z1 = torch.empty_like(X)
+    EM.csr_spmm(*csr, n, n, X.view(batch, n, C * L), None, Z1.view(batch, n, C * L), 1.0, 0.0)
+    Cand_s, Hn_s = torch.empty_like(H), torch.empty_like(H)
+    EM.cell_blend_fwd([X, Z1], Tc, W, b, U.view(nodes, C, h), H.view(nodes, C, h), Cand_s.view(nodes, C, h), Hn_s.view(nodes, C, h))
+    assert rel_err(Hn, Hn_s) < TOL and rel_err(Cand, Cand_s) < TOL
+
+
 def test_fused_aggregation_is_refused_off_its_shapes(hip):
     from stc_hip import StcError
     assert not hip.cell_gather_supported(3, 3, 32, 32, 16) and not hip.cell_gather_supported(2, 2, 16, 32, 16)
