@@ -146,7 +146,7 @@ def main():
     if rank == 0:
         total_ms = sum(d['ms'] for d in per_kernel.values()) or 1.0
         spmm = dict(launches=0, ms=0.0, bytes=0)           # both forms of the aggregation: CSR and row-blocked CSR
-        for name in ('stc_csr_spmm_f32', 'stc_bcsr_spmm_f32', 'stc_spmm_blend_fwd_f32'):
+        for name in ('stc_csr_spmm_f32', 'stc_bcsr_spmm_f32'):
             for key, v in per_kernel.get(name, {}).items():
                 spmm[key] += v
         achieved = (spmm['bytes'] / 1e9) / (spmm['ms'] / 1e3) if spmm['ms'] > 0 else 0.0
@@ -158,7 +158,7 @@ def main():
         if (a.grid, C, a.hidden, B, a.order, a.layers, a.obs, a.pred, a.permute) == (224, 32, 16, 4, 2, 2, 18, 6, False) and os.path.exists(tpath):
             with open(tpath) as fh:
                 doc = json.load(fh)
-            ks = [v for name, v in doc['kernels'].items() if name.startswith('spmm_')]
+            ks = [v for name, v in doc['kernels'].items() if name.startswith('spmm_') and ', 0, ' in name]      # MODE 0 = the plain kernels
             if ks:
                 traffic = sum(v['hbm_bytes_per_launch'] * v['launches'] for v in ks) / sum(v['launches'] for v in ks)
                 traffic_note = 'PMC (2 x FETCH_SIZE + WRITE_SIZE), mean over the SpMM launches of one step of this command: profiles/r01/i_hbm_traffic_bench_b4.json'
@@ -171,13 +171,14 @@ def main():
                                    f'hidden={a.hidden}, K={a.order}, layers={a.layers}, T={a.obs}+{a.pred}',
                        'global_batch': world * B, 'batch_per_gpu': B, 'parallelism': f'batch-shard x{world}',
                        'grad_bucket_bytes': bucket.nbytes},
-            'roofline': {'bound': 'hbm', 'kernel': 'stc_bcsr_spmm_f32 + stc_csr_spmm_f32 + stc_spmm_blend_fwd_f32 (all SpMM launches of the timed steps)', 'achieved': achieved, 'peak': HBM_PEAK_GBPS,
+            'roofline': {'bound': 'hbm', 'kernel': 'stc_bcsr_spmm_f32 + stc_csr_spmm_f32: every plain aggregation launch of the timed steps (rows of C*L floats forward / in-place backward, rows of C*16 floats for the candidate gradient)', 'achieved': achieved, 'peak': HBM_PEAK_GBPS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic, 'traffic_note': traffic_note,
                          'launches': spmm['launches'],
                          'avg_launch_us': 1e3 * spmm['ms'] / max(1, spmm['launches']),
                          'algorithmic_bytes_per_launch': spmm['bytes'] / max(1, spmm['launches'])},
-            'kernels': {k: {'launches': d['launches'], 'ms_per_step': d['ms'] / a.steps,
-                            'share': d['ms'] / total_ms} for k, d in sorted(per_kernel.items(), key=lambda kv: -kv[1]['ms'])},
+            'kernels': {k: {'launches': d['launches'], 'ms_per_step': d['ms'] / a.steps, 'share': d['ms'] / total_ms,
+                            **({'GBps': d['bytes'] / 1e9 / (d['ms'] / 1e3)} if d['bytes'] and d['ms'] > 0 else {})}
+                        for k, d in sorted(per_kernel.items(), key=lambda kv: -kv[1]['ms'])},
             'loss': float(loss.detach()),
             'hbm_peak_allocated_gb': torch.cuda.max_memory_allocated(dev) / 1e9,
             'hbm_peak_reserved_gb': torch.cuda.max_memory_reserved(dev) / 1e9,
