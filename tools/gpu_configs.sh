@@ -10,9 +10,10 @@ print('   top kernels:', ', '.join('%s %.1fms' % (k.replace('stc_','').replace('
 rm -f gpurun_out/configs.log
 run --grid 100 --order 3 --batch-per-gpu 4            # config 4: N=10 000, C=32, T=24, K=3
 run --grid 100 --order 2 --batch-per-gpu 4
-run --grid 224 --order 3 --batch-per-gpu 1            # metric shape at K=3 (1 sample: K=3 saves one more slab per convolution)
-run --grid 224 --categories 64 --batch-per-gpu 1      # config 5 width in fp32 (bf16 has no reference behaviour)
+run --grid 224 --order 3 --batch-per-gpu 2            # metric shape at K=3 (1 sample: K=3 saves one more slab per convolution)
+run --grid 224 --categories 64 --batch-per-gpu 2      # config 5 width in fp32 (bf16 has no reference behaviour)
 run --grid 224 --permute                              # random node order, renumbered internally
 run --grid 224 --permute --no-reorder                 # random node order as given
 run --grid 224 --batch-per-gpu 1
-run --grid 224 --batch-per-gpu 3
+run --grid 224 --batch-per-gpu 2
+run --grid 224 --batch-per-gpu 5
