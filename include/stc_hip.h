@@ -158,12 +158,13 @@ int stc_gru_blend_bwd_f32(const float* dHnew, const float* U, const float* H, co
  * formed.  Backward: dA = dY, dBm = Gs x dY (one narrow stc_csr/bcsr_spmm_f32 by the caller), then this kernel turns
  * (X, dA, dBm) into dX (nodes, C, L), dW (4*Lw, Ho) and db directly -- no second gradient slab, no SpMM after it.
  * Shapes: C in {32, 64}, L in {20, 32}, Ho = 16 (stc_bdg_node_post_supported), else STC_EUNSUPPORTED.
+ * X2 != NULL (L = 32 only): planar input -- X holds columns 0..15 and X2 columns 16..31 of the rows, each (nodes, C, 16).
  * workspace as stc_bdg_node_bwd_f32 (stc_bdg_node_bwd_workspace_bytes(2, 2, C, L, Ho, 0)). */
 int stc_bdg_node_post_supported(int32_t Ks, int32_t Kc, int32_t C, int32_t L, int32_t Ho);
 /* forward: X (nodes, C, L) -> A = sum_c T_c^T (X W_{0,c}) + bias and Bm = sum_c T_c^T (X W_{1,c}), (nodes, C, Ho) each;
  * the caller finishes Y = A + Gs^T x Bm with stc_csr/bcsr_spmm_f32 (Y0 = A) or, for the STC_Cell's candidate
  * convolution, with stc_spmm_blend_fwd_f32 (the GRU blend of STC_GNN.py:76-78 in the SpMM's epilogue). */
-int stc_bdg_node_post_fwd_f32(const float* X, const float* Tc, const float* W, const float* bias,
+int stc_bdg_node_post_fwd_f32(const float* X, const float* X2, const float* Tc, const float* W, const float* bias,
                               float* A, float* Bm,
                               int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t Ho, void* stream);
 /* Y = A + S x Bm on rows of C*h floats (h = 16) with the blend as epilogue: Cand = tanh(Y), Hnew = (1-U)*H + U*Cand,
@@ -175,7 +176,7 @@ int stc_spmm_blend_fwd_f32(const int32_t* rowptr, const int32_t* colidx, const f
                            float* copy0, int32_t copy0_ld, int32_t copy0_off, const float* side_src, int32_t side_cin,
                            float* copy1, int32_t copy1_ld, int32_t copy1_off,
                            int32_t batch, int32_t C, int32_t h, void* stream);
-int stc_bdg_node_post_bwd_f32(const float* X, const float* Tc, const float* W, const float* dA, const float* dB,
+int stc_bdg_node_post_bwd_f32(const float* X, const float* X2, const float* Tc, const float* W, const float* dA, const float* dB,
                               float* dX, float* dW, float* db, void* workspace, size_t workspace_bytes,
                               int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t Ho, void* stream);
 
@@ -226,6 +227,25 @@ int stc_cell_blend_fwd_f32(const float* const* Z, int32_t Ks, const float* Tc, i
                            float* copy0, int32_t copy0_ld, int32_t copy0_off, const float* side_src, int32_t side_cin,
                            float* copy1, int32_t copy1_ld, int32_t copy1_off,
                            int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t h, void* stream);
+
+/* ---- planar cell inputs (Ks = Kc = 2, cin = h = 16) ---------------------------------------------------------------
+ * The [Xt | H] rows of STC_GNN.py:68 kept as two contiguous (nodes, C, h) planes instead of one concatenated row: a state
+ * tensor then IS the X plane of the next layer's cell and the H plane of the next step's cell (no concat, no copies), and
+ * its aggregation S x state is computed once (narrow SpMM) and shared by both.  X/H: the planes; SX/SH: their aggregations.
+ * Forward: U, Rg (nodes, C, h) and the R*H plane RH -- the candidate convolution's input is (X, RH), see
+ * stc_bdg_node_post_fwd_f32's X2.  Backward: as the Cand form of stc_cell_gates_bwd_f32 with dCandIn (nodes, C, 2h) the
+ * interleaved gradient rows [d x part | d RH] produced by stc_bdg_node_post_bwd_f32; dZ[0], dZ[1] interleaved (nodes, C, 2h). */
+int stc_cell_planar_supported(int32_t Ks, int32_t Kc, int32_t C, int32_t h);
+int stc_cell_gates_fwd_planar_f32(const float* X, const float* H, const float* SX, const float* SH,
+                                  const float* Tc, const float* W, const float* bias,
+                                  float* U, float* Rg, float* RH,
+                                  int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream);
+int stc_cell_gates_bwd_planar_f32(const float* X, const float* H, const float* SX, const float* SH,
+                                  const float* Tc, const float* W,
+                                  const float* dCandIn, const float* Cand, const float* U, const float* Rg, const float* dHnew,
+                                  float* const* dZ, float* dW, float* db, float* dH,
+                                  void* workspace, size_t workspace_bytes,
+                                  int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream);
 
 /* ---- the same two cell convolutions with the graph aggregation fused in (Ks = Kc = 2) ------------------------------
  * Replaces STC_GNN.py:37 (the 1-mode product Z1 = Gs^T x Z0, one SpMM launch) + :38-45 + :71-78 in ONE launch per

@@ -145,7 +145,22 @@ class EmulatedKernels:
     def node_post_supported(self, Ks, Kc, Cc, L, Ho) -> bool:
         return Ks == 2 and Kc == 2
 
-    def node_post_fwd(self, X, Tc, W, bias, A, Bm):
+    # planar forms: the [Xt | H] rows as two (R, C, 16) planes -- emulated by concatenating them
+    def cell_planar_supported(self, Ks, Kc, Cc, h) -> bool:
+        return Ks == 2 and Kc == 2 and h == 16
+
+    def cell_gates_fwd_planar(self, X, H, SX, SH, Tc, W, bias, U, Rg, RH):
+        CandIn = torch.empty(H.shape[:-1] + (2 * H.shape[-1],), dtype=W.dtype)
+        self.cell_gates_fwd([torch.cat([X, H], -1), torch.cat([SX, SH], -1)], Tc, W, bias, H, U, Rg, CandIn)
+        RH.copy_(CandIn[..., H.shape[-1]:])
+
+    def cell_gates_bwd_planar(self, X, H, SX, SH, Tc, W, dCandIn, Cand, U, Rg, dHnew, dZs, dW, db, dH):
+        self.cell_gates_bwd([torch.cat([X, H], -1), torch.cat([SX, SH], -1)], Tc, W, dCandIn, None, H, U, Rg, dHnew, dZs, dW, db, None, dH,
+                            dH_in_scaled=True, Cand=Cand)
+
+    def node_post_fwd(self, X, Tc, W, bias, A, Bm, X2=None):
+        if X2 is not None:
+            X = torch.cat([X, X2], -1)
         Lw = W.shape[0] // 4
         for n, out in enumerate((A, Bm)):
             acc = torch.zeros_like(out)
@@ -167,7 +182,9 @@ class EmulatedKernels:
             buf[..., :off].copy_(side)
             buf[..., off + h:].zero_()
 
-    def node_post_bwd(self, X, Tc, W, dA, dB, dX, dW, db):
+    def node_post_bwd(self, X, Tc, W, dA, dB, dX, dW, db, X2=None):
+        if X2 is not None:
+            X = torch.cat([X, X2], -1)
         Lw = W.shape[0] // 4
         dW.zero_()
         dX.zero_()

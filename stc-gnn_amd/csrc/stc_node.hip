@@ -483,11 +483,62 @@ extern "C" int stc_cell_cand_bwd_f32(const float* const* Z, int32_t Ks, const fl
     return STC_OK;
 }
 
+// ---- planar cell inputs: [Xt | H] as two contiguous (nodes, C, h) planes (Ks = Kc = 2, cin = h = 16)
+extern "C" int stc_cell_planar_supported(int32_t Ks, int32_t Kc, int32_t C, int32_t h) {
+    return (x3_enabled() && Ks == 2 && Kc == 2 && (C == 32 || C == 64) && h == 16) ? 1 : 0;
+}
+
+extern "C" int stc_cell_gates_fwd_planar_f32(const float* X, const float* H, const float* SX, const float* SH,
+                                             const float* Tc, const float* W, const float* bias,
+                                             float* U, float* Rg, float* RH,
+                                             int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream) {
+    if (int rc = check_dims("stc_cell_gates_fwd_planar_f32", 2, 2, C, 2 * h, Lw, 2 * h, nodes)) return rc;
+    if (!stc_cell_planar_supported(2, 2, C, h)) return stc::fail(STC_EUNSUPPORTED, "stc_cell_gates_fwd_planar_f32: shape not on the planar path");
+    if (nodes == 0) return STC_OK;
+    STC_REQUIRE(X && H && SX && SH && Tc && W && U && Rg && RH, STC_EINVAL, "stc_cell_gates_fwd_planar_f32: null pointer");
+    const int rc = stc_cell_gates_fwd_planar_x3(X, H, SX, SH, Tc, W, bias, U, Rg, RH, nodes, C, Lw, static_cast<hipStream_t>(stream));
+    return rc == STC_NOT_HANDLED ? stc::fail(STC_EUNSUPPORTED, "stc_cell_gates_fwd_planar_f32: operands not usable (alignment)") : rc;
+}
+
+extern "C" int stc_cell_gates_bwd_planar_f32(const float* X, const float* H, const float* SX, const float* SH,
+                                             const float* Tc, const float* W,
+                                             const float* dCandIn, const float* Cand, const float* U, const float* Rg, const float* dHnew,
+                                             float* const* dZ, float* dW, float* db, float* dH,
+                                             void* workspace, size_t workspace_bytes,
+                                             int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream) {
+    const int L = 2 * h, Ho = 2 * h;
+    if (int rc = check_dims("stc_cell_gates_bwd_planar_f32", 2, 2, C, L, Lw, Ho, nodes)) return rc;
+    if (!stc_cell_planar_supported(2, 2, C, h)) return stc::fail(STC_EUNSUPPORTED, "stc_cell_gates_bwd_planar_f32: shape not on the planar path");
+    STC_REQUIRE(W && dZ && dW && Tc, STC_EINVAL, "stc_cell_gates_bwd_planar_f32: null W/dZ/dW/Tc");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int nW = 4 * Lw * Ho;
+    if (nodes == 0) {
+        if (int rc = stc::hip_status(hipMemsetAsync(dW, 0, (size_t)nW * sizeof(float), s), "memset dW")) return rc;
+        if (db) if (int rc = stc::hip_status(hipMemsetAsync(db, 0, (size_t)Ho * sizeof(float), s), "memset db")) return rc;
+        return STC_OK;
+    }
+    STC_REQUIRE(X && H && SX && SH && dCandIn && Cand && U && Rg && dHnew && dH && dZ[0] && dZ[1], STC_EINVAL, "stc_cell_gates_bwd_planar_f32: null pointer");
+    STC_REQUIRE(workspace && stc::aligned16(workspace), STC_EALIGN, "stc_cell_gates_bwd_planar_f32: workspace null or not 16-byte aligned");
+    STC_REQUIRE(workspace_bytes >= stc_bdg_node_bwd_workspace_bytes(2, 2, C, L, Ho, 0), STC_EINVAL,
+                "stc_cell_gates_bwd_planar_f32: workspace of %zu B is too small", workspace_bytes);
+    int n_parts = 0;
+    float* partial = static_cast<float*>(workspace);
+    const int rc = stc_cell_gates_bwd_planar_x3(X, H, SX, SH, Tc, W, dCandIn, Cand, U, Rg, dHnew, dZ, dH, partial, &n_parts, db != nullptr,
+                                                nodes, C, Lw, s);
+    if (rc == STC_NOT_HANDLED) return stc::fail(STC_EUNSUPPORTED, "stc_cell_gates_bwd_planar_f32: operands not usable (alignment)");
+    if (rc != STC_OK) return rc;
+    const int stride = nW + Ho;
+    hipLaunchKernelGGL(bdg_node_reduce_kernel, dim3((stride + RED_ELEMS - 1) / RED_ELEMS), dim3(NODE_THREADS), 0, s,
+                       partial, n_parts, stride, nW, Ho, 0, dW, db, static_cast<float*>(nullptr));
+    STC_LAUNCH_CHECK("stc_bdg_node_reduce launch");
+    return STC_OK;
+}
+
 extern "C" int stc_bdg_node_post_supported(int32_t Ks, int32_t Kc, int32_t C, int32_t L, int32_t Ho) {
     return (x3_enabled() && Ks == Kc && stc_node_post_shape_ok(Ks, C, L, Ho)) ? 1 : 0;
 }
 
-extern "C" int stc_bdg_node_post_fwd_f32(const float* X, const float* Tc, const float* W, const float* bias,
+extern "C" int stc_bdg_node_post_fwd_f32(const float* X, const float* X2, const float* Tc, const float* W, const float* bias,
                                          float* A, float* Bm,
                                          int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t Ho, void* stream) {
     if (int rc = check_dims("stc_bdg_node_post_fwd_f32", 2, 2, C, L, Lw, Ho, nodes)) return rc;
@@ -495,11 +546,12 @@ extern "C" int stc_bdg_node_post_fwd_f32(const float* X, const float* Tc, const 
     if (nodes == 0) return STC_OK;
     STC_REQUIRE(X && Tc && W && A && Bm, STC_EINVAL, "stc_bdg_node_post_fwd_f32: null pointer");
     STC_REQUIRE(A != Bm && X != A && X != Bm, STC_EINVAL, "stc_bdg_node_post_fwd_f32: outputs must not alias");
-    const int rc = stc_node_post_fwd_x3(X, Tc, W, bias, A, Bm, nodes, C, L, Lw, Ho, static_cast<hipStream_t>(stream));
+    STC_REQUIRE(!X2 || L == 32, STC_EINVAL, "stc_bdg_node_post_fwd_f32: planar input (X2) needs rows of 16 + 16 columns, L = %d", L);
+    const int rc = stc_node_post_fwd_x3(X, X2, Tc, W, bias, A, Bm, nodes, C, L, Lw, Ho, static_cast<hipStream_t>(stream));
     return rc == STC_NOT_HANDLED ? stc::fail(STC_EUNSUPPORTED, "stc_bdg_node_post_fwd_f32: operands not usable (alignment)") : rc;
 }
 
-extern "C" int stc_bdg_node_post_bwd_f32(const float* X, const float* Tc, const float* W, const float* dA, const float* dB,
+extern "C" int stc_bdg_node_post_bwd_f32(const float* X, const float* X2, const float* Tc, const float* W, const float* dA, const float* dB,
                                          float* dX, float* dW, float* db, void* workspace, size_t workspace_bytes,
                                          int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t Ho, void* stream) {
     if (int rc = check_dims("stc_bdg_node_post_bwd_f32", 2, 2, C, L, Lw, Ho, nodes)) return rc;
@@ -518,7 +570,8 @@ extern "C" int stc_bdg_node_post_bwd_f32(const float* X, const float* Tc, const 
                 "stc_bdg_node_post_bwd_f32: workspace of %zu B is too small", workspace_bytes);
     int n_parts = 0;
     float* partial = static_cast<float*>(workspace);
-    const int rc = stc_node_post_bwd_x3(X, Tc, W, dA, dB, dX, partial, &n_parts, db != nullptr, nodes, C, L, Lw, Ho, s);
+    STC_REQUIRE(!X2 || L == 32, STC_EINVAL, "stc_bdg_node_post_bwd_f32: planar input (X2) needs rows of 16 + 16 columns, L = %d", L);
+    const int rc = stc_node_post_bwd_x3(X, X2, Tc, W, dA, dB, dX, partial, &n_parts, db != nullptr, nodes, C, L, Lw, Ho, s);
     if (rc == STC_NOT_HANDLED) return stc::fail(STC_EUNSUPPORTED, "stc_bdg_node_post_bwd_f32: operands not usable (alignment)");
     if (rc != STC_OK) return rc;
     const int stride = nW + Ho;

@@ -14,7 +14,8 @@ constexpr int MF_THREADS = 256;
 constexpr int MF_WAVES = MF_THREADS / 64;
 constexpr int MF_BWD_MAX_GRID = 512;     // partial rows the caller's workspace holds
 
-struct ZPtrs { const float* p[STC_MAX_K]; };
+// q: second plane of a slab in the planar layout ([Xt | H] kept as two contiguous (nodes, C, 16) planes); null otherwise
+struct ZPtrs { const float* p[STC_MAX_K]; const float* q[STC_MAX_K]; };
 struct DZPtrs { float* p[STC_MAX_K]; };
 
 template <int N>

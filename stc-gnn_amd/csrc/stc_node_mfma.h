@@ -78,7 +78,15 @@ int stc_cell_cand_bwd_x3(const float* const* Z, int K, const float* Tc, const fl
 
 // Post-aggregation form of a K = 2 convolution, Y = A + S.Bm (stc_node_x3.hip): backward from (X, dA = dY, dBm = S^T dY).
 int stc_node_post_shape_ok(int K, int C, int L, int Ho);
-int stc_node_post_bwd_x3(const float* X, const float* Tc, const float* W, const float* dA, const float* dB, float* dX,
+int stc_node_post_bwd_x3(const float* X, const float* X2, const float* Tc, const float* W, const float* dA, const float* dB, float* dX,
                          float* partial, int* n_partials, int want_db, long long nodes, int C, int L, int Lw, int Ho, hipStream_t stream);
-int stc_node_post_fwd_x3(const float* X, const float* Tc, const float* W, const float* bias, float* A, float* Bm,
+int stc_node_post_fwd_x3(const float* X, const float* X2, const float* Tc, const float* W, const float* bias, float* A, float* Bm,
                          long long nodes, int C, int L, int Lw, int Ho, hipStream_t stream);
+
+// Planar cell inputs (stc_node_x3.hip): the [Xt | H] rows as two contiguous (nodes, C, 16) planes each, K = 2.
+int stc_cell_gates_fwd_planar_x3(const float* X, const float* H, const float* SX, const float* SH, const float* Tc, const float* W,
+                                 const float* bias, float* U, float* R, float* RH, long long nodes, int C, int Lw, hipStream_t stream);
+int stc_cell_gates_bwd_planar_x3(const float* X, const float* H, const float* SX, const float* SH, const float* Tc, const float* W,
+                                 const float* dCandIn, const float* Cand, const float* U, const float* R, const float* dHnew,
+                                 float* const* dZ, float* dH, float* partial, int* n_partials, int want_db,
+                                 long long nodes, int C, int Lw, hipStream_t stream);

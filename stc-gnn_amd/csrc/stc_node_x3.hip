@@ -110,6 +110,13 @@ struct Row8 {
         if (L == 32 || 8 * g < L) a = *reinterpret_cast<const f32x4*>(row + 8 * g);
         if (L == 32 || 8 * g + 4 < L) b = *reinterpret_cast<const f32x4*>(row + 8 * g + 4);
     }
+    // planar layout: columns 0..15 of the row live in one (rows, 16) plane, 16..31 in another
+    __device__ __forceinline__ void load_planes(const float* __restrict__ xrow, const float* __restrict__ hrow, int g) {
+        static_assert(L == 32, "planar rows are 16 + 16 columns");
+        const float* src = (g < 2 ? xrow : hrow) + 8 * (g & 1);
+        a = *reinterpret_cast<const f32x4*>(src);
+        b = *reinterpret_cast<const f32x4*>(src + 4);
+    }
     __device__ __forceinline__ float at(int e) const { return e < 4 ? a[e & 3] : b[e & 3]; }
     __device__ __forceinline__ void fma(float v, const Row8& o) {
 #pragma unroll
@@ -133,7 +140,9 @@ struct GatherArgs {
 };
 
 // --------------------------------------------------------------------------------------- forward
-template <int NB2, int HB, int K, int L, int EPI, int GATHER>
+// PL = 1: planar inputs (Z.p[n] = columns 0..15, Z.q[n] = columns 16..31 of slab n, each (nodes, C, 16)); with EPI_GATES the
+// candidate's input then is planar too: its X plane is Xt itself and only the R*H plane (epi.CandIn, 16 wide) is written
+template <int NB2, int HB, int K, int L, int EPI, int GATHER, int PL = 0>
 __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_kernel(
     ZPtrs Z, const float* __restrict__ Tc, const float* __restrict__ W, const float* __restrict__ bias,
     float* __restrict__ Y, int nodes, int Lw, FwdEpi epi, GatherArgs ga) {
@@ -181,7 +190,10 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
 #pragma unroll
         for (int n = 0; n < KL; ++n)
 #pragma unroll
-            for (int rb = 0; rb < NRB; ++rb) z[n][rb].load(Z.p[n] + ((size_t)nd * C + 16 * rb + x) * L, g);
+            for (int rb = 0; rb < NRB; ++rb) {
+                if constexpr (PL) z[n][rb].load_planes(Z.p[n] + ((size_t)nd * C + 16 * rb + x) * 16, Z.q[n] + ((size_t)nd * C + 16 * rb + x) * 16, g);
+                else z[n][rb].load(Z.p[n] + ((size_t)nd * C + 16 * rb + x) * L, g);
+            }
     };
     if (node < nodes) load_rows(cur, node);
     while (node < nodes) {
@@ -191,7 +203,7 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
         float hv[NRB][4], uv[NRB][4], side[NRB][4];
         // EPI_GATES: lane x < L - 16 also writes one column of CandIn outside the R*H block, in the same row layout:
         // column x of Xt (re-read from slab 0, an L2 hit) while x < cin, else the zero of pad column x + 16
-        const bool has_side = EPI == EPI_GATES && x < L - HID;
+        const bool has_side = EPI == EPI_GATES && !PL && x < L - HID;
         if (EPI != EPI_NONE) {
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb)
@@ -200,7 +212,7 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
                     const size_t row = (size_t)node * C + 16 * rb + 4 * g + r, e = row * HID + x;
                     hv[rb][r] = epi.H[e];
                     if (EPI == EPI_BLEND) uv[rb][r] = epi.U[e];
-                    if (EPI == EPI_GATES) side[rb][r] = (has_side && x < epi.cin) ? Z.p[0][row * L + x] : 0.f;
+                    if (EPI == EPI_GATES && !PL) side[rb][r] = (has_side && x < epi.cin) ? Z.p[0][row * L + x] : 0.f;
                 }
         }
         Row8<L> z1[NRB];
@@ -298,7 +310,8 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
                     const float gate = fast_sigmoid(acc[rb][HB - 1][r] + bv[HB - 1]);
                     epi.U_out[row * HID + x] = u;
                     epi.R_out[row * HID + x] = gate;
-                    epi.CandIn[row * L + epi.cin + x] = gate * hv[rb][r];
+                    if (PL) epi.CandIn[row * HID + x] = gate * hv[rb][r];           // the R*H plane
+                    else epi.CandIn[row * L + epi.cin + x] = gate * hv[rb][r];
                 }
             if (has_side) {
                 const int scol = x < epi.cin ? x : x + HID;
@@ -338,7 +351,7 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
 //   Qd_c (rows c', cols o)  = T_c . dY               A = T_c table (same table), B = dY in accumulator layout
 //   dW_{n,c} (rows l, cols o) += Z_n^T . Q_c         A = Z columns (slots = rows c'), B = dY / Qd accumulators
 // dW / db stay in registers across all nodes of a wave; fixed-order combine at the end (combine_dw).
-template <int NB2, int HB, int K, int L>
+template <int NB2, int HB, int K, int L, int PL = 0>
 struct NodeIn {      // what one node contributes from HBM: its dY fragments and its Z columns
     static constexpr int NRB = 2 * NB2, LB = (L + 15) / 16;
     DyFrag<NRB, HB> g;
@@ -351,12 +364,13 @@ struct NodeIn {      // what one node contributes from HBM: its dY fragments and
 #pragma unroll
             for (int lb = 0; lb < LB; ++lb) {
                 const bool ok = 16 * lb + x < L;
-                const float* col = Z.p[n] + r0 * L + 16 * lb + (ok ? x : 0);
+                constexpr int LD = PL ? 16 : L;                  // planar: block lb of the row is plane lb, 16 floats per row
+                const float* col = PL ? (lb == 0 ? Z.p[n] : Z.q[n]) + r0 * 16 + x : Z.p[n] + r0 * L + 16 * lb + (ok ? x : 0);
 #pragma unroll
                 for (int kb = 0; kb < NRB; ++kb)
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        const float zv = col[(size_t)(16 * kb + 4 * gq + t) * L];
+                        const float zv = col[(size_t)(16 * kb + 4 * gq + t) * LD];
                         za[n][lb][kb][t] = ok ? zv : 0.f;
                     }
             }
@@ -368,7 +382,7 @@ struct NodeIn {      // what one node contributes from HBM: its dY fragments and
 template <int NB2, int K>
 struct BwdSched { static constexpr int waves = (NB2 == 1 && K <= 2) ? 2 : 1; };
 
-template <int NB2, int HB, int K, int L, int PRO>
+template <int NB2, int HB, int K, int L, int PRO, int PL = 0>
 __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bwd_x3_kernel(
     ZPtrs Z, const float* __restrict__ Tc, const float* __restrict__ W, const float* __restrict__ dY,
     DZPtrs dZ, float* __restrict__ partial, int nodes, int want_db, int Lw, BwdPro pro) {
@@ -419,7 +433,8 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
     for (int hb = 0; hb < HB; ++hb) dbp[hb] = 0.f;
 
     int node = blockIdx.x * MF_WAVES + wave;
-    NodeIn<NB2, HB, K, L> in, nx;
+    static_assert(!PL || L == 32, "planar rows are 16 + 16 columns");
+    NodeIn<NB2, HB, K, L, PL> in, nx;
     if (PF && node < nodes) { in.g.load(dY, node, x, g); in.load_z(Z, node, x, g); }
     while (node < nodes) {
         const int next_node = node + nw;
@@ -552,9 +567,9 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
 //   dX^T (rows l, cols c') = sum_n sum_{c,o} W[(n,c,l)][o] Q^n_c[c'][o]        dW_{n,c} (rows l, cols o) += X^T Q^n_c
 // forward of the post-aggregation form: one input slab X, the two weight sets of the Chebyshev orders kept apart
 //     A = sum_c T_c^T (X W_{0,c}) + b      Bm = sum_c T_c^T (X W_{1,c})           (nodes, C, Ho) each
-template <int NB2, int HB, int L>
+template <int NB2, int HB, int L, int PL = 0>       // PL: X is two planes, X (columns 0..15) and X2 (columns 16..31)
 __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd2_x3_kernel(
-    const float* __restrict__ X, const float* __restrict__ Tc, const float* __restrict__ W, const float* __restrict__ bias,
+    const float* __restrict__ X, const float* __restrict__ X2, const float* __restrict__ Tc, const float* __restrict__ W, const float* __restrict__ bias,
     float* __restrict__ A, float* __restrict__ Bm, int nodes, int Lw) {
     constexpr int K = 2, NRB = 2 * NB2, C = 32 * NB2, Ho = 16 * HB, NCB = K * HB;
     constexpr int nWx = K * NCB, nTx = NRB * NB2;
@@ -593,7 +608,10 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd2_x3_k
     Row8<L> cur[NRB], nxt[NRB];
     auto load_rows = [&](Row8<L> (&z)[NRB], int nd) {
 #pragma unroll
-        for (int rb = 0; rb < NRB; ++rb) z[rb].load(X + ((size_t)nd * C + 16 * rb + x) * L, g);
+        for (int rb = 0; rb < NRB; ++rb) {
+            if constexpr (PL) z[rb].load_planes(X + ((size_t)nd * C + 16 * rb + x) * 16, X2 + ((size_t)nd * C + 16 * rb + x) * 16, g);
+            else z[rb].load(X + ((size_t)nd * C + 16 * rb + x) * L, g);
+        }
     };
     if (node < nodes) load_rows(cur, node);
     while (node < nodes) {
@@ -650,9 +668,9 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd2_x3_k
     }
 }
 
-template <int NB2, int HB, int L>
+template <int NB2, int HB, int L, int PL = 0>
 __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_kernel(
-    const float* __restrict__ X, const float* __restrict__ Tc, const float* __restrict__ W,
+    const float* __restrict__ X, const float* __restrict__ X2, const float* __restrict__ Tc, const float* __restrict__ W,
     const float* __restrict__ dA, const float* __restrict__ dB, float* __restrict__ dX,
     float* __restrict__ partial, int nodes, int want_db, int Lw) {
     constexpr int K = 2, NRB = 2 * NB2, C = 32 * NB2, Ho = 16 * HB, LB = (L + 15) / 16;
@@ -707,12 +725,13 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
 #pragma unroll
         for (int lb = 0; lb < LB; ++lb) {
             const bool ok = 16 * lb + x < L;
-            const float* col = X + r0 * L + 16 * lb + (ok ? x : 0);
+            constexpr int LD = PL ? 16 : L;
+            const float* col = PL ? (lb == 0 ? X : X2) + r0 * 16 + x : X + r0 * L + 16 * lb + (ok ? x : 0);
 #pragma unroll
             for (int kb = 0; kb < NRB; ++kb)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    const float zv = col[(size_t)(16 * kb + 4 * g + t) * L];
+                    const float zv = col[(size_t)(16 * kb + 4 * g + t) * LD];
                     za[lb][kb][t] = ok ? zv : 0.f;
                 }
         }
@@ -824,17 +843,17 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
 }
 
 // --------------------------------------------------------------------------------------- host side
-template <int NB2, int HB, int K, int L, int EPI = EPI_NONE, int GATHER = 0>
+template <int NB2, int HB, int K, int L, int EPI = EPI_NONE, int GATHER = 0, int PL = 0>
 int launch_fwd(const float* const* Z, const float* Tc, const float* W, const float* bias, float* Y,
                long long nodes, int Lw, hipStream_t stream, FwdEpi epi = FwdEpi{}, GatherArgs ga = GatherArgs{}) {
     constexpr int NRB = 2 * NB2, NCB = K * HB;
     const size_t lds = (size_t)(K * NCB + (K - 1) * NRB * NB2) * 3 * 64 * 16;
     if (lds > stc::kMaxLdsBytes) return STC_NOT_HANDLED;
-    auto kern = node_fwd_x3_kernel<NB2, HB, K, L, EPI, GATHER>;
+    auto kern = node_fwd_x3_kernel<NB2, HB, K, L, EPI, GATHER, PL>;
     if (int rc = stc::hip_status(stc::allow_lds(kern, lds), "hipFuncSetAttribute(node fwd x3)")) return rc;
     static const int resident = stc::resident_blocks(kern, MF_THREADS, lds, 2);   // persistent grid = what fits at once
     ZPtrs zp{};
-    for (int n = 0; n < (GATHER ? 1 : K); ++n) zp.p[n] = Z[n];
+    for (int n = 0; n < (GATHER ? 1 : K); ++n) { zp.p[n] = Z[n]; if (PL) zp.q[n] = Z[K + n]; }      // planar: Z = {X planes, H planes}
     const long long want = (nodes + MF_WAVES - 1) / MF_WAVES;
     const int grid = (int)(want < resident ? want : resident);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(MF_THREADS), lds, stream, zp, Tc, W, bias, Y, (int)nodes, Lw, epi, ga);
@@ -842,7 +861,7 @@ int launch_fwd(const float* const* Z, const float* Tc, const float* W, const flo
     return STC_OK;
 }
 
-template <int NB2, int HB, int K, int L, int PRO = PRO_NONE>
+template <int NB2, int HB, int K, int L, int PRO = PRO_NONE, int PL = 0>
 int launch_bwd(const float* const* Z, const float* Tc, const float* W, const float* dY, float* const* dZ,
                float* partial, int* n_partials, int want_db, long long nodes, int Lw, hipStream_t stream, BwdPro pro = BwdPro{}) {
     constexpr int NRB = 2 * NB2, Ho = 16 * HB, LB = (L + 15) / 16, NBK = K * HB, S = (NBK + 1) / 2, nW = K * K * L * Ho;
@@ -850,12 +869,12 @@ int launch_bwd(const float* const* Z, const float* Tc, const float* W, const flo
     const size_t slabs = (size_t)MF_WAVES * (nW + Ho) * sizeof(float);
     const size_t lds = frag > slabs ? frag : slabs;
     if (lds > stc::kMaxLdsBytes) return STC_NOT_HANDLED;
-    auto kern = node_bwd_x3_kernel<NB2, HB, K, L, PRO>;
+    auto kern = node_bwd_x3_kernel<NB2, HB, K, L, PRO, PL>;
     if (int rc = stc::hip_status(stc::allow_lds(kern, lds), "hipFuncSetAttribute(node bwd x3)")) return rc;
     static const int resident = stc::resident_blocks(kern, MF_THREADS, lds, BwdSched<NB2, K>::waves);
     ZPtrs zp{};
     DZPtrs dzp{};
-    for (int n = 0; n < K; ++n) { zp.p[n] = Z[n]; dzp.p[n] = dZ[n]; }
+    for (int n = 0; n < K; ++n) { zp.p[n] = Z[n]; dzp.p[n] = dZ[n]; if (PL) zp.q[n] = Z[K + n]; }
     const long long want = (nodes + MF_WAVES - 1) / MF_WAVES;
     int grid = resident < MF_BWD_MAX_GRID ? resident : MF_BWD_MAX_GRID;
     if (want < grid) grid = (int)want;
@@ -1033,37 +1052,37 @@ int stc_cell_blend_fwd_gather_x3(const int* rowptr, const int* colidx, const flo
 }
 
 // ---- post-aggregation backward (K = 2): (X, dA, dBm) -> dX, dW partials
-template <int NB2, int HB, int L>
-static int launch_bwd2(const float* X, const float* Tc, const float* W, const float* dA, const float* dB, float* dX,
+template <int NB2, int HB, int L, int PL = 0>
+static int launch_bwd2(const float* X, const float* X2, const float* Tc, const float* W, const float* dA, const float* dB, float* dX,
                        float* partial, int* n_partials, int want_db, long long nodes, int Lw, hipStream_t stream) {
     constexpr int K = 2, NRB = 2 * NB2, Ho = 16 * HB, LB = (L + 15) / 16, NBK = K * HB, S = (NBK + 1) / 2, nW = K * K * L * Ho;
     const size_t frag = (size_t)(NRB * NB2 + K * LB * S) * 3 * 64 * 16;
     const size_t slabs = (size_t)MF_WAVES * (nW + Ho) * sizeof(float);
     const size_t lds = frag > slabs ? frag : slabs;
     if (lds > stc::kMaxLdsBytes) return STC_NOT_HANDLED;
-    auto kern = node_bwd2_x3_kernel<NB2, HB, L>;
+    auto kern = node_bwd2_x3_kernel<NB2, HB, L, PL>;
     if (int rc = stc::hip_status(stc::allow_lds(kern, lds), "hipFuncSetAttribute(node bwd2 x3)")) return rc;
     static const int resident = stc::resident_blocks(kern, MF_THREADS, lds, NB2 == 1 ? 2 : 1);
     const long long want = (nodes + MF_WAVES - 1) / MF_WAVES;
     int grid = resident < MF_BWD_MAX_GRID ? resident : MF_BWD_MAX_GRID;
     if (want < grid) grid = (int)want;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(MF_THREADS), lds, stream, X, Tc, W, dA, dB, dX, partial, (int)nodes, want_db, Lw);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(MF_THREADS), lds, stream, X, X2, Tc, W, dA, dB, dX, partial, (int)nodes, want_db, Lw);
     STC_LAUNCH_CHECK("node_bwd2_x3 launch");
     *n_partials = grid;
     return STC_OK;
 }
 
-template <int NB2, int HB, int L>
-static int launch_fwd2(const float* X, const float* Tc, const float* W, const float* bias, float* A, float* Bm,
+template <int NB2, int HB, int L, int PL = 0>
+static int launch_fwd2(const float* X, const float* X2, const float* Tc, const float* W, const float* bias, float* A, float* Bm,
                        long long nodes, int Lw, hipStream_t stream) {
     constexpr int K = 2, NRB = 2 * NB2, NCB = K * HB;
     const size_t lds = (size_t)(K * NCB + NRB * NB2) * 3 * 64 * 16;
-    auto kern = node_fwd2_x3_kernel<NB2, HB, L>;
+    auto kern = node_fwd2_x3_kernel<NB2, HB, L, PL>;
     if (int rc = stc::hip_status(stc::allow_lds(kern, lds), "hipFuncSetAttribute(node fwd2 x3)")) return rc;
     static const int resident = stc::resident_blocks(kern, MF_THREADS, lds, NB2 == 1 ? 2 : 1);
     const long long want = (nodes + MF_WAVES - 1) / MF_WAVES;
     const int grid = (int)(want < resident ? want : resident);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(MF_THREADS), lds, stream, X, Tc, W, bias, A, Bm, (int)nodes, Lw);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(MF_THREADS), lds, stream, X, X2, Tc, W, bias, A, Bm, (int)nodes, Lw);
     STC_LAUNCH_CHECK("node_fwd2_x3 launch");
     return STC_OK;
 }
@@ -1072,11 +1091,17 @@ int stc_node_post_shape_ok(int K, int C, int L, int Ho) {
     return K == 2 && (C == 32 || C == 64) && (L == 20 || L == 32) && Ho == 16;     // Ho < L: where the narrow SpMM pays
 }
 
-int stc_node_post_bwd_x3(const float* X, const float* Tc, const float* W, const float* dA, const float* dB, float* dX,
+int stc_node_post_bwd_x3(const float* X, const float* X2, const float* Tc, const float* W, const float* dA, const float* dB, float* dX,
                          float* partial, int* n_partials, int want_db, long long nodes, int C, int L, int Lw, int Ho, hipStream_t stream) {
     if (!stc_node_post_shape_ok(2, C, L, Ho) || nodes <= 0 || nodes >= (1ll << 31) / C) return STC_NOT_HANDLED;
-    if (!(stc::aligned16(X) && stc::aligned16(dA) && stc::aligned16(dB) && stc::aligned16(dX))) return STC_NOT_HANDLED;
-#define B2_CALL(a, b, d) launch_bwd2<a, b, d>(X, Tc, W, dA, dB, dX, partial, n_partials, want_db, nodes, Lw, stream)
+    if (!(stc::aligned16(X) && stc::aligned16(dA) && stc::aligned16(dB) && stc::aligned16(dX) && (!X2 || stc::aligned16(X2)))) return STC_NOT_HANDLED;
+    if (X2) {                                   // planar input rows (16 + 16 columns)
+        if (L != 32) return STC_NOT_HANDLED;
+        if (C == 32) return launch_bwd2<1, 1, 32, 1>(X, X2, Tc, W, dA, dB, dX, partial, n_partials, want_db, nodes, Lw, stream);
+        if (C == 64) return launch_bwd2<2, 1, 32, 1>(X, X2, Tc, W, dA, dB, dX, partial, n_partials, want_db, nodes, Lw, stream);
+        return STC_NOT_HANDLED;
+    }
+#define B2_CALL(a, b, d) launch_bwd2<a, b, d>(X, nullptr, Tc, W, dA, dB, dX, partial, n_partials, want_db, nodes, Lw, stream)
     if (C == 32 && L == 20) return B2_CALL(1, 1, 20);
     if (C == 32 && L == 32) return B2_CALL(1, 1, 32);
     if (C == 64 && L == 20) return B2_CALL(2, 1, 20);
@@ -1085,15 +1110,50 @@ int stc_node_post_bwd_x3(const float* X, const float* Tc, const float* W, const 
     return STC_NOT_HANDLED;
 }
 
-int stc_node_post_fwd_x3(const float* X, const float* Tc, const float* W, const float* bias, float* A, float* Bm,
+int stc_node_post_fwd_x3(const float* X, const float* X2, const float* Tc, const float* W, const float* bias, float* A, float* Bm,
                          long long nodes, int C, int L, int Lw, int Ho, hipStream_t stream) {
     if (!stc_node_post_shape_ok(2, C, L, Ho) || nodes <= 0 || nodes >= (1ll << 31) / C) return STC_NOT_HANDLED;
-    if (!(stc::aligned16(X) && stc::aligned16(A) && stc::aligned16(Bm))) return STC_NOT_HANDLED;
-#define F2_CALL(a, d) launch_fwd2<a, 1, d>(X, Tc, W, bias, A, Bm, nodes, Lw, stream)
+    if (!(stc::aligned16(X) && stc::aligned16(A) && stc::aligned16(Bm) && (!X2 || stc::aligned16(X2)))) return STC_NOT_HANDLED;
+    if (X2) {
+        if (L != 32) return STC_NOT_HANDLED;
+        if (C == 32) return launch_fwd2<1, 1, 32, 1>(X, X2, Tc, W, bias, A, Bm, nodes, Lw, stream);
+        if (C == 64) return launch_fwd2<2, 1, 32, 1>(X, X2, Tc, W, bias, A, Bm, nodes, Lw, stream);
+        return STC_NOT_HANDLED;
+    }
+#define F2_CALL(a, d) launch_fwd2<a, 1, d>(X, nullptr, Tc, W, bias, A, Bm, nodes, Lw, stream)
     if (C == 32 && L == 20) return F2_CALL(1, 20);
     if (C == 32 && L == 32) return F2_CALL(1, 32);
     if (C == 64 && L == 20) return F2_CALL(2, 20);
     if (C == 64 && L == 32) return F2_CALL(2, 32);
 #undef F2_CALL
+    return STC_NOT_HANDLED;
+}
+
+// ---- planar cell inputs (K = 2, rows of 16 + 16 columns): Z = {X plane, S.X plane, H plane, S.H plane} in launch order {p[0], p[1], q[0], q[1]}
+int stc_cell_gates_fwd_planar_x3(const float* X, const float* H, const float* SX, const float* SH, const float* Tc, const float* W,
+                                 const float* bias, float* U, float* R, float* RH, long long nodes, int C, int Lw, hipStream_t stream) {
+    if (!x3_cell_shape(2, C, 32, nodes)) return STC_NOT_HANDLED;
+    const float* Z[4] = {X, SX, H, SH};
+    if (!all_aligned16(Z, 4)) return STC_NOT_HANDLED;
+    FwdEpi epi{};
+    epi.H = H; epi.U_out = U; epi.R_out = R; epi.CandIn = RH; epi.cin = 16;
+    if (C == 32) return launch_fwd<1, 2, 2, 32, EPI_GATES, 0, 1>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi);
+    if (C == 64) return launch_fwd<2, 2, 2, 32, EPI_GATES, 0, 1>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi);
+    return STC_NOT_HANDLED;
+}
+
+int stc_cell_gates_bwd_planar_x3(const float* X, const float* H, const float* SX, const float* SH, const float* Tc, const float* W,
+                                 const float* dCandIn, const float* Cand, const float* U, const float* R, const float* dHnew,
+                                 float* const* dZ, float* dH, float* partial, int* n_partials, int want_db,
+                                 long long nodes, int C, int Lw, hipStream_t stream) {
+    if (!x3_cell_shape(2, C, 32, nodes)) return STC_NOT_HANDLED;
+    const float* Z[4] = {X, SX, H, SH};
+    if (!all_aligned16(Z, 4) || !stc::aligned16(dZ[0]) || !stc::aligned16(dZ[1])) return STC_NOT_HANDLED;
+    if (!(stc::aligned16(dCandIn) && stc::aligned16(Cand) && stc::aligned16(U) && stc::aligned16(R) && stc::aligned16(dHnew) && stc::aligned16(dH)))
+        return STC_NOT_HANDLED;
+    BwdPro pro{};
+    pro.Cand = Cand; pro.dCandIn = dCandIn; pro.H = H; pro.U = U; pro.R = R; pro.dH_in = dHnew; pro.dH = dH; pro.cin = 16; pro.dh_scaled = 1;
+    if (C == 32) return launch_bwd<1, 2, 2, 32, PRO_GATES_CAND, 1>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro);
+    if (C == 64) return launch_bwd<2, 2, 2, 32, PRO_GATES_CAND, 1>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro);
     return STC_NOT_HANDLED;
 }

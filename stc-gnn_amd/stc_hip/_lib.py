@@ -30,6 +30,7 @@ EXPORTS = (
     'stc_bdg_node_fwd_f32', 'stc_bdg_node_bwd_workspace_bytes', 'stc_bdg_node_bwd_f32',
     'stc_bdg_node_post_supported', 'stc_bdg_node_post_fwd_f32', 'stc_bdg_node_post_bwd_f32', 'stc_spmm_blend_fwd_f32',
     'stc_cell_fused_supported', 'stc_cell_gates_fwd_f32', 'stc_cell_gates_bwd_f32', 'stc_cell_cand_bwd_f32', 'stc_cell_blend_fwd_f32',
+    'stc_cell_planar_supported', 'stc_cell_gates_fwd_planar_f32', 'stc_cell_gates_bwd_planar_f32',
     'stc_cell_gather_supported', 'stc_cell_gates_fwd_gather_f32', 'stc_cell_blend_fwd_gather_f32',
     'stc_gru_gates_fwd_f32', 'stc_gru_gates_bwd_f32', 'stc_gru_blend_fwd_f32', 'stc_gru_blend_bwd_f32',
     'stc_head_fwd_f32', 'stc_head_bwd_workspace_bytes', 'stc_head_bwd_f32',
@@ -63,9 +64,11 @@ def _declare(lib):
         'stc_bdg_node_fwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
         'stc_bdg_node_bwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, C.POINTER(_p), _p, _p, _p,
                                  _p, C.c_size_t, _i64, _i32, _i32, _i32, _i32, _p],
-        'stc_bdg_node_post_fwd_f32': [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
+        'stc_bdg_node_post_fwd_f32': [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
+        'stc_cell_gates_fwd_planar_f32': [_p] * 10 + [_i64, _i32, _i32, _i32, _p],
+        'stc_cell_gates_bwd_planar_f32': [_p] * 11 + [C.POINTER(_p), _p, _p, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _p],
         'stc_spmm_blend_fwd_f32': [_p] * 6 + [_i32, _i32] + [_p] * 6 + [_p, _i32, _i32, _p, _i32, _p, _i32, _i32] + [_i32] * 3 + [_p],
-        'stc_bdg_node_post_bwd_f32': [_p, _p, _p, _p, _p, _p, _p, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _i32, _p],
+        'stc_bdg_node_post_bwd_f32': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _i32, _p],
         'stc_cell_gates_fwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _i32, _p],
         'stc_cell_cand_bwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _p, C.POINTER(_p), _p, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _i32, _p],
         'stc_cell_gates_bwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _i32, C.POINTER(_p), _p, _p, _p, _p,
@@ -92,6 +95,8 @@ def _declare(lib):
     lib.stc_cell_fused_supported.argtypes = [_i32, _i32, _i32, _i32, _i32]
     lib.stc_bdg_node_post_supported.restype = C.c_int
     lib.stc_bdg_node_post_supported.argtypes = [_i32, _i32, _i32, _i32, _i32]
+    lib.stc_cell_planar_supported.restype = C.c_int
+    lib.stc_cell_planar_supported.argtypes = [_i32, _i32, _i32, _i32]
     lib.stc_cell_gather_supported.restype = C.c_int
     lib.stc_cell_gather_supported.argtypes = [_i32, _i32, _i32, _i32, _i32]
     lib.stc_head_bwd_workspace_bytes.restype = C.c_size_t
@@ -375,15 +380,30 @@ class HipKernels:
     def node_post_supported(self, Ks, Kc, Cc, L, Ho) -> bool:
         return bool(self.lib.stc_bdg_node_post_supported(Ks, Kc, Cc, L, Ho))
 
-    def node_post_fwd(self, X, Tc, W, bias, A, Bm):
+    def _post_rows(self, X, X2, Tc, W):
+        """Shapes of the post-aggregation kernels; X2 given: planar rows, X and X2 are the two (R, C, 16) planes."""
+        if X2 is None:
+            return self._node_shapes([X, X], Tc, W)
+        self._f32('post.X', X)
+        self._f32('post.X2', X2, tuple(X.shape))
+        if X.dim() != 3 or X.shape[-1] != 16:
+            raise StcError(f'post: planar input planes must be (rows, C, 16), got {tuple(X.shape)}')
+        R, Cc, _ = X.shape
+        if Tc.dim() != 3 or Tc.shape[0] != 2 or W.dim() != 2 or W.shape[0] % 4:
+            raise StcError('post: planar form needs Ks = Kc = 2')
+        self._f32('post.Tc', Tc, (2, Cc, Cc))
+        self._f32('post.W', W)
+        return 2, 2, R, Cc, 32, W.shape[0] // 4, W.shape[1]
+
+    def node_post_fwd(self, X, Tc, W, bias, A, Bm, X2=None):
         """X -> A = sum_c T_c^T (X W_{0,c}) + bias, Bm = sum_c T_c^T (X W_{1,c}); the caller finishes Y = A + S.Bm."""
-        Ks, Kc, R, Cc, L, Lw, Ho = self._node_shapes([X, X], Tc, W)
+        Ks, Kc, R, Cc, L, Lw, Ho = self._post_rows(X, X2, Tc, W)
         if bias is not None:
             self._f32('post.bias', bias, (Ho,))
         for name, t in (('A', A), ('Bm', Bm)):
             self._f32('post.' + name, t, (R, Cc, Ho))
-        self._same_device(X, Tc, W, bias, A, Bm)
-        self._launch('stc_bdg_node_post_fwd_f32', X, _ptr(X), _ptr(Tc), _ptr(W), _ptr(bias), _ptr(A), _ptr(Bm), R, Cc, L, Lw, Ho)
+        self._same_device(X, X2, Tc, W, bias, A, Bm)
+        self._launch('stc_bdg_node_post_fwd_f32', X, _ptr(X), _ptr(X2), _ptr(Tc), _ptr(W), _ptr(bias), _ptr(A), _ptr(Bm), R, Cc, L, Lw, Ho)
 
     def spmm_blend_fwd(self, rowptr, colidx, val, plan, Bm, A, U, H, Cand, Hnew, copies=(), side=None):
         """Y = A + S.Bm with the GRU blend in the epilogue (stc_spmm_blend_fwd_f32).  Bm/A/U/H/Cand/Hnew (B, n, C, h);
@@ -413,19 +433,63 @@ class HipKernels:
                      _ptr(cp[0][0]), cp[0][1], cp[0][2], _ptr(side), side_cin, _ptr(cp[1][0]), cp[1][1], cp[1][2], B, Cc, h,
                      nbytes=colidx.numel() * 8 + 4 * (n + 1) + 4 * B * n * Cc * h * (6 + len(copies)))
 
-    def node_post_bwd(self, X, Tc, W, dA, dB, dX, dW, db):
-        """(X, dA = dY, dBm = S^T dY) -> dX, dW, db of the convolution in its post-aggregation form."""
-        Ks, Kc, R, Cc, L, Lw, Ho = self._node_shapes([X, X], Tc, W)
+    def node_post_bwd(self, X, Tc, W, dA, dB, dX, dW, db, X2=None):
+        """(X, dA = dY, dBm = S^T dY) -> dX, dW, db of the convolution in its post-aggregation form (dX interleaved rows)."""
+        Ks, Kc, R, Cc, L, Lw, Ho = self._post_rows(X, X2, Tc, W)
         for name, t in (('dA', dA), ('dB', dB)):
             self._f32('post.' + name, t, (R, Cc, Ho))
         self._f32('post.dX', dX, (R, Cc, L))
         self._f32('post.dW', dW, (Ks * Kc * Lw, Ho))
         if db is not None:
             self._f32('post.db', db, (Ho,))
-        self._same_device(X, Tc, W, dA, dB, dX, dW, db)
+        self._same_device(X, X2, Tc, W, dA, dB, dX, dW, db)
         ws = self._get_workspace(X.device, self.lib.stc_bdg_node_bwd_workspace_bytes(Ks, Kc, Cc, L, Ho, 0))
-        self._launch('stc_bdg_node_post_bwd_f32', X, _ptr(X), _ptr(Tc), _ptr(W), _ptr(dA), _ptr(dB), _ptr(dX), _ptr(dW), _ptr(db),
+        self._launch('stc_bdg_node_post_bwd_f32', X, _ptr(X), _ptr(X2), _ptr(Tc), _ptr(W), _ptr(dA), _ptr(dB), _ptr(dX), _ptr(dW), _ptr(db),
                      _ptr(ws), ws.numel(), R, Cc, L, Lw, Ho)
+
+    # ---- planar cell inputs (Ks = Kc = 2, cin = h = 16) ---------------------------------------------
+    def cell_planar_supported(self, Ks, Kc, Cc, h) -> bool:
+        return bool(self.lib.stc_cell_planar_supported(Ks, Kc, Cc, h))
+
+    def _planes(self, what, X, H, SX, SH):
+        R, Cc, h = H.shape
+        for name, t in (('X', X), ('H', H), ('SX', SX), ('SH', SH)):
+            self._f32(f'{what}.{name}', t, (R, Cc, h))
+        return R, Cc, h
+
+    def cell_gates_fwd_planar(self, X, H, SX, SH, Tc, W, bias, U, Rg, RH):
+        """Gates convolution on planar inputs; writes U, Rg and the R*H plane (the candidate's input is (X, RH))."""
+        R, Cc, h = self._planes('planar', X, H, SX, SH)
+        self._f32('planar.Tc', Tc, (2, Cc, Cc))
+        self._f32('planar.W', W)
+        if W.shape != (4 * 2 * h, 2 * h):
+            raise StcError(f'planar gates: W {tuple(W.shape)} is not ({8 * h}, {2 * h})')
+        if bias is not None:
+            self._f32('planar.bias', bias, (2 * h,))
+        for name, t in (('U', U), ('Rg', Rg), ('RH', RH)):
+            self._f32('planar.' + name, t, (R, Cc, h))
+        self._same_device(X, H, SX, SH, Tc, W, bias, U, Rg, RH)
+        self._launch('stc_cell_gates_fwd_planar_f32', H, _ptr(X), _ptr(H), _ptr(SX), _ptr(SH), _ptr(Tc), _ptr(W), _ptr(bias),
+                     _ptr(U), _ptr(Rg), _ptr(RH), R, Cc, 2 * h, h)
+
+    def cell_gates_bwd_planar(self, X, H, SX, SH, Tc, W, dCandIn, Cand, U, Rg, dHnew, dZs, dW, db, dH):
+        R, Cc, h = self._planes('planar', X, H, SX, SH)
+        self._f32('planar.Tc', Tc, (2, Cc, Cc))
+        self._f32('planar.W', W, (8 * h, 2 * h))
+        self._f32('planar.dCandIn', dCandIn, (R, Cc, 2 * h))
+        for name, t in (('Cand', Cand), ('U', U), ('Rg', Rg), ('dHnew', dHnew), ('dH', dH)):
+            self._f32('planar.' + name, t, (R, Cc, h))
+        if len(dZs) != 2:
+            raise StcError('planar gates backward: two gradient slabs')
+        for i, z in enumerate(dZs):
+            self._f32(f'planar.dZ[{i}]', z, (R, Cc, 2 * h))
+        self._f32('planar.dW', dW, (8 * h, 2 * h))
+        if db is not None:
+            self._f32('planar.db', db, (2 * h,))
+        self._same_device(X, H, SX, SH, Tc, W, dCandIn, Cand, U, Rg, dHnew, *dZs, dW, db, dH)
+        ws = self._get_workspace(H.device, self.lib.stc_bdg_node_bwd_workspace_bytes(2, 2, Cc, 2 * h, 2 * h, 0))
+        self._launch('stc_cell_gates_bwd_planar_f32', H, _ptr(X), _ptr(H), _ptr(SX), _ptr(SH), _ptr(Tc), _ptr(W), _ptr(dCandIn), _ptr(Cand),
+                     _ptr(U), _ptr(Rg), _ptr(dHnew), self._ptr_array(dZs), _ptr(dW), _ptr(db), _ptr(dH), _ptr(ws), ws.numel(), R, Cc, 2 * h, h)
 
     # ---- fused cell convolutions ----------------------------------------------------------
     def cell_fused_supported(self, Ks, Kc, Cc, L, h) -> bool:

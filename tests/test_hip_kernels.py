@@ -495,6 +495,50 @@ def test_post_aggregation_forward(hip, batch, grid, C, L, Lw, copy_case):
     assert rel_err(Hn, Hn_s) < TOL and rel_err(Cand, Cand_s) < TOL
 
 
+@pytest.mark.parametrize('nodes,C', [(50, 32), (13, 64), (4500, 32)])
+def test_planar_cell_kernels(hip, nodes, C):
+    """Planar cell inputs ([Xt | H] as two (nodes, C, 16) planes): gates forward / backward and the post-aggregation
+    candidate kernels with a planar X, against the CPU twin (which concatenates the planes)."""
+    h, K = 16, 2
+    assert hip.cell_planar_supported(K, K, C, h)
+    g = torch.Generator().manual_seed(nodes + C)
+    rnd = lambda *s_: torch.randn(*s_, generator=g)
+    X, H, SX, SH = (rnd(nodes, C, h) for _ in range(4))
+    Tc = rnd(K, C, C) / C ** 0.5
+    Tc[0] = torch.eye(C)
+    Wg, bg = rnd(K * K * 2 * h, 2 * h) / (8 * h) ** 0.5, rnd(2 * h)
+    U_w, R_w, RH_w = (torch.empty(nodes, C, h) for _ in range(3))
+    EM.cell_gates_fwd_planar(X, H, SX, SH, Tc, Wg, bg, U_w, R_w, RH_w)
+    nan = lambda *s_: torch.full(s_, float('nan')).cuda()
+    U, R, RH = nan(nodes, C, h), nan(nodes, C, h), nan(nodes, C, h)
+    hip.cell_gates_fwd_planar(cu(X), cu(H), cu(SX), cu(SH), cu(Tc), cu(Wg), cu(bg), U, R, RH)
+    assert rel_err(U, U_w) < TOL and rel_err(R, R_w) < TOL and rel_err(RH, RH_w) < TOL
+
+    dCand, Cand, dHn = rnd(nodes, C, 2 * h), torch.tanh(rnd(nodes, C, h)), rnd(nodes, C, h)
+    dZ_w = [torch.empty(nodes, C, 2 * h) for _ in range(2)]
+    dW_w, db_w, dH_w = torch.empty_like(Wg), torch.empty(2 * h), torch.empty(nodes, C, h)
+    EM.cell_gates_bwd_planar(X, H, SX, SH, Tc, Wg, dCand, Cand, U_w, R_w, dHn, dZ_w, dW_w, db_w, dH_w)
+    dZ = [nan(nodes, C, 2 * h) for _ in range(2)]
+    dW, db, dH = nan(*Wg.shape), nan(2 * h), nan(nodes, C, h)
+    hip.cell_gates_bwd_planar(cu(X), cu(H), cu(SX), cu(SH), cu(Tc), cu(Wg), cu(dCand), cu(Cand), cu(U_w), cu(R_w), cu(dHn), dZ, dW, db, dH)
+    for a, w in zip(dZ, dZ_w):
+        assert rel_err(a, w) < TOL
+    assert rel_err(dW, dW_w) < TOL and rel_err(db, db_w) < TOL and rel_err(dH, dH_w) < TOL
+
+    Wc, bc = rnd(K * K * 2 * h, h) / (8 * h) ** 0.5, rnd(h)
+    A_w, B_w = torch.empty(nodes, C, h), torch.empty(nodes, C, h)
+    EM.node_post_fwd(X, Tc, Wc, bc, A_w, B_w, X2=RH_w)
+    A, Bm = nan(nodes, C, h), nan(nodes, C, h)
+    hip.node_post_fwd(cu(X), cu(Tc), cu(Wc), cu(bc), A, Bm, X2=cu(RH_w))
+    assert rel_err(A, A_w) < TOL and rel_err(Bm, B_w) < TOL
+    dA, dB = rnd(nodes, C, h), rnd(nodes, C, h)
+    dX_w, dWc_w, dbc_w = torch.empty(nodes, C, 2 * h), torch.empty_like(Wc), torch.empty(h)
+    EM.node_post_bwd(X, Tc, Wc, dA, dB, dX_w, dWc_w, dbc_w, X2=RH_w)
+    dX, dWc, dbc = nan(nodes, C, 2 * h), nan(*Wc.shape), nan(h)
+    hip.node_post_bwd(cu(X), cu(Tc), cu(Wc), cu(dA), cu(dB), dX, dWc, dbc, X2=cu(RH_w))
+    assert rel_err(dX, dX_w) < TOL and rel_err(dWc, dWc_w) < TOL and rel_err(dbc, dbc_w) < TOL
+
+
 def test_fused_aggregation_is_refused_off_its_shapes(hip):
     from stc_hip import StcError
     assert not hip.cell_gather_supported(3, 3, 32, 32, 16) and not hip.cell_gather_supported(2, 2, 16, 32, 16)
