@@ -432,6 +432,7 @@ def stc_cell(Xt, H, op: SpatialOperand, Tc, Wg, bg, Wc, bc, Ks: int):
 
 # ----------------------------------------------------------------------------- a whole schedule of cells as ONE autograd node
 _CELL_GRAPH = os.environ.get('STC_CELL_GRAPH', '1') != '0'
+_PLANAR = os.environ.get('STC_PLANAR', '1') != '0'              # cells with 16 + 16-column inputs read them as two planes (no concat, shared S.state)
 _POST_AGG = os.environ.get('STC_POST_AGG', '1') != '0'          # candidate convolution as Y = A + S.Bm (narrow SpMM after the node kernel)
 
 
@@ -456,8 +457,12 @@ class _StcCellGraph(Function):
     """Encoder + decoder (any DAG of STC_Cells whose inputs are other cells' states) as one autograd node.
 
     Per cell the kernels are those of ``_StcCell``'s fused path.  What owning the whole schedule adds:
-      * no concat passes: a cell's new state is written by the blend epilogue straight into the [Xt | H | pad] input rows
-        of the cells that consume it (``stc_cell_blend_fwd_f32`` state copies; reference STC_GNN.py:68 torch.cat);
+      * planar cells (inputs of 16 + 16 columns, i.e. every cell above layer 0): the [Xt | H] row of reference
+        STC_GNN.py:68 is never built -- the kernels read the two state tensors as two planes, and the aggregation S.state is
+        formed ONCE per state (narrow SpMM) for all the cells that consume it (``stc_cell_gates_fwd/bwd_planar_f32``);
+      * interleaved cells (layer 0: 1 + 16 columns padded to 20): no concat pass either -- the producer's blend epilogue
+        writes the new state straight into their input rows (state copies of ``stc_spmm_blend_fwd_f32`` / ``stc_cell_blend_fwd_f32``);
+      * the candidate convolution in post-aggregation form where the kernels exist (``_POST_AGG``);
       * no autograd accumulation passes: a state consumed by two cells (next step, next layer) gets its two gradient
         contributions summed inside the consumers' final split (``stc_split2_f32`` addA2 / addB2), in schedule order.
     schedule[j] = (stack, ('ext', i) | ('cell', k), ('ext', i) | ('cell', k)): parameter set, source of Xt, source of H.
@@ -483,43 +488,41 @@ class _StcCellGraph(Function):
         ref = ext[0]
         B, N, C = ref.shape[:3]
         rows = lambda ts: [t.view(B * N, C, t.shape[-1]) for t in ts]
-        XH = {}
+        source = lambda src: ext[src[1]] if src[0] == 'ext' else state[src[1]]
+        planar_ok = (_PLANAR and _POST_AGG and Ks == 2 and k.cell_planar_supported(Ks, Tc.shape[0], C, h)
+                     and k.node_post_supported(Ks, Tc.shape[0], C, 2 * h, h))
+        planar = [bool(planar_ok and cin[j] == h) for j in range(n_cells)]
+        XH, agg = {}, {}
 
-        def rows_of(j):                                             # the input rows of cell j, allocated at first touch
+        def rows_of(j):                                             # input rows of an interleaved cell, allocated at first touch
             if j not in XH:
                 L = cin[j] + h + (-(cin[j] + h)) % 4
                 XH[j] = ref.new_empty(B, N, C, L)
             return XH[j]
 
-        n_saved = []
+        def aggregated(src):                                        # S.source, once per source tensor
+            if src not in agg:
+                t = source(src)
+                out = torch.empty_like(t)
+                k.csr_spmm(op.fwd_rowptr, op.fwd_colidx, fwd_val, N, N, t.view(B, N, C * h), None, out.view(B, N, C * h), 1.0, 0.0,
+                           plan=op.fwd_plan)
+                agg[src] = out
+            return agg[src]
+
         state = [None] * n_cells                                    # plain (B,N,C,h) new state of every cell
         out_stack = ref.new_empty(len(outputs), B, N, C, h)         # the requested states are produced in place, stacked
         out_slot = {j: i for i, j in enumerate(outputs)}
         if len(out_slot) != len(outputs):
             raise ValueError('stc_cell_graph: duplicate output cells')
-        saved = []
+        saved, n_saved = [], []
         for j, (s_id, x, hs) in enumerate(schedule):
             Wg, bg, Wc, bc = stacks[s_id]
-            Xj = rows_of(j)
-            L = Xj.shape[-1]
-            Hprev = ext[hs[1]] if hs[0] == 'ext' else state[hs[1]]
-            if x[0] == 'ext' and hs[0] == 'ext':
-                k.concat2(ext[x[1]], Hprev, Xj)
-            elif x[0] == 'cell' and hs[0] == 'ext':                 # X part came from its producer; complete the row
-                Xj[..., cin[j]:cin[j] + h].copy_(Hprev)
-                if L > cin[j] + h:
-                    Xj[..., cin[j] + h:].zero_()
-            # (H part from a cell: its producer also wrote an external X part and the pad columns, see below)
-            U, Rg, CandIn = torch.empty_like(Hprev), torch.empty_like(Hprev), torch.empty_like(Xj)
-            Cand = torch.empty_like(Hprev)
-            Hnew = _alias_slice(out_stack, out_slot[j]) if j in out_slot else torch.empty_like(Hprev)
-            Zg = _spatial_slabs(Xj, fwd_val, op, Ks)
-            k.cell_gates_fwd(rows(Zg), Tc, Wg, bg, *rows((Hprev, U, Rg, CandIn)))
-            post = _POST_AGG and k.node_post_supported(Ks, Tc.shape[0], C, L, h)
-            Zc = [CandIn] if post else _spatial_slabs(CandIn, fwd_val, op, Ks)
-            # where else the new state goes: straight into the input rows of the cells that consume it
+            Hprev = source(hs)
+            # where else the new state goes: straight into the input rows of the INTERLEAVED cells that consume it
             copies, side, late_copies, late_rows = [], None, [], []
             for (d, role) in consumers[j]:
+                if planar[d]:
+                    continue                                        # planar consumers read the state tensor itself
                 Xd = rows_of(d)
                 view = Xd.view(B * N, C, Xd.shape[-1])
                 if role == 'x':
@@ -537,14 +540,43 @@ class _StcCellGraph(Function):
             first = 1 if side is not None else 0
             while len(copies) > 2:                                  # the kernel takes two destinations; the rest by torch
                 late_copies.append(copies.pop(len(copies) - 1 if len(copies) - 1 >= first else first))
-            if post:
-                # candidate convolution as Y = A + S.Bm: project first, aggregate the C*h-float rows, blend in the SpMM's epilogue
+            U, Rg, Cand = torch.empty_like(Hprev), torch.empty_like(Hprev), torch.empty_like(Hprev)
+            Hnew = _alias_slice(out_stack, out_slot[j]) if j in out_slot else torch.empty_like(Hprev)
+            if planar[j]:
+                Xp, SXp, SHp, RH = source(x), aggregated(x), aggregated(hs), torch.empty_like(Hprev)
+                k.cell_gates_fwd_planar(*rows((Xp, Hprev, SXp, SHp)), Tc, Wg, bg, *rows((U, Rg, RH)))
                 A, Bm = torch.empty_like(Hprev), torch.empty_like(Hprev)
-                k.node_post_fwd(*rows((CandIn,)), Tc, Wc, bc, *rows((A, Bm)))
+                k.node_post_fwd(*rows((Xp,)), Tc, Wc, bc, *rows((A, Bm)), X2=RH.view(B * N, C, h))
                 k.spmm_blend_fwd(op.fwd_rowptr, op.fwd_colidx, fwd_val, op.fwd_plan, Bm, A, U, Hprev, Cand, Hnew, copies=copies, side=side)
                 del A, Bm
+                saved += [Hprev, U, Rg, Cand, Xp, SXp, SHp, RH]
+                n_saved.append(-8)                                  # negative count: planar cell
             else:
-                k.cell_blend_fwd(rows(Zc), Tc, Wc, bc, *rows((U, Hprev, Cand, Hnew)), copies=copies, side=side)
+                Xj = rows_of(j)
+                L = Xj.shape[-1]
+                if x[0] == 'ext' and hs[0] == 'ext':
+                    k.concat2(ext[x[1]], Hprev, Xj)
+                elif x[0] == 'cell' and hs[0] == 'ext':             # X part came from its producer; complete the row
+                    Xj[..., cin[j]:cin[j] + h].copy_(Hprev)
+                    if L > cin[j] + h:
+                        Xj[..., cin[j] + h:].zero_()
+                # (H part from a cell: its producer also wrote an external X part and the pad columns, see above)
+                CandIn = torch.empty_like(Xj)
+                Zg = _spatial_slabs(Xj, fwd_val, op, Ks)
+                k.cell_gates_fwd(rows(Zg), Tc, Wg, bg, *rows((Hprev, U, Rg, CandIn)))
+                post = _POST_AGG and k.node_post_supported(Ks, Tc.shape[0], C, L, h)
+                if post:
+                    # candidate convolution as Y = A + S.Bm: project first, aggregate C*h-float rows, blend in the SpMM's epilogue
+                    Zc = [CandIn]
+                    A, Bm = torch.empty_like(Hprev), torch.empty_like(Hprev)
+                    k.node_post_fwd(*rows((CandIn,)), Tc, Wc, bc, *rows((A, Bm)))
+                    k.spmm_blend_fwd(op.fwd_rowptr, op.fwd_colidx, fwd_val, op.fwd_plan, Bm, A, U, Hprev, Cand, Hnew, copies=copies, side=side)
+                    del A, Bm
+                else:
+                    Zc = _spatial_slabs(CandIn, fwd_val, op, Ks)
+                    k.cell_blend_fwd(rows(Zc), Tc, Wc, bc, *rows((U, Hprev, Cand, Hnew)), copies=copies, side=side)
+                saved += [Hprev, U, Rg, Cand, *Zg, *Zc]
+                n_saved.append(4 + len(Zg) + len(Zc))
             for buf, off in late_copies:
                 buf[..., off:off + h].copy_(Hnew.view(B * N, C, h))
             for d in late_rows:
@@ -555,8 +587,6 @@ class _StcCellGraph(Function):
                     Xd[..., cin[d]:cin[d] + h].copy_(Hnew)
                     Xd[..., cin[d] + h:].zero_()
             state[j] = Hnew
-            saved += [Hprev, U, Rg, Cand, *Zg, *Zc]
-            n_saved.append(4 + len(Zg) + len(Zc))
         ctx.save_for_backward(Tc, *[p for st in stacks for p in st if p is not None], *saved)
         ctx.meta = (op, Ks, schedule, tuple(outputs), cin, [tuple(p is not None for p in st) for st in stacks], (B, N, C), n_saved)
         return out_stack
@@ -574,8 +604,8 @@ class _StcCellGraph(Function):
             stacks.append(st)
         cells, at = [], 0
         for cnt in n_saved:
-            cells.append(sv[at:at + cnt])
-            at += cnt
+            cells.append(sv[at:at + abs(cnt)])
+            at += abs(cnt)
         h = 16
         rows = lambda ts: [t.view(B * N, C, t.shape[-1]) for t in ts]
         bwd = (op.bwd_rowptr, op.bwd_colidx, op.bwd_val)
@@ -589,35 +619,51 @@ class _StcCellGraph(Function):
             if t is not None:
                 slot[i] = t if slot[i] is None else slot[i].add_(t)
 
+        def narrow_transpose_aggregation(dY):                        # dBm = S^T dY on rows of C*h floats
+            dBm = torch.empty_like(dY)
+            k.csr_spmm(*bwd, N, N, dY.view(B, N, C * h), None, dBm.view(B, N, C * h), 1.0, 0.0, plan=op.bwd_plan)
+            return dBm
+
         for j in range(len(schedule) - 1, -1, -1):
             if j not in G:
                 continue                                             # nothing downstream depends on this cell
             s_id, x, hs = schedule[j]
             Wg, bg, Wc, bc = stacks[s_id]
-            Hprev, U, Rg, Cand, *Z = cells[j]
-            Zg, Zc = Z[:Ks], Z[Ks:]
             dHnew = G.pop(j)
-            L = Zc[0].shape[-1]
-            v3 = lambda t: t.view(B, N, C * L)
-            if len(Zc) == 1 and Ks > 1:                             # the forward ran this convolution as Y = A + S.Bm (no Z_1 slab)
-                # candidate convolution in its post-aggregation form Y = A + S.Bm: the aggregation's transpose runs on the
-                # narrow gradient (C*h floats per row, not C*L) and the node kernel yields d[Xt | R*H] directly
-                dY, dBm = torch.empty_like(Hprev), torch.empty_like(Hprev)
-                k.gru_blend_bwd(dHnew, U, None, Cand, dY, None, None)                      # dY = dHnew * U * (1 - Cand^2)
-                k.csr_spmm(*bwd, N, N, dY.view(B, N, C * h), None, dBm.view(B, N, C * h), 1.0, 0.0, plan=op.bwd_plan)
-                dci, dWc = torch.empty_like(Zc[0]), torch.empty_like(Wc)
-                dbc = Wc.new_empty(h) if bc is not None else None
-                k.node_post_bwd(*rows((Zc[0],)), Tc, Wc, *rows((dY, dBm, dci)), dWc, dbc)
-            else:
-                # candidate convolution, blend backward in its prologue
-                g, dWc, dbc, _, _ = _bdg_backward_slabs(None, Zc, Wc, Tc, op, Ks, bc is not None, False, False, cand=(dHnew, U, Cand))
-                if Ks > 1:
-                    k.csr_spmm(*bwd, N, N, v3(g[1]), v3(g[0]), v3(g[0]), 1.0, 1.0, plan=op.bwd_plan)
-                dci = g[0]
+            Hprev, U, Rg, Cand, *rest = cells[j]
             dH = torch.empty_like(Hprev)
-            # gates convolution, gate + blend backward in its prologue
-            g, dWg, dbg, _, _ = _bdg_backward_slabs(None, Zg, Wg, Tc, op, Ks, bg is not None, False, False,
-                                                    gates=(dci, Cand, Hprev, U, Rg, dHnew, dH))
+            if n_saved[j] < 0:                                       # planar cell: inputs read as planes, gradient rows interleaved
+                Xp, SXp, SHp, RH = rest
+                L = 2 * h
+                dY = torch.empty_like(Hprev)
+                k.gru_blend_bwd(dHnew, U, None, Cand, dY, None, None)                      # dY = dHnew * U * (1 - Cand^2)
+                dBm = narrow_transpose_aggregation(dY)
+                dci, dWc = Hprev.new_empty(B, N, C, L), torch.empty_like(Wc)
+                dbc = Wc.new_empty(h) if bc is not None else None
+                k.node_post_bwd(*rows((Xp,)), Tc, Wc, *rows((dY, dBm, dci)), dWc, dbc, X2=RH.view(B * N, C, h))
+                g = [torch.empty_like(dci), torch.empty_like(dci)]
+                dWg, dbg = torch.empty_like(Wg), (Wg.new_empty(2 * h) if bg is not None else None)
+                k.cell_gates_bwd_planar(*rows((Xp, Hprev, SXp, SHp)), Tc, Wg, *rows((dci, Cand, U, Rg, dHnew)), rows(g), dWg, dbg,
+                                        dH.view(B * N, C, h))
+            else:
+                Zg, Zc = rest[:Ks], rest[Ks:]
+                L = Zc[0].shape[-1]
+                if len(Zc) == 1 and Ks > 1:                         # the forward ran this convolution as Y = A + S.Bm (no Z_1 slab)
+                    dY = torch.empty_like(Hprev)
+                    k.gru_blend_bwd(dHnew, U, None, Cand, dY, None, None)
+                    dBm = narrow_transpose_aggregation(dY)
+                    dci, dWc = torch.empty_like(Zc[0]), torch.empty_like(Wc)
+                    dbc = Wc.new_empty(h) if bc is not None else None
+                    k.node_post_bwd(*rows((Zc[0],)), Tc, Wc, *rows((dY, dBm, dci)), dWc, dbc)
+                else:                                               # slab form, blend backward in the node kernel's prologue
+                    g, dWc, dbc, _, _ = _bdg_backward_slabs(None, Zc, Wc, Tc, op, Ks, bc is not None, False, False, cand=(dHnew, U, Cand))
+                    if Ks > 1:
+                        k.csr_spmm(*bwd, N, N, g[1].view(B, N, C * L), g[0].view(B, N, C * L), g[0].view(B, N, C * L), 1.0, 1.0, plan=op.bwd_plan)
+                    dci = g[0]
+                # gates convolution, gate + blend backward in its prologue
+                g, dWg, dbg, _, _ = _bdg_backward_slabs(None, Zg, Wg, Tc, op, Ks, bg is not None, False, False,
+                                                        gates=(dci, Cand, Hprev, U, Rg, dHnew, dH))
+            v3 = lambda t: t.view(B, N, C * L)
             need_x, need_h = x[0] == 'cell', hs[0] == 'cell'
             if need_x or need_h:
                 if Ks > 1:
