@@ -158,7 +158,8 @@ int stc_gru_blend_bwd_f32(const float* dHnew, const float* U, const float* H, co
  * formed.  Backward: dA = dY, dBm = Gs x dY (one narrow stc_csr/bcsr_spmm_f32 by the caller), then this kernel turns
  * (X, dA, dBm) into dX (nodes, C, L), dW (4*Lw, Ho) and db directly -- no second gradient slab, no SpMM after it.
  * Shapes: C in {32, 64}, L in {20, 32}, Ho = 16 (stc_bdg_node_post_supported), else STC_EUNSUPPORTED.
- * X2 != NULL (L = 32 only): planar input -- X holds columns 0..15 and X2 columns 16..31 of the rows, each (nodes, C, 16).
+ * X2 != NULL (L = 32 only): planar input -- X holds columns 0..15 and X2 columns 16..31 of the rows, each (nodes, C, 16);
+ * the backward then writes the gradient as the two planes dX, dX2 as well (dX2 != NULL exactly when X2 != NULL).
  * workspace as stc_bdg_node_bwd_f32 (stc_bdg_node_bwd_workspace_bytes(2, 2, C, L, Ho, 0)). */
 int stc_bdg_node_post_supported(int32_t Ks, int32_t Kc, int32_t C, int32_t L, int32_t Ho);
 /* forward: X (nodes, C, L) -> A = sum_c T_c^T (X W_{0,c}) + bias and Bm = sum_c T_c^T (X W_{1,c}), (nodes, C, Ho) each;
@@ -177,7 +178,7 @@ int stc_spmm_blend_fwd_f32(const int32_t* rowptr, const int32_t* colidx, const f
                            float* copy1, int32_t copy1_ld, int32_t copy1_off,
                            int32_t batch, int32_t C, int32_t h, void* stream);
 int stc_bdg_node_post_bwd_f32(const float* X, const float* X2, const float* Tc, const float* W, const float* dA, const float* dB,
-                              float* dX, float* dW, float* db, void* workspace, size_t workspace_bytes,
+                              float* dX, float* dX2, float* dW, float* db, void* workspace, size_t workspace_bytes,
                               int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t Ho, void* stream);
 
 /* ---- fused cell convolutions (STC_GNN.py:69-78) ------------------------------------
@@ -233,8 +234,10 @@ int stc_cell_blend_fwd_f32(const float* const* Z, int32_t Ks, const float* Tc, i
  * tensor then IS the X plane of the next layer's cell and the H plane of the next step's cell (no concat, no copies), and
  * its aggregation S x state is computed once (narrow SpMM) and shared by both.  X/H: the planes; SX/SH: their aggregations.
  * Forward: U, Rg (nodes, C, h) and the R*H plane RH -- the candidate convolution's input is (X, RH), see
- * stc_bdg_node_post_fwd_f32's X2.  Backward: as the Cand form of stc_cell_gates_bwd_f32 with dCandIn (nodes, C, 2h) the
- * interleaved gradient rows [d x part | d RH] produced by stc_bdg_node_post_bwd_f32; dZ[0], dZ[1] interleaved (nodes, C, 2h). */
+ * stc_bdg_node_post_fwd_f32's X2.  Backward: as the Cand form of stc_cell_gates_bwd_f32 with dCandIn (nodes, C, h) the
+ * gradient of the R*H plane (dX2 of stc_bdg_node_post_bwd_f32); the gradient slabs come out planar too:
+ * dZ = {d X plane, d SX plane, d H plane, d SH plane}, (nodes, C, h) each, plus dH = the state's share from the gates.
+ * The gradient of a state then is  sum of its consumers' direct planes + S^T (sum of their S planes): stc_spmm_sum_f32. */
 int stc_cell_planar_supported(int32_t Ks, int32_t Kc, int32_t C, int32_t h);
 int stc_cell_gates_fwd_planar_f32(const float* X, const float* H, const float* SX, const float* SH,
                                   const float* Tc, const float* W, const float* bias,
@@ -246,6 +249,15 @@ int stc_cell_gates_bwd_planar_f32(const float* X, const float* H, const float* S
                                   float* const* dZ, float* dW, float* db, float* dH,
                                   void* workspace, size_t workspace_bytes,
                                   int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream);
+
+/* Y = sum_i add[i] + S x (X [+ X2]) on rows of C*h floats (h = 16): the gradient of a state from the pieces its consumers
+ * left -- direct planes as addends (add[i]: columns [add_off[i], add_off[i]+h) of rows of add_ld[i] floats, multiples of 4;
+ * a contiguous plane is ld = h, off = 0), aggregated planes X, X2 through the transposed graph.  n_add <= 5, X2 may be NULL. */
+int stc_spmm_sum_f32(const int32_t* rowptr, const int32_t* colidx, const float* val,
+                     const int32_t* blk_ptr, const int32_t* blk_cols, const float* blk_vals,
+                     int32_t n_rows, int32_t n_cols, const float* X, const float* X2,
+                     int32_t n_add, const float* const* add, const int32_t* add_ld, const int32_t* add_off,
+                     float* Y, int32_t batch, int32_t C, int32_t h, void* stream);
 
 /* ---- the same two cell convolutions with the graph aggregation fused in (Ks = Kc = 2) ------------------------------
  * Replaces STC_GNN.py:37 (the 1-mode product Z1 = Gs^T x Z0, one SpMM launch) + :38-45 + :71-78 in ONE launch per

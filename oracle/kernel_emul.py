@@ -154,9 +154,21 @@ class EmulatedKernels:
         self.cell_gates_fwd([torch.cat([X, H], -1), torch.cat([SX, SH], -1)], Tc, W, bias, H, U, Rg, CandIn)
         RH.copy_(CandIn[..., H.shape[-1]:])
 
-    def cell_gates_bwd_planar(self, X, H, SX, SH, Tc, W, dCandIn, Cand, U, Rg, dHnew, dZs, dW, db, dH):
-        self.cell_gates_bwd([torch.cat([X, H], -1), torch.cat([SX, SH], -1)], Tc, W, dCandIn, None, H, U, Rg, dHnew, dZs, dW, db, None, dH,
+    def cell_gates_bwd_planar(self, X, H, SX, SH, Tc, W, dRH, Cand, U, Rg, dHnew, dZs, dW, db, dH):
+        h = H.shape[-1]
+        rows = [torch.empty(H.shape[:-1] + (2 * h,), dtype=W.dtype) for _ in range(2)]
+        dCandIn = torch.cat([torch.zeros_like(dRH), dRH], -1)             # only the R*H half is read
+        self.cell_gates_bwd([torch.cat([X, H], -1), torch.cat([SX, SH], -1)], Tc, W, dCandIn, None, H, U, Rg, dHnew, rows, dW, db, None, dH,
                             dH_in_scaled=True, Cand=Cand)
+        dZs[0].copy_(rows[0][..., :h]); dZs[2].copy_(rows[0][..., h:])      # d X plane, d H plane
+        dZs[1].copy_(rows[1][..., :h]); dZs[3].copy_(rows[1][..., h:])      # d SX plane, d SH plane
+
+    def spmm_sum(self, rowptr, colidx, val, plan, X, X2, addends, Y):
+        B, n, Cc, h = Y.shape
+        src = X if X2 is None else X + X2
+        self.csr_spmm(rowptr, colidx, val, n, n, src.reshape(B, n, Cc * h), None, Y.view(B, n, Cc * h), 1.0, 0.0)
+        for t, off in addends:
+            Y += t[..., off:off + h]
 
     def node_post_fwd(self, X, Tc, W, bias, A, Bm, X2=None):
         if X2 is not None:
@@ -182,9 +194,12 @@ class EmulatedKernels:
             buf[..., :off].copy_(side)
             buf[..., off + h:].zero_()
 
-    def node_post_bwd(self, X, Tc, W, dA, dB, dX, dW, db, X2=None):
-        if X2 is not None:
-            X = torch.cat([X, X2], -1)
+    def node_post_bwd(self, X, Tc, W, dA, dB, dX, dW, db, X2=None, dX2=None):
+        if X2 is not None:                                     # planar: compute on the concatenated rows, hand back the planes
+            full = torch.empty(X.shape[:-1] + (2 * X.shape[-1],), dtype=W.dtype)
+            self.node_post_bwd(torch.cat([X, X2], -1), Tc, W, dA, dB, full, dW, db)
+            dX.copy_(full[..., :X.shape[-1]]); dX2.copy_(full[..., X.shape[-1]:])
+            return
         Lw = W.shape[0] // 4
         dW.zero_()
         dX.zero_()

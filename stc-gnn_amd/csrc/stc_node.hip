@@ -517,7 +517,8 @@ extern "C" int stc_cell_gates_bwd_planar_f32(const float* X, const float* H, con
         if (db) if (int rc = stc::hip_status(hipMemsetAsync(db, 0, (size_t)Ho * sizeof(float), s), "memset db")) return rc;
         return STC_OK;
     }
-    STC_REQUIRE(X && H && SX && SH && dCandIn && Cand && U && Rg && dHnew && dH && dZ[0] && dZ[1], STC_EINVAL, "stc_cell_gates_bwd_planar_f32: null pointer");
+    STC_REQUIRE(X && H && SX && SH && dCandIn && Cand && U && Rg && dHnew && dH && dZ[0] && dZ[1] && dZ[2] && dZ[3], STC_EINVAL,
+                "stc_cell_gates_bwd_planar_f32: null pointer");
     STC_REQUIRE(workspace && stc::aligned16(workspace), STC_EALIGN, "stc_cell_gates_bwd_planar_f32: workspace null or not 16-byte aligned");
     STC_REQUIRE(workspace_bytes >= stc_bdg_node_bwd_workspace_bytes(2, 2, C, L, Ho, 0), STC_EINVAL,
                 "stc_cell_gates_bwd_planar_f32: workspace of %zu B is too small", workspace_bytes);
@@ -552,7 +553,7 @@ extern "C" int stc_bdg_node_post_fwd_f32(const float* X, const float* X2, const 
 }
 
 extern "C" int stc_bdg_node_post_bwd_f32(const float* X, const float* X2, const float* Tc, const float* W, const float* dA, const float* dB,
-                                         float* dX, float* dW, float* db, void* workspace, size_t workspace_bytes,
+                                         float* dX, float* dX2, float* dW, float* db, void* workspace, size_t workspace_bytes,
                                          int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t Ho, void* stream) {
     if (int rc = check_dims("stc_bdg_node_post_bwd_f32", 2, 2, C, L, Lw, Ho, nodes)) return rc;
     if (!stc_bdg_node_post_supported(2, 2, C, L, Ho)) return stc::fail(STC_EUNSUPPORTED, "stc_bdg_node_post_bwd_f32: shape not on the post-aggregation path");
@@ -571,7 +572,8 @@ extern "C" int stc_bdg_node_post_bwd_f32(const float* X, const float* X2, const 
     int n_parts = 0;
     float* partial = static_cast<float*>(workspace);
     STC_REQUIRE(!X2 || L == 32, STC_EINVAL, "stc_bdg_node_post_bwd_f32: planar input (X2) needs rows of 16 + 16 columns, L = %d", L);
-    const int rc = stc_node_post_bwd_x3(X, X2, Tc, W, dA, dB, dX, partial, &n_parts, db != nullptr, nodes, C, L, Lw, Ho, s);
+    STC_REQUIRE((X2 == nullptr) == (dX2 == nullptr), STC_EINVAL, "stc_bdg_node_post_bwd_f32: planar input (X2) and planar gradient (dX2) go together");
+    const int rc = stc_node_post_bwd_x3(X, X2, Tc, W, dA, dB, dX, dX2, partial, &n_parts, db != nullptr, nodes, C, L, Lw, Ho, s);
     if (rc == STC_NOT_HANDLED) return stc::fail(STC_EUNSUPPORTED, "stc_bdg_node_post_bwd_f32: operands not usable (alignment)");
     if (rc != STC_OK) return rc;
     const int stride = nW + Ho;

@@ -16,7 +16,7 @@ constexpr int MF_BWD_MAX_GRID = 512;     // partial rows the caller's workspace 
 
 // q: second plane of a slab in the planar layout ([Xt | H] kept as two contiguous (nodes, C, 16) planes); null otherwise
 struct ZPtrs { const float* p[STC_MAX_K]; const float* q[STC_MAX_K]; };
-struct DZPtrs { float* p[STC_MAX_K]; };
+struct DZPtrs { float* p[STC_MAX_K]; float* q[STC_MAX_K]; };        // q: second plane of a gradient slab (planar layout)
 
 template <int N>
 struct AtLeast1 { static constexpr int v = N > 0 ? N : 1; };

@@ -439,7 +439,11 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
     while (node < nodes) {
         const int next_node = node + nw;
         const size_t r0 = (size_t)node * C;
-        if constexpr (PRO == PRO_GATES || PRO == PRO_GATES_CAND) { load_gates_grad<NRB, HB, L, PRO == PRO_GATES_CAND>(in.g, pro, node, x, g); in.load_z(Z, node, x, g); }
+        if constexpr (PRO == PRO_GATES || PRO == PRO_GATES_CAND) {
+            // planar: dCandIn is the R*H plane's gradient alone, (nodes, C, 16) with the state columns at offset 0
+            load_gates_grad<NRB, HB, (PL ? 16 : L), PRO == PRO_GATES_CAND>(in.g, pro, node, x, g);
+            in.load_z(Z, node, x, g);
+        }
         else if constexpr (PRO == PRO_BLEND) { load_blend_grad<NRB>(in.g, pro, node, x, g); in.load_z(Z, node, x, g); }
         else if (!PF) { in.g.load(dY, node, x, g); in.load_z(Z, node, x, g); }
         if (PF && next_node < nodes) { nx.g.load(dY, next_node, x, g); nx.load_z(Z, next_node, x, g); }
@@ -505,7 +509,11 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
 #pragma unroll
                     for (int rb = 0; rb < NRB; ++rb) z[rb] = mma6(w, qb[s][rb], z[rb]);
                 }
-                if (16 * lb + 4 * g < L) {
+                if constexpr (PL) {                             // planar gradient slabs: block lb of the row goes to plane lb
+#pragma unroll
+                    for (int rb = 0; rb < NRB; ++rb)
+                        *reinterpret_cast<f32x4*>((lb == 0 ? dZ.p[n] : dZ.q[n]) + (r0 + 16 * rb + x) * 16 + 4 * g) = z[rb];
+                } else if (16 * lb + 4 * g < L) {
 #pragma unroll
                     for (int rb = 0; rb < NRB; ++rb)
                         *reinterpret_cast<f32x4*>(dZ.p[n] + (r0 + 16 * rb + x) * L + 16 * lb + 4 * g) = z[rb];
@@ -671,7 +679,7 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd2_x3_k
 template <int NB2, int HB, int L, int PL = 0>
 __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_kernel(
     const float* __restrict__ X, const float* __restrict__ X2, const float* __restrict__ Tc, const float* __restrict__ W,
-    const float* __restrict__ dA, const float* __restrict__ dB, float* __restrict__ dX,
+    const float* __restrict__ dA, const float* __restrict__ dB, float* __restrict__ dX, float* __restrict__ dX2,
     float* __restrict__ partial, int nodes, int want_db, int Lw) {
     constexpr int K = 2, NRB = 2 * NB2, C = 32 * NB2, Ho = 16 * HB, LB = (L + 15) / 16;
     constexpr int NBK = K * HB, S = (NBK + 1) / 2;
@@ -795,7 +803,11 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
 #pragma unroll
                     for (int rb = 0; rb < NRB; ++rb) z[rb] = mma6(w, qb[n][s][rb], z[rb]);
                 }
-            if (16 * lb + 4 * g < L) {
+            if constexpr (PL) {                                 // planar gradient: columns 0..15 -> dX, 16..31 -> dX2
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb)
+                    *reinterpret_cast<f32x4*>((lb == 0 ? dX : dX2) + (r0 + 16 * rb + x) * 16 + 4 * g) = z[rb];
+            } else if (16 * lb + 4 * g < L) {
 #pragma unroll
                 for (int rb = 0; rb < NRB; ++rb)
                     *reinterpret_cast<f32x4*>(dX + (r0 + 16 * rb + x) * L + 16 * lb + 4 * g) = z[rb];
@@ -874,7 +886,7 @@ int launch_bwd(const float* const* Z, const float* Tc, const float* W, const flo
     static const int resident = stc::resident_blocks(kern, MF_THREADS, lds, BwdSched<NB2, K>::waves);
     ZPtrs zp{};
     DZPtrs dzp{};
-    for (int n = 0; n < K; ++n) { zp.p[n] = Z[n]; dzp.p[n] = dZ[n]; if (PL) zp.q[n] = Z[K + n]; }
+    for (int n = 0; n < K; ++n) { zp.p[n] = Z[n]; dzp.p[n] = dZ[n]; if (PL) { zp.q[n] = Z[K + n]; dzp.q[n] = dZ[K + n]; } }
     const long long want = (nodes + MF_WAVES - 1) / MF_WAVES;
     int grid = resident < MF_BWD_MAX_GRID ? resident : MF_BWD_MAX_GRID;
     if (want < grid) grid = (int)want;
@@ -1053,7 +1065,7 @@ int stc_cell_blend_fwd_gather_x3(const int* rowptr, const int* colidx, const flo
 
 // ---- post-aggregation backward (K = 2): (X, dA, dBm) -> dX, dW partials
 template <int NB2, int HB, int L, int PL = 0>
-static int launch_bwd2(const float* X, const float* X2, const float* Tc, const float* W, const float* dA, const float* dB, float* dX,
+static int launch_bwd2(const float* X, const float* X2, const float* Tc, const float* W, const float* dA, const float* dB, float* dX, float* dX2,
                        float* partial, int* n_partials, int want_db, long long nodes, int Lw, hipStream_t stream) {
     constexpr int K = 2, NRB = 2 * NB2, Ho = 16 * HB, LB = (L + 15) / 16, NBK = K * HB, S = (NBK + 1) / 2, nW = K * K * L * Ho;
     const size_t frag = (size_t)(NRB * NB2 + K * LB * S) * 3 * 64 * 16;
@@ -1066,7 +1078,7 @@ static int launch_bwd2(const float* X, const float* X2, const float* Tc, const f
     const long long want = (nodes + MF_WAVES - 1) / MF_WAVES;
     int grid = resident < MF_BWD_MAX_GRID ? resident : MF_BWD_MAX_GRID;
     if (want < grid) grid = (int)want;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(MF_THREADS), lds, stream, X, X2, Tc, W, dA, dB, dX, partial, (int)nodes, want_db, Lw);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(MF_THREADS), lds, stream, X, X2, Tc, W, dA, dB, dX, dX2, partial, (int)nodes, want_db, Lw);
     STC_LAUNCH_CHECK("node_bwd2_x3 launch");
     *n_partials = grid;
     return STC_OK;
@@ -1091,17 +1103,17 @@ int stc_node_post_shape_ok(int K, int C, int L, int Ho) {
     return K == 2 && (C == 32 || C == 64) && (L == 20 || L == 32) && Ho == 16;     // Ho < L: where the narrow SpMM pays
 }
 
-int stc_node_post_bwd_x3(const float* X, const float* X2, const float* Tc, const float* W, const float* dA, const float* dB, float* dX,
+int stc_node_post_bwd_x3(const float* X, const float* X2, const float* Tc, const float* W, const float* dA, const float* dB, float* dX, float* dX2,
                          float* partial, int* n_partials, int want_db, long long nodes, int C, int L, int Lw, int Ho, hipStream_t stream) {
     if (!stc_node_post_shape_ok(2, C, L, Ho) || nodes <= 0 || nodes >= (1ll << 31) / C) return STC_NOT_HANDLED;
     if (!(stc::aligned16(X) && stc::aligned16(dA) && stc::aligned16(dB) && stc::aligned16(dX) && (!X2 || stc::aligned16(X2)))) return STC_NOT_HANDLED;
-    if (X2) {                                   // planar input rows (16 + 16 columns)
-        if (L != 32) return STC_NOT_HANDLED;
-        if (C == 32) return launch_bwd2<1, 1, 32, 1>(X, X2, Tc, W, dA, dB, dX, partial, n_partials, want_db, nodes, Lw, stream);
-        if (C == 64) return launch_bwd2<2, 1, 32, 1>(X, X2, Tc, W, dA, dB, dX, partial, n_partials, want_db, nodes, Lw, stream);
+    if (X2) {                                   // planar rows (16 + 16 columns): input planes X, X2 and gradient planes dX, dX2
+        if (L != 32 || !dX2 || !stc::aligned16(dX2)) return STC_NOT_HANDLED;
+        if (C == 32) return launch_bwd2<1, 1, 32, 1>(X, X2, Tc, W, dA, dB, dX, dX2, partial, n_partials, want_db, nodes, Lw, stream);
+        if (C == 64) return launch_bwd2<2, 1, 32, 1>(X, X2, Tc, W, dA, dB, dX, dX2, partial, n_partials, want_db, nodes, Lw, stream);
         return STC_NOT_HANDLED;
     }
-#define B2_CALL(a, b, d) launch_bwd2<a, b, d>(X, nullptr, Tc, W, dA, dB, dX, partial, n_partials, want_db, nodes, Lw, stream)
+#define B2_CALL(a, b, d) launch_bwd2<a, b, d>(X, nullptr, Tc, W, dA, dB, dX, nullptr, partial, n_partials, want_db, nodes, Lw, stream)
     if (C == 32 && L == 20) return B2_CALL(1, 1, 20);
     if (C == 32 && L == 32) return B2_CALL(1, 1, 32);
     if (C == 64 && L == 20) return B2_CALL(2, 1, 20);
@@ -1148,11 +1160,13 @@ int stc_cell_gates_bwd_planar_x3(const float* X, const float* H, const float* SX
                                  long long nodes, int C, int Lw, hipStream_t stream) {
     if (!x3_cell_shape(2, C, 32, nodes)) return STC_NOT_HANDLED;
     const float* Z[4] = {X, SX, H, SH};
-    if (!all_aligned16(Z, 4) || !stc::aligned16(dZ[0]) || !stc::aligned16(dZ[1])) return STC_NOT_HANDLED;
+    if (!all_aligned16(Z, 4)) return STC_NOT_HANDLED;
+    for (int i = 0; i < 4; ++i)
+        if (!dZ[i] || !stc::aligned16(dZ[i])) return STC_NOT_HANDLED;
     if (!(stc::aligned16(dCandIn) && stc::aligned16(Cand) && stc::aligned16(U) && stc::aligned16(R) && stc::aligned16(dHnew) && stc::aligned16(dH)))
         return STC_NOT_HANDLED;
-    BwdPro pro{};
-    pro.Cand = Cand; pro.dCandIn = dCandIn; pro.H = H; pro.U = U; pro.R = R; pro.dH_in = dHnew; pro.dH = dH; pro.cin = 16; pro.dh_scaled = 1;
+    BwdPro pro{};       // dCandIn: the gradient of the R*H plane, (nodes, C, 16): the state columns sit at offset 0
+    pro.Cand = Cand; pro.dCandIn = dCandIn; pro.H = H; pro.U = U; pro.R = R; pro.dH_in = dHnew; pro.dH = dH; pro.cin = 0; pro.dh_scaled = 1;
     if (C == 32) return launch_bwd<1, 2, 2, 32, PRO_GATES_CAND, 1>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro);
     if (C == 64) return launch_bwd<2, 2, 2, 32, PRO_GATES_CAND, 1>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro);
     return STC_NOT_HANDLED;

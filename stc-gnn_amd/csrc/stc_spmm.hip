@@ -58,7 +58,7 @@ __device__ __forceinline__ void nt_store4(float4* p, const float4& v) {
     __builtin_nontemporal_store(v4f{v.x, v.y, v.z, v.w}, reinterpret_cast<v4f*>(p));
 }
 
-enum { EP_PLAIN = 0, EP_SPLIT = 1, EP_GATES = 2, EP_BLEND = 3 };
+enum { EP_PLAIN = 0, EP_SPLIT = 1, EP_GATES = 2, EP_BLEND = 3, EP_SUM = 4, EP_SUM2 = 5 };
 
 struct EpiArgs {
     const float4* Y0;                       // base term (PLAIN: optional, scaled by beta; SPLIT/GATES: added)
@@ -74,6 +74,10 @@ struct EpiArgs {
     float *Cand, *Hnew;                     // (rows*C, h)
     float* copy[2]; int copy_ld[2], copy_off[2];
     const float* side_src; int side_cin;    // belongs to copy[0]
+    // SUM / SUM2 (gradient of a state from its consumers' pieces): Y = sum_i add[i] + S.(X [+ X2]), rows of C*h floats;
+    // add[i] = columns [off, off+h) of rows of ld floats (a contiguous plane: ld = h, off = 0)
+    const float4* X2;                       // SUM2: second gathered operand (same batch stride as X)
+    const float* add[5]; int add_ld[5], add_off[5], n_add;
 };
 
 // one element of a [Xt | H | pad] row: l = column, e = (row, category) index, v = its gradient
@@ -139,6 +143,17 @@ __device__ __forceinline__ void epilogue(const EpiArgs& a, size_t rowg, int F4, 
             r.z = fmaf(a.beta, y0.z, r.z); r.w = fmaf(a.beta, y0.w, r.w);
         }
         nt_store4(a.Y + o, r);
+        return;
+    }
+    if (MODE == EP_SUM || MODE == EP_SUM2) {
+        float4 y = acc;
+        const size_t e = rowg * a.C + (ch >> 2);                  // h = 16: piece ch = 4 * category + quarter
+        const int q4 = ch & 3;
+        for (int i = 0; i < a.n_add; ++i) {
+            const float4 t = *reinterpret_cast<const float4*>(a.add[i] + e * a.add_ld[i] + a.add_off[i] + 4 * q4);
+            y.x += t.x; y.y += t.y; y.z += t.z; y.w += t.w;
+        }
+        nt_store4(a.Y + o, y);
         return;
     }
     const float4 y0 = nt_load4(a.Y0 + o);
@@ -258,6 +273,10 @@ __global__ __launch_bounds__(SPMM_THREADS) void spmm_wave_row_kernel(
                     for (int p = 0; p < VPT; ++p) {
                         const int ch = cb + lane + 64 * p;
                         x[u][p] = ch < F4 ? xr[ch] : make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (MODE == EP_SUM2 && ch < F4) {
+                            const float4 t = (ep.X2 + (size_t)b * n_cols * F4 + (size_t)c[u] * F4)[ch];
+                            x[u][p].x += t.x; x[u][p].y += t.y; x[u][p].z += t.z; x[u][p].w += t.w;
+                        }
                     }
                 }
 #pragma unroll
@@ -273,7 +292,14 @@ __global__ __launch_bounds__(SPMM_THREADS) void spmm_wave_row_kernel(
 #pragma unroll
                 for (int p = 0; p < VPT; ++p) {
                     const int ch = cb + lane + 64 * p;
-                    if (ch < F4) fma4(acc[p], v, xr[ch]);
+                    if (ch < F4) {
+                        float4 xv = xr[ch];
+                        if (MODE == EP_SUM2) {
+                            const float4 t = (ep.X2 + (size_t)b * n_cols * F4 + (size_t)c * F4)[ch];
+                            xv.x += t.x; xv.y += t.y; xv.z += t.z; xv.w += t.w;
+                        }
+                        fma4(acc[p], v, xv);
+                    }
                 }
             }
 #pragma unroll
@@ -382,6 +408,10 @@ __global__ __launch_bounds__(SPMM_THREADS) void spmm_bcsr_kernel(
                     for (int p = 0; p < VPT; ++p) {
                         const int ch = cb + lane + 64 * p;
                         x[u][p] = ch < F4 ? xr[ch] : make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (MODE == EP_SUM2 && ch < F4) {
+                            const float4 t = (ep.X2 + (size_t)b * n_cols * F4 + (size_t)c[u] * F4)[ch];
+                            x[u][p].x += t.x; x[u][p].y += t.y; x[u][p].z += t.z; x[u][p].w += t.w;
+                        }
                     }
                 }
 #pragma unroll
@@ -400,7 +430,11 @@ __global__ __launch_bounds__(SPMM_THREADS) void spmm_bcsr_kernel(
                 for (int p = 0; p < VPT; ++p) {
                     const int ch = cb + lane + 64 * p;
                     if (ch < F4) {
-                        const float4 xv = xr[ch];
+                        float4 xv = xr[ch];
+                        if (MODE == EP_SUM2) {
+                            const float4 t = (ep.X2 + (size_t)b * n_cols * F4 + (size_t)c * F4)[ch];
+                            xv.x += t.x; xv.y += t.y; xv.z += t.z; xv.w += t.w;
+                        }
 #pragma unroll
                         for (int r = 0; r < BR; ++r) fma4(acc[r][p], v[r], xv);
                     }
@@ -669,6 +703,34 @@ extern "C" int stc_spmm_blend_fwd_f32(const int32_t* rowptr, const int32_t* coli
     ep.copy[1] = copy1; ep.copy_ld[1] = copy1_ld; ep.copy_off[1] = copy1_off;
     ep.side_src = copy0 ? side_src : nullptr; ep.side_cin = side_cin;
     return launch_vector<EP_BLEND>("stc_spmm_blend_fwd_f32 launch", g, n_rows, n_cols, Bm, batch, C * h, ep, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int stc_spmm_sum_f32(const int32_t* rowptr, const int32_t* colidx, const float* val,
+                                const int32_t* blk_ptr, const int32_t* blk_cols, const float* blk_vals,
+                                int32_t n_rows, int32_t n_cols, const float* X, const float* X2,
+                                int32_t n_add, const float* const* add, const int32_t* add_ld, const int32_t* add_off,
+                                float* Y, int32_t batch, int32_t C, int32_t h, void* stream) {
+    const GraphArgs g{rowptr, colidx, val, blk_ptr, blk_cols, blk_vals};
+    STC_REQUIRE(h == 16, STC_EUNSUPPORTED, "stc_spmm_sum_f32: hidden width %d (built for 16)", h);
+    STC_REQUIRE(n_add >= 0 && n_add <= 5 && (n_add == 0 || (add && add_ld && add_off)), STC_EINVAL, "stc_spmm_sum_f32: 0..5 addends, got %d", n_add);
+    if (int rc = check_fused("stc_spmm_sum_f32", g, n_rows, n_cols, X, Y, batch, C, 0, h, 0)) return rc;      // (Y checked as the aligned "Y0" operand)
+    if (n_rows == 0 || batch == 0) return STC_OK;
+    STC_REQUIRE(X != Y && X2 != Y, STC_EINVAL, "stc_spmm_sum_f32: Y must not alias a gathered operand");
+    STC_REQUIRE(!X2 || stc::aligned16(X2), STC_EALIGN, "stc_spmm_sum_f32: X2 not 16-byte aligned");
+    EpiArgs ep{};
+    ep.Y = reinterpret_cast<float4*>(Y);
+    ep.C = C; ep.L = h; ep.cin = 0; ep.h = h;
+    ep.X2 = reinterpret_cast<const float4*>(X2);
+    ep.n_add = n_add;
+    for (int i = 0; i < n_add; ++i) {
+        STC_REQUIRE(add[i] && add_off[i] >= 0 && add_off[i] + h <= add_ld[i] && ((add_ld[i] | add_off[i]) & 3) == 0 && stc::aligned16(add[i]), STC_EINVAL,
+                    "stc_spmm_sum_f32: addend %d (ld %d, off %d) must be non-null, 16-byte aligned, with ld and off multiples of 4", i, add_ld[i], add_off[i]);
+        STC_REQUIRE(add[i] != Y, STC_EINVAL, "stc_spmm_sum_f32: Y must not alias an addend");
+        ep.add[i] = add[i]; ep.add_ld[i] = add_ld[i]; ep.add_off[i] = add_off[i];
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return X2 ? launch_vector<EP_SUM2>("stc_spmm_sum_f32 launch", g, n_rows, n_cols, X, batch, C * h, ep, s)
+              : launch_vector<EP_SUM>("stc_spmm_sum_f32 launch", g, n_rows, n_cols, X, batch, C * h, ep, s);
 }
 
 extern "C" int stc_csr_sddmm_f32(const int32_t* rowptr, const int32_t* colidx,

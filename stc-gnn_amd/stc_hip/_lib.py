@@ -30,7 +30,7 @@ EXPORTS = (
     'stc_bdg_node_fwd_f32', 'stc_bdg_node_bwd_workspace_bytes', 'stc_bdg_node_bwd_f32',
     'stc_bdg_node_post_supported', 'stc_bdg_node_post_fwd_f32', 'stc_bdg_node_post_bwd_f32', 'stc_spmm_blend_fwd_f32',
     'stc_cell_fused_supported', 'stc_cell_gates_fwd_f32', 'stc_cell_gates_bwd_f32', 'stc_cell_cand_bwd_f32', 'stc_cell_blend_fwd_f32',
-    'stc_cell_planar_supported', 'stc_cell_gates_fwd_planar_f32', 'stc_cell_gates_bwd_planar_f32',
+    'stc_cell_planar_supported', 'stc_cell_gates_fwd_planar_f32', 'stc_cell_gates_bwd_planar_f32', 'stc_spmm_sum_f32',
     'stc_cell_gather_supported', 'stc_cell_gates_fwd_gather_f32', 'stc_cell_blend_fwd_gather_f32',
     'stc_gru_gates_fwd_f32', 'stc_gru_gates_bwd_f32', 'stc_gru_blend_fwd_f32', 'stc_gru_blend_bwd_f32',
     'stc_head_fwd_f32', 'stc_head_bwd_workspace_bytes', 'stc_head_bwd_f32',
@@ -68,7 +68,8 @@ def _declare(lib):
         'stc_cell_gates_fwd_planar_f32': [_p] * 10 + [_i64, _i32, _i32, _i32, _p],
         'stc_cell_gates_bwd_planar_f32': [_p] * 11 + [C.POINTER(_p), _p, _p, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _p],
         'stc_spmm_blend_fwd_f32': [_p] * 6 + [_i32, _i32] + [_p] * 6 + [_p, _i32, _i32, _p, _i32, _p, _i32, _i32] + [_i32] * 3 + [_p],
-        'stc_bdg_node_post_bwd_f32': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _i32, _p],
+        'stc_bdg_node_post_bwd_f32': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _i32, _p],
+        'stc_spmm_sum_f32': [_p] * 6 + [_i32, _i32, _p, _p, _i32, C.POINTER(_p), C.POINTER(_i32), C.POINTER(_i32), _p, _i32, _i32, _i32, _p],
         'stc_cell_gates_fwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _i32, _p],
         'stc_cell_cand_bwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _p, C.POINTER(_p), _p, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _i32, _p],
         'stc_cell_gates_bwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _i32, C.POINTER(_p), _p, _p, _p, _p,
@@ -295,6 +296,27 @@ class HipKernels:
                      nbytes=colidx.numel() * 8 + 4 * (n + 1) + 4 * B * n * Cc * (2 * (cin + h + pad) + (2 if addA is not None else 1) * cin
                                                                                   + (2 if addB is not None else 1) * h))
 
+    def spmm_sum(self, rowptr, colidx, val, plan, X, X2, addends, Y):
+        """Y = sum(addends) + S.(X [+ X2]) on (B, n, C, h) state tensors (stc_spmm_sum_f32).  ``addends``: up to five
+        (tensor, column offset) pairs -- columns [off, off + h) of a (B, n, C, ld) tensor (a plain plane: ld = h, off = 0)."""
+        B, n, Cc, h = Y.shape
+        self._f32('spmm_sum.Y', Y)
+        self._f32('spmm_sum.X', X, (B, n, Cc, h))
+        if X2 is not None:
+            self._f32('spmm_sum.X2', X2, (B, n, Cc, h))
+        if len(addends) > 5:
+            raise StcError(f'spmm_sum: at most five addends, got {len(addends)}')
+        ptrs, lds, offs = (_p * 5)(), (_i32 * 5)(), (_i32 * 5)()
+        for i, (t, off) in enumerate(addends):
+            self._f32(f'spmm_sum.add{i}', t)
+            if t.shape[:3] != (B, n, Cc) or off < 0 or off + h > t.shape[-1] or (t.shape[-1] | off) & 3:
+                raise StcError(f'spmm_sum: addend {i} of shape {tuple(t.shape)} / offset {off} does not fit')
+            ptrs[i], lds[i], offs[i] = t.data_ptr(), t.shape[-1], off
+        self._same_device(rowptr, colidx, val, X, X2, Y, *[t for t, _ in addends])
+        g = self._graph_ptrs(rowptr, colidx, val, plan, n)
+        self._launch('stc_spmm_sum_f32', Y, *g, n, n, _ptr(X), _ptr(X2), len(addends), ptrs, lds, offs, _ptr(Y), B, Cc, h,
+                     nbytes=colidx.numel() * 8 + 4 * (n + 1) + 4 * B * n * Cc * h * (2 + (X2 is not None) + len(addends)))
+
     def csr_sddmm(self, rowptr, colidx, n_rows, n_cols, A, Bm, out, alpha, accumulate):
         B, nr, F = A.shape
         self._f32('sddmm.A', A, (B, n_rows, F))
@@ -433,18 +455,23 @@ class HipKernels:
                      _ptr(cp[0][0]), cp[0][1], cp[0][2], _ptr(side), side_cin, _ptr(cp[1][0]), cp[1][1], cp[1][2], B, Cc, h,
                      nbytes=colidx.numel() * 8 + 4 * (n + 1) + 4 * B * n * Cc * h * (6 + len(copies)))
 
-    def node_post_bwd(self, X, Tc, W, dA, dB, dX, dW, db, X2=None):
-        """(X, dA = dY, dBm = S^T dY) -> dX, dW, db of the convolution in its post-aggregation form (dX interleaved rows)."""
+    def node_post_bwd(self, X, Tc, W, dA, dB, dX, dW, db, X2=None, dX2=None):
+        """(X, dA = dY, dBm = S^T dY) -> dX, dW, db of the convolution in its post-aggregation form.  Planar (X2 given):
+        the gradient comes out as the two planes dX, dX2 as well."""
         Ks, Kc, R, Cc, L, Lw, Ho = self._post_rows(X, X2, Tc, W)
+        if (X2 is None) != (dX2 is None):
+            raise StcError('post: planar input (X2) and planar gradient (dX2) go together')
         for name, t in (('dA', dA), ('dB', dB)):
             self._f32('post.' + name, t, (R, Cc, Ho))
-        self._f32('post.dX', dX, (R, Cc, L))
+        self._f32('post.dX', dX, (R, Cc, L) if X2 is None else (R, Cc, 16))
+        if dX2 is not None:
+            self._f32('post.dX2', dX2, (R, Cc, 16))
         self._f32('post.dW', dW, (Ks * Kc * Lw, Ho))
         if db is not None:
             self._f32('post.db', db, (Ho,))
-        self._same_device(X, X2, Tc, W, dA, dB, dX, dW, db)
+        self._same_device(X, X2, Tc, W, dA, dB, dX, dX2, dW, db)
         ws = self._get_workspace(X.device, self.lib.stc_bdg_node_bwd_workspace_bytes(Ks, Kc, Cc, L, Ho, 0))
-        self._launch('stc_bdg_node_post_bwd_f32', X, _ptr(X), _ptr(X2), _ptr(Tc), _ptr(W), _ptr(dA), _ptr(dB), _ptr(dX), _ptr(dW), _ptr(db),
+        self._launch('stc_bdg_node_post_bwd_f32', X, _ptr(X), _ptr(X2), _ptr(Tc), _ptr(W), _ptr(dA), _ptr(dB), _ptr(dX), _ptr(dX2), _ptr(dW), _ptr(db),
                      _ptr(ws), ws.numel(), R, Cc, L, Lw, Ho)
 
     # ---- planar cell inputs (Ks = Kc = 2, cin = h = 16) ---------------------------------------------
@@ -472,23 +499,23 @@ class HipKernels:
         self._launch('stc_cell_gates_fwd_planar_f32', H, _ptr(X), _ptr(H), _ptr(SX), _ptr(SH), _ptr(Tc), _ptr(W), _ptr(bias),
                      _ptr(U), _ptr(Rg), _ptr(RH), R, Cc, 2 * h, h)
 
-    def cell_gates_bwd_planar(self, X, H, SX, SH, Tc, W, dCandIn, Cand, U, Rg, dHnew, dZs, dW, db, dH):
+    def cell_gates_bwd_planar(self, X, H, SX, SH, Tc, W, dRH, Cand, U, Rg, dHnew, dZs, dW, db, dH):
+        """``dRH``: gradient of the R*H plane; ``dZs`` = [d X plane, d SX plane, d H plane, d SH plane]."""
         R, Cc, h = self._planes('planar', X, H, SX, SH)
         self._f32('planar.Tc', Tc, (2, Cc, Cc))
         self._f32('planar.W', W, (8 * h, 2 * h))
-        self._f32('planar.dCandIn', dCandIn, (R, Cc, 2 * h))
-        for name, t in (('Cand', Cand), ('U', U), ('Rg', Rg), ('dHnew', dHnew), ('dH', dH)):
+        for name, t in (('dRH', dRH), ('Cand', Cand), ('U', U), ('Rg', Rg), ('dHnew', dHnew), ('dH', dH)):
             self._f32('planar.' + name, t, (R, Cc, h))
-        if len(dZs) != 2:
-            raise StcError('planar gates backward: two gradient slabs')
+        if len(dZs) != 4:
+            raise StcError('planar gates backward: four gradient planes (dX, dSX, dH, dSH)')
         for i, z in enumerate(dZs):
-            self._f32(f'planar.dZ[{i}]', z, (R, Cc, 2 * h))
+            self._f32(f'planar.dZ[{i}]', z, (R, Cc, h))
         self._f32('planar.dW', dW, (8 * h, 2 * h))
         if db is not None:
             self._f32('planar.db', db, (2 * h,))
-        self._same_device(X, H, SX, SH, Tc, W, dCandIn, Cand, U, Rg, dHnew, *dZs, dW, db, dH)
+        self._same_device(X, H, SX, SH, Tc, W, dRH, Cand, U, Rg, dHnew, *dZs, dW, db, dH)
         ws = self._get_workspace(H.device, self.lib.stc_bdg_node_bwd_workspace_bytes(2, 2, Cc, 2 * h, 2 * h, 0))
-        self._launch('stc_cell_gates_bwd_planar_f32', H, _ptr(X), _ptr(H), _ptr(SX), _ptr(SH), _ptr(Tc), _ptr(W), _ptr(dCandIn), _ptr(Cand),
+        self._launch('stc_cell_gates_bwd_planar_f32', H, _ptr(X), _ptr(H), _ptr(SX), _ptr(SH), _ptr(Tc), _ptr(W), _ptr(dRH), _ptr(Cand),
                      _ptr(U), _ptr(Rg), _ptr(dHnew), self._ptr_array(dZs), _ptr(dW), _ptr(db), _ptr(dH), _ptr(ws), ws.numel(), R, Cc, 2 * h, h)
 
     # ---- fused cell convolutions ----------------------------------------------------------

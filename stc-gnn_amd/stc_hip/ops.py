@@ -624,27 +624,61 @@ class _StcCellGraph(Function):
             k.csr_spmm(*bwd, N, N, dY.view(B, N, C * h), None, dBm.view(B, N, C * h), 1.0, 0.0, plan=op.bwd_plan)
             return dBm
 
+        # Planar consumers leave PIECES of a state's gradient instead of a finished tensor: direct planes (what the state
+        # is owed as a plane of their inputs) and aggregated planes (what its aggregation S.state is owed).  Aggregation
+        # being linear, the state's gradient is  sum(direct) + S^T sum(aggregated): ONE narrow SpMM per state with the
+        # sums in its gather / epilogue -- instead of a wide transpose SpMM and a split pass per consuming cell.
+        pieces = {}
+
+        def leave(kid, direct, aggregated):
+            pc = pieces.setdefault(kid, dict(direct=[], agg=[]))
+            pc['direct'] += [(t, 0) for t in direct]
+            pc['agg'].append(aggregated)
+
+        def owed(kid):
+            base = G.pop(kid, None)                                  # from interleaved consumers / the outputs: a finished tensor
+            pc = pieces.pop(kid, None)
+            if pc is None:
+                return base
+            add = pc['direct'] + ([(base, 0)] if base is not None else [])
+            aggs = pc['agg']
+            while len(add) > 5:                                      # more consumers than the kernel takes addends for: pre-sum
+                (a, ao), (b_, bo) = add.pop(), add.pop()
+                add.append((a[..., ao:ao + h] + b_[..., bo:bo + h], 0))
+            while len(aggs) > 2:
+                aggs = [aggs[0] + aggs[1]] + aggs[2:]
+            out = aggs[0].new_empty(B, N, C, h)
+            k.spmm_sum(*bwd, op.bwd_plan, aggs[0], aggs[1] if len(aggs) > 1 else None, add, out)
+            return out
+
         for j in range(len(schedule) - 1, -1, -1):
-            if j not in G:
+            if j not in G and j not in pieces:
                 continue                                             # nothing downstream depends on this cell
             s_id, x, hs = schedule[j]
             Wg, bg, Wc, bc = stacks[s_id]
-            dHnew = G.pop(j)
+            dHnew = owed(j)
             Hprev, U, Rg, Cand, *rest = cells[j]
             dH = torch.empty_like(Hprev)
-            if n_saved[j] < 0:                                       # planar cell: inputs read as planes, gradient rows interleaved
+            if n_saved[j] < 0:                                       # planar cell: inputs and gradients as planes
                 Xp, SXp, SHp, RH = rest
-                L = 2 * h
                 dY = torch.empty_like(Hprev)
                 k.gru_blend_bwd(dHnew, U, None, Cand, dY, None, None)                      # dY = dHnew * U * (1 - Cand^2)
                 dBm = narrow_transpose_aggregation(dY)
-                dci, dWc = Hprev.new_empty(B, N, C, L), torch.empty_like(Wc)
+                dXc, dRH, dWc = torch.empty_like(Hprev), torch.empty_like(Hprev), torch.empty_like(Wc)
                 dbc = Wc.new_empty(h) if bc is not None else None
-                k.node_post_bwd(*rows((Xp,)), Tc, Wc, *rows((dY, dBm, dci)), dWc, dbc, X2=RH.view(B * N, C, h))
-                g = [torch.empty_like(dci), torch.empty_like(dci)]
+                k.node_post_bwd(*rows((Xp,)), Tc, Wc, *rows((dY, dBm, dXc)), dWc, dbc, X2=RH.view(B * N, C, h), dX2=dRH.view(B * N, C, h))
+                del dY, dBm
+                dXd, dSX, dHd, dSH = (torch.empty_like(Hprev) for _ in range(4))
                 dWg, dbg = torch.empty_like(Wg), (Wg.new_empty(2 * h) if bg is not None else None)
-                k.cell_gates_bwd_planar(*rows((Xp, Hprev, SXp, SHp)), Tc, Wg, *rows((dci, Cand, U, Rg, dHnew)), rows(g), dWg, dbg,
-                                        dH.view(B * N, C, h))
+                k.cell_gates_bwd_planar(*rows((Xp, Hprev, SXp, SHp)), Tc, Wg, *rows((dRH, Cand, U, Rg, dHnew)),
+                                        rows((dXd, dSX, dHd, dSH)), dWg, dbg, dH.view(B * N, C, h))
+                if x[0] == 'cell':
+                    leave(x[1], (dXd, dXc), dSX)                     # as the X plane: gates' and candidate's direct shares
+                if hs[0] == 'cell':
+                    leave(hs[1], (dHd, dH), dSH)                     # as the H plane: direct share + what the gates prologue owes it
+                for i, t in enumerate((dWg, dbg, dWc, dbc)):
+                    add_to(acc[s_id], i, t)
+                continue
             else:
                 Zg, Zc = rest[:Ks], rest[Ks:]
                 L = Zc[0].shape[-1]

@@ -514,13 +514,13 @@ def test_planar_cell_kernels(hip, nodes, C):
     hip.cell_gates_fwd_planar(cu(X), cu(H), cu(SX), cu(SH), cu(Tc), cu(Wg), cu(bg), U, R, RH)
     assert rel_err(U, U_w) < TOL and rel_err(R, R_w) < TOL and rel_err(RH, RH_w) < TOL
 
-    dCand, Cand, dHn = rnd(nodes, C, 2 * h), torch.tanh(rnd(nodes, C, h)), rnd(nodes, C, h)
-    dZ_w = [torch.empty(nodes, C, 2 * h) for _ in range(2)]
+    dRH, Cand, dHn = rnd(nodes, C, h), torch.tanh(rnd(nodes, C, h)), rnd(nodes, C, h)
+    dZ_w = [torch.empty(nodes, C, h) for _ in range(4)]                       # d X plane, d SX plane, d H plane, d SH plane
     dW_w, db_w, dH_w = torch.empty_like(Wg), torch.empty(2 * h), torch.empty(nodes, C, h)
-    EM.cell_gates_bwd_planar(X, H, SX, SH, Tc, Wg, dCand, Cand, U_w, R_w, dHn, dZ_w, dW_w, db_w, dH_w)
-    dZ = [nan(nodes, C, 2 * h) for _ in range(2)]
+    EM.cell_gates_bwd_planar(X, H, SX, SH, Tc, Wg, dRH, Cand, U_w, R_w, dHn, dZ_w, dW_w, db_w, dH_w)
+    dZ = [nan(nodes, C, h) for _ in range(4)]
     dW, db, dH = nan(*Wg.shape), nan(2 * h), nan(nodes, C, h)
-    hip.cell_gates_bwd_planar(cu(X), cu(H), cu(SX), cu(SH), cu(Tc), cu(Wg), cu(dCand), cu(Cand), cu(U_w), cu(R_w), cu(dHn), dZ, dW, db, dH)
+    hip.cell_gates_bwd_planar(cu(X), cu(H), cu(SX), cu(SH), cu(Tc), cu(Wg), cu(dRH), cu(Cand), cu(U_w), cu(R_w), cu(dHn), dZ, dW, db, dH)
     for a, w in zip(dZ, dZ_w):
         assert rel_err(a, w) < TOL
     assert rel_err(dW, dW_w) < TOL and rel_err(db, db_w) < TOL and rel_err(dH, dH_w) < TOL
@@ -532,11 +532,33 @@ def test_planar_cell_kernels(hip, nodes, C):
     hip.node_post_fwd(cu(X), cu(Tc), cu(Wc), cu(bc), A, Bm, X2=cu(RH_w))
     assert rel_err(A, A_w) < TOL and rel_err(Bm, B_w) < TOL
     dA, dB = rnd(nodes, C, h), rnd(nodes, C, h)
-    dX_w, dWc_w, dbc_w = torch.empty(nodes, C, 2 * h), torch.empty_like(Wc), torch.empty(h)
-    EM.node_post_bwd(X, Tc, Wc, dA, dB, dX_w, dWc_w, dbc_w, X2=RH_w)
-    dX, dWc, dbc = nan(nodes, C, 2 * h), nan(*Wc.shape), nan(h)
-    hip.node_post_bwd(cu(X), cu(Tc), cu(Wc), cu(dA), cu(dB), dX, dWc, dbc, X2=cu(RH_w))
-    assert rel_err(dX, dX_w) < TOL and rel_err(dWc, dWc_w) < TOL and rel_err(dbc, dbc_w) < TOL
+    dX_w, dX2_w, dWc_w, dbc_w = torch.empty(nodes, C, h), torch.empty(nodes, C, h), torch.empty_like(Wc), torch.empty(h)
+    EM.node_post_bwd(X, Tc, Wc, dA, dB, dX_w, dWc_w, dbc_w, X2=RH_w, dX2=dX2_w)
+    dX, dX2, dWc, dbc = nan(nodes, C, h), nan(nodes, C, h), nan(*Wc.shape), nan(h)
+    hip.node_post_bwd(cu(X), cu(Tc), cu(Wc), cu(dA), cu(dB), dX, dWc, dbc, X2=cu(RH_w), dX2=dX2)
+    assert rel_err(dX, dX_w) < TOL and rel_err(dX2, dX2_w) < TOL and rel_err(dWc, dWc_w) < TOL and rel_err(dbc, dbc_w) < TOL
+
+
+@pytest.mark.parametrize('batch,grid,C,n_add,dual', [(2, (5, 5), 32, 3, True), (1, (4, 7), 64, 5, False), (2, (40, 56), 32, 0, True), (1, (1, 1), 32, 2, False)])
+def test_state_gradient_from_pieces(hip, batch, grid, C, n_add, dual):
+    """stc_spmm_sum_f32: Y = sum of addends (contiguous planes and column slices of wider rows) + S.(X [+ X2])."""
+    h = 16
+    graph = CsrGraph.queen_grid(*grid, normalize=True)
+    n = graph.n
+    g = torch.Generator().manual_seed(n + C + n_add)
+    rnd = lambda *s_: torch.randn(*s_, generator=g)
+    X, X2 = rnd(batch, n, C, h), (rnd(batch, n, C, h) if dual else None)
+    adds = [(rnd(batch, n, C, 32), 16) if i % 2 else (rnd(batch, n, C, h), 0) for i in range(n_add)]
+    hst = graph._host
+    csr = tuple(torch.from_numpy(hst[k]) for k in ('bwd_rowptr', 'bwd_colidx', 'bwd_val'))
+    dev = graph.on(torch.device('cuda'))
+    plan = (dev['bwd_blk_ptr'], dev['bwd_blk_cols'], dev['bwd_blk_vals'])
+    Y_w = torch.empty(batch, n, C, h)
+    EM.spmm_sum(*csr, None, X, X2, adds, Y_w)
+    for pl in (plan, None):                                          # row-blocked and plain CSR kernels
+        Y = torch.full((batch, n, C, h), float('nan')).cuda()
+        hip.spmm_sum(*(cu(t) for t in csr), pl, cu(X), None if X2 is None else cu(X2), [(cu(t), o) for t, o in adds], Y)
+        assert rel_err(Y, Y_w) < TOL
 
 
 def test_fused_aggregation_is_refused_off_its_shapes(hip):
