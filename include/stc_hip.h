@@ -237,7 +237,11 @@ int stc_cell_blend_fwd_f32(const float* const* Z, int32_t Ks, const float* Tc, i
  * stc_bdg_node_post_fwd_f32's X2.  Backward: as the Cand form of stc_cell_gates_bwd_f32 with dCandIn (nodes, C, h) the
  * gradient of the R*H plane (dX2 of stc_bdg_node_post_bwd_f32); the gradient slabs come out planar too:
  * dZ = {d X plane, d SX plane, d H plane, d SH plane}, (nodes, C, h) each, plus dH = the state's share from the gates.
- * The gradient of a state then is  sum of its consumers' direct planes + S^T (sum of their S planes): stc_spmm_sum_f32. */
+ * The gradient of a state then is  sum of its consumers' direct planes + S^T (sum of their S planes): stc_spmm_sum_f32.
+ * Narrow input (layer 0): Lw = cin + h with cin in 1..4 -- X / SX are (nodes, C, cin); the kernels read the slab as
+ * [H | Xt | pad] (W's rows permuted inside) and the backward produces only dZ[2], dZ[3] (the input needs no gradient;
+ * dZ[0], dZ[1] may be NULL).  stc_bdg_node_post_fwd/bwd_f32 take the same narrow form: X = the 16-wide plane, X2 = the
+ * (nodes, C, cin) plane, L = 20, gradient for X only. */
 int stc_cell_planar_supported(int32_t Ks, int32_t Kc, int32_t C, int32_t h);
 int stc_cell_gates_fwd_planar_f32(const float* X, const float* H, const float* SX, const float* SH,
                                   const float* Tc, const float* W, const float* bias,

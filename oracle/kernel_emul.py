@@ -150,18 +150,20 @@ class EmulatedKernels:
         return Ks == 2 and Kc == 2 and h == 16
 
     def cell_gates_fwd_planar(self, X, H, SX, SH, Tc, W, bias, U, Rg, RH):
-        CandIn = torch.empty(H.shape[:-1] + (2 * H.shape[-1],), dtype=W.dtype)
+        cin, h = X.shape[-1], H.shape[-1]                        # cin = h, or 1..4 (narrow input plane, layer 0)
+        CandIn = torch.empty(H.shape[:-1] + (cin + h,), dtype=W.dtype)
         self.cell_gates_fwd([torch.cat([X, H], -1), torch.cat([SX, SH], -1)], Tc, W, bias, H, U, Rg, CandIn)
-        RH.copy_(CandIn[..., H.shape[-1]:])
+        RH.copy_(CandIn[..., cin:])
 
     def cell_gates_bwd_planar(self, X, H, SX, SH, Tc, W, dRH, Cand, U, Rg, dHnew, dZs, dW, db, dH):
-        h = H.shape[-1]
-        rows = [torch.empty(H.shape[:-1] + (2 * h,), dtype=W.dtype) for _ in range(2)]
-        dCandIn = torch.cat([torch.zeros_like(dRH), dRH], -1)             # only the R*H half is read
+        cin, h = X.shape[-1], H.shape[-1]
+        rows = [torch.empty(H.shape[:-1] + (cin + h,), dtype=W.dtype) for _ in range(2)]
+        dCandIn = torch.cat([torch.zeros_like(X), dRH], -1)               # only the R*H part is read
         self.cell_gates_bwd([torch.cat([X, H], -1), torch.cat([SX, SH], -1)], Tc, W, dCandIn, None, H, U, Rg, dHnew, rows, dW, db, None, dH,
                             dH_in_scaled=True, Cand=Cand)
-        dZs[0].copy_(rows[0][..., :h]); dZs[2].copy_(rows[0][..., h:])      # d X plane, d H plane
-        dZs[1].copy_(rows[1][..., :h]); dZs[3].copy_(rows[1][..., h:])      # d SX plane, d SH plane
+        dZs[2].copy_(rows[0][..., cin:]); dZs[3].copy_(rows[1][..., cin:])  # d H plane, d SH plane
+        if dZs[0] is not None:
+            dZs[0].copy_(rows[0][..., :cin]); dZs[1].copy_(rows[1][..., :cin])  # d X plane, d SX plane
 
     def spmm_sum(self, rowptr, colidx, val, plan, X, X2, addends, Y):
         B, n, Cc, h = Y.shape
@@ -171,8 +173,8 @@ class EmulatedKernels:
             Y += t[..., off:off + h]
 
     def node_post_fwd(self, X, Tc, W, bias, A, Bm, X2=None):
-        if X2 is not None:
-            X = torch.cat([X, X2], -1)
+        if X2 is not None:                                     # planar: 16 + 16 -> [X | X2]; narrow -> reference order [X2 (input) | X (16-wide)]
+            X = torch.cat([X, X2], -1) if X2.shape[-1] == X.shape[-1] else torch.cat([X2, X], -1)
         Lw = W.shape[0] // 4
         for n, out in enumerate((A, Bm)):
             acc = torch.zeros_like(out)
@@ -196,9 +198,14 @@ class EmulatedKernels:
 
     def node_post_bwd(self, X, Tc, W, dA, dB, dX, dW, db, X2=None, dX2=None):
         if X2 is not None:                                     # planar: compute on the concatenated rows, hand back the planes
-            full = torch.empty(X.shape[:-1] + (2 * X.shape[-1],), dtype=W.dtype)
-            self.node_post_bwd(torch.cat([X, X2], -1), Tc, W, dA, dB, full, dW, db)
-            dX.copy_(full[..., :X.shape[-1]]); dX2.copy_(full[..., X.shape[-1]:])
+            w, w2 = X.shape[-1], X2.shape[-1]
+            full = torch.empty(X.shape[:-1] + (w + w2,), dtype=W.dtype)
+            if w2 == w:
+                self.node_post_bwd(torch.cat([X, X2], -1), Tc, W, dA, dB, full, dW, db)
+                dX.copy_(full[..., :w]); dX2.copy_(full[..., w:])
+            else:                                                  # narrow: reference order [X2 | X]; gradient for the 16-wide plane only
+                self.node_post_bwd(torch.cat([X2, X], -1), Tc, W, dA, dB, full, dW, db)
+                dX.copy_(full[..., w2:])
             return
         Lw = W.shape[0] // 4
         dW.zero_()

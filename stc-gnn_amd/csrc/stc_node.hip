@@ -492,7 +492,8 @@ extern "C" int stc_cell_gates_fwd_planar_f32(const float* X, const float* H, con
                                              const float* Tc, const float* W, const float* bias,
                                              float* U, float* Rg, float* RH,
                                              int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream) {
-    if (int rc = check_dims("stc_cell_gates_fwd_planar_f32", 2, 2, C, 2 * h, Lw, 2 * h, nodes)) return rc;
+    if (int rc = check_dims("stc_cell_gates_fwd_planar_f32", 2, 2, C, Lw == 2 * h ? 2 * h : 20, Lw, 2 * h, nodes)) return rc;
+    STC_REQUIRE(Lw == 2 * h || (Lw > h && Lw <= h + 4), STC_EINVAL, "stc_cell_gates_fwd_planar_f32: input width %d (Lw - h) must be h or 1..4", Lw - h);
     if (!stc_cell_planar_supported(2, 2, C, h)) return stc::fail(STC_EUNSUPPORTED, "stc_cell_gates_fwd_planar_f32: shape not on the planar path");
     if (nodes == 0) return STC_OK;
     STC_REQUIRE(X && H && SX && SH && Tc && W && U && Rg && RH, STC_EINVAL, "stc_cell_gates_fwd_planar_f32: null pointer");
@@ -506,8 +507,9 @@ extern "C" int stc_cell_gates_bwd_planar_f32(const float* X, const float* H, con
                                              float* const* dZ, float* dW, float* db, float* dH,
                                              void* workspace, size_t workspace_bytes,
                                              int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream) {
-    const int L = 2 * h, Ho = 2 * h;
+    const int L = Lw == 2 * h ? 2 * h : 20, Ho = 2 * h;
     if (int rc = check_dims("stc_cell_gates_bwd_planar_f32", 2, 2, C, L, Lw, Ho, nodes)) return rc;
+    STC_REQUIRE(Lw == 2 * h || (Lw > h && Lw <= h + 4), STC_EINVAL, "stc_cell_gates_bwd_planar_f32: input width %d (Lw - h) must be h or 1..4", Lw - h);
     if (!stc_cell_planar_supported(2, 2, C, h)) return stc::fail(STC_EUNSUPPORTED, "stc_cell_gates_bwd_planar_f32: shape not on the planar path");
     STC_REQUIRE(W && dZ && dW && Tc, STC_EINVAL, "stc_cell_gates_bwd_planar_f32: null W/dZ/dW/Tc");
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -517,7 +519,7 @@ extern "C" int stc_cell_gates_bwd_planar_f32(const float* X, const float* H, con
         if (db) if (int rc = stc::hip_status(hipMemsetAsync(db, 0, (size_t)Ho * sizeof(float), s), "memset db")) return rc;
         return STC_OK;
     }
-    STC_REQUIRE(X && H && SX && SH && dCandIn && Cand && U && Rg && dHnew && dH && dZ[0] && dZ[1] && dZ[2] && dZ[3], STC_EINVAL,
+    STC_REQUIRE(X && H && SX && SH && dCandIn && Cand && U && Rg && dHnew && dH && dZ[2] && dZ[3] && (Lw != 2 * h || (dZ[0] && dZ[1])), STC_EINVAL,
                 "stc_cell_gates_bwd_planar_f32: null pointer");
     STC_REQUIRE(workspace && stc::aligned16(workspace), STC_EALIGN, "stc_cell_gates_bwd_planar_f32: workspace null or not 16-byte aligned");
     STC_REQUIRE(workspace_bytes >= stc_bdg_node_bwd_workspace_bytes(2, 2, C, L, Ho, 0), STC_EINVAL,
@@ -547,7 +549,7 @@ extern "C" int stc_bdg_node_post_fwd_f32(const float* X, const float* X2, const 
     if (nodes == 0) return STC_OK;
     STC_REQUIRE(X && Tc && W && A && Bm, STC_EINVAL, "stc_bdg_node_post_fwd_f32: null pointer");
     STC_REQUIRE(A != Bm && X != A && X != Bm, STC_EINVAL, "stc_bdg_node_post_fwd_f32: outputs must not alias");
-    STC_REQUIRE(!X2 || L == 32, STC_EINVAL, "stc_bdg_node_post_fwd_f32: planar input (X2) needs rows of 16 + 16 columns, L = %d", L);
+    STC_REQUIRE(!X2 || L == 32 || (L == 20 && Lw > 16), STC_EINVAL, "stc_bdg_node_post_fwd_f32: planar input (X2) needs rows of 16 + 16 or 16 + cin (<= 4) columns, L = %d", L);
     const int rc = stc_node_post_fwd_x3(X, X2, Tc, W, bias, A, Bm, nodes, C, L, Lw, Ho, static_cast<hipStream_t>(stream));
     return rc == STC_NOT_HANDLED ? stc::fail(STC_EUNSUPPORTED, "stc_bdg_node_post_fwd_f32: operands not usable (alignment)") : rc;
 }
@@ -571,8 +573,9 @@ extern "C" int stc_bdg_node_post_bwd_f32(const float* X, const float* X2, const 
                 "stc_bdg_node_post_bwd_f32: workspace of %zu B is too small", workspace_bytes);
     int n_parts = 0;
     float* partial = static_cast<float*>(workspace);
-    STC_REQUIRE(!X2 || L == 32, STC_EINVAL, "stc_bdg_node_post_bwd_f32: planar input (X2) needs rows of 16 + 16 columns, L = %d", L);
-    STC_REQUIRE((X2 == nullptr) == (dX2 == nullptr), STC_EINVAL, "stc_bdg_node_post_bwd_f32: planar input (X2) and planar gradient (dX2) go together");
+    STC_REQUIRE(!X2 || L == 32 || (L == 20 && Lw > 16), STC_EINVAL, "stc_bdg_node_post_bwd_f32: planar input (X2) needs rows of 16 + 16 or 16 + cin (<= 4) columns, L = %d", L);
+    STC_REQUIRE(L == 20 ? dX2 == nullptr : (X2 == nullptr) == (dX2 == nullptr), STC_EINVAL,
+                "stc_bdg_node_post_bwd_f32: planar input (X2) and planar gradient (dX2) go together (the narrow input plane of L = 20 gets no gradient)");
     const int rc = stc_node_post_bwd_x3(X, X2, Tc, W, dA, dB, dX, dX2, partial, &n_parts, db != nullptr, nodes, C, L, Lw, Ho, s);
     if (rc == STC_NOT_HANDLED) return stc::fail(STC_EUNSUPPORTED, "stc_bdg_node_post_bwd_f32: operands not usable (alignment)");
     if (rc != STC_OK) return rc;

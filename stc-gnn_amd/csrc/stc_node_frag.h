@@ -190,12 +190,19 @@ __device__ __forceinline__ void load_blend_grad(DyFrag<NRB, 1>& g, const BwdPro&
     }
 }
 
+// Planar layout with a narrow input plane (layer 0: cin <= 4 input columns): the slab is read as [state plane (16) | input
+// plane (cin) | pad], i.e. with the reference's [Xt | H] column order swapped.  W keeps its reference row order; this maps a
+// slab column to the W row it multiplies (-1: padding).
+__host__ __device__ __forceinline__ int stc_wrow_swapped(int col, int cin) {
+    return col < 16 ? cin + col : (col < 16 + cin ? col - 16 : -1);
+}
+
 // End of a backward kernel: the workgroup's four waves hold dW tiles (rows l = 16lb + 4g + r, columns o = 16hb + x) and
 // db partial sums in registers; combine them through LDS in a fixed order (bitwise reproducible) into ONE partial row
 // [dW in W layout | db] per workgroup, which bdg_node_reduce_kernel then sums over workgroups.
 template <int K, int LB, int HB>
 __device__ __forceinline__ void combine_dw(float* smem, const f32x4 (&dWt)[K][LB][K][HB], const float (&dbp)[HB],
-                                           float* __restrict__ partial, int Lw, int want_db) {
+                                           float* __restrict__ partial, int Lw, int want_db, int swapped_cin = -1) {
     constexpr int Ho = 16 * HB;
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -212,8 +219,9 @@ __device__ __forceinline__ void combine_dw(float* smem, const f32x4 (&dWt)[K][LB
                 for (int hb = 0; hb < HB; ++hb)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int l = 16 * lb + 4 * q + r;
-                        if (l < Lw) slab[((n * K + c) * Lw + l) * Ho + 16 * hb + j] = dWt[n][lb][c][hb][r];
+                        const int col = 16 * lb + 4 * q + r;
+                        const int l = swapped_cin < 0 ? col : stc_wrow_swapped(col, swapped_cin);      // slab column -> W row
+                        if (l >= 0 && l < Lw) slab[((n * K + c) * Lw + l) * Ho + 16 * hb + j] = dWt[n][lb][c][hb][r];
                     }
 #pragma unroll
     for (int hb = 0; hb < HB; ++hb) {

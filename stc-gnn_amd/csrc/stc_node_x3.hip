@@ -117,6 +117,18 @@ struct Row8 {
         a = *reinterpret_cast<const f32x4*>(src);
         b = *reinterpret_cast<const f32x4*>(src + 4);
     }
+    // planar layout with a narrow input plane: columns 0..15 from the (rows, 16) state plane, 16..16+cin-1 from the
+    // (rows, cin) input plane, cin <= 4; everything else zero
+    __device__ __forceinline__ void load_planes_narrow(const float* __restrict__ prow, const float* __restrict__ xrow, int cin, int g) {
+        a = kZero4; b = kZero4;
+        if (g < 2) {
+            a = *reinterpret_cast<const f32x4*>(prow + 8 * g);
+            b = *reinterpret_cast<const f32x4*>(prow + 8 * g + 4);
+        } else if (g == 2) {
+            const float x0 = xrow[0], x1 = cin > 1 ? xrow[1] : 0.f, x2 = cin > 2 ? xrow[2] : 0.f, x3 = cin > 3 ? xrow[3] : 0.f;
+            a = f32x4{x0, x1, x2, x3};
+        }
+    }
     __device__ __forceinline__ float at(int e) const { return e < 4 ? a[e & 3] : b[e & 3]; }
     __device__ __forceinline__ void fma(float v, const Row8& o) {
 #pragma unroll
@@ -141,7 +153,9 @@ struct GatherArgs {
 
 // --------------------------------------------------------------------------------------- forward
 // PL = 1: planar inputs (Z.p[n] = columns 0..15, Z.q[n] = columns 16..31 of slab n, each (nodes, C, 16)); with EPI_GATES the
-// candidate's input then is planar too: its X plane is Xt itself and only the R*H plane (epi.CandIn, 16 wide) is written
+// candidate's input then is planar too: its X plane is Xt itself and only the R*H plane (epi.CandIn, 16 wide) is written.
+// PL = 2 (L = 20): planar with a narrow input plane -- Z.p[n] = the STATE plane (nodes, C, 16), Z.q[n] = the input plane
+// (nodes, C, cin), cin = Lw - 16 <= 4; slab columns are [state | input | pad] and W's rows are permuted to match
 template <int NB2, int HB, int K, int L, int EPI, int GATHER, int PL = 0>
 __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_kernel(
     ZPtrs Z, const float* __restrict__ Tc, const float* __restrict__ W, const float* __restrict__ bias,
@@ -164,7 +178,8 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int l = 8 * gg + e;
-            v[e] = l < Lw ? W[((size_t)(n * K + c) * Lw + l) * Ho + o] : 0.f;       // pad columns contribute nothing
+            const int wl = PL == 2 ? stc_wrow_swapped(l, Lw - 16) : l;                // PL = 2: slab columns are [state | input | pad]
+            v[e] = (wl >= 0 && wl < Lw) ? W[((size_t)(n * K + c) * Lw + wl) * Ho + o] : 0.f;       // pad columns contribute nothing
         }
         put_frag(Wx, f, ll, v);
     }
@@ -191,7 +206,9 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
         for (int n = 0; n < KL; ++n)
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) {
-                if constexpr (PL) z[n][rb].load_planes(Z.p[n] + ((size_t)nd * C + 16 * rb + x) * 16, Z.q[n] + ((size_t)nd * C + 16 * rb + x) * 16, g);
+                if constexpr (PL == 1) z[n][rb].load_planes(Z.p[n] + ((size_t)nd * C + 16 * rb + x) * 16, Z.q[n] + ((size_t)nd * C + 16 * rb + x) * 16, g);
+                else if constexpr (PL == 2) z[n][rb].load_planes_narrow(Z.p[n] + ((size_t)nd * C + 16 * rb + x) * 16,
+                                                                        Z.q[n] + ((size_t)nd * C + 16 * rb + x) * (Lw - 16), Lw - 16, g);
                 else z[n][rb].load(Z.p[n] + ((size_t)nd * C + 16 * rb + x) * L, g);
             }
     };
@@ -356,16 +373,29 @@ struct NodeIn {      // what one node contributes from HBM: its dY fragments and
     static constexpr int NRB = 2 * NB2, LB = (L + 15) / 16;
     DyFrag<NRB, HB> g;
     float za[K][LB][NRB][4];     // Z_n[16kb + 4g + t][16lb + x]
-    __device__ __forceinline__ void load_z(const ZPtrs& Z, int node, int x, int gq) {
+    __device__ __forceinline__ void load_z(const ZPtrs& Z, int node, int x, int gq, int cinx = 0) {
         constexpr int C = 32 * NB2;
         const size_t r0 = (size_t)node * C;
+        if constexpr (PL == 2) {        // [state plane (16) | input plane (cinx) | pad]: block 0 from p, column x < cinx of block 1 from q
+#pragma unroll
+            for (int n = 0; n < K; ++n)
+#pragma unroll
+                for (int kb = 0; kb < NRB; ++kb)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const size_t row = r0 + 16 * kb + 4 * gq + t;
+                        za[n][0][kb][t] = Z.p[n][row * 16 + x];
+                        za[n][1][kb][t] = x < cinx ? Z.q[n][row * cinx + x] : 0.f;
+                    }
+            return;
+        }
 #pragma unroll
         for (int n = 0; n < K; ++n)
 #pragma unroll
             for (int lb = 0; lb < LB; ++lb) {
                 const bool ok = 16 * lb + x < L;
-                constexpr int LD = PL ? 16 : L;                  // planar: block lb of the row is plane lb, 16 floats per row
-                const float* col = PL ? (lb == 0 ? Z.p[n] : Z.q[n]) + r0 * 16 + x : Z.p[n] + r0 * L + 16 * lb + (ok ? x : 0);
+                constexpr int LD = PL == 1 ? 16 : L;             // planar: block lb of the row is plane lb, 16 floats per row
+                const float* col = PL == 1 ? (lb == 0 ? Z.p[n] : Z.q[n]) + r0 * 16 + x : Z.p[n] + r0 * L + 16 * lb + (ok ? x : 0);
 #pragma unroll
                 for (int kb = 0; kb < NRB; ++kb)
 #pragma unroll
@@ -410,7 +440,8 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int b = 2 * s + (e >> 2), c = b / HB, hb = b % HB;
-            v[e] = (b < NBK && l < Lw) ? W[((size_t)(n * K + c) * Lw + l) * Ho + 16 * hb + 4 * gg + (e & 3)] : 0.f;
+            const int wl = PL == 2 ? stc_wrow_swapped(l, Lw - 16) : l;
+            v[e] = (b < NBK && wl >= 0 && wl < Lw) ? W[((size_t)(n * K + c) * Lw + wl) * Ho + 16 * hb + 4 * gg + (e & 3)] : 0.f;
         }
         put_frag(WA, f, ll, v);
     }
@@ -433,7 +464,8 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
     for (int hb = 0; hb < HB; ++hb) dbp[hb] = 0.f;
 
     int node = blockIdx.x * MF_WAVES + wave;
-    static_assert(!PL || L == 32, "planar rows are 16 + 16 columns");
+    static_assert(PL != 1 || L == 32, "planar rows are 16 + 16 columns");
+    static_assert(PL != 2 || L == 20, "narrow planar rows are 16 + cin columns padded to 20");
     NodeIn<NB2, HB, K, L, PL> in, nx;
     if (PF && node < nodes) { in.g.load(dY, node, x, g); in.load_z(Z, node, x, g); }
     while (node < nodes) {
@@ -442,7 +474,7 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
         if constexpr (PRO == PRO_GATES || PRO == PRO_GATES_CAND) {
             // planar: dCandIn is the R*H plane's gradient alone, (nodes, C, 16) with the state columns at offset 0
             load_gates_grad<NRB, HB, (PL ? 16 : L), PRO == PRO_GATES_CAND>(in.g, pro, node, x, g);
-            in.load_z(Z, node, x, g);
+            in.load_z(Z, node, x, g, Lw - 16);
         }
         else if constexpr (PRO == PRO_BLEND) { load_blend_grad<NRB>(in.g, pro, node, x, g); in.load_z(Z, node, x, g); }
         else if (!PF) { in.g.load(dY, node, x, g); in.load_z(Z, node, x, g); }
@@ -509,10 +541,16 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
 #pragma unroll
                     for (int rb = 0; rb < NRB; ++rb) z[rb] = mma6(w, qb[s][rb], z[rb]);
                 }
-                if constexpr (PL) {                             // planar gradient slabs: block lb of the row goes to plane lb
+                if constexpr (PL == 1) {                        // planar gradient slabs: block lb of the row goes to plane lb
 #pragma unroll
                     for (int rb = 0; rb < NRB; ++rb)
                         *reinterpret_cast<f32x4*>((lb == 0 ? dZ.p[n] : dZ.q[n]) + (r0 + 16 * rb + x) * 16 + 4 * g) = z[rb];
+                } else if constexpr (PL == 2) {                 // narrow input plane: only the state plane's gradient is wanted
+                    if (lb == 0) {
+#pragma unroll
+                        for (int rb = 0; rb < NRB; ++rb)
+                            *reinterpret_cast<f32x4*>(dZ.p[n] + (r0 + 16 * rb + x) * 16 + 4 * g) = z[rb];
+                    }
                 } else if (16 * lb + 4 * g < L) {
 #pragma unroll
                     for (int rb = 0; rb < NRB; ++rb)
@@ -561,7 +599,7 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
         if (PF) in = nx;
         node = next_node;
     }
-    combine_dw<K, LB, HB>(reinterpret_cast<float*>(smem_raw), dWt, dbp, partial, Lw, want_db);
+    combine_dw<K, LB, HB>(reinterpret_cast<float*>(smem_raw), dWt, dbp, partial, Lw, want_db, PL == 2 ? Lw - 16 : -1);
 }
 
 // --------------------------------------------------------------------------------------- post-aggregation form (K = 2)
@@ -575,7 +613,8 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
 //   dX^T (rows l, cols c') = sum_n sum_{c,o} W[(n,c,l)][o] Q^n_c[c'][o]        dW_{n,c} (rows l, cols o) += X^T Q^n_c
 // forward of the post-aggregation form: one input slab X, the two weight sets of the Chebyshev orders kept apart
 //     A = sum_c T_c^T (X W_{0,c}) + b      Bm = sum_c T_c^T (X W_{1,c})           (nodes, C, Ho) each
-template <int NB2, int HB, int L, int PL = 0>       // PL: X is two planes, X (columns 0..15) and X2 (columns 16..31)
+template <int NB2, int HB, int L, int PL = 0>       // PL = 1: X is two planes, X (columns 0..15) and X2 (columns 16..31); PL = 2 (L = 20): X =
+                                                   // the 16-wide plane, X2 = the narrow input plane (cin = Lw - 16), columns [X | X2 | pad]
 __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd2_x3_kernel(
     const float* __restrict__ X, const float* __restrict__ X2, const float* __restrict__ Tc, const float* __restrict__ W, const float* __restrict__ bias,
     float* __restrict__ A, float* __restrict__ Bm, int nodes, int Lw) {
@@ -593,7 +632,8 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd2_x3_k
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int l = 8 * gg + e;
-            v[e] = l < Lw ? W[((size_t)(n * K + c) * Lw + l) * Ho + o] : 0.f;
+            const int wl = PL == 2 ? stc_wrow_swapped(l, Lw - 16) : l;
+            v[e] = (wl >= 0 && wl < Lw) ? W[((size_t)(n * K + c) * Lw + wl) * Ho + o] : 0.f;
         }
         put_frag(Wx, f, ll, v);
     }
@@ -617,7 +657,8 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd2_x3_k
     auto load_rows = [&](Row8<L> (&z)[NRB], int nd) {
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) {
-            if constexpr (PL) z[rb].load_planes(X + ((size_t)nd * C + 16 * rb + x) * 16, X2 + ((size_t)nd * C + 16 * rb + x) * 16, g);
+            if constexpr (PL == 1) z[rb].load_planes(X + ((size_t)nd * C + 16 * rb + x) * 16, X2 + ((size_t)nd * C + 16 * rb + x) * 16, g);
+            else if constexpr (PL == 2) z[rb].load_planes_narrow(X + ((size_t)nd * C + 16 * rb + x) * 16, X2 + ((size_t)nd * C + 16 * rb + x) * (Lw - 16), Lw - 16, g);
             else z[rb].load(X + ((size_t)nd * C + 16 * rb + x) * L, g);
         }
     };
@@ -703,7 +744,8 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int b = 2 * s + (e >> 2), c = b / HB, hb = b % HB;
-            v[e] = (b < NBK && l < Lw) ? W[((size_t)(n * K + c) * Lw + l) * Ho + 16 * hb + 4 * gg + (e & 3)] : 0.f;
+            const int wl = PL == 2 ? stc_wrow_swapped(l, Lw - 16) : l;
+            v[e] = (b < NBK && wl >= 0 && wl < Lw) ? W[((size_t)(n * K + c) * Lw + wl) * Ho + 16 * hb + 4 * gg + (e & 3)] : 0.f;
         }
         put_frag(WA, f, ll, v);
     }
@@ -733,14 +775,20 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
 #pragma unroll
         for (int lb = 0; lb < LB; ++lb) {
             const bool ok = 16 * lb + x < L;
-            constexpr int LD = PL ? 16 : L;
-            const float* col = PL ? (lb == 0 ? X : X2) + r0 * 16 + x : X + r0 * L + 16 * lb + (ok ? x : 0);
+            constexpr int LD = PL == 1 ? 16 : L;
+            const int cinx = Lw - 16;
+            const float* col = PL == 1 ? (lb == 0 ? X : X2) + r0 * 16 + x : X + r0 * L + 16 * lb + (ok ? x : 0);
 #pragma unroll
             for (int kb = 0; kb < NRB; ++kb)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    const float zv = col[(size_t)(16 * kb + 4 * g + t) * LD];
-                    za[lb][kb][t] = ok ? zv : 0.f;
+                    if constexpr (PL == 2) {
+                        const size_t row = r0 + 16 * kb + 4 * g + t;
+                        za[lb][kb][t] = lb == 0 ? X[row * 16 + x] : (x < cinx ? X2[row * cinx + x] : 0.f);
+                    } else {
+                        const float zv = col[(size_t)(16 * kb + 4 * g + t) * LD];
+                        za[lb][kb][t] = ok ? zv : 0.f;
+                    }
                 }
         }
         const int lo = opaque(lane);
@@ -803,10 +851,16 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
 #pragma unroll
                     for (int rb = 0; rb < NRB; ++rb) z[rb] = mma6(w, qb[n][s][rb], z[rb]);
                 }
-            if constexpr (PL) {                                 // planar gradient: columns 0..15 -> dX, 16..31 -> dX2
+            if constexpr (PL == 1) {                            // planar gradient: columns 0..15 -> dX, 16..31 -> dX2
 #pragma unroll
                 for (int rb = 0; rb < NRB; ++rb)
                     *reinterpret_cast<f32x4*>((lb == 0 ? dX : dX2) + (r0 + 16 * rb + x) * 16 + 4 * g) = z[rb];
+            } else if constexpr (PL == 2) {                     // narrow input plane: only the 16-wide plane's gradient is wanted
+                if (lb == 0) {
+#pragma unroll
+                    for (int rb = 0; rb < NRB; ++rb)
+                        *reinterpret_cast<f32x4*>(dX + (r0 + 16 * rb + x) * 16 + 4 * g) = z[rb];
+                }
             } else if (16 * lb + 4 * g < L) {
 #pragma unroll
                 for (int rb = 0; rb < NRB; ++rb)
@@ -851,7 +905,7 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
                             dWt[n][lb][c][hb] = mma6(a, c == 0 ? gd[n][hb][p] : qd[n][hb][p], dWt[n][lb][c][hb]);
             }
     }
-    combine_dw<K, LB, HB>(reinterpret_cast<float*>(smem_raw), dWt, dbp, partial, Lw, want_db);
+    combine_dw<K, LB, HB>(reinterpret_cast<float*>(smem_raw), dWt, dbp, partial, Lw, want_db, PL == 2 ? Lw - 16 : -1);
 }
 
 // --------------------------------------------------------------------------------------- host side
@@ -1106,7 +1160,13 @@ int stc_node_post_shape_ok(int K, int C, int L, int Ho) {
 int stc_node_post_bwd_x3(const float* X, const float* X2, const float* Tc, const float* W, const float* dA, const float* dB, float* dX, float* dX2,
                          float* partial, int* n_partials, int want_db, long long nodes, int C, int L, int Lw, int Ho, hipStream_t stream) {
     if (!stc_node_post_shape_ok(2, C, L, Ho) || nodes <= 0 || nodes >= (1ll << 31) / C) return STC_NOT_HANDLED;
-    if (!(stc::aligned16(X) && stc::aligned16(dA) && stc::aligned16(dB) && stc::aligned16(dX) && (!X2 || stc::aligned16(X2)))) return STC_NOT_HANDLED;
+    if (!(stc::aligned16(X) && stc::aligned16(dA) && stc::aligned16(dB) && stc::aligned16(dX) && (!X2 || L == 20 || stc::aligned16(X2)))) return STC_NOT_HANDLED;
+    if (X2 && L == 20) {                        // narrow planar rows: gradient of the 16-wide plane only (dX); the input plane gets none
+        if (Lw - 16 < 1 || Lw - 16 > 4) return STC_NOT_HANDLED;
+        if (C == 32) return launch_bwd2<1, 1, 20, 2>(X, X2, Tc, W, dA, dB, dX, nullptr, partial, n_partials, want_db, nodes, Lw, stream);
+        if (C == 64) return launch_bwd2<2, 1, 20, 2>(X, X2, Tc, W, dA, dB, dX, nullptr, partial, n_partials, want_db, nodes, Lw, stream);
+        return STC_NOT_HANDLED;
+    }
     if (X2) {                                   // planar rows (16 + 16 columns): input planes X, X2 and gradient planes dX, dX2
         if (L != 32 || !dX2 || !stc::aligned16(dX2)) return STC_NOT_HANDLED;
         if (C == 32) return launch_bwd2<1, 1, 32, 1>(X, X2, Tc, W, dA, dB, dX, dX2, partial, n_partials, want_db, nodes, Lw, stream);
@@ -1125,7 +1185,13 @@ int stc_node_post_bwd_x3(const float* X, const float* X2, const float* Tc, const
 int stc_node_post_fwd_x3(const float* X, const float* X2, const float* Tc, const float* W, const float* bias, float* A, float* Bm,
                          long long nodes, int C, int L, int Lw, int Ho, hipStream_t stream) {
     if (!stc_node_post_shape_ok(2, C, L, Ho) || nodes <= 0 || nodes >= (1ll << 31) / C) return STC_NOT_HANDLED;
-    if (!(stc::aligned16(X) && stc::aligned16(A) && stc::aligned16(Bm) && (!X2 || stc::aligned16(X2)))) return STC_NOT_HANDLED;
+    if (!(stc::aligned16(X) && stc::aligned16(A) && stc::aligned16(Bm) && (!X2 || L == 20 || stc::aligned16(X2)))) return STC_NOT_HANDLED;
+    if (X2 && L == 20) {                        // narrow planar rows: X = the 16-wide plane, X2 = the input plane (Lw - 16 <= 4 columns)
+        if (Lw - 16 < 1 || Lw - 16 > 4) return STC_NOT_HANDLED;
+        if (C == 32) return launch_fwd2<1, 1, 20, 2>(X, X2, Tc, W, bias, A, Bm, nodes, Lw, stream);
+        if (C == 64) return launch_fwd2<2, 1, 20, 2>(X, X2, Tc, W, bias, A, Bm, nodes, Lw, stream);
+        return STC_NOT_HANDLED;
+    }
     if (X2) {
         if (L != 32) return STC_NOT_HANDLED;
         if (C == 32) return launch_fwd2<1, 1, 32, 1>(X, X2, Tc, W, bias, A, Bm, nodes, Lw, stream);
@@ -1144,13 +1210,21 @@ int stc_node_post_fwd_x3(const float* X, const float* X2, const float* Tc, const
 // ---- planar cell inputs (K = 2, rows of 16 + 16 columns): Z = {X plane, S.X plane, H plane, S.H plane} in launch order {p[0], p[1], q[0], q[1]}
 int stc_cell_gates_fwd_planar_x3(const float* X, const float* H, const float* SX, const float* SH, const float* Tc, const float* W,
                                  const float* bias, float* U, float* R, float* RH, long long nodes, int C, int Lw, hipStream_t stream) {
-    if (!x3_cell_shape(2, C, 32, nodes)) return STC_NOT_HANDLED;
-    const float* Z[4] = {X, SX, H, SH};
-    if (!all_aligned16(Z, 4)) return STC_NOT_HANDLED;
+    const int cin = Lw - 16;
+    if (!x3_cell_shape(2, C, cin == 16 ? 32 : 20, nodes) || !(cin == 16 || (cin >= 1 && cin <= 4))) return STC_NOT_HANDLED;
     FwdEpi epi{};
-    epi.H = H; epi.U_out = U; epi.R_out = R; epi.CandIn = RH; epi.cin = 16;
-    if (C == 32) return launch_fwd<1, 2, 2, 32, EPI_GATES, 0, 1>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi);
-    if (C == 64) return launch_fwd<2, 2, 2, 32, EPI_GATES, 0, 1>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi);
+    epi.H = H; epi.U_out = U; epi.R_out = R; epi.CandIn = RH; epi.cin = cin;
+    if (cin == 16) {
+        const float* Z[4] = {X, SX, H, SH};
+        if (!all_aligned16(Z, 4)) return STC_NOT_HANDLED;
+        if (C == 32) return launch_fwd<1, 2, 2, 32, EPI_GATES, 0, 1>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi);
+        if (C == 64) return launch_fwd<2, 2, 2, 32, EPI_GATES, 0, 1>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi);
+        return STC_NOT_HANDLED;
+    }
+    const float* Z[4] = {H, SH, X, SX};          // narrow input: the STATE plane leads, columns [H | Xt | pad]
+    if (!stc::aligned16(H) || !stc::aligned16(SH)) return STC_NOT_HANDLED;
+    if (C == 32) return launch_fwd<1, 2, 2, 20, EPI_GATES, 0, 2>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi);
+    if (C == 64) return launch_fwd<2, 2, 2, 20, EPI_GATES, 0, 2>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi);
     return STC_NOT_HANDLED;
 }
 
@@ -1158,7 +1232,20 @@ int stc_cell_gates_bwd_planar_x3(const float* X, const float* H, const float* SX
                                  const float* dCandIn, const float* Cand, const float* U, const float* R, const float* dHnew,
                                  float* const* dZ, float* dH, float* partial, int* n_partials, int want_db,
                                  long long nodes, int C, int Lw, hipStream_t stream) {
-    if (!x3_cell_shape(2, C, 32, nodes)) return STC_NOT_HANDLED;
+    const int cin = Lw - 16;
+    if (!x3_cell_shape(2, C, cin == 16 ? 32 : 20, nodes) || !(cin == 16 || (cin >= 1 && cin <= 4))) return STC_NOT_HANDLED;
+    if (cin != 16) {                               // narrow input plane: only d H plane (dZ[2]) and d SH plane (dZ[3]) are produced
+        if (!(stc::aligned16(H) && stc::aligned16(SH) && dZ[2] && dZ[3] && stc::aligned16(dZ[2]) && stc::aligned16(dZ[3]))) return STC_NOT_HANDLED;
+        if (!(stc::aligned16(dCandIn) && stc::aligned16(Cand) && stc::aligned16(U) && stc::aligned16(R) && stc::aligned16(dHnew) && stc::aligned16(dH)))
+            return STC_NOT_HANDLED;
+        const float* Zn[4] = {H, SH, X, SX};
+        float* dZn[4] = {dZ[2], dZ[3], nullptr, nullptr};
+        BwdPro pn{};
+        pn.Cand = Cand; pn.dCandIn = dCandIn; pn.H = H; pn.U = U; pn.R = R; pn.dH_in = dHnew; pn.dH = dH; pn.cin = 0; pn.dh_scaled = 1;
+        if (C == 32) return launch_bwd<1, 2, 2, 20, PRO_GATES_CAND, 2>(Zn, Tc, W, nullptr, dZn, partial, n_partials, want_db, nodes, Lw, stream, pn);
+        if (C == 64) return launch_bwd<2, 2, 2, 20, PRO_GATES_CAND, 2>(Zn, Tc, W, nullptr, dZn, partial, n_partials, want_db, nodes, Lw, stream, pn);
+        return STC_NOT_HANDLED;
+    }
     const float* Z[4] = {X, SX, H, SH};
     if (!all_aligned16(Z, 4)) return STC_NOT_HANDLED;
     for (int i = 0; i < 4; ++i)

@@ -407,15 +407,18 @@ class HipKernels:
         if X2 is None:
             return self._node_shapes([X, X], Tc, W)
         self._f32('post.X', X)
-        self._f32('post.X2', X2, tuple(X.shape))
         if X.dim() != 3 or X.shape[-1] != 16:
-            raise StcError(f'post: planar input planes must be (rows, C, 16), got {tuple(X.shape)}')
+            raise StcError(f'post: the leading planar input plane must be (rows, C, 16), got {tuple(X.shape)}')
         R, Cc, _ = X.shape
-        if Tc.dim() != 3 or Tc.shape[0] != 2 or W.dim() != 2 or W.shape[0] % 4:
-            raise StcError('post: planar form needs Ks = Kc = 2')
+        w2 = X2.shape[-1]
+        self._f32('post.X2', X2, (R, Cc, w2))
+        if not (w2 == 16 or 1 <= w2 <= 4):
+            raise StcError(f'post: second plane must be 16 or 1..4 columns wide, got {w2}')
+        if Tc.dim() != 3 or Tc.shape[0] != 2 or W.dim() != 2 or W.shape[0] != 4 * (16 + w2):
+            raise StcError(f'post: planar form needs Ks = Kc = 2 and W with 4 x {16 + w2} rows, got {tuple(W.shape)}')
         self._f32('post.Tc', Tc, (2, Cc, Cc))
         self._f32('post.W', W)
-        return 2, 2, R, Cc, 32, W.shape[0] // 4, W.shape[1]
+        return 2, 2, R, Cc, (32 if w2 == 16 else 20), 16 + w2, W.shape[1]
 
     def node_post_fwd(self, X, Tc, W, bias, A, Bm, X2=None):
         """X -> A = sum_c T_c^T (X W_{0,c}) + bias, Bm = sum_c T_c^T (X W_{1,c}); the caller finishes Y = A + S.Bm."""
@@ -459,8 +462,9 @@ class HipKernels:
         """(X, dA = dY, dBm = S^T dY) -> dX, dW, db of the convolution in its post-aggregation form.  Planar (X2 given):
         the gradient comes out as the two planes dX, dX2 as well."""
         Ks, Kc, R, Cc, L, Lw, Ho = self._post_rows(X, X2, Tc, W)
-        if (X2 is None) != (dX2 is None):
-            raise StcError('post: planar input (X2) and planar gradient (dX2) go together')
+        narrow = X2 is not None and X2.shape[-1] != 16
+        if (dX2 is not None) != (X2 is not None and not narrow):
+            raise StcError('post: a planar gradient (dX2) goes with a 16 + 16 planar input and only with it')
         for name, t in (('dA', dA), ('dB', dB)):
             self._f32('post.' + name, t, (R, Cc, Ho))
         self._f32('post.dX', dX, (R, Cc, L) if X2 is None else (R, Cc, 16))
@@ -479,44 +483,54 @@ class HipKernels:
         return bool(self.lib.stc_cell_planar_supported(Ks, Kc, Cc, h))
 
     def _planes(self, what, X, H, SX, SH):
+        """State planes (R, C, h); input planes (R, C, cin) with cin = h or 1..4 (narrow: layer 0)."""
         R, Cc, h = H.shape
-        for name, t in (('X', X), ('H', H), ('SX', SX), ('SH', SH)):
+        cin = X.shape[-1]
+        if not (cin == h or 1 <= cin <= 4):
+            raise StcError(f'{what}: input plane width {cin} must be {h} or 1..4')
+        for name, t in (('H', H), ('SH', SH)):
             self._f32(f'{what}.{name}', t, (R, Cc, h))
-        return R, Cc, h
+        for name, t in (('X', X), ('SX', SX)):
+            self._f32(f'{what}.{name}', t, (R, Cc, cin))
+        return R, Cc, h, cin
 
     def cell_gates_fwd_planar(self, X, H, SX, SH, Tc, W, bias, U, Rg, RH):
         """Gates convolution on planar inputs; writes U, Rg and the R*H plane (the candidate's input is (X, RH))."""
-        R, Cc, h = self._planes('planar', X, H, SX, SH)
+        R, Cc, h, cin = self._planes('planar', X, H, SX, SH)
         self._f32('planar.Tc', Tc, (2, Cc, Cc))
         self._f32('planar.W', W)
-        if W.shape != (4 * 2 * h, 2 * h):
-            raise StcError(f'planar gates: W {tuple(W.shape)} is not ({8 * h}, {2 * h})')
+        if W.shape != (4 * (cin + h), 2 * h):
+            raise StcError(f'planar gates: W {tuple(W.shape)} is not ({4 * (cin + h)}, {2 * h})')
         if bias is not None:
             self._f32('planar.bias', bias, (2 * h,))
         for name, t in (('U', U), ('Rg', Rg), ('RH', RH)):
             self._f32('planar.' + name, t, (R, Cc, h))
         self._same_device(X, H, SX, SH, Tc, W, bias, U, Rg, RH)
         self._launch('stc_cell_gates_fwd_planar_f32', H, _ptr(X), _ptr(H), _ptr(SX), _ptr(SH), _ptr(Tc), _ptr(W), _ptr(bias),
-                     _ptr(U), _ptr(Rg), _ptr(RH), R, Cc, 2 * h, h)
+                     _ptr(U), _ptr(Rg), _ptr(RH), R, Cc, cin + h, h)
 
     def cell_gates_bwd_planar(self, X, H, SX, SH, Tc, W, dRH, Cand, U, Rg, dHnew, dZs, dW, db, dH):
-        """``dRH``: gradient of the R*H plane; ``dZs`` = [d X plane, d SX plane, d H plane, d SH plane]."""
-        R, Cc, h = self._planes('planar', X, H, SX, SH)
+        """``dRH``: gradient of the R*H plane; ``dZs`` = [d X plane, d SX plane, d H plane, d SH plane] (the first two
+        None for a narrow input plane, which needs no gradient)."""
+        R, Cc, h, cin = self._planes('planar', X, H, SX, SH)
         self._f32('planar.Tc', Tc, (2, Cc, Cc))
-        self._f32('planar.W', W, (8 * h, 2 * h))
+        self._f32('planar.W', W, (4 * (cin + h), 2 * h))
         for name, t in (('dRH', dRH), ('Cand', Cand), ('U', U), ('Rg', Rg), ('dHnew', dHnew), ('dH', dH)):
             self._f32('planar.' + name, t, (R, Cc, h))
         if len(dZs) != 4:
             raise StcError('planar gates backward: four gradient planes (dX, dSX, dH, dSH)')
         for i, z in enumerate(dZs):
+            if z is None and i < 2 and cin != h:
+                continue
             self._f32(f'planar.dZ[{i}]', z, (R, Cc, h))
-        self._f32('planar.dW', dW, (8 * h, 2 * h))
+        self._f32('planar.dW', dW, (4 * (cin + h), 2 * h))
         if db is not None:
             self._f32('planar.db', db, (2 * h,))
         self._same_device(X, H, SX, SH, Tc, W, dRH, Cand, U, Rg, dHnew, *dZs, dW, db, dH)
         ws = self._get_workspace(H.device, self.lib.stc_bdg_node_bwd_workspace_bytes(2, 2, Cc, 2 * h, 2 * h, 0))
+        zp = (_p * 4)(*[0 if z is None else z.data_ptr() for z in dZs])
         self._launch('stc_cell_gates_bwd_planar_f32', H, _ptr(X), _ptr(H), _ptr(SX), _ptr(SH), _ptr(Tc), _ptr(W), _ptr(dRH), _ptr(Cand),
-                     _ptr(U), _ptr(Rg), _ptr(dHnew), self._ptr_array(dZs), _ptr(dW), _ptr(db), _ptr(dH), _ptr(ws), ws.numel(), R, Cc, 2 * h, h)
+                     _ptr(U), _ptr(Rg), _ptr(dHnew), zp, _ptr(dW), _ptr(db), _ptr(dH), _ptr(ws), ws.numel(), R, Cc, cin + h, h)
 
     # ---- fused cell convolutions ----------------------------------------------------------
     def cell_fused_supported(self, Ks, Kc, Cc, L, h) -> bool:

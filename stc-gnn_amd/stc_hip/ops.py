@@ -491,7 +491,9 @@ class _StcCellGraph(Function):
         source = lambda src: ext[src[1]] if src[0] == 'ext' else state[src[1]]
         planar_ok = (_PLANAR and _POST_AGG and Ks == 2 and k.cell_planar_supported(Ks, Tc.shape[0], C, h)
                      and k.node_post_supported(Ks, Tc.shape[0], C, 2 * h, h))
-        planar = [bool(planar_ok and cin[j] == h) for j in range(n_cells)]
+        post20 = bool(planar_ok) and k.node_post_supported(Ks, Tc.shape[0], C, 20, h)
+        # 16 + 16 columns, or (layer 0) a narrow input plane of 1..4 columns beside the 16 state columns
+        planar = [bool(planar_ok and (cin[j] == h or (post20 and 1 <= cin[j] <= 4))) for j in range(n_cells)]
         XH, agg = {}, {}
 
         def rows_of(j):                                             # input rows of an interleaved cell, allocated at first touch
@@ -503,8 +505,8 @@ class _StcCellGraph(Function):
         def aggregated(src):                                        # S.source, once per source tensor
             if src not in agg:
                 t = source(src)
-                out = torch.empty_like(t)
-                k.csr_spmm(op.fwd_rowptr, op.fwd_colidx, fwd_val, N, N, t.view(B, N, C * h), None, out.view(B, N, C * h), 1.0, 0.0,
+                out, w = torch.empty_like(t), t.shape[-1]
+                k.csr_spmm(op.fwd_rowptr, op.fwd_colidx, fwd_val, N, N, t.view(B, N, C * w), None, out.view(B, N, C * w), 1.0, 0.0,
                            plan=op.fwd_plan)
                 agg[src] = out
             return agg[src]
@@ -546,7 +548,8 @@ class _StcCellGraph(Function):
                 Xp, SXp, SHp, RH = source(x), aggregated(x), aggregated(hs), torch.empty_like(Hprev)
                 k.cell_gates_fwd_planar(*rows((Xp, Hprev, SXp, SHp)), Tc, Wg, bg, *rows((U, Rg, RH)))
                 A, Bm = torch.empty_like(Hprev), torch.empty_like(Hprev)
-                k.node_post_fwd(*rows((Xp,)), Tc, Wc, bc, *rows((A, Bm)), X2=RH.view(B * N, C, h))
+                lead, second = (Xp, RH) if cin[j] == h else (RH, Xp)     # narrow input plane: the 16-wide plane leads
+                k.node_post_fwd(*rows((lead,)), Tc, Wc, bc, *rows((A, Bm)), X2=second.view(B * N, C, second.shape[-1]))
                 k.spmm_blend_fwd(op.fwd_rowptr, op.fwd_colidx, fwd_val, op.fwd_plan, Bm, A, U, Hprev, Cand, Hnew, copies=copies, side=side)
                 del A, Bm
                 saved += [Hprev, U, Rg, Cand, Xp, SXp, SHp, RH]
@@ -664,15 +667,22 @@ class _StcCellGraph(Function):
                 dY = torch.empty_like(Hprev)
                 k.gru_blend_bwd(dHnew, U, None, Cand, dY, None, None)                      # dY = dHnew * U * (1 - Cand^2)
                 dBm = narrow_transpose_aggregation(dY)
-                dXc, dRH, dWc = torch.empty_like(Hprev), torch.empty_like(Hprev), torch.empty_like(Wc)
+                dRH, dWc = torch.empty_like(Hprev), torch.empty_like(Wc)
                 dbc = Wc.new_empty(h) if bc is not None else None
-                k.node_post_bwd(*rows((Xp,)), Tc, Wc, *rows((dY, dBm, dXc)), dWc, dbc, X2=RH.view(B * N, C, h), dX2=dRH.view(B * N, C, h))
-                del dY, dBm
-                dXd, dSX, dHd, dSH = (torch.empty_like(Hprev) for _ in range(4))
+                wide = cin[j] == h                                   # else: narrow input plane (layer 0), which needs no gradient
                 dWg, dbg = torch.empty_like(Wg), (Wg.new_empty(2 * h) if bg is not None else None)
-                k.cell_gates_bwd_planar(*rows((Xp, Hprev, SXp, SHp)), Tc, Wg, *rows((dRH, Cand, U, Rg, dHnew)),
-                                        rows((dXd, dSX, dHd, dSH)), dWg, dbg, dH.view(B * N, C, h))
-                if x[0] == 'cell':
+                dHd, dSH = torch.empty_like(Hprev), torch.empty_like(Hprev)
+                if wide:
+                    dXc, dXd, dSX = (torch.empty_like(Hprev) for _ in range(3))
+                    k.node_post_bwd(*rows((Xp,)), Tc, Wc, *rows((dY, dBm, dXc)), dWc, dbc, X2=RH.view(B * N, C, h), dX2=dRH.view(B * N, C, h))
+                    planes = rows((dXd, dSX, dHd, dSH))
+                else:
+                    k.node_post_bwd(*rows((RH,)), Tc, Wc, *rows((dY, dBm, dRH)), dWc, dbc, X2=Xp.view(B * N, C, cin[j]))
+                    planes = [None, None] + rows((dHd, dSH))
+                del dY, dBm
+                k.cell_gates_bwd_planar(*rows((Xp, Hprev, SXp, SHp)), Tc, Wg, *rows((dRH, Cand, U, Rg, dHnew)), planes, dWg, dbg,
+                                        dH.view(B * N, C, h))
+                if wide and x[0] == 'cell':
                     leave(x[1], (dXd, dXc), dSX)                     # as the X plane: gates' and candidate's direct shares
                 if hs[0] == 'cell':
                     leave(hs[1], (dHd, dH), dSH)                     # as the H plane: direct share + what the gates prologue owes it

@@ -539,6 +539,49 @@ def test_planar_cell_kernels(hip, nodes, C):
     assert rel_err(dX, dX_w) < TOL and rel_err(dX2, dX2_w) < TOL and rel_err(dWc, dWc_w) < TOL and rel_err(dbc, dbc_w) < TOL
 
 
+@pytest.mark.parametrize('nodes,C,cin', [(50, 32, 1), (13, 64, 4), (4500, 32, 1), (9, 32, 3)])
+def test_planar_cell_kernels_narrow_input(hip, nodes, C, cin):
+    """Layer-0 form of the planar kernels: a (nodes, C, cin) input plane with cin in 1..4 beside the 16-wide state plane; the
+    kernels read the slab as [H | Xt | pad] with W's rows permuted inside -- results must equal the reference order."""
+    h, K = 16, 2
+    Lw = cin + h
+    g = torch.Generator().manual_seed(nodes + C + cin)
+    rnd = lambda *s_: torch.randn(*s_, generator=g)
+    X, SX, H, SH = rnd(nodes, C, cin), rnd(nodes, C, cin), rnd(nodes, C, h), rnd(nodes, C, h)
+    Tc = rnd(K, C, C) / C ** 0.5
+    Tc[0] = torch.eye(C)
+    Wg, bg = rnd(K * K * Lw, 2 * h) / (4 * Lw) ** 0.5, rnd(2 * h)
+    U_w, R_w, RH_w = (torch.empty(nodes, C, h) for _ in range(3))
+    EM.cell_gates_fwd_planar(X, H, SX, SH, Tc, Wg, bg, U_w, R_w, RH_w)
+    nan = lambda *s_: torch.full(s_, float('nan')).cuda()
+    U, R, RH = nan(nodes, C, h), nan(nodes, C, h), nan(nodes, C, h)
+    hip.cell_gates_fwd_planar(cu(X), cu(H), cu(SX), cu(SH), cu(Tc), cu(Wg), cu(bg), U, R, RH)
+    assert rel_err(U, U_w) < TOL and rel_err(R, R_w) < TOL and rel_err(RH, RH_w) < TOL
+
+    dRH, Cand, dHn = rnd(nodes, C, h), torch.tanh(rnd(nodes, C, h)), rnd(nodes, C, h)
+    dZ_w = [None, None, torch.empty(nodes, C, h), torch.empty(nodes, C, h)]
+    dW_w, db_w, dH_w = torch.empty_like(Wg), torch.empty(2 * h), torch.empty(nodes, C, h)
+    EM.cell_gates_bwd_planar(X, H, SX, SH, Tc, Wg, dRH, Cand, U_w, R_w, dHn, dZ_w, dW_w, db_w, dH_w)
+    dZ = [None, None, nan(nodes, C, h), nan(nodes, C, h)]
+    dW, db, dH = nan(*Wg.shape), nan(2 * h), nan(nodes, C, h)
+    hip.cell_gates_bwd_planar(cu(X), cu(H), cu(SX), cu(SH), cu(Tc), cu(Wg), cu(dRH), cu(Cand), cu(U_w), cu(R_w), cu(dHn), dZ, dW, db, dH)
+    assert rel_err(dZ[2], dZ_w[2]) < TOL and rel_err(dZ[3], dZ_w[3]) < TOL
+    assert rel_err(dW, dW_w) < TOL and rel_err(db, db_w) < TOL and rel_err(dH, dH_w) < TOL
+
+    Wc, bc = rnd(K * K * Lw, h) / (4 * Lw) ** 0.5, rnd(h)
+    A_w, B_w = torch.empty(nodes, C, h), torch.empty(nodes, C, h)
+    EM.node_post_fwd(RH_w, Tc, Wc, bc, A_w, B_w, X2=X)
+    A, Bm = nan(nodes, C, h), nan(nodes, C, h)
+    hip.node_post_fwd(cu(RH_w), cu(Tc), cu(Wc), cu(bc), A, Bm, X2=cu(X))
+    assert rel_err(A, A_w) < TOL and rel_err(Bm, B_w) < TOL
+    dA, dB = rnd(nodes, C, h), rnd(nodes, C, h)
+    dX_w, dWc_w, dbc_w = torch.empty(nodes, C, h), torch.empty_like(Wc), torch.empty(h)
+    EM.node_post_bwd(RH_w, Tc, Wc, dA, dB, dX_w, dWc_w, dbc_w, X2=X)
+    dX, dWc, dbc = nan(nodes, C, h), nan(*Wc.shape), nan(h)
+    hip.node_post_bwd(cu(RH_w), cu(Tc), cu(Wc), cu(dA), cu(dB), dX, dWc, dbc, X2=cu(X))
+    assert rel_err(dX, dX_w) < TOL and rel_err(dWc, dWc_w) < TOL and rel_err(dbc, dbc_w) < TOL
+
+
 @pytest.mark.parametrize('batch,grid,C,n_add,dual', [(2, (5, 5), 32, 3, True), (1, (4, 7), 64, 5, False), (2, (40, 56), 32, 0, True), (1, (1, 1), 32, 2, False)])
 def test_state_gradient_from_pieces(hip, batch, grid, C, n_add, dual):
     """stc_spmm_sum_f32: Y = sum of addends (contiguous planes and column slices of wider rows) + S.(X [+ X2])."""
