@@ -34,6 +34,8 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling ~6300
+# every C-ABI entry point that is an aggregation Y = S.X (+ epilogue): the kernels the metric's roofline is about
+SPMM_ENTRY_POINTS = ('stc_bcsr_spmm_f32', 'stc_csr_spmm_f32', 'stc_spmm_sum_f32', 'stc_spmm_blend_fwd_f32')
 METRIC = 'STC-GNN fwd+bwd samples/sec at N=50k,C=32; SpMM HBM GB/s vs peak, 1/8 GPU'
 
 
@@ -49,7 +51,7 @@ def parse():
     ap.add_argument('--layers', type=int, default=2)
     ap.add_argument('--obs', type=int, default=18)
     ap.add_argument('--pred', type=int, default=6)
-    ap.add_argument('--batch-per-gpu', type=int, default=4, help='samples per GPU (weak scaling); 49 GB of saved activations per sample: 4 = 199 GB of the 288 GB (5 fits too: 249 GB)')
+    ap.add_argument('--batch-per-gpu', type=int, default=5, help='samples per GPU (weak scaling); 38 GB of saved activations per sample: 5 = 189 GB of the 288 GB (6 fits too: 227 GB)')
     ap.add_argument('--permute', action='store_true', help='random node order (seed 1234) instead of row-major')
     ap.add_argument('--no-reorder', action='store_true', help='keep the given node order (skip the internal RCM renumbering)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -146,7 +148,7 @@ def main():
     if rank == 0:
         total_ms = sum(d['ms'] for d in per_kernel.values()) or 1.0
         spmm = dict(launches=0, ms=0.0, bytes=0)           # both forms of the aggregation: CSR and row-blocked CSR
-        for name in ('stc_csr_spmm_f32', 'stc_bcsr_spmm_f32'):
+        for name in SPMM_ENTRY_POINTS:
             for key, v in per_kernel.get(name, {}).items():
                 spmm[key] += v
         achieved = (spmm['bytes'] / 1e9) / (spmm['ms'] / 1e3) if spmm['ms'] > 0 else 0.0
@@ -154,14 +156,14 @@ def main():
         # separate rocprofv3 --pmc runs, as MI355X_MICROARCH.md prescribes; tools/gpu_pmc_bench.sh): averaged over all SpMM
         # launches of a step exactly like roofline.achieved.  Only valid for the configuration it was collected on.
         traffic, traffic_note = None, None
-        tpath = os.path.join(REPO, 'profiles', 'r01', 'i_hbm_traffic_bench_b4.json')
-        if (a.grid, C, a.hidden, B, a.order, a.layers, a.obs, a.pred, a.permute) == (224, 32, 16, 4, 2, 2, 18, 6, False) and os.path.exists(tpath):
+        tpath = os.path.join(REPO, 'profiles', 'r01', 'j_hbm_traffic_bench_b5.json')
+        if (a.grid, C, a.hidden, B, a.order, a.layers, a.obs, a.pred, a.permute) == (224, 32, 16, 5, 2, 2, 18, 6, False) and os.path.exists(tpath):
             with open(tpath) as fh:
                 doc = json.load(fh)
-            ks = [v for name, v in doc['kernels'].items() if name.startswith('spmm_') and ', 0, ' in name]      # MODE 0 = the plain kernels
+            ks = [v for name, v in doc['kernels'].items() if name.startswith('spmm_')]
             if ks:
                 traffic = sum(v['hbm_bytes_per_launch'] * v['launches'] for v in ks) / sum(v['launches'] for v in ks)
-                traffic_note = 'PMC (2 x FETCH_SIZE + WRITE_SIZE), mean over the SpMM launches of one step of this command: profiles/r01/i_hbm_traffic_bench_b4.json'
+                traffic_note = 'PMC (2 x FETCH_SIZE + WRITE_SIZE), mean over the SpMM launches of one step of this command: profiles/r01/j_hbm_traffic_bench_b5.json'
         out = {
             'metric': METRIC, 'value': world * B * a.steps / elapsed, 'unit': 'samples/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * elapsed / a.steps,
@@ -171,7 +173,7 @@ def main():
                                    f'hidden={a.hidden}, K={a.order}, layers={a.layers}, T={a.obs}+{a.pred}',
                        'global_batch': world * B, 'batch_per_gpu': B, 'parallelism': f'batch-shard x{world}',
                        'grad_bucket_bytes': bucket.nbytes},
-            'roofline': {'bound': 'hbm', 'kernel': 'stc_bcsr_spmm_f32 + stc_csr_spmm_f32: every plain aggregation launch of the timed steps (rows of C*L floats forward / in-place backward, rows of C*16 floats for the candidate gradient)', 'achieved': achieved, 'peak': HBM_PEAK_GBPS,
+            'roofline': {'bound': 'hbm', 'kernel': ' + '.join(SPMM_ENTRY_POINTS) + ': every aggregation (SpMM) launch of the timed steps -- plain, with the GRU blend in its epilogue, and the state-gradient sum form', 'achieved': achieved, 'peak': HBM_PEAK_GBPS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic, 'traffic_note': traffic_note,
                          'launches': spmm['launches'],
                          'avg_launch_us': 1e3 * spmm['ms'] / max(1, spmm['launches']),

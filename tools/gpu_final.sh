@@ -4,7 +4,7 @@ set -u
 cd "${GRAFT_REPO_ROOT:-.}"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-echo "== bench B=5"; timeout 900 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --batch-per-gpu 5 2>&1 | tail -1 | cut -c1-260
+echo "== bench B=6"; timeout 900 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --batch-per-gpu 6 2>&1 | tail -1 | cut -c1-260
 echo "== bench default (with cpu baseline)"; timeout 900 python bench.py > gpurun_out/bench_default.log 2>&1; tail -1 gpurun_out/bench_default.log | cut -c1-260
 echo "== rocprofv3 kernel trace"
 rm -rf gpurun_out/prof
