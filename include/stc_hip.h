@@ -256,12 +256,15 @@ int stc_cell_gates_bwd_planar_f32(const float* X, const float* H, const float* S
 
 /* Y = sum_i add[i] + S x (X [+ X2]) on rows of C*h floats (h = 16): the gradient of a state from the pieces its consumers
  * left -- direct planes as addends (add[i]: columns [add_off[i], add_off[i]+h) of rows of add_ld[i] floats, multiples of 4;
- * a contiguous plane is ld = h, off = 0), aggregated planes X, X2 through the transposed graph.  n_add <= 5, X2 may be NULL. */
+ * a contiguous plane is ld = h, off = 0), aggregated planes X, X2 through the transposed graph.  n_add <= 5, X2 may be NULL.
+ * dY != NULL: the epilogue also writes dY = Y*U*(1-Cand^2), the blend backward (STC_GNN.py:76-78) of the cell that owns the
+ * state, from that cell's saved U and Cand -- the gradient is then not read again just to form it. */
 int stc_spmm_sum_f32(const int32_t* rowptr, const int32_t* colidx, const float* val,
                      const int32_t* blk_ptr, const int32_t* blk_cols, const float* blk_vals,
                      int32_t n_rows, int32_t n_cols, const float* X, const float* X2,
                      int32_t n_add, const float* const* add, const int32_t* add_ld, const int32_t* add_off,
-                     float* Y, int32_t batch, int32_t C, int32_t h, void* stream);
+                     float* Y, const float* U, const float* Cand, float* dY,
+                     int32_t batch, int32_t C, int32_t h, void* stream);
 
 /* ---- the same two cell convolutions with the graph aggregation fused in (Ks = Kc = 2) ------------------------------
  * Replaces STC_GNN.py:37 (the 1-mode product Z1 = Gs^T x Z0, one SpMM launch) + :38-45 + :71-78 in ONE launch per

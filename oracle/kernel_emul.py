@@ -165,12 +165,15 @@ class EmulatedKernels:
         if dZs[0] is not None:
             dZs[0].copy_(rows[0][..., :cin]); dZs[1].copy_(rows[1][..., :cin])  # d X plane, d SX plane
 
-    def spmm_sum(self, rowptr, colidx, val, plan, X, X2, addends, Y):
+    def spmm_sum(self, rowptr, colidx, val, plan, X, X2, addends, Y, blend=None):
         B, n, Cc, h = Y.shape
         src = X if X2 is None else X + X2
         self.csr_spmm(rowptr, colidx, val, n, n, src.reshape(B, n, Cc * h), None, Y.view(B, n, Cc * h), 1.0, 0.0)
         for t, off in addends:
             Y += t[..., off:off + h]
+        if blend is not None:
+            U, Cand, dY = blend
+            dY.copy_(Y * U * (1 - Cand * Cand))
 
     def node_post_fwd(self, X, Tc, W, bias, A, Bm, X2=None):
         if X2 is not None:                                     # planar: 16 + 16 -> [X | X2]; narrow -> reference order [X2 (input) | X (16-wide)]

@@ -78,6 +78,7 @@ struct EpiArgs {
     // add[i] = columns [off, off+h) of rows of ld floats (a contiguous plane: ld = h, off = 0)
     const float4* X2;                       // SUM2: second gathered operand (same batch stride as X)
     const float* add[5]; int add_ld[5], add_off[5], n_add;
+    const float *gU, *gCand; float* dYout;  // SUM, optional: also dY = Y * U * (1 - Cand^2), the blend backward of the cell that owns the state
 };
 
 // one element of a [Xt | H | pad] row: l = column, e = (row, category) index, v = its gradient
@@ -154,6 +155,11 @@ __device__ __forceinline__ void epilogue(const EpiArgs& a, size_t rowg, int F4, 
             y.x += t.x; y.y += t.y; y.z += t.z; y.w += t.w;
         }
         nt_store4(a.Y + o, y);
+        if (a.dYout) {
+            const float4 u = *reinterpret_cast<const float4*>(a.gU + 4 * o), c = *reinterpret_cast<const float4*>(a.gCand + 4 * o);
+            nt_store4(reinterpret_cast<float4*>(a.dYout) + o,
+                      make_float4(y.x * u.x * (1.f - c.x * c.x), y.y * u.y * (1.f - c.y * c.y), y.z * u.z * (1.f - c.z * c.z), y.w * u.w * (1.f - c.w * c.w)));
+        }
         return;
     }
     const float4 y0 = nt_load4(a.Y0 + o);
@@ -709,7 +715,8 @@ extern "C" int stc_spmm_sum_f32(const int32_t* rowptr, const int32_t* colidx, co
                                 const int32_t* blk_ptr, const int32_t* blk_cols, const float* blk_vals,
                                 int32_t n_rows, int32_t n_cols, const float* X, const float* X2,
                                 int32_t n_add, const float* const* add, const int32_t* add_ld, const int32_t* add_off,
-                                float* Y, int32_t batch, int32_t C, int32_t h, void* stream) {
+                                float* Y, const float* U, const float* Cand, float* dY,
+                                int32_t batch, int32_t C, int32_t h, void* stream) {
     const GraphArgs g{rowptr, colidx, val, blk_ptr, blk_cols, blk_vals};
     STC_REQUIRE(h == 16, STC_EUNSUPPORTED, "stc_spmm_sum_f32: hidden width %d (built for 16)", h);
     STC_REQUIRE(n_add >= 0 && n_add <= 5 && (n_add == 0 || (add && add_ld && add_off)), STC_EINVAL, "stc_spmm_sum_f32: 0..5 addends, got %d", n_add);
@@ -721,6 +728,9 @@ extern "C" int stc_spmm_sum_f32(const int32_t* rowptr, const int32_t* colidx, co
     ep.Y = reinterpret_cast<float4*>(Y);
     ep.C = C; ep.L = h; ep.cin = 0; ep.h = h;
     ep.X2 = reinterpret_cast<const float4*>(X2);
+    STC_REQUIRE(!dY || (U && Cand && stc::aligned16(U) && stc::aligned16(Cand) && stc::aligned16(dY) && dY != Y), STC_EINVAL,
+                "stc_spmm_sum_f32: dY needs U and Cand (16-byte aligned, not aliasing Y)");
+    ep.gU = U; ep.gCand = Cand; ep.dYout = dY;
     ep.n_add = n_add;
     for (int i = 0; i < n_add; ++i) {
         STC_REQUIRE(add[i] && add_off[i] >= 0 && add_off[i] + h <= add_ld[i] && ((add_ld[i] | add_off[i]) & 3) == 0 && stc::aligned16(add[i]), STC_EINVAL,

@@ -69,7 +69,7 @@ def _declare(lib):
         'stc_cell_gates_bwd_planar_f32': [_p] * 11 + [C.POINTER(_p), _p, _p, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _p],
         'stc_spmm_blend_fwd_f32': [_p] * 6 + [_i32, _i32] + [_p] * 6 + [_p, _i32, _i32, _p, _i32, _p, _i32, _i32] + [_i32] * 3 + [_p],
         'stc_bdg_node_post_bwd_f32': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _i32, _p],
-        'stc_spmm_sum_f32': [_p] * 6 + [_i32, _i32, _p, _p, _i32, C.POINTER(_p), C.POINTER(_i32), C.POINTER(_i32), _p, _i32, _i32, _i32, _p],
+        'stc_spmm_sum_f32': [_p] * 6 + [_i32, _i32, _p, _p, _i32, C.POINTER(_p), C.POINTER(_i32), C.POINTER(_i32), _p, _p, _p, _p, _i32, _i32, _i32, _p],
         'stc_cell_gates_fwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _i32, _p],
         'stc_cell_cand_bwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _p, C.POINTER(_p), _p, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _i32, _p],
         'stc_cell_gates_bwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _i32, C.POINTER(_p), _p, _p, _p, _p,
@@ -296,7 +296,7 @@ class HipKernels:
                      nbytes=colidx.numel() * 8 + 4 * (n + 1) + 4 * B * n * Cc * (2 * (cin + h + pad) + (2 if addA is not None else 1) * cin
                                                                                   + (2 if addB is not None else 1) * h))
 
-    def spmm_sum(self, rowptr, colidx, val, plan, X, X2, addends, Y):
+    def spmm_sum(self, rowptr, colidx, val, plan, X, X2, addends, Y, blend=None):
         """Y = sum(addends) + S.(X [+ X2]) on (B, n, C, h) state tensors (stc_spmm_sum_f32).  ``addends``: up to five
         (tensor, column offset) pairs -- columns [off, off + h) of a (B, n, C, ld) tensor (a plain plane: ld = h, off = 0)."""
         B, n, Cc, h = Y.shape
@@ -312,10 +312,16 @@ class HipKernels:
             if t.shape[:3] != (B, n, Cc) or off < 0 or off + h > t.shape[-1] or (t.shape[-1] | off) & 3:
                 raise StcError(f'spmm_sum: addend {i} of shape {tuple(t.shape)} / offset {off} does not fit')
             ptrs[i], lds[i], offs[i] = t.data_ptr(), t.shape[-1], off
-        self._same_device(rowptr, colidx, val, X, X2, Y, *[t for t, _ in addends])
+        U = Cand = dY = None
+        if blend is not None:                                     # (U, Cand, dY): also dY = Y * U * (1 - Cand^2)
+            U, Cand, dY = blend
+            for name, t in (('U', U), ('Cand', Cand), ('dY', dY)):
+                self._f32('spmm_sum.' + name, t, (B, n, Cc, h))
+        self._same_device(rowptr, colidx, val, X, X2, Y, U, Cand, dY, *[t for t, _ in addends])
         g = self._graph_ptrs(rowptr, colidx, val, plan, n)
-        self._launch('stc_spmm_sum_f32', Y, *g, n, n, _ptr(X), _ptr(X2), len(addends), ptrs, lds, offs, _ptr(Y), B, Cc, h,
-                     nbytes=colidx.numel() * 8 + 4 * (n + 1) + 4 * B * n * Cc * h * (2 + (X2 is not None) + len(addends)))
+        self._launch('stc_spmm_sum_f32', Y, *g, n, n, _ptr(X), _ptr(X2), len(addends), ptrs, lds, offs, _ptr(Y), _ptr(U), _ptr(Cand), _ptr(dY),
+                     B, Cc, h,
+                     nbytes=colidx.numel() * 8 + 4 * (n + 1) + 4 * B * n * Cc * h * (2 + (X2 is not None) + len(addends) + (3 if blend else 0)))
 
     def csr_sddmm(self, rowptr, colidx, n_rows, n_cols, A, Bm, out, alpha, accumulate):
         B, nr, F = A.shape

@@ -638,11 +638,16 @@ class _StcCellGraph(Function):
             pc['direct'] += [(t, 0) for t in direct]
             pc['agg'].append(aggregated)
 
-        def owed(kid):
+        def owed(kid, blend=None):
+            """The gradient of state ``kid``; with ``blend`` = (U, Cand) of its cell also dY = gradient * U * (1 - Cand^2)."""
             base = G.pop(kid, None)                                  # from interleaved consumers / the outputs: a finished tensor
             pc = pieces.pop(kid, None)
             if pc is None:
-                return base
+                if blend is None:
+                    return base
+                dY = torch.empty_like(base)
+                k.gru_blend_bwd(base, blend[0], None, blend[1], dY, None, None)
+                return base, dY
             add = pc['direct'] + ([(base, 0)] if base is not None else [])
             aggs = pc['agg']
             while len(add) > 5:                                      # more consumers than the kernel takes addends for: pre-sum
@@ -651,21 +656,22 @@ class _StcCellGraph(Function):
             while len(aggs) > 2:
                 aggs = [aggs[0] + aggs[1]] + aggs[2:]
             out = aggs[0].new_empty(B, N, C, h)
-            k.spmm_sum(*bwd, op.bwd_plan, aggs[0], aggs[1] if len(aggs) > 1 else None, add, out)
-            return out
+            dY = torch.empty_like(out) if blend is not None else None
+            k.spmm_sum(*bwd, op.bwd_plan, aggs[0], aggs[1] if len(aggs) > 1 else None, add, out,
+                       blend=None if blend is None else (blend[0], blend[1], dY))
+            return out if blend is None else (out, dY)
 
         for j in range(len(schedule) - 1, -1, -1):
             if j not in G and j not in pieces:
                 continue                                             # nothing downstream depends on this cell
             s_id, x, hs = schedule[j]
             Wg, bg, Wc, bc = stacks[s_id]
-            dHnew = owed(j)
             Hprev, U, Rg, Cand, *rest = cells[j]
+            post_form = n_saved[j] < 0 or (len(rest) == Ks + 1 and Ks > 1)     # candidate backward starts from dY = dHnew * U * (1 - Cand^2)
+            dHnew, dY = owed(j, (U, Cand)) if post_form else (owed(j), None)
             dH = torch.empty_like(Hprev)
             if n_saved[j] < 0:                                       # planar cell: inputs and gradients as planes
                 Xp, SXp, SHp, RH = rest
-                dY = torch.empty_like(Hprev)
-                k.gru_blend_bwd(dHnew, U, None, Cand, dY, None, None)                      # dY = dHnew * U * (1 - Cand^2)
                 dBm = narrow_transpose_aggregation(dY)
                 dRH, dWc = torch.empty_like(Hprev), torch.empty_like(Wc)
                 dbc = Wc.new_empty(h) if bc is not None else None
@@ -693,8 +699,6 @@ class _StcCellGraph(Function):
                 Zg, Zc = rest[:Ks], rest[Ks:]
                 L = Zc[0].shape[-1]
                 if len(Zc) == 1 and Ks > 1:                         # the forward ran this convolution as Y = A + S.Bm (no Z_1 slab)
-                    dY = torch.empty_like(Hprev)
-                    k.gru_blend_bwd(dHnew, U, None, Cand, dY, None, None)
                     dBm = narrow_transpose_aggregation(dY)
                     dci, dWc = torch.empty_like(Zc[0]), torch.empty_like(Wc)
                     dbc = Wc.new_empty(h) if bc is not None else None

@@ -596,12 +596,17 @@ def test_state_gradient_from_pieces(hip, batch, grid, C, n_add, dual):
     csr = tuple(torch.from_numpy(hst[k]) for k in ('bwd_rowptr', 'bwd_colidx', 'bwd_val'))
     dev = graph.on(torch.device('cuda'))
     plan = (dev['bwd_blk_ptr'], dev['bwd_blk_cols'], dev['bwd_blk_vals'])
-    Y_w = torch.empty(batch, n, C, h)
-    EM.spmm_sum(*csr, None, X, X2, adds, Y_w)
+    Y_w, dY_w = torch.empty(batch, n, C, h), torch.empty(batch, n, C, h)
+    U, Cand = torch.rand(batch, n, C, h, generator=g), torch.tanh(rnd(batch, n, C, h))
+    EM.spmm_sum(*csr, None, X, X2, adds, Y_w, blend=(U, Cand, dY_w))
     for pl in (plan, None):                                          # row-blocked and plain CSR kernels
         Y = torch.full((batch, n, C, h), float('nan')).cuda()
         hip.spmm_sum(*(cu(t) for t in csr), pl, cu(X), None if X2 is None else cu(X2), [(cu(t), o) for t, o in adds], Y)
         assert rel_err(Y, Y_w) < TOL
+        Y2, dY = torch.full_like(Y, float('nan')), torch.full_like(Y, float('nan'))
+        hip.spmm_sum(*(cu(t) for t in csr), pl, cu(X), None if X2 is None else cu(X2), [(cu(t), o) for t, o in adds], Y2,
+                     blend=(cu(U), cu(Cand), dY))                    # + the owning cell's blend backward in the epilogue
+        assert torch.equal(Y2, Y) and rel_err(dY, dY_w) < TOL
 
 
 def test_fused_aggregation_is_refused_off_its_shapes(hip):
