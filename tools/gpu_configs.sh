@@ -16,4 +16,5 @@ run --grid 224 --permute                              # random node order, renum
 run --grid 224 --permute --no-reorder                 # random node order as given
 run --grid 224 --batch-per-gpu 1
 run --grid 224 --batch-per-gpu 2
-run --grid 224 --batch-per-gpu 5
+run --grid 224 --batch-per-gpu 4
+run --grid 224 --batch-per-gpu 6
