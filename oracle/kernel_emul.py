@@ -149,11 +149,17 @@ class EmulatedKernels:
     def cell_planar_supported(self, Ks, Kc, Cc, h) -> bool:
         return Ks == 2 and Kc == 2 and h == 16
 
-    def cell_gates_fwd_planar(self, X, H, SX, SH, Tc, W, bias, U, Rg, RH):
+    def cell_planar_post_fused(self, Cc) -> bool:
+        return True
+
+    def cell_gates_fwd_planar(self, X, H, SX, SH, Tc, W, bias, U, Rg, RH, post=None):
         cin, h = X.shape[-1], H.shape[-1]                        # cin = h, or 1..4 (narrow input plane, layer 0)
         CandIn = torch.empty(H.shape[:-1] + (cin + h,), dtype=W.dtype)
         self.cell_gates_fwd([torch.cat([X, H], -1), torch.cat([SX, SH], -1)], Tc, W, bias, H, U, Rg, CandIn)
         RH.copy_(CandIn[..., cin:])
+        if post is not None:                                   # + the candidate's projection on [Xt | R*H]
+            Wc, bc, A, Bm = post
+            self.node_post_fwd(CandIn, Tc, Wc, bc, A, Bm)
 
     def cell_gates_bwd_planar(self, X, H, SX, SH, Tc, W, dRH, Cand, U, Rg, dHnew, dZs, dW, db, dH):
         cin, h = X.shape[-1], H.shape[-1]

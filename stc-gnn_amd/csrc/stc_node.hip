@@ -491,13 +491,16 @@ extern "C" int stc_cell_planar_supported(int32_t Ks, int32_t Kc, int32_t C, int3
 extern "C" int stc_cell_gates_fwd_planar_f32(const float* X, const float* H, const float* SX, const float* SH,
                                              const float* Tc, const float* W, const float* bias,
                                              float* U, float* Rg, float* RH,
+                                             const float* Wc, const float* bc, float* A, float* Bm,
                                              int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream) {
     if (int rc = check_dims("stc_cell_gates_fwd_planar_f32", 2, 2, C, Lw == 2 * h ? 2 * h : 20, Lw, 2 * h, nodes)) return rc;
     STC_REQUIRE(Lw == 2 * h || (Lw > h && Lw <= h + 4), STC_EINVAL, "stc_cell_gates_fwd_planar_f32: input width %d (Lw - h) must be h or 1..4", Lw - h);
     if (!stc_cell_planar_supported(2, 2, C, h)) return stc::fail(STC_EUNSUPPORTED, "stc_cell_gates_fwd_planar_f32: shape not on the planar path");
     if (nodes == 0) return STC_OK;
     STC_REQUIRE(X && H && SX && SH && Tc && W && U && Rg && RH, STC_EINVAL, "stc_cell_gates_fwd_planar_f32: null pointer");
-    const int rc = stc_cell_gates_fwd_planar_x3(X, H, SX, SH, Tc, W, bias, U, Rg, RH, nodes, C, Lw, static_cast<hipStream_t>(stream));
+    STC_REQUIRE((A == nullptr) == (Bm == nullptr) && (!A || Wc), STC_EINVAL, "stc_cell_gates_fwd_planar_f32: A, Bm and Wc go together");
+    STC_REQUIRE(!A || C == 32, STC_EUNSUPPORTED, "stc_cell_gates_fwd_planar_f32: the fused candidate projection is built for C = 32 (got %d)", C);
+    const int rc = stc_cell_gates_fwd_planar_x3(X, H, SX, SH, Tc, W, bias, U, Rg, RH, Wc, bc, A, Bm, nodes, C, Lw, static_cast<hipStream_t>(stream));
     return rc == STC_NOT_HANDLED ? stc::fail(STC_EUNSUPPORTED, "stc_cell_gates_fwd_planar_f32: operands not usable (alignment)") : rc;
 }
 

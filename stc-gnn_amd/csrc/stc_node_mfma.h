@@ -85,7 +85,9 @@ int stc_node_post_fwd_x3(const float* X, const float* X2, const float* Tc, const
 
 // Planar cell inputs (stc_node_x3.hip): the [Xt | H] rows as two contiguous (nodes, C, 16) planes each, K = 2.
 int stc_cell_gates_fwd_planar_x3(const float* X, const float* H, const float* SX, const float* SH, const float* Tc, const float* W,
-                                 const float* bias, float* U, float* R, float* RH, long long nodes, int C, int Lw, hipStream_t stream);
+                                 const float* bias, float* U, float* R, float* RH,
+                                 const float* Wc, const float* bc, float* A, float* Bm,      // A != null: + the candidate's projection (C = 32)
+                                 long long nodes, int C, int Lw, hipStream_t stream);
 int stc_cell_gates_bwd_planar_x3(const float* X, const float* H, const float* SX, const float* SH, const float* Tc, const float* W,
                                  const float* dCandIn, const float* Cand, const float* U, const float* R, const float* dHnew,
                                  float* const* dZ, float* dH, float* partial, int* n_partials, int want_db,

@@ -156,11 +156,18 @@ struct GatherArgs {
 // candidate's input then is planar too: its X plane is Xt itself and only the R*H plane (epi.CandIn, 16 wide) is written.
 // PL = 2 (L = 20): planar with a narrow input plane -- Z.p[n] = the STATE plane (nodes, C, 16), Z.q[n] = the input plane
 // (nodes, C, cin), cin = Lw - 16 <= 4; slab columns are [state | input | pad] and W's rows are permuted to match
-template <int NB2, int HB, int K, int L, int EPI, int GATHER, int PL = 0>
+// POST = 1 (planar gates kernel only): the candidate convolution's projection runs as a second stage of the same launch.
+// Its input [Xt | R*H] is already with the wave -- Xt in the row fragments it loaded, R*H in its accumulator-layout epilogue
+// registers, brought to row layout through a per-wave LDS tile -- so the post-aggregation pair A, Bm (stc_bdg_node_post_fwd_f32)
+// is written without re-reading Xt and R*H from HBM.
+struct PostArgs { const float* Wc; const float* bc; float* A; float* Bm; };
+
+template <int NB2, int HB, int K, int L, int EPI, int GATHER, int PL = 0, int POST = 0>
 __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_kernel(
     ZPtrs Z, const float* __restrict__ Tc, const float* __restrict__ W, const float* __restrict__ bias,
-    float* __restrict__ Y, int nodes, int Lw, FwdEpi epi, GatherArgs ga) {
+    float* __restrict__ Y, int nodes, int Lw, FwdEpi epi, GatherArgs ga, PostArgs post) {
     static_assert(!GATHER || K == 2, "the fused aggregation produces the first-order slab only");
+    static_assert(!POST || (PL != 0 && EPI == EPI_GATES && K == 2), "the fused candidate projection belongs to the planar gates kernel");
     constexpr int KL = GATHER ? 1 : K;                  // slabs read from HBM
     constexpr int NRB = 2 * NB2, C = 32 * NB2, Ho = 16 * HB, NCB = K * HB;
     constexpr int HID = 16;
@@ -169,6 +176,10 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32x4* Wx = reinterpret_cast<u32x4*>(smem_raw);        // [K n][NCB]          B: W[(n, c, l = slot)][o = 16 hb + x]
     u32x4* Tx = Wx + nWx * 3 * 64;                          // [K-1][NRB rb][NB2]  A: T_c[c' = 32 p + pair_row][d = 16 rb + x]
+    constexpr int nWp = POST ? K * K : 0;                   // POST: [K n][K c]    B: Wc[(n, c, l = slot)][o = x]   (Ho = 16)
+    constexpr int TRS = 20;                                 // row stride of the transpose tiles (16 + 4: conflict-free row reads)
+    u32x4* Wp = Tx + nTx * 3 * 64;
+    float* tr = reinterpret_cast<float*>(Wp + nWp * 3 * 64);   // POST: [wave][NRB][16 rows][TRS]  R*H, accumulator -> row layout
     const int tid = threadIdx.x, lane = tid & 63, x = lane & 15, g = lane >> 4;
 
     for (int idx = tid; idx < nWx * 64; idx += MF_THREADS) {
@@ -182,6 +193,17 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
             v[e] = (wl >= 0 && wl < Lw) ? W[((size_t)(n * K + c) * Lw + wl) * Ho + o] : 0.f;       // pad columns contribute nothing
         }
         put_frag(Wx, f, ll, v);
+    }
+    for (int idx = tid; idx < nWp * 64; idx += MF_THREADS) {      // the candidate's weights, same slab-column order (Ho = 16)
+        const int ll = idx & 63, f = idx >> 6, c = f % K, n = f / K, gg = ll >> 4;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int l = 8 * gg + e;
+            const int wl = PL == 2 ? stc_wrow_swapped(l, Lw - 16) : l;
+            v[e] = (wl >= 0 && wl < Lw) ? post.Wc[((size_t)(n * K + c) * Lw + wl) * 16 + (ll & 15)] : 0.f;
+        }
+        put_frag(Wp, f, ll, v);
     }
     for (int idx = tid; idx < nTx * 64; idx += MF_THREADS) {
         const int ll = idx & 63, f = idx >> 6, p = f % NB2, rb = (f / NB2) % NRB, c1 = f / (NB2 * NRB), gg = ll >> 4;
@@ -329,7 +351,56 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
                     epi.R_out[row * HID + x] = gate;
                     if (PL) epi.CandIn[row * HID + x] = gate * hv[rb][r];           // the R*H plane
                     else epi.CandIn[row * L + epi.cin + x] = gate * hv[rb][r];
+                    if (POST) tr[((wave * NRB + rb) * 16 + 4 * g + r) * TRS + x] = gate * hv[rb][r];
                 }
+            if constexpr (POST) {
+                // ---- candidate projection on [Xt | R*H] (PL = 1) / [R*H | x | pad] (PL = 2): A = sum_c T_c^T (. Wc_{0,c}) + bc, Bm likewise with Wc_{1,c}
+                __builtin_amdgcn_wave_barrier();
+                X3 zc[NRB];
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) {
+                    const float* trow = tr + ((wave * NRB + rb) * 16 + x) * TRS;          // this lane's row of R*H
+                    f32x4 a4 = kZero4, b4 = kZero4;
+                    if (PL == 1) {
+                        if (g < 2) { a4 = cur[0][rb].a; b4 = cur[0][rb].b; }              // Xt columns 8g..8g+7
+                        else { a4 = *reinterpret_cast<const f32x4*>(trow + 8 * (g - 2)); b4 = *reinterpret_cast<const f32x4*>(trow + 8 * (g - 2) + 4); }
+                    } else {
+                        if (g < 2) { a4 = *reinterpret_cast<const f32x4*>(trow + 8 * g); b4 = *reinterpret_cast<const f32x4*>(trow + 8 * g + 4); }
+                        else if (g == 2) a4 = cur[0][rb].a;                               // the narrow input columns
+                    }
+                    zc[rb] = split8(a4, b4);
+                }
+                f32x4 pa[K][NRB][K];
+#pragma unroll
+                for (int n = 0; n < K; ++n)
+#pragma unroll
+                    for (int c = 0; c < K; ++c) {
+                        const X3 w = get_frag(Wp, n * K + c, lo);
+#pragma unroll
+                        for (int rb = 0; rb < NRB; ++rb) pa[n][rb][c] = mma6(zc[rb], w, kZero4);
+                    }
+#pragma unroll
+                for (int n = 0; n < K; ++n)
+#pragma unroll
+                    for (int p = 0; p < NB2; ++p) {
+                        const X3 u = split8(pa[n][2 * p][1], pa[n][2 * p + 1][1]);
+#pragma unroll
+                        for (int rb = 0; rb < NRB; ++rb) {
+                            const X3 t = get_frag(Tx, rb * NB2 + p, lo);
+                            pa[n][rb][0] = mma6(t, u, pa[n][rb][0]);
+                        }
+                    }
+                const float bcv = post.bc ? post.bc[x] : 0.f;
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const size_t o = ((size_t)node * C + 16 * rb + 4 * g + r) * HID + x;
+                        post.A[o] = pa[0][rb][0][r] + bcv;
+                        post.Bm[o] = pa[1][rb][0][r];
+                    }
+                __builtin_amdgcn_wave_barrier();
+            }
             if (has_side) {
                 const int scol = x < epi.cin ? x : x + HID;
 #pragma unroll
@@ -909,20 +980,20 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
 }
 
 // --------------------------------------------------------------------------------------- host side
-template <int NB2, int HB, int K, int L, int EPI = EPI_NONE, int GATHER = 0, int PL = 0>
+template <int NB2, int HB, int K, int L, int EPI = EPI_NONE, int GATHER = 0, int PL = 0, int POST = 0>
 int launch_fwd(const float* const* Z, const float* Tc, const float* W, const float* bias, float* Y,
-               long long nodes, int Lw, hipStream_t stream, FwdEpi epi = FwdEpi{}, GatherArgs ga = GatherArgs{}) {
+               long long nodes, int Lw, hipStream_t stream, FwdEpi epi = FwdEpi{}, GatherArgs ga = GatherArgs{}, PostArgs post = PostArgs{}) {
     constexpr int NRB = 2 * NB2, NCB = K * HB;
-    const size_t lds = (size_t)(K * NCB + (K - 1) * NRB * NB2) * 3 * 64 * 16;
+    const size_t lds = (size_t)(K * NCB + (K - 1) * NRB * NB2 + (POST ? K * K : 0)) * 3 * 64 * 16 + (POST ? (size_t)MF_WAVES * NRB * 16 * 20 * 4 : 0);
     if (lds > stc::kMaxLdsBytes) return STC_NOT_HANDLED;
-    auto kern = node_fwd_x3_kernel<NB2, HB, K, L, EPI, GATHER, PL>;
+    auto kern = node_fwd_x3_kernel<NB2, HB, K, L, EPI, GATHER, PL, POST>;
     if (int rc = stc::hip_status(stc::allow_lds(kern, lds), "hipFuncSetAttribute(node fwd x3)")) return rc;
     static const int resident = stc::resident_blocks(kern, MF_THREADS, lds, 2);   // persistent grid = what fits at once
     ZPtrs zp{};
     for (int n = 0; n < (GATHER ? 1 : K); ++n) { zp.p[n] = Z[n]; if (PL) zp.q[n] = Z[K + n]; }      // planar: Z = {X planes, H planes}
     const long long want = (nodes + MF_WAVES - 1) / MF_WAVES;
     const int grid = (int)(want < resident ? want : resident);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(MF_THREADS), lds, stream, zp, Tc, W, bias, Y, (int)nodes, Lw, epi, ga);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(MF_THREADS), lds, stream, zp, Tc, W, bias, Y, (int)nodes, Lw, epi, ga, post);
     STC_LAUNCH_CHECK("node_fwd_x3 launch");
     return STC_OK;
 }
@@ -1209,22 +1280,29 @@ int stc_node_post_fwd_x3(const float* X, const float* X2, const float* Tc, const
 
 // ---- planar cell inputs (K = 2, rows of 16 + 16 columns): Z = {X plane, S.X plane, H plane, S.H plane} in launch order {p[0], p[1], q[0], q[1]}
 int stc_cell_gates_fwd_planar_x3(const float* X, const float* H, const float* SX, const float* SH, const float* Tc, const float* W,
-                                 const float* bias, float* U, float* R, float* RH, long long nodes, int C, int Lw, hipStream_t stream) {
+                                 const float* bias, float* U, float* R, float* RH,
+                                 const float* Wc, const float* bc, float* A, float* Bm,
+                                 long long nodes, int C, int Lw, hipStream_t stream) {
     const int cin = Lw - 16;
+    const PostArgs post{Wc, bc, A, Bm};
+    const bool fused = A != nullptr;             // also the candidate's projection (A, Bm) in this launch
+    if (fused && !(Wc && Bm && stc::aligned16(A) && stc::aligned16(Bm))) return STC_NOT_HANDLED;
     if (!x3_cell_shape(2, C, cin == 16 ? 32 : 20, nodes) || !(cin == 16 || (cin >= 1 && cin <= 4))) return STC_NOT_HANDLED;
     FwdEpi epi{};
     epi.H = H; epi.U_out = U; epi.R_out = R; epi.CandIn = RH; epi.cin = cin;
     if (cin == 16) {
         const float* Z[4] = {X, SX, H, SH};
         if (!all_aligned16(Z, 4)) return STC_NOT_HANDLED;
+        if (C == 32 && fused) return launch_fwd<1, 2, 2, 32, EPI_GATES, 0, 1, 1>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi, GatherArgs{}, post);
         if (C == 32) return launch_fwd<1, 2, 2, 32, EPI_GATES, 0, 1>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi);
-        if (C == 64) return launch_fwd<2, 2, 2, 32, EPI_GATES, 0, 1>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi);
+        if (C == 64 && !fused) return launch_fwd<2, 2, 2, 32, EPI_GATES, 0, 1>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi);
         return STC_NOT_HANDLED;
     }
     const float* Z[4] = {H, SH, X, SX};          // narrow input: the STATE plane leads, columns [H | Xt | pad]
     if (!stc::aligned16(H) || !stc::aligned16(SH)) return STC_NOT_HANDLED;
+    if (C == 32 && fused) return launch_fwd<1, 2, 2, 20, EPI_GATES, 0, 2, 1>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi, GatherArgs{}, post);
     if (C == 32) return launch_fwd<1, 2, 2, 20, EPI_GATES, 0, 2>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi);
-    if (C == 64) return launch_fwd<2, 2, 2, 20, EPI_GATES, 0, 2>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi);
+    if (C == 64 && !fused) return launch_fwd<2, 2, 2, 20, EPI_GATES, 0, 2>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi);
     return STC_NOT_HANDLED;
 }
 

@@ -65,7 +65,7 @@ def _declare(lib):
         'stc_bdg_node_bwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, C.POINTER(_p), _p, _p, _p,
                                  _p, C.c_size_t, _i64, _i32, _i32, _i32, _i32, _p],
         'stc_bdg_node_post_fwd_f32': [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
-        'stc_cell_gates_fwd_planar_f32': [_p] * 10 + [_i64, _i32, _i32, _i32, _p],
+        'stc_cell_gates_fwd_planar_f32': [_p] * 14 + [_i64, _i32, _i32, _i32, _p],
         'stc_cell_gates_bwd_planar_f32': [_p] * 11 + [C.POINTER(_p), _p, _p, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _p],
         'stc_spmm_blend_fwd_f32': [_p] * 6 + [_i32, _i32] + [_p] * 6 + [_p, _i32, _i32, _p, _i32, _p, _i32, _i32] + [_i32] * 3 + [_p],
         'stc_bdg_node_post_bwd_f32': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _i32, _p],
@@ -500,8 +500,13 @@ class HipKernels:
             self._f32(f'{what}.{name}', t, (R, Cc, cin))
         return R, Cc, h, cin
 
-    def cell_gates_fwd_planar(self, X, H, SX, SH, Tc, W, bias, U, Rg, RH):
-        """Gates convolution on planar inputs; writes U, Rg and the R*H plane (the candidate's input is (X, RH))."""
+    def cell_planar_post_fused(self, Cc) -> bool:
+        """Whether cell_gates_fwd_planar can also run the candidate's projection (``post=``) for this category count."""
+        return Cc == 32
+
+    def cell_gates_fwd_planar(self, X, H, SX, SH, Tc, W, bias, U, Rg, RH, post=None):
+        """Gates convolution on planar inputs; writes U, Rg and the R*H plane (the candidate's input is (X, RH)).
+        ``post`` = (Wc, bc, A, Bm): the same launch also writes the candidate's post-aggregation pair A, Bm."""
         R, Cc, h, cin = self._planes('planar', X, H, SX, SH)
         self._f32('planar.Tc', Tc, (2, Cc, Cc))
         self._f32('planar.W', W)
@@ -511,9 +516,17 @@ class HipKernels:
             self._f32('planar.bias', bias, (2 * h,))
         for name, t in (('U', U), ('Rg', Rg), ('RH', RH)):
             self._f32('planar.' + name, t, (R, Cc, h))
-        self._same_device(X, H, SX, SH, Tc, W, bias, U, Rg, RH)
+        Wc = bc = A = Bm = None
+        if post is not None:
+            Wc, bc, A, Bm = post
+            self._f32('planar.Wc', Wc, (4 * (cin + h), h))
+            if bc is not None:
+                self._f32('planar.bc', bc, (h,))
+            for name, t in (('A', A), ('Bm', Bm)):
+                self._f32('planar.' + name, t, (R, Cc, h))
+        self._same_device(X, H, SX, SH, Tc, W, bias, U, Rg, RH, Wc, bc, A, Bm)
         self._launch('stc_cell_gates_fwd_planar_f32', H, _ptr(X), _ptr(H), _ptr(SX), _ptr(SH), _ptr(Tc), _ptr(W), _ptr(bias),
-                     _ptr(U), _ptr(Rg), _ptr(RH), R, Cc, cin + h, h)
+                     _ptr(U), _ptr(Rg), _ptr(RH), _ptr(Wc), _ptr(bc), _ptr(A), _ptr(Bm), R, Cc, cin + h, h)
 
     def cell_gates_bwd_planar(self, X, H, SX, SH, Tc, W, dRH, Cand, U, Rg, dHnew, dZs, dW, db, dH):
         """``dRH``: gradient of the R*H plane; ``dZs`` = [d X plane, d SX plane, d H plane, d SH plane] (the first two

@@ -432,6 +432,7 @@ def stc_cell(Xt, H, op: SpatialOperand, Tc, Wg, bg, Wc, bc, Ks: int):
 
 # ----------------------------------------------------------------------------- a whole schedule of cells as ONE autograd node
 _CELL_GRAPH = os.environ.get('STC_CELL_GRAPH', '1') != '0'
+_FUSE_POST = os.environ.get('STC_FUSE_POST', '1') != '0'        # candidate projection as a second stage of the planar gates forward
 _PLANAR = os.environ.get('STC_PLANAR', '1') != '0'              # cells with 16 + 16-column inputs read them as two planes (no concat, shared S.state)
 _POST_AGG = os.environ.get('STC_POST_AGG', '1') != '0'          # candidate convolution as Y = A + S.Bm (narrow SpMM after the node kernel)
 
@@ -546,10 +547,13 @@ class _StcCellGraph(Function):
             Hnew = _alias_slice(out_stack, out_slot[j]) if j in out_slot else torch.empty_like(Hprev)
             if planar[j]:
                 Xp, SXp, SHp, RH = source(x), aggregated(x), aggregated(hs), torch.empty_like(Hprev)
-                k.cell_gates_fwd_planar(*rows((Xp, Hprev, SXp, SHp)), Tc, Wg, bg, *rows((U, Rg, RH)))
                 A, Bm = torch.empty_like(Hprev), torch.empty_like(Hprev)
-                lead, second = (Xp, RH) if cin[j] == h else (RH, Xp)     # narrow input plane: the 16-wide plane leads
-                k.node_post_fwd(*rows((lead,)), Tc, Wc, bc, *rows((A, Bm)), X2=second.view(B * N, C, second.shape[-1]))
+                if _FUSE_POST and k.cell_planar_post_fused(C):        # the candidate's projection rides in the gates launch
+                    k.cell_gates_fwd_planar(*rows((Xp, Hprev, SXp, SHp)), Tc, Wg, bg, *rows((U, Rg, RH)), post=(Wc, bc, *rows((A, Bm))))
+                else:
+                    k.cell_gates_fwd_planar(*rows((Xp, Hprev, SXp, SHp)), Tc, Wg, bg, *rows((U, Rg, RH)))
+                    lead, second = (Xp, RH) if cin[j] == h else (RH, Xp)     # narrow input plane: the 16-wide plane leads
+                    k.node_post_fwd(*rows((lead,)), Tc, Wc, bc, *rows((A, Bm)), X2=second.view(B * N, C, second.shape[-1]))
                 k.spmm_blend_fwd(op.fwd_rowptr, op.fwd_colidx, fwd_val, op.fwd_plan, Bm, A, U, Hprev, Cand, Hnew, copies=copies, side=side)
                 del A, Bm
                 saved += [Hprev, U, Rg, Cand, Xp, SXp, SHp, RH]

@@ -531,6 +531,12 @@ def test_planar_cell_kernels(hip, nodes, C):
     A, Bm = nan(nodes, C, h), nan(nodes, C, h)
     hip.node_post_fwd(cu(X), cu(Tc), cu(Wc), cu(bc), A, Bm, X2=cu(RH_w))
     assert rel_err(A, A_w) < TOL and rel_err(Bm, B_w) < TOL
+    if hip.cell_planar_post_fused(C):          # the same pair from the gates launch itself (candidate projection as its second stage)
+        U2, R2, RH2, A2, B2 = (nan(nodes, C, h) for _ in range(5))
+        hip.cell_gates_fwd_planar(cu(X), cu(H), cu(SX), cu(SH), cu(Tc), cu(Wg), cu(bg), U2, R2, RH2, post=(cu(Wc), cu(bc), A2, B2))
+        assert torch.equal(U2, U) and torch.equal(RH2, RH) and rel_err(A2, A_w) < TOL and rel_err(B2, B_w) < TOL
+        hip.cell_gates_fwd_planar(cu(X), cu(H), cu(SX), cu(SH), cu(Tc), cu(Wg), cu(bg), U2, R2, RH2, post=(cu(Wc), None, A2, B2))
+        assert rel_err(A2, A_w - bc) < TOL
     dA, dB = rnd(nodes, C, h), rnd(nodes, C, h)
     dX_w, dX2_w, dWc_w, dbc_w = torch.empty(nodes, C, h), torch.empty(nodes, C, h), torch.empty_like(Wc), torch.empty(h)
     EM.node_post_bwd(X, Tc, Wc, dA, dB, dX_w, dWc_w, dbc_w, X2=RH_w, dX2=dX2_w)
@@ -574,6 +580,10 @@ def test_planar_cell_kernels_narrow_input(hip, nodes, C, cin):
     A, Bm = nan(nodes, C, h), nan(nodes, C, h)
     hip.node_post_fwd(cu(RH_w), cu(Tc), cu(Wc), cu(bc), A, Bm, X2=cu(X))
     assert rel_err(A, A_w) < TOL and rel_err(Bm, B_w) < TOL
+    if hip.cell_planar_post_fused(C):
+        U2, R2, RH2, A2, B2 = (nan(nodes, C, h) for _ in range(5))
+        hip.cell_gates_fwd_planar(cu(X), cu(H), cu(SX), cu(SH), cu(Tc), cu(Wg), cu(bg), U2, R2, RH2, post=(cu(Wc), cu(bc), A2, B2))
+        assert torch.equal(U2, U) and torch.equal(RH2, RH) and rel_err(A2, A_w) < TOL and rel_err(B2, B_w) < TOL
     dA, dB = rnd(nodes, C, h), rnd(nodes, C, h)
     dX_w, dWc_w, dbc_w = torch.empty(nodes, C, h), torch.empty_like(Wc), torch.empty(h)
     EM.node_post_bwd(RH_w, Tc, Wc, dA, dB, dX_w, dWc_w, dbc_w, X2=X)
