@@ -383,3 +383,59 @@ def test_cell_graph_equals_the_per_cell_path(dev, monkeypatch, layers, T, horizo
     assert set(g1) == set(g0)
     for n in g0:
         _close(g1[n], g0[n], 2e-6, f'cell-graph d{n} vs per-cell', gpu_tol=5e-6)
+
+
+@pytest.mark.parametrize('planar,post_agg', [(True, True), (False, True), (False, False)])
+def test_cell_graph_general_schedules_match_autograd(dev, monkeypatch, planar, post_agg):
+    """``ops.stc_cell_graph`` on schedules STCGNN never builds -- a state consumed by FOUR cells (twice as input, twice as state),
+    a cell fed by the same state on both sides, external inputs of both widths -- against the same DAG composed from
+    ``ops.stc_cell`` with autograd doing the bookkeeping.  Exercises the overflow paths of the state copies and of the
+    gradient pieces (more consumers than the kernels take destinations / addends for)."""
+    monkeypatch.setattr(ops, '_PLANAR', planar)
+    monkeypatch.setattr(ops, '_POST_AGG', post_agg)
+    C = 32 if DEV == 'cuda' else 4
+    Hh, Ww, h, K, B = 4, 5, 16, 2, 2
+    N = Hh * Ww
+    torch.manual_seed(77)
+    graph = CsrGraph.queen_grid(Hh, Ww, normalize=True)
+    pair = M._graphs(graph, torch.softmax(torch.randn(C, C), -1).to(DEV), K, K)
+    wide = M.STC_Cell(N, C, K, K, h, h).to(DEV)               # 16 + 16 columns
+    narrow = M.STC_Cell(N, C, K, K, 1, h).to(DEV)             # 1 + 16 columns
+    x0 = torch.rand(B, N, C, 1).to(DEV)
+    xw = torch.rand(B, N, C, h).to(DEV)
+    h0 = torch.rand(B, N, C, h).to(DEV)
+    #        stack, Xt source,   H source
+    schedule = [(1, ('ext', 0), ('ext', 2)),      # 0: narrow cell on external input and state
+                (0, ('ext', 1), ('cell', 0)),     # 1: wide, state from 0
+                (0, ('cell', 0), ('cell', 0)),    # 2: wide, both sides from 0
+                (0, ('cell', 0), ('cell', 1)),    # 3: wide, input from 0 (its third consumer), state from 1
+                (1, ('ext', 0), ('cell', 0)),     # 4: narrow, state from 0 (fourth consumer)
+                (0, ('cell', 2), ('cell', 3)),    # 5
+                (0, ('cell', 4), ('cell', 5))]    # 6
+    outputs = [6, 3]
+    cells = (wide, narrow)
+    stacks = [(c.gates.W, c.gates.b, c.candi.W, c.candi.b) for c in cells]
+    Rw = torch.randn(len(outputs), B, N, C, h).to(DEV)
+
+    def grads():
+        g = {}
+        for i, c in enumerate(cells):
+            for n, p in c.named_parameters():
+                g[f'{i}.{n}'] = p.grad.detach().clone()
+                p.grad = None
+        return g
+
+    got = ops.stc_cell_graph(pair.spatial, pair.Tc, K, schedule, outputs, [x0, xw, h0], stacks)
+    (got * Rw).sum().backward()
+    g1 = grads()
+    ext = [x0, xw, h0]
+    state = []
+    for s_id, xs, hs in schedule:
+        src = lambda t: ext[t[1]] if t[0] == 'ext' else state[t[1]]
+        state.append(cells[s_id](pair, None, src(xs), src(hs)))
+    want = torch.stack([state[j] for j in outputs])
+    (want * Rw).sum().backward()
+    g0 = grads()
+    _close(got, want, 2e-6, 'general schedule: states', gpu_tol=3e-6)
+    for n in g0:
+        _close(g1[n], g0[n], 3e-6, f'general schedule: d{n}', gpu_tol=6e-6)
