@@ -103,7 +103,8 @@ def test_trainer_on_the_gpu_reproduces_the_reference_epoch_losses(tmp_path, monk
 
 
 @pytest.mark.gpu
-def test_hip_graph_replay_of_a_train_step_equals_eager(monkeypatch):
+@pytest.mark.parametrize('C', [5, 32])       # 5: one autograd node per cell (generic kernels); 32: the planar cell graph
+def test_hip_graph_replay_of_a_train_step_equals_eager(monkeypatch, C):
     """The whole step (forward, ComboLoss, backward, Adam) captured with torch.cuda.graph: every launch goes to the
     capturing stream and allocates only through torch, so replay must reproduce the eager parameters bit for bit."""
     import STC_GNN as M
@@ -114,15 +115,15 @@ def test_hip_graph_replay_of_a_train_step_equals_eager(monkeypatch):
 
     def build():
         torch.manual_seed(5)
-        model = M.STCGNN(64, 5, 2, 2, 1, 16, 2, 2, graph_mode='csr-fixed').to(dev)
+        model = M.STCGNN(64, C, 2, 2, 1, 16, 2, 2, graph_mode='csr-fixed').to(dev)
         opt = torch.optim.Adam(model.parameters(), lr=2e-3, weight_decay=1e-4, capturable=True)
         return model, opt
 
     graph = CsrGraph.queen_grid(8, 8, device=dev)
     gen = torch.Generator().manual_seed(1)
-    X = (torch.rand(4, 3, 64, 5, generator=gen) < 0.3).float().to(dev)
-    Y = (torch.rand(4, 2, 64, 5, generator=gen) < 0.3).float().to(dev)
-    Gc = torch.softmax(torch.randn(5, 5, generator=gen), -1).to(dev)
+    X = (torch.rand(4, 3, 64, C, generator=gen) < 0.3).float().to(dev)
+    Y = (torch.rand(4, 2, 64, C, generator=gen) < 0.3).float().to(dev)
+    Gc = torch.softmax(torch.randn(C, C, generator=gen), -1).to(dev)
     crit = ComboLoss()
 
     def make_step(model, opt):
