@@ -225,70 +225,61 @@ inline bool vec_ok(std::initializer_list<const void*> ptrs, std::initializer_lis
 constexpr int HEAD_MAX_H = 64;
 constexpr int HEAD_PARTS = 1024;
 
+// LPR lanes share a row of h floats, one 16-byte piece each: a wave instruction then moves 1 KiB of CONTIGUOUS memory
+// (one thread per row made every instruction touch 64 different 64-byte rows: 2.6 TB/s instead of ~5).
+template <int LPR>
 __global__ __launch_bounds__(EW_THREADS) void head_fwd_kernel(const float* __restrict__ H, const float* __restrict__ w,
                                                                const float* __restrict__ b, float* __restrict__ y,
                                                                long long rows, int h) {
-    __shared__ float sw[HEAD_MAX_H + 1];
-    if ((int)threadIdx.x < h) sw[threadIdx.x] = w[threadIdx.x];
-    if (threadIdx.x == 0) sw[HEAD_MAX_H] = b[0];
-    __syncthreads();
-    const int h4 = h / 4;
-    for (long long r = (long long)blockIdx.x * EW_THREADS + threadIdx.x; r < rows; r += (long long)gridDim.x * EW_THREADS) {
-        const float4* row = reinterpret_cast<const float4*>(H + r * h);
-        float s = sw[HEAD_MAX_H];
-        for (int k = 0; k < h4; ++k) {
-            const float4 v = row[k];
-            s = fmaf(v.x, sw[4 * k], fmaf(v.y, sw[4 * k + 1], fmaf(v.z, sw[4 * k + 2], fmaf(v.w, sw[4 * k + 3], s))));
+    constexpr int RPB = EW_THREADS / LPR;              // rows per workgroup pass
+    const int h4 = h / 4, q = threadIdx.x % LPR;
+    float4 wq = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < h4) wq = reinterpret_cast<const float4*>(w)[q];
+    const float bias = b[0];
+    for (long long r = (long long)blockIdx.x * RPB + threadIdx.x / LPR; r < rows; r += (long long)gridDim.x * RPB) {
+        float s = 0.f;
+        if (q < h4) {
+            const float4 v = reinterpret_cast<const float4*>(H + r * h)[q];
+            s = fmaf(v.x, wq.x, fmaf(v.y, wq.y, fmaf(v.z, wq.z, v.w * wq.w)));
         }
-        y[r] = sigmoidf_(s);
+#pragma unroll
+        for (int off = LPR / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (q == 0) y[r] = sigmoidf_(s + bias);
     }
 }
 
 // dH = g * w (streamed); per-workgroup partial sums of dw | db in a fixed order -> workspace[block][h+1]
+template <int LPR>
 __global__ __launch_bounds__(EW_THREADS) void head_bwd_kernel(const float* __restrict__ H, const float* __restrict__ w,
                                                                const float* __restrict__ y, const float* __restrict__ dy,
                                                                float* __restrict__ dH, float* __restrict__ partial,
                                                                long long rows, int h) {
-    __shared__ float sw[HEAD_MAX_H];
-    __shared__ float red[EW_THREADS / 64][HEAD_MAX_H + 1];
-    if ((int)threadIdx.x < h) sw[threadIdx.x] = w[threadIdx.x];
-    __syncthreads();
-    const int h4 = h / 4;
-    float acc[HEAD_MAX_H + 1];
-#pragma unroll
-    for (int k = 0; k <= HEAD_MAX_H; ++k) acc[k] = 0.f;
-    for (long long r = (long long)blockIdx.x * EW_THREADS + threadIdx.x; r < rows; r += (long long)gridDim.x * EW_THREADS) {
+    constexpr int RPB = EW_THREADS / LPR;
+    __shared__ float red[EW_THREADS][5];
+    const int h4 = h / 4, q = threadIdx.x % LPR;
+    float4 wq = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < h4) wq = reinterpret_cast<const float4*>(w)[q];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float accg = 0.f;
+    for (long long r = (long long)blockIdx.x * RPB + threadIdx.x / LPR; r < rows; r += (long long)gridDim.x * RPB) {
         const float yy = y[r];
         const float g = dy[r] * yy * (1.f - yy);
-        const float4* row = reinterpret_cast<const float4*>(H + r * h);
-        float4* out = reinterpret_cast<float4*>(dH + r * h);
-        acc[HEAD_MAX_H] += g;
-#pragma unroll
-        for (int k = 0; k < HEAD_MAX_H / 4; ++k) {
-            if (k < h4) {
-                const float4 v = row[k];
-                out[k] = make_float4(g * sw[4 * k], g * sw[4 * k + 1], g * sw[4 * k + 2], g * sw[4 * k + 3]);
-                acc[4 * k] = fmaf(g, v.x, acc[4 * k]);
-                acc[4 * k + 1] = fmaf(g, v.y, acc[4 * k + 1]);
-                acc[4 * k + 2] = fmaf(g, v.z, acc[4 * k + 2]);
-                acc[4 * k + 3] = fmaf(g, v.w, acc[4 * k + 3]);
-            }
+        if (q == 0) accg += g;
+        if (q < h4) {
+            const float4 v = reinterpret_cast<const float4*>(H + r * h)[q];
+            reinterpret_cast<float4*>(dH + r * h)[q] = make_float4(g * wq.x, g * wq.y, g * wq.z, g * wq.w);
+            acc.x = fmaf(g, v.x, acc.x); acc.y = fmaf(g, v.y, acc.y); acc.z = fmaf(g, v.z, acc.z); acc.w = fmaf(g, v.w, acc.w);
         }
     }
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-#pragma unroll
-    for (int k = 0; k <= HEAD_MAX_H; ++k) {
-        if (k < h || k == HEAD_MAX_H) {
-            const float v = stc_wave_sum(acc[k]);
-            if (lane == 0) red[wave][k] = v;
-        }
-    }
+    red[threadIdx.x][0] = acc.x; red[threadIdx.x][1] = acc.y; red[threadIdx.x][2] = acc.z; red[threadIdx.x][3] = acc.w;
+    red[threadIdx.x][4] = accg;
     __syncthreads();
-    if ((int)threadIdx.x <= h) {
-        const int k = (int)threadIdx.x < h ? threadIdx.x : HEAD_MAX_H;
-        float v = red[0][k];
-        for (int wv = 1; wv < EW_THREADS / 64; ++wv) v += red[wv][k];
-        partial[(size_t)blockIdx.x * (h + 1) + threadIdx.x] = v;
+    if ((int)threadIdx.x <= h) {                      // element k of dw (k < h) or db (k == h): its lanes in a fixed order
+        const int k = threadIdx.x;
+        const int lane_q = k < h ? k / 4 : 0, comp = k < h ? k % 4 : 4;
+        float v = 0.f;
+        for (int t = lane_q; t < EW_THREADS; t += LPR) v += red[t][comp];
+        partial[(size_t)blockIdx.x * (h + 1) + k] = v;
     }
 }
 
@@ -456,7 +447,11 @@ extern "C" int stc_head_fwd_f32(const float* H, const float* w, const float* b, 
     STC_REQUIRE(h >= 4 && h <= HEAD_MAX_H && h % 4 == 0, STC_ELIMIT, "stc_head_fwd_f32: h=%d must be a multiple of 4 in [4,%d]", h, HEAD_MAX_H);
     STC_EW_PROLOGUE("stc_head_fwd_f32", rows, H && w && b && y);
     STC_REQUIRE(stc::aligned16(H), STC_EALIGN, "stc_head_fwd_f32: H not 16-byte aligned");
-    hipLaunchKernelGGL(head_fwd_kernel, ew_grid(rows), dim3(EW_THREADS), 0, s, H, w, b, y, (long long)rows, h);
+    STC_REQUIRE(stc::aligned16(w), STC_EALIGN, "stc_head_fwd_f32: w not 16-byte aligned");
+    const int h4 = h / 4;
+#define STC_HEAD_FWD(LPR_) hipLaunchKernelGGL(head_fwd_kernel<LPR_>, ew_grid(rows * LPR_), dim3(EW_THREADS), 0, s, H, w, b, y, (long long)rows, h)
+    if (h4 <= 1) STC_HEAD_FWD(1); else if (h4 <= 2) STC_HEAD_FWD(2); else if (h4 <= 4) STC_HEAD_FWD(4); else if (h4 <= 8) STC_HEAD_FWD(8); else STC_HEAD_FWD(16);
+#undef STC_HEAD_FWD
     STC_LAUNCH_CHECK("stc_head_fwd_f32 launch");
     return STC_OK;
 }
@@ -473,10 +468,15 @@ extern "C" int stc_head_bwd_f32(const float* H, const float* w, const float* y, 
     STC_REQUIRE(stc::aligned16(H) && stc::aligned16(dH) && workspace && stc::aligned16(workspace), STC_EALIGN,
                 "stc_head_bwd_f32: H/dH/workspace must be 16-byte aligned");
     STC_REQUIRE(workspace_bytes >= stc_head_bwd_workspace_bytes(h), STC_EINVAL, "stc_head_bwd_f32: workspace too small");
-    long long blocks = (rows + EW_THREADS - 1) / EW_THREADS;
+    STC_REQUIRE(stc::aligned16(w), STC_EALIGN, "stc_head_bwd_f32: w not 16-byte aligned");
+    const int h4 = h / 4;
+    const int lpr = h4 <= 1 ? 1 : h4 <= 2 ? 2 : h4 <= 4 ? 4 : h4 <= 8 ? 8 : 16;
+    long long blocks = (rows * lpr + EW_THREADS - 1) / EW_THREADS;
     const int grid = (int)(blocks < HEAD_PARTS ? blocks : HEAD_PARTS);
     float* partial = static_cast<float*>(workspace);
-    hipLaunchKernelGGL(head_bwd_kernel, dim3(grid), dim3(EW_THREADS), 0, s, H, w, y, dy, dH, partial, (long long)rows, h);
+#define STC_HEAD_BWD(LPR_) hipLaunchKernelGGL(head_bwd_kernel<LPR_>, dim3(grid), dim3(EW_THREADS), 0, s, H, w, y, dy, dH, partial, (long long)rows, h)
+    if (lpr == 1) STC_HEAD_BWD(1); else if (lpr == 2) STC_HEAD_BWD(2); else if (lpr == 4) STC_HEAD_BWD(4); else if (lpr == 8) STC_HEAD_BWD(8); else STC_HEAD_BWD(16);
+#undef STC_HEAD_BWD
     hipLaunchKernelGGL(head_reduce_kernel, dim3(h + 1), dim3(EW_THREADS), 0, s, partial, grid, h + 1, dwb);
     STC_LAUNCH_CHECK("stc_head_bwd_f32 launch");
     return STC_OK;
