@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define STC_ABI_VERSION 9
+#define STC_ABI_VERSION 10
 #define STC_MAX_K 4          /* highest Chebyshev order (Ks, Kc) the node kernels accept */
 
 #define STC_OK 0
@@ -69,6 +69,21 @@ int stc_bcsr_spmm_f32(const int32_t* blk_ptr, const int32_t* blk_cols, const flo
                       int32_t n_rows, int32_t n_cols,
                       const float* X, const float* Y0, float* Y,
                       int32_t batch, int32_t F, float alpha, float beta, void* stream);
+
+/* ---- bf16 storage (BASELINE.json configuration 5: N = 50 176, C = 64, bf16) ------------------------------------
+ * The same two products with the feature rows stored in bf16: X, Y0, Y are bf16 (2 bytes per element, passed as
+ * void*), the graph values, every product and the row sums are fp32, and the result is rounded to bf16 once (round to
+ * nearest even).  A bf16 value widens to fp32 exactly, so these equal the fp32 entry points run on the same
+ * bf16-valued inputs up to that one final rounding.  F must be a multiple of 8 (16-byte pieces); 16-byte aligned
+ * operands.  The reference has no bf16 behaviour of its own (it builds an fp32 identity, STC_GNN.py:26). */
+int stc_csr_spmm_bf16(const int32_t* rowptr, const int32_t* colidx, const float* val,
+                      int32_t n_rows, int32_t n_cols,
+                      const void* X, const void* Y0, void* Y,
+                      int32_t batch, int32_t F, float alpha, float beta, void* stream);
+int stc_bcsr_spmm_bf16(const int32_t* blk_ptr, const int32_t* blk_cols, const float* blk_vals,
+                       int32_t n_rows, int32_t n_cols,
+                       const void* X, const void* Y0, void* Y,
+                       int32_t batch, int32_t F, float alpha, float beta, void* stream);
 
 /* Backward products of an STC_Cell with the element-wise consumer folded into the epilogue (autograd of
  * STC_GNN.py:68-75).  Rows are node rows of C categories x (cin + h + pad) features (the [Xt | H | 0-pad]

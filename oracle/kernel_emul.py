@@ -46,6 +46,12 @@ class EmulatedKernels:
             out = out + beta * Y0
         Y.copy_(out)
 
+    # ---- stc_csr/bcsr_spmm_bf16: the same product on bf16-stored rows, fp32 sums, one rounding at the end
+    def csr_spmm_bf16(self, rowptr, colidx, val, n_rows, n_cols, X, Y0, Y, alpha, beta, plan=None):
+        out = torch.empty(Y.shape, dtype=torch.float32)
+        self.csr_spmm(rowptr, colidx, val, n_rows, n_cols, X.float(), None if Y0 is None else Y0.float(), out, alpha, beta)
+        Y.copy_(out.to(torch.bfloat16))
+
     # ---- stc_spmm_bwd_gates/split_f32: backward products with their element-wise consumer in the epilogue
     def spmm_bwd_gates(self, rowptr, colidx, val, plan, X, Y0, dU, H, U, Rg, dH_in, dG, dXt, dH):
         B, n, F = X.shape

@@ -19,13 +19,13 @@ import torch
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG_ROOT, 'libstc_hip.so')
-ABI_VERSION = 9
+ABI_VERSION = 10
 MAX_K = 4
 
 #: every symbol ``include/stc_hip.h`` declares (the CPU test-suite checks the .so exports them all)
 EXPORTS = (
     'stc_version', 'stc_last_error',
-    'stc_csr_spmm_f32', 'stc_bcsr_spmm_f32', 'stc_spmm_bwd_gates_f32', 'stc_spmm_bwd_split_f32', 'stc_csr_sddmm_f32',
+    'stc_csr_spmm_f32', 'stc_bcsr_spmm_f32', 'stc_csr_spmm_bf16', 'stc_bcsr_spmm_bf16', 'stc_spmm_bwd_gates_f32', 'stc_spmm_bwd_split_f32', 'stc_csr_sddmm_f32',
     'stc_cheby_dense_fwd_f32', 'stc_cheby_dense_bwd_f32',
     'stc_bdg_node_fwd_f32', 'stc_bdg_node_bwd_workspace_bytes', 'stc_bdg_node_bwd_f32',
     'stc_bdg_node_post_supported', 'stc_bdg_node_post_fwd_f32', 'stc_bdg_node_post_bwd_f32', 'stc_spmm_blend_fwd_f32',
@@ -56,6 +56,8 @@ def _declare(lib):
     sig = {
         'stc_csr_spmm_f32': [_p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _f32, _p],
         'stc_bcsr_spmm_f32': [_p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _f32, _p],
+        'stc_csr_spmm_bf16': [_p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _f32, _p],
+        'stc_bcsr_spmm_bf16': [_p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _f32, _p],
         'stc_spmm_bwd_gates_f32': [_p] * 6 + [_i32, _i32] + [_p] * 10 + [_i32] * 5 + [_p],
         'stc_spmm_bwd_split_f32': [_p] * 6 + [_i32, _i32] + [_p] * 6 + [_i32] * 5 + [_p],
         'stc_csr_sddmm_f32': [_p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _i32, _p],
@@ -199,6 +201,18 @@ class HipKernels:
         return t
 
     @staticmethod
+    def _bf16(name, t, shape=None):
+        if not isinstance(t, torch.Tensor) or not t.is_cuda:
+            raise StcError(f'{name}: expected a ROCm (cuda) tensor; no CPU fallback')
+        if t.dtype != torch.bfloat16:
+            raise StcError(f'{name}: expected bfloat16, got {t.dtype}')
+        if not t.is_contiguous():
+            raise StcError(f'{name}: tensor must be contiguous')
+        if shape is not None and tuple(t.shape) != tuple(shape):
+            raise StcError(f'{name}: shape {tuple(t.shape)}, expected {tuple(shape)}')
+        return t
+
+    @staticmethod
     def _i32(name, t, numel=None):
         if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.int32 or not t.is_contiguous():
             raise StcError(f'{name}: expected a contiguous int32 ROCm tensor')
@@ -245,6 +259,32 @@ class HipKernels:
             return
         self._launch('stc_csr_spmm_f32', X, _ptr(rowptr), _ptr(colidx), _ptr(val), n_rows, n_cols, _ptr(X), _ptr(Y0), _ptr(Y), B, F, float(alpha), float(beta),
                      nbytes=nbytes)
+
+    def csr_spmm_bf16(self, rowptr, colidx, val, n_rows, n_cols, X, Y0, Y, alpha, beta, plan=None):
+        """bf16-storage form of ``csr_spmm`` (stc_csr_spmm_bf16 / stc_bcsr_spmm_bf16): X, Y0, Y bfloat16 with F % 8 == 0,
+        graph values fp32, fp32 sums, one rounding at the end."""
+        B, nc, F = X.shape
+        self._bf16('spmm_bf16.X', X, (B, n_cols, F))
+        self._bf16('spmm_bf16.Y', Y, (B, n_rows, F))
+        if Y0 is not None:
+            self._bf16('spmm_bf16.Y0', Y0, (B, n_rows, F))
+        if F % 8:
+            raise StcError(f'spmm_bf16: F = {F} must be a multiple of 8')
+        self._i32('spmm.rowptr', rowptr, n_rows + 1)
+        self._i32('spmm.colidx', colidx)
+        self._f32('spmm.val', val, (colidx.numel(),))
+        self._same_device(rowptr, colidx, val, X, Y0, Y)
+        nbytes = colidx.numel() * 8 + 4 * (n_rows + 1) + (2 if Y0 is None or beta == 0 else 3) * 2 * B * n_rows * F
+        if plan is not None:
+            blk_ptr, blk_cols, blk_vals = plan
+            self._i32('spmm.blk_ptr', blk_ptr, (n_rows + 3) // 4 + 1)
+            self._i32('spmm.blk_cols', blk_cols)
+            self._f32('spmm.blk_vals', blk_vals, (blk_cols.numel(), 4))
+            self._launch('stc_bcsr_spmm_bf16', X, _ptr(blk_ptr), _ptr(blk_cols), _ptr(blk_vals), n_rows, n_cols,
+                         _ptr(X), _ptr(Y0), _ptr(Y), B, F, float(alpha), float(beta), nbytes=nbytes)
+            return
+        self._launch('stc_csr_spmm_bf16', X, _ptr(rowptr), _ptr(colidx), _ptr(val), n_rows, n_cols, _ptr(X), _ptr(Y0), _ptr(Y), B, F,
+                     float(alpha), float(beta), nbytes=nbytes)
 
     def _graph_ptrs(self, rowptr, colidx, val, plan, n_rows):
         self._i32('spmm.rowptr', rowptr, n_rows + 1)

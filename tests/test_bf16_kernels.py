@@ -1,0 +1,134 @@
+"""-m gpu: the bf16-storage kernels (BASELINE.json configuration 5) through the C ABI.
+
+The reference has no bf16 behaviour, so the contract is the build's own: a bf16-storage kernel equals the
+fp32 kernel run on the same bf16-valued inputs, rounded to bf16 once.  fp32 sums taken in a different order can land on
+the other side of a rounding boundary, so the bound is ONE bf16 ulp per element (2^-8 relative, checked as
+|a - b| <= 2^-7 |b| + the fp32 summation noise of the terms), with all but a small fraction of the elements bit-identical.
+"""
+import pytest
+import torch
+
+from oracle.kernel_emul import EmulatedKernels
+from stc_hip import CsrGraph
+from tests.conftest import rel_err
+from tests.test_hip_kernels import _banded_graph, cu, random_csr
+
+pytestmark = pytest.mark.gpu
+EM = EmulatedKernels()
+
+
+@pytest.fixture(scope='module')
+def hip():
+    from stc_hip._lib import HipKernels
+    return HipKernels()
+
+
+def assert_one_ulp(got, want, max_mismatch=0.02):
+    """bf16 tensors: every element within one bf16 ulp, at most ``max_mismatch`` of them different at all."""
+    g, w = got.float().cpu(), want.float().cpu()
+    assert torch.isfinite(g).all()
+    diff = (g - w).abs()
+    # a result that cancels to far below its terms carries the fp32 summation-order noise of those terms, which can
+    # exceed a bf16 ulp of the tiny result: allow that noise (4e-6 of the largest value) besides the one ulp
+    floor = 4e-6 * float(w.abs().max())
+    assert bool((diff <= w.abs() * 2.0 ** -7 + floor).all()), f'beyond one bf16 ulp: max diff {float(diff.max())}'
+    assert float((diff > 0).float().mean()) <= max_mismatch
+
+
+@pytest.mark.parametrize('n_rows,n_cols,F,B,density', [
+    (37, 37, 1024, 2, 0.2),      # two pieces per lane, ragged last tile
+    (64, 50, 160, 3, 0.3),       # 20 pieces: lanes beyond the row idle
+    (40, 40, 512, 1, 1.0),       # exactly one piece per lane
+    (300, 300, 256, 1, 1.0),     # rows longer than the staged segment
+    (9, 9, 4096, 1, 0.5),        # several column blocks per row
+    (5, 7, 8, 1, 0.5),           # one piece per row
+])
+@pytest.mark.parametrize('alpha,beta', [(1.0, 0.0), (2.0, -1.0)])
+def test_csr_spmm_bf16(hip, n_rows, n_cols, F, B, density, alpha, beta):
+    rowptr, colidx, val, dense = random_csr(n_rows, n_cols, density, seed=n_rows * 7 + F, empty_rows=(1, n_rows - 1))
+    g = torch.Generator().manual_seed(F)
+    X = torch.randn(B, n_cols, F, generator=g).bfloat16()
+    Y0 = torch.randn(B, n_rows, F, generator=g).bfloat16() if beta != 0 else None
+    want = torch.empty(B, n_rows, F, dtype=torch.bfloat16)
+    EM.csr_spmm_bf16(rowptr, colidx, val, n_rows, n_cols, X, Y0, want, alpha, beta)
+    got = torch.full((B, n_rows, F), float('nan'), dtype=torch.bfloat16).cuda()
+    hip.csr_spmm_bf16(cu(rowptr), cu(colidx), cu(val), n_rows, n_cols, cu(X), cu(Y0), got, alpha, beta)
+    assert_one_ulp(got, want)
+    # the fp32 kernel on the same bf16-valued inputs, rounded once
+    f32 = torch.empty(B, n_rows, F).cuda()
+    hip.csr_spmm(cu(rowptr), cu(colidx), cu(val), n_rows, n_cols, cu(X.float()), None if Y0 is None else cu(Y0.float()), f32, alpha, beta)
+    assert_one_ulp(got, f32.bfloat16())
+    if Y0 is not None:                                          # in-place epilogue: Y0 aliases Y
+        buf = Y0.clone().cuda()
+        hip.csr_spmm_bf16(cu(rowptr), cu(colidx), cu(val), n_rows, n_cols, cu(X), buf, buf, alpha, beta)
+        assert torch.equal(buf, got)
+
+
+@pytest.mark.parametrize('n,F,B,hw', [(203, 2048, 1, 4), (77, 640, 2, 3), (64, 256, 1, 6), (1001, 64, 1, 2), (30, 4096, 1, 40)])
+def test_bcsr_spmm_bf16_equals_csr(hip, n, F, B, hw):
+    """Row-blocked bf16 kernel vs the CSR bf16 kernel vs the fp32 product: ragged last block, an empty row, block lists
+    longer than the staged segment (hw = 40), several column blocks, in-place beta epilogue, both graph orientations."""
+    graph, V = _banded_graph(n, hw, seed=n + F)
+    d = graph.on(torch.device('cuda'))
+    g = torch.Generator().manual_seed(F)
+    X = torch.randn(B, n, F, generator=g).bfloat16()
+    Y0 = torch.randn(B, n, F, generator=g).bfloat16()
+    for side, dense in (('fwd', V.t()), ('bwd', V)):
+        rp, ci, vals = d[f'{side}_rowptr'], d[f'{side}_colidx'], d[f'{side}_val']
+        plan = (d[f'{side}_blk_ptr'], d[f'{side}_blk_cols'], d[f'{side}_blk_vals'])
+        for alpha, beta in ((1.0, 0.0), (2.0, -1.0)):
+            want = (alpha * torch.einsum('rc,bcf->brf', dense, X.float()) + beta * Y0.float()).bfloat16()
+            csr = Y0.clone().cuda()
+            hip.csr_spmm_bf16(rp, ci, vals, n, n, cu(X), csr if beta else None, csr, alpha, beta)
+            blocked = Y0.clone().cuda()
+            hip.csr_spmm_bf16(rp, ci, vals, n, n, cu(X), blocked if beta else None, blocked, alpha, beta, plan=plan)
+            assert_one_ulp(csr, want)
+            assert_one_ulp(blocked, want)
+            assert_one_ulp(blocked, csr)
+
+
+def test_spmm_bf16_zero_sizes_and_errors(hip):
+    from stc_hip._lib import StcError
+    rowptr = torch.zeros(5, dtype=torch.int32).cuda()
+    colidx = torch.zeros(0, dtype=torch.int32).cuda()
+    val = torch.zeros(0).cuda()
+    X = torch.ones(1, 4, 64, dtype=torch.bfloat16).cuda()
+    Y = torch.full((1, 4, 64), float('nan'), dtype=torch.bfloat16).cuda()
+    hip.csr_spmm_bf16(rowptr, colidx, val, 4, 4, X, None, Y, 1.0, 0.0)          # a graph without edges: all zeros
+    assert float(Y.float().abs().max()) == 0.0
+    with pytest.raises(StcError):                                                # fp32 rows handed to the bf16 entry point
+        hip.csr_spmm_bf16(rowptr, colidx, val, 4, 4, X.float(), None, Y, 1.0, 0.0)
+    with pytest.raises(StcError):                                                # F not a multiple of 8
+        hip.csr_spmm_bf16(rowptr, colidx, val, 4, 4, X[..., :60].contiguous(), None, Y[..., :60].contiguous(), 1.0, 0.0)
+    with pytest.raises(StcError):                                                # beta without Y0 (C side)
+        hip.csr_spmm_bf16(rowptr, colidx, val, 4, 4, X, None, Y, 1.0, 1.0)
+
+
+def test_full_size_spmm_bf16_properties(hip):
+    """Configuration 5 size (224x224 queen grid, C = 64, L = 32 -> F = 2048 bf16 = the fp32 row's 4 KiB): the row-stochastic
+    graph maps a constant field to itself exactly; the adjoint identity ties both orientations; blocked == direct kernel."""
+    H = W = 224
+    graph = CsrGraph.queen_grid(H, W, normalize=True)
+    d = graph.on(torch.device('cuda'))
+    N, F = H * W, 2048
+    plan_f = (d['fwd_blk_ptr'], d['fwd_blk_cols'], d['fwd_blk_vals'])
+    plan_b = (d['bwd_blk_ptr'], d['bwd_blk_cols'], d['bwd_blk_vals'])
+    ones = torch.ones(1, N, F, device='cuda', dtype=torch.bfloat16)
+    out = torch.empty_like(ones)
+    hip.csr_spmm_bf16(d['bwd_rowptr'], d['bwd_colidx'], d['bwd_val'], N, N, ones, None, out, 1.0, 0.0, plan=plan_b)
+    assert float((out.float() - 1).abs().max()) == 0.0           # |sum - 1| ~ 1e-7 rounds back to 1 in bf16
+    g = torch.Generator(device='cuda').manual_seed(0)
+    x = torch.randn(1, N, F, device='cuda', generator=g).bfloat16()
+    y = torch.randn(1, N, F, device='cuda', generator=g).bfloat16()
+    STx, STx_direct, Sy = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    hip.csr_spmm_bf16(d['fwd_rowptr'], d['fwd_colidx'], d['fwd_val'], N, N, x, None, STx, 1.0, 0.0, plan=plan_f)
+    hip.csr_spmm_bf16(d['fwd_rowptr'], d['fwd_colidx'], d['fwd_val'], N, N, x, None, STx_direct, 1.0, 0.0)
+    assert_one_ulp(STx, STx_direct)
+    hip.csr_spmm_bf16(d['bwd_rowptr'], d['bwd_colidx'], d['bwd_val'], N, N, y, None, Sy, 1.0, 0.0, plan=plan_b)
+    lhs, rhs = (STx.double() * y.double()).sum(), (x.double() * Sy.double()).sum()
+    # each output carries an independent rounding of relative size <= 2^-9: the two sums differ by a random walk over 1e8 terms
+    noise = 2.0 ** -9 * float(((STx.double() * y.double()) ** 2).sum() + ((x.double() * Sy.double()) ** 2).sum()) ** 0.5
+    assert abs(float(lhs - rhs)) < 8 * noise
+    f32 = torch.empty(1, N, F, device='cuda')
+    hip.csr_spmm(d['fwd_rowptr'], d['fwd_colidx'], d['fwd_val'], N, N, x.float(), None, f32, 1.0, 0.0, plan=plan_f)
+    assert_one_ulp(STx, f32.bfloat16())

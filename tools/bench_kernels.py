@@ -55,6 +55,21 @@ def main():
         print(f'{name:34s} {us:9.1f} us   {nbytes/1e6:9.1f} MB   {nbytes/us/1e3:8.1f} GB/s', flush=True)
 
     R = 4                                  # buffer sets rotated through (4 x >= 200 MB >> 256 MiB of Infinity Cache)
+    if a.only == 'spmm-bf16':              # bf16 storage (configuration 5 runs this with --C 64): rows of C*L bf16
+        for L in (32, 16):
+            F = C * L
+            Xs = [torch.randn(B, N, F, device=dev).bfloat16() for _ in range(R)]
+            Ys = [torch.empty(B, N, F, device=dev, dtype=torch.bfloat16) for _ in range(R)]
+            us = timeit(lambda i: hip.csr_spmm_bf16(g['fwd_rowptr'], g['fwd_colidx'], g['fwd_val'], N, N, Xs[i % R], None, Ys[i % R], 1.0, 0.0, plan=plan_f), a.iters)
+            report(f'spmm bf16 fwd F={F}', us, nnz * 8 + 4 * (N + 1) + 2 * B * N * F * 2)
+            us = timeit(lambda i: hip.csr_spmm_bf16(g['bwd_rowptr'], g['bwd_colidx'], g['bwd_val'], N, N, Xs[i % R], Ys[i % R], Ys[i % R], 1.0, 1.0, plan=plan_b), a.iters)
+            report(f'spmm bf16 bwd F={F} (+=, in place)', us, nnz * 8 + 4 * (N + 1) + 3 * B * N * F * 2)
+            del Xs, Ys
+        Xc = [torch.randn(B, N, C * 16, device=dev) for _ in range(R)]
+        Yc = [torch.empty_like(x) for x in Xc]
+        us = timeit(lambda i: Yc[i % R].copy_(Xc[i % R]), a.iters)
+        report('torch copy (HBM reference)', us, 2 * Xc[0].numel() * 4)
+        return
     for L in (32, 20):
         F = C * L
         Xs = [torch.randn(B, N, F, device=dev) for _ in range(R)]
