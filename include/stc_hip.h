@@ -85,6 +85,25 @@ int stc_bcsr_spmm_bf16(const int32_t* blk_ptr, const int32_t* blk_cols, const fl
                        const void* X, const void* Y0, void* Y,
                        int32_t batch, int32_t F, float alpha, float beta, void* stream);
 
+/* bf16-storage node kernel (2-mode product + concat + projection + bias, STC_GNN.py:38-45) and its backward: the slabs
+ * Z_n (nodes, C, L), the output Y / its gradient dY (nodes, C, Ho) and the slab gradients dZ_n are bf16 (void*); Tc, W,
+ * bias, dW, db are fp32 (master weights: rounded to bf16 once per launch for the matrix cores).  Every contraction runs
+ * on v_mfma_f32_16x16x32_bf16 with fp32 accumulation; intermediate tiles that feed a second contraction (U_c = sum_n
+ * Z_n W_{n,c} in the forward, Q_c = T_c dY in the backward) are rounded to bf16 in between.  T_0 is taken as the identity
+ * (STC_GNN.py:26) whatever Tc[0] holds.  No dTc (the bf16 path is for fixed category graphs).
+ * Shapes: Ks = Kc <= 3, C in {32, 64}, L in {16, 32}, Ho in {16, 32} (stc_bdg_node_bf16_supported), else
+ * STC_EUNSUPPORTED.  Lw <= L real columns: pad columns must hold finite values and get zero gradient.
+ * workspace as stc_bdg_node_bwd_f32 (stc_bdg_node_bwd_workspace_bytes(Ks, Kc, C, L, Ho, 0)). */
+int stc_bdg_node_bf16_supported(int32_t Ks, int32_t Kc, int32_t C, int32_t L, int32_t Ho);
+int stc_bdg_node_fwd_bf16(const void* const* Z, int32_t Ks, const float* Tc, int32_t Kc,
+                          const float* W, const float* bias, void* Y,
+                          int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t Ho, void* stream);
+int stc_bdg_node_bwd_bf16(const void* const* Z, int32_t Ks, const float* Tc, int32_t Kc,
+                          const float* W, const void* dY,
+                          void* const* dZ, float* dW, float* db,
+                          void* workspace, size_t workspace_bytes,
+                          int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t Ho, void* stream);
+
 /* Backward products of an STC_Cell with the element-wise consumer folded into the epilogue (autograd of
  * STC_GNN.py:68-75).  Rows are node rows of C categories x (cin + h + pad) features (the [Xt | H | 0-pad]
  * layout of stc_concat2_f32).  The graph comes in either form: BCSR when blk_ptr != NULL, else CSR.

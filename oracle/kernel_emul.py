@@ -121,6 +121,45 @@ class EmulatedKernels:
             out += bias
         Y.copy_(out)
 
+    # ---- stc_bdg_node_fwd/bwd_bf16: the same kernels on bf16 slabs with the hardware path's rounding points
+    # (weights and T_c rounded to bf16 once; U_c / Q_c rounded between the two contractions; fp32 sums; one final rounding)
+    def node_bf16_supported(self, Ks, Kc, Cc, L, Ho):
+        return Ks == Kc and 1 <= Ks <= 3 and Cc in (32, 64) and L in (16, 32) and Ho in (16, 32)
+
+    def bdg_node_fwd_bf16(self, Zs, Tc, W, bias, Y):
+        bf = torch.bfloat16
+        Ks, Kc = len(Zs), Tc.shape[0]
+        Ho = W.shape[1]
+        Lw = W.shape[0] // (Ks * Kc)
+        Wv = W.to(bf).float().view(Ks, Kc, Lw, Ho)
+        out = torch.zeros(*Zs[0].shape[:2], Ho)
+        for c in range(Kc):
+            U = sum(Zs[n][..., :Lw].float() @ Wv[n, c] for n in range(Ks)).to(bf).float()
+            out += U if c == 0 else torch.einsum('pd,rpo->rdo', Tc[c].to(bf).float(), U)
+        if bias is not None:
+            out += bias
+        Y.copy_(out.to(bf))
+
+    def bdg_node_bwd_bf16(self, Zs, Tc, W, dY, dZs, dW, db):
+        bf = torch.bfloat16
+        Ks, Kc = len(Zs), Tc.shape[0]
+        L = Zs[0].shape[-1]
+        Ho = W.shape[1]
+        Lw = W.shape[0] // (Ks * Kc)
+        Wv = W.to(bf).float().view(Ks, Kc, Lw, Ho)
+        g = dY.float()
+        Q = [g if c == 0 else torch.einsum('pd,rdo->rpo', Tc[c].to(bf).float(), g).to(bf).float() for c in range(Kc)]
+        dWv = torch.zeros(Ks, Kc, Lw, Ho)
+        for n in range(Ks):
+            acc = torch.zeros(*Zs[n].shape[:2], L)
+            for c in range(Kc):
+                acc[..., :Lw] += Q[c] @ Wv[n, c].t()
+                dWv[n, c] = torch.einsum('rpl,rpo->lo', Zs[n][..., :Lw].float(), Q[c])
+            dZs[n].copy_(acc.to(bf))
+        dW.copy_(dWv.view(Ks * Kc * Lw, Ho))
+        if db is not None:
+            db.copy_(g.sum(dim=(0, 1)))
+
     # ---- stc_bdg_node_bwd_f32: autograd of the above
     def bdg_node_bwd(self, Zs, Tc, W, dY, dZs, dW, db, dTc):
         Ks, Kc = len(Zs), Tc.shape[0]

@@ -356,6 +356,15 @@ int bwd_grid(const NodeDims& d, long long nodes) {
 
 }  // namespace
 
+// fixed-order sum of per-workgroup partial rows [dW | db] (stride nW + Ho) -- shared with stc_node_bf16.hip
+int stc_node_reduce_partials(const float* partial, int n_parts, int nW, int Ho, float* dW, float* db, hipStream_t s) {
+    const int stride = nW + Ho;
+    hipLaunchKernelGGL(bdg_node_reduce_kernel, dim3((stride + RED_ELEMS - 1) / RED_ELEMS), dim3(NODE_THREADS), 0, s,
+                       partial, n_parts, stride, nW, Ho, 0, dW, db, static_cast<float*>(nullptr));
+    STC_LAUNCH_CHECK("stc_bdg_node_reduce launch");
+    return STC_OK;
+}
+
 extern "C" int stc_bdg_node_fwd_f32(const float* const* Z, int32_t Ks, const float* Tc, int32_t Kc,
                                     const float* W, const float* bias, float* Y,
                                     int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t Ho, void* stream) {

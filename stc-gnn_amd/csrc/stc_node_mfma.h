@@ -92,3 +92,6 @@ int stc_cell_gates_bwd_planar_x3(const float* X, const float* H, const float* SX
                                  const float* dCandIn, const float* Cand, const float* U, const float* R, const float* dHnew,
                                  float* const* dZ, float* dH, float* partial, int* n_partials, int want_db,
                                  long long nodes, int C, int Lw, hipStream_t stream);
+
+// Fixed-order reduction of the backward kernels' per-workgroup partial rows [dW (nW) | db (Ho)] into dW, db (db may be null).
+int stc_node_reduce_partials(const float* partial, int n_parts, int nW, int Ho, float* dW, float* db, hipStream_t stream);

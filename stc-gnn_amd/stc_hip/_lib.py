@@ -25,7 +25,8 @@ MAX_K = 4
 #: every symbol ``include/stc_hip.h`` declares (the CPU test-suite checks the .so exports them all)
 EXPORTS = (
     'stc_version', 'stc_last_error',
-    'stc_csr_spmm_f32', 'stc_bcsr_spmm_f32', 'stc_csr_spmm_bf16', 'stc_bcsr_spmm_bf16', 'stc_spmm_bwd_gates_f32', 'stc_spmm_bwd_split_f32', 'stc_csr_sddmm_f32',
+    'stc_csr_spmm_f32', 'stc_bcsr_spmm_f32', 'stc_csr_spmm_bf16', 'stc_bcsr_spmm_bf16', 'stc_bdg_node_bf16_supported', 'stc_bdg_node_fwd_bf16', 'stc_bdg_node_bwd_bf16',
+    'stc_spmm_bwd_gates_f32', 'stc_spmm_bwd_split_f32', 'stc_csr_sddmm_f32',
     'stc_cheby_dense_fwd_f32', 'stc_cheby_dense_bwd_f32',
     'stc_bdg_node_fwd_f32', 'stc_bdg_node_bwd_workspace_bytes', 'stc_bdg_node_bwd_f32',
     'stc_bdg_node_post_supported', 'stc_bdg_node_post_fwd_f32', 'stc_bdg_node_post_bwd_f32', 'stc_spmm_blend_fwd_f32',
@@ -66,6 +67,9 @@ def _declare(lib):
         'stc_bdg_node_fwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
         'stc_bdg_node_bwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, C.POINTER(_p), _p, _p, _p,
                                  _p, C.c_size_t, _i64, _i32, _i32, _i32, _i32, _p],
+        'stc_bdg_node_fwd_bf16': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
+        'stc_bdg_node_bwd_bf16': [C.POINTER(_p), _i32, _p, _i32, _p, _p, C.POINTER(_p), _p, _p,
+                                  _p, C.c_size_t, _i64, _i32, _i32, _i32, _i32, _p],
         'stc_bdg_node_post_fwd_f32': [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
         'stc_cell_gates_fwd_planar_f32': [_p] * 14 + [_i64, _i32, _i32, _i32, _p],
         'stc_cell_gates_bwd_planar_f32': [_p] * 11 + [C.POINTER(_p), _p, _p, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _p],
@@ -98,6 +102,8 @@ def _declare(lib):
     lib.stc_cell_fused_supported.argtypes = [_i32, _i32, _i32, _i32, _i32]
     lib.stc_bdg_node_post_supported.restype = C.c_int
     lib.stc_bdg_node_post_supported.argtypes = [_i32, _i32, _i32, _i32, _i32]
+    lib.stc_bdg_node_bf16_supported.restype = C.c_int
+    lib.stc_bdg_node_bf16_supported.argtypes = [_i32, _i32, _i32, _i32, _i32]
     lib.stc_cell_planar_supported.restype = C.c_int
     lib.stc_cell_planar_supported.argtypes = [_i32, _i32, _i32, _i32]
     lib.stc_cell_gather_supported.restype = C.c_int
@@ -443,6 +449,49 @@ class HipKernels:
         nbytes = self.lib.stc_bdg_node_bwd_workspace_bytes(Ks, Kc, Cc, L, Ho, int(dTc is not None))
         ws = self._get_workspace(dY.device, nbytes)
         self._launch('stc_bdg_node_bwd_f32', dY, self._ptr_array(Zs), Ks, _ptr(Tc), Kc, _ptr(W), _ptr(dY), self._ptr_array(dZs), _ptr(dW), _ptr(db), _ptr(dTc), _ptr(ws), ws.numel(), R, Cc, L, Lw, Ho)
+
+    # ---- bf16 storage (configuration 5) ------------------------------------------------------------
+    def node_bf16_supported(self, Ks, Kc, Cc, L, Ho) -> bool:
+        return bool(self.lib.stc_bdg_node_bf16_supported(Ks, Kc, Cc, L, Ho))
+
+    def _node_shapes_bf16(self, Zs, Tc, W):
+        Ks, Kc = len(Zs), Tc.shape[0]
+        R, Cc, L = Zs[0].shape
+        Ho = W.shape[1]
+        Lw = W.shape[0] // (Ks * Kc)
+        if Lw < 1 or Lw > L or W.shape[0] != Ks * Kc * Lw:
+            raise StcError(f'node_bf16.W: {W.shape[0]} rows give Lw={Lw} per block, slabs are {L} wide')
+        for i, z in enumerate(Zs):
+            self._bf16(f'node_bf16.Z[{i}]', z, (R, Cc, L))
+        self._f32('node_bf16.Tc', Tc, (Kc, Cc, Cc))
+        self._f32('node_bf16.W', W, (Ks * Kc * Lw, Ho))
+        return Ks, Kc, R, Cc, L, Lw, Ho
+
+    def bdg_node_fwd_bf16(self, Zs: Sequence[torch.Tensor], Tc, W, bias, Y):
+        """bf16 slabs / output, fp32 weights (stc_bdg_node_fwd_bf16)."""
+        Ks, Kc, R, Cc, L, Lw, Ho = self._node_shapes_bf16(Zs, Tc, W)
+        if bias is not None:
+            self._f32('node_bf16.bias', bias, (Ho,))
+        self._bf16('node_bf16.Y', Y, (R, Cc, Ho))
+        self._same_device(*Zs, Tc, W, bias, Y)
+        self._launch('stc_bdg_node_fwd_bf16', Y, self._ptr_array(Zs), Ks, _ptr(Tc), Kc, _ptr(W), _ptr(bias), _ptr(Y), R, Cc, L, Lw, Ho,
+                     nbytes=2 * R * Cc * (Ks * L + Ho))
+
+    def bdg_node_bwd_bf16(self, Zs, Tc, W, dY, dZs, dW, db):
+        Ks, Kc, R, Cc, L, Lw, Ho = self._node_shapes_bf16(Zs, Tc, W)
+        self._bf16('node_bf16.dY', dY, (R, Cc, Ho))
+        if len(dZs) != Ks:
+            raise StcError('node_bf16.dZ: need one gradient slab per Chebyshev order')
+        for i, z in enumerate(dZs):
+            self._bf16(f'node_bf16.dZ[{i}]', z, (R, Cc, L))
+        self._f32('node_bf16.dW', dW, (Ks * Kc * Lw, Ho))
+        if db is not None:
+            self._f32('node_bf16.db', db, (Ho,))
+        self._same_device(*Zs, Tc, W, dY, *dZs, dW, db)
+        nbytes = self.lib.stc_bdg_node_bwd_workspace_bytes(Ks, Kc, Cc, L, Ho, 0)
+        ws = self._get_workspace(dY.device, nbytes)
+        self._launch('stc_bdg_node_bwd_bf16', dY, self._ptr_array(Zs), Ks, _ptr(Tc), Kc, _ptr(W), _ptr(dY), self._ptr_array(dZs), _ptr(dW), _ptr(db),
+                     _ptr(ws), ws.numel(), R, Cc, L, Lw, Ho, nbytes=2 * R * Cc * (2 * Ks * L + Ho))
 
     # ---- post-aggregation form (Ks = Kc = 2): Y = A + S.Bm --------------------------------------
     def node_post_supported(self, Ks, Kc, Cc, L, Ho) -> bool:

@@ -132,3 +132,93 @@ def test_full_size_spmm_bf16_properties(hip):
     f32 = torch.empty(1, N, F, device='cuda')
     hip.csr_spmm(d['fwd_rowptr'], d['fwd_colidx'], d['fwd_val'], N, N, x.float(), None, f32, 1.0, 0.0, plan=plan_f)
     assert_one_ulp(STx, f32.bfloat16())
+
+
+# ------------------------------------------------------------------ node kernel (projection + category mix) on bf16 slabs
+def _node_inputs_bf16(nodes, C, L, Lw, Ho, K, seed):
+    g = torch.Generator().manual_seed(seed)
+    Zs = [torch.randn(nodes, C, L, generator=g).bfloat16() for _ in range(K)]
+    Tc = torch.softmax(torch.randn(K, C, C, generator=g), -1)
+    Tc[0] = torch.eye(C)
+    for k in range(2, K):
+        Tc[k] = 2 * Tc[1] @ Tc[k - 1] - Tc[k - 2]
+    W = torch.randn(K * K * Lw, Ho, generator=g) * 0.2
+    b = torch.randn(Ho, generator=g)
+    return Zs, Tc, W, b
+
+
+NODE_SHAPES_BF16 = [
+    # nodes, C, L, Lw, Ho, K
+    (50, 64, 32, 32, 32, 2),      # configuration 5: gates convolution width
+    (50, 64, 32, 32, 16, 2),      # candidate width
+    (13, 32, 32, 32, 32, 3),
+    (21, 32, 16, 16, 16, 1),
+    (9, 64, 32, 17, 32, 2),       # padded rows (in + hidden = 17)
+    (7, 32, 16, 9, 32, 3),
+    (4500, 64, 32, 32, 32, 2),    # persistent grid wraps
+    (1, 64, 16, 16, 16, 3),
+]
+
+
+@pytest.mark.parametrize('shape', NODE_SHAPES_BF16)
+@pytest.mark.parametrize('bias', [True, False])
+def test_bdg_node_fwd_bf16(hip, shape, bias):
+    nodes, C, L, Lw, Ho, K = shape
+    assert hip.node_bf16_supported(K, K, C, L, Ho) and EM.node_bf16_supported(K, K, C, L, Ho)
+    Zs, Tc, W, b = _node_inputs_bf16(nodes, C, L, Lw, Ho, K, seed=nodes + C + L + Ho)
+    b = b if bias else None
+    want = torch.empty(nodes, C, Ho, dtype=torch.bfloat16)
+    EM.bdg_node_fwd_bf16(Zs, Tc, W, b, want)
+    got = torch.full((nodes, C, Ho), float('nan'), dtype=torch.bfloat16).cuda()
+    hip.bdg_node_fwd_bf16([cu(z) for z in Zs], cu(Tc), cu(W), cu(b), got)
+    assert torch.isfinite(got.float()).all()
+    # twin with the same rounding points: a flipped rounding of an intermediate U_c moves Y by about one ulp
+    assert rel_err(got.float().cpu(), want.float()) < 2.0 ** -7
+    assert float((got.float().cpu() - want.float()).abs().mean()) < 2.0 ** -11 * float(want.float().abs().mean()) + 1e-9
+    # the exact fp32 math on the same bf16 inputs (emulated fp32 kernel): bf16 rounding of weights / intermediates / output
+    exact = torch.empty(nodes, C, Ho)
+    EM.bdg_node_fwd([z.float() for z in Zs], Tc, W, b, exact)
+    assert rel_err(got.float().cpu(), exact) < 2e-2
+
+
+@pytest.mark.parametrize('shape', NODE_SHAPES_BF16)
+@pytest.mark.parametrize('want_db', [True, False])
+def test_bdg_node_bwd_bf16(hip, shape, want_db):
+    nodes, C, L, Lw, Ho, K = shape
+    Zs, Tc, W, _ = _node_inputs_bf16(nodes, C, L, Lw, Ho, K, seed=3 * nodes + C + L + Ho)
+    dY = torch.randn(nodes, C, Ho, generator=torch.Generator().manual_seed(nodes)).bfloat16()
+    w_dZ = [torch.empty(nodes, C, L, dtype=torch.bfloat16) for _ in range(K)]
+    w_dW, w_db = torch.empty_like(W), torch.empty(Ho)
+    EM.bdg_node_bwd_bf16(Zs, Tc, W, dY, w_dZ, w_dW, w_db)
+    g_dZ = [torch.full((nodes, C, L), float('nan'), dtype=torch.bfloat16).cuda() for _ in range(K)]
+    g_dW = torch.full_like(W, float('nan')).cuda()
+    g_db = torch.full((Ho,), float('nan')).cuda() if want_db else None
+    hip.bdg_node_bwd_bf16([cu(z) for z in Zs], cu(Tc), cu(W), cu(dY), g_dZ, g_dW, g_db)
+    for n in range(K):
+        assert torch.isfinite(g_dZ[n].float()).all()
+        assert rel_err(g_dZ[n].float().cpu(), w_dZ[n].float()) < 2.0 ** -7
+        if Lw < L:
+            assert float(g_dZ[n][..., Lw:].float().abs().max()) == 0.0          # pad columns get zero gradient
+    assert rel_err(g_dW.cpu(), w_dW) < 2e-3                                     # fp32 sums of bf16-rounded products
+    if want_db:
+        assert rel_err(g_db.cpu(), w_db) < 1e-5                                 # exact operands, fp32 sums
+    # against the exact fp32 math on the same bf16 inputs
+    e_dZ = [torch.empty(nodes, C, L) for _ in range(K)]
+    e_dW, e_db = torch.empty_like(W), torch.empty(Ho)
+    EM.bdg_node_bwd([z.float() for z in Zs], Tc, W, dY.float(), e_dZ, e_dW, e_db, None)
+    for n in range(K):
+        assert rel_err(g_dZ[n].float().cpu(), e_dZ[n]) < 2e-2
+    assert rel_err(g_dW.cpu(), e_dW) < 2e-2
+    # bitwise reproducible weight gradients
+    g_dW2 = torch.empty_like(g_dW)
+    hip.bdg_node_bwd_bf16([cu(z) for z in Zs], cu(Tc), cu(W), cu(dY), g_dZ, g_dW2, g_db)
+    assert torch.equal(g_dW, g_dW2)
+
+
+def test_node_bf16_unsupported_shapes_are_refused(hip):
+    from stc_hip._lib import StcError
+    assert not hip.node_bf16_supported(2, 2, 16, 32, 32) and not hip.node_bf16_supported(2, 3, 32, 32, 32)
+    assert not hip.node_bf16_supported(2, 2, 32, 24, 32) and not hip.node_bf16_supported(4, 4, 32, 32, 32)
+    Zs, Tc, W, b = _node_inputs_bf16(5, 16, 32, 32, 32, 2, seed=1)
+    with pytest.raises(StcError):
+        hip.bdg_node_fwd_bf16([cu(z) for z in Zs], cu(Tc), cu(W), cu(b), torch.empty(5, 16, 32, dtype=torch.bfloat16).cuda())

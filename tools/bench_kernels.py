@@ -52,7 +52,7 @@ def main():
           f'SPMM_VARIANT={os.environ.get("STC_SPMM_VARIANT", "default")} row_blocked={plan_f is not None}')
 
     def report(name, us, nbytes):
-        print(f'{name:34s} {us:9.1f} us   {nbytes/1e6:9.1f} MB   {nbytes/us/1e3:8.1f} GB/s', flush=True)
+        print(f'{name:44s} {us:9.1f} us   {nbytes/1e6:9.1f} MB   {nbytes/us/1e3:8.1f} GB/s', flush=True)
 
     R = 4                                  # buffer sets rotated through (4 x >= 200 MB >> 256 MiB of Infinity Cache)
     if a.only == 'spmm-bf16':              # bf16 storage (configuration 5 runs this with --C 64): rows of C*L bf16
@@ -65,6 +65,24 @@ def main():
             us = timeit(lambda i: hip.csr_spmm_bf16(g['bwd_rowptr'], g['bwd_colidx'], g['bwd_val'], N, N, Xs[i % R], Ys[i % R], Ys[i % R], 1.0, 1.0, plan=plan_b), a.iters)
             report(f'spmm bf16 bwd F={F} (+=, in place)', us, nnz * 8 + 4 * (N + 1) + 3 * B * N * F * 2)
             del Xs, Ys
+        bf = torch.bfloat16
+        Tc = torch.softmax(torch.randn(K, C, C, device=dev), -1)
+        Tc[0] = torch.eye(C, device=dev)
+        L = 32
+        for Ho in (2 * h, h):
+            Zs = [[torch.randn(B * N, C, L, device=dev).to(bf) for _ in range(K)] for _ in range(R)]
+            W = torch.randn(K * K * L, Ho, device=dev) * 0.1
+            b = torch.randn(Ho, device=dev)
+            Yn = [torch.empty(B * N, C, Ho, device=dev, dtype=bf) for _ in range(R)]
+            us = timeit(lambda i: hip.bdg_node_fwd_bf16(Zs[i % R], Tc, W, b, Yn[i % R]), a.iters)
+            flops = 2 * B * N * C * Ho * K * (K * L + C)            # projection + category mix (T_0 = I counted: it runs)
+            report(f'node bf16 fwd L={L} Ho={Ho} ({flops / us / 1e6:.1f} TFLOP/s)', us, (K * L + Ho) * B * N * C * 2)
+            dY = [torch.randn(B * N, C, Ho, device=dev).to(bf) for _ in range(R)]
+            dZs = [[torch.empty_like(z) for z in zs] for zs in Zs]
+            dW, db = torch.empty_like(W), torch.empty_like(b)
+            us = timeit(lambda i: hip.bdg_node_bwd_bf16(Zs[i % R], Tc, W, dY[i % R], dZs[i % R], dW, db), a.iters)
+            report(f'node bf16 bwd L={L} Ho={Ho}', us, (2 * K * L + Ho) * B * N * C * 2)
+            del Zs, Yn, dY, dZs
         Xc = [torch.randn(B, N, C * 16, device=dev) for _ in range(R)]
         Yc = [torch.empty_like(x) for x in Xc]
         us = timeit(lambda i: Yc[i % R].copy_(Xc[i % R]), a.iters)
