@@ -104,6 +104,40 @@ int stc_bdg_node_bwd_bf16(const void* const* Z, int32_t Ks, const float* Tc, int
                           void* workspace, size_t workspace_bytes,
                           int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t Ho, void* stream);
 
+/* The planar STC_Cell (see "planar cell inputs" below) on bf16 planes, K = 2, hidden 16, C in {32, 64}: every state, gate
+ * and gradient plane is (nodes, C, 16) bf16 -- 32-byte rows -- the input plane of layer 0 is (nodes, C, cin) with cin in
+ * 1..4; weights, biases and their gradients stay fp32.  Same mathematics and argument meaning as the _f32 entry points of
+ * the same names (stc_cell_gates_fwd/bwd_planar_f32 with its fused candidate projection, stc_bdg_node_post_bwd_f32 with
+ * X2, stc_spmm_blend_fwd_f32 without state copies, stc_spmm_sum_f32 with contiguous addends, stc_gru_blend_bwd_f32 in its
+ * dCpre-only form); sums are fp32, each stored plane is rounded to bf16 once. */
+int stc_cell_planar_bf16_supported(int32_t Ks, int32_t Kc, int32_t C, int32_t h);
+int stc_cell_gates_fwd_planar_bf16(const void* X, const void* H, const void* SX, const void* SH,
+                                   const float* Tc, const float* W, const float* bias,
+                                   void* U, void* Rg, void* RH,
+                                   const float* Wc, const float* bc, void* A, void* Bm,
+                                   int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream);
+int stc_cell_gates_bwd_planar_bf16(const void* X, const void* H, const void* SX, const void* SH,
+                                   const float* Tc, const float* W,
+                                   const void* dCandIn, const void* Cand, const void* U, const void* Rg, const void* dHnew,
+                                   void* const* dZ, float* dW, float* db, void* dH,
+                                   void* workspace, size_t workspace_bytes,
+                                   int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream);
+int stc_bdg_node_post_bwd_bf16(const void* X, const void* X2, const float* Tc, const float* W, const void* dA, const void* dB,
+                               void* dX, void* dX2, float* dW, float* db, void* workspace, size_t workspace_bytes,
+                               int64_t nodes, int32_t C, int32_t Lw, int32_t Ho, void* stream);
+int stc_spmm_blend_fwd_bf16(const int32_t* rowptr, const int32_t* colidx, const float* val,
+                            const int32_t* blk_ptr, const int32_t* blk_cols, const float* blk_vals,
+                            int32_t n_rows, int32_t n_cols, const void* Bm, const void* A,
+                            const void* U, const void* H, void* Cand, void* Hnew,
+                            int32_t batch, int32_t C, int32_t h, void* stream);
+int stc_spmm_sum_bf16(const int32_t* rowptr, const int32_t* colidx, const float* val,
+                      const int32_t* blk_ptr, const int32_t* blk_cols, const float* blk_vals,
+                      int32_t n_rows, int32_t n_cols, const void* X, const void* X2,
+                      int32_t n_add, const void* const* add,
+                      void* Y, const void* U, const void* Cand, void* dY,
+                      int32_t batch, int32_t C, int32_t h, void* stream);
+int stc_gru_blend_bwd_bf16(const void* dHnew, const void* U, const void* Cand, void* dCpre, int64_t n, void* stream);
+
 /* Backward products of an STC_Cell with the element-wise consumer folded into the epilogue (autograd of
  * STC_GNN.py:68-75).  Rows are node rows of C categories x (cin + h + pad) features (the [Xt | H | 0-pad]
  * layout of stc_concat2_f32).  The graph comes in either form: BCSR when blk_ptr != NULL, else CSR.

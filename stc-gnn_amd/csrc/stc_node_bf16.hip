@@ -173,6 +173,210 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_bf16_
     }
 }
 
+// --------------------------------------------------------------------------------------- planar cell: gates forward
+// The gates convolution of an STC_Cell (reference STC_GNN.py:68-75) on planar bf16 inputs, K = 2: the [Xt | H] row is read
+// as two (nodes, C, 16) planes -- lanes g < 2 take 8 columns of the X plane, g >= 2 of the H plane, which together ARE the
+// 32-slot operand -- once for the cell's own rows (X, H) and once for their aggregations (SX = S.X, SH = S.H).  The
+// transposed mix leaves lane (x, g) with columns 4g..4g+3 of BOTH gates of category row x, so the epilogue is element-wise
+// in registers: U = sigmoid(.), R = sigmoid(.), RH = R * H, each an 8-byte store.
+// NARROW (layer 0): the input plane has cin = Lw - 16 <= 4 columns; the slab is read as [state (16) | input (cin) | 0] and
+// W's rows are permuted to match (stc_wrow_swapped), so the reference's state_dict layout is untouched.
+// POST: the candidate convolution's projection in post-aggregation form (A = sum_c T_c^T ([Xt | RH] Wc_{0,c}) + bc, Bm
+// likewise with Wc_{1,c}; the caller finishes Y = A + S.Bm) runs as a second stage of the same launch: Xt is still in the
+// row registers and RH is moved from the epilogue's layout to row layout with four ds_bpermute per 16 rows.
+__device__ __forceinline__ float fast_sigmoid(float v) {      // hardware exp2 / rcp: |err| < 2e-7, far below a bf16 ulp
+    return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
+}
+__device__ __forceinline__ float fast_tanh(float v) {
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.8853900817779268f * v));
+}
+__device__ __forceinline__ f32x4 unpack4(const u32x2 v) {
+    return f32x4{__uint_as_float(v[0] << 16), __uint_as_float(v[0] & 0xffff0000u), __uint_as_float(v[1] << 16), __uint_as_float(v[1] & 0xffff0000u)};
+}
+// 8 columns of one row of a planar slab: wide = [P0 (16) | P1 (16)]; narrow = [P1 (16) | P0 (cin) | 0]
+template <int NARROW>
+__device__ __forceinline__ u32x4 load_planar8(const bf16_t* __restrict__ P0, const bf16_t* __restrict__ P1, size_t row, int g, int cin) {
+    if (!NARROW) return *reinterpret_cast<const u32x4*>((g < 2 ? P0 : P1) + row * 16 + 8 * (g & 1));
+    if (g < 2) return *reinterpret_cast<const u32x4*>(P1 + row * 16 + 8 * g);
+    u32x4 r = kZeroU4;
+    if (g == 2) {
+        const bf16_t* q = P0 + row * cin;
+        const unsigned v0 = q[0], v1 = cin > 1 ? q[1] : 0u, v2 = cin > 2 ? q[2] : 0u, v3 = cin > 3 ? q[3] : 0u;
+        r[0] = v0 | (v1 << 16);
+        r[1] = v2 | (v3 << 16);
+    }
+    return r;
+}
+
+struct GatesFwd {
+    const bf16_t *X, *H, *SX, *SH;     // planes: X / SX (nodes, C, cin), H / SH (nodes, C, 16)
+    bf16_t *U, *R, *RH;                // out (nodes, C, 16)
+    const float *Wc, *bc;              // POST: candidate weights (4 Lw, 16), bias (16) or null
+    bf16_t *A, *Bm;                    // POST out (nodes, C, 16)
+};
+
+template <int NB2, int NARROW, int POST>
+__global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void cell_gates_fwd_bf16_kernel(
+    GatesFwd a, const float* __restrict__ Tc, const float* __restrict__ W, const float* __restrict__ bias, int nodes, int Lw) {
+    constexpr int K = 2, HB = 2, NRB = 2 * NB2, C = 32 * NB2, NCB = K * HB;
+    constexpr int nWx = K * NCB, nTx = K * NB2 * NRB, nWp = POST ? K * K : 0;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32x4* Wx = reinterpret_cast<u32x4*>(smem_raw);        // [K n][NCB = (c, hb)]   B: W[(n, c, l = slot)][o = 16 hb + x]
+    u32x4* Tx = Wx + nWx * 64;                              // [K c][NB2 p][NRB db]   B: T_c[c' = 32 p + pair_row][d = 16 db + x]
+    u32x4* Wp = Tx + nTx * 64;                              // POST: [K n][K c]       B: Wc[(n, c, l = slot)][o = x]
+    const int tid = threadIdx.x, lane = tid & 63, x = lane & 15, g = lane >> 4;
+    const int cin = Lw - 16;
+
+    for (int idx = tid; idx < (nWx + nWp) * 64; idx += MF_THREADS) {
+        const int ll = idx & 63, f = idx >> 6, gg = ll >> 4;
+        const bool post = f >= nWx;
+        const int fp = f - nWx;
+        const int n = post ? fp / K : f / NCB, c = post ? fp % K : (f % NCB) / HB;
+        const int Ho = post ? 16 : 32, o = (post ? 0 : ((f % NCB) % HB) * 16) + (ll & 15);
+        const float* Wsrc = post ? a.Wc : W;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int l = 8 * gg + e;
+            const int wl = NARROW ? stc_wrow_swapped(l, cin) : l;
+            v[e] = (wl >= 0 && wl < Lw) ? Wsrc[((size_t)(n * K + c) * Lw + wl) * Ho + o] : 0.f;
+        }
+        put_frag(Wx, f < nWx ? f : nWx + nTx + fp, ll, v);
+    }
+    for (int idx = tid; idx < nTx * 64; idx += MF_THREADS) {
+        const int ll = idx & 63, f = idx >> 6, db = f % NRB, p = (f / NRB) % NB2, c = f / (NRB * NB2), gg = ll >> 4;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int cp = 32 * p + pair_row(gg, e), d = 16 * db + (ll & 15);
+            v[e] = c == 0 ? (cp == d ? 1.f : 0.f) : Tc[(size_t)c * C * C + cp * C + d];
+        }
+        put_frag(Tx, f, ll, v);
+    }
+    __syncthreads();
+
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nw = gridDim.x * MF_WAVES;
+    f32x4 bv[HB], bcv = kZero4;
+#pragma unroll
+    for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[hb][r] = bias ? bias[16 * hb + 4 * g + r] : 0.f;
+    if (POST && a.bc)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bcv[r] = a.bc[4 * g + r];
+
+    int node = blockIdx.x * MF_WAVES + wave;
+    u32x4 cur[K][NRB], nxt[K][NRB];
+    auto load_rows = [&](u32x4 (&z)[K][NRB], int nd) {
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) {
+            const size_t row = (size_t)nd * C + 16 * rb + x;
+            z[0][rb] = load_planar8<NARROW>(a.X, a.H, row, g, cin);
+            z[1][rb] = load_planar8<NARROW>(a.SX, a.SH, row, g, cin);
+        }
+    };
+    if (node < nodes) load_rows(cur, node);
+    while (node < nodes) {
+        const int next_node = node + nw;
+        if (next_node < nodes) load_rows(nxt, next_node);
+        u32x2 hq[NRB];                                          // H in the epilogue's layout: row 16 db + x, columns 4g..4g+3
+#pragma unroll
+        for (int db = 0; db < NRB; ++db) hq[db] = *reinterpret_cast<const u32x2*>(a.H + ((size_t)node * C + 16 * db + x) * 16 + 4 * g);
+        __builtin_amdgcn_sched_barrier(0);
+        const int lo = opaque(lane);
+
+        f32x4 acc[NRB][NCB];
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = kZero4;
+#pragma unroll
+        for (int n = 0; n < K; ++n)
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                const u32x4 w = Wx[(n * NCB + cb) * 64 + lo];
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) acc[rb][cb] = mma(cur[n][rb], w, acc[rb][cb]);
+            }
+        f32x4 yT[HB][NRB];
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+            for (int db = 0; db < NRB; ++db) yT[hb][db] = bv[hb];
+#pragma unroll
+        for (int c = 0; c < K; ++c)
+#pragma unroll
+            for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+                for (int p = 0; p < NB2; ++p) {
+                    const u32x4 u = pack8(acc[2 * p][c * HB + hb], acc[2 * p + 1][c * HB + hb]);
+#pragma unroll
+                    for (int db = 0; db < NRB; ++db) yT[hb][db] = mma(u, Tx[((c * NB2 + p) * NRB + db) * 64 + lo], yT[hb][db]);
+                }
+        u32x2 rhp[NRB];
+#pragma unroll
+        for (int db = 0; db < NRB; ++db) {
+            const size_t e = ((size_t)node * C + 16 * db + x) * 16 + 4 * g;
+            const f32x4 hh = unpack4(hq[db]);
+            f32x4 u, rg, rh;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                u[r] = fast_sigmoid(yT[0][db][r]);
+                rg[r] = fast_sigmoid(yT[1][db][r]);
+                rh[r] = rg[r] * hh[r];
+            }
+            rhp[db] = pack4(rh);
+            *reinterpret_cast<u32x2*>(a.U + e) = pack4(u);
+            *reinterpret_cast<u32x2*>(a.R + e) = pack4(rg);
+            *reinterpret_cast<u32x2*>(a.RH + e) = rhp[db];
+        }
+        if constexpr (POST) {
+            // the candidate's input row [Xt | RH] (narrow: [RH | x | 0]) as an operand: RH columns 8j..8j+7 of row x sit with lanes (x, 2j), (x, 2j+1)
+            const int j = NARROW ? (g & 1) : (g - 2 < 0 ? 0 : g - 2);
+            const int s0 = 4 * (x + 32 * j), s1 = s0 + 64;          // byte addresses of the two source lanes
+            u32x4 zc[NRB];
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+                const u32x4 rr = {(unsigned)__builtin_amdgcn_ds_bpermute(s0, (int)rhp[rb][0]), (unsigned)__builtin_amdgcn_ds_bpermute(s0, (int)rhp[rb][1]),
+                                  (unsigned)__builtin_amdgcn_ds_bpermute(s1, (int)rhp[rb][0]), (unsigned)__builtin_amdgcn_ds_bpermute(s1, (int)rhp[rb][1])};
+                zc[rb] = (NARROW ? g < 2 : g >= 2) ? rr : cur[0][rb];
+            }
+            f32x4 pa[K][NRB][K];
+#pragma unroll
+            for (int n = 0; n < K; ++n)
+#pragma unroll
+                for (int c = 0; c < K; ++c) {
+                    const u32x4 w = Wp[(n * K + c) * 64 + lo];
+#pragma unroll
+                    for (int rb = 0; rb < NRB; ++rb) pa[n][rb][c] = mma(zc[rb], w, kZero4);
+                }
+#pragma unroll
+            for (int n = 0; n < K; ++n) {
+                f32x4 yA[NRB];
+#pragma unroll
+                for (int db = 0; db < NRB; ++db) yA[db] = n == 0 ? bcv : kZero4;
+#pragma unroll
+                for (int c = 0; c < K; ++c)
+#pragma unroll
+                    for (int p = 0; p < NB2; ++p) {
+                        const u32x4 u = pack8(pa[n][2 * p][c], pa[n][2 * p + 1][c]);
+#pragma unroll
+                        for (int db = 0; db < NRB; ++db) yA[db] = mma(u, Tx[((c * NB2 + p) * NRB + db) * 64 + lo], yA[db]);
+                    }
+#pragma unroll
+                for (int db = 0; db < NRB; ++db)
+                    *reinterpret_cast<u32x2*>((n == 0 ? a.A : a.Bm) + ((size_t)node * C + 16 * db + x) * 16 + 4 * g) = pack4(yA[db]);
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < K; ++n)
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) cur[n][rb] = nxt[n][rb];
+        node = next_node;
+    }
+}
+
 // --------------------------------------------------------------------------------------- backward
 // Per node, with Q_0 = dY and Q_c = T_c dY (c >= 1):
 //   gd (tiles rows d, cols o)     = dY rows . selector                     accumulator-layout copy of dY (exact)
@@ -185,11 +389,32 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_bf16_
 template <int NB2, int K>
 struct BwdWaves { static constexpr int v = (NB2 == 1 && K <= 2) ? 2 : 1; };
 
-template <int NB2, int HB, int K, int L>
+// PL = 1: planar slabs (Z.p[n] = columns 0..15, Z.q[n] = columns 16..31 of slab n, (nodes, C, 16) planes each) and planar
+// gradients (dZ.p[n], dZ.q[n] likewise).  PL = 2: planar with a narrow input plane -- Z.q[n] = the 16-wide state plane,
+// Z.p[n] = the (nodes, C, cin) input plane, slab columns [state | input | 0], W rows permuted; only dZ.q[n] is produced.
+// PRO = 1 (planar gates convolution of an STC_Cell, Ho = 32): dY is not read but formed per row from the GRU's saved planes
+// (autograd of STC_GNN.py:71-78):  dY = [dHnew (Cand - H) U (1-U) | dRH H R (1-R)],  and the by-product
+// dH = dRH R + dHnew (1-U) -- what the previous state is owed outside the convolution -- is written on the way.
+struct GatesPro { const bf16_t *dRH, *Cand, *H, *U, *R, *dHnew; bf16_t* dH; };
+struct BPtrs2 { const bf16_t* p[STC_MAX_K]; const bf16_t* q[STC_MAX_K]; };
+struct BDPtrs2 { bf16_t* p[STC_MAX_K]; bf16_t* q[STC_MAX_K]; };
+
+__device__ __forceinline__ void unpack8(const u32x4 v, float (&r)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { r[2 * i] = __uint_as_float(v[i] << 16); r[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u); }
+}
+__device__ __forceinline__ u32x4 pack8f(const float (&r)[8]) {
+    return u32x4{pk_bf16(r[0], r[1]), pk_bf16(r[2], r[3]), pk_bf16(r[4], r[5]), pk_bf16(r[6], r[7])};
+}
+
+template <int NB2, int HB, int K, int L, int PL = 0, int PRO = 0>
 __global__ __launch_bounds__(MF_THREADS, (BwdWaves<NB2, K>::v)) void node_bwd_bf16_kernel(
-    BPtrs Z, const float* __restrict__ Tc, const float* __restrict__ W, const bf16_t* __restrict__ dY,
-    BDPtrs dZ, float* __restrict__ partial, int nodes, int want_db, int Lw) {
+    BPtrs2 Z, const float* __restrict__ Tc, const float* __restrict__ W, const bf16_t* __restrict__ dY,
+    BDPtrs2 dZ, float* __restrict__ partial, int nodes, int want_db, int Lw, GatesPro pro) {
+    static_assert(!PL || (L == 32 && K == 2), "planar slabs are 16 + 16 columns, K = 2");
+    static_assert(!PRO || (PL && HB == 2), "the gates prologue belongs to the planar gates convolution");
     constexpr int NRB = 2 * NB2, C = 32 * NB2, Ho = 16 * HB, LB = (L + 15) / 16;
+    const int cin = Lw - 16;                            // PL = 2: width of the narrow input plane
     constexpr int nTB = (K - 1) * NRB * NB2, nWA = K * LB * K;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32x4* TB = reinterpret_cast<u32x4*>(smem_raw);     // [K-1][NRB rb][NB2 p]   T_c[16 rb + x][32 p + pair_row]
@@ -211,7 +436,8 @@ __global__ __launch_bounds__(MF_THREADS, (BwdWaves<NB2, K>::v)) void node_bwd_bf
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int o = c == 0 ? 8 * gg + e : pair_row(gg, e);      // Q_0 comes as dY rows (natural order), Q_c from accumulators
-            v[e] = (o < Ho && l < Lw) ? W[((size_t)(n * K + c) * Lw + l) * Ho + o] : 0.f;
+            const int wl = PL == 2 ? stc_wrow_swapped(l, cin) : l;
+            v[e] = (o < Ho && wl >= 0 && wl < Lw) ? W[((size_t)(n * K + c) * Lw + wl) * Ho + o] : 0.f;
         }
         put_frag(WA, f, ll, v);
     }
@@ -240,11 +466,37 @@ __global__ __launch_bounds__(MF_THREADS, (BwdWaves<NB2, K>::v)) void node_bwd_bf
         const size_t r0 = (size_t)node * C;
         u32x4 dyr[NRB], zr[K][NRB];
 #pragma unroll
-        for (int rb = 0; rb < NRB; ++rb) dyr[rb] = load_row8<Ho>(dY, r0 + 16 * rb + x, g);
-#pragma unroll
         for (int n = 0; n < K; ++n)
 #pragma unroll
-            for (int rb = 0; rb < NRB; ++rb) zr[n][rb] = load_row8<L>(Z.p[n], r0 + 16 * rb + x, g);
+            for (int rb = 0; rb < NRB; ++rb) {
+                if constexpr (PL != 0) zr[n][rb] = load_planar8<PL == 2>(Z.p[n], Z.q[n], r0 + 16 * rb + x, g, cin);
+                else zr[n][rb] = load_row8<L>(Z.p[n], r0 + 16 * rb + x, g);
+            }
+        if constexpr (PRO != 0) {
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+                const size_t e = (r0 + 16 * rb + x) * 16 + 8 * (g & 1);       // lanes g and g + 2 read the same 8 columns
+                float gn[8], cd[8], hh[8], uu[8], dr[8], rr[8], gy[8], dh[8];
+                unpack8(*reinterpret_cast<const u32x4*>(pro.dHnew + e), gn);
+                unpack8(*reinterpret_cast<const u32x4*>(pro.Cand + e), cd);
+                unpack8(*reinterpret_cast<const u32x4*>(pro.H + e), hh);
+                unpack8(*reinterpret_cast<const u32x4*>(pro.U + e), uu);
+                unpack8(*reinterpret_cast<const u32x4*>(pro.dRH + e), dr);
+                unpack8(*reinterpret_cast<const u32x4*>(pro.R + e), rr);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float gu = gn[i] * (cd[i] - hh[i]) * uu[i] * (1.f - uu[i]);
+                    const float gr = dr[i] * hh[i] * rr[i] * (1.f - rr[i]);
+                    gy[i] = g < 2 ? gu : gr;
+                    dh[i] = fmaf(dr[i], rr[i], gn[i] * (1.f - uu[i]));
+                }
+                dyr[rb] = pack8f(gy);
+                if (g < 2) *reinterpret_cast<u32x4*>(pro.dH + e) = pack8f(dh);
+            }
+        } else {
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) dyr[rb] = load_row8<Ho>(dY, r0 + 16 * rb + x, g);
+        }
         const int lo = opaque(lane);
 
         // ---- dY in accumulator layout (rows d = 16 kb + 4g + r, column o = 16 hb + x), db, and as operands
@@ -290,9 +542,21 @@ __global__ __launch_bounds__(MF_THREADS, (BwdWaves<NB2, K>::v)) void node_bwd_bf
 #pragma unroll
                     for (int rb = 0; rb < NRB; ++rb) z[rb] = mma(w, qb[c][rb], z[rb]);
                 }
+                if constexpr (PL == 1) {                        // planar gradient slabs: block lb of the row goes to plane lb
 #pragma unroll
-                for (int rb = 0; rb < NRB; ++rb)
-                    *reinterpret_cast<u32x2*>(dZ.p[n] + (r0 + 16 * rb + x) * L + 16 * lb + 4 * g) = pack4(z[rb]);
+                    for (int rb = 0; rb < NRB; ++rb)
+                        *reinterpret_cast<u32x2*>((lb == 0 ? dZ.p[n] : dZ.q[n]) + (r0 + 16 * rb + x) * 16 + 4 * g) = pack4(z[rb]);
+                } else if constexpr (PL == 2) {                 // narrow input plane: only the state plane's gradient is wanted
+                    if (lb == 0) {
+#pragma unroll
+                        for (int rb = 0; rb < NRB; ++rb)
+                            *reinterpret_cast<u32x2*>(dZ.q[n] + (r0 + 16 * rb + x) * 16 + 4 * g) = pack4(z[rb]);
+                    }
+                } else {
+#pragma unroll
+                    for (int rb = 0; rb < NRB; ++rb)
+                        *reinterpret_cast<u32x2*>(dZ.p[n] + (r0 + 16 * rb + x) * L + 16 * lb + 4 * g) = pack4(z[rb]);
+                }
             }
 
         // ---- Qd_c tiles (rows c', columns o) as operands: slots = rows c' of the tile pair p
@@ -332,7 +596,144 @@ __global__ __launch_bounds__(MF_THREADS, (BwdWaves<NB2, K>::v)) void node_bwd_bf
                             dWt[n][lb][c][hb] = mma(a, c == 0 ? gd[hb][p] : qd[c > 0 ? c - 1 : 0][hb][p], dWt[n][lb][c][hb]);
                 }
     }
-    combine_dw<K, LB, HB>(reinterpret_cast<float*>(smem_raw), dWt, dbp, partial, Lw, want_db);
+    combine_dw<K, LB, HB>(reinterpret_cast<float*>(smem_raw), dWt, dbp, partial, Lw, want_db, PL == 2 ? cin : -1);
+}
+
+// --------------------------------------------------------------------------------------- post-aggregation backward (K = 2, Ho = 16)
+// Candidate convolution in the form Y = A + S.Bm (see stc_node_x3.hip): from the input row [X | X2] (planar) and the two
+// gradients dA = dY, dB = S^T dY, produce the input's gradient and dW / db in one pass:
+//   per weight set n (dY_0 = dA, dY_1 = dB):  Q^n_0 = dY_n,  Q^n_1 = T_1 dY_n
+//   d[X | X2]^T (rows l, cols c') = sum_n sum_c W_{n,c} (Q^n_c)^T        dW_{n,c} (rows l, cols o) += [X | X2]^T Q^n_c
+// bf16-native: the row [dA | dB] (lanes g < 2 take dA, g >= 2 take dB) is one 32-slot operand -- "Ho = 32 with hb = n" --
+// so the structure is the generic backward's with the weight set in the place of the column block.
+template <int NB2, int NARROW>
+__global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_post_bwd_bf16_kernel(
+    const bf16_t* __restrict__ X, const bf16_t* __restrict__ X2, const float* __restrict__ Tc, const float* __restrict__ W,
+    const bf16_t* __restrict__ dA, const bf16_t* __restrict__ dB, bf16_t* __restrict__ dX, bf16_t* __restrict__ dX2,
+    float* __restrict__ partial, int nodes, int want_db, int Lw) {
+    constexpr int K = 2, NRB = 2 * NB2, C = 32 * NB2, LB = 2;
+    constexpr int nTB = NRB * NB2, nWA = LB * K;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32x4* TB = reinterpret_cast<u32x4*>(smem_raw);     // [NRB rb][NB2 p]   T_1[16 rb + x][32 p + pair_row]
+    u32x4* WA = TB + nTB * 64;                           // [LB][K c]         A: W[(n(slot), c, 16 lb + x)][o(slot)]
+    const int tid = threadIdx.x, lane = tid & 63, x = lane & 15, g = lane >> 4;
+    const int cin = Lw - 16;
+
+    for (int idx = tid; idx < nTB * 64; idx += MF_THREADS) {
+        const int ll = idx & 63, f = idx >> 6, p = f % NB2, rb = f / NB2, gg = ll >> 4;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = Tc[(size_t)C * C + (16 * rb + (ll & 15)) * C + 32 * p + pair_row(gg, e)];
+        put_frag(TB, f, ll, v);
+    }
+    for (int idx = tid; idx < nWA * 64; idx += MF_THREADS) {
+        const int ll = idx & 63, f = idx >> 6, c = f % K, lb = f / K, gg = ll >> 4;
+        const int l = 16 * lb + (ll & 15);
+        const int wl = NARROW ? stc_wrow_swapped(l, cin) : l;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int n = c == 0 ? gg >> 1 : e >> 2;                         // the [dA | dB] row: natural order; accumulators: pair order
+            const int o = c == 0 ? 8 * (gg & 1) + e : 4 * gg + (e & 3);
+            v[e] = (wl >= 0 && wl < Lw) ? W[((size_t)(n * K + c) * Lw + wl) * 16 + o] : 0.f;
+        }
+        put_frag(WA, f, ll, v);
+    }
+    __syncthreads();
+
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nw = gridDim.x * MF_WAVES;
+    u32x4 sel[2];
+    sel[0] = selector(0, x, g);
+    sel[1] = selector(1, x, g);
+    f32x4 dWt[K][LB][K][1];
+    float dbp[1] = {0.f};
+#pragma unroll
+    for (int n = 0; n < K; ++n)
+#pragma unroll
+        for (int lb = 0; lb < LB; ++lb)
+#pragma unroll
+            for (int c = 0; c < K; ++c) dWt[n][lb][c][0] = kZero4;
+
+    for (int node = blockIdx.x * MF_WAVES + wave; node < nodes; node += nw) {
+        const size_t r0 = (size_t)node * C;
+        u32x4 dyr[NRB], zr[NRB];
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) {
+            dyr[rb] = load_planar8<0>(dA, dB, r0 + 16 * rb + x, g, 16);
+            zr[rb] = NARROW ? load_planar8<1>(X2, X, r0 + 16 * rb + x, g, cin) : load_planar8<0>(X, X2, r0 + 16 * rb + x, g, 16);
+        }
+        const int lo = opaque(lane);
+
+        u32x4 gd[K][NB2];                                       // dY_n in accumulator layout (rows d, column o = x) as operands
+#pragma unroll
+        for (int n = 0; n < K; ++n)
+#pragma unroll
+            for (int p = 0; p < NB2; ++p) {
+                const f32x4 t0 = mma(dyr[2 * p], sel[n], kZero4), t1 = mma(dyr[2 * p + 1], sel[n], kZero4);
+                if (n == 0) dbp[0] += ((t0[0] + t0[1]) + (t0[2] + t0[3])) + ((t1[0] + t1[1]) + (t1[2] + t1[3]));      // the bias sits on A only
+                gd[n][p] = pack8(t0, t1);
+            }
+        u32x4 qb1[NRB];                                         // (T_1 dY_n)^T, both n, as the B operand of the c = 1 step
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) {
+            f32x4 Qv[K] = {kZero4, kZero4};
+#pragma unroll
+            for (int p = 0; p < NB2; ++p) {
+                const u32x4 t = TB[(rb * NB2 + p) * 64 + lo];
+#pragma unroll
+                for (int n = 0; n < K; ++n) Qv[n] = mma(gd[n][p], t, Qv[n]);
+            }
+            qb1[rb] = pack8(Qv[0], Qv[1]);
+        }
+#pragma unroll
+        for (int lb = 0; lb < LB; ++lb) {
+            if (NARROW && lb == 1) continue;                    // the narrow input plane needs no gradient
+            const u32x4 w0 = WA[(lb * K + 0) * 64 + lo], w1 = WA[(lb * K + 1) * 64 + lo];
+            bf16_t* dst = lb == 0 ? dX : dX2;
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+                const f32x4 z = mma(w1, qb1[rb], mma(w0, dyr[rb], kZero4));
+                *reinterpret_cast<u32x2*>(dst + (r0 + 16 * rb + x) * 16 + 4 * g) = pack4(z);
+            }
+        }
+        u32x4 qd[K][NB2];                                       // T_1 dY_n (rows c', columns o) as operands
+#pragma unroll
+        for (int n = 0; n < K; ++n) {
+            f32x4 Qd[NRB];
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+                Qd[rb] = kZero4;
+#pragma unroll
+                for (int p = 0; p < NB2; ++p) Qd[rb] = mma(TB[(rb * NB2 + p) * 64 + lo], gd[n][p], Qd[rb]);
+            }
+#pragma unroll
+            for (int p = 0; p < NB2; ++p) qd[n][p] = pack8(Qd[2 * p], Qd[2 * p + 1]);
+        }
+#pragma unroll
+        for (int lb = 0; lb < LB; ++lb)
+#pragma unroll
+            for (int p = 0; p < NB2; ++p) {
+                const u32x4 a = pack8(mma(zr[2 * p], sel[lb], kZero4), mma(zr[2 * p + 1], sel[lb], kZero4));
+#pragma unroll
+                for (int n = 0; n < K; ++n)
+#pragma unroll
+                    for (int c = 0; c < K; ++c) dWt[n][lb][c][0] = mma(a, c == 0 ? gd[n][p] : qd[n][p], dWt[n][lb][c][0]);
+            }
+    }
+    combine_dw<K, LB, 1>(reinterpret_cast<float*>(smem_raw), dWt, dbp, partial, Lw, want_db, NARROW ? cin : -1);
+}
+
+// dY = dHnew * U * (1 - Cand^2): the blend backward alone, for a state whose gradient arrives as a finished tensor
+__global__ __launch_bounds__(256) void blend_bwd_bf16_kernel(const u32x4* __restrict__ dHnew, const u32x4* __restrict__ U,
+                                                             const u32x4* __restrict__ Cand, u32x4* __restrict__ dY, long long n8) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+        float gn[8], u[8], c[8];
+        unpack8(dHnew[i], gn); unpack8(U[i], u); unpack8(Cand[i], c);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) gn[k] = gn[k] * u[k] * (1.f - c[k] * c[k]);
+        dY[i] = pack8f(gn);
+    }
 }
 
 // --------------------------------------------------------------------------------------- host side
@@ -363,14 +764,66 @@ int launch_bwd(const void* const* Z, const float* Tc, const float* W, const void
     auto kern = node_bwd_bf16_kernel<NB2, HB, K, L>;
     if (int rc = stc::hip_status(stc::allow_lds(kern, lds), "hipFuncSetAttribute(node bwd bf16)")) return rc;
     static const int resident = stc::resident_blocks(kern, MF_THREADS, lds, BwdWaves<NB2, K>::v);
-    BPtrs zp{};
-    BDPtrs dzp{};
+    BPtrs2 zp{};
+    BDPtrs2 dzp{};
     for (int n = 0; n < K; ++n) { zp.p[n] = static_cast<const bf16_t*>(Z[n]); dzp.p[n] = static_cast<bf16_t*>(dZ[n]); }
     const long long want = (nodes + MF_WAVES - 1) / MF_WAVES;
     int grid = resident < MF_BWD_MAX_GRID ? resident : MF_BWD_MAX_GRID;
     if (want < grid) grid = (int)want;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(MF_THREADS), lds, stream, zp, Tc, W, static_cast<const bf16_t*>(dY), dzp, partial, (int)nodes, want_db, Lw);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(MF_THREADS), lds, stream, zp, Tc, W, static_cast<const bf16_t*>(dY), dzp, partial, (int)nodes, want_db, Lw, GatesPro{});
     STC_LAUNCH_CHECK("node_bwd_bf16 launch");
+    *n_partials = grid;
+    return STC_OK;
+}
+
+template <int NB2, int NARROW, int POST>
+int launch_gates_fwd(const GatesFwd& a, const float* Tc, const float* W, const float* bias, long long nodes, int Lw, hipStream_t stream) {
+    constexpr int NRB = 2 * NB2;
+    const size_t lds = (size_t)(2 * 4 + 2 * NB2 * NRB + (POST ? 4 : 0)) * 64 * 16;
+    auto kern = cell_gates_fwd_bf16_kernel<NB2, NARROW, POST>;
+    if (int rc = stc::hip_status(stc::allow_lds(kern, lds), "hipFuncSetAttribute(gates fwd bf16)")) return rc;
+    static const int resident = stc::resident_blocks(kern, MF_THREADS, lds, 2);
+    const long long want = (nodes + MF_WAVES - 1) / MF_WAVES;
+    const int grid = (int)(want < resident ? want : resident);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(MF_THREADS), lds, stream, a, Tc, W, bias, (int)nodes, Lw);
+    STC_LAUNCH_CHECK("cell_gates_fwd_bf16 launch");
+    return STC_OK;
+}
+
+template <int NB2, int PL>
+int launch_gates_bwd(const BPtrs2& zp, const BDPtrs2& dzp, const GatesPro& pro, const float* Tc, const float* W,
+                     float* partial, int* n_partials, int want_db, long long nodes, int Lw, hipStream_t stream) {
+    constexpr int NRB = 2 * NB2, K = 2, LB = 2, nW = K * K * 32 * 32;
+    const size_t frag = (size_t)(NRB * NB2 + K * LB * K) * 64 * 16;
+    const size_t slabs = (size_t)MF_WAVES * (nW + 32) * sizeof(float);
+    const size_t lds = frag > slabs ? frag : slabs;
+    auto kern = node_bwd_bf16_kernel<NB2, 2, 2, 32, PL, 1>;
+    if (int rc = stc::hip_status(stc::allow_lds(kern, lds), "hipFuncSetAttribute(gates bwd bf16)")) return rc;
+    static const int resident = stc::resident_blocks(kern, MF_THREADS, lds, BwdWaves<NB2, 2>::v);
+    const long long want = (nodes + MF_WAVES - 1) / MF_WAVES;
+    int grid = resident < MF_BWD_MAX_GRID ? resident : MF_BWD_MAX_GRID;
+    if (want < grid) grid = (int)want;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(MF_THREADS), lds, stream, zp, Tc, W, static_cast<const bf16_t*>(nullptr), dzp, partial, (int)nodes, want_db, Lw, pro);
+    STC_LAUNCH_CHECK("cell_gates_bwd_bf16 launch");
+    *n_partials = grid;
+    return STC_OK;
+}
+
+template <int NB2, int NARROW>
+int launch_post_bwd(const bf16_t* X, const bf16_t* X2, const float* Tc, const float* W, const bf16_t* dA, const bf16_t* dB, bf16_t* dX, bf16_t* dX2,
+                    float* partial, int* n_partials, int want_db, long long nodes, int Lw, hipStream_t stream) {
+    constexpr int NRB = 2 * NB2, nW = 4 * 32 * 16;
+    const size_t frag = (size_t)(NRB * NB2 + 4) * 64 * 16;
+    const size_t slabs = (size_t)MF_WAVES * (nW + 16) * sizeof(float);
+    const size_t lds = frag > slabs ? frag : slabs;
+    auto kern = node_post_bwd_bf16_kernel<NB2, NARROW>;
+    if (int rc = stc::hip_status(stc::allow_lds(kern, lds), "hipFuncSetAttribute(post bwd bf16)")) return rc;
+    static const int resident = stc::resident_blocks(kern, MF_THREADS, lds, NB2 == 1 ? 2 : 1);
+    const long long want = (nodes + MF_WAVES - 1) / MF_WAVES;
+    int grid = resident < MF_BWD_MAX_GRID ? resident : MF_BWD_MAX_GRID;
+    if (want < grid) grid = (int)want;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(MF_THREADS), lds, stream, X, X2, Tc, W, dA, dB, dX, dX2, partial, (int)nodes, want_db, Lw);
+    STC_LAUNCH_CHECK("node_post_bwd_bf16 launch");
     *n_partials = grid;
     return STC_OK;
 }
@@ -447,4 +900,127 @@ extern "C" int stc_bdg_node_bwd_bf16(const void* const* Z, int32_t Ks, const flo
     };
     if (int rc = run()) return rc;
     return stc_node_reduce_partials(partial, n_parts, nW, Ho, dW, db, s);
+}
+
+// ---- planar STC_Cell on bf16 planes (K = 2, hidden 16)
+extern "C" int stc_cell_planar_bf16_supported(int32_t Ks, int32_t Kc, int32_t C, int32_t h) {
+    return (Ks == 2 && Kc == 2 && (C == 32 || C == 64) && h == 16) ? 1 : 0;
+}
+
+extern "C" int stc_cell_gates_fwd_planar_bf16(const void* X, const void* H, const void* SX, const void* SH,
+                                              const float* Tc, const float* W, const float* bias,
+                                              void* U, void* Rg, void* RH,
+                                              const float* Wc, const float* bc, void* A, void* Bm,
+                                              int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream) {
+    STC_REQUIRE(stc_cell_planar_bf16_supported(2, 2, C, h), STC_EUNSUPPORTED, "stc_cell_gates_fwd_planar_bf16: C=%d h=%d not on the bf16 planar path", C, h);
+    const int cin = Lw - 16;
+    STC_REQUIRE(cin == 16 || (cin >= 1 && cin <= 4), STC_EUNSUPPORTED, "stc_cell_gates_fwd_planar_bf16: input plane of %d columns (16, or 1..4)", cin);
+    STC_REQUIRE(nodes >= 0 && nodes < (1ll << 31) / C, STC_ELIMIT, "stc_cell_gates_fwd_planar_bf16: nodes=%lld", (long long)nodes);
+    if (nodes == 0) return STC_OK;
+    STC_REQUIRE(X && H && SX && SH && Tc && W && U && Rg && RH, STC_EINVAL, "stc_cell_gates_fwd_planar_bf16: null pointer");
+    STC_REQUIRE((A == nullptr) == (Bm == nullptr) && (A == nullptr) == (Wc == nullptr), STC_EINVAL, "stc_cell_gates_fwd_planar_bf16: Wc, A, Bm go together");
+    STC_REQUIRE(stc::aligned16(H) && stc::aligned16(SH) && stc::aligned16(U) && stc::aligned16(Rg) && stc::aligned16(RH) &&
+                    (cin != 16 || (stc::aligned16(X) && stc::aligned16(SX))) && (!A || (stc::aligned16(A) && stc::aligned16(Bm))),
+                STC_EALIGN, "stc_cell_gates_fwd_planar_bf16: planes must be 16-byte aligned");
+    const GatesFwd a{static_cast<const bf16_t*>(X), static_cast<const bf16_t*>(H), static_cast<const bf16_t*>(SX), static_cast<const bf16_t*>(SH),
+                     static_cast<bf16_t*>(U), static_cast<bf16_t*>(Rg), static_cast<bf16_t*>(RH), Wc, bc, static_cast<bf16_t*>(A), static_cast<bf16_t*>(Bm)};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool narrow = cin != 16, post = A != nullptr;
+#define GF(NB2_) (narrow ? (post ? launch_gates_fwd<NB2_, 1, 1>(a, Tc, W, bias, nodes, Lw, s) : launch_gates_fwd<NB2_, 1, 0>(a, Tc, W, bias, nodes, Lw, s)) \
+                         : (post ? launch_gates_fwd<NB2_, 0, 1>(a, Tc, W, bias, nodes, Lw, s) : launch_gates_fwd<NB2_, 0, 0>(a, Tc, W, bias, nodes, Lw, s)))
+    return C == 32 ? GF(1) : GF(2);
+#undef GF
+}
+
+// planar form: X / SX (nodes, C, cin), H / SH and everything else (nodes, C, 16); dZ = {dX, dSX, dH plane, dSH} (the first two
+// unused and may be null for a narrow input plane); dH: the previous state's share from the gates prologue
+extern "C" int stc_cell_gates_bwd_planar_bf16(const void* X, const void* H, const void* SX, const void* SH,
+                                              const float* Tc, const float* W,
+                                              const void* dCandIn, const void* Cand, const void* U, const void* Rg, const void* dHnew,
+                                              void* const* dZ, float* dW, float* db, void* dH,
+                                              void* workspace, size_t workspace_bytes,
+                                              int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream) {
+    STC_REQUIRE(stc_cell_planar_bf16_supported(2, 2, C, h), STC_EUNSUPPORTED, "stc_cell_gates_bwd_planar_bf16: C=%d h=%d not on the bf16 planar path", C, h);
+    const int cin = Lw - 16;
+    STC_REQUIRE(cin == 16 || (cin >= 1 && cin <= 4), STC_EUNSUPPORTED, "stc_cell_gates_bwd_planar_bf16: input plane of %d columns (16, or 1..4)", cin);
+    STC_REQUIRE(nodes >= 0 && nodes < (1ll << 31) / C, STC_ELIMIT, "stc_cell_gates_bwd_planar_bf16: nodes=%lld", (long long)nodes);
+    STC_REQUIRE(W && dW && Tc, STC_EINVAL, "stc_cell_gates_bwd_planar_bf16: null W/dW/Tc");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int nW = 4 * Lw * 32;
+    if (nodes == 0) {
+        if (int rc = stc::hip_status(hipMemsetAsync(dW, 0, (size_t)nW * sizeof(float), s), "memset dW")) return rc;
+        if (db) if (int rc = stc::hip_status(hipMemsetAsync(db, 0, 32 * sizeof(float), s), "memset db")) return rc;
+        return STC_OK;
+    }
+    const bool narrow = cin != 16;
+    STC_REQUIRE(X && H && SX && SH && dCandIn && Cand && U && Rg && dHnew && dZ && dH && dZ[2] && dZ[3] && (narrow || (dZ[0] && dZ[1])), STC_EINVAL,
+                "stc_cell_gates_bwd_planar_bf16: null pointer");
+    for (const void* q : {H, SH, dCandIn, Cand, U, Rg, dHnew, (const void*)dH, (const void*)dZ[2], (const void*)dZ[3]})
+        STC_REQUIRE(stc::aligned16(q), STC_EALIGN, "stc_cell_gates_bwd_planar_bf16: planes must be 16-byte aligned");
+    if (!narrow) STC_REQUIRE(stc::aligned16(X) && stc::aligned16(SX) && stc::aligned16(dZ[0]) && stc::aligned16(dZ[1]), STC_EALIGN,
+                             "stc_cell_gates_bwd_planar_bf16: planes must be 16-byte aligned");
+    STC_REQUIRE(workspace && stc::aligned16(workspace) && workspace_bytes >= stc_bdg_node_bwd_workspace_bytes(2, 2, C, 32, 32, 0), STC_EINVAL,
+                "stc_cell_gates_bwd_planar_bf16: workspace null, misaligned or too small (%zu B)", workspace_bytes);
+    auto B = [](const void* q) { return static_cast<const bf16_t*>(q); };
+    auto M = [](void* q) { return static_cast<bf16_t*>(q); };
+    BPtrs2 zp{};
+    BDPtrs2 dzp{};
+    zp.p[0] = B(X); zp.p[1] = B(SX); zp.q[0] = B(H); zp.q[1] = B(SH);
+    dzp.p[0] = narrow ? nullptr : M(dZ[0]); dzp.p[1] = narrow ? nullptr : M(dZ[1]); dzp.q[0] = M(dZ[2]); dzp.q[1] = M(dZ[3]);
+    const GatesPro pro{B(dCandIn), B(Cand), B(H), B(U), B(Rg), B(dHnew), M(dH)};
+    float* partial = static_cast<float*>(workspace);
+    int n_parts = 0;
+    const int rc = C == 32 ? (narrow ? launch_gates_bwd<1, 2>(zp, dzp, pro, Tc, W, partial, &n_parts, db != nullptr, nodes, Lw, s)
+                                     : launch_gates_bwd<1, 1>(zp, dzp, pro, Tc, W, partial, &n_parts, db != nullptr, nodes, Lw, s))
+                           : (narrow ? launch_gates_bwd<2, 2>(zp, dzp, pro, Tc, W, partial, &n_parts, db != nullptr, nodes, Lw, s)
+                                     : launch_gates_bwd<2, 1>(zp, dzp, pro, Tc, W, partial, &n_parts, db != nullptr, nodes, Lw, s));
+    if (rc != STC_OK) return rc;
+    return stc_node_reduce_partials(partial, n_parts, nW, 32, dW, db, s);
+}
+
+// post-aggregation backward of the candidate convolution on planes: wide -- X (columns 0..15), X2 (16..31), gradients dX, dX2;
+// narrow (Lw = 16 + cin, cin <= 4) -- X = the 16-wide plane, X2 = the (nodes, C, cin) input plane, gradient for X only (dX2 null)
+extern "C" int stc_bdg_node_post_bwd_bf16(const void* X, const void* X2, const float* Tc, const float* W, const void* dA, const void* dB,
+                                          void* dX, void* dX2, float* dW, float* db, void* workspace, size_t workspace_bytes,
+                                          int64_t nodes, int32_t C, int32_t Lw, int32_t Ho, void* stream) {
+    STC_REQUIRE((C == 32 || C == 64) && Ho == 16, STC_EUNSUPPORTED, "stc_bdg_node_post_bwd_bf16: C=%d Ho=%d not on the bf16 planar path", C, Ho);
+    const int cin = Lw - 16;
+    STC_REQUIRE(cin == 16 || (cin >= 1 && cin <= 4), STC_EUNSUPPORTED, "stc_bdg_node_post_bwd_bf16: second plane of %d columns (16, or 1..4)", cin);
+    STC_REQUIRE(nodes >= 0 && nodes < (1ll << 31) / C, STC_ELIMIT, "stc_bdg_node_post_bwd_bf16: nodes=%lld", (long long)nodes);
+    STC_REQUIRE(W && dW && Tc, STC_EINVAL, "stc_bdg_node_post_bwd_bf16: null W/dW/Tc");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int nW = 4 * Lw * 16;
+    if (nodes == 0) {
+        if (int rc = stc::hip_status(hipMemsetAsync(dW, 0, (size_t)nW * sizeof(float), s), "memset dW")) return rc;
+        if (db) if (int rc = stc::hip_status(hipMemsetAsync(db, 0, 16 * sizeof(float), s), "memset db")) return rc;
+        return STC_OK;
+    }
+    const bool narrow = cin != 16;
+    STC_REQUIRE(X && X2 && dA && dB && dX && (narrow ? dX2 == nullptr : dX2 != nullptr), STC_EINVAL,
+                "stc_bdg_node_post_bwd_bf16: null pointer (the narrow input plane gets no gradient: dX2 must be null there)");
+    STC_REQUIRE(stc::aligned16(X) && stc::aligned16(dA) && stc::aligned16(dB) && stc::aligned16(dX) && (narrow || (stc::aligned16(X2) && stc::aligned16(dX2))),
+                STC_EALIGN, "stc_bdg_node_post_bwd_bf16: planes must be 16-byte aligned");
+    STC_REQUIRE(workspace && stc::aligned16(workspace) && workspace_bytes >= stc_bdg_node_bwd_workspace_bytes(2, 2, C, 32, 16, 0), STC_EINVAL,
+                "stc_bdg_node_post_bwd_bf16: workspace null, misaligned or too small (%zu B)", workspace_bytes);
+    auto B = [](const void* q) { return static_cast<const bf16_t*>(q); };
+    float* partial = static_cast<float*>(workspace);
+    int n_parts = 0;
+#define PB(NB2_, NAR_) launch_post_bwd<NB2_, NAR_>(B(X), B(X2), Tc, W, B(dA), B(dB), static_cast<bf16_t*>(dX), static_cast<bf16_t*>(dX2), partial, &n_parts, db != nullptr, nodes, Lw, s)
+    const int rc = C == 32 ? (narrow ? PB(1, 1) : PB(1, 0)) : (narrow ? PB(2, 1) : PB(2, 0));
+#undef PB
+    if (rc != STC_OK) return rc;
+    return stc_node_reduce_partials(partial, n_parts, nW, 16, dW, db, s);
+}
+
+extern "C" int stc_gru_blend_bwd_bf16(const void* dHnew, const void* U, const void* Cand, void* dCpre, int64_t n, void* stream) {
+    STC_REQUIRE(n >= 0 && n % 8 == 0, STC_EINVAL, "stc_gru_blend_bwd_bf16: n=%lld must be a non-negative multiple of 8", (long long)n);
+    if (n == 0) return STC_OK;
+    STC_REQUIRE(dHnew && U && Cand && dCpre, STC_EINVAL, "stc_gru_blend_bwd_bf16: null pointer");
+    STC_REQUIRE(stc::aligned16(dHnew) && stc::aligned16(U) && stc::aligned16(Cand) && stc::aligned16(dCpre), STC_EALIGN, "stc_gru_blend_bwd_bf16: misaligned operand");
+    const long long n8 = n / 8;
+    const long long blocks = (n8 + 255) / 256;
+    hipLaunchKernelGGL(blend_bwd_bf16_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const u32x4*>(dHnew), static_cast<const u32x4*>(U), static_cast<const u32x4*>(Cand), static_cast<u32x4*>(dCpre), n8);
+    STC_LAUNCH_CHECK("stc_gru_blend_bwd_bf16 launch");
+    return STC_OK;
 }

@@ -54,26 +54,84 @@ struct Acc8 {                       // one 16-byte piece = 8 bf16 columns, accum
     }
 };
 
-struct Epi { const u32x4* Y0; u32x4* Y; float alpha, beta; };
+enum { EP_PLAIN = 0, EP_BLEND = 1, EP_SUM = 2, EP_SUM2 = 3 };
 
+struct Epi {
+    const u32x4* Y0;                 // PLAIN: optional base term (scaled by beta); BLEND: A (bias included)
+    u32x4* Y;                        // PLAIN / SUM output
+    float alpha, beta;               // PLAIN
+    // BLEND (forward of the candidate convolution in post-aggregation form, STC_GNN.py:76-78): rows are state rows,
+    // Cand = tanh(A + S.Bm), Hnew = (1-U)*H + U*Cand
+    const u32x4 *U, *H;
+    u32x4 *Cand, *Hnew;
+    // SUM / SUM2 (gradient of a state from its consumers' pieces): Y = sum_i add[i] + S.(X [+ X2]); optional
+    // dY = Y * U * (1 - Cand^2), the blend backward of the cell that owns the state (U, gCand: that cell's saved gates)
+    const u32x4* X2;
+    const u32x4* add[5]; int n_add;
+    const u32x4* gCand; u32x4* dY;
+};
+
+__device__ __forceinline__ void unpack8(const u32x4 v, float (&r)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { r[2 * i] = lo_f(v[i]); r[2 * i + 1] = hi_f(v[i]); }
+}
+__device__ __forceinline__ u32x4 pack8(const float (&r)[8]) {
+    return u32x4{pk_bf16(r[0], r[1]), pk_bf16(r[2], r[3]), pk_bf16(r[4], r[5]), pk_bf16(r[6], r[7])};
+}
+__device__ __forceinline__ float tanh_fast(float v) {          // 1 - 2 / (e^{2v} + 1) on the hardware exp2 / rcp
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.8853900817779268f * v));
+}
+
+// BLEND: the epilogue's own operands, requested before the gather so that they arrive under it
+struct BlendIn { u32x4 a, u, h; };
+__device__ __forceinline__ void blend_piece(const Epi& ep, size_t o, const Acc8& acc, const BlendIn& in) {
+    float a[8], u[8], h[8], c[8], hn[8];
+    unpack8(in.a, a); unpack8(in.u, u); unpack8(in.h, h);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        c[i] = tanh_fast(acc.v[i] + a[i]);
+        hn[i] = (1.f - u[i]) * h[i] + u[i] * c[i];
+    }
+    ep.Cand[o] = pack8(c);
+    ep.Hnew[o] = pack8(hn);
+}
+
+template <int MODE>
 __device__ __forceinline__ void finish(const Epi& ep, size_t o, const Acc8& acc) {
     float r[8];
+    if (MODE == EP_PLAIN) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) r[i] = ep.alpha * acc.v[i];
-    if (ep.beta != 0.f) {
-        const u32x4 y0 = __builtin_nontemporal_load(ep.Y0 + o);
+        for (int i = 0; i < 8; ++i) r[i] = ep.alpha * acc.v[i];
+        if (ep.beta != 0.f) {
+            float y0[8];
+            unpack8(__builtin_nontemporal_load(ep.Y0 + o), y0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            r[2 * i] = fmaf(ep.beta, lo_f(y0[i]), r[2 * i]);
-            r[2 * i + 1] = fmaf(ep.beta, hi_f(y0[i]), r[2 * i + 1]);
+            for (int i = 0; i < 8; ++i) r[i] = fmaf(ep.beta, y0[i], r[i]);
         }
+        __builtin_nontemporal_store(pack8(r), ep.Y + o);
+        return;
     }
-    const u32x4 out = {pk_bf16(r[0], r[1]), pk_bf16(r[2], r[3]), pk_bf16(r[4], r[5]), pk_bf16(r[6], r[7])};
-    __builtin_nontemporal_store(out, ep.Y + o);
+    // SUM / SUM2
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = acc.v[i];
+    for (int k = 0; k < ep.n_add; ++k) {
+        float t[8];
+        unpack8(ep.add[k][o], t);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r[i] += t[i];
+    }
+    __builtin_nontemporal_store(pack8(r), ep.Y + o);
+    if (ep.dY) {
+        float u[8], c[8];
+        unpack8(ep.U[o], u); unpack8(ep.gCand[o], c);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r[i] = r[i] * u[i] * (1.f - c[i] * c[i]);
+        __builtin_nontemporal_store(pack8(r), ep.dY + o);
+    }
 }
 
 // ---- CSR: one wave per output row (learned dense graphs, graphs without a row-block plan)
-template <int VPT>
+template <int VPT, int MODE>
 __global__ __launch_bounds__(SPMM_THREADS) void spmm_wave_row_bf16_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ colidx, const float* __restrict__ val,
     int n_rows, int n_cols, const u32x4* __restrict__ X, int F8, int n_tiles, Epi ep) {
@@ -99,6 +157,7 @@ __global__ __launch_bounds__(SPMM_THREADS) void spmm_wave_row_bf16_kernel(
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const u32x4* Xb = X + (size_t)b * n_cols * F8;
+    const u32x4* X2b = MODE == EP_SUM2 ? ep.X2 + (size_t)b * n_cols * F8 : nullptr;
     const u32x4 zero = {0u, 0u, 0u, 0u};
 
     for (int r = wave; r < nr; r += SPMM_WAVES) {
@@ -108,6 +167,17 @@ __global__ __launch_bounds__(SPMM_THREADS) void spmm_wave_row_bf16_kernel(
             Acc8 acc[VPT];
 #pragma unroll
             for (int p = 0; p < VPT; ++p) acc[p].zero();
+            BlendIn bin[VPT];
+            if (MODE == EP_BLEND) {
+#pragma unroll
+                for (int p = 0; p < VPT; ++p) {
+                    const int ch = cb + lane + 64 * p;
+                    if (ch < F8) {
+                        const size_t o = rowg * F8 + ch;
+                        bin[p].a = __builtin_nontemporal_load(ep.Y0 + o); bin[p].u = ep.U[o]; bin[p].h = ep.H[o];
+                    }
+                }
+            }
             auto entry = [&](int j, int& c, float& v) {
                 if (j < SPMM_SEG_CAP) { c = s_col[j]; v = s_val[j]; }
                 else { c = colidx[seg0 + j]; v = val[seg0 + j]; }      // rows longer than the staged segment
@@ -120,7 +190,7 @@ __global__ __launch_bounds__(SPMM_THREADS) void spmm_wave_row_bf16_kernel(
                 float v[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) entry(j + u, c[u], v[u]);
-                u32x4 x[4][VPT];
+                u32x4 x[4][VPT], x2[MODE == EP_SUM2 ? 4 : 1][VPT];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const u32x4* xr = Xb + (size_t)c[u] * F8;
@@ -128,12 +198,16 @@ __global__ __launch_bounds__(SPMM_THREADS) void spmm_wave_row_bf16_kernel(
                     for (int p = 0; p < VPT; ++p) {
                         const int ch = cb + lane + 64 * p;
                         x[u][p] = ch < F8 ? xr[ch] : zero;
+                        if (MODE == EP_SUM2) x2[MODE == EP_SUM2 ? u : 0][p] = ch < F8 ? (X2b + (size_t)c[u] * F8)[ch] : zero;
                     }
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
-                    for (int p = 0; p < VPT; ++p) acc[p].fma(v[u], x[u][p]);
+                    for (int p = 0; p < VPT; ++p) {
+                        acc[p].fma(v[u], x[u][p]);
+                        if (MODE == EP_SUM2) acc[p].fma(v[u], x2[MODE == EP_SUM2 ? u : 0][p]);
+                    }
             }
             for (; j < je; ++j) {
                 int c;
@@ -143,20 +217,26 @@ __global__ __launch_bounds__(SPMM_THREADS) void spmm_wave_row_bf16_kernel(
 #pragma unroll
                 for (int p = 0; p < VPT; ++p) {
                     const int ch = cb + lane + 64 * p;
-                    if (ch < F8) acc[p].fma(v, xr[ch]);
+                    if (ch < F8) {
+                        acc[p].fma(v, xr[ch]);
+                        if (MODE == EP_SUM2) acc[p].fma(v, (X2b + (size_t)c * F8)[ch]);
+                    }
                 }
             }
 #pragma unroll
             for (int p = 0; p < VPT; ++p) {
                 const int ch = cb + lane + 64 * p;
-                if (ch < F8) finish(ep, rowg * F8 + ch, acc[p]);
+                if (ch < F8) {
+                    if (MODE == EP_BLEND) blend_piece(ep, rowg * F8 + ch, acc[p], bin[p]);
+                    else finish<MODE>(ep, rowg * F8 + ch, acc[p]);
+                }
             }
         }
     }
 }
 
 // ---- row-blocked (BCSR 4x1): one wave (pair) produces 4 consecutive output rows, each distinct neighbour row fetched once
-template <int VPT>
+template <int VPT, int MODE>
 __global__ __launch_bounds__(SPMM_THREADS) void spmm_bcsr_bf16_kernel(
     const int* __restrict__ blk_ptr, const int* __restrict__ blk_cols, const float* __restrict__ blk_vals,
     int n_rows, int n_cols, const u32x4* __restrict__ X, int F8, int n_blocks, int n_tiles, Epi ep) {
@@ -181,6 +261,7 @@ __global__ __launch_bounds__(SPMM_THREADS) void spmm_bcsr_bf16_kernel(
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const u32x4* Xb = X + (size_t)b * n_cols * F8;
+    const u32x4* X2b = MODE == EP_SUM2 ? ep.X2 + (size_t)b * n_cols * F8 : nullptr;
     const u32x4 zero = {0u, 0u, 0u, 0u};
 
     for (int bi = wave / WPB; bi < nb; bi += SPMM_WAVES / WPB) {
@@ -193,6 +274,20 @@ __global__ __launch_bounds__(SPMM_THREADS) void spmm_bcsr_bf16_kernel(
             for (int r = 0; r < BR; ++r)
 #pragma unroll
                 for (int p = 0; p < VPT; ++p) acc[r][p].zero();
+            BlendIn bin[MODE == EP_BLEND ? BR : 1][VPT];
+            if (MODE == EP_BLEND) {
+#pragma unroll
+                for (int r = 0; r < BR; ++r)
+#pragma unroll
+                    for (int p = 0; p < VPT; ++p) {
+                        const int ch = cb + lane + 64 * p;
+                        if (r < rows_here && ch < F8) {
+                            const size_t o = ((size_t)b * n_rows + row_base + r) * F8 + ch;
+                            BlendIn& t = bin[MODE == EP_BLEND ? r : 0][p];
+                            t.a = __builtin_nontemporal_load(ep.Y0 + o); t.u = ep.U[o]; t.h = ep.H[o];
+                        }
+                    }
+            }
             auto entry = [&](int j, int& c, float (&v)[BR]) {
                 if (j < BC_CAP) {
                     c = s_col[j];
@@ -213,7 +308,7 @@ __global__ __launch_bounds__(SPMM_THREADS) void spmm_bcsr_bf16_kernel(
                 float v[4][BR];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) entry(j + u, c[u], v[u]);
-                u32x4 x[4][VPT];
+                u32x4 x[4][VPT], x2[MODE == EP_SUM2 ? 4 : 1][VPT];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const u32x4* xr = Xb + (size_t)c[u] * F8;
@@ -221,6 +316,7 @@ __global__ __launch_bounds__(SPMM_THREADS) void spmm_bcsr_bf16_kernel(
                     for (int p = 0; p < VPT; ++p) {
                         const int ch = cb + lane + 64 * p;
                         x[u][p] = ch < F8 ? xr[ch] : zero;
+                        if (MODE == EP_SUM2) x2[MODE == EP_SUM2 ? u : 0][p] = ch < F8 ? (X2b + (size_t)c[u] * F8)[ch] : zero;
                     }
                 }
 #pragma unroll
@@ -228,7 +324,10 @@ __global__ __launch_bounds__(SPMM_THREADS) void spmm_bcsr_bf16_kernel(
 #pragma unroll
                     for (int r = 0; r < BR; ++r)
 #pragma unroll
-                        for (int p = 0; p < VPT; ++p) acc[r][p].fma(v[u][r], x[u][p]);
+                        for (int p = 0; p < VPT; ++p) {
+                            acc[r][p].fma(v[u][r], x[u][p]);
+                            if (MODE == EP_SUM2) acc[r][p].fma(v[u][r], x2[MODE == EP_SUM2 ? u : 0][p]);
+                        }
             }
             for (; j < je; ++j) {
                 int c;
@@ -242,6 +341,11 @@ __global__ __launch_bounds__(SPMM_THREADS) void spmm_bcsr_bf16_kernel(
                         const u32x4 xv = xr[ch];
 #pragma unroll
                         for (int r = 0; r < BR; ++r) acc[r][p].fma(v[r], xv);
+                        if (MODE == EP_SUM2) {
+                            const u32x4 xw = (X2b + (size_t)c * F8)[ch];
+#pragma unroll
+                            for (int r = 0; r < BR; ++r) acc[r][p].fma(v[r], xw);
+                        }
                     }
                 }
             }
@@ -252,7 +356,10 @@ __global__ __launch_bounds__(SPMM_THREADS) void spmm_bcsr_bf16_kernel(
 #pragma unroll
                     for (int p = 0; p < VPT; ++p) {
                         const int ch = cb + lane + 64 * p;
-                        if (ch < F8) finish(ep, rowg * F8 + ch, acc[r][p]);
+                        if (ch < F8) {
+                            if (MODE == EP_BLEND) blend_piece(ep, rowg * F8 + ch, acc[r][p], bin[MODE == EP_BLEND ? r : 0][p]);
+                            else finish<MODE>(ep, rowg * F8 + ch, acc[r][p]);
+                        }
                     }
                 }
             }
@@ -274,6 +381,46 @@ int check_common(const char* who, int n_rows, int n_cols, const void* X, const v
     return STC_OK;
 }
 
+struct GraphArgs {      // either form of the same matrix; BCSR is used when blk_ptr is given
+    const int32_t *rowptr, *colidx; const float* val;
+    const int32_t *blk_ptr, *blk_cols; const float* blk_vals;
+};
+
+template <int MODE>
+int launch(const char* who, const GraphArgs& g, int n_rows, int n_cols, const void* X, int batch, int F, const Epi& ep, hipStream_t s) {
+    const u32x4* X8 = reinterpret_cast<const u32x4*>(X);
+    const int F8 = F / 8;
+    if (g.blk_ptr) {
+        const int n_blocks = (n_rows + BR - 1) / BR;
+        const int n_tiles = (n_blocks + BC_BLOCKS - 1) / BC_BLOCKS;
+        const int per = (n_tiles + stc::kNumXcd - 1) / stc::kNumXcd;
+        const dim3 grid(per * stc::kNumXcd, batch), block(SPMM_THREADS);
+        if (F8 <= 128)        // two waves per block: each covers every other column block of 64*VPT pieces
+            hipLaunchKernelGGL((spmm_bcsr_bf16_kernel<1, MODE>), grid, block, 0, s, g.blk_ptr, g.blk_cols, g.blk_vals, n_rows, n_cols, X8, F8, n_blocks, n_tiles, ep);
+        else
+            hipLaunchKernelGGL((spmm_bcsr_bf16_kernel<2, MODE>), grid, block, 0, s, g.blk_ptr, g.blk_cols, g.blk_vals, n_rows, n_cols, X8, F8, n_blocks, n_tiles, ep);
+    } else {
+        const int n_tiles = (n_rows + SPMM_ROWS - 1) / SPMM_ROWS;
+        const int per = (n_tiles + stc::kNumXcd - 1) / stc::kNumXcd;
+        const dim3 grid(per * stc::kNumXcd, batch), block(SPMM_THREADS);
+        if (F8 <= 64)
+            hipLaunchKernelGGL((spmm_wave_row_bf16_kernel<1, MODE>), grid, block, 0, s, g.rowptr, g.colidx, g.val, n_rows, n_cols, X8, F8, n_tiles, ep);
+        else
+            hipLaunchKernelGGL((spmm_wave_row_bf16_kernel<2, MODE>), grid, block, 0, s, g.rowptr, g.colidx, g.val, n_rows, n_cols, X8, F8, n_tiles, ep);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return stc::hip_status(e, who);
+    return STC_OK;
+}
+
+int check_state_rows(const char* who, const GraphArgs& g, int n_rows, int batch, int C, int h) {
+    STC_REQUIRE(h == 16, STC_EUNSUPPORTED, "%s: hidden width %d (built for 16)", who, h);
+    STC_REQUIRE(n_rows >= 0 && batch >= 0 && C >= 1, STC_EINVAL, "%s: bad sizes", who);
+    STC_REQUIRE(batch <= 65535, STC_ELIMIT, "%s: batch %d > 65535 (grid.y)", who, batch);
+    STC_REQUIRE(n_rows == 0 || batch == 0 || g.blk_ptr || g.rowptr, STC_EINVAL, "%s: neither graph form given", who);
+    return STC_OK;
+}
+
 }  // namespace
 
 extern "C" int stc_csr_spmm_bf16(const int32_t* rowptr, const int32_t* colidx, const float* val,
@@ -283,19 +430,10 @@ extern "C" int stc_csr_spmm_bf16(const int32_t* rowptr, const int32_t* colidx, c
     if (int rc = check_common("stc_csr_spmm_bf16", n_rows, n_cols, X, Y0, Y, batch, F, beta)) return rc;
     if (n_rows == 0 || batch == 0 || F == 0) return STC_OK;
     STC_REQUIRE(rowptr, STC_EINVAL, "stc_csr_spmm_bf16: null rowptr");      // colidx / val may be null for a graph without edges
-    const Epi ep{reinterpret_cast<const u32x4*>(Y0), reinterpret_cast<u32x4*>(Y), alpha, beta};
-    const u32x4* X8 = reinterpret_cast<const u32x4*>(X);
-    const int F8 = F / 8;
-    const int n_tiles = (n_rows + SPMM_ROWS - 1) / SPMM_ROWS;
-    const int per = (n_tiles + stc::kNumXcd - 1) / stc::kNumXcd;
-    const dim3 grid(per * stc::kNumXcd, batch), block(SPMM_THREADS);
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    if (F8 <= 64)
-        hipLaunchKernelGGL((spmm_wave_row_bf16_kernel<1>), grid, block, 0, s, rowptr, colidx, val, n_rows, n_cols, X8, F8, n_tiles, ep);
-    else
-        hipLaunchKernelGGL((spmm_wave_row_bf16_kernel<2>), grid, block, 0, s, rowptr, colidx, val, n_rows, n_cols, X8, F8, n_tiles, ep);
-    STC_LAUNCH_CHECK("stc_csr_spmm_bf16 launch");
-    return STC_OK;
+    Epi ep{};
+    ep.Y0 = reinterpret_cast<const u32x4*>(Y0); ep.Y = reinterpret_cast<u32x4*>(Y); ep.alpha = alpha; ep.beta = beta;
+    const GraphArgs g{rowptr, colidx, val, nullptr, nullptr, nullptr};
+    return launch<EP_PLAIN>("stc_csr_spmm_bf16 launch", g, n_rows, n_cols, X, batch, F, ep, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int stc_bcsr_spmm_bf16(const int32_t* blk_ptr, const int32_t* blk_cols, const float* blk_vals,
@@ -305,18 +443,56 @@ extern "C" int stc_bcsr_spmm_bf16(const int32_t* blk_ptr, const int32_t* blk_col
     if (int rc = check_common("stc_bcsr_spmm_bf16", n_rows, n_cols, X, Y0, Y, batch, F, beta)) return rc;
     if (n_rows == 0 || batch == 0 || F == 0) return STC_OK;
     STC_REQUIRE(blk_ptr, STC_EINVAL, "stc_bcsr_spmm_bf16: null blk_ptr");
-    const Epi ep{reinterpret_cast<const u32x4*>(Y0), reinterpret_cast<u32x4*>(Y), alpha, beta};
-    const u32x4* X8 = reinterpret_cast<const u32x4*>(X);
-    const int F8 = F / 8;
-    const int n_blocks = (n_rows + BR - 1) / BR;
-    const int n_tiles = (n_blocks + BC_BLOCKS - 1) / BC_BLOCKS;
-    const int per = (n_tiles + stc::kNumXcd - 1) / stc::kNumXcd;
-    const dim3 grid(per * stc::kNumXcd, batch), block(SPMM_THREADS);
+    Epi ep{};
+    ep.Y0 = reinterpret_cast<const u32x4*>(Y0); ep.Y = reinterpret_cast<u32x4*>(Y); ep.alpha = alpha; ep.beta = beta;
+    const GraphArgs g{nullptr, nullptr, nullptr, blk_ptr, blk_cols, blk_vals};
+    return launch<EP_PLAIN>("stc_bcsr_spmm_bf16 launch", g, n_rows, n_cols, X, batch, F, ep, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int stc_spmm_blend_fwd_bf16(const int32_t* rowptr, const int32_t* colidx, const float* val,
+                                       const int32_t* blk_ptr, const int32_t* blk_cols, const float* blk_vals,
+                                       int32_t n_rows, int32_t n_cols, const void* Bm, const void* A,
+                                       const void* U, const void* H, void* Cand, void* Hnew,
+                                       int32_t batch, int32_t C, int32_t h, void* stream) {
+    const GraphArgs g{rowptr, colidx, val, blk_ptr, blk_cols, blk_vals};
+    if (int rc = check_state_rows("stc_spmm_blend_fwd_bf16", g, n_rows, batch, C, h)) return rc;
+    if (n_rows == 0 || batch == 0) return STC_OK;
+    STC_REQUIRE(Bm && A && U && H && Cand && Hnew && n_cols > 0, STC_EINVAL, "stc_spmm_blend_fwd_bf16: null pointer");
+    STC_REQUIRE(stc::aligned16(Bm) && stc::aligned16(A) && stc::aligned16(U) && stc::aligned16(H) && stc::aligned16(Cand) && stc::aligned16(Hnew),
+                STC_EALIGN, "stc_spmm_blend_fwd_bf16: operands must be 16-byte aligned");
+    STC_REQUIRE(Bm != Cand && Bm != Hnew, STC_EINVAL, "stc_spmm_blend_fwd_bf16: outputs must not alias Bm (its rows are gathered by other rows)");
+    Epi ep{};
+    ep.Y0 = reinterpret_cast<const u32x4*>(A);
+    ep.U = reinterpret_cast<const u32x4*>(U); ep.H = reinterpret_cast<const u32x4*>(H);
+    ep.Cand = reinterpret_cast<u32x4*>(Cand); ep.Hnew = reinterpret_cast<u32x4*>(Hnew);
+    return launch<EP_BLEND>("stc_spmm_blend_fwd_bf16 launch", g, n_rows, n_cols, Bm, batch, C * h, ep, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int stc_spmm_sum_bf16(const int32_t* rowptr, const int32_t* colidx, const float* val,
+                                 const int32_t* blk_ptr, const int32_t* blk_cols, const float* blk_vals,
+                                 int32_t n_rows, int32_t n_cols, const void* X, const void* X2,
+                                 int32_t n_add, const void* const* add,
+                                 void* Y, const void* U, const void* Cand, void* dY,
+                                 int32_t batch, int32_t C, int32_t h, void* stream) {
+    const GraphArgs g{rowptr, colidx, val, blk_ptr, blk_cols, blk_vals};
+    if (int rc = check_state_rows("stc_spmm_sum_bf16", g, n_rows, batch, C, h)) return rc;
+    STC_REQUIRE(n_add >= 0 && n_add <= 5 && (n_add == 0 || add), STC_EINVAL, "stc_spmm_sum_bf16: 0..5 addends, got %d", n_add);
+    if (n_rows == 0 || batch == 0) return STC_OK;
+    STC_REQUIRE(X && Y && n_cols > 0, STC_EINVAL, "stc_spmm_sum_bf16: null pointer");
+    STC_REQUIRE(stc::aligned16(X) && stc::aligned16(Y) && (!X2 || stc::aligned16(X2)), STC_EALIGN, "stc_spmm_sum_bf16: operands must be 16-byte aligned");
+    STC_REQUIRE(X != Y && X2 != Y, STC_EINVAL, "stc_spmm_sum_bf16: Y must not alias a gathered operand");
+    STC_REQUIRE(!dY || (U && Cand && stc::aligned16(U) && stc::aligned16(Cand) && stc::aligned16(dY) && dY != Y), STC_EINVAL,
+                "stc_spmm_sum_bf16: dY needs U and Cand (16-byte aligned, not aliasing Y)");
+    Epi ep{};
+    ep.Y = reinterpret_cast<u32x4*>(Y);
+    ep.X2 = reinterpret_cast<const u32x4*>(X2);
+    ep.U = reinterpret_cast<const u32x4*>(U); ep.gCand = reinterpret_cast<const u32x4*>(Cand); ep.dY = reinterpret_cast<u32x4*>(dY);
+    ep.n_add = n_add;
+    for (int i = 0; i < n_add; ++i) {
+        STC_REQUIRE(add[i] && stc::aligned16(add[i]) && add[i] != Y, STC_EINVAL, "stc_spmm_sum_bf16: addend %d null, misaligned or aliasing Y", i);
+        ep.add[i] = reinterpret_cast<const u32x4*>(add[i]);
+    }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (F8 <= 128)        // two waves per block: each covers every other column block of 64*VPT pieces
-        hipLaunchKernelGGL((spmm_bcsr_bf16_kernel<1>), grid, block, 0, s, blk_ptr, blk_cols, blk_vals, n_rows, n_cols, X8, F8, n_blocks, n_tiles, ep);
-    else
-        hipLaunchKernelGGL((spmm_bcsr_bf16_kernel<2>), grid, block, 0, s, blk_ptr, blk_cols, blk_vals, n_rows, n_cols, X8, F8, n_blocks, n_tiles, ep);
-    STC_LAUNCH_CHECK("stc_bcsr_spmm_bf16 launch");
-    return STC_OK;
+    return X2 ? launch<EP_SUM2>("stc_spmm_sum_bf16 launch", g, n_rows, n_cols, X, batch, C * h, ep, s)
+              : launch<EP_SUM>("stc_spmm_sum_bf16 launch", g, n_rows, n_cols, X, batch, C * h, ep, s);
 }

@@ -26,6 +26,8 @@ MAX_K = 4
 EXPORTS = (
     'stc_version', 'stc_last_error',
     'stc_csr_spmm_f32', 'stc_bcsr_spmm_f32', 'stc_csr_spmm_bf16', 'stc_bcsr_spmm_bf16', 'stc_bdg_node_bf16_supported', 'stc_bdg_node_fwd_bf16', 'stc_bdg_node_bwd_bf16',
+    'stc_cell_planar_bf16_supported', 'stc_cell_gates_fwd_planar_bf16', 'stc_cell_gates_bwd_planar_bf16', 'stc_bdg_node_post_bwd_bf16',
+    'stc_spmm_blend_fwd_bf16', 'stc_spmm_sum_bf16', 'stc_gru_blend_bwd_bf16',
     'stc_spmm_bwd_gates_f32', 'stc_spmm_bwd_split_f32', 'stc_csr_sddmm_f32',
     'stc_cheby_dense_fwd_f32', 'stc_cheby_dense_bwd_f32',
     'stc_bdg_node_fwd_f32', 'stc_bdg_node_bwd_workspace_bytes', 'stc_bdg_node_bwd_f32',
@@ -70,6 +72,12 @@ def _declare(lib):
         'stc_bdg_node_fwd_bf16': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
         'stc_bdg_node_bwd_bf16': [C.POINTER(_p), _i32, _p, _i32, _p, _p, C.POINTER(_p), _p, _p,
                                   _p, C.c_size_t, _i64, _i32, _i32, _i32, _i32, _p],
+        'stc_cell_gates_fwd_planar_bf16': [_p] * 14 + [_i64, _i32, _i32, _i32, _p],
+        'stc_cell_gates_bwd_planar_bf16': [_p] * 11 + [C.POINTER(_p), _p, _p, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _p],
+        'stc_bdg_node_post_bwd_bf16': [_p] * 11 + [C.c_size_t, _i64, _i32, _i32, _i32, _p],
+        'stc_spmm_blend_fwd_bf16': [_p] * 6 + [_i32, _i32] + [_p] * 6 + [_i32] * 3 + [_p],
+        'stc_spmm_sum_bf16': [_p] * 6 + [_i32, _i32, _p, _p, _i32, C.POINTER(_p), _p, _p, _p, _p, _i32, _i32, _i32, _p],
+        'stc_gru_blend_bwd_bf16': [_p, _p, _p, _p, _i64, _p],
         'stc_bdg_node_post_fwd_f32': [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
         'stc_cell_gates_fwd_planar_f32': [_p] * 14 + [_i64, _i32, _i32, _i32, _p],
         'stc_cell_gates_bwd_planar_f32': [_p] * 11 + [C.POINTER(_p), _p, _p, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _p],
@@ -102,6 +110,8 @@ def _declare(lib):
     lib.stc_cell_fused_supported.argtypes = [_i32, _i32, _i32, _i32, _i32]
     lib.stc_bdg_node_post_supported.restype = C.c_int
     lib.stc_bdg_node_post_supported.argtypes = [_i32, _i32, _i32, _i32, _i32]
+    lib.stc_cell_planar_bf16_supported.restype = C.c_int
+    lib.stc_cell_planar_bf16_supported.argtypes = [_i32, _i32, _i32, _i32]
     lib.stc_bdg_node_bf16_supported.restype = C.c_int
     lib.stc_bdg_node_bf16_supported.argtypes = [_i32, _i32, _i32, _i32, _i32]
     lib.stc_cell_planar_supported.restype = C.c_int
@@ -492,6 +502,14 @@ class HipKernels:
         ws = self._get_workspace(dY.device, nbytes)
         self._launch('stc_bdg_node_bwd_bf16', dY, self._ptr_array(Zs), Ks, _ptr(Tc), Kc, _ptr(W), _ptr(dY), self._ptr_array(dZs), _ptr(dW), _ptr(db),
                      _ptr(ws), ws.numel(), R, Cc, L, Lw, Ho, nbytes=2 * R * Cc * (2 * Ks * L + Ho))
+
+    @property
+    def bf16(self):
+        """The planar-cell kernel set for bf16 planes (``_Bf16Planar``): what ``ops.stc_cell_graph`` launches through when its
+        state tensors are bfloat16."""
+        if getattr(self, '_bf16_front', None) is None:
+            self._bf16_front = _Bf16Planar(self)
+        return self._bf16_front
 
     # ---- post-aggregation form (Ks = Kc = 2): Y = A + S.Bm --------------------------------------
     def node_post_supported(self, Ks, Kc, Cc, L, Ho) -> bool:
@@ -887,3 +905,156 @@ class HipKernels:
                 self._f32('split2.' + name, t, like.shape)
         self._launch('stc_split2_f32', src, _ptr(src), _ptr(addA), _ptr(addB), _ptr(A), _ptr(Bm), rows, a, b, pad,
                      int(addA_ld if addA is not None else 0), _ptr(addA2), _ptr(addB2))
+
+
+class _Bf16Planar:
+    """bf16-plane counterpart of the planar-cell methods of ``HipKernels`` (same names and argument meaning, so that the
+    cell-graph executor runs unchanged): state / gate / gradient planes bfloat16 (R, C, 16), weights and their gradients fp32.
+    Only what an all-planar schedule needs exists here; interleaved rows and state copies are fp32-path features."""
+
+    name = 'hip-gfx950-bf16'
+
+    def __init__(self, base: HipKernels):
+        self.b = base
+
+    def _pl(self, name, t, shape):
+        return self.b._bf16(name, t, shape)
+
+    def cell_fused_supported(self, Ks, Kc, Cc, L, h) -> bool:
+        return self.cell_planar_supported(Ks, Kc, Cc, h)
+
+    def cell_planar_supported(self, Ks, Kc, Cc, h) -> bool:
+        return bool(self.b.lib.stc_cell_planar_bf16_supported(Ks, Kc, Cc, h))
+
+    def node_post_supported(self, Ks, Kc, Cc, L, Ho) -> bool:
+        return self.cell_planar_supported(Ks, Kc, Cc, Ho) and L in (20, 32)
+
+    def cell_planar_post_fused(self, Cc) -> bool:
+        return True
+
+    def csr_spmm(self, rowptr, colidx, val, n_rows, n_cols, X, Y0, Y, alpha, beta, plan=None):
+        self.b.csr_spmm_bf16(rowptr, colidx, val, n_rows, n_cols, X, Y0, Y, alpha, beta, plan=plan)
+
+    def _planes(self, X, H, SX, SH):
+        R, Cc, h = H.shape
+        cin = X.shape[-1]
+        if h != 16 or not (cin == h or 1 <= cin <= 4):
+            raise StcError(f'planar bf16: hidden {h} / input plane width {cin} (16, and 16 or 1..4)')
+        for name, t in (('H', H), ('SH', SH)):
+            self._pl('planar.' + name, t, (R, Cc, h))
+        for name, t in (('X', X), ('SX', SX)):
+            self._pl('planar.' + name, t, (R, Cc, cin))
+        return R, Cc, h, cin
+
+    def cell_gates_fwd_planar(self, X, H, SX, SH, Tc, W, bias, U, Rg, RH, post=None):
+        b = self.b
+        R, Cc, h, cin = self._planes(X, H, SX, SH)
+        b._f32('planar.Tc', Tc, (2, Cc, Cc))
+        b._f32('planar.W', W, (4 * (cin + h), 2 * h))
+        if bias is not None:
+            b._f32('planar.bias', bias, (2 * h,))
+        for name, t in (('U', U), ('Rg', Rg), ('RH', RH)):
+            self._pl('planar.' + name, t, (R, Cc, h))
+        Wc = bc = A = Bm = None
+        if post is not None:
+            Wc, bc, A, Bm = post
+            b._f32('planar.Wc', Wc, (4 * (cin + h), h))
+            if bc is not None:
+                b._f32('planar.bc', bc, (h,))
+            for name, t in (('A', A), ('Bm', Bm)):
+                self._pl('planar.' + name, t, (R, Cc, h))
+        b._same_device(X, H, SX, SH, Tc, W, bias, U, Rg, RH, Wc, bc, A, Bm)
+        b._launch('stc_cell_gates_fwd_planar_bf16', H, _ptr(X), _ptr(H), _ptr(SX), _ptr(SH), _ptr(Tc), _ptr(W), _ptr(bias),
+                  _ptr(U), _ptr(Rg), _ptr(RH), _ptr(Wc), _ptr(bc), _ptr(A), _ptr(Bm), R, Cc, cin + h, h)
+
+    def node_post_fwd(self, *a, **kw):
+        raise StcError('bf16 planar path: the candidate projection runs inside cell_gates_fwd_planar (post=); STC_FUSE_POST=0 is an fp32-path switch')
+
+    def spmm_blend_fwd(self, rowptr, colidx, val, plan, Bm, A, U, H, Cand, Hnew, copies=(), side=None):
+        b = self.b
+        if copies or side is not None:
+            raise StcError('bf16 planar path: state copies into interleaved rows do not exist (every cell reads planes)')
+        B, n, Cc, h = H.shape
+        for name, t in (('Bm', Bm), ('A', A), ('U', U), ('H', H), ('Cand', Cand), ('Hnew', Hnew)):
+            self._pl('spmm_blend.' + name, t, (B, n, Cc, h))
+        b._same_device(rowptr, colidx, val, Bm, A, U, H, Cand, Hnew)
+        g = b._graph_ptrs(rowptr, colidx, val, plan, n)
+        b._launch('stc_spmm_blend_fwd_bf16', H, *g, n, n, _ptr(Bm), _ptr(A), _ptr(U), _ptr(H), _ptr(Cand), _ptr(Hnew), B, Cc, h,
+                  nbytes=colidx.numel() * 8 + 4 * (n + 1) + 2 * B * n * Cc * h * 6)
+
+    def spmm_sum(self, rowptr, colidx, val, plan, X, X2, addends, Y, blend=None):
+        b = self.b
+        B, n, Cc, h = Y.shape
+        self._pl('spmm_sum.Y', Y, (B, n, Cc, h))
+        self._pl('spmm_sum.X', X, (B, n, Cc, h))
+        if X2 is not None:
+            self._pl('spmm_sum.X2', X2, (B, n, Cc, h))
+        if len(addends) > 5:
+            raise StcError(f'spmm_sum: at most five addends, got {len(addends)}')
+        ptrs = (_p * 5)()
+        for i, (t, off) in enumerate(addends):
+            self._pl(f'spmm_sum.add{i}', t, (B, n, Cc, h))
+            if off != 0:
+                raise StcError('spmm_sum (bf16): addends are whole planes')
+            ptrs[i] = t.data_ptr()
+        U = Cand = dY = None
+        if blend is not None:
+            U, Cand, dY = blend
+            for name, t in (('U', U), ('Cand', Cand), ('dY', dY)):
+                self._pl('spmm_sum.' + name, t, (B, n, Cc, h))
+        b._same_device(rowptr, colidx, val, X, X2, Y, U, Cand, dY, *[t for t, _ in addends])
+        g = b._graph_ptrs(rowptr, colidx, val, plan, n)
+        b._launch('stc_spmm_sum_bf16', Y, *g, n, n, _ptr(X), _ptr(X2), len(addends), ptrs, _ptr(Y), _ptr(U), _ptr(Cand), _ptr(dY), B, Cc, h,
+                  nbytes=colidx.numel() * 8 + 4 * (n + 1) + 2 * B * n * Cc * h * (2 + (X2 is not None) + len(addends) + (3 if blend else 0)))
+
+    def gru_blend_bwd(self, dHnew, U, H, Cand, dCpre, dU, dH):
+        if dU is not None or dH is not None:
+            raise StcError('gru_blend_bwd (bf16): only the dCpre form exists')
+        for name, t in (('dHnew', dHnew), ('U', U), ('Cand', Cand), ('dCpre', dCpre)):
+            self._pl('blend_bwd.' + name, t, tuple(dHnew.shape))
+        self.b._launch('stc_gru_blend_bwd_bf16', dHnew, _ptr(dHnew), _ptr(U), _ptr(Cand), _ptr(dCpre), dHnew.numel())
+
+    def node_post_bwd(self, X, Tc, W, dA, dB, dX, dW, db, X2=None, dX2=None):
+        b = self.b
+        if X2 is None:
+            raise StcError('node_post_bwd (bf16): planar form only (X2)')
+        R, Cc, h = X.shape
+        w2 = X2.shape[-1]
+        narrow = w2 != 16
+        if (dX2 is not None) == narrow:
+            raise StcError('post: a planar gradient (dX2) goes with a 16 + 16 planar input and only with it')
+        self._pl('post.X', X, (R, Cc, 16))
+        self._pl('post.X2', X2, (R, Cc, w2))
+        for name, t in (('dA', dA), ('dB', dB), ('dX', dX)) + ((('dX2', dX2),) if dX2 is not None else ()):
+            self._pl('post.' + name, t, (R, Cc, 16))
+        b._f32('post.Tc', Tc, (2, Cc, Cc))
+        b._f32('post.W', W, (4 * (16 + w2), 16))
+        b._f32('post.dW', dW, (4 * (16 + w2), 16))
+        if db is not None:
+            b._f32('post.db', db, (16,))
+        b._same_device(X, X2, Tc, W, dA, dB, dX, dX2, dW, db)
+        ws = b._get_workspace(X.device, b.lib.stc_bdg_node_bwd_workspace_bytes(2, 2, Cc, 32, 16, 0))
+        b._launch('stc_bdg_node_post_bwd_bf16', X, _ptr(X), _ptr(X2), _ptr(Tc), _ptr(W), _ptr(dA), _ptr(dB), _ptr(dX), _ptr(dX2), _ptr(dW), _ptr(db),
+                  _ptr(ws), ws.numel(), R, Cc, 16 + w2, 16)
+
+    def cell_gates_bwd_planar(self, X, H, SX, SH, Tc, W, dRH, Cand, U, Rg, dHnew, dZs, dW, db, dH):
+        b = self.b
+        R, Cc, h, cin = self._planes(X, H, SX, SH)
+        b._f32('planar.Tc', Tc, (2, Cc, Cc))
+        b._f32('planar.W', W, (4 * (cin + h), 2 * h))
+        for name, t in (('dRH', dRH), ('Cand', Cand), ('U', U), ('Rg', Rg), ('dHnew', dHnew), ('dH', dH)):
+            self._pl('planar.' + name, t, (R, Cc, h))
+        if len(dZs) != 4:
+            raise StcError('planar gates backward: four gradient planes (dX, dSX, dH, dSH)')
+        for i, z in enumerate(dZs):
+            if z is None and i < 2 and cin != h:
+                continue
+            self._pl(f'planar.dZ[{i}]', z, (R, Cc, h))
+        b._f32('planar.dW', dW, (4 * (cin + h), 2 * h))
+        if db is not None:
+            b._f32('planar.db', db, (2 * h,))
+        b._same_device(X, H, SX, SH, Tc, W, dRH, Cand, U, Rg, dHnew, *dZs, dW, db, dH)
+        ws = b._get_workspace(H.device, b.lib.stc_bdg_node_bwd_workspace_bytes(2, 2, Cc, 2 * h, 2 * h, 0))
+        zp = (_p * 4)(*[0 if z is None else z.data_ptr() for z in dZs])
+        b._launch('stc_cell_gates_bwd_planar_bf16', H, _ptr(X), _ptr(H), _ptr(SX), _ptr(SH), _ptr(Tc), _ptr(W), _ptr(dRH), _ptr(Cand),
+                  _ptr(U), _ptr(Rg), _ptr(dHnew), zp, _ptr(dW), _ptr(db), _ptr(dH), _ptr(ws), ws.numel(), R, Cc, cin + h, h)

@@ -222,3 +222,124 @@ def test_node_bf16_unsupported_shapes_are_refused(hip):
     Zs, Tc, W, b = _node_inputs_bf16(5, 16, 32, 32, 32, 2, seed=1)
     with pytest.raises(StcError):
         hip.bdg_node_fwd_bf16([cu(z) for z in Zs], cu(Tc), cu(W), cu(b), torch.empty(5, 16, 32, dtype=torch.bfloat16).cuda())
+
+
+# ------------------------------------------------------------------ planar STC_Cell kernels on bf16 planes
+BTOL = 2e-2          # max-norm relative error against the fp32 twin on the same bf16-valued inputs (bf16 weights, intermediates, outputs)
+
+
+def _close(got, want, tol=BTOL):
+    g, w = got.float().cpu(), want.float()
+    assert torch.isfinite(g).all()
+    assert rel_err(g, w) < tol, f'rel err {rel_err(g, w)}'
+    assert float((g - w).abs().mean()) < 0.25 * tol * float(w.abs().mean()) + 1e-9       # and not just one lucky maximum
+
+
+@pytest.mark.parametrize('nodes,C,cin', [(50, 32, 16), (13, 64, 16), (4500, 64, 16), (50, 32, 1), (13, 64, 4), (9, 32, 3), (4500, 64, 1)])
+def test_planar_cell_kernels_bf16(hip, nodes, C, cin):
+    """Gates forward (+ the fused candidate projection), gates backward with its GRU prologue and the post-aggregation
+    backward on bf16 planes, wide (16 + 16) and narrow (layer 0: cin + 16) inputs, against the fp32 CPU twins."""
+    bf, h, K = torch.bfloat16, 16, 2
+    kb = hip.bf16
+    assert kb.cell_planar_supported(K, K, C, h)
+    Lw = cin + h
+    g = torch.Generator().manual_seed(nodes + C + cin)
+    rnd = lambda *s_: torch.randn(*s_, generator=g)
+    rb = lambda *s_: rnd(*s_).to(bf)                       # bf16-valued inputs
+    X, SX, H, SH = rb(nodes, C, cin), rb(nodes, C, cin), rb(nodes, C, h), rb(nodes, C, h)
+    Tc = rnd(K, C, C) / C ** 0.5
+    Tc[0] = torch.eye(C)
+    Wg, bg = rnd(K * K * Lw, 2 * h) / (4 * Lw) ** 0.5, rnd(2 * h)
+    Wc, bc = rnd(K * K * Lw, h) / (4 * Lw) ** 0.5, rnd(h)
+    f = lambda t: t.float()
+    U_w, R_w, RH_w, A_w, B_w = (torch.empty(nodes, C, h) for _ in range(5))
+    EM.cell_gates_fwd_planar(f(X), f(H), f(SX), f(SH), Tc, Wg, bg, U_w, R_w, RH_w)
+    nan = lambda *s_: torch.full(s_, float('nan'), dtype=bf).cuda()
+    nanf = lambda *s_: torch.full(s_, float('nan')).cuda()
+    U, R, RH, A, Bm = (nan(nodes, C, h) for _ in range(5))
+    kb.cell_gates_fwd_planar(cu(X), cu(H), cu(SX), cu(SH), cu(Tc), cu(Wg), cu(bg), U, R, RH, post=(cu(Wc), cu(bc), A, Bm))
+    _close(U, U_w); _close(R, R_w); _close(RH, RH_w)
+    # the candidate's projection sees the ROUNDED R*H plane the kernel stored
+    if cin == h:
+        EM.node_post_fwd(f(X), Tc, Wc, bc, A_w, B_w, X2=RH.float().cpu())
+    else:
+        EM.node_post_fwd(RH.float().cpu(), Tc, Wc, bc, A_w, B_w, X2=f(X))
+    _close(A, A_w); _close(Bm, B_w)
+    U2, R2, RH2 = (nan(nodes, C, h) for _ in range(3))
+    kb.cell_gates_fwd_planar(cu(X), cu(H), cu(SX), cu(SH), cu(Tc), cu(Wg), cu(bg), U2, R2, RH2)                # without the second stage
+    assert torch.equal(U2, U) and torch.equal(R2, R) and torch.equal(RH2, RH)
+
+    # ---- gates backward (GRU prologue inside)
+    dRH, Cand, dHn = rb(nodes, C, h), torch.tanh(rnd(nodes, C, h)).to(bf), rb(nodes, C, h)
+    Ub, Rb = U.cpu(), R.cpu()
+    wide = cin == h
+    dZ_w = [torch.empty(nodes, C, h) if (wide or i >= 2) else None for i in range(4)]
+    dW_w, db_w, dH_w = torch.empty_like(Wg), torch.empty(2 * h), torch.empty(nodes, C, h)
+    EM.cell_gates_bwd_planar(f(X), f(H), f(SX), f(SH), Tc, Wg, f(dRH), f(Cand), f(Ub), f(Rb), f(dHn), dZ_w, dW_w, db_w, dH_w)
+    dZ = [nan(nodes, C, h) if (wide or i >= 2) else None for i in range(4)]
+    dW, db, dH = nanf(*Wg.shape), nanf(2 * h), nan(nodes, C, h)
+    kb.cell_gates_bwd_planar(cu(X), cu(H), cu(SX), cu(SH), cu(Tc), cu(Wg), cu(dRH), cu(Cand), cu(Ub), cu(Rb), cu(dHn), dZ, dW, db, dH)
+    for a, w in zip(dZ, dZ_w):
+        if w is not None:
+            _close(a, w)
+    _close(dH, dH_w)
+    assert rel_err(dW.cpu(), dW_w) < BTOL and rel_err(db.cpu(), db_w) < BTOL
+    dW2 = nanf(*Wg.shape)
+    kb.cell_gates_bwd_planar(cu(X), cu(H), cu(SX), cu(SH), cu(Tc), cu(Wg), cu(dRH), cu(Cand), cu(Ub), cu(Rb), cu(dHn), dZ, dW2, None, dH)
+    assert torch.equal(dW2, dW)                                                                                # reproducible, db optional
+
+    # ---- post-aggregation backward of the candidate convolution
+    dA, dB = rb(nodes, C, h), rb(nodes, C, h)
+    RHc = RH.cpu()
+    dX_w, dX2_w, dWc_w, dbc_w = torch.empty(nodes, C, h), torch.empty(nodes, C, h), torch.empty_like(Wc), torch.empty(h)
+    dX, dX2, dWc, dbc = nan(nodes, C, h), nan(nodes, C, h), nanf(*Wc.shape), nanf(h)
+    if wide:
+        EM.node_post_bwd(f(X), Tc, Wc, f(dA), f(dB), dX_w, dWc_w, dbc_w, X2=f(RHc), dX2=dX2_w)
+        kb.node_post_bwd(cu(X), cu(Tc), cu(Wc), cu(dA), cu(dB), dX, dWc, dbc, X2=cu(RHc), dX2=dX2)
+        _close(dX2, dX2_w)
+    else:
+        EM.node_post_bwd(f(RHc), Tc, Wc, f(dA), f(dB), dX_w, dWc_w, dbc_w, X2=f(X))
+        kb.node_post_bwd(cu(RHc), cu(Tc), cu(Wc), cu(dA), cu(dB), dX, dWc, dbc, X2=cu(X))
+    _close(dX, dX_w)
+    assert rel_err(dWc.cpu(), dWc_w) < BTOL and rel_err(dbc.cpu(), dbc_w) < BTOL
+
+
+@pytest.mark.parametrize('batch,grid,C,n_add,dual', [(2, (5, 5), 32, 3, True), (1, (4, 7), 64, 5, False), (2, (40, 56), 64, 0, True), (1, (1, 1), 32, 2, False)])
+def test_state_aggregations_bf16(hip, batch, grid, C, n_add, dual):
+    """stc_spmm_sum_bf16 (gradient of a state from its pieces, optional blend backward), stc_spmm_blend_fwd_bf16 (Y = A + S.Bm
+    with the GRU blend) and stc_gru_blend_bwd_bf16, row-blocked and plain CSR, against the fp32 twins on the same inputs."""
+    bf, h = torch.bfloat16, 16
+    kb = hip.bf16
+    graph = CsrGraph.queen_grid(*grid, normalize=True)
+    n = graph.n
+    g = torch.Generator().manual_seed(n + C + n_add)
+    rb = lambda *s_: torch.randn(*s_, generator=g).to(bf)
+    f = lambda t: None if t is None else t.float()
+    X, X2 = rb(batch, n, C, h), (rb(batch, n, C, h) if dual else None)
+    adds = [(rb(batch, n, C, h), 0) for _ in range(n_add)]
+    hst = graph._host
+    dev = graph.on(torch.device('cuda'))
+    U, Cand = torch.rand(batch, n, C, h, generator=g).to(bf), torch.tanh(torch.randn(batch, n, C, h, generator=g)).to(bf)
+    for side in ('bwd', 'fwd'):
+        csr = tuple(torch.from_numpy(hst[f'{side}_{k}']) for k in ('rowptr', 'colidx', 'val'))
+        plan = (dev[f'{side}_blk_ptr'], dev[f'{side}_blk_cols'], dev[f'{side}_blk_vals'])
+        Y_w, dY_w = torch.empty(batch, n, C, h), torch.empty(batch, n, C, h)
+        EM.spmm_sum(*csr, None, f(X), f(X2), [(f(t), o) for t, o in adds], Y_w, blend=(f(U), f(Cand), dY_w))
+        Cand_w, Hn_w = torch.empty(batch, n, C, h), torch.empty(batch, n, C, h)
+        A, H = adds[0][0] if adds else X, X
+        EM.spmm_blend_fwd(*csr, None, f(X), f(A), f(U), f(H), Cand_w, Hn_w)
+        for pl in (plan, None):
+            Y, dY = (torch.full((batch, n, C, h), float('nan'), dtype=bf).cuda() for _ in range(2))
+            kb.spmm_sum(*(cu(t) for t in csr), pl, cu(X), cu(X2), [(cu(t), o) for t, o in adds], Y, blend=(cu(U), cu(Cand), dY))
+            assert_one_ulp(Y, Y_w.to(bf), max_mismatch=0.05)
+            _close(dY, dY_w, tol=2.0 ** -7)
+            Y1 = torch.full_like(Y, float('nan'))
+            kb.spmm_sum(*(cu(t) for t in csr), pl, cu(X), cu(X2), [(cu(t), o) for t, o in adds], Y1)
+            assert torch.equal(Y1, Y)
+            Cd, Hn = (torch.full((batch, n, C, h), float('nan'), dtype=bf).cuda() for _ in range(2))
+            kb.spmm_blend_fwd(*(cu(t) for t in csr), pl, cu(X), cu(A), cu(U), cu(H), Cd, Hn)
+            _close(Cd, Cand_w, tol=2.0 ** -7)
+            _close(Hn, Hn_w, tol=2.0 ** -7)
+    dC = torch.full((batch, n, C, h), float('nan'), dtype=bf).cuda()
+    kb.gru_blend_bwd(cu(X), cu(U), None, cu(Cand), dC, None, None)
+    assert_one_ulp(dC, (f(X) * f(U) * (1 - f(Cand) ** 2)).to(bf), max_mismatch=0.05)
