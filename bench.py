@@ -35,7 +35,8 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling ~6300
 # every C-ABI entry point that is an aggregation Y = S.X (+ epilogue): the kernels the metric's roofline is about
-SPMM_ENTRY_POINTS = ('stc_bcsr_spmm_f32', 'stc_csr_spmm_f32', 'stc_spmm_sum_f32', 'stc_spmm_blend_fwd_f32')
+SPMM_ENTRY_POINTS = ('stc_bcsr_spmm_f32', 'stc_csr_spmm_f32', 'stc_spmm_sum_f32', 'stc_spmm_blend_fwd_f32',
+                     'stc_bcsr_spmm_bf16', 'stc_csr_spmm_bf16', 'stc_spmm_sum_bf16', 'stc_spmm_blend_fwd_bf16')
 METRIC = 'STC-GNN fwd+bwd samples/sec at N=50k,C=32; SpMM HBM GB/s vs peak, 1/8 GPU'
 
 
@@ -55,6 +56,9 @@ def parse():
     ap.add_argument('--permute', action='store_true', help='random node order (seed 1234) instead of row-major')
     ap.add_argument('--no-reorder', action='store_true', help='keep the given node order (skip the internal RCM renumbering)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--storage', choices=('f32', 'bf16'), default='f32',
+                    help='storage type of states / gates / their gradients: f32 = the metric (reference arithmetic); bf16 = BASELINE configuration 5 '
+                         '(not the metric: bf16 has no reference behaviour), fp32 parameters and fp32 sums inside every kernel')
     return ap.parse_args()
 
 
@@ -104,7 +108,8 @@ def main():
     graph = CsrGraph.queen_grid(a.grid, a.grid, normalize=True, permute_seed=1234 if a.permute else None, device=dev)
     Gc_cpu = torch.softmax(torch.randn(C, C, generator=torch.Generator().manual_seed(7)), -1)
     torch.manual_seed(42)                                                       # same parameters on every rank
-    model = M.STCGNN(N, C, a.order, a.order, 1, a.hidden, a.layers, a.pred, graph_mode='csr-fixed', reorder_nodes=not a.no_reorder)
+    model = M.STCGNN(N, C, a.order, a.order, 1, a.hidden, a.layers, a.pred, graph_mode='csr-fixed', reorder_nodes=not a.no_reorder,
+                     storage_dtype=torch.bfloat16 if a.storage == 'bf16' else torch.float32)
     sd_cpu = {k: v.clone() for k, v in model.state_dict().items()}
     model = model.to(dev)
     Gc = Gc_cpu.to(dev)
@@ -157,7 +162,7 @@ def main():
         # launches of a step exactly like roofline.achieved.  Only valid for the configuration it was collected on.
         traffic, traffic_note = None, None
         tpath = os.path.join(REPO, 'profiles', 'r01', 'j_hbm_traffic_bench_b5.json')
-        if (a.grid, C, a.hidden, B, a.order, a.layers, a.obs, a.pred, a.permute) == (224, 32, 16, 5, 2, 2, 18, 6, False) and os.path.exists(tpath):
+        if a.storage == 'f32' and (a.grid, C, a.hidden, B, a.order, a.layers, a.obs, a.pred, a.permute) == (224, 32, 16, 5, 2, 2, 18, 6, False) and os.path.exists(tpath):
             with open(tpath) as fh:
                 doc = json.load(fh)
             ks = [v for name, v in doc['kernels'].items() if name.startswith('spmm_')]
@@ -167,10 +172,10 @@ def main():
         out = {
             'metric': METRIC, 'value': world * B * a.steps / elapsed, 'unit': 'samples/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * elapsed / a.steps,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.storage, 'data': 'synthetic',
             'config': {'workload': f'full STC-GNN train step (fwd + ComboLoss + bwd + grad all-reduce + Adam), csr-fixed, '
                                    f'{a.grid}x{a.grid} queen grid N={N} nnz={graph.nnz}{" permuted" if a.permute else ""}, C={C}, '
-                                   f'hidden={a.hidden}, K={a.order}, layers={a.layers}, T={a.obs}+{a.pred}',
+                                   f'hidden={a.hidden}, K={a.order}, layers={a.layers}, T={a.obs}+{a.pred}' + (', bf16 state storage' if a.storage == 'bf16' else ''),
                        'global_batch': world * B, 'batch_per_gpu': B, 'parallelism': f'batch-shard x{world}',
                        'grad_bucket_bytes': bucket.nbytes},
             'roofline': {'bound': 'hbm', 'kernel': ' + '.join(SPMM_ENTRY_POINTS) + ': every aggregation (SpMM) launch of the timed steps -- plain, with the GRU blend in its epilogue, and the state-gradient sum form', 'achieved': achieved, 'peak': HBM_PEAK_GBPS,

@@ -28,10 +28,47 @@ def _expand_rows(rowptr: Tensor) -> Tensor:
     return torch.repeat_interleave(torch.arange(counts.numel()), counts)
 
 
+class _Bf16Emulated:
+    """CPU stand-in for ``HipKernels.bf16``: every bfloat16 tensor argument (also inside lists / tuples) is widened to fp32,
+    the fp32 twin runs, and the results are rounded back into the caller's bf16 tensors -- i.e. "fp32 math on bf16-valued
+    planes, one rounding per stored plane", the contract of the bf16 kernels (their extra internal roundings are what the
+    GPU tests bound)."""
+
+    name = 'emulated-cpu-bf16'
+
+    def __init__(self, em):
+        self.em = em
+
+    def __getattr__(self, name):
+        fn = getattr(self.em, name)
+        pairs = []
+
+        def widen(a):
+            if isinstance(a, torch.Tensor) and a.dtype == torch.bfloat16:
+                w = a.float()
+                pairs.append((a, w))
+                return w
+            if isinstance(a, (list, tuple)):
+                return type(a)(widen(v) for v in a)
+            return a
+
+        def call(*args, **kw):
+            out = fn(*[widen(a) for a in args], **{k: widen(v) for k, v in kw.items()})
+            for orig, w in pairs:
+                orig.copy_(w)
+            pairs.clear()
+            return out
+        return call
+
+
 class EmulatedKernels:
     """Drop-in for ``stc_hip._lib.HipKernels`` on CPU tensors."""
 
     name = 'emulated-cpu'
+
+    @property
+    def bf16(self):
+        return _Bf16Emulated(self)
 
     # ---- stc_csr_spmm_f32: 1-mode product + Chebyshev epilogue (STC_GNN.py:28, 37)
     def csr_spmm(self, rowptr, colidx, val, n_rows, n_cols, X, Y0, Y, alpha, beta, plan=None):

@@ -292,10 +292,17 @@ class STCGNN(nn.Module):
     def __init__(self, num_nodes: int, num_categories: int, Ks: int, Kc: int, input_dim: int, hidden_dim: int,
                  num_layers: int, out_horizon: int, use_bias=True, activation=None,
                  graph_mode: str = 'dense-learned', reorder_nodes: bool = True, batch_sharded: bool = False,
-                 fusion_rank: Optional[int] = None):
+                 fusion_rank: Optional[int] = None, storage_dtype: torch.dtype = torch.float32):
         super().__init__()
         if graph_mode not in ('dense-learned', 'csr-fixed'):
             raise ValueError("graph_mode must be 'dense-learned' (reference semantics) or 'csr-fixed'")
+        if storage_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError('storage_dtype must be torch.float32 (reference arithmetic) or torch.bfloat16')
+        if storage_dtype == torch.bfloat16 and graph_mode != 'csr-fixed':
+            raise ValueError("storage_dtype=torch.bfloat16 needs graph_mode='csr-fixed' (BASELINE configuration 5)")
+        # bfloat16: states, gates and their gradients are stored in bf16 (fp32 parameters, fp32 sums inside every kernel);
+        # not reference behaviour (the reference is fp32-only) -- the large-N configuration's memory / bandwidth option
+        self.storage_dtype = storage_dtype
         self.graph_mode = graph_mode
         self.reorder_nodes = reorder_nodes      # csr-fixed + CsrGraph: renumber nodes internally when that restores locality
         self.Ks, self.Kc = Ks, Kc
@@ -329,9 +336,11 @@ class STCGNN(nn.Module):
                     X_seq = X_seq.index_select(2, idx[0])
                     inv = idx[1]
         pair = _graphs(Gs, Gc, self.Ks, self.Kc)
-        stacked = self._run_cell_graph(pair, X_seq.unsqueeze(-1))
+        stacked = self._run_cell_graph(pair, X_seq.unsqueeze(-1).to(self.storage_dtype))
+        if stacked is None and self.storage_dtype != torch.float32:
+            raise ValueError('storage_dtype=torch.bfloat16: shape outside the bf16 cell kernels (Ks = Kc = 2, hidden 16, C in {32, 64}, input_dim <= 4)')
         if stacked is not None:
-            y = self._head(stacked).transpose(0, 1)                       # (horizon, B, N, C) -> (B, horizon, N, C), a view
+            y = self._head(stacked.float()).transpose(0, 1)               # (horizon, B, N, C) -> (B, horizon, N, C), a view
         else:                                                             # general path: one autograd node per cell
             _, states = self.encoder._run(pair, None, X_seq.unsqueeze(-1))     # per-layer output stacks are not needed here
             step_in = states[-1]
@@ -355,10 +364,10 @@ class STCGNN(nn.Module):
             return None
         h = hidden.pop()
         B, T, N, C, cin0 = X.shape
-        if X.requires_grad or not ops.cell_graph_supported(pair.spatial, pair.Tc, self.Ks, C, h, [cin0, h]):
+        if X.requires_grad or not ops.cell_graph_supported(pair.spatial, pair.Tc, self.Ks, C, h, [cin0, h], dtype=X.dtype):
             return None
         n_layers, horizon = len(enc), self.decoder.out_horizon
-        ext = [X[:, t] for t in range(T)] + [c.init_hidden(B) for c in enc]           # inputs, then the zero initial states
+        ext = [X[:, t] for t in range(T)] + [c.init_hidden(B).to(X.dtype) for c in enc]   # inputs, then the zero initial states
         eid = lambda l, t: l * T + t                                                    # encoder: layer-major, then time
         did = lambda l, s_: n_layers * T + s_ * n_layers + l                            # decoder: step-major, then layer
         schedule = []

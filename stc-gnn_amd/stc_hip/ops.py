@@ -437,12 +437,16 @@ _PLANAR = os.environ.get('STC_PLANAR', '1') != '0'              # cells with 16 
 _POST_AGG = os.environ.get('STC_POST_AGG', '1') != '0'          # candidate convolution as Y = A + S.Bm (narrow SpMM after the node kernel)
 
 
-def cell_graph_supported(op: SpatialOperand, Tc, Ks: int, C: int, h: int, x_widths) -> bool:
+def cell_graph_supported(op: SpatialOperand, Tc, Ks: int, C: int, h: int, x_widths, dtype=torch.float32) -> bool:
     """Whether ``stc_cell_graph`` can run a schedule: matrix-core cell kernels for every row width that occurs, hidden 16,
-    graphs that need no gradient (``csr-fixed`` mode)."""
+    graphs that need no gradient (``csr-fixed`` mode).  ``dtype`` = storage type of the state tensors: bfloat16 runs the
+    all-planar bf16 kernel set (Ks = Kc = 2; inputs 16 or 1..4 columns wide)."""
     if not _CELL_GRAPH or h != 16 or Tc.requires_grad or op.fwd_val.requires_grad:
         return False
     k = kernels()
+    if dtype == torch.bfloat16:
+        return (_PLANAR and _POST_AGG and _FUSE_POST and Ks == 2 and Tc.shape[0] == 2 and k.bf16.cell_planar_supported(Ks, 2, C, h)
+                and all(w == h or 1 <= w <= 4 for w in x_widths))
     return all(k.cell_fused_supported(Ks, Tc.shape[0], C, w + h + (-(w + h)) % 4, h) for w in set(x_widths))
 
 
@@ -473,6 +477,9 @@ class _StcCellGraph(Function):
     def forward(ctx, op: SpatialOperand, Ks: int, schedule, outputs, n_ext: int, Tc, fwd_val, *tensors):
         k = kernels()
         ext = [_c(t) for t in tensors[:n_ext]]
+        bf16 = ext[0].dtype == torch.bfloat16                       # bf16 state planes: the all-planar bf16 kernel set
+        if bf16:
+            k = k.bf16
         flat = tensors[n_ext:]
         stacks = [tuple(None if p is None else _c(p) for p in flat[i:i + 4]) for i in range(0, len(flat), 4)]   # (Wg, bg, Wc, bc)
         Tc, fwd_val = _c(Tc), _c(fwd_val)
@@ -495,6 +502,8 @@ class _StcCellGraph(Function):
         post20 = bool(planar_ok) and k.node_post_supported(Ks, Tc.shape[0], C, 20, h)
         # 16 + 16 columns, or (layer 0) a narrow input plane of 1..4 columns beside the 16 state columns
         planar = [bool(planar_ok and (cin[j] == h or (post20 and 1 <= cin[j] <= 4))) for j in range(n_cells)]
+        if bf16 and not all(planar):
+            raise ValueError('stc_cell_graph: bfloat16 states need an all-planar schedule (Ks = 2, inputs 16 or 1..4 columns wide)')
         XH, agg = {}, {}
 
         def rows_of(j):                                             # input rows of an interleaved cell, allocated at first touch
@@ -602,6 +611,8 @@ class _StcCellGraph(Function):
     @once_differentiable
     def backward(ctx, grad_stack):
         k = kernels()
+        if grad_stack.dtype == torch.bfloat16:
+            k = k.bf16
         op, Ks, schedule, outputs, cin, present, (B, N, C), n_saved = ctx.meta
         sv = list(ctx.saved_tensors)
         Tc = sv.pop(0)

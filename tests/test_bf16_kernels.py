@@ -343,3 +343,64 @@ def test_state_aggregations_bf16(hip, batch, grid, C, n_add, dual):
     dC = torch.full((batch, n, C, h), float('nan'), dtype=bf).cuda()
     kb.gru_blend_bwd(cu(X), cu(U), None, cu(Cand), dC, None, None)
     assert_one_ulp(dC, (f(X) * f(U) * (1 - f(Cand) ** 2)).to(bf), max_mismatch=0.05)
+
+
+# ------------------------------------------------------------------ the whole model with bf16 state storage
+@pytest.mark.parametrize('C,layers,T,horizon,cin', [(32, 2, 3, 2, 1), (64, 2, 2, 2, 1), (32, 1, 2, 1, 3), (64, 3, 2, 2, 1)])
+def test_model_bf16_storage_tracks_fp32(hip, C, layers, T, horizon, cin):
+    """STCGNN(storage_dtype=bfloat16) -- every state, gate and gradient plane in bf16, fp32 parameters -- against the same
+    model in fp32 (the parity-checked path) on the same inputs and parameters: prediction within bf16 noise of a 2 x (T +
+    horizon)-cell recurrence, every parameter gradient pointing the same way (cosine) with the same size."""
+    import STC_GNN as M
+    from stc_hip import ops
+    Hh, Ww, h, K, B = 6, 7, 16, 2, 2
+    torch.manual_seed(C + layers + T)
+    graph = CsrGraph.queen_grid(Hh, Ww, normalize=True)
+    N = Hh * Ww
+    kw = dict(num_nodes=N, num_categories=C, Ks=K, Kc=K, input_dim=cin, hidden_dim=h, num_layers=layers, out_horizon=horizon, graph_mode='csr-fixed')
+    m32 = M.STCGNN(**kw).cuda()
+    m16 = M.STCGNN(**kw, storage_dtype=torch.bfloat16).cuda()
+    m16.load_state_dict(m32.state_dict())
+    if cin != 1:                                               # keep the prediction scalar per (node, category)
+        m32._head = lambda Hs: torch.sigmoid(Hs.sum(-1))
+        m16._head = lambda Hs: torch.sigmoid(Hs.sum(-1))
+    Gc = torch.softmax(torch.randn(C, C), -1).cuda()
+    X = (torch.rand(B, T, N, C, cin) < 0.3).float().cuda()           # bf16-exact inputs, as the incident indicators are
+    Rw = torch.randn(B, horizon, N, C).cuda()
+    calls = []
+    real = ops.stc_cell_graph
+    ops.stc_cell_graph = lambda *a, **k: (calls.append(a[5][0].dtype), real(*a, **k))[1]
+    try:
+        out = {}
+        for name, m in (('f32', m32), ('bf16', m16)):
+            m.zero_grad(set_to_none=True)
+            pair = M._graphs(graph, Gc, K, K)
+            stacked = m._run_cell_graph(pair, X.to(m.storage_dtype))
+            assert stacked is not None and stacked.dtype == m.storage_dtype
+            y = m._head(stacked.float()).transpose(0, 1)
+            (y * Rw).sum().backward()
+            out[name] = (y.detach(), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
+    finally:
+        ops.stc_cell_graph = real
+    assert calls == [torch.float32, torch.bfloat16]
+    (y32, g32), (y16, g16) = out['f32'], out['bf16']
+    assert torch.isfinite(y16).all()
+    assert float((y16 - y32).abs().max()) < 2e-2                      # predictions are in (0, 1)
+    assert set(g16) == set(g32)
+    for n in g32:
+        a, b = g16[n].flatten().double(), g32[n].flatten().double()
+        cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
+        assert cos > 0.995, f'd{n}: cosine {cos}'
+        assert abs(float(a.norm() / (b.norm() + 1e-30)) - 1) < 5e-2, f'd{n}: norm ratio {float(a.norm() / b.norm())}'
+
+
+def test_model_bf16_storage_refuses_what_it_cannot_run():
+    import STC_GNN as M
+    with pytest.raises(ValueError):
+        M.STCGNN(30, 32, 2, 2, 1, 16, 2, 2, storage_dtype=torch.bfloat16)                       # learned graphs: fp32 only
+    with pytest.raises(ValueError):
+        M.STCGNN(30, 32, 2, 2, 1, 16, 2, 2, graph_mode='csr-fixed', storage_dtype=torch.float16)
+    m = M.STCGNN(30, 32, 3, 3, 1, 16, 1, 1, graph_mode='csr-fixed', storage_dtype=torch.bfloat16).cuda()     # K = 3: no bf16 cell kernels
+    graph = CsrGraph.queen_grid(5, 6, normalize=True)
+    with pytest.raises(ValueError):
+        m(X_seq=torch.zeros(1, 2, 30, 32).cuda(), As=graph, Ac=torch.eye(32).cuda())
