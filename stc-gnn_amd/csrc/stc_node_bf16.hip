@@ -24,6 +24,8 @@
 // must hold finite values), Ks = Kc = K <= 3.  Everything else: STC_EUNSUPPORTED.
 #include "stc_node_frag.h"
 
+#include <cstdlib>
+
 namespace {
 
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
@@ -407,8 +409,8 @@ __device__ __forceinline__ u32x4 pack8f(const float (&r)[8]) {
     return u32x4{pk_bf16(r[0], r[1]), pk_bf16(r[2], r[3]), pk_bf16(r[4], r[5]), pk_bf16(r[6], r[7])};
 }
 
-template <int NB2, int HB, int K, int L, int PL = 0, int PRO = 0>
-__global__ __launch_bounds__(MF_THREADS, (BwdWaves<NB2, K>::v)) void node_bwd_bf16_kernel(
+template <int NB2, int HB, int K, int L, int PL = 0, int PRO = 0, int WAVES = BwdWaves<NB2, K>::v>
+__global__ __launch_bounds__(MF_THREADS, WAVES) void node_bwd_bf16_kernel(
     BPtrs2 Z, const float* __restrict__ Tc, const float* __restrict__ W, const bf16_t* __restrict__ dY,
     BDPtrs2 dZ, float* __restrict__ partial, int nodes, int want_db, int Lw, GatesPro pro) {
     static_assert(!PL || (L == 32 && K == 2), "planar slabs are 16 + 16 columns, K = 2");
@@ -462,27 +464,50 @@ __global__ __launch_bounds__(MF_THREADS, (BwdWaves<NB2, K>::v)) void node_bwd_bf
 #pragma unroll
     for (int hb = 0; hb < HB; ++hb) dbp[hb] = 0.f;
 
-    for (int node = blockIdx.x * MF_WAVES + wave; node < nodes; node += nw) {
-        const size_t r0 = (size_t)node * C;
-        u32x4 dyr[NRB], zr[K][NRB];
+    // One wave per SIMD (C = 64 with the prologue: > 256 registers) has no partner wave to hide the loads behind, so the next
+    // node's slabs and prologue planes are requested before this node's arithmetic starts (software prefetch, raw registers).
+    constexpr bool PF = PRO != 0 && WAVES == 1;
+    u32x4 zr[K][NRB], znx[PF ? K : 1][PF ? NRB : 1];
+    u32x4 pr[PRO ? 6 : 1][PRO ? NRB : 1], pnx[PF ? 6 : 1][PF ? NRB : 1];
+    auto fetch_z = [&](auto& z, int nd) {
 #pragma unroll
         for (int n = 0; n < K; ++n)
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) {
-                if constexpr (PL != 0) zr[n][rb] = load_planar8<PL == 2>(Z.p[n], Z.q[n], r0 + 16 * rb + x, g, cin);
-                else zr[n][rb] = load_row8<L>(Z.p[n], r0 + 16 * rb + x, g);
+                if constexpr (PL != 0) z[n][rb] = load_planar8<PL == 2>(Z.p[n], Z.q[n], (size_t)nd * C + 16 * rb + x, g, cin);
+                else z[n][rb] = load_row8<L>(Z.p[n], (size_t)nd * C + 16 * rb + x, g);
             }
+    };
+    auto fetch_pro = [&](auto& q, int nd) {
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) {
+            const size_t e = ((size_t)nd * C + 16 * rb + x) * 16 + 8 * (g & 1);       // lanes g and g + 2 read the same 8 columns
+            q[0][rb] = *reinterpret_cast<const u32x4*>(pro.dHnew + e);
+            q[1][rb] = *reinterpret_cast<const u32x4*>(pro.Cand + e);
+            q[2][rb] = *reinterpret_cast<const u32x4*>(pro.H + e);
+            q[3][rb] = *reinterpret_cast<const u32x4*>(pro.U + e);
+            q[4][rb] = *reinterpret_cast<const u32x4*>(pro.dRH + e);
+            q[5][rb] = *reinterpret_cast<const u32x4*>(pro.R + e);
+        }
+    };
+    int node = blockIdx.x * MF_WAVES + wave;
+    if constexpr (PF) { if (node < nodes) { fetch_z(zr, node); fetch_pro(pr, node); } }
+    for (; node < nodes; node += nw) {
+        const size_t r0 = (size_t)node * C;
+        u32x4 dyr[NRB];
+        if constexpr (!PF) {
+            fetch_z(zr, node);
+            if constexpr (PRO != 0) fetch_pro(pr, node);
+        } else {
+            if (node + nw < nodes) { fetch_z(znx, node + nw); fetch_pro(pnx, node + nw); }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if constexpr (PRO != 0) {
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) {
-                const size_t e = (r0 + 16 * rb + x) * 16 + 8 * (g & 1);       // lanes g and g + 2 read the same 8 columns
                 float gn[8], cd[8], hh[8], uu[8], dr[8], rr[8], gy[8], dh[8];
-                unpack8(*reinterpret_cast<const u32x4*>(pro.dHnew + e), gn);
-                unpack8(*reinterpret_cast<const u32x4*>(pro.Cand + e), cd);
-                unpack8(*reinterpret_cast<const u32x4*>(pro.H + e), hh);
-                unpack8(*reinterpret_cast<const u32x4*>(pro.U + e), uu);
-                unpack8(*reinterpret_cast<const u32x4*>(pro.dRH + e), dr);
-                unpack8(*reinterpret_cast<const u32x4*>(pro.R + e), rr);
+                unpack8(pr[0][rb], gn); unpack8(pr[1][rb], cd); unpack8(pr[2][rb], hh);
+                unpack8(pr[3][rb], uu); unpack8(pr[4][rb], dr); unpack8(pr[5][rb], rr);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const float gu = gn[i] * (cd[i] - hh[i]) * uu[i] * (1.f - uu[i]);
@@ -491,7 +516,7 @@ __global__ __launch_bounds__(MF_THREADS, (BwdWaves<NB2, K>::v)) void node_bwd_bf
                     dh[i] = fmaf(dr[i], rr[i], gn[i] * (1.f - uu[i]));
                 }
                 dyr[rb] = pack8f(gy);
-                if (g < 2) *reinterpret_cast<u32x4*>(pro.dH + e) = pack8f(dh);
+                if (g < 2) *reinterpret_cast<u32x4*>(pro.dH + (r0 + 16 * rb + x) * 16 + 8 * g) = pack8f(dh);
             }
         } else {
 #pragma unroll
@@ -595,6 +620,15 @@ __global__ __launch_bounds__(MF_THREADS, (BwdWaves<NB2, K>::v)) void node_bwd_bf
                         for (int hb = 0; hb < HB; ++hb)
                             dWt[n][lb][c][hb] = mma(a, c == 0 ? gd[hb][p] : qd[c > 0 ? c - 1 : 0][hb][p], dWt[n][lb][c][hb]);
                 }
+        if constexpr (PF) {
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+#pragma unroll
+                for (int n = 0; n < K; ++n) zr[n][rb] = znx[n][rb];
+#pragma unroll
+                for (int q = 0; q < 6; ++q) pr[q][rb] = pnx[q][rb];
+            }
+        }
     }
     combine_dw<K, LB, HB>(reinterpret_cast<float*>(smem_raw), dWt, dbp, partial, Lw, want_db, PL == 2 ? cin : -1);
 }
@@ -790,16 +824,16 @@ int launch_gates_fwd(const GatesFwd& a, const float* Tc, const float* W, const f
     return STC_OK;
 }
 
-template <int NB2, int PL>
+template <int NB2, int PL, int WAVES = BwdWaves<NB2, 2>::v>
 int launch_gates_bwd(const BPtrs2& zp, const BDPtrs2& dzp, const GatesPro& pro, const float* Tc, const float* W,
                      float* partial, int* n_partials, int want_db, long long nodes, int Lw, hipStream_t stream) {
     constexpr int NRB = 2 * NB2, K = 2, LB = 2, nW = K * K * 32 * 32;
     const size_t frag = (size_t)(NRB * NB2 + K * LB * K) * 64 * 16;
     const size_t slabs = (size_t)MF_WAVES * (nW + 32) * sizeof(float);
     const size_t lds = frag > slabs ? frag : slabs;
-    auto kern = node_bwd_bf16_kernel<NB2, 2, 2, 32, PL, 1>;
+    auto kern = node_bwd_bf16_kernel<NB2, 2, 2, 32, PL, 1, WAVES>;
     if (int rc = stc::hip_status(stc::allow_lds(kern, lds), "hipFuncSetAttribute(gates bwd bf16)")) return rc;
-    static const int resident = stc::resident_blocks(kern, MF_THREADS, lds, BwdWaves<NB2, 2>::v);
+    static const int resident = stc::resident_blocks(kern, MF_THREADS, lds, WAVES);
     const long long want = (nodes + MF_WAVES - 1) / MF_WAVES;
     int grid = resident < MF_BWD_MAX_GRID ? resident : MF_BWD_MAX_GRID;
     if (want < grid) grid = (int)want;
@@ -970,10 +1004,15 @@ extern "C" int stc_cell_gates_bwd_planar_bf16(const void* X, const void* H, cons
     const GatesPro pro{B(dCandIn), B(Cand), B(H), B(U), B(Rg), B(dHnew), M(dH)};
     float* partial = static_cast<float*>(workspace);
     int n_parts = 0;
+    // C = 64: one wave per SIMD with software prefetch (default); STC_BF16_BWD_WAVES=2 caps the kernel at 256 registers for two
+    // waves per SIMD, which spills (measured 2313 vs 1840 us per launch before the prefetch existed)
+    static const bool two = [] { const char* e = std::getenv("STC_BF16_BWD_WAVES"); return e && e[0] == '2'; }();
     const int rc = C == 32 ? (narrow ? launch_gates_bwd<1, 2>(zp, dzp, pro, Tc, W, partial, &n_parts, db != nullptr, nodes, Lw, s)
                                      : launch_gates_bwd<1, 1>(zp, dzp, pro, Tc, W, partial, &n_parts, db != nullptr, nodes, Lw, s))
-                           : (narrow ? launch_gates_bwd<2, 2>(zp, dzp, pro, Tc, W, partial, &n_parts, db != nullptr, nodes, Lw, s)
-                                     : launch_gates_bwd<2, 1>(zp, dzp, pro, Tc, W, partial, &n_parts, db != nullptr, nodes, Lw, s));
+                           : two ? (narrow ? launch_gates_bwd<2, 2, 2>(zp, dzp, pro, Tc, W, partial, &n_parts, db != nullptr, nodes, Lw, s)
+                                           : launch_gates_bwd<2, 1, 2>(zp, dzp, pro, Tc, W, partial, &n_parts, db != nullptr, nodes, Lw, s))
+                                 : (narrow ? launch_gates_bwd<2, 2, 1>(zp, dzp, pro, Tc, W, partial, &n_parts, db != nullptr, nodes, Lw, s)
+                                           : launch_gates_bwd<2, 1, 1>(zp, dzp, pro, Tc, W, partial, &n_parts, db != nullptr, nodes, Lw, s));
     if (rc != STC_OK) return rc;
     return stc_node_reduce_partials(partial, n_parts, nW, 32, dW, db, s);
 }

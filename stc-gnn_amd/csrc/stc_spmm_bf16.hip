@@ -23,7 +23,6 @@ constexpr int SPMM_WAVES = SPMM_THREADS / 64;
 constexpr int SPMM_ROWS = 8;         // CSR kernel: output rows per workgroup
 constexpr int SPMM_SEG_CAP = 1024;   // CSR entries staged in LDS per workgroup
 constexpr int BR = STC_SPMM_BLOCK_ROWS;
-constexpr int BC_BLOCKS = 2;         // row blocks per workgroup (two waves share a block and split its column blocks)
 constexpr int BC_CAP = 512;          // block entries staged in LDS per workgroup
 
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
@@ -236,7 +235,9 @@ __global__ __launch_bounds__(SPMM_THREADS) void spmm_wave_row_bf16_kernel(
 }
 
 // ---- row-blocked (BCSR 4x1): one wave (pair) produces 4 consecutive output rows, each distinct neighbour row fetched once
-template <int VPT, int MODE>
+// BC_BLOCKS row blocks per workgroup: 2 (two waves share a block and split its column blocks of 64*VPT pieces) or, for rows
+// of at most 64 pieces (state planes at C = 32: 1 KiB), 4 (one wave per block) -- otherwise half the waves would idle.
+template <int VPT, int MODE, int BC_BLOCKS>
 __global__ __launch_bounds__(SPMM_THREADS) void spmm_bcsr_bf16_kernel(
     const int* __restrict__ blk_ptr, const int* __restrict__ blk_cols, const float* __restrict__ blk_vals,
     int n_rows, int n_cols, const u32x4* __restrict__ X, int F8, int n_blocks, int n_tiles, Epi ep) {
@@ -392,13 +393,16 @@ int launch(const char* who, const GraphArgs& g, int n_rows, int n_cols, const vo
     const int F8 = F / 8;
     if (g.blk_ptr) {
         const int n_blocks = (n_rows + BR - 1) / BR;
-        const int n_tiles = (n_blocks + BC_BLOCKS - 1) / BC_BLOCKS;
+        const int blocks = F8 <= 64 ? 4 : 2;
+        const int n_tiles = (n_blocks + blocks - 1) / blocks;
         const int per = (n_tiles + stc::kNumXcd - 1) / stc::kNumXcd;
         const dim3 grid(per * stc::kNumXcd, batch), block(SPMM_THREADS);
-        if (F8 <= 128)        // two waves per block: each covers every other column block of 64*VPT pieces
-            hipLaunchKernelGGL((spmm_bcsr_bf16_kernel<1, MODE>), grid, block, 0, s, g.blk_ptr, g.blk_cols, g.blk_vals, n_rows, n_cols, X8, F8, n_blocks, n_tiles, ep);
+        if (F8 <= 64)         // one wave per row block
+            hipLaunchKernelGGL((spmm_bcsr_bf16_kernel<1, MODE, 4>), grid, block, 0, s, g.blk_ptr, g.blk_cols, g.blk_vals, n_rows, n_cols, X8, F8, n_blocks, n_tiles, ep);
+        else if (F8 <= 128)   // two waves per block: each covers every other column block of 64*VPT pieces
+            hipLaunchKernelGGL((spmm_bcsr_bf16_kernel<1, MODE, 2>), grid, block, 0, s, g.blk_ptr, g.blk_cols, g.blk_vals, n_rows, n_cols, X8, F8, n_blocks, n_tiles, ep);
         else
-            hipLaunchKernelGGL((spmm_bcsr_bf16_kernel<2, MODE>), grid, block, 0, s, g.blk_ptr, g.blk_cols, g.blk_vals, n_rows, n_cols, X8, F8, n_blocks, n_tiles, ep);
+            hipLaunchKernelGGL((spmm_bcsr_bf16_kernel<2, MODE, 2>), grid, block, 0, s, g.blk_ptr, g.blk_cols, g.blk_vals, n_rows, n_cols, X8, F8, n_blocks, n_tiles, ep);
     } else {
         const int n_tiles = (n_rows + SPMM_ROWS - 1) / SPMM_ROWS;
         const int per = (n_tiles + stc::kNumXcd - 1) / stc::kNumXcd;
