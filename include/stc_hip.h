@@ -137,6 +137,11 @@ int stc_spmm_sum_bf16(const int32_t* rowptr, const int32_t* colidx, const float*
                       void* Y, const void* U, const void* Cand, void* dY,
                       int32_t batch, int32_t C, int32_t h, void* stream);
 int stc_gru_blend_bwd_bf16(const void* dHnew, const void* U, const void* Cand, void* dCpre, int64_t n, void* stream);
+/* Output head on bf16 state rows (h = 16): H / dH bf16, y / dy and w, b, dwb fp32; otherwise as stc_head_fwd/bwd_f32
+ * (workspace: stc_head_bwd_workspace_bytes(16)). */
+int stc_head_fwd_bf16(const void* H, const float* w, const float* b, float* y, int64_t rows, int32_t h, void* stream);
+int stc_head_bwd_bf16(const void* H, const float* w, const float* y, const float* dy, void* dH, float* dwb,
+                      void* workspace, size_t workspace_bytes, int64_t rows, int32_t h, void* stream);
 
 /* Backward products of an STC_Cell with the element-wise consumer folded into the epilogue (autograd of
  * STC_GNN.py:68-75).  Rows are node rows of C categories x (cin + h + pad) features (the [Xt | H | 0-pad]

@@ -396,9 +396,10 @@ class EmulatedKernels:
 
     # ---- stc_head_fwd/bwd_f32: the two bias-ful Linears of the output head folded into one map + sigmoid (STC_GNN.py:182-183, 206)
     def head_fwd(self, H, w, b, y):
-        y.copy_(torch.sigmoid(H @ w + b))
+        y.copy_(torch.sigmoid(H.to(w.dtype) @ w + b))          # bf16 state rows (stc_head_fwd_bf16): fp32 arithmetic, fp32 y
 
     def head_bwd(self, H, w, y, dy, dH, dwb):
+        H = H.to(w.dtype)
         g = dy * y * (1 - y)
         dH.copy_(g.unsqueeze(-1) * w)
         dwb[:-1].copy_((g.unsqueeze(-1) * H).reshape(-1, H.shape[-1]).sum(0))

@@ -340,7 +340,7 @@ class STCGNN(nn.Module):
         if stacked is None and self.storage_dtype != torch.float32:
             raise ValueError('storage_dtype=torch.bfloat16: shape outside the bf16 cell kernels (Ks = Kc = 2, hidden 16, C in {32, 64}, input_dim <= 4)')
         if stacked is not None:
-            y = self._head(stacked.float()).transpose(0, 1)               # (horizon, B, N, C) -> (B, horizon, N, C), a view
+            y = self._head(stacked).transpose(0, 1)                       # (horizon, B, N, C) -> (B, horizon, N, C), a view
         else:                                                             # general path: one autograd node per cell
             _, states = self.encoder._run(pair, None, X_seq.unsqueeze(-1))     # per-layer output stacks are not needed here
             step_in = states[-1]
@@ -392,8 +392,8 @@ class STCGNN(nn.Module):
         streaming part runs in one fused HIP kernel instead of two skinny GEMMs."""
         lin1, lin2 = self.out_proj[0], self.out_proj[1]
         h = lin1.in_features
-        if lin2.out_features != 1 or h % 4 or h > 64:
-            return torch.sigmoid(self.out_proj(H)).squeeze(dim=-1)
+        if lin2.out_features != 1 or h % 4 or h > 64 or (H.dtype == torch.bfloat16 and h != 16):
+            return torch.sigmoid(self.out_proj(H.float())).squeeze(dim=-1)
         w = (lin2.weight @ lin1.weight).reshape(h)
         if lin1.bias is not None:
             b = lin2.weight @ lin1.bias + lin2.bias

@@ -283,6 +283,70 @@ __global__ __launch_bounds__(EW_THREADS) void head_bwd_kernel(const float* __res
     }
 }
 
+// bf16 state rows, hidden 16 (the bf16-storage configuration): a row is 32 bytes, two lanes share it with one 16-byte piece of
+// 8 bf16 each; y, dy and the weight gradient stay fp32
+using head_u4 = __attribute__((ext_vector_type(4))) unsigned;
+using head_bf2 = __attribute__((ext_vector_type(2))) __bf16;
+__device__ __forceinline__ void head_unpack8(const head_u4 v, float (&r)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { r[2 * i] = __uint_as_float(v[i] << 16); r[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u); }
+}
+__device__ __forceinline__ unsigned head_pk(float a, float b) {
+    const head_bf2 v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, v);
+}
+
+__global__ __launch_bounds__(EW_THREADS) void head_fwd_bf16_kernel(const head_u4* __restrict__ H, const float* __restrict__ w,
+                                                                    const float* __restrict__ b, float* __restrict__ y, long long rows) {
+    constexpr int RPB = EW_THREADS / 2;
+    const int q = threadIdx.x & 1;
+    float wq[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) wq[i] = w[8 * q + i];
+    const float bias = b[0];
+    for (long long r = (long long)blockIdx.x * RPB + threadIdx.x / 2; r < rows; r += (long long)gridDim.x * RPB) {
+        float v[8];
+        head_unpack8(H[2 * r + q], v);
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s = fmaf(v[i], wq[i], s);
+        s += __shfl_xor(s, 1, 64);
+        if (q == 0) y[r] = sigmoidf_(s + bias);
+    }
+}
+
+__global__ __launch_bounds__(EW_THREADS) void head_bwd_bf16_kernel(const head_u4* __restrict__ H, const float* __restrict__ w,
+                                                                    const float* __restrict__ y, const float* __restrict__ dy,
+                                                                    head_u4* __restrict__ dH, float* __restrict__ partial, long long rows) {
+    constexpr int RPB = EW_THREADS / 2, h = 16;
+    __shared__ float red[EW_THREADS][9];
+    const int q = threadIdx.x & 1;
+    float wq[8], acc[8], accg = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { wq[i] = w[8 * q + i]; acc[i] = 0.f; }
+    for (long long r = (long long)blockIdx.x * RPB + threadIdx.x / 2; r < rows; r += (long long)gridDim.x * RPB) {
+        const float yy = y[r];
+        const float g = dy[r] * yy * (1.f - yy);
+        if (q == 0) accg += g;
+        float v[8];
+        head_unpack8(H[2 * r + q], v);
+        dH[2 * r + q] = head_u4{head_pk(g * wq[0], g * wq[1]), head_pk(g * wq[2], g * wq[3]), head_pk(g * wq[4], g * wq[5]), head_pk(g * wq[6], g * wq[7])};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = fmaf(g, v[i], acc[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[threadIdx.x][i] = acc[i];
+    red[threadIdx.x][8] = accg;
+    __syncthreads();
+    if ((int)threadIdx.x <= h) {                      // element k of dw (k < 16) or db (k == 16): its lanes in a fixed order
+        const int k = threadIdx.x;
+        const int lane_q = k < h ? k / 8 : 0, comp = k < h ? k % 8 : 8;
+        float v = 0.f;
+        for (int t = lane_q; t < EW_THREADS; t += 2) v += red[t][comp];
+        partial[(size_t)blockIdx.x * (h + 1) + k] = v;
+    }
+}
+
 __global__ __launch_bounds__(EW_THREADS) void head_reduce_kernel(const float* __restrict__ partial, int n_parts, int stride, float* __restrict__ out) {
     __shared__ float red[EW_THREADS];
     const int e = blockIdx.x;                       // one output element per workgroup
@@ -479,6 +543,35 @@ extern "C" int stc_head_bwd_f32(const float* H, const float* w, const float* y, 
 #undef STC_HEAD_BWD
     hipLaunchKernelGGL(head_reduce_kernel, dim3(h + 1), dim3(EW_THREADS), 0, s, partial, grid, h + 1, dwb);
     STC_LAUNCH_CHECK("stc_head_bwd_f32 launch");
+    return STC_OK;
+}
+
+extern "C" int stc_head_fwd_bf16(const void* H, const float* w, const float* b, float* y, int64_t rows, int32_t h, void* stream) {
+    STC_REQUIRE(h == 16, STC_EUNSUPPORTED, "stc_head_fwd_bf16: hidden width %d (built for 16)", h);
+    STC_EW_PROLOGUE("stc_head_fwd_bf16", rows, H && w && b && y);
+    STC_REQUIRE(stc::aligned16(H), STC_EALIGN, "stc_head_fwd_bf16: H not 16-byte aligned");
+    hipLaunchKernelGGL(head_fwd_bf16_kernel, ew_grid(rows * 2), dim3(EW_THREADS), 0, s, static_cast<const head_u4*>(H), w, b, y, (long long)rows);
+    STC_LAUNCH_CHECK("stc_head_fwd_bf16 launch");
+    return STC_OK;
+}
+
+extern "C" int stc_head_bwd_bf16(const void* H, const float* w, const float* y, const float* dy, void* dH, float* dwb,
+                                 void* workspace, size_t workspace_bytes, int64_t rows, int32_t h, void* stream) {
+    STC_REQUIRE(h == 16, STC_EUNSUPPORTED, "stc_head_bwd_bf16: hidden width %d (built for 16)", h);
+    STC_REQUIRE(rows >= 0 && dwb, STC_EINVAL, "stc_head_bwd_bf16: negative rows or null dwb");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (rows == 0) return stc::hip_status(hipMemsetAsync(dwb, 0, (size_t)(h + 1) * sizeof(float), s), "memset dwb");
+    STC_REQUIRE(H && w && y && dy && dH, STC_EINVAL, "stc_head_bwd_bf16: null pointer");
+    STC_REQUIRE(stc::aligned16(H) && stc::aligned16(dH) && workspace && stc::aligned16(workspace), STC_EALIGN,
+                "stc_head_bwd_bf16: H/dH/workspace must be 16-byte aligned");
+    STC_REQUIRE(workspace_bytes >= stc_head_bwd_workspace_bytes(h), STC_EINVAL, "stc_head_bwd_bf16: workspace too small");
+    long long blocks = (rows * 2 + EW_THREADS - 1) / EW_THREADS;
+    const int grid = (int)(blocks < HEAD_PARTS ? blocks : HEAD_PARTS);
+    float* partial = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(head_bwd_bf16_kernel, dim3(grid), dim3(EW_THREADS), 0, s, static_cast<const head_u4*>(H), w, y, dy,
+                       static_cast<head_u4*>(dH), partial, (long long)rows);
+    hipLaunchKernelGGL(head_reduce_kernel, dim3(h + 1), dim3(EW_THREADS), 0, s, partial, grid, h + 1, dwb);
+    STC_LAUNCH_CHECK("stc_head_bwd_bf16 launch");
     return STC_OK;
 }
 

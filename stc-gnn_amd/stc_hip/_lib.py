@@ -27,7 +27,7 @@ EXPORTS = (
     'stc_version', 'stc_last_error',
     'stc_csr_spmm_f32', 'stc_bcsr_spmm_f32', 'stc_csr_spmm_bf16', 'stc_bcsr_spmm_bf16', 'stc_bdg_node_bf16_supported', 'stc_bdg_node_fwd_bf16', 'stc_bdg_node_bwd_bf16',
     'stc_cell_planar_bf16_supported', 'stc_cell_gates_fwd_planar_bf16', 'stc_cell_gates_bwd_planar_bf16', 'stc_bdg_node_post_bwd_bf16',
-    'stc_spmm_blend_fwd_bf16', 'stc_spmm_sum_bf16', 'stc_gru_blend_bwd_bf16',
+    'stc_spmm_blend_fwd_bf16', 'stc_spmm_sum_bf16', 'stc_gru_blend_bwd_bf16', 'stc_head_fwd_bf16', 'stc_head_bwd_bf16',
     'stc_spmm_bwd_gates_f32', 'stc_spmm_bwd_split_f32', 'stc_csr_sddmm_f32',
     'stc_cheby_dense_fwd_f32', 'stc_cheby_dense_bwd_f32',
     'stc_bdg_node_fwd_f32', 'stc_bdg_node_bwd_workspace_bytes', 'stc_bdg_node_bwd_f32',
@@ -78,6 +78,8 @@ def _declare(lib):
         'stc_spmm_blend_fwd_bf16': [_p] * 6 + [_i32, _i32] + [_p] * 6 + [_i32] * 3 + [_p],
         'stc_spmm_sum_bf16': [_p] * 6 + [_i32, _i32, _p, _p, _i32, C.POINTER(_p), _p, _p, _p, _p, _i32, _i32, _i32, _p],
         'stc_gru_blend_bwd_bf16': [_p, _p, _p, _p, _i64, _p],
+        'stc_head_fwd_bf16': [_p, _p, _p, _p, _i64, _i32, _p],
+        'stc_head_bwd_bf16': [_p, _p, _p, _p, _p, _p, _p, C.c_size_t, _i64, _i32, _p],
         'stc_bdg_node_post_fwd_f32': [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
         'stc_cell_gates_fwd_planar_f32': [_p] * 14 + [_i64, _i32, _i32, _i32, _p],
         'stc_cell_gates_bwd_planar_f32': [_p] * 11 + [C.POINTER(_p), _p, _p, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _p],
@@ -853,6 +855,13 @@ class HipKernels:
     def head_fwd(self, H, w, b, y):
         h = H.shape[-1]
         rows = H.shape[:-1].numel()
+        if H.dtype == torch.bfloat16:                       # bf16 state rows (hidden 16); y stays fp32
+            self._bf16('head.H', H)
+            self._f32('head.w', w, (h,))
+            self._f32('head.b', b, (1,))
+            self._f32('head.y', y, tuple(H.shape[:-1]))
+            self._launch('stc_head_fwd_bf16', H, _ptr(H), _ptr(w), _ptr(b), _ptr(y), rows, h)
+            return
         self._f32('head.H', H)
         self._f32('head.w', w, (h,))
         self._f32('head.b', b, (1,))
@@ -862,6 +871,16 @@ class HipKernels:
     def head_bwd(self, H, w, y, dy, dH, dwb):
         h = H.shape[-1]
         rows = H.shape[:-1].numel()
+        if H.dtype == torch.bfloat16:
+            self._bf16('head.H', H)
+            self._bf16('head.dH', dH, tuple(H.shape))
+            self._f32('head.w', w, (h,))
+            self._f32('head.y', y, tuple(H.shape[:-1]))
+            self._f32('head.dy', dy, tuple(H.shape[:-1]))
+            self._f32('head.dwb', dwb, (h + 1,))
+            ws = self._get_workspace(H.device, self.lib.stc_head_bwd_workspace_bytes(h))
+            self._launch('stc_head_bwd_bf16', H, _ptr(H), _ptr(w), _ptr(y), _ptr(dy), _ptr(dH), _ptr(dwb), _ptr(ws), ws.numel(), rows, h)
+            return
         self._f32('head.H', H)
         self._f32('head.w', w, (h,))
         self._f32('head.y', y, tuple(H.shape[:-1]))

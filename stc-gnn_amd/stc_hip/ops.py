@@ -286,7 +286,7 @@ class _Head(Function):
     @staticmethod
     def forward(ctx, H, w, b):
         H, w, b = _c(H), _c(w), _c(b)
-        y = H.new_empty(H.shape[:-1])
+        y = H.new_empty(H.shape[:-1], dtype=torch.float32)          # bf16 state rows: the prediction stays fp32
         kernels().head_fwd(H, w, b, y)
         ctx.save_for_backward(H, w, y)
         return y

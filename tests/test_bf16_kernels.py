@@ -362,8 +362,8 @@ def test_model_bf16_storage_tracks_fp32(hip, C, layers, T, horizon, cin):
     m16 = M.STCGNN(**kw, storage_dtype=torch.bfloat16).cuda()
     m16.load_state_dict(m32.state_dict())
     if cin != 1:                                               # keep the prediction scalar per (node, category)
-        m32._head = lambda Hs: torch.sigmoid(Hs.sum(-1))
-        m16._head = lambda Hs: torch.sigmoid(Hs.sum(-1))
+        m32._head = lambda Hs: torch.sigmoid(Hs.float().sum(-1))
+        m16._head = lambda Hs: torch.sigmoid(Hs.float().sum(-1))
     Gc = torch.softmax(torch.randn(C, C), -1).cuda()
     X = (torch.rand(B, T, N, C, cin) < 0.3).float().cuda()           # bf16-exact inputs, as the incident indicators are
     Rw = torch.randn(B, horizon, N, C).cuda()
@@ -377,7 +377,7 @@ def test_model_bf16_storage_tracks_fp32(hip, C, layers, T, horizon, cin):
             pair = M._graphs(graph, Gc, K, K)
             stacked = m._run_cell_graph(pair, X.to(m.storage_dtype))
             assert stacked is not None and stacked.dtype == m.storage_dtype
-            y = m._head(stacked.float()).transpose(0, 1)
+            y = m._head(stacked).transpose(0, 1)              # bf16 states go through the bf16 head kernels
             (y * Rw).sum().backward()
             out[name] = (y.detach(), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
     finally:
@@ -404,3 +404,27 @@ def test_model_bf16_storage_refuses_what_it_cannot_run():
     graph = CsrGraph.queen_grid(5, 6, normalize=True)
     with pytest.raises(ValueError):
         m(X_seq=torch.zeros(1, 2, 30, 32).cuda(), As=graph, Ac=torch.eye(32).cuda())
+
+
+@pytest.mark.parametrize('shape', [(2, 3, 50, 5), (1, 6, 777, 4), (3, 7), (1, 300000)])
+def test_output_head_bf16(hip, shape):
+    """stc_head_fwd/bwd_bf16 (bf16 state rows of 16, fp32 y / dy / weight gradient) against the fp32 twin on the same values."""
+    h = 16
+    g = torch.Generator().manual_seed(sum(shape))
+    H = torch.randn(*shape, h, generator=g).bfloat16()
+    w, b = torch.randn(h, generator=g), torch.randn(1, generator=g)
+    y_w = torch.empty(shape)
+    EM.head_fwd(H.float(), w, b, y_w)
+    y = torch.full(shape, float('nan')).cuda()
+    hip.head_fwd(cu(H), cu(w), cu(b), y)
+    assert rel_err(y, y_w) < 1e-5
+    dy = torch.randn(*shape, generator=g)
+    dH_w, dwb_w = torch.empty(*shape, h), torch.empty(h + 1)
+    EM.head_bwd(H.float(), w, y_w, dy, dH_w, dwb_w)
+    dH, dwb = torch.full((*shape, h), float('nan'), dtype=torch.bfloat16).cuda(), torch.full((h + 1,), float('nan')).cuda()
+    hip.head_bwd(cu(H), cu(w), cu(y_w), cu(dy), dH, dwb)
+    assert_one_ulp(dH, dH_w.bfloat16(), max_mismatch=0.05)
+    assert rel_err(dwb, dwb_w) < 2e-5
+    dwb2 = torch.empty_like(dwb)
+    hip.head_bwd(cu(H), cu(w), cu(y_w), cu(dy), dH, dwb2)
+    assert torch.equal(dwb, dwb2)
