@@ -109,7 +109,9 @@ int stc_bdg_node_bwd_bf16(const void* const* Z, int32_t Ks, const float* Tc, int
  * 1..4; weights, biases and their gradients stay fp32.  Same mathematics and argument meaning as the _f32 entry points of
  * the same names (stc_cell_gates_fwd/bwd_planar_f32 with its fused candidate projection, stc_bdg_node_post_bwd_f32 with
  * X2, stc_spmm_blend_fwd_f32 without state copies, stc_spmm_sum_f32 with contiguous addends, stc_gru_blend_bwd_f32 in its
- * dCpre-only form); sums are fp32, each stored plane is rounded to bf16 once. */
+ * dCpre-only form); sums are fp32, each stored plane is rounded to bf16 once.  One extension: stc_cell_gates_bwd_planar_bf16
+ * accepts dH == NULL and then adds the previous state's share from the GRU prologue (dRH R + dHnew (1-U)) into dZ[2], the
+ * H plane's gradient, so that the state receives one gradient plane from the cell instead of two. */
 int stc_cell_planar_bf16_supported(int32_t Ks, int32_t Kc, int32_t C, int32_t h);
 int stc_cell_gates_fwd_planar_bf16(const void* X, const void* H, const void* SX, const void* SH,
                                    const float* Tc, const float* W, const float* bias,

@@ -35,6 +35,7 @@ class _Bf16Emulated:
     GPU tests bound)."""
 
     name = 'emulated-cpu-bf16'
+    folds_dH = True
 
     def __init__(self, em):
         self.em = em
@@ -245,11 +246,14 @@ class EmulatedKernels:
 
     def cell_gates_bwd_planar(self, X, H, SX, SH, Tc, W, dRH, Cand, U, Rg, dHnew, dZs, dW, db, dH):
         cin, h = X.shape[-1], H.shape[-1]
+        fold = dH is None                                                   # bf16 kernels: the prologue's share goes into dZs[2]
+        if fold:
+            dH = torch.empty_like(H)
         rows = [torch.empty(H.shape[:-1] + (cin + h,), dtype=W.dtype) for _ in range(2)]
         dCandIn = torch.cat([torch.zeros_like(X), dRH], -1)               # only the R*H part is read
         self.cell_gates_bwd([torch.cat([X, H], -1), torch.cat([SX, SH], -1)], Tc, W, dCandIn, None, H, U, Rg, dHnew, rows, dW, db, None, dH,
                             dH_in_scaled=True, Cand=Cand)
-        dZs[2].copy_(rows[0][..., cin:]); dZs[3].copy_(rows[1][..., cin:])  # d H plane, d SH plane
+        dZs[2].copy_(rows[0][..., cin:] + (dH if fold else 0)); dZs[3].copy_(rows[1][..., cin:])  # d H plane, d SH plane
         if dZs[0] is not None:
             dZs[0].copy_(rows[0][..., :cin]); dZs[1].copy_(rows[1][..., :cin])  # d X plane, d SX plane
 

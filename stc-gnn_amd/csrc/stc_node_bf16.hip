@@ -515,7 +515,7 @@ __global__ __launch_bounds__(MF_THREADS, WAVES) void node_bwd_bf16_kernel(
                     dh[i] = fmaf(dr[i], rr[i], gn[i] * (1.f - uu[i]));
                 }
                 dyr[rb] = pack8f(gy);
-                if (g < 2) *reinterpret_cast<u32x4*>(pro.dH + (r0 + 16 * rb + x) * 16 + 8 * g) = pack8f(dh);
+                if (pro.dH && g < 2) *reinterpret_cast<u32x4*>(pro.dH + (r0 + 16 * rb + x) * 16 + 8 * g) = pack8f(dh);
             }
         } else {
 #pragma unroll
@@ -565,6 +565,21 @@ __global__ __launch_bounds__(MF_THREADS, WAVES) void node_bwd_bf16_kernel(
                     const u32x4 w = WA[((n * LB + lb) * K + c) * 64 + lo];
 #pragma unroll
                     for (int rb = 0; rb < NRB; ++rb) z[rb] = mma(w, qb[c][rb], z[rb]);
+                }
+                if constexpr (PRO != 0) {
+                    // dH == null: the previous state's other share, dRH R + dHnew (1-U), is added to its H-plane gradient here, in
+                    // the tile's own layout (row x, columns 4g..4g+3: four 8-byte loads of lines the prologue just brought in), so
+                    // the state's gradient gets ONE plane from this cell instead of two
+                    if (n == 0 && lb == (PL == 1 ? 1 : 0) && !pro.dH) {
+#pragma unroll
+                        for (int rb = 0; rb < NRB; ++rb) {
+                            const size_t e = (r0 + 16 * rb + x) * 16 + 4 * g;
+                            const f32x4 dr = unpack4(*reinterpret_cast<const u32x2*>(pro.dRH + e)), rr = unpack4(*reinterpret_cast<const u32x2*>(pro.R + e));
+                            const f32x4 gn = unpack4(*reinterpret_cast<const u32x2*>(pro.dHnew + e)), uu = unpack4(*reinterpret_cast<const u32x2*>(pro.U + e));
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) z[rb][r] += fmaf(dr[r], rr[r], gn[r] * (1.f - uu[r]));
+                        }
+                    }
                 }
                 if constexpr (PL == 1) {                        // planar gradient slabs: block lb of the row goes to plane lb
 #pragma unroll
@@ -966,7 +981,8 @@ extern "C" int stc_cell_gates_fwd_planar_bf16(const void* X, const void* H, cons
 }
 
 // planar form: X / SX (nodes, C, cin), H / SH and everything else (nodes, C, 16); dZ = {dX, dSX, dH plane, dSH} (the first two
-// unused and may be null for a narrow input plane); dH: the previous state's share from the gates prologue
+// unused and may be null for a narrow input plane); dH: the previous state's share from the gates prologue, or null to have it
+// added into dZ[2] (one gradient plane for the previous state instead of two)
 extern "C" int stc_cell_gates_bwd_planar_bf16(const void* X, const void* H, const void* SX, const void* SH,
                                               const float* Tc, const float* W,
                                               const void* dCandIn, const void* Cand, const void* U, const void* Rg, const void* dHnew,
@@ -986,9 +1002,9 @@ extern "C" int stc_cell_gates_bwd_planar_bf16(const void* X, const void* H, cons
         return STC_OK;
     }
     const bool narrow = cin != 16;
-    STC_REQUIRE(X && H && SX && SH && dCandIn && Cand && U && Rg && dHnew && dZ && dH && dZ[2] && dZ[3] && (narrow || (dZ[0] && dZ[1])), STC_EINVAL,
+    STC_REQUIRE(X && H && SX && SH && dCandIn && Cand && U && Rg && dHnew && dZ && dZ[2] && dZ[3] && (narrow || (dZ[0] && dZ[1])), STC_EINVAL,
                 "stc_cell_gates_bwd_planar_bf16: null pointer");
-    for (const void* q : {H, SH, dCandIn, Cand, U, Rg, dHnew, (const void*)dH, (const void*)dZ[2], (const void*)dZ[3]})
+    for (const void* q : {H, SH, dCandIn, Cand, U, Rg, dHnew, (const void*)dH, (const void*)dZ[2], (const void*)dZ[3]})       // (null dH is aligned)
         STC_REQUIRE(stc::aligned16(q), STC_EALIGN, "stc_cell_gates_bwd_planar_bf16: planes must be 16-byte aligned");
     if (!narrow) STC_REQUIRE(stc::aligned16(X) && stc::aligned16(SX) && stc::aligned16(dZ[0]) && stc::aligned16(dZ[1]), STC_EALIGN,
                              "stc_cell_gates_bwd_planar_bf16: planes must be 16-byte aligned");

@@ -927,6 +927,8 @@ class HipKernels:
 
 
 class _Bf16Planar:
+    folds_dH = True          # cell_gates_bwd_planar(dH=None) adds the prologue's share of the previous state into the H plane's gradient
+
     """bf16-plane counterpart of the planar-cell methods of ``HipKernels`` (same names and argument meaning, so that the
     cell-graph executor runs unchanged): state / gate / gradient planes bfloat16 (R, C, 16), weights and their gradients fp32.
     Only what an all-planar schedule needs exists here; interleaved rows and state copies are fp32-path features."""
@@ -1061,8 +1063,8 @@ class _Bf16Planar:
         R, Cc, h, cin = self._planes(X, H, SX, SH)
         b._f32('planar.Tc', Tc, (2, Cc, Cc))
         b._f32('planar.W', W, (4 * (cin + h), 2 * h))
-        for name, t in (('dRH', dRH), ('Cand', Cand), ('U', U), ('Rg', Rg), ('dHnew', dHnew), ('dH', dH)):
-            self._pl('planar.' + name, t, (R, Cc, h))
+        for name, t in (('dRH', dRH), ('Cand', Cand), ('U', U), ('Rg', Rg), ('dHnew', dHnew)) + ((('dH', dH),) if dH is not None else ()):
+            self._pl('planar.' + name, t, (R, Cc, h))                 # dH None: folded into dZs[2] by the kernel
         if len(dZs) != 4:
             raise StcError('planar gates backward: four gradient planes (dX, dSX, dH, dSH)')
         for i, z in enumerate(dZs):

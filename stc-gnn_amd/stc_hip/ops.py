@@ -684,7 +684,7 @@ class _StcCellGraph(Function):
             Hprev, U, Rg, Cand, *rest = cells[j]
             post_form = n_saved[j] < 0 or (len(rest) == Ks + 1 and Ks > 1)     # candidate backward starts from dY = dHnew * U * (1 - Cand^2)
             dHnew, dY = owed(j, (U, Cand)) if post_form else (owed(j), None)
-            dH = torch.empty_like(Hprev)
+            dH = None if (n_saved[j] < 0 and getattr(k, 'folds_dH', False)) else torch.empty_like(Hprev)
             if n_saved[j] < 0:                                       # planar cell: inputs and gradients as planes
                 Xp, SXp, SHp, RH = rest
                 dBm = narrow_transpose_aggregation(dY)
@@ -701,12 +701,13 @@ class _StcCellGraph(Function):
                     k.node_post_bwd(*rows((RH,)), Tc, Wc, *rows((dY, dBm, dRH)), dWc, dbc, X2=Xp.view(B * N, C, cin[j]))
                     planes = [None, None] + rows((dHd, dSH))
                 del dY, dBm
+                fold = getattr(k, 'folds_dH', False)                 # the kernel adds the prologue's share into the H plane's gradient
                 k.cell_gates_bwd_planar(*rows((Xp, Hprev, SXp, SHp)), Tc, Wg, *rows((dRH, Cand, U, Rg, dHnew)), planes, dWg, dbg,
-                                        dH.view(B * N, C, h))
+                                        None if fold else dH.view(B * N, C, h))
                 if wide and x[0] == 'cell':
                     leave(x[1], (dXd, dXc), dSX)                     # as the X plane: gates' and candidate's direct shares
                 if hs[0] == 'cell':
-                    leave(hs[1], (dHd, dH), dSH)                     # as the H plane: direct share + what the gates prologue owes it
+                    leave(hs[1], (dHd,) if fold else (dHd, dH), dSH)  # as the H plane: direct share + what the gates prologue owes it
                 for i, t in enumerate((dWg, dbg, dWc, dbc)):
                     add_to(acc[s_id], i, t)
                 continue

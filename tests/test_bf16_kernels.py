@@ -287,6 +287,11 @@ def test_planar_cell_kernels_bf16(hip, nodes, C, cin):
     dW2 = nanf(*Wg.shape)
     kb.cell_gates_bwd_planar(cu(X), cu(H), cu(SX), cu(SH), cu(Tc), cu(Wg), cu(dRH), cu(Cand), cu(Ub), cu(Rb), cu(dHn), dZ, dW2, None, dH)
     assert torch.equal(dW2, dW)                                                                                # reproducible, db optional
+    # dH = None: the prologue's share of the previous state is added into the H plane's gradient (what the cell graph uses)
+    dZf = [nan(nodes, C, h) if (wide or i >= 2) else None for i in range(4)]
+    kb.cell_gates_bwd_planar(cu(X), cu(H), cu(SX), cu(SH), cu(Tc), cu(Wg), cu(dRH), cu(Cand), cu(Ub), cu(Rb), cu(dHn), dZf, dW2, None, None)
+    _close(dZf[2], dZ_w[2] + dH_w)
+    assert torch.equal(dZf[3], dZ[3]) and (not wide or (torch.equal(dZf[0], dZ[0]) and torch.equal(dZf[1], dZ[1])))
 
     # ---- post-aggregation backward of the candidate convolution
     dA, dB = rb(nodes, C, h), rb(nodes, C, h)
