@@ -162,6 +162,14 @@ def main():
         # launches of a step exactly like roofline.achieved.  Only valid for the configuration it was collected on.
         traffic, traffic_note = None, None
         tpath = os.path.join(REPO, 'profiles', 'r01', 'j_hbm_traffic_bench_b5.json')
+        if a.storage == 'bf16' and (a.grid, C, a.hidden, B, a.order, a.layers, a.obs, a.pred, a.permute) == (224, 64, 16, 5, 2, 2, 18, 6, False):
+            tb = os.path.join(REPO, 'profiles', 'r01', 'k_hbm_traffic_bench_bf16_c64.json')       # the same passes over --storage bf16 --categories 64
+            if os.path.exists(tb):
+                with open(tb) as fh:
+                    ks = [v for name, v in json.load(fh)['kernels'].items() if name.startswith('spmm_')]
+                if ks:
+                    traffic = sum(v['hbm_bytes_per_launch'] * v['launches'] for v in ks) / sum(v['launches'] for v in ks)
+                    traffic_note = 'PMC (2 x FETCH_SIZE + WRITE_SIZE), mean over the SpMM launches of one step of this command: profiles/r01/k_hbm_traffic_bench_bf16_c64.json'
         if a.storage == 'f32' and (a.grid, C, a.hidden, B, a.order, a.layers, a.obs, a.pred, a.permute) == (224, 32, 16, 5, 2, 2, 18, 6, False) and os.path.exists(tpath):
             with open(tpath) as fh:
                 doc = json.load(fh)

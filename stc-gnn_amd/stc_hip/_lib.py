@@ -927,13 +927,12 @@ class HipKernels:
 
 
 class _Bf16Planar:
-    folds_dH = True          # cell_gates_bwd_planar(dH=None) adds the prologue's share of the previous state into the H plane's gradient
-
     """bf16-plane counterpart of the planar-cell methods of ``HipKernels`` (same names and argument meaning, so that the
     cell-graph executor runs unchanged): state / gate / gradient planes bfloat16 (R, C, 16), weights and their gradients fp32.
     Only what an all-planar schedule needs exists here; interleaved rows and state copies are fp32-path features."""
 
     name = 'hip-gfx950-bf16'
+    folds_dH = True          # cell_gates_bwd_planar(dH=None) adds the prologue's share of the previous state into the H plane's gradient
 
     def __init__(self, base: HipKernels):
         self.b = base
