@@ -433,3 +433,40 @@ def test_output_head_bf16(hip, shape):
     dwb2 = torch.empty_like(dwb)
     hip.head_bwd(cu(H), cu(w), cu(y_w), cu(dy), dH, dwb2)
     assert torch.equal(dwb, dwb2)
+
+
+def test_adam_trajectory_with_bf16_storage_tracks_fp32(hip):
+    """Eight Adam steps (the reference trainer's lr / weight decay, ComboLoss) with bf16 state storage against the fp32 model
+    from the same initial parameters and data: the loss trajectories stay together (bf16 rounding of states and gradients is
+    noise to Adam, fp32 master weights take the updates)."""
+    import STC_GNN as M
+    from stc_hip.loss import ComboLoss
+    Hh, Ww, C, h, K, B, T, horizon = 6, 7, 32, 16, 2, 4, 4, 2
+    torch.manual_seed(3)
+    graph = CsrGraph.queen_grid(Hh, Ww, normalize=True)
+    N = Hh * Ww
+    kw = dict(num_nodes=N, num_categories=C, Ks=K, Kc=K, input_dim=1, hidden_dim=h, num_layers=2, out_horizon=horizon, graph_mode='csr-fixed')
+    m32 = M.STCGNN(**kw).cuda()
+    m16 = M.STCGNN(**kw, storage_dtype=torch.bfloat16).cuda()
+    m16.load_state_dict(m32.state_dict())
+    Gc = torch.softmax(torch.randn(C, C), -1).cuda()
+    X = (torch.rand(B, T, N, C) < 0.1635).float().cuda()
+    Y = (torch.rand(B, horizon, N, C) < 0.1635).float().cuda()
+    crit = ComboLoss()
+    traj = {}
+    for name, m in (('f32', m32), ('bf16', m16)):
+        opt = torch.optim.Adam(m.parameters(), lr=2e-3, weight_decay=1e-4)
+        losses = []
+        for _ in range(8):
+            opt.zero_grad(set_to_none=True)
+            loss = crit(m(X_seq=X, As=graph, Ac=Gc), Y)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+        traj[name] = losses
+    assert traj['f32'][-1] < traj['f32'][0]                                     # it trains
+    worst = max(abs(a - b) for a, b in zip(traj['f32'], traj['bf16']))
+    assert worst < 5e-3, (worst, traj)
+    # the parameters after eight steps: same place up to the accumulated rounding noise
+    for (n, p), (_, q) in zip(m32.named_parameters(), m16.named_parameters()):
+        assert float((p - q).detach().abs().max()) < 5e-3 + 5e-2 * float(p.detach().abs().max()), n
