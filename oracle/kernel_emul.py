@@ -73,6 +73,8 @@ class EmulatedKernels:
 
     # ---- stc_csr_spmm_f32: 1-mode product + Chebyshev epilogue (STC_GNN.py:28, 37)
     def csr_spmm(self, rowptr, colidx, val, n_rows, n_cols, X, Y0, Y, alpha, beta, plan=None):
+        if X.dtype == torch.bfloat16:
+            return self.csr_spmm_bf16(rowptr, colidx, val, n_rows, n_cols, X, Y0, Y, alpha, beta)
         B, nc, F = X.shape
         assert nc == n_cols and Y.shape == (B, n_rows, F)
         rows = _expand_rows(rowptr)
@@ -144,6 +146,8 @@ class EmulatedKernels:
 
         Project-then-mix order: U_c = sum_n Z_n W_{n,c}, then Y = sum_c Tc[c]^T U_c.
         """
+        if Zs[0].dtype == torch.bfloat16:
+            return self.bdg_node_fwd_bf16(Zs, Tc, W, bias, Y)
         Ks, Kc = len(Zs), Tc.shape[0]
         R, C, L = Zs[0].shape
         Ho = W.shape[1]
@@ -200,6 +204,9 @@ class EmulatedKernels:
 
     # ---- stc_bdg_node_bwd_f32: autograd of the above
     def bdg_node_bwd(self, Zs, Tc, W, dY, dZs, dW, db, dTc):
+        if Zs[0].dtype == torch.bfloat16:
+            assert dTc is None
+            return self.bdg_node_bwd_bf16(Zs, Tc, W, dY, dZs, dW, db)
         Ks, Kc = len(Zs), Tc.shape[0]
         R, C, L = Zs[0].shape
         Ho = W.shape[1]

@@ -257,6 +257,8 @@ class HipKernels:
         """``plan`` = (blk_ptr, blk_cols, blk_vals) of ``graph._row_block_plan`` (fixed graphs): use the
         row-blocked kernel when the operands allow it (F % 4 == 0, 16-byte aligned); otherwise, or without a
         plan (learned dense graph: values change every step), the CSR kernel."""
+        if X.dtype == torch.bfloat16:                       # bf16 rows: the bf16-storage kernels (fp32 values and sums)
+            return self.csr_spmm_bf16(rowptr, colidx, val, n_rows, n_cols, X, Y0, Y, alpha, beta, plan=plan)
         B, nc, F = X.shape
         self._f32('spmm.X', X, (B, n_cols, F))
         self._f32('spmm.Y', Y, (B, n_rows, F))
@@ -430,6 +432,8 @@ class HipKernels:
         return Ks, Kc, R, Cc, L, Lw, Ho
 
     def bdg_node_fwd(self, Zs: Sequence[torch.Tensor], Tc, W, bias, Y):
+        if Zs[0].dtype == torch.bfloat16:
+            return self.bdg_node_fwd_bf16(Zs, Tc, W, bias, Y)
         Ks, Kc, R, Cc, L, Lw, Ho = self._node_shapes(Zs, Tc, W)
         if bias is not None:
             self._f32('node.bias', bias, (Ho,))
@@ -446,6 +450,10 @@ class HipKernels:
         return ws
 
     def bdg_node_bwd(self, Zs, Tc, W, dY, dZs, dW, db, dTc):
+        if Zs[0].dtype == torch.bfloat16:
+            if dTc is not None:
+                raise StcError('bdg_node_bwd: bf16 slabs are for fixed category graphs (no dTc)')
+            return self.bdg_node_bwd_bf16(Zs, Tc, W, dY, dZs, dW, db)
         Ks, Kc, R, Cc, L, Lw, Ho = self._node_shapes(Zs, Tc, W)
         self._f32('node.dY', dY, (R, Cc, Ho))
         if len(dZs) != Ks:

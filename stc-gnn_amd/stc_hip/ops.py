@@ -140,7 +140,10 @@ def _bdg_backward_slabs(dY, Zs, W, Tc, op: SpatialOperand, Ks: int, has_bias: bo
     for order in range(Ks - 1, 1, -1):
         k.csr_spmm(op.bwd_rowptr, op.bwd_colidx, op.bwd_val, N, N, v3(dZ[order]), v3(dZ[order - 1]),
                    v3(dZ[order - 1]), 2.0, 1.0, plan=op.bwd_plan)
-        k.axpy(-1.0, dZ[order], dZ[order - 2])
+        if dZ[order].dtype == torch.bfloat16:
+            dZ[order - 2].sub_(dZ[order])                        # bf16 slabs, Ks >= 3 only: a torch stream op (no bf16 axpy entry point)
+        else:
+            k.axpy(-1.0, dZ[order], dZ[order - 2])
         if need_val:
             k.csr_sddmm(op.fwd_rowptr, op.fwd_colidx, N, N, v3(dZ[order]), v3(Zs[order - 1]), dval, 2.0, True)
     if Ks > 1 and need_val:
@@ -196,6 +199,12 @@ def bdg_dif(X: torch.Tensor, op: SpatialOperand, Tc: torch.Tensor, W: torch.Tens
         raise ValueError(f'X has {C} categories, the category graph {Tc.shape[1]}')
     if W.shape[0] != Ks * Kc * (L - pad):
         raise ValueError(f'W has {W.shape[0]} rows, expected Ks*Kc*L = {Ks * Kc * (L - pad)}')
+    if X.dtype == torch.bfloat16:
+        # bf16 feature rows (BASELINE configuration 5): fixed graphs only, shapes of the bf16 matrix-core kernels, no fallback
+        if Tc.requires_grad or op.fwd_val.requires_grad:
+            raise ValueError('BDG_Dif on bfloat16 features needs fixed graphs (no gradient for Gs / Gc)')
+        if not kernels().node_bf16_supported(Ks, Kc, C, L, W.shape[1]):
+            raise ValueError(f'BDG_Dif on bfloat16 features: Ks=Kc<=3, C in (32, 64), L in (16, 32), Ho in (16, 32); got Ks={Ks} Kc={Kc} C={C} L={L} Ho={W.shape[1]}')
     return _BdgDif.apply(X, W, b, Tc, op.fwd_val, op, Ks)
 
 

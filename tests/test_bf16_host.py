@@ -91,3 +91,28 @@ def test_bf16_storage_constructor_checks():
         M.STCGNN(30, 32, 2, 2, 1, 16, 2, 2, graph_mode='csr-fixed', storage_dtype=torch.float16)
     m = M.STCGNN(30, 32, 2, 2, 1, 16, 2, 2, graph_mode='csr-fixed', storage_dtype=torch.bfloat16)
     assert all(p.dtype == torch.float32 for p in m.parameters())                                # master weights stay fp32
+
+
+@pytest.mark.parametrize('K', [1, 2, 3])
+def test_bdg_dif_module_on_bf16_features_emulated(monkeypatch, K):
+    """BDG_Dif fed bfloat16 features through the host path (SpMM hops, feature-side recurrence and its backward, node kernels) on
+    the emulated kernel set, against the same module in fp32."""
+    monkeypatch.setattr(ops, '_kernels', EM)
+    torch.manual_seed(K)
+    C, L, Ho, N = 32, 32, 16, 20
+    graph = CsrGraph.queen_grid(4, 5, normalize=True)
+    conv = M.BDG_Dif(K, K, L, Ho)
+    Gc = torch.softmax(torch.randn(C, C), -1)
+    X = torch.randn(2, N, C, L).bfloat16()
+    Rw = torch.randn(2, N, C, Ho)
+    out = {}
+    for name, x in (('f32', X.float().requires_grad_()), ('bf16', X.clone().requires_grad_())):
+        conv.zero_grad(set_to_none=True)
+        y = conv(x, graph, Gc)
+        assert y.dtype == x.dtype
+        (y.float() * Rw).sum().backward()
+        out[name] = (y.detach().float(), x.grad.float(), conv.W.grad.clone(), conv.b.grad.clone())
+    for a, b in zip(out['bf16'], out['f32']):
+        assert rel_err(a, b) < 3e-2
+    with pytest.raises(ValueError):
+        conv(torch.zeros(1, N, 16, L, dtype=torch.bfloat16), graph, torch.eye(16))          # C = 16 is off the bf16 kernels

@@ -470,3 +470,32 @@ def test_adam_trajectory_with_bf16_storage_tracks_fp32(hip):
     # the parameters after eight steps: same place up to the accumulated rounding noise
     for (n, p), (_, q) in zip(m32.named_parameters(), m16.named_parameters()):
         assert float((p - q).detach().abs().max()) < 5e-3 + 5e-2 * float(p.detach().abs().max()), n
+
+
+@pytest.mark.parametrize('K,C,L,Ho', [(2, 64, 32, 32), (3, 32, 32, 16), (1, 32, 16, 32), (3, 64, 16, 16)])
+def test_bdg_dif_module_on_bf16_features(hip, K, C, L, Ho):
+    """The drop-in ``BDG_Dif`` module fed bfloat16 features (fixed CSR graph): forward and every gradient against the same module on
+    the same values in fp32 -- SpMM hops, the feature-side Chebyshev recurrence and the node kernels all run in their bf16 forms."""
+    import STC_GNN as M
+    torch.manual_seed(K * 100 + C + L)
+    Hh, Ww, B = 7, 9, 2
+    graph = CsrGraph.queen_grid(Hh, Ww, normalize=True)
+    N = Hh * Ww
+    conv = M.BDG_Dif(K, K, L, Ho).cuda()
+    with torch.no_grad():
+        conv.b.copy_(torch.randn(Ho))
+    Gc = torch.softmax(torch.randn(C, C), -1).cuda()
+    X = torch.randn(B, N, C, L).bfloat16().cuda()
+    Rw = torch.randn(B, N, C, Ho).cuda()
+    res = {}
+    for name, x in (('f32', X.float().requires_grad_()), ('bf16', X.clone().requires_grad_())):
+        conv.zero_grad(set_to_none=True)
+        y = conv(x, graph, Gc)
+        assert y.dtype == x.dtype
+        (y.float() * Rw).sum().backward()
+        res[name] = (y.detach().float(), x.grad.float(), conv.W.grad.clone(), conv.b.grad.clone())
+    for a, b, what in zip(res['bf16'], res['f32'], ('Y', 'dX', 'dW', 'db')):
+        assert rel_err(a, b) < 3e-2, (what, rel_err(a, b))
+    import pytest as _pt
+    with _pt.raises(ValueError):                       # shapes off the bf16 kernels are refused, not silently widened
+        M.BDG_Dif(K, K, 24, Ho).cuda()(torch.zeros(1, N, C, 24, dtype=torch.bfloat16).cuda(), graph, Gc)
