@@ -499,3 +499,49 @@ def test_bdg_dif_module_on_bf16_features(hip, K, C, L, Ho):
     import pytest as _pt
     with _pt.raises(ValueError):                       # shapes off the bf16 kernels are refused, not silently widened
         M.BDG_Dif(K, K, 24, Ho).cuda()(torch.zeros(1, N, C, 24, dtype=torch.bfloat16).cuda(), graph, Gc)
+
+
+def test_bf16_entry_points_edge_cases(hip):
+    """Zero sizes launch nothing (and zero the weight gradients), bad arguments come back as StcError with the C side's text."""
+    import ctypes as C_
+    from stc_hip._lib import StcError
+    kb, bf, h = hip.bf16, torch.bfloat16, 16
+    Cc = 32
+    z = lambda *s_: torch.zeros(*s_, dtype=bf).cuda()
+    Tc = torch.eye(Cc).repeat(2, 1, 1).cuda()
+    Wg, Wc = torch.zeros(4 * 32, 32).cuda(), torch.zeros(4 * 32, 16).cuda()
+    # nodes = 0: nothing to do, dW / db zeroed by the backward entry points
+    e = z(0, Cc, h)
+    kb.cell_gates_fwd_planar(e, e, e, e, Tc, Wg, None, z(0, Cc, h), z(0, Cc, h), z(0, Cc, h))
+    dW, db = torch.full((4 * 32, 32), float('nan')).cuda(), torch.full((32,), float('nan')).cuda()
+    kb.cell_gates_bwd_planar(e, e, e, e, Tc, Wg, e, e, e, e, e, [z(0, Cc, h) for _ in range(4)], dW, db, None)
+    assert float(dW.abs().max()) == 0.0 and float(db.abs().max()) == 0.0
+    dWc = torch.full((4 * 32, 16), float('nan')).cuda()
+    kb.node_post_bwd(e, Tc, Wc, e, e, z(0, Cc, h), dWc, None, X2=z(0, Cc, h), dX2=z(0, Cc, h))
+    assert float(dWc.abs().max()) == 0.0
+    hip.bdg_node_fwd_bf16([z(0, Cc, 32)], Tc[:1], torch.zeros(32, 16).cuda(), None, z(0, Cc, 16))
+    # host-side shape / dtype checks
+    X = z(5, Cc, h)
+    with pytest.raises(StcError):                                  # fp32 plane handed to the bf16 front
+        kb.cell_gates_fwd_planar(X.float(), X, X, X, Tc, Wg, None, z(5, Cc, h), z(5, Cc, h), z(5, Cc, h))
+    with pytest.raises(StcError):                                  # input plane of 7 columns
+        kb.cell_gates_fwd_planar(z(5, Cc, 7), X, z(5, Cc, 7), X, Tc, torch.zeros(4 * 23, 32).cuda(), None, z(5, Cc, h), z(5, Cc, h), z(5, Cc, h))
+    with pytest.raises(StcError):                                  # state copies are an fp32-path feature
+        kb.spmm_blend_fwd(None, None, None, None, X, X, X, X, X, X, copies=[(X, 0)])
+    # C side: unsupported category count, misaligned plane, null pointer
+    lib = hip.lib
+    s0 = torch.cuda.current_stream().cuda_stream
+    rc = lib.stc_cell_gates_fwd_planar_bf16(X.data_ptr(), X.data_ptr(), X.data_ptr(), X.data_ptr(), Tc.data_ptr(), Wg.data_ptr(), None,
+                                            X.data_ptr(), X.data_ptr(), X.data_ptr(), None, None, None, None, 5, 48, 32, 16, s0)
+    assert rc == -4 and b'C=48' in lib.stc_last_error()            # STC_EUNSUPPORTED
+    big = z(6, Cc, h)
+    off = big.view(-1)[4:4 + 5 * Cc * h]                           # 8-byte offset: not 16-byte aligned
+    rc = lib.stc_cell_gates_fwd_planar_bf16(X.data_ptr(), off.data_ptr(), X.data_ptr(), X.data_ptr(), Tc.data_ptr(), Wg.data_ptr(), None,
+                                            X.data_ptr(), X.data_ptr(), X.data_ptr(), None, None, None, None, 5, Cc, 32, 16, s0)
+    assert rc == -2                                                # STC_EALIGN
+    rc = lib.stc_spmm_sum_bf16(None, None, None, None, None, None, 4, 4, None, None, 0, None, X.data_ptr(), None, None, None, 1, Cc, 16, s0)
+    assert rc == -1                                                # STC_EINVAL: no graph, no operand
+    rc = lib.stc_head_fwd_bf16(X.data_ptr(), Tc.data_ptr(), Tc.data_ptr(), Tc.data_ptr(), 5, 8, s0)
+    assert rc == -4                                                # hidden width 8: not built
+    assert lib.stc_gru_blend_bwd_bf16(X.data_ptr(), X.data_ptr(), X.data_ptr(), X.data_ptr(), 12, s0) == -1       # n not a multiple of 8
+    torch.cuda.synchronize()
