@@ -137,6 +137,20 @@ def _bdg_backward_slabs(dY, Zs, W, Tc, op: SpatialOperand, Ks: int, has_bias: bo
         k.bdg_node_bwd(rows(Zs), Tc, W, dY.view(B * N, C, Ho), rows(dZ), dW, db, dTc)
     dval = torch.zeros_like(op.fwd_val) if need_val else None
     v3 = lambda t: t.view(B, N, F)
+    dense = op.nnz == N * N                                        # learned dense Gs: the "pattern" is the whole matrix
+
+    def values_grad(A, Bm, alpha):
+        """dval[i, j] += alpha * sum_b <A[b, i, :], Bm[b, j, :]> (gradient of the 1-mode product w.r.t. the graph values)."""
+        if dense:
+            # on the full pattern this is ONE dense GEMM, (N, B*F) x (B*F, N): a plain library GEMM (rocBLAS through torch),
+            # not a sampled product -- one wave per stored entry (stc_csr_sddmm_f32) took 524 us per call at the SF shape,
+            # 62 % of the learned-graph train step
+            a2 = A.transpose(0, 1).reshape(N, B * F)
+            b2 = Bm.transpose(0, 1).reshape(N, B * F)
+            dval.view(N, N).addmm_(a2, b2.t(), alpha=alpha)
+        else:
+            k.csr_sddmm(op.fwd_rowptr, op.fwd_colidx, N, N, A, Bm, dval, alpha, True)
+
     for order in range(Ks - 1, 1, -1):
         k.csr_spmm(op.bwd_rowptr, op.bwd_colidx, op.bwd_val, N, N, v3(dZ[order]), v3(dZ[order - 1]),
                    v3(dZ[order - 1]), 2.0, 1.0, plan=op.bwd_plan)
@@ -145,9 +159,9 @@ def _bdg_backward_slabs(dY, Zs, W, Tc, op: SpatialOperand, Ks: int, has_bias: bo
         else:
             k.axpy(-1.0, dZ[order], dZ[order - 2])
         if need_val:
-            k.csr_sddmm(op.fwd_rowptr, op.fwd_colidx, N, N, v3(dZ[order]), v3(Zs[order - 1]), dval, 2.0, True)
+            values_grad(v3(dZ[order]), v3(Zs[order - 1]), 2.0)
     if Ks > 1 and need_val:
-        k.csr_sddmm(op.fwd_rowptr, op.fwd_colidx, N, N, v3(dZ[1]), v3(Zs[0]), dval, 1.0, True)
+        values_grad(v3(dZ[1]), v3(Zs[0]), 1.0)
     return dZ[:2], dW, db, dTc, dval
 
 
