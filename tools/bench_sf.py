@@ -19,6 +19,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--mode', default='csr-fixed')
 ap.add_argument('--steps', type=int, default=10)
 ap.add_argument('--graph', action='store_true', help='capture the whole train step in a HIP graph and replay it')
+ap.add_argument('--fused-adam', action='store_true', help='torch.optim.Adam(fused=True): one multi-tensor kernel per step instead of ~10 passes')
 a = ap.parse_args()
 dev = torch.device('cuda')
 torch.manual_seed(0)
@@ -32,7 +33,7 @@ else:
     As = CsrGraph.queen_grid(10, 10, normalize=False).to_dense().to(dev)
 Ac = torch.rand(C, C, device=dev)
 crit = ComboLoss()
-opt = torch.optim.Adam(model.parameters(), lr=2e-3, weight_decay=1e-4, capturable=a.graph)
+opt = torch.optim.Adam(model.parameters(), lr=2e-3, weight_decay=1e-4, capturable=a.graph, **({'fused': True} if a.fused_adam else {}))
 
 
 def step():
@@ -64,5 +65,5 @@ for _ in range(a.steps):
     loss = step()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.steps
-print(f'SF shape {a.mode}{" hipGraph" if a.graph else ""}: {1e3 * dt:.2f} ms/step, {B / dt:.1f} samples/s, loss {float(loss.detach()):.4f}, '
+print(f'SF shape {a.mode}{" hipGraph" if a.graph else ""}{" fused-adam" if a.fused_adam else ""}: {1e3 * dt:.2f} ms/step, {B / dt:.1f} samples/s, loss {float(loss.detach()):.4f}, '
       f'{sum(p.numel() for p in model.parameters())} parameters', flush=True)
