@@ -13,7 +13,7 @@ import torch
 from oracle.kernel_emul import EmulatedKernels
 from stc_hip import data as sdata, ops
 from stc_hip.trainer import Trainer
-from tests.conftest import load_golden, sub_dict
+from tests.conftest import REPO, load_golden, sub_dict
 from tests.golden.make_golden import pipeline_inputs
 
 SF = '/root/reference/data/SF-incidents-4h.npz'
@@ -178,3 +178,37 @@ def test_metrics_match_the_reference(where):
     for s, got in enumerate(steps):
         assert list(got.keys()) == list(g[f'names{s}'])
         assert np.allclose(list(got.values()), g[f'values{s}'].numpy(), rtol=0, atol=1.01e-4), (got, g[f'values{s}'])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('storage', ['f32', 'bf16'])
+def test_bench_line_contract(storage):
+    """bench.py prints ONE JSON line with the driver's contract fields, the roofline object of the aggregation launches and
+    (fp32, one GPU) the CPU baseline; run here on a small grid so that it takes seconds."""
+    import json
+    import subprocess
+    import sys
+    cmd = [sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1', '--grid', '12',
+           '--batch-per-gpu', '2', '--obs', '3', '--pred', '2', '--storage', storage]
+    if storage == 'bf16':
+        cmd.append('--no-cpu-baseline')
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.strip().split('\n') if l.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
+                'data', 'config', 'roofline'):
+        assert key in d, key
+    assert d['n_gpus'] == 1 and d['steps'] == 2 and d['warmup'] == 1 and d['unit'] == 'samples/s' and d['higher_is_better'] is True
+    assert d['scaling'] == 'weak' and d['vs_baseline'] is None and d['data'] == 'synthetic' and d['dtype'] == storage
+    assert d['value'] > 0 and abs(d['value'] - 2 * 1e3 / d['ms_per_step']) < 1e-6 * d['value']
+    assert 'workload' in d['config'] and 'model' not in d['config']
+    r = d['roofline']
+    assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0 and r['launches'] > 0
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12 and r['algorithmic_bytes_per_launch'] > 0
+    names = set(d['kernels'])
+    assert any(n.endswith('_bf16') for n in names) == (storage == 'bf16')
+    if storage == 'f32':
+        c = d['cpu_baseline']
+        assert c['kind'] == 'port' and c['cores'] >= 1 and c['value'] > 0 and c['unit'] == 'samples/s' and 'sample' in c
