@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """Benchmark of the STC-GNN hot path on MI355X: BASELINE.json's metric on BASELINE.json's config.
 
-    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 either comes in already launched by ``torch.distributed.run`` (one rank per GPU, RANK / WORLD_SIZE in
+the environment) or -- plain ``python bench.py --gpus N`` -- launches itself that way: before anything
+touches the GPU this process starts ``python -m torch.distributed.run --nproc-per-node N bench.py ...`` as a
+CHILD, relays its output (rank 0's single JSON line) and exits with its code.  It never exec()s.
 
 One "step" = one train step of the full encoder-decoder STC-GNN in ``csr-fixed`` mode on synthetic
 tensors already resident in HBM: forward, ComboLoss, backward, the RCCL all-reduce of the gradient
@@ -11,36 +16,34 @@ T = 18 observed + 6 predicted steps, Bernoulli(0.1635) inputs, batch per GPU fix
 the batch x time-window dimension is sharded, the graph replicated, no data-path collective).
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline      the CSR-SpMM aggregation (the kernel the metric names): algorithmic bytes per launch
-                (nnz*(4+4) + 4*(N+1) + 2*B*N*F*4; + B*N*F*4 for the launches whose epilogue
-                also reads Y0, i.e. Y = Y0 + S.X of the backward) / mean launch duration, measured with
-                HIP events on the launching stream around every SpMM launch of the timed steps
-  kernels       time share of every C-ABI entry point over the same steps (same events)
-  cpu_baseline  the CPU oracle (oracle/stc_oracle.py, sparse feature-side variant because the
-                reference's dense N x N formulation needs 20 GB at this N) on a bounded sample
+  roofline      the PLAIN aggregation launch Y = S.X of the train step (entry point stc_bcsr_spmm_f32, device kernel
+                spmm_bcsr_kernel): SURVEY 8(d3)'s algorithmic bytes nnz*(4+4) + 4*(N+1) + 2*B*N*F*4 per launch / its mean
+                duration from HIP events recorded on the launching stream around every such launch of the TIMED steps.
+                ``aggregate`` beside it = every aggregation launch of the step (plain, GRU blend in the epilogue,
+                state-gradient sums) with every operand counted once; ``unit_d3`` = the exact 8(d3) unit (B = 1,
+                F = C*L = 1024) timed cold, >= 50 launches, in this same process after the timed steps
+  kernels       time share of every C-ABI entry point over the timed steps (same events)
+  step_breakdown  forward+backward / all-reduce / Adam milliseconds per step (HIP events), and what the per-launch
+                event records cost (the same step re-timed with the timer off)
+  cpu_baseline  the CPU oracle (oracle/stc_oracle.py) on a bounded sample: 1 warm-up + 3 timed shots, median
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
-for _p in (REPO, os.path.join(REPO, 'stc-gnn_amd')):
-    if _p not in sys.path:
-        sys.path.insert(0, _p)
-
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling ~6300
-# every C-ABI entry point that is an aggregation Y = S.X (+ epilogue): the kernels the metric's roofline is about
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling ~5.4-6.3 TB/s
+PLAIN_SPMM = ('stc_bcsr_spmm_f32', 'stc_bcsr_spmm_bf16')
+# every C-ABI entry point that is an aggregation Y = S.X (+ epilogue)
 SPMM_ENTRY_POINTS = ('stc_bcsr_spmm_f32', 'stc_csr_spmm_f32', 'stc_spmm_sum_f32', 'stc_spmm_blend_fwd_f32',
                      'stc_bcsr_spmm_bf16', 'stc_csr_spmm_bf16', 'stc_spmm_sum_bf16', 'stc_spmm_blend_fwd_bf16')
 METRIC = 'STC-GNN fwd+bwd samples/sec at N=50k,C=32; SpMM HBM GB/s vs peak, 1/8 GPU'
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
@@ -56,42 +59,174 @@ def parse():
     ap.add_argument('--permute', action='store_true', help='random node order (seed 1234) instead of row-major')
     ap.add_argument('--no-reorder', action='store_true', help='keep the given node order (skip the internal RCM renumbering)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-unit-d3', action='store_true', help='skip the cold SURVEY 8(d3) SpMM unit measurement')
     ap.add_argument('--storage', choices=('f32', 'bf16'), default='f32',
                     help='storage type of states / gates / their gradients: f32 = the metric (reference arithmetic); bf16 = BASELINE configuration 5 '
                          '(not the metric: bf16 has no reference behaviour), fp32 parameters and fp32 sums inside every kernel')
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
-def cpu_baseline(a, graph_dense_sparseT, Gc, sd_cpu):
-    """Oracle fwd+bwd on the host cores for a bounded sample of the same workload.
+def self_launch(a) -> int:
+    """``python bench.py --gpus N`` outside torchrun: start the N ranks as a CHILD process tree and wait for it.
 
-    Sample: the same graph/width, batch 1, but 1 observed + 1 predicted step (4 of the 2*(obs+pred)
-    cell evaluations of a full sample); samples/s is scaled by the cell count.  kind = "port": the
-    oracle's sparse restatement (the reference itself cannot run N = 50 176: dense Gs + eye = 20 GB
-    and an N^3 cheby_poly), validated against the dense reference at N = 1 024 / 10 000 in tests/.
+    Runs before this process has imported torch or touched the GPU; the child is ``python -m torch.distributed.run``
+    with the driver's own argument form (one node, 127.0.0.1 rendezvous).  Output is inherited, so rank 0's JSON line is
+    this command's JSON line; the exit code is the child's."""
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')        # dmabuf IPC: what RCCL needs on this host driver
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // max(1, a.gpus))))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={a.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def _median(xs):
+    xs = sorted(xs)
+    return xs[len(xs) // 2] if len(xs) % 2 else 0.5 * (xs[len(xs) // 2 - 1] + xs[len(xs) // 2])
+
+
+def cpu_baseline(a, GsT_sparse, Gc, sd_cpu):
+    """Oracle fwd+bwd on the host cores for a bounded sample of the same workload: 1 warm-up + 3 timed, median.
+
+    Sample: one STC_Cell of each kind the model has (layer 0: 1 + 16 input columns; the others: 16 + 16), batch 1, same
+    graph / width / parameters, forward + backward through ``oracle.stc_cell``; a full sample is ``layers * (obs + pred)``
+    such cells, so samples/s = 1 / (n0 t0 + n1 t1).  kind = "port": the oracle's sparse feature-side restatement (the
+    reference itself cannot run N = 50 176: dense Gs + eye = 20 GB and an N^3 cheby_poly), validated against the dense
+    reference at N = 1 024 / 10 000 in tests/.  ``dense_anchor`` ties the port to the true reference: the oracle's DENSE
+    ``bdg_dif`` (the reference's algorithm op for op) at BASELINE.md section 2's N = 10 000 shape (0.90 s there, 8 cores).
     """
+    import torch
     from oracle import stc_oracle as O
     threads = min(os.cpu_count() or 1, 32)      # more threads than this only slow the torch CPU ops down on a 2-socket host
     torch.set_num_threads(threads)
-    N, C = a.grid * a.grid, a.categories
+    N, C, h, K = a.grid * a.grid, a.categories, a.hidden, a.order
     g = torch.Generator().manual_seed(0)
-    X = (torch.rand(1, 1, N, C, generator=g) < 0.1635).float()
-    Y = (torch.rand(1, 1, N, C, generator=g) < 0.1635).float()
-    sd = {k: v.clone().requires_grad_() for k, v in sd_cpu.items()}
-    t0 = time.perf_counter()
-    yhat = O.encdec_forward(X, graph_dense_sparseT, Gc, sd, a.order, a.order, a.hidden, a.layers, 1,
-                            conv=O.bdg_dif_sparse)
-    O.combo_loss(yhat, Y).backward()
-    dt = time.perf_counter() - t0
-    cells_sample = a.layers * 2
-    cells_full = a.layers * (a.obs + a.pred)
-    return dict(value=1.0 / (dt * cells_full / cells_sample), unit='samples/s', cores=threads, kind='port',
-                sample=f'oracle (torch CPU, sparse feature-side variant) fwd+bwd, batch 1, same graph/width, '
-                       f'1 obs + 1 pred step = {cells_sample} of {cells_full} cell evaluations, {dt:.1f} s; scaled by cell count')
+
+    def one_cell(prefix, cin):
+        Xt = (torch.rand(1, N, C, cin, generator=g) < 0.1635).float() if cin == 1 else torch.rand(1, N, C, cin, generator=g) - 0.5
+        Xt.requires_grad_(cin != 1)
+        H = (torch.rand(1, N, C, h, generator=g) - 0.5).requires_grad_()
+        R = torch.rand(1, N, C, h, generator=g)
+        p = [sd_cpu[f'{prefix}.{n}'].clone().requires_grad_() for n in ('gates.W', 'gates.b', 'candi.W', 'candi.b')]
+        ts = []
+        for shot in range(4):
+            t0 = time.perf_counter()
+            out = O.stc_cell(GsT_sparse, Gc, Xt, H, *p, K, K, conv=O.bdg_dif_sparse)
+            (out * R).sum().backward()
+            ts.append(time.perf_counter() - t0)
+        return _median(ts[1:]), ts
+
+    t0, shots0 = one_cell('encoder.cell_list.0', 1)
+    t1, shots1 = one_cell('encoder.cell_list.1' if a.layers > 1 else 'decoder.cell_list.0', h)
+    n0 = a.obs                                                  # encoder layer 0 is the only cell with a 1-column input
+    n1 = a.layers * (a.obs + a.pred) - n0
+    per_sample = n0 * t0 + n1 * t1
+    out = dict(value=1.0 / per_sample, unit='samples/s', cores=threads, kind='port',
+               sample=f'oracle.stc_cell (torch CPU, sparse feature-side variant) fwd+bwd, batch 1, same graph/width/parameters: one layer-0 cell '
+                      f'(median {t0:.2f} s) and one 16+16 cell (median {t1:.2f} s), 1 warm-up + 3 timed each; a sample = {n0} + {n1} such cells '
+                      f'= {per_sample:.0f} s',
+               shots_s=dict(layer0=[round(t, 3) for t in shots0], wide=[round(t, 3) for t in shots1]))
+    if not os.environ.get('STC_BENCH_NO_DENSE_ANCHOR'):
+        try:
+            Nd = 10000
+            gd = torch.Generator().manual_seed(3)
+            Gs = torch.rand(Nd, Nd, generator=gd)
+            Gs /= Gs.sum(-1, keepdim=True)
+            X = torch.rand(1, Nd, 32, 32, generator=gd)
+            W = torch.randn(4 * 32, 32, generator=gd) * 0.1
+            Gc32 = torch.softmax(torch.randn(32, 32, generator=gd), -1)
+            ts = []
+            with torch.no_grad():
+                for shot in range(4):
+                    t = time.perf_counter()
+                    O.bdg_dif(X, Gs, Gc32, W, None, 2, 2)
+                    ts.append(time.perf_counter() - t)
+            out['dense_anchor'] = dict(what='oracle.bdg_dif forward (the reference algorithm: dense einsum, matrix-side cheby_poly, concat + projection), '
+                                            'B=1 N=10000 C=32 L=32 Ho=32 K=2, dense 400 MB Gs; 1 warm-up + 3 timed, median',
+                                       seconds=_median(ts[1:]), cores=threads,
+                                       reference_in_survey_container_s=0.90, reference_cores=8)
+        except MemoryError:
+            pass
+    return out
+
+
+def spmm_unit_d3(graph, dev, C, L, dtype, launches=60, rotate=6):
+    """SURVEY 8(d3)'s unit of work exactly: one application Y = S^T X over rows of F = C*L values, B = 1, timed COLD
+    (operands rotated over ``rotate`` buffer pairs >> the 256 MiB Infinity Cache) with HIP events on the launch stream."""
+    import torch
+    from stc_hip import ops
+    from stc_hip.graph import csr_operand
+    k = ops.kernels()
+    op = csr_operand(graph, dev)
+    N, F = graph.n, C * L
+    Xs = [torch.randn(1, N, F, device=dev).to(dtype) for _ in range(rotate)]
+    Ys = [torch.empty(1, N, F, device=dev, dtype=dtype) for _ in range(rotate)]
+
+    def run(i):
+        k.csr_spmm(op.fwd_rowptr, op.fwd_colidx, op.fwd_val, N, N, Xs[i % rotate], None, Ys[i % rotate], 1.0, 0.0, plan=op.fwd_plan)
+
+    for i in range(rotate):
+        run(i)
+    torch.cuda.synchronize(dev)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    stream = torch.cuda.current_stream(dev)
+    s.record(stream)
+    for i in range(launches):
+        run(i)
+    e.record(stream)
+    torch.cuda.synchronize(dev)
+    us = 1e3 * s.elapsed_time(e) / launches
+    nbytes = graph.nnz * 8 + 4 * (N + 1) + 2 * N * F * Xs[0].element_size()
+    return dict(what=f'Y = S^T X, B=1, F=C*L={F}, N={N}, nnz={graph.nnz}, {launches} cold launches (operands rotated over {rotate} x {2 * N * F * Xs[0].element_size() / 1e6:.0f} MB)',
+                algorithmic_bytes=nbytes, avg_launch_us=us, achieved=nbytes / us / 1e3, unit='GB/s', frac=nbytes / us / 1e3 / HBM_PEAK_GBPS,
+                target_frac=0.40)
+
+
+def csrc_sha():
+    """Hash of the kernel sources: a PMC traffic file is only quoted by the bench line while it matches."""
+    import hashlib
+    d = os.path.join(REPO, 'stc-gnn_amd', 'csrc')
+    hsh = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith(('.hip', '.h')):
+            with open(os.path.join(d, f), 'rb') as fh:
+                hsh.update(f.encode() + b'\0' + fh.read())
+    return hsh.hexdigest()[:16]
+
+
+def pmc_traffic(a, config_key):
+    """HBM bytes per plain SpMM launch from a PMC pass over THIS command (tools/gpu_pmc_bench.sh: FETCH_SIZE and WRITE_SIZE
+    in separate ``rocprofv3 --pmc`` runs), quoted only if the file was collected on the same kernel sources (csrc_sha)
+    and the same configuration; otherwise null.  Never a number from an older build."""
+    path = os.path.join(REPO, 'profiles', 'r02', 'hbm_traffic_bench.json')
+    if not os.path.exists(path):
+        return None, None
+    with open(path) as fh:
+        doc = json.load(fh)
+    if doc.get('csrc_sha') != csrc_sha() or doc.get('config_key') != config_key:
+        return None, f'profiles/r02/hbm_traffic_bench.json is from other sources/configuration ({doc.get("csrc_sha")}, {doc.get("config_key")}): not quoted'
+    ks = [v for name, v in doc['kernels'].items() if name.startswith('spmm_bcsr_kernel')]
+    if not ks:
+        return None, None
+    traffic = sum(v['hbm_bytes_per_launch'] * v['launches'] for v in ks) / sum(v['launches'] for v in ks)
+    return traffic, ('PMC (FETCH_SIZE, WRITE_SIZE in separate rocprofv3 --pmc passes, unit-corrected as MI355X_MICROARCH.md prescribes), mean over the '
+                     f'spmm_bcsr_kernel launches of one step of this command on these sources (csrc {doc["csrc_sha"]}): profiles/r02/hbm_traffic_bench.json')
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and 'RANK' not in os.environ:
+        sys.exit(self_launch(a))            # before torch / the GPU are touched: the ranks are children of this process
+
+    for _p in (REPO, os.path.join(REPO, 'stc-gnn_amd')):
+        if _p not in sys.path:
+            sys.path.insert(0, _p)
+    import torch
+    import torch.distributed as dist
     from stc_hip import CsrGraph, ops
     from stc_hip import dist as sdist
     from stc_hip._lib import KernelTimer
@@ -113,23 +248,37 @@ def main():
     sd_cpu = {k: v.clone() for k, v in model.state_dict().items()}
     model = model.to(dev)
     Gc = Gc_cpu.to(dev)
-    g = torch.Generator().manual_seed(1000 + rank)                              # a different shard of samples per rank
+    # SURVEY 8(d1) names seeds 0 / 1 for inputs / targets; a sharded batch needs a different draw per rank, so rank r uses
+    # 1000 + r for both (rank 0 of a 1-GPU run: seed 1000).  Bernoulli(0.1635) either way.
+    g = torch.Generator().manual_seed(1000 + rank)
     X = (torch.rand(B, a.obs, N, C, generator=g) < 0.1635).float().to(dev)
     Y = (torch.rand(B, a.pred, N, C, generator=g) < 0.1635).float().to(dev)
     crit = ComboLoss()
     bucket = sdist.GradBucket(model.parameters())
     opt = torch.optim.Adam(model.parameters(), lr=2e-3, weight_decay=1e-4)
+    stream = torch.cuda.current_stream(dev)
+    marks = []                                                                  # (t_begin, t_backward_done, t_allreduce_done, t_adam_done) events
 
-    def step():
+    def step(mark=False):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if mark else None
+        if mark:
+            ev[0].record(stream)
         bucket.zero()
         loss = crit(model(X_seq=X, As=graph, Ac=Gc), Y)
         loss.backward()
+        if mark:
+            ev[1].record(stream)
         bucket.allreduce_mean()
+        if mark:
+            ev[2].record(stream)
         opt.step()
+        if mark:
+            ev[3].record(stream)
+            marks.append(ev)
         return loss
 
     def fence():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -140,57 +289,88 @@ def main():
     hip.timer = KernelTimer()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        loss = step()
+        loss = step(mark=True)
     fence()
     elapsed = time.perf_counter() - t0
     per_kernel = hip.timer.summary()
     hip.timer = None
-    if world > 1:
+    n_ranks_seen = 1
+    if dist.is_initialized():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)                                                   # every rank really took part in a collective
+        n_ranks_seen = int(ones.item())
+    phases = [sum(ev[i].elapsed_time(ev[i + 1]) for ev in marks) / max(1, len(marks)) for i in range(3)]
+
+    # the same step with the per-launch event records off: what the instrumentation of the timed region costs
+    untimed_steps = min(a.steps, 3)
+    fence()
+    t1 = time.perf_counter()
+    for _ in range(untimed_steps):
+        step()
+    fence()
+    untimed_ms = 1e3 * (time.perf_counter() - t1) / max(1, untimed_steps)
 
     if rank == 0:
         total_ms = sum(d['ms'] for d in per_kernel.values()) or 1.0
-        spmm = dict(launches=0, ms=0.0, bytes=0)           # both forms of the aggregation: CSR and row-blocked CSR
-        for name in SPMM_ENTRY_POINTS:
-            for key, v in per_kernel.get(name, {}).items():
-                spmm[key] += v
-        achieved = (spmm['bytes'] / 1e9) / (spmm['ms'] / 1e3) if spmm['ms'] > 0 else 0.0
-        # HBM bytes per SpMM launch from the committed PMC passes over this same command (FETCH_SIZE x 2 + WRITE_SIZE in
-        # separate rocprofv3 --pmc runs, as MI355X_MICROARCH.md prescribes; tools/gpu_pmc_bench.sh): averaged over all SpMM
-        # launches of a step exactly like roofline.achieved.  Only valid for the configuration it was collected on.
-        traffic, traffic_note = None, None
-        tpath = os.path.join(REPO, 'profiles', 'r01', 'j_hbm_traffic_bench_b5.json')
-        if a.storage == 'bf16' and (a.grid, C, a.hidden, B, a.order, a.layers, a.obs, a.pred, a.permute) == (224, 64, 16, 5, 2, 2, 18, 6, False):
-            tb = os.path.join(REPO, 'profiles', 'r01', 'k_hbm_traffic_bench_bf16_c64.json')       # the same passes over --storage bf16 --categories 64
-            if os.path.exists(tb):
-                with open(tb) as fh:
-                    ks = [v for name, v in json.load(fh)['kernels'].items() if name.startswith('spmm_')]
-                if ks:
-                    traffic = sum(v['hbm_bytes_per_launch'] * v['launches'] for v in ks) / sum(v['launches'] for v in ks)
-                    traffic_note = 'PMC (2 x FETCH_SIZE + WRITE_SIZE), mean over the SpMM launches of one step of this command: profiles/r01/k_hbm_traffic_bench_bf16_c64.json'
-        if a.storage == 'f32' and (a.grid, C, a.hidden, B, a.order, a.layers, a.obs, a.pred, a.permute) == (224, 32, 16, 5, 2, 2, 18, 6, False) and os.path.exists(tpath):
-            with open(tpath) as fh:
-                doc = json.load(fh)
-            ks = [v for name, v in doc['kernels'].items() if name.startswith('spmm_')]
-            if ks:
-                traffic = sum(v['hbm_bytes_per_launch'] * v['launches'] for v in ks) / sum(v['launches'] for v in ks)
-                traffic_note = 'PMC (2 x FETCH_SIZE + WRITE_SIZE), mean over the SpMM launches of one step of this command: profiles/r01/j_hbm_traffic_bench_b5.json'
+
+        def gather(names, tag=None):
+            acc = dict(launches=0, ms=0.0, bytes=0)
+            for name in names:
+                d = per_kernel.get(name)
+                if d is None:
+                    continue
+                src = d if tag is None else d.get('tags', {}).get(tag)
+                if src:
+                    for key in acc:
+                        acc[key] += src[key]
+            return acc
+
+        def rate(acc):
+            return (acc['bytes'] / 1e9) / (acc['ms'] / 1e3) if acc['ms'] > 0 else 0.0
+
+        plain = gather(PLAIN_SPMM, 'plain')                 # Y = S.X, no Y0: SURVEY 8(d3)'s byte formula verbatim
+        every = gather(SPMM_ENTRY_POINTS)
+        config_key = f'{a.storage}:{a.grid}:{C}:{a.hidden}:{B}:{a.order}:{a.layers}:{a.obs}:{a.pred}:{int(a.permute)}'
+        traffic, traffic_note = pmc_traffic(a, config_key)
+        achieved = rate(plain)
+        roofline = {
+            'bound': 'hbm',
+            'kernel': 'spmm_bcsr_kernel (C-ABI stc_bcsr_spmm_' + a.storage + '): the plain aggregation launches Y = S.X of the timed train steps '
+                      f'(S.state forward, S^T.dY backward; rows of C*hidden = {C * a.hidden} values, {B} samples per launch)',
+            'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS,
+            'traffic': traffic, 'traffic_note': traffic_note,
+            'launches': plain['launches'], 'avg_launch_us': 1e3 * plain['ms'] / max(1, plain['launches']),
+            'algorithmic_bytes_per_launch': plain['bytes'] / max(1, plain['launches']),
+            'bytes_formula': 'nnz*8 + 4*(N+1) + 2*B*N*F*sizeof(x)  (SURVEY 8(d3))',
+            'aggregate': {'what': 'every aggregation launch of the timed steps (' + ' + '.join(n for n in SPMM_ENTRY_POINTS if n in per_kernel)
+                                  + '): plain, with the GRU blend in the epilogue, state-gradient sums; graph once + every operand read once + every result written once',
+                          'achieved': rate(every), 'frac': rate(every) / HBM_PEAK_GBPS, 'launches': every['launches'],
+                          'avg_launch_us': 1e3 * every['ms'] / max(1, every['launches']),
+                          'algorithmic_bytes_per_launch': every['bytes'] / max(1, every['launches'])},
+        }
+        if not a.no_unit_d3:
+            roofline['unit_d3'] = spmm_unit_d3(graph, dev, C, 2 * a.hidden, torch.bfloat16 if a.storage == 'bf16' else torch.float32)
+        value = world * B * a.steps / elapsed
         out = {
-            'metric': METRIC, 'value': world * B * a.steps / elapsed, 'unit': 'samples/s',
+            'metric': METRIC, 'value': value, 'unit': 'samples/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * elapsed / a.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.storage, 'data': 'synthetic',
+            'n_ranks_seen': n_ranks_seen,
             'config': {'workload': f'full STC-GNN train step (fwd + ComboLoss + bwd + grad all-reduce + Adam), csr-fixed, '
                                    f'{a.grid}x{a.grid} queen grid N={N} nnz={graph.nnz}{" permuted" if a.permute else ""}, C={C}, '
                                    f'hidden={a.hidden}, K={a.order}, layers={a.layers}, T={a.obs}+{a.pred}' + (', bf16 state storage' if a.storage == 'bf16' else ''),
                        'global_batch': world * B, 'batch_per_gpu': B, 'parallelism': f'batch-shard x{world}',
-                       'grad_bucket_bytes': bucket.nbytes},
-            'roofline': {'bound': 'hbm', 'kernel': ' + '.join(SPMM_ENTRY_POINTS) + ': every aggregation (SpMM) launch of the timed steps -- plain, with the GRU blend in its epilogue, and the state-gradient sum form', 'achieved': achieved, 'peak': HBM_PEAK_GBPS,
-                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic, 'traffic_note': traffic_note,
-                         'launches': spmm['launches'],
-                         'avg_launch_us': 1e3 * spmm['ms'] / max(1, spmm['launches']),
-                         'algorithmic_bytes_per_launch': spmm['bytes'] / max(1, spmm['launches'])},
+                       'grad_bucket_bytes': bucket.nbytes, 'input_seeds': 'X, Y: Bernoulli(0.1635), torch seed 1000 + rank'},
+            'roofline': roofline,
+            'step_breakdown': {'fwd_loss_bwd_ms': phases[0], 'grad_allreduce_ms': phases[1], 'adam_ms': phases[2],
+                               'samples_per_s_excluding_optimizer': world * B / ((phases[0] + phases[1]) / 1e3) if phases[0] > 0 else None,
+                               'ms_per_step_without_launch_events': untimed_ms,
+                               'note': 'value / ms_per_step are the whole step (Adam included) with two HIP-event records around every kernel launch; '
+                                       'the phases are HIP events on the compute stream of rank 0; ms_per_step_without_launch_events re-times '
+                                       f'{untimed_steps} steps with the launch timer off'},
             'kernels': {k: {'launches': d['launches'], 'ms_per_step': d['ms'] / a.steps, 'share': d['ms'] / total_ms,
                             **({'GBps': d['bytes'] / 1e9 / (d['ms'] / 1e3)} if d['bytes'] and d['ms'] > 0 else {})}
                         for k, d in sorted(per_kernel.items(), key=lambda kv: -kv[1]['ms'])},
@@ -202,13 +382,14 @@ def main():
             GsT = graph.to_dense().t().contiguous().to_sparse_csr() if N <= 4096 else _sparse_T(graph)
             out['cpu_baseline'] = cpu_baseline(a, GsT, Gc_cpu, sd_cpu)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 
 
 def _sparse_T(graph):
     """torch sparse CSR of Gs^T straight from the graph's forward operand (no dense N x N detour)."""
+    import torch
     h = graph._host
     return torch.sparse_csr_tensor(torch.from_numpy(h['fwd_rowptr']).long(), torch.from_numpy(h['fwd_colidx']).long(),
                                    torch.from_numpy(h['fwd_val']), size=(graph.n, graph.n))

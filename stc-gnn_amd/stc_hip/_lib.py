@@ -153,20 +153,23 @@ class KernelTimer:
     launched on (torch's current stream), immediately around the launch."""
 
     def __init__(self):
-        self.spans = []          # (name, start_event, end_event, algorithmic_bytes)
+        self.spans = []          # (name, start_event, end_event, algorithmic_bytes, tag)
 
-    def add(self, name, start, end, nbytes):
-        self.spans.append((name, start, end, nbytes))
+    def add(self, name, start, end, nbytes, tag=None):
+        self.spans.append((name, start, end, nbytes, tag))
 
     def summary(self):
-        """{name: dict(launches, ms, bytes)} after synchronising; clears the recorded spans."""
+        """{name: dict(launches, ms, bytes[, tags: {tag: dict(launches, ms, bytes)}])} after synchronising; clears the
+        recorded spans.  A tag names the form of a launch where one entry point has several ('plain' = Y = S.X with no Y0)."""
         torch.cuda.synchronize()
         out = {}
-        for name, s, e, nb in self.spans:
+        for name, s, e, nb, tag in self.spans:
             d = out.setdefault(name, dict(launches=0, ms=0.0, bytes=0))
-            d['launches'] += 1
-            d['ms'] += s.elapsed_time(e)
-            d['bytes'] += nb
+            ms = s.elapsed_time(e)
+            for acc in (d,) if tag is None else (d, d.setdefault('tags', {}).setdefault(tag, dict(launches=0, ms=0.0, bytes=0))):
+                acc['launches'] += 1
+                acc['ms'] += ms
+                acc['bytes'] += nb
         self.spans = []
         return out
 
@@ -187,7 +190,7 @@ class HipKernels:
         self._workspace = {}
         self.timer: Optional[KernelTimer] = None      # set by bench.py to time every launch with HIP events
 
-    def _launch(self, name, on, *args, nbytes=0):
+    def _launch(self, name, on, *args, nbytes=0, tag=None):
         """Call C entry point ``name`` with ``args`` + the current stream of ``on``'s device."""
         fn = getattr(self.lib, name)
         with torch.cuda.device(on.device):
@@ -199,7 +202,7 @@ class HipKernels:
                 start.record(stream)
                 rc = fn(*args, stream.cuda_stream)
                 end.record(stream)
-                self.timer.add(name, start, end, nbytes)
+                self.timer.add(name, start, end, nbytes, tag)
         if rc != 0:
             msg = self.lib.stc_last_error()
             raise StcError(f'{name} failed with code {rc}: {msg.decode() if msg else "?"}')
@@ -268,17 +271,19 @@ class HipKernels:
         self._i32('spmm.colidx', colidx)
         self._f32('spmm.val', val, (colidx.numel(),))
         self._same_device(rowptr, colidx, val, X, Y0, Y)
-        nbytes = colidx.numel() * 8 + 4 * (n_rows + 1) + (2 if Y0 is None or beta == 0 else 3) * 4 * B * n_rows * F
+        plain = Y0 is None or beta == 0
+        nbytes = colidx.numel() * 8 + 4 * (n_rows + 1) + (2 if plain else 3) * 4 * B * n_rows * F
+        tag = 'plain' if plain else 'with_y0'
         if plan is not None and F % 4 == 0 and F >= 64 and all(t is None or t.data_ptr() % 16 == 0 for t in (X, Y0, Y)):
             blk_ptr, blk_cols, blk_vals = plan
             self._i32('spmm.blk_ptr', blk_ptr, (n_rows + 3) // 4 + 1)
             self._i32('spmm.blk_cols', blk_cols)
             self._f32('spmm.blk_vals', blk_vals, (blk_cols.numel(), 4))
             self._launch('stc_bcsr_spmm_f32', X, _ptr(blk_ptr), _ptr(blk_cols), _ptr(blk_vals), n_rows, n_cols,
-                         _ptr(X), _ptr(Y0), _ptr(Y), B, F, float(alpha), float(beta), nbytes=nbytes)
+                         _ptr(X), _ptr(Y0), _ptr(Y), B, F, float(alpha), float(beta), nbytes=nbytes, tag=tag)
             return
         self._launch('stc_csr_spmm_f32', X, _ptr(rowptr), _ptr(colidx), _ptr(val), n_rows, n_cols, _ptr(X), _ptr(Y0), _ptr(Y), B, F, float(alpha), float(beta),
-                     nbytes=nbytes)
+                     nbytes=nbytes, tag=tag)
 
     def csr_spmm_bf16(self, rowptr, colidx, val, n_rows, n_cols, X, Y0, Y, alpha, beta, plan=None):
         """bf16-storage form of ``csr_spmm`` (stc_csr_spmm_bf16 / stc_bcsr_spmm_bf16): X, Y0, Y bfloat16 with F % 8 == 0,
@@ -294,17 +299,19 @@ class HipKernels:
         self._i32('spmm.colidx', colidx)
         self._f32('spmm.val', val, (colidx.numel(),))
         self._same_device(rowptr, colidx, val, X, Y0, Y)
-        nbytes = colidx.numel() * 8 + 4 * (n_rows + 1) + (2 if Y0 is None or beta == 0 else 3) * 2 * B * n_rows * F
+        plain = Y0 is None or beta == 0
+        nbytes = colidx.numel() * 8 + 4 * (n_rows + 1) + (2 if plain else 3) * 2 * B * n_rows * F
+        tag = 'plain' if plain else 'with_y0'
         if plan is not None:
             blk_ptr, blk_cols, blk_vals = plan
             self._i32('spmm.blk_ptr', blk_ptr, (n_rows + 3) // 4 + 1)
             self._i32('spmm.blk_cols', blk_cols)
             self._f32('spmm.blk_vals', blk_vals, (blk_cols.numel(), 4))
             self._launch('stc_bcsr_spmm_bf16', X, _ptr(blk_ptr), _ptr(blk_cols), _ptr(blk_vals), n_rows, n_cols,
-                         _ptr(X), _ptr(Y0), _ptr(Y), B, F, float(alpha), float(beta), nbytes=nbytes)
+                         _ptr(X), _ptr(Y0), _ptr(Y), B, F, float(alpha), float(beta), nbytes=nbytes, tag=tag)
             return
         self._launch('stc_csr_spmm_bf16', X, _ptr(rowptr), _ptr(colidx), _ptr(val), n_rows, n_cols, _ptr(X), _ptr(Y0), _ptr(Y), B, F,
-                     float(alpha), float(beta), nbytes=nbytes)
+                     float(alpha), float(beta), nbytes=nbytes, tag=tag)
 
     def _graph_ptrs(self, rowptr, colidx, val, plan, n_rows):
         self._i32('spmm.rowptr', rowptr, n_rows + 1)

@@ -25,14 +25,25 @@ import torch
 import torch.distributed as dist
 
 
-def shard_batch(t: torch.Tensor, rank: int, world: int) -> torch.Tensor:
-    """Contiguous, equal shard ``rank`` of ``world`` along dim 0 (the sample dimension)."""
+def shard_bounds(n: int, rank: int, world: int) -> tuple:
+    """[lo, hi) of contiguous shard ``rank`` of ``world`` over ``n`` samples; the first ``n % world`` shards hold one more."""
+    per, extra = divmod(n, world)
+    lo = rank * per + min(rank, extra)
+    return lo, lo + per + (1 if rank < extra else 0)
+
+
+def shard_batch(t: torch.Tensor, rank: int, world: int, ragged: bool = False) -> torch.Tensor:
+    """Contiguous shard ``rank`` of ``world`` along dim 0 (the sample dimension).
+
+    Equal shards by default (then the plain mean of the shard gradients IS the full-batch gradient).  ``ragged=True``
+    accepts any batch size -- the last batch of an epoch -- with shard sizes differing by at most one (possibly empty);
+    the caller then scales the shard loss by ``len(shard) / n * world`` before ``backward()`` (see ``GradBucket.allreduce_mean``)."""
     n = t.shape[0]
-    if n % world:
+    if n % world and not ragged:
         raise ValueError(f'global batch {n} is not divisible by world size {world}: shards must be equal '
                          'for the averaged gradients to equal the full-batch gradients')
-    per = n // world
-    return t[rank * per:(rank + 1) * per]
+    lo, hi = shard_bounds(n, rank, world)
+    return t[lo:hi]
 
 
 class GradBucket:
@@ -68,7 +79,11 @@ class GradBucket:
         return all(p.grad is not None and p.grad.untyped_storage().data_ptr() == base for p in self.params)
 
     def allreduce_mean(self, group=None, async_op: bool = False):
-        """Sum the bucket over ranks and divide by the world size (gradient of the global-batch mean loss)."""
+        """Sum the bucket over ranks and divide by the world size (gradient of the global-batch mean loss).
+
+        Unequal shards (``shard_batch(..., ragged=True)``): scale the shard loss by ``len(shard) / n * world`` before
+        ``backward()``; the mean over ranks is then the share-weighted sum = the full-batch gradient (ComboLoss is a mean of
+        per-sample and per-element terms, Model_Trainer.py:14-23), also through ``allreduce_sum`` (learned graphs)."""
         if not (dist.is_available() and dist.is_initialized()):
             return None
         world = dist.get_world_size(group)
@@ -108,7 +123,9 @@ def allreduce_sum(x: torch.Tensor, group=None) -> torch.Tensor:
 
 
 def init_from_env(backend: str = None) -> tuple:
-    """(rank, world, local_rank) from torchrun's environment; initialises the process group when world > 1.
+    """(rank, world, local_rank) from torchrun's environment; initialises the process group whenever the process was
+    started by a launcher (``RANK`` is set) -- also for a single rank, so that a one-GPU ``torchrun`` run goes through the
+    same RCCL communicator set-up, collectives and tear-down as an eight-GPU one.
 
     Test hooks (a 1-GPU box cannot run RCCL between two ranks): ``STC_DIST_BACKEND=gloo`` forces the backend and
     ``STC_DIST_ONE_DEVICE=1`` maps every rank onto device 0, so the N > 1 code path can be exercised on one GPU."""
@@ -118,7 +135,7 @@ def init_from_env(backend: str = None) -> tuple:
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if os.environ.get('STC_DIST_ONE_DEVICE') == '1':
         local = 0
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or 'RANK' in os.environ) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         backend = backend or os.environ.get('STC_DIST_BACKEND')
         if backend is None:

@@ -6,6 +6,13 @@ the modes, best-validation checkpoint ``{epoch, train_loss, val_loss, state_dict
 differences: the running loss is accumulated as a Python float (the reference adds the loss TENSOR and so keeps
 every step's autograd graph alive: +0.7 GB per step, ``Model_Trainer.py:85``); evaluation runs under
 ``no_grad`` (``:136-138`` does not); no ``empty_cache()`` per step.  Checkpoints interchange with the reference.
+
+Batch-sharded training: when a process group is initialised (``stc_hip.dist.init_from_env`` under
+``torchrun``, one rank per GPU) every rank holds the whole window set, takes its contiguous shard of each batch
+(``shard_batch``), and the parameter gradients -- views into ONE flat ``GradBucket`` -- are summed by a single RCCL
+all-reduce per step, each rank weighted by its share of the batch (so a ragged last batch stays exact).  Losses are
+reduced the same way; rank 0 writes the checkpoint.  With learned graphs the model must be built ``batch_sharded=True``
+(done here): MGP_Gen sums over the batch before its softmax.  One rank: the same code, no collective.
 """
 from __future__ import annotations
 
@@ -17,6 +24,7 @@ import numpy as np
 import torch
 from torch import optim
 
+from . import dist as sdist
 from .loss import ComboLoss
 
 
@@ -33,11 +41,16 @@ class Trainer:
                             torch.from_numpy(np.asarray(data['c_cor'])).float().to(dev)]
         if params.get('model', 'STC-GNN') != 'STC-GNN':
             raise NotImplementedError('Invalid model name.')
+        import torch.distributed as tdist
+        self.rank = tdist.get_rank() if tdist.is_available() and tdist.is_initialized() else 0
+        self.world = tdist.get_world_size() if tdist.is_available() and tdist.is_initialized() else 1
         self.model = STCGNN(num_nodes=params['H'] * params['W'], num_categories=params['C'],
                             Ks=params['cheby_order'], Kc=params['cheby_order'], input_dim=1,
                             hidden_dim=params['hidden_dim'], num_layers=params['nn_layers'],
-                            out_horizon=params['pred_len'], graph_mode=graph_mode).to(dev)
+                            out_horizon=params['pred_len'], graph_mode=graph_mode,
+                            batch_sharded=self.world > 1 and graph_mode == 'dense-learned').to(dev)
         self.criterion = ComboLoss()
+        self.bucket = sdist.GradBucket(self.model.parameters())        # every .grad is a view into one flat buffer
         self.optimizer = optim.Adam(self.model.parameters(), lr=params['learn_rate'], weight_decay=params['decay_rate'])
 
     @property
@@ -58,33 +71,64 @@ class Trainer:
                 self.model.train(mode == 'train')
                 total, seen, t0 = 0.0, 0, time.time()
                 for x_seq, y_true in data_loader[mode]:
+                    n = y_true.shape[0]
+                    if self.world > 1:                                   # this rank's contiguous shard of the batch
+                        x_seq = sdist.shard_batch(x_seq, self.rank, self.world, ragged=True)
+                        y_true = sdist.shard_batch(y_true, self.rank, self.world, ragged=True)
+                    share = y_true.shape[0] / n
                     with torch.set_grad_enabled(mode == 'train'):
-                        loss = self.criterion(self._forward(x_seq), y_true)
                         if mode == 'train':
-                            self.optimizer.zero_grad()
-                            loss.backward()
+                            self.bucket.zero()                           # zero_grad() that keeps the bucket views
+                        if y_true.shape[0]:
+                            loss = self.criterion(self._forward(x_seq), y_true)
+                            if mode == 'train':
+                                # unequal shards (ragged last batch): weight by this rank's share so that the mean over
+                                # ranks of the bucket is the full-batch gradient; equal shards: the factor is exactly 1
+                                (loss if share * self.world == 1 else loss * (share * self.world)).backward()
+                            loss = loss.detach()
+                        elif self.model.graph_mode == 'dense-learned':
+                            raise ValueError(f'batch of {n} samples on {self.world} ranks leaves a rank without samples: the learned '
+                                             'graphs need every rank in their forward all-reduce')
+                        else:                                            # more ranks than samples in a ragged last batch
+                            loss = torch.zeros((), device=y_true.device)
+                        if mode == 'train':
+                            self.bucket.allreduce_mean()                 # the one collective of a step (no-op on one rank)
                             self.optimizer.step()
-                    total += float(loss.detach()) * y_true.shape[0]     # a float: no graph is kept alive
-                    seen += y_true.shape[0]
+                    total += float(self._global_loss(loss, share)) * n   # a float: no graph is kept alive
+                    seen += n
                 run_time[mode].append(time.time() - t0)
                 history[mode].append(total / max(seen, 1))
             val = history['validate'][-1] if 'validate' in history else history['train'][-1]
             if val < best_val:
                 best_val, patience = val, early_stop_patience
-                torch.save({'epoch': epoch, 'train_loss': history['train'][-1], 'val_loss': val,
-                            'state_dict': self.model.state_dict()}, self.checkpoint_path)
+                if self.rank == 0:
+                    torch.save({'epoch': epoch, 'train_loss': history['train'][-1], 'val_loss': val,
+                                'state_dict': self.model.state_dict()}, self.checkpoint_path)
                 note = 'checkpoint updated'
             else:
                 patience -= 1
                 note = f'no improvement ({patience} left)'
-            if verbose:
+            if verbose and self.rank == 0:
                 print(f'Epoch {epoch}: train {history["train"][-1]:.4f} ({run_time["train"][-1]:.2f} s), '
                       f'validate {val:.4f}; {note}')
             if patience == 0:
-                if verbose:
+                if verbose and self.rank == 0:
                     print(f'Early stopping triggered at epoch {epoch}.')
                 break
+        if self.world > 1:
+            import torch.distributed as tdist
+            tdist.barrier()                                              # the checkpoint is on disk before any rank tests
         return dict(loss=history, seconds=run_time, best_val=best_val)
+
+    def _global_loss(self, loss: torch.Tensor, share: float) -> torch.Tensor:
+        """The full-batch loss from the shard losses: ComboLoss is a mean over samples / elements, so it is the
+        share-weighted sum over ranks (every rank gets the same value, hence the same early-stopping decisions)."""
+        if self.world == 1:
+            return loss
+        import torch.distributed as tdist
+        t = (loss * share).reshape(1).clone()
+        tdist.all_reduce(t)
+        return t[0]
 
     @torch.no_grad()
     def test(self, data_loader: Dict[str, Iterable], modes: List[str] = ('test',), checkpoint: Optional[str] = None) -> dict:

@@ -21,6 +21,10 @@ stored, only numbers.  Sets follow SURVEY.md section 8(c4):
   g8_large_n10000   one STC_Cell at N=10 000, C=32, h=16 through the dense reference, sampled rows
   g9_pipeline       Data_Container windows/split/batches and a 2-epoch Model_Trainer run on a synthetic series
   g10_metrics       Metrics.mask_data and ModelEvaluator.one_step_eval_bi on synthetic predictions
+  g11_bench_c32     the BENCH path's widths through the reference: encoder-decoder-head (graphs given, as g5) at C=32, h=16, K=2,
+                    2 layers, 6x8 non-symmetric grid graph, B=2, T=3+2 -> yhat, ComboLoss, every gradient
+  g12_bench_c64     the same at C=64;  g13_bench_c32_k3  the same at C=32, K=3 (configuration 4's order)
+  g8b_large_n10000_grads   g8 with backward: sampled rows of Ht, dXt, dHt + the full parameter gradients
 
 Large inputs (g7, g8) are regenerated from seeds by ``synth_inputs`` below,
 which the tests import too; a few checksums are stored to catch RNG drift.
@@ -80,6 +84,20 @@ def synth_inputs(name):
     R = torch.randn(B, N, C, h, generator=g)
     return dict(N=N, C=C, cin=cin, h=h, K=K, B=B, Gs=Gs, Gc=Gc, Xt=Xt, Ht=Ht,
                 gates_W=gw, gates_b=gb, candi_W=cw, candi_b=cb, R=R)
+
+
+def bench_path_inputs(C, K, H=6, W=8, h=16, layers=2, horizon=2, B=2, T=3):
+    """Inputs of g11-g13: the widths the bench runs (C in {32, 64}, hidden 16) on a small NON-symmetric graph -- the queen grid
+    with every entry scaled by a random factor in [0.5, 1.5), then row-normalised -- and a non-symmetric category graph."""
+    N = H * W
+    g = torch.Generator().manual_seed(1100 + C + K)
+    A = grid_graph_dense(H, W)
+    A = A * (0.5 + torch.rand(N, N, generator=g)) * (A > 0)
+    Gs = A / A.sum(1, keepdim=True)
+    Gc = torch.softmax(torch.randn(C, C, generator=g), -1)
+    X = (torch.rand(B, T, N, C, generator=g) < 0.3).float()
+    Y = (torch.rand(B, horizon, N, C, generator=g) < 0.3).float()
+    return dict(N=N, C=C, K=K, h=h, layers=layers, horizon=horizon, Gs=Gs, Gc=Gc, X=X, Y=Y)
 
 
 def sample_rows(N, count, seed=99):
@@ -320,6 +338,56 @@ def main():
           chk_Ht=s['Ht'].double().sum(), chk_W=s['gates_W'].double().sum())
 
 
+def bench_path_golden(ref_framework='/root/reference/framework'):
+    """g11 / g12 / g13 and g8b: the reference itself at the widths (and, g8b, a size) the bench runs."""
+    sys.path.insert(0, ref_framework)
+    import STC_GNN as ref
+    from Model_Trainer import ComboLoss
+    torch.set_num_threads(8)
+    for name, C, K in (('g11_bench_c32', 32, 2), ('g12_bench_c64', 64, 2), ('g13_bench_c32_k3', 32, 3)):
+        s = bench_path_inputs(C, K)
+        torch.manual_seed(1100 + C + 10 * K)
+        full = ref.STCGNN(s['N'], C, K, K, 1, s['h'], s['layers'], s['horizon'])
+        with torch.no_grad():
+            for m in list(full.encoder.cell_list) + list(full.decoder.cell_list):
+                m.gates.b.normal_(0, 0.3)
+                m.candi.b.normal_(0, 0.3)
+        Gs = s['Gs'].clone().requires_grad_()
+        Gc = s['Gc'].clone().requires_grad_()
+        # STCGNN.forward after MGP_Gen (STC_GNN.py:189-207) on the reference's own modules, graphs handed in
+        _, states = full.encoder(Gs=Gs, Gc=Gc, X_seq=s['X'].unsqueeze(-1), H0_l=None)
+        dec_in, outs = states[-1], []
+        for _ in range(s['horizon']):
+            dec_in, states = full.decoder(Gs=Gs, Gc=Gc, Xt=dec_in, H0_l=states)
+            outs.append(dec_in)
+        yhat = torch.sigmoid(full.out_proj(torch.stack(outs, 1))).squeeze(-1)
+        loss = ComboLoss()(yhat, s['Y'])
+        loss.backward()
+        out = dict(N=s['N'], C=C, K=K, h=s['h'], layers=s['layers'], horizon=s['horizon'], yhat=yhat, loss=loss,
+                   chk_Gs=s['Gs'].double().sum(), chk_X=s['X'].double().sum(), chk_Gc=s['Gc'].double().sum())
+        for k, v in full.state_dict().items():
+            if not k.startswith('mix_graph_pair'):
+                out['sd/' + k] = v.clone()
+        for k, p in full.named_parameters():
+            if not k.startswith('mix_graph_pair'):
+                out['grad/' + k] = p.grad.clone()
+        _save(name, **out)
+    # g8b: N = 10 000 through the dense reference WITH backward (sampled rows of the input gradients, full parameter gradients)
+    s = synth_inputs('g8')
+    cell = ref.STC_Cell(s['N'], s['C'], s['K'], s['K'], s['cin'], s['h'])
+    with torch.no_grad():
+        cell.gates.W.copy_(s['gates_W']); cell.gates.b.copy_(s['gates_b'])
+        cell.candi.W.copy_(s['candi_W']); cell.candi.b.copy_(s['candi_b'])
+    Xt = s['Xt'].clone().requires_grad_()
+    Ht = s['Ht'].clone().requires_grad_()
+    out = cell(s['Gs'], s['Gc'], Xt, Ht)
+    (out * s['R']).sum().backward()
+    rows = sample_rows(s['N'], 128)
+    _save('g8b_large_n10000_grads', rows=rows, Hout=out[:, rows], dXt=Xt.grad[:, rows], dHt=Ht.grad[:, rows],
+          d_gates_W=cell.gates.W.grad, d_gates_b=cell.gates.b.grad, d_candi_W=cell.candi.W.grad, d_candi_b=cell.candi.b.grad,
+          chk_Gs=s['Gs'].double().sum(), chk_Xt=s['Xt'].double().sum())
+
+
 def pipeline_inputs():
     """Synthetic incident series + trainer params shared by make_golden and the tests (g9)."""
     g = torch.Generator().manual_seed(9)
@@ -422,7 +490,10 @@ if __name__ == '__main__':
         metrics_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == 'pipeline':
         pipeline_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'bench_path':
+        bench_path_golden()
     else:
         main()
         pipeline_golden()
         metrics_golden()
+        bench_path_golden()

@@ -159,3 +159,55 @@ def test_shard_batch_and_bucket_guards():
     assert float(lin.weight.grad.abs().sum()) == 0.0 and bucket.check_views()
     torch.optim.SGD(lin.parameters(), lr=0.1).zero_grad(set_to_none=True)
     assert not bucket.check_views()
+
+
+def _worker_trainer(rank, world, port, out_dir):
+    for p in (REPO, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from oracle.kernel_emul import EmulatedKernels
+    from stc_hip import data as sdata, dist as sdist, ops
+    from stc_hip.trainer import Trainer
+    from tests.golden.make_golden import pipeline_inputs
+    ops._kernels = EmulatedKernels()
+    sdist.init_from_env(backend='gloo')
+    data, params = pipeline_inputs()
+    params = dict(params, output_dir=out_dir, _allow_cpu_for_tests=True)
+    loaders = sdata.get_data_loader(params, data, params['obs_len'], params['pred_len'], params['split_ratio'])
+    torch.manual_seed(123)                                                # same initial parameters on every rank
+    trainer = Trainer(params, data)
+    assert trainer.world == world and trainer.model.mix_graph_pair.batch_sharded
+    hist = trainer.train(loaders, verbose=False)
+    torch.save({'hist': hist, 'flat': torch.cat([p.detach().flatten() for p in trainer.model.parameters()])},
+               os.path.join(out_dir, f'rank{rank}.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_trainer_reproduces_the_reference_epoch_losses(tmp_path):
+    """The trainer counterpart (Model_Trainer.py:52-121) batch-sharded over two ranks -- shard_batch on every batch incl.
+    the ragged last one (3 samples: 2 + 1), one GradBucket all-reduce per step, learned graphs with the batch-sum
+    all-reduce -- follows the REFERENCE's own 2-epoch loss curves (g9), and both ranks end on the same parameters."""
+    import numpy as np
+    from tests.conftest import load_golden
+    world = 2
+    mp.start_processes(_worker_trainer, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True, start_method='spawn')
+    got = [torch.load(tmp_path / f'rank{r}.pt', weights_only=False) for r in range(world)]
+    g = load_golden('g9_pipeline')
+    for r in range(world):
+        assert np.allclose(got[r]['hist']['loss']['train'], g['train_curve'].numpy(), rtol=0, atol=3e-5), got[r]['hist']['loss']
+        assert np.allclose(got[r]['hist']['loss']['validate'], g['val_curve'].numpy(), rtol=0, atol=3e-5), got[r]['hist']['loss']
+    assert torch.equal(got[0]['flat'], got[1]['flat'])
+    assert os.path.exists(tmp_path / 'STC-GNN-4.pkl')                     # written once, by rank 0
+
+
+def test_ragged_shards_cover_the_batch():
+    from stc_hip import dist as sdist
+    for n in (0, 1, 3, 7, 8, 26, 32):
+        for world in (1, 2, 3, 8):
+            parts = [sdist.shard_batch(torch.arange(n), r, world, ragged=True) for r in range(world)]
+            assert torch.equal(torch.cat(parts), torch.arange(n))
+            sizes = [len(p) for p in parts]
+            assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)

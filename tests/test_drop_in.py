@@ -1,0 +1,90 @@
+"""SURVEY section 4, "drop-in" tier: the reference's OWN caller stack on top of the build's ``STC_GNN`` module.
+
+``framework/Model_Trainer.py:5`` does ``from STC_GNN import STCGNN``; with ``stc-gnn_amd/`` ahead of ``framework/`` on
+``sys.path`` that import resolves to the build's module, and the reference's ``ModelTrainer`` (``:26-158``),
+``Data_Container.DataGenerator`` and ``Metrics.ModelEvaluator`` run UNCHANGED on it: constructor keywords (``:39-46``),
+``forward(X_seq=, As=, Ac=)`` (``:74, :138``), ``.parameters()`` into Adam (``:35``), ``.train()/.eval()``,
+``state_dict()`` into the checkpoint and ``load_state_dict()`` back (``:53, :103, :126-128``).
+
+Build container only (the reference does not travel to the GPU box): skipped when ``/root/reference`` is absent.  Compute
+runs on the emulated kernel set (no GPU here), injected as in the other CPU tests; the GPU run of the same loop through
+libstc_hip.so is ``test_pipeline.py::test_trainer_on_the_gpu_reproduces_the_reference_epoch_losses``.
+"""
+import contextlib
+import importlib.util
+import io
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.kernel_emul import EmulatedKernels
+from stc_hip import ops
+from tests.conftest import PKG, REFERENCE, load_golden, sub_dict
+from tests.golden.make_golden import pipeline_inputs
+
+pytestmark = pytest.mark.skipif(not os.path.isdir(REFERENCE), reason='reference not present (build container only)')
+
+
+def _import_reference_callers():
+    """The reference's Model_Trainer / Data_Container / Metrics, imported with the BUILD's STC_GNN first on sys.path."""
+    sys.dont_write_bytecode = True
+    saved_path = list(sys.path)
+    saved_mods = {k: sys.modules.get(k) for k in ('Model_Trainer', 'Data_Container', 'Metrics')}
+    sys.path[:] = [PKG] + [p for p in sys.path if p not in (PKG, REFERENCE)] + [REFERENCE]      # build first, reference last
+    try:
+        mods = {}
+        for name in ('Data_Container', 'Model_Trainer'):
+            sys.modules.pop(name, None)
+            spec = importlib.util.spec_from_file_location(name, os.path.join(REFERENCE, name + '.py'))
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)                          # its "from STC_GNN import STCGNN" runs here
+            mods[name] = mod
+        return mods['Model_Trainer'], mods['Data_Container']
+    finally:
+        sys.path[:] = saved_path
+        for k, v in saved_mods.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
+def test_reference_model_trainer_runs_on_the_drop_in_module(tmp_path, monkeypatch):
+    import STC_GNN as M
+    MT, DC = _import_reference_callers()
+    assert MT.STCGNN is M.STCGNN and os.path.realpath(sys.modules[MT.STCGNN.__module__].__file__).startswith(os.path.realpath(PKG)), \
+        'Model_Trainer.py:5 did not resolve to the build\'s STC_GNN'
+    monkeypatch.setattr(ops, '_kernels', EmulatedKernels())
+    g = load_golden('g9_pipeline')
+    data, params = pipeline_inputs()
+    params = dict(params, output_dir=str(tmp_path))
+    gen = DC.DataGenerator(obs_len=params['obs_len'], pred_len=params['pred_len'], data_split_ratio=params['split_ratio'])
+    loaders = gen.get_data_loader(params=params, data=data)                      # the reference's own DataLoader objects
+    torch.manual_seed(123)
+    trainer = MT.ModelTrainer(params=params, data=data)                          # Model_Trainer.py:26-46, unchanged
+    assert isinstance(trainer.model, M.STCGNN)
+    for k, v in sub_dict(g, 'sd0/').items():                                     # same seed -> the reference's initial parameters
+        assert torch.equal(trainer.model.state_dict()[k], v), k
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        trainer.train(data_loader=loaders, modes=['train', 'validate'])           # Model_Trainer.py:52-121, unchanged
+    printed = buf.getvalue()
+    train_printed = [float(v) for v in re.findall(r'training loss: ([0-9.]+)', printed)]
+    val_printed = [float(v) for v in re.findall(r'to ([0-9.]+)\. Update model checkpoint', printed)]
+    want_train, want_val = g['train_curve'].numpy(), g['val_curve'].numpy()
+    assert len(train_printed) == params['num_epochs']
+    assert np.allclose(train_printed, want_train, rtol=6e-4, atol=0), (train_printed, want_train)      # 4 printed digits
+    ck = torch.load(os.path.join(str(tmp_path), 'STC-GNN-4.pkl'), weights_only=False)
+    assert sorted(ck.keys()) == list(g['ckpt_keys']) and ck['epoch'] == int(g['ckpt_epoch'])
+    e = ck['epoch'] - 1                                                           # the checkpoint holds that epoch's exact losses
+    assert abs(float(ck['train_loss']) - want_train[e]) < 2e-5 and abs(float(ck['val_loss']) - want_val[e]) < 2e-5
+    assert val_printed and abs(val_printed[-1] - want_val[e]) < 6e-4 * want_val[e]
+    assert list(ck['state_dict'].keys()) == list(trainer.model.state_dict().keys())
+    with contextlib.redirect_stdout(io.StringIO()):
+        trainer.test(data_loader=loaders, modes=['test'])                         # :124-158: load_state_dict, forward, Metrics
+    csv = os.path.join(str(tmp_path), 'STC-GNN_eval-bi-metrics.csv')
+    assert os.path.exists(csv) and 'Macro-F1' in open(csv).read()

@@ -23,7 +23,7 @@ from oracle import stc_oracle as O
 from oracle.kernel_emul import EmulatedKernels
 from stc_hip import CsrGraph, ops
 from tests.conftest import REPO, load_golden, rel_err, sub_dict
-from tests.golden.make_golden import synth_inputs
+from tests.golden.make_golden import bench_path_inputs, synth_inputs
 
 FWD = 2e-6       # CPU-emulated bound, forward
 GRAD = 5e-6      # CPU-emulated bound, gradients
@@ -261,6 +261,51 @@ def test_large_n10000_against_dense_reference_rows():
     with torch.no_grad():
         out = cell(graph, s['Gc'], s['Xt'], s['Ht'])
     _close(out[:, g['rows']], g['Hout'], FWD, 'Ht rows N=10000')
+
+
+def test_large_n10000_gradients_against_dense_reference_rows():
+    """g8b: the same cell WITH backward -- sampled rows of dXt / dHt and the full parameter gradients of the dense reference."""
+    g = _golden('g8b_large_n10000_grads')
+    s = synth_inputs('g8')
+    graph = CsrGraph.from_dense(s.pop('Gs'))
+    s = {k: (v.to(DEV) if isinstance(v, torch.Tensor) else v) for k, v in s.items()}
+    cell = M.STC_Cell(s['N'], s['C'], s['K'], s['K'], s['cin'], s['h']).to(DEV)
+    cell.load_state_dict({'gates.W': s['gates_W'], 'gates.b': s['gates_b'], 'candi.W': s['candi_W'], 'candi.b': s['candi_b']})
+    Xt, Ht = _leaf(s['Xt']), _leaf(s['Ht'])
+    out = cell(graph, s['Gc'], Xt, Ht)
+    rows = g['rows']
+    _close(out[:, rows], g['Hout'], FWD, 'Ht rows N=10000 (g8b)')
+    (out * s['R']).sum().backward()
+    _close(Xt.grad[:, rows], g['dXt'], GRAD, 'dXt rows N=10000')
+    _close(Ht.grad[:, rows], g['dHt'], GRAD, 'dHt rows N=10000')
+    for name, p in (('d_gates_W', cell.gates.W), ('d_gates_b', cell.gates.b), ('d_candi_W', cell.candi.W), ('d_candi_b', cell.candi.b)):
+        _close(p.grad, g[name], 2e-5, name + ' N=10000', gpu_tol=2e-5)
+
+
+@pytest.mark.parametrize('name,C,K', [('g11_bench_c32', 32, 2), ('g12_bench_c64', 64, 2), ('g13_bench_c32_k3', 32, 3)])
+def test_bench_path_against_reference_goldens(monkeypatch, name, C, K):
+    """The path bench.py runs -- csr-fixed STCGNN at C in {32, 64}, hidden 16, encoder + decoder as ONE cell-graph node on the
+    planar / split-operand matrix-core kernels -- against goldens the REFERENCE generated at exactly these widths
+    (STC_GNN.py:185-207 after MGP_Gen, Model_Trainer.py:14-23): prediction, ComboLoss, every parameter gradient, 1e-5."""
+    g = _golden(name)
+    s = bench_path_inputs(C, K)
+    model = _small_model(g, graph_mode='csr-fixed')
+    sd = sub_dict(g, 'sd/')
+    assert sorted(model.state_dict().keys()) == sorted(sd.keys())
+    model.load_state_dict(sd)
+    graph = CsrGraph.from_dense(s['Gs'])
+    calls = []
+    real = ops.stc_cell_graph
+    monkeypatch.setattr(ops, 'stc_cell_graph', lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    yhat = model(X_seq=s['X'].to(DEV), As=graph, Ac=s['Gc'].to(DEV))
+    assert calls, 'the cell-graph path (the one the bench runs) was not taken'
+    _close(yhat, g['yhat'], FWD, f'{name} yhat')
+    loss = O.combo_loss(yhat, s['Y'].to(DEV))
+    assert abs(float(loss.detach()) - float(g['loss'])) < 5e-6
+    loss.backward()
+    grads = dict(model.named_parameters())
+    for k, v in sub_dict(g, 'grad/').items():
+        _close(grads[k].grad, v, GRAD, f'{name} d{k}')
 
 
 @pytest.mark.parametrize('golden', ['g5_sf_shape', 'g7_csr_n1024'])

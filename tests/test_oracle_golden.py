@@ -10,7 +10,7 @@ import torch
 
 from oracle import stc_oracle as O
 from tests.conftest import load_golden, rel_err, sub_dict
-from tests.golden.make_golden import grid_graph_dense, sample_rows, synth_inputs
+from tests.golden.make_golden import bench_path_inputs, grid_graph_dense, sample_rows, synth_inputs
 
 TOL = 1e-6
 
@@ -251,3 +251,39 @@ def test_live_reference_sf_data_adjacency(reference_module):
     A = np.zeros((100, 100), dtype=z['s_adj'].dtype)
     A[r.numpy(), c.numpy()] = 1
     assert np.array_equal(A, z['s_adj'])
+
+
+@pytest.mark.parametrize('name,C,K', [('g11_bench_c32', 32, 2), ('g12_bench_c64', 64, 2), ('g13_bench_c32_k3', 32, 3)])
+def test_g11_g13_bench_path_widths(name, C, K):
+    """The widths the bench runs (C = 32 / 64, hidden 16, K = 2 / 3) through the REFERENCE's encoder-decoder-head: the oracle
+    (dense form and sparse feature-side form) reproduces prediction, ComboLoss and every parameter gradient."""
+    g = load_golden(name)
+    s = bench_path_inputs(C, K)
+    assert abs(float(s['Gs'].double().sum()) - float(g['chk_Gs'])) < 1e-9 and abs(float(s['X'].double().sum()) - float(g['chk_X'])) < 1e-9
+    assert abs(float(s['Gc'].double().sum()) - float(g['chk_Gc'])) < 1e-6
+    for conv, Gs in ((O.bdg_dif, s['Gs']), (O.bdg_dif_sparse, s['Gs'].t().contiguous().to_sparse_csr())):
+        sd = {k: _leaf(v) for k, v in sub_dict(g, 'sd/').items()}
+        yhat = O.encdec_forward(s['X'], Gs, s['Gc'], sd, K, K, int(g['h']), int(g['layers']), int(g['horizon']), conv=conv)
+        assert rel_err(yhat, g['yhat']) < TOL
+        loss = O.combo_loss(yhat, s['Y'])
+        assert abs(float(loss.detach()) - float(g['loss'])) < 2e-6
+        loss.backward()
+        for k, v in sub_dict(g, 'grad/').items():
+            assert rel_err(sd[k].grad, v) < (2e-6 if conv is O.bdg_dif else 5e-6), (k, conv.__name__)
+
+
+def test_g8b_large_n_gradients_sparse_oracle():
+    """N = 10 000 with backward: the sparse feature-side oracle (the CPU baseline's form) against sampled rows of the dense
+    reference's input gradients and its full parameter gradients."""
+    g = load_golden('g8b_large_n10000_grads')
+    s = synth_inputs('g8')
+    GsT = s['Gs'].t().contiguous().to_sparse_csr()
+    Xt, Ht = _leaf(s['Xt']), _leaf(s['Ht'])
+    p = [_leaf(s[k]) for k in ('gates_W', 'gates_b', 'candi_W', 'candi_b')]
+    out = O.stc_cell(GsT, s['Gc'], Xt, Ht, *p, s['K'], s['K'], conv=O.bdg_dif_sparse)
+    rows = g['rows']
+    assert rel_err(out[:, rows], g['Hout']) < 2e-6
+    (out * s['R']).sum().backward()
+    assert rel_err(Xt.grad[:, rows], g['dXt']) < 5e-6 and rel_err(Ht.grad[:, rows], g['dHt']) < 5e-6
+    for t, k in zip(p, ('d_gates_W', 'd_gates_b', 'd_candi_W', 'd_candi_b')):
+        assert rel_err(t.grad, g[k]) < 2e-5, k

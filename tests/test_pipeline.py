@@ -180,35 +180,86 @@ def test_metrics_match_the_reference(where):
         assert np.allclose(list(got.values()), g[f'values{s}'].numpy(), rtol=0, atol=1.01e-4), (got, g[f'values{s}'])
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize('storage', ['f32', 'bf16'])
-def test_bench_line_contract(storage):
-    """bench.py prints ONE JSON line with the driver's contract fields, the roofline object of the aggregation launches and
-    (fp32, one GPU) the CPU baseline; run here on a small grid so that it takes seconds."""
+def _run_bench(extra, env=None, timeout=900):
     import json
     import subprocess
     import sys
-    cmd = [sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1', '--grid', '12',
-           '--batch-per-gpu', '2', '--obs', '3', '--pred', '2', '--storage', storage]
-    if storage == 'bf16':
-        cmd.append('--no-cpu-baseline')
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
+    cmd = [sys.executable, os.path.join(REPO, 'bench.py'), '--steps', '2', '--warmup', '1', '--batch-per-gpu', '2', '--obs', '3', '--pred', '2'] + extra
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=None if env is None else {**os.environ, **env})
+    assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.strip().split('\n') if l.startswith('{')]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('storage', ['f32', 'bf16'])
+def test_bench_line_contract(storage):
+    """bench.py prints ONE JSON line with the driver's contract fields, the roofline object of the plain aggregation launches
+    (SURVEY 8(d3) unit beside it) and (fp32, one GPU) the CPU baseline; run here on a small grid so that it takes seconds."""
+    d = _run_bench(['--gpus', '1', '--grid', '12', '--storage', storage] + (['--no-cpu-baseline'] if storage == 'bf16' else []),
+                   env={'STC_BENCH_NO_DENSE_ANCHOR': '1'})
     for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
-                'data', 'config', 'roofline'):
+                'data', 'config', 'roofline', 'n_ranks_seen', 'step_breakdown'):
         assert key in d, key
     assert d['n_gpus'] == 1 and d['steps'] == 2 and d['warmup'] == 1 and d['unit'] == 'samples/s' and d['higher_is_better'] is True
     assert d['scaling'] == 'weak' and d['vs_baseline'] is None and d['data'] == 'synthetic' and d['dtype'] == storage
-    assert d['value'] > 0 and abs(d['value'] - 2 * 1e3 / d['ms_per_step']) < 1e-6 * d['value']
+    assert d['value'] > 0 and abs(d['value'] - 2 * 1e3 / d['ms_per_step']) < 1e-6 * d['value'] and d['n_ranks_seen'] == 1
     assert 'workload' in d['config'] and 'model' not in d['config']
     r = d['roofline']
-    assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0 and r['launches'] > 0
-    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12 and r['algorithmic_bytes_per_launch'] > 0
+    assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0 and r['launches'] > 0 and 'spmm_bcsr_kernel' in r['kernel']
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12
+    N, nnz, C, B = 144, 4 * 3 + 40 * 5 + 100 * 8, 32, 2                      # 12 x 12 queen grid
+    esize = 2 if storage == 'bf16' else 4
+    assert r['algorithmic_bytes_per_launch'] == nnz * 8 + 4 * (N + 1) + 2 * B * N * C * 16 * esize     # SURVEY 8(d3), verbatim
+    assert r['traffic'] is None                                              # no PMC pass over this configuration: never a stale number
+    u = r['unit_d3']
+    assert u['algorithmic_bytes'] == nnz * 8 + 4 * (N + 1) + 2 * N * C * 32 * esize and u['avg_launch_us'] > 0
+    assert r['aggregate']['launches'] >= r['launches'] and r['aggregate']['achieved'] > 0
+    sb = d['step_breakdown']
+    assert sb['fwd_loss_bwd_ms'] > 0 and sb['adam_ms'] > 0 and sb['ms_per_step_without_launch_events'] > 0
+    assert sb['fwd_loss_bwd_ms'] + sb['grad_allreduce_ms'] + sb['adam_ms'] <= d['ms_per_step'] * 1.05
     names = set(d['kernels'])
     assert any(n.endswith('_bf16') for n in names) == (storage == 'bf16')
     if storage == 'f32':
         c = d['cpu_baseline']
         assert c['kind'] == 'port' and c['cores'] >= 1 and c['value'] > 0 and c['unit'] == 'samples/s' and 'sample' in c
+        assert len(c['shots_s']['layer0']) == 4 and len(c['shots_s']['wide']) == 4     # 1 warm-up + 3 timed
+
+
+@pytest.mark.gpu
+def test_bench_launches_its_own_ranks():
+    """``python bench.py --gpus 2`` with no launcher environment (the driver's plain form) starts torch.distributed.run as a
+    child, both ranks take part in the collectives, rank 0 prints the one line.  A one-GPU box cannot run RCCL between two
+    ranks, so the ranks share device 0 and talk over gloo (test hooks of stc_hip.dist.init_from_env); the launch path,
+    sharding, barrier / max-over-ranks timing and tear-down are the ones an 8-GPU RCCL run takes."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    import json
+    import subprocess
+    import sys
+    cmd = [sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--grid', '32', '--batch-per-gpu', '2',
+           '--obs', '3', '--pred', '2']
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env={**env, 'STC_DIST_BACKEND': 'gloo', 'STC_DIST_ONE_DEVICE': '1'})
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.strip().split('\n') if l.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['n_ranks_seen'] == 2 and d['config']['global_batch'] == 4 and d['config']['parallelism'] == 'batch-shard x2'
+    assert abs(d['value'] - 4 * 1e3 / d['ms_per_step']) < 1e-6 * d['value'] and 'cpu_baseline' not in d
+    assert d['step_breakdown']['grad_allreduce_ms'] > 0
+
+
+@pytest.mark.gpu
+def test_bench_under_torchrun_single_rank_goes_through_rccl():
+    """The driver's N > 1 form with N = 1: torch.distributed.run sets RANK, so the process group IS initialised (backend
+    nccl = RCCL) and the barrier, the max-over-ranks all-reduce and destroy_process_group run on the real communicator."""
+    import json
+    import subprocess
+    import sys
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1', '--master-port', '29533',
+           os.path.join(REPO, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1', '--grid', '12', '--batch-per-gpu', '2', '--obs', '3', '--pred', '2',
+           '--no-cpu-baseline']
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.strip().split('\n') if l.startswith('{')][0])
+    assert d['n_gpus'] == 1 and d['n_ranks_seen'] == 1

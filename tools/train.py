@@ -2,6 +2,8 @@
 """CLI counterpart of the reference's ``framework/Main.py``: same flags, MI355X path.
 
     python tools/train.py -city SF -in /path/to/data -epoch 5            # learned graphs, reference semantics
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/train.py -city SF ...
+                                                                         # batch-sharded: one rank per GPU, RCCL all-reduce
 """
 import argparse
 import os
@@ -10,6 +12,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (REPO, os.path.join(REPO, 'stc-gnn_amd')):
     sys.path.insert(0, p)
 from stc_hip import data as sdata          # noqa: E402
+from stc_hip import dist as sdist          # noqa: E402
 from stc_hip.trainer import Trainer        # noqa: E402
 
 CITY = {'SF': dict(C=5, H=10, W=10, time_slice=4), 'NYC': dict(C=8, H=20, W=15, time_slice=6), 'CHI': dict(C=4, H=10, W=24, time_slice=4)}
@@ -31,6 +34,9 @@ ap.add_argument('-dr', '--decay_rate', type=float, default=1e-4)
 ap.add_argument('-epoch', '--num_epochs', type=int, default=100)
 ap.add_argument('-test', '--test_only', type=int, default=0, choices=[0, 1])
 params = vars(ap.parse_args())
+rank, world, local = sdist.init_from_env()                      # under torchrun: one rank per GPU, each on its own device
+if world > 1:
+    params['device'] = f'cuda:{local}'
 params.update(CITY[params['city']], model='STC-GNN')
 params['output_dir'] = os.path.join(params['output_dir'], params['city'])
 data = sdata.load_incidents(os.path.join(params['input_dir'], f'{params["city"]}-incidents-{params["time_slice"]}h.npz'))
@@ -39,4 +45,5 @@ trainer = Trainer(params, data)
 if not params['test_only']:
     trainer.train(loaders)
 res = trainer.test(loaders)
-print({m: {k: v for k, v in r.items() if k in ('bce', 'mae', 'epoch')} for m, r in res.items()})
+if rank == 0:
+    print({m: {k: v for k, v in r.items() if k in ('bce', 'mae', 'epoch')} for m, r in res.items()})
