@@ -359,14 +359,23 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
                 X3 zc[NRB];
 #pragma unroll
                 for (int rb = 0; rb < NRB; ++rb) {
-                    const float* trow = tr + ((wave * NRB + rb) * 16 + x) * TRS;          // this lane's row of R*H
-                    f32x4 a4 = kZero4, b4 = kZero4;
-                    if (PL == 1) {
-                        if (g < 2) { a4 = cur[0][rb].a; b4 = cur[0][rb].b; }              // Xt columns 8g..8g+7
-                        else { a4 = *reinterpret_cast<const f32x4*>(trow + 8 * (g - 2)); b4 = *reinterpret_cast<const f32x4*>(trow + 8 * (g - 2) + 4); }
-                    } else {
-                        if (g < 2) { a4 = *reinterpret_cast<const f32x4*>(trow + 8 * g); b4 = *reinterpret_cast<const f32x4*>(trow + 8 * g + 4); }
-                        else if (g == 2) a4 = cur[0][rb].a;                               // the narrow input columns
+                    // this lane's row of R*H, columns 8(g&1)..: EVERY lane reads the tile and the row fragments are chosen by VALUE.
+                    // (Branching between "a register of cur" and "a load from the tile" made the compiler select between two
+                    // ADDRESSES instead: cur[0] was stored to scratch on every node -- 64 B x 64 lanes x 250 880 nodes = 1.03 GB of
+                    // dead stores per launch, the 1.39x HBM traffic rocprofv3 showed for this kernel, profiles/r02/.)
+                    const float* trow = tr + ((wave * NRB + rb) * 16 + x) * TRS + 8 * (g & 1);
+                    const f32x4 ta = *reinterpret_cast<const f32x4*>(trow), tb = *reinterpret_cast<const f32x4*>(trow + 4);
+                    const f32x4 xa = cur[0][rb].a, xb = cur[0][rb].b;
+                    f32x4 a4, b4;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (PL == 1) {                                                    // [Xt columns 8g.. | R*H columns 8(g-2)..]
+                            a4[i] = g < 2 ? xa[i] : ta[i];
+                            b4[i] = g < 2 ? xb[i] : tb[i];
+                        } else {                                                          // [R*H | the narrow input columns | zero]
+                            a4[i] = g < 2 ? ta[i] : (g == 2 ? xa[i] : 0.f);
+                            b4[i] = g < 2 ? tb[i] : 0.f;
+                        }
                     }
                     zc[rb] = split8(a4, b4);
                 }
