@@ -330,13 +330,21 @@ __global__ __launch_bounds__(SPMM_THREADS) void spmm_wave_row_kernel(
 constexpr int BR = STC_SPMM_BLOCK_ROWS;
 constexpr int BC_CAP = 512;           // block entries staged in LDS per workgroup
 
-template <int VPT, int MODE, int BC_BLOCKS>
+// PIPE = 1: the gather is software-pipelined -- batches of PU = 6 neighbour rows (the 8-neighbour grid's interior blocks list
+// 18 rows: three full batches, no remainder; graph.py pads every block's list to a multiple of 6 with zero-weight repeats
+// of its last column), the NEXT batch's row loads issued before the current batch is accumulated, so that a wave always
+// has 6 KiB in flight instead of alternating between "4 loads outstanding" and "none while it multiplies"; the old form
+// also walked a remainder (18 = 4 x 4 + 2) one exposed round trip per row.
+constexpr int PU = 6;
+
+template <int VPT, int MODE, int BC_BLOCKS, int PIPE = 0, int FULL = 0>      // FULL: F4 is a multiple of the columns the waves of a row block cover
 __global__ __launch_bounds__(SPMM_THREADS) void spmm_bcsr_kernel(
     const int* __restrict__ blk_ptr, const int* __restrict__ blk_cols, const float* __restrict__ blk_vals,
     int n_rows, int n_cols, const float4* __restrict__ X, int F4, int n_blocks, int n_tiles, EpiArgs ep) {
+    static_assert(BR == 4, "the pipelined gather reads one float4 of values per entry");
     __shared__ int s_bp[BC_BLOCKS + 1];
-    __shared__ int s_col[BC_CAP];
-    __shared__ float s_val[BC_CAP * BR];
+    __shared__ __attribute__((aligned(16))) int s_col[BC_CAP];
+    __shared__ __attribute__((aligned(16))) float s_val[BC_CAP * BR];
 
     const int tile = stc_xcd_tile(blockIdx.x, n_tiles);
     if (tile < 0) return;
@@ -401,6 +409,69 @@ __global__ __launch_bounds__(SPMM_THREADS) void spmm_bcsr_kernel(
             };
 
             int j = js;
+            if constexpr (PIPE) {
+                // rows of one batch: PU neighbour rows, this lane's VPT pieces of each (second gathered operand summed in).
+                // The six column indices come out of LDS in three 8-byte reads issued together (one wait, not six).
+                constexpr bool full_cols = FULL != 0;                     // every lane's pieces exist: no per-load column guard
+                auto issue = [&](int j0, float4 (&x)[PU][VPT]) {
+                    const int2* cp = reinterpret_cast<const int2*>(s_col + j0);
+                    const int2 c01 = cp[0], c23 = cp[1], c45 = cp[2];
+                    const int cc[PU] = {c01.x, c01.y, c23.x, c23.y, c45.x, c45.y};
+#pragma unroll
+                    for (int u = 0; u < PU; ++u) {
+                        const int c = __builtin_amdgcn_readfirstlane(cc[u]);
+                        const float4* xr = Xb + (size_t)c * F4;
+#pragma unroll
+                        for (int p = 0; p < VPT; ++p) {
+                            const int ch = cb + lane + 64 * p;
+                            if (full_cols) {
+                                x[u][p] = xr[ch];
+                                if (MODE == EP_SUM2) {
+                                    const float4 t = (ep.X2 + (size_t)b * n_cols * F4 + (size_t)c * F4)[ch];
+                                    x[u][p].x += t.x; x[u][p].y += t.y; x[u][p].z += t.z; x[u][p].w += t.w;
+                                }
+                            } else {
+                                x[u][p] = ch < F4 ? xr[ch] : make_float4(0.f, 0.f, 0.f, 0.f);
+                                if (MODE == EP_SUM2 && ch < F4) {
+                                    const float4 t = (ep.X2 + (size_t)b * n_cols * F4 + (size_t)c * F4)[ch];
+                                    x[u][p].x += t.x; x[u][p].y += t.y; x[u][p].z += t.z; x[u][p].w += t.w;
+                                }
+                            }
+                        }
+                    }
+                };
+                auto consume = [&](int j0, const float4 (&x)[PU][VPT]) {
+                    const float4* vp = reinterpret_cast<const float4*>(s_val + (size_t)j0 * BR);      // BR = 4 values per entry: one 16-byte read each
+                    float4 vv[PU];
+#pragma unroll
+                    for (int u = 0; u < PU; ++u) vv[u] = vp[u];
+#pragma unroll
+                    for (int u = 0; u < PU; ++u) {
+                        const float v[BR] = {vv[u].x, vv[u].y, vv[u].z, vv[u].w};
+#pragma unroll
+                        for (int r = 0; r < BR; ++r)
+#pragma unroll
+                            for (int p = 0; p < VPT; ++p) fma4(acc[r][p], v[r], x[u][p]);
+                    }
+                };
+                // (a workgroup whose lists outgrow the staged segment -- not a sparse graph any more -- or whose list starts at an
+                // odd entry -- an unpadded plan: the 8-byte LDS reads want an even index -- takes the remainder loop)
+                const int jfull = (je <= BC_CAP && (js & 1) == 0) ? js + (je - js) / PU * PU : js;
+                if (j < jfull) {
+                    float4 xa[PU][VPT], xb[PU][VPT];
+                    issue(j, xa);
+                    while (true) {
+                        if (j + PU < jfull) issue(j + PU, xb);
+                        consume(j, xa);
+                        j += PU;
+                        if (j >= jfull) break;
+                        if (j + PU < jfull) issue(j + PU, xa);
+                        consume(j, xb);
+                        j += PU;
+                        if (j >= jfull) break;
+                    }
+                }
+            } else
             for (; j + 4 <= je; j += 4) {
                 int c[4];
                 float v[4][BR];
@@ -427,7 +498,7 @@ __global__ __launch_bounds__(SPMM_THREADS) void spmm_bcsr_kernel(
 #pragma unroll
                         for (int p = 0; p < VPT; ++p) fma4(acc[r][p], v[u][r], x[u][p]);
             }
-            for (; j < je; ++j) {
+            for (; j < je; ++j) {                 // remainder (PIPE: lists that are not a multiple of PU, i.e. unpadded plans)
                 int c;
                 float v[BR];
                 entry(j, c, v);
@@ -539,8 +610,16 @@ int launch_vector(const char* who, const GraphArgs& g, int n_rows, int n_cols, c
         const int n_tiles = (n_blocks + blocks - 1) / blocks;
         const int per = (n_tiles + stc::kNumXcd - 1) / stc::kNumXcd;
         const dim3 grid(per * stc::kNumXcd, batch), block(SPMM_THREADS);
-#define STC_BCSR_GO(VPT_, BLK_) hipLaunchKernelGGL((spmm_bcsr_kernel<VPT_, MODE, BLK_>), grid, block, 0, s, g.blk_ptr, g.blk_cols, g.blk_vals, \
-                                                   n_rows, n_cols, X4, F4, n_blocks, n_tiles, ep)
+        // The pipelined gather is used where it measured faster on MI355X (profiles/r02/c_kbench_spmm.txt): the plain product
+        // Y = alpha S.X with full column blocks (F=1024, B=1: 99 -> 86 us; F=512, B=5: 218 -> 210 us).  With a Y0 operand or an
+        // epilogue (sum / blend forms) the extra live registers cost what the pipelining gains (equal or slower): old loop.
+        // STC_SPMM_PIPE=0 (A/B runs): the un-pipelined gather loop everywhere
+        static const bool pipe_on = [] { const char* e = std::getenv("STC_SPMM_PIPE"); return !(e && e[0] == '0'); }();
+        const bool pipe = pipe_on && MODE == EP_PLAIN && (ep.Y0 == nullptr || ep.beta == 0.f);
+#define STC_BCSR_GO(VPT_, BLK_) do { if (pipe && BLK_ == 2 && F4 % (128 * VPT_) == 0) hipLaunchKernelGGL((spmm_bcsr_kernel<VPT_, MODE, 2, (MODE == EP_PLAIN), (MODE == EP_PLAIN)>), grid, block, 0, s, g.blk_ptr, g.blk_cols, g.blk_vals, \
+                                                   n_rows, n_cols, X4, F4, n_blocks, n_tiles, ep); \
+                                     else hipLaunchKernelGGL((spmm_bcsr_kernel<VPT_, MODE, BLK_, 0, 0>), grid, block, 0, s, g.blk_ptr, g.blk_cols, g.blk_vals, \
+                                                   n_rows, n_cols, X4, F4, n_blocks, n_tiles, ep); } while (0)
         if (blocks == 2) {            // two waves per block: each covers every other column block of 64*VPT float4
             if (F4 <= 128) STC_BCSR_GO(1, 2); else if (F4 <= 256) STC_BCSR_GO(2, 2); else STC_BCSR_GO(4, 2);
         } else if (blocks == 4) {

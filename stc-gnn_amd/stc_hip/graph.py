@@ -33,6 +33,7 @@ def _csr_from_coo(rows: np.ndarray, cols: np.ndarray, vals: np.ndarray, n: int):
 
 
 BLOCK_ROWS = 4      # = STC_SPMM_BLOCK_ROWS of include/stc_hip.h
+BLOCK_BATCH = 6     # = PU of csrc/stc_spmm.hip: neighbour rows per pipelined gather batch
 
 
 def _row_block_plan(rowptr: np.ndarray, colidx: np.ndarray, val: np.ndarray, n: int):
@@ -50,7 +51,27 @@ def _row_block_plan(rowptr: np.ndarray, colidx: np.ndarray, val: np.ndarray, n: 
     blk_ptr = np.searchsorted(uniq // max(n, 1), np.arange(n_blocks + 1))
     vals = np.zeros((uniq.size, BLOCK_ROWS), dtype=np.float32)
     vals[inverse, row_of % BLOCK_ROWS] = val
-    return dict(blk_ptr=blk_ptr.astype(np.int32), blk_cols=(uniq % max(n, 1)).astype(np.int32), blk_vals=vals)
+    cols = uniq % max(n, 1)
+    distinct = int(uniq.size)
+    # Every block's list is padded to a multiple of BLOCK_BATCH entries with zero-weight repeats of its last column (a row the
+    # block fetches anyway: the repeat is an L1 / L2 hit): the kernel's pipelined gather then runs in whole batches with no
+    # remainder loop.  The 8-neighbour grid's interior blocks list 18 columns and need no padding at all.
+    counts = np.diff(blk_ptr)
+    padded = -(-counts // BLOCK_BATCH) * BLOCK_BATCH
+    if (padded != counts).any():
+        new_ptr = np.concatenate([[0], np.cumsum(padded)])
+        dst = np.repeat(new_ptr[:-1] - blk_ptr[:-1], counts) + np.arange(uniq.size)      # where each real entry goes
+        out_cols = np.zeros(int(new_ptr[-1]), dtype=np.int64)
+        out_vals = np.zeros((int(new_ptr[-1]), BLOCK_ROWS), dtype=np.float32)
+        out_cols[dst] = cols
+        out_vals[dst] = vals
+        pad_n = padded - counts
+        has = counts > 0
+        pad_dst = np.repeat(new_ptr[:-1] + counts, pad_n) + (np.arange(int(pad_n.sum())) - np.repeat(np.cumsum(pad_n) - pad_n, pad_n))
+        last_col = np.where(has, cols[np.maximum(blk_ptr[1:] - 1, 0)] if uniq.size else 0, 0)
+        out_cols[pad_dst] = np.repeat(last_col, pad_n)
+        cols, vals, blk_ptr = out_cols, out_vals, new_ptr
+    return dict(blk_ptr=blk_ptr.astype(np.int32), blk_cols=cols.astype(np.int32), blk_vals=vals, distinct=distinct)
 
 
 class CsrGraph:
@@ -85,10 +106,13 @@ class CsrGraph:
         perm = inv_f[b_order]                      # position in fwd order of each bwd entry
         self._host = dict(fwd_rowptr=f_rp, fwd_colidx=f_ci, fwd_val=f_v,
                           bwd_rowptr=b_rp, bwd_colidx=b_ci, bwd_val=b_v, bwd_perm=perm.astype(np.int64))
+        distinct = {}
         for side, (rp, ci, v) in (('fwd', (f_rp, f_ci, f_v)), ('bwd', (b_rp, b_ci, b_v))):
-            self._host.update({f'{side}_{k}': a for k, a in _row_block_plan(rp, ci, v, n).items()})
+            plan = _row_block_plan(rp, ci, v, n)
+            distinct[side] = plan.pop('distinct')
+            self._host.update({f'{side}_{k}': a for k, a in plan.items()})
         #: distinct neighbour rows fetched per output row by the row-blocked kernel (CSR: nnz / n)
-        self.fetches_per_row = tuple(self._host[f'{s_}_blk_cols'].size / max(n, 1) for s_ in ('fwd', 'bwd'))
+        self.fetches_per_row = tuple(distinct[s_] / max(n, 1) for s_ in ('fwd', 'bwd'))
         self._dev: Dict[torch.device, Dict[str, torch.Tensor]] = {}
         if device is not None:
             self.on(torch.device(device))

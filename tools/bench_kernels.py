@@ -88,7 +88,7 @@ def main():
         us = timeit(lambda i: Yc[i % R].copy_(Xc[i % R]), a.iters)
         report('torch copy (HBM reference)', us, 2 * Xc[0].numel() * 4)
         return
-    for L in (32, 20):
+    for L in ((32, 20, 16) if a.only == 'spmm' else (32, 20)):
         F = C * L
         Xs = [torch.randn(B, N, F, device=dev) for _ in range(R)]
         Ys = [torch.empty(B, N, F, device=dev) for _ in range(R)]
