@@ -78,21 +78,25 @@ def test_row_block_plan_reconstructs_the_graph():
     """Host logic of the row-blocked SpMM: the BCSR arrays must hold exactly the entries of the CSR matrix."""
     import numpy as np
     from stc_hip import CsrGraph
-    from stc_hip.graph import BLOCK_ROWS
+    from stc_hip.graph import BLOCK_BATCH, BLOCK_ROWS
     for g in (CsrGraph.queen_grid(13, 9), CsrGraph.queen_grid(7, 5, permute_seed=3), CsrGraph.from_dense(torch.zeros(6, 6))):
         dense = g.to_dense().numpy()
         for side, want in (('fwd', dense.T), ('bwd', dense)):
             h = g._host
             bp, bc, bv = h[f'{side}_blk_ptr'], h[f'{side}_blk_cols'], h[f'{side}_blk_vals']
             got = np.zeros_like(want)
+            assert np.all(np.diff(bp) % BLOCK_BATCH == 0)              # whole gather batches: no remainder loop in the kernel
             for blk in range(len(bp) - 1):
-                cols = bc[bp[blk]:bp[blk + 1]]
-                assert np.all(np.diff(cols) > 0)                       # distinct and sorted within a block
+                cols, vals = bc[bp[blk]:bp[blk + 1]], bv[bp[blk]:bp[blk + 1]]
+                real = np.concatenate([[True], np.diff(cols) > 0]) if cols.size else np.zeros(0, bool)
+                assert np.all(np.diff(cols) >= 0) and real[:int(real.sum())].all()   # sorted, distinct, then the padding
+                assert not vals[~real].any() and np.all(cols[~real] == cols[real][-1] if (~real).any() else True)   # zero-weight repeats of the last column
+                assert (~real).sum() < BLOCK_BATCH
                 for r in range(BLOCK_ROWS):
                     if blk * BLOCK_ROWS + r < g.n:
-                        got[blk * BLOCK_ROWS + r, cols] = bv[bp[blk]:bp[blk + 1], r]
+                        got[blk * BLOCK_ROWS + r, cols[real]] = vals[real, r]
                     else:
-                        assert not bv[bp[blk]:bp[blk + 1], r].any()    # rows past the end carry zeros
+                        assert not vals[:, r].any()                    # rows past the end carry zeros
             assert np.array_equal(got, want)
             assert bp[-1] == bc.size == bv.shape[0] and bv.shape[1] == BLOCK_ROWS
 
