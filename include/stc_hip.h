@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define STC_ABI_VERSION 10
+#define STC_ABI_VERSION 11
 #define STC_MAX_K 4          /* highest Chebyshev order (Ks, Kc) the node kernels accept */
 
 #define STC_OK 0
@@ -333,15 +333,45 @@ int stc_cell_gates_bwd_planar_f32(const float* X, const float* H, const float* S
                                   void* workspace, size_t workspace_bytes,
                                   int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream);
 
-/* Y = sum_i add[i] + S x (X [+ X2]) on rows of C*h floats (h = 16): the gradient of a state from the pieces its consumers
- * left -- direct planes as addends (add[i]: columns [add_off[i], add_off[i]+h) of rows of add_ld[i] floats, multiples of 4;
- * a contiguous plane is ld = h, off = 0), aggregated planes X, X2 through the transposed graph.  n_add <= 5, X2 may be NULL.
+/* ---- planar cell convolutions of Chebyshev order K = 3 (C = 32, h = 16) ----------------------------------------------
+ * The planar form above for BDG_Dif.cheby_poly order 3 (STC_GNN.py:24-29, 35-39; BASELINE configuration 4).  Zx[n] / Zh[n],
+ * n < K: T_n(S) applied to the plane on the X side / the H side of the [X | H] row -- the plane itself, S x plane and
+ * 2 S (S x plane) - plane, the feature-side Chebyshev recurrence -- each (nodes, C, h); a narrow input (layer 0) has Zx[n]
+ * (nodes, C, Lw - h) with Lw - h in 1..4.  A state's three planes are computed once and shared by the cells that consume it.
+ *   gates_fwd: U, Rg, RH = R*H as stc_cell_gates_fwd_planar_f32.            W (K*K*Lw, 2h)
+ *   cand_fwd:  candidate convolution on [X | R*H] (Zh[n] = T_n(S) R*H) with the tanh + GRU blend epilogue of
+ *              stc_cell_blend_fwd_f32: Cand, Hnew from U and the previous state H.      W (K*K*Lw, h)
+ *   *_bwd:     gradients of all 2K planes (dZx[n], dZh[n]; dZx may be NULL for a narrow input) and of W, b; the gate /
+ *              blend backward run as prologues exactly as in stc_cell_gates_bwd_planar_f32 / stc_cell_cand_bwd_f32.
+ * The gradient of a plane's source is  d0 - d2 + S^T (d1 + 2 S^T d2)  (Clenshaw form of sum_n T_n(S)^T d_n): two
+ * stc_spmm_sum_f32 launches with alpha / add_scale.  stc_cell_planar_k_supported() tells whether (K, C, h) is built. */
+int stc_cell_planar_k_supported(int32_t K, int32_t C, int32_t h);
+int stc_cell_gates_fwd_planar_k_f32(const float* const* Zx, const float* const* Zh, int32_t K, const float* Tc, const float* W, const float* bias,
+                                    float* U, float* Rg, float* RH, int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream);
+int stc_cell_cand_fwd_planar_k_f32(const float* const* Zx, const float* const* Zh, int32_t K, const float* Tc, const float* W, const float* bias,
+                                   const float* U, const float* H, float* Cand, float* Hnew,
+                                   int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream);
+int stc_cell_gates_bwd_planar_k_f32(const float* const* Zx, const float* const* Zh, int32_t K, const float* Tc, const float* W,
+                                    const float* dRH, const float* Cand, const float* U, const float* Rg, const float* dHnew,
+                                    float* const* dZx, float* const* dZh, float* dW, float* db, float* dH,
+                                    void* workspace, size_t workspace_bytes, int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream);
+int stc_cell_cand_bwd_planar_k_f32(const float* const* Zx, const float* const* Zh, int32_t K, const float* Tc, const float* W,
+                                   const float* dHnew, const float* U, const float* Cand,
+                                   float* const* dZx, float* const* dZh, float* dW, float* db,
+                                   void* workspace, size_t workspace_bytes, int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream);
+
+/* Y = sum_i add_scale[i] add[i] + alpha S x (X [+ X2]) on rows of C*h floats (h = 16): the gradient of a state from the pieces
+ * its consumers left -- direct planes as addends (add[i]: columns [add_off[i], add_off[i]+h) of rows of add_ld[i] floats,
+ * multiples of 4; a contiguous plane is ld = h, off = 0), aggregated planes X, X2 through the transposed graph.
+ * n_add <= STC_SPMM_SUM_MAX_ADD, X2 may be NULL, add_scale may be NULL (all +1).  alpha / add_scale serve the order-3 form
+ * (d0 - d2 + S^T (d1 + 2 S^T d2)); alpha = 1 and no scales give the order-2 sum.
  * dY != NULL: the epilogue also writes dY = Y*U*(1-Cand^2), the blend backward (STC_GNN.py:76-78) of the cell that owns the
  * state, from that cell's saved U and Cand -- the gradient is then not read again just to form it. */
+#define STC_SPMM_SUM_MAX_ADD 8
 int stc_spmm_sum_f32(const int32_t* rowptr, const int32_t* colidx, const float* val,
                      const int32_t* blk_ptr, const int32_t* blk_cols, const float* blk_vals,
-                     int32_t n_rows, int32_t n_cols, const float* X, const float* X2,
-                     int32_t n_add, const float* const* add, const int32_t* add_ld, const int32_t* add_off,
+                     int32_t n_rows, int32_t n_cols, const float* X, const float* X2, float alpha,
+                     int32_t n_add, const float* const* add, const int32_t* add_ld, const int32_t* add_off, const float* add_scale,
                      float* Y, const float* U, const float* Cand, float* dY,
                      int32_t batch, int32_t C, int32_t h, void* stream);
 

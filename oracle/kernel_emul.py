@@ -264,15 +264,52 @@ class EmulatedKernels:
         if dZs[0] is not None:
             dZs[0].copy_(rows[0][..., :cin]); dZs[1].copy_(rows[1][..., :cin])  # d X plane, d SX plane
 
-    def spmm_sum(self, rowptr, colidx, val, plan, X, X2, addends, Y, blend=None):
+    def spmm_sum(self, rowptr, colidx, val, plan, X, X2, addends, Y, blend=None, alpha=1.0):
         B, n, Cc, h = Y.shape
         src = X if X2 is None else X + X2
-        self.csr_spmm(rowptr, colidx, val, n, n, src.reshape(B, n, Cc * h), None, Y.view(B, n, Cc * h), 1.0, 0.0)
-        for t, off in addends:
-            Y += t[..., off:off + h]
+        self.csr_spmm(rowptr, colidx, val, n, n, src.reshape(B, n, Cc * h), None, Y.view(B, n, Cc * h), float(alpha), 0.0)
+        for ent in addends:
+            t, off = ent[0], ent[1]
+            Y += (ent[2] if len(ent) > 2 else 1.0) * t[..., off:off + h]
         if blend is not None:
             U, Cand, dY = blend
             dY.copy_(Y * U * (1 - Cand * Cand))
+
+    # planar cell convolutions of order K (stc_cell_*_planar_k_f32): composed from the slab-form twins on concatenated planes
+    def cell_planar_k_supported(self, K, Cc, h) -> bool:
+        return K == 3 and h == 16
+
+    @staticmethod
+    def _cat_planes(Zx, Zh):
+        return [torch.cat([x, hh], -1) for x, hh in zip(Zx, Zh)]            # reference column order [X | H]
+
+    def cell_gates_fwd_planar_k(self, Zx, Zh, Tc, W, bias, U, Rg, RH):
+        cin, h = Zx[0].shape[-1], Zh[0].shape[-1]
+        CandIn = torch.empty(Zh[0].shape[:-1] + (cin + h,), dtype=W.dtype)
+        self.cell_gates_fwd(self._cat_planes(Zx, Zh), Tc, W, bias, Zh[0], U, Rg, CandIn)
+        RH.copy_(CandIn[..., cin:])
+
+    def cell_cand_fwd_planar_k(self, Zx, Zh, Tc, W, bias, U, H, Cand, Hnew):
+        self.cell_blend_fwd(self._cat_planes(Zx, Zh), Tc, W, bias, U, H, Cand, Hnew)
+
+    def _split_planes(self, rows, dZx, dZh, cin):
+        for n, r in enumerate(rows):
+            dZh[n].copy_(r[..., cin:])
+            if dZx[n] is not None:
+                dZx[n].copy_(r[..., :cin])
+
+    def cell_gates_bwd_planar_k(self, Zx, Zh, Tc, W, dRH, Cand, U, Rg, dHnew, dZx, dZh, dW, db, dH):
+        cin, h = Zx[0].shape[-1], Zh[0].shape[-1]
+        rows = [torch.empty(Zh[0].shape[:-1] + (cin + h,), dtype=W.dtype) for _ in Zh]
+        dCandIn = torch.cat([torch.zeros_like(Zx[0]), dRH], -1)               # only the R*H part is read
+        self.cell_gates_bwd(self._cat_planes(Zx, Zh), Tc, W, dCandIn, None, Zh[0], U, Rg, dHnew, rows, dW, db, None, dH, dH_in_scaled=True, Cand=Cand)
+        self._split_planes(rows, dZx, dZh, cin)
+
+    def cell_cand_bwd_planar_k(self, Zx, Zh, Tc, W, dHnew, U, Cand, dZx, dZh, dW, db):
+        cin, h = Zx[0].shape[-1], Zh[0].shape[-1]
+        rows = [torch.empty(Zh[0].shape[:-1] + (cin + h,), dtype=W.dtype) for _ in Zh]
+        self.cell_cand_bwd(self._cat_planes(Zx, Zh), Tc, W, dHnew, U, Cand, rows, dW, db)
+        self._split_planes(rows, dZx, dZh, cin)
 
     def node_post_fwd(self, X, Tc, W, bias, A, Bm, X2=None):
         if X2 is not None:                                     # planar: 16 + 16 -> [X | X2]; narrow -> reference order [X2 (input) | X (16-wide)]

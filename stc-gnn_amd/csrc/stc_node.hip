@@ -549,6 +549,85 @@ extern "C" int stc_cell_gates_bwd_planar_f32(const float* X, const float* H, con
     return STC_OK;
 }
 
+// ---- planar cell convolutions of Chebyshev order K (= 3; K = 2 has the entry points above): see stc_cell_conv_*_planar_k_x3
+extern "C" int stc_cell_planar_k_supported(int32_t K, int32_t C, int32_t h) {
+    return (x3_enabled() && stc_cell_planar_k_shape_ok(K, C, h)) ? 1 : 0;
+}
+
+static int planar_k_common(const char* who, const float* const* Zx, const float* const* Zh, int K, int C, int Lw, int h, int Ho, long long nodes) {
+    if (int rc = check_dims(who, K, K, C, Lw == 2 * h ? 2 * h : 20, Lw, Ho, nodes)) return rc;
+    STC_REQUIRE(Lw == 2 * h || (Lw > h && Lw <= h + 4), STC_EINVAL, "%s: input width %d (Lw - h) must be h or 1..4", who, Lw - h);
+    if (!stc_cell_planar_k_supported(K, C, h)) return stc::fail(STC_EUNSUPPORTED, "%s: K=%d C=%d h=%d is not on the order-K planar path", who, K, C, h);
+    STC_REQUIRE(Zx && Zh, STC_EINVAL, "%s: null plane arrays", who);
+    if (nodes > 0)
+        for (int n = 0; n < K; ++n) STC_REQUIRE(Zx[n] && Zh[n], STC_EINVAL, "%s: plane %d is null", who, n);
+    return STC_OK;
+}
+
+extern "C" int stc_cell_gates_fwd_planar_k_f32(const float* const* Zx, const float* const* Zh, int32_t K, const float* Tc, const float* W, const float* bias,
+                                               float* U, float* Rg, float* RH, int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream) {
+    if (int rc = planar_k_common("stc_cell_gates_fwd_planar_k_f32", Zx, Zh, K, C, Lw, h, 2 * h, nodes)) return rc;
+    if (nodes == 0) return STC_OK;
+    STC_REQUIRE(Tc && W && U && Rg && RH, STC_EINVAL, "stc_cell_gates_fwd_planar_k_f32: null pointer");
+    const int rc = stc_cell_conv_fwd_planar_k_x3(Zx, Zh, K, Tc, W, bias, 1, Zh[0], nullptr, U, Rg, RH, nullptr, nullptr, nodes, C, Lw, static_cast<hipStream_t>(stream));
+    return rc == STC_NOT_HANDLED ? stc::fail(STC_EUNSUPPORTED, "stc_cell_gates_fwd_planar_k_f32: operands not usable (alignment)") : rc;
+}
+
+extern "C" int stc_cell_cand_fwd_planar_k_f32(const float* const* Zx, const float* const* Zh, int32_t K, const float* Tc, const float* W, const float* bias,
+                                              const float* U, const float* H, float* Cand, float* Hnew,
+                                              int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream) {
+    if (int rc = planar_k_common("stc_cell_cand_fwd_planar_k_f32", Zx, Zh, K, C, Lw, h, h, nodes)) return rc;
+    if (nodes == 0) return STC_OK;
+    STC_REQUIRE(Tc && W && U && H && Cand && Hnew, STC_EINVAL, "stc_cell_cand_fwd_planar_k_f32: null pointer");
+    STC_REQUIRE(stc::aligned16(U) && stc::aligned16(H) && stc::aligned16(Cand) && stc::aligned16(Hnew), STC_EALIGN, "stc_cell_cand_fwd_planar_k_f32: misaligned operand");
+    const int rc = stc_cell_conv_fwd_planar_k_x3(Zx, Zh, K, Tc, W, bias, 2, H, U, nullptr, nullptr, nullptr, Cand, Hnew, nodes, C, Lw, static_cast<hipStream_t>(stream));
+    return rc == STC_NOT_HANDLED ? stc::fail(STC_EUNSUPPORTED, "stc_cell_cand_fwd_planar_k_f32: operands not usable (alignment)") : rc;
+}
+
+static int planar_k_bwd(const char* who, const float* const* Zx, const float* const* Zh, int K, const float* Tc, const float* W, int mode,
+                        const float* dRH, const float* Cand, const float* U, const float* Rg, const float* dHnew,
+                        float* const* dZx, float* const* dZh, float* dW, float* db, float* dH, void* workspace, size_t workspace_bytes,
+                        long long nodes, int C, int Lw, int h, hipStream_t s) {
+    const int L = Lw == 2 * h ? 2 * h : 20, Ho = mode == 1 ? 2 * h : h;
+    if (int rc = planar_k_common(who, Zx, Zh, K, C, Lw, h, Ho, nodes)) return rc;
+    STC_REQUIRE(W && dW && Tc && dZh && (Lw != 2 * h || dZx), STC_EINVAL, "%s: null W/dW/Tc/dZ", who);
+    const int nW = K * K * Lw * Ho;
+    if (nodes == 0) {
+        if (int rc = stc::hip_status(hipMemsetAsync(dW, 0, (size_t)nW * sizeof(float), s), "memset dW")) return rc;
+        if (db) if (int rc = stc::hip_status(hipMemsetAsync(db, 0, (size_t)Ho * sizeof(float), s), "memset db")) return rc;
+        return STC_OK;
+    }
+    STC_REQUIRE(Cand && U && dHnew && (mode != 1 || (dRH && Rg && dH)), STC_EINVAL, "%s: null pointer", who);
+    STC_REQUIRE(workspace && stc::aligned16(workspace), STC_EALIGN, "%s: workspace null or not 16-byte aligned", who);
+    STC_REQUIRE(workspace_bytes >= stc_bdg_node_bwd_workspace_bytes(K, K, C, L, Ho, 0), STC_EINVAL, "%s: workspace of %zu B is too small", who, workspace_bytes);
+    int n_parts = 0;
+    float* partial = static_cast<float*>(workspace);
+    const int rc = stc_cell_conv_bwd_planar_k_x3(Zx, Zh, K, Tc, W, mode, dRH, Cand, U, Rg, dHnew, dZx, dZh, dH, partial, &n_parts, db != nullptr, nodes, C, Lw, s);
+    if (rc == STC_NOT_HANDLED) return stc::fail(STC_EUNSUPPORTED, "%s: operands not usable (alignment / null gradient plane)", who);
+    if (rc != STC_OK) return rc;
+    const int stride = nW + Ho;
+    hipLaunchKernelGGL(bdg_node_reduce_kernel, dim3((stride + RED_ELEMS - 1) / RED_ELEMS), dim3(NODE_THREADS), 0, s,
+                       partial, n_parts, stride, nW, Ho, 0, dW, db, static_cast<float*>(nullptr));
+    STC_LAUNCH_CHECK("stc_bdg_node_reduce launch");
+    return STC_OK;
+}
+
+extern "C" int stc_cell_gates_bwd_planar_k_f32(const float* const* Zx, const float* const* Zh, int32_t K, const float* Tc, const float* W,
+                                               const float* dRH, const float* Cand, const float* U, const float* Rg, const float* dHnew,
+                                               float* const* dZx, float* const* dZh, float* dW, float* db, float* dH,
+                                               void* workspace, size_t workspace_bytes, int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream) {
+    return planar_k_bwd("stc_cell_gates_bwd_planar_k_f32", Zx, Zh, K, Tc, W, 1, dRH, Cand, U, Rg, dHnew, dZx, dZh, dW, db, dH, workspace, workspace_bytes,
+                        nodes, C, Lw, h, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int stc_cell_cand_bwd_planar_k_f32(const float* const* Zx, const float* const* Zh, int32_t K, const float* Tc, const float* W,
+                                              const float* dHnew, const float* U, const float* Cand,
+                                              float* const* dZx, float* const* dZh, float* dW, float* db,
+                                              void* workspace, size_t workspace_bytes, int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream) {
+    return planar_k_bwd("stc_cell_cand_bwd_planar_k_f32", Zx, Zh, K, Tc, W, 2, nullptr, Cand, U, nullptr, dHnew, dZx, dZh, dW, db, nullptr, workspace, workspace_bytes,
+                        nodes, C, Lw, h, static_cast<hipStream_t>(stream));
+}
+
 extern "C" int stc_bdg_node_post_supported(int32_t Ks, int32_t Kc, int32_t C, int32_t L, int32_t Ho) {
     return (x3_enabled() && Ks == Kc && stc_node_post_shape_ok(Ks, C, L, Ho)) ? 1 : 0;
 }

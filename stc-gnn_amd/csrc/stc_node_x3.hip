@@ -547,7 +547,7 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
     static_assert(PL != 1 || L == 32, "planar rows are 16 + 16 columns");
     static_assert(PL != 2 || L == 20, "narrow planar rows are 16 + cin columns padded to 20");
     NodeIn<NB2, HB, K, L, PL> in, nx;
-    if (PF && node < nodes) { in.g.load(dY, node, x, g); in.load_z(Z, node, x, g); }
+    if (PF && node < nodes) { in.g.load(dY, node, x, g); in.load_z(Z, node, x, g, Lw - 16); }      // (the width matters to PL = 2 only)
     while (node < nodes) {
         const int next_node = node + nw;
         const size_t r0 = (size_t)node * C;
@@ -556,9 +556,9 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
             load_gates_grad<NRB, HB, (PL ? 16 : L), PRO == PRO_GATES_CAND>(in.g, pro, node, x, g);
             in.load_z(Z, node, x, g, Lw - 16);
         }
-        else if constexpr (PRO == PRO_BLEND) { load_blend_grad<NRB>(in.g, pro, node, x, g); in.load_z(Z, node, x, g); }
-        else if (!PF) { in.g.load(dY, node, x, g); in.load_z(Z, node, x, g); }
-        if (PF && next_node < nodes) { nx.g.load(dY, next_node, x, g); nx.load_z(Z, next_node, x, g); }
+        else if constexpr (PRO == PRO_BLEND) { load_blend_grad<NRB>(in.g, pro, node, x, g); in.load_z(Z, node, x, g, Lw - 16); }
+        else if (!PF) { in.g.load(dY, node, x, g); in.load_z(Z, node, x, g, Lw - 16); }
+        if (PF && next_node < nodes) { nx.g.load(dY, next_node, x, g); nx.load_z(Z, next_node, x, g, Lw - 16); }
         if (PF) __builtin_amdgcn_sched_barrier(0);
         const int lo = opaque(lane);
         const DyFrag<NRB, HB>& gr = in.g;
@@ -1344,4 +1344,55 @@ int stc_cell_gates_bwd_planar_x3(const float* X, const float* H, const float* SX
     if (C == 32) return launch_bwd<1, 2, 2, 32, PRO_GATES_CAND, 1>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro);
     if (C == 64) return launch_bwd<2, 2, 2, 32, PRO_GATES_CAND, 1>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro);
     return STC_NOT_HANDLED;
+}
+
+// ---- planar cell convolutions of Chebyshev order K = 3 (C = 32, hidden 16).  Zx[n] / Zh[n] = T_n(S) applied to the plane on the
+// X side / the H side of the [X | H] row (n = 0: the plane itself), each (nodes, C, 16); a narrow input (layer 0: Lw - 16 = 1..4
+// columns) has Zx[n] (nodes, C, Lw - 16) and the 16-wide side leads inside the kernels, as in the K = 2 planar launches.
+// mode 1 = gates convolution with the sigmoid / R*H epilogue (prologue: gate + blend backward), mode 2 = candidate convolution
+// on [X | R*H] with the tanh + GRU-blend epilogue (prologue: blend backward).  Same templates as everything above.
+int stc_cell_planar_k_shape_ok(int K, int C, int h) { return K == 3 && C == 32 && h == 16; }
+
+int stc_cell_conv_fwd_planar_k_x3(const float* const* Zx, const float* const* Zh, int K, const float* Tc, const float* W, const float* bias, int mode,
+                                  const float* H, const float* Uin, float* U, float* R, float* RH, float* Cand, float* Hnew,
+                                  long long nodes, int C, int Lw, hipStream_t stream) {
+    const int cin = Lw - 16;
+    if (!stc_cell_planar_k_shape_ok(K, C, 16) || !x3_cell_shape(K, C, cin == 16 ? 32 : 20, nodes) || !(cin == 16 || (cin >= 1 && cin <= 4))) return STC_NOT_HANDLED;
+    if (!all_aligned16(Zh, K) || (cin == 16 && !all_aligned16(Zx, K))) return STC_NOT_HANDLED;
+    FwdEpi epi{};
+    if (mode == 1) { epi.H = H; epi.U_out = U; epi.R_out = R; epi.CandIn = RH; epi.cin = cin; }
+    else { epi.H = H; epi.U = Uin; epi.Cand = Cand; epi.Hnew = Hnew; }
+    const float* Z[6];
+    for (int n = 0; n < 3; ++n) { Z[n] = cin == 16 ? Zx[n] : Zh[n]; Z[3 + n] = cin == 16 ? Zh[n] : Zx[n]; }
+    if (mode == 1) return cin == 16 ? launch_fwd<1, 2, 3, 32, EPI_GATES, 0, 1>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi)
+                                    : launch_fwd<1, 2, 3, 20, EPI_GATES, 0, 2>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi);
+    return cin == 16 ? launch_fwd<1, 1, 3, 32, EPI_BLEND, 0, 1>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi)
+                     : launch_fwd<1, 1, 3, 20, EPI_BLEND, 0, 2>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi);
+}
+
+int stc_cell_conv_bwd_planar_k_x3(const float* const* Zx, const float* const* Zh, int K, const float* Tc, const float* W, int mode,
+                                  const float* dRH, const float* Cand, const float* U, const float* R, const float* dHnew,
+                                  float* const* dZx, float* const* dZh, float* dH, float* partial, int* n_partials, int want_db,
+                                  long long nodes, int C, int Lw, hipStream_t stream) {
+    const int cin = Lw - 16;
+    if (!stc_cell_planar_k_shape_ok(K, C, 16) || !x3_cell_shape(K, C, cin == 16 ? 32 : 20, nodes) || !(cin == 16 || (cin >= 1 && cin <= 4))) return STC_NOT_HANDLED;
+    if (!all_aligned16(Zh, K) || (cin == 16 && !all_aligned16(Zx, K))) return STC_NOT_HANDLED;
+    const float* Z[6];
+    float* dZ[6];
+    for (int n = 0; n < 3; ++n) {
+        if (!dZh[n] || !stc::aligned16(dZh[n]) || (cin == 16 && (!dZx[n] || !stc::aligned16(dZx[n])))) return STC_NOT_HANDLED;
+        Z[n] = cin == 16 ? Zx[n] : Zh[n]; Z[3 + n] = cin == 16 ? Zh[n] : Zx[n];
+        dZ[n] = cin == 16 ? dZx[n] : dZh[n]; dZ[3 + n] = cin == 16 ? dZh[n] : nullptr;      // a narrow input plane gets no gradient
+    }
+    if (!(stc::aligned16(Cand) && stc::aligned16(U) && stc::aligned16(dHnew))) return STC_NOT_HANDLED;
+    BwdPro pro{};
+    if (mode == 1) {
+        if (!(stc::aligned16(dRH) && stc::aligned16(R) && stc::aligned16(dH))) return STC_NOT_HANDLED;
+        pro.Cand = Cand; pro.dCandIn = dRH; pro.H = Zh[0]; pro.U = U; pro.R = R; pro.dH_in = dHnew; pro.dH = dH; pro.cin = 0; pro.dh_scaled = 1;
+        return cin == 16 ? launch_bwd<1, 2, 3, 32, PRO_GATES_CAND, 1>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro)
+                         : launch_bwd<1, 2, 3, 20, PRO_GATES_CAND, 2>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro);
+    }
+    pro.dH_in = dHnew; pro.U = U; pro.Cand = Cand;
+    return cin == 16 ? launch_bwd<1, 1, 3, 32, PRO_BLEND, 1>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro)
+                     : launch_bwd<1, 1, 3, 20, PRO_BLEND, 2>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro);
 }

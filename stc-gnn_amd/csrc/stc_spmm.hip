@@ -77,7 +77,8 @@ struct EpiArgs {
     // SUM / SUM2 (gradient of a state from its consumers' pieces): Y = sum_i add[i] + S.(X [+ X2]), rows of C*h floats;
     // add[i] = columns [off, off+h) of rows of ld floats (a contiguous plane: ld = h, off = 0)
     const float4* X2;                       // SUM2: second gathered operand (same batch stride as X)
-    const float* add[5]; int add_ld[5], add_off[5], n_add;
+    const float* add[STC_SPMM_SUM_MAX_ADD]; int add_ld[STC_SPMM_SUM_MAX_ADD], add_off[STC_SPMM_SUM_MAX_ADD], n_add;
+    float add_scale[STC_SPMM_SUM_MAX_ADD];   // SUM: Y = sum_i add_scale[i] add[i] + alpha S.(X [+ X2])
     const float *gU, *gCand; float* dYout;  // SUM, optional: also dY = Y * U * (1 - Cand^2), the blend backward of the cell that owns the state
 };
 
@@ -147,12 +148,13 @@ __device__ __forceinline__ void epilogue(const EpiArgs& a, size_t rowg, int F4, 
         return;
     }
     if (MODE == EP_SUM || MODE == EP_SUM2) {
-        float4 y = acc;
+        float4 y = make_float4(a.alpha * acc.x, a.alpha * acc.y, a.alpha * acc.z, a.alpha * acc.w);
         const size_t e = rowg * a.C + (ch >> 2);                  // h = 16: piece ch = 4 * category + quarter
         const int q4 = ch & 3;
         for (int i = 0; i < a.n_add; ++i) {
             const float4 t = *reinterpret_cast<const float4*>(a.add[i] + e * a.add_ld[i] + a.add_off[i] + 4 * q4);
-            y.x += t.x; y.y += t.y; y.z += t.z; y.w += t.w;
+            const float sc = a.add_scale[i];
+            y.x = fmaf(sc, t.x, y.x); y.y = fmaf(sc, t.y, y.y); y.z = fmaf(sc, t.z, y.z); y.w = fmaf(sc, t.w, y.w);
         }
         nt_store4(a.Y + o, y);
         if (a.dYout) {
@@ -792,13 +794,14 @@ extern "C" int stc_spmm_blend_fwd_f32(const int32_t* rowptr, const int32_t* coli
 
 extern "C" int stc_spmm_sum_f32(const int32_t* rowptr, const int32_t* colidx, const float* val,
                                 const int32_t* blk_ptr, const int32_t* blk_cols, const float* blk_vals,
-                                int32_t n_rows, int32_t n_cols, const float* X, const float* X2,
-                                int32_t n_add, const float* const* add, const int32_t* add_ld, const int32_t* add_off,
+                                int32_t n_rows, int32_t n_cols, const float* X, const float* X2, float alpha,
+                                int32_t n_add, const float* const* add, const int32_t* add_ld, const int32_t* add_off, const float* add_scale,
                                 float* Y, const float* U, const float* Cand, float* dY,
                                 int32_t batch, int32_t C, int32_t h, void* stream) {
     const GraphArgs g{rowptr, colidx, val, blk_ptr, blk_cols, blk_vals};
     STC_REQUIRE(h == 16, STC_EUNSUPPORTED, "stc_spmm_sum_f32: hidden width %d (built for 16)", h);
-    STC_REQUIRE(n_add >= 0 && n_add <= 5 && (n_add == 0 || (add && add_ld && add_off)), STC_EINVAL, "stc_spmm_sum_f32: 0..5 addends, got %d", n_add);
+    STC_REQUIRE(n_add >= 0 && n_add <= STC_SPMM_SUM_MAX_ADD && (n_add == 0 || (add && add_ld && add_off)), STC_EINVAL,
+                "stc_spmm_sum_f32: 0..%d addends, got %d", STC_SPMM_SUM_MAX_ADD, n_add);
     if (int rc = check_fused("stc_spmm_sum_f32", g, n_rows, n_cols, X, Y, batch, C, 0, h, 0)) return rc;      // (Y checked as the aligned "Y0" operand)
     if (n_rows == 0 || batch == 0) return STC_OK;
     STC_REQUIRE(X != Y && X2 != Y, STC_EINVAL, "stc_spmm_sum_f32: Y must not alias a gathered operand");
@@ -810,12 +813,13 @@ extern "C" int stc_spmm_sum_f32(const int32_t* rowptr, const int32_t* colidx, co
     STC_REQUIRE(!dY || (U && Cand && stc::aligned16(U) && stc::aligned16(Cand) && stc::aligned16(dY) && dY != Y), STC_EINVAL,
                 "stc_spmm_sum_f32: dY needs U and Cand (16-byte aligned, not aliasing Y)");
     ep.gU = U; ep.gCand = Cand; ep.dYout = dY;
+    ep.alpha = alpha;
     ep.n_add = n_add;
     for (int i = 0; i < n_add; ++i) {
         STC_REQUIRE(add[i] && add_off[i] >= 0 && add_off[i] + h <= add_ld[i] && ((add_ld[i] | add_off[i]) & 3) == 0 && stc::aligned16(add[i]), STC_EINVAL,
                     "stc_spmm_sum_f32: addend %d (ld %d, off %d) must be non-null, 16-byte aligned, with ld and off multiples of 4", i, add_ld[i], add_off[i]);
         STC_REQUIRE(add[i] != Y, STC_EINVAL, "stc_spmm_sum_f32: Y must not alias an addend");
-        ep.add[i] = add[i]; ep.add_ld[i] = add_ld[i]; ep.add_off[i] = add_off[i];
+        ep.add[i] = add[i]; ep.add_ld[i] = add_ld[i]; ep.add_off[i] = add_off[i]; ep.add_scale[i] = add_scale ? add_scale[i] : 1.f;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     return X2 ? launch_vector<EP_SUM2>("stc_spmm_sum_f32 launch", g, n_rows, n_cols, X, batch, C * h, ep, s)

@@ -19,8 +19,9 @@ import torch
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG_ROOT, 'libstc_hip.so')
-ABI_VERSION = 10
+ABI_VERSION = 11
 MAX_K = 4
+SPMM_SUM_MAX_ADD = 8     # = STC_SPMM_SUM_MAX_ADD of include/stc_hip.h
 
 #: every symbol ``include/stc_hip.h`` declares (the CPU test-suite checks the .so exports them all)
 EXPORTS = (
@@ -34,6 +35,8 @@ EXPORTS = (
     'stc_bdg_node_post_supported', 'stc_bdg_node_post_fwd_f32', 'stc_bdg_node_post_bwd_f32', 'stc_spmm_blend_fwd_f32',
     'stc_cell_fused_supported', 'stc_cell_gates_fwd_f32', 'stc_cell_gates_bwd_f32', 'stc_cell_cand_bwd_f32', 'stc_cell_blend_fwd_f32',
     'stc_cell_planar_supported', 'stc_cell_gates_fwd_planar_f32', 'stc_cell_gates_bwd_planar_f32', 'stc_spmm_sum_f32',
+    'stc_cell_planar_k_supported', 'stc_cell_gates_fwd_planar_k_f32', 'stc_cell_cand_fwd_planar_k_f32', 'stc_cell_gates_bwd_planar_k_f32',
+    'stc_cell_cand_bwd_planar_k_f32',
     'stc_cell_gather_supported', 'stc_cell_gates_fwd_gather_f32', 'stc_cell_blend_fwd_gather_f32',
     'stc_gru_gates_fwd_f32', 'stc_gru_gates_bwd_f32', 'stc_gru_blend_fwd_f32', 'stc_gru_blend_bwd_f32',
     'stc_head_fwd_f32', 'stc_head_bwd_workspace_bytes', 'stc_head_bwd_f32',
@@ -85,7 +88,14 @@ def _declare(lib):
         'stc_cell_gates_bwd_planar_f32': [_p] * 11 + [C.POINTER(_p), _p, _p, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _p],
         'stc_spmm_blend_fwd_f32': [_p] * 6 + [_i32, _i32] + [_p] * 6 + [_p, _i32, _i32, _p, _i32, _p, _i32, _i32] + [_i32] * 3 + [_p],
         'stc_bdg_node_post_bwd_f32': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _i32, _p],
-        'stc_spmm_sum_f32': [_p] * 6 + [_i32, _i32, _p, _p, _i32, C.POINTER(_p), C.POINTER(_i32), C.POINTER(_i32), _p, _p, _p, _p, _i32, _i32, _i32, _p],
+        'stc_spmm_sum_f32': [_p] * 6 + [_i32, _i32, _p, _p, _f32, _i32, C.POINTER(_p), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_f32), _p, _p, _p, _p,
+                             _i32, _i32, _i32, _p],
+        'stc_cell_gates_fwd_planar_k_f32': [C.POINTER(_p), C.POINTER(_p), _i32, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p],
+        'stc_cell_cand_fwd_planar_k_f32': [C.POINTER(_p), C.POINTER(_p), _i32, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p],
+        'stc_cell_gates_bwd_planar_k_f32': [C.POINTER(_p), C.POINTER(_p), _i32, _p, _p, _p, _p, _p, _p, _p, C.POINTER(_p), C.POINTER(_p), _p, _p, _p,
+                                            _p, C.c_size_t, _i64, _i32, _i32, _i32, _p],
+        'stc_cell_cand_bwd_planar_k_f32': [C.POINTER(_p), C.POINTER(_p), _i32, _p, _p, _p, _p, _p, C.POINTER(_p), C.POINTER(_p), _p, _p,
+                                           _p, C.c_size_t, _i64, _i32, _i32, _i32, _p],
         'stc_cell_gates_fwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _i32, _p],
         'stc_cell_cand_bwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _p, C.POINTER(_p), _p, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _i32, _p],
         'stc_cell_gates_bwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _i32, C.POINTER(_p), _p, _p, _p, _p,
@@ -118,6 +128,8 @@ def _declare(lib):
     lib.stc_bdg_node_bf16_supported.argtypes = [_i32, _i32, _i32, _i32, _i32]
     lib.stc_cell_planar_supported.restype = C.c_int
     lib.stc_cell_planar_supported.argtypes = [_i32, _i32, _i32, _i32]
+    lib.stc_cell_planar_k_supported.restype = C.c_int
+    lib.stc_cell_planar_k_supported.argtypes = [_i32, _i32, _i32]
     lib.stc_cell_gather_supported.restype = C.c_int
     lib.stc_cell_gather_supported.argtypes = [_i32, _i32, _i32, _i32, _i32]
     lib.stc_head_bwd_workspace_bytes.restype = C.c_size_t
@@ -363,30 +375,32 @@ class HipKernels:
                      nbytes=colidx.numel() * 8 + 4 * (n + 1) + 4 * B * n * Cc * (2 * (cin + h + pad) + (2 if addA is not None else 1) * cin
                                                                                   + (2 if addB is not None else 1) * h))
 
-    def spmm_sum(self, rowptr, colidx, val, plan, X, X2, addends, Y, blend=None):
-        """Y = sum(addends) + S.(X [+ X2]) on (B, n, C, h) state tensors (stc_spmm_sum_f32).  ``addends``: up to five
-        (tensor, column offset) pairs -- columns [off, off + h) of a (B, n, C, ld) tensor (a plain plane: ld = h, off = 0)."""
+    def spmm_sum(self, rowptr, colidx, val, plan, X, X2, addends, Y, blend=None, alpha=1.0):
+        """Y = sum(scale * addend) + alpha * S.(X [+ X2]) on (B, n, C, h) state tensors (stc_spmm_sum_f32).  ``addends``: up to
+        eight (tensor, column offset[, scale]) entries -- columns [off, off + h) of a (B, n, C, ld) tensor (a plain plane:
+        ld = h, off = 0); scale defaults to 1."""
         B, n, Cc, h = Y.shape
         self._f32('spmm_sum.Y', Y)
         self._f32('spmm_sum.X', X, (B, n, Cc, h))
         if X2 is not None:
             self._f32('spmm_sum.X2', X2, (B, n, Cc, h))
-        if len(addends) > 5:
-            raise StcError(f'spmm_sum: at most five addends, got {len(addends)}')
-        ptrs, lds, offs = (_p * 5)(), (_i32 * 5)(), (_i32 * 5)()
-        for i, (t, off) in enumerate(addends):
+        if len(addends) > SPMM_SUM_MAX_ADD:
+            raise StcError(f'spmm_sum: at most {SPMM_SUM_MAX_ADD} addends, got {len(addends)}')
+        ptrs, lds, offs, scales = (_p * SPMM_SUM_MAX_ADD)(), (_i32 * SPMM_SUM_MAX_ADD)(), (_i32 * SPMM_SUM_MAX_ADD)(), (_f32 * SPMM_SUM_MAX_ADD)()
+        for i, ent in enumerate(addends):
+            t, off = ent[0], ent[1]
             self._f32(f'spmm_sum.add{i}', t)
             if t.shape[:3] != (B, n, Cc) or off < 0 or off + h > t.shape[-1] or (t.shape[-1] | off) & 3:
                 raise StcError(f'spmm_sum: addend {i} of shape {tuple(t.shape)} / offset {off} does not fit')
-            ptrs[i], lds[i], offs[i] = t.data_ptr(), t.shape[-1], off
+            ptrs[i], lds[i], offs[i], scales[i] = t.data_ptr(), t.shape[-1], off, (float(ent[2]) if len(ent) > 2 else 1.0)
         U = Cand = dY = None
         if blend is not None:                                     # (U, Cand, dY): also dY = Y * U * (1 - Cand^2)
             U, Cand, dY = blend
             for name, t in (('U', U), ('Cand', Cand), ('dY', dY)):
                 self._f32('spmm_sum.' + name, t, (B, n, Cc, h))
-        self._same_device(rowptr, colidx, val, X, X2, Y, U, Cand, dY, *[t for t, _ in addends])
+        self._same_device(rowptr, colidx, val, X, X2, Y, U, Cand, dY, *[ent[0] for ent in addends])
         g = self._graph_ptrs(rowptr, colidx, val, plan, n)
-        self._launch('stc_spmm_sum_f32', Y, *g, n, n, _ptr(X), _ptr(X2), len(addends), ptrs, lds, offs, _ptr(Y), _ptr(U), _ptr(Cand), _ptr(dY),
+        self._launch('stc_spmm_sum_f32', Y, *g, n, n, _ptr(X), _ptr(X2), float(alpha), len(addends), ptrs, lds, offs, scales, _ptr(Y), _ptr(U), _ptr(Cand), _ptr(dY),
                      B, Cc, h,
                      nbytes=colidx.numel() * 8 + 4 * (n + 1) + 4 * B * n * Cc * h * (2 + (X2 is not None) + len(addends) + (3 if blend else 0)))
 
@@ -674,6 +688,83 @@ class HipKernels:
         zp = (_p * 4)(*[0 if z is None else z.data_ptr() for z in dZs])
         self._launch('stc_cell_gates_bwd_planar_f32', H, _ptr(X), _ptr(H), _ptr(SX), _ptr(SH), _ptr(Tc), _ptr(W), _ptr(dRH), _ptr(Cand),
                      _ptr(U), _ptr(Rg), _ptr(dHnew), zp, _ptr(dW), _ptr(db), _ptr(dH), _ptr(ws), ws.numel(), R, Cc, cin + h, h)
+
+    # ---- planar cell convolutions of Chebyshev order K = 3 ------------------------------------------------
+    def cell_planar_k_supported(self, K, Cc, h) -> bool:
+        return bool(self.lib.stc_cell_planar_k_supported(K, Cc, h))
+
+    def _planes_k(self, what, Zx, Zh, Tc, W, Ho):
+        """Zx / Zh: K planes each, T_n(S) of the X-side / H-side plane: Zh[n] (R, C, h); Zx[n] (R, C, cin), cin = h or 1..4."""
+        K = len(Zh)
+        if len(Zx) != K or K < 2:
+            raise StcError(f'{what}: {len(Zx)} X-side planes for {K} H-side planes')
+        R, Cc, h = Zh[0].shape
+        cin = Zx[0].shape[-1]
+        if not (cin == h or 1 <= cin <= 4):
+            raise StcError(f'{what}: input plane width {cin} must be {h} or 1..4')
+        for n in range(K):
+            self._f32(f'{what}.Zh[{n}]', Zh[n], (R, Cc, h))
+            self._f32(f'{what}.Zx[{n}]', Zx[n], (R, Cc, cin))
+        self._f32(what + '.Tc', Tc, (K, Cc, Cc))
+        self._f32(what + '.W', W, (K * K * (cin + h), Ho))
+        return K, R, Cc, h, cin
+
+    def cell_gates_fwd_planar_k(self, Zx, Zh, Tc, W, bias, U, Rg, RH):
+        K, R, Cc, h, cin = self._planes_k('planar_k gates', Zx, Zh, Tc, W, 2 * Zh[0].shape[-1])
+        if bias is not None:
+            self._f32('planar_k.bias', bias, (2 * h,))
+        for name, t in (('U', U), ('Rg', Rg), ('RH', RH)):
+            self._f32('planar_k.' + name, t, (R, Cc, h))
+        self._same_device(*Zx, *Zh, Tc, W, bias, U, Rg, RH)
+        self._launch('stc_cell_gates_fwd_planar_k_f32', U, self._ptr_array(Zx), self._ptr_array(Zh), K, _ptr(Tc), _ptr(W), _ptr(bias),
+                     _ptr(U), _ptr(Rg), _ptr(RH), R, Cc, cin + h, h)
+
+    def cell_cand_fwd_planar_k(self, Zx, Zh, Tc, W, bias, U, H, Cand, Hnew):
+        """Candidate convolution on [X | R*H] (Zh = the T_n(S) planes of R*H) + tanh + GRU blend: Cand, Hnew."""
+        K, R, Cc, h, cin = self._planes_k('planar_k cand', Zx, Zh, Tc, W, Zh[0].shape[-1])
+        if bias is not None:
+            self._f32('planar_k.bias', bias, (h,))
+        for name, t in (('U', U), ('H', H), ('Cand', Cand), ('Hnew', Hnew)):
+            self._f32('planar_k.' + name, t, (R, Cc, h))
+        self._same_device(*Zx, *Zh, Tc, W, bias, U, H, Cand, Hnew)
+        self._launch('stc_cell_cand_fwd_planar_k_f32', U, self._ptr_array(Zx), self._ptr_array(Zh), K, _ptr(Tc), _ptr(W), _ptr(bias),
+                     _ptr(U), _ptr(H), _ptr(Cand), _ptr(Hnew), R, Cc, cin + h, h)
+
+    def _grad_planes_k(self, what, dZx, dZh, K, R, Cc, h, cin):
+        if len(dZh) != K or len(dZx) != K:
+            raise StcError(f'{what}: need {K} gradient planes per side')
+        for n in range(K):
+            self._f32(f'{what}.dZh[{n}]', dZh[n], (R, Cc, h))
+            if dZx[n] is None and cin != h:
+                continue                                              # a narrow input plane needs no gradient
+            self._f32(f'{what}.dZx[{n}]', dZx[n], (R, Cc, cin))
+        return (_p * K)(*[0 if z is None else z.data_ptr() for z in dZx]), (_p * K)(*[z.data_ptr() for z in dZh])
+
+    def cell_gates_bwd_planar_k(self, Zx, Zh, Tc, W, dRH, Cand, U, Rg, dHnew, dZx, dZh, dW, db, dH):
+        K, R, Cc, h, cin = self._planes_k('planar_k gates bwd', Zx, Zh, Tc, W, 2 * Zh[0].shape[-1])
+        for name, t in (('dRH', dRH), ('Cand', Cand), ('U', U), ('Rg', Rg), ('dHnew', dHnew), ('dH', dH)):
+            self._f32('planar_k.' + name, t, (R, Cc, h))
+        zx, zh = self._grad_planes_k('planar_k gates bwd', dZx, dZh, K, R, Cc, h, cin)
+        self._f32('planar_k.dW', dW, tuple(W.shape))
+        if db is not None:
+            self._f32('planar_k.db', db, (2 * h,))
+        self._same_device(*Zx, *Zh, Tc, W, dRH, Cand, U, Rg, dHnew, *dZx, *dZh, dW, db, dH)
+        ws = self._get_workspace(U.device, self.lib.stc_bdg_node_bwd_workspace_bytes(K, K, Cc, 2 * h, 2 * h, 0))
+        self._launch('stc_cell_gates_bwd_planar_k_f32', U, self._ptr_array(Zx), self._ptr_array(Zh), K, _ptr(Tc), _ptr(W), _ptr(dRH), _ptr(Cand),
+                     _ptr(U), _ptr(Rg), _ptr(dHnew), zx, zh, _ptr(dW), _ptr(db), _ptr(dH), _ptr(ws), ws.numel(), R, Cc, cin + h, h)
+
+    def cell_cand_bwd_planar_k(self, Zx, Zh, Tc, W, dHnew, U, Cand, dZx, dZh, dW, db):
+        K, R, Cc, h, cin = self._planes_k('planar_k cand bwd', Zx, Zh, Tc, W, Zh[0].shape[-1])
+        for name, t in (('dHnew', dHnew), ('U', U), ('Cand', Cand)):
+            self._f32('planar_k.' + name, t, (R, Cc, h))
+        zx, zh = self._grad_planes_k('planar_k cand bwd', dZx, dZh, K, R, Cc, h, cin)
+        self._f32('planar_k.dW', dW, tuple(W.shape))
+        if db is not None:
+            self._f32('planar_k.db', db, (h,))
+        self._same_device(*Zx, *Zh, Tc, W, dHnew, U, Cand, *dZx, *dZh, dW, db)
+        ws = self._get_workspace(U.device, self.lib.stc_bdg_node_bwd_workspace_bytes(K, K, Cc, 2 * h, 2 * h, 0))
+        self._launch('stc_cell_cand_bwd_planar_k_f32', U, self._ptr_array(Zx), self._ptr_array(Zh), K, _ptr(Tc), _ptr(W), _ptr(dHnew), _ptr(U), _ptr(Cand),
+                     zx, zh, _ptr(dW), _ptr(db), _ptr(ws), ws.numel(), R, Cc, cin + h, h)
 
     # ---- fused cell convolutions ----------------------------------------------------------
     def cell_fused_supported(self, Ks, Kc, Cc, L, h) -> bool:

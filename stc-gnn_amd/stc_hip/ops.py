@@ -458,6 +458,7 @@ _CELL_GRAPH = os.environ.get('STC_CELL_GRAPH', '1') != '0'
 _FUSE_POST = os.environ.get('STC_FUSE_POST', '1') != '0'        # candidate projection as a second stage of the planar gates forward
 _PLANAR = os.environ.get('STC_PLANAR', '1') != '0'              # cells with 16 + 16-column inputs read them as two planes (no concat, shared S.state)
 _POST_AGG = os.environ.get('STC_POST_AGG', '1') != '0'          # candidate convolution as Y = A + S.Bm (narrow SpMM after the node kernel)
+_PLANAR_K3 = os.environ.get('STC_PLANAR_K3', '1') != '0'        # Chebyshev order 3: planar cells on three planes per side (T_0, T_1, T_2 of S)
 
 
 def cell_graph_supported(op: SpatialOperand, Tc, Ks: int, C: int, h: int, x_widths, dtype=torch.float32) -> bool:
@@ -523,8 +524,11 @@ class _StcCellGraph(Function):
         planar_ok = (_PLANAR and _POST_AGG and Ks == 2 and k.cell_planar_supported(Ks, Tc.shape[0], C, h)
                      and k.node_post_supported(Ks, Tc.shape[0], C, 2 * h, h))
         post20 = bool(planar_ok) and k.node_post_supported(Ks, Tc.shape[0], C, 20, h)
+        # order 3 (BASELINE configuration 4): planar cells on the three Chebyshev planes of each side, candidate in slab-planar form
+        planar_k = bool(_PLANAR and _PLANAR_K3 and not bf16 and Ks == 3 and Tc.shape[0] == 3 and k.cell_planar_k_supported(Ks, C, h))
         # 16 + 16 columns, or (layer 0) a narrow input plane of 1..4 columns beside the 16 state columns
-        planar = [bool(planar_ok and (cin[j] == h or (post20 and 1 <= cin[j] <= 4))) for j in range(n_cells)]
+        planar = [bool((planar_ok and (cin[j] == h or (post20 and 1 <= cin[j] <= 4))) or (planar_k and (cin[j] == h or 1 <= cin[j] <= 4)))
+                  for j in range(n_cells)]
         if bf16 and not all(planar):
             raise ValueError('stc_cell_graph: bfloat16 states need an all-planar schedule (Ks = 2, inputs 16 or 1..4 columns wide)')
         XH, agg = {}, {}
@@ -542,6 +546,19 @@ class _StcCellGraph(Function):
                 k.csr_spmm(op.fwd_rowptr, op.fwd_colidx, fwd_val, N, N, t.view(B, N, C * w), None, out.view(B, N, C * w), 1.0, 0.0,
                            plan=op.fwd_plan)
                 agg[src] = out
+            return agg[src]
+
+        def cheb_planes(t):                                         # [t, S.t, 2 S.(S.t) - t]: the feature-side recurrence, order 3
+            w = t.shape[-1]
+            v3 = lambda a: a.view(B, N, C * w)
+            s1, s2 = torch.empty_like(t), torch.empty_like(t)
+            k.csr_spmm(op.fwd_rowptr, op.fwd_colidx, fwd_val, N, N, v3(t), None, v3(s1), 1.0, 0.0, plan=op.fwd_plan)
+            k.csr_spmm(op.fwd_rowptr, op.fwd_colidx, fwd_val, N, N, v3(s1), v3(t), v3(s2), 2.0, -1.0, plan=op.fwd_plan)
+            return [t, s1, s2]
+
+        def planes_of(src):                                         # once per source tensor, shared by every cell that consumes it
+            if src not in agg:
+                agg[src] = cheb_planes(source(src))
             return agg[src]
 
         state = [None] * n_cells                                    # plain (B,N,C,h) new state of every cell
@@ -577,7 +594,14 @@ class _StcCellGraph(Function):
                 late_copies.append(copies.pop(len(copies) - 1 if len(copies) - 1 >= first else first))
             U, Rg, Cand = torch.empty_like(Hprev), torch.empty_like(Hprev), torch.empty_like(Hprev)
             Hnew = _alias_slice(out_stack, out_slot[j]) if j in out_slot else torch.empty_like(Hprev)
-            if planar[j]:
+            if planar[j] and planar_k:
+                Zx, Zh, RH = planes_of(x), planes_of(hs), torch.empty_like(Hprev)
+                k.cell_gates_fwd_planar_k(rows(Zx), rows(Zh), Tc, Wg, bg, *rows((U, Rg, RH)))
+                Zr = cheb_planes(RH)                                # the candidate's H side: T_n(S) of R*H (its X side is Zx again)
+                k.cell_cand_fwd_planar_k(rows(Zx), rows(Zr), Tc, Wc, bc, *rows((U, Hprev, Cand, Hnew)))
+                saved += [Hprev, U, Rg, Cand, *Zx, *Zh[1:], *Zr]
+                n_saved.append(-12)                                 # negative count: planar cell (12: order 3)
+            elif planar[j]:
                 Xp, SXp, SHp, RH = source(x), aggregated(x), aggregated(hs), torch.empty_like(Hprev)
                 A, Bm = torch.empty_like(Hprev), torch.empty_like(Hprev)
                 if _FUSE_POST and k.cell_planar_post_fused(C):        # the candidate's projection rides in the gates launch
@@ -699,13 +723,65 @@ class _StcCellGraph(Function):
                        blend=None if blend is None else (blend[0], blend[1], dY))
             return out if blend is None else (out, dY)
 
+        # Order 3: a consumer leaves direct planes d0 and the gradients d1, d2 of the S / T_2(S) planes; the source's gradient is
+        #   sum d0 - sum d2 + S^T (sum d1 + 2 S^T sum d2)          (Clenshaw form of sum_n T_n(S)^T d_n)
+        # = two narrow SpMMs with the sums in their gather / epilogue (alpha and signed addends of stc_spmm_sum_f32).
+        def leave3(kid, d0, d1, d2):
+            pc = pieces.setdefault(kid, dict(d0=[], d1=[], d2=[]))
+            pc['d0'] += list(d0); pc['d1'] += list(d1); pc['d2'] += list(d2)
+
+        def clenshaw(d0, d1, d2):
+            """sum d0 - sum d2 + S^T (sum d1 + 2 S^T sum d2) from lists of planes (d2 non-empty)."""
+            while len(d2) > 2:                                       # the kernel gathers two operands: pre-sum the rest
+                d2 = [d2[0] + d2[1]] + d2[2:]
+            t = d2[0].new_empty(B, N, C, h)
+            k.spmm_sum(*bwd, op.bwd_plan, d2[0], d2[1] if len(d2) > 1 else None, [(a, 0) for a in d1], t, alpha=2.0)
+            adds = [(a, 0) for a in d0] + [(a, 0, -1.0) for a in d2]
+            while len(adds) > 8:
+                (a, _), (b_, _) = adds.pop(0), adds.pop(0)
+                adds.insert(0, (a + b_, 0))
+            out = t.new_empty(B, N, C, h)
+            k.spmm_sum(*bwd, op.bwd_plan, t, None, adds, out)
+            return out
+
+        def owed3(kid):
+            base = G.pop(kid, None)
+            pc = pieces.pop(kid, None)
+            if pc is None:
+                return base
+            return clenshaw(pc['d0'] + ([base] if base is not None else []), pc['d1'], pc['d2'])
+
         for j in range(len(schedule) - 1, -1, -1):
             if j not in G and j not in pieces:
                 continue                                             # nothing downstream depends on this cell
             s_id, x, hs = schedule[j]
             Wg, bg, Wc, bc = stacks[s_id]
             Hprev, U, Rg, Cand, *rest = cells[j]
+            if n_saved[j] == -12:                                    # order-3 planar cell
+                Zx, Zh, Zr = rest[:3], [Hprev] + rest[3:5], rest[5:8]
+                dHnew = owed3(j)
+                wide = cin[j] == h
+                new = lambda: torch.empty_like(Hprev)
+                dXc, dR = ([new(), new(), new()] if wide else [None] * 3), [new(), new(), new()]
+                dWc, dbc = torch.empty_like(Wc), (Wc.new_empty(h) if bc is not None else None)
+                k.cell_cand_bwd_planar_k(rows(Zx), rows(Zr), Tc, Wc, *rows((dHnew, U, Cand)),
+                                         [None if t is None else t.view(B * N, C, h) for t in dXc], rows(dR), dWc, dbc)
+                dRH = clenshaw([dR[0]], [dR[1]], [dR[2]])            # gradient of the R*H plane from its three Chebyshev planes
+                del dR
+                dXg, dHg, dH = ([new(), new(), new()] if wide else [None] * 3), [new(), new(), new()], new()
+                dWg, dbg = torch.empty_like(Wg), (Wg.new_empty(2 * h) if bg is not None else None)
+                k.cell_gates_bwd_planar_k(rows(Zx), rows(Zh), Tc, Wg, *rows((dRH, Cand, U, Rg, dHnew)),
+                                          [None if t is None else t.view(B * N, C, h) for t in dXg], rows(dHg), dWg, dbg, dH.view(B * N, C, h))
+                if wide and x[0] == 'cell':
+                    leave3(x[1], (dXg[0], dXc[0]), (dXg[1], dXc[1]), (dXg[2], dXc[2]))
+                if hs[0] == 'cell':
+                    leave3(hs[1], (dHg[0], dH), (dHg[1],), (dHg[2],))
+                for i, t in enumerate((dWg, dbg, dWc, dbc)):
+                    add_to(acc[s_id], i, t)
+                continue
             post_form = n_saved[j] < 0 or (len(rest) == Ks + 1 and Ks > 1)     # candidate backward starts from dY = dHnew * U * (1 - Cand^2)
+            if Ks == 3 and j in pieces:                              # an interleaved cell whose state order-3 planar cells consumed
+                G[j] = owed3(j)
             dHnew, dY = owed(j, (U, Cand)) if post_form else (owed(j), None)
             dH = None if (n_saved[j] < 0 and getattr(k, 'folds_dH', False)) else torch.empty_like(Hprev)
             if n_saved[j] < 0:                                       # planar cell: inputs and gradients as planes

@@ -111,7 +111,7 @@ def test_ctypes_signatures_match_the_header():
     protos = re.findall(r'\b(?:int|size_t|const char\*)\s+(stc_[a-z0-9_]+)\s*\(([^)]*)\)\s*;', text)
     assert len(protos) == len(_lib.EXPORTS)
     kind = {C.c_void_p: 'ptr', C.c_int32: 'i32', C.c_int64: 'i64', C.c_float: 'f32', C.c_size_t: 'size', C.POINTER(C.c_void_p): 'ptr',
-            C.POINTER(C.c_int32): 'ptr'}
+            C.POINTER(C.c_int32): 'ptr', C.POINTER(C.c_float): 'ptr'}
     for name, params in protos:
         want = []
         for prm in [q.strip() for q in params.split(',') if q.strip() and q.strip() != 'void']:

@@ -619,6 +619,93 @@ def test_state_gradient_from_pieces(hip, batch, grid, C, n_add, dual):
         assert torch.equal(Y2, Y) and rel_err(dY, dY_w) < TOL
 
 
+@pytest.mark.parametrize('batch,grid,alpha', [(2, (5, 6), 2.0), (1, (30, 41), 2.0), (2, (4, 4), -0.5)])
+def test_state_gradient_sum_with_scales(hip, batch, grid, alpha):
+    """stc_spmm_sum_f32 with alpha and signed addends: the two launches of the order-3 (Clenshaw) state gradient
+    d0 - d2 + S^T (d1 + 2 S^T d2), up to the kernel's eight addends."""
+    h, C = 16, 32
+    graph = CsrGraph.queen_grid(*grid, normalize=True)
+    n = graph.n
+    g = torch.Generator().manual_seed(n + 5)
+    rnd = lambda *s_: torch.randn(*s_, generator=g)
+    X, X2 = rnd(batch, n, C, h), rnd(batch, n, C, h)
+    adds = [(rnd(batch, n, C, h), 0, sc) for sc in (1.0, 1.0, -1.0, 1.0, -1.0, 0.5, 1.0, -2.0)]
+    hst = graph._host
+    csr = tuple(torch.from_numpy(hst[k]) for k in ('bwd_rowptr', 'bwd_colidx', 'bwd_val'))
+    dev = graph.on(torch.device('cuda'))
+    plan = (dev['bwd_blk_ptr'], dev['bwd_blk_cols'], dev['bwd_blk_vals'])
+    for n_add in (8, 3, 0):
+        Y_w = torch.empty(batch, n, C, h)
+        EM.spmm_sum(*csr, None, X, X2, adds[:n_add], Y_w, alpha=alpha)
+        want = alpha * torch.einsum('ij,bjch->bich', graph.to_dense(), X + X2) + sum((sc * t for t, _, sc in adds[:n_add]), torch.zeros(()))
+        assert rel_err(Y_w, want) < 1e-6                                 # the twin itself against plain dense algebra
+        for pl in (plan, None):
+            Y = torch.full((batch, n, C, h), float('nan')).cuda()
+            hip.spmm_sum(*(cu(t) for t in csr), pl, cu(X), cu(X2), [(cu(t), o, sc) for t, o, sc in adds[:n_add]], Y, alpha=alpha)
+            assert rel_err(Y, Y_w) < TOL
+    from stc_hip import StcError
+    with pytest.raises(StcError):
+        hip.spmm_sum(*(cu(t) for t in csr), plan, cu(X), None, [(cu(X2), 0)] * 9, torch.empty_like(cu(X)))
+
+
+@pytest.mark.parametrize('nodes,cin', [(50, 16), (4500, 16), (37, 1), (600, 4), (9, 3)])
+def test_planar_cell_kernels_order3(hip, nodes, cin):
+    """Order-3 planar cell kernels (stc_cell_{gates,cand}_{fwd,bwd}_planar_k_f32): three Chebyshev planes per side, 16 + 16
+    columns or a narrow input plane, against the CPU twin (slab form on the concatenated planes)."""
+    h, K, C = 16, 3, 32
+    assert hip.cell_planar_k_supported(K, C, h) and not hip.cell_planar_k_supported(2, C, h) and not hip.cell_planar_k_supported(3, 64, h)
+    Lw = cin + h
+    g = torch.Generator().manual_seed(nodes + cin)
+    rnd = lambda *s_: torch.randn(*s_, generator=g)
+    Zx, Zh, Zr = [rnd(nodes, C, cin) for _ in range(K)], [rnd(nodes, C, h) for _ in range(K)], [rnd(nodes, C, h) for _ in range(K)]
+    Tc = rnd(K, C, C) / C ** 0.5
+    Tc[0] = torch.eye(C)
+    Wg, bg = rnd(K * K * Lw, 2 * h) / (K * K * Lw) ** 0.5, rnd(2 * h)
+    Wc, bc = rnd(K * K * Lw, h) / (K * K * Lw) ** 0.5, rnd(h)
+    nan = lambda *s_: torch.full(s_, float('nan')).cuda()
+    cus = lambda ts: [cu(t) for t in ts]
+    # gates forward
+    U_w, R_w, RH_w = (torch.empty(nodes, C, h) for _ in range(3))
+    EM.cell_gates_fwd_planar_k(Zx, Zh, Tc, Wg, bg, U_w, R_w, RH_w)
+    U, R, RH = nan(nodes, C, h), nan(nodes, C, h), nan(nodes, C, h)
+    hip.cell_gates_fwd_planar_k(cus(Zx), cus(Zh), cu(Tc), cu(Wg), cu(bg), U, R, RH)
+    assert rel_err(U, U_w) < TOL and rel_err(R, R_w) < TOL and rel_err(RH, RH_w) < TOL
+    # candidate forward + blend
+    Cand_w, Hn_w = torch.empty(nodes, C, h), torch.empty(nodes, C, h)
+    EM.cell_cand_fwd_planar_k(Zx, Zr, Tc, Wc, bc, U_w, Zh[0], Cand_w, Hn_w)
+    Cand, Hn = nan(nodes, C, h), nan(nodes, C, h)
+    hip.cell_cand_fwd_planar_k(cus(Zx), cus(Zr), cu(Tc), cu(Wc), cu(bc), cu(U_w), cu(Zh[0]), Cand, Hn)
+    assert rel_err(Cand, Cand_w) < TOL and rel_err(Hn, Hn_w) < TOL
+    hip.cell_cand_fwd_planar_k(cus(Zx), cus(Zr), cu(Tc), cu(Wc), None, cu(U_w), cu(Zh[0]), Cand, Hn)        # no bias
+    EM.cell_cand_fwd_planar_k(Zx, Zr, Tc, Wc, None, U_w, Zh[0], Cand_w, Hn_w)
+    assert rel_err(Cand, Cand_w) < TOL
+    EM.cell_cand_fwd_planar_k(Zx, Zr, Tc, Wc, bc, U_w, Zh[0], Cand_w, Hn_w)
+    # candidate backward (blend backward in the prologue)
+    wide = cin == h
+    dHn = rnd(nodes, C, h)
+    gx = lambda make: [make() for _ in range(K)] if wide else [None] * K
+    dXc_w, dR_w = gx(lambda: torch.empty(nodes, C, cin)), [torch.empty(nodes, C, h) for _ in range(K)]
+    dWc_w, dbc_w = torch.empty_like(Wc), torch.empty(h)
+    EM.cell_cand_bwd_planar_k(Zx, Zr, Tc, Wc, dHn, U_w, Cand_w, dXc_w, dR_w, dWc_w, dbc_w)
+    dXc, dR = gx(lambda: nan(nodes, C, cin)), [nan(nodes, C, h) for _ in range(K)]
+    dWc, dbc = nan(*Wc.shape), nan(h)
+    hip.cell_cand_bwd_planar_k(cus(Zx), cus(Zr), cu(Tc), cu(Wc), cu(dHn), cu(U_w), cu(Cand_w), dXc, dR, dWc, dbc)
+    for a, w in zip(dR + (dXc if wide else []), dR_w + (dXc_w if wide else [])):
+        assert rel_err(a, w) < TOL
+    assert rel_err(dWc, dWc_w) < TOL and rel_err(dbc, dbc_w) < TOL
+    # gates backward (gate + blend backward in the prologue)
+    dRH = rnd(nodes, C, h)
+    dXg_w, dHg_w = gx(lambda: torch.empty(nodes, C, cin)), [torch.empty(nodes, C, h) for _ in range(K)]
+    dWg_w, dbg_w, dH_w = torch.empty_like(Wg), torch.empty(2 * h), torch.empty(nodes, C, h)
+    EM.cell_gates_bwd_planar_k(Zx, Zh, Tc, Wg, dRH, Cand_w, U_w, R_w, dHn, dXg_w, dHg_w, dWg_w, dbg_w, dH_w)
+    dXg, dHg = gx(lambda: nan(nodes, C, cin)), [nan(nodes, C, h) for _ in range(K)]
+    dWg, dbg, dH = nan(*Wg.shape), nan(2 * h), nan(nodes, C, h)
+    hip.cell_gates_bwd_planar_k(cus(Zx), cus(Zh), cu(Tc), cu(Wg), cu(dRH), cu(Cand_w), cu(U_w), cu(R_w), cu(dHn), dXg, dHg, dWg, dbg, dH)
+    for a, w in zip(dHg + (dXg if wide else []), dHg_w + (dXg_w if wide else [])):
+        assert rel_err(a, w) < TOL
+    assert rel_err(dWg, dWg_w) < TOL and rel_err(dbg, dbg_w) < TOL and rel_err(dH, dH_w) < TOL
+
+
 def test_fused_aggregation_is_refused_off_its_shapes(hip):
     from stc_hip import StcError
     assert not hip.cell_gather_supported(3, 3, 32, 32, 16) and not hip.cell_gather_supported(2, 2, 16, 32, 16)

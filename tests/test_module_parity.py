@@ -385,12 +385,13 @@ def test_factorised_mixed_fusion_option(dev):
         assert sum(p.numel() for p in big.parameters()) == 2 * (2 * 10 ** 6 * 8 + 10 ** 6)
 
 
-@pytest.mark.parametrize('layers,T,horizon,cin', [(2, 4, 3, 1), (1, 3, 2, 1), (3, 2, 2, 4)])
-def test_cell_graph_equals_the_per_cell_path(dev, monkeypatch, layers, T, horizon, cin):
+@pytest.mark.parametrize('layers,T,horizon,cin,K', [(2, 4, 3, 1, 2), (1, 3, 2, 1, 2), (3, 2, 2, 4, 2), (2, 3, 2, 1, 3), (3, 2, 2, 4, 3)])
+def test_cell_graph_equals_the_per_cell_path(dev, monkeypatch, layers, T, horizon, cin, K):
     """Encoder + decoder as one autograd node (no concat / gradient-accumulation passes between the cells) vs one node per
-    cell: same prediction, same parameter gradients.  Hidden 16; 32 categories on the GPU (matrix-core shapes)."""
+    cell: same prediction, same parameter gradients.  Hidden 16; 32 categories on the GPU (matrix-core shapes).  K = 3: the
+    order-3 planar cells (three Chebyshev planes per side, Clenshaw state gradients) against the per-cell slab form."""
     C = 32 if DEV == 'cuda' else 5
-    Hh, Ww, h, K, B = 5, 6, 16, 2, 2
+    Hh, Ww, h, B = 5, 6, 16, 2
     torch.manual_seed(layers * 10 + T)
     graph = CsrGraph.queen_grid(Hh, Ww, normalize=True)
     model = M.STCGNN(Hh * Ww, C, K, K, cin, h, layers, horizon, graph_mode='csr-fixed').to(DEV)
@@ -427,11 +428,14 @@ def test_cell_graph_equals_the_per_cell_path(dev, monkeypatch, layers, T, horizo
     _close(y1, y0, 1e-6, 'cell-graph prediction vs per-cell', gpu_tol=2e-6)
     assert set(g1) == set(g0)
     for n in g0:
-        _close(g1[n], g0[n], 2e-6, f'cell-graph d{n} vs per-cell', gpu_tol=5e-6)
+        # (the head's bias gradient is one long, cancelling sum over every output element, taken in (horizon, B) order on one
+        # path and (B, horizon) order on the other: summation-order noise of a few 1e-6 although the predictions are identical)
+        head_bias = n.startswith('out_proj') and n.endswith('bias')
+        _close(g1[n], g0[n], 2e-5 if head_bias else 2e-6, f'cell-graph d{n} vs per-cell', gpu_tol=2e-5 if head_bias else 5e-6)
 
 
-@pytest.mark.parametrize('planar,post_agg', [(True, True), (False, True), (False, False)])
-def test_cell_graph_general_schedules_match_autograd(dev, monkeypatch, planar, post_agg):
+@pytest.mark.parametrize('planar,post_agg,K', [(True, True, 2), (False, True, 2), (False, False, 2), (True, True, 3), (False, True, 3)])
+def test_cell_graph_general_schedules_match_autograd(dev, monkeypatch, planar, post_agg, K):
     """``ops.stc_cell_graph`` on schedules STCGNN never builds -- a state consumed by FOUR cells (twice as input, twice as state),
     a cell fed by the same state on both sides, external inputs of both widths -- against the same DAG composed from
     ``ops.stc_cell`` with autograd doing the bookkeeping.  Exercises the overflow paths of the state copies and of the
@@ -439,7 +443,7 @@ def test_cell_graph_general_schedules_match_autograd(dev, monkeypatch, planar, p
     monkeypatch.setattr(ops, '_PLANAR', planar)
     monkeypatch.setattr(ops, '_POST_AGG', post_agg)
     C = 32 if DEV == 'cuda' else 4
-    Hh, Ww, h, K, B = 4, 5, 16, 2, 2
+    Hh, Ww, h, B = 4, 5, 16, 2
     N = Hh * Ww
     torch.manual_seed(77)
     graph = CsrGraph.queen_grid(Hh, Ww, normalize=True)
