@@ -543,6 +543,57 @@ __global__ __launch_bounds__(SPMM_THREADS) void spmm_bcsr_kernel(
     }
 }
 
+// ---- row-blocked, NARROW rows (F4 = F/4 in {1, 2, 4, 8, 16} float4 per row: the layer-0 input plane, C = 32 floats = 128 bytes) --------
+// A 64-lane wave would leave all but F4 lanes idle on such rows, so it is split into G = 64 / F4 lane groups and each group
+// produces its OWN block of 4 rows: 4 G rows per wave.  Block lists differ per group, so column / values are per-lane loads
+// (identical within a group: one L1 transaction each) and the loop runs to the longest list with the finished groups masked.
+// Same arithmetic order per row as spmm_bcsr_kernel (block list order, fmaf chain), plain epilogue Y = alpha S.X + beta Y0.
+template <int F4>
+__global__ __launch_bounds__(SPMM_THREADS) void spmm_bcsr_narrow_kernel(
+    const int* __restrict__ blk_ptr, const int* __restrict__ blk_cols, const float4* __restrict__ blk_vals,
+    int n_rows, int n_cols, const float4* __restrict__ X, const float4* __restrict__ Y0, float4* __restrict__ Y,
+    int n_blocks, float alpha, float beta) {
+    constexpr int G = 64 / F4;                       // row blocks per wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane / F4, ch = lane % F4;
+    const int blk = (blockIdx.x * SPMM_WAVES + wave) * G + grp;
+    const int b = blockIdx.y;
+    if (blk >= n_blocks) return;                     // (no barriers in this kernel)
+    const int js = blk_ptr[blk], je = blk_ptr[blk + 1];
+    const float4* Xb = X + (size_t)b * n_cols * F4 + ch;
+    float4 acc[BR];
+#pragma unroll
+    for (int r = 0; r < BR; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int j = js;
+    for (; j + 3 <= je; j += 3) {                    // three neighbour rows in flight per lane
+        int c[3]; float4 v[3], x[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) { c[u] = blk_cols[j + u]; v[u] = blk_vals[j + u]; }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) x[u] = Xb[(size_t)c[u] * F4];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) { fma4(acc[0], v[u].x, x[u]); fma4(acc[1], v[u].y, x[u]); fma4(acc[2], v[u].z, x[u]); fma4(acc[3], v[u].w, x[u]); }
+    }
+    for (; j < je; ++j) {
+        const int c = blk_cols[j];
+        const float4 v = blk_vals[j], x = Xb[(size_t)c * F4];
+        fma4(acc[0], v.x, x); fma4(acc[1], v.y, x); fma4(acc[2], v.z, x); fma4(acc[3], v.w, x);
+    }
+#pragma unroll
+    for (int r = 0; r < BR; ++r) {
+        const int row = blk * BR + r;
+        if (row < n_rows) {
+            const size_t o = ((size_t)b * n_rows + row) * F4 + ch;
+            float4 y = make_float4(alpha * acc[r].x, alpha * acc[r].y, alpha * acc[r].z, alpha * acc[r].w);
+            if (beta != 0.f) {
+                const float4 y0 = Y0[o];
+                y.x = fmaf(beta, y0.x, y.x); y.y = fmaf(beta, y0.y, y.y); y.z = fmaf(beta, y0.z, y.z); y.w = fmaf(beta, y0.w, y.w);
+            }
+            Y[o] = y;
+        }
+    }
+}
+
 // Any F, any alignment (SF shape: F = C*L = 85): lanes_per_row threads share a row.
 __global__ __launch_bounds__(SPMM_THREADS) void spmm_generic_kernel(
     const int* __restrict__ rowptr, const int* __restrict__ colidx, const float* __restrict__ val,
@@ -708,6 +759,19 @@ extern "C" int stc_bcsr_spmm_f32(const int32_t* blk_ptr, const int32_t* blk_cols
     STC_REQUIRE(stc::aligned16(X) && stc::aligned16(Y) && (!Y0 || stc::aligned16(Y0)), STC_EALIGN,
                 "stc_bcsr_spmm_f32: X / Y / Y0 must be 16-byte aligned");
     STC_REQUIRE(batch <= 65535, STC_ELIMIT, "stc_bcsr_spmm_f32: batch %d > 65535 (grid.y)", batch);
+    const int F4 = F / 4;
+    if (F4 <= 16 && (F4 & (F4 - 1)) == 0) {            // narrow rows (<= 256 bytes): several row blocks per wave
+        const int n_blocks = (n_rows + BR - 1) / BR;
+        hipStream_t s = static_cast<hipStream_t>(stream);
+#define STC_NARROW_GO(F4_) hipLaunchKernelGGL((spmm_bcsr_narrow_kernel<F4_>), dim3((n_blocks + SPMM_WAVES * (64 / F4_) - 1) / (SPMM_WAVES * (64 / F4_)), batch), \
+                                              dim3(SPMM_THREADS), 0, s, blk_ptr, blk_cols, reinterpret_cast<const float4*>(blk_vals), n_rows, n_cols, \
+                                              reinterpret_cast<const float4*>(X), reinterpret_cast<const float4*>(Y0), reinterpret_cast<float4*>(Y), n_blocks, alpha, beta)
+        switch (F4) { case 1: STC_NARROW_GO(1); break; case 2: STC_NARROW_GO(2); break; case 4: STC_NARROW_GO(4); break;
+                      case 8: STC_NARROW_GO(8); break; default: STC_NARROW_GO(16); break; }
+#undef STC_NARROW_GO
+        STC_LAUNCH_CHECK("stc_bcsr_spmm_f32 (narrow rows) launch");
+        return STC_OK;
+    }
     EpiArgs ep{};
     ep.Y0 = reinterpret_cast<const float4*>(Y0);
     ep.Y = reinterpret_cast<float4*>(Y);

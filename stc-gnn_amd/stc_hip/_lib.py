@@ -286,13 +286,15 @@ class HipKernels:
         plain = Y0 is None or beta == 0
         nbytes = colidx.numel() * 8 + 4 * (n_rows + 1) + (2 if plain else 3) * 4 * B * n_rows * F
         tag = 'plain' if plain else 'with_y0'
-        if plan is not None and F % 4 == 0 and F >= 64 and all(t is None or t.data_ptr() % 16 == 0 for t in (X, Y0, Y)):
+        # row-blocked kernel: rows of >= 64 floats, or narrow rows of 4 / 8 / 16 / 32 floats (the layer-0 input plane: several row
+        # blocks per wave); anything else (odd widths, unaligned operands, no plan) goes to the CSR kernels
+        if plan is not None and F % 4 == 0 and (F >= 64 or F in (4, 8, 16, 32)) and all(t is None or t.data_ptr() % 16 == 0 for t in (X, Y0, Y)):
             blk_ptr, blk_cols, blk_vals = plan
             self._i32('spmm.blk_ptr', blk_ptr, (n_rows + 3) // 4 + 1)
             self._i32('spmm.blk_cols', blk_cols)
             self._f32('spmm.blk_vals', blk_vals, (blk_cols.numel(), 4))
             self._launch('stc_bcsr_spmm_f32', X, _ptr(blk_ptr), _ptr(blk_cols), _ptr(blk_vals), n_rows, n_cols,
-                         _ptr(X), _ptr(Y0), _ptr(Y), B, F, float(alpha), float(beta), nbytes=nbytes, tag=tag)
+                         _ptr(X), _ptr(Y0), _ptr(Y), B, F, float(alpha), float(beta), nbytes=nbytes, tag=tag if F >= 64 else tag + '_narrow_rows')
             return
         self._launch('stc_csr_spmm_f32', X, _ptr(rowptr), _ptr(colidx), _ptr(val), n_rows, n_cols, _ptr(X), _ptr(Y0), _ptr(Y), B, F, float(alpha), float(beta),
                      nbytes=nbytes, tag=tag)

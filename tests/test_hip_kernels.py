@@ -79,11 +79,13 @@ def _banded_graph(n, half_width, seed):
     return CsrGraph.from_dense(V), V
 
 
-@pytest.mark.parametrize('n,F,B,hw', [(203, 1024, 1, 4), (77, 640, 2, 3), (64, 256, 1, 6), (1001, 64, 1, 2), (30, 2048, 1, 40)])
+@pytest.mark.parametrize('n,F,B,hw', [(203, 1024, 1, 4), (77, 640, 2, 3), (64, 256, 1, 6), (1001, 64, 1, 2), (30, 2048, 1, 40),
+                                      (1001, 32, 3, 2), (203, 16, 1, 4), (77, 8, 2, 3), (50, 4, 1, 40), (4099, 32, 2, 1)])
 def test_bcsr_spmm_equals_csr(hip, n, F, B, hw):
     """Row-blocked kernel (4 output rows per wave, distinct neighbour rows fetched once per block) vs the CSR kernel
     vs a dense matmul; ragged last block (n % 4 != 0), an empty row, block lists longer than the LDS-staged
-    segment (dense band, hw=40), two column blocks (F=2048), in-place beta epilogue, both graph orientations."""
+    segment (dense band, hw=40), two column blocks (F=2048), in-place beta epilogue, both graph orientations; narrow rows of
+    4 .. 32 floats (the layer-0 input plane: several row blocks per wave, spmm_bcsr_narrow_kernel)."""
     graph, V = _banded_graph(n, hw, seed=n + F)
     d = graph.on(torch.device('cuda'))
     g = torch.Generator().manual_seed(F)
