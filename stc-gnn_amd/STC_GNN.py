@@ -316,6 +316,15 @@ class STCGNN(nn.Module):
         self.out_proj = nn.Sequential(nn.Linear(hidden_dim, hidden_dim // 2, bias=use_bias),
                                       nn.Linear(hidden_dim // 2, input_dim, bias=use_bias))
 
+    def prepare_graph(self, graph: CsrGraph, device=None) -> CsrGraph:
+        """Do at set-up time what ``forward`` would otherwise do on the first step for a ``CsrGraph`` in ``csr-fixed`` mode: the
+        host-side locality analysis (reverse Cuthill-McKee, needs scipy; skipped with a warning without it), the renumbered
+        copy when it pays, and the upload of the CSR / row-blocked arrays.  Returns ``graph`` (pass the same object to forward)."""
+        g = graph.with_locality()[0] if self.reorder_nodes else graph
+        if device is not None:
+            g.on(torch.device(device))
+        return graph
+
     def forward(self, X_seq: torch.Tensor, As: GraphLike, Ac: torch.Tensor):
         assert X_seq.dim() == 4, 'STC-GNN must take in 4D tensor as input X_seq'
         inv = None

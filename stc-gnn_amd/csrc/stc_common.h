@@ -48,13 +48,19 @@ inline hipError_t allow_lds(K kernel, size_t bytes) {
 template <typename K>
 inline int resident_blocks(K kernel, int threads, size_t lds, int fallback_per_cu = 1) {
     int per_cu = 0, dev = 0, cus = kNumCu;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds) != hipSuccess || per_cu < 1)
+    bool failed = false;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds) != hipSuccess || per_cu < 1) {
         per_cu = fallback_per_cu;
+        failed = true;
+    }
     if (hipGetDevice(&dev) == hipSuccess) {
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+        else failed = true;
+    } else {
+        failed = true;
     }
-    (void)hipGetLastError();
+    if (failed) (void)hipGetLastError();      // drop only the error a failed QUERY here left behind, never an earlier launch's
     return per_cu * cus;
 }
 

@@ -200,6 +200,7 @@ class HipKernels:
         if not torch.cuda.is_available():
             raise StcError('no ROCm device visible: the STC-GNN hot path runs on MI355X only (no CPU fallback)')
         self._workspace = {}
+        self._retired = []                            # outgrown workspaces, kept alive (see _get_workspace)
         self.timer: Optional[KernelTimer] = None      # set by bench.py to time every launch with HIP events
 
     def _launch(self, name, on, *args, nbytes=0, tag=None):
@@ -465,11 +466,19 @@ class HipKernels:
         self._launch('stc_bdg_node_fwd_f32', Y, self._ptr_array(Zs), Ks, _ptr(Tc), Kc, _ptr(W), _ptr(bias), _ptr(Y), R, Cc, L, Lw, Ho)
 
     def _get_workspace(self, device, nbytes):
-        ws = self._workspace.get(device)
+        """Scratch for the backward kernels' per-workgroup partial sums: one buffer per (device, stream) -- launches on two
+        streams never share one -- sized up front for the largest shape on the matrix-core paths, so that it is not replaced
+        in practice; if a larger request does come, the old buffer is KEPT alive (a captured HIP graph or a launch still in
+        flight may hold its address) and a new one is used from then on."""
+        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        ws = self._workspace.get(key)
         if ws is None or ws.numel() < nbytes:
-            # persistent per-device scratch: survives the trainer's torch.cuda.empty_cache() after every step
-            ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
-            self._workspace[device] = ws
+            if ws is not None:
+                self._retired.append(ws)
+            floor = self.lib.stc_bdg_node_bwd_workspace_bytes(3, 3, 64, 32, 32, 1)      # K = 3, C = 64, L = Ho = 32, dTc wanted
+            # persistent scratch: survives the trainer's torch.cuda.empty_cache() after every step
+            ws = torch.empty(max(nbytes, floor, 1 << 20), dtype=torch.uint8, device=device)
+            self._workspace[key] = ws
         return ws
 
     def bdg_node_bwd(self, Zs, Tc, W, dY, dZs, dW, db, dTc):

@@ -193,10 +193,16 @@ class CsrGraph:
         if cached is None:
             cached = (self, None)
             if self.n > 64 and self.nnz > 0:
-                order = self.locality_order()
-                cand = self.permuted(order)
-                if self.fetches_per_row[0] >= min_gain * cand.fetches_per_row[0]:
-                    cached = (cand, order)
+                try:
+                    order = self.locality_order()
+                except ImportError:                 # scipy (reverse Cuthill-McKee) is optional: without it the given order is kept
+                    import warnings
+                    warnings.warn('scipy is not installed: the spatial graph keeps its node order (no locality renumbering)')
+                    order = None
+                if order is not None:
+                    cand = self.permuted(order)
+                    if self.fetches_per_row[0] >= min_gain * cand.fetches_per_row[0]:
+                        cached = (cand, order)
             self._locality = cached
         return cached
 

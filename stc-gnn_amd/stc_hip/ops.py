@@ -25,6 +25,7 @@ first call raises ``StcError``.
 from __future__ import annotations
 
 import os
+import weakref
 from typing import Optional
 
 import torch
@@ -652,6 +653,9 @@ class _StcCellGraph(Function):
             state[j] = Hnew
         ctx.save_for_backward(Tc, *[p for st in stacks for p in st if p is not None], *saved)
         ctx.meta = (op, Ks, schedule, tuple(outputs), cin, [tuple(p is not None for p in st) for st in stacks], (B, N, C), n_saved)
+        # the saved states of the output cells ALIAS out_stack's storage without sharing its autograd version counter: the
+        # returned stack is read-only for its consumers; its version is checked again in backward
+        ctx.out_stack_ref, ctx.out_stack_version = weakref.ref(out_stack), out_stack._version      # (weak: no output -> ctx -> output cycle)
         return out_stack
 
     @staticmethod
@@ -661,6 +665,10 @@ class _StcCellGraph(Function):
         if grad_stack.dtype == torch.bfloat16:
             k = k.bf16
         op, Ks, schedule, outputs, cin, present, (B, N, C), n_saved = ctx.meta
+        stack = ctx.out_stack_ref()
+        if stack is not None and stack._version != ctx.out_stack_version:
+            raise RuntimeError('stc_cell_graph: the returned state stack was modified in place after the forward pass; the states saved for '
+                               'backward share its storage (treat the stack as read-only, or clone it before editing)')
         sv = list(ctx.saved_tensors)
         Tc = sv.pop(0)
         stacks = []

@@ -488,3 +488,21 @@ def test_cell_graph_general_schedules_match_autograd(dev, monkeypatch, planar, p
     _close(got, want, 2e-6, 'general schedule: states', gpu_tol=3e-6)
     for n in g0:
         _close(g1[n], g0[n], 3e-6, f'general schedule: d{n}', gpu_tol=6e-6)
+
+
+def test_cell_graph_output_stack_is_guarded_against_in_place_edits(dev):
+    """The states saved for backward alias the returned stack's storage (no copy); an in-place edit of the stack between
+    forward and backward is reported instead of silently corrupting the gradients."""
+    C = 32 if DEV == 'cuda' else 4
+    graph = CsrGraph.queen_grid(4, 5, normalize=True)
+    torch.manual_seed(1)
+    model = M.STCGNN(20, C, 2, 2, 1, 16, 1, 2, graph_mode='csr-fixed').to(DEV)
+    pair = M._graphs(graph, torch.softmax(torch.randn(C, C), -1).to(DEV), 2, 2)
+    X = torch.rand(2, 2, 20, C, 1).to(DEV)
+    stacked = model._run_cell_graph(pair, X)
+    assert stacked is not None
+    loss = stacked.sum()
+    with torch.no_grad():
+        stacked.mul_(2.0)
+    with pytest.raises(RuntimeError, match='modified in place'):
+        loss.backward()
