@@ -311,7 +311,8 @@ int stc_cell_blend_fwd_f32(const float* const* Z, int32_t Ks, const float* Tc, i
  * Forward: U, Rg (nodes, C, h) and the R*H plane RH -- the candidate convolution's input is (X, RH), see
  * stc_bdg_node_post_fwd_f32's X2.  Backward: as the Cand form of stc_cell_gates_bwd_f32 with dCandIn (nodes, C, h) the
  * gradient of the R*H plane (dX2 of stc_bdg_node_post_bwd_f32); the gradient slabs come out planar too:
- * dZ = {d X plane, d SX plane, d H plane, d SH plane}, (nodes, C, h) each, plus dH = the state's share from the gates.
+ * dZ = {d X plane, d SX plane, d H plane, d SH plane}, (nodes, C, h) each, plus dH = the state's share from the gates
+ * (dH = NULL: the kernel adds that share into the H plane's gradient dZ[2] itself -- one plane less to write and to sum).
  * The gradient of a state then is  sum of its consumers' direct planes + S^T (sum of their S planes): stc_spmm_sum_f32.
  * Narrow input (layer 0): Lw = cin + h with cin in 1..4 -- X / SX are (nodes, C, cin); the kernels read the slab as
  * [H | Xt | pad] (W's rows permuted inside) and the backward produces only dZ[2], dZ[3] (the input needs no gradient;

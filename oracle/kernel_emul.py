@@ -300,10 +300,15 @@ class EmulatedKernels:
 
     def cell_gates_bwd_planar_k(self, Zx, Zh, Tc, W, dRH, Cand, U, Rg, dHnew, dZx, dZh, dW, db, dH):
         cin, h = Zx[0].shape[-1], Zh[0].shape[-1]
+        fold = dH is None                                                   # the prologue's share goes into dZh[0]
+        if fold:
+            dH = torch.empty_like(Zh[0])
         rows = [torch.empty(Zh[0].shape[:-1] + (cin + h,), dtype=W.dtype) for _ in Zh]
         dCandIn = torch.cat([torch.zeros_like(Zx[0]), dRH], -1)               # only the R*H part is read
         self.cell_gates_bwd(self._cat_planes(Zx, Zh), Tc, W, dCandIn, None, Zh[0], U, Rg, dHnew, rows, dW, db, None, dH, dH_in_scaled=True, Cand=Cand)
         self._split_planes(rows, dZx, dZh, cin)
+        if fold:
+            dZh[0] += dH
 
     def cell_cand_bwd_planar_k(self, Zx, Zh, Tc, W, dHnew, U, Cand, dZx, dZh, dW, db):
         cin, h = Zx[0].shape[-1], Zh[0].shape[-1]

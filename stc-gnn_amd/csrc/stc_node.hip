@@ -531,8 +531,8 @@ extern "C" int stc_cell_gates_bwd_planar_f32(const float* X, const float* H, con
         if (db) if (int rc = stc::hip_status(hipMemsetAsync(db, 0, (size_t)Ho * sizeof(float), s), "memset db")) return rc;
         return STC_OK;
     }
-    STC_REQUIRE(X && H && SX && SH && dCandIn && Cand && U && Rg && dHnew && dH && dZ[2] && dZ[3] && (Lw != 2 * h || (dZ[0] && dZ[1])), STC_EINVAL,
-                "stc_cell_gates_bwd_planar_f32: null pointer");
+    STC_REQUIRE(X && H && SX && SH && dCandIn && Cand && U && Rg && dHnew && dZ[2] && dZ[3] && (Lw != 2 * h || (dZ[0] && dZ[1])), STC_EINVAL,
+                "stc_cell_gates_bwd_planar_f32: null pointer");       // (dH may be null: its values are then folded into dZ[2])
     STC_REQUIRE(workspace && stc::aligned16(workspace), STC_EALIGN, "stc_cell_gates_bwd_planar_f32: workspace null or not 16-byte aligned");
     STC_REQUIRE(workspace_bytes >= stc_bdg_node_bwd_workspace_bytes(2, 2, C, L, Ho, 0), STC_EINVAL,
                 "stc_cell_gates_bwd_planar_f32: workspace of %zu B is too small", workspace_bytes);
@@ -597,7 +597,7 @@ static int planar_k_bwd(const char* who, const float* const* Zx, const float* co
         if (db) if (int rc = stc::hip_status(hipMemsetAsync(db, 0, (size_t)Ho * sizeof(float), s), "memset db")) return rc;
         return STC_OK;
     }
-    STC_REQUIRE(Cand && U && dHnew && (mode != 1 || (dRH && Rg && dH)), STC_EINVAL, "%s: null pointer", who);
+    STC_REQUIRE(Cand && U && dHnew && (mode != 1 || (dRH && Rg)), STC_EINVAL, "%s: null pointer", who);      // (dH may be null: folded into dZh[0])
     STC_REQUIRE(workspace && stc::aligned16(workspace), STC_EALIGN, "%s: workspace null or not 16-byte aligned", who);
     STC_REQUIRE(workspace_bytes >= stc_bdg_node_bwd_workspace_bytes(K, K, C, L, Ho, 0), STC_EINVAL, "%s: workspace of %zu B is too small", who, workspace_bytes);
     int n_parts = 0;

@@ -123,8 +123,12 @@ struct BwdPro {
     int dh_scaled;                                    // dH_in enters as dH_in * (1 - U)
 };
 
-template <int NRB, int HB, int L, bool FROM_CAND>      // FROM_CAND is a compile-time switch: a run-time branch here would
-__device__ __forceinline__ void load_gates_grad(DyFrag<NRB, HB>& g, const BwdPro& p, int node, int j, int q) {      // split the load batches
+// FOLD (planar kernels): the state's share dH is not written to HBM; it is parked in a lane-private LDS slot (stash[kb * 64 + lane],
+// same lane writes and reads: no barrier) and becomes the initial value of the H plane's gradient tile, whose register layout --
+// lane (j, q) = row 16kb + j, columns 4q .. 4q+3 -- is exactly this one: one plane less written here and one addend less read by the
+// state-gradient SpMM, at no live register across the kernel's body (keeping the eight values in registers spilled at the 256 cap).
+template <int NRB, int HB, int L, bool FROM_CAND, bool FOLD = false>      // FROM_CAND is a compile-time switch: a run-time branch here would
+__device__ __forceinline__ void load_gates_grad(DyFrag<NRB, HB>& g, const BwdPro& p, int node, int j, int q, float4* stash = nullptr) {      // split the load batches
     static_assert(HB == 2, "gates prologue needs Ho = 2 * 16");
     constexpr int C = 16 * NRB, HID = 16;
     const size_t r0 = (size_t)node * C;
@@ -161,7 +165,9 @@ __device__ __forceinline__ void load_gates_grad(DyFrag<NRB, HB>& g, const BwdPro
         else d = make_float4(cr[p.cin + 4 * q], cr[p.cin + 4 * q + 1], cr[p.cin + 4 * q + 2], cr[p.cin + 4 * q + 3]);
         g.v[kb][0] = f32x4{du.x * u.x * (1.f - u.x), du.y * u.y * (1.f - u.y), du.z * u.z * (1.f - u.z), du.w * u.w * (1.f - u.w)};
         g.v[kb][1] = f32x4{d.x * hh.x * r.x * (1.f - r.x), d.y * hh.y * r.y * (1.f - r.y), d.z * hh.z * r.z * (1.f - r.z), d.w * hh.w * r.w * (1.f - r.w)};
-        *reinterpret_cast<float4*>(p.dH + e) = make_float4(d.x * r.x + own.x, d.y * r.y + own.y, d.z * r.z + own.z, d.w * r.w + own.w);
+        const float4 dh = make_float4(d.x * r.x + own.x, d.y * r.y + own.y, d.z * r.z + own.z, d.w * r.w + own.w);
+        if constexpr (FOLD) stash[kb * 64 + (q * 16 + j)] = dh;
+        else *reinterpret_cast<float4*>(p.dH + e) = dh;
         if (p.dXt)
             for (int c0 = 4 * q; c0 < p.cin; c0 += 16)
 #pragma unroll

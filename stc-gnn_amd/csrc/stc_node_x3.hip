@@ -492,7 +492,7 @@ struct NodeIn {      // what one node contributes from HBM: its dY fragments and
 template <int NB2, int K>
 struct BwdSched { static constexpr int waves = (NB2 == 1 && K <= 2) ? 2 : 1; };
 
-template <int NB2, int HB, int K, int L, int PRO, int PL = 0>
+template <int NB2, int HB, int K, int L, int PRO, int PL = 0, int FOLD = 0>      // FOLD: see load_gates_grad (planar gates backward only)
 __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bwd_x3_kernel(
     ZPtrs Z, const float* __restrict__ Tc, const float* __restrict__ W, const float* __restrict__ dY,
     DZPtrs dZ, float* __restrict__ partial, int nodes, int want_db, int Lw, BwdPro pro) {
@@ -503,7 +503,9 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32x4* TB = reinterpret_cast<u32x4*>(smem_raw);     // [K-1][NRB rb][NB2 p]   T_c[16rb + x][32p + pair_row]
     u32x4* WA = TB + nTB * 3 * 64;                       // [K n][LB][S]           W[(n, c, 16lb + x)][16hb + 4g + (e&3)], block 2s + (e>>2)
+    static_assert(!FOLD || ((PRO == PRO_GATES || PRO == PRO_GATES_CAND) && PL != 0), "FOLD belongs to the planar gates backward");
     const int tid = threadIdx.x, lane = tid & 63, x = lane & 15, g = lane >> 4;
+    float4* stash = reinterpret_cast<float4*>(WA + nWA * 3 * 64) + (tid >> 6) * NRB * 64;     // FOLD: [wave][NRB][64 lanes], lane-private
 
     for (int idx = tid; idx < nTB * 64; idx += MF_THREADS) {
         const int ll = idx & 63, f = idx >> 6, p = f % NB2, rb = (f / NB2) % NRB, c1 = f / (NB2 * NRB), gg = ll >> 4;
@@ -553,7 +555,7 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
         const size_t r0 = (size_t)node * C;
         if constexpr (PRO == PRO_GATES || PRO == PRO_GATES_CAND) {
             // planar: dCandIn is the R*H plane's gradient alone, (nodes, C, 16) with the state columns at offset 0
-            load_gates_grad<NRB, HB, (PL ? 16 : L), PRO == PRO_GATES_CAND>(in.g, pro, node, x, g);
+            load_gates_grad<NRB, HB, (PL ? 16 : L), PRO == PRO_GATES_CAND, FOLD != 0>(in.g, pro, node, x, g, stash);
             in.load_z(Z, node, x, g, Lw - 16);
         }
         else if constexpr (PRO == PRO_BLEND) { load_blend_grad<NRB>(in.g, pro, node, x, g); in.load_z(Z, node, x, g, Lw - 16); }
@@ -613,8 +615,16 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
 #pragma unroll
             for (int lb = 0; lb < LB; ++lb) {
                 f32x4 z[NRB];
+                constexpr int HLB = PL == 2 ? 0 : 1;            // the block of the row that is the H (state) plane
 #pragma unroll
-                for (int rb = 0; rb < NRB; ++rb) z[rb] = kZero4;
+                for (int rb = 0; rb < NRB; ++rb) {
+                    if (FOLD && n == 0 && lb == HLB) {          // the tile starts from the state's share parked by the prologue
+                        const float4 sh = stash[rb * 64 + lane];
+                        z[rb] = f32x4{sh.x, sh.y, sh.z, sh.w};
+                    } else {
+                        z[rb] = kZero4;
+                    }
+                }
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
                     const X3 w = get_frag(WA, (n * LB + lb) * S + s, lo);
@@ -1007,15 +1017,15 @@ int launch_fwd(const float* const* Z, const float* Tc, const float* W, const flo
     return STC_OK;
 }
 
-template <int NB2, int HB, int K, int L, int PRO = PRO_NONE, int PL = 0>
+template <int NB2, int HB, int K, int L, int PRO = PRO_NONE, int PL = 0, int FOLD = 0>
 int launch_bwd(const float* const* Z, const float* Tc, const float* W, const float* dY, float* const* dZ,
                float* partial, int* n_partials, int want_db, long long nodes, int Lw, hipStream_t stream, BwdPro pro = BwdPro{}) {
     constexpr int NRB = 2 * NB2, Ho = 16 * HB, LB = (L + 15) / 16, NBK = K * HB, S = (NBK + 1) / 2, nW = K * K * L * Ho;
-    const size_t frag = (size_t)((K - 1) * NRB * NB2 + K * LB * S) * 3 * 64 * 16;
+    const size_t frag = (size_t)((K - 1) * NRB * NB2 + K * LB * S) * 3 * 64 * 16 + (FOLD ? (size_t)MF_WAVES * NRB * 64 * 16 : 0);
     const size_t slabs = (size_t)MF_WAVES * (nW + Ho) * sizeof(float);
     const size_t lds = frag > slabs ? frag : slabs;
     if (lds > stc::kMaxLdsBytes) return STC_NOT_HANDLED;
-    auto kern = node_bwd_x3_kernel<NB2, HB, K, L, PRO, PL>;
+    auto kern = node_bwd_x3_kernel<NB2, HB, K, L, PRO, PL, FOLD>;
     if (int rc = stc::hip_status(stc::allow_lds(kern, lds), "hipFuncSetAttribute(node bwd x3)")) return rc;
     static const int resident = stc::resident_blocks(kern, MF_THREADS, lds, BwdSched<NB2, K>::waves);
     ZPtrs zp{};
@@ -1323,12 +1333,14 @@ int stc_cell_gates_bwd_planar_x3(const float* X, const float* H, const float* SX
     if (!x3_cell_shape(2, C, cin == 16 ? 32 : 20, nodes) || !(cin == 16 || (cin >= 1 && cin <= 4))) return STC_NOT_HANDLED;
     if (cin != 16) {                               // narrow input plane: only d H plane (dZ[2]) and d SH plane (dZ[3]) are produced
         if (!(stc::aligned16(H) && stc::aligned16(SH) && dZ[2] && dZ[3] && stc::aligned16(dZ[2]) && stc::aligned16(dZ[3]))) return STC_NOT_HANDLED;
-        if (!(stc::aligned16(dCandIn) && stc::aligned16(Cand) && stc::aligned16(U) && stc::aligned16(R) && stc::aligned16(dHnew) && stc::aligned16(dH)))
+        if (!(stc::aligned16(dCandIn) && stc::aligned16(Cand) && stc::aligned16(U) && stc::aligned16(R) && stc::aligned16(dHnew) && (!dH || stc::aligned16(dH))))
             return STC_NOT_HANDLED;
         const float* Zn[4] = {H, SH, X, SX};
         float* dZn[4] = {dZ[2], dZ[3], nullptr, nullptr};
         BwdPro pn{};
         pn.Cand = Cand; pn.dCandIn = dCandIn; pn.H = H; pn.U = U; pn.R = R; pn.dH_in = dHnew; pn.dH = dH; pn.cin = 0; pn.dh_scaled = 1;
+        if (C == 32 && !dH) return launch_bwd<1, 2, 2, 20, PRO_GATES_CAND, 2, 1>(Zn, Tc, W, nullptr, dZn, partial, n_partials, want_db, nodes, Lw, stream, pn);
+        if (C == 64 && !dH) return launch_bwd<2, 2, 2, 20, PRO_GATES_CAND, 2, 1>(Zn, Tc, W, nullptr, dZn, partial, n_partials, want_db, nodes, Lw, stream, pn);
         if (C == 32) return launch_bwd<1, 2, 2, 20, PRO_GATES_CAND, 2>(Zn, Tc, W, nullptr, dZn, partial, n_partials, want_db, nodes, Lw, stream, pn);
         if (C == 64) return launch_bwd<2, 2, 2, 20, PRO_GATES_CAND, 2>(Zn, Tc, W, nullptr, dZn, partial, n_partials, want_db, nodes, Lw, stream, pn);
         return STC_NOT_HANDLED;
@@ -1337,10 +1349,13 @@ int stc_cell_gates_bwd_planar_x3(const float* X, const float* H, const float* SX
     if (!all_aligned16(Z, 4)) return STC_NOT_HANDLED;
     for (int i = 0; i < 4; ++i)
         if (!dZ[i] || !stc::aligned16(dZ[i])) return STC_NOT_HANDLED;
-    if (!(stc::aligned16(dCandIn) && stc::aligned16(Cand) && stc::aligned16(U) && stc::aligned16(R) && stc::aligned16(dHnew) && stc::aligned16(dH)))
+    if (!(stc::aligned16(dCandIn) && stc::aligned16(Cand) && stc::aligned16(U) && stc::aligned16(R) && stc::aligned16(dHnew) && (!dH || stc::aligned16(dH))))
         return STC_NOT_HANDLED;
     BwdPro pro{};       // dCandIn: the gradient of the R*H plane, (nodes, C, 16): the state columns sit at offset 0
     pro.Cand = Cand; pro.dCandIn = dCandIn; pro.H = H; pro.U = U; pro.R = R; pro.dH_in = dHnew; pro.dH = dH; pro.cin = 0; pro.dh_scaled = 1;
+    // dH == null: the state's share from the gate prologue is folded into the H plane's gradient dZ[2] (FOLD)
+    if (C == 32 && !dH) return launch_bwd<1, 2, 2, 32, PRO_GATES_CAND, 1, 1>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro);
+    if (C == 64 && !dH) return launch_bwd<2, 2, 2, 32, PRO_GATES_CAND, 1, 1>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro);
     if (C == 32) return launch_bwd<1, 2, 2, 32, PRO_GATES_CAND, 1>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro);
     if (C == 64) return launch_bwd<2, 2, 2, 32, PRO_GATES_CAND, 1>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro);
     return STC_NOT_HANDLED;
@@ -1387,8 +1402,11 @@ int stc_cell_conv_bwd_planar_k_x3(const float* const* Zx, const float* const* Zh
     if (!(stc::aligned16(Cand) && stc::aligned16(U) && stc::aligned16(dHnew))) return STC_NOT_HANDLED;
     BwdPro pro{};
     if (mode == 1) {
-        if (!(stc::aligned16(dRH) && stc::aligned16(R) && stc::aligned16(dH))) return STC_NOT_HANDLED;
+        if (!(stc::aligned16(dRH) && stc::aligned16(R) && (!dH || stc::aligned16(dH)))) return STC_NOT_HANDLED;
         pro.Cand = Cand; pro.dCandIn = dRH; pro.H = Zh[0]; pro.U = U; pro.R = R; pro.dH_in = dHnew; pro.dH = dH; pro.cin = 0; pro.dh_scaled = 1;
+        if (!dH)        // the state's share from the gate prologue is folded into dZh[0]
+            return cin == 16 ? launch_bwd<1, 2, 3, 32, PRO_GATES_CAND, 1, 1>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro)
+                             : launch_bwd<1, 2, 3, 20, PRO_GATES_CAND, 2, 1>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro);
         return cin == 16 ? launch_bwd<1, 2, 3, 32, PRO_GATES_CAND, 1>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro)
                          : launch_bwd<1, 2, 3, 20, PRO_GATES_CAND, 2>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro);
     }

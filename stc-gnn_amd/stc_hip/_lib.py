@@ -194,6 +194,8 @@ class HipKernels:
     """Tensor-level front of the C ABI; the one object ``stc_hip.ops`` launches through."""
 
     name = 'hip-gfx950'
+    #: the planar gates backward adds the state's share from its gate prologue into the H plane's gradient itself (dH=None)
+    folds_dH = os.environ.get('STC_FOLD_DH', '1') != '0'
 
     def __init__(self):
         self.lib = load_library()
@@ -683,8 +685,8 @@ class HipKernels:
         R, Cc, h, cin = self._planes('planar', X, H, SX, SH)
         self._f32('planar.Tc', Tc, (2, Cc, Cc))
         self._f32('planar.W', W, (4 * (cin + h), 2 * h))
-        for name, t in (('dRH', dRH), ('Cand', Cand), ('U', U), ('Rg', Rg), ('dHnew', dHnew), ('dH', dH)):
-            self._f32('planar.' + name, t, (R, Cc, h))
+        for name, t in (('dRH', dRH), ('Cand', Cand), ('U', U), ('Rg', Rg), ('dHnew', dHnew)) + ((('dH', dH),) if dH is not None else ()):
+            self._f32('planar.' + name, t, (R, Cc, h))      # dH None: the kernel folds the state's share into dZs[2]
         if len(dZs) != 4:
             raise StcError('planar gates backward: four gradient planes (dX, dSX, dH, dSH)')
         for i, z in enumerate(dZs):
@@ -753,8 +755,8 @@ class HipKernels:
 
     def cell_gates_bwd_planar_k(self, Zx, Zh, Tc, W, dRH, Cand, U, Rg, dHnew, dZx, dZh, dW, db, dH):
         K, R, Cc, h, cin = self._planes_k('planar_k gates bwd', Zx, Zh, Tc, W, 2 * Zh[0].shape[-1])
-        for name, t in (('dRH', dRH), ('Cand', Cand), ('U', U), ('Rg', Rg), ('dHnew', dHnew), ('dH', dH)):
-            self._f32('planar_k.' + name, t, (R, Cc, h))
+        for name, t in (('dRH', dRH), ('Cand', Cand), ('U', U), ('Rg', Rg), ('dHnew', dHnew)) + ((('dH', dH),) if dH is not None else ()):
+            self._f32('planar_k.' + name, t, (R, Cc, h))    # dH None: the kernel folds the state's share into dZh[0]
         zx, zh = self._grad_planes_k('planar_k gates bwd', dZx, dZh, K, R, Cc, h, cin)
         self._f32('planar_k.dW', dW, tuple(W.shape))
         if db is not None:

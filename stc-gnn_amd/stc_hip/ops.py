@@ -776,14 +776,16 @@ class _StcCellGraph(Function):
                                          [None if t is None else t.view(B * N, C, h) for t in dXc], rows(dR), dWc, dbc)
                 dRH = clenshaw([dR[0]], [dR[1]], [dR[2]])            # gradient of the R*H plane from its three Chebyshev planes
                 del dR
-                dXg, dHg, dH = ([new(), new(), new()] if wide else [None] * 3), [new(), new(), new()], new()
+                fold = getattr(k, 'folds_dH', False)                  # the kernel adds the prologue's share into the H plane's gradient
+                dXg, dHg, dH = ([new(), new(), new()] if wide else [None] * 3), [new(), new(), new()], (None if fold else new())
                 dWg, dbg = torch.empty_like(Wg), (Wg.new_empty(2 * h) if bg is not None else None)
                 k.cell_gates_bwd_planar_k(rows(Zx), rows(Zh), Tc, Wg, *rows((dRH, Cand, U, Rg, dHnew)),
-                                          [None if t is None else t.view(B * N, C, h) for t in dXg], rows(dHg), dWg, dbg, dH.view(B * N, C, h))
+                                          [None if t is None else t.view(B * N, C, h) for t in dXg], rows(dHg), dWg, dbg,
+                                          None if fold else dH.view(B * N, C, h))
                 if wide and x[0] == 'cell':
                     leave3(x[1], (dXg[0], dXc[0]), (dXg[1], dXc[1]), (dXg[2], dXc[2]))
                 if hs[0] == 'cell':
-                    leave3(hs[1], (dHg[0], dH), (dHg[1],), (dHg[2],))
+                    leave3(hs[1], (dHg[0],) if fold else (dHg[0], dH), (dHg[1],), (dHg[2],))
                 for i, t in enumerate((dWg, dbg, dWc, dbc)):
                     add_to(acc[s_id], i, t)
                 continue

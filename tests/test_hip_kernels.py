@@ -526,6 +526,12 @@ def test_planar_cell_kernels(hip, nodes, C):
     for a, w in zip(dZ, dZ_w):
         assert rel_err(a, w) < TOL
     assert rel_err(dW, dW_w) < TOL and rel_err(db, db_w) < TOL and rel_err(dH, dH_w) < TOL
+    # dH = None: the kernel folds the state's share from the gate prologue into the H plane's gradient (lane-private LDS slot)
+    dZf = [nan(nodes, C, h) for _ in range(4)]
+    hip.cell_gates_bwd_planar(cu(X), cu(H), cu(SX), cu(SH), cu(Tc), cu(Wg), cu(dRH), cu(Cand), cu(U_w), cu(R_w), cu(dHn), dZf, dW, db, None)
+    assert rel_err(dZf[2], dZ_w[2] + dH_w) < TOL and rel_err(dW, dW_w) < TOL
+    for i in (0, 1, 3):
+        assert torch.equal(dZf[i], dZ[i])
 
     Wc, bc = rnd(K * K * 2 * h, h) / (8 * h) ** 0.5, rnd(h)
     A_w, B_w = torch.empty(nodes, C, h), torch.empty(nodes, C, h)
@@ -575,6 +581,9 @@ def test_planar_cell_kernels_narrow_input(hip, nodes, C, cin):
     hip.cell_gates_bwd_planar(cu(X), cu(H), cu(SX), cu(SH), cu(Tc), cu(Wg), cu(dRH), cu(Cand), cu(U_w), cu(R_w), cu(dHn), dZ, dW, db, dH)
     assert rel_err(dZ[2], dZ_w[2]) < TOL and rel_err(dZ[3], dZ_w[3]) < TOL
     assert rel_err(dW, dW_w) < TOL and rel_err(db, db_w) < TOL and rel_err(dH, dH_w) < TOL
+    dZf = [None, None, nan(nodes, C, h), nan(nodes, C, h)]               # dH = None: the share is folded into the H plane's gradient
+    hip.cell_gates_bwd_planar(cu(X), cu(H), cu(SX), cu(SH), cu(Tc), cu(Wg), cu(dRH), cu(Cand), cu(U_w), cu(R_w), cu(dHn), dZf, dW, db, None)
+    assert rel_err(dZf[2], dZ_w[2] + dH_w) < TOL and torch.equal(dZf[3], dZ[3])
 
     Wc, bc = rnd(K * K * Lw, h) / (4 * Lw) ** 0.5, rnd(h)
     A_w, B_w = torch.empty(nodes, C, h), torch.empty(nodes, C, h)
@@ -706,6 +715,9 @@ def test_planar_cell_kernels_order3(hip, nodes, cin):
     for a, w in zip(dHg + (dXg if wide else []), dHg_w + (dXg_w if wide else [])):
         assert rel_err(a, w) < TOL
     assert rel_err(dWg, dWg_w) < TOL and rel_err(dbg, dbg_w) < TOL and rel_err(dH, dH_w) < TOL
+    dHf = [nan(nodes, C, h) for _ in range(K)]                            # dH = None: folded into dZh[0]
+    hip.cell_gates_bwd_planar_k(cus(Zx), cus(Zh), cu(Tc), cu(Wg), cu(dRH), cu(Cand_w), cu(U_w), cu(R_w), cu(dHn), dXg, dHf, dWg, dbg, None)
+    assert rel_err(dHf[0], dHg_w[0] + dH_w) < TOL and torch.equal(dHf[1], dHg[1]) and torch.equal(dHf[2], dHg[2])
 
 
 def test_fused_aggregation_is_refused_off_its_shapes(hip):
