@@ -361,6 +361,20 @@ int stc_cell_cand_bwd_planar_k_f32(const float* const* Zx, const float* const* Z
                                    float* const* dZx, float* const* dZh, float* dW, float* db,
                                    void* workspace, size_t workspace_bytes, int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream);
 
+/* Post-aggregation form of an order-3 convolution on planar input (the candidate convolution of the order-3 planar cell):
+ *     Y = sum_n T_n(S) P_n,  P_n = sum_c T_c^T ([X | X2] W_{n,c})     =>     Y = (P_0 - P_2 + b) + S x (P_1 + 2 S x P_2)   (Clenshaw)
+ * fwd writes P[0] = P_0 - P_2 + b, P[1] = P_1, P[2] = P_2, each (nodes, C, Ho); the caller runs the two narrow SpMMs
+ * (M = P[1] + 2 S x P[2] with stc_bcsr_spmm_f32's Y0; Y = P[0] + S x M with stc_spmm_blend_fwd_f32).  bwd takes dP[0] = dY,
+ * dP[1] = S^T dY, dP[2] = 2 S^T dP[1] - dY and returns dX (, dX2), dW, db -- one direct gradient plane per input plane, no
+ * aggregated pieces.  X: the 16-wide plane; X2: the second 16-wide plane (L = 32) or the narrow input plane (L = 20, Lw - 16 in 1..4
+ * columns, no gradient: dX2 = NULL).  K = 3, C = 32, Ho = 16; stc_bdg_node_post_k_supported() tells. */
+int stc_bdg_node_post_k_supported(int32_t K, int32_t C, int32_t L, int32_t Ho);
+int stc_bdg_node_post_fwd_k_f32(const float* X, const float* X2, int32_t K, const float* Tc, const float* W, const float* bias,
+                                float* const* P, int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t Ho, void* stream);
+int stc_bdg_node_post_bwd_k_f32(const float* X, const float* X2, int32_t K, const float* Tc, const float* W, const float* const* dP,
+                                float* dX, float* dX2, float* dW, float* db, void* workspace, size_t workspace_bytes,
+                                int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t Ho, void* stream);
+
 /* Y = sum_i add_scale[i] add[i] + alpha S x (X [+ X2]) on rows of C*h floats (h = 16): the gradient of a state from the pieces
  * its consumers left -- direct planes as addends (add[i]: columns [add_off[i], add_off[i]+h) of rows of add_ld[i] floats,
  * multiples of 4; a contiguous plane is ld = h, off = 0), aggregated planes X, X2 through the transposed graph.

@@ -275,6 +275,48 @@ class EmulatedKernels:
             U, Cand, dY = blend
             dY.copy_(Y * U * (1 - Cand * Cand))
 
+    # post-aggregation form at order 3 on planar input: P = [P_0 - P_2 + b, P_1, P_2], P_n = sum_c T_c^T ([X | X2] W_{n,c})
+    def node_post_k_supported(self, K, Cc, L, Ho) -> bool:
+        return K == 3 and Ho == 16
+
+    @staticmethod
+    def _post_k_row(X, X2):
+        return torch.cat([X, X2], -1) if X2.shape[-1] == X.shape[-1] else torch.cat([X2, X], -1)      # narrow: reference order [input | 16-wide]
+
+    def node_post_fwd_k(self, X, Tc, W, bias, P, X2):
+        K = len(P)
+        row = self._post_k_row(X, X2)
+        Lw = W.shape[0] // (K * K)
+        Pn = []
+        for n in range(K):
+            acc = torch.zeros_like(P[0])
+            for c in range(K):
+                proj = row[..., :Lw] @ W[(n * K + c) * Lw:(n * K + c + 1) * Lw]
+                acc += proj if c == 0 else torch.einsum('pd,rpo->rdo', Tc[c], proj)
+            Pn.append(acc)
+        P[0].copy_(Pn[0] - Pn[2] + (bias if bias is not None else 0))
+        P[1].copy_(Pn[1]); P[2].copy_(Pn[2])
+
+    def node_post_bwd_k(self, X, Tc, W, dP, dX, dW, db, X2, dX2=None):
+        K = len(dP)
+        row = self._post_k_row(X, X2)
+        Lw = W.shape[0] // (K * K)
+        drow = torch.zeros_like(row)
+        dW.zero_()
+        for n in range(K):
+            for c in range(K):
+                Q = dP[n] if c == 0 else torch.einsum('pd,rdo->rpo', Tc[c], dP[n])
+                Wnc = W[(n * K + c) * Lw:(n * K + c + 1) * Lw]
+                drow[..., :Lw] += torch.einsum('rpo,lo->rpl', Q, Wnc)
+                dW[(n * K + c) * Lw:(n * K + c + 1) * Lw] += torch.einsum('rpl,rpo->lo', row[..., :Lw], Q)
+        if db is not None:
+            db.copy_(dP[0].sum((0, 1)))
+        w, w2 = X.shape[-1], X2.shape[-1]
+        if w2 == w:
+            dX.copy_(drow[..., :w]); dX2.copy_(drow[..., w:])
+        else:
+            dX.copy_(drow[..., w2:])
+
     # planar cell convolutions of order K (stc_cell_*_planar_k_f32): composed from the slab-form twins on concatenated planes
     def cell_planar_k_supported(self, K, Cc, h) -> bool:
         return K == 3 and h == 16

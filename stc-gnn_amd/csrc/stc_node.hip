@@ -677,6 +677,56 @@ extern "C" int stc_bdg_node_post_bwd_f32(const float* X, const float* X2, const 
     return STC_OK;
 }
 
+// ---- post-aggregation form at Chebyshev order 3 (planar input): see node_fwd2k_x3_kernel
+extern "C" int stc_bdg_node_post_k_supported(int32_t K, int32_t C, int32_t L, int32_t Ho) {
+    return (x3_enabled() && stc_node_post_k_shape_ok(K, C, L, Ho)) ? 1 : 0;
+}
+
+extern "C" int stc_bdg_node_post_fwd_k_f32(const float* X, const float* X2, int32_t K, const float* Tc, const float* W, const float* bias,
+                                           float* const* P, int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t Ho, void* stream) {
+    if (int rc = check_dims("stc_bdg_node_post_fwd_k_f32", K, K, C, L, Lw, Ho, nodes)) return rc;
+    if (!stc_bdg_node_post_k_supported(K, C, L, Ho)) return stc::fail(STC_EUNSUPPORTED, "stc_bdg_node_post_fwd_k_f32: K=%d C=%d L=%d Ho=%d is not built", K, C, L, Ho);
+    if (nodes == 0) return STC_OK;
+    STC_REQUIRE(X && X2 && Tc && W && P, STC_EINVAL, "stc_bdg_node_post_fwd_k_f32: null pointer (the order-K form takes planar input: X and X2)");
+    for (int n = 0; n < K; ++n) STC_REQUIRE(P[n] && P[n] != X && P[n] != X2, STC_EINVAL, "stc_bdg_node_post_fwd_k_f32: output plane %d null or aliasing the input", n);
+    STC_REQUIRE(P[0] != P[1] && P[0] != P[2] && P[1] != P[2], STC_EINVAL, "stc_bdg_node_post_fwd_k_f32: outputs must not alias");
+    STC_REQUIRE(L == 32 || (L == 20 && Lw > 16), STC_EINVAL, "stc_bdg_node_post_fwd_k_f32: rows of 16 + 16 or 16 + cin (<= 4) columns, L = %d", L);
+    const int rc = stc_node_post_fwd_k_x3(X, X2, K, Tc, W, bias, P, nodes, C, L, Lw, Ho, static_cast<hipStream_t>(stream));
+    return rc == STC_NOT_HANDLED ? stc::fail(STC_EUNSUPPORTED, "stc_bdg_node_post_fwd_k_f32: operands not usable (alignment)") : rc;
+}
+
+extern "C" int stc_bdg_node_post_bwd_k_f32(const float* X, const float* X2, int32_t K, const float* Tc, const float* W, const float* const* dP,
+                                           float* dX, float* dX2, float* dW, float* db, void* workspace, size_t workspace_bytes,
+                                           int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t Ho, void* stream) {
+    if (int rc = check_dims("stc_bdg_node_post_bwd_k_f32", K, K, C, L, Lw, Ho, nodes)) return rc;
+    if (!stc_bdg_node_post_k_supported(K, C, L, Ho)) return stc::fail(STC_EUNSUPPORTED, "stc_bdg_node_post_bwd_k_f32: K=%d C=%d L=%d Ho=%d is not built", K, C, L, Ho);
+    STC_REQUIRE(W && dW && Tc, STC_EINVAL, "stc_bdg_node_post_bwd_k_f32: null W/dW/Tc");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int nW = K * K * Lw * Ho;
+    if (nodes == 0) {
+        if (int rc = stc::hip_status(hipMemsetAsync(dW, 0, (size_t)nW * sizeof(float), s), "memset dW")) return rc;
+        if (db) if (int rc = stc::hip_status(hipMemsetAsync(db, 0, (size_t)Ho * sizeof(float), s), "memset db")) return rc;
+        return STC_OK;
+    }
+    STC_REQUIRE(X && X2 && dP && dX, STC_EINVAL, "stc_bdg_node_post_bwd_k_f32: null pointer");
+    for (int n = 0; n < K; ++n) STC_REQUIRE(dP[n], STC_EINVAL, "stc_bdg_node_post_bwd_k_f32: gradient plane %d is null", n);
+    STC_REQUIRE(L == 20 ? dX2 == nullptr : dX2 != nullptr, STC_EINVAL,
+                "stc_bdg_node_post_bwd_k_f32: dX2 goes with 16 + 16 column rows and only with them (a narrow input plane gets no gradient)");
+    STC_REQUIRE(workspace && stc::aligned16(workspace), STC_EALIGN, "stc_bdg_node_post_bwd_k_f32: workspace null or not 16-byte aligned");
+    STC_REQUIRE(workspace_bytes >= stc_bdg_node_bwd_workspace_bytes(K, K, C, L, Ho, 0), STC_EINVAL,
+                "stc_bdg_node_post_bwd_k_f32: workspace of %zu B is too small", workspace_bytes);
+    int n_parts = 0;
+    float* partial = static_cast<float*>(workspace);
+    const int rc = stc_node_post_bwd_k_x3(X, X2, K, Tc, W, dP, dX, dX2, partial, &n_parts, db != nullptr, nodes, C, L, Lw, Ho, s);
+    if (rc == STC_NOT_HANDLED) return stc::fail(STC_EUNSUPPORTED, "stc_bdg_node_post_bwd_k_f32: operands not usable (alignment)");
+    if (rc != STC_OK) return rc;
+    const int stride = nW + Ho;
+    hipLaunchKernelGGL(bdg_node_reduce_kernel, dim3((stride + RED_ELEMS - 1) / RED_ELEMS), dim3(NODE_THREADS), 0, s,
+                       partial, n_parts, stride, nW, Ho, 0, dW, db, static_cast<float*>(nullptr));
+    STC_LAUNCH_CHECK("stc_bdg_node_reduce launch");
+    return STC_OK;
+}
+
 extern "C" int stc_cell_blend_fwd_f32(const float* const* Z, int32_t Ks, const float* Tc, int32_t Kc,
                                       const float* W, const float* bias, const float* U, const float* H,
                                       float* Cand, float* Hnew,

@@ -103,5 +103,12 @@ int stc_cell_conv_bwd_planar_k_x3(const float* const* Zx, const float* const* Zh
                                   float* const* dZx, float* const* dZh, float* dH, float* partial, int* n_partials, int want_db,
                                   long long nodes, int C, int Lw, hipStream_t stream);
 
+// Post-aggregation form at order 3 (planar input only): P[0] = P_0 - P_2 + b, P[1] = P_1, P[2] = P_2; backward from dP[0..2].
+int stc_node_post_k_shape_ok(int K, int C, int L, int Ho);
+int stc_node_post_fwd_k_x3(const float* X, const float* X2, int K, const float* Tc, const float* W, const float* bias, float* const* P,
+                           long long nodes, int C, int L, int Lw, int Ho, hipStream_t stream);
+int stc_node_post_bwd_k_x3(const float* X, const float* X2, int K, const float* Tc, const float* W, const float* const* dP, float* dX, float* dX2,
+                           float* partial, int* n_partials, int want_db, long long nodes, int C, int L, int Lw, int Ho, hipStream_t stream);
+
 // Fixed-order reduction of the backward kernels' per-workgroup partial rows [dW (nW) | db (Ho)] into dW, db (db may be null).
 int stc_node_reduce_partials(const float* partial, int n_parts, int nW, int Ho, float* dW, float* db, hipStream_t stream);

@@ -36,7 +36,7 @@ EXPORTS = (
     'stc_cell_fused_supported', 'stc_cell_gates_fwd_f32', 'stc_cell_gates_bwd_f32', 'stc_cell_cand_bwd_f32', 'stc_cell_blend_fwd_f32',
     'stc_cell_planar_supported', 'stc_cell_gates_fwd_planar_f32', 'stc_cell_gates_bwd_planar_f32', 'stc_spmm_sum_f32',
     'stc_cell_planar_k_supported', 'stc_cell_gates_fwd_planar_k_f32', 'stc_cell_cand_fwd_planar_k_f32', 'stc_cell_gates_bwd_planar_k_f32',
-    'stc_cell_cand_bwd_planar_k_f32',
+    'stc_cell_cand_bwd_planar_k_f32', 'stc_bdg_node_post_k_supported', 'stc_bdg_node_post_fwd_k_f32', 'stc_bdg_node_post_bwd_k_f32',
     'stc_cell_gather_supported', 'stc_cell_gates_fwd_gather_f32', 'stc_cell_blend_fwd_gather_f32',
     'stc_gru_gates_fwd_f32', 'stc_gru_gates_bwd_f32', 'stc_gru_blend_fwd_f32', 'stc_gru_blend_bwd_f32',
     'stc_head_fwd_f32', 'stc_head_bwd_workspace_bytes', 'stc_head_bwd_f32',
@@ -96,6 +96,8 @@ def _declare(lib):
                                             _p, C.c_size_t, _i64, _i32, _i32, _i32, _p],
         'stc_cell_cand_bwd_planar_k_f32': [C.POINTER(_p), C.POINTER(_p), _i32, _p, _p, _p, _p, _p, C.POINTER(_p), C.POINTER(_p), _p, _p,
                                            _p, C.c_size_t, _i64, _i32, _i32, _i32, _p],
+        'stc_bdg_node_post_fwd_k_f32': [_p, _p, _i32, _p, _p, _p, C.POINTER(_p), _i64, _i32, _i32, _i32, _i32, _p],
+        'stc_bdg_node_post_bwd_k_f32': [_p, _p, _i32, _p, _p, C.POINTER(_p), _p, _p, _p, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _i32, _p],
         'stc_cell_gates_fwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _i32, _p],
         'stc_cell_cand_bwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _p, C.POINTER(_p), _p, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _i32, _p],
         'stc_cell_gates_bwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _i32, C.POINTER(_p), _p, _p, _p, _p,
@@ -130,6 +132,8 @@ def _declare(lib):
     lib.stc_cell_planar_supported.argtypes = [_i32, _i32, _i32, _i32]
     lib.stc_cell_planar_k_supported.restype = C.c_int
     lib.stc_cell_planar_k_supported.argtypes = [_i32, _i32, _i32]
+    lib.stc_bdg_node_post_k_supported.restype = C.c_int
+    lib.stc_bdg_node_post_k_supported.argtypes = [_i32, _i32, _i32, _i32]
     lib.stc_cell_gather_supported.restype = C.c_int
     lib.stc_cell_gather_supported.argtypes = [_i32, _i32, _i32, _i32, _i32]
     lib.stc_head_bwd_workspace_bytes.restype = C.c_size_t
@@ -778,6 +782,51 @@ class HipKernels:
         ws = self._get_workspace(U.device, self.lib.stc_bdg_node_bwd_workspace_bytes(K, K, Cc, 2 * h, 2 * h, 0))
         self._launch('stc_cell_cand_bwd_planar_k_f32', U, self._ptr_array(Zx), self._ptr_array(Zh), K, _ptr(Tc), _ptr(W), _ptr(dHnew), _ptr(U), _ptr(Cand),
                      zx, zh, _ptr(dW), _ptr(db), _ptr(ws), ws.numel(), R, Cc, cin + h, h)
+
+    # ---- post-aggregation form at order 3 (planar input) -------------------------------------------------
+    def node_post_k_supported(self, K, Cc, L, Ho) -> bool:
+        return bool(self.lib.stc_bdg_node_post_k_supported(K, Cc, L, Ho))
+
+    def _post_k_rows(self, what, X, X2, Tc, W, K):
+        R, Cc, h = X.shape
+        w2 = X2.shape[-1]
+        if h != 16 or not (w2 == 16 or 1 <= w2 <= 4):
+            raise StcError(f'{what}: planes of 16 + (16 or 1..4) columns, got {h} + {w2}')
+        self._f32(what + '.X', X, (R, Cc, 16))
+        self._f32(what + '.X2', X2, (R, Cc, w2))
+        self._f32(what + '.Tc', Tc, (K, Cc, Cc))
+        Lw = 16 + w2
+        self._f32(what + '.W', W, (K * K * Lw, 16))
+        return R, Cc, (32 if w2 == 16 else 20), Lw
+
+    def node_post_fwd_k(self, X, Tc, W, bias, P, X2):
+        """P = [P_0 - P_2 + b, P_1, P_2] of the order-3 convolution on the planar row [X | X2] (narrow X2: reference order [X2 | X])."""
+        K = len(P)
+        R, Cc, L, Lw = self._post_k_rows('post_k', X, X2, Tc, W, K)
+        if bias is not None:
+            self._f32('post_k.bias', bias, (16,))
+        for n, t in enumerate(P):
+            self._f32(f'post_k.P[{n}]', t, (R, Cc, 16))
+        self._same_device(X, X2, Tc, W, bias, *P)
+        self._launch('stc_bdg_node_post_fwd_k_f32', X, _ptr(X), _ptr(X2), K, _ptr(Tc), _ptr(W), _ptr(bias), self._ptr_array(P), R, Cc, L, Lw, 16)
+
+    def node_post_bwd_k(self, X, Tc, W, dP, dX, dW, db, X2, dX2=None):
+        K = len(dP)
+        R, Cc, L, Lw = self._post_k_rows('post_k bwd', X, X2, Tc, W, K)
+        for n, t in enumerate(dP):
+            self._f32(f'post_k.dP[{n}]', t, (R, Cc, 16))
+        self._f32('post_k.dX', dX, (R, Cc, 16))
+        if (dX2 is not None) != (L == 32):
+            raise StcError('post_k bwd: dX2 goes with a 16 + 16 planar input and only with it')
+        if dX2 is not None:
+            self._f32('post_k.dX2', dX2, (R, Cc, 16))
+        self._f32('post_k.dW', dW, tuple(W.shape))
+        if db is not None:
+            self._f32('post_k.db', db, (16,))
+        self._same_device(X, X2, Tc, W, *dP, dX, dX2, dW, db)
+        ws = self._get_workspace(X.device, self.lib.stc_bdg_node_bwd_workspace_bytes(K, K, Cc, L, 16, 0))
+        self._launch('stc_bdg_node_post_bwd_k_f32', X, _ptr(X), _ptr(X2), K, _ptr(Tc), _ptr(W), self._ptr_array(dP), _ptr(dX), _ptr(dX2), _ptr(dW), _ptr(db),
+                     _ptr(ws), ws.numel(), R, Cc, L, Lw, 16)
 
     # ---- fused cell convolutions ----------------------------------------------------------
     def cell_fused_supported(self, Ks, Kc, Cc, L, h) -> bool:

@@ -460,6 +460,10 @@ _FUSE_POST = os.environ.get('STC_FUSE_POST', '1') != '0'        # candidate proj
 _PLANAR = os.environ.get('STC_PLANAR', '1') != '0'              # cells with 16 + 16-column inputs read them as two planes (no concat, shared S.state)
 _POST_AGG = os.environ.get('STC_POST_AGG', '1') != '0'          # candidate convolution as Y = A + S.Bm (narrow SpMM after the node kernel)
 _PLANAR_K3 = os.environ.get('STC_PLANAR_K3', '1') != '0'        # Chebyshev order 3: planar cells on three planes per side (T_0, T_1, T_2 of S)
+# ... with the candidate in post-aggregation (Clenshaw) form, Y = (P0 - P2) + S.(P1 + 2 S.P2).  Opt-in: same number of narrow SpMMs per
+# cell as the slab-planar candidate, 23 % less saved activation memory (36.0 vs 46.8 GB at N = 10 000, batch 4), but its backward kernel
+# (382 registers, one wave per SIMD) is slower than the slab-planar one: 78.0 vs 75.9 ms per step on MI355X (profiles/r02/i_*).
+_POST_K3 = os.environ.get('STC_POST_K3', '0') == '1'
 
 
 def cell_graph_supported(op: SpatialOperand, Tc, Ks: int, C: int, h: int, x_widths, dtype=torch.float32) -> bool:
@@ -598,10 +602,24 @@ class _StcCellGraph(Function):
             if planar[j] and planar_k:
                 Zx, Zh, RH = planes_of(x), planes_of(hs), torch.empty_like(Hprev)
                 k.cell_gates_fwd_planar_k(rows(Zx), rows(Zh), Tc, Wg, bg, *rows((U, Rg, RH)))
-                Zr = cheb_planes(RH)                                # the candidate's H side: T_n(S) of R*H (its X side is Zx again)
-                k.cell_cand_fwd_planar_k(rows(Zx), rows(Zr), Tc, Wc, bc, *rows((U, Hprev, Cand, Hnew)))
-                saved += [Hprev, U, Rg, Cand, *Zx, *Zh[1:], *Zr]
-                n_saved.append(-12)                                 # negative count: planar cell (12: order 3)
+                if _POST_K3 and k.node_post_k_supported(Ks, C, 2 * h if cin[j] == h else 20, h):
+                    # candidate in post-aggregation form: project [X | R*H] first (three planes), aggregate in Clenshaw order --
+                    # M = P1 + 2 S.P2, then Y = (P0 - P2 + b) + S.M with the GRU blend in that SpMM's epilogue
+                    P = [torch.empty_like(Hprev) for _ in range(3)]
+                    lead, second = (Zx[0], RH) if cin[j] == h else (RH, Zx[0])        # narrow input plane: the 16-wide plane leads
+                    k.node_post_fwd_k(*rows((lead,)), Tc, Wc, bc, rows(P), second.view(B * N, C, second.shape[-1]))
+                    M = torch.empty_like(Hprev)
+                    k.csr_spmm(op.fwd_rowptr, op.fwd_colidx, fwd_val, N, N, P[2].view(B, N, C * h), P[1].view(B, N, C * h), M.view(B, N, C * h), 2.0, 1.0,
+                               plan=op.fwd_plan)
+                    k.spmm_blend_fwd(op.fwd_rowptr, op.fwd_colidx, fwd_val, op.fwd_plan, M, P[0], U, Hprev, Cand, Hnew)
+                    del P, M
+                    saved += [Hprev, U, Rg, Cand, *Zx, *Zh[1:], RH]
+                    n_saved.append(-10)                             # negative count: planar cell (10: order 3, post-aggregation candidate)
+                else:
+                    Zr = cheb_planes(RH)                            # the candidate's H side: T_n(S) of R*H (its X side is Zx again)
+                    k.cell_cand_fwd_planar_k(rows(Zx), rows(Zr), Tc, Wc, bc, *rows((U, Hprev, Cand, Hnew)))
+                    saved += [Hprev, U, Rg, Cand, *Zx, *Zh[1:], *Zr]
+                    n_saved.append(-12)                             # negative count: planar cell (12: order 3, slab-planar candidate)
             elif planar[j]:
                 Xp, SXp, SHp, RH = source(x), aggregated(x), aggregated(hs), torch.empty_like(Hprev)
                 A, Bm = torch.empty_like(Hprev), torch.empty_like(Hprev)
@@ -738,8 +756,9 @@ class _StcCellGraph(Function):
             pc = pieces.setdefault(kid, dict(d0=[], d1=[], d2=[]))
             pc['d0'] += list(d0); pc['d1'] += list(d1); pc['d2'] += list(d2)
 
-        def clenshaw(d0, d1, d2):
-            """sum d0 - sum d2 + S^T (sum d1 + 2 S^T sum d2) from lists of planes (d2 non-empty)."""
+        def clenshaw(d0, d1, d2, blend=None):
+            """sum d0 - sum d2 + S^T (sum d1 + 2 S^T sum d2) from lists of planes (d2 non-empty); with ``blend`` = (U, Cand) also
+            dY = result * U * (1 - Cand^2) from the second launch's epilogue."""
             while len(d2) > 2:                                       # the kernel gathers two operands: pre-sum the rest
                 d2 = [d2[0] + d2[1]] + d2[2:]
             t = d2[0].new_empty(B, N, C, h)
@@ -749,15 +768,20 @@ class _StcCellGraph(Function):
                 (a, _), (b_, _) = adds.pop(0), adds.pop(0)
                 adds.insert(0, (a + b_, 0))
             out = t.new_empty(B, N, C, h)
-            k.spmm_sum(*bwd, op.bwd_plan, t, None, adds, out)
-            return out
+            dY = torch.empty_like(out) if blend is not None else None
+            k.spmm_sum(*bwd, op.bwd_plan, t, None, adds, out, blend=None if blend is None else (blend[0], blend[1], dY))
+            return out if blend is None else (out, dY)
 
-        def owed3(kid):
+        def owed3(kid, blend=None):
             base = G.pop(kid, None)
             pc = pieces.pop(kid, None)
             if pc is None:
-                return base
-            return clenshaw(pc['d0'] + ([base] if base is not None else []), pc['d1'], pc['d2'])
+                if blend is None:
+                    return base
+                dY = torch.empty_like(base)
+                k.gru_blend_bwd(base, blend[0], None, blend[1], dY, None, None)
+                return base, dY
+            return clenshaw(pc['d0'] + ([base] if base is not None else []), pc['d1'], pc['d2'], blend)
 
         for j in range(len(schedule) - 1, -1, -1):
             if j not in G and j not in pieces:
@@ -765,17 +789,33 @@ class _StcCellGraph(Function):
             s_id, x, hs = schedule[j]
             Wg, bg, Wc, bc = stacks[s_id]
             Hprev, U, Rg, Cand, *rest = cells[j]
-            if n_saved[j] == -12:                                    # order-3 planar cell
-                Zx, Zh, Zr = rest[:3], [Hprev] + rest[3:5], rest[5:8]
-                dHnew = owed3(j)
+            if n_saved[j] in (-10, -12):                             # order-3 planar cell
+                Zx, Zh = rest[:3], [Hprev] + rest[3:5]
                 wide = cin[j] == h
                 new = lambda: torch.empty_like(Hprev)
-                dXc, dR = ([new(), new(), new()] if wide else [None] * 3), [new(), new(), new()]
                 dWc, dbc = torch.empty_like(Wc), (Wc.new_empty(h) if bc is not None else None)
-                k.cell_cand_bwd_planar_k(rows(Zx), rows(Zr), Tc, Wc, *rows((dHnew, U, Cand)),
-                                         [None if t is None else t.view(B * N, C, h) for t in dXc], rows(dR), dWc, dbc)
-                dRH = clenshaw([dR[0]], [dR[1]], [dR[2]])            # gradient of the R*H plane from its three Chebyshev planes
-                del dR
+                if n_saved[j] == -10:                                # candidate in post-aggregation form
+                    RH = rest[5]
+                    dHnew, dY = owed3(j, (U, Cand))
+                    dM = narrow_transpose_aggregation(dY)            # dP1 = S^T dY
+                    dP2 = torch.empty_like(dY)                       # dP2 = 2 S^T dP1 - dY
+                    k.csr_spmm(*bwd, N, N, dM.view(B, N, C * h), dY.view(B, N, C * h), dP2.view(B, N, C * h), 2.0, -1.0, plan=op.bwd_plan)
+                    dRH = new()
+                    dXc0 = new() if wide else None                   # ONE direct plane for the X side: the aggregation came after the projection
+                    if wide:
+                        k.node_post_bwd_k(*rows((Zx[0],)), Tc, Wc, rows((dY, dM, dP2)), dXc0.view(B * N, C, h), dWc, dbc, RH.view(B * N, C, h), dRH.view(B * N, C, h))
+                    else:
+                        k.node_post_bwd_k(*rows((RH,)), Tc, Wc, rows((dY, dM, dP2)), dRH.view(B * N, C, h), dWc, dbc, Zx[0].view(B * N, C, cin[j]))
+                    del dY, dM, dP2
+                    dXc = [dXc0, None, None]
+                else:                                                # slab-planar candidate
+                    Zr = rest[5:8]
+                    dHnew = owed3(j)
+                    dXc, dR = ([new(), new(), new()] if wide else [None] * 3), [new(), new(), new()]
+                    k.cell_cand_bwd_planar_k(rows(Zx), rows(Zr), Tc, Wc, *rows((dHnew, U, Cand)),
+                                             [None if t is None else t.view(B * N, C, h) for t in dXc], rows(dR), dWc, dbc)
+                    dRH = clenshaw([dR[0]], [dR[1]], [dR[2]])        # gradient of the R*H plane from its three Chebyshev planes
+                    del dR
                 fold = getattr(k, 'folds_dH', False)                  # the kernel adds the prologue's share into the H plane's gradient
                 dXg, dHg, dH = ([new(), new(), new()] if wide else [None] * 3), [new(), new(), new()], (None if fold else new())
                 dWg, dbg = torch.empty_like(Wg), (Wg.new_empty(2 * h) if bg is not None else None)
@@ -783,7 +823,7 @@ class _StcCellGraph(Function):
                                           [None if t is None else t.view(B * N, C, h) for t in dXg], rows(dHg), dWg, dbg,
                                           None if fold else dH.view(B * N, C, h))
                 if wide and x[0] == 'cell':
-                    leave3(x[1], (dXg[0], dXc[0]), (dXg[1], dXc[1]), (dXg[2], dXc[2]))
+                    leave3(x[1], (dXg[0], dXc[0]), [t for t in (dXg[1], dXc[1]) if t is not None], [t for t in (dXg[2], dXc[2]) if t is not None])
                 if hs[0] == 'cell':
                     leave3(hs[1], (dHg[0],) if fold else (dHg[0], dH), (dHg[1],), (dHg[2],))
                 for i, t in enumerate((dWg, dbg, dWc, dbc)):

@@ -720,6 +720,39 @@ def test_planar_cell_kernels_order3(hip, nodes, cin):
     assert rel_err(dHf[0], dHg_w[0] + dH_w) < TOL and torch.equal(dHf[1], dHg[1]) and torch.equal(dHf[2], dHg[2])
 
 
+@pytest.mark.parametrize('nodes,cin', [(50, 16), (4500, 16), (37, 1), (600, 4)])
+def test_post_aggregation_order3_kernels(hip, nodes, cin):
+    """stc_bdg_node_post_fwd/bwd_k_f32: the order-3 candidate convolution in Clenshaw form -- P = [P_0 - P_2 + b, P_1, P_2] from the
+    planar row, and (dX, dX2, dW, db) from the three gradient planes -- against the CPU twin (plain einsum algebra)."""
+    h, K, C = 16, 3, 32
+    assert hip.node_post_k_supported(K, C, 32 if cin == h else 20, h) and not hip.node_post_k_supported(2, C, 32, h)
+    Lw = cin + h
+    g = torch.Generator().manual_seed(nodes * 3 + cin)
+    rnd = lambda *s_: torch.randn(*s_, generator=g)
+    X16, Xin = rnd(nodes, C, h), rnd(nodes, C, cin)              # the 16-wide plane (R*H, or X when both are 16 wide) and the other plane
+    Tc = rnd(K, C, C) / C ** 0.5
+    Tc[0] = torch.eye(C)
+    W, b = rnd(K * K * Lw, h) / (K * K * Lw) ** 0.5, rnd(h)
+    nan = lambda *s_: torch.full(s_, float('nan')).cuda()
+    P_w = [torch.empty(nodes, C, h) for _ in range(K)]
+    EM.node_post_fwd_k(X16, Tc, W, b, P_w, Xin)
+    P = [nan(nodes, C, h) for _ in range(K)]
+    hip.node_post_fwd_k(cu(X16), cu(Tc), cu(W), cu(b), P, cu(Xin))
+    for a, w in zip(P, P_w):
+        assert rel_err(a, w) < TOL
+    hip.node_post_fwd_k(cu(X16), cu(Tc), cu(W), None, P, cu(Xin))
+    assert rel_err(P[0], P_w[0] - b) < TOL
+    dP = [rnd(nodes, C, h) for _ in range(K)]
+    wide = cin == h
+    dX_w, dX2_w, dW_w, db_w = torch.empty(nodes, C, h), (torch.empty(nodes, C, h) if wide else None), torch.empty_like(W), torch.empty(h)
+    EM.node_post_bwd_k(X16, Tc, W, dP, dX_w, dW_w, db_w, Xin, dX2_w)
+    dX, dX2, dW, db = nan(nodes, C, h), (nan(nodes, C, h) if wide else None), nan(*W.shape), nan(h)
+    hip.node_post_bwd_k(cu(X16), cu(Tc), cu(W), [cu(t) for t in dP], dX, dW, db, cu(Xin), dX2)
+    assert rel_err(dX, dX_w) < TOL and rel_err(dW, dW_w) < TOL and rel_err(db, db_w) < TOL
+    if wide:
+        assert rel_err(dX2, dX2_w) < TOL
+
+
 def test_fused_aggregation_is_refused_off_its_shapes(hip):
     from stc_hip import StcError
     assert not hip.cell_gather_supported(3, 3, 32, 32, 16) and not hip.cell_gather_supported(2, 2, 16, 32, 16)
