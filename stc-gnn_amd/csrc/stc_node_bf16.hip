@@ -421,6 +421,11 @@ __global__ __launch_bounds__(MF_THREADS, WAVES) void node_bwd_bf16_kernel(
     u32x4* TB = reinterpret_cast<u32x4*>(smem_raw);     // [K-1][NRB rb][NB2 p]   T_c[16 rb + x][32 p + pair_row]
     u32x4* WA = TB + nTB * 64;                           // [K n][LB][K c]         A: W[(n, c, 16 lb + x)][o(slot)]
     const int tid = threadIdx.x, lane = tid & 63, x = lane & 15, g = lane >> 4;
+    // PRO, dH == null: the state's share dRH R + dHnew (1-U) is parked here by the prologue ([wave][NRB][16 rows][16 columns] fp32,
+    // written by the lanes that computed it, read back by the lanes that own those columns of the H plane's gradient tile: same
+    // wave, program order) instead of being re-formed at the tile's store from four more loads per row block -- at one wave per SIMD
+    // (C = 64) those late loads went back to HBM (8.7 GB per launch against 6.7 GB algorithmic)
+    float* stash = reinterpret_cast<float*>(WA + nWA * 64) + (size_t)(tid >> 6) * NRB * 256;
 
     for (int idx = tid; idx < nTB * 64; idx += MF_THREADS) {
         const int ll = idx & 63, f = idx >> 6, p = f % NB2, rb = (f / NB2) % NRB, c1 = f / (NB2 * NRB), gg = ll >> 4;
@@ -515,7 +520,15 @@ __global__ __launch_bounds__(MF_THREADS, WAVES) void node_bwd_bf16_kernel(
                     dh[i] = fmaf(dr[i], rr[i], gn[i] * (1.f - uu[i]));
                 }
                 dyr[rb] = pack8f(gy);
-                if (pro.dH && g < 2) *reinterpret_cast<u32x4*>(pro.dH + (r0 + 16 * rb + x) * 16 + 8 * g) = pack8f(dh);
+                if (g < 2) {
+                    if (pro.dH) {
+                        *reinterpret_cast<u32x4*>(pro.dH + (r0 + 16 * rb + x) * 16 + 8 * g) = pack8f(dh);
+                    } else {                                    // park the share: row x, columns 8g .. 8g+7 of block rb
+                        float4* slot = reinterpret_cast<float4*>(stash + (rb * 16 + x) * 16 + 8 * g);
+                        slot[0] = make_float4(dh[0], dh[1], dh[2], dh[3]);
+                        slot[1] = make_float4(dh[4], dh[5], dh[6], dh[7]);
+                    }
+                }
             }
         } else {
 #pragma unroll
@@ -573,11 +586,8 @@ __global__ __launch_bounds__(MF_THREADS, WAVES) void node_bwd_bf16_kernel(
                     if (n == 0 && lb == (PL == 1 ? 1 : 0) && !pro.dH) {
 #pragma unroll
                         for (int rb = 0; rb < NRB; ++rb) {
-                            const size_t e = (r0 + 16 * rb + x) * 16 + 4 * g;
-                            const f32x4 dr = unpack4(*reinterpret_cast<const u32x2*>(pro.dRH + e)), rr = unpack4(*reinterpret_cast<const u32x2*>(pro.R + e));
-                            const f32x4 gn = unpack4(*reinterpret_cast<const u32x2*>(pro.dHnew + e)), uu = unpack4(*reinterpret_cast<const u32x2*>(pro.U + e));
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) z[rb][r] += fmaf(dr[r], rr[r], gn[r] * (1.f - uu[r]));
+                            const float4 sh = *reinterpret_cast<const float4*>(stash + (rb * 16 + x) * 16 + 4 * g);
+                            z[rb][0] += sh.x; z[rb][1] += sh.y; z[rb][2] += sh.z; z[rb][3] += sh.w;
                         }
                     }
                 }
@@ -842,7 +852,7 @@ template <int NB2, int PL, int WAVES = BwdWaves<NB2, 2>::v>
 int launch_gates_bwd(const BPtrs2& zp, const BDPtrs2& dzp, const GatesPro& pro, const float* Tc, const float* W,
                      float* partial, int* n_partials, int want_db, long long nodes, int Lw, hipStream_t stream) {
     constexpr int NRB = 2 * NB2, K = 2, LB = 2, nW = K * K * 32 * 32;
-    const size_t frag = (size_t)(NRB * NB2 + K * LB * K) * 64 * 16;
+    const size_t frag = (size_t)(NRB * NB2 + K * LB * K) * 64 * 16 + (size_t)MF_WAVES * NRB * 256 * sizeof(float);     // tables + the dH stash
     const size_t slabs = (size_t)MF_WAVES * (nW + 32) * sizeof(float);
     const size_t lds = frag > slabs ? frag : slabs;
     auto kern = node_bwd_bf16_kernel<NB2, 2, 2, 32, PL, 1, WAVES>;
