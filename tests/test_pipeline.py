@@ -264,3 +264,47 @@ def test_bench_under_torchrun_single_rank_goes_through_rccl():
     assert out.returncode == 0, out.stderr[-3000:]
     d = json.loads([l for l in out.stdout.strip().split('\n') if l.startswith('{')][0])
     assert d['n_gpus'] == 1 and d['n_ranks_seen'] == 1
+
+
+_SHARDED_TRAINER_SCRIPT = r'''
+import json, os, sys
+sys.path.insert(0, os.environ['STC_REPO']); sys.path.insert(0, os.path.join(os.environ['STC_REPO'], 'stc-gnn_amd'))
+import torch
+from stc_hip import data as sdata, dist as sdist
+from stc_hip.trainer import Trainer
+from tests.golden.make_golden import pipeline_inputs
+rank, world, local = sdist.init_from_env()
+data, params = pipeline_inputs()
+params = dict(params, device=f'cuda:{local}', output_dir=os.environ['STC_OUT'])
+loaders = sdata.get_data_loader(params, data, params['obs_len'], params['pred_len'], params['split_ratio'])
+torch.manual_seed(123)
+trainer = Trainer(params, data)
+hist = trainer.train(loaders, verbose=False)
+flat = torch.cat([p.detach().flatten() for p in trainer.model.parameters()]).double()
+if rank == 0:
+    print(json.dumps(dict(world=trainer.world, train=hist['loss']['train'], val=hist['loss']['validate'], checksum=float(flat.sum()))))
+torch.distributed.barrier(); torch.distributed.destroy_process_group()
+'''
+
+
+@pytest.mark.gpu
+def test_batch_sharded_trainer_on_the_gpu_follows_the_reference_curves(tmp_path):
+    """The trainer counterpart under ``torch.distributed.run`` with two ranks through libstc_hip.so (learned graphs with the batch-sum
+    all-reduce, ragged last batch, one gradient-bucket all-reduce per step): the REFERENCE's 2-epoch loss curves of g9.  The box has one
+    GPU, so both ranks sit on it and talk over gloo (the hooks of stc_hip.dist.init_from_env); on a node this is RCCL, one rank per GPU."""
+    import json
+    import subprocess
+    import sys
+    script = tmp_path / 'sharded_trainer.py'
+    script.write_text(_SHARDED_TRAINER_SCRIPT)
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(STC_REPO=REPO, STC_OUT=str(tmp_path), STC_DIST_BACKEND='gloo', STC_DIST_ONE_DEVICE='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', '29547', str(script)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.strip().split('\n') if l.startswith('{')][0])
+    g = load_golden('g9_pipeline')
+    assert d['world'] == 2
+    assert np.allclose(d['train'], g['train_curve'].numpy(), rtol=0, atol=1e-4), d
+    assert np.allclose(d['val'], g['val_curve'].numpy(), rtol=0, atol=1e-4), d
+    assert os.path.exists(tmp_path / 'STC-GNN-4.pkl')
