@@ -38,4 +38,4 @@ echo "== SF shape"
 (timeout 300 python tools/bench_sf.py --mode csr-fixed 2>&1 | tail -1; timeout 300 python tools/bench_sf.py --mode csr-fixed --graph --steps 50 2>&1 | tail -2; timeout 600 python tools/bench_sf.py --mode dense-learned --steps 5 2>&1 | tail -1) | tee gpurun_out/z_sf_shape.txt
 echo "== 2-rank rehearsal of python bench.py --gpus 2 (gloo, both ranks on this one GPU; NOT an RCCL number)"
 STC_DIST_BACKEND=gloo STC_DIST_ONE_DEVICE=1 timeout 900 python3 bench.py --gpus 2 --steps 3 --warmup 1 --batch-per-gpu 2 --no-unit-d3 > gpurun_out/z_bench_2rank_gloo.json 2> gpurun_out/z_bench_2rank.err; echo "exit $?"
-python3 -c "import json;d=json.load(open('gpurun_out/z_bench_2rank_gloo.json'));print('2 ranks', d['n_ranks_seen'], round(d['value'],2), 'samples/s', round(d['ms_per_step'],1), 'ms', d['step_breakdown']['grad_allreduce_ms'])"
+python3 -c "import json;d=json.loads([l for l in open('gpurun_out/z_bench_2rank_gloo.json') if l.startswith('{')][0]);print('2 ranks', d['n_ranks_seen'], round(d['value'],2), 'samples/s', round(d['ms_per_step'],1), 'ms', d['step_breakdown']['grad_allreduce_ms'])"
