@@ -46,20 +46,25 @@ class GraphPair:
         if isinstance(Gs, CsrGraph):
             self.spatial: SpatialOperand = csr_operand(Gs, Gc.device)
         elif isinstance(Gs, torch.Tensor) and Gs.layout != torch.strided:
-            cached = getattr(Gs, '_stc_csr', None)
-            if cached is None:
-                cached = CsrGraph.from_torch_sparse(Gs)
-                try:
-                    Gs._stc_csr = cached
-                except AttributeError:
-                    pass
-            self.spatial = csr_operand(cached, Gc.device)
+            self.spatial = csr_operand(_as_csr_graph(Gs), Gc.device)
         elif isinstance(Gs, torch.Tensor):
             self.spatial = dense_operand(Gs)
         else:
             raise TypeError(f'Gs must be a tensor or a CsrGraph, got {type(Gs).__name__}')
         self.Ks, self.Kc = Ks, Kc
         self.Tc = ops.cheby_dense(Gc, Kc)
+
+
+def _as_csr_graph(Gs: torch.Tensor) -> CsrGraph:
+    """The CsrGraph of a torch sparse tensor (COO / CSR), built once and cached on the tensor object."""
+    cached = getattr(Gs, '_stc_csr', None)
+    if cached is None:
+        cached = CsrGraph.from_torch_sparse(Gs)
+        try:
+            Gs._stc_csr = cached
+        except AttributeError:
+            pass
+    return cached
 
 
 def _graphs(Gs: GraphLike, Gc: Optional[torch.Tensor], Ks: int, Kc: int) -> GraphPair:
@@ -332,6 +337,8 @@ class STCGNN(nn.Module):
             Gs, Gc = self.mix_graph_pair(X_seq, As, Ac)
         else:
             Gs, Gc = As, Ac
+            if isinstance(Gs, torch.Tensor) and Gs.layout != torch.strided:
+                Gs = _as_csr_graph(Gs)                  # a torch sparse graph gets the same treatment as a CsrGraph (cached on the tensor)
             if self.reorder_nodes and isinstance(Gs, CsrGraph):
                 # a graph given in a cache-hostile node order is renumbered once (reverse Cuthill-McKee); inputs are
                 # gathered into that order here and the prediction scattered back, so callers never see it

@@ -336,6 +336,10 @@ def test_internal_node_reordering_is_invisible():
     R = torch.randn(2, 2, N, C).to(DEV)
     ya, yb = plain(X_seq=X, As=graph, Ac=Gc), smart(X_seq=X, As=graph, Ac=Gc)
     _close(yb, ya, FWD, 'reordered yhat')
+    sparse = graph.to_dense().to_sparse_coo()                     # a torch sparse graph is renumbered internally as well
+    yc = smart(X_seq=X, As=sparse, Ac=Gc)
+    assert sparse._stc_csr.with_locality()[1] is not None
+    _close(yc, ya, FWD, 'reordered yhat (torch sparse input)')
     (ya * R).sum().backward()
     (yb * R).sum().backward()
     for (k, pa), (_, pb) in zip(plain.named_parameters(), smart.named_parameters()):
