@@ -209,7 +209,8 @@ def pmc_traffic(a, config_key):
         doc = json.load(fh)
     if doc.get('csrc_sha') != csrc_sha() or doc.get('config_key') != config_key:
         return None, f'profiles/r02/hbm_traffic_bench.json is from other sources/configuration ({doc.get("csrc_sha")}, {doc.get("config_key")}): not quoted'
-    ks = [v for name, v in doc['kernels'].items() if name.startswith('spmm_bcsr_kernel')]
+    import re
+    ks = [v for name, v in doc['kernels'].items() if re.match(r'spmm_bcsr_kernel<\d+, 0,', name)]      # MODE = 0 (EP_PLAIN): the plain launches only
     if not ks:
         return None, None
     traffic = sum(v['hbm_bytes_per_launch'] * v['launches'] for v in ks) / sum(v['launches'] for v in ks)
