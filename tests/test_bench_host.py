@@ -1,0 +1,56 @@
+"""Host logic of bench.py that needs no GPU: the self-launch of ``--gpus N`` and the guards around ``roofline.traffic``."""
+import json
+import os
+import sys
+
+import pytest
+
+from tests.conftest import REPO
+
+sys.path.insert(0, REPO)
+import bench  # noqa: E402
+
+
+def test_gpus_n_without_a_launcher_starts_torchrun_as_a_child(monkeypatch):
+    """``python bench.py --gpus 4`` (no RANK in the environment): torch.distributed.run is started as a child process with the
+    driver's argument form, the original flags are passed through, and the exit code is the child's."""
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen['cmd'], seen['env'] = cmd, env
+        return 7
+
+    monkeypatch.setattr(bench.subprocess, 'call', fake_call)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4', '--steps', '20', '--warmup', '5'])
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        monkeypatch.delenv(k, raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen['cmd']
+    assert cmd[:3] == [sys.executable, '-m', 'torch.distributed.run'] and '--nnodes=1' in cmd and '--nproc-per-node=4' in cmd
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and int(cmd[cmd.index('--master-port') + 1]) > 0
+    i = cmd.index(os.path.join(REPO, 'bench.py'))
+    assert cmd[i + 1:] == ['--gpus', '4', '--steps', '20', '--warmup', '5']
+    assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+
+
+def test_traffic_is_quoted_only_for_matching_sources_and_configuration(tmp_path, monkeypatch):
+    key = 'f32:224:32:16:5:2:2:18:6:0'
+    doc = dict(csrc_sha=bench.csrc_sha(), config_key=key,
+               kernels={'spmm_bcsr_kernel<1, 0, 2, 1, 1>': dict(hbm_bytes_per_launch=100.0, launches=3),
+                        'spmm_bcsr_kernel<1, 3, 2, 0, 0>': dict(hbm_bytes_per_launch=900.0, launches=5),       # a sum form: not the plain launch
+                        'node_fwd_x3_kernel<1, 2, 2, 32, 1, 0, 1, 1>': dict(hbm_bytes_per_launch=5.0, launches=1)})
+    monkeypatch.setattr(bench, 'REPO', str(tmp_path))
+    os.makedirs(tmp_path / 'profiles' / 'r02')
+    monkeypatch.setattr(bench, 'csrc_sha', lambda: doc['csrc_sha'])
+    path = tmp_path / 'profiles' / 'r02' / 'hbm_traffic_bench.json'
+    path.write_text(json.dumps(doc))
+    t, note = bench.pmc_traffic(None, key)
+    assert t == 100.0 and 'profiles/r02/hbm_traffic_bench.json' in note
+    assert bench.pmc_traffic(None, 'f32:100:32:16:4:3:2:18:6:0')[0] is None            # another configuration
+    path.write_text(json.dumps(dict(doc, csrc_sha='0' * 16)))
+    t, note = bench.pmc_traffic(None, key)
+    assert t is None and 'not quoted' in note                                           # other kernel sources: never a stale number
+    os.remove(path)
+    assert bench.pmc_traffic(None, key) == (None, None)
