@@ -3,6 +3,7 @@
     mask_data(x, H, W, mask)                 drop the masked grid cells before evaluation     (Metrics.py:8-33)
     one_step_eval_bi(prob, true, threshold)  the reference's per-step metric dict             (Metrics.py:88-152)
     evaluate_binary(prob, true, threshold)   one dict per horizon step                        (Metrics.py:43-70)
+    append_metrics_csv(path, params, ...)    the reference's ``<model>_eval-bi-metrics.csv`` log (Metrics.py:54-59, 72-85)
 
 Inputs may be torch tensors on any device (the trainer's predictions stay on the GPU) or numpy arrays; the work is
 torch ops on the input's device -- confusion counts, two sorts for the AUCs -- in float64, and only the handful of
@@ -105,3 +106,19 @@ def evaluate_binary(prob, true, threshold: Sequence[float], beta: int = 2) -> Li
     prob, true = _t(prob), _t(true)
     assert prob.shape == true.shape
     return [one_step_eval_bi(prob[:, s], true[:, s], threshold, beta) for s in range(prob.shape[1])]
+
+
+def append_metrics_csv(path: str, params: dict, mode: str, multistep_metrics: List[Dict[str, float]]) -> None:
+    """Append one evaluation to the reference's CSV log, same layout (``Metrics.py:54-59, 72-85``): a start marker, the full
+    parameter dump on one line, a header row (' ', metric names), one row per horizon step, an end marker and a blank line."""
+    import time
+    with open(path, 'a') as cf:
+        cf.write(f'*****, Evaluation starts, {mode}, {time.ctime()}, ***** \n')
+        for key in params.keys():
+            cf.write(f'{key}: {params[key]},')
+        cf.write('\n')
+        names = list(multistep_metrics[0].keys()) if multistep_metrics else []
+        cf.write(','.join([' '] + names) + '\n')
+        for step, m in enumerate(multistep_metrics):
+            cf.write(','.join([f'Step {step}'] + [str(v) for v in m.values()]) + '\n')
+        cf.write(f'*****, Evaluation ends, {mode}, {time.ctime()}, ***** \n \n')

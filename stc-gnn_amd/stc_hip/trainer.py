@@ -155,4 +155,8 @@ class Trainer:
                 mask = None if self.mask is None else [tuple(int(v) for v in m) for m in np.asarray(self.mask).reshape(-1, 2)]
                 out[mode]['metrics'] = smetrics.evaluate_binary(smetrics.mask_data(pred_d, H, W, mask),
                                                                  smetrics.mask_data(truth_d, H, W, mask), list(np.asarray(self.threshold)))
+                if self.rank == 0:                                   # the reference's CSV log, same file name and layout (Metrics.py:54-85)
+                    log_params = {k: v for k, v in self.params.items() if not k.startswith('_')}
+                    smetrics.append_metrics_csv(os.path.join(self.params['output_dir'], f'{self.params.get("model", "STC-GNN")}_eval-bi-metrics.csv'),
+                                                log_params, mode, out[mode]['metrics'])
         return out

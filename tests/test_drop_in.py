@@ -88,3 +88,23 @@ def test_reference_model_trainer_runs_on_the_drop_in_module(tmp_path, monkeypatc
         trainer.test(data_loader=loaders, modes=['test'])                         # :124-158: load_state_dict, forward, Metrics
     csv = os.path.join(str(tmp_path), 'STC-GNN_eval-bi-metrics.csv')
     assert os.path.exists(csv) and 'Macro-F1' in open(csv).read()
+    # the build's trainer counterpart writes the same log: same file name, same line structure, same header row, same values
+    from stc_hip import data as sdata
+    from stc_hip.trainer import Trainer
+    ref_lines = open(csv).read().split('\n')
+    os.remove(csv)
+    mine = Trainer(dict(params, _allow_cpu_for_tests=True), data)
+    mine.test(sdata.get_data_loader(params, data, params['obs_len'], params['pred_len'], params['split_ratio']))
+    my_lines = open(csv).read().split('\n')
+    assert len(my_lines) == len(ref_lines)
+    scrub = lambda l: re.sub(r'(starts|ends), (\w+), [^,]*,', r'\1, \2, TIME,', l)
+    for a, b in zip(my_lines, ref_lines):
+        if a.startswith('*****'):
+            assert scrub(a) == scrub(b)
+        elif a.startswith('device:') or 'device:' in a[:40]:
+            assert a == b                                            # the parameter dump
+        elif a.startswith('Step'):
+            assert a.split(',')[0] == b.split(',')[0]
+            assert np.allclose([float(v) for v in a.split(',')[1:]], [float(v) for v in b.split(',')[1:]], atol=1.01e-4)
+        else:
+            assert a == b                                            # header row, blank lines
