@@ -319,7 +319,7 @@ int stc_cell_blend_fwd_f32(const float* const* Z, int32_t Ks, const float* Tc, i
  * dZ[0], dZ[1] may be NULL).  stc_bdg_node_post_fwd/bwd_f32 take the same narrow form: X = the 16-wide plane, X2 = the
  * (nodes, C, cin) plane, L = 20, gradient for X only. */
 int stc_cell_planar_supported(int32_t Ks, int32_t Kc, int32_t C, int32_t h);
-/* A != NULL (C = 32): the same launch also runs the candidate convolution's projection on [Xt | R*H], which the wave still
+/* A != NULL: the same launch also runs the candidate convolution's projection on [Xt | R*H], which the wave still
  * holds in registers: A, Bm (nodes, C, h) as stc_bdg_node_post_fwd_f32 would give for weights Wc (4*Lw, h) and bias bc --
  * that launch and its re-read of Xt and R*H are then not needed.  RH is written regardless (the backward needs it). */
 int stc_cell_gates_fwd_planar_f32(const float* X, const float* H, const float* SX, const float* SH,

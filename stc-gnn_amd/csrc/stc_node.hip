@@ -508,7 +508,6 @@ extern "C" int stc_cell_gates_fwd_planar_f32(const float* X, const float* H, con
     if (nodes == 0) return STC_OK;
     STC_REQUIRE(X && H && SX && SH && Tc && W && U && Rg && RH, STC_EINVAL, "stc_cell_gates_fwd_planar_f32: null pointer");
     STC_REQUIRE((A == nullptr) == (Bm == nullptr) && (!A || Wc), STC_EINVAL, "stc_cell_gates_fwd_planar_f32: A, Bm and Wc go together");
-    STC_REQUIRE(!A || C == 32, STC_EUNSUPPORTED, "stc_cell_gates_fwd_planar_f32: the fused candidate projection is built for C = 32 (got %d)", C);
     const int rc = stc_cell_gates_fwd_planar_x3(X, H, SX, SH, Tc, W, bias, U, Rg, RH, Wc, bc, A, Bm, nodes, C, Lw, static_cast<hipStream_t>(stream));
     return rc == STC_NOT_HANDLED ? stc::fail(STC_EUNSUPPORTED, "stc_cell_gates_fwd_planar_f32: operands not usable (alignment)") : rc;
 }

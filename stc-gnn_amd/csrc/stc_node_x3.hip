@@ -1610,14 +1610,16 @@ int stc_cell_gates_fwd_planar_x3(const float* X, const float* H, const float* SX
         if (!all_aligned16(Z, 4)) return STC_NOT_HANDLED;
         if (C == 32 && fused) return launch_fwd<1, 2, 2, 32, EPI_GATES, 0, 1, 1>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi, GatherArgs{}, post);
         if (C == 32) return launch_fwd<1, 2, 2, 32, EPI_GATES, 0, 1>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi);
-        if (C == 64 && !fused) return launch_fwd<2, 2, 2, 32, EPI_GATES, 0, 1>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi);
+        if (C == 64 && fused) return launch_fwd<2, 2, 2, 32, EPI_GATES, 0, 1, 1>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi, GatherArgs{}, post);
+        if (C == 64) return launch_fwd<2, 2, 2, 32, EPI_GATES, 0, 1>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi);
         return STC_NOT_HANDLED;
     }
     const float* Z[4] = {H, SH, X, SX};          // narrow input: the STATE plane leads, columns [H | Xt | pad]
     if (!stc::aligned16(H) || !stc::aligned16(SH)) return STC_NOT_HANDLED;
     if (C == 32 && fused) return launch_fwd<1, 2, 2, 20, EPI_GATES, 0, 2, 1>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi, GatherArgs{}, post);
     if (C == 32) return launch_fwd<1, 2, 2, 20, EPI_GATES, 0, 2>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi);
-    if (C == 64 && !fused) return launch_fwd<2, 2, 2, 20, EPI_GATES, 0, 2>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi);
+    if (C == 64 && fused) return launch_fwd<2, 2, 2, 20, EPI_GATES, 0, 2, 1>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi, GatherArgs{}, post);
+    if (C == 64) return launch_fwd<2, 2, 2, 20, EPI_GATES, 0, 2>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi);
     return STC_NOT_HANDLED;
 }
 

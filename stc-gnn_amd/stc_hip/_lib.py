@@ -656,8 +656,9 @@ class HipKernels:
         return R, Cc, h, cin
 
     def cell_planar_post_fused(self, Cc) -> bool:
-        """Whether cell_gates_fwd_planar can also run the candidate's projection (``post=``) for this category count."""
-        return Cc == 32
+        """Whether cell_gates_fwd_planar can also run the candidate's projection (``post=``) for this category count
+        (``STC_FUSE_POST_C64=0`` keeps it a launch of its own at C = 64: A/B runs)."""
+        return Cc == 32 or (Cc == 64 and os.environ.get('STC_FUSE_POST_C64', '1') != '0')
 
     def cell_gates_fwd_planar(self, X, H, SX, SH, Tc, W, bias, U, Rg, RH, post=None):
         """Gates convolution on planar inputs; writes U, Rg and the R*H plane (the candidate's input is (X, RH)).
