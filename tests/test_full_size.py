@@ -100,3 +100,43 @@ def test_full_size_batch_equals_single_samples_beyond_2gb(monkeypatch):
         g_sum = g_b if g_sum is None else {n: g_sum[n] + g_b[n] for n in g_b}
     for n in g_all:
         assert rel_err(g_all[n], g_sum[n]) < 1e-5, n
+
+
+@pytest.mark.gpu
+def test_full_size_model_against_oracle_end_to_end(monkeypatch):
+    """The whole path at N = 50 176 -- encoder (1 observed step) + decoder (1 predicted step), 2 layers = 4 cells, head, ComboLoss,
+    backward -- against the CPU oracle's sparse restatement: every prediction and every parameter gradient."""
+    monkeypatch.setattr(ops, '_kernels', None)
+    dev = torch.device('cuda')
+    N, C, h, K, B = GRID * GRID, 32, 16, 2, 1
+    graph = CsrGraph.queen_grid(GRID, GRID, normalize=True)
+    torch.manual_seed(42)
+    model = M.STCGNN(N, C, K, K, 1, h, 2, 1, graph_mode='csr-fixed')
+    with torch.no_grad():
+        for cell in list(model.encoder.cell_list) + list(model.decoder.cell_list):
+            cell.gates.b.normal_(0, 0.3)
+            cell.candi.b.normal_(0, 0.3)
+    g = torch.Generator().manual_seed(8)
+    Gc = torch.softmax(torch.randn(C, C, generator=g), -1)
+    X = (torch.rand(B, 1, N, C, generator=g) < 0.1635).float()
+    Y = (torch.rand(B, 1, N, C, generator=g) < 0.1635).float()
+    torch.set_num_threads(min(32, torch.get_num_threads() or 32))
+    # The oracle runs in float64 here (it is dtype-generic): at 1.6 M rows the fp32 CPU sums of the head's weight gradients are
+    # themselves off by 1e-5 .. 1e-3 (tools/probes/head_grad_precision.py: torch CPU fp32 1.7e-5 vs this build's head kernel 4.6e-8
+    # against float64), so a float32 oracle would be the less exact side of the comparison.
+    sd = {k: v.double().clone().requires_grad_() for k, v in model.state_dict().items()}
+    want = O.encdec_forward(X.double(), _sparse_T(graph).double(), Gc.double(), sd, K, K, h, 2, 1, conv=O.bdg_dif_sparse)
+    loss_w = O.combo_loss(want, Y.double())
+    loss_w.backward()
+    model = model.to(dev)
+    calls = []
+    real = ops.stc_cell_graph
+    monkeypatch.setattr(ops, 'stc_cell_graph', lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    got = model(X_seq=X.to(dev), As=graph, Ac=Gc.to(dev))
+    assert calls, 'the cell-graph path (the one the bench runs) was not taken'
+    loss = O.combo_loss(got, Y.to(dev))
+    loss.backward()
+    torch.cuda.synchronize()
+    assert rel_err(got, want) < 1e-5 and abs(float(loss.detach()) - float(loss_w.detach())) < 1e-5
+    for name, p in model.named_parameters():
+        assert rel_err(p.grad, sd[name].grad) < 2e-5, name
