@@ -26,6 +26,20 @@ def load_incidents(path: str) -> dict:
                     s_adj=z['s_adj'], c_cor=z['c_cor'])
 
 
+def synthetic_incidents(H: int, W: int, C: int, T: int, rate: float = 0.1635, seed: int = 0, sparse_graph: bool = False) -> dict:
+    """A dataset dict of the reference's schema without a city file: Bernoulli(``rate``) incidents (T, H, W, C)
+    (0.1635 = the SF file's mean incidence), the H x W 8-neighbour adjacency (``s_adj`` of the SF file for 10 x 10) -- dense 0/1 as
+    in the file, or with ``sparse_graph`` a row-normalised ``CsrGraph`` for ``csr-fixed`` training at sizes where N x N does not
+    exist -- a seeded category graph, per-category historical averages as thresholds, no masked cells."""
+    from .graph import CsrGraph
+    g = torch.Generator().manual_seed(seed)
+    inc = (torch.rand(T, H, W, C, generator=g) < rate).to(torch.int32).numpy()
+    c_cor = torch.softmax(torch.randn(C, C, generator=torch.Generator().manual_seed(7)), -1).double().numpy()
+    graph = CsrGraph.queen_grid(H, W, normalize=sparse_graph)
+    s_adj = graph if sparse_graph else graph.to_dense().double().numpy()
+    return dict(inc=inc, mask=[], HA=inc.reshape(T, -1, C).mean((0, 1)), s_adj=s_adj, c_cor=c_cor)
+
+
 def sliding_windows(data: torch.Tensor, obs_len: int, pred_len: int) -> Tuple[torch.Tensor, torch.Tensor]:
     """(x, y) views of ``data`` (T, N, C): window w observes data[w:w+obs] and predicts data[w+obs:w+obs+pred].
 

@@ -37,8 +37,12 @@ class Trainer:
             raise ValueError("device must be 'cuda:k': the STC-GNN hot path has no CPU implementation")
         self.mask = data.get('mask')
         self.threshold = data.get('HA')
-        self.prior_graph = [torch.from_numpy(np.asarray(data['s_adj'])).float().to(dev),
+        from .graph import CsrGraph
+        s_adj = data['s_adj']                                    # the reference's dense (N, N) array, or a CsrGraph (csr-fixed, any N)
+        self.prior_graph = [s_adj if isinstance(s_adj, CsrGraph) else torch.from_numpy(np.asarray(s_adj)).float().to(dev),
                             torch.from_numpy(np.asarray(data['c_cor'])).float().to(dev)]
+        if isinstance(s_adj, CsrGraph) and graph_mode != 'csr-fixed':
+            raise ValueError("a CsrGraph prior graph needs graph_mode='csr-fixed' (the learned-graph mode mixes a dense prior)")
         if params.get('model', 'STC-GNN') != 'STC-GNN':
             raise NotImplementedError('Invalid model name.')
         import torch.distributed as tdist
@@ -152,7 +156,7 @@ class Trainer:
             if self.threshold is not None:
                 # the reference's evaluation protocol (Model_Trainer.py:148-154): masked cells dropped, per-step metrics
                 H, W = self.params['H'], self.params['W']
-                mask = None if self.mask is None else [tuple(int(v) for v in m) for m in np.asarray(self.mask).reshape(-1, 2)]
+                mask = None if self.mask is None or len(self.mask) == 0 else [tuple(int(v) for v in m) for m in np.asarray(self.mask).reshape(-1, 2)]
                 out[mode]['metrics'] = smetrics.evaluate_binary(smetrics.mask_data(pred_d, H, W, mask),
                                                                  smetrics.mask_data(truth_d, H, W, mask), list(np.asarray(self.threshold)))
                 if self.rank == 0:                                   # the reference's CSV log, same file name and layout (Metrics.py:54-85)

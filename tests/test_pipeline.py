@@ -5,6 +5,7 @@ trainer runs here on the emulated kernel set (CPU) -- the GPU run of the same lo
 Adam-trajectory case and tools/train.py.
 """
 import os
+import re
 
 import numpy as np
 import pytest
@@ -308,3 +309,28 @@ def test_batch_sharded_trainer_on_the_gpu_follows_the_reference_curves(tmp_path)
     assert np.allclose(d['train'], g['train_curve'].numpy(), rtol=0, atol=1e-4), d
     assert np.allclose(d['val'], g['val_curve'].numpy(), rtol=0, atol=1e-4), d
     assert os.path.exists(tmp_path / 'STC-GNN-4.pkl')
+
+
+def test_synthetic_dataset_follows_the_reference_schema():
+    d = sdata.synthetic_incidents(10, 10, 5, 40)
+    assert set(d) == {'inc', 'mask', 'HA', 's_adj', 'c_cor'} and d['inc'].shape == (40, 10, 10, 5) and d['inc'].dtype == np.int32
+    assert d['s_adj'].shape == (100, 100) and d['s_adj'].sum() == 684 and (d['s_adj'] == d['s_adj'].T).all()      # the SF file's s_adj
+    assert d['c_cor'].shape == (5, 5) and d['HA'].shape == (5,) and 0.1 < d['HA'].mean() < 0.23
+    from stc_hip import CsrGraph
+    assert isinstance(sdata.synthetic_incidents(4, 5, 3, 12, sparse_graph=True)['s_adj'], CsrGraph)
+
+
+@pytest.mark.gpu
+def test_train_cli_on_a_synthetic_grid_with_a_fixed_sparse_graph(tmp_path):
+    """tools/train.py (Main.py's flags + -synthetic / -graph): two epochs of csr-fixed training at N = 1 600, C = 32 through the planar
+    cell graph, best-validation checkpoint, test from the checkpoint, the metrics CSV."""
+    import subprocess
+    import sys
+    cmd = [sys.executable, os.path.join(REPO, 'tools', 'train.py'), '-synthetic', '40', '40', '32', '44', '-graph', 'csr-fixed', '-epoch', '2',
+           '-batch', '4', '-obs', '4', '-pred', '2', '-out', str(tmp_path)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    losses = [float(v) for v in re.findall(r'Epoch \d+: train ([0-9.]+)', out.stdout)]
+    assert len(losses) == 2 and losses[1] < losses[0], out.stdout
+    assert os.path.exists(tmp_path / 'synthetic' / 'STC-GNN-4.pkl') and os.path.exists(tmp_path / 'synthetic' / 'STC-GNN_eval-bi-metrics.csv')
+    assert "'test'" in out.stdout and 'bce' in out.stdout

@@ -21,7 +21,7 @@ ap = argparse.ArgumentParser(description='Run multi-incident co-prediction on MI
 ap.add_argument('-device', '--device', default='cuda:0')
 ap.add_argument('-in', '--input_dir', default='../data')
 ap.add_argument('-out', '--output_dir', default='./output')
-ap.add_argument('-city', '--city', required=True, choices=sorted(CITY))
+ap.add_argument('-city', '--city', default='SF', choices=sorted(CITY))
 ap.add_argument('-obs', '--obs_len', type=int, default=9)
 ap.add_argument('-pred', '--pred_len', type=int, default=3)
 ap.add_argument('-split', '--split_ratio', type=int, nargs='+', default=[6, 1, 1])
@@ -33,15 +33,27 @@ ap.add_argument('-lr', '--learn_rate', type=float, default=2e-3)
 ap.add_argument('-dr', '--decay_rate', type=float, default=1e-4)
 ap.add_argument('-epoch', '--num_epochs', type=int, default=100)
 ap.add_argument('-test', '--test_only', type=int, default=0, choices=[0, 1])
+# beyond Main.py: fixed sparse graphs (any N) and a synthetic incident series, so that the trainer runs at sizes the SF file does not have
+ap.add_argument('-graph', '--graph_mode', default='dense-learned', choices=['dense-learned', 'csr-fixed'],
+                help="dense-learned = the reference's learned graphs (MGP_Gen, N <~ 300); csr-fixed = the prior graph used as given, row-normalised")
+ap.add_argument('-synthetic', '--synthetic', type=int, nargs=4, metavar=('H', 'W', 'C', 'T'), default=None,
+                help='train on a Bernoulli(0.1635) incident series of T steps on an H x W queen grid with C categories instead of a city file')
+ap.add_argument('-stride', '--time_slice', type=int, default=None, help=argparse.SUPPRESS)
 params = vars(ap.parse_args())
 rank, world, local = sdist.init_from_env()                      # under torchrun: one rank per GPU, each on its own device
 if world > 1:
     params['device'] = f'cuda:{local}'
+syn = params.pop('synthetic')
+ts = params.pop('time_slice')
 params.update(CITY[params['city']], model='STC-GNN')
-params['output_dir'] = os.path.join(params['output_dir'], params['city'])
-data = sdata.load_incidents(os.path.join(params['input_dir'], f'{params["city"]}-incidents-{params["time_slice"]}h.npz'))
+params['output_dir'] = os.path.join(params['output_dir'], params['city'] if syn is None else 'synthetic')
+if syn is None:
+    data = sdata.load_incidents(os.path.join(params['input_dir'], f'{params["city"]}-incidents-{params["time_slice"]}h.npz'))
+else:
+    params.update(H=syn[0], W=syn[1], C=syn[2], time_slice=ts or 4)
+    data = sdata.synthetic_incidents(*syn, sparse_graph=params['graph_mode'] == 'csr-fixed')
 loaders = sdata.get_data_loader(params, data, params['obs_len'], params['pred_len'], params['split_ratio'])
-trainer = Trainer(params, data)
+trainer = Trainer(params, data, graph_mode=params.pop('graph_mode'))
 if not params['test_only']:
     trainer.train(loaders)
 res = trainer.test(loaders)
