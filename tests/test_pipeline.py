@@ -334,3 +334,33 @@ def test_train_cli_on_a_synthetic_grid_with_a_fixed_sparse_graph(tmp_path):
     assert len(losses) == 2 and losses[1] < losses[0], out.stdout
     assert os.path.exists(tmp_path / 'synthetic' / 'STC-GNN-4.pkl') and os.path.exists(tmp_path / 'synthetic' / 'STC-GNN_eval-bi-metrics.csv')
     assert "'test'" in out.stdout and 'bce' in out.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['dense-learned', 'csr-fixed'])
+def test_trainer_with_hip_graph_replay_equals_eager(tmp_path, monkeypatch, mode):
+    """Trainer(hip_graph=True): after two eager steps per batch shape the whole step is replayed from a captured HIP graph.  Same
+    epoch losses as the eager trainer (the learned-graph run: the reference's g9 curves) and the same final parameters."""
+    monkeypatch.setattr(ops, '_kernels', None)
+    g = load_golden('g9_pipeline')
+    data, params = pipeline_inputs()
+    params = dict(params, device='cuda:0', num_epochs=3)
+    if mode == 'csr-fixed':
+        from stc_hip import CsrGraph
+        data = dict(data, s_adj=CsrGraph.queen_grid(params['H'], params['W'], normalize=True))
+    hist, flat = {}, {}
+    for graphed in (False, True):
+        out = tmp_path / str(graphed)
+        os.makedirs(out)
+        loaders = sdata.get_data_loader(params, data, params['obs_len'], params['pred_len'], params['split_ratio'])
+        torch.manual_seed(123)
+        trainer = Trainer(dict(params, output_dir=str(out)), data, graph_mode=mode, hip_graph=graphed)
+        hist[graphed] = trainer.train(loaders, verbose=False)['loss']
+        flat[graphed] = torch.cat([p.detach().flatten() for p in trainer.model.parameters()])
+        if graphed:
+            assert any(slot[1] is not None for slot in trainer._captured.values()), 'no step was captured'
+    assert np.allclose(hist[True]['train'], hist[False]['train'], rtol=0, atol=1e-6), hist
+    assert np.allclose(hist[True]['validate'], hist[False]['validate'], rtol=0, atol=1e-6), hist
+    assert float((flat[True] - flat[False]).abs().max()) < 1e-6
+    if mode == 'dense-learned':
+        assert np.allclose(hist[True]['train'][:2], g['train_curve'].numpy(), rtol=0, atol=5e-5)

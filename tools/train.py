@@ -39,6 +39,7 @@ ap.add_argument('-graph', '--graph_mode', default='dense-learned', choices=['den
 ap.add_argument('-synthetic', '--synthetic', type=int, nargs=4, metavar=('H', 'W', 'C', 'T'), default=None,
                 help='train on a Bernoulli(0.1635) incident series of T steps on an H x W queen grid with C categories instead of a city file')
 ap.add_argument('-stride', '--time_slice', type=int, default=None, help=argparse.SUPPRESS)
+ap.add_argument('-hipgraph', '--hip_graph', type=int, default=0, choices=[0, 1], help='replay the train step as a captured HIP graph (one rank; launch-bound shapes)')
 params = vars(ap.parse_args())
 rank, world, local = sdist.init_from_env()                      # under torchrun: one rank per GPU, each on its own device
 if world > 1:
@@ -53,7 +54,7 @@ else:
     params.update(H=syn[0], W=syn[1], C=syn[2], time_slice=ts or 4)
     data = sdata.synthetic_incidents(*syn, sparse_graph=params['graph_mode'] == 'csr-fixed')
 loaders = sdata.get_data_loader(params, data, params['obs_len'], params['pred_len'], params['split_ratio'])
-trainer = Trainer(params, data, graph_mode=params.pop('graph_mode'))
+trainer = Trainer(params, data, graph_mode=params.pop('graph_mode'), hip_graph=bool(params.pop('hip_graph')))
 if not params['test_only']:
     trainer.train(loaders)
 res = trainer.test(loaders)
