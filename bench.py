@@ -60,6 +60,9 @@ def parse(argv=None):
     ap.add_argument('--no-reorder', action='store_true', help='keep the given node order (skip the internal RCM renumbering)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-unit-d3', action='store_true', help='skip the cold SURVEY 8(d3) SpMM unit measurement')
+    ap.add_argument('--hip-graph', action='store_true',
+                    help='(one GPU; not the default line) time replays of the train step captured into a HIP graph: removes the launch gaps that '
+                         'matter at small N; the per-kernel events then come from eager steps after the timed region')
     ap.add_argument('--storage', choices=('f32', 'bf16'), default='f32',
                     help='storage type of states / gates / their gradients: f32 = the metric (reference arithmetic); bf16 = BASELINE configuration 5 '
                          '(not the metric: bf16 has no reference behaviour), fp32 parameters and fp32 sums inside every kernel')
@@ -256,7 +259,8 @@ def main():
     Y = (torch.rand(B, a.pred, N, C, generator=g) < 0.1635).float().to(dev)
     crit = ComboLoss()
     bucket = sdist.GradBucket(model.parameters())
-    opt = torch.optim.Adam(model.parameters(), lr=2e-3, weight_decay=1e-4)
+    graphed = a.hip_graph and world == 1
+    opt = torch.optim.Adam(model.parameters(), lr=2e-3, weight_decay=1e-4, capturable=graphed)
     stream = torch.cuda.current_stream(dev)
     marks = []                                                                  # (t_begin, t_backward_done, t_allreduce_done, t_adam_done) events
 
@@ -283,18 +287,46 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
+    for _ in range(max(a.warmup, 2 if graphed else 0)):
         step()
     hip = ops.kernels()
     fence()
-    hip.timer = KernelTimer()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        loss = step(mark=True)
-    fence()
-    elapsed = time.perf_counter() - t0
-    per_kernel = hip.timer.summary()
-    hip.timer = None
+    if graphed:
+        # the whole step as ONE captured HIP graph: `value` is over replays; the launch timer cannot run inside a replay, so the per-kernel
+        # events (roofline, kernels) are taken from eager steps after the timed region
+        torch.cuda.empty_cache()                                     # the graph gets a memory pool of its own: hand the eager pool back first
+        cg = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(cg):
+            step()
+        cg.replay()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            cg.replay()
+        fence()
+        elapsed = time.perf_counter() - t0
+        del cg
+        torch.cuda.empty_cache()
+        hip.timer = KernelTimer()
+        for _ in range(min(a.steps, 3)):
+            loss = step(mark=True)
+        fence()
+        per_kernel = hip.timer.summary()
+        for d_ in per_kernel.values():                               # scale the event sums to the step count of the line
+            for key in ('launches', 'ms', 'bytes'):
+                d_[key] = d_[key] * a.steps / min(a.steps, 3)
+                for t_ in d_.get('tags', {}).values():
+                    t_[key] = t_[key] * a.steps / min(a.steps, 3)
+        hip.timer = None
+    else:
+        hip.timer = KernelTimer()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            loss = step(mark=True)
+        fence()
+        elapsed = time.perf_counter() - t0
+        per_kernel = hip.timer.summary()
+        hip.timer = None
     n_ranks_seen = 1
     if dist.is_initialized():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -359,7 +391,7 @@ def main():
             'metric': METRIC, 'value': value, 'unit': 'samples/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * elapsed / a.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.storage, 'data': 'synthetic',
-            'n_ranks_seen': n_ranks_seen,
+            'n_ranks_seen': n_ranks_seen, 'hip_graph': bool(graphed),
             'config': {'workload': f'full STC-GNN train step (fwd + ComboLoss + bwd + grad all-reduce + Adam), csr-fixed, '
                                    f'{a.grid}x{a.grid} queen grid N={N} nnz={graph.nnz}{" permuted" if a.permute else ""}, C={C}, '
                                    f'hidden={a.hidden}, K={a.order}, layers={a.layers}, T={a.obs}+{a.pred}' + (', bf16 state storage' if a.storage == 'bf16' else ''),

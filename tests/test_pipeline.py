@@ -364,3 +364,13 @@ def test_trainer_with_hip_graph_replay_equals_eager(tmp_path, monkeypatch, mode)
     assert float((flat[True] - flat[False]).abs().max()) < 1e-6
     if mode == 'dense-learned':
         assert np.allclose(hist[True]['train'][:2], g['train_curve'].numpy(), rtol=0, atol=5e-5)
+
+
+@pytest.mark.gpu
+def test_bench_hip_graph_option():
+    """bench.py --hip-graph: `value` over replays of the captured train step; the per-kernel events come from eager steps afterwards."""
+    d = _run_bench(['--gpus', '1', '--grid', '12', '--hip-graph', '--no-cpu-baseline'])
+    assert d['hip_graph'] is True and d['value'] > 0 and d['roofline']['launches'] > 0 and d['roofline']['achieved'] > 0
+    assert abs(d['value'] - 2 * 1e3 / d['ms_per_step']) < 1e-6 * d['value']
+    e = _run_bench(['--gpus', '1', '--grid', '12', '--no-cpu-baseline'])
+    assert e['hip_graph'] is False and abs(e['loss'] - d['loss']) < 1e-4
