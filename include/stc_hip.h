@@ -344,6 +344,8 @@ int stc_cell_gates_bwd_planar_f32(const float* X, const float* H, const float* S
  *              stc_cell_blend_fwd_f32: Cand, Hnew from U and the previous state H.      W (K*K*Lw, h)
  *   *_bwd:     gradients of all 2K planes (dZx[n], dZh[n]; dZx may be NULL for a narrow input) and of W, b; the gate /
  *              blend backward run as prologues exactly as in stc_cell_gates_bwd_planar_f32 / stc_cell_cand_bwd_f32.
+ * gates_bwd with accumulate_x != 0 (wide input, dH = NULL): dZx[n] already hold the candidate convolution's gradients of the same X-side
+ * planes (cand_bwd's dZx) and the gates' are ADDED to them, so the source receives one plane per order from the cell.
  * The gradient of a plane's source is  d0 - d2 + S^T (d1 + 2 S^T d2)  (Clenshaw form of sum_n T_n(S)^T d_n): two
  * stc_spmm_sum_f32 launches with alpha / add_scale.  stc_cell_planar_k_supported() tells whether (K, C, h) is built. */
 int stc_cell_planar_k_supported(int32_t K, int32_t C, int32_t h);
@@ -354,7 +356,7 @@ int stc_cell_cand_fwd_planar_k_f32(const float* const* Zx, const float* const* Z
                                    int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream);
 int stc_cell_gates_bwd_planar_k_f32(const float* const* Zx, const float* const* Zh, int32_t K, const float* Tc, const float* W,
                                     const float* dRH, const float* Cand, const float* U, const float* Rg, const float* dHnew,
-                                    float* const* dZx, float* const* dZh, float* dW, float* db, float* dH,
+                                    float* const* dZx, float* const* dZh, float* dW, float* db, float* dH, int32_t accumulate_x,
                                     void* workspace, size_t workspace_bytes, int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream);
 int stc_cell_cand_bwd_planar_k_f32(const float* const* Zx, const float* const* Zh, int32_t K, const float* Tc, const float* W,
                                    const float* dHnew, const float* U, const float* Cand,

@@ -340,8 +340,9 @@ class EmulatedKernels:
             if dZx[n] is not None:
                 dZx[n].copy_(r[..., :cin])
 
-    def cell_gates_bwd_planar_k(self, Zx, Zh, Tc, W, dRH, Cand, U, Rg, dHnew, dZx, dZh, dW, db, dH):
+    def cell_gates_bwd_planar_k(self, Zx, Zh, Tc, W, dRH, Cand, U, Rg, dHnew, dZx, dZh, dW, db, dH, accumulate_x=False):
         cin, h = Zx[0].shape[-1], Zh[0].shape[-1]
+        before = [z.clone() for z in dZx] if accumulate_x else None              # the candidate's gradients already in the X-side planes
         fold = dH is None                                                   # the prologue's share goes into dZh[0]
         if fold:
             dH = torch.empty_like(Zh[0])
@@ -351,6 +352,9 @@ class EmulatedKernels:
         self._split_planes(rows, dZx, dZh, cin)
         if fold:
             dZh[0] += dH
+        if accumulate_x:
+            for z, b in zip(dZx, before):
+                z += b
 
     def cell_cand_bwd_planar_k(self, Zx, Zh, Tc, W, dHnew, U, Cand, dZx, dZh, dW, db):
         cin, h = Zx[0].shape[-1], Zh[0].shape[-1]

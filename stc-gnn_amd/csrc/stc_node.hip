@@ -586,7 +586,7 @@ extern "C" int stc_cell_cand_fwd_planar_k_f32(const float* const* Zx, const floa
 static int planar_k_bwd(const char* who, const float* const* Zx, const float* const* Zh, int K, const float* Tc, const float* W, int mode,
                         const float* dRH, const float* Cand, const float* U, const float* Rg, const float* dHnew,
                         float* const* dZx, float* const* dZh, float* dW, float* db, float* dH, void* workspace, size_t workspace_bytes,
-                        long long nodes, int C, int Lw, int h, hipStream_t s) {
+                        long long nodes, int C, int Lw, int h, hipStream_t s, int accumulate_x = 0) {
     const int L = Lw == 2 * h ? 2 * h : 20, Ho = mode == 1 ? 2 * h : h;
     if (int rc = planar_k_common(who, Zx, Zh, K, C, Lw, h, Ho, nodes)) return rc;
     STC_REQUIRE(W && dW && Tc && dZh && (Lw != 2 * h || dZx), STC_EINVAL, "%s: null W/dW/Tc/dZ", who);
@@ -601,8 +601,9 @@ static int planar_k_bwd(const char* who, const float* const* Zx, const float* co
     STC_REQUIRE(workspace_bytes >= stc_bdg_node_bwd_workspace_bytes(K, K, C, L, Ho, 0), STC_EINVAL, "%s: workspace of %zu B is too small", who, workspace_bytes);
     int n_parts = 0;
     float* partial = static_cast<float*>(workspace);
-    const int rc = stc_cell_conv_bwd_planar_k_x3(Zx, Zh, K, Tc, W, mode, dRH, Cand, U, Rg, dHnew, dZx, dZh, dH, partial, &n_parts, db != nullptr, nodes, C, Lw, s);
-    if (rc == STC_NOT_HANDLED) return stc::fail(STC_EUNSUPPORTED, "%s: operands not usable (alignment / null gradient plane)", who);
+    const int rc = stc_cell_conv_bwd_planar_k_x3(Zx, Zh, K, Tc, W, mode, dRH, Cand, U, Rg, dHnew, dZx, dZh, dH, partial, &n_parts, db != nullptr, nodes, C, Lw,
+                                                 accumulate_x, s);
+    if (rc == STC_NOT_HANDLED) return stc::fail(STC_EUNSUPPORTED, "%s: operands not usable (alignment / null gradient plane / accumulate_x outside the wide folded form)", who);
     if (rc != STC_OK) return rc;
     const int stride = nW + Ho;
     hipLaunchKernelGGL(bdg_node_reduce_kernel, dim3((stride + RED_ELEMS - 1) / RED_ELEMS), dim3(NODE_THREADS), 0, s,
@@ -613,10 +614,10 @@ static int planar_k_bwd(const char* who, const float* const* Zx, const float* co
 
 extern "C" int stc_cell_gates_bwd_planar_k_f32(const float* const* Zx, const float* const* Zh, int32_t K, const float* Tc, const float* W,
                                                const float* dRH, const float* Cand, const float* U, const float* Rg, const float* dHnew,
-                                               float* const* dZx, float* const* dZh, float* dW, float* db, float* dH,
+                                               float* const* dZx, float* const* dZh, float* dW, float* db, float* dH, int32_t accumulate_x,
                                                void* workspace, size_t workspace_bytes, int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream) {
     return planar_k_bwd("stc_cell_gates_bwd_planar_k_f32", Zx, Zh, K, Tc, W, 1, dRH, Cand, U, Rg, dHnew, dZx, dZh, dW, db, dH, workspace, workspace_bytes,
-                        nodes, C, Lw, h, static_cast<hipStream_t>(stream));
+                        nodes, C, Lw, h, static_cast<hipStream_t>(stream), accumulate_x);
 }
 
 extern "C" int stc_cell_cand_bwd_planar_k_f32(const float* const* Zx, const float* const* Zh, int32_t K, const float* Tc, const float* W,

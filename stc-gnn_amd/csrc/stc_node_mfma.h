@@ -101,7 +101,7 @@ int stc_cell_conv_fwd_planar_k_x3(const float* const* Zx, const float* const* Zh
 int stc_cell_conv_bwd_planar_k_x3(const float* const* Zx, const float* const* Zh, int K, const float* Tc, const float* W, int mode,
                                   const float* dRH, const float* Cand, const float* U, const float* R, const float* dHnew,
                                   float* const* dZx, float* const* dZh, float* dH, float* partial, int* n_partials, int want_db,
-                                  long long nodes, int C, int Lw, hipStream_t stream);
+                                  long long nodes, int C, int Lw, int accumulate_x, hipStream_t stream);
 
 // Post-aggregation form at order 3 (planar input only): P[0] = P_0 - P_2 + b, P[1] = P_1, P[2] = P_2; backward from dP[0..2].
 int stc_node_post_k_shape_ok(int K, int C, int L, int Ho);

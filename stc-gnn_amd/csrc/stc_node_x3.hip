@@ -492,7 +492,10 @@ struct NodeIn {      // what one node contributes from HBM: its dY fragments and
 template <int NB2, int K>
 struct BwdSched { static constexpr int waves = (NB2 == 1 && K <= 2) ? 2 : 1; };
 
-template <int NB2, int HB, int K, int L, int PRO, int PL = 0, int FOLD = 0>      // FOLD: see load_gates_grad (planar gates backward only)
+// ACC (planar, PL = 1): the X-side gradient planes dZ.p[n] already hold another convolution's gradients for the same planes (the
+// candidate's) and this kernel ADDS its own: the tile's accumulators start from the stored values -- the source then gets one plane per
+// Chebyshev order from the cell instead of two.
+template <int NB2, int HB, int K, int L, int PRO, int PL = 0, int FOLD = 0, int ACC = 0>      // FOLD: see load_gates_grad (planar gates backward only)
 __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bwd_x3_kernel(
     ZPtrs Z, const float* __restrict__ Tc, const float* __restrict__ W, const float* __restrict__ dY,
     DZPtrs dZ, float* __restrict__ partial, int nodes, int want_db, int Lw, BwdPro pro) {
@@ -621,6 +624,8 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
                     if (FOLD && n == 0 && lb == HLB) {          // the tile starts from the state's share parked by the prologue
                         const float4 sh = stash[rb * 64 + lane];
                         z[rb] = f32x4{sh.x, sh.y, sh.z, sh.w};
+                    } else if (ACC && PL == 1 && lb == 0) {     // ... or from what the plane already holds
+                        z[rb] = *reinterpret_cast<const f32x4*>(dZ.p[n] + (r0 + 16 * rb + x) * 16 + 4 * g);
                     } else {
                         z[rb] = kZero4;
                     }
@@ -1313,7 +1318,7 @@ int launch_fwd(const float* const* Z, const float* Tc, const float* W, const flo
     return STC_OK;
 }
 
-template <int NB2, int HB, int K, int L, int PRO = PRO_NONE, int PL = 0, int FOLD = 0>
+template <int NB2, int HB, int K, int L, int PRO = PRO_NONE, int PL = 0, int FOLD = 0, int ACC = 0>
 int launch_bwd(const float* const* Z, const float* Tc, const float* W, const float* dY, float* const* dZ,
                float* partial, int* n_partials, int want_db, long long nodes, int Lw, hipStream_t stream, BwdPro pro = BwdPro{}) {
     constexpr int NRB = 2 * NB2, Ho = 16 * HB, LB = (L + 15) / 16, NBK = K * HB, S = (NBK + 1) / 2, nW = K * K * L * Ho;
@@ -1321,7 +1326,7 @@ int launch_bwd(const float* const* Z, const float* Tc, const float* W, const flo
     const size_t slabs = (size_t)MF_WAVES * (nW + Ho) * sizeof(float);
     const size_t lds = frag > slabs ? frag : slabs;
     if (lds > stc::kMaxLdsBytes) return STC_NOT_HANDLED;
-    auto kern = node_bwd_x3_kernel<NB2, HB, K, L, PRO, PL, FOLD>;
+    auto kern = node_bwd_x3_kernel<NB2, HB, K, L, PRO, PL, FOLD, ACC>;
     if (int rc = stc::hip_status(stc::allow_lds(kern, lds), "hipFuncSetAttribute(node bwd x3)")) return rc;
     static const int resident = stc::resident_blocks(kern, MF_THREADS, lds, BwdSched<NB2, K>::waves);
     ZPtrs zp{};
@@ -1686,7 +1691,7 @@ int stc_cell_conv_fwd_planar_k_x3(const float* const* Zx, const float* const* Zh
 int stc_cell_conv_bwd_planar_k_x3(const float* const* Zx, const float* const* Zh, int K, const float* Tc, const float* W, int mode,
                                   const float* dRH, const float* Cand, const float* U, const float* R, const float* dHnew,
                                   float* const* dZx, float* const* dZh, float* dH, float* partial, int* n_partials, int want_db,
-                                  long long nodes, int C, int Lw, hipStream_t stream) {
+                                  long long nodes, int C, int Lw, int accumulate_x, hipStream_t stream) {
     const int cin = Lw - 16;
     if (!stc_cell_planar_k_shape_ok(K, C, 16) || !x3_cell_shape(K, C, cin == 16 ? 32 : 20, nodes) || !(cin == 16 || (cin >= 1 && cin <= 4))) return STC_NOT_HANDLED;
     if (!all_aligned16(Zh, K) || (cin == 16 && !all_aligned16(Zx, K))) return STC_NOT_HANDLED;
@@ -1702,6 +1707,10 @@ int stc_cell_conv_bwd_planar_k_x3(const float* const* Zx, const float* const* Zh
     if (mode == 1) {
         if (!(stc::aligned16(dRH) && stc::aligned16(R) && (!dH || stc::aligned16(dH)))) return STC_NOT_HANDLED;
         pro.Cand = Cand; pro.dCandIn = dRH; pro.H = Zh[0]; pro.U = U; pro.R = R; pro.dH_in = dHnew; pro.dH = dH; pro.cin = 0; pro.dh_scaled = 1;
+        if (accumulate_x) {                                     // wide, folded form only: what the cell graph runs
+            if (dH || cin != 16) return STC_NOT_HANDLED;
+            return launch_bwd<1, 2, 3, 32, PRO_GATES_CAND, 1, 1, 1>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro);
+        }
         if (!dH)        // the state's share from the gate prologue is folded into dZh[0]
             return cin == 16 ? launch_bwd<1, 2, 3, 32, PRO_GATES_CAND, 1, 1>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro)
                              : launch_bwd<1, 2, 3, 20, PRO_GATES_CAND, 2, 1>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro);

@@ -92,7 +92,7 @@ def _declare(lib):
                              _i32, _i32, _i32, _p],
         'stc_cell_gates_fwd_planar_k_f32': [C.POINTER(_p), C.POINTER(_p), _i32, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p],
         'stc_cell_cand_fwd_planar_k_f32': [C.POINTER(_p), C.POINTER(_p), _i32, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p],
-        'stc_cell_gates_bwd_planar_k_f32': [C.POINTER(_p), C.POINTER(_p), _i32, _p, _p, _p, _p, _p, _p, _p, C.POINTER(_p), C.POINTER(_p), _p, _p, _p,
+        'stc_cell_gates_bwd_planar_k_f32': [C.POINTER(_p), C.POINTER(_p), _i32, _p, _p, _p, _p, _p, _p, _p, C.POINTER(_p), C.POINTER(_p), _p, _p, _p, _i32,
                                             _p, C.c_size_t, _i64, _i32, _i32, _i32, _p],
         'stc_cell_cand_bwd_planar_k_f32': [C.POINTER(_p), C.POINTER(_p), _i32, _p, _p, _p, _p, _p, C.POINTER(_p), C.POINTER(_p), _p, _p,
                                            _p, C.c_size_t, _i64, _i32, _i32, _i32, _p],
@@ -758,8 +758,12 @@ class HipKernels:
             self._f32(f'{what}.dZx[{n}]', dZx[n], (R, Cc, cin))
         return (_p * K)(*[0 if z is None else z.data_ptr() for z in dZx]), (_p * K)(*[z.data_ptr() for z in dZh])
 
-    def cell_gates_bwd_planar_k(self, Zx, Zh, Tc, W, dRH, Cand, U, Rg, dHnew, dZx, dZh, dW, db, dH):
+    def cell_gates_bwd_planar_k(self, Zx, Zh, Tc, W, dRH, Cand, U, Rg, dHnew, dZx, dZh, dW, db, dH, accumulate_x=False):
+        """``accumulate_x``: the X-side planes ``dZx`` hold the candidate's gradients of the same planes; the gates' are added to them
+        (wide input, ``dH=None`` only)."""
         K, R, Cc, h, cin = self._planes_k('planar_k gates bwd', Zx, Zh, Tc, W, 2 * Zh[0].shape[-1])
+        if accumulate_x and (dH is not None or cin != h):
+            raise StcError('planar_k gates bwd: accumulate_x goes with a 16-wide input and dH=None')
         for name, t in (('dRH', dRH), ('Cand', Cand), ('U', U), ('Rg', Rg), ('dHnew', dHnew)) + ((('dH', dH),) if dH is not None else ()):
             self._f32('planar_k.' + name, t, (R, Cc, h))    # dH None: the kernel folds the state's share into dZh[0]
         zx, zh = self._grad_planes_k('planar_k gates bwd', dZx, dZh, K, R, Cc, h, cin)
@@ -769,7 +773,7 @@ class HipKernels:
         self._same_device(*Zx, *Zh, Tc, W, dRH, Cand, U, Rg, dHnew, *dZx, *dZh, dW, db, dH)
         ws = self._get_workspace(U.device, self.lib.stc_bdg_node_bwd_workspace_bytes(K, K, Cc, 2 * h, 2 * h, 0))
         self._launch('stc_cell_gates_bwd_planar_k_f32', U, self._ptr_array(Zx), self._ptr_array(Zh), K, _ptr(Tc), _ptr(W), _ptr(dRH), _ptr(Cand),
-                     _ptr(U), _ptr(Rg), _ptr(dHnew), zx, zh, _ptr(dW), _ptr(db), _ptr(dH), _ptr(ws), ws.numel(), R, Cc, cin + h, h)
+                     _ptr(U), _ptr(Rg), _ptr(dHnew), zx, zh, _ptr(dW), _ptr(db), _ptr(dH), int(bool(accumulate_x)), _ptr(ws), ws.numel(), R, Cc, cin + h, h)
 
     def cell_cand_bwd_planar_k(self, Zx, Zh, Tc, W, dHnew, U, Cand, dZx, dZh, dW, db):
         K, R, Cc, h, cin = self._planes_k('planar_k cand bwd', Zx, Zh, Tc, W, Zh[0].shape[-1])

@@ -817,13 +817,20 @@ class _StcCellGraph(Function):
                     dRH = clenshaw([dR[0]], [dR[1]], [dR[2]])        # gradient of the R*H plane from its three Chebyshev planes
                     del dR
                 fold = getattr(k, 'folds_dH', False)                  # the kernel adds the prologue's share into the H plane's gradient
-                dXg, dHg, dH = ([new(), new(), new()] if wide else [None] * 3), [new(), new(), new()], (None if fold else new())
+                # slab-planar candidate on a wide input: the gates' X-side gradients are ADDED into the candidate's three planes by the
+                # kernel (accumulate_x), so the source gets one plane per order from this cell and its Clenshaw sums need no pre-sum
+                into = fold and wide and n_saved[j] == -12
+                dXg = dXc if into else ([new(), new(), new()] if wide else [None] * 3)
+                dHg, dH = [new(), new(), new()], (None if fold else new())
                 dWg, dbg = torch.empty_like(Wg), (Wg.new_empty(2 * h) if bg is not None else None)
                 k.cell_gates_bwd_planar_k(rows(Zx), rows(Zh), Tc, Wg, *rows((dRH, Cand, U, Rg, dHnew)),
                                           [None if t is None else t.view(B * N, C, h) for t in dXg], rows(dHg), dWg, dbg,
-                                          None if fold else dH.view(B * N, C, h))
+                                          None if fold else dH.view(B * N, C, h), accumulate_x=into)
+                if into:
+                    dXc = [None] * 3
                 if wide and x[0] == 'cell':
-                    leave3(x[1], (dXg[0], dXc[0]), [t for t in (dXg[1], dXc[1]) if t is not None], [t for t in (dXg[2], dXc[2]) if t is not None])
+                    leave3(x[1], [t for t in (dXg[0], dXc[0]) if t is not None], [t for t in (dXg[1], dXc[1]) if t is not None],
+                           [t for t in (dXg[2], dXc[2]) if t is not None])
                 if hs[0] == 'cell':
                     leave3(hs[1], (dHg[0],) if fold else (dHg[0], dH), (dHg[1],), (dHg[2],))
                 for i, t in enumerate((dWg, dbg, dWc, dbc)):

@@ -718,6 +718,12 @@ def test_planar_cell_kernels_order3(hip, nodes, cin):
     dHf = [nan(nodes, C, h) for _ in range(K)]                            # dH = None: folded into dZh[0]
     hip.cell_gates_bwd_planar_k(cus(Zx), cus(Zh), cu(Tc), cu(Wg), cu(dRH), cu(Cand_w), cu(U_w), cu(R_w), cu(dHn), dXg, dHf, dWg, dbg, None)
     assert rel_err(dHf[0], dHg_w[0] + dH_w) < TOL and torch.equal(dHf[1], dHg[1]) and torch.equal(dHf[2], dHg[2])
+    if wide:                                                              # accumulate_x: the gates' X-side gradients are added into planes that hold the candidate's
+        acc = [t.clone() for t in dXc]
+        hip.cell_gates_bwd_planar_k(cus(Zx), cus(Zh), cu(Tc), cu(Wg), cu(dRH), cu(Cand_w), cu(U_w), cu(R_w), cu(dHn), acc, dHf, dWg, dbg, None, accumulate_x=True)
+        for n in range(K):
+            assert rel_err(acc[n], dXc_w[n] + dXg_w[n]) < TOL
+        assert rel_err(dWg, dWg_w) < TOL
 
 
 @pytest.mark.parametrize('nodes,cin', [(50, 16), (4500, 16), (37, 1), (600, 4)])
