@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define STC_ABI_VERSION 11
+#define STC_ABI_VERSION 12
 #define STC_MAX_K 4          /* highest Chebyshev order (Ks, Kc) the node kernels accept */
 
 #define STC_OK 0
@@ -321,7 +321,8 @@ int stc_cell_blend_fwd_f32(const float* const* Z, int32_t Ks, const float* Tc, i
 int stc_cell_planar_supported(int32_t Ks, int32_t Kc, int32_t C, int32_t h);
 /* A != NULL: the same launch also runs the candidate convolution's projection on [Xt | R*H], which the wave still
  * holds in registers: A, Bm (nodes, C, h) as stc_bdg_node_post_fwd_f32 would give for weights Wc (4*Lw, h) and bias bc --
- * that launch and its re-read of Xt and R*H are then not needed.  RH is written regardless (the backward needs it). */
+ * that launch and its re-read of Xt and R*H are then not needed.  RH may then be NULL (not written): stc_cell_bwd_planar_f32
+ * forms R*H itself; stc_bdg_node_post_bwd_f32 needs the plane. */
 int stc_cell_gates_fwd_planar_f32(const float* X, const float* H, const float* SX, const float* SH,
                                   const float* Tc, const float* W, const float* bias,
                                   float* U, float* Rg, float* RH,
@@ -333,6 +334,27 @@ int stc_cell_gates_bwd_planar_f32(const float* X, const float* H, const float* S
                                   float* const* dZ, float* dW, float* db, float* dH,
                                   void* workspace, size_t workspace_bytes,
                                   int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream);
+
+/* The whole backward of one planar cell step (autograd of STC_GNN.py:65-79 for the forward pair stc_cell_gates_fwd_planar_f32 with
+ * its fused candidate projection + stc_spmm_blend_fwd_f32) in ONE launch: stc_bdg_node_post_bwd_f32 on (X, R*H; dA = dY, dB = dBm) and
+ * stc_cell_gates_bwd_planar_f32 (dH = NULL form) back to back per node, with
+ *   dY = dHnew * U * (1 - Cand^2) formed in the kernel (dBm = S^T dY is the caller's narrow SpMM on the dY plane it already has),
+ *   R*H formed from Rg and H (the forward need not store that plane),
+ *   the R*H plane's gradient handed from the candidate to the gate prologue inside the wave (never written),
+ *   dX = the candidate's PLUS the gates' gradient of the X plane (one plane for the source's gradient sum instead of two).
+ * In: X, H, SX, SH as above, gates Rg / U / Cand, dHnew and dBm (nodes, C, h); Wg (4*Lw, 2h), Wc (4*Lw, h).
+ * Out: dX, dSX, dH (the H plane's gradient incl. the prologue's share), dSH (nodes, C, h); dWg, dbg, dWc, dbc (db* may be NULL).
+ * Narrow input (Lw - h in 1..4): dX, dSX are not produced (may be NULL).  stc_cell_bwd_planar_supported() tells whether (C, h)
+ * is built (C = 32, h = 16); workspace >= stc_cell_bwd_planar_workspace_bytes(C, Lw, h) bytes, 16-byte aligned. */
+int stc_cell_bwd_planar_supported(int32_t C, int32_t h);
+size_t stc_cell_bwd_planar_workspace_bytes(int32_t C, int32_t Lw, int32_t h);
+int stc_cell_bwd_planar_f32(const float* X, const float* H, const float* SX, const float* SH,
+                            const float* Tc, const float* Wg, const float* Wc,
+                            const float* U, const float* Rg, const float* Cand, const float* dHnew, const float* dBm,
+                            float* dX, float* dSX, float* dH, float* dSH,
+                            float* dWg, float* dbg, float* dWc, float* dbc,
+                            void* workspace, size_t workspace_bytes,
+                            int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream);
 
 /* ---- planar cell convolutions of Chebyshev order K = 3 (C = 32, h = 16) ----------------------------------------------
  * The planar form above for BDG_Dif.cheby_poly order 3 (STC_GNN.py:24-29, 35-39; BASELINE configuration 4).  Zx[n] / Zh[n],

@@ -246,7 +246,8 @@ class EmulatedKernels:
         cin, h = X.shape[-1], H.shape[-1]                        # cin = h, or 1..4 (narrow input plane, layer 0)
         CandIn = torch.empty(H.shape[:-1] + (cin + h,), dtype=W.dtype)
         self.cell_gates_fwd([torch.cat([X, H], -1), torch.cat([SX, SH], -1)], Tc, W, bias, H, U, Rg, CandIn)
-        RH.copy_(CandIn[..., cin:])
+        if RH is not None:                                      # optional with post=: cell_bwd_planar forms R*H itself
+            RH.copy_(CandIn[..., cin:])
         if post is not None:                                   # + the candidate's projection on [Xt | R*H]
             Wc, bc, A, Bm = post
             self.node_post_fwd(CandIn, Tc, Wc, bc, A, Bm)
@@ -263,6 +264,23 @@ class EmulatedKernels:
         dZs[2].copy_(rows[0][..., cin:] + (dH if fold else 0)); dZs[3].copy_(rows[1][..., cin:])  # d H plane, d SH plane
         if dZs[0] is not None:
             dZs[0].copy_(rows[0][..., :cin]); dZs[1].copy_(rows[1][..., :cin])  # d X plane, d SX plane
+
+    # stc_cell_bwd_planar_f32: candidate (post-aggregation form) + gates backward of one planar cell step, composed from the two twins
+    def cell_bwd_planar_supported(self, Cc, h) -> bool:
+        return h == 16
+
+    def cell_bwd_planar(self, X, H, SX, SH, Tc, Wg, Wc, U, Rg, Cand, dHnew, dBm, dZs, dWg, dbg, dWc, dbc):
+        cin, h = X.shape[-1], H.shape[-1]
+        dY = dHnew * U * (1 - Cand * Cand)
+        RH, dRH = Rg * H, torch.empty_like(H)
+        if cin == h:
+            dXc = torch.empty_like(H)
+            self.node_post_bwd(X, Tc, Wc, dY, dBm, dXc, dWc, dbc, X2=RH, dX2=dRH)
+        else:
+            self.node_post_bwd(RH, Tc, Wc, dY, dBm, dRH, dWc, dbc, X2=X)
+        self.cell_gates_bwd_planar(X, H, SX, SH, Tc, Wg, dRH, Cand, U, Rg, dHnew, dZs, dWg, dbg, None)
+        if cin == h:
+            dZs[0].add_(dXc)
 
     def spmm_sum(self, rowptr, colidx, val, plan, X, X2, addends, Y, blend=None, alpha=1.0):
         B, n, Cc, h = Y.shape

@@ -1,0 +1,378 @@
+// The whole backward of one planar STC_Cell step (reference STC_GNN.py:65-79 through autograd; K = 2, C = 32, hidden 16) in ONE
+// launch on the split-operand matrix cores of gfx950: the candidate convolution's backward in post-aggregation form
+// (node_bwd2_x3_kernel) and the gates convolution's backward with the gate / blend backward as its prologue
+// (node_bwd_x3_kernel<.., PRO_GATES_CAND, PL, FOLD>) run back to back on the same node while its operands are with the wave.
+//
+// What the fusion removes from HBM per cell step and sample (planes of nodes x C x 16 floats):
+//   * dY = dHnew * U * (1 - Cand^2) is formed here from three planes the gate prologue reads anyway (the candidate kernel read it);
+//   * the R*H plane's gradient goes from the candidate's dX tile to the gate prologue through a per-wave LDS tile -- never written;
+//   * the candidate's X-side gradient is parked in a lane-private LDS slot and the gates' X tile STARTS from it: one plane instead of
+//     two for the source's gradient sum;
+//   * X and R*H are not read a second time (R*H = R.H is formed from planes the prologue holds, so the forward need not store it).
+// 13 planes (9 in: X, H, S.X, S.H, U, R, Cand, dHnew, dBm; 4 out: dX, dS.X, dH, dS.H) instead of 19, and one addend less in the
+// state-gradient sum that follows.
+//
+// Registers: both convolutions' dW tiles persist across the nodes of a wave (64 + 32 registers) and the gates phase alone fills the 256
+// registers of two waves per SIMD; at that budget the fused body spilled 72 registers to scratch (scratch stores go through to HBM:
+// 4.6 GB per launch, more than the fusion saves).  The kernel therefore runs ONE wave per SIMD with the full 512-register file and hides
+// HBM latency itself: the next node's 120 operand registers are requested before the current node is computed (software prefetch).
+#include "stc_x3_frag.h"
+
+namespace {
+
+constexpr int CB_WAVES = 4, CB_THREADS = CB_WAVES * 64;
+constexpr int CB_TRS = 20;                      // row stride of the transpose tile (16 + 4: conflict-free column reads)
+
+struct CellBwdArgs {
+    const float *X, *H, *SX, *SH;               // PL = 1: (nodes, C, 16) planes; PL = 2: X, SX are the narrow input planes (nodes, C, cin)
+    const float *U, *R, *Cand, *dHnew, *dBm;    // (nodes, C, 16)
+    const float *Tc, *Wg, *Wc;                  // (2, C, C); (4 Lw, 32); (4 Lw, 16)
+    float *dX, *dSX, *dH, *dSH;                 // gradient planes (dX, dSX: PL = 1 only)
+    float *partial_g, *partial_c;               // one row [dW | db] per workgroup for each convolution
+    int nodes, want_dbg, want_dbc, Lw;
+};
+
+// per-wave LDS block: [stash_h 2 x 64 float4][stash_x 2 x 64 float4][tile 32 x CB_TRS floats]
+constexpr int CB_WAVE_BYTES = 2 * 64 * 16 + 2 * 64 * 16 + 32 * CB_TRS * 4;
+constexpr int CB_TABLE_FRAGS = 2 + 8 + 4;       // T_1 (2), gates W (K LB S = 8), candidate W (K LB = 4)
+constexpr size_t CB_LDS_BYTES = (size_t)CB_TABLE_FRAGS * 3 * 64 * 16 + (size_t)CB_WAVES * CB_WAVE_BYTES;
+
+template <int L, int PL>        // PL = 1: L = 32, rows [X | H];  PL = 2: L = 20, rows [H | x (cin = Lw - 16 <= 4) | pad], W rows permuted to match
+__global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs a) {
+    constexpr int K = 2, NRB = 2, C = 32, LB = 2, HID = 16;
+    constexpr int RHB = PL == 1 ? 1 : 0;          // block of the row that is the state plane (H for the gates, R*H for the candidate)
+    constexpr int LBD = PL == 1 ? 2 : 1;          // blocks of the row whose gradient is wanted (a narrow input plane gets none)
+    static_assert((PL == 1 && L == 32) || (PL == 2 && L == 20), "planar rows are 16 + 16 or 16 + cin columns");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32x4* TB = reinterpret_cast<u32x4*>(smem_raw);     // [NRB rb]          T_1[16rb + x][pair_row]
+    u32x4* WG = TB + 2 * 3 * 64;                         // [K n][LB][S = 2]  Wg[(n, c, 16lb + x)][16hb + 4g + (e&3)], block 2s + (e>>2) = (c, hb)
+    u32x4* WC = WG + 8 * 3 * 64;                         // [K n][LB]         Wc[(n, c, 16lb + x)][4g + (e&3)], block (e>>2) = c
+    const int tid = threadIdx.x, lane = tid & 63, x = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned char* mine = reinterpret_cast<unsigned char*>(WC + 4 * 3 * 64) + (size_t)wave * CB_WAVE_BYTES;
+    float4* stash_h = reinterpret_cast<float4*>(mine);               // the state's share of the gate prologue, lane-private
+    float4* stash_x = stash_h + 2 * 64;                               // the candidate's X-side gradient, lane-private
+    float* tile = reinterpret_cast<float*>(stash_x + 2 * 64);         // d(R*H): row-on-lane -> accumulator layout
+    const int cin = a.Lw - 16;
+
+    for (int idx = tid; idx < 2 * 64; idx += CB_THREADS) {
+        const int ll = idx & 63, rb = idx >> 6, gg = ll >> 4;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = a.Tc[(size_t)C * C + (16 * rb + (ll & 15)) * C + pair_row(gg, e)];
+        put_frag(TB, rb, ll, v);
+    }
+    for (int idx = tid; idx < 8 * 64; idx += CB_THREADS) {
+        const int ll = idx & 63, f = idx >> 6, s = f % 2, lb = (f / 2) % LB, n = f / (2 * LB), gg = ll >> 4;
+        const int l = 16 * lb + (ll & 15);
+        const int wl = PL == 2 ? stc_wrow_swapped(l, cin) : l;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int b = 2 * s + (e >> 2), c = b / 2, hb = b % 2;
+            v[e] = (wl >= 0 && wl < a.Lw) ? a.Wg[((size_t)(n * K + c) * a.Lw + wl) * 32 + 16 * hb + 4 * gg + (e & 3)] : 0.f;
+        }
+        put_frag(WG, f, ll, v);
+    }
+    for (int idx = tid; idx < 4 * 64; idx += CB_THREADS) {
+        const int ll = idx & 63, f = idx >> 6, lb = f % LB, n = f / LB, gg = ll >> 4;
+        const int l = 16 * lb + (ll & 15);
+        const int wl = PL == 2 ? stc_wrow_swapped(l, cin) : l;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = e >> 2;
+            v[e] = (wl >= 0 && wl < a.Lw) ? a.Wc[((size_t)(n * K + c) * a.Lw + wl) * 16 + 4 * gg + (e & 3)] : 0.f;
+        }
+        put_frag(WC, f, ll, v);
+    }
+    __syncthreads();
+
+    const int nw = gridDim.x * CB_WAVES;
+    f32x4 dWg[K][LB][K][2];            // gates dW tiles: rows l = 16lb + 4g + r, columns o = 16hb + x
+    float dbg[2] = {0.f, 0.f}, dbc[1] = {0.f};
+#pragma unroll
+    for (int n = 0; n < K; ++n)
+#pragma unroll
+        for (int lb = 0; lb < LB; ++lb)
+#pragma unroll
+            for (int c = 0; c < K; ++c)
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb) dWg[n][lb][c][hb] = kZero4;
+    f32x4 dWc[K][LB][K][1];            // candidate dW tiles: rows l, columns o = x
+#pragma unroll
+    for (int n = 0; n < K; ++n)
+#pragma unroll
+        for (int lb = 0; lb < LB; ++lb)
+#pragma unroll
+            for (int c = 0; c < K; ++c) dWc[n][lb][c][0] = kZero4;
+
+    const float* P0[K] = {PL == 1 ? a.X : a.H, PL == 1 ? a.SX : a.SH};          // block 0 of slab n
+    const float* P1[K] = {PL == 1 ? a.H : a.X, PL == 1 ? a.SH : a.SX};          // block 1 of slab n (PL = 2: the narrow plane)
+
+    // One node's operands: slab columns and gate planes in accumulator layout (row 16kb + 4g + t, column x), and the gate planes again in
+    // row-on-lane layout (row 16kb + x, columns 4g .. 4g+3: the same lines, cache hits).
+    struct Ops {
+        float zg[K][LB][NRB][4];
+        float ud[NRB][4], rd[NRB][4], cd[NRB][4], gn[NRB][4], bm[NRB][4];
+        f32x4 uv[NRB], rv[NRB], cv[NRB], gv[NRB], hv[NRB], bv[NRB];
+    };
+    auto load_ops = [&](Ops& o, int nd) {
+        const size_t r0 = (size_t)nd * C;
+#pragma unroll
+        for (int kb = 0; kb < NRB; ++kb)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const size_t row = r0 + 16 * kb + 4 * g + t, e = row * HID + x;
+#pragma unroll
+                for (int n = 0; n < K; ++n) {
+                    o.zg[n][0][kb][t] = P0[n][e];
+                    if constexpr (PL == 1) o.zg[n][1][kb][t] = P1[n][e];
+                    else o.zg[n][1][kb][t] = x < cin ? P1[n][row * cin + x] : 0.f;
+                }
+                o.ud[kb][t] = a.U[e]; o.rd[kb][t] = a.R[e]; o.cd[kb][t] = a.Cand[e]; o.gn[kb][t] = a.dHnew[e]; o.bm[kb][t] = a.dBm[e];
+            }
+#pragma unroll
+        for (int kb = 0; kb < NRB; ++kb) {
+            const size_t e = (r0 + 16 * kb + x) * HID + 4 * g;
+            o.uv[kb] = *reinterpret_cast<const f32x4*>(a.U + e);
+            o.rv[kb] = *reinterpret_cast<const f32x4*>(a.R + e);
+            o.cv[kb] = *reinterpret_cast<const f32x4*>(a.Cand + e);
+            o.gv[kb] = *reinterpret_cast<const f32x4*>(a.dHnew + e);
+            o.hv[kb] = *reinterpret_cast<const f32x4*>(a.H + e);
+            o.bv[kb] = *reinterpret_cast<const f32x4*>(a.dBm + e);
+        }
+    };
+    Ops cur, nxt;
+    int node = blockIdx.x * CB_WAVES + wave;
+    if (node < a.nodes) load_ops(cur, node);
+    // The first node's loads are waited for HERE: left pending into the loop, the compiler's wait-count pass merges them with the loop's own
+    // state and makes every iteration wait for the loads it has just issued for the NEXT node (vmcnt counts in order) -- no prefetch at all.
+    __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0), expcnt / lgkmcnt untouched
+    while (node < a.nodes) {
+        const int next_node = node + nw;
+        if (next_node < a.nodes) load_ops(nxt, next_node);         // software prefetch: lands while this node computes
+        __builtin_amdgcn_sched_barrier(0);
+        const size_t r0 = (size_t)node * C;
+        const auto& zg = cur.zg;
+        const auto &ud = cur.ud, &rd = cur.rd, &cd = cur.cd, &gn = cur.gn, &bm = cur.bm;
+        const auto &uv = cur.uv, &rv = cur.rv, &cv = cur.cv, &gv = cur.gv, &hv = cur.hv, &bv = cur.bv;
+        const int lo = opaque(lane);
+        const float (&hd)[NRB][4] = zg[0][RHB];                    // the previous state H in accumulator layout
+
+        // =========================================================== candidate convolution (post-aggregation form): dA = dY, dBm given
+        f32x4 drh[NRB];                                            // gradient of the R*H plane, row-on-lane layout
+        {
+            DyFrag<NRB, 1> gr[K];
+#pragma unroll
+            for (int kb = 0; kb < NRB; ++kb) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    gr[0].d[kb][0][t] = gn[kb][t] * ud[kb][t] * (1.f - cd[kb][t] * cd[kb][t]);      // dY = dHnew * U * (1 - Cand^2)
+                    gr[1].d[kb][0][t] = bm[kb][t];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) gr[0].v[kb][0][i] = gv[kb][i] * uv[kb][i] * (1.f - cv[kb][i] * cv[kb][i]);
+                gr[1].v[kb][0] = bv[kb];
+            }
+#pragma unroll
+            for (int kb = 0; kb < NRB; ++kb)
+                dbc[0] += (gr[0].d[kb][0][0] + gr[0].d[kb][0][1]) + (gr[0].d[kb][0][2] + gr[0].d[kb][0][3]);
+            X3 gd[K];
+#pragma unroll
+            for (int n = 0; n < K; ++n) gd[n] = split8(gr[n].d[0][0], gr[n].d[1][0]);
+            // B operands of dX: per weight set n, the (c, o) blocks of (Q^n_c)^T for columns c' = 16rb + x
+            X3 qb[K][NRB];
+#pragma unroll
+            for (int n = 0; n < K; ++n)
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) {
+                    const f32x4 qv = mma6(gd[n], get_frag(TB, rb, lo), kZero4);      // (T_1 dY_n)^T tile
+                    qb[n][rb] = split8(gr[n].v[rb][0], qv);
+                }
+#pragma unroll
+            for (int lb = 0; lb < LBD; ++lb) {
+                f32x4 z[NRB] = {kZero4, kZero4};
+#pragma unroll
+                for (int n = 0; n < K; ++n) {
+                    const X3 w = get_frag(WC, n * LB + lb, lo);
+#pragma unroll
+                    for (int rb = 0; rb < NRB; ++rb) z[rb] = mma6(w, qb[n][rb], z[rb]);
+                }
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) {
+                    if (lb == RHB) drh[rb] = z[rb];
+                    else stash_x[rb * 64 + lane] = make_float4(z[rb][0], z[rb][1], z[rb][2], z[rb][3]);      // the X plane's share
+                }
+            }
+            // dWc_{n,c} (rows l, columns o) += [X | R*H]^T Q^n_c
+            X3 qd[K];
+#pragma unroll
+            for (int n = 0; n < K; ++n) {
+                const f32x4 q0 = mma6(get_frag(TB, 0, lo), gd[n], kZero4), q1 = mma6(get_frag(TB, 1, lo), gd[n], kZero4);
+                qd[n] = split8(q0, q1);
+            }
+#pragma unroll
+            for (int lb = 0; lb < LB; ++lb) {
+                f32x4 c0, c1;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    c0[t] = lb == RHB ? rd[0][t] * hd[0][t] : zg[0][lb][0][t];
+                    c1[t] = lb == RHB ? rd[1][t] * hd[1][t] : zg[0][lb][1][t];
+                }
+                const X3 za = split8(c0, c1);
+#pragma unroll
+                for (int n = 0; n < K; ++n)
+#pragma unroll
+                    for (int c = 0; c < K; ++c) dWc[n][lb][c][0] = mma6(za, c == 0 ? gd[n] : qd[n], dWc[n][lb][c][0]);
+            }
+        }
+
+        // =========================================================== gate + blend backward (prologue of the gates convolution)
+        DyFrag<NRB, 2> gr;
+        {
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb)
+                *reinterpret_cast<f32x4*>(tile + (16 * rb + x) * CB_TRS + 4 * g) = drh[rb];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int kb = 0; kb < NRB; ++kb) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float u = ud[kb][t], r = rd[kb][t], h = hd[kb][t];
+                    const float dr = tile[(16 * kb + 4 * g + t) * CB_TRS + x];
+                    gr.d[kb][0][t] = gn[kb][t] * (cd[kb][t] - h) * u * (1.f - u);
+                    gr.d[kb][1][t] = dr * h * r * (1.f - r);
+                }
+                f32x4 own;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float u = uv[kb][i], r = rv[kb][i], h = hv[kb][i], d = drh[kb][i];
+                    gr.v[kb][0][i] = gv[kb][i] * (cv[kb][i] - h) * u * (1.f - u);
+                    gr.v[kb][1][i] = d * h * r * (1.f - r);
+                    own[i] = d * r + gv[kb][i] * (1.f - u);        // what H is owed directly: reset-gate path + its share of the blend
+                }
+                stash_h[kb * 64 + lane] = make_float4(own[0], own[1], own[2], own[3]);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+
+        // =========================================================== gates convolution (slab form on the planes), as node_bwd_x3_kernel
+#pragma unroll
+        for (int kb = 0; kb < NRB; ++kb)
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb)
+                dbg[hb] += (gr.d[kb][hb][0] + gr.d[kb][hb][1]) + (gr.d[kb][hb][2] + gr.d[kb][hb][3]);
+        X3 gd[2];
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) gd[hb] = split8(gr.d[0][hb], gr.d[1][hb]);
+        f32x4 Qv[NRB][2];
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) {
+            const X3 t = get_frag(TB, rb, lo);
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) Qv[rb][hb] = mma6(gd[hb], t, kZero4);
+        }
+        X3 qb[2][NRB];                                             // step s: blocks (c = s, hb = 0), (c = s, hb = 1)
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) {
+            qb[0][rb] = split8(gr.v[rb][0], gr.v[rb][1]);
+            qb[1][rb] = split8(Qv[rb][0], Qv[rb][1]);
+        }
+        float* const dP[K][LB] = {{PL == 1 ? a.dX : a.dH, PL == 1 ? a.dH : nullptr}, {PL == 1 ? a.dSX : a.dSH, PL == 1 ? a.dSH : nullptr}};
+#pragma unroll
+        for (int n = 0; n < K; ++n)
+#pragma unroll
+            for (int lb = 0; lb < LBD; ++lb) {
+                f32x4 z[NRB];
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) {
+                    if (n == 0 && lb == RHB) {                     // the H plane's tile starts from the prologue's share
+                        const float4 sh = stash_h[rb * 64 + lane];
+                        z[rb] = f32x4{sh.x, sh.y, sh.z, sh.w};
+                    } else if (n == 0) {                           // the X plane's tile from the candidate's share (PL = 1)
+                        const float4 sh = stash_x[rb * 64 + lane];
+                        z[rb] = f32x4{sh.x, sh.y, sh.z, sh.w};
+                    } else {
+                        z[rb] = kZero4;
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const X3 w = get_frag(WG, (n * LB + lb) * 2 + s, lo);
+#pragma unroll
+                    for (int rb = 0; rb < NRB; ++rb) z[rb] = mma6(w, qb[s][rb], z[rb]);
+                }
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb)
+                    *reinterpret_cast<f32x4*>(dP[n][lb] + (r0 + 16 * rb + x) * HID + 4 * g) = z[rb];
+            }
+        X3 qd[2];
+        {
+            f32x4 Qd[NRB][2];
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+                const X3 t = get_frag(TB, rb, lo);
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb) Qd[rb][hb] = mma6(t, gd[hb], kZero4);
+            }
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) qd[hb] = split8(Qd[0][hb], Qd[1][hb]);
+        }
+#pragma unroll
+        for (int n = 0; n < K; ++n)
+#pragma unroll
+            for (int lb = 0; lb < LB; ++lb) {
+                const float (&zc)[NRB][4] = zg[n][lb];
+                const X3 za = split8(f32x4{zc[0][0], zc[0][1], zc[0][2], zc[0][3]}, f32x4{zc[1][0], zc[1][1], zc[1][2], zc[1][3]});
+#pragma unroll
+                for (int c = 0; c < K; ++c)
+#pragma unroll
+                    for (int hb = 0; hb < 2; ++hb) dWg[n][lb][c][hb] = mma6(za, c == 0 ? gd[hb] : qd[hb], dWg[n][lb][c][hb]);
+            }
+        cur = nxt;
+        node = next_node;
+    }
+
+    combine_dw<K, LB, 2, CB_WAVES>(reinterpret_cast<float*>(smem_raw), dWg, dbg, a.partial_g, a.Lw, a.want_dbg, PL == 2 ? cin : -1);
+    combine_dw<K, LB, 1, CB_WAVES>(reinterpret_cast<float*>(smem_raw), dWc, dbc, a.partial_c, a.Lw, a.want_dbc, PL == 2 ? cin : -1);
+}
+
+template <int L, int PL>
+int launch_cell_bwd(const CellBwdArgs& a, int* n_partials, hipStream_t stream) {
+    const size_t slabs = (size_t)CB_WAVES * (4 * L * 32 + 32) * sizeof(float);
+    const size_t lds = CB_LDS_BYTES > slabs ? CB_LDS_BYTES : slabs;
+    static_assert(CB_LDS_BYTES <= stc::kMaxLdsBytes, "tables + per-wave tiles must fit the CU's LDS");
+    if (lds > stc::kMaxLdsBytes) return STC_NOT_HANDLED;
+    auto kern = cell_bwd_x3_kernel<L, PL>;
+    if (int rc = stc::hip_status(stc::allow_lds(kern, lds), "hipFuncSetAttribute(cell bwd x3)")) return rc;
+    static const int resident = stc::resident_blocks(kern, CB_THREADS, lds, 1);
+    const long long want = (a.nodes + CB_WAVES - 1) / CB_WAVES;
+    int grid = resident < MF_BWD_MAX_GRID ? resident : MF_BWD_MAX_GRID;
+    if (want < grid) grid = (int)want;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(CB_THREADS), lds, stream, a);
+    STC_LAUNCH_CHECK("cell_bwd_x3 launch");
+    *n_partials = grid;
+    return STC_OK;
+}
+
+}  // namespace
+
+int stc_cell_bwd_planar_shape_ok(int C, int h) { return C == 32 && h == 16; }
+
+int stc_cell_bwd_planar_x3(const float* X, const float* H, const float* SX, const float* SH, const float* Tc, const float* Wg, const float* Wc,
+                           const float* U, const float* R, const float* Cand, const float* dHnew, const float* dBm,
+                           float* dX, float* dSX, float* dH, float* dSH, float* partial_g, float* partial_c, int* n_partials,
+                           int want_dbg, int want_dbc, long long nodes, int C, int Lw, hipStream_t stream) {
+    const int cin = Lw - 16;
+    if (!stc_cell_bwd_planar_shape_ok(C, 16) || nodes <= 0 || nodes >= (1ll << 31) / C || !(cin == 16 || (cin >= 1 && cin <= 4))) return STC_NOT_HANDLED;
+    const float* wide[] = {H, SH, U, R, Cand, dHnew, dBm, dH, dSH};
+    if (!all_aligned16(wide, 9)) return STC_NOT_HANDLED;
+    CellBwdArgs a{X, H, SX, SH, U, R, Cand, dHnew, dBm, Tc, Wg, Wc, dX, dSX, dH, dSH, partial_g, partial_c, (int)nodes, want_dbg, want_dbc, Lw};
+    if (cin == 16) {
+        const float* more[] = {X, SX, dX, dSX};
+        if (!dX || !dSX || !all_aligned16(more, 4)) return STC_NOT_HANDLED;
+        return launch_cell_bwd<32, 1>(a, n_partials, stream);
+    }
+    return launch_cell_bwd<20, 2>(a, n_partials, stream);
+}

@@ -506,7 +506,7 @@ extern "C" int stc_cell_gates_fwd_planar_f32(const float* X, const float* H, con
     STC_REQUIRE(Lw == 2 * h || (Lw > h && Lw <= h + 4), STC_EINVAL, "stc_cell_gates_fwd_planar_f32: input width %d (Lw - h) must be h or 1..4", Lw - h);
     if (!stc_cell_planar_supported(2, 2, C, h)) return stc::fail(STC_EUNSUPPORTED, "stc_cell_gates_fwd_planar_f32: shape not on the planar path");
     if (nodes == 0) return STC_OK;
-    STC_REQUIRE(X && H && SX && SH && Tc && W && U && Rg && RH, STC_EINVAL, "stc_cell_gates_fwd_planar_f32: null pointer");
+    STC_REQUIRE(X && H && SX && SH && Tc && W && U && Rg && (RH || A), STC_EINVAL, "stc_cell_gates_fwd_planar_f32: null pointer");
     STC_REQUIRE((A == nullptr) == (Bm == nullptr) && (!A || Wc), STC_EINVAL, "stc_cell_gates_fwd_planar_f32: A, Bm and Wc go together");
     const int rc = stc_cell_gates_fwd_planar_x3(X, H, SX, SH, Tc, W, bias, U, Rg, RH, Wc, bc, A, Bm, nodes, C, Lw, static_cast<hipStream_t>(stream));
     return rc == STC_NOT_HANDLED ? stc::fail(STC_EUNSUPPORTED, "stc_cell_gates_fwd_planar_f32: operands not usable (alignment)") : rc;
@@ -546,6 +546,54 @@ extern "C" int stc_cell_gates_bwd_planar_f32(const float* X, const float* H, con
                        partial, n_parts, stride, nW, Ho, 0, dW, db, static_cast<float*>(nullptr));
     STC_LAUNCH_CHECK("stc_bdg_node_reduce launch");
     return STC_OK;
+}
+
+// ---- the whole backward of a planar cell step in one launch (stc_cell_bwd_x3.hip)
+extern "C" int stc_cell_bwd_planar_supported(int32_t C, int32_t h) {
+    return (x3_enabled() && stc_cell_bwd_planar_shape_ok(C, h)) ? 1 : 0;
+}
+
+extern "C" size_t stc_cell_bwd_planar_workspace_bytes(int32_t C, int32_t Lw, int32_t h) {
+    const int L = Lw == 2 * h ? 2 * h : 20;
+    return stc_bdg_node_bwd_workspace_bytes(2, 2, C, L, 2 * h, 0) + stc_bdg_node_bwd_workspace_bytes(2, 2, C, L, h, 0);
+}
+
+extern "C" int stc_cell_bwd_planar_f32(const float* X, const float* H, const float* SX, const float* SH,
+                                       const float* Tc, const float* Wg, const float* Wc,
+                                       const float* U, const float* Rg, const float* Cand, const float* dHnew, const float* dBm,
+                                       float* dX, float* dSX, float* dH, float* dSH,
+                                       float* dWg, float* dbg, float* dWc, float* dbc,
+                                       void* workspace, size_t workspace_bytes,
+                                       int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream) {
+    const int L = Lw == 2 * h ? 2 * h : 20;
+    if (int rc = check_dims("stc_cell_bwd_planar_f32", 2, 2, C, L, Lw, 2 * h, nodes)) return rc;
+    STC_REQUIRE(Lw == 2 * h || (Lw > h && Lw <= h + 4), STC_EINVAL, "stc_cell_bwd_planar_f32: input width %d (Lw - h) must be h or 1..4", Lw - h);
+    if (!stc_cell_bwd_planar_supported(C, h)) return stc::fail(STC_EUNSUPPORTED, "stc_cell_bwd_planar_f32: C=%d h=%d is not built (C = 32, h = 16)", C, h);
+    STC_REQUIRE(Wg && Wc && dWg && dWc && Tc, STC_EINVAL, "stc_cell_bwd_planar_f32: null W/dW/Tc");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int nWg = 4 * Lw * 2 * h, nWc = 4 * Lw * h;
+    if (nodes == 0) {
+        if (int rc = stc::hip_status(hipMemsetAsync(dWg, 0, (size_t)nWg * sizeof(float), s), "memset dWg")) return rc;
+        if (int rc = stc::hip_status(hipMemsetAsync(dWc, 0, (size_t)nWc * sizeof(float), s), "memset dWc")) return rc;
+        if (dbg) if (int rc = stc::hip_status(hipMemsetAsync(dbg, 0, (size_t)2 * h * sizeof(float), s), "memset dbg")) return rc;
+        if (dbc) if (int rc = stc::hip_status(hipMemsetAsync(dbc, 0, (size_t)h * sizeof(float), s), "memset dbc")) return rc;
+        return STC_OK;
+    }
+    STC_REQUIRE(X && H && SX && SH && U && Rg && Cand && dHnew && dBm && dH && dSH && (Lw != 2 * h || (dX && dSX)), STC_EINVAL,
+                "stc_cell_bwd_planar_f32: null pointer");
+    STC_REQUIRE(workspace && stc::aligned16(workspace), STC_EALIGN, "stc_cell_bwd_planar_f32: workspace null or not 16-byte aligned");
+    const size_t bytes_g = stc_bdg_node_bwd_workspace_bytes(2, 2, C, L, 2 * h, 0);
+    STC_REQUIRE(workspace_bytes >= stc_cell_bwd_planar_workspace_bytes(C, Lw, h), STC_EINVAL,
+                "stc_cell_bwd_planar_f32: workspace of %zu B is too small", workspace_bytes);
+    float* partial_g = static_cast<float*>(workspace);
+    float* partial_c = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + bytes_g);
+    int n_parts = 0;
+    const int rc = stc_cell_bwd_planar_x3(X, H, SX, SH, Tc, Wg, Wc, U, Rg, Cand, dHnew, dBm, dX, dSX, dH, dSH, partial_g, partial_c, &n_parts,
+                                          dbg != nullptr, dbc != nullptr, nodes, C, Lw, s);
+    if (rc == STC_NOT_HANDLED) return stc::fail(STC_EUNSUPPORTED, "stc_cell_bwd_planar_f32: operands not usable (alignment)");
+    if (rc != STC_OK) return rc;
+    if (int r2 = stc_node_reduce_partials(partial_g, n_parts, nWg, 2 * h, dWg, dbg, s)) return r2;
+    return stc_node_reduce_partials(partial_c, n_parts, nWc, h, dWc, dbc, s);
 }
 
 // ---- planar cell convolutions of Chebyshev order K (= 3; K = 2 has the entry points above): see stc_cell_conv_*_planar_k_x3

@@ -205,8 +205,8 @@ __host__ __device__ __forceinline__ int stc_wrow_swapped(int col, int cin) {
 
 // End of a backward kernel: the workgroup's four waves hold dW tiles (rows l = 16lb + 4g + r, columns o = 16hb + x) and
 // db partial sums in registers; combine them through LDS in a fixed order (bitwise reproducible) into ONE partial row
-// [dW in W layout | db] per workgroup, which bdg_node_reduce_kernel then sums over workgroups.
-template <int K, int LB, int HB>
+// [dW in W layout | db] per workgroup, which bdg_node_reduce_kernel then sums over workgroups.  (WAVES: waves per workgroup.)
+template <int K, int LB, int HB, int WAVES = MF_WAVES>
 __device__ __forceinline__ void combine_dw(float* smem, const f32x4 (&dWt)[K][LB][K][HB], const float (&dbp)[HB],
                                            float* __restrict__ partial, int Lw, int want_db, int swapped_cin = -1) {
     constexpr int Ho = 16 * HB;
@@ -238,10 +238,10 @@ __device__ __forceinline__ void combine_dw(float* smem, const f32x4 (&dWt)[K][LB
     }
     __syncthreads();
     float* out = partial + (size_t)blockIdx.x * (nW + Ho);
-    for (int e = tid; e < nW + Ho; e += MF_THREADS) {
+    for (int e = tid; e < nW + Ho; e += WAVES * 64) {
         float s = smem[e];
 #pragma unroll
-        for (int w = 1; w < MF_WAVES; ++w) s += smem[(size_t)w * (nW + Ho) + e];
+        for (int w = 1; w < WAVES; ++w) s += smem[(size_t)w * (nW + Ho) + e];
         out[e] = (e >= nW && !want_db) ? 0.f : s;
     }
 }

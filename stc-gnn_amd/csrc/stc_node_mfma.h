@@ -93,6 +93,14 @@ int stc_cell_gates_bwd_planar_x3(const float* X, const float* H, const float* SX
                                  float* const* dZ, float* dH, float* partial, int* n_partials, int want_db,
                                  long long nodes, int C, int Lw, hipStream_t stream);
 
+// The whole backward of a planar K = 2 cell step in one launch (stc_cell_bwd_x3.hip; C = 32): candidate (post-aggregation form) and
+// gates convolutions back to back per node.  partial_g / partial_c: per-workgroup rows [dW | db] of the two convolutions.
+int stc_cell_bwd_planar_shape_ok(int C, int h);
+int stc_cell_bwd_planar_x3(const float* X, const float* H, const float* SX, const float* SH, const float* Tc, const float* Wg, const float* Wc,
+                           const float* U, const float* R, const float* Cand, const float* dHnew, const float* dBm,
+                           float* dX, float* dSX, float* dH, float* dSH, float* partial_g, float* partial_c, int* n_partials,
+                           int want_dbg, int want_dbc, long long nodes, int C, int Lw, hipStream_t stream);
+
 // Planar cell convolutions of order K = 3 (stc_node_x3.hip): Zx[n] / Zh[n] = T_n(S) of the X-side / H-side plane; mode 1 gates, 2 candidate.
 int stc_cell_planar_k_shape_ok(int K, int C, int h);
 int stc_cell_conv_fwd_planar_k_x3(const float* const* Zx, const float* const* Zh, int K, const float* Tc, const float* W, const float* bias, int mode,

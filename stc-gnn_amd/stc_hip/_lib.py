@@ -19,7 +19,7 @@ import torch
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG_ROOT, 'libstc_hip.so')
-ABI_VERSION = 11
+ABI_VERSION = 12
 MAX_K = 4
 SPMM_SUM_MAX_ADD = 8     # = STC_SPMM_SUM_MAX_ADD of include/stc_hip.h
 
@@ -35,6 +35,7 @@ EXPORTS = (
     'stc_bdg_node_post_supported', 'stc_bdg_node_post_fwd_f32', 'stc_bdg_node_post_bwd_f32', 'stc_spmm_blend_fwd_f32',
     'stc_cell_fused_supported', 'stc_cell_gates_fwd_f32', 'stc_cell_gates_bwd_f32', 'stc_cell_cand_bwd_f32', 'stc_cell_blend_fwd_f32',
     'stc_cell_planar_supported', 'stc_cell_gates_fwd_planar_f32', 'stc_cell_gates_bwd_planar_f32', 'stc_spmm_sum_f32',
+    'stc_cell_bwd_planar_supported', 'stc_cell_bwd_planar_workspace_bytes', 'stc_cell_bwd_planar_f32',
     'stc_cell_planar_k_supported', 'stc_cell_gates_fwd_planar_k_f32', 'stc_cell_cand_fwd_planar_k_f32', 'stc_cell_gates_bwd_planar_k_f32',
     'stc_cell_cand_bwd_planar_k_f32', 'stc_bdg_node_post_k_supported', 'stc_bdg_node_post_fwd_k_f32', 'stc_bdg_node_post_bwd_k_f32',
     'stc_cell_gather_supported', 'stc_cell_gates_fwd_gather_f32', 'stc_cell_blend_fwd_gather_f32',
@@ -86,6 +87,7 @@ def _declare(lib):
         'stc_bdg_node_post_fwd_f32': [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
         'stc_cell_gates_fwd_planar_f32': [_p] * 14 + [_i64, _i32, _i32, _i32, _p],
         'stc_cell_gates_bwd_planar_f32': [_p] * 11 + [C.POINTER(_p), _p, _p, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _p],
+        'stc_cell_bwd_planar_f32': [_p] * 21 + [C.c_size_t, _i64, _i32, _i32, _i32, _p],
         'stc_spmm_blend_fwd_f32': [_p] * 6 + [_i32, _i32] + [_p] * 6 + [_p, _i32, _i32, _p, _i32, _p, _i32, _i32] + [_i32] * 3 + [_p],
         'stc_bdg_node_post_bwd_f32': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _i32, _p],
         'stc_spmm_sum_f32': [_p] * 6 + [_i32, _i32, _p, _p, _f32, _i32, C.POINTER(_p), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_f32), _p, _p, _p, _p,
@@ -132,6 +134,10 @@ def _declare(lib):
     lib.stc_cell_planar_supported.argtypes = [_i32, _i32, _i32, _i32]
     lib.stc_cell_planar_k_supported.restype = C.c_int
     lib.stc_cell_planar_k_supported.argtypes = [_i32, _i32, _i32]
+    lib.stc_cell_bwd_planar_supported.restype = C.c_int
+    lib.stc_cell_bwd_planar_supported.argtypes = [_i32, _i32]
+    lib.stc_cell_bwd_planar_workspace_bytes.restype = C.c_size_t
+    lib.stc_cell_bwd_planar_workspace_bytes.argtypes = [_i32, _i32, _i32]
     lib.stc_bdg_node_post_k_supported.restype = C.c_int
     lib.stc_bdg_node_post_k_supported.argtypes = [_i32, _i32, _i32, _i32]
     lib.stc_cell_gather_supported.restype = C.c_int
@@ -662,15 +668,18 @@ class HipKernels:
 
     def cell_gates_fwd_planar(self, X, H, SX, SH, Tc, W, bias, U, Rg, RH, post=None):
         """Gates convolution on planar inputs; writes U, Rg and the R*H plane (the candidate's input is (X, RH)).
-        ``post`` = (Wc, bc, A, Bm): the same launch also writes the candidate's post-aggregation pair A, Bm."""
+        ``post`` = (Wc, bc, A, Bm): the same launch also writes the candidate's post-aggregation pair A, Bm; ``RH`` may then be
+        None (not written: ``cell_bwd_planar`` forms R*H itself)."""
         R, Cc, h, cin = self._planes('planar', X, H, SX, SH)
+        if RH is None and post is None:
+            raise StcError('planar gates: the R*H plane is optional only with the fused candidate projection (post=)')
         self._f32('planar.Tc', Tc, (2, Cc, Cc))
         self._f32('planar.W', W)
         if W.shape != (4 * (cin + h), 2 * h):
             raise StcError(f'planar gates: W {tuple(W.shape)} is not ({4 * (cin + h)}, {2 * h})')
         if bias is not None:
             self._f32('planar.bias', bias, (2 * h,))
-        for name, t in (('U', U), ('Rg', Rg), ('RH', RH)):
+        for name, t in (('U', U), ('Rg', Rg)) + ((('RH', RH),) if RH is not None else ()):
             self._f32('planar.' + name, t, (R, Cc, h))
         Wc = bc = A = Bm = None
         if post is not None:
@@ -706,6 +715,37 @@ class HipKernels:
         zp = (_p * 4)(*[0 if z is None else z.data_ptr() for z in dZs])
         self._launch('stc_cell_gates_bwd_planar_f32', H, _ptr(X), _ptr(H), _ptr(SX), _ptr(SH), _ptr(Tc), _ptr(W), _ptr(dRH), _ptr(Cand),
                      _ptr(U), _ptr(Rg), _ptr(dHnew), zp, _ptr(dW), _ptr(db), _ptr(dH), _ptr(ws), ws.numel(), R, Cc, cin + h, h)
+
+    # ---- the whole backward of a planar cell step in one launch ----------------------------------------
+    def cell_bwd_planar_supported(self, Cc, h) -> bool:
+        return os.environ.get('STC_FUSE_CELL_BWD', '1') != '0' and bool(self.lib.stc_cell_bwd_planar_supported(Cc, h))
+
+    def cell_bwd_planar(self, X, H, SX, SH, Tc, Wg, Wc, U, Rg, Cand, dHnew, dBm, dZs, dWg, dbg, dWc, dbc):
+        """Candidate (post-aggregation form) + gates backward of one planar cell step in one launch.  ``dBm`` = S^T dY with
+        dY = dHnew U (1 - Cand^2) (the kernel re-forms dY itself); ``dZs`` = [dX, dSX, dH, dSH] gradient planes: dX = the candidate's
+        plus the gates' share of the X plane, dH includes the gate prologue's share (dX, dSX None for a narrow input plane)."""
+        R, Cc, h, cin = self._planes('cell_bwd', X, H, SX, SH)
+        self._f32('cell_bwd.Tc', Tc, (2, Cc, Cc))
+        self._f32('cell_bwd.Wg', Wg, (4 * (cin + h), 2 * h))
+        self._f32('cell_bwd.Wc', Wc, (4 * (cin + h), h))
+        for name, t in (('U', U), ('Rg', Rg), ('Cand', Cand), ('dHnew', dHnew), ('dBm', dBm)):
+            self._f32('cell_bwd.' + name, t, (R, Cc, h))
+        if len(dZs) != 4:
+            raise StcError('cell backward: four gradient planes (dX, dSX, dH, dSH)')
+        for i, z in enumerate(dZs):
+            if z is None and i < 2 and cin != h:
+                continue
+            self._f32(f'cell_bwd.dZ[{i}]', z, (R, Cc, h))
+        self._f32('cell_bwd.dWg', dWg, (4 * (cin + h), 2 * h))
+        self._f32('cell_bwd.dWc', dWc, (4 * (cin + h), h))
+        if dbg is not None:
+            self._f32('cell_bwd.dbg', dbg, (2 * h,))
+        if dbc is not None:
+            self._f32('cell_bwd.dbc', dbc, (h,))
+        self._same_device(X, H, SX, SH, Tc, Wg, Wc, U, Rg, Cand, dHnew, dBm, *dZs, dWg, dbg, dWc, dbc)
+        ws = self._get_workspace(H.device, self.lib.stc_cell_bwd_planar_workspace_bytes(Cc, 2 * h, h))
+        self._launch('stc_cell_bwd_planar_f32', H, _ptr(X), _ptr(H), _ptr(SX), _ptr(SH), _ptr(Tc), _ptr(Wg), _ptr(Wc), _ptr(U), _ptr(Rg), _ptr(Cand),
+                     _ptr(dHnew), _ptr(dBm), *[_ptr(z) for z in dZs], _ptr(dWg), _ptr(dbg), _ptr(dWc), _ptr(dbc), _ptr(ws), ws.numel(), R, Cc, cin + h, h)
 
     # ---- planar cell convolutions of Chebyshev order K = 3 ------------------------------------------------
     def cell_planar_k_supported(self, K, Cc, h) -> bool:

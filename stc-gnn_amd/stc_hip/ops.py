@@ -621,18 +621,23 @@ class _StcCellGraph(Function):
                     saved += [Hprev, U, Rg, Cand, *Zx, *Zh[1:], *Zr]
                     n_saved.append(-12)                             # negative count: planar cell (12: order 3, slab-planar candidate)
             elif planar[j]:
-                Xp, SXp, SHp, RH = source(x), aggregated(x), aggregated(hs), torch.empty_like(Hprev)
+                Xp, SXp, SHp = source(x), aggregated(x), aggregated(hs)
+                fused_post = _FUSE_POST and k.cell_planar_post_fused(C)
+                # one-launch backward (stc_cell_bwd_planar_f32) forms R*H itself: with the fused projection the plane is not stored at all
+                one_bwd = fused_post and not bf16 and k.cell_bwd_planar_supported(C, h)
+                RH = None if one_bwd else torch.empty_like(Hprev)
                 A, Bm = torch.empty_like(Hprev), torch.empty_like(Hprev)
-                if _FUSE_POST and k.cell_planar_post_fused(C):        # the candidate's projection rides in the gates launch
-                    k.cell_gates_fwd_planar(*rows((Xp, Hprev, SXp, SHp)), Tc, Wg, bg, *rows((U, Rg, RH)), post=(Wc, bc, *rows((A, Bm))))
+                if fused_post:                                        # the candidate's projection rides in the gates launch
+                    k.cell_gates_fwd_planar(*rows((Xp, Hprev, SXp, SHp)), Tc, Wg, bg, *rows((U, Rg)), None if RH is None else RH.view(B * N, C, h),
+                                            post=(Wc, bc, *rows((A, Bm))))
                 else:
                     k.cell_gates_fwd_planar(*rows((Xp, Hprev, SXp, SHp)), Tc, Wg, bg, *rows((U, Rg, RH)))
                     lead, second = (Xp, RH) if cin[j] == h else (RH, Xp)     # narrow input plane: the 16-wide plane leads
                     k.node_post_fwd(*rows((lead,)), Tc, Wc, bc, *rows((A, Bm)), X2=second.view(B * N, C, second.shape[-1]))
                 k.spmm_blend_fwd(op.fwd_rowptr, op.fwd_colidx, fwd_val, op.fwd_plan, Bm, A, U, Hprev, Cand, Hnew, copies=copies, side=side)
                 del A, Bm
-                saved += [Hprev, U, Rg, Cand, Xp, SXp, SHp, RH]
-                n_saved.append(-8)                                  # negative count: planar cell
+                saved += [Hprev, U, Rg, Cand, Xp, SXp, SHp] + ([] if RH is None else [RH])
+                n_saved.append(-7 if RH is None else -8)            # negative count: planar cell (-7: no R*H plane, one-launch backward)
             else:
                 Xj = rows_of(j)
                 L = Xj.shape[-1]
@@ -840,7 +845,26 @@ class _StcCellGraph(Function):
             if Ks == 3 and j in pieces:                              # an interleaved cell whose state order-3 planar cells consumed
                 G[j] = owed3(j)
             dHnew, dY = owed(j, (U, Cand)) if post_form else (owed(j), None)
-            dH = None if (n_saved[j] < 0 and getattr(k, 'folds_dH', False)) else torch.empty_like(Hprev)
+            dH = None if (n_saved[j] == -7 or (n_saved[j] < 0 and getattr(k, 'folds_dH', False))) else torch.empty_like(Hprev)
+            if n_saved[j] == -7:                                     # planar cell, candidate + gates backward in ONE launch
+                Xp, SXp, SHp = rest
+                dBm = narrow_transpose_aggregation(dY)
+                del dY                                               # (the kernel re-forms dY from dHnew, U, Cand)
+                wide = cin[j] == h
+                new = lambda: torch.empty_like(Hprev)
+                dWg, dbg = torch.empty_like(Wg), (Wg.new_empty(2 * h) if bg is not None else None)
+                dWc, dbc = torch.empty_like(Wc), (Wc.new_empty(h) if bc is not None else None)
+                dXd, dSX = (new(), new()) if wide else (None, None)
+                dHd, dSH = new(), new()
+                k.cell_bwd_planar(*rows((Xp, Hprev, SXp, SHp)), Tc, Wg, Wc, *rows((U, Rg, Cand, dHnew, dBm)),
+                                  [None if t is None else t.view(B * N, C, h) for t in (dXd, dSX, dHd, dSH)], dWg, dbg, dWc, dbc)
+                if wide and x[0] == 'cell':
+                    leave(x[1], (dXd,), dSX)                         # as the X plane: ONE direct plane (candidate's + gates' share)
+                if hs[0] == 'cell':
+                    leave(hs[1], (dHd,), dSH)                        # as the H plane: direct share incl. what the gate prologue owes it
+                for i, t in enumerate((dWg, dbg, dWc, dbc)):
+                    add_to(acc[s_id], i, t)
+                continue
             if n_saved[j] < 0:                                       # planar cell: inputs and gradients as planes
                 Xp, SXp, SHp, RH = rest
                 dBm = narrow_transpose_aggregation(dY)

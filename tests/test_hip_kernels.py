@@ -603,6 +603,63 @@ def test_planar_cell_kernels_narrow_input(hip, nodes, C, cin):
     assert rel_err(dX, dX_w) < TOL and rel_err(dWc, dWc_w) < TOL and rel_err(dbc, dbc_w) < TOL
 
 
+@pytest.mark.parametrize('nodes,cin,bias', [(50, 16, True), (3, 16, False), (4500, 16, True), (50, 1, True), (9, 3, False), (4500, 1, True), (13, 4, True)])
+def test_cell_backward_in_one_launch(hip, nodes, cin, bias):
+    """stc_cell_bwd_planar_f32: the candidate's post-aggregation backward + the gates backward of one planar cell step fused per node
+    (dY formed inside, R*H formed inside, d(R*H) handed over in the wave, dX = both convolutions' shares) -- against the CPU twin
+    (which composes the two separate twins) and against the two separate HIP launches; the forward may skip the R*H plane."""
+    C, h, K = 32, 16, 2
+    assert hip.cell_bwd_planar_supported(C, h)
+    Lw = cin + h
+    g = torch.Generator().manual_seed(nodes + cin)
+    rnd = lambda *s_: torch.randn(*s_, generator=g)
+    X, SX, H, SH = rnd(nodes, C, cin), rnd(nodes, C, cin), torch.tanh(rnd(nodes, C, h)), rnd(nodes, C, h)
+    Tc = rnd(K, C, C) / C ** 0.5
+    Tc[0] = torch.eye(C)
+    Wg, Wc = rnd(K * K * Lw, 2 * h) / (4 * Lw) ** 0.5, rnd(K * K * Lw, h) / (4 * Lw) ** 0.5
+    U, R, Cand = torch.sigmoid(rnd(nodes, C, h)), torch.sigmoid(rnd(nodes, C, h)), torch.tanh(rnd(nodes, C, h))
+    dHn, dBm = rnd(nodes, C, h), rnd(nodes, C, h)
+    wide = cin == h
+    new = lambda dev: [torch.full((nodes, C, h), float('nan'), device=dev) if (wide or i >= 2) else None for i in range(4)]
+    dZ_w, dWg_w, dWc_w = new('cpu'), torch.empty_like(Wg), torch.empty_like(Wc)
+    dbg_w, dbc_w = (torch.empty(2 * h), torch.empty(h)) if bias else (None, None)
+    EM.cell_bwd_planar(X, H, SX, SH, Tc, Wg, Wc, U, R, Cand, dHn, dBm, dZ_w, dWg_w, dbg_w, dWc_w, dbc_w)
+    nan = lambda *s_: torch.full(s_, float('nan')).cuda()
+    dZ, dWg, dWc = new('cuda'), nan(*Wg.shape), nan(*Wc.shape)
+    dbg, dbc = (nan(2 * h), nan(h)) if bias else (None, None)
+    ops_ = [cu(t) for t in (X, H, SX, SH, Tc, Wg, Wc, U, R, Cand, dHn, dBm)]
+    hip.cell_bwd_planar(*ops_, dZ, dWg, dbg, dWc, dbc)
+    for a_, w_ in zip(dZ, dZ_w):
+        assert (a_ is None) == (w_ is None) and (a_ is None or rel_err(a_, w_) < TOL)
+    assert rel_err(dWg, dWg_w) < TOL and rel_err(dWc, dWc_w) < TOL
+    if bias:
+        assert rel_err(dbg, dbg_w) < TOL and rel_err(dbc, dbc_w) < TOL
+    # the two separate launches on the same operands (dY and R*H as planes)
+    dY, RH = cu(dHn * U * (1 - Cand * Cand)), cu(R * H)
+    dRH, dXc, dWc2, dZ2, dWg2 = nan(nodes, C, h), nan(nodes, C, h), nan(*Wc.shape), new('cuda'), nan(*Wg.shape)
+    if wide:
+        hip.node_post_bwd(cu(X), cu(Tc), cu(Wc), dY, cu(dBm), dXc, dWc2, None, X2=RH, dX2=dRH)
+    else:
+        hip.node_post_bwd(RH, cu(Tc), cu(Wc), dY, cu(dBm), dRH, dWc2, None, X2=cu(X))
+    hip.cell_gates_bwd_planar(cu(X), cu(H), cu(SX), cu(SH), cu(Tc), cu(Wg), dRH, cu(Cand), cu(U), cu(R), cu(dHn), dZ2, dWg2, None, None)
+    assert rel_err(dWc, dWc2) < 2e-6 and rel_err(dWg, dWg2) < 2e-6 and rel_err(dZ[2], dZ2[2]) < 2e-6 and rel_err(dZ[3], dZ2[3]) < 2e-6
+    if wide:
+        assert rel_err(dZ[0], dZ2[0] + dXc) < 2e-6 and rel_err(dZ[1], dZ2[1]) < 2e-6
+    # bitwise reproducible (fixed-order combine of the per-workgroup partial sums)
+    dZ3, dWg3, dWc3 = new('cuda'), nan(*Wg.shape), nan(*Wc.shape)
+    hip.cell_bwd_planar(*ops_, dZ3, dWg3, None, dWc3, None)
+    assert torch.equal(dWg3, dWg) and torch.equal(dWc3, dWc) and torch.equal(dZ3[2], dZ[2])
+    # forward with the fused candidate projection and no R*H plane: same U, R, A, Bm as with the plane
+    if hip.cell_planar_post_fused(C):
+        bg, bc = rnd(2 * h), rnd(h)
+        outs = [[nan(nodes, C, h) for _ in range(5)] for _ in range(2)]
+        for o, with_rh in zip(outs, (True, False)):
+            hip.cell_gates_fwd_planar(cu(X), cu(H), cu(SX), cu(SH), cu(Tc), cu(Wg), cu(bg), o[0], o[1], o[2] if with_rh else None, post=(cu(Wc), cu(bc), o[3], o[4]))
+        for i in (0, 1, 3, 4):
+            assert torch.equal(outs[0][i], outs[1][i])
+        assert torch.isnan(outs[1][2]).all()
+
+
 @pytest.mark.parametrize('batch,grid,C,n_add,dual', [(2, (5, 5), 32, 3, True), (1, (4, 7), 64, 5, False), (2, (40, 56), 32, 0, True), (1, (1, 1), 32, 2, False)])
 def test_state_gradient_from_pieces(hip, batch, grid, C, n_add, dual):
     """stc_spmm_sum_f32: Y = sum of addends (contiguous planes and column slices of wider rows) + S.(X [+ X2])."""
