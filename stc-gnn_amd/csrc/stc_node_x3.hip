@@ -159,10 +159,13 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
             }
     };
     if (node < nodes) load_rows(cur, node);
+    // The first node's rows are waited for HERE: left pending into the loop, the compiler's wait-count pass merges them into the loop's state
+    // and makes every iteration wait for the rows it has just requested for the NEXT node right away (vmcnt counts in order).
+    __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0); expcnt / lgkmcnt untouched
     while (node < nodes) {
         const int next_node = node + nw;
-        if (next_node < nodes) load_rows(nxt, next_node);        // software prefetch: lands while this node computes
-        // epilogue operands in accumulator layout (row 16rb + 4g + r, column x): needed only after the MFMAs
+        // epilogue operands in accumulator layout (row 16rb + 4g + r, column x): needed only after the MFMAs.  Requested BEFORE the next
+        // node's rows: vmcnt counts in order, so the other way round the epilogue would wait for the whole prefetch
         float hv[NRB][4], uv[NRB][4], side[NRB][4];
         // EPI_GATES: lane x < L - 16 also writes one column of CandIn outside the R*H block, in the same row layout:
         // column x of Xt (re-read from slab 0, an L2 hit) while x < cin, else the zero of pad column x + 16
@@ -178,6 +181,7 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
                     if (EPI == EPI_GATES && !PL) side[rb][r] = (has_side && x < epi.cin) ? Z.p[0][row * L + x] : 0.f;
                 }
         }
+        if (next_node < nodes) load_rows(nxt, next_node);        // software prefetch: lands while this node computes
         Row8<L> z1[NRB];
         if (GATHER) {
             const int b = node / ga.n, i = node - b * ga.n;
@@ -477,6 +481,7 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
     static_assert(PL != 2 || L == 20, "narrow planar rows are 16 + cin columns padded to 20");
     NodeIn<NB2, HB, K, L, PL> in, nx;
     if (PF && node < nodes) { in.g.load(dY, node, x, g); in.load_z(Z, node, x, g, Lw - 16); }      // (the width matters to PL = 2 only)
+    if (PF) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) before the loop: see node_fwd_x3_kernel
     while (node < nodes) {
         const int next_node = node + nw;
         const size_t r0 = (size_t)node * C;
@@ -682,6 +687,7 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd2_x3_k
         }
     };
     if (node < nodes) load_rows(cur, node);
+    __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0) before the loop: see node_fwd_x3_kernel
     while (node < nodes) {
         const int next_node = node + nw;
         if (next_node < nodes) load_rows(nxt, next_node);
@@ -985,6 +991,7 @@ __global__ __launch_bounds__(MF_THREADS, 1) void node_fwd2k_x3_kernel(
         }
     };
     if (node < nodes) load_rows(cur, node);
+    __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0) before the loop: see node_fwd_x3_kernel
     while (node < nodes) {
         const int next_node = node + nw;
         if (next_node < nodes) load_rows(nxt, next_node);

@@ -46,7 +46,8 @@ def main():
             dZ = [o[0], o[1], o[2], o[3]] if wide else [None, None, o[2], o[3]]
             k.cell_gates_bwd_planar(X, H, SX, SH, Tc, Wg, o[5], Cand, U, R, dHn, dZ, dWg, dbg, None)
 
-        for name, fn in (('one launch', fused), ('two launches', separate)):
+        label = 'one launch (' + ('one wave per SIMD' if os.environ.get('STC_CELL_BWD_PAIR') == '0' else 'C/G wave pairs') + ')'
+        for name, fn in ((label, fused), ('two launches', separate)):
             for st in sets:
                 fn(st)
             torch.cuda.synchronize()
@@ -56,8 +57,8 @@ def main():
                 fn(sets[i % len(sets)])
             torch.cuda.synchronize()
             us = (time.perf_counter() - t0) / reps * 1e6
-            planes = (13 if wide else 11) if name == 'one launch' else (19 if wide else 15)
-            print(f'cin={cin:2d} {name:13s}: {us:8.1f} us per cell step   ({planes} planes of {nodes * C * h * 4 / 1e6:.0f} MB -> {planes * nodes * C * h * 4 / us / 1e6:.2f} TB/s)', flush=True)
+            planes = (13 if wide else 11) if name != 'two launches' else (19 if wide else 15)
+            print(f'cin={cin:2d} {name:32s}: {us:8.1f} us per cell step   ({planes} planes of {nodes * C * h * 4 / 1e6:.0f} MB -> {planes * nodes * C * h * 4 / us / 1e6:.2f} TB/s)', flush=True)
 
 
 if __name__ == '__main__':
