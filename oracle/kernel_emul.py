@@ -16,6 +16,7 @@ Reference lines each kernel accounts for are cited per method.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -267,7 +268,7 @@ class EmulatedKernels:
 
     # stc_cell_bwd_planar_f32: candidate (post-aggregation form) + gates backward of one planar cell step, composed from the two twins
     def cell_bwd_planar_supported(self, Cc, h) -> bool:
-        return h == 16
+        return h == 16 and os.environ.get('STC_FUSE_CELL_BWD', '1') != '0'
 
     def cell_bwd_planar(self, X, H, SX, SH, Tc, Wg, Wc, U, Rg, Cand, dHnew, dBm, dZs, dWg, dbg, dWc, dbc):
         cin, h = X.shape[-1], H.shape[-1]

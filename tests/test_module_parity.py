@@ -390,13 +390,14 @@ def test_factorised_mixed_fusion_option(dev):
 
 
 @pytest.mark.parametrize('layers,T,horizon,cin,K', [(2, 4, 3, 1, 2), (1, 3, 2, 1, 2), (3, 2, 2, 4, 2), (2, 3, 2, 1, 3), (3, 2, 2, 4, 3)])
-def test_cell_graph_equals_the_per_cell_path(dev, monkeypatch, layers, T, horizon, cin, K, post_k3=False):
+def test_cell_graph_equals_the_per_cell_path(dev, monkeypatch, layers, T, horizon, cin, K, post_k3=False, one_launch_bwd=True):
     """Encoder + decoder as one autograd node (no concat / gradient-accumulation passes between the cells) vs one node per
     cell: same prediction, same parameter gradients.  Hidden 16; 32 categories on the GPU (matrix-core shapes).  K = 3: the
     order-3 planar cells (three Chebyshev planes per side, Clenshaw state gradients) against the per-cell slab form."""
     C = 32 if DEV == 'cuda' else 5
     Hh, Ww, h, B = 5, 6, 16, 2
     monkeypatch.setattr(ops, '_POST_K3', post_k3)
+    monkeypatch.setenv('STC_FUSE_CELL_BWD', '1' if one_launch_bwd else '0')
     torch.manual_seed(layers * 10 + T)
     graph = CsrGraph.queen_grid(Hh, Ww, normalize=True)
     model = M.STCGNN(Hh * Ww, C, K, K, cin, h, layers, horizon, graph_mode='csr-fixed').to(DEV)
@@ -518,3 +519,10 @@ def test_order3_post_aggregation_candidate_option(dev, monkeypatch, layers, T, h
     """STC_POST_K3=1: the order-3 candidate convolution in post-aggregation (Clenshaw) form, Y = (P0 - P2 + b) + S.(P1 + 2 S.P2) --
     same predictions and gradients as the per-cell slab form (an opt-in that trades a slower backward kernel for less saved memory)."""
     test_cell_graph_equals_the_per_cell_path(dev, monkeypatch, layers, T, horizon, cin, 3, post_k3=True)
+
+
+@pytest.mark.parametrize('layers,T,horizon,cin', [(2, 3, 2, 1), (3, 2, 2, 4)])
+def test_two_launch_cell_backward_option(dev, monkeypatch, layers, T, horizon, cin):
+    """STC_FUSE_CELL_BWD=0: the planar cells' backward as two launches (stc_bdg_node_post_bwd_f32 + stc_cell_gates_bwd_planar_f32, with
+    the R*H plane stored by the forward) instead of stc_cell_bwd_planar_f32 -- same predictions and gradients."""
+    test_cell_graph_equals_the_per_cell_path(dev, monkeypatch, layers, T, horizon, cin, 2, one_launch_bwd=False)
