@@ -17,11 +17,29 @@ __device__ __forceinline__ unsigned pk_bf16(float a, float b) {     // v_cvt_pk_
     return __builtin_bit_cast(unsigned, v);
 }
 
+// a - (low half of pk as a float) and a - (high half): ONE v_dot2c_f32_bf16 each (a + pk.lo * -1 + pk.hi * 0) instead of shift / mask +
+// subtract.  The products and the sum are exact in fp32 (the remainder of a bf16 rounding is representable), so the pieces are the same
+// bits as before; 13 -> 7 vector instructions per pair of values in kernels that are bound by vector issue.
+// The constant pair must NOT reach the instruction as an inline constant: the compiler encodes {-1, 0} as the inline operand -1.0, which
+// this instruction does not read as a bf16 pair on MI355X (tools/probes/dot2c_bf16.hip: r0 = 1.2422 instead of 1.9276e-4; the 32-bit
+// literal 0xBF800000 and register operands are right).  Hence the constants come out of an s_mov the optimiser cannot see through.
+__device__ __forceinline__ unsigned x3_pair_const(unsigned bits) {
+    unsigned v;
+    asm("s_mov_b32 %0, %1" : "=s"(v) : "i"(bits));
+    return v;
+}
+__device__ __forceinline__ float minus_lo(float a, unsigned pk) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, pk), __builtin_bit_cast(bf16x2, x3_pair_const(0x0000BF80u)), a, false);
+}
+__device__ __forceinline__ float minus_hi(float a, unsigned pk) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, pk), __builtin_bit_cast(bf16x2, x3_pair_const(0xBF800000u)), a, false);
+}
+
 __device__ __forceinline__ void split2(float a0, float a1, unsigned& h, unsigned& m, unsigned& l) {
     h = pk_bf16(a0, a1);
-    const float r0 = a0 - __uint_as_float(h << 16), r1 = a1 - __uint_as_float(h & 0xffff0000u);      // exact
+    const float r0 = minus_lo(a0, h), r1 = minus_hi(a1, h);      // exact
     m = pk_bf16(r0, r1);
-    const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);      // exact
+    const float s0 = minus_lo(r0, m), s1 = minus_hi(r1, m);      // exact
     l = pk_bf16(s0, s1);
 }
 
