@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define STC_ABI_VERSION 12
+#define STC_ABI_VERSION 13
 #define STC_MAX_K 4          /* highest Chebyshev order (Ks, Kc) the node kernels accept */
 
 #define STC_OK 0
@@ -344,6 +344,9 @@ int stc_cell_gates_bwd_planar_f32(const float* X, const float* H, const float* S
  *   dX = the candidate's PLUS the gates' gradient of the X plane (one plane for the source's gradient sum instead of two).
  * In: X, H, SX, SH as above, gates Rg / U / Cand, dHnew and dBm (nodes, C, h); Wg (4*Lw, 2h), Wc (4*Lw, h).
  * Out: dX, dSX, dH (the H plane's gradient incl. the prologue's share), dSH (nodes, C, h); dWg, dbg, dWc, dbc (db* may be NULL).
+ * accumulate_x / accumulate_h != 0: dX, dSX / dH, dSH already hold the gradients another cell computed for the SAME state (its other
+ * consumer) and this launch adds its own to them, so the state owns one direct and one aggregated plane and stc_spmm_sum_f32 gathers one
+ * operand for it instead of two.
  * Narrow input (Lw - h in 1..4): dX, dSX are not produced (may be NULL).  stc_cell_bwd_planar_supported() tells whether (C, h)
  * is built (C = 32, h = 16); workspace >= stc_cell_bwd_planar_workspace_bytes(C, Lw, h) bytes, 16-byte aligned. */
 int stc_cell_bwd_planar_supported(int32_t C, int32_t h);
@@ -353,6 +356,7 @@ int stc_cell_bwd_planar_f32(const float* X, const float* H, const float* SX, con
                             const float* U, const float* Rg, const float* Cand, const float* dHnew, const float* dBm,
                             float* dX, float* dSX, float* dH, float* dSH,
                             float* dWg, float* dbg, float* dWc, float* dbc,
+                            int32_t accumulate_x, int32_t accumulate_h,
                             void* workspace, size_t workspace_bytes,
                             int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream);
 

@@ -270,8 +270,9 @@ class EmulatedKernels:
     def cell_bwd_planar_supported(self, Cc, h) -> bool:
         return h == 16 and os.environ.get('STC_FUSE_CELL_BWD', '1') != '0'
 
-    def cell_bwd_planar(self, X, H, SX, SH, Tc, Wg, Wc, U, Rg, Cand, dHnew, dBm, dZs, dWg, dbg, dWc, dbc):
+    def cell_bwd_planar(self, X, H, SX, SH, Tc, Wg, Wc, U, Rg, Cand, dHnew, dBm, dZs, dWg, dbg, dWc, dbc, accumulate_x=False, accumulate_h=False):
         cin, h = X.shape[-1], H.shape[-1]
+        old = [None if (z is None or not acc) else z.clone() for z, acc in zip(dZs, (accumulate_x, accumulate_x, accumulate_h, accumulate_h))]
         dY = dHnew * U * (1 - Cand * Cand)
         RH, dRH = Rg * H, torch.empty_like(H)
         if cin == h:
@@ -282,6 +283,9 @@ class EmulatedKernels:
         self.cell_gates_bwd_planar(X, H, SX, SH, Tc, Wg, dRH, Cand, U, Rg, dHnew, dZs, dWg, dbg, None)
         if cin == h:
             dZs[0].add_(dXc)
+        for z, o in zip(dZs, old):
+            if o is not None:
+                z.add_(o)
 
     def spmm_sum(self, rowptr, colidx, val, plan, X, X2, addends, Y, blend=None, alpha=1.0):
         B, n, Cc, h = Y.shape

@@ -40,12 +40,16 @@ constexpr int CB_WAVE_BYTES = 2 * 64 * 16 + 2 * 64 * 16 + 32 * CB_TRS * 4;
 constexpr int CB_TABLE_FRAGS = 2 + 8 + 4;       // T_1 (2), gates W (K LB S = 8), candidate W (K LB = 4)
 constexpr size_t CB_LDS_BYTES = (size_t)CB_TABLE_FRAGS * 3 * 64 * 16 + (size_t)CB_WAVES * CB_WAVE_BYTES;
 
-template <int L, int PL>        // PL = 1: L = 32, rows [X | H];  PL = 2: L = 20, rows [H | x (cin = Lw - 16 <= 4) | pad], W rows permuted to match
+// ACCX / ACCH: the X-side (dX, dS.X) / H-side (dH, dS.H) gradient planes already hold another cell's gradients for the same state -- its
+// other consumer's -- and this launch ADDS its own: the state then owns ONE direct and ONE aggregated plane, and the state-gradient SpMM
+// that follows gathers one operand instead of two (8 -> 6 planes there, 2 more streamed reads here, where HBM is not the bound).
+template <int L, int PL, int ACCX = 0, int ACCH = 0>        // PL = 1: L = 32, rows [X | H];  PL = 2: L = 20, rows [H | x (cin = Lw - 16 <= 4) | pad], W rows permuted to match
 __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs a) {
     constexpr int K = 2, NRB = 2, C = 32, LB = 2, HID = 16;
     constexpr int RHB = PL == 1 ? 1 : 0;          // block of the row that is the state plane (H for the gates, R*H for the candidate)
     constexpr int LBD = PL == 1 ? 2 : 1;          // blocks of the row whose gradient is wanted (a narrow input plane gets none)
     static_assert((PL == 1 && L == 32) || (PL == 2 && L == 20), "planar rows are 16 + 16 or 16 + cin columns");
+    static_assert(PL == 1 || !ACCX, "a narrow input plane gets no gradient");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32x4* TB = reinterpret_cast<u32x4*>(smem_raw);     // [NRB rb]          T_1[16rb + x][pair_row]
     u32x4* WG = TB + 2 * 3 * 64;                         // [K n][LB][S = 2]  Wg[(n, c, 16lb + x)][16hb + 4g + (e&3)], block 2s + (e>>2) = (c, hb)
@@ -120,6 +124,8 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
         float ud[NRB][4], rd[NRB][4], cd[NRB][4], gn[NRB][4], bm[NRB][4];
         f32x4 uv[NRB], rv[NRB], cv[NRB], gv[NRB], hv[NRB], bv[NRB];
     };
+    float* const dP[K][LB] = {{PL == 1 ? a.dX : a.dH, PL == 1 ? a.dH : nullptr}, {PL == 1 ? a.dSX : a.dSH, PL == 1 ? a.dSH : nullptr}};
+    constexpr bool ACC[LB] = {PL == 1 ? ACCX != 0 : ACCH != 0, PL == 1 ? ACCH != 0 : false};      // per block of the row
     auto load_ops = [&](Ops& o, int nd) {
         const size_t r0 = (size_t)nd * C;
 #pragma unroll
@@ -154,6 +160,16 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
     __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0), expcnt / lgkmcnt untouched
     while (node < a.nodes) {
         const int next_node = node + nw;
+        // ACCX / ACCH: what the gradient planes already hold (tile layout: row 16rb + x, columns 4g .. 4g+3).  Requested for THIS node, before
+        // the next node's operands (vmcnt counts in order); first used in the gates phase, microseconds from here.
+        f32x4 old[K][LB][NRB];
+#pragma unroll
+        for (int n = 0; n < K; ++n)
+#pragma unroll
+            for (int lb = 0; lb < LBD; ++lb)
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb)
+                    if (ACC[lb]) old[n][lb][rb] = *reinterpret_cast<const f32x4*>(dP[n][lb] + ((size_t)node * C + 16 * rb + x) * HID + 4 * g);
         if (next_node < a.nodes) load_ops(nxt, next_node);         // software prefetch: lands while this node computes
         __builtin_amdgcn_sched_barrier(0);
         const size_t r0 = (size_t)node * C;
@@ -282,7 +298,6 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
             qb[0][rb] = split8(gr.v[rb][0], gr.v[rb][1]);
             qb[1][rb] = split8(Qv[rb][0], Qv[rb][1]);
         }
-        float* const dP[K][LB] = {{PL == 1 ? a.dX : a.dH, PL == 1 ? a.dH : nullptr}, {PL == 1 ? a.dSX : a.dSH, PL == 1 ? a.dSH : nullptr}};
 #pragma unroll
         for (int n = 0; n < K; ++n)
 #pragma unroll
@@ -299,6 +314,7 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
                     } else {
                         z[rb] = kZero4;
                     }
+                    if (ACC[lb]) z[rb] += old[n][lb][rb];          // the other consumer's gradients of the same plane
                 }
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
@@ -341,13 +357,13 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
     combine_dw<K, LB, 1, CB_WAVES>(reinterpret_cast<float*>(smem_raw), dWc, dbc, a.partial_c, a.Lw, a.want_dbc, PL == 2 ? cin : -1);
 }
 
-template <int L, int PL>
+template <int L, int PL, int ACCX = 0, int ACCH = 0>
 int launch_cell_bwd(const CellBwdArgs& a, int* n_partials, hipStream_t stream) {
     const size_t slabs = (size_t)CB_WAVES * (4 * L * 32 + 32) * sizeof(float);
     const size_t lds = CB_LDS_BYTES > slabs ? CB_LDS_BYTES : slabs;
     static_assert(CB_LDS_BYTES <= stc::kMaxLdsBytes, "tables + per-wave tiles must fit the CU's LDS");
     if (lds > stc::kMaxLdsBytes) return STC_NOT_HANDLED;
-    auto kern = cell_bwd_x3_kernel<L, PL>;
+    auto kern = cell_bwd_x3_kernel<L, PL, ACCX, ACCH>;
     if (int rc = stc::hip_status(stc::allow_lds(kern, lds), "hipFuncSetAttribute(cell bwd x3)")) return rc;
     static const int resident = stc::resident_blocks(kern, CB_THREADS, lds, 1);
     const long long want = (a.nodes + CB_WAVES - 1) / CB_WAVES;
@@ -366,7 +382,7 @@ int stc_cell_bwd_planar_shape_ok(int C, int h) { return C == 32 && h == 16; }
 int stc_cell_bwd_planar_x3(const float* X, const float* H, const float* SX, const float* SH, const float* Tc, const float* Wg, const float* Wc,
                            const float* U, const float* R, const float* Cand, const float* dHnew, const float* dBm,
                            float* dX, float* dSX, float* dH, float* dSH, float* partial_g, float* partial_c, int* n_partials,
-                           int want_dbg, int want_dbc, long long nodes, int C, int Lw, hipStream_t stream) {
+                           int want_dbg, int want_dbc, int accumulate_x, int accumulate_h, long long nodes, int C, int Lw, hipStream_t stream) {
     const int cin = Lw - 16;
     if (!stc_cell_bwd_planar_shape_ok(C, 16) || nodes <= 0 || nodes >= (1ll << 31) / C || !(cin == 16 || (cin >= 1 && cin <= 4))) return STC_NOT_HANDLED;
     const float* wide[] = {H, SH, U, R, Cand, dHnew, dBm, dH, dSH};
@@ -375,7 +391,11 @@ int stc_cell_bwd_planar_x3(const float* X, const float* H, const float* SX, cons
     if (cin == 16) {
         const float* more[] = {X, SX, dX, dSX};
         if (!dX || !dSX || !all_aligned16(more, 4)) return STC_NOT_HANDLED;
+        if (accumulate_x && accumulate_h) return launch_cell_bwd<32, 1, 1, 1>(a, n_partials, stream);
+        if (accumulate_x) return launch_cell_bwd<32, 1, 1, 0>(a, n_partials, stream);
+        if (accumulate_h) return launch_cell_bwd<32, 1, 0, 1>(a, n_partials, stream);
         return launch_cell_bwd<32, 1>(a, n_partials, stream);
     }
-    return launch_cell_bwd<20, 2>(a, n_partials, stream);
+    if (accumulate_x) return STC_NOT_HANDLED;       // a narrow input plane gets no gradient
+    return accumulate_h ? launch_cell_bwd<20, 2, 0, 1>(a, n_partials, stream) : launch_cell_bwd<20, 2>(a, n_partials, stream);
 }

@@ -563,6 +563,7 @@ extern "C" int stc_cell_bwd_planar_f32(const float* X, const float* H, const flo
                                        const float* U, const float* Rg, const float* Cand, const float* dHnew, const float* dBm,
                                        float* dX, float* dSX, float* dH, float* dSH,
                                        float* dWg, float* dbg, float* dWc, float* dbc,
+                                       int32_t accumulate_x, int32_t accumulate_h,
                                        void* workspace, size_t workspace_bytes,
                                        int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream) {
     const int L = Lw == 2 * h ? 2 * h : 20;
@@ -570,6 +571,7 @@ extern "C" int stc_cell_bwd_planar_f32(const float* X, const float* H, const flo
     STC_REQUIRE(Lw == 2 * h || (Lw > h && Lw <= h + 4), STC_EINVAL, "stc_cell_bwd_planar_f32: input width %d (Lw - h) must be h or 1..4", Lw - h);
     if (!stc_cell_bwd_planar_supported(C, h)) return stc::fail(STC_EUNSUPPORTED, "stc_cell_bwd_planar_f32: C=%d h=%d is not built (C = 32, h = 16)", C, h);
     STC_REQUIRE(Wg && Wc && dWg && dWc && Tc, STC_EINVAL, "stc_cell_bwd_planar_f32: null W/dW/Tc");
+    STC_REQUIRE(!accumulate_x || Lw == 2 * h, STC_EINVAL, "stc_cell_bwd_planar_f32: accumulate_x with a narrow input plane (it gets no gradient)");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int nWg = 4 * Lw * 2 * h, nWc = 4 * Lw * h;
     if (nodes == 0) {
@@ -589,7 +591,7 @@ extern "C" int stc_cell_bwd_planar_f32(const float* X, const float* H, const flo
     float* partial_c = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + bytes_g);
     int n_parts = 0;
     const int rc = stc_cell_bwd_planar_x3(X, H, SX, SH, Tc, Wg, Wc, U, Rg, Cand, dHnew, dBm, dX, dSX, dH, dSH, partial_g, partial_c, &n_parts,
-                                          dbg != nullptr, dbc != nullptr, nodes, C, Lw, s);
+                                          dbg != nullptr, dbc != nullptr, accumulate_x != 0, accumulate_h != 0, nodes, C, Lw, s);
     if (rc == STC_NOT_HANDLED) return stc::fail(STC_EUNSUPPORTED, "stc_cell_bwd_planar_f32: operands not usable (alignment)");
     if (rc != STC_OK) return rc;
     if (int r2 = stc_node_reduce_partials(partial_g, n_parts, nWg, 2 * h, dWg, dbg, s)) return r2;

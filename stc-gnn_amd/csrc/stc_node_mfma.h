@@ -99,7 +99,7 @@ int stc_cell_bwd_planar_shape_ok(int C, int h);
 int stc_cell_bwd_planar_x3(const float* X, const float* H, const float* SX, const float* SH, const float* Tc, const float* Wg, const float* Wc,
                            const float* U, const float* R, const float* Cand, const float* dHnew, const float* dBm,
                            float* dX, float* dSX, float* dH, float* dSH, float* partial_g, float* partial_c, int* n_partials,
-                           int want_dbg, int want_dbc, long long nodes, int C, int Lw, hipStream_t stream);
+                           int want_dbg, int want_dbc, int accumulate_x, int accumulate_h, long long nodes, int C, int Lw, hipStream_t stream);
 
 // Planar cell convolutions of order K = 3 (stc_node_x3.hip): Zx[n] / Zh[n] = T_n(S) of the X-side / H-side plane; mode 1 gates, 2 candidate.
 int stc_cell_planar_k_shape_ok(int K, int C, int h);

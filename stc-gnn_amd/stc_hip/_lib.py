@@ -19,7 +19,7 @@ import torch
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG_ROOT, 'libstc_hip.so')
-ABI_VERSION = 12
+ABI_VERSION = 13
 MAX_K = 4
 SPMM_SUM_MAX_ADD = 8     # = STC_SPMM_SUM_MAX_ADD of include/stc_hip.h
 
@@ -87,7 +87,7 @@ def _declare(lib):
         'stc_bdg_node_post_fwd_f32': [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
         'stc_cell_gates_fwd_planar_f32': [_p] * 14 + [_i64, _i32, _i32, _i32, _p],
         'stc_cell_gates_bwd_planar_f32': [_p] * 11 + [C.POINTER(_p), _p, _p, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _p],
-        'stc_cell_bwd_planar_f32': [_p] * 21 + [C.c_size_t, _i64, _i32, _i32, _i32, _p],
+        'stc_cell_bwd_planar_f32': [_p] * 20 + [_i32, _i32, _p, C.c_size_t, _i64, _i32, _i32, _i32, _p],
         'stc_spmm_blend_fwd_f32': [_p] * 6 + [_i32, _i32] + [_p] * 6 + [_p, _i32, _i32, _p, _i32, _p, _i32, _i32] + [_i32] * 3 + [_p],
         'stc_bdg_node_post_bwd_f32': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _i32, _p],
         'stc_spmm_sum_f32': [_p] * 6 + [_i32, _i32, _p, _p, _f32, _i32, C.POINTER(_p), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_f32), _p, _p, _p, _p,
@@ -720,10 +720,11 @@ class HipKernels:
     def cell_bwd_planar_supported(self, Cc, h) -> bool:
         return os.environ.get('STC_FUSE_CELL_BWD', '1') != '0' and bool(self.lib.stc_cell_bwd_planar_supported(Cc, h))
 
-    def cell_bwd_planar(self, X, H, SX, SH, Tc, Wg, Wc, U, Rg, Cand, dHnew, dBm, dZs, dWg, dbg, dWc, dbc):
+    def cell_bwd_planar(self, X, H, SX, SH, Tc, Wg, Wc, U, Rg, Cand, dHnew, dBm, dZs, dWg, dbg, dWc, dbc, accumulate_x=False, accumulate_h=False):
         """Candidate (post-aggregation form) + gates backward of one planar cell step in one launch.  ``dBm`` = S^T dY with
         dY = dHnew U (1 - Cand^2) (the kernel re-forms dY itself); ``dZs`` = [dX, dSX, dH, dSH] gradient planes: dX = the candidate's
-        plus the gates' share of the X plane, dH includes the gate prologue's share (dX, dSX None for a narrow input plane)."""
+        plus the gates' share of the X plane, dH includes the gate prologue's share (dX, dSX None for a narrow input plane).
+        ``accumulate_x`` / ``accumulate_h``: the X-side / H-side planes already hold the state's other consumer's gradients; add to them."""
         R, Cc, h, cin = self._planes('cell_bwd', X, H, SX, SH)
         self._f32('cell_bwd.Tc', Tc, (2, Cc, Cc))
         self._f32('cell_bwd.Wg', Wg, (4 * (cin + h), 2 * h))
@@ -744,8 +745,11 @@ class HipKernels:
             self._f32('cell_bwd.dbc', dbc, (h,))
         self._same_device(X, H, SX, SH, Tc, Wg, Wc, U, Rg, Cand, dHnew, dBm, *dZs, dWg, dbg, dWc, dbc)
         ws = self._get_workspace(H.device, self.lib.stc_cell_bwd_planar_workspace_bytes(Cc, 2 * h, h))
+        if accumulate_x and cin != h:
+            raise StcError('cell backward: accumulate_x with a narrow input plane (it gets no gradient)')
         self._launch('stc_cell_bwd_planar_f32', H, _ptr(X), _ptr(H), _ptr(SX), _ptr(SH), _ptr(Tc), _ptr(Wg), _ptr(Wc), _ptr(U), _ptr(Rg), _ptr(Cand),
-                     _ptr(dHnew), _ptr(dBm), *[_ptr(z) for z in dZs], _ptr(dWg), _ptr(dbg), _ptr(dWc), _ptr(dbc), _ptr(ws), ws.numel(), R, Cc, cin + h, h)
+                     _ptr(dHnew), _ptr(dBm), *[_ptr(z) for z in dZs], _ptr(dWg), _ptr(dbg), _ptr(dWc), _ptr(dbc), int(bool(accumulate_x)), int(bool(accumulate_h)),
+                     _ptr(ws), ws.numel(), R, Cc, cin + h, h)
 
     # ---- planar cell convolutions of Chebyshev order K = 3 ------------------------------------------------
     def cell_planar_k_supported(self, K, Cc, h) -> bool:

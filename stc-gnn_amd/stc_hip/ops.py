@@ -464,6 +464,7 @@ _PLANAR_K3 = os.environ.get('STC_PLANAR_K3', '1') != '0'        # Chebyshev orde
 # cell as the slab-planar candidate, 23 % less saved activation memory (36.0 vs 46.8 GB at N = 10 000, batch 4), but its backward kernel
 # (382 registers, one wave per SIMD) is slower than the slab-planar one: 78.0 vs 75.9 ms per step on MI355X (profiles/r02/i_*).
 _POST_K3 = os.environ.get('STC_POST_K3', '0') == '1'
+_ACC_PLANES = os.environ.get('STC_ACC_PLANES', '1') != '0'      # one-launch cell backward: a state's second consumer adds into the first one's planes
 
 
 def cell_graph_supported(op: SpatialOperand, Tc, Ks: int, C: int, h: int, x_widths, dtype=torch.float32) -> bool:
@@ -854,14 +855,30 @@ class _StcCellGraph(Function):
                 new = lambda: torch.empty_like(Hprev)
                 dWg, dbg = torch.empty_like(Wg), (Wg.new_empty(2 * h) if bg is not None else None)
                 dWc, dbc = torch.empty_like(Wc), (Wc.new_empty(h) if bc is not None else None)
-                dXd, dSX = (new(), new()) if wide else (None, None)
-                dHd, dSH = new(), new()
+                # A state has two consumers (next step as H, next layer as X): the first one processed writes the state's direct and
+                # aggregated gradient planes, the second ADDS into them (accumulate_x / accumulate_h), so the state-gradient SpMM gathers
+                # one operand instead of two and reads one direct plane instead of two.
+                taken = set()
+
+                def planes_of_state(src):
+                    if src[0] != 'cell':
+                        return new(), new(), False                   # an external tensor: gradients computed, nobody owed
+                    pc = pieces.get(src[1])
+                    if _ACC_PLANES and pc is not None and pc.get('own') is not None and src[1] not in taken:
+                        taken.add(src[1])
+                        return pc['own'][0], pc['own'][1], True
+                    d, a_ = new(), new()
+                    leave(src[1], (d,), a_)
+                    if pieces[src[1]].get('own') is None:
+                        pieces[src[1]]['own'] = (d, a_)
+                        taken.add(src[1])
+                    return d, a_, False
+
+                dXd, dSX, acc_x = planes_of_state(x) if wide else (None, None, False)
+                dHd, dSH, acc_h = planes_of_state(hs)
                 k.cell_bwd_planar(*rows((Xp, Hprev, SXp, SHp)), Tc, Wg, Wc, *rows((U, Rg, Cand, dHnew, dBm)),
-                                  [None if t is None else t.view(B * N, C, h) for t in (dXd, dSX, dHd, dSH)], dWg, dbg, dWc, dbc)
-                if wide and x[0] == 'cell':
-                    leave(x[1], (dXd,), dSX)                         # as the X plane: ONE direct plane (candidate's + gates' share)
-                if hs[0] == 'cell':
-                    leave(hs[1], (dHd,), dSH)                        # as the H plane: direct share incl. what the gate prologue owes it
+                                  [None if t is None else t.view(B * N, C, h) for t in (dXd, dSX, dHd, dSH)], dWg, dbg, dWc, dbc,
+                                  accumulate_x=acc_x, accumulate_h=acc_h)
                 for i, t in enumerate((dWg, dbg, dWc, dbc)):
                     add_to(acc[s_id], i, t)
                 continue

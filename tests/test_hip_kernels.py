@@ -645,7 +645,15 @@ def test_cell_backward_in_one_launch(hip, nodes, cin, bias):
     assert rel_err(dWc, dWc2) < 2e-6 and rel_err(dWg, dWg2) < 2e-6 and rel_err(dZ[2], dZ2[2]) < 2e-6 and rel_err(dZ[3], dZ2[3]) < 2e-6
     if wide:
         assert rel_err(dZ[0], dZ2[0] + dXc) < 2e-6 and rel_err(dZ[1], dZ2[1]) < 2e-6
-    # bitwise reproducible (fixed-order combine of the per-workgroup partial sums)
+    # accumulate_x / accumulate_h: the planes already hold the state's other consumer's gradients; the launch adds its own
+    for acc_x, acc_h in ((wide, False), (False, True), (wide, True)):
+        base = [None if z is None else torch.randn(nodes, C, h, generator=g) for z in dZ_w]
+        dZa = [None if b_ is None else cu(b_).clone() for b_ in base]
+        hip.cell_bwd_planar(*ops_, dZa, dWg, dbg, dWc, dbc, accumulate_x=acc_x, accumulate_h=acc_h)
+        for i, (a_, w_, b_) in enumerate(zip(dZa, dZ_w, base)):
+            if a_ is not None:
+                assert rel_err(a_, w_ + b_ if (acc_x if i < 2 else acc_h) else w_) < TOL, (i, acc_x, acc_h)
+        # bitwise reproducible (fixed-order combine of the per-workgroup partial sums)
     dZ3, dWg3, dWc3 = new('cuda'), nan(*Wg.shape), nan(*Wc.shape)
     hip.cell_bwd_planar(*ops_, dZ3, dWg3, None, dWc3, None)
     assert torch.equal(dWg3, dWg) and torch.equal(dWc3, dWc) and torch.equal(dZ3[2], dZ[2])
