@@ -50,6 +50,7 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
     constexpr int LBD = PL == 1 ? 2 : 1;          // blocks of the row whose gradient is wanted (a narrow input plane gets none)
     static_assert((PL == 1 && L == 32) || (PL == 2 && L == 20), "planar rows are 16 + 16 or 16 + cin columns");
     static_assert(PL == 1 || !ACCX, "a narrow input plane gets no gradient");
+    constexpr bool AHEAD = !(ACCX && ACCH);       // W fragments fetched one product group ahead (12 registers; the both-sides variant has none to spare)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32x4* TB = reinterpret_cast<u32x4*>(smem_raw);     // [NRB rb]          T_1[16rb + x][pair_row]
     u32x4* WG = TB + 2 * 3 * 64;                         // [K n][LB][S = 2]  Wg[(n, c, 16lb + x)][16hb + 4g + (e&3)], block 2s + (e>>2) = (c, hb)
@@ -152,6 +153,8 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
             o.bv[kb] = *reinterpret_cast<const f32x4*>(a.dBm + e);
         }
     };
+    // the two T_1 fragments are used four times per node (both orientations, both convolutions): kept in registers for the whole kernel
+    const X3 tb0 = get_frag(TB, 0, lane), tb1 = get_frag(TB, 1, lane);
     Ops cur, nxt;
     int node = blockIdx.x * CB_WAVES + wave;
     if (node < a.nodes) load_ops(cur, node);
@@ -206,15 +209,19 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
             for (int n = 0; n < K; ++n)
 #pragma unroll
                 for (int rb = 0; rb < NRB; ++rb) {
-                    const f32x4 qv = mma6(gd[n], get_frag(TB, rb, lo), kZero4);      // (T_1 dY_n)^T tile
+                    const f32x4 qv = mma6(gd[n], rb == 0 ? tb0 : tb1, kZero4);      // (T_1 dY_n)^T tile
                     qb[n][rb] = split8(gr[n].v[rb][0], qv);
                 }
+            X3 wc;                                                  // fragments fetched one step ahead of the products that use them
+            if (AHEAD) wc = get_frag(WC, 0, lo);
 #pragma unroll
             for (int lb = 0; lb < LBD; ++lb) {
                 f32x4 z[NRB] = {kZero4, kZero4};
 #pragma unroll
                 for (int n = 0; n < K; ++n) {
-                    const X3 w = get_frag(WC, n * LB + lb, lo);
+                    const X3 w = AHEAD ? wc : get_frag(WC, n * LB + lb, lo);
+                    const int nn = n + 1 < K ? n + 1 : 0, nlb = n + 1 < K ? lb : lb + 1;
+                    if (AHEAD && nlb < LBD) wc = get_frag(WC, nn * LB + nlb, lo);
 #pragma unroll
                     for (int rb = 0; rb < NRB; ++rb) z[rb] = mma6(w, qb[n][rb], z[rb]);
                 }
@@ -228,7 +235,7 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
             X3 qd[K];
 #pragma unroll
             for (int n = 0; n < K; ++n) {
-                const f32x4 q0 = mma6(get_frag(TB, 0, lo), gd[n], kZero4), q1 = mma6(get_frag(TB, 1, lo), gd[n], kZero4);
+                const f32x4 q0 = mma6(tb0, gd[n], kZero4), q1 = mma6(tb1, gd[n], kZero4);
                 qd[n] = split8(q0, q1);
             }
 #pragma unroll
@@ -288,7 +295,7 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
         f32x4 Qv[NRB][2];
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) {
-            const X3 t = get_frag(TB, rb, lo);
+            const X3& t = rb == 0 ? tb0 : tb1;
 #pragma unroll
             for (int hb = 0; hb < 2; ++hb) Qv[rb][hb] = mma6(gd[hb], t, kZero4);
         }
@@ -298,6 +305,8 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
             qb[0][rb] = split8(gr.v[rb][0], gr.v[rb][1]);
             qb[1][rb] = split8(Qv[rb][0], Qv[rb][1]);
         }
+        X3 wg;
+        if (AHEAD) wg = get_frag(WG, 0, lo);
 #pragma unroll
         for (int n = 0; n < K; ++n)
 #pragma unroll
@@ -318,7 +327,11 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
                 }
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    const X3 w = get_frag(WG, (n * LB + lb) * 2 + s, lo);
+                    const X3 w = AHEAD ? wg : get_frag(WG, (n * LB + lb) * 2 + s, lo);
+                    if (AHEAD) {                                               // the next fragment in this loop nest's order: (n, lb, s) -> s, lb, n
+                        const int ns = s + 1 < 2 ? s + 1 : 0, nlb = s + 1 < 2 ? lb : (lb + 1 < LBD ? lb + 1 : 0), nn = (s + 1 < 2 || lb + 1 < LBD) ? n : n + 1;
+                        if (nn < K) wg = get_frag(WG, (nn * LB + nlb) * 2 + ns, lo);
+                    }
 #pragma unroll
                     for (int rb = 0; rb < NRB; ++rb) z[rb] = mma6(w, qb[s][rb], z[rb]);
                 }
@@ -331,7 +344,7 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
             f32x4 Qd[NRB][2];
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) {
-                const X3 t = get_frag(TB, rb, lo);
+                const X3& t = rb == 0 ? tb0 : tb1;
 #pragma unroll
                 for (int hb = 0; hb < 2; ++hb) Qd[rb][hb] = mma6(t, gd[hb], kZero4);
             }
