@@ -668,6 +668,7 @@ int launch_vector(const char* who, const GraphArgs& g, int n_rows, int n_cols, c
         // epilogue (sum / blend forms) the extra live registers cost what the pipelining gains (equal or slower): old loop.
         // STC_SPMM_PIPE=0 (A/B runs): the un-pipelined gather loop everywhere
         static const bool pipe_on = [] { const char* e = std::getenv("STC_SPMM_PIPE"); return !(e && e[0] == '0'); }();
+        // (measured again for the state-gradient sum with ONE gathered operand, which is what the cell graph launches now: 27.1 vs 27.3 ms)
         const bool pipe = pipe_on && MODE == EP_PLAIN && (ep.Y0 == nullptr || ep.beta == 0.f);
         static const int pad_lds = [] { const char* e = std::getenv("STC_SPMM_PAD_LDS"); return e ? std::atoi(e) : 0; }();     // diagnostic: fewer resident workgroups
 #define STC_BCSR_GO(VPT_, BLK_) do { if (pipe && BLK_ == 2 && F4 % (128 * VPT_) == 0) hipLaunchKernelGGL((spmm_bcsr_kernel<VPT_, MODE, 2, (MODE == EP_PLAIN), (MODE == EP_PLAIN)>), grid, block, pad_lds, s, g.blk_ptr, g.blk_cols, g.blk_vals, \
