@@ -43,17 +43,30 @@ __device__ __forceinline__ void split2(float a0, float a1, unsigned& h, unsigned
     l = pk_bf16(s0, s1);
 }
 
+// Eight values at once, LEVEL BY LEVEL over the four pairs: on MI355X a vector instruction that depends on the previous one issues 8 cycles
+// after it, not 4, and v_cvt_pk_bf16_f32 is a half-rate instruction (tools/probes/valu_rates.hip: 8.1 cycles independent, 8.4 dependent;
+// v_dot2c / v_sub / v_perm 4.8-5.3 independent, 8.4 dependent) -- one pair's chain cvt -> dot2c -> cvt -> dot2c -> cvt alone runs at the
+// dependent rate, four pairs interleaved at the independent one.  The last piece needs no rounding: the second remainder has at most 8
+// significant bits, so its upper 16 bits ARE its bf16 value -- one full-rate v_perm_b32 per pair instead of a conversion.
 __device__ __forceinline__ X3 split8(const f32x4 a, const f32x4 b) {     // slots 0..3 from a, 4..7 from b
+    const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
     unsigned h[4], m[4], l[4];
-    split2(a[0], a[1], h[0], m[0], l[0]);
-    split2(a[2], a[3], h[1], m[1], l[1]);
-    split2(b[0], b[1], h[2], m[2], l[2]);
-    split2(b[2], b[3], h[3], m[3], l[3]);
-    X3 r;
-    r.h = u32x4{h[0], h[1], h[2], h[3]};
-    r.m = u32x4{m[0], m[1], m[2], m[3]};
-    r.l = u32x4{l[0], l[1], l[2], l[3]};
-    return r;
+    float r[8], s[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) h[i] = pk_bf16(v[2 * i], v[2 * i + 1]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { r[2 * i] = minus_lo(v[2 * i], h[i]); r[2 * i + 1] = minus_hi(v[2 * i + 1], h[i]); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) m[i] = pk_bf16(r[2 * i], r[2 * i + 1]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { s[2 * i] = minus_lo(r[2 * i], m[i]); s[2 * i + 1] = minus_hi(r[2 * i + 1], m[i]); }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) l[i] = __builtin_amdgcn_perm(__float_as_uint(s[2 * i + 1]), __float_as_uint(s[2 * i]), 0x07060302u);
+    X3 o;
+    o.h = u32x4{h[0], h[1], h[2], h[3]};
+    o.m = u32x4{m[0], m[1], m[2], m[3]};
+    o.l = u32x4{l[0], l[1], l[2], l[3]};
+    return o;
 }
 
 __device__ __forceinline__ f32x4 mma(const u32x4 a, const u32x4 b, const f32x4 c) {
