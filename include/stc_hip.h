@@ -31,8 +31,19 @@
 extern "C" {
 #endif
 
-#define STC_ABI_VERSION 13
+#define STC_ABI_VERSION 14
 #define STC_MAX_K 4          /* highest Chebyshev order (Ks, Kc) the node kernels accept */
+
+/* Operand formats of the split-operand matrix-core kernels (C = 32 / 64, hidden 16).  Every fp32 operand is split into low-precision
+ * pieces whose products are exact in the fp32 accumulator:
+ *   STC_FMT_BF16X3  three bf16 pieces, six products  -- fp32's range, error at the fp32 rounding level (8.5e-8 on 32-term dot products);
+ *   STC_FMT_F16X2   two fp16 pieces, three products  -- half the matrix instructions; error 1.7-2.9e-7 (an fp32 fmaf chain: 1.3-2.4e-7).
+ * fp16 has a 5-bit exponent, so F16X2 kernels normalise their operands by powers of two (exact): weight and category-graph tables from
+ * their own maxima inside the kernel, gradient operands from the launch's gradient maximum, which the caller hands over in device
+ * memory (grad_amax arguments; stc_spmm_sum_f32 produces it on the way).  Activations enter unscaled: |value| must stay below 65504
+ * (states and gates of an STC_Cell are below 1 by construction); beyond that the result is NaN, never a silently wrong number. */
+#define STC_FMT_BF16X3 0
+#define STC_FMT_F16X2 1
 
 #define STC_OK 0
 #define STC_EINVAL (-1)
@@ -327,6 +338,7 @@ int stc_cell_gates_fwd_planar_f32(const float* X, const float* H, const float* S
                                   const float* Tc, const float* W, const float* bias,
                                   float* U, float* Rg, float* RH,
                                   const float* Wc, const float* bc, float* A, float* Bm,
+                                  int32_t operand_format,
                                   int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream);
 int stc_cell_gates_bwd_planar_f32(const float* X, const float* H, const float* SX, const float* SH,
                                   const float* Tc, const float* W,
@@ -348,7 +360,10 @@ int stc_cell_gates_bwd_planar_f32(const float* X, const float* H, const float* S
  * consumer) and this launch adds its own to them, so the state owns one direct and one aggregated plane and stc_spmm_sum_f32 gathers one
  * operand for it instead of two.
  * Narrow input (Lw - h in 1..4): dX, dSX are not produced (may be NULL).  stc_cell_bwd_planar_supported() tells whether (C, h)
- * is built (C = 32, h = 16); workspace >= stc_cell_bwd_planar_workspace_bytes(C, Lw, h) bytes, 16-byte aligned. */
+ * is built (C = 32, h = 16); workspace >= stc_cell_bwd_planar_workspace_bytes(C, Lw, h) bytes, 16-byte aligned.
+ * grad_amax != NULL selects the fp16 x 2 operand format (see "operand formats" above): n_amax device floats whose maximum is
+ * max |dHnew| over the launch's rows (stc_spmm_sum_f32 leaves them; any bound within 2^8 above the true maximum serves).  NULL keeps
+ * the bf16 x 3 format, which needs no range information. */
 int stc_cell_bwd_planar_supported(int32_t C, int32_t h);
 size_t stc_cell_bwd_planar_workspace_bytes(int32_t C, int32_t Lw, int32_t h);
 int stc_cell_bwd_planar_f32(const float* X, const float* H, const float* SX, const float* SH,
@@ -357,6 +372,7 @@ int stc_cell_bwd_planar_f32(const float* X, const float* H, const float* SX, con
                             float* dX, float* dSX, float* dH, float* dSH,
                             float* dWg, float* dbg, float* dWc, float* dbc,
                             int32_t accumulate_x, int32_t accumulate_h,
+                            const float* grad_amax, int32_t n_amax,
                             void* workspace, size_t workspace_bytes,
                             int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream);
 
@@ -409,13 +425,16 @@ int stc_bdg_node_post_bwd_k_f32(const float* X, const float* X2, int32_t K, cons
  * n_add <= STC_SPMM_SUM_MAX_ADD, X2 may be NULL, add_scale may be NULL (all +1).  alpha / add_scale serve the order-3 form
  * (d0 - d2 + S^T (d1 + 2 S^T d2)); alpha = 1 and no scales give the order-2 sum.
  * dY != NULL: the epilogue also writes dY = Y*U*(1-Cand^2), the blend backward (STC_GNN.py:76-78) of the cell that owns the
- * state, from that cell's saved U and Cand -- the gradient is then not read again just to form it. */
+ * state, from that cell's saved U and Cand -- the gradient is then not read again just to form it.
+ * amax != NULL: n_amax floats, ZERO before the launch; afterwards their maximum is max |Y| over the launch (each wave leaves its own
+ * maximum in one slot by an atomic max) -- the grad_amax operand of stc_cell_bwd_planar_f32, at no extra pass over Y. */
 #define STC_SPMM_SUM_MAX_ADD 8
 int stc_spmm_sum_f32(const int32_t* rowptr, const int32_t* colidx, const float* val,
                      const int32_t* blk_ptr, const int32_t* blk_cols, const float* blk_vals,
                      int32_t n_rows, int32_t n_cols, const float* X, const float* X2, float alpha,
                      int32_t n_add, const float* const* add, const int32_t* add_ld, const int32_t* add_off, const float* add_scale,
                      float* Y, const float* U, const float* Cand, float* dY,
+                     float* amax, int32_t n_amax,
                      int32_t batch, int32_t C, int32_t h, void* stream);
 
 /* ---- the same two cell convolutions with the graph aggregation fused in (Ks = Kc = 2) ------------------------------

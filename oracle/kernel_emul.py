@@ -270,7 +270,8 @@ class EmulatedKernels:
     def cell_bwd_planar_supported(self, Cc, h) -> bool:
         return h == 16 and os.environ.get('STC_FUSE_CELL_BWD', '1') != '0'
 
-    def cell_bwd_planar(self, X, H, SX, SH, Tc, Wg, Wc, U, Rg, Cand, dHnew, dBm, dZs, dWg, dbg, dWc, dbc, accumulate_x=False, accumulate_h=False):
+    def cell_bwd_planar(self, X, H, SX, SH, Tc, Wg, Wc, U, Rg, Cand, dHnew, dBm, dZs, dWg, dbg, dWc, dbc, accumulate_x=False, accumulate_h=False,
+                        grad_amax=None):
         cin, h = X.shape[-1], H.shape[-1]
         old = [None if (z is None or not acc) else z.clone() for z, acc in zip(dZs, (accumulate_x, accumulate_x, accumulate_h, accumulate_h))]
         dY = dHnew * U * (1 - Cand * Cand)
@@ -287,13 +288,15 @@ class EmulatedKernels:
             if o is not None:
                 z.add_(o)
 
-    def spmm_sum(self, rowptr, colidx, val, plan, X, X2, addends, Y, blend=None, alpha=1.0):
+    def spmm_sum(self, rowptr, colidx, val, plan, X, X2, addends, Y, blend=None, alpha=1.0, amax=None):
         B, n, Cc, h = Y.shape
         src = X if X2 is None else X + X2
         self.csr_spmm(rowptr, colidx, val, n, n, src.reshape(B, n, Cc * h), None, Y.view(B, n, Cc * h), float(alpha), 0.0)
         for ent in addends:
             t, off = ent[0], ent[1]
             Y += (ent[2] if len(ent) > 2 else 1.0) * t[..., off:off + h]
+        if amax is not None:                                       # any slot may hold the maximum
+            amax[0] = torch.maximum(amax[0], Y.abs().max())
         if blend is not None:
             U, Cand, dY = blend
             dY.copy_(Y * U * (1 - Cand * Cand))

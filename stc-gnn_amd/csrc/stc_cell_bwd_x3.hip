@@ -33,18 +33,26 @@ struct CellBwdArgs {
     float *dX, *dSX, *dH, *dSH;                 // gradient planes (dX, dSX: PL = 1 only)
     float *partial_g, *partial_c;               // one row [dW | db] per workgroup for each convolution
     int nodes, want_dbg, want_dbc, Lw;
+    const float* gmax; int n_gmax;              // fp16 x 2 format: slots whose maximum is max |dHnew| of this launch (device memory)
 };
 
 // per-wave LDS block: [stash_h 2 x 64 float4][stash_x 2 x 64 float4][tile 32 x CB_TRS floats]
 constexpr int CB_WAVE_BYTES = 2 * 64 * 16 + 2 * 64 * 16 + 32 * CB_TRS * 4;
 constexpr int CB_TABLE_FRAGS = 2 + 8 + 4;       // T_1 (2), gates W (K LB S = 8), candidate W (K LB = 4)
-constexpr size_t CB_LDS_BYTES = (size_t)CB_TABLE_FRAGS * 3 * 64 * 16 + (size_t)CB_WAVES * CB_WAVE_BYTES;
+template <class F>
+constexpr size_t cb_lds_bytes() { return (size_t)CB_TABLE_FRAGS * F::NP * 64 * 16 + (size_t)CB_WAVES * CB_WAVE_BYTES; }
 
 // ACCX / ACCH: the X-side (dX, dS.X) / H-side (dH, dS.H) gradient planes already hold another cell's gradients for the same state -- its
 // other consumer's -- and this launch ADDS its own: the state then owns ONE direct and ONE aggregated plane, and the state-gradient SpMM
 // that follows gathers one operand instead of two (8 -> 6 planes there, 2 more streamed reads here, where HBM is not the bound).
-template <int L, int PL, int ACCX = 0, int ACCH = 0>        // PL = 1: L = 32, rows [X | H];  PL = 2: L = 20, rows [H | x (cin = Lw - 16 <= 4) | pad], W rows permuted to match
+// F: operand format of the matrix-core products (stc_x3_frag.h): FmtB3 = three bf16 pieces / six products, FmtH2 = two fp16 pieces / three
+// products with the gradient side of the kernel run in a space scaled by sg = 2^k (from the launch's gradient maximum, a.gmax) and the
+// tables normalised per workgroup: block c = 0 of W carries sW sT, blocks c >= 1 carry sW and T_1 carries sT, so both halves of a
+// contraction over (c, o) arrive with the same factor sg sT sW, which the tile's store takes out again.
+template <class F, int L, int PL, int ACCX = 0, int ACCH = 0>        // PL = 1: L = 32, rows [X | H];  PL = 2: L = 20, rows [H | x (cin = Lw - 16 <= 4) | pad], W rows permuted to match
 __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs a) {
+    using Op = typename F::Op;
+    constexpr int NP = F::NP;
     constexpr int K = 2, NRB = 2, C = 32, LB = 2, HID = 16;
     constexpr int RHB = PL == 1 ? 1 : 0;          // block of the row that is the state plane (H for the gates, R*H for the candidate)
     constexpr int LBD = PL == 1 ? 2 : 1;          // blocks of the row whose gradient is wanted (a narrow input plane gets none)
@@ -53,22 +61,33 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
     constexpr bool AHEAD = !(ACCX && ACCH);       // W fragments fetched one product group ahead (12 registers; the both-sides variant has none to spare)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32x4* TB = reinterpret_cast<u32x4*>(smem_raw);     // [NRB rb]          T_1[16rb + x][pair_row]
-    u32x4* WG = TB + 2 * 3 * 64;                         // [K n][LB][S = 2]  Wg[(n, c, 16lb + x)][16hb + 4g + (e&3)], block 2s + (e>>2) = (c, hb)
-    u32x4* WC = WG + 8 * 3 * 64;                         // [K n][LB]         Wc[(n, c, 16lb + x)][4g + (e&3)], block (e>>2) = c
+    u32x4* WG = TB + 2 * NP * 64;                        // [K n][LB][S = 2]  Wg[(n, c, 16lb + x)][16hb + 4g + (e&3)], block 2s + (e>>2) = (c, hb)
+    u32x4* WC = WG + 8 * NP * 64;                        // [K n][LB]         Wc[(n, c, 16lb + x)][4g + (e&3)], block (e>>2) = c
     const int tid = threadIdx.x, lane = tid & 63, x = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    unsigned char* mine = reinterpret_cast<unsigned char*>(WC + 4 * 3 * 64) + (size_t)wave * CB_WAVE_BYTES;
+    unsigned char* mine = reinterpret_cast<unsigned char*>(WC + 4 * NP * 64) + (size_t)wave * CB_WAVE_BYTES;
     float4* stash_h = reinterpret_cast<float4*>(mine);               // the state's share of the gate prologue, lane-private
     float4* stash_x = stash_h + 2 * 64;                               // the candidate's X-side gradient, lane-private
     float* tile = reinterpret_cast<float*>(stash_x + 2 * 64);         // d(R*H): row-on-lane -> accumulator layout
     const int cin = a.Lw - 16;
+
+    // FmtH2: table scales from the tables' own maxima (same in every workgroup), gradient scale from the producer's slots
+    float sT = 1.f, sWg = 1.f, sWc = 1.f, sg = 1.f;
+    if constexpr (F::SCALED) {
+        float* scratch = reinterpret_cast<float*>(smem_raw);
+        sT = pow2_scale(block_absmax(a.Tc + (size_t)C * C, C * C, scratch, CB_THREADS), 0);
+        sT = fminf(fmaxf(sT, 0.0625f), 4096.f);          // W's block 0 carries sT as well: keep it inside fp16's range
+        sWg = pow2_scale(block_absmax(a.Wg, 4 * a.Lw * 32, scratch, CB_THREADS), 0);
+        sWc = pow2_scale(block_absmax(a.Wc, 4 * a.Lw * 16, scratch, CB_THREADS), 0);
+        sg = pow2_scale(slots_max(a.gmax, a.n_gmax), 4);
+    }
 
     for (int idx = tid; idx < 2 * 64; idx += CB_THREADS) {
         const int ll = idx & 63, rb = idx >> 6, gg = ll >> 4;
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = a.Tc[(size_t)C * C + (16 * rb + (ll & 15)) * C + pair_row(gg, e)];
-        put_frag(TB, rb, ll, v);
+        F::put(TB, rb, ll, v, sT);
     }
     for (int idx = tid; idx < 8 * 64; idx += CB_THREADS) {
         const int ll = idx & 63, f = idx >> 6, s = f % 2, lb = (f / 2) % LB, n = f / (2 * LB), gg = ll >> 4;
@@ -80,7 +99,7 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
             const int b = 2 * s + (e >> 2), c = b / 2, hb = b % 2;
             v[e] = (wl >= 0 && wl < a.Lw) ? a.Wg[((size_t)(n * K + c) * a.Lw + wl) * 32 + 16 * hb + 4 * gg + (e & 3)] : 0.f;
         }
-        put_frag(WG, f, ll, v);
+        F::put(WG, f, ll, v, s == 0 ? sWg * sT : sWg);              // step s holds the blocks of c = s
     }
     for (int idx = tid; idx < 4 * 64; idx += CB_THREADS) {
         const int ll = idx & 63, f = idx >> 6, lb = f % LB, n = f / LB, gg = ll >> 4;
@@ -90,9 +109,9 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int c = e >> 2;
-            v[e] = (wl >= 0 && wl < a.Lw) ? a.Wc[((size_t)(n * K + c) * a.Lw + wl) * 16 + 4 * gg + (e & 3)] : 0.f;
+            v[e] = (wl >= 0 && wl < a.Lw) ? a.Wc[((size_t)(n * K + c) * a.Lw + wl) * 16 + 4 * gg + (e & 3)] * (F::SCALED && c == 0 ? sT : 1.f) : 0.f;
         }
-        put_frag(WC, f, ll, v);
+        F::put(WC, f, ll, v, sWc);
     }
     __syncthreads();
 
@@ -154,7 +173,9 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
         }
     };
     // the two T_1 fragments are used four times per node (both orientations, both convolutions): kept in registers for the whole kernel
-    const X3 tb0 = get_frag(TB, 0, lane), tb1 = get_frag(TB, 1, lane);
+    const Op tb0 = F::get(TB, 0, lane), tb1 = F::get(TB, 1, lane);
+    // FmtH2 factors (all powers of two; 1 for FmtB3): what a tile of each phase carries besides sg, and their inverses
+    const float kc = sT * sWc, kg = sT * sWg, ikc = 1.f / kc, ikg_sg = 1.f / (kg * sg);
     Ops cur, nxt;
     int node = blockIdx.x * CB_WAVES + wave;
     if (node < a.nodes) load_ops(cur, node);
@@ -176,6 +197,15 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
         if (next_node < a.nodes) load_ops(nxt, next_node);         // software prefetch: lands while this node computes
         __builtin_amdgcn_sched_barrier(0);
         const size_t r0 = (size_t)node * C;
+        if constexpr (F::SCALED) {                                 // the gradient operands enter the scaled space: everything below is linear in them
+#pragma unroll
+            for (int kb = 0; kb < NRB; ++kb) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { cur.gn[kb][t] *= sg; cur.bm[kb][t] *= sg; }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { cur.gv[kb][i] *= sg; cur.bv[kb][i] *= sg; }
+            }
+        }
         const auto& zg = cur.zg;
         const auto &ud = cur.ud, &rd = cur.rd, &cd = cur.cd, &gn = cur.gn, &bm = cur.bm;
         const auto &uv = cur.uv, &rv = cur.rv, &cv = cur.cv, &gv = cur.gv, &hv = cur.hv, &bv = cur.bv;
@@ -200,43 +230,47 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
 #pragma unroll
             for (int kb = 0; kb < NRB; ++kb)
                 dbc[0] += (gr[0].d[kb][0][0] + gr[0].d[kb][0][1]) + (gr[0].d[kb][0][2] + gr[0].d[kb][0][3]);
-            X3 gd[K];
+            Op gd[K];
 #pragma unroll
-            for (int n = 0; n < K; ++n) gd[n] = split8(gr[n].d[0][0], gr[n].d[1][0]);
+            for (int n = 0; n < K; ++n) gd[n] = F::split(gr[n].d[0][0], gr[n].d[1][0]);
             // B operands of dX: per weight set n, the (c, o) blocks of (Q^n_c)^T for columns c' = 16rb + x
-            X3 qb[K][NRB];
+            Op qb[K][NRB];
 #pragma unroll
             for (int n = 0; n < K; ++n)
 #pragma unroll
                 for (int rb = 0; rb < NRB; ++rb) {
-                    const f32x4 qv = mma6(gd[n], rb == 0 ? tb0 : tb1, kZero4);      // (T_1 dY_n)^T tile
-                    qb[n][rb] = split8(gr[n].v[rb][0], qv);
+                    const f32x4 qv = F::mm(gd[n], rb == 0 ? tb0 : tb1, kZero4);      // (T_1 dY_n)^T tile
+                    qb[n][rb] = F::split(gr[n].v[rb][0], qv);
                 }
-            X3 wc;                                                  // fragments fetched one step ahead of the products that use them
-            if (AHEAD) wc = get_frag(WC, 0, lo);
+            Op wc;                                                  // fragments fetched one step ahead of the products that use them
+            if (AHEAD) wc = F::get(WC, 0, lo);
 #pragma unroll
             for (int lb = 0; lb < LBD; ++lb) {
                 f32x4 z[NRB] = {kZero4, kZero4};
 #pragma unroll
                 for (int n = 0; n < K; ++n) {
-                    const X3 w = AHEAD ? wc : get_frag(WC, n * LB + lb, lo);
+                    const Op w = AHEAD ? wc : F::get(WC, n * LB + lb, lo);
                     const int nn = n + 1 < K ? n + 1 : 0, nlb = n + 1 < K ? lb : lb + 1;
-                    if (AHEAD && nlb < LBD) wc = get_frag(WC, nn * LB + nlb, lo);
+                    if (AHEAD && nlb < LBD) wc = F::get(WC, nn * LB + nlb, lo);
 #pragma unroll
-                    for (int rb = 0; rb < NRB; ++rb) z[rb] = mma6(w, qb[n][rb], z[rb]);
+                    for (int rb = 0; rb < NRB; ++rb) z[rb] = F::mm(w, qb[n][rb], z[rb]);
                 }
 #pragma unroll
                 for (int rb = 0; rb < NRB; ++rb) {
-                    if (lb == RHB) drh[rb] = z[rb];
-                    else stash_x[rb * 64 + lane] = make_float4(z[rb][0], z[rb][1], z[rb][2], z[rb][3]);      // the X plane's share
+                    if (lb == RHB) {                               // stays in the sg-scaled space of the prologue
+                        if constexpr (F::SCALED) drh[rb] = z[rb] * ikc; else drh[rb] = z[rb];
+                    } else {                                       // the X plane's share: becomes the start of a gates tile (factor sg kg)
+                        if constexpr (F::SCALED) z[rb] *= ikc * kg;
+                        stash_x[rb * 64 + lane] = make_float4(z[rb][0], z[rb][1], z[rb][2], z[rb][3]);
+                    }
                 }
             }
             // dWc_{n,c} (rows l, columns o) += [X | R*H]^T Q^n_c
-            X3 qd[K];
+            Op qd[K];
 #pragma unroll
             for (int n = 0; n < K; ++n) {
-                const f32x4 q0 = mma6(tb0, gd[n], kZero4), q1 = mma6(tb1, gd[n], kZero4);
-                qd[n] = split8(q0, q1);
+                const f32x4 q0 = F::mm(tb0, gd[n], kZero4), q1 = F::mm(tb1, gd[n], kZero4);
+                qd[n] = F::split(q0, q1);
             }
 #pragma unroll
             for (int lb = 0; lb < LB; ++lb) {
@@ -246,11 +280,11 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
                     c0[t] = lb == RHB ? rd[0][t] * hd[0][t] : zg[0][lb][0][t];
                     c1[t] = lb == RHB ? rd[1][t] * hd[1][t] : zg[0][lb][1][t];
                 }
-                const X3 za = split8(c0, c1);
+                const Op za = F::split(c0, c1);
 #pragma unroll
                 for (int n = 0; n < K; ++n)
 #pragma unroll
-                    for (int c = 0; c < K; ++c) dWc[n][lb][c][0] = mma6(za, c == 0 ? gd[n] : qd[n], dWc[n][lb][c][0]);
+                    for (int c = 0; c < K; ++c) dWc[n][lb][c][0] = F::mm(za, c == 0 ? gd[n] : qd[n], dWc[n][lb][c][0]);
             }
         }
 
@@ -277,6 +311,7 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
                     gr.v[kb][0][i] = gv[kb][i] * (cv[kb][i] - h) * u * (1.f - u);
                     gr.v[kb][1][i] = d * h * r * (1.f - r);
                     own[i] = d * r + gv[kb][i] * (1.f - u);        // what H is owed directly: reset-gate path + its share of the blend
+                    if constexpr (F::SCALED) own[i] *= kg;          // the H plane's gates tile starts from it
                 }
                 stash_h[kb * 64 + lane] = make_float4(own[0], own[1], own[2], own[3]);
             }
@@ -289,24 +324,24 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
 #pragma unroll
             for (int hb = 0; hb < 2; ++hb)
                 dbg[hb] += (gr.d[kb][hb][0] + gr.d[kb][hb][1]) + (gr.d[kb][hb][2] + gr.d[kb][hb][3]);
-        X3 gd[2];
+        Op gd[2];
 #pragma unroll
-        for (int hb = 0; hb < 2; ++hb) gd[hb] = split8(gr.d[0][hb], gr.d[1][hb]);
+        for (int hb = 0; hb < 2; ++hb) gd[hb] = F::split(gr.d[0][hb], gr.d[1][hb]);
         f32x4 Qv[NRB][2];
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) {
-            const X3& t = rb == 0 ? tb0 : tb1;
+            const Op& t = rb == 0 ? tb0 : tb1;
 #pragma unroll
-            for (int hb = 0; hb < 2; ++hb) Qv[rb][hb] = mma6(gd[hb], t, kZero4);
+            for (int hb = 0; hb < 2; ++hb) Qv[rb][hb] = F::mm(gd[hb], t, kZero4);
         }
-        X3 qb[2][NRB];                                             // step s: blocks (c = s, hb = 0), (c = s, hb = 1)
+        Op qb[2][NRB];                                             // step s: blocks (c = s, hb = 0), (c = s, hb = 1)
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) {
-            qb[0][rb] = split8(gr.v[rb][0], gr.v[rb][1]);
-            qb[1][rb] = split8(Qv[rb][0], Qv[rb][1]);
+            qb[0][rb] = F::split(gr.v[rb][0], gr.v[rb][1]);
+            qb[1][rb] = F::split(Qv[rb][0], Qv[rb][1]);
         }
-        X3 wg;
-        if (AHEAD) wg = get_frag(WG, 0, lo);
+        Op wg;
+        if (AHEAD) wg = F::get(WG, 0, lo);
 #pragma unroll
         for (int n = 0; n < K; ++n)
 #pragma unroll
@@ -323,62 +358,69 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
                     } else {
                         z[rb] = kZero4;
                     }
-                    if (ACC[lb]) z[rb] += old[n][lb][rb];          // the other consumer's gradients of the same plane
+                    if (!F::SCALED && ACC[lb]) z[rb] += old[n][lb][rb];          // the other consumer's gradients of the same plane
                 }
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    const X3 w = AHEAD ? wg : get_frag(WG, (n * LB + lb) * 2 + s, lo);
+                    const Op w = AHEAD ? wg : F::get(WG, (n * LB + lb) * 2 + s, lo);
                     if (AHEAD) {                                               // the next fragment in this loop nest's order: (n, lb, s) -> s, lb, n
                         const int ns = s + 1 < 2 ? s + 1 : 0, nlb = s + 1 < 2 ? lb : (lb + 1 < LBD ? lb + 1 : 0), nn = (s + 1 < 2 || lb + 1 < LBD) ? n : n + 1;
-                        if (nn < K) wg = get_frag(WG, (nn * LB + nlb) * 2 + ns, lo);
+                        if (nn < K) wg = F::get(WG, (nn * LB + nlb) * 2 + ns, lo);
                     }
 #pragma unroll
-                    for (int rb = 0; rb < NRB; ++rb) z[rb] = mma6(w, qb[s][rb], z[rb]);
+                    for (int rb = 0; rb < NRB; ++rb) z[rb] = F::mm(w, qb[s][rb], z[rb]);
                 }
 #pragma unroll
-                for (int rb = 0; rb < NRB; ++rb)
+                for (int rb = 0; rb < NRB; ++rb) {
+                    if constexpr (F::SCALED) {                     // out of the scaled space (+ the other consumer's gradients of the same plane)
+                        if (ACC[lb]) z[rb] = z[rb] * ikg_sg + old[n][lb][rb];
+                        else z[rb] *= ikg_sg;
+                    }
                     *reinterpret_cast<f32x4*>(dP[n][lb] + (r0 + 16 * rb + x) * HID + 4 * g) = z[rb];
+                }
             }
-        X3 qd[2];
+        Op qd[2];
         {
             f32x4 Qd[NRB][2];
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) {
-                const X3& t = rb == 0 ? tb0 : tb1;
+                const Op& t = rb == 0 ? tb0 : tb1;
 #pragma unroll
-                for (int hb = 0; hb < 2; ++hb) Qd[rb][hb] = mma6(t, gd[hb], kZero4);
+                for (int hb = 0; hb < 2; ++hb) Qd[rb][hb] = F::mm(t, gd[hb], kZero4);
             }
 #pragma unroll
-            for (int hb = 0; hb < 2; ++hb) qd[hb] = split8(Qd[0][hb], Qd[1][hb]);
+            for (int hb = 0; hb < 2; ++hb) qd[hb] = F::split(Qd[0][hb], Qd[1][hb]);
         }
 #pragma unroll
         for (int n = 0; n < K; ++n)
 #pragma unroll
             for (int lb = 0; lb < LB; ++lb) {
                 const float (&zc)[NRB][4] = zg[n][lb];
-                const X3 za = split8(f32x4{zc[0][0], zc[0][1], zc[0][2], zc[0][3]}, f32x4{zc[1][0], zc[1][1], zc[1][2], zc[1][3]});
+                const Op za = F::split(f32x4{zc[0][0], zc[0][1], zc[0][2], zc[0][3]}, f32x4{zc[1][0], zc[1][1], zc[1][2], zc[1][3]});
 #pragma unroll
                 for (int c = 0; c < K; ++c)
 #pragma unroll
-                    for (int hb = 0; hb < 2; ++hb) dWg[n][lb][c][hb] = mma6(za, c == 0 ? gd[hb] : qd[hb], dWg[n][lb][c][hb]);
+                    for (int hb = 0; hb < 2; ++hb) dWg[n][lb][c][hb] = F::mm(za, c == 0 ? gd[hb] : qd[hb], dWg[n][lb][c][hb]);
             }
         cur = nxt;
         node = next_node;
     }
 
-    combine_dw<K, LB, 2, CB_WAVES>(reinterpret_cast<float*>(smem_raw), dWg, dbg, a.partial_g, a.Lw, a.want_dbg, PL == 2 ? cin : -1);
-    combine_dw<K, LB, 1, CB_WAVES>(reinterpret_cast<float*>(smem_raw), dWc, dbc, a.partial_c, a.Lw, a.want_dbc, PL == 2 ? cin : -1);
+    // dW tiles of block c carry sg (c = 0) or sg sT (c = 1: Q_1 = T_1 dY); db carries sg
+    const float isg = 1.f / sg, isgt = isg / sT;
+    combine_dw<K, LB, 2, CB_WAVES>(reinterpret_cast<float*>(smem_raw), dWg, dbg, a.partial_g, a.Lw, a.want_dbg, PL == 2 ? cin : -1, isg, isgt, isg);
+    combine_dw<K, LB, 1, CB_WAVES>(reinterpret_cast<float*>(smem_raw), dWc, dbc, a.partial_c, a.Lw, a.want_dbc, PL == 2 ? cin : -1, isg, isgt, isg);
 }
 
-template <int L, int PL, int ACCX = 0, int ACCH = 0>
+template <class F, int L, int PL, int ACCX = 0, int ACCH = 0>
 int launch_cell_bwd(const CellBwdArgs& a, int* n_partials, hipStream_t stream) {
     const size_t slabs = (size_t)CB_WAVES * (4 * L * 32 + 32) * sizeof(float);
-    const size_t lds = CB_LDS_BYTES > slabs ? CB_LDS_BYTES : slabs;
-    static_assert(CB_LDS_BYTES <= stc::kMaxLdsBytes, "tables + per-wave tiles must fit the CU's LDS");
+    const size_t lds = cb_lds_bytes<F>() > slabs ? cb_lds_bytes<F>() : slabs;
+    static_assert(cb_lds_bytes<F>() <= stc::kMaxLdsBytes, "tables + per-wave tiles must fit the CU's LDS");
     if (lds > stc::kMaxLdsBytes) return STC_NOT_HANDLED;
-    auto kern = cell_bwd_x3_kernel<L, PL, ACCX, ACCH>;
+    auto kern = cell_bwd_x3_kernel<F, L, PL, ACCX, ACCH>;
     if (int rc = stc::hip_status(stc::allow_lds(kern, lds), "hipFuncSetAttribute(cell bwd x3)")) return rc;
-    static const int resident = stc::resident_blocks(kern, CB_THREADS, lds, 1);
+    static const int resident = stc::resident_blocks(kern, CB_THREADS, lds, 1);      // (one static per instantiation)
     const long long want = (a.nodes + CB_WAVES - 1) / CB_WAVES;
     int grid = resident < MF_BWD_MAX_GRID ? resident : MF_BWD_MAX_GRID;
     if (want < grid) grid = (int)want;
@@ -392,23 +434,35 @@ int launch_cell_bwd(const CellBwdArgs& a, int* n_partials, hipStream_t stream) {
 
 int stc_cell_bwd_planar_shape_ok(int C, int h) { return C == 32 && h == 16; }
 
+template <class F>
+static int dispatch_cell_bwd(const CellBwdArgs& a, int cin, int accumulate_x, int accumulate_h, int* n_partials, hipStream_t stream) {
+    if (cin == 16) {
+        if (accumulate_x && accumulate_h) return launch_cell_bwd<F, 32, 1, 1, 1>(a, n_partials, stream);
+        if (accumulate_x) return launch_cell_bwd<F, 32, 1, 1, 0>(a, n_partials, stream);
+        if (accumulate_h) return launch_cell_bwd<F, 32, 1, 0, 1>(a, n_partials, stream);
+        return launch_cell_bwd<F, 32, 1>(a, n_partials, stream);
+    }
+    return accumulate_h ? launch_cell_bwd<F, 20, 2, 0, 1>(a, n_partials, stream) : launch_cell_bwd<F, 20, 2>(a, n_partials, stream);
+}
+
+// gmax != null selects the fp16 x 2 operand format (n_gmax >= 1 device floats whose maximum is max |dHnew| over the launch's rows, or any
+// upper bound of it within a factor 2^8); null keeps the bf16 x 3 format, which needs no range information.
 int stc_cell_bwd_planar_x3(const float* X, const float* H, const float* SX, const float* SH, const float* Tc, const float* Wg, const float* Wc,
                            const float* U, const float* R, const float* Cand, const float* dHnew, const float* dBm,
                            float* dX, float* dSX, float* dH, float* dSH, float* partial_g, float* partial_c, int* n_partials,
-                           int want_dbg, int want_dbc, int accumulate_x, int accumulate_h, long long nodes, int C, int Lw, hipStream_t stream) {
+                           int want_dbg, int want_dbc, int accumulate_x, int accumulate_h, const float* gmax, int n_gmax,
+                           long long nodes, int C, int Lw, hipStream_t stream) {
     const int cin = Lw - 16;
     if (!stc_cell_bwd_planar_shape_ok(C, 16) || nodes <= 0 || nodes >= (1ll << 31) / C || !(cin == 16 || (cin >= 1 && cin <= 4))) return STC_NOT_HANDLED;
     const float* wide[] = {H, SH, U, R, Cand, dHnew, dBm, dH, dSH};
     if (!all_aligned16(wide, 9)) return STC_NOT_HANDLED;
-    CellBwdArgs a{X, H, SX, SH, U, R, Cand, dHnew, dBm, Tc, Wg, Wc, dX, dSX, dH, dSH, partial_g, partial_c, (int)nodes, want_dbg, want_dbc, Lw};
+    CellBwdArgs a{X, H, SX, SH, U, R, Cand, dHnew, dBm, Tc, Wg, Wc, dX, dSX, dH, dSH, partial_g, partial_c, (int)nodes, want_dbg, want_dbc, Lw, gmax, n_gmax};
     if (cin == 16) {
         const float* more[] = {X, SX, dX, dSX};
         if (!dX || !dSX || !all_aligned16(more, 4)) return STC_NOT_HANDLED;
-        if (accumulate_x && accumulate_h) return launch_cell_bwd<32, 1, 1, 1>(a, n_partials, stream);
-        if (accumulate_x) return launch_cell_bwd<32, 1, 1, 0>(a, n_partials, stream);
-        if (accumulate_h) return launch_cell_bwd<32, 1, 0, 1>(a, n_partials, stream);
-        return launch_cell_bwd<32, 1>(a, n_partials, stream);
+    } else if (accumulate_x) {
+        return STC_NOT_HANDLED;       // a narrow input plane gets no gradient
     }
-    if (accumulate_x) return STC_NOT_HANDLED;       // a narrow input plane gets no gradient
-    return accumulate_h ? launch_cell_bwd<20, 2, 0, 1>(a, n_partials, stream) : launch_cell_bwd<20, 2>(a, n_partials, stream);
+    return gmax ? dispatch_cell_bwd<FmtH2>(a, cin, accumulate_x, accumulate_h, n_partials, stream)
+                : dispatch_cell_bwd<FmtB3>(a, cin, accumulate_x, accumulate_h, n_partials, stream);
 }

@@ -501,14 +501,17 @@ extern "C" int stc_cell_gates_fwd_planar_f32(const float* X, const float* H, con
                                              const float* Tc, const float* W, const float* bias,
                                              float* U, float* Rg, float* RH,
                                              const float* Wc, const float* bc, float* A, float* Bm,
+                                             int32_t operand_format,
                                              int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream) {
     if (int rc = check_dims("stc_cell_gates_fwd_planar_f32", 2, 2, C, Lw == 2 * h ? 2 * h : 20, Lw, 2 * h, nodes)) return rc;
+    STC_REQUIRE(operand_format == STC_FMT_BF16X3 || operand_format == STC_FMT_F16X2, STC_EINVAL,
+                "stc_cell_gates_fwd_planar_f32: operand_format %d (STC_FMT_BF16X3 or STC_FMT_F16X2)", operand_format);
     STC_REQUIRE(Lw == 2 * h || (Lw > h && Lw <= h + 4), STC_EINVAL, "stc_cell_gates_fwd_planar_f32: input width %d (Lw - h) must be h or 1..4", Lw - h);
     if (!stc_cell_planar_supported(2, 2, C, h)) return stc::fail(STC_EUNSUPPORTED, "stc_cell_gates_fwd_planar_f32: shape not on the planar path");
     if (nodes == 0) return STC_OK;
     STC_REQUIRE(X && H && SX && SH && Tc && W && U && Rg && (RH || A), STC_EINVAL, "stc_cell_gates_fwd_planar_f32: null pointer");
     STC_REQUIRE((A == nullptr) == (Bm == nullptr) && (!A || Wc), STC_EINVAL, "stc_cell_gates_fwd_planar_f32: A, Bm and Wc go together");
-    const int rc = stc_cell_gates_fwd_planar_x3(X, H, SX, SH, Tc, W, bias, U, Rg, RH, Wc, bc, A, Bm, nodes, C, Lw, static_cast<hipStream_t>(stream));
+    const int rc = stc_cell_gates_fwd_planar_x3(X, H, SX, SH, Tc, W, bias, U, Rg, RH, Wc, bc, A, Bm, operand_format, nodes, C, Lw, static_cast<hipStream_t>(stream));
     return rc == STC_NOT_HANDLED ? stc::fail(STC_EUNSUPPORTED, "stc_cell_gates_fwd_planar_f32: operands not usable (alignment)") : rc;
 }
 
@@ -564,10 +567,12 @@ extern "C" int stc_cell_bwd_planar_f32(const float* X, const float* H, const flo
                                        float* dX, float* dSX, float* dH, float* dSH,
                                        float* dWg, float* dbg, float* dWc, float* dbc,
                                        int32_t accumulate_x, int32_t accumulate_h,
+                                       const float* grad_amax, int32_t n_amax,
                                        void* workspace, size_t workspace_bytes,
                                        int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream) {
     const int L = Lw == 2 * h ? 2 * h : 20;
     if (int rc = check_dims("stc_cell_bwd_planar_f32", 2, 2, C, L, Lw, 2 * h, nodes)) return rc;
+    STC_REQUIRE(!grad_amax || n_amax >= 1, STC_EINVAL, "stc_cell_bwd_planar_f32: grad_amax with %d slots", n_amax);
     STC_REQUIRE(Lw == 2 * h || (Lw > h && Lw <= h + 4), STC_EINVAL, "stc_cell_bwd_planar_f32: input width %d (Lw - h) must be h or 1..4", Lw - h);
     if (!stc_cell_bwd_planar_supported(C, h)) return stc::fail(STC_EUNSUPPORTED, "stc_cell_bwd_planar_f32: C=%d h=%d is not built (C = 32, h = 16)", C, h);
     STC_REQUIRE(Wg && Wc && dWg && dWc && Tc, STC_EINVAL, "stc_cell_bwd_planar_f32: null W/dW/Tc");
@@ -591,7 +596,7 @@ extern "C" int stc_cell_bwd_planar_f32(const float* X, const float* H, const flo
     float* partial_c = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + bytes_g);
     int n_parts = 0;
     const int rc = stc_cell_bwd_planar_x3(X, H, SX, SH, Tc, Wg, Wc, U, Rg, Cand, dHnew, dBm, dX, dSX, dH, dSH, partial_g, partial_c, &n_parts,
-                                          dbg != nullptr, dbc != nullptr, accumulate_x != 0, accumulate_h != 0, nodes, C, Lw, s);
+                                          dbg != nullptr, dbc != nullptr, accumulate_x != 0, accumulate_h != 0, grad_amax, n_amax, nodes, C, Lw, s);
     if (rc == STC_NOT_HANDLED) return stc::fail(STC_EUNSUPPORTED, "stc_cell_bwd_planar_f32: operands not usable (alignment)");
     if (rc != STC_OK) return rc;
     if (int r2 = stc_node_reduce_partials(partial_g, n_parts, nWg, 2 * h, dWg, dbg, s)) return r2;

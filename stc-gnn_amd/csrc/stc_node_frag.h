@@ -208,7 +208,8 @@ __host__ __device__ __forceinline__ int stc_wrow_swapped(int col, int cin) {
 // [dW in W layout | db] per workgroup, which bdg_node_reduce_kernel then sums over workgroups.  (WAVES: waves per workgroup.)
 template <int K, int LB, int HB, int WAVES = MF_WAVES>
 __device__ __forceinline__ void combine_dw(float* smem, const f32x4 (&dWt)[K][LB][K][HB], const float (&dbp)[HB],
-                                           float* __restrict__ partial, int Lw, int want_db, int swapped_cin = -1) {
+                                           float* __restrict__ partial, int Lw, int want_db, int swapped_cin = -1,
+                                           float unscale0 = 1.f, float unscale1 = 1.f, float db_unscale = 1.f) {      // scaled operand formats: factor of the tiles of block c = 0 / c >= 1
     constexpr int Ho = 16 * HB;
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -227,14 +228,14 @@ __device__ __forceinline__ void combine_dw(float* smem, const f32x4 (&dWt)[K][LB
                     for (int r = 0; r < 4; ++r) {
                         const int col = 16 * lb + 4 * q + r;
                         const int l = swapped_cin < 0 ? col : stc_wrow_swapped(col, swapped_cin);      // slab column -> W row
-                        if (l >= 0 && l < Lw) slab[((n * K + c) * Lw + l) * Ho + 16 * hb + j] = dWt[n][lb][c][hb][r];
+                        if (l >= 0 && l < Lw) slab[((n * K + c) * Lw + l) * Ho + 16 * hb + j] = dWt[n][lb][c][hb][r] * (c == 0 ? unscale0 : unscale1);
                     }
 #pragma unroll
     for (int hb = 0; hb < HB; ++hb) {
         float v = dbp[hb];
         v += __shfl_xor(v, 16, 64);
         v += __shfl_xor(v, 32, 64);
-        if (q == 0) slab[nW + 16 * hb + j] = v;
+        if (q == 0) slab[nW + 16 * hb + j] = v * db_unscale;
     }
     __syncthreads();
     float* out = partial + (size_t)blockIdx.x * (nW + Ho);

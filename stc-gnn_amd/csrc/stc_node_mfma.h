@@ -87,6 +87,7 @@ int stc_node_post_fwd_x3(const float* X, const float* X2, const float* Tc, const
 int stc_cell_gates_fwd_planar_x3(const float* X, const float* H, const float* SX, const float* SH, const float* Tc, const float* W,
                                  const float* bias, float* U, float* R, float* RH,
                                  const float* Wc, const float* bc, float* A, float* Bm,      // A != null: + the candidate's projection (C = 32)
+                                 int fmt,                                                   // STC_FMT_*: operand format of the matrix-core products
                                  long long nodes, int C, int Lw, hipStream_t stream);
 int stc_cell_gates_bwd_planar_x3(const float* X, const float* H, const float* SX, const float* SH, const float* Tc, const float* W,
                                  const float* dCandIn, const float* Cand, const float* U, const float* R, const float* dHnew,
@@ -99,7 +100,8 @@ int stc_cell_bwd_planar_shape_ok(int C, int h);
 int stc_cell_bwd_planar_x3(const float* X, const float* H, const float* SX, const float* SH, const float* Tc, const float* Wg, const float* Wc,
                            const float* U, const float* R, const float* Cand, const float* dHnew, const float* dBm,
                            float* dX, float* dSX, float* dH, float* dSH, float* partial_g, float* partial_c, int* n_partials,
-                           int want_dbg, int want_dbc, int accumulate_x, int accumulate_h, long long nodes, int C, int Lw, hipStream_t stream);
+                           int want_dbg, int want_dbc, int accumulate_x, int accumulate_h, const float* gmax, int n_gmax,
+                           long long nodes, int C, int Lw, hipStream_t stream);
 
 // Planar cell convolutions of order K = 3 (stc_node_x3.hip): Zx[n] / Zh[n] = T_n(S) of the X-side / H-side plane; mode 1 gates, 2 candidate.
 int stc_cell_planar_k_shape_ok(int K, int C, int h);

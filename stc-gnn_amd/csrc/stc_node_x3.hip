@@ -86,10 +86,15 @@ struct GatherArgs {
 // is written without re-reading Xt and R*H from HBM.
 struct PostArgs { const float* Wc; const float* bc; float* A; float* Bm; };
 
-template <int NB2, int HB, int K, int L, int EPI, int GATHER, int PL = 0, int POST = 0>
+// F: operand format (stc_x3_frag.h).  FmtH2 (two fp16 pieces, three products): W and T_c are normalised per workgroup at table-fill time
+// (W's blocks c = 0 carry sW sT, blocks c >= 1 carry sW, T_c carries sT: projection and category mix then meet in one accumulator with the
+// common factor sW sT, taken out in the epilogue); activations enter as they are (bounded by construction).
+template <int NB2, int HB, int K, int L, int EPI, int GATHER, int PL = 0, int POST = 0, class F = FmtB3>
 __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_kernel(
     ZPtrs Z, const float* __restrict__ Tc, const float* __restrict__ W, const float* __restrict__ bias,
     float* __restrict__ Y, int nodes, int Lw, FwdEpi epi, GatherArgs ga, PostArgs post) {
+    using Op = typename F::Op;
+    constexpr int NP = F::NP;
     static_assert(!GATHER || K == 2, "the fused aggregation produces the first-order slab only");
     static_assert(!POST || (PL != 0 && EPI == EPI_GATES && K == 2), "the fused candidate projection belongs to the planar gates kernel");
     constexpr int KL = GATHER ? 1 : K;                  // slabs read from HBM
@@ -99,12 +104,23 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
     static_assert(EPI == EPI_NONE || (EPI == EPI_GATES && HB == 2) || (EPI == EPI_BLEND && HB == 1), "epilogue needs hidden = 16");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32x4* Wx = reinterpret_cast<u32x4*>(smem_raw);        // [K n][NCB]          B: W[(n, c, l = slot)][o = 16 hb + x]
-    u32x4* Tx = Wx + nWx * 3 * 64;                          // [K-1][NRB rb][NB2]  A: T_c[c' = 32 p + pair_row][d = 16 rb + x]
+    u32x4* Tx = Wx + nWx * NP * 64;                         // [K-1][NRB rb][NB2]  A: T_c[c' = 32 p + pair_row][d = 16 rb + x]
     constexpr int nWp = POST ? K * K : 0;                   // POST: [K n][K c]    B: Wc[(n, c, l = slot)][o = x]   (Ho = 16)
     constexpr int TRS = 20;                                 // row stride of the transpose tiles (16 + 4: conflict-free row reads)
-    u32x4* Wp = Tx + nTx * 3 * 64;
-    float* tr = reinterpret_cast<float*>(Wp + nWp * 3 * 64);   // POST: [wave][NRB][16 rows][TRS]  R*H, accumulator -> row layout
+    u32x4* Wp = Tx + nTx * NP * 64;
+    float* tr = reinterpret_cast<float*>(Wp + nWp * NP * 64);  // POST: [wave][NRB][16 rows][TRS]  R*H, accumulator -> row layout
     const int tid = threadIdx.x, lane = tid & 63, x = lane & 15, g = lane >> 4;
+
+    float sT = 1.f, sW = 1.f, sWp = 1.f;                    // FmtH2: powers of two from the tables' own maxima (same in every workgroup)
+    if constexpr (F::SCALED) {
+        float* scratch = reinterpret_cast<float*>(smem_raw);
+        if (K > 1) {
+            sT = pow2_scale(block_absmax(Tc + (size_t)C * C, (K - 1) * C * C, scratch, MF_THREADS), 0);
+            sT = fminf(fmaxf(sT, 0.0625f), 4096.f);         // W's block 0 carries sT as well: keep it inside fp16's range
+        }
+        sW = pow2_scale(block_absmax(W, K * K * Lw * Ho, scratch, MF_THREADS), 0);
+        if (POST) sWp = pow2_scale(block_absmax(post.Wc, K * K * Lw * 16, scratch, MF_THREADS), 0);
+    }
 
     for (int idx = tid; idx < nWx * 64; idx += MF_THREADS) {
         const int ll = idx & 63, f = idx >> 6, cb = f % NCB, n = f / NCB;
@@ -116,7 +132,7 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
             const int wl = PL == 2 ? stc_wrow_swapped(l, Lw - 16) : l;                // PL = 2: slab columns are [state | input | pad]
             v[e] = (wl >= 0 && wl < Lw) ? W[((size_t)(n * K + c) * Lw + wl) * Ho + o] : 0.f;       // pad columns contribute nothing
         }
-        put_frag(Wx, f, ll, v);
+        F::put(Wx, f, ll, v, c == 0 ? sW * sT : sW);
     }
     for (int idx = tid; idx < nWp * 64; idx += MF_THREADS) {      // the candidate's weights, same slab-column order (Ho = 16)
         const int ll = idx & 63, f = idx >> 6, c = f % K, n = f / K, gg = ll >> 4;
@@ -127,7 +143,7 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
             const int wl = PL == 2 ? stc_wrow_swapped(l, Lw - 16) : l;
             v[e] = (wl >= 0 && wl < Lw) ? post.Wc[((size_t)(n * K + c) * Lw + wl) * 16 + (ll & 15)] : 0.f;
         }
-        put_frag(Wp, f, ll, v);
+        F::put(Wp, f, ll, v, c == 0 ? sWp * sT : sWp);
     }
     for (int idx = tid; idx < nTx * 64; idx += MF_THREADS) {
         const int ll = idx & 63, f = idx >> 6, p = f % NB2, rb = (f / NB2) % NRB, c1 = f / (NB2 * NRB), gg = ll >> 4;
@@ -135,12 +151,13 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
 #pragma unroll
         for (int e = 0; e < 8; ++e)
             v[e] = Tc[(size_t)(c1 + 1) * C * C + (32 * p + pair_row(gg, e)) * C + 16 * rb + (ll & 15)];
-        put_frag(Tx, f, ll, v);
+        F::put(Tx, f, ll, v, sT);
     }
     __syncthreads();
 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nw = gridDim.x * MF_WAVES;
+    const float inv = 1.f / (sW * sT), invp = 1.f / (sWp * sT);       // (1 for FmtB3)
     float bv[HB];
 #pragma unroll
     for (int hb = 0; hb < HB; ++hb) bv[hb] = bias ? bias[16 * hb + x] : 0.f;
@@ -230,17 +247,17 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
         // project: U[rb][cb] += Z_n rows (A) * W_{n,c} (B)
 #pragma unroll
         for (int n = 0; n < K; ++n) {
-            X3 za[NRB];
+            Op za[NRB];
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) {
                 const Row8<L>& zr = (GATHER && n == 1) ? z1[rb] : cur[n < KL ? n : 0][rb];
-                za[rb] = split8(zr.a, zr.b);
+                za[rb] = F::split(zr.a, zr.b);
             }
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) {
-                const X3 w = get_frag(Wx, n * NCB + cb, lo);
+                const Op w = F::get(Wx, n * NCB + cb, lo);
 #pragma unroll
-                for (int rb = 0; rb < NRB; ++rb) acc[rb][cb] = mma6(za[rb], w, acc[rb][cb]);
+                for (int rb = 0; rb < NRB; ++rb) acc[rb][cb] = F::mm(za[rb], w, acc[rb][cb]);
             }
         }
 
@@ -251,11 +268,11 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
             for (int hb = 0; hb < HB; ++hb)
 #pragma unroll
                 for (int p = 0; p < NB2; ++p) {
-                    const X3 u = split8(acc[2 * p][(c1 + 1) * HB + hb], acc[2 * p + 1][(c1 + 1) * HB + hb]);
+                    const Op u = F::split(acc[2 * p][(c1 + 1) * HB + hb], acc[2 * p + 1][(c1 + 1) * HB + hb]);
 #pragma unroll
                     for (int rb = 0; rb < NRB; ++rb) {
-                        const X3 t = get_frag(Tx, (c1 * NRB + rb) * NB2 + p, lo);
-                        acc[rb][hb] = mma6(t, u, acc[rb][hb]);
+                        const Op t = F::get(Tx, (c1 * NRB + rb) * NB2 + p, lo);
+                        acc[rb][hb] = F::mm(t, u, acc[rb][hb]);
                     }
                 }
 
@@ -266,15 +283,15 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
                 for (int hb = 0; hb < HB; ++hb)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        Y[((size_t)node * C + 16 * rb + 4 * g + r) * Ho + 16 * hb + x] = acc[rb][hb][r] + bv[hb];
+                        Y[((size_t)node * C + 16 * rb + 4 * g + r) * Ho + 16 * hb + x] = F::SCALED ? fmaf(acc[rb][hb][r], inv, bv[hb]) : acc[rb][hb][r] + bv[hb];
         } else if (EPI == EPI_GATES) {
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const size_t row = (size_t)node * C + 16 * rb + 4 * g + r;
-                    const float u = fast_sigmoid(acc[rb][0][r] + bv[0]);
-                    const float gate = fast_sigmoid(acc[rb][HB - 1][r] + bv[HB - 1]);
+                    const float u = fast_sigmoid(F::SCALED ? fmaf(acc[rb][0][r], inv, bv[0]) : acc[rb][0][r] + bv[0]);
+                    const float gate = fast_sigmoid(F::SCALED ? fmaf(acc[rb][HB - 1][r], inv, bv[HB - 1]) : acc[rb][HB - 1][r] + bv[HB - 1]);
                     epi.U_out[row * HID + x] = u;
                     epi.R_out[row * HID + x] = gate;
                     if (PL) { if (!POST || epi.CandIn) epi.CandIn[row * HID + x] = gate * hv[rb][r]; }      // the R*H plane (optional with POST)
@@ -284,7 +301,7 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
             if constexpr (POST) {
                 // ---- candidate projection on [Xt | R*H] (PL = 1) / [R*H | x | pad] (PL = 2): A = sum_c T_c^T (. Wc_{0,c}) + bc, Bm likewise with Wc_{1,c}
                 __builtin_amdgcn_wave_barrier();
-                X3 zc[NRB];
+                Op zc[NRB];
 #pragma unroll
                 for (int rb = 0; rb < NRB; ++rb) {
                     // this lane's row of R*H, columns 8(g&1)..: EVERY lane reads the tile and the row fragments are chosen by VALUE.
@@ -305,26 +322,26 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
                             b4[i] = g < 2 ? tb[i] : 0.f;
                         }
                     }
-                    zc[rb] = split8(a4, b4);
+                    zc[rb] = F::split(a4, b4);
                 }
                 f32x4 pa[K][NRB][K];
 #pragma unroll
                 for (int n = 0; n < K; ++n)
 #pragma unroll
                     for (int c = 0; c < K; ++c) {
-                        const X3 w = get_frag(Wp, n * K + c, lo);
+                        const Op w = F::get(Wp, n * K + c, lo);
 #pragma unroll
-                        for (int rb = 0; rb < NRB; ++rb) pa[n][rb][c] = mma6(zc[rb], w, kZero4);
+                        for (int rb = 0; rb < NRB; ++rb) pa[n][rb][c] = F::mm(zc[rb], w, kZero4);
                     }
 #pragma unroll
                 for (int n = 0; n < K; ++n)
 #pragma unroll
                     for (int p = 0; p < NB2; ++p) {
-                        const X3 u = split8(pa[n][2 * p][1], pa[n][2 * p + 1][1]);
+                        const Op u = F::split(pa[n][2 * p][1], pa[n][2 * p + 1][1]);
 #pragma unroll
                         for (int rb = 0; rb < NRB; ++rb) {
-                            const X3 t = get_frag(Tx, rb * NB2 + p, lo);
-                            pa[n][rb][0] = mma6(t, u, pa[n][rb][0]);
+                            const Op t = F::get(Tx, rb * NB2 + p, lo);
+                            pa[n][rb][0] = F::mm(t, u, pa[n][rb][0]);
                         }
                     }
                 const float bcv = post.bc ? post.bc[x] : 0.f;
@@ -333,8 +350,8 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const size_t o = ((size_t)node * C + 16 * rb + 4 * g + r) * HID + x;
-                        post.A[o] = pa[0][rb][0][r] + bcv;
-                        post.Bm[o] = pa[1][rb][0][r];
+                        post.A[o] = F::SCALED ? fmaf(pa[0][rb][0][r], invp, bcv) : pa[0][rb][0][r] + bcv;
+                        post.Bm[o] = F::SCALED ? pa[1][rb][0][r] * invp : pa[1][rb][0][r];
                     }
                 __builtin_amdgcn_wave_barrier();
             }
@@ -353,7 +370,7 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const size_t e = ((size_t)node * C + 16 * rb + 4 * g + r) * HID + x;
-                    const float c = fast_tanh(acc[rb][0][r] + bv[0]);
+                    const float c = fast_tanh(F::SCALED ? fmaf(acc[rb][0][r], inv, bv[0]) : acc[rb][0][r] + bv[0]);
                     const float u = uv[rb][r];
                     hn[rb][r] = (1.f - u) * hv[rb][r] + u * c;
                     epi.Cand[e] = c;
@@ -1231,13 +1248,13 @@ __global__ __launch_bounds__(MF_THREADS, 1) void node_bwd2k_x3_kernel(
 }
 
 // --------------------------------------------------------------------------------------- host side
-template <int NB2, int HB, int K, int L, int EPI = EPI_NONE, int GATHER = 0, int PL = 0, int POST = 0>
+template <int NB2, int HB, int K, int L, int EPI = EPI_NONE, int GATHER = 0, int PL = 0, int POST = 0, class F = FmtB3>
 int launch_fwd(const float* const* Z, const float* Tc, const float* W, const float* bias, float* Y,
                long long nodes, int Lw, hipStream_t stream, FwdEpi epi = FwdEpi{}, GatherArgs ga = GatherArgs{}, PostArgs post = PostArgs{}) {
     constexpr int NRB = 2 * NB2, NCB = K * HB;
-    const size_t lds = (size_t)(K * NCB + (K - 1) * NRB * NB2 + (POST ? K * K : 0)) * 3 * 64 * 16 + (POST ? (size_t)MF_WAVES * NRB * 16 * 20 * 4 : 0);
+    const size_t lds = (size_t)(K * NCB + (K - 1) * NRB * NB2 + (POST ? K * K : 0)) * F::NP * 64 * 16 + (POST ? (size_t)MF_WAVES * NRB * 16 * 20 * 4 : 0);
     if (lds > stc::kMaxLdsBytes) return STC_NOT_HANDLED;
-    auto kern = node_fwd_x3_kernel<NB2, HB, K, L, EPI, GATHER, PL, POST>;
+    auto kern = node_fwd_x3_kernel<NB2, HB, K, L, EPI, GATHER, PL, POST, F>;
     if (int rc = stc::hip_status(stc::allow_lds(kern, lds), "hipFuncSetAttribute(node fwd x3)")) return rc;
     static const int resident = stc::resident_blocks(kern, MF_THREADS, lds, 2);   // persistent grid = what fits at once
     ZPtrs zp{};
@@ -1530,9 +1547,30 @@ int stc_node_post_fwd_x3(const float* X, const float* X2, const float* Tc, const
 }
 
 // ---- planar cell inputs (K = 2, rows of 16 + 16 columns): Z = {X plane, S.X plane, H plane, S.H plane} in launch order {p[0], p[1], q[0], q[1]}
+template <class F>
+static int gates_fwd_planar_go(const float* X, const float* H, const float* SX, const float* SH, const float* Tc, const float* W, const float* bias,
+                               const FwdEpi& epi, const PostArgs& post, bool fused, int cin, long long nodes, int C, int Lw, hipStream_t stream) {
+    if (cin == 16) {
+        const float* Z[4] = {X, SX, H, SH};
+        if (!all_aligned16(Z, 4)) return STC_NOT_HANDLED;
+        if (C == 32 && fused) return launch_fwd<1, 2, 2, 32, EPI_GATES, 0, 1, 1, F>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi, GatherArgs{}, post);
+        if (C == 32) return launch_fwd<1, 2, 2, 32, EPI_GATES, 0, 1, 0, F>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi);
+        if (C == 64 && fused) return launch_fwd<2, 2, 2, 32, EPI_GATES, 0, 1, 1, F>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi, GatherArgs{}, post);
+        if (C == 64) return launch_fwd<2, 2, 2, 32, EPI_GATES, 0, 1, 0, F>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi);
+        return STC_NOT_HANDLED;
+    }
+    const float* Z[4] = {H, SH, X, SX};          // narrow input: the STATE plane leads, columns [H | Xt | pad]
+    if (!stc::aligned16(H) || !stc::aligned16(SH)) return STC_NOT_HANDLED;
+    if (C == 32 && fused) return launch_fwd<1, 2, 2, 20, EPI_GATES, 0, 2, 1, F>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi, GatherArgs{}, post);
+    if (C == 32) return launch_fwd<1, 2, 2, 20, EPI_GATES, 0, 2, 0, F>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi);
+    if (C == 64 && fused) return launch_fwd<2, 2, 2, 20, EPI_GATES, 0, 2, 1, F>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi, GatherArgs{}, post);
+    if (C == 64) return launch_fwd<2, 2, 2, 20, EPI_GATES, 0, 2, 0, F>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi);
+    return STC_NOT_HANDLED;
+}
+
 int stc_cell_gates_fwd_planar_x3(const float* X, const float* H, const float* SX, const float* SH, const float* Tc, const float* W,
                                  const float* bias, float* U, float* R, float* RH,
-                                 const float* Wc, const float* bc, float* A, float* Bm,
+                                 const float* Wc, const float* bc, float* A, float* Bm, int fmt,
                                  long long nodes, int C, int Lw, hipStream_t stream) {
     const int cin = Lw - 16;
     const PostArgs post{Wc, bc, A, Bm};
@@ -1541,22 +1579,8 @@ int stc_cell_gates_fwd_planar_x3(const float* X, const float* H, const float* SX
     if (!x3_cell_shape(2, C, cin == 16 ? 32 : 20, nodes) || !(cin == 16 || (cin >= 1 && cin <= 4))) return STC_NOT_HANDLED;
     FwdEpi epi{};
     epi.H = H; epi.U_out = U; epi.R_out = R; epi.CandIn = RH; epi.cin = cin;
-    if (cin == 16) {
-        const float* Z[4] = {X, SX, H, SH};
-        if (!all_aligned16(Z, 4)) return STC_NOT_HANDLED;
-        if (C == 32 && fused) return launch_fwd<1, 2, 2, 32, EPI_GATES, 0, 1, 1>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi, GatherArgs{}, post);
-        if (C == 32) return launch_fwd<1, 2, 2, 32, EPI_GATES, 0, 1>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi);
-        if (C == 64 && fused) return launch_fwd<2, 2, 2, 32, EPI_GATES, 0, 1, 1>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi, GatherArgs{}, post);
-        if (C == 64) return launch_fwd<2, 2, 2, 32, EPI_GATES, 0, 1>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi);
-        return STC_NOT_HANDLED;
-    }
-    const float* Z[4] = {H, SH, X, SX};          // narrow input: the STATE plane leads, columns [H | Xt | pad]
-    if (!stc::aligned16(H) || !stc::aligned16(SH)) return STC_NOT_HANDLED;
-    if (C == 32 && fused) return launch_fwd<1, 2, 2, 20, EPI_GATES, 0, 2, 1>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi, GatherArgs{}, post);
-    if (C == 32) return launch_fwd<1, 2, 2, 20, EPI_GATES, 0, 2>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi);
-    if (C == 64 && fused) return launch_fwd<2, 2, 2, 20, EPI_GATES, 0, 2, 1>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi, GatherArgs{}, post);
-    if (C == 64) return launch_fwd<2, 2, 2, 20, EPI_GATES, 0, 2>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi);
-    return STC_NOT_HANDLED;
+    return fmt == STC_FMT_F16X2 ? gates_fwd_planar_go<FmtH2>(X, H, SX, SH, Tc, W, bias, epi, post, fused, cin, nodes, C, Lw, stream)
+                                : gates_fwd_planar_go<FmtB3>(X, H, SX, SH, Tc, W, bias, epi, post, fused, cin, nodes, C, Lw, stream);
 }
 
 int stc_cell_gates_bwd_planar_x3(const float* X, const float* H, const float* SX, const float* SH, const float* Tc, const float* W,

@@ -80,7 +80,20 @@ struct EpiArgs {
     const float* add[STC_SPMM_SUM_MAX_ADD]; int add_ld[STC_SPMM_SUM_MAX_ADD], add_off[STC_SPMM_SUM_MAX_ADD], n_add;
     float add_scale[STC_SPMM_SUM_MAX_ADD];   // SUM: Y = sum_i add_scale[i] add[i] + alpha S.(X [+ X2])
     const float *gU, *gCand; float* dYout;  // SUM, optional: also dY = Y * U * (1 - Cand^2), the blend backward of the cell that owns the state
+    unsigned* amax; int n_amax;             // SUM, optional: max |Y| of the launch as float bits, spread over n_amax slots (zero before the launch)
 };
+
+// SUM / SUM2 with ep.amax: every wave leaves the largest |Y| it produced in one of the slots (atomic max on the bits of a non-negative
+// float, which order like the values) -- the consumer of Y (stc_cell_bwd_planar_f32, fp16 x 2 operand format) takes the maximum over the
+// slots as the launch's gradient scale, without another pass over Y and without a host round trip.  Slots spread the atomics over lines.
+__device__ __forceinline__ void publish_amax(const EpiArgs& ep, float m) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) {
+        const unsigned slot = (blockIdx.x + blockIdx.y * gridDim.x + (threadIdx.x >> 6) * 7u) % (unsigned)ep.n_amax;
+        atomicMax(ep.amax + slot, __float_as_uint(m));
+    }
+}
 
 // one element of a [Xt | H | pad] row: l = column, e = (row, category) index, v = its gradient
 template <int MODE>
@@ -135,7 +148,7 @@ __device__ __forceinline__ void blend_piece(const EpiArgs& a, size_t rowg, int c
 
 // rowg = b*n_rows + row; ch = float4 index inside the row; acc = sum_j val_j X[col_j] for that piece
 template <int MODE>
-__device__ __forceinline__ void epilogue(const EpiArgs& a, size_t rowg, int F4, int ch, const float4& acc) {
+__device__ __forceinline__ void epilogue(const EpiArgs& a, size_t rowg, int F4, int ch, const float4& acc, float& amax) {     // amax: running max |Y| (SUM forms)
     const size_t o = rowg * F4 + ch;
     if (MODE == EP_PLAIN) {
         float4 r = make_float4(a.alpha * acc.x, a.alpha * acc.y, a.alpha * acc.z, a.alpha * acc.w);
@@ -157,6 +170,7 @@ __device__ __forceinline__ void epilogue(const EpiArgs& a, size_t rowg, int F4, 
             y.x = fmaf(sc, t.x, y.x); y.y = fmaf(sc, t.y, y.y); y.z = fmaf(sc, t.z, y.z); y.w = fmaf(sc, t.w, y.w);
         }
         nt_store4(a.Y + o, y);
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(y.x), fabsf(y.y))), fmaxf(fabsf(y.z), fabsf(y.w)));
         if (a.dYout) {
             const float4 u = *reinterpret_cast<const float4*>(a.gU + 4 * o), c = *reinterpret_cast<const float4*>(a.gCand + 4 * o);
             nt_store4(reinterpret_cast<float4*>(a.dYout) + o,
@@ -228,6 +242,7 @@ __global__ __launch_bounds__(SPMM_THREADS) void spmm_wave_row_kernel(
 
     const int tile = stc_xcd_tile(blockIdx.x, n_tiles);
     if (tile < 0) return;                       // whole workgroup leaves together
+    float wmax = 0.f;                           // SUM forms: largest |Y| this lane produced
     const int b = blockIdx.y;
     const int row0 = tile * SPMM_ROWS;
     const int nr = min(SPMM_ROWS, n_rows - row0);
@@ -313,10 +328,11 @@ __global__ __launch_bounds__(SPMM_THREADS) void spmm_wave_row_kernel(
 #pragma unroll
             for (int p = 0; p < VPT; ++p) {
                 const int ch = cb + lane + 64 * p;
-                if (ch < F4) epilogue<MODE>(ep, rowg, F4, ch, acc[p]);
+                if (ch < F4) epilogue<MODE>(ep, rowg, F4, ch, acc[p], wmax);
             }
         }
     }
+    if ((MODE == EP_SUM || MODE == EP_SUM2) && ep.amax) publish_amax(ep, wmax);
 }
 
 // ---- row-blocked (BCSR 4x1): one wave produces 4 consecutive output rows -----------------------------------------
@@ -350,6 +366,7 @@ __global__ __launch_bounds__(SPMM_THREADS) void spmm_bcsr_kernel(
 
     const int tile = stc_xcd_tile(blockIdx.x, n_tiles);
     if (tile < 0) return;
+    float wmax = 0.f;                           // SUM forms: largest |Y| this lane produced
     const int b = blockIdx.y;
     const int blk0 = tile * BC_BLOCKS;
     const int nb = min(BC_BLOCKS, n_blocks - blk0);
@@ -533,7 +550,7 @@ __global__ __launch_bounds__(SPMM_THREADS) void spmm_bcsr_kernel(
                                                              acc[r][p].z + pa[rp][p].z, acc[r][p].w + pa[rp][p].w);
                                 blend_piece(ep, rowg, ch, rowg * F4 + ch, y, pu[rp][p], ph[rp][p]);
                             } else {
-                                epilogue<MODE>(ep, rowg, F4, ch, acc[r][p]);
+                                epilogue<MODE>(ep, rowg, F4, ch, acc[r][p], wmax);
                             }
                         }
                     }
@@ -541,6 +558,7 @@ __global__ __launch_bounds__(SPMM_THREADS) void spmm_bcsr_kernel(
             }
         }
     }
+    if ((MODE == EP_SUM || MODE == EP_SUM2) && ep.amax) publish_amax(ep, wmax);
 }
 
 // ---- row-blocked, NARROW rows (F4 = F/4 in {1, 2, 4, 8, 16} float4 per row: the layer-0 input plane, C = 32 floats = 128 bytes) --------
@@ -863,9 +881,11 @@ extern "C" int stc_spmm_sum_f32(const int32_t* rowptr, const int32_t* colidx, co
                                 int32_t n_rows, int32_t n_cols, const float* X, const float* X2, float alpha,
                                 int32_t n_add, const float* const* add, const int32_t* add_ld, const int32_t* add_off, const float* add_scale,
                                 float* Y, const float* U, const float* Cand, float* dY,
+                                float* amax, int32_t n_amax,
                                 int32_t batch, int32_t C, int32_t h, void* stream) {
     const GraphArgs g{rowptr, colidx, val, blk_ptr, blk_cols, blk_vals};
     STC_REQUIRE(h == 16, STC_EUNSUPPORTED, "stc_spmm_sum_f32: hidden width %d (built for 16)", h);
+    STC_REQUIRE(!amax || n_amax >= 1, STC_EINVAL, "stc_spmm_sum_f32: amax with %d slots", n_amax);
     STC_REQUIRE(n_add >= 0 && n_add <= STC_SPMM_SUM_MAX_ADD && (n_add == 0 || (add && add_ld && add_off)), STC_EINVAL,
                 "stc_spmm_sum_f32: 0..%d addends, got %d", STC_SPMM_SUM_MAX_ADD, n_add);
     if (int rc = check_fused("stc_spmm_sum_f32", g, n_rows, n_cols, X, Y, batch, C, 0, h, 0)) return rc;      // (Y checked as the aligned "Y0" operand)
@@ -879,6 +899,7 @@ extern "C" int stc_spmm_sum_f32(const int32_t* rowptr, const int32_t* colidx, co
     STC_REQUIRE(!dY || (U && Cand && stc::aligned16(U) && stc::aligned16(Cand) && stc::aligned16(dY) && dY != Y), STC_EINVAL,
                 "stc_spmm_sum_f32: dY needs U and Cand (16-byte aligned, not aliasing Y)");
     ep.gU = U; ep.gCand = Cand; ep.dYout = dY;
+    ep.amax = reinterpret_cast<unsigned*>(amax); ep.n_amax = n_amax;
     ep.alpha = alpha;
     ep.n_add = n_add;
     for (int i = 0; i < n_add; ++i) {

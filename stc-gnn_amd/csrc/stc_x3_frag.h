@@ -99,6 +99,136 @@ __device__ __forceinline__ X3 get_frag(const u32x4* tab, int frag, int lo) {
     return r;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Second operand format: TWO fp16 pieces per fp32 value, a s = a_h + a_l (11 + 11 significant bits, s a power of two chosen per operand
+// class), and THREE piece products a_l b_h + a_h b_l + a_h b_h on v_mfma_f32_16x16x32_f16 -- half the matrix instructions of the bf16 x 3
+// scheme and 4-5 instead of 7 vector instructions per split pair of values.  fp16 x fp16 products are exact in the fp32 accumulator; what
+// is dropped is a_l b_l and the second rounding, <= 2^-22 |a||b| each (tools/probes/operand_format_error.py: 1.7-2.9e-7 on 32-term dot
+// products against float64, the fp32 fmaf chain of the reference 1.3-2.4e-7).  fp16 has 5 exponent bits: the low piece of a value below
+// 2^-3 is a subnormal, i.e. the pair carries an ABSOLUTE error floor of 2^-25, and values above 65504 do not exist.  Hence the scales:
+//   tables (W, T_c)     normalised per workgroup to a maximum in [1/2, 1) at table-fill time (max taken in the kernel, no host round trip);
+//   gradient operands   scaled into [2^3, 2^4) from the launch's gradient maximum, which the producing kernel leaves in device memory;
+//   activations         bounded by construction (gate outputs, states in (-1, 1), aggregates of those); an optional bound scales them DOWN only.
+// All scales are powers of two (exact), products of scaled operands are unscaled on the fp32 result.
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+
+struct X2 { u32x4 h, l; };          // 8 fp32 values as two fp16x8 pieces
+
+// 2^k with amax 2^k in [2^(t-1), 2^t); 1 for zero / subnormal / non-finite amax; |k| <= 100
+__device__ __forceinline__ float pow2_scale(float amax, int t) {
+    const int e = (int)((__float_as_uint(amax) >> 23) & 255u);          // amax in [2^(e-127), 2^(e-126))
+    if (e == 0 || e == 255) return 1.f;
+    int k = t - (e - 126);
+    k = k < -100 ? -100 : (k > 100 ? 100 : k);
+    return __uint_as_float((unsigned)(k + 127) << 23);
+}
+
+// v_cvt_pk_f16_f32 (round to nearest even), emitted by the COMPILER from the casts -- not inline assembly: an instruction that reads an
+// MFMA result must wait the architected number of cycles after the MFMA, which the compiler's hazard recogniser inserts for instructions it
+// knows and cannot insert for the operands of an asm block (found the hard way: with the conversions in asm, accumulator-fed splits read
+// half-written registers and results differed by 2e-5 from run to run).
+using f16x2 = __attribute__((ext_vector_type(2))) _Float16;
+__device__ __forceinline__ unsigned pk_f16(float a, float b) {
+    const f16x2 v = {(_Float16)a, (_Float16)b};
+    return __builtin_bit_cast(unsigned, v);
+}
+// a - float(h.lo) / a - float(h.hi): v_fma_mix_f32 reads an fp16 half as an operand of an fp32 fma -- ONE instruction, exact (the remainder
+// of a rounding is representable).  The compiler does not form it from C (it emits v_cvt_f32_f16 + v_sub_f32), hence asm; that is safe
+// here because h is the result of a compiler-emitted conversion OF a: by the time h exists, a has been readable for a while.
+__device__ __forceinline__ float minus_lo_h(float a, unsigned h) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(a));
+    return r;
+}
+__device__ __forceinline__ float minus_hi_h(float a, unsigned h) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(a));
+    return r;
+}
+
+struct FmtB3 {                      // three bf16 pieces, six products: range of fp32, no scales
+    static constexpr int NP = 3;
+    static constexpr bool SCALED = false;
+    using Op = X3;
+    static __device__ __forceinline__ Op split(const f32x4 a, const f32x4 b) { return split8(a, b); }
+    static __device__ __forceinline__ Op split_scaled(const f32x4 a, const f32x4 b, float, float) { return split8(a, b); }
+    static __device__ __forceinline__ f32x4 mm(const Op& A, const Op& B, f32x4 c) { return mma6(A, B, c); }
+    static __device__ __forceinline__ void put(u32x4* tab, int frag, int lane, const float (&v)[8], float) { put_frag(tab, frag, lane, v); }
+    static __device__ __forceinline__ Op get(const u32x4* tab, int frag, int lo) { return get_frag(tab, frag, lo); }
+};
+
+struct FmtH2 {                      // two fp16 pieces, three products: operands scaled per class (see above)
+    static constexpr int NP = 2;
+    static constexpr bool SCALED = true;
+    using Op = X2;
+    // level by level over the four pairs, as split8 (a dependent vector instruction issues 8 cycles after its producer):
+    // 4 conversions (half rate), 8 v_fma_mix_f32, 4 conversions = 26 issue cycles per pair against 41 for the bf16 x 3 split
+    static __device__ __forceinline__ Op split(const f32x4 a, const f32x4 b) {
+        const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        unsigned h[4], l[4];
+        float r[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) h[i] = pk_f16(v[2 * i], v[2 * i + 1]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { r[2 * i] = minus_lo_h(v[2 * i], h[i]); r[2 * i + 1] = minus_hi_h(v[2 * i + 1], h[i]); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) l[i] = pk_f16(r[2 * i], r[2 * i + 1]);
+        Op o;
+        o.h = u32x4{h[0], h[1], h[2], h[3]};
+        o.l = u32x4{l[0], l[1], l[2], l[3]};
+        return o;
+    }
+    // slots 0..3 = a * sa, slots 4..7 = b * sb (powers of two: exact).  Table fills only (once per workgroup), so the scale is a plain
+    // multiplication; v_fma_mixlo/hi_f16 would fold it into the conversion at the same issue cost (tools/probes/f16_split_rates.hip).
+    static __device__ __forceinline__ Op split_scaled(const f32x4 a, const f32x4 b, float sa, float sb) {
+        return split(a * sa, b * sb);
+    }
+    static __device__ __forceinline__ f32x4 mm1(const u32x4 a, const u32x4 b, const f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 mm(const Op& A, const Op& B, f32x4 c) {      // smallest terms first
+        c = mm1(A.l, B.h, c);
+        c = mm1(A.h, B.l, c);
+        c = mm1(A.h, B.h, c);
+        return c;
+    }
+    static __device__ __forceinline__ void put(u32x4* tab, int frag, int lane, const float (&v)[8], float s) {
+        const Op o = split_scaled(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]}, s, s);
+        tab[(frag * 2 + 0) * 64 + lane] = o.h;
+        tab[(frag * 2 + 1) * 64 + lane] = o.l;
+    }
+    static __device__ __forceinline__ Op get(const u32x4* tab, int frag, int lo) {
+        Op r;
+        r.h = tab[(frag * 2 + 0) * 64 + lo];
+        r.l = tab[(frag * 2 + 1) * 64 + lo];
+        return r;
+    }
+};
+
+// max |p[i]|, i < n, over the workgroup (every thread gets it); scratch: one float per wave of the workgroup, not otherwise in use.
+// Ends with a barrier: scratch may be reused right away.
+__device__ __forceinline__ float block_absmax(const float* __restrict__ p, int n, float* scratch, int threads) {
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n; i += threads) m = fmaxf(m, fabsf(p[i]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = m;
+    __syncthreads();
+    float r = 0.f;
+    for (int w = 0; w < threads / 64; ++w) r = fmaxf(r, scratch[w]);
+    __syncthreads();
+    return r;
+}
+
+// the launch's gradient maximum from the slots its producer filled (stc_spmm_sum_f32 amax / the caller): max over n floats, wave-uniform
+__device__ __forceinline__ float slots_max(const float* __restrict__ slots, int n) {
+    float m = 0.f;
+    for (int i = threadIdx.x & 63; i < n; i += 64) m = fmaxf(m, slots[i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(m)));      // (the builtin takes an int: pass the BITS, not the value)
+}
+
 // row of a pair of 16-row tiles that slot (g, e) of an accumulator-fed operand stands for
 __host__ __device__ constexpr int pair_row(int g, int e) { return 16 * (e >> 2) + 4 * g + (e & 3); }
 

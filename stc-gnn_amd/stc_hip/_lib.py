@@ -19,7 +19,8 @@ import torch
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG_ROOT, 'libstc_hip.so')
-ABI_VERSION = 13
+ABI_VERSION = 14
+FMT_BF16X3, FMT_F16X2 = 0, 1          # STC_FMT_* of include/stc_hip.h: operand formats of the split-operand matrix-core kernels
 MAX_K = 4
 SPMM_SUM_MAX_ADD = 8     # = STC_SPMM_SUM_MAX_ADD of include/stc_hip.h
 
@@ -85,13 +86,13 @@ def _declare(lib):
         'stc_head_fwd_bf16': [_p, _p, _p, _p, _i64, _i32, _p],
         'stc_head_bwd_bf16': [_p, _p, _p, _p, _p, _p, _p, C.c_size_t, _i64, _i32, _p],
         'stc_bdg_node_post_fwd_f32': [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
-        'stc_cell_gates_fwd_planar_f32': [_p] * 14 + [_i64, _i32, _i32, _i32, _p],
+        'stc_cell_gates_fwd_planar_f32': [_p] * 14 + [_i32, _i64, _i32, _i32, _i32, _p],
         'stc_cell_gates_bwd_planar_f32': [_p] * 11 + [C.POINTER(_p), _p, _p, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _p],
-        'stc_cell_bwd_planar_f32': [_p] * 20 + [_i32, _i32, _p, C.c_size_t, _i64, _i32, _i32, _i32, _p],
+        'stc_cell_bwd_planar_f32': [_p] * 20 + [_i32, _i32, _p, _i32, _p, C.c_size_t, _i64, _i32, _i32, _i32, _p],
         'stc_spmm_blend_fwd_f32': [_p] * 6 + [_i32, _i32] + [_p] * 6 + [_p, _i32, _i32, _p, _i32, _p, _i32, _i32] + [_i32] * 3 + [_p],
         'stc_bdg_node_post_bwd_f32': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _i32, _p],
         'stc_spmm_sum_f32': [_p] * 6 + [_i32, _i32, _p, _p, _f32, _i32, C.POINTER(_p), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_f32), _p, _p, _p, _p,
-                             _i32, _i32, _i32, _p],
+                             _p, _i32, _i32, _i32, _i32, _p],
         'stc_cell_gates_fwd_planar_k_f32': [C.POINTER(_p), C.POINTER(_p), _i32, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p],
         'stc_cell_cand_fwd_planar_k_f32': [C.POINTER(_p), C.POINTER(_p), _i32, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p],
         'stc_cell_gates_bwd_planar_k_f32': [C.POINTER(_p), C.POINTER(_p), _i32, _p, _p, _p, _p, _p, _p, _p, C.POINTER(_p), C.POINTER(_p), _p, _p, _p, _i32,
@@ -206,6 +207,9 @@ class HipKernels:
     name = 'hip-gfx950'
     #: the planar gates backward adds the state's share from its gate prologue into the H plane's gradient itself (dH=None)
     folds_dH = os.environ.get('STC_FOLD_DH', '1') != '0'
+    #: operand format of the split-operand matrix-core cell kernels (include/stc_hip.h "operand formats"): two fp16 pieces / three
+    #: products by default, STC_OPERAND_FORMAT=bf16x3 keeps three bf16 pieces / six products (fp32's range, twice the matrix instructions)
+    operand_format = {'f16x2': FMT_F16X2, 'bf16x3': FMT_BF16X3}[os.environ.get('STC_OPERAND_FORMAT', 'f16x2')]
 
     def __init__(self):
         self.lib = load_library()
@@ -390,10 +394,11 @@ class HipKernels:
                      nbytes=colidx.numel() * 8 + 4 * (n + 1) + 4 * B * n * Cc * (2 * (cin + h + pad) + (2 if addA is not None else 1) * cin
                                                                                   + (2 if addB is not None else 1) * h))
 
-    def spmm_sum(self, rowptr, colidx, val, plan, X, X2, addends, Y, blend=None, alpha=1.0):
+    def spmm_sum(self, rowptr, colidx, val, plan, X, X2, addends, Y, blend=None, alpha=1.0, amax=None):
         """Y = sum(scale * addend) + alpha * S.(X [+ X2]) on (B, n, C, h) state tensors (stc_spmm_sum_f32).  ``addends``: up to
         eight (tensor, column offset[, scale]) entries -- columns [off, off + h) of a (B, n, C, ld) tensor (a plain plane:
-        ld = h, off = 0); scale defaults to 1."""
+        ld = h, off = 0); scale defaults to 1.  ``amax``: float32 device tensor of slots, ZERO on entry; afterwards its maximum is
+        max |Y| (the ``grad_amax`` operand of ``cell_bwd_planar``)."""
         B, n, Cc, h = Y.shape
         self._f32('spmm_sum.Y', Y)
         self._f32('spmm_sum.X', X, (B, n, Cc, h))
@@ -413,10 +418,12 @@ class HipKernels:
             U, Cand, dY = blend
             for name, t in (('U', U), ('Cand', Cand), ('dY', dY)):
                 self._f32('spmm_sum.' + name, t, (B, n, Cc, h))
-        self._same_device(rowptr, colidx, val, X, X2, Y, U, Cand, dY, *[ent[0] for ent in addends])
+        if amax is not None:
+            self._f32('spmm_sum.amax', amax)
+        self._same_device(rowptr, colidx, val, X, X2, Y, U, Cand, dY, amax, *[ent[0] for ent in addends])
         g = self._graph_ptrs(rowptr, colidx, val, plan, n)
         self._launch('stc_spmm_sum_f32', Y, *g, n, n, _ptr(X), _ptr(X2), float(alpha), len(addends), ptrs, lds, offs, scales, _ptr(Y), _ptr(U), _ptr(Cand), _ptr(dY),
-                     B, Cc, h,
+                     _ptr(amax), 0 if amax is None else amax.numel(), B, Cc, h,
                      nbytes=colidx.numel() * 8 + 4 * (n + 1) + 4 * B * n * Cc * h * (2 + (X2 is not None) + len(addends) + (3 if blend else 0)))
 
     def csr_sddmm(self, rowptr, colidx, n_rows, n_cols, A, Bm, out, alpha, accumulate):
@@ -691,7 +698,7 @@ class HipKernels:
                 self._f32('planar.' + name, t, (R, Cc, h))
         self._same_device(X, H, SX, SH, Tc, W, bias, U, Rg, RH, Wc, bc, A, Bm)
         self._launch('stc_cell_gates_fwd_planar_f32', H, _ptr(X), _ptr(H), _ptr(SX), _ptr(SH), _ptr(Tc), _ptr(W), _ptr(bias),
-                     _ptr(U), _ptr(Rg), _ptr(RH), _ptr(Wc), _ptr(bc), _ptr(A), _ptr(Bm), R, Cc, cin + h, h)
+                     _ptr(U), _ptr(Rg), _ptr(RH), _ptr(Wc), _ptr(bc), _ptr(A), _ptr(Bm), self.operand_format, R, Cc, cin + h, h)
 
     def cell_gates_bwd_planar(self, X, H, SX, SH, Tc, W, dRH, Cand, U, Rg, dHnew, dZs, dW, db, dH):
         """``dRH``: gradient of the R*H plane; ``dZs`` = [d X plane, d SX plane, d H plane, d SH plane] (the first two
@@ -720,11 +727,14 @@ class HipKernels:
     def cell_bwd_planar_supported(self, Cc, h) -> bool:
         return os.environ.get('STC_FUSE_CELL_BWD', '1') != '0' and bool(self.lib.stc_cell_bwd_planar_supported(Cc, h))
 
-    def cell_bwd_planar(self, X, H, SX, SH, Tc, Wg, Wc, U, Rg, Cand, dHnew, dBm, dZs, dWg, dbg, dWc, dbc, accumulate_x=False, accumulate_h=False):
+    def cell_bwd_planar(self, X, H, SX, SH, Tc, Wg, Wc, U, Rg, Cand, dHnew, dBm, dZs, dWg, dbg, dWc, dbc, accumulate_x=False, accumulate_h=False,
+                        grad_amax=None):
         """Candidate (post-aggregation form) + gates backward of one planar cell step in one launch.  ``dBm`` = S^T dY with
         dY = dHnew U (1 - Cand^2) (the kernel re-forms dY itself); ``dZs`` = [dX, dSX, dH, dSH] gradient planes: dX = the candidate's
         plus the gates' share of the X plane, dH includes the gate prologue's share (dX, dSX None for a narrow input plane).
-        ``accumulate_x`` / ``accumulate_h``: the X-side / H-side planes already hold the state's other consumer's gradients; add to them."""
+        ``accumulate_x`` / ``accumulate_h``: the X-side / H-side planes already hold the state's other consumer's gradients; add to them.
+        ``grad_amax`` (fp16 x 2 operand format): float32 device tensor whose maximum is max |dHnew| -- what ``spmm_sum(amax=)`` left
+        when it produced dHnew; without it the maximum is taken here by one more pass over dHnew."""
         R, Cc, h, cin = self._planes('cell_bwd', X, H, SX, SH)
         self._f32('cell_bwd.Tc', Tc, (2, Cc, Cc))
         self._f32('cell_bwd.Wg', Wg, (4 * (cin + h), 2 * h))
@@ -747,9 +757,16 @@ class HipKernels:
         ws = self._get_workspace(H.device, self.lib.stc_cell_bwd_planar_workspace_bytes(Cc, 2 * h, h))
         if accumulate_x and cin != h:
             raise StcError('cell backward: accumulate_x with a narrow input plane (it gets no gradient)')
+        if self.operand_format == FMT_F16X2:
+            if grad_amax is None:
+                grad_amax = torch.linalg.vector_norm(dHnew, ord=float('inf')).reshape(1)
+            self._f32('cell_bwd.grad_amax', grad_amax)
+            self._same_device(H, grad_amax)
+        else:
+            grad_amax = None
         self._launch('stc_cell_bwd_planar_f32', H, _ptr(X), _ptr(H), _ptr(SX), _ptr(SH), _ptr(Tc), _ptr(Wg), _ptr(Wc), _ptr(U), _ptr(Rg), _ptr(Cand),
                      _ptr(dHnew), _ptr(dBm), *[_ptr(z) for z in dZs], _ptr(dWg), _ptr(dbg), _ptr(dWc), _ptr(dbc), int(bool(accumulate_x)), int(bool(accumulate_h)),
-                     _ptr(ws), ws.numel(), R, Cc, cin + h, h)
+                     _ptr(grad_amax), 0 if grad_amax is None else grad_amax.numel(), _ptr(ws), ws.numel(), R, Cc, cin + h, h)
 
     # ---- planar cell convolutions of Chebyshev order K = 3 ------------------------------------------------
     def cell_planar_k_supported(self, K, Cc, h) -> bool:

@@ -122,6 +122,16 @@ def allreduce_sum(x: torch.Tensor, group=None) -> torch.Tensor:
     return _AllReduceSum.apply(x, group)
 
 
+def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> None:
+    """Every rank starts from rank ``src``'s parameters and buffers.  Each rank builds the model from its own RNG state; the gradient
+    bucket only averages GRADIENTS, so without this the replicas would apply the same update to different points and drift apart."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t.data, src=src, group=group)
+
+
 def init_from_env(backend: str = None) -> tuple:
     """(rank, world, local_rank) from torchrun's environment; initialises the process group whenever the process was
     started by a launcher (``RANK`` is set) -- also for a single rank, so that a one-GPU ``torchrun`` run goes through the
@@ -137,6 +147,10 @@ def init_from_env(backend: str = None) -> tuple:
         local = 0
     if (world > 1 or 'RANK' in os.environ) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        # RCCL shares device buffers between the ranks of a node through IPC handles; this driver stack supports the dmabuf form only
+        # (without it: hipIpcGetMemHandle "invalid argument" at communicator set-up).  Set before the communicator exists, for every
+        # way a rank can be started (bench.py's own launcher, the driver's torchrun form, tools/train.py).
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         backend = backend or os.environ.get('STC_DIST_BACKEND')
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'

@@ -686,7 +686,8 @@ class _StcCellGraph(Function):
     @once_differentiable
     def backward(ctx, grad_stack):
         k = kernels()
-        if grad_stack.dtype == torch.bfloat16:
+        bf16_planes = grad_stack.dtype == torch.bfloat16
+        if bf16_planes:
             k = k.bf16
         op, Ks, schedule, outputs, cin, present, (B, N, C), n_saved = ctx.meta
         stack = ctx.out_stack_ref()
@@ -732,7 +733,18 @@ class _StcCellGraph(Function):
             pc['direct'] += [(t, 0) for t in direct]
             pc['agg'].append(aggregated)
 
-        def owed(kid, blend=None):
+        # fp16 x 2 operand format of the one-launch cell backward: the launch scales its gradient operands by a power of two taken from
+        # max |dHnew|, which the state-gradient SpMM that produces dHnew leaves in a row of slots (one zero fill per backward pass)
+        n_slots = 256
+        amax_rows = {}
+
+        def amax_slots(kid):
+            if 'all' not in amax_rows:
+                amax_rows['all'] = grad_stack.new_zeros(len(schedule), n_slots, dtype=torch.float32)
+            amax_rows[kid] = amax_rows['all'][kid]
+            return amax_rows[kid]
+
+        def owed(kid, blend=None, want_amax=False):
             """The gradient of state ``kid``; with ``blend`` = (U, Cand) of its cell also dY = gradient * U * (1 - Cand^2)."""
             base = G.pop(kid, None)                                  # from interleaved consumers / the outputs: a finished tensor
             pc = pieces.pop(kid, None)
@@ -752,7 +764,7 @@ class _StcCellGraph(Function):
             out = aggs[0].new_empty(B, N, C, h)
             dY = torch.empty_like(out) if blend is not None else None
             k.spmm_sum(*bwd, op.bwd_plan, aggs[0], aggs[1] if len(aggs) > 1 else None, add, out,
-                       blend=None if blend is None else (blend[0], blend[1], dY))
+                       blend=None if blend is None else (blend[0], blend[1], dY), **(dict(amax=amax_slots(kid)) if want_amax else {}))
             return out if blend is None else (out, dY)
 
         # Order 3: a consumer leaves direct planes d0 and the gradients d1, d2 of the S / T_2(S) planes; the source's gradient is
@@ -845,7 +857,8 @@ class _StcCellGraph(Function):
             post_form = n_saved[j] < 0 or (len(rest) == Ks + 1 and Ks > 1)     # candidate backward starts from dY = dHnew * U * (1 - Cand^2)
             if Ks == 3 and j in pieces:                              # an interleaved cell whose state order-3 planar cells consumed
                 G[j] = owed3(j)
-            dHnew, dY = owed(j, (U, Cand)) if post_form else (owed(j), None)
+            one_launch = n_saved[j] == -7 and not bf16_planes and getattr(k, 'operand_format', 0) == 1 and os.environ.get('STC_AMAX_FUSED', '1') != '0'
+            dHnew, dY = owed(j, (U, Cand), want_amax=one_launch) if post_form else (owed(j), None)
             dH = None if (n_saved[j] == -7 or (n_saved[j] < 0 and getattr(k, 'folds_dH', False))) else torch.empty_like(Hprev)
             if n_saved[j] == -7:                                     # planar cell, candidate + gates backward in ONE launch
                 Xp, SXp, SHp = rest
@@ -878,7 +891,7 @@ class _StcCellGraph(Function):
                 dHd, dSH, acc_h = planes_of_state(hs)
                 k.cell_bwd_planar(*rows((Xp, Hprev, SXp, SHp)), Tc, Wg, Wc, *rows((U, Rg, Cand, dHnew, dBm)),
                                   [None if t is None else t.view(B * N, C, h) for t in (dXd, dSX, dHd, dSH)], dWg, dbg, dWc, dbc,
-                                  accumulate_x=acc_x, accumulate_h=acc_h)
+                                  accumulate_x=acc_x, accumulate_h=acc_h, **(dict(grad_amax=amax_rows[j]) if j in amax_rows else {}))
                 for i, t in enumerate((dWg, dbg, dWc, dbc)):
                     add_to(acc[s_id], i, t)
                 continue

@@ -58,12 +58,15 @@ class Trainer:
                             hidden_dim=params['hidden_dim'], num_layers=params['nn_layers'],
                             out_horizon=params['pred_len'], graph_mode=graph_mode,
                             batch_sharded=self.world > 1 and graph_mode == 'dense-learned').to(dev)
+        sdist.broadcast_parameters(self.model)                          # every replica starts from rank 0's draw
         self.criterion = ComboLoss()
         self.bucket = sdist.GradBucket(self.model.parameters())        # every .grad is a view into one flat buffer
         self.hip_graph = bool(hip_graph) and self.world == 1 and str(dev).startswith('cuda')
         self.optimizer = optim.Adam(self.model.parameters(), lr=params['learn_rate'], weight_decay=params['decay_rate'],
                                     capturable=self.hip_graph)
         self._captured = {}                                           # batch shape -> [eager steps seen, graph, static x, static y, static loss]
+        self._capture_shape = None                                    # only the FIRST batch shape seen (the full batch) is captured
+        self._capture_stream = torch.cuda.Stream(dev) if self.hip_graph else None
 
     @property
     def checkpoint_path(self) -> str:
@@ -82,15 +85,24 @@ class Trainer:
 
     def _graphed_step(self, x_seq, y_true):
         key = (tuple(x_seq.shape), tuple(y_true.shape))
+        if self._capture_shape is None:
+            self._capture_shape = key
+        if key != self._capture_shape:                                # e.g. the ragged last batch of an epoch: a graph of its own would
+            return self._step(x_seq, y_true)                          # hold a second private pool of activations; it runs eagerly
         slot = self._captured.setdefault(key, [0, None, None, None, None])
         if slot[1] is None:
-            if slot[0] < 2:                                           # eager warm-up steps (they are real steps): optimizer state,
-                slot[0] += 1                                          # cached graph operands and workspaces exist before the capture
-                return self._step(x_seq, y_true)
+            if slot[0] < 2:                                           # eager warm-up steps (they are real steps), run on the stream the
+                slot[0] += 1                                          # capture will use: optimizer state, cached graph operands and that
+                cs = self._capture_stream                             # stream's kernel workspace all exist before the capture begins
+                cs.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(cs):
+                    loss = self._step(x_seq, y_true)
+                torch.cuda.current_stream().wait_stream(cs)
+                return loss
             slot[2], slot[3] = x_seq.clone(), y_true.clone()
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, stream=self._capture_stream):
                 slot[4] = self._step(slot[2], slot[3])
             slot[1] = graph
         slot[2].copy_(x_seq)
@@ -110,10 +122,17 @@ class Trainer:
                 total, seen, t0 = 0.0, 0, time.time()
                 for x_seq, y_true in data_loader[mode]:
                     n = y_true.shape[0]
-                    if self.world > 1:                                   # this rank's contiguous shard of the batch
+                    # fewer samples than ranks (a short last batch): decided from n, which every rank knows, BEFORE any collective --
+                    # every rank then runs the whole small batch (same gradient on every rank, so their mean is that gradient)
+                    replicated = self.world > 1 and n < self.world
+                    if self.world > 1 and not replicated:                # this rank's contiguous shard of the batch
                         x_seq = sdist.shard_batch(x_seq, self.rank, self.world, ragged=True)
                         y_true = sdist.shard_batch(y_true, self.rank, self.world, ragged=True)
-                    share = y_true.shape[0] / n
+                    share = 1.0 / self.world if replicated else y_true.shape[0] / n
+                    mgp = getattr(self.model, 'mix_graph_pair', None)
+                    sharded_graphs = bool(mgp is not None and getattr(mgp, 'batch_sharded', False))
+                    if replicated and sharded_graphs:
+                        mgp.batch_sharded = False                        # the batch sum is already complete on every rank
                     if mode == 'train' and self.hip_graph:
                         total += float(self._graphed_step(x_seq, y_true)) * n
                         seen += n
@@ -121,18 +140,16 @@ class Trainer:
                     with torch.set_grad_enabled(mode == 'train'):
                         if mode == 'train':
                             self.bucket.zero()                           # zero_grad() that keeps the bucket views
-                        if y_true.shape[0]:
+                        try:
                             loss = self.criterion(self._forward(x_seq), y_true)
                             if mode == 'train':
                                 # unequal shards (ragged last batch): weight by this rank's share so that the mean over
                                 # ranks of the bucket is the full-batch gradient; equal shards: the factor is exactly 1
                                 (loss if share * self.world == 1 else loss * (share * self.world)).backward()
                             loss = loss.detach()
-                        elif self.model.graph_mode == 'dense-learned':
-                            raise ValueError(f'batch of {n} samples on {self.world} ranks leaves a rank without samples: the learned '
-                                             'graphs need every rank in their forward all-reduce')
-                        else:                                            # more ranks than samples in a ragged last batch
-                            loss = torch.zeros((), device=y_true.device)
+                        finally:
+                            if replicated and sharded_graphs:
+                                mgp.batch_sharded = True
                         if mode == 'train':
                             self.bucket.allreduce_mean()                 # the one collective of a step (no-op on one rank)
                             self.optimizer.step()
@@ -181,10 +198,20 @@ class Trainer:
         from . import metrics as smetrics
         for mode in modes:
             pred, truth = [], []
-            with torch.no_grad():
-                for x_seq, y_true in data_loader[mode]:
-                    pred.append(self._forward(x_seq))
-                    truth.append(y_true)
+            # every rank evaluates the WHOLE batches (the forecasts are wanted whole on rank 0, and evaluation is a forward pass only):
+            # the learned graphs' batch sum is then complete on each rank and must not be all-reduced again
+            mgp = getattr(self.model, 'mix_graph_pair', None)
+            sharded_graphs = bool(mgp is not None and getattr(mgp, 'batch_sharded', False))
+            if sharded_graphs:
+                mgp.batch_sharded = False
+            try:
+                with torch.no_grad():
+                    for x_seq, y_true in data_loader[mode]:
+                        pred.append(self._forward(x_seq))
+                        truth.append(y_true)
+            finally:
+                if sharded_graphs:
+                    mgp.batch_sharded = True
             pred_d, truth_d = torch.cat(pred, 0), torch.cat(truth, 0)        # stay on the device for the evaluation
             pred, truth = pred_d.cpu().numpy(), truth_d.cpu().numpy()
             eps = 1e-7

@@ -176,11 +176,14 @@ def _worker_trainer(rank, world, port, out_dir):
     data, params = pipeline_inputs()
     params = dict(params, output_dir=out_dir, _allow_cpu_for_tests=True)
     loaders = sdata.get_data_loader(params, data, params['obs_len'], params['pred_len'], params['split_ratio'])
-    torch.manual_seed(123)                                                # same initial parameters on every rank
-    trainer = Trainer(params, data)
+    torch.manual_seed(123 if rank == 0 else 1000 + rank)                  # rank 0 draws the reference's initial parameters; the other
+    trainer = Trainer(params, data)                                       # ranks draw different ones and must receive rank 0's (broadcast)
     assert trainer.world == world and trainer.model.mix_graph_pair.batch_sharded
     hist = trainer.train(loaders, verbose=False)
-    torch.save({'hist': hist, 'flat': torch.cat([p.detach().flatten() for p in trainer.model.parameters()])},
+    test = trainer.test(loaders)['test']
+    assert trainer.model.mix_graph_pair.batch_sharded                     # restored after the whole-batch evaluation
+    torch.save({'hist': hist, 'flat': torch.cat([p.detach().flatten() for p in trainer.model.parameters()]),
+                'forecast': test['forecast'], 'bce': test['bce']},
                os.path.join(out_dir, f'rank{rank}.pt'))
     dist.barrier()
     dist.destroy_process_group()
@@ -201,6 +204,22 @@ def test_two_rank_trainer_reproduces_the_reference_epoch_losses(tmp_path):
         assert np.allclose(got[r]['hist']['loss']['validate'], g['val_curve'].numpy(), rtol=0, atol=3e-5), got[r]['hist']['loss']
     assert torch.equal(got[0]['flat'], got[1]['flat'])
     assert os.path.exists(tmp_path / 'STC-GNN-4.pkl')                     # written once, by rank 0
+    # Trainer.test() under two ranks = the one-rank evaluation of the same checkpoint: every rank runs the whole batches, so the
+    # learned graphs' batch sum must NOT be all-reduced again (it would come out world times too large before the softmax)
+    from oracle.kernel_emul import EmulatedKernels
+    from stc_hip import data as sdata, ops
+    from stc_hip.trainer import Trainer
+    from tests.golden.make_golden import pipeline_inputs
+    ops._kernels = EmulatedKernels()
+    try:
+        data, params = pipeline_inputs()
+        params = dict(params, output_dir=str(tmp_path), _allow_cpu_for_tests=True)
+        loaders = sdata.get_data_loader(params, data, params['obs_len'], params['pred_len'], params['split_ratio'])
+        one = Trainer(params, data).test(loaders)['test']
+    finally:
+        ops._kernels = None
+    for r in range(world):
+        assert np.abs(got[r]['forecast'] - one['forecast']).max() < 1e-6 and abs(got[r]['bce'] - one['bce']) < 1e-6
 
 
 def test_ragged_shards_cover_the_batch():

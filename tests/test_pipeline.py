@@ -278,7 +278,7 @@ rank, world, local = sdist.init_from_env()
 data, params = pipeline_inputs()
 params = dict(params, device=f'cuda:{local}', output_dir=os.environ['STC_OUT'])
 loaders = sdata.get_data_loader(params, data, params['obs_len'], params['pred_len'], params['split_ratio'])
-torch.manual_seed(123)
+torch.manual_seed(123 if rank == 0 else 1000 + rank)      # the other ranks must receive rank 0's parameters (broadcast in Trainer)
 trainer = Trainer(params, data)
 hist = trainer.train(loaders, verbose=False)
 flat = torch.cat([p.detach().flatten() for p in trainer.model.parameters()]).double()
