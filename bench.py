@@ -22,10 +22,16 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                 ``aggregate`` beside it = every aggregation launch of the step (plain, GRU blend in the epilogue,
                 state-gradient sums) with every operand counted once; ``unit_d3`` = the exact 8(d3) unit (B = 1,
                 F = C*L = 1024) timed cold, >= 50 launches, in this same process after the timed steps
-  kernels       time share of every C-ABI entry point over the timed steps (same events)
   step_breakdown  forward+backward / all-reduce / Adam milliseconds per step (HIP events), and what the per-launch
                 event records cost (the same step re-timed with the timer off)
-  cpu_baseline  the CPU oracle (oracle/stc_oracle.py) on a bounded sample: 1 warm-up + 3 timed shots, median
+                ``dominant`` = the entry point with the largest share of the step (the one-launch cell backward), its algorithmic
+                plane bytes / its mean launch duration; ``mfma`` = matrix-pipe / vector-pipe busy fractions of the projection
+                kernels from the committed PMC pass (profiles/r03/mfma_util.json), quoted only for the same kernel sources
+  kernels       time share of every C-ABI entry point over the timed steps (same events)
+  cpu_baseline  the CPU oracle (oracle/stc_oracle.py) on a bounded sample: 2 warm-up + 7 timed shots, median
+
+``--preset cfg4 | cfg5 | sf`` selects BASELINE.json's other configurations (same schema, not the metric); ``--preset cfg2`` times the single
+BDG_Dif layer of configuration 2.  ``--global-batch G`` fixes the total batch (strong scaling: G / N samples per GPU).
 """
 import argparse
 import json
@@ -41,6 +47,7 @@ PLAIN_SPMM = ('stc_bcsr_spmm_f32', 'stc_bcsr_spmm_bf16')
 SPMM_ENTRY_POINTS = ('stc_bcsr_spmm_f32', 'stc_csr_spmm_f32', 'stc_spmm_sum_f32', 'stc_spmm_blend_fwd_f32',
                      'stc_bcsr_spmm_bf16', 'stc_csr_spmm_bf16', 'stc_spmm_sum_bf16', 'stc_spmm_blend_fwd_bf16')
 METRIC = 'STC-GNN fwd+bwd samples/sec at N=50k,C=32; SpMM HBM GB/s vs peak, 1/8 GPU'
+CPU_WARMUP, CPU_TIMED = 2, 7    # 2 warm-up + 7 timed iterations, median
 
 
 def parse(argv=None):
@@ -55,7 +62,12 @@ def parse(argv=None):
     ap.add_argument('--layers', type=int, default=2)
     ap.add_argument('--obs', type=int, default=18)
     ap.add_argument('--pred', type=int, default=6)
-    ap.add_argument('--batch-per-gpu', type=int, default=5, help='samples per GPU (weak scaling); 38 GB of saved activations per sample: 5 = 189 GB of the 288 GB (6 fits too: 227 GB)')
+    ap.add_argument('--batch-per-gpu', type=int, default=5, help='samples per GPU (weak scaling); ~30 GB of saved activations per sample')
+    ap.add_argument('--global-batch', type=int, default=0, help='total batch over all GPUs (strong scaling: each rank takes global-batch / gpus samples); 0 = weak scaling')
+    ap.add_argument('--preset', choices=('cfg2', 'cfg4', 'cfg5', 'sf'), default=None,
+                    help="BASELINE.json's other configurations through the same bench (not the metric): cfg4 = N 10 000, K = 3, batch 4; cfg5 = C = 64, "
+                         'bf16 state storage; sf = the SF-incidents shape (N = 100, C = 5, T = 9 + 3, batch 32, fixed sparse graph); cfg2 = one BDG_Dif layer '
+                         '(B = 32, N = 200, C = 8, L = 32, Ho = 32), forward and forward + backward')
     ap.add_argument('--permute', action='store_true', help='random node order (seed 1234) instead of row-major')
     ap.add_argument('--no-reorder', action='store_true', help='keep the given node order (skip the internal RCM renumbering)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -66,7 +78,18 @@ def parse(argv=None):
     ap.add_argument('--storage', choices=('f32', 'bf16'), default='f32',
                     help='storage type of states / gates / their gradients: f32 = the metric (reference arithmetic); bf16 = BASELINE configuration 5 '
                          '(not the metric: bf16 has no reference behaviour), fp32 parameters and fp32 sums inside every kernel')
-    return ap.parse_args(argv)
+    a = ap.parse_args(argv)
+    if a.preset == 'cfg4':
+        a.grid, a.order, a.batch_per_gpu = 100, 3, 4
+    elif a.preset == 'cfg5':
+        a.categories, a.storage, a.no_cpu_baseline = 64, 'bf16', True
+    elif a.preset == 'sf':
+        a.grid, a.categories, a.obs, a.pred, a.batch_per_gpu, a.no_unit_d3 = 10, 5, 9, 3, 32, True
+    if a.global_batch:
+        if a.global_batch % a.gpus:
+            ap.error(f'--global-batch {a.global_batch} is not divisible by --gpus {a.gpus}: shards must be equal')
+        a.batch_per_gpu = a.global_batch // a.gpus
+    return a
 
 
 def self_launch(a) -> int:
@@ -93,7 +116,7 @@ def _median(xs):
 
 
 def cpu_baseline(a, GsT_sparse, Gc, sd_cpu):
-    """Oracle fwd+bwd on the host cores for a bounded sample of the same workload: 1 warm-up + 3 timed, median.
+    """Oracle fwd+bwd on the host cores for a bounded sample of the same workload: 2 warm-up + 7 timed, median.
 
     Sample: one STC_Cell of each kind the model has (layer 0: 1 + 16 input columns; the others: 16 + 16), batch 1, same
     graph / width / parameters, forward + backward through ``oracle.stc_cell``; a full sample is ``layers * (obs + pred)``
@@ -116,12 +139,12 @@ def cpu_baseline(a, GsT_sparse, Gc, sd_cpu):
         R = torch.rand(1, N, C, h, generator=g)
         p = [sd_cpu[f'{prefix}.{n}'].clone().requires_grad_() for n in ('gates.W', 'gates.b', 'candi.W', 'candi.b')]
         ts = []
-        for shot in range(4):
+        for shot in range(CPU_WARMUP + CPU_TIMED):
             t0 = time.perf_counter()
             out = O.stc_cell(GsT_sparse, Gc, Xt, H, *p, K, K, conv=O.bdg_dif_sparse)
             (out * R).sum().backward()
             ts.append(time.perf_counter() - t0)
-        return _median(ts[1:]), ts
+        return _median(ts[CPU_WARMUP:]), ts
 
     t0, shots0 = one_cell('encoder.cell_list.0', 1)
     t1, shots1 = one_cell('encoder.cell_list.1' if a.layers > 1 else 'decoder.cell_list.0', h)
@@ -130,7 +153,7 @@ def cpu_baseline(a, GsT_sparse, Gc, sd_cpu):
     per_sample = n0 * t0 + n1 * t1
     out = dict(value=1.0 / per_sample, unit='samples/s', cores=threads, kind='port',
                sample=f'oracle.stc_cell (torch CPU, sparse feature-side variant) fwd+bwd, batch 1, same graph/width/parameters: one layer-0 cell '
-                      f'(median {t0:.2f} s) and one 16+16 cell (median {t1:.2f} s), 1 warm-up + 3 timed each; a sample = {n0} + {n1} such cells '
+                      f'(median {t0:.2f} s) and one 16+16 cell (median {t1:.2f} s), {CPU_WARMUP} warm-up + {CPU_TIMED} timed each; a sample = {n0} + {n1} such cells '
                       f'= {per_sample:.0f} s',
                shots_s=dict(layer0=[round(t, 3) for t in shots0], wide=[round(t, 3) for t in shots1]))
     if not os.environ.get('STC_BENCH_NO_DENSE_ANCHOR'):
@@ -157,13 +180,19 @@ def cpu_baseline(a, GsT_sparse, Gc, sd_cpu):
     return out
 
 
-def spmm_unit_d3(graph, dev, C, L, dtype, launches=60, rotate=6):
-    """SURVEY 8(d3)'s unit of work exactly: one application Y = S^T X over rows of F = C*L values, B = 1, timed COLD
-    (operands rotated over ``rotate`` buffer pairs >> the 256 MiB Infinity Cache) with HIP events on the launch stream."""
+def spmm_unit_d3(graph, dev, C, L, dtype, launches=60, rotate=6, reorder=True):
+    """SURVEY 8(d3)'s unit of work exactly: one application of the FORWARD operand, Y = S.X with S = Gs^T (reference STC_GNN.py:37),
+    over rows of F = C*L values, B = 1, timed COLD (operands rotated over ``rotate`` buffer pairs >> the 256 MiB Infinity Cache)
+    with HIP events on the launch stream.  The graph is taken in the node order the timed step uses: the internally renumbered
+    copy (``with_locality``) when the model renumbers, the given order otherwise."""
     import torch
     from stc_hip import ops
     from stc_hip.graph import csr_operand
     k = ops.kernels()
+    renumbered = False
+    if reorder:
+        g2, order = graph.with_locality()
+        renumbered, graph = order is not None, g2
     op = csr_operand(graph, dev)
     N, F = graph.n, C * L
     Xs = [torch.randn(1, N, F, device=dev).to(dtype) for _ in range(rotate)]
@@ -184,7 +213,9 @@ def spmm_unit_d3(graph, dev, C, L, dtype, launches=60, rotate=6):
     torch.cuda.synchronize(dev)
     us = 1e3 * s.elapsed_time(e) / launches
     nbytes = graph.nnz * 8 + 4 * (N + 1) + 2 * N * F * Xs[0].element_size()
-    return dict(what=f'Y = S^T X, B=1, F=C*L={F}, N={N}, nnz={graph.nnz}, {launches} cold launches (operands rotated over {rotate} x {2 * N * F * Xs[0].element_size() / 1e6:.0f} MB)',
+    return dict(what=f'Y = S.X (S = Gs^T, the forward operand), B=1, F=C*L={F}, N={N}, nnz={graph.nnz}, node order '
+                     f'{"renumbered internally (as the timed step)" if renumbered else "as given (as the timed step)"}, {launches} cold launches '
+                     f'(operands rotated over {rotate} x {2 * N * F * Xs[0].element_size() / 1e6:.0f} MB)',
                 algorithmic_bytes=nbytes, avg_launch_us=us, achieved=nbytes / us / 1e3, unit='GB/s', frac=nbytes / us / 1e3 / HBM_PEAK_GBPS,
                 target_frac=0.40)
 
@@ -205,26 +236,47 @@ def pmc_traffic(a, config_key):
     """HBM bytes per plain SpMM launch from a PMC pass over THIS command (tools/gpu_pmc_bench.sh: FETCH_SIZE and WRITE_SIZE
     in separate ``rocprofv3 --pmc`` runs), quoted only if the file was collected on the same kernel sources (csrc_sha)
     and the same configuration; otherwise null.  Never a number from an older build."""
-    path = os.path.join(REPO, 'profiles', 'r02', 'hbm_traffic_bench.json')
+    path = os.path.join(REPO, 'profiles', 'r03', 'hbm_traffic_bench.json')
     if not os.path.exists(path):
         return None, None
     with open(path) as fh:
         doc = json.load(fh)
     if doc.get('csrc_sha') != csrc_sha() or doc.get('config_key') != config_key:
-        return None, f'profiles/r02/hbm_traffic_bench.json is from other sources/configuration ({doc.get("csrc_sha")}, {doc.get("config_key")}): not quoted'
+        return None, f'profiles/r03/hbm_traffic_bench.json is from other sources/configuration ({doc.get("csrc_sha")}, {doc.get("config_key")}): not quoted'
     import re
     ks = [v for name, v in doc['kernels'].items() if re.match(r'spmm_bcsr_kernel<\d+, 0,', name)]      # MODE = 0 (EP_PLAIN): the plain launches only
     if not ks:
         return None, None
     traffic = sum(v['hbm_bytes_per_launch'] * v['launches'] for v in ks) / sum(v['launches'] for v in ks)
     return traffic, ('PMC (FETCH_SIZE, WRITE_SIZE in separate rocprofv3 --pmc passes, unit-corrected as MI355X_MICROARCH.md prescribes), mean over the '
-                     f'spmm_bcsr_kernel launches of one step of this command on these sources (csrc {doc["csrc_sha"]}): profiles/r02/hbm_traffic_bench.json')
+                     f'spmm_bcsr_kernel launches of one step of this command on these sources (csrc {doc["csrc_sha"]}): profiles/r03/hbm_traffic_bench.json')
+
+
+def pmc_mfma(config_key):
+    """Matrix-pipe / vector-pipe busy fractions of the projection kernels (the split-operand MFMA cell kernels) from the committed
+    ``rocprofv3 --pmc`` passes over THIS command (tools/gpu_pmc_mfma.sh -> profiles/r03/mfma_util.json): quoted only while the
+    file's kernel-source hash and configuration equal the running tree's, else null with a note."""
+    path = os.path.join(REPO, 'profiles', 'r03', 'mfma_util.json')
+    if not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        doc = json.load(fh)
+    if doc.get('csrc_sha') != csrc_sha() or doc.get('config_key') != config_key:
+        return {'value': None, 'note': f'profiles/r03/mfma_util.json is from other sources/configuration ({doc.get("csrc_sha")}, {doc.get("config_key")}): not quoted'}
+    keep = {name: {'launches': v['launches'], 'mfma_busy': v['mfma_util'], 'valu_busy': v['valu_busy']} for name, v in doc['kernels'].items()
+            if 'cell_bwd' in name or 'node_fwd' in name or 'node_bwd' in name}
+    return {'source': 'committed', 'file': 'profiles/r03/mfma_util.json', 'csrc_sha': doc['csrc_sha'],
+            'definition': doc.get('definition'),
+            'peak_note': 'busy fraction of the matrix pipe while the kernel runs; 1.0 = the dense MFMA peak of the instruction in use',
+            'kernels': keep}
 
 
 def main():
     a = parse()
     if a.gpus > 1 and 'RANK' not in os.environ:
         sys.exit(self_launch(a))            # before torch / the GPU are touched: the ranks are children of this process
+    if a.preset == 'cfg2':
+        return bench_cfg2(a)
 
     for _p in (REPO, os.path.join(REPO, 'stc-gnn_amd')):
         if _p not in sys.path:
@@ -374,7 +426,7 @@ def main():
             'kernel': 'spmm_bcsr_kernel (C-ABI stc_bcsr_spmm_' + a.storage + '): the plain aggregation launches Y = S.X of the timed train steps '
                       f'(S.state forward, S^T.dY backward; rows of C*hidden = {C * a.hidden} values, {B} samples per launch)',
             'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS,
-            'traffic': traffic, 'traffic_note': traffic_note,
+            'traffic': traffic, 'traffic_source': 'committed' if traffic is not None else None, 'traffic_note': traffic_note,
             'launches': plain['launches'], 'avg_launch_us': 1e3 * plain['ms'] / max(1, plain['launches']),
             'algorithmic_bytes_per_launch': plain['bytes'] / max(1, plain['launches']),
             'bytes_formula': 'nnz*8 + 4*(N+1) + 2*B*N*F*sizeof(x)  (SURVEY 8(d3))',
@@ -384,18 +436,35 @@ def main():
                           'avg_launch_us': 1e3 * every['ms'] / max(1, every['launches']),
                           'algorithmic_bytes_per_launch': every['bytes'] / max(1, every['launches'])},
         }
+        dom_name = max(per_kernel, key=lambda n: per_kernel[n]['ms']) if per_kernel else None
+        if dom_name is not None:
+            dk = per_kernel[dom_name]
+            dom = {'entry_point': dom_name, 'share_of_kernel_time': dk['ms'] / total_ms, 'launches': dk['launches'],
+                   'avg_launch_us': 1e3 * dk['ms'] / max(1, dk['launches'])}
+            if dk['bytes']:
+                dom.update(algorithmic_bytes_per_launch=dk['bytes'] / max(1, dk['launches']), achieved=rate(dk), unit='GB/s', frac=rate(dk) / HBM_PEAK_GBPS,
+                           bytes_formula='every operand plane read once + every result plane written once (planes of batch*N*C*hidden*4 bytes; '
+                                         'an accumulated plane is read and written)')
+                for tag, tv in dk.get('tags', {}).items():
+                    dom.setdefault('forms', {})[tag] = {'launches': tv['launches'], 'avg_launch_us': 1e3 * tv['ms'] / max(1, tv['launches']),
+                                                        'achieved': rate(tv), 'frac': rate(tv) / HBM_PEAK_GBPS}
+            roofline['dominant'] = dom
+        roofline['mfma'] = pmc_mfma(config_key)
         if not a.no_unit_d3:
-            roofline['unit_d3'] = spmm_unit_d3(graph, dev, C, 2 * a.hidden, torch.bfloat16 if a.storage == 'bf16' else torch.float32)
+            roofline['unit_d3'] = spmm_unit_d3(graph, dev, C, 2 * a.hidden, torch.bfloat16 if a.storage == 'bf16' else torch.float32,
+                                               reorder=not a.no_reorder)
         value = world * B * a.steps / elapsed
         out = {
             'metric': METRIC, 'value': value, 'unit': 'samples/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * elapsed / a.steps,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.storage, 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'strong' if a.global_batch else 'weak', 'vs_baseline': None, 'dtype': a.storage, 'data': 'synthetic',
             'n_ranks_seen': n_ranks_seen, 'hip_graph': bool(graphed),
             'config': {'workload': f'full STC-GNN train step (fwd + ComboLoss + bwd + grad all-reduce + Adam), csr-fixed, '
                                    f'{a.grid}x{a.grid} queen grid N={N} nnz={graph.nnz}{" permuted" if a.permute else ""}, C={C}, '
                                    f'hidden={a.hidden}, K={a.order}, layers={a.layers}, T={a.obs}+{a.pred}' + (', bf16 state storage' if a.storage == 'bf16' else ''),
                        'global_batch': world * B, 'batch_per_gpu': B, 'parallelism': f'batch-shard x{world}',
+                       **({'preset': a.preset} if a.preset else {}),
+                       'operand_format': {0: 'bf16x3', 1: 'f16x2'}.get(getattr(hip, 'operand_format', None)),
                        'grad_bucket_bytes': bucket.nbytes, 'input_seeds': 'X, Y: Bernoulli(0.1635), torch seed 1000 + rank'},
             'roofline': roofline,
             'step_breakdown': {'fwd_loss_bwd_ms': phases[0], 'grad_allreduce_ms': phases[1], 'adam_ms': phases[2],
@@ -418,6 +487,62 @@ def main():
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+
+
+def bench_cfg2(a):
+    """BASELINE configuration 2: ONE BDG_Dif layer (reference STC_GNN.py:31-47) at B = 32, N = 200 (10 x 20 queen grid), C = 8, L = 32,
+    Ho = 32, Chebyshev order ``--order``, dense learned-style Gs (full N x N pattern, differentiable) -- forward and forward + backward
+    through the drop-in module, HIP events over ``--steps`` repetitions after ``--warmup``; BASELINE.md section 2 holds the reference's
+    CPU times for this shape (13.3 / 25.8 ms at K = 2, 29.6 / 55.2 ms at K = 3 on 8 cores)."""
+    for _p in (REPO, os.path.join(REPO, 'stc-gnn_amd')):
+        if _p not in sys.path:
+            sys.path.insert(0, _p)
+    import torch
+    import STC_GNN as M
+    dev = torch.device('cuda', 0)
+    B, N, C, L, Ho, K = 32, 200, 8, 32, 32, a.order
+    g = torch.Generator().manual_seed(0)
+    torch.manual_seed(42)
+    layer = M.BDG_Dif(K, K, L, Ho).to(dev)
+    Gs = torch.softmax(torch.randn(N, N, generator=g), -1).to(dev).requires_grad_()
+    Gc = torch.softmax(torch.randn(C, C, generator=g), -1).to(dev).requires_grad_()
+    X = torch.randn(B, N, C, L, generator=g).to(dev).requires_grad_()
+    R = torch.randn(B, N, C, Ho, generator=g).to(dev)
+    steps, warm = max(a.steps, 20), max(a.warmup, 3)
+
+    def timed(fn):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(steps):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) / steps
+
+    def fwd():
+        with torch.no_grad():
+            return layer(X, Gs, Gc)
+
+    def fwd_bwd():
+        for t in (X, Gs, Gc, *layer.parameters()):
+            t.grad = None
+        (layer(X, Gs, Gc) * R).sum().backward()
+
+    ms_f, ms_fb = timed(fwd), timed(fwd_bwd)
+    ref = {2: (13.3, 25.8), 3: (29.6, 55.2)}.get(K)
+    print(json.dumps({
+        'metric': 'BDG_Dif layer forward+backward layer-applications/sec (BASELINE configuration 2; not the headline metric)', 'value': 1e3 / ms_fb,
+        'unit': 'layers/s', 'n_gpus': 1, 'steps': steps, 'warmup': warm, 'ms_per_step': ms_fb, 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f'single BDG_Dif layer, B={B} N={N} C={C} L={L} Ho={Ho} K={K}, dense differentiable Gs and Gc (gradients of X, W, b, Gs, Gc)',
+                   'preset': 'cfg2'},
+        'forward_ms': ms_f, 'forward_backward_ms': ms_fb,
+        'reference_cpu_ms': None if ref is None else {'forward': ref[0], 'forward_backward': ref[1], 'cores': 8,
+                                                      'source': 'BASELINE.md section 2 (reference imported unmodified in the survey container)'},
+    }), flush=True)
 
 
 def _sparse_T(graph):

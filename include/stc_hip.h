@@ -53,6 +53,10 @@ extern "C" {
 
 int stc_version(void);
 const char* stc_last_error(void);
+/* Ceiling of the node / cell kernel dispatch, process-wide (tests, A/B runs): 0 = every path (default: split-operand matrix-core
+ * kernels, then the fp32-MFMA kernels, then the generic ones), 1 = no split-operand kernels, 2 = generic kernels only.  The entry
+ * points read no environment variables; apart from this setting and the thread-local error text the library keeps no state. */
+int stc_set_dispatch_level(int32_t level);
 
 /* ---- spatial aggregation -------------------------------------------------
  * Y[b,i,:] = alpha * sum_{j in row i} val[j] * X[b, colidx[j], :] + beta * Y0[b,i,:]
@@ -155,26 +159,6 @@ int stc_gru_blend_bwd_bf16(const void* dHnew, const void* U, const void* Cand, v
 int stc_head_fwd_bf16(const void* H, const float* w, const float* b, float* y, int64_t rows, int32_t h, void* stream);
 int stc_head_bwd_bf16(const void* H, const float* w, const float* y, const float* dy, void* dH, float* dwb,
                       void* workspace, size_t workspace_bytes, int64_t rows, int32_t h, void* stream);
-
-/* Backward products of an STC_Cell with the element-wise consumer folded into the epilogue (autograd of
- * STC_GNN.py:68-75).  Rows are node rows of C categories x (cin + h + pad) features (the [Xt | H | 0-pad]
- * layout of stc_concat2_f32).  The graph comes in either form: BCSR when blk_ptr != NULL, else CSR.
- *   gates:  d = Y0 + S.X   (= gradient of [Xt | R*H | pad]);   dXt = d[x part];
- *           dG = [dU*U*(1-U) | d[h part]*H*R*(1-R)];   dH = d[h part]*R + dH_in      (dH_in may be NULL / alias dH)
- *   split:  d = Y0 + S.X   (= gradient of [Xt | H | pad]);     outA = d[x part] + addA;  outB = d[h part] + addB
- *           (addA / addB may be NULL and may alias outA / outB)
- * X, Y0 (batch, n, C*(cin+h+pad)); dU, H, U, Rg, dH_in, dH (batch*n*C, h); dG (.., 2h); dXt / outA (.., cin). */
-int stc_spmm_bwd_gates_f32(const int32_t* rowptr, const int32_t* colidx, const float* val,
-                           const int32_t* blk_ptr, const int32_t* blk_cols, const float* blk_vals,
-                           int32_t n_rows, int32_t n_cols, const float* X, const float* Y0,
-                           const float* dU, const float* H, const float* U, const float* Rg, const float* dH_in,
-                           float* dG, float* dXt, float* dH,
-                           int32_t batch, int32_t C, int32_t cin, int32_t h, int32_t pad, void* stream);
-int stc_spmm_bwd_split_f32(const int32_t* rowptr, const int32_t* colidx, const float* val,
-                           const int32_t* blk_ptr, const int32_t* blk_cols, const float* blk_vals,
-                           int32_t n_rows, int32_t n_cols, const float* X, const float* Y0,
-                           const float* addA, const float* addB, float* outA, float* outB,
-                           int32_t batch, int32_t C, int32_t cin, int32_t h, int32_t pad, void* stream);
 
 /* out[j] (+)= alpha * sum_b < A[b,i,:], Bm[b,colidx[j],:] >   for j in row i
  * A (batch, n_rows, F), Bm (batch, n_cols, F), out (nnz).  Gradient of the
@@ -405,20 +389,6 @@ int stc_cell_cand_bwd_planar_k_f32(const float* const* Zx, const float* const* Z
                                    float* const* dZx, float* const* dZh, float* dW, float* db,
                                    void* workspace, size_t workspace_bytes, int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream);
 
-/* Post-aggregation form of an order-3 convolution on planar input (the candidate convolution of the order-3 planar cell):
- *     Y = sum_n T_n(S) P_n,  P_n = sum_c T_c^T ([X | X2] W_{n,c})     =>     Y = (P_0 - P_2 + b) + S x (P_1 + 2 S x P_2)   (Clenshaw)
- * fwd writes P[0] = P_0 - P_2 + b, P[1] = P_1, P[2] = P_2, each (nodes, C, Ho); the caller runs the two narrow SpMMs
- * (M = P[1] + 2 S x P[2] with stc_bcsr_spmm_f32's Y0; Y = P[0] + S x M with stc_spmm_blend_fwd_f32).  bwd takes dP[0] = dY,
- * dP[1] = S^T dY, dP[2] = 2 S^T dP[1] - dY and returns dX (, dX2), dW, db -- one direct gradient plane per input plane, no
- * aggregated pieces.  X: the 16-wide plane; X2: the second 16-wide plane (L = 32) or the narrow input plane (L = 20, Lw - 16 in 1..4
- * columns, no gradient: dX2 = NULL).  K = 3, C = 32, Ho = 16; stc_bdg_node_post_k_supported() tells. */
-int stc_bdg_node_post_k_supported(int32_t K, int32_t C, int32_t L, int32_t Ho);
-int stc_bdg_node_post_fwd_k_f32(const float* X, const float* X2, int32_t K, const float* Tc, const float* W, const float* bias,
-                                float* const* P, int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t Ho, void* stream);
-int stc_bdg_node_post_bwd_k_f32(const float* X, const float* X2, int32_t K, const float* Tc, const float* W, const float* const* dP,
-                                float* dX, float* dX2, float* dW, float* db, void* workspace, size_t workspace_bytes,
-                                int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t Ho, void* stream);
-
 /* Y = sum_i add_scale[i] add[i] + alpha S x (X [+ X2]) on rows of C*h floats (h = 16): the gradient of a state from the pieces
  * its consumers left -- direct planes as addends (add[i]: columns [add_off[i], add_off[i]+h) of rows of add_ld[i] floats,
  * multiples of 4; a contiguous plane is ld = h, off = 0), aggregated planes X, X2 through the transposed graph.
@@ -436,24 +406,6 @@ int stc_spmm_sum_f32(const int32_t* rowptr, const int32_t* colidx, const float* 
                      float* Y, const float* U, const float* Cand, float* dY,
                      float* amax, int32_t n_amax,
                      int32_t batch, int32_t C, int32_t h, void* stream);
-
-/* ---- the same two cell convolutions with the graph aggregation fused in (Ks = Kc = 2) ------------------------------
- * Replaces STC_GNN.py:37 (the 1-mode product Z1 = Gs^T x Z0, one SpMM launch) + :38-45 + :71-78 in ONE launch per
- * convolution: each wave gathers the neighbour rows of Z0 for its node from the CSR rows of S = Gs^T (rowptr / colidx /
- * val over the n nodes of one sample; nodes = batch * n, row (b, i) = b*n + i), accumulates them in CSR order exactly
- * like stc_csr_spmm_f32, WRITES Z1 (nodes, C, L) for the backward and feeds it to the matrix cores from registers.
- * Saves the SpMM launch and one HBM pass over Z0 and Z1 per convolution.  Intended for sparse fixed graphs (a row of S
- * costs one gather per entry); stc_cell_gather_supported() tells whether the shape is on this path
- * (C in {32, 64}, L in {20, 32}, h = 16), else STC_EUNSUPPORTED.  Other arguments as the non-gather entry points. */
-int stc_cell_gather_supported(int32_t Ks, int32_t Kc, int32_t C, int32_t L, int32_t h);
-int stc_cell_gates_fwd_gather_f32(const int32_t* rowptr, const int32_t* colidx, const float* val, int64_t n,
-                                  const float* Z0, float* Z1, const float* Tc, const float* W, const float* bias,
-                                  const float* H, float* U, float* Rg, float* CandIn,
-                                  int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t h, int32_t cin, void* stream);
-int stc_cell_blend_fwd_gather_f32(const int32_t* rowptr, const int32_t* colidx, const float* val, int64_t n,
-                                  const float* Z0, float* Z1, const float* Tc, const float* W, const float* bias,
-                                  const float* U, const float* H, float* Cand, float* Hnew,
-                                  int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t h, void* stream);
 
 /* ---- output head (STC_GNN.py:182-183, 206) -----------------------------------
  * The reference applies Linear(h, h/2) then Linear(h/2, 1) with NO nonlinearity in between, then a sigmoid:

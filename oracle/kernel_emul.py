@@ -93,25 +93,6 @@ class EmulatedKernels:
         self.csr_spmm(rowptr, colidx, val, n_rows, n_cols, X.float(), None if Y0 is None else Y0.float(), out, alpha, beta)
         Y.copy_(out.to(torch.bfloat16))
 
-    # ---- stc_spmm_bwd_gates/split_f32: backward products with their element-wise consumer in the epilogue
-    def spmm_bwd_gates(self, rowptr, colidx, val, plan, X, Y0, dU, H, U, Rg, dH_in, dG, dXt, dH):
-        B, n, F = X.shape
-        d = torch.empty_like(Y0)
-        self.csr_spmm(rowptr, colidx, val, n, n, X, Y0, d, 1.0, 1.0)
-        Cc = H.shape[-2]
-        self.gru_gates_bwd(d.view(B * n * Cc, F // Cc), dU.reshape(-1, dU.shape[-1]), H.reshape(-1, H.shape[-1]),
-                           U.reshape(-1, H.shape[-1]), Rg.reshape(-1, H.shape[-1]), dG.view(-1, dG.shape[-1]),
-                           dXt.view(-1, dXt.shape[-1]), dH.view(-1, dH.shape[-1]),
-                           dH_in=None if dH_in is None else dH_in.reshape(-1, H.shape[-1]).clone())
-
-    def spmm_bwd_split(self, rowptr, colidx, val, plan, X, Y0, Cc, outA, outB, addA=None, addB=None):
-        B, n, F = X.shape
-        d = torch.empty_like(Y0)
-        self.csr_spmm(rowptr, colidx, val, n, n, X, Y0, d, 1.0, 1.0)
-        self.split2(d.view(B * n * Cc, F // Cc), outA.view(-1, outA.shape[-1]), outB.view(-1, outB.shape[-1]),
-                    addA=None if addA is None else addA.reshape(-1, outA.shape[-1]).clone(),
-                    addB=None if addB is None else addB.reshape(-1, outB.shape[-1]).clone())
-
     # ---- stc_csr_sddmm_f32: gradient of the 1-mode product w.r.t. the graph values (autograd of :37)
     def csr_sddmm(self, rowptr, colidx, n_rows, n_cols, A, Bm, out, alpha, accumulate):
         rows = _expand_rows(rowptr)
@@ -301,48 +282,6 @@ class EmulatedKernels:
             U, Cand, dY = blend
             dY.copy_(Y * U * (1 - Cand * Cand))
 
-    # post-aggregation form at order 3 on planar input: P = [P_0 - P_2 + b, P_1, P_2], P_n = sum_c T_c^T ([X | X2] W_{n,c})
-    def node_post_k_supported(self, K, Cc, L, Ho) -> bool:
-        return K == 3 and Ho == 16
-
-    @staticmethod
-    def _post_k_row(X, X2):
-        return torch.cat([X, X2], -1) if X2.shape[-1] == X.shape[-1] else torch.cat([X2, X], -1)      # narrow: reference order [input | 16-wide]
-
-    def node_post_fwd_k(self, X, Tc, W, bias, P, X2):
-        K = len(P)
-        row = self._post_k_row(X, X2)
-        Lw = W.shape[0] // (K * K)
-        Pn = []
-        for n in range(K):
-            acc = torch.zeros_like(P[0])
-            for c in range(K):
-                proj = row[..., :Lw] @ W[(n * K + c) * Lw:(n * K + c + 1) * Lw]
-                acc += proj if c == 0 else torch.einsum('pd,rpo->rdo', Tc[c], proj)
-            Pn.append(acc)
-        P[0].copy_(Pn[0] - Pn[2] + (bias if bias is not None else 0))
-        P[1].copy_(Pn[1]); P[2].copy_(Pn[2])
-
-    def node_post_bwd_k(self, X, Tc, W, dP, dX, dW, db, X2, dX2=None):
-        K = len(dP)
-        row = self._post_k_row(X, X2)
-        Lw = W.shape[0] // (K * K)
-        drow = torch.zeros_like(row)
-        dW.zero_()
-        for n in range(K):
-            for c in range(K):
-                Q = dP[n] if c == 0 else torch.einsum('pd,rdo->rpo', Tc[c], dP[n])
-                Wnc = W[(n * K + c) * Lw:(n * K + c + 1) * Lw]
-                drow[..., :Lw] += torch.einsum('rpo,lo->rpl', Q, Wnc)
-                dW[(n * K + c) * Lw:(n * K + c + 1) * Lw] += torch.einsum('rpl,rpo->lo', row[..., :Lw], Q)
-        if db is not None:
-            db.copy_(dP[0].sum((0, 1)))
-        w, w2 = X.shape[-1], X2.shape[-1]
-        if w2 == w:
-            dX.copy_(drow[..., :w]); dX2.copy_(drow[..., w:])
-        else:
-            dX.copy_(drow[..., w2:])
-
     # planar cell convolutions of order K (stc_cell_*_planar_k_f32): composed from the slab-form twins on concatenated planes
     def cell_planar_k_supported(self, K, Cc, h) -> bool:
         return K == 3 and h == 16
@@ -471,22 +410,6 @@ class EmulatedKernels:
             buf, off = copies[0]
             buf[..., :off].copy_(side)
             buf[..., off + h:].zero_()
-
-    # ---- stc_cell_*_fwd_gather_f32: the same with Z1 = S.Z0 produced inside (include/stc_hip.h)
-    def cell_gather_supported(self, Ks, Kc, Cc, L, h) -> bool:
-        return Ks == 2 and Kc == 2
-
-    def _gather(self, rowptr, colidx, val, n, Z0, Z1):
-        R, Cc, L = Z0.shape
-        self.csr_spmm(rowptr, colidx, val, n, n, Z0.view(R // n, n, Cc * L), None, Z1.view(R // n, n, Cc * L), 1.0, 0.0)
-
-    def cell_gates_fwd_gather(self, rowptr, colidx, val, n, Z0, Z1, Tc, W, bias, H, U, Rg, CandIn):
-        self._gather(rowptr, colidx, val, n, Z0, Z1)
-        self.cell_gates_fwd([Z0, Z1], Tc, W, bias, H, U, Rg, CandIn)
-
-    def cell_blend_fwd_gather(self, rowptr, colidx, val, n, Z0, Z1, Tc, W, bias, U, H, Cand, Hnew):
-        self._gather(rowptr, colidx, val, n, Z0, Z1)
-        self.cell_blend_fwd([Z0, Z1], Tc, W, bias, U, H, Cand, Hnew)
 
     # ---- stc_gru_gates_fwd/bwd_f32: split + sigmoids + reset*H + second concat (STC_GNN.py:71-75)
     def gru_gates_fwd(self, G, Xt, H, U, Rg, CandIn):

@@ -21,6 +21,7 @@
 #include "stc_common.h"
 #include "stc_node_mfma.h"
 
+#include <atomic>
 #include <cstdlib>
 
 namespace {
@@ -337,17 +338,12 @@ int check_dims(const char* who, int Ks, int Kc, int C, int L, int Lw, int Ho, lo
     return STC_OK;
 }
 
-// STC_DISABLE_MFMA=1 forces the generic kernels (A/B runs, tests of both paths)
-bool mfma_enabled() {
-    const char* e = std::getenv("STC_DISABLE_MFMA");
-    return !(e && e[0] == '1');
-}
-
-// STC_DISABLE_X3=1 keeps the matrix-core kernels on the fp32 MFMA instead of the split-operand bf16 MFMA
-bool x3_enabled() {
-    const char* e = std::getenv("STC_DISABLE_X3");
-    return mfma_enabled() && !(e && e[0] == '1');
-}
+// Dispatch ceiling of the node / cell kernels (stc_set_dispatch_level): 0 = every path (split-operand matrix cores, then fp32 MFMA, then the
+// generic kernels), 1 = no split-operand kernels, 2 = generic kernels only.  A process-wide setting for tests and A/B runs -- the entry
+// points themselves read no environment.
+std::atomic<int> g_dispatch_level{0};
+bool mfma_enabled() { return g_dispatch_level.load(std::memory_order_relaxed) < 2; }
+bool x3_enabled() { return g_dispatch_level.load(std::memory_order_relaxed) < 1; }
 
 int bwd_grid(const NodeDims& d, long long nodes) {
     const long long n_tiles = (nodes + d.TN - 1) / d.TN;
@@ -732,56 +728,6 @@ extern "C" int stc_bdg_node_post_bwd_f32(const float* X, const float* X2, const 
     return STC_OK;
 }
 
-// ---- post-aggregation form at Chebyshev order 3 (planar input): see node_fwd2k_x3_kernel
-extern "C" int stc_bdg_node_post_k_supported(int32_t K, int32_t C, int32_t L, int32_t Ho) {
-    return (x3_enabled() && stc_node_post_k_shape_ok(K, C, L, Ho)) ? 1 : 0;
-}
-
-extern "C" int stc_bdg_node_post_fwd_k_f32(const float* X, const float* X2, int32_t K, const float* Tc, const float* W, const float* bias,
-                                           float* const* P, int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t Ho, void* stream) {
-    if (int rc = check_dims("stc_bdg_node_post_fwd_k_f32", K, K, C, L, Lw, Ho, nodes)) return rc;
-    if (!stc_bdg_node_post_k_supported(K, C, L, Ho)) return stc::fail(STC_EUNSUPPORTED, "stc_bdg_node_post_fwd_k_f32: K=%d C=%d L=%d Ho=%d is not built", K, C, L, Ho);
-    if (nodes == 0) return STC_OK;
-    STC_REQUIRE(X && X2 && Tc && W && P, STC_EINVAL, "stc_bdg_node_post_fwd_k_f32: null pointer (the order-K form takes planar input: X and X2)");
-    for (int n = 0; n < K; ++n) STC_REQUIRE(P[n] && P[n] != X && P[n] != X2, STC_EINVAL, "stc_bdg_node_post_fwd_k_f32: output plane %d null or aliasing the input", n);
-    STC_REQUIRE(P[0] != P[1] && P[0] != P[2] && P[1] != P[2], STC_EINVAL, "stc_bdg_node_post_fwd_k_f32: outputs must not alias");
-    STC_REQUIRE(L == 32 || (L == 20 && Lw > 16), STC_EINVAL, "stc_bdg_node_post_fwd_k_f32: rows of 16 + 16 or 16 + cin (<= 4) columns, L = %d", L);
-    const int rc = stc_node_post_fwd_k_x3(X, X2, K, Tc, W, bias, P, nodes, C, L, Lw, Ho, static_cast<hipStream_t>(stream));
-    return rc == STC_NOT_HANDLED ? stc::fail(STC_EUNSUPPORTED, "stc_bdg_node_post_fwd_k_f32: operands not usable (alignment)") : rc;
-}
-
-extern "C" int stc_bdg_node_post_bwd_k_f32(const float* X, const float* X2, int32_t K, const float* Tc, const float* W, const float* const* dP,
-                                           float* dX, float* dX2, float* dW, float* db, void* workspace, size_t workspace_bytes,
-                                           int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t Ho, void* stream) {
-    if (int rc = check_dims("stc_bdg_node_post_bwd_k_f32", K, K, C, L, Lw, Ho, nodes)) return rc;
-    if (!stc_bdg_node_post_k_supported(K, C, L, Ho)) return stc::fail(STC_EUNSUPPORTED, "stc_bdg_node_post_bwd_k_f32: K=%d C=%d L=%d Ho=%d is not built", K, C, L, Ho);
-    STC_REQUIRE(W && dW && Tc, STC_EINVAL, "stc_bdg_node_post_bwd_k_f32: null W/dW/Tc");
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const int nW = K * K * Lw * Ho;
-    if (nodes == 0) {
-        if (int rc = stc::hip_status(hipMemsetAsync(dW, 0, (size_t)nW * sizeof(float), s), "memset dW")) return rc;
-        if (db) if (int rc = stc::hip_status(hipMemsetAsync(db, 0, (size_t)Ho * sizeof(float), s), "memset db")) return rc;
-        return STC_OK;
-    }
-    STC_REQUIRE(X && X2 && dP && dX, STC_EINVAL, "stc_bdg_node_post_bwd_k_f32: null pointer");
-    for (int n = 0; n < K; ++n) STC_REQUIRE(dP[n], STC_EINVAL, "stc_bdg_node_post_bwd_k_f32: gradient plane %d is null", n);
-    STC_REQUIRE(L == 20 ? dX2 == nullptr : dX2 != nullptr, STC_EINVAL,
-                "stc_bdg_node_post_bwd_k_f32: dX2 goes with 16 + 16 column rows and only with them (a narrow input plane gets no gradient)");
-    STC_REQUIRE(workspace && stc::aligned16(workspace), STC_EALIGN, "stc_bdg_node_post_bwd_k_f32: workspace null or not 16-byte aligned");
-    STC_REQUIRE(workspace_bytes >= stc_bdg_node_bwd_workspace_bytes(K, K, C, L, Ho, 0), STC_EINVAL,
-                "stc_bdg_node_post_bwd_k_f32: workspace of %zu B is too small", workspace_bytes);
-    int n_parts = 0;
-    float* partial = static_cast<float*>(workspace);
-    const int rc = stc_node_post_bwd_k_x3(X, X2, K, Tc, W, dP, dX, dX2, partial, &n_parts, db != nullptr, nodes, C, L, Lw, Ho, s);
-    if (rc == STC_NOT_HANDLED) return stc::fail(STC_EUNSUPPORTED, "stc_bdg_node_post_bwd_k_f32: operands not usable (alignment)");
-    if (rc != STC_OK) return rc;
-    const int stride = nW + Ho;
-    hipLaunchKernelGGL(bdg_node_reduce_kernel, dim3((stride + RED_ELEMS - 1) / RED_ELEMS), dim3(NODE_THREADS), 0, s,
-                       partial, n_parts, stride, nW, Ho, 0, dW, db, static_cast<float*>(nullptr));
-    STC_LAUNCH_CHECK("stc_bdg_node_reduce launch");
-    return STC_OK;
-}
-
 extern "C" int stc_cell_blend_fwd_f32(const float* const* Z, int32_t Ks, const float* Tc, int32_t Kc,
                                       const float* W, const float* bias, const float* U, const float* H,
                                       float* Cand, float* Hnew,
@@ -806,49 +752,10 @@ extern "C" int stc_cell_blend_fwd_f32(const float* const* Z, int32_t Ks, const f
     return rc == STC_NOT_HANDLED ? stc::fail(STC_EUNSUPPORTED, "stc_cell_blend_fwd_f32: operands not usable by the fused path (alignment)") : rc;
 }
 
-extern "C" int stc_cell_gather_supported(int32_t Ks, int32_t Kc, int32_t C, int32_t L, int32_t h) {
-    return (x3_enabled() && Ks == Kc && stc_cell_gather_shape_ok(Ks, C, L, h)) ? 1 : 0;
-}
-
-namespace {
-int check_gather(const char* who, const int32_t* rowptr, const int32_t* colidx, const float* val, int64_t n,
-                 const float* Z0, const float* Z1, int64_t nodes) {
-    STC_REQUIRE(n >= 1 && n < (1ll << 31) && nodes % n == 0, STC_EINVAL, "%s: nodes=%lld is not a multiple of the graph size n=%lld", who, (long long)nodes, (long long)n);
-    STC_REQUIRE(rowptr && Z0 && Z1, STC_EINVAL, "%s: null rowptr / Z0 / Z1", who);
-    STC_REQUIRE(Z0 != Z1, STC_EINVAL, "%s: Z1 must not alias Z0", who);
-    (void)colidx; (void)val;      // may be null for a graph without edges (never read then)
+extern "C" int stc_set_dispatch_level(int32_t level) {
+    STC_REQUIRE(level >= 0 && level <= 2, STC_EINVAL, "stc_set_dispatch_level: level %d (0 = all paths, 1 = no split-operand kernels, 2 = generic kernels only)", level);
+    g_dispatch_level.store(level, std::memory_order_relaxed);
     return STC_OK;
-}
-}  // namespace
-
-extern "C" int stc_cell_gates_fwd_gather_f32(const int32_t* rowptr, const int32_t* colidx, const float* val, int64_t n,
-                                             const float* Z0, float* Z1, const float* Tc, const float* W, const float* bias,
-                                             const float* H, float* U, float* Rg, float* CandIn,
-                                             int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t h, int32_t cin, void* stream) {
-    if (int rc = check_dims("stc_cell_gates_fwd_gather_f32", 2, 2, C, L, Lw, 2 * h, nodes)) return rc;
-    STC_REQUIRE(cin >= 0 && cin + h <= L, STC_EINVAL, "stc_cell_gates_fwd_gather_f32: cin=%d + h=%d exceed the row width L=%d", cin, h, L);
-    if (!stc_cell_gather_supported(2, 2, C, L, h)) return stc::fail(STC_EUNSUPPORTED, "stc_cell_gates_fwd_gather_f32: shape not on the fused-aggregation path");
-    if (nodes == 0) return STC_OK;
-    if (int rc = check_gather("stc_cell_gates_fwd_gather_f32", rowptr, colidx, val, n, Z0, Z1, nodes)) return rc;
-    STC_REQUIRE(Tc && W && H && U && Rg && CandIn, STC_EINVAL, "stc_cell_gates_fwd_gather_f32: null pointer");
-    STC_REQUIRE(Z0 != CandIn && Z1 != CandIn, STC_EINVAL, "stc_cell_gates_fwd_gather_f32: CandIn must not alias Z0 / Z1");
-    const int rc = stc_cell_gates_fwd_gather_x3(rowptr, colidx, val, n, Z0, Z1, Tc, W, bias, H, U, Rg, CandIn, nodes, C, L, Lw, cin,
-                                                static_cast<hipStream_t>(stream));
-    return rc == STC_NOT_HANDLED ? stc::fail(STC_EUNSUPPORTED, "stc_cell_gates_fwd_gather_f32: operands not usable by the fused path (alignment)") : rc;
-}
-
-extern "C" int stc_cell_blend_fwd_gather_f32(const int32_t* rowptr, const int32_t* colidx, const float* val, int64_t n,
-                                             const float* Z0, float* Z1, const float* Tc, const float* W, const float* bias,
-                                             const float* U, const float* H, float* Cand, float* Hnew,
-                                             int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t h, void* stream) {
-    if (int rc = check_dims("stc_cell_blend_fwd_gather_f32", 2, 2, C, L, Lw, h, nodes)) return rc;
-    if (!stc_cell_gather_supported(2, 2, C, L, h)) return stc::fail(STC_EUNSUPPORTED, "stc_cell_blend_fwd_gather_f32: shape not on the fused-aggregation path");
-    if (nodes == 0) return STC_OK;
-    if (int rc = check_gather("stc_cell_blend_fwd_gather_f32", rowptr, colidx, val, n, Z0, Z1, nodes)) return rc;
-    STC_REQUIRE(Tc && W && U && H && Cand && Hnew, STC_EINVAL, "stc_cell_blend_fwd_gather_f32: null pointer");
-    const int rc = stc_cell_blend_fwd_gather_x3(rowptr, colidx, val, n, Z0, Z1, Tc, W, bias, U, H, Cand, Hnew, nodes, C, L, Lw,
-                                                static_cast<hipStream_t>(stream));
-    return rc == STC_NOT_HANDLED ? stc::fail(STC_EUNSUPPORTED, "stc_cell_blend_fwd_gather_f32: operands not usable by the fused path (alignment)") : rc;
 }
 
 extern "C" size_t stc_bdg_node_bwd_workspace_bytes(int32_t Ks, int32_t Kc, int32_t C, int32_t L, int32_t Ho,

@@ -1029,15 +1029,11 @@ extern "C" int stc_cell_gates_bwd_planar_bf16(const void* X, const void* H, cons
     const GatesPro pro{B(dCandIn), B(Cand), B(H), B(U), B(Rg), B(dHnew), M(dH)};
     float* partial = static_cast<float*>(workspace);
     int n_parts = 0;
-    // C = 64: one wave per SIMD with software prefetch (default); STC_BF16_BWD_WAVES=2 caps the kernel at 256 registers for two
-    // waves per SIMD, which spills (measured 2313 vs 1840 us per launch before the prefetch existed)
-    static const bool two = [] { const char* e = std::getenv("STC_BF16_BWD_WAVES"); return e && e[0] == '2'; }();
+    // C = 64: one wave per SIMD with software prefetch (a 256-register two-wave build spilled: 2313 vs 1840 us per launch, not kept)
     const int rc = C == 32 ? (narrow ? launch_gates_bwd<1, 2>(zp, dzp, pro, Tc, W, partial, &n_parts, db != nullptr, nodes, Lw, s)
                                      : launch_gates_bwd<1, 1>(zp, dzp, pro, Tc, W, partial, &n_parts, db != nullptr, nodes, Lw, s))
-                           : two ? (narrow ? launch_gates_bwd<2, 2, 2>(zp, dzp, pro, Tc, W, partial, &n_parts, db != nullptr, nodes, Lw, s)
-                                           : launch_gates_bwd<2, 1, 2>(zp, dzp, pro, Tc, W, partial, &n_parts, db != nullptr, nodes, Lw, s))
-                                 : (narrow ? launch_gates_bwd<2, 2, 1>(zp, dzp, pro, Tc, W, partial, &n_parts, db != nullptr, nodes, Lw, s)
-                                           : launch_gates_bwd<2, 1, 1>(zp, dzp, pro, Tc, W, partial, &n_parts, db != nullptr, nodes, Lw, s));
+                           : (narrow ? launch_gates_bwd<2, 2, 1>(zp, dzp, pro, Tc, W, partial, &n_parts, db != nullptr, nodes, Lw, s)
+                                     : launch_gates_bwd<2, 1, 1>(zp, dzp, pro, Tc, W, partial, &n_parts, db != nullptr, nodes, Lw, s));
     if (rc != STC_OK) return rc;
     return stc_node_reduce_partials(partial, n_parts, nW, 32, dW, db, s);
 }

@@ -54,18 +54,6 @@ int stc_cell_gates_bwd_x3(const float* const* Z, int K, const float* Tc, const f
                           float* const* dZ, float* dXt, float* dH, float* partial, int* n_partials, int want_db,
                           long long nodes, int C, int L, int Lw, int cin, int dh_scaled, hipStream_t stream);
 
-// Fused aggregation variants (Ks = Kc = 2): the kernel gathers Z1 = S.Z0 itself from the CSR rows of S (n nodes per
-// sample, nodes = batch * n) and writes it for the backward.
-int stc_cell_gather_shape_ok(int K, int C, int L, int h);
-int stc_cell_gates_fwd_gather_x3(const int* rowptr, const int* colidx, const float* val, long long n,
-                                 const float* Z0, float* Z1, const float* Tc, const float* W, const float* bias,
-                                 const float* H, float* U, float* R, float* CandIn,
-                                 long long nodes, int C, int L, int Lw, int cin, hipStream_t stream);
-int stc_cell_blend_fwd_gather_x3(const int* rowptr, const int* colidx, const float* val, long long n,
-                                 const float* Z0, float* Z1, const float* Tc, const float* W, const float* bias,
-                                 const float* U, const float* H, float* Cand, float* Hnew,
-                                 long long nodes, int C, int L, int Lw, hipStream_t stream);
-
 // Candidate convolution's backward with the blend backward as its prologue (hidden 16): dY = dHnew * U * (1 - Cand^2).
 int stc_cell_cand_bwd_mfma(const float* const* Z, int K, const float* Tc, const float* W,
                            const float* dHnew, const float* U, const float* Cand,
@@ -112,13 +100,6 @@ int stc_cell_conv_bwd_planar_k_x3(const float* const* Zx, const float* const* Zh
                                   const float* dRH, const float* Cand, const float* U, const float* R, const float* dHnew,
                                   float* const* dZx, float* const* dZh, float* dH, float* partial, int* n_partials, int want_db,
                                   long long nodes, int C, int Lw, int accumulate_x, hipStream_t stream);
-
-// Post-aggregation form at order 3 (planar input only): P[0] = P_0 - P_2 + b, P[1] = P_1, P[2] = P_2; backward from dP[0..2].
-int stc_node_post_k_shape_ok(int K, int C, int L, int Ho);
-int stc_node_post_fwd_k_x3(const float* X, const float* X2, int K, const float* Tc, const float* W, const float* bias, float* const* P,
-                           long long nodes, int C, int L, int Lw, int Ho, hipStream_t stream);
-int stc_node_post_bwd_k_x3(const float* X, const float* X2, int K, const float* Tc, const float* W, const float* const* dP, float* dX, float* dX2,
-                           float* partial, int* n_partials, int want_db, long long nodes, int C, int L, int Lw, int Ho, hipStream_t stream);
 
 // Fixed-order reduction of the backward kernels' per-workgroup partial rows [dW (nW) | db (Ho)] into dW, db (db may be null).
 int stc_node_reduce_partials(const float* partial, int n_parts, int nW, int Ho, float* dW, float* db, hipStream_t stream);

@@ -64,17 +64,6 @@ struct Row8 {
     }
 };
 
-// Fused aggregation (K = 2 only): instead of reading a precomputed slab Z_1 = S.Z_0 (one SpMM launch and one more pass
-// over Z_0), the wave gathers the node's neighbour rows of Z_0 itself -- CSR row of S, wave-uniform scalar loads of
-// (column, value), row loads that mostly hit L2 because the node's own row and its neighbours' are being read by the
-// resident waves anyway -- accumulates them in the SpMM kernel's order, writes Z_1 for the backward, and feeds it to the
-// MFMAs from registers.
-struct GatherArgs {
-    const int* rowptr; const int* colidx; const float* val;   // S in CSR over the n nodes of one sample
-    int n;                                                    // nodes per sample: row (b, i) of the batch is b*n + i
-    float* Z1;                                                // out: (nodes, C, L)
-};
-
 // --------------------------------------------------------------------------------------- forward
 // PL = 1: planar inputs (Z.p[n] = columns 0..15, Z.q[n] = columns 16..31 of slab n, each (nodes, C, 16)); with EPI_GATES the
 // candidate's input then is planar too: its X plane is Xt itself and only the R*H plane (epi.CandIn, 16 wide) is written.
@@ -89,15 +78,14 @@ struct PostArgs { const float* Wc; const float* bc; float* A; float* Bm; };
 // F: operand format (stc_x3_frag.h).  FmtH2 (two fp16 pieces, three products): W and T_c are normalised per workgroup at table-fill time
 // (W's blocks c = 0 carry sW sT, blocks c >= 1 carry sW, T_c carries sT: projection and category mix then meet in one accumulator with the
 // common factor sW sT, taken out in the epilogue); activations enter as they are (bounded by construction).
-template <int NB2, int HB, int K, int L, int EPI, int GATHER, int PL = 0, int POST = 0, class F = FmtB3>
+template <int NB2, int HB, int K, int L, int EPI, int PL = 0, int POST = 0, class F = FmtB3>
 __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_kernel(
     ZPtrs Z, const float* __restrict__ Tc, const float* __restrict__ W, const float* __restrict__ bias,
-    float* __restrict__ Y, int nodes, int Lw, FwdEpi epi, GatherArgs ga, PostArgs post) {
+    float* __restrict__ Y, int nodes, int Lw, FwdEpi epi, PostArgs post) {
     using Op = typename F::Op;
     constexpr int NP = F::NP;
-    static_assert(!GATHER || K == 2, "the fused aggregation produces the first-order slab only");
     static_assert(!POST || (PL != 0 && EPI == EPI_GATES && K == 2), "the fused candidate projection belongs to the planar gates kernel");
-    constexpr int KL = GATHER ? 1 : K;                  // slabs read from HBM
+    constexpr int KL = K;                               // slabs read from HBM
     constexpr int NRB = 2 * NB2, C = 32 * NB2, Ho = 16 * HB, NCB = K * HB;
     constexpr int HID = 16;
     constexpr int nWx = K * NCB, nTx = (K - 1) * NRB * NB2;
@@ -199,42 +187,6 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
                 }
         }
         if (next_node < nodes) load_rows(nxt, next_node);        // software prefetch: lands while this node computes
-        Row8<L> z1[NRB];
-        if (GATHER) {
-            const int b = node / ga.n, i = node - b * ga.n;
-            const float* Zb = Z.p[0] + ((size_t)b * ga.n * C + x) * L;
-            const int e0 = ga.rowptr[i], e1 = ga.rowptr[i + 1];
-#pragma unroll
-            for (int rb = 0; rb < NRB; ++rb) { z1[rb].a = kZero4; z1[rb].b = kZero4; }
-            int e = e0;
-            for (; e + 3 <= e1; e += 3) {                     // three neighbours' rows in flight
-                Row8<L> t[3][NRB];
-                float v[3];
-#pragma unroll
-                for (int u = 0; u < 3; ++u) {
-                    const int c = ga.colidx[e + u];
-                    v[u] = ga.val[e + u];
-#pragma unroll
-                    for (int rb = 0; rb < NRB; ++rb) t[u][rb].load(Zb + ((size_t)c * C + 16 * rb) * L, g);
-                }
-#pragma unroll
-                for (int u = 0; u < 3; ++u)
-#pragma unroll
-                    for (int rb = 0; rb < NRB; ++rb) z1[rb].fma(v[u], t[u][rb]);
-            }
-            for (; e < e1; ++e) {
-                const int c = ga.colidx[e];
-                const float v = ga.val[e];
-#pragma unroll
-                for (int rb = 0; rb < NRB; ++rb) {
-                    Row8<L> t;
-                    t.load(Zb + ((size_t)c * C + 16 * rb) * L, g);
-                    z1[rb].fma(v, t);
-                }
-            }
-#pragma unroll
-            for (int rb = 0; rb < NRB; ++rb) z1[rb].store(ga.Z1 + ((size_t)node * C + 16 * rb + x) * L, g);
-        }
         __builtin_amdgcn_sched_barrier(0);
         const int lo = opaque(lane);
 
@@ -250,7 +202,7 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
             Op za[NRB];
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) {
-                const Row8<L>& zr = (GATHER && n == 1) ? z1[rb] : cur[n < KL ? n : 0][rb];
+                const Row8<L>& zr = cur[n][rb];
                 za[rb] = F::split(zr.a, zr.b);
             }
 #pragma unroll
@@ -950,318 +902,21 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
     combine_dw<K, LB, HB>(reinterpret_cast<float*>(smem_raw), dWt, dbp, partial, Lw, want_db, PL == 2 ? Lw - 16 : -1);
 }
 
-// --------------------------------------------------------------------------------------- post-aggregation form, order 3
-// Chebyshev order 3 (reference STC_GNN.py:24-29: T_2 = 2 Gs T_1 - I), aggregation after the projection, in Clenshaw form:
-//     Y = sum_n T_n(S) P_n,  P_n = sum_c T_c^T (X W_{n,c})      =>      Y = (P_0 - P_2 + b) + S . (P_1 + 2 S . P_2)
-// The forward kernel writes the three planes  A = P_0 - P_2 + b,  B1 = P_1,  B2 = P_2  (nodes, C, Ho); the caller forms
-// M = B1 + 2 S.B2 (narrow SpMM with Y0) and Y = A + S.M (narrow SpMM, GRU blend in its epilogue).  Backward: dP_0 = dY,
-// dP_1 = S^T dY, dP_2 = 2 S^T dP_1 - dY (two narrow SpMMs by the caller), and the kernel below turns (X, dP_0..2) into dX, dW.
-// Separate kernels from the order-2 pair above (which keep their register budget for two waves per SIMD): these process
-// one weight set at a time.
-struct PostOut3 { float* p[3]; };
-struct PostGrad3 { const float* p[3]; };
-
-template <int NB2, int HB, int L, int PL = 0>
-__global__ __launch_bounds__(MF_THREADS, 1) void node_fwd2k_x3_kernel(
-    const float* __restrict__ X, const float* __restrict__ X2, const float* __restrict__ Tc, const float* __restrict__ W, const float* __restrict__ bias,
-    PostOut3 out, int nodes, int Lw) {
-    constexpr int K = 3, NRB = 2 * NB2, C = 32 * NB2, Ho = 16 * HB, NCB = K * HB;
-    constexpr int nWx = K * NCB, nTx = (K - 1) * NRB * NB2;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    u32x4* Wx = reinterpret_cast<u32x4*>(smem_raw);        // [K n][NCB]          B: W[(n, c, l = slot)][o = 16 hb + x]
-    u32x4* Tx = Wx + nWx * 3 * 64;                          // [K-1][NRB rb][NB2]  A: T_c[c' = 32 p + pair_row][d = 16 rb + x]
-    const int tid = threadIdx.x, lane = tid & 63, x = lane & 15, g = lane >> 4;
-    for (int idx = tid; idx < nWx * 64; idx += MF_THREADS) {
-        const int ll = idx & 63, f = idx >> 6, cb = f % NCB, n = f / NCB;
-        const int c = cb / HB, o = (cb % HB) * 16 + (ll & 15), gg = ll >> 4;
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int l = 8 * gg + e;
-            const int wl = PL == 2 ? stc_wrow_swapped(l, Lw - 16) : l;
-            v[e] = (wl >= 0 && wl < Lw) ? W[((size_t)(n * K + c) * Lw + wl) * Ho + o] : 0.f;
-        }
-        put_frag(Wx, f, ll, v);
-    }
-    for (int idx = tid; idx < nTx * 64; idx += MF_THREADS) {
-        const int ll = idx & 63, f = idx >> 6, p = f % NB2, rb = (f / NB2) % NRB, c1 = f / (NB2 * NRB), gg = ll >> 4;
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = Tc[(size_t)(c1 + 1) * C * C + (32 * p + pair_row(gg, e)) * C + 16 * rb + (ll & 15)];
-        put_frag(Tx, f, ll, v);
-    }
-    __syncthreads();
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nw = gridDim.x * MF_WAVES;
-    float bv[HB];
-#pragma unroll
-    for (int hb = 0; hb < HB; ++hb) bv[hb] = bias ? bias[16 * hb + x] : 0.f;
-
-    int node = blockIdx.x * MF_WAVES + wave;
-    Row8<L> cur[NRB], nxt[NRB];
-    auto load_rows = [&](Row8<L> (&z)[NRB], int nd) {
-#pragma unroll
-        for (int rb = 0; rb < NRB; ++rb) {
-            if constexpr (PL == 1) z[rb].load_planes(X + ((size_t)nd * C + 16 * rb + x) * 16, X2 + ((size_t)nd * C + 16 * rb + x) * 16, g);
-            else if constexpr (PL == 2) z[rb].load_planes_narrow(X + ((size_t)nd * C + 16 * rb + x) * 16, X2 + ((size_t)nd * C + 16 * rb + x) * (Lw - 16), Lw - 16, g);
-            else z[rb].load(X + ((size_t)nd * C + 16 * rb + x) * L, g);
-        }
-    };
-    if (node < nodes) load_rows(cur, node);
-    __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0) before the loop: see node_fwd_x3_kernel
-    while (node < nodes) {
-        const int next_node = node + nw;
-        if (next_node < nodes) load_rows(nxt, next_node);
-        __builtin_amdgcn_sched_barrier(0);
-        const int lo = opaque(lane);
-        X3 za[NRB];                                              // the rows are split once for all three weight sets
-#pragma unroll
-        for (int rb = 0; rb < NRB; ++rb) za[rb] = split8(cur[rb].a, cur[rb].b);
-        f32x4 keep[NRB][HB];                                     // P_0 (+ b) until P_2 is known
-#pragma unroll
-        for (int n = 0; n < K; ++n) {
-            f32x4 acc[NRB][NCB];
-#pragma unroll
-            for (int rb = 0; rb < NRB; ++rb)
-#pragma unroll
-                for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = kZero4;
-#pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) {
-                const X3 w = get_frag(Wx, n * NCB + cb, lo);
-#pragma unroll
-                for (int rb = 0; rb < NRB; ++rb) acc[rb][cb] = mma6(za[rb], w, acc[rb][cb]);
-            }
-#pragma unroll
-            for (int c1 = 0; c1 < K - 1; ++c1)                   // mix: [rb][hb] += T_{c1+1}^T [.][(c1+1) HB + hb]
-#pragma unroll
-                for (int hb = 0; hb < HB; ++hb)
-#pragma unroll
-                    for (int p = 0; p < NB2; ++p) {
-                        const X3 u = split8(acc[2 * p][(c1 + 1) * HB + hb], acc[2 * p + 1][(c1 + 1) * HB + hb]);
-#pragma unroll
-                        for (int rb = 0; rb < NRB; ++rb) {
-                            const X3 t = get_frag(Tx, (c1 * NRB + rb) * NB2 + p, lo);
-                            acc[rb][hb] = mma6(t, u, acc[rb][hb]);
-                        }
-                    }
-#pragma unroll
-            for (int rb = 0; rb < NRB; ++rb)
-#pragma unroll
-                for (int hb = 0; hb < HB; ++hb) {
-                    if (n == 0) {
-                        keep[rb][hb] = acc[rb][hb];
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const size_t o = ((size_t)node * C + 16 * rb + 4 * g + r) * Ho + 16 * hb + x;
-                            out.p[n][o] = acc[rb][hb][r];
-                            if (n == 2) out.p[0][o] = keep[rb][hb][r] - acc[rb][hb][r] + bv[hb];
-                        }
-                    }
-                }
-        }
-#pragma unroll
-        for (int rb = 0; rb < NRB; ++rb) cur[rb] = nxt[rb];
-        node = next_node;
-    }
-}
-
-template <int NB2, int HB, int L, int PL = 0>
-__global__ __launch_bounds__(MF_THREADS, 1) void node_bwd2k_x3_kernel(
-    const float* __restrict__ X, const float* __restrict__ X2, const float* __restrict__ Tc, const float* __restrict__ W,
-    PostGrad3 dP, float* __restrict__ dX, float* __restrict__ dX2, float* __restrict__ partial, int nodes, int want_db, int Lw) {
-    constexpr int K = 3, NRB = 2 * NB2, C = 32 * NB2, Ho = 16 * HB, LB = (L + 15) / 16;
-    constexpr int NBK = K * HB, S = (NBK + 1) / 2;
-    constexpr int nTB = (K - 1) * NRB * NB2, nWA = K * LB * S;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    u32x4* TB = reinterpret_cast<u32x4*>(smem_raw);     // [K-1][NRB rb][NB2 p]   T_c[16rb + x][32p + pair_row]
-    u32x4* WA = TB + nTB * 3 * 64;                       // [K n][LB][S]           W[(n, c, 16lb + x)][16hb + 4g + (e&3)], block 2s + (e>>2)
-    const int tid = threadIdx.x, lane = tid & 63, x = lane & 15, g = lane >> 4;
-    for (int idx = tid; idx < nTB * 64; idx += MF_THREADS) {
-        const int ll = idx & 63, f = idx >> 6, p = f % NB2, rb = (f / NB2) % NRB, c1 = f / (NB2 * NRB), gg = ll >> 4;
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = Tc[(size_t)(c1 + 1) * C * C + (16 * rb + (ll & 15)) * C + 32 * p + pair_row(gg, e)];
-        put_frag(TB, f, ll, v);
-    }
-    for (int idx = tid; idx < nWA * 64; idx += MF_THREADS) {
-        const int ll = idx & 63, f = idx >> 6, s = f % S, lb = (f / S) % LB, n = f / (S * LB), gg = ll >> 4;
-        const int l = 16 * lb + (ll & 15);
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int b = 2 * s + (e >> 2), c = b / HB, hb = b % HB;
-            const int wl = PL == 2 ? stc_wrow_swapped(l, Lw - 16) : l;
-            v[e] = (b < NBK && wl >= 0 && wl < Lw) ? W[((size_t)(n * K + c) * Lw + wl) * Ho + 16 * hb + 4 * gg + (e & 3)] : 0.f;
-        }
-        put_frag(WA, f, ll, v);
-    }
-    __syncthreads();
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nw = gridDim.x * MF_WAVES;
-    f32x4 dWt[K][LB][K][HB];
-    float dbp[HB];
-#pragma unroll
-    for (int n = 0; n < K; ++n)
-#pragma unroll
-        for (int lb = 0; lb < LB; ++lb)
-#pragma unroll
-            for (int c = 0; c < K; ++c)
-#pragma unroll
-                for (int hb = 0; hb < HB; ++hb) dWt[n][lb][c][hb] = kZero4;
-#pragma unroll
-    for (int hb = 0; hb < HB; ++hb) dbp[hb] = 0.f;
-
-    for (int node = blockIdx.x * MF_WAVES + wave; node < nodes; node += nw) {
-        const size_t r0 = (size_t)node * C;
-        float za[LB][NRB][4];                                   // X[16kb + 4g + t][16lb + x]
-#pragma unroll
-        for (int lb = 0; lb < LB; ++lb) {
-            const bool ok = 16 * lb + x < L;
-            constexpr int LD = PL == 1 ? 16 : L;
-            const int cinx = Lw - 16;
-            const float* col = PL == 1 ? (lb == 0 ? X : X2) + r0 * 16 + x : X + r0 * L + 16 * lb + (ok ? x : 0);
-#pragma unroll
-            for (int kb = 0; kb < NRB; ++kb)
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    if constexpr (PL == 2) {
-                        const size_t row = r0 + 16 * kb + 4 * g + t;
-                        za[lb][kb][t] = lb == 0 ? X[row * 16 + x] : (x < cinx ? X2[row * cinx + x] : 0.f);
-                    } else {
-                        const float zv = col[(size_t)(16 * kb + 4 * g + t) * LD];
-                        za[lb][kb][t] = ok ? zv : 0.f;
-                    }
-                }
-        }
-        const int lo = opaque(lane);
-        f32x4 z[LB][NRB];                                       // dX^T tiles, summed over the three weight sets
-#pragma unroll
-        for (int lb = 0; lb < LB; ++lb)
-#pragma unroll
-            for (int rb = 0; rb < NRB; ++rb) z[lb][rb] = kZero4;
-#pragma unroll
-        for (int n = 0; n < K; ++n) {                           // one weight set / gradient plane at a time
-            DyFrag<NRB, HB> gr;
-            gr.load(dP.p[n], node, x, g);
-            if (n == 0) {                                       // the bias sits on A = P_0 - P_2 + b: db = sum dP_0
-#pragma unroll
-                for (int kb = 0; kb < NRB; ++kb)
-#pragma unroll
-                    for (int hb = 0; hb < HB; ++hb) dbp[hb] += (gr.d[kb][hb][0] + gr.d[kb][hb][1]) + (gr.d[kb][hb][2] + gr.d[kb][hb][3]);
-            }
-            X3 gd[HB][NB2];
-#pragma unroll
-            for (int hb = 0; hb < HB; ++hb)
-#pragma unroll
-                for (int p = 0; p < NB2; ++p) gd[hb][p] = split8(gr.d[2 * p][hb], gr.d[2 * p + 1][hb]);
-            // (T_c dP_n)^T tiles (rows o, columns c'), then the B operands of dX for this weight set
-            f32x4 Qv[K - 1][NRB][HB];
-#pragma unroll
-            for (int c1 = 0; c1 < K - 1; ++c1)
-#pragma unroll
-                for (int rb = 0; rb < NRB; ++rb) {
-#pragma unroll
-                    for (int hb = 0; hb < HB; ++hb) Qv[c1][rb][hb] = kZero4;
-#pragma unroll
-                    for (int p = 0; p < NB2; ++p) {
-                        const X3 t = get_frag(TB, (c1 * NRB + rb) * NB2 + p, lo);
-#pragma unroll
-                        for (int hb = 0; hb < HB; ++hb) Qv[c1][rb][hb] = mma6(gd[hb][p], t, Qv[c1][rb][hb]);
-                    }
-                }
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                X3 qb[NRB];
-#pragma unroll
-                for (int rb = 0; rb < NRB; ++rb) {
-                    f32x4 blk[2];
-#pragma unroll
-                    for (int h2 = 0; h2 < 2; ++h2) {
-                        const int b = 2 * s + h2, c = b / HB, hb = b % HB;
-                        blk[h2] = b >= NBK ? kZero4 : (c == 0 ? gr.v[rb][hb] : Qv[c > 0 ? c - 1 : 0][rb][hb]);
-                    }
-                    qb[rb] = split8(blk[0], blk[1]);
-                }
-#pragma unroll
-                for (int lb = 0; lb < LB; ++lb) {
-                    const X3 w = get_frag(WA, (n * LB + lb) * S + s, lo);
-#pragma unroll
-                    for (int rb = 0; rb < NRB; ++rb) z[lb][rb] = mma6(w, qb[rb], z[lb][rb]);
-                }
-            }
-            // T_c dP_n tiles (rows c', columns o) as operands, then dW_{n,c} += X^T (T_c dP_n)
-            X3 qd[K - 1][HB][NB2];
-#pragma unroll
-            for (int c1 = 0; c1 < K - 1; ++c1) {
-                f32x4 Qd[NRB][HB];
-#pragma unroll
-                for (int rb = 0; rb < NRB; ++rb) {
-#pragma unroll
-                    for (int hb = 0; hb < HB; ++hb) Qd[rb][hb] = kZero4;
-#pragma unroll
-                    for (int p = 0; p < NB2; ++p) {
-                        const X3 t = get_frag(TB, (c1 * NRB + rb) * NB2 + p, lo);
-#pragma unroll
-                        for (int hb = 0; hb < HB; ++hb) Qd[rb][hb] = mma6(t, gd[hb][p], Qd[rb][hb]);
-                    }
-                }
-#pragma unroll
-                for (int hb = 0; hb < HB; ++hb)
-#pragma unroll
-                    for (int p = 0; p < NB2; ++p) qd[c1][hb][p] = split8(Qd[2 * p][hb], Qd[2 * p + 1][hb]);
-            }
-#pragma unroll
-            for (int lb = 0; lb < LB; ++lb)
-#pragma unroll
-                for (int p = 0; p < NB2; ++p) {
-                    const float (&zc)[NRB][4] = za[lb];
-                    const X3 a = split8(f32x4{zc[2 * p][0], zc[2 * p][1], zc[2 * p][2], zc[2 * p][3]},
-                                        f32x4{zc[2 * p + 1][0], zc[2 * p + 1][1], zc[2 * p + 1][2], zc[2 * p + 1][3]});
-#pragma unroll
-                    for (int c = 0; c < K; ++c)
-#pragma unroll
-                        for (int hb = 0; hb < HB; ++hb)
-                            dWt[n][lb][c][hb] = mma6(a, c == 0 ? gd[hb][p] : qd[c > 0 ? c - 1 : 0][hb][p], dWt[n][lb][c][hb]);
-                }
-        }
-#pragma unroll
-        for (int lb = 0; lb < LB; ++lb) {
-            if constexpr (PL == 1) {
-#pragma unroll
-                for (int rb = 0; rb < NRB; ++rb)
-                    *reinterpret_cast<f32x4*>((lb == 0 ? dX : dX2) + (r0 + 16 * rb + x) * 16 + 4 * g) = z[lb][rb];
-            } else if constexpr (PL == 2) {
-                if (lb == 0) {
-#pragma unroll
-                    for (int rb = 0; rb < NRB; ++rb)
-                        *reinterpret_cast<f32x4*>(dX + (r0 + 16 * rb + x) * 16 + 4 * g) = z[lb][rb];
-                }
-            } else if (16 * lb + 4 * g < L) {
-#pragma unroll
-                for (int rb = 0; rb < NRB; ++rb)
-                    *reinterpret_cast<f32x4*>(dX + (r0 + 16 * rb + x) * L + 16 * lb + 4 * g) = z[lb][rb];
-            }
-        }
-    }
-    combine_dw<K, LB, HB>(reinterpret_cast<float*>(smem_raw), dWt, dbp, partial, Lw, want_db, PL == 2 ? Lw - 16 : -1);
-}
-
 // --------------------------------------------------------------------------------------- host side
-template <int NB2, int HB, int K, int L, int EPI = EPI_NONE, int GATHER = 0, int PL = 0, int POST = 0, class F = FmtB3>
+template <int NB2, int HB, int K, int L, int EPI = EPI_NONE, int PL = 0, int POST = 0, class F = FmtB3>
 int launch_fwd(const float* const* Z, const float* Tc, const float* W, const float* bias, float* Y,
-               long long nodes, int Lw, hipStream_t stream, FwdEpi epi = FwdEpi{}, GatherArgs ga = GatherArgs{}, PostArgs post = PostArgs{}) {
+               long long nodes, int Lw, hipStream_t stream, FwdEpi epi = FwdEpi{}, PostArgs post = PostArgs{}) {
     constexpr int NRB = 2 * NB2, NCB = K * HB;
     const size_t lds = (size_t)(K * NCB + (K - 1) * NRB * NB2 + (POST ? K * K : 0)) * F::NP * 64 * 16 + (POST ? (size_t)MF_WAVES * NRB * 16 * 20 * 4 : 0);
     if (lds > stc::kMaxLdsBytes) return STC_NOT_HANDLED;
-    auto kern = node_fwd_x3_kernel<NB2, HB, K, L, EPI, GATHER, PL, POST, F>;
+    auto kern = node_fwd_x3_kernel<NB2, HB, K, L, EPI, PL, POST, F>;
     if (int rc = stc::hip_status(stc::allow_lds(kern, lds), "hipFuncSetAttribute(node fwd x3)")) return rc;
     static const int resident = stc::resident_blocks(kern, MF_THREADS, lds, 2);   // persistent grid = what fits at once
     ZPtrs zp{};
-    for (int n = 0; n < (GATHER ? 1 : K); ++n) { zp.p[n] = Z[n]; if (PL) zp.q[n] = Z[K + n]; }      // planar: Z = {X planes, H planes}
+    for (int n = 0; n < K; ++n) { zp.p[n] = Z[n]; if (PL) zp.q[n] = Z[K + n]; }      // planar: Z = {X planes, H planes}
     const long long want = (nodes + MF_WAVES - 1) / MF_WAVES;
     const int grid = (int)(want < resident ? want : resident);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(MF_THREADS), lds, stream, zp, Tc, W, bias, Y, (int)nodes, Lw, epi, ga, post);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(MF_THREADS), lds, stream, zp, Tc, W, bias, Y, (int)nodes, Lw, epi, post);
     STC_LAUNCH_CHECK("node_fwd_x3 launch");
     return STC_OK;
 }
@@ -1415,48 +1070,6 @@ int stc_cell_cand_bwd_x3(const float* const* Z, int K, const float* Tc, const fl
     return STC_NOT_HANDLED;
 }
 
-// ---- fused aggregation + cell convolution (K = 2): Z1 = S.Z0 is produced by the kernel, not read
-#define STC_X3_GATHER_CASE(CALL)                                                                        \
-    if (C == 32 && L == 20) return CALL(1, 20);                                                         \
-    if (C == 32 && L == 32) return CALL(1, 32);                                                         \
-    if (C == 64 && L == 20) return CALL(2, 20);                                                         \
-    if (C == 64 && L == 32) return CALL(2, 32);
-
-int stc_cell_gather_shape_ok(int K, int C, int L, int h) {
-    return K == 2 && (C == 32 || C == 64) && (L == 20 || L == 32) && h == 16;
-}
-
-int stc_cell_gates_fwd_gather_x3(const int* rowptr, const int* colidx, const float* val, long long n,
-                                 const float* Z0, float* Z1, const float* Tc, const float* W, const float* bias,
-                                 const float* H, float* U, float* R, float* CandIn,
-                                 long long nodes, int C, int L, int Lw, int cin, hipStream_t stream) {
-    if (!x3_cell_shape(2, C, L, nodes) || !stc::aligned16(Z0) || !stc::aligned16(Z1)) return STC_NOT_HANDLED;
-    FwdEpi epi{};
-    epi.H = H; epi.U_out = U; epi.R_out = R; epi.CandIn = CandIn; epi.cin = cin;
-    const GatherArgs ga{rowptr, colidx, val, (int)n, Z1};
-    const float* Z[1] = {Z0};
-#define GG_CALL(a, d) launch_fwd<a, 2, 2, d, EPI_GATES, 1>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi, ga)
-    STC_X3_GATHER_CASE(GG_CALL)
-#undef GG_CALL
-    return STC_NOT_HANDLED;
-}
-
-int stc_cell_blend_fwd_gather_x3(const int* rowptr, const int* colidx, const float* val, long long n,
-                                 const float* Z0, float* Z1, const float* Tc, const float* W, const float* bias,
-                                 const float* U, const float* H, float* Cand, float* Hnew,
-                                 long long nodes, int C, int L, int Lw, hipStream_t stream) {
-    if (!x3_cell_shape(2, C, L, nodes) || !stc::aligned16(Z0) || !stc::aligned16(Z1)) return STC_NOT_HANDLED;
-    FwdEpi epi{};
-    epi.H = H; epi.U = U; epi.Cand = Cand; epi.Hnew = Hnew;
-    const GatherArgs ga{rowptr, colidx, val, (int)n, Z1};
-    const float* Z[1] = {Z0};
-#define BG_CALL(a, d) launch_fwd<a, 1, 2, d, EPI_BLEND, 1>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi, ga)
-    STC_X3_GATHER_CASE(BG_CALL)
-#undef BG_CALL
-    return STC_NOT_HANDLED;
-}
-
-// ---- post-aggregation backward (K = 2): (X, dA, dBm) -> dX, dW partials
 template <int NB2, int HB, int L, int PL = 0>
 static int launch_bwd2(const float* X, const float* X2, const float* Tc, const float* W, const float* dA, const float* dB, float* dX, float* dX2,
                        float* partial, int* n_partials, int want_db, long long nodes, int Lw, hipStream_t stream) {
@@ -1553,18 +1166,18 @@ static int gates_fwd_planar_go(const float* X, const float* H, const float* SX, 
     if (cin == 16) {
         const float* Z[4] = {X, SX, H, SH};
         if (!all_aligned16(Z, 4)) return STC_NOT_HANDLED;
-        if (C == 32 && fused) return launch_fwd<1, 2, 2, 32, EPI_GATES, 0, 1, 1, F>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi, GatherArgs{}, post);
-        if (C == 32) return launch_fwd<1, 2, 2, 32, EPI_GATES, 0, 1, 0, F>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi);
-        if (C == 64 && fused) return launch_fwd<2, 2, 2, 32, EPI_GATES, 0, 1, 1, F>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi, GatherArgs{}, post);
-        if (C == 64) return launch_fwd<2, 2, 2, 32, EPI_GATES, 0, 1, 0, F>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi);
+        if (C == 32 && fused) return launch_fwd<1, 2, 2, 32, EPI_GATES, 1, 1, F>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi, post);
+        if (C == 32) return launch_fwd<1, 2, 2, 32, EPI_GATES, 1, 0, F>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi);
+        if (C == 64 && fused) return launch_fwd<2, 2, 2, 32, EPI_GATES, 1, 1, F>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi, post);
+        if (C == 64) return launch_fwd<2, 2, 2, 32, EPI_GATES, 1, 0, F>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi);
         return STC_NOT_HANDLED;
     }
     const float* Z[4] = {H, SH, X, SX};          // narrow input: the STATE plane leads, columns [H | Xt | pad]
     if (!stc::aligned16(H) || !stc::aligned16(SH)) return STC_NOT_HANDLED;
-    if (C == 32 && fused) return launch_fwd<1, 2, 2, 20, EPI_GATES, 0, 2, 1, F>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi, GatherArgs{}, post);
-    if (C == 32) return launch_fwd<1, 2, 2, 20, EPI_GATES, 0, 2, 0, F>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi);
-    if (C == 64 && fused) return launch_fwd<2, 2, 2, 20, EPI_GATES, 0, 2, 1, F>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi, GatherArgs{}, post);
-    if (C == 64) return launch_fwd<2, 2, 2, 20, EPI_GATES, 0, 2, 0, F>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi);
+    if (C == 32 && fused) return launch_fwd<1, 2, 2, 20, EPI_GATES, 2, 1, F>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi, post);
+    if (C == 32) return launch_fwd<1, 2, 2, 20, EPI_GATES, 2, 0, F>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi);
+    if (C == 64 && fused) return launch_fwd<2, 2, 2, 20, EPI_GATES, 2, 1, F>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi, post);
+    if (C == 64) return launch_fwd<2, 2, 2, 20, EPI_GATES, 2, 0, F>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi);
     return STC_NOT_HANDLED;
 }
 
@@ -1637,10 +1250,10 @@ int stc_cell_conv_fwd_planar_k_x3(const float* const* Zx, const float* const* Zh
     else { epi.H = H; epi.U = Uin; epi.Cand = Cand; epi.Hnew = Hnew; }
     const float* Z[6];
     for (int n = 0; n < 3; ++n) { Z[n] = cin == 16 ? Zx[n] : Zh[n]; Z[3 + n] = cin == 16 ? Zh[n] : Zx[n]; }
-    if (mode == 1) return cin == 16 ? launch_fwd<1, 2, 3, 32, EPI_GATES, 0, 1>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi)
-                                    : launch_fwd<1, 2, 3, 20, EPI_GATES, 0, 2>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi);
-    return cin == 16 ? launch_fwd<1, 1, 3, 32, EPI_BLEND, 0, 1>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi)
-                     : launch_fwd<1, 1, 3, 20, EPI_BLEND, 0, 2>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi);
+    if (mode == 1) return cin == 16 ? launch_fwd<1, 2, 3, 32, EPI_GATES, 1>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi)
+                                    : launch_fwd<1, 2, 3, 20, EPI_GATES, 2>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi);
+    return cin == 16 ? launch_fwd<1, 1, 3, 32, EPI_BLEND, 1>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi)
+                     : launch_fwd<1, 1, 3, 20, EPI_BLEND, 2>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi);
 }
 
 int stc_cell_conv_bwd_planar_k_x3(const float* const* Zx, const float* const* Zh, int K, const float* Tc, const float* W, int mode,
@@ -1675,57 +1288,4 @@ int stc_cell_conv_bwd_planar_k_x3(const float* const* Zx, const float* const* Zh
     pro.dH_in = dHnew; pro.U = U; pro.Cand = Cand;
     return cin == 16 ? launch_bwd<1, 1, 3, 32, PRO_BLEND, 1>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro)
                      : launch_bwd<1, 1, 3, 20, PRO_BLEND, 2>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro);
-}
-
-// ---- post-aggregation form of order 3 (C = 32, Ho = 16, planar input: X = the 16-wide plane; X2 = the second 16-wide plane or the
-// narrow input plane), see node_fwd2k_x3_kernel
-int stc_node_post_k_shape_ok(int K, int C, int L, int Ho) { return K == 3 && C == 32 && (L == 20 || L == 32) && Ho == 16; }
-
-int stc_node_post_fwd_k_x3(const float* X, const float* X2, int K, const float* Tc, const float* W, const float* bias, float* const* P,
-                           long long nodes, int C, int L, int Lw, int Ho, hipStream_t stream) {
-    if (!stc_node_post_k_shape_ok(K, C, L, Ho) || !X2 || nodes <= 0 || nodes >= (1ll << 31) / C) return STC_NOT_HANDLED;
-    if (!(stc::aligned16(X) && stc::aligned16(P[0]) && stc::aligned16(P[1]) && stc::aligned16(P[2]) && (L == 20 || stc::aligned16(X2)))) return STC_NOT_HANDLED;
-    if (L == 20 && (Lw - 16 < 1 || Lw - 16 > 4)) return STC_NOT_HANDLED;
-    constexpr int KK = 3, NRB = 2, NCB = KK;
-    const size_t lds = (size_t)(KK * NCB + (KK - 1) * NRB) * 3 * 64 * 16;
-    const PostOut3 out{{P[0], P[1], P[2]}};
-    const long long want = (nodes + MF_WAVES - 1) / MF_WAVES;
-#define F2K_GO(L_, PL_) do { auto kern = node_fwd2k_x3_kernel<1, 1, L_, PL_>; \
-        if (int rc = stc::hip_status(stc::allow_lds(kern, lds), "hipFuncSetAttribute(node fwd2k x3)")) return rc; \
-        static const int resident = stc::resident_blocks(kern, MF_THREADS, lds, 1); \
-        const int grid = (int)(want < resident ? want : resident); \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(MF_THREADS), lds, stream, X, X2, Tc, W, bias, out, (int)nodes, Lw); } while (0)
-    if (L == 32) F2K_GO(32, 1); else F2K_GO(20, 2);
-#undef F2K_GO
-    STC_LAUNCH_CHECK("node_fwd2k_x3 launch");
-    return STC_OK;
-}
-
-int stc_node_post_bwd_k_x3(const float* X, const float* X2, int K, const float* Tc, const float* W, const float* const* dP, float* dX, float* dX2,
-                           float* partial, int* n_partials, int want_db, long long nodes, int C, int L, int Lw, int Ho, hipStream_t stream) {
-    if (!stc_node_post_k_shape_ok(K, C, L, Ho) || !X2 || nodes <= 0 || nodes >= (1ll << 31) / C) return STC_NOT_HANDLED;
-    if (!(stc::aligned16(X) && stc::aligned16(dP[0]) && stc::aligned16(dP[1]) && stc::aligned16(dP[2]) && stc::aligned16(dX) && (L == 20 || stc::aligned16(X2))))
-        return STC_NOT_HANDLED;
-    if (L == 32 && (!dX2 || !stc::aligned16(dX2))) return STC_NOT_HANDLED;
-    if (L == 20 && (Lw - 16 < 1 || Lw - 16 > 4)) return STC_NOT_HANDLED;
-    constexpr int KK = 3, NRB = 2, HB = 1, NBK = KK * HB, S = (NBK + 1) / 2;
-    const int LB = (L + 15) / 16, nW = KK * KK * L * 16;
-    const size_t frag = (size_t)((KK - 1) * NRB + KK * LB * S) * 3 * 64 * 16;
-    const size_t slabs = (size_t)MF_WAVES * (nW + 16) * sizeof(float);
-    const size_t lds = frag > slabs ? frag : slabs;
-    if (lds > stc::kMaxLdsBytes) return STC_NOT_HANDLED;
-    const PostGrad3 g{{dP[0], dP[1], dP[2]}};
-    const long long want = (nodes + MF_WAVES - 1) / MF_WAVES;
-    int grid = 0;
-#define B2K_GO(L_, PL_) do { auto kern = node_bwd2k_x3_kernel<1, 1, L_, PL_>; \
-        if (int rc = stc::hip_status(stc::allow_lds(kern, lds), "hipFuncSetAttribute(node bwd2k x3)")) return rc; \
-        static const int resident = stc::resident_blocks(kern, MF_THREADS, lds, 1); \
-        grid = resident < MF_BWD_MAX_GRID ? resident : MF_BWD_MAX_GRID; \
-        if (want < grid) grid = (int)want; \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(MF_THREADS), lds, stream, X, X2, Tc, W, g, dX, (PL_ == 1 ? dX2 : nullptr), partial, (int)nodes, want_db, Lw); } while (0)
-    if (L == 32) B2K_GO(32, 1); else B2K_GO(20, 2);
-#undef B2K_GO
-    STC_LAUNCH_CHECK("node_bwd2k_x3 launch");
-    *n_partials = grid;
-    return STC_OK;
 }

@@ -18,13 +18,10 @@
 //   output     = non-temporal stores (written once; keeps the output stream from evicting the X rows the
 //                neighbours still need from L2); Y0 read non-temporally for the same reason
 //
-// Epilogues.  The backward of an STC_Cell consumes the result of two of these products element-wise
-// (reference STC_GNN.py:68-75 through autograd): EP_GATES turns  dCandIn = dZ0 + Gs.dZ1  straight into the
-// gate pre-activation gradients dG, dXt and the running dH;  EP_SPLIT turns  d[Xt|H] = dZ0 + Gs.dZ1  into
-// dXt += ..., dH += ... -- so neither concatenated gradient tensor is ever written to HBM.
+// Epilogues: the GRU blend of the forward (EP_BLEND: Cand = tanh(A + S.Bm), Hnew = (1-U) H + U Cand, reference STC_GNN.py:76-78) and the
+// state-gradient sums of the backward (EP_SUM / EP_SUM2: Y = sum of addend planes + alpha S.(X [+ X2]), optionally with the blend backward
+// dY = Y U (1 - Cand^2) and the launch's max |Y| on the way) run on the accumulators, so neither intermediate is written to HBM.
 #include "stc_common.h"
-
-#include <cstdlib>
 
 #ifndef STC_BCSR_DEFAULT_BLOCKS
 #define STC_BCSR_DEFAULT_BLOCKS 2
@@ -58,17 +55,14 @@ __device__ __forceinline__ void nt_store4(float4* p, const float4& v) {
     __builtin_nontemporal_store(v4f{v.x, v.y, v.z, v.w}, reinterpret_cast<v4f*>(p));
 }
 
-enum { EP_PLAIN = 0, EP_SPLIT = 1, EP_GATES = 2, EP_BLEND = 3, EP_SUM = 4, EP_SUM2 = 5 };
+enum { EP_PLAIN = 0, EP_BLEND = 3, EP_SUM = 4, EP_SUM2 = 5 };
 
 struct EpiArgs {
-    const float4* Y0;                       // base term (PLAIN: optional, scaled by beta; SPLIT/GATES: added)
-    float4* Y;                              // PLAIN output
-    float alpha, beta;                      // PLAIN
-    int C, L, cin, h;                       // row geometry of SPLIT/GATES: F = C*L, L = cin + h + pad
-    const float *dU, *H, *U, *R, *dH_in;    // GATES inputs, (rows*C, h)
-    float* dG;                              // GATES output, (rows*C, 2h)
-    const float *addA, *addB;               // SPLIT: gradients already owed to Xt / H (may be null, may alias outA/outB)
-    float *outA, *outB;                     // dXt (rows*C, cin), dH (rows*C, h)
+    const float4* Y0;                       // base term (PLAIN: optional, scaled by beta; BLEND: A)
+    float4* Y;                              // PLAIN / SUM output
+    float alpha, beta;                      // PLAIN (SUM: alpha)
+    int C, L, cin, h;                       // row geometry: rows of C categories x h = 16 floats (L = h, cin = 0)
+    const float *H, *U;                     // BLEND inputs, (rows*C, h)
     // BLEND (forward, post-aggregation candidate convolution): Y0 = A (bias included), rows of C*h floats;
     // Cand = tanh(A + S.Bm), Hnew = (1-U)*H + U*Cand, plus the state copies of stc_cell_blend_fwd_f32
     float *Cand, *Hnew;                     // (rows*C, h)
@@ -92,26 +86,6 @@ __device__ __forceinline__ void publish_amax(const EpiArgs& ep, float m) {
     if ((threadIdx.x & 63) == 0 && m > 0.f) {
         const unsigned slot = (blockIdx.x + blockIdx.y * gridDim.x + (threadIdx.x >> 6) * 7u) % (unsigned)ep.n_amax;
         atomicMax(ep.amax + slot, __float_as_uint(m));
-    }
-}
-
-// one element of a [Xt | H | pad] row: l = column, e = (row, category) index, v = its gradient
-template <int MODE>
-__device__ __forceinline__ void route_scalar(const EpiArgs& a, size_t e, int l, float v) {
-    if (l < a.cin) {
-        const size_t i = e * a.cin + l;
-        a.outA[i] = (MODE == EP_SPLIT && a.addA) ? v + a.addA[i] : v;
-    } else if (l < a.cin + a.h) {
-        const int k = l - a.cin;
-        const size_t i = e * a.h + k;
-        if (MODE == EP_SPLIT) {
-            a.outB[i] = a.addB ? v + a.addB[i] : v;
-        } else {
-            const float u = a.U[i], r = a.R[i];
-            a.dG[e * 2 * a.h + k] = a.dU[i] * u * (1.f - u);
-            a.dG[e * 2 * a.h + a.h + k] = v * a.H[i] * r * (1.f - r);
-            a.outB[i] = a.dH_in ? fmaf(v, r, a.dH_in[i]) : v * r;
-        }
     }
 }
 
@@ -178,57 +152,11 @@ __device__ __forceinline__ void epilogue(const EpiArgs& a, size_t rowg, int F4, 
         }
         return;
     }
+    // EP_BLEND: rows are (category, h) with h = 16: piece ch = 4 * category + quarter
     const float4 y0 = nt_load4(a.Y0 + o);
     const float4 v = make_float4(acc.x + y0.x, acc.y + y0.y, acc.z + y0.z, acc.w + y0.w);
-    if (MODE == EP_BLEND) {                 // rows are (category, h) with h = 16: piece ch = 4 * category + quarter
-        const float4 u = *reinterpret_cast<const float4*>(a.U + 4 * o), hh = *reinterpret_cast<const float4*>(a.H + 4 * o);
-        blend_piece(a, rowg, ch, o, v, u, hh);
-        return;
-    }
-    const int f = ch * 4;
-    const int c = f / a.L, l = f - c * a.L;
-    const size_t e = rowg * a.C + c;
-    if (((a.cin | a.h) & 3) == 0) {          // a 16-byte piece never straddles the Xt | H | pad boundaries
-        if (l < a.cin) {
-            float4* dst = reinterpret_cast<float4*>(a.outA + e * a.cin + l);
-            if (MODE == EP_SPLIT && a.addA) {
-                const float4 p = *reinterpret_cast<const float4*>(a.addA + e * a.cin + l);
-                *dst = make_float4(v.x + p.x, v.y + p.y, v.z + p.z, v.w + p.w);
-            } else {
-                *dst = v;
-            }
-        } else if (l < a.cin + a.h) {
-            const size_t i = e * a.h + (l - a.cin);
-            float4* dst = reinterpret_cast<float4*>(a.outB + i);
-            if (MODE == EP_SPLIT) {
-                if (a.addB) {
-                    const float4 p = *reinterpret_cast<const float4*>(a.addB + i);
-                    *dst = make_float4(v.x + p.x, v.y + p.y, v.z + p.z, v.w + p.w);
-                } else {
-                    *dst = v;
-                }
-            } else {
-                const float4 u = *reinterpret_cast<const float4*>(a.U + i), r = *reinterpret_cast<const float4*>(a.R + i);
-                const float4 du = *reinterpret_cast<const float4*>(a.dU + i), hh = *reinterpret_cast<const float4*>(a.H + i);
-                float* g = a.dG + e * 2 * a.h + (l - a.cin);
-                *reinterpret_cast<float4*>(g) = make_float4(du.x * u.x * (1.f - u.x), du.y * u.y * (1.f - u.y),
-                                                            du.z * u.z * (1.f - u.z), du.w * u.w * (1.f - u.w));
-                *reinterpret_cast<float4*>(g + a.h) = make_float4(v.x * hh.x * r.x * (1.f - r.x), v.y * hh.y * r.y * (1.f - r.y),
-                                                                  v.z * hh.z * r.z * (1.f - r.z), v.w * hh.w * r.w * (1.f - r.w));
-                float4 dh = make_float4(v.x * r.x, v.y * r.y, v.z * r.z, v.w * r.w);
-                if (a.dH_in) {
-                    const float4 p = *reinterpret_cast<const float4*>(a.dH_in + i);
-                    dh.x += p.x; dh.y += p.y; dh.z += p.z; dh.w += p.w;
-                }
-                *dst = dh;
-            }
-        }
-    } else {                                   // in + hidden = 17 padded to 20: route the four elements one by one
-        route_scalar<MODE>(a, e, l, v.x);
-        route_scalar<MODE>(a, e, l + 1, v.y);
-        route_scalar<MODE>(a, e, l + 2, v.z);
-        route_scalar<MODE>(a, e, l + 3, v.w);
-    }
+    const float4 u = *reinterpret_cast<const float4*>(a.U + 4 * o), hh = *reinterpret_cast<const float4*>(a.H + 4 * o);
+    blend_piece(a, rowg, ch, o, v, u, hh);
 }
 
 // ---- CSR: one wave per output row ------------------------------------------------------------------------------
@@ -675,21 +603,16 @@ int launch_vector(const char* who, const GraphArgs& g, int n_rows, int n_cols, c
     const float4* X4 = reinterpret_cast<const float4*>(X);
     if (g.blk_ptr) {
         const int n_blocks = (n_rows + BR - 1) / BR;
-        // STC_BCSR_BLOCKS (A/B runs): row blocks per workgroup, 2 / 4 / 8
-        static const int blocks = [] { const char* e = std::getenv("STC_BCSR_BLOCKS"); const int v = e ? std::atoi(e) : STC_BCSR_DEFAULT_BLOCKS;
-                                       return (v == 2 || v == 4 || v == 8) ? v : STC_BCSR_DEFAULT_BLOCKS; }();
+        constexpr int blocks = STC_BCSR_DEFAULT_BLOCKS;      // row blocks per workgroup (2: two waves share a block; 4 and 8 measured slower)
         const int n_tiles = (n_blocks + blocks - 1) / blocks;
         const int per = (n_tiles + stc::kNumXcd - 1) / stc::kNumXcd;
         const dim3 grid(per * stc::kNumXcd, batch), block(SPMM_THREADS);
         // The pipelined gather is used where it measured faster on MI355X (profiles/r02/c_kbench_spmm.txt): the plain product
         // Y = alpha S.X with full column blocks (F=1024, B=1: 99 -> 86 us; F=512, B=5: 218 -> 210 us).  With a Y0 operand or an
         // epilogue (sum / blend forms) the extra live registers cost what the pipelining gains (equal or slower): old loop.
-        // STC_SPMM_PIPE=0 (A/B runs): the un-pipelined gather loop everywhere
-        static const bool pipe_on = [] { const char* e = std::getenv("STC_SPMM_PIPE"); return !(e && e[0] == '0'); }();
         // (measured again for the state-gradient sum with ONE gathered operand, which is what the cell graph launches now: 27.1 vs 27.3 ms)
-        const bool pipe = pipe_on && MODE == EP_PLAIN && (ep.Y0 == nullptr || ep.beta == 0.f);
-        static const int pad_lds = [] { const char* e = std::getenv("STC_SPMM_PAD_LDS"); return e ? std::atoi(e) : 0; }();     // diagnostic: fewer resident workgroups
-#define STC_BCSR_GO(VPT_, BLK_) do { if (pipe && BLK_ == 2 && F4 % (128 * VPT_) == 0) hipLaunchKernelGGL((spmm_bcsr_kernel<VPT_, MODE, 2, (MODE == EP_PLAIN), (MODE == EP_PLAIN)>), grid, block, pad_lds, s, g.blk_ptr, g.blk_cols, g.blk_vals, \
+        const bool pipe = MODE == EP_PLAIN && (ep.Y0 == nullptr || ep.beta == 0.f);
+#define STC_BCSR_GO(VPT_, BLK_) do { if (pipe && BLK_ == 2 && F4 % (128 * VPT_) == 0) hipLaunchKernelGGL((spmm_bcsr_kernel<VPT_, MODE, 2, (MODE == EP_PLAIN), (MODE == EP_PLAIN)>), grid, block, 0, s, g.blk_ptr, g.blk_cols, g.blk_vals, \
                                                    n_rows, n_cols, X4, F4, n_blocks, n_tiles, ep); \
                                      else hipLaunchKernelGGL((spmm_bcsr_kernel<VPT_, MODE, BLK_, 0, 0>), grid, block, 0, s, g.blk_ptr, g.blk_cols, g.blk_vals, \
                                                    n_rows, n_cols, X4, F4, n_blocks, n_tiles, ep); } while (0)
@@ -799,48 +722,6 @@ extern "C" int stc_bcsr_spmm_f32(const int32_t* blk_ptr, const int32_t* blk_cols
     ep.beta = beta;
     const GraphArgs g{nullptr, nullptr, nullptr, blk_ptr, blk_cols, blk_vals};
     return launch_vector<EP_PLAIN>("stc_bcsr_spmm_f32 launch", g, n_rows, n_cols, X, batch, F, ep, static_cast<hipStream_t>(stream));
-}
-
-extern "C" int stc_spmm_bwd_gates_f32(const int32_t* rowptr, const int32_t* colidx, const float* val,
-                                      const int32_t* blk_ptr, const int32_t* blk_cols, const float* blk_vals,
-                                      int32_t n_rows, int32_t n_cols, const float* X, const float* Y0,
-                                      const float* dU, const float* H, const float* U, const float* Rg, const float* dH_in,
-                                      float* dG, float* dXt, float* dH,
-                                      int32_t batch, int32_t C, int32_t cin, int32_t h, int32_t pad, void* stream) {
-    const GraphArgs g{rowptr, colidx, val, blk_ptr, blk_cols, blk_vals};
-    if (int rc = check_fused("stc_spmm_bwd_gates_f32", g, n_rows, n_cols, X, Y0, batch, C, cin, h, pad)) return rc;
-    if (n_rows == 0 || batch == 0) return STC_OK;
-    STC_REQUIRE(dU && H && U && Rg && dG && dH && (cin == 0 || dXt), STC_EINVAL, "stc_spmm_bwd_gates_f32: null pointer");
-    if (((cin | h) & 3) == 0)
-        STC_REQUIRE(stc::aligned16(dU) && stc::aligned16(H) && stc::aligned16(U) && stc::aligned16(Rg) && stc::aligned16(dG) &&
-                        stc::aligned16(dH) && (!dH_in || stc::aligned16(dH_in)) && (!dXt || stc::aligned16(dXt)),
-                    STC_EALIGN, "stc_spmm_bwd_gates_f32: operands must be 16-byte aligned");
-    EpiArgs ep{};
-    ep.Y0 = reinterpret_cast<const float4*>(Y0);
-    ep.C = C; ep.L = cin + h + pad; ep.cin = cin; ep.h = h;
-    ep.dU = dU; ep.H = H; ep.U = U; ep.R = Rg; ep.dH_in = dH_in; ep.dG = dG; ep.outA = dXt; ep.outB = dH;
-    return launch_vector<EP_GATES>("stc_spmm_bwd_gates_f32 launch", g, n_rows, n_cols, X, batch, C * (cin + h + pad), ep,
-                                   static_cast<hipStream_t>(stream));
-}
-
-extern "C" int stc_spmm_bwd_split_f32(const int32_t* rowptr, const int32_t* colidx, const float* val,
-                                      const int32_t* blk_ptr, const int32_t* blk_cols, const float* blk_vals,
-                                      int32_t n_rows, int32_t n_cols, const float* X, const float* Y0,
-                                      const float* addA, const float* addB, float* outA, float* outB,
-                                      int32_t batch, int32_t C, int32_t cin, int32_t h, int32_t pad, void* stream) {
-    const GraphArgs g{rowptr, colidx, val, blk_ptr, blk_cols, blk_vals};
-    if (int rc = check_fused("stc_spmm_bwd_split_f32", g, n_rows, n_cols, X, Y0, batch, C, cin, h, pad)) return rc;
-    if (n_rows == 0 || batch == 0) return STC_OK;
-    STC_REQUIRE(outB && (cin == 0 || outA), STC_EINVAL, "stc_spmm_bwd_split_f32: null output");
-    if (((cin | h) & 3) == 0)
-        STC_REQUIRE(stc::aligned16(outB) && (!outA || stc::aligned16(outA)) && (!addA || stc::aligned16(addA)) && (!addB || stc::aligned16(addB)),
-                    STC_EALIGN, "stc_spmm_bwd_split_f32: operands must be 16-byte aligned");
-    EpiArgs ep{};
-    ep.Y0 = reinterpret_cast<const float4*>(Y0);
-    ep.C = C; ep.L = cin + h + pad; ep.cin = cin; ep.h = h;
-    ep.addA = addA; ep.addB = addB; ep.outA = outA; ep.outB = outB;
-    return launch_vector<EP_SPLIT>("stc_spmm_bwd_split_f32 launch", g, n_rows, n_cols, X, batch, C * (cin + h + pad), ep,
-                                   static_cast<hipStream_t>(stream));
 }
 
 extern "C" int stc_spmm_blend_fwd_f32(const int32_t* rowptr, const int32_t* colidx, const float* val,

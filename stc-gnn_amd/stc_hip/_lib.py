@@ -30,7 +30,7 @@ EXPORTS = (
     'stc_csr_spmm_f32', 'stc_bcsr_spmm_f32', 'stc_csr_spmm_bf16', 'stc_bcsr_spmm_bf16', 'stc_bdg_node_bf16_supported', 'stc_bdg_node_fwd_bf16', 'stc_bdg_node_bwd_bf16',
     'stc_cell_planar_bf16_supported', 'stc_cell_gates_fwd_planar_bf16', 'stc_cell_gates_bwd_planar_bf16', 'stc_bdg_node_post_bwd_bf16',
     'stc_spmm_blend_fwd_bf16', 'stc_spmm_sum_bf16', 'stc_gru_blend_bwd_bf16', 'stc_head_fwd_bf16', 'stc_head_bwd_bf16',
-    'stc_spmm_bwd_gates_f32', 'stc_spmm_bwd_split_f32', 'stc_csr_sddmm_f32',
+    'stc_csr_sddmm_f32', 'stc_set_dispatch_level',
     'stc_cheby_dense_fwd_f32', 'stc_cheby_dense_bwd_f32',
     'stc_bdg_node_fwd_f32', 'stc_bdg_node_bwd_workspace_bytes', 'stc_bdg_node_bwd_f32',
     'stc_bdg_node_post_supported', 'stc_bdg_node_post_fwd_f32', 'stc_bdg_node_post_bwd_f32', 'stc_spmm_blend_fwd_f32',
@@ -38,8 +38,7 @@ EXPORTS = (
     'stc_cell_planar_supported', 'stc_cell_gates_fwd_planar_f32', 'stc_cell_gates_bwd_planar_f32', 'stc_spmm_sum_f32',
     'stc_cell_bwd_planar_supported', 'stc_cell_bwd_planar_workspace_bytes', 'stc_cell_bwd_planar_f32',
     'stc_cell_planar_k_supported', 'stc_cell_gates_fwd_planar_k_f32', 'stc_cell_cand_fwd_planar_k_f32', 'stc_cell_gates_bwd_planar_k_f32',
-    'stc_cell_cand_bwd_planar_k_f32', 'stc_bdg_node_post_k_supported', 'stc_bdg_node_post_fwd_k_f32', 'stc_bdg_node_post_bwd_k_f32',
-    'stc_cell_gather_supported', 'stc_cell_gates_fwd_gather_f32', 'stc_cell_blend_fwd_gather_f32',
+    'stc_cell_cand_bwd_planar_k_f32',
     'stc_gru_gates_fwd_f32', 'stc_gru_gates_bwd_f32', 'stc_gru_blend_fwd_f32', 'stc_gru_blend_bwd_f32',
     'stc_head_fwd_f32', 'stc_head_bwd_workspace_bytes', 'stc_head_bwd_f32',
     'stc_axpy_f32', 'stc_concat2_f32', 'stc_split2_f32',
@@ -66,8 +65,6 @@ def _declare(lib):
         'stc_bcsr_spmm_f32': [_p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _f32, _p],
         'stc_csr_spmm_bf16': [_p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _f32, _p],
         'stc_bcsr_spmm_bf16': [_p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _f32, _p],
-        'stc_spmm_bwd_gates_f32': [_p] * 6 + [_i32, _i32] + [_p] * 10 + [_i32] * 5 + [_p],
-        'stc_spmm_bwd_split_f32': [_p] * 6 + [_i32, _i32] + [_p] * 6 + [_i32] * 5 + [_p],
         'stc_csr_sddmm_f32': [_p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _i32, _p],
         'stc_cheby_dense_fwd_f32': [_p, _i32, _i32, _p, _p],
         'stc_cheby_dense_bwd_f32': [_p, _p, _p, _i32, _i32, _p, _p],
@@ -99,16 +96,12 @@ def _declare(lib):
                                             _p, C.c_size_t, _i64, _i32, _i32, _i32, _p],
         'stc_cell_cand_bwd_planar_k_f32': [C.POINTER(_p), C.POINTER(_p), _i32, _p, _p, _p, _p, _p, C.POINTER(_p), C.POINTER(_p), _p, _p,
                                            _p, C.c_size_t, _i64, _i32, _i32, _i32, _p],
-        'stc_bdg_node_post_fwd_k_f32': [_p, _p, _i32, _p, _p, _p, C.POINTER(_p), _i64, _i32, _i32, _i32, _i32, _p],
-        'stc_bdg_node_post_bwd_k_f32': [_p, _p, _i32, _p, _p, C.POINTER(_p), _p, _p, _p, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _i32, _p],
         'stc_cell_gates_fwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _i32, _p],
         'stc_cell_cand_bwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _p, C.POINTER(_p), _p, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _i32, _p],
         'stc_cell_gates_bwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _i32, C.POINTER(_p), _p, _p, _p, _p,
                                    _p, C.c_size_t, _i64, _i32, _i32, _i32, _i32, _i32, _p],
         'stc_cell_blend_fwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _p, _i32, _p, _i32, _i32,
                                    _i64, _i32, _i32, _i32, _i32, _p],
-        'stc_cell_gates_fwd_gather_f32': [_p, _p, _p, _i64] + [_p] * 9 + [_i64, _i32, _i32, _i32, _i32, _i32, _p],
-        'stc_cell_blend_fwd_gather_f32': [_p, _p, _p, _i64] + [_p] * 9 + [_i64, _i32, _i32, _i32, _i32, _p],
         'stc_gru_gates_fwd_f32': [_p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p],
         'stc_gru_gates_bwd_f32': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p],
         'stc_gru_blend_fwd_f32': [_p, _p, _p, _p, _p, _i64, _p],
@@ -139,10 +132,8 @@ def _declare(lib):
     lib.stc_cell_bwd_planar_supported.argtypes = [_i32, _i32]
     lib.stc_cell_bwd_planar_workspace_bytes.restype = C.c_size_t
     lib.stc_cell_bwd_planar_workspace_bytes.argtypes = [_i32, _i32, _i32]
-    lib.stc_bdg_node_post_k_supported.restype = C.c_int
-    lib.stc_bdg_node_post_k_supported.argtypes = [_i32, _i32, _i32, _i32]
-    lib.stc_cell_gather_supported.restype = C.c_int
-    lib.stc_cell_gather_supported.argtypes = [_i32, _i32, _i32, _i32, _i32]
+    lib.stc_set_dispatch_level.restype = C.c_int
+    lib.stc_set_dispatch_level.argtypes = [_i32]
     lib.stc_head_bwd_workspace_bytes.restype = C.c_size_t
     lib.stc_head_bwd_workspace_bytes.argtypes = [_i32]
     lib.stc_bdg_node_bwd_workspace_bytes.restype = C.c_size_t
@@ -206,7 +197,7 @@ class HipKernels:
 
     name = 'hip-gfx950'
     #: the planar gates backward adds the state's share from its gate prologue into the H plane's gradient itself (dH=None)
-    folds_dH = os.environ.get('STC_FOLD_DH', '1') != '0'
+    folds_dH = True
     #: operand format of the split-operand matrix-core cell kernels (include/stc_hip.h "operand formats"): two fp16 pieces / three
     #: products by default, STC_OPERAND_FORMAT=bf16x3 keeps three bf16 pieces / six products (fp32's range, twice the matrix instructions)
     operand_format = {'f16x2': FMT_F16X2, 'bf16x3': FMT_BF16X3}[os.environ.get('STC_OPERAND_FORMAT', 'f16x2')]
@@ -218,6 +209,13 @@ class HipKernels:
         self._workspace = {}
         self._retired = []                            # outgrown workspaces, kept alive (see _get_workspace)
         self.timer: Optional[KernelTimer] = None      # set by bench.py to time every launch with HIP events
+
+    def set_dispatch_level(self, level: int):
+        """0 = every kernel path (default), 1 = no split-operand matrix-core kernels (fp32 MFMA instead), 2 = generic kernels only:
+        process-wide ceiling of the node / cell kernel dispatch (stc_set_dispatch_level), for tests and A/B runs."""
+        rc = self.lib.stc_set_dispatch_level(int(level))
+        if rc != 0:
+            raise StcError(f'stc_set_dispatch_level({level}) failed: {self.lib.stc_last_error().decode()}')
 
     def _launch(self, name, on, *args, nbytes=0, tag=None):
         """Call C entry point ``name`` with ``args`` + the current stream of ``on``'s device."""
@@ -364,35 +362,6 @@ class HipKernels:
         if F % C or F // C < cin + h:
             raise StcError(f'{what}: row of {F} floats is not C={C} x (cin={cin} + h={h} + pad)')
         return B, n, F // C - cin - h
-
-    def spmm_bwd_gates(self, rowptr, colidx, val, plan, X, Y0, dU, H, U, Rg, dH_in, dG, dXt, dH):
-        """dCandIn = Y0 + S.X consumed in the epilogue: dG, dXt, dH (+= dH_in).  See stc_spmm_bwd_gates_f32."""
-        Cc, h, cin = H.shape[-2], H.shape[-1], dXt.shape[-1]
-        B, n, pad = self._cell_rows('spmm_bwd_gates', X, Y0, Cc, cin, h)
-        for name, t, w in (('dU', dU, h), ('H', H, h), ('U', U, h), ('Rg', Rg, h), ('dH', dH, h), ('dG', dG, 2 * h), ('dXt', dXt, cin)) \
-                + ((('dH_in', dH_in, h),) if dH_in is not None else ()):
-            self._f32('spmm_bwd_gates.' + name, t)
-            if t.numel() != B * n * Cc * w:
-                raise StcError(f'spmm_bwd_gates.{name}: {t.numel()} elements, expected {B * n * Cc * w}')
-        g = self._graph_ptrs(rowptr, colidx, val, plan, n)
-        self._launch('stc_spmm_bwd_gates_f32', X, *g, n, n, _ptr(X), _ptr(Y0), _ptr(dU), _ptr(H), _ptr(U), _ptr(Rg), _ptr(dH_in),
-                     _ptr(dG), _ptr(dXt), _ptr(dH), B, Cc, cin, h, pad,
-                     nbytes=colidx.numel() * 8 + 4 * (n + 1) + 4 * B * n * Cc * (2 * (cin + h + pad) + 5 * h + 2 * h + cin + h))
-
-    def spmm_bwd_split(self, rowptr, colidx, val, plan, X, Y0, Cc, outA, outB, addA=None, addB=None):
-        """d[Xt|H] = Y0 + S.X consumed in the epilogue: outA = d[x] (+ addA), outB = d[h] (+ addB)."""
-        cin, h = outA.shape[-1], outB.shape[-1]
-        B, n, pad = self._cell_rows('spmm_bwd_split', X, Y0, Cc, cin, h)
-        for name, t, w in (('outA', outA, cin), ('outB', outB, h)) + ((('addA', addA, cin),) if addA is not None else ()) \
-                + ((('addB', addB, h),) if addB is not None else ()):
-            self._f32('spmm_bwd_split.' + name, t)
-            if t.numel() != B * n * Cc * w:
-                raise StcError(f'spmm_bwd_split.{name}: {t.numel()} elements, expected {B * n * Cc * w}')
-        g = self._graph_ptrs(rowptr, colidx, val, plan, n)
-        self._launch('stc_spmm_bwd_split_f32', X, *g, n, n, _ptr(X), _ptr(Y0), _ptr(addA), _ptr(addB), _ptr(outA), _ptr(outB),
-                     B, Cc, cin, h, pad,
-                     nbytes=colidx.numel() * 8 + 4 * (n + 1) + 4 * B * n * Cc * (2 * (cin + h + pad) + (2 if addA is not None else 1) * cin
-                                                                                  + (2 if addB is not None else 1) * h))
 
     def spmm_sum(self, rowptr, colidx, val, plan, X, X2, addends, Y, blend=None, alpha=1.0, amax=None):
         """Y = sum(scale * addend) + alpha * S.(X [+ X2]) on (B, n, C, h) state tensors (stc_spmm_sum_f32).  ``addends``: up to
@@ -669,9 +638,8 @@ class HipKernels:
         return R, Cc, h, cin
 
     def cell_planar_post_fused(self, Cc) -> bool:
-        """Whether cell_gates_fwd_planar can also run the candidate's projection (``post=``) for this category count
-        (``STC_FUSE_POST_C64=0`` keeps it a launch of its own at C = 64: A/B runs)."""
-        return Cc == 32 or (Cc == 64 and os.environ.get('STC_FUSE_POST_C64', '1') != '0')
+        """Whether cell_gates_fwd_planar can also run the candidate's projection (``post=``) for this category count."""
+        return Cc in (32, 64)
 
     def cell_gates_fwd_planar(self, X, H, SX, SH, Tc, W, bias, U, Rg, RH, post=None):
         """Gates convolution on planar inputs; writes U, Rg and the R*H plane (the candidate's input is (X, RH)).
@@ -698,7 +666,9 @@ class HipKernels:
                 self._f32('planar.' + name, t, (R, Cc, h))
         self._same_device(X, H, SX, SH, Tc, W, bias, U, Rg, RH, Wc, bc, A, Bm)
         self._launch('stc_cell_gates_fwd_planar_f32', H, _ptr(X), _ptr(H), _ptr(SX), _ptr(SH), _ptr(Tc), _ptr(W), _ptr(bias),
-                     _ptr(U), _ptr(Rg), _ptr(RH), _ptr(Wc), _ptr(bc), _ptr(A), _ptr(Bm), self.operand_format, R, Cc, cin + h, h)
+                     _ptr(U), _ptr(Rg), _ptr(RH), _ptr(Wc), _ptr(bc), _ptr(A), _ptr(Bm), self.operand_format, R, Cc, cin + h, h,
+                     # algorithmic bytes: X, SX (cin wide), H, SH in; U, Rg (+ RH, + A, Bm) out -- every plane once
+                     nbytes=4 * R * Cc * (2 * cin + 2 * h + h * (2 + (RH is not None) + (2 if post is not None else 0))))
 
     def cell_gates_bwd_planar(self, X, H, SX, SH, Tc, W, dRH, Cand, U, Rg, dHnew, dZs, dW, db, dH):
         """``dRH``: gradient of the R*H plane; ``dZs`` = [d X plane, d SX plane, d H plane, d SH plane] (the first two
@@ -725,7 +695,7 @@ class HipKernels:
 
     # ---- the whole backward of a planar cell step in one launch ----------------------------------------
     def cell_bwd_planar_supported(self, Cc, h) -> bool:
-        return os.environ.get('STC_FUSE_CELL_BWD', '1') != '0' and bool(self.lib.stc_cell_bwd_planar_supported(Cc, h))
+        return bool(self.lib.stc_cell_bwd_planar_supported(Cc, h))
 
     def cell_bwd_planar(self, X, H, SX, SH, Tc, Wg, Wc, U, Rg, Cand, dHnew, dBm, dZs, dWg, dbg, dWc, dbc, accumulate_x=False, accumulate_h=False,
                         grad_amax=None):
@@ -766,7 +736,11 @@ class HipKernels:
             grad_amax = None
         self._launch('stc_cell_bwd_planar_f32', H, _ptr(X), _ptr(H), _ptr(SX), _ptr(SH), _ptr(Tc), _ptr(Wg), _ptr(Wc), _ptr(U), _ptr(Rg), _ptr(Cand),
                      _ptr(dHnew), _ptr(dBm), *[_ptr(z) for z in dZs], _ptr(dWg), _ptr(dbg), _ptr(dWc), _ptr(dbc), int(bool(accumulate_x)), int(bool(accumulate_h)),
-                     _ptr(grad_amax), 0 if grad_amax is None else grad_amax.numel(), _ptr(ws), ws.numel(), R, Cc, cin + h, h)
+                     _ptr(grad_amax), 0 if grad_amax is None else grad_amax.numel(), _ptr(ws), ws.numel(), R, Cc, cin + h, h,
+                     # algorithmic bytes: X, SX (cin wide), H, SH, U, Rg, Cand, dHnew, dBm in; dH, dSH (+ dX, dSX) out; a plane that is
+                     # accumulated into is also read -- every plane once
+                     nbytes=4 * R * Cc * (2 * cin + 7 * h + 2 * h * (1 + bool(accumulate_h)) + (2 * h * (1 + bool(accumulate_x)) if cin == h else 0)),
+                     tag='wide' if cin == h else 'layer0')
 
     # ---- planar cell convolutions of Chebyshev order K = 3 ------------------------------------------------
     def cell_planar_k_supported(self, K, Cc, h) -> bool:
@@ -848,51 +822,6 @@ class HipKernels:
         ws = self._get_workspace(U.device, self.lib.stc_bdg_node_bwd_workspace_bytes(K, K, Cc, 2 * h, 2 * h, 0))
         self._launch('stc_cell_cand_bwd_planar_k_f32', U, self._ptr_array(Zx), self._ptr_array(Zh), K, _ptr(Tc), _ptr(W), _ptr(dHnew), _ptr(U), _ptr(Cand),
                      zx, zh, _ptr(dW), _ptr(db), _ptr(ws), ws.numel(), R, Cc, cin + h, h)
-
-    # ---- post-aggregation form at order 3 (planar input) -------------------------------------------------
-    def node_post_k_supported(self, K, Cc, L, Ho) -> bool:
-        return bool(self.lib.stc_bdg_node_post_k_supported(K, Cc, L, Ho))
-
-    def _post_k_rows(self, what, X, X2, Tc, W, K):
-        R, Cc, h = X.shape
-        w2 = X2.shape[-1]
-        if h != 16 or not (w2 == 16 or 1 <= w2 <= 4):
-            raise StcError(f'{what}: planes of 16 + (16 or 1..4) columns, got {h} + {w2}')
-        self._f32(what + '.X', X, (R, Cc, 16))
-        self._f32(what + '.X2', X2, (R, Cc, w2))
-        self._f32(what + '.Tc', Tc, (K, Cc, Cc))
-        Lw = 16 + w2
-        self._f32(what + '.W', W, (K * K * Lw, 16))
-        return R, Cc, (32 if w2 == 16 else 20), Lw
-
-    def node_post_fwd_k(self, X, Tc, W, bias, P, X2):
-        """P = [P_0 - P_2 + b, P_1, P_2] of the order-3 convolution on the planar row [X | X2] (narrow X2: reference order [X2 | X])."""
-        K = len(P)
-        R, Cc, L, Lw = self._post_k_rows('post_k', X, X2, Tc, W, K)
-        if bias is not None:
-            self._f32('post_k.bias', bias, (16,))
-        for n, t in enumerate(P):
-            self._f32(f'post_k.P[{n}]', t, (R, Cc, 16))
-        self._same_device(X, X2, Tc, W, bias, *P)
-        self._launch('stc_bdg_node_post_fwd_k_f32', X, _ptr(X), _ptr(X2), K, _ptr(Tc), _ptr(W), _ptr(bias), self._ptr_array(P), R, Cc, L, Lw, 16)
-
-    def node_post_bwd_k(self, X, Tc, W, dP, dX, dW, db, X2, dX2=None):
-        K = len(dP)
-        R, Cc, L, Lw = self._post_k_rows('post_k bwd', X, X2, Tc, W, K)
-        for n, t in enumerate(dP):
-            self._f32(f'post_k.dP[{n}]', t, (R, Cc, 16))
-        self._f32('post_k.dX', dX, (R, Cc, 16))
-        if (dX2 is not None) != (L == 32):
-            raise StcError('post_k bwd: dX2 goes with a 16 + 16 planar input and only with it')
-        if dX2 is not None:
-            self._f32('post_k.dX2', dX2, (R, Cc, 16))
-        self._f32('post_k.dW', dW, tuple(W.shape))
-        if db is not None:
-            self._f32('post_k.db', db, (16,))
-        self._same_device(X, X2, Tc, W, *dP, dX, dX2, dW, db)
-        ws = self._get_workspace(X.device, self.lib.stc_bdg_node_bwd_workspace_bytes(K, K, Cc, L, 16, 0))
-        self._launch('stc_bdg_node_post_bwd_k_f32', X, _ptr(X), _ptr(X2), K, _ptr(Tc), _ptr(W), self._ptr_array(dP), _ptr(dX), _ptr(dX2), _ptr(dW), _ptr(db),
-                     _ptr(ws), ws.numel(), R, Cc, L, Lw, 16)
 
     # ---- fused cell convolutions ----------------------------------------------------------
     def cell_fused_supported(self, Ks, Kc, Cc, L, h) -> bool:
@@ -992,52 +921,6 @@ class HipKernels:
         self._launch('stc_cell_blend_fwd_f32', H, self._ptr_array(Zs), Ks, _ptr(Tc), Kc, _ptr(W), _ptr(bias), _ptr(U), _ptr(H),
                      _ptr(Cand), _ptr(Hnew), _ptr(cp[0][0]), cp[0][1], cp[0][2], _ptr(side), side_cin, _ptr(cp[1][0]), cp[1][1], cp[1][2],
                      R, Cc, L, Lw, h)
-
-    # ---- the same with the aggregation Z1 = S.Z0 fused in (Ks = Kc = 2) -------------------------
-    def cell_gather_supported(self, Ks, Kc, Cc, L, h) -> bool:
-        return bool(self.lib.stc_cell_gather_supported(Ks, Kc, Cc, L, h))
-
-    def _gather_args(self, rowptr, colidx, val, n, Z0, Z1, Tc, W):
-        R, Cc, L = Z0.shape
-        self._f32('gather.Z0', Z0, (R, Cc, L))
-        self._f32('gather.Z1', Z1, (R, Cc, L))
-        if n < 1 or R % n:
-            raise StcError(f'gather: {R} node rows are not a multiple of the graph size {n}')
-        self._i32('gather.rowptr', rowptr, n + 1)
-        self._i32('gather.colidx', colidx)
-        self._f32('gather.val', val, (colidx.numel(),))
-        if Tc.dim() != 3 or Tc.shape[0] != 2:
-            raise StcError(f'gather: the fused aggregation needs Ks = Kc = 2, got Tc {tuple(Tc.shape)}')
-        return self._node_shapes([Z0, Z1], Tc, W)
-
-    def cell_gates_fwd_gather(self, rowptr, colidx, val, n, Z0, Z1, Tc, W, bias, H, U, Rg, CandIn):
-        """cell_gates_fwd with Z1 = S.Z0 gathered inside the kernel (and written to ``Z1``)."""
-        Ks, Kc, R, Cc, L, Lw, Ho = self._gather_args(rowptr, colidx, val, n, Z0, Z1, Tc, W)
-        h = H.shape[-1]
-        cin = Lw - h
-        if Ho != 2 * h or cin < 0:
-            raise StcError(f'cell_gates: W gives Ho={Ho}, Lw={Lw} for hidden {h}')
-        if bias is not None:
-            self._f32('cell.bias', bias, (Ho,))
-        for name, t in (('H', H), ('U', U), ('Rg', Rg)):
-            self._f32('cell.' + name, t, (R, Cc, h))
-        self._f32('cell.CandIn', CandIn, (R, Cc, L))
-        self._same_device(rowptr, colidx, val, Z0, Z1, Tc, W, bias, H, U, Rg, CandIn)
-        self._launch('stc_cell_gates_fwd_gather_f32', H, _ptr(rowptr), _ptr(colidx), _ptr(val), n, _ptr(Z0), _ptr(Z1), _ptr(Tc), _ptr(W),
-                     _ptr(bias), _ptr(H), _ptr(U), _ptr(Rg), _ptr(CandIn), R, Cc, L, Lw, h, cin)
-
-    def cell_blend_fwd_gather(self, rowptr, colidx, val, n, Z0, Z1, Tc, W, bias, U, H, Cand, Hnew):
-        Ks, Kc, R, Cc, L, Lw, Ho = self._gather_args(rowptr, colidx, val, n, Z0, Z1, Tc, W)
-        h = H.shape[-1]
-        if Ho != h:
-            raise StcError(f'cell_blend: W gives Ho={Ho} for hidden {h}')
-        if bias is not None:
-            self._f32('cell.bias', bias, (Ho,))
-        for name, t in (('U', U), ('H', H), ('Cand', Cand), ('Hnew', Hnew)):
-            self._f32('cell.' + name, t, (R, Cc, h))
-        self._same_device(rowptr, colidx, val, Z0, Z1, Tc, W, bias, U, H, Cand, Hnew)
-        self._launch('stc_cell_blend_fwd_gather_f32', H, _ptr(rowptr), _ptr(colidx), _ptr(val), n, _ptr(Z0), _ptr(Z1), _ptr(Tc), _ptr(W),
-                     _ptr(bias), _ptr(U), _ptr(H), _ptr(Cand), _ptr(Hnew), R, Cc, L, Lw, h)
 
     # ---- GRU gate math -------------------------------------------------------------------
     def gru_gates_fwd(self, G, Xt, H, U, Rg, CandIn):

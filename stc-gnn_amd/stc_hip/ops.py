@@ -24,7 +24,6 @@ first call raises ``StcError``.
 """
 from __future__ import annotations
 
-import os
 import weakref
 from typing import Optional
 
@@ -35,12 +34,6 @@ from torch.autograd.function import once_differentiable
 from .graph import SpatialOperand
 
 _kernels = None
-# Fused aggregation in the cell forward (sparse graphs, Ks = 2; stc_cell_*_fwd_gather_f32).  Opt-in: measured SLOWER in the
-# full step on MI355X (gates 622 us vs 358 + 190 us for kernel + SpMM, 2 samples): one node per wave gathers 9 rows per node
-# through L2 where the row-blocked SpMM needs 4.5, and the node kernel becomes L2-bandwidth bound.
-_FUSE_GATHER = os.environ.get('STC_FUSE_GATHER') == '1'
-_GATHER_MAX_DEGREE = 32                                            # mean entries per row above which the SpMM kernel is kept
-_FUSE_BWD = os.environ.get('STC_FUSE_BWD') == '1'
 
 
 def kernels():
@@ -356,13 +349,7 @@ class _StcCell(Function):
         Cand, Hnew = torch.empty_like(H), torch.empty_like(H)
         B, N, C, L = XH.shape
         rows = lambda ts: [t.view(B * N, C, t.shape[-1]) for t in ts]
-        if _FUSE_GATHER and op.nnz <= _GATHER_MAX_DEGREE * N and k.cell_gather_supported(Ks, Tc.shape[0], C, L, h):
-            # sparse graph, Ks = 2: the aggregation Z1 = S.Z0 is gathered inside the two cell kernels too (no SpMM launch)
-            csr = (op.fwd_rowptr, op.fwd_colidx, fwd_val, N)
-            Zg, Zc = [XH, torch.empty_like(XH)], [CandIn, torch.empty_like(XH)]
-            k.cell_gates_fwd_gather(*csr, *rows(Zg), Tc, Wg, bg, *rows((H, U, Rg, CandIn)))
-            k.cell_blend_fwd_gather(*csr, *rows(Zc), Tc, Wc, bc, *rows((U, H, Cand, Hnew)))
-        elif k.cell_fused_supported(Ks, Tc.shape[0], C, L, h):
+        if k.cell_fused_supported(Ks, Tc.shape[0], C, L, h):
             # gate math in the node kernels' epilogues: the pre-activations never go to HBM
             Zg = _spatial_slabs(XH, fwd_val, op, Ks)
             k.cell_gates_fwd(rows(Zg), Tc, Wg, bg, *rows((H, U, Rg, CandIn)))
@@ -391,14 +378,10 @@ class _StcCell(Function):
         B, N, C, L = Zc[0].shape
         v3 = lambda t: t.view(B, N, C * L)
         bwd = (op.bwd_rowptr, op.bwd_colidx, op.bwd_val, op.bwd_plan)
-        # Folding the gate backward / the split into the last SpMM's epilogue is available (stc_spmm_bwd_*_f32) but measured
-        # slower in the full step on MI355X (397 us vs ~354 us for SpMM + gate kernel: the epilogue's loads are not
-        # overlapped with the gather, and the intermediate is served from the Infinity Cache anyway): opt-in only.
-        fuse = _FUSE_BWD and Ks > 1 and C * L >= 64
         # the gate backward can run as the prologue of the gates convolution's node backward (dG is never stored); it then
         # also takes over two pure data movements: the state's (1 - U) share of the blend (read from dHnew in place) and
         # dXt = d[x part] (left in place, added by the final split straight from the candidate gradient's rows)
-        pro = not fuse and not (need_Tc or need_val) and k.cell_fused_supported(Ks, Tc.shape[0], C, L, H.shape[-1])
+        pro = not (need_Tc or need_val) and k.cell_fused_supported(Ks, Tc.shape[0], C, L, H.shape[-1])
         dHnew = _c(dHnew)
         dH = torch.empty_like(H)
         dXt = H.new_empty(H.shape[:-1] + (cin,))
@@ -412,27 +395,21 @@ class _StcCell(Function):
             # candidate convolution: d[Xt | R*H] = g0 + Gs.g1, consumed by the gate backward
             g, dWc, dbc, dTc, dval = _bdg_backward_slabs(dCpre, Zc, Wc, Tc, op, Ks, ctx.bias[1], need_Tc, need_val)
         gates_pro, dci = None, g[0]
-        if fuse:
-            k.spmm_bwd_gates(*bwd, v3(g[1]), v3(g[0]), dU, H, U, Rg, dH, dG, dXt, dH)   # dH += d[h part] * R ; dXt = d[x part]
+        if Ks > 1:
+            k.csr_spmm(*bwd[:3], N, N, v3(g[1]), v3(g[0]), v3(g[0]), 1.0, 1.0, plan=op.bwd_plan)
+        if pro:
+            gates_pro = (dci, Cand, H, U, Rg, dHnew, dH)
         else:
-            if Ks > 1:
-                k.csr_spmm(*bwd[:3], N, N, v3(g[1]), v3(g[0]), v3(g[0]), 1.0, 1.0, plan=op.bwd_plan)
-            if pro:
-                gates_pro = (dci, Cand, H, U, Rg, dHnew, dH)
-            else:
-                k.gru_gates_bwd(dci, dU, H, U, Rg, dG, dXt, dH, dH_in=dH)
+            k.gru_gates_bwd(dci, dU, H, U, Rg, dG, dXt, dH, dH_in=dH)
         # gates convolution: d[Xt | H] = g0 + Gs.g1, split and added to what Xt and H are already owed
         g, dWg, dbg, dTc2, dval2 = _bdg_backward_slabs(dG, Zg, Wg, Tc, op, Ks, ctx.bias[0], need_Tc, need_val, gates=gates_pro)
         if need_Xt or need_H:
-            if fuse:
-                k.spmm_bwd_split(*bwd, v3(g[1]), v3(g[0]), C, dXt, dH, addA=dXt, addB=dH)
+            if Ks > 1:
+                k.csr_spmm(*bwd[:3], N, N, v3(g[1]), v3(g[0]), v3(g[0]), 1.0, 1.0, plan=op.bwd_plan)
+            if pro:
+                k.split2(g[0], dXt, dH, addA=dci, addB=dH, addA_ld=L)             # + d[x part] of the candidate, read in place
             else:
-                if Ks > 1:
-                    k.csr_spmm(*bwd[:3], N, N, v3(g[1]), v3(g[0]), v3(g[0]), 1.0, 1.0, plan=op.bwd_plan)
-                if pro:
-                    k.split2(g[0], dXt, dH, addA=dci, addB=dH, addA_ld=L)         # + d[x part] of the candidate, read in place
-                else:
-                    k.split2(g[0], dXt, dH, addA=dXt, addB=dH)                    # + the concat's share, in place
+                k.split2(g[0], dXt, dH, addA=dXt, addB=dH)                        # + the concat's share, in place
         if need_Tc:
             dTc = dTc + dTc2
         if need_val:
@@ -455,16 +432,14 @@ def stc_cell(Xt, H, op: SpatialOperand, Tc, Wg, bg, Wc, bc, Ks: int):
 
 
 # ----------------------------------------------------------------------------- a whole schedule of cells as ONE autograd node
-_CELL_GRAPH = os.environ.get('STC_CELL_GRAPH', '1') != '0'
-_FUSE_POST = os.environ.get('STC_FUSE_POST', '1') != '0'        # candidate projection as a second stage of the planar gates forward
-_PLANAR = os.environ.get('STC_PLANAR', '1') != '0'              # cells with 16 + 16-column inputs read them as two planes (no concat, shared S.state)
-_POST_AGG = os.environ.get('STC_POST_AGG', '1') != '0'          # candidate convolution as Y = A + S.Bm (narrow SpMM after the node kernel)
-_PLANAR_K3 = os.environ.get('STC_PLANAR_K3', '1') != '0'        # Chebyshev order 3: planar cells on three planes per side (T_0, T_1, T_2 of S)
-# ... with the candidate in post-aggregation (Clenshaw) form, Y = (P0 - P2) + S.(P1 + 2 S.P2).  Opt-in: same number of narrow SpMMs per
-# cell as the slab-planar candidate, 23 % less saved activation memory (36.0 vs 46.8 GB at N = 10 000, batch 4), but its backward kernel
-# (382 registers, one wave per SIMD) is slower than the slab-planar one: 78.0 vs 75.9 ms per step on MI355X (profiles/r02/i_*).
-_POST_K3 = os.environ.get('STC_POST_K3', '0') == '1'
-_ACC_PLANES = os.environ.get('STC_ACC_PLANES', '1') != '0'      # one-launch cell backward: a state's second consumer adds into the first one's planes
+# Which forms the cell-graph executor uses.  Module constants (tests flip them to reach the forms other shapes still take -- C = 64 runs the
+# two-launch backward, K = 3 the order-3 planar cells, other widths the interleaved rows); not environment switches.
+_CELL_GRAPH = True       # encoder + decoder as ONE autograd node (False: one node per cell, ``_StcCell``)
+_FUSE_POST = True        # candidate projection as a second stage of the planar gates forward
+_PLANAR = True           # cells with 16 + 16-column inputs read them as two planes (no concat, shared S.state)
+_POST_AGG = True         # candidate convolution as Y = A + S.Bm (narrow SpMM after the node kernel)
+_PLANAR_K3 = True        # Chebyshev order 3: planar cells on three planes per side (T_0, T_1, T_2 of S)
+_ACC_PLANES = True       # one-launch cell backward: a state's second consumer adds into the first one's planes
 
 
 def cell_graph_supported(op: SpatialOperand, Tc, Ks: int, C: int, h: int, x_widths, dtype=torch.float32) -> bool:
@@ -603,24 +578,10 @@ class _StcCellGraph(Function):
             if planar[j] and planar_k:
                 Zx, Zh, RH = planes_of(x), planes_of(hs), torch.empty_like(Hprev)
                 k.cell_gates_fwd_planar_k(rows(Zx), rows(Zh), Tc, Wg, bg, *rows((U, Rg, RH)))
-                if _POST_K3 and k.node_post_k_supported(Ks, C, 2 * h if cin[j] == h else 20, h):
-                    # candidate in post-aggregation form: project [X | R*H] first (three planes), aggregate in Clenshaw order --
-                    # M = P1 + 2 S.P2, then Y = (P0 - P2 + b) + S.M with the GRU blend in that SpMM's epilogue
-                    P = [torch.empty_like(Hprev) for _ in range(3)]
-                    lead, second = (Zx[0], RH) if cin[j] == h else (RH, Zx[0])        # narrow input plane: the 16-wide plane leads
-                    k.node_post_fwd_k(*rows((lead,)), Tc, Wc, bc, rows(P), second.view(B * N, C, second.shape[-1]))
-                    M = torch.empty_like(Hprev)
-                    k.csr_spmm(op.fwd_rowptr, op.fwd_colidx, fwd_val, N, N, P[2].view(B, N, C * h), P[1].view(B, N, C * h), M.view(B, N, C * h), 2.0, 1.0,
-                               plan=op.fwd_plan)
-                    k.spmm_blend_fwd(op.fwd_rowptr, op.fwd_colidx, fwd_val, op.fwd_plan, M, P[0], U, Hprev, Cand, Hnew)
-                    del P, M
-                    saved += [Hprev, U, Rg, Cand, *Zx, *Zh[1:], RH]
-                    n_saved.append(-10)                             # negative count: planar cell (10: order 3, post-aggregation candidate)
-                else:
-                    Zr = cheb_planes(RH)                            # the candidate's H side: T_n(S) of R*H (its X side is Zx again)
-                    k.cell_cand_fwd_planar_k(rows(Zx), rows(Zr), Tc, Wc, bc, *rows((U, Hprev, Cand, Hnew)))
-                    saved += [Hprev, U, Rg, Cand, *Zx, *Zh[1:], *Zr]
-                    n_saved.append(-12)                             # negative count: planar cell (12: order 3, slab-planar candidate)
+                Zr = cheb_planes(RH)                                # the candidate's H side: T_n(S) of R*H (its X side is Zx again)
+                k.cell_cand_fwd_planar_k(rows(Zx), rows(Zr), Tc, Wc, bc, *rows((U, Hprev, Cand, Hnew)))
+                saved += [Hprev, U, Rg, Cand, *Zx, *Zh[1:], *Zr]
+                n_saved.append(-12)                                 # negative count: planar cell (12: order 3, slab-planar candidate)
             elif planar[j]:
                 Xp, SXp, SHp = source(x), aggregated(x), aggregated(hs)
                 fused_post = _FUSE_POST and k.cell_planar_post_fused(C)
@@ -807,37 +768,22 @@ class _StcCellGraph(Function):
             s_id, x, hs = schedule[j]
             Wg, bg, Wc, bc = stacks[s_id]
             Hprev, U, Rg, Cand, *rest = cells[j]
-            if n_saved[j] in (-10, -12):                             # order-3 planar cell
+            if n_saved[j] == -12:                                    # order-3 planar cell
                 Zx, Zh = rest[:3], [Hprev] + rest[3:5]
                 wide = cin[j] == h
                 new = lambda: torch.empty_like(Hprev)
                 dWc, dbc = torch.empty_like(Wc), (Wc.new_empty(h) if bc is not None else None)
-                if n_saved[j] == -10:                                # candidate in post-aggregation form
-                    RH = rest[5]
-                    dHnew, dY = owed3(j, (U, Cand))
-                    dM = narrow_transpose_aggregation(dY)            # dP1 = S^T dY
-                    dP2 = torch.empty_like(dY)                       # dP2 = 2 S^T dP1 - dY
-                    k.csr_spmm(*bwd, N, N, dM.view(B, N, C * h), dY.view(B, N, C * h), dP2.view(B, N, C * h), 2.0, -1.0, plan=op.bwd_plan)
-                    dRH = new()
-                    dXc0 = new() if wide else None                   # ONE direct plane for the X side: the aggregation came after the projection
-                    if wide:
-                        k.node_post_bwd_k(*rows((Zx[0],)), Tc, Wc, rows((dY, dM, dP2)), dXc0.view(B * N, C, h), dWc, dbc, RH.view(B * N, C, h), dRH.view(B * N, C, h))
-                    else:
-                        k.node_post_bwd_k(*rows((RH,)), Tc, Wc, rows((dY, dM, dP2)), dRH.view(B * N, C, h), dWc, dbc, Zx[0].view(B * N, C, cin[j]))
-                    del dY, dM, dP2
-                    dXc = [dXc0, None, None]
-                else:                                                # slab-planar candidate
-                    Zr = rest[5:8]
-                    dHnew = owed3(j)
-                    dXc, dR = ([new(), new(), new()] if wide else [None] * 3), [new(), new(), new()]
-                    k.cell_cand_bwd_planar_k(rows(Zx), rows(Zr), Tc, Wc, *rows((dHnew, U, Cand)),
-                                             [None if t is None else t.view(B * N, C, h) for t in dXc], rows(dR), dWc, dbc)
-                    dRH = clenshaw([dR[0]], [dR[1]], [dR[2]])        # gradient of the R*H plane from its three Chebyshev planes
-                    del dR
+                Zr = rest[5:8]                                       # slab-planar candidate
+                dHnew = owed3(j)
+                dXc, dR = ([new(), new(), new()] if wide else [None] * 3), [new(), new(), new()]
+                k.cell_cand_bwd_planar_k(rows(Zx), rows(Zr), Tc, Wc, *rows((dHnew, U, Cand)),
+                                         [None if t is None else t.view(B * N, C, h) for t in dXc], rows(dR), dWc, dbc)
+                dRH = clenshaw([dR[0]], [dR[1]], [dR[2]])            # gradient of the R*H plane from its three Chebyshev planes
+                del dR
                 fold = getattr(k, 'folds_dH', False)                  # the kernel adds the prologue's share into the H plane's gradient
                 # slab-planar candidate on a wide input: the gates' X-side gradients are ADDED into the candidate's three planes by the
                 # kernel (accumulate_x), so the source gets one plane per order from this cell and its Clenshaw sums need no pre-sum
-                into = fold and wide and n_saved[j] == -12
+                into = fold and wide
                 dXg = dXc if into else ([new(), new(), new()] if wide else [None] * 3)
                 dHg, dH = [new(), new(), new()], (None if fold else new())
                 dWg, dbg = torch.empty_like(Wg), (Wg.new_empty(2 * h) if bg is not None else None)
@@ -857,7 +803,7 @@ class _StcCellGraph(Function):
             post_form = n_saved[j] < 0 or (len(rest) == Ks + 1 and Ks > 1)     # candidate backward starts from dY = dHnew * U * (1 - Cand^2)
             if Ks == 3 and j in pieces:                              # an interleaved cell whose state order-3 planar cells consumed
                 G[j] = owed3(j)
-            one_launch = n_saved[j] == -7 and not bf16_planes and getattr(k, 'operand_format', 0) == 1 and os.environ.get('STC_AMAX_FUSED', '1') != '0'
+            one_launch = n_saved[j] == -7 and not bf16_planes and getattr(k, 'operand_format', 0) == 1
             dHnew, dY = owed(j, (U, Cand), want_amax=one_launch) if post_form else (owed(j), None)
             dH = None if (n_saved[j] == -7 or (n_saved[j] < 0 and getattr(k, 'folds_dH', False))) else torch.empty_like(Hprev)
             if n_saved[j] == -7:                                     # planar cell, candidate + gates backward in ONE launch

@@ -25,6 +25,7 @@ stored, only numbers.  Sets follow SURVEY.md section 8(c4):
                     2 layers, 6x8 non-symmetric grid graph, B=2, T=3+2 -> yhat, ComboLoss, every gradient
   g12_bench_c64     the same at C=64;  g13_bench_c32_k3  the same at C=32, K=3 (configuration 4's order)
   g8b_large_n10000_grads   g8 with backward: sampled rows of Ht, dXt, dHt + the full parameter gradients
+  g8c_large_n10000_k3      the same cell at Chebyshev order K = 3 (BASELINE configuration 4) through the dense reference, with backward
 
 Large inputs (g7, g8) are regenerated from seeds by ``synth_inputs`` below,
 which the tests import too; a few checksums are stored to catch RNG drift.
@@ -64,9 +65,9 @@ def synth_inputs(name):
         H = W = 32
         N, C, cin, h, K, B = H * W, 8, 2, 8, 3, 2
         Gs = grid_graph_dense(H, W, permute_seed=1234 if name == 'g7p' else None)
-    elif name == 'g8':
+    elif name in ('g8', 'g8c'):
         H = W = 100
-        N, C, cin, h, K, B = H * W, 32, 16, 16, 2, 1
+        N, C, cin, h, K, B = H * W, 32, 16, 16, (3 if name == 'g8c' else 2), 1
         Gs = grid_graph_dense(H, W)
     else:
         raise KeyError(name)
@@ -388,6 +389,27 @@ def bench_path_golden(ref_framework='/root/reference/framework'):
           chk_Gs=s['Gs'].double().sum(), chk_Xt=s['Xt'].double().sum())
 
 
+def large_k3_golden(ref_framework='/root/reference/framework'):
+    """g8c: one reference STC_Cell at N = 10 000, C = 32, h = 16, K = 3 (dense Gs, matrix-side cheby_poly with its two N^3 products per
+    BDG_Dif call, STC_GNN.py:24-29) forward + backward: 256 sampled rows of Ht, dXt, dHt and the full parameter gradients."""
+    sys.path.insert(0, ref_framework)
+    import STC_GNN as ref
+    torch.set_num_threads(8)
+    s = synth_inputs('g8c')
+    cell = ref.STC_Cell(s['N'], s['C'], s['K'], s['K'], s['cin'], s['h'])
+    with torch.no_grad():
+        cell.gates.W.copy_(s['gates_W']); cell.gates.b.copy_(s['gates_b'])
+        cell.candi.W.copy_(s['candi_W']); cell.candi.b.copy_(s['candi_b'])
+    Xt = s['Xt'].clone().requires_grad_()
+    Ht = s['Ht'].clone().requires_grad_()
+    out = cell(s['Gs'], s['Gc'], Xt, Ht)
+    (out * s['R']).sum().backward()
+    rows = sample_rows(s['N'], 256, seed=98)
+    _save('g8c_large_n10000_k3', rows=rows, Hout=out[:, rows], dXt=Xt.grad[:, rows], dHt=Ht.grad[:, rows],
+          d_gates_W=cell.gates.W.grad, d_gates_b=cell.gates.b.grad, d_candi_W=cell.candi.W.grad, d_candi_b=cell.candi.b.grad,
+          chk_Gs=s['Gs'].double().sum(), chk_Xt=s['Xt'].double().sum())
+
+
 def pipeline_inputs():
     """Synthetic incident series + trainer params shared by make_golden and the tests (g9)."""
     g = torch.Generator().manual_seed(9)
@@ -492,8 +514,11 @@ if __name__ == '__main__':
         pipeline_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == 'bench_path':
         bench_path_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'large_k3':
+        large_k3_golden()
     else:
         main()
         pipeline_golden()
         metrics_golden()
         bench_path_golden()
+        large_k3_golden()

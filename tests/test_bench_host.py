@@ -42,15 +42,44 @@ def test_traffic_is_quoted_only_for_matching_sources_and_configuration(tmp_path,
                         'spmm_bcsr_kernel<1, 3, 2, 0, 0>': dict(hbm_bytes_per_launch=900.0, launches=5),       # a sum form: not the plain launch
                         'node_fwd_x3_kernel<1, 2, 2, 32, 1, 0, 1, 1>': dict(hbm_bytes_per_launch=5.0, launches=1)})
     monkeypatch.setattr(bench, 'REPO', str(tmp_path))
-    os.makedirs(tmp_path / 'profiles' / 'r02')
+    os.makedirs(tmp_path / 'profiles' / 'r03')
     monkeypatch.setattr(bench, 'csrc_sha', lambda: doc['csrc_sha'])
-    path = tmp_path / 'profiles' / 'r02' / 'hbm_traffic_bench.json'
+    path = tmp_path / 'profiles' / 'r03' / 'hbm_traffic_bench.json'
     path.write_text(json.dumps(doc))
     t, note = bench.pmc_traffic(None, key)
-    assert t == 100.0 and 'profiles/r02/hbm_traffic_bench.json' in note
+    assert t == 100.0 and 'profiles/r03/hbm_traffic_bench.json' in note
     assert bench.pmc_traffic(None, 'f32:100:32:16:4:3:2:18:6:0')[0] is None            # another configuration
     path.write_text(json.dumps(dict(doc, csrc_sha='0' * 16)))
     t, note = bench.pmc_traffic(None, key)
     assert t is None and 'not quoted' in note                                           # other kernel sources: never a stale number
     os.remove(path)
     assert bench.pmc_traffic(None, key) == (None, None)
+
+
+def test_matrix_pipe_counters_are_quoted_only_for_matching_sources(tmp_path, monkeypatch):
+    key = 'f32:224:32:16:5:2:2:18:6:0'
+    doc = dict(csrc_sha=bench.csrc_sha(), config_key=key, definition='...',
+               kernels={'cell_bwd_x3_kernel<FmtH2, 32, 1, 0, 0>': dict(launches=48, mfma_util=0.3, valu_busy=0.4),
+                        'spmm_bcsr_kernel<1, 0, 2, 1, 1>': dict(launches=97, mfma_util=0.0, valu_busy=0.1)})
+    monkeypatch.setattr(bench, 'REPO', str(tmp_path))
+    os.makedirs(tmp_path / 'profiles' / 'r03')
+    monkeypatch.setattr(bench, 'csrc_sha', lambda: doc['csrc_sha'])
+    assert bench.pmc_mfma(key) is None                                                  # no file: nothing to quote
+    path = tmp_path / 'profiles' / 'r03' / 'mfma_util.json'
+    path.write_text(json.dumps(doc))
+    m = bench.pmc_mfma(key)
+    assert m['source'] == 'committed' and list(m['kernels']) == ['cell_bwd_x3_kernel<FmtH2, 32, 1, 0, 0>']      # the projection kernels only
+    assert m['kernels']['cell_bwd_x3_kernel<FmtH2, 32, 1, 0, 0>'] == dict(launches=48, mfma_busy=0.3, valu_busy=0.4)
+    path.write_text(json.dumps(dict(doc, csrc_sha='0' * 16)))
+    assert bench.pmc_mfma(key)['value'] is None                                         # other kernel sources: never a stale number
+
+
+def test_presets_and_global_batch():
+    a = bench.parse(['--preset', 'cfg4'])
+    assert (a.grid, a.order, a.batch_per_gpu) == (100, 3, 4)
+    a = bench.parse(['--preset', 'cfg5'])
+    assert (a.categories, a.storage) == (64, 'bf16')
+    a = bench.parse(['--gpus', '4', '--global-batch', '8'])
+    assert a.batch_per_gpu == 2
+    with pytest.raises(SystemExit):
+        bench.parse(['--gpus', '4', '--global-batch', '6'])

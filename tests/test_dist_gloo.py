@@ -222,6 +222,47 @@ def test_two_rank_trainer_reproduces_the_reference_epoch_losses(tmp_path):
         assert np.abs(got[r]['forecast'] - one['forecast']).max() < 1e-6 and abs(got[r]['bce'] - one['bce']) < 1e-6
 
 
+def _worker_short_batch(rank, world, port, out_dir):
+    for p in (REPO, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from oracle.kernel_emul import EmulatedKernels
+    from stc_hip import data as sdata, dist as sdist, ops
+    from stc_hip.trainer import Trainer
+    from tests.golden.make_golden import pipeline_inputs
+    ops._kernels = EmulatedKernels()
+    if world > 1:
+        sdist.init_from_env(backend='gloo')
+    data, params = pipeline_inputs()
+    params = dict(params, output_dir=out_dir, _allow_cpu_for_tests=True, num_epochs=1)
+    loaders = sdata.get_data_loader(params, data, params['obs_len'], params['pred_len'], params['split_ratio'])
+    x, y = next(iter(loaders['train']))
+    one = {'train': [(x[:1], y[:1]), (x[1:4], y[1:4])], 'validate': [(x[:1], y[:1])]}      # a 1-sample batch: fewer samples than ranks
+    torch.manual_seed(123 if rank == 0 else 77)
+    trainer = Trainer(params, data)
+    hist = trainer.train(one, verbose=False)
+    torch.save({'hist': hist, 'flat': torch.cat([p.detach().flatten() for p in trainer.model.parameters()])}, os.path.join(out_dir, f'w{world}r{rank}.pt'))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_batch_with_fewer_samples_than_ranks_runs_replicated(tmp_path):
+    """A batch of ONE sample on two ranks with learned graphs (whose forward all-reduces over the ranks): decided from the batch size
+    before any collective, every rank runs the whole small batch -- no rank is left out of a collective, and the step equals the
+    one-rank step (losses and final parameters)."""
+    mp.start_processes(_worker_short_batch, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True, start_method='spawn')
+    mp.start_processes(_worker_short_batch, args=(1, 0, str(tmp_path)), nprocs=1, join=True, start_method='spawn')      # (a process of its own: the worker changes thread counts and the kernel set)
+    two = [torch.load(tmp_path / f'w2r{r}.pt', weights_only=False) for r in range(2)]
+    one = torch.load(tmp_path / 'w1r0.pt', weights_only=False)
+    assert torch.equal(two[0]['flat'], two[1]['flat'])
+    assert float((two[0]['flat'] - one['flat']).abs().max()) < 1e-6
+    for m in ('train', 'validate'):
+        assert abs(two[0]['hist']['loss'][m][0] - one['hist']['loss'][m][0]) < 1e-6
+
+
 def test_ragged_shards_cover_the_batch():
     from stc_hip import dist as sdist
     for n in (0, 1, 3, 7, 8, 26, 32):

@@ -7,6 +7,8 @@
   properties: every sample of a batch equals the same sample run alone (samples are independent on this path, SURVEY
   8(e1)), and the batch's parameter gradients are the sum of the single-sample gradients (linearity of the backward).
   Together with the per-cell oracle check this guards the 32-bit index arithmetic at the sizes the bench runs.
+* BASELINE configuration 5 at its own size: two chained planar cells at N = 50 176, C = 64 with bf16 state storage against the same
+  cells on the fp32 HIP path (the parity-checked one), under the bf16 contract of DESIGN.md (the reference has no bf16 behaviour).
 """
 import pytest
 import torch
@@ -140,3 +142,46 @@ def test_full_size_model_against_oracle_end_to_end(monkeypatch):
     assert rel_err(got, want) < 1e-5 and abs(float(loss.detach()) - float(loss_w.detach())) < 1e-5
     for name, p in model.named_parameters():
         assert rel_err(p.grad, sd[name].grad) < 2e-5, name
+
+
+@pytest.mark.gpu
+def test_full_size_bf16_storage_cells_track_the_fp32_path(monkeypatch):
+    """BASELINE configuration 5 (N = 50 176, C = 64, bf16 state storage): cell 0 reads external planes, cell 1 reads cell 0's state as
+    X and as H (so the state's gradient is assembled from its consumers' pieces) -- the bf16-storage kernels against the fp32 HIP path
+    on the same bf16-exact inputs and parameters: new states on 256 sampled rows within 2e-2 (states are in (-1, 1)), every parameter
+    gradient with cosine > 0.995 and norm within 5 % (the contract of tests/test_bf16_kernels.py, at the size the configuration names)."""
+    monkeypatch.setattr(ops, '_kernels', None)
+    from stc_hip.graph import csr_operand
+    dev = torch.device('cuda')
+    N, C, h, K = GRID * GRID, 64, 16, 2
+    graph = CsrGraph.queen_grid(GRID, GRID, normalize=True, device=dev)
+    op = csr_operand(graph, dev)
+    g = torch.Generator().manual_seed(21)
+    Gc = torch.softmax(torch.randn(C, C, generator=g), -1).to(dev)
+    Tc = ops.cheby_dense(Gc, K)
+    bfx = lambda t: t.to(torch.bfloat16).float()                     # bf16-exact values in both runs
+    X = bfx(torch.rand(1, N, C, h, generator=g) - 0.5).to(dev)
+    H = bfx(torch.tanh(torch.randn(1, N, C, h, generator=g))).to(dev)
+    R = torch.randn(1, N, C, h, generator=g).to(dev)
+    L = 2 * h
+    P = [torch.randn(K * K * L, 2 * h, generator=g) * (2.0 / (K * K * L + 2 * h)) ** 0.5, torch.randn(2 * h, generator=g) * 0.1,
+         torch.randn(K * K * L, h, generator=g) * (2.0 / (K * K * L + h)) ** 0.5, torch.randn(h, generator=g) * 0.1]
+    sched = [(0, ('ext', 0), ('ext', 1)), (0, ('cell', 0), ('cell', 0))]
+    rows = sample_rows(N, 256, seed=7).to(dev)
+    got = {}
+    for name, dt in (('f32', torch.float32), ('bf16', torch.bfloat16)):
+        p = [t.clone().to(dev).requires_grad_() for t in P]
+        assert ops.cell_graph_supported(op, Tc, K, C, h, [h], dtype=dt)
+        out = ops.stc_cell_graph(op, Tc, K, sched, [0, 1], [X.to(dt), H.to(dt)], [tuple(p)])
+        assert out.dtype == dt
+        (out[1].float() * R).sum().backward()
+        torch.cuda.synchronize()
+        got[name] = (out.detach().float()[:, :, rows], [t.grad.detach().clone() for t in p])
+        del out
+    (s32, g32), (s16, g16) = got['f32'], got['bf16']
+    assert torch.isfinite(s16).all() and float((s16 - s32).abs().max()) < 2e-2
+    for a_, b_, name in zip(g16, g32, ('gates.W', 'gates.b', 'candi.W', 'candi.b')):
+        a, b = a_.flatten().double(), b_.flatten().double()
+        cos = float((a @ b) / (a.norm() * b.norm() + 1e-300))
+        assert cos > 0.995, f'd{name}: cosine {cos}'
+        assert abs(float(a.norm() / (b.norm() + 1e-300)) - 1) < 5e-2, f'd{name}: norm ratio {float(a.norm() / b.norm())}'

@@ -104,40 +104,6 @@ def test_bcsr_spmm_equals_csr(hip, n, F, B, hw):
             assert rel_err(blocked, csr) < 2e-6
 
 
-@pytest.mark.parametrize('n,C,cin,h,B,form', [(203, 8, 16, 16, 1, 'bcsr'), (203, 8, 16, 16, 2, 'csr'), (90, 5, 1, 16, 2, 'bcsr'),
-                                                (90, 5, 1, 16, 1, 'csr'), (64, 8, 2, 8, 1, 'bcsr'), (37, 32, 16, 16, 1, 'bcsr')])
-def test_spmm_backward_epilogues(hip, n, C, cin, h, B, form):
-    """dZ0 + Gs.dZ1 with the gate backward / the split-and-accumulate folded into the epilogue, vs the CPU twin
-    (SpMM, then the element-wise kernel).  cin = 16: 16-byte routing; cin = 1, 2: padded rows, element routing."""
-    graph, V = _banded_graph(n, 3, seed=n + C + cin)
-    d = graph.on(torch.device('cuda'))
-    L = cin + h + (-(cin + h)) % 4
-    g = torch.Generator().manual_seed(cin * 7 + h)
-    rnd = lambda *s_: torch.randn(*s_, generator=g)
-    X, Y0 = rnd(B, n, C * L), rnd(B, n, C * L)
-    dU, H, U, Rg, owed = rnd(B, n, C, h), rnd(B, n, C, h), torch.rand(B, n, C, h, generator=g), torch.rand(B, n, C, h, generator=g), rnd(B, n, C, h)
-    args_cpu = (graph._host['bwd_rowptr'], graph._host['bwd_colidx'], graph._host['bwd_val'])
-    args_cpu = tuple(torch.from_numpy(a) for a in args_cpu)
-    plan = (d['bwd_blk_ptr'], d['bwd_blk_cols'], d['bwd_blk_vals']) if form == 'bcsr' else None
-    gargs = (d['bwd_rowptr'], d['bwd_colidx'], d['bwd_val'], plan)
-
-    dG_w, dXt_w, dH_w = torch.empty(B, n, C, 2 * h), torch.empty(B, n, C, cin), owed.clone()
-    EM.spmm_bwd_gates(*args_cpu, None, X, Y0, dU, H, U, Rg, dH_w, dG_w, dXt_w, dH_w)
-    dG, dXt, dH = torch.full((B, n, C, 2 * h), float('nan')).cuda(), torch.full((B, n, C, cin), float('nan')).cuda(), owed.clone().cuda()
-    hip.spmm_bwd_gates(*gargs, cu(X), cu(Y0), cu(dU), cu(H), cu(U), cu(Rg), dH, dG, dXt, dH)
-    assert rel_err(dG, dG_w) < TOL and rel_err(dXt, dXt_w) < TOL and rel_err(dH, dH_w) < TOL
-
-    oa_w, ob_w = rnd(B, n, C, cin), rnd(B, n, C, h)
-    oa, ob = oa_w.clone().cuda(), ob_w.clone().cuda()
-    EM.spmm_bwd_split(*args_cpu, None, X, Y0, C, oa_w, ob_w, addA=oa_w, addB=ob_w)
-    hip.spmm_bwd_split(*gargs, cu(X), cu(Y0), C, oa, ob, addA=oa, addB=ob)
-    assert rel_err(oa, oa_w) < TOL and rel_err(ob, ob_w) < TOL
-    oa2, ob2 = torch.full_like(oa, float('nan')), torch.full_like(ob, float('nan'))
-    hip.spmm_bwd_split(*gargs, cu(X), cu(Y0), C, oa2, ob2)               # no accumulation operands
-    ref = (Y0 + torch.einsum('rc,bcf->brf', V, X)).view(B, n, C, L)
-    assert rel_err(oa2, ref[..., :cin]) < TOL and rel_err(ob2, ref[..., cin:cin + h]) < TOL
-
-
 def test_row_block_plan_fetch_counts():
     assert CsrGraph.queen_grid(40, 40).fetches_per_row[0] < 5.0                      # 18 fetches per 4 rows in the interior
     assert CsrGraph.queen_grid(40, 40, permute_seed=1).fetches_per_row[0] > 7.0     # random node order: nothing to share
@@ -236,26 +202,20 @@ def _node_inputs(nodes, C, L, Ho, Ks, Kc, seed):
 
 
 @pytest.fixture(params=['default', 'fp32-mfma', 'generic-only'])
-def node_path(request, monkeypatch):
-    """Run every node-kernel case three times: default dispatch (split-operand bf16 MFMA where the shape allows, then
-    fp32 MFMA, then generic), fp32 MFMA or generic only, generic VALU only."""
-    monkeypatch.delenv('STC_DISABLE_MFMA', raising=False)
-    monkeypatch.delenv('STC_DISABLE_X3', raising=False)
-    if request.param == 'generic-only':
-        monkeypatch.setenv('STC_DISABLE_MFMA', '1')
-    elif request.param == 'fp32-mfma':
-        monkeypatch.setenv('STC_DISABLE_X3', '1')
-    return request.param
+def node_path(request, hip):
+    """Run every node-kernel case three times: default dispatch (split-operand MFMA where the shape allows, then fp32 MFMA, then
+    generic), fp32 MFMA or generic only, generic VALU only (stc_set_dispatch_level: the library reads no environment)."""
+    hip.set_dispatch_level({'default': 0, 'fp32-mfma': 1, 'generic-only': 2}[request.param])
+    yield request.param
+    hip.set_dispatch_level(0)
 
 
 @pytest.fixture(params=['default', 'fp32-mfma'])
-def fused_path(request, monkeypatch):
+def fused_path(request, hip):
     """The fused cell kernels exist in both matrix-core flavours."""
-    monkeypatch.delenv('STC_DISABLE_MFMA', raising=False)
-    monkeypatch.delenv('STC_DISABLE_X3', raising=False)
-    if request.param == 'fp32-mfma':
-        monkeypatch.setenv('STC_DISABLE_X3', '1')
-    return request.param
+    hip.set_dispatch_level({'default': 0, 'fp32-mfma': 1}[request.param])
+    yield request.param
+    hip.set_dispatch_level(0)
 
 
 @pytest.mark.parametrize('shape', NODE_SHAPES)
@@ -368,55 +328,6 @@ def test_fused_cell_epilogues(hip, nodes, C, cin, K, fused_path):
     EM.cell_blend_fwd(Zs, Tc, Wc, bc, U_w, H, Cand_w, Hn_w)
     hip.cell_blend_fwd([cu(z) for z in Zs], cu(Tc), cu(Wc), cu(bc), cu(U_w), cu(H), Cand, Hn)
     assert rel_err(Cand, Cand_w) < TOL and rel_err(Hn, Hn_w) < TOL
-
-
-@pytest.mark.parametrize('batch,grid,C,cin', [(2, (5, 5), 32, 16), (3, (4, 7), 32, 1), (1, (3, 3), 64, 1), (2, (40, 56), 32, 16), (1, (1, 1), 32, 16)])
-def test_fused_aggregation_cell_kernels(hip, batch, grid, C, cin):
-    """stc_cell_*_fwd_gather_f32: the kernel gathers Z1 = S.Z0 itself (and writes it) -- vs SpMM + fused cell kernel of the twin.
-    Includes a random sparse matrix with an empty row, besides the queen grids."""
-    from stc_hip import CsrGraph
-    h, K = 16, 2
-    Lw = cin + h
-    L = Lw + (-Lw) % 4
-    assert hip.cell_gather_supported(K, K, C, L, h)
-    graph = CsrGraph.queen_grid(*grid, normalize=True)
-    n = graph.n
-    hst = graph._host
-    rowptr, colidx, val = (torch.from_numpy(hst[k]) for k in ('fwd_rowptr', 'fwd_colidx', 'fwd_val'))
-    if n > 4:                                                      # knock a row out: rows without entries must give Z1 = 0
-        keep = torch.ones(colidx.numel(), dtype=torch.bool)
-        keep[rowptr[2]:rowptr[3]] = False
-        counts = torch.diff(rowptr).clone()
-        counts[2] = 0
-        rowptr = torch.cat([torch.zeros(1, dtype=torch.int32), torch.cumsum(counts, 0).to(torch.int32)])
-        colidx, val = colidx[keep].contiguous(), val[keep].contiguous()
-    nodes = batch * n
-    g = torch.Generator().manual_seed(nodes + C + cin)
-    Z0 = torch.randn(nodes, C, L, generator=g)
-    Z0[..., Lw:] = 0.0
-    Tc = torch.randn(K, C, C, generator=g) / C ** 0.5
-    Tc[0] = torch.eye(C)
-    H = torch.randn(nodes, C, h, generator=g)
-    Wg = torch.randn(K * K * Lw, 2 * h, generator=g) / (K * K * Lw) ** 0.5
-    bg = torch.randn(2 * h, generator=g)
-    Z1_w, U_w, R_w, Ci_w = torch.empty_like(Z0), torch.empty_like(H), torch.empty_like(H), torch.empty(nodes, C, L)
-    EM.cell_gates_fwd_gather(rowptr, colidx, val, n, Z0, Z1_w, Tc, Wg, bg, H, U_w, R_w, Ci_w)
-    nan = lambda t: torch.full(t.shape, float('nan')).cuda()
-    Z1, U, R, Ci = nan(Z0), nan(H), nan(H), nan(Ci_w)
-    csr = (cu(rowptr), cu(colidx), cu(val), n)
-    hip.cell_gates_fwd_gather(*csr, cu(Z0), Z1, cu(Tc), cu(Wg), cu(bg), cu(H), U, R, Ci)
-    assert rel_err(Z1, Z1_w) < TOL and rel_err(U, U_w) < TOL and rel_err(R, R_w) < TOL and rel_err(Ci, Ci_w) < TOL
-    if n > 4:
-        assert float(Z1.view(batch, n, C, L)[:, 2].abs().max()) == 0.0
-    assert torch.equal(Ci[..., :cin].cpu(), Z0[..., :cin])
-
-    Wc = torch.randn(K * K * Lw, h, generator=g) / (K * K * Lw) ** 0.5
-    bc = torch.randn(h, generator=g)
-    Cand_w, Hn_w = torch.empty_like(H), torch.empty_like(H)
-    EM.cell_blend_fwd_gather(rowptr, colidx, val, n, Ci_w, Z1_w, Tc, Wc, bc, U_w, H, Cand_w, Hn_w)
-    Z1c, Cand, Hn = nan(Z0), nan(H), nan(H)
-    hip.cell_blend_fwd_gather(*csr, cu(Ci_w), Z1c, cu(Tc), cu(Wc), cu(bc), cu(U_w), cu(H), Cand, Hn)
-    assert rel_err(Z1c, Z1_w) < TOL and rel_err(Cand, Cand_w) < TOL and rel_err(Hn, Hn_w) < TOL
 
 
 @pytest.mark.parametrize('nodes,C,L,Lw', [(50, 32, 32, 32), (50, 32, 20, 17), (13, 64, 32, 32), (9, 64, 20, 20), (4500, 32, 32, 32)])
@@ -791,51 +702,6 @@ def test_planar_cell_kernels_order3(hip, nodes, cin):
         assert rel_err(dWg, dWg_w) < TOL
 
 
-@pytest.mark.parametrize('nodes,cin', [(50, 16), (4500, 16), (37, 1), (600, 4)])
-def test_post_aggregation_order3_kernels(hip, nodes, cin):
-    """stc_bdg_node_post_fwd/bwd_k_f32: the order-3 candidate convolution in Clenshaw form -- P = [P_0 - P_2 + b, P_1, P_2] from the
-    planar row, and (dX, dX2, dW, db) from the three gradient planes -- against the CPU twin (plain einsum algebra)."""
-    h, K, C = 16, 3, 32
-    assert hip.node_post_k_supported(K, C, 32 if cin == h else 20, h) and not hip.node_post_k_supported(2, C, 32, h)
-    Lw = cin + h
-    g = torch.Generator().manual_seed(nodes * 3 + cin)
-    rnd = lambda *s_: torch.randn(*s_, generator=g)
-    X16, Xin = rnd(nodes, C, h), rnd(nodes, C, cin)              # the 16-wide plane (R*H, or X when both are 16 wide) and the other plane
-    Tc = rnd(K, C, C) / C ** 0.5
-    Tc[0] = torch.eye(C)
-    W, b = rnd(K * K * Lw, h) / (K * K * Lw) ** 0.5, rnd(h)
-    nan = lambda *s_: torch.full(s_, float('nan')).cuda()
-    P_w = [torch.empty(nodes, C, h) for _ in range(K)]
-    EM.node_post_fwd_k(X16, Tc, W, b, P_w, Xin)
-    P = [nan(nodes, C, h) for _ in range(K)]
-    hip.node_post_fwd_k(cu(X16), cu(Tc), cu(W), cu(b), P, cu(Xin))
-    for a, w in zip(P, P_w):
-        assert rel_err(a, w) < TOL
-    hip.node_post_fwd_k(cu(X16), cu(Tc), cu(W), None, P, cu(Xin))
-    assert rel_err(P[0], P_w[0] - b) < TOL
-    dP = [rnd(nodes, C, h) for _ in range(K)]
-    wide = cin == h
-    dX_w, dX2_w, dW_w, db_w = torch.empty(nodes, C, h), (torch.empty(nodes, C, h) if wide else None), torch.empty_like(W), torch.empty(h)
-    EM.node_post_bwd_k(X16, Tc, W, dP, dX_w, dW_w, db_w, Xin, dX2_w)
-    dX, dX2, dW, db = nan(nodes, C, h), (nan(nodes, C, h) if wide else None), nan(*W.shape), nan(h)
-    hip.node_post_bwd_k(cu(X16), cu(Tc), cu(W), [cu(t) for t in dP], dX, dW, db, cu(Xin), dX2)
-    assert rel_err(dX, dX_w) < TOL and rel_err(dW, dW_w) < TOL and rel_err(db, db_w) < TOL
-    if wide:
-        assert rel_err(dX2, dX2_w) < TOL
-
-
-def test_fused_aggregation_is_refused_off_its_shapes(hip):
-    from stc_hip import StcError
-    assert not hip.cell_gather_supported(3, 3, 32, 32, 16) and not hip.cell_gather_supported(2, 2, 16, 32, 16)
-    Z0 = torch.zeros(4, 16, 32).cuda()
-    rp = torch.zeros(5, dtype=torch.int32).cuda()
-    ci, va = torch.zeros(0, dtype=torch.int32).cuda(), torch.zeros(0).cuda()
-    H = torch.zeros(4, 16, 16).cuda()
-    with pytest.raises(StcError):
-        hip.cell_gates_fwd_gather(rp, ci, va, 4, Z0, torch.empty_like(Z0), torch.zeros(2, 16, 16).cuda(), torch.zeros(2 * 2 * 32, 32).cuda(), None,
-                                  H, torch.empty_like(H), torch.empty_like(H), torch.empty_like(Z0))
-
-
 @pytest.mark.parametrize('nodes,C,cin,K', [(50, 32, 16, 2), (50, 32, 1, 2), (21, 16, 16, 3), (13, 64, 1, 2), (4500, 32, 16, 2), (9, 32, 13, 1)])
 def test_fused_gates_backward_prologue(hip, nodes, C, cin, K, fused_path):
     """Gate backward as the prologue of the node backward (dG never stored) vs gate kernel + node backward of the twin."""
@@ -922,8 +788,13 @@ def test_fused_cell_unsupported_shapes_are_refused(hip, monkeypatch):
     with pytest.raises(StcError, match='fused path'):
         hip.cell_gates_fwd(Zs, Tc, torch.randn(2 * 2 * 17, 32).cuda(), None, H, torch.empty_like(H), torch.empty_like(H),
                            torch.empty(6, 5, 20).cuda())
-    monkeypatch.setenv('STC_DISABLE_MFMA', '1')
-    assert not hip.cell_fused_supported(2, 2, 32, 32, 16)
+    hip.set_dispatch_level(2)
+    try:
+        assert not hip.cell_fused_supported(2, 2, 32, 32, 16)
+        with pytest.raises(StcError, match='level'):
+            hip.set_dispatch_level(3)
+    finally:
+        hip.set_dispatch_level(0)
 
 
 def test_bdg_node_bwd_many_tiles_exercises_grid_stride(hip):

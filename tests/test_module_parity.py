@@ -282,6 +282,96 @@ def test_large_n10000_gradients_against_dense_reference_rows():
         _close(p.grad, g[name], 2e-5, name + ' N=10000', gpu_tol=2e-5)
 
 
+@pytest.mark.parametrize('K', [2, 3])
+def test_bdg_dif_at_baseline_configuration_2(K):
+    """BASELINE configuration 2 at its own shape: ONE BDG_Dif layer (STC_GNN.py:31-47), B = 32, N = 200, C = 8, L = 32, Ho = 32, dense
+    learned (differentiable) Gs and Gc, against the oracle's op-for-op restatement of the reference (``oracle.bdg_dif``: dense einsum,
+    matrix-side cheby_poly, concat + projection) -- forward and dX, dW, db, dGs, dGc."""
+    B, N, C, L, Ho = 32, 200, 8, 32, 32
+    gen = torch.Generator().manual_seed(200 + K)
+    X = torch.randn(B, N, C, L, generator=gen)
+    Gs = torch.softmax(torch.randn(N, N, generator=gen), -1)                 # row-stochastic, dense, NON-symmetric (as MGP_Gen's output)
+    Gc = torch.softmax(torch.randn(C, C, generator=gen), -1)
+    W = torch.randn(K * K * L, Ho, generator=gen) * (2.0 / (K * K * L + Ho)) ** 0.5
+    bias = torch.randn(Ho, generator=gen) * 0.1
+    R = torch.randn(B, N, C, Ho, generator=gen)
+    # the oracle in float64 (it is dtype-generic): dGc and dW are sums over B*N*L = 204 800 .. 1.6 M products, where an fp32 CPU sum is
+    # itself 1e-5 away from the exact value -- the more exact side of the comparison must be the reference side
+    want_in = [t.double().requires_grad_() for t in (X, Gs, Gc, W, bias)]
+    want = O.bdg_dif(want_in[0], want_in[1], want_in[2], want_in[3], want_in[4], K, K)
+    (want * R.double()).sum().backward()
+    layer = M.BDG_Dif(K, K, L, Ho).to(DEV)
+    layer.load_state_dict({'W': W, 'b': bias})
+    Xd, Gsd, Gcd = _leaf(X), _leaf(Gs), _leaf(Gc)
+    got = layer(Xd, Gsd, Gcd)
+    _close(got, want.detach().float().to(DEV), FWD, f'cfg2 K={K} Y')
+    (got * R.to(DEV)).sum().backward()
+    for name, t, w in (('dX', Xd.grad, want_in[0].grad), ('dGs', Gsd.grad, want_in[1].grad), ('dGc', Gcd.grad, want_in[2].grad),
+                       ('dW', layer.W.grad, want_in[3].grad), ('db', layer.b.grad, want_in[4].grad)):
+        _close(t, w.float().to(DEV), GRAD, f'cfg2 K={K} {name}')
+
+
+def test_large_n10000_order_3_against_dense_reference_rows():
+    """g8c: one STC_Cell at N = 10 000, C = 32, h = 16, Chebyshev order K = 3 (BASELINE configuration 4) against the dense reference
+    (STC_GNN.py:24-29, 65-79) -- new state, dXt, dHt on 256 sampled rows and the full parameter gradients."""
+    g = _golden('g8c_large_n10000_k3')
+    s = synth_inputs('g8c')
+    graph = CsrGraph.from_dense(s.pop('Gs'))
+    s = {k: (v.to(DEV) if isinstance(v, torch.Tensor) else v) for k, v in s.items()}
+    cell = M.STC_Cell(s['N'], s['C'], 3, 3, s['cin'], s['h']).to(DEV)
+    cell.load_state_dict({'gates.W': s['gates_W'], 'gates.b': s['gates_b'], 'candi.W': s['candi_W'], 'candi.b': s['candi_b']})
+    Xt, Ht = _leaf(s['Xt']), _leaf(s['Ht'])
+    out = cell(graph, s['Gc'], Xt, Ht)
+    rows = g['rows']
+    _close(out[:, rows], g['Hout'], FWD, 'Ht rows N=10000 K=3 (g8c)')
+    (out * s['R']).sum().backward()
+    _close(Xt.grad[:, rows], g['dXt'], GRAD, 'dXt rows N=10000 K=3')
+    _close(Ht.grad[:, rows], g['dHt'], GRAD, 'dHt rows N=10000 K=3')
+    for name, p in (('d_gates_W', cell.gates.W), ('d_gates_b', cell.gates.b), ('d_candi_W', cell.candi.W), ('d_candi_b', cell.candi.b)):
+        _close(p.grad, g[name], 2e-5, name + ' N=10000 K=3', gpu_tol=2e-5)
+
+
+def test_large_n10000_order_3_planar_cells_against_dense_reference_rows():
+    """g8c through the path the bench takes at order 3: the cell as a one-cell schedule of ``ops.stc_cell_graph``, i.e. the order-3 PLANAR
+    kernels (three Chebyshev planes per side, stc_cell_*_planar_k_f32) at N = 10 000 -- new state on 256 rows and every parameter gradient
+    of the dense reference; then two chained cells (the second one reads the first one's state as X and as H, so the state's gradient is
+    assembled from its consumers' planes by the Clenshaw sums) against the oracle's sparse restatement."""
+    g = _golden('g8c_large_n10000_k3')
+    s = synth_inputs('g8c')
+    graph = CsrGraph.from_dense(s.pop('Gs'))
+    sc = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in s.items()}
+    s = {k: (v.to(DEV) if isinstance(v, torch.Tensor) else v) for k, v in s.items()}
+    from stc_hip.graph import csr_operand
+    op = csr_operand(graph, torch.device(DEV))
+    Tc = ops.cheby_dense(s['Gc'], 3)
+    assert ops.cell_graph_supported(op, Tc, 3, s['C'], s['h'], [s['cin']]), 'order-3 planar cells are not available for this shape'
+    p = [_leaf(s[k]) for k in ('gates_W', 'gates_b', 'candi_W', 'candi_b')]
+    out = ops.stc_cell_graph(op, Tc, 3, [(0, ('ext', 0), ('ext', 1))], [0], [s['Xt'], s['Ht']], [tuple(p)])[0]
+    rows = g['rows']
+    _close(out[:, rows], g['Hout'], FWD, 'planar-K Ht rows N=10000 K=3 (g8c)')
+    (out * s['R']).sum().backward()
+    for t, name in zip(p, ('d_gates_W', 'd_gates_b', 'd_candi_W', 'd_candi_b')):
+        _close(t.grad, g[name], 2e-5, 'planar-K ' + name + ' N=10000 K=3', gpu_tol=2e-5)
+    # two chained cells: state gradients through the Clenshaw sums, against the oracle (float64: sums over 320 000 rows)
+    p2 = [_leaf(s[k]) for k in ('gates_W', 'gates_b', 'candi_W', 'candi_b')]
+    out2 = ops.stc_cell_graph(op, Tc, 3, [(0, ('ext', 0), ('ext', 1)), (0, ('cell', 0), ('cell', 0))], [1], [s['Xt'], s['Ht']], [tuple(p2)])[0]
+    (out2 * s['R']).sum().backward()
+    GsT = graph_dense_T_csr(sc, graph)
+    po = [sc[k].double().requires_grad_() for k in ('gates_W', 'gates_b', 'candi_W', 'candi_b')]
+    s0 = O.stc_cell(GsT, sc['Gc'].double(), sc['Xt'].double(), sc['Ht'].double(), *po, 3, 3, conv=O.bdg_dif_sparse)
+    s1 = O.stc_cell(GsT, sc['Gc'].double(), s0, s0, *po, 3, 3, conv=O.bdg_dif_sparse)
+    (s1 * sc['R'].double()).sum().backward()
+    _close(out2[:, rows], s1.detach()[:, rows.cpu()].float().to(DEV), FWD, 'two chained planar-K cells: Ht rows')
+    for t, w, name in zip(p2, po, ('d_gates_W', 'd_gates_b', 'd_candi_W', 'd_candi_b')):
+        _close(t.grad, w.grad.float().to(DEV), 2e-5, 'two chained planar-K cells: ' + name, gpu_tol=2e-5)
+
+
+def graph_dense_T_csr(s, graph):
+    h = graph._host
+    return torch.sparse_csr_tensor(torch.from_numpy(h['fwd_rowptr']).long(), torch.from_numpy(h['fwd_colidx']).long(),
+                                   torch.from_numpy(h['fwd_val']).double(), size=(graph.n, graph.n))
+
+
 @pytest.mark.parametrize('name,C,K', [('g11_bench_c32', 32, 2), ('g12_bench_c64', 64, 2), ('g13_bench_c32_k3', 32, 3)])
 def test_bench_path_against_reference_goldens(monkeypatch, name, C, K):
     """The path bench.py runs -- csr-fixed STCGNN at C in {32, 64}, hidden 16, encoder + decoder as ONE cell-graph node on the
@@ -306,16 +396,6 @@ def test_bench_path_against_reference_goldens(monkeypatch, name, C, K):
     grads = dict(model.named_parameters())
     for k, v in sub_dict(g, 'grad/').items():
         _close(grads[k].grad, v, GRAD, f'{name} d{k}')
-
-
-@pytest.mark.parametrize('golden', ['g5_sf_shape', 'g7_csr_n1024'])
-def test_opt_in_fused_backward_epilogues(monkeypatch, golden):
-    """STC_FUSE_BWD=1 routes the cell backward through stc_spmm_bwd_gates/split_f32: same gradients."""
-    monkeypatch.setattr(ops, '_FUSE_BWD', True)
-    if golden == 'g5_sf_shape':
-        test_sf_shape_fixed_graphs_through_modules()
-    else:
-        test_csr_fixed_graph_equals_dense_reference('g7', golden, 'CsrGraph')
 
 
 def test_internal_node_reordering_is_invisible():
@@ -390,14 +470,14 @@ def test_factorised_mixed_fusion_option(dev):
 
 
 @pytest.mark.parametrize('layers,T,horizon,cin,K', [(2, 4, 3, 1, 2), (1, 3, 2, 1, 2), (3, 2, 2, 4, 2), (2, 3, 2, 1, 3), (3, 2, 2, 4, 3)])
-def test_cell_graph_equals_the_per_cell_path(dev, monkeypatch, layers, T, horizon, cin, K, post_k3=False, one_launch_bwd=True):
+def test_cell_graph_equals_the_per_cell_path(dev, monkeypatch, layers, T, horizon, cin, K, one_launch_bwd=True):
     """Encoder + decoder as one autograd node (no concat / gradient-accumulation passes between the cells) vs one node per
     cell: same prediction, same parameter gradients.  Hidden 16; 32 categories on the GPU (matrix-core shapes).  K = 3: the
     order-3 planar cells (three Chebyshev planes per side, Clenshaw state gradients) against the per-cell slab form."""
     C = 32 if DEV == 'cuda' else 5
     Hh, Ww, h, B = 5, 6, 16, 2
-    monkeypatch.setattr(ops, '_POST_K3', post_k3)
-    monkeypatch.setenv('STC_FUSE_CELL_BWD', '1' if one_launch_bwd else '0')
+    if not one_launch_bwd:          # the two-launch backward is what C = 64 runs (the one-launch kernel is built for C = 32): force it at C = 32
+        monkeypatch.setattr(type(ops.kernels()), 'cell_bwd_planar_supported', lambda self, Cc, hh: False)
     torch.manual_seed(layers * 10 + T)
     graph = CsrGraph.queen_grid(Hh, Ww, normalize=True)
     model = M.STCGNN(Hh * Ww, C, K, K, cin, h, layers, horizon, graph_mode='csr-fixed').to(DEV)
@@ -515,14 +595,7 @@ def test_cell_graph_output_stack_is_guarded_against_in_place_edits(dev):
 
 
 @pytest.mark.parametrize('layers,T,horizon,cin', [(2, 3, 2, 1), (3, 2, 2, 4)])
-def test_order3_post_aggregation_candidate_option(dev, monkeypatch, layers, T, horizon, cin):
-    """STC_POST_K3=1: the order-3 candidate convolution in post-aggregation (Clenshaw) form, Y = (P0 - P2 + b) + S.(P1 + 2 S.P2) --
-    same predictions and gradients as the per-cell slab form (an opt-in that trades a slower backward kernel for less saved memory)."""
-    test_cell_graph_equals_the_per_cell_path(dev, monkeypatch, layers, T, horizon, cin, 3, post_k3=True)
-
-
-@pytest.mark.parametrize('layers,T,horizon,cin', [(2, 3, 2, 1), (3, 2, 2, 4)])
 def test_two_launch_cell_backward_option(dev, monkeypatch, layers, T, horizon, cin):
-    """STC_FUSE_CELL_BWD=0: the planar cells' backward as two launches (stc_bdg_node_post_bwd_f32 + stc_cell_gates_bwd_planar_f32, with
+    """The planar cells' backward as two launches (stc_bdg_node_post_bwd_f32 + stc_cell_gates_bwd_planar_f32, with
     the R*H plane stored by the forward) instead of stc_cell_bwd_planar_f32 -- same predictions and gradients."""
     test_cell_graph_equals_the_per_cell_path(dev, monkeypatch, layers, T, horizon, cin, 2, one_launch_bwd=False)

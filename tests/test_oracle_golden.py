@@ -287,3 +287,21 @@ def test_g8b_large_n_gradients_sparse_oracle():
     assert rel_err(Xt.grad[:, rows], g['dXt']) < 5e-6 and rel_err(Ht.grad[:, rows], g['dHt']) < 5e-6
     for t, k in zip(p, ('d_gates_W', 'd_gates_b', 'd_candi_W', 'd_candi_b')):
         assert rel_err(t.grad, g[k]) < 2e-5, k
+
+
+def test_g8c_large_n_order_3_sparse_oracle():
+    """N = 10 000 at Chebyshev order 3 (BASELINE configuration 4) with backward: the sparse feature-side oracle against sampled rows of
+    the dense reference (matrix-side cheby_poly, STC_GNN.py:24-29) and its full parameter gradients."""
+    g = load_golden('g8c_large_n10000_k3')
+    s = synth_inputs('g8c')
+    assert s['K'] == 3
+    GsT = s['Gs'].t().contiguous().to_sparse_csr()
+    Xt, Ht = _leaf(s['Xt']), _leaf(s['Ht'])
+    p = [_leaf(s[k]) for k in ('gates_W', 'gates_b', 'candi_W', 'candi_b')]
+    out = O.stc_cell(GsT, s['Gc'], Xt, Ht, *p, 3, 3, conv=O.bdg_dif_sparse)
+    rows = g['rows']
+    assert rel_err(out[:, rows], g['Hout']) < 2e-6
+    (out * s['R']).sum().backward()
+    assert rel_err(Xt.grad[:, rows], g['dXt']) < 5e-6 and rel_err(Ht.grad[:, rows], g['dHt']) < 5e-6
+    for t, k in zip(p, ('d_gates_W', 'd_gates_b', 'd_candi_W', 'd_candi_b')):
+        assert rel_err(t.grad, g[k]) < 2e-5, k

@@ -214,7 +214,10 @@ def test_bench_line_contract(storage):
     esize = 2 if storage == 'bf16' else 4
     if storage == 'f32':                 # (bf16 also sends its narrow layer-0 input planes, F = C, through the row-blocked kernel)
         assert r['algorithmic_bytes_per_launch'] == nnz * 8 + 4 * (N + 1) + 2 * B * N * C * 16 * esize     # SURVEY 8(d3), verbatim
-    assert r['traffic'] is None                                              # no PMC pass over this configuration: never a stale number
+    assert r['traffic'] is None and r['traffic_source'] is None              # no PMC pass over this configuration: never a stale number
+    dom = r['dominant']
+    assert dom['entry_point'] in d['kernels'] and 0 < dom['share_of_kernel_time'] <= 1 and dom['launches'] > 0
+    assert r['mfma'] is None or r['mfma'].get('value', 0) is None or r['mfma']['source'] == 'committed'     # quoted only for the same kernel sources
     u = r['unit_d3']
     assert u['algorithmic_bytes'] == nnz * 8 + 4 * (N + 1) + 2 * N * C * 32 * esize and u['avg_launch_us'] > 0
     assert r['aggregate']['launches'] >= r['launches'] and r['aggregate']['achieved'] > 0
@@ -226,7 +229,7 @@ def test_bench_line_contract(storage):
     if storage == 'f32':
         c = d['cpu_baseline']
         assert c['kind'] == 'port' and c['cores'] >= 1 and c['value'] > 0 and c['unit'] == 'samples/s' and 'sample' in c
-        assert len(c['shots_s']['layer0']) == 4 and len(c['shots_s']['wide']) == 4     # 1 warm-up + 3 timed
+        assert len(c['shots_s']['layer0']) == 9 and len(c['shots_s']['wide']) == 9     # 2 warm-up + 7 timed
 
 
 @pytest.mark.gpu
@@ -249,6 +252,75 @@ def test_bench_launches_its_own_ranks():
     assert d['n_gpus'] == 2 and d['n_ranks_seen'] == 2 and d['config']['global_batch'] == 4 and d['config']['parallelism'] == 'batch-shard x2'
     assert abs(d['value'] - 4 * 1e3 / d['ms_per_step']) < 1e-6 * d['value'] and 'cpu_baseline' not in d
     assert d['step_breakdown']['grad_allreduce_ms'] > 0
+
+
+def _two_gpus():
+    """RCCL between ranks needs one GPU per rank: these tests run on a node with >= 2 visible GPUs and say so loudly otherwise."""
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip(f'RCCL between two ranks needs two GPUs; {n} visible on this box (the gloo / one-device form of the same path runs in '
+                    'test_bench_launches_its_own_ranks and test_batch_sharded_trainer_on_the_gpu_follows_the_reference_curves)')
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_over_rccl():
+    """``python bench.py --gpus 2`` with the DEFAULT backend (nccl = RCCL over xGMI), one rank per GPU: both ranks take part in the
+    collectives, and rank 0's loss equals the gloo run's (same shards, same parameters: the backend must not change the arithmetic).
+    Strong scaling form (``--global-batch``) as well."""
+    _two_gpus()
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'STC_DIST_BACKEND', 'STC_DIST_ONE_DEVICE')}
+    base = [sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--grid', '32', '--obs', '3', '--pred', '2']
+    got = {}
+    for name, extra, e in (('rccl', ['--batch-per-gpu', '2'], env), ('gloo', ['--batch-per-gpu', '2'], {**env, 'STC_DIST_BACKEND': 'gloo'}),
+                           ('strong', ['--global-batch', '4'], env)):
+        out = subprocess.run(base + extra, capture_output=True, text=True, timeout=900, env=e)
+        assert out.returncode == 0, (name, out.stderr[-3000:])
+        got[name] = json.loads([l for l in out.stdout.strip().split('\n') if l.startswith('{')][0])
+    for name, d in got.items():
+        assert d['n_gpus'] == 2 and d['n_ranks_seen'] == 2 and d['config']['global_batch'] == 4, name
+        assert d['step_breakdown']['grad_allreduce_ms'] > 0
+    assert abs(got['rccl']['loss'] - got['gloo']['loss']) < 1e-6 and abs(got['strong']['loss'] - got['rccl']['loss']) < 1e-6
+    assert got['rccl']['scaling'] == 'weak' and got['strong']['scaling'] == 'strong'
+
+
+@pytest.mark.gpu
+def test_batch_sharded_trainer_over_rccl_follows_the_reference_curves(tmp_path):
+    """The trainer counterpart under ``torch.distributed.run``, two ranks on two GPUs over RCCL (default backend): parameters broadcast
+    from rank 0, learned graphs with the batch-sum all-reduce, ragged last batch, one gradient-bucket all-reduce per step -- the
+    REFERENCE's 2-epoch loss curves of g9."""
+    _two_gpus()
+    import json
+    import subprocess
+    import sys
+    script = tmp_path / 'sharded_trainer.py'
+    script.write_text(_SHARDED_TRAINER_SCRIPT)
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'STC_DIST_BACKEND', 'STC_DIST_ONE_DEVICE')}
+    env.update(STC_REPO=REPO, STC_OUT=str(tmp_path))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', '29549', str(script)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.strip().split('\n') if l.startswith('{')][0])
+    g = load_golden('g9_pipeline')
+    assert d['world'] == 2
+    assert np.allclose(d['train'], g['train_curve'].numpy(), rtol=0, atol=1e-4), d
+    assert np.allclose(d['val'], g['val_curve'].numpy(), rtol=0, atol=1e-4), d
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('K', [2, 3])
+def test_bench_preset_cfg2(K):
+    """bench.py --preset cfg2: the single BDG_Dif layer of BASELINE configuration 2, forward and forward + backward, beside the reference's CPU times."""
+    import json
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--preset', 'cfg2', '--order', str(K)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.strip().split('\n') if l.startswith('{')][0])
+    assert d['config']['preset'] == 'cfg2' and d['forward_ms'] > 0 and d['forward_backward_ms'] > d['forward_ms'] * 0.5
+    assert d['reference_cpu_ms']['forward'] == {2: 13.3, 3: 29.6}[K] and d['vs_baseline'] is None
 
 
 @pytest.mark.gpu

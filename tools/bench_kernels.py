@@ -48,7 +48,7 @@ def main():
     nnz = g['fwd_colidx'].numel()
     plan_f = (g['fwd_blk_ptr'], g['fwd_blk_cols'], g['fwd_blk_vals']) if not a.no_tile else None
     plan_b = (g['bwd_blk_ptr'], g['bwd_blk_cols'], g['bwd_blk_vals']) if not a.no_tile else None
-    print(f'# N={N} nnz={nnz} C={C} h={h} K={K} B={B} permute={a.permute} MFMA={"off" if os.environ.get("STC_DISABLE_MFMA") == "1" else "on"} '
+    print(f'# N={N} nnz={nnz} C={C} h={h} K={K} B={B} permute={a.permute} '
           f'SPMM_VARIANT={os.environ.get("STC_SPMM_VARIANT", "default")} row_blocked={plan_f is not None}')
 
     def report(name, us, nbytes):

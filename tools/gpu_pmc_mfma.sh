@@ -10,7 +10,7 @@ run() { n=$1; shift; rm -rf $R/gpurun_out/pmcm_$n; timeout 1200 rocprofv3 --pmc 
 run sq SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVES
 run grbm GRBM_GUI_ACTIVE
 cd $R/gpurun_out
-python3 - "$TAG" <<'PY'
+BENCH_ARGS="${BENCH_ARGS:-}" python3 - "$TAG" <<'PY'
 import csv, glob, json, collections, re, sys
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(collections.Counter)
 for d in ('pmcm_sq', 'pmcm_grbm'):
@@ -27,7 +27,16 @@ for k, v in agg.items():
                   mfma_busy_cycles_per_launch=per['SQ_VALU_MFMA_BUSY_CYCLES'], mfma_util=per['SQ_VALU_MFMA_BUSY_CYCLES'] / (cyc * 1024),
                   valu_insts_per_launch=per['SQ_INSTS_VALU'], valu_busy=4 * per['SQ_ACTIVE_INST_VALU'] / (cyc * 1024),
                   wave_cycles_stalled_on_issue=per['SQ_WAIT_INST_ANY'] / max(per['SQ_WAVE_CYCLES'], 1), wave_cycles_parked=per['SQ_WAIT_ANY'] / max(per['SQ_WAVE_CYCLES'], 1))
-json.dump(out, open(f'mfma_util_{sys.argv[1]}.json', 'w'), indent=1)
+import os
+sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
+import bench
+a = bench.parse(os.environ.get('BENCH_ARGS', '').split())
+config_key = f'{a.storage}:{a.grid}:{a.categories}:{a.hidden}:{a.batch_per_gpu}:{a.order}:{a.layers}:{a.obs}:{a.pred}:{int(a.permute)}'
+json.dump(dict(csrc_sha=bench.csrc_sha(), config_key=config_key,
+               command='python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline ' + os.environ.get('BENCH_ARGS', ''),
+               definition='mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs); valu_busy = 4 SQ_ACTIVE_INST_VALU / the same; '
+                          'SQ and GRBM counters in separate rocprofv3 --pmc passes over one step of the command',
+               kernels=out), open(f'mfma_util_{sys.argv[1]}.json', 'w'), indent=1)
 for k, v in sorted(out.items(), key=lambda kv: -kv[1]['gpu_cycles_per_launch'] * kv[1]['launches']):
     print(f"{k[:58]:58s} x{v['launches']:4d}  mfma_util {100 * v['mfma_util']:5.1f} %  valu_busy {100 * v['valu_busy']:5.1f} %  issue-stall {100 * v['wave_cycles_stalled_on_issue']:4.1f} %  parked {100 * v['wave_cycles_parked']:4.1f} %")
 PY
