@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define STC_ABI_VERSION 14
+#define STC_ABI_VERSION 15
 #define STC_MAX_K 4          /* highest Chebyshev order (Ks, Kc) the node kernels accept */
 
 /* Operand formats of the split-operand matrix-core kernels (C = 32 / 64, hidden 16).  Every fp32 operand is split into low-precision
@@ -328,6 +328,7 @@ int stc_cell_gates_bwd_planar_f32(const float* X, const float* H, const float* S
                                   const float* Tc, const float* W,
                                   const float* dCandIn, const float* Cand, const float* U, const float* Rg, const float* dHnew,
                                   float* const* dZ, float* dW, float* db, float* dH,
+                                  const float* grad_amax, int32_t n_amax,      /* fp16 x 2 format: max over the slots bounds |dHnew| and |dCandIn| */
                                   void* workspace, size_t workspace_bytes,
                                   int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream);
 
@@ -376,17 +377,20 @@ int stc_cell_bwd_planar_f32(const float* X, const float* H, const float* SX, con
  * stc_spmm_sum_f32 launches with alpha / add_scale.  stc_cell_planar_k_supported() tells whether (K, C, h) is built. */
 int stc_cell_planar_k_supported(int32_t K, int32_t C, int32_t h);
 int stc_cell_gates_fwd_planar_k_f32(const float* const* Zx, const float* const* Zh, int32_t K, const float* Tc, const float* W, const float* bias,
-                                    float* U, float* Rg, float* RH, int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream);
+                                    float* U, float* Rg, float* RH, int32_t operand_format,
+                                    int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream);
 int stc_cell_cand_fwd_planar_k_f32(const float* const* Zx, const float* const* Zh, int32_t K, const float* Tc, const float* W, const float* bias,
-                                   const float* U, const float* H, float* Cand, float* Hnew,
+                                   const float* U, const float* H, float* Cand, float* Hnew, int32_t operand_format,
                                    int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream);
 int stc_cell_gates_bwd_planar_k_f32(const float* const* Zx, const float* const* Zh, int32_t K, const float* Tc, const float* W,
                                     const float* dRH, const float* Cand, const float* U, const float* Rg, const float* dHnew,
                                     float* const* dZx, float* const* dZh, float* dW, float* db, float* dH, int32_t accumulate_x,
+                                    const float* grad_amax, int32_t n_amax,     /* fp16 x 2 format: max over the slots bounds |dHnew| and |dRH| */
                                     void* workspace, size_t workspace_bytes, int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream);
 int stc_cell_cand_bwd_planar_k_f32(const float* const* Zx, const float* const* Zh, int32_t K, const float* Tc, const float* W,
                                    const float* dHnew, const float* U, const float* Cand,
                                    float* const* dZx, float* const* dZh, float* dW, float* db,
+                                   const float* grad_amax, int32_t n_amax,      /* fp16 x 2 format: max over the slots bounds |dHnew| */
                                    void* workspace, size_t workspace_bytes, int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream);
 
 /* Y = sum_i add_scale[i] add[i] + alpha S x (X [+ X2]) on rows of C*h floats (h = 16): the gradient of a state from the pieces

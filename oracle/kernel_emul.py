@@ -234,7 +234,7 @@ class EmulatedKernels:
             Wc, bc, A, Bm = post
             self.node_post_fwd(CandIn, Tc, Wc, bc, A, Bm)
 
-    def cell_gates_bwd_planar(self, X, H, SX, SH, Tc, W, dRH, Cand, U, Rg, dHnew, dZs, dW, db, dH):
+    def cell_gates_bwd_planar(self, X, H, SX, SH, Tc, W, dRH, Cand, U, Rg, dHnew, dZs, dW, db, dH, grad_amax=None):
         cin, h = X.shape[-1], H.shape[-1]
         fold = dH is None                                                   # bf16 kernels: the prologue's share goes into dZs[2]
         if fold:
@@ -305,7 +305,7 @@ class EmulatedKernels:
             if dZx[n] is not None:
                 dZx[n].copy_(r[..., :cin])
 
-    def cell_gates_bwd_planar_k(self, Zx, Zh, Tc, W, dRH, Cand, U, Rg, dHnew, dZx, dZh, dW, db, dH, accumulate_x=False):
+    def cell_gates_bwd_planar_k(self, Zx, Zh, Tc, W, dRH, Cand, U, Rg, dHnew, dZx, dZh, dW, db, dH, accumulate_x=False, grad_amax=None):
         cin, h = Zx[0].shape[-1], Zh[0].shape[-1]
         before = [z.clone() for z in dZx] if accumulate_x else None              # the candidate's gradients already in the X-side planes
         fold = dH is None                                                   # the prologue's share goes into dZh[0]
@@ -321,7 +321,7 @@ class EmulatedKernels:
             for z, b in zip(dZx, before):
                 z += b
 
-    def cell_cand_bwd_planar_k(self, Zx, Zh, Tc, W, dHnew, U, Cand, dZx, dZh, dW, db):
+    def cell_cand_bwd_planar_k(self, Zx, Zh, Tc, W, dHnew, U, Cand, dZx, dZh, dW, db, grad_amax=None):
         cin, h = Zx[0].shape[-1], Zh[0].shape[-1]
         rows = [torch.empty(Zh[0].shape[:-1] + (cin + h,), dtype=W.dtype) for _ in Zh]
         self.cell_cand_bwd(self._cat_planes(Zx, Zh), Tc, W, dHnew, U, Cand, rows, dW, db)

@@ -515,10 +515,12 @@ extern "C" int stc_cell_gates_bwd_planar_f32(const float* X, const float* H, con
                                              const float* Tc, const float* W,
                                              const float* dCandIn, const float* Cand, const float* U, const float* Rg, const float* dHnew,
                                              float* const* dZ, float* dW, float* db, float* dH,
+                                             const float* grad_amax, int32_t n_amax,
                                              void* workspace, size_t workspace_bytes,
                                              int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream) {
     const int L = Lw == 2 * h ? 2 * h : 20, Ho = 2 * h;
     if (int rc = check_dims("stc_cell_gates_bwd_planar_f32", 2, 2, C, L, Lw, Ho, nodes)) return rc;
+    STC_REQUIRE(!grad_amax || n_amax >= 1, STC_EINVAL, "stc_cell_gates_bwd_planar_f32: grad_amax with %d slots", n_amax);
     STC_REQUIRE(Lw == 2 * h || (Lw > h && Lw <= h + 4), STC_EINVAL, "stc_cell_gates_bwd_planar_f32: input width %d (Lw - h) must be h or 1..4", Lw - h);
     if (!stc_cell_planar_supported(2, 2, C, h)) return stc::fail(STC_EUNSUPPORTED, "stc_cell_gates_bwd_planar_f32: shape not on the planar path");
     STC_REQUIRE(W && dZ && dW && Tc, STC_EINVAL, "stc_cell_gates_bwd_planar_f32: null W/dZ/dW/Tc");
@@ -537,7 +539,7 @@ extern "C" int stc_cell_gates_bwd_planar_f32(const float* X, const float* H, con
     int n_parts = 0;
     float* partial = static_cast<float*>(workspace);
     const int rc = stc_cell_gates_bwd_planar_x3(X, H, SX, SH, Tc, W, dCandIn, Cand, U, Rg, dHnew, dZ, dH, partial, &n_parts, db != nullptr,
-                                                nodes, C, Lw, s);
+                                                grad_amax, n_amax, nodes, C, Lw, s);
     if (rc == STC_NOT_HANDLED) return stc::fail(STC_EUNSUPPORTED, "stc_cell_gates_bwd_planar_f32: operands not usable (alignment)");
     if (rc != STC_OK) return rc;
     const int stride = nW + Ho;
@@ -615,32 +617,36 @@ static int planar_k_common(const char* who, const float* const* Zx, const float*
 }
 
 extern "C" int stc_cell_gates_fwd_planar_k_f32(const float* const* Zx, const float* const* Zh, int32_t K, const float* Tc, const float* W, const float* bias,
-                                               float* U, float* Rg, float* RH, int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream) {
+                                               float* U, float* Rg, float* RH, int32_t operand_format,
+                                               int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream) {
     if (int rc = planar_k_common("stc_cell_gates_fwd_planar_k_f32", Zx, Zh, K, C, Lw, h, 2 * h, nodes)) return rc;
+    STC_REQUIRE(operand_format == STC_FMT_BF16X3 || operand_format == STC_FMT_F16X2, STC_EINVAL, "stc_cell_gates_fwd_planar_k_f32: operand_format %d", operand_format);
     if (nodes == 0) return STC_OK;
     STC_REQUIRE(Tc && W && U && Rg && RH, STC_EINVAL, "stc_cell_gates_fwd_planar_k_f32: null pointer");
-    const int rc = stc_cell_conv_fwd_planar_k_x3(Zx, Zh, K, Tc, W, bias, 1, Zh[0], nullptr, U, Rg, RH, nullptr, nullptr, nodes, C, Lw, static_cast<hipStream_t>(stream));
+    const int rc = stc_cell_conv_fwd_planar_k_x3(Zx, Zh, K, Tc, W, bias, 1, Zh[0], nullptr, U, Rg, RH, nullptr, nullptr, operand_format, nodes, C, Lw, static_cast<hipStream_t>(stream));
     return rc == STC_NOT_HANDLED ? stc::fail(STC_EUNSUPPORTED, "stc_cell_gates_fwd_planar_k_f32: operands not usable (alignment)") : rc;
 }
 
 extern "C" int stc_cell_cand_fwd_planar_k_f32(const float* const* Zx, const float* const* Zh, int32_t K, const float* Tc, const float* W, const float* bias,
-                                              const float* U, const float* H, float* Cand, float* Hnew,
+                                              const float* U, const float* H, float* Cand, float* Hnew, int32_t operand_format,
                                               int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream) {
     if (int rc = planar_k_common("stc_cell_cand_fwd_planar_k_f32", Zx, Zh, K, C, Lw, h, h, nodes)) return rc;
+    STC_REQUIRE(operand_format == STC_FMT_BF16X3 || operand_format == STC_FMT_F16X2, STC_EINVAL, "stc_cell_cand_fwd_planar_k_f32: operand_format %d", operand_format);
     if (nodes == 0) return STC_OK;
     STC_REQUIRE(Tc && W && U && H && Cand && Hnew, STC_EINVAL, "stc_cell_cand_fwd_planar_k_f32: null pointer");
     STC_REQUIRE(stc::aligned16(U) && stc::aligned16(H) && stc::aligned16(Cand) && stc::aligned16(Hnew), STC_EALIGN, "stc_cell_cand_fwd_planar_k_f32: misaligned operand");
-    const int rc = stc_cell_conv_fwd_planar_k_x3(Zx, Zh, K, Tc, W, bias, 2, H, U, nullptr, nullptr, nullptr, Cand, Hnew, nodes, C, Lw, static_cast<hipStream_t>(stream));
+    const int rc = stc_cell_conv_fwd_planar_k_x3(Zx, Zh, K, Tc, W, bias, 2, H, U, nullptr, nullptr, nullptr, Cand, Hnew, operand_format, nodes, C, Lw, static_cast<hipStream_t>(stream));
     return rc == STC_NOT_HANDLED ? stc::fail(STC_EUNSUPPORTED, "stc_cell_cand_fwd_planar_k_f32: operands not usable (alignment)") : rc;
 }
 
 static int planar_k_bwd(const char* who, const float* const* Zx, const float* const* Zh, int K, const float* Tc, const float* W, int mode,
                         const float* dRH, const float* Cand, const float* U, const float* Rg, const float* dHnew,
                         float* const* dZx, float* const* dZh, float* dW, float* db, float* dH, void* workspace, size_t workspace_bytes,
-                        long long nodes, int C, int Lw, int h, hipStream_t s, int accumulate_x = 0) {
+                        long long nodes, int C, int Lw, int h, hipStream_t s, const float* grad_amax, int n_amax, int accumulate_x = 0) {
     const int L = Lw == 2 * h ? 2 * h : 20, Ho = mode == 1 ? 2 * h : h;
     if (int rc = planar_k_common(who, Zx, Zh, K, C, Lw, h, Ho, nodes)) return rc;
     STC_REQUIRE(W && dW && Tc && dZh && (Lw != 2 * h || dZx), STC_EINVAL, "%s: null W/dW/Tc/dZ", who);
+    STC_REQUIRE(!grad_amax || n_amax >= 1, STC_EINVAL, "%s: grad_amax with %d slots", who, n_amax);
     const int nW = K * K * Lw * Ho;
     if (nodes == 0) {
         if (int rc = stc::hip_status(hipMemsetAsync(dW, 0, (size_t)nW * sizeof(float), s), "memset dW")) return rc;
@@ -653,7 +659,7 @@ static int planar_k_bwd(const char* who, const float* const* Zx, const float* co
     int n_parts = 0;
     float* partial = static_cast<float*>(workspace);
     const int rc = stc_cell_conv_bwd_planar_k_x3(Zx, Zh, K, Tc, W, mode, dRH, Cand, U, Rg, dHnew, dZx, dZh, dH, partial, &n_parts, db != nullptr, nodes, C, Lw,
-                                                 accumulate_x, s);
+                                                 accumulate_x, grad_amax, n_amax, s);
     if (rc == STC_NOT_HANDLED) return stc::fail(STC_EUNSUPPORTED, "%s: operands not usable (alignment / null gradient plane / accumulate_x outside the wide folded form)", who);
     if (rc != STC_OK) return rc;
     const int stride = nW + Ho;
@@ -666,17 +672,19 @@ static int planar_k_bwd(const char* who, const float* const* Zx, const float* co
 extern "C" int stc_cell_gates_bwd_planar_k_f32(const float* const* Zx, const float* const* Zh, int32_t K, const float* Tc, const float* W,
                                                const float* dRH, const float* Cand, const float* U, const float* Rg, const float* dHnew,
                                                float* const* dZx, float* const* dZh, float* dW, float* db, float* dH, int32_t accumulate_x,
+                                               const float* grad_amax, int32_t n_amax,
                                                void* workspace, size_t workspace_bytes, int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream) {
     return planar_k_bwd("stc_cell_gates_bwd_planar_k_f32", Zx, Zh, K, Tc, W, 1, dRH, Cand, U, Rg, dHnew, dZx, dZh, dW, db, dH, workspace, workspace_bytes,
-                        nodes, C, Lw, h, static_cast<hipStream_t>(stream), accumulate_x);
+                        nodes, C, Lw, h, static_cast<hipStream_t>(stream), grad_amax, n_amax, accumulate_x);
 }
 
 extern "C" int stc_cell_cand_bwd_planar_k_f32(const float* const* Zx, const float* const* Zh, int32_t K, const float* Tc, const float* W,
                                               const float* dHnew, const float* U, const float* Cand,
                                               float* const* dZx, float* const* dZh, float* dW, float* db,
+                                              const float* grad_amax, int32_t n_amax,
                                               void* workspace, size_t workspace_bytes, int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream) {
     return planar_k_bwd("stc_cell_cand_bwd_planar_k_f32", Zx, Zh, K, Tc, W, 2, nullptr, Cand, U, nullptr, dHnew, dZx, dZh, dW, db, nullptr, workspace, workspace_bytes,
-                        nodes, C, Lw, h, static_cast<hipStream_t>(stream));
+                        nodes, C, Lw, h, static_cast<hipStream_t>(stream), grad_amax, n_amax);
 }
 
 extern "C" int stc_bdg_node_post_supported(int32_t Ks, int32_t Kc, int32_t C, int32_t L, int32_t Ho) {

@@ -121,6 +121,7 @@ struct BwdPro {
     float *dXt, *dH;                                  // (nodes,C,cin) or null, (nodes,C,16)
     int cin;
     int dh_scaled;                                    // dH_in enters as dH_in * (1 - U)
+    const float* gmax; int n_gmax;                    // fp16 x 2 operand format: slots whose maximum is the launch's gradient maximum (device)
 };
 
 // FOLD (planar kernels): the state's share dH is not written to HBM; it is parked in a lane-private LDS slot (stash[kb * 64 + lane],

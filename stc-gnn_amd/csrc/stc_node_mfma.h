@@ -79,7 +79,7 @@ int stc_cell_gates_fwd_planar_x3(const float* X, const float* H, const float* SX
                                  long long nodes, int C, int Lw, hipStream_t stream);
 int stc_cell_gates_bwd_planar_x3(const float* X, const float* H, const float* SX, const float* SH, const float* Tc, const float* W,
                                  const float* dCandIn, const float* Cand, const float* U, const float* R, const float* dHnew,
-                                 float* const* dZ, float* dH, float* partial, int* n_partials, int want_db,
+                                 float* const* dZ, float* dH, float* partial, int* n_partials, int want_db, const float* gmax, int n_gmax,
                                  long long nodes, int C, int Lw, hipStream_t stream);
 
 // The whole backward of a planar K = 2 cell step in one launch (stc_cell_bwd_x3.hip; C = 32): candidate (post-aggregation form) and
@@ -94,12 +94,12 @@ int stc_cell_bwd_planar_x3(const float* X, const float* H, const float* SX, cons
 // Planar cell convolutions of order K = 3 (stc_node_x3.hip): Zx[n] / Zh[n] = T_n(S) of the X-side / H-side plane; mode 1 gates, 2 candidate.
 int stc_cell_planar_k_shape_ok(int K, int C, int h);
 int stc_cell_conv_fwd_planar_k_x3(const float* const* Zx, const float* const* Zh, int K, const float* Tc, const float* W, const float* bias, int mode,
-                                  const float* H, const float* Uin, float* U, float* R, float* RH, float* Cand, float* Hnew,
+                                  const float* H, const float* Uin, float* U, float* R, float* RH, float* Cand, float* Hnew, int fmt,
                                   long long nodes, int C, int Lw, hipStream_t stream);
 int stc_cell_conv_bwd_planar_k_x3(const float* const* Zx, const float* const* Zh, int K, const float* Tc, const float* W, int mode,
                                   const float* dRH, const float* Cand, const float* U, const float* R, const float* dHnew,
                                   float* const* dZx, float* const* dZh, float* dH, float* partial, int* n_partials, int want_db,
-                                  long long nodes, int C, int Lw, int accumulate_x, hipStream_t stream);
+                                  long long nodes, int C, int Lw, int accumulate_x, const float* gmax, int n_gmax, hipStream_t stream);
 
 // Fixed-order reduction of the backward kernels' per-workgroup partial rows [dW (nW) | db (Ho)] into dW, db (db may be null).
 int stc_node_reduce_partials(const float* partial, int n_parts, int nW, int Ho, float* dW, float* db, hipStream_t stream);

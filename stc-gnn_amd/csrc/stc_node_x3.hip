@@ -392,20 +392,36 @@ struct BwdSched { static constexpr int waves = (NB2 == 1 && K <= 2) ? 2 : 1; };
 // ACC (planar, PL = 1): the X-side gradient planes dZ.p[n] already hold another convolution's gradients for the same planes (the
 // candidate's) and this kernel ADDS its own: the tile's accumulators start from the stored values -- the source then gets one plane per
 // Chebyshev order from the cell instead of two.
-template <int NB2, int HB, int K, int L, int PRO, int PL = 0, int FOLD = 0, int ACC = 0>      // FOLD: see load_gates_grad (planar gates backward only)
+// F = FmtH2 (two fp16 pieces, three products; see cell_bwd_x3_kernel): the gradient fragments are taken into a space scaled by sg = 2^k
+// (from pro.gmax, the launch's gradient maximum) right after they are loaded / formed, W's blocks of c = 0 carry sW sT, those of c >= 1
+// carry sW and the T_c tables sT, so every (c, o) block of a dZ contraction arrives with the factor sg sT sW, taken out at the store.
+template <int NB2, int HB, int K, int L, int PRO, int PL = 0, int FOLD = 0, int ACC = 0, class F = FmtB3>      // FOLD: see load_gates_grad (planar gates backward only)
 __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bwd_x3_kernel(
     ZPtrs Z, const float* __restrict__ Tc, const float* __restrict__ W, const float* __restrict__ dY,
     DZPtrs dZ, float* __restrict__ partial, int nodes, int want_db, int Lw, BwdPro pro) {
+    using Op = typename F::Op;
+    constexpr int NP = F::NP;
     constexpr int NRB = 2 * NB2, C = 32 * NB2, Ho = 16 * HB, LB = (L + 15) / 16;
     constexpr int NBK = K * HB, S = (NBK + 1) / 2;             // (c, o) blocks of 16 and 32-wide steps over them
     constexpr int nTB = (K - 1) * NRB * NB2, nWA = K * LB * S;
     constexpr bool PF = PRO == PRO_NONE && BwdSched<NB2, K>::waves == 1;      // prefetch the next node's operands
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32x4* TB = reinterpret_cast<u32x4*>(smem_raw);     // [K-1][NRB rb][NB2 p]   T_c[16rb + x][32p + pair_row]
-    u32x4* WA = TB + nTB * 3 * 64;                       // [K n][LB][S]           W[(n, c, 16lb + x)][16hb + 4g + (e&3)], block 2s + (e>>2)
+    u32x4* WA = TB + nTB * NP * 64;                      // [K n][LB][S]           W[(n, c, 16lb + x)][16hb + 4g + (e&3)], block 2s + (e>>2)
     static_assert(!FOLD || ((PRO == PRO_GATES || PRO == PRO_GATES_CAND) && PL != 0), "FOLD belongs to the planar gates backward");
     const int tid = threadIdx.x, lane = tid & 63, x = lane & 15, g = lane >> 4;
-    float4* stash = reinterpret_cast<float4*>(WA + nWA * 3 * 64) + (tid >> 6) * NRB * 64;     // FOLD: [wave][NRB][64 lanes], lane-private
+    float4* stash = reinterpret_cast<float4*>(WA + nWA * NP * 64) + (tid >> 6) * NRB * 64;    // FOLD: [wave][NRB][64 lanes], lane-private
+
+    float sT = 1.f, sW = 1.f, sg = 1.f;                  // FmtH2: table scales from the tables' own maxima, gradient scale from pro.gmax
+    if constexpr (F::SCALED) {
+        float* scratch = reinterpret_cast<float*>(smem_raw);
+        if (K > 1) {
+            sT = pow2_scale(block_absmax(Tc + (size_t)C * C, (K - 1) * C * C, scratch, MF_THREADS), 0);
+            sT = fminf(fmaxf(sT, 0.0625f), 4096.f);
+        }
+        sW = pow2_scale(block_absmax(W, K * K * Lw * Ho, scratch, MF_THREADS), 0);
+        sg = pow2_scale(slots_max(pro.gmax, pro.n_gmax), 4);
+    }
 
     for (int idx = tid; idx < nTB * 64; idx += MF_THREADS) {
         const int ll = idx & 63, f = idx >> 6, p = f % NB2, rb = (f / NB2) % NRB, c1 = f / (NB2 * NRB), gg = ll >> 4;
@@ -413,7 +429,7 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
 #pragma unroll
         for (int e = 0; e < 8; ++e)
             v[e] = Tc[(size_t)(c1 + 1) * C * C + (16 * rb + (ll & 15)) * C + 32 * p + pair_row(gg, e)];
-        put_frag(TB, f, ll, v);
+        F::put(TB, f, ll, v, sT);
     }
     for (int idx = tid; idx < nWA * 64; idx += MF_THREADS) {
         const int ll = idx & 63, f = idx >> 6, s = f % S, lb = (f / S) % LB, n = f / (S * LB), gg = ll >> 4;
@@ -423,14 +439,15 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
         for (int e = 0; e < 8; ++e) {
             const int b = 2 * s + (e >> 2), c = b / HB, hb = b % HB;
             const int wl = PL == 2 ? stc_wrow_swapped(l, Lw - 16) : l;
-            v[e] = (b < NBK && wl >= 0 && wl < Lw) ? W[((size_t)(n * K + c) * Lw + wl) * Ho + 16 * hb + 4 * gg + (e & 3)] : 0.f;
+            v[e] = (b < NBK && wl >= 0 && wl < Lw) ? W[((size_t)(n * K + c) * Lw + wl) * Ho + 16 * hb + 4 * gg + (e & 3)] * (F::SCALED && c == 0 ? sT : 1.f) : 0.f;
         }
-        put_frag(WA, f, ll, v);
+        F::put(WA, f, ll, v, sW);
     }
     __syncthreads();
 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nw = gridDim.x * MF_WAVES;
+    const float kz = sT * sW, ikz_sg = 1.f / (kz * sg);       // (1 for FmtB3)
 
     f32x4 dWt[K][LB][K][HB];          // dW tiles: rows l = 16lb + 4g + r, columns o = 16hb + x
     float dbp[HB];
@@ -464,6 +481,12 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
         if (PF && next_node < nodes) { nx.g.load(dY, next_node, x, g); nx.load_z(Z, next_node, x, g, Lw - 16); }
         if (PF) __builtin_amdgcn_sched_barrier(0);
         const int lo = opaque(lane);
+        if constexpr (F::SCALED) {                             // into the scaled space: everything below is linear in the gradient
+#pragma unroll
+            for (int kb = 0; kb < NRB; ++kb)
+#pragma unroll
+                for (int hb = 0; hb < HB; ++hb) { in.g.d[kb][hb] *= sg; in.g.v[kb][hb] *= sg; }
+        }
         const DyFrag<NRB, HB>& gr = in.g;
 
 #pragma unroll
@@ -473,11 +496,11 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
                 dbp[hb] += (gr.d[kb][hb][0] + gr.d[kb][hb][1]) + (gr.d[kb][hb][2] + gr.d[kb][hb][3]);
 
         // dY in accumulator layout as an operand: slots = rows d of the tile pair p
-        X3 gd[HB][NB2];
+        Op gd[HB][NB2];
 #pragma unroll
         for (int hb = 0; hb < HB; ++hb)
 #pragma unroll
-            for (int p = 0; p < NB2; ++p) gd[hb][p] = split8(gr.d[2 * p][hb], gr.d[2 * p + 1][hb]);
+            for (int p = 0; p < NB2; ++p) gd[hb][p] = F::split(gr.d[2 * p][hb], gr.d[2 * p + 1][hb]);
 
         // ---- Qv_c tiles (rows o, columns c')
         f32x4 Qv[AtLeast1<K - 1>::v][NRB][HB];
@@ -489,14 +512,14 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
                 for (int hb = 0; hb < HB; ++hb) Qv[c1][rb][hb] = kZero4;
 #pragma unroll
                 for (int p = 0; p < NB2; ++p) {
-                    const X3 t = get_frag(TB, (c1 * NRB + rb) * NB2 + p, lo);
+                    const Op t = F::get(TB, (c1 * NRB + rb) * NB2 + p, lo);
 #pragma unroll
-                    for (int hb = 0; hb < HB; ++hb) Qv[c1][rb][hb] = mma6(gd[hb][p], t, Qv[c1][rb][hb]);
+                    for (int hb = 0; hb < HB; ++hb) Qv[c1][rb][hb] = F::mm(gd[hb][p], t, Qv[c1][rb][hb]);
                 }
             }
 
         // ---- B operands of dZ: step s covers the (c, o) blocks 2s, 2s+1; block (c, hb) of Q_c^T for columns c' = 16rb + x
-        X3 qb[S][NRB];
+        Op qb[S][NRB];
 #pragma unroll
         for (int s = 0; s < S; ++s)
 #pragma unroll
@@ -507,7 +530,7 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
                     const int b = 2 * s + h2, c = b / HB, hb = b % HB;
                     blk[h2] = b >= NBK ? kZero4 : (c == 0 ? gr.v[rb][hb] : Qv[c > 0 ? c - 1 : 0][rb][hb]);
                 }
-                qb[s][rb] = split8(blk[0], blk[1]);
+                qb[s][rb] = F::split(blk[0], blk[1]);
             }
 
         // ---- dZ_n^T tile (rows l, columns c')
@@ -522,7 +545,8 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
                     if (FOLD && n == 0 && lb == HLB) {          // the tile starts from the state's share parked by the prologue
                         const float4 sh = stash[rb * 64 + lane];
                         z[rb] = f32x4{sh.x, sh.y, sh.z, sh.w};
-                    } else if (ACC && PL == 1 && lb == 0) {     // ... or from what the plane already holds
+                        if constexpr (F::SCALED) z[rb] *= sg * kz;      // (parked unscaled)
+                    } else if (ACC && PL == 1 && lb == 0 && !F::SCALED) {     // ... or from what the plane already holds
                         z[rb] = *reinterpret_cast<const f32x4*>(dZ.p[n] + (r0 + 16 * rb + x) * 16 + 4 * g);
                     } else {
                         z[rb] = kZero4;
@@ -530,9 +554,16 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
                 }
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
-                    const X3 w = get_frag(WA, (n * LB + lb) * S + s, lo);
+                    const Op w = F::get(WA, (n * LB + lb) * S + s, lo);
 #pragma unroll
-                    for (int rb = 0; rb < NRB; ++rb) z[rb] = mma6(w, qb[s][rb], z[rb]);
+                    for (int rb = 0; rb < NRB; ++rb) z[rb] = F::mm(w, qb[s][rb], z[rb]);
+                }
+                if constexpr (F::SCALED) {                      // out of the scaled space (+ what the plane already holds)
+#pragma unroll
+                    for (int rb = 0; rb < NRB; ++rb) {
+                        if (ACC && PL == 1 && lb == 0) z[rb] = z[rb] * ikz_sg + *reinterpret_cast<const f32x4*>(dZ.p[n] + (r0 + 16 * rb + x) * 16 + 4 * g);
+                        else z[rb] *= ikz_sg;
+                    }
                 }
                 if constexpr (PL == 1) {                        // planar gradient slabs: block lb of the row goes to plane lb
 #pragma unroll
@@ -552,7 +583,7 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
             }
 
         // ---- Qd_c tiles (rows c', columns o), then as operands: slots = rows c' of the tile pair p
-        X3 qd[AtLeast1<K - 1>::v][HB][NB2];
+        Op qd[AtLeast1<K - 1>::v][HB][NB2];
 #pragma unroll
         for (int c1 = 0; c1 < K - 1; ++c1) {
             f32x4 Qd[NRB][HB];
@@ -562,15 +593,15 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
                 for (int hb = 0; hb < HB; ++hb) Qd[rb][hb] = kZero4;
 #pragma unroll
                 for (int p = 0; p < NB2; ++p) {
-                    const X3 t = get_frag(TB, (c1 * NRB + rb) * NB2 + p, lo);
+                    const Op t = F::get(TB, (c1 * NRB + rb) * NB2 + p, lo);
 #pragma unroll
-                    for (int hb = 0; hb < HB; ++hb) Qd[rb][hb] = mma6(t, gd[hb][p], Qd[rb][hb]);
+                    for (int hb = 0; hb < HB; ++hb) Qd[rb][hb] = F::mm(t, gd[hb][p], Qd[rb][hb]);
                 }
             }
 #pragma unroll
             for (int hb = 0; hb < HB; ++hb)
 #pragma unroll
-                for (int p = 0; p < NB2; ++p) qd[c1][hb][p] = split8(Qd[2 * p][hb], Qd[2 * p + 1][hb]);
+                for (int p = 0; p < NB2; ++p) qd[c1][hb][p] = F::split(Qd[2 * p][hb], Qd[2 * p + 1][hb]);
         }
 
         // ---- dW_{n,c} tile (rows l, columns o) += Z_n^T . Q_c
@@ -581,18 +612,19 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
 #pragma unroll
                 for (int p = 0; p < NB2; ++p) {
                     const float (&zc)[NRB][4] = in.za[n][lb];
-                    const X3 a = split8(f32x4{zc[2 * p][0], zc[2 * p][1], zc[2 * p][2], zc[2 * p][3]},
-                                        f32x4{zc[2 * p + 1][0], zc[2 * p + 1][1], zc[2 * p + 1][2], zc[2 * p + 1][3]});
+                    const Op a = F::split(f32x4{zc[2 * p][0], zc[2 * p][1], zc[2 * p][2], zc[2 * p][3]},
+                                          f32x4{zc[2 * p + 1][0], zc[2 * p + 1][1], zc[2 * p + 1][2], zc[2 * p + 1][3]});
 #pragma unroll
                     for (int c = 0; c < K; ++c)
 #pragma unroll
                         for (int hb = 0; hb < HB; ++hb)
-                            dWt[n][lb][c][hb] = mma6(a, c == 0 ? gd[hb][p] : qd[c > 0 ? c - 1 : 0][hb][p], dWt[n][lb][c][hb]);
+                            dWt[n][lb][c][hb] = F::mm(a, c == 0 ? gd[hb][p] : qd[c > 0 ? c - 1 : 0][hb][p], dWt[n][lb][c][hb]);
                 }
         if (PF) in = nx;
         node = next_node;
     }
-    combine_dw<K, LB, HB>(reinterpret_cast<float*>(smem_raw), dWt, dbp, partial, Lw, want_db, PL == 2 ? Lw - 16 : -1);
+    const float isg = 1.f / sg;                                // dW tiles of block c carry sg (c = 0) or sg sT (c >= 1); db carries sg
+    combine_dw<K, LB, HB>(reinterpret_cast<float*>(smem_raw), dWt, dbp, partial, Lw, want_db, PL == 2 ? Lw - 16 : -1, isg, isg / sT, isg);
 }
 
 // --------------------------------------------------------------------------------------- post-aggregation form (K = 2)
@@ -921,15 +953,15 @@ int launch_fwd(const float* const* Z, const float* Tc, const float* W, const flo
     return STC_OK;
 }
 
-template <int NB2, int HB, int K, int L, int PRO = PRO_NONE, int PL = 0, int FOLD = 0, int ACC = 0>
+template <int NB2, int HB, int K, int L, int PRO = PRO_NONE, int PL = 0, int FOLD = 0, int ACC = 0, class F = FmtB3>
 int launch_bwd(const float* const* Z, const float* Tc, const float* W, const float* dY, float* const* dZ,
                float* partial, int* n_partials, int want_db, long long nodes, int Lw, hipStream_t stream, BwdPro pro = BwdPro{}) {
     constexpr int NRB = 2 * NB2, Ho = 16 * HB, LB = (L + 15) / 16, NBK = K * HB, S = (NBK + 1) / 2, nW = K * K * L * Ho;
-    const size_t frag = (size_t)((K - 1) * NRB * NB2 + K * LB * S) * 3 * 64 * 16 + (FOLD ? (size_t)MF_WAVES * NRB * 64 * 16 : 0);
+    const size_t frag = (size_t)((K - 1) * NRB * NB2 + K * LB * S) * F::NP * 64 * 16 + (FOLD ? (size_t)MF_WAVES * NRB * 64 * 16 : 0);
     const size_t slabs = (size_t)MF_WAVES * (nW + Ho) * sizeof(float);
     const size_t lds = frag > slabs ? frag : slabs;
     if (lds > stc::kMaxLdsBytes) return STC_NOT_HANDLED;
-    auto kern = node_bwd_x3_kernel<NB2, HB, K, L, PRO, PL, FOLD, ACC>;
+    auto kern = node_bwd_x3_kernel<NB2, HB, K, L, PRO, PL, FOLD, ACC, F>;
     if (int rc = stc::hip_status(stc::allow_lds(kern, lds), "hipFuncSetAttribute(node bwd x3)")) return rc;
     static const int resident = stc::resident_blocks(kern, MF_THREADS, lds, BwdSched<NB2, K>::waves);
     ZPtrs zp{};
@@ -1196,40 +1228,51 @@ int stc_cell_gates_fwd_planar_x3(const float* X, const float* H, const float* SX
                                 : gates_fwd_planar_go<FmtB3>(X, H, SX, SH, Tc, W, bias, epi, post, fused, cin, nodes, C, Lw, stream);
 }
 
+template <class F>
+static int gates_bwd_planar_go(const float* const* Z, float* const* dZ, const float* Tc, const float* W, bool narrow, bool fold, const BwdPro& pro,
+                               float* partial, int* n_partials, int want_db, long long nodes, int C, int Lw, hipStream_t stream) {
+    if (narrow) {
+        // (C = 32, narrow: the fp16 x 2 build of this instantiation spills 80-96 B per lane at its 256-register cap for two waves per SIMD, and
+        // it is not a launch the default path takes -- C = 32 runs the one-launch cell backward -- so it stays on the bf16 x 3 format)
+        if (C == 32 && fold) return launch_bwd<1, 2, 2, 20, PRO_GATES_CAND, 2, 1, 0, FmtB3>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro);
+        if (C == 64 && fold) return launch_bwd<2, 2, 2, 20, PRO_GATES_CAND, 2, 1, 0, F>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro);
+        if (C == 32) return launch_bwd<1, 2, 2, 20, PRO_GATES_CAND, 2, 0, 0, FmtB3>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro);
+        if (C == 64) return launch_bwd<2, 2, 2, 20, PRO_GATES_CAND, 2, 0, 0, F>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro);
+        return STC_NOT_HANDLED;
+    }
+    // fold: the state's share from the gate prologue is folded into the H plane's gradient dZ[2] (FOLD)
+    if (C == 32 && fold) return launch_bwd<1, 2, 2, 32, PRO_GATES_CAND, 1, 1, 0, F>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro);
+    if (C == 64 && fold) return launch_bwd<2, 2, 2, 32, PRO_GATES_CAND, 1, 1, 0, F>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro);
+    if (C == 32) return launch_bwd<1, 2, 2, 32, PRO_GATES_CAND, 1, 0, 0, F>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro);
+    if (C == 64) return launch_bwd<2, 2, 2, 32, PRO_GATES_CAND, 1, 0, 0, F>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro);
+    return STC_NOT_HANDLED;
+}
+
+// gmax != null: fp16 x 2 operand format (device floats whose maximum bounds |dHnew| and |dCandIn| of the launch); null: bf16 x 3
 int stc_cell_gates_bwd_planar_x3(const float* X, const float* H, const float* SX, const float* SH, const float* Tc, const float* W,
                                  const float* dCandIn, const float* Cand, const float* U, const float* R, const float* dHnew,
-                                 float* const* dZ, float* dH, float* partial, int* n_partials, int want_db,
+                                 float* const* dZ, float* dH, float* partial, int* n_partials, int want_db, const float* gmax, int n_gmax,
                                  long long nodes, int C, int Lw, hipStream_t stream) {
     const int cin = Lw - 16;
     if (!x3_cell_shape(2, C, cin == 16 ? 32 : 20, nodes) || !(cin == 16 || (cin >= 1 && cin <= 4))) return STC_NOT_HANDLED;
-    if (cin != 16) {                               // narrow input plane: only d H plane (dZ[2]) and d SH plane (dZ[3]) are produced
-        if (!(stc::aligned16(H) && stc::aligned16(SH) && dZ[2] && dZ[3] && stc::aligned16(dZ[2]) && stc::aligned16(dZ[3]))) return STC_NOT_HANDLED;
-        if (!(stc::aligned16(dCandIn) && stc::aligned16(Cand) && stc::aligned16(U) && stc::aligned16(R) && stc::aligned16(dHnew) && (!dH || stc::aligned16(dH))))
-            return STC_NOT_HANDLED;
-        const float* Zn[4] = {H, SH, X, SX};
-        float* dZn[4] = {dZ[2], dZ[3], nullptr, nullptr};
-        BwdPro pn{};
-        pn.Cand = Cand; pn.dCandIn = dCandIn; pn.H = H; pn.U = U; pn.R = R; pn.dH_in = dHnew; pn.dH = dH; pn.cin = 0; pn.dh_scaled = 1;
-        if (C == 32 && !dH) return launch_bwd<1, 2, 2, 20, PRO_GATES_CAND, 2, 1>(Zn, Tc, W, nullptr, dZn, partial, n_partials, want_db, nodes, Lw, stream, pn);
-        if (C == 64 && !dH) return launch_bwd<2, 2, 2, 20, PRO_GATES_CAND, 2, 1>(Zn, Tc, W, nullptr, dZn, partial, n_partials, want_db, nodes, Lw, stream, pn);
-        if (C == 32) return launch_bwd<1, 2, 2, 20, PRO_GATES_CAND, 2>(Zn, Tc, W, nullptr, dZn, partial, n_partials, want_db, nodes, Lw, stream, pn);
-        if (C == 64) return launch_bwd<2, 2, 2, 20, PRO_GATES_CAND, 2>(Zn, Tc, W, nullptr, dZn, partial, n_partials, want_db, nodes, Lw, stream, pn);
-        return STC_NOT_HANDLED;
-    }
-    const float* Z[4] = {X, SX, H, SH};
-    if (!all_aligned16(Z, 4)) return STC_NOT_HANDLED;
-    for (int i = 0; i < 4; ++i)
-        if (!dZ[i] || !stc::aligned16(dZ[i])) return STC_NOT_HANDLED;
     if (!(stc::aligned16(dCandIn) && stc::aligned16(Cand) && stc::aligned16(U) && stc::aligned16(R) && stc::aligned16(dHnew) && (!dH || stc::aligned16(dH))))
         return STC_NOT_HANDLED;
     BwdPro pro{};       // dCandIn: the gradient of the R*H plane, (nodes, C, 16): the state columns sit at offset 0
     pro.Cand = Cand; pro.dCandIn = dCandIn; pro.H = H; pro.U = U; pro.R = R; pro.dH_in = dHnew; pro.dH = dH; pro.cin = 0; pro.dh_scaled = 1;
-    // dH == null: the state's share from the gate prologue is folded into the H plane's gradient dZ[2] (FOLD)
-    if (C == 32 && !dH) return launch_bwd<1, 2, 2, 32, PRO_GATES_CAND, 1, 1>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro);
-    if (C == 64 && !dH) return launch_bwd<2, 2, 2, 32, PRO_GATES_CAND, 1, 1>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro);
-    if (C == 32) return launch_bwd<1, 2, 2, 32, PRO_GATES_CAND, 1>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro);
-    if (C == 64) return launch_bwd<2, 2, 2, 32, PRO_GATES_CAND, 1>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro);
-    return STC_NOT_HANDLED;
+    pro.gmax = gmax; pro.n_gmax = n_gmax;
+    const float* Zw[4] = {X, SX, H, SH};
+    const float* Zn[4] = {H, SH, X, SX};           // narrow input plane: the state plane leads; only d H plane (dZ[2]) and d SH plane (dZ[3]) are produced
+    float* dZn[4] = {dZ[2], dZ[3], nullptr, nullptr};
+    const bool narrow = cin != 16;
+    if (narrow) {
+        if (!(stc::aligned16(H) && stc::aligned16(SH) && dZ[2] && dZ[3] && stc::aligned16(dZ[2]) && stc::aligned16(dZ[3]))) return STC_NOT_HANDLED;
+    } else {
+        if (!all_aligned16(Zw, 4)) return STC_NOT_HANDLED;
+        for (int i = 0; i < 4; ++i)
+            if (!dZ[i] || !stc::aligned16(dZ[i])) return STC_NOT_HANDLED;
+    }
+    return gmax ? gates_bwd_planar_go<FmtH2>(narrow ? Zn : Zw, narrow ? dZn : dZ, Tc, W, narrow, dH == nullptr, pro, partial, n_partials, want_db, nodes, C, Lw, stream)
+                : gates_bwd_planar_go<FmtB3>(narrow ? Zn : Zw, narrow ? dZn : dZ, Tc, W, narrow, dH == nullptr, pro, partial, n_partials, want_db, nodes, C, Lw, stream);
 }
 
 // ---- planar cell convolutions of Chebyshev order K = 3 (C = 32, hidden 16).  Zx[n] / Zh[n] = T_n(S) applied to the plane on the
@@ -1240,7 +1283,7 @@ int stc_cell_gates_bwd_planar_x3(const float* X, const float* H, const float* SX
 int stc_cell_planar_k_shape_ok(int K, int C, int h) { return K == 3 && C == 32 && h == 16; }
 
 int stc_cell_conv_fwd_planar_k_x3(const float* const* Zx, const float* const* Zh, int K, const float* Tc, const float* W, const float* bias, int mode,
-                                  const float* H, const float* Uin, float* U, float* R, float* RH, float* Cand, float* Hnew,
+                                  const float* H, const float* Uin, float* U, float* R, float* RH, float* Cand, float* Hnew, int fmt,
                                   long long nodes, int C, int Lw, hipStream_t stream) {
     const int cin = Lw - 16;
     if (!stc_cell_planar_k_shape_ok(K, C, 16) || !x3_cell_shape(K, C, cin == 16 ? 32 : 20, nodes) || !(cin == 16 || (cin >= 1 && cin <= 4))) return STC_NOT_HANDLED;
@@ -1250,16 +1293,39 @@ int stc_cell_conv_fwd_planar_k_x3(const float* const* Zx, const float* const* Zh
     else { epi.H = H; epi.U = Uin; epi.Cand = Cand; epi.Hnew = Hnew; }
     const float* Z[6];
     for (int n = 0; n < 3; ++n) { Z[n] = cin == 16 ? Zx[n] : Zh[n]; Z[3 + n] = cin == 16 ? Zh[n] : Zx[n]; }
+    if (fmt == STC_FMT_F16X2) {
+        if (mode == 1) return cin == 16 ? launch_fwd<1, 2, 3, 32, EPI_GATES, 1, 0, FmtH2>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi)
+                                        : launch_fwd<1, 2, 3, 20, EPI_GATES, 2, 0, FmtH2>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi);
+        return cin == 16 ? launch_fwd<1, 1, 3, 32, EPI_BLEND, 1, 0, FmtH2>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi)
+                         : launch_fwd<1, 1, 3, 20, EPI_BLEND, 2, 0, FmtH2>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi);
+    }
     if (mode == 1) return cin == 16 ? launch_fwd<1, 2, 3, 32, EPI_GATES, 1>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi)
                                     : launch_fwd<1, 2, 3, 20, EPI_GATES, 2>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi);
     return cin == 16 ? launch_fwd<1, 1, 3, 32, EPI_BLEND, 1>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi)
                      : launch_fwd<1, 1, 3, 20, EPI_BLEND, 2>(Z, Tc, W, bias, nullptr, nodes, Lw, stream, epi);
 }
 
+template <class F>
+static int conv_bwd_planar_k_go(const float* const* Z, float* const* dZ, const float* Tc, const float* W, int mode, int cin, bool fold, int accumulate_x,
+                                const BwdPro& pro, float* partial, int* n_partials, int want_db, long long nodes, int Lw, hipStream_t stream) {
+    if (mode == 1) {
+        if (accumulate_x) return launch_bwd<1, 2, 3, 32, PRO_GATES_CAND, 1, 1, 1, F>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro);
+        if (fold)       // the state's share from the gate prologue is folded into dZh[0]
+            return cin == 16 ? launch_bwd<1, 2, 3, 32, PRO_GATES_CAND, 1, 1, 0, F>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro)
+                             : launch_bwd<1, 2, 3, 20, PRO_GATES_CAND, 2, 1, 0, F>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro);
+        return cin == 16 ? launch_bwd<1, 2, 3, 32, PRO_GATES_CAND, 1, 0, 0, F>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro)
+                         : launch_bwd<1, 2, 3, 20, PRO_GATES_CAND, 2, 0, 0, F>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro);
+    }
+    return cin == 16 ? launch_bwd<1, 1, 3, 32, PRO_BLEND, 1, 0, 0, F>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro)
+                     : launch_bwd<1, 1, 3, 20, PRO_BLEND, 2, 0, 0, F>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro);
+}
+
+// gmax != null: fp16 x 2 operand format (n_gmax device floats whose maximum bounds every gradient operand of the launch: dHnew, and for the
+// gates convolution dRH as well); null: bf16 x 3
 int stc_cell_conv_bwd_planar_k_x3(const float* const* Zx, const float* const* Zh, int K, const float* Tc, const float* W, int mode,
                                   const float* dRH, const float* Cand, const float* U, const float* R, const float* dHnew,
                                   float* const* dZx, float* const* dZh, float* dH, float* partial, int* n_partials, int want_db,
-                                  long long nodes, int C, int Lw, int accumulate_x, hipStream_t stream) {
+                                  long long nodes, int C, int Lw, int accumulate_x, const float* gmax, int n_gmax, hipStream_t stream) {
     const int cin = Lw - 16;
     if (!stc_cell_planar_k_shape_ok(K, C, 16) || !x3_cell_shape(K, C, cin == 16 ? 32 : 20, nodes) || !(cin == 16 || (cin >= 1 && cin <= 4))) return STC_NOT_HANDLED;
     if (!all_aligned16(Zh, K) || (cin == 16 && !all_aligned16(Zx, K))) return STC_NOT_HANDLED;
@@ -1272,20 +1338,14 @@ int stc_cell_conv_bwd_planar_k_x3(const float* const* Zx, const float* const* Zh
     }
     if (!(stc::aligned16(Cand) && stc::aligned16(U) && stc::aligned16(dHnew))) return STC_NOT_HANDLED;
     BwdPro pro{};
+    pro.gmax = gmax; pro.n_gmax = n_gmax;
     if (mode == 1) {
         if (!(stc::aligned16(dRH) && stc::aligned16(R) && (!dH || stc::aligned16(dH)))) return STC_NOT_HANDLED;
         pro.Cand = Cand; pro.dCandIn = dRH; pro.H = Zh[0]; pro.U = U; pro.R = R; pro.dH_in = dHnew; pro.dH = dH; pro.cin = 0; pro.dh_scaled = 1;
-        if (accumulate_x) {                                     // wide, folded form only: what the cell graph runs
-            if (dH || cin != 16) return STC_NOT_HANDLED;
-            return launch_bwd<1, 2, 3, 32, PRO_GATES_CAND, 1, 1, 1>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro);
-        }
-        if (!dH)        // the state's share from the gate prologue is folded into dZh[0]
-            return cin == 16 ? launch_bwd<1, 2, 3, 32, PRO_GATES_CAND, 1, 1>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro)
-                             : launch_bwd<1, 2, 3, 20, PRO_GATES_CAND, 2, 1>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro);
-        return cin == 16 ? launch_bwd<1, 2, 3, 32, PRO_GATES_CAND, 1>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro)
-                         : launch_bwd<1, 2, 3, 20, PRO_GATES_CAND, 2>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro);
+        if (accumulate_x && (dH || cin != 16)) return STC_NOT_HANDLED;      // wide, folded form only: what the cell graph runs
+    } else {
+        pro.dH_in = dHnew; pro.U = U; pro.Cand = Cand;
     }
-    pro.dH_in = dHnew; pro.U = U; pro.Cand = Cand;
-    return cin == 16 ? launch_bwd<1, 1, 3, 32, PRO_BLEND, 1>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro)
-                     : launch_bwd<1, 1, 3, 20, PRO_BLEND, 2>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro);
+    return gmax ? conv_bwd_planar_k_go<FmtH2>(Z, dZ, Tc, W, mode, cin, dH == nullptr, accumulate_x, pro, partial, n_partials, want_db, nodes, Lw, stream)
+                : conv_bwd_planar_k_go<FmtB3>(Z, dZ, Tc, W, mode, cin, dH == nullptr, accumulate_x, pro, partial, n_partials, want_db, nodes, Lw, stream);
 }

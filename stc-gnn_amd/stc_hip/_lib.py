@@ -19,7 +19,7 @@ import torch
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG_ROOT, 'libstc_hip.so')
-ABI_VERSION = 14
+ABI_VERSION = 15
 FMT_BF16X3, FMT_F16X2 = 0, 1          # STC_FMT_* of include/stc_hip.h: operand formats of the split-operand matrix-core kernels
 MAX_K = 4
 SPMM_SUM_MAX_ADD = 8     # = STC_SPMM_SUM_MAX_ADD of include/stc_hip.h
@@ -84,18 +84,18 @@ def _declare(lib):
         'stc_head_bwd_bf16': [_p, _p, _p, _p, _p, _p, _p, C.c_size_t, _i64, _i32, _p],
         'stc_bdg_node_post_fwd_f32': [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
         'stc_cell_gates_fwd_planar_f32': [_p] * 14 + [_i32, _i64, _i32, _i32, _i32, _p],
-        'stc_cell_gates_bwd_planar_f32': [_p] * 11 + [C.POINTER(_p), _p, _p, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _p],
+        'stc_cell_gates_bwd_planar_f32': [_p] * 11 + [C.POINTER(_p), _p, _p, _p, _p, _i32, _p, C.c_size_t, _i64, _i32, _i32, _i32, _p],
         'stc_cell_bwd_planar_f32': [_p] * 20 + [_i32, _i32, _p, _i32, _p, C.c_size_t, _i64, _i32, _i32, _i32, _p],
         'stc_spmm_blend_fwd_f32': [_p] * 6 + [_i32, _i32] + [_p] * 6 + [_p, _i32, _i32, _p, _i32, _p, _i32, _i32] + [_i32] * 3 + [_p],
         'stc_bdg_node_post_bwd_f32': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _i32, _p],
         'stc_spmm_sum_f32': [_p] * 6 + [_i32, _i32, _p, _p, _f32, _i32, C.POINTER(_p), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_f32), _p, _p, _p, _p,
                              _p, _i32, _i32, _i32, _i32, _p],
-        'stc_cell_gates_fwd_planar_k_f32': [C.POINTER(_p), C.POINTER(_p), _i32, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p],
-        'stc_cell_cand_fwd_planar_k_f32': [C.POINTER(_p), C.POINTER(_p), _i32, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p],
+        'stc_cell_gates_fwd_planar_k_f32': [C.POINTER(_p), C.POINTER(_p), _i32, _p, _p, _p, _p, _p, _p, _i32, _i64, _i32, _i32, _i32, _p],
+        'stc_cell_cand_fwd_planar_k_f32': [C.POINTER(_p), C.POINTER(_p), _i32, _p, _p, _p, _p, _p, _p, _p, _i32, _i64, _i32, _i32, _i32, _p],
         'stc_cell_gates_bwd_planar_k_f32': [C.POINTER(_p), C.POINTER(_p), _i32, _p, _p, _p, _p, _p, _p, _p, C.POINTER(_p), C.POINTER(_p), _p, _p, _p, _i32,
-                                            _p, C.c_size_t, _i64, _i32, _i32, _i32, _p],
+                                            _p, _i32, _p, C.c_size_t, _i64, _i32, _i32, _i32, _p],
         'stc_cell_cand_bwd_planar_k_f32': [C.POINTER(_p), C.POINTER(_p), _i32, _p, _p, _p, _p, _p, C.POINTER(_p), C.POINTER(_p), _p, _p,
-                                           _p, C.c_size_t, _i64, _i32, _i32, _i32, _p],
+                                           _p, _i32, _p, C.c_size_t, _i64, _i32, _i32, _i32, _p],
         'stc_cell_gates_fwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _i32, _p],
         'stc_cell_cand_bwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _p, C.POINTER(_p), _p, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _i32, _p],
         'stc_cell_gates_bwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _i32, C.POINTER(_p), _p, _p, _p, _p,
@@ -209,6 +209,17 @@ class HipKernels:
         self._workspace = {}
         self._retired = []                            # outgrown workspaces, kept alive (see _get_workspace)
         self.timer: Optional[KernelTimer] = None      # set by bench.py to time every launch with HIP events
+
+    def _grad_amax(self, what, given, *planes):
+        """(pointer, count) of the gradient-maximum slots of an fp16 x 2 backward launch: the caller's slots (what ``spmm_sum(amax=)`` left),
+        or -- without them -- the maximum taken here by one more pass over the gradient planes; (None, 0) on the bf16 x 3 format."""
+        if self.operand_format != FMT_F16X2:
+            return None, 0
+        if given is None:
+            given = torch.stack([torch.linalg.vector_norm(p, ord=float('inf')) for p in planes])
+        self._f32(what + '.grad_amax', given)
+        self._same_device(planes[0], given)
+        return given.data_ptr(), given.numel()      # (a temporary made here may be freed after the launch is queued: the allocator is stream-ordered)
 
     def set_dispatch_level(self, level: int):
         """0 = every kernel path (default), 1 = no split-operand matrix-core kernels (fp32 MFMA instead), 2 = generic kernels only:
@@ -670,7 +681,7 @@ class HipKernels:
                      # algorithmic bytes: X, SX (cin wide), H, SH in; U, Rg (+ RH, + A, Bm) out -- every plane once
                      nbytes=4 * R * Cc * (2 * cin + 2 * h + h * (2 + (RH is not None) + (2 if post is not None else 0))))
 
-    def cell_gates_bwd_planar(self, X, H, SX, SH, Tc, W, dRH, Cand, U, Rg, dHnew, dZs, dW, db, dH):
+    def cell_gates_bwd_planar(self, X, H, SX, SH, Tc, W, dRH, Cand, U, Rg, dHnew, dZs, dW, db, dH, grad_amax=None):
         """``dRH``: gradient of the R*H plane; ``dZs`` = [d X plane, d SX plane, d H plane, d SH plane] (the first two
         None for a narrow input plane, which needs no gradient)."""
         R, Cc, h, cin = self._planes('planar', X, H, SX, SH)
@@ -691,7 +702,8 @@ class HipKernels:
         ws = self._get_workspace(H.device, self.lib.stc_bdg_node_bwd_workspace_bytes(2, 2, Cc, 2 * h, 2 * h, 0))
         zp = (_p * 4)(*[0 if z is None else z.data_ptr() for z in dZs])
         self._launch('stc_cell_gates_bwd_planar_f32', H, _ptr(X), _ptr(H), _ptr(SX), _ptr(SH), _ptr(Tc), _ptr(W), _ptr(dRH), _ptr(Cand),
-                     _ptr(U), _ptr(Rg), _ptr(dHnew), zp, _ptr(dW), _ptr(db), _ptr(dH), _ptr(ws), ws.numel(), R, Cc, cin + h, h)
+                     _ptr(U), _ptr(Rg), _ptr(dHnew), zp, _ptr(dW), _ptr(db), _ptr(dH), *self._grad_amax('planar', grad_amax, dHnew, dRH),
+                     _ptr(ws), ws.numel(), R, Cc, cin + h, h)
 
     # ---- the whole backward of a planar cell step in one launch ----------------------------------------
     def cell_bwd_planar_supported(self, Cc, h) -> bool:
@@ -727,16 +739,10 @@ class HipKernels:
         ws = self._get_workspace(H.device, self.lib.stc_cell_bwd_planar_workspace_bytes(Cc, 2 * h, h))
         if accumulate_x and cin != h:
             raise StcError('cell backward: accumulate_x with a narrow input plane (it gets no gradient)')
-        if self.operand_format == FMT_F16X2:
-            if grad_amax is None:
-                grad_amax = torch.linalg.vector_norm(dHnew, ord=float('inf')).reshape(1)
-            self._f32('cell_bwd.grad_amax', grad_amax)
-            self._same_device(H, grad_amax)
-        else:
-            grad_amax = None
+        amax_ptr, amax_n = self._grad_amax('cell_bwd', grad_amax, dHnew)
         self._launch('stc_cell_bwd_planar_f32', H, _ptr(X), _ptr(H), _ptr(SX), _ptr(SH), _ptr(Tc), _ptr(Wg), _ptr(Wc), _ptr(U), _ptr(Rg), _ptr(Cand),
                      _ptr(dHnew), _ptr(dBm), *[_ptr(z) for z in dZs], _ptr(dWg), _ptr(dbg), _ptr(dWc), _ptr(dbc), int(bool(accumulate_x)), int(bool(accumulate_h)),
-                     _ptr(grad_amax), 0 if grad_amax is None else grad_amax.numel(), _ptr(ws), ws.numel(), R, Cc, cin + h, h,
+                     amax_ptr, amax_n, _ptr(ws), ws.numel(), R, Cc, cin + h, h,
                      # algorithmic bytes: X, SX (cin wide), H, SH, U, Rg, Cand, dHnew, dBm in; dH, dSH (+ dX, dSX) out; a plane that is
                      # accumulated into is also read -- every plane once
                      nbytes=4 * R * Cc * (2 * cin + 7 * h + 2 * h * (1 + bool(accumulate_h)) + (2 * h * (1 + bool(accumulate_x)) if cin == h else 0)),
@@ -770,7 +776,7 @@ class HipKernels:
             self._f32('planar_k.' + name, t, (R, Cc, h))
         self._same_device(*Zx, *Zh, Tc, W, bias, U, Rg, RH)
         self._launch('stc_cell_gates_fwd_planar_k_f32', U, self._ptr_array(Zx), self._ptr_array(Zh), K, _ptr(Tc), _ptr(W), _ptr(bias),
-                     _ptr(U), _ptr(Rg), _ptr(RH), R, Cc, cin + h, h)
+                     _ptr(U), _ptr(Rg), _ptr(RH), self.operand_format, R, Cc, cin + h, h)
 
     def cell_cand_fwd_planar_k(self, Zx, Zh, Tc, W, bias, U, H, Cand, Hnew):
         """Candidate convolution on [X | R*H] (Zh = the T_n(S) planes of R*H) + tanh + GRU blend: Cand, Hnew."""
@@ -781,7 +787,7 @@ class HipKernels:
             self._f32('planar_k.' + name, t, (R, Cc, h))
         self._same_device(*Zx, *Zh, Tc, W, bias, U, H, Cand, Hnew)
         self._launch('stc_cell_cand_fwd_planar_k_f32', U, self._ptr_array(Zx), self._ptr_array(Zh), K, _ptr(Tc), _ptr(W), _ptr(bias),
-                     _ptr(U), _ptr(H), _ptr(Cand), _ptr(Hnew), R, Cc, cin + h, h)
+                     _ptr(U), _ptr(H), _ptr(Cand), _ptr(Hnew), self.operand_format, R, Cc, cin + h, h)
 
     def _grad_planes_k(self, what, dZx, dZh, K, R, Cc, h, cin):
         if len(dZh) != K or len(dZx) != K:
@@ -793,7 +799,7 @@ class HipKernels:
             self._f32(f'{what}.dZx[{n}]', dZx[n], (R, Cc, cin))
         return (_p * K)(*[0 if z is None else z.data_ptr() for z in dZx]), (_p * K)(*[z.data_ptr() for z in dZh])
 
-    def cell_gates_bwd_planar_k(self, Zx, Zh, Tc, W, dRH, Cand, U, Rg, dHnew, dZx, dZh, dW, db, dH, accumulate_x=False):
+    def cell_gates_bwd_planar_k(self, Zx, Zh, Tc, W, dRH, Cand, U, Rg, dHnew, dZx, dZh, dW, db, dH, accumulate_x=False, grad_amax=None):
         """``accumulate_x``: the X-side planes ``dZx`` hold the candidate's gradients of the same planes; the gates' are added to them
         (wide input, ``dH=None`` only)."""
         K, R, Cc, h, cin = self._planes_k('planar_k gates bwd', Zx, Zh, Tc, W, 2 * Zh[0].shape[-1])
@@ -808,9 +814,10 @@ class HipKernels:
         self._same_device(*Zx, *Zh, Tc, W, dRH, Cand, U, Rg, dHnew, *dZx, *dZh, dW, db, dH)
         ws = self._get_workspace(U.device, self.lib.stc_bdg_node_bwd_workspace_bytes(K, K, Cc, 2 * h, 2 * h, 0))
         self._launch('stc_cell_gates_bwd_planar_k_f32', U, self._ptr_array(Zx), self._ptr_array(Zh), K, _ptr(Tc), _ptr(W), _ptr(dRH), _ptr(Cand),
-                     _ptr(U), _ptr(Rg), _ptr(dHnew), zx, zh, _ptr(dW), _ptr(db), _ptr(dH), int(bool(accumulate_x)), _ptr(ws), ws.numel(), R, Cc, cin + h, h)
+                     _ptr(U), _ptr(Rg), _ptr(dHnew), zx, zh, _ptr(dW), _ptr(db), _ptr(dH), int(bool(accumulate_x)),
+                     *self._grad_amax('planar_k', grad_amax, dHnew, dRH), _ptr(ws), ws.numel(), R, Cc, cin + h, h)
 
-    def cell_cand_bwd_planar_k(self, Zx, Zh, Tc, W, dHnew, U, Cand, dZx, dZh, dW, db):
+    def cell_cand_bwd_planar_k(self, Zx, Zh, Tc, W, dHnew, U, Cand, dZx, dZh, dW, db, grad_amax=None):
         K, R, Cc, h, cin = self._planes_k('planar_k cand bwd', Zx, Zh, Tc, W, Zh[0].shape[-1])
         for name, t in (('dHnew', dHnew), ('U', U), ('Cand', Cand)):
             self._f32('planar_k.' + name, t, (R, Cc, h))
@@ -821,7 +828,7 @@ class HipKernels:
         self._same_device(*Zx, *Zh, Tc, W, dHnew, U, Cand, *dZx, *dZh, dW, db)
         ws = self._get_workspace(U.device, self.lib.stc_bdg_node_bwd_workspace_bytes(K, K, Cc, 2 * h, 2 * h, 0))
         self._launch('stc_cell_cand_bwd_planar_k_f32', U, self._ptr_array(Zx), self._ptr_array(Zh), K, _ptr(Tc), _ptr(W), _ptr(dHnew), _ptr(U), _ptr(Cand),
-                     zx, zh, _ptr(dW), _ptr(db), _ptr(ws), ws.numel(), R, Cc, cin + h, h)
+                     zx, zh, _ptr(dW), _ptr(db), *self._grad_amax('planar_k', grad_amax, dHnew), _ptr(ws), ws.numel(), R, Cc, cin + h, h)
 
     # ---- fused cell convolutions ----------------------------------------------------------
     def cell_fused_supported(self, Ks, Kc, Cc, L, h) -> bool:

@@ -698,12 +698,14 @@ class _StcCellGraph(Function):
         # max |dHnew|, which the state-gradient SpMM that produces dHnew leaves in a row of slots (one zero fill per backward pass)
         n_slots = 256
         amax_rows = {}
+        f16x2 = not bf16_planes and getattr(k, 'operand_format', 0) == 1
 
-        def amax_slots(kid):
+        def amax_slots(kid, which=0):
+            """Row ``which`` of cell ``kid``'s slots: 0 = its state gradient dHnew, 1 = the gradient of its R*H plane (order 3)."""
             if 'all' not in amax_rows:
-                amax_rows['all'] = grad_stack.new_zeros(len(schedule), n_slots, dtype=torch.float32)
-            amax_rows[kid] = amax_rows['all'][kid]
-            return amax_rows[kid]
+                amax_rows['all'] = grad_stack.new_zeros(len(schedule), 2, n_slots, dtype=torch.float32)
+            amax_rows.setdefault(kid, amax_rows['all'][kid])
+            return amax_rows[kid][which]
 
         def owed(kid, blend=None, want_amax=False):
             """The gradient of state ``kid``; with ``blend`` = (U, Cand) of its cell also dY = gradient * U * (1 - Cand^2)."""
@@ -725,7 +727,7 @@ class _StcCellGraph(Function):
             out = aggs[0].new_empty(B, N, C, h)
             dY = torch.empty_like(out) if blend is not None else None
             k.spmm_sum(*bwd, op.bwd_plan, aggs[0], aggs[1] if len(aggs) > 1 else None, add, out,
-                       blend=None if blend is None else (blend[0], blend[1], dY), **(dict(amax=amax_slots(kid)) if want_amax else {}))
+                       blend=None if blend is None else (blend[0], blend[1], dY), **(dict(amax=amax_slots(kid, 0)) if want_amax else {}))
             return out if blend is None else (out, dY)
 
         # Order 3: a consumer leaves direct planes d0 and the gradients d1, d2 of the S / T_2(S) planes; the source's gradient is
@@ -735,9 +737,9 @@ class _StcCellGraph(Function):
             pc = pieces.setdefault(kid, dict(d0=[], d1=[], d2=[]))
             pc['d0'] += list(d0); pc['d1'] += list(d1); pc['d2'] += list(d2)
 
-        def clenshaw(d0, d1, d2, blend=None):
+        def clenshaw(d0, d1, d2, blend=None, amax=None):
             """sum d0 - sum d2 + S^T (sum d1 + 2 S^T sum d2) from lists of planes (d2 non-empty); with ``blend`` = (U, Cand) also
-            dY = result * U * (1 - Cand^2) from the second launch's epilogue."""
+            dY = result * U * (1 - Cand^2) from the second launch's epilogue; ``amax``: slots that receive max |result|."""
             while len(d2) > 2:                                       # the kernel gathers two operands: pre-sum the rest
                 d2 = [d2[0] + d2[1]] + d2[2:]
             t = d2[0].new_empty(B, N, C, h)
@@ -748,10 +750,11 @@ class _StcCellGraph(Function):
                 adds.insert(0, (a + b_, 0))
             out = t.new_empty(B, N, C, h)
             dY = torch.empty_like(out) if blend is not None else None
-            k.spmm_sum(*bwd, op.bwd_plan, t, None, adds, out, blend=None if blend is None else (blend[0], blend[1], dY))
+            k.spmm_sum(*bwd, op.bwd_plan, t, None, adds, out, blend=None if blend is None else (blend[0], blend[1], dY),
+                       **({} if amax is None else dict(amax=amax)))
             return out if blend is None else (out, dY)
 
-        def owed3(kid, blend=None):
+        def owed3(kid, blend=None, want_amax=False):
             base = G.pop(kid, None)
             pc = pieces.pop(kid, None)
             if pc is None:
@@ -760,7 +763,7 @@ class _StcCellGraph(Function):
                 dY = torch.empty_like(base)
                 k.gru_blend_bwd(base, blend[0], None, blend[1], dY, None, None)
                 return base, dY
-            return clenshaw(pc['d0'] + ([base] if base is not None else []), pc['d1'], pc['d2'], blend)
+            return clenshaw(pc['d0'] + ([base] if base is not None else []), pc['d1'], pc['d2'], blend, amax=amax_slots(kid, 0) if want_amax else None)
 
         for j in range(len(schedule) - 1, -1, -1):
             if j not in G and j not in pieces:
@@ -774,11 +777,14 @@ class _StcCellGraph(Function):
                 new = lambda: torch.empty_like(Hprev)
                 dWc, dbc = torch.empty_like(Wc), (Wc.new_empty(h) if bc is not None else None)
                 Zr = rest[5:8]                                       # slab-planar candidate
-                dHnew = owed3(j)
+                dHnew = owed3(j, want_amax=f16x2)
+                have = f16x2 and j in amax_rows                      # (no pieces: the wrapper takes the maximum itself)
                 dXc, dR = ([new(), new(), new()] if wide else [None] * 3), [new(), new(), new()]
                 k.cell_cand_bwd_planar_k(rows(Zx), rows(Zr), Tc, Wc, *rows((dHnew, U, Cand)),
-                                         [None if t is None else t.view(B * N, C, h) for t in dXc], rows(dR), dWc, dbc)
-                dRH = clenshaw([dR[0]], [dR[1]], [dR[2]])            # gradient of the R*H plane from its three Chebyshev planes
+                                         [None if t is None else t.view(B * N, C, h) for t in dXc], rows(dR), dWc, dbc,
+                                         **(dict(grad_amax=amax_rows[j][0]) if have else {}))
+                # gradient of the R*H plane from its three Chebyshev planes (its maximum beside dHnew's: the gates backward scales by both)
+                dRH = clenshaw([dR[0]], [dR[1]], [dR[2]], amax=amax_slots(j, 1) if have else None)
                 del dR
                 fold = getattr(k, 'folds_dH', False)                  # the kernel adds the prologue's share into the H plane's gradient
                 # slab-planar candidate on a wide input: the gates' X-side gradients are ADDED into the candidate's three planes by the
@@ -789,7 +795,8 @@ class _StcCellGraph(Function):
                 dWg, dbg = torch.empty_like(Wg), (Wg.new_empty(2 * h) if bg is not None else None)
                 k.cell_gates_bwd_planar_k(rows(Zx), rows(Zh), Tc, Wg, *rows((dRH, Cand, U, Rg, dHnew)),
                                           [None if t is None else t.view(B * N, C, h) for t in dXg], rows(dHg), dWg, dbg,
-                                          None if fold else dH.view(B * N, C, h), accumulate_x=into)
+                                          None if fold else dH.view(B * N, C, h), accumulate_x=into,
+                                          **(dict(grad_amax=amax_rows[j].view(-1)) if have else {}))
                 if into:
                     dXc = [None] * 3
                 if wide and x[0] == 'cell':
@@ -803,8 +810,8 @@ class _StcCellGraph(Function):
             post_form = n_saved[j] < 0 or (len(rest) == Ks + 1 and Ks > 1)     # candidate backward starts from dY = dHnew * U * (1 - Cand^2)
             if Ks == 3 and j in pieces:                              # an interleaved cell whose state order-3 planar cells consumed
                 G[j] = owed3(j)
-            one_launch = n_saved[j] == -7 and not bf16_planes and getattr(k, 'operand_format', 0) == 1
-            dHnew, dY = owed(j, (U, Cand), want_amax=one_launch) if post_form else (owed(j), None)
+            # fp16 x 2 operand format: the planar backward kernels scale their gradient operands from max |dHnew|, left by the sum that forms it
+            dHnew, dY = owed(j, (U, Cand), want_amax=f16x2 and n_saved[j] in (-7, -8)) if post_form else (owed(j), None)
             dH = None if (n_saved[j] == -7 or (n_saved[j] < 0 and getattr(k, 'folds_dH', False))) else torch.empty_like(Hprev)
             if n_saved[j] == -7:                                     # planar cell, candidate + gates backward in ONE launch
                 Xp, SXp, SHp = rest
@@ -837,7 +844,7 @@ class _StcCellGraph(Function):
                 dHd, dSH, acc_h = planes_of_state(hs)
                 k.cell_bwd_planar(*rows((Xp, Hprev, SXp, SHp)), Tc, Wg, Wc, *rows((U, Rg, Cand, dHnew, dBm)),
                                   [None if t is None else t.view(B * N, C, h) for t in (dXd, dSX, dHd, dSH)], dWg, dbg, dWc, dbc,
-                                  accumulate_x=acc_x, accumulate_h=acc_h, **(dict(grad_amax=amax_rows[j]) if j in amax_rows else {}))
+                                  accumulate_x=acc_x, accumulate_h=acc_h, **(dict(grad_amax=amax_rows[j][0]) if j in amax_rows else {}))
                 for i, t in enumerate((dWg, dbg, dWc, dbc)):
                     add_to(acc[s_id], i, t)
                 continue
@@ -859,7 +866,9 @@ class _StcCellGraph(Function):
                 del dY, dBm
                 fold = getattr(k, 'folds_dH', False)                 # the kernel adds the prologue's share into the H plane's gradient
                 k.cell_gates_bwd_planar(*rows((Xp, Hprev, SXp, SHp)), Tc, Wg, *rows((dRH, Cand, U, Rg, dHnew)), planes, dWg, dbg,
-                                        None if fold else dH.view(B * N, C, h))
+                                        None if fold else dH.view(B * N, C, h),
+                                        # (the R*H plane's gradient is a few times the state gradient at most: inside the format's 2^8 headroom)
+                                        **(dict(grad_amax=amax_rows[j][0]) if j in amax_rows else {}))
                 if wide and x[0] == 'cell':
                     leave(x[1], (dXd, dXc), dSX)                     # as the X plane: gates' and candidate's direct shares
                 if hs[0] == 'cell':
