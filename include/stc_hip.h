@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define STC_ABI_VERSION 15
+#define STC_ABI_VERSION 16
 #define STC_MAX_K 4          /* highest Chebyshev order (Ks, Kc) the node kernels accept */
 
 /* Operand formats of the split-operand matrix-core kernels (C = 32 / 64, hidden 16).  Every fp32 operand is split into low-precision
@@ -248,7 +248,9 @@ int stc_spmm_blend_fwd_f32(const int32_t* rowptr, const int32_t* colidx, const f
                            float* copy1, int32_t copy1_ld, int32_t copy1_off,
                            int32_t batch, int32_t C, int32_t h, void* stream);
 int stc_bdg_node_post_bwd_f32(const float* X, const float* X2, const float* Tc, const float* W, const float* dA, const float* dB,
-                              float* dX, float* dX2, float* dW, float* db, void* workspace, size_t workspace_bytes,
+                              float* dX, float* dX2, float* dW, float* db,
+                              const float* grad_amax, int32_t n_amax,      /* fp16 x 2 format (planar forms, C = 64): max over the slots bounds |dA|, |dB| */
+                              void* workspace, size_t workspace_bytes,
                               int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t Ho, void* stream);
 
 /* ---- fused cell convolutions (STC_GNN.py:69-78) ------------------------------------

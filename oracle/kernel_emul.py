@@ -351,7 +351,7 @@ class EmulatedKernels:
             buf[..., :off].copy_(side)
             buf[..., off + h:].zero_()
 
-    def node_post_bwd(self, X, Tc, W, dA, dB, dX, dW, db, X2=None, dX2=None):
+    def node_post_bwd(self, X, Tc, W, dA, dB, dX, dW, db, X2=None, dX2=None, grad_amax=None):
         if X2 is not None:                                     # planar: compute on the concatenated rows, hand back the planes
             w, w2 = X.shape[-1], X2.shape[-1]
             full = torch.empty(X.shape[:-1] + (w + w2,), dtype=W.dtype)

@@ -705,9 +705,11 @@ extern "C" int stc_bdg_node_post_fwd_f32(const float* X, const float* X2, const 
 }
 
 extern "C" int stc_bdg_node_post_bwd_f32(const float* X, const float* X2, const float* Tc, const float* W, const float* dA, const float* dB,
-                                         float* dX, float* dX2, float* dW, float* db, void* workspace, size_t workspace_bytes,
+                                         float* dX, float* dX2, float* dW, float* db, const float* grad_amax, int32_t n_amax,
+                                         void* workspace, size_t workspace_bytes,
                                          int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t Ho, void* stream) {
     if (int rc = check_dims("stc_bdg_node_post_bwd_f32", 2, 2, C, L, Lw, Ho, nodes)) return rc;
+    STC_REQUIRE(!grad_amax || n_amax >= 1, STC_EINVAL, "stc_bdg_node_post_bwd_f32: grad_amax with %d slots", n_amax);
     if (!stc_bdg_node_post_supported(2, 2, C, L, Ho)) return stc::fail(STC_EUNSUPPORTED, "stc_bdg_node_post_bwd_f32: shape not on the post-aggregation path");
     STC_REQUIRE(W && dW && Tc, STC_EINVAL, "stc_bdg_node_post_bwd_f32: null W/dW/Tc");
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -726,7 +728,7 @@ extern "C" int stc_bdg_node_post_bwd_f32(const float* X, const float* X2, const 
     STC_REQUIRE(!X2 || L == 32 || (L == 20 && Lw > 16), STC_EINVAL, "stc_bdg_node_post_bwd_f32: planar input (X2) needs rows of 16 + 16 or 16 + cin (<= 4) columns, L = %d", L);
     STC_REQUIRE(L == 20 ? dX2 == nullptr : (X2 == nullptr) == (dX2 == nullptr), STC_EINVAL,
                 "stc_bdg_node_post_bwd_f32: planar input (X2) and planar gradient (dX2) go together (the narrow input plane of L = 20 gets no gradient)");
-    const int rc = stc_node_post_bwd_x3(X, X2, Tc, W, dA, dB, dX, dX2, partial, &n_parts, db != nullptr, nodes, C, L, Lw, Ho, s);
+    const int rc = stc_node_post_bwd_x3(X, X2, Tc, W, dA, dB, dX, dX2, partial, &n_parts, db != nullptr, grad_amax, n_amax, nodes, C, L, Lw, Ho, s);
     if (rc == STC_NOT_HANDLED) return stc::fail(STC_EUNSUPPORTED, "stc_bdg_node_post_bwd_f32: operands not usable (alignment)");
     if (rc != STC_OK) return rc;
     const int stride = nW + Ho;

@@ -67,7 +67,8 @@ int stc_cell_cand_bwd_x3(const float* const* Z, int K, const float* Tc, const fl
 // Post-aggregation form of a K = 2 convolution, Y = A + S.Bm (stc_node_x3.hip): backward from (X, dA = dY, dBm = S^T dY).
 int stc_node_post_shape_ok(int K, int C, int L, int Ho);
 int stc_node_post_bwd_x3(const float* X, const float* X2, const float* Tc, const float* W, const float* dA, const float* dB, float* dX, float* dX2,
-                         float* partial, int* n_partials, int want_db, long long nodes, int C, int L, int Lw, int Ho, hipStream_t stream);
+                         float* partial, int* n_partials, int want_db, const float* gmax, int n_gmax,
+                         long long nodes, int C, int L, int Lw, int Ho, hipStream_t stream);
 int stc_node_post_fwd_x3(const float* X, const float* X2, const float* Tc, const float* W, const float* bias, float* A, float* Bm,
                          long long nodes, int C, int L, int Lw, int Ho, hipStream_t stream);
 

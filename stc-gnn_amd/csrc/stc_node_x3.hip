@@ -743,25 +743,35 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd2_x3_k
     }
 }
 
-template <int NB2, int HB, int L, int PL = 0>
+template <int NB2, int HB, int L, int PL = 0, class F = FmtB3>      // F: operand format, scales as in node_bwd_x3_kernel (gmax: the launch's gradient maximum)
 __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_kernel(
     const float* __restrict__ X, const float* __restrict__ X2, const float* __restrict__ Tc, const float* __restrict__ W,
     const float* __restrict__ dA, const float* __restrict__ dB, float* __restrict__ dX, float* __restrict__ dX2,
-    float* __restrict__ partial, int nodes, int want_db, int Lw) {
+    float* __restrict__ partial, int nodes, int want_db, int Lw, const float* __restrict__ gmax, int n_gmax) {
+    using Op = typename F::Op;
+    constexpr int NP = F::NP;
     constexpr int K = 2, NRB = 2 * NB2, C = 32 * NB2, Ho = 16 * HB, LB = (L + 15) / 16;
     constexpr int NBK = K * HB, S = (NBK + 1) / 2;
     constexpr int nTB = NRB * NB2, nWA = K * LB * S;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32x4* TB = reinterpret_cast<u32x4*>(smem_raw);     // [NRB rb][NB2 p]        T_1[16rb + x][32p + pair_row]
-    u32x4* WA = TB + nTB * 3 * 64;                       // [K n][LB][S]           W[(n, c, 16lb + x)][16hb + 4g + (e&3)], block 2s + (e>>2)
+    u32x4* WA = TB + nTB * NP * 64;                      // [K n][LB][S]           W[(n, c, 16lb + x)][16hb + 4g + (e&3)], block 2s + (e>>2)
     const int tid = threadIdx.x, lane = tid & 63, x = lane & 15, g = lane >> 4;
+
+    float sT = 1.f, sW = 1.f, sg = 1.f;
+    if constexpr (F::SCALED) {
+        float* scratch = reinterpret_cast<float*>(smem_raw);
+        sT = fminf(fmaxf(pow2_scale(block_absmax(Tc + (size_t)C * C, C * C, scratch, MF_THREADS), 0), 0.0625f), 4096.f);
+        sW = pow2_scale(block_absmax(W, K * K * Lw * Ho, scratch, MF_THREADS), 0);
+        sg = pow2_scale(slots_max(gmax, n_gmax), 4);
+    }
 
     for (int idx = tid; idx < nTB * 64; idx += MF_THREADS) {
         const int ll = idx & 63, f = idx >> 6, p = f % NB2, rb = f / NB2, gg = ll >> 4;
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = Tc[(size_t)C * C + (16 * rb + (ll & 15)) * C + 32 * p + pair_row(gg, e)];
-        put_frag(TB, f, ll, v);
+        F::put(TB, f, ll, v, sT);
     }
     for (int idx = tid; idx < nWA * 64; idx += MF_THREADS) {
         const int ll = idx & 63, f = idx >> 6, s = f % S, lb = (f / S) % LB, n = f / (S * LB), gg = ll >> 4;
@@ -771,14 +781,15 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
         for (int e = 0; e < 8; ++e) {
             const int b = 2 * s + (e >> 2), c = b / HB, hb = b % HB;
             const int wl = PL == 2 ? stc_wrow_swapped(l, Lw - 16) : l;
-            v[e] = (b < NBK && wl >= 0 && wl < Lw) ? W[((size_t)(n * K + c) * Lw + wl) * Ho + 16 * hb + 4 * gg + (e & 3)] : 0.f;
+            v[e] = (b < NBK && wl >= 0 && wl < Lw) ? W[((size_t)(n * K + c) * Lw + wl) * Ho + 16 * hb + 4 * gg + (e & 3)] * (F::SCALED && c == 0 ? sT : 1.f) : 0.f;
         }
-        put_frag(WA, f, ll, v);
+        F::put(WA, f, ll, v, sW);
     }
     __syncthreads();
 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nw = gridDim.x * MF_WAVES;
+    const float ikz_sg = 1.f / (sT * sW * sg);
     f32x4 dWt[K][LB][K][HB];
     float dbp[HB];
 #pragma unroll
@@ -797,6 +808,14 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
         DyFrag<NRB, HB> gr[K];
         gr[0].load(dA, node, x, g);
         gr[1].load(dB, node, x, g);
+        if constexpr (F::SCALED) {
+#pragma unroll
+            for (int n = 0; n < K; ++n)
+#pragma unroll
+                for (int kb = 0; kb < NRB; ++kb)
+#pragma unroll
+                    for (int hb = 0; hb < HB; ++hb) { gr[n].d[kb][hb] *= sg; gr[n].v[kb][hb] *= sg; }
+        }
         float za[LB][NRB][4];                                   // X[16kb + 4g + t][16lb + x]
 #pragma unroll
         for (int lb = 0; lb < LB; ++lb) {
@@ -825,16 +844,16 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
             for (int hb = 0; hb < HB; ++hb)                       // the bias sits on A only
                 dbp[hb] += (gr[0].d[kb][hb][0] + gr[0].d[kb][hb][1]) + (gr[0].d[kb][hb][2] + gr[0].d[kb][hb][3]);
 
-        X3 gd[K][HB][NB2];
+        Op gd[K][HB][NB2];
 #pragma unroll
         for (int n = 0; n < K; ++n)
 #pragma unroll
             for (int hb = 0; hb < HB; ++hb)
 #pragma unroll
-                for (int p = 0; p < NB2; ++p) gd[n][hb][p] = split8(gr[n].d[2 * p][hb], gr[n].d[2 * p + 1][hb]);
+                for (int p = 0; p < NB2; ++p) gd[n][hb][p] = F::split(gr[n].d[2 * p][hb], gr[n].d[2 * p + 1][hb]);
 
         // ---- B operands of dX: per slab n, step s covers the (c, o) blocks 2s, 2s+1 of (Q^n_c)^T
-        X3 qb[K][S][NRB];
+        Op qb[K][S][NRB];
 #pragma unroll
         for (int n = 0; n < K; ++n) {
             f32x4 Qv[NRB][HB];                                   // (T_1 dY_n)^T tiles (rows o, columns c')
@@ -844,9 +863,9 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
                 for (int hb = 0; hb < HB; ++hb) Qv[rb][hb] = kZero4;
 #pragma unroll
                 for (int p = 0; p < NB2; ++p) {
-                    const X3 t = get_frag(TB, rb * NB2 + p, lo);
+                    const Op t = F::get(TB, rb * NB2 + p, lo);
 #pragma unroll
-                    for (int hb = 0; hb < HB; ++hb) Qv[rb][hb] = mma6(gd[n][hb][p], t, Qv[rb][hb]);
+                    for (int hb = 0; hb < HB; ++hb) Qv[rb][hb] = F::mm(gd[n][hb][p], t, Qv[rb][hb]);
                 }
             }
 #pragma unroll
@@ -859,7 +878,7 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
                         const int b = 2 * s + h2, c = b / HB, hb = b % HB;
                         blk[h2] = b >= NBK ? kZero4 : (c == 0 ? gr[n].v[rb][hb] : Qv[rb][hb]);
                     }
-                    qb[n][s][rb] = split8(blk[0], blk[1]);
+                    qb[n][s][rb] = F::split(blk[0], blk[1]);
                 }
         }
 
@@ -873,10 +892,14 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
             for (int n = 0; n < K; ++n)
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
-                    const X3 w = get_frag(WA, (n * LB + lb) * S + s, lo);
+                    const Op w = F::get(WA, (n * LB + lb) * S + s, lo);
 #pragma unroll
-                    for (int rb = 0; rb < NRB; ++rb) z[rb] = mma6(w, qb[n][s][rb], z[rb]);
+                    for (int rb = 0; rb < NRB; ++rb) z[rb] = F::mm(w, qb[n][s][rb], z[rb]);
                 }
+            if constexpr (F::SCALED) {
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) z[rb] *= ikz_sg;
+            }
             if constexpr (PL == 1) {                            // planar gradient: columns 0..15 -> dX, 16..31 -> dX2
 #pragma unroll
                 for (int rb = 0; rb < NRB; ++rb)
@@ -895,7 +918,7 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
         }
 
         // ---- Q^n_1 tiles (rows c', columns o) as operands, then dW_{n,c} += X^T Q^n_c (the X columns are split once)
-        X3 qd[K][HB][NB2];
+        Op qd[K][HB][NB2];
 #pragma unroll
         for (int n = 0; n < K; ++n) {
             f32x4 Qd[NRB][HB];
@@ -905,22 +928,22 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
                 for (int hb = 0; hb < HB; ++hb) Qd[rb][hb] = kZero4;
 #pragma unroll
                 for (int p = 0; p < NB2; ++p) {
-                    const X3 t = get_frag(TB, rb * NB2 + p, lo);
+                    const Op t = F::get(TB, rb * NB2 + p, lo);
 #pragma unroll
-                    for (int hb = 0; hb < HB; ++hb) Qd[rb][hb] = mma6(t, gd[n][hb][p], Qd[rb][hb]);
+                    for (int hb = 0; hb < HB; ++hb) Qd[rb][hb] = F::mm(t, gd[n][hb][p], Qd[rb][hb]);
                 }
             }
 #pragma unroll
             for (int hb = 0; hb < HB; ++hb)
 #pragma unroll
-                for (int p = 0; p < NB2; ++p) qd[n][hb][p] = split8(Qd[2 * p][hb], Qd[2 * p + 1][hb]);
+                for (int p = 0; p < NB2; ++p) qd[n][hb][p] = F::split(Qd[2 * p][hb], Qd[2 * p + 1][hb]);
         }
 #pragma unroll
         for (int lb = 0; lb < LB; ++lb)
 #pragma unroll
             for (int p = 0; p < NB2; ++p) {
                 const float (&zc)[NRB][4] = za[lb];
-                const X3 a = split8(f32x4{zc[2 * p][0], zc[2 * p][1], zc[2 * p][2], zc[2 * p][3]},
+                const Op a = F::split(f32x4{zc[2 * p][0], zc[2 * p][1], zc[2 * p][2], zc[2 * p][3]},
                                     f32x4{zc[2 * p + 1][0], zc[2 * p + 1][1], zc[2 * p + 1][2], zc[2 * p + 1][3]});
 #pragma unroll
                 for (int n = 0; n < K; ++n)
@@ -928,10 +951,11 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
                     for (int c = 0; c < K; ++c)
 #pragma unroll
                         for (int hb = 0; hb < HB; ++hb)
-                            dWt[n][lb][c][hb] = mma6(a, c == 0 ? gd[n][hb][p] : qd[n][hb][p], dWt[n][lb][c][hb]);
+                            dWt[n][lb][c][hb] = F::mm(a, c == 0 ? gd[n][hb][p] : qd[n][hb][p], dWt[n][lb][c][hb]);
             }
     }
-    combine_dw<K, LB, HB>(reinterpret_cast<float*>(smem_raw), dWt, dbp, partial, Lw, want_db, PL == 2 ? Lw - 16 : -1);
+    const float isg = 1.f / sg;
+    combine_dw<K, LB, HB>(reinterpret_cast<float*>(smem_raw), dWt, dbp, partial, Lw, want_db, PL == 2 ? Lw - 16 : -1, isg, isg / sT, isg);
 }
 
 // --------------------------------------------------------------------------------------- host side
@@ -1102,21 +1126,21 @@ int stc_cell_cand_bwd_x3(const float* const* Z, int K, const float* Tc, const fl
     return STC_NOT_HANDLED;
 }
 
-template <int NB2, int HB, int L, int PL = 0>
+template <int NB2, int HB, int L, int PL = 0, class F = FmtB3>
 static int launch_bwd2(const float* X, const float* X2, const float* Tc, const float* W, const float* dA, const float* dB, float* dX, float* dX2,
-                       float* partial, int* n_partials, int want_db, long long nodes, int Lw, hipStream_t stream) {
+                       float* partial, int* n_partials, int want_db, long long nodes, int Lw, hipStream_t stream, const float* gmax = nullptr, int n_gmax = 0) {
     constexpr int K = 2, NRB = 2 * NB2, Ho = 16 * HB, LB = (L + 15) / 16, NBK = K * HB, S = (NBK + 1) / 2, nW = K * K * L * Ho;
-    const size_t frag = (size_t)(NRB * NB2 + K * LB * S) * 3 * 64 * 16;
+    const size_t frag = (size_t)(NRB * NB2 + K * LB * S) * F::NP * 64 * 16;
     const size_t slabs = (size_t)MF_WAVES * (nW + Ho) * sizeof(float);
     const size_t lds = frag > slabs ? frag : slabs;
     if (lds > stc::kMaxLdsBytes) return STC_NOT_HANDLED;
-    auto kern = node_bwd2_x3_kernel<NB2, HB, L, PL>;
+    auto kern = node_bwd2_x3_kernel<NB2, HB, L, PL, F>;
     if (int rc = stc::hip_status(stc::allow_lds(kern, lds), "hipFuncSetAttribute(node bwd2 x3)")) return rc;
     static const int resident = stc::resident_blocks(kern, MF_THREADS, lds, NB2 == 1 ? 2 : 1);
     const long long want = (nodes + MF_WAVES - 1) / MF_WAVES;
     int grid = resident < MF_BWD_MAX_GRID ? resident : MF_BWD_MAX_GRID;
     if (want < grid) grid = (int)want;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(MF_THREADS), lds, stream, X, X2, Tc, W, dA, dB, dX, dX2, partial, (int)nodes, want_db, Lw);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(MF_THREADS), lds, stream, X, X2, Tc, W, dA, dB, dX, dX2, partial, (int)nodes, want_db, Lw, gmax, n_gmax);
     STC_LAUNCH_CHECK("node_bwd2_x3 launch");
     *n_partials = grid;
     return STC_OK;
@@ -1141,19 +1165,24 @@ int stc_node_post_shape_ok(int K, int C, int L, int Ho) {
     return K == 2 && (C == 32 || C == 64) && (L == 20 || L == 32) && Ho == 16;     // Ho < L: where the narrow SpMM pays
 }
 
+// gmax != null: fp16 x 2 operand format for the planar forms at C = 64 (what the two-launch cell backward runs; C = 32 runs the one-launch
+// kernel and keeps bf16 x 3 here: its two-waves-per-SIMD build has no registers to spare); null: bf16 x 3
 int stc_node_post_bwd_x3(const float* X, const float* X2, const float* Tc, const float* W, const float* dA, const float* dB, float* dX, float* dX2,
-                         float* partial, int* n_partials, int want_db, long long nodes, int C, int L, int Lw, int Ho, hipStream_t stream) {
+                         float* partial, int* n_partials, int want_db, const float* gmax, int n_gmax,
+                         long long nodes, int C, int L, int Lw, int Ho, hipStream_t stream) {
     if (!stc_node_post_shape_ok(2, C, L, Ho) || nodes <= 0 || nodes >= (1ll << 31) / C) return STC_NOT_HANDLED;
     if (!(stc::aligned16(X) && stc::aligned16(dA) && stc::aligned16(dB) && stc::aligned16(dX) && (!X2 || L == 20 || stc::aligned16(X2)))) return STC_NOT_HANDLED;
     if (X2 && L == 20) {                        // narrow planar rows: gradient of the 16-wide plane only (dX); the input plane gets none
         if (Lw - 16 < 1 || Lw - 16 > 4) return STC_NOT_HANDLED;
         if (C == 32) return launch_bwd2<1, 1, 20, 2>(X, X2, Tc, W, dA, dB, dX, nullptr, partial, n_partials, want_db, nodes, Lw, stream);
+        if (C == 64 && gmax) return launch_bwd2<2, 1, 20, 2, FmtH2>(X, X2, Tc, W, dA, dB, dX, nullptr, partial, n_partials, want_db, nodes, Lw, stream, gmax, n_gmax);
         if (C == 64) return launch_bwd2<2, 1, 20, 2>(X, X2, Tc, W, dA, dB, dX, nullptr, partial, n_partials, want_db, nodes, Lw, stream);
         return STC_NOT_HANDLED;
     }
     if (X2) {                                   // planar rows (16 + 16 columns): input planes X, X2 and gradient planes dX, dX2
         if (L != 32 || !dX2 || !stc::aligned16(dX2)) return STC_NOT_HANDLED;
         if (C == 32) return launch_bwd2<1, 1, 32, 1>(X, X2, Tc, W, dA, dB, dX, dX2, partial, n_partials, want_db, nodes, Lw, stream);
+        if (C == 64 && gmax) return launch_bwd2<2, 1, 32, 1, FmtH2>(X, X2, Tc, W, dA, dB, dX, dX2, partial, n_partials, want_db, nodes, Lw, stream, gmax, n_gmax);
         if (C == 64) return launch_bwd2<2, 1, 32, 1>(X, X2, Tc, W, dA, dB, dX, dX2, partial, n_partials, want_db, nodes, Lw, stream);
         return STC_NOT_HANDLED;
     }

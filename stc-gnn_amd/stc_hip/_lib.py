@@ -19,7 +19,7 @@ import torch
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG_ROOT, 'libstc_hip.so')
-ABI_VERSION = 15
+ABI_VERSION = 16
 FMT_BF16X3, FMT_F16X2 = 0, 1          # STC_FMT_* of include/stc_hip.h: operand formats of the split-operand matrix-core kernels
 MAX_K = 4
 SPMM_SUM_MAX_ADD = 8     # = STC_SPMM_SUM_MAX_ADD of include/stc_hip.h
@@ -87,7 +87,7 @@ def _declare(lib):
         'stc_cell_gates_bwd_planar_f32': [_p] * 11 + [C.POINTER(_p), _p, _p, _p, _p, _i32, _p, C.c_size_t, _i64, _i32, _i32, _i32, _p],
         'stc_cell_bwd_planar_f32': [_p] * 20 + [_i32, _i32, _p, _i32, _p, C.c_size_t, _i64, _i32, _i32, _i32, _p],
         'stc_spmm_blend_fwd_f32': [_p] * 6 + [_i32, _i32] + [_p] * 6 + [_p, _i32, _i32, _p, _i32, _p, _i32, _i32] + [_i32] * 3 + [_p],
-        'stc_bdg_node_post_bwd_f32': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _i32, _p],
+        'stc_bdg_node_post_bwd_f32': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, C.c_size_t, _i64, _i32, _i32, _i32, _i32, _p],
         'stc_spmm_sum_f32': [_p] * 6 + [_i32, _i32, _p, _p, _f32, _i32, C.POINTER(_p), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_f32), _p, _p, _p, _p,
                              _p, _i32, _i32, _i32, _i32, _p],
         'stc_cell_gates_fwd_planar_k_f32': [C.POINTER(_p), C.POINTER(_p), _i32, _p, _p, _p, _p, _p, _p, _i32, _i64, _i32, _i32, _i32, _p],
@@ -612,7 +612,7 @@ class HipKernels:
                      _ptr(cp[0][0]), cp[0][1], cp[0][2], _ptr(side), side_cin, _ptr(cp[1][0]), cp[1][1], cp[1][2], B, Cc, h,
                      nbytes=colidx.numel() * 8 + 4 * (n + 1) + 4 * B * n * Cc * h * (6 + len(copies)))
 
-    def node_post_bwd(self, X, Tc, W, dA, dB, dX, dW, db, X2=None, dX2=None):
+    def node_post_bwd(self, X, Tc, W, dA, dB, dX, dW, db, X2=None, dX2=None, grad_amax=None):
         """(X, dA = dY, dBm = S^T dY) -> dX, dW, db of the convolution in its post-aggregation form.  Planar (X2 given):
         the gradient comes out as the two planes dX, dX2 as well."""
         Ks, Kc, R, Cc, L, Lw, Ho = self._post_rows(X, X2, Tc, W)
@@ -630,6 +630,7 @@ class HipKernels:
         self._same_device(X, X2, Tc, W, dA, dB, dX, dX2, dW, db)
         ws = self._get_workspace(X.device, self.lib.stc_bdg_node_bwd_workspace_bytes(Ks, Kc, Cc, L, Ho, 0))
         self._launch('stc_bdg_node_post_bwd_f32', X, _ptr(X), _ptr(X2), _ptr(Tc), _ptr(W), _ptr(dA), _ptr(dB), _ptr(dX), _ptr(dX2), _ptr(dW), _ptr(db),
+                     *(self._grad_amax('post', grad_amax, dA, dB) if (X2 is not None and Cc == 64) else (None, 0)),      # (the forms built for fp16 x 2)
                      _ptr(ws), ws.numel(), R, Cc, L, Lw, Ho)
 
     # ---- planar cell inputs (Ks = Kc = 2, cin = h = 16) ---------------------------------------------

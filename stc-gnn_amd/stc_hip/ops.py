@@ -850,6 +850,7 @@ class _StcCellGraph(Function):
                 continue
             if n_saved[j] < 0:                                       # planar cell: inputs and gradients as planes
                 Xp, SXp, SHp, RH = rest
+                amax_kw = dict(grad_amax=amax_rows[j][0]) if j in amax_rows else {}      # |dY| <= |dHnew|, |S^T dY| within the format's headroom
                 dBm = narrow_transpose_aggregation(dY)
                 dRH, dWc = torch.empty_like(Hprev), torch.empty_like(Wc)
                 dbc = Wc.new_empty(h) if bc is not None else None
@@ -858,17 +859,17 @@ class _StcCellGraph(Function):
                 dHd, dSH = torch.empty_like(Hprev), torch.empty_like(Hprev)
                 if wide:
                     dXc, dXd, dSX = (torch.empty_like(Hprev) for _ in range(3))
-                    k.node_post_bwd(*rows((Xp,)), Tc, Wc, *rows((dY, dBm, dXc)), dWc, dbc, X2=RH.view(B * N, C, h), dX2=dRH.view(B * N, C, h))
+                    k.node_post_bwd(*rows((Xp,)), Tc, Wc, *rows((dY, dBm, dXc)), dWc, dbc, X2=RH.view(B * N, C, h), dX2=dRH.view(B * N, C, h), **amax_kw)
                     planes = rows((dXd, dSX, dHd, dSH))
                 else:
-                    k.node_post_bwd(*rows((RH,)), Tc, Wc, *rows((dY, dBm, dRH)), dWc, dbc, X2=Xp.view(B * N, C, cin[j]))
+                    k.node_post_bwd(*rows((RH,)), Tc, Wc, *rows((dY, dBm, dRH)), dWc, dbc, X2=Xp.view(B * N, C, cin[j]), **amax_kw)
                     planes = [None, None] + rows((dHd, dSH))
                 del dY, dBm
                 fold = getattr(k, 'folds_dH', False)                 # the kernel adds the prologue's share into the H plane's gradient
                 k.cell_gates_bwd_planar(*rows((Xp, Hprev, SXp, SHp)), Tc, Wg, *rows((dRH, Cand, U, Rg, dHnew)), planes, dWg, dbg,
                                         None if fold else dH.view(B * N, C, h),
                                         # (the R*H plane's gradient is a few times the state gradient at most: inside the format's 2^8 headroom)
-                                        **(dict(grad_amax=amax_rows[j][0]) if j in amax_rows else {}))
+                                        **amax_kw)
                 if wide and x[0] == 'cell':
                     leave(x[1], (dXd, dXc), dSX)                     # as the X plane: gates' and candidate's direct shares
                 if hs[0] == 'cell':
