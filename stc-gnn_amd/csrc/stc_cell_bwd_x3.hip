@@ -16,7 +16,7 @@
 // registers of two waves per SIMD; at that budget the fused body spilled 72 registers to scratch (scratch stores go through to HBM:
 // 4.6 GB per launch, more than the fusion saves).  The kernel therefore runs ONE wave per SIMD with the full 512-register file and hides
 // HBM latency itself: the next node's 120 operand registers are requested before the current node is computed (software prefetch).
-// Measured alternatives (MI355X, 250 880 nodes): splitting the node's work between a candidate wave and a gates wave
+// Measured alternatives (MI355X, 250 880 nodes; HISTORY.md section 3c): splitting the node's work between a candidate wave and a gates wave
 // per SIMD with an LDS hand-over (two waves per SIMD, 234 registers each) runs at the same 1.98 ms per launch; forcing MFMA / VALU
 // interleaving with sched_group_barrier pipelines ended in scratch spills (2.8 ms).
 #include "stc_x3_frag.h"

@@ -32,7 +32,7 @@ class Trainer:
     """``hip_graph=True`` (one rank): after two eager steps per batch shape the whole train step -- forward, ComboLoss, backward, Adam --
     is captured into a HIP graph (``torch.cuda.graph``; every kernel of this path launches on the capturing stream and allocates only
     through torch) and replayed for every later batch of that shape from static input buffers.  At the SF shape the step is ~700 launches
-    of a few microseconds each, i.e. launch-bound: replay halves it; same parameters as eager, bit for bit."""
+    of a few microseconds each, i.e. launch-bound: replay halves it (HISTORY.md, section 5); same parameters as eager, bit for bit."""
 
     def __init__(self, params: dict, data: dict, graph_mode: str = 'dense-learned', hip_graph: bool = False):
         from STC_GNN import STCGNN
