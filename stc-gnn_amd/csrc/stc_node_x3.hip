@@ -97,6 +97,12 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
     constexpr int TRS = 20;                                 // row stride of the transpose tiles (16 + 4: conflict-free row reads)
     u32x4* Wp = Tx + nTx * NP * 64;
     float* tr = reinterpret_cast<float*>(Wp + nWp * NP * 64);  // POST: [wave][NRB][16 rows][TRS]  R*H, accumulator -> row layout
+    // Planar gates kernel: the epilogue wants the previous state H in accumulator layout, and the H plane is already with the wave in row
+    // layout (it is one of the planes of slab 0).  Loading it a second time from global memory re-fetched 0.74 of a plane per launch from
+    // beyond L2 (rocprofv3 FETCH_SIZE: 2 435 MB against the 2 055 MB of the four input planes -- the rows a wave loaded one node ago have
+    // left the XCD's 4 MiB L2 by the time it asks again): the rows go through a per-wave LDS tile instead, row layout -> accumulator layout.
+    constexpr bool HT = EPI == EPI_GATES && PL != 0;
+    float* th = tr + (POST ? MF_WAVES * NRB * 16 * TRS : 0);    // HT: [wave][NRB][16 rows][TRS]
     const int tid = threadIdx.x, lane = tid & 63, x = lane & 15, g = lane >> 4;
 
     float sT = 1.f, sW = 1.f, sWp = 1.f;                    // FmtH2: powers of two from the tables' own maxima (same in every workgroup)
@@ -175,7 +181,22 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
         // EPI_GATES: lane x < L - 16 also writes one column of CandIn outside the R*H block, in the same row layout:
         // column x of Xt (re-read from slab 0, an L2 hit) while x < cin, else the zero of pad column x + 16
         const bool has_side = EPI == EPI_GATES && !PL && x < L - HID;
-        if (EPI != EPI_NONE) {
+        if constexpr (HT) {
+            const bool mine = PL == 1 ? g >= 2 : g < 2;          // PL = 1: rows are [X | H]; PL = 2: [H | x | pad]
+            if (mine) {
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) {
+                    float* dst = th + ((wave * NRB + rb) * 16 + x) * TRS + 8 * (g & 1);
+                    *reinterpret_cast<f32x4*>(dst) = cur[0][rb].a;
+                    *reinterpret_cast<f32x4*>(dst + 4) = cur[0][rb].b;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hv[rb][r] = th[((wave * NRB + rb) * 16 + 4 * g + r) * TRS + x];
+        } else if (EPI != EPI_NONE) {
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
@@ -963,7 +984,8 @@ template <int NB2, int HB, int K, int L, int EPI = EPI_NONE, int PL = 0, int POS
 int launch_fwd(const float* const* Z, const float* Tc, const float* W, const float* bias, float* Y,
                long long nodes, int Lw, hipStream_t stream, FwdEpi epi = FwdEpi{}, PostArgs post = PostArgs{}) {
     constexpr int NRB = 2 * NB2, NCB = K * HB;
-    const size_t lds = (size_t)(K * NCB + (K - 1) * NRB * NB2 + (POST ? K * K : 0)) * F::NP * 64 * 16 + (POST ? (size_t)MF_WAVES * NRB * 16 * 20 * 4 : 0);
+    const size_t lds = (size_t)(K * NCB + (K - 1) * NRB * NB2 + (POST ? K * K : 0)) * F::NP * 64 * 16
+                       + ((POST ? 1 : 0) + (EPI == EPI_GATES && PL != 0 ? 1 : 0)) * (size_t)MF_WAVES * NRB * 16 * 20 * 4;      // R*H tile (POST), H tile (planar gates)
     if (lds > stc::kMaxLdsBytes) return STC_NOT_HANDLED;
     auto kern = node_fwd_x3_kernel<NB2, HB, K, L, EPI, PL, POST, F>;
     if (int rc = stc::hip_status(stc::allow_lds(kern, lds), "hipFuncSetAttribute(node fwd x3)")) return rc;
