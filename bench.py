@@ -78,13 +78,15 @@ def parse(argv=None):
     ap.add_argument('--storage', choices=('f32', 'bf16'), default='f32',
                     help='storage type of states / gates / their gradients: f32 = the metric (reference arithmetic); bf16 = BASELINE configuration 5 '
                          '(not the metric: bf16 has no reference behaviour), fp32 parameters and fp32 sums inside every kernel')
+    # a preset changes DEFAULTS (explicit flags still win): found first, then the full parse
+    pre, _ = ap.parse_known_args(argv)
+    if pre.preset == 'cfg4':
+        ap.set_defaults(grid=100, order=3, batch_per_gpu=4)
+    elif pre.preset == 'cfg5':
+        ap.set_defaults(categories=64, storage='bf16', no_cpu_baseline=True)
+    elif pre.preset == 'sf':
+        ap.set_defaults(grid=10, categories=5, obs=9, pred=3, batch_per_gpu=32, no_unit_d3=True)
     a = ap.parse_args(argv)
-    if a.preset == 'cfg4':
-        a.grid, a.order, a.batch_per_gpu = 100, 3, 4
-    elif a.preset == 'cfg5':
-        a.categories, a.storage, a.no_cpu_baseline = 64, 'bf16', True
-    elif a.preset == 'sf':
-        a.grid, a.categories, a.obs, a.pred, a.batch_per_gpu, a.no_unit_d3 = 10, 5, 9, 3, 32, True
     if a.global_batch:
         if a.global_batch % a.gpus:
             ap.error(f'--global-batch {a.global_batch} is not divisible by --gpus {a.gpus}: shards must be equal')

@@ -405,6 +405,69 @@ struct NodeIn {      // what one node contributes from HBM: its dY fragments and
     }
 };
 
+// One-wave kernels with a gate / blend prologue (order 3, C = 64): what the prologue reads per node, in ROW layout only (lane (x, g): row
+// 16kb + x, columns 4g .. 4g+3; six 16-byte loads per 16 rows), so that the NEXT node's planes can be requested a node ahead in 24-48
+// registers.  With one wave per SIMD nobody else covers a load: rocprofv3 showed the order-3 gates backward 62 % parked on memory at 16 %
+// matrix-pipe busy.  The prologue's products are formed once, in row layout, and reach the accumulator layout (row 16kb + 4g + t, column x)
+// through a per-wave LDS tile -- the old prologue loaded and multiplied everything a second time in that layout (48 four-byte loads).
+template <int NRB>
+struct GateRows {
+    f32x4 u[NRB], r[NRB], h[NRB], c[NRB], gn[NRB], dci[NRB];
+    template <bool GATES>
+    __device__ __forceinline__ void load(const BwdPro& p, int node, int x, int g) {
+        constexpr int C = 16 * NRB;
+#pragma unroll
+        for (int kb = 0; kb < NRB; ++kb) {
+            const size_t e = ((size_t)node * C + 16 * kb + x) * 16 + 4 * g;
+            u[kb] = *reinterpret_cast<const f32x4*>(p.U + e);
+            c[kb] = *reinterpret_cast<const f32x4*>(p.Cand + e);
+            gn[kb] = *reinterpret_cast<const f32x4*>(p.dH_in + e);
+            if constexpr (GATES) {
+                r[kb] = *reinterpret_cast<const f32x4*>(p.R + e);
+                h[kb] = *reinterpret_cast<const f32x4*>(p.H + e);
+                dci[kb] = *reinterpret_cast<const f32x4*>(p.dCandIn + e);      // planar: the R*H plane's gradient, rows of 16
+            }
+        }
+    }
+};
+
+// dY of the gates convolution (PRO_GATES_CAND, HB = 2) or of the candidate convolution (PRO_BLEND, HB = 1) from the row-layout planes, both
+// register layouts; the gates form also leaves the state's share dH = dRH R + dHnew (1 - U) in the stash (FOLD) or in p.dH.
+template <int NRB, int HB, bool FOLD, int TRS>
+__device__ __forceinline__ void form_dy(DyFrag<NRB, HB>& gq, const GateRows<NRB>& w, const BwdPro& p, int node, int x, int g, float4* stash, float* tile) {
+    constexpr int C = 16 * NRB;
+#pragma unroll
+    for (int kb = 0; kb < NRB; ++kb) {
+        f32x4 dh;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if constexpr (HB == 2) {
+                const float u = w.u[kb][i], r = w.r[kb][i], hh = w.h[kb][i], d = w.dci[kb][i], gn = w.gn[kb][i];
+                gq.v[kb][0][i] = gn * (w.c[kb][i] - hh) * u * (1.f - u);
+                gq.v[kb][1][i] = d * hh * r * (1.f - r);
+                dh[i] = d * r + gn * (1.f - u);
+            } else {
+                const float cc = w.c[kb][i];
+                gq.v[kb][0][i] = w.gn[kb][i] * w.u[kb][i] * (1.f - cc * cc);
+            }
+        }
+        if constexpr (HB == 2) {
+            if constexpr (FOLD) stash[kb * 64 + (g * 16 + x)] = make_float4(dh[0], dh[1], dh[2], dh[3]);
+            else *reinterpret_cast<f32x4*>(p.dH + ((size_t)node * C + 16 * kb + x) * 16 + 4 * g) = dh;
+        }
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb) *reinterpret_cast<f32x4*>(tile + ((hb * NRB + kb) * 16 + x) * TRS + 4 * g) = gq.v[kb][hb];
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int kb = 0; kb < NRB; ++kb)
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) gq.d[kb][hb][t] = tile[((hb * NRB + kb) * 16 + 4 * g + t) * TRS + x];
+    __builtin_amdgcn_wave_barrier();
+}
+
 // C = 32 with K <= 2 fits two waves per SIMD (<= 256 registers): the partner wave hides load and LDS latency, so no
 // software prefetch; the larger shapes run one wave per SIMD and prefetch the next node's operands instead.
 template <int NB2, int K>
@@ -426,12 +489,17 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
     constexpr int NBK = K * HB, S = (NBK + 1) / 2;             // (c, o) blocks of 16 and 32-wide steps over them
     constexpr int nTB = (K - 1) * NRB * NB2, nWA = K * LB * S;
     constexpr bool PF = PRO == PRO_NONE && BwdSched<NB2, K>::waves == 1;      // prefetch the next node's operands
+    // ... also with a gate / blend prologue on planar inputs: row-layout planes a node ahead (GateRows), dY through an LDS tile
+    constexpr bool PFG = (PRO == PRO_GATES_CAND || PRO == PRO_BLEND) && PL != 0 && BwdSched<NB2, K>::waves == 1;
+    constexpr int TRS = 20;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u32x4* TB = reinterpret_cast<u32x4*>(smem_raw);     // [K-1][NRB rb][NB2 p]   T_c[16rb + x][32p + pair_row]
     u32x4* WA = TB + nTB * NP * 64;                      // [K n][LB][S]           W[(n, c, 16lb + x)][16hb + 4g + (e&3)], block 2s + (e>>2)
     static_assert(!FOLD || ((PRO == PRO_GATES || PRO == PRO_GATES_CAND) && PL != 0), "FOLD belongs to the planar gates backward");
     const int tid = threadIdx.x, lane = tid & 63, x = lane & 15, g = lane >> 4;
     float4* stash = reinterpret_cast<float4*>(WA + nWA * NP * 64) + (tid >> 6) * NRB * 64;    // FOLD: [wave][NRB][64 lanes], lane-private
+    float* dy_tile = reinterpret_cast<float*>(reinterpret_cast<float4*>(WA + nWA * NP * 64) + (FOLD ? MF_WAVES * NRB * 64 : 0))
+                     + (tid >> 6) * (HB * NRB * 16 * TRS);                                    // PFG: [wave][HB][NRB][16 rows][TRS]
 
     float sT = 1.f, sW = 1.f, sg = 1.f;                  // FmtH2: table scales from the tables' own maxima, gradient scale from pro.gmax
     if constexpr (F::SCALED) {
@@ -487,12 +555,26 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
     static_assert(PL != 1 || L == 32, "planar rows are 16 + 16 columns");
     static_assert(PL != 2 || L == 20, "narrow planar rows are 16 + cin columns padded to 20");
     NodeIn<NB2, HB, K, L, PL> in, nx;
+    GateRows<NRB> rows_cur, rows_nxt;
     if (PF && node < nodes) { in.g.load(dY, node, x, g); in.load_z(Z, node, x, g, Lw - 16); }      // (the width matters to PL = 2 only)
-    if (PF) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) before the loop: see node_fwd_x3_kernel
+    if (PFG && node < nodes) { rows_cur.template load<PRO == PRO_GATES_CAND>(pro, node, x, g); in.load_z(Z, node, x, g, Lw - 16); }
+    if (PF || PFG) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) before the loop: see node_fwd_x3_kernel
     while (node < nodes) {
         const int next_node = node + nw;
         const size_t r0 = (size_t)node * C;
-        if constexpr (PRO == PRO_GATES || PRO == PRO_GATES_CAND) {
+        f32x4 old[K][NRB];                                     // ACC: what the X-side planes already hold, requested BEFORE the prefetch (vmcnt counts in order)
+        if constexpr (PFG) {
+            if constexpr (ACC != 0 && PL == 1 && F::SCALED) {
+#pragma unroll
+                for (int n = 0; n < K; ++n)
+#pragma unroll
+                    for (int rb = 0; rb < NRB; ++rb) old[n][rb] = *reinterpret_cast<const f32x4*>(dZ.p[n] + (r0 + 16 * rb + x) * 16 + 4 * g);
+            }
+            if (next_node < nodes) { rows_nxt.template load<PRO == PRO_GATES_CAND>(pro, next_node, x, g); nx.load_z(Z, next_node, x, g, Lw - 16); }
+            __builtin_amdgcn_sched_barrier(0);
+            form_dy<NRB, HB, FOLD != 0, TRS>(in.g, rows_cur, pro, node, x, g, stash, dy_tile);
+        }
+        else if constexpr (PRO == PRO_GATES || PRO == PRO_GATES_CAND) {
             // planar: dCandIn is the R*H plane's gradient alone, (nodes, C, 16) with the state columns at offset 0
             load_gates_grad<NRB, HB, (PL ? 16 : L), PRO == PRO_GATES_CAND, FOLD != 0>(in.g, pro, node, x, g, stash);
             in.load_z(Z, node, x, g, Lw - 16);
@@ -582,7 +664,7 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
                 if constexpr (F::SCALED) {                      // out of the scaled space (+ what the plane already holds)
 #pragma unroll
                     for (int rb = 0; rb < NRB; ++rb) {
-                        if (ACC && PL == 1 && lb == 0) z[rb] = z[rb] * ikz_sg + *reinterpret_cast<const f32x4*>(dZ.p[n] + (r0 + 16 * rb + x) * 16 + 4 * g);
+                        if (ACC && PL == 1 && lb == 0) z[rb] = z[rb] * ikz_sg + (PFG ? old[n][rb] : *reinterpret_cast<const f32x4*>(dZ.p[n] + (r0 + 16 * rb + x) * 16 + 4 * g));
                         else z[rb] *= ikz_sg;
                     }
                 }
@@ -642,6 +724,17 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
                             dWt[n][lb][c][hb] = F::mm(a, c == 0 ? gd[hb][p] : qd[c > 0 ? c - 1 : 0][hb][p], dWt[n][lb][c][hb]);
                 }
         if (PF) in = nx;
+        if constexpr (PFG) {
+            rows_cur = rows_nxt;
+#pragma unroll
+            for (int n = 0; n < K; ++n)
+#pragma unroll
+                for (int lb = 0; lb < LB; ++lb)
+#pragma unroll
+                    for (int kb = 0; kb < NRB; ++kb)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) in.za[n][lb][kb][t] = nx.za[n][lb][kb][t];
+        }
         node = next_node;
     }
     const float isg = 1.f / sg;                                // dW tiles of block c carry sg (c = 0) or sg sT (c >= 1); db carries sg
@@ -1003,7 +1096,9 @@ template <int NB2, int HB, int K, int L, int PRO = PRO_NONE, int PL = 0, int FOL
 int launch_bwd(const float* const* Z, const float* Tc, const float* W, const float* dY, float* const* dZ,
                float* partial, int* n_partials, int want_db, long long nodes, int Lw, hipStream_t stream, BwdPro pro = BwdPro{}) {
     constexpr int NRB = 2 * NB2, Ho = 16 * HB, LB = (L + 15) / 16, NBK = K * HB, S = (NBK + 1) / 2, nW = K * K * L * Ho;
-    const size_t frag = (size_t)((K - 1) * NRB * NB2 + K * LB * S) * F::NP * 64 * 16 + (FOLD ? (size_t)MF_WAVES * NRB * 64 * 16 : 0);
+    constexpr bool PFG = (PRO == PRO_GATES_CAND || PRO == PRO_BLEND) && PL != 0 && BwdSched<NB2, K>::waves == 1;      // as in the kernel
+    const size_t frag = (size_t)((K - 1) * NRB * NB2 + K * LB * S) * F::NP * 64 * 16 + (FOLD ? (size_t)MF_WAVES * NRB * 64 * 16 : 0)
+                        + (PFG ? (size_t)MF_WAVES * HB * NRB * 16 * 20 * 4 : 0);
     const size_t slabs = (size_t)MF_WAVES * (nW + Ho) * sizeof(float);
     const size_t lds = frag > slabs ? frag : slabs;
     if (lds > stc::kMaxLdsBytes) return STC_NOT_HANDLED;
