@@ -36,8 +36,10 @@ struct CellBwdArgs {
     const float* gmax; int n_gmax;              // fp16 x 2 format: slots whose maximum is max |dHnew| of this launch (device memory)
 };
 
-// per-wave LDS block: [stash_h 2 x 64 float4][stash_x 2 x 64 float4][tile 32 x CB_TRS floats]
-constexpr int CB_WAVE_BYTES = 2 * 64 * 16 + 2 * 64 * 16 + 32 * CB_TRS * 4;
+// per-wave LDS block: [stash_h 2 x 64 float4][stash_x 2 x 64 float4][CB_TILES transposition tiles of 32 x CB_TRS floats]
+constexpr int CB_TILES = 5;                     // dY, dBm, R*H (candidate phase), the two halves of the gates' dY
+constexpr int CB_TILE_FLOATS = 32 * CB_TRS;
+constexpr int CB_WAVE_BYTES = 2 * 64 * 16 + 2 * 64 * 16 + CB_TILES * CB_TILE_FLOATS * 4;
 constexpr int CB_TABLE_FRAGS = 2 + 8 + 4;       // T_1 (2), gates W (K LB S = 8), candidate W (K LB = 4)
 template <class F>
 constexpr size_t cb_lds_bytes() { return (size_t)CB_TABLE_FRAGS * F::NP * 64 * 16 + (size_t)CB_WAVES * CB_WAVE_BYTES; }
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
     unsigned char* mine = reinterpret_cast<unsigned char*>(WC + 4 * NP * 64) + (size_t)wave * CB_WAVE_BYTES;
     float4* stash_h = reinterpret_cast<float4*>(mine);               // the state's share of the gate prologue, lane-private
     float4* stash_x = stash_h + 2 * 64;                               // the candidate's X-side gradient, lane-private
-    float* tile = reinterpret_cast<float*>(stash_x + 2 * 64);         // d(R*H): row-on-lane -> accumulator layout
+    float* tiles = reinterpret_cast<float*>(stash_x + 2 * 64);        // row-on-lane -> accumulator layout (to_acc below)
     const int cin = a.Lw - 16;
 
     // FmtH2: table scales from the tables' own maxima (same in every workgroup), gradient scale from the producer's slots
@@ -137,12 +139,25 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
     const float* P0[K] = {PL == 1 ? a.X : a.H, PL == 1 ? a.SX : a.SH};          // block 0 of slab n
     const float* P1[K] = {PL == 1 ? a.H : a.X, PL == 1 ? a.SH : a.SX};          // block 1 of slab n (PL = 2: the narrow plane)
 
-    // One node's operands: slab columns and gate planes in accumulator layout (row 16kb + 4g + t, column x), and the gate planes again in
-    // row-on-lane layout (row 16kb + x, columns 4g .. 4g+3: the same lines, cache hits).
+    // One node's operands: the slab columns in accumulator layout (row 16kb + 4g + t, column x: the A operands of the dW products) and the
+    // gate planes in row-on-lane layout (row 16kb + x, columns 4g .. 4g+3).  Everything element-wise is formed ONCE, in row layout, and
+    // taken to the accumulator layout through per-wave LDS tiles (to_acc): the kernel used to load the five gate planes a second time in
+    // accumulator layout (40 four-byte loads per node, half of the node's load instructions) and to repeat the gate / blend arithmetic there.
     struct Ops {
         float zg[K][LB][NRB][4];
-        float ud[NRB][4], rd[NRB][4], cd[NRB][4], gn[NRB][4], bm[NRB][4];
         f32x4 uv[NRB], rv[NRB], cv[NRB], gv[NRB], hv[NRB], bv[NRB];
+    };
+    // rows 16kb + x of a pair of 16-row blocks, columns 4g .. 4g+3  ->  rows 16kb + 4g + t, column x.  Same wave writes and reads (LDS
+    // operations of a wave complete in order); stride CB_TRS: conflict-free both ways.
+    auto to_acc = [&](int which, const f32x4 (&v)[NRB], f32x4 (&d)[NRB]) {
+        float* t = tiles + which * CB_TILE_FLOATS;
+#pragma unroll
+        for (int kb = 0; kb < NRB; ++kb) *reinterpret_cast<f32x4*>(t + (16 * kb + x) * CB_TRS + 4 * g) = v[kb];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int kb = 0; kb < NRB; ++kb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) d[kb][i] = t[(16 * kb + 4 * g + i) * CB_TRS + x];
     };
     float* const dP[K][LB] = {{PL == 1 ? a.dX : a.dH, PL == 1 ? a.dH : nullptr}, {PL == 1 ? a.dSX : a.dSH, PL == 1 ? a.dSH : nullptr}};
     constexpr bool ACC[LB] = {PL == 1 ? ACCX != 0 : ACCH != 0, PL == 1 ? ACCH != 0 : false};      // per block of the row
@@ -159,7 +174,6 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
                     if constexpr (PL == 1) o.zg[n][1][kb][t] = P1[n][e];
                     else o.zg[n][1][kb][t] = x < cin ? P1[n][row * cin + x] : 0.f;
                 }
-                o.ud[kb][t] = a.U[e]; o.rd[kb][t] = a.R[e]; o.cd[kb][t] = a.Cand[e]; o.gn[kb][t] = a.dHnew[e]; o.bm[kb][t] = a.dBm[e];
             }
 #pragma unroll
         for (int kb = 0; kb < NRB; ++kb) {
@@ -201,31 +215,37 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
 #pragma unroll
             for (int kb = 0; kb < NRB; ++kb) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) { cur.gn[kb][t] *= sg; cur.bm[kb][t] *= sg; }
-#pragma unroll
                 for (int i = 0; i < 4; ++i) { cur.gv[kb][i] *= sg; cur.bv[kb][i] *= sg; }
             }
         }
         const auto& zg = cur.zg;
-        const auto &ud = cur.ud, &rd = cur.rd, &cd = cur.cd, &gn = cur.gn, &bm = cur.bm;
         const auto &uv = cur.uv, &rv = cur.rv, &cv = cur.cv, &gv = cur.gv, &hv = cur.hv, &bv = cur.bv;
         const int lo = opaque(lane);
-        const float (&hd)[NRB][4] = zg[0][RHB];                    // the previous state H in accumulator layout
 
         // =========================================================== candidate convolution (post-aggregation form): dA = dY, dBm given
         f32x4 drh[NRB];                                            // gradient of the R*H plane, row-on-lane layout
         {
             DyFrag<NRB, 1> gr[K];
+            f32x4 rh_v[NRB], rh_d[NRB];                             // R*H, the candidate's second input plane (re-formed, not stored by the forward)
+            {
+                f32x4 v0[NRB], v1[NRB], d0[NRB], d1[NRB];
 #pragma unroll
-            for (int kb = 0; kb < NRB; ++kb) {
+                for (int kb = 0; kb < NRB; ++kb) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    gr[0].d[kb][0][t] = gn[kb][t] * ud[kb][t] * (1.f - cd[kb][t] * cd[kb][t]);      // dY = dHnew * U * (1 - Cand^2)
-                    gr[1].d[kb][0][t] = bm[kb][t];
+                    for (int i = 0; i < 4; ++i) {
+                        v0[kb][i] = gv[kb][i] * uv[kb][i] * (1.f - cv[kb][i] * cv[kb][i]);      // dY = dHnew * U * (1 - Cand^2)
+                        rh_v[kb][i] = rv[kb][i] * hv[kb][i];
+                    }
+                    v1[kb] = bv[kb];
                 }
+                to_acc(0, v0, d0);
+                to_acc(1, v1, d1);
+                to_acc(2, rh_v, rh_d);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) gr[0].v[kb][0][i] = gv[kb][i] * uv[kb][i] * (1.f - cv[kb][i] * cv[kb][i]);
-                gr[1].v[kb][0] = bv[kb];
+                for (int kb = 0; kb < NRB; ++kb) {
+                    gr[0].v[kb][0] = v0[kb]; gr[1].v[kb][0] = v1[kb];
+                    gr[0].d[kb][0] = d0[kb]; gr[1].d[kb][0] = d1[kb];
+                }
             }
 #pragma unroll
             for (int kb = 0; kb < NRB; ++kb)
@@ -277,8 +297,8 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
                 f32x4 c0, c1;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    c0[t] = lb == RHB ? rd[0][t] * hd[0][t] : zg[0][lb][0][t];
-                    c1[t] = lb == RHB ? rd[1][t] * hd[1][t] : zg[0][lb][1][t];
+                    c0[t] = lb == RHB ? rh_d[0][t] : zg[0][lb][0][t];
+                    c1[t] = lb == RHB ? rh_d[1][t] : zg[0][lb][1][t];
                 }
                 const Op za = F::split(c0, c1);
 #pragma unroll
@@ -291,29 +311,26 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
         // =========================================================== gate + blend backward (prologue of the gates convolution)
         DyFrag<NRB, 2> gr;
         {
-#pragma unroll
-            for (int rb = 0; rb < NRB; ++rb)
-                *reinterpret_cast<f32x4*>(tile + (16 * rb + x) * CB_TRS + 4 * g) = drh[rb];
-            __builtin_amdgcn_wave_barrier();
+            f32x4 v0[NRB], v1[NRB], d0[NRB], d1[NRB];
 #pragma unroll
             for (int kb = 0; kb < NRB; ++kb) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const float u = ud[kb][t], r = rd[kb][t], h = hd[kb][t];
-                    const float dr = tile[(16 * kb + 4 * g + t) * CB_TRS + x];
-                    gr.d[kb][0][t] = gn[kb][t] * (cd[kb][t] - h) * u * (1.f - u);
-                    gr.d[kb][1][t] = dr * h * r * (1.f - r);
-                }
                 f32x4 own;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float u = uv[kb][i], r = rv[kb][i], h = hv[kb][i], d = drh[kb][i];
-                    gr.v[kb][0][i] = gv[kb][i] * (cv[kb][i] - h) * u * (1.f - u);
-                    gr.v[kb][1][i] = d * h * r * (1.f - r);
+                    v0[kb][i] = gv[kb][i] * (cv[kb][i] - h) * u * (1.f - u);
+                    v1[kb][i] = d * h * r * (1.f - r);
                     own[i] = d * r + gv[kb][i] * (1.f - u);        // what H is owed directly: reset-gate path + its share of the blend
                     if constexpr (F::SCALED) own[i] *= kg;          // the H plane's gates tile starts from it
                 }
                 stash_h[kb * 64 + lane] = make_float4(own[0], own[1], own[2], own[3]);
+            }
+            to_acc(3, v0, d0);
+            to_acc(4, v1, d1);
+#pragma unroll
+            for (int kb = 0; kb < NRB; ++kb) {
+                gr.v[kb][0] = v0[kb]; gr.v[kb][1] = v1[kb];
+                gr.d[kb][0] = d0[kb]; gr.d[kb][1] = d1[kb];
             }
             __builtin_amdgcn_wave_barrier();
         }
