@@ -190,9 +190,10 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
     const Op tb0 = F::get(TB, 0, lane), tb1 = F::get(TB, 1, lane);
     // FmtH2 factors (all powers of two; 1 for FmtB3): what a tile of each phase carries besides sg, and their inverses
     const float kc = sT * sWc, kg = sT * sWg, ikc = 1.f / kc, ikg_sg = 1.f / (kg * sg);
-    Ops cur, nxt;
+    Ops cur, nxt, nx2;                            // operands two nodes ahead: ~40 MB in flight chip-wide instead of 20
     int node = blockIdx.x * CB_WAVES + wave;
     if (node < a.nodes) load_ops(cur, node);
+    if (node + nw < a.nodes) load_ops(nxt, node + nw);
     // The first node's loads are waited for HERE: left pending into the loop, the compiler's wait-count pass merges them with the loop's own
     // state and makes every iteration wait for the loads it has just issued for the NEXT node (vmcnt counts in order) -- no prefetch at all.
     __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0), expcnt / lgkmcnt untouched
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
 #pragma unroll
                 for (int rb = 0; rb < NRB; ++rb)
                     if (ACC[lb]) old[n][lb][rb] = *reinterpret_cast<const f32x4*>(dP[n][lb] + ((size_t)node * C + 16 * rb + x) * HID + 4 * g);
-        if (next_node < a.nodes) load_ops(nxt, next_node);         // software prefetch: lands while this node computes
+        if (next_node + nw < a.nodes) load_ops(nx2, next_node + nw);      // software prefetch, two nodes ahead
         __builtin_amdgcn_sched_barrier(0);
         const size_t r0 = (size_t)node * C;
         if constexpr (F::SCALED) {                                 // the gradient operands enter the scaled space: everything below is linear in them
@@ -420,6 +421,7 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
                     for (int hb = 0; hb < 2; ++hb) dWg[n][lb][c][hb] = F::mm(za, c == 0 ? gd[hb] : qd[hb], dWg[n][lb][c][hb]);
             }
         cur = nxt;
+        nxt = nx2;
         node = next_node;
     }
 
