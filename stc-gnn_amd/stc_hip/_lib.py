@@ -229,18 +229,27 @@ class HipKernels:
             raise StcError(f'stc_set_dispatch_level({level}) failed: {self.lib.stc_last_error().decode()}')
 
     def _launch(self, name, on, *args, nbytes=0, tag=None):
-        """Call C entry point ``name`` with ``args`` + the current stream of ``on``'s device."""
+        """Call C entry point ``name`` with ``args`` + the current stream of ``on``'s device.
+
+        The host side of a launch matters at small shapes: at the SF shape a train step is ~700 launches of ~7 us of GPU time each, and the
+        ``torch.cuda.device`` context + ``torch.cuda.current_stream`` objects alone cost more than that per launch
+        (tools/probes/sf_host_profile.py).  So: the raw stream handle straight from torch's C layer, and a device switch only when the
+        tensor does not live on the current device."""
         fn = getattr(self.lib, name)
-        with torch.cuda.device(on.device):
-            stream = torch.cuda.current_stream(on.device)
-            if self.timer is None:
-                rc = fn(*args, stream.cuda_stream)
-            else:
-                start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                start.record(stream)
-                rc = fn(*args, stream.cuda_stream)
-                end.record(stream)
-                self.timer.add(name, start, end, nbytes, tag)
+        index = on.device.index
+        if self.timer is None and index == torch._C._cuda_getDevice():
+            rc = fn(*args, torch._C._cuda_getCurrentRawStream(index))
+        else:
+            with torch.cuda.device(on.device):
+                stream = torch.cuda.current_stream(on.device)
+                if self.timer is None:
+                    rc = fn(*args, stream.cuda_stream)
+                else:
+                    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    start.record(stream)
+                    rc = fn(*args, stream.cuda_stream)
+                    end.record(stream)
+                    self.timer.add(name, start, end, nbytes, tag)
         if rc != 0:
             msg = self.lib.stc_last_error()
             raise StcError(f'{name} failed with code {rc}: {msg.decode() if msg else "?"}')
@@ -462,14 +471,15 @@ class HipKernels:
             self._f32('node.bias', bias, (Ho,))
         self._f32('node.Y', Y, (R, Cc, Ho))
         self._same_device(*Zs, Tc, W, bias, Y)
-        self._launch('stc_bdg_node_fwd_f32', Y, self._ptr_array(Zs), Ks, _ptr(Tc), Kc, _ptr(W), _ptr(bias), _ptr(Y), R, Cc, L, Lw, Ho)
+        self._launch('stc_bdg_node_fwd_f32', Y, self._ptr_array(Zs), Ks, _ptr(Tc), Kc, _ptr(W), _ptr(bias), _ptr(Y), R, Cc, L, Lw, Ho,
+                     nbytes=4 * R * Cc * (Ks * L + Ho))          # the Ks slabs in, Y out
 
     def _get_workspace(self, device, nbytes):
         """Scratch for the backward kernels' per-workgroup partial sums: one buffer per (device, stream) -- launches on two
         streams never share one -- sized up front for the largest shape on the matrix-core paths, so that it is not replaced
         in practice; if a larger request does come, the old buffer is KEPT alive (a captured HIP graph or a launch still in
         flight may hold its address) and a new one is used from then on."""
-        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        key = (device, torch._C._cuda_getCurrentRawStream(device.index if device.index is not None else torch._C._cuda_getDevice()))
         ws = self._workspace.get(key)
         if ws is None or ws.numel() < nbytes:
             if ws is not None:
@@ -499,7 +509,8 @@ class HipKernels:
         self._same_device(*Zs, Tc, W, dY, *dZs, dW, db, dTc)
         nbytes = self.lib.stc_bdg_node_bwd_workspace_bytes(Ks, Kc, Cc, L, Ho, int(dTc is not None))
         ws = self._get_workspace(dY.device, nbytes)
-        self._launch('stc_bdg_node_bwd_f32', dY, self._ptr_array(Zs), Ks, _ptr(Tc), Kc, _ptr(W), _ptr(dY), self._ptr_array(dZs), _ptr(dW), _ptr(db), _ptr(dTc), _ptr(ws), ws.numel(), R, Cc, L, Lw, Ho)
+        self._launch('stc_bdg_node_bwd_f32', dY, self._ptr_array(Zs), Ks, _ptr(Tc), Kc, _ptr(W), _ptr(dY), self._ptr_array(dZs), _ptr(dW), _ptr(db), _ptr(dTc), _ptr(ws), ws.numel(), R, Cc, L, Lw, Ho,
+                     nbytes=4 * R * Cc * (2 * Ks * L + Ho))      # the Ks slabs and dY in, the Ks gradient slabs out
 
     # ---- bf16 storage (configuration 5) ------------------------------------------------------------
     def node_bf16_supported(self, Ks, Kc, Cc, L, Ho) -> bool:
