@@ -75,6 +75,7 @@ def parse(argv=None):
     ap.add_argument('--hip-graph', action='store_true',
                     help='(one GPU; not the default line) time replays of the train step captured into a HIP graph: removes the launch gaps that '
                          'matter at small N; the per-kernel events then come from eager steps after the timed region')
+    ap.add_argument('--eager', dest='hip_graph', action='store_false', help='per-launch dispatch where a preset defaults to HIP-graph replay (--preset sf)')
     ap.add_argument('--storage', choices=('f32', 'bf16'), default='f32',
                     help='storage type of states / gates / their gradients: f32 = the metric (reference arithmetic); bf16 = BASELINE configuration 5 '
                          '(not the metric: bf16 has no reference behaviour), fp32 parameters and fp32 sums inside every kernel')
@@ -85,7 +86,8 @@ def parse(argv=None):
     elif pre.preset == 'cfg5':
         ap.set_defaults(categories=64, storage='bf16', no_cpu_baseline=True)
     elif pre.preset == 'sf':
-        ap.set_defaults(grid=10, categories=5, obs=9, pred=3, batch_per_gpu=32, no_unit_d3=True)
+        # launch-bound (~700 launches of ~7 us per step): the step is replayed from ONE captured HIP graph (--eager keeps per-launch dispatch)
+        ap.set_defaults(grid=10, categories=5, obs=9, pred=3, batch_per_gpu=32, no_unit_d3=True, hip_graph=True)
     a = ap.parse_args(argv)
     if a.global_batch:
         if a.global_batch % a.gpus:
