@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define STC_ABI_VERSION 16
+#define STC_ABI_VERSION 17
 #define STC_MAX_K 4          /* highest Chebyshev order (Ks, Kc) the node kernels accept */
 
 /* Operand formats of the split-operand matrix-core kernels (C = 32 / 64, hidden 16).  Every fp32 operand is split into low-precision
@@ -159,6 +159,13 @@ int stc_gru_blend_bwd_bf16(const void* dHnew, const void* U, const void* Cand, v
 int stc_head_fwd_bf16(const void* H, const float* w, const float* b, float* y, int64_t rows, int32_t h, void* stream);
 int stc_head_bwd_bf16(const void* H, const float* w, const float* y, const float* dy, void* dH, float* dwb,
                       void* workspace, size_t workspace_bytes, int64_t rows, int32_t h, void* stream);
+
+/* The same product with a DENSE graph matrix (the reference's learned Gs is dense: STC_GNN.py:227-243; this is :37 and its autograd
+ * w.r.t. the features as they stand in the reference):  Y[b] = alpha * S x X[b] + beta * Y0[b],  S (n_rows, n_cols) row-major,
+ * X (batch, n_cols, F), Y0 / Y (batch, n_rows, F); Y0 may be NULL when beta == 0 and may alias Y.  Runs on the exact-fp32 matrix
+ * cores (v_mfma_f32_16x16x4_f32: an fmaf chain per output element), any sizes. */
+int stc_dense_agg_f32(const float* S, int32_t n_rows, int32_t n_cols, const float* X, const float* Y0, float* Y,
+                      int32_t batch, int32_t F, float alpha, float beta, void* stream);
 
 /* out[j] (+)= alpha * sum_b < A[b,i,:], Bm[b,colidx[j],:] >   for j in row i
  * A (batch, n_rows, F), Bm (batch, n_cols, F), out (nnz).  Gradient of the

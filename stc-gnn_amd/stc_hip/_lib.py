@@ -19,7 +19,7 @@ import torch
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG_ROOT, 'libstc_hip.so')
-ABI_VERSION = 16
+ABI_VERSION = 17
 FMT_BF16X3, FMT_F16X2 = 0, 1          # STC_FMT_* of include/stc_hip.h: operand formats of the split-operand matrix-core kernels
 MAX_K = 4
 SPMM_SUM_MAX_ADD = 8     # = STC_SPMM_SUM_MAX_ADD of include/stc_hip.h
@@ -30,7 +30,7 @@ EXPORTS = (
     'stc_csr_spmm_f32', 'stc_bcsr_spmm_f32', 'stc_csr_spmm_bf16', 'stc_bcsr_spmm_bf16', 'stc_bdg_node_bf16_supported', 'stc_bdg_node_fwd_bf16', 'stc_bdg_node_bwd_bf16',
     'stc_cell_planar_bf16_supported', 'stc_cell_gates_fwd_planar_bf16', 'stc_cell_gates_bwd_planar_bf16', 'stc_bdg_node_post_bwd_bf16',
     'stc_spmm_blend_fwd_bf16', 'stc_spmm_sum_bf16', 'stc_gru_blend_bwd_bf16', 'stc_head_fwd_bf16', 'stc_head_bwd_bf16',
-    'stc_csr_sddmm_f32', 'stc_set_dispatch_level',
+    'stc_csr_sddmm_f32', 'stc_set_dispatch_level', 'stc_dense_agg_f32',
     'stc_cheby_dense_fwd_f32', 'stc_cheby_dense_bwd_f32',
     'stc_bdg_node_fwd_f32', 'stc_bdg_node_bwd_workspace_bytes', 'stc_bdg_node_bwd_f32',
     'stc_bdg_node_post_supported', 'stc_bdg_node_post_fwd_f32', 'stc_bdg_node_post_bwd_f32', 'stc_spmm_blend_fwd_f32',
@@ -65,6 +65,7 @@ def _declare(lib):
         'stc_bcsr_spmm_f32': [_p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _f32, _p],
         'stc_csr_spmm_bf16': [_p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _f32, _p],
         'stc_bcsr_spmm_bf16': [_p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _f32, _p],
+        'stc_dense_agg_f32': [_p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _f32, _p],
         'stc_csr_sddmm_f32': [_p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _i32, _p],
         'stc_cheby_dense_fwd_f32': [_p, _i32, _i32, _p, _p],
         'stc_cheby_dense_bwd_f32': [_p, _p, _p, _i32, _i32, _p, _p],
@@ -319,6 +320,12 @@ class HipKernels:
         self._f32('spmm.val', val, (colidx.numel(),))
         self._same_device(rowptr, colidx, val, X, Y0, Y)
         plain = Y0 is None or beta == 0
+        if plan is None:
+            from .graph import is_full_pattern
+            if is_full_pattern(colidx, n_rows, n_cols):       # a learned dense graph: the product is dense -> exact-fp32 matrix cores
+                self._launch('stc_dense_agg_f32', X, _ptr(val), n_rows, n_cols, _ptr(X), _ptr(Y0), _ptr(Y), B, F, float(alpha), float(beta),
+                             nbytes=4 * n_rows * n_cols + (2 if plain else 3) * 4 * B * n_rows * F, tag='dense')
+                return
         nbytes = colidx.numel() * 8 + 4 * (n_rows + 1) + (2 if plain else 3) * 4 * B * n_rows * F
         tag = 'plain' if plain else 'with_y0'
         # row-blocked kernel: rows of >= 64 floats, or narrow rows of 4 / 8 / 16 / 32 floats (the layer-0 input plane: several row

@@ -244,6 +244,7 @@ class SpatialOperand:
 
 
 _PATTERN_CACHE: Dict[Tuple[int, torch.device], Tuple[torch.Tensor, torch.Tensor]] = {}
+_PATTERN_PTRS: Dict[int, int] = {}          # address of a cached colidx -> its n
 
 
 def full_pattern(n: int, device: torch.device):
@@ -258,7 +259,16 @@ def full_pattern(n: int, device: torch.device):
         colidx = torch.arange(n, dtype=torch.int32).repeat(n).to(device)
         got = (rowptr, colidx)
         _PATTERN_CACHE[key] = got
+        _PATTERN_PTRS[colidx.data_ptr()] = n
     return got
+
+
+def is_full_pattern(colidx: torch.Tensor, n_rows: int, n_cols: int) -> bool:
+    """Whether ``colidx`` IS the cached column array of the dense pattern (``full_pattern``): the values that go with it are then a dense
+    row-major (n_rows, n_cols) matrix, and the aggregation is a dense product (``stc_dense_agg_f32``)."""
+    if n_rows != n_cols or colidx.numel() != n_rows * n_cols:
+        return False
+    return _PATTERN_PTRS.get(colidx.data_ptr()) == n_cols          # (the cache keeps the array alive, so the address cannot be reused)
 
 
 def dense_operand(Gs: torch.Tensor) -> SpatialOperand:

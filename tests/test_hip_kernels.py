@@ -12,6 +12,7 @@ import pytest
 import torch
 
 from oracle.kernel_emul import EmulatedKernels
+from stc_hip._lib import KernelTimer
 from stc_hip import CsrGraph
 from tests.conftest import rel_err
 
@@ -102,6 +103,34 @@ def test_bcsr_spmm_equals_csr(hip, n, F, B, hw):
             hip.csr_spmm(rp, ci, vals, n, n, cu(X), blocked if beta else None, blocked, alpha, beta, plan=plan)
             assert rel_err(csr, want) < TOL and rel_err(blocked, want) < TOL
             assert rel_err(blocked, csr) < 2e-6
+
+
+@pytest.mark.parametrize('n,F,B', [(100, 160, 32), (100, 100, 3), (12, 20, 2), (200, 256, 4), (37, 7, 1), (300, 64, 2), (16, 16, 1)])
+@pytest.mark.parametrize('alpha,beta', [(1.0, 0.0), (2.0, -1.0)])
+def test_dense_graph_aggregation(hip, n, F, B, alpha, beta):
+    """stc_dense_agg_f32 (exact-fp32 matrix cores): Y = alpha S.X + beta Y0 with a dense S -- what ``csr_spmm`` launches when it is handed the
+    full N x N pattern of a learned graph -- against the dense product in float64 and against the CSR kernel on the same values; sizes
+    off every tile boundary (rows / graph columns not multiples of 16 / 4, feature columns not a multiple of 16), in place (Y0 = Y)."""
+    from stc_hip.graph import full_pattern, is_full_pattern
+    g = torch.Generator().manual_seed(n + F)
+    S = torch.softmax(torch.randn(n, n, generator=g), -1)
+    X, Y0 = torch.randn(B, n, F, generator=g), torch.randn(B, n, F, generator=g)
+    want = (alpha * torch.einsum('rc,bcf->brf', S.double(), X.double()) + beta * Y0.double()).float()
+    rowptr, colidx = full_pattern(n, torch.device('cuda'))
+    assert is_full_pattern(colidx, n, n) and not is_full_pattern(colidx.clone(), n, n)
+    val = cu(S).reshape(-1)
+    Y = Y0.clone().cuda()
+    hip.timer = KernelTimer()
+    try:
+        hip.csr_spmm(rowptr, colidx, val, n, n, cu(X), Y if beta else None, Y, alpha, beta)          # in place when there is a Y0
+        names = set(hip.timer.summary())
+    finally:
+        hip.timer = None
+    assert names == {'stc_dense_agg_f32'}, names
+    assert rel_err(Y, want) < TOL
+    Yc = Y0.clone().cuda()
+    hip.csr_spmm(rowptr, colidx.clone(), val, n, n, cu(X), Yc if beta else None, Yc, alpha, beta)     # same values through the CSR kernel
+    assert rel_err(Y, Yc) < 2e-6
 
 
 def test_row_block_plan_fetch_counts():

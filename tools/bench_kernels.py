@@ -49,7 +49,7 @@ def main():
     plan_f = (g['fwd_blk_ptr'], g['fwd_blk_cols'], g['fwd_blk_vals']) if not a.no_tile else None
     plan_b = (g['bwd_blk_ptr'], g['bwd_blk_cols'], g['bwd_blk_vals']) if not a.no_tile else None
     print(f'# N={N} nnz={nnz} C={C} h={h} K={K} B={B} permute={a.permute} '
-          f'SPMM_VARIANT={os.environ.get("STC_SPMM_VARIANT", "default")} row_blocked={plan_f is not None}')
+          f"row_blocked={plan_f is not None}")
 
     def report(name, us, nbytes):
         print(f'{name:44s} {us:9.1f} us   {nbytes/1e6:9.1f} MB   {nbytes/us/1e3:8.1f} GB/s', flush=True)
