@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define STC_ABI_VERSION 17
+#define STC_ABI_VERSION 18
 #define STC_MAX_K 4          /* highest Chebyshev order (Ks, Kc) the node kernels accept */
 
 /* Operand formats of the split-operand matrix-core kernels (C = 32 / 64, hidden 16).  Every fp32 operand is split into low-precision
@@ -433,6 +433,35 @@ size_t stc_head_bwd_workspace_bytes(int32_t h);
 int stc_head_bwd_f32(const float* H, const float* w, const float* y, const float* dy,
                      float* dH, float* dwb, void* workspace, size_t workspace_bytes,
                      int64_t rows, int32_t h, void* stream);
+
+/* ---- small graphs: one STC_Cell step in ONE launch (ABI v18) ------------------
+ * Reference STC_GNN.py:65-79 (STC_Cell.forward, with BDG_Dif :31-47 for the gates and the candidate) and its autograd, for graphs small
+ * enough that a sample's planes stay in cache (the SF-incidents shape: N = 100, C = 5): one workgroup per sample runs the aggregation,
+ * the gates convolution, sigmoid, reset, the second aggregation, the candidate convolution, tanh and the GRU blend in sequence, on the
+ * exact-fp32 matrix cores.  Ks = 2, Kc = 2, hidden 16, C <= 16, cin = 16 or 1..4 (stc_cell_small_supported).
+ *   X (batch, N, C, cin), H (batch, N, C, 16): Xt and Ht_1;  CSR (rowptr, colidx, val) of Gs^T (forward) / of Gs (backward), fixed graphs;
+ *   Tc (Kc, C, C): Chebyshev stack of the category graph;  Wg (Ks*Kc*(cin+16), 32), bg (32) | NULL, Wc (.., 16), bc (16) | NULL in the
+ *   reference's layout;  outputs U, R, Cand, Hnew (batch, N, C, 16) and, kept for the backward, RH = R*H, Zg = Gs^T x [H | Xt | 0]
+ *   (batch, N*C, 16 + 4*XQ floats per row, XQ = 4 for cin = 16 else 1) and Zc = Gs^T x RH (batch, N*C, 16).
+ * Backward: dHnew -> dX / dH (NULL = not wanted; accumulate_x / accumulate_h: ADD to what the buffer holds, the state's other consumer
+ * having written it) and the parameter gradients ADDED into row b of dparams (batch, params_ld):
+ *   [dWg (Ks*Kc*L*32) | dbg (32) | dWc (Ks*Kc*L*16) | dbc (16)], L = cin + 16 -- per-sample partials, no atomics: the caller zeroes
+ * the buffer once per backward pass, every cell of a layer adds to it, and one sum over the batch finishes the gradient.
+ * workspace: stc_cell_small_workspace_bytes(N, C, cin, batch), 16-byte aligned. */
+int stc_cell_small_supported(int32_t Ks, int32_t Kc, int32_t C, int32_t cin, int32_t h);
+size_t stc_cell_small_workspace_bytes(int32_t n_nodes, int32_t C, int32_t cin, int32_t batch);
+int stc_cell_small_fwd_f32(const int32_t* rowptr, const int32_t* colidx, const float* val, int32_t n_nodes,
+                           const float* X, int32_t cin, const float* H, const float* Tc, int32_t Kc,
+                           const float* Wg, const float* bg, const float* Wc, const float* bc,
+                           float* U, float* R, float* Cand, float* Hnew, float* RH, float* Zg, float* Zc,
+                           int32_t batch, int32_t C, void* stream);
+int stc_cell_small_bwd_f32(const int32_t* rowptr, const int32_t* colidx, const float* val, int32_t n_nodes,
+                           const float* X, int32_t cin, const float* H, const float* Tc, int32_t Kc,
+                           const float* Wg, const float* Wc, const float* U, const float* R, const float* Cand,
+                           const float* RH, const float* Zg, const float* Zc, const float* dHnew,
+                           float* dX, int32_t accumulate_x, float* dH, int32_t accumulate_h,
+                           float* dparams, int64_t params_ld, int32_t has_bg, int32_t has_bc,
+                           void* workspace, size_t workspace_bytes, int32_t batch, int32_t C, void* stream);
 
 /* ---- small helpers ---------------------------------------------------------
  * y += a*x over n elements (Chebyshev backward g_{k-2} -= g_k) */

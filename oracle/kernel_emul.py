@@ -213,6 +213,90 @@ class EmulatedKernels:
                     U += Zs[n][..., :Lw] @ Wv[n, c]
                 dTc[c].copy_(torch.einsum('rpo,rdo->pd', U, dY))
 
+    # ---- stc_cell_small_fwd/bwd_f32: one STC_Cell step of a small graph per launch (STC_GNN.py:65-79 and its autograd)
+    SMALL_MAX_ROWS = 4096
+
+    def cell_small_supported(self, Ks, Kc, Cc, cin, h, n_nodes=0) -> bool:
+        return Ks == 2 and Kc == 2 and 1 <= Cc <= 16 and h == 16 and (cin == 16 or 1 <= cin <= 4) and n_nodes * Cc <= self.SMALL_MAX_ROWS
+
+    @staticmethod
+    def cell_small_zg_width(cin) -> int:
+        return 32 if cin == 16 else 20
+
+    @staticmethod
+    def cell_small_params(Ks, Kc, cin, h=16) -> int:
+        return Ks * Kc * (cin + h) * 3 * h + 3 * h
+
+    def _small_agg(self, rowptr, colidx, val, T):
+        """S.T over the node axis of T (B, N, C, w)."""
+        B, N, Cc, w = T.shape
+        out = torch.empty(B, N, Cc * w, dtype=T.dtype)
+        self.csr_spmm(rowptr, colidx, val, N, N, T.reshape(B, N, Cc * w), None, out, 1.0, 0.0)
+        return out.view(B, N, Cc, w)
+
+    def cell_small_fwd(self, rowptr, colidx, val, X, H, Tc, Wg, bg, Wc, bc, U, R, Cand, Hnew, RH, Zg, Zc, checked=True):
+        B, N, Cc, h = H.shape
+        cin = X.shape[-1]
+        rows = lambda t: t.reshape(B * N, Cc, t.shape[-1])
+        XH = torch.cat([X, H], -1)
+        SXH = self._small_agg(rowptr, colidx, val, XH)
+        G = torch.empty(B * N, Cc, 2 * h, dtype=H.dtype)
+        self.bdg_node_fwd([rows(XH), rows(SXH)], Tc, Wg, bg, G)
+        G = G.view(B, N, Cc, 2 * h)
+        U.copy_(torch.sigmoid(G[..., :h]))
+        R.copy_(torch.sigmoid(G[..., h:]))
+        RH.copy_(R * H)
+        SRH = self._small_agg(rowptr, colidx, val, RH)
+        Zg.zero_()
+        Zgv = Zg.view(B, N, Cc, Zg.shape[-1])
+        Zgv[..., :h] = SXH[..., cin:]
+        Zgv[..., h:h + cin] = SXH[..., :cin]
+        Zc.copy_(SRH.reshape(B, N * Cc, h))
+        Y = torch.empty(B * N, Cc, h, dtype=H.dtype)
+        self.bdg_node_fwd([rows(torch.cat([X, RH], -1)), rows(torch.cat([SXH[..., :cin], SRH], -1))], Tc, Wc, bc, Y)
+        Cand.copy_(torch.tanh(Y.view(B, N, Cc, h)))
+        Hnew.copy_((1.0 - U) * H + U * Cand)
+
+    def cell_small_bwd(self, rowptr, colidx, val, X, H, Tc, Wg, Wc, U, R, Cand, RH, Zg, Zc, dHnew, dX, accumulate_x, dH, accumulate_h,
+                       dparams, has_bg, has_bc, checked=True):
+        B, N, Cc, h = H.shape
+        cin = X.shape[-1]
+        L = cin + h
+        Kc = Tc.shape[0]
+        Zgv = Zg.view(B, N, Cc, Zg.shape[-1])
+        SX, SH, SRH = Zgv[..., h:h + cin], Zgv[..., :h], Zc.view(B, N, Cc, h)
+        nW = 2 * Kc * L
+        dWg, dbg = dparams[:, :nW * 2 * h], dparams[:, nW * 2 * h:nW * 2 * h + 2 * h]
+        dWc, dbc = dparams[:, nW * 2 * h + 2 * h:nW * 3 * h + 2 * h], dparams[:, nW * 3 * h + 2 * h:nW * 3 * h + 3 * h]
+
+        def conv_bwd(Z0, Z1, W, dY, dW_rows, db_rows):
+            """d[Z0] + S^T d[Z1] of one convolution (B, N, C, L); parameter gradients per sample."""
+            out = torch.empty(B, N, Cc, L, dtype=H.dtype)
+            for b in range(B):
+                dZ = [torch.empty(N, Cc, L, dtype=H.dtype), torch.empty(N, Cc, L, dtype=H.dtype)]
+                dW, db = torch.empty_like(W), torch.empty(W.shape[1], dtype=H.dtype)
+                self.bdg_node_bwd([Z0[b], Z1[b]], Tc, W, dY[b], dZ, dW, db, None)
+                dW_rows[b] += dW.reshape(-1)
+                if db_rows is not None:
+                    db_rows[b] += db
+                back = torch.empty(1, N, Cc * L, dtype=H.dtype)
+                self.csr_spmm(rowptr, colidx, val, N, N, dZ[1].reshape(1, N, Cc * L), dZ[0].reshape(1, N, Cc * L), back, 1.0, 1.0)
+                out[b] = back.view(N, Cc, L)
+            return out
+
+        dCpre = dHnew * U * (1.0 - Cand * Cand)
+        dCI = conv_bwd(torch.cat([X, RH], -1), torch.cat([SX, SRH], -1), Wc, dCpre, dWc, dbc if has_bc else None)
+        dRH, dXc = dCI[..., cin:], dCI[..., :cin]
+        dGu = dHnew * (Cand - H) * U * (1.0 - U)
+        dGr = dRH * H * R * (1.0 - R)
+        dXH = conv_bwd(torch.cat([X, H], -1), torch.cat([SX, SH], -1), Wg, torch.cat([dGu, dGr], -1), dWg, dbg if has_bg else None)
+        if dH is not None:
+            g = dHnew * (1.0 - U) + dRH * R + dXH[..., cin:]
+            dH.copy_(dH + g if accumulate_h else g)
+        if dX is not None:
+            g = dXc + dXH[..., :cin]
+            dX.copy_(dX + g if accumulate_x else g)
+
     # ---- stc_bdg_node_post_bwd_f32: Y = A + S.Bm (Ks = Kc = 2); backward from (X, dA, dBm)
     def node_post_supported(self, Ks, Kc, Cc, L, Ho) -> bool:
         return Ks == 2 and Kc == 2

@@ -19,7 +19,7 @@ import torch
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG_ROOT, 'libstc_hip.so')
-ABI_VERSION = 17
+ABI_VERSION = 18
 FMT_BF16X3, FMT_F16X2 = 0, 1          # STC_FMT_* of include/stc_hip.h: operand formats of the split-operand matrix-core kernels
 MAX_K = 4
 SPMM_SUM_MAX_ADD = 8     # = STC_SPMM_SUM_MAX_ADD of include/stc_hip.h
@@ -39,6 +39,7 @@ EXPORTS = (
     'stc_cell_bwd_planar_supported', 'stc_cell_bwd_planar_workspace_bytes', 'stc_cell_bwd_planar_f32',
     'stc_cell_planar_k_supported', 'stc_cell_gates_fwd_planar_k_f32', 'stc_cell_cand_fwd_planar_k_f32', 'stc_cell_gates_bwd_planar_k_f32',
     'stc_cell_cand_bwd_planar_k_f32',
+    'stc_cell_small_supported', 'stc_cell_small_workspace_bytes', 'stc_cell_small_fwd_f32', 'stc_cell_small_bwd_f32',
     'stc_gru_gates_fwd_f32', 'stc_gru_gates_bwd_f32', 'stc_gru_blend_fwd_f32', 'stc_gru_blend_bwd_f32',
     'stc_head_fwd_f32', 'stc_head_bwd_workspace_bytes', 'stc_head_bwd_f32',
     'stc_axpy_f32', 'stc_concat2_f32', 'stc_split2_f32',
@@ -66,6 +67,9 @@ def _declare(lib):
         'stc_csr_spmm_bf16': [_p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _f32, _p],
         'stc_bcsr_spmm_bf16': [_p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _f32, _p],
         'stc_dense_agg_f32': [_p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _f32, _p],
+        'stc_cell_small_fwd_f32': [_p, _p, _p, _i32, _p, _i32, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _p],
+        'stc_cell_small_bwd_f32': [_p, _p, _p, _i32, _p, _i32, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _i32, _p, _i64, _i32, _i32,
+                                   _p, C.c_size_t, _i32, _i32, _p],
         'stc_csr_sddmm_f32': [_p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _i32, _p],
         'stc_cheby_dense_fwd_f32': [_p, _i32, _i32, _p, _p],
         'stc_cheby_dense_bwd_f32': [_p, _p, _p, _i32, _i32, _p, _p],
@@ -133,6 +137,10 @@ def _declare(lib):
     lib.stc_cell_bwd_planar_supported.argtypes = [_i32, _i32]
     lib.stc_cell_bwd_planar_workspace_bytes.restype = C.c_size_t
     lib.stc_cell_bwd_planar_workspace_bytes.argtypes = [_i32, _i32, _i32]
+    lib.stc_cell_small_supported.restype = C.c_int
+    lib.stc_cell_small_supported.argtypes = [_i32, _i32, _i32, _i32, _i32]
+    lib.stc_cell_small_workspace_bytes.restype = C.c_size_t
+    lib.stc_cell_small_workspace_bytes.argtypes = [_i32, _i32, _i32, _i32]
     lib.stc_set_dispatch_level.restype = C.c_int
     lib.stc_set_dispatch_level.argtypes = [_i32]
     lib.stc_head_bwd_workspace_bytes.restype = C.c_size_t
@@ -766,6 +774,85 @@ class HipKernels:
                      # accumulated into is also read -- every plane once
                      nbytes=4 * R * Cc * (2 * cin + 7 * h + 2 * h * (1 + bool(accumulate_h)) + (2 * h * (1 + bool(accumulate_x)) if cin == h else 0)),
                      tag='wide' if cin == h else 'layer0')
+
+    # ---- small graphs: one STC_Cell step per launch --------------------------------------------------------
+    SMALL_MAX_ROWS = 4096        # N*C rows per sample the one-workgroup-per-sample kernels are meant for (planes stay in L2)
+
+    def cell_small_supported(self, Ks, Kc, Cc, cin, h, n_nodes=0) -> bool:
+        return n_nodes * Cc <= self.SMALL_MAX_ROWS and bool(self.lib.stc_cell_small_supported(Ks, Kc, Cc, cin, h))
+
+    @staticmethod
+    def cell_small_zg_width(cin) -> int:
+        """Floats per row of the saved aggregate ``Zg = S.[H | Xt | 0]``."""
+        return 32 if cin == 16 else 20
+
+    @staticmethod
+    def cell_small_params(Ks, Kc, cin, h=16) -> int:
+        """Floats per sample of the parameter-gradient partials: [dWg | dbg | dWc | dbc]."""
+        return Ks * Kc * (cin + h) * 3 * h + 3 * h
+
+    def _small_shapes(self, what, rowptr, colidx, val, X, H, Tc, Wg, Wc, planes, Zg, Zc):
+        if H.dim() != 4 or X.dim() != 4 or X.shape[:3] != H.shape[:3]:
+            raise StcError(f'{what}: X {tuple(X.shape)} / H {tuple(H.shape)} must be (B, N, C, cin) / (B, N, C, 16)')
+        B, N, Cc, h = H.shape
+        cin = X.shape[-1]
+        Kc = Tc.shape[0]
+        if not self.cell_small_supported(2, Kc, Cc, cin, h, N):
+            raise StcError(f'{what}: shape outside the small-graph cell kernels (Ks = Kc = 2, hidden 16, C <= 16, cin = 16 or 1..4, '
+                           f'N*C <= {self.SMALL_MAX_ROWS}): Kc={Kc} C={Cc} cin={cin} h={h} N={N}')
+        self._f32(what + '.X', X)
+        self._f32(what + '.H', H)
+        self._f32(what + '.Tc', Tc, (Kc, Cc, Cc))
+        L = cin + h
+        self._f32(what + '.Wg', Wg, (2 * Kc * L, 2 * h))
+        self._f32(what + '.Wc', Wc, (2 * Kc * L, h))
+        self._i32(what + '.rowptr', rowptr, N + 1)
+        self._i32(what + '.colidx', colidx, val.numel())
+        self._f32(what + '.val', val)
+        for name, t in planes.items():
+            self._f32(f'{what}.{name}', t, (B, N, Cc, h))
+        self._f32(what + '.Zg', Zg, (B, N * Cc, self.cell_small_zg_width(cin)))
+        self._f32(what + '.Zc', Zc, (B, N * Cc, h))
+        self._same_device(H, X, Tc, Wg, Wc, rowptr, colidx, val, Zg, Zc, *planes.values())
+        return B, N, Cc, cin, Kc
+
+    def cell_small_fwd(self, rowptr, colidx, val, X, H, Tc, Wg, bg, Wc, bc, U, R, Cand, Hnew, RH, Zg, Zc, checked=True):
+        """One STC_Cell step (reference STC_GNN.py:65-79) in one launch: ``stc_cell_small_fwd_f32``.  (rowptr, colidx, val): CSR of Gs^T.
+        ``checked=False``: the caller built every buffer itself from shapes it already validated (the cell-graph executor)."""
+        if checked:
+            B, N, Cc, cin, Kc = self._small_shapes('cell_small_fwd', rowptr, colidx, val, X, H, Tc, Wg, Wc, dict(U=U, R=R, Cand=Cand, Hnew=Hnew, RH=RH), Zg, Zc)
+            for name, b_, n in (('bg', bg, 32), ('bc', bc, 16)):
+                if b_ is not None:
+                    self._f32('cell_small_fwd.' + name, b_, (n,))
+        else:
+            (B, N, Cc, _), cin, Kc = H.shape, X.shape[-1], Tc.shape[0]
+        self._launch('stc_cell_small_fwd_f32', H, rowptr.data_ptr(), colidx.data_ptr(), val.data_ptr(), N, X.data_ptr(), cin, H.data_ptr(), Tc.data_ptr(), Kc,
+                     Wg.data_ptr(), _ptr(bg), Wc.data_ptr(), _ptr(bc), U.data_ptr(), R.data_ptr(), Cand.data_ptr(), Hnew.data_ptr(), RH.data_ptr(),
+                     Zg.data_ptr(), Zc.data_ptr(), B, Cc, nbytes=4 * B * N * Cc * (cin + 16 * 8 + 2 * self.cell_small_zg_width(cin)))
+
+    def cell_small_bwd(self, rowptr, colidx, val, X, H, Tc, Wg, Wc, U, R, Cand, RH, Zg, Zc, dHnew, dX, accumulate_x, dH, accumulate_h,
+                       dparams, has_bg, has_bc, checked=True):
+        """Autograd of ``cell_small_fwd`` in one launch (``stc_cell_small_bwd_f32``).  (rowptr, colidx, val): CSR of Gs.  dX / dH may be
+        None; ``accumulate_*``: add to what the buffer holds.  ``dparams`` (B, P >= cell_small_params): per-sample parameter-gradient
+        partials, ADDED to."""
+        if checked:
+            B, N, Cc, cin, Kc = self._small_shapes('cell_small_bwd', rowptr, colidx, val, X, H, Tc, Wg, Wc,
+                                                   dict(U=U, R=R, Cand=Cand, RH=RH, dHnew=dHnew, **({} if dH is None else dict(dH=dH))), Zg, Zc)
+            if dX is not None:
+                self._f32('cell_small_bwd.dX', dX, tuple(X.shape))
+            self._f32('cell_small_bwd.dparams', dparams)
+            if dparams.dim() != 2 or dparams.shape[0] != B or dparams.shape[1] < self.cell_small_params(2, Kc, cin):
+                raise StcError(f'cell_small_bwd: dparams {tuple(dparams.shape)}, expected ({B}, >= {self.cell_small_params(2, Kc, cin)})')
+            self._same_device(H, dHnew, dparams, *([dX] if dX is not None else []))
+        else:
+            (B, N, Cc, _), cin, Kc = H.shape, X.shape[-1], Tc.shape[0]
+        nbytes = self.lib.stc_cell_small_workspace_bytes(N, Cc, cin, B)
+        ws = self._get_workspace(H.device, nbytes)
+        self._launch('stc_cell_small_bwd_f32', H, rowptr.data_ptr(), colidx.data_ptr(), val.data_ptr(), N, X.data_ptr(), cin, H.data_ptr(), Tc.data_ptr(), Kc,
+                     Wg.data_ptr(), Wc.data_ptr(), U.data_ptr(), R.data_ptr(), Cand.data_ptr(), RH.data_ptr(), Zg.data_ptr(), Zc.data_ptr(),
+                     dHnew.data_ptr(), _ptr(dX), int(bool(accumulate_x)), _ptr(dH), int(bool(accumulate_h)), dparams.data_ptr(), dparams.shape[1],
+                     int(bool(has_bg)), int(bool(has_bc)), ws.data_ptr(), ws.numel(), B, Cc,
+                     nbytes=4 * B * N * Cc * (2 * cin + 16 * 9 + 5 * self.cell_small_zg_width(cin) + 64))
 
     # ---- planar cell convolutions of Chebyshev order K = 3 ------------------------------------------------
     def cell_planar_k_supported(self, K, Cc, h) -> bool:

@@ -1,0 +1,140 @@
+"""The small-graph cell kernels (stc_cell_small_fwd/bwd_f32: one STC_Cell step per launch, reference STC_GNN.py:65-79).
+
+CPU: the kernels' CPU twin (oracle/kernel_emul.py) against the oracle's STC_Cell and ITS autograd, in float64 -- the twin restates the
+launch's contract (saved aggregates in [H | X | 0] order, per-sample parameter-gradient partials that are added to, accumulate flags).
+GPU (-m gpu): the HIP kernels against the twin on the same inputs, through the C ABI; bound 1e-5 (max-norm relative, as everywhere).
+"""
+import pytest
+import torch
+
+from oracle import stc_oracle as oracle
+from oracle.kernel_emul import EmulatedKernels
+from stc_hip import CsrGraph
+from stc_hip.graph import csr_operand
+from tests.conftest import rel_err
+
+EM = EmulatedKernels()
+TOL = 1e-5
+
+
+def _graph(N, seed, dense=False):
+    g = torch.Generator().manual_seed(seed)
+    if dense:
+        G = torch.softmax(torch.randn(N, N, generator=g), -1)
+    else:
+        G = (torch.rand(N, N, generator=g) < min(1.0, 6.0 / N)).float() * torch.rand(N, N, generator=g)
+        G[0] = 0.0                                                  # an empty row, an empty column
+        G[:, N - 1] = 0.0
+        G = G + 0.5 * torch.eye(N)
+        G[0, 0] = 0.0
+    return CsrGraph.from_dense(G)
+
+
+def _inputs(B, N, C, cin, seed, dtype=torch.float32, bias=True):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g).to(dtype)
+    L = cin + 16
+    Gc = torch.softmax(torch.randn(C, C, generator=g), -1).to(dtype)
+    Tc = torch.stack([torch.eye(C, dtype=dtype), Gc])
+    return dict(X=r(B, N, C, cin), H=0.5 * r(B, N, C, 16), Gc=Gc, Tc=Tc, Wg=0.3 * r(4 * L, 32), bg=0.1 * r(32) if bias else None,
+                Wc=0.3 * r(4 * L, 16), bc=0.1 * r(16) if bias else None, dHnew=r(B, N, C, 16))
+
+
+def _buffers(B, N, C, cin, dtype, k):
+    new = lambda *s: torch.full(s, float('nan'), dtype=dtype)
+    P = k.cell_small_params(2, 2, cin) + 5                          # a leading dimension larger than needed
+    return dict(U=new(B, N, C, 16), R=new(B, N, C, 16), Cand=new(B, N, C, 16), Hnew=new(B, N, C, 16), RH=new(B, N, C, 16),
+                Zg=new(B, N * C, k.cell_small_zg_width(cin)), Zc=new(B, N * C, 16)), P
+
+
+def _run(k, op, t, buf, P, to, acc_x=False, acc_h=False, want_x=True, want_h=True):
+    """Forward + backward through kernel set ``k`` on device / dtype converter ``to``; returns plain CPU tensors."""
+    d = {n: (None if v is None else to(v)) for n, v in t.items()}
+    b = {n: to(v) for n, v in buf.items()}
+    k.cell_small_fwd(op.fwd_rowptr, op.fwd_colidx, to(op.fwd_val), d['X'], d['H'], d['Tc'], d['Wg'], d['bg'], d['Wc'], d['bc'],
+                     b['U'], b['R'], b['Cand'], b['Hnew'], b['RH'], b['Zg'], b['Zc'])
+    B = d['H'].shape[0]
+    dX = to(torch.full(t['X'].shape, 0.25, dtype=t['X'].dtype)) if want_x else None
+    dH = to(torch.full(t['H'].shape, -0.5, dtype=t['H'].dtype)) if want_h else None
+    dP = to(torch.full((B, P), 0.125, dtype=t['H'].dtype))
+    k.cell_small_bwd(op.bwd_rowptr, op.bwd_colidx, to(op.bwd_val), d['X'], d['H'], d['Tc'], d['Wg'], d['Wc'], b['U'], b['R'], b['Cand'], b['RH'],
+                     b['Zg'], b['Zc'], d['dHnew'], dX, acc_x, dH, acc_h, dP, t['bg'] is not None, t['bc'] is not None)
+    out = dict(b, dX=dX, dH=dH, dP=dP)
+    return {n: (None if v is None else v.detach().cpu()) for n, v in out.items()}
+
+
+def _split_params(dP, cin):
+    L = cin + 16
+    nW = 4 * L
+    return (dP[:, :nW * 32].sum(0).view(nW, 32), dP[:, nW * 32:nW * 32 + 32].sum(0), dP[:, nW * 32 + 32:nW * 48 + 32].sum(0).view(nW, 16),
+            dP[:, nW * 48 + 32:nW * 48 + 48].sum(0), dP[:, nW * 48 + 48:])
+
+
+@pytest.mark.parametrize('B,N,C,cin,bias', [(3, 12, 5, 1, True), (2, 9, 4, 16, True), (2, 7, 3, 3, False)])
+def test_small_cell_twin_is_the_reference_cell(B, N, C, cin, bias):
+    """oracle.stc_cell (dense Gs, the reference's op order) and its autograd, float64, against the twin's forward / backward."""
+    dt = torch.float64
+    graph = _graph(N, seed=N + cin)
+    op = csr_operand(graph, torch.device('cpu'))
+    t = _inputs(B, N, C, cin, seed=7 * N + C, dtype=dt, bias=bias)
+    buf, P = _buffers(B, N, C, cin, dt, EM)
+    got = _run(EM, op, t, buf, P, lambda v: v.clone().to(dt) if v.is_floating_point() else v)
+    leaves = {n: t[n].clone().requires_grad_(True) for n in ('X', 'H', 'Wg', 'Wc') + (('bg', 'bc') if bias else ())}
+    Hnew = oracle.stc_cell(graph.to_dense().to(dt), t['Gc'], leaves['X'], leaves['H'], leaves['Wg'], leaves.get('bg'), leaves['Wc'], leaves.get('bc'), 2, 2)
+    Hnew.backward(t['dHnew'])
+    assert rel_err(got['Hnew'], Hnew.detach()) < 1e-12
+    dWg, dbg, dWc, dbc, rest = _split_params(got['dP'] - 0.125, cin)
+    assert float(rest.abs().max()) == 0.0                           # columns beyond the parameters: untouched
+    assert rel_err(got['dX'], leaves['X'].grad) < 1e-12 and rel_err(got['dH'], leaves['H'].grad) < 1e-12
+    assert rel_err(dWg, leaves['Wg'].grad) < 1e-12 and rel_err(dWc, leaves['Wc'].grad) < 1e-12
+    if bias:
+        assert rel_err(dbg, leaves['bg'].grad) < 1e-12 and rel_err(dbc, leaves['bc'].grad) < 1e-12
+    else:
+        assert float(dbg.abs().max()) == 0.0 and float(dbc.abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,N,C,cin,dense', [
+    (32, 100, 5, 1, False),      # the SF shape, layer 0
+    (32, 100, 5, 16, False),     # the SF shape, layers above
+    (3, 100, 5, 16, True),       # the reference's dense graph on the full pattern
+    (2, 37, 8, 16, False),       # two whole nodes per row tile, ragged last tile
+    (2, 200, 8, 3, False),       # BASELINE configuration 3's nominal size (N ~ 200, C ~ 8)
+    (1, 10, 16, 4, False),       # one node per tile
+    (2, 7, 1, 2, False),         # one category: no mix partner rows
+    (2, 33, 7, 16, False),       # 2 nodes of 7 rows per tile (14 of 16 rows used)
+])
+@pytest.mark.parametrize('bias,acc', [(True, False), (False, True)])
+def test_small_cell_kernels(B, N, C, cin, dense, bias, acc):
+    from stc_hip._lib import HipKernels
+    hip = HipKernels()
+    assert hip.cell_small_supported(2, 2, C, cin, 16, N)
+    graph = _graph(N, seed=N + cin, dense=dense)
+    t = _inputs(B, N, C, cin, seed=3 * N + C + cin, bias=bias)
+    buf, P = _buffers(B, N, C, cin, torch.float32, hip)
+    want = _run(EM, csr_operand(graph, torch.device('cpu')), t, buf, P, lambda v: v.clone(), acc_x=acc, acc_h=acc)
+    got = _run(hip, csr_operand(graph, torch.device('cuda')), t, buf, P, lambda v: v.cuda(), acc_x=acc, acc_h=acc)
+    for name in ('U', 'R', 'RH', 'Zg', 'Zc', 'Cand', 'Hnew'):
+        assert rel_err(got[name], want[name]) < TOL, name
+    for name in ('dX', 'dH'):
+        assert rel_err(got[name], want[name]) < TOL, name
+    for a, b, name in zip(_split_params(got['dP'], cin), _split_params(want['dP'], cin), ('dWg', 'dbg', 'dWc', 'dbc', 'rest')):
+        assert rel_err(a, b) < TOL, name
+    # inputs that need no gradient: NULL outputs
+    got = _run(hip, csr_operand(graph, torch.device('cuda')), t, buf, P, lambda v: v.cuda(), want_x=False, want_h=False)
+    assert got['dX'] is None and got['dH'] is None
+    for a, b, name in zip(_split_params(got['dP'], cin), _split_params(want['dP'], cin), ('dWg', 'dbg', 'dWc', 'dbc', 'rest')):
+        assert rel_err(a, b) < TOL, name
+
+
+@pytest.mark.gpu
+def test_small_cell_refuses_other_shapes():
+    from stc_hip._lib import HipKernels, StcError
+    hip = HipKernels()
+    assert not hip.cell_small_supported(3, 2, 5, 16, 16, 100) and not hip.cell_small_supported(2, 2, 17, 16, 16, 100)
+    assert not hip.cell_small_supported(2, 2, 5, 8, 16, 100) and not hip.cell_small_supported(2, 2, 32, 16, 16, 50176)
+    graph = _graph(12, seed=1)
+    t = _inputs(2, 12, 5, 8, seed=2)
+    buf, P = _buffers(2, 12, 5, 8, torch.float32, hip)
+    with pytest.raises(StcError, match='outside the small-graph cell kernels'):
+        _run(hip, csr_operand(graph, torch.device('cuda')), t, buf, P, lambda v: v.cuda())
