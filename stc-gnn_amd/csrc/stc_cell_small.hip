@@ -26,6 +26,13 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 constexpr int SC_THREADS = 512, SC_WAVES = SC_THREADS / 64, SC_H = 16, SC_KS = 2;
 constexpr int SC_MAXC = 16, SC_MAXKC = 3;
 
+// Probe hook (tools/probes/small_cell_phases.py builds this file with -DSC_STOP_AFTER=n and times the truncated launches; the
+// library is built without it: the condition is a compile-time false).
+#ifndef SC_STOP_AFTER
+#define SC_STOP_AFTER 99
+#endif
+#define SC_PHASE_END(n) do { if (SC_STOP_AFTER <= (n)) return; } while (0)
+
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -212,6 +219,7 @@ __global__ __launch_bounds__(SC_THREADS) void small_fwd_kernel(SmallFwd a) {
         [](int, int) -> f32x4 { return f32x4{0.f, 0.f, 0.f, 0.f}; },
         [&](int row, int q, f32x4 s) { st4(Zgb + (size_t)row * LP + 4 * q, s); });
     __syncthreads();
+    SC_PHASE_END(1);
 
     // 2: gates
     {
@@ -229,11 +237,13 @@ __global__ __launch_bounds__(SC_THREADS) void small_fwd_kernel(SmallFwd a) {
             });
     }
     __syncthreads();
+    SC_PHASE_END(2);
 
     // 3: Zc = S.(R*H)
     aggregate_rows(a.g, NC, C, 4, [&](int src, int q) -> f32x4 { return ld4(RHb + (size_t)src * SC_H + 4 * q); },
                    [](int, int) -> f32x4 { return f32x4{0.f, 0.f, 0.f, 0.f}; }, [&](int row, int q, f32x4 s) { st4(Zcb + (size_t)row * SC_H + 4 * q, s); });
     __syncthreads();
+    SC_PHASE_END(3);
 
     // 4: candidate + blend
     {
@@ -480,6 +490,7 @@ __global__ __launch_bounds__(SC_THREADS) void small_bwd_kernel(SmallBwd a) {
                                   return y;
                               });
     // (conv_bwd_phase ends on a workgroup barrier: the dZ slabs are complete)
+    SC_PHASE_END(1);
 
     // 2: d[R*H | X] = dZ_0 + S^T dZ_1, gate backward
     aggregate_rows(a.g, NC, C, LP / 4, [&](int src, int q) -> f32x4 { return ld4(dZ1 + (size_t)src * LP + 4 * q); },
@@ -517,11 +528,13 @@ __global__ __launch_bounds__(SC_THREADS) void small_bwd_kernel(SmallBwd a) {
             }
         });
     __syncthreads();
+    SC_PHASE_END(2);
 
     // 3: gates convolution
     conv_bwd_phase<KC, XQ, 2>(Slabs{Hb, Xb, Zgb, LP, Zgb + SC_H, LP}, a.Wg, Tl, dvs[wave], red, dZ0, dZ1, dWg, a.has_bg ? dbg : nullptr, a.rpt, a.tiles,
                               NC, C, cin, [&](int grow, int qd, int ot) -> f32x4 { return ld4(dYg + (size_t)grow * 32 + 16 * ot + 4 * qd); });
 
+    SC_PHASE_END(3);
     // 4: d[H | X] += dZ_0 + S^T dZ_1
     if (dHb || dXb)
         aggregate_rows(a.g, NC, C, LP / 4, [&](int src, int q) -> f32x4 { return ld4(dZ1 + (size_t)src * LP + 4 * q); },

@@ -32,6 +32,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from .graph import SpatialOperand
+from .small import small_graph_supported, stc_small_graph
 
 _kernels = None
 
@@ -440,6 +441,7 @@ _PLANAR = True           # cells with 16 + 16-column inputs read them as two pla
 _POST_AGG = True         # candidate convolution as Y = A + S.Bm (narrow SpMM after the node kernel)
 _PLANAR_K3 = True        # Chebyshev order 3: planar cells on three planes per side (T_0, T_1, T_2 of S)
 _ACC_PLANES = True       # one-launch cell backward: a state's second consumer adds into the first one's planes
+_SMALL = True            # small graphs (N*C rows per sample fit the caches, C <= 16): one launch per cell step and direction
 
 
 def cell_graph_supported(op: SpatialOperand, Tc, Ks: int, C: int, h: int, x_widths, dtype=torch.float32) -> bool:
@@ -452,6 +454,8 @@ def cell_graph_supported(op: SpatialOperand, Tc, Ks: int, C: int, h: int, x_widt
     if dtype == torch.bfloat16:
         return (_PLANAR and _POST_AGG and _FUSE_POST and Ks == 2 and Tc.shape[0] == 2 and k.bf16.cell_planar_supported(Ks, 2, C, h)
                 and all(w == h or 1 <= w <= 4 for w in x_widths))
+    if _SMALL and small_graph_supported(k, op, Tc, Ks, C, h, x_widths, dtype):
+        return True                                                   # small graphs: one launch per cell step (stc_hip/small.py)
     return all(k.cell_fused_supported(Ks, Tc.shape[0], C, w + h + (-(w + h)) % 4, h) for w in set(x_widths))
 
 
@@ -924,5 +928,9 @@ def stc_cell_graph(op: SpatialOperand, Tc, Ks: int, schedule, outputs, ext, stac
     """Run a schedule of STC_Cells (see ``_StcCellGraph``).  ``ext``: external (B,N,C,*) tensors (inputs, initial states;
     they get no gradient); ``stacks``: [(Wg, bg, Wc, bc)] parameter sets; returns the new states of the ``outputs`` cells
     stacked along a new leading axis, (len(outputs), B, N, C, h) -- written in place by the kernels, no stack pass."""
+    k = kernels()
+    if _SMALL and small_graph_supported(k, op, Tc, Ks, ext[0].shape[2], 16, {ext[x[1]].shape[-1] if x[0] == 'ext' else 16 for _, x, _ in schedule},
+                                        ext[0].dtype):
+        return stc_small_graph(k, op, Tc, Ks, schedule, outputs, ext, stacks)
     flat = [p for st in stacks for p in st]
     return _StcCellGraph.apply(op, Ks, list(schedule), list(outputs), len(ext), Tc, op.fwd_val, *ext, *flat)

@@ -1,0 +1,181 @@
+"""A schedule of STC_Cells on a SMALL graph as one autograd node: one launch per cell step in each direction.
+
+The SF-incidents shape (N = 100, C = 5, hidden 16) is bound by the host's launch rate on the general path (~15 launches
+per cell and direction).  ``stc_cell_small_fwd/bwd_f32`` run a whole cell step -- both aggregations, both convolutions, the gate math
+and the blend (reference STC_GNN.py:65-79) -- in one launch with one workgroup per sample; this module is the bookkeeping around them,
+with the same interface as ``ops.stc_cell_graph``:
+
+  * states, gates and the saved aggregates of all cells live in a handful of stacked buffers (one allocation per kind and pass);
+  * a state's gradient is ONE buffer that its consumer cells write / add to in place (``accumulate_x`` / ``accumulate_h`` of the
+    backward kernel), in reverse schedule order -- no autograd accumulation passes;
+  * parameter gradients are per-sample partials that every cell of a parameter set adds to; one sum over the batch per backward pass.
+Fixed graphs only (``csr-fixed``: no gradient to Gs / Gc).
+"""
+from __future__ import annotations
+
+import weakref
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from .graph import SpatialOperand
+
+H16 = 16
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def small_graph_supported(k, op: SpatialOperand, Tc, Ks: int, C: int, h: int, x_widths, dtype=torch.float32) -> bool:
+    if dtype != torch.float32 or Tc.requires_grad or op.fwd_val.requires_grad or not hasattr(k, 'cell_small_supported'):
+        return False
+    return all(k.cell_small_supported(Ks, Tc.shape[0], C, w, h, op.n) for w in set(x_widths))
+
+
+def _alias(base: torch.Tensor) -> torch.Tensor:
+    """The same storage as a tensor of its own (not a view in autograd's books): saved for backward while ``base`` is the node's output."""
+    t = base.new_empty(0)
+    t.set_(base.untyped_storage(), base.storage_offset(), base.shape, base.stride())
+    return t
+
+
+class _StcSmallGraph(Function):
+    """schedule[j] = (stack, ('ext', i) | ('cell', k), ('ext', i) | ('cell', k)): parameter set, source of Xt, source of H."""
+
+    @staticmethod
+    def forward(ctx, k, op: SpatialOperand, Ks: int, schedule, outputs, n_ext: int, Tc, fwd_val, *tensors):
+        ext = [_c(t) for t in tensors[:n_ext]]
+        flat = tensors[n_ext:]
+        stacks = [tuple(None if p is None else _c(p) for p in flat[i:i + 4]) for i in range(0, len(flat), 4)]   # (Wg, bg, Wc, bc)
+        Tc, fwd_val = _c(Tc), _c(fwd_val)
+        n_cells = len(schedule)
+        ref = ext[0]
+        B, N, C = ref.shape[:3]
+        cin = [ext[x[1]].shape[-1] if x[0] == 'ext' else H16 for _, x, _ in schedule]
+        for t in ext:                                                # (the per-cell launches below skip the wrapper's checks)
+            if t.shape[:3] != (B, N, C) or t.dtype != torch.float32 or t.device != ref.device:
+                raise ValueError(f'stc_cell_graph: external tensors must be float32 (B, N, C, *) on one device, got {tuple(t.shape)} {t.dtype}')
+        if N != op.n or Tc.shape[1:] != (C, C):
+            raise ValueError(f'stc_cell_graph: graphs are for N={op.n}, C={Tc.shape[1]}; got N={N}, C={C}')
+        for (s_id, _, hs), w in zip(schedule, cin):
+            Wg, bg, Wc, bc = stacks[s_id]
+            rows = Ks * Tc.shape[0] * (w + H16)
+            if Wg.shape != (rows, 2 * H16) or Wc.shape != (rows, H16) or (hs[0] == 'ext' and ext[hs[1]].shape[-1] != H16):
+                raise ValueError(f'stc_cell_graph: parameter set {s_id} does not fit an input of {w} + {H16} columns')
+        out_slot = {j: i for i, j in enumerate(outputs)}
+        if len(out_slot) != len(outputs):
+            raise ValueError('stc_cell_graph: duplicate output cells')
+        out_stack = ref.new_empty(len(outputs), B, N, C, H16)        # the requested states are produced in place, stacked
+        inner = ref.new_empty(max(1, n_cells - len(outputs)), B, N, C, H16)
+        planes = ref.new_empty(5, n_cells, B, N, C, H16)             # U, R, Cand, R*H, S.(R*H) of every cell
+        wide = [j for j in range(n_cells) if cin[j] == H16]
+        zg_w = ref.new_empty(max(1, len(wide)), B, N * C, k.cell_small_zg_width(H16))
+        zg_n = ref.new_empty(max(1, n_cells - len(wide)), B, N * C, k.cell_small_zg_width(1))
+        out_alias = _alias(out_stack)
+        state, zg, nxt, wi, ni = [], [], 0, 0, 0
+        for j in range(n_cells):
+            if j in out_slot:
+                state.append(out_alias[out_slot[j]])
+            else:
+                state.append(inner[nxt])
+                nxt += 1
+            if cin[j] == H16:
+                zg.append(zg_w[wi])
+                wi += 1
+            else:
+                zg.append(zg_n[ni])
+                ni += 1
+        U, R, Cand, RH, Zc = (p.unbind(0) for p in planes.unbind(0))
+        source = lambda src: ext[src[1]] if src[0] == 'ext' else state[src[1]]
+        for j, (s_id, x, hs) in enumerate(schedule):
+            Wg, bg, Wc, bc = stacks[s_id]
+            k.cell_small_fwd(op.fwd_rowptr, op.fwd_colidx, fwd_val, source(x), source(hs), Tc, Wg, bg, Wc, bc, U[j], R[j], Cand[j], state[j], RH[j],
+                             zg[j], Zc[j].view(B, N * C, H16), checked=False)
+        ctx.save_for_backward(Tc, out_alias, inner, planes, zg_w, zg_n, *ext, *[p for st in stacks for p in st if p is not None])
+        ctx.meta = (k, op, Ks, list(schedule), tuple(outputs), cin, [tuple(p is not None for p in st) for st in stacks], (B, N, C), len(ext))
+        ctx.out_stack_ref, ctx.out_stack_version = weakref.ref(out_stack), out_stack._version
+        return out_stack
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_stack):
+        k, op, Ks, schedule, outputs, cin, present, (B, N, C), n_ext = ctx.meta
+        stack = ctx.out_stack_ref()
+        if stack is not None and stack._version != ctx.out_stack_version:
+            raise RuntimeError('stc_cell_graph: the returned state stack was modified in place after the forward pass; the states saved for '
+                               'backward share its storage (treat the stack as read-only, or clone it before editing)')
+        Tc, out_alias, inner, planes, zg_w, zg_n, *rest = ctx.saved_tensors
+        ext, rest = rest[:n_ext], rest[n_ext:]
+        stacks = []
+        for pres in present:
+            st = []
+            for p in pres:
+                st.append(rest.pop(0) if p else None)
+            stacks.append(st)
+        n_cells = len(schedule)
+        out_slot = {j: i for i, j in enumerate(outputs)}
+        state, zg, nxt, wi, ni = [], [], 0, 0, 0
+        for j in range(n_cells):
+            if j in out_slot:
+                state.append(out_alias[out_slot[j]])
+            else:
+                state.append(inner[nxt])
+                nxt += 1
+            if cin[j] == H16:
+                zg.append(zg_w[wi])
+                wi += 1
+            else:
+                zg.append(zg_n[ni])
+                ni += 1
+        U, R, Cand, RH, Zc = (p.unbind(0) for p in planes.unbind(0))
+        source = lambda src: ext[src[1]] if src[0] == 'ext' else state[src[1]]
+        Kc = Tc.shape[0]
+        P = max(k.cell_small_params(Ks, Kc, w) for w in cin)
+        dP = Tc.new_zeros(len(stacks), B, P)                         # per-sample parameter-gradient partials, every cell adds to its set's rows
+        G = Tc.new_empty(n_cells, B, N, C, H16)                      # gradient owed to every cell's state
+        owed = [False] * n_cells
+        grad_stack = _c(grad_stack)
+        for i, j in enumerate(outputs):
+            G[j].copy_(grad_stack[i])
+            owed[j] = True
+        Gv, dPv = G.unbind(0), dP.unbind(0)
+        for j in range(n_cells - 1, -1, -1):
+            if not owed[j]:
+                continue                                             # nothing downstream depends on this cell
+            s_id, x, hs = schedule[j]
+            Wg, bg, Wc, bc = stacks[s_id]
+            dX = dH = None
+            acc_x = acc_h = False
+            late = None
+            if hs[0] == 'cell':
+                dH, acc_h = Gv[hs[1]], owed[hs[1]]
+                owed[hs[1]] = True
+            if x[0] == 'cell':
+                if hs[0] == 'cell' and hs[1] == x[1]:                # one state as both inputs: the kernel's two outputs must not alias
+                    dX, late = torch.empty_like(Gv[x[1]]), x[1]
+                else:
+                    dX, acc_x = Gv[x[1]], owed[x[1]]
+                    owed[x[1]] = True
+            k.cell_small_bwd(op.bwd_rowptr, op.bwd_colidx, op.bwd_val, source(x), source(hs), Tc, Wg, Wc, U[j], R[j], Cand[j], RH[j], zg[j],
+                             Zc[j].view(B, N * C, H16), Gv[j], dX, acc_x, dH, acc_h, dPv[s_id], bg is not None, bc is not None, checked=False)
+            if late is not None:
+                Gv[late].add_(dX)
+        sums = dP.sum(1)                                             # (sets, P)
+        flat = []
+        for s_id, st in enumerate(stacks):
+            w = next((cin[j] for j, sc in enumerate(schedule) if sc[0] == s_id), None)
+            if w is None:
+                flat += [None if p is None else torch.zeros_like(p) for p in st]
+                continue
+            nW, row = Ks * Kc * (w + H16), sums[s_id]
+            dWg, dbg = row[:nW * 32].view(nW, 32), row[nW * 32:nW * 32 + 32]
+            dWc, dbc = row[nW * 32 + 32:nW * 48 + 32].view(nW, H16), row[nW * 48 + 32:nW * 48 + 48]
+            flat += [dWg, dbg if st[1] is not None else None, dWc, dbc if st[3] is not None else None]
+        return (None,) * 8 + (None,) * n_ext + tuple(flat)
+
+
+def stc_small_graph(k, op: SpatialOperand, Tc, Ks: int, schedule, outputs, ext, stacks):
+    flat = [p for st in stacks for p in st]
+    return _StcSmallGraph.apply(k, op, Ks, list(schedule), list(outputs), len(ext), Tc, op.fwd_val, *ext, *flat)

@@ -24,6 +24,7 @@ stored, only numbers.  Sets follow SURVEY.md section 8(c4):
   g11_bench_c32     the BENCH path's widths through the reference: encoder-decoder-head (graphs given, as g5) at C=32, h=16, K=2,
                     2 layers, 6x8 non-symmetric grid graph, B=2, T=3+2 -> yhat, ComboLoss, every gradient
   g12_bench_c64     the same at C=64;  g13_bench_c32_k3  the same at C=32, K=3 (configuration 4's order)
+  g14_sf_shape      the same at the SF-incidents shape: N=100 (10 x 10), C=5, T=9+3, K=2, h=16 (the small-graph cell kernels' shape)
   g8b_large_n10000_grads   g8 with backward: sampled rows of Ht, dXt, dHt + the full parameter gradients
   g8c_large_n10000_k3      the same cell at Chebyshev order K = 3 (BASELINE configuration 4) through the dense reference, with backward
 
@@ -339,14 +340,20 @@ def main():
           chk_Ht=s['Ht'].double().sum(), chk_W=s['gates_W'].double().sum())
 
 
-def bench_path_golden(ref_framework='/root/reference/framework'):
-    """g11 / g12 / g13 and g8b: the reference itself at the widths (and, g8b, a size) the bench runs."""
+SF_SHAPE = dict(H=10, W=10, horizon=3, B=3, T=9)          # g14: the SF-incidents shape (N = 100, C = 5, T = 9 + 3), graphs given
+BENCH_PATH_GOLDENS = (('g11_bench_c32', 32, 2, {}), ('g12_bench_c64', 64, 2, {}), ('g13_bench_c32_k3', 32, 3, {}), ('g14_sf_shape', 5, 2, SF_SHAPE))
+
+
+def bench_path_golden(ref_framework='/root/reference/framework', only=None):
+    """g11 / g12 / g13 / g14 and g8b: the reference itself at the widths (and, g8b, a size) the bench runs; g14 at the SF shape."""
     sys.path.insert(0, ref_framework)
     import STC_GNN as ref
     from Model_Trainer import ComboLoss
     torch.set_num_threads(8)
-    for name, C, K in (('g11_bench_c32', 32, 2), ('g12_bench_c64', 64, 2), ('g13_bench_c32_k3', 32, 3)):
-        s = bench_path_inputs(C, K)
+    for name, C, K, kw in BENCH_PATH_GOLDENS:
+        if only is not None and name != only:
+            continue
+        s = bench_path_inputs(C, K, **kw)
         torch.manual_seed(1100 + C + 10 * K)
         full = ref.STCGNN(s['N'], C, K, K, 1, s['h'], s['layers'], s['horizon'])
         with torch.no_grad():
@@ -373,6 +380,8 @@ def bench_path_golden(ref_framework='/root/reference/framework'):
             if not k.startswith('mix_graph_pair'):
                 out['grad/' + k] = p.grad.clone()
         _save(name, **out)
+    if only is not None:
+        return
     # g8b: N = 10 000 through the dense reference WITH backward (sampled rows of the input gradients, full parameter gradients)
     s = synth_inputs('g8')
     cell = ref.STC_Cell(s['N'], s['C'], s['K'], s['K'], s['cin'], s['h'])
@@ -513,7 +522,7 @@ if __name__ == '__main__':
     elif len(sys.argv) > 1 and sys.argv[1] == 'pipeline':
         pipeline_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == 'bench_path':
-        bench_path_golden()
+        bench_path_golden(only=sys.argv[2] if len(sys.argv) > 2 else None)
     elif len(sys.argv) > 1 and sys.argv[1] == 'large_k3':
         large_k3_golden()
     else:

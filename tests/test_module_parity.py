@@ -23,7 +23,7 @@ from oracle import stc_oracle as O
 from oracle.kernel_emul import EmulatedKernels
 from stc_hip import CsrGraph, ops
 from tests.conftest import REPO, load_golden, rel_err, sub_dict
-from tests.golden.make_golden import bench_path_inputs, synth_inputs
+from tests.golden.make_golden import SF_SHAPE, bench_path_inputs, synth_inputs
 
 FWD = 2e-6       # CPU-emulated bound, forward
 GRAD = 5e-6      # CPU-emulated bound, gradients
@@ -372,13 +372,18 @@ def graph_dense_T_csr(s, graph):
                                    torch.from_numpy(h['fwd_val']).double(), size=(graph.n, graph.n))
 
 
-@pytest.mark.parametrize('name,C,K', [('g11_bench_c32', 32, 2), ('g12_bench_c64', 64, 2), ('g13_bench_c32_k3', 32, 3)])
+@pytest.mark.parametrize('name,C,K', [('g11_bench_c32', 32, 2), ('g12_bench_c64', 64, 2), ('g13_bench_c32_k3', 32, 3), ('g14_sf_shape', 5, 2)])
 def test_bench_path_against_reference_goldens(monkeypatch, name, C, K):
     """The path bench.py runs -- csr-fixed STCGNN at C in {32, 64}, hidden 16, encoder + decoder as ONE cell-graph node on the
     planar / split-operand matrix-core kernels -- against goldens the REFERENCE generated at exactly these widths
-    (STC_GNN.py:185-207 after MGP_Gen, Model_Trainer.py:14-23): prediction, ComboLoss, every parameter gradient, 1e-5."""
+    (STC_GNN.py:185-207 after MGP_Gen, Model_Trainer.py:14-23): prediction, ComboLoss, every parameter gradient, 1e-5.
+    g14: the SF-incidents shape (N = 100, C = 5, T = 9 + 3; ``bench.py --preset sf``), which runs on the small-graph cell kernels
+    (one launch per cell step: stc_cell_small_fwd/bwd_f32) -- asserted taken."""
     g = _golden(name)
-    s = bench_path_inputs(C, K)
+    s = bench_path_inputs(C, K, **(SF_SHAPE if name == 'g14_sf_shape' else {}))
+    small_calls = []
+    real_small = ops.stc_small_graph
+    monkeypatch.setattr(ops, 'stc_small_graph', lambda *a, **k: (small_calls.append(1), real_small(*a, **k))[1])
     model = _small_model(g, graph_mode='csr-fixed')
     sd = sub_dict(g, 'sd/')
     assert sorted(model.state_dict().keys()) == sorted(sd.keys())
@@ -389,6 +394,7 @@ def test_bench_path_against_reference_goldens(monkeypatch, name, C, K):
     monkeypatch.setattr(ops, 'stc_cell_graph', lambda *a, **k: (calls.append(1), real(*a, **k))[1])
     yhat = model(X_seq=s['X'].to(DEV), As=graph, Ac=s['Gc'].to(DEV))
     assert calls, 'the cell-graph path (the one the bench runs) was not taken'
+    assert bool(small_calls) == (name == 'g14_sf_shape')
     _close(yhat, g['yhat'], FWD, f'{name} yhat')
     loss = O.combo_loss(yhat, s['Y'].to(DEV))
     assert abs(float(loss.detach()) - float(g['loss'])) < 5e-6
@@ -469,12 +475,21 @@ def test_factorised_mixed_fusion_option(dev):
         assert sum(p.numel() for p in big.parameters()) == 2 * (2 * 10 ** 6 * 8 + 10 ** 6)
 
 
+@pytest.mark.parametrize('small', [False, True], ids=['wide', 'small'])
 @pytest.mark.parametrize('layers,T,horizon,cin,K', [(2, 4, 3, 1, 2), (1, 3, 2, 1, 2), (3, 2, 2, 4, 2), (2, 3, 2, 1, 3), (3, 2, 2, 4, 3)])
-def test_cell_graph_equals_the_per_cell_path(dev, monkeypatch, layers, T, horizon, cin, K, one_launch_bwd=True):
+def test_cell_graph_equals_the_per_cell_path(dev, monkeypatch, layers, T, horizon, cin, K, small, one_launch_bwd=True):
     """Encoder + decoder as one autograd node (no concat / gradient-accumulation passes between the cells) vs one node per
     cell: same prediction, same parameter gradients.  Hidden 16; 32 categories on the GPU (matrix-core shapes).  K = 3: the
-    order-3 planar cells (three Chebyshev planes per side, Clenshaw state gradients) against the per-cell slab form."""
-    C = 32 if DEV == 'cuda' else 5
+    order-3 planar cells (three Chebyshev planes per side, Clenshaw state gradients) against the per-cell slab form.
+    ``small``: 5 categories -- the small-graph executor (stc_hip/small.py: one launch per cell step, per-sample parameter-gradient
+    partials) against the same per-cell path."""
+    if small and K != 2:
+        pytest.skip('the small-graph cell kernels are built for Chebyshev order 2')
+    monkeypatch.setattr(ops, '_SMALL', small)
+    taken = []
+    real_small = ops.stc_small_graph
+    monkeypatch.setattr(ops, 'stc_small_graph', lambda *a, **k: (taken.append(1), real_small(*a, **k))[1])
+    C = 5 if (small or DEV == 'cpu') else 32
     Hh, Ww, h, B = 5, 6, 16, 2
     if not one_launch_bwd:          # the two-launch backward is what C = 64 runs (the one-launch kernel is built for C = 32): force it at C = 32
         monkeypatch.setattr(type(ops.kernels()), 'cell_bwd_planar_supported', lambda self, Cc, hh: False)
@@ -510,14 +525,16 @@ def test_cell_graph_equals_the_per_cell_path(dev, monkeypatch, layers, T, horizo
 
     y1, g1 = run(True)
     assert calls, 'the cell-graph path was not taken'
+    assert bool(taken) == small
     y0, g0 = run(False)
     _close(y1, y0, 1e-6, 'cell-graph prediction vs per-cell', gpu_tol=2e-6)
     assert set(g1) == set(g0)
     for n in g0:
         # (the head's bias gradient is one long, cancelling sum over every output element, taken in (horizon, B) order on one
-        # path and (B, horizon) order on the other: summation-order noise of a few 1e-6 although the predictions are identical)
+        # path and (B, horizon) order on the other: summation-order noise of a few 1e-6 although the predictions are identical;
+        # the small-graph executor sums parameter gradients per sample first, then over the batch: 5e-6)
         head_bias = n.startswith('out_proj') and n.endswith('bias')
-        _close(g1[n], g0[n], 2e-5 if head_bias else 2e-6, f'cell-graph d{n} vs per-cell', gpu_tol=2e-5 if head_bias else 5e-6)
+        _close(g1[n], g0[n], 2e-5 if head_bias else (5e-6 if small else 2e-6), f'cell-graph d{n} vs per-cell', gpu_tol=2e-5 if head_bias else 5e-6)
 
 
 @pytest.mark.parametrize('planar,post_agg,K', [(True, True, 2), (False, True, 2), (False, False, 2), (True, True, 3), (False, True, 3)])
@@ -528,7 +545,21 @@ def test_cell_graph_general_schedules_match_autograd(dev, monkeypatch, planar, p
     gradient pieces (more consumers than the kernels take destinations / addends for)."""
     monkeypatch.setattr(ops, '_PLANAR', planar)
     monkeypatch.setattr(ops, '_POST_AGG', post_agg)
-    C = 32 if DEV == 'cuda' else 4
+    monkeypatch.setattr(ops, '_SMALL', False)
+    _general_schedule(32 if DEV == 'cuda' else 4, K)
+
+
+def test_small_graph_general_schedules_match_autograd(dev, monkeypatch):
+    """The same unusual schedules through the small-graph executor (one launch per cell step; gradients of a state written / added in
+    place by its consumers, the both-sides-from-one-state cell through a temporary)."""
+    taken = []
+    real_small = ops.stc_small_graph
+    monkeypatch.setattr(ops, 'stc_small_graph', lambda *a, **k: (taken.append(1), real_small(*a, **k))[1])
+    _general_schedule(5, 2, tol=6e-6)
+    assert taken
+
+
+def _general_schedule(C, K, tol=3e-6):
     Hh, Ww, h, B = 4, 5, 16, 2
     N = Hh * Ww
     torch.manual_seed(77)
@@ -573,13 +604,15 @@ def test_cell_graph_general_schedules_match_autograd(dev, monkeypatch, planar, p
     g0 = grads()
     _close(got, want, 2e-6, 'general schedule: states', gpu_tol=3e-6)
     for n in g0:
-        _close(g1[n], g0[n], 3e-6, f'general schedule: d{n}', gpu_tol=6e-6)
+        _close(g1[n], g0[n], tol, f'general schedule: d{n}', gpu_tol=6e-6)
 
 
-def test_cell_graph_output_stack_is_guarded_against_in_place_edits(dev):
+@pytest.mark.parametrize('small', [False, True], ids=['wide', 'small'])
+def test_cell_graph_output_stack_is_guarded_against_in_place_edits(dev, monkeypatch, small):
     """The states saved for backward alias the returned stack's storage (no copy); an in-place edit of the stack between
     forward and backward is reported instead of silently corrupting the gradients."""
-    C = 32 if DEV == 'cuda' else 4
+    monkeypatch.setattr(ops, '_SMALL', small)
+    C = 4 if (small or DEV == 'cpu') else 32
     graph = CsrGraph.queen_grid(4, 5, normalize=True)
     torch.manual_seed(1)
     model = M.STCGNN(20, C, 2, 2, 1, 16, 1, 2, graph_mode='csr-fixed').to(DEV)
@@ -598,4 +631,4 @@ def test_cell_graph_output_stack_is_guarded_against_in_place_edits(dev):
 def test_two_launch_cell_backward_option(dev, monkeypatch, layers, T, horizon, cin):
     """The planar cells' backward as two launches (stc_bdg_node_post_bwd_f32 + stc_cell_gates_bwd_planar_f32, with
     the R*H plane stored by the forward) instead of stc_cell_bwd_planar_f32 -- same predictions and gradients."""
-    test_cell_graph_equals_the_per_cell_path(dev, monkeypatch, layers, T, horizon, cin, 2, one_launch_bwd=False)
+    test_cell_graph_equals_the_per_cell_path(dev, monkeypatch, layers, T, horizon, cin, 2, False, one_launch_bwd=False)
