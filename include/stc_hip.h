@@ -443,19 +443,23 @@ int stc_head_bwd_f32(const float* H, const float* w, const float* y, const float
  *   Tc (Kc, C, C): Chebyshev stack of the category graph;  Wg (Ks*Kc*(cin+16), 32), bg (32) | NULL, Wc (.., 16), bc (16) | NULL in the
  *   reference's layout;  outputs U, R, Cand, Hnew (batch, N, C, 16) and, kept for the backward, RH = R*H, Zg = Gs^T x [H | Xt | 0]
  *   (batch, N*C, 16 + 4*XQ floats per row, XQ = 4 for cin = 16 else 1) and Zc = Gs^T x RH (batch, N*C, 16).
+ * When the sample fits the compute unit's LDS (graph of nnz entries + the planes: the SF shape does) the gathers run from LDS; larger
+ * samples take the same kernels with the gathers served by L2.
  * Backward: dHnew -> dX / dH (NULL = not wanted; accumulate_x / accumulate_h: ADD to what the buffer holds, the state's other consumer
- * having written it) and the parameter gradients ADDED into row b of dparams (batch, params_ld):
- *   [dWg (Ks*Kc*L*32) | dbg (32) | dWc (Ks*Kc*L*16) | dbc (16)], L = cin + 16 -- per-sample partials, no atomics: the caller zeroes
- * the buffer once per backward pass, every cell of a layer adds to it, and one sum over the batch finishes the gradient.
+ * having written it) and the parameter gradients ADDED into the rows of sample b of dparams (batch * R, params_ld),
+ * R = stc_cell_small_param_rows() (one row per wave of the sample's workgroup):
+ *   [dWg (Ks*Kc*L*32) | dbg (32) | dWc (Ks*Kc*L*16) | dbc (16)], L = cin + 16 -- partial sums, no atomics, no cross-wave reduction: the
+ * caller zeroes the buffer once per backward pass, every cell of a layer adds to it, and one sum over the rows finishes the gradient.
  * workspace: stc_cell_small_workspace_bytes(N, C, cin, batch), 16-byte aligned. */
 int stc_cell_small_supported(int32_t Ks, int32_t Kc, int32_t C, int32_t cin, int32_t h);
 size_t stc_cell_small_workspace_bytes(int32_t n_nodes, int32_t C, int32_t cin, int32_t batch);
-int stc_cell_small_fwd_f32(const int32_t* rowptr, const int32_t* colidx, const float* val, int32_t n_nodes,
+int stc_cell_small_param_rows(void);
+int stc_cell_small_fwd_f32(const int32_t* rowptr, const int32_t* colidx, const float* val, int32_t n_nodes, int32_t nnz,
                            const float* X, int32_t cin, const float* H, const float* Tc, int32_t Kc,
                            const float* Wg, const float* bg, const float* Wc, const float* bc,
                            float* U, float* R, float* Cand, float* Hnew, float* RH, float* Zg, float* Zc,
                            int32_t batch, int32_t C, void* stream);
-int stc_cell_small_bwd_f32(const int32_t* rowptr, const int32_t* colidx, const float* val, int32_t n_nodes,
+int stc_cell_small_bwd_f32(const int32_t* rowptr, const int32_t* colidx, const float* val, int32_t n_nodes, int32_t nnz,
                            const float* X, int32_t cin, const float* H, const float* Tc, int32_t Kc,
                            const float* Wg, const float* Wc, const float* U, const float* R, const float* Cand,
                            const float* RH, const float* Zg, const float* Zc, const float* dHnew,

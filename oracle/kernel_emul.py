@@ -227,6 +227,8 @@ class EmulatedKernels:
     def cell_small_params(Ks, Kc, cin, h=16) -> int:
         return Ks * Kc * (cin + h) * 3 * h + 3 * h
 
+    cell_small_param_rows = 4          # rows of the parameter-gradient partials per sample (the twin adds to the first)
+
     def _small_agg(self, rowptr, colidx, val, T):
         """S.T over the node axis of T (B, N, C, w)."""
         B, N, Cc, w = T.shape
@@ -266,8 +268,10 @@ class EmulatedKernels:
         Zgv = Zg.view(B, N, Cc, Zg.shape[-1])
         SX, SH, SRH = Zgv[..., h:h + cin], Zgv[..., :h], Zc.view(B, N, Cc, h)
         nW = 2 * Kc * L
-        dWg, dbg = dparams[:, :nW * 2 * h], dparams[:, nW * 2 * h:nW * 2 * h + 2 * h]
-        dWc, dbc = dparams[:, nW * 2 * h + 2 * h:nW * 3 * h + 2 * h], dparams[:, nW * 3 * h + 2 * h:nW * 3 * h + 3 * h]
+        first = dparams[::self.cell_small_param_rows]                # (a view: row 0 of every sample's group)
+        assert first.shape[0] == B
+        dWg, dbg = first[:, :nW * 2 * h], first[:, nW * 2 * h:nW * 2 * h + 2 * h]
+        dWc, dbc = first[:, nW * 2 * h + 2 * h:nW * 3 * h + 2 * h], first[:, nW * 3 * h + 2 * h:nW * 3 * h + 3 * h]
 
         def conv_bwd(Z0, Z1, W, dY, dW_rows, db_rows):
             """d[Z0] + S^T d[Z1] of one convolution (B, N, C, L); parameter gradients per sample."""

@@ -2,9 +2,10 @@
 // one launch: the SF-incidents shape (N = 100, C = 5, hidden 16), where a cell is ~15 launches of a few microseconds on
 // the general path and the step is bound by the host's launch rate.
 //
-// One workgroup = one sample.  The sample's planes (N*C rows of 16 or cin floats: 32 KB at the SF shape) stay in L1 / L2; the phases of
-// the cell follow each other inside the launch, separated by workgroup barriers where a phase reads its neighbours' rows:
-//   forward   1  Zg = S.[H | X]                          (gather over the CSR rows; LP = 16 + 4 XQ columns, zero padded)
+// One workgroup = one sample; the phases of the cell follow each other inside the launch, separated by workgroup barriers where a phase
+// reads its neighbours' rows:
+//   forward   0  stage the graph and the sample's [H | X] rows in LDS
+//             1  Zg = S.[H | X]                          (gather over the CSR rows; LP = 16 + 4 XQ columns, zero padded)
 //             2  gates: [H|X], Zg -> project (fp32 MFMA) -> category mix -> sigmoid -> U, R, R*H
 //             3  Zc = S.(R*H)                            (the X part of S.[X | R*H] is Zg's)
 //             4  candidate: [R*H|X], [Zc|Zg.x] -> project -> mix -> tanh -> blend -> Cand, Hnew
@@ -12,19 +13,27 @@
 //             2  d[R*H | X] = dZc_0 + S^T dZc_1; gate backward -> dYg, first share of dH, dX
 //             3  dYg -> mix^T -> dWg, dbg partials; dZg_0, dZg_1
 //             4  dH, dX += dZg_0 + S^T dZg_1
+// A launch is a chain of short dependent phases on ONE compute unit per sample, so what it costs is latency, not bandwidth: the first
+// version (everything gathered from L2) took 61 / 119 us forward / backward at the SF shape against ~11 / 22 us of matrix-pipe time.
+// Hence, when the sample fits (STAGED): the graph, the gathered planes ([H | X], R*H; in the backward the slab dZ_1) live in LDS, the
+// operands that must come from global memory (the aggregates of the previous phase) are requested one row tile ahead, the forward runs
+// 16 waves (each wave owns ONE 16-column tile of the output: 32 W registers), and the backward's parameter-gradient partials go to one
+// row PER WAVE of the caller's buffer (no cross-wave reduction, no barriers).  Samples that do not fit take the same code with the planes
+// and the graph read from global memory.
 // Projections are project-then-mix:  V_kc = sum_ks Z_ks . W[(ks,kc,:)],  Y[(n,c')] = V_0 + sum_{kc>=1} sum_c T_kc[c,c'] V_kc[(n,c)] + b,
 // on v_mfma_f32_16x16x4_f32 (fp32 operands and accumulator: an fmaf chain per element, no split format).  A row tile = the C rows of
-// floor(16 / C) whole nodes, so the category mix stays inside a wave: the V_kc accumulators go through a per-wave LDS tile.  W lives in
-// registers in operand order for the whole phase (64 registers for the gates).  Parameter gradients are accumulated per SAMPLE into
-// (batch, P) partials (a workgroup owns its row: deterministic, no atomics); the caller sums them over the batch once per backward pass.
+// floor(16 / C) whole nodes, so the category mix stays inside a wave: the V_kc accumulators go through a per-wave LDS tile.
+#include <atomic>
+
 #include "stc_common.h"
 
 namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-constexpr int SC_THREADS = 512, SC_WAVES = SC_THREADS / 64, SC_H = 16, SC_KS = 2;
-constexpr int SC_MAXC = 16, SC_MAXKC = 3;
+constexpr int SF_THREADS = 1024, SF_WAVES = SF_THREADS / 64;      // forward: 16 waves, <= 128 registers
+constexpr int SB_THREADS = 1024, SB_WAVES = SB_THREADS / 64;      // backward: 16 waves = 4 quads, four waves per row tile (slab x role)
+constexpr int SC_H = 16, SC_KS = 2, SC_MAXC = 16;
 
 // Probe hook (tools/probes/small_cell_phases.py builds this file with -DSC_STOP_AFTER=n and times the truncated launches; the
 // library is built without it: the condition is a compile-time false).
@@ -32,29 +41,52 @@ constexpr int SC_MAXC = 16, SC_MAXKC = 3;
 #define SC_STOP_AFTER 99
 #endif
 #define SC_PHASE_END(n) do { if (SC_STOP_AFTER <= (n)) return; } while (0)
+#ifndef SC_MAX_TILES
+#define SC_MAX_TILES (1 << 30)                     // probe: the backward convolutions stop after this many row tiles
+#endif
+#ifndef SC_SKIP_ROLE
+#define SC_SKIP_ROLE (-1)                          // probe: the waves of this backward role (0: dZ, 1: dW) do nothing
+#endif
 
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
+// x / C for x < 65536 and C <= 16 with inv = ceil(2^20 / C): exact (x (inv C - 2^20) < 2^20); a runtime integer division is ~25 instructions
+// and the gathers below would do two per item.
+__device__ __forceinline__ int div_c(int x, int inv) { return (int)(((unsigned)x * (unsigned)inv) >> 20); }
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+// p[idx] where ok, else 0 -- as an UNCONDITIONAL load of a clamped address plus a select.  Written as `ok ? p[idx] : 0` every such load
+// becomes its own exec-masked block with a wait at the join: the launch's few dozen guarded operand loads per tile then run one L2 round
+// trip after the other.  p[0] must be readable.  Offsets inside a sample are 32-bit (unsigned) everywhere in this file: with size_t
+// indices every operand address is a chain of 64-bit VALU operations, and at four waves per SIMD those, not the matrix pipe, set the pace.
+__device__ __forceinline__ float ld_if(const float* p, unsigned idx, bool ok) {
+    const float v = p[ok ? idx : 0];
+    return ok ? v : 0.f;
+}
 
 struct SmallGraph {
     const int32_t* rowptr;
     const int32_t* colidx;
     const float* val;
+    int nnz;
 };
 
+__host__ __device__ constexpr int plane_stride(int xq) { return xq == 4 ? 36 : 28; }      // floats per staged [H | X] row: 16-byte reads of
+constexpr int SQ = 20;                                                                     // 16 consecutive rows fall on distinct banks
+
 // out[row][quad] = base + sum_e val[e] * fetch(colidx[e] * C + c, quad)  for the rows of one sample; fetch returns 4 columns of a source row.
-template <class Fetch, class Base, class Store>
-__device__ __forceinline__ void aggregate_rows(const SmallGraph& g, int NC, int C, int quads, Fetch fetch, Base base, Store store) {
-    for (int item = threadIdx.x; item < NC * quads; item += SC_THREADS) {
-        const int row = item / quads, q = item - row * quads;
-        const int n = row / C, c = row - n * C;
+template <int THREADS, int QUADS, class Fetch, class Base, class Store>
+__device__ __forceinline__ void aggregate_rows(const int* __restrict__ gp, const int* __restrict__ gc, const float* __restrict__ gv, int NC, int C,
+                                               int invC, Fetch fetch, Base base, Store store) {
+    for (int item = threadIdx.x; item < NC * QUADS; item += THREADS) {
+        const int row = item / QUADS, q = item - row * QUADS;
+        const int n = div_c(row, invC), c = row - n * C;
         f32x4 s = base(row, q);
-        const int e1 = g.rowptr[n + 1];
-        for (int e = g.rowptr[n]; e < e1; ++e) {
-            const float v = g.val[e];
-            const f32x4 x = fetch(g.colidx[e] * C + c, q);
+        const int e1 = gp[n + 1];
+        for (int e = gp[n]; e < e1; ++e) {
+            const float v = gv[e];
+            const f32x4 x = fetch(gc[e] * C + c, q);
 #pragma unroll
             for (int i = 0; i < 4; ++i) s[i] = fmaf(v, x[i], s[i]);
         }
@@ -62,123 +94,131 @@ __device__ __forceinline__ void aggregate_rows(const SmallGraph& g, int NC, int 
     }
 }
 
-// The two slabs of a convolution's input as the kernel reads them: slab 0 = [P0h (16 columns, row stride 16) | P0x (cin columns, row
-// stride cin)], slab 1 = [P1h (row stride ld1h) | P1x (row stride ld1x, zero padded to 4 XQ columns)].
-struct Slabs {
-    const float* P0h;
-    const float* P0x;
-    const float* P1h;
-    int ld1h;
-    const float* P1x;
-    int ld1x;
-};
+template <int THREADS>
+__device__ __forceinline__ void stage_graph(const SmallGraph& g, int N, int* gp, int* gc, float* gv) {
+    for (int i = threadIdx.x; i <= N; i += THREADS) gp[i] = g.rowptr[i];
+    for (int i = threadIdx.x; i < g.nnz; i += THREADS) {
+        gc[i] = g.colidx[i];
+        gv[i] = g.val[i];
+    }
+}
 
-// W (Ks*Kc*L, HO) in B-operand order for the forward products: step s < 4 of slab ks feeds l = cin + 4 kq + s (the H block: one
-// 16-byte load of a row gives a lane its A operands of four steps; any bijection of the contraction index serves a sum), steps 4.. the X
-// block (wide: l = 4 kq + s; narrow: l = 4 s + kq).
-template <int KC, int XQ, int CT>
-__device__ __forceinline__ void load_w_fwd(float (&Wr)[SC_KS][KC][CT][4 + (XQ == 4 ? 4 : XQ)], const float* __restrict__ W, int cin, int j, int kq) {
-    constexpr int XS = XQ == 4 ? 4 : XQ, HO = 16 * CT;
+// A operands of one lane for one slab of a row tile: the H block (4 steps from one 16-byte read) and the X block.
+template <int XS>
+struct AOp {
+    f32x4 h;
+    float x[XS];
+};
+template <int XS>
+__device__ __forceinline__ AOp<XS> zero_op() {
+    AOp<XS> a;
+    a.h = zero4();
+#pragma unroll
+    for (int s = 0; s < XS; ++s) a.x[s] = 0.f;
+    return a;
+}
+// lane (row, kq) of a slab stored as [h-part pointer, row stride ldh | x-part pointer, row stride ldx]; narrow X blocks are zero padded
+// to 4 columns where `padded`, else bounded by cin.
+template <int XQ>
+__device__ __forceinline__ AOp<(XQ == 4 ? 4 : XQ)> load_op(const float* ph, int ldh, const float* px, int ldx, bool padded, int cin, int row, int kq) {
+    constexpr int XS = XQ == 4 ? 4 : XQ;
+    AOp<XS> a;
+    a.h = ld4(ph + (unsigned)row * ldh + 4 * kq);
+    if (XQ == 4) {
+        const f32x4 v = ld4(px + (unsigned)row * ldx + 4 * kq);
+#pragma unroll
+        for (int s = 0; s < XS; ++s) a.x[s] = v[s];
+    } else {
+#pragma unroll
+        for (int s = 0; s < XS; ++s) a.x[s] = ld_if(px, (unsigned)row * ldx + 4 * s + kq, padded || 4 * s + kq < cin);
+    }
+    return a;
+}
+
+// W (Ks*Kc*L, HO) in B-operand order for the forward products of output column `col`: step s < 4 of slab ks feeds l = cin + 4 kq + s (the
+// H block: one 16-byte read of a row gives a lane its A operands of four steps; any bijection of the contraction index serves a sum),
+// steps 4.. the X block (wide: l = 4 kq + s; narrow: l = 4 s + kq).
+template <int KC, int XQ>
+__device__ __forceinline__ void load_w_fwd(float (&Wr)[SC_KS][KC][4 + (XQ == 4 ? 4 : XQ)], const float* __restrict__ W, int HO, int col, int cin, int kq) {
+    constexpr int XS = XQ == 4 ? 4 : XQ;
     const int L = cin + SC_H;
 #pragma unroll
     for (int ks = 0; ks < SC_KS; ++ks)
 #pragma unroll
-        for (int kc = 0; kc < KC; ++kc)
+        for (int kc = 0; kc < KC; ++kc) {
+            const float* Wb = W + (unsigned)((ks * KC + kc) * L) * HO + col;
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                const float* Wb = W + (size_t)((ks * KC + kc) * L) * HO + ct * 16 + j;
+            for (int s = 0; s < 4; ++s) Wr[ks][kc][s] = Wb[(unsigned)(cin + 4 * kq + s) * HO];
 #pragma unroll
-                for (int s = 0; s < 4; ++s) Wr[ks][kc][ct][s] = Wb[(size_t)(cin + 4 * kq + s) * HO];
-#pragma unroll
-                for (int s = 0; s < XS; ++s) {
-                    const int l = XQ == 4 ? 4 * kq + s : 4 * s + kq;
-                    Wr[ks][kc][ct][4 + s] = l < cin ? Wb[(size_t)l * HO] : 0.f;
-                }
-            }
-}
-
-// One row tile of a forward convolution: acc[kc][ct] (lane (j, kq): rows 4 kq .. 4 kq + 3 of the tile, column 16 ct + j) = V_kc, then the
-// category mix through the wave's LDS tile; epi(local row, global row, r, y[CT]) receives the finished pre-activations (bias not added).
-template <int KC, int XQ, int CT, class Epi>
-__device__ __forceinline__ void project_tile(const Slabs& z, const float (&Wr)[SC_KS][KC][CT][4 + (XQ == 4 ? 4 : XQ)], const float* __restrict__ Tl,
-                                             float* __restrict__ ms, int row0, int RPT, int NC, int C, int cin, int j, int kq, Epi epi) {
-    constexpr int XS = XQ == 4 ? 4 : XQ, MS = 16 * CT + 1;
-    const int row = row0 + j;
-    const bool ok = j < RPT && row < NC;
-    f32x4 acc[KC][CT];
-#pragma unroll
-    for (int kc = 0; kc < KC; ++kc)
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) acc[kc][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < SC_KS; ++ks) {
-        f32x4 ah = {0.f, 0.f, 0.f, 0.f};
-        float ax[XS];
-#pragma unroll
-        for (int s = 0; s < XS; ++s) ax[s] = 0.f;
-        if (ok) {
-            if (ks == 0) {
-                ah = ld4(z.P0h + (size_t)row * SC_H + 4 * kq);
-                if (XQ == 4) {
-                    const f32x4 v = ld4(z.P0x + (size_t)row * SC_H + 4 * kq);
-#pragma unroll
-                    for (int s = 0; s < XS; ++s) ax[s] = v[s];
-                } else {
-#pragma unroll
-                    for (int s = 0; s < XS; ++s)
-                        if (4 * s + kq < cin) ax[s] = z.P0x[(size_t)row * cin + 4 * s + kq];
-                }
-            } else {
-                ah = ld4(z.P1h + (size_t)row * z.ld1h + 4 * kq);
-                if (XQ == 4) {
-                    const f32x4 v = ld4(z.P1x + (size_t)row * z.ld1x + 4 * kq);
-#pragma unroll
-                    for (int s = 0; s < XS; ++s) ax[s] = v[s];
-                } else {
-#pragma unroll
-                    for (int s = 0; s < XS; ++s) ax[s] = z.P1x[(size_t)row * z.ld1x + 4 * s + kq];
-                }
+            for (int s = 0; s < XS; ++s) {
+                const int l = XQ == 4 ? 4 * kq + s : 4 * s + kq;
+                Wr[ks][kc][4 + s] = ld_if(Wb, (unsigned)l * HO, l < cin);
             }
         }
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int kc = 0; kc < KC; ++kc)
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) acc[kc][ct] = mfma4(ah[s], Wr[ks][kc][ct][s], acc[kc][ct]);
-#pragma unroll
-        for (int s = 0; s < XS; ++s)
-#pragma unroll
-            for (int kc = 0; kc < KC; ++kc)
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) acc[kc][ct] = mfma4(ax[s], Wr[ks][kc][ct][4 + s], acc[kc][ct]);
-    }
+}
+
+// The category mix of a row tile as a matrix product on the tile itself: a tile holds whole nodes, so mixing the C rows of each node is
+//   out = M . V,   M[i][k] = T[c(k)][c(i)] (forward;  T[c(i)][c(k)] for the transposed mix of the backward) when rows i, k belong to the same
+// node, else 0 -- a 16 x 16 x 16 product = four v_mfma_f32_16x16x4_f32 whose B operands ARE the accumulator registers of V (contraction index
+// of step s: 4 kq + s = the row that register s of lane (., kq) holds).  M's A operands are four registers per lane, built once per launch.
+// (The first version mixed with a VALU loop over LDS: C dependent LDS reads per output element, ~1 us per tile, most of the phase.)
+template <int KC>
+__device__ __forceinline__ void build_mix(float (&M)[KC][4], const float* __restrict__ Tc, bool transposed, int rpt, int C, int invC, int j, int kq) {
+    const int ni = div_c(j, invC), ci = j - ni * C;
 #pragma unroll
     for (int kc = 1; kc < KC; ++kc)
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
+        for (int s = 0; s < 4; ++s) {
+            const int k = 4 * kq + s, nk = div_c(k, invC), ck = k - nk * C;
+            const bool same = j < rpt && k < rpt && ni == nk;
+            M[kc][s] = same ? (transposed ? Tc[(kc * C + ci) * C + ck] : Tc[(kc * C + ck) * C + ci]) : 0.f;
+        }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ms[((kc - 1) * 16 + 4 * kq + r) * MS + 16 * ct + j] = acc[kc][ct][r];
-    __builtin_amdgcn_wave_barrier();
+    for (int s = 0; s < 4; ++s) M[0][s] = 0.f;                    // (T_0 = I: never multiplied)
+}
+
+// The row tiles tile0, tile0 + tstep, .. of a forward convolution for ONE 16-column tile of its output: V_kc in the accumulators (lane
+// (j, kq): rows 4 kq .. 4 kq + 3 of the tile, column j), the category mix as four more matrix instructions per kc >= 1 into V_0's
+// accumulator, epi(global row, y) per finished pre-activation (bias not added).  z0(row) / z1(row): the lane's A operands of slab 0 /
+// slab 1; slab 1 (the aggregate the previous phase left in global memory) is requested one tile ahead.
+template <int KC, int XQ, class Z0, class Z1, class Epi>
+__device__ __forceinline__ void fwd_conv(const float (&Wr)[SC_KS][KC][4 + (XQ == 4 ? 4 : XQ)], const float (&M)[KC][4], int tile0, int tstep, int tiles,
+                                         int rpt, int NC, int j, int kq, Z0 z0, Z1 z1, Epi epi) {
+    constexpr int XS = XQ == 4 ? 4 : XQ;
+    // rows that do not exist (beyond the tile's nodes / the sample) read row 0: their products land in accumulator rows nobody stores, and
+    // the mix couples rows of one node only
+    auto row_of = [&](int tile) { return tile < tiles && j < rpt && tile * rpt + j < NC ? tile * rpt + j : 0; };
+    AOp<XS> nxt = z1(row_of(tile0));
+    for (int tile = tile0; tile < tiles; tile += tstep) {
+        const int row0 = tile * rpt;
+        AOp<XS> a[SC_KS];
+        a[1] = nxt;
+        nxt = z1(row_of(tile + tstep));
+        a[0] = z0(row_of(tile));
+        f32x4 acc[KC];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int lrow = 4 * kq + r, grow = row0 + lrow;
-        if (lrow < RPT && grow < NC) {
-            const int nl = lrow / C, cp = lrow - nl * C;
-            float y[CT];
+        for (int kc = 0; kc < KC; ++kc) acc[kc] = zero4();
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) y[ct] = acc[0][ct][r];
+        for (int ks = 0; ks < SC_KS; ++ks) {
 #pragma unroll
-            for (int kc = 1; kc < KC; ++kc)
-                for (int c = 0; c < C; ++c) {
-                    const float tt = Tl[(kc * C + c) * C + cp];
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
-                    for (int ct = 0; ct < CT; ++ct) y[ct] = fmaf(tt, ms[((kc - 1) * 16 + nl * C + c) * MS + 16 * ct + j], y[ct]);
-                }
-            epi(grow, y);
+                for (int kc = 0; kc < KC; ++kc) acc[kc] = mfma4(a[ks].h[s], Wr[ks][kc][s], acc[kc]);
+#pragma unroll
+            for (int s = 0; s < XS; ++s)
+#pragma unroll
+                for (int kc = 0; kc < KC; ++kc) acc[kc] = mfma4(a[ks].x[s], Wr[ks][kc][4 + s], acc[kc]);
+        }
+#pragma unroll
+        for (int kc = 1; kc < KC; ++kc)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc[0] = mfma4(M[kc][s], acc[kc][s], acc[0]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int lrow = 4 * kq + r, grow = row0 + lrow;
+            if (lrow < rpt && grow < NC) epi(grow, acc[0][r]);
         }
     }
-    __builtin_amdgcn_wave_barrier();            // the next tile overwrites ms
 }
 
 struct SmallFwd {
@@ -188,255 +228,329 @@ struct SmallFwd {
     int N, C, cin, rpt, tiles;
 };
 
-template <int KC, int XQ>
-__global__ __launch_bounds__(SC_THREADS) void small_fwd_kernel(SmallFwd a) {
-    constexpr int LP = 16 + 4 * XQ, XS = XQ == 4 ? 4 : XQ;
-    __shared__ float Tl[SC_MAXKC * SC_MAXC * SC_MAXC];
-    __shared__ float mixs[SC_WAVES][(KC - 1) * 16 * 33];
+template <int KC>
+__host__ __device__ constexpr int fwd_lds_fixed() { return 0; }                                         // floats of LDS every launch needs
+
+template <int KC, int XQ, bool STAGED>
+__global__ __launch_bounds__(SF_THREADS) void small_fwd_kernel(SmallFwd a) {
+    constexpr int LP = 16 + 4 * XQ, XS = XQ == 4 ? 4 : XQ, SP = plane_stride(XQ);
+    extern __shared__ __align__(16) float lds[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, j = lane & 15, kq = lane >> 4;
-    const int C = a.C, NC = a.N * C, cin = a.cin;
+    const int C = a.C, N = a.N, NC = N * C, cin = a.cin, invC = ((1 << 20) + C - 1) / C;
+    float* P = lds + fwd_lds_fixed<KC>();                   // STAGED: [H | X | 0] rows of the sample, stride SP
+    float* Q = P + (size_t)NC * SP;                         //         R*H rows, stride SQ
+    int* gpl = reinterpret_cast<int*>(Q + (size_t)NC * SQ);
+    int* gcl = gpl + ((N + 4) & ~3);
+    float* gvl = reinterpret_cast<float*>(gcl + ((a.g.nnz + 3) & ~3));
+    const int* gp = STAGED ? gpl : a.g.rowptr;
+    const int* gc = STAGED ? gcl : a.g.colidx;
+    const float* gv = STAGED ? gvl : a.g.val;
     const size_t r0 = (size_t)blockIdx.x * NC;
     const float* Xb = a.X + r0 * cin;
     const float* Hb = a.H + r0 * SC_H;
     float* Ub = a.U + r0 * SC_H;
     float* Rb = a.R + r0 * SC_H;
-    float* RHb = a.RH + r0 * SC_H;           // (written in phase 2, read in 3 and 4: never through a __restrict__ / const path)
+    float* RHb = a.RH + r0 * SC_H;           // (written in phase 2, read later in the launch: never through a __restrict__ / const path)
     float* Zgb = a.Zg + r0 * LP;
     float* Zcb = a.Zc + r0 * SC_H;
-    for (int i = t; i < KC * C * C; i += SC_THREADS) Tl[i] = a.Tc[i];
+
+    // 0: tables, graph and the sample's rows into LDS (the gates' W operands are requested first: in flight during phases 0 and 1)
+    const int ct = wave & 1;                                 // gates: wave w owns column tile w % 2 (0: update, 1: reset)
+    float Wg_r[SC_KS][KC][4 + XS];
+    load_w_fwd<KC, XQ>(Wg_r, a.Wg, 2 * SC_H, 16 * ct + j, cin, kq);
+    float M[KC][4];
+    build_mix<KC>(M, a.Tc, false, a.rpt, C, invC, j, kq);
+    if (STAGED) {
+        stage_graph<SF_THREADS>(a.g, N, gpl, gcl, gvl);
+        for (int item = t; item < NC * 4; item += SF_THREADS) {
+            const int row = item >> 2, q = item & 3;
+            st4(P + (unsigned)row * SP + 4 * q, ld4(Hb + (unsigned)row * SC_H + 4 * q));
+            if (XQ == 4) st4(P + (unsigned)row * SP + 16 + 4 * q, ld4(Xb + (unsigned)row * SC_H + 4 * q));
+        }
+        if (XQ != 4)
+            for (int item = t; item < NC * XQ; item += SF_THREADS) {
+                const int row = item / XQ, q = item - row * XQ;
+                f32x4 x = zero4();
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (4 * q + i < cin) x[i] = Xb[(unsigned)row * cin + 4 * q + i];
+                st4(P + (unsigned)row * SP + 16 + 4 * q, x);
+            }
+    }
+    __syncthreads();
 
     // 1: Zg = S.[H | X]
-    aggregate_rows(a.g, NC, C, LP / 4,
+    aggregate_rows<SF_THREADS, LP / 4>(gp, gc, gv, NC, C, invC,
         [&](int src, int q) -> f32x4 {
-            if (q < 4) return ld4(Hb + (size_t)src * SC_H + 4 * q);
-            if (XQ == 4) return ld4(Xb + (size_t)src * SC_H + 4 * (q - 4));
-            f32x4 x = {0.f, 0.f, 0.f, 0.f};
+            if (STAGED) return ld4(P + (unsigned)src * SP + 4 * q);
+            if (q < 4) return ld4(Hb + (unsigned)src * SC_H + 4 * q);
+            if (XQ == 4) return ld4(Xb + (unsigned)src * SC_H + 4 * (q - 4));
+            f32x4 x = zero4();
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                if (4 * (q - 4) + i < cin) x[i] = Xb[(size_t)src * cin + 4 * (q - 4) + i];
+                if (4 * (q - 4) + i < cin) x[i] = Xb[(unsigned)src * cin + 4 * (q - 4) + i];
             return x;
         },
-        [](int, int) -> f32x4 { return f32x4{0.f, 0.f, 0.f, 0.f}; },
-        [&](int row, int q, f32x4 s) { st4(Zgb + (size_t)row * LP + 4 * q, s); });
+        [](int, int) -> f32x4 { return zero4(); }, [&](int row, int q, f32x4 s) { st4(Zgb + (unsigned)row * LP + 4 * q, s); });
     __syncthreads();
     SC_PHASE_END(1);
 
-    // 2: gates
+    // 2: gates -- wave w: column tile w % 2 of the row tiles w / 2, w / 2 + 8, ..
     {
-        float Wr[SC_KS][KC][2][4 + XS];
-        load_w_fwd<KC, XQ, 2>(Wr, a.Wg, cin, j, kq);
-        const float bu = a.bg ? a.bg[j] : 0.f, br = a.bg ? a.bg[SC_H + j] : 0.f;
-        const Slabs z{Hb, Xb, Zgb, LP, Zgb + SC_H, LP};
-        for (int tile = wave; tile < a.tiles; tile += SC_WAVES)
-            project_tile<KC, XQ, 2>(z, Wr, Tl, mixs[wave], tile * a.rpt, a.rpt, NC, C, cin, j, kq, [&](int grow, const float (&y)[2]) {
-                const size_t e = (size_t)grow * SC_H + j;
-                const float u = sigm(y[0] + bu), rr = sigm(y[1] + br);
-                Ub[e] = u;
-                Rb[e] = rr;
-                RHb[e] = rr * Hb[e];
+        const float bias = a.bg ? a.bg[16 * ct + j] : 0.f;
+        fwd_conv<KC, XQ>(Wg_r, M, wave >> 1, SF_WAVES / 2, a.tiles, a.rpt, NC, j, kq,
+            [&](int row) { return STAGED ? load_op<XQ>(P, SP, P + 16, SP, true, cin, row, kq) : load_op<XQ>(Hb, SC_H, Xb, cin, false, cin, row, kq); },
+            [&](int row) { return load_op<XQ>(Zgb, LP, Zgb + 16, LP, true, cin, row, kq); },
+            [&](int grow, float y) {
+                const size_t e = (unsigned)grow * SC_H + j;
+                const float g = sigm(y + bias);
+                if (ct == 0) {
+                    Ub[e] = g;
+                } else {
+                    const float rh = g * (STAGED ? P[(unsigned)grow * SP + j] : Hb[e]);
+                    Rb[e] = g;
+                    RHb[e] = rh;
+                    if (STAGED) Q[(unsigned)grow * SQ + j] = rh;
+                }
             });
     }
     __syncthreads();
     SC_PHASE_END(2);
 
-    // 3: Zc = S.(R*H)
-    aggregate_rows(a.g, NC, C, 4, [&](int src, int q) -> f32x4 { return ld4(RHb + (size_t)src * SC_H + 4 * q); },
-                   [](int, int) -> f32x4 { return f32x4{0.f, 0.f, 0.f, 0.f}; }, [&](int row, int q, f32x4 s) { st4(Zcb + (size_t)row * SC_H + 4 * q, s); });
+    // 3: Zc = S.(R*H)   (the candidate's W operands in flight meanwhile)
+    float Wc_r[SC_KS][KC][4 + XS];
+    load_w_fwd<KC, XQ>(Wc_r, a.Wc, SC_H, j, cin, kq);
+    aggregate_rows<SF_THREADS, 4>(gp, gc, gv, NC, C, invC,
+        [&](int src, int q) -> f32x4 { return STAGED ? ld4(Q + (unsigned)src * SQ + 4 * q) : ld4(RHb + (unsigned)src * SC_H + 4 * q); },
+        [](int, int) -> f32x4 { return zero4(); }, [&](int row, int q, f32x4 s) { st4(Zcb + (unsigned)row * SC_H + 4 * q, s); });
     __syncthreads();
     SC_PHASE_END(3);
 
     // 4: candidate + blend
     {
-        float Wr[SC_KS][KC][1][4 + XS];
-        load_w_fwd<KC, XQ, 1>(Wr, a.Wc, cin, j, kq);
-        const float bcj = a.bc ? a.bc[j] : 0.f;
-        const Slabs z{RHb, Xb, Zcb, SC_H, Zgb + SC_H, LP};
+        const float bias = a.bc ? a.bc[j] : 0.f;
         float* Cb = a.Cand + r0 * SC_H;
         float* Hn = a.Hnew + r0 * SC_H;
-        for (int tile = wave; tile < a.tiles; tile += SC_WAVES)
-            project_tile<KC, XQ, 1>(z, Wr, Tl, mixs[wave], tile * a.rpt, a.rpt, NC, C, cin, j, kq, [&](int grow, const float (&y)[1]) {
-                const size_t e = (size_t)grow * SC_H + j;
-                const float cd = tanhf(y[0] + bcj), u = Ub[e];
+        fwd_conv<KC, XQ>(Wc_r, M, wave, SF_WAVES, a.tiles, a.rpt, NC, j, kq,
+            [&](int row) { return STAGED ? load_op<XQ>(Q, SQ, P + 16, SP, true, cin, row, kq) : load_op<XQ>(RHb, SC_H, Xb, cin, false, cin, row, kq); },
+            [&](int row) { return load_op<XQ>(Zcb, SC_H, Zgb + 16, LP, true, cin, row, kq); },
+            [&](int grow, float y) {
+                const size_t e = (unsigned)grow * SC_H + j;
+                const float cd = tanhf(y + bias), u = Ub[e], hh = STAGED ? P[(unsigned)grow * SP + j] : Hb[e];
                 Cb[e] = cd;
-                Hn[e] = (1.f - u) * Hb[e] + u * cd;
+                Hn[e] = (1.f - u) * hh + u * cd;
             });
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------------------ backward
-// W in B-operand order for dZ = dV . W^T: step st feeds the contraction index (kc, o) = (st / (HO/4), 4 (st % (HO/4)) + kq); output
-// column tile lt = 0: the H block (l = cin + j), lt = 1: the X block (l = j < cin).
+// 16 waves: FOUR waves share a row tile, one per (slab ks, role): role 0 forms dZ_ks = dV . W[(ks, :, :)]^T (32 registers of W^T), role 1
+// accumulates the slab's share of dW (32 accumulator registers) and, for slab 0, db.  All four form the mixed gradients dV_kc themselves,
+// each in its own LDS tile.  Per wave that is ~80 registers, so four waves per SIMD hide each other's LDS / global latencies (8 waves
+// carrying both slabs and both roles: 53 us for the gates convolution at the SF shape against 15 us of matrix-pipe time), and the
+// two roles run the same number of matrix instructions per tile.
+// W in B-operand order for dZ_ks: step st feeds the contraction index (kc, o) = (st / (HO/4), 4 (st % (HO/4)) + kq); output column tile
+// lt = 0: the H block (l = cin + j), lt = 1: the X block (l = j < cin).
 template <int KC, int OT>
-__device__ __forceinline__ void load_w_bwd(float (&WT)[SC_KS][2][KC * 4 * OT], const float* __restrict__ W, int cin, int j, int kq) {
+__device__ __forceinline__ void load_w_bwd(float (&WT)[2][KC * 4 * OT], const float* __restrict__ W, int ks, int cin, int j, int kq) {
     constexpr int HO = 16 * OT, SPK = HO / 4;
     const int L = cin + SC_H;
 #pragma unroll
-    for (int ks = 0; ks < SC_KS; ++ks)
+    for (int lt = 0; lt < 2; ++lt) {
+        const int l = lt == 0 ? cin + j : j;
+        const bool ok = lt == 0 || j < cin;
 #pragma unroll
-        for (int lt = 0; lt < 2; ++lt) {
-            const int l = lt == 0 ? cin + j : j;
-            const bool ok = lt == 0 || j < cin;
-#pragma unroll
-            for (int st = 0; st < KC * SPK; ++st) {
-                const int kc = st / SPK, o = 4 * (st % SPK) + kq;
-                WT[ks][lt][st] = ok ? W[(size_t)((ks * KC + kc) * L + l) * HO + o] : 0.f;
-            }
+        for (int st = 0; st < KC * SPK; ++st) {
+            const int kc = st / SPK, o = 4 * (st % SPK) + kq;
+            WT[lt][st] = ld_if(W, (unsigned)((ks * KC + kc) * L + l) * HO + o, ok);
         }
+    }
 }
 
-// Backward of one convolution over the row tiles of a sample.  form_dy(local row, global row, quad) -> 4 columns of dY per column tile;
-// the mixed gradients dV_kc live in the wave's LDS tile dv[kc][16][HO + 1]; dZ_0 / dZ_1 go to the workspace slabs, the dW / db partial
-// sums stay in registers across the wave's tiles.
-template <int KC, int XQ, int OT, class FormDy>
-__device__ __forceinline__ void conv_bwd_phase(const Slabs& z, const float* __restrict__ W, const float* __restrict__ Tl, float* __restrict__ dv,
-                                               float* __restrict__ red, float* __restrict__ dZ0, float* __restrict__ dZ1, float* __restrict__ dW,
-                                               float* __restrict__ db, int rpt, int tiles, int NC, int C, int cin, FormDy form_dy) {
-    constexpr int LP = 16 + 4 * XQ, HO = 16 * OT, DS = HO + 1, SPK = HO / 4;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, j = lane & 15, kq = lane >> 4, L = cin + SC_H;
-    float WT[SC_KS][2][KC * SPK];
-    load_w_bwd<KC, OT>(WT, W, cin, j, kq);
-    f32x4 dw[SC_KS][2][KC][OT];
-    float dbv[OT];
+struct Slab {                                    // one slab of a convolution's input as the backward reads it (global memory):
+    const float* Ph;                             // [Ph (16 columns, row stride ldh) | Px (cin columns, row stride ldx)]
+    int ldh;
+    const float* Px;
+    int ldx;
+};
+
+// Backward of one convolution over the row tiles of a sample, for the slab ks = wave % 2 and the role (wave / 2) % 2.  load_dy(global
+// row, column) -> the raw operands of one element of dY per column tile (requested one tile ahead), form_dy(raw, column tile) -> dY.  A lane
+// holds dY in ACCUMULATOR layout (rows 4 kq + s, column j), so the transposed category mix dV_kc = M . dY is four matrix instructions per
+// kc >= 1 (build_mix) and dY / dV_kc are, as they stand in registers, the B operands of the dW products (contraction = the tile's rows in
+// the order 4 kq + s): role 1 touches no LDS at all.  Role 0 needs dV_kc with rows on lanes (A operands of dZ): one pass through the
+// wave's LDS tile dv[kc][16][HO + 1].  dZ_ks goes to `dZ` (slab 1: LDS when staged); the dW / db partial sums stay in registers across the
+// wave's tiles and are added to the row of the parameter-gradient partials that the tile's four waves share (disjoint parts).
+template <int KC, int XQ, int OT, class Raw, class LoadDy, class FormDy>
+__device__ __forceinline__ void conv_bwd_phase(const Slab& z, const float* __restrict__ W, int ks, int role, const float (&M)[KC][4],
+                                               float* __restrict__ dv, float* dZ, float* __restrict__ dW, float* __restrict__ db, int rpt, int tiles,
+                                               int NC, int cin, LoadDy load_dy, FormDy form_dy) {
+    constexpr int LP = 16 + 4 * XQ, HO = 16 * OT, DS = HO + 1, SPK = HO / 4, QUADS = SB_WAVES / 4;
+    const int t = threadIdx.x, lane = t & 63, quad = t >> 8, j = lane & 15, kq = lane >> 4, L = cin + SC_H;
+    // Rows 4 kq + s of a tile as a lane addresses them: clamped into the sample (rows of a tile beyond its nodes or beyond the sample, and
+    // whole tiles requested past the end, read the last row: finite values that meet a zero mask) -- one v_min per row and tile instead of a
+    // compare / select pair per LOAD: the vector unit, not the matrix pipe, paces these loops (a matrix instruction holds the issue port).
+    struct Rows {
+        unsigned r[4];
+    };
+    auto rows_of = [&](int tile) {
+        Rows w;
 #pragma unroll
-    for (int ks = 0; ks < SC_KS; ++ks)
+        for (int s = 0; s < 4; ++s) w.r[s] = min((unsigned)(tile * rpt + 4 * kq + s), (unsigned)(NC - 1));
+        return w;
+    };
+    bool in_tile[4];
 #pragma unroll
-        for (int lt = 0; lt < 2; ++lt)
+    for (int s = 0; s < 4; ++s) in_tile[s] = 4 * kq + s < rpt;
+    auto mask_of = [&](int tile, int s) { return in_tile[s] && tile * rpt + 4 * kq + s < NC; };
+    auto request = [&](const Rows& w, Raw (&raw)[4]) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) raw[s] = load_dy(w.r[s], j);
+    };
+    // dY (rows 4 kq + s, column 16 ot + j) and the mixed gradients dV_kc = M . dY of a tile, both in accumulator layout
+    auto form_and_mix = [&](int tile, const Raw (&cur)[4], float (&dy)[OT][4], f32x4 (&dvk)[KC][OT]) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float m = mask_of(tile, s) ? 1.f : 0.f;
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot) dy[ot][s] = m * form_dy(cur[s], ot);
+        }
+#pragma unroll
+        for (int kc = 1; kc < KC; ++kc)
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot) {
+                dvk[kc][ot] = zero4();
+#pragma unroll
+                for (int s = 0; s < 4; ++s) dvk[kc][ot] = mfma4(M[kc][s], dy[ot][s], dvk[kc][ot]);
+            }
+    };
+    if (role == SC_SKIP_ROLE) return;
+    Raw nxt[4];
+    request(rows_of(quad), nxt);
+
+    if (role == 0) {
+        float WT[2][KC * SPK];
+        load_w_bwd<KC, OT>(WT, W, ks, cin, j, kq);
+        for (int tile = quad; tile < tiles; tile += QUADS) {
+            const int row0 = tile * rpt;
+            Raw cur[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) cur[s] = nxt[s];
+            request(rows_of(tile + QUADS), nxt);
+            float dy[OT][4];
+            f32x4 dvk[KC][OT];
+            form_and_mix(tile, cur, dy, dvk);
 #pragma unroll
             for (int kc = 0; kc < KC; ++kc)
 #pragma unroll
-                for (int ot = 0; ot < OT; ++ot) dw[ks][lt][kc][ot] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int ot = 0; ot < OT; ++ot)
 #pragma unroll
-    for (int ot = 0; ot < OT; ++ot) dbv[ot] = 0.f;
-
-    for (int tile = wave; tile < tiles; tile += SC_WAVES) {
-        const int row0 = tile * rpt;
-        {   // dY of the tile, row layout: lane -> (row lane / 4, columns 4 (lane % 4) .. + 3 of every column tile)
-            const int rr = lane >> 2, qd = lane & 3, grow = row0 + rr;
-            const bool ok = rr < rpt && grow < NC;
-#pragma unroll
-            for (int ot = 0; ot < OT; ++ot) {
-                const f32x4 d = ok ? form_dy(grow, qd, ot) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) dv[rr * DS + 16 * ot + 4 * qd + i] = d[i];
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        // mix^T: dV_kc[(n, c)] = sum_c' T_kc[c, c'] dY[(n, c')]
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int lrow = 4 * kq + r;
-            const int nl = lrow / C, c = lrow - nl * C;
-            const bool ok = lrow < rpt && row0 + lrow < NC;
-#pragma unroll
-            for (int kc = 1; kc < KC; ++kc) {
-                float s[OT];
-#pragma unroll
-                for (int ot = 0; ot < OT; ++ot) s[ot] = 0.f;
-                if (ok)
-                    for (int cp = 0; cp < C; ++cp) {
-                        const float tt = Tl[(kc * C + c) * C + cp];
-#pragma unroll
-                        for (int ot = 0; ot < OT; ++ot) s[ot] = fmaf(tt, dv[(nl * C + cp) * DS + 16 * ot + j], s[ot]);
-                    }
-#pragma unroll
-                for (int ot = 0; ot < OT; ++ot) dv[(kc * 16 + lrow) * DS + 16 * ot + j] = s[ot];
-            }
-#pragma unroll
-            for (int ot = 0; ot < OT; ++ot) dbv[ot] += dv[lrow * DS + 16 * ot + j];
-        }
-        __builtin_amdgcn_wave_barrier();
-        // dZ_ks = sum_kc dV_kc . W[(ks, kc, :)]^T
-        {
-            f32x4 dz[SC_KS][2];
-#pragma unroll
-            for (int ks = 0; ks < SC_KS; ++ks)
-#pragma unroll
-                for (int lt = 0; lt < 2; ++lt) dz[ks][lt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int r = 0; r < 4; ++r) dv[(kc * 16 + 4 * kq + r) * DS + 16 * ot + j] = kc == 0 ? dy[ot][r] : dvk[kc][ot][r];
+            __builtin_amdgcn_wave_barrier();
+            f32x4 dz[2] = {zero4(), zero4()};
 #pragma unroll
             for (int st = 0; st < KC * SPK; ++st) {
                 const int kc = st / SPK, o = 4 * (st % SPK) + kq;
                 const float av = dv[(kc * 16 + j) * DS + o];
 #pragma unroll
-                for (int ks = 0; ks < SC_KS; ++ks)
-#pragma unroll
-                    for (int lt = 0; lt < 2; ++lt) dz[ks][lt] = mfma4(av, WT[ks][lt][st], dz[ks][lt]);
+                for (int lt = 0; lt < 2; ++lt) dz[lt] = mfma4(av, WT[lt][st], dz[lt]);
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int lrow = 4 * kq + r, grow = row0 + lrow;
-                if (lrow < rpt && grow < NC) {
-                    dZ0[(size_t)grow * LP + j] = dz[0][0][r];
-                    dZ1[(size_t)grow * LP + j] = dz[1][0][r];
-                    if (j < LP - 16) {
-                        dZ0[(size_t)grow * LP + 16 + j] = dz[0][1][r];
-                        dZ1[(size_t)grow * LP + 16 + j] = dz[1][1][r];
-                    }
+            for (int r = 0; r < 4; ++r)
+                if (mask_of(tile, r)) {
+                    const unsigned e = (unsigned)(row0 + 4 * kq + r) * LP + j;
+                    dZ[e] = dz[0][r];
+                    if (j < LP - 16) dZ[e + 16] = dz[1][r];
                 }
-            }
+            __builtin_amdgcn_wave_barrier();    // the next tile overwrites dv
         }
-        // dW[(ks, kc, l), o] += sum_rows Z_ks[row, l] dV_kc[row, o]: the rows are the contraction (4 steps of 4 rows)
+        return;
+    }
+    // role 1: dW[(ks, kc, l), o] += sum_rows Z_ks[row, l] dV_kc[row, o] -- the rows are the contraction (4 steps: rows 4 kq + st)
+    f32x4 dw[2][KC][OT];
+    float dbv[OT];
+#pragma unroll
+    for (int lt = 0; lt < 2; ++lt)
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot) dw[lt][kc][ot] = zero4();
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) dbv[ot] = 0.f;
+    // the A operands of a tile (rows 4 kq + st of Z_ks, column j), requested one tile ahead like dY.  Not masked: rows that do not exist meet
+    // dY = 0, and columns >= cin of a narrow X block (read as column cin - 1) feed dW entries that are never stored.
+    const unsigned jx = min(j, cin - 1);
+    auto request_z = [&](const Rows& w, float (&az)[4][2]) {
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
-            const int lrow = 4 * st + kq, grow = row0 + lrow;
-            const bool ok = lrow < rpt && grow < NC;
-            float az[SC_KS][2];
-            az[0][0] = ok ? z.P0h[(size_t)grow * SC_H + j] : 0.f;
-            az[0][1] = ok && j < cin ? z.P0x[(size_t)grow * cin + j] : 0.f;
-            az[1][0] = ok ? z.P1h[(size_t)grow * z.ld1h + j] : 0.f;
-            az[1][1] = ok && j < cin ? z.P1x[(size_t)grow * z.ld1x + j] : 0.f;
+            az[st][0] = z.Ph[w.r[st] * (unsigned)z.ldh + j];
+            az[st][1] = z.Px[w.r[st] * (unsigned)z.ldx + jx];
+        }
+    };
+    float azn[4][2];
+    request_z(rows_of(quad), azn);
+    for (int tile = quad; tile < tiles; tile += QUADS) {
+        Raw cur[4];
+        float az[4][2];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            cur[s] = nxt[s];
+            az[s][0] = azn[s][0];
+            az[s][1] = azn[s][1];
+        }
+        const Rows w = rows_of(tile + QUADS);
+        request(w, nxt);
+        request_z(w, azn);
+        float dy[OT][4];
+        f32x4 dvk[KC][OT];
+        form_and_mix(tile, cur, dy, dvk);
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
 #pragma unroll
             for (int kc = 0; kc < KC; ++kc)
 #pragma unroll
                 for (int ot = 0; ot < OT; ++ot) {
-                    const float bv = dv[(kc * 16 + lrow) * DS + 16 * ot + j];
+                    const float bv = kc == 0 ? dy[ot][st] : dvk[kc][ot][st];
+                    if (kc == 0) dbv[ot] += bv;
 #pragma unroll
-                    for (int ks = 0; ks < SC_KS; ++ks)
-#pragma unroll
-                        for (int lt = 0; lt < 2; ++lt) dw[ks][lt][kc][ot] = mfma4(az[ks][lt], bv, dw[ks][lt][kc][ot]);
+                    for (int lt = 0; lt < 2; ++lt) dw[lt][kc][ot] = mfma4(az[st][lt], bv, dw[lt][kc][ot]);
                 }
-        }
-        __builtin_amdgcn_wave_barrier();        // the next tile overwrites dv
     }
-
-    // the waves' partial sums, added in wave order (deterministic), then into the sample's row of the parameter-gradient partials
-    constexpr int NW = SC_KS * 2 * KC * OT * 4;
-    for (int w = 0; w < SC_WAVES; ++w) {
-        if (wave == w) {
+    // lane (j, kq), register r: l = 4 kq + r of tile lt, o = 16 ot + j.  All the old values are requested first, then added and stored
+    // (one read-modify-write after the other would be one L2 round trip each).
+    {
+        float old[2][KC][OT][4];
+        auto at = [&](int lt, int kc, int ot, int r) {
+            const int li = 4 * kq + r;
+            return dW + (unsigned)((ks * KC + kc) * L + (lt == 0 ? cin + li : li)) * HO + 16 * ot + j;
+        };
 #pragma unroll
-            for (int ks = 0; ks < SC_KS; ++ks)
+        for (int lt = 0; lt < 2; ++lt)
 #pragma unroll
-                for (int lt = 0; lt < 2; ++lt)
+            for (int kc = 0; kc < KC; ++kc)
 #pragma unroll
-                    for (int kc = 0; kc < KC; ++kc)
+                for (int ot = 0; ot < OT; ++ot)
 #pragma unroll
-                        for (int ot = 0; ot < OT; ++ot)
+                    for (int r = 0; r < 4; ++r) old[lt][kc][ot][r] = *at(lt, kc, ot, r);      // (rows l >= cin of the X block: some other row of W, readable, not stored)
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                float* p = red + ((((ks * 2 + lt) * KC + kc) * OT + ot) * 4 + r) * 64 + lane;
-                                *p = w == 0 ? dw[ks][lt][kc][ot][r] : *p + dw[ks][lt][kc][ot][r];
-                            }
+        for (int lt = 0; lt < 2; ++lt)
 #pragma unroll
-            for (int ot = 0; ot < OT; ++ot) {
-                float* p = red + (NW + ot) * 64 + lane;
-                *p = w == 0 ? dbv[ot] : *p + dbv[ot];
-            }
-        }
-        __syncthreads();
+            for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+                for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (lt == 0 || 4 * kq + r < cin) *at(lt, kc, ot, r) = old[lt][kc][ot][r] + dw[lt][kc][ot][r];
     }
-    for (int i = t; i < NW * 64; i += SC_THREADS) {
-        const int ln = i & 63, idx = i >> 6, r = idx & 3, ot = (idx >> 2) % OT, kc = (idx / (4 * OT)) % KC, lt = (idx / (4 * OT * KC)) & 1,
-                  ks = idx / (8 * OT * KC);
-        const int li = 4 * (ln >> 4) + r, o = 16 * ot + (ln & 15);
-        if (lt == 1 && li >= cin) continue;
-        const int l = lt == 0 ? cin + li : li;
-        dW[(size_t)((ks * KC + kc) * L + l) * HO + o] += red[i];
-    }
-    if (db != nullptr)
-        for (int o = t; o < HO; o += SC_THREADS) {
-            const float* p = red + (NW + o / 16) * 64 + (o & 15);
-            db[o] += (p[0] + p[16]) + (p[32] + p[48]);
+    if (db != nullptr && ks == 0) {
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) {
+            float v = dbv[ot];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (kq == 0) db[16 * ot + j] += v;
         }
-    __syncthreads();                             // red and dv are reused by the next phase
+    }
 }
 
 struct SmallBwd {
@@ -444,17 +558,33 @@ struct SmallBwd {
     const float *X, *H, *Tc, *Wg, *Wc, *U, *R, *Cand, *RH, *Zg, *Zc, *dHnew;
     float *dX, *dH, *dP, *ws;
     int N, C, cin, rpt, tiles, acc_x, acc_h, has_bg, has_bc;
-    long long P;                                 // floats per sample in dP: [dWg | dbg (32) | dWc | dbc (16)]
+    long long P;                                 // floats per row of dP: [dWg | dbg (32) | dWc | dbc (16)]; SB_WAVES / 4 rows per sample
 };
 
-template <int KC, int XQ>
-__global__ __launch_bounds__(SC_THREADS) void small_bwd_kernel(SmallBwd a) {
+struct Raw3 {
+    float d, u, c;
+};
+struct Raw2 {
+    float a, b;
+};
+
+template <int KC>
+__host__ __device__ constexpr int bwd_lds_fixed() { return SB_WAVES * KC * 16 * 33; }                     // floats: the waves' dV tiles
+
+template <int KC, int XQ, bool STAGED>
+__global__ __launch_bounds__(SB_THREADS) void small_bwd_kernel(SmallBwd a) {
     constexpr int LP = 16 + 4 * XQ;
-    __shared__ float Tl[SC_MAXKC * SC_MAXC * SC_MAXC];
-    __shared__ float dvs[SC_WAVES][KC * 16 * 33];
-    __shared__ float red[(SC_KS * 2 * KC * 2 * 4 + 2) * 64];
+    extern __shared__ __align__(16) float lds[];
     const int t = threadIdx.x, wave = t >> 6;
-    const int C = a.C, NC = a.N * C, cin = a.cin, L = cin + SC_H;
+    const int C = a.C, N = a.N, NC = N * C, cin = a.cin, L = cin + SC_H, invC = ((1 << 20) + C - 1) / C;
+    float* dv = lds + wave * KC * 16 * 33;
+    float* D1 = lds + bwd_lds_fixed<KC>();                   // STAGED: the slab dZ_1 of the convolution in flight, stride LP
+    int* gpl = reinterpret_cast<int*>(D1 + (size_t)NC * LP);
+    int* gcl = gpl + ((N + 4) & ~3);
+    float* gvl = reinterpret_cast<float*>(gcl + ((a.g.nnz + 3) & ~3));
+    const int* gp = STAGED ? gpl : a.g.rowptr;
+    const int* gc = STAGED ? gcl : a.g.colidx;
+    const float* gv = STAGED ? gvl : a.g.val;
     const size_t r0 = (size_t)blockIdx.x * NC;
     const float* Xb = a.X + r0 * cin;
     const float* Hb = a.H + r0 * SC_H;
@@ -469,35 +599,37 @@ __global__ __launch_bounds__(SC_THREADS) void small_bwd_kernel(SmallBwd a) {
     float* dHb = a.dH ? a.dH + r0 * SC_H : nullptr;
     float* wsb = a.ws + (size_t)blockIdx.x * NC * (2 * LP + 32);
     float* dZ0 = wsb;
-    float* dZ1 = wsb + (size_t)NC * LP;
+    float* dZ1 = STAGED ? D1 : wsb + (size_t)NC * LP;
     float* dYg = wsb + (size_t)NC * 2 * LP;
-    float* dPb = a.dP + (size_t)blockIdx.x * a.P;
-    float* dWg = dPb;
-    float* dbg = dPb + (size_t)SC_KS * KC * L * 32;
+    const int ks = wave & 1, role = (wave >> 1) & 1;
+    float* dPw = a.dP + ((size_t)blockIdx.x * (SB_WAVES / 4) + (wave >> 2)) * a.P;
+    float* dWg = dPw;
+    float* dbg = dPw + (size_t)SC_KS * KC * L * 32;
     float* dWc = dbg + 32;
     float* dbc = dWc + (size_t)SC_KS * KC * L * 16;
-    for (int i = t; i < KC * C * C; i += SC_THREADS) Tl[i] = a.Tc[i];
+    const int lane = t & 63;
+    float M[KC][4];
+    build_mix<KC>(M, a.Tc, true, a.rpt, C, invC, lane & 15, lane >> 4);
+    if (STAGED) stage_graph<SB_THREADS>(a.g, N, gpl, gcl, gvl);
     __syncthreads();
 
     // 1: candidate convolution
-    conv_bwd_phase<KC, XQ, 1>(Slabs{RHb, Xb, Zcb, SC_H, Zgb + SC_H, LP}, a.Wc, Tl, dvs[wave], red, dZ0, dZ1, dWc, a.has_bc ? dbc : nullptr, a.rpt,
-                              a.tiles, NC, C, cin, [&](int grow, int qd, int) -> f32x4 {
-                                  const size_t e = (size_t)grow * SC_H + 4 * qd;
-                                  const f32x4 d = ld4(dHn + e), u = ld4(Ub + e), cd = ld4(Cb + e);
-                                  f32x4 y;
-#pragma unroll
-                                  for (int i = 0; i < 4; ++i) y[i] = d[i] * u[i] * (1.f - cd[i] * cd[i]);
-                                  return y;
-                              });
-    // (conv_bwd_phase ends on a workgroup barrier: the dZ slabs are complete)
+    conv_bwd_phase<KC, XQ, 1, Raw3>(ks == 0 ? Slab{RHb, SC_H, Xb, cin} : Slab{Zcb, SC_H, Zgb + SC_H, LP}, a.Wc, ks, role, M, dv, ks == 0 ? dZ0 : dZ1, dWc,
+        a.has_bc ? dbc : nullptr, a.rpt, min(a.tiles, SC_MAX_TILES), NC, cin,
+        [&](int grow, int col) {
+            const size_t e = (unsigned)grow * SC_H + col;
+            return Raw3{dHn[e], Ub[e], Cb[e]};
+        },
+        [](const Raw3& w, int) { return w.d * w.u * (1.f - w.c * w.c); });
+    __syncthreads();                             // the dZ slabs are complete
     SC_PHASE_END(1);
 
     // 2: d[R*H | X] = dZ_0 + S^T dZ_1, gate backward
-    aggregate_rows(a.g, NC, C, LP / 4, [&](int src, int q) -> f32x4 { return ld4(dZ1 + (size_t)src * LP + 4 * q); },
-        [&](int row, int q) -> f32x4 { return ld4(dZ0 + (size_t)row * LP + 4 * q); },
+    aggregate_rows<SB_THREADS, LP / 4>(gp, gc, gv, NC, C, invC, [&](int src, int q) -> f32x4 { return ld4(dZ1 + (unsigned)src * LP + 4 * q); },
+        [&](int row, int q) -> f32x4 { return ld4(dZ0 + (unsigned)row * LP + 4 * q); },
         [&](int row, int q, f32x4 s) {
             if (q < 4) {
-                const size_t e = (size_t)row * SC_H + 4 * q;
+                const size_t e = (unsigned)row * SC_H + 4 * q;
                 const f32x4 hh = ld4(Hb + e), rr = ld4(Rb + e), u = ld4(Ub + e), cd = ld4(Cb + e), d = ld4(dHn + e);
                 f32x4 gu, gr, dh;
 #pragma unroll
@@ -506,8 +638,8 @@ __global__ __launch_bounds__(SC_THREADS) void small_bwd_kernel(SmallBwd a) {
                     gr[i] = s[i] * hh[i] * rr[i] * (1.f - rr[i]);
                     dh[i] = fmaf(d[i], 1.f - u[i], s[i] * rr[i]);
                 }
-                st4(dYg + (size_t)row * 32 + 4 * q, gu);
-                st4(dYg + (size_t)row * 32 + 16 + 4 * q, gr);
+                st4(dYg + (unsigned)row * 32 + 4 * q, gu);
+                st4(dYg + (unsigned)row * 32 + 16 + 4 * q, gr);
                 if (dHb) {
                     if (a.acc_h) {
                         const f32x4 o = ld4(dHb + e);
@@ -521,7 +653,7 @@ __global__ __launch_bounds__(SC_THREADS) void small_bwd_kernel(SmallBwd a) {
                 for (int i = 0; i < 4; ++i) {
                     const int col = 4 * (q - 4) + i;
                     if (col < cin) {
-                        float* p = dXb + (size_t)row * cin + col;
+                        float* p = dXb + (unsigned)row * cin + col;
                         *p = a.acc_x ? *p + s[i] : s[i];
                     }
                 }
@@ -531,18 +663,21 @@ __global__ __launch_bounds__(SC_THREADS) void small_bwd_kernel(SmallBwd a) {
     SC_PHASE_END(2);
 
     // 3: gates convolution
-    conv_bwd_phase<KC, XQ, 2>(Slabs{Hb, Xb, Zgb, LP, Zgb + SC_H, LP}, a.Wg, Tl, dvs[wave], red, dZ0, dZ1, dWg, a.has_bg ? dbg : nullptr, a.rpt, a.tiles,
-                              NC, C, cin, [&](int grow, int qd, int ot) -> f32x4 { return ld4(dYg + (size_t)grow * 32 + 16 * ot + 4 * qd); });
-
+    conv_bwd_phase<KC, XQ, 2, Raw2>(ks == 0 ? Slab{Hb, SC_H, Xb, cin} : Slab{Zgb, LP, Zgb + SC_H, LP}, a.Wg, ks, role, M, dv, ks == 0 ? dZ0 : dZ1, dWg,
+        a.has_bg ? dbg : nullptr, a.rpt, min(a.tiles, SC_MAX_TILES), NC, cin,
+        [&](int grow, int col) { return Raw2{dYg[(unsigned)grow * 32 + col], dYg[(unsigned)grow * 32 + 16 + col]}; },
+        [](const Raw2& w, int ot) { return ot == 0 ? w.a : w.b; });
+    __syncthreads();
     SC_PHASE_END(3);
+
     // 4: d[H | X] += dZ_0 + S^T dZ_1
     if (dHb || dXb)
-        aggregate_rows(a.g, NC, C, LP / 4, [&](int src, int q) -> f32x4 { return ld4(dZ1 + (size_t)src * LP + 4 * q); },
-            [&](int row, int q) -> f32x4 { return ld4(dZ0 + (size_t)row * LP + 4 * q); },
+        aggregate_rows<SB_THREADS, LP / 4>(gp, gc, gv, NC, C, invC, [&](int src, int q) -> f32x4 { return ld4(dZ1 + (unsigned)src * LP + 4 * q); },
+            [&](int row, int q) -> f32x4 { return ld4(dZ0 + (unsigned)row * LP + 4 * q); },
             [&](int row, int q, f32x4 s) {
                 if (q < 4) {
                     if (dHb) {
-                        float* p = dHb + (size_t)row * SC_H + 4 * q;
+                        float* p = dHb + (unsigned)row * SC_H + 4 * q;
                         const f32x4 o = ld4(p);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) s[i] += o[i];
@@ -552,19 +687,34 @@ __global__ __launch_bounds__(SC_THREADS) void small_bwd_kernel(SmallBwd a) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int col = 4 * (q - 4) + i;
-                        if (col < cin) dXb[(size_t)row * cin + col] += s[i];
+                        if (col < cin) dXb[(unsigned)row * cin + col] += s[i];
                     }
                 }
             });
 }
 
 int xq_of(int cin) { return cin == SC_H ? 4 : (cin >= 1 && cin <= 4 ? 1 : 0); }
+size_t graph_lds_bytes(int N, int nnz) { return (size_t)(((N + 4) & ~3) + 2 * ((nnz + 3) & ~3)) * 4; }
+constexpr size_t SC_LDS_BUDGET = 156 * 1024;     // of the 160 KB of a compute unit
+
+// Raise a kernel's dynamic-LDS cap only when a launch needs more than it was already granted (the attribute call costs microseconds, a
+// launch here is tens of them).  One process drives one GPU.
+template <class K>
+hipError_t allow_lds_once(K kern, size_t bytes, std::atomic<size_t>& granted) {
+    if (bytes <= granted.load(std::memory_order_relaxed)) return hipSuccess;
+    const hipError_t e = stc::allow_lds(kern, bytes);
+    if (e == hipSuccess) granted.store(bytes, std::memory_order_relaxed);
+    return e;
+}
+std::atomic<size_t> g_granted[2][2][2];          // [direction][wide input][staged]
 
 }  // namespace
 
 extern "C" int stc_cell_small_supported(int32_t Ks, int32_t Kc, int32_t C, int32_t cin, int32_t h) {
     return Ks == SC_KS && Kc == 2 && C >= 1 && C <= SC_MAXC && h == SC_H && xq_of(cin) != 0;
 }
+
+extern "C" int stc_cell_small_param_rows(void) { return SB_WAVES / 4; }
 
 extern "C" size_t stc_cell_small_workspace_bytes(int32_t n_nodes, int32_t C, int32_t cin, int32_t batch) {
     const int xq = xq_of(cin);
@@ -573,52 +723,68 @@ extern "C" size_t stc_cell_small_workspace_bytes(int32_t n_nodes, int32_t C, int
 }
 
 #define SC_COMMON_CHECKS(name)                                                                                                        \
-    STC_REQUIRE(n_nodes >= 0 && batch >= 0, STC_EINVAL, name ": negative size (n_nodes=%d batch=%d)", n_nodes, batch);                 \
+    STC_REQUIRE(n_nodes >= 0 && batch >= 0 && nnz >= 0, STC_EINVAL, name ": negative size (n_nodes=%d nnz=%d batch=%d)", n_nodes, nnz, batch); \
     STC_REQUIRE(stc_cell_small_supported(SC_KS, Kc, C, cin, SC_H), STC_EINVAL, name ": unsupported shape (Kc=%d C=%d cin=%d)", Kc, C, cin); \
-    STC_REQUIRE((long long)n_nodes * C * batch < (1ll << 26), STC_ELIMIT, name ": %lld rows: not a small graph", (long long)n_nodes * C * batch); \
+    STC_REQUIRE((long long)n_nodes * C < 65536 && (long long)n_nodes * C * batch < (1ll << 26), STC_ELIMIT,                             \
+                name ": %lld rows per sample, %d samples: not a small graph", (long long)n_nodes * C, batch);                           \
     if (n_nodes == 0 || batch == 0) return STC_OK;
 
-extern "C" int stc_cell_small_fwd_f32(const int32_t* rowptr, const int32_t* colidx, const float* val, int32_t n_nodes, const float* X, int32_t cin,
-                                      const float* H, const float* Tc, int32_t Kc, const float* Wg, const float* bg, const float* Wc,
+extern "C" int stc_cell_small_fwd_f32(const int32_t* rowptr, const int32_t* colidx, const float* val, int32_t n_nodes, int32_t nnz, const float* X,
+                                      int32_t cin, const float* H, const float* Tc, int32_t Kc, const float* Wg, const float* bg, const float* Wc,
                                       const float* bc, float* U, float* R, float* Cand, float* Hnew, float* RH, float* Zg, float* Zc,
                                       int32_t batch, int32_t C, void* stream) {
     SC_COMMON_CHECKS("stc_cell_small_fwd_f32")
-    STC_REQUIRE(rowptr && colidx && val && X && H && Tc && Wg && Wc && U && R && Cand && Hnew && RH && Zg && Zc, STC_EINVAL,
+    STC_REQUIRE(rowptr && (nnz == 0 || (colidx && val)) && X && H && Tc && Wg && Wc && U && R && Cand && Hnew && RH && Zg && Zc, STC_EINVAL,
                 "stc_cell_small_fwd_f32: null operand");
     STC_REQUIRE(Hnew != H, STC_EINVAL, "stc_cell_small_fwd_f32: Hnew must not alias H (neighbour rows are read after the first rows are written)");
     const int xq = xq_of(cin);
     STC_REQUIRE(stc::aligned16(H) && stc::aligned16(U) && stc::aligned16(R) && stc::aligned16(RH) && stc::aligned16(Zg) && stc::aligned16(Zc) &&
                     (xq != 4 || stc::aligned16(X)), STC_EINVAL, "stc_cell_small_fwd_f32: planes must be 16-byte aligned");
     const int npt = 16 / C, rpt = npt * C;
-    SmallFwd a{{rowptr, colidx, val}, X, H, Tc, Wg, bg, Wc, bc, U, R, Cand, Hnew, RH, Zg, Zc, n_nodes, C, cin, rpt, (n_nodes + npt - 1) / npt};
-    auto kern = xq == 4 ? small_fwd_kernel<2, 4> : small_fwd_kernel<2, 1>;
-    hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(SC_THREADS), 0, static_cast<hipStream_t>(stream), a);
+    SmallFwd a{{rowptr, colidx, val, nnz}, X, H, Tc, Wg, bg, Wc, bc, U, R, Cand, Hnew, RH, Zg, Zc, n_nodes, C, cin, rpt, (n_nodes + npt - 1) / npt};
+    const size_t fixed = (size_t)fwd_lds_fixed<2>() * 4;
+    const size_t staged = fixed + (size_t)n_nodes * C * (plane_stride(xq) + SQ) * 4 + graph_lds_bytes(n_nodes, nnz);
+    const bool st = staged <= SC_LDS_BUDGET;
+    const size_t lds = st ? staged : fixed;
+    auto kern = st ? (xq == 4 ? small_fwd_kernel<2, 4, true> : small_fwd_kernel<2, 1, true>)
+                   : (xq == 4 ? small_fwd_kernel<2, 4, false> : small_fwd_kernel<2, 1, false>);
+    const hipError_t e = allow_lds_once(kern, lds, g_granted[0][xq == 4][st]);
+    if (e != hipSuccess) return stc::hip_status(e, "stc_cell_small_fwd_f32 LDS attribute");
+    hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(SF_THREADS), lds, static_cast<hipStream_t>(stream), a);
     STC_LAUNCH_CHECK("stc_cell_small_fwd_f32 launch");
     return STC_OK;
 }
 
-extern "C" int stc_cell_small_bwd_f32(const int32_t* rowptr, const int32_t* colidx, const float* val, int32_t n_nodes, const float* X, int32_t cin,
-                                      const float* H, const float* Tc, int32_t Kc, const float* Wg, const float* Wc, const float* U,
+extern "C" int stc_cell_small_bwd_f32(const int32_t* rowptr, const int32_t* colidx, const float* val, int32_t n_nodes, int32_t nnz, const float* X,
+                                      int32_t cin, const float* H, const float* Tc, int32_t Kc, const float* Wg, const float* Wc, const float* U,
                                       const float* R, const float* Cand, const float* RH, const float* Zg, const float* Zc, const float* dHnew,
                                       float* dX, int32_t accumulate_x, float* dH, int32_t accumulate_h, float* dparams, int64_t params_ld,
                                       int32_t has_bg, int32_t has_bc, void* workspace, size_t workspace_bytes, int32_t batch, int32_t C,
                                       void* stream) {
     SC_COMMON_CHECKS("stc_cell_small_bwd_f32")
-    STC_REQUIRE(rowptr && colidx && val && X && H && Tc && Wg && Wc && U && R && Cand && RH && Zg && Zc && dHnew && dparams && workspace, STC_EINVAL,
-                "stc_cell_small_bwd_f32: null operand");
-    const int xq = xq_of(cin), L = cin + SC_H;
+    STC_REQUIRE(rowptr && (nnz == 0 || (colidx && val)) && X && H && Tc && Wg && Wc && U && R && Cand && RH && Zg && Zc && dHnew && dparams && workspace,
+                STC_EINVAL, "stc_cell_small_bwd_f32: null operand");
+    const int xq = xq_of(cin), L = cin + SC_H, LP = 16 + 4 * xq;
     const long long P = (long long)SC_KS * Kc * L * 48 + 48;
-    STC_REQUIRE(params_ld >= P, STC_EINVAL, "stc_cell_small_bwd_f32: params_ld %lld < %lld floats per sample", (long long)params_ld, P);
+    STC_REQUIRE(params_ld >= P, STC_EINVAL, "stc_cell_small_bwd_f32: params_ld %lld < %lld floats per row", (long long)params_ld, P);
     STC_REQUIRE(workspace_bytes >= stc_cell_small_workspace_bytes(n_nodes, C, cin, batch), STC_EINVAL, "stc_cell_small_bwd_f32: workspace too small");
     STC_REQUIRE(stc::aligned16(H) && stc::aligned16(U) && stc::aligned16(R) && stc::aligned16(Cand) && stc::aligned16(RH) && stc::aligned16(Zg) &&
                     stc::aligned16(Zc) && stc::aligned16(dHnew) && stc::aligned16(workspace) && (dH == nullptr || stc::aligned16(dH)),
                 STC_EINVAL, "stc_cell_small_bwd_f32: planes must be 16-byte aligned");
-    STC_REQUIRE(dH != dHnew && (const float*)dX != dHnew, STC_EINVAL, "stc_cell_small_bwd_f32: dHnew must not alias an output");
+    STC_REQUIRE(dH != dHnew && (const float*)dX != dHnew && (dX == nullptr || (const float*)dX != (const float*)dH), STC_EINVAL,
+                "stc_cell_small_bwd_f32: dHnew, dX and dH must be distinct buffers");
     const int npt = 16 / C, rpt = npt * C;
-    SmallBwd a{{rowptr, colidx, val}, X, H, Tc, Wg, Wc, U, R, Cand, RH, Zg, Zc, dHnew, dX, dH, dparams, static_cast<float*>(workspace),
+    SmallBwd a{{rowptr, colidx, val, nnz}, X, H, Tc, Wg, Wc, U, R, Cand, RH, Zg, Zc, dHnew, dX, dH, dparams, static_cast<float*>(workspace),
                n_nodes, C, cin, rpt, (n_nodes + npt - 1) / npt, accumulate_x, accumulate_h, has_bg, has_bc, params_ld};
-    auto kern = xq == 4 ? small_bwd_kernel<2, 4> : small_bwd_kernel<2, 1>;
-    hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(SC_THREADS), 0, static_cast<hipStream_t>(stream), a);
+    const size_t fixed = (size_t)bwd_lds_fixed<2>() * 4;
+    const size_t staged = fixed + (size_t)n_nodes * C * LP * 4 + graph_lds_bytes(n_nodes, nnz);
+    const bool st = staged <= SC_LDS_BUDGET;
+    const size_t lds = st ? staged : fixed;
+    auto kern = st ? (xq == 4 ? small_bwd_kernel<2, 4, true> : small_bwd_kernel<2, 1, true>)
+                   : (xq == 4 ? small_bwd_kernel<2, 4, false> : small_bwd_kernel<2, 1, false>);
+    const hipError_t e = allow_lds_once(kern, lds, g_granted[1][xq == 4][st]);
+    if (e != hipSuccess) return stc::hip_status(e, "stc_cell_small_bwd_f32 LDS attribute");
+    hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(SB_THREADS), lds, static_cast<hipStream_t>(stream), a);
     STC_LAUNCH_CHECK("stc_cell_small_bwd_f32 launch");
     return STC_OK;
 }

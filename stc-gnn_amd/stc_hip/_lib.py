@@ -39,7 +39,7 @@ EXPORTS = (
     'stc_cell_bwd_planar_supported', 'stc_cell_bwd_planar_workspace_bytes', 'stc_cell_bwd_planar_f32',
     'stc_cell_planar_k_supported', 'stc_cell_gates_fwd_planar_k_f32', 'stc_cell_cand_fwd_planar_k_f32', 'stc_cell_gates_bwd_planar_k_f32',
     'stc_cell_cand_bwd_planar_k_f32',
-    'stc_cell_small_supported', 'stc_cell_small_workspace_bytes', 'stc_cell_small_fwd_f32', 'stc_cell_small_bwd_f32',
+    'stc_cell_small_supported', 'stc_cell_small_workspace_bytes', 'stc_cell_small_param_rows', 'stc_cell_small_fwd_f32', 'stc_cell_small_bwd_f32',
     'stc_gru_gates_fwd_f32', 'stc_gru_gates_bwd_f32', 'stc_gru_blend_fwd_f32', 'stc_gru_blend_bwd_f32',
     'stc_head_fwd_f32', 'stc_head_bwd_workspace_bytes', 'stc_head_bwd_f32',
     'stc_axpy_f32', 'stc_concat2_f32', 'stc_split2_f32',
@@ -67,8 +67,8 @@ def _declare(lib):
         'stc_csr_spmm_bf16': [_p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _f32, _p],
         'stc_bcsr_spmm_bf16': [_p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _f32, _p],
         'stc_dense_agg_f32': [_p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _f32, _p],
-        'stc_cell_small_fwd_f32': [_p, _p, _p, _i32, _p, _i32, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _p],
-        'stc_cell_small_bwd_f32': [_p, _p, _p, _i32, _p, _i32, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _i32, _p, _i64, _i32, _i32,
+        'stc_cell_small_fwd_f32': [_p, _p, _p, _i32, _i32, _p, _i32, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _p],
+        'stc_cell_small_bwd_f32': [_p, _p, _p, _i32, _i32, _p, _i32, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _i32, _p, _i64, _i32, _i32,
                                    _p, C.c_size_t, _i32, _i32, _p],
         'stc_csr_sddmm_f32': [_p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _i32, _p],
         'stc_cheby_dense_fwd_f32': [_p, _i32, _i32, _p, _p],
@@ -139,6 +139,8 @@ def _declare(lib):
     lib.stc_cell_bwd_planar_workspace_bytes.argtypes = [_i32, _i32, _i32]
     lib.stc_cell_small_supported.restype = C.c_int
     lib.stc_cell_small_supported.argtypes = [_i32, _i32, _i32, _i32, _i32]
+    lib.stc_cell_small_param_rows.restype = C.c_int
+    lib.stc_cell_small_param_rows.argtypes = []
     lib.stc_cell_small_workspace_bytes.restype = C.c_size_t
     lib.stc_cell_small_workspace_bytes.argtypes = [_i32, _i32, _i32, _i32]
     lib.stc_set_dispatch_level.restype = C.c_int
@@ -788,8 +790,13 @@ class HipKernels:
 
     @staticmethod
     def cell_small_params(Ks, Kc, cin, h=16) -> int:
-        """Floats per sample of the parameter-gradient partials: [dWg | dbg | dWc | dbc]."""
+        """Floats per row of the parameter-gradient partials: [dWg | dbg | dWc | dbc]."""
         return Ks * Kc * (cin + h) * 3 * h + 3 * h
+
+    @property
+    def cell_small_param_rows(self) -> int:
+        """Rows of the parameter-gradient partials per sample (one per wave of the backward's workgroup)."""
+        return self.lib.stc_cell_small_param_rows()
 
     def _small_shapes(self, what, rowptr, colidx, val, X, H, Tc, Wg, Wc, planes, Zg, Zc):
         if H.dim() != 4 or X.dim() != 4 or X.shape[:3] != H.shape[:3]:
@@ -826,29 +833,30 @@ class HipKernels:
                     self._f32('cell_small_fwd.' + name, b_, (n,))
         else:
             (B, N, Cc, _), cin, Kc = H.shape, X.shape[-1], Tc.shape[0]
-        self._launch('stc_cell_small_fwd_f32', H, rowptr.data_ptr(), colidx.data_ptr(), val.data_ptr(), N, X.data_ptr(), cin, H.data_ptr(), Tc.data_ptr(), Kc,
+        self._launch('stc_cell_small_fwd_f32', H, rowptr.data_ptr(), colidx.data_ptr(), val.data_ptr(), N, val.numel(), X.data_ptr(), cin, H.data_ptr(), Tc.data_ptr(), Kc,
                      Wg.data_ptr(), _ptr(bg), Wc.data_ptr(), _ptr(bc), U.data_ptr(), R.data_ptr(), Cand.data_ptr(), Hnew.data_ptr(), RH.data_ptr(),
                      Zg.data_ptr(), Zc.data_ptr(), B, Cc, nbytes=4 * B * N * Cc * (cin + 16 * 8 + 2 * self.cell_small_zg_width(cin)))
 
     def cell_small_bwd(self, rowptr, colidx, val, X, H, Tc, Wg, Wc, U, R, Cand, RH, Zg, Zc, dHnew, dX, accumulate_x, dH, accumulate_h,
                        dparams, has_bg, has_bc, checked=True):
         """Autograd of ``cell_small_fwd`` in one launch (``stc_cell_small_bwd_f32``).  (rowptr, colidx, val): CSR of Gs.  dX / dH may be
-        None; ``accumulate_*``: add to what the buffer holds.  ``dparams`` (B, P >= cell_small_params): per-sample parameter-gradient
-        partials, ADDED to."""
+        None; ``accumulate_*``: add to what the buffer holds.  ``dparams`` (B * cell_small_param_rows, P >= cell_small_params):
+        parameter-gradient partials (one row per sample and wave), ADDED to."""
         if checked:
             B, N, Cc, cin, Kc = self._small_shapes('cell_small_bwd', rowptr, colidx, val, X, H, Tc, Wg, Wc,
                                                    dict(U=U, R=R, Cand=Cand, RH=RH, dHnew=dHnew, **({} if dH is None else dict(dH=dH))), Zg, Zc)
             if dX is not None:
                 self._f32('cell_small_bwd.dX', dX, tuple(X.shape))
             self._f32('cell_small_bwd.dparams', dparams)
-            if dparams.dim() != 2 or dparams.shape[0] != B or dparams.shape[1] < self.cell_small_params(2, Kc, cin):
-                raise StcError(f'cell_small_bwd: dparams {tuple(dparams.shape)}, expected ({B}, >= {self.cell_small_params(2, Kc, cin)})')
+            if dparams.dim() != 2 or dparams.shape[0] != B * self.cell_small_param_rows or dparams.shape[1] < self.cell_small_params(2, Kc, cin):
+                raise StcError(f'cell_small_bwd: dparams {tuple(dparams.shape)}, expected ({B * self.cell_small_param_rows}, '
+                               f'>= {self.cell_small_params(2, Kc, cin)})')
             self._same_device(H, dHnew, dparams, *([dX] if dX is not None else []))
         else:
             (B, N, Cc, _), cin, Kc = H.shape, X.shape[-1], Tc.shape[0]
         nbytes = self.lib.stc_cell_small_workspace_bytes(N, Cc, cin, B)
         ws = self._get_workspace(H.device, nbytes)
-        self._launch('stc_cell_small_bwd_f32', H, rowptr.data_ptr(), colidx.data_ptr(), val.data_ptr(), N, X.data_ptr(), cin, H.data_ptr(), Tc.data_ptr(), Kc,
+        self._launch('stc_cell_small_bwd_f32', H, rowptr.data_ptr(), colidx.data_ptr(), val.data_ptr(), N, val.numel(), X.data_ptr(), cin, H.data_ptr(), Tc.data_ptr(), Kc,
                      Wg.data_ptr(), Wc.data_ptr(), U.data_ptr(), R.data_ptr(), Cand.data_ptr(), RH.data_ptr(), Zg.data_ptr(), Zc.data_ptr(),
                      dHnew.data_ptr(), _ptr(dX), int(bool(accumulate_x)), _ptr(dH), int(bool(accumulate_h)), dparams.data_ptr(), dparams.shape[1],
                      int(bool(has_bg)), int(bool(has_bc)), ws.data_ptr(), ws.numel(), B, Cc,

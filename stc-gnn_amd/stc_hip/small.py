@@ -8,7 +8,8 @@ with the same interface as ``ops.stc_cell_graph``:
   * states, gates and the saved aggregates of all cells live in a handful of stacked buffers (one allocation per kind and pass);
   * a state's gradient is ONE buffer that its consumer cells write / add to in place (``accumulate_x`` / ``accumulate_h`` of the
     backward kernel), in reverse schedule order -- no autograd accumulation passes;
-  * parameter gradients are per-sample partials that every cell of a parameter set adds to; one sum over the batch per backward pass.
+  * parameter gradients are partial sums (one row per sample and wave) that every cell of a parameter set adds to; one sum over the
+    rows per backward pass.
 Fixed graphs only (``csr-fixed``: no gradient to Gs / Gc).
 """
 from __future__ import annotations
@@ -133,7 +134,7 @@ class _StcSmallGraph(Function):
         source = lambda src: ext[src[1]] if src[0] == 'ext' else state[src[1]]
         Kc = Tc.shape[0]
         P = max(k.cell_small_params(Ks, Kc, w) for w in cin)
-        dP = Tc.new_zeros(len(stacks), B, P)                         # per-sample parameter-gradient partials, every cell adds to its set's rows
+        dP = Tc.new_zeros(len(stacks), B * k.cell_small_param_rows, P)   # parameter-gradient partials, every cell adds to its set's rows
         G = Tc.new_empty(n_cells, B, N, C, H16)                      # gradient owed to every cell's state
         owed = [False] * n_cells
         grad_stack = _c(grad_stack)

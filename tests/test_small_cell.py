@@ -56,7 +56,7 @@ def _run(k, op, t, buf, P, to, acc_x=False, acc_h=False, want_x=True, want_h=Tru
     B = d['H'].shape[0]
     dX = to(torch.full(t['X'].shape, 0.25, dtype=t['X'].dtype)) if want_x else None
     dH = to(torch.full(t['H'].shape, -0.5, dtype=t['H'].dtype)) if want_h else None
-    dP = to(torch.full((B, P), 0.125, dtype=t['H'].dtype))
+    dP = to(torch.full((B * k.cell_small_param_rows, P), 0.125, dtype=t['H'].dtype))
     k.cell_small_bwd(op.bwd_rowptr, op.bwd_colidx, to(op.bwd_val), d['X'], d['H'], d['Tc'], d['Wg'], d['Wc'], b['U'], b['R'], b['Cand'], b['RH'],
                      b['Zg'], b['Zc'], d['dHnew'], dX, acc_x, dH, acc_h, dP, t['bg'] is not None, t['bc'] is not None)
     out = dict(b, dX=dX, dH=dH, dP=dP)

@@ -33,7 +33,7 @@ U, R, Cand, Hnew, RH, Zc = (torch.zeros(B, N, Cc, 16, device=dev) for _ in range
 Zg = torch.zeros(B, N * Cc, LP, device=dev)
 dX, dH = torch.zeros_like(X), torch.zeros_like(H)
 P = 4 * L * 48 + 48
-dP = torch.zeros(B, P, device=dev)
+dP = torch.zeros(B * 4, P, device=dev)
 ws = torch.zeros(B * N * Cc * (2 * LP + 32), device=dev)
 p = lambda t: C.c_void_p(t.data_ptr())
 
@@ -52,20 +52,21 @@ def timed(fn, n=200):
 
 
 rows = []
+extra = [a for a in sys.argv[5:] if a.startswith('-D')]          # e.g. -DSC_SKIP_ROLE=1
 for stop in (1, 2, 3, 99):
     so = os.path.join(tmp, f'small_{stop}.so')
-    subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', f'-DSC_STOP_AFTER={stop}',
+    subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', f'-DSC_STOP_AFTER={stop}', *extra,
                            '-I' + os.path.join(REPO, 'include'), os.path.join(csrc, 'stc_cell_small.hip'), os.path.join(csrc, 'stc_gates.hip'), '-o', so])      # (stc_gates.hip: stc_last_error's buffer)
     lib = C.CDLL(so)
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    fwd = lambda: lib.stc_cell_small_fwd_f32(p(op.fwd_rowptr), p(op.fwd_colidx), p(op.fwd_val), N, p(X), cin, p(H), p(Tc), 2, p(Wg), p(bg), p(Wc), p(bc),
+    fwd = lambda: lib.stc_cell_small_fwd_f32(p(op.fwd_rowptr), p(op.fwd_colidx), p(op.fwd_val), N, op.fwd_val.numel(), p(X), cin, p(H), p(Tc), 2, p(Wg), p(bg), p(Wc), p(bc),
                                              p(U), p(R), p(Cand), p(Hnew), p(RH), p(Zg), p(Zc), B, Cc, stream)
-    bwd = lambda: lib.stc_cell_small_bwd_f32(p(op.bwd_rowptr), p(op.bwd_colidx), p(op.bwd_val), N, p(X), cin, p(H), p(Tc), 2, p(Wg), p(Wc), p(U), p(R),
+    bwd = lambda: lib.stc_cell_small_bwd_f32(p(op.bwd_rowptr), p(op.bwd_colidx), p(op.bwd_val), N, op.bwd_val.numel(), p(X), cin, p(H), p(Tc), 2, p(Wg), p(Wc), p(U), p(R),
                                              p(Cand), p(RH), p(Zg), p(Zc), p(dHn), p(dX), 0, p(dH), 0, p(dP), C.c_int64(P), 1, 1, p(ws),
                                              C.c_size_t(ws.numel() * 4), B, Cc, stream)
     assert fwd() == 0 and bwd() == 0
     rows.append((stop, timed(fwd), timed(bwd)))
-print(f'small cell launch, N={N} C={Cc} cin={cin} B={B}: cumulative us after each phase (forward | backward)')
+print(f'small cell launch, N={N} C={Cc} cin={cin} B={B} {" ".join(extra)}: cumulative us after each phase (forward | backward)')
 prev = (0.0, 0.0)
 for stop, f, b_ in rows:
     print(f'  phase {stop if stop < 99 else 4}: fwd {f:7.1f} (+{f - prev[0]:6.1f})   bwd {b_:7.1f} (+{b_ - prev[1]:6.1f})')
