@@ -42,6 +42,7 @@ import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling ~5.4-6.3 TB/s
+FP32_MATRIX_PEAK_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32 / 32x32x2 (f32 in, f32 accumulate), whole chip (MI355X_MICROARCH.md)
 PLAIN_SPMM = ('stc_bcsr_spmm_f32', 'stc_bcsr_spmm_bf16')
 # every C-ABI entry point that is an aggregation Y = S.X (+ epilogue)
 SPMM_ENTRY_POINTS = ('stc_bcsr_spmm_f32', 'stc_csr_spmm_f32', 'stc_spmm_sum_f32', 'stc_spmm_blend_fwd_f32',
@@ -452,6 +453,32 @@ def main():
                 for tag, tv in dk.get('tags', {}).items():
                     dom.setdefault('forms', {})[tag] = {'launches': tv['launches'], 'avg_launch_us': 1e3 * tv['ms'] / max(1, tv['launches']),
                                                         'achieved': rate(tv), 'frac': rate(tv) / HBM_PEAK_GBPS}
+            if dom_name.startswith('stc_cell_small'):
+                # the small-graph cell launches (one workgroup per sample) are bound by the exact-fp32 matrix pipe + the vector instructions
+                # around it, not by HBM: price them in flops against the fp32 matrix peak, and against the share of the chip a launch can use
+                h, Kk = a.hidden, a.order
+                def flops(cin, bwd):
+                    proj = 2.0 * N * C * (Kk * Kk * (cin + h)) * 3 * h
+                    mix = 2.0 * N * C * C * (Kk - 1) * 3 * h
+                    agg = 2.0 * graph.nnz * C * (cin + 2 * h)
+                    return B * ((2 * proj + mix + 2.0 * graph.nnz * C * 2 * (cin + h)) if bwd else (proj + mix + agg))
+                narrow, wide = a.obs, (a.layers - 1) * a.obs + a.layers * a.pred
+                per_launch = (narrow * flops(1, dom_name.endswith('bwd_f32')) + wide * flops(h, dom_name.endswith('bwd_f32'))) / max(1, narrow + wide)
+                tf = per_launch / (dom['avg_launch_us'] * 1e-6) / 1e12
+                cus = min(B, 256)
+                dom['matrix'] = {'what': 'algorithmic flops of a cell launch (projections, category mix, aggregation; backward: dZ + dW) on '
+                                         'v_mfma_f32_16x16x4_f32, averaged over the narrow (layer 0) and wide cells of the schedule',
+                                 'flops_per_launch': per_launch, 'achieved': tf, 'peak': FP32_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                 'frac': tf / FP32_MATRIX_PEAK_TFLOPS, 'compute_units_in_use': cus,
+                                 'frac_of_the_units_in_use': tf / (FP32_MATRIX_PEAK_TFLOPS * cus / 256.0)}
+                if plain['launches'] == 0:                  # no aggregation launch in this step at all: the dominant kernel IS the roofline entry
+                    roofline.update(bound='mfma', kernel=f'{dom_name}: one STC_Cell step per launch, one workgroup per sample '
+                                                         f'({cus} of 256 compute units), exact-fp32 matrix instructions',
+                                    achieved=tf, peak=FP32_MATRIX_PEAK_TFLOPS, unit='TFLOP/s', frac=tf / FP32_MATRIX_PEAK_TFLOPS,
+                                    launches=dk['launches'], avg_launch_us=dom['avg_launch_us'], algorithmic_flops_per_launch=per_launch,
+                                    frac_of_the_units_in_use=dom['matrix']['frac_of_the_units_in_use'])
+                    for key in ('algorithmic_bytes_per_launch', 'bytes_formula', 'aggregate'):
+                        roofline.pop(key, None)
             roofline['dominant'] = dom
         roofline['mfma'] = pmc_mfma(config_key)
         if not a.no_unit_d3:

@@ -48,7 +48,10 @@ constexpr int SC_H = 16, SC_KS = 2, SC_MAXC = 16;
 #define SC_SKIP_ROLE (-1)                          // probe: the waves of this backward role (0: dZ, 1: dW) do nothing
 #endif
 
-__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
+// Gate nonlinearities on the hardware exp2 / rcp (1 ulp each; absolute error < 2e-7), as in the large-graph cell kernels (stc_x3_frag.h): libm expf /
+// tanhf and the IEEE division are ~30 vector instructions each, four per lane and tile, in loops that run at the sum of their vector and matrix cycles.
+__device__ __forceinline__ float sigm(float v) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v)); }
+__device__ __forceinline__ float tanh_hw(float v) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.8853900817779268f * v)); }
 // x / C for x < 65536 and C <= 16 with inv = ceil(2^20 / C): exact (x (inv C - 2^20) < 2^20); a runtime integer division is ~25 instructions
 // and the gathers below would do two per item.
 __device__ __forceinline__ int div_c(int x, int inv) { return (int)(((unsigned)x * (unsigned)inv) >> 20); }
@@ -336,7 +339,7 @@ __global__ __launch_bounds__(SF_THREADS) void small_fwd_kernel(SmallFwd a) {
             [&](int row) { return load_op<XQ>(Zcb, SC_H, Zgb + 16, LP, true, cin, row, kq); },
             [&](int grow, float y) {
                 const size_t e = (unsigned)grow * SC_H + j;
-                const float cd = tanhf(y + bias), u = Ub[e], hh = STAGED ? P[(unsigned)grow * SP + j] : Hb[e];
+                const float cd = tanh_hw(y + bias), u = Ub[e], hh = STAGED ? P[(unsigned)grow * SP + j] : Hb[e];
                 Cb[e] = cd;
                 Hn[e] = (1.f - u) * hh + u * cd;
             });
