@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define STC_ABI_VERSION 18
+#define STC_ABI_VERSION 19
 #define STC_MAX_K 4          /* highest Chebyshev order (Ks, Kc) the node kernels accept */
 
 /* Operand formats of the split-operand matrix-core kernels (C = 32 / 64, hidden 16).  Every fp32 operand is split into low-precision
@@ -450,21 +450,28 @@ int stc_head_bwd_f32(const float* H, const float* w, const float* y, const float
  * R = stc_cell_small_param_rows() (one row per wave of the sample's workgroup):
  *   [dWg (Ks*Kc*L*32) | dbg (32) | dWc (Ks*Kc*L*16) | dbc (16)], L = cin + 16 -- partial sums, no atomics, no cross-wave reduction: the
  * caller zeroes the buffer once per backward pass, every cell of a layer adds to it, and one sum over the rows finishes the gradient.
- * workspace: stc_cell_small_workspace_bytes(N, C, cin, batch), 16-byte aligned. */
+ * workspace: stc_cell_small_workspace_bytes(N, C, cin, batch), 16-byte aligned.
+ * Learned graphs (ABI v19): the gradients of Gs and Gc are products over ALL cells of a step, so the launches only leave their operands --
+ * Z0 (forward, optional): the slab [H | Xt | 0] as Zg is laid out; dZ1c / dZ1g (backward, optional, like Zg): the gradients of the
+ * candidate's / gates' aggregated slab; dYg (optional, (batch, N*C, 32)): the gate pre-activation gradients -- and the host forms
+ * dGs^T = sum dZ1 x Z0 and dT_c = sum V_c x dY with a few stacked products per backward pass (stc_hip/small.py).  NULL = not wanted.
+ * graph_is_dense != 0: the caller vouches that the CSR is the FULL n x n pattern with columns in order (nnz = n*n), i.e. val is a dense
+ * row-major matrix (graph.full_pattern): the aggregations then run as matrix products on the staged planes instead of row gathers. */
 int stc_cell_small_supported(int32_t Ks, int32_t Kc, int32_t C, int32_t cin, int32_t h);
 size_t stc_cell_small_workspace_bytes(int32_t n_nodes, int32_t C, int32_t cin, int32_t batch);
 int stc_cell_small_param_rows(void);
 int stc_cell_small_fwd_f32(const int32_t* rowptr, const int32_t* colidx, const float* val, int32_t n_nodes, int32_t nnz,
-                           const float* X, int32_t cin, const float* H, const float* Tc, int32_t Kc,
+                           int32_t graph_is_dense, const float* X, int32_t cin, const float* H, const float* Tc, int32_t Kc,
                            const float* Wg, const float* bg, const float* Wc, const float* bc,
-                           float* U, float* R, float* Cand, float* Hnew, float* RH, float* Zg, float* Zc,
+                           float* U, float* R, float* Cand, float* Hnew, float* RH, float* Zg, float* Zc, float* Z0,
                            int32_t batch, int32_t C, void* stream);
 int stc_cell_small_bwd_f32(const int32_t* rowptr, const int32_t* colidx, const float* val, int32_t n_nodes, int32_t nnz,
-                           const float* X, int32_t cin, const float* H, const float* Tc, int32_t Kc,
+                           int32_t graph_is_dense, const float* X, int32_t cin, const float* H, const float* Tc, int32_t Kc,
                            const float* Wg, const float* Wc, const float* U, const float* R, const float* Cand,
                            const float* RH, const float* Zg, const float* Zc, const float* dHnew,
                            float* dX, int32_t accumulate_x, float* dH, int32_t accumulate_h,
                            float* dparams, int64_t params_ld, int32_t has_bg, int32_t has_bc,
+                           float* dZ1c, float* dZ1g, float* dYg,
                            void* workspace, size_t workspace_bytes, int32_t batch, int32_t C, void* stream);
 
 /* ---- small helpers ---------------------------------------------------------

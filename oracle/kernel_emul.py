@@ -236,7 +236,7 @@ class EmulatedKernels:
         self.csr_spmm(rowptr, colidx, val, N, N, T.reshape(B, N, Cc * w), None, out, 1.0, 0.0)
         return out.view(B, N, Cc, w)
 
-    def cell_small_fwd(self, rowptr, colidx, val, X, H, Tc, Wg, bg, Wc, bc, U, R, Cand, Hnew, RH, Zg, Zc, checked=True):
+    def cell_small_fwd(self, rowptr, colidx, val, X, H, Tc, Wg, bg, Wc, bc, U, R, Cand, Hnew, RH, Zg, Zc, checked=True, Z0=None):
         B, N, Cc, h = H.shape
         cin = X.shape[-1]
         rows = lambda t: t.reshape(B * N, Cc, t.shape[-1])
@@ -254,13 +254,18 @@ class EmulatedKernels:
         Zgv[..., :h] = SXH[..., cin:]
         Zgv[..., h:h + cin] = SXH[..., :cin]
         Zc.copy_(SRH.reshape(B, N * Cc, h))
+        if Z0 is not None:
+            Z0.zero_()
+            Z0v = Z0.view(B, N, Cc, Z0.shape[-1])
+            Z0v[..., :h] = H
+            Z0v[..., h:h + cin] = X
         Y = torch.empty(B * N, Cc, h, dtype=H.dtype)
         self.bdg_node_fwd([rows(torch.cat([X, RH], -1)), rows(torch.cat([SXH[..., :cin], SRH], -1))], Tc, Wc, bc, Y)
         Cand.copy_(torch.tanh(Y.view(B, N, Cc, h)))
         Hnew.copy_((1.0 - U) * H + U * Cand)
 
     def cell_small_bwd(self, rowptr, colidx, val, X, H, Tc, Wg, Wc, U, R, Cand, RH, Zg, Zc, dHnew, dX, accumulate_x, dH, accumulate_h,
-                       dparams, has_bg, has_bc, checked=True):
+                       dparams, has_bg, has_bc, checked=True, dZ1c=None, dZ1g=None, dYg=None):
         B, N, Cc, h = H.shape
         cin = X.shape[-1]
         L = cin + h
@@ -273,9 +278,11 @@ class EmulatedKernels:
         dWg, dbg = first[:, :nW * 2 * h], first[:, nW * 2 * h:nW * 2 * h + 2 * h]
         dWc, dbc = first[:, nW * 2 * h + 2 * h:nW * 3 * h + 2 * h], first[:, nW * 3 * h + 2 * h:nW * 3 * h + 3 * h]
 
-        def conv_bwd(Z0, Z1, W, dY, dW_rows, db_rows):
-            """d[Z0] + S^T d[Z1] of one convolution (B, N, C, L); parameter gradients per sample."""
+        def conv_bwd(Z0, Z1, W, dY, dW_rows, db_rows, dump=None):
+            """d[Z0] + S^T d[Z1] of one convolution (B, N, C, L); parameter gradients per sample; ``dump``: receives d[Z1] in [H | X | 0] order."""
             out = torch.empty(B, N, Cc, L, dtype=H.dtype)
+            if dump is not None:
+                dump.zero_()
             for b in range(B):
                 dZ = [torch.empty(N, Cc, L, dtype=H.dtype), torch.empty(N, Cc, L, dtype=H.dtype)]
                 dW, db = torch.empty_like(W), torch.empty(W.shape[1], dtype=H.dtype)
@@ -283,17 +290,23 @@ class EmulatedKernels:
                 dW_rows[b] += dW.reshape(-1)
                 if db_rows is not None:
                     db_rows[b] += db
+                if dump is not None:
+                    dv_ = dump[b].view(N, Cc, dump.shape[-1])
+                    dv_[..., :h] = dZ[1][..., cin:]
+                    dv_[..., h:h + cin] = dZ[1][..., :cin]
                 back = torch.empty(1, N, Cc * L, dtype=H.dtype)
                 self.csr_spmm(rowptr, colidx, val, N, N, dZ[1].reshape(1, N, Cc * L), dZ[0].reshape(1, N, Cc * L), back, 1.0, 1.0)
                 out[b] = back.view(N, Cc, L)
             return out
 
         dCpre = dHnew * U * (1.0 - Cand * Cand)
-        dCI = conv_bwd(torch.cat([X, RH], -1), torch.cat([SX, SRH], -1), Wc, dCpre, dWc, dbc if has_bc else None)
+        dCI = conv_bwd(torch.cat([X, RH], -1), torch.cat([SX, SRH], -1), Wc, dCpre, dWc, dbc if has_bc else None, dump=dZ1c)
         dRH, dXc = dCI[..., cin:], dCI[..., :cin]
         dGu = dHnew * (Cand - H) * U * (1.0 - U)
         dGr = dRH * H * R * (1.0 - R)
-        dXH = conv_bwd(torch.cat([X, H], -1), torch.cat([SX, SH], -1), Wg, torch.cat([dGu, dGr], -1), dWg, dbg if has_bg else None)
+        dXH = conv_bwd(torch.cat([X, H], -1), torch.cat([SX, SH], -1), Wg, torch.cat([dGu, dGr], -1), dWg, dbg if has_bg else None, dump=dZ1g)
+        if dYg is not None:
+            dYg.copy_(torch.cat([dGu, dGr], -1).reshape(B, N * Cc, 2 * h))
         if dH is not None:
             g = dHnew * (1.0 - U) + dRH * R + dXH[..., cin:]
             dH.copy_(dH + g if accumulate_h else g)

@@ -97,6 +97,53 @@ __device__ __forceinline__ void aggregate_rows(const int* __restrict__ gp, const
     }
 }
 
+// The same aggregation for a DENSE graph (the reference's learned Gs: the CSR is the full N x N pattern, `S` its values as a row-major matrix)
+// as a matrix product on the staged plane: out^T tile = src^T . S^T, i.e. A = 16 columns of the source rows (LDS), B = 16 nodes' rows of S
+// (one 16-byte global load = the lane's B operands of four steps), so that a lane ends up with 4 consecutive COLUMNS of one output row --
+// the quad the CSR form's base / store callbacks take.  (Gathering 100 neighbour rows per output row from L2 instead costs ~100 us per phase.)
+template <int THREADS, int QUADS, class Base, class Store>
+__device__ __forceinline__ void aggregate_dense(const float* __restrict__ S, int N, int C, const float* src, int stride, Base base, Store store) {
+    constexpr int CT = (QUADS + 3) / 4;                          // 16-column tiles per (node, category) row
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, kq = lane >> 4;
+    const int rtiles = (N + 15) >> 4, per_rt = C * CT, tiles = rtiles * per_rt;
+    const bool vec = (N & 3) == 0;
+    for (int tile = wave; tile < tiles; tile += THREADS / 64) {
+        const int rt = tile / per_rt, rem = tile - rt * per_rt, c = rem / CT, lb = rem - c * CT;
+        const int node = 16 * rt + j;
+        const bool node_ok = node < N;
+        const unsigned srow = (unsigned)(node_ok ? node : 0) * N;
+        const int col = min(16 * lb + j, 4 * QUADS - 1);         // the source column this lane feeds as A operand (clamped: extra columns are not stored)
+        auto load_s = [&](int kb) {                              // S[node][16 kb + 4 kq .. + 3], unmasked (clamped); the mask is applied when it is consumed
+            const int k0 = 16 * kb + 4 * kq;
+            if (vec) return ld4(S + (k0 < N ? srow + k0 : srow));
+            f32x4 v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = S[srow + min(k0 + i, N - 1)];
+            return v;
+        };
+        f32x4 acc = zero4(), bn = load_s(0);
+        for (int kb = 0; kb < rtiles; ++kb) {
+            f32x4 b = bn;
+            if (kb + 1 < rtiles) bn = load_s(kb + 1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = 16 * kb + 4 * kq + i;
+                const float bv = node_ok && m < N ? b[i] : 0.f;
+                const float av = src[(unsigned)(min(m, N - 1) * C + c) * stride + col];
+                acc = mfma4(av, bv, acc);
+            }
+        }
+        const int q = 4 * lb + kq;
+        if (node_ok && q < QUADS) {
+            const int row = node * C + c;
+            f32x4 s = base(row, q);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s[i] += acc[i];
+            store(row, q, s);
+        }
+    }
+}
+
 template <int THREADS>
 __device__ __forceinline__ void stage_graph(const SmallGraph& g, int N, int* gp, int* gc, float* gv) {
     for (int i = threadIdx.x; i <= N; i += THREADS) gp[i] = g.rowptr[i];
@@ -228,15 +275,18 @@ struct SmallFwd {
     SmallGraph g;
     const float *X, *H, *Tc, *Wg, *bg, *Wc, *bc;
     float *U, *R, *Cand, *Hnew, *RH, *Zg, *Zc;
+    float* Z0;                                   // optional: the slab [H | X | 0] itself, for the graph-gradient products of learned graphs
     int N, C, cin, rpt, tiles;
 };
 
 template <int KC>
 __host__ __device__ constexpr int fwd_lds_fixed() { return 0; }                                         // floats of LDS every launch needs
 
-template <int KC, int XQ, bool STAGED>
+// MODE 0: graph and planes read from global memory; 1: CSR graph + planes staged in LDS; 2: dense graph (matrix-product aggregation), planes staged
+template <int KC, int XQ, int MODE>
 __global__ __launch_bounds__(SF_THREADS) void small_fwd_kernel(SmallFwd a) {
     constexpr int LP = 16 + 4 * XQ, XS = XQ == 4 ? 4 : XQ, SP = plane_stride(XQ);
+    constexpr bool STAGED = MODE >= 1, DENSE = MODE == 2;
     extern __shared__ __align__(16) float lds[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, j = lane & 15, kq = lane >> 4;
     const int C = a.C, N = a.N, NC = N * C, cin = a.cin, invC = ((1 << 20) + C - 1) / C;
@@ -245,9 +295,9 @@ __global__ __launch_bounds__(SF_THREADS) void small_fwd_kernel(SmallFwd a) {
     int* gpl = reinterpret_cast<int*>(Q + (size_t)NC * SQ);
     int* gcl = gpl + ((N + 4) & ~3);
     float* gvl = reinterpret_cast<float*>(gcl + ((a.g.nnz + 3) & ~3));
-    const int* gp = STAGED ? gpl : a.g.rowptr;
-    const int* gc = STAGED ? gcl : a.g.colidx;
-    const float* gv = STAGED ? gvl : a.g.val;
+    const int* gp = STAGED && !DENSE ? gpl : a.g.rowptr;
+    const int* gc = STAGED && !DENSE ? gcl : a.g.colidx;
+    const float* gv = STAGED && !DENSE ? gvl : a.g.val;
     const size_t r0 = (size_t)blockIdx.x * NC;
     const float* Xb = a.X + r0 * cin;
     const float* Hb = a.H + r0 * SC_H;
@@ -264,7 +314,7 @@ __global__ __launch_bounds__(SF_THREADS) void small_fwd_kernel(SmallFwd a) {
     float M[KC][4];
     build_mix<KC>(M, a.Tc, false, a.rpt, C, invC, j, kq);
     if (STAGED) {
-        stage_graph<SF_THREADS>(a.g, N, gpl, gcl, gvl);
+        if (!DENSE) stage_graph<SF_THREADS>(a.g, N, gpl, gcl, gvl);
         for (int item = t; item < NC * 4; item += SF_THREADS) {
             const int row = item >> 2, q = item & 3;
             st4(P + (unsigned)row * SP + 4 * q, ld4(Hb + (unsigned)row * SC_H + 4 * q));
@@ -282,19 +332,47 @@ __global__ __launch_bounds__(SF_THREADS) void small_fwd_kernel(SmallFwd a) {
     }
     __syncthreads();
 
-    // 1: Zg = S.[H | X]
-    aggregate_rows<SF_THREADS, LP / 4>(gp, gc, gv, NC, C, invC,
-        [&](int src, int q) -> f32x4 {
-            if (STAGED) return ld4(P + (unsigned)src * SP + 4 * q);
-            if (q < 4) return ld4(Hb + (unsigned)src * SC_H + 4 * q);
-            if (XQ == 4) return ld4(Xb + (unsigned)src * SC_H + 4 * (q - 4));
-            f32x4 x = zero4();
+    if (a.Z0 != nullptr) {                                   // (learned graphs only)
+        float* Z0b = a.Z0 + r0 * LP;
+        for (int item = t; item < NC * (LP / 4); item += SF_THREADS) {
+            const int row = item / (LP / 4), q = item - row * (LP / 4);
+            f32x4 x;
+            if (STAGED) {
+                x = ld4(P + (unsigned)row * SP + 4 * q);
+            } else if (q < 4) {
+                x = ld4(Hb + (unsigned)row * SC_H + 4 * q);
+            } else if (XQ == 4) {
+                x = ld4(Xb + (unsigned)row * SC_H + 4 * (q - 4));
+            } else {
+                x = zero4();
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (4 * (q - 4) + i < cin) x[i] = Xb[(unsigned)src * cin + 4 * (q - 4) + i];
-            return x;
-        },
-        [](int, int) -> f32x4 { return zero4(); }, [&](int row, int q, f32x4 s) { st4(Zgb + (unsigned)row * LP + 4 * q, s); });
+                for (int i = 0; i < 4; ++i)
+                    if (4 * (q - 4) + i < cin) x[i] = Xb[(unsigned)row * cin + 4 * (q - 4) + i];
+            }
+            st4(Z0b + (unsigned)row * LP + 4 * q, x);
+        }
+    }
+
+    // 1: Zg = S.[H | X]
+    {
+        auto none = [](int, int) -> f32x4 { return zero4(); };
+        auto put = [&](int row, int q, f32x4 s) { st4(Zgb + (unsigned)row * LP + 4 * q, s); };
+        if (DENSE)
+            aggregate_dense<SF_THREADS, LP / 4>(a.g.val, N, C, P, SP, none, put);
+        else
+            aggregate_rows<SF_THREADS, LP / 4>(gp, gc, gv, NC, C, invC,
+                [&](int src, int q) -> f32x4 {
+                    if (STAGED) return ld4(P + (unsigned)src * SP + 4 * q);
+                    if (q < 4) return ld4(Hb + (unsigned)src * SC_H + 4 * q);
+                    if (XQ == 4) return ld4(Xb + (unsigned)src * SC_H + 4 * (q - 4));
+                    f32x4 x = zero4();
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (4 * (q - 4) + i < cin) x[i] = Xb[(unsigned)src * cin + 4 * (q - 4) + i];
+                    return x;
+                },
+                none, put);
+    }
     __syncthreads();
     SC_PHASE_END(1);
 
@@ -323,9 +401,15 @@ __global__ __launch_bounds__(SF_THREADS) void small_fwd_kernel(SmallFwd a) {
     // 3: Zc = S.(R*H)   (the candidate's W operands in flight meanwhile)
     float Wc_r[SC_KS][KC][4 + XS];
     load_w_fwd<KC, XQ>(Wc_r, a.Wc, SC_H, j, cin, kq);
-    aggregate_rows<SF_THREADS, 4>(gp, gc, gv, NC, C, invC,
-        [&](int src, int q) -> f32x4 { return STAGED ? ld4(Q + (unsigned)src * SQ + 4 * q) : ld4(RHb + (unsigned)src * SC_H + 4 * q); },
-        [](int, int) -> f32x4 { return zero4(); }, [&](int row, int q, f32x4 s) { st4(Zcb + (unsigned)row * SC_H + 4 * q, s); });
+    {
+        auto none = [](int, int) -> f32x4 { return zero4(); };
+        auto put = [&](int row, int q, f32x4 s) { st4(Zcb + (unsigned)row * SC_H + 4 * q, s); };
+        if (DENSE)
+            aggregate_dense<SF_THREADS, 4>(a.g.val, N, C, Q, SQ, none, put);
+        else
+            aggregate_rows<SF_THREADS, 4>(gp, gc, gv, NC, C, invC,
+                [&](int src, int q) -> f32x4 { return STAGED ? ld4(Q + (unsigned)src * SQ + 4 * q) : ld4(RHb + (unsigned)src * SC_H + 4 * q); }, none, put);
+    }
     __syncthreads();
     SC_PHASE_END(3);
 
@@ -386,8 +470,8 @@ struct Slab {                                    // one slab of a convolution's 
 // wave's tiles and are added to the row of the parameter-gradient partials that the tile's four waves share (disjoint parts).
 template <int KC, int XQ, int OT, class Raw, class LoadDy, class FormDy>
 __device__ __forceinline__ void conv_bwd_phase(const Slab& z, const float* __restrict__ W, int ks, int role, const float (&M)[KC][4],
-                                               float* __restrict__ dv, float* dZ, float* __restrict__ dW, float* __restrict__ db, int rpt, int tiles,
-                                               int NC, int cin, LoadDy load_dy, FormDy form_dy) {
+                                               float* __restrict__ dv, float* dZ, float* __restrict__ dump, float* __restrict__ dW, float* __restrict__ db,
+                                               int rpt, int tiles, int NC, int cin, LoadDy load_dy, FormDy form_dy) {
     constexpr int LP = 16 + 4 * XQ, HO = 16 * OT, DS = HO + 1, SPK = HO / 4, QUADS = SB_WAVES / 4;
     const int t = threadIdx.x, lane = t & 63, quad = t >> 8, j = lane & 15, kq = lane >> 4, L = cin + SC_H;
     // Rows 4 kq + s of a tile as a lane addresses them: clamped into the sample (rows of a tile beyond its nodes or beyond the sample, and
@@ -464,6 +548,10 @@ __device__ __forceinline__ void conv_bwd_phase(const Slab& z, const float* __res
                     const unsigned e = (unsigned)(row0 + 4 * kq + r) * LP + j;
                     dZ[e] = dz[0][r];
                     if (j < LP - 16) dZ[e + 16] = dz[1][r];
+                    if (dump != nullptr) {                       // (slab 1 of a learned graph: kept for the graph-gradient product)
+                        dump[e] = dz[0][r];
+                        if (j < LP - 16) dump[e + 16] = dz[1][r];
+                    }
                 }
             __builtin_amdgcn_wave_barrier();    // the next tile overwrites dv
         }
@@ -560,6 +648,7 @@ struct SmallBwd {
     SmallGraph g;                                // CSR of Gs (the transpose of the forward's)
     const float *X, *H, *Tc, *Wg, *Wc, *U, *R, *Cand, *RH, *Zg, *Zc, *dHnew;
     float *dX, *dH, *dP, *ws;
+    float *dZ1c, *dZ1g, *dYg;                    // optional dumps for learned graphs: gradients of the two aggregated slabs, gate pre-activation gradients
     int N, C, cin, rpt, tiles, acc_x, acc_h, has_bg, has_bc;
     long long P;                                 // floats per row of dP: [dWg | dbg (32) | dWc | dbc (16)]; SB_WAVES / 4 rows per sample
 };
@@ -574,9 +663,10 @@ struct Raw2 {
 template <int KC>
 __host__ __device__ constexpr int bwd_lds_fixed() { return SB_WAVES * KC * 16 * 33; }                     // floats: the waves' dV tiles
 
-template <int KC, int XQ, bool STAGED>
+template <int KC, int XQ, int MODE>
 __global__ __launch_bounds__(SB_THREADS) void small_bwd_kernel(SmallBwd a) {
     constexpr int LP = 16 + 4 * XQ;
+    constexpr bool STAGED = MODE >= 1, DENSE = MODE == 2;
     extern __shared__ __align__(16) float lds[];
     const int t = threadIdx.x, wave = t >> 6;
     const int C = a.C, N = a.N, NC = N * C, cin = a.cin, L = cin + SC_H, invC = ((1 << 20) + C - 1) / C;
@@ -585,9 +675,9 @@ __global__ __launch_bounds__(SB_THREADS) void small_bwd_kernel(SmallBwd a) {
     int* gpl = reinterpret_cast<int*>(D1 + (size_t)NC * LP);
     int* gcl = gpl + ((N + 4) & ~3);
     float* gvl = reinterpret_cast<float*>(gcl + ((a.g.nnz + 3) & ~3));
-    const int* gp = STAGED ? gpl : a.g.rowptr;
-    const int* gc = STAGED ? gcl : a.g.colidx;
-    const float* gv = STAGED ? gvl : a.g.val;
+    const int* gp = STAGED && !DENSE ? gpl : a.g.rowptr;
+    const int* gc = STAGED && !DENSE ? gcl : a.g.colidx;
+    const float* gv = STAGED && !DENSE ? gvl : a.g.val;
     const size_t r0 = (size_t)blockIdx.x * NC;
     const float* Xb = a.X + r0 * cin;
     const float* Hb = a.H + r0 * SC_H;
@@ -603,7 +693,7 @@ __global__ __launch_bounds__(SB_THREADS) void small_bwd_kernel(SmallBwd a) {
     float* wsb = a.ws + (size_t)blockIdx.x * NC * (2 * LP + 32);
     float* dZ0 = wsb;
     float* dZ1 = STAGED ? D1 : wsb + (size_t)NC * LP;
-    float* dYg = wsb + (size_t)NC * 2 * LP;
+    float* dYg = a.dYg ? a.dYg + r0 * 32 : wsb + (size_t)NC * 2 * LP;
     const int ks = wave & 1, role = (wave >> 1) & 1;
     float* dPw = a.dP + ((size_t)blockIdx.x * (SB_WAVES / 4) + (wave >> 2)) * a.P;
     float* dWg = dPw;
@@ -613,11 +703,12 @@ __global__ __launch_bounds__(SB_THREADS) void small_bwd_kernel(SmallBwd a) {
     const int lane = t & 63;
     float M[KC][4];
     build_mix<KC>(M, a.Tc, true, a.rpt, C, invC, lane & 15, lane >> 4);
-    if (STAGED) stage_graph<SB_THREADS>(a.g, N, gpl, gcl, gvl);
+    if (STAGED && !DENSE) stage_graph<SB_THREADS>(a.g, N, gpl, gcl, gvl);
     __syncthreads();
 
     // 1: candidate convolution
-    conv_bwd_phase<KC, XQ, 1, Raw3>(ks == 0 ? Slab{RHb, SC_H, Xb, cin} : Slab{Zcb, SC_H, Zgb + SC_H, LP}, a.Wc, ks, role, M, dv, ks == 0 ? dZ0 : dZ1, dWc,
+    conv_bwd_phase<KC, XQ, 1, Raw3>(ks == 0 ? Slab{RHb, SC_H, Xb, cin} : Slab{Zcb, SC_H, Zgb + SC_H, LP}, a.Wc, ks, role, M, dv, ks == 0 ? dZ0 : dZ1,
+        ks == 1 && a.dZ1c ? a.dZ1c + r0 * LP : nullptr, dWc,
         a.has_bc ? dbc : nullptr, a.rpt, min(a.tiles, SC_MAX_TILES), NC, cin,
         [&](int grow, int col) {
             const size_t e = (unsigned)grow * SC_H + col;
@@ -628,8 +719,10 @@ __global__ __launch_bounds__(SB_THREADS) void small_bwd_kernel(SmallBwd a) {
     SC_PHASE_END(1);
 
     // 2: d[R*H | X] = dZ_0 + S^T dZ_1, gate backward
-    aggregate_rows<SB_THREADS, LP / 4>(gp, gc, gv, NC, C, invC, [&](int src, int q) -> f32x4 { return ld4(dZ1 + (unsigned)src * LP + 4 * q); },
-        [&](int row, int q) -> f32x4 { return ld4(dZ0 + (unsigned)row * LP + 4 * q); },
+    {
+        auto from_dz1 = [&](int src, int q) -> f32x4 { return ld4(dZ1 + (unsigned)src * LP + 4 * q); };
+        auto from_dz0 = [&](int row, int q) -> f32x4 { return ld4(dZ0 + (unsigned)row * LP + 4 * q); };
+        auto gate_bwd =
         [&](int row, int q, f32x4 s) {
             if (q < 4) {
                 const size_t e = (unsigned)row * SC_H + 4 * q;
@@ -661,12 +754,18 @@ __global__ __launch_bounds__(SB_THREADS) void small_bwd_kernel(SmallBwd a) {
                     }
                 }
             }
-        });
+        };
+        if (DENSE)
+            aggregate_dense<SB_THREADS, LP / 4>(a.g.val, N, C, dZ1, LP, from_dz0, gate_bwd);
+        else
+            aggregate_rows<SB_THREADS, LP / 4>(gp, gc, gv, NC, C, invC, from_dz1, from_dz0, gate_bwd);
+    }
     __syncthreads();
     SC_PHASE_END(2);
 
     // 3: gates convolution
-    conv_bwd_phase<KC, XQ, 2, Raw2>(ks == 0 ? Slab{Hb, SC_H, Xb, cin} : Slab{Zgb, LP, Zgb + SC_H, LP}, a.Wg, ks, role, M, dv, ks == 0 ? dZ0 : dZ1, dWg,
+    conv_bwd_phase<KC, XQ, 2, Raw2>(ks == 0 ? Slab{Hb, SC_H, Xb, cin} : Slab{Zgb, LP, Zgb + SC_H, LP}, a.Wg, ks, role, M, dv, ks == 0 ? dZ0 : dZ1,
+        ks == 1 && a.dZ1g ? a.dZ1g + r0 * LP : nullptr, dWg,
         a.has_bg ? dbg : nullptr, a.rpt, min(a.tiles, SC_MAX_TILES), NC, cin,
         [&](int grow, int col) { return Raw2{dYg[(unsigned)grow * 32 + col], dYg[(unsigned)grow * 32 + 16 + col]}; },
         [](const Raw2& w, int ot) { return ot == 0 ? w.a : w.b; });
@@ -674,9 +773,10 @@ __global__ __launch_bounds__(SB_THREADS) void small_bwd_kernel(SmallBwd a) {
     SC_PHASE_END(3);
 
     // 4: d[H | X] += dZ_0 + S^T dZ_1
-    if (dHb || dXb)
-        aggregate_rows<SB_THREADS, LP / 4>(gp, gc, gv, NC, C, invC, [&](int src, int q) -> f32x4 { return ld4(dZ1 + (unsigned)src * LP + 4 * q); },
-            [&](int row, int q) -> f32x4 { return ld4(dZ0 + (unsigned)row * LP + 4 * q); },
+    if (dHb || dXb) {
+        auto from_dz1 = [&](int src, int q) -> f32x4 { return ld4(dZ1 + (unsigned)src * LP + 4 * q); };
+        auto from_dz0 = [&](int row, int q) -> f32x4 { return ld4(dZ0 + (unsigned)row * LP + 4 * q); };
+        auto add_in =
             [&](int row, int q, f32x4 s) {
                 if (q < 4) {
                     if (dHb) {
@@ -693,7 +793,12 @@ __global__ __launch_bounds__(SB_THREADS) void small_bwd_kernel(SmallBwd a) {
                         if (col < cin) dXb[(unsigned)row * cin + col] += s[i];
                     }
                 }
-            });
+            };
+        if (DENSE)
+            aggregate_dense<SB_THREADS, LP / 4>(a.g.val, N, C, dZ1, LP, from_dz0, add_in);
+        else
+            aggregate_rows<SB_THREADS, LP / 4>(gp, gc, gv, NC, C, invC, from_dz1, from_dz0, add_in);
+    }
 }
 
 int xq_of(int cin) { return cin == SC_H ? 4 : (cin >= 1 && cin <= 4 ? 1 : 0); }
@@ -709,7 +814,7 @@ hipError_t allow_lds_once(K kern, size_t bytes, std::atomic<size_t>& granted) {
     if (e == hipSuccess) granted.store(bytes, std::memory_order_relaxed);
     return e;
 }
-std::atomic<size_t> g_granted[2][2][2];          // [direction][wide input][staged]
+std::atomic<size_t> g_granted[2][2][3];          // [direction][wide input][mode]
 
 }  // namespace
 
@@ -732,9 +837,10 @@ extern "C" size_t stc_cell_small_workspace_bytes(int32_t n_nodes, int32_t C, int
                 name ": %lld rows per sample, %d samples: not a small graph", (long long)n_nodes * C, batch);                           \
     if (n_nodes == 0 || batch == 0) return STC_OK;
 
-extern "C" int stc_cell_small_fwd_f32(const int32_t* rowptr, const int32_t* colidx, const float* val, int32_t n_nodes, int32_t nnz, const float* X,
+extern "C" int stc_cell_small_fwd_f32(const int32_t* rowptr, const int32_t* colidx, const float* val, int32_t n_nodes, int32_t nnz,
+                                      int32_t graph_is_dense, const float* X,
                                       int32_t cin, const float* H, const float* Tc, int32_t Kc, const float* Wg, const float* bg, const float* Wc,
-                                      const float* bc, float* U, float* R, float* Cand, float* Hnew, float* RH, float* Zg, float* Zc,
+                                      const float* bc, float* U, float* R, float* Cand, float* Hnew, float* RH, float* Zg, float* Zc, float* Z0,
                                       int32_t batch, int32_t C, void* stream) {
     SC_COMMON_CHECKS("stc_cell_small_fwd_f32")
     STC_REQUIRE(rowptr && (nnz == 0 || (colidx && val)) && X && H && Tc && Wg && Wc && U && R && Cand && Hnew && RH && Zg && Zc, STC_EINVAL,
@@ -742,28 +848,31 @@ extern "C" int stc_cell_small_fwd_f32(const int32_t* rowptr, const int32_t* coli
     STC_REQUIRE(Hnew != H, STC_EINVAL, "stc_cell_small_fwd_f32: Hnew must not alias H (neighbour rows are read after the first rows are written)");
     const int xq = xq_of(cin);
     STC_REQUIRE(stc::aligned16(H) && stc::aligned16(U) && stc::aligned16(R) && stc::aligned16(RH) && stc::aligned16(Zg) && stc::aligned16(Zc) &&
-                    (xq != 4 || stc::aligned16(X)), STC_EINVAL, "stc_cell_small_fwd_f32: planes must be 16-byte aligned");
+                    (xq != 4 || stc::aligned16(X)) && stc::aligned16(Z0), STC_EINVAL, "stc_cell_small_fwd_f32: planes must be 16-byte aligned");
     const int npt = 16 / C, rpt = npt * C;
-    SmallFwd a{{rowptr, colidx, val, nnz}, X, H, Tc, Wg, bg, Wc, bc, U, R, Cand, Hnew, RH, Zg, Zc, n_nodes, C, cin, rpt, (n_nodes + npt - 1) / npt};
-    const size_t fixed = (size_t)fwd_lds_fixed<2>() * 4;
-    const size_t staged = fixed + (size_t)n_nodes * C * (plane_stride(xq) + SQ) * 4 + graph_lds_bytes(n_nodes, nnz);
-    const bool st = staged <= SC_LDS_BUDGET;
-    const size_t lds = st ? staged : fixed;
-    auto kern = st ? (xq == 4 ? small_fwd_kernel<2, 4, true> : small_fwd_kernel<2, 1, true>)
-                   : (xq == 4 ? small_fwd_kernel<2, 4, false> : small_fwd_kernel<2, 1, false>);
-    const hipError_t e = allow_lds_once(kern, lds, g_granted[0][xq == 4][st]);
+    SmallFwd a{{rowptr, colidx, val, nnz}, X, H, Tc, Wg, bg, Wc, bc, U, R, Cand, Hnew, RH, Zg, Zc, Z0, n_nodes, C, cin, rpt, (n_nodes + npt - 1) / npt};
+    const size_t fixed = (size_t)fwd_lds_fixed<2>() * 4, planes = (size_t)n_nodes * C * (plane_stride(xq) + SQ) * 4;
+    const bool dense = graph_is_dense && nnz == (long long)n_nodes * n_nodes && fixed + planes <= SC_LDS_BUDGET;
+    const size_t staged = fixed + planes + (dense ? 0 : graph_lds_bytes(n_nodes, nnz));
+    const int mode = dense ? 2 : (staged <= SC_LDS_BUDGET ? 1 : 0);
+    const size_t lds = mode ? staged : fixed;
+    auto kern = mode == 2 ? (xq == 4 ? small_fwd_kernel<2, 4, 2> : small_fwd_kernel<2, 1, 2>)
+              : mode == 1 ? (xq == 4 ? small_fwd_kernel<2, 4, 1> : small_fwd_kernel<2, 1, 1>)
+                          : (xq == 4 ? small_fwd_kernel<2, 4, 0> : small_fwd_kernel<2, 1, 0>);
+    const hipError_t e = allow_lds_once(kern, lds, g_granted[0][xq == 4][mode]);
     if (e != hipSuccess) return stc::hip_status(e, "stc_cell_small_fwd_f32 LDS attribute");
     hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(SF_THREADS), lds, static_cast<hipStream_t>(stream), a);
     STC_LAUNCH_CHECK("stc_cell_small_fwd_f32 launch");
     return STC_OK;
 }
 
-extern "C" int stc_cell_small_bwd_f32(const int32_t* rowptr, const int32_t* colidx, const float* val, int32_t n_nodes, int32_t nnz, const float* X,
+extern "C" int stc_cell_small_bwd_f32(const int32_t* rowptr, const int32_t* colidx, const float* val, int32_t n_nodes, int32_t nnz,
+                                      int32_t graph_is_dense, const float* X,
                                       int32_t cin, const float* H, const float* Tc, int32_t Kc, const float* Wg, const float* Wc, const float* U,
                                       const float* R, const float* Cand, const float* RH, const float* Zg, const float* Zc, const float* dHnew,
                                       float* dX, int32_t accumulate_x, float* dH, int32_t accumulate_h, float* dparams, int64_t params_ld,
-                                      int32_t has_bg, int32_t has_bc, void* workspace, size_t workspace_bytes, int32_t batch, int32_t C,
-                                      void* stream) {
+                                      int32_t has_bg, int32_t has_bc, float* dZ1c, float* dZ1g, float* dYg, void* workspace, size_t workspace_bytes,
+                                      int32_t batch, int32_t C, void* stream) {
     SC_COMMON_CHECKS("stc_cell_small_bwd_f32")
     STC_REQUIRE(rowptr && (nnz == 0 || (colidx && val)) && X && H && Tc && Wg && Wc && U && R && Cand && RH && Zg && Zc && dHnew && dparams && workspace,
                 STC_EINVAL, "stc_cell_small_bwd_f32: null operand");
@@ -772,20 +881,23 @@ extern "C" int stc_cell_small_bwd_f32(const int32_t* rowptr, const int32_t* coli
     STC_REQUIRE(params_ld >= P, STC_EINVAL, "stc_cell_small_bwd_f32: params_ld %lld < %lld floats per row", (long long)params_ld, P);
     STC_REQUIRE(workspace_bytes >= stc_cell_small_workspace_bytes(n_nodes, C, cin, batch), STC_EINVAL, "stc_cell_small_bwd_f32: workspace too small");
     STC_REQUIRE(stc::aligned16(H) && stc::aligned16(U) && stc::aligned16(R) && stc::aligned16(Cand) && stc::aligned16(RH) && stc::aligned16(Zg) &&
-                    stc::aligned16(Zc) && stc::aligned16(dHnew) && stc::aligned16(workspace) && (dH == nullptr || stc::aligned16(dH)),
+                    stc::aligned16(Zc) && stc::aligned16(dHnew) && stc::aligned16(workspace) && (dH == nullptr || stc::aligned16(dH)) &&
+                    stc::aligned16(dYg),
                 STC_EINVAL, "stc_cell_small_bwd_f32: planes must be 16-byte aligned");
     STC_REQUIRE(dH != dHnew && (const float*)dX != dHnew && (dX == nullptr || (const float*)dX != (const float*)dH), STC_EINVAL,
                 "stc_cell_small_bwd_f32: dHnew, dX and dH must be distinct buffers");
     const int npt = 16 / C, rpt = npt * C;
     SmallBwd a{{rowptr, colidx, val, nnz}, X, H, Tc, Wg, Wc, U, R, Cand, RH, Zg, Zc, dHnew, dX, dH, dparams, static_cast<float*>(workspace),
-               n_nodes, C, cin, rpt, (n_nodes + npt - 1) / npt, accumulate_x, accumulate_h, has_bg, has_bc, params_ld};
-    const size_t fixed = (size_t)bwd_lds_fixed<2>() * 4;
-    const size_t staged = fixed + (size_t)n_nodes * C * LP * 4 + graph_lds_bytes(n_nodes, nnz);
-    const bool st = staged <= SC_LDS_BUDGET;
-    const size_t lds = st ? staged : fixed;
-    auto kern = st ? (xq == 4 ? small_bwd_kernel<2, 4, true> : small_bwd_kernel<2, 1, true>)
-                   : (xq == 4 ? small_bwd_kernel<2, 4, false> : small_bwd_kernel<2, 1, false>);
-    const hipError_t e = allow_lds_once(kern, lds, g_granted[1][xq == 4][st]);
+               dZ1c, dZ1g, dYg, n_nodes, C, cin, rpt, (n_nodes + npt - 1) / npt, accumulate_x, accumulate_h, has_bg, has_bc, params_ld};
+    const size_t fixed = (size_t)bwd_lds_fixed<2>() * 4, planes = (size_t)n_nodes * C * LP * 4;
+    const bool dense = graph_is_dense && nnz == (long long)n_nodes * n_nodes && fixed + planes <= SC_LDS_BUDGET;
+    const size_t staged = fixed + planes + (dense ? 0 : graph_lds_bytes(n_nodes, nnz));
+    const int mode = dense ? 2 : (staged <= SC_LDS_BUDGET ? 1 : 0);
+    const size_t lds = mode ? staged : fixed;
+    auto kern = mode == 2 ? (xq == 4 ? small_bwd_kernel<2, 4, 2> : small_bwd_kernel<2, 1, 2>)
+              : mode == 1 ? (xq == 4 ? small_bwd_kernel<2, 4, 1> : small_bwd_kernel<2, 1, 1>)
+                          : (xq == 4 ? small_bwd_kernel<2, 4, 0> : small_bwd_kernel<2, 1, 0>);
+    const hipError_t e = allow_lds_once(kern, lds, g_granted[1][xq == 4][mode]);
     if (e != hipSuccess) return stc::hip_status(e, "stc_cell_small_bwd_f32 LDS attribute");
     hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(SB_THREADS), lds, static_cast<hipStream_t>(stream), a);
     STC_LAUNCH_CHECK("stc_cell_small_bwd_f32 launch");

@@ -17,9 +17,11 @@ from typing import Optional, Sequence
 
 import torch
 
+from .graph import is_full_pattern
+
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG_ROOT, 'libstc_hip.so')
-ABI_VERSION = 18
+ABI_VERSION = 19
 FMT_BF16X3, FMT_F16X2 = 0, 1          # STC_FMT_* of include/stc_hip.h: operand formats of the split-operand matrix-core kernels
 MAX_K = 4
 SPMM_SUM_MAX_ADD = 8     # = STC_SPMM_SUM_MAX_ADD of include/stc_hip.h
@@ -67,9 +69,9 @@ def _declare(lib):
         'stc_csr_spmm_bf16': [_p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _f32, _p],
         'stc_bcsr_spmm_bf16': [_p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _f32, _p],
         'stc_dense_agg_f32': [_p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _f32, _p],
-        'stc_cell_small_fwd_f32': [_p, _p, _p, _i32, _i32, _p, _i32, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _p],
-        'stc_cell_small_bwd_f32': [_p, _p, _p, _i32, _i32, _p, _i32, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _i32, _p, _i64, _i32, _i32,
-                                   _p, C.c_size_t, _i32, _i32, _p],
+        'stc_cell_small_fwd_f32': [_p, _p, _p, _i32, _i32, _i32, _p, _i32, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _p],
+        'stc_cell_small_bwd_f32': [_p, _p, _p, _i32, _i32, _i32, _p, _i32, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _i32, _p, _i64, _i32, _i32,
+                                   _p, _p, _p, _p, C.c_size_t, _i32, _i32, _p],
         'stc_csr_sddmm_f32': [_p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _i32, _p],
         'stc_cheby_dense_fwd_f32': [_p, _i32, _i32, _p, _p],
         'stc_cheby_dense_bwd_f32': [_p, _p, _p, _i32, _i32, _p, _p],
@@ -823,22 +825,27 @@ class HipKernels:
         self._same_device(H, X, Tc, Wg, Wc, rowptr, colidx, val, Zg, Zc, *planes.values())
         return B, N, Cc, cin, Kc
 
-    def cell_small_fwd(self, rowptr, colidx, val, X, H, Tc, Wg, bg, Wc, bc, U, R, Cand, Hnew, RH, Zg, Zc, checked=True):
+    def cell_small_fwd(self, rowptr, colidx, val, X, H, Tc, Wg, bg, Wc, bc, U, R, Cand, Hnew, RH, Zg, Zc, checked=True, Z0=None):
         """One STC_Cell step (reference STC_GNN.py:65-79) in one launch: ``stc_cell_small_fwd_f32``.  (rowptr, colidx, val): CSR of Gs^T.
-        ``checked=False``: the caller built every buffer itself from shapes it already validated (the cell-graph executor)."""
+        ``checked=False``: the caller built every buffer itself from shapes it already validated (the cell-graph executor).
+        ``Z0`` (optional, like Zg): receives the slab [H | Xt | 0] (learned graphs: operand of the graph-gradient product)."""
         if checked:
             B, N, Cc, cin, Kc = self._small_shapes('cell_small_fwd', rowptr, colidx, val, X, H, Tc, Wg, Wc, dict(U=U, R=R, Cand=Cand, Hnew=Hnew, RH=RH), Zg, Zc)
+            if Z0 is not None:
+                self._f32('cell_small_fwd.Z0', Z0, tuple(Zg.shape))
+                self._same_device(H, Z0)
             for name, b_, n in (('bg', bg, 32), ('bc', bc, 16)):
                 if b_ is not None:
                     self._f32('cell_small_fwd.' + name, b_, (n,))
         else:
             (B, N, Cc, _), cin, Kc = H.shape, X.shape[-1], Tc.shape[0]
-        self._launch('stc_cell_small_fwd_f32', H, rowptr.data_ptr(), colidx.data_ptr(), val.data_ptr(), N, val.numel(), X.data_ptr(), cin, H.data_ptr(), Tc.data_ptr(), Kc,
+        self._launch('stc_cell_small_fwd_f32', H, rowptr.data_ptr(), colidx.data_ptr(), val.data_ptr(), N, val.numel(), int(is_full_pattern(colidx, N, N)),
+                     X.data_ptr(), cin, H.data_ptr(), Tc.data_ptr(), Kc,
                      Wg.data_ptr(), _ptr(bg), Wc.data_ptr(), _ptr(bc), U.data_ptr(), R.data_ptr(), Cand.data_ptr(), Hnew.data_ptr(), RH.data_ptr(),
-                     Zg.data_ptr(), Zc.data_ptr(), B, Cc, nbytes=4 * B * N * Cc * (cin + 16 * 8 + 2 * self.cell_small_zg_width(cin)))
+                     Zg.data_ptr(), Zc.data_ptr(), _ptr(Z0), B, Cc, nbytes=4 * B * N * Cc * (cin + 16 * 8 + 2 * self.cell_small_zg_width(cin)))
 
     def cell_small_bwd(self, rowptr, colidx, val, X, H, Tc, Wg, Wc, U, R, Cand, RH, Zg, Zc, dHnew, dX, accumulate_x, dH, accumulate_h,
-                       dparams, has_bg, has_bc, checked=True):
+                       dparams, has_bg, has_bc, checked=True, dZ1c=None, dZ1g=None, dYg=None):
         """Autograd of ``cell_small_fwd`` in one launch (``stc_cell_small_bwd_f32``).  (rowptr, colidx, val): CSR of Gs.  dX / dH may be
         None; ``accumulate_*``: add to what the buffer holds.  ``dparams`` (B * cell_small_param_rows, P >= cell_small_params):
         parameter-gradient partials (one row per sample and wave), ADDED to."""
@@ -851,15 +858,19 @@ class HipKernels:
             if dparams.dim() != 2 or dparams.shape[0] != B * self.cell_small_param_rows or dparams.shape[1] < self.cell_small_params(2, Kc, cin):
                 raise StcError(f'cell_small_bwd: dparams {tuple(dparams.shape)}, expected ({B * self.cell_small_param_rows}, '
                                f'>= {self.cell_small_params(2, Kc, cin)})')
-            self._same_device(H, dHnew, dparams, *([dX] if dX is not None else []))
+            for name, t_, shape in (('dZ1c', dZ1c, tuple(Zg.shape)), ('dZ1g', dZ1g, tuple(Zg.shape)), ('dYg', dYg, (B, N * Cc, 32))):
+                if t_ is not None:
+                    self._f32('cell_small_bwd.' + name, t_, shape)
+            self._same_device(H, dHnew, dparams, dZ1c, dZ1g, dYg, *([dX] if dX is not None else []))
         else:
             (B, N, Cc, _), cin, Kc = H.shape, X.shape[-1], Tc.shape[0]
         nbytes = self.lib.stc_cell_small_workspace_bytes(N, Cc, cin, B)
         ws = self._get_workspace(H.device, nbytes)
-        self._launch('stc_cell_small_bwd_f32', H, rowptr.data_ptr(), colidx.data_ptr(), val.data_ptr(), N, val.numel(), X.data_ptr(), cin, H.data_ptr(), Tc.data_ptr(), Kc,
+        self._launch('stc_cell_small_bwd_f32', H, rowptr.data_ptr(), colidx.data_ptr(), val.data_ptr(), N, val.numel(), int(is_full_pattern(colidx, N, N)),
+                     X.data_ptr(), cin, H.data_ptr(), Tc.data_ptr(), Kc,
                      Wg.data_ptr(), Wc.data_ptr(), U.data_ptr(), R.data_ptr(), Cand.data_ptr(), RH.data_ptr(), Zg.data_ptr(), Zc.data_ptr(),
                      dHnew.data_ptr(), _ptr(dX), int(bool(accumulate_x)), _ptr(dH), int(bool(accumulate_h)), dparams.data_ptr(), dparams.shape[1],
-                     int(bool(has_bg)), int(bool(has_bc)), ws.data_ptr(), ws.numel(), B, Cc,
+                     int(bool(has_bg)), int(bool(has_bc)), _ptr(dZ1c), _ptr(dZ1g), _ptr(dYg), ws.data_ptr(), ws.numel(), B, Cc,
                      nbytes=4 * B * N * Cc * (2 * cin + 16 * 9 + 5 * self.cell_small_zg_width(cin) + 64))
 
     # ---- planar cell convolutions of Chebyshev order K = 3 ------------------------------------------------

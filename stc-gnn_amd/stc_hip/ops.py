@@ -448,14 +448,16 @@ def cell_graph_supported(op: SpatialOperand, Tc, Ks: int, C: int, h: int, x_widt
     """Whether ``stc_cell_graph`` can run a schedule: matrix-core cell kernels for every row width that occurs, hidden 16,
     graphs that need no gradient (``csr-fixed`` mode).  ``dtype`` = storage type of the state tensors: bfloat16 runs the
     all-planar bf16 kernel set (Ks = Kc = 2; inputs 16 or 1..4 columns wide)."""
-    if not _CELL_GRAPH or h != 16 or Tc.requires_grad or op.fwd_val.requires_grad:
+    if not _CELL_GRAPH or h != 16:
         return False
     k = kernels()
+    if _SMALL and small_graph_supported(k, op, Tc, Ks, C, h, x_widths, dtype):
+        return True                                                   # small graphs, fixed or learned: one launch per cell step (stc_hip/small.py)
+    if Tc.requires_grad or op.fwd_val.requires_grad:
+        return False
     if dtype == torch.bfloat16:
         return (_PLANAR and _POST_AGG and _FUSE_POST and Ks == 2 and Tc.shape[0] == 2 and k.bf16.cell_planar_supported(Ks, 2, C, h)
                 and all(w == h or 1 <= w <= 4 for w in x_widths))
-    if _SMALL and small_graph_supported(k, op, Tc, Ks, C, h, x_widths, dtype):
-        return True                                                   # small graphs: one launch per cell step (stc_hip/small.py)
     return all(k.cell_fused_supported(Ks, Tc.shape[0], C, w + h + (-(w + h)) % 4, h) for w in set(x_widths))
 
 

@@ -10,7 +10,10 @@ with the same interface as ``ops.stc_cell_graph``:
     backward kernel), in reverse schedule order -- no autograd accumulation passes;
   * parameter gradients are partial sums (one row per sample and wave) that every cell of a parameter set adds to; one sum over the
     rows per backward pass.
-Fixed graphs only (``csr-fixed``: no gradient to Gs / Gc).
+Learned graphs (the reference's own mode: dense Gs from MGP_Gen, Gc through its Chebyshev stack): the gradients of Gs and Gc are sums over
+ALL cells of a step, so the launches only leave their operands (the slab [H | X | 0], the gradients of the two aggregated slabs, the gate
+pre-activation gradients) and the backward forms  dGs^T = sum_cells dZ_1 x Z_0  and  dT_c = sum_cells V_c x dY  as a few stacked
+products per parameter set at the end -- not per cell.
 """
 from __future__ import annotations
 
@@ -30,7 +33,9 @@ def _c(t):
 
 
 def small_graph_supported(k, op: SpatialOperand, Tc, Ks: int, C: int, h: int, x_widths, dtype=torch.float32) -> bool:
-    if dtype != torch.float32 or Tc.requires_grad or op.fwd_val.requires_grad or not hasattr(k, 'cell_small_supported'):
+    """Fixed graphs, or the reference's learned ones: a learned spatial graph must be dense (values = the full N x N pattern, as
+    ``graph.dense_operand`` builds it) -- its gradient is formed as a dense product."""
+    if dtype != torch.float32 or not hasattr(k, 'cell_small_supported') or (op.fwd_val.requires_grad and op.nnz != op.n * op.n):
         return False
     return all(k.cell_small_supported(Ks, Tc.shape[0], C, w, h, op.n) for w in set(x_widths))
 
@@ -74,8 +79,11 @@ class _StcSmallGraph(Function):
         wide = [j for j in range(n_cells) if cin[j] == H16]
         zg_w = ref.new_empty(max(1, len(wide)), B, N * C, k.cell_small_zg_width(H16))
         zg_n = ref.new_empty(max(1, n_cells - len(wide)), B, N * C, k.cell_small_zg_width(1))
+        learned = bool(ctx.needs_input_grad[6] or ctx.needs_input_grad[7])
+        z0_w = torch.empty_like(zg_w) if learned else zg_w.new_empty(0)
+        z0_n = torch.empty_like(zg_n) if learned else zg_n.new_empty(0)
         out_alias = _alias(out_stack)
-        state, zg, nxt, wi, ni = [], [], 0, 0, 0
+        state, zg, z0, nxt, wi, ni = [], [], [], 0, 0, 0
         for j in range(n_cells):
             if j in out_slot:
                 state.append(out_alias[out_slot[j]])
@@ -84,17 +92,19 @@ class _StcSmallGraph(Function):
                 nxt += 1
             if cin[j] == H16:
                 zg.append(zg_w[wi])
+                z0.append(z0_w[wi] if learned else None)
                 wi += 1
             else:
                 zg.append(zg_n[ni])
+                z0.append(z0_n[ni] if learned else None)
                 ni += 1
         U, R, Cand, RH, Zc = (p.unbind(0) for p in planes.unbind(0))
         source = lambda src: ext[src[1]] if src[0] == 'ext' else state[src[1]]
         for j, (s_id, x, hs) in enumerate(schedule):
             Wg, bg, Wc, bc = stacks[s_id]
             k.cell_small_fwd(op.fwd_rowptr, op.fwd_colidx, fwd_val, source(x), source(hs), Tc, Wg, bg, Wc, bc, U[j], R[j], Cand[j], state[j], RH[j],
-                             zg[j], Zc[j].view(B, N * C, H16), checked=False)
-        ctx.save_for_backward(Tc, out_alias, inner, planes, zg_w, zg_n, *ext, *[p for st in stacks for p in st if p is not None])
+                             zg[j], Zc[j].view(B, N * C, H16), checked=False, Z0=z0[j])
+        ctx.save_for_backward(Tc, out_alias, inner, planes, zg_w, zg_n, z0_w, z0_n, *ext, *[p for st in stacks for p in st if p is not None])
         ctx.meta = (k, op, Ks, list(schedule), tuple(outputs), cin, [tuple(p is not None for p in st) for st in stacks], (B, N, C), len(ext))
         ctx.out_stack_ref, ctx.out_stack_version = weakref.ref(out_stack), out_stack._version
         return out_stack
@@ -107,7 +117,9 @@ class _StcSmallGraph(Function):
         if stack is not None and stack._version != ctx.out_stack_version:
             raise RuntimeError('stc_cell_graph: the returned state stack was modified in place after the forward pass; the states saved for '
                                'backward share its storage (treat the stack as read-only, or clone it before editing)')
-        Tc, out_alias, inner, planes, zg_w, zg_n, *rest = ctx.saved_tensors
+        Tc, out_alias, inner, planes, zg_w, zg_n, z0_w, z0_n, *rest = ctx.saved_tensors
+        need_Tc, need_val = ctx.needs_input_grad[6], ctx.needs_input_grad[7]
+        learned = bool(need_Tc or need_val)
         ext, rest = rest[:n_ext], rest[n_ext:]
         stacks = []
         for pres in present:
@@ -117,25 +129,30 @@ class _StcSmallGraph(Function):
             stacks.append(st)
         n_cells = len(schedule)
         out_slot = {j: i for i, j in enumerate(outputs)}
-        state, zg, nxt, wi, ni = [], [], 0, 0, 0
+        # learned graphs: what the launches leave for the graph-gradient products (zeros where a cell is never reached)
+        dzc_w, dzg_w = (torch.zeros_like(zg_w), torch.zeros_like(zg_w)) if learned else (None, None)
+        dzc_n, dzg_n = (torch.zeros_like(zg_n), torch.zeros_like(zg_n)) if learned else (None, None)
+        dyg = Tc.new_zeros(n_cells, B, N * C, 2 * H16) if learned else None
+        state, zg, z0, dzc, dzg, nxt, wi, ni = [], [], [], [], [], 0, 0, 0
         for j in range(n_cells):
             if j in out_slot:
                 state.append(out_alias[out_slot[j]])
             else:
                 state.append(inner[nxt])
                 nxt += 1
-            if cin[j] == H16:
-                zg.append(zg_w[wi])
-                wi += 1
-            else:
-                zg.append(zg_n[ni])
-                ni += 1
+            wide = cin[j] == H16
+            i = wi if wide else ni
+            zg.append((zg_w if wide else zg_n)[i])
+            z0.append((z0_w if wide else z0_n)[i] if learned else None)
+            dzc.append((dzc_w if wide else dzc_n)[i] if learned else None)
+            dzg.append((dzg_w if wide else dzg_n)[i] if learned else None)
+            wi, ni = wi + wide, ni + (not wide)
         U, R, Cand, RH, Zc = (p.unbind(0) for p in planes.unbind(0))
         source = lambda src: ext[src[1]] if src[0] == 'ext' else state[src[1]]
         Kc = Tc.shape[0]
         P = max(k.cell_small_params(Ks, Kc, w) for w in cin)
         dP = Tc.new_zeros(len(stacks), B * k.cell_small_param_rows, P)   # parameter-gradient partials, every cell adds to its set's rows
-        G = Tc.new_empty(n_cells, B, N, C, H16)                      # gradient owed to every cell's state
+        G = (Tc.new_zeros if learned else Tc.new_empty)(n_cells, B, N, C, H16)      # gradient owed to every cell's state
         owed = [False] * n_cells
         grad_stack = _c(grad_stack)
         for i, j in enumerate(outputs):
@@ -160,7 +177,8 @@ class _StcSmallGraph(Function):
                     dX, acc_x = Gv[x[1]], owed[x[1]]
                     owed[x[1]] = True
             k.cell_small_bwd(op.bwd_rowptr, op.bwd_colidx, op.bwd_val, source(x), source(hs), Tc, Wg, Wc, U[j], R[j], Cand[j], RH[j], zg[j],
-                             Zc[j].view(B, N * C, H16), Gv[j], dX, acc_x, dH, acc_h, dPv[s_id], bg is not None, bc is not None, checked=False)
+                             Zc[j].view(B, N * C, H16), Gv[j], dX, acc_x, dH, acc_h, dPv[s_id], bg is not None, bc is not None, checked=False,
+                             dZ1c=dzc[j], dZ1g=dzg[j], dYg=None if dyg is None else dyg[j])
             if late is not None:
                 Gv[late].add_(dX)
         sums = dP.sum(1)                                             # (sets, P)
@@ -174,7 +192,54 @@ class _StcSmallGraph(Function):
             dWg, dbg = row[:nW * 32].view(nW, 32), row[nW * 32:nW * 32 + 32]
             dWc, dbc = row[nW * 32 + 32:nW * 48 + 32].view(nW, H16), row[nW * 48 + 32:nW * 48 + 48]
             flat += [dWg, dbg if st[1] is not None else None, dWc, dbc if st[3] is not None else None]
-        return (None,) * 8 + (None,) * n_ext + tuple(flat)
+        dT = dS = None
+        if learned:
+            dT, dS = _graph_gradients(Tc, Ks, stacks, schedule, cin, (B, N, C), planes, G, zg, z0, dzc, dzg, dyg, need_Tc, need_val)
+        return (None,) * 6 + (dT, dS) + (None,) * n_ext + tuple(flat)
+
+
+def _graph_gradients(Tc, Ks, stacks, schedule, cin, dims, planes, G, zg, z0, dzc, dzg, dyg, need_Tc, need_val):
+    """(dT_c, d fwd_val) of a learned-graph backward pass from what the cell launches left (module docstring).  Slabs are in the
+    kernels' column order [H (16) | X (cin) | 0]; W's rows are re-ordered to match.  Per parameter set a handful of LARGE plain GEMMs
+    (contraction over every cell, sample and node at once -- as batched products with a sum they cost 5 ms per step at the SF shape):
+      d fwd_val = sum  D^T-style products  (N, K) x (K, N),  K = cells * B * C * LP;
+      dT_c[c, d] = < W[(ks, c)], Q_ks[c, :, d, :] >  with  Q_ks = Z_ks^T . dY  ((C * LP, R) x (R, C * Ho), R = cells * B * N)."""
+    B, N, C = dims
+    Kc = Tc.shape[0]
+    dT = torch.zeros_like(Tc) if need_Tc else None
+    dS = Tc.new_zeros(N, N) if need_val else None
+    for s_id, (Wg, bg, Wc, bc) in enumerate(stacks):
+        cells = [j for j, sc in enumerate(schedule) if sc[0] == s_id]
+        if not cells:
+            continue
+        w, k_ = cin[cells[0]], len(cells)
+        stack = lambda views: torch.stack([views[j] for j in cells])               # (k, B, N*C, LP); (no index tensor: nothing here may come
+        #                                                                            from host memory -- the step may be under HIP-graph capture)
+        Z0, Zg, dZg, dZc = stack(z0), stack(zg), stack(dzg), stack(dzc)
+        LP = Z0.shape[-1]
+        U, Cand, RH, Zc = (stack(planes[i]) for i in (0, 2, 3, 4))                  # (k, B, N, C, 16)
+        Z0c = Z0.clone()                                                          # the candidate's slab 0: [R*H | X | 0]
+        Z0c.view(k_, B, N, C, LP)[..., :H16] = RH
+        if need_val:
+            by_node = lambda t: t.view(k_ * B, N, C * LP).transpose(0, 1).reshape(N, -1)       # (N, K): a node's row = every (cell, sample, c, l)
+            dS.addmm_(by_node(dZg), by_node(Z0).t())
+            dS.addmm_(by_node(dZc), by_node(Z0c).t())
+        if need_Tc:
+            L = w + H16
+            Z1c = Zg.clone()                                                      # the candidate's slab 1: [S.(R*H) | S.X | 0]
+            Z1c.view(k_, B, N, C, LP)[..., :H16] = Zc
+            dCpre = stack(G) * U * (1.0 - Cand * Cand)
+            rows = lambda t: t.reshape(k_ * B * N, -1)                              # (R, C * width)
+            for s0, s1, W, dY in ((Z0, Zg, Wg, stack(dyg)), (Z0c, Z1c, Wc, dCpre)):
+                Ho = W.shape[1]
+                Wv = W.view(Ks, Kc, L, Ho)
+                Wp = W.new_zeros(Ks, Kc, LP, Ho)
+                Wp[:, :, :H16] = Wv[:, :, w:]
+                Wp[:, :, H16:H16 + w] = Wv[:, :, :w]
+                dYr = rows(dY)                                                    # (R, C * Ho)
+                Q = torch.stack([rows(s0).t() @ dYr, rows(s1).t() @ dYr]).view(Ks, C, LP, C, Ho)
+                dT += torch.einsum('scldo,sklo->kcd', Q, Wp)
+    return dT, (None if dS is None else dS.reshape(-1))
 
 
 def stc_small_graph(k, op: SpatialOperand, Tc, Ks: int, schedule, outputs, ext, stacks):

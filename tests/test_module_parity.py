@@ -211,7 +211,13 @@ def test_adam_trajectory_through_drop_in():
     assert torch.allclose(torch.tensor(losses, dtype=torch.float64), g['adam_losses'].cpu(), rtol=0, atol=2e-5), losses
 
 
-def test_sf_shape_fixed_graphs_through_modules():
+def test_sf_shape_fixed_graphs_through_modules(monkeypatch):
+    """g5: the reference's encoder-decoder-head at the SF shape (B = 32, T = 9, N = 100, C = 5, h = 16) on the dense graphs its own MGP_Gen
+    produced, handed in as differentiable leaves: prediction, every parameter gradient, dGs and dGc.  Runs on the small-graph cell kernels
+    with LEARNED graphs (asserted): dGs / dGc come from the stacked products of stc_hip/small.py over what the cell launches leave."""
+    small_calls = []
+    real_small = ops.stc_small_graph
+    monkeypatch.setattr(ops, 'stc_small_graph', lambda *a, **k: (small_calls.append(1), real_small(*a, **k))[1])
     g = _golden('g5_sf_shape')
     model = _small_model(g, graph_mode='csr-fixed')
     sd = sub_dict(g, 'sd/')
@@ -219,7 +225,7 @@ def test_sf_shape_fixed_graphs_through_modules():
     model.load_state_dict(sd)
     Gs, Gc = _leaf(g['Gs']), _leaf(g['Gc'])
     yhat = model(X_seq=g['X'].float(), As=Gs, Ac=Gc)                  # a dense Gs handed in directly stays differentiable
-    assert yhat.shape == (32, 3, 100, 5)
+    assert yhat.shape == (32, 3, 100, 5) and small_calls, 'the small-graph path was not taken'
     _close(yhat, g['yhat'], FWD, 'SF yhat')
     O.combo_loss(yhat, g['Y'].float()).backward()
     grads = dict(model.named_parameters())

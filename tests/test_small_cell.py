@@ -10,7 +10,7 @@ import torch
 from oracle import stc_oracle as oracle
 from oracle.kernel_emul import EmulatedKernels
 from stc_hip import CsrGraph
-from stc_hip.graph import csr_operand
+from stc_hip.graph import csr_operand, dense_operand
 from tests.conftest import rel_err
 
 EM = EmulatedKernels()
@@ -47,19 +47,22 @@ def _buffers(B, N, C, cin, dtype, k):
                 Zg=new(B, N * C, k.cell_small_zg_width(cin)), Zc=new(B, N * C, 16)), P
 
 
-def _run(k, op, t, buf, P, to, acc_x=False, acc_h=False, want_x=True, want_h=True):
+def _run(k, op, t, buf, P, to, acc_x=False, acc_h=False, want_x=True, want_h=True, want_dumps=False):
     """Forward + backward through kernel set ``k`` on device / dtype converter ``to``; returns plain CPU tensors."""
     d = {n: (None if v is None else to(v)) for n, v in t.items()}
     b = {n: to(v) for n, v in buf.items()}
+    dumps = {n: to(torch.full_like(buf['Zg'], float('nan'))) for n in ('Z0', 'dZ1c', 'dZ1g')} if want_dumps else {}
     k.cell_small_fwd(op.fwd_rowptr, op.fwd_colidx, to(op.fwd_val), d['X'], d['H'], d['Tc'], d['Wg'], d['bg'], d['Wc'], d['bc'],
-                     b['U'], b['R'], b['Cand'], b['Hnew'], b['RH'], b['Zg'], b['Zc'])
+                     b['U'], b['R'], b['Cand'], b['Hnew'], b['RH'], b['Zg'], b['Zc'], Z0=dumps.get('Z0'))
     B = d['H'].shape[0]
     dX = to(torch.full(t['X'].shape, 0.25, dtype=t['X'].dtype)) if want_x else None
     dH = to(torch.full(t['H'].shape, -0.5, dtype=t['H'].dtype)) if want_h else None
     dP = to(torch.full((B * k.cell_small_param_rows, P), 0.125, dtype=t['H'].dtype))
     k.cell_small_bwd(op.bwd_rowptr, op.bwd_colidx, to(op.bwd_val), d['X'], d['H'], d['Tc'], d['Wg'], d['Wc'], b['U'], b['R'], b['Cand'], b['RH'],
-                     b['Zg'], b['Zc'], d['dHnew'], dX, acc_x, dH, acc_h, dP, t['bg'] is not None, t['bc'] is not None)
-    out = dict(b, dX=dX, dH=dH, dP=dP)
+                     b['Zg'], b['Zc'], d['dHnew'], dX, acc_x, dH, acc_h, dP, t['bg'] is not None, t['bc'] is not None,
+                     dZ1c=dumps.get('dZ1c'), dZ1g=dumps.get('dZ1g'), dYg=dumps.setdefault('dYg', to(torch.full((B, buf['Zg'].shape[1], 32), float('nan'),
+                                                                                                    dtype=t['H'].dtype))) if want_dumps else None)
+    out = dict(b, dX=dX, dH=dH, dP=dP, **dumps)
     return {n: (None if v is None else v.detach().cpu()) for n, v in out.items()}
 
 
@@ -97,7 +100,10 @@ def test_small_cell_twin_is_the_reference_cell(B, N, C, cin, bias):
 @pytest.mark.parametrize('B,N,C,cin,dense', [
     (32, 100, 5, 1, False),      # the SF shape, layer 0
     (32, 100, 5, 16, False),     # the SF shape, layers above
-    (3, 100, 5, 16, True),       # the reference's dense graph on the full pattern
+    (3, 100, 5, 16, True),       # a dense graph as a CSR the kernels know nothing about: row gathers
+    (32, 100, 5, 16, 'operand'), # the reference's learned dense Gs (graph.dense_operand): aggregation as matrix products on the staged planes
+    (4, 100, 5, 1, 'operand'),
+    (2, 37, 8, 3, 'operand'),    # N not a multiple of 16 nor of 4
     (2, 37, 8, 16, False),       # two whole nodes per row tile, ragged last tile
     (2, 200, 8, 3, False),       # BASELINE configuration 3's nominal size (N ~ 200, C ~ 8)
     (1, 10, 16, 4, False),       # one node per tile
@@ -109,19 +115,20 @@ def test_small_cell_kernels(B, N, C, cin, dense, bias, acc):
     from stc_hip._lib import HipKernels
     hip = HipKernels()
     assert hip.cell_small_supported(2, 2, C, cin, 16, N)
-    graph = _graph(N, seed=N + cin, dense=dense)
+    graph = _graph(N, seed=N + cin, dense=bool(dense))
+    operand = (lambda dev: dense_operand(graph.to_dense().to(dev))) if dense == 'operand' else (lambda dev: csr_operand(graph, torch.device(dev)))
     t = _inputs(B, N, C, cin, seed=3 * N + C + cin, bias=bias)
     buf, P = _buffers(B, N, C, cin, torch.float32, hip)
-    want = _run(EM, csr_operand(graph, torch.device('cpu')), t, buf, P, lambda v: v.clone(), acc_x=acc, acc_h=acc)
-    got = _run(hip, csr_operand(graph, torch.device('cuda')), t, buf, P, lambda v: v.cuda(), acc_x=acc, acc_h=acc)
-    for name in ('U', 'R', 'RH', 'Zg', 'Zc', 'Cand', 'Hnew'):
+    want = _run(EM, operand('cpu'), t, buf, P, lambda v: v.clone(), acc_x=acc, acc_h=acc, want_dumps=acc)
+    got = _run(hip, operand('cuda'), t, buf, P, lambda v: v.cuda(), acc_x=acc, acc_h=acc, want_dumps=acc)
+    for name in ('U', 'R', 'RH', 'Zg', 'Zc', 'Cand', 'Hnew') + (('Z0', 'dZ1c', 'dZ1g', 'dYg') if acc else ()):   # (dumps: what learned graphs keep)
         assert rel_err(got[name], want[name]) < TOL, name
     for name in ('dX', 'dH'):
         assert rel_err(got[name], want[name]) < TOL, name
     for a, b, name in zip(_split_params(got['dP'], cin), _split_params(want['dP'], cin), ('dWg', 'dbg', 'dWc', 'dbc', 'rest')):
         assert rel_err(a, b) < TOL, name
     # inputs that need no gradient: NULL outputs
-    got = _run(hip, csr_operand(graph, torch.device('cuda')), t, buf, P, lambda v: v.cuda(), want_x=False, want_h=False)
+    got = _run(hip, operand('cuda'), t, buf, P, lambda v: v.cuda(), want_x=False, want_h=False)
     assert got['dX'] is None and got['dH'] is None
     for a, b, name in zip(_split_params(got['dP'], cin), _split_params(want['dP'], cin), ('dWg', 'dbg', 'dWc', 'dbc', 'rest')):
         assert rel_err(a, b) < TOL, name

@@ -20,6 +20,7 @@ ap.add_argument('--mode', default='csr-fixed')
 ap.add_argument('--steps', type=int, default=10)
 ap.add_argument('--graph', action='store_true', help='capture the whole train step in a HIP graph and replay it')
 ap.add_argument('--fused-adam', action='store_true', help='torch.optim.Adam(fused=True): one multi-tensor kernel per step instead of ~10 passes')
+ap.add_argument('--profile', action='store_true', help='print the kernels of 3 steps by GPU time (torch.profiler)')
 a = ap.parse_args()
 dev = torch.device('cuda')
 torch.manual_seed(0)
@@ -67,3 +68,10 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.steps
 print(f'SF shape {a.mode}{" hipGraph" if a.graph else ""}{" fused-adam" if a.fused_adam else ""}: {1e3 * dt:.2f} ms/step, {B / dt:.1f} samples/s, loss {float(loss.detach()):.4f}, '
       f'{sum(p.numel() for p in model.parameters())} parameters', flush=True)
+if a.profile:
+    from torch.profiler import ProfilerActivity, profile
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+    print(prof.key_averages().table(sort_by='cuda_time_total', row_limit=22, max_name_column_width=60), flush=True)

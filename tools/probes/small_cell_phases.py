@@ -59,10 +59,10 @@ for stop in (1, 2, 3, 99):
                            '-I' + os.path.join(REPO, 'include'), os.path.join(csrc, 'stc_cell_small.hip'), os.path.join(csrc, 'stc_gates.hip'), '-o', so])      # (stc_gates.hip: stc_last_error's buffer)
     lib = C.CDLL(so)
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    fwd = lambda: lib.stc_cell_small_fwd_f32(p(op.fwd_rowptr), p(op.fwd_colidx), p(op.fwd_val), N, op.fwd_val.numel(), p(X), cin, p(H), p(Tc), 2, p(Wg), p(bg), p(Wc), p(bc),
-                                             p(U), p(R), p(Cand), p(Hnew), p(RH), p(Zg), p(Zc), B, Cc, stream)
-    bwd = lambda: lib.stc_cell_small_bwd_f32(p(op.bwd_rowptr), p(op.bwd_colidx), p(op.bwd_val), N, op.bwd_val.numel(), p(X), cin, p(H), p(Tc), 2, p(Wg), p(Wc), p(U), p(R),
-                                             p(Cand), p(RH), p(Zg), p(Zc), p(dHn), p(dX), 0, p(dH), 0, p(dP), C.c_int64(P), 1, 1, p(ws),
+    fwd = lambda: lib.stc_cell_small_fwd_f32(p(op.fwd_rowptr), p(op.fwd_colidx), p(op.fwd_val), N, op.fwd_val.numel(), 0, p(X), cin, p(H), p(Tc), 2, p(Wg), p(bg), p(Wc), p(bc),
+                                             p(U), p(R), p(Cand), p(Hnew), p(RH), p(Zg), p(Zc), None, B, Cc, stream)
+    bwd = lambda: lib.stc_cell_small_bwd_f32(p(op.bwd_rowptr), p(op.bwd_colidx), p(op.bwd_val), N, op.bwd_val.numel(), 0, p(X), cin, p(H), p(Tc), 2, p(Wg), p(Wc), p(U), p(R),
+                                             p(Cand), p(RH), p(Zg), p(Zc), p(dHn), p(dX), 0, p(dH), 0, p(dP), C.c_int64(P), 1, 1, None, None, None, p(ws),
                                              C.c_size_t(ws.numel() * 4), B, Cc, stream)
     assert fwd() == 0 and bwd() == 0
     rows.append((stop, timed(fwd), timed(bwd)))
