@@ -65,10 +65,13 @@ def parse(argv=None):
     ap.add_argument('--pred', type=int, default=6)
     ap.add_argument('--batch-per-gpu', type=int, default=5, help='samples per GPU (weak scaling); ~30 GB of saved activations per sample')
     ap.add_argument('--global-batch', type=int, default=0, help='total batch over all GPUs (strong scaling: each rank takes global-batch / gpus samples); 0 = weak scaling')
-    ap.add_argument('--preset', choices=('cfg2', 'cfg4', 'cfg5', 'sf'), default=None,
+    ap.add_argument('--preset', choices=('cfg2', 'cfg4', 'cfg5', 'sf', 'sf-learned'), default=None,
                     help="BASELINE.json's other configurations through the same bench (not the metric): cfg4 = N 10 000, K = 3, batch 4; cfg5 = C = 64, "
-                         'bf16 state storage; sf = the SF-incidents shape (N = 100, C = 5, T = 9 + 3, batch 32, fixed sparse graph); cfg2 = one BDG_Dif layer '
+                         'bf16 state storage; sf = the SF-incidents shape (N = 100, C = 5, T = 9 + 3, batch 32, fixed sparse graph); sf-learned = the same shape with '
+                         "the reference's FULL model: MGP_Gen's learned dense graphs (2e8 parameters in MixedFusion), fused Adam; cfg2 = one BDG_Dif layer "
                          '(B = 32, N = 200, C = 8, L = 32, Ho = 32), forward and forward + backward')
+    ap.add_argument('--graph-mode', choices=('csr-fixed', 'dense-learned'), default='csr-fixed',
+                    help="csr-fixed = the metric's mode (caller-supplied sparse Gs); dense-learned = the reference's semantics (MGP_Gen, N <~ 300)")
     ap.add_argument('--permute', action='store_true', help='random node order (seed 1234) instead of row-major')
     ap.add_argument('--no-reorder', action='store_true', help='keep the given node order (skip the internal RCM renumbering)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -89,6 +92,9 @@ def parse(argv=None):
     elif pre.preset == 'sf':
         # launch-bound (~700 launches of ~7 us per step): the step is replayed from ONE captured HIP graph (--eager keeps per-launch dispatch)
         ap.set_defaults(grid=10, categories=5, obs=9, pred=3, batch_per_gpu=32, no_unit_d3=True, hip_graph=True)
+    elif pre.preset == 'sf-learned':
+        ap.set_defaults(grid=10, categories=5, obs=9, pred=3, batch_per_gpu=32, no_unit_d3=True, hip_graph=True, graph_mode='dense-learned',
+                        no_cpu_baseline=True)
     a = ap.parse_args(argv)
     if a.global_batch:
         if a.global_batch % a.gpus:
@@ -304,11 +310,14 @@ def main():
     graph = CsrGraph.queen_grid(a.grid, a.grid, normalize=True, permute_seed=1234 if a.permute else None, device=dev)
     Gc_cpu = torch.softmax(torch.randn(C, C, generator=torch.Generator().manual_seed(7)), -1)
     torch.manual_seed(42)                                                       # same parameters on every rank
-    model = M.STCGNN(N, C, a.order, a.order, 1, a.hidden, a.layers, a.pred, graph_mode='csr-fixed', reorder_nodes=not a.no_reorder,
+    learned = a.graph_mode == 'dense-learned'
+    model = M.STCGNN(N, C, a.order, a.order, 1, a.hidden, a.layers, a.pred, graph_mode=a.graph_mode, reorder_nodes=not a.no_reorder,
                      storage_dtype=torch.bfloat16 if a.storage == 'bf16' else torch.float32)
-    sd_cpu = {k: v.clone() for k, v in model.state_dict().items()}
+    sd_cpu = None if a.no_cpu_baseline else {k: v.clone() for k, v in model.state_dict().items()}
     model = model.to(dev)
     Gc = Gc_cpu.to(dev)
+    # learned graphs: MGP_Gen takes the raw adjacencies (the reference's Main.py hands it the 0/1 grid adjacency and a category matrix)
+    As_in = CsrGraph.queen_grid(a.grid, a.grid, normalize=False).to_dense().to(dev) if learned else graph
     # SURVEY 8(d1) names seeds 0 / 1 for inputs / targets; a sharded batch needs a different draw per rank, so rank r uses
     # 1000 + r for both (rank 0 of a 1-GPU run: seed 1000).  Bernoulli(0.1635) either way.
     g = torch.Generator().manual_seed(1000 + rank)
@@ -317,7 +326,7 @@ def main():
     crit = ComboLoss()
     bucket = sdist.GradBucket(model.parameters())
     graphed = a.hip_graph and world == 1
-    opt = torch.optim.Adam(model.parameters(), lr=2e-3, weight_decay=1e-4, capturable=graphed)
+    opt = torch.optim.Adam(model.parameters(), lr=2e-3, weight_decay=1e-4, capturable=graphed, **({'fused': True} if learned else {}))
     stream = torch.cuda.current_stream(dev)
     marks = []                                                                  # (t_begin, t_backward_done, t_allreduce_done, t_adam_done) events
 
@@ -326,7 +335,7 @@ def main():
         if mark:
             ev[0].record(stream)
         bucket.zero()
-        loss = crit(model(X_seq=X, As=graph, Ac=Gc), Y)
+        loss = crit(model(X_seq=X, As=As_in, Ac=Gc), Y)
         loss.backward()
         if mark:
             ev[1].record(stream)
@@ -490,7 +499,8 @@ def main():
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * elapsed / a.steps,
             'higher_is_better': True, 'scaling': 'strong' if a.global_batch else 'weak', 'vs_baseline': None, 'dtype': a.storage, 'data': 'synthetic',
             'n_ranks_seen': n_ranks_seen, 'hip_graph': bool(graphed),
-            'config': {'workload': f'full STC-GNN train step (fwd + ComboLoss + bwd + grad all-reduce + Adam), csr-fixed, '
+            'config': {'workload': f'full STC-GNN train step (fwd + ComboLoss + bwd + grad all-reduce + Adam), {a.graph_mode}'
+                                   f'{" (MGP_Gen learned dense graphs, " + str(sum(p.numel() for p in model.parameters())) + " parameters)" if learned else ""}, '
                                    f'{a.grid}x{a.grid} queen grid N={N} nnz={graph.nnz}{" permuted" if a.permute else ""}, C={C}, '
                                    f'hidden={a.hidden}, K={a.order}, layers={a.layers}, T={a.obs}+{a.pred}' + (', bf16 state storage' if a.storage == 'bf16' else ''),
                        'global_batch': world * B, 'batch_per_gpu': B, 'parallelism': f'batch-shard x{world}',

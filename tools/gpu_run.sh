@@ -4,7 +4,7 @@
 #   tests:<expr>     pytest -k <expr>
 #   bench            default bench line (driver form, 20 steps) -> gpurun_out/bench_default.json
 #   quick            2-step bench without the CPU baseline, per-kernel table printed
-#   presets          --preset cfg2 (K = 2, 3) / cfg4 / cfg5 / sf lines -> gpurun_out/preset_*.json
+#   presets          --preset cfg2 (K = 2, 3) / cfg4 / cfg5 / sf / sf-learned lines -> gpurun_out/preset_*.json
 #   stats            rocprofv3 --kernel-trace --stats of the bench command -> gpurun_out/kernel_stats.csv
 #   traffic          FETCH_SIZE / WRITE_SIZE PMC passes (tools/gpu_pmc_bench.sh) -> gpurun_out/spmm_traffic_bench.json
 #   mfma             SQ / GRBM PMC passes (tools/gpu_pmc_mfma.sh) -> gpurun_out/mfma_util_f32.json
@@ -28,7 +28,7 @@ for k, v in d['kernels'].items():
 PY
            ;;
     presets) rc=0
-           for p in "cfg2 --order 2" "cfg2 --order 3" "cfg4" "cfg5" "sf"; do
+           for p in "cfg2 --order 2" "cfg2 --order 3" "cfg4" "cfg5" "sf" "sf-learned"; do
              n=$(echo $p | tr -d ' -'); timeout -k 10 600 python bench.py --preset $p --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/preset_$n.json 2> gpurun_out/preset_$n.err || rc=1
              python -c "import json,sys;d=json.loads(open('gpurun_out/preset_$n.json').read().strip().split('\n')[-1]);print('$p',round(d['value'],2),d['unit'],round(d['ms_per_step'],3),'ms')" || rc=1
            done ;;
