@@ -179,8 +179,9 @@ class KernelTimer:
     """Per-launch HIP-event timing for ``bench.py``: events are recorded on the stream the kernel is
     launched on (torch's current stream), immediately around the launch."""
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.spans = []          # (name, start_event, end_event, algorithmic_bytes, tag)
+        self.only = None if only is None else frozenset(only)      # time these entry points only (the others launch without event records)
 
     def add(self, name, start, end, nbytes, tag=None):
         self.spans.append((name, start, end, nbytes, tag))
@@ -250,19 +251,22 @@ class HipKernels:
         tensor does not live on the current device."""
         fn = getattr(self.lib, name)
         index = on.device.index
-        if self.timer is None and index == torch._C._cuda_getDevice():
+        timer = self.timer
+        if timer is not None and timer.only is not None and name not in timer.only:
+            timer = None
+        if timer is None and index == torch._C._cuda_getDevice():
             rc = fn(*args, torch._C._cuda_getCurrentRawStream(index))
         else:
             with torch.cuda.device(on.device):
                 stream = torch.cuda.current_stream(on.device)
-                if self.timer is None:
+                if timer is None:
                     rc = fn(*args, stream.cuda_stream)
                 else:
                     start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     start.record(stream)
                     rc = fn(*args, stream.cuda_stream)
                     end.record(stream)
-                    self.timer.add(name, start, end, nbytes, tag)
+                    timer.add(name, start, end, nbytes, tag)
         if rc != 0:
             msg = self.lib.stc_last_error()
             raise StcError(f'{name} failed with code {rc}: {msg.decode() if msg else "?"}')

@@ -236,9 +236,13 @@ def _graph_gradients(Tc, Ks, stacks, schedule, cin, dims, planes, G, zg, z0, dzc
                 Wp = W.new_zeros(Ks, Kc, LP, Ho)
                 Wp[:, :, :H16] = Wv[:, :, w:]
                 Wp[:, :, H16:H16 + w] = Wv[:, :, :w]
-                dYr = rows(dY)                                                    # (R, C * Ho)
-                Q = torch.stack([rows(s0).t() @ dYr, rows(s1).t() @ dYr]).view(Ks, C, LP, C, Ho)
-                dT += torch.einsum('scldo,sklo->kcd', Q, Wp)
+                # float64 for this one product: R = 10^4 .. 10^5 terms per entry with heavy cancellation, and dT_c feeds MGP_Gen's own
+                # ill-conditioned backward (in fp32 the SF golden's dGc came out at 1.1e-5 instead of 8e-7).  As one batched product per
+                # (cell, sample) summed afterwards: a single 160 x R x 160 DGEMM has four output tiles and no split-K (3 ms each).
+                per = lambda t: t.reshape(k_ * B, N, -1).double()                   # (cells * B, N, C * width)
+                dYp = per(dY)
+                Q = torch.stack([torch.bmm(per(s0).transpose(1, 2), dYp).sum(0), torch.bmm(per(s1).transpose(1, 2), dYp).sum(0)]).view(Ks, C, LP, C, Ho)
+                dT += torch.einsum('scldo,sklo->kcd', Q, Wp.double()).to(dT.dtype)
     return dT, (None if dS is None else dS.reshape(-1))
 
 
