@@ -105,14 +105,19 @@ template <int THREADS, int QUADS, class Base, class Store>
 __device__ __forceinline__ void aggregate_dense(const float* __restrict__ S, int N, int C, const float* src, int stride, Base base, Store store) {
     constexpr int CT = (QUADS + 3) / 4;                          // 16-column tiles per (node, category) row
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, kq = lane >> 4;
-    const int rtiles = (N + 15) >> 4, per_rt = C * CT, tiles = rtiles * per_rt;
+    const int rtiles = (N + 15) >> 4, per_rt = C * CT, pairs = (per_rt + 1) >> 1, items = rtiles * pairs;
     const bool vec = (N & 3) == 0;
-    for (int tile = wave; tile < tiles; tile += THREADS / 64) {
-        const int rt = tile / per_rt, rem = tile - rt * per_rt, c = rem / CT, lb = rem - c * CT;
+    // a wave takes TWO column tiles of one row tile at a time: they share the B operand (the rows of S) and give the matrix pipe two
+    // independent accumulators (one accumulator = a chain of dependent instructions, 40 cycles each instead of 32)
+    for (int item = wave; item < items; item += THREADS / 64) {
+        const int rt = item / pairs, t0 = 2 * (item - rt * pairs), t1 = min(t0 + 1, per_rt - 1);
+        const bool two = t0 + 1 < per_rt;
+        const int c0 = t0 / CT, lb0 = t0 - c0 * CT, c1 = t1 / CT, lb1 = t1 - c1 * CT;
         const int node = 16 * rt + j;
         const bool node_ok = node < N;
         const unsigned srow = (unsigned)(node_ok ? node : 0) * N;
-        const int col = min(16 * lb + j, 4 * QUADS - 1);         // the source column this lane feeds as A operand (clamped: extra columns are not stored)
+        // the source column this lane feeds as A operand (clamped: extra columns are not stored)
+        const unsigned a0 = (unsigned)c0 * stride + min(16 * lb0 + j, 4 * QUADS - 1), a1 = (unsigned)c1 * stride + min(16 * lb1 + j, 4 * QUADS - 1);
         auto load_s = [&](int kb) {                              // S[node][16 kb + 4 kq .. + 3], unmasked (clamped); the mask is applied when it is consumed
             const int k0 = 16 * kb + 4 * kq;
             if (vec) return ld4(S + (k0 < N ? srow + k0 : srow));
@@ -121,7 +126,7 @@ __device__ __forceinline__ void aggregate_dense(const float* __restrict__ S, int
             for (int i = 0; i < 4; ++i) v[i] = S[srow + min(k0 + i, N - 1)];
             return v;
         };
-        f32x4 acc = zero4(), bn = load_s(0);
+        f32x4 acc0 = zero4(), acc1 = zero4(), bn = load_s(0);
         for (int kb = 0; kb < rtiles; ++kb) {
             f32x4 b = bn;
             if (kb + 1 < rtiles) bn = load_s(kb + 1);
@@ -129,17 +134,27 @@ __device__ __forceinline__ void aggregate_dense(const float* __restrict__ S, int
             for (int i = 0; i < 4; ++i) {
                 const int m = 16 * kb + 4 * kq + i;
                 const float bv = node_ok && m < N ? b[i] : 0.f;
-                const float av = src[(unsigned)(min(m, N - 1) * C + c) * stride + col];
-                acc = mfma4(av, bv, acc);
+                const unsigned mrow = (unsigned)(min(m, N - 1) * C) * stride;
+                acc0 = mfma4(src[mrow + a0], bv, acc0);
+                acc1 = mfma4(src[mrow + a1], bv, acc1);
             }
         }
-        const int q = 4 * lb + kq;
-        if (node_ok && q < QUADS) {
-            const int row = node * C + c;
-            f32x4 s = base(row, q);
+        if (node_ok) {
+            const int q0 = 4 * lb0 + kq, q1 = 4 * lb1 + kq;
+            if (q0 < QUADS) {
+                const int row = node * C + c0;
+                f32x4 s = base(row, q0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) s[i] += acc[i];
-            store(row, q, s);
+                for (int i = 0; i < 4; ++i) s[i] += acc0[i];
+                store(row, q0, s);
+            }
+            if (two && q1 < QUADS) {
+                const int row = node * C + c1;
+                f32x4 s = base(row, q1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s[i] += acc1[i];
+                store(row, q1, s);
+            }
         }
     }
 }
