@@ -784,7 +784,12 @@ class HipKernels:
                      tag='wide' if cin == h else 'layer0')
 
     # ---- small graphs: one STC_Cell step per launch --------------------------------------------------------
-    SMALL_MAX_ROWS = 4096        # N*C rows per sample the one-workgroup-per-sample kernels are meant for (planes stay in L2)
+    SMALL_MAX_ROWS = 65535       # N*C rows per sample the kernels take at all (16-bit row arithmetic)
+    #: N*C rows per sample up to which the executor PREFERS these kernels: about what a compute unit's LDS stages (N = 100, C = 5: 500).
+    #: One workgroup per sample means `batch` of the 256 compute units work; measured as HIP-graph replays at batch 32: 2.96 vs 4.96 ms
+    #: per step at 500 rows, but 10.8 vs 7.6 ms at 1 568 rows (N = 196, C = 8) and 21.9 vs 11.5 ms at 3 200 -- the general path's ~700
+    #: launches fill the chip there.
+    SMALL_PREFERRED_ROWS = 704
 
     def cell_small_supported(self, Ks, Kc, Cc, cin, h, n_nodes=0) -> bool:
         return n_nodes * Cc <= self.SMALL_MAX_ROWS and bool(self.lib.stc_cell_small_supported(Ks, Kc, Cc, cin, h))

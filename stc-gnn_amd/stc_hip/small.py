@@ -37,6 +37,8 @@ def small_graph_supported(k, op: SpatialOperand, Tc, Ks: int, C: int, h: int, x_
     ``graph.dense_operand`` builds it) -- its gradient is formed as a dense product."""
     if dtype != torch.float32 or not hasattr(k, 'cell_small_supported') or (op.fwd_val.requires_grad and op.nnz != op.n * op.n):
         return False
+    if op.n * C > k.SMALL_PREFERRED_ROWS:                           # larger samples: the general path's many launches fill the chip better
+        return False
     return all(k.cell_small_supported(Ks, Tc.shape[0], C, w, h, op.n) for w in set(x_widths))
 
 
