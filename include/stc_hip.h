@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define STC_ABI_VERSION 19
+#define STC_ABI_VERSION 20
 #define STC_MAX_K 4          /* highest Chebyshev order (Ks, Kc) the node kernels accept */
 
 /* Operand formats of the split-operand matrix-core kernels (C = 32 / 64, hidden 16).  Every fp32 operand is split into low-precision
@@ -456,7 +456,12 @@ int stc_head_bwd_f32(const float* H, const float* w, const float* y, const float
  * candidate's / gates' aggregated slab; dYg (optional, (batch, N*C, 32)): the gate pre-activation gradients -- and the host forms
  * dGs^T = sum dZ1 x Z0 and dT_c = sum V_c x dY with a few stacked products per backward pass (stc_hip/small.py).  NULL = not wanted.
  * graph_is_dense != 0: the caller vouches that the CSR is the FULL n x n pattern with columns in order (nnz = n*n), i.e. val is a dense
- * row-major matrix (graph.full_pattern): the aggregations then run as matrix products on the staged planes instead of row gathers. */
+ * row-major matrix (graph.full_pattern): the aggregations then run as matrix products on the staged planes instead of row gathers.
+ * phase / splits (ABI v20): phase = 0, splits = 1: the whole cell step in this launch, one workgroup per sample (`batch` of the chip's 256
+ * compute units work).  phase = 1..4, splits = G: ONLY that phase (forward: aggregate, gates, aggregate R*H, candidate; backward:
+ * candidate convolution, transpose-aggregate + gate backward, gates convolution, transpose-aggregate), the sample's rows dealt over G
+ * workgroups -- the caller launches the four phases in order, the launch boundaries being the barriers; same buffers, same results.
+ * dparams then has R * G rows per sample (row (b * G + g) * R + r). */
 int stc_cell_small_supported(int32_t Ks, int32_t Kc, int32_t C, int32_t cin, int32_t h);
 size_t stc_cell_small_workspace_bytes(int32_t n_nodes, int32_t C, int32_t cin, int32_t batch);
 int stc_cell_small_param_rows(void);
@@ -464,7 +469,7 @@ int stc_cell_small_fwd_f32(const int32_t* rowptr, const int32_t* colidx, const f
                            int32_t graph_is_dense, const float* X, int32_t cin, const float* H, const float* Tc, int32_t Kc,
                            const float* Wg, const float* bg, const float* Wc, const float* bc,
                            float* U, float* R, float* Cand, float* Hnew, float* RH, float* Zg, float* Zc, float* Z0,
-                           int32_t batch, int32_t C, void* stream);
+                           int32_t phase, int32_t splits, int32_t batch, int32_t C, void* stream);
 int stc_cell_small_bwd_f32(const int32_t* rowptr, const int32_t* colidx, const float* val, int32_t n_nodes, int32_t nnz,
                            int32_t graph_is_dense, const float* X, int32_t cin, const float* H, const float* Tc, int32_t Kc,
                            const float* Wg, const float* Wc, const float* U, const float* R, const float* Cand,
@@ -472,7 +477,7 @@ int stc_cell_small_bwd_f32(const int32_t* rowptr, const int32_t* colidx, const f
                            float* dX, int32_t accumulate_x, float* dH, int32_t accumulate_h,
                            float* dparams, int64_t params_ld, int32_t has_bg, int32_t has_bc,
                            float* dZ1c, float* dZ1g, float* dYg,
-                           void* workspace, size_t workspace_bytes, int32_t batch, int32_t C, void* stream);
+                           void* workspace, size_t workspace_bytes, int32_t phase, int32_t splits, int32_t batch, int32_t C, void* stream);
 
 /* ---- small helpers ---------------------------------------------------------
  * y += a*x over n elements (Chebyshev backward g_{k-2} -= g_k) */

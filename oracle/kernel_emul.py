@@ -215,7 +215,8 @@ class EmulatedKernels:
 
     # ---- stc_cell_small_fwd/bwd_f32: one STC_Cell step of a small graph per launch (STC_GNN.py:65-79 and its autograd)
     SMALL_MAX_ROWS = 65535
-    SMALL_PREFERRED_ROWS = 704
+    SMALL_PREFERRED_ROWS = 65535
+    SMALL_STAGED_ROWS = 640      # N*C rows per sample that a compute unit's LDS stages (above: every gather from L2, and the forward split too)
 
     def cell_small_supported(self, Ks, Kc, Cc, cin, h, n_nodes=0) -> bool:
         return Ks == 2 and Kc == 2 and 1 <= Cc <= 16 and h == 16 and (cin == 16 or 1 <= cin <= 4) and n_nodes * Cc <= self.SMALL_MAX_ROWS
@@ -228,7 +229,14 @@ class EmulatedKernels:
     def cell_small_params(Ks, Kc, cin, h=16) -> int:
         return Ks * Kc * (cin + h) * 3 * h + 3 * h
 
-    cell_small_param_rows = 4          # rows of the parameter-gradient partials per sample (the twin adds to the first)
+    cell_small_param_rows = 4          # rows of the parameter-gradient partials per sample and split (the twin adds to the first)
+
+    @staticmethod
+    def cell_small_splits(batch: int, rows: int = 0) -> int:
+        g = max(1, min(8, 256 // max(1, batch)))
+        while g > 1 and rows and rows < 48 * g:
+            g //= 2
+        return g
 
     def _small_agg(self, rowptr, colidx, val, T):
         """S.T over the node axis of T (B, N, C, w)."""
@@ -237,7 +245,7 @@ class EmulatedKernels:
         self.csr_spmm(rowptr, colidx, val, N, N, T.reshape(B, N, Cc * w), None, out, 1.0, 0.0)
         return out.view(B, N, Cc, w)
 
-    def cell_small_fwd(self, rowptr, colidx, val, X, H, Tc, Wg, bg, Wc, bc, U, R, Cand, Hnew, RH, Zg, Zc, checked=True, Z0=None):
+    def cell_small_fwd(self, rowptr, colidx, val, X, H, Tc, Wg, bg, Wc, bc, U, R, Cand, Hnew, RH, Zg, Zc, checked=True, Z0=None, splits=1):
         B, N, Cc, h = H.shape
         cin = X.shape[-1]
         rows = lambda t: t.reshape(B * N, Cc, t.shape[-1])
@@ -266,7 +274,7 @@ class EmulatedKernels:
         Hnew.copy_((1.0 - U) * H + U * Cand)
 
     def cell_small_bwd(self, rowptr, colidx, val, X, H, Tc, Wg, Wc, U, R, Cand, RH, Zg, Zc, dHnew, dX, accumulate_x, dH, accumulate_h,
-                       dparams, has_bg, has_bc, checked=True, dZ1c=None, dZ1g=None, dYg=None):
+                       dparams, has_bg, has_bc, checked=True, dZ1c=None, dZ1g=None, dYg=None, splits=1):
         B, N, Cc, h = H.shape
         cin = X.shape[-1]
         L = cin + h
@@ -274,7 +282,7 @@ class EmulatedKernels:
         Zgv = Zg.view(B, N, Cc, Zg.shape[-1])
         SX, SH, SRH = Zgv[..., h:h + cin], Zgv[..., :h], Zc.view(B, N, Cc, h)
         nW = 2 * Kc * L
-        first = dparams[::self.cell_small_param_rows]                # (a view: row 0 of every sample's group)
+        first = dparams[::self.cell_small_param_rows * splits]       # (a view: row 0 of every sample's group)
         assert first.shape[0] == B
         dWg, dbg = first[:, :nW * 2 * h], first[:, nW * 2 * h:nW * 2 * h + 2 * h]
         dWc, dbc = first[:, nW * 2 * h + 2 * h:nW * 3 * h + 2 * h], first[:, nW * 3 * h + 2 * h:nW * 3 * h + 3 * h]

@@ -81,8 +81,8 @@ constexpr int SQ = 20;                                                          
 // out[row][quad] = base + sum_e val[e] * fetch(colidx[e] * C + c, quad)  for the rows of one sample; fetch returns 4 columns of a source row.
 template <int THREADS, int QUADS, class Fetch, class Base, class Store>
 __device__ __forceinline__ void aggregate_rows(const int* __restrict__ gp, const int* __restrict__ gc, const float* __restrict__ gv, int NC, int C,
-                                               int invC, Fetch fetch, Base base, Store store) {
-    for (int item = threadIdx.x; item < NC * QUADS; item += THREADS) {
+                                               int invC, int split, int splits, Fetch fetch, Base base, Store store) {
+    for (int item = threadIdx.x + THREADS * split; item < NC * QUADS; item += THREADS * splits) {
         const int row = item / QUADS, q = item - row * QUADS;
         const int n = div_c(row, invC), c = row - n * C;
         f32x4 s = base(row, q);
@@ -292,7 +292,8 @@ struct SmallFwd {
     float *U, *R, *Cand, *Hnew, *RH, *Zg, *Zc;
     float* Z0;                                   // optional: the slab [H | X | 0] itself, for the graph-gradient products of learned graphs
     int N, C, cin, rpt, tiles;
-};
+    int phase;                                   // 0: the whole cell in this launch (one workgroup per sample); 1..4: that phase only, the sample's
+};                                               // rows split over gridDim.y workgroups -- the launch boundary is the barrier between phases
 
 template <int KC>
 __host__ __device__ constexpr int fwd_lds_fixed() { return 0; }                                         // floats of LDS every launch needs
@@ -322,10 +323,16 @@ __global__ __launch_bounds__(SF_THREADS) void small_fwd_kernel(SmallFwd a) {
     float* Zgb = a.Zg + r0 * LP;
     float* Zcb = a.Zc + r0 * SC_H;
 
+    // Split form (phase != 0): this launch runs ONE phase, with the sample's tiles / rows dealt over gridDim.y workgroups, so that a step of
+    // few samples still fills the chip; the caller launches the phases in order (the launch boundary replaces the workgroup barrier).
+    const int phase = a.phase, split = blockIdx.y, splits = gridDim.y;
+    auto runs = [&](int p) { return phase == 0 || phase == p; };
+    auto sync = [&] { if (phase == 0) __syncthreads(); };
+
     // 0: tables, graph and the sample's rows into LDS (the gates' W operands are requested first: in flight during phases 0 and 1)
     const int ct = wave & 1;                                 // gates: wave w owns column tile w % 2 (0: update, 1: reset)
     float Wg_r[SC_KS][KC][4 + XS];
-    load_w_fwd<KC, XQ>(Wg_r, a.Wg, 2 * SC_H, 16 * ct + j, cin, kq);
+    if (runs(2)) load_w_fwd<KC, XQ>(Wg_r, a.Wg, 2 * SC_H, 16 * ct + j, cin, kq);
     float M[KC][4];
     build_mix<KC>(M, a.Tc, false, a.rpt, C, invC, j, kq);
     if (STAGED) {
@@ -345,11 +352,11 @@ __global__ __launch_bounds__(SF_THREADS) void small_fwd_kernel(SmallFwd a) {
                 st4(P + (unsigned)row * SP + 16 + 4 * q, x);
             }
     }
-    __syncthreads();
+    sync();
 
-    if (a.Z0 != nullptr) {                                   // (learned graphs only)
+    if (a.Z0 != nullptr && runs(1)) {                        // (learned graphs only)
         float* Z0b = a.Z0 + r0 * LP;
-        for (int item = t; item < NC * (LP / 4); item += SF_THREADS) {
+        for (int item = t + SF_THREADS * split; item < NC * (LP / 4); item += SF_THREADS * splits) {
             const int row = item / (LP / 4), q = item - row * (LP / 4);
             f32x4 x;
             if (STAGED) {
@@ -369,13 +376,13 @@ __global__ __launch_bounds__(SF_THREADS) void small_fwd_kernel(SmallFwd a) {
     }
 
     // 1: Zg = S.[H | X]
-    {
+    if (runs(1)) {
         auto none = [](int, int) -> f32x4 { return zero4(); };
         auto put = [&](int row, int q, f32x4 s) { st4(Zgb + (unsigned)row * LP + 4 * q, s); };
         if (DENSE)
             aggregate_dense<SF_THREADS, LP / 4>(a.g.val, N, C, P, SP, none, put);
         else
-            aggregate_rows<SF_THREADS, LP / 4>(gp, gc, gv, NC, C, invC,
+            aggregate_rows<SF_THREADS, LP / 4>(gp, gc, gv, NC, C, invC, split, splits,
                 [&](int src, int q) -> f32x4 {
                     if (STAGED) return ld4(P + (unsigned)src * SP + 4 * q);
                     if (q < 4) return ld4(Hb + (unsigned)src * SC_H + 4 * q);
@@ -388,13 +395,13 @@ __global__ __launch_bounds__(SF_THREADS) void small_fwd_kernel(SmallFwd a) {
                 },
                 none, put);
     }
-    __syncthreads();
+    sync();
     SC_PHASE_END(1);
 
     // 2: gates -- wave w: column tile w % 2 of the row tiles w / 2, w / 2 + 8, ..
-    {
+    if (runs(2)) {
         const float bias = a.bg ? a.bg[16 * ct + j] : 0.f;
-        fwd_conv<KC, XQ>(Wg_r, M, wave >> 1, SF_WAVES / 2, a.tiles, a.rpt, NC, j, kq,
+        fwd_conv<KC, XQ>(Wg_r, M, (wave >> 1) + (SF_WAVES / 2) * split, (SF_WAVES / 2) * splits, a.tiles, a.rpt, NC, j, kq,
             [&](int row) { return STAGED ? load_op<XQ>(P, SP, P + 16, SP, true, cin, row, kq) : load_op<XQ>(Hb, SC_H, Xb, cin, false, cin, row, kq); },
             [&](int row) { return load_op<XQ>(Zgb, LP, Zgb + 16, LP, true, cin, row, kq); },
             [&](int grow, float y) {
@@ -410,30 +417,30 @@ __global__ __launch_bounds__(SF_THREADS) void small_fwd_kernel(SmallFwd a) {
                 }
             });
     }
-    __syncthreads();
+    sync();
     SC_PHASE_END(2);
 
     // 3: Zc = S.(R*H)   (the candidate's W operands in flight meanwhile)
     float Wc_r[SC_KS][KC][4 + XS];
-    load_w_fwd<KC, XQ>(Wc_r, a.Wc, SC_H, j, cin, kq);
-    {
+    if (runs(4)) load_w_fwd<KC, XQ>(Wc_r, a.Wc, SC_H, j, cin, kq);
+    if (runs(3)) {
         auto none = [](int, int) -> f32x4 { return zero4(); };
         auto put = [&](int row, int q, f32x4 s) { st4(Zcb + (unsigned)row * SC_H + 4 * q, s); };
         if (DENSE)
             aggregate_dense<SF_THREADS, 4>(a.g.val, N, C, Q, SQ, none, put);
         else
-            aggregate_rows<SF_THREADS, 4>(gp, gc, gv, NC, C, invC,
+            aggregate_rows<SF_THREADS, 4>(gp, gc, gv, NC, C, invC, split, splits,
                 [&](int src, int q) -> f32x4 { return STAGED ? ld4(Q + (unsigned)src * SQ + 4 * q) : ld4(RHb + (unsigned)src * SC_H + 4 * q); }, none, put);
     }
-    __syncthreads();
+    sync();
     SC_PHASE_END(3);
 
     // 4: candidate + blend
-    {
+    if (runs(4)) {
         const float bias = a.bc ? a.bc[j] : 0.f;
         float* Cb = a.Cand + r0 * SC_H;
         float* Hn = a.Hnew + r0 * SC_H;
-        fwd_conv<KC, XQ>(Wc_r, M, wave, SF_WAVES, a.tiles, a.rpt, NC, j, kq,
+        fwd_conv<KC, XQ>(Wc_r, M, wave + SF_WAVES * split, SF_WAVES * splits, a.tiles, a.rpt, NC, j, kq,
             [&](int row) { return STAGED ? load_op<XQ>(Q, SQ, P + 16, SP, true, cin, row, kq) : load_op<XQ>(RHb, SC_H, Xb, cin, false, cin, row, kq); },
             [&](int row) { return load_op<XQ>(Zcb, SC_H, Zgb + 16, LP, true, cin, row, kq); },
             [&](int grow, float y) {
@@ -486,9 +493,10 @@ struct Slab {                                    // one slab of a convolution's 
 template <int KC, int XQ, int OT, class Raw, class LoadDy, class FormDy>
 __device__ __forceinline__ void conv_bwd_phase(const Slab& z, const float* __restrict__ W, int ks, int role, const float (&M)[KC][4],
                                                float* __restrict__ dv, float* dZ, float* __restrict__ dump, float* __restrict__ dW, float* __restrict__ db,
-                                               int rpt, int tiles, int NC, int cin, LoadDy load_dy, FormDy form_dy) {
-    constexpr int LP = 16 + 4 * XQ, HO = 16 * OT, DS = HO + 1, SPK = HO / 4, QUADS = SB_WAVES / 4;
-    const int t = threadIdx.x, lane = t & 63, quad = t >> 8, j = lane & 15, kq = lane >> 4, L = cin + SC_H;
+                                               int rpt, int tiles, int tile0, int tstep, int NC, int cin, LoadDy load_dy, FormDy form_dy) {
+    constexpr int LP = 16 + 4 * XQ, HO = 16 * OT, DS = HO + 1, SPK = HO / 4;
+    const int t = threadIdx.x, lane = t & 63, j = lane & 15, kq = lane >> 4, L = cin + SC_H;
+    const int quad = tile0, QUADS = tstep;                       // the wave's first tile and its stride (one launch per cell: t / 256 and 4)
     // Rows 4 kq + s of a tile as a lane addresses them: clamped into the sample (rows of a tile beyond its nodes or beyond the sample, and
     // whole tiles requested past the end, read the last row: finite values that meet a zero mask) -- one v_min per row and tile instead of a
     // compare / select pair per LOAD: the vector unit, not the matrix pipe, paces these loops (a matrix instruction holds the issue port).
@@ -665,6 +673,7 @@ struct SmallBwd {
     float *dX, *dH, *dP, *ws;
     float *dZ1c, *dZ1g, *dYg;                    // optional dumps for learned graphs: gradients of the two aggregated slabs, gate pre-activation gradients
     int N, C, cin, rpt, tiles, acc_x, acc_h, has_bg, has_bc;
+    int phase;                                   // as in SmallFwd
     long long P;                                 // floats per row of dP: [dWg | dbg (32) | dWc | dbc (16)]; SB_WAVES / 4 rows per sample
 };
 
@@ -710,7 +719,11 @@ __global__ __launch_bounds__(SB_THREADS) void small_bwd_kernel(SmallBwd a) {
     float* dZ1 = STAGED ? D1 : wsb + (size_t)NC * LP;
     float* dYg = a.dYg ? a.dYg + r0 * 32 : wsb + (size_t)NC * 2 * LP;
     const int ks = wave & 1, role = (wave >> 1) & 1;
-    float* dPw = a.dP + ((size_t)blockIdx.x * (SB_WAVES / 4) + (wave >> 2)) * a.P;
+    const int phase = a.phase, split = blockIdx.y, splits = gridDim.y;
+    auto runs = [&](int p) { return phase == 0 || phase == p; };
+    auto sync = [&] { if (phase == 0) __syncthreads(); };
+    const int tile0 = (wave >> 2) + (SB_WAVES / 4) * split, tstep = (SB_WAVES / 4) * splits;
+    float* dPw = a.dP + (((size_t)blockIdx.x * splits + split) * (SB_WAVES / 4) + (wave >> 2)) * a.P;
     float* dWg = dPw;
     float* dbg = dPw + (size_t)SC_KS * KC * L * 32;
     float* dWc = dbg + 32;
@@ -719,22 +732,22 @@ __global__ __launch_bounds__(SB_THREADS) void small_bwd_kernel(SmallBwd a) {
     float M[KC][4];
     build_mix<KC>(M, a.Tc, true, a.rpt, C, invC, lane & 15, lane >> 4);
     if (STAGED && !DENSE) stage_graph<SB_THREADS>(a.g, N, gpl, gcl, gvl);
-    __syncthreads();
+    sync();
 
     // 1: candidate convolution
-    conv_bwd_phase<KC, XQ, 1, Raw3>(ks == 0 ? Slab{RHb, SC_H, Xb, cin} : Slab{Zcb, SC_H, Zgb + SC_H, LP}, a.Wc, ks, role, M, dv, ks == 0 ? dZ0 : dZ1,
+    if (runs(1)) conv_bwd_phase<KC, XQ, 1, Raw3>(ks == 0 ? Slab{RHb, SC_H, Xb, cin} : Slab{Zcb, SC_H, Zgb + SC_H, LP}, a.Wc, ks, role, M, dv, ks == 0 ? dZ0 : dZ1,
         ks == 1 && a.dZ1c ? a.dZ1c + r0 * LP : nullptr, dWc,
-        a.has_bc ? dbc : nullptr, a.rpt, min(a.tiles, SC_MAX_TILES), NC, cin,
+        a.has_bc ? dbc : nullptr, a.rpt, min(a.tiles, SC_MAX_TILES), tile0, tstep, NC, cin,
         [&](int grow, int col) {
             const size_t e = (unsigned)grow * SC_H + col;
             return Raw3{dHn[e], Ub[e], Cb[e]};
         },
         [](const Raw3& w, int) { return w.d * w.u * (1.f - w.c * w.c); });
-    __syncthreads();                             // the dZ slabs are complete
+    sync();                                      // the dZ slabs are complete
     SC_PHASE_END(1);
 
     // 2: d[R*H | X] = dZ_0 + S^T dZ_1, gate backward
-    {
+    if (runs(2)) {
         auto from_dz1 = [&](int src, int q) -> f32x4 { return ld4(dZ1 + (unsigned)src * LP + 4 * q); };
         auto from_dz0 = [&](int row, int q) -> f32x4 { return ld4(dZ0 + (unsigned)row * LP + 4 * q); };
         auto gate_bwd =
@@ -773,22 +786,22 @@ __global__ __launch_bounds__(SB_THREADS) void small_bwd_kernel(SmallBwd a) {
         if (DENSE)
             aggregate_dense<SB_THREADS, LP / 4>(a.g.val, N, C, dZ1, LP, from_dz0, gate_bwd);
         else
-            aggregate_rows<SB_THREADS, LP / 4>(gp, gc, gv, NC, C, invC, from_dz1, from_dz0, gate_bwd);
+            aggregate_rows<SB_THREADS, LP / 4>(gp, gc, gv, NC, C, invC, split, splits, from_dz1, from_dz0, gate_bwd);
     }
-    __syncthreads();
+    sync();
     SC_PHASE_END(2);
 
     // 3: gates convolution
-    conv_bwd_phase<KC, XQ, 2, Raw2>(ks == 0 ? Slab{Hb, SC_H, Xb, cin} : Slab{Zgb, LP, Zgb + SC_H, LP}, a.Wg, ks, role, M, dv, ks == 0 ? dZ0 : dZ1,
+    if (runs(3)) conv_bwd_phase<KC, XQ, 2, Raw2>(ks == 0 ? Slab{Hb, SC_H, Xb, cin} : Slab{Zgb, LP, Zgb + SC_H, LP}, a.Wg, ks, role, M, dv, ks == 0 ? dZ0 : dZ1,
         ks == 1 && a.dZ1g ? a.dZ1g + r0 * LP : nullptr, dWg,
-        a.has_bg ? dbg : nullptr, a.rpt, min(a.tiles, SC_MAX_TILES), NC, cin,
+        a.has_bg ? dbg : nullptr, a.rpt, min(a.tiles, SC_MAX_TILES), tile0, tstep, NC, cin,
         [&](int grow, int col) { return Raw2{dYg[(unsigned)grow * 32 + col], dYg[(unsigned)grow * 32 + 16 + col]}; },
         [](const Raw2& w, int ot) { return ot == 0 ? w.a : w.b; });
-    __syncthreads();
+    sync();
     SC_PHASE_END(3);
 
     // 4: d[H | X] += dZ_0 + S^T dZ_1
-    if (dHb || dXb) {
+    if ((dHb || dXb) && runs(4)) {
         auto from_dz1 = [&](int src, int q) -> f32x4 { return ld4(dZ1 + (unsigned)src * LP + 4 * q); };
         auto from_dz0 = [&](int row, int q) -> f32x4 { return ld4(dZ0 + (unsigned)row * LP + 4 * q); };
         auto add_in =
@@ -812,7 +825,7 @@ __global__ __launch_bounds__(SB_THREADS) void small_bwd_kernel(SmallBwd a) {
         if (DENSE)
             aggregate_dense<SB_THREADS, LP / 4>(a.g.val, N, C, dZ1, LP, from_dz0, add_in);
         else
-            aggregate_rows<SB_THREADS, LP / 4>(gp, gc, gv, NC, C, invC, from_dz1, from_dz0, add_in);
+            aggregate_rows<SB_THREADS, LP / 4>(gp, gc, gv, NC, C, invC, split, splits, from_dz1, from_dz0, add_in);
     }
 }
 
@@ -856,7 +869,7 @@ extern "C" int stc_cell_small_fwd_f32(const int32_t* rowptr, const int32_t* coli
                                       int32_t graph_is_dense, const float* X,
                                       int32_t cin, const float* H, const float* Tc, int32_t Kc, const float* Wg, const float* bg, const float* Wc,
                                       const float* bc, float* U, float* R, float* Cand, float* Hnew, float* RH, float* Zg, float* Zc, float* Z0,
-                                      int32_t batch, int32_t C, void* stream) {
+                                      int32_t phase, int32_t splits, int32_t batch, int32_t C, void* stream) {
     SC_COMMON_CHECKS("stc_cell_small_fwd_f32")
     STC_REQUIRE(rowptr && (nnz == 0 || (colidx && val)) && X && H && Tc && Wg && Wc && U && R && Cand && Hnew && RH && Zg && Zc, STC_EINVAL,
                 "stc_cell_small_fwd_f32: null operand");
@@ -865,18 +878,22 @@ extern "C" int stc_cell_small_fwd_f32(const int32_t* rowptr, const int32_t* coli
     STC_REQUIRE(stc::aligned16(H) && stc::aligned16(U) && stc::aligned16(R) && stc::aligned16(RH) && stc::aligned16(Zg) && stc::aligned16(Zc) &&
                     (xq != 4 || stc::aligned16(X)) && stc::aligned16(Z0), STC_EINVAL, "stc_cell_small_fwd_f32: planes must be 16-byte aligned");
     const int npt = 16 / C, rpt = npt * C;
-    SmallFwd a{{rowptr, colidx, val, nnz}, X, H, Tc, Wg, bg, Wc, bc, U, R, Cand, Hnew, RH, Zg, Zc, Z0, n_nodes, C, cin, rpt, (n_nodes + npt - 1) / npt};
+    STC_REQUIRE(phase >= 0 && phase <= 4 && splits >= 1 && splits <= 64 && (phase != 0 || splits == 1), STC_EINVAL,
+                "stc_cell_small_fwd_f32: phase %d / splits %d (phase 0 = the whole cell, one workgroup per sample; 1..4 = one phase over `splits` workgroups)",
+                phase, splits);
+    SmallFwd a{{rowptr, colidx, val, nnz}, X, H, Tc, Wg, bg, Wc, bc, U, R, Cand, Hnew, RH, Zg, Zc, Z0, n_nodes, C, cin, rpt, (n_nodes + npt - 1) / npt,
+               phase};
     const size_t fixed = (size_t)fwd_lds_fixed<2>() * 4, planes = (size_t)n_nodes * C * (plane_stride(xq) + SQ) * 4;
-    const bool dense = graph_is_dense && nnz == (long long)n_nodes * n_nodes && fixed + planes <= SC_LDS_BUDGET;
+    const bool dense = phase == 0 && graph_is_dense && nnz == (long long)n_nodes * n_nodes && fixed + planes <= SC_LDS_BUDGET;
     const size_t staged = fixed + planes + (dense ? 0 : graph_lds_bytes(n_nodes, nnz));
-    const int mode = dense ? 2 : (staged <= SC_LDS_BUDGET ? 1 : 0);
+    const int mode = dense ? 2 : (phase == 0 && staged <= SC_LDS_BUDGET ? 1 : 0);
     const size_t lds = mode ? staged : fixed;
     auto kern = mode == 2 ? (xq == 4 ? small_fwd_kernel<2, 4, 2> : small_fwd_kernel<2, 1, 2>)
               : mode == 1 ? (xq == 4 ? small_fwd_kernel<2, 4, 1> : small_fwd_kernel<2, 1, 1>)
                           : (xq == 4 ? small_fwd_kernel<2, 4, 0> : small_fwd_kernel<2, 1, 0>);
     const hipError_t e = allow_lds_once(kern, lds, g_granted[0][xq == 4][mode]);
     if (e != hipSuccess) return stc::hip_status(e, "stc_cell_small_fwd_f32 LDS attribute");
-    hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(SF_THREADS), lds, static_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)batch, (unsigned)splits), dim3(SF_THREADS), lds, static_cast<hipStream_t>(stream), a);
     STC_LAUNCH_CHECK("stc_cell_small_fwd_f32 launch");
     return STC_OK;
 }
@@ -887,7 +904,7 @@ extern "C" int stc_cell_small_bwd_f32(const int32_t* rowptr, const int32_t* coli
                                       const float* R, const float* Cand, const float* RH, const float* Zg, const float* Zc, const float* dHnew,
                                       float* dX, int32_t accumulate_x, float* dH, int32_t accumulate_h, float* dparams, int64_t params_ld,
                                       int32_t has_bg, int32_t has_bc, float* dZ1c, float* dZ1g, float* dYg, void* workspace, size_t workspace_bytes,
-                                      int32_t batch, int32_t C, void* stream) {
+                                      int32_t phase, int32_t splits, int32_t batch, int32_t C, void* stream) {
     SC_COMMON_CHECKS("stc_cell_small_bwd_f32")
     STC_REQUIRE(rowptr && (nnz == 0 || (colidx && val)) && X && H && Tc && Wg && Wc && U && R && Cand && RH && Zg && Zc && dHnew && dparams && workspace,
                 STC_EINVAL, "stc_cell_small_bwd_f32: null operand");
@@ -903,18 +920,20 @@ extern "C" int stc_cell_small_bwd_f32(const int32_t* rowptr, const int32_t* coli
                 "stc_cell_small_bwd_f32: dHnew, dX and dH must be distinct buffers");
     const int npt = 16 / C, rpt = npt * C;
     SmallBwd a{{rowptr, colidx, val, nnz}, X, H, Tc, Wg, Wc, U, R, Cand, RH, Zg, Zc, dHnew, dX, dH, dparams, static_cast<float*>(workspace),
-               dZ1c, dZ1g, dYg, n_nodes, C, cin, rpt, (n_nodes + npt - 1) / npt, accumulate_x, accumulate_h, has_bg, has_bc, params_ld};
+               dZ1c, dZ1g, dYg, n_nodes, C, cin, rpt, (n_nodes + npt - 1) / npt, accumulate_x, accumulate_h, has_bg, has_bc, phase, params_ld};
+    STC_REQUIRE(phase >= 0 && phase <= 4 && splits >= 1 && splits <= 64 && (phase != 0 || splits == 1), STC_EINVAL,
+                "stc_cell_small_bwd_f32: phase %d / splits %d", phase, splits);
     const size_t fixed = (size_t)bwd_lds_fixed<2>() * 4, planes = (size_t)n_nodes * C * LP * 4;
-    const bool dense = graph_is_dense && nnz == (long long)n_nodes * n_nodes && fixed + planes <= SC_LDS_BUDGET;
+    const bool dense = phase == 0 && graph_is_dense && nnz == (long long)n_nodes * n_nodes && fixed + planes <= SC_LDS_BUDGET;
     const size_t staged = fixed + planes + (dense ? 0 : graph_lds_bytes(n_nodes, nnz));
-    const int mode = dense ? 2 : (staged <= SC_LDS_BUDGET ? 1 : 0);
+    const int mode = dense ? 2 : (phase == 0 && staged <= SC_LDS_BUDGET ? 1 : 0);
     const size_t lds = mode ? staged : fixed;
     auto kern = mode == 2 ? (xq == 4 ? small_bwd_kernel<2, 4, 2> : small_bwd_kernel<2, 1, 2>)
               : mode == 1 ? (xq == 4 ? small_bwd_kernel<2, 4, 1> : small_bwd_kernel<2, 1, 1>)
                           : (xq == 4 ? small_bwd_kernel<2, 4, 0> : small_bwd_kernel<2, 1, 0>);
     const hipError_t e = allow_lds_once(kern, lds, g_granted[1][xq == 4][mode]);
     if (e != hipSuccess) return stc::hip_status(e, "stc_cell_small_bwd_f32 LDS attribute");
-    hipLaunchKernelGGL(kern, dim3((unsigned)batch), dim3(SB_THREADS), lds, static_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)batch, (unsigned)splits), dim3(SB_THREADS), lds, static_cast<hipStream_t>(stream), a);
     STC_LAUNCH_CHECK("stc_cell_small_bwd_f32 launch");
     return STC_OK;
 }

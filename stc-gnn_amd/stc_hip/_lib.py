@@ -21,7 +21,7 @@ from .graph import is_full_pattern
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG_ROOT, 'libstc_hip.so')
-ABI_VERSION = 19
+ABI_VERSION = 20
 FMT_BF16X3, FMT_F16X2 = 0, 1          # STC_FMT_* of include/stc_hip.h: operand formats of the split-operand matrix-core kernels
 MAX_K = 4
 SPMM_SUM_MAX_ADD = 8     # = STC_SPMM_SUM_MAX_ADD of include/stc_hip.h
@@ -69,9 +69,9 @@ def _declare(lib):
         'stc_csr_spmm_bf16': [_p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _f32, _p],
         'stc_bcsr_spmm_bf16': [_p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _f32, _p],
         'stc_dense_agg_f32': [_p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _f32, _p],
-        'stc_cell_small_fwd_f32': [_p, _p, _p, _i32, _i32, _i32, _p, _i32, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _p],
+        'stc_cell_small_fwd_f32': [_p, _p, _p, _i32, _i32, _i32, _p, _i32, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p],
         'stc_cell_small_bwd_f32': [_p, _p, _p, _i32, _i32, _i32, _p, _i32, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _i32, _p, _i64, _i32, _i32,
-                                   _p, _p, _p, _p, C.c_size_t, _i32, _i32, _p],
+                                   _p, _p, _p, _p, C.c_size_t, _i32, _i32, _i32, _i32, _p],
         'stc_csr_sddmm_f32': [_p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _i32, _p],
         'stc_cheby_dense_fwd_f32': [_p, _i32, _i32, _p, _p],
         'stc_cheby_dense_bwd_f32': [_p, _p, _p, _i32, _i32, _p, _p],
@@ -785,11 +785,12 @@ class HipKernels:
 
     # ---- small graphs: one STC_Cell step per launch --------------------------------------------------------
     SMALL_MAX_ROWS = 65535       # N*C rows per sample the kernels take at all (16-bit row arithmetic)
-    #: N*C rows per sample up to which the executor PREFERS these kernels: about what a compute unit's LDS stages (N = 100, C = 5: 500).
-    #: One workgroup per sample means `batch` of the 256 compute units work; measured as HIP-graph replays at batch 32: 2.96 vs 4.96 ms
-    #: per step at 500 rows, but 10.8 vs 7.6 ms at 1 568 rows (N = 196, C = 8) and 21.9 vs 11.5 ms at 3 200 -- the general path's ~700
-    #: launches fill the chip there.
-    SMALL_PREFERRED_ROWS = 704
+    #: N*C rows per sample up to which the executor prefers these kernels over the general path (C <= 16 has no split-operand matrix-core
+    #: kernels there).  Measured as HIP-graph replays at batch 32, these kernels | general path, ms per step: 500 rows (SF) 2.2 | 4.9;
+    #: 1 568 (N = 196, C = 8) 2.9 | 7.6;  3 200: 4.5 | 11.5;  6 912 (C = 12): 8.8 | 22.4;  32 768 (C = 8): 37 | 90;  but 16 384 rows at
+    #: C = 16: 18.3 | 13.4 (the general path's fp32-MFMA node kernels take C = 16) -- hence the extra rule in small.small_graph_supported.
+    SMALL_PREFERRED_ROWS = 65535
+    SMALL_STAGED_ROWS = 640      # N*C rows per sample that a compute unit's LDS stages (above: every gather from L2, and the forward split too)
 
     def cell_small_supported(self, Ks, Kc, Cc, cin, h, n_nodes=0) -> bool:
         return n_nodes * Cc <= self.SMALL_MAX_ROWS and bool(self.lib.stc_cell_small_supported(Ks, Kc, Cc, cin, h))
@@ -834,10 +835,12 @@ class HipKernels:
         self._same_device(H, X, Tc, Wg, Wc, rowptr, colidx, val, Zg, Zc, *planes.values())
         return B, N, Cc, cin, Kc
 
-    def cell_small_fwd(self, rowptr, colidx, val, X, H, Tc, Wg, bg, Wc, bc, U, R, Cand, Hnew, RH, Zg, Zc, checked=True, Z0=None):
+    def cell_small_fwd(self, rowptr, colidx, val, X, H, Tc, Wg, bg, Wc, bc, U, R, Cand, Hnew, RH, Zg, Zc, checked=True, Z0=None, splits=1):
         """One STC_Cell step (reference STC_GNN.py:65-79) in one launch: ``stc_cell_small_fwd_f32``.  (rowptr, colidx, val): CSR of Gs^T.
         ``checked=False``: the caller built every buffer itself from shapes it already validated (the cell-graph executor).
-        ``Z0`` (optional, like Zg): receives the slab [H | Xt | 0] (learned graphs: operand of the graph-gradient product)."""
+        ``Z0`` (optional, like Zg): receives the slab [H | Xt | 0] (learned graphs: operand of the graph-gradient product).
+        ``splits`` = G > 1: the cell as FOUR launches (one per phase), each over G workgroups per sample -- for batches too small to fill
+        the chip with one workgroup per sample (``cell_small_splits``)."""
         if checked:
             B, N, Cc, cin, Kc = self._small_shapes('cell_small_fwd', rowptr, colidx, val, X, H, Tc, Wg, Wc, dict(U=U, R=R, Cand=Cand, Hnew=Hnew, RH=RH), Zg, Zc)
             if Z0 is not None:
@@ -848,13 +851,24 @@ class HipKernels:
                     self._f32('cell_small_fwd.' + name, b_, (n,))
         else:
             (B, N, Cc, _), cin, Kc = H.shape, X.shape[-1], Tc.shape[0]
-        self._launch('stc_cell_small_fwd_f32', H, rowptr.data_ptr(), colidx.data_ptr(), val.data_ptr(), N, val.numel(), int(is_full_pattern(colidx, N, N)),
-                     X.data_ptr(), cin, H.data_ptr(), Tc.data_ptr(), Kc,
-                     Wg.data_ptr(), _ptr(bg), Wc.data_ptr(), _ptr(bc), U.data_ptr(), R.data_ptr(), Cand.data_ptr(), Hnew.data_ptr(), RH.data_ptr(),
-                     Zg.data_ptr(), Zc.data_ptr(), _ptr(Z0), B, Cc, nbytes=4 * B * N * Cc * (cin + 16 * 8 + 2 * self.cell_small_zg_width(cin)))
+        dense = int(is_full_pattern(colidx, N, N))
+        for phase in ((0,) if splits == 1 else (1, 2, 3, 4)):
+            self._launch('stc_cell_small_fwd_f32', H, rowptr.data_ptr(), colidx.data_ptr(), val.data_ptr(), N, val.numel(), dense, X.data_ptr(), cin,
+                         H.data_ptr(), Tc.data_ptr(), Kc, Wg.data_ptr(), _ptr(bg), Wc.data_ptr(), _ptr(bc), U.data_ptr(), R.data_ptr(), Cand.data_ptr(),
+                         Hnew.data_ptr(), RH.data_ptr(), Zg.data_ptr(), Zc.data_ptr(), _ptr(Z0), phase, splits, B, Cc,
+                         nbytes=(4 * B * N * Cc * (cin + 16 * 8 + 2 * self.cell_small_zg_width(cin))) // (1 if splits == 1 else 4))
+
+    @staticmethod
+    def cell_small_splits(batch: int, rows: int = 0) -> int:
+        """Workgroups per sample for a batch: 1 = one launch per cell step (a workgroup per sample); G > 1 = four launches per step over
+        G workgroups per sample, so that ~256 workgroups are in flight (rows: N * C of a sample -- a split wants at least a few tiles)."""
+        g = max(1, min(8, 256 // max(1, batch)))
+        while g > 1 and rows and rows < 48 * g:
+            g //= 2
+        return g
 
     def cell_small_bwd(self, rowptr, colidx, val, X, H, Tc, Wg, Wc, U, R, Cand, RH, Zg, Zc, dHnew, dX, accumulate_x, dH, accumulate_h,
-                       dparams, has_bg, has_bc, checked=True, dZ1c=None, dZ1g=None, dYg=None):
+                       dparams, has_bg, has_bc, checked=True, dZ1c=None, dZ1g=None, dYg=None, splits=1):
         """Autograd of ``cell_small_fwd`` in one launch (``stc_cell_small_bwd_f32``).  (rowptr, colidx, val): CSR of Gs.  dX / dH may be
         None; ``accumulate_*``: add to what the buffer holds.  ``dparams`` (B * cell_small_param_rows, P >= cell_small_params):
         parameter-gradient partials (one row per sample and wave), ADDED to."""
@@ -864,8 +878,8 @@ class HipKernels:
             if dX is not None:
                 self._f32('cell_small_bwd.dX', dX, tuple(X.shape))
             self._f32('cell_small_bwd.dparams', dparams)
-            if dparams.dim() != 2 or dparams.shape[0] != B * self.cell_small_param_rows or dparams.shape[1] < self.cell_small_params(2, Kc, cin):
-                raise StcError(f'cell_small_bwd: dparams {tuple(dparams.shape)}, expected ({B * self.cell_small_param_rows}, '
+            if dparams.dim() != 2 or dparams.shape[0] != B * splits * self.cell_small_param_rows or dparams.shape[1] < self.cell_small_params(2, Kc, cin):
+                raise StcError(f'cell_small_bwd: dparams {tuple(dparams.shape)}, expected ({B * splits * self.cell_small_param_rows}, '
                                f'>= {self.cell_small_params(2, Kc, cin)})')
             for name, t_, shape in (('dZ1c', dZ1c, tuple(Zg.shape)), ('dZ1g', dZ1g, tuple(Zg.shape)), ('dYg', dYg, (B, N * Cc, 32))):
                 if t_ is not None:
@@ -875,12 +889,14 @@ class HipKernels:
             (B, N, Cc, _), cin, Kc = H.shape, X.shape[-1], Tc.shape[0]
         nbytes = self.lib.stc_cell_small_workspace_bytes(N, Cc, cin, B)
         ws = self._get_workspace(H.device, nbytes)
-        self._launch('stc_cell_small_bwd_f32', H, rowptr.data_ptr(), colidx.data_ptr(), val.data_ptr(), N, val.numel(), int(is_full_pattern(colidx, N, N)),
-                     X.data_ptr(), cin, H.data_ptr(), Tc.data_ptr(), Kc,
-                     Wg.data_ptr(), Wc.data_ptr(), U.data_ptr(), R.data_ptr(), Cand.data_ptr(), RH.data_ptr(), Zg.data_ptr(), Zc.data_ptr(),
-                     dHnew.data_ptr(), _ptr(dX), int(bool(accumulate_x)), _ptr(dH), int(bool(accumulate_h)), dparams.data_ptr(), dparams.shape[1],
-                     int(bool(has_bg)), int(bool(has_bc)), _ptr(dZ1c), _ptr(dZ1g), _ptr(dYg), ws.data_ptr(), ws.numel(), B, Cc,
-                     nbytes=4 * B * N * Cc * (2 * cin + 16 * 9 + 5 * self.cell_small_zg_width(cin) + 64))
+        dense = int(is_full_pattern(colidx, N, N))
+        for phase in ((0,) if splits == 1 else (1, 2, 3, 4)):
+            self._launch('stc_cell_small_bwd_f32', H, rowptr.data_ptr(), colidx.data_ptr(), val.data_ptr(), N, val.numel(), dense, X.data_ptr(), cin,
+                         H.data_ptr(), Tc.data_ptr(), Kc, Wg.data_ptr(), Wc.data_ptr(), U.data_ptr(), R.data_ptr(), Cand.data_ptr(), RH.data_ptr(),
+                         Zg.data_ptr(), Zc.data_ptr(), dHnew.data_ptr(), _ptr(dX), int(bool(accumulate_x)), _ptr(dH), int(bool(accumulate_h)),
+                         dparams.data_ptr(), dparams.shape[1], int(bool(has_bg)), int(bool(has_bc)), _ptr(dZ1c), _ptr(dZ1g), _ptr(dYg),
+                         ws.data_ptr(), ws.numel(), phase, splits, B, Cc,
+                         nbytes=(4 * B * N * Cc * (2 * cin + 16 * 9 + 5 * self.cell_small_zg_width(cin) + 64)) // (1 if splits == 1 else 4))
 
     # ---- planar cell convolutions of Chebyshev order K = 3 ------------------------------------------------
     def cell_planar_k_supported(self, K, Cc, h) -> bool:

@@ -1,4 +1,4 @@
-"""A schedule of STC_Cells on a SMALL graph as one autograd node: one launch per cell step in each direction.
+"""A schedule of STC_Cells with FEW CATEGORIES (C <= 16: the SF-incidents shape and its relatives) as one autograd node.
 
 The SF-incidents shape (N = 100, C = 5, hidden 16) is bound by the host's launch rate on the general path (~15 launches
 per cell and direction).  ``stc_cell_small_fwd/bwd_f32`` run a whole cell step -- both aggregations, both convolutions, the gate math
@@ -37,8 +37,8 @@ def small_graph_supported(k, op: SpatialOperand, Tc, Ks: int, C: int, h: int, x_
     ``graph.dense_operand`` builds it) -- its gradient is formed as a dense product."""
     if dtype != torch.float32 or not hasattr(k, 'cell_small_supported') or (op.fwd_val.requires_grad and op.nnz != op.n * op.n):
         return False
-    if op.n * C > k.SMALL_PREFERRED_ROWS:                           # larger samples: the general path's many launches fill the chip better
-        return False
+    if op.n * C > k.SMALL_PREFERRED_ROWS or (C == 16 and op.n * C > 4096):
+        return False                                                # (16 categories on large graphs: the general path's fp32-MFMA node kernels win, 13.4 vs 18.3 ms)
     return all(k.cell_small_supported(Ks, Tc.shape[0], C, w, h, op.n) for w in set(x_widths))
 
 
@@ -102,19 +102,25 @@ class _StcSmallGraph(Function):
                 ni += 1
         U, R, Cand, RH, Zc = (p.unbind(0) for p in planes.unbind(0))
         source = lambda src: ext[src[1]] if src[0] == 'ext' else state[src[1]]
+        # Few samples: the BACKWARD runs as four launches per cell step (one per phase) over several workgroups per sample instead of one
+        # workgroup per sample -- 79 -> ~55 us per cell at the SF shape.  The forward stays one launch: its phases are latency-bound
+        # (~10 us each as separate launches against 32 us for the whole staged cell).  Dense learned graphs keep the one-launch form in
+        # both directions: their aggregation is the matrix product on the staged planes.
+        splits = 1 if op.nnz == N * N else k.cell_small_splits(B, N * C)
+        fwd_splits = splits if N * C > k.SMALL_STAGED_ROWS else 1       # (samples too large to stage in LDS: the forward is split as well)
         for j, (s_id, x, hs) in enumerate(schedule):
             Wg, bg, Wc, bc = stacks[s_id]
             k.cell_small_fwd(op.fwd_rowptr, op.fwd_colidx, fwd_val, source(x), source(hs), Tc, Wg, bg, Wc, bc, U[j], R[j], Cand[j], state[j], RH[j],
-                             zg[j], Zc[j].view(B, N * C, H16), checked=False, Z0=z0[j])
+                             zg[j], Zc[j].view(B, N * C, H16), checked=False, Z0=z0[j], splits=fwd_splits)
         ctx.save_for_backward(Tc, out_alias, inner, planes, zg_w, zg_n, z0_w, z0_n, *ext, *[p for st in stacks for p in st if p is not None])
-        ctx.meta = (k, op, Ks, list(schedule), tuple(outputs), cin, [tuple(p is not None for p in st) for st in stacks], (B, N, C), len(ext))
+        ctx.meta = (k, op, Ks, list(schedule), tuple(outputs), cin, [tuple(p is not None for p in st) for st in stacks], (B, N, C), len(ext), splits)
         ctx.out_stack_ref, ctx.out_stack_version = weakref.ref(out_stack), out_stack._version
         return out_stack
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_stack):
-        k, op, Ks, schedule, outputs, cin, present, (B, N, C), n_ext = ctx.meta
+        k, op, Ks, schedule, outputs, cin, present, (B, N, C), n_ext, splits = ctx.meta
         stack = ctx.out_stack_ref()
         if stack is not None and stack._version != ctx.out_stack_version:
             raise RuntimeError('stc_cell_graph: the returned state stack was modified in place after the forward pass; the states saved for '
@@ -153,7 +159,7 @@ class _StcSmallGraph(Function):
         source = lambda src: ext[src[1]] if src[0] == 'ext' else state[src[1]]
         Kc = Tc.shape[0]
         P = max(k.cell_small_params(Ks, Kc, w) for w in cin)
-        dP = Tc.new_zeros(len(stacks), B * k.cell_small_param_rows, P)   # parameter-gradient partials, every cell adds to its set's rows
+        dP = Tc.new_zeros(len(stacks), B * splits * k.cell_small_param_rows, P)   # parameter-gradient partials, every cell adds to its set's rows
         G = (Tc.new_zeros if learned else Tc.new_empty)(n_cells, B, N, C, H16)      # gradient owed to every cell's state
         owed = [False] * n_cells
         grad_stack = _c(grad_stack)
@@ -180,7 +186,7 @@ class _StcSmallGraph(Function):
                     owed[x[1]] = True
             k.cell_small_bwd(op.bwd_rowptr, op.bwd_colidx, op.bwd_val, source(x), source(hs), Tc, Wg, Wc, U[j], R[j], Cand[j], RH[j], zg[j],
                              Zc[j].view(B, N * C, H16), Gv[j], dX, acc_x, dH, acc_h, dPv[s_id], bg is not None, bc is not None, checked=False,
-                             dZ1c=dzc[j], dZ1g=dzg[j], dYg=None if dyg is None else dyg[j])
+                             dZ1c=dzc[j], dZ1g=dzg[j], dYg=None if dyg is None else dyg[j], splits=splits)
             if late is not None:
                 Gv[late].add_(dX)
         sums = dP.sum(1)                                             # (sets, P)

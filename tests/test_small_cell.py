@@ -47,21 +47,22 @@ def _buffers(B, N, C, cin, dtype, k):
                 Zg=new(B, N * C, k.cell_small_zg_width(cin)), Zc=new(B, N * C, 16)), P
 
 
-def _run(k, op, t, buf, P, to, acc_x=False, acc_h=False, want_x=True, want_h=True, want_dumps=False):
+def _run(k, op, t, buf, P, to, acc_x=False, acc_h=False, want_x=True, want_h=True, want_dumps=False, splits=1):
     """Forward + backward through kernel set ``k`` on device / dtype converter ``to``; returns plain CPU tensors."""
     d = {n: (None if v is None else to(v)) for n, v in t.items()}
     b = {n: to(v) for n, v in buf.items()}
     dumps = {n: to(torch.full_like(buf['Zg'], float('nan'))) for n in ('Z0', 'dZ1c', 'dZ1g')} if want_dumps else {}
     k.cell_small_fwd(op.fwd_rowptr, op.fwd_colidx, to(op.fwd_val), d['X'], d['H'], d['Tc'], d['Wg'], d['bg'], d['Wc'], d['bc'],
-                     b['U'], b['R'], b['Cand'], b['Hnew'], b['RH'], b['Zg'], b['Zc'], Z0=dumps.get('Z0'))
+                     b['U'], b['R'], b['Cand'], b['Hnew'], b['RH'], b['Zg'], b['Zc'], Z0=dumps.get('Z0'), splits=splits)
     B = d['H'].shape[0]
     dX = to(torch.full(t['X'].shape, 0.25, dtype=t['X'].dtype)) if want_x else None
     dH = to(torch.full(t['H'].shape, -0.5, dtype=t['H'].dtype)) if want_h else None
-    dP = to(torch.full((B * k.cell_small_param_rows, P), 0.125, dtype=t['H'].dtype))
+    dP = to(torch.full((B * splits * k.cell_small_param_rows, P), 0.125, dtype=t['H'].dtype))
     k.cell_small_bwd(op.bwd_rowptr, op.bwd_colidx, to(op.bwd_val), d['X'], d['H'], d['Tc'], d['Wg'], d['Wc'], b['U'], b['R'], b['Cand'], b['RH'],
                      b['Zg'], b['Zc'], d['dHnew'], dX, acc_x, dH, acc_h, dP, t['bg'] is not None, t['bc'] is not None,
                      dZ1c=dumps.get('dZ1c'), dZ1g=dumps.get('dZ1g'), dYg=dumps.setdefault('dYg', to(torch.full((B, buf['Zg'].shape[1], 32), float('nan'),
-                                                                                                    dtype=t['H'].dtype))) if want_dumps else None)
+                                                                                                    dtype=t['H'].dtype))) if want_dumps else None,
+                     splits=splits)
     out = dict(b, dX=dX, dH=dH, dP=dP, **dumps)
     return {n: (None if v is None else v.detach().cpu()) for n, v in out.items()}
 
@@ -132,6 +133,28 @@ def test_small_cell_kernels(B, N, C, cin, dense, bias, acc):
     assert got['dX'] is None and got['dH'] is None
     for a, b, name in zip(_split_params(got['dP'], cin), _split_params(want['dP'], cin), ('dWg', 'dbg', 'dWc', 'dbc', 'rest')):
         assert rel_err(a, b) < TOL, name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,N,C,cin,splits', [(2, 100, 5, 16, 8), (3, 100, 5, 1, 4), (1, 37, 8, 16, 2), (2, 200, 8, 3, 8), (1, 7, 1, 2, 3)])
+def test_small_cell_kernels_split_over_workgroups(B, N, C, cin, splits):
+    """The same cell step as four launches per direction (one per phase) over ``splits`` workgroups per sample -- what the executor uses when
+    the batch is too small to fill the chip with one workgroup per sample: same buffers, same results (parameter-gradient partials in
+    splits x as many rows), dumps included."""
+    from stc_hip._lib import HipKernels
+    hip = HipKernels()
+    graph = _graph(N, seed=N + cin)
+    t = _inputs(B, N, C, cin, seed=5 * N + C + cin)
+    buf, P = _buffers(B, N, C, cin, torch.float32, hip)
+    want = _run(EM, csr_operand(graph, torch.device('cpu')), t, buf, P, lambda v: v.clone(), acc_x=True, acc_h=True, want_dumps=True)
+    got = _run(hip, csr_operand(graph, torch.device('cuda')), t, buf, P, lambda v: v.cuda(), acc_x=True, acc_h=True, want_dumps=True, splits=splits)
+    for name in ('U', 'R', 'RH', 'Zg', 'Zc', 'Cand', 'Hnew', 'Z0', 'dZ1c', 'dZ1g', 'dYg', 'dX', 'dH'):
+        assert rel_err(got[name], want[name]) < TOL, name
+    for a, b, name in zip(_split_params(got['dP'], cin), _split_params(want['dP'], cin), ('dWg', 'dbg', 'dWc', 'dbc')):
+        # (both sides start from 0.125 in every row: the split form has `splits` times the rows)
+        extra = 0.125 * (got['dP'].shape[0] - want['dP'].shape[0])
+        assert rel_err(a - extra, b) < TOL, name
+    assert hip.cell_small_splits(32, 500) == 8 and hip.cell_small_splits(256, 500) == 1 and hip.cell_small_splits(4, 100) == 2
 
 
 @pytest.mark.gpu

@@ -60,10 +60,10 @@ for stop in (1, 2, 3, 99):
     lib = C.CDLL(so)
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     fwd = lambda: lib.stc_cell_small_fwd_f32(p(op.fwd_rowptr), p(op.fwd_colidx), p(op.fwd_val), N, op.fwd_val.numel(), 0, p(X), cin, p(H), p(Tc), 2, p(Wg), p(bg), p(Wc), p(bc),
-                                             p(U), p(R), p(Cand), p(Hnew), p(RH), p(Zg), p(Zc), None, B, Cc, stream)
+                                             p(U), p(R), p(Cand), p(Hnew), p(RH), p(Zg), p(Zc), None, 0, 1, B, Cc, stream)
     bwd = lambda: lib.stc_cell_small_bwd_f32(p(op.bwd_rowptr), p(op.bwd_colidx), p(op.bwd_val), N, op.bwd_val.numel(), 0, p(X), cin, p(H), p(Tc), 2, p(Wg), p(Wc), p(U), p(R),
                                              p(Cand), p(RH), p(Zg), p(Zc), p(dHn), p(dX), 0, p(dH), 0, p(dP), C.c_int64(P), 1, 1, None, None, None, p(ws),
-                                             C.c_size_t(ws.numel() * 4), B, Cc, stream)
+                                             C.c_size_t(ws.numel() * 4), 0, 1, B, Cc, stream)
     assert fwd() == 0 and bwd() == 0
     rows.append((stop, timed(fwd), timed(bwd)))
 print(f'small cell launch, N={N} C={Cc} cin={cin} B={B} {" ".join(extra)}: cumulative us after each phase (forward | backward)')
