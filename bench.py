@@ -491,17 +491,22 @@ def main():
                     agg = 2.0 * graph.nnz * C * (cin + 2 * h)
                     return B * ((2 * proj + mix + 2.0 * graph.nnz * C * 2 * (cin + h)) if bwd else (proj + mix + agg))
                 narrow, wide = a.obs, (a.layers - 1) * a.obs + a.layers * a.pred
-                per_launch = (narrow * flops(1, dom_name.endswith('bwd_f32')) + wide * flops(h, dom_name.endswith('bwd_f32'))) / max(1, narrow + wide)
-                tf = per_launch / (dom['avg_launch_us'] * 1e-6) / 1e12
-                cus = min(B, 256)
-                dom['matrix'] = {'what': 'algorithmic flops of a cell launch (projections, category mix, aggregation; backward: dZ + dW) on '
+                per_cell = (narrow * flops(1, dom_name.endswith('bwd_f32')) + wide * flops(h, dom_name.endswith('bwd_f32'))) / max(1, narrow + wide)
+                # a cell step is ONE launch (a workgroup per sample) or, split over several workgroups per sample, one launch per phase (four)
+                launches_per_cell = max(1, round(dk['launches'] / a.steps / max(1, narrow + wide)))
+                cell_us = dom['avg_launch_us'] * launches_per_cell
+                tf = per_cell / (cell_us * 1e-6) / 1e12
+                cus = min(256, B * (hip.cell_small_splits(B, N * C) if launches_per_cell > 1 else 1))
+                dom['matrix'] = {'what': 'algorithmic flops of a cell step (projections, category mix, aggregation; backward: dZ + dW) on '
                                          'v_mfma_f32_16x16x4_f32, averaged over the narrow (layer 0) and wide cells of the schedule',
-                                 'flops_per_launch': per_launch, 'achieved': tf, 'peak': FP32_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                 'flops_per_cell_step': per_cell, 'launches_per_cell_step': launches_per_cell, 'cell_step_us': cell_us,
+                                 'achieved': tf, 'peak': FP32_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                                  'frac': tf / FP32_MATRIX_PEAK_TFLOPS, 'compute_units_in_use': cus,
                                  'frac_of_the_units_in_use': tf / (FP32_MATRIX_PEAK_TFLOPS * cus / 256.0)}
+                per_launch = per_cell / launches_per_cell
                 if plain['launches'] == 0:                  # no aggregation launch in this step at all: the dominant kernel IS the roofline entry
-                    roofline.update(bound='mfma', kernel=f'{dom_name}: one STC_Cell step per launch, one workgroup per sample '
-                                                         f'({cus} of 256 compute units), exact-fp32 matrix instructions',
+                    roofline.update(bound='mfma', kernel=f'{dom_name}: one STC_Cell step in {launches_per_cell} launch(es), '
+                                                         f'{cus} of 256 compute units at work, exact-fp32 matrix instructions',
                                     achieved=tf, peak=FP32_MATRIX_PEAK_TFLOPS, unit='TFLOP/s', frac=tf / FP32_MATRIX_PEAK_TFLOPS,
                                     launches=dk['launches'], avg_launch_us=dom['avg_launch_us'], algorithmic_flops_per_launch=per_launch,
                                     frac_of_the_units_in_use=dom['matrix']['frac_of_the_units_in_use'])
