@@ -102,14 +102,15 @@ __device__ __forceinline__ void aggregate_rows(const int* __restrict__ gp, const
 // (one 16-byte global load = the lane's B operands of four steps), so that a lane ends up with 4 consecutive COLUMNS of one output row --
 // the quad the CSR form's base / store callbacks take.  (Gathering 100 neighbour rows per output row from L2 instead costs ~100 us per phase.)
 template <int THREADS, int QUADS, class Base, class Store>
-__device__ __forceinline__ void aggregate_dense(const float* __restrict__ S, int N, int C, const float* src, int stride, Base base, Store store) {
+__device__ __forceinline__ void aggregate_dense(const float* __restrict__ S, int N, int C, const float* src, int stride, int split, int splits, Base base,
+                                                Store store) {
     constexpr int CT = (QUADS + 3) / 4;                          // 16-column tiles per (node, category) row
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, kq = lane >> 4;
     const int rtiles = (N + 15) >> 4, per_rt = C * CT, pairs = (per_rt + 1) >> 1, items = rtiles * pairs;
     const bool vec = (N & 3) == 0;
     // a wave takes TWO column tiles of one row tile at a time: they share the B operand (the rows of S) and give the matrix pipe two
     // independent accumulators (one accumulator = a chain of dependent instructions, 40 cycles each instead of 32)
-    for (int item = wave; item < items; item += THREADS / 64) {
+    for (int item = wave + (THREADS / 64) * split; item < items; item += (THREADS / 64) * splits) {
         const int rt = item / pairs, t0 = 2 * (item - rt * pairs), t1 = min(t0 + 1, per_rt - 1);
         const bool two = t0 + 1 < per_rt;
         const int c0 = t0 / CT, lb0 = t0 - c0 * CT, c1 = t1 / CT, lb1 = t1 - c1 * CT;
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(SF_THREADS) void small_fwd_kernel(SmallFwd a) {
         auto none = [](int, int) -> f32x4 { return zero4(); };
         auto put = [&](int row, int q, f32x4 s) { st4(Zgb + (unsigned)row * LP + 4 * q, s); };
         if (DENSE)
-            aggregate_dense<SF_THREADS, LP / 4>(a.g.val, N, C, P, SP, none, put);
+            aggregate_dense<SF_THREADS, LP / 4>(a.g.val, N, C, P, SP, 0, 1, none, put);
         else
             aggregate_rows<SF_THREADS, LP / 4>(gp, gc, gv, NC, C, invC, split, splits,
                 [&](int src, int q) -> f32x4 {
@@ -427,7 +428,7 @@ __global__ __launch_bounds__(SF_THREADS) void small_fwd_kernel(SmallFwd a) {
         auto none = [](int, int) -> f32x4 { return zero4(); };
         auto put = [&](int row, int q, f32x4 s) { st4(Zcb + (unsigned)row * SC_H + 4 * q, s); };
         if (DENSE)
-            aggregate_dense<SF_THREADS, 4>(a.g.val, N, C, Q, SQ, none, put);
+            aggregate_dense<SF_THREADS, 4>(a.g.val, N, C, Q, SQ, 0, 1, none, put);
         else
             aggregate_rows<SF_THREADS, 4>(gp, gc, gv, NC, C, invC, split, splits,
                 [&](int src, int q) -> f32x4 { return STAGED ? ld4(Q + (unsigned)src * SQ + 4 * q) : ld4(RHb + (unsigned)src * SC_H + 4 * q); }, none, put);
@@ -687,10 +688,10 @@ struct Raw2 {
 template <int KC>
 __host__ __device__ constexpr int bwd_lds_fixed() { return SB_WAVES * KC * 16 * 33; }                     // floats: the waves' dV tiles
 
-template <int KC, int XQ, int MODE>
+template <int KC, int XQ, int MODE>      // MODE 3 (backward only): dense graph, nothing staged -- the split form of a learned graph's backward
 __global__ __launch_bounds__(SB_THREADS) void small_bwd_kernel(SmallBwd a) {
     constexpr int LP = 16 + 4 * XQ;
-    constexpr bool STAGED = MODE >= 1, DENSE = MODE == 2;
+    constexpr bool STAGED = MODE == 1 || MODE == 2, DENSE = MODE >= 2;
     extern __shared__ __align__(16) float lds[];
     const int t = threadIdx.x, wave = t >> 6;
     const int C = a.C, N = a.N, NC = N * C, cin = a.cin, L = cin + SC_H, invC = ((1 << 20) + C - 1) / C;
@@ -784,7 +785,7 @@ __global__ __launch_bounds__(SB_THREADS) void small_bwd_kernel(SmallBwd a) {
             }
         };
         if (DENSE)
-            aggregate_dense<SB_THREADS, LP / 4>(a.g.val, N, C, dZ1, LP, from_dz0, gate_bwd);
+            aggregate_dense<SB_THREADS, LP / 4>(a.g.val, N, C, dZ1, LP, split, splits, from_dz0, gate_bwd);
         else
             aggregate_rows<SB_THREADS, LP / 4>(gp, gc, gv, NC, C, invC, split, splits, from_dz1, from_dz0, gate_bwd);
     }
@@ -823,7 +824,7 @@ __global__ __launch_bounds__(SB_THREADS) void small_bwd_kernel(SmallBwd a) {
                 }
             };
         if (DENSE)
-            aggregate_dense<SB_THREADS, LP / 4>(a.g.val, N, C, dZ1, LP, from_dz0, add_in);
+            aggregate_dense<SB_THREADS, LP / 4>(a.g.val, N, C, dZ1, LP, split, splits, from_dz0, add_in);
         else
             aggregate_rows<SB_THREADS, LP / 4>(gp, gc, gv, NC, C, invC, split, splits, from_dz1, from_dz0, add_in);
     }
@@ -842,7 +843,7 @@ hipError_t allow_lds_once(K kern, size_t bytes, std::atomic<size_t>& granted) {
     if (e == hipSuccess) granted.store(bytes, std::memory_order_relaxed);
     return e;
 }
-std::atomic<size_t> g_granted[2][2][3];          // [direction][wide input][mode]
+std::atomic<size_t> g_granted[2][2][4];          // [direction][wide input][mode]
 
 }  // namespace
 
@@ -924,11 +925,13 @@ extern "C" int stc_cell_small_bwd_f32(const int32_t* rowptr, const int32_t* coli
     STC_REQUIRE(phase >= 0 && phase <= 4 && splits >= 1 && splits <= 64 && (phase != 0 || splits == 1), STC_EINVAL,
                 "stc_cell_small_bwd_f32: phase %d / splits %d", phase, splits);
     const size_t fixed = (size_t)bwd_lds_fixed<2>() * 4, planes = (size_t)n_nodes * C * LP * 4;
-    const bool dense = phase == 0 && graph_is_dense && nnz == (long long)n_nodes * n_nodes && fixed + planes <= SC_LDS_BUDGET;
+    const bool full = graph_is_dense && nnz == (long long)n_nodes * n_nodes;
+    const bool dense = phase == 0 && full && fixed + planes <= SC_LDS_BUDGET;
     const size_t staged = fixed + planes + (dense ? 0 : graph_lds_bytes(n_nodes, nnz));
-    const int mode = dense ? 2 : (phase == 0 && staged <= SC_LDS_BUDGET ? 1 : 0);
-    const size_t lds = mode ? staged : fixed;
-    auto kern = mode == 2 ? (xq == 4 ? small_bwd_kernel<2, 4, 2> : small_bwd_kernel<2, 1, 2>)
+    const int mode = dense ? 2 : (phase != 0 && full ? 3 : (phase == 0 && staged <= SC_LDS_BUDGET ? 1 : 0));
+    const size_t lds = mode == 1 || mode == 2 ? staged : fixed;
+    auto kern = mode == 3 ? (xq == 4 ? small_bwd_kernel<2, 4, 3> : small_bwd_kernel<2, 1, 3>)
+              : mode == 2 ? (xq == 4 ? small_bwd_kernel<2, 4, 2> : small_bwd_kernel<2, 1, 2>)
               : mode == 1 ? (xq == 4 ? small_bwd_kernel<2, 4, 1> : small_bwd_kernel<2, 1, 1>)
                           : (xq == 4 ? small_bwd_kernel<2, 4, 0> : small_bwd_kernel<2, 1, 0>);
     const hipError_t e = allow_lds_once(kern, lds, g_granted[1][xq == 4][mode]);

@@ -103,11 +103,11 @@ class _StcSmallGraph(Function):
         U, R, Cand, RH, Zc = (p.unbind(0) for p in planes.unbind(0))
         source = lambda src: ext[src[1]] if src[0] == 'ext' else state[src[1]]
         # Few samples: the BACKWARD runs as four launches per cell step (one per phase) over several workgroups per sample instead of one
-        # workgroup per sample -- 79 -> ~55 us per cell at the SF shape.  The forward stays one launch: its phases are latency-bound
-        # (~10 us each as separate launches against 32 us for the whole staged cell).  Dense learned graphs keep the one-launch form in
-        # both directions: their aggregation is the matrix product on the staged planes.
-        splits = 1 if op.nnz == N * N else k.cell_small_splits(B, N * C)
-        fwd_splits = splits if N * C > k.SMALL_STAGED_ROWS else 1       # (samples too large to stage in LDS: the forward is split as well)
+        # workgroup per sample -- 79 -> ~55 us per cell at the SF shape.  The forward stays one launch while the sample fits the LDS: its
+        # phases are latency-bound (~10 us each as separate launches against 32 us for the whole staged cell).  Dense learned graphs: the
+        # same, their aggregations being matrix products either on the staged planes (one launch) or over all workgroups (split).
+        splits = k.cell_small_splits(B, N * C)
+        fwd_splits = splits if (N * C > k.SMALL_STAGED_ROWS and op.nnz != N * N) else 1    # (samples too large to stage: the forward is split as well)
         for j, (s_id, x, hs) in enumerate(schedule):
             Wg, bg, Wc, bc = stacks[s_id]
             k.cell_small_fwd(op.fwd_rowptr, op.fwd_colidx, fwd_val, source(x), source(hs), Tc, Wg, bg, Wc, bc, U[j], R[j], Cand[j], state[j], RH[j],

@@ -136,18 +136,21 @@ def test_small_cell_kernels(B, N, C, cin, dense, bias, acc):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('B,N,C,cin,splits', [(2, 100, 5, 16, 8), (3, 100, 5, 1, 4), (1, 37, 8, 16, 2), (2, 200, 8, 3, 8), (1, 7, 1, 2, 3)])
-def test_small_cell_kernels_split_over_workgroups(B, N, C, cin, splits):
+@pytest.mark.parametrize('B,N,C,cin,splits,dense', [(2, 100, 5, 16, 8, False), (3, 100, 5, 1, 4, False), (1, 37, 8, 16, 2, False), (2, 200, 8, 3, 8, False),
+                                                     (1, 7, 1, 2, 3, False), (2, 100, 5, 16, 8, True), (2, 37, 8, 3, 4, True)])
+def test_small_cell_kernels_split_over_workgroups(B, N, C, cin, splits, dense):
     """The same cell step as four launches per direction (one per phase) over ``splits`` workgroups per sample -- what the executor uses when
     the batch is too small to fill the chip with one workgroup per sample: same buffers, same results (parameter-gradient partials in
     splits x as many rows), dumps included."""
     from stc_hip._lib import HipKernels
     hip = HipKernels()
-    graph = _graph(N, seed=N + cin)
+    graph = _graph(N, seed=N + cin, dense=dense)
+    # (dense: the learned graph's operand -- the split backward then aggregates as matrix products over all workgroups)
+    operand = (lambda dev: dense_operand(graph.to_dense().to(dev))) if dense else (lambda dev: csr_operand(graph, torch.device(dev)))
     t = _inputs(B, N, C, cin, seed=5 * N + C + cin)
     buf, P = _buffers(B, N, C, cin, torch.float32, hip)
-    want = _run(EM, csr_operand(graph, torch.device('cpu')), t, buf, P, lambda v: v.clone(), acc_x=True, acc_h=True, want_dumps=True)
-    got = _run(hip, csr_operand(graph, torch.device('cuda')), t, buf, P, lambda v: v.cuda(), acc_x=True, acc_h=True, want_dumps=True, splits=splits)
+    want = _run(EM, operand('cpu'), t, buf, P, lambda v: v.clone(), acc_x=True, acc_h=True, want_dumps=True)
+    got = _run(hip, operand('cuda'), t, buf, P, lambda v: v.cuda(), acc_x=True, acc_h=True, want_dumps=True, splits=splits)
     for name in ('U', 'R', 'RH', 'Zg', 'Zc', 'Cand', 'Hnew', 'Z0', 'dZ1c', 'dZ1g', 'dYg', 'dX', 'dH'):
         assert rel_err(got[name], want[name]) < TOL, name
     for a, b, name in zip(_split_params(got['dP'], cin), _split_params(want['dP'], cin), ('dWg', 'dbg', 'dWc', 'dbc')):
