@@ -452,8 +452,9 @@ int stc_head_bwd_f32(const float* H, const float* w, const float* y, const float
  * caller zeroes the buffer once per backward pass, every cell of a layer adds to it, and one sum over the rows finishes the gradient.
  * workspace: stc_cell_small_workspace_bytes(N, C, cin, batch), 16-byte aligned.
  * Learned graphs (ABI v19): the gradients of Gs and Gc are products over ALL cells of a step, so the launches only leave their operands --
- * Z0 (forward, optional): the slab [H | Xt | 0] as Zg is laid out; dZ1c / dZ1g (backward, optional, like Zg): the gradients of the
- * candidate's / gates' aggregated slab; dYg (optional, (batch, N*C, 32)): the gate pre-activation gradients -- and the host forms
+ * Z0, Z0c, Z1c (forward, optional, laid out like Zg): the slabs [H | Xt | 0], [R*H | Xt | 0] and [Gs^T x (R*H) | Gs^T x Xt | 0];
+ * dZ1c / dZ1g (backward, optional, like Zg): the gradients of the candidate's / gates' aggregated slab; dYg (batch, N*C, 32) / dYc
+ * (batch, N*C, 16), optional: the gate / candidate pre-activation gradients -- and stc_graph_grad_f32 / stc_mix_grad_f32 form
  * dGs^T = sum dZ1 x Z0 and dT_c = sum V_c x dY with a few stacked products per backward pass (stc_hip/small.py).  NULL = not wanted.
  * graph_is_dense != 0: the caller vouches that the CSR is the FULL n x n pattern with columns in order (nnz = n*n), i.e. val is a dense
  * row-major matrix (graph.full_pattern): the aggregations then run as matrix products on the staged planes instead of row gathers.
@@ -469,15 +470,27 @@ int stc_cell_small_fwd_f32(const int32_t* rowptr, const int32_t* colidx, const f
                            int32_t graph_is_dense, const float* X, int32_t cin, const float* H, const float* Tc, int32_t Kc,
                            const float* Wg, const float* bg, const float* Wc, const float* bc,
                            float* U, float* R, float* Cand, float* Hnew, float* RH, float* Zg, float* Zc, float* Z0,
-                           int32_t phase, int32_t splits, int32_t batch, int32_t C, void* stream);
+                           float* Z0c, float* Z1c, int32_t phase, int32_t splits, int32_t batch, int32_t C, void* stream);
 int stc_cell_small_bwd_f32(const int32_t* rowptr, const int32_t* colidx, const float* val, int32_t n_nodes, int32_t nnz,
                            int32_t graph_is_dense, const float* X, int32_t cin, const float* H, const float* Tc, int32_t Kc,
                            const float* Wg, const float* Wc, const float* U, const float* R, const float* Cand,
                            const float* RH, const float* Zg, const float* Zc, const float* dHnew,
                            float* dX, int32_t accumulate_x, float* dH, int32_t accumulate_h,
                            float* dparams, int64_t params_ld, int32_t has_bg, int32_t has_bc,
-                           float* dZ1c, float* dZ1g, float* dYg,
+                           float* dZ1c, float* dZ1g, float* dYg, float* dYc,
                            void* workspace, size_t workspace_bytes, int32_t phase, int32_t splits, int32_t batch, int32_t C, void* stream);
+
+/* Gradients of learned graphs from the planes the cell launches left (ABI v20): sums over every selected cell step and sample, g = sel * batch
+ * + sample -> plane (cell0 + sel * cell_step) * batch + sample of buffers holding (cells, batch, N, F):
+ *   stc_graph_grad_f32:  partials[chunk][n][m]   = sum_{g = chunk, chunk + n_chunks, ..} sum_f A[g][n][f] * B[g][m][f]      (F % 4 == 0)
+ *   stc_mix_grad_f32:    partials[chunk][fa][fb] = sum_g sum_n A[g][n][fa] * B[g][n][fb]                                   
+ * fp32 products and per-g sums on the matrix cores, FLOAT64 accumulation over g; partials (n_chunks, ..) in float64 are WRITTEN (no
+ * atomics: the caller adds them).  The dGs^T of a learned dense Gs is  sum [dZ1g x Z0 + dZ1c x Z0c]  (graph form); dT_c[c][d] =
+ * sum_{ks, l, o} W[(ks, c, l), o] * Q_ks[c, l, d, o]  with  Q_ks = Z_ks^T . dY  (mix form), per convolution and parameter set. */
+int stc_graph_grad_f32(const float* A, const float* B, double* partials, int32_t n_chunks, int32_t cell0, int32_t cell_step, int32_t n_sel,
+                       int32_t batch, int32_t N, int32_t F, void* stream);
+int stc_mix_grad_f32(const float* A, const float* B, double* partials, int32_t n_chunks, int32_t cell0, int32_t cell_step, int32_t n_sel,
+                     int32_t batch, int32_t N, int32_t Fa, int32_t Fb, void* stream);
 
 /* ---- small helpers ---------------------------------------------------------
  * y += a*x over n elements (Chebyshev backward g_{k-2} -= g_k) */

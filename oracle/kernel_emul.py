@@ -245,7 +245,8 @@ class EmulatedKernels:
         self.csr_spmm(rowptr, colidx, val, N, N, T.reshape(B, N, Cc * w), None, out, 1.0, 0.0)
         return out.view(B, N, Cc, w)
 
-    def cell_small_fwd(self, rowptr, colidx, val, X, H, Tc, Wg, bg, Wc, bc, U, R, Cand, Hnew, RH, Zg, Zc, checked=True, Z0=None, splits=1):
+    def cell_small_fwd(self, rowptr, colidx, val, X, H, Tc, Wg, bg, Wc, bc, U, R, Cand, Hnew, RH, Zg, Zc, checked=True, Z0=None, splits=1, Z0c=None,
+                       Z1c=None):
         B, N, Cc, h = H.shape
         cin = X.shape[-1]
         rows = lambda t: t.reshape(B * N, Cc, t.shape[-1])
@@ -268,13 +269,17 @@ class EmulatedKernels:
             Z0v = Z0.view(B, N, Cc, Z0.shape[-1])
             Z0v[..., :h] = H
             Z0v[..., h:h + cin] = X
+        if Z0c is not None:
+            for dst, hpart in ((Z0c, RH), (Z1c, SRH)):
+                dst.copy_(Zg if dst is Z1c else Z0)
+                dst.view(B, N, Cc, dst.shape[-1])[..., :h] = hpart
         Y = torch.empty(B * N, Cc, h, dtype=H.dtype)
         self.bdg_node_fwd([rows(torch.cat([X, RH], -1)), rows(torch.cat([SXH[..., :cin], SRH], -1))], Tc, Wc, bc, Y)
         Cand.copy_(torch.tanh(Y.view(B, N, Cc, h)))
         Hnew.copy_((1.0 - U) * H + U * Cand)
 
     def cell_small_bwd(self, rowptr, colidx, val, X, H, Tc, Wg, Wc, U, R, Cand, RH, Zg, Zc, dHnew, dX, accumulate_x, dH, accumulate_h,
-                       dparams, has_bg, has_bc, checked=True, dZ1c=None, dZ1g=None, dYg=None, splits=1):
+                       dparams, has_bg, has_bc, checked=True, dZ1c=None, dZ1g=None, dYg=None, splits=1, dYc=None):
         B, N, Cc, h = H.shape
         cin = X.shape[-1]
         L = cin + h
@@ -309,6 +314,8 @@ class EmulatedKernels:
             return out
 
         dCpre = dHnew * U * (1.0 - Cand * Cand)
+        if dYc is not None:
+            dYc.copy_(dCpre.reshape(B, N * Cc, h))
         dCI = conv_bwd(torch.cat([X, RH], -1), torch.cat([SX, SRH], -1), Wc, dCpre, dWc, dbc if has_bc else None, dump=dZ1c)
         dRH, dXc = dCI[..., cin:], dCI[..., :cin]
         dGu = dHnew * (Cand - H) * U * (1.0 - U)
@@ -322,6 +329,18 @@ class EmulatedKernels:
         if dX is not None:
             g = dXc + dXH[..., :cin]
             dX.copy_(dX + g if accumulate_x else g)
+
+    # ---- stc_graph_grad_f32 / stc_mix_grad_f32: the graph-gradient products of learned graphs, float64 sums over cells and samples
+    @staticmethod
+    def _selected(t, cell0, cell_step, n_sel, N):
+        sel = t[cell0:cell0 + (n_sel - 1) * cell_step + 1:cell_step] if n_sel else t[:0]
+        return sel.reshape(sel.shape[0] * sel.shape[1], N, -1).double()           # (g, N, C * width)
+
+    def graph_grad(self, A, Bm, cell0, cell_step, n_sel, N):
+        return torch.einsum('gnf,gmf->nm', self._selected(A, cell0, cell_step, n_sel, N), self._selected(Bm, cell0, cell_step, n_sel, N))
+
+    def mix_grad(self, A, Bm, cell0, cell_step, n_sel, N):
+        return torch.einsum('gna,gnb->ab', self._selected(A, cell0, cell_step, n_sel, N), self._selected(Bm, cell0, cell_step, n_sel, N))
 
     # ---- stc_bdg_node_post_bwd_f32: Y = A + S.Bm (Ks = Kc = 2); backward from (X, dA, dBm)
     def node_post_supported(self, Ks, Kc, Cc, L, Ho) -> bool:

@@ -291,7 +291,8 @@ struct SmallFwd {
     SmallGraph g;
     const float *X, *H, *Tc, *Wg, *bg, *Wc, *bc;
     float *U, *R, *Cand, *Hnew, *RH, *Zg, *Zc;
-    float* Z0;                                   // optional: the slab [H | X | 0] itself, for the graph-gradient products of learned graphs
+    float *Z0, *Z0c, *Z1c;                       // optional (learned graphs: operands of the graph-gradient products): the slabs [H | X | 0],
+                                                 // [R*H | X | 0] and [S.(R*H) | S.X | 0]
     int N, C, cin, rpt, tiles;
     int phase;                                   // 0: the whole cell in this launch (one workgroup per sample); 1..4: that phase only, the sample's
 };                                               // rows split over gridDim.y workgroups -- the launch boundary is the barrier between phases
@@ -435,6 +436,17 @@ __global__ __launch_bounds__(SF_THREADS) void small_fwd_kernel(SmallFwd a) {
     }
     sync();
     SC_PHASE_END(3);
+
+    if (a.Z0c != nullptr && a.Z0 != nullptr && runs(4)) {    // (learned graphs only; R*H, Zc, Zg and Z0 are complete: two barriers / launches ago)
+        const float* Z0b = a.Z0 + r0 * LP;
+        float* Z0cb = a.Z0c + r0 * LP;
+        float* Z1cb = a.Z1c + r0 * LP;
+        for (int item = t + SF_THREADS * split; item < NC * (LP / 4); item += SF_THREADS * splits) {
+            const int row = item / (LP / 4), q = item - row * (LP / 4);
+            st4(Z0cb + (unsigned)row * LP + 4 * q, q < 4 ? ld4(RHb + (unsigned)row * SC_H + 4 * q) : ld4(Z0b + (unsigned)row * LP + 4 * q));
+            st4(Z1cb + (unsigned)row * LP + 4 * q, q < 4 ? ld4(Zcb + (unsigned)row * SC_H + 4 * q) : ld4(Zgb + (unsigned)row * LP + 4 * q));
+        }
+    }
 
     // 4: candidate + blend
     if (runs(4)) {
@@ -672,7 +684,8 @@ struct SmallBwd {
     SmallGraph g;                                // CSR of Gs (the transpose of the forward's)
     const float *X, *H, *Tc, *Wg, *Wc, *U, *R, *Cand, *RH, *Zg, *Zc, *dHnew;
     float *dX, *dH, *dP, *ws;
-    float *dZ1c, *dZ1g, *dYg;                    // optional dumps for learned graphs: gradients of the two aggregated slabs, gate pre-activation gradients
+    float *dZ1c, *dZ1g, *dYg, *dYc;              // optional dumps for learned graphs: gradients of the two aggregated slabs, gate and candidate
+                                                 // pre-activation gradients
     int N, C, cin, rpt, tiles, acc_x, acc_h, has_bg, has_bc;
     int phase;                                   // as in SmallFwd
     long long P;                                 // floats per row of dP: [dWg | dbg (32) | dWc | dbc (16)]; SB_WAVES / 4 rows per sample
@@ -762,6 +775,12 @@ __global__ __launch_bounds__(SB_THREADS) void small_bwd_kernel(SmallBwd a) {
                     gu[i] = d[i] * (cd[i] - hh[i]) * u[i] * (1.f - u[i]);
                     gr[i] = s[i] * hh[i] * rr[i] * (1.f - rr[i]);
                     dh[i] = fmaf(d[i], 1.f - u[i], s[i] * rr[i]);
+                }
+                if (a.dYc != nullptr) {
+                    f32x4 yc;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) yc[i] = d[i] * u[i] * (1.f - cd[i] * cd[i]);
+                    st4(a.dYc + (r0 + (unsigned)row) * SC_H + 4 * q, yc);
                 }
                 st4(dYg + (unsigned)row * 32 + 4 * q, gu);
                 st4(dYg + (unsigned)row * 32 + 16 + 4 * q, gr);
@@ -870,7 +889,7 @@ extern "C" int stc_cell_small_fwd_f32(const int32_t* rowptr, const int32_t* coli
                                       int32_t graph_is_dense, const float* X,
                                       int32_t cin, const float* H, const float* Tc, int32_t Kc, const float* Wg, const float* bg, const float* Wc,
                                       const float* bc, float* U, float* R, float* Cand, float* Hnew, float* RH, float* Zg, float* Zc, float* Z0,
-                                      int32_t phase, int32_t splits, int32_t batch, int32_t C, void* stream) {
+                                      float* Z0c, float* Z1c, int32_t phase, int32_t splits, int32_t batch, int32_t C, void* stream) {
     SC_COMMON_CHECKS("stc_cell_small_fwd_f32")
     STC_REQUIRE(rowptr && (nnz == 0 || (colidx && val)) && X && H && Tc && Wg && Wc && U && R && Cand && Hnew && RH && Zg && Zc, STC_EINVAL,
                 "stc_cell_small_fwd_f32: null operand");
@@ -882,8 +901,10 @@ extern "C" int stc_cell_small_fwd_f32(const int32_t* rowptr, const int32_t* coli
     STC_REQUIRE(phase >= 0 && phase <= 4 && splits >= 1 && splits <= 64 && (phase != 0 || splits == 1), STC_EINVAL,
                 "stc_cell_small_fwd_f32: phase %d / splits %d (phase 0 = the whole cell, one workgroup per sample; 1..4 = one phase over `splits` workgroups)",
                 phase, splits);
-    SmallFwd a{{rowptr, colidx, val, nnz}, X, H, Tc, Wg, bg, Wc, bc, U, R, Cand, Hnew, RH, Zg, Zc, Z0, n_nodes, C, cin, rpt, (n_nodes + npt - 1) / npt,
-               phase};
+    STC_REQUIRE((Z0c == nullptr) == (Z1c == nullptr) && (Z0c == nullptr || Z0 != nullptr) && stc::aligned16(Z0c) && stc::aligned16(Z1c), STC_EINVAL,
+                "stc_cell_small_fwd_f32: Z0c and Z1c come together, with Z0, 16-byte aligned");
+    SmallFwd a{{rowptr, colidx, val, nnz}, X, H, Tc, Wg, bg, Wc, bc, U, R, Cand, Hnew, RH, Zg, Zc, Z0, Z0c, Z1c, n_nodes, C, cin, rpt,
+               (n_nodes + npt - 1) / npt, phase};
     const size_t fixed = (size_t)fwd_lds_fixed<2>() * 4, planes = (size_t)n_nodes * C * (plane_stride(xq) + SQ) * 4;
     const bool dense = phase == 0 && graph_is_dense && nnz == (long long)n_nodes * n_nodes && fixed + planes <= SC_LDS_BUDGET;
     const size_t staged = fixed + planes + (dense ? 0 : graph_lds_bytes(n_nodes, nnz));
@@ -904,8 +925,8 @@ extern "C" int stc_cell_small_bwd_f32(const int32_t* rowptr, const int32_t* coli
                                       int32_t cin, const float* H, const float* Tc, int32_t Kc, const float* Wg, const float* Wc, const float* U,
                                       const float* R, const float* Cand, const float* RH, const float* Zg, const float* Zc, const float* dHnew,
                                       float* dX, int32_t accumulate_x, float* dH, int32_t accumulate_h, float* dparams, int64_t params_ld,
-                                      int32_t has_bg, int32_t has_bc, float* dZ1c, float* dZ1g, float* dYg, void* workspace, size_t workspace_bytes,
-                                      int32_t phase, int32_t splits, int32_t batch, int32_t C, void* stream) {
+                                      int32_t has_bg, int32_t has_bc, float* dZ1c, float* dZ1g, float* dYg, float* dYc, void* workspace,
+                                      size_t workspace_bytes, int32_t phase, int32_t splits, int32_t batch, int32_t C, void* stream) {
     SC_COMMON_CHECKS("stc_cell_small_bwd_f32")
     STC_REQUIRE(rowptr && (nnz == 0 || (colidx && val)) && X && H && Tc && Wg && Wc && U && R && Cand && RH && Zg && Zc && dHnew && dparams && workspace,
                 STC_EINVAL, "stc_cell_small_bwd_f32: null operand");
@@ -921,7 +942,7 @@ extern "C" int stc_cell_small_bwd_f32(const int32_t* rowptr, const int32_t* coli
                 "stc_cell_small_bwd_f32: dHnew, dX and dH must be distinct buffers");
     const int npt = 16 / C, rpt = npt * C;
     SmallBwd a{{rowptr, colidx, val, nnz}, X, H, Tc, Wg, Wc, U, R, Cand, RH, Zg, Zc, dHnew, dX, dH, dparams, static_cast<float*>(workspace),
-               dZ1c, dZ1g, dYg, n_nodes, C, cin, rpt, (n_nodes + npt - 1) / npt, accumulate_x, accumulate_h, has_bg, has_bc, phase, params_ld};
+               dZ1c, dZ1g, dYg, dYc, n_nodes, C, cin, rpt, (n_nodes + npt - 1) / npt, accumulate_x, accumulate_h, has_bg, has_bc, phase, params_ld};
     STC_REQUIRE(phase >= 0 && phase <= 4 && splits >= 1 && splits <= 64 && (phase != 0 || splits == 1), STC_EINVAL,
                 "stc_cell_small_bwd_f32: phase %d / splits %d", phase, splits);
     const size_t fixed = (size_t)bwd_lds_fixed<2>() * 4, planes = (size_t)n_nodes * C * LP * 4;

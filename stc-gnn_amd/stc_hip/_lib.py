@@ -41,7 +41,7 @@ EXPORTS = (
     'stc_cell_bwd_planar_supported', 'stc_cell_bwd_planar_workspace_bytes', 'stc_cell_bwd_planar_f32',
     'stc_cell_planar_k_supported', 'stc_cell_gates_fwd_planar_k_f32', 'stc_cell_cand_fwd_planar_k_f32', 'stc_cell_gates_bwd_planar_k_f32',
     'stc_cell_cand_bwd_planar_k_f32',
-    'stc_cell_small_supported', 'stc_cell_small_workspace_bytes', 'stc_cell_small_param_rows', 'stc_cell_small_fwd_f32', 'stc_cell_small_bwd_f32',
+    'stc_cell_small_supported', 'stc_cell_small_workspace_bytes', 'stc_cell_small_param_rows', 'stc_graph_grad_f32', 'stc_mix_grad_f32', 'stc_cell_small_fwd_f32', 'stc_cell_small_bwd_f32',
     'stc_gru_gates_fwd_f32', 'stc_gru_gates_bwd_f32', 'stc_gru_blend_fwd_f32', 'stc_gru_blend_bwd_f32',
     'stc_head_fwd_f32', 'stc_head_bwd_workspace_bytes', 'stc_head_bwd_f32',
     'stc_axpy_f32', 'stc_concat2_f32', 'stc_split2_f32',
@@ -69,9 +69,11 @@ def _declare(lib):
         'stc_csr_spmm_bf16': [_p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _f32, _p],
         'stc_bcsr_spmm_bf16': [_p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _f32, _p],
         'stc_dense_agg_f32': [_p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _f32, _p],
-        'stc_cell_small_fwd_f32': [_p, _p, _p, _i32, _i32, _i32, _p, _i32, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p],
+        'stc_cell_small_fwd_f32': [_p, _p, _p, _i32, _i32, _i32, _p, _i32, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p],
+        'stc_graph_grad_f32': [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p],
+        'stc_mix_grad_f32': [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p],
         'stc_cell_small_bwd_f32': [_p, _p, _p, _i32, _i32, _i32, _p, _i32, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _i32, _p, _i64, _i32, _i32,
-                                   _p, _p, _p, _p, C.c_size_t, _i32, _i32, _i32, _i32, _p],
+                                   _p, _p, _p, _p, _p, C.c_size_t, _i32, _i32, _i32, _i32, _p],
         'stc_csr_sddmm_f32': [_p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _i32, _p],
         'stc_cheby_dense_fwd_f32': [_p, _i32, _i32, _p, _p],
         'stc_cheby_dense_bwd_f32': [_p, _p, _p, _i32, _i32, _p, _p],
@@ -835,7 +837,8 @@ class HipKernels:
         self._same_device(H, X, Tc, Wg, Wc, rowptr, colidx, val, Zg, Zc, *planes.values())
         return B, N, Cc, cin, Kc
 
-    def cell_small_fwd(self, rowptr, colidx, val, X, H, Tc, Wg, bg, Wc, bc, U, R, Cand, Hnew, RH, Zg, Zc, checked=True, Z0=None, splits=1):
+    def cell_small_fwd(self, rowptr, colidx, val, X, H, Tc, Wg, bg, Wc, bc, U, R, Cand, Hnew, RH, Zg, Zc, checked=True, Z0=None, splits=1, Z0c=None,
+                       Z1c=None):
         """One STC_Cell step (reference STC_GNN.py:65-79) in one launch: ``stc_cell_small_fwd_f32``.  (rowptr, colidx, val): CSR of Gs^T.
         ``checked=False``: the caller built every buffer itself from shapes it already validated (the cell-graph executor).
         ``Z0`` (optional, like Zg): receives the slab [H | Xt | 0] (learned graphs: operand of the graph-gradient product).
@@ -843,9 +846,10 @@ class HipKernels:
         the chip with one workgroup per sample (``cell_small_splits``)."""
         if checked:
             B, N, Cc, cin, Kc = self._small_shapes('cell_small_fwd', rowptr, colidx, val, X, H, Tc, Wg, Wc, dict(U=U, R=R, Cand=Cand, Hnew=Hnew, RH=RH), Zg, Zc)
-            if Z0 is not None:
-                self._f32('cell_small_fwd.Z0', Z0, tuple(Zg.shape))
-                self._same_device(H, Z0)
+            for name, t_ in (('Z0', Z0), ('Z0c', Z0c), ('Z1c', Z1c)):
+                if t_ is not None:
+                    self._f32('cell_small_fwd.' + name, t_, tuple(Zg.shape))
+                    self._same_device(H, t_)
             for name, b_, n in (('bg', bg, 32), ('bc', bc, 16)):
                 if b_ is not None:
                     self._f32('cell_small_fwd.' + name, b_, (n,))
@@ -855,7 +859,7 @@ class HipKernels:
         for phase in ((0,) if splits == 1 else (1, 2, 3, 4)):
             self._launch('stc_cell_small_fwd_f32', H, rowptr.data_ptr(), colidx.data_ptr(), val.data_ptr(), N, val.numel(), dense, X.data_ptr(), cin,
                          H.data_ptr(), Tc.data_ptr(), Kc, Wg.data_ptr(), _ptr(bg), Wc.data_ptr(), _ptr(bc), U.data_ptr(), R.data_ptr(), Cand.data_ptr(),
-                         Hnew.data_ptr(), RH.data_ptr(), Zg.data_ptr(), Zc.data_ptr(), _ptr(Z0), phase, splits, B, Cc,
+                         Hnew.data_ptr(), RH.data_ptr(), Zg.data_ptr(), Zc.data_ptr(), _ptr(Z0), _ptr(Z0c), _ptr(Z1c), phase, splits, B, Cc,
                          nbytes=(4 * B * N * Cc * (cin + 16 * 8 + 2 * self.cell_small_zg_width(cin))) // (1 if splits == 1 else 4))
 
     @staticmethod
@@ -868,7 +872,7 @@ class HipKernels:
         return g
 
     def cell_small_bwd(self, rowptr, colidx, val, X, H, Tc, Wg, Wc, U, R, Cand, RH, Zg, Zc, dHnew, dX, accumulate_x, dH, accumulate_h,
-                       dparams, has_bg, has_bc, checked=True, dZ1c=None, dZ1g=None, dYg=None, splits=1):
+                       dparams, has_bg, has_bc, checked=True, dZ1c=None, dZ1g=None, dYg=None, splits=1, dYc=None):
         """Autograd of ``cell_small_fwd`` in one launch (``stc_cell_small_bwd_f32``).  (rowptr, colidx, val): CSR of Gs.  dX / dH may be
         None; ``accumulate_*``: add to what the buffer holds.  ``dparams`` (B * cell_small_param_rows, P >= cell_small_params):
         parameter-gradient partials (one row per sample and wave), ADDED to."""
@@ -881,7 +885,7 @@ class HipKernels:
             if dparams.dim() != 2 or dparams.shape[0] != B * splits * self.cell_small_param_rows or dparams.shape[1] < self.cell_small_params(2, Kc, cin):
                 raise StcError(f'cell_small_bwd: dparams {tuple(dparams.shape)}, expected ({B * splits * self.cell_small_param_rows}, '
                                f'>= {self.cell_small_params(2, Kc, cin)})')
-            for name, t_, shape in (('dZ1c', dZ1c, tuple(Zg.shape)), ('dZ1g', dZ1g, tuple(Zg.shape)), ('dYg', dYg, (B, N * Cc, 32))):
+            for name, t_, shape in (('dZ1c', dZ1c, tuple(Zg.shape)), ('dZ1g', dZ1g, tuple(Zg.shape)), ('dYg', dYg, (B, N * Cc, 32)), ('dYc', dYc, (B, N * Cc, 16))):
                 if t_ is not None:
                     self._f32('cell_small_bwd.' + name, t_, shape)
             self._same_device(H, dHnew, dparams, dZ1c, dZ1g, dYg, *([dX] if dX is not None else []))
@@ -894,9 +898,44 @@ class HipKernels:
             self._launch('stc_cell_small_bwd_f32', H, rowptr.data_ptr(), colidx.data_ptr(), val.data_ptr(), N, val.numel(), dense, X.data_ptr(), cin,
                          H.data_ptr(), Tc.data_ptr(), Kc, Wg.data_ptr(), Wc.data_ptr(), U.data_ptr(), R.data_ptr(), Cand.data_ptr(), RH.data_ptr(),
                          Zg.data_ptr(), Zc.data_ptr(), dHnew.data_ptr(), _ptr(dX), int(bool(accumulate_x)), _ptr(dH), int(bool(accumulate_h)),
-                         dparams.data_ptr(), dparams.shape[1], int(bool(has_bg)), int(bool(has_bc)), _ptr(dZ1c), _ptr(dZ1g), _ptr(dYg),
+                         dparams.data_ptr(), dparams.shape[1], int(bool(has_bg)), int(bool(has_bc)), _ptr(dZ1c), _ptr(dZ1g), _ptr(dYg), _ptr(dYc),
                          ws.data_ptr(), ws.numel(), phase, splits, B, Cc,
                          nbytes=(4 * B * N * Cc * (2 * cin + 16 * 9 + 5 * self.cell_small_zg_width(cin) + 64)) // (1 if splits == 1 else 4))
+
+    GRAD_CHUNKS = 96             # float64 partials of a graph-gradient product (x tile groups = workgroups; every partial is written and re-read)
+
+    def _grad_operands(self, what, A, Bm, cell0, cell_step, n_sel, N):
+        for name, t_ in (('A', A), ('B', Bm)):
+            self._f32(f'{what}.{name}', t_)
+            if t_.dim() != 4:
+                raise StcError(f'{what}.{name}: expected (cells, batch, N*C, width), got {tuple(t_.shape)}')
+        if A.shape[:3] != Bm.shape[:3] or A.shape[2] % N:
+            raise StcError(f'{what}: operands {tuple(A.shape)} / {tuple(Bm.shape)} do not describe the same cells, samples and N = {N} nodes')
+        if n_sel < 0 or cell0 < 0 or cell_step < 1 or (n_sel and cell0 + (n_sel - 1) * cell_step >= A.shape[0]):
+            raise StcError(f'{what}: cells {cell0} + {cell_step} * [0, {n_sel}) outside the buffer of {A.shape[0]} cells')
+        self._same_device(A, Bm)
+        return A.shape[1], A.shape[2] // N
+
+    def graph_grad(self, A, Bm, cell0, cell_step, n_sel, N):
+        """(N, N) float64:  sum over the selected cells and samples of  A_g . B_g^T  with A, B (cells, batch, N*C, width) read as (N, C*width)
+        per plane -- the dGs^T piece of a learned dense graph (``stc_graph_grad_f32``)."""
+        batch, Cc = self._grad_operands('graph_grad', A, Bm, cell0, cell_step, n_sel, N)
+        if A.shape[3] != Bm.shape[3]:
+            raise StcError(f'graph_grad: widths {A.shape[3]} / {Bm.shape[3]} differ')
+        chunks = max(1, min(256, n_sel * batch))          # (an N x N float64 partial is small: one workgroup per ~2 planes)
+        part = torch.empty(chunks, N, N, dtype=torch.float64, device=A.device)
+        self._launch('stc_graph_grad_f32', A, A.data_ptr(), Bm.data_ptr(), part.data_ptr(), chunks, cell0, cell_step, n_sel, batch, N, Cc * A.shape[3])
+        return part.sum(0)
+
+    def mix_grad(self, A, Bm, cell0, cell_step, n_sel, N):
+        """(C*wa, C*wb) float64:  sum over the selected cells and samples of  A_g^T . B_g  (contraction over the N nodes) -- Q = Z^T . dY of one
+        slab of one convolution (``stc_mix_grad_f32``)."""
+        batch, Cc = self._grad_operands('mix_grad', A, Bm, cell0, cell_step, n_sel, N)
+        Fa, Fb = Cc * A.shape[3], Cc * Bm.shape[3]
+        chunks = max(1, min(self.GRAD_CHUNKS, n_sel * batch))
+        part = torch.empty(chunks, Fa, Fb, dtype=torch.float64, device=A.device)
+        self._launch('stc_mix_grad_f32', A, A.data_ptr(), Bm.data_ptr(), part.data_ptr(), chunks, cell0, cell_step, n_sel, batch, N, Fa, Fb)
+        return part.sum(0)
 
     # ---- planar cell convolutions of Chebyshev order K = 3 ------------------------------------------------
     def cell_planar_k_supported(self, K, Cc, h) -> bool:

@@ -49,6 +49,23 @@ def _alias(base: torch.Tensor) -> torch.Tensor:
     return t
 
 
+def _layout(schedule, cin, n_cells, outputs):
+    """Where every cell's tensors live: slot in the output stack or the inner-state buffer, position inside its width group (cells whose
+    input is 16 columns wide / 1..4 columns wide keep their aggregates in two buffers of different row widths)."""
+    out_slot = {j: i for i, j in enumerate(outputs)}
+    if len(out_slot) != len(outputs):
+        raise ValueError('stc_cell_graph: duplicate output cells')
+    pos, counts, inner_slot, nxt = [], [0, 0], {}, 0
+    for j in range(n_cells):
+        wide = cin[j] == H16
+        pos.append((wide, counts[wide]))
+        counts[wide] += 1
+        if j not in out_slot:
+            inner_slot[j] = nxt
+            nxt += 1
+    return out_slot, inner_slot, pos, counts
+
+
 class _StcSmallGraph(Function):
     """schedule[j] = (stack, ('ext', i) | ('cell', k), ('ext', i) | ('cell', k)): parameter set, source of Xt, source of H."""
 
@@ -72,34 +89,16 @@ class _StcSmallGraph(Function):
             rows = Ks * Tc.shape[0] * (w + H16)
             if Wg.shape != (rows, 2 * H16) or Wc.shape != (rows, H16) or (hs[0] == 'ext' and ext[hs[1]].shape[-1] != H16):
                 raise ValueError(f'stc_cell_graph: parameter set {s_id} does not fit an input of {w} + {H16} columns')
-        out_slot = {j: i for i, j in enumerate(outputs)}
-        if len(out_slot) != len(outputs):
-            raise ValueError('stc_cell_graph: duplicate output cells')
+        out_slot, inner_slot, pos, counts = _layout(schedule, cin, n_cells, outputs)
         out_stack = ref.new_empty(len(outputs), B, N, C, H16)        # the requested states are produced in place, stacked
         inner = ref.new_empty(max(1, n_cells - len(outputs)), B, N, C, H16)
         planes = ref.new_empty(5, n_cells, B, N, C, H16)             # U, R, Cand, R*H, S.(R*H) of every cell
-        wide = [j for j in range(n_cells) if cin[j] == H16]
-        zg_w = ref.new_empty(max(1, len(wide)), B, N * C, k.cell_small_zg_width(H16))
-        zg_n = ref.new_empty(max(1, n_cells - len(wide)), B, N * C, k.cell_small_zg_width(1))
         learned = bool(ctx.needs_input_grad[6] or ctx.needs_input_grad[7])
-        z0_w = torch.empty_like(zg_w) if learned else zg_w.new_empty(0)
-        z0_n = torch.empty_like(zg_n) if learned else zg_n.new_empty(0)
+        # per width group: the aggregate Zg of every cell and, for learned graphs, the slabs Z0, Z0c, Z1c the graph-gradient products read
+        widths = (k.cell_small_zg_width(1), k.cell_small_zg_width(H16))
+        slabs = [ref.new_empty(4 if learned else 1, max(1, counts[w]), B, N * C, widths[w]) for w in (0, 1)]
         out_alias = _alias(out_stack)
-        state, zg, z0, nxt, wi, ni = [], [], [], 0, 0, 0
-        for j in range(n_cells):
-            if j in out_slot:
-                state.append(out_alias[out_slot[j]])
-            else:
-                state.append(inner[nxt])
-                nxt += 1
-            if cin[j] == H16:
-                zg.append(zg_w[wi])
-                z0.append(z0_w[wi] if learned else None)
-                wi += 1
-            else:
-                zg.append(zg_n[ni])
-                z0.append(z0_n[ni] if learned else None)
-                ni += 1
+        state = [out_alias[out_slot[j]] if j in out_slot else inner[inner_slot[j]] for j in range(n_cells)]
         U, R, Cand, RH, Zc = (p.unbind(0) for p in planes.unbind(0))
         source = lambda src: ext[src[1]] if src[0] == 'ext' else state[src[1]]
         # Few samples: the BACKWARD runs as four launches per cell step (one per phase) over several workgroups per sample instead of one
@@ -110,9 +109,11 @@ class _StcSmallGraph(Function):
         fwd_splits = splits if (N * C > k.SMALL_STAGED_ROWS and op.nnz != N * N) else 1    # (samples too large to stage: the forward is split as well)
         for j, (s_id, x, hs) in enumerate(schedule):
             Wg, bg, Wc, bc = stacks[s_id]
+            w, i = pos[j]
+            extra = dict(Z0=slabs[w][1, i], Z0c=slabs[w][2, i], Z1c=slabs[w][3, i]) if learned else {}
             k.cell_small_fwd(op.fwd_rowptr, op.fwd_colidx, fwd_val, source(x), source(hs), Tc, Wg, bg, Wc, bc, U[j], R[j], Cand[j], state[j], RH[j],
-                             zg[j], Zc[j].view(B, N * C, H16), checked=False, Z0=z0[j], splits=fwd_splits)
-        ctx.save_for_backward(Tc, out_alias, inner, planes, zg_w, zg_n, z0_w, z0_n, *ext, *[p for st in stacks for p in st if p is not None])
+                             slabs[w][0, i], Zc[j].view(B, N * C, H16), checked=False, splits=fwd_splits, **extra)
+        ctx.save_for_backward(Tc, out_alias, inner, planes, slabs[0], slabs[1], *ext, *[p for st in stacks for p in st if p is not None])
         ctx.meta = (k, op, Ks, list(schedule), tuple(outputs), cin, [tuple(p is not None for p in st) for st in stacks], (B, N, C), len(ext), splits)
         ctx.out_stack_ref, ctx.out_stack_version = weakref.ref(out_stack), out_stack._version
         return out_stack
@@ -125,7 +126,8 @@ class _StcSmallGraph(Function):
         if stack is not None and stack._version != ctx.out_stack_version:
             raise RuntimeError('stc_cell_graph: the returned state stack was modified in place after the forward pass; the states saved for '
                                'backward share its storage (treat the stack as read-only, or clone it before editing)')
-        Tc, out_alias, inner, planes, zg_w, zg_n, z0_w, z0_n, *rest = ctx.saved_tensors
+        Tc, out_alias, inner, planes, slabs_n, slabs_w, *rest = ctx.saved_tensors
+        slabs = (slabs_n, slabs_w)
         need_Tc, need_val = ctx.needs_input_grad[6], ctx.needs_input_grad[7]
         learned = bool(need_Tc or need_val)
         ext, rest = rest[:n_ext], rest[n_ext:]
@@ -136,31 +138,19 @@ class _StcSmallGraph(Function):
                 st.append(rest.pop(0) if p else None)
             stacks.append(st)
         n_cells = len(schedule)
-        out_slot = {j: i for i, j in enumerate(outputs)}
-        # learned graphs: what the launches leave for the graph-gradient products (zeros where a cell is never reached)
-        dzc_w, dzg_w = (torch.zeros_like(zg_w), torch.zeros_like(zg_w)) if learned else (None, None)
-        dzc_n, dzg_n = (torch.zeros_like(zg_n), torch.zeros_like(zg_n)) if learned else (None, None)
-        dyg = Tc.new_zeros(n_cells, B, N * C, 2 * H16) if learned else None
-        state, zg, z0, dzc, dzg, nxt, wi, ni = [], [], [], [], [], 0, 0, 0
-        for j in range(n_cells):
-            if j in out_slot:
-                state.append(out_alias[out_slot[j]])
-            else:
-                state.append(inner[nxt])
-                nxt += 1
-            wide = cin[j] == H16
-            i = wi if wide else ni
-            zg.append((zg_w if wide else zg_n)[i])
-            z0.append((z0_w if wide else z0_n)[i] if learned else None)
-            dzc.append((dzc_w if wide else dzc_n)[i] if learned else None)
-            dzg.append((dzg_w if wide else dzg_n)[i] if learned else None)
-            wi, ni = wi + wide, ni + (not wide)
+        out_slot, inner_slot, pos, counts = _layout(schedule, cin, n_cells, outputs)
+        state = [out_alias[out_slot[j]] if j in out_slot else inner[inner_slot[j]] for j in range(n_cells)]
+        # learned graphs: what the launches leave for the graph-gradient products, per width group (zeros where a cell is never reached):
+        # the gradients of the two aggregated slabs, the gate and candidate pre-activation gradients
+        dslab = [Tc.new_zeros(2, max(1, counts[w]), B, N * C, slabs[w].shape[-1]) for w in (0, 1)] if learned else None
+        dyg = [Tc.new_zeros(max(1, counts[w]), B, N * C, 2 * H16) for w in (0, 1)] if learned else None
+        dyc = [Tc.new_zeros(max(1, counts[w]), B, N * C, H16) for w in (0, 1)] if learned else None
         U, R, Cand, RH, Zc = (p.unbind(0) for p in planes.unbind(0))
         source = lambda src: ext[src[1]] if src[0] == 'ext' else state[src[1]]
         Kc = Tc.shape[0]
         P = max(k.cell_small_params(Ks, Kc, w) for w in cin)
         dP = Tc.new_zeros(len(stacks), B * splits * k.cell_small_param_rows, P)   # parameter-gradient partials, every cell adds to its set's rows
-        G = (Tc.new_zeros if learned else Tc.new_empty)(n_cells, B, N, C, H16)      # gradient owed to every cell's state
+        G = Tc.new_empty(n_cells, B, N, C, H16)                      # gradient owed to every cell's state
         owed = [False] * n_cells
         grad_stack = _c(grad_stack)
         for i, j in enumerate(outputs):
@@ -184,9 +174,11 @@ class _StcSmallGraph(Function):
                 else:
                     dX, acc_x = Gv[x[1]], owed[x[1]]
                     owed[x[1]] = True
-            k.cell_small_bwd(op.bwd_rowptr, op.bwd_colidx, op.bwd_val, source(x), source(hs), Tc, Wg, Wc, U[j], R[j], Cand[j], RH[j], zg[j],
+            w, i = pos[j]
+            extra = dict(dZ1c=dslab[w][0, i], dZ1g=dslab[w][1, i], dYg=dyg[w][i], dYc=dyc[w][i]) if learned else {}
+            k.cell_small_bwd(op.bwd_rowptr, op.bwd_colidx, op.bwd_val, source(x), source(hs), Tc, Wg, Wc, U[j], R[j], Cand[j], RH[j], slabs[w][0, i],
                              Zc[j].view(B, N * C, H16), Gv[j], dX, acc_x, dH, acc_h, dPv[s_id], bg is not None, bc is not None, checked=False,
-                             dZ1c=dzc[j], dZ1g=dzg[j], dYg=None if dyg is None else dyg[j], splits=splits)
+                             splits=splits, **extra)
             if late is not None:
                 Gv[late].add_(dX)
         sums = dP.sum(1)                                             # (sets, P)
@@ -202,56 +194,50 @@ class _StcSmallGraph(Function):
             flat += [dWg, dbg if st[1] is not None else None, dWc, dbc if st[3] is not None else None]
         dT = dS = None
         if learned:
-            dT, dS = _graph_gradients(Tc, Ks, stacks, schedule, cin, (B, N, C), planes, G, zg, z0, dzc, dzg, dyg, need_Tc, need_val)
+            dT, dS = _graph_gradients(k, Tc, Ks, stacks, schedule, cin, pos, counts, (B, N, C), slabs, dslab, dyg, dyc, need_Tc, need_val)
         return (None,) * 6 + (dT, dS) + (None,) * n_ext + tuple(flat)
 
 
-def _graph_gradients(Tc, Ks, stacks, schedule, cin, dims, planes, G, zg, z0, dzc, dzg, dyg, need_Tc, need_val):
-    """(dT_c, d fwd_val) of a learned-graph backward pass from what the cell launches left (module docstring).  Slabs are in the
-    kernels' column order [H (16) | X (cin) | 0]; W's rows are re-ordered to match.  Per parameter set a handful of LARGE plain GEMMs
-    (contraction over every cell, sample and node at once -- as batched products with a sum they cost 5 ms per step at the SF shape):
-      d fwd_val = sum  D^T-style products  (N, K) x (K, N),  K = cells * B * C * LP;
-      dT_c[c, d] = < W[(ks, c)], Q_ks[c, :, d, :] >  with  Q_ks = Z_ks^T . dY  ((C * LP, R) x (R, C * Ho), R = cells * B * N)."""
+def _graph_gradients(k, Tc, Ks, stacks, schedule, cin, pos, counts, dims, slabs, dslab, dyg, dyc, need_Tc, need_val):
+    """(dT_c, d fwd_val) of a learned-graph backward pass from what the cell launches left (module docstring), per width group (index 0:
+    narrow inputs, 1: 16-column inputs).  slabs[w] = (Zg, Z0, Z0c, Z1c), dslab[w] = (dZ1c, dZ1g) of every cell of the group, in the kernels'
+    column order [H (16) | X (cin) | 0]; W's rows are re-ordered to match.  The sums over cells and samples run in ``graph_grad`` /
+    ``mix_grad`` (stc_graph_grad_f32 / stc_mix_grad_f32: fp32 matrix products per plane, float64 accumulation):
+      d fwd_val = sum_cells [dZ1g x Z0 + dZ1c x Z0c]                                      (every cell of a width at once)
+      dT_c[c, d] = < W[(ks, c)], Q_ks[c, :, d, :] >,  Q_ks = Z_ks^T . dY                  (per parameter set and convolution)."""
     B, N, C = dims
     Kc = Tc.shape[0]
-    dT = torch.zeros_like(Tc) if need_Tc else None
-    dS = Tc.new_zeros(N, N) if need_val else None
-    for s_id, (Wg, bg, Wc, bc) in enumerate(stacks):
-        cells = [j for j, sc in enumerate(schedule) if sc[0] == s_id]
-        if not cells:
-            continue
-        w, k_ = cin[cells[0]], len(cells)
-        stack = lambda views: torch.stack([views[j] for j in cells])               # (k, B, N*C, LP); (no index tensor: nothing here may come
-        #                                                                            from host memory -- the step may be under HIP-graph capture)
-        Z0, Zg, dZg, dZc = stack(z0), stack(zg), stack(dzg), stack(dzc)
-        LP = Z0.shape[-1]
-        U, Cand, RH, Zc = (stack(planes[i]) for i in (0, 2, 3, 4))                  # (k, B, N, C, 16)
-        Z0c = Z0.clone()                                                          # the candidate's slab 0: [R*H | X | 0]
-        Z0c.view(k_, B, N, C, LP)[..., :H16] = RH
-        if need_val:
-            by_node = lambda t: t.view(k_ * B, N, C * LP).transpose(0, 1).reshape(N, -1)       # (N, K): a node's row = every (cell, sample, c, l)
-            dS.addmm_(by_node(dZg), by_node(Z0).t())
-            dS.addmm_(by_node(dZc), by_node(Z0c).t())
-        if need_Tc:
-            L = w + H16
-            Z1c = Zg.clone()                                                      # the candidate's slab 1: [S.(R*H) | S.X | 0]
-            Z1c.view(k_, B, N, C, LP)[..., :H16] = Zc
-            dCpre = stack(G) * U * (1.0 - Cand * Cand)
-            rows = lambda t: t.reshape(k_ * B * N, -1)                              # (R, C * width)
-            for s0, s1, W, dY in ((Z0, Zg, Wg, stack(dyg)), (Z0c, Z1c, Wc, dCpre)):
+    dT = torch.zeros(Tc.shape, dtype=torch.float64, device=Tc.device) if need_Tc else None
+    dS = torch.zeros(N, N, dtype=torch.float64, device=Tc.device) if need_val else None
+    if need_val:
+        for w in (0, 1):
+            if counts[w]:
+                dS += k.graph_grad(dslab[w][1], slabs[w][1], 0, 1, counts[w], N) + k.graph_grad(dslab[w][0], slabs[w][2], 0, 1, counts[w], N)
+    if need_Tc:
+        for s_id, (Wg, bg, Wc, bc) in enumerate(stacks):
+            cells = [j for j, sc in enumerate(schedule) if sc[0] == s_id]
+            if not cells:
+                continue
+            w, first = pos[cells[0]]
+            where = [pos[j][1] for j in cells]
+            step = where[1] - where[0] if len(where) > 1 else 1
+            cw, LP = cin[cells[0]], slabs[w].shape[-1]
+            L = cw + H16
+            operands = ((slabs[w][1], slabs[w][0], Wg, dyg[w]), (slabs[w][2], slabs[w][3], Wc, dyc[w]))
+            if step < 1 or any(b_ - a_ != step for a_, b_ in zip(where, where[1:])):
+                # (a schedule STCGNN never builds: the set's cells are not evenly spaced inside their width group -- gather them)
+                pick = lambda t: torch.stack([t[i] for i in where])
+                operands = tuple((pick(s0), pick(s1), W, pick(dY)) for s0, s1, W, dY in operands)
+                first, step = 0, 1
+            for s0, s1, W, dY in operands:
                 Ho = W.shape[1]
                 Wv = W.view(Ks, Kc, L, Ho)
                 Wp = W.new_zeros(Ks, Kc, LP, Ho)
-                Wp[:, :, :H16] = Wv[:, :, w:]
-                Wp[:, :, H16:H16 + w] = Wv[:, :, :w]
-                # float64 for this one product: R = 10^4 .. 10^5 terms per entry with heavy cancellation, and dT_c feeds MGP_Gen's own
-                # ill-conditioned backward (in fp32 the SF golden's dGc came out at 1.1e-5 instead of 8e-7).  As one batched product per
-                # (cell, sample) summed afterwards: a single 160 x R x 160 DGEMM has four output tiles and no split-K (3 ms each).
-                per = lambda t: t.reshape(k_ * B, N, -1).double()                   # (cells * B, N, C * width)
-                dYp = per(dY)
-                Q = torch.stack([torch.bmm(per(s0).transpose(1, 2), dYp).sum(0), torch.bmm(per(s1).transpose(1, 2), dYp).sum(0)]).view(Ks, C, LP, C, Ho)
-                dT += torch.einsum('scldo,sklo->kcd', Q, Wp.double()).to(dT.dtype)
-    return dT, (None if dS is None else dS.reshape(-1))
+                Wp[:, :, :H16] = Wv[:, :, cw:]
+                Wp[:, :, H16:H16 + cw] = Wv[:, :, :cw]
+                Q = torch.stack([k.mix_grad(s0, dY, first, step, len(cells), N), k.mix_grad(s1, dY, first, step, len(cells), N)]).view(Ks, C, LP, C, Ho)
+                dT += torch.einsum('scldo,sklo->kcd', Q, Wp.double())
+    return (None if dT is None else dT.to(Tc.dtype)), (None if dS is None else dS.to(Tc.dtype).reshape(-1))
 
 
 def stc_small_graph(k, op: SpatialOperand, Tc, Ks: int, schedule, outputs, ext, stacks):

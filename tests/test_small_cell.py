@@ -171,3 +171,21 @@ def test_small_cell_refuses_other_shapes():
     buf, P = _buffers(2, 12, 5, 8, torch.float32, hip)
     with pytest.raises(StcError, match='outside the small-graph cell kernels'):
         _run(hip, csr_operand(graph, torch.device('cuda')), t, buf, P, lambda v: v.cuda())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('cells,B,N,C,wa,wb,sel', [(9, 32, 100, 5, 32, 32, (0, 1, 9)), (6, 3, 100, 5, 32, 16, (1, 2, 3)), (4, 2, 37, 8, 20, 32, (0, 3, 2)),
+                                                  (3, 2, 12, 3, 20, 16, (2, 1, 1)), (2, 1, 130, 1, 32, 32, (0, 1, 2))])
+def test_graph_gradient_products(cells, B, N, C, wa, wb, sel):
+    """stc_graph_grad_f32 / stc_mix_grad_f32 (the dGs / dGc products of learned graphs: sums over selected cells and samples, float64
+    accumulation) against float64 einsums; strided cell selections, N and widths off the tile boundaries."""
+    from stc_hip._lib import HipKernels
+    hip = HipKernels()
+    g = torch.Generator().manual_seed(cells * N + wa)
+    A, Bm, Bn = (torch.randn(cells, B, N * C, w_, generator=g) for w_ in (wa, wa, wb))
+    want = EM.graph_grad(A, Bm, *sel, N)
+    got = hip.graph_grad(A.cuda(), Bm.cuda(), *sel, N).cpu()
+    assert got.dtype == torch.float64 and rel_err(got, want) < 1e-6
+    want = EM.mix_grad(A, Bn, *sel, N)
+    got = hip.mix_grad(A.cuda(), Bn.cuda(), *sel, N).cpu()
+    assert got.shape == (C * wa, C * wb) and rel_err(got, want) < 1e-6
