@@ -1,9 +1,8 @@
-// One STC_Cell step of a SMALL graph in one launch (reference STC_GNN.py:65-79 with BDG_Dif :31-47 inside, Ks = 2), and its autograd in
-// one launch: the SF-incidents shape (N = 100, C = 5, hidden 16), where a cell is ~15 launches of a few microseconds on
-// the general path and the step is bound by the host's launch rate.
+// One STC_Cell step for FEW CATEGORIES (C <= 16; reference STC_GNN.py:65-79 with BDG_Dif :31-47 inside, Ks = Kc = 2, hidden 16), and its
+// autograd: the SF-incidents shape (N = 100, C = 5) and its relatives, where the general path is ~15 launches of generic
+// vector kernels per cell and direction and the step is bound by the host's launch rate.
 //
-// One workgroup = one sample; the phases of the cell follow each other inside the launch, separated by workgroup barriers where a phase
-// reads its neighbours' rows:
+// The phases of a cell, each reading its neighbours' rows from the previous one:
 //   forward   0  stage the graph and the sample's [H | X] rows in LDS
 //             1  Zg = S.[H | X]                          (gather over the CSR rows; LP = 16 + 4 XQ columns, zero padded)
 //             2  gates: [H|X], Zg -> project (fp32 MFMA) -> category mix -> sigmoid -> U, R, R*H
@@ -13,16 +12,20 @@
 //             2  d[R*H | X] = dZc_0 + S^T dZc_1; gate backward -> dYg, first share of dH, dX
 //             3  dYg -> mix^T -> dWg, dbg partials; dZg_0, dZg_1
 //             4  dH, dX += dZg_0 + S^T dZg_1
-// A launch is a chain of short dependent phases on ONE compute unit per sample, so what it costs is latency, not bandwidth: the first
-// version (everything gathered from L2) took 61 / 119 us forward / backward at the SF shape against ~11 / 22 us of matrix-pipe time.
-// Hence, when the sample fits (STAGED): the graph, the gathered planes ([H | X], R*H; in the backward the slab dZ_1) live in LDS, the
-// operands that must come from global memory (the aggregates of the previous phase) are requested one row tile ahead, the forward runs
-// 16 waves (each wave owns ONE 16-column tile of the output: 32 W registers), and the backward's parameter-gradient partials go to one
-// row PER WAVE of the caller's buffer (no cross-wave reduction, no barriers).  Samples that do not fit take the same code with the planes
-// and the graph read from global memory.
+// Two forms of a launch (argument `phase`):
+//   * phase 0 -- the whole cell in ONE launch, one workgroup per sample, workgroup barriers between the phases.  What it costs is latency,
+//     not bandwidth (first version, everything gathered from L2: 61 / 119 us forward / backward at the SF shape against ~11 / 22 us of
+//     matrix-pipe time).  Hence, when the sample fits (MODE 1 / 2): the graph and the gathered planes ([H | X], R*H; in the backward the
+//     slab dZ_1) live in LDS, operands that must come from global memory are requested one row tile ahead, 16 waves (forward: a wave owns
+//     one 16-column tile of the output; backward: four waves per row tile, one per slab and role), parameter-gradient partials to one row
+//     per tile quad of the caller's buffer (no cross-wave reduction).  A dense learned graph (MODE 2) aggregates as a matrix product on the
+//     staged plane.
+//   * phase 1..4 with `splits` = G -- ONE phase per launch, the sample's rows dealt over G workgroups (nothing staged; the launch boundary
+//     is the barrier): one workgroup per sample keeps only `batch` of the 256 compute units busy, and at batch 32 the four short launches
+//     win for the backward (79 -> 4 x 13 us at the SF shape) and, for samples too large to stage, for the forward too.
 // Projections are project-then-mix:  V_kc = sum_ks Z_ks . W[(ks,kc,:)],  Y[(n,c')] = V_0 + sum_{kc>=1} sum_c T_kc[c,c'] V_kc[(n,c)] + b,
 // on v_mfma_f32_16x16x4_f32 (fp32 operands and accumulator: an fmaf chain per element, no split format).  A row tile = the C rows of
-// floor(16 / C) whole nodes, so the category mix stays inside a wave: the V_kc accumulators go through a per-wave LDS tile.
+// floor(16 / C) whole nodes, so the category mix stays inside a tile -- and is itself four matrix instructions on the accumulators (build_mix).
 #include <atomic>
 
 #include "stc_common.h"
