@@ -324,6 +324,29 @@ def test_bench_preset_cfg2(K):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('preset', ['sf', 'sf-learned'])
+def test_bench_preset_sf(preset):
+    """bench.py --preset sf / sf-learned: the SF-incidents shape (fixed sparse graph / the reference's full model with MGP_Gen's learned dense
+    graphs) runs on the few-category cell kernels, replayed as a HIP graph, and the line prices them against the fp32 matrix peak."""
+    import json
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--preset', preset, '--steps', '3', '--warmup', '2', '--no-cpu-baseline'],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.strip().split('\n') if l.startswith('{')][0])
+    r = d['roofline']
+    assert d['hip_graph'] is True and d['config']['preset'] == preset and d['config']['global_batch'] == 32
+    assert ('dense-learned' in d['config']['workload']) == (preset == 'sf-learned')
+    assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and 0 < r['frac'] < 1 and r['dominant']['entry_point'].startswith('stc_cell_small')
+    m = r['dominant']['matrix']
+    assert m['launches_per_cell_step'] in (1, 4) and m['compute_units_in_use'] in (32, 256)
+    assert set(d['kernels']) >= {'stc_cell_small_fwd_f32', 'stc_cell_small_bwd_f32'}
+    if preset == 'sf-learned':
+        assert {'stc_graph_grad_f32', 'stc_mix_grad_f32'} <= set(d['kernels'])
+
+
+@pytest.mark.gpu
 def test_bench_under_torchrun_single_rank_goes_through_rccl():
     """The driver's N > 1 form with N = 1: torch.distributed.run sets RANK, so the process group IS initialised (backend
     nccl = RCCL) and the barrier, the max-over-ranks all-reduce and destroy_process_group run on the real communicator."""
