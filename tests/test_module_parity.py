@@ -235,15 +235,15 @@ def test_sf_shape_fixed_graphs_through_modules(monkeypatch):
     _close(Gc.grad, g['dGc'], 1e-5, 'SF dGc', gpu_tol=2e-5)
 
 
-@pytest.mark.parametrize('N,C,layers,T,horizon', [(12, 3, 2, 4, 2), (20, 5, 1, 3, 3)])
-def test_learned_graphs_on_the_small_graph_kernels(dev, monkeypatch, N, C, layers, T, horizon):
+@pytest.mark.parametrize('N,C,layers,T,horizon,seed', [(12, 3, 2, 4, 2, 7), (20, 5, 1, 3, 3, 25)])
+def test_learned_graphs_on_the_small_graph_kernels(dev, monkeypatch, N, C, layers, T, horizon, seed):
     """The reference's FULL model (MGP_Gen's learned dense Gs and Gc, STC_GNN.py:185-261) at hidden 16 runs its cells on the small-graph
     kernels (asserted); every gradient -- including those that reach MGP_Gen's parameters through dGs and dGc, which this path forms as
     stacked products over all cells (stc_hip/small.py) -- against the float64 oracle of the same model."""
     calls = []
     real_small = ops.stc_small_graph
     monkeypatch.setattr(ops, 'stc_small_graph', lambda *a, **k: (calls.append(1), real_small(*a, **k))[1])
-    torch.manual_seed(N + C)
+    torch.manual_seed(seed)
     model = M.STCGNN(N, C, 2, 2, 1, 16, layers, horizon).to(DEV)
     X = (torch.rand(2, T, N, C) < 0.3).float()
     As, Ac, Rw = torch.rand(N, N), torch.rand(C, C), torch.randn(2, horizon, N, C)
@@ -260,13 +260,11 @@ def test_learned_graphs_on_the_small_graph_kernels(dev, monkeypatch, N, C, layer
     (want * Rw.double()).sum().backward()
     _close(y, want.detach().float().to(DEV), FWD, 'learned small-graph yhat')
     for n in got:
-        if n.startswith('mix_graph_pair'):
-            # MGP_Gen's own backward (torch fp32 ops on both paths, from the same dGs / dGc) is ill-conditioned for some draws: 3.5e-5 from
-            # the float64 value with EITHER path, identically -- so these are held to the general path, which takes dGs / dGc per convolution
+        # (the draws are chosen well-conditioned: for about half of all seeds MGP_Gen's OWN fp32 backward -- torch ops on either path -- is
+        # 1e-5 .. 4e-5 away from the float64 value on the 3 x 3 category graph's parameters, identically on both paths)
+        _close(got[n], sd[n].grad.float().to(DEV), 1e-5, f'learned small-graph d{n}', gpu_tol=2e-5)
+        if n.startswith('mix_graph_pair'):        # and against the general path, which forms dGs / dGc per convolution
             _close(got[n], per_cell[n], 5e-6, f'learned small-graph d{n} vs the per-cell path', gpu_tol=1e-5)
-            _close(got[n], sd[n].grad.float().to(DEV), 1e-4, f'learned small-graph d{n}', gpu_tol=1e-4)
-        else:
-            _close(got[n], sd[n].grad.float().to(DEV), 1e-5, f'learned small-graph d{n}', gpu_tol=2e-5)
 
 
 @pytest.mark.parametrize('tag,fname', [('g7', 'g7_csr_n1024'), ('g7p', 'g7_csr_n1024_perm')])
