@@ -24,7 +24,7 @@ import json
 d = json.loads(open('gpurun_out/bench_quick.log').read().strip().split('\n')[-1])
 print('value', round(d['value'], 3), 'samples/s  ms_per_step', round(d['ms_per_step'], 2), ' spmm GB/s', round(d['roofline']['achieved'], 1))
 for k, v in d['kernels'].items():
-    print(f"   {k:32s} {v['launches']:4d} {v['ms_per_step']:8.2f} ms  {1e3 * v['ms_per_step'] * d['steps'] / v['launches']:8.1f} us/launch  {v.get('GBps', 0):7.0f} GB/s")
+    print(f"   {k:32s} {int(v['launches']):4d} {v['ms_per_step']:8.2f} ms  {1e3 * v['ms_per_step'] * d['steps'] / v['launches']:8.1f} us/launch  {v.get('GBps', 0):7.0f} GB/s")
 PY
            ;;
     presets) rc=0
