@@ -37,6 +37,8 @@ def small_graph_supported(k, op: SpatialOperand, Tc, Ks: int, C: int, h: int, x_
     ``graph.dense_operand`` builds it) -- its gradient is formed as a dense product."""
     if dtype != torch.float32 or not hasattr(k, 'cell_small_supported') or (op.fwd_val.requires_grad and op.nnz != op.n * op.n):
         return False
+    if op.nnz == op.n * op.n and op.n * C > k.SMALL_STAGED_ROWS:
+        return False                                                # a dense graph aggregates as a matrix product on the STAGED plane: the sample must fit the LDS
     if op.n * C > k.SMALL_PREFERRED_ROWS or (C == 16 and op.n * C > 4096):
         return False                                                # (16 categories on large graphs: the general path's fp32-MFMA node kernels win, 13.4 vs 18.3 ms)
     return all(k.cell_small_supported(Ks, Tc.shape[0], C, w, h, op.n) for w in set(x_widths))
