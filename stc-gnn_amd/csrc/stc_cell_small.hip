@@ -20,9 +20,10 @@
 //     one 16-column tile of the output; backward: four waves per row tile, one per slab and role), parameter-gradient partials to one row
 //     per tile quad of the caller's buffer (no cross-wave reduction).  A dense learned graph (MODE 2) aggregates as a matrix product on the
 //     staged plane.
-//   * phase 1..4 with `splits` = G -- ONE phase per launch, the sample's rows dealt over G workgroups (nothing staged; the launch boundary
-//     is the barrier): one workgroup per sample keeps only `batch` of the 256 compute units busy, and at batch 32 the four short launches
-//     win for the backward (79 -> 4 x 13 us at the SF shape) and, for samples too large to stage, for the forward too.
+//   * phase 1..4 with `splits` = G -- ONE phase per launch, the sample's row tiles dealt in contiguous ranges over G workgroups (nothing
+//     staged; the launch boundary is the barrier): one workgroup per sample keeps only `batch` of the 256 compute units busy, and at batch 32
+//     the short launches win for the backward (79 -> 4 x 13 us at the SF shape) and, for samples too large to stage, for the forward too.
+//     Phases whose input is the workgroup's OWN rows share a launch: 5 = 1 + 2 and 6 = 3 + 4 (forward), 7 = 2 + 3 (backward, CSR graphs).
 // Projections are project-then-mix:  V_kc = sum_ks Z_ks . W[(ks,kc,:)],  Y[(n,c')] = V_0 + sum_{kc>=1} sum_c T_kc[c,c'] V_kc[(n,c)] + b,
 // on v_mfma_f32_16x16x4_f32 (fp32 operands and accumulator: an fmaf chain per element, no split format).  A row tile = the C rows of
 // floor(16 / C) whole nodes, so the category mix stays inside a tile -- and is itself four matrix instructions on the accumulators (build_mix).
@@ -84,9 +85,10 @@ constexpr int SQ = 20;                                                          
 // out[row][quad] = base + sum_e val[e] * fetch(colidx[e] * C + c, quad)  for the rows of one sample; fetch returns 4 columns of a source row.
 template <int THREADS, int QUADS, class Fetch, class Base, class Store>
 __device__ __forceinline__ void aggregate_rows(const int* __restrict__ gp, const int* __restrict__ gc, const float* __restrict__ gv, int NC, int C,
-                                               int invC, int split, int splits, Fetch fetch, Base base, Store store) {
-    for (int item = threadIdx.x + THREADS * split; item < NC * QUADS; item += THREADS * splits) {
-        const int row = item / QUADS, q = item - row * QUADS;
+                                               int invC, int row_lo, int row_hi, Fetch fetch, Base base, Store store) {
+    (void)NC;
+    for (int item = threadIdx.x; item < (row_hi - row_lo) * QUADS; item += THREADS) {       // the workgroup's own rows [row_lo, row_hi)
+        const int row = row_lo + item / QUADS, q = item - (row - row_lo) * QUADS;
         const int n = div_c(row, invC), c = row - n * C;
         f32x4 s = base(row, q);
         const int e1 = gp[n + 1];
@@ -254,9 +256,10 @@ template <int KC, int XQ, class Z0, class Z1, class Epi>
 __device__ __forceinline__ void fwd_conv(const float (&Wr)[SC_KS][KC][4 + (XQ == 4 ? 4 : XQ)], const float (&M)[KC][4], int tile0, int tstep, int tiles,
                                          int rpt, int NC, int j, int kq, Z0 z0, Z1 z1, Epi epi) {
     constexpr int XS = XQ == 4 ? 4 : XQ;
-    // rows that do not exist (beyond the tile's nodes / the sample) read row 0: their products land in accumulator rows nobody stores, and
-    // the mix couples rows of one node only
-    auto row_of = [&](int tile) { return tile < tiles && j < rpt && tile * rpt + j < NC ? tile * rpt + j : 0; };
+    // rows that do not exist (beyond the tile's nodes / the sample) read the tile's first row -- a row this workgroup owns, so a FINITE value
+    // even when other workgroups are still writing theirs (fused phases): their products land in accumulator rows nobody stores, but the
+    // mix multiplies them by zeros.  (A tile requested past the end reads an in-bounds row that nobody uses.)
+    auto row_of = [&](int tile) { return j < rpt && tile * rpt + j < NC ? tile * rpt + j : min(tile * rpt, NC - 1); };
     AOp<XS> nxt = z1(row_of(tile0));
     for (int tile = tile0; tile < tiles; tile += tstep) {
         const int row0 = tile * rpt;
@@ -330,9 +333,14 @@ __global__ __launch_bounds__(SF_THREADS) void small_fwd_kernel(SmallFwd a) {
 
     // Split form (phase != 0): this launch runs ONE phase, with the sample's tiles / rows dealt over gridDim.y workgroups, so that a step of
     // few samples still fills the chip; the caller launches the phases in order (the launch boundary replaces the workgroup barrier).
+    // phase 5 = phases 1 + 2, phase 6 = phases 3 + 4 in one launch: a workgroup OWNS a contiguous range of row tiles, and the gates /
+    // candidate convolution of a tile needs the aggregate of its own rows only (the aggregation reads the neighbours' INPUT rows, complete
+    // before the launch), so only the step from phase 2 to phase 3 -- R*H of the neighbours -- needs a launch boundary.
     const int phase = a.phase, split = blockIdx.y, splits = gridDim.y;
-    auto runs = [&](int p) { return phase == 0 || phase == p; };
-    auto sync = [&] { if (phase == 0) __syncthreads(); };
+    auto runs = [&](int p) { return phase == 0 || phase == p || (phase == 5 && p <= 2) || (phase == 6 && p >= 3); };
+    auto sync = [&](int after) { if (phase == 0 || (phase == 5 && after == 1) || (phase == 6 && after == 3)) __syncthreads(); };
+    const int t_lo = (int)((long long)a.tiles * split / splits), t_hi = (int)((long long)a.tiles * (split + 1) / splits);
+    const int row_lo = min(t_lo * a.rpt, NC), row_hi = min(t_hi * a.rpt, NC);
 
     // 0: tables, graph and the sample's rows into LDS (the gates' W operands are requested first: in flight during phases 0 and 1)
     const int ct = wave & 1;                                 // gates: wave w owns column tile w % 2 (0: update, 1: reset)
@@ -357,12 +365,12 @@ __global__ __launch_bounds__(SF_THREADS) void small_fwd_kernel(SmallFwd a) {
                 st4(P + (unsigned)row * SP + 16 + 4 * q, x);
             }
     }
-    sync();
+    if (phase == 0) __syncthreads();
 
     if (a.Z0 != nullptr && runs(1)) {                        // (learned graphs only)
         float* Z0b = a.Z0 + r0 * LP;
-        for (int item = t + SF_THREADS * split; item < NC * (LP / 4); item += SF_THREADS * splits) {
-            const int row = item / (LP / 4), q = item - row * (LP / 4);
+        for (int item = t; item < (row_hi - row_lo) * (LP / 4); item += SF_THREADS) {
+            const int row = row_lo + item / (LP / 4), q = item - (row - row_lo) * (LP / 4);
             f32x4 x;
             if (STAGED) {
                 x = ld4(P + (unsigned)row * SP + 4 * q);
@@ -387,7 +395,7 @@ __global__ __launch_bounds__(SF_THREADS) void small_fwd_kernel(SmallFwd a) {
         if (DENSE)
             aggregate_dense<SF_THREADS, LP / 4>(a.g.val, N, C, P, SP, 0, 1, none, put);
         else
-            aggregate_rows<SF_THREADS, LP / 4>(gp, gc, gv, NC, C, invC, split, splits,
+            aggregate_rows<SF_THREADS, LP / 4>(gp, gc, gv, NC, C, invC, row_lo, row_hi,
                 [&](int src, int q) -> f32x4 {
                     if (STAGED) return ld4(P + (unsigned)src * SP + 4 * q);
                     if (q < 4) return ld4(Hb + (unsigned)src * SC_H + 4 * q);
@@ -400,13 +408,13 @@ __global__ __launch_bounds__(SF_THREADS) void small_fwd_kernel(SmallFwd a) {
                 },
                 none, put);
     }
-    sync();
+    sync(1);
     SC_PHASE_END(1);
 
-    // 2: gates -- wave w: column tile w % 2 of the row tiles w / 2, w / 2 + 8, ..
+    // 2: gates -- wave w: column tile w % 2 of the workgroup's row tiles t_lo + w / 2, t_lo + w / 2 + 8, ..
     if (runs(2)) {
         const float bias = a.bg ? a.bg[16 * ct + j] : 0.f;
-        fwd_conv<KC, XQ>(Wg_r, M, (wave >> 1) + (SF_WAVES / 2) * split, (SF_WAVES / 2) * splits, a.tiles, a.rpt, NC, j, kq,
+        fwd_conv<KC, XQ>(Wg_r, M, t_lo + (wave >> 1), SF_WAVES / 2, t_hi, a.rpt, NC, j, kq,
             [&](int row) { return STAGED ? load_op<XQ>(P, SP, P + 16, SP, true, cin, row, kq) : load_op<XQ>(Hb, SC_H, Xb, cin, false, cin, row, kq); },
             [&](int row) { return load_op<XQ>(Zgb, LP, Zgb + 16, LP, true, cin, row, kq); },
             [&](int grow, float y) {
@@ -422,7 +430,7 @@ __global__ __launch_bounds__(SF_THREADS) void small_fwd_kernel(SmallFwd a) {
                 }
             });
     }
-    sync();
+    sync(2);
     SC_PHASE_END(2);
 
     // 3: Zc = S.(R*H)   (the candidate's W operands in flight meanwhile)
@@ -434,18 +442,18 @@ __global__ __launch_bounds__(SF_THREADS) void small_fwd_kernel(SmallFwd a) {
         if (DENSE)
             aggregate_dense<SF_THREADS, 4>(a.g.val, N, C, Q, SQ, 0, 1, none, put);
         else
-            aggregate_rows<SF_THREADS, 4>(gp, gc, gv, NC, C, invC, split, splits,
+            aggregate_rows<SF_THREADS, 4>(gp, gc, gv, NC, C, invC, row_lo, row_hi,
                 [&](int src, int q) -> f32x4 { return STAGED ? ld4(Q + (unsigned)src * SQ + 4 * q) : ld4(RHb + (unsigned)src * SC_H + 4 * q); }, none, put);
     }
-    sync();
+    sync(3);
     SC_PHASE_END(3);
 
     if (a.Z0c != nullptr && a.Z0 != nullptr && runs(4)) {    // (learned graphs only; R*H, Zc, Zg and Z0 are complete: two barriers / launches ago)
         const float* Z0b = a.Z0 + r0 * LP;
         float* Z0cb = a.Z0c + r0 * LP;
         float* Z1cb = a.Z1c + r0 * LP;
-        for (int item = t + SF_THREADS * split; item < NC * (LP / 4); item += SF_THREADS * splits) {
-            const int row = item / (LP / 4), q = item - row * (LP / 4);
+        for (int item = t; item < (row_hi - row_lo) * (LP / 4); item += SF_THREADS) {
+            const int row = row_lo + item / (LP / 4), q = item - (row - row_lo) * (LP / 4);
             st4(Z0cb + (unsigned)row * LP + 4 * q, q < 4 ? ld4(RHb + (unsigned)row * SC_H + 4 * q) : ld4(Z0b + (unsigned)row * LP + 4 * q));
             st4(Z1cb + (unsigned)row * LP + 4 * q, q < 4 ? ld4(Zcb + (unsigned)row * SC_H + 4 * q) : ld4(Zgb + (unsigned)row * LP + 4 * q));
         }
@@ -456,7 +464,7 @@ __global__ __launch_bounds__(SF_THREADS) void small_fwd_kernel(SmallFwd a) {
         const float bias = a.bc ? a.bc[j] : 0.f;
         float* Cb = a.Cand + r0 * SC_H;
         float* Hn = a.Hnew + r0 * SC_H;
-        fwd_conv<KC, XQ>(Wc_r, M, wave + SF_WAVES * split, SF_WAVES * splits, a.tiles, a.rpt, NC, j, kq,
+        fwd_conv<KC, XQ>(Wc_r, M, t_lo + wave, SF_WAVES, t_hi, a.rpt, NC, j, kq,
             [&](int row) { return STAGED ? load_op<XQ>(Q, SQ, P + 16, SP, true, cin, row, kq) : load_op<XQ>(RHb, SC_H, Xb, cin, false, cin, row, kq); },
             [&](int row) { return load_op<XQ>(Zcb, SC_H, Zgb + 16, LP, true, cin, row, kq); },
             [&](int grow, float y) {
@@ -514,7 +522,7 @@ __device__ __forceinline__ void conv_bwd_phase(const Slab& z, const float* __res
     const int t = threadIdx.x, lane = t & 63, j = lane & 15, kq = lane >> 4, L = cin + SC_H;
     const int quad = tile0, QUADS = tstep;                       // the wave's first tile and its stride (one launch per cell: t / 256 and 4)
     // Rows 4 kq + s of a tile as a lane addresses them: clamped into the sample (rows of a tile beyond its nodes or beyond the sample, and
-    // whole tiles requested past the end, read the last row: finite values that meet a zero mask) -- one v_min per row and tile instead of a
+    // whole tiles requested past the end, read the last row or a neighbouring tile's: values the mask replaces by zero) -- one v_min per row and tile instead of a
     // compare / select pair per LOAD: the vector unit, not the matrix pipe, paces these loops (a matrix instruction holds the issue port).
     struct Rows {
         unsigned r[4];
@@ -537,9 +545,9 @@ __device__ __forceinline__ void conv_bwd_phase(const Slab& z, const float* __res
     auto form_and_mix = [&](int tile, const Raw (&cur)[4], float (&dy)[OT][4], f32x4 (&dvk)[KC][OT]) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const float m = mask_of(tile, s) ? 1.f : 0.f;
-#pragma unroll
-            for (int ot = 0; ot < OT; ++ot) dy[ot][s] = m * form_dy(cur[s], ot);
+            const bool m = mask_of(tile, s);           // (a select, not a product: the row read instead may be one another workgroup is still
+#pragma unroll                                         //  writing -- phase 7 -- i.e. anything, NaN included)
+            for (int ot = 0; ot < OT; ++ot) dy[ot][s] = m ? form_dy(cur[s], ot) : 0.f;
         }
 #pragma unroll
         for (int kc = 1; kc < KC; ++kc)
@@ -731,15 +739,21 @@ __global__ __launch_bounds__(SB_THREADS) void small_bwd_kernel(SmallBwd a) {
     const float* dHn = a.dHnew + r0 * SC_H;
     float* dXb = a.dX ? a.dX + r0 * cin : nullptr;
     float* dHb = a.dH ? a.dH + r0 * SC_H : nullptr;
-    float* wsb = a.ws + (size_t)blockIdx.x * NC * (2 * LP + 32);
+    float* wsb = a.ws + (size_t)blockIdx.x * NC * (3 * LP + 32);
     float* dZ0 = wsb;
     float* dZ1 = STAGED ? D1 : wsb + (size_t)NC * LP;
+    float* dZ1s = STAGED ? D1 : wsb + (size_t)NC * (2 * LP + 32);     // the gates convolution's dZ_1: its own slab, so that a workgroup may run phase 3
+                                                                      // while another still reads the candidate's dZ_1 in phase 2 (phase 7)
     float* dYg = a.dYg ? a.dYg + r0 * 32 : wsb + (size_t)NC * 2 * LP;
     const int ks = wave & 1, role = (wave >> 1) & 1;
+    // phase 7 = phases 2 + 3 in one launch: the gates convolution of a tile reads the gate pre-activation gradients of its OWN rows only, which
+    // phase 2 has just formed (a workgroup owns a contiguous range of row tiles); phases 1 -> 2 and 3 -> 4 read the neighbours' dZ_1.
     const int phase = a.phase, split = blockIdx.y, splits = gridDim.y;
-    auto runs = [&](int p) { return phase == 0 || phase == p; };
-    auto sync = [&] { if (phase == 0) __syncthreads(); };
-    const int tile0 = (wave >> 2) + (SB_WAVES / 4) * split, tstep = (SB_WAVES / 4) * splits;
+    auto runs = [&](int p) { return phase == 0 || phase == p || (phase == 7 && (p == 2 || p == 3)); };
+    auto sync = [&](int after) { if (phase == 0 || (phase == 7 && after == 2)) __syncthreads(); };
+    const int t_lo = (int)((long long)a.tiles * split / splits), t_hi = (int)((long long)a.tiles * (split + 1) / splits);
+    const int row_lo = min(t_lo * a.rpt, NC), row_hi = min(t_hi * a.rpt, NC);
+    const int tile0 = t_lo + (wave >> 2), tstep = SB_WAVES / 4;
     float* dPw = a.dP + (((size_t)blockIdx.x * splits + split) * (SB_WAVES / 4) + (wave >> 2)) * a.P;
     float* dWg = dPw;
     float* dbg = dPw + (size_t)SC_KS * KC * L * 32;
@@ -749,18 +763,18 @@ __global__ __launch_bounds__(SB_THREADS) void small_bwd_kernel(SmallBwd a) {
     float M[KC][4];
     build_mix<KC>(M, a.Tc, true, a.rpt, C, invC, lane & 15, lane >> 4);
     if (STAGED && !DENSE) stage_graph<SB_THREADS>(a.g, N, gpl, gcl, gvl);
-    sync();
+    if (phase == 0) __syncthreads();
 
     // 1: candidate convolution
     if (runs(1)) conv_bwd_phase<KC, XQ, 1, Raw3>(ks == 0 ? Slab{RHb, SC_H, Xb, cin} : Slab{Zcb, SC_H, Zgb + SC_H, LP}, a.Wc, ks, role, M, dv, ks == 0 ? dZ0 : dZ1,
         ks == 1 && a.dZ1c ? a.dZ1c + r0 * LP : nullptr, dWc,
-        a.has_bc ? dbc : nullptr, a.rpt, min(a.tiles, SC_MAX_TILES), tile0, tstep, NC, cin,
+        a.has_bc ? dbc : nullptr, a.rpt, min(t_hi, SC_MAX_TILES), tile0, tstep, NC, cin,
         [&](int grow, int col) {
             const size_t e = (unsigned)grow * SC_H + col;
             return Raw3{dHn[e], Ub[e], Cb[e]};
         },
         [](const Raw3& w, int) { return w.d * w.u * (1.f - w.c * w.c); });
-    sync();                                      // the dZ slabs are complete
+    sync(1);                                     // the dZ slabs are complete
     SC_PHASE_END(1);
 
     // 2: d[R*H | X] = dZ_0 + S^T dZ_1, gate backward
@@ -809,23 +823,23 @@ __global__ __launch_bounds__(SB_THREADS) void small_bwd_kernel(SmallBwd a) {
         if (DENSE)
             aggregate_dense<SB_THREADS, LP / 4>(a.g.val, N, C, dZ1, LP, split, splits, from_dz0, gate_bwd);
         else
-            aggregate_rows<SB_THREADS, LP / 4>(gp, gc, gv, NC, C, invC, split, splits, from_dz1, from_dz0, gate_bwd);
+            aggregate_rows<SB_THREADS, LP / 4>(gp, gc, gv, NC, C, invC, row_lo, row_hi, from_dz1, from_dz0, gate_bwd);
     }
-    sync();
+    sync(2);
     SC_PHASE_END(2);
 
     // 3: gates convolution
-    if (runs(3)) conv_bwd_phase<KC, XQ, 2, Raw2>(ks == 0 ? Slab{Hb, SC_H, Xb, cin} : Slab{Zgb, LP, Zgb + SC_H, LP}, a.Wg, ks, role, M, dv, ks == 0 ? dZ0 : dZ1,
+    if (runs(3)) conv_bwd_phase<KC, XQ, 2, Raw2>(ks == 0 ? Slab{Hb, SC_H, Xb, cin} : Slab{Zgb, LP, Zgb + SC_H, LP}, a.Wg, ks, role, M, dv, ks == 0 ? dZ0 : dZ1s,
         ks == 1 && a.dZ1g ? a.dZ1g + r0 * LP : nullptr, dWg,
-        a.has_bg ? dbg : nullptr, a.rpt, min(a.tiles, SC_MAX_TILES), tile0, tstep, NC, cin,
+        a.has_bg ? dbg : nullptr, a.rpt, min(t_hi, SC_MAX_TILES), tile0, tstep, NC, cin,
         [&](int grow, int col) { return Raw2{dYg[(unsigned)grow * 32 + col], dYg[(unsigned)grow * 32 + 16 + col]}; },
         [](const Raw2& w, int ot) { return ot == 0 ? w.a : w.b; });
-    sync();
+    sync(3);
     SC_PHASE_END(3);
 
     // 4: d[H | X] += dZ_0 + S^T dZ_1
     if ((dHb || dXb) && runs(4)) {
-        auto from_dz1 = [&](int src, int q) -> f32x4 { return ld4(dZ1 + (unsigned)src * LP + 4 * q); };
+        auto from_dz1 = [&](int src, int q) -> f32x4 { return ld4(dZ1s + (unsigned)src * LP + 4 * q); };
         auto from_dz0 = [&](int row, int q) -> f32x4 { return ld4(dZ0 + (unsigned)row * LP + 4 * q); };
         auto add_in =
             [&](int row, int q, f32x4 s) {
@@ -846,9 +860,9 @@ __global__ __launch_bounds__(SB_THREADS) void small_bwd_kernel(SmallBwd a) {
                 }
             };
         if (DENSE)
-            aggregate_dense<SB_THREADS, LP / 4>(a.g.val, N, C, dZ1, LP, split, splits, from_dz0, add_in);
+            aggregate_dense<SB_THREADS, LP / 4>(a.g.val, N, C, dZ1s, LP, split, splits, from_dz0, add_in);
         else
-            aggregate_rows<SB_THREADS, LP / 4>(gp, gc, gv, NC, C, invC, split, splits, from_dz1, from_dz0, add_in);
+            aggregate_rows<SB_THREADS, LP / 4>(gp, gc, gv, NC, C, invC, row_lo, row_hi, from_dz1, from_dz0, add_in);
     }
 }
 
@@ -878,7 +892,7 @@ extern "C" int stc_cell_small_param_rows(void) { return SB_WAVES / 4; }
 extern "C" size_t stc_cell_small_workspace_bytes(int32_t n_nodes, int32_t C, int32_t cin, int32_t batch) {
     const int xq = xq_of(cin);
     if (xq == 0 || n_nodes < 0 || C < 0 || batch < 0) return 0;
-    return (size_t)batch * n_nodes * C * (2 * (16 + 4 * xq) + 32) * sizeof(float);
+    return (size_t)batch * n_nodes * C * (3 * (16 + 4 * xq) + 32) * sizeof(float);
 }
 
 #define SC_COMMON_CHECKS(name)                                                                                                        \
@@ -901,9 +915,9 @@ extern "C" int stc_cell_small_fwd_f32(const int32_t* rowptr, const int32_t* coli
     STC_REQUIRE(stc::aligned16(H) && stc::aligned16(U) && stc::aligned16(R) && stc::aligned16(RH) && stc::aligned16(Zg) && stc::aligned16(Zc) &&
                     (xq != 4 || stc::aligned16(X)) && stc::aligned16(Z0), STC_EINVAL, "stc_cell_small_fwd_f32: planes must be 16-byte aligned");
     const int npt = 16 / C, rpt = npt * C;
-    STC_REQUIRE(phase >= 0 && phase <= 4 && splits >= 1 && splits <= 64 && (phase != 0 || splits == 1), STC_EINVAL,
-                "stc_cell_small_fwd_f32: phase %d / splits %d (phase 0 = the whole cell, one workgroup per sample; 1..4 = one phase over `splits` workgroups)",
-                phase, splits);
+    STC_REQUIRE(phase >= 0 && phase <= 6 && splits >= 1 && splits <= 64 && (phase != 0 || splits == 1), STC_EINVAL,
+                "stc_cell_small_fwd_f32: phase %d / splits %d (phase 0 = the whole cell, one workgroup per sample; 1..4 = one phase, 5 = 1 + 2, "
+                "6 = 3 + 4 over `splits` workgroups)", phase, splits);
     STC_REQUIRE((Z0c == nullptr) == (Z1c == nullptr) && (Z0c == nullptr || Z0 != nullptr) && stc::aligned16(Z0c) && stc::aligned16(Z1c), STC_EINVAL,
                 "stc_cell_small_fwd_f32: Z0c and Z1c come together, with Z0, 16-byte aligned");
     SmallFwd a{{rowptr, colidx, val, nnz}, X, H, Tc, Wg, bg, Wc, bc, U, R, Cand, Hnew, RH, Zg, Zc, Z0, Z0c, Z1c, n_nodes, C, cin, rpt,
@@ -946,8 +960,10 @@ extern "C" int stc_cell_small_bwd_f32(const int32_t* rowptr, const int32_t* coli
     const int npt = 16 / C, rpt = npt * C;
     SmallBwd a{{rowptr, colidx, val, nnz}, X, H, Tc, Wg, Wc, U, R, Cand, RH, Zg, Zc, dHnew, dX, dH, dparams, static_cast<float*>(workspace),
                dZ1c, dZ1g, dYg, dYc, n_nodes, C, cin, rpt, (n_nodes + npt - 1) / npt, accumulate_x, accumulate_h, has_bg, has_bc, phase, params_ld};
-    STC_REQUIRE(phase >= 0 && phase <= 4 && splits >= 1 && splits <= 64 && (phase != 0 || splits == 1), STC_EINVAL,
-                "stc_cell_small_bwd_f32: phase %d / splits %d", phase, splits);
+    STC_REQUIRE(((phase >= 0 && phase <= 4) || phase == 7) && splits >= 1 && splits <= 64 && (phase != 0 || splits == 1), STC_EINVAL,
+                "stc_cell_small_bwd_f32: phase %d / splits %d (0 = the whole cell; 1..4 = one phase; 7 = 2 + 3)", phase, splits);
+    STC_REQUIRE(phase != 7 || !(graph_is_dense && nnz == (long long)n_nodes * n_nodes), STC_EINVAL,
+                "stc_cell_small_bwd_f32: the fused phase is for CSR graphs (a dense graph's aggregation deals node tiles, not row tiles, over the workgroups)");
     const size_t fixed = (size_t)bwd_lds_fixed<2>() * 4, planes = (size_t)n_nodes * C * LP * 4;
     const bool full = graph_is_dense && nnz == (long long)n_nodes * n_nodes;
     const bool dense = phase == 0 && full && fixed + planes <= SC_LDS_BUDGET;

@@ -842,8 +842,9 @@ class HipKernels:
         """One STC_Cell step (reference STC_GNN.py:65-79) in one launch: ``stc_cell_small_fwd_f32``.  (rowptr, colidx, val): CSR of Gs^T.
         ``checked=False``: the caller built every buffer itself from shapes it already validated (the cell-graph executor).
         ``Z0`` (optional, like Zg): receives the slab [H | Xt | 0] (learned graphs: operand of the graph-gradient product).
-        ``splits`` = G > 1: the cell as FOUR launches (one per phase), each over G workgroups per sample -- for batches too small to fill
-        the chip with one workgroup per sample (``cell_small_splits``)."""
+        ``splits`` = G > 1: the cell as TWO launches (phases 1 + 2, then 3 + 4: R*H of the neighbours is the one dependency that crosses
+        workgroups), each over G workgroups per sample that own a contiguous range of row tiles -- for batches too small to fill the chip
+        with one workgroup per sample (``cell_small_splits``)."""
         if checked:
             B, N, Cc, cin, Kc = self._small_shapes('cell_small_fwd', rowptr, colidx, val, X, H, Tc, Wg, Wc, dict(U=U, R=R, Cand=Cand, Hnew=Hnew, RH=RH), Zg, Zc)
             for name, t_ in (('Z0', Z0), ('Z0c', Z0c), ('Z1c', Z1c)):
@@ -856,15 +857,21 @@ class HipKernels:
         else:
             (B, N, Cc, _), cin, Kc = H.shape, X.shape[-1], Tc.shape[0]
         dense = int(is_full_pattern(colidx, N, N))
-        for phase in ((0,) if splits == 1 else (1, 2, 3, 4)):
+        for phase in ((0,) if splits == 1 else self.SMALL_FWD_PHASES):
             self._launch('stc_cell_small_fwd_f32', H, rowptr.data_ptr(), colidx.data_ptr(), val.data_ptr(), N, val.numel(), dense, X.data_ptr(), cin,
                          H.data_ptr(), Tc.data_ptr(), Kc, Wg.data_ptr(), _ptr(bg), Wc.data_ptr(), _ptr(bc), U.data_ptr(), R.data_ptr(), Cand.data_ptr(),
                          Hnew.data_ptr(), RH.data_ptr(), Zg.data_ptr(), Zc.data_ptr(), _ptr(Z0), _ptr(Z0c), _ptr(Z1c), phase, splits, B, Cc,
-                         nbytes=(4 * B * N * Cc * (cin + 16 * 8 + 2 * self.cell_small_zg_width(cin))) // (1 if splits == 1 else 4))
+                         nbytes=(4 * B * N * Cc * (cin + 16 * 8 + 2 * self.cell_small_zg_width(cin))) // (1 if splits == 1 else len(self.SMALL_FWD_PHASES)))
+
+    # Launches of a split cell step (phase codes of stc_cell_small_*_f32; 5 = 1 + 2, 6 = 3 + 4, 7 = 2 + 3).  A dense graph's backward
+    # aggregation deals node tiles (not row tiles) over the workgroups: one phase per launch there.
+    SMALL_FWD_PHASES = (5, 6)
+    SMALL_BWD_PHASES = (1, 7, 4)
+    SMALL_BWD_PHASES_DENSE = (1, 2, 3, 4)
 
     @staticmethod
     def cell_small_splits(batch: int, rows: int = 0) -> int:
-        """Workgroups per sample for a batch: 1 = one launch per cell step (a workgroup per sample); G > 1 = four launches per step over
+        """Workgroups per sample for a batch: 1 = one launch per cell step (a workgroup per sample); G > 1 = a few launches per step over
         G workgroups per sample, so that ~256 workgroups are in flight (rows: N * C of a sample -- a split wants at least a few tiles)."""
         g = max(1, min(8, 256 // max(1, batch)))
         while g > 1 and rows and rows < 48 * g:
@@ -894,13 +901,14 @@ class HipKernels:
         nbytes = self.lib.stc_cell_small_workspace_bytes(N, Cc, cin, B)
         ws = self._get_workspace(H.device, nbytes)
         dense = int(is_full_pattern(colidx, N, N))
-        for phase in ((0,) if splits == 1 else (1, 2, 3, 4)):
+        phases = (0,) if splits == 1 else self.SMALL_BWD_PHASES_DENSE if dense else self.SMALL_BWD_PHASES
+        for phase in phases:
             self._launch('stc_cell_small_bwd_f32', H, rowptr.data_ptr(), colidx.data_ptr(), val.data_ptr(), N, val.numel(), dense, X.data_ptr(), cin,
                          H.data_ptr(), Tc.data_ptr(), Kc, Wg.data_ptr(), Wc.data_ptr(), U.data_ptr(), R.data_ptr(), Cand.data_ptr(), RH.data_ptr(),
                          Zg.data_ptr(), Zc.data_ptr(), dHnew.data_ptr(), _ptr(dX), int(bool(accumulate_x)), _ptr(dH), int(bool(accumulate_h)),
                          dparams.data_ptr(), dparams.shape[1], int(bool(has_bg)), int(bool(has_bc)), _ptr(dZ1c), _ptr(dZ1g), _ptr(dYg), _ptr(dYc),
                          ws.data_ptr(), ws.numel(), phase, splits, B, Cc,
-                         nbytes=(4 * B * N * Cc * (2 * cin + 16 * 9 + 5 * self.cell_small_zg_width(cin) + 64)) // (1 if splits == 1 else 4))
+                         nbytes=(4 * B * N * Cc * (2 * cin + 16 * 9 + 5 * self.cell_small_zg_width(cin) + 64)) // len(phases))
 
     GRAD_CHUNKS = 96             # float64 partials of a graph-gradient product (x tile groups = workgroups; every partial is written and re-read)
 

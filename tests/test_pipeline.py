@@ -340,7 +340,7 @@ def test_bench_preset_sf(preset):
     assert ('dense-learned' in d['config']['workload']) == (preset == 'sf-learned')
     assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and 0 < r['frac'] < 1 and r['dominant']['entry_point'].startswith('stc_cell_small')
     m = r['dominant']['matrix']
-    assert m['launches_per_cell_step'] in (1, 4) and m['compute_units_in_use'] in (32, 256)
+    assert m['launches_per_cell_step'] in (1, 2, 3, 4) and m['compute_units_in_use'] in (32, 256)
     assert set(d['kernels']) >= {'stc_cell_small_fwd_f32', 'stc_cell_small_bwd_f32'}
     if preset == 'sf-learned':
         assert {'stc_graph_grad_f32', 'stc_mix_grad_f32'} <= set(d['kernels'])
