@@ -216,7 +216,7 @@ class EmulatedKernels:
     # ---- stc_cell_small_fwd/bwd_f32: one STC_Cell step of a small graph per launch (STC_GNN.py:65-79 and its autograd)
     SMALL_MAX_ROWS = 65535
     SMALL_PREFERRED_ROWS = 65535
-    SMALL_STAGED_ROWS = 640      # N*C rows per sample that a compute unit's LDS stages (above: every gather from L2, and the forward split too)
+    SMALL_STAGED_ROWS = 640      # N*C rows per sample that a compute unit's LDS stages (above: every gather from L2; dense graphs go to the general path)
 
     def cell_small_supported(self, Ks, Kc, Cc, cin, h, n_nodes=0) -> bool:
         return Ks == 2 and Kc == 2 and 1 <= Cc <= 16 and h == 16 and (cin == 16 or 1 <= cin <= 4) and n_nodes * Cc <= self.SMALL_MAX_ROWS

@@ -792,7 +792,7 @@ class HipKernels:
     #: 1 568 (N = 196, C = 8) 2.9 | 7.6;  3 200: 4.5 | 11.5;  6 912 (C = 12): 8.8 | 22.4;  32 768 (C = 8): 37 | 90;  but 16 384 rows at
     #: C = 16: 18.3 | 13.4 (the general path's fp32-MFMA node kernels take C = 16) -- hence the extra rule in small.small_graph_supported.
     SMALL_PREFERRED_ROWS = 65535
-    SMALL_STAGED_ROWS = 640      # N*C rows per sample that a compute unit's LDS stages (above: every gather from L2, and the forward split too)
+    SMALL_STAGED_ROWS = 640      # N*C rows per sample that a compute unit's LDS stages (above: every gather from L2; dense graphs go to the general path)
 
     def cell_small_supported(self, Ks, Kc, Cc, cin, h, n_nodes=0) -> bool:
         return n_nodes * Cc <= self.SMALL_MAX_ROWS and bool(self.lib.stc_cell_small_supported(Ks, Kc, Cc, cin, h))

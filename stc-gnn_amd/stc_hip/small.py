@@ -103,12 +103,13 @@ class _StcSmallGraph(Function):
         state = [out_alias[out_slot[j]] if j in out_slot else inner[inner_slot[j]] for j in range(n_cells)]
         U, R, Cand, RH, Zc = (p.unbind(0) for p in planes.unbind(0))
         source = lambda src: ext[src[1]] if src[0] == 'ext' else state[src[1]]
-        # Few samples: the BACKWARD runs as four launches per cell step (one per phase) over several workgroups per sample instead of one
-        # workgroup per sample -- 79 -> ~55 us per cell at the SF shape.  The forward stays one launch while the sample fits the LDS: its
-        # phases are latency-bound (~10 us each as separate launches against 32 us for the whole staged cell).  Dense learned graphs: the
-        # same, their aggregations being matrix products either on the staged planes (one launch) or over all workgroups (split).
+        # Few samples: a cell step runs as a few launches over several workgroups per sample (each owning a contiguous range of row tiles)
+        # instead of one launch with one workgroup per sample -- at the SF shape (batch 32) backward 79 -> ~45 us per cell in three
+        # launches, forward 35 -> 24 us in two.  Dense learned graphs: the forward stays one launch on the staged planes (its aggregations
+        # are matrix products there; the split forward would gather N neighbour rows per row from L2), the backward splits with its
+        # aggregations as matrix products over all workgroups.
         splits = k.cell_small_splits(B, N * C)
-        fwd_splits = splits if (N * C > k.SMALL_STAGED_ROWS and op.nnz != N * N) else 1    # (samples too large to stage: the forward is split as well)
+        fwd_splits = splits if op.nnz != N * N else 1
         for j, (s_id, x, hs) in enumerate(schedule):
             Wg, bg, Wc, bc = stacks[s_id]
             w, i = pos[j]
