@@ -178,12 +178,12 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
 #pragma unroll
         for (int kb = 0; kb < NRB; ++kb) {
             const size_t e = (r0 + 16 * kb + x) * HID + 4 * g;
-            o.uv[kb] = *reinterpret_cast<const f32x4*>(a.U + e);
-            o.rv[kb] = *reinterpret_cast<const f32x4*>(a.R + e);
-            o.cv[kb] = *reinterpret_cast<const f32x4*>(a.Cand + e);
-            o.gv[kb] = *reinterpret_cast<const f32x4*>(a.dHnew + e);
-            o.hv[kb] = *reinterpret_cast<const f32x4*>(a.H + e);
-            o.bv[kb] = *reinterpret_cast<const f32x4*>(a.dBm + e);
+            o.uv[kb] = stc_ld_once(reinterpret_cast<const f32x4*>(a.U + e));
+            o.rv[kb] = stc_ld_once(reinterpret_cast<const f32x4*>(a.R + e));
+            o.cv[kb] = stc_ld_once(reinterpret_cast<const f32x4*>(a.Cand + e));
+            o.gv[kb] = stc_ld_once(reinterpret_cast<const f32x4*>(a.dHnew + e));
+            o.hv[kb] = stc_ld_once(reinterpret_cast<const f32x4*>(a.H + e));
+            o.bv[kb] = stc_ld_once(reinterpret_cast<const f32x4*>(a.dBm + e));
         }
     };
     // the two T_1 fragments are used four times per node (both orientations, both convolutions): kept in registers for the whole kernel
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
             for (int lb = 0; lb < LBD; ++lb)
 #pragma unroll
                 for (int rb = 0; rb < NRB; ++rb)
-                    if (ACC[lb]) old[n][lb][rb] = *reinterpret_cast<const f32x4*>(dP[n][lb] + ((size_t)node * C + 16 * rb + x) * HID + 4 * g);
+                    if (ACC[lb]) old[n][lb][rb] = stc_ld_once(reinterpret_cast<const f32x4*>(dP[n][lb] + ((size_t)node * C + 16 * rb + x) * HID + 4 * g));
         if (next_node + nw < a.nodes) load_ops(nx2, next_node + nw);      // software prefetch, two nodes ahead
         __builtin_amdgcn_sched_barrier(0);
         const size_t r0 = (size_t)node * C;
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
                         if (ACC[lb]) z[rb] = z[rb] * ikg_sg + old[n][lb][rb];
                         else z[rb] *= ikg_sg;
                     }
-                    *reinterpret_cast<f32x4*>(dP[n][lb] + (r0 + 16 * rb + x) * HID + 4 * g) = z[rb];
+                    stc_st_once(reinterpret_cast<f32x4*>(dP[n][lb] + (r0 + 16 * rb + x) * HID + 4 * g), z[rb]);
                 }
             }
         Op qd[2];

@@ -22,6 +22,17 @@
 // Shapes: C = 32 * NB2 categories, Ho = 16 * HB outputs, L <= 32 features per slab (one 32-wide step, zero padded),
 // Ks = Kc = K.  Other shapes stay on the fp32 MFMA / VALU kernels.
 #include "stc_x3_frag.h"
+// Default cache policy here, measured: a lane's two 16-byte pieces of a row come from two load instructions that share every 128-byte
+// line, and the results leave as 4-byte accumulator-layout stores (half a line per instruction) -- with the non-temporal policy the
+// gates forward ran 5 % (loads) and 17 % (stores) SLOWER; the full-line accesses of the cell backward and of the aggregation epilogues gain.
+#ifndef STC_X3_NT_LD
+#define STC_X3_NT_LD 0
+#endif
+#ifndef STC_X3_NT_ST
+#define STC_X3_NT_ST 0
+#endif
+template <class T> __device__ __forceinline__ T x3_ld(const T* p) { if (STC_X3_NT_LD) return stc_ld_once(p); return *p; }
+template <class T> __device__ __forceinline__ void x3_st(T* p, const T& v) { if (STC_X3_NT_ST) stc_st_once(p, v); else *p = v; }
 
 namespace {
 
@@ -31,23 +42,23 @@ struct Row8 {
     f32x4 a, b;
     __device__ __forceinline__ void load(const float* __restrict__ row, int g) {
         a = kZero4; b = kZero4;
-        if (L == 32 || 8 * g < L) a = *reinterpret_cast<const f32x4*>(row + 8 * g);
-        if (L == 32 || 8 * g + 4 < L) b = *reinterpret_cast<const f32x4*>(row + 8 * g + 4);
+        if (L == 32 || 8 * g < L) a = x3_ld(reinterpret_cast<const f32x4*>(row + 8 * g));
+        if (L == 32 || 8 * g + 4 < L) b = x3_ld(reinterpret_cast<const f32x4*>(row + 8 * g + 4));
     }
     // planar layout: columns 0..15 of the row live in one (rows, 16) plane, 16..31 in another
     __device__ __forceinline__ void load_planes(const float* __restrict__ xrow, const float* __restrict__ hrow, int g) {
         static_assert(L == 32, "planar rows are 16 + 16 columns");
         const float* src = (g < 2 ? xrow : hrow) + 8 * (g & 1);
-        a = *reinterpret_cast<const f32x4*>(src);
-        b = *reinterpret_cast<const f32x4*>(src + 4);
+        a = x3_ld(reinterpret_cast<const f32x4*>(src));
+        b = x3_ld(reinterpret_cast<const f32x4*>(src + 4));
     }
     // planar layout with a narrow input plane: columns 0..15 from the (rows, 16) state plane, 16..16+cin-1 from the
     // (rows, cin) input plane, cin <= 4; everything else zero
     __device__ __forceinline__ void load_planes_narrow(const float* __restrict__ prow, const float* __restrict__ xrow, int cin, int g) {
         a = kZero4; b = kZero4;
         if (g < 2) {
-            a = *reinterpret_cast<const f32x4*>(prow + 8 * g);
-            b = *reinterpret_cast<const f32x4*>(prow + 8 * g + 4);
+            a = x3_ld(reinterpret_cast<const f32x4*>(prow + 8 * g));
+            b = x3_ld(reinterpret_cast<const f32x4*>(prow + 8 * g + 4));
         } else if (g == 2) {
             const float x0 = xrow[0], x1 = cin > 1 ? xrow[1] : 0.f, x2 = cin > 2 ? xrow[2] : 0.f, x3 = cin > 3 ? xrow[3] : 0.f;
             a = f32x4{x0, x1, x2, x3};
@@ -59,8 +70,8 @@ struct Row8 {
         for (int i = 0; i < 4; ++i) { a[i] = fmaf(v, o.a[i], a[i]); b[i] = fmaf(v, o.b[i], b[i]); }
     }
     __device__ __forceinline__ void store(float* __restrict__ row, int g) const {
-        if (L == 32 || 8 * g < L) *reinterpret_cast<f32x4*>(row + 8 * g) = a;
-        if (L == 32 || 8 * g + 4 < L) *reinterpret_cast<f32x4*>(row + 8 * g + 4) = b;
+        if (L == 32 || 8 * g < L) x3_st(reinterpret_cast<f32x4*>(row + 8 * g), a);
+        if (L == 32 || 8 * g + 4 < L) x3_st(reinterpret_cast<f32x4*>(row + 8 * g + 4), b);
     }
 };
 
@@ -265,9 +276,9 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
                     const size_t row = (size_t)node * C + 16 * rb + 4 * g + r;
                     const float u = fast_sigmoid(F::SCALED ? fmaf(acc[rb][0][r], inv, bv[0]) : acc[rb][0][r] + bv[0]);
                     const float gate = fast_sigmoid(F::SCALED ? fmaf(acc[rb][HB - 1][r], inv, bv[HB - 1]) : acc[rb][HB - 1][r] + bv[HB - 1]);
-                    epi.U_out[row * HID + x] = u;
-                    epi.R_out[row * HID + x] = gate;
-                    if (PL) { if (!POST || epi.CandIn) epi.CandIn[row * HID + x] = gate * hv[rb][r]; }      // the R*H plane (optional with POST)
+                    x3_st(epi.U_out + row * HID + x, u);
+                    x3_st(epi.R_out + row * HID + x, gate);
+                    if (PL) { if (!POST || epi.CandIn) x3_st(epi.CandIn + row * HID + x, gate * hv[rb][r]); }      // the R*H plane (optional with POST)
                     else epi.CandIn[row * L + epi.cin + x] = gate * hv[rb][r];
                     if (POST) tr[((wave * NRB + rb) * 16 + 4 * g + r) * TRS + x] = gate * hv[rb][r];
                 }
@@ -323,8 +334,8 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const size_t o = ((size_t)node * C + 16 * rb + 4 * g + r) * HID + x;
-                        post.A[o] = F::SCALED ? fmaf(pa[0][rb][0][r], invp, bcv) : pa[0][rb][0][r] + bcv;
-                        post.Bm[o] = F::SCALED ? pa[1][rb][0][r] * invp : pa[1][rb][0][r];
+                        x3_st(post.A + o, F::SCALED ? fmaf(pa[0][rb][0][r], invp, bcv) : pa[0][rb][0][r] + bcv);
+                        x3_st(post.Bm + o, F::SCALED ? pa[1][rb][0][r] * invp : pa[1][rb][0][r]);
                     }
                 __builtin_amdgcn_wave_barrier();
             }
@@ -419,13 +430,13 @@ struct GateRows {
 #pragma unroll
         for (int kb = 0; kb < NRB; ++kb) {
             const size_t e = ((size_t)node * C + 16 * kb + x) * 16 + 4 * g;
-            u[kb] = *reinterpret_cast<const f32x4*>(p.U + e);
-            c[kb] = *reinterpret_cast<const f32x4*>(p.Cand + e);
-            gn[kb] = *reinterpret_cast<const f32x4*>(p.dH_in + e);
+            u[kb] = stc_ld_once(reinterpret_cast<const f32x4*>(p.U + e));
+            c[kb] = stc_ld_once(reinterpret_cast<const f32x4*>(p.Cand + e));
+            gn[kb] = stc_ld_once(reinterpret_cast<const f32x4*>(p.dH_in + e));
             if constexpr (GATES) {
-                r[kb] = *reinterpret_cast<const f32x4*>(p.R + e);
-                h[kb] = *reinterpret_cast<const f32x4*>(p.H + e);
-                dci[kb] = *reinterpret_cast<const f32x4*>(p.dCandIn + e);      // planar: the R*H plane's gradient, rows of 16
+                r[kb] = stc_ld_once(reinterpret_cast<const f32x4*>(p.R + e));
+                h[kb] = stc_ld_once(reinterpret_cast<const f32x4*>(p.H + e));
+                dci[kb] = stc_ld_once(reinterpret_cast<const f32x4*>(p.dCandIn + e));      // planar: the R*H plane's gradient, rows of 16
             }
         }
     }
@@ -453,7 +464,7 @@ __device__ __forceinline__ void form_dy(DyFrag<NRB, HB>& gq, const GateRows<NRB>
         }
         if constexpr (HB == 2) {
             if constexpr (FOLD) stash[kb * 64 + (g * 16 + x)] = make_float4(dh[0], dh[1], dh[2], dh[3]);
-            else *reinterpret_cast<f32x4*>(p.dH + ((size_t)node * C + 16 * kb + x) * 16 + 4 * g) = dh;
+            else stc_st_once(reinterpret_cast<f32x4*>(p.dH + ((size_t)node * C + 16 * kb + x) * 16 + 4 * g), dh);
         }
 #pragma unroll
         for (int hb = 0; hb < HB; ++hb) *reinterpret_cast<f32x4*>(tile + ((hb * NRB + kb) * 16 + x) * TRS + 4 * g) = gq.v[kb][hb];
@@ -568,7 +579,7 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
 #pragma unroll
                 for (int n = 0; n < K; ++n)
 #pragma unroll
-                    for (int rb = 0; rb < NRB; ++rb) old[n][rb] = *reinterpret_cast<const f32x4*>(dZ.p[n] + (r0 + 16 * rb + x) * 16 + 4 * g);
+                    for (int rb = 0; rb < NRB; ++rb) old[n][rb] = stc_ld_once(reinterpret_cast<const f32x4*>(dZ.p[n] + (r0 + 16 * rb + x) * 16 + 4 * g));
             }
             if (next_node < nodes) { rows_nxt.template load<PRO == PRO_GATES_CAND>(pro, next_node, x, g); nx.load_z(Z, next_node, x, g, Lw - 16); }
             __builtin_amdgcn_sched_barrier(0);
@@ -650,7 +661,7 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
                         z[rb] = f32x4{sh.x, sh.y, sh.z, sh.w};
                         if constexpr (F::SCALED) z[rb] *= sg * kz;      // (parked unscaled)
                     } else if (ACC && PL == 1 && lb == 0 && !F::SCALED) {     // ... or from what the plane already holds
-                        z[rb] = *reinterpret_cast<const f32x4*>(dZ.p[n] + (r0 + 16 * rb + x) * 16 + 4 * g);
+                        z[rb] = stc_ld_once(reinterpret_cast<const f32x4*>(dZ.p[n] + (r0 + 16 * rb + x) * 16 + 4 * g));
                     } else {
                         z[rb] = kZero4;
                     }
@@ -664,19 +675,19 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
                 if constexpr (F::SCALED) {                      // out of the scaled space (+ what the plane already holds)
 #pragma unroll
                     for (int rb = 0; rb < NRB; ++rb) {
-                        if (ACC && PL == 1 && lb == 0) z[rb] = z[rb] * ikz_sg + (PFG ? old[n][rb] : *reinterpret_cast<const f32x4*>(dZ.p[n] + (r0 + 16 * rb + x) * 16 + 4 * g));
+                        if (ACC && PL == 1 && lb == 0) z[rb] = z[rb] * ikz_sg + (PFG ? old[n][rb] : stc_ld_once(reinterpret_cast<const f32x4*>(dZ.p[n] + (r0 + 16 * rb + x) * 16 + 4 * g)));
                         else z[rb] *= ikz_sg;
                     }
                 }
                 if constexpr (PL == 1) {                        // planar gradient slabs: block lb of the row goes to plane lb
 #pragma unroll
                     for (int rb = 0; rb < NRB; ++rb)
-                        *reinterpret_cast<f32x4*>((lb == 0 ? dZ.p[n] : dZ.q[n]) + (r0 + 16 * rb + x) * 16 + 4 * g) = z[rb];
+                        stc_st_once(reinterpret_cast<f32x4*>((lb == 0 ? dZ.p[n] : dZ.q[n]) + (r0 + 16 * rb + x) * 16 + 4 * g), z[rb]);
                 } else if constexpr (PL == 2) {                 // narrow input plane: only the state plane's gradient is wanted
                     if (lb == 0) {
 #pragma unroll
                         for (int rb = 0; rb < NRB; ++rb)
-                            *reinterpret_cast<f32x4*>(dZ.p[n] + (r0 + 16 * rb + x) * 16 + 4 * g) = z[rb];
+                            stc_st_once(reinterpret_cast<f32x4*>(dZ.p[n] + (r0 + 16 * rb + x) * 16 + 4 * g), z[rb]);
                     }
                 } else if (16 * lb + 4 * g < L) {
 #pragma unroll
@@ -1017,12 +1028,12 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
             if constexpr (PL == 1) {                            // planar gradient: columns 0..15 -> dX, 16..31 -> dX2
 #pragma unroll
                 for (int rb = 0; rb < NRB; ++rb)
-                    *reinterpret_cast<f32x4*>((lb == 0 ? dX : dX2) + (r0 + 16 * rb + x) * 16 + 4 * g) = z[rb];
+                    stc_st_once(reinterpret_cast<f32x4*>((lb == 0 ? dX : dX2) + (r0 + 16 * rb + x) * 16 + 4 * g), z[rb]);
             } else if constexpr (PL == 2) {                     // narrow input plane: only the 16-wide plane's gradient is wanted
                 if (lb == 0) {
 #pragma unroll
                     for (int rb = 0; rb < NRB; ++rb)
-                        *reinterpret_cast<f32x4*>(dX + (r0 + 16 * rb + x) * 16 + 4 * g) = z[rb];
+                        stc_st_once(reinterpret_cast<f32x4*>(dX + (r0 + 16 * rb + x) * 16 + 4 * g), z[rb]);
                 }
             } else if (16 * lb + 4 * g < L) {
 #pragma unroll

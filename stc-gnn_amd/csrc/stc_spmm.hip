@@ -97,8 +97,8 @@ __device__ __forceinline__ void blend_piece(const EpiArgs& a, size_t rowg, int c
     const float4 c = make_float4(tanh_fast(v.x), tanh_fast(v.y), tanh_fast(v.z), tanh_fast(v.w));
     const float4 hn = make_float4((1.f - u.x) * hh.x + u.x * c.x, (1.f - u.y) * hh.y + u.y * c.y,
                                   (1.f - u.z) * hh.z + u.z * c.z, (1.f - u.w) * hh.w + u.w * c.w);
-    *reinterpret_cast<float4*>(a.Cand + 4 * o) = c;
-    *reinterpret_cast<float4*>(a.Hnew + 4 * o) = hn;
+    nt_store4(reinterpret_cast<float4*>(a.Cand + 4 * o), c);
+    nt_store4(reinterpret_cast<float4*>(a.Hnew + 4 * o), hn);
     const int q4 = ch & 3;
     const size_t e = rowg * a.C + (ch >> 2);
 #pragma unroll
@@ -139,14 +139,14 @@ __device__ __forceinline__ void epilogue(const EpiArgs& a, size_t rowg, int F4, 
         const size_t e = rowg * a.C + (ch >> 2);                  // h = 16: piece ch = 4 * category + quarter
         const int q4 = ch & 3;
         for (int i = 0; i < a.n_add; ++i) {
-            const float4 t = *reinterpret_cast<const float4*>(a.add[i] + e * a.add_ld[i] + a.add_off[i] + 4 * q4);
+            const float4 t = nt_load4(reinterpret_cast<const float4*>(a.add[i] + e * a.add_ld[i] + a.add_off[i] + 4 * q4));
             const float sc = a.add_scale[i];
             y.x = fmaf(sc, t.x, y.x); y.y = fmaf(sc, t.y, y.y); y.z = fmaf(sc, t.z, y.z); y.w = fmaf(sc, t.w, y.w);
         }
         nt_store4(a.Y + o, y);
         amax = fmaxf(fmaxf(amax, fmaxf(fabsf(y.x), fabsf(y.y))), fmaxf(fabsf(y.z), fabsf(y.w)));
         if (a.dYout) {
-            const float4 u = *reinterpret_cast<const float4*>(a.gU + 4 * o), c = *reinterpret_cast<const float4*>(a.gCand + 4 * o);
+            const float4 u = nt_load4(reinterpret_cast<const float4*>(a.gU + 4 * o)), c = nt_load4(reinterpret_cast<const float4*>(a.gCand + 4 * o));
             nt_store4(reinterpret_cast<float4*>(a.dYout) + o,
                       make_float4(y.x * u.x * (1.f - c.x * c.x), y.y * u.y * (1.f - c.y * c.y), y.z * u.z * (1.f - c.z * c.z), y.w * u.w * (1.f - c.w * c.w)));
         }
@@ -155,7 +155,7 @@ __device__ __forceinline__ void epilogue(const EpiArgs& a, size_t rowg, int F4, 
     // EP_BLEND: rows are (category, h) with h = 16: piece ch = 4 * category + quarter
     const float4 y0 = nt_load4(a.Y0 + o);
     const float4 v = make_float4(acc.x + y0.x, acc.y + y0.y, acc.z + y0.z, acc.w + y0.w);
-    const float4 u = *reinterpret_cast<const float4*>(a.U + 4 * o), hh = *reinterpret_cast<const float4*>(a.H + 4 * o);
+    const float4 u = nt_load4(reinterpret_cast<const float4*>(a.U + 4 * o)), hh = nt_load4(reinterpret_cast<const float4*>(a.H + 4 * o));
     blend_piece(a, rowg, ch, o, v, u, hh);
 }
 
@@ -334,8 +334,8 @@ __global__ __launch_bounds__(SPMM_THREADS) void spmm_bcsr_kernel(
                         if (r < rows_here && ch < F4) {
                             const size_t o = ((size_t)b * n_rows + row_base + r) * F4 + ch;
                             pa[r][p] = nt_load4(ep.Y0 + o);
-                            pu[r][p] = *reinterpret_cast<const float4*>(ep.U + 4 * o);
-                            ph[r][p] = *reinterpret_cast<const float4*>(ep.H + 4 * o);
+                            pu[r][p] = nt_load4(reinterpret_cast<const float4*>(ep.U + 4 * o));
+                            ph[r][p] = nt_load4(reinterpret_cast<const float4*>(ep.H + 4 * o));
                         }
                     }
             }
