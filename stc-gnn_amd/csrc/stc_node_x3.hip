@@ -52,6 +52,14 @@ struct Row8 {
         a = x3_ld(reinterpret_cast<const f32x4*>(src));
         b = x3_ld(reinterpret_cast<const f32x4*>(src + 4));
     }
+    // planar layout, PIECE order: this lane takes the 16-byte piece g of the row from EACH plane (slots 0..3 = X columns 4g.., slots 4..7 =
+    // H columns 4g..), so that one load instruction covers 16 whole rows (1 KiB, whole 128-byte lines) and can carry the non-temporal
+    // policy; the weight tables are filled in the same slot order (piece_slot_row).
+    __device__ __forceinline__ void load_pieces(const float* __restrict__ xrow, const float* __restrict__ hrow, int g) {
+        static_assert(L == 32, "planar rows are 16 + 16 columns");
+        a = stc_ld_once(reinterpret_cast<const f32x4*>(xrow + 4 * g));
+        b = stc_ld_once(reinterpret_cast<const f32x4*>(hrow + 4 * g));
+    }
     // planar layout with a narrow input plane: columns 0..15 from the (rows, 16) state plane, 16..16+cin-1 from the
     // (rows, cin) input plane, cin <= 4; everything else zero
     __device__ __forceinline__ void load_planes_narrow(const float* __restrict__ prow, const float* __restrict__ xrow, int cin, int g) {
@@ -86,6 +94,9 @@ struct Row8 {
 // is written without re-reading Xt and R*H from HBM.
 struct PostArgs { const float* Wc; const float* bc; float* A; float* Bm; };
 
+// Row of the [X | H] slab that contraction slot e of lane group gg carries: natural order 8 gg + e, or Row8::load_pieces' order.
+__host__ __device__ constexpr int piece_slot_row(bool pieces, int gg, int e) { return !pieces ? 8 * gg + e : (e < 4 ? 4 * gg + e : 16 + 4 * gg + (e - 4)); }
+
 // F: operand format (stc_x3_frag.h).  FmtH2 (two fp16 pieces, three products): W and T_c are normalised per workgroup at table-fill time
 // (W's blocks c = 0 carry sW sT, blocks c >= 1 carry sW, T_c carries sT: projection and category mix then meet in one accumulator with the
 // common factor sW sT, taken out in the epilogue); activations enter as they are (bounded by construction).
@@ -113,6 +124,7 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
     // beyond L2 (rocprofv3 FETCH_SIZE: 2 435 MB against the 2 055 MB of the four input planes -- the rows a wave loaded one node ago have
     // left the XCD's 4 MiB L2 by the time it asks again): the rows go through a per-wave LDS tile instead, row layout -> accumulator layout.
     constexpr bool HT = EPI == EPI_GATES && PL != 0;
+    constexpr bool PIECES = PL == 1;                        // two full planes per slab: piece-order loads (Row8::load_pieces)
     float* th = tr + (POST ? MF_WAVES * NRB * 16 * TRS : 0);    // HT: [wave][NRB][16 rows][TRS]
     const int tid = threadIdx.x, lane = tid & 63, x = lane & 15, g = lane >> 4;
 
@@ -133,7 +145,7 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int l = 8 * gg + e;
+            const int l = piece_slot_row(PIECES, gg, e);
             const int wl = PL == 2 ? stc_wrow_swapped(l, Lw - 16) : l;                // PL = 2: slab columns are [state | input | pad]
             v[e] = (wl >= 0 && wl < Lw) ? W[((size_t)(n * K + c) * Lw + wl) * Ho + o] : 0.f;       // pad columns contribute nothing
         }
@@ -144,7 +156,7 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int l = 8 * gg + e;
+            const int l = piece_slot_row(PIECES, gg, e);
             const int wl = PL == 2 ? stc_wrow_swapped(l, Lw - 16) : l;
             v[e] = (wl >= 0 && wl < Lw) ? post.Wc[((size_t)(n * K + c) * Lw + wl) * 16 + (ll & 15)] : 0.f;
         }
@@ -174,7 +186,7 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
         for (int n = 0; n < KL; ++n)
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) {
-                if constexpr (PL == 1) z[n][rb].load_planes(Z.p[n] + ((size_t)nd * C + 16 * rb + x) * 16, Z.q[n] + ((size_t)nd * C + 16 * rb + x) * 16, g);
+                if constexpr (PL == 1) z[n][rb].load_pieces(Z.p[n] + ((size_t)nd * C + 16 * rb + x) * 16, Z.q[n] + ((size_t)nd * C + 16 * rb + x) * 16, g);
                 else if constexpr (PL == 2) z[n][rb].load_planes_narrow(Z.p[n] + ((size_t)nd * C + 16 * rb + x) * 16,
                                                                         Z.q[n] + ((size_t)nd * C + 16 * rb + x) * (Lw - 16), Lw - 16, g);
                 else z[n][rb].load(Z.p[n] + ((size_t)nd * C + 16 * rb + x) * L, g);
@@ -193,8 +205,10 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
         // column x of Xt (re-read from slab 0, an L2 hit) while x < cin, else the zero of pad column x + 16
         const bool has_side = EPI == EPI_GATES && !PL && x < L - HID;
         if constexpr (HT) {
-            const bool mine = PL == 1 ? g >= 2 : g < 2;          // PL = 1: rows are [X | H]; PL = 2: [H | x | pad]
-            if (mine) {
+            if constexpr (PIECES) {                                // every lane holds the piece g of its H row
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) *reinterpret_cast<f32x4*>(th + ((wave * NRB + rb) * 16 + x) * TRS + 4 * g) = cur[0][rb].b;
+            } else if (g < 2) {                                    // PL = 2: [H | x | pad]
 #pragma unroll
                 for (int rb = 0; rb < NRB; ++rb) {
                     float* dst = th + ((wave * NRB + rb) * 16 + x) * TRS + 8 * (g & 1);
@@ -269,6 +283,53 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
                     for (int r = 0; r < 4; ++r)
                         Y[((size_t)node * C + 16 * rb + 4 * g + r) * Ho + 16 * hb + x] = F::SCALED ? fmaf(acc[rb][hb][r], inv, bv[hb]) : acc[rb][hb][r] + bv[hb];
         } else if (EPI == EPI_GATES) {
+            // Planar results leave in ROW layout, non-temporally: an accumulator-layout store instruction covers half a 128-byte line of each of
+            // four rows, the row-layout one sixteen whole rows (the H tile is free once hv is read: it is the transposition scratch).  Timing
+            // probe with the same bytes: gates forward 714 -> 700 us, and the blend aggregation that reads these planes next 569 -> 548 us.
+            auto put_plane = [&](float* __restrict__ plane, const float (&v)[NRB][4]) {
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) th[((wave * NRB + rb) * 16 + 4 * g + r) * TRS + x] = v[rb][r];
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb)
+                    stc_st_once(reinterpret_cast<f32x4*>(plane + ((size_t)node * C + 16 * rb + x) * HID + 4 * g),
+                                *reinterpret_cast<const f32x4*>(th + ((wave * NRB + rb) * 16 + x) * TRS + 4 * g));
+                __builtin_amdgcn_wave_barrier();                // the next plane overwrites the tile
+            };
+            if constexpr (HT) {
+                float uu[NRB][4], gt[NRB][4];
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) uu[rb][r] = fast_sigmoid(F::SCALED ? fmaf(acc[rb][0][r], inv, bv[0]) : acc[rb][0][r] + bv[0]);
+                put_plane(epi.U_out, uu);
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) gt[rb][r] = fast_sigmoid(F::SCALED ? fmaf(acc[rb][HB - 1][r], inv, bv[HB - 1]) : acc[rb][HB - 1][r] + bv[HB - 1]);
+                put_plane(epi.R_out, gt);
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) gt[rb][r] *= hv[rb][r];                     // R*H
+                if constexpr (POST) {
+#pragma unroll
+                    for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) tr[((wave * NRB + rb) * 16 + 4 * g + r) * TRS + x] = gt[rb][r];
+                    if (epi.CandIn) {                               // (the R*H plane is optional with POST)
+                        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                        for (int rb = 0; rb < NRB; ++rb)
+                            stc_st_once(reinterpret_cast<f32x4*>(epi.CandIn + ((size_t)node * C + 16 * rb + x) * HID + 4 * g),
+                                        *reinterpret_cast<const f32x4*>(tr + ((wave * NRB + rb) * 16 + x) * TRS + 4 * g));
+                    }
+                } else {
+                    put_plane(epi.CandIn, gt);
+                }
+            } else {
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
@@ -276,12 +337,11 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
                     const size_t row = (size_t)node * C + 16 * rb + 4 * g + r;
                     const float u = fast_sigmoid(F::SCALED ? fmaf(acc[rb][0][r], inv, bv[0]) : acc[rb][0][r] + bv[0]);
                     const float gate = fast_sigmoid(F::SCALED ? fmaf(acc[rb][HB - 1][r], inv, bv[HB - 1]) : acc[rb][HB - 1][r] + bv[HB - 1]);
-                    x3_st(epi.U_out + row * HID + x, u);
-                    x3_st(epi.R_out + row * HID + x, gate);
-                    if (PL) { if (!POST || epi.CandIn) x3_st(epi.CandIn + row * HID + x, gate * hv[rb][r]); }      // the R*H plane (optional with POST)
-                    else epi.CandIn[row * L + epi.cin + x] = gate * hv[rb][r];
-                    if (POST) tr[((wave * NRB + rb) * 16 + 4 * g + r) * TRS + x] = gate * hv[rb][r];
+                    epi.U_out[row * HID + x] = u;
+                    epi.R_out[row * HID + x] = gate;
+                    epi.CandIn[row * L + epi.cin + x] = gate * hv[rb][r];
                 }
+            }
             if constexpr (POST) {
                 // ---- candidate projection on [Xt | R*H] (PL = 1) / [R*H | x | pad] (PL = 2): A = sum_c T_c^T (. Wc_{0,c}) + bc, Bm likewise with Wc_{1,c}
                 __builtin_amdgcn_wave_barrier();
@@ -292,16 +352,16 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
                     // (Branching between "a register of cur" and "a load from the tile" made the compiler select between two
                     // ADDRESSES instead: cur[0] was stored to scratch on every node -- 64 B x 64 lanes x 250 880 nodes = 1.03 GB of
                     // dead stores per launch, the 1.39x HBM traffic rocprofv3 showed for this kernel, profiles/r02/.)
-                    const float* trow = tr + ((wave * NRB + rb) * 16 + x) * TRS + 8 * (g & 1);
-                    const f32x4 ta = *reinterpret_cast<const f32x4*>(trow), tb = *reinterpret_cast<const f32x4*>(trow + 4);
-                    const f32x4 xa = cur[0][rb].a, xb = cur[0][rb].b;
                     f32x4 a4, b4;
+                    if constexpr (PIECES) {                                               // piece order: [Xt columns 4g.. | R*H columns 4g..]
+                        a4 = cur[0][rb].a;
+                        b4 = *reinterpret_cast<const f32x4*>(tr + ((wave * NRB + rb) * 16 + x) * TRS + 4 * g);
+                    } else {
+                        const float* trow = tr + ((wave * NRB + rb) * 16 + x) * TRS + 8 * (g & 1);
+                        const f32x4 ta = *reinterpret_cast<const f32x4*>(trow), tb = *reinterpret_cast<const f32x4*>(trow + 4);
+                        const f32x4 xa = cur[0][rb].a;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        if (PL == 1) {                                                    // [Xt columns 8g.. | R*H columns 8(g-2)..]
-                            a4[i] = g < 2 ? xa[i] : ta[i];
-                            b4[i] = g < 2 ? xb[i] : tb[i];
-                        } else {                                                          // [R*H | the narrow input columns | zero]
+                        for (int i = 0; i < 4; ++i) {                                     // [R*H | the narrow input columns | zero]
                             a4[i] = g < 2 ? ta[i] : (g == 2 ? xa[i] : 0.f);
                             b4[i] = g < 2 ? tb[i] : 0.f;
                         }
@@ -329,15 +389,17 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
                         }
                     }
                 const float bcv = post.bc ? post.bc[x] : 0.f;
+                float ov[NRB][4];
 #pragma unroll
                 for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const size_t o = ((size_t)node * C + 16 * rb + 4 * g + r) * HID + x;
-                        x3_st(post.A + o, F::SCALED ? fmaf(pa[0][rb][0][r], invp, bcv) : pa[0][rb][0][r] + bcv);
-                        x3_st(post.Bm + o, F::SCALED ? pa[1][rb][0][r] * invp : pa[1][rb][0][r]);
-                    }
-                __builtin_amdgcn_wave_barrier();
+                    for (int r = 0; r < 4; ++r) ov[rb][r] = F::SCALED ? fmaf(pa[0][rb][0][r], invp, bcv) : pa[0][rb][0][r] + bcv;
+                put_plane(post.A, ov);
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ov[rb][r] = F::SCALED ? pa[1][rb][0][r] * invp : pa[1][rb][0][r];
+                put_plane(post.Bm, ov);
             }
             if (has_side) {
                 const int scol = x < epi.cin ? x : x + HID;
