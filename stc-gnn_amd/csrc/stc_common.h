@@ -88,20 +88,12 @@ __device__ __forceinline__ int stc_xcd_tile(int bid, int n_tiles) {
 
 // Planes that a launch streams ONCE (an operand plane read by exactly one lane, a result plane nobody re-reads in this launch) carry the
 // non-temporal cache policy: on this chip a 2 x 514 MB copy runs at 5.13 TB/s with default-policy accesses, 5.32 with nt stores and 5.63
-// with nt loads as well (tools/probes/copy_patterns.hip).  Never on rows that other lanes gather again (the aggregation's neighbour rows).
-#ifndef STC_STREAM_NT
-#define STC_STREAM_NT 1
-#endif
+// with nt loads as well (tools/probes/copy_patterns.hip).  Only for instructions that cover whole 128-byte lines; never on rows that other
+// lanes gather again (the aggregation's neighbour rows).
 template <class T>
-__device__ __forceinline__ T stc_ld_once(const T* p) {
-    if (STC_STREAM_NT) return __builtin_nontemporal_load(p);
-    return *p;
-}
+__device__ __forceinline__ T stc_ld_once(const T* p) { return __builtin_nontemporal_load(p); }
 template <class T>
-__device__ __forceinline__ void stc_st_once(T* p, const T& v) {
-    if (STC_STREAM_NT) __builtin_nontemporal_store(v, p);
-    else *p = v;
-}
+__device__ __forceinline__ void stc_st_once(T* p, const T& v) { __builtin_nontemporal_store(v, p); }
 
 __device__ __forceinline__ float stc_wave_sum(float v) {
 #pragma unroll

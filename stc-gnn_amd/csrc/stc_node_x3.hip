@@ -22,17 +22,10 @@
 // Shapes: C = 32 * NB2 categories, Ho = 16 * HB outputs, L <= 32 features per slab (one 32-wide step, zero padded),
 // Ks = Kc = K.  Other shapes stay on the fp32 MFMA / VALU kernels.
 #include "stc_x3_frag.h"
-// Default cache policy here, measured: a lane's two 16-byte pieces of a row come from two load instructions that share every 128-byte
-// line, and the results leave as 4-byte accumulator-layout stores (half a line per instruction) -- with the non-temporal policy the
-// gates forward ran 5 % (loads) and 17 % (stores) SLOWER; the full-line accesses of the cell backward and of the aggregation epilogues gain.
-#ifndef STC_X3_NT_LD
-#define STC_X3_NT_LD 0
-#endif
-#ifndef STC_X3_NT_ST
-#define STC_X3_NT_ST 0
-#endif
-template <class T> __device__ __forceinline__ T x3_ld(const T* p) { if (STC_X3_NT_LD) return stc_ld_once(p); return *p; }
-template <class T> __device__ __forceinline__ void x3_st(T* p, const T& v) { if (STC_X3_NT_ST) stc_st_once(p, v); else *p = v; }
+// Cache policy of this file's streams (stc_common.h: stc_ld_once / stc_st_once), measured: whole-line accesses carry the non-temporal
+// policy (Row8::load_pieces, put_plane, the backward kernels' row-layout planes); where a lane's two 16-byte pieces of a row come from two
+// load instructions that share every 128-byte line (Row8::load, load_planes) or results leave as 4-byte accumulator-layout stores (half a
+// line per instruction), the default policy stays -- with the non-temporal one the gates forward ran 5 % (loads) and 17 % (stores) slower.
 
 namespace {
 
@@ -42,15 +35,15 @@ struct Row8 {
     f32x4 a, b;
     __device__ __forceinline__ void load(const float* __restrict__ row, int g) {
         a = kZero4; b = kZero4;
-        if (L == 32 || 8 * g < L) a = x3_ld(reinterpret_cast<const f32x4*>(row + 8 * g));
-        if (L == 32 || 8 * g + 4 < L) b = x3_ld(reinterpret_cast<const f32x4*>(row + 8 * g + 4));
+        if (L == 32 || 8 * g < L) a = *reinterpret_cast<const f32x4*>(row + 8 * g);
+        if (L == 32 || 8 * g + 4 < L) b = *reinterpret_cast<const f32x4*>(row + 8 * g + 4);
     }
     // planar layout: columns 0..15 of the row live in one (rows, 16) plane, 16..31 in another
     __device__ __forceinline__ void load_planes(const float* __restrict__ xrow, const float* __restrict__ hrow, int g) {
         static_assert(L == 32, "planar rows are 16 + 16 columns");
         const float* src = (g < 2 ? xrow : hrow) + 8 * (g & 1);
-        a = x3_ld(reinterpret_cast<const f32x4*>(src));
-        b = x3_ld(reinterpret_cast<const f32x4*>(src + 4));
+        a = *reinterpret_cast<const f32x4*>(src);
+        b = *reinterpret_cast<const f32x4*>(src + 4);
     }
     // planar layout, PIECE order: this lane takes the 16-byte piece g of the row from EACH plane (slots 0..3 = X columns 4g.., slots 4..7 =
     // H columns 4g..), so that one load instruction covers 16 whole rows (1 KiB, whole 128-byte lines) and can carry the non-temporal
@@ -65,8 +58,8 @@ struct Row8 {
     __device__ __forceinline__ void load_planes_narrow(const float* __restrict__ prow, const float* __restrict__ xrow, int cin, int g) {
         a = kZero4; b = kZero4;
         if (g < 2) {
-            a = x3_ld(reinterpret_cast<const f32x4*>(prow + 8 * g));
-            b = x3_ld(reinterpret_cast<const f32x4*>(prow + 8 * g + 4));
+            a = *reinterpret_cast<const f32x4*>(prow + 8 * g);
+            b = *reinterpret_cast<const f32x4*>(prow + 8 * g + 4);
         } else if (g == 2) {
             const float x0 = xrow[0], x1 = cin > 1 ? xrow[1] : 0.f, x2 = cin > 2 ? xrow[2] : 0.f, x3 = cin > 3 ? xrow[3] : 0.f;
             a = f32x4{x0, x1, x2, x3};
@@ -78,8 +71,8 @@ struct Row8 {
         for (int i = 0; i < 4; ++i) { a[i] = fmaf(v, o.a[i], a[i]); b[i] = fmaf(v, o.b[i], b[i]); }
     }
     __device__ __forceinline__ void store(float* __restrict__ row, int g) const {
-        if (L == 32 || 8 * g < L) x3_st(reinterpret_cast<f32x4*>(row + 8 * g), a);
-        if (L == 32 || 8 * g + 4 < L) x3_st(reinterpret_cast<f32x4*>(row + 8 * g + 4), b);
+        if (L == 32 || 8 * g < L) *reinterpret_cast<f32x4*>(row + 8 * g) = a;
+        if (L == 32 || 8 * g + 4 < L) *reinterpret_cast<f32x4*>(row + 8 * g + 4) = b;
     }
 };
 
