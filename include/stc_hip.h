@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define STC_ABI_VERSION 20
+#define STC_ABI_VERSION 21
 #define STC_MAX_K 4          /* highest Chebyshev order (Ks, Kc) the node kernels accept */
 
 /* Operand formats of the split-operand matrix-core kernels (C = 32 / 64, hidden 16).  Every fp32 operand is split into low-precision
@@ -458,10 +458,13 @@ int stc_head_bwd_f32(const float* H, const float* w, const float* y, const float
  * dGs^T = sum dZ1 x Z0 and dT_c = sum V_c x dY with a few stacked products per backward pass (stc_hip/small.py).  NULL = not wanted.
  * graph_is_dense != 0: the caller vouches that the CSR is the FULL n x n pattern with columns in order (nnz = n*n), i.e. val is a dense
  * row-major matrix (graph.full_pattern): the aggregations then run as matrix products on the staged planes instead of row gathers.
- * phase / splits (ABI v20): phase = 0, splits = 1: the whole cell step in this launch, one workgroup per sample (`batch` of the chip's 256
- * compute units work).  phase = 1..4, splits = G: ONLY that phase (forward: aggregate, gates, aggregate R*H, candidate; backward:
- * candidate convolution, transpose-aggregate + gate backward, gates convolution, transpose-aggregate), the sample's rows dealt over G
- * workgroups -- the caller launches the four phases in order, the launch boundaries being the barriers; same buffers, same results.
+ * phase / splits (ABI v20; fused phases v21): phase = 0, splits = 1: the whole cell step in this launch, one workgroup per sample (`batch` of
+ * the chip's 256 compute units work).  phase != 0, splits = G: the sample's row tiles are dealt in CONTIGUOUS ranges over G workgroups and
+ * the launch runs ONLY phase 1..4 (forward: aggregate, gates, aggregate R*H, candidate; backward: candidate convolution,
+ * transpose-aggregate + gate backward, gates convolution, transpose-aggregate) or, v21, a pair of phases whose second half reads only the
+ * workgroup's own rows: forward 5 = 1 + 2, 6 = 3 + 4; backward 7 = 2 + 3 (not with graph_is_dense: a dense backward deals node tiles).
+ * The caller launches the phases in order -- (5, 6) and (1, 7, 4), or one by one -- the launch boundaries being the barriers; same
+ * buffers, same results.  The workspace holds three gradient slabs and the gate gradients per row (stc_cell_small_workspace_bytes).
  * dparams then has R * G rows per sample (row (b * G + g) * R + r). */
 int stc_cell_small_supported(int32_t Ks, int32_t Kc, int32_t C, int32_t cin, int32_t h);
 size_t stc_cell_small_workspace_bytes(int32_t n_nodes, int32_t C, int32_t cin, int32_t batch);
