@@ -285,6 +285,63 @@ def pmc_mfma(config_key):
             'kernels': keep}
 
 
+class PowerSampler:
+    """Package power and shader clock of this rank's GPU, sampled ~10 times a second over the timed region (amdsmi; rank 0 reports).
+    The metric step runs at the package power limit with the shader clock throttled (profiles/r03/clock_trace.txt), so the line says
+    under which power / clock its value was measured.  Never allowed to break the line: any failure -> ``"power": null``."""
+
+    def __init__(self, index):
+        import threading
+        self.rows, self.stop_flag, self.thread, self.err = [], threading.Event(), None, None
+        try:
+            import amdsmi
+            self.smi = amdsmi
+            amdsmi.amdsmi_init()
+            handles = amdsmi.amdsmi_get_processor_handles()
+            self.h = handles[index] if index < len(handles) else handles[0]
+            self.limit = self._num(amdsmi.amdsmi_get_power_info(self.h).get('power_limit'))
+            self.rated = self._num(amdsmi.amdsmi_get_clock_info(self.h, amdsmi.AmdSmiClkType.GFX).get('max_clk'))
+            self.thread = threading.Thread(target=self._run, daemon=True)
+        except Exception as e:                                       # noqa: BLE001 -- no amdsmi, no permission, no such device: no power block
+            self.err = repr(e)
+
+    @staticmethod
+    def _num(v):
+        return float(v) if isinstance(v, (int, float)) else None
+
+    def _run(self):
+        while not self.stop_flag.is_set():
+            try:
+                w = self._num(self.smi.amdsmi_get_power_info(self.h).get('current_socket_power'))
+                c = self._num(self.smi.amdsmi_get_clock_info(self.h, self.smi.AmdSmiClkType.GFX).get('clk'))
+                if w is not None and c is not None:
+                    self.rows.append((w, c))
+            except Exception as e:                                   # noqa: BLE001
+                self.err = repr(e)
+                return
+            self.stop_flag.wait(0.1)
+
+    def start(self):
+        if self.thread is not None:
+            self.thread.start()
+
+    def stop(self):
+        if self.thread is None:
+            return None
+        self.stop_flag.set()
+        self.thread.join(timeout=2.0)
+        try:
+            self.smi.amdsmi_shut_down()
+        except Exception:                                            # noqa: BLE001
+            pass
+        if not self.rows:
+            return None
+        w, c = [r[0] for r in self.rows], [r[1] for r in self.rows]
+        limit_w = self.limit / 1e6 if self.limit and self.limit > 1e5 else self.limit       # (amdsmi reports the limit in microwatts)
+        return {'source': 'amdsmi, ~10 samples/s over the timed region', 'samples': len(w), 'package_w_mean': sum(w) / len(w), 'package_w_max': max(w),
+                'package_w_limit': limit_w, 'sclk_mhz_mean': sum(c) / len(c), 'sclk_mhz_min': min(c), 'sclk_mhz_rated': self.rated}
+
+
 def main():
     a = parse()
     if a.gpus > 1 and 'RANK' not in os.environ:
@@ -369,11 +426,14 @@ def main():
             step()
         cg.replay()
         fence()
+        sampler = PowerSampler(local)
+        sampler.start()
         t0 = time.perf_counter()
         for _ in range(a.steps):
             cg.replay()
         fence()
         elapsed = time.perf_counter() - t0
+        power = sampler.stop()
         del cg
         torch.cuda.empty_cache()
         hip.timer = KernelTimer()
@@ -392,11 +452,14 @@ def main():
         # around all ~700 launches of a step -- 1 400 event records per step cost 2 ms of the 174; the complete per-kernel table comes
         # from two further steps with every launch timed, scaled to the step count (the priced entry points keep their timed-region numbers)
         hip.timer = KernelTimer(only=PRICED_ENTRY_POINTS)
+        sampler = PowerSampler(local)
+        sampler.start()
         t0 = time.perf_counter()
         for _ in range(a.steps):
             loss = step(mark=True)
         fence()
         elapsed = time.perf_counter() - t0
+        power = sampler.stop()
         priced = hip.timer.summary()
         hip.timer = KernelTimer()
         table_steps = min(a.steps, 2)
@@ -532,6 +595,7 @@ def main():
                        'operand_format': {0: 'bf16x3', 1: 'f16x2'}.get(getattr(hip, 'operand_format', None)),
                        'grad_bucket_bytes': bucket.nbytes, 'input_seeds': 'X, Y: Bernoulli(0.1635), torch seed 1000 + rank'},
             'roofline': roofline,
+            'power': power,
             'step_breakdown': {'fwd_loss_bwd_ms': phases[0], 'grad_allreduce_ms': phases[1], 'adam_ms': phases[2],
                                'samples_per_s_excluding_optimizer': world * B / ((phases[0] + phases[1]) / 1e3) if phases[0] > 0 else None,
                                'ms_per_step_without_launch_events': untimed_ms,

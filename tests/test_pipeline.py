@@ -221,6 +221,8 @@ def test_bench_line_contract(storage):
     u = r['unit_d3']
     assert u['algorithmic_bytes'] == nnz * 8 + 4 * (N + 1) + 2 * N * C * 32 * esize and u['avg_launch_us'] > 0
     assert r['aggregate']['launches'] >= r['launches'] and r['aggregate']['achieved'] > 0
+    pw = d['power']                       # package power / shader clock over the timed region (amdsmi), or null where it cannot be read
+    assert pw is None or (pw['samples'] > 0 and pw['package_w_mean'] > 0 and 0 < pw['sclk_mhz_min'] <= pw['sclk_mhz_mean'])
     sb = d['step_breakdown']
     assert sb['fwd_loss_bwd_ms'] > 0 and sb['adam_ms'] > 0 and sb['ms_per_step_without_launch_events'] > 0
     assert sb['fwd_loss_bwd_ms'] + sb['grad_allreduce_ms'] + sb['adam_ms'] <= d['ms_per_step'] * 1.05
