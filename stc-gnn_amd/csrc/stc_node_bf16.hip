@@ -196,13 +196,19 @@ __device__ __forceinline__ f32x4 unpack4(const u32x2 v) {
     return f32x4{__uint_as_float(v[0] << 16), __uint_as_float(v[0] & 0xffff0000u), __uint_as_float(v[1] << 16), __uint_as_float(v[1] & 0xffff0000u)};
 }
 // 8 columns of one row of a planar slab: wide = [P0 (16) | P1 (16)]; narrow = [P1 (16) | P0 (cin) | 0]
-template <int NARROW>
+// ONCE: the planes are streamed once by this launch (non-temporal policy, stc_common.h); false where the wave reads a plane again (the
+// gates forward takes H a second time for its epilogue: with the policy on the first read that one missed -- 842 -> 918 us)
+template <int NARROW, bool ONCE = true>
 __device__ __forceinline__ u32x4 load_planar8(const bf16_t* __restrict__ P0, const bf16_t* __restrict__ P1, size_t row, int g, int cin) {
-    if (!NARROW) return *reinterpret_cast<const u32x4*>((g < 2 ? P0 : P1) + row * 16 + 8 * (g & 1));
+    if (!NARROW) {
+        const u32x4* p = reinterpret_cast<const u32x4*>((g < 2 ? P0 : P1) + row * 16 + 8 * (g & 1));
+        return ONCE ? stc_ld_once(p) : *p;
+    }
     // branch-free: every lane issues the same five loads (valid addresses, cache hits for the lanes that discard them) and
     // selects afterwards -- divergent, cin-dependent branches around 2-byte loads serialised their latencies (the narrow
     // kernels ran 1.4-1.6x slower than the wide ones on fewer bytes)
-    const u32x4 st = *reinterpret_cast<const u32x4*>(P1 + row * 16 + 8 * (g & 1));
+    const u32x4* ps = reinterpret_cast<const u32x4*>(P1 + row * 16 + 8 * (g & 1));
+    const u32x4 st = ONCE ? stc_ld_once(ps) : *ps;
     const bf16_t* q = P0 + row * cin;
     const unsigned v0 = q[0], v1 = q[cin > 1 ? 1 : 0], v2 = q[cin > 2 ? 2 : 0], v3 = q[cin > 3 ? 3 : 0];
     const u32x4 in = {v0 | (cin > 1 ? v1 << 16 : 0u), cin > 2 ? (v2 | (cin > 3 ? v3 << 16 : 0u)) : 0u, 0u, 0u};
@@ -273,7 +279,7 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void cell_gates_fwd
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) {
             const size_t row = (size_t)nd * C + 16 * rb + x;
-            z[0][rb] = load_planar8<NARROW>(a.X, a.H, row, g, cin);
+            z[0][rb] = load_planar8<NARROW, false>(a.X, a.H, row, g, cin);     // (H comes again below, for the epilogue)
             z[1][rb] = load_planar8<NARROW>(a.SX, a.SH, row, g, cin);
         }
     };
@@ -283,7 +289,7 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void cell_gates_fwd
         if (next_node < nodes) load_rows(nxt, next_node);
         u32x2 hq[NRB];                                          // H in the epilogue's layout: row 16 db + x, columns 4g..4g+3
 #pragma unroll
-        for (int db = 0; db < NRB; ++db) hq[db] = *reinterpret_cast<const u32x2*>(a.H + ((size_t)node * C + 16 * db + x) * 16 + 4 * g);
+        for (int db = 0; db < NRB; ++db) hq[db] = stc_ld_once(reinterpret_cast<const u32x2*>(a.H + ((size_t)node * C + 16 * db + x) * 16 + 4 * g));
         __builtin_amdgcn_sched_barrier(0);
         const int lo = opaque(lane);
 
@@ -328,9 +334,9 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void cell_gates_fwd
                 rh[r] = rg[r] * hh[r];
             }
             rhp[db] = pack4(rh);
-            *reinterpret_cast<u32x2*>(a.U + e) = pack4(u);
-            *reinterpret_cast<u32x2*>(a.R + e) = pack4(rg);
-            *reinterpret_cast<u32x2*>(a.RH + e) = rhp[db];
+            stc_st_once(reinterpret_cast<u32x2*>(a.U + e), pack4(u));
+            stc_st_once(reinterpret_cast<u32x2*>(a.R + e), pack4(rg));
+            stc_st_once(reinterpret_cast<u32x2*>(a.RH + e), rhp[db]);
         }
         if constexpr (POST) {
             // the candidate's input row [Xt | RH] (narrow: [RH | x | 0]) as an operand: RH columns 8j..8j+7 of row x sit with lanes (x, 2j), (x, 2j+1)
@@ -367,7 +373,7 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void cell_gates_fwd
                     }
 #pragma unroll
                 for (int db = 0; db < NRB; ++db)
-                    *reinterpret_cast<u32x2*>((n == 0 ? a.A : a.Bm) + ((size_t)node * C + 16 * db + x) * 16 + 4 * g) = pack4(yA[db]);
+                    stc_st_once(reinterpret_cast<u32x2*>((n == 0 ? a.A : a.Bm) + ((size_t)node * C + 16 * db + x) * 16 + 4 * g), pack4(yA[db]));
             }
         }
 #pragma unroll
@@ -486,12 +492,12 @@ __global__ __launch_bounds__(MF_THREADS, WAVES) void node_bwd_bf16_kernel(
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) {
             const size_t e = ((size_t)nd * C + 16 * rb + x) * 16 + 8 * (g & 1);       // lanes g and g + 2 read the same 8 columns
-            q[0][rb] = *reinterpret_cast<const u32x4*>(pro.dHnew + e);
-            q[1][rb] = *reinterpret_cast<const u32x4*>(pro.Cand + e);
-            q[2][rb] = *reinterpret_cast<const u32x4*>(pro.H + e);
-            q[3][rb] = *reinterpret_cast<const u32x4*>(pro.U + e);
-            q[4][rb] = *reinterpret_cast<const u32x4*>(pro.dRH + e);
-            q[5][rb] = *reinterpret_cast<const u32x4*>(pro.R + e);
+            q[0][rb] = stc_ld_once(reinterpret_cast<const u32x4*>(pro.dHnew + e));
+            q[1][rb] = stc_ld_once(reinterpret_cast<const u32x4*>(pro.Cand + e));
+            q[2][rb] = stc_ld_once(reinterpret_cast<const u32x4*>(pro.H + e));
+            q[3][rb] = stc_ld_once(reinterpret_cast<const u32x4*>(pro.U + e));
+            q[4][rb] = stc_ld_once(reinterpret_cast<const u32x4*>(pro.dRH + e));
+            q[5][rb] = stc_ld_once(reinterpret_cast<const u32x4*>(pro.R + e));
         }
     };
     int node = blockIdx.x * MF_WAVES + wave;
@@ -522,7 +528,7 @@ __global__ __launch_bounds__(MF_THREADS, WAVES) void node_bwd_bf16_kernel(
                 dyr[rb] = pack8f(gy);
                 if (g < 2) {
                     if (pro.dH) {
-                        *reinterpret_cast<u32x4*>(pro.dH + (r0 + 16 * rb + x) * 16 + 8 * g) = pack8f(dh);
+                        stc_st_once(reinterpret_cast<u32x4*>(pro.dH + (r0 + 16 * rb + x) * 16 + 8 * g), pack8f(dh));
                     } else {                                    // park the share: row x, columns 8g .. 8g+7 of block rb
                         float4* slot = reinterpret_cast<float4*>(stash + (rb * 16 + x) * 16 + 8 * g);
                         slot[0] = make_float4(dh[0], dh[1], dh[2], dh[3]);
@@ -594,12 +600,12 @@ __global__ __launch_bounds__(MF_THREADS, WAVES) void node_bwd_bf16_kernel(
                 if constexpr (PL == 1) {                        // planar gradient slabs: block lb of the row goes to plane lb
 #pragma unroll
                     for (int rb = 0; rb < NRB; ++rb)
-                        *reinterpret_cast<u32x2*>((lb == 0 ? dZ.p[n] : dZ.q[n]) + (r0 + 16 * rb + x) * 16 + 4 * g) = pack4(z[rb]);
+                        stc_st_once(reinterpret_cast<u32x2*>((lb == 0 ? dZ.p[n] : dZ.q[n]) + (r0 + 16 * rb + x) * 16 + 4 * g), pack4(z[rb]));
                 } else if constexpr (PL == 2) {                 // narrow input plane: only the state plane's gradient is wanted
                     if (lb == 0) {
 #pragma unroll
                         for (int rb = 0; rb < NRB; ++rb)
-                            *reinterpret_cast<u32x2*>(dZ.q[n] + (r0 + 16 * rb + x) * 16 + 4 * g) = pack4(z[rb]);
+                            stc_st_once(reinterpret_cast<u32x2*>(dZ.q[n] + (r0 + 16 * rb + x) * 16 + 4 * g), pack4(z[rb]));
                     }
                 } else {
 #pragma unroll
@@ -752,7 +758,7 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_post_bwd_
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) {
                 const f32x4 z = mma(w1, qb1[rb], mma(w0, dyr[rb], kZero4));
-                *reinterpret_cast<u32x2*>(dst + (r0 + 16 * rb + x) * 16 + 4 * g) = pack4(z);
+                stc_st_once(reinterpret_cast<u32x2*>(dst + (r0 + 16 * rb + x) * 16 + 4 * g), pack4(z));
             }
         }
         u32x4 qd[K][NB2];                                       // T_1 dY_n (rows c', columns o) as operands

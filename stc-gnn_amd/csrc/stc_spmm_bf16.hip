@@ -91,8 +91,8 @@ __device__ __forceinline__ void blend_piece(const Epi& ep, size_t o, const Acc8&
         c[i] = tanh_fast(acc.v[i] + a[i]);
         hn[i] = (1.f - u[i]) * h[i] + u[i] * c[i];
     }
-    ep.Cand[o] = pack8(c);
-    ep.Hnew[o] = pack8(hn);
+    __builtin_nontemporal_store(pack8(c), ep.Cand + o);
+    __builtin_nontemporal_store(pack8(hn), ep.Hnew + o);
 }
 
 template <int MODE>
@@ -115,14 +115,14 @@ __device__ __forceinline__ void finish(const Epi& ep, size_t o, const Acc8& acc)
     for (int i = 0; i < 8; ++i) r[i] = acc.v[i];
     for (int k = 0; k < ep.n_add; ++k) {
         float t[8];
-        unpack8(ep.add[k][o], t);
+        unpack8(__builtin_nontemporal_load(ep.add[k] + o), t);
 #pragma unroll
         for (int i = 0; i < 8; ++i) r[i] += t[i];
     }
     __builtin_nontemporal_store(pack8(r), ep.Y + o);
     if (ep.dY) {
         float u[8], c[8];
-        unpack8(ep.U[o], u); unpack8(ep.gCand[o], c);
+        unpack8(__builtin_nontemporal_load(ep.U + o), u); unpack8(__builtin_nontemporal_load(ep.gCand + o), c);
 #pragma unroll
         for (int i = 0; i < 8; ++i) r[i] = r[i] * u[i] * (1.f - c[i] * c[i]);
         __builtin_nontemporal_store(pack8(r), ep.dY + o);
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(SPMM_THREADS) void spmm_wave_row_bf16_kernel(
                     const int ch = cb + lane + 64 * p;
                     if (ch < F8) {
                         const size_t o = rowg * F8 + ch;
-                        bin[p].a = __builtin_nontemporal_load(ep.Y0 + o); bin[p].u = ep.U[o]; bin[p].h = ep.H[o];
+                        bin[p].a = __builtin_nontemporal_load(ep.Y0 + o); bin[p].u = __builtin_nontemporal_load(ep.U + o); bin[p].h = __builtin_nontemporal_load(ep.H + o);
                     }
                 }
             }
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(SPMM_THREADS) void spmm_bcsr_bf16_kernel(
                         if (r < rows_here && ch < F8) {
                             const size_t o = ((size_t)b * n_rows + row_base + r) * F8 + ch;
                             BlendIn& t = bin[MODE == EP_BLEND ? r : 0][p];
-                            t.a = __builtin_nontemporal_load(ep.Y0 + o); t.u = ep.U[o]; t.h = ep.H[o];
+                            t.a = __builtin_nontemporal_load(ep.Y0 + o); t.u = __builtin_nontemporal_load(ep.U + o); t.h = __builtin_nontemporal_load(ep.H + o);
                         }
                     }
             }
