@@ -56,9 +56,12 @@ constexpr int SC_H = 16, SC_KS = 2, SC_MAXC = 16;
 // tanhf and the IEEE division are ~30 vector instructions each, four per lane and tile, in loops that run at the sum of their vector and matrix cycles.
 __device__ __forceinline__ float sigm(float v) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v)); }
 __device__ __forceinline__ float tanh_hw(float v) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.8853900817779268f * v)); }
-// x / C for x < 65536 and C <= 16 with inv = ceil(2^20 / C): exact (x (inv C - 2^20) < 2^20); a runtime integer division is ~25 instructions
-// and the gathers below would do two per item.
-__device__ __forceinline__ int div_c(int x, int inv) { return (int)(((unsigned)x * (unsigned)inv) >> 20); }
+// x / C for x < 65536 and C <= 16 with inv = ceil(2^31 / C), as the high word of the 64-bit product 2x * inv (a shift and one
+// v_mul_hi_u32): exact, since x (inv C - 2^31) < 65536 * 16 < 2^31, and nothing wraps (2x inv < 2^49; inv = 2^31 for C = 1 still fits 32
+// bits).  A 2^20 reciprocal in a 32-bit product wrapped from x = 4096 C on.  A runtime integer division is ~25 instructions and the gathers
+// below would do two per item.
+__host__ __device__ constexpr unsigned inv_c(int C) { return (unsigned)((0x80000000ull + (unsigned)C - 1) / (unsigned)C); }
+__device__ __forceinline__ int div_c(int x, unsigned inv) { return (int)__umulhi((unsigned)x << 1, inv); }
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
@@ -85,7 +88,7 @@ constexpr int SQ = 20;                                                          
 // out[row][quad] = base + sum_e val[e] * fetch(colidx[e] * C + c, quad)  for the rows of one sample; fetch returns 4 columns of a source row.
 template <int THREADS, int QUADS, class Fetch, class Base, class Store>
 __device__ __forceinline__ void aggregate_rows(const int* __restrict__ gp, const int* __restrict__ gc, const float* __restrict__ gv, int NC, int C,
-                                               int invC, int row_lo, int row_hi, Fetch fetch, Base base, Store store) {
+                                               unsigned invC, int row_lo, int row_hi, Fetch fetch, Base base, Store store) {
     (void)NC;
     for (int item = threadIdx.x; item < (row_hi - row_lo) * QUADS; item += THREADS) {       // the workgroup's own rows [row_lo, row_hi)
         const int row = row_lo + item / QUADS, q = item - (row - row_lo) * QUADS;
@@ -234,7 +237,7 @@ __device__ __forceinline__ void load_w_fwd(float (&Wr)[SC_KS][KC][4 + (XQ == 4 ?
 // of step s: 4 kq + s = the row that register s of lane (., kq) holds).  M's A operands are four registers per lane, built once per launch.
 // (The first version mixed with a VALU loop over LDS: C dependent LDS reads per output element, ~1 us per tile, most of the phase.)
 template <int KC>
-__device__ __forceinline__ void build_mix(float (&M)[KC][4], const float* __restrict__ Tc, bool transposed, int rpt, int C, int invC, int j, int kq) {
+__device__ __forceinline__ void build_mix(float (&M)[KC][4], const float* __restrict__ Tc, bool transposed, int rpt, int C, unsigned invC, int j, int kq) {
     const int ni = div_c(j, invC), ci = j - ni * C;
 #pragma unroll
     for (int kc = 1; kc < KC; ++kc)
@@ -313,7 +316,8 @@ __global__ __launch_bounds__(SF_THREADS) void small_fwd_kernel(SmallFwd a) {
     constexpr bool STAGED = MODE >= 1, DENSE = MODE == 2;
     extern __shared__ __align__(16) float lds[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, j = lane & 15, kq = lane >> 4;
-    const int C = a.C, N = a.N, NC = N * C, cin = a.cin, invC = ((1 << 20) + C - 1) / C;
+    const int C = a.C, N = a.N, NC = N * C, cin = a.cin;
+    const unsigned invC = inv_c(C);
     float* P = lds + fwd_lds_fixed<KC>();                   // STAGED: [H | X | 0] rows of the sample, stride SP
     float* Q = P + (size_t)NC * SP;                         //         R*H rows, stride SQ
     int* gpl = reinterpret_cast<int*>(Q + (size_t)NC * SQ);
@@ -718,7 +722,8 @@ __global__ __launch_bounds__(SB_THREADS) void small_bwd_kernel(SmallBwd a) {
     constexpr bool STAGED = MODE == 1 || MODE == 2, DENSE = MODE >= 2;
     extern __shared__ __align__(16) float lds[];
     const int t = threadIdx.x, wave = t >> 6;
-    const int C = a.C, N = a.N, NC = N * C, cin = a.cin, L = cin + SC_H, invC = ((1 << 20) + C - 1) / C;
+    const int C = a.C, N = a.N, NC = N * C, cin = a.cin, L = cin + SC_H;
+    const unsigned invC = inv_c(C);
     float* dv = lds + wave * KC * 16 * 33;
     float* D1 = lds + bwd_lds_fixed<KC>();                   // STAGED: the slab dZ_1 of the convolution in flight, stride LP
     int* gpl = reinterpret_cast<int*>(D1 + (size_t)NC * LP);
@@ -870,16 +875,22 @@ int xq_of(int cin) { return cin == SC_H ? 4 : (cin >= 1 && cin <= 4 ? 1 : 0); }
 size_t graph_lds_bytes(int N, int nnz) { return (size_t)(((N + 4) & ~3) + 2 * ((nnz + 3) & ~3)) * 4; }
 constexpr size_t SC_LDS_BUDGET = 156 * 1024;     // of the 160 KB of a compute unit
 
-// Raise a kernel's dynamic-LDS cap only when a launch needs more than it was already granted (the attribute call costs microseconds, a
-// launch here is tens of them).  One process drives one GPU.
+// Raise a kernel's dynamic-LDS cap only when a launch needs more than it was already granted ON THE CURRENT DEVICE (the attribute belongs to
+// the device's copy of the function; the attribute call costs microseconds, a launch here is tens of them).  Devices beyond the table are
+// granted on every launch.
+constexpr int SC_MAX_DEVICES = 16;
+struct Grants { std::atomic<size_t> per_device[SC_MAX_DEVICES]; };
 template <class K>
-hipError_t allow_lds_once(K kern, size_t bytes, std::atomic<size_t>& granted) {
-    if (bytes <= granted.load(std::memory_order_relaxed)) return hipSuccess;
+hipError_t allow_lds_once(K kern, size_t bytes, Grants& grants) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+    std::atomic<size_t>* granted = dev >= 0 && dev < SC_MAX_DEVICES ? &grants.per_device[dev] : nullptr;
+    if (granted && bytes <= granted->load(std::memory_order_relaxed)) return hipSuccess;
     const hipError_t e = stc::allow_lds(kern, bytes);
-    if (e == hipSuccess) granted.store(bytes, std::memory_order_relaxed);
+    if (e == hipSuccess && granted) granted->store(bytes, std::memory_order_relaxed);
     return e;
 }
-std::atomic<size_t> g_granted[2][2][4];          // [direction][wide input][mode]
+Grants g_granted[2][2][4];                       // [direction][wide input][mode]
 
 }  // namespace
 

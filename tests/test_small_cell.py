@@ -110,6 +110,10 @@ def test_small_cell_twin_is_the_reference_cell(B, N, C, cin, bias):
     (1, 10, 16, 4, False),       # one node per tile
     (2, 7, 1, 2, False),         # one category: no mix partner rows
     (2, 33, 7, 16, False),       # 2 nodes of 7 rows per tile (14 of 16 rows used)
+    (2, 5000, 5, 1, False),      # rows beyond 4096 C: the row -> (node, category) division must be exact up to 65535 rows (round 3's wrapped)
+    (1, 5000, 5, 16, False),
+    (1, 13000, 5, 16, False),    # 65 000 rows: the top of the accepted range
+    (1, 4500, 7, 3, False),
 ])
 @pytest.mark.parametrize('bias,acc', [(True, False), (False, True)])
 def test_small_cell_kernels(B, N, C, cin, dense, bias, acc):
@@ -137,7 +141,8 @@ def test_small_cell_kernels(B, N, C, cin, dense, bias, acc):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('B,N,C,cin,splits,dense', [(2, 100, 5, 16, 8, False), (3, 100, 5, 1, 4, False), (1, 37, 8, 16, 2, False), (2, 200, 8, 3, 8, False),
-                                                     (1, 7, 1, 2, 3, False), (2, 100, 5, 16, 8, True), (2, 37, 8, 3, 4, True)])
+                                                     (1, 7, 1, 2, 3, False), (2, 100, 5, 16, 8, True), (2, 37, 8, 3, 4, True),
+                                                     (2, 5000, 5, 16, 8, False), (1, 4500, 7, 3, 4, False), (1, 13000, 5, 1, 16, False)])
 def test_small_cell_kernels_split_over_workgroups(B, N, C, cin, splits, dense):
     """The same cell step as four launches per direction (one per phase) over ``splits`` workgroups per sample -- what the executor uses when
     the batch is too small to fill the chip with one workgroup per sample: same buffers, same results (parameter-gradient partials in
