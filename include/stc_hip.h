@@ -31,19 +31,26 @@
 extern "C" {
 #endif
 
-#define STC_ABI_VERSION 21
+#define STC_ABI_VERSION 22
 #define STC_MAX_K 4          /* highest Chebyshev order (Ks, Kc) the node kernels accept */
 
 /* Operand formats of the split-operand matrix-core kernels (C = 32 / 64, hidden 16).  Every fp32 operand is split into low-precision
  * pieces whose products are exact in the fp32 accumulator:
  *   STC_FMT_BF16X3  three bf16 pieces, six products  -- fp32's range, error at the fp32 rounding level (8.5e-8 on 32-term dot products);
  *   STC_FMT_F16X2   two fp16 pieces, three products  -- half the matrix instructions; error 1.7-2.9e-7 (an fp32 fmaf chain: 1.3-2.4e-7).
- * fp16 has a 5-bit exponent, so F16X2 kernels normalise their operands by powers of two (exact): weight and category-graph tables from
- * their own maxima inside the kernel, gradient operands from the launch's gradient maximum, which the caller hands over in device
- * memory (grad_amax arguments; stc_spmm_sum_f32 produces it on the way).  Activations enter unscaled: |value| must stay below 65504
- * (states and gates of an STC_Cell are below 1 by construction); beyond that the result is NaN, never a silently wrong number. */
+ * fp16 has a 5-bit exponent, so F16X2 kernels normalise EVERY operand class by powers of two (exact) -- the reference's einsum is
+ * scale-free (STC_GNN.py:37-42) and so are they, for magnitudes 2^-100 .. 2^100:
+ *   tables      weight and category-graph tables from their own maxima, inside the kernel;
+ *   gradients   from the launch's gradient maximum, which the caller hands over in device memory (grad_amax arguments; stc_spmm_sum_f32 and
+ *               stc_bdg_node_post_bwd_f32 produce it on the way);
+ *   activations forward: one scale per NODE, from the maximum over the node's rows of all input planes, found by the wave that owns the
+ *               node (no argument); backward: the dW products sum over nodes, so they take one scale per input PLANE and launch, from
+ *               the maxima the forward launch left in device memory (act_amax arguments: STC_ACT_AMAX_SLOTS floats per plane, ZERO before
+ *               the forward launch, each wave leaves its own maximum by an atomic max; NULL in the backward = unscaled, i.e. plane maxima
+ *               assumed within [2^-3, 65504)). */
 #define STC_FMT_BF16X3 0
 #define STC_FMT_F16X2 1
+#define STC_ACT_AMAX_SLOTS 256   /* floats per plane row of an act_amax buffer */
 
 #define STC_OK 0
 #define STC_EINVAL (-1)
@@ -257,6 +264,10 @@ int stc_spmm_blend_fwd_f32(const int32_t* rowptr, const int32_t* colidx, const f
 int stc_bdg_node_post_bwd_f32(const float* X, const float* X2, const float* Tc, const float* W, const float* dA, const float* dB,
                               float* dX, float* dX2, float* dW, float* db,
                               const float* grad_amax, int32_t n_amax,      /* fp16 x 2 format (planar forms, C = 64): max over the slots bounds |dA|, |dB| */
+                              const float* act_amax_x, const float* act_amax_x2,      /* fp16 x 2, optional: STC_ACT_AMAX_SLOTS floats each whose maximum is
+                                                                                         max |X| / max |X2| (a row of a forward launch's act_amax; R*H takes H's) */
+                              float* out_amax,                             /* fp16 x 2, optional: (2, STC_ACT_AMAX_SLOTS) floats, ZERO before the launch, that
+                                                                              receive max |dX| and max |dX2| (grad_amax of the gates backward that follows) */
                               void* workspace, size_t workspace_bytes,
                               int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t Ho, void* stream);
 
@@ -332,12 +343,15 @@ int stc_cell_gates_fwd_planar_f32(const float* X, const float* H, const float* S
                                   float* U, float* Rg, float* RH,
                                   const float* Wc, const float* bc, float* A, float* Bm,
                                   int32_t operand_format,
+                                  float* act_amax,      /* STC_FMT_F16X2, optional: (4, STC_ACT_AMAX_SLOTS) floats, ZERO before the launch, that receive the
+                                                           maxima of |X|, |SX|, |H|, |SH| (wide input) or |H|, |SH|, |X|, |SX| (narrow): act_amax of the backward */
                                   int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream);
 int stc_cell_gates_bwd_planar_f32(const float* X, const float* H, const float* SX, const float* SH,
                                   const float* Tc, const float* W,
                                   const float* dCandIn, const float* Cand, const float* U, const float* Rg, const float* dHnew,
                                   float* const* dZ, float* dW, float* db, float* dH,
                                   const float* grad_amax, int32_t n_amax,      /* fp16 x 2 format: max over the slots bounds |dHnew| and |dCandIn| */
+                                  const float* act_amax,                       /* fp16 x 2, optional: what stc_cell_gates_fwd_planar_f32 left for these planes */
                                   void* workspace, size_t workspace_bytes,
                                   int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream);
 
@@ -357,7 +371,8 @@ int stc_cell_gates_bwd_planar_f32(const float* X, const float* H, const float* S
  * is built (C = 32, h = 16); workspace >= stc_cell_bwd_planar_workspace_bytes(C, Lw, h) bytes, 16-byte aligned.
  * grad_amax != NULL selects the fp16 x 2 operand format (see "operand formats" above): n_amax device floats whose maximum is
  * max |dHnew| over the launch's rows (stc_spmm_sum_f32 leaves them; any bound within 2^8 above the true maximum serves).  NULL keeps
- * the bf16 x 3 format, which needs no range information. */
+ * the bf16 x 3 format, which needs no range information.  act_amax (fp16 x 2, optional): the (4, STC_ACT_AMAX_SLOTS) plane maxima the
+ * forward launch (stc_cell_gates_fwd_planar_f32) left for the same X, H, SX, SH: the scales of the dW products' activation operands. */
 int stc_cell_bwd_planar_supported(int32_t C, int32_t h);
 size_t stc_cell_bwd_planar_workspace_bytes(int32_t C, int32_t Lw, int32_t h);
 int stc_cell_bwd_planar_f32(const float* X, const float* H, const float* SX, const float* SH,
@@ -366,7 +381,7 @@ int stc_cell_bwd_planar_f32(const float* X, const float* H, const float* SX, con
                             float* dX, float* dSX, float* dH, float* dSH,
                             float* dWg, float* dbg, float* dWc, float* dbc,
                             int32_t accumulate_x, int32_t accumulate_h,
-                            const float* grad_amax, int32_t n_amax,
+                            const float* grad_amax, int32_t n_amax, const float* act_amax,
                             void* workspace, size_t workspace_bytes,
                             int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream);
 
@@ -387,19 +402,23 @@ int stc_cell_bwd_planar_f32(const float* X, const float* H, const float* SX, con
 int stc_cell_planar_k_supported(int32_t K, int32_t C, int32_t h);
 int stc_cell_gates_fwd_planar_k_f32(const float* const* Zx, const float* const* Zh, int32_t K, const float* Tc, const float* W, const float* bias,
                                     float* U, float* Rg, float* RH, int32_t operand_format,
+                                    float* act_amax,      /* STC_FMT_F16X2, optional: (2 K, STC_ACT_AMAX_SLOTS) zero floats that receive max |plane| of
+                                                             Zx[0..K-1], Zh[0..K-1] (wide input; Zh first for a narrow one): act_amax of the matching backward */
                                     int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream);
 int stc_cell_cand_fwd_planar_k_f32(const float* const* Zx, const float* const* Zh, int32_t K, const float* Tc, const float* W, const float* bias,
-                                   const float* U, const float* H, float* Cand, float* Hnew, int32_t operand_format,
+                                   const float* U, const float* H, float* Cand, float* Hnew, int32_t operand_format, float* act_amax,
                                    int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream);
 int stc_cell_gates_bwd_planar_k_f32(const float* const* Zx, const float* const* Zh, int32_t K, const float* Tc, const float* W,
                                     const float* dRH, const float* Cand, const float* U, const float* Rg, const float* dHnew,
                                     float* const* dZx, float* const* dZh, float* dW, float* db, float* dH, int32_t accumulate_x,
                                     const float* grad_amax, int32_t n_amax,     /* fp16 x 2 format: max over the slots bounds |dHnew| and |dRH| */
+                                    const float* act_amax,                      /* fp16 x 2, optional: as left by stc_cell_gates_fwd_planar_k_f32 */
                                     void* workspace, size_t workspace_bytes, int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream);
 int stc_cell_cand_bwd_planar_k_f32(const float* const* Zx, const float* const* Zh, int32_t K, const float* Tc, const float* W,
                                    const float* dHnew, const float* U, const float* Cand,
                                    float* const* dZx, float* const* dZh, float* dW, float* db,
                                    const float* grad_amax, int32_t n_amax,      /* fp16 x 2 format: max over the slots bounds |dHnew| */
+                                   const float* act_amax,                       /* fp16 x 2, optional: as left by stc_cell_cand_fwd_planar_k_f32 */
                                    void* workspace, size_t workspace_bytes, int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream);
 
 /* Y = sum_i add_scale[i] add[i] + alpha S x (X [+ X2]) on rows of C*h floats (h = 16): the gradient of a state from the pieces

@@ -63,10 +63,90 @@ class _Bf16Emulated:
         return call
 
 
+def _pow2_scale(amax: Tensor, t: int) -> Tensor:
+    """2^k with amax 2^k in [2^(t-1), 2^t), elementwise; 1 where amax is zero / not finite; |k| <= 100 (csrc/stc_x3_frag.h: pow2_scale)."""
+    a = amax.detach().double()
+    _, e = torch.frexp(a)                                   # a = m 2^e, m in [1/2, 1)
+    k = (t - e).clamp(-100, 100).double()
+    return torch.where((a > 0) & torch.isfinite(a), torch.pow(torch.tensor(2.0, dtype=torch.float64), k), torch.ones_like(a))
+
+
+def _q2(x: Tensor, s) -> Tensor:
+    """x as the fp16 x 2 operand format carries it: (h + l) / s with h = fp16(x s), l = fp16(x s - h) (round to nearest even, subnormals kept,
+    overflow to infinity) -- 22 significant bits above the subnormal floor of the SCALED value, an absolute floor of 2^-25 / s below it."""
+    y = (x.double() * s).float()
+    h = y.half().float()
+    l = (y - h).half().float()
+    return ((h.double() + l.double()) / s).to(x.dtype)
+
+
 class EmulatedKernels:
-    """Drop-in for ``stc_hip._lib.HipKernels`` on CPU tensors."""
+    """Drop-in for ``stc_hip._lib.HipKernels`` on CPU tensors.
+
+    ``operand_format='f16x2'``: the planar cell kernels' matrix products take their operands as the fp16 x 2 format of the HIP kernels carries
+    them (csrc/stc_x3_frag.h: weight / category tables normalised to a maximum in [1/2, 1); gradient operands scaled into [2^3, 2^4) from the
+    launch's gradient maximum; activations scaled per NODE in the forward and per PLANE in the backward's dW products) -- products and sums
+    stay exact, so what the CPU suite sees is the format's representation error, floors included.  ``act_scales=False`` feeds activations
+    unscaled, as the round-3 kernels did: the tests use it to show that the scale sweep would catch the absolute floor."""
 
     name = 'emulated-cpu'
+    ACT_AMAX_SLOTS = 256
+
+    def __init__(self, operand_format: Optional[str] = None, act_scales: bool = True):
+        assert operand_format in (None, 'f16x2')
+        self.fmt = operand_format
+        self.act_scales = act_scales
+        if operand_format == 'f16x2':
+            self.operand_format = 1                          # what stc_hip.ops looks at (FMT_F16X2): amax / act_amax plumbing on
+
+    def act_amax_buffer(self, like, *lead):
+        return torch.zeros(*lead, self.ACT_AMAX_SLOTS, dtype=torch.float32) if self.fmt == 'f16x2' else None
+
+    # ---- fp16 x 2 format emulation helpers (planar entry points only: the kernels that run the format)
+    def _tables(self, *ts):
+        """Weight / category tables as the kernels hold them: normalised by their own maximum."""
+        if self.fmt != 'f16x2':
+            return ts
+        return tuple(None if t is None else _q2(t, _pow2_scale(t.abs().max(), 0)) for t in ts)
+
+    def _mix_tables(self, Tc):
+        if self.fmt != 'f16x2':
+            return Tc
+        out = Tc.clone()
+        if Tc.shape[0] > 1:
+            out[1:] = _q2(Tc[1:], _pow2_scale(Tc[1:].abs().max(), 0))
+        return out
+
+    def _node_scaled(self, planes):
+        """Forward: one scale per node (row of the (R, C, w) planes), from the maximum over all planes of the launch."""
+        if self.fmt != 'f16x2':
+            return list(planes)
+        if not self.act_scales:
+            return [_q2(p, 1.0) for p in planes]
+        m = torch.stack([p.abs().amax(dim=(1, 2)) for p in planes]).amax(0)
+        s = _pow2_scale(m, 4).view(-1, 1, 1)
+        return [_q2(p, s) for p in planes]
+
+    def _plane_scaled(self, planes, act_amax, rows):
+        """Backward: one scale per plane and launch, from the slots the forward launch left (row ``rows[i]`` for plane i)."""
+        if self.fmt != 'f16x2':
+            return list(planes)
+        if not self.act_scales or act_amax is None:
+            return [_q2(p, 1.0) for p in planes]
+        return [_q2(p, _pow2_scale(act_amax[r].max(), 4)) for p, r in zip(planes, rows)]
+
+    def _grad_scaled(self, grads, grad_amax):
+        if self.fmt != 'f16x2':
+            return list(grads)
+        m = grad_amax.max() if grad_amax is not None else torch.stack([g.abs().max() for g in grads]).max()
+        s = _pow2_scale(m, 4)
+        return [_q2(g, s) for g in grads]
+
+    @staticmethod
+    def _leave_maxima(act_amax, planes):
+        if act_amax is not None:
+            for i, p in enumerate(planes):
+                act_amax[i, 0] = torch.maximum(act_amax[i, 0], p.abs().max().float())      # any slot may hold the maximum
 
     @property
     def bf16(self):
@@ -353,18 +433,48 @@ class EmulatedKernels:
     def cell_planar_post_fused(self, Cc) -> bool:
         return True
 
-    def cell_gates_fwd_planar(self, X, H, SX, SH, Tc, W, bias, U, Rg, RH, post=None):
+    def cell_gates_fwd_planar(self, X, H, SX, SH, Tc, W, bias, U, Rg, RH, post=None, act_amax=None):
         cin, h = X.shape[-1], H.shape[-1]                        # cin = h, or 1..4 (narrow input plane, layer 0)
+        self._leave_maxima(act_amax, (X, SX, H, SH) if cin == h else (H, SH, X, SX))      # rows in the launch order of the planes
         CandIn = torch.empty(H.shape[:-1] + (cin + h,), dtype=W.dtype)
-        self.cell_gates_fwd([torch.cat([X, H], -1), torch.cat([SX, SH], -1)], Tc, W, bias, H, U, Rg, CandIn)
+        Xq, Hq, SXq, SHq = self._node_scaled((X, H, SX, SH))
+        (Wq,), Tq = self._tables(W), self._mix_tables(Tc)
+        self.cell_gates_fwd([torch.cat([Xq, Hq], -1), torch.cat([SXq, SHq], -1)], Tq, Wq, bias, H, U, Rg, CandIn)
+        CandIn[..., :cin] = X                                   # (the row's X part is the input itself, not its operand representation)
         if RH is not None:                                      # optional with post=: cell_bwd_planar forms R*H itself
             RH.copy_(CandIn[..., cin:])
         if post is not None:                                   # + the candidate's projection on [Xt | R*H]
             Wc, bc, A, Bm = post
-            self.node_post_fwd(CandIn, Tc, Wc, bc, A, Bm)
+            if self.fmt == 'f16x2':                             # the node's scale covers [Xt | R*H] too (|R*H| <= |H|)
+                Xc, RHc = (self._node_scaled((X, H, SX, SH, CandIn[..., cin:].contiguous()))[i] for i in (0, 4)) if self.act_scales else \
+                          (_q2(X, 1.0), _q2(CandIn[..., cin:], 1.0))
+                (Wcq,) = self._tables(Wc)
+                self.node_post_fwd(torch.cat([Xc, RHc], -1), Tq, Wcq, bc, A, Bm)
+            else:
+                self.node_post_fwd(CandIn, Tc, Wc, bc, A, Bm)
 
-    def cell_gates_bwd_planar(self, X, H, SX, SH, Tc, W, dRH, Cand, U, Rg, dHnew, dZs, dW, db, dH, grad_amax=None):
+    def cell_gates_bwd_planar(self, X, H, SX, SH, Tc, W, dRH, Cand, U, Rg, dHnew, dZs, dW, db, dH, grad_amax=None, act_amax=None):
         cin, h = X.shape[-1], H.shape[-1]
+        if self.fmt == 'f16x2':
+            # As the kernel: the gate prologue runs in fp32 on the planes themselves (dG and the state's own share are exact); the matrix
+            # products take dG, the tables and -- the dW products -- the planes, each as its format carries it.
+            order = (0, 1, 2, 3) if cin == h else (2, 3, 0, 1)                # rows of the slots: wide {X, S.X, H, S.H}, narrow {H, S.H, x, S.x}
+            Xq, SXq, Hq, SHq = self._plane_scaled((X, SX, H, SH), act_amax, order)
+            (Wq,), Tq = self._tables(W), self._mix_tables(Tc)
+            dG = torch.cat([dHnew * (Cand - H) * U * (1 - U), dRH * H * Rg * (1 - Rg)], -1)
+            (dGq,) = self._grad_scaled((dG,), grad_amax)
+            own = dRH * Rg + dHnew * (1 - U)
+            rows = [torch.empty(H.shape[:-1] + (cin + h,), dtype=W.dtype) for _ in range(2)]
+            EmulatedKernels().bdg_node_bwd([torch.cat([Xq, Hq], -1), torch.cat([SXq, SHq], -1)], Tq, Wq, dGq, rows, dW, None, None)
+            if db is not None:
+                db.copy_(dG.sum(dim=(0, 1)))                                  # (summed from the fp32 fragments in the kernel)
+            fold = dH is None
+            dZs[2].copy_(rows[0][..., cin:] + (own if fold else 0)); dZs[3].copy_(rows[1][..., cin:])
+            if dZs[0] is not None:
+                dZs[0].copy_(rows[0][..., :cin]); dZs[1].copy_(rows[1][..., :cin])
+            if not fold:
+                dH.copy_(own)
+            return
         fold = dH is None                                                   # bf16 kernels: the prologue's share goes into dZs[2]
         if fold:
             dH = torch.empty_like(H)
@@ -381,17 +491,19 @@ class EmulatedKernels:
         return h == 16 and os.environ.get('STC_FUSE_CELL_BWD', '1') != '0'
 
     def cell_bwd_planar(self, X, H, SX, SH, Tc, Wg, Wc, U, Rg, Cand, dHnew, dBm, dZs, dWg, dbg, dWc, dbc, accumulate_x=False, accumulate_h=False,
-                        grad_amax=None):
+                        grad_amax=None, act_amax=None):
         cin, h = X.shape[-1], H.shape[-1]
         old = [None if (z is None or not acc) else z.clone() for z, acc in zip(dZs, (accumulate_x, accumulate_x, accumulate_h, accumulate_h))]
         dY = dHnew * U * (1 - Cand * Cand)
         RH, dRH = Rg * H, torch.empty_like(H)
+        xr, hr = (0, 2) if cin == h else (2, 0)                   # slot rows of the X plane and of the H plane (R*H rides on H's)
+        post_amax = None if act_amax is None else ((act_amax[xr], act_amax[hr]) if cin == h else (act_amax[hr], act_amax[xr]))
         if cin == h:
             dXc = torch.empty_like(H)
-            self.node_post_bwd(X, Tc, Wc, dY, dBm, dXc, dWc, dbc, X2=RH, dX2=dRH)
+            self.node_post_bwd(X, Tc, Wc, dY, dBm, dXc, dWc, dbc, X2=RH, dX2=dRH, grad_amax=grad_amax, act_amax=post_amax)
         else:
-            self.node_post_bwd(RH, Tc, Wc, dY, dBm, dRH, dWc, dbc, X2=X)
-        self.cell_gates_bwd_planar(X, H, SX, SH, Tc, Wg, dRH, Cand, U, Rg, dHnew, dZs, dWg, dbg, None)
+            self.node_post_bwd(RH, Tc, Wc, dY, dBm, dRH, dWc, dbc, X2=X, grad_amax=grad_amax, act_amax=post_amax)
+        self.cell_gates_bwd_planar(X, H, SX, SH, Tc, Wg, dRH, Cand, U, Rg, dHnew, dZs, dWg, dbg, None, grad_amax=None, act_amax=act_amax)
         if cin == h:
             dZs[0].add_(dXc)
         for z, o in zip(dZs, old):
@@ -419,14 +531,24 @@ class EmulatedKernels:
     def _cat_planes(Zx, Zh):
         return [torch.cat([x, hh], -1) for x, hh in zip(Zx, Zh)]            # reference column order [X | H]
 
-    def cell_gates_fwd_planar_k(self, Zx, Zh, Tc, W, bias, U, Rg, RH):
+    def _planes_k_fwd(self, Zx, Zh, Tc, W, act_amax):
+        """Order-3 forward launches: slots in launch order (Zx first for a wide input, Zh first for a narrow one), operands in their format."""
+        wide = Zx[0].shape[-1] == Zh[0].shape[-1]
+        self._leave_maxima(act_amax, (list(Zx) + list(Zh)) if wide else (list(Zh) + list(Zx)))
+        q = self._node_scaled(list(Zx) + list(Zh))
+        (Wq,), Tq = self._tables(W), self._mix_tables(Tc)
+        return q[:len(Zx)], q[len(Zx):], Tq, Wq
+
+    def cell_gates_fwd_planar_k(self, Zx, Zh, Tc, W, bias, U, Rg, RH, act_amax=None):
         cin, h = Zx[0].shape[-1], Zh[0].shape[-1]
         CandIn = torch.empty(Zh[0].shape[:-1] + (cin + h,), dtype=W.dtype)
-        self.cell_gates_fwd(self._cat_planes(Zx, Zh), Tc, W, bias, Zh[0], U, Rg, CandIn)
+        Zxq, Zhq, Tq, Wq = self._planes_k_fwd(Zx, Zh, Tc, W, act_amax)
+        self.cell_gates_fwd(self._cat_planes(Zxq, Zhq), Tq, Wq, bias, Zh[0], U, Rg, CandIn)
         RH.copy_(CandIn[..., cin:])
 
-    def cell_cand_fwd_planar_k(self, Zx, Zh, Tc, W, bias, U, H, Cand, Hnew):
-        self.cell_blend_fwd(self._cat_planes(Zx, Zh), Tc, W, bias, U, H, Cand, Hnew)
+    def cell_cand_fwd_planar_k(self, Zx, Zh, Tc, W, bias, U, H, Cand, Hnew, act_amax=None):
+        Zxq, Zhq, Tq, Wq = self._planes_k_fwd(Zx, Zh, Tc, W, act_amax)
+        self.cell_blend_fwd(self._cat_planes(Zxq, Zhq), Tq, Wq, bias, U, H, Cand, Hnew)
 
     def _split_planes(self, rows, dZx, dZh, cin):
         for n, r in enumerate(rows):
@@ -434,7 +556,7 @@ class EmulatedKernels:
             if dZx[n] is not None:
                 dZx[n].copy_(r[..., :cin])
 
-    def cell_gates_bwd_planar_k(self, Zx, Zh, Tc, W, dRH, Cand, U, Rg, dHnew, dZx, dZh, dW, db, dH, accumulate_x=False, grad_amax=None):
+    def cell_gates_bwd_planar_k(self, Zx, Zh, Tc, W, dRH, Cand, U, Rg, dHnew, dZx, dZh, dW, db, dH, accumulate_x=False, grad_amax=None, act_amax=None):
         cin, h = Zx[0].shape[-1], Zh[0].shape[-1]
         before = [z.clone() for z in dZx] if accumulate_x else None              # the candidate's gradients already in the X-side planes
         fold = dH is None                                                   # the prologue's share goes into dZh[0]
@@ -450,7 +572,7 @@ class EmulatedKernels:
             for z, b in zip(dZx, before):
                 z += b
 
-    def cell_cand_bwd_planar_k(self, Zx, Zh, Tc, W, dHnew, U, Cand, dZx, dZh, dW, db, grad_amax=None):
+    def cell_cand_bwd_planar_k(self, Zx, Zh, Tc, W, dHnew, U, Cand, dZx, dZh, dW, db, grad_amax=None, act_amax=None):
         cin, h = Zx[0].shape[-1], Zh[0].shape[-1]
         rows = [torch.empty(Zh[0].shape[:-1] + (cin + h,), dtype=W.dtype) for _ in Zh]
         self.cell_cand_bwd(self._cat_planes(Zx, Zh), Tc, W, dHnew, U, Cand, rows, dW, db)
@@ -480,7 +602,17 @@ class EmulatedKernels:
             buf[..., :off].copy_(side)
             buf[..., off + h:].zero_()
 
-    def node_post_bwd(self, X, Tc, W, dA, dB, dX, dW, db, X2=None, dX2=None, grad_amax=None):
+    def node_post_bwd(self, X, Tc, W, dA, dB, dX, dW, db, X2=None, dX2=None, grad_amax=None, act_amax=None, out_amax=None):
+        if X2 is not None and self.fmt == 'f16x2':             # operands in their format, then the exact twin
+            Xq, X2q = self._plane_scaled((X, X2), None if act_amax is None else torch.stack([a.reshape(-1) for a in act_amax]), (0, 1))
+            dAq, dBq = self._grad_scaled((dA, dB), grad_amax)
+            (Wq,), Tq = self._tables(W), self._mix_tables(Tc)
+            EmulatedKernels().node_post_bwd(Xq, Tq, Wq, dAq, dBq, dX, dW, db, X2=X2q, dX2=dX2)
+            if out_amax is not None:
+                out_amax[0, 0] = torch.maximum(out_amax[0, 0], dX.abs().max().float())
+                if dX2 is not None:
+                    out_amax[1, 0] = torch.maximum(out_amax[1, 0], dX2.abs().max().float())
+            return
         if X2 is not None:                                     # planar: compute on the concatenated rows, hand back the planes
             w, w2 = X.shape[-1], X2.shape[-1]
             full = torch.empty(X.shape[:-1] + (w + w2,), dtype=W.dtype)

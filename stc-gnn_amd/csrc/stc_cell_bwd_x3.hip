@@ -34,6 +34,8 @@ struct CellBwdArgs {
     float *partial_g, *partial_c;               // one row [dW | db] per workgroup for each convolution
     int nodes, want_dbg, want_dbc, Lw;
     const float* gmax; int n_gmax;              // fp16 x 2 format: slots whose maximum is max |dHnew| of this launch (device memory)
+    const float* zmax;                          // fp16 x 2 format, optional: (4, 256) slots of max |plane| as the gates forward left them (launch order of its
+                                                //   planes: PL = 1 {X, S.X, H, S.H}, PL = 2 {H, S.H, x, S.x}): scales of the dW products' activation operands
 };
 
 // per-wave LDS block: [stash_h 2 x 64 float4][stash_x 2 x 64 float4][CB_TILES transposition tiles of 32 x CB_TRS floats]
@@ -83,6 +85,13 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
         sWc = pow2_scale(block_absmax(a.Wc, 4 * a.Lw * 16, scratch, CB_THREADS), 0);
         sg = pow2_scale(slots_max(a.gmax, a.n_gmax), 4);
     }
+    // activation operands of the dW products (sums over nodes: one scale per plane and launch); block lb of slab n is row lb K + n of the slots.
+    // R*H takes the H plane's scale (|R*H| <= |H|): block RHB of slab 0, where H itself sits.
+    float sz[K][LB];
+#pragma unroll
+    for (int n = 0; n < K; ++n)
+#pragma unroll
+        for (int lb = 0; lb < LB; ++lb) sz[n][lb] = F::SCALED ? plane_scale(a.zmax, lb * K + n) : 1.f;
 
     for (int idx = tid; idx < 2 * 64; idx += CB_THREADS) {
         const int ll = idx & 63, rb = idx >> 6, gg = ll >> 4;
@@ -301,7 +310,8 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
                     c0[t] = lb == RHB ? rh_d[0][t] : zg[0][lb][0][t];
                     c1[t] = lb == RHB ? rh_d[1][t] : zg[0][lb][1][t];
                 }
-                const Op za = F::split(c0, c1);
+                Op za;
+                if constexpr (F::SCALED) za = F::split(c0 * sz[0][lb], c1 * sz[0][lb]); else za = F::split(c0, c1);
 #pragma unroll
                 for (int n = 0; n < K; ++n)
 #pragma unroll
@@ -414,7 +424,9 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
 #pragma unroll
             for (int lb = 0; lb < LB; ++lb) {
                 const float (&zc)[NRB][4] = zg[n][lb];
-                const Op za = F::split(f32x4{zc[0][0], zc[0][1], zc[0][2], zc[0][3]}, f32x4{zc[1][0], zc[1][1], zc[1][2], zc[1][3]});
+                Op za;
+                if constexpr (F::SCALED) za = F::split(f32x4{zc[0][0], zc[0][1], zc[0][2], zc[0][3]} * sz[n][lb], f32x4{zc[1][0], zc[1][1], zc[1][2], zc[1][3]} * sz[n][lb]);
+                else za = F::split(f32x4{zc[0][0], zc[0][1], zc[0][2], zc[0][3]}, f32x4{zc[1][0], zc[1][1], zc[1][2], zc[1][3]});
 #pragma unroll
                 for (int c = 0; c < K; ++c)
 #pragma unroll
@@ -427,8 +439,13 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
 
     // dW tiles of block c carry sg (c = 0) or sg sT (c = 1: Q_1 = T_1 dY); db carries sg
     const float isg = 1.f / sg, isgt = isg / sT;
-    combine_dw<K, LB, 2, CB_WAVES>(reinterpret_cast<float*>(smem_raw), dWg, dbg, a.partial_g, a.Lw, a.want_dbg, PL == 2 ? cin : -1, isg, isgt, isg);
-    combine_dw<K, LB, 1, CB_WAVES>(reinterpret_cast<float*>(smem_raw), dWc, dbc, a.partial_c, a.Lw, a.want_dbc, PL == 2 ? cin : -1, isg, isgt, isg);
+    PlaneUnscale<K, LB> pug, puc;
+#pragma unroll
+    for (int n = 0; n < K; ++n)
+#pragma unroll
+        for (int lb = 0; lb < LB; ++lb) { pug.v[n][lb] = inv_pow2(sz[n][lb]); puc.v[n][lb] = inv_pow2(sz[0][lb]); }      // the candidate's input is slab 0, [X | R*H], for both weight sets
+    combine_dw<K, LB, 2, CB_WAVES>(reinterpret_cast<float*>(smem_raw), dWg, dbg, a.partial_g, a.Lw, a.want_dbg, PL == 2 ? cin : -1, isg, isgt, isg, pug);
+    combine_dw<K, LB, 1, CB_WAVES>(reinterpret_cast<float*>(smem_raw), dWc, dbc, a.partial_c, a.Lw, a.want_dbc, PL == 2 ? cin : -1, isg, isgt, isg, puc);
 }
 
 template <class F, int L, int PL, int ACCX = 0, int ACCH = 0>
@@ -469,13 +486,13 @@ static int dispatch_cell_bwd(const CellBwdArgs& a, int cin, int accumulate_x, in
 int stc_cell_bwd_planar_x3(const float* X, const float* H, const float* SX, const float* SH, const float* Tc, const float* Wg, const float* Wc,
                            const float* U, const float* R, const float* Cand, const float* dHnew, const float* dBm,
                            float* dX, float* dSX, float* dH, float* dSH, float* partial_g, float* partial_c, int* n_partials,
-                           int want_dbg, int want_dbc, int accumulate_x, int accumulate_h, const float* gmax, int n_gmax,
+                           int want_dbg, int want_dbc, int accumulate_x, int accumulate_h, const float* gmax, int n_gmax, const float* zmax,
                            long long nodes, int C, int Lw, hipStream_t stream) {
     const int cin = Lw - 16;
     if (!stc_cell_bwd_planar_shape_ok(C, 16) || nodes <= 0 || nodes >= (1ll << 31) / C || !(cin == 16 || (cin >= 1 && cin <= 4))) return STC_NOT_HANDLED;
     const float* wide[] = {H, SH, U, R, Cand, dHnew, dBm, dH, dSH};
     if (!all_aligned16(wide, 9)) return STC_NOT_HANDLED;
-    CellBwdArgs a{X, H, SX, SH, U, R, Cand, dHnew, dBm, Tc, Wg, Wc, dX, dSX, dH, dSH, partial_g, partial_c, (int)nodes, want_dbg, want_dbc, Lw, gmax, n_gmax};
+    CellBwdArgs a{X, H, SX, SH, U, R, Cand, dHnew, dBm, Tc, Wg, Wc, dX, dSX, dH, dSH, partial_g, partial_c, (int)nodes, want_dbg, want_dbc, Lw, gmax, n_gmax, zmax};
     if (cin == 16) {
         const float* more[] = {X, SX, dX, dSX};
         if (!dX || !dSX || !all_aligned16(more, 4)) return STC_NOT_HANDLED;

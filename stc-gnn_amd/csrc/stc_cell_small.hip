@@ -52,10 +52,11 @@ constexpr int SC_H = 16, SC_KS = 2, SC_MAXC = 16;
 #define SC_SKIP_ROLE (-1)                          // probe: the waves of this backward role (0: dZ, 1: dW) do nothing
 #endif
 
-// Gate nonlinearities on the hardware exp2 / rcp (1 ulp each; absolute error < 2e-7), as in the large-graph cell kernels (stc_x3_frag.h): libm expf /
-// tanhf and the IEEE division are ~30 vector instructions each, four per lane and tile, in loops that run at the sum of their vector and matrix cycles.
-__device__ __forceinline__ float sigm(float v) { return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v)); }
-__device__ __forceinline__ float tanh_hw(float v) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.8853900817779268f * v)); }
+// Gate nonlinearities on the hardware exp2 / rcp, as in the large-graph cell kernels (stc_common.h: accurate relative to the result for every
+// argument): libm expf / tanhf and the IEEE division are ~30 vector instructions each, four per lane and tile, in loops that run at the sum of
+// their vector and matrix cycles.
+__device__ __forceinline__ float sigm(float v) { return stc_sigmoid(v); }
+__device__ __forceinline__ float tanh_hw(float v) { return stc_tanh(v); }
 // x / C for x < 65536 and C <= 16 with inv = ceil(2^31 / C), as the high word of the 64-bit product 2x * inv (a shift and one
 // v_mul_hi_u32): exact, since x (inv C - 2^31) < 65536 * 16 < 2^31, and nothing wraps (2x inv < 2^49; inv = 2^31 for C = 1 still fits 32
 // bits).  A 2^20 reciprocal in a 32-bit product wrapped from x = 4096 C on.  A runtime integer division is ~25 instructions and the gathers

@@ -95,6 +95,24 @@ __device__ __forceinline__ T stc_ld_once(const T* p) { return __builtin_nontempo
 template <class T>
 __device__ __forceinline__ void stc_st_once(T* p, const T& v) { __builtin_nontemporal_store(v, p); }
 
+// Gate nonlinearities of the fused epilogues on the hardware exp2 / rcp (1 ulp each) -- the IEEE division and libm expf / tanhf are ~30 vector
+// instructions each in kernels that are bound by vector issue.  Both are accurate RELATIVE to their result for every argument, as the
+// reference's torch.sigmoid / torch.tanh are (STC_GNN.py:72-78): the sigmoid by construction; the tanh form 1 - 2 / (e^{2v} + 1) cancels
+// for small arguments (its absolute error of ~1.2e-7 is a relative error of 1.2e-7 / |v|: 1e-3 at |v| = 1e-4), so below 1/4 the odd Taylor
+// polynomial through v^9 takes over (truncation 9e-3 v^10 < 1e-8 relative), selected by value -- no branch.  Above 1/4: <= 5e-7 relative.
+__device__ __forceinline__ float stc_sigmoid(float v) {
+    return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
+}
+__device__ __forceinline__ float stc_tanh(float v) {
+    const float big = 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.8853900817779268f * v));      // saturates cleanly at +-1
+    const float t = v * v;
+    float p = fmaf(t, 62.f / 2835.f, -17.f / 315.f);
+    p = fmaf(p, t, 2.f / 15.f);
+    p = fmaf(p, t, -1.f / 3.f);
+    const float small = fmaf(p * t, v, v);
+    return fabsf(v) < 0.25f ? small : big;
+}
+
 __device__ __forceinline__ float stc_wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

@@ -186,12 +186,8 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_bf16_
 // POST: the candidate convolution's projection in post-aggregation form (A = sum_c T_c^T ([Xt | RH] Wc_{0,c}) + bc, Bm
 // likewise with Wc_{1,c}; the caller finishes Y = A + S.Bm) runs as a second stage of the same launch: Xt is still in the
 // row registers and RH is moved from the epilogue's layout to row layout with four ds_bpermute per 16 rows.
-__device__ __forceinline__ float fast_sigmoid(float v) {      // hardware exp2 / rcp: |err| < 2e-7, far below a bf16 ulp
-    return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
-}
-__device__ __forceinline__ float fast_tanh(float v) {
-    return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.8853900817779268f * v));
-}
+__device__ __forceinline__ float fast_sigmoid(float v) { return stc_sigmoid(v); }      // hardware exp2 / rcp (stc_common.h)
+__device__ __forceinline__ float fast_tanh(float v) { return stc_tanh(v); }
 __device__ __forceinline__ f32x4 unpack4(const u32x2 v) {
     return f32x4{__uint_as_float(v[0] << 16), __uint_as_float(v[0] & 0xffff0000u), __uint_as_float(v[1] << 16), __uint_as_float(v[1] & 0xffff0000u)};
 }

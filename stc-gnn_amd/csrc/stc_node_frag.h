@@ -50,6 +50,8 @@ struct FwdEpi {
     StateCopy also[2];    // BLEND out, optional: further destinations of Hnew
     const float* side_src;   // BLEND, optional, belongs to also[0]: (nodes, C, side_cin) values for its columns [0, side_cin);
     int side_cin;            //   its pad columns [side_cin + 16, ld) are zeroed -- the consumer's row is then complete
+    float* zmax;             // fp16 x 2 planar forms, optional: (2 K, 256) slots, zero-filled by the caller, that receive max |plane| of the
+                             //   launch's 2 K input planes (rows in the launch order of Z): the scales of the backward's dW products
 };
 
 inline void set_state_copies(FwdEpi& epi, const StcStateCopies* c) {
@@ -122,6 +124,8 @@ struct BwdPro {
     int cin;
     int dh_scaled;                                    // dH_in enters as dH_in * (1 - U)
     const float* gmax; int n_gmax;                    // fp16 x 2 operand format: slots whose maximum is the launch's gradient maximum (device)
+    const float* zmax;                                // fp16 x 2, optional: (2 K, 256) slots of max |plane| of the launch's input planes (rows in the
+                                                      //   launch order of Z, as the forward launch left them): scales of the dW products' activation operands
 };
 
 // FOLD (planar kernels): the state's share dH is not written to HBM; it is parked in a lane-private LDS slot (stash[kb * 64 + lane],
@@ -207,10 +211,22 @@ __host__ __device__ __forceinline__ int stc_wrow_swapped(int col, int cin) {
 // End of a backward kernel: the workgroup's four waves hold dW tiles (rows l = 16lb + 4g + r, columns o = 16hb + x) and
 // db partial sums in registers; combine them through LDS in a fixed order (bitwise reproducible) into ONE partial row
 // [dW in W layout | db] per workgroup, which bdg_node_reduce_kernel then sums over workgroups.  (WAVES: waves per workgroup.)
+template <int K, int LB>
+struct PlaneUnscale {     // fp16 x 2: 1 / (activation scale) of the plane that is block lb of slab n (the A operands of the dW tiles [n][lb][.][.])
+    float v[K][LB];
+    __device__ __forceinline__ PlaneUnscale() {
+#pragma unroll
+        for (int n = 0; n < K; ++n)
+#pragma unroll
+            for (int lb = 0; lb < LB; ++lb) v[n][lb] = 1.f;
+    }
+};
+
 template <int K, int LB, int HB, int WAVES = MF_WAVES>
 __device__ __forceinline__ void combine_dw(float* smem, const f32x4 (&dWt)[K][LB][K][HB], const float (&dbp)[HB],
                                            float* __restrict__ partial, int Lw, int want_db, int swapped_cin = -1,
-                                           float unscale0 = 1.f, float unscale1 = 1.f, float db_unscale = 1.f) {      // scaled operand formats: factor of the tiles of block c = 0 / c >= 1
+                                           float unscale0 = 1.f, float unscale1 = 1.f, float db_unscale = 1.f,      // scaled operand formats: factor of the tiles of block c = 0 / c >= 1
+                                           const PlaneUnscale<K, LB>& pu = PlaneUnscale<K, LB>()) {
     constexpr int Ho = 16 * HB;
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -229,7 +245,7 @@ __device__ __forceinline__ void combine_dw(float* smem, const f32x4 (&dWt)[K][LB
                     for (int r = 0; r < 4; ++r) {
                         const int col = 16 * lb + 4 * q + r;
                         const int l = swapped_cin < 0 ? col : stc_wrow_swapped(col, swapped_cin);      // slab column -> W row
-                        if (l >= 0 && l < Lw) slab[((n * K + c) * Lw + l) * Ho + 16 * hb + j] = dWt[n][lb][c][hb][r] * (c == 0 ? unscale0 : unscale1);
+                        if (l >= 0 && l < Lw) slab[((n * K + c) * Lw + l) * Ho + 16 * hb + j] = dWt[n][lb][c][hb][r] * ((c == 0 ? unscale0 : unscale1) * pu.v[n][lb]);
                     }
 #pragma unroll
     for (int hb = 0; hb < HB; ++hb) {

@@ -92,7 +92,8 @@ __host__ __device__ constexpr int piece_slot_row(bool pieces, int gg, int e) { r
 
 // F: operand format (stc_x3_frag.h).  FmtH2 (two fp16 pieces, three products): W and T_c are normalised per workgroup at table-fill time
 // (W's blocks c = 0 carry sW sT, blocks c >= 1 carry sW, T_c carries sT: projection and category mix then meet in one accumulator with the
-// common factor sW sT, taken out in the epilogue); activations enter as they are (bounded by construction).
+// common factor sW sT, taken out in the epilogue); activations carry one power of two per NODE, from the node's own maximum (the
+// reference's einsum is scale-free, two fp16 pieces are not: stc_x3_frag.h), taken out in the same epilogue.
 template <int NB2, int HB, int K, int L, int EPI, int PL = 0, int POST = 0, class F = FmtB3>
 __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_kernel(
     ZPtrs Z, const float* __restrict__ Tc, const float* __restrict__ W, const float* __restrict__ bias,
@@ -173,6 +174,11 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
     for (int hb = 0; hb < HB; ++hb) bv[hb] = bias ? bias[16 * hb + x] : 0.f;
 
     int node = blockIdx.x * MF_WAVES + wave;
+    constexpr bool ASC = F::SCALED && PL != 0;              // activation scales (planar forms: the only ones that run the fp16 x 2 format)
+    static_assert(!F::SCALED || PL != 0, "the fp16 x 2 format is instantiated for the planar forms only");
+    float pmax[KL], qmax[KL];
+#pragma unroll
+    for (int n = 0; n < KL; ++n) { pmax[n] = 0.f; qmax[n] = 0.f; }
     Row8<L> cur[KL][NRB], nxt[KL][NRB];
     auto load_rows = [&](Row8<L> (&z)[KL][NRB], int nd) {
 #pragma unroll
@@ -229,6 +235,25 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
         __builtin_amdgcn_sched_barrier(0);
         const int lo = opaque(lane);
 
+        // FmtH2: this node's activation scale sz = 2^k, from the maximum over every row the wave holds for it (stc_x3_frag.h); the wave's
+        // running per-plane maxima go to the launch's slots after the loop (what the backward's dW products scale by)
+        float sz = 1.f, invn = inv, invpn = invp;
+        if constexpr (ASC) {
+            float nm = 0.f;
+#pragma unroll
+            for (int n = 0; n < KL; ++n)
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) {
+                    const float ma = absmax4(cur[n][rb].a), mb = absmax4(cur[n][rb].b);
+                    if constexpr (PL == 1) { pmax[n] = __builtin_fmaxf(pmax[n], ma); qmax[n] = __builtin_fmaxf(qmax[n], mb); }
+                    else { pmax[n] = __builtin_fmaxf(pmax[n], g < 2 ? __builtin_fmaxf(ma, mb) : 0.f); qmax[n] = __builtin_fmaxf(qmax[n], g < 2 ? 0.f : ma); }
+                    nm = __builtin_fmaxf(nm, __builtin_fmaxf(ma, mb));
+                }
+            sz = pow2_scale(wave_max_nonneg(nm), 4);
+            const float isz = inv_pow2(sz);
+            invn = inv * isz; invpn = invp * isz;
+        }
+
         f32x4 acc[NRB][NCB];
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb)
@@ -242,7 +267,8 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) {
                 const Row8<L>& zr = cur[n][rb];
-                za[rb] = F::split(zr.a, zr.b);
+                if constexpr (ASC) za[rb] = F::split(zr.a * sz, zr.b * sz);
+                else za[rb] = F::split(zr.a, zr.b);
             }
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) {
@@ -274,7 +300,7 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
                 for (int hb = 0; hb < HB; ++hb)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        Y[((size_t)node * C + 16 * rb + 4 * g + r) * Ho + 16 * hb + x] = F::SCALED ? fmaf(acc[rb][hb][r], inv, bv[hb]) : acc[rb][hb][r] + bv[hb];
+                        Y[((size_t)node * C + 16 * rb + 4 * g + r) * Ho + 16 * hb + x] = F::SCALED ? fmaf(acc[rb][hb][r], invn, bv[hb]) : acc[rb][hb][r] + bv[hb];
         } else if (EPI == EPI_GATES) {
             // Planar results leave in ROW layout, non-temporally: an accumulator-layout store instruction covers half a 128-byte line of each of
             // four rows, the row-layout one sixteen whole rows (the H tile is free once hv is read: it is the transposition scratch).  Timing
@@ -296,12 +322,12 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
 #pragma unroll
                 for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) uu[rb][r] = fast_sigmoid(F::SCALED ? fmaf(acc[rb][0][r], inv, bv[0]) : acc[rb][0][r] + bv[0]);
+                    for (int r = 0; r < 4; ++r) uu[rb][r] = fast_sigmoid(F::SCALED ? fmaf(acc[rb][0][r], invn, bv[0]) : acc[rb][0][r] + bv[0]);
                 put_plane(epi.U_out, uu);
 #pragma unroll
                 for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) gt[rb][r] = fast_sigmoid(F::SCALED ? fmaf(acc[rb][HB - 1][r], inv, bv[HB - 1]) : acc[rb][HB - 1][r] + bv[HB - 1]);
+                    for (int r = 0; r < 4; ++r) gt[rb][r] = fast_sigmoid(F::SCALED ? fmaf(acc[rb][HB - 1][r], invn, bv[HB - 1]) : acc[rb][HB - 1][r] + bv[HB - 1]);
                 put_plane(epi.R_out, gt);
 #pragma unroll
                 for (int rb = 0; rb < NRB; ++rb)
@@ -328,8 +354,8 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const size_t row = (size_t)node * C + 16 * rb + 4 * g + r;
-                    const float u = fast_sigmoid(F::SCALED ? fmaf(acc[rb][0][r], inv, bv[0]) : acc[rb][0][r] + bv[0]);
-                    const float gate = fast_sigmoid(F::SCALED ? fmaf(acc[rb][HB - 1][r], inv, bv[HB - 1]) : acc[rb][HB - 1][r] + bv[HB - 1]);
+                    const float u = fast_sigmoid(F::SCALED ? fmaf(acc[rb][0][r], invn, bv[0]) : acc[rb][0][r] + bv[0]);
+                    const float gate = fast_sigmoid(F::SCALED ? fmaf(acc[rb][HB - 1][r], invn, bv[HB - 1]) : acc[rb][HB - 1][r] + bv[HB - 1]);
                     epi.U_out[row * HID + x] = u;
                     epi.R_out[row * HID + x] = gate;
                     epi.CandIn[row * L + epi.cin + x] = gate * hv[rb][r];
@@ -359,7 +385,8 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
                             b4[i] = g < 2 ? tb[i] : 0.f;
                         }
                     }
-                    zc[rb] = F::split(a4, b4);
+                    if constexpr (ASC) zc[rb] = F::split(a4 * sz, b4 * sz);          // (|R*H| <= |H|: the node's scale covers it)
+                    else zc[rb] = F::split(a4, b4);
                 }
                 f32x4 pa[K][NRB][K];
 #pragma unroll
@@ -386,12 +413,12 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
 #pragma unroll
                 for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) ov[rb][r] = F::SCALED ? fmaf(pa[0][rb][0][r], invp, bcv) : pa[0][rb][0][r] + bcv;
+                    for (int r = 0; r < 4; ++r) ov[rb][r] = F::SCALED ? fmaf(pa[0][rb][0][r], invpn, bcv) : pa[0][rb][0][r] + bcv;
                 put_plane(post.A, ov);
 #pragma unroll
                 for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) ov[rb][r] = F::SCALED ? pa[1][rb][0][r] * invp : pa[1][rb][0][r];
+                    for (int r = 0; r < 4; ++r) ov[rb][r] = F::SCALED ? pa[1][rb][0][r] * invpn : pa[1][rb][0][r];
                 put_plane(post.Bm, ov);
             }
             if (has_side) {
@@ -409,7 +436,7 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const size_t e = ((size_t)node * C + 16 * rb + 4 * g + r) * HID + x;
-                    const float c = fast_tanh(F::SCALED ? fmaf(acc[rb][0][r], inv, bv[0]) : acc[rb][0][r] + bv[0]);
+                    const float c = fast_tanh(F::SCALED ? fmaf(acc[rb][0][r], invn, bv[0]) : acc[rb][0][r] + bv[0]);
                     const float u = uv[rb][r];
                     hn[rb][r] = (1.f - u) * hv[rb][r] + u * c;
                     epi.Cand[e] = c;
@@ -422,6 +449,13 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) cur[n][rb] = nxt[n][rb];
         node = next_node;
+    }
+    if constexpr (ASC) {
+        if (epi.zmax) {                                          // rows [p planes of slab 0..K-1 | q planes of slab 0..K-1], launch order of Z
+            const int slot = blockIdx.x * MF_WAVES + wave;
+#pragma unroll
+            for (int n = 0; n < KL; ++n) { leave_max(epi.zmax + n * STC_ACT_SLOTS, slot, pmax[n]); leave_max(epi.zmax + (KL + n) * STC_ACT_SLOTS, slot, qmax[n]); }
+        }
     }
 }
 
@@ -577,6 +611,13 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
         sW = pow2_scale(block_absmax(W, K * K * Lw * Ho, scratch, MF_THREADS), 0);
         sg = pow2_scale(slots_max(pro.gmax, pro.n_gmax), 4);
     }
+    // activation operands of the dW products: one scale per plane and launch, from the slots the forward launch filled (block lb of slab n =
+    // row lb K + n; see cell_bwd_x3_kernel)
+    float sz[K][LB];
+#pragma unroll
+    for (int n = 0; n < K; ++n)
+#pragma unroll
+        for (int lb = 0; lb < LB; ++lb) sz[n][lb] = (F::SCALED && PL != 0) ? plane_scale(pro.zmax, lb * K + n) : 1.f;
 
     for (int idx = tid; idx < nTB * 64; idx += MF_THREADS) {
         const int ll = idx & 63, f = idx >> 6, p = f % NB2, rb = (f / NB2) % NRB, c1 = f / (NB2 * NRB), gg = ll >> 4;
@@ -781,8 +822,11 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
 #pragma unroll
                 for (int p = 0; p < NB2; ++p) {
                     const float (&zc)[NRB][4] = in.za[n][lb];
-                    const Op a = F::split(f32x4{zc[2 * p][0], zc[2 * p][1], zc[2 * p][2], zc[2 * p][3]},
-                                          f32x4{zc[2 * p + 1][0], zc[2 * p + 1][1], zc[2 * p + 1][2], zc[2 * p + 1][3]});
+                    Op a;
+                    if constexpr (F::SCALED) a = F::split(f32x4{zc[2 * p][0], zc[2 * p][1], zc[2 * p][2], zc[2 * p][3]} * sz[n][lb],
+                                                          f32x4{zc[2 * p + 1][0], zc[2 * p + 1][1], zc[2 * p + 1][2], zc[2 * p + 1][3]} * sz[n][lb]);
+                    else a = F::split(f32x4{zc[2 * p][0], zc[2 * p][1], zc[2 * p][2], zc[2 * p][3]},
+                                      f32x4{zc[2 * p + 1][0], zc[2 * p + 1][1], zc[2 * p + 1][2], zc[2 * p + 1][3]});
 #pragma unroll
                     for (int c = 0; c < K; ++c)
 #pragma unroll
@@ -804,7 +848,12 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
         node = next_node;
     }
     const float isg = 1.f / sg;                                // dW tiles of block c carry sg (c = 0) or sg sT (c >= 1); db carries sg
-    combine_dw<K, LB, HB>(reinterpret_cast<float*>(smem_raw), dWt, dbp, partial, Lw, want_db, PL == 2 ? Lw - 16 : -1, isg, isg / sT, isg);
+    PlaneUnscale<K, LB> pu;
+#pragma unroll
+    for (int n = 0; n < K; ++n)
+#pragma unroll
+        for (int lb = 0; lb < LB; ++lb) pu.v[n][lb] = inv_pow2(sz[n][lb]);
+    combine_dw<K, LB, HB>(reinterpret_cast<float*>(smem_raw), dWt, dbp, partial, Lw, want_db, PL == 2 ? Lw - 16 : -1, isg, isg / sT, isg, pu);
 }
 
 // --------------------------------------------------------------------------------------- post-aggregation form (K = 2)
@@ -927,7 +976,11 @@ template <int NB2, int HB, int L, int PL = 0, class F = FmtB3>      // F: operan
 __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_kernel(
     const float* __restrict__ X, const float* __restrict__ X2, const float* __restrict__ Tc, const float* __restrict__ W,
     const float* __restrict__ dA, const float* __restrict__ dB, float* __restrict__ dX, float* __restrict__ dX2,
-    float* __restrict__ partial, int nodes, int want_db, int Lw, const float* __restrict__ gmax, int n_gmax) {
+    float* __restrict__ partial, int nodes, int want_db, int Lw, const float* __restrict__ gmax, int n_gmax,
+    const float* __restrict__ zmax_x, const float* __restrict__ zmax_x2, float* __restrict__ out_amax) {
+    // zmax_x / zmax_x2 (fp16 x 2, optional): 256 slots each of max |X| / max |X2| (a row of the slots a forward launch filled; R*H takes H's): the
+    // scales of the dW products' activation operands.  out_amax (optional): (2, 256) zero-filled slots that receive max |dX| and max |dX2| -- the
+    // gates backward that consumes the R*H plane's gradient scales its gradient operands by it.
     using Op = typename F::Op;
     constexpr int NP = F::NP;
     constexpr int K = 2, NRB = 2 * NB2, C = 32 * NB2, Ho = 16 * HB, LB = (L + 15) / 16;
@@ -945,6 +998,11 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
         sW = pow2_scale(block_absmax(W, K * K * Lw * Ho, scratch, MF_THREADS), 0);
         sg = pow2_scale(slots_max(gmax, n_gmax), 4);
     }
+    float sz[LB];
+#pragma unroll
+    for (int lb = 0; lb < LB; ++lb) sz[lb] = (F::SCALED && PL != 0) ? plane_scale(lb == 0 ? zmax_x : zmax_x2, 0) : 1.f;
+    static_assert(LB == 2, "rows of 16 + 16 or 16 + cin columns");
+    float omax[LB] = {0.f, 0.f};                        // running max |dX| / |dX2| of this lane
 
     for (int idx = tid; idx < nTB * 64; idx += MF_THREADS) {
         const int ll = idx & 63, f = idx >> 6, p = f % NB2, rb = f / NB2, gg = ll >> 4;
@@ -1078,7 +1136,7 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
                 }
             if constexpr (F::SCALED) {
 #pragma unroll
-                for (int rb = 0; rb < NRB; ++rb) z[rb] *= ikz_sg;
+                for (int rb = 0; rb < NRB; ++rb) { z[rb] *= ikz_sg; omax[lb] = __builtin_fmaxf(omax[lb], absmax4(z[rb])); }
             }
             if constexpr (PL == 1) {                            // planar gradient: columns 0..15 -> dX, 16..31 -> dX2
 #pragma unroll
@@ -1123,8 +1181,11 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
 #pragma unroll
             for (int p = 0; p < NB2; ++p) {
                 const float (&zc)[NRB][4] = za[lb];
-                const Op a = F::split(f32x4{zc[2 * p][0], zc[2 * p][1], zc[2 * p][2], zc[2 * p][3]},
-                                    f32x4{zc[2 * p + 1][0], zc[2 * p + 1][1], zc[2 * p + 1][2], zc[2 * p + 1][3]});
+                Op a;
+                if constexpr (F::SCALED) a = F::split(f32x4{zc[2 * p][0], zc[2 * p][1], zc[2 * p][2], zc[2 * p][3]} * sz[lb],
+                                                      f32x4{zc[2 * p + 1][0], zc[2 * p + 1][1], zc[2 * p + 1][2], zc[2 * p + 1][3]} * sz[lb]);
+                else a = F::split(f32x4{zc[2 * p][0], zc[2 * p][1], zc[2 * p][2], zc[2 * p][3]},
+                                  f32x4{zc[2 * p + 1][0], zc[2 * p + 1][1], zc[2 * p + 1][2], zc[2 * p + 1][3]});
 #pragma unroll
                 for (int n = 0; n < K; ++n)
 #pragma unroll
@@ -1135,7 +1196,19 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
             }
     }
     const float isg = 1.f / sg;
-    combine_dw<K, LB, HB>(reinterpret_cast<float*>(smem_raw), dWt, dbp, partial, Lw, want_db, PL == 2 ? Lw - 16 : -1, isg, isg / sT, isg);
+    if constexpr (F::SCALED) {
+        if (out_amax) {
+            const int slot = blockIdx.x * MF_WAVES + wave;
+            leave_max(out_amax, slot, omax[0]);
+            leave_max(out_amax + STC_ACT_SLOTS, slot, omax[1]);
+        }
+    }
+    PlaneUnscale<K, LB> pu;
+#pragma unroll
+    for (int n = 0; n < K; ++n)
+#pragma unroll
+        for (int lb = 0; lb < LB; ++lb) pu.v[n][lb] = inv_pow2(sz[lb]);
+    combine_dw<K, LB, HB>(reinterpret_cast<float*>(smem_raw), dWt, dbp, partial, Lw, want_db, PL == 2 ? Lw - 16 : -1, isg, isg / sT, isg, pu);
 }
 
 // --------------------------------------------------------------------------------------- host side
@@ -1311,7 +1384,8 @@ int stc_cell_cand_bwd_x3(const float* const* Z, int K, const float* Tc, const fl
 
 template <int NB2, int HB, int L, int PL = 0, class F = FmtB3>
 static int launch_bwd2(const float* X, const float* X2, const float* Tc, const float* W, const float* dA, const float* dB, float* dX, float* dX2,
-                       float* partial, int* n_partials, int want_db, long long nodes, int Lw, hipStream_t stream, const float* gmax = nullptr, int n_gmax = 0) {
+                       float* partial, int* n_partials, int want_db, long long nodes, int Lw, hipStream_t stream, const float* gmax = nullptr, int n_gmax = 0,
+                       const float* zmax_x = nullptr, const float* zmax_x2 = nullptr, float* out_amax = nullptr) {
     constexpr int K = 2, NRB = 2 * NB2, Ho = 16 * HB, LB = (L + 15) / 16, NBK = K * HB, S = (NBK + 1) / 2, nW = K * K * L * Ho;
     const size_t frag = (size_t)(NRB * NB2 + K * LB * S) * F::NP * 64 * 16;
     const size_t slabs = (size_t)MF_WAVES * (nW + Ho) * sizeof(float);
@@ -1323,7 +1397,7 @@ static int launch_bwd2(const float* X, const float* X2, const float* Tc, const f
     const long long want = (nodes + MF_WAVES - 1) / MF_WAVES;
     int grid = resident < MF_BWD_MAX_GRID ? resident : MF_BWD_MAX_GRID;
     if (want < grid) grid = (int)want;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(MF_THREADS), lds, stream, X, X2, Tc, W, dA, dB, dX, dX2, partial, (int)nodes, want_db, Lw, gmax, n_gmax);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(MF_THREADS), lds, stream, X, X2, Tc, W, dA, dB, dX, dX2, partial, (int)nodes, want_db, Lw, gmax, n_gmax, zmax_x, zmax_x2, out_amax);
     STC_LAUNCH_CHECK("node_bwd2_x3 launch");
     *n_partials = grid;
     return STC_OK;
@@ -1352,20 +1426,21 @@ int stc_node_post_shape_ok(int K, int C, int L, int Ho) {
 // kernel and keeps bf16 x 3 here: its two-waves-per-SIMD build has no registers to spare); null: bf16 x 3
 int stc_node_post_bwd_x3(const float* X, const float* X2, const float* Tc, const float* W, const float* dA, const float* dB, float* dX, float* dX2,
                          float* partial, int* n_partials, int want_db, const float* gmax, int n_gmax,
+                         const float* zmax_x, const float* zmax_x2, float* out_amax,
                          long long nodes, int C, int L, int Lw, int Ho, hipStream_t stream) {
     if (!stc_node_post_shape_ok(2, C, L, Ho) || nodes <= 0 || nodes >= (1ll << 31) / C) return STC_NOT_HANDLED;
     if (!(stc::aligned16(X) && stc::aligned16(dA) && stc::aligned16(dB) && stc::aligned16(dX) && (!X2 || L == 20 || stc::aligned16(X2)))) return STC_NOT_HANDLED;
     if (X2 && L == 20) {                        // narrow planar rows: gradient of the 16-wide plane only (dX); the input plane gets none
         if (Lw - 16 < 1 || Lw - 16 > 4) return STC_NOT_HANDLED;
         if (C == 32) return launch_bwd2<1, 1, 20, 2>(X, X2, Tc, W, dA, dB, dX, nullptr, partial, n_partials, want_db, nodes, Lw, stream);
-        if (C == 64 && gmax) return launch_bwd2<2, 1, 20, 2, FmtH2>(X, X2, Tc, W, dA, dB, dX, nullptr, partial, n_partials, want_db, nodes, Lw, stream, gmax, n_gmax);
+        if (C == 64 && gmax) return launch_bwd2<2, 1, 20, 2, FmtH2>(X, X2, Tc, W, dA, dB, dX, nullptr, partial, n_partials, want_db, nodes, Lw, stream, gmax, n_gmax, zmax_x, zmax_x2, out_amax);
         if (C == 64) return launch_bwd2<2, 1, 20, 2>(X, X2, Tc, W, dA, dB, dX, nullptr, partial, n_partials, want_db, nodes, Lw, stream);
         return STC_NOT_HANDLED;
     }
     if (X2) {                                   // planar rows (16 + 16 columns): input planes X, X2 and gradient planes dX, dX2
         if (L != 32 || !dX2 || !stc::aligned16(dX2)) return STC_NOT_HANDLED;
         if (C == 32) return launch_bwd2<1, 1, 32, 1>(X, X2, Tc, W, dA, dB, dX, dX2, partial, n_partials, want_db, nodes, Lw, stream);
-        if (C == 64 && gmax) return launch_bwd2<2, 1, 32, 1, FmtH2>(X, X2, Tc, W, dA, dB, dX, dX2, partial, n_partials, want_db, nodes, Lw, stream, gmax, n_gmax);
+        if (C == 64 && gmax) return launch_bwd2<2, 1, 32, 1, FmtH2>(X, X2, Tc, W, dA, dB, dX, dX2, partial, n_partials, want_db, nodes, Lw, stream, gmax, n_gmax, zmax_x, zmax_x2, out_amax);
         if (C == 64) return launch_bwd2<2, 1, 32, 1>(X, X2, Tc, W, dA, dB, dX, dX2, partial, n_partials, want_db, nodes, Lw, stream);
         return STC_NOT_HANDLED;
     }
@@ -1427,7 +1502,7 @@ static int gates_fwd_planar_go(const float* X, const float* H, const float* SX, 
 
 int stc_cell_gates_fwd_planar_x3(const float* X, const float* H, const float* SX, const float* SH, const float* Tc, const float* W,
                                  const float* bias, float* U, float* R, float* RH,
-                                 const float* Wc, const float* bc, float* A, float* Bm, int fmt,
+                                 const float* Wc, const float* bc, float* A, float* Bm, int fmt, float* zmax,
                                  long long nodes, int C, int Lw, hipStream_t stream) {
     const int cin = Lw - 16;
     const PostArgs post{Wc, bc, A, Bm};
@@ -1435,7 +1510,7 @@ int stc_cell_gates_fwd_planar_x3(const float* X, const float* H, const float* SX
     if (fused && !(Wc && Bm && stc::aligned16(A) && stc::aligned16(Bm))) return STC_NOT_HANDLED;
     if (!x3_cell_shape(2, C, cin == 16 ? 32 : 20, nodes) || !(cin == 16 || (cin >= 1 && cin <= 4))) return STC_NOT_HANDLED;
     FwdEpi epi{};
-    epi.H = H; epi.U_out = U; epi.R_out = R; epi.CandIn = RH; epi.cin = cin;
+    epi.H = H; epi.U_out = U; epi.R_out = R; epi.CandIn = RH; epi.cin = cin; epi.zmax = zmax;
     return fmt == STC_FMT_F16X2 ? gates_fwd_planar_go<FmtH2>(X, H, SX, SH, Tc, W, bias, epi, post, fused, cin, nodes, C, Lw, stream)
                                 : gates_fwd_planar_go<FmtB3>(X, H, SX, SH, Tc, W, bias, epi, post, fused, cin, nodes, C, Lw, stream);
 }
@@ -1463,7 +1538,7 @@ static int gates_bwd_planar_go(const float* const* Z, float* const* dZ, const fl
 // gmax != null: fp16 x 2 operand format (device floats whose maximum bounds |dHnew| and |dCandIn| of the launch); null: bf16 x 3
 int stc_cell_gates_bwd_planar_x3(const float* X, const float* H, const float* SX, const float* SH, const float* Tc, const float* W,
                                  const float* dCandIn, const float* Cand, const float* U, const float* R, const float* dHnew,
-                                 float* const* dZ, float* dH, float* partial, int* n_partials, int want_db, const float* gmax, int n_gmax,
+                                 float* const* dZ, float* dH, float* partial, int* n_partials, int want_db, const float* gmax, int n_gmax, const float* zmax,
                                  long long nodes, int C, int Lw, hipStream_t stream) {
     const int cin = Lw - 16;
     if (!x3_cell_shape(2, C, cin == 16 ? 32 : 20, nodes) || !(cin == 16 || (cin >= 1 && cin <= 4))) return STC_NOT_HANDLED;
@@ -1471,7 +1546,7 @@ int stc_cell_gates_bwd_planar_x3(const float* X, const float* H, const float* SX
         return STC_NOT_HANDLED;
     BwdPro pro{};       // dCandIn: the gradient of the R*H plane, (nodes, C, 16): the state columns sit at offset 0
     pro.Cand = Cand; pro.dCandIn = dCandIn; pro.H = H; pro.U = U; pro.R = R; pro.dH_in = dHnew; pro.dH = dH; pro.cin = 0; pro.dh_scaled = 1;
-    pro.gmax = gmax; pro.n_gmax = n_gmax;
+    pro.gmax = gmax; pro.n_gmax = n_gmax; pro.zmax = zmax;
     const float* Zw[4] = {X, SX, H, SH};
     const float* Zn[4] = {H, SH, X, SX};           // narrow input plane: the state plane leads; only d H plane (dZ[2]) and d SH plane (dZ[3]) are produced
     float* dZn[4] = {dZ[2], dZ[3], nullptr, nullptr};
@@ -1495,7 +1570,7 @@ int stc_cell_gates_bwd_planar_x3(const float* X, const float* H, const float* SX
 int stc_cell_planar_k_shape_ok(int K, int C, int h) { return K == 3 && C == 32 && h == 16; }
 
 int stc_cell_conv_fwd_planar_k_x3(const float* const* Zx, const float* const* Zh, int K, const float* Tc, const float* W, const float* bias, int mode,
-                                  const float* H, const float* Uin, float* U, float* R, float* RH, float* Cand, float* Hnew, int fmt,
+                                  const float* H, const float* Uin, float* U, float* R, float* RH, float* Cand, float* Hnew, int fmt, float* zmax,
                                   long long nodes, int C, int Lw, hipStream_t stream) {
     const int cin = Lw - 16;
     if (!stc_cell_planar_k_shape_ok(K, C, 16) || !x3_cell_shape(K, C, cin == 16 ? 32 : 20, nodes) || !(cin == 16 || (cin >= 1 && cin <= 4))) return STC_NOT_HANDLED;
@@ -1503,6 +1578,7 @@ int stc_cell_conv_fwd_planar_k_x3(const float* const* Zx, const float* const* Zh
     FwdEpi epi{};
     if (mode == 1) { epi.H = H; epi.U_out = U; epi.R_out = R; epi.CandIn = RH; epi.cin = cin; }
     else { epi.H = H; epi.U = Uin; epi.Cand = Cand; epi.Hnew = Hnew; }
+    epi.zmax = zmax;
     const float* Z[6];
     for (int n = 0; n < 3; ++n) { Z[n] = cin == 16 ? Zx[n] : Zh[n]; Z[3 + n] = cin == 16 ? Zh[n] : Zx[n]; }
     if (fmt == STC_FMT_F16X2) {
@@ -1537,7 +1613,7 @@ static int conv_bwd_planar_k_go(const float* const* Z, float* const* dZ, const f
 int stc_cell_conv_bwd_planar_k_x3(const float* const* Zx, const float* const* Zh, int K, const float* Tc, const float* W, int mode,
                                   const float* dRH, const float* Cand, const float* U, const float* R, const float* dHnew,
                                   float* const* dZx, float* const* dZh, float* dH, float* partial, int* n_partials, int want_db,
-                                  long long nodes, int C, int Lw, int accumulate_x, const float* gmax, int n_gmax, hipStream_t stream) {
+                                  long long nodes, int C, int Lw, int accumulate_x, const float* gmax, int n_gmax, const float* zmax, hipStream_t stream) {
     const int cin = Lw - 16;
     if (!stc_cell_planar_k_shape_ok(K, C, 16) || !x3_cell_shape(K, C, cin == 16 ? 32 : 20, nodes) || !(cin == 16 || (cin >= 1 && cin <= 4))) return STC_NOT_HANDLED;
     if (!all_aligned16(Zh, K) || (cin == 16 && !all_aligned16(Zx, K))) return STC_NOT_HANDLED;
@@ -1550,7 +1626,7 @@ int stc_cell_conv_bwd_planar_k_x3(const float* const* Zx, const float* const* Zh
     }
     if (!(stc::aligned16(Cand) && stc::aligned16(U) && stc::aligned16(dHnew))) return STC_NOT_HANDLED;
     BwdPro pro{};
-    pro.gmax = gmax; pro.n_gmax = n_gmax;
+    pro.gmax = gmax; pro.n_gmax = n_gmax; pro.zmax = zmax;
     if (mode == 1) {
         if (!(stc::aligned16(dRH) && stc::aligned16(R) && (!dH || stc::aligned16(dH)))) return STC_NOT_HANDLED;
         pro.Cand = Cand; pro.dCandIn = dRH; pro.H = Zh[0]; pro.U = U; pro.R = R; pro.dH_in = dHnew; pro.dH = dH; pro.cin = 0; pro.dh_scaled = 1;

@@ -90,9 +90,7 @@ __device__ __forceinline__ void publish_amax(const EpiArgs& ep, float m) {
 }
 
 // the GRU blend on one 16-byte piece of a (row, category) state row, plus its copies (EP_BLEND)
-__device__ __forceinline__ float tanh_fast(float v) {          // 1 - 2 / (e^{2v} + 1) on the hardware exp2 / rcp: |err| < 2e-7
-    return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.8853900817779268f * v));
-}
+__device__ __forceinline__ float tanh_fast(float v) { return stc_tanh(v); }      // hardware exp2 / rcp, polynomial below 1/4 (stc_common.h)
 __device__ __forceinline__ void blend_piece(const EpiArgs& a, size_t rowg, int ch, size_t o, const float4& v, const float4& u, const float4& hh) {
     const float4 c = make_float4(tanh_fast(v.x), tanh_fast(v.y), tanh_fast(v.z), tanh_fast(v.w));
     const float4 hn = make_float4((1.f - u.x) * hh.x + u.x * c.x, (1.f - u.y) * hh.y + u.y * c.y,

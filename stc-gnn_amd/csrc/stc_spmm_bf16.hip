@@ -77,9 +77,7 @@ __device__ __forceinline__ void unpack8(const u32x4 v, float (&r)[8]) {
 __device__ __forceinline__ u32x4 pack8(const float (&r)[8]) {
     return u32x4{pk_bf16(r[0], r[1]), pk_bf16(r[2], r[3]), pk_bf16(r[4], r[5]), pk_bf16(r[6], r[7])};
 }
-__device__ __forceinline__ float tanh_fast(float v) {          // 1 - 2 / (e^{2v} + 1) on the hardware exp2 / rcp
-    return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.8853900817779268f * v));
-}
+__device__ __forceinline__ float tanh_fast(float v) { return stc_tanh(v); }      // hardware exp2 / rcp, polynomial below 1/4 (stc_common.h)
 
 // BLEND: the epilogue's own operands, requested before the gather so that they arrive under it
 struct BlendIn { u32x4 a, u, h; };

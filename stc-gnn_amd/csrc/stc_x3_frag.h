@@ -229,18 +229,59 @@ __device__ __forceinline__ float slots_max(const float* __restrict__ slots, int 
     return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(m)));      // (the builtin takes an int: pass the BITS, not the value)
 }
 
+// ---- activation operands of the fp16 x 2 format.  The reference's einsum / tanh are scale-free (STC_GNN.py:37-42, 72-78); two fp16 pieces
+// are not: below 2^-3 the low piece is a subnormal (absolute floor 2^-25) and nothing exists above 65504.  Hence activations carry powers of
+// two as well (exact), taken from maxima the kernels find themselves:
+//   forward   ONE scale per node, from the maximum over every row the wave has loaded for that node (all planes; R*H <= H rides on it):
+//             a wave reduction on the vector pipe (DPP) + scalar exponent arithmetic per node; the node's epilogue takes it out again.
+//             The wave also keeps running per-plane maxima and leaves them in the launch's slots (one atomic max per plane and wave);
+//   backward  the dW products sum over nodes in one accumulator, so they take ONE scale per plane and launch, from those slots
+//             (the dW tiles of a plane are their own accumulators: the combine takes each plane's scale out).
+// Non-negative floats order as their bit patterns: maxima are taken on the bits where that saves a conversion.
+constexpr int STC_ACT_SLOTS = 256;          // slots per plane row of an activation-maximum buffer
+
+__device__ __forceinline__ float absmax4(const f32x4 v) {
+    return __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])), __builtin_fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3])));
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_max(float m) {
+    const int o = __builtin_amdgcn_update_dpp(0, __float_as_int(m), CTRL, 0xF, 0xF, true);
+    return __builtin_fmaxf(m, __int_as_float(o));
+}
+// max of a NON-NEGATIVE value over the wave, wave-uniform (scalar register): quad swaps, half-row and row mirrors, then the four rows
+__device__ __forceinline__ float wave_max_nonneg(float m) {
+    m = dpp_max<0xB1>(m);            // quad_perm:[1,0,3,2]
+    m = dpp_max<0x4E>(m);            // quad_perm:[2,3,0,1]
+    m = dpp_max<0x141>(m);           // row_half_mirror
+    m = dpp_max<0x140>(m);           // row_mirror: every lane of a row of 16 holds the row's maximum
+    const int b = __float_as_int(m);
+    const int r0 = __builtin_amdgcn_readlane(b, 0), r1 = __builtin_amdgcn_readlane(b, 16), r2 = __builtin_amdgcn_readlane(b, 32), r3 = __builtin_amdgcn_readlane(b, 48);
+    const int a = r0 > r1 ? r0 : r1, c = r2 > r3 ? r2 : r3;
+    return __int_as_float(a > c ? a : c);
+}
+// 1 / s for s = 2^k, |k| <= 126, on the exponent field
+__device__ __forceinline__ float inv_pow2(float s) { return __uint_as_float(0x7F000000u - __float_as_uint(s)); }
+// one wave's running maximum into its slot of a row of STC_ACT_SLOTS (the row was zero-filled before the launch)
+__device__ __forceinline__ void leave_max(float* __restrict__ row, int slot, float m) {
+    m = wave_max_nonneg(m);
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<int*>(row) + (slot & (STC_ACT_SLOTS - 1)), __float_as_int(m));
+}
+
+// scale 2^k of the plane whose maxima sit in row `row` of the forward launch's slots (1 without slots: the caller gave no range information)
+__device__ __forceinline__ float plane_scale(const float* __restrict__ zmax, int row) {
+    if (!zmax) return 1.f;
+    float m = 0.f;
+    for (int i = threadIdx.x & 63; i < STC_ACT_SLOTS; i += 64) m = fmaxf(m, zmax[row * STC_ACT_SLOTS + i]);
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pow2_scale(wave_max_nonneg(m), 4))));      // (a scalar register)
+}
+
 // row of a pair of 16-row tiles that slot (g, e) of an accumulator-fed operand stands for
 __host__ __device__ constexpr int pair_row(int g, int e) { return 16 * (e >> 2) + 4 * g + (e & 3); }
 
 #define kZero4 (f32x4{0.f, 0.f, 0.f, 0.f})
 
-// Gate nonlinearities of the fused epilogues on the hardware exp2 / rcp (1 ulp each): absolute error < 2e-7, against the
-// ~30 VALU instructions each of the IEEE division and libm expf / tanhf -- these kernels are VALU-issue bound.
-__device__ __forceinline__ float fast_sigmoid(float v) {
-    return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
-}
-__device__ __forceinline__ float fast_tanh(float v) {       // 1 - 2 / (e^{2v} + 1); saturates cleanly at +-1
-    return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.8853900817779268f * v));
-}
+// Gate nonlinearities of the fused epilogues: stc_common.h (hardware exp2 / rcp, accurate relative to the result for every argument)
+__device__ __forceinline__ float fast_sigmoid(float v) { return stc_sigmoid(v); }
+__device__ __forceinline__ float fast_tanh(float v) { return stc_tanh(v); }
 
 }  // namespace

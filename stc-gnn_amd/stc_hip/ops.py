@@ -548,6 +548,13 @@ class _StcCellGraph(Function):
                 agg[src] = cheb_planes(source(src))
             return agg[src]
 
+        # fp16 x 2 operand format: every planar forward launch leaves the maxima of its input planes in a row of slots (one zero fill per
+        # forward pass); the matching backward launch scales the activation operands of its dW products by them (_lib.act_amax_buffer)
+        zmax_all = k.act_amax_buffer(ref, n_cells, 2, 2 * Ks) if (not bf16 and any(planar)) else None
+
+        def act_slots(j, which=0):                                  # which: 0 = the gates convolution's planes, 1 = the candidate's (order 3)
+            return {} if zmax_all is None else dict(act_amax=zmax_all[j, which])
+
         state = [None] * n_cells                                    # plain (B,N,C,h) new state of every cell
         out_stack = ref.new_empty(len(outputs), B, N, C, h)         # the requested states are produced in place, stacked
         out_slot = {j: i for i, j in enumerate(outputs)}
@@ -583,9 +590,9 @@ class _StcCellGraph(Function):
             Hnew = _alias_slice(out_stack, out_slot[j]) if j in out_slot else torch.empty_like(Hprev)
             if planar[j] and planar_k:
                 Zx, Zh, RH = planes_of(x), planes_of(hs), torch.empty_like(Hprev)
-                k.cell_gates_fwd_planar_k(rows(Zx), rows(Zh), Tc, Wg, bg, *rows((U, Rg, RH)))
+                k.cell_gates_fwd_planar_k(rows(Zx), rows(Zh), Tc, Wg, bg, *rows((U, Rg, RH)), **act_slots(j, 0))
                 Zr = cheb_planes(RH)                                # the candidate's H side: T_n(S) of R*H (its X side is Zx again)
-                k.cell_cand_fwd_planar_k(rows(Zx), rows(Zr), Tc, Wc, bc, *rows((U, Hprev, Cand, Hnew)))
+                k.cell_cand_fwd_planar_k(rows(Zx), rows(Zr), Tc, Wc, bc, *rows((U, Hprev, Cand, Hnew)), **act_slots(j, 1))
                 saved += [Hprev, U, Rg, Cand, *Zx, *Zh[1:], *Zr]
                 n_saved.append(-12)                                 # negative count: planar cell (12: order 3, slab-planar candidate)
             elif planar[j]:
@@ -597,9 +604,9 @@ class _StcCellGraph(Function):
                 A, Bm = torch.empty_like(Hprev), torch.empty_like(Hprev)
                 if fused_post:                                        # the candidate's projection rides in the gates launch
                     k.cell_gates_fwd_planar(*rows((Xp, Hprev, SXp, SHp)), Tc, Wg, bg, *rows((U, Rg)), None if RH is None else RH.view(B * N, C, h),
-                                            post=(Wc, bc, *rows((A, Bm))))
+                                            post=(Wc, bc, *rows((A, Bm))), **act_slots(j))
                 else:
-                    k.cell_gates_fwd_planar(*rows((Xp, Hprev, SXp, SHp)), Tc, Wg, bg, *rows((U, Rg, RH)))
+                    k.cell_gates_fwd_planar(*rows((Xp, Hprev, SXp, SHp)), Tc, Wg, bg, *rows((U, Rg, RH)), **act_slots(j))
                     lead, second = (Xp, RH) if cin[j] == h else (RH, Xp)     # narrow input plane: the 16-wide plane leads
                     k.node_post_fwd(*rows((lead,)), Tc, Wc, bc, *rows((A, Bm)), X2=second.view(B * N, C, second.shape[-1]))
                 k.spmm_blend_fwd(op.fwd_rowptr, op.fwd_colidx, fwd_val, op.fwd_plan, Bm, A, U, Hprev, Cand, Hnew, copies=copies, side=side)
@@ -644,6 +651,7 @@ class _StcCellGraph(Function):
             state[j] = Hnew
         ctx.save_for_backward(Tc, *[p for st in stacks for p in st if p is not None], *saved)
         ctx.meta = (op, Ks, schedule, tuple(outputs), cin, [tuple(p is not None for p in st) for st in stacks], (B, N, C), n_saved)
+        ctx.zmax_all = zmax_all
         # the saved states of the output cells ALIAS out_stack's storage without sharing its autograd version counter: the
         # returned stack is read-only for its consumers; its version is checked again in backward
         ctx.out_stack_ref, ctx.out_stack_version = weakref.ref(out_stack), out_stack._version      # (weak: no output -> ctx -> output cycle)
@@ -719,11 +727,16 @@ class _StcCellGraph(Function):
         n_slots = 256
         amax_rows = {}
         f16x2 = not bf16_planes and getattr(k, 'operand_format', 0) == 1
+        zmax_all = ctx.zmax_all
+
+        def act_slots(j, which=0):                                   # what cell j's forward launches left: the activation scales of its dW products
+            return {} if zmax_all is None else dict(act_amax=zmax_all[j, which])
 
         def amax_slots(kid, which=0):
-            """Row ``which`` of cell ``kid``'s slots: 0 = its state gradient dHnew, 1 = the gradient of its R*H plane (order 3)."""
+            """Row ``which`` of cell ``kid``'s slots: 0 = its state gradient dHnew; 1 = the gradient of its R*H plane (order 3), or 1, 2 = the
+            gradients of the candidate's two input planes (two-launch backward: what ``node_post_bwd`` leaves)."""
             if 'all' not in amax_rows:
-                amax_rows['all'] = grad_stack.new_zeros(len(schedule), 2, n_slots, dtype=torch.float32)
+                amax_rows['all'] = grad_stack.new_zeros(len(schedule), 3, n_slots, dtype=torch.float32)
             amax_rows.setdefault(kid, amax_rows['all'][kid])
             return amax_rows[kid][which]
 
@@ -802,7 +815,7 @@ class _StcCellGraph(Function):
                 dXc, dR = ([new(), new(), new()] if wide else [None] * 3), [new(), new(), new()]
                 k.cell_cand_bwd_planar_k(rows(Zx), rows(Zr), Tc, Wc, *rows((dHnew, U, Cand)),
                                          [None if t is None else t.view(B * N, C, h) for t in dXc], rows(dR), dWc, dbc,
-                                         **(dict(grad_amax=amax_rows[j][0]) if have else {}))
+                                         **(dict(grad_amax=amax_rows[j][0]) if have else {}), **act_slots(j, 1))
                 # gradient of the R*H plane from its three Chebyshev planes (its maximum beside dHnew's: the gates backward scales by both)
                 dRH = clenshaw([dR[0]], [dR[1]], [dR[2]], amax=amax_slots(j, 1) if have else None)
                 del dR
@@ -815,7 +828,7 @@ class _StcCellGraph(Function):
                 k.cell_gates_bwd_planar_k(rows(Zx), rows(Zh), Tc, Wg, *rows((dRH, Cand, U, Rg, dHnew)),
                                           [None if t is None else t.view(B * N, C, h) for t in dXg], rows(dHg), dWg, dbg,
                                           None if fold else dH.view(B * N, C, h), accumulate_x=into,
-                                          **(dict(grad_amax=amax_rows[j].view(-1)) if have else {}))
+                                          **(dict(grad_amax=amax_rows[j].view(-1)) if have else {}), **act_slots(j, 0))
                 if into:
                     dXc = [None] * 3
                 if wide and x[0] == 'cell':
@@ -860,29 +873,36 @@ class _StcCellGraph(Function):
                 dHd, dSH, acc_h = planes_of_state(hs)
                 k.cell_bwd_planar(*rows((Xp, Hprev, SXp, SHp)), Tc, Wg, Wc, *rows((U, Rg, Cand, dHnew, dBm)),
                                   [None if t is None else t.view(B * N, C, h) for t in (dXd, dSX, dHd, dSH)], dWg, dbg, dWc, dbc,
-                                  accumulate_x=acc_x, accumulate_h=acc_h, **(dict(grad_amax=amax_rows[j][0]) if j in amax_rows else {}))
+                                  accumulate_x=acc_x, accumulate_h=acc_h, **(dict(grad_amax=amax_rows[j][0]) if j in amax_rows else {}), **act_slots(j))
                 continue                                             # (parameter gradients: rows of the set's buffer, summed at the end)
             if n_saved[j] < 0:                                       # planar cell: inputs and gradients as planes
                 Xp, SXp, SHp, RH = rest
                 amax_kw = dict(grad_amax=amax_rows[j][0]) if j in amax_rows else {}      # |dY| <= |dHnew|, |S^T dY| within the format's headroom
+                wide = cin[j] == h                                   # else: narrow input plane (layer 0), which needs no gradient
+                post_kw, gates_kw = dict(amax_kw), dict(amax_kw)
+                if j in amax_rows and zmax_all is not None:
+                    # the candidate's input planes are (X, R*H): X's maximum as the gates forward left it, R*H rides on H's (|R*H| <= |H|).  Slot
+                    # rows of that launch: wide {X, S.X, H, S.H}, narrow {H, S.H, x, S.x}; the post kernel takes (16-wide plane, other plane).
+                    zr = zmax_all[j, 0]
+                    post_kw.update(act_amax=(zr[0], zr[2]), out_amax=amax_rows[j][1:3])
+                    # the gates backward's gradient operands are dHnew AND the R*H plane's gradient, which the launch above measures (rows 1, 2:
+                    # max |dX|, max |dX2| -- the R*H gradient is one of them, the X plane's candidate share the other: both bound it)
+                    gates_kw.update(grad_amax=amax_rows[j].view(-1), act_amax=zr)
                 dBm = narrow_transpose_aggregation(dY)
                 dRH = torch.empty_like(Hprev)
                 dWg, dbg, dWc, dbc = grads_for(s_id)
-                wide = cin[j] == h                                   # else: narrow input plane (layer 0), which needs no gradient
                 dHd, dSH = torch.empty_like(Hprev), torch.empty_like(Hprev)
                 if wide:
                     dXc, dXd, dSX = (torch.empty_like(Hprev) for _ in range(3))
-                    k.node_post_bwd(*rows((Xp,)), Tc, Wc, *rows((dY, dBm, dXc)), dWc, dbc, X2=RH.view(B * N, C, h), dX2=dRH.view(B * N, C, h), **amax_kw)
+                    k.node_post_bwd(*rows((Xp,)), Tc, Wc, *rows((dY, dBm, dXc)), dWc, dbc, X2=RH.view(B * N, C, h), dX2=dRH.view(B * N, C, h), **post_kw)
                     planes = rows((dXd, dSX, dHd, dSH))
                 else:
-                    k.node_post_bwd(*rows((RH,)), Tc, Wc, *rows((dY, dBm, dRH)), dWc, dbc, X2=Xp.view(B * N, C, cin[j]), **amax_kw)
+                    k.node_post_bwd(*rows((RH,)), Tc, Wc, *rows((dY, dBm, dRH)), dWc, dbc, X2=Xp.view(B * N, C, cin[j]), **post_kw)
                     planes = [None, None] + rows((dHd, dSH))
                 del dY, dBm
                 fold = getattr(k, 'folds_dH', False)                 # the kernel adds the prologue's share into the H plane's gradient
                 k.cell_gates_bwd_planar(*rows((Xp, Hprev, SXp, SHp)), Tc, Wg, *rows((dRH, Cand, U, Rg, dHnew)), planes, dWg, dbg,
-                                        None if fold else dH.view(B * N, C, h),
-                                        # (the R*H plane's gradient is a few times the state gradient at most: inside the format's 2^8 headroom)
-                                        **amax_kw)
+                                        None if fold else dH.view(B * N, C, h), **gates_kw)
                 if wide and x[0] == 'cell':
                     leave(x[1], (dXd, dXc), dSX)                     # as the X plane: gates' and candidate's direct shares
                 if hs[0] == 'cell':
