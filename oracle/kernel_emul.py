@@ -135,12 +135,22 @@ class EmulatedKernels:
             return [_q2(p, 1.0) for p in planes]
         return [_q2(p, _pow2_scale(act_amax[r].max(), 4)) for p, r in zip(planes, rows)]
 
-    def _grad_scaled(self, grads, grad_amax):
+    def _grad_scaled(self, grads, planes=(), plane_scales=()):
+        """Backward: the gradient fragments of a launch take one scale per NODE (row of the (R, C, w) planes), from the node's own maximum over
+        all of them; the dW products sum over nodes at a reference scale (the kernels: the wave's running maximum; here: the launch's), so
+        their activation operand ``planes[i]`` (plane scale ``plane_scales[i]``) is multiplied by reference / node scale, capped at 2^8."""
         if self.fmt != 'f16x2':
-            return list(grads)
-        m = grad_amax.max() if grad_amax is not None else torch.stack([g.abs().max() for g in grads]).max()
-        s = _pow2_scale(m, 4)
-        return [_q2(g, s) for g in grads]
+            return list(grads), list(planes)
+        m = torch.stack([g.abs().amax(dim=(1, 2)) for g in grads]).amax(0)
+        a_n = _pow2_scale(m, 4).view(-1, 1, 1)
+        ref = _pow2_scale(m.max(), 4)
+        shift = torch.where(m.view(-1, 1, 1) > 0, (ref / a_n).clamp(max=256.0), torch.ones_like(a_n))
+        return [_q2(g, a_n) for g in grads], [_q2(p, sp * shift) for p, sp in zip(planes, plane_scales)]
+
+    def _plane_scales(self, act_amax, rows):
+        if not self.act_scales or act_amax is None:
+            return [1.0 for _ in rows]
+        return [_pow2_scale(act_amax[r].max(), 4) for r in rows]
 
     @staticmethod
     def _leave_maxima(act_amax, planes):
@@ -459,10 +469,9 @@ class EmulatedKernels:
             # As the kernel: the gate prologue runs in fp32 on the planes themselves (dG and the state's own share are exact); the matrix
             # products take dG, the tables and -- the dW products -- the planes, each as its format carries it.
             order = (0, 1, 2, 3) if cin == h else (2, 3, 0, 1)                # rows of the slots: wide {X, S.X, H, S.H}, narrow {H, S.H, x, S.x}
-            Xq, SXq, Hq, SHq = self._plane_scaled((X, SX, H, SH), act_amax, order)
             (Wq,), Tq = self._tables(W), self._mix_tables(Tc)
             dG = torch.cat([dHnew * (Cand - H) * U * (1 - U), dRH * H * Rg * (1 - Rg)], -1)
-            (dGq,) = self._grad_scaled((dG,), grad_amax)
+            (dGq,), (Xq, SXq, Hq, SHq) = self._grad_scaled((dG,), (X, SX, H, SH), self._plane_scales(act_amax, order))
             own = dRH * Rg + dHnew * (1 - U)
             rows = [torch.empty(H.shape[:-1] + (cin + h,), dtype=W.dtype) for _ in range(2)]
             EmulatedKernels().bdg_node_bwd([torch.cat([Xq, Hq], -1), torch.cat([SXq, SHq], -1)], Tq, Wq, dGq, rows, dW, None, None)
@@ -604,8 +613,8 @@ class EmulatedKernels:
 
     def node_post_bwd(self, X, Tc, W, dA, dB, dX, dW, db, X2=None, dX2=None, grad_amax=None, act_amax=None, out_amax=None):
         if X2 is not None and self.fmt == 'f16x2':             # operands in their format, then the exact twin
-            Xq, X2q = self._plane_scaled((X, X2), None if act_amax is None else torch.stack([a.reshape(-1) for a in act_amax]), (0, 1))
-            dAq, dBq = self._grad_scaled((dA, dB), grad_amax)
+            (dAq, dBq), (Xq, X2q) = self._grad_scaled((dA, dB), (X, X2), self._plane_scales(
+                None if act_amax is None else torch.stack([a.reshape(-1) for a in act_amax]), (0, 1)))
             (Wq,), Tq = self._tables(W), self._mix_tables(Tc)
             EmulatedKernels().node_post_bwd(Xq, Tq, Wq, dAq, dBq, dX, dW, db, X2=X2q, dX2=dX2)
             if out_amax is not None:

@@ -50,9 +50,10 @@ constexpr size_t cb_lds_bytes() { return (size_t)CB_TABLE_FRAGS * F::NP * 64 * 1
 // other consumer's -- and this launch ADDS its own: the state then owns ONE direct and ONE aggregated plane, and the state-gradient SpMM
 // that follows gathers one operand instead of two (8 -> 6 planes there, 2 more streamed reads here, where HBM is not the bound).
 // F: operand format of the matrix-core products (stc_x3_frag.h): FmtB3 = three bf16 pieces / six products, FmtH2 = two fp16 pieces / three
-// products with the gradient side of the kernel run in a space scaled by sg = 2^k (from the launch's gradient maximum, a.gmax) and the
-// tables normalised per workgroup: block c = 0 of W carries sW sT, blocks c >= 1 carry sW and T_1 carries sT, so both halves of a
-// contraction over (c, o) arrive with the same factor sg sT sW, which the tile's store takes out again.
+// products with every operand class scaled by powers of two (stc_x3_frag.h): gradient fragments per node (a_n, from the node's own maximum;
+// the dW / db sums over nodes at the wave's reference scale), activation operands of the dW products per plane (a.zmax), and the tables
+// normalised per workgroup: block c = 0 of W carries sW sT, blocks c >= 1 carry sW and T_1 carries sT, so both halves of a contraction over
+// (c, o) arrive with the same factor a_n sT sW, which the tile's store takes out again.
 template <class F, int L, int PL, int ACCX = 0, int ACCH = 0>        // PL = 1: L = 32, rows [X | H];  PL = 2: L = 20, rows [H | x (cin = Lw - 16 <= 4) | pad], W rows permuted to match
 __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs a) {
     using Op = typename F::Op;
@@ -76,15 +77,15 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
     const int cin = a.Lw - 16;
 
     // FmtH2: table scales from the tables' own maxima (same in every workgroup), gradient scale from the producer's slots
-    float sT = 1.f, sWg = 1.f, sWc = 1.f, sg = 1.f;
+    float sT = 1.f, sWg = 1.f, sWc = 1.f;
     if constexpr (F::SCALED) {
         float* scratch = reinterpret_cast<float*>(smem_raw);
         sT = pow2_scale(block_absmax(a.Tc + (size_t)C * C, C * C, scratch, CB_THREADS), 0);
         sT = fminf(fmaxf(sT, 0.0625f), 4096.f);          // W's block 0 carries sT as well: keep it inside fp16's range
         sWg = pow2_scale(block_absmax(a.Wg, 4 * a.Lw * 32, scratch, CB_THREADS), 0);
         sWc = pow2_scale(block_absmax(a.Wc, 4 * a.Lw * 16, scratch, CB_THREADS), 0);
-        sg = pow2_scale(slots_max(a.gmax, a.n_gmax), 4);
     }
+    RunScale rc, rg;                                     // gradient scales of the candidate / the gates phase (stc_x3_frag.h: per node + the wave's reference)
     // activation operands of the dW products (sums over nodes: one scale per plane and launch); block lb of slab n is row lb K + n of the slots.
     // R*H takes the H plane's scale (|R*H| <= |H|): block RHB of slab 0, where H itself sits.
     float sz[K][LB];
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
     // the two T_1 fragments are used four times per node (both orientations, both convolutions): kept in registers for the whole kernel
     const Op tb0 = F::get(TB, 0, lane), tb1 = F::get(TB, 1, lane);
     // FmtH2 factors (all powers of two; 1 for FmtB3): what a tile of each phase carries besides sg, and their inverses
-    const float kc = sT * sWc, kg = sT * sWg, ikc = 1.f / kc, ikg_sg = 1.f / (kg * sg);
+    const float kc = sT * sWc, kg = sT * sWg, ikc = 1.f / kc, ikg = 1.f / kg;
     Ops cur, nxt, nx2;                            // operands two nodes ahead: ~40 MB in flight chip-wide instead of 20
     int node = blockIdx.x * CB_WAVES + wave;
     if (node < a.nodes) load_ops(cur, node);
@@ -208,6 +209,29 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
     __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0), expcnt / lgkmcnt untouched
     while (node < a.nodes) {
         const int next_node = node + nw;
+        if constexpr (F::SCALED) {                                 // the running maxima crossed a binade: bring the accumulators to the new reference scales
+            const float pc = rc.pending(), pg = rg.pending();
+            if (pc != 1.f) {
+#pragma unroll
+                for (int n = 0; n < K; ++n)
+#pragma unroll
+                    for (int lb = 0; lb < LB; ++lb)
+#pragma unroll
+                        for (int c = 0; c < K; ++c) dWc[n][lb][c][0] *= pc;
+                dbc[0] *= pc;
+            }
+            if (pg != 1.f) {
+#pragma unroll
+                for (int n = 0; n < K; ++n)
+#pragma unroll
+                    for (int lb = 0; lb < LB; ++lb)
+#pragma unroll
+                        for (int c = 0; c < K; ++c)
+#pragma unroll
+                            for (int hb = 0; hb < 2; ++hb) dWg[n][lb][c][hb] *= pg;
+                dbg[0] *= pg; dbg[1] *= pg;
+            }
+        }
         // ACCX / ACCH: what the gradient planes already hold (tile layout: row 16rb + x, columns 4g .. 4g+3).  Requested for THIS node, before
         // the next node's operands (vmcnt counts in order); first used in the gates phase, microseconds from here.
         f32x4 old[K][LB][NRB];
@@ -221,19 +245,13 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
         if (next_node + nw < a.nodes) load_ops(nx2, next_node + nw);      // software prefetch, two nodes ahead
         __builtin_amdgcn_sched_barrier(0);
         const size_t r0 = (size_t)node * C;
-        if constexpr (F::SCALED) {                                 // the gradient operands enter the scaled space: everything below is linear in them
-#pragma unroll
-            for (int kb = 0; kb < NRB; ++kb) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { cur.gv[kb][i] *= sg; cur.bv[kb][i] *= sg; }
-            }
-        }
         const auto& zg = cur.zg;
         const auto &uv = cur.uv, &rv = cur.rv, &cv = cur.cv, &gv = cur.gv, &hv = cur.hv, &bv = cur.bv;
         const int lo = opaque(lane);
 
         // =========================================================== candidate convolution (post-aggregation form): dA = dY, dBm given
         f32x4 drh[NRB];                                            // gradient of the R*H plane, row-on-lane layout
+        float a_c = 1.f, sh_c = 1.f;                               // FmtH2: this node's gradient scale in the candidate phase, and a / a_n for the sums over nodes
         {
             DyFrag<NRB, 1> gr[K];
             f32x4 rh_v[NRB], rh_d[NRB];                             // R*H, the candidate's second input plane (re-formed, not stored by the forward)
@@ -248,6 +266,14 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
                     }
                     v1[kb] = bv[kb];
                 }
+                if constexpr (F::SCALED) {                         // into the node's own scale: everything below is linear in (dY, dBm)
+                    float m = 0.f;
+#pragma unroll
+                    for (int kb = 0; kb < NRB; ++kb) m = __builtin_fmaxf(m, __builtin_fmaxf(absmax4(v0[kb]), absmax4(v1[kb])));
+                    a_c = rc.node(wave_max_bits(m), sh_c);
+#pragma unroll
+                    for (int kb = 0; kb < NRB; ++kb) { v0[kb] *= a_c; v1[kb] *= a_c; }
+                }
                 to_acc(0, v0, d0);
                 to_acc(1, v1, d1);
                 to_acc(2, rh_v, rh_d);
@@ -259,7 +285,7 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
             }
 #pragma unroll
             for (int kb = 0; kb < NRB; ++kb)
-                dbc[0] += (gr[0].d[kb][0][0] + gr[0].d[kb][0][1]) + (gr[0].d[kb][0][2] + gr[0].d[kb][0][3]);
+                dbc[0] += sh_c * ((gr[0].d[kb][0][0] + gr[0].d[kb][0][1]) + (gr[0].d[kb][0][2] + gr[0].d[kb][0][3]));
             Op gd[K];
 #pragma unroll
             for (int n = 0; n < K; ++n) gd[n] = F::split(gr[n].d[0][0], gr[n].d[1][0]);
@@ -287,10 +313,10 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
                 }
 #pragma unroll
                 for (int rb = 0; rb < NRB; ++rb) {
-                    if (lb == RHB) {                               // stays in the sg-scaled space of the prologue
-                        if constexpr (F::SCALED) drh[rb] = z[rb] * ikc; else drh[rb] = z[rb];
-                    } else {                                       // the X plane's share: becomes the start of a gates tile (factor sg kg)
-                        if constexpr (F::SCALED) z[rb] *= ikc * kg;
+                    if (lb == RHB) {                               // out of the scaled space: the prologue works on plain values
+                        if constexpr (F::SCALED) drh[rb] = z[rb] * (ikc * inv_pow2(a_c)); else drh[rb] = z[rb];
+                    } else {                                       // the X plane's share: becomes the start of a gates tile (factor kg here, the gates' scale there)
+                        if constexpr (F::SCALED) z[rb] *= ikc * inv_pow2(a_c) * kg;
                         stash_x[rb * 64 + lane] = make_float4(z[rb][0], z[rb][1], z[rb][2], z[rb][3]);
                     }
                 }
@@ -311,7 +337,7 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
                     c1[t] = lb == RHB ? rh_d[1][t] : zg[0][lb][1][t];
                 }
                 Op za;
-                if constexpr (F::SCALED) za = F::split(c0 * sz[0][lb], c1 * sz[0][lb]); else za = F::split(c0, c1);
+                if constexpr (F::SCALED) za = F::split(c0 * (sz[0][lb] * sh_c), c1 * (sz[0][lb] * sh_c)); else za = F::split(c0, c1);
 #pragma unroll
                 for (int n = 0; n < K; ++n)
 #pragma unroll
@@ -321,6 +347,7 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
 
         // =========================================================== gate + blend backward (prologue of the gates convolution)
         DyFrag<NRB, 2> gr;
+        float a_g = 1.f, sh_g = 1.f;                               // FmtH2: this node's gradient scale in the gates phase, and a / a_n
         {
             f32x4 v0[NRB], v1[NRB], d0[NRB], d1[NRB];
 #pragma unroll
@@ -332,9 +359,17 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
                     v0[kb][i] = gv[kb][i] * (cv[kb][i] - h) * u * (1.f - u);
                     v1[kb][i] = d * h * r * (1.f - r);
                     own[i] = d * r + gv[kb][i] * (1.f - u);        // what H is owed directly: reset-gate path + its share of the blend
-                    if constexpr (F::SCALED) own[i] *= kg;          // the H plane's gates tile starts from it
+                    if constexpr (F::SCALED) own[i] *= kg;          // the H plane's gates tile starts from it (times the gates' scale, below)
                 }
                 stash_h[kb * 64 + lane] = make_float4(own[0], own[1], own[2], own[3]);
+            }
+            if constexpr (F::SCALED) {                             // the gates' dY into the node's own scale
+                float m = 0.f;
+#pragma unroll
+                for (int kb = 0; kb < NRB; ++kb) m = __builtin_fmaxf(m, __builtin_fmaxf(absmax4(v0[kb]), absmax4(v1[kb])));
+                a_g = rg.node(wave_max_bits(m), sh_g);
+#pragma unroll
+                for (int kb = 0; kb < NRB; ++kb) { v0[kb] *= a_g; v1[kb] *= a_g; }
             }
             to_acc(3, v0, d0);
             to_acc(4, v1, d1);
@@ -351,7 +386,7 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
         for (int kb = 0; kb < NRB; ++kb)
 #pragma unroll
             for (int hb = 0; hb < 2; ++hb)
-                dbg[hb] += (gr.d[kb][hb][0] + gr.d[kb][hb][1]) + (gr.d[kb][hb][2] + gr.d[kb][hb][3]);
+                dbg[hb] += sh_g * ((gr.d[kb][hb][0] + gr.d[kb][hb][1]) + (gr.d[kb][hb][2] + gr.d[kb][hb][3]));
         Op gd[2];
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) gd[hb] = F::split(gr.d[0][hb], gr.d[1][hb]);
@@ -380,9 +415,11 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
                     if (n == 0 && lb == RHB) {                     // the H plane's tile starts from the prologue's share
                         const float4 sh = stash_h[rb * 64 + lane];
                         z[rb] = f32x4{sh.x, sh.y, sh.z, sh.w};
+                        if constexpr (F::SCALED) z[rb] *= a_g;      // (parked with the factor kg only)
                     } else if (n == 0) {                           // the X plane's tile from the candidate's share (PL = 1)
                         const float4 sh = stash_x[rb * 64 + lane];
                         z[rb] = f32x4{sh.x, sh.y, sh.z, sh.w};
+                        if constexpr (F::SCALED) z[rb] *= a_g;
                     } else {
                         z[rb] = kZero4;
                     }
@@ -401,8 +438,9 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
 #pragma unroll
                 for (int rb = 0; rb < NRB; ++rb) {
                     if constexpr (F::SCALED) {                     // out of the scaled space (+ the other consumer's gradients of the same plane)
-                        if (ACC[lb]) z[rb] = z[rb] * ikg_sg + old[n][lb][rb];
-                        else z[rb] *= ikg_sg;
+                        const float ikg_n = ikg * inv_pow2(a_g);
+                        if (ACC[lb]) z[rb] = z[rb] * ikg_n + old[n][lb][rb];
+                        else z[rb] *= ikg_n;
                     }
                     stc_st_once(reinterpret_cast<f32x4*>(dP[n][lb] + (r0 + 16 * rb + x) * HID + 4 * g), z[rb]);
                 }
@@ -425,7 +463,7 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
             for (int lb = 0; lb < LB; ++lb) {
                 const float (&zc)[NRB][4] = zg[n][lb];
                 Op za;
-                if constexpr (F::SCALED) za = F::split(f32x4{zc[0][0], zc[0][1], zc[0][2], zc[0][3]} * sz[n][lb], f32x4{zc[1][0], zc[1][1], zc[1][2], zc[1][3]} * sz[n][lb]);
+                if constexpr (F::SCALED) za = F::split(f32x4{zc[0][0], zc[0][1], zc[0][2], zc[0][3]} * (sz[n][lb] * sh_g), f32x4{zc[1][0], zc[1][1], zc[1][2], zc[1][3]} * (sz[n][lb] * sh_g));
                 else za = F::split(f32x4{zc[0][0], zc[0][1], zc[0][2], zc[0][3]}, f32x4{zc[1][0], zc[1][1], zc[1][2], zc[1][3]});
 #pragma unroll
                 for (int c = 0; c < K; ++c)
@@ -437,15 +475,15 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
         node = next_node;
     }
 
-    // dW tiles of block c carry sg (c = 0) or sg sT (c = 1: Q_1 = T_1 dY); db carries sg
-    const float isg = 1.f / sg, isgt = isg / sT;
+    // dW tiles of block c carry the wave's final gradient scale (c = 0) or that times sT (c = 1: Q_1 = T_1 dY); db carries the scale
+    const float isg_g = exp2i(-rg.k), isg_c = exp2i(-rc.k);
     PlaneUnscale<K, LB> pug, puc;
 #pragma unroll
     for (int n = 0; n < K; ++n)
 #pragma unroll
         for (int lb = 0; lb < LB; ++lb) { pug.v[n][lb] = inv_pow2(sz[n][lb]); puc.v[n][lb] = inv_pow2(sz[0][lb]); }      // the candidate's input is slab 0, [X | R*H], for both weight sets
-    combine_dw<K, LB, 2, CB_WAVES>(reinterpret_cast<float*>(smem_raw), dWg, dbg, a.partial_g, a.Lw, a.want_dbg, PL == 2 ? cin : -1, isg, isgt, isg, pug);
-    combine_dw<K, LB, 1, CB_WAVES>(reinterpret_cast<float*>(smem_raw), dWc, dbc, a.partial_c, a.Lw, a.want_dbc, PL == 2 ? cin : -1, isg, isgt, isg, puc);
+    combine_dw<K, LB, 2, CB_WAVES>(reinterpret_cast<float*>(smem_raw), dWg, dbg, a.partial_g, a.Lw, a.want_dbg, PL == 2 ? cin : -1, isg_g, isg_g / sT, isg_g, pug);
+    combine_dw<K, LB, 1, CB_WAVES>(reinterpret_cast<float*>(smem_raw), dWc, dbc, a.partial_c, a.Lw, a.want_dbc, PL == 2 ? cin : -1, isg_c, isg_c / sT, isg_c, puc);
 }
 
 template <class F, int L, int PL, int ACCX = 0, int ACCH = 0>

@@ -577,7 +577,7 @@ struct BwdSched { static constexpr int waves = (NB2 == 1 && K <= 2) ? 2 : 1; };
 // candidate's) and this kernel ADDS its own: the tile's accumulators start from the stored values -- the source then gets one plane per
 // Chebyshev order from the cell instead of two.
 // F = FmtH2 (two fp16 pieces, three products; see cell_bwd_x3_kernel): the gradient fragments are taken into a space scaled by sg = 2^k
-// (from pro.gmax, the launch's gradient maximum) right after they are loaded / formed, W's blocks of c = 0 carry sW sT, those of c >= 1
+// (per node, from the node's own maximum: stc_x3_frag.h, RunScale) right after they are loaded / formed, W's blocks of c = 0 carry sW sT, those of c >= 1
 // carry sW and the T_c tables sT, so every (c, o) block of a dZ contraction arrives with the factor sg sT sW, taken out at the store.
 template <int NB2, int HB, int K, int L, int PRO, int PL = 0, int FOLD = 0, int ACC = 0, class F = FmtB3>      // FOLD: see load_gates_grad (planar gates backward only)
 __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bwd_x3_kernel(
@@ -601,7 +601,7 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
     float* dy_tile = reinterpret_cast<float*>(reinterpret_cast<float4*>(WA + nWA * NP * 64) + (FOLD ? MF_WAVES * NRB * 64 : 0))
                      + (tid >> 6) * (HB * NRB * 16 * TRS);                                    // PFG: [wave][HB][NRB][16 rows][TRS]
 
-    float sT = 1.f, sW = 1.f, sg = 1.f;                  // FmtH2: table scales from the tables' own maxima, gradient scale from pro.gmax
+    float sT = 1.f, sW = 1.f;                            // FmtH2: table scales from the tables' own maxima
     if constexpr (F::SCALED) {
         float* scratch = reinterpret_cast<float*>(smem_raw);
         if (K > 1) {
@@ -609,8 +609,8 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
             sT = fminf(fmaxf(sT, 0.0625f), 4096.f);
         }
         sW = pow2_scale(block_absmax(W, K * K * Lw * Ho, scratch, MF_THREADS), 0);
-        sg = pow2_scale(slots_max(pro.gmax, pro.n_gmax), 4);
     }
+    RunScale rs;                                         // FmtH2: gradient scales (stc_x3_frag.h: per node + the wave's reference for the sums over nodes)
     // activation operands of the dW products: one scale per plane and launch, from the slots the forward launch filled (block lb of slab n =
     // row lb K + n; see cell_bwd_x3_kernel)
     float sz[K][LB];
@@ -643,7 +643,7 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nw = gridDim.x * MF_WAVES;
-    const float kz = sT * sW, ikz_sg = 1.f / (kz * sg);       // (1 for FmtB3)
+    const float kz = sT * sW, ikz = 1.f / kz;                 // (1 for FmtB3)
 
     f32x4 dWt[K][LB][K][HB];          // dW tiles: rows l = 16lb + 4g + r, columns o = 16hb + x
     float dbp[HB];
@@ -667,6 +667,20 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
     if (PFG && node < nodes) { rows_cur.template load<PRO == PRO_GATES_CAND>(pro, node, x, g); in.load_z(Z, node, x, g, Lw - 16); }
     if (PF || PFG) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) before the loop: see node_fwd_x3_kernel
     while (node < nodes) {
+      if constexpr (F::SCALED) {                               // (re-)entry of the node loop: the accumulators to the wave's current reference scale
+        const float pr = rs.pending();
+#pragma unroll
+        for (int n = 0; n < K; ++n)
+#pragma unroll
+            for (int lb = 0; lb < LB; ++lb)
+#pragma unroll
+                for (int c = 0; c < K; ++c)
+#pragma unroll
+                    for (int hb = 0; hb < HB; ++hb) dWt[n][lb][c][hb] *= pr;
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb) dbp[hb] *= pr;
+      }
+      do {
         const int next_node = node + nw;
         const size_t r0 = (size_t)node * C;
         f32x4 old[K][NRB];                                     // ACC: what the X-side planes already hold, requested BEFORE the prefetch (vmcnt counts in order)
@@ -691,19 +705,27 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
         if (PF && next_node < nodes) { nx.g.load(dY, next_node, x, g); nx.load_z(Z, next_node, x, g, Lw - 16); }
         if (PF) __builtin_amdgcn_sched_barrier(0);
         const int lo = opaque(lane);
-        if constexpr (F::SCALED) {                             // into the scaled space: everything below is linear in the gradient
+        float sg = 1.f, sh = 1.f;                              // FmtH2: this node's gradient scale a_n, and a / a_n for the sums over nodes
+        if constexpr (F::SCALED) {                             // into the node's own scale: everything below is linear in the gradient
+            float m = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < NRB; ++kb)
+#pragma unroll
+                for (int hb = 0; hb < HB; ++hb) m = __builtin_fmaxf(m, absmax4(in.g.v[kb][hb]));
+            sg = rs.node(wave_max_bits(m), sh);
 #pragma unroll
             for (int kb = 0; kb < NRB; ++kb)
 #pragma unroll
                 for (int hb = 0; hb < HB; ++hb) { in.g.d[kb][hb] *= sg; in.g.v[kb][hb] *= sg; }
         }
+        const float ikz_sg = ikz * inv_pow2(sg);
         const DyFrag<NRB, HB>& gr = in.g;
 
 #pragma unroll
         for (int kb = 0; kb < NRB; ++kb)
 #pragma unroll
             for (int hb = 0; hb < HB; ++hb)
-                dbp[hb] += (gr.d[kb][hb][0] + gr.d[kb][hb][1]) + (gr.d[kb][hb][2] + gr.d[kb][hb][3]);
+                dbp[hb] += sh * ((gr.d[kb][hb][0] + gr.d[kb][hb][1]) + (gr.d[kb][hb][2] + gr.d[kb][hb][3]));
 
         // dY in accumulator layout as an operand: slots = rows d of the tile pair p
         Op gd[HB][NB2];
@@ -823,8 +845,8 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
                 for (int p = 0; p < NB2; ++p) {
                     const float (&zc)[NRB][4] = in.za[n][lb];
                     Op a;
-                    if constexpr (F::SCALED) a = F::split(f32x4{zc[2 * p][0], zc[2 * p][1], zc[2 * p][2], zc[2 * p][3]} * sz[n][lb],
-                                                          f32x4{zc[2 * p + 1][0], zc[2 * p + 1][1], zc[2 * p + 1][2], zc[2 * p + 1][3]} * sz[n][lb]);
+                    if constexpr (F::SCALED) a = F::split(f32x4{zc[2 * p][0], zc[2 * p][1], zc[2 * p][2], zc[2 * p][3]} * (sz[n][lb] * sh),
+                                                          f32x4{zc[2 * p + 1][0], zc[2 * p + 1][1], zc[2 * p + 1][2], zc[2 * p + 1][3]} * (sz[n][lb] * sh));
                     else a = F::split(f32x4{zc[2 * p][0], zc[2 * p][1], zc[2 * p][2], zc[2 * p][3]},
                                       f32x4{zc[2 * p + 1][0], zc[2 * p + 1][1], zc[2 * p + 1][2], zc[2 * p + 1][3]});
 #pragma unroll
@@ -846,8 +868,9 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
                         for (int t = 0; t < 4; ++t) in.za[n][lb][kb][t] = nx.za[n][lb][kb][t];
         }
         node = next_node;
+      } while (node < nodes && !(F::SCALED && rs.changed()));
     }
-    const float isg = 1.f / sg;                                // dW tiles of block c carry sg (c = 0) or sg sT (c >= 1); db carries sg
+    const float isg = exp2i(-rs.k);                            // dW tiles of block c carry the wave's final gradient scale (c = 0) or that times sT (c >= 1); db the scale
     PlaneUnscale<K, LB> pu;
 #pragma unroll
     for (int n = 0; n < K; ++n)
@@ -991,13 +1014,13 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
     u32x4* WA = TB + nTB * NP * 64;                      // [K n][LB][S]           W[(n, c, 16lb + x)][16hb + 4g + (e&3)], block 2s + (e>>2)
     const int tid = threadIdx.x, lane = tid & 63, x = lane & 15, g = lane >> 4;
 
-    float sT = 1.f, sW = 1.f, sg = 1.f;
+    float sT = 1.f, sW = 1.f;
     if constexpr (F::SCALED) {
         float* scratch = reinterpret_cast<float*>(smem_raw);
         sT = fminf(fmaxf(pow2_scale(block_absmax(Tc + (size_t)C * C, C * C, scratch, MF_THREADS), 0), 0.0625f), 4096.f);
         sW = pow2_scale(block_absmax(W, K * K * Lw * Ho, scratch, MF_THREADS), 0);
-        sg = pow2_scale(slots_max(gmax, n_gmax), 4);
     }
+    RunScale rs;                                         // FmtH2: gradient scales (stc_x3_frag.h: per node + the wave's reference for the sums over nodes)
     float sz[LB];
 #pragma unroll
     for (int lb = 0; lb < LB; ++lb) sz[lb] = (F::SCALED && PL != 0) ? plane_scale(lb == 0 ? zmax_x : zmax_x2, 0) : 1.f;
@@ -1027,7 +1050,7 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nw = gridDim.x * MF_WAVES;
-    const float ikz_sg = 1.f / (sT * sW * sg);
+    const float ikz = 1.f / (sT * sW);
     f32x4 dWt[K][LB][K][HB];
     float dbp[HB];
 #pragma unroll
@@ -1043,10 +1066,37 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
 
     for (int node = blockIdx.x * MF_WAVES + wave; node < nodes; node += nw) {
         const size_t r0 = (size_t)node * C;
+        if constexpr (F::SCALED) {                             // the running maximum crossed a binade: bring the accumulators to the new reference scale
+            const float pr = rs.pending();
+            __builtin_amdgcn_sched_barrier(0);
+            if (pr != 1.f) {
+#pragma unroll
+                for (int n = 0; n < K; ++n)
+#pragma unroll
+                    for (int lb = 0; lb < LB; ++lb)
+#pragma unroll
+                        for (int c = 0; c < K; ++c)
+#pragma unroll
+                            for (int hb = 0; hb < HB; ++hb) dWt[n][lb][c][hb] *= pr;
+#pragma unroll
+                for (int hb = 0; hb < HB; ++hb) dbp[hb] *= pr;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         DyFrag<NRB, HB> gr[K];
         gr[0].load(dA, node, x, g);
         gr[1].load(dB, node, x, g);
+        float ikz_sg = ikz, sh = 1.f;
         if constexpr (F::SCALED) {
+            float m = 0.f;
+#pragma unroll
+            for (int n = 0; n < K; ++n)
+#pragma unroll
+                for (int kb = 0; kb < NRB; ++kb)
+#pragma unroll
+                    for (int hb = 0; hb < HB; ++hb) m = __builtin_fmaxf(m, absmax4(gr[n].v[kb][hb]));
+            const float sg = rs.node(wave_max_bits(m), sh);
+            ikz_sg = ikz * inv_pow2(sg);
 #pragma unroll
             for (int n = 0; n < K; ++n)
 #pragma unroll
@@ -1080,7 +1130,7 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
         for (int kb = 0; kb < NRB; ++kb)
 #pragma unroll
             for (int hb = 0; hb < HB; ++hb)                       // the bias sits on A only
-                dbp[hb] += (gr[0].d[kb][hb][0] + gr[0].d[kb][hb][1]) + (gr[0].d[kb][hb][2] + gr[0].d[kb][hb][3]);
+                dbp[hb] += sh * ((gr[0].d[kb][hb][0] + gr[0].d[kb][hb][1]) + (gr[0].d[kb][hb][2] + gr[0].d[kb][hb][3]));
 
         Op gd[K][HB][NB2];
 #pragma unroll
@@ -1182,8 +1232,8 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
             for (int p = 0; p < NB2; ++p) {
                 const float (&zc)[NRB][4] = za[lb];
                 Op a;
-                if constexpr (F::SCALED) a = F::split(f32x4{zc[2 * p][0], zc[2 * p][1], zc[2 * p][2], zc[2 * p][3]} * sz[lb],
-                                                      f32x4{zc[2 * p + 1][0], zc[2 * p + 1][1], zc[2 * p + 1][2], zc[2 * p + 1][3]} * sz[lb]);
+                if constexpr (F::SCALED) a = F::split(f32x4{zc[2 * p][0], zc[2 * p][1], zc[2 * p][2], zc[2 * p][3]} * (sz[lb] * sh),
+                                                      f32x4{zc[2 * p + 1][0], zc[2 * p + 1][1], zc[2 * p + 1][2], zc[2 * p + 1][3]} * (sz[lb] * sh));
                 else a = F::split(f32x4{zc[2 * p][0], zc[2 * p][1], zc[2 * p][2], zc[2 * p][3]},
                                   f32x4{zc[2 * p + 1][0], zc[2 * p + 1][1], zc[2 * p + 1][2], zc[2 * p + 1][3]});
 #pragma unroll
@@ -1195,7 +1245,7 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
                             dWt[n][lb][c][hb] = F::mm(a, c == 0 ? gd[n][hb][p] : qd[n][hb][p], dWt[n][lb][c][hb]);
             }
     }
-    const float isg = 1.f / sg;
+    const float isg = exp2i(-rs.k);
     if constexpr (F::SCALED) {
         if (out_amax) {
             const int slot = blockIdx.x * MF_WAVES + wave;

