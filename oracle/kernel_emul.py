@@ -124,7 +124,7 @@ class EmulatedKernels:
         if not self.act_scales:
             return [_q2(p, 1.0) for p in planes]
         m = torch.stack([p.abs().amax(dim=(1, 2)) for p in planes]).amax(0)
-        s = _pow2_scale(m, 4).view(-1, 1, 1)
+        s = _pow2_scale(m, 8).view(-1, 1, 1)                          # STC_ACT_TARGET_FWD
         return [_q2(p, s) for p in planes]
 
     def _plane_scaled(self, planes, act_amax, rows):
@@ -133,7 +133,7 @@ class EmulatedKernels:
             return list(planes)
         if not self.act_scales or act_amax is None:
             return [_q2(p, 1.0) for p in planes]
-        return [_q2(p, _pow2_scale(act_amax[r].max(), 4)) for p, r in zip(planes, rows)]
+        return [_q2(p, _pow2_scale(act_amax[r].max(), 6)) for p, r in zip(planes, rows)]
 
     def _grad_scaled(self, grads, planes=(), plane_scales=()):
         """Backward: the gradient fragments of a launch take one scale per NODE (row of the (R, C, w) planes), from the node's own maximum over
@@ -150,7 +150,7 @@ class EmulatedKernels:
     def _plane_scales(self, act_amax, rows):
         if not self.act_scales or act_amax is None:
             return [1.0 for _ in rows]
-        return [_pow2_scale(act_amax[r].max(), 4) for r in rows]
+        return [_pow2_scale(act_amax[r].max(), 6) for r in rows]                  # STC_ACT_TARGET_BWD
 
     @staticmethod
     def _leave_maxima(act_amax, planes):

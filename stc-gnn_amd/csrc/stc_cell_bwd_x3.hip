@@ -270,7 +270,17 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
                     float m = 0.f;
 #pragma unroll
                     for (int kb = 0; kb < NRB; ++kb) m = __builtin_fmaxf(m, __builtin_fmaxf(absmax4(v0[kb]), absmax4(v1[kb])));
-                    a_c = rc.node(wave_max_bits(m), sh_c);
+                    bool restart;
+                    a_c = rc.node(wave_max_bits(m), sh_c, restart);
+                    if (restart) {
+#pragma unroll
+                        for (int n = 0; n < K; ++n)
+#pragma unroll
+                            for (int lb = 0; lb < LB; ++lb)
+#pragma unroll
+                                for (int c = 0; c < K; ++c) dWc[n][lb][c][0] = kZero4;
+                        dbc[0] = 0.f;
+                    }
 #pragma unroll
                     for (int kb = 0; kb < NRB; ++kb) { v0[kb] *= a_c; v1[kb] *= a_c; }
                 }
@@ -367,7 +377,19 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
                 float m = 0.f;
 #pragma unroll
                 for (int kb = 0; kb < NRB; ++kb) m = __builtin_fmaxf(m, __builtin_fmaxf(absmax4(v0[kb]), absmax4(v1[kb])));
-                a_g = rg.node(wave_max_bits(m), sh_g);
+                bool restart;
+                a_g = rg.node(wave_max_bits(m), sh_g, restart);
+                if (restart) {
+#pragma unroll
+                    for (int n = 0; n < K; ++n)
+#pragma unroll
+                        for (int lb = 0; lb < LB; ++lb)
+#pragma unroll
+                            for (int c = 0; c < K; ++c)
+#pragma unroll
+                                for (int hb = 0; hb < 2; ++hb) dWg[n][lb][c][hb] = kZero4;
+                    dbg[0] = 0.f; dbg[1] = 0.f;
+                }
 #pragma unroll
                 for (int kb = 0; kb < NRB; ++kb) { v0[kb] *= a_g; v1[kb] *= a_g; }
             }

@@ -249,7 +249,7 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
                     else { pmax[n] = __builtin_fmaxf(pmax[n], g < 2 ? __builtin_fmaxf(ma, mb) : 0.f); qmax[n] = __builtin_fmaxf(qmax[n], g < 2 ? 0.f : ma); }
                     nm = __builtin_fmaxf(nm, __builtin_fmaxf(ma, mb));
                 }
-            sz = pow2_scale(wave_max_nonneg(nm), 4);
+            sz = pow2_scale(wave_max_nonneg(nm), STC_ACT_TARGET_FWD);
             const float isz = inv_pow2(sz);
             invn = inv * isz; invpn = invp * isz;
         }
@@ -712,7 +712,20 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
             for (int kb = 0; kb < NRB; ++kb)
 #pragma unroll
                 for (int hb = 0; hb < HB; ++hb) m = __builtin_fmaxf(m, absmax4(in.g.v[kb][hb]));
-            sg = rs.node(wave_max_bits(m), sh);
+            bool restart;
+            sg = rs.node(wave_max_bits(m), sh, restart);
+            if (restart) {
+#pragma unroll
+                for (int n = 0; n < K; ++n)
+#pragma unroll
+                    for (int lb = 0; lb < LB; ++lb)
+#pragma unroll
+                        for (int c = 0; c < K; ++c)
+#pragma unroll
+                            for (int hb = 0; hb < HB; ++hb) dWt[n][lb][c][hb] = kZero4;
+#pragma unroll
+                for (int hb = 0; hb < HB; ++hb) dbp[hb] = 0.f;
+            }
 #pragma unroll
             for (int kb = 0; kb < NRB; ++kb)
 #pragma unroll
@@ -1095,7 +1108,20 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
                 for (int kb = 0; kb < NRB; ++kb)
 #pragma unroll
                     for (int hb = 0; hb < HB; ++hb) m = __builtin_fmaxf(m, absmax4(gr[n].v[kb][hb]));
-            const float sg = rs.node(wave_max_bits(m), sh);
+            bool restart;
+            const float sg = rs.node(wave_max_bits(m), sh, restart);
+            if (restart) {
+#pragma unroll
+                for (int n = 0; n < K; ++n)
+#pragma unroll
+                    for (int lb = 0; lb < LB; ++lb)
+#pragma unroll
+                        for (int c = 0; c < K; ++c)
+#pragma unroll
+                            for (int hb = 0; hb < HB; ++hb) dWt[n][lb][c][hb] = kZero4;
+#pragma unroll
+                for (int hb = 0; hb < HB; ++hb) dbp[hb] = 0.f;
+            }
             ikz_sg = ikz * inv_pow2(sg);
 #pragma unroll
             for (int n = 0; n < K; ++n)

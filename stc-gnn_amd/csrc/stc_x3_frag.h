@@ -239,6 +239,11 @@ __device__ __forceinline__ float slots_max(const float* __restrict__ slots, int 
 //             (the dW tiles of a plane are their own accumulators: the combine takes each plane's scale out).
 // Non-negative floats order as their bit patterns: maxima are taken on the bits where that saves a conversion.
 constexpr int STC_ACT_SLOTS = 256;          // slots per plane row of an activation-maximum buffer
+// Where the maxima go.  Two fp16 pieces carry 22 bits for values of at least 2^-3, so a maximum in [2^(t-1), 2^t) leaves t + 2 binades below it at
+// full precision -- what the planes of one node may differ by (S.X against X with graph row sums of 50: 5.6 binades).  The ceiling is set by the
+// second-stage operands: a projected value is a sum of K x 32 products with a table normalised below 1, at most 96 x 2^8 < 65504 in the forward.
+constexpr int STC_ACT_TARGET_FWD = 8;       // forward: the node's maximum over its rows into [2^7, 2^8)
+constexpr int STC_ACT_TARGET_BWD = 6;       // backward: a plane's maximum into [2^5, 2^6); times at most 2^8 (RunScale) stays below 2^14
 
 __device__ __forceinline__ float absmax4(const f32x4 v) {
     return __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])), __builtin_fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3])));
@@ -275,7 +280,7 @@ __device__ __forceinline__ void leave_max(float* __restrict__ row, int slot, flo
 // accumulators sum over the wave's nodes and carry the wave's REFERENCE scale a = 2^k (from the running maximum of the nodes before): a node
 // joins them with its activation operand multiplied by a / a_n -- the product of the two operands then has the accumulators' scale.
 //   a / a_n > 1   the node's gradients exceed everything before: the excess goes to the activation operand (<= 2^8) and, beyond that, into a_n
-//                 itself (fp16 holds 2^11 above the target): 2^19 of headroom per node before anything overflows (to infinity, never silently);
+//                 itself (<= 2^6: its second-stage operands must fit too): 2^14 of headroom per node; beyond it the node replaces the sums (`restart`);
 //   a / a_n < 1   the node's gradients are small against the wave's: its activation operand shrinks and loses low bits exactly in proportion
 //                 to how little the node adds to the sum.
 // After the node the running maximum is updated; when it has crossed a binade the node loop is LEFT, the accumulators are multiplied by
@@ -284,6 +289,9 @@ __device__ __forceinline__ void leave_max(float* __restrict__ row, int slot, flo
 // wave's final 1 / a goes into the combine.  All bookkeeping is integer arithmetic on exponents (scalar unit).
 __device__ __forceinline__ float exp2i(int k) { return __uint_as_float((unsigned)(k + 127) << 23); }
 struct RunScale {
+    // Room above the targets: the activation operand of a dW product (plane maximum in [2^5, 2^6)) takes 2^8 more, a gradient fragment (node
+    // maximum in [2^3, 2^4)) 2^6 more -- its second-stage operands (T_c dY: sums of 32 products with a normalised table) must fit fp16 too.
+    static constexpr int ROOM_ACT = 8, ROOM_GRAD = 6;
     int amax_bits = 0;                  // running maximum over the wave's nodes so far (bits of a non-negative float)
     int k = 0;                          // accumulators carry 2^k
     static __device__ __forceinline__ bool usable(int bits) { const int e = (bits >> 23) & 255; return e != 0 && e != 255; }
@@ -291,12 +299,18 @@ struct RunScale {
         int kk = 4 - (((bits >> 23) & 255) - 126);
         return kk < -100 ? -100 : (kk > 100 ? 100 : kk);
     }
-    // the node's maximum (bits, wave-uniform) -> a_n; shift = (a / a_n) for the activation side and the db sums
-    __device__ __forceinline__ float node(int mbits, float& shift) {
+    // the node's maximum (bits, wave-uniform) -> a_n; shift = (a / a_n) for the activation side and the db sums; restart: the node's
+    // gradients exceed everything the wave has summed so far by more than 2^14 -- beyond what the two fp16 operands can take up -- so the
+    // caller ZEROES its accumulators (constants into registers: unlike a multiplication this costs the node loop no scratch) and the node
+    // becomes the reference.  What is dropped is below (nodes so far) x 2^-14 of what this node adds, in practice many orders less: such
+    // jumps occur where gates saturate (factors e^-x).
+    __device__ __forceinline__ float node(int mbits, float& shift, bool& restart) {
         int kn = usable(mbits) ? exponent_for(mbits) : k;
         if (amax_bits == 0 && usable(mbits)) k = kn;                      // the first gradient the wave meets: its accumulators are still zero
         int j = k - kn;
-        if (j > 8) { kn += j - 8; j = 8; }
+        restart = j > ROOM_ACT + ROOM_GRAD;
+        if (restart) { k = kn; j = 0; amax_bits = mbits; }
+        if (j > ROOM_ACT) { kn += j - ROOM_ACT; j = ROOM_ACT; }
         if (j < -100) j = -100;
         if (usable(mbits) && mbits > amax_bits) amax_bits = mbits;
         shift = exp2i(j);
@@ -319,7 +333,7 @@ __device__ __forceinline__ float plane_scale(const float* __restrict__ zmax, int
     if (!zmax) return 1.f;
     float m = 0.f;
     for (int i = threadIdx.x & 63; i < STC_ACT_SLOTS; i += 64) m = fmaxf(m, zmax[row * STC_ACT_SLOTS + i]);
-    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pow2_scale(wave_max_nonneg(m), 4))));      // (a scalar register)
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pow2_scale(wave_max_nonneg(m), STC_ACT_TARGET_BWD))));      // (a scalar register)
 }
 
 // row of a pair of 16-row tiles that slot (g, e) of an accumulator-fed operand stands for
