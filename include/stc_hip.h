@@ -41,8 +41,9 @@ extern "C" {
  * fp16 has a 5-bit exponent, so F16X2 kernels normalise EVERY operand class by powers of two (exact) -- the reference's einsum is
  * scale-free (STC_GNN.py:37-42) and so are they, for magnitudes 2^-100 .. 2^100:
  *   tables      weight and category-graph tables from their own maxima, inside the kernel;
- *   gradients   from the launch's gradient maximum, which the caller hands over in device memory (grad_amax arguments; stc_spmm_sum_f32 and
- *               stc_bdg_node_post_bwd_f32 produce it on the way);
+ *   gradients   one scale per NODE, from the maximum over the node's gradient fragments, found by the wave that owns the node (what the gate
+ *               prologues form can sit tens of binades below the state gradient); the dW / db sums over nodes run at a per-wave reference
+ *               scale that follows the running maximum (no argument: nothing about the gradient's magnitude has to be known);
  *   activations forward: one scale per NODE, from the maximum over the node's rows of all input planes, found by the wave that owns the
  *               node (no argument); backward: the dW products sum over nodes, so they take one scale per input PLANE and launch, from
  *               the maxima the forward launch left in device memory (act_amax arguments: STC_ACT_AMAX_SLOTS floats per plane, ZERO before
@@ -263,11 +264,9 @@ int stc_spmm_blend_fwd_f32(const int32_t* rowptr, const int32_t* colidx, const f
                            int32_t batch, int32_t C, int32_t h, void* stream);
 int stc_bdg_node_post_bwd_f32(const float* X, const float* X2, const float* Tc, const float* W, const float* dA, const float* dB,
                               float* dX, float* dX2, float* dW, float* db,
-                              const float* grad_amax, int32_t n_amax,      /* fp16 x 2 format (planar forms, C = 64): max over the slots bounds |dA|, |dB| */
+                              int32_t operand_format,                      /* STC_FMT_*: the planar forms at C = 64 take STC_FMT_F16X2, everything else runs bf16 x 3 */
                               const float* act_amax_x, const float* act_amax_x2,      /* fp16 x 2, optional: STC_ACT_AMAX_SLOTS floats each whose maximum is
                                                                                          max |X| / max |X2| (a row of a forward launch's act_amax; R*H takes H's) */
-                              float* out_amax,                             /* fp16 x 2, optional: (2, STC_ACT_AMAX_SLOTS) floats, ZERO before the launch, that
-                                                                              receive max |dX| and max |dX2| (grad_amax of the gates backward that follows) */
                               void* workspace, size_t workspace_bytes,
                               int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t Ho, void* stream);
 
@@ -350,7 +349,7 @@ int stc_cell_gates_bwd_planar_f32(const float* X, const float* H, const float* S
                                   const float* Tc, const float* W,
                                   const float* dCandIn, const float* Cand, const float* U, const float* Rg, const float* dHnew,
                                   float* const* dZ, float* dW, float* db, float* dH,
-                                  const float* grad_amax, int32_t n_amax,      /* fp16 x 2 format: max over the slots bounds |dHnew| and |dCandIn| */
+                                  int32_t operand_format,                      /* STC_FMT_* */
                                   const float* act_amax,                       /* fp16 x 2, optional: what stc_cell_gates_fwd_planar_f32 left for these planes */
                                   void* workspace, size_t workspace_bytes,
                                   int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream);
@@ -369,10 +368,9 @@ int stc_cell_gates_bwd_planar_f32(const float* X, const float* H, const float* S
  * operand for it instead of two.
  * Narrow input (Lw - h in 1..4): dX, dSX are not produced (may be NULL).  stc_cell_bwd_planar_supported() tells whether (C, h)
  * is built (C = 32, h = 16); workspace >= stc_cell_bwd_planar_workspace_bytes(C, Lw, h) bytes, 16-byte aligned.
- * grad_amax != NULL selects the fp16 x 2 operand format (see "operand formats" above): n_amax device floats whose maximum is
- * max |dHnew| over the launch's rows (stc_spmm_sum_f32 leaves them; any bound within 2^8 above the true maximum serves).  NULL keeps
- * the bf16 x 3 format, which needs no range information.  act_amax (fp16 x 2, optional): the (4, STC_ACT_AMAX_SLOTS) plane maxima the
- * forward launch (stc_cell_gates_fwd_planar_f32) left for the same X, H, SX, SH: the scales of the dW products' activation operands. */
+ * operand_format: STC_FMT_F16X2 or STC_FMT_BF16X3 (see "operand formats" above).  act_amax (fp16 x 2, optional): the
+ * (4, STC_ACT_AMAX_SLOTS) plane maxima the forward launch (stc_cell_gates_fwd_planar_f32) left for the same X, H, SX, SH: the scales of
+ * the dW products' activation operands. */
 int stc_cell_bwd_planar_supported(int32_t C, int32_t h);
 size_t stc_cell_bwd_planar_workspace_bytes(int32_t C, int32_t Lw, int32_t h);
 int stc_cell_bwd_planar_f32(const float* X, const float* H, const float* SX, const float* SH,
@@ -381,7 +379,7 @@ int stc_cell_bwd_planar_f32(const float* X, const float* H, const float* SX, con
                             float* dX, float* dSX, float* dH, float* dSH,
                             float* dWg, float* dbg, float* dWc, float* dbc,
                             int32_t accumulate_x, int32_t accumulate_h,
-                            const float* grad_amax, int32_t n_amax, const float* act_amax,
+                            int32_t operand_format, const float* act_amax,
                             void* workspace, size_t workspace_bytes,
                             int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream);
 
@@ -411,13 +409,13 @@ int stc_cell_cand_fwd_planar_k_f32(const float* const* Zx, const float* const* Z
 int stc_cell_gates_bwd_planar_k_f32(const float* const* Zx, const float* const* Zh, int32_t K, const float* Tc, const float* W,
                                     const float* dRH, const float* Cand, const float* U, const float* Rg, const float* dHnew,
                                     float* const* dZx, float* const* dZh, float* dW, float* db, float* dH, int32_t accumulate_x,
-                                    const float* grad_amax, int32_t n_amax,     /* fp16 x 2 format: max over the slots bounds |dHnew| and |dRH| */
+                                    int32_t operand_format,                     /* STC_FMT_* */
                                     const float* act_amax,                      /* fp16 x 2, optional: as left by stc_cell_gates_fwd_planar_k_f32 */
                                     void* workspace, size_t workspace_bytes, int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream);
 int stc_cell_cand_bwd_planar_k_f32(const float* const* Zx, const float* const* Zh, int32_t K, const float* Tc, const float* W,
                                    const float* dHnew, const float* U, const float* Cand,
                                    float* const* dZx, float* const* dZh, float* dW, float* db,
-                                   const float* grad_amax, int32_t n_amax,      /* fp16 x 2 format: max over the slots bounds |dHnew| */
+                                   int32_t operand_format,                      /* STC_FMT_* */
                                    const float* act_amax,                       /* fp16 x 2, optional: as left by stc_cell_cand_fwd_planar_k_f32 */
                                    void* workspace, size_t workspace_bytes, int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream);
 
@@ -429,7 +427,8 @@ int stc_cell_cand_bwd_planar_k_f32(const float* const* Zx, const float* const* Z
  * dY != NULL: the epilogue also writes dY = Y*U*(1-Cand^2), the blend backward (STC_GNN.py:76-78) of the cell that owns the
  * state, from that cell's saved U and Cand -- the gradient is then not read again just to form it.
  * amax != NULL: n_amax floats, ZERO before the launch; afterwards their maximum is max |Y| over the launch (each wave leaves its own
- * maximum in one slot by an atomic max) -- the grad_amax operand of stc_cell_bwd_planar_f32, at no extra pass over Y. */
+ * maximum in one slot by an atomic max), at no extra pass over Y.  (Until ABI v21 the cell backward kernels took it as their gradient
+ * scale; since v22 they find their gradient maxima themselves, per node.) */
 #define STC_SPMM_SUM_MAX_ADD 8
 int stc_spmm_sum_f32(const int32_t* rowptr, const int32_t* colidx, const float* val,
                      const int32_t* blk_ptr, const int32_t* blk_cols, const float* blk_vals,

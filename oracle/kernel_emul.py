@@ -104,17 +104,18 @@ class EmulatedKernels:
 
     # ---- fp16 x 2 format emulation helpers (planar entry points only: the kernels that run the format)
     def _tables(self, *ts):
-        """Weight / category tables as the kernels hold them: normalised by their own maximum."""
+        """Weight tables as the kernels hold them: normalised by their own maximum into [2^3, 2^4) (STC_W_TARGET)."""
         if self.fmt != 'f16x2':
             return ts
-        return tuple(None if t is None else _q2(t, _pow2_scale(t.abs().max(), 0)) for t in ts)
+        return tuple(None if t is None else _q2(t, _pow2_scale(t.abs().max(), 4)) for t in ts)
 
-    def _mix_tables(self, Tc):
+    def _mix_tables(self, Tc, backward=False):
+        """Category-mix tables T_c, c >= 1: maximum into [2^3, 2^4) in the forward, [2^1, 2^2) in the backward (STC_T_TARGET_*)."""
         if self.fmt != 'f16x2':
             return Tc
         out = Tc.clone()
         if Tc.shape[0] > 1:
-            out[1:] = _q2(Tc[1:], _pow2_scale(Tc[1:].abs().max(), 0))
+            out[1:] = _q2(Tc[1:], _pow2_scale(Tc[1:].abs().max(), 2 if backward else 4))
         return out
 
     def _node_scaled(self, planes):
@@ -124,7 +125,7 @@ class EmulatedKernels:
         if not self.act_scales:
             return [_q2(p, 1.0) for p in planes]
         m = torch.stack([p.abs().amax(dim=(1, 2)) for p in planes]).amax(0)
-        s = _pow2_scale(m, 8).view(-1, 1, 1)                          # STC_ACT_TARGET_FWD
+        s = _pow2_scale(m, 5).view(-1, 1, 1)                          # STC_ACT_TARGET_FWD
         return [_q2(p, s) for p in planes]
 
     def _plane_scaled(self, planes, act_amax, rows):
@@ -463,13 +464,13 @@ class EmulatedKernels:
             else:
                 self.node_post_fwd(CandIn, Tc, Wc, bc, A, Bm)
 
-    def cell_gates_bwd_planar(self, X, H, SX, SH, Tc, W, dRH, Cand, U, Rg, dHnew, dZs, dW, db, dH, grad_amax=None, act_amax=None):
+    def cell_gates_bwd_planar(self, X, H, SX, SH, Tc, W, dRH, Cand, U, Rg, dHnew, dZs, dW, db, dH, act_amax=None):
         cin, h = X.shape[-1], H.shape[-1]
         if self.fmt == 'f16x2':
             # As the kernel: the gate prologue runs in fp32 on the planes themselves (dG and the state's own share are exact); the matrix
             # products take dG, the tables and -- the dW products -- the planes, each as its format carries it.
             order = (0, 1, 2, 3) if cin == h else (2, 3, 0, 1)                # rows of the slots: wide {X, S.X, H, S.H}, narrow {H, S.H, x, S.x}
-            (Wq,), Tq = self._tables(W), self._mix_tables(Tc)
+            (Wq,), Tq = self._tables(W), self._mix_tables(Tc, backward=True)
             dG = torch.cat([dHnew * (Cand - H) * U * (1 - U), dRH * H * Rg * (1 - Rg)], -1)
             (dGq,), (Xq, SXq, Hq, SHq) = self._grad_scaled((dG,), (X, SX, H, SH), self._plane_scales(act_amax, order))
             own = dRH * Rg + dHnew * (1 - U)
@@ -500,7 +501,7 @@ class EmulatedKernels:
         return h == 16 and os.environ.get('STC_FUSE_CELL_BWD', '1') != '0'
 
     def cell_bwd_planar(self, X, H, SX, SH, Tc, Wg, Wc, U, Rg, Cand, dHnew, dBm, dZs, dWg, dbg, dWc, dbc, accumulate_x=False, accumulate_h=False,
-                        grad_amax=None, act_amax=None):
+                        act_amax=None):
         cin, h = X.shape[-1], H.shape[-1]
         old = [None if (z is None or not acc) else z.clone() for z, acc in zip(dZs, (accumulate_x, accumulate_x, accumulate_h, accumulate_h))]
         dY = dHnew * U * (1 - Cand * Cand)
@@ -509,10 +510,10 @@ class EmulatedKernels:
         post_amax = None if act_amax is None else ((act_amax[xr], act_amax[hr]) if cin == h else (act_amax[hr], act_amax[xr]))
         if cin == h:
             dXc = torch.empty_like(H)
-            self.node_post_bwd(X, Tc, Wc, dY, dBm, dXc, dWc, dbc, X2=RH, dX2=dRH, grad_amax=grad_amax, act_amax=post_amax)
+            self.node_post_bwd(X, Tc, Wc, dY, dBm, dXc, dWc, dbc, X2=RH, dX2=dRH, act_amax=post_amax)
         else:
-            self.node_post_bwd(RH, Tc, Wc, dY, dBm, dRH, dWc, dbc, X2=X, grad_amax=grad_amax, act_amax=post_amax)
-        self.cell_gates_bwd_planar(X, H, SX, SH, Tc, Wg, dRH, Cand, U, Rg, dHnew, dZs, dWg, dbg, None, grad_amax=None, act_amax=act_amax)
+            self.node_post_bwd(RH, Tc, Wc, dY, dBm, dRH, dWc, dbc, X2=X, act_amax=post_amax)
+        self.cell_gates_bwd_planar(X, H, SX, SH, Tc, Wg, dRH, Cand, U, Rg, dHnew, dZs, dWg, dbg, None, act_amax=act_amax)
         if cin == h:
             dZs[0].add_(dXc)
         for z, o in zip(dZs, old):
@@ -565,7 +566,7 @@ class EmulatedKernels:
             if dZx[n] is not None:
                 dZx[n].copy_(r[..., :cin])
 
-    def cell_gates_bwd_planar_k(self, Zx, Zh, Tc, W, dRH, Cand, U, Rg, dHnew, dZx, dZh, dW, db, dH, accumulate_x=False, grad_amax=None, act_amax=None):
+    def cell_gates_bwd_planar_k(self, Zx, Zh, Tc, W, dRH, Cand, U, Rg, dHnew, dZx, dZh, dW, db, dH, accumulate_x=False, act_amax=None):
         cin, h = Zx[0].shape[-1], Zh[0].shape[-1]
         before = [z.clone() for z in dZx] if accumulate_x else None              # the candidate's gradients already in the X-side planes
         fold = dH is None                                                   # the prologue's share goes into dZh[0]
@@ -581,7 +582,7 @@ class EmulatedKernels:
             for z, b in zip(dZx, before):
                 z += b
 
-    def cell_cand_bwd_planar_k(self, Zx, Zh, Tc, W, dHnew, U, Cand, dZx, dZh, dW, db, grad_amax=None, act_amax=None):
+    def cell_cand_bwd_planar_k(self, Zx, Zh, Tc, W, dHnew, U, Cand, dZx, dZh, dW, db, act_amax=None):
         cin, h = Zx[0].shape[-1], Zh[0].shape[-1]
         rows = [torch.empty(Zh[0].shape[:-1] + (cin + h,), dtype=W.dtype) for _ in Zh]
         self.cell_cand_bwd(self._cat_planes(Zx, Zh), Tc, W, dHnew, U, Cand, rows, dW, db)
@@ -611,16 +612,12 @@ class EmulatedKernels:
             buf[..., :off].copy_(side)
             buf[..., off + h:].zero_()
 
-    def node_post_bwd(self, X, Tc, W, dA, dB, dX, dW, db, X2=None, dX2=None, grad_amax=None, act_amax=None, out_amax=None):
+    def node_post_bwd(self, X, Tc, W, dA, dB, dX, dW, db, X2=None, dX2=None, act_amax=None):
         if X2 is not None and self.fmt == 'f16x2':             # operands in their format, then the exact twin
             (dAq, dBq), (Xq, X2q) = self._grad_scaled((dA, dB), (X, X2), self._plane_scales(
                 None if act_amax is None else torch.stack([a.reshape(-1) for a in act_amax]), (0, 1)))
-            (Wq,), Tq = self._tables(W), self._mix_tables(Tc)
+            (Wq,), Tq = self._tables(W), self._mix_tables(Tc, backward=True)
             EmulatedKernels().node_post_bwd(Xq, Tq, Wq, dAq, dBq, dX, dW, db, X2=X2q, dX2=dX2)
-            if out_amax is not None:
-                out_amax[0, 0] = torch.maximum(out_amax[0, 0], dX.abs().max().float())
-                if dX2 is not None:
-                    out_amax[1, 0] = torch.maximum(out_amax[1, 0], dX2.abs().max().float())
             return
         if X2 is not None:                                     # planar: compute on the concatenated rows, hand back the planes
             w, w2 = X.shape[-1], X2.shape[-1]

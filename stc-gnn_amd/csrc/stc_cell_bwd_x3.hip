@@ -33,7 +33,6 @@ struct CellBwdArgs {
     float *dX, *dSX, *dH, *dSH;                 // gradient planes (dX, dSX: PL = 1 only)
     float *partial_g, *partial_c;               // one row [dW | db] per workgroup for each convolution
     int nodes, want_dbg, want_dbc, Lw;
-    const float* gmax; int n_gmax;              // fp16 x 2 format: slots whose maximum is max |dHnew| of this launch (device memory)
     const float* zmax;                          // fp16 x 2 format, optional: (4, 256) slots of max |plane| as the gates forward left them (launch order of its
                                                 //   planes: PL = 1 {X, S.X, H, S.H}, PL = 2 {H, S.H, x, S.x}): scales of the dW products' activation operands
 };
@@ -80,10 +79,9 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
     float sT = 1.f, sWg = 1.f, sWc = 1.f;
     if constexpr (F::SCALED) {
         float* scratch = reinterpret_cast<float*>(smem_raw);
-        sT = pow2_scale(block_absmax(a.Tc + (size_t)C * C, C * C, scratch, CB_THREADS), 0);
-        sT = fminf(fmaxf(sT, 0.0625f), 4096.f);          // W's block 0 carries sT as well: keep it inside fp16's range
-        sWg = pow2_scale(block_absmax(a.Wg, 4 * a.Lw * 32, scratch, CB_THREADS), 0);
-        sWc = pow2_scale(block_absmax(a.Wc, 4 * a.Lw * 16, scratch, CB_THREADS), 0);
+        sT = clamp_mix_scale(pow2_scale(block_absmax(a.Tc + (size_t)C * C, C * C, scratch, CB_THREADS), STC_T_TARGET_BWD));      // (W's block 0 carries sT as well)
+        sWg = pow2_scale(block_absmax(a.Wg, 4 * a.Lw * 32, scratch, CB_THREADS), STC_W_TARGET);
+        sWc = pow2_scale(block_absmax(a.Wc, 4 * a.Lw * 16, scratch, CB_THREADS), STC_W_TARGET);
     }
     RunScale rc, rg;                                     // gradient scales of the candidate / the gates phase (stc_x3_frag.h: per node + the wave's reference)
     // activation operands of the dW products (sums over nodes: one scale per plane and launch); block lb of slab n is row lb K + n of the slots.
@@ -541,24 +539,24 @@ static int dispatch_cell_bwd(const CellBwdArgs& a, int cin, int accumulate_x, in
     return accumulate_h ? launch_cell_bwd<F, 20, 2, 0, 1>(a, n_partials, stream) : launch_cell_bwd<F, 20, 2>(a, n_partials, stream);
 }
 
-// gmax != null selects the fp16 x 2 operand format (n_gmax >= 1 device floats whose maximum is max |dHnew| over the launch's rows, or any
-// upper bound of it within a factor 2^8); null keeps the bf16 x 3 format, which needs no range information.
+// fmt: STC_FMT_F16X2 (two fp16 pieces; every operand class scaled by powers of two the kernel finds itself, the activation planes of the dW
+// products from zmax, the slots the gates forward left) or STC_FMT_BF16X3 (three bf16 pieces: fp32's range, no scales).
 int stc_cell_bwd_planar_x3(const float* X, const float* H, const float* SX, const float* SH, const float* Tc, const float* Wg, const float* Wc,
                            const float* U, const float* R, const float* Cand, const float* dHnew, const float* dBm,
                            float* dX, float* dSX, float* dH, float* dSH, float* partial_g, float* partial_c, int* n_partials,
-                           int want_dbg, int want_dbc, int accumulate_x, int accumulate_h, const float* gmax, int n_gmax, const float* zmax,
+                           int want_dbg, int want_dbc, int accumulate_x, int accumulate_h, int fmt, const float* zmax,
                            long long nodes, int C, int Lw, hipStream_t stream) {
     const int cin = Lw - 16;
     if (!stc_cell_bwd_planar_shape_ok(C, 16) || nodes <= 0 || nodes >= (1ll << 31) / C || !(cin == 16 || (cin >= 1 && cin <= 4))) return STC_NOT_HANDLED;
     const float* wide[] = {H, SH, U, R, Cand, dHnew, dBm, dH, dSH};
     if (!all_aligned16(wide, 9)) return STC_NOT_HANDLED;
-    CellBwdArgs a{X, H, SX, SH, U, R, Cand, dHnew, dBm, Tc, Wg, Wc, dX, dSX, dH, dSH, partial_g, partial_c, (int)nodes, want_dbg, want_dbc, Lw, gmax, n_gmax, zmax};
+    CellBwdArgs a{X, H, SX, SH, U, R, Cand, dHnew, dBm, Tc, Wg, Wc, dX, dSX, dH, dSH, partial_g, partial_c, (int)nodes, want_dbg, want_dbc, Lw, zmax};
     if (cin == 16) {
         const float* more[] = {X, SX, dX, dSX};
         if (!dX || !dSX || !all_aligned16(more, 4)) return STC_NOT_HANDLED;
     } else if (accumulate_x) {
         return STC_NOT_HANDLED;       // a narrow input plane gets no gradient
     }
-    return gmax ? dispatch_cell_bwd<FmtH2>(a, cin, accumulate_x, accumulate_h, n_partials, stream)
-                : dispatch_cell_bwd<FmtB3>(a, cin, accumulate_x, accumulate_h, n_partials, stream);
+    return fmt == STC_FMT_F16X2 ? dispatch_cell_bwd<FmtH2>(a, cin, accumulate_x, accumulate_h, n_partials, stream)
+                                : dispatch_cell_bwd<FmtB3>(a, cin, accumulate_x, accumulate_h, n_partials, stream);
 }

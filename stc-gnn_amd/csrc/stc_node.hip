@@ -515,12 +515,12 @@ extern "C" int stc_cell_gates_bwd_planar_f32(const float* X, const float* H, con
                                              const float* Tc, const float* W,
                                              const float* dCandIn, const float* Cand, const float* U, const float* Rg, const float* dHnew,
                                              float* const* dZ, float* dW, float* db, float* dH,
-                                             const float* grad_amax, int32_t n_amax, const float* act_amax,
+                                             int32_t operand_format, const float* act_amax,
                                              void* workspace, size_t workspace_bytes,
                                              int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream) {
     const int L = Lw == 2 * h ? 2 * h : 20, Ho = 2 * h;
     if (int rc = check_dims("stc_cell_gates_bwd_planar_f32", 2, 2, C, L, Lw, Ho, nodes)) return rc;
-    STC_REQUIRE(!grad_amax || n_amax >= 1, STC_EINVAL, "stc_cell_gates_bwd_planar_f32: grad_amax with %d slots", n_amax);
+    STC_REQUIRE(operand_format == STC_FMT_BF16X3 || operand_format == STC_FMT_F16X2, STC_EINVAL, "stc_cell_gates_bwd_planar_f32: operand_format %d", operand_format);
     STC_REQUIRE(Lw == 2 * h || (Lw > h && Lw <= h + 4), STC_EINVAL, "stc_cell_gates_bwd_planar_f32: input width %d (Lw - h) must be h or 1..4", Lw - h);
     if (!stc_cell_planar_supported(2, 2, C, h)) return stc::fail(STC_EUNSUPPORTED, "stc_cell_gates_bwd_planar_f32: shape not on the planar path");
     STC_REQUIRE(W && dZ && dW && Tc, STC_EINVAL, "stc_cell_gates_bwd_planar_f32: null W/dZ/dW/Tc");
@@ -539,7 +539,7 @@ extern "C" int stc_cell_gates_bwd_planar_f32(const float* X, const float* H, con
     int n_parts = 0;
     float* partial = static_cast<float*>(workspace);
     const int rc = stc_cell_gates_bwd_planar_x3(X, H, SX, SH, Tc, W, dCandIn, Cand, U, Rg, dHnew, dZ, dH, partial, &n_parts, db != nullptr,
-                                                grad_amax, n_amax, act_amax, nodes, C, Lw, s);
+                                                operand_format, act_amax, nodes, C, Lw, s);
     if (rc == STC_NOT_HANDLED) return stc::fail(STC_EUNSUPPORTED, "stc_cell_gates_bwd_planar_f32: operands not usable (alignment)");
     if (rc != STC_OK) return rc;
     const int stride = nW + Ho;
@@ -565,12 +565,12 @@ extern "C" int stc_cell_bwd_planar_f32(const float* X, const float* H, const flo
                                        float* dX, float* dSX, float* dH, float* dSH,
                                        float* dWg, float* dbg, float* dWc, float* dbc,
                                        int32_t accumulate_x, int32_t accumulate_h,
-                                       const float* grad_amax, int32_t n_amax, const float* act_amax,
+                                       int32_t operand_format, const float* act_amax,
                                        void* workspace, size_t workspace_bytes,
                                        int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream) {
     const int L = Lw == 2 * h ? 2 * h : 20;
     if (int rc = check_dims("stc_cell_bwd_planar_f32", 2, 2, C, L, Lw, 2 * h, nodes)) return rc;
-    STC_REQUIRE(!grad_amax || n_amax >= 1, STC_EINVAL, "stc_cell_bwd_planar_f32: grad_amax with %d slots", n_amax);
+    STC_REQUIRE(operand_format == STC_FMT_BF16X3 || operand_format == STC_FMT_F16X2, STC_EINVAL, "stc_cell_bwd_planar_f32: operand_format %d", operand_format);
     STC_REQUIRE(Lw == 2 * h || (Lw > h && Lw <= h + 4), STC_EINVAL, "stc_cell_bwd_planar_f32: input width %d (Lw - h) must be h or 1..4", Lw - h);
     if (!stc_cell_bwd_planar_supported(C, h)) return stc::fail(STC_EUNSUPPORTED, "stc_cell_bwd_planar_f32: C=%d h=%d is not built (C = 32, h = 16)", C, h);
     STC_REQUIRE(Wg && Wc && dWg && dWc && Tc, STC_EINVAL, "stc_cell_bwd_planar_f32: null W/dW/Tc");
@@ -594,7 +594,7 @@ extern "C" int stc_cell_bwd_planar_f32(const float* X, const float* H, const flo
     float* partial_c = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + bytes_g);
     int n_parts = 0;
     const int rc = stc_cell_bwd_planar_x3(X, H, SX, SH, Tc, Wg, Wc, U, Rg, Cand, dHnew, dBm, dX, dSX, dH, dSH, partial_g, partial_c, &n_parts,
-                                          dbg != nullptr, dbc != nullptr, accumulate_x != 0, accumulate_h != 0, grad_amax, n_amax, act_amax, nodes, C, Lw, s);
+                                          dbg != nullptr, dbc != nullptr, accumulate_x != 0, accumulate_h != 0, operand_format, act_amax, nodes, C, Lw, s);
     if (rc == STC_NOT_HANDLED) return stc::fail(STC_EUNSUPPORTED, "stc_cell_bwd_planar_f32: operands not usable (alignment)");
     if (rc != STC_OK) return rc;
     if (int r2 = stc_node_reduce_partials(partial_g, n_parts, nWg, 2 * h, dWg, dbg, s)) return r2;
@@ -642,11 +642,11 @@ extern "C" int stc_cell_cand_fwd_planar_k_f32(const float* const* Zx, const floa
 static int planar_k_bwd(const char* who, const float* const* Zx, const float* const* Zh, int K, const float* Tc, const float* W, int mode,
                         const float* dRH, const float* Cand, const float* U, const float* Rg, const float* dHnew,
                         float* const* dZx, float* const* dZh, float* dW, float* db, float* dH, void* workspace, size_t workspace_bytes,
-                        long long nodes, int C, int Lw, int h, hipStream_t s, const float* grad_amax, int n_amax, const float* act_amax, int accumulate_x = 0) {
+                        long long nodes, int C, int Lw, int h, hipStream_t s, int operand_format, const float* act_amax, int accumulate_x = 0) {
     const int L = Lw == 2 * h ? 2 * h : 20, Ho = mode == 1 ? 2 * h : h;
     if (int rc = planar_k_common(who, Zx, Zh, K, C, Lw, h, Ho, nodes)) return rc;
     STC_REQUIRE(W && dW && Tc && dZh && (Lw != 2 * h || dZx), STC_EINVAL, "%s: null W/dW/Tc/dZ", who);
-    STC_REQUIRE(!grad_amax || n_amax >= 1, STC_EINVAL, "%s: grad_amax with %d slots", who, n_amax);
+    STC_REQUIRE(operand_format == STC_FMT_BF16X3 || operand_format == STC_FMT_F16X2, STC_EINVAL, "%s: operand_format %d", who, operand_format);
     const int nW = K * K * Lw * Ho;
     if (nodes == 0) {
         if (int rc = stc::hip_status(hipMemsetAsync(dW, 0, (size_t)nW * sizeof(float), s), "memset dW")) return rc;
@@ -659,7 +659,7 @@ static int planar_k_bwd(const char* who, const float* const* Zx, const float* co
     int n_parts = 0;
     float* partial = static_cast<float*>(workspace);
     const int rc = stc_cell_conv_bwd_planar_k_x3(Zx, Zh, K, Tc, W, mode, dRH, Cand, U, Rg, dHnew, dZx, dZh, dH, partial, &n_parts, db != nullptr, nodes, C, Lw,
-                                                 accumulate_x, grad_amax, n_amax, act_amax, s);
+                                                 accumulate_x, operand_format, act_amax, s);
     if (rc == STC_NOT_HANDLED) return stc::fail(STC_EUNSUPPORTED, "%s: operands not usable (alignment / null gradient plane / accumulate_x outside the wide folded form)", who);
     if (rc != STC_OK) return rc;
     const int stride = nW + Ho;
@@ -672,19 +672,19 @@ static int planar_k_bwd(const char* who, const float* const* Zx, const float* co
 extern "C" int stc_cell_gates_bwd_planar_k_f32(const float* const* Zx, const float* const* Zh, int32_t K, const float* Tc, const float* W,
                                                const float* dRH, const float* Cand, const float* U, const float* Rg, const float* dHnew,
                                                float* const* dZx, float* const* dZh, float* dW, float* db, float* dH, int32_t accumulate_x,
-                                               const float* grad_amax, int32_t n_amax, const float* act_amax,
+                                               int32_t operand_format, const float* act_amax,
                                                void* workspace, size_t workspace_bytes, int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream) {
     return planar_k_bwd("stc_cell_gates_bwd_planar_k_f32", Zx, Zh, K, Tc, W, 1, dRH, Cand, U, Rg, dHnew, dZx, dZh, dW, db, dH, workspace, workspace_bytes,
-                        nodes, C, Lw, h, static_cast<hipStream_t>(stream), grad_amax, n_amax, act_amax, accumulate_x);
+                        nodes, C, Lw, h, static_cast<hipStream_t>(stream), operand_format, act_amax, accumulate_x);
 }
 
 extern "C" int stc_cell_cand_bwd_planar_k_f32(const float* const* Zx, const float* const* Zh, int32_t K, const float* Tc, const float* W,
                                               const float* dHnew, const float* U, const float* Cand,
                                               float* const* dZx, float* const* dZh, float* dW, float* db,
-                                              const float* grad_amax, int32_t n_amax, const float* act_amax,
+                                              int32_t operand_format, const float* act_amax,
                                               void* workspace, size_t workspace_bytes, int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream) {
     return planar_k_bwd("stc_cell_cand_bwd_planar_k_f32", Zx, Zh, K, Tc, W, 2, nullptr, Cand, U, nullptr, dHnew, dZx, dZh, dW, db, nullptr, workspace, workspace_bytes,
-                        nodes, C, Lw, h, static_cast<hipStream_t>(stream), grad_amax, n_amax, act_amax);
+                        nodes, C, Lw, h, static_cast<hipStream_t>(stream), operand_format, act_amax);
 }
 
 extern "C" int stc_bdg_node_post_supported(int32_t Ks, int32_t Kc, int32_t C, int32_t L, int32_t Ho) {
@@ -705,12 +705,12 @@ extern "C" int stc_bdg_node_post_fwd_f32(const float* X, const float* X2, const 
 }
 
 extern "C" int stc_bdg_node_post_bwd_f32(const float* X, const float* X2, const float* Tc, const float* W, const float* dA, const float* dB,
-                                         float* dX, float* dX2, float* dW, float* db, const float* grad_amax, int32_t n_amax,
-                                         const float* act_amax_x, const float* act_amax_x2, float* out_amax,
+                                         float* dX, float* dX2, float* dW, float* db, int32_t operand_format,
+                                         const float* act_amax_x, const float* act_amax_x2,
                                          void* workspace, size_t workspace_bytes,
                                          int64_t nodes, int32_t C, int32_t L, int32_t Lw, int32_t Ho, void* stream) {
     if (int rc = check_dims("stc_bdg_node_post_bwd_f32", 2, 2, C, L, Lw, Ho, nodes)) return rc;
-    STC_REQUIRE(!grad_amax || n_amax >= 1, STC_EINVAL, "stc_bdg_node_post_bwd_f32: grad_amax with %d slots", n_amax);
+    STC_REQUIRE(operand_format == STC_FMT_BF16X3 || operand_format == STC_FMT_F16X2, STC_EINVAL, "stc_bdg_node_post_bwd_f32: operand_format %d", operand_format);
     if (!stc_bdg_node_post_supported(2, 2, C, L, Ho)) return stc::fail(STC_EUNSUPPORTED, "stc_bdg_node_post_bwd_f32: shape not on the post-aggregation path");
     STC_REQUIRE(W && dW && Tc, STC_EINVAL, "stc_bdg_node_post_bwd_f32: null W/dW/Tc");
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -729,7 +729,7 @@ extern "C" int stc_bdg_node_post_bwd_f32(const float* X, const float* X2, const 
     STC_REQUIRE(!X2 || L == 32 || (L == 20 && Lw > 16), STC_EINVAL, "stc_bdg_node_post_bwd_f32: planar input (X2) needs rows of 16 + 16 or 16 + cin (<= 4) columns, L = %d", L);
     STC_REQUIRE(L == 20 ? dX2 == nullptr : (X2 == nullptr) == (dX2 == nullptr), STC_EINVAL,
                 "stc_bdg_node_post_bwd_f32: planar input (X2) and planar gradient (dX2) go together (the narrow input plane of L = 20 gets no gradient)");
-    const int rc = stc_node_post_bwd_x3(X, X2, Tc, W, dA, dB, dX, dX2, partial, &n_parts, db != nullptr, grad_amax, n_amax, act_amax_x, act_amax_x2, out_amax, nodes, C, L, Lw, Ho, s);
+    const int rc = stc_node_post_bwd_x3(X, X2, Tc, W, dA, dB, dX, dX2, partial, &n_parts, db != nullptr, operand_format, act_amax_x, act_amax_x2, nodes, C, L, Lw, Ho, s);
     if (rc == STC_NOT_HANDLED) return stc::fail(STC_EUNSUPPORTED, "stc_bdg_node_post_bwd_f32: operands not usable (alignment)");
     if (rc != STC_OK) return rc;
     const int stride = nW + Ho;

@@ -123,7 +123,6 @@ struct BwdPro {
     float *dXt, *dH;                                  // (nodes,C,cin) or null, (nodes,C,16)
     int cin;
     int dh_scaled;                                    // dH_in enters as dH_in * (1 - U)
-    const float* gmax; int n_gmax;                    // fp16 x 2 operand format: slots whose maximum is the launch's gradient maximum (device)
     const float* zmax;                                // fp16 x 2, optional: (2 K, 256) slots of max |plane| of the launch's input planes (rows in the
                                                       //   launch order of Z, as the forward launch left them): scales of the dW products' activation operands
 };
@@ -245,7 +244,7 @@ __device__ __forceinline__ void combine_dw(float* smem, const f32x4 (&dWt)[K][LB
                     for (int r = 0; r < 4; ++r) {
                         const int col = 16 * lb + 4 * q + r;
                         const int l = swapped_cin < 0 ? col : stc_wrow_swapped(col, swapped_cin);      // slab column -> W row
-                        if (l >= 0 && l < Lw) slab[((n * K + c) * Lw + l) * Ho + 16 * hb + j] = dWt[n][lb][c][hb][r] * ((c == 0 ? unscale0 : unscale1) * pu.v[n][lb]);
+                        if (l >= 0 && l < Lw) slab[((n * K + c) * Lw + l) * Ho + 16 * hb + j] = (dWt[n][lb][c][hb][r] * (c == 0 ? unscale0 : unscale1)) * pu.v[n][lb];      // (one factor at a time: their product alone may underflow)
                     }
 #pragma unroll
     for (int hb = 0; hb < HB; ++hb) {

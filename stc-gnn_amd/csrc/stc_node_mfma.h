@@ -67,8 +67,8 @@ int stc_cell_cand_bwd_x3(const float* const* Z, int K, const float* Tc, const fl
 // Post-aggregation form of a K = 2 convolution, Y = A + S.Bm (stc_node_x3.hip): backward from (X, dA = dY, dBm = S^T dY).
 int stc_node_post_shape_ok(int K, int C, int L, int Ho);
 int stc_node_post_bwd_x3(const float* X, const float* X2, const float* Tc, const float* W, const float* dA, const float* dB, float* dX, float* dX2,
-                         float* partial, int* n_partials, int want_db, const float* gmax, int n_gmax,
-                         const float* zmax_x, const float* zmax_x2, float* out_amax,      // fp16 x 2: activation-maximum slots in, gradient-maximum slots out
+                         float* partial, int* n_partials, int want_db, int fmt,
+                         const float* zmax_x, const float* zmax_x2,      // fp16 x 2: activation-maximum slots of the two input planes
                          long long nodes, int C, int L, int Lw, int Ho, hipStream_t stream);
 int stc_node_post_fwd_x3(const float* X, const float* X2, const float* Tc, const float* W, const float* bias, float* A, float* Bm,
                          long long nodes, int C, int L, int Lw, int Ho, hipStream_t stream);
@@ -82,7 +82,7 @@ int stc_cell_gates_fwd_planar_x3(const float* X, const float* H, const float* SX
                                  long long nodes, int C, int Lw, hipStream_t stream);
 int stc_cell_gates_bwd_planar_x3(const float* X, const float* H, const float* SX, const float* SH, const float* Tc, const float* W,
                                  const float* dCandIn, const float* Cand, const float* U, const float* R, const float* dHnew,
-                                 float* const* dZ, float* dH, float* partial, int* n_partials, int want_db, const float* gmax, int n_gmax, const float* zmax,
+                                 float* const* dZ, float* dH, float* partial, int* n_partials, int want_db, int fmt, const float* zmax,
                                  long long nodes, int C, int Lw, hipStream_t stream);
 
 // The whole backward of a planar K = 2 cell step in one launch (stc_cell_bwd_x3.hip; C = 32): candidate (post-aggregation form) and
@@ -91,7 +91,7 @@ int stc_cell_bwd_planar_shape_ok(int C, int h);
 int stc_cell_bwd_planar_x3(const float* X, const float* H, const float* SX, const float* SH, const float* Tc, const float* Wg, const float* Wc,
                            const float* U, const float* R, const float* Cand, const float* dHnew, const float* dBm,
                            float* dX, float* dSX, float* dH, float* dSH, float* partial_g, float* partial_c, int* n_partials,
-                           int want_dbg, int want_dbc, int accumulate_x, int accumulate_h, const float* gmax, int n_gmax, const float* zmax,
+                           int want_dbg, int want_dbc, int accumulate_x, int accumulate_h, int fmt, const float* zmax,
                            long long nodes, int C, int Lw, hipStream_t stream);
 
 // Planar cell convolutions of order K = 3 (stc_node_x3.hip): Zx[n] / Zh[n] = T_n(S) of the X-side / H-side plane; mode 1 gates, 2 candidate.
@@ -102,7 +102,7 @@ int stc_cell_conv_fwd_planar_k_x3(const float* const* Zx, const float* const* Zh
 int stc_cell_conv_bwd_planar_k_x3(const float* const* Zx, const float* const* Zh, int K, const float* Tc, const float* W, int mode,
                                   const float* dRH, const float* Cand, const float* U, const float* R, const float* dHnew,
                                   float* const* dZx, float* const* dZh, float* dH, float* partial, int* n_partials, int want_db,
-                                  long long nodes, int C, int Lw, int accumulate_x, const float* gmax, int n_gmax, const float* zmax, hipStream_t stream);
+                                  long long nodes, int C, int Lw, int accumulate_x, int fmt, const float* zmax, hipStream_t stream);
 
 // Fixed-order reduction of the backward kernels' per-workgroup partial rows [dW (nW) | db (Ho)] into dW, db (db may be null).
 int stc_node_reduce_partials(const float* partial, int n_parts, int nW, int Ho, float* dW, float* db, hipStream_t stream);

@@ -126,11 +126,10 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
     if constexpr (F::SCALED) {
         float* scratch = reinterpret_cast<float*>(smem_raw);
         if (K > 1) {
-            sT = pow2_scale(block_absmax(Tc + (size_t)C * C, (K - 1) * C * C, scratch, MF_THREADS), 0);
-            sT = fminf(fmaxf(sT, 0.0625f), 4096.f);         // W's block 0 carries sT as well: keep it inside fp16's range
+            sT = clamp_mix_scale(pow2_scale(block_absmax(Tc + (size_t)C * C, (K - 1) * C * C, scratch, MF_THREADS), STC_T_TARGET_FWD));      // (W's block 0 carries sT as well)
         }
-        sW = pow2_scale(block_absmax(W, K * K * Lw * Ho, scratch, MF_THREADS), 0);
-        if (POST) sWp = pow2_scale(block_absmax(post.Wc, K * K * Lw * 16, scratch, MF_THREADS), 0);
+        sW = pow2_scale(block_absmax(W, K * K * Lw * Ho, scratch, MF_THREADS), STC_W_TARGET);
+        if (POST) sWp = pow2_scale(block_absmax(post.Wc, K * K * Lw * 16, scratch, MF_THREADS), STC_W_TARGET);
     }
 
     for (int idx = tid; idx < nWx * 64; idx += MF_THREADS) {
@@ -605,10 +604,9 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
     if constexpr (F::SCALED) {
         float* scratch = reinterpret_cast<float*>(smem_raw);
         if (K > 1) {
-            sT = pow2_scale(block_absmax(Tc + (size_t)C * C, (K - 1) * C * C, scratch, MF_THREADS), 0);
-            sT = fminf(fmaxf(sT, 0.0625f), 4096.f);
+            sT = clamp_mix_scale(pow2_scale(block_absmax(Tc + (size_t)C * C, (K - 1) * C * C, scratch, MF_THREADS), STC_T_TARGET_BWD));
         }
-        sW = pow2_scale(block_absmax(W, K * K * Lw * Ho, scratch, MF_THREADS), 0);
+        sW = pow2_scale(block_absmax(W, K * K * Lw * Ho, scratch, MF_THREADS), STC_W_TARGET);
     }
     RunScale rs;                                         // FmtH2: gradient scales (stc_x3_frag.h: per node + the wave's reference for the sums over nodes)
     // activation operands of the dW products: one scale per plane and launch, from the slots the forward launch filled (block lb of slab n =
@@ -1008,15 +1006,14 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd2_x3_k
     }
 }
 
-template <int NB2, int HB, int L, int PL = 0, class F = FmtB3>      // F: operand format, scales as in node_bwd_x3_kernel (gmax: the launch's gradient maximum)
+template <int NB2, int HB, int L, int PL = 0, class F = FmtB3>      // F: operand format, scales as in node_bwd_x3_kernel
 __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_kernel(
     const float* __restrict__ X, const float* __restrict__ X2, const float* __restrict__ Tc, const float* __restrict__ W,
     const float* __restrict__ dA, const float* __restrict__ dB, float* __restrict__ dX, float* __restrict__ dX2,
-    float* __restrict__ partial, int nodes, int want_db, int Lw, const float* __restrict__ gmax, int n_gmax,
-    const float* __restrict__ zmax_x, const float* __restrict__ zmax_x2, float* __restrict__ out_amax) {
+    float* __restrict__ partial, int nodes, int want_db, int Lw,
+    const float* __restrict__ zmax_x, const float* __restrict__ zmax_x2) {
     // zmax_x / zmax_x2 (fp16 x 2, optional): 256 slots each of max |X| / max |X2| (a row of the slots a forward launch filled; R*H takes H's): the
-    // scales of the dW products' activation operands.  out_amax (optional): (2, 256) zero-filled slots that receive max |dX| and max |dX2| -- the
-    // gates backward that consumes the R*H plane's gradient scales its gradient operands by it.
+    // scales of the dW products' activation operands.
     using Op = typename F::Op;
     constexpr int NP = F::NP;
     constexpr int K = 2, NRB = 2 * NB2, C = 32 * NB2, Ho = 16 * HB, LB = (L + 15) / 16;
@@ -1030,15 +1027,13 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
     float sT = 1.f, sW = 1.f;
     if constexpr (F::SCALED) {
         float* scratch = reinterpret_cast<float*>(smem_raw);
-        sT = fminf(fmaxf(pow2_scale(block_absmax(Tc + (size_t)C * C, C * C, scratch, MF_THREADS), 0), 0.0625f), 4096.f);
-        sW = pow2_scale(block_absmax(W, K * K * Lw * Ho, scratch, MF_THREADS), 0);
+        sT = clamp_mix_scale(pow2_scale(block_absmax(Tc + (size_t)C * C, C * C, scratch, MF_THREADS), STC_T_TARGET_BWD));
+        sW = pow2_scale(block_absmax(W, K * K * Lw * Ho, scratch, MF_THREADS), STC_W_TARGET);
     }
     RunScale rs;                                         // FmtH2: gradient scales (stc_x3_frag.h: per node + the wave's reference for the sums over nodes)
     float sz[LB];
 #pragma unroll
     for (int lb = 0; lb < LB; ++lb) sz[lb] = (F::SCALED && PL != 0) ? plane_scale(lb == 0 ? zmax_x : zmax_x2, 0) : 1.f;
-    static_assert(LB == 2, "rows of 16 + 16 or 16 + cin columns");
-    float omax[LB] = {0.f, 0.f};                        // running max |dX| / |dX2| of this lane
 
     for (int idx = tid; idx < nTB * 64; idx += MF_THREADS) {
         const int ll = idx & 63, f = idx >> 6, p = f % NB2, rb = f / NB2, gg = ll >> 4;
@@ -1212,7 +1207,7 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
                 }
             if constexpr (F::SCALED) {
 #pragma unroll
-                for (int rb = 0; rb < NRB; ++rb) { z[rb] *= ikz_sg; omax[lb] = __builtin_fmaxf(omax[lb], absmax4(z[rb])); }
+                for (int rb = 0; rb < NRB; ++rb) z[rb] *= ikz_sg;
             }
             if constexpr (PL == 1) {                            // planar gradient: columns 0..15 -> dX, 16..31 -> dX2
 #pragma unroll
@@ -1272,13 +1267,6 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
             }
     }
     const float isg = exp2i(-rs.k);
-    if constexpr (F::SCALED) {
-        if (out_amax) {
-            const int slot = blockIdx.x * MF_WAVES + wave;
-            leave_max(out_amax, slot, omax[0]);
-            leave_max(out_amax + STC_ACT_SLOTS, slot, omax[1]);
-        }
-    }
     PlaneUnscale<K, LB> pu;
 #pragma unroll
     for (int n = 0; n < K; ++n)
@@ -1460,8 +1448,8 @@ int stc_cell_cand_bwd_x3(const float* const* Z, int K, const float* Tc, const fl
 
 template <int NB2, int HB, int L, int PL = 0, class F = FmtB3>
 static int launch_bwd2(const float* X, const float* X2, const float* Tc, const float* W, const float* dA, const float* dB, float* dX, float* dX2,
-                       float* partial, int* n_partials, int want_db, long long nodes, int Lw, hipStream_t stream, const float* gmax = nullptr, int n_gmax = 0,
-                       const float* zmax_x = nullptr, const float* zmax_x2 = nullptr, float* out_amax = nullptr) {
+                       float* partial, int* n_partials, int want_db, long long nodes, int Lw, hipStream_t stream,
+                       const float* zmax_x = nullptr, const float* zmax_x2 = nullptr) {
     constexpr int K = 2, NRB = 2 * NB2, Ho = 16 * HB, LB = (L + 15) / 16, NBK = K * HB, S = (NBK + 1) / 2, nW = K * K * L * Ho;
     const size_t frag = (size_t)(NRB * NB2 + K * LB * S) * F::NP * 64 * 16;
     const size_t slabs = (size_t)MF_WAVES * (nW + Ho) * sizeof(float);
@@ -1473,7 +1461,7 @@ static int launch_bwd2(const float* X, const float* X2, const float* Tc, const f
     const long long want = (nodes + MF_WAVES - 1) / MF_WAVES;
     int grid = resident < MF_BWD_MAX_GRID ? resident : MF_BWD_MAX_GRID;
     if (want < grid) grid = (int)want;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(MF_THREADS), lds, stream, X, X2, Tc, W, dA, dB, dX, dX2, partial, (int)nodes, want_db, Lw, gmax, n_gmax, zmax_x, zmax_x2, out_amax);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(MF_THREADS), lds, stream, X, X2, Tc, W, dA, dB, dX, dX2, partial, (int)nodes, want_db, Lw, zmax_x, zmax_x2);
     STC_LAUNCH_CHECK("node_bwd2_x3 launch");
     *n_partials = grid;
     return STC_OK;
@@ -1498,25 +1486,25 @@ int stc_node_post_shape_ok(int K, int C, int L, int Ho) {
     return K == 2 && (C == 32 || C == 64) && (L == 20 || L == 32) && Ho == 16;     // Ho < L: where the narrow SpMM pays
 }
 
-// gmax != null: fp16 x 2 operand format for the planar forms at C = 64 (what the two-launch cell backward runs; C = 32 runs the one-launch
-// kernel and keeps bf16 x 3 here: its two-waves-per-SIMD build has no registers to spare); null: bf16 x 3
+// fmt == STC_FMT_F16X2: fp16 x 2 operand format for the planar forms at C = 64 (what the two-launch cell backward runs; C = 32 runs the
+// one-launch kernel and keeps bf16 x 3 here: its two-waves-per-SIMD build has no registers to spare); else bf16 x 3
 int stc_node_post_bwd_x3(const float* X, const float* X2, const float* Tc, const float* W, const float* dA, const float* dB, float* dX, float* dX2,
-                         float* partial, int* n_partials, int want_db, const float* gmax, int n_gmax,
-                         const float* zmax_x, const float* zmax_x2, float* out_amax,
+                         float* partial, int* n_partials, int want_db, int fmt,
+                         const float* zmax_x, const float* zmax_x2,
                          long long nodes, int C, int L, int Lw, int Ho, hipStream_t stream) {
     if (!stc_node_post_shape_ok(2, C, L, Ho) || nodes <= 0 || nodes >= (1ll << 31) / C) return STC_NOT_HANDLED;
     if (!(stc::aligned16(X) && stc::aligned16(dA) && stc::aligned16(dB) && stc::aligned16(dX) && (!X2 || L == 20 || stc::aligned16(X2)))) return STC_NOT_HANDLED;
     if (X2 && L == 20) {                        // narrow planar rows: gradient of the 16-wide plane only (dX); the input plane gets none
         if (Lw - 16 < 1 || Lw - 16 > 4) return STC_NOT_HANDLED;
         if (C == 32) return launch_bwd2<1, 1, 20, 2>(X, X2, Tc, W, dA, dB, dX, nullptr, partial, n_partials, want_db, nodes, Lw, stream);
-        if (C == 64 && gmax) return launch_bwd2<2, 1, 20, 2, FmtH2>(X, X2, Tc, W, dA, dB, dX, nullptr, partial, n_partials, want_db, nodes, Lw, stream, gmax, n_gmax, zmax_x, zmax_x2, out_amax);
+        if (C == 64 && fmt == STC_FMT_F16X2) return launch_bwd2<2, 1, 20, 2, FmtH2>(X, X2, Tc, W, dA, dB, dX, nullptr, partial, n_partials, want_db, nodes, Lw, stream, zmax_x, zmax_x2);
         if (C == 64) return launch_bwd2<2, 1, 20, 2>(X, X2, Tc, W, dA, dB, dX, nullptr, partial, n_partials, want_db, nodes, Lw, stream);
         return STC_NOT_HANDLED;
     }
     if (X2) {                                   // planar rows (16 + 16 columns): input planes X, X2 and gradient planes dX, dX2
         if (L != 32 || !dX2 || !stc::aligned16(dX2)) return STC_NOT_HANDLED;
         if (C == 32) return launch_bwd2<1, 1, 32, 1>(X, X2, Tc, W, dA, dB, dX, dX2, partial, n_partials, want_db, nodes, Lw, stream);
-        if (C == 64 && gmax) return launch_bwd2<2, 1, 32, 1, FmtH2>(X, X2, Tc, W, dA, dB, dX, dX2, partial, n_partials, want_db, nodes, Lw, stream, gmax, n_gmax, zmax_x, zmax_x2, out_amax);
+        if (C == 64 && fmt == STC_FMT_F16X2) return launch_bwd2<2, 1, 32, 1, FmtH2>(X, X2, Tc, W, dA, dB, dX, dX2, partial, n_partials, want_db, nodes, Lw, stream, zmax_x, zmax_x2);
         if (C == 64) return launch_bwd2<2, 1, 32, 1>(X, X2, Tc, W, dA, dB, dX, dX2, partial, n_partials, want_db, nodes, Lw, stream);
         return STC_NOT_HANDLED;
     }
@@ -1611,10 +1599,10 @@ static int gates_bwd_planar_go(const float* const* Z, float* const* dZ, const fl
     return STC_NOT_HANDLED;
 }
 
-// gmax != null: fp16 x 2 operand format (device floats whose maximum bounds |dHnew| and |dCandIn| of the launch); null: bf16 x 3
+// fmt: STC_FMT_F16X2 or STC_FMT_BF16X3 (stc_x3_frag.h)
 int stc_cell_gates_bwd_planar_x3(const float* X, const float* H, const float* SX, const float* SH, const float* Tc, const float* W,
                                  const float* dCandIn, const float* Cand, const float* U, const float* R, const float* dHnew,
-                                 float* const* dZ, float* dH, float* partial, int* n_partials, int want_db, const float* gmax, int n_gmax, const float* zmax,
+                                 float* const* dZ, float* dH, float* partial, int* n_partials, int want_db, int fmt, const float* zmax,
                                  long long nodes, int C, int Lw, hipStream_t stream) {
     const int cin = Lw - 16;
     if (!x3_cell_shape(2, C, cin == 16 ? 32 : 20, nodes) || !(cin == 16 || (cin >= 1 && cin <= 4))) return STC_NOT_HANDLED;
@@ -1622,7 +1610,7 @@ int stc_cell_gates_bwd_planar_x3(const float* X, const float* H, const float* SX
         return STC_NOT_HANDLED;
     BwdPro pro{};       // dCandIn: the gradient of the R*H plane, (nodes, C, 16): the state columns sit at offset 0
     pro.Cand = Cand; pro.dCandIn = dCandIn; pro.H = H; pro.U = U; pro.R = R; pro.dH_in = dHnew; pro.dH = dH; pro.cin = 0; pro.dh_scaled = 1;
-    pro.gmax = gmax; pro.n_gmax = n_gmax; pro.zmax = zmax;
+    pro.zmax = zmax;
     const float* Zw[4] = {X, SX, H, SH};
     const float* Zn[4] = {H, SH, X, SX};           // narrow input plane: the state plane leads; only d H plane (dZ[2]) and d SH plane (dZ[3]) are produced
     float* dZn[4] = {dZ[2], dZ[3], nullptr, nullptr};
@@ -1634,7 +1622,7 @@ int stc_cell_gates_bwd_planar_x3(const float* X, const float* H, const float* SX
         for (int i = 0; i < 4; ++i)
             if (!dZ[i] || !stc::aligned16(dZ[i])) return STC_NOT_HANDLED;
     }
-    return gmax ? gates_bwd_planar_go<FmtH2>(narrow ? Zn : Zw, narrow ? dZn : dZ, Tc, W, narrow, dH == nullptr, pro, partial, n_partials, want_db, nodes, C, Lw, stream)
+    return fmt == STC_FMT_F16X2 ? gates_bwd_planar_go<FmtH2>(narrow ? Zn : Zw, narrow ? dZn : dZ, Tc, W, narrow, dH == nullptr, pro, partial, n_partials, want_db, nodes, C, Lw, stream)
                 : gates_bwd_planar_go<FmtB3>(narrow ? Zn : Zw, narrow ? dZn : dZ, Tc, W, narrow, dH == nullptr, pro, partial, n_partials, want_db, nodes, C, Lw, stream);
 }
 
@@ -1684,12 +1672,11 @@ static int conv_bwd_planar_k_go(const float* const* Z, float* const* dZ, const f
                      : launch_bwd<1, 1, 3, 20, PRO_BLEND, 2, 0, 0, F>(Z, Tc, W, nullptr, dZ, partial, n_partials, want_db, nodes, Lw, stream, pro);
 }
 
-// gmax != null: fp16 x 2 operand format (n_gmax device floats whose maximum bounds every gradient operand of the launch: dHnew, and for the
-// gates convolution dRH as well); null: bf16 x 3
+// fmt: STC_FMT_F16X2 or STC_FMT_BF16X3 (stc_x3_frag.h)
 int stc_cell_conv_bwd_planar_k_x3(const float* const* Zx, const float* const* Zh, int K, const float* Tc, const float* W, int mode,
                                   const float* dRH, const float* Cand, const float* U, const float* R, const float* dHnew,
                                   float* const* dZx, float* const* dZh, float* dH, float* partial, int* n_partials, int want_db,
-                                  long long nodes, int C, int Lw, int accumulate_x, const float* gmax, int n_gmax, const float* zmax, hipStream_t stream) {
+                                  long long nodes, int C, int Lw, int accumulate_x, int fmt, const float* zmax, hipStream_t stream) {
     const int cin = Lw - 16;
     if (!stc_cell_planar_k_shape_ok(K, C, 16) || !x3_cell_shape(K, C, cin == 16 ? 32 : 20, nodes) || !(cin == 16 || (cin >= 1 && cin <= 4))) return STC_NOT_HANDLED;
     if (!all_aligned16(Zh, K) || (cin == 16 && !all_aligned16(Zx, K))) return STC_NOT_HANDLED;
@@ -1702,7 +1689,7 @@ int stc_cell_conv_bwd_planar_k_x3(const float* const* Zx, const float* const* Zh
     }
     if (!(stc::aligned16(Cand) && stc::aligned16(U) && stc::aligned16(dHnew))) return STC_NOT_HANDLED;
     BwdPro pro{};
-    pro.gmax = gmax; pro.n_gmax = n_gmax; pro.zmax = zmax;
+    pro.zmax = zmax;
     if (mode == 1) {
         if (!(stc::aligned16(dRH) && stc::aligned16(R) && (!dH || stc::aligned16(dH)))) return STC_NOT_HANDLED;
         pro.Cand = Cand; pro.dCandIn = dRH; pro.H = Zh[0]; pro.U = U; pro.R = R; pro.dH_in = dHnew; pro.dH = dH; pro.cin = 0; pro.dh_scaled = 1;
@@ -1710,6 +1697,6 @@ int stc_cell_conv_bwd_planar_k_x3(const float* const* Zx, const float* const* Zh
     } else {
         pro.dH_in = dHnew; pro.U = U; pro.Cand = Cand;
     }
-    return gmax ? conv_bwd_planar_k_go<FmtH2>(Z, dZ, Tc, W, mode, cin, dH == nullptr, accumulate_x, pro, partial, n_partials, want_db, nodes, Lw, stream)
+    return fmt == STC_FMT_F16X2 ? conv_bwd_planar_k_go<FmtH2>(Z, dZ, Tc, W, mode, cin, dH == nullptr, accumulate_x, pro, partial, n_partials, want_db, nodes, Lw, stream)
                 : conv_bwd_planar_k_go<FmtB3>(Z, dZ, Tc, W, mode, cin, dH == nullptr, accumulate_x, pro, partial, n_partials, want_db, nodes, Lw, stream);
 }

@@ -242,8 +242,18 @@ constexpr int STC_ACT_SLOTS = 256;          // slots per plane row of an activat
 // Where the maxima go.  Two fp16 pieces carry 22 bits for values of at least 2^-3, so a maximum in [2^(t-1), 2^t) leaves t + 2 binades below it at
 // full precision -- what the planes of one node may differ by (S.X against X with graph row sums of 50: 5.6 binades).  The ceiling is set by the
 // second-stage operands: a projected value is a sum of K x 32 products with a table normalised below 1, at most 96 x 2^8 < 65504 in the forward.
-constexpr int STC_ACT_TARGET_FWD = 8;       // forward: the node's maximum over its rows into [2^7, 2^8)
+constexpr int STC_ACT_TARGET_FWD = 5;       // forward: the node's maximum over its rows into [2^4, 2^5)
 constexpr int STC_ACT_TARGET_BWD = 6;       // backward: a plane's maximum into [2^5, 2^6); times at most 2^8 (RunScale) stays below 2^14
+// Tables (W, T_c; normalised per workgroup from their own maxima): the same window argument -- Gaussian weights and the entries of
+// T_2 = 2 Gc^2 - I spread over many binades, and with a maximum in [1/2, 1) (round 3) everything below an eighth of it sat on the absolute
+// floor: with graph row sums of 50 that alone was 25x the reference's own fp32 noise in the forward (tests/test_scale_sweep.py).
+//   forward   |U_c| <= 32 K x 2^5 x 2^4 = 49 152 at K = 3: the projected values still fit fp16 as operands of the category mix;
+//   backward  |T_c dY| <= 32 x 2^2 x 2^(4+4): gradient fragments (node maximum in [2^3, 2^4), RunScale::ROOM_GRAD) against the mix table.
+// W's block c = 0 carries sT as well (the two halves of a contraction meet in one accumulator): sT <= 2^11 keeps it inside fp16.
+constexpr int STC_W_TARGET = 4;             // weight tables: maximum into [2^3, 2^4)
+constexpr int STC_T_TARGET_FWD = 4;         // category-mix tables, forward
+constexpr int STC_T_TARGET_BWD = 2;         // category-mix tables, backward
+__device__ __forceinline__ float clamp_mix_scale(float sT) { return fminf(fmaxf(sT, 0.0625f), 2048.f); }
 
 __device__ __forceinline__ float absmax4(const f32x4 v) {
     return __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])), __builtin_fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3])));
@@ -280,7 +290,7 @@ __device__ __forceinline__ void leave_max(float* __restrict__ row, int slot, flo
 // accumulators sum over the wave's nodes and carry the wave's REFERENCE scale a = 2^k (from the running maximum of the nodes before): a node
 // joins them with its activation operand multiplied by a / a_n -- the product of the two operands then has the accumulators' scale.
 //   a / a_n > 1   the node's gradients exceed everything before: the excess goes to the activation operand (<= 2^8) and, beyond that, into a_n
-//                 itself (<= 2^6: its second-stage operands must fit too): 2^14 of headroom per node; beyond it the node replaces the sums (`restart`);
+//                 itself (<= 2^4: its second-stage operands must fit too): 2^12 of headroom per node; beyond it the node replaces the sums (`restart`);
 //   a / a_n < 1   the node's gradients are small against the wave's: its activation operand shrinks and loses low bits exactly in proportion
 //                 to how little the node adds to the sum.
 // After the node the running maximum is updated; when it has crossed a binade the node loop is LEFT, the accumulators are multiplied by
@@ -290,8 +300,8 @@ __device__ __forceinline__ void leave_max(float* __restrict__ row, int slot, flo
 __device__ __forceinline__ float exp2i(int k) { return __uint_as_float((unsigned)(k + 127) << 23); }
 struct RunScale {
     // Room above the targets: the activation operand of a dW product (plane maximum in [2^5, 2^6)) takes 2^8 more, a gradient fragment (node
-    // maximum in [2^3, 2^4)) 2^6 more -- its second-stage operands (T_c dY: sums of 32 products with a normalised table) must fit fp16 too.
-    static constexpr int ROOM_ACT = 8, ROOM_GRAD = 6;
+    // maximum in [2^3, 2^4)) 2^4 more -- its second-stage operands (T_c dY: sums of 32 products with a normalised table) must fit fp16 too.
+    static constexpr int ROOM_ACT = 8, ROOM_GRAD = 4;
     int amax_bits = 0;                  // running maximum over the wave's nodes so far (bits of a non-negative float)
     int k = 0;                          // accumulators carry 2^k
     static __device__ __forceinline__ bool usable(int bits) { const int e = (bits >> 23) & 255; return e != 0 && e != 255; }
@@ -300,9 +310,9 @@ struct RunScale {
         return kk < -100 ? -100 : (kk > 100 ? 100 : kk);
     }
     // the node's maximum (bits, wave-uniform) -> a_n; shift = (a / a_n) for the activation side and the db sums; restart: the node's
-    // gradients exceed everything the wave has summed so far by more than 2^14 -- beyond what the two fp16 operands can take up -- so the
+    // gradients exceed everything the wave has summed so far by more than 2^12 -- beyond what the two fp16 operands can take up -- so the
     // caller ZEROES its accumulators (constants into registers: unlike a multiplication this costs the node loop no scratch) and the node
-    // becomes the reference.  What is dropped is below (nodes so far) x 2^-14 of what this node adds, in practice many orders less: such
+    // becomes the reference.  What is dropped is below (nodes so far) x 2^-12 of what this node adds, in practice many orders less: such
     // jumps occur where gates saturate (factors e^-x).
     __device__ __forceinline__ float node(int mbits, float& shift, bool& restart) {
         int kn = usable(mbits) ? exponent_for(mbits) : k;

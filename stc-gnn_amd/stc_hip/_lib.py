@@ -93,18 +93,18 @@ def _declare(lib):
         'stc_head_bwd_bf16': [_p, _p, _p, _p, _p, _p, _p, C.c_size_t, _i64, _i32, _p],
         'stc_bdg_node_post_fwd_f32': [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
         'stc_cell_gates_fwd_planar_f32': [_p] * 14 + [_i32, _p, _i64, _i32, _i32, _i32, _p],
-        'stc_cell_gates_bwd_planar_f32': [_p] * 11 + [C.POINTER(_p), _p, _p, _p, _p, _i32, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _p],
-        'stc_cell_bwd_planar_f32': [_p] * 20 + [_i32, _i32, _p, _i32, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _p],
+        'stc_cell_gates_bwd_planar_f32': [_p] * 11 + [C.POINTER(_p), _p, _p, _p, _i32, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _p],
+        'stc_cell_bwd_planar_f32': [_p] * 20 + [_i32, _i32, _i32, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _p],
         'stc_spmm_blend_fwd_f32': [_p] * 6 + [_i32, _i32] + [_p] * 6 + [_p, _i32, _i32, _p, _i32, _p, _i32, _i32] + [_i32] * 3 + [_p],
-        'stc_bdg_node_post_bwd_f32': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _i32, _p],
+        'stc_bdg_node_post_bwd_f32': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _i32, _p],
         'stc_spmm_sum_f32': [_p] * 6 + [_i32, _i32, _p, _p, _f32, _i32, C.POINTER(_p), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_f32), _p, _p, _p, _p,
                              _p, _i32, _i32, _i32, _i32, _p],
         'stc_cell_gates_fwd_planar_k_f32': [C.POINTER(_p), C.POINTER(_p), _i32, _p, _p, _p, _p, _p, _p, _i32, _p, _i64, _i32, _i32, _i32, _p],
         'stc_cell_cand_fwd_planar_k_f32': [C.POINTER(_p), C.POINTER(_p), _i32, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _i64, _i32, _i32, _i32, _p],
         'stc_cell_gates_bwd_planar_k_f32': [C.POINTER(_p), C.POINTER(_p), _i32, _p, _p, _p, _p, _p, _p, _p, C.POINTER(_p), C.POINTER(_p), _p, _p, _p, _i32,
-                                            _p, _i32, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _p],
+                                            _i32, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _p],
         'stc_cell_cand_bwd_planar_k_f32': [C.POINTER(_p), C.POINTER(_p), _i32, _p, _p, _p, _p, _p, C.POINTER(_p), C.POINTER(_p), _p, _p,
-                                           _p, _i32, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _p],
+                                           _i32, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _p],
         'stc_cell_gates_fwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _i32, _p],
         'stc_cell_cand_bwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _p, C.POINTER(_p), _p, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _i32, _p],
         'stc_cell_gates_bwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _i32, C.POINTER(_p), _p, _p, _p, _p,
@@ -225,17 +225,6 @@ class HipKernels:
         self._workspace = {}
         self._retired = []                            # outgrown workspaces, kept alive (see _get_workspace)
         self.timer: Optional[KernelTimer] = None      # set by bench.py to time every launch with HIP events
-
-    def _grad_amax(self, what, given, *planes):
-        """(pointer, count) of the gradient-maximum slots of an fp16 x 2 backward launch: the caller's slots (what ``spmm_sum(amax=)`` left),
-        or -- without them -- the maximum taken here by one more pass over the gradient planes; (None, 0) on the bf16 x 3 format."""
-        if self.operand_format != FMT_F16X2:
-            return None, 0
-        if given is None:
-            given = torch.stack([torch.linalg.vector_norm(p, ord=float('inf')) for p in planes])
-        self._f32(what + '.grad_amax', given)
-        self._same_device(planes[0], given)
-        return given.data_ptr(), given.numel()      # (a temporary made here may be freed after the launch is queued: the allocator is stream-ordered)
 
     ACT_AMAX_SLOTS = 256         # STC_ACT_AMAX_SLOTS: floats per plane row of an activation-maximum buffer
 
@@ -429,7 +418,7 @@ class HipKernels:
         """Y = sum(scale * addend) + alpha * S.(X [+ X2]) on (B, n, C, h) state tensors (stc_spmm_sum_f32).  ``addends``: up to
         eight (tensor, column offset[, scale]) entries -- columns [off, off + h) of a (B, n, C, ld) tensor (a plain plane:
         ld = h, off = 0); scale defaults to 1.  ``amax``: float32 device tensor of slots, ZERO on entry; afterwards its maximum is
-        max |Y| (the ``grad_amax`` operand of ``cell_bwd_planar``)."""
+        max |Y| (an option kept for callers: the cell backward kernels find their gradient scales themselves since ABI v22)."""
         B, n, Cc, h = Y.shape
         self._f32('spmm_sum.Y', Y)
         self._f32('spmm_sum.X', X, (B, n, Cc, h))
@@ -665,10 +654,10 @@ class HipKernels:
                      _ptr(cp[0][0]), cp[0][1], cp[0][2], _ptr(side), side_cin, _ptr(cp[1][0]), cp[1][1], cp[1][2], B, Cc, h,
                      nbytes=colidx.numel() * 8 + 4 * (n + 1) + 4 * B * n * Cc * h * (6 + len(copies)))
 
-    def node_post_bwd(self, X, Tc, W, dA, dB, dX, dW, db, X2=None, dX2=None, grad_amax=None, act_amax=None, out_amax=None):
+    def node_post_bwd(self, X, Tc, W, dA, dB, dX, dW, db, X2=None, dX2=None, act_amax=None):
         """(X, dA = dY, dBm = S^T dY) -> dX, dW, db of the convolution in its post-aggregation form.  Planar (X2 given):
         the gradient comes out as the two planes dX, dX2 as well.  fp16 x 2 format (planar, C = 64): ``act_amax`` = (slots of max |X|, slots of
-        max |X2|), rows of what a forward launch left (R*H takes H's); ``out_amax`` (2, 256) zero floats that receive max |dX|, max |dX2|."""
+        max |X2|), rows of what a forward launch left (R*H takes H's)."""
         Ks, Kc, R, Cc, L, Lw, Ho = self._post_rows(X, X2, Tc, W)
         f16 = X2 is not None and Cc == 64
         narrow = X2 is not None and X2.shape[-1] != 16
@@ -685,10 +674,9 @@ class HipKernels:
         self._same_device(X, X2, Tc, W, dA, dB, dX, dX2, dW, db)
         ws = self._get_workspace(X.device, self.lib.stc_bdg_node_bwd_workspace_bytes(Ks, Kc, Cc, L, Ho, 0))
         self._launch('stc_bdg_node_post_bwd_f32', X, _ptr(X), _ptr(X2), _ptr(Tc), _ptr(W), _ptr(dA), _ptr(dB), _ptr(dX), _ptr(dX2), _ptr(dW), _ptr(db),
-                     *(self._grad_amax('post', grad_amax, dA, dB) if f16 else (None, 0)),      # (the forms built for fp16 x 2)
+                     self.operand_format if f16 else FMT_BF16X3,      # (the forms built for fp16 x 2)
                      self._act_amax('post.x', None if act_amax is None else act_amax[0].view(1, -1), 1, X) if f16 else None,
                      self._act_amax('post.x2', None if act_amax is None else act_amax[1].view(1, -1), 1, X) if f16 else None,
-                     self._act_amax('post.out', out_amax, 2, X) if f16 else None,
                      _ptr(ws), ws.numel(), R, Cc, L, Lw, Ho)
 
     # ---- planar cell inputs (Ks = Kc = 2, cin = h = 16) ---------------------------------------------
@@ -742,7 +730,7 @@ class HipKernels:
                      # algorithmic bytes: X, SX (cin wide), H, SH in; U, Rg (+ RH, + A, Bm) out -- every plane once
                      nbytes=4 * R * Cc * (2 * cin + 2 * h + h * (2 + (RH is not None) + (2 if post is not None else 0))))
 
-    def cell_gates_bwd_planar(self, X, H, SX, SH, Tc, W, dRH, Cand, U, Rg, dHnew, dZs, dW, db, dH, grad_amax=None, act_amax=None):
+    def cell_gates_bwd_planar(self, X, H, SX, SH, Tc, W, dRH, Cand, U, Rg, dHnew, dZs, dW, db, dH, act_amax=None):
         """``dRH``: gradient of the R*H plane; ``dZs`` = [d X plane, d SX plane, d H plane, d SH plane] (the first two
         None for a narrow input plane, which needs no gradient)."""
         R, Cc, h, cin = self._planes('planar', X, H, SX, SH)
@@ -763,7 +751,7 @@ class HipKernels:
         ws = self._get_workspace(H.device, self.lib.stc_bdg_node_bwd_workspace_bytes(2, 2, Cc, 2 * h, 2 * h, 0))
         zp = (_p * 4)(*[0 if z is None else z.data_ptr() for z in dZs])
         self._launch('stc_cell_gates_bwd_planar_f32', H, _ptr(X), _ptr(H), _ptr(SX), _ptr(SH), _ptr(Tc), _ptr(W), _ptr(dRH), _ptr(Cand),
-                     _ptr(U), _ptr(Rg), _ptr(dHnew), zp, _ptr(dW), _ptr(db), _ptr(dH), *self._grad_amax('planar', grad_amax, dHnew, dRH),
+                     _ptr(U), _ptr(Rg), _ptr(dHnew), zp, _ptr(dW), _ptr(db), _ptr(dH), self.operand_format,
                      self._act_amax('planar', act_amax, 4, H), _ptr(ws), ws.numel(), R, Cc, cin + h, h)
 
     # ---- the whole backward of a planar cell step in one launch ----------------------------------------
@@ -771,14 +759,13 @@ class HipKernels:
         return bool(self.lib.stc_cell_bwd_planar_supported(Cc, h))
 
     def cell_bwd_planar(self, X, H, SX, SH, Tc, Wg, Wc, U, Rg, Cand, dHnew, dBm, dZs, dWg, dbg, dWc, dbc, accumulate_x=False, accumulate_h=False,
-                        grad_amax=None, act_amax=None):
+                        act_amax=None):
         """Candidate (post-aggregation form) + gates backward of one planar cell step in one launch.  ``dBm`` = S^T dY with
         dY = dHnew U (1 - Cand^2) (the kernel re-forms dY itself); ``dZs`` = [dX, dSX, dH, dSH] gradient planes: dX = the candidate's
         plus the gates' share of the X plane, dH includes the gate prologue's share (dX, dSX None for a narrow input plane).
         ``accumulate_x`` / ``accumulate_h``: the X-side / H-side planes already hold the state's other consumer's gradients; add to them.
-        ``grad_amax`` (fp16 x 2 operand format): float32 device tensor whose maximum is max |dHnew| -- what ``spmm_sum(amax=)`` left
-        when it produced dHnew; without it the maximum is taken here by one more pass over dHnew.  ``act_amax``: the (4, 256) plane maxima
-        the forward launch (``cell_gates_fwd_planar(act_amax=)``) left for the same X, H, SX, SH."""
+        ``act_amax`` (fp16 x 2 operand format): the (4, 256) plane maxima the forward launch (``cell_gates_fwd_planar(act_amax=)``) left for the
+        same X, H, SX, SH; gradient scales the kernel finds itself."""
         R, Cc, h, cin = self._planes('cell_bwd', X, H, SX, SH)
         self._f32('cell_bwd.Tc', Tc, (2, Cc, Cc))
         self._f32('cell_bwd.Wg', Wg, (4 * (cin + h), 2 * h))
@@ -801,10 +788,9 @@ class HipKernels:
         ws = self._get_workspace(H.device, self.lib.stc_cell_bwd_planar_workspace_bytes(Cc, 2 * h, h))
         if accumulate_x and cin != h:
             raise StcError('cell backward: accumulate_x with a narrow input plane (it gets no gradient)')
-        amax_ptr, amax_n = self._grad_amax('cell_bwd', grad_amax, dHnew)
         self._launch('stc_cell_bwd_planar_f32', H, _ptr(X), _ptr(H), _ptr(SX), _ptr(SH), _ptr(Tc), _ptr(Wg), _ptr(Wc), _ptr(U), _ptr(Rg), _ptr(Cand),
                      _ptr(dHnew), _ptr(dBm), *[_ptr(z) for z in dZs], _ptr(dWg), _ptr(dbg), _ptr(dWc), _ptr(dbc), int(bool(accumulate_x)), int(bool(accumulate_h)),
-                     amax_ptr, amax_n, self._act_amax('cell_bwd', act_amax, 4, H), _ptr(ws), ws.numel(), R, Cc, cin + h, h,
+                     self.operand_format, self._act_amax('cell_bwd', act_amax, 4, H), _ptr(ws), ws.numel(), R, Cc, cin + h, h,
                      # algorithmic bytes: X, SX (cin wide), H, SH, U, Rg, Cand, dHnew, dBm in; dH, dSH (+ dX, dSX) out; a plane that is
                      # accumulated into is also read -- every plane once
                      nbytes=4 * R * Cc * (2 * cin + 7 * h + 2 * h * (1 + bool(accumulate_h)) + (2 * h * (1 + bool(accumulate_x)) if cin == h else 0)),
@@ -1021,7 +1007,7 @@ class HipKernels:
             self._f32(f'{what}.dZx[{n}]', dZx[n], (R, Cc, cin))
         return (_p * K)(*[0 if z is None else z.data_ptr() for z in dZx]), (_p * K)(*[z.data_ptr() for z in dZh])
 
-    def cell_gates_bwd_planar_k(self, Zx, Zh, Tc, W, dRH, Cand, U, Rg, dHnew, dZx, dZh, dW, db, dH, accumulate_x=False, grad_amax=None, act_amax=None):
+    def cell_gates_bwd_planar_k(self, Zx, Zh, Tc, W, dRH, Cand, U, Rg, dHnew, dZx, dZh, dW, db, dH, accumulate_x=False, act_amax=None):
         """``accumulate_x``: the X-side planes ``dZx`` hold the candidate's gradients of the same planes; the gates' are added to them
         (wide input, ``dH=None`` only)."""
         K, R, Cc, h, cin = self._planes_k('planar_k gates bwd', Zx, Zh, Tc, W, 2 * Zh[0].shape[-1])
@@ -1037,9 +1023,9 @@ class HipKernels:
         ws = self._get_workspace(U.device, self.lib.stc_bdg_node_bwd_workspace_bytes(K, K, Cc, 2 * h, 2 * h, 0))
         self._launch('stc_cell_gates_bwd_planar_k_f32', U, self._ptr_array(Zx), self._ptr_array(Zh), K, _ptr(Tc), _ptr(W), _ptr(dRH), _ptr(Cand),
                      _ptr(U), _ptr(Rg), _ptr(dHnew), zx, zh, _ptr(dW), _ptr(db), _ptr(dH), int(bool(accumulate_x)),
-                     *self._grad_amax('planar_k', grad_amax, dHnew, dRH), self._act_amax('planar_k', act_amax, 2 * K, U), _ptr(ws), ws.numel(), R, Cc, cin + h, h)
+                     self.operand_format, self._act_amax('planar_k', act_amax, 2 * K, U), _ptr(ws), ws.numel(), R, Cc, cin + h, h)
 
-    def cell_cand_bwd_planar_k(self, Zx, Zh, Tc, W, dHnew, U, Cand, dZx, dZh, dW, db, grad_amax=None, act_amax=None):
+    def cell_cand_bwd_planar_k(self, Zx, Zh, Tc, W, dHnew, U, Cand, dZx, dZh, dW, db, act_amax=None):
         K, R, Cc, h, cin = self._planes_k('planar_k cand bwd', Zx, Zh, Tc, W, Zh[0].shape[-1])
         for name, t in (('dHnew', dHnew), ('U', U), ('Cand', Cand)):
             self._f32('planar_k.' + name, t, (R, Cc, h))
@@ -1050,7 +1036,7 @@ class HipKernels:
         self._same_device(*Zx, *Zh, Tc, W, dHnew, U, Cand, *dZx, *dZh, dW, db)
         ws = self._get_workspace(U.device, self.lib.stc_bdg_node_bwd_workspace_bytes(K, K, Cc, 2 * h, 2 * h, 0))
         self._launch('stc_cell_cand_bwd_planar_k_f32', U, self._ptr_array(Zx), self._ptr_array(Zh), K, _ptr(Tc), _ptr(W), _ptr(dHnew), _ptr(U), _ptr(Cand),
-                     zx, zh, _ptr(dW), _ptr(db), *self._grad_amax('planar_k', grad_amax, dHnew), self._act_amax('planar_k', act_amax, 2 * K, U),
+                     zx, zh, _ptr(dW), _ptr(db), self.operand_format, self._act_amax('planar_k', act_amax, 2 * K, U),
                      _ptr(ws), ws.numel(), R, Cc, cin + h, h)
 
     # ---- fused cell convolutions ----------------------------------------------------------

@@ -722,25 +722,14 @@ class _StcCellGraph(Function):
             pc['direct'] += [(t, 0) for t in direct]
             pc['agg'].append(aggregated)
 
-        # fp16 x 2 operand format of the one-launch cell backward: the launch scales its gradient operands by a power of two taken from
-        # max |dHnew|, which the state-gradient SpMM that produces dHnew leaves in a row of slots (one zero fill per backward pass)
-        n_slots = 256
-        amax_rows = {}
-        f16x2 = not bf16_planes and getattr(k, 'operand_format', 0) == 1
+        # fp16 x 2 operand format: the backward launches scale the activation operands of their dW products by the plane maxima the forward
+        # launches left (gradient scales they find themselves, per node)
         zmax_all = ctx.zmax_all
 
-        def act_slots(j, which=0):                                   # what cell j's forward launches left: the activation scales of its dW products
+        def act_slots(j, which=0):                                   # what cell j's forward launches left
             return {} if zmax_all is None else dict(act_amax=zmax_all[j, which])
 
-        def amax_slots(kid, which=0):
-            """Row ``which`` of cell ``kid``'s slots: 0 = its state gradient dHnew; 1 = the gradient of its R*H plane (order 3), or 1, 2 = the
-            gradients of the candidate's two input planes (two-launch backward: what ``node_post_bwd`` leaves)."""
-            if 'all' not in amax_rows:
-                amax_rows['all'] = grad_stack.new_zeros(len(schedule), 3, n_slots, dtype=torch.float32)
-            amax_rows.setdefault(kid, amax_rows['all'][kid])
-            return amax_rows[kid][which]
-
-        def owed(kid, blend=None, want_amax=False):
+        def owed(kid, blend=None):
             """The gradient of state ``kid``; with ``blend`` = (U, Cand) of its cell also dY = gradient * U * (1 - Cand^2)."""
             base = G.pop(kid, None)                                  # from interleaved consumers / the outputs: a finished tensor
             pc = pieces.pop(kid, None)
@@ -760,7 +749,7 @@ class _StcCellGraph(Function):
             out = aggs[0].new_empty(B, N, C, h)
             dY = torch.empty_like(out) if blend is not None else None
             k.spmm_sum(*bwd, op.bwd_plan, aggs[0], aggs[1] if len(aggs) > 1 else None, add, out,
-                       blend=None if blend is None else (blend[0], blend[1], dY), **(dict(amax=amax_slots(kid, 0)) if want_amax else {}))
+                       blend=None if blend is None else (blend[0], blend[1], dY))
             return out if blend is None else (out, dY)
 
         # Order 3: a consumer leaves direct planes d0 and the gradients d1, d2 of the S / T_2(S) planes; the source's gradient is
@@ -770,9 +759,9 @@ class _StcCellGraph(Function):
             pc = pieces.setdefault(kid, dict(d0=[], d1=[], d2=[]))
             pc['d0'] += list(d0); pc['d1'] += list(d1); pc['d2'] += list(d2)
 
-        def clenshaw(d0, d1, d2, blend=None, amax=None):
+        def clenshaw(d0, d1, d2, blend=None):
             """sum d0 - sum d2 + S^T (sum d1 + 2 S^T sum d2) from lists of planes (d2 non-empty); with ``blend`` = (U, Cand) also
-            dY = result * U * (1 - Cand^2) from the second launch's epilogue; ``amax``: slots that receive max |result|."""
+            dY = result * U * (1 - Cand^2) from the second launch's epilogue."""
             while len(d2) > 2:                                       # the kernel gathers two operands: pre-sum the rest
                 d2 = [d2[0] + d2[1]] + d2[2:]
             t = d2[0].new_empty(B, N, C, h)
@@ -783,11 +772,10 @@ class _StcCellGraph(Function):
                 adds.insert(0, (a + b_, 0))
             out = t.new_empty(B, N, C, h)
             dY = torch.empty_like(out) if blend is not None else None
-            k.spmm_sum(*bwd, op.bwd_plan, t, None, adds, out, blend=None if blend is None else (blend[0], blend[1], dY),
-                       **({} if amax is None else dict(amax=amax)))
+            k.spmm_sum(*bwd, op.bwd_plan, t, None, adds, out, blend=None if blend is None else (blend[0], blend[1], dY))
             return out if blend is None else (out, dY)
 
-        def owed3(kid, blend=None, want_amax=False):
+        def owed3(kid, blend=None):
             base = G.pop(kid, None)
             pc = pieces.pop(kid, None)
             if pc is None:
@@ -796,7 +784,7 @@ class _StcCellGraph(Function):
                 dY = torch.empty_like(base)
                 k.gru_blend_bwd(base, blend[0], None, blend[1], dY, None, None)
                 return base, dY
-            return clenshaw(pc['d0'] + ([base] if base is not None else []), pc['d1'], pc['d2'], blend, amax=amax_slots(kid, 0) if want_amax else None)
+            return clenshaw(pc['d0'] + ([base] if base is not None else []), pc['d1'], pc['d2'], blend)
 
         for j in range(len(schedule) - 1, -1, -1):
             if j not in G and j not in pieces:
@@ -810,14 +798,12 @@ class _StcCellGraph(Function):
                 new = lambda: torch.empty_like(Hprev)
                 dWg, dbg, dWc, dbc = grads_for(s_id)
                 Zr = rest[5:8]                                       # slab-planar candidate
-                dHnew = owed3(j, want_amax=f16x2)
-                have = f16x2 and j in amax_rows                      # (no pieces: the wrapper takes the maximum itself)
+                dHnew = owed3(j)
                 dXc, dR = ([new(), new(), new()] if wide else [None] * 3), [new(), new(), new()]
                 k.cell_cand_bwd_planar_k(rows(Zx), rows(Zr), Tc, Wc, *rows((dHnew, U, Cand)),
-                                         [None if t is None else t.view(B * N, C, h) for t in dXc], rows(dR), dWc, dbc,
-                                         **(dict(grad_amax=amax_rows[j][0]) if have else {}), **act_slots(j, 1))
-                # gradient of the R*H plane from its three Chebyshev planes (its maximum beside dHnew's: the gates backward scales by both)
-                dRH = clenshaw([dR[0]], [dR[1]], [dR[2]], amax=amax_slots(j, 1) if have else None)
+                                         [None if t is None else t.view(B * N, C, h) for t in dXc], rows(dR), dWc, dbc, **act_slots(j, 1))
+                # gradient of the R*H plane from its three Chebyshev planes
+                dRH = clenshaw([dR[0]], [dR[1]], [dR[2]])
                 del dR
                 fold = getattr(k, 'folds_dH', False)                  # the kernel adds the prologue's share into the H plane's gradient
                 # slab-planar candidate on a wide input: the gates' X-side gradients are ADDED into the candidate's three planes by the
@@ -827,8 +813,7 @@ class _StcCellGraph(Function):
                 dHg, dH = [new(), new(), new()], (None if fold else new())
                 k.cell_gates_bwd_planar_k(rows(Zx), rows(Zh), Tc, Wg, *rows((dRH, Cand, U, Rg, dHnew)),
                                           [None if t is None else t.view(B * N, C, h) for t in dXg], rows(dHg), dWg, dbg,
-                                          None if fold else dH.view(B * N, C, h), accumulate_x=into,
-                                          **(dict(grad_amax=amax_rows[j].view(-1)) if have else {}), **act_slots(j, 0))
+                                          None if fold else dH.view(B * N, C, h), accumulate_x=into, **act_slots(j, 0))
                 if into:
                     dXc = [None] * 3
                 if wide and x[0] == 'cell':
@@ -840,8 +825,7 @@ class _StcCellGraph(Function):
             post_form = n_saved[j] < 0 or (len(rest) == Ks + 1 and Ks > 1)     # candidate backward starts from dY = dHnew * U * (1 - Cand^2)
             if Ks == 3 and j in pieces:                              # an interleaved cell whose state order-3 planar cells consumed
                 G[j] = owed3(j)
-            # fp16 x 2 operand format: the planar backward kernels scale their gradient operands from max |dHnew|, left by the sum that forms it
-            dHnew, dY = owed(j, (U, Cand), want_amax=f16x2 and n_saved[j] in (-7, -8)) if post_form else (owed(j), None)
+            dHnew, dY = owed(j, (U, Cand)) if post_form else (owed(j), None)
             dH = None if (n_saved[j] == -7 or (n_saved[j] < 0 and getattr(k, 'folds_dH', False))) else torch.empty_like(Hprev)
             if n_saved[j] == -7:                                     # planar cell, candidate + gates backward in ONE launch
                 Xp, SXp, SHp = rest
@@ -873,21 +857,18 @@ class _StcCellGraph(Function):
                 dHd, dSH, acc_h = planes_of_state(hs)
                 k.cell_bwd_planar(*rows((Xp, Hprev, SXp, SHp)), Tc, Wg, Wc, *rows((U, Rg, Cand, dHnew, dBm)),
                                   [None if t is None else t.view(B * N, C, h) for t in (dXd, dSX, dHd, dSH)], dWg, dbg, dWc, dbc,
-                                  accumulate_x=acc_x, accumulate_h=acc_h, **(dict(grad_amax=amax_rows[j][0]) if j in amax_rows else {}), **act_slots(j))
+                                  accumulate_x=acc_x, accumulate_h=acc_h, **act_slots(j))
                 continue                                             # (parameter gradients: rows of the set's buffer, summed at the end)
             if n_saved[j] < 0:                                       # planar cell: inputs and gradients as planes
                 Xp, SXp, SHp, RH = rest
-                amax_kw = dict(grad_amax=amax_rows[j][0]) if j in amax_rows else {}      # |dY| <= |dHnew|, |S^T dY| within the format's headroom
                 wide = cin[j] == h                                   # else: narrow input plane (layer 0), which needs no gradient
-                post_kw, gates_kw = dict(amax_kw), dict(amax_kw)
-                if j in amax_rows and zmax_all is not None:
+                post_kw, gates_kw = {}, {}
+                if zmax_all is not None:
                     # the candidate's input planes are (X, R*H): X's maximum as the gates forward left it, R*H rides on H's (|R*H| <= |H|).  Slot
                     # rows of that launch: wide {X, S.X, H, S.H}, narrow {H, S.H, x, S.x}; the post kernel takes (16-wide plane, other plane).
                     zr = zmax_all[j, 0]
-                    post_kw.update(act_amax=(zr[0], zr[2]), out_amax=amax_rows[j][1:3])
-                    # the gates backward's gradient operands are dHnew AND the R*H plane's gradient, which the launch above measures (rows 1, 2:
-                    # max |dX|, max |dX2| -- the R*H gradient is one of them, the X plane's candidate share the other: both bound it)
-                    gates_kw.update(grad_amax=amax_rows[j].view(-1), act_amax=zr)
+                    post_kw.update(act_amax=(zr[0], zr[2]))
+                    gates_kw.update(act_amax=zr)
                 dBm = narrow_transpose_aggregation(dY)
                 dRH = torch.empty_like(Hprev)
                 dWg, dbg, dWc, dbc = grads_for(s_id)
