@@ -207,29 +207,6 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
     __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0), expcnt / lgkmcnt untouched
     while (node < a.nodes) {
         const int next_node = node + nw;
-        if constexpr (F::SCALED) {                                 // the running maxima crossed a binade: bring the accumulators to the new reference scales
-            const float pc = rc.pending(), pg = rg.pending();
-            if (pc != 1.f) {
-#pragma unroll
-                for (int n = 0; n < K; ++n)
-#pragma unroll
-                    for (int lb = 0; lb < LB; ++lb)
-#pragma unroll
-                        for (int c = 0; c < K; ++c) dWc[n][lb][c][0] *= pc;
-                dbc[0] *= pc;
-            }
-            if (pg != 1.f) {
-#pragma unroll
-                for (int n = 0; n < K; ++n)
-#pragma unroll
-                    for (int lb = 0; lb < LB; ++lb)
-#pragma unroll
-                        for (int c = 0; c < K; ++c)
-#pragma unroll
-                            for (int hb = 0; hb < 2; ++hb) dWg[n][lb][c][hb] *= pg;
-                dbg[0] *= pg; dbg[1] *= pg;
-            }
-        }
         // ACCX / ACCH: what the gradient planes already hold (tile layout: row 16rb + x, columns 4g .. 4g+3).  Requested for THIS node, before
         // the next node's operands (vmcnt counts in order); first used in the gates phase, microseconds from here.
         f32x4 old[K][LB][NRB];
@@ -270,7 +247,8 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
                     for (int kb = 0; kb < NRB; ++kb) m = __builtin_fmaxf(m, __builtin_fmaxf(absmax4(v0[kb]), absmax4(v1[kb])));
                     bool restart;
                     a_c = rc.node(wave_max_bits(m), sh_c, restart);
-                    if (restart) {
+                    if (__builtin_expect(restart, 0)) {
+                        asm volatile("; the node replaces the sums" ::: "memory");      // (keeps this a branch: as a select it would touch every accumulator on every node)
 #pragma unroll
                         for (int n = 0; n < K; ++n)
 #pragma unroll
@@ -280,7 +258,7 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
                         dbc[0] = 0.f;
                     }
 #pragma unroll
-                    for (int kb = 0; kb < NRB; ++kb) { v0[kb] = mul4(v0[kb], a_c); v1[kb] = mul4(v1[kb], a_c); }
+                    for (int kb = 0; kb < NRB; ++kb) { v0[kb] *= a_c; v1[kb] *= a_c; }
                 }
                 to_acc(0, v0, d0);
                 to_acc(1, v1, d1);
@@ -322,9 +300,9 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
 #pragma unroll
                 for (int rb = 0; rb < NRB; ++rb) {
                     if (lb == RHB) {                               // out of the scaled space: the prologue works on plain values
-                        if constexpr (F::SCALED) drh[rb] = mul4(z[rb], ikc * inv_pow2(a_c)); else drh[rb] = z[rb];
+                        if constexpr (F::SCALED) drh[rb] = z[rb] * (ikc * inv_pow2(a_c)); else drh[rb] = z[rb];
                     } else {                                       // the X plane's share: becomes the start of a gates tile (factor kg here, the gates' scale there)
-                        if constexpr (F::SCALED) z[rb] = mul4(z[rb], ikc * inv_pow2(a_c) * kg);
+                        if constexpr (F::SCALED) z[rb] *= ikc * inv_pow2(a_c) * kg;
                         stash_x[rb * 64 + lane] = make_float4(z[rb][0], z[rb][1], z[rb][2], z[rb][3]);
                     }
                 }
@@ -345,7 +323,7 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
                     c1[t] = lb == RHB ? rh_d[1][t] : zg[0][lb][1][t];
                 }
                 Op za;
-                if constexpr (F::SCALED) za = F::split(mul4(c0, sz[0][lb] * sh_c), mul4(c1, sz[0][lb] * sh_c)); else za = F::split(c0, c1);
+                if constexpr (F::SCALED) za = F::split(c0 * (sz[0][lb] * sh_c), c1 * (sz[0][lb] * sh_c)); else za = F::split(c0, c1);
 #pragma unroll
                 for (int n = 0; n < K; ++n)
 #pragma unroll
@@ -377,7 +355,8 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
                 for (int kb = 0; kb < NRB; ++kb) m = __builtin_fmaxf(m, __builtin_fmaxf(absmax4(v0[kb]), absmax4(v1[kb])));
                 bool restart;
                 a_g = rg.node(wave_max_bits(m), sh_g, restart);
-                if (restart) {
+                if (__builtin_expect(restart, 0)) {
+                        asm volatile("; the node replaces the sums" ::: "memory");      // (keeps this a branch: as a select it would touch every accumulator on every node)
 #pragma unroll
                     for (int n = 0; n < K; ++n)
 #pragma unroll
@@ -389,7 +368,7 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
                     dbg[0] = 0.f; dbg[1] = 0.f;
                 }
 #pragma unroll
-                for (int kb = 0; kb < NRB; ++kb) { v0[kb] = mul4(v0[kb], a_g); v1[kb] = mul4(v1[kb], a_g); }
+                for (int kb = 0; kb < NRB; ++kb) { v0[kb] *= a_g; v1[kb] *= a_g; }
             }
             to_acc(3, v0, d0);
             to_acc(4, v1, d1);
@@ -435,11 +414,11 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
                     if (n == 0 && lb == RHB) {                     // the H plane's tile starts from the prologue's share
                         const float4 sh = stash_h[rb * 64 + lane];
                         z[rb] = f32x4{sh.x, sh.y, sh.z, sh.w};
-                        if constexpr (F::SCALED) z[rb] = mul4(z[rb], a_g);      // (parked with the factor kg only)
+                        if constexpr (F::SCALED) z[rb] *= a_g;      // (parked with the factor kg only)
                     } else if (n == 0) {                           // the X plane's tile from the candidate's share (PL = 1)
                         const float4 sh = stash_x[rb * 64 + lane];
                         z[rb] = f32x4{sh.x, sh.y, sh.z, sh.w};
-                        if constexpr (F::SCALED) z[rb] = mul4(z[rb], a_g);
+                        if constexpr (F::SCALED) z[rb] *= a_g;
                     } else {
                         z[rb] = kZero4;
                     }
@@ -459,8 +438,8 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
                 for (int rb = 0; rb < NRB; ++rb) {
                     if constexpr (F::SCALED) {                     // out of the scaled space (+ the other consumer's gradients of the same plane)
                         const float ikg_n = ikg * inv_pow2(a_g);
-                        if (ACC[lb]) z[rb] = fma4(z[rb], ikg_n, old[n][lb][rb]);
-                        else z[rb] = mul4(z[rb], ikg_n);
+                        if (ACC[lb]) z[rb] = z[rb] * ikg_n + old[n][lb][rb];
+                        else z[rb] *= ikg_n;
                     }
                     stc_st_once(reinterpret_cast<f32x4*>(dP[n][lb] + (r0 + 16 * rb + x) * HID + 4 * g), z[rb]);
                 }
@@ -485,7 +464,7 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
                 Op za;
                 if constexpr (F::SCALED) {
                     const float zs = sz[n][lb] * sh_g;
-                    za = F::split(f32x4{zc[0][0] * zs, zc[0][1] * zs, zc[0][2] * zs, zc[0][3] * zs}, f32x4{zc[1][0] * zs, zc[1][1] * zs, zc[1][2] * zs, zc[1][3] * zs});
+                    za = F::split(f32x4{zc[0][0], zc[0][1], zc[0][2], zc[0][3]} * zs, f32x4{zc[1][0], zc[1][1], zc[1][2], zc[1][3]} * zs);
                 }
                 else za = F::split(f32x4{zc[0][0], zc[0][1], zc[0][2], zc[0][3]}, f32x4{zc[1][0], zc[1][1], zc[1][2], zc[1][3]});
 #pragma unroll
@@ -499,7 +478,7 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
     }
 
     // dW tiles of block c carry the wave's final gradient scale (c = 0) or that times sT (c = 1: Q_1 = T_1 dY); db carries the scale
-    const float isg_g = exp2i(-rg.k), isg_c = exp2i(-rc.k);
+    const float isg_g = exp2i(rg.k > 100 ? 0 : -rg.k), isg_c = exp2i(rc.k > 100 ? 0 : -rc.k);      // (a wave that met no node: sums of zeros)
     PlaneUnscale<K, LB> pug, puc;
 #pragma unroll
     for (int n = 0; n < K; ++n)

@@ -665,20 +665,6 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
     if (PFG && node < nodes) { rows_cur.template load<PRO == PRO_GATES_CAND>(pro, node, x, g); in.load_z(Z, node, x, g, Lw - 16); }
     if (PF || PFG) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) before the loop: see node_fwd_x3_kernel
     while (node < nodes) {
-      if constexpr (F::SCALED) {                               // (re-)entry of the node loop: the accumulators to the wave's current reference scale
-        const float pr = rs.pending();
-#pragma unroll
-        for (int n = 0; n < K; ++n)
-#pragma unroll
-            for (int lb = 0; lb < LB; ++lb)
-#pragma unroll
-                for (int c = 0; c < K; ++c)
-#pragma unroll
-                    for (int hb = 0; hb < HB; ++hb) dWt[n][lb][c][hb] *= pr;
-#pragma unroll
-        for (int hb = 0; hb < HB; ++hb) dbp[hb] *= pr;
-      }
-      do {
         const int next_node = node + nw;
         const size_t r0 = (size_t)node * C;
         f32x4 old[K][NRB];                                     // ACC: what the X-side planes already hold, requested BEFORE the prefetch (vmcnt counts in order)
@@ -712,7 +698,8 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
                 for (int hb = 0; hb < HB; ++hb) m = __builtin_fmaxf(m, absmax4(in.g.v[kb][hb]));
             bool restart;
             sg = rs.node(wave_max_bits(m), sh, restart);
-            if (restart) {
+            if (__builtin_expect(restart, 0)) {
+                        asm volatile("; the node replaces the sums" ::: "memory");      // (keeps this a branch: as a select it would touch every accumulator on every node)
 #pragma unroll
                 for (int n = 0; n < K; ++n)
 #pragma unroll
@@ -879,9 +866,8 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
                         for (int t = 0; t < 4; ++t) in.za[n][lb][kb][t] = nx.za[n][lb][kb][t];
         }
         node = next_node;
-      } while (node < nodes && !(F::SCALED && rs.changed()));
     }
-    const float isg = exp2i(-rs.k);                            // dW tiles of block c carry the wave's final gradient scale (c = 0) or that times sT (c >= 1); db the scale
+    const float isg = exp2i(rs.k > 100 ? 0 : -rs.k);                            // dW tiles of block c carry the wave's final gradient scale (c = 0) or that times sT (c >= 1); db the scale
     PlaneUnscale<K, LB> pu;
 #pragma unroll
     for (int n = 0; n < K; ++n)
@@ -1074,23 +1060,6 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
 
     for (int node = blockIdx.x * MF_WAVES + wave; node < nodes; node += nw) {
         const size_t r0 = (size_t)node * C;
-        if constexpr (F::SCALED) {                             // the running maximum crossed a binade: bring the accumulators to the new reference scale
-            const float pr = rs.pending();
-            __builtin_amdgcn_sched_barrier(0);
-            if (pr != 1.f) {
-#pragma unroll
-                for (int n = 0; n < K; ++n)
-#pragma unroll
-                    for (int lb = 0; lb < LB; ++lb)
-#pragma unroll
-                        for (int c = 0; c < K; ++c)
-#pragma unroll
-                            for (int hb = 0; hb < HB; ++hb) dWt[n][lb][c][hb] *= pr;
-#pragma unroll
-                for (int hb = 0; hb < HB; ++hb) dbp[hb] *= pr;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
         DyFrag<NRB, HB> gr[K];
         gr[0].load(dA, node, x, g);
         gr[1].load(dB, node, x, g);
@@ -1105,7 +1074,8 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
                     for (int hb = 0; hb < HB; ++hb) m = __builtin_fmaxf(m, absmax4(gr[n].v[kb][hb]));
             bool restart;
             const float sg = rs.node(wave_max_bits(m), sh, restart);
-            if (restart) {
+            if (__builtin_expect(restart, 0)) {
+                        asm volatile("; the node replaces the sums" ::: "memory");      // (keeps this a branch: as a select it would touch every accumulator on every node)
 #pragma unroll
                 for (int n = 0; n < K; ++n)
 #pragma unroll
@@ -1266,7 +1236,7 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
                             dWt[n][lb][c][hb] = F::mm(a, c == 0 ? gd[n][hb][p] : qd[n][hb][p], dWt[n][lb][c][hb]);
             }
     }
-    const float isg = exp2i(-rs.k);
+    const float isg = exp2i(rs.k > 100 ? 0 : -rs.k);
     PlaneUnscale<K, LB> pu;
 #pragma unroll
     for (int n = 0; n < K; ++n)

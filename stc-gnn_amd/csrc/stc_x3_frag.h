@@ -290,56 +290,39 @@ __device__ __forceinline__ void leave_max(float* __restrict__ row, int slot, flo
 
 // GRADIENT operands of the fp16 x 2 format.  What the gate prologues form (dHnew (Cand - H) U (1 - U), dRH H R (1 - R), dHnew U (1 - Cand^2)) can
 // sit many binades below the state gradient (with states of 1e-8 round 3's launch-wide scale, taken from max |dHnew|, flushed them to zero),
-// and nothing is known about them before the launch.  So every NODE's gradient fragments get their own power of two a_n, from the node's own
-// maximum (a wave reduction; target [2^3, 2^4)): the dZ tiles, which belong to the node, are unscaled by 1 / a_n on the spot.  The dW / db
-// accumulators sum over the wave's nodes and carry the wave's REFERENCE scale a = 2^k (from the running maximum of the nodes before): a node
-// joins them with its activation operand multiplied by a / a_n -- the product of the two operands then has the accumulators' scale.
-//   a / a_n > 1   the node's gradients exceed everything before: the excess goes to the activation operand (<= 2^8) and, beyond that, into a_n
-//                 itself (<= 2^4: its second-stage operands must fit too): 2^12 of headroom per node; beyond it the node replaces the sums (`restart`);
-//   a / a_n < 1   the node's gradients are small against the wave's: its activation operand shrinks and loses low bits exactly in proportion
-//                 to how little the node adds to the sum.
-// After the node the running maximum is updated; when it has crossed a binade the node loop is LEFT, the accumulators are multiplied by
-// a_new / a_old (exact) and the loop is entered again: the multiplication of ~100 accumulator registers inside the loop body -- even at its
-// top, even behind scheduling barriers -- cost the one-wave-per-SIMD kernels 24 - 270 bytes of scratch per lane, outside it nothing.  The
-// wave's final 1 / a goes into the combine.  All bookkeeping is integer arithmetic on exponents (scalar unit).
+// differ by tens of binades from node to node where gates saturate, and nothing is known about them before the launch.  So every NODE's
+// gradient fragments get their own power of two a_n = 2^kn, from the node's own maximum (a wave reduction; target [2^3, 2^4)): the dZ tiles,
+// which belong to the node, are unscaled by 1 / a_n on the spot.  The dW / db accumulators sum over the wave's nodes and carry the wave's
+// REFERENCE scale a = 2^k, set by the first gradient the wave meets: a node joins them with its activation operand multiplied by
+// a / a_n = 2^j -- the product of the two operands then has the accumulators' scale.
+//   j < 0             the node's gradients are small against the reference: its activation operand shrinks and loses low bits exactly in
+//                     proportion to how little the node adds to the sum;
+//   0 < j <= 8 + 4    the node exceeds the reference: the excess goes to the activation operand (plane maximum in [2^5, 2^6): 2^8 of room)
+//                     and, beyond that, into a_n itself (2^4: the fragment's second-stage operands T_c dY -- sums of 32 products with a table
+//                     below 2^2 -- must fit fp16 too);
+//   j > 12            the node REPLACES the sums: the accumulators are zeroed (constants into registers: unlike a multiplication, which put
+//                     10 - 50 scratch accesses per node into these one-wave-per-SIMD loops even in a never-taken branch, this costs nothing)
+//                     and the node becomes the reference.  What is dropped is below (nodes so far) x 2^-12 of what the node adds; jumps of
+//                     that size between the nodes of one wave occur where gates saturate (factors e^-x: then by tens of binades), or when the
+//                     wave's first node carries no gradient at all.
+// The wave's final 1 / a goes into the combine.  All bookkeeping is integer arithmetic on exponents (scalar unit); a zero maximum gives the
+// largest scale (harmless), a non-finite one the smallest (the NaN goes where it has to).
 __device__ __forceinline__ float exp2i(int k) { return __uint_as_float((unsigned)(k + 127) << 23); }
 struct RunScale {
-    // Room above the targets: the activation operand of a dW product (plane maximum in [2^5, 2^6)) takes 2^8 more, a gradient fragment (node
-    // maximum in [2^3, 2^4)) 2^4 more -- its second-stage operands (T_c dY: sums of 32 products with a normalised table) must fit fp16 too.
     static constexpr int ROOM_ACT = 8, ROOM_GRAD = 4;
-    int amax_bits = 0;                  // running maximum over the wave's nodes so far (bits of a non-negative float)
-    int k = 0;                          // accumulators carry 2^k
-    static __device__ __forceinline__ bool usable(int bits) { const int e = (bits >> 23) & 255; return e != 0 && e != 255; }
-    static __device__ __forceinline__ int exponent_for(int bits) {      // k with max 2^k in [2^3, 2^4)
-        int kk = 4 - (((bits >> 23) & 255) - 126);
-        return kk < -100 ? -100 : (kk > 100 ? 100 : kk);
-    }
-    // the node's maximum (bits, wave-uniform) -> a_n; shift = (a / a_n) for the activation side and the db sums; restart: the node's
-    // gradients exceed everything the wave has summed so far by more than 2^12 -- beyond what the two fp16 operands can take up -- so the
-    // caller ZEROES its accumulators (constants into registers: unlike a multiplication this costs the node loop no scratch) and the node
-    // becomes the reference.  What is dropped is below (nodes so far) x 2^-12 of what this node adds, in practice many orders less: such
-    // jumps occur where gates saturate (factors e^-x).
+    int k = 120;                        // accumulators carry 2^k; the start value makes the first node a restart (of sums that are zero)
+    // mbits: the node's gradient maximum (bits of a non-negative float, wave-uniform) -> a_n; shift = a / a_n for the activation side and the
+    // db sums; restart: zero the accumulators first
     __device__ __forceinline__ float node(int mbits, float& shift, bool& restart) {
-        int kn = usable(mbits) ? exponent_for(mbits) : k;
-        if (amax_bits == 0 && usable(mbits)) k = kn;                      // the first gradient the wave meets: its accumulators are still zero
+        int kn = 130 - ((mbits >> 23) & 255);                             // max 2^kn in [2^3, 2^4)
+        kn = kn < -100 ? -100 : (kn > 100 ? 100 : kn);
         int j = k - kn;
         restart = j > ROOM_ACT + ROOM_GRAD;
-        if (restart) { k = kn; j = 0; amax_bits = mbits; }
-        if (j > ROOM_ACT) { kn += j - ROOM_ACT; j = ROOM_ACT; }
-        if (j < -100) j = -100;
-        if (usable(mbits) && mbits > amax_bits) amax_bits = mbits;
-        shift = exp2i(j);
-        return exp2i(kn);
-    }
-    // has the running maximum crossed a binade since the accumulators were last rescaled?
-    __device__ __forceinline__ bool changed() const { return amax_bits != 0 && exponent_for(amax_bits) != k; }
-    // a_new / a_old for the accumulators (1 if nothing changed); the reference becomes the new scale
-    __device__ __forceinline__ float pending() {
-        if (amax_bits == 0) return 1.f;
-        const int kt = exponent_for(amax_bits);
-        const float r = exp2i(kt - k);
-        k = kt;
-        return r;
+        if (restart) { k = kn; j = 0; }
+        const int up = j > ROOM_ACT ? j - ROOM_ACT : 0;
+        j -= up;
+        shift = exp2i(j < -100 ? -100 : j);
+        return exp2i(kn + up);
     }
 };
 
