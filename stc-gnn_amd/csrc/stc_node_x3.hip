@@ -266,7 +266,7 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) {
                 const Row8<L>& zr = cur[n][rb];
-                if constexpr (ASC) za[rb] = F::split(mul4(zr.a, sz), mul4(zr.b, sz));
+                if constexpr (ASC) za[rb] = F::split(zr.a * sz, zr.b * sz);
                 else za[rb] = F::split(zr.a, zr.b);
             }
 #pragma unroll
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
                             b4[i] = g < 2 ? tb[i] : 0.f;
                         }
                     }
-                    if constexpr (ASC) zc[rb] = F::split(mul4(a4, sz), mul4(b4, sz));          // (|R*H| <= |H|: the node's scale covers it)
+                    if constexpr (ASC) zc[rb] = F::split(a4 * sz, b4 * sz);          // (|R*H| <= |H|: the node's scale covers it)
                     else zc[rb] = F::split(a4, b4);
                 }
                 f32x4 pa[K][NRB][K];
@@ -714,7 +714,7 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
 #pragma unroll
             for (int kb = 0; kb < NRB; ++kb)
 #pragma unroll
-                for (int hb = 0; hb < HB; ++hb) { in.g.d[kb][hb] = mul4(in.g.d[kb][hb], sg); in.g.v[kb][hb] = mul4(in.g.v[kb][hb], sg); }
+                for (int hb = 0; hb < HB; ++hb) { in.g.d[kb][hb] *= sg; in.g.v[kb][hb] *= sg; }
         }
         const float ikz_sg = ikz * inv_pow2(sg);
         const DyFrag<NRB, HB>& gr = in.g;
@@ -775,7 +775,7 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
                     if (FOLD && n == 0 && lb == HLB) {          // the tile starts from the state's share parked by the prologue
                         const float4 sh = stash[rb * 64 + lane];
                         z[rb] = f32x4{sh.x, sh.y, sh.z, sh.w};
-                        if constexpr (F::SCALED) z[rb] = mul4(z[rb], sg * kz);      // (parked unscaled)
+                        if constexpr (F::SCALED) z[rb] *= sg * kz;      // (parked unscaled)
                     } else if (ACC && PL == 1 && lb == 0 && !F::SCALED) {     // ... or from what the plane already holds
                         z[rb] = stc_ld_once(reinterpret_cast<const f32x4*>(dZ.p[n] + (r0 + 16 * rb + x) * 16 + 4 * g));
                     } else {
@@ -791,8 +791,8 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
                 if constexpr (F::SCALED) {                      // out of the scaled space (+ what the plane already holds)
 #pragma unroll
                     for (int rb = 0; rb < NRB; ++rb) {
-                        if (ACC && PL == 1 && lb == 0) z[rb] = fma4(z[rb], ikz_sg, PFG ? old[n][rb] : stc_ld_once(reinterpret_cast<const f32x4*>(dZ.p[n] + (r0 + 16 * rb + x) * 16 + 4 * g)));
-                        else z[rb] = mul4(z[rb], ikz_sg);
+                        if (ACC && PL == 1 && lb == 0) z[rb] = z[rb] * ikz_sg + (PFG ? old[n][rb] : stc_ld_once(reinterpret_cast<const f32x4*>(dZ.p[n] + (r0 + 16 * rb + x) * 16 + 4 * g)));
+                        else z[rb] *= ikz_sg;
                     }
                 }
                 if constexpr (PL == 1) {                        // planar gradient slabs: block lb of the row goes to plane lb
@@ -843,8 +843,8 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
                 for (int p = 0; p < NB2; ++p) {
                     const float (&zc)[NRB][4] = in.za[n][lb];
                     Op a;
-                    if constexpr (F::SCALED) a = F::split(mul4(f32x4{zc[2 * p][0], zc[2 * p][1], zc[2 * p][2], zc[2 * p][3]}, sz[n][lb] * sh),
-                                                          mul4(f32x4{zc[2 * p + 1][0], zc[2 * p + 1][1], zc[2 * p + 1][2], zc[2 * p + 1][3]}, sz[n][lb] * sh));
+                    if constexpr (F::SCALED) a = F::split(f32x4{zc[2 * p][0], zc[2 * p][1], zc[2 * p][2], zc[2 * p][3]} * (sz[n][lb] * sh),
+                                                          f32x4{zc[2 * p + 1][0], zc[2 * p + 1][1], zc[2 * p + 1][2], zc[2 * p + 1][3]} * (sz[n][lb] * sh));
                     else a = F::split(f32x4{zc[2 * p][0], zc[2 * p][1], zc[2 * p][2], zc[2 * p][3]},
                                       f32x4{zc[2 * p + 1][0], zc[2 * p + 1][1], zc[2 * p + 1][2], zc[2 * p + 1][3]});
 #pragma unroll
@@ -1093,7 +1093,7 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
 #pragma unroll
                 for (int kb = 0; kb < NRB; ++kb)
 #pragma unroll
-                    for (int hb = 0; hb < HB; ++hb) { gr[n].d[kb][hb] = mul4(gr[n].d[kb][hb], sg); gr[n].v[kb][hb] = mul4(gr[n].v[kb][hb], sg); }
+                    for (int hb = 0; hb < HB; ++hb) { gr[n].d[kb][hb] *= sg; gr[n].v[kb][hb] *= sg; }
         }
         float za[LB][NRB][4];                                   // X[16kb + 4g + t][16lb + x]
 #pragma unroll
@@ -1177,7 +1177,7 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
                 }
             if constexpr (F::SCALED) {
 #pragma unroll
-                for (int rb = 0; rb < NRB; ++rb) z[rb] = mul4(z[rb], ikz_sg);
+                for (int rb = 0; rb < NRB; ++rb) z[rb] *= ikz_sg;
             }
             if constexpr (PL == 1) {                            // planar gradient: columns 0..15 -> dX, 16..31 -> dX2
 #pragma unroll
@@ -1223,8 +1223,8 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
             for (int p = 0; p < NB2; ++p) {
                 const float (&zc)[NRB][4] = za[lb];
                 Op a;
-                if constexpr (F::SCALED) a = F::split(mul4(f32x4{zc[2 * p][0], zc[2 * p][1], zc[2 * p][2], zc[2 * p][3]}, sz[lb] * sh),
-                                                      mul4(f32x4{zc[2 * p + 1][0], zc[2 * p + 1][1], zc[2 * p + 1][2], zc[2 * p + 1][3]}, sz[lb] * sh));
+                if constexpr (F::SCALED) a = F::split(f32x4{zc[2 * p][0], zc[2 * p][1], zc[2 * p][2], zc[2 * p][3]} * (sz[lb] * sh),
+                                                      f32x4{zc[2 * p + 1][0], zc[2 * p + 1][1], zc[2 * p + 1][2], zc[2 * p + 1][3]} * (sz[lb] * sh));
                 else a = F::split(f32x4{zc[2 * p][0], zc[2 * p][1], zc[2 * p][2], zc[2 * p][3]},
                                   f32x4{zc[2 * p + 1][0], zc[2 * p + 1][1], zc[2 * p + 1][2], zc[2 * p + 1][3]});
 #pragma unroll

@@ -122,7 +122,9 @@ def test_scale_sweep_on_the_gpu(monkeypatch, family, fmt, x_scale, setting):
     got = _run(model, s, X, Gs, 'cuda')
     assert bool(small_calls) == (family == 'sf')                      # the few-category kernels take the SF shape, the planar ones the rest
     bad = _check(f'scale_sweep[{family}-{fmt}-x{x_scale:g}-{setting}]', got, _oracle(sd, s, X, Gs, K, torch.float64), _oracle(sd, s, X, Gs, K, torch.float32), 'cuda',
-                 noise_factor=40.0 if fmt == 'f16x2' else 10.0)
+                 # (order 3 on a graph with row sums of 50: T_2(S) X is 5 000 x X -- 12 binades between the planes of one node, which share
+                 #  a scale with 8 binades of full precision below the maximum: the small planes lose 4 bits.  DESIGN.md section 3.3.)
+                 noise_factor=(100.0 if (family == 'c32k3' and 'heavy' in setting) else 40.0) if fmt == 'f16x2' else 10.0)
     assert not bad, bad
 
 
