@@ -78,6 +78,7 @@ def parse(argv=None):
     ap.add_argument('--permute', action='store_true', help='random node order (seed 1234) instead of row-major')
     ap.add_argument('--no-reorder', action='store_true', help='keep the given node order (skip the internal RCM renumbering)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-shots', default=f'{CPU_WARMUP},{CPU_TIMED}', help='warm-up,timed shots of the CPU baseline (SURVEY 8(d4): 2,7)')
     ap.add_argument('--no-unit-d3', action='store_true', help='skip the cold SURVEY 8(d3) SpMM unit measurement')
     ap.add_argument('--hip-graph', action='store_true',
                     help='(one GPU; not the default line) time replays of the train step captured into a HIP graph: removes the launch gaps that '
@@ -91,13 +92,12 @@ def parse(argv=None):
     if pre.preset == 'cfg4':
         ap.set_defaults(grid=100, order=3, batch_per_gpu=4)
     elif pre.preset == 'cfg5':
-        ap.set_defaults(categories=64, storage='bf16', no_cpu_baseline=True)
+        ap.set_defaults(categories=64, storage='bf16', cpu_shots='1,3')       # (a C = 64 oracle cell is ~20 s on the host: fewer shots)
     elif pre.preset == 'sf':
         # launch-bound (~700 launches of ~7 us per step): the step is replayed from ONE captured HIP graph (--eager keeps per-launch dispatch)
         ap.set_defaults(grid=10, categories=5, obs=9, pred=3, batch_per_gpu=32, no_unit_d3=True, hip_graph=True)
     elif pre.preset == 'sf-learned':
-        ap.set_defaults(grid=10, categories=5, obs=9, pred=3, batch_per_gpu=32, no_unit_d3=True, hip_graph=True, graph_mode='dense-learned',
-                        no_cpu_baseline=True)
+        ap.set_defaults(grid=10, categories=5, obs=9, pred=3, batch_per_gpu=32, no_unit_d3=True, hip_graph=True, graph_mode='dense-learned')
     a = ap.parse_args(argv)
     if a.global_batch:
         if a.global_batch % a.gpus:
@@ -129,6 +129,39 @@ def _median(xs):
     return xs[len(xs) // 2] if len(xs) % 2 else 0.5 * (xs[len(xs) // 2 - 1] + xs[len(xs) // 2])
 
 
+def cpu_baseline_small(a, Gs_dense, Gc, sd_cpu, As_dense=None):
+    """Small graphs (the SF shape and its relatives): the oracle's WHOLE model -- the reference's algorithm op for op, dense einsum included
+    (oracle.encdec_forward; with learned graphs oracle.stcgnn_forward, MGP_Gen and its 2 N^4 MixedFusion parameters included) -- forward,
+    ComboLoss and backward at the bench's own batch on the host cores; no optimizer step (the GPU value includes Adam)."""
+    import torch
+    from oracle import stc_oracle as O
+    threads = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(threads)
+    warm, timed = (int(v) for v in a.cpu_shots.split(','))
+    N, C, B = a.grid * a.grid, a.categories, a.batch_per_gpu
+    g = torch.Generator().manual_seed(1000)
+    X = (torch.rand(B, a.obs, N, C, generator=g) < 0.1635).float()
+    Y = (torch.rand(B, a.pred, N, C, generator=g) < 0.1635).float()
+    leaves = {k: v.clone().requires_grad_() for k, v in sd_cpu.items()}
+    ts = []
+    for shot in range(warm + timed):
+        for v in leaves.values():
+            v.grad = None
+        t0 = time.perf_counter()
+        if As_dense is not None:
+            yhat = O.stcgnn_forward(X, As_dense, Gc, leaves, a.order, a.order, a.hidden, a.layers, a.pred)
+        else:
+            yhat = O.encdec_forward(X, Gs_dense, Gc, leaves, a.order, a.order, a.hidden, a.layers, a.pred)
+        O.combo_loss(yhat, Y).backward()
+        ts.append(time.perf_counter() - t0)
+    t = _median(ts[warm:])
+    return dict(value=B / t, unit='samples/s', cores=threads, kind='port',
+                sample=f'the oracle\'s whole model (reference algorithm op for op: dense einsum, matrix-side cheby_poly'
+                       f'{", MGP_Gen + MixedFusion" if As_dense is not None else ""}) forward + ComboLoss + backward, batch {B}, no optimizer step; '
+                       f'{warm} warm-up + {timed} timed, median {t:.3f} s per step',
+                shots_s=[round(v, 4) for v in ts])
+
+
 def cpu_baseline(a, GsT_sparse, Gc, sd_cpu):
     """Oracle fwd+bwd on the host cores for a bounded sample of the same workload: 2 warm-up + 7 timed, median.
 
@@ -143,6 +176,7 @@ def cpu_baseline(a, GsT_sparse, Gc, sd_cpu):
     from oracle import stc_oracle as O
     threads = min(os.cpu_count() or 1, 32)      # more threads than this only slow the torch CPU ops down on a 2-socket host
     torch.set_num_threads(threads)
+    CPU_WARMUP, CPU_TIMED = (int(v) for v in a.cpu_shots.split(','))
     N, C, h, K = a.grid * a.grid, a.categories, a.hidden, a.order
     g = torch.Generator().manual_seed(0)
 
@@ -170,6 +204,28 @@ def cpu_baseline(a, GsT_sparse, Gc, sd_cpu):
                       f'(median {t0:.2f} s) and one 16+16 cell (median {t1:.2f} s), {CPU_WARMUP} warm-up + {CPU_TIMED} timed each; a sample = {n0} + {n1} such cells '
                       f'= {per_sample:.0f} s',
                shots_s=dict(layer0=[round(t, 3) for t in shots0], wide=[round(t, 3) for t in shots1]))
+    if a.preset == 'cfg4' and N <= 10000 and not os.environ.get('STC_BENCH_NO_DENSE_ANCHOR'):
+        # configuration 4's own anchor: ONE STC_Cell forward of the reference's dense algorithm at this N and order (7.9 s on 8
+        # cores, most of it the two N^3 matrix products of cheby_poly), 1 warm-up + 3 timed
+        try:
+            gd = torch.Generator().manual_seed(5)
+            Gs = torch.rand(N, N, generator=gd)
+            Gs /= Gs.sum(-1, keepdim=True)
+            Xt = (torch.rand(1, N, C, 1, generator=gd) < 0.1635).float()
+            Ht = torch.rand(1, N, C, h, generator=gd) - 0.5
+            p = [sd_cpu[f'encoder.cell_list.0.{n}'] for n in ('gates.W', 'gates.b', 'candi.W', 'candi.b')]
+            ts = []
+            with torch.no_grad():
+                for shot in range(4):
+                    t = time.perf_counter()
+                    O.stc_cell(Gs, Gc, Xt, Ht, *p, K, K)
+                    ts.append(time.perf_counter() - t)
+            out['dense_cell_anchor'] = dict(what=f'oracle.stc_cell forward (the reference algorithm: dense einsum, matrix-side cheby_poly of order {K}), B=1 N={N} C={C} '
+                                                 'hidden 16, dense Gs; 1 warm-up + 3 timed, median', seconds=_median(ts[1:]), cores=threads,
+                                            reference_in_survey_container_s=7.9, reference_cores=8)
+            del Gs
+        except MemoryError:
+            pass
     if not os.environ.get('STC_BENCH_NO_DENSE_ANCHOR'):
         try:
             Nd = 10000
@@ -246,40 +302,47 @@ def csrc_sha():
     return hsh.hexdigest()[:16]
 
 
+def _profile_doc(name):
+    """The newest ``profiles/r*/<name>`` (highest round first): PMC files are committed per round."""
+    root = os.path.join(REPO, 'profiles')
+    for rnd in sorted((d for d in os.listdir(root) if d.startswith('r') and d[1:].isdigit()), key=lambda d: -int(d[1:])) if os.path.isdir(root) else ():
+        path = os.path.join(root, rnd, name)
+        if os.path.exists(path):
+            with open(path) as fh:
+                return json.load(fh), f'profiles/{rnd}/{name}'
+    return None, None
+
+
 def pmc_traffic(a, config_key):
     """HBM bytes per plain SpMM launch from a PMC pass over THIS command (tools/gpu_pmc_bench.sh: FETCH_SIZE and WRITE_SIZE
     in separate ``rocprofv3 --pmc`` runs), quoted only if the file was collected on the same kernel sources (csrc_sha)
     and the same configuration; otherwise null.  Never a number from an older build."""
-    path = os.path.join(REPO, 'profiles', 'r03', 'hbm_traffic_bench.json')
-    if not os.path.exists(path):
+    doc, where = _profile_doc('hbm_traffic_bench.json')
+    if doc is None:
         return None, None
-    with open(path) as fh:
-        doc = json.load(fh)
     if doc.get('csrc_sha') != csrc_sha() or doc.get('config_key') != config_key:
-        return None, f'profiles/r03/hbm_traffic_bench.json is from other sources/configuration ({doc.get("csrc_sha")}, {doc.get("config_key")}): not quoted'
+        return None, f'{where} is from other sources/configuration ({doc.get("csrc_sha")}, {doc.get("config_key")}): not quoted'
     import re
     ks = [v for name, v in doc['kernels'].items() if re.match(r'spmm_bcsr_kernel<\d+, 0,', name)]      # MODE = 0 (EP_PLAIN): the plain launches only
     if not ks:
         return None, None
     traffic = sum(v['hbm_bytes_per_launch'] * v['launches'] for v in ks) / sum(v['launches'] for v in ks)
     return traffic, ('PMC (FETCH_SIZE, WRITE_SIZE in separate rocprofv3 --pmc passes, unit-corrected as MI355X_MICROARCH.md prescribes), mean over the '
-                     f'spmm_bcsr_kernel launches of one step of this command on these sources (csrc {doc["csrc_sha"]}): profiles/r03/hbm_traffic_bench.json')
+                     f'spmm_bcsr_kernel launches of one step of this command on these sources (csrc {doc["csrc_sha"]}): {where}')
 
 
 def pmc_mfma(config_key):
     """Matrix-pipe / vector-pipe busy fractions of the projection kernels (the split-operand MFMA cell kernels) from the committed
     ``rocprofv3 --pmc`` passes over THIS command (tools/gpu_pmc_mfma.sh -> profiles/r03/mfma_util.json): quoted only while the
     file's kernel-source hash and configuration equal the running tree's, else null with a note."""
-    path = os.path.join(REPO, 'profiles', 'r03', 'mfma_util.json')
-    if not os.path.exists(path):
+    doc, where = _profile_doc('mfma_util.json')
+    if doc is None:
         return None
-    with open(path) as fh:
-        doc = json.load(fh)
     if doc.get('csrc_sha') != csrc_sha() or doc.get('config_key') != config_key:
-        return {'value': None, 'note': f'profiles/r03/mfma_util.json is from other sources/configuration ({doc.get("csrc_sha")}, {doc.get("config_key")}): not quoted'}
+        return {'value': None, 'note': f'{where} is from other sources/configuration ({doc.get("csrc_sha")}, {doc.get("config_key")}): not quoted'}
     keep = {name: {'launches': v['launches'], 'mfma_busy': v['mfma_util'], 'valu_busy': v['valu_busy']} for name, v in doc['kernels'].items()
             if 'cell_bwd' in name or 'node_fwd' in name or 'node_bwd' in name}
-    return {'source': 'committed', 'file': 'profiles/r03/mfma_util.json', 'csrc_sha': doc['csrc_sha'],
+    return {'source': 'committed', 'file': where, 'csrc_sha': doc['csrc_sha'],
             'definition': doc.get('definition'),
             'peak_note': 'busy fraction of the matrix pipe while the kernel runs; 1.0 = the dense MFMA peak of the instruction in use',
             'kernels': keep}
@@ -295,10 +358,22 @@ class PowerSampler:
         self.rows, self.stop_flag, self.thread, self.err = [], threading.Event(), None, None
         try:
             import amdsmi
+            import torch
             self.smi = amdsmi
             amdsmi.amdsmi_init()
             handles = amdsmi.amdsmi_get_processor_handles()
-            self.h = handles[index] if index < len(handles) else handles[0]
+            # amdsmi lists every physical GPU of the host, whatever HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES say and in its own order:
+            # the rank's device is found by its PCI bus id, not by its HIP index (no match: no power block rather than another GPU's)
+            want = self._bdf(torch.cuda.get_device_properties(index).pci_bus_id) if hasattr(torch.cuda.get_device_properties(index), 'pci_bus_id') else None
+            self.h = None
+            for h_ in handles:
+                if want is not None and self._bdf(amdsmi.amdsmi_get_gpu_device_bdf(h_)) == want:
+                    self.h = h_
+            if self.h is None:
+                if want is None and len(handles) == 1:
+                    self.h = handles[0]
+                else:
+                    raise RuntimeError(f'no amdsmi handle with PCI bus id {want}')
             self.limit = self._num(amdsmi.amdsmi_get_power_info(self.h).get('power_limit'))
             self.rated = self._num(amdsmi.amdsmi_get_clock_info(self.h, amdsmi.AmdSmiClkType.GFX).get('max_clk'))
             self.thread = threading.Thread(target=self._run, daemon=True)
@@ -308,6 +383,18 @@ class PowerSampler:
     @staticmethod
     def _num(v):
         return float(v) if isinstance(v, (int, float)) else None
+
+    @staticmethod
+    def _bdf(v):
+        """'0000:c3:00.0' / 'c3:00.0' / 195 (a bare bus number) -> (bus, device, function), None if unreadable."""
+        try:
+            if isinstance(v, int):
+                return (v, 0, 0)
+            parts = str(v).lower().replace('.', ':').split(':')
+            bus, dev_, fn = parts[-3], parts[-2], parts[-1]
+            return (int(bus, 16), int(dev_, 16), int(fn, 16))
+        except Exception:                                            # noqa: BLE001
+            return None
 
     def _run(self):
         while not self.stop_flag.is_set():
@@ -330,10 +417,11 @@ class PowerSampler:
             return None
         self.stop_flag.set()
         self.thread.join(timeout=2.0)
-        try:
-            self.smi.amdsmi_shut_down()
-        except Exception:                                            # noqa: BLE001
-            pass
+        if not self.thread.is_alive():                               # (still inside an amdsmi call after the timeout: leave the library up)
+            try:
+                self.smi.amdsmi_shut_down()
+            except Exception:                                        # noqa: BLE001
+                pass
         if not self.rows:
             return None
         w, c = [r[0] for r in self.rows], [r[1] for r in self.rows]
@@ -343,6 +431,7 @@ class PowerSampler:
 
 
 def main():
+    t_start = time.perf_counter()
     a = parse()
     if a.gpus > 1 and 'RANK' not in os.environ:
         sys.exit(self_launch(a))            # before torch / the GPU are touched: the ranks are children of this process
@@ -413,10 +502,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    torch.cuda.synchronize()
+    t_built = time.perf_counter()                                                # process start -> graph, model, inputs resident
     for _ in range(max(a.warmup, 2 if graphed else 0)):
         step()
     hip = ops.kernels()
     fence()
+    t_warm = time.perf_counter()                                                 # ... -> warm-up done (first launches: graph renumbering, plans, workspaces)
     if graphed:
         # the whole step as ONE captured HIP graph: `value` is over replays; the launch timer cannot run inside a replay, so the per-kernel
         # events (roofline, kernels) are taken from eager steps after the timed region
@@ -475,7 +567,13 @@ def main():
                     t_[key] = t_[key] * a.steps / table_steps
         per_kernel.update(priced)
     n_ranks_seen = 1
+    per_rank = {'ms_per_step': [1e3 * elapsed / a.steps], 'build_s': [t_built - t_start], 'warmup_s': [t_warm - t_built]}
     if dist.is_initialized():
+        mine = torch.tensor([elapsed, t_built - t_start, t_warm - t_built], device=dev, dtype=torch.float64)
+        every_rank = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every_rank, mine)
+        per_rank = {'ms_per_step': [1e3 * float(t[0]) / a.steps for t in every_rank], 'build_s': [float(t[1]) for t in every_rank],
+                    'warmup_s': [float(t[2]) for t in every_rank]}
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
@@ -586,6 +684,11 @@ def main():
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * elapsed / a.steps,
             'higher_is_better': True, 'scaling': 'strong' if a.global_batch else 'weak', 'vs_baseline': None, 'dtype': a.storage, 'data': 'synthetic',
             'n_ranks_seen': n_ranks_seen, 'hip_graph': bool(graphed),
+            # what a first multi-GPU run needs to explain itself: every rank's own step time over the timed region (the value uses the
+            # slowest), and how long each took to get there (process start -> resident model; warm-up incl. node renumbering and plans)
+            'per_rank': {'ms_per_step_min': min(per_rank['ms_per_step']), 'ms_per_step_max': max(per_rank['ms_per_step']),
+                         'ms_per_step': [round(v, 3) for v in per_rank['ms_per_step']],
+                         'build_s_max': max(per_rank['build_s']), 'warmup_s_max': max(per_rank['warmup_s'])},
             'config': {'workload': f'full STC-GNN train step (fwd + ComboLoss + bwd + grad all-reduce + Adam), {a.graph_mode}'
                                    f'{" (MGP_Gen learned dense graphs, " + str(sum(p.numel() for p in model.parameters())) + " parameters)" if learned else ""}, '
                                    f'{a.grid}x{a.grid} queen grid N={N} nnz={graph.nnz}{" permuted" if a.permute else ""}, C={C}, '
@@ -610,8 +713,11 @@ def main():
             'hbm_peak_reserved_gb': torch.cuda.max_memory_reserved(dev) / 1e9,
         }
         if world == 1 and not a.no_cpu_baseline:
-            GsT = graph.to_dense().t().contiguous().to_sparse_csr() if N <= 4096 else _sparse_T(graph)
-            out['cpu_baseline'] = cpu_baseline(a, GsT, Gc_cpu, sd_cpu)
+            if N <= 1024:                                        # small graphs: the whole model through the oracle's dense (reference) algorithm
+                out['cpu_baseline'] = cpu_baseline_small(a, graph.to_dense(), Gc_cpu, sd_cpu,
+                                                         As_dense=CsrGraph.queen_grid(a.grid, a.grid, normalize=False).to_dense() if learned else None)
+            else:
+                out['cpu_baseline'] = cpu_baseline(a, _sparse_T(graph), Gc_cpu, sd_cpu)
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()
@@ -662,13 +768,41 @@ def bench_cfg2(a):
 
     ms_f, ms_fb = timed(fwd), timed(fwd_bwd)
     ref = {2: (13.3, 25.8), 3: (29.6, 55.2)}.get(K)
+    cpu = None
+    if not a.no_cpu_baseline:                                    # the oracle's bdg_dif (the reference's algorithm op for op) on the host cores
+        from oracle import stc_oracle as O
+        threads = min(os.cpu_count() or 1, 32)
+        torch.set_num_threads(threads)
+        warm_c, timed_c = (int(v) for v in a.cpu_shots.split(','))
+        W_, b_ = (p.detach().cpu().clone().requires_grad_() for p in (layer.W, layer.b))
+        Xc, Gsc, Gcc, Rc = X.detach().cpu().requires_grad_(), Gs.detach().cpu().requires_grad_(), Gc.detach().cpu().requires_grad_(), R.cpu()
+        tf, tfb = [], []
+        for shot in range(warm_c + timed_c):
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                O.bdg_dif(Xc, Gsc, Gcc, W_, b_, K, K)
+            tf.append(time.perf_counter() - t0)
+            for t_ in (Xc, Gsc, Gcc, W_, b_):
+                t_.grad = None
+            t0 = time.perf_counter()
+            (O.bdg_dif(Xc, Gsc, Gcc, W_, b_, K, K) * Rc).sum().backward()
+            tfb.append(time.perf_counter() - t0)
+        cpu = dict(value=1.0 / _median(tfb[warm_c:]), unit='layers/s', cores=threads, kind='port',
+                   sample=f'oracle.bdg_dif (reference algorithm op for op) at the same shape, {warm_c} warm-up + {timed_c} timed, median: forward '
+                          f'{1e3 * _median(tf[warm_c:]):.2f} ms, forward + backward {1e3 * _median(tfb[warm_c:]):.2f} ms',
+                   forward_ms=1e3 * _median(tf[warm_c:]), forward_backward_ms=1e3 * _median(tfb[warm_c:]))
     print(json.dumps({
         'metric': 'BDG_Dif layer forward+backward layer-applications/sec (BASELINE configuration 2; not the headline metric)', 'value': 1e3 / ms_fb,
         'unit': 'layers/s', 'n_gpus': 1, 'steps': steps, 'warmup': warm, 'ms_per_step': ms_fb, 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': f'single BDG_Dif layer, B={B} N={N} C={C} L={L} Ho={Ho} K={K}, dense differentiable Gs and Gc (gradients of X, W, b, Gs, Gc)',
                    'preset': 'cfg2'},
-        'forward_ms': ms_f, 'forward_backward_ms': ms_fb,
+        'forward_ms': ms_f, 'forward_backward_ms': ms_fb, 'cpu_baseline': cpu,
+        'roofline': {'bound': 'mfma', 'kernel': 'stc_dense_agg_f32 + the node kernels of one BDG_Dif (exact-fp32 matrix instructions)',
+                     'achieved': (2.0 * B * N * N * C * L * (K - 1) + 2.0 * B * N * C * (K * K * L) * Ho + 2.0 * B * N * C * C * (K - 1) * Ho) / (ms_f * 1e-3) / 1e12,
+                     'peak': FP32_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': (2.0 * B * N * N * C * L * (K - 1) + 2.0 * B * N * C * (K * K * L) * Ho + 2.0 * B * N * C * C * (K - 1) * Ho) / (ms_f * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS,
+                     'traffic': None, 'what': 'algorithmic flops of the FORWARD (dense aggregation on the features, projection, category mix) / its time'},
         'reference_cpu_ms': None if ref is None else {'forward': ref[0], 'forward_backward': ref[1], 'cores': 8,
                                                       'source': 'BASELINE.md section 2 (reference imported unmodified in the survey container)'},
     }), flush=True)

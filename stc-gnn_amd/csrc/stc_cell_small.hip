@@ -39,17 +39,23 @@ constexpr int SF_THREADS = 1024, SF_WAVES = SF_THREADS / 64;      // forward: 16
 constexpr int SB_THREADS = 1024, SB_WAVES = SB_THREADS / 64;      // backward: 16 waves = 4 quads, four waves per row tile (slab x role)
 constexpr int SC_H = 16, SC_KS = 2, SC_MAXC = 16;
 
-// Probe hook (tools/probes/small_cell_phases.py builds this file with -DSC_STOP_AFTER=n and times the truncated launches; the
-// library is built without it: the condition is a compile-time false).
+// Probe hooks: tools/probes/small_cell_phases.py builds this file with -DSTC_PROBE -DSC_STOP_AFTER=n (-DSC_MAX_TILES, -DSC_SKIP_ROLE) and times
+// the truncated launches.  The library is built without STC_PROBE: the hooks then do not exist.
+#ifdef STC_PROBE
 #ifndef SC_STOP_AFTER
 #define SC_STOP_AFTER 99
 #endif
 #define SC_PHASE_END(n) do { if (SC_STOP_AFTER <= (n)) return; } while (0)
 #ifndef SC_MAX_TILES
-#define SC_MAX_TILES (1 << 30)                     // probe: the backward convolutions stop after this many row tiles
+#define SC_MAX_TILES (1 << 30)                     // the backward convolutions stop after this many row tiles
 #endif
 #ifndef SC_SKIP_ROLE
-#define SC_SKIP_ROLE (-1)                          // probe: the waves of this backward role (0: dZ, 1: dW) do nothing
+#define SC_SKIP_ROLE (-1)                          // the waves of this backward role (0: dZ, 1: dW) do nothing
+#endif
+#else
+#define SC_PHASE_END(n) do { } while (0)
+#define SC_MAX_TILES (1 << 30)
+#define SC_SKIP_ROLE (-1)
 #endif
 
 // Gate nonlinearities on the hardware exp2 / rcp, as in the large-graph cell kernels (stc_common.h: accurate relative to the result for every

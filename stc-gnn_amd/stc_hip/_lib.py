@@ -677,7 +677,8 @@ class HipKernels:
                      self.operand_format if f16 else FMT_BF16X3,      # (the forms built for fp16 x 2)
                      self._act_amax('post.x', None if act_amax is None else act_amax[0].view(1, -1), 1, X) if f16 else None,
                      self._act_amax('post.x2', None if act_amax is None else act_amax[1].view(1, -1), 1, X) if f16 else None,
-                     _ptr(ws), ws.numel(), R, Cc, L, Lw, Ho)
+                     _ptr(ws), ws.numel(), R, Cc, L, Lw, Ho,
+                     nbytes=4 * R * Cc * ((16 if X2 is not None else L) + (0 if X2 is None else X2.shape[-1]) + 2 * Ho + (16 if X2 is not None else L) + (16 if dX2 is not None else 0)))
 
     # ---- planar cell inputs (Ks = Kc = 2, cin = h = 16) ---------------------------------------------
     def cell_planar_supported(self, Ks, Kc, Cc, h) -> bool:
@@ -752,7 +753,8 @@ class HipKernels:
         zp = (_p * 4)(*[0 if z is None else z.data_ptr() for z in dZs])
         self._launch('stc_cell_gates_bwd_planar_f32', H, _ptr(X), _ptr(H), _ptr(SX), _ptr(SH), _ptr(Tc), _ptr(W), _ptr(dRH), _ptr(Cand),
                      _ptr(U), _ptr(Rg), _ptr(dHnew), zp, _ptr(dW), _ptr(db), _ptr(dH), self.operand_format,
-                     self._act_amax('planar', act_amax, 4, H), _ptr(ws), ws.numel(), R, Cc, cin + h, h)
+                     self._act_amax('planar', act_amax, 4, H), _ptr(ws), ws.numel(), R, Cc, cin + h, h,
+                     nbytes=4 * R * Cc * (2 * cin + 2 * h + 5 * h + 2 * h + (2 * h if cin == h else 0) + (h if dH is not None else 0)))
 
     # ---- the whole backward of a planar cell step in one launch ----------------------------------------
     def cell_bwd_planar_supported(self, Cc, h) -> bool:
@@ -984,7 +986,8 @@ class HipKernels:
             self._f32('planar_k.' + name, t, (R, Cc, h))
         self._same_device(*Zx, *Zh, Tc, W, bias, U, Rg, RH)
         self._launch('stc_cell_gates_fwd_planar_k_f32', U, self._ptr_array(Zx), self._ptr_array(Zh), K, _ptr(Tc), _ptr(W), _ptr(bias),
-                     _ptr(U), _ptr(Rg), _ptr(RH), self.operand_format, self._act_amax('planar_k', act_amax, 2 * K, U), R, Cc, cin + h, h)
+                     _ptr(U), _ptr(Rg), _ptr(RH), self.operand_format, self._act_amax('planar_k', act_amax, 2 * K, U), R, Cc, cin + h, h,
+                     nbytes=4 * R * Cc * (K * (cin + h) + 3 * h))
 
     def cell_cand_fwd_planar_k(self, Zx, Zh, Tc, W, bias, U, H, Cand, Hnew, act_amax=None):
         """Candidate convolution on [X | R*H] (Zh = the T_n(S) planes of R*H) + tanh + GRU blend: Cand, Hnew."""
@@ -995,7 +998,8 @@ class HipKernels:
             self._f32('planar_k.' + name, t, (R, Cc, h))
         self._same_device(*Zx, *Zh, Tc, W, bias, U, H, Cand, Hnew)
         self._launch('stc_cell_cand_fwd_planar_k_f32', U, self._ptr_array(Zx), self._ptr_array(Zh), K, _ptr(Tc), _ptr(W), _ptr(bias),
-                     _ptr(U), _ptr(H), _ptr(Cand), _ptr(Hnew), self.operand_format, self._act_amax('planar_k', act_amax, 2 * K, U), R, Cc, cin + h, h)
+                     _ptr(U), _ptr(H), _ptr(Cand), _ptr(Hnew), self.operand_format, self._act_amax('planar_k', act_amax, 2 * K, U), R, Cc, cin + h, h,
+                     nbytes=4 * R * Cc * (K * (cin + h) + 4 * h))
 
     def _grad_planes_k(self, what, dZx, dZh, K, R, Cc, h, cin):
         if len(dZh) != K or len(dZx) != K:
@@ -1023,7 +1027,8 @@ class HipKernels:
         ws = self._get_workspace(U.device, self.lib.stc_bdg_node_bwd_workspace_bytes(K, K, Cc, 2 * h, 2 * h, 0))
         self._launch('stc_cell_gates_bwd_planar_k_f32', U, self._ptr_array(Zx), self._ptr_array(Zh), K, _ptr(Tc), _ptr(W), _ptr(dRH), _ptr(Cand),
                      _ptr(U), _ptr(Rg), _ptr(dHnew), zx, zh, _ptr(dW), _ptr(db), _ptr(dH), int(bool(accumulate_x)),
-                     self.operand_format, self._act_amax('planar_k', act_amax, 2 * K, U), _ptr(ws), ws.numel(), R, Cc, cin + h, h)
+                     self.operand_format, self._act_amax('planar_k', act_amax, 2 * K, U), _ptr(ws), ws.numel(), R, Cc, cin + h, h,
+                     nbytes=4 * R * Cc * (K * (cin + h) + 5 * h + K * h + (K * h * (2 if accumulate_x else 1) if cin == h else 0) + (h if dH is not None else 0)))
 
     def cell_cand_bwd_planar_k(self, Zx, Zh, Tc, W, dHnew, U, Cand, dZx, dZh, dW, db, act_amax=None):
         K, R, Cc, h, cin = self._planes_k('planar_k cand bwd', Zx, Zh, Tc, W, Zh[0].shape[-1])
@@ -1037,7 +1042,8 @@ class HipKernels:
         ws = self._get_workspace(U.device, self.lib.stc_bdg_node_bwd_workspace_bytes(K, K, Cc, 2 * h, 2 * h, 0))
         self._launch('stc_cell_cand_bwd_planar_k_f32', U, self._ptr_array(Zx), self._ptr_array(Zh), K, _ptr(Tc), _ptr(W), _ptr(dHnew), _ptr(U), _ptr(Cand),
                      zx, zh, _ptr(dW), _ptr(db), self.operand_format, self._act_amax('planar_k', act_amax, 2 * K, U),
-                     _ptr(ws), ws.numel(), R, Cc, cin + h, h)
+                     _ptr(ws), ws.numel(), R, Cc, cin + h, h,
+                     nbytes=4 * R * Cc * (K * (cin + h) + 3 * h + K * h + (K * h if cin == h else 0)))
 
     # ---- fused cell convolutions ----------------------------------------------------------
     def cell_fused_supported(self, Ks, Kc, Cc, L, h) -> bool:
@@ -1318,7 +1324,8 @@ class _Bf16Planar:
                 self._pl('planar.' + name, t, (R, Cc, h))
         b._same_device(X, H, SX, SH, Tc, W, bias, U, Rg, RH, Wc, bc, A, Bm)
         b._launch('stc_cell_gates_fwd_planar_bf16', H, _ptr(X), _ptr(H), _ptr(SX), _ptr(SH), _ptr(Tc), _ptr(W), _ptr(bias),
-                  _ptr(U), _ptr(Rg), _ptr(RH), _ptr(Wc), _ptr(bc), _ptr(A), _ptr(Bm), R, Cc, cin + h, h)
+                  _ptr(U), _ptr(Rg), _ptr(RH), _ptr(Wc), _ptr(bc), _ptr(A), _ptr(Bm), R, Cc, cin + h, h,
+                     nbytes=2 * R * Cc * (2 * cin + 2 * h + h * (3 + (2 if post is not None else 0))))
 
     def node_post_fwd(self, *a, **kw):
         raise StcError('bf16 planar path: the candidate projection runs inside cell_gates_fwd_planar (post=); STC_FUSE_POST=0 is an fp32-path switch')
@@ -1388,7 +1395,8 @@ class _Bf16Planar:
         b._same_device(X, X2, Tc, W, dA, dB, dX, dX2, dW, db)
         ws = b._get_workspace(X.device, b.lib.stc_bdg_node_bwd_workspace_bytes(2, 2, Cc, 32, 16, 0))
         b._launch('stc_bdg_node_post_bwd_bf16', X, _ptr(X), _ptr(X2), _ptr(Tc), _ptr(W), _ptr(dA), _ptr(dB), _ptr(dX), _ptr(dX2), _ptr(dW), _ptr(db),
-                  _ptr(ws), ws.numel(), R, Cc, 16 + w2, 16)
+                  _ptr(ws), ws.numel(), R, Cc, 16 + w2, 16,
+                  nbytes=2 * R * Cc * (16 + w2 + 2 * 16 + 16 + (16 if dX2 is not None else 0)))
 
     def cell_gates_bwd_planar(self, X, H, SX, SH, Tc, W, dRH, Cand, U, Rg, dHnew, dZs, dW, db, dH):
         b = self.b
@@ -1410,4 +1418,5 @@ class _Bf16Planar:
         ws = b._get_workspace(H.device, b.lib.stc_bdg_node_bwd_workspace_bytes(2, 2, Cc, 2 * h, 2 * h, 0))
         zp = (_p * 4)(*[0 if z is None else z.data_ptr() for z in dZs])
         b._launch('stc_cell_gates_bwd_planar_bf16', H, _ptr(X), _ptr(H), _ptr(SX), _ptr(SH), _ptr(Tc), _ptr(W), _ptr(dRH), _ptr(Cand),
-                  _ptr(U), _ptr(Rg), _ptr(dHnew), zp, _ptr(dW), _ptr(db), _ptr(dH), _ptr(ws), ws.numel(), R, Cc, cin + h, h)
+                  _ptr(U), _ptr(Rg), _ptr(dHnew), zp, _ptr(dW), _ptr(db), _ptr(dH), _ptr(ws), ws.numel(), R, Cc, cin + h, h,
+                  nbytes=2 * R * Cc * (2 * cin + 2 * h + 5 * h + 2 * h + (2 * h if cin == h else 0) + (h if dH is not None else 0)))

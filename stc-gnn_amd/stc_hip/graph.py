@@ -186,19 +186,42 @@ class CsrGraph:
         rows = np.repeat(np.arange(self.n, dtype=np.int64), np.diff(h['bwd_rowptr'].astype(np.int64)))
         return CsrGraph(self.n, inv[rows], inv[h['bwd_colidx'].astype(np.int64)], h['bwd_val'])
 
+    def _locality_order_once_per_job(self):
+        """``locality_order()`` computed by rank 0 and broadcast when a process group is up (one process per GPU: eight ranks would otherwise
+        run the same host-side analysis side by side and -- worse -- could disagree if their scipy builds differed: every rank must renumber
+        the nodes the same way, or the replicated graph is no longer the same graph).  Collective: every rank calls it, at the same point
+        (the first forward pass).  None: scipy is missing on rank 0 (the given order is kept everywhere)."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            try:
+                return self.locality_order()
+            except ImportError:                     # scipy (reverse Cuthill-McKee) is optional: without it the given order is kept
+                return None
+        on_gpu = dist.get_backend() == 'nccl'
+        buf = torch.zeros(self.n + 1, dtype=torch.int64)
+        if dist.get_rank() == 0:
+            try:
+                buf[1:] = torch.from_numpy(self.locality_order())
+                buf[0] = 1
+            except ImportError:
+                pass
+        if on_gpu:
+            buf = buf.cuda()
+        dist.broadcast(buf, src=0)
+        buf = buf.cpu()
+        return buf[1:].numpy().copy() if int(buf[0]) == 1 else None
+
     def with_locality(self, min_gain: float = 1.25):
         """(graph, order): a renumbered copy when that cuts the row fetches of the row-blocked SpMM by at least
-        ``min_gain``, else (self, None).  Computed once and cached."""
+        ``min_gain``, else (self, None).  Computed once and cached (under a process group: the order by rank 0, see above)."""
         cached = getattr(self, '_locality', None)
         if cached is None:
             cached = (self, None)
             if self.n > 64 and self.nnz > 0:
-                try:
-                    order = self.locality_order()
-                except ImportError:                 # scipy (reverse Cuthill-McKee) is optional: without it the given order is kept
+                order = self._locality_order_once_per_job()
+                if order is None:
                     import warnings
                     warnings.warn('scipy is not installed: the spatial graph keeps its node order (no locality renumbering)')
-                    order = None
                 if order is not None:
                     cand = self.permuted(order)
                     if self.fetches_per_row[0] >= min_gain * cand.fetches_per_row[0]:

@@ -271,3 +271,94 @@ def test_ragged_shards_cover_the_batch():
             assert torch.equal(torch.cat(parts), torch.arange(n))
             sizes = [len(p) for p in parts]
             assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------- eight ranks
+def _build_eight(seed=5):
+    """A graph big enough for the locality analysis (n > 64) handed over in a scrambled node order, and a batch of 11 samples: over eight
+    ranks that is 2 + 2 + 2 + 1 + 1 + 1 + 1 + 1 (ragged shards)."""
+    import STC_GNN as M
+    from stc_hip import CsrGraph
+    torch.manual_seed(seed)
+    H, W, C, h, K = 9, 8, 3, 4, 2
+    graph = CsrGraph.queen_grid(H, W, normalize=True, permute_seed=3)
+    model = M.STCGNN(H * W, C, K, K, 1, h, 1, 2, graph_mode='csr-fixed')
+    Gc = torch.softmax(torch.randn(C, C), -1)
+    X = (torch.rand(11, 2, H * W, C) < 0.3).float()
+    Y = (torch.rand(11, 2, H * W, C) < 0.3).float()
+    return model, graph, Gc, X, Y
+
+
+def _worker_eight(rank, world, port, out_dir):
+    for p in (REPO, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from oracle import stc_oracle as O
+    from oracle.kernel_emul import EmulatedKernels
+    from stc_hip import dist as sdist, graph as sgraph, ops
+    ops._kernels = EmulatedKernels()
+    sdist.init_from_env(backend='gloo')
+    calls = []
+    real = sgraph.CsrGraph.locality_order
+    sgraph.CsrGraph.locality_order = lambda self: (calls.append(rank), real(self))[1]
+    # (1) csr-fixed, ragged shards: the shard loss weighted by its share of the batch, one bucket all-reduce
+    model, graph, Gc, X, Y = _build_eight()
+    sdist.broadcast_parameters(model)
+    bucket = sdist.GradBucket(model.parameters())
+    bucket.zero()
+    xs, ys = sdist.shard_batch(X, rank, world, ragged=True), sdist.shard_batch(Y, rank, world, ragged=True)
+    loss = O.combo_loss(model(X_seq=xs, As=graph, Ac=Gc), ys) * (len(xs) / len(X) * world)
+    loss.backward()
+    bucket.allreduce_mean()
+    order = graph.with_locality()[1]
+    # (2) learned graphs (the reference's own mode): the batch-summed pre-activation all-reduced forward and backward, equal shards of 8
+    lm, As, Ac, Xl, Yl = _build_learned(batch_sharded=True)
+    Xl, Yl = torch.cat([Xl, Xl.flip(0)]), torch.cat([Yl, Yl.flip(0)])          # 8 samples: one per rank
+    sdist.broadcast_parameters(lm)
+    lb = sdist.GradBucket(lm.parameters())
+    lb.zero()
+    xl, yl = sdist.shard_batch(Xl, rank, world), sdist.shard_batch(Yl, rank, world)
+    Gs, _ = lm.mix_graph_pair(xl, As, Ac)
+    O.combo_loss(lm(X_seq=xl, As=As, Ac=Ac), yl).backward()
+    lb.allreduce_mean()
+    torch.save({'flat': bucket.flat.clone(), 'order': None if order is None else torch.from_numpy(order), 'rcm_calls': calls, 'shard': len(xs),
+                'lflat': lb.flat.clone(), 'Gs': Gs.detach()}, os.path.join(out_dir, f'rank{rank}.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_ragged_shards_learned_graphs_and_one_locality_analysis(tmp_path):
+    """The rank count the bench is judged at, on CPU (gloo, one thread per rank, tiny shapes, emulated kernels): ragged contiguous shards of
+    an 11-sample batch weighted by their share, the flat bucket's mean, the learned graphs' batch-sum all-reduce -- all equal to the one-process
+    full-batch step -- and the host-side node renumbering computed by rank 0 alone and shared (every rank must renumber alike)."""
+    world = 8
+    mp.start_processes(_worker_eight, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True, start_method='spawn')
+    got = [torch.load(tmp_path / f'rank{r}.pt', weights_only=False) for r in range(world)]
+    assert [g_['shard'] for g_ in got] == [2, 2, 2, 1, 1, 1, 1, 1]
+    assert got[0]['rcm_calls'] == [0] and all(g_['rcm_calls'] == [] for g_ in got[1:])      # reverse Cuthill-McKee ran once per job
+    assert got[0]['order'] is not None and all(torch.equal(g_['order'], got[0]['order']) for g_ in got[1:])
+    for key in ('flat', 'lflat', 'Gs'):
+        assert all(torch.equal(g_[key], got[0][key]) for g_ in got[1:]), key
+    from oracle import stc_oracle as O
+    from oracle.kernel_emul import EmulatedKernels
+    from stc_hip import dist as sdist, ops
+    old = ops._kernels
+    ops._kernels = EmulatedKernels()
+    try:
+        model, graph, Gc, X, Y = _build_eight()
+        bucket = sdist.GradBucket(model.parameters())
+        O.combo_loss(model(X_seq=X, As=graph, Ac=Gc), Y).backward()
+        full = bucket.flat.clone()
+        lm, As, Ac, Xl, Yl = _build_learned(batch_sharded=False)
+        Xl, Yl = torch.cat([Xl, Xl.flip(0)]), torch.cat([Yl, Yl.flip(0)])
+        lb = sdist.GradBucket(lm.parameters())
+        Gs, _ = lm.mix_graph_pair(Xl, As, Ac)
+        O.combo_loss(lm(X_seq=Xl, As=As, Ac=Ac), Yl).backward()
+        lfull = lb.flat.clone()
+    finally:
+        ops._kernels = old
+    assert float((got[0]['flat'] - full).abs().max()) / float(full.abs().max()) < 1e-5
+    assert float((got[0]['Gs'] - Gs).abs().max()) < 1e-6
+    assert float((got[0]['lflat'] - lfull).abs().max()) / float(lfull.abs().max()) < 1e-5

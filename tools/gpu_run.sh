@@ -29,7 +29,7 @@ PY
            ;;
     presets) rc=0
            for p in "cfg2 --order 2" "cfg2 --order 3" "cfg4" "cfg5" "sf" "sf-learned"; do
-             n=$(echo $p | tr -d ' -'); timeout -k 10 600 python bench.py --preset $p --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/preset_$n.json 2> gpurun_out/preset_$n.err || rc=1
+             n=$(echo $p | tr -d ' -'); timeout -k 10 900 python bench.py --preset $p --steps 5 --warmup 2 > gpurun_out/preset_$n.json 2> gpurun_out/preset_$n.err || rc=1
              python -c "import json,sys;d=json.loads(open('gpurun_out/preset_$n.json').read().strip().split('\n')[-1]);print('$p',round(d['value'],2),d['unit'],round(d['ms_per_step'],3),'ms')" || rc=1
            done ;;
     stats) cd /tmp && export TMPDIR=/tmp; rm -rf $R/gpurun_out/prof

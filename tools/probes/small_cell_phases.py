@@ -1,4 +1,4 @@
-"""Where the time of a small-graph cell launch goes: builds csrc/stc_cell_small.hip with -DSC_STOP_AFTER=n (the launch returns after
+"""Where the time of a small-graph cell launch goes: builds csrc/stc_cell_small.hip with -DSTC_PROBE -DSC_STOP_AFTER=n (the launch returns after
 phase n) into scratch libraries, times each truncated launch with HIP events at the SF shape, and prints the phase durations as
 differences.  Run on the GPU box:  python tools/probes/small_cell_phases.py [cin] [N] [C] [B]"""
 import ctypes as C
@@ -55,7 +55,7 @@ rows = []
 extra = [a for a in sys.argv[5:] if a.startswith('-D')]          # e.g. -DSC_SKIP_ROLE=1
 for stop in (1, 2, 3, 99):
     so = os.path.join(tmp, f'small_{stop}.so')
-    subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', f'-DSC_STOP_AFTER={stop}', *extra,
+    subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-DSTC_PROBE', f'-DSC_STOP_AFTER={stop}', *extra,
                            '-I' + os.path.join(REPO, 'include'), os.path.join(csrc, 'stc_cell_small.hip'), os.path.join(csrc, 'stc_gates.hip'), '-o', so])      # (stc_gates.hip: stc_last_error's buffer)
     lib = C.CDLL(so)
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
