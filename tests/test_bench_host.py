@@ -82,7 +82,7 @@ def test_presets_and_global_batch():
     a = bench.parse(['--preset', 'sf'])
     assert (a.grid, a.categories, a.obs, a.pred, a.batch_per_gpu, a.graph_mode, a.hip_graph) == (10, 5, 9, 3, 32, 'csr-fixed', True)
     a = bench.parse(['--preset', 'sf-learned', '--eager'])            # an explicit flag beats the preset's default
-    assert (a.graph_mode, a.hip_graph, a.no_cpu_baseline) == ('dense-learned', False, True)
+    assert (a.graph_mode, a.hip_graph, a.no_cpu_baseline) == ('dense-learned', False, False)      # (the preset lines carry a CPU baseline since round 4)
     assert set(bench.PRICED_ENTRY_POINTS) >= set(bench.PLAIN_SPMM) | {'stc_cell_bwd_planar_f32'}
     a = bench.parse(['--gpus', '4', '--global-batch', '8'])
     assert a.batch_per_gpu == 2
