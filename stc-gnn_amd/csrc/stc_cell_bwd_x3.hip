@@ -197,7 +197,7 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
     // the two T_1 fragments are used four times per node (both orientations, both convolutions): kept in registers for the whole kernel
     const Op tb0 = F::get(TB, 0, lane), tb1 = F::get(TB, 1, lane);
     // FmtH2 factors (all powers of two; 1 for FmtB3): what a tile of each phase carries besides sg, and their inverses
-    const float kc = sT * sWc, kg = sT * sWg, ikc = 1.f / kc, ikg = 1.f / kg;
+    const float kc = uniform_bits(sT * sWc), kg = uniform_bits(sT * sWg), ikc = inv_pow2(kc), ikg = inv_pow2(kg);      // (scalar registers)
     Ops cur, nxt, nx2;                            // operands two nodes ahead: ~40 MB in flight chip-wide instead of 20
     int node = blockIdx.x * CB_WAVES + wave;
     if (node < a.nodes) load_ops(cur, node);
@@ -300,9 +300,9 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
 #pragma unroll
                 for (int rb = 0; rb < NRB; ++rb) {
                     if (lb == RHB) {                               // out of the scaled space: the prologue works on plain values
-                        if constexpr (F::SCALED) drh[rb] = z[rb] * (ikc * inv_pow2(a_c)); else drh[rb] = z[rb];
+                        if constexpr (F::SCALED) drh[rb] = z[rb] * pow2_mul(ikc, inv_pow2(a_c)); else drh[rb] = z[rb];
                     } else {                                       // the X plane's share: becomes the start of a gates tile (factor kg here, the gates' scale there)
-                        if constexpr (F::SCALED) z[rb] *= ikc * inv_pow2(a_c) * kg;
+                        if constexpr (F::SCALED) z[rb] *= pow2_mul(pow2_mul(ikc, inv_pow2(a_c)), kg);
                         stash_x[rb * 64 + lane] = make_float4(z[rb][0], z[rb][1], z[rb][2], z[rb][3]);
                     }
                 }
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
                     c1[t] = lb == RHB ? rh_d[1][t] : zg[0][lb][1][t];
                 }
                 Op za;
-                if constexpr (F::SCALED) za = F::split(c0 * (sz[0][lb] * sh_c), c1 * (sz[0][lb] * sh_c)); else za = F::split(c0, c1);
+                if constexpr (F::SCALED) za = F::split(c0 * pow2_mul(sz[0][lb], sh_c), c1 * pow2_mul(sz[0][lb], sh_c)); else za = F::split(c0, c1);
 #pragma unroll
                 for (int n = 0; n < K; ++n)
 #pragma unroll
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
 #pragma unroll
                 for (int rb = 0; rb < NRB; ++rb) {
                     if constexpr (F::SCALED) {                     // out of the scaled space (+ the other consumer's gradients of the same plane)
-                        const float ikg_n = ikg * inv_pow2(a_g);
+                        const float ikg_n = pow2_mul(ikg, inv_pow2(a_g));
                         if (ACC[lb]) z[rb] = z[rb] * ikg_n + old[n][lb][rb];
                         else z[rb] *= ikg_n;
                     }
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
                 const float (&zc)[NRB][4] = zg[n][lb];
                 Op za;
                 if constexpr (F::SCALED) {
-                    const float zs = sz[n][lb] * sh_g;
+                    const float zs = pow2_mul(sz[n][lb], sh_g);
                     za = F::split(f32x4{zc[0][0], zc[0][1], zc[0][2], zc[0][3]} * zs, f32x4{zc[1][0], zc[1][1], zc[1][2], zc[1][3]} * zs);
                 }
                 else za = F::split(f32x4{zc[0][0], zc[0][1], zc[0][2], zc[0][3]}, f32x4{zc[1][0], zc[1][1], zc[1][2], zc[1][3]});

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nw = gridDim.x * MF_WAVES;
-    const float inv = 1.f / (sW * sT), invp = 1.f / (sWp * sT);       // (1 for FmtB3)
+    const float inv = inv_pow2(uniform_bits(sW * sT)), invp = inv_pow2(uniform_bits(sWp * sT));       // (1 for FmtB3; scalar registers)
     float bv[HB];
 #pragma unroll
     for (int hb = 0; hb < HB; ++hb) bv[hb] = bias ? bias[16 * hb + x] : 0.f;
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
                 }
             sz = pow2_scale(wave_max_nonneg(nm), STC_ACT_TARGET_FWD);
             const float isz = inv_pow2(sz);
-            invn = inv * isz; invpn = invp * isz;
+            invn = pow2_mul(inv, isz); invpn = pow2_mul(invp, isz);
         }
 
         f32x4 acc[NRB][NCB];
@@ -641,7 +641,7 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nw = gridDim.x * MF_WAVES;
-    const float kz = sT * sW, ikz = 1.f / kz;                 // (1 for FmtB3)
+    const float kz = uniform_bits(sT * sW), ikz = inv_pow2(kz);      // (1 for FmtB3; scalar registers)
 
     f32x4 dWt[K][LB][K][HB];          // dW tiles: rows l = 16lb + 4g + r, columns o = 16hb + x
     float dbp[HB];
@@ -667,14 +667,7 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
     while (node < nodes) {
         const int next_node = node + nw;
         const size_t r0 = (size_t)node * C;
-        f32x4 old[K][NRB];                                     // ACC: what the X-side planes already hold, requested BEFORE the prefetch (vmcnt counts in order)
         if constexpr (PFG) {
-            if constexpr (ACC != 0 && PL == 1 && F::SCALED) {
-#pragma unroll
-                for (int n = 0; n < K; ++n)
-#pragma unroll
-                    for (int rb = 0; rb < NRB; ++rb) old[n][rb] = stc_ld_once(reinterpret_cast<const f32x4*>(dZ.p[n] + (r0 + 16 * rb + x) * 16 + 4 * g));
-            }
             if (next_node < nodes) { rows_nxt.template load<PRO == PRO_GATES_CAND>(pro, next_node, x, g); nx.load_z(Z, next_node, x, g, Lw - 16); }
             __builtin_amdgcn_sched_barrier(0);
             form_dy<NRB, HB, FOLD != 0, TRS>(in.g, rows_cur, pro, node, x, g, stash, dy_tile);
@@ -716,7 +709,7 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
 #pragma unroll
                 for (int hb = 0; hb < HB; ++hb) { in.g.d[kb][hb] *= sg; in.g.v[kb][hb] *= sg; }
         }
-        const float ikz_sg = ikz * inv_pow2(sg);
+        const float ikz_sg = F::SCALED ? pow2_mul(ikz, inv_pow2(sg)) : 1.f;
         const DyFrag<NRB, HB>& gr = in.g;
 
 #pragma unroll
@@ -775,11 +768,21 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
                     if (FOLD && n == 0 && lb == HLB) {          // the tile starts from the state's share parked by the prologue
                         const float4 sh = stash[rb * 64 + lane];
                         z[rb] = f32x4{sh.x, sh.y, sh.z, sh.w};
-                        if constexpr (F::SCALED) z[rb] *= sg * kz;      // (parked unscaled)
+                        if constexpr (F::SCALED) z[rb] *= pow2_mul(sg, kz);      // (parked unscaled)
                     } else if (ACC && PL == 1 && lb == 0 && !F::SCALED) {     // ... or from what the plane already holds
                         z[rb] = stc_ld_once(reinterpret_cast<const f32x4*>(dZ.p[n] + (r0 + 16 * rb + x) * 16 + 4 * g));
                     } else {
                         z[rb] = kZero4;
+                    }
+                }
+                // ACC (fp16 x 2): what the plane already holds is requested HERE, one tile ahead of its use -- the matrix products of the tile cover
+                // the latency -- and lives for this tile only.  Requested for all K planes at the top of the node (24 registers through the whole
+                // body) the order-3 kernel spilled seven plane addresses and re-read them from scratch on every node: 301 -> 383 us per launch.
+                f32x4 held[NRB];
+                if constexpr (F::SCALED && ACC != 0 && PL == 1) {
+                    if (lb == 0) {
+#pragma unroll
+                        for (int rb = 0; rb < NRB; ++rb) held[rb] = stc_ld_once(reinterpret_cast<const f32x4*>(dZ.p[n] + (r0 + 16 * rb + x) * 16 + 4 * g));
                     }
                 }
 #pragma unroll
@@ -791,7 +794,7 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
                 if constexpr (F::SCALED) {                      // out of the scaled space (+ what the plane already holds)
 #pragma unroll
                     for (int rb = 0; rb < NRB; ++rb) {
-                        if (ACC && PL == 1 && lb == 0) z[rb] = z[rb] * ikz_sg + (PFG ? old[n][rb] : stc_ld_once(reinterpret_cast<const f32x4*>(dZ.p[n] + (r0 + 16 * rb + x) * 16 + 4 * g)));
+                        if (ACC && PL == 1 && lb == 0) z[rb] = z[rb] * ikz_sg + held[rb];
                         else z[rb] *= ikz_sg;
                     }
                 }
@@ -843,8 +846,8 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
                 for (int p = 0; p < NB2; ++p) {
                     const float (&zc)[NRB][4] = in.za[n][lb];
                     Op a;
-                    if constexpr (F::SCALED) a = F::split(f32x4{zc[2 * p][0], zc[2 * p][1], zc[2 * p][2], zc[2 * p][3]} * (sz[n][lb] * sh),
-                                                          f32x4{zc[2 * p + 1][0], zc[2 * p + 1][1], zc[2 * p + 1][2], zc[2 * p + 1][3]} * (sz[n][lb] * sh));
+                    if constexpr (F::SCALED) a = F::split(f32x4{zc[2 * p][0], zc[2 * p][1], zc[2 * p][2], zc[2 * p][3]} * pow2_mul(sz[n][lb], sh),
+                                                          f32x4{zc[2 * p + 1][0], zc[2 * p + 1][1], zc[2 * p + 1][2], zc[2 * p + 1][3]} * pow2_mul(sz[n][lb], sh));
                     else a = F::split(f32x4{zc[2 * p][0], zc[2 * p][1], zc[2 * p][2], zc[2 * p][3]},
                                       f32x4{zc[2 * p + 1][0], zc[2 * p + 1][1], zc[2 * p + 1][2], zc[2 * p + 1][3]});
 #pragma unroll
@@ -1044,7 +1047,7 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nw = gridDim.x * MF_WAVES;
-    const float ikz = 1.f / (sT * sW);
+    const float ikz = inv_pow2(uniform_bits(sT * sW));
     f32x4 dWt[K][LB][K][HB];
     float dbp[HB];
 #pragma unroll
@@ -1087,7 +1090,7 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
 #pragma unroll
                 for (int hb = 0; hb < HB; ++hb) dbp[hb] = 0.f;
             }
-            ikz_sg = ikz * inv_pow2(sg);
+            ikz_sg = pow2_mul(ikz, inv_pow2(sg));
 #pragma unroll
             for (int n = 0; n < K; ++n)
 #pragma unroll
@@ -1223,8 +1226,8 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
             for (int p = 0; p < NB2; ++p) {
                 const float (&zc)[NRB][4] = za[lb];
                 Op a;
-                if constexpr (F::SCALED) a = F::split(f32x4{zc[2 * p][0], zc[2 * p][1], zc[2 * p][2], zc[2 * p][3]} * (sz[lb] * sh),
-                                                      f32x4{zc[2 * p + 1][0], zc[2 * p + 1][1], zc[2 * p + 1][2], zc[2 * p + 1][3]} * (sz[lb] * sh));
+                if constexpr (F::SCALED) a = F::split(f32x4{zc[2 * p][0], zc[2 * p][1], zc[2 * p][2], zc[2 * p][3]} * pow2_mul(sz[lb], sh),
+                                                      f32x4{zc[2 * p + 1][0], zc[2 * p + 1][1], zc[2 * p + 1][2], zc[2 * p + 1][3]} * pow2_mul(sz[lb], sh));
                 else a = F::split(f32x4{zc[2 * p][0], zc[2 * p][1], zc[2 * p][2], zc[2 * p][3]},
                                   f32x4{zc[2 * p + 1][0], zc[2 * p + 1][1], zc[2 * p + 1][2], zc[2 * p + 1][3]});
 #pragma unroll

@@ -278,6 +278,12 @@ __device__ __forceinline__ float wave_max_nonneg(float m) {
     return __int_as_float(a > c ? a : c);
 }
 __device__ __forceinline__ int wave_max_bits(float m) { return __float_as_int(wave_max_nonneg(m)); }
+// a * b for two powers of two, on the exponent fields: integer arithmetic, i.e. the scalar unit when both are wave-uniform -- gfx950 has no
+// scalar float multiply, and as v_mul_f32 every such product is a vector instruction AND a vector register that stays live through the node
+// loop (seven spilled plane addresses in the order-3 gates backward: 27 % of its time).  The result must stay inside the normal range.
+__device__ __forceinline__ float pow2_mul(float a, float b) { return __uint_as_float(__float_as_uint(a) + __float_as_uint(b) - 0x3F800000u); }
+// a wave-uniform value into a scalar register (the compiler cannot know that a value read from LDS is the same in every lane)
+__device__ __forceinline__ float uniform_bits(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 // 1 / s for s = 2^k, |k| <= 126, on the exponent field
 __device__ __forceinline__ float inv_pow2(float s) { return __uint_as_float(0x7F000000u - __float_as_uint(s)); }
 // one wave's running maximum into its slot of a row of STC_ACT_SLOTS (the row was zero-filled before the launch)

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""Where a kernel's scratch (spill) accesses sit: per kernel of a hipcc -S file, the static scratch size and the number of scratch_load /
-scratch_store instructions in basic blocks that also hold matrix instructions (the node loop's hot blocks) against all other blocks (set-up,
-rare branches, exits).  A spill in a cold block costs nothing per node; one in a hot block goes to HBM on every node.
+"""Where a kernel's scratch (spill) accesses sit: per kernel of a hipcc -S file, the number of scratch_load / scratch_store instructions inside
+the node loop (the largest backward-branch span of the kernel; blocks of rare branches that the compiler placed inside the span are told apart
+by holding no matrix instruction AND being jumped over) against the rest (set-up, exits).  A spill outside the loop costs nothing per node;
+one inside is a memory round trip on every node -- eleven reloads of spilled plane addresses made the order-3 gates backward 27 % slower
+while every block with matrix instructions was clean.
 
     python tools/isa_scratch.py file.s [name-pattern ...]
 """
@@ -29,11 +31,19 @@ def main():
                 cur['scratch'] += 'scratch_' in l
                 cur['mfma'] += 'v_mfma' in l
         blocks.append(cur)
-        hot = [b for b in blocks if b['mfma'] >= 8]
-        cold = [b for b in blocks if b['mfma'] < 8]
-        size = next((int(m.group(1)) for l in lines[end:end + 400] for m in [re.search(r'\.amdhsa_private_segment_fixed_size (\d+)', l)] if m), -1)
-        print(f"{name[:110]}\n   scratch bytes/lane {size}; hot blocks: {sum(b['n'] for b in hot)} instr, {sum(b['mfma'] for b in hot)} mfma, "
-              f"{sum(b['scratch'] for b in hot)} scratch ops; other blocks: {sum(b['n'] for b in cold)} instr, {sum(b['scratch'] for b in cold)} scratch ops")
+        body = lines[st + 1:end]
+        labels = {m.group(1): i for i, l in enumerate(body) for m in [re.match(r'^(\.LBB\S+):', l)] if m}
+        span = (0, 0, 0)
+        for i, l in enumerate(body):
+            m = re.match(r'\s+s_c?branch\S*\s+(\.LBB\S+)', l)
+            if m and m.group(1) in labels and labels[m.group(1)] < i and i - labels[m.group(1)] > span[0]:
+                span = (i - labels[m.group(1)], labels[m.group(1)], i)
+        loop = [l for l in body[span[1]:span[2] + 1] if l.startswith('\t') and not l.strip().startswith(('.', ';'))]
+        in_loop = sum('scratch_' in l for l in loop)
+        total = sum(b['scratch'] for b in blocks)
+        with_mfma = sum(b['scratch'] for b in blocks if b['mfma'] >= 8)
+        print(f"{name[:110]}\n   node loop: {len(loop)} instr, {sum('v_mfma' in l for l in loop)} mfma, {in_loop} scratch ops ({with_mfma} in blocks with matrix "
+              f"instructions); outside the loop: {total - in_loop} scratch ops")
 
 
 if __name__ == '__main__':
