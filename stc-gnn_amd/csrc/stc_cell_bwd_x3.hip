@@ -244,7 +244,7 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
                 if constexpr (F::SCALED) {                         // into the node's own scale: everything below is linear in (dY, dBm)
                     float m = 0.f;
 #pragma unroll
-                    for (int kb = 0; kb < NRB; ++kb) m = __builtin_fmaxf(m, __builtin_fmaxf(absmax4(v0[kb]), absmax4(v1[kb])));
+                    for (int kb = 0; kb < NRB; ++kb) m = vmax3_acc(m, absmax4(v0[kb]), absmax4(v1[kb]));
                     bool restart;
                     a_c = rc.node(wave_max_bits(m), sh_c, restart);
                     if (__builtin_expect(restart, 0)) {
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
             if constexpr (F::SCALED) {                             // the gates' dY into the node's own scale
                 float m = 0.f;
 #pragma unroll
-                for (int kb = 0; kb < NRB; ++kb) m = __builtin_fmaxf(m, __builtin_fmaxf(absmax4(v0[kb]), absmax4(v1[kb])));
+                for (int kb = 0; kb < NRB; ++kb) m = vmax3_acc(m, absmax4(v0[kb]), absmax4(v1[kb]));
                 bool restart;
                 a_g = rg.node(wave_max_bits(m), sh_g, restart);
                 if (__builtin_expect(restart, 0)) {

@@ -244,9 +244,9 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd_x3_ke
 #pragma unroll
                 for (int rb = 0; rb < NRB; ++rb) {
                     const float ma = absmax4(cur[n][rb].a), mb = absmax4(cur[n][rb].b);
-                    if constexpr (PL == 1) { pmax[n] = __builtin_fmaxf(pmax[n], ma); qmax[n] = __builtin_fmaxf(qmax[n], mb); }
-                    else { pmax[n] = __builtin_fmaxf(pmax[n], g < 2 ? __builtin_fmaxf(ma, mb) : 0.f); qmax[n] = __builtin_fmaxf(qmax[n], g < 2 ? 0.f : ma); }
-                    nm = __builtin_fmaxf(nm, __builtin_fmaxf(ma, mb));
+                    if constexpr (PL == 1) { pmax[n] = max_nonneg(pmax[n], ma); qmax[n] = max_nonneg(qmax[n], mb); }
+                    else { pmax[n] = max_nonneg(pmax[n], g < 2 ? max_nonneg(ma, mb) : 0.f); qmax[n] = max_nonneg(qmax[n], g < 2 ? 0.f : ma); }
+                    nm = vmax3_acc(nm, ma, mb);
                 }
             sz = pow2_scale(wave_max_nonneg(nm), STC_ACT_TARGET_FWD);
             const float isz = inv_pow2(sz);
@@ -688,7 +688,7 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
 #pragma unroll
             for (int kb = 0; kb < NRB; ++kb)
 #pragma unroll
-                for (int hb = 0; hb < HB; ++hb) m = __builtin_fmaxf(m, absmax4(in.g.v[kb][hb]));
+                for (int hb = 0; hb < HB; ++hb) m = max_nonneg(m, absmax4(in.g.v[kb][hb]));
             bool restart;
             sg = rs.node(wave_max_bits(m), sh, restart);
             if (__builtin_expect(restart, 0)) {
@@ -1074,7 +1074,7 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
 #pragma unroll
                 for (int kb = 0; kb < NRB; ++kb)
 #pragma unroll
-                    for (int hb = 0; hb < HB; ++hb) m = __builtin_fmaxf(m, absmax4(gr[n].v[kb][hb]));
+                    for (int hb = 0; hb < HB; ++hb) m = max_nonneg(m, absmax4(gr[n].v[kb][hb]));
             bool restart;
             const float sg = rs.node(wave_max_bits(m), sh, restart);
             if (__builtin_expect(restart, 0)) {
