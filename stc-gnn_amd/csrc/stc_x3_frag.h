@@ -258,30 +258,18 @@ __device__ __forceinline__ float clamp_mix_scale(float sT) { return fminf(fmaxf(
 // (Vector-by-scalar products of the scaled kernels are written on the vector types and compile to v_pk_mul_f32: element by element -- twice the
 // instructions -- the one-launch cell backward ran 1 270 instead of 1 212 us per launch and the gates forward 704 instead of 682; in these
 // issue-bound loops the instruction count outweighs the packed instruction's extra cycles beside matrix instructions.)
-// Maxima of magnitudes as v_max3_f32 with |.| operand modifiers, in assembly: written with fmaxf / fabsf every maximum gets a
-// canonicalising `v_max_f32 v, v, v` per operand in front of it (IEEE maxnum on values the compiler cannot prove quiet) -- 86 instead of 28
-// instructions for the node maximum of the gates forward.  Operands are loaded values or vector-pipe results, never matrix-instruction
-// outputs (the hazard recogniser cannot pad an asm operand, see the conversions below).  acc must be non-negative.
-__device__ __forceinline__ float vmax3_abs(float a, float b, float c) {
-    float r;
-    asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
+// (Written in assembly as v_max3_f32 with |.| operand modifiers these maxima take a third of the instructions -- fmaxf gets a canonicalising
+// v_max_f32 v, v, v per operand -- and the one-launch cell backward ran 1 214 instead of 1 163 us: the scheduler cannot move matrix
+// instructions across asm statements.  Hence the plain form.)
+__device__ __forceinline__ float absmax4(const f32x4 v) {
+    return __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])), __builtin_fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3])));
 }
-__device__ __forceinline__ float vmax3_acc(float acc, float b, float c) {
-    float r;
-    asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(acc), "v"(b), "v"(c));
-    return r;
-}
-__device__ __forceinline__ float absmax4(const f32x4 v) { return vmax3_acc(vmax3_abs(v[0], v[1], v[2]), v[3], v[3]); }
-// running maximum of non-negative values: on the bit patterns (integer maximum: no canonicalisation either)
-__device__ __forceinline__ float max_nonneg(float a, float b) {
-    const int x = __float_as_int(a), y = __float_as_int(b);
-    return __int_as_float(x > y ? x : y);
-}
+__device__ __forceinline__ float max_nonneg(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ float vmax3_acc(float acc, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(acc, b), c); }      // (b, c non-negative)
 template <int CTRL>
 __device__ __forceinline__ float dpp_max(float m) {
     const int o = __builtin_amdgcn_update_dpp(0, __float_as_int(m), CTRL, 0xF, 0xF, true);
-    return __builtin_fmaxf(m, __int_as_float(o));      // (as an integer maximum the order-3 candidate forward spilled two plane addresses)
+    return __builtin_fmaxf(m, __int_as_float(o));
 }
 // max of a NON-NEGATIVE value over the wave, wave-uniform (scalar register): quad swaps, half-row and row mirrors, then the four rows
 __device__ __forceinline__ float wave_max_nonneg(float m) {

@@ -231,7 +231,10 @@ def test_bench_line_contract(storage):
     if storage == 'f32':
         c = d['cpu_baseline']
         assert c['kind'] == 'port' and c['cores'] >= 1 and c['value'] > 0 and c['unit'] == 'samples/s' and 'sample' in c
-        assert len(c['shots_s']['layer0']) == 9 and len(c['shots_s']['wide']) == 9     # 2 warm-up + 7 timed
+        # a small graph (here 12 x 12): the oracle's WHOLE model, dense reference algorithm, 2 warm-up + 7 timed steps; the
+        # metric's size takes one cell of each kind instead (shots_s = {'layer0': [...], 'wide': [...]})
+        assert len(c['shots_s']) == 9 and 'whole model' in c['sample']
+    assert d['per_rank']['ms_per_step_min'] <= d['per_rank']['ms_per_step_max'] and len(d['per_rank']['ms_per_step']) == 1 and d['per_rank']['build_s_max'] > 0
 
 
 @pytest.mark.gpu
