@@ -26,7 +26,7 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                 event records cost (the same step re-timed with the timer off)
                 ``dominant`` = the entry point with the largest share of the step (the one-launch cell backward), its algorithmic
                 plane bytes / its mean launch duration; ``mfma`` = matrix-pipe / vector-pipe busy fractions of the projection
-                kernels from the committed PMC pass (profiles/r03/mfma_util.json), quoted only for the same kernel sources
+                kernels from the committed PMC pass (profiles/rNN/mfma_util.json, newest round), quoted only for the same kernel sources
   kernels       time share of every C-ABI entry point: the priced ones (plain aggregation, dominant cell kernels) over the timed steps, the
                 rest from two further steps with every launch timed, scaled to the step count
   cpu_baseline  the CPU oracle (oracle/stc_oracle.py) on a bounded sample: 2 warm-up + 7 timed shots, median
@@ -333,7 +333,7 @@ def pmc_traffic(a, config_key):
 
 def pmc_mfma(config_key):
     """Matrix-pipe / vector-pipe busy fractions of the projection kernels (the split-operand MFMA cell kernels) from the committed
-    ``rocprofv3 --pmc`` passes over THIS command (tools/gpu_pmc_mfma.sh -> profiles/r03/mfma_util.json): quoted only while the
+    ``rocprofv3 --pmc`` passes over THIS command (tools/gpu_pmc_mfma.sh -> profiles/rNN/mfma_util.json): quoted only while the
     file's kernel-source hash and configuration equal the running tree's, else null with a note."""
     doc, where = _profile_doc('mfma_util.json')
     if doc is None:

@@ -2,7 +2,7 @@
 # HBM traffic of every kernel of ONE default bench step: FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc
 # passes (no trace domains besides --kernel-trace), aggregated per kernel into gpurun_out/spmm_traffic_bench.json together
 # with the hash of the kernel sources and the bench configuration it was collected on (bench.py quotes roofline.traffic
-# from the copy committed as profiles/r03/hbm_traffic_bench.json only while both still match).
+# from the copy committed as profiles/rNN/hbm_traffic_bench.json (the newest round) only while both still match).
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/gpurun_out && cd /tmp && export TMPDIR=/tmp
