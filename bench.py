@@ -16,8 +16,9 @@ T = 18 observed + 6 predicted steps, Bernoulli(0.1635) inputs, batch per GPU fix
 the batch x time-window dimension is sharded, the graph replicated, no data-path collective).
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline      the PLAIN aggregation launch Y = S.X of the train step (entry point stc_bcsr_spmm_f32, device kernel
-                spmm_bcsr_kernel): SURVEY 8(d3)'s algorithmic bytes nnz*(4+4) + 4*(N+1) + 2*B*N*F*4 per launch / its mean
+  roofline      the PLAIN aggregation launch Y = S.X of the train step (entry point stc_patch_spmm_f32, device kernel
+                spmm_patch_kernel; stc_bcsr_spmm_* / spmm_bcsr_kernel for bf16 storage and graphs without a patch plan):
+                SURVEY 8(d3)'s algorithmic bytes nnz*(4+4) + 4*(N+1) + 2*B*N*F*4 per launch / its mean
                 duration from HIP events recorded on the launching stream around every such launch of the TIMED steps.
                 ``aggregate`` beside it = every aggregation launch of the step (plain, GRU blend in the epilogue,
                 state-gradient sums) with every operand counted once; ``unit_d3`` = the exact 8(d3) unit (B = 1,
@@ -44,9 +45,9 @@ import time
 REPO = os.path.dirname(os.path.abspath(__file__))
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling ~5.4-6.3 TB/s
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32 / 32x32x2 (f32 in, f32 accumulate), whole chip (MI355X_MICROARCH.md)
-PLAIN_SPMM = ('stc_bcsr_spmm_f32', 'stc_bcsr_spmm_bf16')
+PLAIN_SPMM = ('stc_patch_spmm_f32', 'stc_bcsr_spmm_f32', 'stc_bcsr_spmm_bf16')
 # every C-ABI entry point that is an aggregation Y = S.X (+ epilogue)
-SPMM_ENTRY_POINTS = ('stc_bcsr_spmm_f32', 'stc_csr_spmm_f32', 'stc_spmm_sum_f32', 'stc_spmm_blend_fwd_f32',
+SPMM_ENTRY_POINTS = ('stc_patch_spmm_f32', 'stc_bcsr_spmm_f32', 'stc_csr_spmm_f32', 'stc_spmm_sum_f32', 'stc_spmm_blend_fwd_f32',
                      'stc_bcsr_spmm_bf16', 'stc_csr_spmm_bf16', 'stc_spmm_sum_bf16', 'stc_spmm_blend_fwd_bf16')
 # what the timed region records HIP events for: the roofline kernel (plain aggregation) and the entry points that can dominate a step
 PRICED_ENTRY_POINTS = PLAIN_SPMM + ('stc_cell_bwd_planar_f32', 'stc_cell_small_fwd_f32', 'stc_cell_small_bwd_f32')
@@ -323,12 +324,13 @@ def pmc_traffic(a, config_key):
     if doc.get('csrc_sha') != csrc_sha() or doc.get('config_key') != config_key:
         return None, f'{where} is from other sources/configuration ({doc.get("csrc_sha")}, {doc.get("config_key")}): not quoted'
     import re
-    ks = [v for name, v in doc['kernels'].items() if re.match(r'spmm_bcsr_kernel<\d+, 0,', name)]      # MODE = 0 (EP_PLAIN): the plain launches only
+    # the plain launches only: the patch kernel without Y0, or the row-blocked kernel with MODE = 0 (EP_PLAIN)
+    ks = [v for name, v in doc['kernels'].items() if re.match(r'spmm_patch_kernel<\d+, false>|spmm_bcsr_kernel<\d+, 0,', name)]
     if not ks:
         return None, None
     traffic = sum(v['hbm_bytes_per_launch'] * v['launches'] for v in ks) / sum(v['launches'] for v in ks)
     return traffic, ('PMC (FETCH_SIZE, WRITE_SIZE in separate rocprofv3 --pmc passes, unit-corrected as MI355X_MICROARCH.md prescribes), mean over the '
-                     f'spmm_bcsr_kernel launches of one step of this command on these sources (csrc {doc["csrc_sha"]}): {where}')
+                     f'plain aggregation launches of one step of this command on these sources (csrc {doc["csrc_sha"]}): {where}')
 
 
 def pmc_mfma(config_key):
@@ -616,7 +618,9 @@ def main():
         achieved = rate(plain)
         roofline = {
             'bound': 'hbm',
-            'kernel': 'spmm_bcsr_kernel (C-ABI stc_bcsr_spmm_' + a.storage + '): the plain aggregation launches Y = S.X of the timed train steps '
+            'kernel': ('spmm_patch_kernel (C-ABI stc_patch_spmm_f32: source rows of a cluster of 32 output rows staged through LDS)'
+                       if 'stc_patch_spmm_f32' in per_kernel else 'spmm_bcsr_kernel (C-ABI stc_bcsr_spmm_' + a.storage + ')')
+                      + ': the plain aggregation launches Y = S.X of the timed train steps '
                       f'(S.state forward, S^T.dY backward; rows of C*hidden = {C * a.hidden} values, {B} samples per launch)',
             'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS,
             'traffic': traffic, 'traffic_source': 'committed' if traffic is not None else None, 'traffic_note': traffic_note,

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define STC_ABI_VERSION 22
+#define STC_ABI_VERSION 23
 #define STC_MAX_K 4          /* highest Chebyshev order (Ks, Kc) the node kernels accept */
 
 /* Operand formats of the split-operand matrix-core kernels (C = 32 / 64, hidden 16).  Every fp32 operand is split into low-precision
@@ -92,6 +92,31 @@ int stc_bcsr_spmm_f32(const int32_t* blk_ptr, const int32_t* blk_cols, const flo
                       int32_t n_rows, int32_t n_cols,
                       const float* X, const float* Y0, float* Y,
                       int32_t batch, int32_t F, float alpha, float beta, void* stream);
+
+/* Same product on the PATCH form of a fixed graph whose rows cluster (grids and other meshes): the host groups the rows into
+ * patches of up to STC_PATCH_ROWS output rows whose entries touch at most STC_PATCH_MAX_SRC distinct source rows together
+ * (stc_hip/graph.py _patch_plan: 1.98 source rows per output row on the 8-neighbour grid, against 4.5 row fetches through L1 / L2
+ * for the row-blocked form).  One workgroup per (patch, batch element) copies the source rows into LDS, one 1 KiB column chunk at a
+ * time with the next chunk already requested, and forms the patch's output rows out of LDS: the kernel runs at the rate of a plain
+ * copy of X and Y (csrc/stc_spmm_patch.hip).  Per patch p:
+ *   patch_src  (n_patches, STC_PATCH_MAX_SRC)         the source rows (columns of the matrix) it gathers: position q of its list at
+ *                                                     [q % 4][q / 4] (wave q % 4 of the workgroup stages it), positions past the
+ *                                                     end of the list repeat its first source row
+ *   patch_rows (n_patches, STC_PATCH_ROWS)            its output rows, -1 = unused slot; every row of the matrix is in exactly one patch
+ *   patch_cnt  (n_patches, STC_PATCH_ROWS)            entries of each output row
+ *   patch_idx  (n_patches, STC_PATCH_ROWS, width) u8  per entry: position q of its column in the patch's source list
+ *   patch_val  (n_patches, STC_PATCH_ROWS, width)     per entry: its value; entries in the row's CSR order, the tail of the row
+ *                                                     filled with zero-weight repeats of its last entry
+ * width: 4, 8, 12, 16, 24 or 32 (<= STC_PATCH_MAX_WIDTH).  F: a multiple of 256 (STC_EUNSUPPORTED otherwise: use the row-blocked form).
+ * Each row's sum runs over its entries in CSR order, one fmaf each: results equal stc_csr_spmm_f32 / stc_bcsr_spmm_f32 bit for bit.
+ * Y0 / alpha / beta as stc_csr_spmm_f32 (Y0 may alias Y). */
+#define STC_PATCH_ROWS 32
+#define STC_PATCH_MAX_SRC 64
+#define STC_PATCH_MAX_WIDTH 32
+int stc_patch_spmm_f32(const int32_t* patch_src, const int32_t* patch_rows, const int32_t* patch_cnt,
+                       const uint8_t* patch_idx, const float* patch_val, int32_t n_patches, int32_t width,
+                       int32_t n_rows, int32_t n_cols, const float* X, const float* Y0, float* Y,
+                       int32_t batch, int32_t F, float alpha, float beta, void* stream);
 
 /* ---- bf16 storage (BASELINE.json configuration 5: N = 50 176, C = 64, bf16) ------------------------------------
  * The same two products with the feature rows stored in bf16: X, Y0, Y are bf16 (2 bytes per element, passed as

@@ -21,15 +21,16 @@ from .graph import is_full_pattern
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG_ROOT, 'libstc_hip.so')
-ABI_VERSION = 22
+ABI_VERSION = 23
 FMT_BF16X3, FMT_F16X2 = 0, 1          # STC_FMT_* of include/stc_hip.h: operand formats of the split-operand matrix-core kernels
 MAX_K = 4
 SPMM_SUM_MAX_ADD = 8     # = STC_SPMM_SUM_MAX_ADD of include/stc_hip.h
+PATCH_ROWS, PATCH_MAX_SRC = 32, 64          # = STC_PATCH_ROWS, STC_PATCH_MAX_SRC
 
 #: every symbol ``include/stc_hip.h`` declares (the CPU test-suite checks the .so exports them all)
 EXPORTS = (
     'stc_version', 'stc_last_error',
-    'stc_csr_spmm_f32', 'stc_bcsr_spmm_f32', 'stc_csr_spmm_bf16', 'stc_bcsr_spmm_bf16', 'stc_bdg_node_bf16_supported', 'stc_bdg_node_fwd_bf16', 'stc_bdg_node_bwd_bf16',
+    'stc_csr_spmm_f32', 'stc_bcsr_spmm_f32', 'stc_patch_spmm_f32', 'stc_csr_spmm_bf16', 'stc_bcsr_spmm_bf16', 'stc_bdg_node_bf16_supported', 'stc_bdg_node_fwd_bf16', 'stc_bdg_node_bwd_bf16',
     'stc_cell_planar_bf16_supported', 'stc_cell_gates_fwd_planar_bf16', 'stc_cell_gates_bwd_planar_bf16', 'stc_bdg_node_post_bwd_bf16',
     'stc_spmm_blend_fwd_bf16', 'stc_spmm_sum_bf16', 'stc_gru_blend_bwd_bf16', 'stc_head_fwd_bf16', 'stc_head_bwd_bf16',
     'stc_csr_sddmm_f32', 'stc_set_dispatch_level', 'stc_dense_agg_f32',
@@ -66,6 +67,7 @@ def _declare(lib):
     sig = {
         'stc_csr_spmm_f32': [_p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _f32, _p],
         'stc_bcsr_spmm_f32': [_p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _f32, _p],
+        'stc_patch_spmm_f32': [_p] * 5 + [_i32] * 4 + [_p, _p, _p, _i32, _i32, _f32, _f32, _p],
         'stc_csr_spmm_bf16': [_p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _f32, _p],
         'stc_bcsr_spmm_bf16': [_p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _f32, _p],
         'stc_dense_agg_f32': [_p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _f32, _p],
@@ -217,6 +219,10 @@ class HipKernels:
     #: operand format of the split-operand matrix-core cell kernels (include/stc_hip.h "operand formats"): two fp16 pieces / three
     #: products by default, STC_OPERAND_FORMAT=bf16x3 keeps three bf16 pieces / six products (fp32's range, twice the matrix instructions)
     operand_format = {'f16x2': FMT_F16X2, 'bf16x3': FMT_BF16X3}[os.environ.get('STC_OPERAND_FORMAT', 'f16x2')]
+    #: the patch form of the plain aggregation where the graph has one (STC_PATCH_SPMM=0: always the row-blocked kernel -- for A/B timing)
+    patch_spmm = os.environ.get('STC_PATCH_SPMM', '1') != '0'
+    #: ... for launches of at least this many (patch, sample) workgroups: six rounds of the chip's 512 resident ones
+    patch_min_items = 3072
 
     def __init__(self):
         self.lib = load_library()
@@ -354,8 +360,25 @@ class HipKernels:
         tag = 'plain' if plain else 'with_y0'
         # row-blocked kernel: rows of >= 64 floats, or narrow rows of 4 / 8 / 16 / 32 floats (the layer-0 input plane: several row
         # blocks per wave); anything else (odd widths, unaligned operands, no plan) goes to the CSR kernels
-        if plan is not None and F % 4 == 0 and (F >= 64 or F in (4, 8, 16, 32)) and all(t is None or t.data_ptr() % 16 == 0 for t in (X, Y0, Y)):
-            blk_ptr, blk_cols, blk_vals = plan
+        aligned = all(t is None or t.data_ptr() % 16 == 0 for t in (X, Y0, Y))
+        # patch form (a graph whose rows cluster, rows in whole 1 KiB chunks): source rows staged through LDS, copy rate
+        # (one workgroup per (patch, sample): with fewer than six rounds of the chip's 512 resident workgroups the tail of the launch costs
+        #  more than the staging saves -- 86 against 92 us for one sample of 1 024 floats on the bench's graph: row-blocked)
+        if plan is not None and len(plan) > 3 and F % 256 == 0 and aligned and self.patch_spmm and plan[3][3].shape[0] * B >= self.patch_min_items:
+            pt_src, pt_rows, pt_cnt, pt_idx, pt_val = plan[3]
+            n_p, width = pt_idx.shape[0], pt_idx.shape[2]
+            self._i32('spmm.pt_src', pt_src, n_p * PATCH_MAX_SRC)
+            self._i32('spmm.pt_rows', pt_rows, n_p * PATCH_ROWS)
+            self._i32('spmm.pt_cnt', pt_cnt, n_p * PATCH_ROWS)
+            if pt_idx.dtype != torch.uint8 or not pt_idx.is_contiguous() or pt_idx.shape != (n_p, PATCH_ROWS, width):
+                raise StcError(f'spmm.pt_idx must be a contiguous uint8 tensor of shape {(n_p, PATCH_ROWS, width)}')
+            self._f32('spmm.pt_val', pt_val, (n_p, PATCH_ROWS, width))
+            self._same_device(X, pt_src, pt_rows, pt_cnt, pt_idx, pt_val)
+            self._launch('stc_patch_spmm_f32', X, _ptr(pt_src), _ptr(pt_rows), _ptr(pt_cnt), _ptr(pt_idx), _ptr(pt_val), n_p, width,
+                         n_rows, n_cols, _ptr(X), _ptr(Y0), _ptr(Y), B, F, float(alpha), float(beta), nbytes=nbytes, tag=tag)
+            return
+        if plan is not None and F % 4 == 0 and (F >= 64 or F in (4, 8, 16, 32)) and aligned:
+            blk_ptr, blk_cols, blk_vals = plan[:3]
             self._i32('spmm.blk_ptr', blk_ptr, (n_rows + 3) // 4 + 1)
             self._i32('spmm.blk_cols', blk_cols)
             self._f32('spmm.blk_vals', blk_vals, (blk_cols.numel(), 4))
@@ -383,7 +406,7 @@ class HipKernels:
         nbytes = colidx.numel() * 8 + 4 * (n_rows + 1) + (2 if plain else 3) * 2 * B * n_rows * F
         tag = 'plain' if plain else 'with_y0'
         if plan is not None:
-            blk_ptr, blk_cols, blk_vals = plan
+            blk_ptr, blk_cols, blk_vals = plan[:3]
             self._i32('spmm.blk_ptr', blk_ptr, (n_rows + 3) // 4 + 1)
             self._i32('spmm.blk_cols', blk_cols)
             self._f32('spmm.blk_vals', blk_vals, (blk_cols.numel(), 4))
@@ -399,7 +422,7 @@ class HipKernels:
         self._f32('spmm.val', val, (colidx.numel(),))
         if plan is None:
             return [_ptr(rowptr), _ptr(colidx), _ptr(val), None, None, None]
-        blk_ptr, blk_cols, blk_vals = plan
+        blk_ptr, blk_cols, blk_vals = plan[:3]
         self._i32('spmm.blk_ptr', blk_ptr, (n_rows + 3) // 4 + 1)
         self._i32('spmm.blk_cols', blk_cols)
         self._f32('spmm.blk_vals', blk_vals, (blk_cols.numel(), 4))

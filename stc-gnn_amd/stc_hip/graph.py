@@ -74,6 +74,108 @@ def _row_block_plan(rowptr: np.ndarray, colidx: np.ndarray, val: np.ndarray, n: 
     return dict(blk_ptr=blk_ptr.astype(np.int32), blk_cols=cols.astype(np.int32), blk_vals=vals, distinct=distinct)
 
 
+PATCH_ROWS = 32         # = STC_PATCH_ROWS of include/stc_hip.h
+PATCH_MAX_SRC = 64      # = STC_PATCH_MAX_SRC
+PATCH_MAX_WIDTH = 32    # = STC_PATCH_MAX_WIDTH
+PATCH_WAVES = 4         # waves of the kernel's workgroup: slot r of a patch is wave r % 4's
+PATCH_WIDTHS = (4, 8, 12, 16, 24, 32)      # entries per row the kernel is built for
+
+
+def _patch_plan(rowptr: np.ndarray, colidx: np.ndarray, val: np.ndarray, n: int, max_fetch: float = 2.6, min_rows: float = 16.0):
+    """Patch form of a CSR matrix for ``stc_patch_spmm_f32`` (include/stc_hip.h), or None when the graph does not cluster.
+
+    Rows are grouped greedily: the first row not yet in a patch seeds one, which grows breadth-first over the symmetrised pattern
+    (rows not yet taken only) until it holds PATCH_ROWS rows or the distinct columns its rows touch would pass PATCH_MAX_SRC.  On a
+    mesh the patches come out as compact blobs (the 8-neighbour grid: 31.5 rows and 62 source rows per patch, 1.98 source rows per
+    output row; ideal 4 x 8 tiles would have 1.88).  A graph without such locality -- patches of a few rows, more than ``max_fetch``
+    source rows per output row -- or with a row of more than PATCH_MAX_WIDTH entries gets no plan: the row-blocked kernel is the
+    better one there.  Deterministic in the arrays alone (every rank of a job builds the same plan).
+
+    The patches keep the order they were seeded in.  The kernel's workgroups are dispatched in that order, an eighth of the list per XCD,
+    and what neighbouring patches share is found in that XCD's L2 when they are close in the list (measured on the bench's grid, whose
+    patches are seeded row by row: FETCH_SIZE 1.14 x the matrix).  Re-ordering the list as eight narrow sweeps (reverse Cuthill-McKee of
+    the patch graph, cut in eight, each part ordered again) was tried: no faster on a grid in natural or renumbered order, three times
+    slower on a graph numbered at random (tools/probes/patch_spmm_unit.py).
+    """
+    if n == 0 or colidx.size == 0:
+        return None
+    rp = rowptr.astype(np.int64)
+    deg = np.diff(rp)
+    if int(deg.max()) > PATCH_MAX_WIDTH:
+        return None
+    import scipy.sparse as sp
+    A = sp.csr_matrix((np.ones(colidx.size, dtype=np.int8), colidx, rp), shape=(n, n))
+    S = (A + A.T).tocsr()
+    srp, sci = S.indptr.tolist(), S.indices.tolist()
+    rpl, cil = rp.tolist(), colidx.tolist()
+    taken = np.zeros(n, dtype=bool)
+    patches = []                                       # (rows, source rows in first-touch order)
+    for seed in range(n):
+        if taken[seed]:
+            continue
+        rows, src, queue, queued, qi = [], {}, [seed], {seed}, 0
+        while qi < len(queue) and len(rows) < PATCH_ROWS:
+            u = queue[qi]
+            qi += 1
+            new = [c for c in cil[rpl[u]:rpl[u + 1]] if c not in src]
+            if len(src) + len(new) > PATCH_MAX_SRC:
+                continue                               # (rows stay available to later patches; a single row fits: width <= 32)
+            for c in new:
+                src[c] = len(src)
+            rows.append(u)
+            taken[u] = True
+            for w in sci[srp[u]:srp[u + 1]]:
+                if not taken[w] and w not in queued:
+                    queued.add(w)
+                    queue.append(w)
+        patches.append((rows, src))
+    if n / len(patches) < min_rows or sum(len(src) for _, src in patches) / n > max_fetch:
+        return None
+    return _patch_tables(rpl, cil, val, n, patches, int(deg.max()))
+
+
+def _patch_tables(rpl, cil, val, n, patches, max_deg):
+    """The arrays of ``stc_patch_spmm_f32`` for a given grouping: ``patches`` = [(rows, {source row: position in the patch's list})]."""
+    n_p = len(patches)
+    n_src = sum(len(src) for _, src in patches)
+    width = next(w for w in PATCH_WIDTHS if w >= max_deg)
+    pt_src = np.zeros((n_p, PATCH_WAVES, PATCH_MAX_SRC // PATCH_WAVES), dtype=np.int32)
+    pt_nsrc = np.zeros(n_p, dtype=np.int32)
+    pt_rows = np.full((n_p, PATCH_ROWS), -1, dtype=np.int32)
+    pt_cnt = np.zeros((n_p, PATCH_ROWS), dtype=np.int32)
+    pt_idx = np.zeros((n_p, PATCH_ROWS, width), dtype=np.uint8)
+    pt_val = np.zeros((n_p, PATCH_ROWS, width), dtype=np.float32)
+    for p, (rows, src) in enumerate(patches):
+        # position q of the list at [q % 4][q / 4]: the wave that stages it reads its 16 numbers with one scalar load; the record is
+        # filled up with repeats of the first source row (staged like the others: no branch in the kernel, a cache hit)
+        lst = np.full(PATCH_MAX_SRC, next(iter(src)), dtype=np.int32)
+        lst[:len(src)] = list(src)                      # (dicts keep insertion order: position = value)
+        pt_src[p] = lst.reshape(PATCH_MAX_SRC // PATCH_WAVES, PATCH_WAVES).T
+        pt_nsrc[p] = len(src)
+        pt_rows[p, :len(rows)] = rows
+        for r, u in enumerate(rows):
+            a, b = rpl[u], rpl[u + 1]
+            k = b - a
+            pt_cnt[p, r] = k
+            if k:
+                idx = [src[c] for c in cil[a:b]]
+                pt_idx[p, r, :k] = idx
+                pt_val[p, r, :k] = val[a:b]
+                pt_idx[p, r, k:] = idx[-1]              # the tail: zero-weight repeats of the last entry (a row it sums anyway)
+    # Slot r of a patch belongs to wave r % 4 of the workgroup (its i-th row: r = wave + 4 i).  A wave's slots past the patch's rows
+    # repeat that wave's FIRST row, tables and all: the kernel's row loop then needs no "is there a row" branch (a wave computes and
+    # stores the same values twice, in program order; with Y0 aliasing Y both read Y0 before either stores).  Only a wave with no row at
+    # all (patches of 1 .. 3 rows) keeps -1 slots, which the kernel sends to a dump line.
+    n_in = (pt_rows >= 0).sum(1)
+    for p in np.nonzero(n_in < PATCH_ROWS)[0]:
+        for r in range(int(n_in[p]), PATCH_ROWS):
+            if r % PATCH_WAVES < n_in[p]:
+                first = r % PATCH_WAVES
+                pt_rows[p, r], pt_cnt[p, r], pt_idx[p, r], pt_val[p, r] = pt_rows[p, first], pt_cnt[p, first], pt_idx[p, first], pt_val[p, first]
+    return dict(pt_nsrc=pt_nsrc, pt_src=pt_src, pt_rows=pt_rows, pt_cnt=pt_cnt, pt_idx=pt_idx, pt_val=pt_val,
+                fetch=n_src / n, rows_per_patch=n / n_p)
+
+
 class CsrGraph:
     """A fixed N x N spatial graph ``Gs`` resident in HBM as CSR(Gs^T) + CSR(Gs).
 
@@ -107,10 +209,19 @@ class CsrGraph:
         self._host = dict(fwd_rowptr=f_rp, fwd_colidx=f_ci, fwd_val=f_v,
                           bwd_rowptr=b_rp, bwd_colidx=b_ci, bwd_val=b_v, bwd_perm=perm.astype(np.int64))
         distinct = {}
+        #: side -> (source rows per output row, rows per patch) of the patch form, where the graph has one
+        self.patch_stats: Dict[str, Tuple[float, float]] = {}
         for side, (rp, ci, v) in (('fwd', (f_rp, f_ci, f_v)), ('bwd', (b_rp, b_ci, b_v))):
             plan = _row_block_plan(rp, ci, v, n)
             distinct[side] = plan.pop('distinct')
             self._host.update({f'{side}_{k}': a for k, a in plan.items()})
+            try:
+                patch = _patch_plan(rp, ci, v, n)
+            except ImportError:                         # scipy is optional (as for the locality order): no patch form without it
+                patch = None
+            if patch is not None:
+                self.patch_stats[side] = (patch.pop('fetch'), patch.pop('rows_per_patch'))
+                self._host.update({f'{side}_{k}': a for k, a in patch.items()})
         #: distinct neighbour rows fetched per output row by the row-blocked kernel (CSR: nnz / n)
         self.fetches_per_row = tuple(distinct[s_] / max(n, 1) for s_ in ('fwd', 'bwd'))
         self._dev: Dict[torch.device, Dict[str, torch.Tensor]] = {}
@@ -262,8 +373,10 @@ class SpatialOperand:
     bwd_colidx: torch.Tensor
     bwd_val: torch.Tensor            # never differentiable
     nnz: int
-    fwd_plan: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None   # (blk_ptr, blk_cols, blk_vals) of a fixed graph
-    bwd_plan: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None
+    # (blk_ptr, blk_cols, blk_vals) of a fixed graph, plus -- where its rows cluster -- a fourth item: the patch form
+    # (pt_src, pt_rows, pt_cnt, pt_idx, pt_val) of stc_patch_spmm_f32
+    fwd_plan: Optional[tuple] = None
+    bwd_plan: Optional[tuple] = None
 
 
 _PATTERN_CACHE: Dict[Tuple[int, torch.device], Tuple[torch.Tensor, torch.Tensor]] = {}
@@ -311,6 +424,10 @@ def dense_operand(Gs: torch.Tensor) -> SpatialOperand:
 
 def csr_operand(graph: CsrGraph, device: torch.device) -> SpatialOperand:
     d = graph.on(device)
-    plan = lambda side: (d[f'{side}_blk_ptr'], d[f'{side}_blk_cols'], d[f'{side}_blk_vals'])
+    def plan(side):
+        blocks = (d[f'{side}_blk_ptr'], d[f'{side}_blk_cols'], d[f'{side}_blk_vals'])
+        if f'{side}_pt_src' not in d:
+            return blocks
+        return blocks + (tuple(d[f'{side}_pt_{k}'] for k in ('src', 'rows', 'cnt', 'idx', 'val')),)
     return SpatialOperand(graph.n, d['fwd_rowptr'], d['fwd_colidx'], d['fwd_val'],
                           d['bwd_rowptr'], d['bwd_colidx'], d['bwd_val'], graph.nnz, plan('fwd'), plan('bwd'))

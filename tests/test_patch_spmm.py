@@ -1,0 +1,158 @@
+"""The patch form of the plain spatial aggregation Y = alpha S.X + beta Y0 (stc_patch_spmm_f32, csrc/stc_spmm_patch.hip; reference
+STC_GNN.py:37, torch.einsum('bncl,nm->bmcl', X, T_n(Gs))): source rows of a cluster of up to 32 output rows staged through LDS.
+
+CPU: the plan (stc_hip/graph.py _patch_plan) as data -- every row in exactly one patch, source lists within the LDS tile, the plan's
+own product (numpy) equal to the CSR product; which graphs get a plan and which do not.
+GPU: the kernel against the row-blocked kernel BIT FOR BIT (each row's sum runs over its entries in CSR order with one fmaf each in
+both) and against a float64 dense product within 1e-5; ragged patches, empty rows, one and several column chunks, the in-place Y0
+epilogue, both orientations of the graph, a renumbered (reverse Cuthill-McKee) node order; what the cell graph launches.
+"""
+import numpy as np
+import pytest
+import torch
+
+from stc_hip import CsrGraph
+from stc_hip.graph import PATCH_MAX_SRC, PATCH_ROWS, _patch_plan
+from tests.conftest import rel_err
+
+TOL = 1e-5
+
+
+def _weighted_grid(H, W, seed, permute_seed=None, drop=0.15):
+    """H x W 8-neighbour grid with random weights, ~15 % of the edges removed (ragged rows), rows 3 and 10 without entries."""
+    g0 = CsrGraph.queen_grid(H, W, normalize=False, permute_seed=permute_seed)
+    G = g0.to_dense()
+    gen = torch.Generator().manual_seed(seed)
+    G = G * torch.randn(G.shape, generator=gen) * (torch.rand(G.shape, generator=gen) > drop)
+    G[3] = 0
+    G[10] = 0
+    return CsrGraph.from_dense(G), G
+
+
+def _plan_product(h, side, X):
+    src, rows, cnt, idx, val = (h[f'{side}_pt_{k}'] for k in ('src', 'rows', 'cnt', 'idx', 'val'))
+    Y = np.zeros_like(X)
+    for p in range(rows.shape[0]):
+        s = src[p].T.reshape(-1)                                                     # position q of the list at [q % 4][q / 4]
+        for r in range(PATCH_ROWS):
+            if rows[p, r] >= 0:
+                Y[rows[p, r]] = (val[p, r, :, None].astype(np.float64) * X[s[idx[p, r]]]).sum(0) if cnt[p, r] else 0.0
+    return Y
+
+
+@pytest.mark.parametrize('H,W,permute', [(30, 30, None), (17, 41, None), (40, 40, 7)])
+def test_patch_plan_is_the_matrix(H, W, permute):
+    graph, G = _weighted_grid(H, W, seed=H * W, permute_seed=permute)
+    if permute is not None:
+        graph, order = graph.with_locality()
+        assert order is not None
+        G = G[order][:, order]
+    h, n = graph._host, graph.n
+    X = np.random.default_rng(1).standard_normal((n, 5))
+    for side, dense in (('fwd', G.t()), ('bwd', G)):
+        src, rows, nsrc = h[f'{side}_pt_src'], h[f'{side}_pt_rows'], h[f'{side}_pt_nsrc']
+        first = np.full(n, -1)                                                      # the patch each row is in: exactly one
+        for p in range(rows.shape[0]):
+            mine = np.unique(rows[p][rows[p] >= 0])
+            assert (first[mine] == -1).all()
+            first[mine] = p
+            for r in range(PATCH_ROWS):                                             # a repeated slot: the same wave's first row, tables and all
+                if rows[p, r] >= 0 and r >= mine.size:
+                    f = r % 4
+                    assert rows[p, r] == rows[p, f] and np.array_equal(h[f'{side}_pt_idx'][p, r], h[f'{side}_pt_idx'][p, f])
+                    assert np.array_equal(h[f'{side}_pt_val'][p, r], h[f'{side}_pt_val'][p, f])
+        assert (first >= 0).all()
+        assert src.shape[1:] == (4, PATCH_MAX_SRC // 4) and nsrc.max() <= PATCH_MAX_SRC and nsrc.min() >= 0
+        for p in range(rows.shape[0]):                                              # distinct source rows, then repeats of the first
+            lst = src[p].T.reshape(-1)
+            assert np.unique(lst[:nsrc[p]]).size == nsrc[p] and (lst[nsrc[p]:] == lst[0]).all()
+        assert h[f'{side}_pt_idx'].dtype == np.uint8 and h[f'{side}_pt_idx'].shape[2] % 4 == 0
+        np.testing.assert_allclose(_plan_product(h, side, X), dense.double().numpy() @ X, rtol=0, atol=1e-12)
+    fetch, per_patch = graph.patch_stats['fwd']
+    assert fetch < 2.4 and per_patch > 20
+
+
+def test_which_graphs_get_a_patch_plan():
+    assert CsrGraph.queen_grid(224, 224).patch_stats['fwd'][0] < 2.0                 # the bench's graph: 1.98 source rows per output row
+    assert CsrGraph.queen_grid(40, 40, permute_seed=1).patch_stats['fwd'][0] < 2.2   # the clusters follow the edges, not the node numbers
+    g = torch.Generator().manual_seed(0)
+    rows, cols = torch.randint(0, 2000, (2, 16000), generator=g).numpy()
+    keep = np.unique(rows.astype(np.int64) * 2000 + cols, return_index=True)[1]
+    assert CsrGraph(2000, rows[keep], cols[keep], np.ones(keep.size)).patch_stats == {}      # a random graph: patches of a few rows
+    dense = torch.rand(80, 80, generator=g)
+    assert CsrGraph.from_dense(dense).patch_stats == {}                               # rows of 80 entries: wider than the table
+    rp = np.array([0, 0, 0], dtype=np.int32)
+    assert _patch_plan(rp, np.zeros(0, np.int32), np.zeros(0, np.float32), 2) is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('H,W,F,B,permute', [(30, 30, 512, 2, None), (17, 41, 256, 3, None), (40, 40, 1024, 1, 7), (9, 9, 768, 2, None), (224, 8, 512, 1, None)])
+def test_patch_spmm_equals_the_row_blocked_kernel(H, W, F, B, permute):
+    from stc_hip._lib import HipKernels, KernelTimer
+    hip = HipKernels()
+    hip.patch_min_items = 0                                                        # (small launches go to the row-blocked kernel by default)
+    graph, G = _weighted_grid(H, W, seed=H + W + F, permute_seed=permute)
+    if permute is not None:
+        graph, order = graph.with_locality()
+        G = G[order][:, order]
+    n = graph.n
+    d = graph.on(torch.device('cuda'))
+    gen = torch.Generator().manual_seed(F)
+    X = torch.randn(B, n, F, generator=gen)
+    Y0 = torch.randn(B, n, F, generator=gen)
+    for side, dense in (('fwd', G.t()), ('bwd', G)):
+        rp, ci, vals = d[f'{side}_rowptr'], d[f'{side}_colidx'], d[f'{side}_val']
+        blocks = (d[f'{side}_blk_ptr'], d[f'{side}_blk_cols'], d[f'{side}_blk_vals'])
+        patches = blocks + (tuple(d[f'{side}_pt_{k}'] for k in ('src', 'rows', 'cnt', 'idx', 'val')),)
+        for alpha, beta in ((1.0, 0.0), (2.0, -1.0), (1.0, 1.0)):
+            want = alpha * torch.einsum('rc,bcf->brf', dense.double(), X.double()) + beta * Y0.double()
+            blocked = Y0.clone().cuda()
+            hip.csr_spmm(rp, ci, vals, n, n, X.cuda(), blocked if beta else None, blocked, alpha, beta, plan=blocks)
+            patched = Y0.clone().cuda()
+            hip.timer = t = KernelTimer()
+            hip.csr_spmm(rp, ci, vals, n, n, X.cuda(), patched if beta else None, patched, alpha, beta, plan=patches)      # (in place when there is a Y0)
+            hip.timer = None
+            assert list(t.summary()) == ['stc_patch_spmm_f32']
+            assert rel_err(patched, want) < TOL
+            assert torch.equal(patched, blocked)
+
+
+@pytest.mark.gpu
+def test_patch_spmm_rejects_what_it_cannot_do():
+    from stc_hip._lib import HipKernels, KernelTimer, StcError
+    hip = HipKernels()
+    hip.patch_min_items = 0
+    graph, _ = _weighted_grid(12, 12, seed=5)
+    d = graph.on(torch.device('cuda'))
+    pt = tuple(d[f'fwd_pt_{k}'] for k in ('src', 'rows', 'cnt', 'idx', 'val'))
+    n = graph.n
+    X, Y = torch.randn(1, n, 320).cuda(), torch.empty(1, n, 320).cuda()
+    plan = (d['fwd_blk_ptr'], d['fwd_blk_cols'], d['fwd_blk_vals'], pt)
+    hip.timer = t = KernelTimer()
+    hip.csr_spmm(d['fwd_rowptr'], d['fwd_colidx'], d['fwd_val'], n, n, X, None, Y, 1.0, 0.0, plan=plan)      # 320 floats: not whole chunks -> row-blocked
+    hip.timer = None
+    assert list(t.summary()) == ['stc_bcsr_spmm_f32']
+    import ctypes
+    p = lambda a: ctypes.c_void_p(a.data_ptr())
+    rc = hip.lib.stc_patch_spmm_f32(*[p(a) for a in pt], pt[3].shape[0], pt[3].shape[2], n, n, p(X), None, p(Y), 1, 320, 1.0, 0.0, None)
+    assert rc != 0 and b'multiple of 256' in hip.lib.stc_last_error()
+    with pytest.raises(StcError):
+        hip.csr_spmm(d['fwd_rowptr'], d['fwd_colidx'], d['fwd_val'], n, n, torch.randn(1, n, 256).cuda(), None, torch.empty(1, n, 256).cuda(), 1.0, 0.0,
+                     plan=plan[:3] + ((pt[0], pt[1], pt[2], pt[3].to(torch.int32), pt[4]),))
+
+
+@pytest.mark.gpu
+def test_small_launches_keep_the_row_blocked_kernel():
+    """Default dispatch: the patch form from six rounds of resident workgroups on (3 072 (patch, sample) items), the row-blocked one below."""
+    from stc_hip._lib import HipKernels, KernelTimer
+    hip = HipKernels()
+    graph = CsrGraph.queen_grid(64, 64)
+    d = graph.on(torch.device('cuda'))
+    n, n_p = graph.n, d['fwd_pt_idx'].shape[0]
+    plan = (d['fwd_blk_ptr'], d['fwd_blk_cols'], d['fwd_blk_vals'], tuple(d[f'fwd_pt_{k}'] for k in ('src', 'rows', 'cnt', 'idx', 'val')))
+    for B, want in ((1, 'stc_bcsr_spmm_f32'), (-(-3072 // n_p), 'stc_patch_spmm_f32')):
+        X, Y = torch.randn(B, n, 256).cuda(), torch.empty(B, n, 256).cuda()
+        hip.timer = t = KernelTimer()
+        hip.csr_spmm(d['fwd_rowptr'], d['fwd_colidx'], d['fwd_val'], n, n, X, None, Y, 1.0, 0.0, plan=plan)
+        hip.timer = None
+        assert list(t.summary()) == [want]
