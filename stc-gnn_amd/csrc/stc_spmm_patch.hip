@@ -8,10 +8,10 @@
 // element) copies the patch's source rows into LDS once per column chunk -- each lane a 16-byte piece, a wave instruction one
 // whole 1 KiB chunk of a row -- and forms the 32 output rows out of LDS:
 //
-//   chunk c:   LDS <- registers (requested during chunk c-1)  |  request chunk c+1 into registers  |  32 rows x 64 lanes: sum over the
+//   chunk c:   LDS <- registers (requested during chunk c-2)  |  request chunk c+2 into registers  |  32 rows x 64 lanes: sum over the
 //              row's entries of val x LDS[source position], non-temporal store
 //
-// so that a workgroup always has its next 60 KiB in flight while it multiplies (tools/probes/spmm_patch_sweep.hip: 180 us for the
+// so that a workgroup has its next two chunks in flight while it multiplies (tools/probes/spmm_patch_sweep.hip: 180 us for the
 // bench's unit against 211 us row-blocked and 181 us for a plain copy of the same two planes).  The sum of a row runs over its
 // entries in CSR order with one fmaf each, from zero: bit for bit the row-blocked and the CSR kernels' result.
 #include "stc_common.h"
@@ -91,8 +91,10 @@ __global__ __launch_bounds__(PT_THREADS) void spmm_patch_kernel(PatchPlan pl, in
     const int v_cnt = lane < RPW ? pl.cnt[(size_t)p * PT_ROWS + wave + PT_WAVES * lane] : 0;
 
     const v4f* Xb = X + (size_t)b * n_cols * F4 + lane;
-    v4f nx[PT_PER];
-    auto request = [&](int chunk) {
+    // TWO chunks in flight per workgroup (register sets A and B, 16 pieces per lane each): with one, a workgroup had nothing outstanding
+    // while it waited for its first chunk and little while it summed -- 2 x 60 KiB per compute unit kept the chip at 5.2 TB/s.
+    v4f nxa[PT_PER], nxb[PT_PER];
+    auto request = [&](v4f (&nx)[PT_PER], int chunk) {
 #pragma unroll
         for (int k = 0; k < PT_PER; ++k) nx[k] = Xb[(size_t)my_src[k] * F4 + chunk * PT_Q];
     };
@@ -100,7 +102,10 @@ __global__ __launch_bounds__(PT_THREADS) void spmm_patch_kernel(PatchPlan pl, in
     // One chunk: registers -> tile, the next chunk requested, the wave's rows summed out of the tile.  No branch in it: the wait for the
     // NEXT staging can then be counted past this chunk's result stores (vmcnt(8): they stay in flight), where behind a branch the
     // compiler has to drain them -- one exposed store latency per chunk.
-    auto step = [&](int chunk, auto more) {
+    // (With a Y0 operand ONE chunk ahead: memory returns in issue order, so the Y0 pieces of a chunk must be asked for before any later
+    //  chunk's rows or their wait is a wait for those as well -- and a second set of Y0 registers does not fit beside two chunks.)
+    constexpr int DEPTH = HAS_Y0 ? 1 : 2;
+    auto step = [&](v4f (&nx)[PT_PER], v4f (&other)[PT_PER], int chunk, auto more) {
         if (chunk) lds_barrier();                         // the previous chunk's sums are done with the tile
 #pragma unroll
         for (int k = 0; k < PT_PER; ++k) halo[(k * PT_WAVES + wave) * PT_Q + lane] = nx[k];
@@ -115,7 +120,10 @@ __global__ __launch_bounds__(PT_THREADS) void spmm_patch_kernel(PatchPlan pl, in
                 y0[i] = __builtin_nontemporal_load(row < 0 ? patch_dump + lane : Y0 + ((size_t)b * n_rows + row) * F4 + chunk * PT_Q + lane);
             }
         }
-        if (decltype(more)::value) request(chunk + 1);
+        if (decltype(more)::value) {
+            if (DEPTH == 2) request(nx, chunk + 2);      // into the set just emptied
+            else request(other, chunk + 1);
+        }
         // (a slot of the patch without a row -- patches of 1 .. 3 rows only, graph.py -- computes like the others and stores into a dump line)
 #pragma unroll
         for (int i = 0; i < RPW; ++i) {
@@ -139,9 +147,39 @@ __global__ __launch_bounds__(PT_THREADS) void spmm_patch_kernel(PatchPlan pl, in
             __builtin_nontemporal_store(out, row < 0 ? patch_dump + lane : Y + o);
         }
     };
-    request(0);
-    for (int chunk = 0; chunk + 1 < n_chunks; ++chunk) step(chunk, std::true_type{});
-    step(n_chunks - 1, std::false_type{});
+    constexpr std::true_type more{};
+    constexpr std::false_type last{};
+    request(nxa, 0);
+    int chunk = 0;
+    if (DEPTH == 2) {
+        if (n_chunks > 1) request(nxb, 1);
+        for (; chunk + 3 < n_chunks; chunk += 2) {        // pairs of chunks with both successors to request: no branch inside
+            step(nxa, nxb, chunk, more);
+            step(nxb, nxa, chunk + 1, more);
+        }
+        const int rest = n_chunks - chunk;                // 1, 2 or 3 chunks left
+        if (rest == 3) {
+            step(nxa, nxb, chunk, more);
+            step(nxb, nxa, chunk + 1, last);
+            step(nxa, nxb, chunk + 2, last);
+        } else if (rest == 2) {
+            step(nxa, nxb, chunk, last);
+            step(nxb, nxa, chunk + 1, last);
+        } else {
+            step(nxa, nxb, chunk, last);
+        }
+    } else {
+        for (; chunk + 2 < n_chunks; chunk += 2) {
+            step(nxa, nxb, chunk, more);
+            step(nxb, nxa, chunk + 1, more);
+        }
+        if (n_chunks - chunk == 2) {
+            step(nxa, nxb, chunk, more);
+            step(nxb, nxa, chunk + 1, last);
+        } else {
+            step(nxa, nxb, chunk, last);
+        }
+    }
 }
 
 }  // namespace
