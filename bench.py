@@ -753,13 +753,16 @@ def bench_cfg2(a):
         for _ in range(warm):
             fn()
         torch.cuda.synchronize()
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        for _ in range(steps):
-            fn()
-        e.record()
-        torch.cuda.synchronize()
-        return s.elapsed_time(e) / steps
+        rounds = []                                              # three rounds of ``steps``, the median one: a round is a few ms, and one
+        for _ in range(3):                                       # host hiccup (allocator, clock ramp of a fresh box) in it measured 5x
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(steps):
+                fn()
+            e.record()
+            torch.cuda.synchronize()
+            rounds.append(s.elapsed_time(e) / steps)
+        return sorted(rounds)[1]
 
     def fwd():
         with torch.no_grad():
@@ -801,7 +804,7 @@ def bench_cfg2(a):
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': f'single BDG_Dif layer, B={B} N={N} C={C} L={L} Ho={Ho} K={K}, dense differentiable Gs and Gc (gradients of X, W, b, Gs, Gc)',
                    'preset': 'cfg2'},
-        'forward_ms': ms_f, 'forward_backward_ms': ms_fb, 'cpu_baseline': cpu,
+        'forward_ms': ms_f, 'forward_backward_ms': ms_fb, 'timing': f'HIP events over three rounds of {steps} repetitions each, the median round', 'cpu_baseline': cpu,
         'roofline': {'bound': 'mfma', 'kernel': 'stc_dense_agg_f32 + the node kernels of one BDG_Dif (exact-fp32 matrix instructions)',
                      'achieved': (2.0 * B * N * N * C * L * (K - 1) + 2.0 * B * N * C * (K * K * L) * Ho + 2.0 * B * N * C * C * (K - 1) * Ho) / (ms_f * 1e-3) / 1e12,
                      'peak': FP32_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',

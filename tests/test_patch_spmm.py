@@ -12,7 +12,7 @@ import pytest
 import torch
 
 from stc_hip import CsrGraph
-from stc_hip.graph import PATCH_MAX_SRC, PATCH_ROWS, _patch_plan
+from stc_hip.graph import PATCH_MAX_SRC, PATCH_ROWS, PATCH_WAVES, _patch_plan
 from tests.conftest import rel_err
 
 TOL = 1e-5
@@ -33,7 +33,7 @@ def _plan_product(h, side, X):
     src, rows, cnt, idx, val = (h[f'{side}_pt_{k}'] for k in ('src', 'rows', 'cnt', 'idx', 'val'))
     Y = np.zeros_like(X)
     for p in range(rows.shape[0]):
-        s = src[p].T.reshape(-1)                                                     # position q of the list at [q % 4][q / 4]
+        s = src[p].T.reshape(-1)                                                     # position q of the list at [q % waves][q / waves]
         for r in range(PATCH_ROWS):
             if rows[p, r] >= 0:
                 Y[rows[p, r]] = (val[p, r, :, None].astype(np.float64) * X[s[idx[p, r]]]).sum(0) if cnt[p, r] else 0.0
@@ -58,11 +58,11 @@ def test_patch_plan_is_the_matrix(H, W, permute):
             first[mine] = p
             for r in range(PATCH_ROWS):                                             # a repeated slot: the same wave's first row, tables and all
                 if rows[p, r] >= 0 and r >= mine.size:
-                    f = r % 4
+                    f = r % PATCH_WAVES
                     assert rows[p, r] == rows[p, f] and np.array_equal(h[f'{side}_pt_idx'][p, r], h[f'{side}_pt_idx'][p, f])
                     assert np.array_equal(h[f'{side}_pt_val'][p, r], h[f'{side}_pt_val'][p, f])
         assert (first >= 0).all()
-        assert src.shape[1:] == (4, PATCH_MAX_SRC // 4) and nsrc.max() <= PATCH_MAX_SRC and nsrc.min() >= 0
+        assert src.shape[1:] == (PATCH_WAVES, PATCH_MAX_SRC // PATCH_WAVES) and nsrc.max() <= PATCH_MAX_SRC and nsrc.min() >= 0
         for p in range(rows.shape[0]):                                              # distinct source rows, then repeats of the first
             lst = src[p].T.reshape(-1)
             assert np.unique(lst[:nsrc[p]]).size == nsrc[p] and (lst[nsrc[p]:] == lst[0]).all()
