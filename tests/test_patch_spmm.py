@@ -157,3 +157,34 @@ def test_small_launches_keep_the_row_blocked_kernel():
         hip.csr_spmm(d['fwd_rowptr'], d['fwd_colidx'], d['fwd_val'], n, n, X, None, Y, 1.0, 0.0, plan=plan)
         hip.timer = None
         assert list(t.summary()) == [want]
+
+
+@pytest.mark.gpu
+def test_patch_spmm_at_the_bench_size():
+    """BASELINE.json's metric shape (224 x 224 grid, 5 samples, rows of 512 floats; 7 970 workgroups): the default dispatch takes the patch
+    kernel, and its result equals the row-blocked kernel's bit for bit in both orientations; a checksum of checksums against float64 on a
+    sample of rows (the dense product does not fit)."""
+    from stc_hip._lib import HipKernels, KernelTimer
+    hip = HipKernels()
+    graph = CsrGraph.queen_grid(224, 224)
+    d = graph.on(torch.device('cuda'))
+    n, B, F = graph.n, 5, 512
+    gen = torch.Generator().manual_seed(11)
+    X = torch.randn(B, n, F, generator=gen).cuda()
+    for side in ('fwd', 'bwd'):
+        rp, ci, vals = d[f'{side}_rowptr'], d[f'{side}_colidx'], d[f'{side}_val']
+        blocks = (d[f'{side}_blk_ptr'], d[f'{side}_blk_cols'], d[f'{side}_blk_vals'])
+        patches = blocks + (tuple(d[f'{side}_pt_{k}'] for k in ('src', 'rows', 'cnt', 'idx', 'val')),)
+        Yb, Yp = torch.empty_like(X), torch.empty_like(X)
+        hip.csr_spmm(rp, ci, vals, n, n, X, None, Yb, 1.0, 0.0, plan=blocks)
+        hip.timer = t = KernelTimer()
+        hip.csr_spmm(rp, ci, vals, n, n, X, None, Yp, 1.0, 0.0, plan=patches)
+        hip.timer = None
+        assert list(t.summary()) == ['stc_patch_spmm_f32']
+        assert torch.equal(Yp, Yb)
+        rows = torch.randint(0, n, (64,), generator=gen)
+        rpc, cic, vc = rp.cpu().long(), ci.cpu().long(), vals.cpu().double()
+        for r in rows.tolist():
+            cols = cic[rpc[r]:rpc[r + 1]]
+            want = (vc[rpc[r]:rpc[r + 1], None, None] * X[:, cols].cpu().double().transpose(0, 1)).sum(0)      # (B, F)
+            assert rel_err(Yp[:, r].cpu(), want) < TOL
