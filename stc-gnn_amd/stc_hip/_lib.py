@@ -221,8 +221,8 @@ class HipKernels:
     operand_format = {'f16x2': FMT_F16X2, 'bf16x3': FMT_BF16X3}[os.environ.get('STC_OPERAND_FORMAT', 'f16x2')]
     #: the patch form of the plain aggregation where the graph has one (STC_PATCH_SPMM=0: always the row-blocked kernel -- for A/B timing)
     patch_spmm = os.environ.get('STC_PATCH_SPMM', '1') != '0'
-    #: ... for launches of at least this many (patch, sample) workgroups (twice as many without a Y0 operand): six rounds of the chip's 512 resident ones
-    patch_min_items = 3072
+    #: ... for launches of at least this many (patch, sample) workgroups with a Y0 operand (three / six times as many without, see csr_spmm)
+    patch_min_items = 1000
 
     def __init__(self):
         self.lib = load_library()
@@ -362,10 +362,13 @@ class HipKernels:
         # blocks per wave); anything else (odd widths, unaligned operands, no plan) goes to the CSR kernels
         aligned = all(t is None or t.data_ptr() % 16 == 0 for t in (X, Y0, Y))
         # patch form (a graph whose rows cluster, rows in whole 1 KiB chunks): source rows staged through LDS, copy rate
-        # (one workgroup per (patch, sample): with few rounds of the chip's 512 resident workgroups the tail of the launch costs more than
-        #  the staging saves -- bench graph, rows of 1 024 floats, Y = S.X: 86 against 92 us for one sample, 160 against 169 us for two,
-        #  with a Y0 operand 242 against 231 us for two: row-blocked below twelve rounds (six with Y0))
-        if plan is not None and len(plan) > 3 and F % 256 == 0 and aligned and self.patch_spmm and plan[3][3].shape[0] * B >= self.patch_min_items * (2 if plain else 1):
+        # (one workgroup per (patch, sample).  With few rounds of the chip's 512 resident workgroups the tail of the launch costs more than
+        #  the staging saves -- rows of 512 floats, Y = S.X on the bench's grid: 37.7 against 32.7 us for one sample (1 594 workgroups), 83
+        #  against 88 us for two; on a 100 x 100 grid with four samples (1 272): 29.6 against 28.0 us; rows of 1 024 floats (four chunks per
+        #  workgroup; splitting them over two workgroups was slower still): 96 against 86 us for one sample, 169 against 165 for two.  With a
+        #  Y0 operand the patch form wins in all of these (54.6 against 61.6, 108 against 128, 41.5 against 49.7, 127 against 132 us).
+        #  Hence: from 1 000 workgroups with Y0, 3 000 without for rows of <= 512 floats, 6 000 for wider rows.)
+        if plan is not None and len(plan) > 3 and F % 256 == 0 and aligned and self.patch_spmm and plan[3][3].shape[0] * B >= self.patch_min_items * ((3 if F <= 512 else 6) if plain else 1):
             pt_src, pt_rows, pt_cnt, pt_idx, pt_val = plan[3]
             n_p, width = pt_idx.shape[0], pt_idx.shape[2]
             self._i32('spmm.pt_src', pt_src, n_p * PATCH_MAX_SRC)

@@ -143,15 +143,14 @@ def test_patch_spmm_rejects_what_it_cannot_do():
 
 @pytest.mark.gpu
 def test_small_launches_keep_the_row_blocked_kernel():
-    """Default dispatch: the patch form from twelve rounds of resident workgroups on (6 144 (patch, sample) items; six with a Y0 operand),
-    the row-blocked one below."""
+    """Default dispatch: the patch form from 3 000 (patch, sample) workgroups on (1 000 with a Y0 operand), the row-blocked one below."""
     from stc_hip._lib import HipKernels, KernelTimer
     hip = HipKernels()
     graph = CsrGraph.queen_grid(64, 64)
     d = graph.on(torch.device('cuda'))
     n, n_p = graph.n, d['fwd_pt_idx'].shape[0]
     plan = (d['fwd_blk_ptr'], d['fwd_blk_cols'], d['fwd_blk_vals'], tuple(d[f'fwd_pt_{k}'] for k in ('src', 'rows', 'cnt', 'idx', 'val')))
-    for B, want in ((1, 'stc_bcsr_spmm_f32'), (-(-6144 // n_p), 'stc_patch_spmm_f32')):
+    for B, want in ((1, 'stc_bcsr_spmm_f32'), (-(-3000 // n_p), 'stc_patch_spmm_f32')):
         X, Y = torch.randn(B, n, 256).cuda(), torch.empty(B, n, 256).cuda()
         hip.timer = t = KernelTimer()
         hip.csr_spmm(d['fwd_rowptr'], d['fwd_colidx'], d['fwd_val'], n, n, X, None, Y, 1.0, 0.0, plan=plan)

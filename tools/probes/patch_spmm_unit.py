@@ -14,6 +14,8 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 F = int(sys.argv[3]) if len(sys.argv) > 3 else 512
 seed = int(sys.argv[4]) if len(sys.argv) > 4 else None
 hip = HipKernels()
+if os.environ.get('PATCH_MIN') is not None:
+    hip.patch_min_items = int(os.environ['PATCH_MIN'])      # the launch-size rule of _lib.py (default 3 072 / 6 144 items)
 graph = CsrGraph.queen_grid(G, G, permute_seed=seed)
 if os.environ.get('LOCALITY'):
     graph = graph.with_locality()[0]                  # renumbered (reverse Cuthill-McKee), as the model does with a graph in arbitrary order
