@@ -45,9 +45,9 @@ import time
 REPO = os.path.dirname(os.path.abspath(__file__))
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling ~5.4-6.3 TB/s
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32 / 32x32x2 (f32 in, f32 accumulate), whole chip (MI355X_MICROARCH.md)
-PLAIN_SPMM = ('stc_patch_spmm_f32', 'stc_bcsr_spmm_f32', 'stc_bcsr_spmm_bf16')
+PLAIN_SPMM = ('stc_patch_spmm_f32', 'stc_patch_spmm_bf16', 'stc_bcsr_spmm_f32', 'stc_bcsr_spmm_bf16')
 # every C-ABI entry point that is an aggregation Y = S.X (+ epilogue)
-SPMM_ENTRY_POINTS = ('stc_patch_spmm_f32', 'stc_bcsr_spmm_f32', 'stc_csr_spmm_f32', 'stc_spmm_sum_f32', 'stc_spmm_blend_fwd_f32',
+SPMM_ENTRY_POINTS = ('stc_patch_spmm_f32', 'stc_patch_spmm_bf16', 'stc_bcsr_spmm_f32', 'stc_csr_spmm_f32', 'stc_spmm_sum_f32', 'stc_spmm_blend_fwd_f32',
                      'stc_bcsr_spmm_bf16', 'stc_csr_spmm_bf16', 'stc_spmm_sum_bf16', 'stc_spmm_blend_fwd_bf16')
 # what the timed region records HIP events for: the roofline kernel (plain aggregation) and the entry points that can dominate a step
 PRICED_ENTRY_POINTS = PLAIN_SPMM + ('stc_cell_bwd_planar_f32', 'stc_cell_small_fwd_f32', 'stc_cell_small_bwd_f32')
@@ -325,7 +325,7 @@ def pmc_traffic(a, config_key):
         return None, f'{where} is from other sources/configuration ({doc.get("csrc_sha")}, {doc.get("config_key")}): not quoted'
     import re
     # the plain launches only: the patch kernel without Y0, or the row-blocked kernel with MODE = 0 (EP_PLAIN)
-    ks = [v for name, v in doc['kernels'].items() if re.match(r'spmm_patch_kernel<\d+, false>|spmm_bcsr_kernel<\d+, 0,', name)]
+    ks = [v for name, v in doc['kernels'].items() if re.match(r'spmm_patch_kernel<\d+, false|spmm_bcsr_kernel<\d+, 0,', name)]
     if not ks:
         return None, None
     traffic = sum(v['hbm_bytes_per_launch'] * v['launches'] for v in ks) / sum(v['launches'] for v in ks)
@@ -618,8 +618,8 @@ def main():
         achieved = rate(plain)
         roofline = {
             'bound': 'hbm',
-            'kernel': ('spmm_patch_kernel (C-ABI stc_patch_spmm_f32: source rows of a cluster of 32 output rows staged through LDS)'
-                       if 'stc_patch_spmm_f32' in per_kernel else 'spmm_bcsr_kernel (C-ABI stc_bcsr_spmm_' + a.storage + ')')
+            'kernel': ('spmm_patch_kernel (C-ABI stc_patch_spmm_' + a.storage + ': source rows of a cluster of 32 output rows staged through LDS)'
+                       if 'stc_patch_spmm_' + a.storage in per_kernel else 'spmm_bcsr_kernel (C-ABI stc_bcsr_spmm_' + a.storage + ')')
                       + ': the plain aggregation launches Y = S.X of the timed train steps '
                       f'(S.state forward, S^T.dY backward; rows of C*hidden = {C * a.hidden} values, {B} samples per launch)',
             'achieved': achieved, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS,

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define STC_ABI_VERSION 23
+#define STC_ABI_VERSION 24
 #define STC_MAX_K 4          /* highest Chebyshev order (Ks, Kc) the node kernels accept */
 
 /* Operand formats of the split-operand matrix-core kernels (C = 32 / 64, hidden 16).  Every fp32 operand is split into low-precision
@@ -132,6 +132,13 @@ int stc_bcsr_spmm_bf16(const int32_t* blk_ptr, const int32_t* blk_cols, const fl
                        int32_t n_rows, int32_t n_cols,
                        const void* X, const void* Y0, void* Y,
                        int32_t batch, int32_t F, float alpha, float beta, void* stream);
+
+/* stc_patch_spmm_f32 on bf16 rows (X, Y0, Y bf16, F a multiple of 512; values and sums fp32, one rounding at the store: equal to
+ * stc_bcsr_spmm_bf16 bit for bit).  The same plan arrays. */
+int stc_patch_spmm_bf16(const int32_t* patch_src, const int32_t* patch_rows, const int32_t* patch_cnt,
+                        const uint8_t* patch_idx, const float* patch_val, int32_t n_patches, int32_t width,
+                        int32_t n_rows, int32_t n_cols, const void* X, const void* Y0, void* Y,
+                        int32_t batch, int32_t F, float alpha, float beta, void* stream);
 
 /* bf16-storage node kernel (2-mode product + concat + projection + bias, STC_GNN.py:38-45) and its backward: the slabs
  * Z_n (nodes, C, L), the output Y / its gradient dY (nodes, C, Ho) and the slab gradients dZ_n are bf16 (void*); Tc, W,

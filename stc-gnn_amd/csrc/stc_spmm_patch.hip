@@ -30,6 +30,62 @@ constexpr int PT_PER = PT_SRC / PT_WAVES;        // source rows each wave reques
 
 using v4f = __attribute__((ext_vector_type(4))) float;
 
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+
+// A 16-byte piece of a feature row and its fp32 sums: four floats, or eight bf16 (bf16 storage, BASELINE configuration 5: values widen to
+// fp32 exactly, products and sums in fp32, ONE rounding to bf16 at the store -- the contract of csrc/stc_spmm_bf16.hip, same fmaf chain).
+template <bool BF16>
+struct Piece {
+    float v[BF16 ? 8 : 4];
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int i = 0; i < (BF16 ? 8 : 4); ++i) v[i] = 0.f;
+    }
+    __device__ __forceinline__ void fma(float s, const v4f x) {
+        if (BF16) {
+            const u32x4 u = __builtin_bit_cast(u32x4, x);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[2 * i] = fmaf(s, __uint_as_float(u[i] << 16), v[2 * i]);
+                v[2 * i + 1] = fmaf(s, __uint_as_float(u[i] & 0xffff0000u), v[2 * i + 1]);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = fmaf(s, x[i], v[i]);
+        }
+    }
+    // alpha * sum (+ beta * y0), as the piece to store
+    template <bool HAS_Y0>
+    __device__ __forceinline__ v4f finish(float alpha, float beta, const v4f y0) const {
+        float r[BF16 ? 8 : 4];
+#pragma unroll
+        for (int i = 0; i < (BF16 ? 8 : 4); ++i) r[i] = alpha * v[i];
+        if (BF16) {
+            if (HAS_Y0) {
+                const u32x4 u = __builtin_bit_cast(u32x4, y0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    r[2 * i] = fmaf(beta, __uint_as_float(u[i] << 16), r[2 * i]);
+                    r[2 * i + 1] = fmaf(beta, __uint_as_float(u[i] & 0xffff0000u), r[2 * i + 1]);
+                }
+            }
+            u32x4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bf16x2 t = {(__bf16)r[2 * i], (__bf16)r[2 * i + 1]};       // v_cvt_pk_bf16_f32, round to nearest even
+                o[i] = __builtin_bit_cast(unsigned, t);
+            }
+            return __builtin_bit_cast(v4f, o);
+        }
+        if (HAS_Y0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r[i] = fmaf(beta, y0[i], r[i]);
+        }
+        return v4f{r[0], r[1], r[2], r[3]};
+    }
+};
+
 struct PatchPlan {
     const int32_t *src, *rows, *cnt;
     const uint8_t* idx;
@@ -53,7 +109,7 @@ __device__ v4f patch_dump[64];                           // where the slots of a
 // in that XCD's L2 (the host orders each eighth as a narrow sweep, graph.py _swept).  (A persistent variant -- two workgroups per compute
 // unit walking strided runs of patches, tables loaded once per patch -- hid the per-workgroup table loads but lost that: a workgroup's
 // next patch was 64 further down the list, the rows shared with it long evicted; FETCH_SIZE 1.45 x the matrix against 1.05 x.)
-template <int W, bool HAS_Y0>
+template <int W, bool HAS_Y0, bool BF16>
 __global__ __launch_bounds__(PT_THREADS) void spmm_patch_kernel(PatchPlan pl, int n_rows, int n_cols, const v4f* __restrict__ X,
                                                                const v4f* __restrict__ Y0, v4f* __restrict__ Y, int F4, float alpha, float beta) {
     constexpr int RPW = PT_ROWS / PT_WAVES, NV = (RPW * W + 63) / 64;
@@ -129,22 +185,18 @@ __global__ __launch_bounds__(PT_THREADS) void spmm_patch_kernel(PatchPlan pl, in
         for (int i = 0; i < RPW; ++i) {
             const int row = __builtin_amdgcn_readlane(v_row, i);
             const size_t o = ((size_t)b * n_rows + (row < 0 ? 0 : row)) * F4 + chunk * PT_Q + lane;
-            v4f acc = {0.f, 0.f, 0.f, 0.f};
+            Piece<BF16> acc;
+            acc.zero();
             // all W entries (the host fills a row's tail with zero-weight repeats of its last entry: the same sum, term for term)
 #pragma unroll
             for (int w = 0; w < W; ++w) {
                 const int e = i * W + w;
                 const int off = __builtin_amdgcn_readlane(t_off[e / 64], e % 64);
                 const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t_val[e / 64]), e % 64));
-                const v4f x = *reinterpret_cast<const v4f*>(tile + off);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc[c] = fmaf(v, x[c], acc[c]);
+                acc.fma(v, *reinterpret_cast<const v4f*>(tile + off));
             }
-            if (__builtin_amdgcn_readlane(v_cnt, i) == 0) acc = v4f{0.f, 0.f, 0.f, 0.f};      // a row without entries sums nothing
-            v4f out;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) out[c] = HAS_Y0 ? fmaf(beta, y0[i][c], alpha * acc[c]) : alpha * acc[c];
-            __builtin_nontemporal_store(out, row < 0 ? patch_dump + lane : Y + o);
+            if (__builtin_amdgcn_readlane(v_cnt, i) == 0) acc.zero();                          // a row without entries sums nothing
+            __builtin_nontemporal_store(acc.template finish<HAS_Y0>(alpha, beta, y0[HAS_Y0 ? i : 0]), row < 0 ? patch_dump + lane : Y + o);
         }
     };
     constexpr std::true_type more{};
@@ -184,42 +236,69 @@ __global__ __launch_bounds__(PT_THREADS) void spmm_patch_kernel(PatchPlan pl, in
 
 }  // namespace
 
+namespace {
+
+// X / Y0 / Y as 16-byte pieces: F4 of them per row (F / 4 floats or F / 8 bf16)
+int launch_patch(const char* who, const PatchPlan& pl, int n_rows, int n_cols, const void* X, const void* Y0, void* Y, int batch, int F4, bool bf16,
+                 float alpha, float beta, hipStream_t s) {
+    const size_t lds = (size_t)PT_SRC * PT_Q * 16;
+    const bool has_y0 = Y0 != nullptr && beta != 0.f;
+    using Kernel = void (*)(PatchPlan, int, int, const v4f*, const v4f*, v4f*, int, float, float);
+    Kernel kern = nullptr;
+    int slot = 0;
+#define STC_PATCH_W(W_, SLOT_) case W_: kern = bf16 ? (has_y0 ? spmm_patch_kernel<W_, true, true> : spmm_patch_kernel<W_, false, true>)  \
+                                                    : (has_y0 ? spmm_patch_kernel<W_, true, false> : spmm_patch_kernel<W_, false, false>); slot = SLOT_; break
+    switch (pl.width) { STC_PATCH_W(4, 0); STC_PATCH_W(8, 1); STC_PATCH_W(12, 2); STC_PATCH_W(16, 3); STC_PATCH_W(24, 4); STC_PATCH_W(32, 5);
+                        default: STC_REQUIRE(false, STC_EUNSUPPORTED, "%s: width %d (built for 4, 8, 12, 16, 24, 32)", who, pl.width); }
+#undef STC_PATCH_W
+    static std::atomic<int> granted[6][2][2][16];        // 64 KiB of dynamic LDS is above the default limit: once per kernel and device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    if (!granted[slot][has_y0][bf16][dev].load(std::memory_order_acquire)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return stc::hip_status(e, who);
+        granted[slot][has_y0][bf16][dev].store(1, std::memory_order_release);
+    }
+    const int per = (pl.n_patches + stc::kNumXcd - 1) / stc::kNumXcd;
+    hipLaunchKernelGGL(kern, dim3(per * stc::kNumXcd, batch), dim3(PT_THREADS), lds, s, pl, n_rows, n_cols, static_cast<const v4f*>(X),
+                       static_cast<const v4f*>(Y0), static_cast<v4f*>(Y), F4, alpha, beta);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return stc::hip_status(e, who);
+    return STC_OK;
+}
+
+int check_patch(const char* who, const void* patch_src, const void* patch_rows, const void* patch_cnt, const void* patch_idx, const void* patch_val,
+                int n_patches, int n_rows, int n_cols, const void* X, const void* Y0, const void* Y, int batch, int F, int chunk_elems, float beta) {
+    STC_REQUIRE(patch_src && patch_rows && patch_cnt && patch_idx && patch_val && X && Y, STC_EINVAL, "%s: null pointer", who);
+    STC_REQUIRE(n_patches >= 1 && (long long)n_patches * PT_ROWS >= n_rows, STC_EINVAL, "%s: %d patches of %d rows cannot cover %d rows", who, n_patches, PT_ROWS, n_rows);
+    STC_REQUIRE(F % chunk_elems == 0, STC_EUNSUPPORTED, "%s: F=%d must be a multiple of %d (rows in whole 1 KiB chunks)", who, F, chunk_elems);
+    STC_REQUIRE(beta == 0.f || Y0, STC_EINVAL, "%s: beta != 0 needs Y0", who);
+    STC_REQUIRE(X != Y, STC_EINVAL, "%s: X must not alias Y", who);
+    STC_REQUIRE(stc::aligned16(X) && stc::aligned16(Y) && (!Y0 || stc::aligned16(Y0)), STC_EALIGN, "%s: X / Y / Y0 must be 16-byte aligned", who);
+    STC_REQUIRE(batch <= 65535, STC_ELIMIT, "%s: batch %d > 65535 (grid.y)", who, batch);
+    return STC_OK;
+}
+
+}  // namespace
+
 extern "C" int stc_patch_spmm_f32(const int32_t* patch_src, const int32_t* patch_rows, const int32_t* patch_cnt,
                                   const uint8_t* patch_idx, const float* patch_val, int32_t n_patches, int32_t width,
                                   int32_t n_rows, int32_t n_cols, const float* X, const float* Y0, float* Y,
                                   int32_t batch, int32_t F, float alpha, float beta, void* stream) {
     STC_REQUIRE(n_rows >= 0 && n_cols >= 0 && batch >= 0 && F >= 0 && n_patches >= 0, STC_EINVAL, "stc_patch_spmm_f32: negative size");
     if (n_rows == 0 || batch == 0 || F == 0) return STC_OK;
-    STC_REQUIRE(patch_src && patch_rows && patch_cnt && patch_idx && patch_val && X && Y, STC_EINVAL, "stc_patch_spmm_f32: null pointer");
-    STC_REQUIRE(n_patches >= 1 && (long long)n_patches * PT_ROWS >= n_rows, STC_EINVAL,
-                "stc_patch_spmm_f32: %d patches of %d rows cannot cover %d rows", n_patches, PT_ROWS, n_rows);
-    STC_REQUIRE(F % (4 * PT_Q) == 0, STC_EUNSUPPORTED, "stc_patch_spmm_f32: F=%d must be a multiple of %d (rows in whole 1 KiB chunks)", F, 4 * PT_Q);
-    STC_REQUIRE(beta == 0.f || Y0, STC_EINVAL, "stc_patch_spmm_f32: beta != 0 needs Y0");
-    STC_REQUIRE(X != Y, STC_EINVAL, "stc_patch_spmm_f32: X must not alias Y");
-    STC_REQUIRE(stc::aligned16(X) && stc::aligned16(Y) && (!Y0 || stc::aligned16(Y0)), STC_EALIGN, "stc_patch_spmm_f32: X / Y / Y0 must be 16-byte aligned");
-    STC_REQUIRE(batch <= 65535, STC_ELIMIT, "stc_patch_spmm_f32: batch %d > 65535 (grid.y)", batch);
+    if (int rc = check_patch("stc_patch_spmm_f32", patch_src, patch_rows, patch_cnt, patch_idx, patch_val, n_patches, n_rows, n_cols, X, Y0, Y, batch, F, 4 * PT_Q, beta)) return rc;
     const PatchPlan pl{patch_src, patch_rows, patch_cnt, patch_idx, patch_val, n_patches, width};
-    const size_t lds = (size_t)PT_SRC * PT_Q * 16;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    const bool has_y0 = Y0 != nullptr && beta != 0.f;
-    using Kernel = void (*)(PatchPlan, int, int, const v4f*, const v4f*, v4f*, int, float, float);
-    Kernel kern = nullptr;
-    int slot = 0;
-#define STC_PATCH_W(W_, SLOT_) case W_: kern = has_y0 ? spmm_patch_kernel<W_, true> : spmm_patch_kernel<W_, false>; slot = SLOT_; break
-    switch (width) { STC_PATCH_W(4, 0); STC_PATCH_W(8, 1); STC_PATCH_W(12, 2); STC_PATCH_W(16, 3); STC_PATCH_W(24, 4); STC_PATCH_W(32, 5);
-                     default: STC_REQUIRE(false, STC_EUNSUPPORTED, "stc_patch_spmm_f32: width %d (built for 4, 8, 12, 16, 24, 32)", width); }
-#undef STC_PATCH_W
-    static std::atomic<int> granted[6][2][16];           // 64 KiB of dynamic LDS is above the default limit: once per kernel and device
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
-    if (!granted[slot][has_y0][dev].load(std::memory_order_acquire)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return stc::hip_status(e, "stc_patch_spmm_f32 (LDS grant)");
-        granted[slot][has_y0][dev].store(1, std::memory_order_release);
-    }
-    const int per = (n_patches + stc::kNumXcd - 1) / stc::kNumXcd;
-    hipLaunchKernelGGL(kern, dim3(per * stc::kNumXcd, batch), dim3(PT_THREADS), lds, s, pl, n_rows, n_cols, reinterpret_cast<const v4f*>(X),
-                       reinterpret_cast<const v4f*>(Y0), reinterpret_cast<v4f*>(Y), F / 4, alpha, beta);
-    STC_LAUNCH_CHECK("stc_patch_spmm_f32 launch");
-    return STC_OK;
+    return launch_patch("stc_patch_spmm_f32 launch", pl, n_rows, n_cols, X, Y0, Y, batch, F / 4, false, alpha, beta, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int stc_patch_spmm_bf16(const int32_t* patch_src, const int32_t* patch_rows, const int32_t* patch_cnt,
+                                   const uint8_t* patch_idx, const float* patch_val, int32_t n_patches, int32_t width,
+                                   int32_t n_rows, int32_t n_cols, const void* X, const void* Y0, void* Y,
+                                   int32_t batch, int32_t F, float alpha, float beta, void* stream) {
+    STC_REQUIRE(n_rows >= 0 && n_cols >= 0 && batch >= 0 && F >= 0 && n_patches >= 0, STC_EINVAL, "stc_patch_spmm_bf16: negative size");
+    if (n_rows == 0 || batch == 0 || F == 0) return STC_OK;
+    if (int rc = check_patch("stc_patch_spmm_bf16", patch_src, patch_rows, patch_cnt, patch_idx, patch_val, n_patches, n_rows, n_cols, X, Y0, Y, batch, F, 8 * PT_Q, beta)) return rc;
+    const PatchPlan pl{patch_src, patch_rows, patch_cnt, patch_idx, patch_val, n_patches, width};
+    return launch_patch("stc_patch_spmm_bf16 launch", pl, n_rows, n_cols, X, Y0, Y, batch, F / 8, true, alpha, beta, static_cast<hipStream_t>(stream));
 }

@@ -21,7 +21,7 @@ from .graph import is_full_pattern
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG_ROOT, 'libstc_hip.so')
-ABI_VERSION = 23
+ABI_VERSION = 24
 FMT_BF16X3, FMT_F16X2 = 0, 1          # STC_FMT_* of include/stc_hip.h: operand formats of the split-operand matrix-core kernels
 MAX_K = 4
 SPMM_SUM_MAX_ADD = 8     # = STC_SPMM_SUM_MAX_ADD of include/stc_hip.h
@@ -30,7 +30,7 @@ PATCH_ROWS, PATCH_MAX_SRC = 32, 64          # = STC_PATCH_ROWS, STC_PATCH_MAX_SR
 #: every symbol ``include/stc_hip.h`` declares (the CPU test-suite checks the .so exports them all)
 EXPORTS = (
     'stc_version', 'stc_last_error',
-    'stc_csr_spmm_f32', 'stc_bcsr_spmm_f32', 'stc_patch_spmm_f32', 'stc_csr_spmm_bf16', 'stc_bcsr_spmm_bf16', 'stc_bdg_node_bf16_supported', 'stc_bdg_node_fwd_bf16', 'stc_bdg_node_bwd_bf16',
+    'stc_csr_spmm_f32', 'stc_bcsr_spmm_f32', 'stc_patch_spmm_f32', 'stc_patch_spmm_bf16', 'stc_csr_spmm_bf16', 'stc_bcsr_spmm_bf16', 'stc_bdg_node_bf16_supported', 'stc_bdg_node_fwd_bf16', 'stc_bdg_node_bwd_bf16',
     'stc_cell_planar_bf16_supported', 'stc_cell_gates_fwd_planar_bf16', 'stc_cell_gates_bwd_planar_bf16', 'stc_bdg_node_post_bwd_bf16',
     'stc_spmm_blend_fwd_bf16', 'stc_spmm_sum_bf16', 'stc_gru_blend_bwd_bf16', 'stc_head_fwd_bf16', 'stc_head_bwd_bf16',
     'stc_csr_sddmm_f32', 'stc_set_dispatch_level', 'stc_dense_agg_f32',
@@ -68,6 +68,7 @@ def _declare(lib):
         'stc_csr_spmm_f32': [_p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _f32, _p],
         'stc_bcsr_spmm_f32': [_p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _f32, _p],
         'stc_patch_spmm_f32': [_p] * 5 + [_i32] * 4 + [_p, _p, _p, _i32, _i32, _f32, _f32, _p],
+        'stc_patch_spmm_bf16': [_p] * 5 + [_i32] * 4 + [_p, _p, _p, _i32, _i32, _f32, _f32, _p],
         'stc_csr_spmm_bf16': [_p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _f32, _p],
         'stc_bcsr_spmm_bf16': [_p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _f32, _p],
         'stc_dense_agg_f32': [_p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _f32, _p],
@@ -368,17 +369,8 @@ class HipKernels:
         #  workgroup; splitting them over two workgroups was slower still): 96 against 86 us for one sample, 169 against 165 for two.  With a
         #  Y0 operand the patch form wins in all of these (54.6 against 61.6, 108 against 128, 41.5 against 49.7, 127 against 132 us).
         #  Hence: from 1 000 workgroups with Y0, 3 000 without for rows of <= 512 floats, 6 000 for wider rows.)
-        if plan is not None and len(plan) > 3 and F % 256 == 0 and aligned and self.patch_spmm and plan[3][3].shape[0] * B >= self.patch_min_items * ((3 if F <= 512 else 6) if plain else 1):
-            pt_src, pt_rows, pt_cnt, pt_idx, pt_val = plan[3]
-            n_p, width = pt_idx.shape[0], pt_idx.shape[2]
-            self._i32('spmm.pt_src', pt_src, n_p * PATCH_MAX_SRC)
-            self._i32('spmm.pt_rows', pt_rows, n_p * PATCH_ROWS)
-            self._i32('spmm.pt_cnt', pt_cnt, n_p * PATCH_ROWS)
-            if pt_idx.dtype != torch.uint8 or not pt_idx.is_contiguous() or pt_idx.shape != (n_p, PATCH_ROWS, width):
-                raise StcError(f'spmm.pt_idx must be a contiguous uint8 tensor of shape {(n_p, PATCH_ROWS, width)}')
-            self._f32('spmm.pt_val', pt_val, (n_p, PATCH_ROWS, width))
-            self._same_device(X, pt_src, pt_rows, pt_cnt, pt_idx, pt_val)
-            self._launch('stc_patch_spmm_f32', X, _ptr(pt_src), _ptr(pt_rows), _ptr(pt_cnt), _ptr(pt_idx), _ptr(pt_val), n_p, width,
+        if F % 256 == 0 and aligned and self._patch_wanted(plan, plan[3][3].shape[0] * B if plan is not None and len(plan) > 3 else 0, F > 512, plain):
+            self._launch('stc_patch_spmm_f32', X, *self._patch_ptrs(plan[3], X),
                          n_rows, n_cols, _ptr(X), _ptr(Y0), _ptr(Y), B, F, float(alpha), float(beta), nbytes=nbytes, tag=tag)
             return
         if plan is not None and F % 4 == 0 and (F >= 64 or F in (4, 8, 16, 32)) and aligned:
@@ -409,6 +401,11 @@ class HipKernels:
         plain = Y0 is None or beta == 0
         nbytes = colidx.numel() * 8 + 4 * (n_rows + 1) + (2 if plain else 3) * 2 * B * n_rows * F
         tag = 'plain' if plain else 'with_y0'
+        if (F % 512 == 0 and all(t is None or t.data_ptr() % 16 == 0 for t in (X, Y0, Y))
+                and self._patch_wanted(plan, plan[3][3].shape[0] * B if plan is not None and len(plan) > 3 else 0, F > 1024, plain)):
+            self._launch('stc_patch_spmm_bf16', X, *self._patch_ptrs(plan[3], X), n_rows, n_cols, _ptr(X), _ptr(Y0), _ptr(Y), B, F, float(alpha), float(beta),
+                         nbytes=nbytes, tag=tag)
+            return
         if plan is not None:
             blk_ptr, blk_cols, blk_vals = plan[:3]
             self._i32('spmm.blk_ptr', blk_ptr, (n_rows + 3) // 4 + 1)
@@ -419,6 +416,23 @@ class HipKernels:
             return
         self._launch('stc_csr_spmm_bf16', X, _ptr(rowptr), _ptr(colidx), _ptr(val), n_rows, n_cols, _ptr(X), _ptr(Y0), _ptr(Y), B, F,
                      float(alpha), float(beta), nbytes=nbytes, tag=tag)
+
+    def _patch_ptrs(self, patches, on):
+        """Checked arguments (five arrays, n_patches, width) of the patch-form entry points (include/stc_hip.h, stc_patch_spmm_f32)."""
+        pt_src, pt_rows, pt_cnt, pt_idx, pt_val = patches
+        n_p, width = pt_idx.shape[0], pt_idx.shape[2]
+        self._i32('spmm.pt_src', pt_src, n_p * PATCH_MAX_SRC)
+        self._i32('spmm.pt_rows', pt_rows, n_p * PATCH_ROWS)
+        self._i32('spmm.pt_cnt', pt_cnt, n_p * PATCH_ROWS)
+        if pt_idx.dtype != torch.uint8 or not pt_idx.is_contiguous() or pt_idx.shape != (n_p, PATCH_ROWS, width):
+            raise StcError(f'spmm.pt_idx must be a contiguous uint8 tensor of shape {(n_p, PATCH_ROWS, width)}')
+        self._f32('spmm.pt_val', pt_val, (n_p, PATCH_ROWS, width))
+        self._same_device(on, pt_src, pt_rows, pt_cnt, pt_idx, pt_val)
+        return [_ptr(pt_src), _ptr(pt_rows), _ptr(pt_cnt), _ptr(pt_idx), _ptr(pt_val), n_p, width]
+
+    def _patch_wanted(self, plan, items, wide, plain):
+        """The launch-size rule of the patch form (see ``csr_spmm``): ``items`` = (patch, sample) workgroups, ``wide`` = rows of more than 2 KiB."""
+        return plan is not None and len(plan) > 3 and self.patch_spmm and items >= self.patch_min_items * ((6 if wide else 3) if plain else 1)
 
     def _graph_ptrs(self, rowptr, colidx, val, plan, n_rows):
         self._i32('spmm.rowptr', rowptr, n_rows + 1)

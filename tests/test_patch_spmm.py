@@ -187,3 +187,37 @@ def test_patch_spmm_at_the_bench_size():
             cols = cic[rpc[r]:rpc[r + 1]]
             want = (vc[rpc[r]:rpc[r + 1], None, None] * X[:, cols].cpu().double().transpose(0, 1)).sum(0)      # (B, F)
             assert rel_err(Yp[:, r].cpu(), want) < TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('H,W,F,B,permute', [(30, 30, 1024, 2, None), (17, 41, 512, 3, None), (40, 40, 2048, 1, 7)])
+def test_patch_spmm_bf16_equals_the_row_blocked_kernel(H, W, F, B, permute):
+    """bf16 rows (BASELINE configuration 5's storage): stc_patch_spmm_bf16 against stc_bcsr_spmm_bf16 bit for bit (fp32 sums in CSR
+    order, one rounding), and against float64 on the bf16-valued inputs to a bf16 ulp."""
+    from stc_hip._lib import HipKernels, KernelTimer
+    hip = HipKernels()
+    hip.patch_min_items = 0
+    graph, G = _weighted_grid(H, W, seed=H + W + F, permute_seed=permute)
+    if permute is not None:
+        graph, order = graph.with_locality()
+        G = G[order][:, order]
+    n = graph.n
+    d = graph.on(torch.device('cuda'))
+    gen = torch.Generator().manual_seed(F)
+    X = torch.randn(B, n, F, generator=gen).to(torch.bfloat16)
+    Y0 = torch.randn(B, n, F, generator=gen).to(torch.bfloat16)
+    for side, dense in (('fwd', G.t()), ('bwd', G)):
+        rp, ci, vals = d[f'{side}_rowptr'], d[f'{side}_colidx'], d[f'{side}_val']
+        blocks = (d[f'{side}_blk_ptr'], d[f'{side}_blk_cols'], d[f'{side}_blk_vals'])
+        patches = blocks + (tuple(d[f'{side}_pt_{k}'] for k in ('src', 'rows', 'cnt', 'idx', 'val')),)
+        for alpha, beta in ((1.0, 0.0), (2.0, -1.0)):
+            want = alpha * torch.einsum('rc,bcf->brf', dense.double(), X.double()) + beta * Y0.double()
+            blocked = Y0.clone().cuda()
+            hip.csr_spmm(rp, ci, vals, n, n, X.cuda(), blocked if beta else None, blocked, alpha, beta, plan=blocks)
+            patched = Y0.clone().cuda()
+            hip.timer = t = KernelTimer()
+            hip.csr_spmm(rp, ci, vals, n, n, X.cuda(), patched if beta else None, patched, alpha, beta, plan=patches)
+            hip.timer = None
+            assert list(t.summary()) == ['stc_patch_spmm_bf16']
+            assert torch.equal(patched, blocked)
+            assert rel_err(patched.float(), want) < 2.0 ** -8                           # one bf16 rounding of the result
