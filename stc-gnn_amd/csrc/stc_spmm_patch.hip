@@ -36,53 +36,60 @@ using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
 // A 16-byte piece of a feature row and its fp32 sums: four floats, or eight bf16 (bf16 storage, BASELINE configuration 5: values widen to
 // fp32 exactly, products and sums in fp32, ONE rounding to bf16 at the store -- the contract of csrc/stc_spmm_bf16.hip, same fmaf chain).
 template <bool BF16>
-struct Piece {
-    float v[BF16 ? 8 : 4];
+struct Piece;
+
+template <>
+struct Piece<false> {                                     // four floats (kept as ONE vector value: element arrays cost this kernel 16 registers)
+    v4f v;
+    __device__ __forceinline__ void zero() { v = v4f{0.f, 0.f, 0.f, 0.f}; }
+    __device__ __forceinline__ void fma(float s, const v4f x) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = fmaf(s, x[c], v[c]);
+    }
+    template <bool HAS_Y0>                                // alpha * sum (+ beta * y0), as the piece to store
+    __device__ __forceinline__ v4f finish(float alpha, float beta, const v4f y0) const {
+        v4f out;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) out[c] = HAS_Y0 ? fmaf(beta, y0[c], alpha * v[c]) : alpha * v[c];
+        return out;
+    }
+};
+
+template <>
+struct Piece<true> {                                      // eight bf16 columns, summed in fp32
+    float v[8];
     __device__ __forceinline__ void zero() {
 #pragma unroll
-        for (int i = 0; i < (BF16 ? 8 : 4); ++i) v[i] = 0.f;
+        for (int i = 0; i < 8; ++i) v[i] = 0.f;
     }
     __device__ __forceinline__ void fma(float s, const v4f x) {
-        if (BF16) {
-            const u32x4 u = __builtin_bit_cast(u32x4, x);
+        const u32x4 u = __builtin_bit_cast(u32x4, x);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                v[2 * i] = fmaf(s, __uint_as_float(u[i] << 16), v[2 * i]);
-                v[2 * i + 1] = fmaf(s, __uint_as_float(u[i] & 0xffff0000u), v[2 * i + 1]);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = fmaf(s, x[i], v[i]);
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = fmaf(s, __uint_as_float(u[i] << 16), v[2 * i]);
+            v[2 * i + 1] = fmaf(s, __uint_as_float(u[i] & 0xffff0000u), v[2 * i + 1]);
         }
     }
-    // alpha * sum (+ beta * y0), as the piece to store
     template <bool HAS_Y0>
     __device__ __forceinline__ v4f finish(float alpha, float beta, const v4f y0) const {
-        float r[BF16 ? 8 : 4];
+        float r[8];
 #pragma unroll
-        for (int i = 0; i < (BF16 ? 8 : 4); ++i) r[i] = alpha * v[i];
-        if (BF16) {
-            if (HAS_Y0) {
-                const u32x4 u = __builtin_bit_cast(u32x4, y0);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    r[2 * i] = fmaf(beta, __uint_as_float(u[i] << 16), r[2 * i]);
-                    r[2 * i + 1] = fmaf(beta, __uint_as_float(u[i] & 0xffff0000u), r[2 * i + 1]);
-                }
-            }
-            u32x4 o;
+        for (int i = 0; i < 8; ++i) r[i] = alpha * v[i];
+        if (HAS_Y0) {
+            const u32x4 u = __builtin_bit_cast(u32x4, y0);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const bf16x2 t = {(__bf16)r[2 * i], (__bf16)r[2 * i + 1]};       // v_cvt_pk_bf16_f32, round to nearest even
-                o[i] = __builtin_bit_cast(unsigned, t);
+                r[2 * i] = fmaf(beta, __uint_as_float(u[i] << 16), r[2 * i]);
+                r[2 * i + 1] = fmaf(beta, __uint_as_float(u[i] & 0xffff0000u), r[2 * i + 1]);
             }
-            return __builtin_bit_cast(v4f, o);
         }
-        if (HAS_Y0) {
+        u32x4 o;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) r[i] = fmaf(beta, y0[i], r[i]);
+        for (int i = 0; i < 4; ++i) {
+            const bf16x2 t = {(__bf16)r[2 * i], (__bf16)r[2 * i + 1]};           // v_cvt_pk_bf16_f32, round to nearest even
+            o[i] = __builtin_bit_cast(unsigned, t);
         }
-        return v4f{r[0], r[1], r[2], r[3]};
+        return __builtin_bit_cast(v4f, o);
     }
 };
 
@@ -110,7 +117,7 @@ __device__ v4f patch_dump[64];                           // where the slots of a
 // unit walking strided runs of patches, tables loaded once per patch -- hid the per-workgroup table loads but lost that: a workgroup's
 // next patch was 64 further down the list, the rows shared with it long evicted; FETCH_SIZE 1.45 x the matrix against 1.05 x.)
 template <int W, bool HAS_Y0, bool BF16>
-__global__ __launch_bounds__(PT_THREADS) void spmm_patch_kernel(PatchPlan pl, int n_rows, int n_cols, const v4f* __restrict__ X,
+__global__ __launch_bounds__(PT_THREADS, 2) void spmm_patch_kernel(PatchPlan pl, int n_rows, int n_cols, const v4f* __restrict__ X,
                                                                const v4f* __restrict__ Y0, v4f* __restrict__ Y, int F4, float alpha, float beta) {
     constexpr int RPW = PT_ROWS / PT_WAVES, NV = (RPW * W + 63) / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -160,7 +167,8 @@ __global__ __launch_bounds__(PT_THREADS) void spmm_patch_kernel(PatchPlan pl, in
     // compiler has to drain them -- one exposed store latency per chunk.
     // (With a Y0 operand ONE chunk ahead: memory returns in issue order, so the Y0 pieces of a chunk must be asked for before any later
     //  chunk's rows or their wait is a wait for those as well -- and a second set of Y0 registers does not fit beside two chunks.)
-    constexpr int DEPTH = HAS_Y0 ? 1 : 2;
+    // (... and with tables of more than 8 entries per row the second set does not fit in the 256 registers two workgroups per compute unit leave)
+    constexpr int DEPTH = (HAS_Y0 || W > 8) ? 1 : 2;
     auto step = [&](v4f (&nx)[PT_PER], v4f (&other)[PT_PER], int chunk, auto more) {
         if (chunk) lds_barrier();                         // the previous chunk's sums are done with the tile
 #pragma unroll

@@ -27,3 +27,29 @@ def test_no_scratch_access_inside_the_node_loops(tmp_path, source):
     bad = [(name[:90], int(n_scr)) for name, n_instr, n_mfma, n_scr in kernels if int(n_mfma) > 0 and int(n_scr) > 0]
     assert not bad, bad
     shutil.rmtree(tmp_path, ignore_errors=True)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason='hipcc not present')
+def test_patch_aggregation_keeps_two_workgroups_per_cu_and_an_lds_only_barrier(tmp_path):
+    """csrc/stc_spmm_patch.hip is built so that a chunk's result stores stay in flight under the next chunk's staging and two workgroups share a
+    compute unit.  Checked in the assembly of all 24 forms (6 table widths x {plain, Y0} x {fp32, bf16}): at most 256 registers (a refactoring
+    that cost 16 registers once halved the occupancy: 200 -> 270 us), no scratch for tables of up to 16 entries per row, and every s_barrier
+    preceded by ``s_waitcnt lgkmcnt(0)`` alone -- ``__syncthreads()`` would put ``vmcnt(0)`` there, a wait for the previous chunk's stores
+    (HISTORY section 10)."""
+    out = tmp_path / 'patch.s'
+    csrc = os.path.join(REPO, 'stc-gnn_amd', 'csrc')
+    subprocess.check_call([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', f'-I{os.path.join(REPO, "include")}',
+                           '-S', '--cuda-device-only', '-o', str(out), os.path.join(csrc, 'stc_spmm_patch.hip')], stderr=subprocess.DEVNULL)
+    text = out.read_text()
+    bodies = re.findall(r'^(_ZN\S*spmm_patch_kernelILi(\d+)ELb(\d)ELb(\d)E\S*):[^\n]*\n(.*?)s_endpgm', text, flags=re.M | re.S)
+    assert len(bodies) == 24, len(bodies)
+    for name, width, has_y0, bf16, body in bodies:
+        if int(width) <= 16:                                           # (tables of 24 / 32 entries per row spill a few registers: rare shapes)
+            assert 'scratch_' not in body, name
+        regs = re.search(r'\.amdhsa_kernel ' + re.escape(name) + r'\n.*?\.amdhsa_next_free_vgpr (\d+)', text, flags=re.S)
+        assert regs and int(regs.group(1)) <= 256, (name, 'more than 256 registers: one workgroup per compute unit')
+        lines = [ln.strip() for ln in body.split('\n') if ln.strip() and not ln.strip().startswith(';')]
+        barriers = [i for i, ln in enumerate(lines) if ln == 's_barrier']
+        assert len(barriers) >= 2, name
+        assert all(lines[i - 1] == 's_waitcnt lgkmcnt(0)' for i in barriers), (name, [lines[i - 1] for i in barriers])
+    shutil.rmtree(tmp_path, ignore_errors=True)
