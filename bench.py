@@ -700,7 +700,7 @@ def main():
                        'global_batch': world * B, 'batch_per_gpu': B, 'parallelism': f'batch-shard x{world}',
                        **({'preset': a.preset} if a.preset else {}),
                        'operand_format': {0: 'bf16x3', 1: 'f16x2'}.get(getattr(hip, 'operand_format', None)),
-                       'grad_bucket_bytes': bucket.nbytes, 'input_seeds': 'X, Y: Bernoulli(0.1635), torch seed 1000 + rank'},
+                       'grad_bucket_bytes': bucket.nbytes, 'grad_large_bytes': bucket.large_nbytes, 'input_seeds': 'X, Y: Bernoulli(0.1635), torch seed 1000 + rank'},
             'roofline': roofline,
             'power': power,
             'step_breakdown': {'fwd_loss_bwd_ms': phases[0], 'grad_allreduce_ms': phases[1], 'adam_ms': phases[2],

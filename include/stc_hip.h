@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define STC_ABI_VERSION 24
+#define STC_ABI_VERSION 25
 #define STC_MAX_K 4          /* highest Chebyshev order (Ks, Kc) the node kernels accept */
 
 /* Operand formats of the split-operand matrix-core kernels (C = 32 / 64, hidden 16).  Every fp32 operand is split into low-precision
@@ -544,6 +544,21 @@ int stc_graph_grad_f32(const float* A, const float* B, double* partials, int32_t
                        int32_t batch, int32_t N, int32_t F, void* stream);
 int stc_mix_grad_f32(const float* A, const float* B, double* partials, int32_t n_chunks, int32_t cell0, int32_t cell_step, int32_t n_sel,
                      int32_t batch, int32_t N, int32_t Fa, int32_t Fb, void* stream);
+
+/* ---- MixedFusion of the learned graph generator (reference STC_GNN.py:246-261, called by MGP_Gen :227-243) ----------------------------
+ *   gate = sigmoid(W_A vec(A) + b_A + W_P vec(P) + b_P),   G = gate * A + (1 - gate) * P        D = n^2 entries; W_A, W_P (D, D) row-major
+ *                                                                                               (nn.Linear weights), D % 4 == 0
+ * Forward: both matrices streamed once (one wave per output row); `gate` is kept for the backward.  Backward, from dG: db (D) =
+ * dG (A - P) gate (1 - gate) -- the gradient of both biases --, dW_A = db (x) vec(A), dW_P = db (x) vec(P) (D, D, written once),
+ * dP = dG (1 - gate) + W_P^T db and, when dA is not NULL, dA = dG gate + W_A^T db.  The column sums go through per-chunk partials
+ * in the workspace and are added in a fixed order: bitwise reproducible.  Replaces two GEMVs (forward) and two outer products + one or
+ * two transposed GEMVs (backward) of the autograd graph of :253-260. */
+size_t stc_mixed_fusion_workspace_bytes(int32_t D, int32_t want_dA);
+int stc_mixed_fusion_fwd_f32(const float* WA, const float* bA, const float* WP, const float* bP, const float* A, const float* P,
+                             float* gate, float* G, int32_t D, void* stream);
+int stc_mixed_fusion_bwd_f32(const float* WA, const float* WP, const float* A, const float* P, const float* gate, const float* dG,
+                             float* dWA, float* dWP, float* db, float* dP, float* dA,
+                             void* workspace, size_t workspace_bytes, int32_t D, void* stream);
 
 /* ---- small helpers ---------------------------------------------------------
  * y += a*x over n elements (Chebyshev backward g_{k-2} -= g_k) */

@@ -233,8 +233,10 @@ class FactorisedLinear(nn.Module):
 class MixedFusion(nn.Module):
     """Element-wise gated mix of a prior graph A and a learned graph P (reference ``STC_GNN.py:246-261``).
 
-    Two ``Linear(n^2, n^2)`` layers: usable for small n only; stays on torch (rocBLAS GEMV).  ``rank`` (not in the
-    reference) replaces them by rank-r factors so that a learned graph is affordable beyond n ~ 300.
+    Two ``Linear(n^2, n^2)`` layers: usable for small n only.  On the GPU (fp32, n^2 a multiple of 4) the gate's two matrix-vector
+    products, the mix and their autograd are ``stc_mixed_fusion_fwd/bwd_f32`` -- the matrices are streamed once per direction; other
+    shapes stay on torch.  ``rank`` (not in the reference) replaces the layers by rank-r factors so that a learned graph is affordable
+    beyond n ~ 300.
     """
 
     def __init__(self, in_dim: int, rank: Optional[int] = None):
@@ -250,6 +252,10 @@ class MixedFusion(nn.Module):
     def forward(self, A: torch.Tensor, P: torch.Tensor):
         assert A.dim() == 2 and P.dim() == 2
         n = self.in_dim
+        if isinstance(self.lin_A, nn.Linear) and A.is_cuda:
+            params = (self.lin_A.weight, self.lin_A.bias, self.lin_P.weight, self.lin_P.bias)
+            if ops.mixed_fusion_supported(A, P, *params):                # both 2 x n^4-byte matrices streamed once per direction
+                return ops.mixed_fusion(A, P, *params)
         gate = torch.sigmoid(self.lin_A(A.reshape(n * n)) + self.lin_P(P.reshape(n * n))).reshape(n, n)
         return gate * A + (1 - gate) * P
 

@@ -21,7 +21,7 @@ from .graph import is_full_pattern
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG_ROOT, 'libstc_hip.so')
-ABI_VERSION = 24
+ABI_VERSION = 25
 FMT_BF16X3, FMT_F16X2 = 0, 1          # STC_FMT_* of include/stc_hip.h: operand formats of the split-operand matrix-core kernels
 MAX_K = 4
 SPMM_SUM_MAX_ADD = 8     # = STC_SPMM_SUM_MAX_ADD of include/stc_hip.h
@@ -42,7 +42,7 @@ EXPORTS = (
     'stc_cell_bwd_planar_supported', 'stc_cell_bwd_planar_workspace_bytes', 'stc_cell_bwd_planar_f32',
     'stc_cell_planar_k_supported', 'stc_cell_gates_fwd_planar_k_f32', 'stc_cell_cand_fwd_planar_k_f32', 'stc_cell_gates_bwd_planar_k_f32',
     'stc_cell_cand_bwd_planar_k_f32',
-    'stc_cell_small_supported', 'stc_cell_small_workspace_bytes', 'stc_cell_small_param_rows', 'stc_graph_grad_f32', 'stc_mix_grad_f32', 'stc_cell_small_fwd_f32', 'stc_cell_small_bwd_f32',
+    'stc_cell_small_supported', 'stc_cell_small_workspace_bytes', 'stc_cell_small_param_rows', 'stc_graph_grad_f32', 'stc_mix_grad_f32', 'stc_mixed_fusion_workspace_bytes', 'stc_mixed_fusion_fwd_f32', 'stc_mixed_fusion_bwd_f32', 'stc_cell_small_fwd_f32', 'stc_cell_small_bwd_f32',
     'stc_gru_gates_fwd_f32', 'stc_gru_gates_bwd_f32', 'stc_gru_blend_fwd_f32', 'stc_gru_blend_bwd_f32',
     'stc_head_fwd_f32', 'stc_head_bwd_workspace_bytes', 'stc_head_bwd_f32',
     'stc_axpy_f32', 'stc_concat2_f32', 'stc_split2_f32',
@@ -75,6 +75,9 @@ def _declare(lib):
         'stc_cell_small_fwd_f32': [_p, _p, _p, _i32, _i32, _i32, _p, _i32, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p],
         'stc_graph_grad_f32': [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p],
         'stc_mix_grad_f32': [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p],
+        'stc_mixed_fusion_workspace_bytes': [_i32, _i32],
+        'stc_mixed_fusion_fwd_f32': [_p] * 8 + [_i32, _p],
+        'stc_mixed_fusion_bwd_f32': [_p] * 12 + [C.c_size_t, _i32, _p],
         'stc_cell_small_bwd_f32': [_p, _p, _p, _i32, _i32, _i32, _p, _i32, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _i32, _p, _i64, _i32, _i32,
                                    _p, _p, _p, _p, _p, C.c_size_t, _i32, _i32, _i32, _i32, _p],
         'stc_csr_sddmm_f32': [_p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _i32, _p],
@@ -153,6 +156,8 @@ def _declare(lib):
     lib.stc_set_dispatch_level.restype = C.c_int
     lib.stc_set_dispatch_level.argtypes = [_i32]
     lib.stc_head_bwd_workspace_bytes.restype = C.c_size_t
+    lib.stc_mixed_fusion_workspace_bytes.argtypes = [_i32, _i32]
+    lib.stc_mixed_fusion_workspace_bytes.restype = C.c_size_t
     lib.stc_head_bwd_workspace_bytes.argtypes = [_i32]
     lib.stc_bdg_node_bwd_workspace_bytes.restype = C.c_size_t
     lib.stc_bdg_node_bwd_workspace_bytes.argtypes = [_i32, _i32, _i32, _i32, _i32, _i32]
@@ -998,6 +1003,36 @@ class HipKernels:
         part = torch.empty(chunks, Fa, Fb, dtype=torch.float64, device=A.device)
         self._launch('stc_mix_grad_f32', A, A.data_ptr(), Bm.data_ptr(), part.data_ptr(), chunks, cell0, cell_step, n_sel, batch, N, Fa, Fb)
         return part.sum(0)
+
+    # ---- MixedFusion of the learned graph generator (reference STC_GNN.py:246-261) ----------------------------------
+    def mixed_fusion_supported(self, D) -> bool:
+        return D >= 4 and D % 4 == 0
+
+    def mixed_fusion_fwd(self, WA, bA, WP, bP, A, P):
+        """(gate, G) with gate = sigmoid(W_A vec(A) + b_A + W_P vec(P) + b_P), G = gate * A + (1 - gate) * P; A, P (n, n) (``stc_mixed_fusion_fwd_f32``)."""
+        D = A.numel()
+        for name, t, shape in (('WA', WA, (D, D)), ('WP', WP, (D, D)), ('bA', bA, (D,)), ('bP', bP, (D,))):
+            self._f32('mixed_fusion.' + name, t, shape)
+        self._f32('mixed_fusion.A', A)
+        self._f32('mixed_fusion.P', P, tuple(A.shape))
+        self._same_device(WA, bA, WP, bP, A, P)
+        gate, G = torch.empty_like(A), torch.empty_like(A)
+        self._launch('stc_mixed_fusion_fwd_f32', A, _ptr(WA), _ptr(bA), _ptr(WP), _ptr(bP), _ptr(A), _ptr(P), _ptr(gate), _ptr(G), D, nbytes=8 * D * D)
+        return gate, G
+
+    def mixed_fusion_bwd(self, WA, WP, A, P, gate, dG, want_dA):
+        """(dW_A, dW_P, db, dP, dA or None) from dG (``stc_mixed_fusion_bwd_f32``); db is the gradient of both biases."""
+        D = A.numel()
+        for name, t in (('gate', gate), ('dG', dG), ('P', P)):
+            self._f32('mixed_fusion.' + name, t, tuple(A.shape))
+        self._same_device(WA, WP, A, P, gate, dG)
+        dWA, dWP = torch.empty_like(WA), torch.empty_like(WP)
+        db, dP = torch.empty(D, dtype=torch.float32, device=A.device), torch.empty_like(A)
+        dA = torch.empty_like(A) if want_dA else None
+        ws = torch.empty(self.lib.stc_mixed_fusion_workspace_bytes(D, int(want_dA)) // 4, dtype=torch.float32, device=A.device)
+        self._launch('stc_mixed_fusion_bwd_f32', A, _ptr(WA), _ptr(WP), _ptr(A), _ptr(P), _ptr(gate), _ptr(dG), _ptr(dWA), _ptr(dWP), _ptr(db), _ptr(dP), _ptr(dA),
+                     _ptr(ws), ws.numel() * 4, D, nbytes=(12 + (4 if want_dA else 0)) * D * D)
+        return dWA, dWP, db, dP, dA
 
     # ---- planar cell convolutions of Chebyshev order K = 3 ------------------------------------------------
     def cell_planar_k_supported(self, K, Cc, h) -> bool:

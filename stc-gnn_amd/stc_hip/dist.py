@@ -46,40 +46,68 @@ def shard_batch(t: torch.Tensor, rank: int, world: int, ragged: bool = False) ->
     return t[lo:hi]
 
 
-class GradBucket:
-    """All gradients of ``params`` in one flat buffer; ``allreduce_mean()`` is the only collective."""
+class _Works:
+    """The handles of several asynchronous collectives as one."""
 
-    def __init__(self, params: Iterable[torch.nn.Parameter]):
-        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
-        if not self.params:
+    def __init__(self, works):
+        self.works = [w for w in works if w is not None]
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+
+
+class GradBucket:
+    """All gradients of ``params`` in one flat buffer; ``allreduce_mean()`` is the only collective.
+
+    A parameter of ``large_bytes`` or more stays OUT of the buffer (the reference's ``MixedFusion`` holds two (n^2, n^2) matrices -- 2 x 400 MB
+    at the SF shape, 99.99 % of the model): in the buffer its gradient costs a fill of its bytes per step plus autograd's read-add-write into
+    the view (3 x its bytes) where a fresh ``.grad`` is just the tensor the backward kernel wrote -- 0.6 ms of the 7.6 ms learned-graph SF
+    step.  ``zero()`` drops such a gradient (``None``), ``allreduce_mean()`` reduces it by itself: a message of that size needs no bucketing.
+    """
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], large_bytes: int = 64 << 20):
+        every = [p for p in params if p.requires_grad]
+        if not every:
             raise ValueError('no trainable parameters')
-        dev = {p.device for p in self.params}
-        dt = {p.dtype for p in self.params}
+        dev = {p.device for p in every}
+        dt = {p.dtype for p in every}
         if len(dev) != 1 or len(dt) != 1:
             raise ValueError(f'parameters must share one device and dtype, got {dev} / {dt}')
+        self.large: List[torch.nn.Parameter] = [p for p in every if p.numel() * p.element_size() >= large_bytes]
+        self.params: List[torch.nn.Parameter] = [p for p in every if p.numel() * p.element_size() < large_bytes]
         total = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(total, dtype=self.params[0].dtype, device=self.params[0].device)
+        self.flat = torch.zeros(total, dtype=every[0].dtype, device=every[0].device)
         off = 0
         for p in self.params:
             n = p.numel()
             p.grad = self.flat[off:off + n].view_as(p)      # autograd accumulates into the view in place
             off += n
+        for p in self.large:
+            p.grad = None
 
     @property
     def nbytes(self) -> int:
         return self.flat.numel() * self.flat.element_size()
 
+    @property
+    def large_nbytes(self) -> int:
+        return sum(p.numel() * p.element_size() for p in self.large)
+
     def zero(self):
-        """Replaces ``optimizer.zero_grad()``: keeps the views, zeroes the storage in one fill."""
+        """Replaces ``optimizer.zero_grad()``: keeps the views, zeroes the storage in one fill (large parameters: gradient dropped)."""
         self.flat.zero_()
+        for p in self.large:
+            p.grad = None
 
     def check_views(self):
-        """True while every ``.grad`` still aliases the bucket (``zero_grad(set_to_none=True)`` breaks it)."""
+        """True while every bucketed ``.grad`` still aliases the bucket (``zero_grad(set_to_none=True)`` breaks it)."""
         base = self.flat.untyped_storage().data_ptr()
         return all(p.grad is not None and p.grad.untyped_storage().data_ptr() == base for p in self.params)
 
     def allreduce_mean(self, group=None, async_op: bool = False):
-        """Sum the bucket over ranks and divide by the world size (gradient of the global-batch mean loss).
+        """Sum the gradients over ranks and divide by the world size (gradient of the global-batch mean loss): the bucket in one collective,
+        every large parameter in its own.
 
         Unequal shards (``shard_batch(..., ragged=True)``): scale the shard loss by ``len(shard) / n * world`` before
         ``backward()``; the mean over ranks is then the share-weighted sum = the full-batch gradient (ComboLoss is a mean of
@@ -93,7 +121,13 @@ class GradBucket:
             raise RuntimeError('a parameter .grad no longer aliases the bucket: use bucket.zero(), not '
                                'optimizer.zero_grad(set_to_none=True)')
         self.flat.div_(world)                                # pre-scale: the sum then is the mean
-        return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        works = [dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)] if self.flat.numel() else []
+        for p in self.large:
+            if p.grad is None:                               # (every rank ran the same graph: the parameter was unused everywhere)
+                continue
+            p.grad.div_(world)
+            works.append(dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=group, async_op=async_op))
+        return _Works(works) if async_op else None
 
 
 class _AllReduceSum(torch.autograd.Function):

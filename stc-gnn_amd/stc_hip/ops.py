@@ -947,3 +947,38 @@ def stc_cell_graph(op: SpatialOperand, Tc, Ks: int, schedule, outputs, ext, stac
         return stc_small_graph(k, op, Tc, Ks, schedule, outputs, ext, stacks)
     flat = [p for st in stacks for p in st]
     return _StcCellGraph.apply(op, Ks, list(schedule), list(outputs), len(ext), Tc, op.fwd_val, *ext, *flat)
+
+
+# ---- MixedFusion of the learned graph generator ---------------------------------------------------------------------------------------
+class _MixedFusion(torch.autograd.Function):
+    """G = gate * A + (1 - gate) * P with gate = sigmoid(lin_A(vec A) + lin_P(vec P)) (reference STC_GNN.py:253-260) in one streaming launch per
+    direction (``stc_mixed_fusion_fwd/bwd_f32``): the two (n^2, n^2) weight matrices are read once forward and once backward, their
+    gradients written once."""
+
+    @staticmethod
+    def forward(ctx, A, P, WA, bA, WP, bP):
+        k = kernels()
+        A_, P_ = A.detach().contiguous(), P.detach().contiguous()
+        gate, G = k.mixed_fusion_fwd(WA.detach(), bA.detach(), WP.detach(), bP.detach(), A_, P_)
+        ctx.save_for_backward(A_, P_, WA, WP, gate)
+        return G
+
+    @staticmethod
+    def backward(ctx, dG):
+        A, P, WA, WP, gate = ctx.saved_tensors
+        want_dA = ctx.needs_input_grad[0]
+        dWA, dWP, db, dP, dA = kernels().mixed_fusion_bwd(WA.detach(), WP.detach(), A, P, gate, dG.contiguous(), want_dA)
+        need = ctx.needs_input_grad
+        return (dA if need[0] else None, dP if need[1] else None, dWA if need[2] else None, db if need[3] else None,
+                dWP if need[4] else None, db if need[5] else None)
+
+
+def mixed_fusion_supported(A: torch.Tensor, P: torch.Tensor, *params: torch.Tensor) -> bool:
+    """Whether ``mixed_fusion`` takes these operands: float32 on a GPU, contiguous weights, n^2 a multiple of 4."""
+    ts = (A, P) + params
+    return (all(t.is_cuda and t.dtype == torch.float32 for t in ts) and all(t.is_contiguous() for t in params)
+            and kernels().mixed_fusion_supported(A.numel()))
+
+
+def mixed_fusion(A, P, WA, bA, WP, bP):
+    return _MixedFusion.apply(A, P, WA, bA, WP, bP)

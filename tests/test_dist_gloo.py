@@ -362,3 +362,54 @@ def test_eight_ranks_ragged_shards_learned_graphs_and_one_locality_analysis(tmp_
     assert float((got[0]['flat'] - full).abs().max()) / float(full.abs().max()) < 1e-5
     assert float((got[0]['Gs'] - Gs).abs().max()) < 1e-6
     assert float((got[0]['lflat'] - lfull).abs().max()) / float(lfull.abs().max()) < 1e-5
+
+
+def _worker_large(rank, world, port, out_dir):
+    for p in (REPO, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from oracle import stc_oracle as O
+    from oracle.kernel_emul import EmulatedKernels
+    from stc_hip import dist as sdist, ops
+    ops._kernels = EmulatedKernels()
+    sdist.init_from_env(backend='gloo')
+    model, graph, Gc, X, Y = _build()
+    bucket = sdist.GradBucket(model.parameters(), large_bytes=1024)      # every parameter of 256 floats or more reduces by itself
+    assert bucket.large and bucket.params
+    for step in range(2):                                                # (the second step: zero() dropped the large gradients, nothing accumulated)
+        bucket.zero()
+        assert all(p.grad is None for p in bucket.large)
+        xs, ys = sdist.shard_batch(X, rank, world), sdist.shard_batch(Y, rank, world)
+        O.combo_loss(model(X_seq=xs, As=graph, Ac=Gc), ys).backward()
+        assert bucket.check_views()
+        bucket.allreduce_mean()
+    torch.save({n: p.grad.clone() for n, p in model.named_parameters()}, os.path.join(out_dir, f'rank{rank}.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_large_parameters_reduce_outside_the_bucket(tmp_path):
+    """GradBucket(large_bytes=...): parameters above the threshold (the reference's MixedFusion matrices: 2 x 400 MB at the SF shape) keep a
+    gradient of their own -- no fill, no accumulation into a view -- and are all-reduced one by one; the result equals the one-bucket one."""
+    world = 2
+    port = _free_port()
+    mp.start_processes(_worker_large, args=(world, port, str(tmp_path)), nprocs=world, join=True, start_method='spawn')
+    got = [torch.load(tmp_path / f'rank{r}.pt') for r in range(world)]
+    from oracle import stc_oracle as O
+    from oracle.kernel_emul import EmulatedKernels
+    from stc_hip import dist as sdist, ops
+    old = ops._kernels
+    ops._kernels = EmulatedKernels()
+    try:
+        model, graph, Gc, X, Y = _build()
+        bucket = sdist.GradBucket(model.parameters())
+        assert not bucket.large
+        O.combo_loss(model(X_seq=X, As=graph, Ac=Gc), Y).backward()
+        want = {n: p.grad.clone() for n, p in model.named_parameters()}
+    finally:
+        ops._kernels = old
+    for name, w in want.items():
+        assert torch.equal(got[0][name], got[1][name]), name
+        assert float((got[0][name] - w).abs().max()) <= 5e-6 * max(float(w.abs().max()), 1e-3), name

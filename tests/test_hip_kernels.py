@@ -981,3 +981,31 @@ def test_full_size_spmm_properties(hip):
     out_p = torch.empty_like(x)
     hip.csr_spmm(dp['fwd_rowptr'], dp['fwd_colidx'], dp['fwd_val'], N, N, x[:, p].contiguous(), None, out_p, 1.0, 0.0)
     assert rel_err(out_p, STx[:, p]) < TOL
+
+
+@pytest.mark.parametrize('n,needs_dA', [(10, True), (14, False), (32, True), (100, False)])
+def test_mixed_fusion(hip, n, needs_dA):
+    """stc_mixed_fusion_fwd/bwd_f32 (reference STC_GNN.py:246-261) against float64 autograd of the reference's own expression: the mixed graph,
+    and the gradients of both weight matrices, both biases, P and (when asked for) A; D = n^2 in {100, 196, 1024, 10^4 (the SF shape)}."""
+    from stc_hip import ops as O2
+    D = n * n
+    g = torch.Generator().manual_seed(n)
+    A = torch.rand(n, n, generator=g)
+    P = torch.softmax(torch.randn(n, n, generator=g), -1)
+    WA, WP = (torch.randn(D, D, generator=g) * (1.0 / D) ** 0.5 for _ in range(2))
+    bA, bP = (torch.randn(D, generator=g) * 0.1 for _ in range(2))
+    R = torch.randn(n, n, generator=g)
+    ref = [t.double().requires_grad_() for t in (A, P, WA, bA, WP, bP)]
+    a = torch.sigmoid(ref[2] @ ref[0].reshape(D) + ref[3] + ref[4] @ ref[1].reshape(D) + ref[5]).reshape(n, n)
+    Gref = a * ref[0] + (1 - a) * ref[1]
+    (Gref * R.double()).sum().backward()
+    dev = [t.cuda().requires_grad_(i != 0 or needs_dA) for i, t in enumerate((A, P, WA, bA, WP, bP))]
+    assert O2.mixed_fusion_supported(*dev)
+    G = O2.mixed_fusion(*dev)
+    (G * R.cuda()).sum().backward()
+    assert rel_err(G, Gref) < TOL
+    for name, got, want in zip(('dA', 'dP', 'dWA', 'dbA', 'dWP', 'dbP'), dev, ref):
+        if name == 'dA' and not needs_dA:
+            assert got.grad is None
+            continue
+        assert rel_err(got.grad, want.grad) < 2e-5, name
