@@ -106,6 +106,7 @@ def _patch_plan(rowptr: np.ndarray, colidx: np.ndarray, val: np.ndarray, n: int,
     import scipy.sparse as sp
     A = sp.csr_matrix((np.ones(colidx.size, dtype=np.int8), colidx, rp), shape=(n, n))
     S = (A + A.T).tocsr()
+    S.sort_indices()                                   # (neighbours in index order whatever the scipy build: every rank grows the same patches)
     srp, sci = S.indptr.tolist(), S.indices.tolist()
     rpl, cil = rp.tolist(), colidx.tolist()
     taken = np.zeros(n, dtype=bool)
