@@ -85,6 +85,24 @@ def test_which_graphs_get_a_patch_plan():
     assert _patch_plan(rp, np.zeros(0, np.int32), np.zeros(0, np.float32), 2) is None
 
 
+def test_grid_graphs_get_tile_patches():
+    """A graph that is a 4- / 8-neighbour lattice in its node numbering gets 4 x 8 tiles (every slot of an interior patch used, 60 source rows);
+    one long-range edge, or a random numbering, and the greedy clusters take over."""
+    from stc_hip.graph import _grid_tiles
+    g = CsrGraph.queen_grid(224, 224)
+    assert g.patch_stats['fwd'] == (pytest.approx(1.8505, abs=1e-3), 32.0) and g._host['fwd_pt_rows'].shape[0] == 56 * 28
+    assert (g._host['fwd_pt_nsrc'].max(), g._host['fwd_pt_rows'].min()) == (60, 0)
+    h = CsrGraph.queen_grid(64, 48)._host
+    assert _grid_tiles(h['fwd_rowptr'].astype(np.int64), h['fwd_colidx'], 64 * 48) is not None
+    rook = [(i, j) for i in range(40 * 30) for j in (i - 30, i - 1, i + 1, i + 30) if 0 <= j < 1200 and (abs(j - i) == 30 or j // 30 == i // 30)]
+    r, c = np.array(rook).T
+    assert CsrGraph(1200, r, c, np.ones(r.size)).patch_stats['fwd'][1] > 28                       # 4-neighbour lattice: tiles as well
+    p = CsrGraph.queen_grid(40, 40, permute_seed=3)._host
+    assert _grid_tiles(p['fwd_rowptr'].astype(np.int64), p['fwd_colidx'], 1600) is None
+    far = CsrGraph(1200, np.append(r, 5), np.append(c, 900), np.ones(r.size + 1))._host          # one edge across the lattice
+    assert _grid_tiles(far['fwd_rowptr'].astype(np.int64), far['fwd_colidx'], 1200) is None
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('H,W,F,B,permute', [(30, 30, 512, 2, None), (17, 41, 256, 3, None), (40, 40, 1024, 1, 7), (9, 9, 768, 2, None), (224, 8, 512, 1, None)])
 def test_patch_spmm_equals_the_row_blocked_kernel(H, W, F, B, permute):
