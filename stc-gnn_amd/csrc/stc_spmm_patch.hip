@@ -4,7 +4,7 @@
 // The row-blocked kernel gathers every neighbour row of a block of 4 output rows through L1 / L2: 4.5 row fetches per output row
 // on the 8-neighbour grid, all but one of them cache hits -- and it is those hits (L2 -> CU traffic, not HBM) that hold it at
 // 0.61 of the HBM peak.  Here the host clusters the graph's rows into PATCHES (graph.py _patch_plan: up to 32 output rows whose
-// neighbour rows number at most 64 together; 1.98 source rows per output row on that grid) and one workgroup per (patch, batch
+// neighbour rows number at most 64 together; 1.85 source rows per output row on that grid as 4 x 8 tiles) and one workgroup per (patch, batch
 // element) copies the patch's source rows into LDS once per column chunk -- each lane a 16-byte piece, a wave instruction one
 // whole 1 KiB chunk of a row -- and forms the 32 output rows out of LDS:
 //
