@@ -105,7 +105,7 @@ def _patch_plan(rowptr: np.ndarray, colidx: np.ndarray, val: np.ndarray, n: int,
         return None
     rpl, cil = rp.tolist(), colidx.tolist()
     tiles = _grid_tiles(rp, colidx, n)
-    if tiles is not None:
+    if tiles is not None and n / len(tiles) >= min_rows and sum(len(src) for _, src in tiles) / n <= max_fetch:      # (a narrow lattice: clusters)
         return _patch_tables(rpl, cil, val, n, tiles, int(deg.max()))
     import scipy.sparse as sp
     A = sp.csr_matrix((np.ones(colidx.size, dtype=np.int8), colidx, rp), shape=(n, n))
@@ -188,7 +188,7 @@ def _patch_tables(rpl, cil, val, n, patches, max_deg):
     for p, (rows, src) in enumerate(patches):
         # position q of the list at [q % 4][q / 4]: the wave that stages it reads its 16 numbers with one scalar load; the record is
         # filled up with repeats of the first source row (staged like the others: no branch in the kernel, a cache hit)
-        lst = np.full(PATCH_MAX_SRC, next(iter(src)), dtype=np.int32)
+        lst = np.full(PATCH_MAX_SRC, next(iter(src), 0), dtype=np.int32)      # (a patch of rows without entries gathers nothing: any row)
         lst[:len(src)] = list(src)                      # (dicts keep insertion order: position = value)
         pt_src[p] = lst.reshape(PATCH_MAX_SRC // PATCH_WAVES, PATCH_WAVES).T
         pt_nsrc[p] = len(src)

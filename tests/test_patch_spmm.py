@@ -99,6 +99,9 @@ def test_grid_graphs_get_tile_patches():
     assert CsrGraph(1200, r, c, np.ones(r.size)).patch_stats['fwd'][1] > 28                       # 4-neighbour lattice: tiles as well
     p = CsrGraph.queen_grid(40, 40, permute_seed=3)._host
     assert _grid_tiles(p['fwd_rowptr'].astype(np.int64), p['fwd_colidx'], 1600) is None
+    band = [(i, j) for i in range(1001) for j in range(max(0, i - 2), min(1001, i + 3)) if i not in (3, 4, 5, 6, 7, 8, 9, 10)]      # a lattice 2 wide, rows 3..10 empty
+    br, bc = np.array(band).T
+    assert CsrGraph(1001, br, bc, np.ones(br.size)).patch_stats['fwd'][1] > 16                    # ... too narrow for tiles: clusters
     far = CsrGraph(1200, np.append(r, 5), np.append(c, 900), np.ones(r.size + 1))._host          # one edge across the lattice
     assert _grid_tiles(far['fwd_rowptr'].astype(np.int64), far['fwd_colidx'], 1200) is None
 
