@@ -286,7 +286,8 @@ def spmm_unit_d3(graph, dev, C, L, dtype, launches=60, rotate=6, reorder=True):
     nbytes = graph.nnz * 8 + 4 * (N + 1) + 2 * N * F * Xs[0].element_size()
     return dict(what=f'Y = S.X (S = Gs^T, the forward operand), B=1, F=C*L={F}, N={N}, nnz={graph.nnz}, node order '
                      f'{"renumbered internally (as the timed step)" if renumbered else "as given (as the timed step)"}, {launches} cold launches '
-                     f'(operands rotated over {rotate} x {2 * N * F * Xs[0].element_size() / 1e6:.0f} MB)',
+                     f'(operands rotated over {rotate} x {2 * N * F * Xs[0].element_size() / 1e6:.0f} MB); the binding\'s default dispatch: one sample of '
+                     f'rows this wide is below the patch kernel\'s launch-size rule, i.e. the row-blocked kernel (stc_bcsr_spmm_*)',
                 algorithmic_bytes=nbytes, avg_launch_us=us, achieved=nbytes / us / 1e3, unit='GB/s', frac=nbytes / us / 1e3 / HBM_PEAK_GBPS,
                 target_frac=0.40)
 
