@@ -161,16 +161,28 @@ def _grid_tiles(rp: np.ndarray, colidx: np.ndarray, n: int):
         return None
     H, (TY, TX) = -(-n // W), GRID_TILE
     rpl, cil = rp.tolist(), colidx.tolist()
+    # Tile order = the order the kernel's workgroups are dispatched in, an eighth of the list per XCD (stc_xcd_tile).  The tile grid is cut into 8
+    # regions, one per XCD, each listed row by row: a tile's neighbours above are then one region WIDTH back in the list -- 7 tiles (0.85 MB of
+    # source rows) on the bench's grid, inside the XCD's 4 MiB L2, where whole rows of 28 tiles (3.4 MB, two chunks in flight) lost part of
+    # them: FETCH_SIZE 564 -> 547 MB, 190.7 -> 181.0 us.  The regions have to coincide with the XCDs' shares: strips 4 - 6 or 8 - 10 tiles wide,
+    # which straddle them, measured 190 - 198 us.
+    TR, TC = -(-H // TY), -(-W // TX)
+    gx = min((g for g in (1, 2, 4, 8) if TC >= g and TR >= 8 // g), key=lambda g: abs(TC / g - 7.0), default=1)
+    col_parts = np.array_split(np.arange(TC), gx)
+    row_parts = np.array_split(np.arange(TR), 8 // gx if TR >= 8 // gx else 1)
     tiles = []
-    for ty in range(0, H, TY):
-        for tx in range(0, W, TX):
-            rows = [y * W + x for y in range(ty, min(ty + TY, H)) for x in range(tx, min(tx + TX, W)) if y * W + x < n]
-            if not rows:
-                continue
-            src = {}
-            for c in sorted({c for u in rows for c in cil[rpl[u]:rpl[u + 1]]}):
-                src[c] = len(src)
-            tiles.append((rows, src))
+    for cols in col_parts:
+        for rws in row_parts:
+            for tr in rws.tolist():
+                for tc in cols.tolist():
+                    ty, tx = tr * TY, tc * TX
+                    rows = [y * W + x for y in range(ty, min(ty + TY, H)) for x in range(tx, min(tx + TX, W)) if y * W + x < n]
+                    if not rows:
+                        continue
+                    src = {}
+                    for c in sorted({c for u in rows for c in cil[rpl[u]:rpl[u + 1]]}):
+                        src[c] = len(src)
+                    tiles.append((rows, src))
     return tiles
 
 
