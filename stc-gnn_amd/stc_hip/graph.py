@@ -103,6 +103,11 @@ def _patch_plan(rowptr: np.ndarray, colidx: np.ndarray, val: np.ndarray, n: int,
     deg = np.diff(rp)
     if int(deg.max()) > PATCH_MAX_WIDTH:
         return None
+    # the kernel sums a FIXED number of entries per row (the table width, zero-weight padding included): a few long rows among short ones -- the
+    # in-neighbour lists of a k-nearest-neighbour graph: 8 on average, up to ~20 -- would make every row pay for the longest (measured: 793
+    # against 264 us row-blocked).  Such a matrix keeps the row-blocked form.
+    if next(w for w in PATCH_WIDTHS if w >= int(deg.max())) > max(8.0, 1.5 * float(deg.mean())):
+        return None
     rpl, cil = rp.tolist(), colidx.tolist()
     tiles = _grid_tiles(rp, colidx, n)
     if tiles is not None and n / len(tiles) >= min_rows and sum(len(src) for _, src in tiles) / n <= max_fetch:      # (a narrow lattice: clusters)
@@ -134,6 +139,17 @@ def _patch_plan(rowptr: np.ndarray, colidx: np.ndarray, val: np.ndarray, n: int,
                     queue.append(w)
         patches.append((rows, src))
     if n / len(patches) < min_rows or sum(len(src) for _, src in patches) / n > max_fetch:
+        return None
+    # ... and whose patches gather RUNS of consecutive rows: the kernel asks HBM for 1 KiB of a row at a time, which it serves at full rate only
+    # when neighbouring requests fall into the same DRAM pages.  Mean run length of the sorted source lists -- the bench's grid 9.9 (tiles), the
+    # same grid renumbered by reverse Cuthill-McKee 7.6 (197 us against 213 - 225 row-blocked); a k-nearest-neighbour mesh of random points,
+    # renumbered: 3.4, and 740 us against 252 row-blocked.  Below 5: no plan.
+    n_src = n_runs = 0
+    for _, src in patches:
+        l = np.sort(np.fromiter(src, dtype=np.int64, count=len(src)))
+        n_src += l.size
+        n_runs += int((np.diff(l) != 1).sum()) + 1
+    if n_src < 5 * n_runs:
         return None
     return _patch_tables(rpl, cil, val, n, patches, int(deg.max()))
 

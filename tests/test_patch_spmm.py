@@ -74,13 +74,20 @@ def test_patch_plan_is_the_matrix(H, W, permute):
 
 def test_which_graphs_get_a_patch_plan():
     assert CsrGraph.queen_grid(224, 224).patch_stats['fwd'][0] < 2.0                 # the bench's graph: 1.98 source rows per output row
-    assert CsrGraph.queen_grid(40, 40, permute_seed=1).patch_stats['fwd'][0] < 2.2   # the clusters follow the edges, not the node numbers
+    assert CsrGraph.queen_grid(40, 40, permute_seed=1).patch_stats == {}             # clusters exist, but their rows lie all over the plane
+    assert CsrGraph.queen_grid(40, 40, permute_seed=1).with_locality()[0].patch_stats['fwd'][0] < 2.2      # ... renumbered: runs of rows
     g = torch.Generator().manual_seed(0)
     rows, cols = torch.randint(0, 2000, (2, 16000), generator=g).numpy()
     keep = np.unique(rows.astype(np.int64) * 2000 + cols, return_index=True)[1]
     assert CsrGraph(2000, rows[keep], cols[keep], np.ones(keep.size)).patch_stats == {}      # a random graph: patches of a few rows
     dense = torch.rand(80, 80, generator=g)
     assert CsrGraph.from_dense(dense).patch_stats == {}                               # rows of 80 entries: wider than the table
+    # a k-nearest-neighbour graph: out-lists of exactly 8, in-lists of 8 on average but up to ~20 -> only the orientation with even rows gets a plan
+    from scipy.spatial import cKDTree
+    pts = np.random.default_rng(0).random((4000, 2))
+    nb = cKDTree(pts).query(pts, k=9)[1][:, 1:]
+    knn = CsrGraph(4000, np.repeat(np.arange(4000), 8), nb.ravel(), np.ones(32000)).with_locality()[0]
+    assert knn.patch_stats == {}                                                     # (in-lists: skewed lengths; out-lists: scattered rows)
     rp = np.array([0, 0, 0], dtype=np.int32)
     assert _patch_plan(rp, np.zeros(0, np.int32), np.zeros(0, np.float32), 2) is None
 
@@ -107,7 +114,7 @@ def test_grid_graphs_get_tile_patches():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('H,W,F,B,permute', [(30, 30, 512, 2, None), (17, 41, 256, 3, None), (40, 40, 1024, 1, 7), (9, 9, 768, 2, None), (224, 8, 512, 1, None)])
+@pytest.mark.parametrize('H,W,F,B,permute', [(30, 30, 512, 2, None), (17, 41, 256, 3, None), (40, 40, 1024, 1, 7), (12, 12, 768, 2, None), (224, 8, 512, 1, None)])
 def test_patch_spmm_equals_the_row_blocked_kernel(H, W, F, B, permute):
     from stc_hip._lib import HipKernels, KernelTimer
     hip = HipKernels()

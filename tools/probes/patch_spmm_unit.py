@@ -1,4 +1,5 @@
-"""The plain aggregation unit of the bench (224 x 224 queen grid, B = 5, F = 512 floats) through the row-blocked and the patch kernel,
+"""The plain aggregation unit of the bench (224 x 224 queen grid, B = 5, F = 512 floats; KNN=1: a k-nearest-neighbour mesh of as many random
+points) through the row-blocked and the patch kernel,
 alone on the GPU (alternating buffer pairs, HIP events around 30 launches):  python tools/probes/patch_spmm_unit.py [grid] [B] [F] [permute_seed]"""
 import os
 import sys
@@ -16,7 +17,18 @@ seed = int(sys.argv[4]) if len(sys.argv) > 4 else None
 hip = HipKernels()
 if os.environ.get('PATCH_MIN') is not None:
     hip.patch_min_items = int(os.environ['PATCH_MIN'])      # the launch-size rule of _lib.py (default 3 072 / 6 144 items)
-graph = CsrGraph.queen_grid(G, G, permute_seed=seed)
+if os.environ.get('KNN'):                         # an irregular mesh instead of the grid: G*G random points in the plane, 8 nearest neighbours each
+    import numpy as np
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(0)
+    pts = rng.random((G * G, 2))
+    idx = cKDTree(pts).query(pts, k=9)[1]
+    key = np.unique(np.repeat(np.arange(G * G, dtype=np.int64), 8) * (G * G) + idx[:, 1:].ravel())
+    if os.environ.get('KNN') == 'sym':             # ... made symmetric (an undirected mesh)
+        key = np.unique(np.concatenate([key, (key % (G * G)) * (G * G) + key // (G * G)]))
+    graph = CsrGraph(G * G, key // (G * G), key % (G * G), np.full(key.size, 0.125, dtype=np.float32))
+else:
+    graph = CsrGraph.queen_grid(G, G, permute_seed=seed)
 if os.environ.get('LOCALITY'):
     graph = graph.with_locality()[0]                  # renumbered (reverse Cuthill-McKee), as the model does with a graph in arbitrary order
 print('patch plan:', graph.patch_stats, ' row-blocked fetches per row:', graph.fetches_per_row)
@@ -58,6 +70,8 @@ def copy_rate():
 
 copy_rate()
 for side in ('fwd', 'bwd'):
+    if f'{side}_pt_src' not in d:
+        print(f'{side}: no patch plan for this orientation')
     blocks = (d[f'{side}_blk_ptr'], d[f'{side}_blk_cols'], d[f'{side}_blk_vals'])
     forms = {'row-blocked': blocks}
     if f'{side}_pt_src' in d:
