@@ -93,7 +93,8 @@ int stc_bcsr_spmm_f32(const int32_t* blk_ptr, const int32_t* blk_cols, const flo
                       const float* X, const float* Y0, float* Y,
                       int32_t batch, int32_t F, float alpha, float beta, void* stream);
 
-/* Same product on the PATCH form of a fixed graph whose rows cluster (grids and other meshes): the host groups the rows into
+/* Same product on the PATCH form of a fixed graph whose rows cluster AND whose clusters gather runs of consecutive rows (lattices in their
+ * node numbering, grids renumbered by reverse Cuthill-McKee; not irregular meshes, whose scattered 1 KiB requests HBM serves slowly): the host groups the rows into
  * patches of up to STC_PATCH_ROWS output rows whose entries touch at most STC_PATCH_MAX_SRC distinct source rows together
  * (stc_hip/graph.py _patch_plan: 4 x 8 tiles of a lattice, greedy clusters otherwise; 1.85 source rows per output row on the 8-neighbour grid, against 4.5 row fetches through L1 / L2
  * for the row-blocked form).  One workgroup per (patch, batch element) copies the source rows into LDS, one 1 KiB column chunk at a
