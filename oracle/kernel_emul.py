@@ -102,8 +102,18 @@ class EmulatedKernels:
     def act_amax_buffer(self, like, *lead):
         return torch.zeros(*lead, self.ACT_AMAX_SLOTS, dtype=torch.float32) if self.fmt == 'f16x2' else None
 
+    HEAVY_ROW_SUM = 24.0
+
+    def for_graph(self, row_sum_bound):
+        """As ``HipKernels.for_graph``: heavy graphs leave the fp16 x 2 format for the 24-bit one (here: the exact twin)."""
+        if self.fmt != 'f16x2' or not (row_sum_bound > self.HEAVY_ROW_SUM):
+            return self
+        if getattr(self, '_b3_view', None) is None:
+            self._b3_view = EmulatedKernels()
+        return self._b3_view
+
     # ---- fp16 x 2 format emulation helpers (planar entry points only: the kernels that run the format)
-    def _tables(self, *ts):
+    def _tables(self, *ts, backward=False):
         """Weight tables as the kernels hold them: normalised by their own maximum into [2^3, 2^4) (STC_W_TARGET)."""
         if self.fmt != 'f16x2':
             return ts
@@ -136,16 +146,41 @@ class EmulatedKernels:
             return [_q2(p, 1.0) for p in planes]
         return [_q2(p, _pow2_scale(act_amax[r].max(), 6)) for p, r in zip(planes, rows)]
 
+    #: waves a backward launch deals its nodes to (node r -> wave r % GRAD_WAVES, in order of r): 256 workgroups x 4 waves on the MI355X; the
+    #: CPU tests lower it so that several nodes share a wave's sums
+    GRAD_WAVES = 1024
+
     def _grad_scaled(self, grads, planes=(), plane_scales=()):
-        """Backward: the gradient fragments of a launch take one scale per NODE (row of the (R, C, w) planes), from the node's own maximum over
-        all of them; the dW products sum over nodes at a reference scale (the kernels: the wave's running maximum; here: the launch's), so
-        their activation operand ``planes[i]`` (plane scale ``plane_scales[i]``) is multiplied by reference / node scale, capped at 2^8."""
+        """Backward: the gradient fragments of a launch take one scale per NODE (row of the (R, C, w) planes), a_n = 2^kn from the node's own
+        maximum over all of them.  The dW products sum over the nodes a wave owns at the wave's REFERENCE scale a = 2^k, set by the first non-zero
+        node: a node joins with its activation operand ``planes[i]`` (plane scale ``plane_scales[i]``) times a / a_n = 2^j, up to 2^8 there and up to
+        2^4 more inside a_n; a node more than 2^12 above the reference ends the wave's pass -- the sums so far are added to the partial row and the
+        node becomes the reference of the next pass (csrc/stc_x3_frag.h: RunScale).  Sums are exact here, so a pass boundary only shows in the
+        scales the operands are represented at."""
         if self.fmt != 'f16x2':
             return list(grads), list(planes)
-        m = torch.stack([g.abs().amax(dim=(1, 2)) for g in grads]).amax(0)
-        a_n = _pow2_scale(m, 4).view(-1, 1, 1)
-        ref = _pow2_scale(m.max(), 4)
-        shift = torch.where(m.view(-1, 1, 1) > 0, (ref / a_n).clamp(max=256.0), torch.ones_like(a_n))
+        m = torch.stack([g.abs().amax(dim=(1, 2)) for g in grads]).amax(0).double()
+        R = m.numel()
+        _, e = torch.frexp(m)
+        kn = (4 - e).clamp(-100, 100)                                  # node maximum 2^kn in [2^3, 2^4)
+        kn = torch.where(torch.isfinite(m), kn, torch.full_like(kn, -100))
+        nw = min(self.GRAD_WAVES, R)
+        EMPTY = 120
+        k = torch.full((nw,), EMPTY, dtype=kn.dtype)
+        a_exp, shift_exp = torch.zeros(R, dtype=torch.float64), torch.zeros(R, dtype=torch.float64)
+        for t in range(0, R, nw):
+            idx = torch.arange(t, min(t + nw, R))
+            w = idx - t
+            knt, zero = kn[idx], m[idx] == 0
+            j = k[w] - knt
+            fresh = (j > 12) & ~zero                                   # first gradient of the wave, or a node that ends its pass: the new reference
+            k[w] = torch.where(fresh, knt, k[w])
+            j = torch.where(fresh | zero, torch.zeros_like(j), j)
+            up = (j - 8).clamp(min=0)
+            a_exp[idx] = torch.where(zero, torch.zeros_like(j), knt + up).double()
+            shift_exp[idx] = (j - up).clamp(min=-100).double()
+        two = torch.tensor(2.0, dtype=torch.float64)
+        a_n, shift = torch.pow(two, a_exp).view(-1, 1, 1), torch.pow(two, shift_exp).view(-1, 1, 1)
         return [_q2(g, a_n) for g in grads], [_q2(p, sp * shift) for p, sp in zip(planes, plane_scales)]
 
     def _plane_scales(self, act_amax, rows):
@@ -470,7 +505,7 @@ class EmulatedKernels:
             # As the kernel: the gate prologue runs in fp32 on the planes themselves (dG and the state's own share are exact); the matrix
             # products take dG, the tables and -- the dW products -- the planes, each as its format carries it.
             order = (0, 1, 2, 3) if cin == h else (2, 3, 0, 1)                # rows of the slots: wide {X, S.X, H, S.H}, narrow {H, S.H, x, S.x}
-            (Wq,), Tq = self._tables(W), self._mix_tables(Tc, backward=True)
+            (Wq,), Tq = self._tables(W, backward=True), self._mix_tables(Tc, backward=True)
             dG = torch.cat([dHnew * (Cand - H) * U * (1 - U), dRH * H * Rg * (1 - Rg)], -1)
             (dGq,), (Xq, SXq, Hq, SHq) = self._grad_scaled((dG,), (X, SX, H, SH), self._plane_scales(act_amax, order))
             own = dRH * Rg + dHnew * (1 - U)
@@ -616,7 +651,7 @@ class EmulatedKernels:
         if X2 is not None and self.fmt == 'f16x2':             # operands in their format, then the exact twin
             (dAq, dBq), (Xq, X2q) = self._grad_scaled((dA, dB), (X, X2), self._plane_scales(
                 None if act_amax is None else torch.stack([a.reshape(-1) for a in act_amax]), (0, 1)))
-            (Wq,), Tq = self._tables(W), self._mix_tables(Tc, backward=True)
+            (Wq,), Tq = self._tables(W, backward=True), self._mix_tables(Tc, backward=True)
             EmulatedKernels().node_post_bwd(Xq, Tq, Wq, dAq, dBq, dX, dW, db, X2=X2q, dX2=dX2)
             return
         if X2 is not None:                                     # planar: compute on the concatenated rows, hand back the planes

@@ -54,7 +54,7 @@ constexpr size_t cb_lds_bytes() { return (size_t)CB_TABLE_FRAGS * F::NP * 64 * 1
 // normalised per workgroup: block c = 0 of W carries sW sT, blocks c >= 1 carry sW and T_1 carries sT, so both halves of a contraction over
 // (c, o) arrive with the same factor a_n sT sW, which the tile's store takes out again.
 template <class F, int L, int PL, int ACCX = 0, int ACCH = 0>        // PL = 1: L = 32, rows [X | H];  PL = 2: L = 20, rows [H | x (cin = Lw - 16 <= 4) | pad], W rows permuted to match
-__global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs a) {
+__global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs args_in_kernarg_segment) {
     using Op = typename F::Op;
     constexpr int NP = F::NP;
     constexpr int K = 2, NRB = 2, C = 32, LB = 2, HID = 16;
@@ -73,8 +73,16 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
     float4* stash_h = reinterpret_cast<float4*>(mine);               // the state's share of the gate prologue, lane-private
     float4* stash_x = stash_h + 2 * 64;                               // the candidate's X-side gradient, lane-private
     float* tiles = reinterpret_cast<float*>(stash_x + 2 * 64);        // row-on-lane -> accumulator layout (to_acc below)
+    const int nw = gridDim.x * CB_WAVES;
+    // fp16 x 2: the kernel body runs in PASSES.  A node whose gradients exceed the sums' scale by more than 2^12 -- the candidate's or the gates' -- ends its wave's pass (stc_x3_frag.h:
+    // RunScale): computed to its end with its sums muted and nothing new stored, then the wave leaves the loop at the latch.  After the
+    // combine the body runs again while any wave of the workgroup has nodes left -- tables refilled, operands requested afresh, sums empty,
+    // the partial row added to; nothing is live across passes but the node index and whether that node's candidate phase is already in the rows.
+    int node = blockIdx.x * CB_WAVES + wave;
+    bool cand_done = false;           // the pass starts at a node whose candidate phase is in the partial rows already (its gates phase ended the previous pass)
+    for (int pass = 0;; ++pass) {
+    const CellBwdArgs a = F::SCALED ? kernargs_fresh<CellBwdArgs>() : args_in_kernarg_segment;      // (read per pass: stc_x3_frag.h)
     const int cin = a.Lw - 16;
-
     // FmtH2: table scales from the tables' own maxima (same in every workgroup), gradient scale from the producer's slots
     float sT = 1.f, sWg = 1.f, sWc = 1.f;
     if constexpr (F::SCALED) {
@@ -125,7 +133,6 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
     }
     __syncthreads();
 
-    const int nw = gridDim.x * CB_WAVES;
     f32x4 dWg[K][LB][K][2];            // gates dW tiles: rows l = 16lb + 4g + r, columns o = 16hb + x
     float dbg[2] = {0.f, 0.f}, dbc[1] = {0.f};
 #pragma unroll
@@ -199,13 +206,15 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
     // FmtH2 factors (all powers of two; 1 for FmtB3): what a tile of each phase carries besides sg, and their inverses
     const float kc = uniform_bits(sT * sWc), kg = uniform_bits(sT * sWg), ikc = inv_pow2(kc), ikg = inv_pow2(kg);      // (scalar registers)
     Ops cur, nxt, nx2;                            // operands two nodes ahead: ~40 MB in flight chip-wide instead of 20
-    int node = blockIdx.x * CB_WAVES + wave;
     if (node < a.nodes) load_ops(cur, node);
     if (node + nw < a.nodes) load_ops(nxt, node + nw);
     // The first node's loads are waited for HERE: left pending into the loop, the compiler's wait-count pass merges them with the loop's own
     // state and makes every iteration wait for the loads it has just issued for the NEXT node (vmcnt counts in order) -- no prefetch at all.
     __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0), expcnt / lgkmcnt untouched
+    int resume = -1;
     while (node < a.nodes) {
+        const bool mute_c = cand_done;                             // this node's candidate sums are in the partial rows already (first node of a pass only)
+        bool skip_c = false, skip_g = false;                       // the node is too large for the candidate / the gates sums: it ends the pass and is redone
         const int next_node = node + nw;
         // ACCX / ACCH: what the gradient planes already hold (tile layout: row 16rb + x, columns 4g .. 4g+3).  Requested for THIS node, before
         // the next node's operands (vmcnt counts in order); first used in the gates phase, microseconds from here.
@@ -245,18 +254,9 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
                     float m = 0.f;
 #pragma unroll
                     for (int kb = 0; kb < NRB; ++kb) m = vmax3_acc(m, absmax4(v0[kb]), absmax4(v1[kb]));
-                    bool restart;
-                    a_c = rc.node(wave_max_bits(m), sh_c, restart);
-                    if (__builtin_expect(restart, 0)) {
-                        asm volatile("; the node replaces the sums" ::: "memory");      // (keeps this a branch: as a select it would touch every accumulator on every node)
-#pragma unroll
-                        for (int n = 0; n < K; ++n)
-#pragma unroll
-                            for (int lb = 0; lb < LB; ++lb)
-#pragma unroll
-                                for (int c = 0; c < K; ++c) dWc[n][lb][c][0] = kZero4;
-                        dbc[0] = 0.f;
-                    }
+                    const int k_was = rc.k;
+                    a_c = rc.node(wave_max_bits(m), sh_c, skip_c);
+                    if (mute_c) { rc.k = k_was; sh_c = RunScale::mute(); }               // (a muted node adds nothing: it sets no reference either)
 #pragma unroll
                     for (int kb = 0; kb < NRB; ++kb) { v0[kb] *= a_c; v1[kb] *= a_c; }
                 }
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
                     c1[t] = lb == RHB ? rh_d[1][t] : zg[0][lb][1][t];
                 }
                 Op za;
-                if constexpr (F::SCALED) za = F::split(c0 * pow2_mul(sz[0][lb], sh_c), c1 * pow2_mul(sz[0][lb], sh_c)); else za = F::split(c0, c1);
+                if constexpr (F::SCALED) za = F::split(c0 * pow2_mul(sz[0][lb], sh_c), c1 * pow2_mul(sz[0][lb], sh_c)); else za = F::split(c0, c1);      // (muted / skipped: sh_c = RunScale::mute())
 #pragma unroll
                 for (int n = 0; n < K; ++n)
 #pragma unroll
@@ -353,20 +353,10 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
                 float m = 0.f;
 #pragma unroll
                 for (int kb = 0; kb < NRB; ++kb) m = vmax3_acc(m, absmax4(v0[kb]), absmax4(v1[kb]));
-                bool restart;
-                a_g = rg.node(wave_max_bits(m), sh_g, restart);
-                if (__builtin_expect(restart, 0)) {
-                        asm volatile("; the node replaces the sums" ::: "memory");      // (keeps this a branch: as a select it would touch every accumulator on every node)
-#pragma unroll
-                    for (int n = 0; n < K; ++n)
-#pragma unroll
-                        for (int lb = 0; lb < LB; ++lb)
-#pragma unroll
-                            for (int c = 0; c < K; ++c)
-#pragma unroll
-                                for (int hb = 0; hb < 2; ++hb) dWg[n][lb][c][hb] = kZero4;
-                    dbg[0] = 0.f; dbg[1] = 0.f;
-                }
+                const int k_was = rg.k;
+                a_g = rg.node(wave_max_bits(m), sh_g, skip_g);
+                // skip_g alone: the candidate phase of this node is in its sums, nothing is stored -- the node is redone with that phase muted
+                if (skip_c) { rg.k = k_was; skip_g = true; sh_g = RunScale::mute(); }    // (skipped as a whole: no reference from it, no stores)
 #pragma unroll
                 for (int kb = 0; kb < NRB; ++kb) { v0[kb] *= a_g; v1[kb] *= a_g; }
             }
@@ -437,7 +427,8 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
 #pragma unroll
                 for (int rb = 0; rb < NRB; ++rb) {
                     if constexpr (F::SCALED) {                     // out of the scaled space (+ the other consumer's gradients of the same plane)
-                        const float ikg_n = pow2_mul(ikg, inv_pow2(a_g));
+                        // (a skipped node stores zeros, or what the plane held: whatever it stores is stored again when it is redone -- no branch here)
+                        const float ikg_n = skip_g ? 0.f : pow2_mul(ikg, inv_pow2(a_g));
                         if (ACC[lb]) z[rb] = z[rb] * ikg_n + old[n][lb][rb];
                         else z[rb] *= ikg_n;
                     }
@@ -463,7 +454,7 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
                 const float (&zc)[NRB][4] = zg[n][lb];
                 Op za;
                 if constexpr (F::SCALED) {
-                    const float zs = pow2_mul(sz[n][lb], sh_g);
+                    const float zs = pow2_mul(sz[n][lb], sh_g);                                    // (skipped: sh_g = RunScale::mute())
                     za = F::split(f32x4{zc[0][0], zc[0][1], zc[0][2], zc[0][3]} * zs, f32x4{zc[1][0], zc[1][1], zc[1][2], zc[1][3]} * zs);
                 }
                 else za = F::split(f32x4{zc[0][0], zc[0][1], zc[0][2], zc[0][3]}, f32x4{zc[1][0], zc[1][1], zc[1][2], zc[1][3]});
@@ -474,18 +465,25 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
             }
         cur = nxt;
         nxt = nx2;
-        node = next_node;
+        // skip_g: the wave's pass ends AT this node -- no exit of its own, the loop condition does it
+        cand_done = skip_g && !skip_c;
+        resume = skip_g ? node : resume;
+        node = skip_g ? 0x7fffffff : next_node;
     }
+    if (resume >= 0) node = resume;
 
     // dW tiles of block c carry the wave's final gradient scale (c = 0) or that times sT (c = 1: Q_1 = T_1 dY); db carries the scale
-    const float isg_g = exp2i(rg.k > 100 ? 0 : -rg.k), isg_c = exp2i(rc.k > 100 ? 0 : -rc.k);      // (a wave that met no node: sums of zeros)
+    const float isg_g = rg.unscale(), isg_c = rc.unscale();
     PlaneUnscale<K, LB> pug, puc;
 #pragma unroll
     for (int n = 0; n < K; ++n)
 #pragma unroll
         for (int lb = 0; lb < LB; ++lb) { pug.v[n][lb] = inv_pow2(sz[n][lb]); puc.v[n][lb] = inv_pow2(sz[0][lb]); }      // the candidate's input is slab 0, [X | R*H], for both weight sets
-    combine_dw<K, LB, 2, CB_WAVES>(reinterpret_cast<float*>(smem_raw), dWg, dbg, a.partial_g, a.Lw, a.want_dbg, PL == 2 ? cin : -1, isg_g, isg_g / sT, isg_g, pug);
-    combine_dw<K, LB, 1, CB_WAVES>(reinterpret_cast<float*>(smem_raw), dWc, dbc, a.partial_c, a.Lw, a.want_dbc, PL == 2 ? cin : -1, isg_c, isg_c / sT, isg_c, puc);
+    combine_dw<K, LB, 2, CB_WAVES>(reinterpret_cast<float*>(smem_raw), dWg, dbg, a.partial_g, a.Lw, a.want_dbg, PL == 2 ? cin : -1, isg_g, isg_g / sT, isg_g, pug, pass > 0);
+    combine_dw<K, LB, 1, CB_WAVES>(reinterpret_cast<float*>(smem_raw), dWc, dbc, a.partial_c, a.Lw, a.want_dbc, PL == 2 ? cin : -1, isg_c, isg_c / sT, isg_c, puc, pass > 0);
+    if constexpr (!F::SCALED) break;
+    if (!__syncthreads_or(node < a.nodes)) break;        // (also: every wave is done with the combine's slabs before the tables are filled again)
+    }
 }
 
 template <class F, int L, int PL, int ACCX = 0, int ACCH = 0>

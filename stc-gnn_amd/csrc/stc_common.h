@@ -100,6 +100,9 @@ __device__ __forceinline__ void stc_st_once(T* p, const T& v) { __builtin_nontem
 // reference's torch.sigmoid / torch.tanh are (STC_GNN.py:72-78): the sigmoid by construction; the tanh form 1 - 2 / (e^{2v} + 1) cancels
 // for small arguments (its absolute error of ~1.2e-7 is a relative error of 1.2e-7 / |v|: 1e-3 at |v| = 1e-4), so below 1/4 the odd Taylor
 // polynomial through v^9 takes over (truncation 9e-3 v^10 < 1e-8 relative), selected by value -- no branch.  Above 1/4: <= 5e-7 relative.
+// (Round 5 probe, HISTORY section 11: libm expf / tanhf, or a compensated exponent argument + a Newton step on the reciprocal, change the
+// prediction's error where the model amplifies rounding noise -- graph row sums of 16 .. 50 -- only within its run-to-run spread, 1 - 2.2x the
+// reference's own fp32 noise either way; they cost nothing measurable either.  Left as they are.)
 __device__ __forceinline__ float stc_sigmoid(float v) {
     return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
 }

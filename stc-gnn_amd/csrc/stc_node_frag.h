@@ -210,6 +210,7 @@ __host__ __device__ __forceinline__ int stc_wrow_swapped(int col, int cin) {
 // End of a backward kernel: the workgroup's four waves hold dW tiles (rows l = 16lb + 4g + r, columns o = 16hb + x) and
 // db partial sums in registers; combine them through LDS in a fixed order (bitwise reproducible) into ONE partial row
 // [dW in W layout | db] per workgroup, which bdg_node_reduce_kernel then sums over workgroups.  (WAVES: waves per workgroup.)
+// Called once per flush segment of the fp16 x 2 kernels (normally: once): segments after the first add to the row.
 template <int K, int LB>
 struct PlaneUnscale {     // fp16 x 2: 1 / (activation scale) of the plane that is block lb of slab n (the A operands of the dW tiles [n][lb][.][.])
     float v[K][LB];
@@ -225,7 +226,8 @@ template <int K, int LB, int HB, int WAVES = MF_WAVES>
 __device__ __forceinline__ void combine_dw(float* smem, const f32x4 (&dWt)[K][LB][K][HB], const float (&dbp)[HB],
                                            float* __restrict__ partial, int Lw, int want_db, int swapped_cin = -1,
                                            float unscale0 = 1.f, float unscale1 = 1.f, float db_unscale = 1.f,      // scaled operand formats: factor of the tiles of block c = 0 / c >= 1
-                                           const PlaneUnscale<K, LB>& pu = PlaneUnscale<K, LB>()) {
+                                           const PlaneUnscale<K, LB>& pu = PlaneUnscale<K, LB>(),
+                                           bool accumulate = false) {                        // a flush segment after the first (stc_x3_frag.h: RunScale): add to the row
     constexpr int Ho = 16 * HB;
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, q = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -259,7 +261,8 @@ __device__ __forceinline__ void combine_dw(float* smem, const f32x4 (&dWt)[K][LB
         float s = smem[e];
 #pragma unroll
         for (int w = 1; w < WAVES; ++w) s += smem[(size_t)w * (nW + Ho) + e];
-        out[e] = (e >= nW && !want_db) ? 0.f : s;
+        if (e >= nW && !want_db) s = 0.f;
+        out[e] = accumulate ? out[e] + s : s;
     }
 }
 

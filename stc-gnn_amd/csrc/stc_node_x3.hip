@@ -578,10 +578,11 @@ struct BwdSched { static constexpr int waves = (NB2 == 1 && K <= 2) ? 2 : 1; };
 // F = FmtH2 (two fp16 pieces, three products; see cell_bwd_x3_kernel): the gradient fragments are taken into a space scaled by sg = 2^k
 // (per node, from the node's own maximum: stc_x3_frag.h, RunScale) right after they are loaded / formed, W's blocks of c = 0 carry sW sT, those of c >= 1
 // carry sW and the T_c tables sT, so every (c, o) block of a dZ contraction arrives with the factor sg sT sW, taken out at the store.
+struct BwdArgs {       // the kernel's one parameter (read afresh per pass on the fp16 x 2 format: stc_x3_frag.h, kernargs_fresh)
+    ZPtrs Z; const float *Tc, *W, *dY; DZPtrs dZ; float* partial; int nodes, want_db, Lw; BwdPro pro;
+};
 template <int NB2, int HB, int K, int L, int PRO, int PL = 0, int FOLD = 0, int ACC = 0, class F = FmtB3>      // FOLD: see load_gates_grad (planar gates backward only)
-__global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bwd_x3_kernel(
-    ZPtrs Z, const float* __restrict__ Tc, const float* __restrict__ W, const float* __restrict__ dY,
-    DZPtrs dZ, float* __restrict__ partial, int nodes, int want_db, int Lw, BwdPro pro) {
+__global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bwd_x3_kernel(BwdArgs args_in_kernarg_segment) {
     using Op = typename F::Op;
     constexpr int NP = F::NP;
     constexpr int NRB = 2 * NB2, C = 32 * NB2, Ho = 16 * HB, LB = (L + 15) / 16;
@@ -600,6 +601,23 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
     float* dy_tile = reinterpret_cast<float*>(reinterpret_cast<float4*>(WA + nWA * NP * 64) + (FOLD ? MF_WAVES * NRB * 64 : 0))
                      + (tid >> 6) * (HB * NRB * 16 * TRS);                                    // PFG: [wave][HB][NRB][16 rows][TRS]
 
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nw = gridDim.x * MF_WAVES;
+    // fp16 x 2: the kernel body runs in PASSES.  A node whose gradients exceed the sums' scale by more than 2^12 ends its wave's pass (stc_x3_frag.h:
+    // RunScale): computed to its end with its sums muted and nothing new stored, then the wave leaves the loop at the latch.  After the
+    // combine the body runs again while any wave of the workgroup has nodes left -- tables refilled, operands requested afresh, sums empty,
+    // the partial row added to; nothing is live across passes but the node index.
+    int node = blockIdx.x * MF_WAVES + wave;
+    for (int pass = 0;; ++pass) {
+    const BwdArgs ka = F::SCALED ? kernargs_fresh<BwdArgs>() : args_in_kernarg_segment;
+    const ZPtrs& Z = ka.Z;
+    const DZPtrs& dZ = ka.dZ;
+    const BwdPro& pro = ka.pro;
+    const float* __restrict__ Tc = ka.Tc;
+    const float* __restrict__ W = ka.W;
+    const float* __restrict__ dY = ka.dY;
+    float* __restrict__ partial = ka.partial;
+    const int nodes = ka.nodes, want_db = ka.want_db, Lw = ka.Lw;
     float sT = 1.f, sW = 1.f;                            // FmtH2: table scales from the tables' own maxima
     if constexpr (F::SCALED) {
         float* scratch = reinterpret_cast<float*>(smem_raw);
@@ -639,8 +657,6 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
     }
     __syncthreads();
 
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nw = gridDim.x * MF_WAVES;
     const float kz = uniform_bits(sT * sW), ikz = inv_pow2(kz);      // (1 for FmtB3; scalar registers)
 
     f32x4 dWt[K][LB][K][HB];          // dW tiles: rows l = 16lb + 4g + r, columns o = 16hb + x
@@ -656,7 +672,6 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
 #pragma unroll
     for (int hb = 0; hb < HB; ++hb) dbp[hb] = 0.f;
 
-    int node = blockIdx.x * MF_WAVES + wave;
     static_assert(PL != 1 || L == 32, "planar rows are 16 + 16 columns");
     static_assert(PL != 2 || L == 20, "narrow planar rows are 16 + cin columns padded to 20");
     NodeIn<NB2, HB, K, L, PL> in, nx;
@@ -664,6 +679,8 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
     if (PF && node < nodes) { in.g.load(dY, node, x, g); in.load_z(Z, node, x, g, Lw - 16); }      // (the width matters to PL = 2 only)
     if (PFG && node < nodes) { rows_cur.template load<PRO == PRO_GATES_CAND>(pro, node, x, g); in.load_z(Z, node, x, g, Lw - 16); }
     if (PF || PFG) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) before the loop: see node_fwd_x3_kernel
+    bool skipped = false;                                   // this node ends the wave's pass: the next pass starts AT it
+    int resume = -1;
     while (node < nodes) {
         const int next_node = node + nw;
         const size_t r0 = (size_t)node * C;
@@ -689,27 +706,15 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
             for (int kb = 0; kb < NRB; ++kb)
 #pragma unroll
                 for (int hb = 0; hb < HB; ++hb) m = max_nonneg(m, absmax4(in.g.v[kb][hb]));
-            bool restart;
-            sg = rs.node(wave_max_bits(m), sh, restart);
-            if (__builtin_expect(restart, 0)) {
-                        asm volatile("; the node replaces the sums" ::: "memory");      // (keeps this a branch: as a select it would touch every accumulator on every node)
-#pragma unroll
-                for (int n = 0; n < K; ++n)
-#pragma unroll
-                    for (int lb = 0; lb < LB; ++lb)
-#pragma unroll
-                        for (int c = 0; c < K; ++c)
-#pragma unroll
-                            for (int hb = 0; hb < HB; ++hb) dWt[n][lb][c][hb] = kZero4;
-#pragma unroll
-                for (int hb = 0; hb < HB; ++hb) dbp[hb] = 0.f;
-            }
+            sg = rs.node(wave_max_bits(m), sh, skipped);
+            // (what a stopped node's prologue has stored already -- the state's share -- is stored again, alike, when the node is redone)
 #pragma unroll
             for (int kb = 0; kb < NRB; ++kb)
 #pragma unroll
                 for (int hb = 0; hb < HB; ++hb) { in.g.d[kb][hb] *= sg; in.g.v[kb][hb] *= sg; }
         }
-        const float ikz_sg = F::SCALED ? pow2_mul(ikz, inv_pow2(sg)) : 1.f;
+        // (a skipped node stores zeros, or what the plane held: whatever it stores is stored again when it is redone -- no branch at the stores)
+        const float ikz_sg = F::SCALED ? (skipped ? 0.f : pow2_mul(ikz, inv_pow2(sg))) : 1.f;
         const DyFrag<NRB, HB>& gr = in.g;
 
 #pragma unroll
@@ -846,8 +851,10 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
                 for (int p = 0; p < NB2; ++p) {
                     const float (&zc)[NRB][4] = in.za[n][lb];
                     Op a;
-                    if constexpr (F::SCALED) a = F::split(f32x4{zc[2 * p][0], zc[2 * p][1], zc[2 * p][2], zc[2 * p][3]} * pow2_mul(sz[n][lb], sh),
-                                                          f32x4{zc[2 * p + 1][0], zc[2 * p + 1][1], zc[2 * p + 1][2], zc[2 * p + 1][3]} * pow2_mul(sz[n][lb], sh));
+                    if constexpr (F::SCALED) {
+                        const float zs = pow2_mul(sz[n][lb], sh);                                // (a skipped node: sh = RunScale::mute())
+                        a = F::split(f32x4{zc[2 * p][0], zc[2 * p][1], zc[2 * p][2], zc[2 * p][3]} * zs, f32x4{zc[2 * p + 1][0], zc[2 * p + 1][1], zc[2 * p + 1][2], zc[2 * p + 1][3]} * zs);
+                    }
                     else a = F::split(f32x4{zc[2 * p][0], zc[2 * p][1], zc[2 * p][2], zc[2 * p][3]},
                                       f32x4{zc[2 * p + 1][0], zc[2 * p + 1][1], zc[2 * p + 1][2], zc[2 * p + 1][3]});
 #pragma unroll
@@ -868,15 +875,20 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
 #pragma unroll
                         for (int t = 0; t < 4; ++t) in.za[n][lb][kb][t] = nx.za[n][lb][kb][t];
         }
-        node = next_node;
+        resume = skipped ? node : resume;                    // the wave's pass ends AT this node: no exit of its own, the loop condition does it
+        node = skipped ? 0x7fffffff : next_node;
     }
-    const float isg = exp2i(rs.k > 100 ? 0 : -rs.k);                            // dW tiles of block c carry the wave's final gradient scale (c = 0) or that times sT (c >= 1); db the scale
+    if (resume >= 0) node = resume;
+    const float isg = rs.unscale();                                             // dW tiles of block c carry the wave's final gradient scale (c = 0) or that times sT (c >= 1); db the scale
     PlaneUnscale<K, LB> pu;
 #pragma unroll
     for (int n = 0; n < K; ++n)
 #pragma unroll
         for (int lb = 0; lb < LB; ++lb) pu.v[n][lb] = inv_pow2(sz[n][lb]);
-    combine_dw<K, LB, HB>(reinterpret_cast<float*>(smem_raw), dWt, dbp, partial, Lw, want_db, PL == 2 ? Lw - 16 : -1, isg, isg / sT, isg, pu);
+    combine_dw<K, LB, HB>(reinterpret_cast<float*>(smem_raw), dWt, dbp, partial, Lw, want_db, PL == 2 ? Lw - 16 : -1, isg, isg / sT, isg, pu, pass > 0);
+    if constexpr (!F::SCALED) break;
+    if (!__syncthreads_or(node < nodes)) break;          // (also: every wave is done with the combine's slabs before the tables are filled again)
+    }
 }
 
 // --------------------------------------------------------------------------------------- post-aggregation form (K = 2)
@@ -995,12 +1007,11 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_fwd2_x3_k
     }
 }
 
+struct Bwd2Args {      // the kernel's one parameter (read afresh per pass on the fp16 x 2 format: stc_x3_frag.h, kernargs_fresh)
+    const float *X, *X2, *Tc, *W, *dA, *dB; float *dX, *dX2, *partial; int nodes, want_db, Lw; const float *zmax_x, *zmax_x2;
+};
 template <int NB2, int HB, int L, int PL = 0, class F = FmtB3>      // F: operand format, scales as in node_bwd_x3_kernel
-__global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_kernel(
-    const float* __restrict__ X, const float* __restrict__ X2, const float* __restrict__ Tc, const float* __restrict__ W,
-    const float* __restrict__ dA, const float* __restrict__ dB, float* __restrict__ dX, float* __restrict__ dX2,
-    float* __restrict__ partial, int nodes, int want_db, int Lw,
-    const float* __restrict__ zmax_x, const float* __restrict__ zmax_x2) {
+__global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_kernel(Bwd2Args args_in_kernarg_segment) {
     // zmax_x / zmax_x2 (fp16 x 2, optional): 256 slots each of max |X| / max |X2| (a row of the slots a forward launch filled; R*H takes H's): the
     // scales of the dW products' activation operands.
     using Op = typename F::Op;
@@ -1012,7 +1023,20 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
     u32x4* TB = reinterpret_cast<u32x4*>(smem_raw);     // [NRB rb][NB2 p]        T_1[16rb + x][32p + pair_row]
     u32x4* WA = TB + nTB * NP * 64;                      // [K n][LB][S]           W[(n, c, 16lb + x)][16hb + 4g + (e&3)], block 2s + (e>>2)
     const int tid = threadIdx.x, lane = tid & 63, x = lane & 15, g = lane >> 4;
-
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nw = gridDim.x * MF_WAVES;
+    // fp16 x 2: the kernel body runs in PASSES.  A node whose gradients exceed the sums' scale by more than 2^12 ends its wave's pass (stc_x3_frag.h:
+    // RunScale): computed to its end with its sums muted and nothing new stored, then the wave leaves the loop at the latch.  After the
+    // combine the body runs again while any wave of the workgroup has nodes left -- tables refilled, operands requested afresh, sums empty,
+    // the partial row added to; nothing is live across passes but the node index.
+    int node = blockIdx.x * MF_WAVES + wave;
+    for (int pass = 0;; ++pass) {
+    const Bwd2Args ka = F::SCALED ? kernargs_fresh<Bwd2Args>() : args_in_kernarg_segment;
+    const float* __restrict__ X = ka.X; const float* __restrict__ X2 = ka.X2; const float* __restrict__ Tc = ka.Tc; const float* __restrict__ W = ka.W;
+    const float* __restrict__ dA = ka.dA; const float* __restrict__ dB = ka.dB;
+    float* __restrict__ dX = ka.dX; float* __restrict__ dX2 = ka.dX2; float* __restrict__ partial = ka.partial;
+    const int nodes = ka.nodes, want_db = ka.want_db, Lw = ka.Lw;
+    const float* __restrict__ zmax_x = ka.zmax_x; const float* __restrict__ zmax_x2 = ka.zmax_x2;
     float sT = 1.f, sW = 1.f;
     if constexpr (F::SCALED) {
         float* scratch = reinterpret_cast<float*>(smem_raw);
@@ -1045,8 +1069,6 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
     }
     __syncthreads();
 
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nw = gridDim.x * MF_WAVES;
     const float ikz = inv_pow2(uniform_bits(sT * sW));
     f32x4 dWt[K][LB][K][HB];
     float dbp[HB];
@@ -1061,7 +1083,9 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
 #pragma unroll
     for (int hb = 0; hb < HB; ++hb) dbp[hb] = 0.f;
 
-    for (int node = blockIdx.x * MF_WAVES + wave; node < nodes; node += nw) {
+    bool skipped = false;                                   // this node ends the wave's pass: the next pass starts AT it
+    int resume = -1;
+    for (; node < nodes; resume = skipped ? node : resume, node = skipped ? 0x7fffffff : node + nw) {
         const size_t r0 = (size_t)node * C;
         DyFrag<NRB, HB> gr[K];
         gr[0].load(dA, node, x, g);
@@ -1075,22 +1099,8 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
                 for (int kb = 0; kb < NRB; ++kb)
 #pragma unroll
                     for (int hb = 0; hb < HB; ++hb) m = max_nonneg(m, absmax4(gr[n].v[kb][hb]));
-            bool restart;
-            const float sg = rs.node(wave_max_bits(m), sh, restart);
-            if (__builtin_expect(restart, 0)) {
-                        asm volatile("; the node replaces the sums" ::: "memory");      // (keeps this a branch: as a select it would touch every accumulator on every node)
-#pragma unroll
-                for (int n = 0; n < K; ++n)
-#pragma unroll
-                    for (int lb = 0; lb < LB; ++lb)
-#pragma unroll
-                        for (int c = 0; c < K; ++c)
-#pragma unroll
-                            for (int hb = 0; hb < HB; ++hb) dWt[n][lb][c][hb] = kZero4;
-#pragma unroll
-                for (int hb = 0; hb < HB; ++hb) dbp[hb] = 0.f;
-            }
-            ikz_sg = pow2_mul(ikz, inv_pow2(sg));
+            const float sg = rs.node(wave_max_bits(m), sh, skipped);
+            ikz_sg = skipped ? 0.f : pow2_mul(ikz, inv_pow2(sg));      // (a skipped node stores zeros: it is stored again when it is redone)
 #pragma unroll
             for (int n = 0; n < K; ++n)
 #pragma unroll
@@ -1226,8 +1236,10 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
             for (int p = 0; p < NB2; ++p) {
                 const float (&zc)[NRB][4] = za[lb];
                 Op a;
-                if constexpr (F::SCALED) a = F::split(f32x4{zc[2 * p][0], zc[2 * p][1], zc[2 * p][2], zc[2 * p][3]} * pow2_mul(sz[lb], sh),
-                                                      f32x4{zc[2 * p + 1][0], zc[2 * p + 1][1], zc[2 * p + 1][2], zc[2 * p + 1][3]} * pow2_mul(sz[lb], sh));
+                if constexpr (F::SCALED) {
+                    const float zs = pow2_mul(sz[lb], sh);                                       // (a skipped node: sh = RunScale::mute())
+                    a = F::split(f32x4{zc[2 * p][0], zc[2 * p][1], zc[2 * p][2], zc[2 * p][3]} * zs, f32x4{zc[2 * p + 1][0], zc[2 * p + 1][1], zc[2 * p + 1][2], zc[2 * p + 1][3]} * zs);
+                }
                 else a = F::split(f32x4{zc[2 * p][0], zc[2 * p][1], zc[2 * p][2], zc[2 * p][3]},
                                   f32x4{zc[2 * p + 1][0], zc[2 * p + 1][1], zc[2 * p + 1][2], zc[2 * p + 1][3]});
 #pragma unroll
@@ -1239,13 +1251,17 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
                             dWt[n][lb][c][hb] = F::mm(a, c == 0 ? gd[n][hb][p] : qd[n][hb][p], dWt[n][lb][c][hb]);
             }
     }
-    const float isg = exp2i(rs.k > 100 ? 0 : -rs.k);
+    if (resume >= 0) node = resume;
+    const float isg = rs.unscale();
     PlaneUnscale<K, LB> pu;
 #pragma unroll
     for (int n = 0; n < K; ++n)
 #pragma unroll
         for (int lb = 0; lb < LB; ++lb) pu.v[n][lb] = inv_pow2(sz[lb]);
-    combine_dw<K, LB, HB>(reinterpret_cast<float*>(smem_raw), dWt, dbp, partial, Lw, want_db, PL == 2 ? Lw - 16 : -1, isg, isg / sT, isg, pu);
+    combine_dw<K, LB, HB>(reinterpret_cast<float*>(smem_raw), dWt, dbp, partial, Lw, want_db, PL == 2 ? Lw - 16 : -1, isg, isg / sT, isg, pu, pass > 0);
+    if constexpr (!F::SCALED) break;
+    if (!__syncthreads_or(node < nodes)) break;          // (also: every wave is done with the combine's slabs before the tables are filled again)
+    }
 }
 
 // --------------------------------------------------------------------------------------- host side
@@ -1287,7 +1303,7 @@ int launch_bwd(const float* const* Z, const float* Tc, const float* W, const flo
     const long long want = (nodes + MF_WAVES - 1) / MF_WAVES;
     int grid = resident < MF_BWD_MAX_GRID ? resident : MF_BWD_MAX_GRID;
     if (want < grid) grid = (int)want;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(MF_THREADS), lds, stream, zp, Tc, W, dY, dzp, partial, (int)nodes, want_db, Lw, pro);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(MF_THREADS), lds, stream, BwdArgs{zp, Tc, W, dY, dzp, partial, (int)nodes, want_db, Lw, pro});
     STC_LAUNCH_CHECK("node_bwd_x3 launch");
     *n_partials = grid;
     return STC_OK;
@@ -1434,7 +1450,7 @@ static int launch_bwd2(const float* X, const float* X2, const float* Tc, const f
     const long long want = (nodes + MF_WAVES - 1) / MF_WAVES;
     int grid = resident < MF_BWD_MAX_GRID ? resident : MF_BWD_MAX_GRID;
     if (want < grid) grid = (int)want;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(MF_THREADS), lds, stream, X, X2, Tc, W, dA, dB, dX, dX2, partial, (int)nodes, want_db, Lw, zmax_x, zmax_x2);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(MF_THREADS), lds, stream, Bwd2Args{X, X2, Tc, W, dA, dB, dX, dX2, partial, (int)nodes, want_db, Lw, zmax_x, zmax_x2});
     STC_LAUNCH_CHECK("node_bwd2_x3 launch");
     *n_partials = grid;
     return STC_OK;

@@ -113,12 +113,14 @@ __device__ v4f patch_dump[64];                           // where the slots of a
 //
 // One workgroup per (patch, batch element), dispatched in order: XCD x (workgroup id % 8, the hardware's round-robin) works through the
 // x-th eighth of the patch list front to back, about 64 patches in flight, and a patch's neighbours in the list find the rows they share
-// in that XCD's L2 (the host orders each eighth as a narrow sweep, graph.py _swept).  (A persistent variant -- two workgroups per compute
+// in that XCD's L2 (the host lists each eighth row by row, graph.py _grid_tiles / _patch_plan).  (A persistent variant -- two workgroups per compute
 // unit walking strided runs of patches, tables loaded once per patch -- hid the per-workgroup table loads but lost that: a workgroup's
 // next patch was 64 further down the list, the rows shared with it long evicted; FETCH_SIZE 1.45 x the matrix against 1.05 x.)
 template <int W, bool HAS_Y0, bool BF16>
 __global__ __launch_bounds__(PT_THREADS, 2) void spmm_patch_kernel(PatchPlan pl, int n_rows, int n_cols, const v4f* __restrict__ X,
-                                                               const v4f* __restrict__ Y0, v4f* __restrict__ Y, int F4, float alpha, float beta) {
+                                                               const v4f* Y0, v4f* Y, int F4, float alpha, float beta) {
+    // (Y0 may BE Y -- the backward sums run in place, include/stc_hip.h -- and a ragged patch stores a row twice through its duplicated slots:
+    //  neither pointer may carry __restrict__, or the compiler may sink a Y0 load below the store of the row's duplicate.)
     constexpr int RPW = PT_ROWS / PT_WAVES, NV = (RPW * W + 63) / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     v4f* halo = reinterpret_cast<v4f*>(lds_raw);                                   // [PT_SRC][PT_Q]
@@ -260,12 +262,12 @@ int launch_patch(const char* who, const PatchPlan& pl, int n_rows, int n_cols, c
                         default: STC_REQUIRE(false, STC_EUNSUPPORTED, "%s: width %d (built for 4, 8, 12, 16, 24, 32)", who, pl.width); }
 #undef STC_PATCH_W
     static std::atomic<int> granted[6][2][2][16];        // 64 KiB of dynamic LDS is above the default limit: once per kernel and device
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
-    if (!granted[slot][has_y0][bf16][dev].load(std::memory_order_acquire)) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = -1;      // a device the table does not cover: granted on every launch
+    if (dev < 0 || !granted[slot][has_y0][bf16][dev].load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return stc::hip_status(e, who);
-        granted[slot][has_y0][bf16][dev].store(1, std::memory_order_release);
+        if (dev >= 0) granted[slot][has_y0][bf16][dev].store(1, std::memory_order_release);
     }
     const int per = (pl.n_patches + stc::kNumXcd - 1) / stc::kNumXcd;
     hipLaunchKernelGGL(kern, dim3(per * stc::kNumXcd, batch), dim3(PT_THREADS), lds, s, pl, n_rows, n_cols, static_cast<const v4f*>(X),

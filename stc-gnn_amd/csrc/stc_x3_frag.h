@@ -302,38 +302,73 @@ __device__ __forceinline__ void leave_max(float* __restrict__ row, int slot, flo
 // differ by tens of binades from node to node where gates saturate, and nothing is known about them before the launch.  So every NODE's
 // gradient fragments get their own power of two a_n = 2^kn, from the node's own maximum (a wave reduction; target [2^3, 2^4)): the dZ tiles,
 // which belong to the node, are unscaled by 1 / a_n on the spot.  The dW / db accumulators sum over the wave's nodes and carry the wave's
-// REFERENCE scale a = 2^k, set by the first gradient the wave meets: a node joins them with its activation operand multiplied by
+// REFERENCE scale a = 2^k, set by the first non-zero gradient the wave meets: a node joins them with its activation operand multiplied by
 // a / a_n = 2^j -- the product of the two operands then has the accumulators' scale.
 //   j < 0             the node's gradients are small against the reference: its activation operand shrinks and loses low bits exactly in
 //                     proportion to how little the node adds to the sum;
 //   0 < j <= 8 + 4    the node exceeds the reference: the excess goes to the activation operand (plane maximum in [2^5, 2^6): 2^8 of room)
 //                     and, beyond that, into a_n itself (2^4: the fragment's second-stage operands T_c dY -- sums of 32 products with a table
 //                     below 2^2 -- must fit fp16 too);
-//   j > 12            the node REPLACES the sums: the accumulators are zeroed (constants into registers: unlike a multiplication, which put
-//                     10 - 50 scratch accesses per node into these one-wave-per-SIMD loops even in a never-taken branch, this costs nothing)
-//                     and the node becomes the reference.  What is dropped is below (nodes so far) x 2^-12 of what the node adds; jumps of
-//                     that size between the nodes of one wave occur where gates saturate (factors e^-x: then by tens of binades), or when the
-//                     wave's first node carries no gradient at all.
-// The wave's final 1 / a goes into the combine.  All bookkeeping is integer arithmetic on exponents (scalar unit); a zero maximum gives the
-// largest scale (harmless), a non-finite one the smallest (the NaN goes where it has to).
+//   j > 12            the node cannot join at the sums' scale (its operands would leave fp16's range): the wave's PASS ends at this node.  The
+//                     node is computed to its end at its own scale with its contributions to the sums muted (shift = 2^-24: RunScale::mute) and nothing -- or what the planes held -- stored, so the loop body has no exit of its own: the wave leaves the node
+//                     loop at the latch and waits in the end-of-kernel combine, where what the workgroup's waves hold goes to the workgroup's
+//                     partial row (every wave's own 1 / a applied).  While any wave of the workgroup has nodes left the kernel body runs again
+//                     (tables refilled, operands requested afresh, sums empty; later passes ADD to the row): the stopped wave resumes AT its node,
+//                     which now sets the reference.  (Rounds 3-4 zeroed the accumulators instead and lost up to half of the restarting node's own
+//                     magnitude: node maxima 1, 64, 4096, 8192 dropped the 4096 node.)  Nothing touches the ~100 accumulator registers inside
+//                     the loop (a rescaling multiplication there, even in a never-taken branch, put 10 - 50 scratch accesses per node into these
+//                     one-wave-per-SIMD loops) and no wave polls another's state (an LDS flag read at every node top cost 130 instructions and
+//                     4 - 12 scratch accesses per node through worse register allocation).  The price is paid where it happens: a stopped wave
+//                     idles until the others finish their pass, so a launch with such jumps can take twice as long.  References only move
+//                     towards larger gradients, by at least 2^13 per pass: at most ~16 passes whatever the data.  Jumps of that size between the
+//                     nodes of one wave occur where gates saturate (factors e^-x: then by tens of binades).
+// A node whose gradients are all zero joins at any scale and leaves the reference alone.  The wave's final 1 / a goes into the combine.  All
+// bookkeeping is integer arithmetic on exponents (scalar unit); a non-finite maximum gives the smallest scale (the NaN goes where it has to).
 __device__ __forceinline__ float exp2i(int k) { return __uint_as_float((unsigned)(k + 127) << 23); }
 struct RunScale {
-    static constexpr int ROOM_ACT = 8, ROOM_GRAD = 4;
-    int k = 120;                        // accumulators carry 2^k; the start value makes the first node a restart (of sums that are zero)
+    static constexpr int ROOM_ACT = 8, ROOM_GRAD = 4, EMPTY = 120;
+    int k = EMPTY;                      // accumulators carry 2^k; EMPTY: they hold no gradient yet (the first non-zero node sets the reference)
     // mbits: the node's gradient maximum (bits of a non-negative float, wave-uniform) -> a_n; shift = a / a_n for the activation side and the
-    // db sums; restart: zero the accumulators first
-    __device__ __forceinline__ float node(int mbits, float& shift, bool& restart) {
+    // db sums; stop: the node is too large for the sums' scale -- the caller stores nothing of it (or what the planes held), ends its pass and
+    // comes back to the node with empty sums.  The returned scale is then the node's own (nothing overflows on the way) and shift = mute() =
+    // 2^-24 instead of the 2^j >= 2^13 the node would have needed: what it adds to the sums it cannot join is 2^-37 of its own contribution
+    // (which the next pass adds in full) -- far below the sums' rounding -- without a select in the loop.  (Plane scales are powers of two
+    // within 2^+-100, so the product of the two stays a normal number for pow2_mul.)
+    static __device__ __forceinline__ float mute() { return exp2i(-24); }
+    __device__ __forceinline__ float node(int mbits, float& shift, bool& stop) {
         int kn = 130 - ((mbits >> 23) & 255);                             // max 2^kn in [2^3, 2^4)
         kn = kn < -100 ? -100 : (kn > 100 ? 100 : kn);
+        shift = 1.f;
+        stop = false;
+        if ((mbits & 0x7FFFFFFF) == 0) return 1.f;                        // no gradient at this node: zeros at any scale
         int j = k - kn;
-        restart = j > ROOM_ACT + ROOM_GRAD;
-        if (restart) { k = kn; j = 0; }
+        if (j > ROOM_ACT + ROOM_GRAD) {
+            if (k != EMPTY) { stop = true; shift = mute(); return exp2i(kn); }
+            k = kn; j = 0;
+        }
         const int up = j > ROOM_ACT ? j - ROOM_ACT : 0;
         j -= up;
         shift = exp2i(j < -100 ? -100 : j);
         return exp2i(kn + up);
     }
+    __device__ __forceinline__ float unscale() const { return exp2i(k == EMPTY ? 0 : -k); }      // 1 / a for the combine (sums of zeros: 1)
 };
+
+// A kernel's argument block read afresh from the kernarg segment, through a pointer the optimiser cannot see through.  The fp16 x 2 backward
+// kernels run their body in passes (RunScale): with the arguments as ordinary kernel parameters everything the table fill and the combine
+// need (a dozen pointers and sizes) stays live in scalar registers ACROSS the node loop of every pass, where there are none to spare -- the
+// order-3 gates backward spilled seven plane addresses and reloaded them on every node.  Read at the top of a pass, they die where the
+// single-pass kernel let them die.  T must be the kernel's ONLY parameter.
+template <class T>
+__device__ __forceinline__ T kernargs_fresh() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    auto p = (const __attribute__((address_space(4))) T*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *p;
+#else
+    return T{};                                   // (the host pass of hipcc only parses device code)
+#endif
+}
 
 // scale 2^k of the plane whose maxima sit in row `row` of the forward launch's slots (1 without slots: the caller gave no range information)
 __device__ __forceinline__ float plane_scale(const float* __restrict__ zmax, int row) {

@@ -225,6 +225,12 @@ class HipKernels:
     #: operand format of the split-operand matrix-core cell kernels (include/stc_hip.h "operand formats"): two fp16 pieces / three
     #: products by default, STC_OPERAND_FORMAT=bf16x3 keeps three bf16 pieces / six products (fp32's range, twice the matrix instructions)
     operand_format = {'f16x2': FMT_F16X2, 'bf16x3': FMT_BF16X3}[os.environ.get('STC_OPERAND_FORMAT', 'f16x2')]
+    #: Graphs whose largest absolute row sum (either orientation) exceeds this run the planar cell kernels on the 24-bit format (bf16 x 3) even
+    #: when fp16 x 2 is the default: an aggregation amplifies a state -- and its rounding noise -- by up to that factor per cell step, and
+    #: where the model amplifies noise the 22-bit operands show as 4-5x the reference's own fp32 noise (row sums of 50: 2.7e-5 on the prediction
+    #: against a reference noise of 5e-6; bf16 x 3: 7-10e-6; row sums of 16: both 1e-6 -- tests/test_scale_sweep.py).  Row-stochastic graphs
+    #: (the bench's, the reference's softmax part) have 1 .. 1.5, the reference's raw 0/1 adjacency 8.
+    HEAVY_ROW_SUM = 24.0
     #: the patch form of the plain aggregation where the graph has one (STC_PATCH_SPMM=0: always the row-blocked kernel -- for A/B timing)
     patch_spmm = os.environ.get('STC_PATCH_SPMM', '1') != '0'
     #: ... for launches of at least this many (patch, sample) workgroups with a Y0 operand (three / six times as many without, see csr_spmm)
@@ -254,6 +260,21 @@ class HipKernels:
         self._f32(what + '.act_amax', given, (rows, self.ACT_AMAX_SLOTS))
         self._same_device(on, given)
         return given.data_ptr()
+
+    def for_graph(self, row_sum_bound: float):
+        """The kernel set a schedule on a graph with that row-sum bound launches through: ``self``, or -- fp16 x 2 default, heavy graph -- a
+        view of it on the bf16 x 3 format (same library, workspaces and timer)."""
+        if self.operand_format != FMT_F16X2 or not (row_sum_bound > self.HEAVY_ROW_SUM):
+            return self
+        view = getattr(self, '_b3_view', None)
+        if view is None:
+            import copy
+            view = copy.copy(self)
+            view.operand_format = FMT_BF16X3
+            view._bf16_front = None
+            self._b3_view = view
+        view.timer = self.timer
+        return view
 
     def set_dispatch_level(self, level: int):
         """0 = every kernel path (default), 1 = no split-operand matrix-core kernels (fp32 MFMA instead), 2 = generic kernels only:

@@ -276,6 +276,11 @@ class CsrGraph:
         perm = inv_f[b_order]                      # position in fwd order of each bwd entry
         self._host = dict(fwd_rowptr=f_rp, fwd_colidx=f_ci, fwd_val=f_v,
                           bwd_rowptr=b_rp, bwd_colidx=b_ci, bwd_val=b_v, bwd_perm=perm.astype(np.int64))
+        #: max over both orientations of the largest absolute row sum: what ONE aggregation can amplify a state (and its rounding noise) by.
+        #: Row-stochastic graphs: 1; the reference's raw 0/1 adjacency: 8.  ``ops`` routes graphs beyond ``HEAVY_ROW_SUM`` to the 24-bit
+        #: operand format (see there).
+        self.row_sum_bound = float(max((np.add.reduceat(np.abs(v), rp[:-1][np.diff(rp) > 0]).max() if v.size else 0.0)
+                                       for rp, v in ((f_rp.astype(np.int64), f_v), (b_rp.astype(np.int64), b_v))))
         distinct = {}
         #: side -> (source rows per output row, rows per patch) of the patch form, where the graph has one
         self.patch_stats: Dict[str, Tuple[float, float]] = {}
@@ -368,8 +373,10 @@ class CsrGraph:
     def _locality_order_once_per_job(self):
         """``locality_order()`` computed by rank 0 and broadcast when a process group is up (one process per GPU: eight ranks would otherwise
         run the same host-side analysis side by side and -- worse -- could disagree if their scipy builds differed: every rank must renumber
-        the nodes the same way, or the replicated graph is no longer the same graph).  Collective: every rank calls it, at the same point
-        (the first forward pass).  None: scipy is missing on rank 0 (the given order is kept everywhere)."""
+        the nodes the same way, or the replicated graph is no longer the same graph).  Collective on the default group: every rank calls it, at
+        the same point (the first forward pass of a graph) -- a graph only SOME ranks use must be renumbered beforehand, or not at all:
+        ``CsrGraph.with_locality(collective=False)`` computes the order locally.  None: scipy is missing on rank 0 (the given order is kept
+        everywhere); any other failure on rank 0 is raised on every rank."""
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             try:
@@ -378,26 +385,41 @@ class CsrGraph:
                 return None
         on_gpu = dist.get_backend() == 'nccl'
         buf = torch.zeros(self.n + 1, dtype=torch.int64)
+        failure = None
         if dist.get_rank() == 0:
             try:
                 buf[1:] = torch.from_numpy(self.locality_order())
                 buf[0] = 1
             except ImportError:
                 pass
+            except Exception as e:                  # whatever goes wrong here must not leave the other ranks waiting in the broadcast
+                failure = e
+                buf[0] = 2
         if on_gpu:
             buf = buf.cuda()
         dist.broadcast(buf, src=0)
         buf = buf.cpu()
-        return buf[1:].numpy().copy() if int(buf[0]) == 1 else None
+        status = int(buf[0])
+        if status == 2:                             # every rank raises: rank 0 its own exception, the others what they were told
+            raise failure if failure is not None else RuntimeError('CsrGraph: rank 0 failed to compute the node renumbering (see its log)')
+        return buf[1:].numpy().copy() if status == 1 else None
 
-    def with_locality(self, min_gain: float = 1.25):
+    def with_locality(self, min_gain: float = 1.25, collective: bool = True):
         """(graph, order): a renumbered copy when that cuts the row fetches of the row-blocked SpMM by at least
-        ``min_gain``, else (self, None).  Computed once and cached (under a process group: the order by rank 0, see above)."""
+        ``min_gain``, else (self, None).  Computed once and cached.  Under a process group the order comes from rank 0 (a collective on the
+        default group, see above); ``collective=False`` computes it in this process alone -- for a graph that not every rank uses (rank-0-only
+        evaluation on a new graph): call it once before the first forward pass."""
         cached = getattr(self, '_locality', None)
         if cached is None:
             cached = (self, None)
             if self.n > 64 and self.nnz > 0:
-                order = self._locality_order_once_per_job()
+                if collective:
+                    order = self._locality_order_once_per_job()
+                else:
+                    try:
+                        order = self.locality_order()
+                    except ImportError:
+                        order = None
                 if order is None:
                     import warnings
                     warnings.warn('scipy is not installed: the spatial graph keeps its node order (no locality renumbering)')
@@ -445,6 +467,7 @@ class SpatialOperand:
     # (pt_src, pt_rows, pt_cnt, pt_idx, pt_val) of stc_patch_spmm_f32
     fwd_plan: Optional[tuple] = None
     bwd_plan: Optional[tuple] = None
+    row_sum_bound: float = 1.0       # fixed graphs: max absolute row sum over both orientations (CsrGraph.row_sum_bound)
 
 
 _PATTERN_CACHE: Dict[Tuple[int, torch.device], Tuple[torch.Tensor, torch.Tensor]] = {}
@@ -498,4 +521,4 @@ def csr_operand(graph: CsrGraph, device: torch.device) -> SpatialOperand:
             return blocks
         return blocks + (tuple(d[f'{side}_pt_{k}'] for k in ('src', 'rows', 'cnt', 'idx', 'val')),)
     return SpatialOperand(graph.n, d['fwd_rowptr'], d['fwd_colidx'], d['fwd_val'],
-                          d['bwd_rowptr'], d['bwd_colidx'], d['bwd_val'], graph.nnz, plan('fwd'), plan('bwd'))
+                          d['bwd_rowptr'], d['bwd_colidx'], d['bwd_val'], graph.nnz, plan('fwd'), plan('bwd'), graph.row_sum_bound)

@@ -486,7 +486,7 @@ class _StcCellGraph(Function):
 
     @staticmethod
     def forward(ctx, op: SpatialOperand, Ks: int, schedule, outputs, n_ext: int, Tc, fwd_val, *tensors):
-        k = kernels()
+        k = kernels().for_graph(op.row_sum_bound)                   # (a heavy graph: the 24-bit operand format, _lib.HEAVY_ROW_SUM)
         ext = [_c(t) for t in tensors[:n_ext]]
         bf16 = ext[0].dtype == torch.bfloat16                       # bf16 state planes: the all-planar bf16 kernel set
         if bf16:
@@ -660,7 +660,7 @@ class _StcCellGraph(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_stack):
-        k = kernels()
+        k = kernels().for_graph(ctx.meta[0].row_sum_bound)
         bf16_planes = grad_stack.dtype == torch.bfloat16
         if bf16_planes:
             k = k.bf16
@@ -974,9 +974,10 @@ class _MixedFusion(torch.autograd.Function):
 
 
 def mixed_fusion_supported(A: torch.Tensor, P: torch.Tensor, *params: torch.Tensor) -> bool:
-    """Whether ``mixed_fusion`` takes these operands: float32 on a GPU, contiguous weights, n^2 a multiple of 4."""
+    """Whether ``mixed_fusion`` takes these operands: float32 on a GPU, contiguous weights, 16-byte aligned, n^2 a multiple of 4."""
     ts = (A, P) + params
     return (all(t.is_cuda and t.dtype == torch.float32 for t in ts) and all(t.is_contiguous() for t in params)
+            and all(t.data_ptr() % 16 == 0 for t in ts)               # (a slice / a view into a flat parameter buffer may not be: torch ops then)
             and kernels().mixed_fusion_supported(A.numel()))
 
 

@@ -6,14 +6,21 @@ absolute floor (2^-25 for a pair whose value is below 2^-3) and nothing above 65
 per node in the forward, one per plane in the backward's dW products -- and the gate tanh switches to its Taylor polynomial below 1/4.  This
 file sweeps what the goldens never did (they all have O(1) activations):
 
-    X_seq x s, s in {1e-6, 1e-3, 1, 1e3, 1e5};  parameters x {1e-2, 1};  biases zero / 0.3 sigma;  Gs row sums x {1, 50}
+    X_seq x s, s in {1e-6, 1e-3, 1, 1e3, 1e5};  parameters x {1e-2, 1};  biases zero / 0.3 sigma;  Gs row sums x {1, 50} (and 4, 8, 16 at
+    amplitude 1: the reference's raw 0/1 adjacency has row sums of 8)
 
 through the four kernel families (C = 32 planar one-launch backward, C = 64 two-launch backward, C = 32 order 3, C = 5 few-category cells) and
 the bf16 x 3 format, against the float64 oracle of the reference's encoder-decoder + ComboLoss:
 
-    forward   max-norm relative error <= 1e-5 (north_star)
+    forward   max-norm relative error <= 1e-5 (north_star), or THREE times the reference's own fp32 noise on the prediction where that is larger
+              (round 4 let 40x pass: 4.8e-5 with row sums of 50, 10x the noise).  Where the model amplifies rounding noise the max-norm error
+              of ANY fp32-grade implementation is a draw of 1 - 2.2x the reference's noise: the few-category kernels (exact fp32 products)
+              measure 1.9x at row sums of 16, 0.9x with libm gate functions and 2.1x with both gates refined (round 5 probes,
+              profiles/r05/gate_function_probe.txt) -- a bound of 1x cannot be met by construction, 3x holds the line.  Graphs whose row
+              sums exceed 24 leave the fp16 x 2 format (22-bit operands: 4 - 5x the noise) for bf16 x 3 by themselves (_lib.HEAVY_ROW_SUM)
     gradient  <= the bounds every other parity test uses (1e-5; 2e-5 for the long reductions)
-    or, where that is larger, a multiple of the reference's OWN fp32 noise on that tensor -- the error of the oracle run in float32 (op for op
+    or (gradients), where that is larger, a multiple of the reference's OWN
+    fp32 noise on that tensor -- the error of the oracle run in float32 (op for op
     the reference's arithmetic) against its float64 run.  That clause only matters where the model amplifies rounding noise: at X x 1e3 and
     above (pre-activations of 1e5 .. 5e6 carry an absolute fp32 rounding error of 1e-2 .. 0.3 in the reference itself, gates saturate and lose
     1 - U to cancellation; the reference's own gradients are off by up to 60 % against float64 at X x 1e5 with Gs x 50) and with graph row sums
@@ -44,8 +51,12 @@ from tests.golden.make_golden import SF_SHAPE, bench_path_inputs
 FAMILIES = {'c32': (32, 2, {}), 'c64': (64, 2, {}), 'c32k3': (32, 3, {}), 'sf': (5, 2, SF_SHAPE)}
 X_SCALES = [1e-6, 1e-3, 1.0, 1e3, 1e5]
 # (parameter scale, bias sigma, Gs row-sum factor)
-SETTINGS = {'plain': (1.0, 0.3, 1.0), 'small-params-zero-bias': (1e-2, 0.0, 1.0), 'heavy-graph-zero-bias': (1.0, 0.0, 50.0), 'small-params-heavy-graph': (1e-2, 0.3, 50.0)}
+SETTINGS = {'plain': (1.0, 0.3, 1.0), 'small-params-zero-bias': (1e-2, 0.0, 1.0), 'heavy-graph-zero-bias': (1.0, 0.0, 50.0), 'small-params-heavy-graph': (1e-2, 0.3, 50.0),
+            'graph-x4': (1.0, 0.0, 4.0), 'graph-x8': (1.0, 0.0, 8.0), 'graph-x16': (1.0, 0.0, 16.0)}
+SWEPT = [(x, st) for st in ('plain', 'small-params-zero-bias', 'heavy-graph-zero-bias', 'small-params-heavy-graph') for x in X_SCALES] + \
+        [(1.0, st) for st in ('graph-x4', 'graph-x8', 'graph-x16')]
 FWD_BOUND, GRAD_BOUND = 1e-5, 2e-5
+FWD_NOISE_FACTOR = 3.0            # the prediction: what an independent fp32 implementation draws (module docstring)
 
 
 def rel_l2(a, b):
@@ -96,7 +107,8 @@ def _check(tag, got, want64, want32, dev, fwd_bound=FWD_BOUND, grad_bound=GRAD_B
         noise = max(rel_err(b32, b), rel_l2(b32, b))                             # the reference's own fp32 noise on this tensor
         void = noise > 0.1
         lines.append(f'{tag}\t{name}\t{e_max:.3e}\tl2={e_l2:.3e}\tref_fp32_noise={noise:.1e}{" (void)" if void else ""}\n')
-        if not torch.isfinite(a).all() or (not void and max(e_max, e_l2) >= max(bound, noise_factor * noise)):
+        allowed = max(bound, (noise_factor if is_grad else FWD_NOISE_FACTOR) * noise)
+        if not torch.isfinite(a).all() or (not void and max(e_max, e_l2) >= allowed):
             worst.append((name, e_max, e_l2, noise))
     if dev == 'cuda':
         out = os.path.join(REPO, 'gpurun_out')
@@ -107,8 +119,7 @@ def _check(tag, got, want64, want32, dev, fwd_bound=FWD_BOUND, grad_bound=GRAD_B
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('setting', list(SETTINGS))
-@pytest.mark.parametrize('x_scale', X_SCALES)
+@pytest.mark.parametrize('x_scale,setting', SWEPT)
 @pytest.mark.parametrize('family,fmt', [('c32', 'f16x2'), ('c32', 'bf16x3'), ('c64', 'f16x2'), ('c32k3', 'f16x2'), ('sf', 'f16x2')])
 def test_scale_sweep_on_the_gpu(monkeypatch, family, fmt, x_scale, setting):
     from stc_hip import _lib
@@ -128,7 +139,8 @@ def test_scale_sweep_on_the_gpu(monkeypatch, family, fmt, x_scale, setting):
     assert not bad, bad
 
 
-@pytest.mark.parametrize('x_scale,setting', [(1e-6, 'small-params-zero-bias'), (1e-3, 'plain'), (1.0, 'plain'), (1e5, 'heavy-graph-zero-bias')])
+@pytest.mark.parametrize('x_scale,setting', [(1e-6, 'small-params-zero-bias'), (1e-3, 'plain'), (1.0, 'plain'), (1e5, 'heavy-graph-zero-bias'),
+                                             (1.0, 'heavy-graph-zero-bias'), (1.0, 'graph-x16')])
 @pytest.mark.parametrize('family', ['c32', 'c32k3'])
 def test_scale_sweep_through_the_emulated_format(monkeypatch, family, x_scale, setting):
     """CPU: host logic + the fp16 x 2 operand representation (scales as the kernels take them) against the float64 oracle."""
@@ -145,3 +157,21 @@ def test_the_sweep_catches_unscaled_activations(monkeypatch):
     model, sd, s, X, Gs, (C, K) = _case('c32', 1e-3, 'small-params-zero-bias')
     bad = _check('emulated-unscaled', _run(model, s, X, Gs, 'cpu'), _oracle(sd, s, X, Gs, K, torch.float64), _oracle(sd, s, X, Gs, K, torch.float32), 'cpu')
     assert bad, 'unscaled activations should have failed the sweep'
+
+
+def test_heavy_graphs_leave_the_fp16x2_format(monkeypatch):
+    """A graph whose row sums exceed HEAVY_ROW_SUM is run on the 24-bit operand format even when fp16 x 2 is the default: with row sums of 50 the
+    fp16 x 2 format emulated on CPU puts the prediction at 7x the reference's noise (beyond 1e-5); routed, the schedule runs on the exact twin."""
+    em = EmulatedKernels(operand_format='f16x2')
+    monkeypatch.setattr(ops, '_kernels', em)
+    model, sd, s, X, Gs, (C, K) = _case('c32', 1.0, 'heavy-graph-zero-bias')
+    graph = CsrGraph.from_dense(Gs)
+    assert graph.row_sum_bound > em.HEAVY_ROW_SUM and em.for_graph(graph.row_sum_bound) is not em
+    assert CsrGraph.from_dense(_case('c32', 1.0, 'graph-x8')[4]).row_sum_bound <= em.HEAVY_ROW_SUM
+    want64, want32 = _oracle(sd, s, X, Gs, K, torch.float64), _oracle(sd, s, X, Gs, K, torch.float32)
+    bad = _check('emulated-routed', _run(model, s, X, Gs, 'cpu'), want64, want32, 'cpu')
+    assert not bad, bad
+    monkeypatch.setattr(em, 'HEAVY_ROW_SUM', 1e9, raising=False)      # negative control: the same graph kept on the emulated fp16 x 2 format
+    model, sd, s, X, Gs, (C, K) = _case('c32', 1.0, 'heavy-graph-zero-bias')
+    bad = _check('emulated-unrouted', _run(model, s, X, Gs, 'cpu'), want64, want32, 'cpu')
+    assert any(name == 'yhat' for name, *_ in bad), bad
