@@ -80,8 +80,10 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
     // the partial row added to; nothing is live across passes but the node index and whether that node's candidate phase is already in the rows.
     int node = blockIdx.x * CB_WAVES + wave;
     bool cand_done = false;           // the pass starts at a node whose candidate phase is in the partial rows already (its gates phase ended the previous pass)
-    for (int pass = 0;; ++pass) {
-    const CellBwdArgs a = F::SCALED ? kernargs_fresh<CellBwdArgs>() : args_in_kernarg_segment;      // (read per pass: stc_x3_frag.h)
+    // The body is written once and compiled TWICE: the first pass as straight-line code (with the loop over passes around it the node loop of
+    // every launch ran 1.9 % slower -- 1 214 against 1 191 us, same box -- through worse register allocation, with the arguments kept live
+    // across it 4 %), later passes -- rare -- in a loop, their arguments read afresh from the kernarg segment (stc_x3_frag.h).
+    auto run_pass = [&](const int pass, const CellBwdArgs a) __attribute__((always_inline)) {
     const int cin = a.Lw - 16;
     // FmtH2: table scales from the tables' own maxima (same in every workgroup), gradient scale from the producer's slots
     float sT = 1.f, sWg = 1.f, sWc = 1.f;
@@ -481,8 +483,12 @@ __global__ __launch_bounds__(CB_THREADS, 1) void cell_bwd_x3_kernel(CellBwdArgs 
         for (int lb = 0; lb < LB; ++lb) { pug.v[n][lb] = inv_pow2(sz[n][lb]); puc.v[n][lb] = inv_pow2(sz[0][lb]); }      // the candidate's input is slab 0, [X | R*H], for both weight sets
     combine_dw<K, LB, 2, CB_WAVES>(reinterpret_cast<float*>(smem_raw), dWg, dbg, a.partial_g, a.Lw, a.want_dbg, PL == 2 ? cin : -1, isg_g, isg_g / sT, isg_g, pug, pass > 0);
     combine_dw<K, LB, 1, CB_WAVES>(reinterpret_cast<float*>(smem_raw), dWc, dbc, a.partial_c, a.Lw, a.want_dbc, PL == 2 ? cin : -1, isg_c, isg_c / sT, isg_c, puc, pass > 0);
-    if constexpr (!F::SCALED) break;
-    if (!__syncthreads_or(node < a.nodes)) break;        // (also: every wave is done with the combine's slabs before the tables are filled again)
+    };
+    run_pass(0, args_in_kernarg_segment);
+    if constexpr (F::SCALED) {
+        const int nodes = args_in_kernarg_segment.nodes;
+        // (the barrier also means: every wave is done with the combine's slabs before the tables are filled again)
+        for (int pass = 1; __syncthreads_or(node < nodes); ++pass) run_pass(pass, kernargs_fresh<CellBwdArgs>());
     }
 }
 

@@ -608,8 +608,9 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
     // combine the body runs again while any wave of the workgroup has nodes left -- tables refilled, operands requested afresh, sums empty,
     // the partial row added to; nothing is live across passes but the node index.
     int node = blockIdx.x * MF_WAVES + wave;
-    for (int pass = 0;; ++pass) {
-    const BwdArgs ka = F::SCALED ? kernargs_fresh<BwdArgs>() : args_in_kernarg_segment;
+    // The body is written once and compiled TWICE (see cell_bwd_x3_kernel): the first pass as straight-line code, later passes -- rare -- in a
+    // loop with their arguments read afresh from the kernarg segment.
+    auto run_pass = [&](const int pass, const BwdArgs ka) __attribute__((always_inline)) {
     const ZPtrs& Z = ka.Z;
     const DZPtrs& dZ = ka.dZ;
     const BwdPro& pro = ka.pro;
@@ -886,8 +887,12 @@ __global__ __launch_bounds__(MF_THREADS, (BwdSched<NB2, K>::waves)) void node_bw
 #pragma unroll
         for (int lb = 0; lb < LB; ++lb) pu.v[n][lb] = inv_pow2(sz[n][lb]);
     combine_dw<K, LB, HB>(reinterpret_cast<float*>(smem_raw), dWt, dbp, partial, Lw, want_db, PL == 2 ? Lw - 16 : -1, isg, isg / sT, isg, pu, pass > 0);
-    if constexpr (!F::SCALED) break;
-    if (!__syncthreads_or(node < nodes)) break;          // (also: every wave is done with the combine's slabs before the tables are filled again)
+    };
+    run_pass(0, args_in_kernarg_segment);
+    if constexpr (F::SCALED) {
+        const int n_all = args_in_kernarg_segment.nodes;
+        // (the barrier also means: every wave is done with the combine's slabs before the tables are filled again)
+        for (int pass = 1; __syncthreads_or(node < n_all); ++pass) run_pass(pass, kernargs_fresh<BwdArgs>());
     }
 }
 
@@ -1030,8 +1035,9 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
     // combine the body runs again while any wave of the workgroup has nodes left -- tables refilled, operands requested afresh, sums empty,
     // the partial row added to; nothing is live across passes but the node index.
     int node = blockIdx.x * MF_WAVES + wave;
-    for (int pass = 0;; ++pass) {
-    const Bwd2Args ka = F::SCALED ? kernargs_fresh<Bwd2Args>() : args_in_kernarg_segment;
+    // The body is written once and compiled TWICE (see cell_bwd_x3_kernel): the first pass as straight-line code, later passes -- rare -- in a
+    // loop with their arguments read afresh from the kernarg segment.
+    auto run_pass = [&](const int pass, const Bwd2Args ka) __attribute__((always_inline)) {
     const float* __restrict__ X = ka.X; const float* __restrict__ X2 = ka.X2; const float* __restrict__ Tc = ka.Tc; const float* __restrict__ W = ka.W;
     const float* __restrict__ dA = ka.dA; const float* __restrict__ dB = ka.dB;
     float* __restrict__ dX = ka.dX; float* __restrict__ dX2 = ka.dX2; float* __restrict__ partial = ka.partial;
@@ -1259,8 +1265,12 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void node_bwd2_x3_k
 #pragma unroll
         for (int lb = 0; lb < LB; ++lb) pu.v[n][lb] = inv_pow2(sz[lb]);
     combine_dw<K, LB, HB>(reinterpret_cast<float*>(smem_raw), dWt, dbp, partial, Lw, want_db, PL == 2 ? Lw - 16 : -1, isg, isg / sT, isg, pu, pass > 0);
-    if constexpr (!F::SCALED) break;
-    if (!__syncthreads_or(node < nodes)) break;          // (also: every wave is done with the combine's slabs before the tables are filled again)
+    };
+    run_pass(0, args_in_kernarg_segment);
+    if constexpr (F::SCALED) {
+        const int n_all = args_in_kernarg_segment.nodes;
+        // (the barrier also means: every wave is done with the combine's slabs before the tables are filled again)
+        for (int pass = 1; __syncthreads_or(node < n_all); ++pass) run_pass(pass, kernargs_fresh<Bwd2Args>());
     }
 }
 

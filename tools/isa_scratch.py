@@ -33,24 +33,26 @@ def main():
         blocks.append(cur)
         body = lines[st + 1:end]
         labels = {m.group(1): i for i, l in enumerate(body) for m in [re.match(r'^(\.LBB\S+):', l)] if m}
-        # the node loop: the SMALLEST backward-branch span that holds the kernel's matrix instructions (an enclosing loop -- the flush segments
-        # of the fp16 x 2 backward kernels, which also hold the table fill and the end-of-kernel combine -- is not it); kernels without matrix
-        # instructions: the largest span
-        n_mfma = sum('v_mfma' in l for l in body)
+        # the node loops: every backward-branch span that holds matrix instructions and no smaller such span with as many of them (an enclosing
+        # loop -- the loop over PASSES of the fp16 x 2 backward kernels, which also holds the table fill and the combine -- is not a node loop).
+        # Those kernels compile their body twice: the first pass as straight-line code (the loop every launch runs: listed first), later passes
+        # (rare) inside the pass loop.  Kernels without matrix instructions: the largest span.
         spans = []
         for i, l in enumerate(body):
             m = re.match(r'\s+s_c?branch\S*\s+(\.LBB\S+)', l)
             if m and m.group(1) in labels and labels[m.group(1)] < i:
                 lo = labels[m.group(1)]
                 spans.append((i - lo, lo, i, sum('v_mfma' in b for b in body[lo:i + 1])))
-        full = [sp for sp in spans if n_mfma and sp[3] == n_mfma]
-        span = min(full)[:3] if full else (max(spans)[:3] if spans else (0, 0, 0))
-        loop = [l for l in body[span[1]:span[2] + 1] if l.startswith('\t') and not l.strip().startswith(('.', ';'))]
-        in_loop = sum('scratch_' in l for l in loop)
+        with_mfma = [sp for sp in spans if sp[3] > 0]
+        loops = [sp for sp in with_mfma if not any(o is not sp and o[1] >= sp[1] and o[2] <= sp[2] and o[3] == sp[3] and o[0] < sp[0] for o in with_mfma)]
+        loops = sorted(loops, key=lambda sp: sp[1]) or ([max(spans)] if spans else [(0, 0, 0, 0)])
         total = sum(b['scratch'] for b in blocks)
-        with_mfma = sum(b['scratch'] for b in blocks if b['mfma'] >= 8)
-        print(f"{name[:110]}\n   node loop: {len(loop)} instr, {sum('v_mfma' in l for l in loop)} mfma, {in_loop} scratch ops ({with_mfma} in blocks with matrix "
-              f"instructions); outside the loop: {total - in_loop} scratch ops")
+        print(name[:110])
+        for k, span in enumerate(loops):
+            loop = [l for l in body[span[1]:span[2] + 1] if l.startswith('\t') and not l.strip().startswith(('.', ';'))]
+            in_loop = sum('scratch_' in l for l in loop)
+            print(f"   node loop{'' if len(loops) == 1 else f' {k + 1}/{len(loops)}'}: {len(loop)} instr, {sum('v_mfma' in l for l in loop)} mfma, {in_loop} scratch ops; "
+                  f"kernel total: {total} scratch ops")
 
 
 if __name__ == '__main__':
