@@ -45,6 +45,7 @@ import time
 REPO = os.path.dirname(os.path.abspath(__file__))
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling ~5.4-6.3 TB/s
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32 / 32x32x2 (f32 in, f32 accumulate), whole chip (MI355X_MICROARCH.md)
+F16_MATRIX_PEAK_TFLOPS = 2500.0  # v_mfma_f32_16x16x32_f16 / _bf16, dense (MI355X_MICROARCH.md: ~2.5 PF; never the 2:1-sparsity figure)
 PLAIN_SPMM = ('stc_patch_spmm_f32', 'stc_patch_spmm_bf16', 'stc_bcsr_spmm_f32', 'stc_bcsr_spmm_bf16')
 # every C-ABI entry point that is an aggregation Y = S.X (+ epilogue)
 SPMM_ENTRY_POINTS = ('stc_patch_spmm_f32', 'stc_patch_spmm_bf16', 'stc_bcsr_spmm_f32', 'stc_csr_spmm_f32', 'stc_spmm_sum_f32', 'stc_spmm_blend_fwd_f32',
@@ -81,6 +82,8 @@ def parse(argv=None):
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-shots', default=f'{CPU_WARMUP},{CPU_TIMED}', help='warm-up,timed shots of the CPU baseline (SURVEY 8(d4): 2,7)')
     ap.add_argument('--no-unit-d3', action='store_true', help='skip the cold SURVEY 8(d3) SpMM unit measurement')
+    ap.add_argument('--no-extras', action='store_true',
+                    help='skip the side measurements of the default line (alt_formats.bf16x3 and permuted: 1 + 3 steps each, same process)')
     ap.add_argument('--hip-graph', action='store_true',
                     help='(one GPU; not the default line) time replays of the train step captured into a HIP graph: removes the launch gaps that '
                          'matter at small N; the per-kernel events then come from eager steps after the timed region')
@@ -351,6 +354,34 @@ def pmc_mfma(config_key):
             'kernels': keep}
 
 
+def projection_rates(a, per_kernel, R, C):
+    """Algorithmic flops of the dense projections + category mixes (2 B N C K^2 L Ho per projection) of the planar cell kernels of
+    the metric step, over the measured time of those launches, against the dense f16 MFMA peak -- the live counterpart of the PMC busy
+    fractions.  The kernels are HBM-bound (one / two waves per SIMD): the matrix pipe is far from its peak by design; this says how far.
+    ``matrix_instructions`` = what the pipe really executes: three fp16 piece products per fp32 product (six bf16 on the bf16 x 3 format)."""
+    fwd, bwd = per_kernel.get('stc_cell_gates_fwd_planar_f32'), per_kernel.get('stc_cell_bwd_planar_f32')
+    if not fwd or not bwd or a.order != 2 or a.hidden != 16:
+        return None
+    h, K = a.hidden, a.order
+    wide_cells = (a.layers - 1) * a.obs + a.layers * a.pred
+    narrow_cells = a.obs
+
+    def cell(Lw):                                                     # forward: gates (2h) + candidate (h) projections, their category mixes
+        proj = 2.0 * R * C * (K * K * Lw) * 3 * h
+        mix = 2.0 * R * C * C * (K - 1) * (2 * h + K * h)
+        return proj + mix
+    f_fwd = wide_cells * cell(2 * h) + narrow_cells * cell(1 + h)
+    f_bwd = 2.0 * f_fwd                                               # dZ and dW: each the forward's products once more
+    out = {'what': 'algorithmic flops (projections + category mixes, fp32 products) of the planar cell launches of one step / their measured time',
+           'peak': F16_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'pieces_per_product': 3}
+    for name, d, fl in (('gates_forward', fwd, f_fwd), ('cell_backward', bwd, f_bwd)):
+        per_step_s = d['ms'] / a.steps / 1e3
+        tf = fl / per_step_s / 1e12 if per_step_s > 0 else 0.0
+        out[name] = {'flops_per_step': fl, 'achieved': tf, 'frac': tf / F16_MATRIX_PEAK_TFLOPS,
+                     'matrix_instructions': {'achieved': 3 * tf, 'frac': 3 * tf / F16_MATRIX_PEAK_TFLOPS}}
+    return out
+
+
 class PowerSampler:
     """Package power and shader clock of this rank's GPU, sampled ~10 times a second over the timed region (amdsmi; rank 0 reports).
     The metric step runs at the package power limit with the shader clock throttled (profiles/r03/clock_trace.txt), so the line says
@@ -594,6 +625,65 @@ def main():
     fence()
     untimed_ms = 1e3 * (time.perf_counter() - t1) / max(1, untimed_steps)
 
+    # Side measurements of the metric line (one GPU, default configuration): what used to exist as builder-run numbers only.
+    #   alt_formats.bf16x3   the same step on the 24-bit operand format (three bf16 pieces, six products; the default keeps 22 bits)
+    #   permuted             SURVEY 8(d1) variant B: the same graph under a seeded random node order (the host renumbers it: reverse
+    #                        Cuthill-McKee, then greedy clusters for the patch form), with the rate of its plain aggregation launches
+    extras = {}
+    if rank == 0 and world == 1 and not graphed and not a.no_extras and a.preset is None and not learned and a.storage == 'f32':
+        from stc_hip import _lib as _l
+
+        def side(model_, As_, n=3):
+            bucket_ = bucket if model_ is model else sdist.GradBucket(model_.parameters())
+            opt_ = opt if model_ is model else torch.optim.Adam(model_.parameters(), lr=2e-3, weight_decay=1e-4)
+
+            def st():
+                bucket_.zero()
+                crit(model_(X_seq=X, As=As_, Ac=Gc), Y).backward()
+                bucket_.allreduce_mean()
+                opt_.step()
+            t_a = time.perf_counter()
+            st()
+            fence()
+            first_s = time.perf_counter() - t_a
+            hip.timer = KernelTimer(only=PLAIN_SPMM)
+            t_a = time.perf_counter()
+            for _ in range(n):
+                st()
+            fence()
+            dt = time.perf_counter() - t_a
+            got = hip.timer.summary()
+            hip.timer = None
+            pl = dict(launches=0, ms=0.0, bytes=0)
+            for name in PLAIN_SPMM:
+                tv = got.get(name, {}).get('tags', {}).get('plain')
+                if tv:
+                    for key in pl:
+                        pl[key] += tv[key]
+            gbps = (pl['bytes'] / 1e9) / (pl['ms'] / 1e3) if pl['ms'] > 0 else 0.0
+            return {'samples_per_s': B * n / dt, 'ms_per_step': 1e3 * dt / n, 'steps': n, 'first_step_s': first_s,
+                    'plain_aggregation': {'launches': pl['launches'], 'avg_launch_us': 1e3 * pl['ms'] / max(1, pl['launches']), 'achieved': gbps,
+                                          'unit': 'GB/s', 'frac': gbps / HBM_PEAK_GBPS,
+                                          'entry_points': sorted(nm for nm in PLAIN_SPMM if got.get(nm, {}).get('tags', {}).get('plain'))}}
+        if hip.operand_format == _l.FMT_F16X2:
+            hip.operand_format = _l.FMT_BF16X3                        # (instance attribute over the class default)
+            try:
+                extras['alt_formats'] = {'bf16x3': side(model, As_in)}
+            finally:
+                del hip.operand_format
+        if not a.permute:
+            t_p = time.perf_counter()
+            graph_p = CsrGraph.queen_grid(a.grid, a.grid, normalize=True, permute_seed=1234, device=dev)
+            model_p = M.STCGNN(N, C, a.order, a.order, 1, a.hidden, a.layers, a.pred, graph_mode=a.graph_mode, reorder_nodes=not a.no_reorder).to(dev)
+            model_p.load_state_dict(model.state_dict())
+            extras['permuted'] = side(model_p, graph_p)
+            used = graph_p.with_locality()[0] if not a.no_reorder else graph_p
+            extras['permuted'].update(what='SURVEY 8(d1) variant B: the queen grid under torch.Generator().manual_seed(1234) node order; the host renumbers it '
+                                           '(reverse Cuthill-McKee) and plans patches as greedy clusters',
+                                      setup_and_steps_s=time.perf_counter() - t_p, row_fetches_per_output_row=used.fetches_per_row[0],
+                                      patch_stats={k: list(v) for k, v in getattr(used, 'patch_stats', {}).items()})
+            del model_p, graph_p
+
     if rank == 0:
         total_ms = sum(d['ms'] for d in per_kernel.values()) or 1.0
 
@@ -680,6 +770,9 @@ def main():
                         roofline.pop(key, None)
             roofline['dominant'] = dom
         roofline['mfma'] = pmc_mfma(config_key)
+        proj = projection_rates(a, per_kernel, B * N, C)
+        if proj is not None:
+            roofline['mfma'] = dict(roofline['mfma'] or {}, projection=proj)
         if not a.no_unit_d3:
             roofline['unit_d3'] = spmm_unit_d3(graph, dev, C, 2 * a.hidden, torch.bfloat16 if a.storage == 'bf16' else torch.float32,
                                                reorder=not a.no_reorder)
@@ -710,6 +803,7 @@ def main():
                                'note': 'value / ms_per_step are the whole step (Adam included) with two HIP-event records around every PRICED launch (the plain aggregation and the dominant cell kernels); '
                                        'the phases are HIP events on the compute stream of rank 0; ms_per_step_without_launch_events re-times '
                                        f'{untimed_steps} steps with the launch timer off'},
+            **extras,
             'kernels': {k: {'launches': d['launches'], 'ms_per_step': d['ms'] / a.steps, 'share': d['ms'] / total_ms,
                             **({'GBps': d['bytes'] / 1e9 / (d['ms'] / 1e3)} if d['bytes'] and d['ms'] > 0 else {})}
                         for k, d in sorted(per_kernel.items(), key=lambda kv: -kv[1]['ms'])},

@@ -225,7 +225,7 @@ class HipKernels:
     #: operand format of the split-operand matrix-core cell kernels (include/stc_hip.h "operand formats"): two fp16 pieces / three
     #: products by default, STC_OPERAND_FORMAT=bf16x3 keeps three bf16 pieces / six products (fp32's range, twice the matrix instructions)
     operand_format = {'f16x2': FMT_F16X2, 'bf16x3': FMT_BF16X3}[os.environ.get('STC_OPERAND_FORMAT', 'f16x2')]
-    #: Graphs whose largest absolute row sum (either orientation) exceeds this run the planar cell kernels on the 24-bit format (bf16 x 3) even
+    #: Graphs whose largest absolute row sum (either orientation; to the power K - 1 for Chebyshev order K) exceeds this run the planar cell kernels on the 24-bit format (bf16 x 3) even
     #: when fp16 x 2 is the default: an aggregation amplifies a state -- and its rounding noise -- by up to that factor per cell step, and
     #: where the model amplifies noise the 22-bit operands show as 4-5x the reference's own fp32 noise (row sums of 50: 2.7e-5 on the prediction
     #: against a reference noise of 5e-6; bf16 x 3: 7-10e-6; row sums of 16: both 1e-6 -- tests/test_scale_sweep.py).  Row-stochastic graphs

@@ -469,6 +469,12 @@ def _alias_slice(base: torch.Tensor, i: int) -> torch.Tensor:
     return t
 
 
+def _amplification(op: SpatialOperand, Ks: int) -> float:
+    """What one BDG_Dif of order Ks can amplify a state by: the graph's largest absolute row sum to the power Ks - 1 (T_2(S) = 2 S^2 - I has
+    row sums of up to 2 r^2 + 1; order 3 on a graph with row sums of 8 puts the reference's own fp32 noise at 3.5e-4 on the prediction)."""
+    return float(op.row_sum_bound) ** max(1, Ks - 1)
+
+
 class _StcCellGraph(Function):
     """Encoder + decoder (any DAG of STC_Cells whose inputs are other cells' states) as one autograd node.
 
@@ -486,7 +492,7 @@ class _StcCellGraph(Function):
 
     @staticmethod
     def forward(ctx, op: SpatialOperand, Ks: int, schedule, outputs, n_ext: int, Tc, fwd_val, *tensors):
-        k = kernels().for_graph(op.row_sum_bound)                   # (a heavy graph: the 24-bit operand format, _lib.HEAVY_ROW_SUM)
+        k = kernels().for_graph(_amplification(op, Ks))              # (a heavy graph: the 24-bit operand format, _lib.HEAVY_ROW_SUM)
         ext = [_c(t) for t in tensors[:n_ext]]
         bf16 = ext[0].dtype == torch.bfloat16                       # bf16 state planes: the all-planar bf16 kernel set
         if bf16:
@@ -660,7 +666,7 @@ class _StcCellGraph(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_stack):
-        k = kernels().for_graph(ctx.meta[0].row_sum_bound)
+        k = kernels().for_graph(_amplification(ctx.meta[0], ctx.meta[1]))
         bf16_planes = grad_stack.dtype == torch.bfloat16
         if bf16_planes:
             k = k.bf16

@@ -259,6 +259,32 @@ def test_bench_launches_its_own_ranks():
     assert d['step_breakdown']['grad_allreduce_ms'] > 0
 
 
+@pytest.mark.gpu
+def test_bench_many_ranks_contract():
+    """The driver's multi-GPU line, rehearsed at the largest rank count a one-GPU box allows (four ranks + their launcher + this process = the six
+    processes its guard admits -- five ranks were killed by it; the ranks share device 0 and talk over gloo): every rank is seen by a collective, ``per_rank`` holds one step time per rank,
+    ``ms_per_step`` -- hence ``value`` -- is the SLOWEST rank's, the global batch is ranks x batch-per-gpu, and one JSON line comes out.  Nothing in
+    bench.py depends on the rank count beyond these: the first real 8-GPU run takes the same path with ``nccl`` (RCCL) as the backend."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    import json
+    import subprocess
+    import sys
+    n = 4
+    cmd = [sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', str(n), '--steps', '3', '--warmup', '1', '--grid', '32', '--batch-per-gpu', '2',
+           '--obs', '3', '--pred', '2']
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env={**env, 'STC_DIST_BACKEND': 'gloo', 'STC_DIST_ONE_DEVICE': '1'})
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.strip().split('\n') if l.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == n and d['n_ranks_seen'] == n and d['config']['global_batch'] == 2 * n and d['config']['parallelism'] == f'batch-shard x{n}'
+    pr = d['per_rank']
+    assert len(pr['ms_per_step']) == n and abs(pr['ms_per_step_max'] - max(pr['ms_per_step'])) < 1e-3 and abs(pr['ms_per_step_min'] - min(pr['ms_per_step'])) < 1e-3
+    assert abs(d['ms_per_step'] - pr['ms_per_step_max']) < 1e-2 * d['ms_per_step'] + 1e-3          # the slowest rank's clock (list entries are rounded)
+    assert abs(d['value'] - 2 * n * 1e3 / d['ms_per_step']) < 1e-6 * d['value']
+    assert d['scaling'] == 'weak' and 'cpu_baseline' not in d and 'alt_formats' not in d and 'permuted' not in d
+
+
 def _two_gpus():
     """RCCL between ranks needs one GPU per rank: these tests run on a node with >= 2 visible GPUs and say so loudly otherwise."""
     n = torch.cuda.device_count()
