@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define STC_ABI_VERSION 25
+#define STC_ABI_VERSION 26
 #define STC_MAX_K 4          /* highest Chebyshev order (Ks, Kc) the node kernels accept */
 
 /* Operand formats of the split-operand matrix-core kernels (C = 32 / 64, hidden 16).  Every fp32 operand is split into low-precision
@@ -167,7 +167,8 @@ int stc_bdg_node_bwd_bf16(const void* const* Z, int32_t Ks, const float* Tc, int
  * X2, stc_spmm_blend_fwd_f32 without state copies, stc_spmm_sum_f32 with contiguous addends, stc_gru_blend_bwd_f32 in its
  * dCpre-only form); sums are fp32, each stored plane is rounded to bf16 once.  One extension: stc_cell_gates_bwd_planar_bf16
  * accepts dH == NULL and then adds the previous state's share from the GRU prologue (dRH R + dHnew (1-U)) into dZ[2], the
- * H plane's gradient, so that the state receives one gradient plane from the cell instead of two. */
+ * H plane's gradient, so that the state receives one gradient plane from the cell instead of two.  stc_cell_gates_fwd_planar_bf16: RH may be
+ * NULL (not written) when the fused candidate projection is on (Wc, A, Bm given): stc_cell_bwd_planar_bf16 re-forms R*H. */
 int stc_cell_planar_bf16_supported(int32_t Ks, int32_t Kc, int32_t C, int32_t h);
 int stc_cell_gates_fwd_planar_bf16(const void* X, const void* H, const void* SX, const void* SH,
                                    const float* Tc, const float* W, const float* bias,
@@ -180,6 +181,22 @@ int stc_cell_gates_bwd_planar_bf16(const void* X, const void* H, const void* SX,
                                    void* const* dZ, float* dW, float* db, void* dH,
                                    void* workspace, size_t workspace_bytes,
                                    int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream);
+/* The whole backward of a planar cell step on bf16 planes in ONE launch (counterpart of stc_cell_bwd_planar_f32 without its accumulate
+ * flags; reference STC_GNN.py:65-79 through autograd): candidate backward in post-aggregation form + gate / blend backward + gates
+ * backward per node, with dY = dHnew U (1 - Cand^2) and R*H formed inside (rounded to bf16 once, as the stored planes of the two
+ * launches above are), the R*H plane's gradient handed over in fp32 through LDS, the candidate's X-side gradient and the state's
+ * share of the gate prologue added into dX / dH.  9 planes in, 4 out (13 + 6 for stc_bdg_node_post_bwd_bf16 +
+ * stc_cell_gates_bwd_planar_bf16).  Narrow input (Lw - h in 1..4): X, SX are (nodes, C, Lw - h); dX, dSX are not produced (NULL).
+ * stc_cell_bwd_planar_bf16_supported(C, Lw, h): which shapes are built (C = 32: both input widths; C = 64: the wide input).
+ * workspace >= stc_bdg_node_bwd_workspace_bytes(2, 2, C, 32, 32, 0) + stc_bdg_node_bwd_workspace_bytes(2, 2, C, 32, 16, 0) bytes. */
+int stc_cell_bwd_planar_bf16_supported(int32_t C, int32_t Lw, int32_t h);
+int stc_cell_bwd_planar_bf16(const void* X, const void* H, const void* SX, const void* SH,
+                             const float* Tc, const float* Wg, const float* Wc,
+                             const void* U, const void* Rg, const void* Cand, const void* dHnew, const void* dBm,
+                             void* dX, void* dSX, void* dH, void* dSH,
+                             float* dWg, float* dbg, float* dWc, float* dbc,
+                             void* workspace, size_t workspace_bytes,
+                             int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream);
 int stc_bdg_node_post_bwd_bf16(const void* X, const void* X2, const float* Tc, const float* W, const void* dA, const void* dB,
                                void* dX, void* dX2, float* dW, float* db, void* workspace, size_t workspace_bytes,
                                int64_t nodes, int32_t C, int32_t Lw, int32_t Ho, void* stream);

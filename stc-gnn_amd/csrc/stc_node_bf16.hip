@@ -332,7 +332,7 @@ __global__ __launch_bounds__(MF_THREADS, (NB2 == 1 ? 2 : 1)) void cell_gates_fwd
             rhp[db] = pack4(rh);
             stc_st_once(reinterpret_cast<u32x2*>(a.U + e), pack4(u));
             stc_st_once(reinterpret_cast<u32x2*>(a.R + e), pack4(rg));
-            stc_st_once(reinterpret_cast<u32x2*>(a.RH + e), rhp[db]);
+            if (a.RH) stc_st_once(reinterpret_cast<u32x2*>(a.RH + e), rhp[db]);      // (optional with POST: the one-launch backward re-forms R*H)
         }
         if constexpr (POST) {
             // the candidate's input row [Xt | RH] (narrow: [RH | x | 0]) as an operand: RH columns 8j..8j+7 of row x sit with lanes (x, 2j), (x, 2j+1)
@@ -796,6 +796,325 @@ __global__ __launch_bounds__(256) void blend_bwd_bf16_kernel(const u32x4* __rest
     }
 }
 
+// --------------------------------------------------------------------------------------- the whole planar cell backward in ONE launch
+// Candidate backward (post-aggregation form, node_post_bwd_bf16_kernel) and gates backward with the gate / blend prologue (node_bwd_bf16_kernel,
+// PRO) back to back on the same node, as stc_cell_bwd_x3.hip does for fp32 planes (reference STC_GNN.py:65-79 through autograd):
+//   * dY = dHnew U (1 - Cand^2) and R*H are formed here from planes the gate prologue holds anyway (rounded to bf16 once, as the planes the
+//     two-launch path stores): the forward need not store R*H, the state-gradient sum need not write dY for this cell's sake;
+//   * the R*H plane's gradient goes from the candidate's tile to the gate prologue through a per-wave LDS tile, in fp32 -- never written;
+//   * the candidate's X-side gradient is parked in a lane-private LDS slot and added to the gates' X tile: one plane for the source, not two;
+//   * X is read once, H once (the prologue's H columns come from the lanes that hold the H half of the [X | H] row: one ds_bpermute per
+//     register instead of a second read of the plane).
+// 9 planes in (X, H, S.X, S.H, U, R, Cand, dHnew, dBm), 4 out, against 13 + 6 of the two launches.  One wave per SIMD, the next node's 28
+// registers per row block requested a node ahead.
+struct CellBwdB16 {
+    const bf16_t *X, *H, *SX, *SH, *U, *R, *Cand, *dHnew, *dBm;        // X, SX: (nodes, C, cin) when narrow; the rest (nodes, C, 16)
+    const float *Tc, *Wg, *Wc;                                          // (2, C, C); (4 Lw, 32); (4 Lw, 16)
+    bf16_t *dX, *dSX, *dH, *dSH;                                        // dX, dSX: wide input only
+    float *partial_g, *partial_c;
+    int nodes, want_dbg, want_dbc, Lw;
+};
+
+__device__ __forceinline__ u32x4 from_lane(const u32x4 v, int lane_bytes) {
+    return u32x4{(unsigned)__builtin_amdgcn_ds_bpermute(lane_bytes, (int)v[0]), (unsigned)__builtin_amdgcn_ds_bpermute(lane_bytes, (int)v[1]),
+                 (unsigned)__builtin_amdgcn_ds_bpermute(lane_bytes, (int)v[2]), (unsigned)__builtin_amdgcn_ds_bpermute(lane_bytes, (int)v[3])};
+}
+
+template <int NB2, int NARROW>
+__global__ __launch_bounds__(MF_THREADS, 1) void cell_bwd_bf16_kernel(CellBwdB16 a) {
+    constexpr int K = 2, NRB = 2 * NB2, C = 32 * NB2, LB = 2;
+    constexpr int RHB = NARROW ? 0 : 1;                 // block of the slab row that is the state plane (H for the gates, R*H for the candidate)
+    constexpr int nTB = NRB * NB2, nWG = K * LB * K, nWC = LB * K;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u32x4* TB = reinterpret_cast<u32x4*>(smem_raw);     // [NRB rb][NB2 p]        T_1[16 rb + x][32 p + pair_row]
+    u32x4* WG = TB + nTB * 64;                           // [K n][LB][K c]         A: Wg[(n, c, 16 lb + x)][o(slot)]
+    u32x4* WC = WG + nWG * 64;                           // [LB][K c]              A: Wc[(n(slot), c, 16 lb + x)][o(slot)]
+    const int tid = threadIdx.x, lane = tid & 63, x = lane & 15, g = lane >> 4;
+    const int cin = a.Lw - 16;
+    float* mine = reinterpret_cast<float*>(WC + nWC * 64) + (size_t)(tid >> 6) * 3 * NRB * 256;
+    float* stash_h = mine;                              // [NRB][16 rows][16 columns]: dRH R + dHnew (1 - U), what H is owed outside the convolutions
+    float* stash_x = mine + NRB * 256;                  // the candidate's X-side gradient tile, lane-private slots
+    float* tile_rh = mine + 2 * NRB * 256;              // the R*H plane's gradient: candidate tile layout -> prologue layout
+
+    for (int idx = tid; idx < nTB * 64; idx += MF_THREADS) {
+        const int ll = idx & 63, f = idx >> 6, p = f % NB2, rb = f / NB2, gg = ll >> 4;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = a.Tc[(size_t)C * C + (16 * rb + (ll & 15)) * C + 32 * p + pair_row(gg, e)];
+        put_frag(TB, f, ll, v);
+    }
+    for (int idx = tid; idx < nWG * 64; idx += MF_THREADS) {
+        const int ll = idx & 63, f = idx >> 6, c = f % K, lb = (f / K) % LB, n = f / (K * LB), gg = ll >> 4;
+        const int l = 16 * lb + (ll & 15);
+        const int wl = NARROW ? stc_wrow_swapped(l, cin) : l;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int o = c == 0 ? 8 * gg + e : pair_row(gg, e);      // Q_0 comes as dY rows (natural order), Q_1 from accumulators
+            v[e] = (wl >= 0 && wl < a.Lw) ? a.Wg[((size_t)(n * K + c) * a.Lw + wl) * 32 + o] : 0.f;
+        }
+        put_frag(WG, f, ll, v);
+    }
+    for (int idx = tid; idx < nWC * 64; idx += MF_THREADS) {
+        const int ll = idx & 63, f = idx >> 6, c = f % K, lb = f / K, gg = ll >> 4;
+        const int l = 16 * lb + (ll & 15);
+        const int wl = NARROW ? stc_wrow_swapped(l, cin) : l;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int n = c == 0 ? gg >> 1 : e >> 2;                         // the [dY | dBm] row: natural order; accumulators: pair order
+            const int o = c == 0 ? 8 * (gg & 1) + e : 4 * gg + (e & 3);
+            v[e] = (wl >= 0 && wl < a.Lw) ? a.Wc[((size_t)(n * K + c) * a.Lw + wl) * 16 + o] : 0.f;
+        }
+        put_frag(WC, f, ll, v);
+    }
+    __syncthreads();
+
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nw = gridDim.x * MF_WAVES;
+    u32x4 sel[2];
+    sel[0] = selector(0, x, g);
+    sel[1] = selector(1, x, g);
+    f32x4 dWg[K][LB][K][2], dWc[K][LB][K][1];
+    float dbg[2] = {0.f, 0.f}, dbc[1] = {0.f};
+#pragma unroll
+    for (int n = 0; n < K; ++n)
+#pragma unroll
+        for (int lb = 0; lb < LB; ++lb)
+#pragma unroll
+            for (int c = 0; c < K; ++c) { dWg[n][lb][c][0] = kZero4; dWg[n][lb][c][1] = kZero4; dWc[n][lb][c][0] = kZero4; }
+
+    // (the [S.X | S.H] rows are used last -- the dW products of slab 1 -- and are requested at the top of their OWN node, not a node ahead:
+    //  16 registers less across the node at C = 64, where the kernel holds 512)
+    struct Ops { u32x4 zx[NRB], gn[NRB], cd[NRB], uu[NRB], rr[NRB], bm[NRB]; };
+    auto load_ops = [&](Ops& o, int nd) {
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) {
+            const size_t row = (size_t)nd * C + 16 * rb + x, e = row * 16 + 8 * (g & 1);
+            // wide: the [X | H] piece of the lane; narrow: H columns 8 (g & 1) .. in EVERY lane (the input's cin columns: per node, below)
+            if constexpr (NARROW) o.zx[rb] = stc_ld_once(reinterpret_cast<const u32x4*>(a.H + e));
+            else o.zx[rb] = load_planar8<0>(a.X, a.H, row, g, 16);
+            o.gn[rb] = stc_ld_once(reinterpret_cast<const u32x4*>(a.dHnew + e));
+            o.cd[rb] = stc_ld_once(reinterpret_cast<const u32x4*>(a.Cand + e));
+            o.uu[rb] = stc_ld_once(reinterpret_cast<const u32x4*>(a.U + e));
+            o.rr[rb] = stc_ld_once(reinterpret_cast<const u32x4*>(a.R + e));
+            o.bm[rb] = stc_ld_once(reinterpret_cast<const u32x4*>(a.dBm + e));
+        }
+    };
+    const bool holds_h = g >= 2;                            // wide: lanes whose piece of the [X | H] row is the H half (their own prologue columns)
+    Ops cur, nxt;
+    int node = blockIdx.x * MF_WAVES + wave;
+    if (node < a.nodes) load_ops(cur, node);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0) before the loop (see node_fwd_x3_kernel)
+    while (node < a.nodes) {
+        const int next_node = node + nw;
+        const size_t r0 = (size_t)node * C;
+        u32x4 zs[NRB], xin[NARROW ? NRB : 1];                   // narrow: the input plane's columns [x (cin) | 0] as lane group g = 2 carries them
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) {
+            zs[rb] = load_planar8<NARROW>(a.SX, a.SH, r0 + 16 * rb + x, g, cin);
+            if constexpr (NARROW) {
+                const bf16_t* q = a.X + (r0 + 16 * rb + x) * cin;
+                const unsigned v0 = q[0], v1 = q[cin > 1 ? 1 : 0], v2 = q[cin > 2 ? 2 : 0], v3 = q[cin > 3 ? 3 : 0];
+                xin[rb] = u32x4{v0 | (cin > 1 ? v1 << 16 : 0u), cin > 2 ? (v2 | (cin > 3 ? v3 << 16 : 0u)) : 0u, 0u, 0u};
+            }
+        }
+        if (next_node < a.nodes) load_ops(nxt, next_node);      // software prefetch: one wave per SIMD has no partner to hide the loads behind
+        __builtin_amdgcn_sched_barrier(0);
+        const int lo = opaque(lane);
+        // H, columns 8 (g & 1) .. of row 16 rb + x, in every lane: from the lanes that hold the H half of the [X | H] row
+        auto h_cols = [&](int rb) {
+            if constexpr (NARROW) return cur.zx[rb];
+            else { const u32x4 other = from_lane(cur.zx[rb], (lane ^ 32) << 2); return holds_h ? cur.zx[rb] : other; }
+        };
+        // the [X | H] row as the lane's operand piece: wide = what was loaded; narrow = [H | x | 0]
+        auto xh_row = [&](int rb) {
+            if constexpr (NARROW) return g < 2 ? cur.zx[rb] : (g == 2 ? xin[rb] : kZeroU4);
+            else return cur.zx[rb];
+        };
+
+        // =========================================================== candidate convolution: dA = dY, dBm given
+        {
+            u32x4 dyr[NRB], zc[NRB];
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+                float gn[8], cd[8], uu[8], rr[8], hh[8], dy[8], rh[8];
+                unpack8(cur.gn[rb], gn); unpack8(cur.cd[rb], cd); unpack8(cur.uu[rb], uu); unpack8(cur.rr[rb], rr); unpack8(h_cols(rb), hh);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { dy[i] = gn[i] * uu[i] * (1.f - cd[i] * cd[i]); rh[i] = rr[i] * hh[i]; }
+                const u32x4 dyp = pack8f(dy), rhp = pack8f(rh);
+                dyr[rb] = g < 2 ? dyp : cur.bm[rb];               // the [dY | dBm] row
+                zc[rb] = NARROW ? (g < 2 ? rhp : (g == 2 ? xin[NARROW ? rb : 0] : kZeroU4)) : (g < 2 ? cur.zx[rb] : rhp);      // [X | R*H]; narrow: [R*H | x | 0]
+            }
+            u32x4 gd[K][NB2];
+#pragma unroll
+            for (int n = 0; n < K; ++n)
+#pragma unroll
+                for (int p = 0; p < NB2; ++p) {
+                    const f32x4 t0 = mma(dyr[2 * p], sel[n], kZero4), t1 = mma(dyr[2 * p + 1], sel[n], kZero4);
+                    if (n == 0) dbc[0] += ((t0[0] + t0[1]) + (t0[2] + t0[3])) + ((t1[0] + t1[1]) + (t1[2] + t1[3]));      // the bias sits on A only
+                    gd[n][p] = pack8(t0, t1);
+                }
+            u32x4 qb1[NRB];
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+                f32x4 Qv[K] = {kZero4, kZero4};
+#pragma unroll
+                for (int p = 0; p < NB2; ++p) {
+                    const u32x4 t = TB[(rb * NB2 + p) * 64 + lo];
+#pragma unroll
+                    for (int n = 0; n < K; ++n) Qv[n] = mma(gd[n][p], t, Qv[n]);
+                }
+                qb1[rb] = pack8(Qv[0], Qv[1]);
+            }
+#pragma unroll
+            for (int lb = 0; lb < LB; ++lb) {
+                if (NARROW && lb != RHB) continue;              // the narrow input plane needs no gradient
+                const u32x4 w0 = WC[(lb * K + 0) * 64 + lo], w1 = WC[(lb * K + 1) * 64 + lo];
+                float* dst = lb == RHB ? tile_rh : stash_x;
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) {
+                    const f32x4 z = mma(w1, qb1[rb], mma(w0, dyr[rb], kZero4));
+                    *reinterpret_cast<float4*>(dst + (rb * 16 + x) * 16 + 4 * g) = make_float4(z[0], z[1], z[2], z[3]);
+                }
+            }
+            u32x4 qd[K][NB2];
+#pragma unroll
+            for (int n = 0; n < K; ++n) {
+                f32x4 Qd[NRB];
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) {
+                    Qd[rb] = kZero4;
+#pragma unroll
+                    for (int p = 0; p < NB2; ++p) Qd[rb] = mma(TB[(rb * NB2 + p) * 64 + lo], gd[n][p], Qd[rb]);
+                }
+#pragma unroll
+                for (int p = 0; p < NB2; ++p) qd[n][p] = pack8(Qd[2 * p], Qd[2 * p + 1]);
+            }
+#pragma unroll
+            for (int lb = 0; lb < LB; ++lb)
+#pragma unroll
+                for (int p = 0; p < NB2; ++p) {
+                    const u32x4 za = pack8(mma(zc[2 * p], sel[lb], kZero4), mma(zc[2 * p + 1], sel[lb], kZero4));
+#pragma unroll
+                    for (int n = 0; n < K; ++n)
+#pragma unroll
+                        for (int c = 0; c < K; ++c) dWc[n][lb][c][0] = mma(za, c == 0 ? gd[n][p] : qd[n][p], dWc[n][lb][c][0]);
+                }
+        }
+        __builtin_amdgcn_wave_barrier();                        // (LDS operations of one wave complete in order: the tile is readable)
+
+        // =========================================================== gate + blend backward, then the gates convolution
+        u32x4 dyr[NRB];
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) {
+            const float4 d0 = *reinterpret_cast<const float4*>(tile_rh + (rb * 16 + x) * 16 + 8 * (g & 1));
+            const float4 d1 = *reinterpret_cast<const float4*>(tile_rh + (rb * 16 + x) * 16 + 8 * (g & 1) + 4);
+            const float dr[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+            float gn[8], cd[8], uu[8], rr[8], hh[8], gy[8], dh[8];
+            unpack8(cur.gn[rb], gn); unpack8(cur.cd[rb], cd); unpack8(cur.uu[rb], uu); unpack8(cur.rr[rb], rr); unpack8(h_cols(rb), hh);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float gu = gn[i] * (cd[i] - hh[i]) * uu[i] * (1.f - uu[i]);
+                const float gr = dr[i] * hh[i] * rr[i] * (1.f - rr[i]);
+                gy[i] = g < 2 ? gu : gr;
+                dh[i] = fmaf(dr[i], rr[i], gn[i] * (1.f - uu[i]));
+            }
+            dyr[rb] = pack8f(gy);
+            if (g < 2) {
+                float4* slot = reinterpret_cast<float4*>(stash_h + (rb * 16 + x) * 16 + 8 * g);
+                slot[0] = make_float4(dh[0], dh[1], dh[2], dh[3]);
+                slot[1] = make_float4(dh[4], dh[5], dh[6], dh[7]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        u32x4 gd[2][NB2];
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+            for (int p = 0; p < NB2; ++p) {
+                const f32x4 t0 = mma(dyr[2 * p], sel[hb], kZero4), t1 = mma(dyr[2 * p + 1], sel[hb], kZero4);
+                dbg[hb] += ((t0[0] + t0[1]) + (t0[2] + t0[3])) + ((t1[0] + t1[1]) + (t1[2] + t1[3]));
+                gd[hb][p] = pack8(t0, t1);
+            }
+        u32x4 qb[K][NRB];
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) {
+            qb[0][rb] = dyr[rb];
+            f32x4 Qv[2] = {kZero4, kZero4};
+#pragma unroll
+            for (int p = 0; p < NB2; ++p) {
+                const u32x4 t = TB[(rb * NB2 + p) * 64 + lo];
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb) Qv[hb] = mma(gd[hb][p], t, Qv[hb]);
+            }
+            qb[1][rb] = pack8(Qv[0], Qv[1]);
+        }
+#pragma unroll
+        for (int n = 0; n < K; ++n)
+#pragma unroll
+            for (int lb = 0; lb < LB; ++lb) {
+                if (NARROW && lb != RHB) continue;              // narrow input plane: only the state plane's gradient is wanted
+                f32x4 z[NRB];
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) z[rb] = kZero4;
+#pragma unroll
+                for (int c = 0; c < K; ++c) {
+                    const u32x4 w = WG[((n * LB + lb) * K + c) * 64 + lo];
+#pragma unroll
+                    for (int rb = 0; rb < NRB; ++rb) z[rb] = mma(w, qb[c][rb], z[rb]);
+                }
+                if (n == 0) {                                   // the H plane's tile: + the prologue's share; the X plane's: + the candidate's
+                    const float* add = lb == RHB ? stash_h : stash_x;
+#pragma unroll
+                    for (int rb = 0; rb < NRB; ++rb) {
+                        const float4 sh = *reinterpret_cast<const float4*>(add + (rb * 16 + x) * 16 + 4 * g);
+                        z[rb][0] += sh.x; z[rb][1] += sh.y; z[rb][2] += sh.z; z[rb][3] += sh.w;
+                    }
+                }
+                bf16_t* dst = lb == RHB ? (n == 0 ? a.dH : a.dSH) : (n == 0 ? a.dX : a.dSX);
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) stc_st_once(reinterpret_cast<u32x2*>(dst + (r0 + 16 * rb + x) * 16 + 4 * g), pack4(z[rb]));
+            }
+        u32x4 qd[2][NB2];
+        {
+            f32x4 Qd[NRB][2];
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+                Qd[rb][0] = kZero4; Qd[rb][1] = kZero4;
+#pragma unroll
+                for (int p = 0; p < NB2; ++p) {
+                    const u32x4 t = TB[(rb * NB2 + p) * 64 + lo];
+#pragma unroll
+                    for (int hb = 0; hb < 2; ++hb) Qd[rb][hb] = mma(t, gd[hb][p], Qd[rb][hb]);
+                }
+            }
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                for (int p = 0; p < NB2; ++p) qd[hb][p] = pack8(Qd[2 * p][hb], Qd[2 * p + 1][hb]);
+        }
+#pragma unroll
+        for (int n = 0; n < K; ++n)
+#pragma unroll
+            for (int lb = 0; lb < LB; ++lb)
+#pragma unroll
+                for (int p = 0; p < NB2; ++p) {
+                    const u32x4 z0 = n == 0 ? xh_row(2 * p) : zs[2 * p], z1 = n == 0 ? xh_row(2 * p + 1) : zs[2 * p + 1];
+                    const u32x4 za = pack8(mma(z0, sel[lb], kZero4), mma(z1, sel[lb], kZero4));
+#pragma unroll
+                    for (int c = 0; c < K; ++c)
+#pragma unroll
+                        for (int hb = 0; hb < 2; ++hb) dWg[n][lb][c][hb] = mma(za, c == 0 ? gd[hb][p] : qd[hb][p], dWg[n][lb][c][hb]);
+                }
+        __builtin_amdgcn_wave_barrier();                        // the next node overwrites the wave's LDS slots
+        cur = nxt;
+        node = next_node;
+    }
+    combine_dw<K, LB, 2>(reinterpret_cast<float*>(smem_raw), dWg, dbg, a.partial_g, a.Lw, a.want_dbg, NARROW ? cin : -1);
+    combine_dw<K, LB, 1>(reinterpret_cast<float*>(smem_raw), dWc, dbc, a.partial_c, a.Lw, a.want_dbc, NARROW ? cin : -1);
+}
+
 // --------------------------------------------------------------------------------------- host side
 template <int NB2, int HB, int K, int L>
 int launch_fwd(const void* const* Z, const float* Tc, const float* W, const float* bias, void* Y, long long nodes, int Lw, hipStream_t stream) {
@@ -893,6 +1212,24 @@ bool bf16_shape(int Ks, int Kc, int C, int L, int Lw, int Ho, long long nodes) {
            Lw >= 1 && Lw <= L && nodes >= 0 && nodes < (1ll << 31) / C;
 }
 
+template <int NB2, int NARROW>
+int launch_cell_bwd(const CellBwdB16& a, int* n_partials, hipStream_t stream) {
+    constexpr int NRB = 2 * NB2, nW = 4 * 32 * 32;
+    const size_t frag = (size_t)(NRB * NB2 + 8 + 4) * 64 * 16 + (size_t)MF_WAVES * 3 * NRB * 256 * sizeof(float);     // tables + the three per-wave tiles
+    const size_t slabs = (size_t)MF_WAVES * (nW + 32) * sizeof(float);
+    const size_t lds = frag > slabs ? frag : slabs;
+    auto kern = cell_bwd_bf16_kernel<NB2, NARROW>;
+    if (int rc = stc::hip_status(stc::allow_lds(kern, lds), "hipFuncSetAttribute(cell bwd bf16)")) return rc;
+    static const int resident = stc::resident_blocks(kern, MF_THREADS, lds, 1);
+    const long long want = (a.nodes + MF_WAVES - 1) / MF_WAVES;
+    int grid = resident < MF_BWD_MAX_GRID ? resident : MF_BWD_MAX_GRID;
+    if (want < grid) grid = (int)want;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(MF_THREADS), lds, stream, a);
+    STC_LAUNCH_CHECK("cell_bwd_bf16 launch");
+    *n_partials = grid;
+    return STC_OK;
+}
+
 }  // namespace
 
 #define STC_BF16_CASES(NB2_, HB_, CALL)                                                                 \
@@ -977,7 +1314,7 @@ extern "C" int stc_cell_gates_fwd_planar_bf16(const void* X, const void* H, cons
     STC_REQUIRE(cin == 16 || (cin >= 1 && cin <= 4), STC_EUNSUPPORTED, "stc_cell_gates_fwd_planar_bf16: input plane of %d columns (16, or 1..4)", cin);
     STC_REQUIRE(nodes >= 0 && nodes < (1ll << 31) / C, STC_ELIMIT, "stc_cell_gates_fwd_planar_bf16: nodes=%lld", (long long)nodes);
     if (nodes == 0) return STC_OK;
-    STC_REQUIRE(X && H && SX && SH && Tc && W && U && Rg && RH, STC_EINVAL, "stc_cell_gates_fwd_planar_bf16: null pointer");
+    STC_REQUIRE(X && H && SX && SH && Tc && W && U && Rg && (RH || A), STC_EINVAL, "stc_cell_gates_fwd_planar_bf16: null pointer (RH may be NULL only with the fused candidate projection)");
     STC_REQUIRE((A == nullptr) == (Bm == nullptr) && (A == nullptr) == (Wc == nullptr), STC_EINVAL, "stc_cell_gates_fwd_planar_bf16: Wc, A, Bm go together");
     STC_REQUIRE(stc::aligned16(H) && stc::aligned16(SH) && stc::aligned16(U) && stc::aligned16(Rg) && stc::aligned16(RH) &&
                     (cin != 16 || (stc::aligned16(X) && stc::aligned16(SX))) && (!A || (stc::aligned16(A) && stc::aligned16(Bm))),
@@ -1038,6 +1375,59 @@ extern "C" int stc_cell_gates_bwd_planar_bf16(const void* X, const void* H, cons
                                      : launch_gates_bwd<2, 1, 1>(zp, dzp, pro, Tc, W, partial, &n_parts, db != nullptr, nodes, Lw, s));
     if (rc != STC_OK) return rc;
     return stc_node_reduce_partials(partial, n_parts, nW, 32, dW, db, s);
+}
+
+// ---- the whole backward of a planar cell step on bf16 planes in one launch (cell_bwd_bf16_kernel)
+// (C = 64 with a narrow input plane: the kernel does not fit the register file -- 62 scratch accesses per node -- and is not dispatched;
+//  the schedule's layer-0 cells keep the two launches there)
+extern "C" int stc_cell_bwd_planar_bf16_supported(int32_t C, int32_t Lw, int32_t h) {
+    if (!stc_cell_planar_bf16_supported(2, 2, C, h)) return 0;
+    const int cin = Lw - h;
+    return (cin == 16 || (C == 32 && cin >= 1 && cin <= 4)) ? 1 : 0;
+}
+
+extern "C" int stc_cell_bwd_planar_bf16(const void* X, const void* H, const void* SX, const void* SH,
+                                        const float* Tc, const float* Wg, const float* Wc,
+                                        const void* U, const void* Rg, const void* Cand, const void* dHnew, const void* dBm,
+                                        void* dX, void* dSX, void* dH, void* dSH,
+                                        float* dWg, float* dbg, float* dWc, float* dbc,
+                                        void* workspace, size_t workspace_bytes,
+                                        int64_t nodes, int32_t C, int32_t Lw, int32_t h, void* stream) {
+    STC_REQUIRE(stc_cell_bwd_planar_bf16_supported(C, Lw, h), STC_EUNSUPPORTED,
+                "stc_cell_bwd_planar_bf16: C=%d h=%d input width %d is not built (C = 32: 16 or 1..4 columns; C = 64: 16)", C, h, Lw - h);
+    const int cin = Lw - 16;
+    STC_REQUIRE(nodes >= 0 && nodes < (1ll << 31) / C, STC_ELIMIT, "stc_cell_bwd_planar_bf16: nodes=%lld", (long long)nodes);
+    STC_REQUIRE(Wg && Wc && dWg && dWc && Tc, STC_EINVAL, "stc_cell_bwd_planar_bf16: null W/dW/Tc");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int nWg = 4 * Lw * 32, nWc = 4 * Lw * 16;
+    if (nodes == 0) {
+        if (int rc = stc::hip_status(hipMemsetAsync(dWg, 0, (size_t)nWg * sizeof(float), s), "memset dWg")) return rc;
+        if (int rc = stc::hip_status(hipMemsetAsync(dWc, 0, (size_t)nWc * sizeof(float), s), "memset dWc")) return rc;
+        if (dbg) if (int rc = stc::hip_status(hipMemsetAsync(dbg, 0, 32 * sizeof(float), s), "memset dbg")) return rc;
+        if (dbc) if (int rc = stc::hip_status(hipMemsetAsync(dbc, 0, 16 * sizeof(float), s), "memset dbc")) return rc;
+        return STC_OK;
+    }
+    const bool narrow = cin != 16;
+    STC_REQUIRE(X && H && SX && SH && U && Rg && Cand && dHnew && dBm && dH && dSH && (narrow || (dX && dSX)), STC_EINVAL, "stc_cell_bwd_planar_bf16: null pointer");
+    for (const void* q : {H, SH, U, Rg, Cand, dHnew, dBm, (const void*)dH, (const void*)dSH})
+        STC_REQUIRE(stc::aligned16(q), STC_EALIGN, "stc_cell_bwd_planar_bf16: planes must be 16-byte aligned");
+    if (!narrow) STC_REQUIRE(stc::aligned16(X) && stc::aligned16(SX) && stc::aligned16(dX) && stc::aligned16(dSX), STC_EALIGN,
+                             "stc_cell_bwd_planar_bf16: planes must be 16-byte aligned");
+    const size_t bytes_g = stc_bdg_node_bwd_workspace_bytes(2, 2, C, 32, 32, 0);
+    STC_REQUIRE(workspace && stc::aligned16(workspace) && workspace_bytes >= bytes_g + stc_bdg_node_bwd_workspace_bytes(2, 2, C, 32, 16, 0), STC_EINVAL,
+                "stc_cell_bwd_planar_bf16: workspace null, misaligned or too small (%zu B)", workspace_bytes);
+    auto B = [](const void* q) { return static_cast<const bf16_t*>(q); };
+    auto M = [](void* q) { return static_cast<bf16_t*>(q); };
+    float* partial_g = static_cast<float*>(workspace);
+    float* partial_c = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + bytes_g);
+    const CellBwdB16 a{B(X), B(H), B(SX), B(SH), B(U), B(Rg), B(Cand), B(dHnew), B(dBm), Tc, Wg, Wc, M(dX), M(dSX), M(dH), M(dSH),
+                       partial_g, partial_c, (int)nodes, dbg != nullptr, dbc != nullptr, Lw};
+    int n_parts = 0;
+    const int rc = C == 32 ? (narrow ? launch_cell_bwd<1, 1>(a, &n_parts, s) : launch_cell_bwd<1, 0>(a, &n_parts, s))
+                           : launch_cell_bwd<2, 0>(a, &n_parts, s);
+    if (rc != STC_OK) return rc;
+    if (int r2 = stc_node_reduce_partials(partial_g, n_parts, nWg, 32, dWg, dbg, s)) return r2;
+    return stc_node_reduce_partials(partial_c, n_parts, nWc, 16, dWc, dbc, s);
 }
 
 // post-aggregation backward of the candidate convolution on planes: wide -- X (columns 0..15), X2 (16..31), gradients dX, dX2;

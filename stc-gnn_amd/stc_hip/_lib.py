@@ -21,7 +21,7 @@ from .graph import is_full_pattern
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG_ROOT, 'libstc_hip.so')
-ABI_VERSION = 25
+ABI_VERSION = 26
 FMT_BF16X3, FMT_F16X2 = 0, 1          # STC_FMT_* of include/stc_hip.h: operand formats of the split-operand matrix-core kernels
 MAX_K = 4
 SPMM_SUM_MAX_ADD = 8     # = STC_SPMM_SUM_MAX_ADD of include/stc_hip.h
@@ -32,6 +32,7 @@ EXPORTS = (
     'stc_version', 'stc_last_error',
     'stc_csr_spmm_f32', 'stc_bcsr_spmm_f32', 'stc_patch_spmm_f32', 'stc_patch_spmm_bf16', 'stc_csr_spmm_bf16', 'stc_bcsr_spmm_bf16', 'stc_bdg_node_bf16_supported', 'stc_bdg_node_fwd_bf16', 'stc_bdg_node_bwd_bf16',
     'stc_cell_planar_bf16_supported', 'stc_cell_gates_fwd_planar_bf16', 'stc_cell_gates_bwd_planar_bf16', 'stc_bdg_node_post_bwd_bf16',
+    'stc_cell_bwd_planar_bf16_supported', 'stc_cell_bwd_planar_bf16',
     'stc_spmm_blend_fwd_bf16', 'stc_spmm_sum_bf16', 'stc_gru_blend_bwd_bf16', 'stc_head_fwd_bf16', 'stc_head_bwd_bf16',
     'stc_csr_sddmm_f32', 'stc_set_dispatch_level', 'stc_dense_agg_f32',
     'stc_cheby_dense_fwd_f32', 'stc_cheby_dense_bwd_f32',
@@ -91,6 +92,7 @@ def _declare(lib):
                                   _p, C.c_size_t, _i64, _i32, _i32, _i32, _i32, _p],
         'stc_cell_gates_fwd_planar_bf16': [_p] * 14 + [_i64, _i32, _i32, _i32, _p],
         'stc_cell_gates_bwd_planar_bf16': [_p] * 11 + [C.POINTER(_p), _p, _p, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _p],
+        'stc_cell_bwd_planar_bf16': [_p] * 20 + [_p, C.c_size_t, _i64, _i32, _i32, _i32, _p],
         'stc_bdg_node_post_bwd_bf16': [_p] * 11 + [C.c_size_t, _i64, _i32, _i32, _i32, _p],
         'stc_spmm_blend_fwd_bf16': [_p] * 6 + [_i32, _i32] + [_p] * 6 + [_i32] * 3 + [_p],
         'stc_spmm_sum_bf16': [_p] * 6 + [_i32, _i32, _p, _p, _i32, C.POINTER(_p), _p, _p, _p, _p, _i32, _i32, _i32, _p],
@@ -145,6 +147,8 @@ def _declare(lib):
     lib.stc_cell_planar_k_supported.argtypes = [_i32, _i32, _i32]
     lib.stc_cell_bwd_planar_supported.restype = C.c_int
     lib.stc_cell_bwd_planar_supported.argtypes = [_i32, _i32]
+    lib.stc_cell_bwd_planar_bf16_supported.restype = C.c_int
+    lib.stc_cell_bwd_planar_bf16_supported.argtypes = [_i32, _i32, _i32]
     lib.stc_cell_bwd_planar_workspace_bytes.restype = C.c_size_t
     lib.stc_cell_bwd_planar_workspace_bytes.argtypes = [_i32, _i32, _i32]
     lib.stc_cell_small_supported.restype = C.c_int
@@ -1409,7 +1413,9 @@ class _Bf16Planar:
         b._f32('planar.W', W, (4 * (cin + h), 2 * h))
         if bias is not None:
             b._f32('planar.bias', bias, (2 * h,))
-        for name, t in (('U', U), ('Rg', Rg), ('RH', RH)):
+        if RH is None and post is None:
+            raise StcError('planar gates forward (bf16): the R*H plane is optional only with the fused candidate projection (post=)')
+        for name, t in (('U', U), ('Rg', Rg)) + ((('RH', RH),) if RH is not None else ()):
             self._pl('planar.' + name, t, (R, Cc, h))
         Wc = bc = A = Bm = None
         if post is not None:
@@ -1422,7 +1428,7 @@ class _Bf16Planar:
         b._same_device(X, H, SX, SH, Tc, W, bias, U, Rg, RH, Wc, bc, A, Bm)
         b._launch('stc_cell_gates_fwd_planar_bf16', H, _ptr(X), _ptr(H), _ptr(SX), _ptr(SH), _ptr(Tc), _ptr(W), _ptr(bias),
                   _ptr(U), _ptr(Rg), _ptr(RH), _ptr(Wc), _ptr(bc), _ptr(A), _ptr(Bm), R, Cc, cin + h, h,
-                     nbytes=2 * R * Cc * (2 * cin + 2 * h + h * (3 + (2 if post is not None else 0))))
+                     nbytes=2 * R * Cc * (2 * cin + 2 * h + h * (2 + (RH is not None) + (2 if post is not None else 0))))
 
     def node_post_fwd(self, *a, **kw):
         raise StcError('bf16 planar path: the candidate projection runs inside cell_gates_fwd_planar (post=); STC_FUSE_POST=0 is an fp32-path switch')
@@ -1494,6 +1500,39 @@ class _Bf16Planar:
         b._launch('stc_bdg_node_post_bwd_bf16', X, _ptr(X), _ptr(X2), _ptr(Tc), _ptr(W), _ptr(dA), _ptr(dB), _ptr(dX), _ptr(dX2), _ptr(dW), _ptr(db),
                   _ptr(ws), ws.numel(), R, Cc, 16 + w2, 16,
                   nbytes=2 * R * Cc * (16 + w2 + 2 * 16 + 16 + (16 if dX2 is not None else 0)))
+
+    def cell_bwd_planar_supported(self, Cc, h, cin=16) -> bool:
+        """Whether the one-launch backward exists for cells with an input plane of ``cin`` columns (C = 64: the wide input only)."""
+        return bool(self.b.lib.stc_cell_bwd_planar_bf16_supported(Cc, cin + h, h))
+
+    def cell_bwd_planar(self, X, H, SX, SH, Tc, Wg, Wc, U, Rg, Cand, dHnew, dBm, dZs, dWg, dbg, dWc, dbc, accumulate_x=False, accumulate_h=False):
+        """stc_cell_bwd_planar_bf16: candidate + gates backward of one planar cell step in one launch (no accumulate forms on bf16 planes)."""
+        b = self.b
+        if accumulate_x or accumulate_h:
+            raise StcError('cell backward (bf16): the accumulate forms are fp32-path features')
+        R, Cc, h, cin = self._planes(X, H, SX, SH)
+        b._f32('cell_bwd.Tc', Tc, (2, Cc, Cc))
+        b._f32('cell_bwd.Wg', Wg, (4 * (cin + h), 2 * h))
+        b._f32('cell_bwd.Wc', Wc, (4 * (cin + h), h))
+        for name, t in (('U', U), ('Rg', Rg), ('Cand', Cand), ('dHnew', dHnew), ('dBm', dBm)):
+            self._pl('cell_bwd.' + name, t, (R, Cc, h))
+        if len(dZs) != 4:
+            raise StcError('cell backward: four gradient planes (dX, dSX, dH, dSH)')
+        for i, z in enumerate(dZs):
+            if z is None and i < 2 and cin != h:
+                continue
+            self._pl(f'cell_bwd.dZ[{i}]', z, (R, Cc, h))
+        b._f32('cell_bwd.dWg', dWg, (4 * (cin + h), 2 * h))
+        b._f32('cell_bwd.dWc', dWc, (4 * (cin + h), h))
+        if dbg is not None:
+            b._f32('cell_bwd.dbg', dbg, (2 * h,))
+        if dbc is not None:
+            b._f32('cell_bwd.dbc', dbc, (h,))
+        b._same_device(X, H, SX, SH, Tc, Wg, Wc, U, Rg, Cand, dHnew, dBm, *dZs, dWg, dbg, dWc, dbc)
+        ws = b._get_workspace(H.device, b.lib.stc_bdg_node_bwd_workspace_bytes(2, 2, Cc, 32, 32, 0) + b.lib.stc_bdg_node_bwd_workspace_bytes(2, 2, Cc, 32, 16, 0))
+        b._launch('stc_cell_bwd_planar_bf16', H, _ptr(X), _ptr(H), _ptr(SX), _ptr(SH), _ptr(Tc), _ptr(Wg), _ptr(Wc), _ptr(U), _ptr(Rg), _ptr(Cand),
+                  _ptr(dHnew), _ptr(dBm), *[_ptr(z) for z in dZs], _ptr(dWg), _ptr(dbg), _ptr(dWc), _ptr(dbc), _ptr(ws), ws.numel(), R, Cc, cin + h, h,
+                  nbytes=2 * R * Cc * (2 * cin + 7 * h + 2 * h + (2 * h if cin == h else 0)), tag='wide' if cin == h else 'layer0')
 
     def cell_gates_bwd_planar(self, X, H, SX, SH, Tc, W, dRH, Cand, U, Rg, dHnew, dZs, dW, db, dH):
         b = self.b

@@ -605,7 +605,7 @@ class _StcCellGraph(Function):
                 Xp, SXp, SHp = source(x), aggregated(x), aggregated(hs)
                 fused_post = _FUSE_POST and k.cell_planar_post_fused(C)
                 # one-launch backward (stc_cell_bwd_planar_f32) forms R*H itself: with the fused projection the plane is not stored at all
-                one_bwd = fused_post and not bf16 and k.cell_bwd_planar_supported(C, h)
+                one_bwd = fused_post and (k.cell_bwd_planar_supported(C, h, cin[j]) if bf16 else k.cell_bwd_planar_supported(C, h))
                 RH = None if one_bwd else torch.empty_like(Hprev)
                 A, Bm = torch.empty_like(Hprev), torch.empty_like(Hprev)
                 if fused_post:                                        # the candidate's projection rides in the gates launch
@@ -849,7 +849,7 @@ class _StcCellGraph(Function):
                     if src[0] != 'cell':
                         return new(), new(), False                   # an external tensor: gradients computed, nobody owed
                     pc = pieces.get(src[1])
-                    if _ACC_PLANES and pc is not None and pc.get('own') is not None and src[1] not in taken:
+                    if _ACC_PLANES and not bf16_planes and pc is not None and pc.get('own') is not None and src[1] not in taken:
                         taken.add(src[1])
                         return pc['own'][0], pc['own'][1], True
                     d, a_ = new(), new()
@@ -863,7 +863,7 @@ class _StcCellGraph(Function):
                 dHd, dSH, acc_h = planes_of_state(hs)
                 k.cell_bwd_planar(*rows((Xp, Hprev, SXp, SHp)), Tc, Wg, Wc, *rows((U, Rg, Cand, dHnew, dBm)),
                                   [None if t is None else t.view(B * N, C, h) for t in (dXd, dSX, dHd, dSH)], dWg, dbg, dWc, dbc,
-                                  accumulate_x=acc_x, accumulate_h=acc_h, **act_slots(j))
+                                  **(dict(accumulate_x=acc_x, accumulate_h=acc_h, **act_slots(j)) if not bf16_planes else {}))
                 continue                                             # (parameter gradients: rows of the set's buffer, summed at the end)
             if n_saved[j] < 0:                                       # planar cell: inputs and gradients as planes
                 Xp, SXp, SHp, RH = rest

@@ -309,6 +309,65 @@ def test_planar_cell_kernels_bf16(hip, nodes, C, cin):
     assert rel_err(dWc.cpu(), dWc_w) < BTOL and rel_err(dbc.cpu(), dbc_w) < BTOL
 
 
+@pytest.mark.parametrize('nodes,C,cin', [(50, 32, 16), (13, 64, 16), (4500, 64, 16), (4500, 32, 16), (50, 32, 1), (9, 32, 3), (4500, 32, 4)])
+def test_cell_backward_in_one_launch_bf16(hip, nodes, C, cin):
+    """stc_cell_bwd_planar_bf16: candidate + gate / blend + gates backward of one planar cell step per node (dY and R*H formed inside and rounded
+    to bf16 once, d(R*H) handed over in fp32, dX = both convolutions' shares, the prologue's share folded into dH) against the fp32 CPU twin on
+    the bf16-valued planes, and against the two separate bf16 launches; the forward may skip the R*H plane."""
+    bf, h, K = torch.bfloat16, 16, 2
+    kb = hip.bf16
+    assert kb.cell_bwd_planar_supported(C, h, cin) and not kb.cell_bwd_planar_supported(64, h, 1)
+    Lw = cin + h
+    g = torch.Generator().manual_seed(nodes + C + cin)
+    rnd = lambda *s_: torch.randn(*s_, generator=g)
+    rb = lambda *s_: rnd(*s_).to(bf)
+    X, SX, H, SH = rb(nodes, C, cin), rb(nodes, C, cin), torch.tanh(rnd(nodes, C, h)).to(bf), rb(nodes, C, h)
+    Tc = rnd(K, C, C) / C ** 0.5
+    Tc[0] = torch.eye(C)
+    Wg, Wc = rnd(K * K * Lw, 2 * h) / (4 * Lw) ** 0.5, rnd(K * K * Lw, h) / (4 * Lw) ** 0.5
+    U, R, Cand = torch.sigmoid(rnd(nodes, C, h)).to(bf), torch.sigmoid(rnd(nodes, C, h)).to(bf), torch.tanh(rnd(nodes, C, h)).to(bf)
+    dHn, dBm = rb(nodes, C, h), rb(nodes, C, h)
+    f = lambda t: t.float()
+    wide = cin == h
+    dZ_w = [torch.empty(nodes, C, h) if (wide or i >= 2) else None for i in range(4)]
+    dWg_w, dWc_w, dbg_w, dbc_w = torch.empty_like(Wg), torch.empty_like(Wc), torch.empty(2 * h), torch.empty(h)
+    EM.cell_bwd_planar(f(X), f(H), f(SX), f(SH), Tc, Wg, Wc, f(U), f(R), f(Cand), f(dHn), f(dBm), dZ_w, dWg_w, dbg_w, dWc_w, dbc_w)
+    nan = lambda *s_: torch.full(s_, float('nan'), dtype=bf).cuda()
+    nanf = lambda *s_: torch.full(s_, float('nan')).cuda()
+    dZ = [nan(nodes, C, h) if (wide or i >= 2) else None for i in range(4)]
+    dWg, dWc, dbg, dbc = nanf(*Wg.shape), nanf(*Wc.shape), nanf(2 * h), nanf(h)
+    ops_ = [cu(t) for t in (X, H, SX, SH, Tc, Wg, Wc, U, R, Cand, dHn, dBm)]
+    kb.cell_bwd_planar(*ops_, dZ, dWg, dbg, dWc, dbc)
+    for a, w in zip(dZ, dZ_w):
+        assert (a is None) == (w is None)
+        if w is not None:
+            _close(a, w)                      # (the twin keeps dY, R*H and d(R*H) in fp32; the kernel rounds the first two to bf16 as the stored planes are)
+    for a, w in ((dWg, dWg_w), (dWc, dWc_w), (dbg, dbg_w), (dbc, dbc_w)):
+        assert rel_err(a.cpu(), w) < BTOL
+    # the two separate launches on the same operands (dY and R*H as rounded planes, dRH rounded on the way)
+    dY, RH = (f(dHn) * f(U) * (1 - f(Cand) ** 2)).to(bf), (f(R) * f(H)).to(bf)
+    dRH, dXc, dWc2, dZ2, dWg2 = nan(nodes, C, h), nan(nodes, C, h), nanf(*Wc.shape), [nan(nodes, C, h) if (wide or i >= 2) else None for i in range(4)], nanf(*Wg.shape)
+    if wide:
+        kb.node_post_bwd(cu(X), cu(Tc), cu(Wc), cu(dY), cu(dBm), dXc, dWc2, None, X2=cu(RH), dX2=dRH)
+    else:
+        kb.node_post_bwd(cu(RH), cu(Tc), cu(Wc), cu(dY), cu(dBm), dRH, dWc2, None, X2=cu(X))
+    kb.cell_gates_bwd_planar(cu(X), cu(H), cu(SX), cu(SH), cu(Tc), cu(Wg), dRH, cu(Cand), cu(U), cu(R), cu(dHn), dZ2, dWg2, None, None)
+    assert rel_err(dWc, dWc2) < 1e-5 and rel_err(dWg, dWg2) < BTOL            # same operands for dWc; the gates see dRH in fp32 instead of bf16
+    _close(dZ[3], dZ2[3].float().cpu())
+    # bitwise reproducible, biases optional
+    dZ3, dWg3, dWc3 = [nan(nodes, C, h) if (wide or i >= 2) else None for i in range(4)], nanf(*Wg.shape), nanf(*Wc.shape)
+    kb.cell_bwd_planar(*ops_, dZ3, dWg3, None, dWc3, None)
+    assert torch.equal(dWg3, dWg) and torch.equal(dWc3, dWc) and torch.equal(dZ3[2], dZ[2])
+    # forward with the fused candidate projection and no R*H plane: same U, R, A, Bm as with the plane
+    bg, bc = rnd(2 * h), rnd(h)
+    outs = [[nan(nodes, C, h) for _ in range(5)] for _ in range(2)]
+    for o, with_rh in zip(outs, (True, False)):
+        kb.cell_gates_fwd_planar(cu(X), cu(H), cu(SX), cu(SH), cu(Tc), cu(Wg), cu(bg), o[0], o[1], o[2] if with_rh else None, post=(cu(Wc), cu(bc), o[3], o[4]))
+    for i in (0, 1, 3, 4):
+        assert torch.equal(outs[0][i], outs[1][i])
+    assert torch.isnan(outs[1][2]).all()
+
+
 @pytest.mark.parametrize('batch,grid,C,n_add,dual', [(2, (5, 5), 32, 3, True), (1, (4, 7), 64, 5, False), (2, (40, 56), 64, 0, True), (1, (1, 1), 32, 2, False)])
 def test_state_aggregations_bf16(hip, batch, grid, C, n_add, dual):
     """stc_spmm_sum_bf16 (gradient of a state from its pieces, optional blend backward), stc_spmm_blend_fwd_bf16 (Y = A + S.Bm
