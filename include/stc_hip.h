@@ -569,8 +569,9 @@ int stc_mix_grad_f32(const float* A, const float* B, double* partials, int32_t n
  * Forward: both matrices streamed once (one wave per output row); `gate` is kept for the backward.  Backward, from dG: db (D) =
  * dG (A - P) gate (1 - gate) -- the gradient of both biases --, dW_A = db (x) vec(A), dW_P = db (x) vec(P) (D, D, written once),
  * dP = dG (1 - gate) + W_P^T db and, when dA is not NULL, dA = dG gate + W_A^T db.  The column sums go through per-chunk partials
- * in the workspace and are added in a fixed order: bitwise reproducible.  Replaces two GEMVs (forward) and two outer products + one or
- * two transposed GEMVs (backward) of the autograd graph of :253-260. */
+ * in the workspace and are added in a fixed order: bitwise reproducible.  dW_A and dW_P may be NULL together (frozen weights: the two
+ * (D, D) outer products are then not written).  Replaces two GEMVs (forward) and two outer products + one or two transposed GEMVs
+ * (backward) of the autograd graph of :253-260. */
 size_t stc_mixed_fusion_workspace_bytes(int32_t D, int32_t want_dA);
 int stc_mixed_fusion_fwd_f32(const float* WA, const float* bA, const float* WP, const float* bP, const float* A, const float* P,
                              float* gate, float* G, int32_t D, void* stream);

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(MF_THREADS) void mixed_fusion_bwd_kernel(const floa
                 sp[c] = fmaf(xp[r][c], d, sp[c]);
                 if (WANT_DA) sa[c] = fmaf(xa[r][c], d, sa[c]);
             }
-            if (live) {
+            if (live && dWA) {                                   // (frozen weights: no gradient wanted -- dW_A, dW_P both null)
                 __builtin_nontemporal_store(d * a4, reinterpret_cast<v4f*>(dWA) + (size_t)(i + r) * D4 + j);
                 __builtin_nontemporal_store(d * p4, reinterpret_cast<v4f*>(dWP) + (size_t)(i + r) * D4 + j);
             }
@@ -165,7 +165,8 @@ extern "C" int stc_mixed_fusion_bwd_f32(const float* WA, const float* WP, const 
     STC_REQUIRE(D >= 0, STC_EINVAL, "stc_mixed_fusion_bwd_f32: negative size");
     if (D == 0) return STC_OK;
     STC_REQUIRE(D % 4 == 0, STC_EUNSUPPORTED, "stc_mixed_fusion_bwd_f32: D = n^2 = %d must be a multiple of 4", D);
-    STC_REQUIRE(WP && A && P && gate && dG && dWA && dWP && db && dP && (!dA || WA), STC_EINVAL, "stc_mixed_fusion_bwd_f32: null pointer");
+    STC_REQUIRE(WP && A && P && gate && dG && db && dP && (!dA || WA) && ((dWA == nullptr) == (dWP == nullptr)), STC_EINVAL,
+                "stc_mixed_fusion_bwd_f32: null pointer (dW_A and dW_P may be NULL together: frozen weights)");
     STC_REQUIRE(stc::aligned16(WP) && (!dA || stc::aligned16(WA)) && stc::aligned16(A) && stc::aligned16(P) && stc::aligned16(dWA) && stc::aligned16(dWP) && stc::aligned16(db), STC_EALIGN,
                 "stc_mixed_fusion_bwd_f32: matrices, A / P and db must be 16-byte aligned");
     STC_REQUIRE(workspace && stc::aligned16(workspace) && workspace_bytes >= stc_mixed_fusion_workspace_bytes(D, dA != nullptr), STC_EINVAL,

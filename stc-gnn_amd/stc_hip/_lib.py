@@ -1045,18 +1045,19 @@ class HipKernels:
         self._launch('stc_mixed_fusion_fwd_f32', A, _ptr(WA), _ptr(bA), _ptr(WP), _ptr(bP), _ptr(A), _ptr(P), _ptr(gate), _ptr(G), D, nbytes=8 * D * D)
         return gate, G
 
-    def mixed_fusion_bwd(self, WA, WP, A, P, gate, dG, want_dA):
-        """(dW_A, dW_P, db, dP, dA or None) from dG (``stc_mixed_fusion_bwd_f32``); db is the gradient of both biases."""
+    def mixed_fusion_bwd(self, WA, WP, A, P, gate, dG, want_dA, want_dW=True):
+        """(dW_A, dW_P, db, dP, dA or None) from dG (``stc_mixed_fusion_bwd_f32``); db is the gradient of both biases; ``want_dW=False``
+        (frozen weights): the two (D, D) gradients are neither allocated nor written (None, None)."""
         D = A.numel()
         for name, t in (('gate', gate), ('dG', dG), ('P', P)):
             self._f32('mixed_fusion.' + name, t, tuple(A.shape))
         self._same_device(WA, WP, A, P, gate, dG)
-        dWA, dWP = torch.empty_like(WA), torch.empty_like(WP)
+        dWA, dWP = (torch.empty_like(WA), torch.empty_like(WP)) if want_dW else (None, None)
         db, dP = torch.empty(D, dtype=torch.float32, device=A.device), torch.empty_like(A)
         dA = torch.empty_like(A) if want_dA else None
         ws = torch.empty(self.lib.stc_mixed_fusion_workspace_bytes(D, int(want_dA)) // 4, dtype=torch.float32, device=A.device)
         self._launch('stc_mixed_fusion_bwd_f32', A, _ptr(WA), _ptr(WP), _ptr(A), _ptr(P), _ptr(gate), _ptr(dG), _ptr(dWA), _ptr(dWP), _ptr(db), _ptr(dP), _ptr(dA),
-                     _ptr(ws), ws.numel() * 4, D, nbytes=(12 + (4 if want_dA else 0)) * D * D)
+                     _ptr(ws), ws.numel() * 4, D, nbytes=(4 + (8 if want_dW else 0) + (4 if want_dA else 0)) * D * D)
         return dWA, dWP, db, dP, dA
 
     # ---- planar cell convolutions of Chebyshev order K = 3 ------------------------------------------------

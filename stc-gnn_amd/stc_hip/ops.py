@@ -973,8 +973,8 @@ class _MixedFusion(torch.autograd.Function):
     def backward(ctx, dG):
         A, P, WA, WP, gate = ctx.saved_tensors
         want_dA = ctx.needs_input_grad[0]
-        dWA, dWP, db, dP, dA = kernels().mixed_fusion_bwd(WA.detach(), WP.detach(), A, P, gate, dG.contiguous(), want_dA)
         need = ctx.needs_input_grad
+        dWA, dWP, db, dP, dA = kernels().mixed_fusion_bwd(WA.detach(), WP.detach(), A, P, gate, dG.contiguous(), want_dA, want_dW=need[2] or need[4])
         return (dA if need[0] else None, dP if need[1] else None, dWA if need[2] else None, db if need[3] else None,
                 dWP if need[4] else None, db if need[5] else None)
 

@@ -1009,3 +1009,11 @@ def test_mixed_fusion(hip, n, needs_dA):
             assert got.grad is None
             continue
         assert rel_err(got.grad, want.grad) < 2e-5, name
+    # frozen weights: the two (n^2, n^2) gradients are neither allocated nor written; the other gradients are unchanged, bit for bit;
+    # an operand that is not 16-byte aligned (a view into a flat buffer) is refused by the predicate, not by the kernel
+    frozen = [t.detach().clone().requires_grad_(i in (1, 3, 5) or (i == 0 and needs_dA)) for i, t in enumerate(dev)]
+    (O2.mixed_fusion(*frozen) * R.cuda()).sum().backward()
+    assert frozen[2].grad is None and frozen[4].grad is None
+    assert torch.equal(frozen[1].grad, dev[1].grad) and torch.equal(frozen[3].grad, dev[3].grad)
+    flat = torch.zeros(WA.numel() + 1, device='cuda')
+    assert not O2.mixed_fusion_supported(dev[0], dev[1], flat[1:].view_as(WA), dev[3], dev[4], dev[5])

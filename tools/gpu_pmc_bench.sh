@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/gpurun_out && cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf $R/gpurun_out/pmcb_$c
-  timeout 1200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmcb_$c -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-unit-d3 ${BENCH_ARGS:-} > $R/gpurun_out/pmcb_$c.log 2>&1
+  timeout 1200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $R/gpurun_out/pmcb_$c -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-unit-d3 --no-extras ${BENCH_ARGS:-} > $R/gpurun_out/pmcb_$c.log 2>&1
   echo "pmc $c exit $?"; tail -1 $R/gpurun_out/pmcb_$c.log | cut -c1-300
 done
 cd $R/gpurun_out
@@ -33,7 +33,7 @@ for k, v in out.items():
     if 'FETCH_SIZE_KB_per_launch' in v and 'WRITE_SIZE_KB_per_launch' in v:
         v['hbm_bytes_per_launch'] = (2 * v['FETCH_SIZE_KB_per_launch'] + v['WRITE_SIZE_KB_per_launch']) * 1024
         res[k] = v
-json.dump(dict(csrc_sha=bench.csrc_sha(), config_key=config_key, command='python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-unit-d3 ' + os.environ.get('BENCH_ARGS', ''),
+json.dump(dict(csrc_sha=bench.csrc_sha(), config_key=config_key, command='python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-unit-d3 --no-extras ' + os.environ.get('BENCH_ARGS', ''),
                formula='hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE counts 64 B per 128-B request on gfx950 (MI355X_MICROARCH.md, HBM)',
                kernels=res), open('spmm_traffic_bench.json', 'w'), indent=1)
 for k, v in sorted(res.items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch'] * kv[1]['launches'])[:14]:

@@ -6,7 +6,7 @@ set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${TAG:-f32}
 mkdir -p $R/gpurun_out && cd /tmp && export TMPDIR=/tmp
-run() { n=$1; shift; rm -rf $R/gpurun_out/pmcm_$n; timeout 1200 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/gpurun_out/pmcm_$n -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline ${BENCH_ARGS:-} > $R/gpurun_out/pmcm_$n.log 2>&1; echo "pmc $n exit $?"; }
+run() { n=$1; shift; rm -rf $R/gpurun_out/pmcm_$n; timeout 1200 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $R/gpurun_out/pmcm_$n -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras ${BENCH_ARGS:-} > $R/gpurun_out/pmcm_$n.log 2>&1; echo "pmc $n exit $?"; }
 run sq SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVES
 run grbm GRBM_GUI_ACTIVE
 cd $R/gpurun_out
@@ -33,7 +33,7 @@ import bench
 a = bench.parse(os.environ.get('BENCH_ARGS', '').split())
 config_key = f'{a.storage}:{a.grid}:{a.categories}:{a.hidden}:{a.batch_per_gpu}:{a.order}:{a.layers}:{a.obs}:{a.pred}:{int(a.permute)}'
 json.dump(dict(csrc_sha=bench.csrc_sha(), config_key=config_key,
-               command='python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline ' + os.environ.get('BENCH_ARGS', ''),
+               command='python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras ' + os.environ.get('BENCH_ARGS', ''),
                definition='mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs); valu_busy = 4 SQ_ACTIVE_INST_VALU / the same; '
                           'SQ and GRBM counters in separate rocprofv3 --pmc passes over one step of the command',
                kernels=out), open(f'mfma_util_{sys.argv[1]}.json', 'w'), indent=1)

@@ -18,7 +18,7 @@ for step in "$@"; do
     tests:*) timeout -k 10 1100 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -x -k "${step#tests:}" > gpurun_out/pytest_sel.log 2>&1; rc=$?; tail -15 gpurun_out/pytest_sel.log ;;
     bench) timeout -k 10 900 python bench.py --gpus 1 --steps 20 --warmup 5 ${BENCH_ARGS:-} > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err; rc=$?
            python -c "import json;d=json.loads(open('gpurun_out/bench_default.json').read().strip().split('\n')[-1]);print('value',round(d['value'],3),'ms',round(d['ms_per_step'],2),'frac',round(d['roofline']['frac'],4),'dominant',d['roofline'].get('dominant',{}).get('frac'),'cpu',d.get('cpu_baseline',{}).get('value'))" ;;
-    quick) timeout -k 10 900 python bench.py --steps ${BENCH_STEPS:-2} --warmup 1 --no-cpu-baseline ${BENCH_ARGS:-} > gpurun_out/bench_quick.log 2>&1; rc=$?
+    quick) timeout -k 10 900 python bench.py --steps ${BENCH_STEPS:-2} --warmup 1 --no-cpu-baseline --no-extras ${BENCH_ARGS:-} > gpurun_out/bench_quick.log 2>&1; rc=$?
            python - <<'PY'
 import json
 d = json.loads(open('gpurun_out/bench_quick.log').read().strip().split('\n')[-1])
@@ -33,7 +33,7 @@ PY
              python -c "import json,sys;d=json.loads(open('gpurun_out/preset_$n.json').read().strip().split('\n')[-1]);print('$p',round(d['value'],2),d['unit'],round(d['ms_per_step'],3),'ms')" || rc=1
            done ;;
     stats) cd /tmp && export TMPDIR=/tmp; rm -rf $R/gpurun_out/prof
-           timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline ${BENCH_ARGS:-} > $R/gpurun_out/prof.log 2>&1; rc=$?
+           timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras ${BENCH_ARGS:-} > $R/gpurun_out/prof.log 2>&1; rc=$?
            cd $R; f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/kernel_stats.csv && head -12 gpurun_out/kernel_stats.csv | cut -c1-200
            find gpurun_out/prof -name "*.csv" -size +4M -delete ;;
     traffic) bash tools/gpu_pmc_bench.sh; rc=$? ;;
