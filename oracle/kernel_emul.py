@@ -41,6 +41,10 @@ class _Bf16Emulated:
     def __init__(self, em):
         self.em = em
 
+    def cell_bwd_planar_supported(self, Cc, h, cin=16):
+        """As ``_Bf16Planar``: the one-launch backward on bf16 planes exists for C = 32 (both input widths) and for C = 64 with the wide input."""
+        return self.em.cell_bwd_planar_supported(Cc, h) and (cin == h or Cc == 32)
+
     def __getattr__(self, name):
         fn = getattr(self.em, name)
         pairs = []
