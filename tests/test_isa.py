@@ -35,6 +35,26 @@ def test_no_scratch_access_inside_the_node_loops(tmp_path, source):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason='hipcc not present')
+def test_one_launch_bf16_cell_backward_fits_the_register_file(tmp_path):
+    """csrc/stc_node_bf16.hip, cell_bwd_bf16_kernel: one wave per SIMD with the next node's operands requested a node ahead.  The C = 32 forms
+    must not touch scratch; the C = 64 wide form is at the edge of the 512-register file (2 scratch accesses per node as built: bounded here,
+    so that a change that tips it over -- the first version had 22 -- is seen); the C = 64 narrow form (62 per node) must not be built at all."""
+    out = tmp_path / 'bf16.s'
+    csrc = os.path.join(REPO, 'stc-gnn_amd', 'csrc')
+    subprocess.check_call([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', f'-I{os.path.join(REPO, "include")}',
+                           '-S', '--cuda-device-only', '-o', str(out), os.path.join(csrc, 'stc_node_bf16.hip')], stderr=subprocess.DEVNULL)
+    report = subprocess.check_output(['python3', os.path.join(REPO, 'tools', 'isa_scratch.py'), str(out), 'cell_bwd_bf16_kernel'], text=True)
+    kernels = re.split(r'^(_Z\S+)\n', report, flags=re.M)[1:]
+    got = {}
+    for name, lines in zip(kernels[0::2], kernels[1::2]):
+        form = re.search(r'cell_bwd_bf16_kernelILi(\d)ELi(\d)E', name).groups()
+        got[form] = max(int(n) for n in re.findall(r'node loop(?: \d+/\d+)?: \d+ instr, \d+ mfma, (\d+) scratch ops', lines))
+    assert set(got) == {('1', '0'), ('1', '1'), ('2', '0')}, got
+    assert got[('1', '0')] == 0 and got[('1', '1')] == 0 and got[('2', '0')] <= 4, got
+    shutil.rmtree(tmp_path, ignore_errors=True)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason='hipcc not present')
 def test_patch_aggregation_keeps_two_workgroups_per_cu_and_an_lds_only_barrier(tmp_path):
     """csrc/stc_spmm_patch.hip is built so that a chunk's result stores stay in flight under the next chunk's staging and two workgroups share a
     compute unit.  Checked in the assembly of all 24 forms (6 table widths x {plain, Y0} x {fp32, bf16}): at most 256 registers (a refactoring
