@@ -413,3 +413,43 @@ def test_large_parameters_reduce_outside_the_bucket(tmp_path):
     for name, w in want.items():
         assert torch.equal(got[0][name], got[1][name]), name
         assert float((got[0][name] - w).abs().max()) <= 5e-6 * max(float(w.abs().max()), 1e-3), name
+
+
+def _worker_locality_failure(rank, world, port, out_dir):
+    for p in (REPO, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from stc_hip import CsrGraph, dist as sdist
+    sdist.init_from_env(backend='gloo')
+    graph = CsrGraph.queen_grid(9, 9, normalize=True, permute_seed=3)            # (> 64 nodes: the renumbering analysis runs)
+    if rank == 0:
+        def broken():
+            raise ValueError('no renumbering today')
+        graph.locality_order = broken
+    try:
+        graph.with_locality()
+        outcome = 'returned'
+    except ValueError as e:                                                       # rank 0: its own exception
+        outcome = f'ValueError: {e}'
+    except RuntimeError as e:                                                     # the others: told by the status word, not left in the broadcast
+        outcome = f'RuntimeError: {e}'
+    # a graph only THIS rank uses: the analysis without the collective
+    alone = CsrGraph.queen_grid(9, 9, normalize=True, permute_seed=4)
+    g2, order = alone.with_locality(collective=False) if rank == 1 else (None, None)
+    torch.save({'outcome': outcome, 'alone': None if order is None else int(order.size)}, os.path.join(out_dir, f'rank{rank}.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_failed_locality_analysis_on_rank_0_raises_on_every_rank(tmp_path):
+    """``CsrGraph.with_locality`` is a collective on the default group (rank 0 computes the node renumbering, the others receive it): an
+    exception on rank 0 must reach the other ranks as an exception, not as a hang in the broadcast; ``collective=False`` is the form for a
+    graph that only some ranks use."""
+    port = _free_port()
+    mp.spawn(_worker_locality_failure, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(os.path.join(tmp_path, f'rank{r}.pt')) for r in (0, 1))
+    assert r0['outcome'] == 'ValueError: no renumbering today'
+    assert r1['outcome'].startswith('RuntimeError: CsrGraph: rank 0 failed')
+    assert r0['alone'] is None and r1['alone'] == 81
