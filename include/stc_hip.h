@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define STC_ABI_VERSION 26
+#define STC_ABI_VERSION 27
 #define STC_MAX_K 4          /* highest Chebyshev order (Ks, Kc) the node kernels accept */
 
 /* Operand formats of the split-operand matrix-core kernels (C = 32 / 64, hidden 16).  Every fp32 operand is split into low-precision
@@ -140,6 +140,28 @@ int stc_patch_spmm_bf16(const int32_t* patch_src, const int32_t* patch_rows, con
                         const uint8_t* patch_idx, const float* patch_val, int32_t n_patches, int32_t width,
                         int32_t n_rows, int32_t n_cols, const void* X, const void* Y0, void* Y,
                         int32_t batch, int32_t F, float alpha, float beta, void* stream);
+
+/* Two-ring patch aggregation (csrc/stc_spmm_ring2.hip; ABI v27): the gradient of a planar cell's state from its pieces and the transpose
+ * aggregation of the candidate's gradient in ONE launch -- what stc_spmm_sum_f32 (with U, Cand, dY) followed by the plain aggregation of dY
+ * compute in two, without the dY plane:
+ *     Y = sum_k add[k] + S.(A [+ A2])        Z = S.(Y * U * (1 - Cand^2))            planes (batch, n_rows, C, 16) fp32, contiguous
+ * S (square, n_rows x n_rows) comes as a host-built plan over the patches of the patch form (stc_patch_spmm_f32):
+ *   l2_rows  (n_patches, STC_RING2_SECOND)                 the rows staged per patch: every column the first ring's rows touch, padded with repeats
+ *   l1_rows  (n_patches, STC_RING2_FIRST)                  the first ring: the patch's own rows (bit 30 set) and every column they touch; -1 = empty slot
+ *   int_rows (n_patches, STC_RING2_INTERIOR)               the patch's own rows, -1 = empty; every row of S is in exactly one patch
+ *   t1 (n_patches, STC_RING2_FIRST, STC_RING2_WIDTH, 2)    per entry of a first-ring row: (512 x position of its column in l2_rows, value bits);
+ *   t2 (n_patches, STC_RING2_INTERIOR, STC_RING2_WIDTH, 2) per entry of an own row: (512 x slot of its column in l1_rows, value bits); rows
+ *                                                          shorter than the width end in zero-valued repeats of their last entry
+ * Rows of more than STC_RING2_WIDTH entries, patches whose rings exceed the sizes: no plan (the two launches remain).  n_add <= 5. */
+#define STC_RING2_INTERIOR 32
+#define STC_RING2_FIRST 64
+#define STC_RING2_SECOND 96
+#define STC_RING2_WIDTH 8
+int stc_ring2_sum_f32(const int32_t* l2_rows, const int32_t* l1_rows, const int32_t* int_rows, const int32_t* t1, const int32_t* t2,
+                      int32_t n_patches, int32_t n_rows,
+                      const float* A, const float* A2, int32_t n_add, const float* const* add,
+                      const float* U, const float* Cand, float* Y, float* Z,
+                      int32_t batch, int32_t C, int32_t h, void* stream);
 
 /* bf16-storage node kernel (2-mode product + concat + projection + bias, STC_GNN.py:38-45) and its backward: the slabs
  * Z_n (nodes, C, L), the output Y / its gradient dY (nodes, C, Ho) and the slab gradients dZ_n are bf16 (void*); Tc, W,

@@ -223,6 +223,23 @@ class EmulatedKernels:
         self.csr_spmm(rowptr, colidx, val, n_rows, n_cols, X.float(), None if Y0 is None else Y0.float(), out, alpha, beta)
         Y.copy_(out.to(torch.bfloat16))
 
+    # ---- stc_ring2_sum_f32: state-gradient sum + blend backward + the transpose aggregation of dY, without the dY plane
+    RING2_MAX_ADD = 5
+
+    def ring2_sum(self, rowptr, colidx, val, ring2, X, X2, addends, U, Cand, Y, Z):
+        B, n, Cc, h = Y.shape
+        v3 = lambda t: t.reshape(B, n, Cc * h)
+        agg = torch.empty(B, n, Cc * h, dtype=Y.dtype)
+        self.csr_spmm(rowptr, colidx, val, n, n, v3(X if X2 is None else X + X2), None, agg, 1.0, 0.0)
+        dh = agg.view(B, n, Cc, h)
+        for t in addends:
+            dh = dh + t
+        Y.copy_(dh)
+        dY = dh * U * (1 - Cand * Cand)
+        out = torch.empty(B, n, Cc * h, dtype=Y.dtype)
+        self.csr_spmm(rowptr, colidx, val, n, n, v3(dY), None, out, 1.0, 0.0)
+        Z.copy_(out.view(B, n, Cc, h))
+
     # ---- stc_csr_sddmm_f32: gradient of the 1-mode product w.r.t. the graph values (autograd of :37)
     def csr_sddmm(self, rowptr, colidx, n_rows, n_cols, A, Bm, out, alpha, accumulate):
         rows = _expand_rows(rowptr)

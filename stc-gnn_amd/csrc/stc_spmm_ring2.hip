@@ -1,0 +1,201 @@
+// Two-ring patch aggregation: the gradient of a state from its pieces AND the transpose aggregation of the candidate's gradient that
+// follows it, in one launch (reference STC_GNN.py:65-79 through autograd, planar cells; the two launches it replaces: stc_spmm_sum_f32
+// with its blend epilogue, then the plain stc_patch_spmm_f32 of dY):
+//
+//     dH  = sum_k D_k + S.(A [+ A2])          the state's gradient: direct planes + the aggregation of the aggregated planes
+//     dY  = dH * U * (1 - Cand^2)             the candidate pre-activation's gradient (GRU blend + tanh backward) -- NEVER written
+//     dBm = S.dY                              what the post-aggregation candidate backward needs beside dY (dY itself it re-forms)
+//
+// A written plane costs the metric step twice what a read one does: dY existed only to cross the launch boundary
+// between the two aggregations.  Here a workgroup owns a PATCH of <= 32 interior rows (the tiles of stc_spmm_patch.hip), forms dH and dY
+// for the patch's FIRST RING (the interior and every row the interior's S-rows touch: <= 64 rows, 60 on a 4 x 8 tile of the 8-neighbour
+// grid) out of the SECOND ring's rows of A staged in LDS (<= 96 rows), parks dY in LDS and aggregates it for the interior.  The first
+// ring's halo is computed redundantly (1.9 x the gathers; its addends come from L2, where the neighbouring patches leave them).
+//
+// Column chunks of 32 float4 (512 bytes of a row): half a wave per row, 96 x 512 B = 48 KiB of LDS + 6 KiB of tables, two workgroups per
+// compute unit.  Per chunk: staged registers -> LDS | next chunk requested | first ring: gather, addends, dY -> registers | dY -> LDS
+// (over the staged rows) | interior: gather, store.  Tables ((LDS offset, value) pairs) sit in LDS and are read as broadcasts.
+#include "stc_common.h"
+
+#include <atomic>
+
+namespace {
+
+constexpr int R2_THREADS = 256, R2_WAVES = R2_THREADS / 64;
+constexpr int R2_INT = STC_RING2_INTERIOR;       // interior rows per patch (32)
+constexpr int R2_L1 = STC_RING2_FIRST;           // first-ring slots, interior included (64)
+constexpr int R2_L2 = STC_RING2_SECOND;          // second-ring rows staged (96)
+constexpr int R2_W = STC_RING2_WIDTH;            // table entries per row (8)
+constexpr int R2_Q = 32;                         // float4 pieces per chunk and row: half a wave
+constexpr int R2_STAGE = R2_L2 / (2 * R2_WAVES); // rows a half-wave stages per chunk (12)
+constexpr int R2_S1 = R2_L1 / (2 * R2_WAVES);    // first-ring slots per half-wave (8)
+constexpr int R2_S2 = R2_INT / (2 * R2_WAVES);   // interior rows per half-wave (4)
+constexpr int R2_MAX_ADD = 5;
+
+using v4f = __attribute__((ext_vector_type(4))) float;
+
+struct Ring2Plan {
+    const int32_t *l2_rows, *l1_rows, *int_rows;       // (P, 96) staged rows; (P, 64) first-ring rows (-1: empty; bit 30: interior); (P, 32) interior rows (-1: empty)
+    const int32_t *t1, *t2;                            // (P, 64, 8, 2) / (P, 32, 8, 2): (LDS byte offset of the source row, value bits)
+    int n_patches;
+};
+
+struct Ring2Args {
+    Ring2Plan pl;
+    const v4f *A, *A2;                                 // gathered operands (B, n, F4)
+    const v4f* add[R2_MAX_ADD];
+    int n_add;
+    const v4f *U, *Cand;
+    v4f *Y, *Z;                                        // dH, dBm
+    int n, F4;
+};
+
+__device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <bool HAS_A2, int NADD>
+__global__ __launch_bounds__(R2_THREADS, 2) void ring2_sum_kernel(Ring2Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    v4f* tile = reinterpret_cast<v4f*>(lds);                                           // [96][32] staged rows, then [64][32] dY
+    int2* tab1 = reinterpret_cast<int2*>(lds + (size_t)R2_L2 * R2_Q * 16);             // [64][8]
+    int2* tab2 = tab1 + R2_L1 * R2_W;                                                  // [32][8]
+
+    const int p = stc_xcd_tile(blockIdx.x, a.pl.n_patches);
+    if (p < 0) return;
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, q = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hw = wave * 2 + half;                                                    // half-wave 0..7: rows / slots hw, hw + 8, ...
+    const int n_chunks = a.F4 / R2_Q;
+
+    for (int e = tid; e < R2_L1 * R2_W; e += R2_THREADS) tab1[e] = reinterpret_cast<const int2*>(a.pl.t1)[(size_t)p * R2_L1 * R2_W + e];
+    for (int e = tid; e < R2_INT * R2_W; e += R2_THREADS) tab2[e] = reinterpret_cast<const int2*>(a.pl.t2)[(size_t)p * R2_INT * R2_W + e];
+
+    int stage_row[R2_STAGE], l1_row[R2_S1], in_row[R2_S2];
+#pragma unroll
+    for (int k = 0; k < R2_STAGE; ++k) stage_row[k] = a.pl.l2_rows[(size_t)p * R2_L2 + k * 8 + hw];
+#pragma unroll
+    for (int i = 0; i < R2_S1; ++i) l1_row[i] = a.pl.l1_rows[(size_t)p * R2_L1 + i * 8 + hw];
+#pragma unroll
+    for (int i = 0; i < R2_S2; ++i) in_row[i] = a.pl.int_rows[(size_t)p * R2_INT + i * 8 + hw];
+
+    const size_t base = (size_t)b * a.n * a.F4 + q;
+    v4f st[R2_STAGE];
+    auto request = [&](int chunk) {
+#pragma unroll
+        for (int k = 0; k < R2_STAGE; ++k) {
+            const size_t at = base + (size_t)stage_row[k] * a.F4 + chunk * R2_Q;
+            st[k] = a.A[at];
+            if (HAS_A2) st[k] += a.A2[at];
+        }
+    };
+    request(0);
+    for (int chunk = 0; chunk < n_chunks; ++chunk) {
+        if (chunk) lds_only_barrier();                                                 // the previous chunk's interior sums are done with the tile
+#pragma unroll
+        for (int k = 0; k < R2_STAGE; ++k) tile[(k * 8 + hw) * R2_Q + q] = st[k];
+        lds_only_barrier();                                                            // (the first chunk: the tables are in place too)
+        if (chunk + 1 < n_chunks) request(chunk + 1);
+        // ---- first ring: dH = addends + S.A out of the tile; dY = dH U (1 - Cand^2)
+        v4f dy[R2_S1];
+#pragma unroll
+        for (int i = 0; i < R2_S1; ++i) {
+            const int slot = i * 8 + hw, row = l1_row[i];
+            const bool live = row >= 0, interior = live && (row & (1 << 30));
+            const size_t at = base + (size_t)(live ? (row & 0x3FFFFFFF) : 0) * a.F4 + chunk * R2_Q;
+            v4f ad[NADD > 0 ? NADD : 1];
+#pragma unroll
+            for (int k = 0; k < NADD; ++k) ad[k] = a.add[k][at];
+            const v4f u = a.U[at], cd = a.Cand[at];
+            v4f acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < R2_W; ++w) {
+                const int2 t = tab1[slot * R2_W + w];
+                const v4f x = *reinterpret_cast<const v4f*>(lds + t.x + q * 16);
+                const float v = __int_as_float(t.y);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c] = fmaf(v, x[c], acc[c]);
+            }
+            v4f dh = acc;
+#pragma unroll
+            for (int k = 0; k < NADD; ++k) dh += ad[k];
+            if (interior) __builtin_nontemporal_store(dh, a.Y + at);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dy[i][c] = dh[c] * u[c] * (1.f - cd[c] * cd[c]);
+        }
+        lds_only_barrier();                                                            // every wave is done with the staged rows
+#pragma unroll
+        for (int i = 0; i < R2_S1; ++i) tile[(i * 8 + hw) * R2_Q + q] = dy[i];
+        lds_only_barrier();
+        // ---- interior: dBm = S.dY out of the tile
+#pragma unroll
+        for (int i = 0; i < R2_S2; ++i) {
+            const int r = i * 8 + hw, row = in_row[i];
+            v4f acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < R2_W; ++w) {
+                const int2 t = tab2[r * R2_W + w];
+                const v4f x = *reinterpret_cast<const v4f*>(lds + t.x + q * 16);
+                const float v = __int_as_float(t.y);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c] = fmaf(v, x[c], acc[c]);
+            }
+            if (row >= 0) __builtin_nontemporal_store(acc, a.Z + base + (size_t)row * a.F4 + chunk * R2_Q);
+        }
+    }
+}
+
+template <bool HAS_A2>
+int launch_ring2(const Ring2Args& a, int batch, hipStream_t s) {
+    const size_t lds = (size_t)R2_L2 * R2_Q * 16 + (size_t)(R2_L1 + R2_INT) * R2_W * sizeof(int2);
+    using Kernel = void (*)(Ring2Args);
+    Kernel kern = nullptr;
+    switch (a.n_add) {
+        case 0: kern = ring2_sum_kernel<HAS_A2, 0>; break;
+        case 1: kern = ring2_sum_kernel<HAS_A2, 1>; break;
+        case 2: kern = ring2_sum_kernel<HAS_A2, 2>; break;
+        case 3: kern = ring2_sum_kernel<HAS_A2, 3>; break;
+        case 4: kern = ring2_sum_kernel<HAS_A2, 4>; break;
+        default: kern = ring2_sum_kernel<HAS_A2, 5>; break;
+    }
+    static_assert((size_t)R2_L2 * R2_Q * 16 + (size_t)(R2_L1 + R2_INT) * R2_W * sizeof(int2) <= 64 * 1024, "within the default dynamic-LDS limit: no attribute to set");
+    const int per = (a.pl.n_patches + stc::kNumXcd - 1) / stc::kNumXcd;
+    hipLaunchKernelGGL(kern, dim3(per * stc::kNumXcd, batch), dim3(R2_THREADS), lds, s, a);
+    STC_LAUNCH_CHECK("stc_ring2_sum_f32 launch");
+    return STC_OK;
+}
+
+}  // namespace
+
+extern "C" int stc_ring2_sum_f32(const int32_t* l2_rows, const int32_t* l1_rows, const int32_t* int_rows, const int32_t* t1, const int32_t* t2,
+                                 int32_t n_patches, int32_t n_rows,
+                                 const float* A, const float* A2, int32_t n_add, const float* const* add,
+                                 const float* U, const float* Cand, float* Y, float* Z,
+                                 int32_t batch, int32_t C, int32_t h, void* stream) {
+    STC_REQUIRE(h == 16 && C >= 1 && (C * h) % (4 * R2_Q) == 0, STC_EUNSUPPORTED, "stc_ring2_sum_f32: rows of C * h = %d floats (hidden 16, whole 512-byte chunks)", C * h);
+    STC_REQUIRE(n_add >= 0 && n_add <= R2_MAX_ADD, STC_ELIMIT, "stc_ring2_sum_f32: 0..%d addends, got %d", R2_MAX_ADD, n_add);
+    STC_REQUIRE(batch >= 0 && batch <= 65535 && n_rows >= 0 && n_patches >= 0, STC_EINVAL, "stc_ring2_sum_f32: bad sizes");
+    if (batch == 0 || n_rows == 0) return STC_OK;
+    STC_REQUIRE(n_patches >= 1 && (long long)n_patches * R2_INT >= n_rows, STC_EINVAL, "stc_ring2_sum_f32: %d patches cannot cover %d rows", n_patches, n_rows);
+    STC_REQUIRE(l2_rows && l1_rows && int_rows && t1 && t2 && A && U && Cand && Y && Z && (n_add == 0 || add), STC_EINVAL, "stc_ring2_sum_f32: null pointer");
+    STC_REQUIRE(stc::aligned16(A) && (!A2 || stc::aligned16(A2)) && stc::aligned16(U) && stc::aligned16(Cand) && stc::aligned16(Y) && stc::aligned16(Z) &&
+                    (reinterpret_cast<uintptr_t>(t1) % 8 == 0) && (reinterpret_cast<uintptr_t>(t2) % 8 == 0),
+                STC_EALIGN, "stc_ring2_sum_f32: planes must be 16-byte aligned (tables 8-byte)");
+    STC_REQUIRE(Y != A && Y != A2 && Z != A && Z != A2 && Y != Z, STC_EINVAL, "stc_ring2_sum_f32: results must not alias the gathered operands or each other");
+    Ring2Args a{};
+    a.pl = Ring2Plan{l2_rows, l1_rows, int_rows, t1, t2, n_patches};
+    a.A = reinterpret_cast<const v4f*>(A);
+    a.A2 = reinterpret_cast<const v4f*>(A2);
+    a.n_add = n_add;
+    for (int i = 0; i < n_add; ++i) {
+        STC_REQUIRE(add[i] && stc::aligned16(add[i]) && add[i] != Y && add[i] != Z, STC_EINVAL, "stc_ring2_sum_f32: addend %d null, misaligned or aliasing a result", i);
+        a.add[i] = reinterpret_cast<const v4f*>(add[i]);
+    }
+    a.U = reinterpret_cast<const v4f*>(U);
+    a.Cand = reinterpret_cast<const v4f*>(Cand);
+    a.Y = reinterpret_cast<v4f*>(Y);
+    a.Z = reinterpret_cast<v4f*>(Z);
+    a.n = n_rows;
+    a.F4 = C * h / 4;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return A2 ? launch_ring2<true>(a, batch, s) : launch_ring2<false>(a, batch, s);
+}

@@ -21,7 +21,7 @@ from .graph import is_full_pattern
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG_ROOT, 'libstc_hip.so')
-ABI_VERSION = 26
+ABI_VERSION = 27
 FMT_BF16X3, FMT_F16X2 = 0, 1          # STC_FMT_* of include/stc_hip.h: operand formats of the split-operand matrix-core kernels
 MAX_K = 4
 SPMM_SUM_MAX_ADD = 8     # = STC_SPMM_SUM_MAX_ADD of include/stc_hip.h
@@ -30,7 +30,7 @@ PATCH_ROWS, PATCH_MAX_SRC = 32, 64          # = STC_PATCH_ROWS, STC_PATCH_MAX_SR
 #: every symbol ``include/stc_hip.h`` declares (the CPU test-suite checks the .so exports them all)
 EXPORTS = (
     'stc_version', 'stc_last_error',
-    'stc_csr_spmm_f32', 'stc_bcsr_spmm_f32', 'stc_patch_spmm_f32', 'stc_patch_spmm_bf16', 'stc_csr_spmm_bf16', 'stc_bcsr_spmm_bf16', 'stc_bdg_node_bf16_supported', 'stc_bdg_node_fwd_bf16', 'stc_bdg_node_bwd_bf16',
+    'stc_csr_spmm_f32', 'stc_bcsr_spmm_f32', 'stc_patch_spmm_f32', 'stc_patch_spmm_bf16', 'stc_ring2_sum_f32', 'stc_csr_spmm_bf16', 'stc_bcsr_spmm_bf16', 'stc_bdg_node_bf16_supported', 'stc_bdg_node_fwd_bf16', 'stc_bdg_node_bwd_bf16',
     'stc_cell_planar_bf16_supported', 'stc_cell_gates_fwd_planar_bf16', 'stc_cell_gates_bwd_planar_bf16', 'stc_bdg_node_post_bwd_bf16',
     'stc_cell_bwd_planar_bf16_supported', 'stc_cell_bwd_planar_bf16',
     'stc_spmm_blend_fwd_bf16', 'stc_spmm_sum_bf16', 'stc_gru_blend_bwd_bf16', 'stc_head_fwd_bf16', 'stc_head_bwd_bf16',
@@ -93,6 +93,7 @@ def _declare(lib):
         'stc_cell_gates_fwd_planar_bf16': [_p] * 14 + [_i64, _i32, _i32, _i32, _p],
         'stc_cell_gates_bwd_planar_bf16': [_p] * 11 + [C.POINTER(_p), _p, _p, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _p],
         'stc_cell_bwd_planar_bf16': [_p] * 20 + [_p, C.c_size_t, _i64, _i32, _i32, _i32, _p],
+        'stc_ring2_sum_f32': [_p] * 5 + [_i32, _i32, _p, _p, _i32, C.POINTER(_p), _p, _p, _p, _p, _i32, _i32, _i32, _p],
         'stc_bdg_node_post_bwd_bf16': [_p] * 11 + [C.c_size_t, _i64, _i32, _i32, _i32, _p],
         'stc_spmm_blend_fwd_bf16': [_p] * 6 + [_i32, _i32] + [_p] * 6 + [_i32] * 3 + [_p],
         'stc_spmm_sum_bf16': [_p] * 6 + [_i32, _i32, _p, _p, _i32, C.POINTER(_p), _p, _p, _p, _p, _i32, _i32, _i32, _p],
@@ -516,6 +517,31 @@ class HipKernels:
         self._launch('stc_spmm_sum_f32', Y, *g, n, n, _ptr(X), _ptr(X2), float(alpha), len(addends), ptrs, lds, offs, scales, _ptr(Y), _ptr(U), _ptr(Cand), _ptr(dY),
                      _ptr(amax), 0 if amax is None else amax.numel(), B, Cc, h,
                      nbytes=colidx.numel() * 8 + 4 * (n + 1) + 4 * B * n * Cc * h * (2 + (X2 is not None) + len(addends) + (3 if blend else 0)))
+
+    RING2_MAX_ADD = 5
+
+    def ring2_sum(self, rowptr, colidx, val, ring2, X, X2, addends, U, Cand, Y, Z):
+        """Y = sum(addends) + S.(X [+ X2]) and Z = S.(Y * U * (1 - Cand^2)) on (B, n, C, 16) state tensors in one launch (stc_ring2_sum_f32):
+        the state-gradient sum with its blend backward AND the transpose aggregation of the candidate's gradient, without the dY plane.
+        ``ring2`` = (l2_rows, l1_rows, int_rows, t1, t2) of ``graph._ring2_plan`` for S; the CSR arrays are what the CPU twin uses."""
+        B, n, Cc, h = Y.shape
+        for name, t in (('Y', Y), ('Z', Z), ('X', X), ('U', U), ('Cand', Cand)) + ((('X2', X2),) if X2 is not None else ()):
+            self._f32('ring2_sum.' + name, t, (B, n, Cc, h))
+        if len(addends) > self.RING2_MAX_ADD:
+            raise StcError(f'ring2_sum: at most {self.RING2_MAX_ADD} addends, got {len(addends)}')
+        ptrs = (_p * self.RING2_MAX_ADD)()
+        for i, t in enumerate(addends):
+            self._f32(f'ring2_sum.add{i}', t, (B, n, Cc, h))
+            ptrs[i] = t.data_ptr()
+        l2, l1, own, t1, t2 = ring2
+        n_p = l2.shape[0]
+        for name, t, shape in (('l2_rows', l2, (n_p, 96)), ('l1_rows', l1, (n_p, 64)), ('int_rows', own, (n_p, 32)), ('t1', t1, (n_p, 64, 8, 2)), ('t2', t2, (n_p, 32, 8, 2))):
+            if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.int32 or not t.is_contiguous() or tuple(t.shape) != shape:
+                raise StcError(f'ring2_sum.{name}: expected a contiguous int32 ROCm tensor of shape {shape}')
+        self._same_device(l2, l1, own, t1, t2, X, X2, U, Cand, Y, Z, *addends)
+        self._launch('stc_ring2_sum_f32', Y, _ptr(l2), _ptr(l1), _ptr(own), _ptr(t1), _ptr(t2), n_p, n, _ptr(X), _ptr(X2), len(addends), ptrs,
+                     _ptr(U), _ptr(Cand), _ptr(Y), _ptr(Z), B, Cc, h,
+                     nbytes=colidx.numel() * 8 + 4 * (n + 1) + 4 * B * n * Cc * h * (1 + (X2 is not None) + len(addends) + 2 + 2))
 
     def csr_sddmm(self, rowptr, colidx, n_rows, n_cols, A, Bm, out, alpha, accumulate):
         B, nr, F = A.shape

@@ -241,7 +241,64 @@ def _patch_tables(rpl, cil, val, n, patches, max_deg):
                 first = r % PATCH_WAVES
                 pt_rows[p, r], pt_cnt[p, r], pt_idx[p, r], pt_val[p, r] = pt_rows[p, first], pt_cnt[p, first], pt_idx[p, first], pt_val[p, first]
     return dict(pt_nsrc=pt_nsrc, pt_src=pt_src, pt_rows=pt_rows, pt_cnt=pt_cnt, pt_idx=pt_idx, pt_val=pt_val,
-                fetch=n_src / n, rows_per_patch=n / n_p)
+                fetch=n_src / n, rows_per_patch=n / n_p, groups=[rows for rows, _ in patches])
+
+
+RING2_INTERIOR, RING2_FIRST, RING2_SECOND, RING2_WIDTH = 32, 64, 96, 8       # = STC_RING2_* of include/stc_hip.h
+
+
+def _ring2_plan(rowptr: np.ndarray, colidx: np.ndarray, val: np.ndarray, groups):
+    """Two-ring form of a square CSR matrix S over the patches ``groups`` of its patch plan, for ``stc_ring2_sum_f32`` (include/stc_hip.h): per
+    patch its own rows, its first ring (own rows + every column they touch, <= 64), the second ring (every column the first ring's rows
+    touch, <= 96) and (LDS offset, value) tables of width 8 for both levels; None when a ring or a row does not fit (the two launches remain).
+    On the 8-neighbour grid in 4 x 8 tiles: 32 / 60 / 96 rows."""
+    rpl, cil = rowptr.astype(np.int64).tolist(), colidx.tolist()
+    n_p = len(groups)
+    l2 = np.zeros((n_p, RING2_SECOND), dtype=np.int32)
+    l1 = np.full((n_p, RING2_FIRST), -1, dtype=np.int32)
+    own = np.full((n_p, RING2_INTERIOR), -1, dtype=np.int32)
+    t1 = np.zeros((n_p, RING2_FIRST, RING2_WIDTH, 2), dtype=np.int32)
+    t2 = np.zeros((n_p, RING2_INTERIOR, RING2_WIDTH, 2), dtype=np.int32)
+    bits = np.asarray(val, dtype=np.float32).view(np.int32)
+    chunk_bytes = 32 * 16                              # one row of the kernel's LDS tile: 32 float4
+
+    def fill(table, r, a, b, pos):
+        k = b - a
+        if k:
+            table[r, :k, 0] = [pos[c] * chunk_bytes for c in cil[a:b]]
+            table[r, :k, 1] = bits[a:b]
+            table[r, k:, 0] = table[r, k - 1, 0]        # the tail: zero-valued repeats of the last entry (bits 0 = 0.0f)
+
+    for p, rows in enumerate(groups):
+        if len(rows) > RING2_INTERIOR:
+            return None
+        first = {u: i for i, u in enumerate(rows)}      # slot of every first-ring row: own rows lead
+        for u in rows:
+            if rpl[u + 1] - rpl[u] > RING2_WIDTH:
+                return None
+            for c in cil[rpl[u]:rpl[u + 1]]:
+                if c not in first:
+                    first[c] = len(first)
+        if len(first) > RING2_FIRST:
+            return None
+        second = {}
+        for u in first:
+            if rpl[u + 1] - rpl[u] > RING2_WIDTH:
+                return None
+            for c in cil[rpl[u]:rpl[u + 1]]:
+                if c not in second:
+                    second[c] = len(second)
+        if len(second) > RING2_SECOND:
+            return None
+        l2[p] = next(iter(second), 0)
+        l2[p, :len(second)] = list(second)
+        for u, slot in first.items():
+            l1[p, slot] = u | (1 << 30) if slot < len(rows) else u
+            fill(t1[p], slot, rpl[u], rpl[u + 1], second)
+        for r, u in enumerate(rows):
+            own[p, r] = u
+            fill(t2[p], r, rpl[u], rpl[u + 1], first)
+    return dict(r2_l2=l2, r2_l1=l1, r2_own=own, r2_t1=t1, r2_t2=t2)
 
 
 class CsrGraph:
@@ -294,7 +351,12 @@ class CsrGraph:
                 patch = None
             if patch is not None:
                 self.patch_stats[side] = (patch.pop('fetch'), patch.pop('rows_per_patch'))
+                groups = patch.pop('groups')
                 self._host.update({f'{side}_{k}': a for k, a in patch.items()})
+                if side == 'bwd':                       # the state-gradient path aggregates with Gs itself (stc_ring2_sum_f32)
+                    ring2 = _ring2_plan(rp, ci, v, groups)
+                    if ring2 is not None:
+                        self._host.update({f'bwd_{k}': a for k, a in ring2.items()})
         #: distinct neighbour rows fetched per output row by the row-blocked kernel (CSR: nnz / n)
         self.fetches_per_row = tuple(distinct[s_] / max(n, 1) for s_ in ('fwd', 'bwd'))
         self._dev: Dict[torch.device, Dict[str, torch.Tensor]] = {}
@@ -468,6 +530,7 @@ class SpatialOperand:
     fwd_plan: Optional[tuple] = None
     bwd_plan: Optional[tuple] = None
     row_sum_bound: float = 1.0       # fixed graphs: max absolute row sum over both orientations (CsrGraph.row_sum_bound)
+    bwd_ring2: Optional[tuple] = None    # (l2_rows, l1_rows, int_rows, t1, t2) of stc_ring2_sum_f32 for Gs, where its patches' rings fit
 
 
 _PATTERN_CACHE: Dict[Tuple[int, torch.device], Tuple[torch.Tensor, torch.Tensor]] = {}
@@ -521,4 +584,5 @@ def csr_operand(graph: CsrGraph, device: torch.device) -> SpatialOperand:
             return blocks
         return blocks + (tuple(d[f'{side}_pt_{k}'] for k in ('src', 'rows', 'cnt', 'idx', 'val')),)
     return SpatialOperand(graph.n, d['fwd_rowptr'], d['fwd_colidx'], d['fwd_val'],
-                          d['bwd_rowptr'], d['bwd_colidx'], d['bwd_val'], graph.nnz, plan('fwd'), plan('bwd'), graph.row_sum_bound)
+                          d['bwd_rowptr'], d['bwd_colidx'], d['bwd_val'], graph.nnz, plan('fwd'), plan('bwd'), graph.row_sum_bound,
+                          tuple(d[f'bwd_r2_{k}'] for k in ('l2', 'l1', 'own', 't1', 't2')) if 'bwd_r2_l2' in d else None)

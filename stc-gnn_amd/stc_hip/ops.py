@@ -442,6 +442,7 @@ _POST_AGG = True         # candidate convolution as Y = A + S.Bm (narrow SpMM af
 _PLANAR_K3 = True        # Chebyshev order 3: planar cells on three planes per side (T_0, T_1, T_2 of S)
 _ACC_PLANES = True       # one-launch cell backward: a state's second consumer adds into the first one's planes
 _SMALL = True            # small graphs (N*C rows per sample fit the caches, C <= 16): one launch per cell step and direction
+_RING2 = True            # state gradient + transpose aggregation of dY in one launch where the graph has a two-ring plan (no dY plane)
 
 
 def cell_graph_supported(op: SpatialOperand, Tc, Ks: int, C: int, h: int, x_widths, dtype=torch.float32) -> bool:
@@ -758,6 +759,23 @@ class _StcCellGraph(Function):
                        blend=None if blend is None else (blend[0], blend[1], dY))
             return out if blend is None else (out, dY)
 
+        def owed_ring2(kid, U_, Cand_):
+            """(gradient of state ``kid``, S^T (gradient * U * (1 - Cand^2))) in one launch where the graph has a two-ring plan and the state's
+            pieces are whole planes; None: the two launches (``owed`` with its blend epilogue, then the narrow aggregation)."""
+            pc = pieces.get(kid)
+            if pc is None or op.bwd_ring2 is None or not hasattr(k, 'ring2_sum'):
+                return None
+            base = G.get(kid)
+            add = [t for t, off in pc['direct'] if off == 0 and t.shape[-1] == h] + ([base] if base is not None else [])
+            if len(add) != len(pc['direct']) + (base is not None) or len(add) > k.RING2_MAX_ADD or len(pc['agg']) > 2:
+                return None
+            G.pop(kid, None)
+            pieces.pop(kid)
+            aggs = pc['agg']
+            out, dBm_ = aggs[0].new_empty(B, N, C, h), aggs[0].new_empty(B, N, C, h)
+            k.ring2_sum(*bwd, op.bwd_ring2, aggs[0], aggs[1] if len(aggs) > 1 else None, add, U_, Cand_, out, dBm_)
+            return out, dBm_
+
         # Order 3: a consumer leaves direct planes d0 and the gradients d1, d2 of the S / T_2(S) planes; the source's gradient is
         #   sum d0 - sum d2 + S^T (sum d1 + 2 S^T sum d2)          (Clenshaw form of sum_n T_n(S)^T d_n)
         # = two narrow SpMMs with the sums in their gather / epilogue (alpha and signed addends of stc_spmm_sum_f32).
@@ -831,11 +849,19 @@ class _StcCellGraph(Function):
             post_form = n_saved[j] < 0 or (len(rest) == Ks + 1 and Ks > 1)     # candidate backward starts from dY = dHnew * U * (1 - Cand^2)
             if Ks == 3 and j in pieces:                              # an interleaved cell whose state order-3 planar cells consumed
                 G[j] = owed3(j)
-            dHnew, dY = owed(j, (U, Cand)) if post_form else (owed(j), None)
+            dBm = None
+            if n_saved[j] == -7 and _RING2 and not bf16_planes:     # state gradient + S^T dY in one launch, no dY plane (stc_ring2_sum_f32)
+                fused = owed_ring2(j, U, Cand)
+                if fused is not None:
+                    dHnew, dBm = fused
+                    dY = None
+            if dBm is None:
+                dHnew, dY = owed(j, (U, Cand)) if post_form else (owed(j), None)
             dH = None if (n_saved[j] == -7 or (n_saved[j] < 0 and getattr(k, 'folds_dH', False))) else torch.empty_like(Hprev)
             if n_saved[j] == -7:                                     # planar cell, candidate + gates backward in ONE launch
                 Xp, SXp, SHp = rest
-                dBm = narrow_transpose_aggregation(dY)
+                if dBm is None:
+                    dBm = narrow_transpose_aggregation(dY)
                 del dY                                               # (the kernel re-forms dY from dHnew, U, Cand)
                 wide = cin[j] == h
                 new = lambda: torch.empty_like(Hprev)

@@ -1,0 +1,89 @@
+"""Two-ring patch aggregation (csrc/stc_spmm_ring2.hip, ``stc_ring2_sum_f32``): the state-gradient sum with its blend backward and the transpose
+aggregation of the candidate's gradient in one launch, without the dY plane -- against the CPU twin (the two aggregations it replaces, composed)
+and against the two HIP launches it replaces; host plan properties on CPU."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.kernel_emul import EmulatedKernels
+from stc_hip import CsrGraph
+from stc_hip.graph import RING2_FIRST, RING2_INTERIOR, RING2_SECOND, csr_operand
+from tests.conftest import rel_err
+
+EM = EmulatedKernels()
+
+
+def _dense(graph):
+    return graph.to_dense().double().numpy()
+
+
+@pytest.mark.parametrize('H,W', [(12, 20), (9, 33), (31, 8)])
+def test_two_ring_plan_reproduces_the_matrix(H, W):
+    """The plan's tables ARE the matrix: level 2 rebuilds every row of S over the first ring's slots, level 1 every first-ring row over the
+    staged rows; every row of S is some patch's own row exactly once; rings within their sizes."""
+    graph = CsrGraph.queen_grid(H, W, normalize=True)
+    h = graph._host
+    assert 'bwd_r2_l2' in h
+    S = _dense(graph)                                                 # Gs itself: the backward operand
+    l2, l1, own, t1, t2 = (h[f'bwd_r2_{k}'] for k in ('l2', 'l1', 'own', 't1', 't2'))
+    n = H * W
+    seen = np.zeros(n, dtype=int)
+    for p in range(l2.shape[0]):
+        rows = own[p][own[p] >= 0]
+        seen[rows] += 1
+        first = l1[p]
+        assert (first[:len(rows)] & 0x3FFFFFFF == rows).all() and ((first[:len(rows)] >> 30) & 1).all()      # own rows lead, flagged
+        live = first >= 0
+        assert not ((first[live][len(rows):] >> 30) & 1).any()
+        for r, u in enumerate(rows):                                  # level 2
+            got = np.zeros(n)
+            for off, bits in t2[p, r]:
+                got[first[off // 512] & 0x3FFFFFFF] += np.int32(bits).view(np.float32)
+            assert np.allclose(got, S[u], atol=1e-7)
+        for slot in np.nonzero(live)[0]:                              # level 1
+            u = first[slot] & 0x3FFFFFFF
+            got = np.zeros(n)
+            for off, bits in t1[p, slot]:
+                got[l2[p, off // 512]] += np.int32(bits).view(np.float32)
+            assert np.allclose(got, S[u], atol=1e-7)
+    assert (seen == 1).all()
+    assert l1.shape[1] == RING2_FIRST and l2.shape[1] == RING2_SECOND and own.shape[1] == RING2_INTERIOR
+
+
+def test_graphs_whose_rings_do_not_fit_get_no_two_ring_plan():
+    g = torch.Generator().manual_seed(0)
+    dense = (torch.rand(200, 200, generator=g) < 0.08).float()        # ~16 entries per row: wider than the tables
+    assert 'bwd_r2_l2' not in CsrGraph.from_dense(dense)._host
+    assert csr_operand(CsrGraph.from_dense(dense), torch.device('cpu')).bwd_ring2 is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('H,W,B,n_add,dual', [(12, 20, 2, 1, False), (40, 56, 2, 3, True), (9, 33, 1, 0, False), (31, 8, 3, 5, True), (224, 224, 1, 2, False)])
+def test_two_ring_sum_on_the_gpu(H, W, B, n_add, dual):
+    from stc_hip._lib import HipKernels
+    hip = HipKernels()
+    C, h = 32, 16
+    graph = CsrGraph.queen_grid(H, W, normalize=True)
+    n = H * W
+    op_c, op_g = csr_operand(graph, torch.device('cpu')), csr_operand(graph, torch.device('cuda'))
+    g = torch.Generator().manual_seed(H * W + n_add)
+    rnd = lambda: torch.randn(B, n, C, h, generator=g)
+    X, X2 = rnd(), (rnd() if dual else None)
+    adds = [rnd() for _ in range(n_add)]
+    U, Cand = torch.sigmoid(rnd()), torch.tanh(rnd())
+    Y_w, Z_w = torch.empty(B, n, C, h, dtype=torch.float64), torch.empty(B, n, C, h, dtype=torch.float64)
+    d = lambda t: None if t is None else t.double()
+    EM.ring2_sum(op_c.bwd_rowptr, op_c.bwd_colidx, op_c.bwd_val.double(), None, d(X), d(X2), [d(t) for t in adds], d(U), d(Cand), Y_w, Z_w)
+    cu = lambda t: None if t is None else t.cuda()
+    Y, Z = torch.full((B, n, C, h), float('nan')).cuda(), torch.full((B, n, C, h), float('nan')).cuda()
+    hip.ring2_sum(op_g.bwd_rowptr, op_g.bwd_colidx, op_g.bwd_val, op_g.bwd_ring2, cu(X), cu(X2), [cu(t) for t in adds], cu(U), cu(Cand), Y, Z)
+    assert rel_err(Y, Y_w) < 1e-6 and rel_err(Z, Z_w) < 1e-6
+    # the two launches it replaces, on the same operands
+    Y2, dY2, Z2 = (torch.empty(B, n, C, h).cuda() for _ in range(3))
+    hip.spmm_sum(op_g.bwd_rowptr, op_g.bwd_colidx, op_g.bwd_val, op_g.bwd_plan, cu(X), cu(X2), [(cu(t), 0) for t in adds], Y2, blend=(cu(U), cu(Cand), dY2))
+    hip.csr_spmm(op_g.bwd_rowptr, op_g.bwd_colidx, op_g.bwd_val, n, n, dY2.view(B, n, C * h), None, Z2.view(B, n, C * h), 1.0, 0.0, plan=op_g.bwd_plan)
+    assert rel_err(Y, Y2) < 1e-6 and rel_err(Z, Z2) < 1e-6
+    # reproducible
+    Y3, Z3 = torch.empty_like(Y), torch.empty_like(Z)
+    hip.ring2_sum(op_g.bwd_rowptr, op_g.bwd_colidx, op_g.bwd_val, op_g.bwd_ring2, cu(X), cu(X2), [cu(t) for t in adds], cu(U), cu(Cand), Y3, Z3)
+    assert torch.equal(Y3, Y) and torch.equal(Z3, Z)
