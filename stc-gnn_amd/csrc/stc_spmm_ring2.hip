@@ -78,34 +78,59 @@ __global__ __launch_bounds__(R2_THREADS, 2) void ring2_sum_kernel(Ring2Args a) {
 #pragma unroll
     for (int i = 0; i < R2_S2; ++i) in_row[i] = a.pl.int_rows[(size_t)p * R2_INT + i * 8 + hw];
 
-    const size_t base = (size_t)b * a.n * a.F4 + q;
+    // 32-bit piece offsets inside a plane (the entry point checks batch * n * F4 < 2^28): one register per row instead of a 64-bit address per
+    // row AND plane -- with size_t indices the kernel held 64 address registers and spilled
+    const unsigned base = (unsigned)b * (unsigned)a.n * (unsigned)a.F4 + (unsigned)q;
+    unsigned stage_off[R2_STAGE], l1_off[R2_S1];
+#pragma unroll
+    for (int k = 0; k < R2_STAGE; ++k) stage_off[k] = base + (unsigned)stage_row[k] * (unsigned)a.F4;
+#pragma unroll
+    for (int i = 0; i < R2_S1; ++i) l1_off[i] = base + (unsigned)(l1_row[i] >= 0 ? (l1_row[i] & 0x3FFFFFFF) : 0) * (unsigned)a.F4;
     v4f st[R2_STAGE];
     auto request = [&](int chunk) {
 #pragma unroll
         for (int k = 0; k < R2_STAGE; ++k) {
-            const size_t at = base + (size_t)stage_row[k] * a.F4 + chunk * R2_Q;
+            const unsigned at = stage_off[k] + chunk * R2_Q;
             st[k] = a.A[at];
             if (HAS_A2) st[k] += a.A2[at];
         }
     };
+    // The first ring's own operands (addends, U, Cand: NADD + 2 pieces per slot) are requested ONE SLOT AHEAD, and the next chunk's staged rows
+    // only after the last slot's request: memory returns in issue order, so a slot's request made behind the staging request waits for 12 rows
+    // from HBM (the first version: one exposed latency per slot; holding all eight slots' operands a chunk ahead spilled 120 registers).
+    constexpr int NOP = NADD + 2;
+    auto slot_at = [&](int i, int chunk) { return l1_off[i] + (unsigned)(chunk * R2_Q); };
+    auto request_slot = [&](v4f (&o)[NOP], int i, int chunk) {
+        const unsigned at = slot_at(i, chunk);
+#pragma unroll
+        for (int k = 0; k < NADD; ++k) o[k] = a.add[k][at];
+        o[NADD] = a.U[at];
+        o[NADD + 1] = a.Cand[at];
+    };
+    v4f opn[NOP];
     request(0);
+    request_slot(opn, 0, 0);
     for (int chunk = 0; chunk < n_chunks; ++chunk) {
         if (chunk) lds_only_barrier();                                                 // the previous chunk's interior sums are done with the tile
 #pragma unroll
         for (int k = 0; k < R2_STAGE; ++k) tile[(k * 8 + hw) * R2_Q + q] = st[k];
         lds_only_barrier();                                                            // (the first chunk: the tables are in place too)
-        if (chunk + 1 < n_chunks) request(chunk + 1);
+        const bool more = chunk + 1 < n_chunks;
         // ---- first ring: dH = addends + S.A out of the tile; dY = dH U (1 - Cand^2)
         v4f dy[R2_S1];
 #pragma unroll
         for (int i = 0; i < R2_S1; ++i) {
             const int slot = i * 8 + hw, row = l1_row[i];
-            const bool live = row >= 0, interior = live && (row & (1 << 30));
-            const size_t at = base + (size_t)(live ? (row & 0x3FFFFFFF) : 0) * a.F4 + chunk * R2_Q;
-            v4f ad[NADD > 0 ? NADD : 1];
+            const bool interior = row >= 0 && (row & (1 << 30));
+            v4f cur[NOP];
 #pragma unroll
-            for (int k = 0; k < NADD; ++k) ad[k] = a.add[k][at];
-            const v4f u = a.U[at], cd = a.Cand[at];
+            for (int k = 0; k < NOP; ++k) cur[k] = opn[k];
+            if (i + 1 < R2_S1) {
+                request_slot(opn, i + 1, chunk);
+            } else if (more) {                                                         // the next chunk: its staged rows, then its first slot
+                request(chunk + 1);
+                request_slot(opn, 0, chunk + 1);
+            }
             v4f acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int w = 0; w < R2_W; ++w) {
@@ -117,8 +142,9 @@ __global__ __launch_bounds__(R2_THREADS, 2) void ring2_sum_kernel(Ring2Args a) {
             }
             v4f dh = acc;
 #pragma unroll
-            for (int k = 0; k < NADD; ++k) dh += ad[k];
-            if (interior) __builtin_nontemporal_store(dh, a.Y + at);
+            for (int k = 0; k < NADD; ++k) dh += cur[k];
+            if (interior) __builtin_nontemporal_store(dh, a.Y + slot_at(i, chunk));
+            const v4f u = cur[NADD], cd = cur[NADD + 1];
 #pragma unroll
             for (int c = 0; c < 4; ++c) dy[i][c] = dh[c] * u[c] * (1.f - cd[c] * cd[c]);
         }
@@ -139,7 +165,7 @@ __global__ __launch_bounds__(R2_THREADS, 2) void ring2_sum_kernel(Ring2Args a) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) acc[c] = fmaf(v, x[c], acc[c]);
             }
-            if (row >= 0) __builtin_nontemporal_store(acc, a.Z + base + (size_t)row * a.F4 + chunk * R2_Q);
+            if (row >= 0) __builtin_nontemporal_store(acc, a.Z + (base + (unsigned)row * (unsigned)a.F4 + (unsigned)(chunk * R2_Q)));
         }
     }
 }
@@ -174,6 +200,8 @@ extern "C" int stc_ring2_sum_f32(const int32_t* l2_rows, const int32_t* l1_rows,
     STC_REQUIRE(h == 16 && C >= 1 && (C * h) % (4 * R2_Q) == 0, STC_EUNSUPPORTED, "stc_ring2_sum_f32: rows of C * h = %d floats (hidden 16, whole 512-byte chunks)", C * h);
     STC_REQUIRE(n_add >= 0 && n_add <= R2_MAX_ADD, STC_ELIMIT, "stc_ring2_sum_f32: 0..%d addends, got %d", R2_MAX_ADD, n_add);
     STC_REQUIRE(batch >= 0 && batch <= 65535 && n_rows >= 0 && n_patches >= 0, STC_EINVAL, "stc_ring2_sum_f32: bad sizes");
+    STC_REQUIRE((long long)batch * n_rows * (C * h / 4) < (1ll << 28), STC_ELIMIT, "stc_ring2_sum_f32: planes of %lld 16-byte pieces (32-bit offsets: < 2^28)",
+                (long long)batch * n_rows * (C * h / 4));
     if (batch == 0 || n_rows == 0) return STC_OK;
     STC_REQUIRE(n_patches >= 1 && (long long)n_patches * R2_INT >= n_rows, STC_EINVAL, "stc_ring2_sum_f32: %d patches cannot cover %d rows", n_patches, n_rows);
     STC_REQUIRE(l2_rows && l1_rows && int_rows && t1 && t2 && A && U && Cand && Y && Z && (n_add == 0 || add), STC_EINVAL, "stc_ring2_sum_f32: null pointer");
