@@ -162,6 +162,14 @@ int stc_ring2_sum_f32(const int32_t* l2_rows, const int32_t* l1_rows, const int3
                       const float* A, const float* A2, int32_t n_add, const float* const* add,
                       const float* U, const float* Cand, float* Y, float* Z,
                       int32_t batch, int32_t C, int32_t h, void* stream);
+/* The forward counterpart on the same plan format (built for Gs^T): stc_spmm_blend_fwd_f32 (without state copies) and the plain aggregation
+ * of the new state that follows it, in one launch -- the new state is aggregated out of LDS instead of being read back:
+ *     Cand = tanh(A + S.Bm)      Hnew = (1 - U) H + U Cand      SHnew = S.Hnew          (reference STC_GNN.py:76-78, then :37 of the next cell) */
+int stc_ring2_blend_f32(const int32_t* l2_rows, const int32_t* l1_rows, const int32_t* int_rows, const int32_t* t1, const int32_t* t2,
+                        int32_t n_patches, int32_t n_rows,
+                        const float* Bm, const float* A, const float* U, const float* H,
+                        float* Cand, float* Hnew, float* SHnew,
+                        int32_t batch, int32_t C, int32_t h, void* stream);
 
 /* bf16-storage node kernel (2-mode product + concat + projection + bias, STC_GNN.py:38-45) and its backward: the slabs
  * Z_n (nodes, C, L), the output Y / its gradient dY (nodes, C, Ho) and the slab gradients dZ_n are bf16 (void*); Tc, W,

@@ -240,6 +240,14 @@ class EmulatedKernels:
         self.csr_spmm(rowptr, colidx, val, n, n, v3(dY), None, out, 1.0, 0.0)
         Z.copy_(out.view(B, n, Cc, h))
 
+    # ---- stc_ring2_blend_f32: the GRU blend on Y = A + S.Bm and the aggregation of the new state (STC_GNN.py:76-78, then :37 of the next cell)
+    def ring2_blend(self, rowptr, colidx, val, ring2, Bm, A, U, H, Cand, Hnew, SHnew):
+        B, n, Cc, h = H.shape
+        self.spmm_blend_fwd(rowptr, colidx, val, None, Bm, A, U, H, Cand, Hnew)
+        out = torch.empty(B, n, Cc * h, dtype=H.dtype)
+        self.csr_spmm(rowptr, colidx, val, n, n, Hnew.reshape(B, n, Cc * h), None, out, 1.0, 0.0)
+        SHnew.copy_(out.view(B, n, Cc, h))
+
     # ---- stc_csr_sddmm_f32: gradient of the 1-mode product w.r.t. the graph values (autograd of :37)
     def csr_sddmm(self, rowptr, colidx, n_rows, n_cols, A, Bm, out, alpha, accumulate):
         rows = _expand_rows(rowptr)

@@ -45,15 +45,21 @@ struct Ring2Args {
     const v4f *A, *A2;                                 // gathered operands (B, n, F4)
     const v4f* add[R2_MAX_ADD];
     int n_add;
-    const v4f *U, *Cand;
-    v4f *Y, *Z;                                        // dH, dBm
+    const v4f *U, *Cand;                               // BLEND form: Cand = the previous state H
+    v4f *Y, *Y2, *Z;                                   // SUM: dH, -, dBm;  BLEND: Cand, Hnew, S.Hnew
     int n, F4;
 };
 
+// What the first ring computes from the gathered sum and the slot's own operands, and which of it the second aggregation takes:
+//   R2_SUM    dH = sum + addends (stored for interior rows);            V = dH U (1 - Cand^2)              -> Z = S.V = dBm
+//   R2_BLEND  Cand = tanh(sum + A), Hnew = (1 - U) H + U Cand (both stored: the forward of stc_spmm_blend_fwd_f32);  V = Hnew  -> Z = S.Hnew
+enum { R2_SUM = 0, R2_BLEND = 1 };
+
 __device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <bool HAS_A2, int NADD>
+template <int MODE, bool HAS_A2, int NADD>
 __global__ __launch_bounds__(R2_THREADS, 2) void ring2_sum_kernel(Ring2Args a) {
+    static_assert(MODE == R2_SUM || (NADD == 1 && !HAS_A2), "the blend form: one addend (A), one gathered operand (Bm)");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     v4f* tile = reinterpret_cast<v4f*>(lds);                                           // [96][32] staged rows, then [64][32] dY
     int2* tab1 = reinterpret_cast<int2*>(lds + (size_t)R2_L2 * R2_Q * 16);             // [64][8]
@@ -143,10 +149,20 @@ __global__ __launch_bounds__(R2_THREADS, 2) void ring2_sum_kernel(Ring2Args a) {
             v4f dh = acc;
 #pragma unroll
             for (int k = 0; k < NADD; ++k) dh += cur[k];
-            if (interior) __builtin_nontemporal_store(dh, a.Y + slot_at(i, chunk));
             const v4f u = cur[NADD], cd = cur[NADD + 1];
+            if constexpr (MODE == R2_SUM) {
+                if (interior) __builtin_nontemporal_store(dh, a.Y + slot_at(i, chunk));
 #pragma unroll
-            for (int c = 0; c < 4; ++c) dy[i][c] = dh[c] * u[c] * (1.f - cd[c] * cd[c]);
+                for (int c = 0; c < 4; ++c) dy[i][c] = dh[c] * u[c] * (1.f - cd[c] * cd[c]);
+            } else {                                                                   // cd = the previous state H
+                v4f cand;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { cand[c] = stc_tanh(dh[c]); dy[i][c] = (1.f - u[c]) * cd[c] + u[c] * cand[c]; }
+                if (interior) {
+                    __builtin_nontemporal_store(cand, a.Y + slot_at(i, chunk));
+                    __builtin_nontemporal_store(dy[i], a.Y2 + slot_at(i, chunk));
+                }
+            }
         }
         lds_only_barrier();                                                            // every wave is done with the staged rows
 #pragma unroll
@@ -170,23 +186,40 @@ __global__ __launch_bounds__(R2_THREADS, 2) void ring2_sum_kernel(Ring2Args a) {
     }
 }
 
-template <bool HAS_A2>
+template <int MODE, bool HAS_A2>
 int launch_ring2(const Ring2Args& a, int batch, hipStream_t s) {
     const size_t lds = (size_t)R2_L2 * R2_Q * 16 + (size_t)(R2_L1 + R2_INT) * R2_W * sizeof(int2);
+    static_assert((size_t)R2_L2 * R2_Q * 16 + (size_t)(R2_L1 + R2_INT) * R2_W * sizeof(int2) <= 64 * 1024, "within the default dynamic-LDS limit: no attribute to set");
     using Kernel = void (*)(Ring2Args);
     Kernel kern = nullptr;
-    switch (a.n_add) {
-        case 0: kern = ring2_sum_kernel<HAS_A2, 0>; break;
-        case 1: kern = ring2_sum_kernel<HAS_A2, 1>; break;
-        case 2: kern = ring2_sum_kernel<HAS_A2, 2>; break;
-        case 3: kern = ring2_sum_kernel<HAS_A2, 3>; break;
-        case 4: kern = ring2_sum_kernel<HAS_A2, 4>; break;
-        default: kern = ring2_sum_kernel<HAS_A2, 5>; break;
+    if constexpr (MODE == R2_BLEND) {
+        kern = ring2_sum_kernel<R2_BLEND, false, 1>;
+    } else {
+        switch (a.n_add) {
+            case 0: kern = ring2_sum_kernel<R2_SUM, HAS_A2, 0>; break;
+            case 1: kern = ring2_sum_kernel<R2_SUM, HAS_A2, 1>; break;
+            case 2: kern = ring2_sum_kernel<R2_SUM, HAS_A2, 2>; break;
+            case 3: kern = ring2_sum_kernel<R2_SUM, HAS_A2, 3>; break;
+            case 4: kern = ring2_sum_kernel<R2_SUM, HAS_A2, 4>; break;
+            default: kern = ring2_sum_kernel<R2_SUM, HAS_A2, 5>; break;
+        }
     }
-    static_assert((size_t)R2_L2 * R2_Q * 16 + (size_t)(R2_L1 + R2_INT) * R2_W * sizeof(int2) <= 64 * 1024, "within the default dynamic-LDS limit: no attribute to set");
     const int per = (a.pl.n_patches + stc::kNumXcd - 1) / stc::kNumXcd;
     hipLaunchKernelGGL(kern, dim3(per * stc::kNumXcd, batch), dim3(R2_THREADS), lds, s, a);
-    STC_LAUNCH_CHECK("stc_ring2_sum_f32 launch");
+    STC_LAUNCH_CHECK("stc_ring2 launch");
+    return STC_OK;
+}
+
+int check_ring2(const char* who, const void* l2_rows, const void* l1_rows, const void* int_rows, const void* t1, const void* t2, int n_patches, int n_rows,
+                int batch, int C, int h) {
+    STC_REQUIRE(h == 16 && C >= 1 && (C * h) % (4 * R2_Q) == 0, STC_EUNSUPPORTED, "%s: rows of C * h = %d floats (hidden 16, whole 512-byte chunks)", who, C * h);
+    STC_REQUIRE(batch >= 0 && batch <= 65535 && n_rows >= 0 && n_patches >= 0, STC_EINVAL, "%s: bad sizes", who);
+    STC_REQUIRE((long long)batch * n_rows * (C * h / 4) < (1ll << 28), STC_ELIMIT, "%s: planes of %lld 16-byte pieces (32-bit offsets: < 2^28)", who,
+                (long long)batch * n_rows * (C * h / 4));
+    if (batch == 0 || n_rows == 0) return STC_OK;
+    STC_REQUIRE(n_patches >= 1 && (long long)n_patches * R2_INT >= n_rows, STC_EINVAL, "%s: %d patches cannot cover %d rows", who, n_patches, n_rows);
+    STC_REQUIRE(l2_rows && l1_rows && int_rows && t1 && t2, STC_EINVAL, "%s: null plan array", who);
+    STC_REQUIRE(reinterpret_cast<uintptr_t>(t1) % 8 == 0 && reinterpret_cast<uintptr_t>(t2) % 8 == 0, STC_EALIGN, "%s: tables must be 8-byte aligned", who);
     return STC_OK;
 }
 
@@ -197,17 +230,12 @@ extern "C" int stc_ring2_sum_f32(const int32_t* l2_rows, const int32_t* l1_rows,
                                  const float* A, const float* A2, int32_t n_add, const float* const* add,
                                  const float* U, const float* Cand, float* Y, float* Z,
                                  int32_t batch, int32_t C, int32_t h, void* stream) {
-    STC_REQUIRE(h == 16 && C >= 1 && (C * h) % (4 * R2_Q) == 0, STC_EUNSUPPORTED, "stc_ring2_sum_f32: rows of C * h = %d floats (hidden 16, whole 512-byte chunks)", C * h);
     STC_REQUIRE(n_add >= 0 && n_add <= R2_MAX_ADD, STC_ELIMIT, "stc_ring2_sum_f32: 0..%d addends, got %d", R2_MAX_ADD, n_add);
-    STC_REQUIRE(batch >= 0 && batch <= 65535 && n_rows >= 0 && n_patches >= 0, STC_EINVAL, "stc_ring2_sum_f32: bad sizes");
-    STC_REQUIRE((long long)batch * n_rows * (C * h / 4) < (1ll << 28), STC_ELIMIT, "stc_ring2_sum_f32: planes of %lld 16-byte pieces (32-bit offsets: < 2^28)",
-                (long long)batch * n_rows * (C * h / 4));
+    if (int rc = check_ring2("stc_ring2_sum_f32", l2_rows, l1_rows, int_rows, t1, t2, n_patches, n_rows, batch, C, h)) return rc;
     if (batch == 0 || n_rows == 0) return STC_OK;
-    STC_REQUIRE(n_patches >= 1 && (long long)n_patches * R2_INT >= n_rows, STC_EINVAL, "stc_ring2_sum_f32: %d patches cannot cover %d rows", n_patches, n_rows);
-    STC_REQUIRE(l2_rows && l1_rows && int_rows && t1 && t2 && A && U && Cand && Y && Z && (n_add == 0 || add), STC_EINVAL, "stc_ring2_sum_f32: null pointer");
-    STC_REQUIRE(stc::aligned16(A) && (!A2 || stc::aligned16(A2)) && stc::aligned16(U) && stc::aligned16(Cand) && stc::aligned16(Y) && stc::aligned16(Z) &&
-                    (reinterpret_cast<uintptr_t>(t1) % 8 == 0) && (reinterpret_cast<uintptr_t>(t2) % 8 == 0),
-                STC_EALIGN, "stc_ring2_sum_f32: planes must be 16-byte aligned (tables 8-byte)");
+    STC_REQUIRE(A && U && Cand && Y && Z && (n_add == 0 || add), STC_EINVAL, "stc_ring2_sum_f32: null pointer");
+    STC_REQUIRE(stc::aligned16(A) && (!A2 || stc::aligned16(A2)) && stc::aligned16(U) && stc::aligned16(Cand) && stc::aligned16(Y) && stc::aligned16(Z),
+                STC_EALIGN, "stc_ring2_sum_f32: planes must be 16-byte aligned");
     STC_REQUIRE(Y != A && Y != A2 && Z != A && Z != A2 && Y != Z, STC_EINVAL, "stc_ring2_sum_f32: results must not alias the gathered operands or each other");
     Ring2Args a{};
     a.pl = Ring2Plan{l2_rows, l1_rows, int_rows, t1, t2, n_patches};
@@ -225,5 +253,33 @@ extern "C" int stc_ring2_sum_f32(const int32_t* l2_rows, const int32_t* l1_rows,
     a.n = n_rows;
     a.F4 = C * h / 4;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    return A2 ? launch_ring2<true>(a, batch, s) : launch_ring2<false>(a, batch, s);
+    return A2 ? launch_ring2<R2_SUM, true>(a, batch, s) : launch_ring2<R2_SUM, false>(a, batch, s);
+}
+
+extern "C" int stc_ring2_blend_f32(const int32_t* l2_rows, const int32_t* l1_rows, const int32_t* int_rows, const int32_t* t1, const int32_t* t2,
+                                   int32_t n_patches, int32_t n_rows,
+                                   const float* Bm, const float* A, const float* U, const float* H,
+                                   float* Cand, float* Hnew, float* SHnew,
+                                   int32_t batch, int32_t C, int32_t h, void* stream) {
+    if (int rc = check_ring2("stc_ring2_blend_f32", l2_rows, l1_rows, int_rows, t1, t2, n_patches, n_rows, batch, C, h)) return rc;
+    if (batch == 0 || n_rows == 0) return STC_OK;
+    STC_REQUIRE(Bm && A && U && H && Cand && Hnew && SHnew, STC_EINVAL, "stc_ring2_blend_f32: null pointer");
+    for (const void* q : {(const void*)Bm, (const void*)A, (const void*)U, (const void*)H, (const void*)Cand, (const void*)Hnew, (const void*)SHnew})
+        STC_REQUIRE(stc::aligned16(q), STC_EALIGN, "stc_ring2_blend_f32: planes must be 16-byte aligned");
+    for (const float* out : {Cand, Hnew, SHnew})
+        STC_REQUIRE(out != Bm && out != A && out != U && out != H, STC_EINVAL, "stc_ring2_blend_f32: a result aliases an operand (the first ring re-reads them)");
+    STC_REQUIRE(Cand != Hnew && Cand != SHnew && Hnew != SHnew, STC_EINVAL, "stc_ring2_blend_f32: results alias each other");
+    Ring2Args a{};
+    a.pl = Ring2Plan{l2_rows, l1_rows, int_rows, t1, t2, n_patches};
+    a.A = reinterpret_cast<const v4f*>(Bm);
+    a.n_add = 1;
+    a.add[0] = reinterpret_cast<const v4f*>(A);
+    a.U = reinterpret_cast<const v4f*>(U);
+    a.Cand = reinterpret_cast<const v4f*>(H);
+    a.Y = reinterpret_cast<v4f*>(Cand);
+    a.Y2 = reinterpret_cast<v4f*>(Hnew);
+    a.Z = reinterpret_cast<v4f*>(SHnew);
+    a.n = n_rows;
+    a.F4 = C * h / 4;
+    return launch_ring2<R2_BLEND, false>(a, batch, static_cast<hipStream_t>(stream));
 }

@@ -30,7 +30,7 @@ PATCH_ROWS, PATCH_MAX_SRC = 32, 64          # = STC_PATCH_ROWS, STC_PATCH_MAX_SR
 #: every symbol ``include/stc_hip.h`` declares (the CPU test-suite checks the .so exports them all)
 EXPORTS = (
     'stc_version', 'stc_last_error',
-    'stc_csr_spmm_f32', 'stc_bcsr_spmm_f32', 'stc_patch_spmm_f32', 'stc_patch_spmm_bf16', 'stc_ring2_sum_f32', 'stc_csr_spmm_bf16', 'stc_bcsr_spmm_bf16', 'stc_bdg_node_bf16_supported', 'stc_bdg_node_fwd_bf16', 'stc_bdg_node_bwd_bf16',
+    'stc_csr_spmm_f32', 'stc_bcsr_spmm_f32', 'stc_patch_spmm_f32', 'stc_patch_spmm_bf16', 'stc_ring2_sum_f32', 'stc_ring2_blend_f32', 'stc_csr_spmm_bf16', 'stc_bcsr_spmm_bf16', 'stc_bdg_node_bf16_supported', 'stc_bdg_node_fwd_bf16', 'stc_bdg_node_bwd_bf16',
     'stc_cell_planar_bf16_supported', 'stc_cell_gates_fwd_planar_bf16', 'stc_cell_gates_bwd_planar_bf16', 'stc_bdg_node_post_bwd_bf16',
     'stc_cell_bwd_planar_bf16_supported', 'stc_cell_bwd_planar_bf16',
     'stc_spmm_blend_fwd_bf16', 'stc_spmm_sum_bf16', 'stc_gru_blend_bwd_bf16', 'stc_head_fwd_bf16', 'stc_head_bwd_bf16',
@@ -94,6 +94,7 @@ def _declare(lib):
         'stc_cell_gates_bwd_planar_bf16': [_p] * 11 + [C.POINTER(_p), _p, _p, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _p],
         'stc_cell_bwd_planar_bf16': [_p] * 20 + [_p, C.c_size_t, _i64, _i32, _i32, _i32, _p],
         'stc_ring2_sum_f32': [_p] * 5 + [_i32, _i32, _p, _p, _i32, C.POINTER(_p), _p, _p, _p, _p, _i32, _i32, _i32, _p],
+        'stc_ring2_blend_f32': [_p] * 5 + [_i32, _i32] + [_p] * 7 + [_i32, _i32, _i32, _p],
         'stc_bdg_node_post_bwd_bf16': [_p] * 11 + [C.c_size_t, _i64, _i32, _i32, _i32, _p],
         'stc_spmm_blend_fwd_bf16': [_p] * 6 + [_i32, _i32] + [_p] * 6 + [_i32] * 3 + [_p],
         'stc_spmm_sum_bf16': [_p] * 6 + [_i32, _i32, _p, _p, _i32, C.POINTER(_p), _p, _p, _p, _p, _i32, _i32, _i32, _p],
@@ -533,15 +534,29 @@ class HipKernels:
         for i, t in enumerate(addends):
             self._f32(f'ring2_sum.add{i}', t, (B, n, Cc, h))
             ptrs[i] = t.data_ptr()
+        self._same_device(X, X2, U, Cand, Y, Z, *addends)
+        self._launch('stc_ring2_sum_f32', Y, *self._ring2_ptrs('ring2_sum', ring2, Y), n, _ptr(X), _ptr(X2), len(addends), ptrs,
+                     _ptr(U), _ptr(Cand), _ptr(Y), _ptr(Z), B, Cc, h,
+                     nbytes=colidx.numel() * 8 + 4 * (n + 1) + 4 * B * n * Cc * h * (1 + (X2 is not None) + len(addends) + 2 + 2))
+
+    def _ring2_ptrs(self, what, ring2, on):
         l2, l1, own, t1, t2 = ring2
         n_p = l2.shape[0]
         for name, t, shape in (('l2_rows', l2, (n_p, 96)), ('l1_rows', l1, (n_p, 64)), ('int_rows', own, (n_p, 32)), ('t1', t1, (n_p, 64, 8, 2)), ('t2', t2, (n_p, 32, 8, 2))):
             if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.int32 or not t.is_contiguous() or tuple(t.shape) != shape:
-                raise StcError(f'ring2_sum.{name}: expected a contiguous int32 ROCm tensor of shape {shape}')
-        self._same_device(l2, l1, own, t1, t2, X, X2, U, Cand, Y, Z, *addends)
-        self._launch('stc_ring2_sum_f32', Y, _ptr(l2), _ptr(l1), _ptr(own), _ptr(t1), _ptr(t2), n_p, n, _ptr(X), _ptr(X2), len(addends), ptrs,
-                     _ptr(U), _ptr(Cand), _ptr(Y), _ptr(Z), B, Cc, h,
-                     nbytes=colidx.numel() * 8 + 4 * (n + 1) + 4 * B * n * Cc * h * (1 + (X2 is not None) + len(addends) + 2 + 2))
+                raise StcError(f'{what}.{name}: expected a contiguous int32 ROCm tensor of shape {shape}')
+        self._same_device(on, l2, l1, own, t1, t2)
+        return [_ptr(l2), _ptr(l1), _ptr(own), _ptr(t1), _ptr(t2), n_p]
+
+    def ring2_blend(self, rowptr, colidx, val, ring2, Bm, A, U, H, Cand, Hnew, SHnew):
+        """Cand = tanh(A + S.Bm), Hnew = (1 - U) H + U Cand and SHnew = S.Hnew in one launch (stc_ring2_blend_f32): ``spmm_blend_fwd`` without state
+        copies + the plain aggregation of the new state, which is summed out of LDS instead of being read back.  ``ring2``: the plan for S."""
+        B, n, Cc, h = H.shape
+        for name, t in (('Bm', Bm), ('A', A), ('U', U), ('H', H), ('Cand', Cand), ('Hnew', Hnew), ('SHnew', SHnew)):
+            self._f32('ring2_blend.' + name, t, (B, n, Cc, h))
+        self._same_device(Bm, A, U, H, Cand, Hnew, SHnew)
+        self._launch('stc_ring2_blend_f32', H, *self._ring2_ptrs('ring2_blend', ring2, H), n, _ptr(Bm), _ptr(A), _ptr(U), _ptr(H), _ptr(Cand), _ptr(Hnew), _ptr(SHnew),
+                     B, Cc, h, nbytes=colidx.numel() * 8 + 4 * (n + 1) + 4 * B * n * Cc * h * 7)
 
     def csr_sddmm(self, rowptr, colidx, n_rows, n_cols, A, Bm, out, alpha, accumulate):
         B, nr, F = A.shape

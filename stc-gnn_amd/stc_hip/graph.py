@@ -353,10 +353,11 @@ class CsrGraph:
                 self.patch_stats[side] = (patch.pop('fetch'), patch.pop('rows_per_patch'))
                 groups = patch.pop('groups')
                 self._host.update({f'{side}_{k}': a for k, a in patch.items()})
-                if side == 'bwd':                       # the state-gradient path aggregates with Gs itself (stc_ring2_sum_f32)
-                    ring2 = _ring2_plan(rp, ci, v, groups)
-                    if ring2 is not None:
-                        self._host.update({f'bwd_{k}': a for k, a in ring2.items()})
+                # two-ring plans: the forward's blend + aggregation of the new state (Gs^T, stc_ring2_blend_f32) and the state-gradient path (Gs,
+                # stc_ring2_sum_f32)
+                ring2 = _ring2_plan(rp, ci, v, groups)
+                if ring2 is not None:
+                    self._host.update({f'{side}_{k}': a for k, a in ring2.items()})
         #: distinct neighbour rows fetched per output row by the row-blocked kernel (CSR: nnz / n)
         self.fetches_per_row = tuple(distinct[s_] / max(n, 1) for s_ in ('fwd', 'bwd'))
         self._dev: Dict[torch.device, Dict[str, torch.Tensor]] = {}
@@ -531,6 +532,7 @@ class SpatialOperand:
     bwd_plan: Optional[tuple] = None
     row_sum_bound: float = 1.0       # fixed graphs: max absolute row sum over both orientations (CsrGraph.row_sum_bound)
     bwd_ring2: Optional[tuple] = None    # (l2_rows, l1_rows, int_rows, t1, t2) of stc_ring2_sum_f32 for Gs, where its patches' rings fit
+    fwd_ring2: Optional[tuple] = None    # ... of stc_ring2_blend_f32 for Gs^T
 
 
 _PATTERN_CACHE: Dict[Tuple[int, torch.device], Tuple[torch.Tensor, torch.Tensor]] = {}
@@ -585,4 +587,4 @@ def csr_operand(graph: CsrGraph, device: torch.device) -> SpatialOperand:
         return blocks + (tuple(d[f'{side}_pt_{k}'] for k in ('src', 'rows', 'cnt', 'idx', 'val')),)
     return SpatialOperand(graph.n, d['fwd_rowptr'], d['fwd_colidx'], d['fwd_val'],
                           d['bwd_rowptr'], d['bwd_colidx'], d['bwd_val'], graph.nnz, plan('fwd'), plan('bwd'), graph.row_sum_bound,
-                          tuple(d[f'bwd_r2_{k}'] for k in ('l2', 'l1', 'own', 't1', 't2')) if 'bwd_r2_l2' in d else None)
+                          *[tuple(d[f'{sd}_r2_{k}'] for k in ('l2', 'l1', 'own', 't1', 't2')) if f'{sd}_r2_l2' in d else None for sd in ('bwd', 'fwd')])

@@ -443,6 +443,7 @@ _PLANAR_K3 = True        # Chebyshev order 3: planar cells on three planes per s
 _ACC_PLANES = True       # one-launch cell backward: a state's second consumer adds into the first one's planes
 _SMALL = True            # small graphs (N*C rows per sample fit the caches, C <= 16): one launch per cell step and direction
 _RING2 = True            # state gradient + transpose aggregation of dY in one launch where the graph has a two-ring plan (no dY plane)
+_RING2_FWD = True        # ... and the forward's blend + aggregation of the new state (stc_ring2_blend_f32)
 
 
 def cell_graph_supported(op: SpatialOperand, Tc, Ks: int, C: int, h: int, x_widths, dtype=torch.float32) -> bool:
@@ -616,7 +617,15 @@ class _StcCellGraph(Function):
                     k.cell_gates_fwd_planar(*rows((Xp, Hprev, SXp, SHp)), Tc, Wg, bg, *rows((U, Rg, RH)), **act_slots(j))
                     lead, second = (Xp, RH) if cin[j] == h else (RH, Xp)     # narrow input plane: the 16-wide plane leads
                     k.node_post_fwd(*rows((lead,)), Tc, Wc, bc, *rows((A, Bm)), X2=second.view(B * N, C, second.shape[-1]))
-                k.spmm_blend_fwd(op.fwd_rowptr, op.fwd_colidx, fwd_val, op.fwd_plan, Bm, A, U, Hprev, Cand, Hnew, copies=copies, side=side)
+                # the blend and the aggregation of the new state in one launch where the graph has a two-ring plan and some planar cell will
+                # ask for S.Hnew (stc_ring2_blend_f32: the new state is summed out of LDS instead of being read back by a launch of its own)
+                if (_RING2_FWD and not bf16 and op.fwd_ring2 is not None and not copies and side is None and hasattr(k, 'ring2_blend')
+                        and any(planar[d] and not planar_k for d, _ in consumers[j])):
+                    SHn = torch.empty_like(Hprev)
+                    k.ring2_blend(op.fwd_rowptr, op.fwd_colidx, fwd_val, op.fwd_ring2, Bm, A, U, Hprev, Cand, Hnew, SHn)
+                    agg[('cell', j)] = SHn
+                else:
+                    k.spmm_blend_fwd(op.fwd_rowptr, op.fwd_colidx, fwd_val, op.fwd_plan, Bm, A, U, Hprev, Cand, Hnew, copies=copies, side=side)
                 del A, Bm
                 saved += [Hprev, U, Rg, Cand, Xp, SXp, SHp] + ([] if RH is None else [RH])
                 n_saved.append(-7 if RH is None else -8)            # negative count: planar cell (-7: no R*H plane, one-launch backward)

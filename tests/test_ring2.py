@@ -87,3 +87,32 @@ def test_two_ring_sum_on_the_gpu(H, W, B, n_add, dual):
     Y3, Z3 = torch.empty_like(Y), torch.empty_like(Z)
     hip.ring2_sum(op_g.bwd_rowptr, op_g.bwd_colidx, op_g.bwd_val, op_g.bwd_ring2, cu(X), cu(X2), [cu(t) for t in adds], cu(U), cu(Cand), Y3, Z3)
     assert torch.equal(Y3, Y) and torch.equal(Z3, Z)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('H,W,B', [(12, 20, 2), (40, 56, 2), (9, 33, 1), (224, 224, 1)])
+def test_two_ring_blend_on_the_gpu(H, W, B):
+    """stc_ring2_blend_f32 against the CPU twin (float64) and against the two HIP launches it replaces (blend aggregation, then S.Hnew)."""
+    from stc_hip._lib import HipKernels
+    hip = HipKernels()
+    C, h = 32, 16
+    graph = CsrGraph.queen_grid(H, W, normalize=True)
+    n = H * W
+    op_c, op_g = csr_operand(graph, torch.device('cpu')), csr_operand(graph, torch.device('cuda'))
+    assert op_g.fwd_ring2 is not None
+    g = torch.Generator().manual_seed(H * W)
+    rnd = lambda: torch.randn(B, n, C, h, generator=g)
+    Bm, A, U, Hp = rnd(), rnd(), torch.sigmoid(rnd()), torch.tanh(rnd())
+    d = lambda t: t.double()
+    want = [torch.empty(B, n, C, h, dtype=torch.float64) for _ in range(3)]
+    EM.ring2_blend(op_c.fwd_rowptr, op_c.fwd_colidx, op_c.fwd_val.double(), None, d(Bm), d(A), d(U), d(Hp), *want)
+    cu = lambda t: t.cuda()
+    got = [torch.full((B, n, C, h), float('nan')).cuda() for _ in range(3)]
+    hip.ring2_blend(op_g.fwd_rowptr, op_g.fwd_colidx, op_g.fwd_val, op_g.fwd_ring2, cu(Bm), cu(A), cu(U), cu(Hp), *got)
+    for a, w in zip(got, want):
+        assert rel_err(a, w) < 2e-6
+    Cand2, Hn2, SH2 = (torch.empty(B, n, C, h).cuda() for _ in range(3))
+    hip.spmm_blend_fwd(op_g.fwd_rowptr, op_g.fwd_colidx, op_g.fwd_val, op_g.fwd_plan, cu(Bm), cu(A), cu(U), cu(Hp), Cand2, Hn2)
+    hip.csr_spmm(op_g.fwd_rowptr, op_g.fwd_colidx, op_g.fwd_val, n, n, Hn2.view(B, n, C * h), None, SH2.view(B, n, C * h), 1.0, 0.0, plan=op_g.fwd_plan)
+    for a, w in zip(got, (Cand2, Hn2, SH2)):
+        assert rel_err(a, w) < 2e-6
