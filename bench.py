@@ -49,9 +49,10 @@ F16_MATRIX_PEAK_TFLOPS = 2500.0  # v_mfma_f32_16x16x32_f16 / _bf16, dense (MI355
 PLAIN_SPMM = ('stc_patch_spmm_f32', 'stc_patch_spmm_bf16', 'stc_bcsr_spmm_f32', 'stc_bcsr_spmm_bf16')
 # every C-ABI entry point that is an aggregation Y = S.X (+ epilogue)
 SPMM_ENTRY_POINTS = ('stc_patch_spmm_f32', 'stc_patch_spmm_bf16', 'stc_bcsr_spmm_f32', 'stc_csr_spmm_f32', 'stc_spmm_sum_f32', 'stc_spmm_blend_fwd_f32',
-                     'stc_bcsr_spmm_bf16', 'stc_csr_spmm_bf16', 'stc_spmm_sum_bf16', 'stc_spmm_blend_fwd_bf16')
+                     'stc_bcsr_spmm_bf16', 'stc_csr_spmm_bf16', 'stc_spmm_sum_bf16', 'stc_spmm_blend_fwd_bf16',
+                     'stc_ring2_sum_f32', 'stc_ring2_blend_f32')
 # what the timed region records HIP events for: the roofline kernel (plain aggregation) and the entry points that can dominate a step
-PRICED_ENTRY_POINTS = PLAIN_SPMM + ('stc_cell_bwd_planar_f32', 'stc_cell_small_fwd_f32', 'stc_cell_small_bwd_f32')
+PRICED_ENTRY_POINTS = PLAIN_SPMM + ('stc_cell_bwd_planar_f32', 'stc_ring2_sum_f32', 'stc_ring2_blend_f32', 'stc_cell_small_fwd_f32', 'stc_cell_small_bwd_f32')
 METRIC = 'STC-GNN fwd+bwd samples/sec at N=50k,C=32; SpMM HBM GB/s vs peak, 1/8 GPU'
 CPU_WARMUP, CPU_TIMED = 2, 7    # 2 warm-up + 7 timed iterations, median
 
@@ -720,7 +721,7 @@ def main():
             'algorithmic_bytes_per_launch': plain['bytes'] / max(1, plain['launches']),
             'bytes_formula': 'nnz*8 + 4*(N+1) + 2*B*N*F*sizeof(x)  (SURVEY 8(d3))',
             'aggregate': {'what': 'every aggregation launch of a step (two further steps with every launch timed; ' + ' + '.join(n for n in SPMM_ENTRY_POINTS if n in per_kernel)
-                                  + '): plain, with the GRU blend in the epilogue, state-gradient sums; graph once + every operand read once + every result written once',
+                                  + '): plain, with the GRU blend in the epilogue, state-gradient sums, the two-ring forms (two aggregations per launch); graph once + every operand read once + every result written once',
                           'achieved': rate(every), 'frac': rate(every) / HBM_PEAK_GBPS, 'launches': every['launches'],
                           'avg_launch_us': 1e3 * every['ms'] / max(1, every['launches']),
                           'algorithmic_bytes_per_launch': every['bytes'] / max(1, every['launches'])},
