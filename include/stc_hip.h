@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define STC_ABI_VERSION 27
+#define STC_ABI_VERSION 28
 #define STC_MAX_K 4          /* highest Chebyshev order (Ks, Kc) the node kernels accept */
 
 /* Operand formats of the split-operand matrix-core kernels (C = 32 / 64, hidden 16).  Every fp32 operand is split into low-precision
@@ -169,6 +169,18 @@ int stc_ring2_blend_f32(const int32_t* l2_rows, const int32_t* l1_rows, const in
                         int32_t n_patches, int32_t n_rows,
                         const float* Bm, const float* A, const float* U, const float* H,
                         float* Cand, float* Hnew, float* SHnew,
+                        int32_t batch, int32_t C, int32_t h, void* stream);
+/* Two CHAINED aggregations on the same plan format (ABI v28): the feature-side Chebyshev recurrence of order 3 (reference STC_GNN.py:24-29
+ * applied to the features, :37; BASELINE configuration 4) and its transpose, each one launch instead of two:
+ *     V = alpha1 S.(A [+ A2]) + sum_k add1[k]          Z = alpha2 S.V + sum_k scale0[k] add0[k]
+ *   forward   T_1 = S.X (V, stored), T_2 = 2 S.T_1 - X:                       alpha1 = 1, no add1, alpha2 = 2, add0 = {X}, scale0 = {-1}
+ *   backward  d0 - d2 + S^T (d1 + 2 S^T d2)  (Clenshaw form, plan of S^T):    A = d2, alpha1 = 2, add1 = {d1}, V = NULL, alpha2 = 1, add0 = {d0.., d2..}, scale0 = {+1.., -1..}
+ * V may be NULL (not stored).  n_add1 <= 2, 1 <= n_add0 <= 5; scale0 NULL = all +1.  V is formed for the patch's first ring (1.9 x redundant) and never
+ * read back: what the two launches it replaces (stc_spmm_sum_f32 / stc_patch_spmm_f32 twice) pass through HBM. */
+int stc_ring2_chain_f32(const int32_t* l2_rows, const int32_t* l1_rows, const int32_t* int_rows, const int32_t* t1, const int32_t* t2,
+                        int32_t n_patches, int32_t n_rows,
+                        const float* A, const float* A2, float alpha1, int32_t n_add1, const float* const* add1, float* V,
+                        float alpha2, int32_t n_add0, const float* const* add0, const float* scale0, float* Z,
                         int32_t batch, int32_t C, int32_t h, void* stream);
 
 /* bf16-storage node kernel (2-mode product + concat + projection + bias, STC_GNN.py:38-45) and its backward: the slabs

@@ -248,6 +248,22 @@ class EmulatedKernels:
         self.csr_spmm(rowptr, colidx, val, n, n, Hnew.reshape(B, n, Cc * h), None, out, 1.0, 0.0)
         SHnew.copy_(out.view(B, n, Cc, h))
 
+    # ---- stc_ring2_chain_f32: two chained aggregations -- the order-3 feature recurrence (STC_GNN.py:24-29 on the feature side, :37) and its transpose
+    def ring2_chain(self, rowptr, colidx, val, ring2, X, X2, alpha1, add1, V, alpha2, add0, Z):
+        B, n, Cc, h = Z.shape
+        v3 = lambda t: t.reshape(B, n, Cc * h)
+        first = torch.empty(B, n, Cc * h, dtype=Z.dtype)
+        self.csr_spmm(rowptr, colidx, val, n, n, v3(X if X2 is None else X + X2), None, first, float(alpha1), 0.0)
+        for t in add1:
+            first = first + v3(t)
+        if V is not None:
+            V.copy_(first.view(B, n, Cc, h))
+        out = torch.empty(B, n, Cc * h, dtype=Z.dtype)
+        self.csr_spmm(rowptr, colidx, val, n, n, first.contiguous(), None, out, float(alpha2), 0.0)
+        for t, scale in add0:
+            out = out + scale * v3(t)
+        Z.copy_(out.view(B, n, Cc, h))
+
     # ---- stc_csr_sddmm_f32: gradient of the 1-mode product w.r.t. the graph values (autograd of :37)
     def csr_sddmm(self, rowptr, colidx, n_rows, n_cols, A, Bm, out, alpha, accumulate):
         rows = _expand_rows(rowptr)

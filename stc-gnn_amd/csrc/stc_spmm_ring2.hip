@@ -46,20 +46,28 @@ struct Ring2Args {
     const v4f* add[R2_MAX_ADD];
     int n_add;
     const v4f *U, *Cand;                               // BLEND form: Cand = the previous state H
-    v4f *Y, *Y2, *Z;                                   // SUM: dH, -, dBm;  BLEND: Cand, Hnew, S.Hnew
+    v4f *Y, *Y2, *Z;                                   // SUM: dH, -, dBm;  BLEND: Cand, Hnew, S.Hnew;  CHAIN: V (or null), -, Z
     int n, F4;
+    // CHAIN: scales of the two aggregations and the INTERIOR's addends (the first ring's are add[])
+    float alpha1, alpha2;
+    const v4f* add0[R2_MAX_ADD];
+    float scale0[R2_MAX_ADD];
 };
 
 // What the first ring computes from the gathered sum and the slot's own operands, and which of it the second aggregation takes:
 //   R2_SUM    dH = sum + addends (stored for interior rows);            V = dH U (1 - Cand^2)              -> Z = S.V = dBm
 //   R2_BLEND  Cand = tanh(sum + A), Hnew = (1 - U) H + U Cand (both stored: the forward of stc_spmm_blend_fwd_f32);  V = Hnew  -> Z = S.Hnew
-enum { R2_SUM = 0, R2_BLEND = 1 };
+//   R2_CHAIN  V = alpha1 sum + addends (stored for interior rows if Y is given)   -> Z = alpha2 S.V + sum_k scale0[k] add0[k]: two chained
+//             aggregations of the order-3 feature recurrence -- forward 2 S.(S.X) - X (STC_GNN.py:24-29 applied to the feature side, :37), and
+//             its transpose in Clenshaw form, d0 - d2 + S^T (d1 + 2 S^T d2)
+enum { R2_SUM = 0, R2_BLEND = 1, R2_CHAIN = 2 };
 
 __device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int MODE, bool HAS_A2, int NADD>
+template <int MODE, bool HAS_A2, int NADD, int N0 = 0>                 // NADD: addends of the first ring;  N0: of the interior (CHAIN)
 __global__ __launch_bounds__(R2_THREADS, 2) void ring2_sum_kernel(Ring2Args a) {
-    static_assert(MODE == R2_SUM || (NADD == 1 && !HAS_A2), "the blend form: one addend (A), one gathered operand (Bm)");
+    static_assert(MODE != R2_BLEND || (NADD == 1 && !HAS_A2), "the blend form: one addend (A), one gathered operand (Bm)");
+    static_assert((MODE == R2_CHAIN) == (N0 > 0), "interior addends: the chain form, at least one");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     v4f* tile = reinterpret_cast<v4f*>(lds);                                           // [96][32] staged rows, then [64][32] dY
     int2* tab1 = reinterpret_cast<int2*>(lds + (size_t)R2_L2 * R2_Q * 16);             // [64][8]
@@ -104,16 +112,18 @@ __global__ __launch_bounds__(R2_THREADS, 2) void ring2_sum_kernel(Ring2Args a) {
     // The first ring's own operands (addends, U, Cand: NADD + 2 pieces per slot) are requested ONE SLOT AHEAD, and the next chunk's staged rows
     // only after the last slot's request: memory returns in issue order, so a slot's request made behind the staging request waits for 12 rows
     // from HBM (the first version: one exposed latency per slot; holding all eight slots' operands a chunk ahead spilled 120 registers).
-    constexpr int NOP = NADD + 2;
+    constexpr int NOP = MODE == R2_CHAIN ? NADD : NADD + 2, NOPA = NOP > 0 ? NOP : 1;
     auto slot_at = [&](int i, int chunk) { return l1_off[i] + (unsigned)(chunk * R2_Q); };
-    auto request_slot = [&](v4f (&o)[NOP], int i, int chunk) {
+    auto request_slot = [&](v4f (&o)[NOPA], int i, int chunk) {
         const unsigned at = slot_at(i, chunk);
 #pragma unroll
         for (int k = 0; k < NADD; ++k) o[k] = a.add[k][at];
-        o[NADD] = a.U[at];
-        o[NADD + 1] = a.Cand[at];
+        if constexpr (MODE != R2_CHAIN) {
+            o[NADD] = a.U[at];
+            o[NADD + 1] = a.Cand[at];
+        }
     };
-    v4f opn[NOP];
+    v4f opn[NOPA];
     request(0);
     request_slot(opn, 0, 0);
     for (int chunk = 0; chunk < n_chunks; ++chunk) {
@@ -128,7 +138,7 @@ __global__ __launch_bounds__(R2_THREADS, 2) void ring2_sum_kernel(Ring2Args a) {
         for (int i = 0; i < R2_S1; ++i) {
             const int slot = i * 8 + hw, row = l1_row[i];
             const bool interior = row >= 0 && (row & (1 << 30));
-            v4f cur[NOP];
+            v4f cur[NOPA];
 #pragma unroll
             for (int k = 0; k < NOP; ++k) cur[k] = opn[k];
             if (i + 1 < R2_S1) {
@@ -146,15 +156,19 @@ __global__ __launch_bounds__(R2_THREADS, 2) void ring2_sum_kernel(Ring2Args a) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) acc[c] = fmaf(v, x[c], acc[c]);
             }
-            v4f dh = acc;
+            v4f dh = MODE == R2_CHAIN ? a.alpha1 * acc : acc;
 #pragma unroll
             for (int k = 0; k < NADD; ++k) dh += cur[k];
-            const v4f u = cur[NADD], cd = cur[NADD + 1];
-            if constexpr (MODE == R2_SUM) {
+            if constexpr (MODE == R2_CHAIN) {
+                if (a.Y != nullptr && interior) __builtin_nontemporal_store(dh, a.Y + slot_at(i, chunk));
+                dy[i] = dh;
+            } else if constexpr (MODE == R2_SUM) {
+                const v4f u = cur[NOPA - 2], cd = cur[NOPA - 1];
                 if (interior) __builtin_nontemporal_store(dh, a.Y + slot_at(i, chunk));
 #pragma unroll
                 for (int c = 0; c < 4; ++c) dy[i][c] = dh[c] * u[c] * (1.f - cd[c] * cd[c]);
             } else {                                                                   // cd = the previous state H
+                const v4f u = cur[NOPA - 2], cd = cur[NOPA - 1];
                 v4f cand;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) { cand[c] = stc_tanh(dh[c]); dy[i][c] = (1.f - u[c]) * cd[c] + u[c] * cand[c]; }
@@ -167,6 +181,16 @@ __global__ __launch_bounds__(R2_THREADS, 2) void ring2_sum_kernel(Ring2Args a) {
         lds_only_barrier();                                                            // every wave is done with the staged rows
 #pragma unroll
         for (int i = 0; i < R2_S1; ++i) tile[(i * 8 + hw) * R2_Q + q] = dy[i];
+        // CHAIN: the interior rows' own addends, requested now that the first ring's registers are free (they return behind the next chunk's staged
+        // rows, which the next tile write waits for in any case)
+        v4f own[R2_S2][N0 > 0 ? N0 : 1];
+        if constexpr (MODE == R2_CHAIN) {
+#pragma unroll
+            for (int i = 0; i < R2_S2; ++i)
+#pragma unroll
+                for (int k = 0; k < N0; ++k)
+                    own[i][k] = a.add0[k][base + (unsigned)(in_row[i] >= 0 ? in_row[i] : 0) * (unsigned)a.F4 + (unsigned)(chunk * R2_Q)];
+        }
         lds_only_barrier();
         // ---- interior: dBm = S.dY out of the tile
 #pragma unroll
@@ -181,19 +205,31 @@ __global__ __launch_bounds__(R2_THREADS, 2) void ring2_sum_kernel(Ring2Args a) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) acc[c] = fmaf(v, x[c], acc[c]);
             }
+            if constexpr (MODE == R2_CHAIN) {
+                acc *= a.alpha2;
+#pragma unroll
+                for (int k = 0; k < N0; ++k) acc += a.scale0[k] * own[i][k];
+            }
             if (row >= 0) __builtin_nontemporal_store(acc, a.Z + (base + (unsigned)row * (unsigned)a.F4 + (unsigned)(chunk * R2_Q)));
         }
     }
 }
 
 template <int MODE, bool HAS_A2>
-int launch_ring2(const Ring2Args& a, int batch, hipStream_t s) {
+int launch_ring2(const Ring2Args& a, int batch, hipStream_t s, int n_add0 = 0) {
     const size_t lds = (size_t)R2_L2 * R2_Q * 16 + (size_t)(R2_L1 + R2_INT) * R2_W * sizeof(int2);
     static_assert((size_t)R2_L2 * R2_Q * 16 + (size_t)(R2_L1 + R2_INT) * R2_W * sizeof(int2) <= 64 * 1024, "within the default dynamic-LDS limit: no attribute to set");
     using Kernel = void (*)(Ring2Args);
     Kernel kern = nullptr;
     if constexpr (MODE == R2_BLEND) {
         kern = ring2_sum_kernel<R2_BLEND, false, 1>;
+    } else if constexpr (MODE == R2_CHAIN) {
+        static constexpr Kernel table[3][R2_MAX_ADD] = {
+#define STC_R2_ROW(NA) {ring2_sum_kernel<R2_CHAIN, HAS_A2, NA, 1>, ring2_sum_kernel<R2_CHAIN, HAS_A2, NA, 2>, ring2_sum_kernel<R2_CHAIN, HAS_A2, NA, 3>, \
+                        ring2_sum_kernel<R2_CHAIN, HAS_A2, NA, 4>, ring2_sum_kernel<R2_CHAIN, HAS_A2, NA, 5>}
+            STC_R2_ROW(0), STC_R2_ROW(1), STC_R2_ROW(2)};
+#undef STC_R2_ROW
+        kern = table[a.n_add][n_add0 - 1];
     } else {
         switch (a.n_add) {
             case 0: kern = ring2_sum_kernel<R2_SUM, HAS_A2, 0>; break;
@@ -282,4 +318,41 @@ extern "C" int stc_ring2_blend_f32(const int32_t* l2_rows, const int32_t* l1_row
     a.n = n_rows;
     a.F4 = C * h / 4;
     return launch_ring2<R2_BLEND, false>(a, batch, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int stc_ring2_chain_f32(const int32_t* l2_rows, const int32_t* l1_rows, const int32_t* int_rows, const int32_t* t1, const int32_t* t2,
+                                   int32_t n_patches, int32_t n_rows,
+                                   const float* A, const float* A2, float alpha1, int32_t n_add1, const float* const* add1, float* V,
+                                   float alpha2, int32_t n_add0, const float* const* add0, const float* scale0, float* Z,
+                                   int32_t batch, int32_t C, int32_t h, void* stream) {
+    STC_REQUIRE(n_add1 >= 0 && n_add1 <= 2, STC_ELIMIT, "stc_ring2_chain_f32: 0..2 first-ring addends, got %d", n_add1);
+    STC_REQUIRE(n_add0 >= 1 && n_add0 <= R2_MAX_ADD, STC_ELIMIT, "stc_ring2_chain_f32: 1..%d interior addends, got %d", R2_MAX_ADD, n_add0);
+    if (int rc = check_ring2("stc_ring2_chain_f32", l2_rows, l1_rows, int_rows, t1, t2, n_patches, n_rows, batch, C, h)) return rc;
+    if (batch == 0 || n_rows == 0) return STC_OK;
+    STC_REQUIRE(A && Z && add0 && (n_add1 == 0 || add1), STC_EINVAL, "stc_ring2_chain_f32: null pointer");
+    STC_REQUIRE(stc::aligned16(A) && (!A2 || stc::aligned16(A2)) && (!V || stc::aligned16(V)) && stc::aligned16(Z), STC_EALIGN,
+                "stc_ring2_chain_f32: planes must be 16-byte aligned");
+    STC_REQUIRE(Z != A && Z != A2 && V != A && (!V || V != A2) && V != Z, STC_EINVAL, "stc_ring2_chain_f32: results must not alias the gathered operands or each other");
+    Ring2Args a{};
+    a.pl = Ring2Plan{l2_rows, l1_rows, int_rows, t1, t2, n_patches};
+    a.A = reinterpret_cast<const v4f*>(A);
+    a.A2 = reinterpret_cast<const v4f*>(A2);
+    a.n_add = n_add1;
+    for (int i = 0; i < n_add1; ++i) {
+        STC_REQUIRE(add1[i] && stc::aligned16(add1[i]) && add1[i] != Z && add1[i] != V, STC_EINVAL, "stc_ring2_chain_f32: first-ring addend %d null, misaligned or aliasing a result", i);
+        a.add[i] = reinterpret_cast<const v4f*>(add1[i]);
+    }
+    for (int i = 0; i < n_add0; ++i) {
+        STC_REQUIRE(add0[i] && stc::aligned16(add0[i]) && add0[i] != Z && add0[i] != V, STC_EINVAL, "stc_ring2_chain_f32: interior addend %d null, misaligned or aliasing a result", i);
+        a.add0[i] = reinterpret_cast<const v4f*>(add0[i]);
+        a.scale0[i] = scale0 ? scale0[i] : 1.f;
+    }
+    a.alpha1 = alpha1;
+    a.alpha2 = alpha2;
+    a.Y = reinterpret_cast<v4f*>(V);
+    a.Z = reinterpret_cast<v4f*>(Z);
+    a.n = n_rows;
+    a.F4 = C * h / 4;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return A2 ? launch_ring2<R2_CHAIN, true>(a, batch, s, n_add0) : launch_ring2<R2_CHAIN, false>(a, batch, s, n_add0);
 }

@@ -21,7 +21,7 @@ from .graph import is_full_pattern
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG_ROOT, 'libstc_hip.so')
-ABI_VERSION = 27
+ABI_VERSION = 28
 FMT_BF16X3, FMT_F16X2 = 0, 1          # STC_FMT_* of include/stc_hip.h: operand formats of the split-operand matrix-core kernels
 MAX_K = 4
 SPMM_SUM_MAX_ADD = 8     # = STC_SPMM_SUM_MAX_ADD of include/stc_hip.h
@@ -30,7 +30,7 @@ PATCH_ROWS, PATCH_MAX_SRC = 32, 64          # = STC_PATCH_ROWS, STC_PATCH_MAX_SR
 #: every symbol ``include/stc_hip.h`` declares (the CPU test-suite checks the .so exports them all)
 EXPORTS = (
     'stc_version', 'stc_last_error',
-    'stc_csr_spmm_f32', 'stc_bcsr_spmm_f32', 'stc_patch_spmm_f32', 'stc_patch_spmm_bf16', 'stc_ring2_sum_f32', 'stc_ring2_blend_f32', 'stc_csr_spmm_bf16', 'stc_bcsr_spmm_bf16', 'stc_bdg_node_bf16_supported', 'stc_bdg_node_fwd_bf16', 'stc_bdg_node_bwd_bf16',
+    'stc_csr_spmm_f32', 'stc_bcsr_spmm_f32', 'stc_patch_spmm_f32', 'stc_patch_spmm_bf16', 'stc_ring2_sum_f32', 'stc_ring2_blend_f32', 'stc_ring2_chain_f32', 'stc_csr_spmm_bf16', 'stc_bcsr_spmm_bf16', 'stc_bdg_node_bf16_supported', 'stc_bdg_node_fwd_bf16', 'stc_bdg_node_bwd_bf16',
     'stc_cell_planar_bf16_supported', 'stc_cell_gates_fwd_planar_bf16', 'stc_cell_gates_bwd_planar_bf16', 'stc_bdg_node_post_bwd_bf16',
     'stc_cell_bwd_planar_bf16_supported', 'stc_cell_bwd_planar_bf16',
     'stc_spmm_blend_fwd_bf16', 'stc_spmm_sum_bf16', 'stc_gru_blend_bwd_bf16', 'stc_head_fwd_bf16', 'stc_head_bwd_bf16',
@@ -95,6 +95,7 @@ def _declare(lib):
         'stc_cell_bwd_planar_bf16': [_p] * 20 + [_p, C.c_size_t, _i64, _i32, _i32, _i32, _p],
         'stc_ring2_sum_f32': [_p] * 5 + [_i32, _i32, _p, _p, _i32, C.POINTER(_p), _p, _p, _p, _p, _i32, _i32, _i32, _p],
         'stc_ring2_blend_f32': [_p] * 5 + [_i32, _i32] + [_p] * 7 + [_i32, _i32, _i32, _p],
+        'stc_ring2_chain_f32': [_p] * 5 + [_i32, _i32, _p, _p, _f32, _i32, C.POINTER(_p), _p, _f32, _i32, C.POINTER(_p), C.POINTER(_f32), _p, _i32, _i32, _i32, _p],
         'stc_bdg_node_post_bwd_bf16': [_p] * 11 + [C.c_size_t, _i64, _i32, _i32, _i32, _p],
         'stc_spmm_blend_fwd_bf16': [_p] * 6 + [_i32, _i32] + [_p] * 6 + [_i32] * 3 + [_p],
         'stc_spmm_sum_bf16': [_p] * 6 + [_i32, _i32, _p, _p, _i32, C.POINTER(_p), _p, _p, _p, _p, _i32, _i32, _i32, _p],
@@ -557,6 +558,26 @@ class HipKernels:
         self._same_device(Bm, A, U, H, Cand, Hnew, SHnew)
         self._launch('stc_ring2_blend_f32', H, *self._ring2_ptrs('ring2_blend', ring2, H), n, _ptr(Bm), _ptr(A), _ptr(U), _ptr(H), _ptr(Cand), _ptr(Hnew), _ptr(SHnew),
                      B, Cc, h, nbytes=colidx.numel() * 8 + 4 * (n + 1) + 4 * B * n * Cc * h * 7)
+
+    def ring2_chain(self, rowptr, colidx, val, ring2, X, X2, alpha1, add1, V, alpha2, add0, Z):
+        """V = alpha1 S.(X [+ X2]) + sum(add1) and Z = alpha2 S.V + sum(scale * t for (t, scale) in add0) in one launch (stc_ring2_chain_f32): the
+        order-3 feature recurrence [S.X, 2 S.(S.X) - X] and its transpose d0 - d2 + S^T (d1 + 2 S^T d2).  V may be None (not stored)."""
+        B, n, Cc, h = Z.shape
+        for name, t in (('Z', Z), ('X', X)) + ((('X2', X2),) if X2 is not None else ()) + ((('V', V),) if V is not None else ()):
+            self._f32('ring2_chain.' + name, t, (B, n, Cc, h))
+        if len(add1) > 2 or not 1 <= len(add0) <= self.RING2_MAX_ADD:
+            raise StcError(f'ring2_chain: 0..2 first-ring and 1..{self.RING2_MAX_ADD} interior addends, got {len(add1)} and {len(add0)}')
+        p1, p0, s0 = (_p * 2)(), (_p * self.RING2_MAX_ADD)(), (_f32 * self.RING2_MAX_ADD)()
+        for i, t in enumerate(add1):
+            self._f32(f'ring2_chain.add1[{i}]', t, (B, n, Cc, h))
+            p1[i] = t.data_ptr()
+        for i, (t, scale) in enumerate(add0):
+            self._f32(f'ring2_chain.add0[{i}]', t, (B, n, Cc, h))
+            p0[i], s0[i] = t.data_ptr(), float(scale)
+        self._same_device(X, X2, V, Z, *add1, *[t for t, _ in add0])
+        self._launch('stc_ring2_chain_f32', Z, *self._ring2_ptrs('ring2_chain', ring2, Z), n, _ptr(X), _ptr(X2), float(alpha1), len(add1), p1, _ptr(V),
+                     float(alpha2), len(add0), p0, s0, _ptr(Z), B, Cc, h,
+                     nbytes=colidx.numel() * 8 + 4 * (n + 1) + 4 * B * n * Cc * h * (1 + (X2 is not None) + len(add1) + (V is not None) + len(add0) + 1))
 
     def csr_sddmm(self, rowptr, colidx, n_rows, n_cols, A, Bm, out, alpha, accumulate):
         B, nr, F = A.shape

@@ -547,6 +547,10 @@ class _StcCellGraph(Function):
             w = t.shape[-1]
             v3 = lambda a: a.view(B, N, C * w)
             s1, s2 = torch.empty_like(t), torch.empty_like(t)
+            if _RING2_FWD and w == h and not bf16 and op.fwd_ring2 is not None and hasattr(k, 'ring2_chain'):
+                # both aggregations in one launch: S.t for a patch's first ring is formed in LDS and aggregated from there (stc_ring2_chain_f32)
+                k.ring2_chain(op.fwd_rowptr, op.fwd_colidx, fwd_val, op.fwd_ring2, t, None, 1.0, [], s1, 2.0, [(t, -1.0)], s2)
+                return [t, s1, s2]
             k.csr_spmm(op.fwd_rowptr, op.fwd_colidx, fwd_val, N, N, v3(t), None, v3(s1), 1.0, 0.0, plan=op.fwd_plan)
             k.csr_spmm(op.fwd_rowptr, op.fwd_colidx, fwd_val, N, N, v3(s1), v3(t), v3(s2), 2.0, -1.0, plan=op.fwd_plan)
             return [t, s1, s2]
@@ -797,6 +801,13 @@ class _StcCellGraph(Function):
             dY = result * U * (1 - Cand^2) from the second launch's epilogue."""
             while len(d2) > 2:                                       # the kernel gathers two operands: pre-sum the rest
                 d2 = [d2[0] + d2[1]] + d2[2:]
+            if (_RING2 and blend is None and not bf16_planes and op.bwd_ring2 is not None and hasattr(k, 'ring2_chain') and len(d1) <= 2
+                    and 1 <= len(d0) + len(d2) <= k.RING2_MAX_ADD):
+                # both transpose aggregations in one launch (stc_ring2_chain_f32): the inner sum d1 + 2 S^T d2 never leaves the chip
+                out = d2[0].new_empty(B, N, C, h)
+                k.ring2_chain(*bwd, op.bwd_ring2, d2[0], d2[1] if len(d2) > 1 else None, 2.0, list(d1), None, 1.0,
+                              [(a, 1.0) for a in d0] + [(a, -1.0) for a in d2], out)
+                return out
             t = d2[0].new_empty(B, N, C, h)
             k.spmm_sum(*bwd, op.bwd_plan, d2[0], d2[1] if len(d2) > 1 else None, [(a, 0) for a in d1], t, alpha=2.0)
             adds = [(a, 0) for a in d0] + [(a, 0, -1.0) for a in d2]

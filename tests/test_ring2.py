@@ -116,3 +116,70 @@ def test_two_ring_blend_on_the_gpu(H, W, B):
     hip.csr_spmm(op_g.fwd_rowptr, op_g.fwd_colidx, op_g.fwd_val, n, n, Hn2.view(B, n, C * h), None, SH2.view(B, n, C * h), 1.0, 0.0, plan=op_g.fwd_plan)
     for a, w in zip(got, (Cand2, Hn2, SH2)):
         assert rel_err(a, w) < 2e-6
+
+
+def _chain_cases():
+    # (H, W, B, dual, n_add1, n_add0, store V, alpha1, alpha2): the forward recurrence, the transposes the order-3 backward asks for, the limits
+    return [(12, 20, 2, False, 0, 1, True, 1.0, 2.0), (40, 56, 2, True, 2, 4, False, 2.0, 1.0), (9, 33, 1, False, 1, 2, False, 2.0, 1.0),
+            (31, 8, 3, True, 2, 5, True, -0.5, 3.0), (100, 100, 4, True, 2, 5, False, 2.0, 1.0), (224, 224, 1, False, 0, 1, True, 1.0, 2.0)]
+
+
+def test_chain_twin_is_the_order3_recurrence_and_its_transpose():
+    """CPU: ``ring2_chain`` with the forward's arguments is [S.X, 2 S.(S.X) - X] (reference STC_GNN.py:24-29 on the feature side), and with the
+    backward's arguments the transpose of  (d0, d1, d2) -> sum_n T_n(S)^T d_n  -- checked against dense float64 matrices."""
+    graph = CsrGraph.queen_grid(7, 9, normalize=True)
+    op = csr_operand(graph, torch.device('cpu'))
+    B, n, C, h = 2, 63, 4, 16
+    g = torch.Generator().manual_seed(5)
+    rnd = lambda: torch.randn(B, n, C, h, generator=g, dtype=torch.float64)
+    S = torch.zeros(n, n, dtype=torch.float64)                       # the forward operand as a dense matrix, from its CSR arrays
+    rp, ci, vv = op.fwd_rowptr.long(), op.fwd_colidx.long(), op.fwd_val.double()
+    for r in range(n):
+        S[r, ci[rp[r]:rp[r + 1]]] = vv[rp[r]:rp[r + 1]]
+    mul = lambda M, t: torch.einsum('uv,bvcf->bucf', M, t)
+    X = rnd()
+    T1, T2 = torch.empty_like(X), torch.empty_like(X)
+    EM.ring2_chain(op.fwd_rowptr, op.fwd_colidx, op.fwd_val.double(), None, X, None, 1.0, [], T1, 2.0, [(X, -1.0)], T2)
+    assert torch.allclose(T1, mul(S, X), atol=1e-12) and torch.allclose(T2, 2 * mul(S, mul(S, X)) - X, atol=1e-12)
+    d0, d1, d2 = rnd(), rnd(), rnd()
+    out = torch.empty_like(X)
+    EM.ring2_chain(op.bwd_rowptr, op.bwd_colidx, op.bwd_val.double(), None, d2, None, 2.0, [d1], None, 1.0, [(d0, 1.0), (d2, -1.0)], out)
+    St = S.T
+    want = d0 + mul(St, d1) + (2 * mul(St, mul(St, d2)) - d2)          # T_0^T d0 + T_1^T d1 + T_2^T d2
+    assert torch.allclose(out, want, atol=1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('H,W,B,dual,n1,n0,keep,alpha1,alpha2', _chain_cases())
+def test_two_ring_chain_on_the_gpu(H, W, B, dual, n1, n0, keep, alpha1, alpha2):
+    """stc_ring2_chain_f32 against the CPU twin (float64) and against the two HIP launches it replaces (stc_spmm_sum_f32 twice)."""
+    from stc_hip._lib import HipKernels
+    hip = HipKernels()
+    C, h = 32, 16
+    graph = CsrGraph.queen_grid(H, W, normalize=True)
+    n = H * W
+    op_c, op_g = csr_operand(graph, torch.device('cpu')), csr_operand(graph, torch.device('cuda'))
+    g = torch.Generator().manual_seed(H * W + n1 + n0)
+    rnd = lambda: torch.randn(B, n, C, h, generator=g)
+    X, X2 = rnd(), (rnd() if dual else None)
+    add1 = [rnd() for _ in range(n1)]
+    add0 = [(rnd(), s) for s in ([1.0, -1.0, 1.0, -2.5, 0.5][:n0])]
+    d = lambda t: None if t is None else t.double()
+    V_w = torch.empty(B, n, C, h, dtype=torch.float64)
+    Z_w = torch.empty(B, n, C, h, dtype=torch.float64)
+    EM.ring2_chain(op_c.bwd_rowptr, op_c.bwd_colidx, op_c.bwd_val.double(), None, d(X), d(X2), alpha1, [d(t) for t in add1], V_w, alpha2,
+                   [(d(t), s) for t, s in add0], Z_w)
+    cu = lambda t: None if t is None else t.cuda()
+    V = torch.full((B, n, C, h), float('nan')).cuda() if keep else None
+    Z = torch.full((B, n, C, h), float('nan')).cuda()
+    hip.ring2_chain(op_g.bwd_rowptr, op_g.bwd_colidx, op_g.bwd_val, op_g.bwd_ring2, cu(X), cu(X2), alpha1, [cu(t) for t in add1], V, alpha2,
+                    [(cu(t), s) for t, s in add0], Z)
+    assert rel_err(Z, Z_w) < 2e-6 and (V is None or rel_err(V, V_w) < 2e-6)
+    V2, Z2 = torch.empty(B, n, C, h).cuda(), torch.empty(B, n, C, h).cuda()
+    hip.spmm_sum(op_g.bwd_rowptr, op_g.bwd_colidx, op_g.bwd_val, op_g.bwd_plan, cu(X), cu(X2), [(cu(t), 0) for t in add1], V2, alpha=alpha1)
+    hip.spmm_sum(op_g.bwd_rowptr, op_g.bwd_colidx, op_g.bwd_val, op_g.bwd_plan, V2, None, [(cu(t), 0, s) for t, s in add0], Z2, alpha=alpha2)
+    assert rel_err(Z, Z2) < 2e-6 and (V is None or rel_err(V, V2) < 2e-6)
+    Z3 = torch.empty_like(Z)
+    hip.ring2_chain(op_g.bwd_rowptr, op_g.bwd_colidx, op_g.bwd_val, op_g.bwd_ring2, cu(X), cu(X2), alpha1, [cu(t) for t in add1], None, alpha2,
+                    [(cu(t), s) for t, s in add0], Z3)
+    assert torch.equal(Z3, Z)                                          # reproducible, with or without the stored V
