@@ -78,3 +78,27 @@ def test_patch_aggregation_keeps_two_workgroups_per_cu_and_an_lds_only_barrier(t
         assert len(barriers) >= 2, name
         assert all(lines[i - 1] == 's_waitcnt lgkmcnt(0)' for i in barriers), (name, [lines[i - 1] for i in barriers])
     shutil.rmtree(tmp_path, ignore_errors=True)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason='hipcc not present')
+def test_two_ring_kernels_keep_two_workgroups_per_cu_without_scratch(tmp_path):
+    """csrc/stc_spmm_ring2.hip: two workgroups per compute unit (48 KiB tile each) need <= 256 registers; the forms the metric step and
+    configuration 4 dispatch -- the sum with up to two addends and one gathered plane, the blend, every chain form -- must not touch scratch
+    (a version with a deeper operand ring spilled 16 accesses per chunk and ran at 1 004 instead of 590 us); barriers wait for LDS alone."""
+    out = tmp_path / 'ring2.s'
+    csrc = os.path.join(REPO, 'stc-gnn_amd', 'csrc')
+    subprocess.check_call([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', f'-I{os.path.join(REPO, "include")}',
+                           '-S', '--cuda-device-only', '-o', str(out), os.path.join(csrc, 'stc_spmm_ring2.hip')], stderr=subprocess.DEVNULL)
+    text = out.read_text()
+    bodies = re.findall(r'^(_ZN\S*ring2_sum_kernelILi(\d)ELb(\d)ELi(\d)ELi(\d)E\S*):[^\n]*\n(.*?)s_endpgm', text, flags=re.M | re.S)
+    assert len(bodies) == 12 + 1 + 30, len(bodies)                     # sum: {A, A + A2} x 0..5 addends; blend; chain: {A, A + A2} x 0..2 x 1..5
+    for name, mode, dual, n_add, n0, body in bodies:
+        regs = re.search(r'\.amdhsa_kernel ' + re.escape(name) + r'\n.*?\.amdhsa_next_free_vgpr (\d+)', text, flags=re.S)
+        assert regs and int(regs.group(1)) <= 256, (name, 'more than 256 registers: one workgroup per compute unit')
+        if mode != '0' or (dual == '0' and int(n_add) <= 2):
+            assert 'scratch_' not in body, name
+        lines = [ln.strip() for ln in body.split('\n') if ln.strip() and not ln.strip().startswith(';')]
+        barriers = [i for i, ln in enumerate(lines) if ln == 's_barrier']
+        assert len(barriers) >= 4, name
+        assert all(lines[i - 1] == 's_waitcnt lgkmcnt(0)' for i in barriers), (name, [lines[i - 1] for i in barriers])
+    shutil.rmtree(tmp_path, ignore_errors=True)
