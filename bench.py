@@ -339,6 +339,22 @@ def pmc_traffic(a, config_key):
                      f'plain aggregation launches of one step of this command on these sources (csrc {doc["csrc_sha"]}): {where}')
 
 
+# C-ABI entry point -> the kernel it launches, as the PMC file names it
+PMC_KERNEL_OF = {'stc_cell_bwd_planar_f32': r'cell_bwd_x3_kernel<', 'stc_cell_gates_fwd_planar_f32': r'node_fwd_x3_kernel<',
+                 'stc_ring2_sum_f32': r'ring2_sum_kernel<0,', 'stc_ring2_blend_f32': r'ring2_sum_kernel<1,', 'stc_ring2_chain_f32': r'ring2_sum_kernel<2,'}
+
+
+def pmc_entry_traffic(entry_point, config_key):
+    """Mean HBM bytes per launch of one entry point's kernel from the same committed PMC file as ``pmc_traffic`` (same validity rule), or None."""
+    doc, _ = _profile_doc('hbm_traffic_bench.json')
+    pat = PMC_KERNEL_OF.get(entry_point)
+    if doc is None or pat is None or doc.get('csrc_sha') != csrc_sha() or doc.get('config_key') != config_key:
+        return None
+    import re
+    ks = [v for name, v in doc['kernels'].items() if re.match(pat, name)]
+    return sum(v['hbm_bytes_per_launch'] * v['launches'] for v in ks) / sum(v['launches'] for v in ks) if ks else None
+
+
 def pmc_mfma(config_key):
     """Matrix-pipe / vector-pipe busy fractions of the projection kernels (the split-operand MFMA cell kernels) from the committed
     ``rocprofv3 --pmc`` passes over THIS command (tools/gpu_pmc_mfma.sh -> profiles/rNN/mfma_util.json): quoted only while the
@@ -724,7 +740,14 @@ def main():
                                   + '): plain, with the GRU blend in the epilogue, state-gradient sums, the two-ring forms (two aggregations per launch); graph once + every operand read once + every result written once',
                           'achieved': rate(every), 'frac': rate(every) / HBM_PEAK_GBPS, 'launches': every['launches'],
                           'avg_launch_us': 1e3 * every['ms'] / max(1, every['launches']),
-                          'algorithmic_bytes_per_launch': every['bytes'] / max(1, every['launches'])},
+                          'algorithmic_bytes_per_launch': every['bytes'] / max(1, every['launches']),
+                          # the two-ring launches (two aggregations each): where most of the step's aggregation happens since round 5
+                          'two_ring': {name: {'launches': per_kernel[name]['launches'],
+                                              'avg_launch_us': 1e3 * per_kernel[name]['ms'] / max(1, per_kernel[name]['launches']),
+                                              'algorithmic_bytes_per_launch': per_kernel[name]['bytes'] / max(1, per_kernel[name]['launches']),
+                                              'achieved': rate(per_kernel[name]), 'frac': rate(per_kernel[name]) / HBM_PEAK_GBPS,
+                                              'traffic': pmc_entry_traffic(name, config_key)}
+                                       for name in ('stc_ring2_sum_f32', 'stc_ring2_blend_f32', 'stc_ring2_chain_f32') if name in per_kernel}},
         }
         dom_name = max(per_kernel, key=lambda n: per_kernel[n]['ms']) if per_kernel else None
         if dom_name is not None:
@@ -734,6 +757,7 @@ def main():
                    'avg_launch_us': 1e3 * dk['ms'] / max(1, dk['launches'])}
             if dk['bytes']:
                 dom.update(algorithmic_bytes_per_launch=dk['bytes'] / max(1, dk['launches']), achieved=rate(dk), unit='GB/s', frac=rate(dk) / HBM_PEAK_GBPS,
+                           traffic=pmc_entry_traffic(dom_name, config_key),
                            bytes_formula='every operand plane read once + every result plane written once (planes of batch*N*C*hidden*4 bytes; '
                                          'an accumulated plane is read and written)')
                 for tag, tv in dk.get('tags', {}).items():
