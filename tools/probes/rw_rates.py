@@ -23,14 +23,14 @@ def timed(fn, reps=12):
 
 mb = n * 4 / 1e6
 us = timed(lambda i: out[i % 6].fill_(1.0))
-print(f'write only (fill)        {us:7.1f} us  {mb / us:6.2f} TB/s' .replace('TB/s', 'GB/ms'))
+print(f'write only (fill)        {us:7.1f} us  {mb / us:6.2f} TB/s')
 us = timed(lambda i: out[i % 6].zero_())
-print(f'write only (zero_)       {us:7.1f} us  {mb / us / 1e3:6.2f} TB/s')
+print(f'write only (zero_)       {us:7.1f} us  {mb / us:6.2f} TB/s')
 us = timed(lambda i: bufs[i % 6].sum())
-print(f'read only (sum)          {us:7.1f} us  {mb / us / 1e3:6.2f} TB/s')
+print(f'read only (torch.sum)    {us:7.1f} us  {mb / us:6.2f} TB/s')
 us = timed(lambda i: out[i % 6].copy_(bufs[i % 6]))
-print(f'copy (1 R + 1 W)         {us:7.1f} us  {2 * mb / us / 1e3:6.2f} TB/s')
+print(f'copy (1 R + 1 W)         {us:7.1f} us  {2 * mb / us:6.2f} TB/s')
 us = timed(lambda i: torch.add(bufs[i % 6], bufs[(i + 1) % 6], out=out[i % 6]))
-print(f'add (2 R + 1 W)          {us:7.1f} us  {3 * mb / us / 1e3:6.2f} TB/s')
+print(f'add (2 R + 1 W)          {us:7.1f} us  {3 * mb / us:6.2f} TB/s')
 us = timed(lambda i: torch.addcmul(bufs[i % 6], bufs[(i + 1) % 6], bufs[(i + 2) % 6], out=out[i % 6]))
-print(f'addcmul (3 R + 1 W)      {us:7.1f} us  {4 * mb / us / 1e3:6.2f} TB/s')
+print(f'addcmul (3 R + 1 W)      {us:7.1f} us  {4 * mb / us:6.2f} TB/s')
