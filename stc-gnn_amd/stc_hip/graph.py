@@ -247,6 +247,49 @@ def _patch_tables(rpl, cil, val, n, patches, max_deg):
 RING2_INTERIOR, RING2_FIRST, RING2_SECOND, RING2_WIDTH = 32, 64, 96, 8       # = STC_RING2_* of include/stc_hip.h
 
 
+def _ring2_groups(rowptr: np.ndarray, colidx: np.ndarray, n: int, min_rows: float = 16.0):
+    """Patches for the two-ring form on a graph that is not a lattice in its numbering: grown like the clusters of ``_patch_plan`` (breadth-first
+    over the symmetrised pattern from the first row not yet taken), but bounded by what the two-ring kernel stages -- a row joins while the
+    first ring stays within RING2_FIRST rows and the second within RING2_SECOND.  On the bench's grid under a random numbering, renumbered by
+    reverse Cuthill-McKee: 29.4 rows per patch, 1.98 first-ring and 3.2 staged rows per own row (4 x 8 tiles of the lattice: 32, 1.88, 3.0).
+    None when the patches come out small (no locality).  Deterministic in the arrays alone."""
+    import scipy.sparse as sp
+    rp = rowptr.astype(np.int64)
+    if n == 0 or colidx.size == 0 or int(np.diff(rp).max()) > RING2_WIDTH:
+        return None
+    rpl, cil = rp.tolist(), colidx.tolist()
+    A = sp.csr_matrix((np.ones(colidx.size, dtype=np.int8), colidx, rp), shape=(n, n))
+    S = (A + A.T).tocsr()
+    S.sort_indices()
+    srp, sci = S.indptr.tolist(), S.indices.tolist()
+    taken = np.zeros(n, dtype=bool)
+    groups = []
+    for seed in range(n):
+        if taken[seed]:
+            continue
+        rows, first, second, queue, queued, qi = [], set(), set(), [seed], {seed}, 0
+        while qi < len(queue) and len(rows) < RING2_INTERIOR:
+            u = queue[qi]
+            qi += 1
+            grown = first | set(cil[rpl[u]:rpl[u + 1]]) | {u}
+            if len(grown) > RING2_FIRST:
+                continue                               # (the row stays available to later patches; a single row always fits: width <= 8)
+            staged = set(second)
+            for v in grown - first:
+                staged.update(cil[rpl[v]:rpl[v + 1]])
+            if len(staged) > RING2_SECOND:
+                continue
+            first, second = grown, staged
+            rows.append(u)
+            taken[u] = True
+            for w in sci[srp[u]:srp[u + 1]]:
+                if not taken[w] and w not in queued:
+                    queued.add(w)
+                    queue.append(w)
+        groups.append(rows)
+    return groups if n / len(groups) >= min_rows else None
+
+
 def _ring2_plan(rowptr: np.ndarray, colidx: np.ndarray, val: np.ndarray, groups):
     """Two-ring form of a square CSR matrix S over the patches ``groups`` of its patch plan, for ``stc_ring2_sum_f32`` (include/stc_hip.h): per
     patch its own rows, its first ring (own rows + every column they touch, <= 64), the second ring (every column the first ring's rows
@@ -341,6 +384,8 @@ class CsrGraph:
         distinct = {}
         #: side -> (source rows per output row, rows per patch) of the patch form, where the graph has one
         self.patch_stats: Dict[str, Tuple[float, float]] = {}
+        #: the two-ring plans are over ring-bounded clusters (a graph that is not a lattice in its numbering), not over the patch form's patches
+        self.ring2_clusters = False
         for side, (rp, ci, v) in (('fwd', (f_rp, f_ci, f_v)), ('bwd', (b_rp, b_ci, b_v))):
             plan = _row_block_plan(rp, ci, v, n)
             distinct[side] = plan.pop('distinct')
@@ -356,6 +401,10 @@ class CsrGraph:
                 # two-ring plans: the forward's blend + aggregation of the new state (Gs^T, stc_ring2_blend_f32) and the state-gradient path (Gs,
                 # stc_ring2_sum_f32)
                 ring2 = _ring2_plan(rp, ci, v, groups)
+                if ring2 is None:                       # clusters of the patch form whose rings do not fit: patches grown for the rings instead
+                    own = _ring2_groups(rp, ci, n)
+                    ring2 = _ring2_plan(rp, ci, v, own) if own is not None else None
+                    self.ring2_clusters = self.ring2_clusters or ring2 is not None
                 if ring2 is not None:
                     self._host.update({f'{side}_{k}': a for k, a in ring2.items()})
         #: distinct neighbour rows fetched per output row by the row-blocked kernel (CSR: nnz / n)
@@ -533,6 +582,8 @@ class SpatialOperand:
     row_sum_bound: float = 1.0       # fixed graphs: max absolute row sum over both orientations (CsrGraph.row_sum_bound)
     bwd_ring2: Optional[tuple] = None    # (l2_rows, l1_rows, int_rows, t1, t2) of stc_ring2_sum_f32 for Gs, where its patches' rings fit
     fwd_ring2: Optional[tuple] = None    # ... of stc_ring2_blend_f32 for Gs^T
+    ring2_clusters: bool = False         # those plans are over ring-bounded clusters (1 708 ragged patches for the bench's grid under a random order
+                                         # against 1 568 tiles: every launch +17 %), where only the forms that replace two gathering launches pay
 
 
 _PATTERN_CACHE: Dict[Tuple[int, torch.device], Tuple[torch.Tensor, torch.Tensor]] = {}
@@ -587,4 +638,5 @@ def csr_operand(graph: CsrGraph, device: torch.device) -> SpatialOperand:
         return blocks + (tuple(d[f'{side}_pt_{k}'] for k in ('src', 'rows', 'cnt', 'idx', 'val')),)
     return SpatialOperand(graph.n, d['fwd_rowptr'], d['fwd_colidx'], d['fwd_val'],
                           d['bwd_rowptr'], d['bwd_colidx'], d['bwd_val'], graph.nnz, plan('fwd'), plan('bwd'), graph.row_sum_bound,
-                          *[tuple(d[f'{sd}_r2_{k}'] for k in ('l2', 'l1', 'own', 't1', 't2')) if f'{sd}_r2_l2' in d else None for sd in ('bwd', 'fwd')])
+                          *[tuple(d[f'{sd}_r2_{k}'] for k in ('l2', 'l1', 'own', 't1', 't2')) if f'{sd}_r2_l2' in d else None for sd in ('bwd', 'fwd')],
+                          graph.ring2_clusters)

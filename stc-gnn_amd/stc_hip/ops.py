@@ -622,8 +622,9 @@ class _StcCellGraph(Function):
                     lead, second = (Xp, RH) if cin[j] == h else (RH, Xp)     # narrow input plane: the 16-wide plane leads
                     k.node_post_fwd(*rows((lead,)), Tc, Wc, bc, *rows((A, Bm)), X2=second.view(B * N, C, second.shape[-1]))
                 # the blend and the aggregation of the new state in one launch where the graph has a two-ring plan and some planar cell will
-                # ask for S.Hnew (stc_ring2_blend_f32: the new state is summed out of LDS instead of being read back by a launch of its own)
-                if (_RING2_FWD and not bf16 and op.fwd_ring2 is not None and not copies and side is None and hasattr(k, 'ring2_blend')
+                # ask for S.Hnew (stc_ring2_blend_f32: the new state is summed out of LDS instead of being read back by a launch of its own; on ring-bounded
+                # clusters it measured 792 us against 548 + 203 for the two launches: tiles only)
+                if (_RING2_FWD and not bf16 and op.fwd_ring2 is not None and not op.ring2_clusters and not copies and side is None and hasattr(k, 'ring2_blend')
                         and any(planar[d] and not planar_k for d, _ in consumers[j])):
                     SHn = torch.empty_like(Hprev)
                     k.ring2_blend(op.fwd_rowptr, op.fwd_colidx, fwd_val, op.fwd_ring2, Bm, A, U, Hprev, Cand, Hnew, SHn)

@@ -17,11 +17,20 @@ def _dense(graph):
     return graph.to_dense().double().numpy()
 
 
-@pytest.mark.parametrize('H,W', [(12, 20), (9, 33), (31, 8)])
-def test_two_ring_plan_reproduces_the_matrix(H, W):
+def _renumbered(H, W, seed=1234):
+    """The grid under a seeded random node order, renumbered by the host (reverse Cuthill-McKee): not a lattice in its numbering any more, so
+    its two-ring patches are clusters grown under the ring bounds (graph.py _ring2_groups)."""
+    graph, order = CsrGraph.queen_grid(H, W, normalize=True, permute_seed=seed).with_locality(collective=False)
+    assert order is not None                                          # (the random order costs enough row fetches for the host to renumber)
+    return graph
+
+
+@pytest.mark.parametrize('H,W,renumbered', [(12, 20, False), (9, 33, False), (31, 8, False), (24, 30, True), (40, 17, True)])
+def test_two_ring_plan_reproduces_the_matrix(H, W, renumbered):
     """The plan's tables ARE the matrix: level 2 rebuilds every row of S over the first ring's slots, level 1 every first-ring row over the
-    staged rows; every row of S is some patch's own row exactly once; rings within their sizes."""
-    graph = CsrGraph.queen_grid(H, W, normalize=True)
+    staged rows; every row of S is some patch's own row exactly once; rings within their sizes.  Lattices (4 x 8 tiles) and a grid whose
+    numbering is not a lattice (ring-bounded clusters)."""
+    graph = _renumbered(H, W) if renumbered else CsrGraph.queen_grid(H, W, normalize=True)
     h = graph._host
     assert 'bwd_r2_l2' in h
     S = _dense(graph)                                                 # Gs itself: the backward operand
@@ -48,6 +57,8 @@ def test_two_ring_plan_reproduces_the_matrix(H, W):
             assert np.allclose(got, S[u], atol=1e-7)
     assert (seen == 1).all()
     assert l1.shape[1] == RING2_FIRST and l2.shape[1] == RING2_SECOND and own.shape[1] == RING2_INTERIOR
+    if renumbered:
+        assert 'bwd_pt_src' in h and n / l2.shape[0] >= 16          # the patch form's clusters did not fit the rings; these do, at a useful size
 
 
 def test_graphs_whose_rings_do_not_fit_get_no_two_ring_plan():
@@ -183,3 +194,42 @@ def test_two_ring_chain_on_the_gpu(H, W, B, dual, n1, n0, keep, alpha1, alpha2):
     hip.ring2_chain(op_g.bwd_rowptr, op_g.bwd_colidx, op_g.bwd_val, op_g.bwd_ring2, cu(X), cu(X2), alpha1, [cu(t) for t in add1], None, alpha2,
                     [(cu(t), s) for t, s in add0], Z3)
     assert torch.equal(Z3, Z)                                          # reproducible, with or without the stored V
+
+
+@pytest.mark.gpu
+def test_two_ring_launches_on_a_renumbered_grid_on_the_gpu():
+    """The three entry points on ring-bounded CLUSTERS (a grid under a random node order, renumbered by the host: patches of 24 - 32 rows, ragged
+    rings) against the launches they replace."""
+    from stc_hip._lib import HipKernels
+    hip = HipKernels()
+    H, W, B, C, h = 48, 56, 2, 32, 16
+    graph = _renumbered(H, W)
+    n = H * W
+    op = csr_operand(graph, torch.device('cuda'))
+    assert op.bwd_ring2 is not None and op.fwd_ring2 is not None
+    g = torch.Generator().manual_seed(11)
+    rnd = lambda: torch.randn(B, n, C, h, generator=g).cuda()
+    bwd, fwd = (op.bwd_rowptr, op.bwd_colidx, op.bwd_val), (op.fwd_rowptr, op.fwd_colidx, op.fwd_val)
+    v3 = lambda t: t.view(B, n, C * h)
+    # sum
+    X, add, U, Cand = rnd(), rnd(), torch.sigmoid(rnd()), torch.tanh(rnd())
+    Y, Z, Y2, dY2, Z2 = (torch.empty(B, n, C, h).cuda() for _ in range(5))
+    hip.ring2_sum(*bwd, op.bwd_ring2, X, None, [add], U, Cand, Y, Z)
+    hip.spmm_sum(*bwd, op.bwd_plan, X, None, [(add, 0)], Y2, blend=(U, Cand, dY2))
+    hip.csr_spmm(*bwd, n, n, v3(dY2), None, v3(Z2), 1.0, 0.0, plan=op.bwd_plan)
+    assert rel_err(Y, Y2) < 1e-6 and rel_err(Z, Z2) < 1e-6
+    # blend
+    Bm, A, Hp = rnd(), rnd(), torch.tanh(rnd())
+    got = [torch.empty(B, n, C, h).cuda() for _ in range(3)]
+    want = [torch.empty(B, n, C, h).cuda() for _ in range(3)]
+    hip.ring2_blend(*fwd, op.fwd_ring2, Bm, A, U, Hp, *got)
+    hip.spmm_blend_fwd(*fwd, op.fwd_plan, Bm, A, U, Hp, want[0], want[1])
+    hip.csr_spmm(*fwd, n, n, v3(want[1]), None, v3(want[2]), 1.0, 0.0, plan=op.fwd_plan)
+    for a, w in zip(got, want):
+        assert rel_err(a, w) < 2e-6
+    # chain: the forward recurrence
+    T1, T2, S1, S2 = (torch.empty(B, n, C, h).cuda() for _ in range(4))
+    hip.ring2_chain(*fwd, op.fwd_ring2, X, None, 1.0, [], T1, 2.0, [(X, -1.0)], T2)
+    hip.csr_spmm(*fwd, n, n, v3(X), None, v3(S1), 1.0, 0.0, plan=op.fwd_plan)
+    hip.csr_spmm(*fwd, n, n, v3(S1), v3(X), v3(S2), 2.0, -1.0, plan=op.fwd_plan)
+    assert rel_err(T1, S1) < 2e-6 and rel_err(T2, S2) < 2e-6
