@@ -34,3 +34,10 @@ us = timed(lambda i: torch.add(bufs[i % 6], bufs[(i + 1) % 6], out=out[i % 6]))
 print(f'add (2 R + 1 W)          {us:7.1f} us  {3 * mb / us:6.2f} TB/s')
 us = timed(lambda i: torch.addcmul(bufs[i % 6], bufs[(i + 1) % 6], bufs[(i + 2) % 6], out=out[i % 6]))
 print(f'addcmul (3 R + 1 W)      {us:7.1f} us  {4 * mb / us:6.2f} TB/s')
+
+# the SURVEY 8(d3) unit's two planes (B = 1, N = 50 176, F = 1024 floats: 205.5 MB each), buffers rotated so that nothing is cache-resident
+m = 50176 * 1024
+src = [torch.randn(m, device=dev) for _ in range(6)]
+dst = [torch.empty(m, device=dev) for _ in range(6)]
+us = timed(lambda i: dst[i % 6].copy_(src[i % 6]), reps=60)
+print(f'copy of the 8(d3) unit   {us:7.1f} us  {2 * m * 4 / 1e6 / us:6.2f} TB/s   (the unit itself: 414.4 MB of algorithmic bytes)')
