@@ -567,7 +567,9 @@ int stc_head_bwd_f32(const float* H, const float* w, const float* y, const float
  * (batch, N*C, 16), optional: the gate / candidate pre-activation gradients -- and stc_graph_grad_f32 / stc_mix_grad_f32 form
  * dGs^T = sum dZ1 x Z0 and dT_c = sum V_c x dY with a few stacked products per backward pass (stc_hip/small.py).  NULL = not wanted.
  * graph_is_dense != 0: the caller vouches that the CSR is the FULL n x n pattern with columns in order (nnz = n*n), i.e. val is a dense
- * row-major matrix (graph.full_pattern): the aggregations then run as matrix products on the staged planes instead of row gathers.
+ * row-major matrix (graph.full_pattern): the aggregations then run as matrix products instead of row gathers -- on the staged planes with
+ * phase = 0; in the split forward (phase != 0, since round 5) over the node tiles that cover the workgroup's own rows, sources read from
+ * global memory, so that the pairs 5 / 6 work for dense graphs too (a boundary node tile is formed by both neighbours, identically).
  * phase / splits (ABI v20; fused phases v21): phase = 0, splits = 1: the whole cell step in this launch, one workgroup per sample (`batch` of
  * the chip's 256 compute units work).  phase != 0, splits = G: the sample's row tiles are dealt in CONTIGUOUS ranges over G workgroups and
  * the launch runs ONLY phase 1..4 (forward: aggregate, gates, aggregate R*H, candidate; backward: candidate convolution,

@@ -175,6 +175,72 @@ __device__ __forceinline__ void aggregate_dense(const float* __restrict__ S, int
     }
 }
 
+// The dense aggregation for the rows a workgroup OWNS (split form, nothing staged): out[node][c][0 .. 4 QUADS) = sum_m S[node][m] src[m][c][.] for the
+// node tiles that cover the nodes [n_lo, n_hi), the source rows read from global memory (src: rows of `stride` floats per (node, category), `ncols`
+// of them meaningful -- columns beyond read as zero).  Neighbouring workgroups share a boundary node tile and both compute and store it: the same
+// sums in the same order, the same bytes.  With it a phase that needs the aggregate of its own rows only can follow in the same launch.
+template <int THREADS, int QUADS, class Store>
+__device__ __forceinline__ void aggregate_dense_own(const float* __restrict__ S, int N, int C, const float* src, int stride, int ncols, int n_lo, int n_hi,
+                                                    Store store) {
+    constexpr int CT = (QUADS + 3) / 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, kq = lane >> 4;
+    const int rtiles = (N + 15) >> 4, per_rt = C * CT, pairs = (per_rt + 1) >> 1;
+    const int rt_lo = n_lo >> 4, rt_hi = (n_hi + 15) >> 4, items = (rt_hi - rt_lo) * pairs;
+    const bool vec = (N & 3) == 0;
+    for (int item = wave; item < items; item += THREADS / 64) {
+        const int rt = rt_lo + item / pairs, t0 = 2 * (item - (rt - rt_lo) * pairs), t1 = min(t0 + 1, per_rt - 1);
+        const bool two = t0 + 1 < per_rt;
+        const int c0 = t0 / CT, lb0 = t0 - c0 * CT, c1 = t1 / CT, lb1 = t1 - c1 * CT;
+        const int node = 16 * rt + j;
+        const bool node_ok = node < N;
+        const unsigned srow = (unsigned)(node_ok ? node : 0) * N;
+        const int col0 = 16 * lb0 + j, col1 = 16 * lb1 + j;
+        const bool ok0 = col0 < ncols, ok1 = col1 < ncols;
+        const unsigned a0 = (unsigned)c0 * stride + (ok0 ? col0 : 0), a1 = (unsigned)c1 * stride + (ok1 ? col1 : 0);
+        auto load_s = [&](int kb) {
+            const int k0 = 16 * kb + 4 * kq;
+            if (vec) return ld4(S + (k0 < N ? srow + k0 : srow));
+            f32x4 v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = S[srow + min(k0 + i, N - 1)];
+            return v;
+        };
+        auto load_a = [&](int kb, float (&x0)[4], float (&x1)[4]) {         // the lane's source values of four steps (clamped rows; masked where consumed)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned mrow = (unsigned)(min(16 * kb + 4 * kq + i, N - 1) * C) * stride;
+                x0[i] = src[mrow + a0];
+                x1[i] = src[mrow + a1];
+            }
+        };
+        f32x4 acc0 = zero4(), acc1 = zero4(), bn = load_s(0);
+        float xn0[4], xn1[4];
+        load_a(0, xn0, xn1);
+        for (int kb = 0; kb < rtiles; ++kb) {
+            const f32x4 b = bn;
+            float x0[4], x1[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { x0[i] = xn0[i]; x1[i] = xn1[i]; }
+            if (kb + 1 < rtiles) {                                       // the next block's operands are requested before this block's products
+                bn = load_s(kb + 1);
+                load_a(kb + 1, xn0, xn1);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = 16 * kb + 4 * kq + i;
+                const float bv = node_ok && m < N ? b[i] : 0.f;
+                acc0 = mfma4(ok0 ? x0[i] : 0.f, bv, acc0);
+                acc1 = mfma4(ok1 ? x1[i] : 0.f, bv, acc1);
+            }
+        }
+        if (node_ok) {
+            const int q0 = 4 * lb0 + kq, q1 = 4 * lb1 + kq;
+            if (q0 < QUADS) store(node * C + c0, q0, acc0);
+            if (two && q1 < QUADS) store(node * C + c1, q1, acc1);
+        }
+    }
+}
+
 template <int THREADS>
 __device__ __forceinline__ void stage_graph(const SmallGraph& g, int N, int* gp, int* gc, float* gv) {
     for (int i = threadIdx.x; i <= N; i += THREADS) gp[i] = g.rowptr[i];
@@ -316,11 +382,12 @@ struct SmallFwd {
 template <int KC>
 __host__ __device__ constexpr int fwd_lds_fixed() { return 0; }                                         // floats of LDS every launch needs
 
-// MODE 0: graph and planes read from global memory; 1: CSR graph + planes staged in LDS; 2: dense graph (matrix-product aggregation), planes staged
+// MODE 0: graph and planes read from global memory; 1: CSR graph + planes staged in LDS; 2: dense graph (matrix-product aggregation), planes staged;
+// 3: dense graph in the split form (phase != 0): nothing staged, a workgroup aggregates the node tiles that cover its own rows (aggregate_dense_own)
 template <int KC, int XQ, int MODE>
 __global__ __launch_bounds__(SF_THREADS) void small_fwd_kernel(SmallFwd a) {
     constexpr int LP = 16 + 4 * XQ, XS = XQ == 4 ? 4 : XQ, SP = plane_stride(XQ);
-    constexpr bool STAGED = MODE >= 1, DENSE = MODE == 2;
+    constexpr bool STAGED = MODE == 1 || MODE == 2, DENSE = MODE >= 2;
     extern __shared__ __align__(16) float lds[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, j = lane & 15, kq = lane >> 4;
     const int C = a.C, N = a.N, NC = N * C, cin = a.cin;
@@ -352,6 +419,7 @@ __global__ __launch_bounds__(SF_THREADS) void small_fwd_kernel(SmallFwd a) {
     auto sync = [&](int after) { if (phase == 0 || (phase == 5 && after == 1) || (phase == 6 && after == 3)) __syncthreads(); };
     const int t_lo = (int)((long long)a.tiles * split / splits), t_hi = (int)((long long)a.tiles * (split + 1) / splits);
     const int row_lo = min(t_lo * a.rpt, NC), row_hi = min(t_hi * a.rpt, NC);
+    const int n_lo = div_c(row_lo, invC), n_hi = div_c(row_hi + C - 1, invC);      // the nodes of the workgroup's own rows (whole nodes: rpt = a multiple of C)
 
     // 0: tables, graph and the sample's rows into LDS (the gates' W operands are requested first: in flight during phases 0 and 1)
     const int ct = wave & 1;                                 // gates: wave w owns column tile w % 2 (0: update, 1: reset)
@@ -403,9 +471,13 @@ __global__ __launch_bounds__(SF_THREADS) void small_fwd_kernel(SmallFwd a) {
     if (runs(1)) {
         auto none = [](int, int) -> f32x4 { return zero4(); };
         auto put = [&](int row, int q, f32x4 s) { st4(Zgb + (unsigned)row * LP + 4 * q, s); };
-        if (DENSE)
+        if (DENSE && STAGED) {
             aggregate_dense<SF_THREADS, LP / 4>(a.g.val, N, C, P, SP, 0, 1, none, put);
-        else
+        } else if (DENSE) {                                  // the H block and the X block of the slab from their own planes
+            aggregate_dense_own<SF_THREADS, 4>(a.g.val, N, C, Hb, SC_H, SC_H, n_lo, n_hi, put);
+            aggregate_dense_own<SF_THREADS, XQ>(a.g.val, N, C, Xb, cin, cin, n_lo, n_hi,
+                                                [&](int row, int q, f32x4 s) { st4(Zgb + (unsigned)row * LP + SC_H + 4 * q, s); });
+        } else
             aggregate_rows<SF_THREADS, LP / 4>(gp, gc, gv, NC, C, invC, row_lo, row_hi,
                 [&](int src, int q) -> f32x4 {
                     if (STAGED) return ld4(P + (unsigned)src * SP + 4 * q);
@@ -450,8 +522,10 @@ __global__ __launch_bounds__(SF_THREADS) void small_fwd_kernel(SmallFwd a) {
     if (runs(3)) {
         auto none = [](int, int) -> f32x4 { return zero4(); };
         auto put = [&](int row, int q, f32x4 s) { st4(Zcb + (unsigned)row * SC_H + 4 * q, s); };
-        if (DENSE)
+        if (DENSE && STAGED)
             aggregate_dense<SF_THREADS, 4>(a.g.val, N, C, Q, SQ, 0, 1, none, put);
+        else if (DENSE)
+            aggregate_dense_own<SF_THREADS, 4>(a.g.val, N, C, RHb, SC_H, SC_H, n_lo, n_hi, put);
         else
             aggregate_rows<SF_THREADS, 4>(gp, gc, gv, NC, C, invC, row_lo, row_hi,
                 [&](int src, int q) -> f32x4 { return STAGED ? ld4(Q + (unsigned)src * SQ + 4 * q) : ld4(RHb + (unsigned)src * SC_H + 4 * q); }, none, put);
@@ -941,11 +1015,13 @@ extern "C" int stc_cell_small_fwd_f32(const int32_t* rowptr, const int32_t* coli
     SmallFwd a{{rowptr, colidx, val, nnz}, X, H, Tc, Wg, bg, Wc, bc, U, R, Cand, Hnew, RH, Zg, Zc, Z0, Z0c, Z1c, n_nodes, C, cin, rpt,
                (n_nodes + npt - 1) / npt, phase};
     const size_t fixed = (size_t)fwd_lds_fixed<2>() * 4, planes = (size_t)n_nodes * C * (plane_stride(xq) + SQ) * 4;
-    const bool dense = phase == 0 && graph_is_dense && nnz == (long long)n_nodes * n_nodes && fixed + planes <= SC_LDS_BUDGET;
+    const bool dense_graph = graph_is_dense && nnz == (long long)n_nodes * n_nodes;
+    const bool dense = phase == 0 && dense_graph && fixed + planes <= SC_LDS_BUDGET;
     const size_t staged = fixed + planes + (dense ? 0 : graph_lds_bytes(n_nodes, nnz));
-    const int mode = dense ? 2 : (phase == 0 && staged <= SC_LDS_BUDGET ? 1 : 0);
-    const size_t lds = mode ? staged : fixed;
-    auto kern = mode == 2 ? (xq == 4 ? small_fwd_kernel<2, 4, 2> : small_fwd_kernel<2, 1, 2>)
+    const int mode = dense ? 2 : (phase != 0 && dense_graph ? 3 : (phase == 0 && staged <= SC_LDS_BUDGET ? 1 : 0));
+    const size_t lds = mode == 1 || mode == 2 ? staged : fixed;
+    auto kern = mode == 3 ? (xq == 4 ? small_fwd_kernel<2, 4, 3> : small_fwd_kernel<2, 1, 3>)
+              : mode == 2 ? (xq == 4 ? small_fwd_kernel<2, 4, 2> : small_fwd_kernel<2, 1, 2>)
               : mode == 1 ? (xq == 4 ? small_fwd_kernel<2, 4, 1> : small_fwd_kernel<2, 1, 1>)
                           : (xq == 4 ? small_fwd_kernel<2, 4, 0> : small_fwd_kernel<2, 1, 0>);
     const hipError_t e = allow_lds_once(kern, lds, g_granted[0][xq == 4][mode]);

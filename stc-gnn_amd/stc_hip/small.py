@@ -105,11 +105,10 @@ class _StcSmallGraph(Function):
         source = lambda src: ext[src[1]] if src[0] == 'ext' else state[src[1]]
         # Few samples: a cell step runs as a few launches over several workgroups per sample (each owning a contiguous range of row tiles)
         # instead of one launch with one workgroup per sample -- at the SF shape (batch 32) backward 79 -> ~45 us per cell in three
-        # launches, forward 35 -> 24 us in two.  Dense learned graphs: the forward stays one launch on the staged planes (its aggregations
-        # are matrix products there; the split forward would gather N neighbour rows per row from L2), the backward splits with its
-        # aggregations as matrix products over all workgroups.
+        # launches, forward 35 -> 24 us in two.  Dense learned graphs split alike: their aggregations are matrix products, in the forward over
+        # the node tiles that cover a workgroup's own rows (so that the phase pairs still share a launch), in the backward over all workgroups.
         splits = k.cell_small_splits(B, N * C)
-        fwd_splits = splits if op.nnz != N * N else 1
+        fwd_splits = splits
         for j, (s_id, x, hs) in enumerate(schedule):
             Wg, bg, Wc, bc = stacks[s_id]
             w, i = pos[j]
