@@ -568,13 +568,13 @@ int stc_head_bwd_f32(const float* H, const float* w, const float* y, const float
  * dGs^T = sum dZ1 x Z0 and dT_c = sum V_c x dY with a few stacked products per backward pass (stc_hip/small.py).  NULL = not wanted.
  * graph_is_dense != 0: the caller vouches that the CSR is the FULL n x n pattern with columns in order (nnz = n*n), i.e. val is a dense
  * row-major matrix (graph.full_pattern): the aggregations then run as matrix products instead of row gathers -- on the staged planes with
- * phase = 0; in the split forward (phase != 0, since round 5) over the node tiles that cover the workgroup's own rows, sources read from
- * global memory, so that the pairs 5 / 6 work for dense graphs too (a boundary node tile is formed by both neighbours, identically).
+ * phase = 0; in the split form (phase != 0; since round 5) over the node tiles that cover the workgroup's own rows, sources read from
+ * global memory, so that the pairs 5 / 6 / 7 work for dense graphs too (a boundary node tile is formed by both neighbours; each stores its own rows).
  * phase / splits (ABI v20; fused phases v21): phase = 0, splits = 1: the whole cell step in this launch, one workgroup per sample (`batch` of
  * the chip's 256 compute units work).  phase != 0, splits = G: the sample's row tiles are dealt in CONTIGUOUS ranges over G workgroups and
  * the launch runs ONLY phase 1..4 (forward: aggregate, gates, aggregate R*H, candidate; backward: candidate convolution,
  * transpose-aggregate + gate backward, gates convolution, transpose-aggregate) or, v21, a pair of phases whose second half reads only the
- * workgroup's own rows: forward 5 = 1 + 2, 6 = 3 + 4; backward 7 = 2 + 3 (not with graph_is_dense: a dense backward deals node tiles).
+ * workgroup's own rows: forward 5 = 1 + 2, 6 = 3 + 4; backward 7 = 2 + 3 (dense graphs too, since round 5).
  * The caller launches the phases in order -- (5, 6) and (1, 7, 4), or one by one -- the launch boundaries being the barriers; same
  * buffers, same results.  The workspace holds three gradient slabs and the gate gradients per row (stc_cell_small_workspace_bytes).
  * dparams then has R * G rows per sample (row (b * G + g) * R + r). */

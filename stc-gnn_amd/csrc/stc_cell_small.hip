@@ -177,11 +177,12 @@ __device__ __forceinline__ void aggregate_dense(const float* __restrict__ S, int
 
 // The dense aggregation for the rows a workgroup OWNS (split form, nothing staged): out[node][c][0 .. 4 QUADS) = sum_m S[node][m] src[m][c][.] for the
 // node tiles that cover the nodes [n_lo, n_hi), the source rows read from global memory (src: rows of `stride` floats per (node, category), `ncols`
-// of them meaningful -- columns beyond read as zero).  Neighbouring workgroups share a boundary node tile and both compute and store it: the same
-// sums in the same order, the same bytes.  With it a phase that needs the aggregate of its own rows only can follow in the same launch.
-template <int THREADS, int QUADS, class Store>
+// of them meaningful -- columns beyond read as zero), store(row, quad, base(row, quad) + sum) for the OWN rows [row_lo, row_hi) only.  Neighbouring
+// workgroups share a boundary node tile and both compute it (what they do not own they drop), so a store callback may accumulate in place and a
+// phase that needs the aggregate of its own rows only can follow in the same launch.
+template <int THREADS, int QUADS, class Base, class Store>
 __device__ __forceinline__ void aggregate_dense_own(const float* __restrict__ S, int N, int C, const float* src, int stride, int ncols, int n_lo, int n_hi,
-                                                    Store store) {
+                                                    int row_lo, int row_hi, Base base, Store store) {
     constexpr int CT = (QUADS + 3) / 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, kq = lane >> 4;
     const int rtiles = (N + 15) >> 4, per_rt = C * CT, pairs = (per_rt + 1) >> 1;
@@ -234,9 +235,19 @@ __device__ __forceinline__ void aggregate_dense_own(const float* __restrict__ S,
             }
         }
         if (node_ok) {
-            const int q0 = 4 * lb0 + kq, q1 = 4 * lb1 + kq;
-            if (q0 < QUADS) store(node * C + c0, q0, acc0);
-            if (two && q1 < QUADS) store(node * C + c1, q1, acc1);
+            const int q0 = 4 * lb0 + kq, q1 = 4 * lb1 + kq, r0 = node * C + c0, r1 = node * C + c1;
+            if (q0 < QUADS && r0 >= row_lo && r0 < row_hi) {
+                f32x4 s = base(r0, q0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s[i] += acc0[i];
+                store(r0, q0, s);
+            }
+            if (two && q1 < QUADS && r1 >= row_lo && r1 < row_hi) {
+                f32x4 s = base(r1, q1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s[i] += acc1[i];
+                store(r1, q1, s);
+            }
         }
     }
 }
@@ -474,8 +485,8 @@ __global__ __launch_bounds__(SF_THREADS) void small_fwd_kernel(SmallFwd a) {
         if (DENSE && STAGED) {
             aggregate_dense<SF_THREADS, LP / 4>(a.g.val, N, C, P, SP, 0, 1, none, put);
         } else if (DENSE) {                                  // the H block and the X block of the slab from their own planes
-            aggregate_dense_own<SF_THREADS, 4>(a.g.val, N, C, Hb, SC_H, SC_H, n_lo, n_hi, put);
-            aggregate_dense_own<SF_THREADS, XQ>(a.g.val, N, C, Xb, cin, cin, n_lo, n_hi,
+            aggregate_dense_own<SF_THREADS, 4>(a.g.val, N, C, Hb, SC_H, SC_H, n_lo, n_hi, row_lo, row_hi, none, put);
+            aggregate_dense_own<SF_THREADS, XQ>(a.g.val, N, C, Xb, cin, cin, n_lo, n_hi, row_lo, row_hi, none,
                                                 [&](int row, int q, f32x4 s) { st4(Zgb + (unsigned)row * LP + SC_H + 4 * q, s); });
         } else
             aggregate_rows<SF_THREADS, LP / 4>(gp, gc, gv, NC, C, invC, row_lo, row_hi,
@@ -525,7 +536,7 @@ __global__ __launch_bounds__(SF_THREADS) void small_fwd_kernel(SmallFwd a) {
         if (DENSE && STAGED)
             aggregate_dense<SF_THREADS, 4>(a.g.val, N, C, Q, SQ, 0, 1, none, put);
         else if (DENSE)
-            aggregate_dense_own<SF_THREADS, 4>(a.g.val, N, C, RHb, SC_H, SC_H, n_lo, n_hi, put);
+            aggregate_dense_own<SF_THREADS, 4>(a.g.val, N, C, RHb, SC_H, SC_H, n_lo, n_hi, row_lo, row_hi, none, put);
         else
             aggregate_rows<SF_THREADS, 4>(gp, gc, gv, NC, C, invC, row_lo, row_hi,
                 [&](int src, int q) -> f32x4 { return STAGED ? ld4(Q + (unsigned)src * SQ + 4 * q) : ld4(RHb + (unsigned)src * SC_H + 4 * q); }, none, put);
@@ -839,6 +850,7 @@ __global__ __launch_bounds__(SB_THREADS) void small_bwd_kernel(SmallBwd a) {
     auto sync = [&](int after) { if (phase == 0 || (phase == 7 && after == 2)) __syncthreads(); };
     const int t_lo = (int)((long long)a.tiles * split / splits), t_hi = (int)((long long)a.tiles * (split + 1) / splits);
     const int row_lo = min(t_lo * a.rpt, NC), row_hi = min(t_hi * a.rpt, NC);
+    const int n_lo = div_c(row_lo, invC), n_hi = div_c(row_hi + C - 1, invC);      // the nodes of the workgroup's own rows
     const int tile0 = t_lo + (wave >> 2), tstep = SB_WAVES / 4;
     float* dPw = a.dP + (((size_t)blockIdx.x * splits + split) * (SB_WAVES / 4) + (wave >> 2)) * a.P;
     float* dWg = dPw;
@@ -906,7 +918,9 @@ __global__ __launch_bounds__(SB_THREADS) void small_bwd_kernel(SmallBwd a) {
                 }
             }
         };
-        if (DENSE)
+        if (DENSE && !STAGED)
+            aggregate_dense_own<SB_THREADS, LP / 4>(a.g.val, N, C, dZ1, LP, LP, n_lo, n_hi, row_lo, row_hi, from_dz0, gate_bwd);
+        else if (DENSE)
             aggregate_dense<SB_THREADS, LP / 4>(a.g.val, N, C, dZ1, LP, split, splits, from_dz0, gate_bwd);
         else
             aggregate_rows<SB_THREADS, LP / 4>(gp, gc, gv, NC, C, invC, row_lo, row_hi, from_dz1, from_dz0, gate_bwd);
@@ -945,7 +959,9 @@ __global__ __launch_bounds__(SB_THREADS) void small_bwd_kernel(SmallBwd a) {
                     }
                 }
             };
-        if (DENSE)
+        if (DENSE && !STAGED)
+            aggregate_dense_own<SB_THREADS, LP / 4>(a.g.val, N, C, dZ1s, LP, LP, n_lo, n_hi, row_lo, row_hi, from_dz0, add_in);
+        else if (DENSE)
             aggregate_dense<SB_THREADS, LP / 4>(a.g.val, N, C, dZ1s, LP, split, splits, from_dz0, add_in);
         else
             aggregate_rows<SB_THREADS, LP / 4>(gp, gc, gv, NC, C, invC, row_lo, row_hi, from_dz1, from_dz0, add_in);
@@ -1056,8 +1072,6 @@ extern "C" int stc_cell_small_bwd_f32(const int32_t* rowptr, const int32_t* coli
                dZ1c, dZ1g, dYg, dYc, n_nodes, C, cin, rpt, (n_nodes + npt - 1) / npt, accumulate_x, accumulate_h, has_bg, has_bc, phase, params_ld};
     STC_REQUIRE(((phase >= 0 && phase <= 4) || phase == 7) && splits >= 1 && splits <= 64 && (phase != 0 || splits == 1), STC_EINVAL,
                 "stc_cell_small_bwd_f32: phase %d / splits %d (0 = the whole cell; 1..4 = one phase; 7 = 2 + 3)", phase, splits);
-    STC_REQUIRE(phase != 7 || !(graph_is_dense && nnz == (long long)n_nodes * n_nodes), STC_EINVAL,
-                "stc_cell_small_bwd_f32: the fused phase is for CSR graphs (a dense graph's aggregation deals node tiles, not row tiles, over the workgroups)");
     const size_t fixed = (size_t)bwd_lds_fixed<2>() * 4, planes = (size_t)n_nodes * C * LP * 4;
     const bool full = graph_is_dense && nnz == (long long)n_nodes * n_nodes;
     const bool dense = phase == 0 && full && fixed + planes <= SC_LDS_BUDGET;

@@ -1009,11 +1009,9 @@ class HipKernels:
                          Hnew.data_ptr(), RH.data_ptr(), Zg.data_ptr(), Zc.data_ptr(), _ptr(Z0), _ptr(Z0c), _ptr(Z1c), phase, splits, B, Cc,
                          nbytes=(4 * B * N * Cc * (cin + 16 * 8 + 2 * self.cell_small_zg_width(cin))) // (1 if splits == 1 else len(self.SMALL_FWD_PHASES)))
 
-    # Launches of a split cell step (phase codes of stc_cell_small_*_f32; 5 = 1 + 2, 6 = 3 + 4, 7 = 2 + 3).  A dense graph's backward
-    # aggregation deals node tiles (not row tiles) over the workgroups: one phase per launch there.
+    # Launches of a split cell step (phase codes of stc_cell_small_*_f32; 5 = 1 + 2, 6 = 3 + 4, 7 = 2 + 3), CSR and dense graphs alike
     SMALL_FWD_PHASES = (5, 6)
     SMALL_BWD_PHASES = (1, 7, 4)
-    SMALL_BWD_PHASES_DENSE = (1, 2, 3, 4)
 
     @staticmethod
     def cell_small_splits(batch: int, rows: int = 0) -> int:
@@ -1047,7 +1045,7 @@ class HipKernels:
         nbytes = self.lib.stc_cell_small_workspace_bytes(N, Cc, cin, B)
         ws = self._get_workspace(H.device, nbytes)
         dense = int(is_full_pattern(colidx, N, N))
-        phases = (0,) if splits == 1 else self.SMALL_BWD_PHASES_DENSE if dense else self.SMALL_BWD_PHASES
+        phases = (0,) if splits == 1 else self.SMALL_BWD_PHASES
         for phase in phases:
             self._launch('stc_cell_small_bwd_f32', H, rowptr.data_ptr(), colidx.data_ptr(), val.data_ptr(), N, val.numel(), dense, X.data_ptr(), cin,
                          H.data_ptr(), Tc.data_ptr(), Kc, Wg.data_ptr(), Wc.data_ptr(), U.data_ptr(), R.data_ptr(), Cand.data_ptr(), RH.data_ptr(),
