@@ -527,7 +527,9 @@ def main():
     crit = ComboLoss()
     bucket = sdist.GradBucket(model.parameters())
     graphed = a.hip_graph and world == 1
-    opt = torch.optim.Adam(model.parameters(), lr=2e-3, weight_decay=1e-4, capturable=graphed, **({'fused': True} if learned else {}))
+    # learned graphs: the two MixedFusion matrices (2 x 400 MB at the SF shape) on stc_adam_f32, the rest on torch's fused Adam (stc_hip/optim.py)
+    from stc_hip.optim import Adam as StcAdam
+    opt = (StcAdam if learned else torch.optim.Adam)(model.parameters(), lr=2e-3, weight_decay=1e-4, capturable=graphed, **({'fused': True} if learned else {}))
     stream = torch.cuda.current_stream(dev)
     marks = []                                                                  # (t_begin, t_backward_done, t_allreduce_done, t_adam_done) events
 

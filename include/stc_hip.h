@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define STC_ABI_VERSION 28
+#define STC_ABI_VERSION 29
 #define STC_MAX_K 4          /* highest Chebyshev order (Ks, Kc) the node kernels accept */
 
 /* Operand formats of the split-operand matrix-core kernels (C = 32 / 64, hidden 16).  Every fp32 operand is split into low-precision
@@ -622,6 +622,15 @@ int stc_mixed_fusion_fwd_f32(const float* WA, const float* bA, const float* WP, 
 int stc_mixed_fusion_bwd_f32(const float* WA, const float* WP, const float* A, const float* P, const float* gate, const float* dG,
                              float* dWA, float* dWP, float* db, float* dP, float* dA,
                              void* workspace, size_t workspace_bytes, int32_t D, void* stream);
+/* Adam on one large fp32 parameter (ABI v29; the optimizer of the reference's harness step, Model_Trainer.py:71-87: torch.optim.Adam with
+ * L2 weight decay, no amsgrad), one streaming launch: the two MixedFusion matrices above are 2 x 400 MB at the SF shape.
+ *     g' = g + weight_decay p;   m = m + (1 - beta1)(g' - m);   v = beta2 v + (1 - beta2) g'^2
+ *     p -= lr / (1 - beta1^t) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps)
+ * t = *step, a DEVICE float the caller has already incremented (so a captured launch replays with the right bias corrections).
+ * n a multiple of 4, all tensors 16-byte aligned and distinct.  The hyper-parameters come as doubles: 1 - beta is formed in double, as torch forms it. */
+int stc_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, const float* step, double lr, double beta1, double beta2, double eps,
+                 double weight_decay, void* stream);
+
 
 /* ---- small helpers ---------------------------------------------------------
  * y += a*x over n elements (Chebyshev backward g_{k-2} -= g_k) */

@@ -184,3 +184,76 @@ extern "C" int stc_mixed_fusion_bwd_f32(const float* WA, const float* WP, const 
     STC_LAUNCH_CHECK("stc_mixed_fusion_bwd_f32 launch");
     return STC_OK;
 }
+
+// ---- Adam over a large parameter (the harness step of Model_Trainer.py:71-87: torch.optim.Adam(lr, weight_decay), no amsgrad) ----------------
+// The two MixedFusion matrices are 99.99 % of the learned-graph model; torch's fused multi-tensor Adam moves their 5.6 GB per step at 4.4 TB/s
+// (1.26 of the SF step's 6.0 ms).  One streaming launch per tensor: p, g, m, v read once, p, m, v written once, 16-byte non-temporal accesses.
+// The step count lives on the device (`step`: one float, already incremented by the caller) so that a captured HIP graph replays with the
+// right bias corrections.
+namespace {
+
+constexpr int AD_THREADS = 256, AD_PIECES = 4;      // 16-byte pieces per lane and trip: 4 x 4 planes in flight
+
+__global__ __launch_bounds__(AD_THREADS) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                          long long n4, const float* __restrict__ step, float lr, float beta1, float beta2,
+                                                          float omb1, float omb2, float eps, float weight_decay) {      // omb = 1 - beta, formed in double
+    const float t = *step;
+    const float bc1 = 1.f - powf(beta1, t), bc2_sqrt = sqrtf(1.f - powf(beta2, t));
+    const float step_size = lr / bc1, inv_bc2_sqrt = 1.f / bc2_sqrt;
+    v4f* p4 = reinterpret_cast<v4f*>(p);
+    const v4f* g4 = reinterpret_cast<const v4f*>(g);
+    v4f* m4 = reinterpret_cast<v4f*>(m);
+    v4f* v4 = reinterpret_cast<v4f*>(v);
+    // a workgroup takes CONTIGUOUS runs of AD_PIECES x 4 KiB per plane and trip (pieces a whole grid apart per lane ran at 4.3 TB/s: sixteen
+    // distant streams per lane)
+    const long long run = (long long)AD_THREADS * AD_PIECES;
+    for (long long i = (long long)blockIdx.x * run + threadIdx.x; i < n4; i += (long long)gridDim.x * run) {
+        constexpr long long stride = AD_THREADS;
+        v4f pp[AD_PIECES], gg[AD_PIECES], mm[AD_PIECES], vv[AD_PIECES];
+#pragma unroll
+        for (int k = 0; k < AD_PIECES; ++k) {
+            const long long at = i + k * stride;
+            if (at < n4) {
+                pp[k] = __builtin_nontemporal_load(p4 + at); gg[k] = __builtin_nontemporal_load(g4 + at);
+                mm[k] = __builtin_nontemporal_load(m4 + at); vv[k] = __builtin_nontemporal_load(v4 + at);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < AD_PIECES; ++k) {
+            const long long at = i + k * stride;
+            if (at < n4) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float grad = fmaf(weight_decay, pp[k][c], gg[k][c]);                  // L2 weight decay folded into the gradient
+                    mm[k][c] = fmaf(omb1, grad - mm[k][c], mm[k][c]);                           // lerp(m, grad, 1 - beta1)
+                    vv[k][c] = fmaf(beta2, vv[k][c], omb2 * grad * grad);
+                    const float denom = fmaf(sqrtf(vv[k][c]), inv_bc2_sqrt, eps);
+                    pp[k][c] -= step_size * (mm[k][c] / denom);
+                }
+                __builtin_nontemporal_store(pp[k], p4 + at);
+                __builtin_nontemporal_store(mm[k], m4 + at);
+                __builtin_nontemporal_store(vv[k], v4 + at);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int stc_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, const float* step, double lr, double beta1, double beta2, double eps,
+                            double weight_decay, void* stream) {
+    STC_REQUIRE(n >= 0 && n % 4 == 0, STC_EINVAL, "stc_adam_f32: %lld elements (a multiple of 4)", (long long)n);
+    if (n == 0) return STC_OK;
+    STC_REQUIRE(p && g && m && v && step, STC_EINVAL, "stc_adam_f32: null pointer");
+    STC_REQUIRE(stc::aligned16(p) && stc::aligned16(g) && stc::aligned16(m) && stc::aligned16(v), STC_EALIGN, "stc_adam_f32: tensors must be 16-byte aligned");
+    STC_REQUIRE(p != g && p != m && p != v && m != v && g != m && g != v, STC_EINVAL, "stc_adam_f32: tensors must be distinct");
+    STC_REQUIRE(lr >= 0. && beta1 >= 0. && beta1 < 1. && beta2 >= 0. && beta2 < 1. && eps >= 0. && weight_decay >= 0., STC_EINVAL,
+                "stc_adam_f32: lr %g, betas (%g, %g), eps %g, weight decay %g", lr, beta1, beta2, eps, weight_decay);
+    const long long n4 = n / 4;
+    const long long want = (n4 + (long long)AD_THREADS * AD_PIECES - 1) / ((long long)AD_THREADS * AD_PIECES);
+    const int grid = (int)(want < 1 ? 1 : (want > 256 * 8 ? 256 * 8 : want));
+    hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(AD_THREADS), 0, static_cast<hipStream_t>(stream), p, g, m, v, n4, step, (float)lr, (float)beta1, (float)beta2,
+                       (float)(1. - beta1), (float)(1. - beta2), (float)eps, (float)weight_decay);
+    STC_LAUNCH_CHECK("stc_adam_f32 launch");
+    return STC_OK;
+}

@@ -21,7 +21,7 @@ from .graph import is_full_pattern
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG_ROOT, 'libstc_hip.so')
-ABI_VERSION = 28
+ABI_VERSION = 29
 FMT_BF16X3, FMT_F16X2 = 0, 1          # STC_FMT_* of include/stc_hip.h: operand formats of the split-operand matrix-core kernels
 MAX_K = 4
 SPMM_SUM_MAX_ADD = 8     # = STC_SPMM_SUM_MAX_ADD of include/stc_hip.h
@@ -43,7 +43,7 @@ EXPORTS = (
     'stc_cell_bwd_planar_supported', 'stc_cell_bwd_planar_workspace_bytes', 'stc_cell_bwd_planar_f32',
     'stc_cell_planar_k_supported', 'stc_cell_gates_fwd_planar_k_f32', 'stc_cell_cand_fwd_planar_k_f32', 'stc_cell_gates_bwd_planar_k_f32',
     'stc_cell_cand_bwd_planar_k_f32',
-    'stc_cell_small_supported', 'stc_cell_small_workspace_bytes', 'stc_cell_small_param_rows', 'stc_graph_grad_f32', 'stc_mix_grad_f32', 'stc_mixed_fusion_workspace_bytes', 'stc_mixed_fusion_fwd_f32', 'stc_mixed_fusion_bwd_f32', 'stc_cell_small_fwd_f32', 'stc_cell_small_bwd_f32',
+    'stc_cell_small_supported', 'stc_cell_small_workspace_bytes', 'stc_cell_small_param_rows', 'stc_graph_grad_f32', 'stc_mix_grad_f32', 'stc_mixed_fusion_workspace_bytes', 'stc_mixed_fusion_fwd_f32', 'stc_mixed_fusion_bwd_f32', 'stc_adam_f32', 'stc_cell_small_fwd_f32', 'stc_cell_small_bwd_f32',
     'stc_gru_gates_fwd_f32', 'stc_gru_gates_bwd_f32', 'stc_gru_blend_fwd_f32', 'stc_gru_blend_bwd_f32',
     'stc_head_fwd_f32', 'stc_head_bwd_workspace_bytes', 'stc_head_bwd_f32',
     'stc_axpy_f32', 'stc_concat2_f32', 'stc_split2_f32',
@@ -79,6 +79,7 @@ def _declare(lib):
         'stc_mixed_fusion_workspace_bytes': [_i32, _i32],
         'stc_mixed_fusion_fwd_f32': [_p] * 8 + [_i32, _p],
         'stc_mixed_fusion_bwd_f32': [_p] * 12 + [C.c_size_t, _i32, _p],
+        'stc_adam_f32': [_p] * 4 + [_i64, _p] + [C.c_double] * 5 + [_p],
         'stc_cell_small_bwd_f32': [_p, _p, _p, _i32, _i32, _i32, _p, _i32, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _i32, _p, _i64, _i32, _i32,
                                    _p, _p, _p, _p, _p, C.c_size_t, _i32, _i32, _i32, _i32, _p],
         'stc_csr_sddmm_f32': [_p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _i32, _p],
@@ -1119,6 +1120,19 @@ class HipKernels:
         self._launch('stc_mixed_fusion_bwd_f32', A, _ptr(WA), _ptr(WP), _ptr(A), _ptr(P), _ptr(gate), _ptr(dG), _ptr(dWA), _ptr(dWP), _ptr(db), _ptr(dP), _ptr(dA),
                      _ptr(ws), ws.numel() * 4, D, nbytes=(4 + (8 if want_dW else 0) + (4 if want_dA else 0)) * D * D)
         return dWA, dWP, db, dP, dA
+
+    def adam(self, p, g, m, v, step, lr, beta1, beta2, eps, weight_decay):
+        """One Adam update of a large fp32 parameter in place (``stc_adam_f32``: torch.optim.Adam's arithmetic with L2 weight decay); ``step``: a
+        one-element float32 DEVICE tensor holding the count of this update (already incremented)."""
+        n = p.numel()
+        for name, t in (('p', p), ('g', g), ('m', m), ('v', v)):
+            self._f32('adam.' + name, t, tuple(p.shape))
+        self._f32('adam.step', step)
+        if step.numel() != 1:
+            raise StcError(f'adam.step: one element, got {tuple(step.shape)}')
+        self._same_device(p, g, m, v, step)
+        self._launch('stc_adam_f32', p, _ptr(p), _ptr(g), _ptr(m), _ptr(v), n, _ptr(step), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
+                     nbytes=28 * n)
 
     # ---- planar cell convolutions of Chebyshev order K = 3 ------------------------------------------------
     def cell_planar_k_supported(self, K, Cc, h) -> bool:

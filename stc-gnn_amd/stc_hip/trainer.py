@@ -22,10 +22,10 @@ from typing import Dict, Iterable, List, Optional
 
 import numpy as np
 import torch
-from torch import optim
 
 from . import dist as sdist
 from .loss import ComboLoss
+from .optim import Adam as StcAdam
 
 
 class Trainer:
@@ -62,8 +62,9 @@ class Trainer:
         self.criterion = ComboLoss()
         self.bucket = sdist.GradBucket(self.model.parameters())        # every .grad is a view into one flat buffer
         self.hip_graph = bool(hip_graph) and self.world == 1 and str(dev).startswith('cuda')
-        self.optimizer = optim.Adam(self.model.parameters(), lr=params['learn_rate'], weight_decay=params['decay_rate'],
-                                    capturable=self.hip_graph)
+        # torch.optim.Adam, with parameters of >= 64 MiB (MixedFusion's two matrices in the learned-graph mode) updated by stc_adam_f32 (optim.py)
+        self.optimizer = StcAdam(self.model.parameters(), lr=params['learn_rate'], weight_decay=params['decay_rate'],
+                                 capturable=self.hip_graph)
         self._captured = {}                                           # batch shape -> [eager steps seen, graph, static x, static y, static loss]
         self._capture_shape = None                                    # only the FIRST batch shape seen (the full batch) is captured
         self._capture_stream = torch.cuda.Stream(dev) if self.hip_graph else None

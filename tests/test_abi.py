@@ -110,7 +110,7 @@ def test_ctypes_signatures_match_the_header():
     lib = _lib.load_library()
     protos = re.findall(r'\b(?:int|size_t|const char\*)\s+(stc_[a-z0-9_]+)\s*\(([^)]*)\)\s*;', text)
     assert len(protos) == len(_lib.EXPORTS)
-    kind = {C.c_void_p: 'ptr', C.c_int32: 'i32', C.c_int64: 'i64', C.c_float: 'f32', C.c_size_t: 'size', C.POINTER(C.c_void_p): 'ptr',
+    kind = {C.c_void_p: 'ptr', C.c_int32: 'i32', C.c_int64: 'i64', C.c_float: 'f32', C.c_double: 'f64', C.c_size_t: 'size', C.POINTER(C.c_void_p): 'ptr',
             C.POINTER(C.c_int32): 'ptr', C.POINTER(C.c_float): 'ptr'}
     for name, params in protos:
         want = []
@@ -123,6 +123,8 @@ def test_ctypes_signatures_match_the_header():
                 want.append('i64')
             elif prm.startswith('float'):
                 want.append('f32')
+            elif prm.startswith('double'):
+                want.append('f64')
             elif prm.startswith('size_t'):
                 want.append('size')
             else:
