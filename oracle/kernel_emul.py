@@ -226,6 +226,10 @@ class EmulatedKernels:
     # ---- stc_ring2_sum_f32: state-gradient sum + blend backward + the transpose aggregation of dY, without the dY plane
     RING2_MAX_ADD = 5
 
+    @staticmethod
+    def ring2_fits(B, n, Cc, h) -> bool:
+        return h == 16 and (Cc * h) % 128 == 0 and B * n * (Cc * h // 4) < (1 << 28) and B <= 65535
+
     def ring2_sum(self, rowptr, colidx, val, ring2, X, X2, addends, U, Cand, Y, Z):
         B, n, Cc, h = Y.shape
         v3 = lambda t: t.reshape(B, n, Cc * h)

@@ -523,6 +523,11 @@ class HipKernels:
 
     RING2_MAX_ADD = 5
 
+    @staticmethod
+    def ring2_fits(B, n, Cc, h) -> bool:
+        """Whether planes of this size are within the two-ring kernels' 32-bit piece offsets (< 2^28 sixteen-byte pieces) and chunking."""
+        return h == 16 and (Cc * h) % 128 == 0 and B * n * (Cc * h // 4) < (1 << 28) and B <= 65535
+
     def ring2_sum(self, rowptr, colidx, val, ring2, X, X2, addends, U, Cand, Y, Z):
         """Y = sum(addends) + S.(X [+ X2]) and Z = S.(Y * U * (1 - Cand^2)) on (B, n, C, 16) state tensors in one launch (stc_ring2_sum_f32):
         the state-gradient sum with its blend backward AND the transpose aggregation of the candidate's gradient, without the dY plane.

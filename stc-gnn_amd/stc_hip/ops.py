@@ -547,7 +547,7 @@ class _StcCellGraph(Function):
             w = t.shape[-1]
             v3 = lambda a: a.view(B, N, C * w)
             s1, s2 = torch.empty_like(t), torch.empty_like(t)
-            if _RING2_FWD and w == h and not bf16 and op.fwd_ring2 is not None and hasattr(k, 'ring2_chain'):
+            if _RING2_FWD and w == h and not bf16 and op.fwd_ring2 is not None and hasattr(k, 'ring2_chain') and k.ring2_fits(B, N, C, h):
                 # both aggregations in one launch: S.t for a patch's first ring is formed in LDS and aggregated from there (stc_ring2_chain_f32)
                 k.ring2_chain(op.fwd_rowptr, op.fwd_colidx, fwd_val, op.fwd_ring2, t, None, 1.0, [], s1, 2.0, [(t, -1.0)], s2)
                 return [t, s1, s2]
@@ -624,7 +624,7 @@ class _StcCellGraph(Function):
                 # the blend and the aggregation of the new state in one launch where the graph has a two-ring plan and some planar cell will
                 # ask for S.Hnew (stc_ring2_blend_f32: the new state is summed out of LDS instead of being read back by a launch of its own; on ring-bounded
                 # clusters it measured 792 us against 548 + 203 for the two launches: tiles only)
-                if (_RING2_FWD and not bf16 and op.fwd_ring2 is not None and not op.ring2_clusters and not copies and side is None and hasattr(k, 'ring2_blend')
+                if (_RING2_FWD and not bf16 and op.fwd_ring2 is not None and not op.ring2_clusters and not copies and side is None and hasattr(k, 'ring2_blend') and k.ring2_fits(B, N, C, h)
                         and any(planar[d] and not planar_k for d, _ in consumers[j])):
                     SHn = torch.empty_like(Hprev)
                     k.ring2_blend(op.fwd_rowptr, op.fwd_colidx, fwd_val, op.fwd_ring2, Bm, A, U, Hprev, Cand, Hnew, SHn)
@@ -777,7 +777,7 @@ class _StcCellGraph(Function):
             """(gradient of state ``kid``, S^T (gradient * U * (1 - Cand^2))) in one launch where the graph has a two-ring plan and the state's
             pieces are whole planes; None: the two launches (``owed`` with its blend epilogue, then the narrow aggregation)."""
             pc = pieces.get(kid)
-            if pc is None or op.bwd_ring2 is None or not hasattr(k, 'ring2_sum'):
+            if pc is None or op.bwd_ring2 is None or not hasattr(k, 'ring2_sum') or not k.ring2_fits(B, N, C, h):
                 return None
             base = G.get(kid)
             add = [t for t, off in pc['direct'] if off == 0 and t.shape[-1] == h] + ([base] if base is not None else [])
@@ -802,7 +802,7 @@ class _StcCellGraph(Function):
             dY = result * U * (1 - Cand^2) from the second launch's epilogue."""
             while len(d2) > 2:                                       # the kernel gathers two operands: pre-sum the rest
                 d2 = [d2[0] + d2[1]] + d2[2:]
-            if (_RING2 and blend is None and not bf16_planes and op.bwd_ring2 is not None and hasattr(k, 'ring2_chain') and len(d1) <= 2
+            if (_RING2 and blend is None and not bf16_planes and op.bwd_ring2 is not None and hasattr(k, 'ring2_chain') and k.ring2_fits(B, N, C, h) and len(d1) <= 2
                     and 1 <= len(d0) + len(d2) <= k.RING2_MAX_ADD):
                 # both transpose aggregations in one launch (stc_ring2_chain_f32): the inner sum d1 + 2 S^T d2 never leaves the chip
                 out = d2[0].new_empty(B, N, C, h)

@@ -233,3 +233,60 @@ def test_two_ring_launches_on_a_renumbered_grid_on_the_gpu():
     hip.csr_spmm(*fwd, n, n, v3(X), None, v3(S1), 1.0, 0.0, plan=op.fwd_plan)
     hip.csr_spmm(*fwd, n, n, v3(S1), v3(X), v3(S2), 2.0, -1.0, plan=op.fwd_plan)
     assert rel_err(T1, S1) < 2e-6 and rel_err(T2, S2) < 2e-6
+
+
+def test_dispatch_limit_of_the_32_bit_piece_offsets():
+    """The two-ring kernels address a plane by 32-bit piece offsets (< 2^28 pieces, checked at the entry points): the executor asks first and
+    keeps the two launches beyond (twin and binding answer alike)."""
+    from stc_hip._lib import HipKernels
+    for k in (EM, HipKernels):
+        assert k.ring2_fits(5, 50176, 32, 16) and k.ring2_fits(4, 10000, 32, 16)
+        assert not k.ring2_fits(60, 50176, 32, 16)                   # 3.85e8 pieces
+        assert not k.ring2_fits(4, 10000, 4, 16) and not k.ring2_fits(4, 10000, 32, 8)      # rows that are not whole 512-byte chunks / another hidden size
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('K,renumbered', [(2, False), (2, True), (3, False), (3, True)])
+def test_cell_graph_with_and_without_the_two_ring_launches(K, renumbered, monkeypatch):
+    """Three chained planar cells through ``ops.stc_cell_graph`` (states consumed as X and as H, so every two-ring form of the order is on the
+    path: sum + blend at order 2, chain forward and transposed at order 3) with the two-ring launches on and off: same states, same gradients."""
+    from stc_hip import ops
+    H, W, B, C, h = 40, 48, 2, 32, 16
+    graph = _renumbered(H, W) if renumbered else CsrGraph.queen_grid(H, W, normalize=True)
+    n = H * W
+    op = csr_operand(graph, torch.device('cuda'))
+    assert op.bwd_ring2 is not None and op.fwd_ring2 is not None and op.ring2_clusters == renumbered
+    g = torch.Generator().manual_seed(K)
+    Gc = torch.rand(C, C, generator=g)
+    Tc = ops.cheby_dense((Gc / Gc.sum(1, keepdim=True)).cuda(), K)
+    rows = K * K * 2 * h
+    base = [torch.randn(B, n, C, h, generator=g), torch.tanh(torch.randn(B, n, C, h, generator=g)),
+            torch.randn(rows, 2 * h, generator=g) * 0.1, torch.zeros(2 * h), torch.randn(rows, h, generator=g) * 0.1, torch.zeros(h),
+            torch.randn(B, n, C, h, generator=g)]
+    schedule = [(0, ('ext', 0), ('ext', 1)), (0, ('cell', 0), ('cell', 0)), (0, ('cell', 1), ('cell', 0))]
+    assert ops.cell_graph_supported(op, Tc, K, C, h, [h])
+
+    def run(on):
+        monkeypatch.setattr(ops, '_RING2', on)
+        monkeypatch.setattr(ops, '_RING2_FWD', on)
+        Xt, Ht, Wg, bg, Wc, bc, R = (t.clone().cuda() for t in base)
+        leaves = [t.requires_grad_() for t in (Xt, Ht, Wg, bg, Wc, bc)]
+        out = ops.stc_cell_graph(op, Tc, K, schedule, [2], [Xt, Ht], [(Wg, bg, Wc, bc)])[0]
+        (out * R).sum().backward()
+        return [out.detach()] + [t.grad for t in leaves]
+
+    seen = []
+    real = type(ops.kernels())
+    for name in ('ring2_sum', 'ring2_blend', 'ring2_chain'):
+        fn = getattr(real, name)
+        monkeypatch.setattr(real, name, (lambda f, nm: lambda self, *a, **kw: (seen.append(nm), f(self, *a, **kw))[1])(fn, name))
+    with_ring2 = run(True)
+    used = set(seen)
+    seen.clear()
+    without = run(False)
+    assert not seen
+    assert used == ({'ring2_chain'} if K == 3 else ({'ring2_sum'} if renumbered else {'ring2_sum', 'ring2_blend'})), used
+    for a, b in zip(with_ring2, without):
+        assert (a is None) == (b is None)                              # (external inputs get no gradient from the cell graph)
+        if a is not None:
+            assert rel_err(a, b) < 3e-6
