@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define STC_ABI_VERSION 29
+#define STC_ABI_VERSION 30
 #define STC_MAX_K 4          /* highest Chebyshev order (Ks, Kc) the node kernels accept */
 
 /* Operand formats of the split-operand matrix-core kernels (C = 32 / 64, hidden 16).  Every fp32 operand is split into low-precision
@@ -600,12 +600,13 @@ int stc_cell_small_bwd_f32(const int32_t* rowptr, const int32_t* colidx, const f
  *   stc_graph_grad_f32:  partials[chunk][n][m]   = sum_{g = chunk, chunk + n_chunks, ..} sum_f A[g][n][f] * B[g][m][f]      (F % 4 == 0)
  *   stc_mix_grad_f32:    partials[chunk][fa][fb] = sum_g sum_n A[g][n][fa] * B[g][n][fb]                                   
  * fp32 products and per-g sums on the matrix cores, FLOAT64 accumulation over g; partials (n_chunks, ..) in float64 are WRITTEN (no
- * atomics: the caller adds them).  The dGs^T of a learned dense Gs is  sum [dZ1g x Z0 + dZ1c x Z0c]  (graph form); dT_c[c][d] =
+ * atomics: the caller adds them).  chunk_stride (ABI v30): doubles between the blocks of consecutive chunks, 0 = dense (N * N / Fa * Fb) -- with
+ * a stride the blocks of SEVERAL products sit side by side in one (n_chunks, total) buffer and one sum over its rows adds them all.  The dGs^T of a learned dense Gs is  sum [dZ1g x Z0 + dZ1c x Z0c]  (graph form); dT_c[c][d] =
  * sum_{ks, l, o} W[(ks, c, l), o] * Q_ks[c, l, d, o]  with  Q_ks = Z_ks^T . dY  (mix form), per convolution and parameter set. */
 int stc_graph_grad_f32(const float* A, const float* B, double* partials, int32_t n_chunks, int32_t cell0, int32_t cell_step, int32_t n_sel,
-                       int32_t batch, int32_t N, int32_t F, void* stream);
+                       int32_t batch, int32_t N, int32_t F, int64_t chunk_stride, void* stream);
 int stc_mix_grad_f32(const float* A, const float* B, double* partials, int32_t n_chunks, int32_t cell0, int32_t cell_step, int32_t n_sel,
-                     int32_t batch, int32_t N, int32_t Fa, int32_t Fb, void* stream);
+                     int32_t batch, int32_t N, int32_t Fa, int32_t Fb, int64_t chunk_stride, void* stream);
 
 /* ---- MixedFusion of the learned graph generator (reference STC_GNN.py:246-261, called by MGP_Gen :227-243) ----------------------------
  *   gate = sigmoid(W_A vec(A) + b_A + W_P vec(P) + b_P),   G = gate * A + (1 - gate) * P        D = n^2 entries; W_A, W_P (D, D) row-major

@@ -511,11 +511,25 @@ class EmulatedKernels:
         sel = t[cell0:cell0 + (n_sel - 1) * cell_step + 1:cell_step] if n_sel else t[:0]
         return sel.reshape(sel.shape[0] * sel.shape[1], N, -1).double()           # (g, N, C * width)
 
-    def graph_grad(self, A, Bm, cell0, cell_step, n_sel, N):
-        return torch.einsum('gnf,gmf->nm', self._selected(A, cell0, cell_step, n_sel, N), self._selected(Bm, cell0, cell_step, n_sel, N))
+    GRAD_CHUNKS = 3
 
-    def mix_grad(self, A, Bm, cell0, cell_step, n_sel, N):
-        return torch.einsum('gna,gnb->ab', self._selected(A, cell0, cell_step, n_sel, N), self._selected(Bm, cell0, cell_step, n_sel, N))
+    def grad_partials(self, like, total, chunks=None):
+        return torch.full((self.GRAD_CHUNKS if chunks is None else chunks, total), float('nan'), dtype=torch.float64)
+
+    @staticmethod
+    def _into(into, res):
+        """As the kernels: every chunk's block is WRITTEN (here: the whole sum in chunk 0, zeros in the others)."""
+        part, off = into
+        part[:, off:off + res.numel()] = 0
+        part[0, off:off + res.numel()] = res.reshape(-1).double()
+
+    def graph_grad(self, A, Bm, cell0, cell_step, n_sel, N, into=None):
+        res = torch.einsum('gnf,gmf->nm', self._selected(A, cell0, cell_step, n_sel, N), self._selected(Bm, cell0, cell_step, n_sel, N))
+        return res if into is None else self._into(into, res)
+
+    def mix_grad(self, A, Bm, cell0, cell_step, n_sel, N, into=None):
+        res = torch.einsum('gna,gnb->ab', self._selected(A, cell0, cell_step, n_sel, N), self._selected(Bm, cell0, cell_step, n_sel, N))
+        return res if into is None else self._into(into, res)
 
     # ---- stc_bdg_node_post_bwd_f32: Y = A + S.Bm (Ks = Kc = 2); backward from (X, dA, dBm)
     def node_post_supported(self, Ks, Kc, Cc, L, Ho) -> bool:

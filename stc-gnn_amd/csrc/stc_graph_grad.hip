@@ -27,7 +27,7 @@ struct Sel {
 __device__ __forceinline__ size_t plane_of(const Sel& s, int g) { return (size_t)(s.cell0 + (g / s.batch) * s.cell_step) * s.batch + g % s.batch; }
 
 __global__ __launch_bounds__(GG_THREADS) void graph_grad_kernel(const float* __restrict__ A, const float* __restrict__ B, double* __restrict__ part, Sel sel,
-                                                                int N, int F) {
+                                                                int N, int F, long long chunk_stride) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, kq = lane >> 4;
     const int T = (N + 15) >> 4, tiles = T * T, G = sel.n_sel * sel.batch;
     // the wave's output tiles (blockIdx.y: groups of GG_NT_TPW * GG_WAVES tiles); a tile past the end recomputes tile 0 and is not stored
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(GG_THREADS) void graph_grad_kernel(const float* __r
 #pragma unroll
             for (int r = 0; r < 4; ++r) sum[t][r] += (double)acc[t][r];
     }
-    double* out = part + (size_t)blockIdx.x * N * N;
+    double* out = part + (size_t)blockIdx.x * chunk_stride;
 #pragma unroll
     for (int t = 0; t < GG_NT_TPW; ++t)
         if (live[t]) {
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(GG_THREADS) void graph_grad_kernel(const float* __r
 }
 
 __global__ __launch_bounds__(GG_THREADS) void mix_grad_kernel(const float* __restrict__ A, const float* __restrict__ B, double* __restrict__ part, Sel sel, int N,
-                                                              int Fa, int Fb) {
+                                                              int Fa, int Fb, long long chunk_stride) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, kq = lane >> 4;
     const int Ta = (Fa + 15) >> 4, Tb = (Fb + 15) >> 4, tiles = Ta * Tb, G = sel.n_sel * sel.batch;
     int it[GG_TN_TPW], jt[GG_TN_TPW];
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(GG_THREADS) void mix_grad_kernel(const float* __res
 #pragma unroll
             for (int r = 0; r < 4; ++r) sum[t][r] += (double)acc[t][r];
     }
-    double* out = part + (size_t)blockIdx.x * Fa * Fb;
+    double* out = part + (size_t)blockIdx.x * chunk_stride;
 #pragma unroll
     for (int t = 0; t < GG_TN_TPW; ++t)
         if (live[t]) {
@@ -162,25 +162,27 @@ int check_sel(const char* what, int32_t cell0, int32_t cell_step, int32_t n_sel,
 }  // namespace
 
 extern "C" int stc_graph_grad_f32(const float* A, const float* B, double* partials, int32_t n_chunks, int32_t cell0, int32_t cell_step, int32_t n_sel,
-                                  int32_t batch, int32_t N, int32_t F, void* stream) {
+                                  int32_t batch, int32_t N, int32_t F, int64_t chunk_stride, void* stream) {
     if (int rc = check_sel("stc_graph_grad_f32", cell0, cell_step, n_sel, batch, n_chunks)) return rc;
     STC_REQUIRE(N >= 1 && N <= 4096 && F >= 4 && F % 4 == 0, STC_EINVAL, "stc_graph_grad_f32: N=%d (1..4096), F=%d (a multiple of 4)", N, F);
     STC_REQUIRE(A && B && partials && stc::aligned16(A) && stc::aligned16(B), STC_EINVAL, "stc_graph_grad_f32: null or unaligned operand");
+    STC_REQUIRE(chunk_stride == 0 || chunk_stride >= (int64_t)N * N, STC_EINVAL, "stc_graph_grad_f32: chunk stride %lld below the block of %d x %d", (long long)chunk_stride, N, N);
     const int T = (N + 15) / 16, groups = (T * T + GG_NT_TPW * GG_WAVES - 1) / (GG_NT_TPW * GG_WAVES);
     hipLaunchKernelGGL(graph_grad_kernel, dim3((unsigned)n_chunks, (unsigned)groups), dim3(GG_THREADS), 0, static_cast<hipStream_t>(stream), A, B, partials,
-                       Sel{cell0, cell_step, n_sel, batch}, N, F);
+                       Sel{cell0, cell_step, n_sel, batch}, N, F, (long long)(chunk_stride ? chunk_stride : (int64_t)N * N));
     STC_LAUNCH_CHECK("stc_graph_grad_f32 launch");
     return STC_OK;
 }
 
 extern "C" int stc_mix_grad_f32(const float* A, const float* B, double* partials, int32_t n_chunks, int32_t cell0, int32_t cell_step, int32_t n_sel,
-                                int32_t batch, int32_t N, int32_t Fa, int32_t Fb, void* stream) {
+                                int32_t batch, int32_t N, int32_t Fa, int32_t Fb, int64_t chunk_stride, void* stream) {
     if (int rc = check_sel("stc_mix_grad_f32", cell0, cell_step, n_sel, batch, n_chunks)) return rc;
     STC_REQUIRE(N >= 1 && Fa >= 1 && Fb >= 1 && Fa <= 4096 && Fb <= 4096, STC_EINVAL, "stc_mix_grad_f32: N=%d Fa=%d Fb=%d", N, Fa, Fb);
     STC_REQUIRE(A && B && partials, STC_EINVAL, "stc_mix_grad_f32: null operand");
+    STC_REQUIRE(chunk_stride == 0 || chunk_stride >= (int64_t)Fa * Fb, STC_EINVAL, "stc_mix_grad_f32: chunk stride %lld below the block of %d x %d", (long long)chunk_stride, Fa, Fb);
     const int tiles = ((Fa + 15) / 16) * ((Fb + 15) / 16), groups = (tiles + GG_TN_TPW * GG_WAVES - 1) / (GG_TN_TPW * GG_WAVES);
     hipLaunchKernelGGL(mix_grad_kernel, dim3((unsigned)n_chunks, (unsigned)groups), dim3(GG_THREADS), 0, static_cast<hipStream_t>(stream), A, B, partials,
-                       Sel{cell0, cell_step, n_sel, batch}, N, Fa, Fb);
+                       Sel{cell0, cell_step, n_sel, batch}, N, Fa, Fb, (long long)(chunk_stride ? chunk_stride : (int64_t)Fa * Fb));
     STC_LAUNCH_CHECK("stc_mix_grad_f32 launch");
     return STC_OK;
 }

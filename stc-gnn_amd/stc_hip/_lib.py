@@ -21,7 +21,7 @@ from .graph import is_full_pattern
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG_ROOT, 'libstc_hip.so')
-ABI_VERSION = 29
+ABI_VERSION = 30
 FMT_BF16X3, FMT_F16X2 = 0, 1          # STC_FMT_* of include/stc_hip.h: operand formats of the split-operand matrix-core kernels
 MAX_K = 4
 SPMM_SUM_MAX_ADD = 8     # = STC_SPMM_SUM_MAX_ADD of include/stc_hip.h
@@ -74,8 +74,8 @@ def _declare(lib):
         'stc_bcsr_spmm_bf16': [_p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _f32, _p],
         'stc_dense_agg_f32': [_p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _f32, _p],
         'stc_cell_small_fwd_f32': [_p, _p, _p, _i32, _i32, _i32, _p, _i32, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p],
-        'stc_graph_grad_f32': [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p],
-        'stc_mix_grad_f32': [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p],
+        'stc_graph_grad_f32': [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _p],
+        'stc_mix_grad_f32': [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _p],
         'stc_mixed_fusion_workspace_bytes': [_i32, _i32],
         'stc_mixed_fusion_fwd_f32': [_p] * 8 + [_i32, _p],
         'stc_mixed_fusion_bwd_f32': [_p] * 12 + [C.c_size_t, _i32, _p],
@@ -1074,25 +1074,47 @@ class HipKernels:
         self._same_device(A, Bm)
         return A.shape[1], A.shape[2] // N
 
-    def graph_grad(self, A, Bm, cell0, cell_step, n_sel, N):
+    def grad_partials(self, like, total, chunks=None):
+        """(chunks, total) float64 buffer for the blocks of several graph-gradient products side by side (``graph_grad`` / ``mix_grad`` with
+        ``into=``): ONE ``sum(0)`` then adds the partials of all of them."""
+        return torch.empty(self.GRAD_CHUNKS if chunks is None else chunks, total, dtype=torch.float64, device=like.device)
+
+    def _grad_block(self, what, into, size):
+        part, offset = into
+        if part.dtype != torch.float64 or part.dim() != 2 or not part.is_contiguous() or not part.is_cuda or offset < 0 or offset + size > part.shape[1]:
+            raise StcError(f'{what}: into = (contiguous float64 (chunks, total) ROCm buffer, column offset); block of {size} at {offset} in {tuple(part.shape)}')
+        return part, part.data_ptr() + 8 * offset, part.shape[0], part.shape[1]
+
+    def graph_grad(self, A, Bm, cell0, cell_step, n_sel, N, into=None):
         """(N, N) float64:  sum over the selected cells and samples of  A_g . B_g^T  with A, B (cells, batch, N*C, width) read as (N, C*width)
-        per plane -- the dGs^T piece of a learned dense graph (``stc_graph_grad_f32``)."""
+        per plane -- the dGs^T piece of a learned dense graph (``stc_graph_grad_f32``).  ``into`` = (partial buffer, column offset): the
+        partials go to that block of a shared buffer (``grad_partials``) and nothing is returned -- the caller sums the buffer once."""
         batch, Cc = self._grad_operands('graph_grad', A, Bm, cell0, cell_step, n_sel, N)
         if A.shape[3] != Bm.shape[3]:
             raise StcError(f'graph_grad: widths {A.shape[3]} / {Bm.shape[3]} differ')
+        if into is not None:
+            part, ptr, chunks, stride = self._grad_block('graph_grad', into, N * N)
+            self._same_device(A, part)
+            self._launch('stc_graph_grad_f32', A, A.data_ptr(), Bm.data_ptr(), ptr, chunks, cell0, cell_step, n_sel, batch, N, Cc * A.shape[3], stride)
+            return None
         chunks = max(1, min(256, n_sel * batch))          # (an N x N float64 partial is small: one workgroup per ~2 planes)
         part = torch.empty(chunks, N, N, dtype=torch.float64, device=A.device)
-        self._launch('stc_graph_grad_f32', A, A.data_ptr(), Bm.data_ptr(), part.data_ptr(), chunks, cell0, cell_step, n_sel, batch, N, Cc * A.shape[3])
+        self._launch('stc_graph_grad_f32', A, A.data_ptr(), Bm.data_ptr(), part.data_ptr(), chunks, cell0, cell_step, n_sel, batch, N, Cc * A.shape[3], 0)
         return part.sum(0)
 
-    def mix_grad(self, A, Bm, cell0, cell_step, n_sel, N):
+    def mix_grad(self, A, Bm, cell0, cell_step, n_sel, N, into=None):
         """(C*wa, C*wb) float64:  sum over the selected cells and samples of  A_g^T . B_g  (contraction over the N nodes) -- Q = Z^T . dY of one
-        slab of one convolution (``stc_mix_grad_f32``)."""
+        slab of one convolution (``stc_mix_grad_f32``).  ``into``: as ``graph_grad``."""
         batch, Cc = self._grad_operands('mix_grad', A, Bm, cell0, cell_step, n_sel, N)
         Fa, Fb = Cc * A.shape[3], Cc * Bm.shape[3]
+        if into is not None:
+            part, ptr, chunks, stride = self._grad_block('mix_grad', into, Fa * Fb)
+            self._same_device(A, part)
+            self._launch('stc_mix_grad_f32', A, A.data_ptr(), Bm.data_ptr(), ptr, chunks, cell0, cell_step, n_sel, batch, N, Fa, Fb, stride)
+            return None
         chunks = max(1, min(self.GRAD_CHUNKS, n_sel * batch))
         part = torch.empty(chunks, Fa, Fb, dtype=torch.float64, device=A.device)
-        self._launch('stc_mix_grad_f32', A, A.data_ptr(), Bm.data_ptr(), part.data_ptr(), chunks, cell0, cell_step, n_sel, batch, N, Fa, Fb)
+        self._launch('stc_mix_grad_f32', A, A.data_ptr(), Bm.data_ptr(), part.data_ptr(), chunks, cell0, cell_step, n_sel, batch, N, Fa, Fb, 0)
         return part.sum(0)
 
     # ---- MixedFusion of the learned graph generator (reference STC_GNN.py:246-261) ----------------------------------

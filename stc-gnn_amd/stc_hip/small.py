@@ -209,12 +209,15 @@ def _graph_gradients(k, Tc, Ks, stacks, schedule, cin, pos, counts, dims, slabs,
       dT_c[c, d] = < W[(ks, c)], Q_ks[c, :, d, :] >,  Q_ks = Z_ks^T . dY                  (per parameter set and convolution)."""
     B, N, C = dims
     Kc = Tc.shape[0]
-    dT = torch.zeros(Tc.shape, dtype=torch.float64, device=Tc.device) if need_Tc else None
-    dS = torch.zeros(N, N, dtype=torch.float64, device=Tc.device) if need_val else None
+    # every product of the pass leaves its float64 partials in ONE (chunks, total) buffer, side by side, and one sum adds them all: per
+    # product that was an allocation, a reduction and -- for dT_c -- a stack, three weight copies and an einsum of its own (~100 launches of a
+    # few microseconds per step at the SF shape)
+    graph_jobs = []                                               # (A, B, cells): dGs^T pieces
     if need_val:
         for w in (0, 1):
             if counts[w]:
-                dS += k.graph_grad(dslab[w][1], slabs[w][1], 0, 1, counts[w], N) + k.graph_grad(dslab[w][0], slabs[w][2], 0, 1, counts[w], N)
+                graph_jobs += [(dslab[w][1], slabs[w][1], counts[w]), (dslab[w][0], slabs[w][2], counts[w])]
+    classes = {}                                                  # (width group, convolution) -> [(slab 0, slab 1, W, dY, first cell, step, cells)]
     if need_Tc:
         for s_id, (Wg, bg, Wc, bc) in enumerate(stacks):
             cells = [j for j, sc in enumerate(schedule) if sc[0] == s_id]
@@ -223,22 +226,43 @@ def _graph_gradients(k, Tc, Ks, stacks, schedule, cin, pos, counts, dims, slabs,
             w, first = pos[cells[0]]
             where = [pos[j][1] for j in cells]
             step = where[1] - where[0] if len(where) > 1 else 1
-            cw, LP = cin[cells[0]], slabs[w].shape[-1]
-            L = cw + H16
             operands = ((slabs[w][1], slabs[w][0], Wg, dyg[w]), (slabs[w][2], slabs[w][3], Wc, dyc[w]))
             if step < 1 or any(b_ - a_ != step for a_, b_ in zip(where, where[1:])):
                 # (a schedule STCGNN never builds: the set's cells are not evenly spaced inside their width group -- gather them)
                 pick = lambda t: torch.stack([t[i] for i in where])
                 operands = tuple((pick(s0), pick(s1), W, pick(dY)) for s0, s1, W, dY in operands)
                 first, step = 0, 1
-            for s0, s1, W, dY in operands:
-                Ho = W.shape[1]
-                Wv = W.view(Ks, Kc, L, Ho)
-                Wp = W.new_zeros(Ks, Kc, LP, Ho)
-                Wp[:, :, :H16] = Wv[:, :, cw:]
-                Wp[:, :, H16:H16 + cw] = Wv[:, :, :cw]
-                Q = torch.stack([k.mix_grad(s0, dY, first, step, len(cells), N), k.mix_grad(s1, dY, first, step, len(cells), N)]).view(Ks, C, LP, C, Ho)
-                dT += torch.einsum('scldo,sklo->kcd', Q, Wp.double())
+            for conv, (s0, s1, W, dY) in enumerate(operands):
+                classes.setdefault((w, cin[cells[0]], conv), []).append((s0, s1, W, dY, first, step, len(cells)))
+    block = lambda s0, dY: C * s0.shape[-1] * C * dY.shape[-1]
+    total = len(graph_jobs) * N * N + sum(Ks * block(e[0], e[3]) for es in classes.values() for e in es)
+    if total == 0:
+        return None, None
+    part = k.grad_partials(Tc, total)
+    off = 0
+    for A, Bm, n_sel in graph_jobs:
+        k.graph_grad(A, Bm, 0, 1, n_sel, N, into=(part, off))
+        off += N * N
+    for es in classes.values():
+        for s0, s1, W, dY, first, step, n_sel in es:
+            for slab in (s0, s1)[:Ks]:
+                k.mix_grad(slab, dY, first, step, n_sel, N, into=(part, off))
+                off += block(s0, dY)
+    sums = part.sum(0)
+    dS = sums[:len(graph_jobs) * N * N].view(len(graph_jobs), N, N).sum(0) if need_val and graph_jobs else (
+        torch.zeros(N, N, dtype=torch.float64, device=Tc.device) if need_val else None)
+    dT = torch.zeros(Tc.shape, dtype=torch.float64, device=Tc.device) if need_Tc else None
+    off = len(graph_jobs) * N * N
+    for (w, cw, conv), es in classes.items():
+        LP, Ho, L = es[0][0].shape[-1], es[0][2].shape[1], cw + H16
+        size = len(es) * Ks * block(es[0][0], es[0][3])
+        Q = sums[off:off + size].view(len(es), Ks, C, LP, C, Ho)
+        off += size
+        Wv = torch.stack([e[2] for e in es]).view(len(es), Ks, Kc, L, Ho)
+        Wp = Wv.new_zeros(len(es), Ks, Kc, LP, Ho)              # W's rows in the slabs' column order [H (16) | X (cin) | 0]
+        Wp[..., :H16, :] = Wv[..., cw:, :]
+        Wp[..., H16:H16 + cw, :] = Wv[..., :cw, :]
+        dT += torch.einsum('pscldo,psklo->kcd', Q, Wp.double())
     return (None if dT is None else dT.to(Tc.dtype)), (None if dS is None else dS.to(Tc.dtype).reshape(-1))
 
 
