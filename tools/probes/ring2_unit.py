@@ -36,7 +36,9 @@ def timed(fn):
 
 
 plane_mb = B * n * C * h * 4 / 1e6
+X, Y = planes[0].view(B, n, C * h), outs[0].view(B, n, C * h)
 for name, n_planes, fn in (
+        ('plain patch product', 2, lambda i: hip.csr_spmm(*fwd, n, n, planes[i % 4].view(B, n, C * h), None, outs[i % 3].view(B, n, C * h), 1.0, 0.0, plan=op.fwd_plan)),
         ('ring2_sum, 1 addend', 6, lambda i: hip.ring2_sum(*bwd, op.bwd_ring2, planes[i % 4], None, [planes[4 + i % 3]], U, Cand, outs[i % 3], outs[3 + i % 3])),
         ('ring2_sum, 2 addends', 7, lambda i: hip.ring2_sum(*bwd, op.bwd_ring2, planes[i % 4], None, [planes[4 + i % 3], planes[7 + i % 3]], U, Cand, outs[i % 3], outs[3 + i % 3])),
         ('ring2_blend', 7, lambda i: hip.ring2_blend(*fwd, op.fwd_ring2, planes[i % 4], planes[4 + i % 3], U, planes[7 + i % 3], outs[i % 2], outs[2 + i % 2], outs[4 + i % 2])),
