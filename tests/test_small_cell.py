@@ -142,6 +142,7 @@ def test_small_cell_kernels(B, N, C, cin, dense, bias, acc):
 @pytest.mark.gpu
 @pytest.mark.parametrize('B,N,C,cin,splits,dense', [(2, 100, 5, 16, 8, False), (3, 100, 5, 1, 4, False), (1, 37, 8, 16, 2, False), (2, 200, 8, 3, 8, False),
                                                      (1, 7, 1, 2, 3, False), (2, 100, 5, 16, 8, True), (2, 37, 8, 3, 4, True),
+                                                     (2, 130, 3, 1, 8, True), (1, 16, 16, 16, 2, True), (2, 200, 8, 16, 8, True), (1, 65, 5, 4, 16, True),
                                                      (2, 5000, 5, 16, 8, False), (1, 4500, 7, 3, 4, False), (1, 13000, 5, 1, 16, False)])
 def test_small_cell_kernels_split_over_workgroups(B, N, C, cin, splits, dense):
     """The same cell step as four launches per direction (one per phase) over ``splits`` workgroups per sample -- what the executor uses when
@@ -150,7 +151,8 @@ def test_small_cell_kernels_split_over_workgroups(B, N, C, cin, splits, dense):
     from stc_hip._lib import HipKernels
     hip = HipKernels()
     graph = _graph(N, seed=N + cin, dense=dense)
-    # (dense: the learned graph's operand -- the split backward then aggregates as matrix products over all workgroups)
+    # (dense: the learned graph's operand -- the split launches then aggregate as matrix products over the node tiles that cover a workgroup's own
+    # rows: shapes where those tiles straddle workgroups, N below / at / not a multiple of the 16-node tile, narrow and wide inputs)
     operand = (lambda dev: dense_operand(graph.to_dense().to(dev))) if dense else (lambda dev: csr_operand(graph, torch.device(dev)))
     t = _inputs(B, N, C, cin, seed=5 * N + C + cin)
     buf, P = _buffers(B, N, C, cin, torch.float32, hip)
