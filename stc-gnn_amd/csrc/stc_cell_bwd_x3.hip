@@ -512,12 +512,26 @@ int launch_cell_bwd(const CellBwdArgs& a, int* n_partials, hipStream_t stream) {
 
 }  // namespace
 
+// The form that accumulates on BOTH sides lives in a translation unit of its own (stc_cell_bwd_x3_acc2.hip = this file with
+// STC_CB_ACC2_UNIT defined): this file is compiled with -mllvm -amdgpu-mfma-vgpr-form=1 (Makefile), and that LLVM pass crashes on that one
+// instantiation.  The argument block crosses as an opaque pointer (the struct sits in each unit's anonymous namespace, same definition).
+int stc_cell_bwd_x3_acc2(const void* args, int fmt, int* n_partials, hipStream_t stream);
+
+#if defined(STC_CB_ACC2_UNIT)
+
+int stc_cell_bwd_x3_acc2(const void* args, int fmt, int* n_partials, hipStream_t stream) {
+    const CellBwdArgs& a = *static_cast<const CellBwdArgs*>(args);
+    return fmt == STC_FMT_F16X2 ? launch_cell_bwd<FmtH2, 32, 1, 1, 1>(a, n_partials, stream) : launch_cell_bwd<FmtB3, 32, 1, 1, 1>(a, n_partials, stream);
+}
+
+#else
+
 int stc_cell_bwd_planar_shape_ok(int C, int h) { return C == 32 && h == 16; }
 
 template <class F>
 static int dispatch_cell_bwd(const CellBwdArgs& a, int cin, int accumulate_x, int accumulate_h, int* n_partials, hipStream_t stream) {
     if (cin == 16) {
-        if (accumulate_x && accumulate_h) return launch_cell_bwd<F, 32, 1, 1, 1>(a, n_partials, stream);
+        if (accumulate_x && accumulate_h) return stc_cell_bwd_x3_acc2(&a, F::SCALED ? STC_FMT_F16X2 : STC_FMT_BF16X3, n_partials, stream);
         if (accumulate_x) return launch_cell_bwd<F, 32, 1, 1, 0>(a, n_partials, stream);
         if (accumulate_h) return launch_cell_bwd<F, 32, 1, 0, 1>(a, n_partials, stream);
         return launch_cell_bwd<F, 32, 1>(a, n_partials, stream);
@@ -546,3 +560,5 @@ int stc_cell_bwd_planar_x3(const float* X, const float* H, const float* SX, cons
     return fmt == STC_FMT_F16X2 ? dispatch_cell_bwd<FmtH2>(a, cin, accumulate_x, accumulate_h, n_partials, stream)
                                 : dispatch_cell_bwd<FmtB3>(a, cin, accumulate_x, accumulate_h, n_partials, stream);
 }
+
+#endif      // STC_CB_ACC2_UNIT

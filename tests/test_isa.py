@@ -12,18 +12,25 @@ import pytest
 from tests.conftest import REPO
 
 HIPCC = '/opt/rocm/bin/hipcc'
+CSRC = os.path.join(REPO, 'stc-gnn_amd', 'csrc')
+
+
+def _library_flags(source):
+    """The flags libstc_hip.so compiles ``source`` with (csrc/Makefile: common flags + the file's EXTRA_*), as a list."""
+    out = subprocess.check_output(['make', '-s', '-C', CSRC, 'flags-' + os.path.splitext(source)[0]], text=True)
+    flags = out.split()
+    assert '--offload-arch=gfx950' in flags and '-O3' in flags, out
+    return flags
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason='hipcc not present')
-@pytest.mark.parametrize('source', ['stc_cell_bwd_x3.hip', 'stc_node_x3.hip'])
-def test_no_scratch_access_inside_the_node_loops(tmp_path, source):
+@pytest.mark.parametrize('source,n_kernels', [('stc_cell_bwd_x3.hip', 5), ('stc_cell_bwd_x3_acc2.hip', 1), ('stc_node_x3.hip', 6)])
+def test_no_scratch_access_inside_the_node_loops(tmp_path, source, n_kernels):
     out = tmp_path / (source + '.s')
-    csrc = os.path.join(REPO, 'stc-gnn_amd', 'csrc')
-    subprocess.check_call([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', f'-I{os.path.join(REPO, "include")}', '-fno-slp-vectorize',
-                           '-S', '--cuda-device-only', '-o', str(out), os.path.join(csrc, source)], stderr=subprocess.DEVNULL)
+    subprocess.check_call([HIPCC, *_library_flags(source), '-S', '--cuda-device-only', '-o', str(out), os.path.join(CSRC, source)], stderr=subprocess.DEVNULL)
     report = subprocess.check_output(['python3', os.path.join(REPO, 'tools', 'isa_scratch.py'), str(out), 'FmtH2'], text=True)
     kernels = re.split(r'^(_Z\S+)\n', report, flags=re.M)[1:]                 # name, lines, name, lines, ...
-    assert len(kernels) // 2 >= 6, report
+    assert len(kernels) // 2 >= n_kernels, report
     bad = []
     for name, lines in zip(kernels[0::2], kernels[1::2]):
         loops = re.findall(r'node loop(?: \d+/\d+)?: (\d+) instr, (\d+) mfma, (\d+) scratch ops', lines)
@@ -40,9 +47,8 @@ def test_one_launch_bf16_cell_backward_fits_the_register_file(tmp_path):
     must not touch scratch; the C = 64 wide form is at the edge of the 512-register file (2 scratch accesses per node as built: bounded here,
     so that a change that tips it over -- the first version had 22 -- is seen); the C = 64 narrow form (62 per node) must not be built at all."""
     out = tmp_path / 'bf16.s'
-    csrc = os.path.join(REPO, 'stc-gnn_amd', 'csrc')
-    subprocess.check_call([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', f'-I{os.path.join(REPO, "include")}',
-                           '-S', '--cuda-device-only', '-o', str(out), os.path.join(csrc, 'stc_node_bf16.hip')], stderr=subprocess.DEVNULL)
+    subprocess.check_call([HIPCC, *_library_flags('stc_node_bf16.hip'), '-S', '--cuda-device-only', '-o', str(out), os.path.join(CSRC, 'stc_node_bf16.hip')],
+                          stderr=subprocess.DEVNULL)
     report = subprocess.check_output(['python3', os.path.join(REPO, 'tools', 'isa_scratch.py'), str(out), 'cell_bwd_bf16_kernel'], text=True)
     kernels = re.split(r'^(_Z\S+)\n', report, flags=re.M)[1:]
     got = {}
@@ -62,9 +68,8 @@ def test_patch_aggregation_keeps_two_workgroups_per_cu_and_an_lds_only_barrier(t
     preceded by ``s_waitcnt lgkmcnt(0)`` alone -- ``__syncthreads()`` would put ``vmcnt(0)`` there, a wait for the previous chunk's stores
     (HISTORY section 10)."""
     out = tmp_path / 'patch.s'
-    csrc = os.path.join(REPO, 'stc-gnn_amd', 'csrc')
-    subprocess.check_call([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', f'-I{os.path.join(REPO, "include")}',
-                           '-S', '--cuda-device-only', '-o', str(out), os.path.join(csrc, 'stc_spmm_patch.hip')], stderr=subprocess.DEVNULL)
+    subprocess.check_call([HIPCC, *_library_flags('stc_spmm_patch.hip'), '-S', '--cuda-device-only', '-o', str(out), os.path.join(CSRC, 'stc_spmm_patch.hip')],
+                          stderr=subprocess.DEVNULL)
     text = out.read_text()
     bodies = re.findall(r'^(_ZN\S*spmm_patch_kernelILi(\d+)ELb(\d)ELb(\d)E\S*):[^\n]*\n(.*?)s_endpgm', text, flags=re.M | re.S)
     assert len(bodies) == 24, len(bodies)
@@ -86,9 +91,8 @@ def test_two_ring_kernels_keep_two_workgroups_per_cu_without_scratch(tmp_path):
     configuration 4 dispatch -- the sum with up to two addends and one gathered plane, the blend, every chain form -- must not touch scratch
     (a version with a deeper operand ring spilled 16 accesses per chunk and ran at 1 004 instead of 590 us); barriers wait for LDS alone."""
     out = tmp_path / 'ring2.s'
-    csrc = os.path.join(REPO, 'stc-gnn_amd', 'csrc')
-    subprocess.check_call([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', f'-I{os.path.join(REPO, "include")}',
-                           '-S', '--cuda-device-only', '-o', str(out), os.path.join(csrc, 'stc_spmm_ring2.hip')], stderr=subprocess.DEVNULL)
+    subprocess.check_call([HIPCC, *_library_flags('stc_spmm_ring2.hip'), '-S', '--cuda-device-only', '-o', str(out), os.path.join(CSRC, 'stc_spmm_ring2.hip')],
+                          stderr=subprocess.DEVNULL)
     text = out.read_text()
     bodies = re.findall(r'^(_ZN\S*ring2_sum_kernelILi(\d)ELb(\d)ELi(\d)ELi(\d)E\S*):[^\n]*\n(.*?)s_endpgm', text, flags=re.M | re.S)
     assert len(bodies) == 12 + 1 + 30, len(bodies)                     # sum: {A, A + A2} x 0..5 addends; blend; chain: {A, A + A2} x 0..2 x 1..5
