@@ -781,7 +781,9 @@ class _StcCellGraph(Function):
                 return None
             base = G.get(kid)
             add = [t for t, off in pc['direct'] if off == 0 and t.shape[-1] == h] + ([base] if base is not None else [])
-            if len(add) != len(pc['direct']) + (base is not None) or len(add) > k.RING2_MAX_ADD or len(pc['agg']) > 2:
+            # (the forms that fit the register file: one aggregated plane, up to two addends -- 590 / 680 us for the 555 + 185 they replace; with a
+            #  second aggregated plane the kernel spills and takes 840 - 1 150 us: the two launches stay)
+            if len(add) != len(pc['direct']) + (base is not None) or len(add) > 2 or len(pc['agg']) != 1:
                 return None
             G.pop(kid, None)
             pieces.pop(kid)
