@@ -267,6 +267,49 @@ def test_learned_graphs_on_the_small_graph_kernels(dev, monkeypatch, N, C, layer
             _close(got[n], per_cell[n], 5e-6, f'learned small-graph d{n} vs the per-cell path', gpu_tol=1e-5)
 
 
+def test_learned_graph_gradients_when_a_sets_cells_are_unevenly_spaced(monkeypatch):
+    """``small._graph_gradients`` selects a parameter set's cells by (first, step) inside their width group; a schedule where they are NOT
+    evenly spaced (STCGNN never builds one) takes the gathering fallback -- with every product's partials in the shared buffers.  Learned dense
+    Gs and Gc, two parameter sets interleaved 0, 1, 0, 0, 1: gradients of both graphs and of every parameter against the float64 oracle."""
+    from stc_hip.graph import dense_operand
+    N, C, B, h = 23, 5, 3, 16
+    g = torch.Generator().manual_seed(7)
+    base = {'Gs': torch.rand(N, N, generator=g) / N, 'Gc': torch.rand(C, C, generator=g) / C,
+            'X': torch.randn(B, N, C, h, generator=g), 'H': torch.tanh(torch.randn(B, N, C, h, generator=g)), 'R': torch.randn(B, N, C, h, generator=g)}
+    for s_id in (0, 1):
+        base[f'Wg{s_id}'], base[f'Wc{s_id}'] = torch.randn(4 * 2 * h, 2 * h, generator=g) * 0.1, torch.randn(4 * 2 * h, h, generator=g) * 0.1
+        base[f'bg{s_id}'], base[f'bc{s_id}'] = torch.randn(2 * h, generator=g) * 0.1, torch.randn(h, generator=g) * 0.1
+    schedule = [(0, ('ext', 0), ('ext', 1)), (1, ('cell', 0), ('ext', 1)), (0, ('cell', 1), ('cell', 0)), (0, ('cell', 2), ('cell', 1)), (1, ('cell', 3), ('cell', 2))]
+
+    def run(small):
+        monkeypatch.setattr(ops, '_SMALL', small)
+        t = {k: _leaf(v) for k, v in base.items()}
+        op, Tc = dense_operand(t['Gs']), ops.cheby_dense(t['Gc'], 2)
+        stacks = [(t[f'Wg{s}'], t[f'bg{s}'], t[f'Wc{s}'], t[f'bc{s}']) for s in (0, 1)]
+        if small:
+            assert ops.cell_graph_supported(op, Tc, 2, C, h, [h])
+        out = ops.stc_cell_graph(op, Tc, 2, schedule, [4], [t['X'], t['H']], stacks)[0]
+        (out * t['R']).sum().backward()
+        return out.detach(), {k: v.grad for k, v in t.items() if k not in ('X', 'H', 'R')}
+
+    calls = []
+    from stc_hip import small as small_mod
+    real = small_mod._graph_gradients
+    monkeypatch.setattr(small_mod, '_graph_gradients', lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    out_s, grads_s = run(True)
+    assert calls, 'the few-category executor was not taken'
+    # the float64 oracle of the same schedule (the reference's cell, STC_GNN.py:65-79, dense Gs)
+    w = {k: v.double().requires_grad_() for k, v in base.items()}
+    ext, states = [w['X'], w['H']], []
+    for s_id, x, hs in schedule:
+        src = lambda ref: ext[ref[1]] if ref[0] == 'ext' else states[ref[1]]
+        states.append(O.stc_cell(w['Gs'], w['Gc'], src(x), src(hs), w[f'Wg{s_id}'], w[f'bg{s_id}'], w[f'Wc{s_id}'], w[f'bc{s_id}'], 2, 2))
+    (states[4] * w['R']).sum().backward()
+    _close(out_s, states[4].detach().float().to(DEV), FWD, 'uneven schedule: state')
+    for k in grads_s:
+        _close(grads_s[k], w[k].grad.float().to(DEV), 1e-5, f'uneven schedule: d{k}', gpu_tol=2e-5)
+
+
 @pytest.mark.parametrize('tag,fname', [('g7', 'g7_csr_n1024'), ('g7p', 'g7_csr_n1024_perm')])
 @pytest.mark.parametrize('form', ['CsrGraph', 'torch_sparse'])
 def test_csr_fixed_graph_equals_dense_reference(tag, fname, form):
