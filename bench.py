@@ -50,9 +50,9 @@ PLAIN_SPMM = ('stc_patch_spmm_f32', 'stc_patch_spmm_bf16', 'stc_bcsr_spmm_f32', 
 # every C-ABI entry point that is an aggregation Y = S.X (+ epilogue)
 SPMM_ENTRY_POINTS = ('stc_patch_spmm_f32', 'stc_patch_spmm_bf16', 'stc_bcsr_spmm_f32', 'stc_csr_spmm_f32', 'stc_spmm_sum_f32', 'stc_spmm_blend_fwd_f32',
                      'stc_bcsr_spmm_bf16', 'stc_csr_spmm_bf16', 'stc_spmm_sum_bf16', 'stc_spmm_blend_fwd_bf16',
-                     'stc_ring2_sum_f32', 'stc_ring2_blend_f32')
+                     'stc_ring2_sum_f32', 'stc_ring2_blend_f32', 'stc_ring2_chain_f32')
 # what the timed region records HIP events for: the roofline kernel (plain aggregation) and the entry points that can dominate a step
-PRICED_ENTRY_POINTS = PLAIN_SPMM + ('stc_cell_bwd_planar_f32', 'stc_ring2_sum_f32', 'stc_ring2_blend_f32', 'stc_cell_small_fwd_f32', 'stc_cell_small_bwd_f32')
+PRICED_ENTRY_POINTS = PLAIN_SPMM + ('stc_cell_bwd_planar_f32', 'stc_ring2_sum_f32', 'stc_ring2_blend_f32', 'stc_ring2_chain_f32', 'stc_cell_small_fwd_f32', 'stc_cell_small_bwd_f32')
 METRIC = 'STC-GNN fwd+bwd samples/sec at N=50k,C=32; SpMM HBM GB/s vs peak, 1/8 GPU'
 CPU_WARMUP, CPU_TIMED = 2, 7    # 2 warm-up + 7 timed iterations, median
 

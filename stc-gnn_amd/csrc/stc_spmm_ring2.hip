@@ -272,7 +272,8 @@ extern "C" int stc_ring2_sum_f32(const int32_t* l2_rows, const int32_t* l1_rows,
     STC_REQUIRE(A && U && Cand && Y && Z && (n_add == 0 || add), STC_EINVAL, "stc_ring2_sum_f32: null pointer");
     STC_REQUIRE(stc::aligned16(A) && (!A2 || stc::aligned16(A2)) && stc::aligned16(U) && stc::aligned16(Cand) && stc::aligned16(Y) && stc::aligned16(Z),
                 STC_EALIGN, "stc_ring2_sum_f32: planes must be 16-byte aligned");
-    STC_REQUIRE(Y != A && Y != A2 && Z != A && Z != A2 && Y != Z, STC_EINVAL, "stc_ring2_sum_f32: results must not alias the gathered operands or each other");
+    STC_REQUIRE(Y != A && Y != A2 && Z != A && Z != A2 && Y != Z && Y != U && Y != Cand && Z != U && Z != Cand, STC_EINVAL,
+                "stc_ring2_sum_f32: results must not alias the gathered operands, the first ring's gate planes or each other");
     Ring2Args a{};
     a.pl = Ring2Plan{l2_rows, l1_rows, int_rows, t1, t2, n_patches};
     a.A = reinterpret_cast<const v4f*>(A);

@@ -253,10 +253,10 @@ def _ring2_groups(rowptr: np.ndarray, colidx: np.ndarray, n: int, min_rows: floa
     first ring stays within RING2_FIRST rows and the second within RING2_SECOND.  On the bench's grid under a random numbering, renumbered by
     reverse Cuthill-McKee: 29.4 rows per patch, 1.98 first-ring and 3.2 staged rows per own row (4 x 8 tiles of the lattice: 32, 1.88, 3.0).
     None when the patches come out small (no locality).  Deterministic in the arrays alone."""
-    import scipy.sparse as sp
     rp = rowptr.astype(np.int64)
     if n == 0 or colidx.size == 0 or int(np.diff(rp).max()) > RING2_WIDTH:
         return None
+    import scipy.sparse as sp                           # optional, as for the patch plan: the caller leaves the two launches in place without it
     rpl, cil = rp.tolist(), colidx.tolist()
     A = sp.csr_matrix((np.ones(colidx.size, dtype=np.int8), colidx, rp), shape=(n, n))
     S = (A + A.T).tocsr()
@@ -402,7 +402,10 @@ class CsrGraph:
                 # stc_ring2_sum_f32)
                 ring2 = _ring2_plan(rp, ci, v, groups)
                 if ring2 is None:                       # clusters of the patch form whose rings do not fit: patches grown for the rings instead
-                    own = _ring2_groups(rp, ci, n)
+                    try:
+                        own = _ring2_groups(rp, ci, n)
+                    except ImportError:                 # scipy is optional here too: no ring-bounded clusters, the two launches remain
+                        own = None
                     ring2 = _ring2_plan(rp, ci, v, own) if own is not None else None
                     self.ring2_clusters = self.ring2_clusters or ring2 is not None
                 if ring2 is not None:

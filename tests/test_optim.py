@@ -31,6 +31,21 @@ def test_on_cpu_tensors_it_is_torch_adam():
     assert all(torch.equal(x, y) for x, y in zip(ours, ref))
 
 
+def test_step_hooks_fire_once():
+    """torch wraps ``step`` of every optimizer class in its hook wrapper; this class's step calls the parent's UNWRAPPED implementation, so a
+    registered step hook runs once per step even after a plain torch.optim.Adam was constructed in the process."""
+    torch.optim.Adam(_params('cpu'), lr=1e-3)
+    ours = _params('cpu')
+    opt = Adam(ours, lr=2e-3)
+    calls = {'pre': 0, 'post': 0}
+    opt.register_step_pre_hook(lambda *a, **k: calls.__setitem__('pre', calls['pre'] + 1))
+    opt.register_step_post_hook(lambda *a, **k: calls.__setitem__('post', calls['post'] + 1))
+    for step in range(3):
+        _grads(ours, step)
+        opt.step()
+    assert calls == {'pre': 3, 'post': 3}
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('weight_decay', [0.0, 1e-4])
 def test_large_parameters_follow_torch_adam_on_the_gpu(weight_decay, monkeypatch):

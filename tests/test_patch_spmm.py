@@ -92,6 +92,25 @@ def test_which_graphs_get_a_patch_plan():
     assert _patch_plan(rp, np.zeros(0, np.int32), np.zeros(0, np.float32), 2) is None
 
 
+def test_graphs_build_without_scipy(monkeypatch):
+    """scipy is optional in every plan: a lattice with self-loops (9 entries per row: tiles are found without scipy, the two-ring tables of
+    width 8 do not fit, and the ring-bounded clusters would want scipy) still builds, with the two separate launches left in place."""
+    import sys
+    for name in [m for m in sys.modules if m == 'scipy' or m.startswith('scipy.')]:
+        monkeypatch.delitem(sys.modules, name)
+    monkeypatch.setitem(sys.modules, 'scipy', None)
+    monkeypatch.setitem(sys.modules, 'scipy.sparse', None)
+    with pytest.raises(ImportError):
+        import scipy.sparse  # noqa: F401
+    g0 = CsrGraph.queen_grid(40, 40, normalize=False)
+    h = g0._host
+    rows = np.repeat(np.arange(1600), np.diff(h['bwd_rowptr'].astype(np.int64)))
+    r, c = np.append(rows, np.arange(1600)), np.append(h['bwd_colidx'], np.arange(1600))
+    g = CsrGraph(1600, r, c, np.ones(r.size, dtype=np.float32))
+    assert g.nnz == g0.nnz + 1600 and 'fwd_pt_rows' in g._host
+    assert not any(k.startswith('fwd_r2') or k.startswith('bwd_r2') for k in g._host) and not g.ring2_clusters
+
+
 def test_grid_graphs_get_tile_patches():
     """A graph that is a 4- / 8-neighbour lattice in its node numbering gets 4 x 8 tiles (every slot of an interior patch used, 60 source rows);
     one long-range edge, or a random numbering, and the greedy clusters take over."""

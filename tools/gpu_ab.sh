@@ -6,8 +6,10 @@ set -u
 cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out
 mode=$1; shift
 cp stc-gnn_amd/libstc_hip.so gpurun_out/.tree.so
+trap 'cp gpurun_out/.tree.so stc-gnn_amd/libstc_hip.so' EXIT      # an interrupt or a timeout must not leave a foreign library in the tree
 for name in "$@"; do
-  if [ "$name" = tree ]; then cp gpurun_out/.tree.so stc-gnn_amd/libstc_hip.so; else cp gpurun_ab/$name.so stc-gnn_amd/libstc_hip.so; fi
+  if [ "$name" = tree ]; then cp gpurun_out/.tree.so stc-gnn_amd/libstc_hip.so
+  elif ! cp "gpurun_ab/$name.so" stc-gnn_amd/libstc_hip.so; then echo "$name: no gpurun_ab/$name.so, skipped"; continue; fi
   if [ "$mode" = bench ]; then
     timeout -k 10 600 python bench.py --steps 6 --warmup 2 --no-cpu-baseline > gpurun_out/ab_$name.log 2>&1 || { echo "$name: bench failed"; tail -5 gpurun_out/ab_$name.log; continue; }
     python - "$name" <<'PY'
@@ -23,4 +25,3 @@ PY
     grep yhat gpurun_out/parity_errors.txt | grep -v c32k3 | awk -F'\t' '{printf "   %-58s %s %s\n", $1, $3, $5}'
   fi
 done
-cp gpurun_out/.tree.so stc-gnn_amd/libstc_hip.so
