@@ -29,6 +29,15 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert lib.stc_version() == _lib.ABI_VERSION
 
 
+def test_integration_doc_names_the_current_abi():
+    """INTEGRATION.md is what a maintainer pastes from: its ABI number is the header's, and its sample reads the number from the header."""
+    text = open(os.path.join(REPO, 'INTEGRATION.md')).read()
+    header = open(os.path.join(REPO, 'include', 'stc_hip.h')).read()
+    abi = int(re.search(r'#define\s+STC_ABI_VERSION\s+(\d+)', header).group(1))
+    assert abi == _lib.ABI_VERSION and f'ABI v{abi})' in text
+    assert not re.search(r'stc_version\(\)\s*==\s*\d', text)
+
+
 def test_argument_validation_needs_no_gpu():
     lib = _lib.load_library()
     # negative sizes / null pointers are rejected before any HIP call

@@ -108,3 +108,57 @@ def test_reference_model_trainer_runs_on_the_drop_in_module(tmp_path, monkeypatc
             assert np.allclose([float(v) for v in a.split(',')[1:]], [float(v) for v in b.split(',')[1:]], atol=1.01e-4)
         else:
             assert a == b                                            # header row, blank lines
+
+
+MAIN_SLICES = 320      # time slices of the SF file the default run keeps (STC_MAIN_FULL_FILE=1: all 5 124, ~12 min on 8 cores through the emulated kernels)
+
+
+def test_reference_main_runs_on_the_drop_in_module(tmp_path, monkeypatch):
+    """BASELINE.json configuration 1, literally: the reference's ``Main.py`` (``:64-80``) as a script (``runpy.run_path``) on the SF file, with
+    the build's ``STC_GNN`` first on ``sys.path``: ``-device cpu -city SF -split 1 3 3 -epoch 1`` (the reduced split is SURVEY F8: the reference's
+    trainer keeps every step's autograd graph alive, the default split does not fit this container).  No GPU here, so the kernels are the
+    emulated set (80 ms per sample forward): by default ``-in`` points at a copy of the SF file cut to its first MAIN_SLICES time slices -- same
+    schema, same graphs, ~1 min; with STC_MAIN_FULL_FILE=1 at the reference's own file.  What is checked is the plumbing ``Main.py`` exercises --
+    argument parsing, ``DataInput`` on the ``.npz``, the loaders, ``ModelTrainer`` building the drop-in ``STCGNN`` from ``params``, one epoch of
+    train + validate, the checkpoint, ``test`` and its metrics file."""
+    import runpy
+    import STC_GNN as M
+    data_dir = os.path.join(os.path.dirname(REFERENCE), 'data')
+    if not os.path.exists(os.path.join(data_dir, 'SF-incidents-4h.npz')):
+        pytest.skip('the SF data file is not present')
+    full = os.environ.get('STC_MAIN_FULL_FILE') == '1'
+    if not full:
+        with np.load(os.path.join(data_dir, 'SF-incidents-4h.npz'), allow_pickle=True) as z:
+            cut = {k: (z[k][:MAIN_SLICES] if k in ('incident', 'metadata') else z[k]) for k in z.files}
+        data_dir = str(tmp_path / 'data')
+        os.makedirs(data_dir)
+        np.savez(os.path.join(data_dir, 'SF-incidents-4h.npz'), **cut)
+    monkeypatch.setattr(ops, '_kernels', EmulatedKernels())
+    monkeypatch.setattr(sys, 'path', [PKG] + [p for p in sys.path if p not in (PKG, REFERENCE)] + [REFERENCE])     # build first, reference last
+    for name in ('Model_Trainer', 'Data_Container', 'Metrics'):
+        monkeypatch.delitem(sys.modules, name, raising=False)
+    monkeypatch.setattr(sys, 'dont_write_bytecode', True)
+    monkeypatch.setattr(sys, 'argv', ['Main.py', '-device', 'cpu', '-in', data_dir, '-out', str(tmp_path), '-city', 'SF',
+                                      '-split', '1', '3', '3', '-epoch', '1'])
+    torch.manual_seed(0)
+    buf = io.StringIO()
+    try:
+        with contextlib.redirect_stdout(buf):
+            ns = runpy.run_path(os.path.join(REFERENCE, 'Main.py'), run_name='__main__')
+    finally:
+        for name in ('Model_Trainer', 'Data_Container', 'Metrics'):
+            sys.modules.pop(name, None)
+    printed = buf.getvalue()
+    trainer = ns['trainer']
+    assert type(trainer.model) is M.STCGNN, 'Model_Trainer.py:5 did not resolve to the build\'s STC_GNN'
+    assert ns['params']['C'] == 5 and (ns['params']['H'], ns['params']['W']) == (10, 10)
+    assert ns['data']['inc'].shape == ((5124 if full else MAIN_SLICES), 10, 10, 5)
+    n_windows = ns['data']['inc'].shape[0] - 12
+    assert len(ns['data_loader']['train'].dataset) == n_windows - 2 * int(3 / 7 * n_windows)
+    losses = [float(v) for v in re.findall(r'Epoch \d+: .*?training loss: ([0-9.]+)', printed)]
+    assert len(losses) == 1 and 0.5 < losses[0] < 1.6 and 'Successfully loaded trained STC-GNN model - epoch: 1' in printed, printed[:2000]          # (the reference itself, seed 0, SF defaults: 1.46 falling to 1.28 in 12 steps)
+    ck = torch.load(os.path.join(str(tmp_path), 'SF', 'STC-GNN-4.pkl'), weights_only=False)
+    assert sorted(ck.keys()) == ['epoch', 'state_dict', 'train_loss', 'val_loss'] and ck['epoch'] == 1
+    assert list(ck['state_dict'].keys()) == list(trainer.model.state_dict().keys()) and len(ck['state_dict']) == 32
+    csv = os.path.join(str(tmp_path), 'SF', 'STC-GNN_eval-bi-metrics.csv')
+    assert os.path.exists(csv) and 'Macro-F1' in open(csv).read()

@@ -20,16 +20,21 @@ from tests.golden.make_golden import pipeline_inputs
 SF = '/root/reference/data/SF-incidents-4h.npz'
 
 
-def test_windows_split_and_batches_match_the_reference():
+@pytest.mark.parametrize('device', ['cpu', pytest.param('cuda:0', marks=pytest.mark.gpu)])
+def test_windows_split_and_batches_match_the_reference(device):
+    """Windows, the contiguous split and the batches against what the reference's DataGenerator / DataLoader produced (golden g9;
+    Data_Container.py:84-112) -- bit for bit, with the series resident on the CPU and on the GPU (``params['device']``, as Main.py:11-12 passes it)."""
     g = load_golden('g9_pipeline')
     data, params = pipeline_inputs()
+    params = dict(params, device=device)
     loaders = sdata.get_data_loader(params, data, params['obs_len'], params['pred_len'], params['split_ratio'])
     for mode in sdata.MODES:
         ld = loaders[mode]
         assert ld.length == int(g[f'{mode}_len']) and len(ld) == int(g[f'{mode}_batches'])
         batches = list(ld)
-        assert torch.equal(batches[0][0], g[f'{mode}_x0']) and torch.equal(batches[0][1], g[f'{mode}_y0'])
-        assert torch.equal(batches[-1][0], g[f'{mode}_xlast']) and torch.equal(batches[-1][1], g[f'{mode}_ylast'])
+        assert all(t.device == torch.device(device) for b in batches for t in b[:2])
+        assert torch.equal(batches[0][0].cpu(), g[f'{mode}_x0']) and torch.equal(batches[0][1].cpu(), g[f'{mode}_y0'])
+        assert torch.equal(batches[-1][0].cpu(), g[f'{mode}_xlast']) and torch.equal(batches[-1][1].cpu(), g[f'{mode}_ylast'])
         assert batches[0][0].dtype == torch.float32 and batches[0][0].is_contiguous()
 
 
