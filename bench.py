@@ -85,6 +85,8 @@ def parse(argv=None):
     ap.add_argument('--no-unit-d3', action='store_true', help='skip the cold SURVEY 8(d3) SpMM unit measurement')
     ap.add_argument('--no-extras', action='store_true',
                     help='skip the side measurements of the default line (alt_formats.bf16x3 and permuted: 1 + 3 steps each, same process)')
+    ap.add_argument('--no-presets', action='store_true',
+                    help="skip the `presets` block of the default line (one GPU): BASELINE.json's other configurations, 3 timed steps each, each in a child process after the metric's own measurements")
     ap.add_argument('--hip-graph', action='store_true',
                     help='(one GPU; not the default line) time replays of the train step captured into a HIP graph: removes the launch gaps that '
                          'matter at small N; the per-kernel events then come from eager steps after the timed region')
@@ -482,6 +484,52 @@ class PowerSampler:
                 'package_w_limit': limit_w, 'sclk_mhz_mean': sum(c) / len(c), 'sclk_mhz_min': min(c), 'sclk_mhz_rated': self.rated}
 
 
+PRESET_RUNS = (('cfg2', ['--preset', 'cfg2', '--order', '2']), ('cfg2-order3', ['--preset', 'cfg2', '--order', '3']), ('cfg4', ['--preset', 'cfg4']),
+               ('cfg5', ['--preset', 'cfg5']), ('sf', ['--preset', 'sf']), ('sf-learned', ['--preset', 'sf-learned']))
+
+
+def run_presets(parent_reserved_gb, steps=3, timeout_s=150):
+    """BASELINE.json's other configurations for the default line: each ``--preset`` as a CHILD process of this bench (3 timed steps, 1 warm-up, HIP-graph
+    replays where the preset defaults to them, no CPU baseline), one after the other, after the metric's own measurements; the digest of each child's line.
+    Never re-execs this process (it has touched the GPU); a child that fails or overruns leaves an ``error`` entry instead of ending the line."""
+    digest = {'what': f'python bench.py --preset <name> --steps {steps} --warmup 1 --no-cpu-baseline --no-unit-d3, one child process each, run after the timed region '
+                      'of the metric (its memory handed back first); not the metric -- the full lines of builder runs are profiles/rNN/preset_*.json',
+              'parent_reserved_gb_while_they_ran': parent_reserved_gb}
+    if parent_reserved_gb > 60.0:
+        digest['error'] = 'the metric run still holds its memory: presets skipped'
+        return digest
+    env = dict(os.environ)
+    for key in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(key, None)
+    only = [v for v in os.environ.get('STC_BENCH_PRESETS', '').split(',') if v]         # (tests: a subset by name)
+    for name, flags in PRESET_RUNS:
+        if only and name not in only:
+            continue
+        t0 = time.perf_counter()
+        try:
+            res = subprocess.run([sys.executable, os.path.abspath(__file__), '--gpus', '1', '--steps', str(steps), '--warmup', '1', '--no-cpu-baseline',
+                                  '--no-unit-d3'] + flags, env=env, capture_output=True, text=True, timeout=timeout_s)
+            lines = [ln for ln in res.stdout.strip().split('\n') if ln.startswith('{')]
+            if res.returncode != 0 or not lines:
+                digest[name] = {'error': f'exit code {res.returncode}: ' + (res.stderr.strip().split('\n') or [''])[-1][:300]}
+                continue
+            d = json.loads(lines[-1])
+            roof = d.get('roofline') or {}
+            dom = roof.get('dominant') or {}
+            digest[name] = {'value': d['value'], 'unit': d['unit'], 'ms_per_step': d['ms_per_step'], 'steps': d['steps'], 'hip_graph': d.get('hip_graph'),
+                            'dtype': d.get('dtype'), 'workload': d['config']['workload'],
+                            'roofline': {'bound': roof.get('bound'), 'kernel': (roof.get('kernel') or '')[:160], 'achieved': roof.get('achieved'),
+                                         'peak': roof.get('peak'), 'unit': roof.get('unit'), 'frac': roof.get('frac'),
+                                         'dominant': {k: dom.get(k) for k in ('entry_point', 'share_of_kernel_time', 'avg_launch_us', 'achieved', 'frac') if k in dom}},
+                            **({'forward_ms': d['forward_ms']} if 'forward_ms' in d else {}),
+                            'child_run_s': time.perf_counter() - t0}
+        except subprocess.TimeoutExpired:
+            digest[name] = {'error': f'no line within {timeout_s} s'}
+        except Exception as e:                                       # a malformed child line must not cost the metric's own line
+            digest[name] = {'error': f'{type(e).__name__}: {e}'[:300]}
+    return digest
+
+
 def main():
     t_start = time.perf_counter()
     a = parse()
@@ -688,7 +736,9 @@ def main():
         if hip.operand_format == _l.FMT_F16X2:
             hip.operand_format = _l.FMT_BF16X3                        # (instance attribute over the class default)
             try:
-                extras['alt_formats'] = {'bf16x3': side(model, As_in)}
+                # the number to quote "at the reference's precision": the same model, same inputs, same --steps as the headline, every fp32 operand
+                # of the matrix-core products as three bf16 pieces (24 significant bits = fp32's own)
+                extras['alt_formats'] = {'bf16x3': side(model, As_in, n=a.steps)}
             finally:
                 del hip.operand_format
         if not a.permute:
@@ -751,6 +801,15 @@ def main():
                                               'traffic': pmc_entry_traffic(name, config_key)}
                                        for name in ('stc_ring2_sum_f32', 'stc_ring2_blend_f32', 'stc_ring2_chain_f32') if name in per_kernel}},
         }
+        if plain['launches'] == 0 and every['launches'] > 0:
+            # order 3 on a graph with two-ring plans: every aggregation of the step is a chained two-ring launch (two aggregations each), no plain
+            # Y = S.X is left to price -- the roofline entry is then the aggregation launches as a whole, on their own algorithmic bytes
+            roofline.update(kernel='the aggregation launches of the step as a whole (' + ' + '.join(n for n in SPMM_ENTRY_POINTS if n in per_kernel)
+                                   + '): no plain Y = S.X launch is left in this configuration; graph once + every operand read once + every result written once',
+                            achieved=rate(every), frac=rate(every) / HBM_PEAK_GBPS, launches=every['launches'],
+                            avg_launch_us=1e3 * every['ms'] / max(1, every['launches']),
+                            algorithmic_bytes_per_launch=every['bytes'] / max(1, every['launches']),
+                            bytes_formula='per launch: nnz*8 + 4*(N+1) once + every operand plane read once + every result plane written once')
         dom_name = max(per_kernel, key=lambda n: per_kernel[n]['ms']) if per_kernel else None
         if dom_name is not None:
             dk = per_kernel[dom_name]
@@ -839,12 +898,34 @@ def main():
             'hbm_peak_allocated_gb': torch.cuda.max_memory_allocated(dev) / 1e9,
             'hbm_peak_reserved_gb': torch.cuda.max_memory_reserved(dev) / 1e9,
         }
+        fmt_name = out['config']['operand_format']
+        if 'alt_formats' in extras:
+            g24 = extras['alt_formats']['bf16x3']
+            out['value_fp32_grade'] = {'value': g24['samples_per_s'], 'unit': 'samples/s', 'ms_per_step': g24['ms_per_step'], 'steps': g24['steps'],
+                                       'operand_format': 'bf16x3',
+                                       'what': 'the same train step with every fp32 operand of the matrix-core products held to 24 significant bits (three bf16 pieces, six '
+                                               "products): the figure to compare at the reference's own fp32 precision; `value` runs the default format " + str(fmt_name)}
+        elif fmt_name == 'bf16x3' and a.storage == 'f32':
+            out['value_fp32_grade'] = {'value': value, 'unit': 'samples/s', 'ms_per_step': out['ms_per_step'], 'steps': a.steps, 'operand_format': 'bf16x3',
+                                       'what': '`value` itself: this run uses the 24-bit operand format'}
+        out['dtype_detail'] = ('bf16 state storage, fp32 parameters and sums' if a.storage == 'bf16' else
+                               'fp32 planes, parameters and sums; aggregations in fp32 fmaf; matrix-core products on fp32 operands split as '
+                               + {'f16x2': 'two fp16 pieces (22 significant bits)', 'bf16x3': 'three bf16 pieces (24 significant bits)'}.get(fmt_name, str(fmt_name)))
         if world == 1 and not a.no_cpu_baseline:
             if N <= 1024:                                        # small graphs: the whole model through the oracle's dense (reference) algorithm
                 out['cpu_baseline'] = cpu_baseline_small(a, graph.to_dense(), Gc_cpu, sd_cpu,
                                                          As_dense=CsrGraph.queen_grid(a.grid, a.grid, normalize=False).to_dense() if learned else None)
             else:
                 out['cpu_baseline'] = cpu_baseline(a, _sparse_T(graph), Gc_cpu, sd_cpu)
+        if world == 1 and a.preset is None and not (a.no_presets or a.no_extras or graphed or learned or a.permute) and a.storage == 'f32':
+            # BASELINE.json's other configurations in the same line: the metric's memory goes back first (a preset is a process of its own)
+            del loss
+            model.zero_grad(set_to_none=True)
+            model, opt, bucket, X, Y, As_in, graph = None, None, None, None, None, None, None
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            out['presets'] = run_presets(torch.cuda.memory_reserved(dev) / 1e9)
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()

@@ -88,3 +88,36 @@ def test_presets_and_global_batch():
     assert a.batch_per_gpu == 2
     with pytest.raises(SystemExit):
         bench.parse(['--gpus', '4', '--global-batch', '6'])
+
+
+def test_presets_block_runs_children_and_survives_their_failures(monkeypatch):
+    """``run_presets``: one child process per BASELINE configuration (never a re-exec of the bench process), launcher variables stripped, the digest
+    of each child's line; a child that fails, prints nothing or overruns leaves an ``error`` entry; nothing starts while the parent holds its memory."""
+    import json
+    import subprocess
+    seen = []
+
+    def fake_run(cmd, env=None, capture_output=None, text=None, timeout=None):
+        seen.append((cmd, env))
+        name = cmd[cmd.index('--preset') + 1]
+        if name == 'cfg4':
+            return subprocess.CompletedProcess(cmd, 1, stdout='', stderr='Traceback\nStcError: boom')
+        if name == 'cfg5':
+            raise subprocess.TimeoutExpired(cmd, timeout)
+        if name == 'sf':
+            return subprocess.CompletedProcess(cmd, 0, stdout='not json\n', stderr='')
+        line = {'value': 7.0, 'unit': 'samples/s', 'ms_per_step': 3.0, 'steps': 3, 'hip_graph': True, 'dtype': 'f32', 'config': {'workload': 'w'},
+                'roofline': {'bound': 'hbm', 'kernel': 'k', 'achieved': 1.0, 'peak': 2.0, 'unit': 'GB/s', 'frac': 0.5,
+                             'dominant': {'entry_point': 'e', 'frac': 0.4, 'launches': 9}}}
+        return subprocess.CompletedProcess(cmd, 0, stdout='warning\n' + json.dumps(line) + '\n', stderr='')
+
+    monkeypatch.setattr(bench.subprocess, 'run', fake_run)
+    monkeypatch.setenv('RANK', '0')
+    monkeypatch.delenv('STC_BENCH_PRESETS', raising=False)
+    d = bench.run_presets(0.5)
+    assert [c[c.index('--preset') + 1] for c, _ in seen] == ['cfg2', 'cfg2', 'cfg4', 'cfg5', 'sf', 'sf-learned']
+    assert all('RANK' not in e and c[0] == sys.executable and '--no-cpu-baseline' in c and c[c.index('--steps') + 1] == '3' for c, e in seen)
+    assert d['cfg2']['value'] == 7.0 and d['cfg2']['roofline']['dominant'] == {'entry_point': 'e', 'frac': 0.4} and d['sf-learned']['roofline']['frac'] == 0.5
+    assert 'boom' in d['cfg4']['error'] and 'no line within' in d['cfg5']['error'] and 'exit code 0' in d['sf']['error']
+    seen.clear()
+    assert 'error' in bench.run_presets(140.0) and not seen

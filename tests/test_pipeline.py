@@ -191,6 +191,10 @@ def _run_bench(extra, env=None, timeout=900):
     import subprocess
     import sys
     cmd = [sys.executable, os.path.join(REPO, 'bench.py'), '--steps', '2', '--warmup', '1', '--batch-per-gpu', '2', '--obs', '3', '--pred', '2'] + extra
+    if '--presets' in cmd:
+        cmd.remove('--presets')
+    else:
+        cmd.append('--no-presets')                          # (the presets block has a test of its own: six child processes)
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=None if env is None else {**os.environ, **env})
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.strip().split('\n') if l.startswith('{')]
@@ -243,6 +247,23 @@ def test_bench_line_contract(storage):
 
 
 @pytest.mark.gpu
+def test_bench_presets_block_and_fp32_grade_value():
+    """The default one-GPU line carries (a) ``value_fp32_grade``: the same step on the 24-bit operand format over the SAME --steps as ``value``, and
+    (b) ``presets``: BASELINE.json's other configurations, each a child process run after the metric's measurements (here two of them, by name)."""
+    d = _run_bench(['--gpus', '1', '--grid', '12', '--no-cpu-baseline', '--no-unit-d3', '--presets'], env={'STC_BENCH_PRESETS': 'cfg2,sf'})
+    assert d['dtype'] == 'f32' and d['config']['operand_format'] == 'f16x2' and 'two fp16 pieces' in d['dtype_detail']
+    g = d['value_fp32_grade']
+    assert g['operand_format'] == 'bf16x3' and g['steps'] == d['steps'] == 2 and g['value'] > 0 and g['unit'] == 'samples/s'
+    assert abs(g['value'] - d['alt_formats']['bf16x3']['samples_per_s']) < 1e-9
+    p = d['presets']
+    assert p['parent_reserved_gb_while_they_ran'] < 1.0 and set(p) - {'what', 'parent_reserved_gb_while_they_ran'} == {'cfg2', 'sf'}
+    for name, unit in (('cfg2', 'layers/s'), ('sf', 'samples/s')):
+        assert 'error' not in p[name], p[name]
+        assert p[name]['unit'] == unit and p[name]['value'] > 0 and p[name]['steps'] >= 3 and p[name]['roofline']['frac'] > 0
+    assert p['sf']['hip_graph'] is True and p['sf']['roofline']['dominant']['entry_point'].startswith('stc_cell_small')
+
+
+@pytest.mark.gpu
 def test_bench_launches_its_own_ranks():
     """``python bench.py --gpus 2`` with no launcher environment (the driver's plain form) starts torch.distributed.run as a
     child, both ranks take part in the collectives, rank 0 prints the one line.  A one-GPU box cannot run RCCL between two
@@ -288,6 +309,7 @@ def test_bench_many_ranks_contract():
     assert abs(d['ms_per_step'] - pr['ms_per_step_max']) < 1e-2 * d['ms_per_step'] + 1e-3          # the slowest rank's clock (list entries are rounded)
     assert abs(d['value'] - 2 * n * 1e3 / d['ms_per_step']) < 1e-6 * d['value']
     assert d['scaling'] == 'weak' and 'cpu_baseline' not in d and 'alt_formats' not in d and 'permuted' not in d
+    assert 'presets' not in d and 'value_fp32_grade' not in d             # side measurements and child processes: one GPU, rank 0 only
 
 
 def _two_gpus():
