@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define STC_ABI_VERSION 30
+#define STC_ABI_VERSION 31
 #define STC_MAX_K 4          /* highest Chebyshev order (Ks, Kc) the node kernels accept */
 
 /* Operand formats of the split-operand matrix-core kernels (C = 32 / 64, hidden 16).  Every fp32 operand is split into low-precision
@@ -623,6 +623,23 @@ int stc_mixed_fusion_fwd_f32(const float* WA, const float* bA, const float* WP, 
 int stc_mixed_fusion_bwd_f32(const float* WA, const float* WP, const float* A, const float* P, const float* gate, const float* dG,
                              float* dWA, float* dWP, float* db, float* dP, float* dA,
                              void* workspace, size_t workspace_bytes, int32_t D, void* stream);
+/* ---- front end of the learned graph generator (ABI v31; reference STC_GNN.py:229-232 spatial branch, :237-240 category branch) -----------
+ *   U = tanh(alpha X Wu), V = tanh(alpha X Wv);   P = sum_k U_k V_k^T (R x R);   Ps = softmax(relu(P - P^T), -1)        (the einsum pair of :231)
+ * X is addressed as x[k][r][f] = X[k k_stride + r r_stride + f f_stride] (floats), k = 0..K-1 the (sample, time) slices, r the R rows, f the F
+ * features: the spatial branch takes rows = nodes / features = categories, the category branch the transposed window (:236) -- same kernels.
+ *   stc_mgp_uv_fwd_f32       U, V (R, K, h): the pair product is then the plain matrix product P = U' V'^T on (R, K h) operands (the caller's GEMM)
+ *   stc_mgp_uv_bwd_f32       partials (K, 2, F, h): [k][0] = alpha x_k^T [(1 - U^2) dU]_k, [k][1] likewise for V; the caller sums over k
+ *                            (fixed order: reproducible) -> dWu, dWv.  X gets no gradient (it is the data window).
+ *   stc_mgp_softmax_fwd_f32  Ps (R, R) from P (R, R)
+ *   stc_mgp_softmax_bwd_f32  dP (R, R) from dPs: softmax backward, relu mask (gradient where P - P^T > 0), antisymmetric part; rowdot: R floats
+ *                            of scratch.  dP must not alias an input.
+ * Replaces ~60 torch launches per training step of the reference's full model at the SF shape by 18. */
+int stc_mgp_uv_fwd_f32(const float* X, int64_t k_stride, int64_t r_stride, int64_t f_stride, const float* Wu, const float* Wv, float alpha,
+                       float* U, float* V, int32_t K, int32_t R, int32_t F, int32_t h, void* stream);
+int stc_mgp_uv_bwd_f32(const float* X, int64_t k_stride, int64_t r_stride, int64_t f_stride, const float* U, const float* V,
+                       const float* dU, const float* dV, float alpha, float* partials, int32_t K, int32_t R, int32_t F, int32_t h, void* stream);
+int stc_mgp_softmax_fwd_f32(const float* P, float* Ps, int32_t R, void* stream);
+int stc_mgp_softmax_bwd_f32(const float* P, const float* Ps, const float* dPs, float* rowdot, float* dP, int32_t R, void* stream);
 /* Adam on one large fp32 parameter (ABI v29; the optimizer of the reference's harness step, Model_Trainer.py:71-87: torch.optim.Adam with
  * L2 weight decay, no amsgrad), one streaming launch: the two MixedFusion matrices above are 2 x 400 MB at the SF shape.
  *     g' = g + weight_decay p;   m = m + (1 - beta1)(g' - m);   v = beta2 v + (1 - beta2) g'^2

@@ -21,7 +21,7 @@ from .graph import is_full_pattern
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG_ROOT, 'libstc_hip.so')
-ABI_VERSION = 30
+ABI_VERSION = 31
 FMT_BF16X3, FMT_F16X2 = 0, 1          # STC_FMT_* of include/stc_hip.h: operand formats of the split-operand matrix-core kernels
 MAX_K = 4
 SPMM_SUM_MAX_ADD = 8     # = STC_SPMM_SUM_MAX_ADD of include/stc_hip.h
@@ -43,7 +43,7 @@ EXPORTS = (
     'stc_cell_bwd_planar_supported', 'stc_cell_bwd_planar_workspace_bytes', 'stc_cell_bwd_planar_f32',
     'stc_cell_planar_k_supported', 'stc_cell_gates_fwd_planar_k_f32', 'stc_cell_cand_fwd_planar_k_f32', 'stc_cell_gates_bwd_planar_k_f32',
     'stc_cell_cand_bwd_planar_k_f32',
-    'stc_cell_small_supported', 'stc_cell_small_workspace_bytes', 'stc_cell_small_param_rows', 'stc_graph_grad_f32', 'stc_mix_grad_f32', 'stc_mixed_fusion_workspace_bytes', 'stc_mixed_fusion_fwd_f32', 'stc_mixed_fusion_bwd_f32', 'stc_adam_f32', 'stc_cell_small_fwd_f32', 'stc_cell_small_bwd_f32',
+    'stc_cell_small_supported', 'stc_cell_small_workspace_bytes', 'stc_cell_small_param_rows', 'stc_graph_grad_f32', 'stc_mix_grad_f32', 'stc_mixed_fusion_workspace_bytes', 'stc_mixed_fusion_fwd_f32', 'stc_mixed_fusion_bwd_f32', 'stc_mgp_uv_fwd_f32', 'stc_mgp_uv_bwd_f32', 'stc_mgp_softmax_fwd_f32', 'stc_mgp_softmax_bwd_f32', 'stc_adam_f32', 'stc_cell_small_fwd_f32', 'stc_cell_small_bwd_f32',
     'stc_gru_gates_fwd_f32', 'stc_gru_gates_bwd_f32', 'stc_gru_blend_fwd_f32', 'stc_gru_blend_bwd_f32',
     'stc_head_fwd_f32', 'stc_head_bwd_workspace_bytes', 'stc_head_bwd_f32',
     'stc_axpy_f32', 'stc_concat2_f32', 'stc_split2_f32',
@@ -79,6 +79,10 @@ def _declare(lib):
         'stc_mixed_fusion_workspace_bytes': [_i32, _i32],
         'stc_mixed_fusion_fwd_f32': [_p] * 8 + [_i32, _p],
         'stc_mixed_fusion_bwd_f32': [_p] * 12 + [C.c_size_t, _i32, _p],
+        'stc_mgp_uv_fwd_f32': [_p, _i64, _i64, _i64, _p, _p, _f32, _p, _p, _i32, _i32, _i32, _i32, _p],
+        'stc_mgp_uv_bwd_f32': [_p, _i64, _i64, _i64, _p, _p, _p, _p, _f32, _p, _i32, _i32, _i32, _i32, _p],
+        'stc_mgp_softmax_fwd_f32': [_p, _p, _i32, _p],
+        'stc_mgp_softmax_bwd_f32': [_p, _p, _p, _p, _p, _i32, _p],
         'stc_adam_f32': [_p] * 4 + [_i64, _p] + [C.c_double] * 5 + [_p],
         'stc_cell_small_bwd_f32': [_p, _p, _p, _i32, _i32, _i32, _p, _i32, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _i32, _p, _i64, _i32, _i32,
                                    _p, _p, _p, _p, _p, C.c_size_t, _i32, _i32, _i32, _i32, _p],
@@ -1147,6 +1151,57 @@ class HipKernels:
         self._launch('stc_mixed_fusion_bwd_f32', A, _ptr(WA), _ptr(WP), _ptr(A), _ptr(P), _ptr(gate), _ptr(dG), _ptr(dWA), _ptr(dWP), _ptr(db), _ptr(dP), _ptr(dA),
                      _ptr(ws), ws.numel() * 4, D, nbytes=(4 + (8 if want_dW else 0) + (4 if want_dA else 0)) * D * D)
         return dWA, dWP, db, dP, dA
+
+    # ---- front end of the learned graph generator (reference STC_GNN.py:229-232, 237-240) --------------------------
+    @staticmethod
+    def _mgp_strides(X, rows_axis):
+        """(K, R, F, k_stride, r_stride, f_stride) of a contiguous window X (B, T, N, C) read as x[k][r][f]: rows_axis 2 = the spatial branch (rows =
+        nodes, features = categories), 3 = the category branch (the transposed window of :236)."""
+        B, T, N, Cc = X.shape
+        return (B * T, N, Cc, N * Cc, Cc, 1) if rows_axis == 2 else (B * T, Cc, N, N * Cc, 1, Cc)
+
+    def mgp_uv_fwd(self, X, rows_axis, Wu, Wv, alpha):
+        """(U, V), each (R, K, h): tanh(alpha x Wu), tanh(alpha x Wv) with the (sample, time) slices as the middle axis (``stc_mgp_uv_fwd_f32``)."""
+        self._f32('mgp.X', X)
+        K, R, F, ks, rs, fs = self._mgp_strides(X, rows_axis)
+        h = Wu.shape[1]
+        self._f32('mgp.Wu', Wu, (F, h))
+        self._f32('mgp.Wv', Wv, (F, h))
+        self._same_device(X, Wu, Wv)
+        U, V = torch.empty(R, K, h, dtype=torch.float32, device=X.device), torch.empty(R, K, h, dtype=torch.float32, device=X.device)
+        self._launch('stc_mgp_uv_fwd_f32', X, _ptr(X), ks, rs, fs, _ptr(Wu), _ptr(Wv), float(alpha), _ptr(U), _ptr(V), K, R, F, h)
+        return U, V
+
+    def mgp_uv_bwd(self, X, rows_axis, U, V, dU, dV, alpha):
+        """(dWu, dWv) (F, h) from the gradients of U and V (``stc_mgp_uv_bwd_f32`` + a fixed-order sum over the slices)."""
+        K, R, F, ks, rs, fs = self._mgp_strides(X, rows_axis)
+        h = U.shape[2]
+        for name, t in (('U', U), ('V', V), ('dU', dU), ('dV', dV)):
+            self._f32('mgp.' + name, t, (R, K, h))
+        self._same_device(X, U, V, dU, dV)
+        part = torch.empty(K, 2, F, h, dtype=torch.float32, device=X.device)
+        self._launch('stc_mgp_uv_bwd_f32', X, _ptr(X), ks, rs, fs, _ptr(U), _ptr(V), _ptr(dU), _ptr(dV), float(alpha), _ptr(part), K, R, F, h)
+        dW = part.sum(0)
+        return dW[0], dW[1]
+
+    def mgp_softmax_fwd(self, P):
+        """softmax(relu(P - P^T), -1) of a square P (``stc_mgp_softmax_fwd_f32``)."""
+        self._f32('mgp.P', P)
+        if P.dim() != 2 or P.shape[0] != P.shape[1]:
+            raise StcError(f'mgp.P: square matrix expected, got {tuple(P.shape)}')
+        Ps = torch.empty_like(P)
+        self._launch('stc_mgp_softmax_fwd_f32', P, _ptr(P), _ptr(Ps), P.shape[0])
+        return Ps
+
+    def mgp_softmax_bwd(self, P, Ps, dPs):
+        """dP from dPs (``stc_mgp_softmax_bwd_f32``)."""
+        for name, t in (('Ps', Ps), ('dPs', dPs)):
+            self._f32('mgp.' + name, t, tuple(P.shape))
+        self._same_device(P, Ps, dPs)
+        R = P.shape[0]
+        rowdot, dP = torch.empty(R, dtype=torch.float32, device=P.device), torch.empty_like(P)
+        self._launch('stc_mgp_softmax_bwd_f32', P, _ptr(P), _ptr(Ps), _ptr(dPs), _ptr(rowdot), _ptr(dP), R)
+        return dP
 
     def adam(self, p, g, m, v, step, lr, beta1, beta2, eps, weight_decay):
         """One Adam update of a large fp32 parameter in place (``stc_adam_f32``: torch.optim.Adam's arithmetic with L2 weight decay); ``step``: a

@@ -1038,3 +1038,57 @@ def mixed_fusion_supported(A: torch.Tensor, P: torch.Tensor, *params: torch.Tens
 
 def mixed_fusion(A, P, WA, bA, WP, bP):
     return _MixedFusion.apply(A, P, WA, bA, WP, bP)
+
+
+# ---- front end of the learned graph generator --------------------------------------------------------------------------------------------
+class _MgpUV(torch.autograd.Function):
+    """U, V = tanh(alpha X Wu), tanh(alpha X Wv) (reference STC_GNN.py:229-230 / :237-238) in (rows, slices, hidden) layout, one launch; the data
+    window X gets no gradient."""
+
+    @staticmethod
+    def forward(ctx, X, Wu, Wv, rows_axis, alpha):
+        X_ = X.detach().contiguous()
+        U, V = kernels().mgp_uv_fwd(X_, rows_axis, Wu.detach().contiguous(), Wv.detach().contiguous(), alpha)
+        ctx.save_for_backward(X_, U, V)
+        ctx.meta = (rows_axis, alpha)
+        return U, V
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dU, dV):
+        X_, U, V = ctx.saved_tensors
+        dWu, dWv = kernels().mgp_uv_bwd(X_, ctx.meta[0], U, V, dU.contiguous(), dV.contiguous(), ctx.meta[1])
+        return None, dWu, dWv, None, None
+
+
+class _MgpSoftmax(torch.autograd.Function):
+    """softmax(relu(P - P^T), -1) (reference STC_GNN.py:231-232: the einsum pair is P - P^T) in one launch per direction."""
+
+    @staticmethod
+    def forward(ctx, P):
+        P_ = P.detach().contiguous()
+        Ps = kernels().mgp_softmax_fwd(P_)
+        ctx.save_for_backward(P_, Ps)
+        return Ps
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dPs):
+        P_, Ps = ctx.saved_tensors
+        return kernels().mgp_softmax_bwd(P_, Ps, dPs.contiguous())
+
+
+def mgp_front_supported(X: torch.Tensor, Wu: torch.Tensor, Wv: torch.Tensor) -> bool:
+    """Whether ``mgp_front`` takes these operands: a float32 window (B, T, N, C) and float32 (F, h) parameters on a GPU, no gradient wanted for X."""
+    return (X.is_cuda and X.dim() == 4 and all(t.is_cuda and t.dtype == torch.float32 for t in (X, Wu, Wv)) and not X.requires_grad
+            and Wu.dim() == 2 and Wu.shape == Wv.shape and hasattr(kernels(), 'mgp_uv_fwd'))
+
+
+def mgp_front(X, Wu, Wv, rows_axis: int, alpha: float, reduce=None):
+    """The learned graph of one branch of ``MGP_Gen.forward``: softmax(relu(P - P^T)) with P = sum over (sample, time) of U V^T.  ``reduce``: applied
+    to P before the softmax (the batch-sum all-reduce of a sharded batch)."""
+    U, V = _MgpUV.apply(X, Wu, Wv, rows_axis, alpha)
+    P = U.flatten(1) @ V.flatten(1).t()                                # one plain GEMM over the (slice, hidden) axis; its autograd is two more
+    if reduce is not None:
+        P = reduce(P)
+    return _MgpSoftmax.apply(P)
