@@ -14,10 +14,16 @@
 namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
-constexpr int GG_THREADS = 1024, GG_WAVES = GG_THREADS / 64;
-constexpr int GG_NT_TPW = 4;          // output tiles per wave and tile group (blockIdx.y), graph product: 64 tiles per group
-constexpr int GG_TN_TPW = 4;          // output tiles per wave and tile group, mix product: 64 tiles per group
-constexpr int GG_TN_STEPS = 4;        // contraction steps (of 4 rows) whose operands are in flight together
+#ifndef STC_GG_THREADS                 // (probe builds override these: tools/probes/graph_grad_ab.sh)
+#define STC_GG_THREADS 256              // round 6, same-box A/B on the reference's full model at the SF shape (threads, graph tiles per wave, mix tiles per wave,
+#define STC_GG_NT_TPW 1                 // steps in flight): (1024, 4, 4, 4) mix 42 us / graph 62 us per launch -> (256, 1, 2, 8) 27 / 48: these launches are
+#define STC_GG_TN_TPW 2                 // chains of L2 round trips, and four waves of 80 registers hide each other's better than sixteen of 128
+#define STC_GG_TN_STEPS 8
+#endif
+constexpr int GG_THREADS = STC_GG_THREADS, GG_WAVES = GG_THREADS / 64;
+constexpr int GG_NT_TPW = STC_GG_NT_TPW;          // output tiles per wave and tile group (blockIdx.y), graph product
+constexpr int GG_TN_TPW = STC_GG_TN_TPW;          // output tiles per wave and tile group, mix product
+constexpr int GG_TN_STEPS = STC_GG_TN_STEPS;      // contraction steps (of 4 rows) whose operands are in flight together
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 

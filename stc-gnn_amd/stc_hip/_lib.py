@@ -1064,7 +1064,7 @@ class HipKernels:
                          ws.data_ptr(), ws.numel(), phase, splits, B, Cc,
                          nbytes=(4 * B * N * Cc * (2 * cin + 16 * 9 + 5 * self.cell_small_zg_width(cin) + 64)) // len(phases))
 
-    GRAD_CHUNKS = 96             # float64 partials of a graph-gradient product (x tile groups = workgroups; every partial is written and re-read)
+    GRAD_CHUNKS = int(os.environ.get('STC_GRAD_CHUNKS', '96'))             # float64 partials of a graph-gradient product (x tile groups = workgroups; every partial is written and re-read)
 
     def _grad_operands(self, what, A, Bm, cell0, cell_step, n_sel, N):
         for name, t_ in (('A', A), ('B', Bm)):
