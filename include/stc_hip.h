@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define STC_ABI_VERSION 31
+#define STC_ABI_VERSION 32
 #define STC_MAX_K 4          /* highest Chebyshev order (Ks, Kc) the node kernels accept */
 
 /* Operand formats of the split-operand matrix-core kernels (C = 32 / 64, hidden 16).  Every fp32 operand is split into low-precision
@@ -577,19 +577,27 @@ int stc_head_bwd_f32(const float* H, const float* w, const float* y, const float
  * workgroup's own rows: forward 5 = 1 + 2, 6 = 3 + 4; backward 7 = 2 + 3 (dense graphs too, since round 5).
  * The caller launches the phases in order -- (5, 6) and (1, 7, 4), or one by one -- the launch boundaries being the barriers; same
  * buffers, same results.  The workspace holds three gradient slabs and the gate gradients per row (stc_cell_small_workspace_bytes).
- * dparams then has R * G rows per sample (row (b * G + g) * R + r). */
+ * dparams then has R * G rows per sample (row (b * G + g) * R + r).
+ * Chebyshev ORDER 3 (ABI v32: Ks = Kc = 3; `Ks` and the second-graph arguments are new in both entry points, `Ks` in the workspace query): the
+ * third spatial slab is Z_2 = T_2(S) Z with T_2(S) = 2 S^2 - I formed on the MATRIX side, as the reference's cheby_poly forms it (STC_GNN.py:24-29):
+ * (rowptr2, colidx2, val2, nnz2) is the CSR of T_2 in the orientation of the launch -- forward: 2 (Gs^T)^2 - I, backward: 2 Gs^2 - I -- built by the
+ * caller (stc_hip/graph.py CsrGraph.second_order; 25 entries per row on an 8-neighbour grid).  Z_2 aggregates the same input rows as Z_1, so the
+ * phases and the split forms are those of order 2.  Zg2 (like Zg) and Zc2 (like Zc) hold T_2.[H | Xt | 0] and T_2.(R*H) for the backward.  Fixed CSR
+ * graphs only (graph_is_dense = 0, no learned-graph operands), nothing staged in LDS; order 2: pass NULL / 0 for the new pointers. */
 int stc_cell_small_supported(int32_t Ks, int32_t Kc, int32_t C, int32_t cin, int32_t h);
-size_t stc_cell_small_workspace_bytes(int32_t n_nodes, int32_t C, int32_t cin, int32_t batch);
+size_t stc_cell_small_workspace_bytes(int32_t n_nodes, int32_t C, int32_t cin, int32_t batch, int32_t Ks);
 int stc_cell_small_param_rows(void);
 int stc_cell_small_fwd_f32(const int32_t* rowptr, const int32_t* colidx, const float* val, int32_t n_nodes, int32_t nnz,
-                           int32_t graph_is_dense, const float* X, int32_t cin, const float* H, const float* Tc, int32_t Kc,
+                           int32_t graph_is_dense, const int32_t* rowptr2, const int32_t* colidx2, const float* val2, int32_t nnz2,
+                           const float* X, int32_t cin, const float* H, const float* Tc, int32_t Ks, int32_t Kc,
                            const float* Wg, const float* bg, const float* Wc, const float* bc,
-                           float* U, float* R, float* Cand, float* Hnew, float* RH, float* Zg, float* Zc, float* Z0,
+                           float* U, float* R, float* Cand, float* Hnew, float* RH, float* Zg, float* Zc, float* Zg2, float* Zc2, float* Z0,
                            float* Z0c, float* Z1c, int32_t phase, int32_t splits, int32_t batch, int32_t C, void* stream);
 int stc_cell_small_bwd_f32(const int32_t* rowptr, const int32_t* colidx, const float* val, int32_t n_nodes, int32_t nnz,
-                           int32_t graph_is_dense, const float* X, int32_t cin, const float* H, const float* Tc, int32_t Kc,
+                           int32_t graph_is_dense, const int32_t* rowptr2, const int32_t* colidx2, const float* val2, int32_t nnz2,
+                           const float* X, int32_t cin, const float* H, const float* Tc, int32_t Ks, int32_t Kc,
                            const float* Wg, const float* Wc, const float* U, const float* R, const float* Cand,
-                           const float* RH, const float* Zg, const float* Zc, const float* dHnew,
+                           const float* RH, const float* Zg, const float* Zc, const float* Zg2, const float* Zc2, const float* dHnew,
                            float* dX, int32_t accumulate_x, float* dH, int32_t accumulate_h,
                            float* dparams, int64_t params_ld, int32_t has_bg, int32_t has_bc,
                            float* dZ1c, float* dZ1g, float* dYg, float* dYc,

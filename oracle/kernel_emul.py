@@ -394,7 +394,7 @@ class EmulatedKernels:
     SMALL_STAGED_ROWS = 640      # N*C rows per sample that a compute unit's LDS stages (above: every gather from L2; dense graphs go to the general path)
 
     def cell_small_supported(self, Ks, Kc, Cc, cin, h, n_nodes=0) -> bool:
-        return Ks == 2 and Kc == 2 and 1 <= Cc <= 16 and h == 16 and (cin == 16 or 1 <= cin <= 4) and n_nodes * Cc <= self.SMALL_MAX_ROWS
+        return Ks in (2, 3) and Kc == Ks and 1 <= Cc <= 16 and h == 16 and (cin == 16 or 1 <= cin <= 4) and n_nodes * Cc <= self.SMALL_MAX_ROWS
 
     @staticmethod
     def cell_small_zg_width(cin) -> int:
@@ -421,14 +421,24 @@ class EmulatedKernels:
         return out.view(B, N, Cc, w)
 
     def cell_small_fwd(self, rowptr, colidx, val, X, H, Tc, Wg, bg, Wc, bc, U, R, Cand, Hnew, RH, Zg, Zc, checked=True, Z0=None, splits=1, Z0c=None,
-                       Z1c=None):
+                       Z1c=None, graph2=None, Zg2=None, Zc2=None):
         B, N, Cc, h = H.shape
         cin = X.shape[-1]
+        order3 = Tc.shape[0] == 3                 # the third slab through the second graph T_2(S) = 2 S^2 - I (formed on the matrix side, as the kernels take it)
+        assert order3 == (graph2 is not None) and (not order3 or (Zg2 is not None and Zc2 is not None and Z0 is None))
         rows = lambda t: t.reshape(B * N, Cc, t.shape[-1])
         XH = torch.cat([X, H], -1)
         SXH = self._small_agg(rowptr, colidx, val, XH)
         G = torch.empty(B * N, Cc, 2 * h, dtype=H.dtype)
-        self.bdg_node_fwd([rows(XH), rows(SXH)], Tc, Wg, bg, G)
+        slabs_g = [rows(XH), rows(SXH)]
+        if order3:
+            S2XH = self._small_agg(*graph2, XH)
+            slabs_g.append(rows(S2XH))
+            Zg2.zero_()
+            Zg2v = Zg2.view(B, N, Cc, Zg2.shape[-1])
+            Zg2v[..., :h] = S2XH[..., cin:]
+            Zg2v[..., h:h + cin] = S2XH[..., :cin]
+        self.bdg_node_fwd(slabs_g, Tc, Wg, bg, G)
         G = G.view(B, N, Cc, 2 * h)
         U.copy_(torch.sigmoid(G[..., :h]))
         R.copy_(torch.sigmoid(G[..., h:]))
@@ -449,33 +459,44 @@ class EmulatedKernels:
                 dst.copy_(Zg if dst is Z1c else Z0)
                 dst.view(B, N, Cc, dst.shape[-1])[..., :h] = hpart
         Y = torch.empty(B * N, Cc, h, dtype=H.dtype)
-        self.bdg_node_fwd([rows(torch.cat([X, RH], -1)), rows(torch.cat([SXH[..., :cin], SRH], -1))], Tc, Wc, bc, Y)
+        slabs_c = [rows(torch.cat([X, RH], -1)), rows(torch.cat([SXH[..., :cin], SRH], -1))]
+        if order3:
+            S2RH = self._small_agg(*graph2, RH)
+            Zc2.copy_(S2RH.reshape(B, N * Cc, h))
+            slabs_c.append(rows(torch.cat([S2XH[..., :cin], S2RH], -1)))
+        self.bdg_node_fwd(slabs_c, Tc, Wc, bc, Y)
         Cand.copy_(torch.tanh(Y.view(B, N, Cc, h)))
         Hnew.copy_((1.0 - U) * H + U * Cand)
 
     def cell_small_bwd(self, rowptr, colidx, val, X, H, Tc, Wg, Wc, U, R, Cand, RH, Zg, Zc, dHnew, dX, accumulate_x, dH, accumulate_h,
-                       dparams, has_bg, has_bc, checked=True, dZ1c=None, dZ1g=None, dYg=None, splits=1, dYc=None):
+                       dparams, has_bg, has_bc, checked=True, dZ1c=None, dZ1g=None, dYg=None, splits=1, dYc=None, graph2=None, Zg2=None, Zc2=None):
         B, N, Cc, h = H.shape
         cin = X.shape[-1]
         L = cin + h
-        Kc = Tc.shape[0]
+        Kc = Ks = Tc.shape[0]
+        order3 = Ks == 3
+        assert order3 == (graph2 is not None) and (not order3 or (Zg2 is not None and Zc2 is not None and dZ1c is None))
         Zgv = Zg.view(B, N, Cc, Zg.shape[-1])
         SX, SH, SRH = Zgv[..., h:h + cin], Zgv[..., :h], Zc.view(B, N, Cc, h)
-        nW = 2 * Kc * L
+        if order3:
+            Zg2v = Zg2.view(B, N, Cc, Zg2.shape[-1])
+            S2X, S2H, S2RH = Zg2v[..., h:h + cin], Zg2v[..., :h], Zc2.view(B, N, Cc, h)
+        nW = Ks * Kc * L
         first = dparams[::self.cell_small_param_rows * splits]       # (a view: row 0 of every sample's group)
         assert first.shape[0] == B
         dWg, dbg = first[:, :nW * 2 * h], first[:, nW * 2 * h:nW * 2 * h + 2 * h]
         dWc, dbc = first[:, nW * 2 * h + 2 * h:nW * 3 * h + 2 * h], first[:, nW * 3 * h + 2 * h:nW * 3 * h + 3 * h]
 
-        def conv_bwd(Z0, Z1, W, dY, dW_rows, db_rows, dump=None):
-            """d[Z0] + S^T d[Z1] of one convolution (B, N, C, L); parameter gradients per sample; ``dump``: receives d[Z1] in [H | X | 0] order."""
+        def conv_bwd(Z0, Z1, W, dY, dW_rows, db_rows, dump=None, Z2=None):
+            """d[Z0] + S^T d[Z1] (+ T_2(S)^T d[Z2] at order 3) of one convolution (B, N, C, L); parameter gradients per sample; ``dump``: receives
+            d[Z1] in [H | X | 0] order."""
             out = torch.empty(B, N, Cc, L, dtype=H.dtype)
             if dump is not None:
                 dump.zero_()
             for b in range(B):
-                dZ = [torch.empty(N, Cc, L, dtype=H.dtype), torch.empty(N, Cc, L, dtype=H.dtype)]
+                dZ = [torch.empty(N, Cc, L, dtype=H.dtype) for _ in range(Ks)]
                 dW, db = torch.empty_like(W), torch.empty(W.shape[1], dtype=H.dtype)
-                self.bdg_node_bwd([Z0[b], Z1[b]], Tc, W, dY[b], dZ, dW, db, None)
+                self.bdg_node_bwd([Z0[b], Z1[b]] + ([Z2[b]] if order3 else []), Tc, W, dY[b], dZ, dW, db, None)
                 dW_rows[b] += dW.reshape(-1)
                 if db_rows is not None:
                     db_rows[b] += db
@@ -485,17 +506,23 @@ class EmulatedKernels:
                     dv_[..., h:h + cin] = dZ[1][..., :cin]
                 back = torch.empty(1, N, Cc * L, dtype=H.dtype)
                 self.csr_spmm(rowptr, colidx, val, N, N, dZ[1].reshape(1, N, Cc * L), dZ[0].reshape(1, N, Cc * L), back, 1.0, 1.0)
+                if order3:
+                    back2 = torch.empty_like(back)
+                    self.csr_spmm(*graph2, N, N, dZ[2].reshape(1, N, Cc * L), back, back2, 1.0, 1.0)
+                    back = back2
                 out[b] = back.view(N, Cc, L)
             return out
 
         dCpre = dHnew * U * (1.0 - Cand * Cand)
         if dYc is not None:
             dYc.copy_(dCpre.reshape(B, N * Cc, h))
-        dCI = conv_bwd(torch.cat([X, RH], -1), torch.cat([SX, SRH], -1), Wc, dCpre, dWc, dbc if has_bc else None, dump=dZ1c)
+        dCI = conv_bwd(torch.cat([X, RH], -1), torch.cat([SX, SRH], -1), Wc, dCpre, dWc, dbc if has_bc else None, dump=dZ1c,
+                       Z2=torch.cat([S2X, S2RH], -1) if order3 else None)
         dRH, dXc = dCI[..., cin:], dCI[..., :cin]
         dGu = dHnew * (Cand - H) * U * (1.0 - U)
         dGr = dRH * H * R * (1.0 - R)
-        dXH = conv_bwd(torch.cat([X, H], -1), torch.cat([SX, SH], -1), Wg, torch.cat([dGu, dGr], -1), dWg, dbg if has_bg else None, dump=dZ1g)
+        dXH = conv_bwd(torch.cat([X, H], -1), torch.cat([SX, SH], -1), Wg, torch.cat([dGu, dGr], -1), dWg, dbg if has_bg else None, dump=dZ1g,
+                       Z2=torch.cat([S2X, S2H], -1) if order3 else None)
         if dYg is not None:
             dYg.copy_(torch.cat([dGu, dGr], -1).reshape(B, N * Cc, 2 * h))
         if dH is not None:

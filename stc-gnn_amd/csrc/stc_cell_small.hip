@@ -35,9 +35,21 @@ namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-constexpr int SF_THREADS = 1024, SF_WAVES = SF_THREADS / 64;      // forward: 16 waves, <= 128 registers
+constexpr int SF_THREADS = 1024;                                  // forward: 16 waves, <= 128 registers
 constexpr int SB_THREADS = 1024, SB_WAVES = SB_THREADS / 64;      // backward: 16 waves = 4 quads, four waves per row tile (slab x role)
-constexpr int SC_H = 16, SC_KS = 2, SC_MAXC = 16;
+constexpr int SC_H = 16, SC_MAXC = 16;
+// Chebyshev ORDER 3 (Ks = Kc = 3; round 6).  The third spatial slab is Z_2 = T_2(S) Z with T_2(S) = 2 S^2 - I -- which the reference forms on the
+// MATRIX side (cheby_poly, STC_GNN.py:24-29) and so does the host here: for a graph this small 2 S^2 - I is one more sparse matrix (25 entries per
+// row on an 8-neighbour grid), handed over as a SECOND CSR graph.  Z_2 is then an aggregation of the same input rows as Z_1, not of Z_1's: no
+// phase is added, no dependency crosses workgroups that order 2 does not have, and the split forms (5, 6 / 1, 7, 4) are the same launches.
+// What changes: three slabs per convolution (nine W blocks, two category mixes), workgroups of 8 waves forward (the nine W blocks are 72
+// registers per lane: 256 instead of 128 available) and 12 waves backward (six per row tile: slab x role), nothing staged in LDS (MODE 0),
+// fixed CSR graphs only (a learned dense Gs at order 3 stays on the general path).
+template <int KS> struct WgShape {                                     // workgroup shapes per order
+    static constexpr int FWD_THREADS = KS == 2 ? SF_THREADS : 512, FWD_WAVES = FWD_THREADS / 64;
+    static constexpr int BWD_THREADS = KS == 2 ? SB_THREADS : 768, BWD_WAVES = BWD_THREADS / 64;
+    static constexpr int BWD_GROUPS = BWD_WAVES / (2 * KS);       // row tiles a workgroup convolves at once (4 / 2)
+};
 
 // Probe hooks: tools/probes/small_cell_phases.py builds this file with -DSTC_PROBE -DSC_STOP_AFTER=n (-DSC_MAX_TILES, -DSC_SKIP_ROLE) and times
 // the truncated launches.  The library is built without STC_PROBE: the hooks then do not exist.
@@ -105,6 +117,33 @@ __device__ __forceinline__ void aggregate_rows(const int* __restrict__ gp, const
         for (int e = gp[n]; e < e1; ++e) {
             const float v = gv[e];
             const f32x4 x = fetch(gc[e] * C + c, q);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s[i] = fmaf(v, x[i], s[i]);
+        }
+        store(row, q, s);
+    }
+}
+
+// ... over TWO graphs with a source each (order 3's transposed aggregation  d[in] = dZ_0 + S^T dZ_1 + T_2(S)^T dZ_2):
+template <int THREADS, int QUADS, class Fetch, class Fetch2, class Base, class Store>
+__device__ __forceinline__ void aggregate_rows2(const int* __restrict__ gp, const int* __restrict__ gc, const float* __restrict__ gv,
+                                                const int* __restrict__ gp2, const int* __restrict__ gc2, const float* __restrict__ gv2, int C,
+                                                unsigned invC, int row_lo, int row_hi, Fetch fetch, Fetch2 fetch2, Base base, Store store) {
+    for (int item = threadIdx.x; item < (row_hi - row_lo) * QUADS; item += THREADS) {
+        const int row = row_lo + item / QUADS, q = item - (row - row_lo) * QUADS;
+        const int n = div_c(row, invC), c = row - n * C;
+        f32x4 s = base(row, q);
+        const int e1 = gp[n + 1];
+        for (int e = gp[n]; e < e1; ++e) {
+            const float v = gv[e];
+            const f32x4 x = fetch(gc[e] * C + c, q);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s[i] = fmaf(v, x[i], s[i]);
+        }
+        const int f1 = gp2[n + 1];
+        for (int e = gp2[n]; e < f1; ++e) {
+            const float v = gv2[e];
+            const f32x4 x = fetch2(gc2[e] * C + c, q);
 #pragma unroll
             for (int i = 0; i < 4; ++i) s[i] = fmaf(v, x[i], s[i]);
         }
@@ -296,12 +335,12 @@ __device__ __forceinline__ AOp<(XQ == 4 ? 4 : XQ)> load_op(const float* ph, int 
 // W (Ks*Kc*L, HO) in B-operand order for the forward products of output column `col`: step s < 4 of slab ks feeds l = cin + 4 kq + s (the
 // H block: one 16-byte read of a row gives a lane its A operands of four steps; any bijection of the contraction index serves a sum),
 // steps 4.. the X block (wide: l = 4 kq + s; narrow: l = 4 s + kq).
-template <int KC, int XQ>
-__device__ __forceinline__ void load_w_fwd(float (&Wr)[SC_KS][KC][4 + (XQ == 4 ? 4 : XQ)], const float* __restrict__ W, int HO, int col, int cin, int kq) {
+template <int KS, int KC, int XQ>
+__device__ __forceinline__ void load_w_fwd(float (&Wr)[KS][KC][4 + (XQ == 4 ? 4 : XQ)], const float* __restrict__ W, int HO, int col, int cin, int kq) {
     constexpr int XS = XQ == 4 ? 4 : XQ;
     const int L = cin + SC_H;
 #pragma unroll
-    for (int ks = 0; ks < SC_KS; ++ks)
+    for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
             const float* Wb = W + (unsigned)((ks * KC + kc) * L) * HO + col;
@@ -338,27 +377,32 @@ __device__ __forceinline__ void build_mix(float (&M)[KC][4], const float* __rest
 // The row tiles tile0, tile0 + tstep, .. of a forward convolution for ONE 16-column tile of its output: V_kc in the accumulators (lane
 // (j, kq): rows 4 kq .. 4 kq + 3 of the tile, column j), the category mix as four more matrix instructions per kc >= 1 into V_0's
 // accumulator, epi(global row, y) per finished pre-activation (bias not added).  z0(row) / z1(row): the lane's A operands of slab 0 /
-// slab 1; slab 1 (the aggregate the previous phase left in global memory) is requested one tile ahead.
-template <int KC, int XQ, class Z0, class Z1, class Epi>
-__device__ __forceinline__ void fwd_conv(const float (&Wr)[SC_KS][KC][4 + (XQ == 4 ? 4 : XQ)], const float (&M)[KC][4], int tile0, int tstep, int tiles,
-                                         int rpt, int NC, int j, int kq, Z0 z0, Z1 z1, Epi epi) {
+// slab 1 (z2: slab 2, order 3 only); the aggregated slabs (which the previous phase left in global memory) are requested one tile ahead.
+template <int KS, int KC, int XQ, class Z0, class Z1, class Z2, class Epi>
+__device__ __forceinline__ void fwd_conv(const float (&Wr)[KS][KC][4 + (XQ == 4 ? 4 : XQ)], const float (&M)[KC][4], int tile0, int tstep, int tiles,
+                                         int rpt, int NC, int j, int kq, Z0 z0, Z1 z1, Z2 z2, Epi epi) {
     constexpr int XS = XQ == 4 ? 4 : XQ;
     // rows that do not exist (beyond the tile's nodes / the sample) read the tile's first row -- a row this workgroup owns, so a FINITE value
     // even when other workgroups are still writing theirs (fused phases): their products land in accumulator rows nobody stores, but the
     // mix multiplies them by zeros.  (A tile requested past the end reads an in-bounds row that nobody uses.)
     auto row_of = [&](int tile) { return j < rpt && tile * rpt + j < NC ? tile * rpt + j : min(tile * rpt, NC - 1); };
-    AOp<XS> nxt = z1(row_of(tile0));
+    AOp<XS> nxt = z1(row_of(tile0)), nxt2 = zero_op<XS>();
+    if constexpr (KS == 3) nxt2 = z2(row_of(tile0));
     for (int tile = tile0; tile < tiles; tile += tstep) {
         const int row0 = tile * rpt;
-        AOp<XS> a[SC_KS];
+        AOp<XS> a[KS];
         a[1] = nxt;
         nxt = z1(row_of(tile + tstep));
+        if constexpr (KS == 3) {
+            a[2] = nxt2;
+            nxt2 = z2(row_of(tile + tstep));
+        }
         a[0] = z0(row_of(tile));
         f32x4 acc[KC];
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) acc[kc] = zero4();
 #pragma unroll
-        for (int ks = 0; ks < SC_KS; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -388,17 +432,22 @@ struct SmallFwd {
                                                  // [R*H | X | 0] and [S.(R*H) | S.X | 0]
     int N, C, cin, rpt, tiles;
     int phase;                                   // 0: the whole cell in this launch (one workgroup per sample); 1..4: that phase only, the sample's
-};                                               // rows split over gridDim.y workgroups -- the launch boundary is the barrier between phases
+                                                 // rows split over gridDim.y workgroups -- the launch boundary is the barrier between phases
+    SmallGraph g2;                               // order 3: CSR of T_2(S)^T = 2 (S^T)^2 - I in the forward's orientation
+    float *Zg2, *Zc2;                            // order 3: T_2 . [H | X] (rows of LP floats) and T_2 . (R*H) (rows of 16)
+};
 
 template <int KC>
 __host__ __device__ constexpr int fwd_lds_fixed() { return 0; }                                         // floats of LDS every launch needs
 
 // MODE 0: graph and planes read from global memory; 1: CSR graph + planes staged in LDS; 2: dense graph (matrix-product aggregation), planes staged;
 // 3: dense graph in the split form (phase != 0): nothing staged, a workgroup aggregates the node tiles that cover its own rows (aggregate_dense_own)
-template <int KC, int XQ, int MODE>
-__global__ __launch_bounds__(SF_THREADS) void small_fwd_kernel(SmallFwd a) {
+template <int KS, int KC, int XQ, int MODE>
+__global__ __launch_bounds__(WgShape<KS>::FWD_THREADS) void small_fwd_kernel(SmallFwd a) {
     constexpr int LP = 16 + 4 * XQ, XS = XQ == 4 ? 4 : XQ, SP = plane_stride(XQ);
     constexpr bool STAGED = MODE == 1 || MODE == 2, DENSE = MODE >= 2;
+    constexpr int SF_THREADS = WgShape<KS>::FWD_THREADS, SF_WAVES = WgShape<KS>::FWD_WAVES;      // (shadow the order-2 constants of the file)
+    static_assert(KS == 2 || (KS == 3 && KC == 3 && MODE == 0), "order 3: Ks = Kc = 3, CSR graph, nothing staged");
     extern __shared__ __align__(16) float lds[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, j = lane & 15, kq = lane >> 4;
     const int C = a.C, N = a.N, NC = N * C, cin = a.cin;
@@ -419,6 +468,8 @@ __global__ __launch_bounds__(SF_THREADS) void small_fwd_kernel(SmallFwd a) {
     float* RHb = a.RH + r0 * SC_H;           // (written in phase 2, read later in the launch: never through a __restrict__ / const path)
     float* Zgb = a.Zg + r0 * LP;
     float* Zcb = a.Zc + r0 * SC_H;
+    float* Zg2b = KS == 3 ? a.Zg2 + r0 * LP : nullptr;
+    float* Zc2b = KS == 3 ? a.Zc2 + r0 * SC_H : nullptr;
 
     // Split form (phase != 0): this launch runs ONE phase, with the sample's tiles / rows dealt over gridDim.y workgroups, so that a step of
     // few samples still fills the chip; the caller launches the phases in order (the launch boundary replaces the workgroup barrier).
@@ -434,8 +485,8 @@ __global__ __launch_bounds__(SF_THREADS) void small_fwd_kernel(SmallFwd a) {
 
     // 0: tables, graph and the sample's rows into LDS (the gates' W operands are requested first: in flight during phases 0 and 1)
     const int ct = wave & 1;                                 // gates: wave w owns column tile w % 2 (0: update, 1: reset)
-    float Wg_r[SC_KS][KC][4 + XS];
-    if (runs(2)) load_w_fwd<KC, XQ>(Wg_r, a.Wg, 2 * SC_H, 16 * ct + j, cin, kq);
+    float Wg_r[KS][KC][4 + XS];
+    if (runs(2)) load_w_fwd<KS, KC, XQ>(Wg_r, a.Wg, 2 * SC_H, 16 * ct + j, cin, kq);
     float M[KC][4];
     build_mix<KC>(M, a.Tc, false, a.rpt, C, invC, j, kq);
     if (STAGED) {
@@ -488,9 +539,8 @@ __global__ __launch_bounds__(SF_THREADS) void small_fwd_kernel(SmallFwd a) {
             aggregate_dense_own<SF_THREADS, 4>(a.g.val, N, C, Hb, SC_H, SC_H, n_lo, n_hi, row_lo, row_hi, none, put);
             aggregate_dense_own<SF_THREADS, XQ>(a.g.val, N, C, Xb, cin, cin, n_lo, n_hi, row_lo, row_hi, none,
                                                 [&](int row, int q, f32x4 s) { st4(Zgb + (unsigned)row * LP + SC_H + 4 * q, s); });
-        } else
-            aggregate_rows<SF_THREADS, LP / 4>(gp, gc, gv, NC, C, invC, row_lo, row_hi,
-                [&](int src, int q) -> f32x4 {
+        } else {
+            auto input_rows = [&](int src, int q) -> f32x4 {
                     if (STAGED) return ld4(P + (unsigned)src * SP + 4 * q);
                     if (q < 4) return ld4(Hb + (unsigned)src * SC_H + 4 * q);
                     if (XQ == 4) return ld4(Xb + (unsigned)src * SC_H + 4 * (q - 4));
@@ -499,8 +549,12 @@ __global__ __launch_bounds__(SF_THREADS) void small_fwd_kernel(SmallFwd a) {
                     for (int i = 0; i < 4; ++i)
                         if (4 * (q - 4) + i < cin) x[i] = Xb[(unsigned)src * cin + 4 * (q - 4) + i];
                     return x;
-                },
-                none, put);
+                };
+            aggregate_rows<SF_THREADS, LP / 4>(gp, gc, gv, NC, C, invC, row_lo, row_hi, input_rows, none, put);
+            if constexpr (KS == 3)                           // Zg2 = T_2(S) . [H | X]: the same input rows through the second graph
+                aggregate_rows<SF_THREADS, LP / 4>(a.g2.rowptr, a.g2.colidx, a.g2.val, NC, C, invC, row_lo, row_hi, input_rows, none,
+                                                   [&](int row, int q, f32x4 s) { st4(Zg2b + (unsigned)row * LP + 4 * q, s); });
+        }
     }
     sync(1);
     SC_PHASE_END(1);
@@ -508,9 +562,10 @@ __global__ __launch_bounds__(SF_THREADS) void small_fwd_kernel(SmallFwd a) {
     // 2: gates -- wave w: column tile w % 2 of the workgroup's row tiles t_lo + w / 2, t_lo + w / 2 + 8, ..
     if (runs(2)) {
         const float bias = a.bg ? a.bg[16 * ct + j] : 0.f;
-        fwd_conv<KC, XQ>(Wg_r, M, t_lo + (wave >> 1), SF_WAVES / 2, t_hi, a.rpt, NC, j, kq,
+        fwd_conv<KS, KC, XQ>(Wg_r, M, t_lo + (wave >> 1), SF_WAVES / 2, t_hi, a.rpt, NC, j, kq,
             [&](int row) { return STAGED ? load_op<XQ>(P, SP, P + 16, SP, true, cin, row, kq) : load_op<XQ>(Hb, SC_H, Xb, cin, false, cin, row, kq); },
             [&](int row) { return load_op<XQ>(Zgb, LP, Zgb + 16, LP, true, cin, row, kq); },
+            [&](int row) { return load_op<XQ>(Zg2b, LP, Zg2b + 16, LP, true, cin, row, kq); },
             [&](int grow, float y) {
                 const size_t e = (unsigned)grow * SC_H + j;
                 const float g = sigm(y + bias);
@@ -528,8 +583,8 @@ __global__ __launch_bounds__(SF_THREADS) void small_fwd_kernel(SmallFwd a) {
     SC_PHASE_END(2);
 
     // 3: Zc = S.(R*H)   (the candidate's W operands in flight meanwhile)
-    float Wc_r[SC_KS][KC][4 + XS];
-    if (runs(4)) load_w_fwd<KC, XQ>(Wc_r, a.Wc, SC_H, j, cin, kq);
+    float Wc_r[KS][KC][4 + XS];
+    if (runs(4)) load_w_fwd<KS, KC, XQ>(Wc_r, a.Wc, SC_H, j, cin, kq);
     if (runs(3)) {
         auto none = [](int, int) -> f32x4 { return zero4(); };
         auto put = [&](int row, int q, f32x4 s) { st4(Zcb + (unsigned)row * SC_H + 4 * q, s); };
@@ -537,9 +592,13 @@ __global__ __launch_bounds__(SF_THREADS) void small_fwd_kernel(SmallFwd a) {
             aggregate_dense<SF_THREADS, 4>(a.g.val, N, C, Q, SQ, 0, 1, none, put);
         else if (DENSE)
             aggregate_dense_own<SF_THREADS, 4>(a.g.val, N, C, RHb, SC_H, SC_H, n_lo, n_hi, row_lo, row_hi, none, put);
-        else
-            aggregate_rows<SF_THREADS, 4>(gp, gc, gv, NC, C, invC, row_lo, row_hi,
-                [&](int src, int q) -> f32x4 { return STAGED ? ld4(Q + (unsigned)src * SQ + 4 * q) : ld4(RHb + (unsigned)src * SC_H + 4 * q); }, none, put);
+        else {
+            auto rh_rows = [&](int src, int q) -> f32x4 { return STAGED ? ld4(Q + (unsigned)src * SQ + 4 * q) : ld4(RHb + (unsigned)src * SC_H + 4 * q); };
+            aggregate_rows<SF_THREADS, 4>(gp, gc, gv, NC, C, invC, row_lo, row_hi, rh_rows, none, put);
+            if constexpr (KS == 3)                           // Zc2 = T_2(S) . (R*H)
+                aggregate_rows<SF_THREADS, 4>(a.g2.rowptr, a.g2.colidx, a.g2.val, NC, C, invC, row_lo, row_hi, rh_rows, none,
+                                              [&](int row, int q, f32x4 s) { st4(Zc2b + (unsigned)row * SC_H + 4 * q, s); });
+        }
     }
     sync(3);
     SC_PHASE_END(3);
@@ -560,9 +619,10 @@ __global__ __launch_bounds__(SF_THREADS) void small_fwd_kernel(SmallFwd a) {
         const float bias = a.bc ? a.bc[j] : 0.f;
         float* Cb = a.Cand + r0 * SC_H;
         float* Hn = a.Hnew + r0 * SC_H;
-        fwd_conv<KC, XQ>(Wc_r, M, t_lo + wave, SF_WAVES, t_hi, a.rpt, NC, j, kq,
+        fwd_conv<KS, KC, XQ>(Wc_r, M, t_lo + wave, SF_WAVES, t_hi, a.rpt, NC, j, kq,
             [&](int row) { return STAGED ? load_op<XQ>(Q, SQ, P + 16, SP, true, cin, row, kq) : load_op<XQ>(RHb, SC_H, Xb, cin, false, cin, row, kq); },
             [&](int row) { return load_op<XQ>(Zcb, SC_H, Zgb + 16, LP, true, cin, row, kq); },
+            [&](int row) { return load_op<XQ>(Zc2b, SC_H, Zg2b + 16, LP, true, cin, row, kq); },
             [&](int grow, float y) {
                 const size_t e = (unsigned)grow * SC_H + j;
                 const float cd = tanh_hw(y + bias), u = Ub[e], hh = STAGED ? P[(unsigned)grow * SP + j] : Hb[e];
@@ -796,6 +856,8 @@ struct SmallBwd {
     int N, C, cin, rpt, tiles, acc_x, acc_h, has_bg, has_bc;
     int phase;                                   // as in SmallFwd
     long long P;                                 // floats per row of dP: [dWg | dbg (32) | dWc | dbc (16)]; SB_WAVES / 4 rows per sample
+    SmallGraph g2;                               // order 3: CSR of T_2(S) = 2 S^2 - I (the transpose of the forward's second graph)
+    const float *Zg2, *Zc2;                      // order 3: the forward's third slabs
 };
 
 struct Raw3 {
@@ -805,19 +867,22 @@ struct Raw2 {
     float a, b;
 };
 
-template <int KC>
-__host__ __device__ constexpr int bwd_lds_fixed() { return SB_WAVES * KC * 16 * 33; }                     // floats: the waves' dV tiles
+template <int KS, int KC>
+__host__ __device__ constexpr int bwd_lds_fixed() { return WgShape<KS>::BWD_WAVES * KC * 16 * 33; }           // floats: the waves' dV tiles
+__host__ __device__ constexpr int ws_row_floats(int KS, int LP) { return (2 * KS - 1) * LP + 32; }       // per sample row: dZ_0 | dZ_1 | dYg (32) | dZ_1s [| dZ_2 | dZ_2s]
 
-template <int KC, int XQ, int MODE>      // MODE 3 (backward only): dense graph, nothing staged -- the split form of a learned graph's backward
-__global__ __launch_bounds__(SB_THREADS) void small_bwd_kernel(SmallBwd a) {
+template <int KS, int KC, int XQ, int MODE>      // MODE 3 (backward only): dense graph, nothing staged -- the split form of a learned graph's backward
+__global__ __launch_bounds__(WgShape<KS>::BWD_THREADS) void small_bwd_kernel(SmallBwd a) {
     constexpr int LP = 16 + 4 * XQ;
     constexpr bool STAGED = MODE == 1 || MODE == 2, DENSE = MODE >= 2;
+    constexpr int SB_THREADS = WgShape<KS>::BWD_THREADS;
+    static_assert(KS == 2 || (KS == 3 && KC == 3 && MODE == 0), "order 3: Ks = Kc = 3, CSR graph, nothing staged");
     extern __shared__ __align__(16) float lds[];
     const int t = threadIdx.x, wave = t >> 6;
     const int C = a.C, N = a.N, NC = N * C, cin = a.cin, L = cin + SC_H;
     const unsigned invC = inv_c(C);
     float* dv = lds + wave * KC * 16 * 33;
-    float* D1 = lds + bwd_lds_fixed<KC>();                   // STAGED: the slab dZ_1 of the convolution in flight, stride LP
+    float* D1 = lds + bwd_lds_fixed<KS, KC>();               // STAGED: the slab dZ_1 of the convolution in flight, stride LP
     int* gpl = reinterpret_cast<int*>(D1 + (size_t)NC * LP);
     int* gcl = gpl + ((N + 4) & ~3);
     float* gvl = reinterpret_cast<float*>(gcl + ((a.g.nnz + 3) & ~3));
@@ -836,13 +901,19 @@ __global__ __launch_bounds__(SB_THREADS) void small_bwd_kernel(SmallBwd a) {
     const float* dHn = a.dHnew + r0 * SC_H;
     float* dXb = a.dX ? a.dX + r0 * cin : nullptr;
     float* dHb = a.dH ? a.dH + r0 * SC_H : nullptr;
-    float* wsb = a.ws + (size_t)blockIdx.x * NC * (3 * LP + 32);
+    float* wsb = a.ws + (size_t)blockIdx.x * NC * ws_row_floats(KS, LP);
+    const float* Zg2b = KS == 3 ? a.Zg2 + r0 * LP : nullptr;
+    const float* Zc2b = KS == 3 ? a.Zc2 + r0 * SC_H : nullptr;
+    float* dZ2 = wsb + (size_t)NC * (3 * LP + 32);                    // order 3: the third slab's gradients, candidate / gates convolution
+    float* dZ2s = wsb + (size_t)NC * (4 * LP + 32);
     float* dZ0 = wsb;
     float* dZ1 = STAGED ? D1 : wsb + (size_t)NC * LP;
     float* dZ1s = STAGED ? D1 : wsb + (size_t)NC * (2 * LP + 32);     // the gates convolution's dZ_1: its own slab, so that a workgroup may run phase 3
                                                                       // while another still reads the candidate's dZ_1 in phase 2 (phase 7)
     float* dYg = a.dYg ? a.dYg + r0 * 32 : wsb + (size_t)NC * 2 * LP;
-    const int ks = wave & 1, role = (wave >> 1) & 1;
+    // order 2: four waves per row tile (wave & 1 = slab, (wave >> 1) & 1 = role), four tiles at once; order 3: six per tile, two tiles at once
+    const int unit = KS == 2 ? (wave & 3) : wave % 6, group = KS == 2 ? (wave >> 2) : wave / 6;
+    const int ks = KS == 2 ? (unit & 1) : unit % 3, role = KS == 2 ? (unit >> 1) : unit / 3;
     // phase 7 = phases 2 + 3 in one launch: the gates convolution of a tile reads the gate pre-activation gradients of its OWN rows only, which
     // phase 2 has just formed (a workgroup owns a contiguous range of row tiles); phases 1 -> 2 and 3 -> 4 read the neighbours' dZ_1.
     const int phase = a.phase, split = blockIdx.y, splits = gridDim.y;
@@ -851,12 +922,12 @@ __global__ __launch_bounds__(SB_THREADS) void small_bwd_kernel(SmallBwd a) {
     const int t_lo = (int)((long long)a.tiles * split / splits), t_hi = (int)((long long)a.tiles * (split + 1) / splits);
     const int row_lo = min(t_lo * a.rpt, NC), row_hi = min(t_hi * a.rpt, NC);
     const int n_lo = div_c(row_lo, invC), n_hi = div_c(row_hi + C - 1, invC);      // the nodes of the workgroup's own rows
-    const int tile0 = t_lo + (wave >> 2), tstep = SB_WAVES / 4;
-    float* dPw = a.dP + (((size_t)blockIdx.x * splits + split) * (SB_WAVES / 4) + (wave >> 2)) * a.P;
+    const int tile0 = t_lo + group, tstep = WgShape<KS>::BWD_GROUPS;
+    float* dPw = a.dP + (((size_t)blockIdx.x * splits + split) * (SB_WAVES / 4) + group) * a.P;      // (rows per sample: stc_cell_small_param_rows, either order)
     float* dWg = dPw;
-    float* dbg = dPw + (size_t)SC_KS * KC * L * 32;
+    float* dbg = dPw + (size_t)KS * KC * L * 32;
     float* dWc = dbg + 32;
-    float* dbc = dWc + (size_t)SC_KS * KC * L * 16;
+    float* dbc = dWc + (size_t)KS * KC * L * 16;
     const int lane = t & 63;
     float M[KC][4];
     build_mix<KC>(M, a.Tc, true, a.rpt, C, invC, lane & 15, lane >> 4);
@@ -864,7 +935,8 @@ __global__ __launch_bounds__(SB_THREADS) void small_bwd_kernel(SmallBwd a) {
     if (phase == 0) __syncthreads();
 
     // 1: candidate convolution
-    if (runs(1)) conv_bwd_phase<KC, XQ, 1, Raw3>(ks == 0 ? Slab{RHb, SC_H, Xb, cin} : Slab{Zcb, SC_H, Zgb + SC_H, LP}, a.Wc, ks, role, M, dv, ks == 0 ? dZ0 : dZ1,
+    if (runs(1)) conv_bwd_phase<KC, XQ, 1, Raw3>(ks == 0 ? Slab{RHb, SC_H, Xb, cin} : (ks == 1 ? Slab{Zcb, SC_H, Zgb + SC_H, LP} : Slab{Zc2b, SC_H, Zg2b + SC_H, LP}),
+        a.Wc, ks, role, M, dv, ks == 0 ? dZ0 : (ks == 1 ? dZ1 : dZ2),
         ks == 1 && a.dZ1c ? a.dZ1c + r0 * LP : nullptr, dWc,
         a.has_bc ? dbc : nullptr, a.rpt, min(t_hi, SC_MAX_TILES), tile0, tstep, NC, cin,
         [&](int grow, int col) {
@@ -922,6 +994,9 @@ __global__ __launch_bounds__(SB_THREADS) void small_bwd_kernel(SmallBwd a) {
             aggregate_dense_own<SB_THREADS, LP / 4>(a.g.val, N, C, dZ1, LP, LP, n_lo, n_hi, row_lo, row_hi, from_dz0, gate_bwd);
         else if (DENSE)
             aggregate_dense<SB_THREADS, LP / 4>(a.g.val, N, C, dZ1, LP, split, splits, from_dz0, gate_bwd);
+        else if constexpr (KS == 3)
+            aggregate_rows2<SB_THREADS, LP / 4>(gp, gc, gv, a.g2.rowptr, a.g2.colidx, a.g2.val, C, invC, row_lo, row_hi, from_dz1,
+                                                [&](int src, int q) -> f32x4 { return ld4(dZ2 + (unsigned)src * LP + 4 * q); }, from_dz0, gate_bwd);
         else
             aggregate_rows<SB_THREADS, LP / 4>(gp, gc, gv, NC, C, invC, row_lo, row_hi, from_dz1, from_dz0, gate_bwd);
     }
@@ -929,7 +1004,8 @@ __global__ __launch_bounds__(SB_THREADS) void small_bwd_kernel(SmallBwd a) {
     SC_PHASE_END(2);
 
     // 3: gates convolution
-    if (runs(3)) conv_bwd_phase<KC, XQ, 2, Raw2>(ks == 0 ? Slab{Hb, SC_H, Xb, cin} : Slab{Zgb, LP, Zgb + SC_H, LP}, a.Wg, ks, role, M, dv, ks == 0 ? dZ0 : dZ1s,
+    if (runs(3)) conv_bwd_phase<KC, XQ, 2, Raw2>(ks == 0 ? Slab{Hb, SC_H, Xb, cin} : (ks == 1 ? Slab{Zgb, LP, Zgb + SC_H, LP} : Slab{Zg2b, LP, Zg2b + SC_H, LP}),
+        a.Wg, ks, role, M, dv, ks == 0 ? dZ0 : (ks == 1 ? dZ1s : dZ2s),
         ks == 1 && a.dZ1g ? a.dZ1g + r0 * LP : nullptr, dWg,
         a.has_bg ? dbg : nullptr, a.rpt, min(t_hi, SC_MAX_TILES), tile0, tstep, NC, cin,
         [&](int grow, int col) { return Raw2{dYg[(unsigned)grow * 32 + col], dYg[(unsigned)grow * 32 + 16 + col]}; },
@@ -963,6 +1039,9 @@ __global__ __launch_bounds__(SB_THREADS) void small_bwd_kernel(SmallBwd a) {
             aggregate_dense_own<SB_THREADS, LP / 4>(a.g.val, N, C, dZ1s, LP, LP, n_lo, n_hi, row_lo, row_hi, from_dz0, add_in);
         else if (DENSE)
             aggregate_dense<SB_THREADS, LP / 4>(a.g.val, N, C, dZ1s, LP, split, splits, from_dz0, add_in);
+        else if constexpr (KS == 3)
+            aggregate_rows2<SB_THREADS, LP / 4>(gp, gc, gv, a.g2.rowptr, a.g2.colidx, a.g2.val, C, invC, row_lo, row_hi, from_dz1,
+                                                [&](int src, int q) -> f32x4 { return ld4(dZ2s + (unsigned)src * LP + 4 * q); }, from_dz0, add_in);
         else
             aggregate_rows<SB_THREADS, LP / 4>(gp, gc, gv, NC, C, invC, row_lo, row_hi, from_dz1, from_dz0, add_in);
     }
@@ -988,33 +1067,37 @@ hipError_t allow_lds_once(K kern, size_t bytes, Grants& grants) {
     return e;
 }
 Grants g_granted[2][2][4];                       // [direction][wide input][mode]
+Grants g_granted3[2];                            // order 3, backward: [wide input]
 
 }  // namespace
 
 extern "C" int stc_cell_small_supported(int32_t Ks, int32_t Kc, int32_t C, int32_t cin, int32_t h) {
-    return Ks == SC_KS && Kc == 2 && C >= 1 && C <= SC_MAXC && h == SC_H && xq_of(cin) != 0;
+    return (Ks == 2 || Ks == 3) && Kc == Ks && C >= 1 && C <= SC_MAXC && h == SC_H && xq_of(cin) != 0;
 }
 
 extern "C" int stc_cell_small_param_rows(void) { return SB_WAVES / 4; }
 
-extern "C" size_t stc_cell_small_workspace_bytes(int32_t n_nodes, int32_t C, int32_t cin, int32_t batch) {
+extern "C" size_t stc_cell_small_workspace_bytes(int32_t n_nodes, int32_t C, int32_t cin, int32_t batch, int32_t Ks) {
     const int xq = xq_of(cin);
-    if (xq == 0 || n_nodes < 0 || C < 0 || batch < 0) return 0;
-    return (size_t)batch * n_nodes * C * (3 * (16 + 4 * xq) + 32) * sizeof(float);
+    if (xq == 0 || n_nodes < 0 || C < 0 || batch < 0 || (Ks != 2 && Ks != 3)) return 0;
+    return (size_t)batch * n_nodes * C * ws_row_floats(Ks, 16 + 4 * xq) * sizeof(float);
 }
 
 #define SC_COMMON_CHECKS(name)                                                                                                        \
     STC_REQUIRE(n_nodes >= 0 && batch >= 0 && nnz >= 0, STC_EINVAL, name ": negative size (n_nodes=%d nnz=%d batch=%d)", n_nodes, nnz, batch); \
-    STC_REQUIRE(stc_cell_small_supported(SC_KS, Kc, C, cin, SC_H), STC_EINVAL, name ": unsupported shape (Kc=%d C=%d cin=%d)", Kc, C, cin); \
+    STC_REQUIRE(stc_cell_small_supported(Ks, Kc, C, cin, SC_H), STC_EINVAL, name ": unsupported shape (Ks=%d Kc=%d C=%d cin=%d)", Ks, Kc, C, cin); \
     STC_REQUIRE((long long)n_nodes * C < 65536 && (long long)n_nodes * C * batch < (1ll << 26), STC_ELIMIT,                             \
                 name ": %lld rows per sample, %d samples: not a small graph", (long long)n_nodes * C, batch);                           \
-    if (n_nodes == 0 || batch == 0) return STC_OK;
+    if (n_nodes == 0 || batch == 0) return STC_OK;                                                                                       \
+    STC_REQUIRE(Ks == 2 || (rowptr2 && (nnz2 == 0 || (colidx2 && val2)) && nnz2 >= 0 && !graph_is_dense), STC_EINVAL,                    \
+                name ": order 3 takes the CSR of T_2(S) = 2 S^2 - I as a second graph (and no dense graph)");
 
 extern "C" int stc_cell_small_fwd_f32(const int32_t* rowptr, const int32_t* colidx, const float* val, int32_t n_nodes, int32_t nnz,
-                                      int32_t graph_is_dense, const float* X,
-                                      int32_t cin, const float* H, const float* Tc, int32_t Kc, const float* Wg, const float* bg, const float* Wc,
-                                      const float* bc, float* U, float* R, float* Cand, float* Hnew, float* RH, float* Zg, float* Zc, float* Z0,
-                                      float* Z0c, float* Z1c, int32_t phase, int32_t splits, int32_t batch, int32_t C, void* stream) {
+                                      int32_t graph_is_dense, const int32_t* rowptr2, const int32_t* colidx2, const float* val2, int32_t nnz2,
+                                      const float* X, int32_t cin, const float* H, const float* Tc, int32_t Ks, int32_t Kc, const float* Wg,
+                                      const float* bg, const float* Wc, const float* bc, float* U, float* R, float* Cand, float* Hnew, float* RH,
+                                      float* Zg, float* Zc, float* Zg2, float* Zc2, float* Z0, float* Z0c, float* Z1c, int32_t phase, int32_t splits,
+                                      int32_t batch, int32_t C, void* stream) {
     SC_COMMON_CHECKS("stc_cell_small_fwd_f32")
     STC_REQUIRE(rowptr && (nnz == 0 || (colidx && val)) && X && H && Tc && Wg && Wc && U && R && Cand && Hnew && RH && Zg && Zc, STC_EINVAL,
                 "stc_cell_small_fwd_f32: null operand");
@@ -1029,17 +1112,25 @@ extern "C" int stc_cell_small_fwd_f32(const int32_t* rowptr, const int32_t* coli
     STC_REQUIRE((Z0c == nullptr) == (Z1c == nullptr) && (Z0c == nullptr || Z0 != nullptr) && stc::aligned16(Z0c) && stc::aligned16(Z1c), STC_EINVAL,
                 "stc_cell_small_fwd_f32: Z0c and Z1c come together, with Z0, 16-byte aligned");
     SmallFwd a{{rowptr, colidx, val, nnz}, X, H, Tc, Wg, bg, Wc, bc, U, R, Cand, Hnew, RH, Zg, Zc, Z0, Z0c, Z1c, n_nodes, C, cin, rpt,
-               (n_nodes + npt - 1) / npt, phase};
+               (n_nodes + npt - 1) / npt, phase, {rowptr2, colidx2, val2, nnz2}, Zg2, Zc2};
+    if (Ks == 3) {                                           // order 3: global-memory form only (MODE 0), eight waves
+        STC_REQUIRE(Zg2 && Zc2 && stc::aligned16(Zg2) && stc::aligned16(Zc2) && !Z0 && !Z0c, STC_EINVAL,
+                    "stc_cell_small_fwd_f32: order 3 wants the planes Zg2, Zc2 (16-byte aligned) and has no learned-graph outputs");
+        auto kern3 = xq == 4 ? small_fwd_kernel<3, 3, 4, 0> : small_fwd_kernel<3, 3, 1, 0>;
+        hipLaunchKernelGGL(kern3, dim3((unsigned)batch, (unsigned)splits), dim3(WgShape<3>::FWD_THREADS), 0, static_cast<hipStream_t>(stream), a);
+        STC_LAUNCH_CHECK("stc_cell_small_fwd_f32 (order 3) launch");
+        return STC_OK;
+    }
     const size_t fixed = (size_t)fwd_lds_fixed<2>() * 4, planes = (size_t)n_nodes * C * (plane_stride(xq) + SQ) * 4;
     const bool dense_graph = graph_is_dense && nnz == (long long)n_nodes * n_nodes;
     const bool dense = phase == 0 && dense_graph && fixed + planes <= SC_LDS_BUDGET;
     const size_t staged = fixed + planes + (dense ? 0 : graph_lds_bytes(n_nodes, nnz));
     const int mode = dense ? 2 : (phase != 0 && dense_graph ? 3 : (phase == 0 && staged <= SC_LDS_BUDGET ? 1 : 0));
     const size_t lds = mode == 1 || mode == 2 ? staged : fixed;
-    auto kern = mode == 3 ? (xq == 4 ? small_fwd_kernel<2, 4, 3> : small_fwd_kernel<2, 1, 3>)
-              : mode == 2 ? (xq == 4 ? small_fwd_kernel<2, 4, 2> : small_fwd_kernel<2, 1, 2>)
-              : mode == 1 ? (xq == 4 ? small_fwd_kernel<2, 4, 1> : small_fwd_kernel<2, 1, 1>)
-                          : (xq == 4 ? small_fwd_kernel<2, 4, 0> : small_fwd_kernel<2, 1, 0>);
+    auto kern = mode == 3 ? (xq == 4 ? small_fwd_kernel<2, 2, 4, 3> : small_fwd_kernel<2, 2, 1, 3>)
+              : mode == 2 ? (xq == 4 ? small_fwd_kernel<2, 2, 4, 2> : small_fwd_kernel<2, 2, 1, 2>)
+              : mode == 1 ? (xq == 4 ? small_fwd_kernel<2, 2, 4, 1> : small_fwd_kernel<2, 2, 1, 1>)
+                          : (xq == 4 ? small_fwd_kernel<2, 2, 4, 0> : small_fwd_kernel<2, 2, 1, 0>);
     const hipError_t e = allow_lds_once(kern, lds, g_granted[0][xq == 4][mode]);
     if (e != hipSuccess) return stc::hip_status(e, "stc_cell_small_fwd_f32 LDS attribute");
     hipLaunchKernelGGL(kern, dim3((unsigned)batch, (unsigned)splits), dim3(SF_THREADS), lds, static_cast<hipStream_t>(stream), a);
@@ -1048,9 +1139,10 @@ extern "C" int stc_cell_small_fwd_f32(const int32_t* rowptr, const int32_t* coli
 }
 
 extern "C" int stc_cell_small_bwd_f32(const int32_t* rowptr, const int32_t* colidx, const float* val, int32_t n_nodes, int32_t nnz,
-                                      int32_t graph_is_dense, const float* X,
-                                      int32_t cin, const float* H, const float* Tc, int32_t Kc, const float* Wg, const float* Wc, const float* U,
-                                      const float* R, const float* Cand, const float* RH, const float* Zg, const float* Zc, const float* dHnew,
+                                      int32_t graph_is_dense, const int32_t* rowptr2, const int32_t* colidx2, const float* val2, int32_t nnz2,
+                                      const float* X, int32_t cin, const float* H, const float* Tc, int32_t Ks, int32_t Kc, const float* Wg,
+                                      const float* Wc, const float* U, const float* R, const float* Cand, const float* RH, const float* Zg,
+                                      const float* Zc, const float* Zg2, const float* Zc2, const float* dHnew,
                                       float* dX, int32_t accumulate_x, float* dH, int32_t accumulate_h, float* dparams, int64_t params_ld,
                                       int32_t has_bg, int32_t has_bc, float* dZ1c, float* dZ1g, float* dYg, float* dYc, void* workspace,
                                       size_t workspace_bytes, int32_t phase, int32_t splits, int32_t batch, int32_t C, void* stream) {
@@ -1058,9 +1150,9 @@ extern "C" int stc_cell_small_bwd_f32(const int32_t* rowptr, const int32_t* coli
     STC_REQUIRE(rowptr && (nnz == 0 || (colidx && val)) && X && H && Tc && Wg && Wc && U && R && Cand && RH && Zg && Zc && dHnew && dparams && workspace,
                 STC_EINVAL, "stc_cell_small_bwd_f32: null operand");
     const int xq = xq_of(cin), L = cin + SC_H, LP = 16 + 4 * xq;
-    const long long P = (long long)SC_KS * Kc * L * 48 + 48;
+    const long long P = (long long)Ks * Kc * L * 48 + 48;
     STC_REQUIRE(params_ld >= P, STC_EINVAL, "stc_cell_small_bwd_f32: params_ld %lld < %lld floats per row", (long long)params_ld, P);
-    STC_REQUIRE(workspace_bytes >= stc_cell_small_workspace_bytes(n_nodes, C, cin, batch), STC_EINVAL, "stc_cell_small_bwd_f32: workspace too small");
+    STC_REQUIRE(workspace_bytes >= stc_cell_small_workspace_bytes(n_nodes, C, cin, batch, Ks), STC_EINVAL, "stc_cell_small_bwd_f32: workspace too small");
     STC_REQUIRE(stc::aligned16(H) && stc::aligned16(U) && stc::aligned16(R) && stc::aligned16(Cand) && stc::aligned16(RH) && stc::aligned16(Zg) &&
                     stc::aligned16(Zc) && stc::aligned16(dHnew) && stc::aligned16(workspace) && (dH == nullptr || stc::aligned16(dH)) &&
                     stc::aligned16(dYg),
@@ -1069,19 +1161,31 @@ extern "C" int stc_cell_small_bwd_f32(const int32_t* rowptr, const int32_t* coli
                 "stc_cell_small_bwd_f32: dHnew, dX and dH must be distinct buffers");
     const int npt = 16 / C, rpt = npt * C;
     SmallBwd a{{rowptr, colidx, val, nnz}, X, H, Tc, Wg, Wc, U, R, Cand, RH, Zg, Zc, dHnew, dX, dH, dparams, static_cast<float*>(workspace),
-               dZ1c, dZ1g, dYg, dYc, n_nodes, C, cin, rpt, (n_nodes + npt - 1) / npt, accumulate_x, accumulate_h, has_bg, has_bc, phase, params_ld};
+               dZ1c, dZ1g, dYg, dYc, n_nodes, C, cin, rpt, (n_nodes + npt - 1) / npt, accumulate_x, accumulate_h, has_bg, has_bc, phase, params_ld,
+               {rowptr2, colidx2, val2, nnz2}, Zg2, Zc2};
     STC_REQUIRE(((phase >= 0 && phase <= 4) || phase == 7) && splits >= 1 && splits <= 64 && (phase != 0 || splits == 1), STC_EINVAL,
                 "stc_cell_small_bwd_f32: phase %d / splits %d (0 = the whole cell; 1..4 = one phase; 7 = 2 + 3)", phase, splits);
-    const size_t fixed = (size_t)bwd_lds_fixed<2>() * 4, planes = (size_t)n_nodes * C * LP * 4;
+    if (Ks == 3) {                                           // order 3: global-memory form only (MODE 0), twelve waves
+        STC_REQUIRE(Zg2 && Zc2 && stc::aligned16(Zg2) && stc::aligned16(Zc2) && !dZ1c && !dZ1g && !dYc, STC_EINVAL,
+                    "stc_cell_small_bwd_f32: order 3 wants the planes Zg2, Zc2 (16-byte aligned) and leaves no learned-graph operands");
+        auto kern3 = xq == 4 ? small_bwd_kernel<3, 3, 4, 0> : small_bwd_kernel<3, 3, 1, 0>;
+        const size_t lds3 = (size_t)bwd_lds_fixed<3, 3>() * 4;
+        const hipError_t e3 = allow_lds_once(kern3, lds3, g_granted3[xq == 4]);
+        if (e3 != hipSuccess) return stc::hip_status(e3, "stc_cell_small_bwd_f32 LDS attribute");
+        hipLaunchKernelGGL(kern3, dim3((unsigned)batch, (unsigned)splits), dim3(WgShape<3>::BWD_THREADS), lds3, static_cast<hipStream_t>(stream), a);
+        STC_LAUNCH_CHECK("stc_cell_small_bwd_f32 (order 3) launch");
+        return STC_OK;
+    }
+    const size_t fixed = (size_t)bwd_lds_fixed<2, 2>() * 4, planes = (size_t)n_nodes * C * LP * 4;
     const bool full = graph_is_dense && nnz == (long long)n_nodes * n_nodes;
     const bool dense = phase == 0 && full && fixed + planes <= SC_LDS_BUDGET;
     const size_t staged = fixed + planes + (dense ? 0 : graph_lds_bytes(n_nodes, nnz));
     const int mode = dense ? 2 : (phase != 0 && full ? 3 : (phase == 0 && staged <= SC_LDS_BUDGET ? 1 : 0));
     const size_t lds = mode == 1 || mode == 2 ? staged : fixed;
-    auto kern = mode == 3 ? (xq == 4 ? small_bwd_kernel<2, 4, 3> : small_bwd_kernel<2, 1, 3>)
-              : mode == 2 ? (xq == 4 ? small_bwd_kernel<2, 4, 2> : small_bwd_kernel<2, 1, 2>)
-              : mode == 1 ? (xq == 4 ? small_bwd_kernel<2, 4, 1> : small_bwd_kernel<2, 1, 1>)
-                          : (xq == 4 ? small_bwd_kernel<2, 4, 0> : small_bwd_kernel<2, 1, 0>);
+    auto kern = mode == 3 ? (xq == 4 ? small_bwd_kernel<2, 2, 4, 3> : small_bwd_kernel<2, 2, 1, 3>)
+              : mode == 2 ? (xq == 4 ? small_bwd_kernel<2, 2, 4, 2> : small_bwd_kernel<2, 2, 1, 2>)
+              : mode == 1 ? (xq == 4 ? small_bwd_kernel<2, 2, 4, 1> : small_bwd_kernel<2, 2, 1, 1>)
+                          : (xq == 4 ? small_bwd_kernel<2, 2, 4, 0> : small_bwd_kernel<2, 2, 1, 0>);
     const hipError_t e = allow_lds_once(kern, lds, g_granted[1][xq == 4][mode]);
     if (e != hipSuccess) return stc::hip_status(e, "stc_cell_small_bwd_f32 LDS attribute");
     hipLaunchKernelGGL(kern, dim3((unsigned)batch, (unsigned)splits), dim3(SB_THREADS), lds, static_cast<hipStream_t>(stream), a);

@@ -21,7 +21,7 @@ from .graph import is_full_pattern
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG_ROOT, 'libstc_hip.so')
-ABI_VERSION = 31
+ABI_VERSION = 32
 FMT_BF16X3, FMT_F16X2 = 0, 1          # STC_FMT_* of include/stc_hip.h: operand formats of the split-operand matrix-core kernels
 MAX_K = 4
 SPMM_SUM_MAX_ADD = 8     # = STC_SPMM_SUM_MAX_ADD of include/stc_hip.h
@@ -73,7 +73,7 @@ def _declare(lib):
         'stc_csr_spmm_bf16': [_p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _f32, _p],
         'stc_bcsr_spmm_bf16': [_p, _p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _f32, _p],
         'stc_dense_agg_f32': [_p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _f32, _p],
-        'stc_cell_small_fwd_f32': [_p, _p, _p, _i32, _i32, _i32, _p, _i32, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p],
+        'stc_cell_small_fwd_f32': [_p, _p, _p, _i32, _i32, _i32, _p, _p, _p, _i32, _p, _i32, _p, _p, _i32, _i32] + [_p] * 16 + [_i32, _i32, _i32, _i32, _p],
         'stc_graph_grad_f32': [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _p],
         'stc_mix_grad_f32': [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _p],
         'stc_mixed_fusion_workspace_bytes': [_i32, _i32],
@@ -84,7 +84,7 @@ def _declare(lib):
         'stc_mgp_softmax_fwd_f32': [_p, _p, _i32, _p],
         'stc_mgp_softmax_bwd_f32': [_p, _p, _p, _p, _p, _i32, _p],
         'stc_adam_f32': [_p] * 4 + [_i64, _p] + [C.c_double] * 5 + [_p],
-        'stc_cell_small_bwd_f32': [_p, _p, _p, _i32, _i32, _i32, _p, _i32, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _i32, _p, _i64, _i32, _i32,
+        'stc_cell_small_bwd_f32': [_p, _p, _p, _i32, _i32, _i32, _p, _p, _p, _i32, _p, _i32, _p, _p, _i32, _i32] + [_p] * 12 + [_i32, _p, _i32, _p, _i64, _i32, _i32,
                                    _p, _p, _p, _p, _p, C.c_size_t, _i32, _i32, _i32, _i32, _p],
         'stc_csr_sddmm_f32': [_p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _i32, _p],
         'stc_cheby_dense_fwd_f32': [_p, _i32, _i32, _p, _p],
@@ -164,7 +164,7 @@ def _declare(lib):
     lib.stc_cell_small_param_rows.restype = C.c_int
     lib.stc_cell_small_param_rows.argtypes = []
     lib.stc_cell_small_workspace_bytes.restype = C.c_size_t
-    lib.stc_cell_small_workspace_bytes.argtypes = [_i32, _i32, _i32, _i32]
+    lib.stc_cell_small_workspace_bytes.argtypes = [_i32, _i32, _i32, _i32, _i32]
     lib.stc_set_dispatch_level.restype = C.c_int
     lib.stc_set_dispatch_level.argtypes = [_i32]
     lib.stc_head_bwd_workspace_bytes.restype = C.c_size_t
@@ -973,16 +973,16 @@ class HipKernels:
             raise StcError(f'{what}: X {tuple(X.shape)} / H {tuple(H.shape)} must be (B, N, C, cin) / (B, N, C, 16)')
         B, N, Cc, h = H.shape
         cin = X.shape[-1]
-        Kc = Tc.shape[0]
-        if not self.cell_small_supported(2, Kc, Cc, cin, h, N):
-            raise StcError(f'{what}: shape outside the small-graph cell kernels (Ks = Kc = 2, hidden 16, C <= 16, cin = 16 or 1..4, '
+        Kc = Ks = Tc.shape[0]                                     # (the reference's layers take one order for both graphs: Main.py:24)
+        if not self.cell_small_supported(Ks, Kc, Cc, cin, h, N):
+            raise StcError(f'{what}: shape outside the small-graph cell kernels (Ks = Kc = 2 or 3, hidden 16, C <= 16, cin = 16 or 1..4, '
                            f'N*C <= {self.SMALL_MAX_ROWS}): Kc={Kc} C={Cc} cin={cin} h={h} N={N}')
         self._f32(what + '.X', X)
         self._f32(what + '.H', H)
         self._f32(what + '.Tc', Tc, (Kc, Cc, Cc))
         L = cin + h
-        self._f32(what + '.Wg', Wg, (2 * Kc * L, 2 * h))
-        self._f32(what + '.Wc', Wc, (2 * Kc * L, h))
+        self._f32(what + '.Wg', Wg, (Ks * Kc * L, 2 * h))
+        self._f32(what + '.Wc', Wc, (Ks * Kc * L, h))
         self._i32(what + '.rowptr', rowptr, N + 1)
         self._i32(what + '.colidx', colidx, val.numel())
         self._f32(what + '.val', val)
@@ -993,9 +993,25 @@ class HipKernels:
         self._same_device(H, X, Tc, Wg, Wc, rowptr, colidx, val, Zg, Zc, *planes.values())
         return B, N, Cc, cin, Kc
 
+    def _small_order3(self, what, Tc, graph2, planes2, like_g, like_c, dense, N):
+        """Arguments of the order-3 form: the second graph's CSR (T_2(S) in the launch's orientation) and the third-slab planes; order 2: nulls."""
+        if Tc.shape[0] != 3:
+            return (None, None, None, 0), (None, None)
+        if graph2 is None or planes2 is None or any(t is None for t in planes2) or dense:
+            raise StcError(f'{what}: Chebyshev order 3 takes graph2 = the CSR of T_2(S) = 2 S^2 - I (CsrGraph.second_order), the planes Zg2 / Zc2, and a fixed CSR graph')
+        rp2, ci2, v2 = graph2
+        self._i32(what + '.rowptr2', rp2, N + 1)
+        self._i32(what + '.colidx2', ci2, v2.numel())
+        self._f32(what + '.val2', v2)
+        self._f32(what + '.Zg2', planes2[0], tuple(like_g.shape))
+        self._f32(what + '.Zc2', planes2[1], tuple(like_c.shape))
+        self._same_device(like_g, rp2, ci2, v2, *planes2)
+        return (rp2.data_ptr(), ci2.data_ptr(), v2.data_ptr(), v2.numel()), (planes2[0].data_ptr(), planes2[1].data_ptr())
+
     def cell_small_fwd(self, rowptr, colidx, val, X, H, Tc, Wg, bg, Wc, bc, U, R, Cand, Hnew, RH, Zg, Zc, checked=True, Z0=None, splits=1, Z0c=None,
-                       Z1c=None):
+                       Z1c=None, graph2=None, Zg2=None, Zc2=None):
         """One STC_Cell step (reference STC_GNN.py:65-79) in one launch: ``stc_cell_small_fwd_f32``.  (rowptr, colidx, val): CSR of Gs^T.
+        Chebyshev order 3 (``Tc`` of three matrices): ``graph2`` = (rowptr, colidx, val) of 2 (Gs^T)^2 - I and the planes ``Zg2`` (like Zg), ``Zc2`` (like Zc).
         ``checked=False``: the caller built every buffer itself from shapes it already validated (the cell-graph executor).
         ``Z0`` (optional, like Zg): receives the slab [H | Xt | 0] (learned graphs: operand of the graph-gradient product).
         ``splits`` = G > 1: the cell as TWO launches (phases 1 + 2, then 3 + 4: R*H of the neighbours is the one dependency that crosses
@@ -1013,10 +1029,11 @@ class HipKernels:
         else:
             (B, N, Cc, _), cin, Kc = H.shape, X.shape[-1], Tc.shape[0]
         dense = int(is_full_pattern(colidx, N, N))
+        g2, p2 = self._small_order3('cell_small_fwd', Tc, graph2, (Zg2, Zc2), Zg, Zc, dense, N)
         for phase in ((0,) if splits == 1 else self.SMALL_FWD_PHASES):
-            self._launch('stc_cell_small_fwd_f32', H, rowptr.data_ptr(), colidx.data_ptr(), val.data_ptr(), N, val.numel(), dense, X.data_ptr(), cin,
-                         H.data_ptr(), Tc.data_ptr(), Kc, Wg.data_ptr(), _ptr(bg), Wc.data_ptr(), _ptr(bc), U.data_ptr(), R.data_ptr(), Cand.data_ptr(),
-                         Hnew.data_ptr(), RH.data_ptr(), Zg.data_ptr(), Zc.data_ptr(), _ptr(Z0), _ptr(Z0c), _ptr(Z1c), phase, splits, B, Cc,
+            self._launch('stc_cell_small_fwd_f32', H, rowptr.data_ptr(), colidx.data_ptr(), val.data_ptr(), N, val.numel(), dense, *g2, X.data_ptr(), cin,
+                         H.data_ptr(), Tc.data_ptr(), Kc, Kc, Wg.data_ptr(), _ptr(bg), Wc.data_ptr(), _ptr(bc), U.data_ptr(), R.data_ptr(), Cand.data_ptr(),
+                         Hnew.data_ptr(), RH.data_ptr(), Zg.data_ptr(), Zc.data_ptr(), *p2, _ptr(Z0), _ptr(Z0c), _ptr(Z1c), phase, splits, B, Cc,
                          nbytes=(4 * B * N * Cc * (cin + 16 * 8 + 2 * self.cell_small_zg_width(cin))) // (1 if splits == 1 else len(self.SMALL_FWD_PHASES)))
 
     # Launches of a split cell step (phase codes of stc_cell_small_*_f32; 5 = 1 + 2, 6 = 3 + 4, 7 = 2 + 3), CSR and dense graphs alike
@@ -1027,14 +1044,18 @@ class HipKernels:
     def cell_small_splits(batch: int, rows: int = 0) -> int:
         """Workgroups per sample for a batch: 1 = one launch per cell step (a workgroup per sample); G > 1 = a few launches per step over
         G workgroups per sample, so that ~256 workgroups are in flight (rows: N * C of a sample -- a split wants at least a few tiles)."""
+        forced = os.environ.get('STC_SMALL_SPLITS')                  # (probe: tools/gpu_ab.sh)
+        if forced:
+            return int(forced)
         g = max(1, min(8, 256 // max(1, batch)))
         while g > 1 and rows and rows < 48 * g:
             g //= 2
         return g
 
     def cell_small_bwd(self, rowptr, colidx, val, X, H, Tc, Wg, Wc, U, R, Cand, RH, Zg, Zc, dHnew, dX, accumulate_x, dH, accumulate_h,
-                       dparams, has_bg, has_bc, checked=True, dZ1c=None, dZ1g=None, dYg=None, splits=1, dYc=None):
-        """Autograd of ``cell_small_fwd`` in one launch (``stc_cell_small_bwd_f32``).  (rowptr, colidx, val): CSR of Gs.  dX / dH may be
+                       dparams, has_bg, has_bc, checked=True, dZ1c=None, dZ1g=None, dYg=None, splits=1, dYc=None, graph2=None, Zg2=None, Zc2=None):
+        """Autograd of ``cell_small_fwd`` in one launch (``stc_cell_small_bwd_f32``).  (rowptr, colidx, val): CSR of Gs (order 3: ``graph2`` =
+        the CSR of 2 Gs^2 - I, ``Zg2`` / ``Zc2`` as the forward left them).  dX / dH may be
         None; ``accumulate_*``: add to what the buffer holds.  ``dparams`` (B * cell_small_param_rows, P >= cell_small_params):
         parameter-gradient partials (one row per sample and wave), ADDED to."""
         if checked:
@@ -1043,23 +1064,24 @@ class HipKernels:
             if dX is not None:
                 self._f32('cell_small_bwd.dX', dX, tuple(X.shape))
             self._f32('cell_small_bwd.dparams', dparams)
-            if dparams.dim() != 2 or dparams.shape[0] != B * splits * self.cell_small_param_rows or dparams.shape[1] < self.cell_small_params(2, Kc, cin):
+            if dparams.dim() != 2 or dparams.shape[0] != B * splits * self.cell_small_param_rows or dparams.shape[1] < self.cell_small_params(Kc, Kc, cin):
                 raise StcError(f'cell_small_bwd: dparams {tuple(dparams.shape)}, expected ({B * splits * self.cell_small_param_rows}, '
-                               f'>= {self.cell_small_params(2, Kc, cin)})')
+                               f'>= {self.cell_small_params(Kc, Kc, cin)})')
             for name, t_, shape in (('dZ1c', dZ1c, tuple(Zg.shape)), ('dZ1g', dZ1g, tuple(Zg.shape)), ('dYg', dYg, (B, N * Cc, 32)), ('dYc', dYc, (B, N * Cc, 16))):
                 if t_ is not None:
                     self._f32('cell_small_bwd.' + name, t_, shape)
             self._same_device(H, dHnew, dparams, dZ1c, dZ1g, dYg, *([dX] if dX is not None else []))
         else:
             (B, N, Cc, _), cin, Kc = H.shape, X.shape[-1], Tc.shape[0]
-        nbytes = self.lib.stc_cell_small_workspace_bytes(N, Cc, cin, B)
+        nbytes = self.lib.stc_cell_small_workspace_bytes(N, Cc, cin, B, Kc)
         ws = self._get_workspace(H.device, nbytes)
         dense = int(is_full_pattern(colidx, N, N))
+        g2, p2 = self._small_order3('cell_small_bwd', Tc, graph2, (Zg2, Zc2), Zg, Zc, dense, N)
         phases = (0,) if splits == 1 else self.SMALL_BWD_PHASES
         for phase in phases:
-            self._launch('stc_cell_small_bwd_f32', H, rowptr.data_ptr(), colidx.data_ptr(), val.data_ptr(), N, val.numel(), dense, X.data_ptr(), cin,
-                         H.data_ptr(), Tc.data_ptr(), Kc, Wg.data_ptr(), Wc.data_ptr(), U.data_ptr(), R.data_ptr(), Cand.data_ptr(), RH.data_ptr(),
-                         Zg.data_ptr(), Zc.data_ptr(), dHnew.data_ptr(), _ptr(dX), int(bool(accumulate_x)), _ptr(dH), int(bool(accumulate_h)),
+            self._launch('stc_cell_small_bwd_f32', H, rowptr.data_ptr(), colidx.data_ptr(), val.data_ptr(), N, val.numel(), dense, *g2, X.data_ptr(), cin,
+                         H.data_ptr(), Tc.data_ptr(), Kc, Kc, Wg.data_ptr(), Wc.data_ptr(), U.data_ptr(), R.data_ptr(), Cand.data_ptr(), RH.data_ptr(),
+                         Zg.data_ptr(), Zc.data_ptr(), *p2, dHnew.data_ptr(), _ptr(dX), int(bool(accumulate_x)), _ptr(dH), int(bool(accumulate_h)),
                          dparams.data_ptr(), dparams.shape[1], int(bool(has_bg)), int(bool(has_bc)), _ptr(dZ1c), _ptr(dZ1g), _ptr(dYg), _ptr(dYc),
                          ws.data_ptr(), ws.numel(), phase, splits, B, Cc,
                          nbytes=(4 * B * N * Cc * (2 * cin + 16 * 9 + 5 * self.cell_small_zg_width(cin) + 64)) // len(phases))

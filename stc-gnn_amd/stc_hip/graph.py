@@ -244,6 +244,34 @@ def _patch_tables(rpl, cil, val, n, patches, max_deg):
                 fetch=n_src / n, rows_per_patch=n / n_p, groups=[rows for rows, _ in patches])
 
 
+def _cheb2_csr(rowptr: np.ndarray, colidx: np.ndarray, val: np.ndarray, n: int):
+    """CSR (int32 rowptr / colidx, float32 values, columns ascending) of T_2(A) = 2 A^2 - I for a square CSR matrix A: the second Chebyshev
+    matrix as the reference's ``cheby_poly`` forms it on the matrix side (STC_GNN.py:24-29), products and sums in float64, rounded once.
+    For the small-graph cell kernels at order 3 (N * C < 65 536 rows: A^2 of an 8-neighbour grid has 25 entries per row)."""
+    rp = rowptr.astype(np.int64)
+    ci = colidx.astype(np.int64)
+    v = val.astype(np.float64)
+    deg = np.diff(rp)
+    rows = np.repeat(np.arange(n, dtype=np.int64), deg)                 # row i of every entry (i, k)
+    cnt = deg[ci]                                                       # entries of row k, per entry (i, k)
+    total = int(cnt.sum())
+    pi = np.repeat(rows, cnt)
+    first = np.repeat(rp[ci], cnt)
+    within = np.arange(total, dtype=np.int64) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+    e2 = first + within                                                 # the entry (k, j) each product pairs with
+    key = np.concatenate([pi * n + ci[e2], np.arange(n, dtype=np.int64) * (n + 1)])
+    w = np.concatenate([2.0 * np.repeat(v, cnt) * v[e2], -np.ones(n)])
+    uniq, inv = np.unique(key, return_inverse=True)
+    vals = np.bincount(inv, weights=w, minlength=uniq.size)
+    out_rows = uniq // n
+    rp2 = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(rp2, out_rows + 1, 1)
+    rp2 = np.cumsum(rp2)
+    if uniq.size > INT32_MAX:
+        raise ValueError('T_2 of the graph does not fit int32 CSR indices')
+    return rp2.astype(np.int32), (uniq - out_rows * n).astype(np.int32), vals.astype(np.float32)
+
+
 RING2_INTERIOR, RING2_FIRST, RING2_SECOND, RING2_WIDTH = 32, 64, 96, 8       # = STC_RING2_* of include/stc_hip.h
 
 
@@ -556,6 +584,24 @@ class CsrGraph:
             self._dev[device] = d
         return d
 
+    def second_order(self, device: torch.device) -> Dict[str, torch.Tensor]:
+        """CSR of the second Chebyshev matrix T_2 = 2 S^2 - I in both orientations, on ``device`` (cached): ``fwd2_*`` = 2 (Gs^T)^2 - I for the
+        forward's aggregation, ``bwd2_*`` = 2 Gs^2 - I for its transpose -- what the small-graph cell kernels take as their second graph at
+        Chebyshev order 3 (the reference forms T_2 on the matrix side as well: STC_GNN.py:24-29)."""
+        device = torch.device(device)
+        if device.type == 'cuda' and device.index is None:
+            device = torch.device('cuda', torch.cuda.current_device())
+        cache = self.__dict__.setdefault('_dev2', {})
+        d = cache.get(device)
+        if d is None:
+            h, d = self._host, {}
+            for side in ('fwd', 'bwd'):
+                rp, ci, v = _cheb2_csr(h[f'{side}_rowptr'], h[f'{side}_colidx'], h[f'{side}_val'], self.n)
+                d.update({f'{side}2_rowptr': torch.from_numpy(rp).to(device), f'{side}2_colidx': torch.from_numpy(ci).to(device),
+                          f'{side}2_val': torch.from_numpy(v).to(device)})
+            cache[device] = d
+        return d
+
     def to_dense(self) -> torch.Tensor:
         h = self._host
         G = torch.zeros(self.n, self.n)
@@ -587,6 +633,7 @@ class SpatialOperand:
     fwd_ring2: Optional[tuple] = None    # ... of stc_ring2_blend_f32 for Gs^T
     ring2_clusters: bool = False         # those plans are over ring-bounded clusters (1 708 ragged patches for the bench's grid under a random order
                                          # against 1 568 tiles: every launch +17 %), where only the forms that replace two gathering launches pay
+    source: Optional['CsrGraph'] = None  # the fixed graph this operand came from (its second Chebyshev matrix: CsrGraph.second_order)
 
 
 _PATTERN_CACHE: Dict[Tuple[int, torch.device], Tuple[torch.Tensor, torch.Tensor]] = {}
@@ -642,4 +689,4 @@ def csr_operand(graph: CsrGraph, device: torch.device) -> SpatialOperand:
     return SpatialOperand(graph.n, d['fwd_rowptr'], d['fwd_colidx'], d['fwd_val'],
                           d['bwd_rowptr'], d['bwd_colidx'], d['bwd_val'], graph.nnz, plan('fwd'), plan('bwd'), graph.row_sum_bound,
                           *[tuple(d[f'{sd}_r2_{k}'] for k in ('l2', 'l1', 'own', 't1', 't2')) if f'{sd}_r2_l2' in d else None for sd in ('bwd', 'fwd')],
-                          graph.ring2_clusters)
+                          graph.ring2_clusters, graph)

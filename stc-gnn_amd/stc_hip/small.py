@@ -37,6 +37,8 @@ def small_graph_supported(k, op: SpatialOperand, Tc, Ks: int, C: int, h: int, x_
     ``graph.dense_operand`` builds it) -- its gradient is formed as a dense product."""
     if dtype != torch.float32 or not hasattr(k, 'cell_small_supported') or (op.fwd_val.requires_grad and op.nnz != op.n * op.n):
         return False
+    if Ks == 3 and (op.source is None or op.fwd_val.requires_grad or op.nnz == op.n * op.n):
+        return False                                                # order 3: T_2(S) as a second CSR graph -- fixed sparse graphs only
     if op.nnz == op.n * op.n and op.n * C > k.SMALL_STAGED_ROWS:
         return False                                                # a dense graph aggregates as a matrix product on the STAGED plane: the sample must fit the LDS
     if op.n * C > k.SMALL_PREFERRED_ROWS or (C == 16 and op.n * C > 4096):
@@ -94,14 +96,18 @@ class _StcSmallGraph(Function):
         out_slot, inner_slot, pos, counts = _layout(schedule, cin, n_cells, outputs)
         out_stack = ref.new_empty(len(outputs), B, N, C, H16)        # the requested states are produced in place, stacked
         inner = ref.new_empty(max(1, n_cells - len(outputs)), B, N, C, H16)
-        planes = ref.new_empty(5, n_cells, B, N, C, H16)             # U, R, Cand, R*H, S.(R*H) of every cell
+        planes = ref.new_empty(6 if Ks == 3 else 5, n_cells, B, N, C, H16)   # U, R, Cand, R*H, S.(R*H) of every cell (order 3: + T_2(S).(R*H))
         learned = bool(ctx.needs_input_grad[6] or ctx.needs_input_grad[7])
         # per width group: the aggregate Zg of every cell and, for learned graphs, the slabs Z0, Z0c, Z1c the graph-gradient products read
         widths = (k.cell_small_zg_width(1), k.cell_small_zg_width(H16))
-        slabs = [ref.new_empty(4 if learned else 1, max(1, counts[w]), B, N * C, widths[w]) for w in (0, 1)]
+        if Ks == 3 and learned:
+            raise ValueError('stc_cell_graph: the small-graph cell kernels take learned graphs at Chebyshev order 2 only')
+        # (order 3: slot 1 holds the third slab T_2(S).[H | Xt | 0]; learned graphs -- order 2 only -- keep Z0, Z0c, Z1c in slots 1..3)
+        slabs = [ref.new_empty(4 if learned else (2 if Ks == 3 else 1), max(1, counts[w]), B, N * C, widths[w]) for w in (0, 1)]
+        g2 = op.source.second_order(ref.device) if Ks == 3 else None
         out_alias = _alias(out_stack)
         state = [out_alias[out_slot[j]] if j in out_slot else inner[inner_slot[j]] for j in range(n_cells)]
-        U, R, Cand, RH, Zc = (p.unbind(0) for p in planes.unbind(0))
+        U, R, Cand, RH, Zc, *Zc2 = (p.unbind(0) for p in planes.unbind(0))
         source = lambda src: ext[src[1]] if src[0] == 'ext' else state[src[1]]
         # Few samples: a cell step runs as a few launches over several workgroups per sample (each owning a contiguous range of row tiles)
         # instead of one launch with one workgroup per sample -- at the SF shape (batch 32) backward 79 -> ~45 us per cell in three
@@ -113,6 +119,8 @@ class _StcSmallGraph(Function):
             Wg, bg, Wc, bc = stacks[s_id]
             w, i = pos[j]
             extra = dict(Z0=slabs[w][1, i], Z0c=slabs[w][2, i], Z1c=slabs[w][3, i]) if learned else {}
+            if Ks == 3:
+                extra = dict(graph2=(g2['fwd2_rowptr'], g2['fwd2_colidx'], g2['fwd2_val']), Zg2=slabs[w][1, i], Zc2=Zc2[0][j].view(B, N * C, H16))
             k.cell_small_fwd(op.fwd_rowptr, op.fwd_colidx, fwd_val, source(x), source(hs), Tc, Wg, bg, Wc, bc, U[j], R[j], Cand[j], state[j], RH[j],
                              slabs[w][0, i], Zc[j].view(B, N * C, H16), checked=False, splits=fwd_splits, **extra)
         ctx.save_for_backward(Tc, out_alias, inner, planes, slabs[0], slabs[1], *ext, *[p for st in stacks for p in st if p is not None])
@@ -147,9 +155,10 @@ class _StcSmallGraph(Function):
         dslab = [Tc.new_zeros(2, max(1, counts[w]), B, N * C, slabs[w].shape[-1]) for w in (0, 1)] if learned else None
         dyg = [Tc.new_zeros(max(1, counts[w]), B, N * C, 2 * H16) for w in (0, 1)] if learned else None
         dyc = [Tc.new_zeros(max(1, counts[w]), B, N * C, H16) for w in (0, 1)] if learned else None
-        U, R, Cand, RH, Zc = (p.unbind(0) for p in planes.unbind(0))
+        U, R, Cand, RH, Zc, *Zc2 = (p.unbind(0) for p in planes.unbind(0))
         source = lambda src: ext[src[1]] if src[0] == 'ext' else state[src[1]]
         Kc = Tc.shape[0]
+        g2 = op.source.second_order(Tc.device) if Ks == 3 else None
         P = max(k.cell_small_params(Ks, Kc, w) for w in cin)
         dP = Tc.new_zeros(len(stacks), B * splits * k.cell_small_param_rows, P)   # parameter-gradient partials, every cell adds to its set's rows
         G = Tc.new_empty(n_cells, B, N, C, H16)                      # gradient owed to every cell's state
@@ -178,6 +187,8 @@ class _StcSmallGraph(Function):
                     owed[x[1]] = True
             w, i = pos[j]
             extra = dict(dZ1c=dslab[w][0, i], dZ1g=dslab[w][1, i], dYg=dyg[w][i], dYc=dyc[w][i]) if learned else {}
+            if Ks == 3:
+                extra = dict(graph2=(g2['bwd2_rowptr'], g2['bwd2_colidx'], g2['bwd2_val']), Zg2=slabs[w][1, i], Zc2=Zc2[0][j].view(B, N * C, H16))
             k.cell_small_bwd(op.bwd_rowptr, op.bwd_colidx, op.bwd_val, source(x), source(hs), Tc, Wg, Wc, U[j], R[j], Cand[j], RH[j], slabs[w][0, i],
                              Zc[j].view(B, N * C, H16), Gv[j], dX, acc_x, dH, acc_h, dPv[s_id], bg is not None, bc is not None, checked=False,
                              splits=splits, **extra)

@@ -25,6 +25,7 @@ stored, only numbers.  Sets follow SURVEY.md section 8(c4):
                     2 layers, 6x8 non-symmetric grid graph, B=2, T=3+2 -> yhat, ComboLoss, every gradient
   g12_bench_c64     the same at C=64;  g13_bench_c32_k3  the same at C=32, K=3 (configuration 4's order)
   g14_sf_shape      the same at the SF-incidents shape: N=100 (10 x 10), C=5, T=9+3, K=2, h=16 (the small-graph cell kernels' shape)
+  g15_sf_shape_k3   the same at K=3 (the small-graph cell kernels' order-3 form: T_2(S) as a second graph)
   g8b_large_n10000_grads   g8 with backward: sampled rows of Ht, dXt, dHt + the full parameter gradients
   g8c_large_n10000_k3      the same cell at Chebyshev order K = 3 (BASELINE configuration 4) through the dense reference, with backward
 
@@ -341,7 +342,8 @@ def main():
 
 
 SF_SHAPE = dict(H=10, W=10, horizon=3, B=3, T=9)          # g14: the SF-incidents shape (N = 100, C = 5, T = 9 + 3), graphs given
-BENCH_PATH_GOLDENS = (('g11_bench_c32', 32, 2, {}), ('g12_bench_c64', 64, 2, {}), ('g13_bench_c32_k3', 32, 3, {}), ('g14_sf_shape', 5, 2, SF_SHAPE))
+BENCH_PATH_GOLDENS = (('g11_bench_c32', 32, 2, {}), ('g12_bench_c64', 64, 2, {}), ('g13_bench_c32_k3', 32, 3, {}), ('g14_sf_shape', 5, 2, SF_SHAPE),
+                      ('g15_sf_shape_k3', 5, 3, SF_SHAPE))      # g15: the SF shape at Chebyshev order 3 (Main.py:24 -cheby_order 3)
 
 
 def bench_path_golden(ref_framework='/root/reference/framework', only=None):

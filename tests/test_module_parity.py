@@ -453,15 +453,15 @@ def graph_dense_T_csr(s, graph):
                                    torch.from_numpy(h['fwd_val']).double(), size=(graph.n, graph.n))
 
 
-@pytest.mark.parametrize('name,C,K', [('g11_bench_c32', 32, 2), ('g12_bench_c64', 64, 2), ('g13_bench_c32_k3', 32, 3), ('g14_sf_shape', 5, 2)])
+@pytest.mark.parametrize('name,C,K', [('g11_bench_c32', 32, 2), ('g12_bench_c64', 64, 2), ('g13_bench_c32_k3', 32, 3), ('g14_sf_shape', 5, 2), ('g15_sf_shape_k3', 5, 3)])
 def test_bench_path_against_reference_goldens(monkeypatch, name, C, K):
     """The path bench.py runs -- csr-fixed STCGNN at C in {32, 64}, hidden 16, encoder + decoder as ONE cell-graph node on the
     planar / split-operand matrix-core kernels -- against goldens the REFERENCE generated at exactly these widths
     (STC_GNN.py:185-207 after MGP_Gen, Model_Trainer.py:14-23): prediction, ComboLoss, every parameter gradient, 1e-5.
     g14: the SF-incidents shape (N = 100, C = 5, T = 9 + 3; ``bench.py --preset sf``), which runs on the small-graph cell kernels
-    (one launch per cell step: stc_cell_small_fwd/bwd_f32) -- asserted taken."""
+    (one launch per cell step: stc_cell_small_fwd/bwd_f32) -- asserted taken; g15: the same shape at Chebyshev order 3 (T_2(S) as a second graph)."""
     g = _golden(name)
-    s = bench_path_inputs(C, K, **(SF_SHAPE if name == 'g14_sf_shape' else {}))
+    s = bench_path_inputs(C, K, **(SF_SHAPE if name in ('g14_sf_shape', 'g15_sf_shape_k3') else {}))
     small_calls = []
     real_small = ops.stc_small_graph
     monkeypatch.setattr(ops, 'stc_small_graph', lambda *a, **k: (small_calls.append(1), real_small(*a, **k))[1])
@@ -475,7 +475,7 @@ def test_bench_path_against_reference_goldens(monkeypatch, name, C, K):
     monkeypatch.setattr(ops, 'stc_cell_graph', lambda *a, **k: (calls.append(1), real(*a, **k))[1])
     yhat = model(X_seq=s['X'].to(DEV), As=graph, Ac=s['Gc'].to(DEV))
     assert calls, 'the cell-graph path (the one the bench runs) was not taken'
-    assert bool(small_calls) == (name == 'g14_sf_shape')
+    assert bool(small_calls) == (name in ('g14_sf_shape', 'g15_sf_shape_k3'))
     _close(yhat, g['yhat'], FWD, f'{name} yhat')
     loss = O.combo_loss(yhat, s['Y'].to(DEV))
     assert abs(float(loss.detach()) - float(g['loss'])) < 5e-6
@@ -563,9 +563,7 @@ def test_cell_graph_equals_the_per_cell_path(dev, monkeypatch, layers, T, horizo
     cell: same prediction, same parameter gradients.  Hidden 16; 32 categories on the GPU (matrix-core shapes).  K = 3: the
     order-3 planar cells (three Chebyshev planes per side, Clenshaw state gradients) against the per-cell slab form.
     ``small``: 5 categories -- the small-graph executor (stc_hip/small.py: one launch per cell step, per-sample parameter-gradient
-    partials) against the same per-cell path."""
-    if small and K != 2:
-        pytest.skip('the small-graph cell kernels are built for Chebyshev order 2')
+    partials) against the same per-cell path; at K = 3 with T_2(S) = 2 S^2 - I as a second CSR graph (round 6)."""
     monkeypatch.setattr(ops, '_SMALL', small)
     taken = []
     real_small = ops.stc_small_graph

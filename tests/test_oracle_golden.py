@@ -253,12 +253,12 @@ def test_live_reference_sf_data_adjacency(reference_module):
     assert np.array_equal(A, z['s_adj'])
 
 
-@pytest.mark.parametrize('name,C,K', [('g11_bench_c32', 32, 2), ('g12_bench_c64', 64, 2), ('g13_bench_c32_k3', 32, 3), ('g14_sf_shape', 5, 2)])
+@pytest.mark.parametrize('name,C,K', [('g11_bench_c32', 32, 2), ('g12_bench_c64', 64, 2), ('g13_bench_c32_k3', 32, 3), ('g14_sf_shape', 5, 2), ('g15_sf_shape_k3', 5, 3)])
 def test_g11_g13_bench_path_widths(name, C, K):
     """The widths the bench runs (C = 32 / 64, hidden 16, K = 2 / 3) through the REFERENCE's encoder-decoder-head: the oracle
     (dense form and sparse feature-side form) reproduces prediction, ComboLoss and every parameter gradient."""
     g = load_golden(name)
-    s = bench_path_inputs(C, K, **(SF_SHAPE if name == 'g14_sf_shape' else {}))
+    s = bench_path_inputs(C, K, **(SF_SHAPE if name in ('g14_sf_shape', 'g15_sf_shape_k3') else {}))
     assert abs(float(s['Gs'].double().sum()) - float(g['chk_Gs'])) < 1e-9 and abs(float(s['X'].double().sum()) - float(g['chk_X'])) < 1e-9
     assert abs(float(s['Gc'].double().sum()) - float(g['chk_Gc'])) < 1e-6
     for conv, Gs in ((O.bdg_dif, s['Gs']), (O.bdg_dif_sparse, s['Gs'].t().contiguous().to_sparse_csr())):

@@ -30,21 +30,23 @@ def _graph(N, seed, dense=False):
     return CsrGraph.from_dense(G)
 
 
-def _inputs(B, N, C, cin, seed, dtype=torch.float32, bias=True):
+def _inputs(B, N, C, cin, seed, dtype=torch.float32, bias=True, K=2):
     g = torch.Generator().manual_seed(seed)
     r = lambda *s: torch.randn(*s, generator=g).to(dtype)
     L = cin + 16
     Gc = torch.softmax(torch.randn(C, C, generator=g), -1).to(dtype)
-    Tc = torch.stack([torch.eye(C, dtype=dtype), Gc])
-    return dict(X=r(B, N, C, cin), H=0.5 * r(B, N, C, 16), Gc=Gc, Tc=Tc, Wg=0.3 * r(4 * L, 32), bg=0.1 * r(32) if bias else None,
-                Wc=0.3 * r(4 * L, 16), bc=0.1 * r(16) if bias else None, dHnew=r(B, N, C, 16))
+    Tc = torch.stack([torch.eye(C, dtype=dtype), Gc] + ([2 * Gc @ Gc - torch.eye(C, dtype=dtype)] if K == 3 else []))     # cheby_poly, STC_GNN.py:24-29
+    ws = 0.3 if K == 2 else 0.15                 # (order 3: 9 blocks instead of 4 and |T_2| up to ~2 -- the same pre-activation spread as at order 2)
+    return dict(X=r(B, N, C, cin), H=0.5 * r(B, N, C, 16), Gc=Gc, Tc=Tc, Wg=ws * r(K * K * L, 32), bg=0.1 * r(32) if bias else None,
+                Wc=ws * r(K * K * L, 16), bc=0.1 * r(16) if bias else None, dHnew=r(B, N, C, 16))
 
 
-def _buffers(B, N, C, cin, dtype, k):
+def _buffers(B, N, C, cin, dtype, k, K=2):
     new = lambda *s: torch.full(s, float('nan'), dtype=dtype)
-    P = k.cell_small_params(2, 2, cin) + 5                          # a leading dimension larger than needed
+    P = k.cell_small_params(K, K, cin) + 5                          # a leading dimension larger than needed
+    third = dict(Zg2=new(B, N * C, k.cell_small_zg_width(cin)), Zc2=new(B, N * C, 16)) if K == 3 else {}
     return dict(U=new(B, N, C, 16), R=new(B, N, C, 16), Cand=new(B, N, C, 16), Hnew=new(B, N, C, 16), RH=new(B, N, C, 16),
-                Zg=new(B, N * C, k.cell_small_zg_width(cin)), Zc=new(B, N * C, 16)), P
+                Zg=new(B, N * C, k.cell_small_zg_width(cin)), Zc=new(B, N * C, 16), **third), P
 
 
 def _run(k, op, t, buf, P, to, acc_x=False, acc_h=False, want_x=True, want_h=True, want_dumps=False, splits=1):
@@ -52,8 +54,19 @@ def _run(k, op, t, buf, P, to, acc_x=False, acc_h=False, want_x=True, want_h=Tru
     d = {n: (None if v is None else to(v)) for n, v in t.items()}
     b = {n: to(v) for n, v in buf.items()}
     dumps = {n: to(torch.full_like(buf['Zg'], float('nan'))) for n in ('Z0', 'dZ1c', 'dZ1g')} if want_dumps else {}
+    third_f = third_b = {}
+    if t['Tc'].shape[0] == 3:                    # order 3: T_2(S) = 2 S^2 - I as the second graph, in each launch's orientation
+        g2 = op.source.second_order(b['Zg'].device)
+        third_f = dict(graph2=tuple(g2[f'fwd2_{n}'] for n in ('rowptr', 'colidx', 'val')), Zg2=b['Zg2'], Zc2=b['Zc2'])
+        third_b = dict(third_f, graph2=tuple(g2[f'bwd2_{n}'] for n in ('rowptr', 'colidx', 'val')))
+        if t['H'].dtype == torch.float64:        # (the twin in float64: the second graph's values formed in float64 as well)
+            dense2 = lambda G: 2 * G @ G - torch.eye(G.shape[0], dtype=torch.float64)
+            G = op.source.to_dense().double()
+            vals = lambda M, rp, ci: M[torch.repeat_interleave(torch.arange(M.shape[0]), (rp[1:] - rp[:-1]).long()), ci.long()]
+            third_f['graph2'] = third_f['graph2'][:2] + (vals(dense2(G).t().contiguous(), *third_f['graph2'][:2]),)
+            third_b['graph2'] = third_b['graph2'][:2] + (vals(dense2(G), *third_b['graph2'][:2]),)
     k.cell_small_fwd(op.fwd_rowptr, op.fwd_colidx, to(op.fwd_val), d['X'], d['H'], d['Tc'], d['Wg'], d['bg'], d['Wc'], d['bc'],
-                     b['U'], b['R'], b['Cand'], b['Hnew'], b['RH'], b['Zg'], b['Zc'], Z0=dumps.get('Z0'), splits=splits)
+                     b['U'], b['R'], b['Cand'], b['Hnew'], b['RH'], b['Zg'], b['Zc'], Z0=dumps.get('Z0'), splits=splits, **third_f)
     B = d['H'].shape[0]
     dX = to(torch.full(t['X'].shape, 0.25, dtype=t['X'].dtype)) if want_x else None
     dH = to(torch.full(t['H'].shape, -0.5, dtype=t['H'].dtype)) if want_h else None
@@ -62,14 +75,14 @@ def _run(k, op, t, buf, P, to, acc_x=False, acc_h=False, want_x=True, want_h=Tru
                      b['Zg'], b['Zc'], d['dHnew'], dX, acc_x, dH, acc_h, dP, t['bg'] is not None, t['bc'] is not None,
                      dZ1c=dumps.get('dZ1c'), dZ1g=dumps.get('dZ1g'), dYg=dumps.setdefault('dYg', to(torch.full((B, buf['Zg'].shape[1], 32), float('nan'),
                                                                                                     dtype=t['H'].dtype))) if want_dumps else None,
-                     splits=splits)
+                     splits=splits, **third_b)
     out = dict(b, dX=dX, dH=dH, dP=dP, **dumps)
     return {n: (None if v is None else v.detach().cpu()) for n, v in out.items()}
 
 
-def _split_params(dP, cin):
+def _split_params(dP, cin, K=2):
     L = cin + 16
-    nW = 4 * L
+    nW = K * K * L
     return (dP[:, :nW * 32].sum(0).view(nW, 32), dP[:, nW * 32:nW * 32 + 32].sum(0), dP[:, nW * 32 + 32:nW * 48 + 32].sum(0).view(nW, 16),
             dP[:, nW * 48 + 32:nW * 48 + 48].sum(0), dP[:, nW * 48 + 48:])
 
@@ -95,6 +108,65 @@ def test_small_cell_twin_is_the_reference_cell(B, N, C, cin, bias):
         assert rel_err(dbg, leaves['bg'].grad) < 1e-12 and rel_err(dbc, leaves['bc'].grad) < 1e-12
     else:
         assert float(dbg.abs().max()) == 0.0 and float(dbc.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('B,N,C,cin,bias', [(3, 12, 5, 1, True), (2, 9, 4, 16, True), (2, 7, 3, 3, False)])
+def test_small_cell_twin_at_order_3_is_the_reference_cell(B, N, C, cin, bias):
+    """Chebyshev order 3 (Main.py:24 -cheby_order; cheby_poly STC_GNN.py:24-29): the twin takes T_2(S) = 2 S^2 - I as a SECOND graph, formed on
+    the matrix side as the reference forms it -- against oracle.stc_cell at Ks = Kc = 3 and its autograd, float64."""
+    dt = torch.float64
+    graph = _graph(N, seed=N + cin)
+    op = csr_operand(graph, torch.device('cpu'))
+    t = _inputs(B, N, C, cin, seed=7 * N + C, dtype=dt, bias=bias, K=3)
+    buf, P = _buffers(B, N, C, cin, dt, EM, K=3)
+    got = _run(EM, op, t, buf, P, lambda v: v.clone().to(dt) if v.is_floating_point() else v)
+    leaves = {n: t[n].clone().requires_grad_(True) for n in ('X', 'H', 'Wg', 'Wc') + (('bg', 'bc') if bias else ())}
+    Hnew = oracle.stc_cell(graph.to_dense().to(dt), t['Gc'], leaves['X'], leaves['H'], leaves['Wg'], leaves.get('bg'), leaves['Wc'], leaves.get('bc'), 3, 3)
+    Hnew.backward(t['dHnew'])
+    assert rel_err(got['Hnew'], Hnew.detach()) < 1e-12
+    dWg, dbg, dWc, dbc, rest = _split_params(got['dP'] - 0.125, cin, K=3)
+    assert float(rest.abs().max()) == 0.0
+    assert rel_err(got['dX'], leaves['X'].grad) < 1e-12 and rel_err(got['dH'], leaves['H'].grad) < 1e-12
+    assert rel_err(dWg, leaves['Wg'].grad) < 1e-12 and rel_err(dWc, leaves['Wc'].grad) < 1e-12
+    if bias:
+        assert rel_err(dbg, leaves['bg'].grad) < 1e-12 and rel_err(dbc, leaves['bc'].grad) < 1e-12
+
+
+def test_second_chebyshev_matrix_of_a_graph():
+    """CsrGraph.second_order: 2 S^2 - I in both orientations against the dense product, on a ragged graph with an empty row and an empty column."""
+    graph = _graph(30, seed=4)
+    G = graph.to_dense().double()
+    T2 = 2 * G @ G - torch.eye(30, dtype=torch.float64)
+    d = graph.second_order('cpu')
+    for side, want in (('bwd2', T2), ('fwd2', T2.t())):
+        rp, ci, v = d[f'{side}_rowptr'], d[f'{side}_colidx'], d[f'{side}_val']
+        M = torch.zeros(30, 30, dtype=torch.float64)
+        M[torch.repeat_interleave(torch.arange(30), (rp[1:] - rp[:-1]).long()), ci.long()] = v.double()
+        assert rp.dtype == torch.int32 and ci.dtype == torch.int32 and v.dtype == torch.float32 and float((M - want).abs().max()) < 1e-6
+        assert all(bool((ci[rp[i]:rp[i + 1]][1:] > ci[rp[i]:rp[i + 1]][:-1]).all()) for i in range(30))      # columns ascending within a row
+    assert graph.second_order('cpu') is d                           # cached per device
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,N,C,cin,splits', [(32, 100, 5, 1, 1), (32, 100, 5, 16, 1), (32, 100, 5, 16, 8), (3, 100, 5, 1, 4), (2, 37, 8, 3, 2), (1, 10, 16, 4, 1),
+                                              (2, 7, 1, 2, 3), (2, 33, 7, 16, 1), (2, 200, 8, 16, 8), (2, 5000, 5, 1, 8), (1, 4500, 7, 3, 1), (1, 13000, 5, 16, 16)])
+@pytest.mark.parametrize('bias,acc', [(True, False), (False, True)])
+def test_small_cell_kernels_at_order_3(B, N, C, cin, splits, bias, acc):
+    """stc_cell_small_fwd/bwd_f32 at Ks = Kc = 3 (ABI v32) against the twin: one launch per cell step and the split forms, narrow and wide inputs,
+    ragged tiles, one category, the top of the row range; accumulate flags and absent biases."""
+    from stc_hip._lib import HipKernels
+    hip = HipKernels()
+    assert hip.cell_small_supported(3, 3, C, cin, 16, N)
+    graph = _graph(N, seed=N + cin)
+    t = _inputs(B, N, C, cin, seed=3 * N + C + cin, bias=bias, K=3)
+    buf, P = _buffers(B, N, C, cin, torch.float32, hip, K=3)
+    want = _run(EM, csr_operand(graph, torch.device('cpu')), t, buf, P, lambda v: v.clone(), acc_x=acc, acc_h=acc)
+    got = _run(hip, csr_operand(graph, torch.device('cuda')), t, buf, P, lambda v: v.cuda(), acc_x=acc, acc_h=acc, splits=splits)
+    for name in ('U', 'R', 'RH', 'Zg', 'Zc', 'Zg2', 'Zc2', 'Cand', 'Hnew', 'dX', 'dH'):
+        assert rel_err(got[name], want[name]) < TOL, name
+    extra = 0.125 * (got['dP'].shape[0] - want['dP'].shape[0])      # (both sides start from 0.125 in every row: the split form has `splits` times the rows)
+    for a, b, name in zip(_split_params(got['dP'], cin, K=3), _split_params(want['dP'], cin, K=3), ('dWg', 'dbg', 'dWc', 'dbc')):
+        assert rel_err(a - extra, b) < TOL, name
 
 
 @pytest.mark.gpu

@@ -19,6 +19,14 @@ d = json.loads(open(f'gpurun_out/ab_{sys.argv[1]}.log').read().strip().split('\n
 k = d['kernels']
 print(f"{sys.argv[1]:8s} value {d['value']:.3f}  ms {d['ms_per_step']:.2f}  " + '  '.join(f"{n.replace('stc_', '').replace('_f32', '')} {1e3 * v['ms_per_step'] * d['steps'] / v['launches']:.1f}us" for n, v in list(k.items())[:5]))
 PY
+  elif [ "$mode" = sf ]; then        # the SF shape on a fixed sparse graph (bench.py --preset sf)
+    timeout -k 10 600 python bench.py --preset sf --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/ab_$name.log 2>&1 || { echo "$name: bench failed"; tail -5 gpurun_out/ab_$name.log; continue; }
+    python - "$name" <<'PY'
+import json, sys
+d = json.loads(open(f'gpurun_out/ab_{sys.argv[1]}.log').read().strip().split('\n')[-1])
+k = d['kernels']
+print(f"{sys.argv[1]:16s} ms {d['ms_per_step']:.3f}  " + '  '.join(f"{n.replace('stc_', '').replace('_f32', '')} {1e3 * k[n]['ms_per_step'] * d['steps'] / k[n]['launches']:.1f}us x{k[n]['launches'] / d['steps']:.0f}" for n in ('stc_cell_small_bwd_f32', 'stc_cell_small_fwd_f32') if n in k))
+PY
   elif [ "$mode" = sfl ]; then       # the reference's full model at the SF shape (bench.py --preset sf-learned): step time + the learned-graph gradient launches
     timeout -k 10 600 python bench.py --preset sf-learned --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/ab_$name.log 2>&1 || { echo "$name: bench failed"; tail -5 gpurun_out/ab_$name.log; continue; }
     python - "$name" <<'PY'
