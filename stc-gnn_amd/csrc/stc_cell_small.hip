@@ -46,8 +46,12 @@ constexpr int SC_H = 16, SC_MAXC = 16;
 // registers per lane: 256 instead of 128 available) and 12 waves backward (six per row tile: slab x role), nothing staged in LDS (MODE 0),
 // fixed CSR graphs only (a learned dense Gs at order 3 stays on the general path).
 template <int KS> struct WgShape {                                     // workgroup shapes per order
-    static constexpr int FWD_THREADS = KS == 2 ? SF_THREADS : 512, FWD_WAVES = FWD_THREADS / 64;
-    static constexpr int BWD_THREADS = KS == 2 ? SB_THREADS : 768, BWD_WAVES = BWD_THREADS / 64;
+#ifndef STC_SC_FWD_THREADS             // (probe builds: tools/gpu_ab.sh sf)
+#define STC_SC_FWD_THREADS SF_THREADS
+#define STC_SC_BWD_THREADS SB_THREADS
+#endif
+    static constexpr int FWD_THREADS = KS == 2 ? STC_SC_FWD_THREADS : 512, FWD_WAVES = FWD_THREADS / 64;
+    static constexpr int BWD_THREADS = KS == 2 ? STC_SC_BWD_THREADS : 768, BWD_WAVES = BWD_THREADS / 64;
     static constexpr int BWD_GROUPS = BWD_WAVES / (2 * KS);       // row tiles a workgroup convolves at once (4 / 2)
 };
 
@@ -1133,7 +1137,7 @@ extern "C" int stc_cell_small_fwd_f32(const int32_t* rowptr, const int32_t* coli
                           : (xq == 4 ? small_fwd_kernel<2, 2, 4, 0> : small_fwd_kernel<2, 2, 1, 0>);
     const hipError_t e = allow_lds_once(kern, lds, g_granted[0][xq == 4][mode]);
     if (e != hipSuccess) return stc::hip_status(e, "stc_cell_small_fwd_f32 LDS attribute");
-    hipLaunchKernelGGL(kern, dim3((unsigned)batch, (unsigned)splits), dim3(SF_THREADS), lds, static_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)batch, (unsigned)splits), dim3(WgShape<2>::FWD_THREADS), lds, static_cast<hipStream_t>(stream), a);
     STC_LAUNCH_CHECK("stc_cell_small_fwd_f32 launch");
     return STC_OK;
 }
@@ -1188,7 +1192,7 @@ extern "C" int stc_cell_small_bwd_f32(const int32_t* rowptr, const int32_t* coli
                           : (xq == 4 ? small_bwd_kernel<2, 2, 4, 0> : small_bwd_kernel<2, 2, 1, 0>);
     const hipError_t e = allow_lds_once(kern, lds, g_granted[1][xq == 4][mode]);
     if (e != hipSuccess) return stc::hip_status(e, "stc_cell_small_bwd_f32 LDS attribute");
-    hipLaunchKernelGGL(kern, dim3((unsigned)batch, (unsigned)splits), dim3(SB_THREADS), lds, static_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)batch, (unsigned)splits), dim3(WgShape<2>::BWD_THREADS), lds, static_cast<hipStream_t>(stream), a);
     STC_LAUNCH_CHECK("stc_cell_small_bwd_f32 launch");
     return STC_OK;
 }
