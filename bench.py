@@ -69,7 +69,9 @@ def parse(argv=None):
     ap.add_argument('--layers', type=int, default=2)
     ap.add_argument('--obs', type=int, default=18)
     ap.add_argument('--pred', type=int, default=6)
-    ap.add_argument('--batch-per-gpu', type=int, default=5, help='samples per GPU (weak scaling); ~30 GB of saved activations per sample')
+    ap.add_argument('--batch-per-gpu', type=int, default=8,
+                    help='samples per GPU (weak scaling); ~30 GB of saved activations per sample: 8 = 243 GB of the 309 GB a MI355X reports.  '
+                         'Same box, same library: 31.4 samples/s at 5, 31.6 at 6, 32.1 at 8 (longer launches: shorter tails, fewer boundaries per sample)')
     ap.add_argument('--global-batch', type=int, default=0, help='total batch over all GPUs (strong scaling: each rank takes global-batch / gpus samples); 0 = weak scaling')
     ap.add_argument('--preset', choices=('cfg2', 'cfg4', 'cfg5', 'sf', 'sf-learned'), default=None,
                     help="BASELINE.json's other configurations through the same bench (not the metric): cfg4 = N 10 000, K = 3, batch 4; cfg5 = C = 64, "
@@ -100,7 +102,12 @@ def parse(argv=None):
         # ~3 000 launches of 5 - 25 us per step: replayed from one captured HIP graph on one GPU (63.1 -> 65.2 samples/s; --eager: per-launch dispatch)
         ap.set_defaults(grid=100, order=3, batch_per_gpu=4, hip_graph=True)
     elif pre.preset == 'cfg5':
-        ap.set_defaults(categories=64, storage='bf16', cpu_shots='1,3')       # (a C = 64 oracle cell is ~20 s on the host: fewer shots)
+        # (a C = 64 oracle cell is ~20 s on the host: fewer shots; 5 samples per GPU: at 8 -- 261 GB -- it measured 26.5 against 26.6 samples/s)
+        ap.set_defaults(categories=64, storage='bf16', cpu_shots='1,3', batch_per_gpu=5)
+    elif pre.preset == 'cfg2':
+        # one layer = a handful of 5 - 30 us launches: the host's dispatch, not the chip, sets the eager time; `value` is over HIP-graph replays
+        # of the captured forward + backward (--eager: per-launch dispatch; both are in the line)
+        ap.set_defaults(hip_graph=True)
     elif pre.preset == 'sf':
         # launch-bound (~700 launches of ~7 us per step): the step is replayed from ONE captured HIP graph (--eager keeps per-launch dispatch)
         ap.set_defaults(grid=10, categories=5, obs=9, pred=3, batch_per_gpu=32, no_unit_d3=True, hip_graph=True)
@@ -521,7 +528,7 @@ def run_presets(parent_reserved_gb, steps=3, timeout_s=150):
                             'roofline': {'bound': roof.get('bound'), 'kernel': (roof.get('kernel') or '')[:160], 'achieved': roof.get('achieved'),
                                          'peak': roof.get('peak'), 'unit': roof.get('unit'), 'frac': roof.get('frac'),
                                          'dominant': {k: dom.get(k) for k in ('entry_point', 'share_of_kernel_time', 'avg_launch_us', 'achieved', 'frac') if k in dom}},
-                            **({'forward_ms': d['forward_ms']} if 'forward_ms' in d else {}),
+                            **({'forward_ms': d['forward_ms']} if 'forward_ms' in d else {}), **({'eager': d['eager']} if 'eager' in d else {}),
                             'child_run_s': time.perf_counter() - t0}
         except subprocess.TimeoutExpired:
             digest[name] = {'error': f'no line within {timeout_s} s'}
@@ -978,6 +985,21 @@ def bench_cfg2(a):
         (layer(X, Gs, Gc) * R).sum().backward()
 
     ms_f, ms_fb = timed(fwd), timed(fwd_bwd)
+    eager = dict(forward_ms=ms_f, forward_backward_ms=ms_fb)
+    graphed = bool(a.hip_graph)
+    if graphed:
+        # the same two callables captured once each into a HIP graph (after the eager runs above: every plan, workspace and table exists) and
+        # replayed: the gradients land in the capture's own buffers, re-used by every replay
+        def capture(fn):
+            torch.cuda.synchronize()
+            cg = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(cg):
+                fn()
+            return cg.replay
+        try:
+            ms_f, ms_fb = timed(capture(fwd)), timed(capture(fwd_bwd))
+        except RuntimeError as e:                                  # (something on the path synchronised with the host: the eager numbers stand)
+            graphed, eager['capture_error'] = False, str(e).split('\n')[0][:200]
     ref = {2: (13.3, 25.8), 3: (29.6, 55.2)}.get(K)
     cpu = None
     if not a.no_cpu_baseline:                                    # the oracle's bdg_dif (the reference's algorithm op for op) on the host cores
@@ -1008,7 +1030,9 @@ def bench_cfg2(a):
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': f'single BDG_Dif layer, B={B} N={N} C={C} L={L} Ho={Ho} K={K}, dense differentiable Gs and Gc (gradients of X, W, b, Gs, Gc)',
                    'preset': 'cfg2'},
-        'forward_ms': ms_f, 'forward_backward_ms': ms_fb, 'timing': f'HIP events over three rounds of {steps} repetitions each, the median round', 'cpu_baseline': cpu,
+        'forward_ms': ms_f, 'forward_backward_ms': ms_fb, 'hip_graph': graphed, 'eager': eager,
+        'timing': f'HIP events over three rounds of {steps} repetitions each, the median round' + ('; replays of the captured HIP graph (`eager`: per-launch dispatch)' if graphed else ''),
+        'cpu_baseline': cpu,
         'roofline': {'bound': 'mfma', 'kernel': 'stc_dense_agg_f32 + the node kernels of one BDG_Dif (exact-fp32 matrix instructions)',
                      'achieved': (2.0 * B * N * N * C * L * (K - 1) + 2.0 * B * N * C * (K * K * L) * Ho + 2.0 * B * N * C * C * (K - 1) * Ho) / (ms_f * 1e-3) / 1e12,
                      'peak': FP32_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',

@@ -11,7 +11,9 @@
 //   registers), read back as one ds_read_b128 per row tile = the A operands of four MFMAs; the B operand is 4 x 16 of X per MFMA
 //   (4-byte loads, 64-byte runs, requested one block ahead), reused by every row tile.  The contraction index a lane feeds to step s of a
 //   block is k0 + 4 (lane / 16) + s on BOTH operands -- any bijection serves a sum.
-// Bound by the fp32 matrix pipe (32 cycles per MFMA).
+// Bound by the fp32 matrix pipe (32 cycles per MFMA) -- when the launch fills the chip: the passes over the rows of S are workgroups of
+// their own (blockIdx.y), and a pass is 128, 64 or 32 rows, the largest that still gives two workgroups per compute unit (BASELINE
+// configuration 2, batch 32 x 4 column groups x N = 200: 128 workgroups of two passes each took 34 us, half the chip idle).
 #include "stc_common.h"
 
 namespace {
@@ -19,7 +21,7 @@ namespace {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int DA_THREADS = 256, DA_WAVES = DA_THREADS / 64;
-constexpr int DA_MT = 8;            // row tiles of 16 per pass: 128 rows of S per pass (32 accumulator registers)
+constexpr int DA_MT_MAX = 8;        // row tiles of 16 per pass, at most: 128 rows of S per pass (32 accumulator registers)
 constexpr int DA_KB = 16;           // graph columns per staged block
 constexpr int DA_LD = DA_KB + 4;    // LDS row stride in floats: 16-byte reads of 16 consecutive rows fall on distinct banks
 
@@ -39,7 +41,7 @@ __device__ __forceinline__ f32x4 load_s(const float* __restrict__ S, int row, in
     return v;
 }
 
-template <bool VEC>
+template <bool VEC, int DA_MT>
 __global__ __launch_bounds__(DA_THREADS) void dense_agg_kernel(
     const float* __restrict__ S, int n_rows, int n_cols, const float* __restrict__ X, const float* __restrict__ Y0, float* __restrict__ Y,
     int F, int col_groups, float alpha, float beta) {
@@ -50,25 +52,29 @@ __global__ __launch_bounds__(DA_THREADS) void dense_agg_kernel(
     const float* Xb = X + (size_t)b * n_cols * F + (col_ok ? col : 0);
     const int blocks = (n_cols + DA_KB - 1) / DA_KB;
     const int srow = t >> 1, sk = (t & 1) * 8;                       // staging: thread -> (row of the pass, 8 of the block's 16 columns)
-    for (int m0 = 0; m0 < n_rows; m0 += 16 * DA_MT) {
+    const bool stages = srow < 16 * DA_MT;                           // (passes of fewer than 128 rows: the upper threads stage nothing)
+    {
+        const int m0 = blockIdx.y * 16 * DA_MT;                      // this workgroup's pass over the rows of S
+        const int srow_g = stages ? m0 + srow : n_rows;              // (n_rows: load_s returns zeros without touching memory)
         f32x4 acc[DA_MT];
 #pragma unroll
         for (int mt = 0; mt < DA_MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int mts = min(DA_MT, (n_rows - m0 + 15) / 16);          // row tiles of this pass that exist (workgroup-uniform)
-        f32x4 s0 = load_s<VEC>(S, m0 + srow, sk, n_rows, n_cols), s1 = load_s<VEC>(S, m0 + srow, sk + 4, n_rows, n_cols);
+        f32x4 s0 = load_s<VEC>(S, srow_g, sk, n_rows, n_cols), s1 = load_s<VEC>(S, srow_g, sk + 4, n_rows, n_cols);
         float xb[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) xb[s] = (col_ok && 4 * kq + s < n_cols) ? Xb[(size_t)(4 * kq + s) * F] : 0.f;
-        __syncthreads();                                              // the previous pass has read its last tile
-        *reinterpret_cast<f32x4*>(&tile[0][srow * DA_LD + sk]) = s0;
-        *reinterpret_cast<f32x4*>(&tile[0][srow * DA_LD + sk + 4]) = s1;
+        if (stages) {
+            *reinterpret_cast<f32x4*>(&tile[0][srow * DA_LD + sk]) = s0;
+            *reinterpret_cast<f32x4*>(&tile[0][srow * DA_LD + sk + 4]) = s1;
+        }
         __syncthreads();
         for (int blk = 0; blk < blocks; ++blk) {
             const int kn = (blk + 1) * DA_KB;                          // next block (past the end: zeros, never used)
             float xn[4];
             if (blk + 1 < blocks) {
-                s0 = load_s<VEC>(S, m0 + srow, kn + sk, n_rows, n_cols);
-                s1 = load_s<VEC>(S, m0 + srow, kn + sk + 4, n_rows, n_cols);
+                s0 = load_s<VEC>(S, srow_g, kn + sk, n_rows, n_cols);
+                s1 = load_s<VEC>(S, srow_g, kn + sk + 4, n_rows, n_cols);
 #pragma unroll
                 for (int s = 0; s < 4; ++s) xn[s] = (col_ok && kn + 4 * kq + s < n_cols) ? Xb[(size_t)(kn + 4 * kq + s) * F] : 0.f;
             }
@@ -83,8 +89,10 @@ __global__ __launch_bounds__(DA_THREADS) void dense_agg_kernel(
             }
             if (blk + 1 < blocks) {
                 float* nxt = tile[(blk + 1) & 1];                      // last read two blocks ago: the barrier of the previous block covers it
-                *reinterpret_cast<f32x4*>(&nxt[srow * DA_LD + sk]) = s0;
-                *reinterpret_cast<f32x4*>(&nxt[srow * DA_LD + sk + 4]) = s1;
+                if (stages) {
+                    *reinterpret_cast<f32x4*>(&nxt[srow * DA_LD + sk]) = s0;
+                    *reinterpret_cast<f32x4*>(&nxt[srow * DA_LD + sk + 4]) = s1;
+                }
 #pragma unroll
                 for (int s = 0; s < 4; ++s) xb[s] = xn[s];
             }
@@ -125,8 +133,16 @@ extern "C" int stc_dense_agg_f32(const float* S, int32_t n_rows, int32_t n_cols,
     const long long blocks = (long long)batch * col_groups;
     STC_REQUIRE(blocks < (1ll << 31), STC_ELIMIT, "stc_dense_agg_f32: %lld workgroups", blocks);
     const bool vec = n_cols % 4 == 0 && (reinterpret_cast<uintptr_t>(S) & 15) == 0;
-    auto kern = vec ? dense_agg_kernel<true> : dense_agg_kernel<false>;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(DA_THREADS), 0, static_cast<hipStream_t>(stream),
+    // rows of S per pass: 128 while that still gives ~two workgroups per compute unit, else 64, else 32
+    int mt = DA_MT_MAX;
+    while (mt > 2 && blocks * ((n_rows + 16 * mt - 1) / (16 * mt)) < 2 * stc::kNumCu) mt /= 2;
+    const unsigned passes = (unsigned)((n_rows + 16 * mt - 1) / (16 * mt));
+    STC_REQUIRE(passes <= 65535u, STC_ELIMIT, "stc_dense_agg_f32: %u row passes", passes);
+    using Kernel = void (*)(const float*, int, int, const float*, const float*, float*, int, int, float, float);
+    const Kernel kern = mt == 8 ? (vec ? dense_agg_kernel<true, 8> : dense_agg_kernel<false, 8>)
+                      : mt == 4 ? (vec ? dense_agg_kernel<true, 4> : dense_agg_kernel<false, 4>)
+                                : (vec ? dense_agg_kernel<true, 2> : dense_agg_kernel<false, 2>);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, passes), dim3(DA_THREADS), 0, static_cast<hipStream_t>(stream),
                        S, n_rows, n_cols, X, Y0, Y, F, col_groups, alpha, beta);
     STC_LAUNCH_CHECK("stc_dense_agg_f32 launch");
     return STC_OK;

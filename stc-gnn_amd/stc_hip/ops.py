@@ -77,6 +77,9 @@ def cheby_dense(G: torch.Tensor, K: int) -> torch.Tensor:
 
 
 # ----------------------------------------------------------------------------- BDG_Dif
+_NODE_PACK = True        # few categories (C | 16): 16 / C nodes per row tile of the matrix-core node kernels (``_node_pack``; tests flip it)
+
+
 def _spatial_slabs(X, fwd_val, op: SpatialOperand, Ks: int):
     """[Z_0 = X, Z_1 = Gs^T X, Z_k = 2 Gs^T Z_{k-1} - Z_{k-2}]: the Ks-1 SpMM launches of one BDG_Dif."""
     k = kernels()
@@ -94,6 +97,30 @@ def _spatial_slabs(X, fwd_val, op: SpatialOperand, Ks: int):
     return Zs
 
 
+def _node_pack(X: torch.Tensor, Tc: torch.Tensor, Ks: int, Ho: int) -> int:
+    """How many nodes one row tile of the matrix-core node kernels takes when the categories are few: the kernels (csrc/stc_node_mfma.hip) want
+    C in {16, 32, 64}, and the node kernel is node-local (reference STC_GNN.py:38-45: the 2-mode product and the projection touch one node's
+    C x L rows), so 16 / C consecutive nodes ARE one node of 16 categories whose category graph is block-diagonal -- same rows in memory,
+    T_c repeated on the diagonal (``_block_diag``).  BASELINE configuration 2 (C = 8: two nodes per tile) otherwise runs the generic vector
+    kernel: 35 / 181 us forward / backward for 8 / ~25 on the matrix cores.  1: no packing (C does not divide 16, an odd row count, a shape
+    the matrix-core kernels do not take, bf16 rows)."""
+    B, N, C, L = X.shape
+    if not _NODE_PACK or X.dtype != torch.float32 or C >= 16 or 16 % C or (B * N) % (16 // C):
+        return 1
+    Kc = Tc.shape[0]
+    if Ks != Kc or not 1 <= Ks <= 3 or Ho not in (16, 32) or L not in (20, 32):      # = fast_path_shape of csrc/stc_node_mfma.hip at C = 16
+        return 1
+    return 16 // C
+
+
+def _block_diag(Tc: torch.Tensor, p: int) -> torch.Tensor:
+    """(Kc, C, C) -> (Kc, pC, pC) with T_c on the diagonal blocks: the category graph of p nodes taken as one."""
+    Kc, C, _ = Tc.shape
+    out = Tc.new_zeros(Kc, p, C, p, C)
+    out.diagonal(dim1=1, dim2=3).copy_(Tc.unsqueeze(-1).expand(Kc, C, C, p))       # (diagonal view: (Kc, C, C, p))
+    return out.view(Kc, p * C, p * C)
+
+
 def _bdg_forward(X, W, b, Tc, fwd_val, op: SpatialOperand, Ks: int):
     """Launch sequence of one BDG_Dif forward on raw tensors; returns (Y, [Z_0..Z_{Ks-1}])."""
     k = kernels()
@@ -101,8 +128,24 @@ def _bdg_forward(X, W, b, Tc, fwd_val, op: SpatialOperand, Ks: int):
     Ho = W.shape[1]
     Zs = _spatial_slabs(X, fwd_val, op, Ks)
     Y = X.new_empty(B, N, C, Ho)
-    k.bdg_node_fwd([z.view(B * N, C, L) for z in Zs], Tc, W, b, Y.view(B * N, C, Ho))
+    p = _node_pack(X, Tc, Ks, Ho)
+    R = B * N // p
+    k.bdg_node_fwd([z.view(R, p * C, L) for z in Zs], Tc if p == 1 else _block_diag(Tc, p), W, b, Y.view(R, p * C, Ho))
     return Y, Zs
+
+
+def _mix_grad(Zs, dY, W, Kc: int) -> torch.Tensor:
+    """dT_c[p, d] = sum_r sum_o U_c[r, p, o] dY[r, d, o] with U_c = sum_n Z_n W_{n,c} (autograd of STC_GNN.py:38 w.r.t. the category graph), as
+    dT_c[p, d] = sum_{n,l,o} W[(n, c, l), o] Q_n[p, l, d, o],  Q_n = Z_n^T . dY  over the rows -- Ks plain library GEMMs (C L x rows x C Ho) and
+    one small contraction.  For few categories only (the GEMMs are C / Kc times the projection's flops)."""
+    B, N, C, L = Zs[0].shape
+    Ks, Ho, R = len(Zs), W.shape[1], B * N
+    Lw = W.shape[0] // (Ks * Kc)
+    Q = W.new_empty(Ks, C * L, C * Ho)
+    dYf = dY.view(R, C * Ho)
+    for n, z in enumerate(Zs):
+        torch.mm(z.view(R, C * L).t(), dYf, out=Q[n])
+    return torch.einsum('nklo,npldo->kpd', W.view(Ks, Kc, Lw, Ho), Q.view(Ks, C, L, C, Ho)[:, :, :Lw])
 
 
 def _bdg_backward_slabs(dY, Zs, W, Tc, op: SpatialOperand, Ks: int, has_bias: bool, need_Tc: bool, need_val: bool, gates=None, cand=None):
@@ -129,7 +172,15 @@ def _bdg_backward_slabs(dY, Zs, W, Tc, op: SpatialOperand, Ks: int, has_bias: bo
         k.cell_cand_bwd(rows(Zs), Tc, W, *rows(cand), rows(dZ), dW, db)
     else:
         dY = _c(dY)
-        k.bdg_node_bwd(rows(Zs), Tc, W, dY.view(B * N, C, Ho), rows(dZ), dW, db, dTc)
+        p = _node_pack(Zs[0], Tc, Ks, Ho)
+        if p > 1:
+            # few categories: 16 / C nodes per row tile of the matrix-core kernel (``_node_pack``); that kernel leaves dT_c to the caller
+            R = B * N // p
+            k.bdg_node_bwd([z.view(R, p * C, L) for z in Zs], _block_diag(Tc, p), W, dY.view(R, p * C, Ho), [z.view(R, p * C, L) for z in dZ], dW, db, None)
+            if need_Tc:
+                dTc = _mix_grad(Zs, dY, W, Tc.shape[0])
+        else:
+            k.bdg_node_bwd(rows(Zs), Tc, W, dY.view(B * N, C, Ho), rows(dZ), dW, db, dTc)
     dval = torch.zeros_like(op.fwd_val) if need_val else None
     v3 = lambda t: t.view(B, N, F)
     dense = op.nnz == N * N                                        # learned dense Gs: the "pattern" is the whole matrix

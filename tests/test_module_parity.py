@@ -392,6 +392,48 @@ def test_bdg_dif_at_baseline_configuration_2(K):
         _close(t, w.float().to(DEV), GRAD, f'cfg2 K={K} {name}')
 
 
+@pytest.mark.parametrize('C,N,K,L,Ho', [(8, 50, 2, 32, 32), (4, 36, 3, 32, 16), (2, 24, 2, 20, 32), (8, 25, 2, 32, 32), (5, 20, 2, 32, 32)])
+def test_bdg_dif_packs_few_categories_into_matrix_core_tiles(monkeypatch, C, N, K, L, Ho):
+    """Few categories (C | 16): 16 / C consecutive nodes run as ONE node of 16 categories with a block-diagonal category graph on the
+    matrix-core node kernels (``ops._node_pack``; reference STC_GNN.py:38-45 is node-local), dT_c from ``ops._mix_grad``.  Against the
+    float64 oracle, and equal (to rounding) to the unpacked launches; an odd row count (N = 25, one sample) and C = 5 are not packed."""
+    B = 1 if N == 25 else 3
+    gen = torch.Generator().manual_seed(C * 100 + K)
+    X = torch.randn(B, N, C, L, generator=gen)
+    Lw = L if L == 32 else 17
+    X[..., Lw:] = 0                                                           # (L = 20: rows padded to 16 bytes, W keeps 17 rows per block)
+    Gs = torch.softmax(torch.randn(N, N, generator=gen), -1)
+    Gc = torch.softmax(torch.randn(C, C, generator=gen), -1)
+    W = torch.randn(K * K * Lw, Ho, generator=gen) * (2.0 / (K * K * Lw + Ho)) ** 0.5
+    bias = torch.randn(Ho, generator=gen) * 0.1
+    R = torch.randn(B, N, C, Ho, generator=gen)
+    packs = []
+    real = ops._node_pack
+    monkeypatch.setattr(ops, '_node_pack', lambda *a: packs.append(real(*a)) or packs[-1])
+    want_in = [t.double().requires_grad_() for t in (X[..., :Lw], Gs, Gc, W, bias)]
+    want = O.bdg_dif(*want_in, K, K)
+    (want * R.double()).sum().backward()
+
+    def run():
+        layer = M.BDG_Dif(K, K, Lw, Ho).to(DEV)
+        layer.load_state_dict({'W': W, 'b': bias})
+        Xd, Gsd, Gcd = _leaf(X), _leaf(Gs), _leaf(Gc)
+        Y = layer(Xd, Gsd, Gcd, _pad=L - Lw)
+        (Y * R.to(DEV)).sum().backward()
+        return Y.detach(), Xd.grad[..., :Lw], Gsd.grad, Gcd.grad, layer.W.grad, layer.b.grad
+
+    got = run()
+    expect = 16 // C if (16 % C == 0 and (B * N) % (16 // C) == 0) else 1
+    assert packs and set(packs) == {expect}
+    names = ('Y', 'dX', 'dGs', 'dGc', 'dW', 'db')
+    for name, t, w in zip(names, got, (want.detach(), *(v.grad for v in want_in))):
+        _close(t, w.float().to(DEV), FWD if name == 'Y' else GRAD, f'packed C={C} K={K} {name}')
+    monkeypatch.setattr(ops, '_NODE_PACK', False)
+    plain = run()
+    for name, a, b in zip(names, got, plain):
+        assert rel_err(a, b) < 2e-6, f'packed vs unpacked {name}: {rel_err(a, b):.2e}'
+
+
 def test_large_n10000_order_3_against_dense_reference_rows():
     """g8c: one STC_Cell at N = 10 000, C = 32, h = 16, Chebyshev order K = 3 (BASELINE configuration 4) against the dense reference
     (STC_GNN.py:24-29, 65-79) -- new state, dXt, dHt on 256 sampled rows and the full parameter gradients."""
