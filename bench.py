@@ -74,7 +74,7 @@ def parse(argv=None):
                          'Same box, same library: 31.4 samples/s at 5, 31.6 at 6, 32.1 at 8 (longer launches: shorter tails, fewer boundaries per sample)')
     ap.add_argument('--global-batch', type=int, default=0, help='total batch over all GPUs (strong scaling: each rank takes global-batch / gpus samples); 0 = weak scaling')
     ap.add_argument('--preset', choices=('cfg2', 'cfg4', 'cfg5', 'sf', 'sf-learned'), default=None,
-                    help="BASELINE.json's other configurations through the same bench (not the metric): cfg4 = N 10 000, K = 3, batch 4; cfg5 = C = 64, "
+                    help="BASELINE.json's other configurations through the same bench (not the metric): cfg4 = N 10 000, K = 3, batch 16; cfg5 = C = 64, "
                          'bf16 state storage; sf = the SF-incidents shape (N = 100, C = 5, T = 9 + 3, batch 32, fixed sparse graph); sf-learned = the same shape with '
                          "the reference's FULL model: MGP_Gen's learned dense graphs (2e8 parameters in MixedFusion), fused Adam; cfg2 = one BDG_Dif layer "
                          '(B = 32, N = 200, C = 8, L = 32, Ho = 32), forward and forward + backward')
@@ -100,7 +100,8 @@ def parse(argv=None):
     pre, _ = ap.parse_known_args(argv)
     if pre.preset == 'cfg4':
         # ~3 000 launches of 5 - 25 us per step: replayed from one captured HIP graph on one GPU (63.1 -> 65.2 samples/s; --eager: per-launch dispatch)
-        ap.set_defaults(grid=100, order=3, batch_per_gpu=4, hip_graph=True)
+        # 16 samples per GPU (169 GB): same box, 4 / 8 / 12 / 16 / 24 samples: 71.4 / 76.2 / 77.1 / 77.9 / 77.7 samples/s
+        ap.set_defaults(grid=100, order=3, batch_per_gpu=16, hip_graph=True)
     elif pre.preset == 'cfg5':
         # (a C = 64 oracle cell is ~20 s on the host: fewer shots; 5 samples per GPU: at 8 -- 261 GB -- it measured 26.5 against 26.6 samples/s)
         ap.set_defaults(categories=64, storage='bf16', cpu_shots='1,3', batch_per_gpu=5)

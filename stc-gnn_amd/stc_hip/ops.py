@@ -144,7 +144,7 @@ def _mix_grad(Zs, dY, W, Kc: int) -> torch.Tensor:
     Q = W.new_empty(Ks, C * L, C * Ho)
     dYf = dY.view(R, C * Ho)
     for n, z in enumerate(Zs):
-        torch.mm(z.view(R, C * L).t(), dYf, out=Q[n])
+        torch.mm(z.view(R, C * L).t(), dYf, out=Q[n])      # (as a batched product over row groups + a sum the library took twice as long: measured)
     return torch.einsum('nklo,npldo->kpd', W.view(Ks, Kc, Lw, Ho), Q.view(Ks, C, L, C, Ho)[:, :, :Lw])
 
 

@@ -76,7 +76,7 @@ def test_matrix_pipe_counters_are_quoted_only_for_matching_sources(tmp_path, mon
 
 def test_presets_and_global_batch():
     a = bench.parse(['--preset', 'cfg4'])
-    assert (a.grid, a.order, a.batch_per_gpu) == (100, 3, 4)
+    assert (a.grid, a.order, a.batch_per_gpu) == (100, 3, 16)
     a = bench.parse(['--preset', 'cfg5'])
     assert (a.categories, a.storage) == (64, 'bf16')
     a = bench.parse(['--preset', 'sf'])
