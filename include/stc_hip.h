@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define STC_ABI_VERSION 32
+#define STC_ABI_VERSION 33
 #define STC_MAX_K 4          /* highest Chebyshev order (Ks, Kc) the node kernels accept */
 
 /* Operand formats of the split-operand matrix-core kernels (C = 32 / 64, hidden 16).  Every fp32 operand is split into low-precision
@@ -615,6 +615,19 @@ int stc_graph_grad_f32(const float* A, const float* B, double* partials, int32_t
                        int32_t batch, int32_t N, int32_t F, int64_t chunk_stride, void* stream);
 int stc_mix_grad_f32(const float* A, const float* B, double* partials, int32_t n_chunks, int32_t cell0, int32_t cell_step, int32_t n_sel,
                      int32_t batch, int32_t N, int32_t Fa, int32_t Fb, int64_t chunk_stride, void* stream);
+
+/* Gradient of the category graph through ONE BDG_Dif for FEW categories (ABI v33; reference STC_GNN.py:38-42 through autograd), on the
+ * exact-fp32 matrix cores:  dTc[c][p][d] = sum_r sum_o U_c[r][p][o] * dY[r][d][o],  U_c[r] = sum_n Z_n[r] . W[(n, c, :), :]  (r: nodes).
+ * C divides 16 (stc_mix_dt_supported): the rows of 16 / C consecutive nodes are one tile of 16 rows, as the host packs them for the
+ * matrix-core node kernels (stc_hip/ops.py _node_pack) -- whose backward (stc_bdg_node_bwd_f32 on a block-diagonal category graph, dTc =
+ * NULL) leaves dT_c to this entry point.  Z[n] (rows, L) for n < Ks with rows = nodes * C a multiple of 16, L in {20, 32}, columns >= Lw
+ * are padding; W (Ks * Ks * Lw, Ho), Ho in {16, 32}; dY (rows, Ho); dTc (Ks, C, C) is WRITTEN (dTc[0] = 0: T_0 = I is a constant, as in
+ * stc_bdg_node_bwd_f32).  Fixed-order sums: bitwise reproducible.
+ * workspace: stc_mix_dt_workspace_bytes(Ks), 16-byte aligned. */
+int stc_mix_dt_supported(int32_t Ks, int32_t Kc, int32_t C, int32_t L, int32_t Ho);
+size_t stc_mix_dt_workspace_bytes(int32_t Ks);
+int stc_mix_dt_f32(const float* const* Z, int32_t Ks, const float* W, const float* dY, float* dTc, void* workspace,
+                   size_t workspace_bytes, int64_t rows, int32_t C, int32_t L, int32_t Lw, int32_t Ho, void* stream);
 
 /* ---- MixedFusion of the learned graph generator (reference STC_GNN.py:246-261, called by MGP_Gen :227-243) ----------------------------
  *   gate = sigmoid(W_A vec(A) + b_A + W_P vec(P) + b_P),   G = gate * A + (1 - gate) * P        D = n^2 entries; W_A, W_P (D, D) row-major

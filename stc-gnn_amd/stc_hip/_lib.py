@@ -21,7 +21,7 @@ from .graph import is_full_pattern
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG_ROOT, 'libstc_hip.so')
-ABI_VERSION = 32
+ABI_VERSION = 33
 FMT_BF16X3, FMT_F16X2 = 0, 1          # STC_FMT_* of include/stc_hip.h: operand formats of the split-operand matrix-core kernels
 MAX_K = 4
 SPMM_SUM_MAX_ADD = 8     # = STC_SPMM_SUM_MAX_ADD of include/stc_hip.h
@@ -43,7 +43,7 @@ EXPORTS = (
     'stc_cell_bwd_planar_supported', 'stc_cell_bwd_planar_workspace_bytes', 'stc_cell_bwd_planar_f32',
     'stc_cell_planar_k_supported', 'stc_cell_gates_fwd_planar_k_f32', 'stc_cell_cand_fwd_planar_k_f32', 'stc_cell_gates_bwd_planar_k_f32',
     'stc_cell_cand_bwd_planar_k_f32',
-    'stc_cell_small_supported', 'stc_cell_small_workspace_bytes', 'stc_cell_small_param_rows', 'stc_graph_grad_f32', 'stc_mix_grad_f32', 'stc_mixed_fusion_workspace_bytes', 'stc_mixed_fusion_fwd_f32', 'stc_mixed_fusion_bwd_f32', 'stc_mgp_uv_fwd_f32', 'stc_mgp_uv_bwd_f32', 'stc_mgp_softmax_fwd_f32', 'stc_mgp_softmax_bwd_f32', 'stc_adam_f32', 'stc_cell_small_fwd_f32', 'stc_cell_small_bwd_f32',
+    'stc_cell_small_supported', 'stc_cell_small_workspace_bytes', 'stc_cell_small_param_rows', 'stc_graph_grad_f32', 'stc_mix_grad_f32', 'stc_mix_dt_supported', 'stc_mix_dt_workspace_bytes', 'stc_mix_dt_f32', 'stc_mixed_fusion_workspace_bytes', 'stc_mixed_fusion_fwd_f32', 'stc_mixed_fusion_bwd_f32', 'stc_mgp_uv_fwd_f32', 'stc_mgp_uv_bwd_f32', 'stc_mgp_softmax_fwd_f32', 'stc_mgp_softmax_bwd_f32', 'stc_adam_f32', 'stc_cell_small_fwd_f32', 'stc_cell_small_bwd_f32',
     'stc_gru_gates_fwd_f32', 'stc_gru_gates_bwd_f32', 'stc_gru_blend_fwd_f32', 'stc_gru_blend_bwd_f32',
     'stc_head_fwd_f32', 'stc_head_bwd_workspace_bytes', 'stc_head_bwd_f32',
     'stc_axpy_f32', 'stc_concat2_f32', 'stc_split2_f32',
@@ -88,6 +88,7 @@ def _declare(lib):
                                    _p, _p, _p, _p, _p, C.c_size_t, _i32, _i32, _i32, _i32, _p],
         'stc_csr_sddmm_f32': [_p, _p, _i32, _i32, _p, _p, _p, _i32, _i32, _f32, _i32, _p],
         'stc_cheby_dense_fwd_f32': [_p, _i32, _i32, _p, _p],
+        'stc_mix_dt_f32': [C.POINTER(_p), _i32, _p, _p, _p, _p, C.c_size_t, _i64, _i32, _i32, _i32, _i32, _p],
         'stc_cheby_dense_bwd_f32': [_p, _p, _p, _i32, _i32, _p, _p],
         'stc_bdg_node_fwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, _p, _i64, _i32, _i32, _i32, _i32, _p],
         'stc_bdg_node_bwd_f32': [C.POINTER(_p), _i32, _p, _i32, _p, _p, C.POINTER(_p), _p, _p, _p,
@@ -173,6 +174,10 @@ def _declare(lib):
     lib.stc_head_bwd_workspace_bytes.argtypes = [_i32]
     lib.stc_bdg_node_bwd_workspace_bytes.restype = C.c_size_t
     lib.stc_bdg_node_bwd_workspace_bytes.argtypes = [_i32, _i32, _i32, _i32, _i32, _i32]
+    lib.stc_mix_dt_supported.restype = C.c_int
+    lib.stc_mix_dt_supported.argtypes = [_i32] * 5
+    lib.stc_mix_dt_workspace_bytes.restype = C.c_size_t
+    lib.stc_mix_dt_workspace_bytes.argtypes = [_i32]
 
 
 _LIB = None
@@ -685,6 +690,26 @@ class HipKernels:
         ws = self._get_workspace(dY.device, nbytes)
         self._launch('stc_bdg_node_bwd_f32', dY, self._ptr_array(Zs), Ks, _ptr(Tc), Kc, _ptr(W), _ptr(dY), self._ptr_array(dZs), _ptr(dW), _ptr(db), _ptr(dTc), _ptr(ws), ws.numel(), R, Cc, L, Lw, Ho,
                      nbytes=4 * R * Cc * (2 * Ks * L + Ho))      # the Ks slabs and dY in, the Ks gradient slabs out
+
+    def mix_dT_supported(self, Ks, Kc, Cc, L, Ho) -> bool:
+        return bool(self.lib.stc_mix_dt_supported(Ks, Kc, Cc, L, Ho))
+
+    def mix_dT(self, Zs, W, dY, dTc):
+        """dTc (Kc, C, C) = the category graph's gradient through one BDG_Dif for few categories (stc_mix_dt_f32): Zs = the Ks slabs (R, C, L) with
+        R * C a multiple of 16, dY (R, C, Ho), W (Ks * Kc * Lw, Ho)."""
+        Ks = len(Zs)
+        R, Cc, L = Zs[0].shape
+        Ho = W.shape[1]
+        Lw = W.shape[0] // (Ks * Ks)
+        for i, z in enumerate(Zs):
+            self._f32(f'mix_dT.Z[{i}]', z, (R, Cc, L))
+        self._f32('mix_dT.W', W, (Ks * Ks * Lw, Ho))
+        self._f32('mix_dT.dY', dY, (R, Cc, Ho))
+        self._f32('mix_dT.dTc', dTc, (Ks, Cc, Cc))
+        self._same_device(*Zs, W, dY, dTc)
+        ws = self._get_workspace(dY.device, self.lib.stc_mix_dt_workspace_bytes(Ks))
+        self._launch('stc_mix_dt_f32', dY, self._ptr_array(Zs), Ks, _ptr(W), _ptr(dY), _ptr(dTc), _ptr(ws), ws.numel(), R * Cc, Cc, L, Lw, Ho,
+                     nbytes=4 * R * Cc * (Ks * L + Ho))
 
     # ---- bf16 storage (configuration 5) ------------------------------------------------------------
     def node_bf16_supported(self, Ks, Kc, Cc, L, Ho) -> bool:

@@ -135,17 +135,13 @@ def _bdg_forward(X, W, b, Tc, fwd_val, op: SpatialOperand, Ks: int):
 
 
 def _mix_grad(Zs, dY, W, Kc: int) -> torch.Tensor:
-    """dT_c[p, d] = sum_r sum_o U_c[r, p, o] dY[r, d, o] with U_c = sum_n Z_n W_{n,c} (autograd of STC_GNN.py:38 w.r.t. the category graph), as
-    dT_c[p, d] = sum_{n,l,o} W[(n, c, l), o] Q_n[p, l, d, o],  Q_n = Z_n^T . dY  over the rows -- Ks plain library GEMMs (C L x rows x C Ho) and
-    one small contraction.  For few categories only (the GEMMs are C / Kc times the projection's flops)."""
+    """dT_c[p, d] = sum_r sum_o U_c[r, p, o] dY[r, d, o] with U_c = sum_n Z_n W_{n,c} (autograd of STC_GNN.py:38 w.r.t. the category graph) for few
+    categories: ``stc_mix_dt_f32`` on the tiles of 16 rows the packed node kernels run on.  (As library GEMMs -- Q_n = Z_n^T . dY over the rows,
+    then a contraction with W -- two launches of 41 us at configuration 2's shape, 64 workgroups each.)"""
     B, N, C, L = Zs[0].shape
-    Ks, Ho, R = len(Zs), W.shape[1], B * N
-    Lw = W.shape[0] // (Ks * Kc)
-    Q = W.new_empty(Ks, C * L, C * Ho)
-    dYf = dY.view(R, C * Ho)
-    for n, z in enumerate(Zs):
-        torch.mm(z.view(R, C * L).t(), dYf, out=Q[n])      # (as a batched product over row groups + a sum the library took twice as long: measured)
-    return torch.einsum('nklo,npldo->kpd', W.view(Ks, Kc, Lw, Ho), Q.view(Ks, C, L, C, Ho)[:, :, :Lw])
+    dTc = W.new_empty(Kc, C, C)
+    kernels().mix_dT([z.view(B * N, C, L) for z in Zs], W, dY.view(B * N, C, W.shape[1]), dTc)
+    return dTc
 
 
 def _bdg_backward_slabs(dY, Zs, W, Tc, op: SpatialOperand, Ks: int, has_bias: bool, need_Tc: bool, need_val: bool, gates=None, cand=None):

@@ -1017,3 +1017,43 @@ def test_mixed_fusion(hip, n, needs_dA):
     assert torch.equal(frozen[1].grad, dev[1].grad) and torch.equal(frozen[3].grad, dev[3].grad)
     flat = torch.zeros(WA.numel() + 1, device='cuda')
     assert not O2.mixed_fusion_supported(dev[0], dev[1], flat[1:].view_as(WA), dev[3], dev[4], dev[5])
+
+
+@pytest.mark.parametrize('nodes,C,L,Lw,Ho,K', [
+    (6400, 8, 32, 32, 32, 2),    # BASELINE configuration 2: 3 200 tiles, more than the grid's waves
+    (6400, 8, 32, 32, 32, 3),
+    (6, 8, 20, 17, 32, 2),       # padded rows (in + hidden = 17), three tiles
+    (40, 4, 20, 18, 16, 3),
+    (16, 2, 32, 32, 16, 2),
+    (48, 1, 20, 17, 32, 3),
+    (5, 16, 32, 32, 32, 2),      # C = 16: one node per tile
+    (2, 8, 32, 32, 16, 1),       # K = 1: T_0 = I only, zeros
+])
+def test_mix_dT_for_few_categories(hip, nodes, C, L, Lw, Ho, K):
+    """stc_mix_dt_f32 (the category graph's gradient the packed matrix-core node backward leaves to its caller) against its twin, and the
+    same number twice (fixed-order sums)."""
+    g = torch.Generator().manual_seed(nodes + 10 * C + K)
+    Zs = [torch.randn(nodes, C, L, generator=g) for _ in range(K)]
+    for z in Zs:
+        z[..., Lw:] = 7.0                                          # pad columns hold anything: W has no rows for them
+    W = torch.randn(K * K * Lw, Ho, generator=g)
+    dY = torch.randn(nodes, C, Ho, generator=g)
+    assert hip.mix_dT_supported(K, K, C, L, Ho) and EM.mix_dT_supported(K, K, C, L, Ho)
+    want = torch.empty(K, C, C, dtype=torch.float64)               # (sums over up to 2e5 products: the float64 twin is the exact side)
+    EM.mix_dT([z.double() for z in Zs], W.double(), dY.double(), want)
+    got = torch.full((K, C, C), float('nan')).cuda()
+    hip.mix_dT([cu(z) for z in Zs], cu(W), cu(dY), got)
+    assert float(got[0].abs().max()) == 0.0                        # T_0 = I is a constant
+    if K > 1:
+        assert rel_err(got[1:], want[1:]) < TOL
+    again = torch.empty_like(got)
+    hip.mix_dT([cu(z) for z in Zs], cu(W), cu(dY), again)
+    assert torch.equal(got, again)
+
+
+def test_mix_dT_rejects_what_it_does_not_take(hip):
+    from stc_hip._lib import StcError
+    assert not hip.mix_dT_supported(2, 2, 5, 32, 32) and not hip.mix_dT_supported(2, 3, 8, 32, 32) and not hip.mix_dT_supported(2, 2, 8, 24, 32)
+    Z = [torch.zeros(3, 8, 32).cuda() for _ in range(2)]          # 24 rows: not whole tiles
+    with pytest.raises(StcError, match='whole tiles'):
+        hip.mix_dT(Z, torch.zeros(128, 32).cuda(), torch.zeros(3, 8, 32).cuda(), torch.zeros(2, 8, 8).cuda())
