@@ -618,9 +618,9 @@ int stc_mix_grad_f32(const float* A, const float* B, double* partials, int32_t n
 
 /* Gradient of the category graph through ONE BDG_Dif for FEW categories (ABI v33; reference STC_GNN.py:38-42 through autograd), on the
  * exact-fp32 matrix cores:  dTc[c][p][d] = sum_r sum_o U_c[r][p][o] * dY[r][d][o],  U_c[r] = sum_n Z_n[r] . W[(n, c, :), :]  (r: nodes).
- * C divides 16 (stc_mix_dt_supported): the rows of 16 / C consecutive nodes are one tile of 16 rows, as the host packs them for the
- * matrix-core node kernels (stc_hip/ops.py _node_pack) -- whose backward (stc_bdg_node_bwd_f32 on a block-diagonal category graph, dTc =
- * NULL) leaves dT_c to this entry point.  Z[n] (rows, L) for n < Ks with rows = nodes * C a multiple of 16, L in {20, 32}, columns >= Lw
+ * C <= 16 (stc_mix_dt_supported): the rows of floor(16 / C) consecutive nodes are one tile, as the host packs them for the matrix-core node
+ * kernels (stc_hip/ops.py _node_pack) -- whose backward (stc_bdg_node_bwd_f32 on a block-diagonal category graph, dTc = NULL) leaves dT_c
+ * to this entry point.  Z[n] (rows, L) for n < Ks with rows = nodes * C (any node count: the last tile may hold fewer), L in {20, 32}, columns >= Lw
  * are padding; W (Ks * Ks * Lw, Ho), Ho in {16, 32}; dY (rows, Ho); dTc (Ks, C, C) is WRITTEN (dTc[0] = 0: T_0 = I is a constant, as in
  * stc_bdg_node_bwd_f32).  Fixed-order sums: bitwise reproducible.
  * workspace: stc_mix_dt_workspace_bytes(Ks), 16-byte aligned. */

@@ -391,14 +391,14 @@ class EmulatedKernels:
     # ---- stc_mix_dt_f32: the category graph's gradient through one BDG_Dif for few categories (what the packed matrix-core backward leaves out)
     @staticmethod
     def mix_dT_supported(Ks, Kc, Cc, L, Ho) -> bool:
-        return Ks == Kc and 1 <= Ks <= 3 and 1 <= Cc <= 16 and 16 % Cc == 0 and L in (20, 32) and Ho in (16, 32)
+        return Ks == Kc and 1 <= Ks <= 3 and 1 <= Cc <= 16 and L in (20, 32) and Ho in (16, 32)
 
     def mix_dT(self, Zs, W, dY, dTc):
         Ks = len(Zs)
         R, C, L = Zs[0].shape
         Ho = W.shape[1]
         Lw = W.shape[0] // (Ks * Ks)
-        assert (R * C) % 16 == 0 and self.mix_dT_supported(Ks, Ks, C, L, Ho)
+        assert self.mix_dT_supported(Ks, Ks, C, L, Ho)
         Wv = W.view(Ks, Ks, Lw, Ho)
         dTc[0].zero_()                                                # T_0 = I is a constant of the Chebyshev stack
         for c in range(1, Ks):

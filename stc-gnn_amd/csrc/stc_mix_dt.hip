@@ -3,9 +3,10 @@
 //
 //     dT_c[p, d] = sum_r sum_o U_c[r, p, o] * dY[r, d, o],      U_c[r] = sum_n Z_n[r] . W[(n, c, :), :]      (r: nodes; p, d: categories)
 //
-// The matrix-core node backward (csrc/stc_node_mfma.hip) leaves dT_c to its caller.  With C | 16 the rows of 16 / C consecutive nodes are one
-// tile of 16 rows (stc_hip/ops.py _node_pack): U_c of a tile is a 16 x (Ks L) x Ho product, its contribution to dT_c a 16 x Ho x 16 one whose
-// DIAGONAL C x C blocks are the nodes' -- the off-diagonal ones pair rows of different nodes and are dropped by the final sum.  As library
+// The matrix-core node backward (csrc/stc_node_mfma.hip) leaves dT_c to its caller.  The rows of floor(16 / C) consecutive nodes are one
+// tile of rpt = floor(16 / C) C <= 16 rows (stc_hip/ops.py _node_pack): U_c of a tile is a 16 x (Ks L) x Ho product, its contribution to dT_c a
+// 16 x Ho x 16 one whose DIAGONAL C x C blocks are the nodes' -- the off-diagonal ones pair rows of different nodes and are dropped by the
+// final sum; lanes past the tile's rows read its last row of Z (never used) and zeros of dY.  As library
 // GEMMs (Q_n = Z_n^T . dY over the rows, then a contraction with W) this took two launches of 41 us at BASELINE configuration 2's shape, where
 // the node backward itself takes 22.
 //
@@ -29,7 +30,7 @@ struct DtArgs {
     const float* W;                         // (Ks * Kc * Lw, Ho)
     const float* dY;                        // (tiles, 16, Ho)
     float* partial;                         // (grid, Kc, 16, 16)
-    int tiles, Lw;
+    int tiles, Lw, rpt, rows;               // rpt: rows per tile (<= 16; tiles are rpt rows apart); the last tile may hold fewer nodes
 };
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
@@ -71,12 +72,15 @@ __global__ __launch_bounds__(DT_THREADS) void mix_dt_kernel(DtArgs a) {
     for (int c = 0; c < K; ++c) dT[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int tl = blockIdx.x * DT_WAVES + wave; tl < a.tiles; tl += gridDim.x * DT_WAVES) {
+        const int lim = min(a.rpt, a.rows - tl * a.rpt);         // rows of this tile (the last one: what is left)
+        const int jr = j < lim ? j : lim - 1;
+        const bool live = j < lim;
         // A operands: this lane's row of every slab; B operands of the second product: its run of the dY row
         f32x4 zv[K][N16 > 0 ? N16 : 1];
         float zr[K][NREM > 0 ? NREM : 1];
 #pragma unroll
         for (int n = 0; n < K; ++n) {
-            const float* row = a.Z[n] + ((size_t)tl * 16 + j) * L;
+            const float* row = a.Z[n] + ((size_t)tl * a.rpt + jr) * L;
 #pragma unroll
             for (int m = 0; m < N16; ++m) zv[n][m] = *reinterpret_cast<const f32x4*>(row + 16 * m + 4 * kq);
 #pragma unroll
@@ -84,9 +88,12 @@ __global__ __launch_bounds__(DT_THREADS) void mix_dt_kernel(DtArgs a) {
         }
         f32x4 dyv[RUN / 4];
         {
-            const float* row = a.dY + ((size_t)tl * 16 + j) * HO + RUN * kq;
+            const float* row = a.dY + ((size_t)tl * a.rpt + jr) * HO + RUN * kq;
 #pragma unroll
-            for (int q = 0; q < RUN / 4; ++q) dyv[q] = *reinterpret_cast<const f32x4*>(row + 4 * q);
+            for (int q = 0; q < RUN / 4; ++q) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(row + 4 * q);
+                dyv[q] = live ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
         // U_c = sum_n Z_n . W_{n,c}: accumulator layout (rows 4 kq + r, column 16 ot + j) -> the wave's LDS tile in row layout
 #pragma unroll
@@ -162,14 +169,15 @@ extern "C" size_t stc_mix_dt_workspace_bytes(int32_t Ks) {
 }
 
 extern "C" int stc_mix_dt_supported(int32_t Ks, int32_t Kc, int32_t C, int32_t L, int32_t Ho) {
-    return Ks == Kc && Ks >= 1 && Ks <= DT_MAX_K && C >= 1 && C <= 16 && 16 % C == 0 && (L == 20 || L == 32) && (Ho == 16 || Ho == 32);
+    return Ks == Kc && Ks >= 1 && Ks <= DT_MAX_K && C >= 1 && C <= 16 && (L == 20 || L == 32) && (Ho == 16 || Ho == 32);
 }
 
 extern "C" int stc_mix_dt_f32(const float* const* Z, int32_t Ks, const float* W, const float* dY, float* dTc, void* workspace,
                               size_t workspace_bytes, int64_t rows, int32_t C, int32_t L, int32_t Lw, int32_t Ho, void* stream) {
     STC_REQUIRE(stc_mix_dt_supported(Ks, Ks, C, L, Ho), STC_EUNSUPPORTED,
-                "stc_mix_dt_f32: Ks = Kc in 1..3, C dividing 16, L in (20, 32), Ho in (16, 32); got Ks=%d C=%d L=%d Ho=%d", Ks, C, L, Ho);
-    STC_REQUIRE(rows >= 0 && rows % 16 == 0 && rows < (1ll << 31), STC_EINVAL, "stc_mix_dt_f32: %lld rows (whole tiles of 16 rows)", (long long)rows);
+                "stc_mix_dt_f32: Ks = Kc in 1..3, C in 1..16, L in (20, 32), Ho in (16, 32); got Ks=%d C=%d L=%d Ho=%d", Ks, C, L, Ho);
+    const int rpt = (16 / C) * C;                  // rows per tile: floor(16 / C) whole nodes
+    STC_REQUIRE(rows >= 0 && rows % C == 0 && rows < (1ll << 31), STC_EINVAL, "stc_mix_dt_f32: %lld rows are not whole nodes of %d categories", (long long)rows, C);
     STC_REQUIRE(Lw >= 1 && Lw <= L, STC_EINVAL, "stc_mix_dt_f32: Lw=%d outside 1..L=%d", Lw, L);
     STC_REQUIRE(dTc, STC_EINVAL, "stc_mix_dt_f32: null dTc");
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -185,8 +193,10 @@ extern "C" int stc_mix_dt_f32(const float* const* Z, int32_t Ks, const float* W,
     a.W = W;
     a.dY = dY;
     a.partial = static_cast<float*>(workspace);
-    a.tiles = (int)(rows / 16);
+    a.tiles = (int)((rows + rpt - 1) / rpt);
     a.Lw = Lw;
+    a.rpt = rpt;
+    a.rows = (int)rows;
     const int want = (a.tiles + DT_WAVES - 1) / DT_WAVES;
     const int grid = want < DT_MAX_GRID ? want : DT_MAX_GRID;
     int rc = STC_EUNSUPPORTED;

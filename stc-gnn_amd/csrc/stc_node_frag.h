@@ -102,6 +102,23 @@ struct DyFrag {     // one node's dY in both register layouts
                 v[kb][hb] = f32x4{x.x, x.y, x.z, x.w};
             }
     }
+    // nodes of Cr <= 16 rows (NRB = 1; rows of the node start at r0): rows past the node's enter as zeros
+    __device__ __forceinline__ void load_cr(const float* __restrict__ dY, size_t r0, int Cr, int j, int q) {
+        static_assert(NRB == 1, "ragged row tiles: one row block");
+        constexpr int Ho = 16 * HB;
+        const int jr = j < Cr ? j : Cr - 1;
+#pragma unroll
+        for (int hb = 0; hb < HB; ++hb) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int row = 4 * q + t;
+                const float val = dY[(r0 + (row < Cr ? row : Cr - 1)) * Ho + 16 * hb + j];
+                d[0][hb][t] = row < Cr ? val : 0.f;
+            }
+            const float4 x = *reinterpret_cast<const float4*>(dY + (r0 + jr) * Ho + 16 * hb + 4 * q);
+            v[0][hb] = j < Cr ? f32x4{x.x, x.y, x.z, x.w} : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
 };
 
 // Prologue of the gates convolution's backward (autograd of reference STC_GNN.py:71-75, hidden 16): instead of

@@ -55,6 +55,20 @@ struct ZFrag {      // one node's A operand: this lane's row of every slab / row
                 for (int u = 0; u < NREM; ++u) r[n][rb][u] = row[16 * N16 + 4 * u + q];
             }
     }
+    // FEW categories (NRB = 1, Cr <= 16 rows per node): the node's rows start at r0 = node * Cr; lanes past the node's rows read its last row
+    // (finite; what they produce is never stored and meets zero rows / columns of T_c)
+    __device__ __forceinline__ void load_cr(const ZPtrs& Z, size_t r0, int jr, int q) {
+        static_assert(NRB == 1, "ragged row tiles: one row block");
+        constexpr int L = 4 * LQ;
+#pragma unroll
+        for (int n = 0; n < K; ++n) {
+            const float* row = Z.p[n] + (r0 + jr) * L;
+#pragma unroll
+            for (int m = 0; m < N16; ++m) v4[n][0][m] = *reinterpret_cast<const float4*>(row + 16 * m + 4 * q);
+#pragma unroll
+            for (int u = 0; u < NREM; ++u) r[n][0][u] = row[16 * N16 + 4 * u + q];
+        }
+    }
     // value this lane contributes at k-step s of slab n, row block rb (s is a compile-time constant after unrolling)
     __device__ __forceinline__ float at(int n, int rb, int s) const {
         if (s < 4 * N16) {
@@ -68,9 +82,13 @@ struct ZFrag {      // one node's A operand: this lane's row of every slab / row
 template <int NRB, int HB, int K, int LQ, int EPI>
 __global__ __launch_bounds__(MF_THREADS, ((NRB * K * LQ <= 32) ? 3 : 2)) void node_fwd_mfma_kernel(
     ZPtrs Z, const float* __restrict__ Tc, const float* __restrict__ W, const float* __restrict__ bias,
-    float* __restrict__ Y, int nodes, int Lw, FwdEpi epi) {
+    float* __restrict__ Y, int nodes, int Lw, FwdEpi epi, int Cr) {
     constexpr int C = 16 * NRB, Ho = 16 * HB, L = 4 * LQ, NCB = K * HB;
     constexpr int HID = 16;            // hidden width the fused epilogues are built for
+    // RAG: the plain node kernel at NRB = 1 takes nodes of Cr <= 16 categories (rows of a node start at node * Cr; T_c is (Cr, Cr) and enters the
+    // fragments zero padded): every C <= 16 runs here, and the host packs 16 / C nodes of few categories into one such node (stc_hip/ops.py)
+    constexpr bool RAG = NRB == 1 && EPI == EPI_NONE;
+    const int CR = RAG ? Cr : C;
     static_assert(EPI == EPI_NONE || (EPI == EPI_GATES && HB == 2) || (EPI == EPI_BLEND && HB == 1), "epilogue needs hidden = 16");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Wf = smem;                              // [K][LQ][NCB][64]   B fragments of the projection
@@ -93,7 +111,8 @@ __global__ __launch_bounds__(MF_THREADS, ((NRB * K * LQ <= 32) ? 3 : 2)) void no
         const int kb = t % NRB; t /= NRB;
         const int rb = t % NRB, c1 = t / NRB;
         // A[i = d][k = c'] = T_c[c'][d]  with c' = 16kb + 4q + st, d = 16rb + i
-        Tf[idx] = Tc[(size_t)(c1 + 1) * C * C + (16 * kb + 4 * (ll >> 4) + st) * C + 16 * rb + (ll & 15)];
+        const int kk = 16 * kb + 4 * (ll >> 4) + st, dd = 16 * rb + (ll & 15);
+        Tf[idx] = (kk < CR && dd < CR) ? Tc[(size_t)(c1 + 1) * CR * CR + kk * CR + dd] : 0.f;
     }
     __syncthreads();
 
@@ -105,10 +124,15 @@ __global__ __launch_bounds__(MF_THREADS, ((NRB * K * LQ <= 32) ? 3 : 2)) void no
 
     int node = blockIdx.x * MF_WAVES + wave;
     ZFrag<NRB, K, LQ> cur, nxt;
-    if (node < nodes) cur.load(Z, node, j, q);
+    const int jr = j < CR ? j : CR - 1;
+    auto load_node = [&](ZFrag<NRB, K, LQ>& z, int nd) {
+        if constexpr (RAG) z.load_cr(Z, (size_t)nd * CR, jr, q);
+        else z.load(Z, nd, j, q);
+    };
+    if (node < nodes) load_node(cur, node);
     while (node < nodes) {
         const int next_node = node + nw;
-        if (next_node < nodes) nxt.load(Z, next_node, j, q);     // software prefetch: lands while this node computes
+        if (next_node < nodes) load_node(nxt, next_node);        // software prefetch: lands while this node computes
         // epilogue operands in accumulator layout (row 16rb + 4q + r, column j): needed only after the MFMAs
         float hv[NRB][4], uv[NRB][4];
         if (EPI != EPI_NONE) {
@@ -166,7 +190,7 @@ __global__ __launch_bounds__(MF_THREADS, ((NRB * K * LQ <= 32) ? 3 : 2)) void no
                 for (int hb = 0; hb < HB; ++hb)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        Y[((size_t)node * C + 16 * rb + 4 * q + r) * Ho + 16 * hb + j] = acc[rb][hb][r] + bv[hb];
+                        if (!RAG || 4 * q + r < CR) Y[((size_t)node * CR + 16 * rb + 4 * q + r) * Ho + 16 * hb + j] = acc[rb][hb][r] + bv[hb];
         } else if (EPI == EPI_GATES) {
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb)
@@ -222,9 +246,11 @@ struct BwdPlan {
 template <int NRB, int HB, int K, int LQ, int PRO>
 __global__ __launch_bounds__(MF_THREADS, (BwdPlan<NRB, HB, K, LQ>::prefetch ? 2 : 1)) void node_bwd_mfma_kernel(
     ZPtrs Z, const float* __restrict__ Tc, const float* __restrict__ W, const float* __restrict__ dY,
-    DZPtrs dZ, float* __restrict__ partial, int nodes, int want_db, int Lw, BwdPro pro) {
+    DZPtrs dZ, float* __restrict__ partial, int nodes, int want_db, int Lw, BwdPro pro, int Cr) {
     constexpr int C = 16 * NRB, Ho = 16 * HB, L = 4 * LQ, LB = (L + 15) / 16;
     constexpr bool PF = BwdPlan<NRB, HB, K, LQ>::prefetch && PRO == PRO_NONE;
+    constexpr bool RAG = NRB == 1 && PRO == PRO_NONE;      // nodes of Cr <= 16 categories, as in the forward kernel
+    const int CR = RAG ? Cr : C;
     constexpr int nTf = (K - 1) * NRB * NRB * 4 * 64;
     constexpr int nWf = K * LB * K * HB * 4 * 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -238,7 +264,8 @@ __global__ __launch_bounds__(MF_THREADS, (BwdPlan<NRB, HB, K, LQ>::prefetch ? 2 
         const int st = t & 3; t >>= 2;
         const int kb = t % NRB; t /= NRB;
         const int rb = t % NRB, c1 = t / NRB;
-        TfA[idx] = Tc[(size_t)(c1 + 1) * C * C + (16 * rb + (ll & 15)) * C + 16 * kb + 4 * (ll >> 4) + st];
+        const int rr = 16 * rb + (ll & 15), cc = 16 * kb + 4 * (ll >> 4) + st;
+        TfA[idx] = (rr < CR && cc < CR) ? Tc[(size_t)(c1 + 1) * CR * CR + rr * CR + cc] : 0.f;
     }
     for (int idx = tid; idx < nWf; idx += MF_THREADS) {
         const int ll = idx & 63;
@@ -270,13 +297,17 @@ __global__ __launch_bounds__(MF_THREADS, (BwdPlan<NRB, HB, K, LQ>::prefetch ? 2 
 
     int node = blockIdx.x * MF_WAVES + wave;
     DyFrag<NRB, HB> g, gn;
-    if (PF && node < nodes) g.load(dY, node, j, q);
+    auto load_dy = [&](DyFrag<NRB, HB>& f, int nd) {
+        if constexpr (RAG) f.load_cr(dY, (size_t)nd * CR, CR, j, q);      // rows past the node's: zeros (they meet every product as a factor)
+        else f.load(dY, nd, j, q);
+    };
+    if (PF && node < nodes) load_dy(g, node);
     while (node < nodes) {
         const int next_node = node + nw;
-        const size_t r0 = (size_t)node * C;
+        const size_t r0 = (size_t)node * CR;
         if constexpr (PRO == PRO_GATES || PRO == PRO_GATES_CAND) load_gates_grad<NRB, HB, L, PRO == PRO_GATES_CAND>(g, pro, node, j, q);
         else if constexpr (PRO == PRO_BLEND) load_blend_grad<NRB>(g, pro, node, j, q);
-        else if (!PF) g.load(dY, node, j, q);
+        else if (!PF) load_dy(g, node);
         // this node's Z columns for the dW product (needed last: in flight during the Q and dZ phases)
         float za[K][LB][NRB][4];
 #pragma unroll
@@ -289,11 +320,12 @@ __global__ __launch_bounds__(MF_THREADS, (BwdPlan<NRB, HB, K, LQ>::prefetch ? 2 
                 for (int kb = 0; kb < NRB; ++kb)
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        const float zv = col[(size_t)(16 * kb + 4 * q + t) * L];
+                        const int zrow = 16 * kb + 4 * q + t;        // (RAG: rows past the node's read its last row -- finite, and Q_c is zero there)
+                        const float zv = col[(size_t)(RAG && zrow >= CR ? CR - 1 : zrow) * L];
                         za[n][lb][kb][t] = ok ? zv : 0.f;
                     }
             }
-        if (PF && next_node < nodes) gn.load(dY, next_node, j, q);
+        if (PF && next_node < nodes) load_dy(gn, next_node);
         if (PF) __builtin_amdgcn_sched_barrier(0);
         const int lo = opaque(lane);
 
@@ -344,7 +376,7 @@ __global__ __launch_bounds__(MF_THREADS, (BwdPlan<NRB, HB, K, LQ>::prefetch ? 2 
                                 z[rb] = mfma16(wf, qv, z[rb]);
                             }
                         }
-                if (16 * lb + 4 * q < L) {
+                if (16 * lb + 4 * q < L && (!RAG || j < CR)) {
 #pragma unroll
                     for (int rb = 0; rb < NRB; ++rb)
                         *reinterpret_cast<float4*>(dZ.p[n] + (r0 + 16 * rb + j) * L + 16 * lb + 4 * q) =
@@ -397,7 +429,7 @@ __global__ __launch_bounds__(MF_THREADS, (BwdPlan<NRB, HB, K, LQ>::prefetch ? 2 
 
 template <int NRB, int HB, int K, int LQ, int EPI = EPI_NONE>
 int launch_fwd(const float* const* Z, const float* Tc, const float* W, const float* bias, float* Y,
-               long long nodes, int Lw, hipStream_t stream, FwdEpi epi = FwdEpi{}) {
+               long long nodes, int Lw, hipStream_t stream, FwdEpi epi = FwdEpi{}, int Cr = 16 * NRB) {
     constexpr int NCB = K * HB;
     const size_t lds = (size_t)(K * LQ * NCB * 64 + (K - 1) * NRB * NRB * 4 * 64) * sizeof(float);
     if (lds > stc::kMaxLdsBytes) return STC_NOT_HANDLED;
@@ -408,14 +440,14 @@ int launch_fwd(const float* const* Z, const float* Tc, const float* W, const flo
     for (int n = 0; n < K; ++n) zp.p[n] = Z[n];
     const long long want = (nodes + MF_WAVES - 1) / MF_WAVES;
     const int grid = (int)(want < resident ? want : resident);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(MF_THREADS), lds, stream, zp, Tc, W, bias, Y, (int)nodes, Lw, epi);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(MF_THREADS), lds, stream, zp, Tc, W, bias, Y, (int)nodes, Lw, epi, Cr);
     STC_LAUNCH_CHECK("node_fwd_mfma launch");
     return STC_OK;
 }
 
 template <int NRB, int HB, int K, int LQ, int PRO = PRO_NONE>
 int launch_bwd(const float* const* Z, const float* Tc, const float* W, const float* dY, float* const* dZ,
-               float* partial, int* n_partials, int want_db, long long nodes, int Lw, hipStream_t stream, BwdPro pro = BwdPro{}) {
+               float* partial, int* n_partials, int want_db, long long nodes, int Lw, hipStream_t stream, BwdPro pro = BwdPro{}, int Cr = 16 * NRB) {
     constexpr int L = 4 * LQ, Ho = 16 * HB, LB = (L + 15) / 16, nW = K * K * L * Ho;
     const size_t frag = (size_t)((K - 1) * NRB * NRB * 4 * 64 + K * LB * K * HB * 4 * 64);
     const size_t slabs = (size_t)MF_WAVES * (nW + Ho);
@@ -430,7 +462,7 @@ int launch_bwd(const float* const* Z, const float* Tc, const float* W, const flo
     const long long want = (nodes + MF_WAVES - 1) / MF_WAVES;
     int grid = resident < MF_BWD_MAX_GRID ? resident : MF_BWD_MAX_GRID;
     if (want < grid) grid = (int)want;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(MF_THREADS), lds, stream, zp, Tc, W, dY, dzp, partial, (int)nodes, want_db, Lw, pro);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(MF_THREADS), lds, stream, zp, Tc, W, dY, dzp, partial, (int)nodes, want_db, Lw, pro, Cr);
     STC_LAUNCH_CHECK("node_bwd_mfma launch");
     *n_partials = grid;
     return STC_OK;
@@ -459,9 +491,12 @@ bool fast_path_shape(int Ks, int Kc, int C, int L, int Ho, long long nodes) {
 
 int stc_node_fwd_mfma(const float* const* Z, int Ks, const float* Tc, int Kc, const float* W, const float* bias,
                       float* Y, long long nodes, int C, int L, int Lw, int Ho, hipStream_t stream) {
+    // few categories (1 <= C < 16): the one-row-block kernels on nodes of Cr = C rows (RAG)
+    const int Cr = C;
+    if (C >= 1 && C < 16) C = 16;
     if (!fast_path_shape(Ks, Kc, C, L, Ho, nodes)) return STC_NOT_HANDLED;
     if (!all_aligned16(Z, Ks) || !stc::aligned16(Y)) return STC_NOT_HANDLED;
-#define FWD_CALL(a, b, c, d) launch_fwd<a, b, c, d>(Z, Tc, W, bias, Y, nodes, Lw, stream)
+#define FWD_CALL(a, b, c, d) launch_fwd<a, b, c, d>(Z, Tc, W, bias, Y, nodes, Lw, stream, FwdEpi{}, Cr)
     STC_MF_DISPATCH(FWD_CALL)
 #undef FWD_CALL
     return STC_NOT_HANDLED;
@@ -548,11 +583,13 @@ int stc_node_bwd_mfma_max_partials() { return MF_BWD_MAX_GRID; }
 int stc_node_bwd_mfma(const float* const* Z, int Ks, const float* Tc, int Kc, const float* W, const float* dY,
                       float* const* dZ, float* partial, int* n_partials, int want_db,
                       long long nodes, int C, int L, int Lw, int Ho, hipStream_t stream) {
+    const int Cr = C;
+    if (C >= 1 && C < 16) C = 16;
     if (!fast_path_shape(Ks, Kc, C, L, Ho, nodes)) return STC_NOT_HANDLED;
     if (!all_aligned16(Z, Ks) || !stc::aligned16(dY)) return STC_NOT_HANDLED;
     for (int n = 0; n < Ks; ++n)
         if (!stc::aligned16(dZ[n])) return STC_NOT_HANDLED;
-#define BWD_CALL(a, b, c, d) launch_bwd<a, b, c, d>(Z, Tc, W, dY, dZ, partial, n_partials, want_db, nodes, Lw, stream)
+#define BWD_CALL(a, b, c, d) launch_bwd<a, b, c, d>(Z, Tc, W, dY, dZ, partial, n_partials, want_db, nodes, Lw, stream, BwdPro{}, Cr)
     STC_MF_DISPATCH(BWD_CALL)
 #undef BWD_CALL
     return STC_NOT_HANDLED;

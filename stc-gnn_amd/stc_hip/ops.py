@@ -98,19 +98,21 @@ def _spatial_slabs(X, fwd_val, op: SpatialOperand, Ks: int):
 
 
 def _node_pack(X: torch.Tensor, Tc: torch.Tensor, Ks: int, Ho: int) -> int:
-    """How many nodes one row tile of the matrix-core node kernels takes when the categories are few: the kernels (csrc/stc_node_mfma.hip) want
-    C in {16, 32, 64}, and the node kernel is node-local (reference STC_GNN.py:38-45: the 2-mode product and the projection touch one node's
-    C x L rows), so 16 / C consecutive nodes ARE one node of 16 categories whose category graph is block-diagonal -- same rows in memory,
-    T_c repeated on the diagonal (``_block_diag``).  BASELINE configuration 2 (C = 8: two nodes per tile) otherwise runs the generic vector
-    kernel: 35 / 181 us forward / backward for 8 / ~25 on the matrix cores.  1: no packing (C does not divide 16, an odd row count, a shape
-    the matrix-core kernels do not take, bf16 rows)."""
+    """How many nodes one row tile of the matrix-core node kernels takes when the categories are few (C <= 16); 0: the route does not apply.
+    The fp32-MFMA node kernels (csrc/stc_node_mfma.hip) work on tiles of 16 category rows and take a node of Cr <= 16 rows per tile; the node
+    kernel is node-local (reference STC_GNN.py:38-45: the 2-mode product and the projection touch one node's C x L rows), so floor(16 / C)
+    consecutive nodes ARE one node of p C categories whose category graph is block-diagonal -- same rows in memory, T_c repeated on the
+    diagonal (``_block_diag``).  BASELINE configuration 2 (C = 8: two nodes per tile) otherwise runs the generic vector kernel: 35 / 181 us
+    forward / backward for 13 / 32 + 8 on the matrix cores; the SF shape's C = 5 packs three nodes into 15 rows.  1: one node per tile (an
+    odd row count, or C > 8); 0: C > 16, a shape the matrix-core kernels do not take, bf16 rows, the switch off."""
     B, N, C, L = X.shape
-    if not _NODE_PACK or X.dtype != torch.float32 or C >= 16 or 16 % C or (B * N) % (16 // C):
-        return 1
+    if not _NODE_PACK or X.dtype != torch.float32 or C > 16:
+        return 0
     Kc = Tc.shape[0]
-    if Ks != Kc or not 1 <= Ks <= 3 or Ho not in (16, 32) or L not in (20, 32):      # = fast_path_shape of csrc/stc_node_mfma.hip at C = 16
-        return 1
-    return 16 // C
+    if Ks != Kc or not 1 <= Ks <= 3 or Ho not in (16, 32) or L not in (20, 32):      # = fast_path_shape of csrc/stc_node_mfma.hip
+        return 0
+    p = 16 // C
+    return p if (B * N) % p == 0 else 1
 
 
 def _block_diag(Tc: torch.Tensor, p: int) -> torch.Tensor:
@@ -128,7 +130,7 @@ def _bdg_forward(X, W, b, Tc, fwd_val, op: SpatialOperand, Ks: int):
     Ho = W.shape[1]
     Zs = _spatial_slabs(X, fwd_val, op, Ks)
     Y = X.new_empty(B, N, C, Ho)
-    p = _node_pack(X, Tc, Ks, Ho)
+    p = max(1, _node_pack(X, Tc, Ks, Ho))
     R = B * N // p
     k.bdg_node_fwd([z.view(R, p * C, L) for z in Zs], Tc if p == 1 else _block_diag(Tc, p), W, b, Y.view(R, p * C, Ho))
     return Y, Zs
@@ -169,10 +171,11 @@ def _bdg_backward_slabs(dY, Zs, W, Tc, op: SpatialOperand, Ks: int, has_bias: bo
     else:
         dY = _c(dY)
         p = _node_pack(Zs[0], Tc, Ks, Ho)
-        if p > 1:
-            # few categories: 16 / C nodes per row tile of the matrix-core kernel (``_node_pack``); that kernel leaves dT_c to the caller
+        if p >= 1:
+            # few categories: floor(16 / C) nodes per row tile of the matrix-core kernel (``_node_pack``); that kernel leaves dT_c to the caller
             R = B * N // p
-            k.bdg_node_bwd([z.view(R, p * C, L) for z in Zs], _block_diag(Tc, p), W, dY.view(R, p * C, Ho), [z.view(R, p * C, L) for z in dZ], dW, db, None)
+            k.bdg_node_bwd([z.view(R, p * C, L) for z in Zs], Tc if p == 1 else _block_diag(Tc, p), W, dY.view(R, p * C, Ho),
+                           [z.view(R, p * C, L) for z in dZ], dW, db, None)
             if need_Tc:
                 dTc = _mix_grad(Zs, dY, W, Tc.shape[0])
         else:

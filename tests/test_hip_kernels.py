@@ -1028,6 +1028,12 @@ def test_mixed_fusion(hip, n, needs_dA):
     (48, 1, 20, 17, 32, 3),
     (5, 16, 32, 32, 32, 2),      # C = 16: one node per tile
     (2, 8, 32, 32, 16, 1),       # K = 1: T_0 = I only, zeros
+    (3000, 5, 20, 17, 32, 3),    # the SF shape's C = 5: three nodes = 15 rows per tile
+    (33, 5, 32, 32, 16, 2),
+    (14, 7, 32, 32, 32, 2),      # two nodes = 14 rows per tile
+    (9, 11, 20, 18, 16, 2),      # one node of 11 rows per tile
+    (3200, 5, 32, 32, 16, 3),    # 3 200 nodes in tiles of three: the last tile holds two
+    (7, 8, 32, 32, 32, 2),       # an odd node count at two nodes per tile
 ])
 def test_mix_dT_for_few_categories(hip, nodes, C, L, Lw, Ho, K):
     """stc_mix_dt_f32 (the category graph's gradient the packed matrix-core node backward leaves to its caller) against its twin, and the
@@ -1053,7 +1059,6 @@ def test_mix_dT_for_few_categories(hip, nodes, C, L, Lw, Ho, K):
 
 def test_mix_dT_rejects_what_it_does_not_take(hip):
     from stc_hip._lib import StcError
-    assert not hip.mix_dT_supported(2, 2, 5, 32, 32) and not hip.mix_dT_supported(2, 3, 8, 32, 32) and not hip.mix_dT_supported(2, 2, 8, 24, 32)
-    Z = [torch.zeros(3, 8, 32).cuda() for _ in range(2)]          # 24 rows: not whole tiles
-    with pytest.raises(StcError, match='whole tiles'):
-        hip.mix_dT(Z, torch.zeros(128, 32).cuda(), torch.zeros(3, 8, 32).cuda(), torch.zeros(2, 8, 8).cuda())
+    assert not hip.mix_dT_supported(2, 2, 17, 32, 32) and not hip.mix_dT_supported(2, 3, 8, 32, 32) and not hip.mix_dT_supported(2, 2, 8, 24, 32)
+    with pytest.raises(StcError, match='unsupported|Ks = Kc'):
+        hip.mix_dT([torch.zeros(4, 17, 32).cuda() for _ in range(2)], torch.zeros(128, 32).cuda(), torch.zeros(4, 17, 32).cuda(), torch.zeros(2, 17, 17).cuda())

@@ -392,11 +392,12 @@ def test_bdg_dif_at_baseline_configuration_2(K):
         _close(t, w.float().to(DEV), GRAD, f'cfg2 K={K} {name}')
 
 
-@pytest.mark.parametrize('C,N,K,L,Ho', [(8, 50, 2, 32, 32), (4, 36, 3, 32, 16), (2, 24, 2, 20, 32), (8, 25, 2, 32, 32), (5, 20, 2, 32, 32)])
+@pytest.mark.parametrize('C,N,K,L,Ho', [(8, 50, 2, 32, 32), (4, 36, 3, 32, 16), (2, 24, 2, 20, 32), (8, 25, 2, 32, 32), (5, 20, 2, 32, 32), (5, 100, 3, 20, 32),
+                                        (7, 13, 2, 32, 16), (12, 9, 3, 32, 32), (16, 10, 2, 20, 16)])
 def test_bdg_dif_packs_few_categories_into_matrix_core_tiles(monkeypatch, C, N, K, L, Ho):
-    """Few categories (C | 16): 16 / C consecutive nodes run as ONE node of 16 categories with a block-diagonal category graph on the
-    matrix-core node kernels (``ops._node_pack``; reference STC_GNN.py:38-45 is node-local), dT_c from ``ops._mix_grad``.  Against the
-    float64 oracle, and equal (to rounding) to the unpacked launches; an odd row count (N = 25, one sample) and C = 5 are not packed."""
+    """Few categories (C <= 16): floor(16 / C) consecutive nodes run as ONE node of up to 16 categories with a block-diagonal category graph
+    on the matrix-core node kernels (``ops._node_pack``; reference STC_GNN.py:38-45 is node-local), dT_c from ``ops._mix_grad``.  Against the
+    float64 oracle, and equal (to rounding) to the unpacked launches; an odd row count (N = 25, one sample) is not packed."""
     B = 1 if N == 25 else 3
     gen = torch.Generator().manual_seed(C * 100 + K)
     X = torch.randn(B, N, C, L, generator=gen)
@@ -423,7 +424,7 @@ def test_bdg_dif_packs_few_categories_into_matrix_core_tiles(monkeypatch, C, N, 
         return Y.detach(), Xd.grad[..., :Lw], Gsd.grad, Gcd.grad, layer.W.grad, layer.b.grad
 
     got = run()
-    expect = 16 // C if (16 % C == 0 and (B * N) % (16 // C) == 0) else 1
+    expect = 16 // C if (B * N) % (16 // C) == 0 else 1               # (C = 5: three nodes = 15 rows per tile; an odd row count: one)
     assert packs and set(packs) == {expect}
     names = ('Y', 'dX', 'dGs', 'dGc', 'dW', 'db')
     for name, t, w in zip(names, got, (want.detach(), *(v.grad for v in want_in))):
