@@ -267,6 +267,36 @@ def test_learned_graphs_on_the_small_graph_kernels(dev, monkeypatch, N, C, layer
             _close(got[n], per_cell[n], 5e-6, f'learned small-graph d{n} vs the per-cell path', gpu_tol=1e-5)
 
 
+@pytest.mark.parametrize('N,C,K,layers,T,horizon,seed', [(12, 3, 2, 2, 4, 2, 7), (20, 5, 3, 1, 3, 3, 3), (10, 8, 2, 2, 3, 2, 13), (9, 4, 3, 1, 3, 2, 3)])
+def test_learned_graphs_on_the_general_path_with_packed_node_kernels(dev, monkeypatch, N, C, K, layers, T, horizon, seed):
+    """The reference's FULL model with learned graphs on the GENERAL per-cell path (what learned graphs beyond the few-category cell kernels'
+    reach take, and every learned graph at Chebyshev order 3 -- ``Main.py -K 3``): its node kernels run few categories as packed tiles on the
+    matrix cores (``ops._node_pack``, asserted) and ``stc_mix_dt_f32`` forms dT_c.  Prediction and every gradient against the float64
+    oracle of the same model (STC_GNN.py:185-261)."""
+    packs = []
+    real = ops._node_pack
+    monkeypatch.setattr(ops, '_node_pack', lambda *a: packs.append(real(*a)) or packs[-1])
+    monkeypatch.setattr(ops, '_SMALL', False)
+    torch.manual_seed(seed)
+    model = M.STCGNN(N, C, K, K, 1, 16, layers, horizon).to(DEV)
+    X = (torch.rand(2, T, N, C) < 0.3).float()
+    As, Ac, Rw = torch.rand(N, N), torch.rand(C, C), torch.randn(2, horizon, N, C)
+    y = model(X_seq=X.to(DEV), As=As.to(DEV), Ac=Ac.to(DEV))
+    (y * Rw.to(DEV)).sum().backward()
+    assert packs and min(packs) >= 1 and max(packs) == (16 // C if (2 * N) % (16 // C) == 0 else 1)
+    sd = {k: v.detach().cpu().double().requires_grad_(True) for k, v in model.state_dict().items()}
+    want = O.stcgnn_forward(X.double(), As.double(), Ac.double(), sd, K, K, 16, layers, horizon)
+    (want * Rw.double()).sum().backward()
+    # the reference's own arithmetic (the oracle in float32) against float64: at order 3 the learned graphs' T_2 = 2 G^2 - I amplifies rounding, and
+    # fp32 itself is 1e-4 .. 1e-3 away on MGP_Gen's parameters for most draws -- the bound is 10x that noise where it exceeds the flat one
+    sd32 = {k: v.detach().cpu().float().requires_grad_(True) for k, v in model.state_dict().items()}
+    (O.stcgnn_forward(X, As, Ac, sd32, K, K, 16, layers, horizon) * Rw).sum().backward()
+    _close(y, want.detach().float().to(DEV), FWD, f'learned general-path yhat C={C} K={K}')
+    for n, p in model.named_parameters():
+        noise = rel_err(sd32[n].grad, sd[n].grad)
+        _close(p.grad, sd[n].grad.float().to(DEV), max(1e-5, 10 * noise), f'learned general-path d{n} C={C} K={K}', gpu_tol=max(2e-5, 10 * noise))
+
+
 def test_learned_graph_gradients_when_a_sets_cells_are_unevenly_spaced(monkeypatch):
     """``small._graph_gradients`` selects a parameter set's cells by (first, step) inside their width group; a schedule where they are NOT
     evenly spaced (STCGNN never builds one) takes the gathering fallback -- with every product's partials in the shared buffers.  Learned dense
