@@ -77,7 +77,8 @@ def cheby_dense(G: torch.Tensor, K: int) -> torch.Tensor:
 
 
 # ----------------------------------------------------------------------------- BDG_Dif
-_NODE_PACK = True        # few categories (C | 16): 16 / C nodes per row tile of the matrix-core node kernels (``_node_pack``; tests flip it)
+_NODE_PACK = True        # few categories (C <= 16): floor(16 / C) nodes per row tile of the matrix-core node kernels (``_node_pack``; tests flip it)
+_PACK_SPLIT_ROWS = 1 << 18   # rows from which a node count that the tile does not divide is worth a second launch for its remainder
 
 
 def _spatial_slabs(X, fwd_val, op: SpatialOperand, Ks: int):
@@ -103,8 +104,9 @@ def _node_pack(X: torch.Tensor, Tc: torch.Tensor, Ks: int, Ho: int) -> int:
     kernel is node-local (reference STC_GNN.py:38-45: the 2-mode product and the projection touch one node's C x L rows), so floor(16 / C)
     consecutive nodes ARE one node of p C categories whose category graph is block-diagonal -- same rows in memory, T_c repeated on the
     diagonal (``_block_diag``).  BASELINE configuration 2 (C = 8: two nodes per tile) otherwise runs the generic vector kernel: 35 / 181 us
-    forward / backward for 13 / 32 + 8 on the matrix cores; the SF shape's C = 5 packs three nodes into 15 rows.  1: one node per tile (an
-    odd row count, or C > 8); 0: C > 16, a shape the matrix-core kernels do not take, bf16 rows, the switch off."""
+    forward / backward for 13 / 32 + 8 on the matrix cores; the SF shape's C = 5 packs three nodes into 15 rows.  1: one node per tile
+    (C > 8, or a small node count that p does not divide); 0: C > 16, a shape the matrix-core kernels do not take, bf16 rows, the switch
+    off.  When p does not divide a LARGE node count the last (count mod p) nodes run one per tile in a second launch (``_packed_spans``)."""
     B, N, C, L = X.shape
     if not _NODE_PACK or X.dtype != torch.float32 or C > 16:
         return 0
@@ -112,7 +114,16 @@ def _node_pack(X: torch.Tensor, Tc: torch.Tensor, Ks: int, Ho: int) -> int:
     if Ks != Kc or not 1 <= Ks <= 3 or Ho not in (16, 32) or L not in (20, 32):      # = fast_path_shape of csrc/stc_node_mfma.hip
         return 0
     p = 16 // C
-    return p if (B * N) % p == 0 else 1
+    # a node count that p does not divide: the last nodes run one per tile in a launch of their own (``_packed_spans``) -- worth two more small
+    # launches only when the packed part is large (N = 50 176, C = 5, 8 samples: 38.8 -> 59.3 samples/s; the SF shape's 3 200 nodes at order 3
+    # with learned graphs: 10.1 ms with one node per tile, 11.2 with the split)
+    return p if (B * N) % p == 0 or B * N * C >= _PACK_SPLIT_ROWS else 1
+
+
+def _packed_spans(R: int, p: int):
+    """[(first node, node count, nodes per tile)]: the nodes that fill whole tiles of p, then the remainder one node per tile."""
+    main = R - R % p
+    return [(0, main, p)] + ([(main, R - main, 1)] if main < R else []) if main else [(0, R, 1)]
 
 
 def _block_diag(Tc: torch.Tensor, p: int) -> torch.Tensor:
@@ -131,8 +142,10 @@ def _bdg_forward(X, W, b, Tc, fwd_val, op: SpatialOperand, Ks: int):
     Zs = _spatial_slabs(X, fwd_val, op, Ks)
     Y = X.new_empty(B, N, C, Ho)
     p = max(1, _node_pack(X, Tc, Ks, Ho))
-    R = B * N // p
-    k.bdg_node_fwd([z.view(R, p * C, L) for z in Zs], Tc if p == 1 else _block_diag(Tc, p), W, b, Y.view(R, p * C, Ho))
+    R = B * N
+    for lo, n, q in _packed_spans(R, p):
+        k.bdg_node_fwd([z.view(R, C, L)[lo:lo + n].view(n // q, q * C, L) for z in Zs], Tc if q == 1 else _block_diag(Tc, q), W, b,
+                       Y.view(R, C, Ho)[lo:lo + n].view(n // q, q * C, Ho))
     return Y, Zs
 
 
@@ -173,9 +186,16 @@ def _bdg_backward_slabs(dY, Zs, W, Tc, op: SpatialOperand, Ks: int, has_bias: bo
         p = _node_pack(Zs[0], Tc, Ks, Ho)
         if p >= 1:
             # few categories: floor(16 / C) nodes per row tile of the matrix-core kernel (``_node_pack``); that kernel leaves dT_c to the caller
-            R = B * N // p
-            k.bdg_node_bwd([z.view(R, p * C, L) for z in Zs], Tc if p == 1 else _block_diag(Tc, p), W, dY.view(R, p * C, Ho),
-                           [z.view(R, p * C, L) for z in dZ], dW, db, None)
+            R = B * N
+            for i, (lo, n, q) in enumerate(_packed_spans(R, p)):
+                dW_i, db_i = (dW, db) if i == 0 else (torch.empty_like(dW), None if db is None else torch.empty_like(db))
+                k.bdg_node_bwd([z.view(R, C, L)[lo:lo + n].view(n // q, q * C, L) for z in Zs], Tc if q == 1 else _block_diag(Tc, q), W,
+                               dY.view(R, C, Ho)[lo:lo + n].view(n // q, q * C, Ho), [z.view(R, C, L)[lo:lo + n].view(n // q, q * C, L) for z in dZ],
+                               dW_i, db_i, None)
+                if i:                                                    # (the remainder's share of the parameter gradients)
+                    dW.add_(dW_i)
+                    if db is not None:
+                        db.add_(db_i)
             if need_Tc:
                 dTc = _mix_grad(Zs, dY, W, Tc.shape[0])
         else:
