@@ -126,6 +126,17 @@ def _packed_spans(R: int, p: int):
     return [(0, main, p)] + ([(main, R - main, 1)] if main < R else []) if main else [(0, R, 1)]
 
 
+def _cell_pack(k, R: int, C: int, Ks: int, Kc: int, L: int, h: int) -> int:
+    """Nodes per row tile for the FUSED cell kernels of the per-cell path (gate math in the node kernels' epilogues / prologues): 1 where
+    they take C itself, 16 / C where C divides 16 and the node count (the rows of 16 / C nodes are then exactly one tile: ``_node_pack``),
+    0 where neither holds (the composed sequence: node kernel, gate kernel, node kernel, blend kernel)."""
+    if k.cell_fused_supported(Ks, Kc, C, L, h):
+        return 1
+    if _NODE_PACK and C < 16 and 16 % C == 0 and R % (16 // C) == 0 and k.cell_fused_supported(Ks, Kc, 16, L, h):
+        return 16 // C
+    return 0
+
+
 def _block_diag(Tc: torch.Tensor, p: int) -> torch.Tensor:
     """(Kc, C, C) -> (Kc, pC, pC) with T_c on the diagonal blocks: the category graph of p nodes taken as one."""
     Kc, C, _ = Tc.shape
@@ -159,7 +170,7 @@ def _mix_grad(Zs, dY, W, Kc: int) -> torch.Tensor:
     return dTc
 
 
-def _bdg_backward_slabs(dY, Zs, W, Tc, op: SpatialOperand, Ks: int, has_bias: bool, need_Tc: bool, need_val: bool, gates=None, cand=None):
+def _bdg_backward_slabs(dY, Zs, W, Tc, op: SpatialOperand, Ks: int, has_bias: bool, need_Tc: bool, need_val: bool, gates=None, cand=None, pack: int = 1):
     """Node-kernel backward and every hop of the Chebyshev recurrence but the last.
 
     Returns (g, dW, db | None, dTc | None, dval | None) with g = [g_0, g_1, ...] such that
@@ -174,15 +185,18 @@ def _bdg_backward_slabs(dY, Zs, W, Tc, op: SpatialOperand, Ks: int, has_bias: bo
     dW = torch.empty_like(W)
     db = W.new_empty(Ho) if has_bias else None
     dTc = torch.empty_like(Tc) if need_Tc else None
-    rows = lambda ts: [t.view(B * N, C, t.shape[-1]) for t in ts]
+    # pack > 1 (the fused prologue kernels on few categories, ``_cell_pack``): `pack` nodes are one node of pack * C categories, block-diagonal T_c
+    rows = lambda ts: [t.view(B * N // pack, pack * C, t.shape[-1]) for t in ts]
+    Tcp = Tc if pack == 1 else _block_diag(Tc, pack)
     if gates is not None:       # dY = gate pre-activation gradient, formed inside the kernel from (dCandIn, dU, H, U, R)
         dCandIn, Cand, H, U, Rg, dHnew, dH = gates   # dU = dHnew * (Cand - H); dH = dCandIn[h part] * R + dHnew * (1 - U); dXt stays in dCandIn
         dCandIn, Cand, H, U, Rg, dHnew, dH = rows((dCandIn, Cand, H, U, Rg, dHnew, dH))
-        k.cell_gates_bwd(rows(Zs), Tc, W, dCandIn, None, H, U, Rg, dHnew, rows(dZ), dW, db, None, dH, dH_in_scaled=True, Cand=Cand)
+        k.cell_gates_bwd(rows(Zs), Tcp, W, dCandIn, None, H, U, Rg, dHnew, rows(dZ), dW, db, None, dH, dH_in_scaled=True, Cand=Cand)
     elif cand is not None:      # dY = dHnew * U * (1 - Cand^2), formed inside the kernel
-        k.cell_cand_bwd(rows(Zs), Tc, W, *rows(cand), rows(dZ), dW, db)
+        k.cell_cand_bwd(rows(Zs), Tcp, W, *rows(cand), rows(dZ), dW, db)
     else:
         dY = _c(dY)
+        rows = lambda ts: [t.view(B * N, C, t.shape[-1]) for t in ts]
         p = _node_pack(Zs[0], Tc, Ks, Ho)
         if p >= 1:
             # few categories: floor(16 / C) nodes per row tile of the matrix-core kernel (``_node_pack``); that kernel leaves dT_c to the caller
@@ -419,13 +433,15 @@ class _StcCell(Function):
         U, Rg, CandIn = torch.empty_like(H), torch.empty_like(H), torch.empty_like(XH)
         Cand, Hnew = torch.empty_like(H), torch.empty_like(H)
         B, N, C, L = XH.shape
-        rows = lambda ts: [t.view(B * N, C, t.shape[-1]) for t in ts]
-        if k.cell_fused_supported(Ks, Tc.shape[0], C, L, h):
-            # gate math in the node kernels' epilogues: the pre-activations never go to HBM
+        pack = _cell_pack(k, B * N, C, Ks, Tc.shape[0], L, h)
+        if pack:
+            # gate math in the node kernels' epilogues: the pre-activations never go to HBM (few categories: `pack` nodes per row tile)
+            rows = lambda ts: [t.view(B * N // pack, pack * C, t.shape[-1]) for t in ts]
+            Tcp = Tc if pack == 1 else _block_diag(Tc, pack)
             Zg = _spatial_slabs(XH, fwd_val, op, Ks)
-            k.cell_gates_fwd(rows(Zg), Tc, Wg, bg, *rows((H, U, Rg, CandIn)))
+            k.cell_gates_fwd(rows(Zg), Tcp, Wg, bg, *rows((H, U, Rg, CandIn)))
             Zc = _spatial_slabs(CandIn, fwd_val, op, Ks)
-            k.cell_blend_fwd(rows(Zc), Tc, Wc, bc, *rows((U, H, Cand, Hnew)))
+            k.cell_blend_fwd(rows(Zc), Tcp, Wc, bc, *rows((U, H, Cand, Hnew)))
         else:
             G, Zg = _bdg_forward(XH, Wg, bg, Tc, fwd_val, op, Ks)
             k.gru_gates_fwd(G, Xt, H, U, Rg, CandIn)
@@ -452,13 +468,14 @@ class _StcCell(Function):
         # the gate backward can run as the prologue of the gates convolution's node backward (dG is never stored); it then
         # also takes over two pure data movements: the state's (1 - U) share of the blend (read from dHnew in place) and
         # dXt = d[x part] (left in place, added by the final split straight from the candidate gradient's rows)
-        pro = not (need_Tc or need_val) and k.cell_fused_supported(Ks, Tc.shape[0], C, L, H.shape[-1])
+        pack = 0 if (need_Tc or need_val) else _cell_pack(k, B * N, C, Ks, Tc.shape[0], L, H.shape[-1])
+        pro = pack > 0
         dHnew = _c(dHnew)
         dH = torch.empty_like(H)
         dXt = H.new_empty(H.shape[:-1] + (cin,))
         if pro:         # the blend backward (dCpre, dU, the state share) is formed inside the two node backward kernels
             dCpre = dU = dG = None
-            g, dWc, dbc, dTc, dval = _bdg_backward_slabs(None, Zc, Wc, Tc, op, Ks, ctx.bias[1], False, False, cand=(dHnew, U, Cand))
+            g, dWc, dbc, dTc, dval = _bdg_backward_slabs(None, Zc, Wc, Tc, op, Ks, ctx.bias[1], False, False, cand=(dHnew, U, Cand), pack=pack)
         else:
             dCpre, dU = torch.empty_like(H), torch.empty_like(H)
             k.gru_blend_bwd(dHnew, U, H, Cand, dCpre, dU, dH)                     # dH = dHnew * (1 - U)
@@ -473,7 +490,7 @@ class _StcCell(Function):
         else:
             k.gru_gates_bwd(dci, dU, H, U, Rg, dG, dXt, dH, dH_in=dH)
         # gates convolution: d[Xt | H] = g0 + Gs.g1, split and added to what Xt and H are already owed
-        g, dWg, dbg, dTc2, dval2 = _bdg_backward_slabs(dG, Zg, Wg, Tc, op, Ks, ctx.bias[0], need_Tc, need_val, gates=gates_pro)
+        g, dWg, dbg, dTc2, dval2 = _bdg_backward_slabs(dG, Zg, Wg, Tc, op, Ks, ctx.bias[0], need_Tc, need_val, gates=gates_pro, pack=max(1, pack))
         if need_Xt or need_H:
             if Ks > 1:
                 k.csr_spmm(*bwd[:3], N, N, v3(g[1]), v3(g[0]), v3(g[0]), 1.0, 1.0, plan=op.bwd_plan)

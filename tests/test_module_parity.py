@@ -267,6 +267,41 @@ def test_learned_graphs_on_the_small_graph_kernels(dev, monkeypatch, N, C, layer
             _close(got[n], per_cell[n], 5e-6, f'learned small-graph d{n} vs the per-cell path', gpu_tol=1e-5)
 
 
+@pytest.mark.parametrize('N,C,K,cin', [(10, 8, 2, 1), (12, 4, 2, 16), (9, 8, 3, 4), (8, 2, 2, 1), (7, 8, 2, 1), (10, 5, 2, 1)])
+def test_stc_cell_on_a_fixed_graph_packs_few_categories_into_the_fused_kernels(monkeypatch, N, C, K, cin):
+    """One STC_Cell (STC_GNN.py:65-79) on a fixed sparse graph through the per-cell path: where C divides 16 (and the node count divides too) its
+    FUSED kernels -- gate math in the node kernels' epilogues and prologues -- run 16 / C nodes per row tile (``ops._cell_pack``, asserted); C = 5
+    and an odd node count take the composed sequence on the packed plain node kernels.  New state and every gradient against the float64 oracle."""
+    B, h = 2, 16
+    packs = []
+    real = ops._cell_pack
+    monkeypatch.setattr(ops, '_cell_pack', lambda *a: packs.append(real(*a)) or packs[-1])
+    gen = torch.Generator().manual_seed(31 * N + C + K)
+    Gs = torch.rand(N, N, generator=gen) * (torch.rand(N, N, generator=gen) < 0.4) / 3
+    Gc = torch.softmax(torch.randn(C, C, generator=gen), -1)
+    Xt, Ht = torch.randn(B, N, C, cin, generator=gen), torch.tanh(torch.randn(B, N, C, h, generator=gen))
+    R = torch.randn(B, N, C, h, generator=gen)
+    cell = M.STC_Cell(N, C, K, K, cin, h).to(DEV)
+    sd = {k: v.detach().cpu().double().requires_grad_() for k, v in cell.state_dict().items()}
+    Xd, Hd = _leaf(Xt), _leaf(Ht)
+    out = cell(CsrGraph.from_dense(Gs, device=DEV) if DEV == 'cuda' else CsrGraph.from_dense(Gs), Gc.to(DEV), Xd, Hd)
+    (out * R.to(DEV)).sum().backward()
+    L = cin + h + (-(cin + h)) % 4
+    fused = ops.kernels().cell_fused_supported       # (the CPU twin fuses at any C; the library at C in {16, 32, 64})
+    expect = 1 if fused(K, K, C, L, h) else (16 // C if (16 % C == 0 and (B * N) % (16 // C) == 0 and fused(K, K, 16, L, h)) else 0)
+    assert packs and set(packs) == {expect}
+    if DEV == 'cuda':
+        assert expect == (16 // C if (16 % C == 0 and (B * N) % (16 // C) == 0) else 0)
+    X64, H64 = Xt.double().requires_grad_(), Ht.double().requires_grad_()
+    want = O.stc_cell(Gs.double(), Gc.double(), X64, H64, sd['gates.W'], sd['gates.b'], sd['candi.W'], sd['candi.b'], K, K)
+    (want * R.double()).sum().backward()
+    _close(out, want.detach().float().to(DEV), FWD, f'packed cell Hnew C={C} K={K}')
+    _close(Xd.grad, X64.grad.float().to(DEV), GRAD, f'packed cell dXt C={C} K={K}')
+    _close(Hd.grad, H64.grad.float().to(DEV), GRAD, f'packed cell dHt C={C} K={K}')
+    for n, p_ in cell.named_parameters():
+        _close(p_.grad, sd[n].grad.float().to(DEV), GRAD, f'packed cell d{n} C={C} K={K}')
+
+
 @pytest.mark.parametrize('N,C,K,layers,T,horizon,seed', [(12, 3, 2, 2, 4, 2, 7), (20, 5, 3, 1, 3, 3, 3), (10, 8, 2, 2, 3, 2, 13), (9, 4, 3, 1, 3, 2, 3)])
 def test_learned_graphs_on_the_general_path_with_packed_node_kernels(dev, monkeypatch, N, C, K, layers, T, horizon, seed):
     """The reference's FULL model with learned graphs on the GENERAL per-cell path (what learned graphs beyond the few-category cell kernels'
