@@ -405,7 +405,8 @@ class EmulatedKernels:
             U = torch.zeros(R, C, Ho, dtype=W.dtype)
             for n in range(Ks):
                 U += Zs[n][..., :Lw] @ Wv[n, c]
-            dTc[c].copy_(torch.einsum('rpo,rdo->pd', U, dY))
+            # (the sum over the rows in float64: the kernel's is blocked -- per wave, workgroup, then a tree -- where a flat fp32 sum over 1e5 rows drifts)
+            dTc[c].copy_(torch.einsum('rpo,rdo->pd', U.double(), dY.double()).to(dTc.dtype))
 
     # ---- stc_cell_small_fwd/bwd_f32: one STC_Cell step of a small graph per launch (STC_GNN.py:65-79 and its autograd)
     SMALL_MAX_ROWS = 65535

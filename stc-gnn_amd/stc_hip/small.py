@@ -59,11 +59,15 @@ def _layout(schedule, cin, n_cells, outputs):
     out_slot = {j: i for i, j in enumerate(outputs)}
     if len(out_slot) != len(outputs):
         raise ValueError('stc_cell_graph: duplicate output cells')
-    pos, counts, inner_slot, nxt = [], [0, 0], {}, 0
-    for j in range(n_cells):
+    pos, counts, inner_slot, nxt = [None] * n_cells, [0, 0], {}, 0
+    # inside a width group the cells of ONE parameter set sit side by side (set by set, each in schedule order): the products over a set's
+    # cells -- the learned graphs' dT_c through stc_mix_dt_f32 -- then take one contiguous run of planes (in schedule order the decoder's two
+    # layers interleave)
+    for j in sorted(range(n_cells), key=lambda j: (schedule[j][0], j)):
         wide = cin[j] == H16
-        pos.append((wide, counts[wide]))
+        pos[j] = (wide, counts[wide])
         counts[wide] += 1
+    for j in range(n_cells):
         if j not in out_slot:
             inner_slot[j] = nxt
             nxt += 1
@@ -229,6 +233,7 @@ def _graph_gradients(k, Tc, Ks, stacks, schedule, cin, pos, counts, dims, slabs,
             if counts[w]:
                 graph_jobs += [(dslab[w][1], slabs[w][1], counts[w]), (dslab[w][0], slabs[w][2], counts[w])]
     classes = {}                                                  # (width group, convolution) -> [(slab 0, slab 1, W, dY, first cell, step, cells)]
+    dT_direct = []                                                # dT_c pieces formed directly on the matrix cores (stc_mix_dt_f32)
     if need_Tc:
         for s_id, (Wg, bg, Wc, bc) in enumerate(stacks):
             cells = [j for j, sc in enumerate(schedule) if sc[0] == s_id]
@@ -244,6 +249,22 @@ def _graph_gradients(k, Tc, Ks, stacks, schedule, cin, pos, counts, dims, slabs,
                 operands = tuple((pick(s0), pick(s1), W, pick(dY)) for s0, s1, W, dY in operands)
                 first, step = 0, 1
             for conv, (s0, s1, W, dY) in enumerate(operands):
+                LP, Ho, cw = s0.shape[-1], W.shape[1], cin[cells[0]]
+                if Ks == 2 and step == 1 and hasattr(k, 'mix_dT') and k.mix_dT_supported(Ks, Kc, C, LP, Ho):
+                    # the set's cells are consecutive planes of their slabs: dT_c = sum over their rows of U_c . dY^T in ONE launch on tiles of
+                    # floor(16 / C) nodes (U_c = [Z_0 | Z_1] . W_c re-formed inside) -- instead of Ks products Q = Z^T . dY with float64
+                    # partials, their sum and a contraction with W per class (0.44 + ~0.2 ms of the 4.65 ms learned-graph SF step)
+                    n = len(cells)
+                    Wv = W.view(Ks, Kc, cw + H16, Ho)
+                    Wp = W.new_zeros(Ks, Kc, LP, Ho)                 # W's rows in the slabs' column order [H (16) | X (cin) | 0]
+                    Wp[:, :, :H16] = Wv[:, :, cw:]
+                    Wp[:, :, H16:H16 + cw] = Wv[:, :, :cw]
+                    rows = n * B * N
+                    piece = Tc.new_empty(Kc, C, C)
+                    k.mix_dT([s0[first:first + n].view(rows, C, LP), s1[first:first + n].view(rows, C, LP)], Wp.view(Ks * Kc * LP, Ho),
+                             dY[first:first + n].view(rows, C, Ho), piece)
+                    dT_direct.append(piece)
+                    continue
                 classes.setdefault((w, cin[cells[0]], conv), []).append((s0, s1, W, dY, first, step, len(cells)))
     block = lambda s0, dY: C * s0.shape[-1] * C * dY.shape[-1]
     total = sum(Ks * block(e[0], e[3]) for es in classes.values() for e in es)
@@ -265,6 +286,8 @@ def _graph_gradients(k, Tc, Ks, stacks, schedule, cin, pos, counts, dims, slabs,
                     off += block(s0, dY)
         sums = part.sum(0)
     dT = torch.zeros(Tc.shape, dtype=torch.float64, device=Tc.device) if need_Tc else None
+    if dT_direct:
+        dT += torch.stack(dT_direct).sum(0)
     off = 0
     for (w, cw, conv), es in classes.items():
         LP, Ho, L = es[0][0].shape[-1], es[0][2].shape[1], cw + H16

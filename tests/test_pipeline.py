@@ -401,7 +401,7 @@ def test_bench_preset_sf(preset):
     assert m['launches_per_cell_step'] in (1, 2, 3, 4) and m['compute_units_in_use'] in (32, 256)
     assert set(d['kernels']) >= {'stc_cell_small_fwd_f32', 'stc_cell_small_bwd_f32'}
     if preset == 'sf-learned':
-        assert {'stc_graph_grad_f32', 'stc_mix_grad_f32'} <= set(d['kernels'])
+        assert {'stc_graph_grad_f32', 'stc_mix_dt_f32'} <= set(d['kernels'])      # (dGs pieces; dT_c of every parameter set on the matrix cores)
 
 
 @pytest.mark.gpu
