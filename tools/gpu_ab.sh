@@ -33,7 +33,7 @@ PY
 import json, sys
 d = json.loads(open(f'gpurun_out/ab_{sys.argv[1]}.log').read().strip().split('\n')[-1])
 k = d['kernels']
-print(f"{sys.argv[1]:16s} ms {d['ms_per_step']:.3f}  " + '  '.join(f"{n.replace('stc_', '').replace('_f32', '')} {1e3 * k[n]['ms_per_step'] * d['steps'] / k[n]['launches']:.1f}us x{k[n]['launches'] / d['steps']:.0f}" for n in ('stc_mix_grad_f32', 'stc_graph_grad_f32', 'stc_cell_small_bwd_f32', 'stc_cell_small_fwd_f32') if n in k))
+print(f"{sys.argv[1]:16s} ms {d['ms_per_step']:.3f}  " + '  '.join(f"{n.replace('stc_', '').replace('_f32', '')} {1e3 * k[n]['ms_per_step'] * d['steps'] / k[n]['launches']:.1f}us x{k[n]['launches'] / d['steps']:.0f}" for n in ('stc_mix_dt_f32', 'stc_mix_grad_f32', 'stc_graph_grad_f32', 'stc_cell_small_bwd_f32', 'stc_cell_small_fwd_f32') if n in k))
 PY
   else
     rm -f gpurun_out/parity_errors.txt
